@@ -1,0 +1,202 @@
+/*
+ * khronos_amd.h — C ABI of the MI355X-native active-window volumetric fusion path.
+ *
+ * The reference (MIT-SPARK/Khronos) has NO C ABI for this path: the path sits behind the C++ plugin
+ * class khronos::ActiveWindow (khronos/include/khronos/active_window/active_window.h:67-193), which
+ * calls hydra::ProjectiveIntegrator / khronos::TrackingIntegrator / khronos::FreeSpaceMotionDetector /
+ * hydra::MeshIntegrator on a host-RAM hydra::VolumetricMap.  This header is the thin extern "C" layer
+ * the host-side ActiveWindow replacement (khronos_amd/host/, C++) binds instead; each entry point names
+ * the reference call it replaces.  Plain pointers and sizes only; no exceptions cross this boundary.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative KHR_E* code; khr_last_error() gives text.
+ *  - all calls on one khr_ctx must be externally serialised (the reference serialises spinOnce /
+ *    finishMapping / extractObjects with ActiveWindow::mutex_, active_window.cpp:119,177,193).
+ *  - calls enqueue work on the context's HIP stream and return without waiting unless they hand data
+ *    back to the host (khr_download_*, khr_get_stats, khr_detect_motion, ...), which synchronise.
+ *  - "device pointer" variants (on_device != 0) take HBM-resident buffers on the context's device.
+ *  - voxel arrays of a block are in linear order  x + vps*(y + vps*z)  (spatial_hash convention).
+ */
+#ifndef KHRONOS_AMD_H_
+#define KHRONOS_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KHR_OK 0
+#define KHR_EINVAL (-1)   /* bad argument / config (reference: config::checkValid aborts) */
+#define KHR_ENOMEM (-2)   /* HBM allocation failed or block pool exhausted */
+#define KHR_EDEVICE (-3)  /* HIP runtime error */
+#define KHR_ENOTFOUND (-4)
+#define KHR_ESTATE (-5)
+
+/* per-voxel flag bits (hydra::TrackingVoxel bools + SemanticVoxel::empty) */
+#define KHR_VOX_ACTIVE 1u
+#define KHR_VOX_EVER_FREE 2u
+#define KHR_VOX_TO_REMOVE 4u
+#define KHR_VOX_SEM_VALID 8u /* !SemanticVoxel::empty */
+/* per-block flag bits (hydra::TsdfBlock / TrackingBlock flags) */
+#define KHR_BLK_UPDATED 1u
+#define KHR_BLK_MESH_UPDATED 2u
+#define KHR_BLK_TRACKING_UPDATED 4u
+#define KHR_BLK_HAS_ACTIVE_DATA 8u
+
+typedef struct khr_config {
+  /* hydra::VolumetricMap::Config — YAML volumetric_map{} (uHumans2.yaml:45-49) */
+  float voxel_size;
+  int32_t voxels_per_side; /* 16 (active window) or 8 (object maps, mesh_object_extractor.cpp:208) */
+  float truncation_distance;
+  int32_t with_semantics;
+  int32_t with_tracking;
+  int32_t num_labels; /* K, total label count of the label space */
+  /* hydra::ProjectiveIntegrator::Config — YAML projective_integrator{} */
+  int32_t use_weight_dropoff;
+  float weight_dropoff_epsilon;
+  int32_t use_constant_weight;
+  float max_weight;
+  int32_t interpolation_method; /* 0 nearest, 1 bilinear, 2 adaptive */
+  float adaptive_max_range_difference;
+  int32_t range_mode;    /* 0 z-depth, 1 ray length */
+  int32_t semantic_mode; /* 0 MLESemanticIntegrator, 1 BinarySemanticIntegrator */
+  float label_confidence;
+  /* khronos::TrackingIntegrator::Config — tracking_integrator.h:59-83 */
+  float temporal_buffer;
+  float tsdf_occupancy_threshold;
+  int32_t neighbor_connectivity;
+  float temporal_window;
+  /* khronos::FreeSpaceMotionDetector::Config — free_space_motion_detector.h:72-97 */
+  int32_t md_neighbor_connectivity;
+  int32_t md_min_cluster_size;
+  int32_t md_max_cluster_size;
+  float md_min_separation_distance;
+  float md_max_range;
+  float md_min_z_coordinate;
+  /* hydra::MeshIntegratorConfig */
+  float mesh_min_weight;
+  /* device-side sizing (no reference equivalent: the reference map grows on the host heap) */
+  uint32_t max_blocks;        /* block-pool capacity in HBM */
+  uint32_t max_frame_pixels;  /* largest W*H that will be uploaded */
+  uint32_t num_frame_slots;   /* device-resident frame ring (FrameDataBuffer role, frame_data_buffer.h:52-100) */
+  uint64_t max_mesh_vertices; /* capacity of the mesh vertex buffer */
+  /* placement */
+  int32_t device;     /* HIP device ordinal */
+  int32_t rank;       /* owner-computes sharding: this context integrates blocks with owner == rank */
+  int32_t world_size; /* 1 = unsharded */
+} khr_config;
+
+typedef struct khr_sensor {
+  int32_t width, height;
+  float fx, fy, cx, cy;
+  float min_range, max_range;
+} khr_sensor;
+
+/* hydra::InputData role (fields listed SURVEY.md A.2). Buffers are caller-owned and copied
+ * (host) or read (device) during the call. */
+typedef struct khr_frame {
+  uint64_t timestamp_ns;
+  double world_T_sensor[16]; /* row-major 4x4, InputData::getSensorPose() */
+  const float* depth;        /* H*W f32 metres */
+  const uint8_t* color;      /* H*W*3 u8 rgb, may be NULL */
+  const int32_t* label;      /* H*W i32, may be NULL */
+} khr_frame;
+
+typedef struct khr_stats {
+  uint64_t n_allocated_blocks; /* live blocks in the map */
+  uint64_t n_visible_blocks;   /* last integrate: blocks visited */
+  uint64_t n_new_blocks;       /* last integrate: newly allocated */
+  uint64_t n_visited_voxels;   /* last integrate: N_vis */
+  uint64_t n_updated_voxels;   /* last integrate: N_upd (TSDF weight modified) */
+  uint64_t n_band_voxels;      /* last integrate: N_band (|sdf| < truncation) */
+  uint64_t n_tracking_updated_blocks; /* last tracking update: blocks in the ever-free pass */
+  uint64_t n_seeds;            /* last motion detection */
+  uint64_t n_mesh_blocks;      /* last generate_mesh */
+  uint64_t n_mesh_vertices;
+  uint64_t pool_exhausted;     /* non-zero if an allocation was dropped for lack of pool slots */
+} khr_stats;
+
+typedef struct khr_ctx khr_ctx;
+
+/* -- lifetime --------------------------------------------------------------------------------- */
+/* replaces: hydra::VolumetricMap construction inside hydra::ActiveWindowModule (active_window.cpp:73-76) */
+int khr_create(const khr_config* cfg, khr_ctx** out);
+void khr_destroy(khr_ctx* ctx);
+const char* khr_last_error(void);
+/* use an externally owned hipStream_t (e.g. the stream RCCL collectives run on); NULL = own stream */
+int khr_set_stream(khr_ctx* ctx, void* hip_stream);
+int khr_sync(khr_ctx* ctx);
+/* fill a config with the reference defaults */
+void khr_default_config(khr_config* cfg);
+
+/* -- input ------------------------------------------------------------------------------------- */
+/* replaces: hydra::conversions::parseInputPacket + FrameData allocation (active_window.cpp:268-286).
+ * Copies the frame into device frame slot (ring), computes the range image and packs colour.
+ * Returns the slot id (>= 0) or a negative error. */
+int khr_upload_frame(khr_ctx* ctx, const khr_sensor* sensor, const khr_frame* frame, int on_device);
+/* set / clear FrameData::dynamic_image (frame_data.h:70) or FrameData::object_image (:80) of a slot
+ * from caller memory (H*W i32). image == NULL clears to zero. which: 0 dynamic, 1 object. */
+int khr_set_frame_image(khr_ctx* ctx, int slot, int which, const int32_t* image, int on_device);
+/* read back the normalised input of a slot (any pointer may be NULL): range f32 H*W, vertex map
+ * f32 H*W*3 in world frame, dynamic image i32 H*W */
+int khr_download_frame(khr_ctx* ctx, int slot, float* range, float* vertex_map, int32_t* dynamic_image);
+
+/* -- hot path ---------------------------------------------------------------------------------- */
+/* replaces: hydra::maskNonZero + hydra::ProjectiveIntegrator::updateMap(data.input, map, allocate,
+ * mask) (active_window.cpp:209-210; object maps: mesh_object_extractor.cpp:239-243).
+ * use_mask: non-zero => pixels with dynamic_image != 0 are not integrated (in-band).
+ * object_id >= 0 => binary object label from object_image (object_integrator.cpp:58-81). */
+int khr_integrate(khr_ctx* ctx, int slot, int allocate_blocks, int use_mask, int object_id);
+/* replaces: TrackingIntegrator::updateBlocks (tracking_integrator.cpp:71-104) */
+int khr_update_tracking(khr_ctx* ctx, uint64_t timestamp_ns);
+/* replaces: FreeSpaceMotionDetector::processInput (free_space_motion_detector.cpp:73-103).
+ * Writes the slot's dynamic_image on the device; returns the number of clusters kept (>= 0). */
+int khr_detect_motion(khr_ctx* ctx, int slot);
+/* replaces: hydra::MeshIntegrator::generateMesh(map, only_mesh_updated, clear_flag)
+ * (active_window.cpp:223, mesh_object_extractor.cpp:267) */
+int khr_generate_mesh(khr_ctx* ctx, int only_mesh_updated, int clear_flag);
+/* replaces: TrackingIntegrator::resetInactive (tracking_integrator.cpp:106-131). removed: caller
+ * buffer for 3*cap int32 block indices (may be NULL); *n_removed receives the count. */
+int khr_reset_inactive(khr_ctx* ctx, int32_t* removed, int64_t cap, int64_t* n_removed);
+/* replaces: the has_active_data=false loop of ActiveWindow::finishMapping (active_window.cpp:181-183) */
+int khr_mark_all_inactive(khr_ctx* ctx);
+/* replaces: TsdfBlock::clearUpdated loop (active_window.cpp:169-171) */
+int khr_clear_updated(khr_ctx* ctx);
+/* replaces: VolumetricMap::allocateBlock (mesh_object_extractor.cpp:225) */
+int khr_allocate_blocks(khr_ctx* ctx, const int32_t* indices, int64_t n);
+/* replaces: confidence pruning loop of MeshObjectExtractor (mesh_object_extractor.cpp:246-264) */
+int khr_object_prune(khr_ctx* ctx, float min_confidence, float min_observations, int64_t* n_pruned);
+
+/* -- output / inspection ----------------------------------------------------------------------- */
+int khr_get_stats(khr_ctx* ctx, khr_stats* out);
+int64_t khr_num_blocks(khr_ctx* ctx);
+/* sorted (x, y, z) lexicographically; returns total count, writes min(count, cap) entries.
+ * only_updated != 0 restricts to blocks flagged KHR_BLK_UPDATED (VolumetricMap::cloneUpdated role,
+ * active_window.cpp:229). */
+int64_t khr_block_indices(khr_ctx* ctx, int32_t* out, int64_t cap, int only_updated);
+/* copy one block's voxel arrays to the host (any pointer may be NULL); KHR_ENOTFOUND if absent.
+ * likelihoods: K*n floats laid out [k][voxel]. */
+int khr_download_block(khr_ctx* ctx, int32_t bx, int32_t by, int32_t bz, float* distance, float* weight,
+                       uint8_t* color_rgba, uint64_t* last_observed, uint64_t* last_occupied,
+                       uint8_t* voxel_flags, uint32_t* sem_label, float* likelihoods, uint8_t* block_flags);
+/* mesh produced by the last khr_generate_mesh calls, concatenated over blocks in sorted block order
+ * (utils::combineMeshLayer, geometry_utils.cpp:61-86; faces are implicit: vertex 3i,3i+1,3i+2).
+ * returns the vertex count, or a negative error if cap is too small. */
+int64_t khr_mesh_num_vertices(khr_ctx* ctx);
+int64_t khr_download_mesh(khr_ctx* ctx, float* points, uint8_t* colors_rgba, uint32_t* labels,
+                          uint64_t* first_seen, uint64_t* stamps, int64_t cap);
+
+/* -- measurement ------------------------------------------------------------------------------- */
+/* HIP-event timing of the kernels launched on the context stream. which: 0 tsdf update,
+ * 1 tracking update, 2 ever-free, 3 block allocation+init, 4 motion pixels, 5 mesh, 6 parse input.
+ * Accumulates between khr_timing_reset calls; returns total ms and launch count. */
+int khr_timing_enable(khr_ctx* ctx, int enable);
+int khr_timing_reset(khr_ctx* ctx);
+int khr_timing_get(khr_ctx* ctx, int which, double* total_ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KHRONOS_AMD_H_ */

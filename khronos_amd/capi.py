@@ -1,0 +1,307 @@
+"""ctypes binding of the C ABI in include/khronos_amd.h (plumbing only: the product is the HIP library).
+
+Fails loudly when the HIP extension is missing: there is no CPU fallback for the fusion path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libkhronos_amd.so")
+
+KHR_OK, KHR_EINVAL, KHR_ENOMEM, KHR_EDEVICE, KHR_ENOTFOUND, KHR_ESTATE = 0, -1, -2, -3, -4, -5
+VOX_ACTIVE, VOX_EVER_FREE, VOX_TO_REMOVE, VOX_SEM_VALID = 1, 2, 4, 8
+BLK_UPDATED, BLK_MESH_UPDATED, BLK_TRACKING_UPDATED, BLK_HAS_ACTIVE_DATA = 1, 2, 4, 8
+
+
+class KhrConfig(C.Structure):
+    _fields_ = [
+        ("voxel_size", C.c_float), ("voxels_per_side", C.c_int32), ("truncation_distance", C.c_float),
+        ("with_semantics", C.c_int32), ("with_tracking", C.c_int32), ("num_labels", C.c_int32),
+        ("use_weight_dropoff", C.c_int32), ("weight_dropoff_epsilon", C.c_float),
+        ("use_constant_weight", C.c_int32), ("max_weight", C.c_float), ("interpolation_method", C.c_int32),
+        ("adaptive_max_range_difference", C.c_float), ("range_mode", C.c_int32), ("semantic_mode", C.c_int32),
+        ("label_confidence", C.c_float),
+        ("temporal_buffer", C.c_float), ("tsdf_occupancy_threshold", C.c_float),
+        ("neighbor_connectivity", C.c_int32), ("temporal_window", C.c_float),
+        ("md_neighbor_connectivity", C.c_int32), ("md_min_cluster_size", C.c_int32),
+        ("md_max_cluster_size", C.c_int32), ("md_min_separation_distance", C.c_float),
+        ("md_max_range", C.c_float), ("md_min_z_coordinate", C.c_float),
+        ("mesh_min_weight", C.c_float),
+        ("max_blocks", C.c_uint32), ("max_frame_pixels", C.c_uint32), ("num_frame_slots", C.c_uint32),
+        ("max_mesh_vertices", C.c_uint64),
+        ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
+    ]
+
+
+class KhrSensor(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("min_range", C.c_float), ("max_range", C.c_float)]
+
+
+class KhrFrame(C.Structure):
+    _fields_ = [("timestamp_ns", C.c_uint64), ("world_T_sensor", C.c_double * 16), ("depth", C.c_void_p),
+                ("color", C.c_void_p), ("label", C.c_void_p)]
+
+
+class KhrStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "n_allocated_blocks", "n_visible_blocks", "n_new_blocks", "n_visited_voxels", "n_updated_voxels",
+        "n_band_voxels", "n_tracking_updated_blocks", "n_seeds", "n_mesh_blocks", "n_mesh_vertices",
+        "pool_exhausted")]
+
+
+# every symbol include/khronos_amd.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "khr_create", "khr_destroy", "khr_last_error", "khr_set_stream", "khr_sync", "khr_default_config",
+    "khr_upload_frame", "khr_set_frame_image", "khr_download_frame", "khr_integrate", "khr_update_tracking",
+    "khr_detect_motion", "khr_generate_mesh", "khr_reset_inactive", "khr_mark_all_inactive", "khr_clear_updated",
+    "khr_allocate_blocks", "khr_object_prune", "khr_get_stats", "khr_num_blocks", "khr_block_indices",
+    "khr_download_block", "khr_mesh_num_vertices", "khr_download_mesh", "khr_timing_enable", "khr_timing_reset",
+    "khr_timing_get",
+]
+
+_lib = None
+
+
+class KhronosAmdError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Load libkhronos_amd.so (built by __graft_entry__.build()).  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KhronosAmdError(
+            "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "The khronos_amd fusion path has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64
+    lib.khr_create.argtypes = [C.POINTER(KhrConfig), C.POINTER(vp)]
+    lib.khr_create.restype = i32
+    lib.khr_destroy.argtypes = [vp]
+    lib.khr_destroy.restype = None
+    lib.khr_last_error.restype = C.c_char_p
+    lib.khr_set_stream.argtypes = [vp, vp]
+    lib.khr_sync.argtypes = [vp]
+    lib.khr_default_config.argtypes = [C.POINTER(KhrConfig)]
+    lib.khr_default_config.restype = None
+    lib.khr_upload_frame.argtypes = [vp, C.POINTER(KhrSensor), C.POINTER(KhrFrame), i32]
+    lib.khr_set_frame_image.argtypes = [vp, i32, i32, vp, i32]
+    lib.khr_download_frame.argtypes = [vp, i32, vp, vp, vp]
+    lib.khr_integrate.argtypes = [vp, i32, i32, i32, i32]
+    lib.khr_update_tracking.argtypes = [vp, u64]
+    lib.khr_detect_motion.argtypes = [vp, i32]
+    lib.khr_generate_mesh.argtypes = [vp, i32, i32]
+    lib.khr_reset_inactive.argtypes = [vp, vp, i64, C.POINTER(i64)]
+    lib.khr_mark_all_inactive.argtypes = [vp]
+    lib.khr_clear_updated.argtypes = [vp]
+    lib.khr_allocate_blocks.argtypes = [vp, vp, i64]
+    lib.khr_object_prune.argtypes = [vp, C.c_float, C.c_float, C.POINTER(i64)]
+    lib.khr_get_stats.argtypes = [vp, C.POINTER(KhrStats)]
+    lib.khr_num_blocks.argtypes = [vp]
+    lib.khr_num_blocks.restype = i64
+    lib.khr_block_indices.argtypes = [vp, vp, i64, i32]
+    lib.khr_block_indices.restype = i64
+    lib.khr_download_block.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32] + [vp] * 9
+    lib.khr_mesh_num_vertices.argtypes = [vp]
+    lib.khr_mesh_num_vertices.restype = i64
+    lib.khr_download_mesh.argtypes = [vp, vp, vp, vp, vp, vp, i64]
+    lib.khr_download_mesh.restype = i64
+    lib.khr_timing_enable.argtypes = [vp, i32]
+    lib.khr_timing_reset.argtypes = [vp]
+    lib.khr_timing_get.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64)]
+    _lib = lib
+    return lib
+
+
+def default_config(**overrides):
+    cfg = KhrConfig()
+    load_library().khr_default_config(C.byref(cfg))
+    for k, v in overrides.items():
+        if not hasattr(cfg, k):
+            raise KeyError(k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class FusionContext:
+    """Thin object wrapper over a khr_ctx (one per GPU / per map)."""
+
+    TIMERS = {"tsdf": 0, "tracking": 1, "ever_free": 2, "alloc": 3, "motion_pixels": 4, "mesh": 5, "parse": 6}
+
+    def __init__(self, cfg):
+        self.lib = load_library()
+        self.cfg = cfg
+        h = C.c_void_p()
+        rc = self.lib.khr_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise KhronosAmdError("khr_create failed (%d): %s" % (rc, self.lib.khr_last_error().decode()))
+        self.h = h
+        self.nvox = cfg.voxels_per_side ** 3
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.khr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise KhronosAmdError("khr call failed (%d): %s" % (rc, self.lib.khr_last_error().decode()))
+        return rc
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.lib.khr_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def sync(self):
+        self._chk(self.lib.khr_sync(self.h))
+
+    @staticmethod
+    def make_sensor(width, height, fx, fy, cx, cy, min_range=0.1, max_range=5.0):
+        return KhrSensor(width, height, fx, fy, cx, cy, min_range, max_range)
+
+    def upload_frame(self, sensor, stamp_ns, world_T_sensor, depth, color=None, label=None):
+        """numpy host buffers.  Returns the frame slot."""
+        f = KhrFrame()
+        f.timestamp_ns = int(stamp_ns)
+        T = np.ascontiguousarray(world_T_sensor, dtype=np.float64).reshape(16)
+        for i in range(16):
+            f.world_T_sensor[i] = T[i]
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        keep = [depth]
+        f.depth = depth.ctypes.data
+        if color is not None:
+            color = np.ascontiguousarray(color, dtype=np.uint8)
+            keep.append(color)
+            f.color = color.ctypes.data
+        if label is not None:
+            label = np.ascontiguousarray(label, dtype=np.int32)
+            keep.append(label)
+            f.label = label.ctypes.data
+        return self._chk(self.lib.khr_upload_frame(self.h, C.byref(sensor), C.byref(f), 0))
+
+    def upload_frame_device(self, sensor, stamp_ns, world_T_sensor, depth_ptr, color_ptr=0, label_ptr=0):
+        """HBM-resident buffers given as integer device pointers (e.g. torch tensor .data_ptr())."""
+        f = KhrFrame()
+        f.timestamp_ns = int(stamp_ns)
+        T = np.ascontiguousarray(world_T_sensor, dtype=np.float64).reshape(16)
+        for i in range(16):
+            f.world_T_sensor[i] = T[i]
+        f.depth = depth_ptr
+        f.color = color_ptr or None
+        f.label = label_ptr or None
+        return self._chk(self.lib.khr_upload_frame(self.h, C.byref(sensor), C.byref(f), 1))
+
+    def set_frame_image(self, slot, which, image):
+        if image is None:
+            self._chk(self.lib.khr_set_frame_image(self.h, slot, which, None, 0))
+        else:
+            image = np.ascontiguousarray(image, dtype=np.int32)
+            self._chk(self.lib.khr_set_frame_image(self.h, slot, which, _ptr(image), 0))
+
+    def download_frame(self, slot, shape, range_image=True, vertex_map=False, dynamic_image=False):
+        h, w = shape
+        r = np.empty((h, w), np.float32) if range_image else None
+        v = np.empty((h, w, 3), np.float32) if vertex_map else None
+        d = np.empty((h, w), np.int32) if dynamic_image else None
+        self._chk(self.lib.khr_download_frame(self.h, slot, _ptr(r), _ptr(v), _ptr(d)))
+        return r, v, d
+
+    def integrate(self, slot, allocate_blocks=True, use_mask=False, object_id=-1):
+        self._chk(self.lib.khr_integrate(self.h, slot, int(allocate_blocks), int(use_mask), int(object_id)))
+
+    def update_tracking(self, stamp_ns):
+        self._chk(self.lib.khr_update_tracking(self.h, int(stamp_ns)))
+
+    def detect_motion(self, slot):
+        return self._chk(self.lib.khr_detect_motion(self.h, slot))
+
+    def generate_mesh(self, only_mesh_updated=True, clear_flag=True):
+        self._chk(self.lib.khr_generate_mesh(self.h, int(only_mesh_updated), int(clear_flag)))
+
+    def reset_inactive(self):
+        n = C.c_int64(0)
+        cap = int(self.cfg.max_blocks)
+        out = np.zeros((cap, 3), np.int32)
+        self._chk(self.lib.khr_reset_inactive(self.h, _ptr(out), cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    def mark_all_inactive(self):
+        self._chk(self.lib.khr_mark_all_inactive(self.h))
+
+    def clear_updated(self):
+        self._chk(self.lib.khr_clear_updated(self.h))
+
+    def allocate_blocks(self, indices):
+        idx = np.ascontiguousarray(indices, dtype=np.int32).reshape(-1, 3)
+        self._chk(self.lib.khr_allocate_blocks(self.h, _ptr(idx), idx.shape[0]))
+
+    def object_prune(self, min_confidence, min_observations):
+        n = C.c_int64(0)
+        self._chk(self.lib.khr_object_prune(self.h, min_confidence, min_observations, C.byref(n)))
+        return n.value
+
+    def stats(self):
+        s = KhrStats()
+        self._chk(self.lib.khr_get_stats(self.h, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in KhrStats._fields_}
+
+    def num_blocks(self):
+        return self._chk(self.lib.khr_num_blocks(self.h))
+
+    def block_indices(self, only_updated=False):
+        n = self._chk(self.lib.khr_block_indices(self.h, None, 0, int(only_updated)))
+        out = np.zeros((max(n, 1), 3), np.int32)
+        n = self._chk(self.lib.khr_block_indices(self.h, _ptr(out), n, int(only_updated)))
+        return out[:n]
+
+    def download_block(self, idx, likelihoods=True):
+        nv, K = self.nvox, max(1, self.cfg.num_labels)
+        b = {
+            "distance": np.empty(nv, np.float32), "weight": np.empty(nv, np.float32),
+            "color": np.empty((nv, 4), np.uint8), "last_observed": np.empty(nv, np.uint64),
+            "last_occupied": np.empty(nv, np.uint64), "flags": np.empty(nv, np.uint8),
+            "sem_label": np.empty(nv, np.uint32),
+            "likelihoods": np.zeros((K, nv), np.float32) if (likelihoods and self.cfg.with_semantics) else None,
+        }
+        bf = np.zeros(1, np.uint8)
+        self._chk(self.lib.khr_download_block(
+            self.h, int(idx[0]), int(idx[1]), int(idx[2]), _ptr(b["distance"]), _ptr(b["weight"]), _ptr(b["color"]),
+            _ptr(b["last_observed"]), _ptr(b["last_occupied"]), _ptr(b["flags"]), _ptr(b["sem_label"]),
+            _ptr(b["likelihoods"]), _ptr(bf)))
+        b["block_flags"] = int(bf[0])
+        return b
+
+    def download_mesh(self):
+        n = self._chk(self.lib.khr_mesh_num_vertices(self.h))
+        pts = np.empty((max(n, 1), 3), np.float32)
+        col = np.empty((max(n, 1), 4), np.uint8)
+        lab = np.empty(max(n, 1), np.uint32)
+        fs = np.empty(max(n, 1), np.uint64)
+        st = np.empty(max(n, 1), np.uint64)
+        k = self._chk(self.lib.khr_download_mesh(self.h, _ptr(pts), _ptr(col), _ptr(lab), _ptr(fs), _ptr(st), max(n, 1)))
+        return {"points": pts[:k], "colors": col[:k], "labels": lab[:k], "first_seen": fs[:k], "stamps": st[:k]}
+
+    def timing_enable(self, on=True):
+        self._chk(self.lib.khr_timing_enable(self.h, int(on)))
+
+    def timing_reset(self):
+        self._chk(self.lib.khr_timing_reset(self.h))
+
+    def timing_get(self, name):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        self._chk(self.lib.khr_timing_get(self.h, self.TIMERS[name], C.byref(ms), C.byref(n)))
+        return ms.value, n.value

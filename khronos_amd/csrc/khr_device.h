@@ -1,0 +1,189 @@
+// khr_device.h — HBM data layout of the hashed voxel-block map and the device-side index / projection
+// math shared by all kernels.  gfx950 only.
+//
+// Layout: a fixed-capacity block pool, structure-of-arrays per field with the pool
+// slot as the leading index, so that the 4096 (or 512) voxels of one block are contiguous per field:
+//   dist[slot][nvox] f32 | weight[slot][nvox] f32 | color[slot][nvox] rgba8 | last_obs[slot][nvox] u64
+//   last_occ[slot][nvox] u64 | vflags[slot][nvox] u8 | sem_label[slot][nvox] u32
+//   lik[slot][K][nvox] f32 | freebits[slot][nvox/64] u64
+// plus an open-addressing hash table  packed BlockIndex -> slot.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace khr {
+
+constexpr uint64_t kEmptyKey = ~0ull;
+constexpr uint32_t kInvalidSlot = 0xffffffffu;
+
+// block flag bits 0..3 are the public KHR_BLK_* bits
+constexpr uint32_t BLK_UPDATED = 1u, BLK_MESH_UPDATED = 2u, BLK_TRACKING_UPDATED = 4u, BLK_HAS_ACTIVE = 8u,
+                   BLK_LIVE = 16u;
+constexpr uint8_t VOX_ACTIVE = 1, VOX_EVER_FREE = 2, VOX_TO_REMOVE = 4, VOX_SEM_VALID = 8;
+
+enum Counter : int {
+  C_FREE_HEAD = 0,   // cursor into free_slots
+  C_N_FREE,          // number of valid entries in free_slots
+  C_MAX_SLOT,        // highest slot ever handed out + 1
+  C_N_VISIBLE,       // work list length of the last integrate
+  C_N_NEW,           // newly allocated blocks in the last integrate
+  C_N_EF,            // ever-free work list length
+  C_N_LIVE,          // live blocks
+  C_POOL_EXHAUSTED,
+  C_N_UPD_LO,        // (unused; stats are 64-bit, see stats[])
+  C_N_REMOVED,
+  C_N_SEEDS,
+  C_N_MESH,
+  C_COUNT = 16
+};
+enum Stat64 : int { S_UPD = 0, S_BAND, S_MESH_VERTS, S_PRUNED, S_COUNT = 8 };
+
+struct MeshDesc {
+  uint32_t offset;  // first vertex in the mesh vertex buffer
+  uint32_t count;   // number of vertices (3 per face)
+};
+
+struct DevMap {
+  uint64_t* ht_keys;
+  uint32_t* ht_vals;
+  uint32_t ht_mask;
+  uint32_t capacity;
+  int4* blk_index;      // x,y,z,unused
+  uint32_t* blk_flags;
+  float* dist;
+  float* weight;
+  uint32_t* color;
+  uint64_t* last_obs;
+  uint64_t* last_occ;
+  uint8_t* vflags;
+  uint32_t* sem_label;
+  float* lik;
+  uint64_t* freebits;
+  uint32_t* free_slots;
+  uint32_t* counters;             // Counter
+  unsigned long long* stats;      // Stat64
+  MeshDesc* mesh_desc;            // per slot
+};
+
+struct DevParams {
+  float vs, vs_inv, bs, bs_inv, trunc;
+  int vps, nvox, K;
+  int with_semantics, with_tracking;
+  int use_dropoff, const_weight, interp, range_mode, sem_mode;
+  float dropoff_eps, max_weight, adaptive_diff, log_match, log_nomatch;
+  float occ_thr;
+  double temporal_buffer, temporal_window;
+  int nn;
+  float mesh_min_weight;
+  int rank, world;
+};
+
+struct DevFrame {
+  const float* depth;
+  const float* range;
+  const uint32_t* rgba;
+  const int32_t* label;
+  int32_t* dyn;
+  const int32_t* obj;
+  int W, H;
+  float fx, fy, cx, cy, min_range, max_range;
+  float R[9], t[3];    // sensor_T_world
+  float Rw[9], tw[3];  // world_T_sensor
+  uint64_t stamp;
+  int has_color, has_label;
+};
+
+struct DevFrustum {
+  float n[4][3];
+  float infl;
+  int3 bc;  // camera block
+  int n_steps;
+};
+
+__host__ __device__ inline uint32_t mix32(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return h;
+}
+
+// owner of a block under contiguous-hash-range sharding
+__host__ __device__ inline int ownerOf(int x, int y, int z, int world) {
+  if (world <= 1) return 0;
+  const uint32_t h = mix32(static_cast<uint32_t>(x) * 73856093u ^
+                           mix32(static_cast<uint32_t>(y) * 19349663u ^ mix32(static_cast<uint32_t>(z) * 83492791u)));
+  return static_cast<int>((static_cast<uint64_t>(h) * static_cast<uint64_t>(world)) >> 32);
+}
+
+// 21 bits per axis, biased
+__host__ __device__ inline uint64_t packKey(int x, int y, int z) {
+  return (static_cast<uint64_t>(static_cast<uint32_t>(x + (1 << 20)) & 0x1fffffu)) |
+         (static_cast<uint64_t>(static_cast<uint32_t>(y + (1 << 20)) & 0x1fffffu) << 21) |
+         (static_cast<uint64_t>(static_cast<uint32_t>(z + (1 << 20)) & 0x1fffffu) << 42);
+}
+__host__ __device__ inline void unpackKey(uint64_t k, int* x, int* y, int* z) {
+  *x = static_cast<int>(k & 0x1fffffu) - (1 << 20);
+  *y = static_cast<int>((k >> 21) & 0x1fffffu) - (1 << 20);
+  *z = static_cast<int>((k >> 42) & 0x1fffffu) - (1 << 20);
+}
+__host__ __device__ inline uint32_t hashKey(uint64_t k) {
+  return mix32(static_cast<uint32_t>(k) ^ mix32(static_cast<uint32_t>(k >> 32) + 0x9e3779b9u));
+}
+
+__device__ inline uint32_t htLookup(const DevMap& m, uint64_t key) {
+  uint32_t h = hashKey(key) & m.ht_mask;
+  while (true) {
+    const uint64_t k = m.ht_keys[h];
+    if (k == key) return m.ht_vals[h];
+    if (k == kEmptyKey) return kInvalidSlot;
+    h = (h + 1) & m.ht_mask;
+  }
+}
+
+// insert a key that is known not to be present and that no other thread inserts concurrently
+__device__ inline void htInsertUnique(const DevMap& m, uint64_t key, uint32_t slot) {
+  uint32_t h = hashKey(key) & m.ht_mask;
+  while (true) {
+    const unsigned long long prev =
+        atomicCAS(reinterpret_cast<unsigned long long*>(&m.ht_keys[h]), static_cast<unsigned long long>(kEmptyKey),
+                  static_cast<unsigned long long>(key));
+    if (prev == kEmptyKey) {
+      m.ht_vals[h] = slot;
+      return;
+    }
+    h = (h + 1) & m.ht_mask;
+  }
+}
+
+__device__ inline void xform(const float* R, const float* t, float x, float y, float z, float* o) {
+  o[0] = ((R[0] * x + R[1] * y) + R[2] * z) + t[0];
+  o[1] = ((R[3] * x + R[4] * y) + R[5] * z) + t[1];
+  o[2] = ((R[6] * x + R[7] * y) + R[8] * z) + t[2];
+}
+
+__device__ inline double toSeconds(uint64_t ns) { return static_cast<double>(ns) / 1e9; }
+
+__device__ inline uint32_t laneId() { return __lane_id(); }
+
+// wave-aggregated atomic increment: returns this lane's index in the counter (only for lanes with pred)
+__device__ inline uint32_t waveAggInc(uint32_t* counter, bool pred) {
+  const unsigned long long mask = __ballot(pred);
+  if (mask == 0) return 0;
+  const uint32_t lane = laneId();
+  const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+  const int leader = __ffsll(static_cast<long long>(mask)) - 1;
+  uint32_t base = 0;
+  if (lane == static_cast<uint32_t>(leader)) base = atomicAdd(counter, static_cast<uint32_t>(__popcll(mask)));
+  base = __shfl(base, leader);
+  return base + rank;
+}
+
+__device__ inline uint8_t toU8(float f) {
+  float r = floorf(f + 0.5f);
+  r = fminf(255.f, fmaxf(0.f, r));
+  return static_cast<uint8_t>(r);
+}
+
+}  // namespace khr

@@ -1,0 +1,372 @@
+// khr_kernels_aux.h — motion-detector pixel binning / painting, marching cubes, block archival and
+// map housekeeping kernels.  gfx950, wave64.
+#pragma once
+#include "khr_device.h"
+
+namespace khr {
+
+#include "mc_table.inc"  // kMcTriTable / kMcNumTris (host copies)
+__constant__ int8_t c_mc_tri[256][16];
+__constant__ uint8_t c_mc_ntri[256];
+
+constexpr uint64_t kSeedBit = 1ull << 63;
+
+// ----------------------------------------------------------------------------------------------
+// k_motion_pixels: FreeSpaceMotionDetector::setUpPointMapPart (free_space_motion_detector.cpp:158-203),
+// one thread per pixel: range / z gates, world vertex from depth + pose, tracking-block lookup, voxel
+// index, ever-free test.  Emits a 64-bit sort key per pixel: packed global voxel index (63 bits) with
+// the seed flag in bit 63; ~0 for pixels that are skipped.  The per-voxel pixel lists of the reference
+// (nested hash maps) are recovered by a device radix sort + run-length encode of these keys.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_motion_pixels(DevMap m, DevParams p, DevFrame f, float md_max_range,
+                                                      float min_z_world, uint64_t* __restrict__ keys,
+                                                      uint32_t* __restrict__ pix) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= f.W * f.H) return;
+  uint64_t key = ~0ull;
+  const float r = f.range[i];
+  if (r > 0.f && !(r > md_max_range)) {
+    const float d = f.depth[i];
+    const int u = i % f.W, v = i / f.W;
+    const float x = ((static_cast<float>(u) - f.cx) / f.fx) * d;
+    const float y = ((static_cast<float>(v) - f.cy) / f.fy) * d;
+    float pw[3];
+    xform(f.Rw, f.tw, x, y, d, pw);
+    if (!(pw[2] < min_z_world)) {
+      const int bx = static_cast<int>(floorf(pw[0] * p.bs_inv)), by = static_cast<int>(floorf(pw[1] * p.bs_inv)),
+                bz = static_cast<int>(floorf(pw[2] * p.bs_inv));
+      const uint32_t slot = htLookup(m, packKey(bx, by, bz));
+      if (slot != kInvalidSlot) {
+        const float ox = static_cast<float>(bx) * p.bs, oy = static_cast<float>(by) * p.bs,
+                    oz = static_cast<float>(bz) * p.bs;
+        const int vx = static_cast<int>(floorf((pw[0] - ox) * p.vs_inv));
+        const int vy = static_cast<int>(floorf((pw[1] - oy) * p.vs_inv));
+        const int vz = static_cast<int>(floorf((pw[2] - oz) * p.vs_inv));
+        if (vx >= 0 && vy >= 0 && vz >= 0 && vx < p.vps && vy < p.vps && vz < p.vps) {
+          key = packKey(bx * p.vps + vx, by * p.vps + vy, bz * p.vps + vz);
+          const int lin = vx + p.vps * (vy + p.vps * vz);
+          if (m.vflags[static_cast<size_t>(slot) * p.nvox + lin] & VOX_EVER_FREE) key |= kSeedBit;
+        }
+      }
+    }
+  }
+  keys[i] = key;
+  pix[i] = static_cast<uint32_t>(i);
+  const bool seed = (key != ~0ull) && (key & kSeedBit);
+  const unsigned long long b = __ballot(seed);
+  if (b && laneId() == static_cast<uint32_t>(__ffsll(static_cast<long long>(b)) - 1))
+    atomicAdd(&m.counters[C_N_SEEDS], static_cast<uint32_t>(__popcll(b)));
+}
+
+// paint FrameData::dynamic_image (writeClustersToData, free_space_motion_detector.cpp:381-399):
+// sorted pixel j belongs to run (unique voxel) run_of[j]; run r carries the id of the last cluster that
+// contains it (0 = none).  One thread per sorted pixel; binary search of the run offsets.
+__global__ __launch_bounds__(256) void k_paint_dynamic(const uint32_t* __restrict__ sorted_pix,
+                                                      const uint32_t* __restrict__ run_offsets, int n_runs,
+                                                      const int32_t* __restrict__ run_id, int n_valid,
+                                                      int32_t* __restrict__ dyn) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_valid) return;
+  int lo = 0, hi = n_runs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (run_offsets[mid] <= static_cast<uint32_t>(j)) lo = mid; else hi = mid - 1;
+  }
+  const int id = run_id[lo];
+  if (id) dyn[sorted_pix[j]] = id;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Marching cubes (hydra::MeshIntegrator::generateMesh, ASSUMPTIONS.md A.5).  One workgroup per block;
+// the (VPS+1)^3 distance / weight tile (block + the +x/+y/+z faces, edges and corner of up to 7
+// neighbour blocks) is staged in LDS.  Pass 1 (EMIT=false) counts vertices per block; after an
+// exclusive scan over slots pass 2 (EMIT=true) recomputes the cubes and writes vertices at the block's
+// offset in voxel-linear order (block-wide prefix sum of per-voxel counts), so the output order is
+// deterministic.
+// ----------------------------------------------------------------------------------------------
+struct MeshBuffers {
+  float* points;       // 3 per vertex
+  uint32_t* colors;    // rgba8
+  uint32_t* labels;
+  uint64_t* stamps;    // last_observed of the source voxel (first_seen == stamps, ASSUMPTIONS.md A.5)
+};
+
+template <int VPS, bool EMIT>
+__global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, const uint32_t* __restrict__ work,
+                                                       const uint32_t* __restrict__ n_work,
+                                                       uint32_t* __restrict__ new_count,
+                                                       const uint32_t* __restrict__ new_offset, MeshBuffers out,
+                                                       int clear_flag) {
+  constexpr int NV = VPS * VPS * VPS;
+  constexpr int T = VPS + 1;
+  __shared__ float s_d[T * T * T];
+  __shared__ float s_w[T * T * T];
+  __shared__ uint32_t s_nslot[8];
+  __shared__ uint32_t s_scan[256];
+  const uint32_t n = *n_work;
+  for (uint32_t b = blockIdx.x; b < n; b += gridDim.x) {
+    const size_t slot = work[b];
+    const int4 bi = m.blk_index[slot];
+    __syncthreads();
+    if (threadIdx.x < 8) {
+      const int k = threadIdx.x;
+      s_nslot[k] = k == 0 ? static_cast<uint32_t>(slot)
+                          : htLookup(m, packKey(bi.x + (k & 1), bi.y + ((k >> 1) & 1), bi.z + ((k >> 2) & 1)));
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < T * T * T; c += 256) {
+      int x = c % T, y = (c / T) % T, z = c / (T * T);
+      int sel = 0;
+      if (x >= VPS) { x -= VPS; sel |= 1; }
+      if (y >= VPS) { y -= VPS; sel |= 2; }
+      if (z >= VPS) { z -= VPS; sel |= 4; }
+      const uint32_t ns = s_nslot[sel];
+      float d = 0.f, w = -1.f;  // missing neighbour block => unobserved
+      if (ns != kInvalidSlot) {
+        const size_t o = static_cast<size_t>(ns) * NV + (x + VPS * (y + VPS * z));
+        d = m.dist[o];
+        w = m.weight[o];
+      }
+      s_d[c] = d;
+      s_w[c] = w;
+    }
+    __syncthreads();
+    const float ox = static_cast<float>(bi.x) * p.bs, oy = static_cast<float>(bi.y) * p.bs,
+                oz = static_cast<float>(bi.z) * p.bs;
+    // per-thread: NV/256 cubes, linear index lin = threadIdx.x*PER + j so that a thread's cubes are
+    // consecutive in voxel-linear order and the block prefix sum gives voxel-linear output order.
+    constexpr int PER = NV / 256;
+    uint32_t cnt[PER];
+    int cases[PER];
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int lin = threadIdx.x * PER + j;
+      const int ix = lin % VPS, iy = (lin / VPS) % VPS, iz = lin / (VPS * VPS);
+      int index = 0;
+      bool ok = true;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int cx = ix + ((k == 1 || k == 2 || k == 5 || k == 6) ? 1 : 0);
+        const int cy = iy + ((k == 2 || k == 3 || k == 6 || k == 7) ? 1 : 0);
+        const int cz = iz + (k >= 4 ? 1 : 0);
+        const int c = cx + T * (cy + T * cz);
+        ok = ok && (s_w[c] >= p.mesh_min_weight);
+        if (s_d[c] < 0.f) index |= (1 << k);
+      }
+      if (!ok) index = 0;
+      cases[j] = index;
+      cnt[j] = 3u * c_mc_ntri[index];
+      tsum += cnt[j];
+    }
+    // block exclusive scan of tsum
+    s_scan[threadIdx.x] = tsum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      uint32_t v = 0;
+      if (threadIdx.x >= static_cast<uint32_t>(off)) v = s_scan[threadIdx.x - off];
+      __syncthreads();
+      s_scan[threadIdx.x] += v;
+      __syncthreads();
+    }
+    const uint32_t total = s_scan[255];
+    uint32_t base = s_scan[threadIdx.x] - tsum;
+    if (!EMIT) {
+      if (threadIdx.x == 0) new_count[slot] = total;
+    } else {
+      const uint32_t boff = new_offset[slot];
+      if (threadIdx.x == 0) {
+        m.mesh_desc[slot] = MeshDesc{boff, total};
+        if (clear_flag) m.blk_flags[slot] &= ~BLK_MESH_UPDATED;
+      }
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        if (cnt[j] == 0) continue;
+        const int lin = threadIdx.x * PER + j;
+        const int ix = lin % VPS, iy = (lin / VPS) % VPS, iz = lin / (VPS * VPS);
+        const int index = cases[j];
+        for (int col = 0; c_mc_tri[index][col] != -1; col += 3) {
+          for (int kk = 2; kk >= 0; --kk) {
+            const int e = c_mc_tri[index][col + kk];
+            // edge endpoints
+            const int ea = (e < 8) ? e : (e - 8);
+            const int eb = (e < 4) ? ((e + 1) & 3) : (e < 8 ? 4 + ((e - 4 + 1) & 3) : e - 4);
+            const int ax = (ea == 1 || ea == 2 || ea == 5 || ea == 6), ay = (ea == 2 || ea == 3 || ea == 6 || ea == 7),
+                      az = ea >= 4;
+            const int bx = (eb == 1 || eb == 2 || eb == 5 || eb == 6), by = (eb == 2 || eb == 3 || eb == 6 || eb == 7),
+                      bz = eb >= 4;
+            const float s0 = s_d[(ix + ax) + T * ((iy + ay) + T * (iz + az))];
+            const float s1 = s_d[(ix + bx) + T * ((iy + by) + T * (iz + bz))];
+            const float diff = s0 - s1;
+            float t = 0.5f;
+            if (fabsf(diff) >= 1e-6f) t = s0 / diff;
+            const float p0x = ox + (static_cast<float>(ix + ax) + 0.5f) * p.vs;
+            const float p0y = oy + (static_cast<float>(iy + ay) + 0.5f) * p.vs;
+            const float p0z = oz + (static_cast<float>(iz + az) + 0.5f) * p.vs;
+            const float p1x = ox + (static_cast<float>(ix + bx) + 0.5f) * p.vs;
+            const float p1y = oy + (static_cast<float>(iy + by) + 0.5f) * p.vs;
+            const float p1z = oz + (static_cast<float>(iz + bz) + 0.5f) * p.vs;
+            const size_t vo = static_cast<size_t>(boff) + base;
+            out.points[3 * vo] = p0x + t * (p1x - p0x);
+            out.points[3 * vo + 1] = p0y + t * (p1y - p0y);
+            out.points[3 * vo + 2] = p0z + t * (p1z - p0z);
+            // attributes of the nearer endpoint voxel
+            const int sx = (t <= 0.5f) ? ix + ax : ix + bx, sy = (t <= 0.5f) ? iy + ay : iy + by,
+                      sz = (t <= 0.5f) ? iz + az : iz + bz;
+            int lx = sx, ly = sy, lz = sz, sel = 0;
+            if (lx >= VPS) { lx -= VPS; sel |= 1; }
+            if (ly >= VPS) { ly -= VPS; sel |= 2; }
+            if (lz >= VPS) { lz -= VPS; sel |= 4; }
+            const size_t so = static_cast<size_t>(s_nslot[sel]) * NV + (lx + VPS * (ly + VPS * lz));
+            out.colors[vo] = m.color[so];
+            out.labels[vo] = p.with_semantics ? m.sem_label[so] : 0u;
+            out.stamps[vo] = p.with_tracking ? m.last_obs[so] : 0ull;
+            ++base;
+          }
+        }
+      }
+    }
+  }
+}
+
+// blocks that keep their mesh: carry old count over to the new count array
+__global__ __launch_bounds__(256) void k_mesh_carry_counts(DevMap m, uint32_t* __restrict__ new_count) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= m.counters[C_MAX_SLOT]) return;
+  new_count[s] = (m.blk_flags[s] & BLK_LIVE) ? m.mesh_desc[s].count : 0u;
+}
+
+// copy the meshes of blocks that are not regenerated from the old to the new vertex buffer.
+// one workgroup per slot (grid-stride); `regen` marks slots that pass 2 rewrites.
+__global__ __launch_bounds__(256) void k_mesh_move(DevMap m, const uint8_t* __restrict__ regen,
+                                                  const uint32_t* __restrict__ new_offset, MeshBuffers src,
+                                                  MeshBuffers dst) {
+  const uint32_t n_slots = m.counters[C_MAX_SLOT];
+  for (uint32_t s = blockIdx.x; s < n_slots; s += gridDim.x) {
+    if (!(m.blk_flags[s] & BLK_LIVE) || regen[s]) continue;
+    const MeshDesc d = m.mesh_desc[s];
+    if (d.count == 0) continue;
+    const size_t so = d.offset, dof = new_offset[s];
+    for (uint32_t i = threadIdx.x; i < d.count; i += blockDim.x) {
+      dst.points[3 * (dof + i)] = src.points[3 * (so + i)];
+      dst.points[3 * (dof + i) + 1] = src.points[3 * (so + i) + 1];
+      dst.points[3 * (dof + i) + 2] = src.points[3 * (so + i) + 2];
+      dst.colors[dof + i] = src.colors[so + i];
+      dst.labels[dof + i] = src.labels[so + i];
+      dst.stamps[dof + i] = src.stamps[so + i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) m.mesh_desc[s].offset = static_cast<uint32_t>(dof);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mark_regen(const uint32_t* __restrict__ work, const uint32_t* n_work,
+                                                   uint8_t* __restrict__ regen) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < *n_work) regen[work[i]] = 1;
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_reset_inactive: TrackingIntegrator::resetInactive (tracking_integrator.cpp:106-131).  One workgroup
+// per live block: all-voxels-to_remove reduction; blocks without active data or fully to_remove are
+// dropped from the pool (flags = 0) and their indices appended to the removed list.
+// ----------------------------------------------------------------------------------------------
+template <int VPS>
+__global__ __launch_bounds__(256) void k_reset_inactive(DevMap m, int4* __restrict__ removed) {
+  constexpr int NV = VPS * VPS * VPS;
+  const uint32_t n_slots = m.counters[C_MAX_SLOT];
+  for (uint32_t s = blockIdx.x; s < n_slots; s += gridDim.x) {
+    const uint32_t fl = m.blk_flags[s];
+    if (!(fl & BLK_LIVE)) continue;
+    bool all_remove = true;
+    if (fl & BLK_HAS_ACTIVE) {
+      const uint8_t* vfl = m.vflags + static_cast<size_t>(s) * NV;
+      for (int lin = threadIdx.x; lin < NV; lin += 256) all_remove = all_remove && (vfl[lin] & VOX_TO_REMOVE);
+    }
+    const int keep = __syncthreads_or(all_remove ? 0 : 1);
+    if (threadIdx.x == 0 && (!(fl & BLK_HAS_ACTIVE) || !keep)) {
+      removed[atomicAdd(&m.counters[C_N_REMOVED], 1u)] = m.blk_index[s];
+      m.blk_flags[s] = 0u;
+      m.mesh_desc[s] = MeshDesc{0u, 0u};
+    }
+  }
+}
+
+// rebuild the hash table from live slots after removals (single pass; keys were reset to empty)
+__global__ __launch_bounds__(256) void k_rehash(DevMap m) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= m.counters[C_MAX_SLOT]) return;
+  if (!(m.blk_flags[s] & BLK_LIVE)) return;
+  const int4 bi = m.blk_index[s];
+  htInsertUnique(m, packKey(bi.x, bi.y, bi.z), s);
+}
+
+// rebuild the free list: ordered compaction of non-live slots (single workgroup, ballot prefix sums)
+__global__ __launch_bounds__(1024) void k_rebuild_free_list(DevMap m) {
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_base;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t live_total = 0;
+  for (uint32_t start = 0; start < m.capacity; start += 1024) {
+    const uint32_t s = start + threadIdx.x;
+    const bool is_free = s < m.capacity && !(m.blk_flags[s] & BLK_LIVE);
+    const unsigned long long b = __ballot(is_free);
+    if (lane == 0) s_wave[wave] = __popcll(b);
+    __syncthreads();
+    uint32_t off = s_base;
+    for (uint32_t w = 0; w < wave; ++w) off += s_wave[w];
+    if (is_free) m.free_slots[off + __popcll(b & ((1ull << lane) - 1ull))] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t t = 0;
+      for (int w = 0; w < 16; ++w) t += s_wave[w];
+      s_base += t;
+    }
+    __syncthreads();
+  }
+  (void)live_total;
+  if (threadIdx.x == 0) {
+    m.counters[C_N_FREE] = s_base;
+    m.counters[C_FREE_HEAD] = 0;
+    m.counters[C_N_LIVE] = m.capacity - s_base;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_block_flag_op(DevMap m, uint32_t and_mask, uint32_t or_mask) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= m.counters[C_MAX_SLOT]) return;
+  const uint32_t fl = m.blk_flags[s];
+  if (fl & BLK_LIVE) m.blk_flags[s] = (fl & and_mask) | or_mask;
+}
+
+// MeshObjectExtractor confidence pruning (mesh_object_extractor.cpp:246-264, computeConfidence :342-356)
+template <int VPS>
+__global__ __launch_bounds__(256) void k_object_prune(DevMap m, DevParams p, float min_conf, float min_obs) {
+  constexpr int NV = VPS * VPS * VPS;
+  const uint32_t n_slots = m.counters[C_MAX_SLOT];
+  uint32_t pruned = 0;
+  for (uint32_t s = blockIdx.x; s < n_slots; s += gridDim.x) {
+    if (!(m.blk_flags[s] & BLK_LIVE)) continue;
+    const size_t o = static_cast<size_t>(s) * NV;
+    for (int lin = threadIdx.x; lin < NV; lin += 256) {
+      const float d = m.dist[o + lin];
+      if (d > 0.f) continue;
+      float conf = 0.f;
+      if (m.vflags[o + lin] & VOX_SEM_VALID) {
+        const float l0 = m.lik[(static_cast<size_t>(s) * p.K + 0) * NV + lin];
+        const float l1 = m.lik[(static_cast<size_t>(s) * p.K + 1) * NV + lin];
+        const float total = l0 + l1;
+        conf = total < min_obs ? -1.f : l1 / total;
+      }
+      if (conf < min_conf) {
+        m.dist[o + lin] = p.trunc;
+        ++pruned;
+      }
+    }
+  }
+  if (pruned) atomicAdd(&m.stats[S_PRUNED], static_cast<unsigned long long>(pruned));
+}
+
+}  // namespace khr

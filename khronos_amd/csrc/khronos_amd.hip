@@ -1,0 +1,1118 @@
+// khronos_amd.hip — implementation of the C ABI declared in include/khronos_amd.h.
+// Host code here only owns HBM buffers, enqueues the gfx950 kernels on one HIP stream and does the
+// small sequential parts of the path (motion-cluster graph walk) that the reference also runs
+// sequentially (free_space_motion_detector.cpp:205-379).  There is deliberately NO CPU fallback for any
+// kernel: without a HIP device khr_create fails.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/khronos_amd.h"
+#include "khr_device.h"
+#include "khr_kernels_aux.h"
+#include "khr_kernels_fusion.h"
+
+using namespace khr;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return fail(KHR_EDEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+struct FrameSlot {
+  float* depth = nullptr;
+  float* range = nullptr;
+  uint32_t* rgba = nullptr;
+  int32_t* label = nullptr;
+  int32_t* dyn = nullptr;
+  int32_t* obj = nullptr;
+  uint8_t* rgb_staging = nullptr;
+  khr_sensor sensor{};
+  khr_frame meta{};
+  bool valid = false, has_color = false, has_label = false, has_obj = false;
+};
+
+struct TimingRec {
+  int which;
+  hipEvent_t a, b;
+};
+
+constexpr int kNumTimers = 8;
+
+}  // namespace
+
+struct khr_ctx {
+  khr_config cfg{};
+  DevParams p{};
+  DevMap m{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::vector<void*> allocs;
+  std::vector<FrameSlot> slots;
+  int next_slot = 0;
+  // work lists
+  uint32_t* d_work = nullptr;
+  uint32_t* d_new = nullptr;
+  uint32_t* d_ef = nullptr;
+  int4* d_removed = nullptr;
+  int* d_idx_staging = nullptr;
+  // motion detection scratch
+  uint64_t *d_keys = nullptr, *d_keys_sorted = nullptr, *d_unique = nullptr;
+  uint32_t *d_pix = nullptr, *d_pix_sorted = nullptr, *d_counts = nullptr, *d_num_runs = nullptr,
+           *d_run_offsets = nullptr;
+  int32_t* d_run_id = nullptr;
+  void* d_cub_temp = nullptr;
+  size_t cub_temp_bytes = 0;
+  // mesh
+  MeshBuffers mesh[2]{};
+  int mesh_cur = 0;
+  uint32_t *d_mesh_count = nullptr, *d_mesh_offset = nullptr;
+  uint8_t* d_regen = nullptr;
+  uint32_t* d_mesh_nwork = nullptr;
+  uint64_t mesh_total = 0;
+  // host mirrors
+  std::vector<uint32_t> h_counters;
+  khr_stats stats{};
+  bool host_index_valid = false;
+  std::map<std::array<int32_t, 3>, uint32_t> host_index;
+  std::vector<uint32_t> host_flags;
+  // timing
+  bool timing = false;
+  std::vector<TimingRec> pending;
+  double t_ms[kNumTimers] = {0};
+  uint64_t t_n[kNumTimers] = {0};
+};
+
+namespace {
+
+struct ScopedTimer {
+  khr_ctx* c;
+  int which;
+  hipEvent_t a = nullptr, b = nullptr;
+  ScopedTimer(khr_ctx* ctx, int w) : c(ctx), which(w) {
+    if (c->timing) {
+      hipEventCreate(&a);
+      hipEventCreate(&b);
+      hipEventRecord(a, c->stream);
+    }
+  }
+  ~ScopedTimer() {
+    if (c->timing) {
+      hipEventRecord(b, c->stream);
+      c->pending.push_back({which, a, b});
+    }
+  }
+};
+
+void resolveTimers(khr_ctx* c) {
+  for (auto& r : c->pending) {
+    hipEventSynchronize(r.b);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, r.a, r.b);
+    c->t_ms[r.which] += ms;
+    c->t_n[r.which] += 1;
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  c->pending.clear();
+}
+
+template <typename T>
+int devAlloc(khr_ctx* c, T** out, size_t count, bool zero = true) {
+  void* p = nullptr;
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) return fail(KHR_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+  c->allocs.push_back(p);
+  if (zero) {
+    e = hipMemsetAsync(p, 0, bytes, c->stream);
+    if (e != hipSuccess) return fail(KHR_EDEVICE, "hipMemset failed: %s", hipGetErrorString(e));
+  }
+  *out = static_cast<T*>(p);
+  return KHR_OK;
+}
+
+void makePose(const double* T, float* R, float* t, float* Rw, float* tw) {
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) Rw[3 * r + c] = static_cast<float>(T[4 * r + c]);
+    tw[r] = static_cast<float>(T[4 * r + 3]);
+  }
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) R[3 * r + c] = static_cast<float>(T[4 * c + r]);
+    const double v = -(T[4 * 0 + r] * T[3] + T[4 * 1 + r] * T[7] + T[4 * 2 + r] * T[11]);
+    t[r] = static_cast<float>(v);
+  }
+}
+
+void crossn(const float* a, const float* b, float* o) {
+  const float x = a[1] * b[2] - a[2] * b[1];
+  const float y = a[2] * b[0] - a[0] * b[2];
+  const float z = a[0] * b[1] - a[1] * b[0];
+  const float n = std::sqrt((x * x + y * y) + z * z);
+  o[0] = x / n;
+  o[1] = y / n;
+  o[2] = z / n;
+}
+
+DevFrame makeDevFrame(const khr_ctx* c, const FrameSlot& s) {
+  DevFrame f{};
+  f.depth = s.depth;
+  f.range = s.range;
+  f.rgba = s.rgba;
+  f.label = s.label;
+  f.dyn = s.dyn;
+  f.obj = s.has_obj ? s.obj : nullptr;
+  f.W = s.sensor.width;
+  f.H = s.sensor.height;
+  f.fx = s.sensor.fx;
+  f.fy = s.sensor.fy;
+  f.cx = s.sensor.cx;
+  f.cy = s.sensor.cy;
+  f.min_range = s.sensor.min_range;
+  f.max_range = s.sensor.max_range;
+  makePose(s.meta.world_T_sensor, f.R, f.t, f.Rw, f.tw);
+  f.stamp = s.meta.timestamp_ns;
+  f.has_color = s.has_color;
+  f.has_label = s.has_label;
+  (void)c;
+  return f;
+}
+
+DevFrustum makeFrustum(const khr_ctx* c, const DevFrame& f) {
+  DevFrustum fr{};
+  const float xl = (0.f - f.cx) / f.fx, xr = (static_cast<float>(f.W) - f.cx) / f.fx;
+  const float yt = (0.f - f.cy) / f.fy, yb = (static_cast<float>(f.H) - f.cy) / f.fy;
+  const float tl[3] = {xl, yt, 1.f}, tr[3] = {xr, yt, 1.f}, bl[3] = {xl, yb, 1.f}, br[3] = {xr, yb, 1.f};
+  crossn(bl, tl, fr.n[0]);
+  crossn(tr, br, fr.n[1]);
+  crossn(tl, tr, fr.n[2]);
+  crossn(br, bl, fr.n[3]);
+  fr.infl = 0.8660254f * c->p.bs;
+  fr.n_steps = static_cast<int>(std::ceil(f.max_range * c->p.bs_inv)) + 1;
+  fr.bc = make_int3(static_cast<int>(std::floor(f.tw[0] * c->p.bs_inv)),
+                    static_cast<int>(std::floor(f.tw[1] * c->p.bs_inv)),
+                    static_cast<int>(std::floor(f.tw[2] * c->p.bs_inv)));
+  return fr;
+}
+
+int readCounters(khr_ctx* c) {
+  c->h_counters.resize(C_COUNT);
+  HIP_TRY(hipMemcpyAsync(c->h_counters.data(), c->m.counters, sizeof(uint32_t) * C_COUNT, hipMemcpyDeviceToHost,
+                         c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return KHR_OK;
+}
+
+int ensureHostIndex(khr_ctx* c) {
+  if (c->host_index_valid) return KHR_OK;
+  int rc = readCounters(c);
+  if (rc) return rc;
+  const uint32_t n = c->h_counters[C_MAX_SLOT];
+  std::vector<int4> idx(n);
+  c->host_flags.resize(n);
+  if (n) {
+    HIP_TRY(hipMemcpyAsync(idx.data(), c->m.blk_index, sizeof(int4) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->host_flags.data(), c->m.blk_flags, sizeof(uint32_t) * n, hipMemcpyDeviceToHost,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  c->host_index.clear();
+  for (uint32_t s = 0; s < n; ++s)
+    if (c->host_flags[s] & BLK_LIVE) c->host_index[{idx[s].x, idx[s].y, idx[s].z}] = s;
+  c->host_index_valid = true;
+  return KHR_OK;
+}
+
+inline int gridFor(size_t n, int block = 256) { return static_cast<int>((n + block - 1) / block); }
+
+template <typename F>
+int dispatchVps(khr_ctx* c, F&& f) {
+  if (c->cfg.voxels_per_side == 16) return f(std::integral_constant<int, 16>());
+  if (c->cfg.voxels_per_side == 8) return f(std::integral_constant<int, 8>());
+  return fail(KHR_EINVAL, "voxels_per_side must be 8 or 16");
+}
+
+constexpr int kTsdfGrid = 8192;   // multiple of 8 (XCD-aware walk)
+constexpr int kStreamGrid = 4096;
+
+}  // namespace
+
+extern "C" {
+
+const char* khr_last_error(void) { return g_last_error.c_str(); }
+
+void khr_default_config(khr_config* cfg) {
+  std::memset(cfg, 0, sizeof(*cfg));
+  cfg->voxel_size = 0.1f;
+  cfg->voxels_per_side = 16;
+  cfg->truncation_distance = 0.3f;
+  cfg->with_semantics = 0;  // ActiveWindow::Config() : hydra::ActiveWindowModule::Config(false, true)
+  cfg->with_tracking = 1;
+  cfg->num_labels = 20;
+  cfg->use_weight_dropoff = 1;
+  cfg->weight_dropoff_epsilon = -1.0f;
+  cfg->use_constant_weight = 0;
+  cfg->max_weight = 1e5f;
+  cfg->interpolation_method = 2;
+  cfg->adaptive_max_range_difference = 0.2f;
+  cfg->range_mode = 0;
+  cfg->semantic_mode = 0;
+  cfg->label_confidence = 0.9f;
+  cfg->temporal_buffer = 1.f;
+  cfg->tsdf_occupancy_threshold = -1.5f;
+  cfg->neighbor_connectivity = 18;
+  cfg->temporal_window = 3.f;
+  cfg->md_neighbor_connectivity = 26;
+  cfg->md_min_cluster_size = 0;
+  cfg->md_max_cluster_size = 1000000;
+  cfg->md_min_separation_distance = 1.0f;
+  cfg->md_max_range = 10000.f;
+  cfg->md_min_z_coordinate = -10000.f;
+  cfg->mesh_min_weight = 1e-4f;
+  cfg->max_blocks = 16384;
+  cfg->max_frame_pixels = 1280 * 720;
+  cfg->num_frame_slots = 2;
+  cfg->max_mesh_vertices = 8u << 20;
+  cfg->device = 0;
+  cfg->rank = 0;
+  cfg->world_size = 1;
+}
+
+int khr_create(const khr_config* cfg, khr_ctx** out) {
+  if (!cfg || !out) return fail(KHR_EINVAL, "null argument");
+  *out = nullptr;
+  // config validation (reference: config::checkValid, tracking_integrator.cpp:61-65,
+  // free_space_motion_detector.cpp:63-67)
+  if (!(cfg->voxel_size > 0.f) || !(cfg->truncation_distance > 0.f)) return fail(KHR_EINVAL, "voxel_size / truncation_distance must be > 0");
+  if (cfg->voxels_per_side != 16 && cfg->voxels_per_side != 8) return fail(KHR_EINVAL, "voxels_per_side must be 8 or 16");
+  auto conn_ok = [](int c) { return c == 6 || c == 18 || c == 26; };
+  if (!conn_ok(cfg->neighbor_connectivity) || !conn_ok(cfg->md_neighbor_connectivity)) return fail(KHR_EINVAL, "neighbor_connectivity must be one of {6, 18, 26}");
+  if (!(cfg->temporal_buffer > 0.f) || !(cfg->temporal_window > 0.f)) return fail(KHR_EINVAL, "temporal_buffer / temporal_window must be > 0");
+  if (cfg->tsdf_occupancy_threshold == 0.f) return fail(KHR_EINVAL, "tsdf_occupancy_threshold must be != 0");
+  if (cfg->md_max_cluster_size < cfg->md_min_cluster_size) return fail(KHR_EINVAL, "param 'max_cluster_size' must be >= 'min_cluster_size'");
+  if (!(cfg->md_max_range > 0.f)) return fail(KHR_EINVAL, "md_max_range must be > 0");
+  if (cfg->with_semantics && cfg->num_labels < 1) return fail(KHR_EINVAL, "num_labels must be >= 1 with semantics");
+  if (cfg->semantic_mode == 1 && cfg->with_semantics && cfg->num_labels != 2) return fail(KHR_EINVAL, "binary semantic integrator needs num_labels == 2");
+  if (cfg->max_blocks < 1 || cfg->max_frame_pixels < 1 || cfg->num_frame_slots < 1) return fail(KHR_EINVAL, "capacities must be >= 1");
+  if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(KHR_EINVAL, "bad rank / world_size");
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(KHR_EDEVICE, "no HIP device available: the khronos_amd fusion path has no CPU fallback");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(KHR_EINVAL, "device %d out of range (%d devices)", cfg->device, ndev);
+  HIP_TRY(hipSetDevice(cfg->device));
+
+  auto* c = new khr_ctx();
+  c->cfg = *cfg;
+  c->device = cfg->device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return fail(KHR_EDEVICE, "hipStreamCreate failed");
+  }
+  c->own_stream = true;
+
+  DevParams& p = c->p;
+  p.vs = cfg->voxel_size;
+  p.vs_inv = 1.f / cfg->voxel_size;
+  p.vps = cfg->voxels_per_side;
+  p.nvox = p.vps * p.vps * p.vps;
+  p.bs = cfg->voxel_size * static_cast<float>(cfg->voxels_per_side);
+  p.bs_inv = 1.f / p.bs;
+  p.trunc = cfg->truncation_distance;
+  p.K = cfg->with_semantics ? cfg->num_labels : 1;
+  p.with_semantics = cfg->with_semantics;
+  p.with_tracking = cfg->with_tracking;
+  p.use_dropoff = cfg->use_weight_dropoff;
+  p.const_weight = cfg->use_constant_weight;
+  p.interp = cfg->interpolation_method;
+  p.range_mode = cfg->range_mode;
+  p.sem_mode = cfg->semantic_mode;
+  p.dropoff_eps = cfg->weight_dropoff_epsilon > 0.f ? cfg->weight_dropoff_epsilon : cfg->weight_dropoff_epsilon * -cfg->voxel_size;
+  p.max_weight = cfg->max_weight;
+  p.adaptive_diff = cfg->adaptive_max_range_difference;
+  p.log_match = std::log(cfg->label_confidence);
+  p.log_nomatch = cfg->num_labels > 1 ? std::log((1.f - cfg->label_confidence) / static_cast<float>(cfg->num_labels - 1)) : 0.f;
+  p.occ_thr = cfg->tsdf_occupancy_threshold < 0 ? cfg->tsdf_occupancy_threshold * -cfg->voxel_size : cfg->tsdf_occupancy_threshold;
+  p.temporal_buffer = static_cast<double>(cfg->temporal_buffer);
+  p.temporal_window = static_cast<double>(cfg->temporal_window);
+  p.nn = cfg->neighbor_connectivity;
+  p.mesh_min_weight = cfg->mesh_min_weight;
+  p.rank = cfg->rank;
+  p.world = cfg->world_size;
+
+  DevMap& m = c->m;
+  const size_t cap = cfg->max_blocks, nv = p.nvox;
+  uint32_t ht = 1;
+  while (ht < cap * 4) ht <<= 1;
+  m.ht_mask = ht - 1;
+  m.capacity = static_cast<uint32_t>(cap);
+  int rc = KHR_OK;
+  auto A = [&](int r) { if (rc == KHR_OK) rc = r; };
+  A(devAlloc(c, &m.ht_keys, ht, false));
+  A(devAlloc(c, &m.ht_vals, ht));
+  A(devAlloc(c, &m.blk_index, cap));
+  A(devAlloc(c, &m.blk_flags, cap));
+  A(devAlloc(c, &m.dist, cap * nv, false));
+  A(devAlloc(c, &m.weight, cap * nv, false));
+  A(devAlloc(c, &m.color, cap * nv, false));
+  A(devAlloc(c, &m.vflags, cap * nv, false));
+  A(devAlloc(c, &m.sem_label, cfg->with_semantics ? cap * nv : 1, false));
+  A(devAlloc(c, &m.lik, cfg->with_semantics ? cap * nv * p.K : 1, false));
+  A(devAlloc(c, &m.last_obs, cfg->with_tracking ? cap * nv : 1, false));
+  A(devAlloc(c, &m.last_occ, cfg->with_tracking ? cap * nv : 1, false));
+  A(devAlloc(c, &m.freebits, cfg->with_tracking ? cap * (nv / 64) : 1, false));
+  A(devAlloc(c, &m.free_slots, cap, false));
+  A(devAlloc(c, &m.counters, C_COUNT));
+  A(devAlloc(c, &m.stats, S_COUNT));
+  A(devAlloc(c, &m.mesh_desc, cap));
+  A(devAlloc(c, &c->d_work, cap));
+  A(devAlloc(c, &c->d_new, cap));
+  A(devAlloc(c, &c->d_ef, cap));
+  A(devAlloc(c, &c->d_removed, cap));
+  A(devAlloc(c, &c->d_mesh_count, cap + 1));
+  A(devAlloc(c, &c->d_mesh_offset, cap + 1));
+  A(devAlloc(c, &c->d_regen, cap));
+  A(devAlloc(c, &c->d_mesh_nwork, 4));
+  const size_t npx = cfg->max_frame_pixels;
+  A(devAlloc(c, &c->d_keys, npx, false));
+  A(devAlloc(c, &c->d_keys_sorted, npx, false));
+  A(devAlloc(c, &c->d_unique, npx, false));
+  A(devAlloc(c, &c->d_pix, npx, false));
+  A(devAlloc(c, &c->d_pix_sorted, npx, false));
+  A(devAlloc(c, &c->d_counts, npx, false));
+  A(devAlloc(c, &c->d_run_offsets, npx, false));
+  A(devAlloc(c, &c->d_run_id, npx, false));
+  A(devAlloc(c, &c->d_num_runs, 4));
+  if (rc == KHR_OK) {
+    size_t t1 = 0, t2 = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, t1, c->d_keys, c->d_keys_sorted, c->d_pix, c->d_pix_sorted,
+                                       static_cast<int>(npx), 0, 64, c->stream);
+    hipcub::DeviceRunLengthEncode::Encode(nullptr, t2, c->d_keys_sorted, c->d_unique, c->d_counts, c->d_num_runs,
+                                          static_cast<int>(npx), c->stream);
+    size_t t3 = 0;
+    hipcub::DeviceScan::ExclusiveSum(nullptr, t3, c->d_mesh_count, c->d_mesh_offset, static_cast<int>(cap + 1),
+                                     c->stream);
+    c->cub_temp_bytes = std::max(std::max(t1, t2), t3) + 256;
+    uint8_t* tmp = nullptr;
+    A(devAlloc(c, &tmp, c->cub_temp_bytes, false));
+    c->d_cub_temp = tmp;
+  }
+  for (int b = 0; b < 2 && rc == KHR_OK; ++b) {
+    A(devAlloc(c, &c->mesh[b].points, cfg->max_mesh_vertices * 3, false));
+    A(devAlloc(c, &c->mesh[b].colors, cfg->max_mesh_vertices, false));
+    A(devAlloc(c, &c->mesh[b].labels, cfg->max_mesh_vertices, false));
+    A(devAlloc(c, &c->mesh[b].stamps, cfg->max_mesh_vertices, false));
+  }
+  c->slots.resize(cfg->num_frame_slots);
+  for (auto& s : c->slots) {
+    if (rc != KHR_OK) break;
+    A(devAlloc(c, &s.depth, npx, false));
+    A(devAlloc(c, &s.range, npx, false));
+    A(devAlloc(c, &s.rgba, npx, false));
+    A(devAlloc(c, &s.label, npx, false));
+    A(devAlloc(c, &s.dyn, npx));
+    A(devAlloc(c, &s.obj, npx));
+    A(devAlloc(c, &s.rgb_staging, npx * 3, false));
+  }
+  if (rc != KHR_OK) {
+    khr_destroy(c);
+    return rc;
+  }
+  // initial state: empty hash, free list = identity, constant tables
+  hipError_t e = hipMemsetAsync(m.ht_keys, 0xff, sizeof(uint64_t) * ht, c->stream);
+  if (e == hipSuccess) {
+    std::vector<uint32_t> ident(cap);
+    for (size_t i = 0; i < cap; ++i) ident[i] = static_cast<uint32_t>(i);
+    e = hipMemcpyAsync(m.free_slots, ident.data(), sizeof(uint32_t) * cap, hipMemcpyHostToDevice, c->stream);
+    uint32_t ctr[C_COUNT] = {0};
+    ctr[C_N_FREE] = static_cast<uint32_t>(cap);
+    if (e == hipSuccess) e = hipMemcpyAsync(m.counters, ctr, sizeof(ctr), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_mc_tri), kMcTriTable, sizeof(kMcTriTable));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_mc_ntri), kMcNumTris, sizeof(kMcNumTris));
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  }
+  if (e != hipSuccess) {
+    khr_destroy(c);
+    return fail(KHR_EDEVICE, "context initialisation failed: %s", hipGetErrorString(e));
+  }
+  *out = c;
+  return KHR_OK;
+}
+
+void khr_destroy(khr_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  resolveTimers(c);
+  for (void* p : c->allocs) hipFree(p);
+  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int khr_set_stream(khr_ctx* c, void* hip_stream) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->own_stream) {
+    hipStreamDestroy(c->stream);
+    c->own_stream = false;
+  }
+  if (hip_stream) {
+    c->stream = static_cast<hipStream_t>(hip_stream);
+  } else {
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  return KHR_OK;
+}
+
+int khr_sync(khr_ctx* c) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return KHR_OK;
+}
+
+int khr_upload_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame, int on_device) {
+  if (!c || !sensor || !frame || !frame->depth) return fail(KHR_EINVAL, "null argument");
+  const size_t n = static_cast<size_t>(sensor->width) * sensor->height;
+  if (sensor->width < 2 || sensor->height < 2 || n > c->cfg.max_frame_pixels)
+    return fail(KHR_EINVAL, "frame %dx%d exceeds max_frame_pixels=%u", sensor->width, sensor->height, c->cfg.max_frame_pixels);
+  if (!(sensor->fx > 0.f) || !(sensor->fy > 0.f) || !(sensor->max_range > sensor->min_range))
+    return fail(KHR_EINVAL, "bad intrinsics / range");
+  HIP_TRY(hipSetDevice(c->device));
+  const int slot = c->next_slot;
+  c->next_slot = (c->next_slot + 1) % static_cast<int>(c->slots.size());
+  FrameSlot& s = c->slots[slot];
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  s.sensor = *sensor;
+  s.meta = *frame;
+  s.meta.depth = nullptr;
+  s.meta.color = nullptr;
+  s.meta.label = nullptr;
+  s.has_color = frame->color != nullptr;
+  s.has_label = frame->label != nullptr;
+  s.has_obj = false;
+  ScopedTimer tm(c, 6);
+  HIP_TRY(hipMemcpyAsync(s.depth, frame->depth, n * sizeof(float), kind, c->stream));
+  const uint8_t* rgb_dev = nullptr;
+  if (frame->color) {
+    if (on_device) {
+      rgb_dev = frame->color;
+    } else {
+      HIP_TRY(hipMemcpyAsync(s.rgb_staging, frame->color, n * 3, kind, c->stream));
+      rgb_dev = s.rgb_staging;
+    }
+  }
+  if (frame->label) HIP_TRY(hipMemcpyAsync(s.label, frame->label, n * sizeof(int32_t), kind, c->stream));
+  HIP_TRY(hipMemsetAsync(s.dyn, 0, n * sizeof(int32_t), c->stream));
+  hipLaunchKernelGGL(k_parse_input, dim3(gridFor(n)), dim3(256), 0, c->stream, s.depth, rgb_dev, s.range, s.rgba,
+                     sensor->width, sensor->height, sensor->fx, sensor->fy, sensor->cx, sensor->cy, c->p.range_mode);
+  HIP_TRY(hipGetLastError());
+  if (!on_device) HIP_TRY(hipStreamSynchronize(c->stream));  // caller buffers may be reused after return
+  s.valid = true;
+  return slot;
+}
+
+int khr_set_frame_image(khr_ctx* c, int slot, int which, const int32_t* image, int on_device) {
+  if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
+  FrameSlot& s = c->slots[slot];
+  const size_t n = static_cast<size_t>(s.sensor.width) * s.sensor.height;
+  int32_t* dst = which == 0 ? s.dyn : s.obj;
+  if (image) {
+    HIP_TRY(hipMemcpyAsync(dst, image, n * sizeof(int32_t), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    if (!on_device) HIP_TRY(hipStreamSynchronize(c->stream));
+  } else {
+    HIP_TRY(hipMemsetAsync(dst, 0, n * sizeof(int32_t), c->stream));
+  }
+  if (which == 1) s.has_obj = image != nullptr;
+  return KHR_OK;
+}
+
+int khr_download_frame(khr_ctx* c, int slot, float* range, float* vertex_map, int32_t* dynamic_image) {
+  if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
+  FrameSlot& s = c->slots[slot];
+  const size_t n = static_cast<size_t>(s.sensor.width) * s.sensor.height;
+  if (range) HIP_TRY(hipMemcpyAsync(range, s.range, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (dynamic_image) HIP_TRY(hipMemcpyAsync(dynamic_image, s.dyn, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  if (vertex_map) {
+    float* d_v = nullptr;
+    HIP_TRY(hipMalloc(&d_v, n * 3 * sizeof(float)));
+    hipLaunchKernelGGL(k_vertex_map, dim3(gridFor(n)), dim3(256), 0, c->stream, makeDevFrame(c, s), d_v);
+    hipError_t e = hipMemcpyAsync(vertex_map, d_v, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    hipStreamSynchronize(c->stream);
+    hipFree(d_v);
+    if (e != hipSuccess) return fail(KHR_EDEVICE, "vertex map download failed");
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return KHR_OK;
+}
+
+int khr_integrate(khr_ctx* c, int slot, int allocate_blocks, int use_mask, int object_id) {
+  if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
+  HIP_TRY(hipSetDevice(c->device));
+  FrameSlot& s = c->slots[slot];
+  const DevFrame f = makeDevFrame(c, s);
+  DevMap& m = c->m;
+  // reset per-call counters
+  HIP_TRY(hipMemsetAsync(&m.counters[C_N_VISIBLE], 0, sizeof(uint32_t) * 2, c->stream));  // N_VISIBLE, N_NEW
+  HIP_TRY(hipMemsetAsync(&m.stats[S_UPD], 0, sizeof(unsigned long long) * 2, c->stream));
+  if (allocate_blocks) {
+    ScopedTimer tm(c, 3);
+    const DevFrustum fr = makeFrustum(c, f);
+    const int S = 2 * fr.n_steps + 1;
+    const size_t total = static_cast<size_t>(S) * S * S;
+    hipLaunchKernelGGL(k_alloc_visible, dim3(gridFor(total)), dim3(256), 0, c->stream, m, c->p, f, fr, c->d_work, c->d_new);
+    hipLaunchKernelGGL(k_init_blocks, dim3(2048), dim3(256), 0, c->stream, m, c->p, c->d_new);
+    c->host_index_valid = false;
+  } else {
+    hipLaunchKernelGGL(k_list_live, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_work,
+                       &m.counters[C_N_VISIBLE], 0u);
+  }
+  {
+    ScopedTimer tm(c, 0);
+    int rc = dispatchVps(c, [&](auto vps) {
+      hipLaunchKernelGGL((k_tsdf_update<decltype(vps)::value>), dim3(kTsdfGrid), dim3(256), 0, c->stream, m, c->p, f,
+                         c->d_work, &m.counters[C_N_VISIBLE], use_mask, object_id);
+      return KHR_OK;
+    });
+    if (rc) return rc;
+  }
+  HIP_TRY(hipGetLastError());
+  return KHR_OK;
+}
+
+int khr_update_tracking(khr_ctx* c, uint64_t stamp) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  if (!c->cfg.with_tracking) return KHR_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  DevMap& m = c->m;
+  HIP_TRY(hipMemsetAsync(&m.counters[C_N_EF], 0, sizeof(uint32_t), c->stream));
+  return dispatchVps(c, [&](auto vps) {
+    {
+      ScopedTimer tm(c, 1);
+      hipLaunchKernelGGL((k_tracking_update<decltype(vps)::value>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p,
+                         stamp, c->d_ef);
+    }
+    {
+      ScopedTimer tm(c, 2);
+      hipLaunchKernelGGL((k_ever_free<decltype(vps)::value>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, c->d_ef);
+    }
+    HIP_TRY(hipGetLastError());
+    return KHR_OK;
+  });
+}
+
+// ---------------------------------------------------------------------------------------------
+// motion detection: device pixel pass + sort / run-length encode, host graph walk, device paint
+// ---------------------------------------------------------------------------------------------
+int khr_detect_motion(khr_ctx* c, int slot) {
+  if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
+  HIP_TRY(hipSetDevice(c->device));
+  FrameSlot& s = c->slots[slot];
+  const size_t n = static_cast<size_t>(s.sensor.width) * s.sensor.height;
+  HIP_TRY(hipMemsetAsync(s.dyn, 0, n * sizeof(int32_t), c->stream));
+  c->stats.n_seeds = 0;
+  if (!c->cfg.with_tracking) return 0;
+  DevMap& m = c->m;
+  const DevFrame f = makeDevFrame(c, s);
+  // free_space_motion_detector.cpp:80
+  const float min_z_world = static_cast<float>(s.meta.world_T_sensor[11] + static_cast<double>(c->cfg.md_min_z_coordinate));
+  HIP_TRY(hipMemsetAsync(&m.counters[C_N_SEEDS], 0, sizeof(uint32_t), c->stream));
+  {
+    ScopedTimer tm(c, 4);
+    hipLaunchKernelGGL(k_motion_pixels, dim3(gridFor(n)), dim3(256), 0, c->stream, m, c->p, f, c->cfg.md_max_range,
+                       min_z_world, c->d_keys, c->d_pix);
+  }
+  uint32_t n_seed_px = 0;
+  HIP_TRY(hipMemcpyAsync(&n_seed_px, &m.counters[C_N_SEEDS], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (n_seed_px == 0) return 0;  // no seeds => no clusters (clusterDynamicVoxels loops over seeds only)
+
+  size_t tb = c->cub_temp_bytes;
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->d_cub_temp, tb, c->d_keys, c->d_keys_sorted, c->d_pix, c->d_pix_sorted,
+                                             static_cast<int>(n), 0, 64, c->stream));
+  tb = c->cub_temp_bytes;
+  HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(c->d_cub_temp, tb, c->d_keys_sorted, c->d_unique, c->d_counts,
+                                                c->d_num_runs, static_cast<int>(n), c->stream));
+  uint32_t n_runs = 0;
+  HIP_TRY(hipMemcpyAsync(&n_runs, c->d_num_runs, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  std::vector<uint64_t> keys(n_runs);
+  std::vector<uint32_t> counts(n_runs);
+  HIP_TRY(hipMemcpyAsync(keys.data(), c->d_unique, sizeof(uint64_t) * n_runs, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(counts.data(), c->d_counts, sizeof(uint32_t) * n_runs, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (n_runs && keys[n_runs - 1] == ~0ull) --n_runs;  // skipped pixels sort last
+  // runs are sorted by key: [non-seed voxels ascending][seed voxels ascending]
+  uint32_t first_seed = n_runs;
+  {
+    auto it = std::lower_bound(keys.begin(), keys.begin() + n_runs, kSeedBit);
+    first_seed = static_cast<uint32_t>(it - keys.begin());
+  }
+  std::vector<uint32_t> offsets(n_runs + 1, 0);
+  for (uint32_t i = 0; i < n_runs; ++i) offsets[i + 1] = offsets[i] + counts[i];
+  const uint32_t n_valid = offsets[n_runs];
+  const uint32_t n_seed_vox = n_runs - first_seed;
+  c->stats.n_seeds = n_seed_vox;
+
+  auto findRun = [&](uint64_t k, bool seed) -> int {
+    const uint64_t kk = seed ? (k | kSeedBit) : k;
+    auto b = keys.begin() + (seed ? first_seed : 0), e = keys.begin() + (seed ? n_runs : first_seed);
+    auto it = std::lower_bound(b, e, kk);
+    return (it != e && *it == kk) ? static_cast<int>(it - keys.begin()) : -1;
+  };
+  struct G { int64_t x, y, z; };
+  auto unpack = [](uint64_t k) {
+    int x, y, z;
+    unpackKey(k & ~kSeedBit, &x, &y, &z);
+    return G{x, y, z};
+  };
+  // canonical seed order: ascending (x, y, z) (ASSUMPTIONS.md C.1)
+  std::vector<uint32_t> seed_runs(n_seed_vox);
+  for (uint32_t i = 0; i < n_seed_vox; ++i) seed_runs[i] = first_seed + i;
+  std::sort(seed_runs.begin(), seed_runs.end(), [&](uint32_t a, uint32_t b) {
+    const G ga = unpack(keys[a]), gb = unpack(keys[b]);
+    return ga.x != gb.x ? ga.x < gb.x : (ga.y != gb.y ? ga.y < gb.y : ga.z < gb.z);
+  });
+  static const int kOff[26][3] = {
+      {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1},
+      {-1, -1, 0}, {-1, 1, 0}, {1, -1, 0}, {1, 1, 0}, {-1, 0, -1}, {-1, 0, 1}, {1, 0, -1}, {1, 0, 1},
+      {0, -1, -1}, {0, -1, 1}, {0, 1, -1}, {0, 1, 1},
+      {-1, -1, -1}, {-1, -1, 1}, {-1, 1, -1}, {-1, 1, 1}, {1, -1, -1}, {1, -1, 1}, {1, 1, -1}, {1, 1, 1}};
+  struct Cluster {
+    uint64_t n_pixels = 0;          // with the duplicates the reference produces (:255-265)
+    std::vector<uint32_t> runs;     // voxel set (run indices)
+    int64_t lo[3], hi[3];
+  };
+  std::vector<Cluster> clusters;
+  std::vector<uint8_t> closed(n_runs, 0);
+  const int nn = c->cfg.md_neighbor_connectivity;
+  // clusterDynamicVoxels (free_space_motion_detector.cpp:205-272)
+  for (uint32_t sr : seed_runs) {
+    if (closed[sr]) continue;
+    std::vector<uint32_t> stack = {sr};
+    Cluster cl;
+    while (!stack.empty()) {
+      const uint32_t r = stack.back();
+      stack.pop_back();
+      if (closed[r]) continue;
+      closed[r] = 1;
+      cl.n_pixels += counts[r];
+      cl.runs.push_back(r);
+      const G g = unpack(keys[r]);
+      for (int k = 0; k < nn; ++k) {
+        const uint64_t nk = packKey(static_cast<int>(g.x + kOff[k][0]), static_cast<int>(g.y + kOff[k][1]),
+                                    static_cast<int>(g.z + kOff[k][2]));
+        const int sn = findRun(nk, true);
+        if (sn >= 0) {
+          stack.push_back(static_cast<uint32_t>(sn));
+        } else {
+          const int on = findRun(nk, false);
+          if (on >= 0) {
+            cl.n_pixels += counts[on];
+            cl.runs.push_back(static_cast<uint32_t>(on));
+            closed[on] = 1;
+          }
+        }
+      }
+    }
+    std::sort(cl.runs.begin(), cl.runs.end());
+    cl.runs.erase(std::unique(cl.runs.begin(), cl.runs.end()), cl.runs.end());
+    clusters.push_back(std::move(cl));
+  }
+  const size_t nc = clusters.size();
+  std::vector<std::vector<G>> vox(nc);
+  for (size_t i = 0; i < nc; ++i) {
+    Cluster& cl = clusters[i];
+    for (int d = 0; d < 3; ++d) { cl.lo[d] = INT64_MAX; cl.hi[d] = INT64_MIN; }
+    for (uint32_t r : cl.runs) {
+      const G g = unpack(keys[r]);
+      vox[i].push_back(g);
+      const int64_t v[3] = {g.x, g.y, g.z};
+      for (int d = 0; d < 3; ++d) { cl.lo[d] = std::min(cl.lo[d], v[d]); cl.hi[d] = std::max(cl.hi[d], v[d]); }
+    }
+  }
+  // mergeClusters (:274-355); (p1 - p2).norm() on int64 vectors truncates to integer (ASSUMPTIONS.md C.2)
+  const float sep = c->cfg.md_min_separation_distance;
+  auto overlapTest = [&](size_t i, size_t j) {
+    // exact bounding-box rejection: a lower bound of every pairwise squared distance
+    int64_t gap2 = 0;
+    for (int d = 0; d < 3; ++d) {
+      const int64_t gp = std::max<int64_t>(0, std::max(clusters[i].lo[d] - clusters[j].hi[d], clusters[j].lo[d] - clusters[i].hi[d]));
+      gap2 += gp * gp;
+    }
+    if (!(static_cast<float>(static_cast<int64_t>(std::sqrt(static_cast<double>(gap2)))) < sep)) return false;
+    for (const G& a : vox[i])
+      for (const G& b : vox[j]) {
+        const int64_t dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+        const int64_t n2 = dx * dx + dy * dy + dz * dz;
+        if (static_cast<float>(static_cast<int64_t>(std::sqrt(static_cast<double>(n2)))) < sep) return true;
+      }
+    return false;
+  };
+  std::vector<uint8_t> overlap(nc * nc, 0);
+  for (size_t i = 0; i < nc; ++i)
+    for (size_t j = i + 1; j < nc; ++j) overlap[i * nc + j] = overlap[j * nc + i] = overlapTest(i, j);
+  std::vector<uint8_t> merged(nc, 0), keep(nc, 0);
+  std::function<void(size_t, std::vector<size_t>&)> connected = [&](size_t ci, std::vector<size_t>& outv) {
+    for (size_t i = 0; i < nc; ++i) {
+      if (merged[i]) continue;
+      if (overlap[ci * nc + i]) {
+        merged[i] = 1;
+        outv.push_back(i);
+        connected(i, outv);
+      }
+    }
+  };
+  for (size_t cur = 0; cur < nc; ++cur) {
+    if (merged[cur]) continue;
+    std::vector<size_t> idx;
+    connected(cur, idx);
+    for (size_t i : idx) {
+      if (i == cur) continue;
+      clusters[cur].n_pixels += clusters[i].n_pixels;
+      clusters[cur].runs.insert(clusters[cur].runs.end(), clusters[i].runs.begin(), clusters[i].runs.end());
+    }
+    keep[cur] = 1;
+  }
+  // applyClusterLevelFilters (:365-379) + writeClustersToData (:381-399)
+  std::vector<int32_t> run_id(n_runs, 0);
+  int id = 1, n_out = 0;
+  for (size_t ci = 0; ci < nc; ++ci) {
+    if (!keep[ci]) continue;
+    const int size = static_cast<int>(clusters[ci].n_pixels);
+    if (size < c->cfg.md_min_cluster_size || size > c->cfg.md_max_cluster_size) continue;
+    for (uint32_t r : clusters[ci].runs) run_id[r] = id;
+    if (id < 255) ++id;
+    ++n_out;
+  }
+  if (n_out > 0 && n_valid > 0) {
+    HIP_TRY(hipMemcpyAsync(c->d_run_offsets, offsets.data(), sizeof(uint32_t) * n_runs, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_run_id, run_id.data(), sizeof(int32_t) * n_runs, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_paint_dynamic, dim3(gridFor(n_valid)), dim3(256), 0, c->stream, c->d_pix_sorted,
+                       c->d_run_offsets, static_cast<int>(n_runs), c->d_run_id, static_cast<int>(n_valid), s.dyn);
+    HIP_TRY(hipStreamSynchronize(c->stream));  // host vectors go out of scope
+  }
+  return n_out;
+}
+
+int khr_generate_mesh(khr_ctx* c, int only_mesh_updated, int clear_flag) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  HIP_TRY(hipSetDevice(c->device));
+  DevMap& m = c->m;
+  const size_t cap = m.capacity;
+  ScopedTimer tm(c, 5);
+  HIP_TRY(hipMemsetAsync(c->d_mesh_nwork, 0, sizeof(uint32_t), c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_regen, 0, cap, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_mesh_count, 0, sizeof(uint32_t) * (cap + 1), c->stream));
+  hipLaunchKernelGGL(k_list_live, dim3(gridFor(cap)), dim3(256), 0, c->stream, m, c->d_work, c->d_mesh_nwork,
+                     only_mesh_updated ? BLK_MESH_UPDATED : 0u);
+  hipLaunchKernelGGL(k_mesh_carry_counts, dim3(gridFor(cap)), dim3(256), 0, c->stream, m, c->d_mesh_count);
+  hipLaunchKernelGGL(k_mark_regen, dim3(gridFor(cap)), dim3(256), 0, c->stream, c->d_work, c->d_mesh_nwork, c->d_regen);
+  MeshBuffers src = c->mesh[c->mesh_cur], dst = c->mesh[c->mesh_cur ^ 1];
+  int rc = dispatchVps(c, [&](auto vps) {
+    constexpr int V = decltype(vps)::value;
+    hipLaunchKernelGGL((k_marching_cubes<V, false>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, c->d_work,
+                       c->d_mesh_nwork, c->d_mesh_count, c->d_mesh_offset, dst, clear_flag);
+    size_t tb = c->cub_temp_bytes;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->d_cub_temp, tb, c->d_mesh_count, c->d_mesh_offset,
+                                             static_cast<int>(cap + 1), c->stream));
+    // capacity check before writing
+    uint32_t total = 0, nwork = 0;
+    HIP_TRY(hipMemcpyAsync(&total, c->d_mesh_offset + cap, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&nwork, c->d_mesh_nwork, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (total > c->cfg.max_mesh_vertices)
+      return fail(KHR_ENOMEM, "mesh needs %u vertices, max_mesh_vertices=%llu", total,
+                  static_cast<unsigned long long>(c->cfg.max_mesh_vertices));
+    hipLaunchKernelGGL(k_mesh_move, dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->d_regen, c->d_mesh_offset, src, dst);
+    hipLaunchKernelGGL((k_marching_cubes<V, true>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, c->d_work,
+                       c->d_mesh_nwork, c->d_mesh_count, c->d_mesh_offset, dst, clear_flag);
+    c->mesh_total = total;
+    c->stats.n_mesh_blocks = nwork;
+    c->stats.n_mesh_vertices = total;
+    return KHR_OK;
+  });
+  if (rc) return rc;
+  c->mesh_cur ^= 1;
+  HIP_TRY(hipGetLastError());
+  return KHR_OK;
+}
+
+int khr_reset_inactive(khr_ctx* c, int32_t* removed, int64_t cap, int64_t* n_removed) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  if (n_removed) *n_removed = 0;
+  if (!c->cfg.with_tracking) return KHR_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  DevMap& m = c->m;
+  HIP_TRY(hipMemsetAsync(&m.counters[C_N_REMOVED], 0, sizeof(uint32_t), c->stream));
+  int rc = dispatchVps(c, [&](auto vps) {
+    hipLaunchKernelGGL((k_reset_inactive<decltype(vps)::value>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->d_removed);
+    return KHR_OK;
+  });
+  if (rc) return rc;
+  uint32_t n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, &m.counters[C_N_REMOVED], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (n_removed) *n_removed = n;
+  if (n == 0) return KHR_OK;
+  // rebuild hash table + free list from the surviving blocks
+  HIP_TRY(hipMemsetAsync(m.ht_keys, 0xff, sizeof(uint64_t) * (static_cast<size_t>(m.ht_mask) + 1), c->stream));
+  hipLaunchKernelGGL(k_rehash, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m);
+  hipLaunchKernelGGL(k_rebuild_free_list, dim3(1), dim3(1024), 0, c->stream, m);
+  c->host_index_valid = false;
+  if (removed && cap > 0) {
+    std::vector<int4> tmp(n);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), c->d_removed, sizeof(int4) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::sort(tmp.begin(), tmp.end(), [](const int4& a, const int4& b) {
+      return a.x != b.x ? a.x < b.x : (a.y != b.y ? a.y < b.y : a.z < b.z);
+    });
+    for (int64_t i = 0; i < std::min<int64_t>(n, cap); ++i) {
+      removed[3 * i] = tmp[i].x;
+      removed[3 * i + 1] = tmp[i].y;
+      removed[3 * i + 2] = tmp[i].z;
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return KHR_OK;
+}
+
+int khr_mark_all_inactive(khr_ctx* c) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  hipLaunchKernelGGL(k_block_flag_op, dim3(gridFor(c->m.capacity)), dim3(256), 0, c->stream, c->m, ~BLK_HAS_ACTIVE, 0u);
+  HIP_TRY(hipGetLastError());
+  c->host_index_valid = false;
+  return KHR_OK;
+}
+
+int khr_clear_updated(khr_ctx* c) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  hipLaunchKernelGGL(k_block_flag_op, dim3(gridFor(c->m.capacity)), dim3(256), 0, c->stream, c->m, ~BLK_UPDATED, 0u);
+  HIP_TRY(hipGetLastError());
+  c->host_index_valid = false;
+  return KHR_OK;
+}
+
+int khr_allocate_blocks(khr_ctx* c, const int32_t* indices, int64_t n) {
+  if (!c || (!indices && n > 0)) return fail(KHR_EINVAL, "null argument");
+  if (n <= 0) return KHR_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  // de-duplicate on the host: the device insert requires unique keys per launch
+  std::vector<std::array<int32_t, 3>> v(n);
+  for (int64_t i = 0; i < n; ++i) v[i] = {indices[3 * i], indices[3 * i + 1], indices[3 * i + 2]};
+  std::sort(v.begin(), v.end());
+  v.erase(std::unique(v.begin(), v.end()), v.end());
+  int* d_idx = nullptr;
+  HIP_TRY(hipMalloc(&d_idx, sizeof(int32_t) * 3 * v.size()));
+  hipError_t e = hipMemcpyAsync(d_idx, v.data(), sizeof(int32_t) * 3 * v.size(), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(&c->m.counters[C_N_NEW], 0, sizeof(uint32_t), c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_alloc_list, dim3(gridFor(v.size())), dim3(256), 0, c->stream, c->m, d_idx,
+                       static_cast<int>(v.size()), c->d_new);
+    hipLaunchKernelGGL(k_init_blocks, dim3(2048), dim3(256), 0, c->stream, c->m, c->p, c->d_new);
+    e = hipStreamSynchronize(c->stream);
+  }
+  hipFree(d_idx);
+  c->host_index_valid = false;
+  if (e != hipSuccess) return fail(KHR_EDEVICE, "allocate_blocks failed: %s", hipGetErrorString(e));
+  return KHR_OK;
+}
+
+int khr_object_prune(khr_ctx* c, float min_confidence, float min_observations, int64_t* n_pruned) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  if (!c->cfg.with_semantics || c->p.K < 2) return fail(KHR_ESTATE, "object pruning needs a binary semantic layer");
+  HIP_TRY(hipMemsetAsync(&c->m.stats[S_PRUNED], 0, sizeof(unsigned long long), c->stream));
+  int rc = dispatchVps(c, [&](auto vps) {
+    hipLaunchKernelGGL((k_object_prune<decltype(vps)::value>), dim3(kStreamGrid), dim3(256), 0, c->stream, c->m, c->p,
+                       min_confidence, min_observations);
+    return KHR_OK;
+  });
+  if (rc) return rc;
+  unsigned long long np = 0;
+  HIP_TRY(hipMemcpyAsync(&np, &c->m.stats[S_PRUNED], sizeof(np), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (n_pruned) *n_pruned = static_cast<int64_t>(np);
+  return KHR_OK;
+}
+
+int khr_get_stats(khr_ctx* c, khr_stats* out) {
+  if (!c || !out) return fail(KHR_EINVAL, "null argument");
+  int rc = readCounters(c);
+  if (rc) return rc;
+  unsigned long long st[S_COUNT];
+  HIP_TRY(hipMemcpy(st, c->m.stats, sizeof(st), hipMemcpyDeviceToHost));
+  // live-block count
+  rc = ensureHostIndex(c);
+  if (rc) return rc;
+  khr_stats s = c->stats;
+  s.n_allocated_blocks = c->host_index.size();
+  s.n_visible_blocks = c->h_counters[C_N_VISIBLE];
+  s.n_new_blocks = c->h_counters[C_N_NEW];
+  s.n_visited_voxels = static_cast<uint64_t>(c->h_counters[C_N_VISIBLE]) * c->p.nvox;
+  s.n_updated_voxels = st[S_UPD];
+  s.n_band_voxels = st[S_BAND];
+  s.n_tracking_updated_blocks = c->h_counters[C_N_EF];
+  s.pool_exhausted = c->h_counters[C_POOL_EXHAUSTED];
+  *out = s;
+  return KHR_OK;
+}
+
+int64_t khr_num_blocks(khr_ctx* c) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  int rc = ensureHostIndex(c);
+  if (rc) return rc;
+  return static_cast<int64_t>(c->host_index.size());
+}
+
+int64_t khr_block_indices(khr_ctx* c, int32_t* out, int64_t cap, int only_updated) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  int rc = ensureHostIndex(c);
+  if (rc) return rc;
+  int64_t n = 0;
+  for (auto& kv : c->host_index) {  // std::map => sorted (x, y, z)
+    if (only_updated && !(c->host_flags[kv.second] & BLK_UPDATED)) continue;
+    if (out && n < cap) {
+      out[3 * n] = kv.first[0];
+      out[3 * n + 1] = kv.first[1];
+      out[3 * n + 2] = kv.first[2];
+    }
+    ++n;
+  }
+  return n;
+}
+
+int khr_download_block(khr_ctx* c, int32_t bx, int32_t by, int32_t bz, float* distance, float* weight,
+                       uint8_t* color_rgba, uint64_t* last_observed, uint64_t* last_occupied, uint8_t* voxel_flags,
+                       uint32_t* sem_label, float* likelihoods, uint8_t* block_flags) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  int rc = ensureHostIndex(c);
+  if (rc) return rc;
+  auto it = c->host_index.find({bx, by, bz});
+  if (it == c->host_index.end()) return fail(KHR_ENOTFOUND, "block (%d,%d,%d) not allocated", bx, by, bz);
+  const size_t slot = it->second, nv = c->p.nvox;
+  const DevMap& m = c->m;
+  auto D = [&](void* dst, const void* src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream); };
+  if (distance) HIP_TRY(D(distance, m.dist + slot * nv, nv * 4));
+  if (weight) HIP_TRY(D(weight, m.weight + slot * nv, nv * 4));
+  if (color_rgba) HIP_TRY(D(color_rgba, m.color + slot * nv, nv * 4));
+  if (voxel_flags) HIP_TRY(D(voxel_flags, m.vflags + slot * nv, nv));
+  if (last_observed) {
+    if (c->cfg.with_tracking) HIP_TRY(D(last_observed, m.last_obs + slot * nv, nv * 8));
+    else std::memset(last_observed, 0, nv * 8);
+  }
+  if (last_occupied) {
+    if (c->cfg.with_tracking) HIP_TRY(D(last_occupied, m.last_occ + slot * nv, nv * 8));
+    else std::memset(last_occupied, 0, nv * 8);
+  }
+  if (sem_label) {
+    if (c->cfg.with_semantics) HIP_TRY(D(sem_label, m.sem_label + slot * nv, nv * 4));
+    else std::memset(sem_label, 0, nv * 4);
+  }
+  if (likelihoods && c->cfg.with_semantics) HIP_TRY(D(likelihoods, m.lik + slot * nv * c->p.K, nv * c->p.K * 4));
+  uint32_t bf = 0;
+  if (block_flags) HIP_TRY(D(&bf, m.blk_flags + slot, 4));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (block_flags) *block_flags = static_cast<uint8_t>(bf & 0xfu);
+  // voxels whose semantic entry is still empty carry undefined likelihood storage: report zeros
+  if (likelihoods && c->cfg.with_semantics) {
+    std::vector<uint8_t> fl(nv);
+    const uint8_t* f = voxel_flags;
+    if (!f) {
+      HIP_TRY(hipMemcpy(fl.data(), m.vflags + slot * nv, nv, hipMemcpyDeviceToHost));
+      f = fl.data();
+    }
+    for (size_t i = 0; i < nv; ++i)
+      if (!(f[i] & VOX_SEM_VALID))
+        for (int k = 0; k < c->p.K; ++k) likelihoods[static_cast<size_t>(k) * nv + i] = 0.f;
+  }
+  return KHR_OK;
+}
+
+int64_t khr_mesh_num_vertices(khr_ctx* c) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  return static_cast<int64_t>(c->mesh_total);
+}
+
+int64_t khr_download_mesh(khr_ctx* c, float* points, uint8_t* colors_rgba, uint32_t* labels, uint64_t* first_seen,
+                          uint64_t* stamps, int64_t cap) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  int rc = ensureHostIndex(c);
+  if (rc) return rc;
+  const uint32_t nslots = static_cast<uint32_t>(c->host_flags.size());
+  std::vector<MeshDesc> desc(nslots);
+  if (nslots) HIP_TRY(hipMemcpy(desc.data(), c->m.mesh_desc, sizeof(MeshDesc) * nslots, hipMemcpyDeviceToHost));
+  int64_t total = 0;
+  for (auto& kv : c->host_index) total += desc[kv.second].count;
+  if (total > cap) return fail(KHR_EINVAL, "mesh has %lld vertices, cap %lld", static_cast<long long>(total), static_cast<long long>(cap));
+  if (total == 0) return 0;
+  const MeshBuffers& mb = c->mesh[c->mesh_cur];
+  const size_t all = c->mesh_total;
+  std::vector<float> hp(points ? all * 3 : 0);
+  std::vector<uint32_t> hc(colors_rgba ? all : 0), hl(labels ? all : 0);
+  std::vector<uint64_t> hs((first_seen || stamps) ? all : 0);
+  if (points) HIP_TRY(hipMemcpy(hp.data(), mb.points, all * 12, hipMemcpyDeviceToHost));
+  if (colors_rgba) HIP_TRY(hipMemcpy(hc.data(), mb.colors, all * 4, hipMemcpyDeviceToHost));
+  if (labels) HIP_TRY(hipMemcpy(hl.data(), mb.labels, all * 4, hipMemcpyDeviceToHost));
+  if (first_seen || stamps) HIP_TRY(hipMemcpy(hs.data(), mb.stamps, all * 8, hipMemcpyDeviceToHost));
+  int64_t n = 0;
+  for (auto& kv : c->host_index) {  // sorted block order (combineMeshLayer iterates the mesh layer)
+    const MeshDesc d = desc[kv.second];
+    if (!d.count) continue;
+    if (points) std::memcpy(points + 3 * n, hp.data() + 3 * static_cast<size_t>(d.offset), 12ull * d.count);
+    if (colors_rgba) std::memcpy(colors_rgba + 4 * n, hc.data() + d.offset, 4ull * d.count);
+    if (labels) std::memcpy(labels + n, hl.data() + d.offset, 4ull * d.count);
+    if (first_seen) std::memcpy(first_seen + n, hs.data() + d.offset, 8ull * d.count);
+    if (stamps) std::memcpy(stamps + n, hs.data() + d.offset, 8ull * d.count);
+    n += d.count;
+  }
+  return n;
+}
+
+int khr_timing_enable(khr_ctx* c, int enable) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  c->timing = enable != 0;
+  return KHR_OK;
+}
+int khr_timing_reset(khr_ctx* c) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  resolveTimers(c);
+  for (int i = 0; i < kNumTimers; ++i) { c->t_ms[i] = 0; c->t_n[i] = 0; }
+  return KHR_OK;
+}
+int khr_timing_get(khr_ctx* c, int which, double* total_ms, uint64_t* launches) {
+  if (!c || which < 0 || which >= kNumTimers) return fail(KHR_EINVAL, "bad timer");
+  resolveTimers(c);
+  if (total_ms) *total_ms = c->t_ms[which];
+  if (launches) *launches = c->t_n[which];
+  return KHR_OK;
+}
+
+}  // extern "C"

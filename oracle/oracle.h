@@ -1,0 +1,149 @@
+/*
+ * oracle.h — CPU restatement ("oracle") of the Khronos active-window volumetric
+ * fusion path.  TEST INFRASTRUCTURE ONLY: nothing under khronos_amd/ may include,
+ * link or call this.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker / CPU baseline.
+ *
+ * PARITY UNPINNED: the reference (/root/reference) ships no tests or golden
+ * vectors, and the arithmetic of ProjectiveIntegrator / MeshIntegrator /
+ * spatial_hash lives in un-vendored, un-pinned dependencies (MIT-SPARK/Hydra @
+ * main, MIT-SPARK/Spatial-Hash @ main; install/https.rosinstall:5-8,33-36).
+ * In-repo semantics (tracking integrator, motion detector, object integrator,
+ * object extractor, orchestration) are restated from the cited reference
+ * file:line; upstream semantics follow ASSUMPTIONS.md (each item is a named
+ * switch in orc_config).
+ *
+ * Plain C ABI so that Python (ctypes) tests can drive it.
+ */
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_config {
+  /* hydra::VolumetricMap::Config (fields: mesh_object_extractor.cpp:201-211) */
+  float voxel_size;
+  int32_t voxels_per_side;
+  float truncation_distance;
+  int32_t with_semantics;
+  int32_t with_tracking;
+  int32_t num_labels; /* K */
+  /* hydra::ProjectiveIntegrator::Config (ASSUMPTIONS.md A.3) */
+  int32_t use_weight_dropoff;
+  float weight_dropoff_epsilon; /* <0 => multiples of voxel size */
+  int32_t use_constant_weight;
+  float max_weight;
+  int32_t interpolation_method; /* 0 nearest, 1 bilinear, 2 adaptive */
+  float adaptive_max_range_difference;
+  int32_t range_mode;    /* 0 = z-depth, 1 = ray length */
+  int32_t semantic_mode; /* 0 = MLE, 1 = binary (object_integrator.cpp:44-48) */
+  float label_confidence;
+  /* khronos::TrackingIntegrator::Config (tracking_integrator.h:59-83) */
+  float temporal_buffer;
+  float tsdf_occupancy_threshold; /* <0 => multiples of voxel size */
+  int32_t neighbor_connectivity;  /* 6 / 18 / 26 */
+  float temporal_window;
+  /* khronos::FreeSpaceMotionDetector::Config (free_space_motion_detector.h:72-97) */
+  int32_t md_neighbor_connectivity;
+  int32_t md_min_cluster_size;
+  int32_t md_max_cluster_size;
+  float md_min_separation_distance;
+  float md_max_range;
+  float md_min_z_coordinate;
+  /* hydra::MeshIntegratorConfig (ASSUMPTIONS.md A.5) */
+  float mesh_min_weight;
+  /* host threads (default_num_threads semantics) */
+  int32_t num_threads;
+  /* multi-GPU emulation: only blocks with owner(block) == rank are allocated */
+  int32_t rank;
+  int32_t world_size;
+} orc_config;
+
+typedef struct orc_sensor {
+  int32_t width, height;
+  float fx, fy, cx, cy;
+  float min_range, max_range;
+} orc_sensor;
+
+typedef struct orc_frame {
+  uint64_t timestamp_ns;
+  double world_T_sensor[16]; /* row-major 4x4 */
+  const float* depth;        /* H*W metres, <=0 or NaN = invalid */
+  const uint8_t* color;      /* H*W*3 rgb, may be NULL */
+  const int32_t* label;      /* H*W, may be NULL */
+  const int32_t* mask;       /* H*W, non-zero = do not integrate (in band), may be NULL */
+  const int32_t* object_image; /* H*W, for object integration, may be NULL */
+  int32_t object_id;           /* target id for binary label (object_integrator.cpp:77-79) */
+} orc_frame;
+
+typedef struct orc_stats {
+  uint64_t n_visible_blocks;
+  uint64_t n_new_blocks;
+  uint64_t n_visited_voxels;
+  uint64_t n_updated_voxels;
+  uint64_t n_band_voxels;
+} orc_stats;
+
+typedef struct orc_map orc_map;
+
+orc_map* orc_create(const orc_config* cfg);
+void orc_destroy(orc_map* m);
+
+/* parseInputPacket role (active_window.cpp:275; ASSUMPTIONS.md A.2) */
+void orc_parse_input(const orc_config* cfg, const orc_sensor* s, const double* world_T_sensor,
+                     const float* depth, float* range_out, float* vertex_out /* H*W*3 */);
+
+/* hydra::ProjectiveIntegrator::updateMap (call active_window.cpp:210) */
+int orc_integrate(orc_map* m, const orc_sensor* s, const orc_frame* f, int allocate_blocks,
+                  orc_stats* stats);
+
+/* TrackingIntegrator::updateBlocks (tracking_integrator.cpp:71-104) */
+int orc_update_tracking(orc_map* m, uint64_t timestamp_ns);
+
+/* TrackingIntegrator::resetInactive (tracking_integrator.cpp:106-131); returns count, fills
+ * removed[3*i..] up to cap entries */
+int64_t orc_reset_inactive(orc_map* m, int32_t* removed, int64_t cap);
+
+/* ActiveWindow::finishMapping part 1 (active_window.cpp:181-183) */
+void orc_mark_all_inactive(orc_map* m);
+
+/* clear TsdfBlock updated flags (active_window.cpp:169-171) */
+void orc_clear_updated(orc_map* m);
+
+/* FreeSpaceMotionDetector::processInput (free_space_motion_detector.cpp:73-103).
+ * dynamic_image_out H*W int32 (0 = static, cluster ids 1..255). returns #clusters. */
+int orc_detect_motion(orc_map* m, const orc_sensor* s, const orc_frame* f, int32_t* dynamic_image_out,
+                      int64_t* n_seeds_out);
+
+/* hydra::MeshIntegrator::generateMesh (calls active_window.cpp:223, mesh_object_extractor.cpp:267).
+ * Mesh is kept inside the map per block. returns #mesh blocks regenerated. */
+int64_t orc_generate_mesh(orc_map* m, int only_mesh_updated, int clear_flag);
+/* total vertex count of all mesh blocks (3 per face, no de-duplication) */
+int64_t orc_mesh_num_vertices(orc_map* m);
+/* concatenated mesh (utils::combineMeshLayer, geometry_utils.cpp:61-86), blocks in sorted index order */
+int64_t orc_mesh_copy(orc_map* m, float* points /*3n*/, uint8_t* colors /*4n*/, uint32_t* labels,
+                      uint64_t* first_seen, uint64_t* stamps, int64_t cap);
+
+/* MeshObjectExtractor confidence pruning (mesh_object_extractor.cpp:246-264,342-356) */
+int64_t orc_object_prune(orc_map* m, float min_confidence, float min_observations);
+
+/* explicit allocation (mesh_object_extractor.cpp:218-228) */
+void orc_allocate_block(orc_map* m, int32_t bx, int32_t by, int32_t bz);
+
+/* access for comparison */
+int64_t orc_num_blocks(const orc_map* m);
+/* sorted lexicographically (x, then y, then z) */
+int64_t orc_block_indices(const orc_map* m, int32_t* out, int64_t cap);
+/* copy one block into SoA arrays (any pointer may be NULL). returns 0 if found */
+int orc_get_block(const orc_map* m, int32_t bx, int32_t by, int32_t bz, float* distance, float* weight,
+                  uint8_t* color /*4n*/, uint64_t* last_observed, uint64_t* last_occupied,
+                  uint8_t* flags /* bit0 active, bit1 ever_free, bit2 to_remove, bit3 sem non-empty */,
+                  uint32_t* sem_label, float* likelihoods /* K*n, [k][voxel] */,
+                  uint8_t* block_flags /* 1 byte: bit0 updated,1 mesh_updated,2 tracking_updated,3 has_active_data */);
+
+#ifdef __cplusplus
+}
+#endif

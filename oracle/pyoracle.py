@@ -1,0 +1,238 @@
+"""ctypes wrapper over oracle/liboracle.so — TEST INFRASTRUCTURE ONLY (see oracle/oracle.h).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [
+        ("voxel_size", C.c_float), ("voxels_per_side", C.c_int32), ("truncation_distance", C.c_float),
+        ("with_semantics", C.c_int32), ("with_tracking", C.c_int32), ("num_labels", C.c_int32),
+        ("use_weight_dropoff", C.c_int32), ("weight_dropoff_epsilon", C.c_float),
+        ("use_constant_weight", C.c_int32), ("max_weight", C.c_float), ("interpolation_method", C.c_int32),
+        ("adaptive_max_range_difference", C.c_float), ("range_mode", C.c_int32), ("semantic_mode", C.c_int32),
+        ("label_confidence", C.c_float),
+        ("temporal_buffer", C.c_float), ("tsdf_occupancy_threshold", C.c_float),
+        ("neighbor_connectivity", C.c_int32), ("temporal_window", C.c_float),
+        ("md_neighbor_connectivity", C.c_int32), ("md_min_cluster_size", C.c_int32),
+        ("md_max_cluster_size", C.c_int32), ("md_min_separation_distance", C.c_float),
+        ("md_max_range", C.c_float), ("md_min_z_coordinate", C.c_float),
+        ("mesh_min_weight", C.c_float), ("num_threads", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
+    ]
+
+
+class OrcSensor(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("min_range", C.c_float), ("max_range", C.c_float)]
+
+
+class OrcFrame(C.Structure):
+    _fields_ = [("timestamp_ns", C.c_uint64), ("world_T_sensor", C.c_double * 16), ("depth", C.c_void_p),
+                ("color", C.c_void_p), ("label", C.c_void_p), ("mask", C.c_void_p), ("object_image", C.c_void_p),
+                ("object_id", C.c_int32)]
+
+
+class OrcStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_visible_blocks", "n_new_blocks", "n_visited_voxels",
+                                          "n_updated_voxels", "n_band_voxels")]
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    lib.orc_create.argtypes = [C.POINTER(OrcConfig)]
+    lib.orc_create.restype = vp
+    lib.orc_destroy.argtypes = [vp]
+    lib.orc_destroy.restype = None
+    lib.orc_parse_input.argtypes = [C.POINTER(OrcConfig), C.POINTER(OrcSensor), vp, vp, vp, vp]
+    lib.orc_parse_input.restype = None
+    lib.orc_integrate.argtypes = [vp, C.POINTER(OrcSensor), C.POINTER(OrcFrame), i32, C.POINTER(OrcStats)]
+    lib.orc_update_tracking.argtypes = [vp, C.c_uint64]
+    lib.orc_reset_inactive.argtypes = [vp, vp, i64]
+    lib.orc_reset_inactive.restype = i64
+    lib.orc_mark_all_inactive.argtypes = [vp]
+    lib.orc_mark_all_inactive.restype = None
+    lib.orc_clear_updated.argtypes = [vp]
+    lib.orc_clear_updated.restype = None
+    lib.orc_detect_motion.argtypes = [vp, C.POINTER(OrcSensor), C.POINTER(OrcFrame), vp, C.POINTER(i64)]
+    lib.orc_generate_mesh.argtypes = [vp, i32, i32]
+    lib.orc_generate_mesh.restype = i64
+    lib.orc_mesh_num_vertices.argtypes = [vp]
+    lib.orc_mesh_num_vertices.restype = i64
+    lib.orc_mesh_copy.argtypes = [vp, vp, vp, vp, vp, vp, i64]
+    lib.orc_mesh_copy.restype = i64
+    lib.orc_object_prune.argtypes = [vp, C.c_float, C.c_float]
+    lib.orc_object_prune.restype = i64
+    lib.orc_allocate_block.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
+    lib.orc_allocate_block.restype = None
+    lib.orc_num_blocks.argtypes = [vp]
+    lib.orc_num_blocks.restype = i64
+    lib.orc_block_indices.argtypes = [vp, vp, i64]
+    lib.orc_block_indices.restype = i64
+    lib.orc_get_block.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32] + [vp] * 9
+    _lib = lib
+    return lib
+
+
+def config_from(khr_cfg, num_threads=0):
+    """OrcConfig with the same field values as a khronos_amd KhrConfig (or any object with those attrs)."""
+    o = OrcConfig()
+    for name, _ in OrcConfig._fields_:
+        if name == "num_threads":
+            o.num_threads = num_threads
+        else:
+            setattr(o, name, getattr(khr_cfg, name))
+    return o
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class OracleMap:
+    def __init__(self, cfg):
+        self.lib = load()
+        self.cfg = cfg
+        self.h = C.c_void_p(self.lib.orc_create(C.byref(cfg)))
+        self.nvox = cfg.voxels_per_side ** 3
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.orc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def make_sensor(width, height, fx, fy, cx, cy, min_range=0.1, max_range=5.0):
+        return OrcSensor(width, height, fx, fy, cx, cy, min_range, max_range)
+
+    def _frame(self, stamp_ns, T, depth, color=None, label=None, mask=None, object_image=None, object_id=-1):
+        f = OrcFrame()
+        f.timestamp_ns = int(stamp_ns)
+        Tf = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+        for i in range(16):
+            f.world_T_sensor[i] = Tf[i]
+        keep = []
+
+        def put(a, dt):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=dt)
+            keep.append(a)
+            return a.ctypes.data
+        f.depth = put(depth, np.float32)
+        f.color = put(color, np.uint8)
+        f.label = put(label, np.int32)
+        f.mask = put(mask, np.int32)
+        f.object_image = put(object_image, np.int32)
+        f.object_id = object_id
+        return f, keep
+
+    def parse_input(self, sensor, T, depth):
+        h, w = sensor.height, sensor.width
+        r = np.empty((h, w), np.float32)
+        v = np.empty((h, w, 3), np.float32)
+        Tf = np.ascontiguousarray(T, dtype=np.float64)
+        d = np.ascontiguousarray(depth, dtype=np.float32)
+        self.lib.orc_parse_input(C.byref(self.cfg), C.byref(sensor), _ptr(Tf), _ptr(d), _ptr(r), _ptr(v))
+        return r, v
+
+    def integrate(self, sensor, stamp_ns, T, depth, color=None, label=None, mask=None, object_image=None,
+                  object_id=-1, allocate_blocks=True):
+        f, keep = self._frame(stamp_ns, T, depth, color, label, mask, object_image, object_id)
+        st = OrcStats()
+        self.lib.orc_integrate(self.h, C.byref(sensor), C.byref(f), int(allocate_blocks), C.byref(st))
+        return {n: getattr(st, n) for n, _ in OrcStats._fields_}
+
+    def update_tracking(self, stamp_ns):
+        self.lib.orc_update_tracking(self.h, int(stamp_ns))
+
+    def detect_motion(self, sensor, stamp_ns, T, depth):
+        f, keep = self._frame(stamp_ns, T, depth)
+        dyn = np.zeros((sensor.height, sensor.width), np.int32)
+        ns = C.c_int64(0)
+        n = self.lib.orc_detect_motion(self.h, C.byref(sensor), C.byref(f), _ptr(dyn), C.byref(ns))
+        return n, dyn, ns.value
+
+    def generate_mesh(self, only_mesh_updated=True, clear_flag=True):
+        return self.lib.orc_generate_mesh(self.h, int(only_mesh_updated), int(clear_flag))
+
+    def mesh(self):
+        n = self.lib.orc_mesh_num_vertices(self.h)
+        pts = np.empty((max(n, 1), 3), np.float32)
+        col = np.empty((max(n, 1), 4), np.uint8)
+        lab = np.empty(max(n, 1), np.uint32)
+        fs = np.empty(max(n, 1), np.uint64)
+        st = np.empty(max(n, 1), np.uint64)
+        k = self.lib.orc_mesh_copy(self.h, _ptr(pts), _ptr(col), _ptr(lab), _ptr(fs), _ptr(st), max(n, 1))
+        return {"points": pts[:k], "colors": col[:k], "labels": lab[:k], "first_seen": fs[:k], "stamps": st[:k]}
+
+    def reset_inactive(self):
+        cap = max(1, self.num_blocks())
+        out = np.zeros((cap, 3), np.int32)
+        n = self.lib.orc_reset_inactive(self.h, _ptr(out), cap)
+        return out[:n].copy()
+
+    def mark_all_inactive(self):
+        self.lib.orc_mark_all_inactive(self.h)
+
+    def clear_updated(self):
+        self.lib.orc_clear_updated(self.h)
+
+    def allocate_blocks(self, indices):
+        for b in np.asarray(indices, np.int32).reshape(-1, 3):
+            self.lib.orc_allocate_block(self.h, int(b[0]), int(b[1]), int(b[2]))
+
+    def object_prune(self, min_confidence, min_observations):
+        return self.lib.orc_object_prune(self.h, min_confidence, min_observations)
+
+    def num_blocks(self):
+        return self.lib.orc_num_blocks(self.h)
+
+    def block_indices(self):
+        n = self.num_blocks()
+        out = np.zeros((max(n, 1), 3), np.int32)
+        self.lib.orc_block_indices(self.h, _ptr(out), n)
+        return out[:n]
+
+    def get_block(self, idx, likelihoods=True):
+        nv, K = self.nvox, max(1, self.cfg.num_labels)
+        b = {
+            "distance": np.empty(nv, np.float32), "weight": np.empty(nv, np.float32),
+            "color": np.empty((nv, 4), np.uint8), "last_observed": np.empty(nv, np.uint64),
+            "last_occupied": np.empty(nv, np.uint64), "flags": np.empty(nv, np.uint8),
+            "sem_label": np.empty(nv, np.uint32),
+            "likelihoods": np.zeros((K, nv), np.float32) if (likelihoods and self.cfg.with_semantics) else None,
+        }
+        bf = np.zeros(1, np.uint8)
+        rc = self.lib.orc_get_block(self.h, int(idx[0]), int(idx[1]), int(idx[2]), _ptr(b["distance"]),
+                                    _ptr(b["weight"]), _ptr(b["color"]), _ptr(b["last_observed"]),
+                                    _ptr(b["last_occupied"]), _ptr(b["flags"]), _ptr(b["sem_label"]),
+                                    _ptr(b["likelihoods"]), _ptr(bf))
+        if rc != 0:
+            raise KeyError(tuple(idx))
+        b["block_flags"] = int(bf[0])
+        return b

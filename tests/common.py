@@ -1,0 +1,75 @@
+"""Shared helpers for the parity tests: one config -> (HIP context, oracle map), frame feeding, and
+block-by-block comparison."""
+import numpy as np
+
+from khronos_amd import FusionContext, default_config
+from khronos_amd.synth import SyntheticStream
+from oracle import pyoracle as po
+
+# the float tolerance BASELINE.json states (per-voxel SDF / weight / label within 1e-4)
+TOL = 1e-4
+
+
+def make_pair(width=320, height=240, seed=1234, stream_kw=None, **cfg_kw):
+    kw = dict(voxel_size=0.1, truncation_distance=0.3, with_semantics=1, with_tracking=1, max_blocks=4096,
+              max_frame_pixels=width * height, md_min_cluster_size=20, md_min_separation_distance=2.0, md_max_range=5.0)
+    kw.update(cfg_kw)
+    cfg = default_config(**kw)
+    ctx = FusionContext(cfg)
+    ora = po.OracleMap(po.config_from(cfg, 0))
+    s = SyntheticStream(width, height, seed=seed, **(stream_kw or {}))
+    sen = ctx.make_sensor(width, height, s.fx, s.fy, s.cx, s.cy)
+    osen = ora.make_sensor(width, height, s.fx, s.fy, s.cx, s.cy)
+    return cfg, ctx, ora, s, sen, osen
+
+
+def step_both(ctx, ora, sen, osen, fr, motion=False, track=True, use_color=True, use_label=True):
+    """One ActiveWindow::spinOnce worth of volumetric work (active_window.cpp:127,203-215) on both."""
+    color = fr["rgb"] if use_color else None
+    label = fr["label"] if use_label else None
+    slot = ctx.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], color, label)
+    dyn_o = None
+    out = {}
+    if motion:
+        out["n_gpu"] = ctx.detect_motion(slot)
+        out["n_ora"], dyn_o, out["seeds_ora"] = ora.detect_motion(osen, fr["stamp"], fr["pose"], fr["depth"])
+        out["dyn_ora"] = dyn_o
+        out["dyn_gpu"] = ctx.download_frame(slot, fr["depth"].shape, range_image=False, dynamic_image=True)[2]
+    ctx.integrate(slot, allocate_blocks=True, use_mask=motion)
+    out["ostats"] = ora.integrate(osen, fr["stamp"], fr["pose"], fr["depth"], color, label, mask=dyn_o)
+    if track:
+        ctx.update_tracking(fr["stamp"])
+        ora.update_tracking(fr["stamp"])
+    out["slot"] = slot
+    return out
+
+
+def compare_maps(ctx, ora, max_blocks=None, rng=None, check_lik=True):
+    """Block index sets bit-exact; per-voxel fields within TOL (integers / flags exact)."""
+    gi, oi = ctx.block_indices(), ora.block_indices()
+    assert gi.shape == oi.shape, (gi.shape, oi.shape)
+    assert (gi == oi).all(), "block index sets differ"
+    sel = np.arange(len(gi))
+    if max_blocks is not None and len(gi) > max_blocks:
+        rng = rng or np.random.default_rng(0)
+        sel = np.sort(rng.choice(len(gi), max_blocks, replace=False))
+    worst = {"distance": 0.0, "weight_rel": 0.0, "lik": 0.0, "color": 0}
+    for i in sel:
+        idx = gi[i]
+        g, o = ctx.download_block(idx), ora.get_block(idx)
+        worst["distance"] = max(worst["distance"], float(np.abs(g["distance"] - o["distance"]).max()))
+        wr = np.abs(g["weight"] - o["weight"]) / np.maximum(1.0, np.abs(o["weight"]))
+        worst["weight_rel"] = max(worst["weight_rel"], float(wr.max()))
+        worst["color"] = max(worst["color"], int(np.abs(g["color"].astype(int) - o["color"].astype(int)).max()))
+        assert (g["last_observed"] == o["last_observed"]).all(), ("last_observed", idx)
+        assert (g["last_occupied"] == o["last_occupied"]).all(), ("last_occupied", idx)
+        assert (g["flags"] == o["flags"]).all(), ("flags", idx, np.flatnonzero(g["flags"] != o["flags"])[:8])
+        assert (g["sem_label"] == o["sem_label"]).all(), ("sem_label", idx)
+        assert g["block_flags"] == o["block_flags"], ("block_flags", idx, g["block_flags"], o["block_flags"])
+        if check_lik and g["likelihoods"] is not None:
+            worst["lik"] = max(worst["lik"], float(np.abs(g["likelihoods"] - o["likelihoods"]).max()))
+    assert worst["distance"] <= TOL, worst
+    assert worst["weight_rel"] <= TOL, worst
+    assert worst["lik"] <= TOL * 10, worst  # log-likelihood sums grow with observations
+    assert worst["color"] <= 1, worst
+    return worst, len(gi)

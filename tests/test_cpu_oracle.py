@@ -1,0 +1,250 @@
+"""-m "not gpu": the oracle against known answers derived by hand from the in-repo reference formulas
+(SURVEY.md §8(c) "known-answer tests derivable from in-repo code alone"), the marching-cubes table, and
+the C-ABI library surface."""
+import ctypes
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+from khronos_amd import capi
+from khronos_amd.synth import SyntheticStream, camera_pose
+from oracle import pyoracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg(**kw):
+    base = dict(voxel_size=0.1, voxels_per_side=16, truncation_distance=0.3, with_semantics=1, with_tracking=1,
+                num_labels=20, use_weight_dropoff=1, weight_dropoff_epsilon=-1.0, use_constant_weight=0,
+                max_weight=1e5, interpolation_method=2, adaptive_max_range_difference=0.2, range_mode=0,
+                semantic_mode=0, label_confidence=0.9, temporal_buffer=1.0, tsdf_occupancy_threshold=-1.5,
+                neighbor_connectivity=18, temporal_window=3.0, md_neighbor_connectivity=26, md_min_cluster_size=0,
+                md_max_cluster_size=1000000, md_min_separation_distance=1.0, md_max_range=10000.0,
+                md_min_z_coordinate=-10000.0, mesh_min_weight=1e-4, rank=0, world_size=1)
+    base.update(kw)
+    o = po.OrcConfig()
+    for k, v in base.items():
+        setattr(o, k, v)
+    o.num_threads = 2
+    return o
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads and exports every symbol include/khronos_amd.h declares (no compute)."""
+    hdr = open(os.path.join(ROOT, "include", "khronos_amd.h")).read()
+    declared = set(re.findall(r"\b(khr_[a-z_]+)\s*\(", hdr))
+    assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_create_fails_loudly_without_gpu_or_bad_config():
+    import torch
+    lib = capi.load_library()
+    cfg = capi.default_config()
+    h = ctypes.c_void_p()
+    if not torch.cuda.is_available():
+        rc = lib.khr_create(ctypes.byref(cfg), ctypes.byref(h))
+        assert rc == capi.KHR_EDEVICE and b"no CPU fallback" in lib.khr_last_error()
+    bad = capi.default_config(neighbor_connectivity=7)
+    assert lib.khr_create(ctypes.byref(bad), ctypes.byref(h)) == capi.KHR_EINVAL
+    bad = capi.default_config(tsdf_occupancy_threshold=0.0)  # tracking_integrator.cpp:64
+    assert lib.khr_create(ctypes.byref(bad), ctypes.byref(h)) == capi.KHR_EINVAL
+    bad = capi.default_config(md_min_cluster_size=10, md_max_cluster_size=5)  # free_space_motion_detector.cpp:64
+    assert lib.khr_create(ctypes.byref(bad), ctypes.byref(h)) == capi.KHR_EINVAL
+
+
+def test_mc_table_is_valid_and_crack_free():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_mc_table as g
+    assert g.validate() == []
+    assert g.count_cracks() == 0
+    # generated copies are in sync with the generator
+    for rel in ("oracle/mc_table.inc", "khronos_amd/csrc/mc_table.inc"):
+        tmp = os.path.join(ROOT, rel + ".chk")
+        g.emit(tmp)
+        same = open(tmp).read() == open(os.path.join(ROOT, rel)).read()
+        os.remove(tmp)
+        assert same, rel
+
+
+def _one_block_map(cfg):
+    m = po.OracleMap(cfg)
+    m.allocate_blocks([[0, 0, 0]])
+    return m
+
+
+def _wall_frame(W=64, H=48, depth=1.0):
+    """camera at origin looking along +x (world), flat wall at distance `depth`."""
+    T = camera_pose(np.array([0.0, 0.8, 0.8]), 0.0)
+    d = np.full((H, W), depth, np.float32)
+    sen = po.OrcSensor(W, H, W / 2.0, W / 2.0, W / 2.0, H / 2.0, 0.1, 5.0)
+    return T, d, sen
+
+
+def test_tsdf_known_answer_single_voxel():
+    """One voxel on the optical axis: sdf, weight and running average by hand (ASSUMPTIONS.md A.3)."""
+    cfg = _cfg(with_semantics=0, interpolation_method=0)
+    m = _one_block_map(cfg)
+    T, d, sen = _wall_frame(depth=1.0)
+    m.integrate(sen, 10**9, T, d, allocate_blocks=False)
+    b = m.get_block([0, 0, 0])
+    # voxel (7,7,7): centre (0.75,0.75,0.75); camera at (0,0.8,0.8) looking +x -> z_cam = 0.75
+    lin = 7 + 16 * (7 + 16 * 7)
+    z = np.float32(0.75)
+    sdf = np.float32(1.0) - z
+    w = np.float32(32.0 * 32.0) * (np.float32(0.1) / z) ** 2 / (z * z)
+    assert b["weight"][lin] == pytest.approx(float(w), rel=1e-6)
+    assert b["distance"][lin] == pytest.approx(float(sdf), rel=1e-6)
+    assert b["last_observed"][lin] == 10**9
+    # second observation at depth 0.9: weighted mean of the two sdfs
+    m.integrate(sen, 2 * 10**9, T, np.full_like(d, 0.9), allocate_blocks=False)
+    b2 = m.get_block([0, 0, 0])
+    assert b2["distance"][lin] == pytest.approx((0.25 + 0.15) / 2, rel=1e-5)
+    assert b2["weight"][lin] == pytest.approx(2 * float(w), rel=1e-6)
+    # behind the surface by more than the truncation distance: untouched
+    lin_far = 15 + 16 * (7 + 16 * 7)  # x = 1.55 -> sdf = -0.55 < -0.3
+    assert b2["weight"][lin_far] == 0.0 and b2["last_observed"][lin_far] == 0
+
+
+def test_tsdf_weight_dropoff_and_truncation():
+    cfg = _cfg(with_semantics=0, interpolation_method=0)
+    m = _one_block_map(cfg)
+    T, d, sen = _wall_frame(depth=1.0)
+    m.integrate(sen, 10**9, T, d, allocate_blocks=False)
+    b = m.get_block([0, 0, 0])
+    # voxel x index 11: centre x = 1.15 -> sdf = -0.15 (behind surface, inside band, beyond eps = 0.1)
+    lin = 11 + 16 * (7 + 16 * 7)
+    z = np.float32(1.15)
+    w0 = np.float32(1024.0) * (np.float32(0.1) / z) ** 2 / (z * z)
+    w = w0 * (np.float32(0.3) + (np.float32(1.0) - z)) / (np.float32(0.3) - np.float32(0.1))
+    assert b["weight"][lin] == pytest.approx(float(w), rel=1e-5)
+    # free space far in front: sdf clamped to +truncation
+    lin_front = 2 + 16 * (7 + 16 * 7)  # x = 0.25 -> sdf = 0.75 -> clamp 0.3
+    assert b["distance"][lin_front] == pytest.approx(0.3, rel=1e-6)
+
+
+def test_semantic_mle_and_binary():
+    cfg = _cfg(interpolation_method=0, num_labels=4, label_confidence=0.9)
+    m = _one_block_map(cfg)
+    T, d, sen = _wall_frame(depth=1.0)
+    lab = np.full(d.shape, 2, np.int32)
+    m.integrate(sen, 10**9, T, d, label=lab, allocate_blocks=False)
+    b = m.get_block([0, 0, 0])
+    lin = 9 + 16 * (7 + 16 * 7)  # x = 0.95 -> |sdf| = 0.05 < trunc
+    assert b["flags"][lin] & 8 and b["sem_label"][lin] == 2
+    exp = np.full(4, np.log(np.float32(0.1) / np.float32(3)), np.float32)
+    exp[2] = np.log(np.float32(0.9))
+    assert np.allclose(b["likelihoods"][:, lin], exp, rtol=1e-6)
+    lin_out = 2 + 16 * (7 + 16 * 7)  # outside the band: no label
+    assert not (b["flags"][lin_out] & 8)
+    # binary integrator (object_integrator.cpp:44-48,77-79; counts read at mesh_object_extractor.cpp:348-355)
+    cfg2 = _cfg(interpolation_method=0, num_labels=2, semantic_mode=1)
+    m2 = _one_block_map(cfg2)
+    obj = np.zeros(d.shape, np.int32)
+    obj[:, : d.shape[1] // 2] = 5
+    for k in range(3):
+        m2.integrate(sen, (k + 1) * 10**9, T, d, object_image=obj, object_id=5, allocate_blocks=False)
+    b = m2.get_block([0, 0, 0])
+    tot = b["likelihoods"][0] + b["likelihoods"][1]
+    band = (b["flags"] & 8) > 0
+    assert band.any() and np.all(tot[band] == 3.0)
+    assert set(np.unique(b["likelihoods"][1][band])) <= {0.0, 3.0}
+
+
+def test_tracking_duration_truth_table():
+    """updateTrackingDuration / voxelIsFree (tracking_integrator.cpp:224-252)."""
+    cfg = _cfg(with_semantics=0, interpolation_method=0, temporal_window=3.0, temporal_buffer=1.0)
+    m = _one_block_map(cfg)
+    T, d, sen = _wall_frame(depth=1.0)
+    s = 10**9
+    t0 = 100 * s
+    m.integrate(sen, t0, T, d, allocate_blocks=False)
+    m.update_tracking(t0)
+    b = m.get_block([0, 0, 0])
+    occ = 9 + 16 * (7 + 16 * 7)   # sdf 0.05 < 0.15 = 1.5 * voxel  -> occupied
+    free = 2 + 16 * (7 + 16 * 7)  # sdf clamp 0.3 -> not occupied
+    unobs = 15 + 16 * (7 + 16 * 7)
+    assert b["last_occupied"][occ] == t0 and b["flags"][occ] & 1
+    assert b["last_occupied"][free] == 0 and b["flags"][free] & 1
+    # NB: an unobserved voxel has distance 0 < threshold => counted occupied (tracking_integrator.cpp:231);
+    # it is not active because last_observed = 0 is older than the window (for stamps > temporal_window)
+    assert b["last_occupied"][unobs] == t0 and not (b["flags"][unobs] & 1)
+    assert b["block_flags"] & 8  # has_active_data
+    assert not (b["block_flags"] & 4)  # tracking_updated cleared (:146)
+    # exactly at the window edge the voxel stays active (>=), just beyond it is deactivated + to_remove
+    m.update_tracking(t0 + 3 * s)
+    assert m.get_block([0, 0, 0])["flags"][occ] & 1
+    m.update_tracking(t0 + 3 * s + 1000)
+    b = m.get_block([0, 0, 0])
+    assert not (b["flags"][occ] & 1) and (b["flags"][occ] & 4)
+    assert not (b["block_flags"] & 8)
+    removed = m.reset_inactive()
+    assert removed.tolist() == [[0, 0, 0]] and m.num_blocks() == 0
+    # quirk restated literally: for stamps < temporal_window even never-observed voxels are "active"
+    m2 = _one_block_map(cfg)
+    m2.update_tracking(1 * s)
+    assert (m2.get_block([0, 0, 0])["flags"] & 1).all()
+
+
+def test_ever_free_needs_buffer_time_and_all_neighbours():
+    """updateBlockEverFree / voxelIsFree (tracking_integrator.cpp:168-222,248-252)."""
+    cfg = _cfg(with_semantics=0, interpolation_method=0)
+    m = _one_block_map(cfg)
+    T, d, sen = _wall_frame(depth=1.4)
+    s = 10**9
+    t0 = 100 * s
+    # an allocated but unobserved block: distance 0 < threshold => every voxel "occupied" at t0 (:231)
+    m.update_tracking(t0)
+    assert (m.get_block([0, 0, 0])["last_occupied"] == t0).all()
+    # observed free from t0+0.1 on: voxelIsFree needs last_occupied < now - temporal_buffer (strict)
+    for k in range(1, 11):
+        t = t0 + k * 10**8
+        m.integrate(sen, t, T, d, allocate_blocks=False)
+        m.update_tracking(t)
+    assert not (m.get_block([0, 0, 0])["flags"] & 2).any()  # now - 1.0 == t0: not yet
+    t = t0 + 11 * 10**8
+    m.integrate(sen, t, T, d, allocate_blocks=False)
+    m.update_tracking(t)
+    b = m.get_block([0, 0, 0])
+    ef = (b["flags"] & 2) > 0
+    assert ef.any()
+    # border voxels can never be ever-free here: their neighbour blocks do not exist (:198-202)
+    iz, iy, ix = np.unravel_index(np.flatnonzero(ef), (16, 16, 16))
+    assert min(ix.min(), iy.min(), iz.min()) >= 1 and max(ix.max(), iy.max(), iz.max()) <= 14
+    # an ever-free voxel has only free-or-ever-free 18-neighbours: all of them were observed
+    obs = (b["last_observed"] != 0).reshape(16, 16, 16)
+    for z, y, x in list(zip(iz, iy, ix))[:50]:
+        assert obs[z, y, x - 1] and obs[z, y, x + 1] and obs[z - 1, y, x] and obs[z + 1, y + 1, x]
+
+
+def test_object_prune_confidence():
+    """computeConfidence -> {0, -1, n1/(n0+n1)} (mesh_object_extractor.cpp:342-356)."""
+    cfg = _cfg(interpolation_method=0, num_labels=2, semantic_mode=1, with_tracking=0)
+    m = _one_block_map(cfg)
+    T, d, sen = _wall_frame(depth=1.0)
+    obj = np.zeros(d.shape, np.int32)
+    obj[: d.shape[0] // 2] = 1
+    for k in range(4):
+        m.integrate(sen, (k + 1) * 10**9, T, d, object_image=obj, object_id=1, allocate_blocks=False)
+    before = m.get_block([0, 0, 0])
+    n = m.object_prune(0.5, 3.0)
+    after = m.get_block([0, 0, 0])
+    changed = before["distance"] != after["distance"]
+    assert n == changed.sum() and n > 0
+    assert np.all(after["distance"][changed] == np.float32(0.3))
+    neg = before["distance"] <= 0
+    keep = neg & ~changed
+    assert np.all(before["likelihoods"][1][keep] / (before["likelihoods"][0][keep] + before["likelihoods"][1][keep]) >= 0.5)
+
+
+def test_synth_is_deterministic_and_labelled():
+    s1, s2 = SyntheticStream(160, 120), SyntheticStream(160, 120, threads=3)
+    a, b = s1.render(7), s2.render(7)
+    assert np.array_equal(a["depth"], b["depth"]) and np.array_equal(a["label"], b["label"])
+    assert a["depth"].max() <= 5.0 and a["label"].min() >= 1
+    assert s1.stamp_ns(10) - s1.stamp_ns(0) == 10**9

@@ -1,0 +1,127 @@
+"""-m gpu: HIP path (through the C ABI) vs the CPU oracle on identical seeded frame sequences."""
+import numpy as np
+import pytest
+
+from common import TOL, compare_maps, make_pair, step_both
+
+pytestmark = pytest.mark.gpu
+
+
+def test_single_frame_tsdf_semantics():
+    cfg, ctx, ora, s, sen, osen = make_pair()
+    fr = s.render(0)
+    out = step_both(ctx, ora, sen, osen, fr, track=False)
+    st = ctx.stats()
+    assert st["n_visible_blocks"] == out["ostats"]["n_visible_blocks"]
+    assert st["n_new_blocks"] == out["ostats"]["n_new_blocks"]
+    assert st["n_updated_voxels"] == out["ostats"]["n_updated_voxels"]
+    assert st["n_band_voxels"] == out["ostats"]["n_band_voxels"]
+    assert st["pool_exhausted"] == 0
+    worst, n = compare_maps(ctx, ora)
+    assert n > 20
+
+
+def test_parse_input_range_and_vertex_map():
+    cfg, ctx, ora, s, sen, osen = make_pair(range_mode=1)
+    fr = s.render(3)
+    fr["depth"][5:9, 7:30] = 0.0
+    fr["depth"][20, 20] = np.nan
+    slot = ctx.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+    r, v, _ = ctx.download_frame(slot, fr["depth"].shape, vertex_map=True)
+    ro, vo = ora.parse_input(osen, fr["pose"], fr["depth"])
+    assert np.array_equal(r, ro)
+    assert np.array_equal(v, vo)
+
+
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_sequence_tsdf_tracking(interp):
+    cfg, ctx, ora, s, sen, osen = make_pair(interpolation_method=interp)
+    for i in range(14):  # > temporal_buffer (1 s) so ever-free voxels appear
+        step_both(ctx, ora, sen, osen, s.render(i))
+    worst, n = compare_maps(ctx, ora, max_blocks=160)
+    # ever-free must actually have been exercised
+    idx = ctx.block_indices()
+    ef = sum(int((ctx.download_block(b, likelihoods=False)["flags"] & 2).sum()) for b in idx[::7])
+    assert ef > 0
+
+
+def test_sequence_with_motion_detection():
+    cfg, ctx, ora, s, sen, osen = make_pair(width=320, height=240)
+    fired = 0
+    for i in range(22):
+        out = step_both(ctx, ora, sen, osen, s.render(i), motion=True)
+        assert out["n_gpu"] == out["n_ora"], (i, out["n_gpu"], out["n_ora"])
+        assert np.array_equal(out["dyn_gpu"], out["dyn_ora"]), i
+        fired += out["n_gpu"]
+    assert fired > 0, "motion detector never fired: scenario does not exercise a9-a11"
+    compare_maps(ctx, ora, max_blocks=120)
+
+
+def test_mesh_and_archival():
+    cfg, ctx, ora, s, sen, osen = make_pair(temporal_window=0.55)
+    for i in range(12):
+        step_both(ctx, ora, sen, osen, s.render(i))
+        if i % 4 == 3:  # extractOutputData cadence (active_window.cpp:217-249)
+            ctx.generate_mesh(True, True)
+            ora.generate_mesh(True, True)
+            gm, om = ctx.download_mesh(), ora.mesh()
+            assert gm["points"].shape == om["points"].shape
+            assert np.abs(gm["points"] - om["points"]).max() <= TOL
+            assert np.array_equal(gm["labels"], om["labels"])
+            assert np.array_equal(gm["stamps"], om["stamps"])
+            assert np.abs(gm["colors"].astype(int) - om["colors"].astype(int)).max() <= 1
+            rg, ro = ctx.reset_inactive(), ora.reset_inactive()
+            assert np.array_equal(rg, ro)
+            ctx.clear_updated()
+            ora.clear_updated()
+            compare_maps(ctx, ora, max_blocks=60)
+    assert ctx.num_blocks() == ora.num_blocks()
+
+
+def test_no_semantics_no_color_8vps_object_map():
+    # object mini-map configuration (mesh_object_extractor.cpp:201-211): vps 8, binary labels, no tracking
+    cfg, ctx, ora, s, sen, osen = make_pair(voxels_per_side=8, voxel_size=0.04, truncation_distance=0.08,
+                                            with_tracking=0, semantic_mode=1, num_labels=2)
+    fr0 = s.render(0)
+    # allocate the blocks covering a box (mesh_object_extractor.cpp:218-228), integrate without allocation
+    bl = np.array([[x, y, z] for x in range(2, 8) for y in range(-3, 3) for z in range(0, 6)], np.int32)
+    ctx.allocate_blocks(bl)
+    ora.allocate_blocks(bl)
+    for i in range(4):
+        fr = s.render(i)
+        obj = (fr["label"] == fr0["label"][120, 160]).astype(np.int32) * 3
+        slot = ctx.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], None)
+        ctx.set_frame_image(slot, 1, obj)
+        ctx.integrate(slot, allocate_blocks=False, use_mask=False, object_id=3)
+        ora.integrate(osen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], None, object_image=obj, object_id=3,
+                      allocate_blocks=False)
+    compare_maps(ctx, ora)
+    ng, no = ctx.object_prune(0.5, 2.0), ora.object_prune(0.5, 2.0)
+    assert ng == no
+    ctx.generate_mesh(True, False)
+    ora.generate_mesh(True, False)
+    gm, om = ctx.download_mesh(), ora.mesh()
+    assert gm["points"].shape == om["points"].shape
+    if len(om["points"]):
+        assert np.abs(gm["points"] - om["points"]).max() <= TOL
+    compare_maps(ctx, ora)
+
+
+def test_sharded_union_equals_unsharded():
+    # owner-computes hash-range sharding: the union of 2 shards equals the unsharded map (TSDF part)
+    cfg, ctx, ora, s, sen, osen = make_pair()
+    _, c0, o0, _, _, _ = make_pair(rank=0, world_size=2)
+    _, c1, o1, _, _, _ = make_pair(rank=1, world_size=2)
+    for i in range(3):
+        fr = s.render(i)
+        for c in (ctx, c0, c1):
+            slot = c.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+            c.integrate(slot)
+    a, b, u = c0.block_indices(), c1.block_indices(), ctx.block_indices()
+    assert len(a) + len(b) == len(u) and len(a) > 0 and len(b) > 0
+    both = np.concatenate([a, b])
+    both = both[np.lexsort((both[:, 2], both[:, 1], both[:, 0]))]
+    assert np.array_equal(both, u)
+    for idx in a[::9]:
+        g, h = c0.download_block(idx), ctx.download_block(idx)
+        assert np.array_equal(g["distance"], h["distance"]) and np.array_equal(g["weight"], h["weight"])

@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py — active-window frames/s (+ Mvoxel-updates/s) of the MI355X fusion path.
+
+A "step" is one ActiveWindow::spinOnce worth of volumetric work on one synthetic RGB-D+label frame per
+camera (reference order, active_window.cpp:118-174): motion detection -> projective TSDF / label
+integration (with the dynamic mask) -> tracking + ever-free update, and every `--output-every` frames
+the output extraction (marching cubes on updated blocks, archival of inactive blocks, flag clearing;
+active_window.cpp:217-249 at uHumans2's min_output_separation = 0.4 s).
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 1280x720 RGB-D + labels,
+2 cm voxels, truncation 6 cm, 16^3 blocks, K = 20 labels, MotionDetector on.  Frames are rendered on the
+host BEFORE the timed region and are resident in HBM when it starts.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): rank r owns camera r of an N-camera rig
+and the hash-range shard r of the block map; every tick the N camera frames are all-gathered over RCCL
+and each rank integrates all of them into the blocks it owns (owner-computes, weak scaling).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--voxel-size", type=float, default=0.02)
+    ap.add_argument("--num-labels", type=int, default=20)
+    ap.add_argument("--max-blocks", type=int, default=40960)
+    ap.add_argument("--output-every", type=int, default=4)
+    ap.add_argument("--no-motion", action="store_true")
+    ap.add_argument("--cpu-baseline-frames", type=int, default=-1,
+                    help="frames of the same stream timed on the CPU oracle (rank 0, N=1); -1 = auto, 0 = skip")
+    ap.add_argument("--no-roofline-timers", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the fusion path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if dist is not None:
+        dist.barrier()
+    from khronos_amd import FusionContext, default_config
+    from khronos_amd.synth import SyntheticStream
+
+    W, H, vs = args.width, args.height, args.voxel_size
+    K = args.num_labels
+    n_total = args.warmup + args.steps
+    cfg = default_config(
+        voxel_size=vs, truncation_distance=3.0 * vs, voxels_per_side=16, with_semantics=1, with_tracking=1,
+        num_labels=K, max_blocks=args.max_blocks, max_frame_pixels=W * H, num_frame_slots=max(2, world),
+        max_mesh_vertices=48 << 20,
+        # khronos_ros/config/mapper/uHumans2.yaml:52-57
+        md_min_cluster_size=500, md_min_separation_distance=2.0, md_max_range=5.0,
+        device=local_rank, rank=rank, world_size=world)
+    ctx = FusionContext(cfg)
+    # one explicit (non-default) HIP stream shared by torch / RCCL and the fusion kernels
+    stream = torch.cuda.Stream(device=local_rank)
+    ctx.set_stream(stream.cuda_stream)
+
+    # ---- synthetic input, rendered before the timed region, resident in HBM ----------------------
+    s = SyntheticStream(W, H, seed=1234)
+    sensor = ctx.make_sensor(W, H, s.fx, s.fy, s.cx, s.cy, 0.1, 5.0)
+    yaw = 2.0 * math.pi * rank / world
+    frames_host = []
+    dev = torch.device("cuda", local_rank)
+    d_depth, d_rgb, d_label, poses, stamps = [], [], [], [], []
+    for i in range(n_total):
+        fr = s.render(i, yaw_offset=yaw)
+        if rank == 0 and world == 1:
+            frames_host.append(fr)
+        d_depth.append(torch.from_numpy(fr["depth"]).to(dev))
+        d_rgb.append(torch.from_numpy(fr["rgb"]).to(dev))
+        d_label.append(torch.from_numpy(fr["label"]).to(dev))
+        stamps.append(fr["stamp"])
+        poses.append([s.pose(i, yaw_offset=2.0 * math.pi * r / world) for r in range(world)])
+    if world > 1:
+        g_depth = [torch.empty_like(d_depth[0]) for _ in range(world)]
+        g_rgb = [torch.empty_like(d_rgb[0]) for _ in range(world)]
+        g_label = [torch.empty_like(d_label[0]) for _ in range(world)]
+    torch.cuda.synchronize()
+
+    def step(i):
+        with torch.cuda.stream(stream):
+            _step(i)
+
+    def _step(i):
+        if world > 1:
+            dist.all_gather(g_depth, d_depth[i])
+            dist.all_gather(g_rgb, d_rgb[i])
+            dist.all_gather(g_label, d_label[i])
+            cams = [(g_depth[r], g_rgb[r], g_label[r], poses[i][r]) for r in range(world)]
+        else:
+            cams = [(d_depth[i], d_rgb[i], d_label[i], poses[i][0])]
+        for (dep, rgb, lab, pose) in cams:
+            slot = ctx.upload_frame_device(sensor, stamps[i], pose, dep.data_ptr(), rgb.data_ptr(), lab.data_ptr())
+            use_mask = False
+            if not args.no_motion and world == 1:
+                ctx.detect_motion(slot)
+                use_mask = True
+            ctx.integrate(slot, allocate_blocks=True, use_mask=use_mask)
+        ctx.update_tracking(stamps[i])
+        if args.output_every > 0 and (i + 1) % args.output_every == 0:
+            ctx.generate_mesh(True, True)
+            ctx.reset_inactive()
+            ctx.clear_updated()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    st0 = ctx.stats()
+    if not args.no_roofline_timers:
+        ctx.timing_reset()
+        ctx.timing_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_total):
+        step(i)
+    sync_all()
+    dt = time.perf_counter() - t0
+    ctx.timing_enable(False)
+    st1 = ctx.stats()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    n_upd = st1["cum_updated_voxels"] - st0["cum_updated_voxels"]
+    n_band = st1["cum_band_voxels"] - st0["cum_band_voxels"]
+    n_vis = st1["cum_visited_voxels"] - st0["cum_visited_voxels"]
+    n_calls = st1["cum_integrate_calls"] - st0["cum_integrate_calls"] + 0
+    if dist is not None:
+        t = torch.tensor([n_upd, n_band, n_vis], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        n_upd_all, n_band_all, n_vis_all = [float(x) for x in t.tolist()]
+    else:
+        n_upd_all, n_band_all, n_vis_all = float(n_upd), float(n_band), float(n_vis)
+
+    frames = args.steps * world  # camera frames fused by the whole job
+    fps = frames / dt
+    out = {
+        "metric": "active-window frames/sec (+ Mvoxel-updates/sec) at %dx%d RGB-D+labels, %g cm voxels" % (W, H, vs * 100),
+        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: %dx%d synthetic RGB-D+labels, %g cm voxels, vps 16, K=%d labels, "
+                               "MotionDetector %s, output extraction every %d frames; %d camera(s)"
+                               % (W, H, vs * 100, K, "off" if (args.no_motion or world > 1) else "on",
+                                  args.output_every, world),
+                   "parallelism": "hash-range block shard x%d, owner-computes, RCCL all-gather of frames" % world
+                   if world > 1 else "single GPU"},
+        "mvoxel_updates_per_s": 1e-6 * n_upd_all / dt,
+        "voxels": {"visited": n_vis_all, "updated": n_upd_all, "band": n_band_all, "allocated_blocks": st1["n_allocated_blocks"]},
+    }
+
+    # ---- roofline of the dominant kernel (k_tsdf_update), from HIP events on the kernel's stream ----
+    if not args.no_roofline_timers and rank == 0:
+        ms, launches = ctx.timing_get("tsdf")
+        # ALGORITHMIC bytes: 24 B per updated voxel (R+W distance, weight; W last_observed)
+        # + (12 + 8K) B per in-band voxel (R+W colour, R+W K likelihoods, W label) + 15 B per pixel (images once)
+        bytes_total = 24.0 * n_upd + (12.0 + 8.0 * K) * n_band + 15.0 * W * H * max(1, launches)
+        achieved = bytes_total / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_tsdf_update_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"kernel": "k_tsdf_update", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
+                           "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                           "avg_launch_us": 1e3 * ms / max(1, launches), "launches": launches,
+                           "algorithmic_bytes_per_launch": bytes_total / max(1, launches)}
+        kern = {}
+        for name in ("tsdf", "tracking", "ever_free", "alloc", "motion_pixels", "mesh", "parse"):
+            m_, n_ = ctx.timing_get(name)
+            kern[name] = {"ms_total": m_, "launches": n_}
+        out["kernel_ms"] = kern
+
+    # ---- CPU baseline: the oracle on a bounded sample of the same stream (rank 0, N = 1 only) ----
+    nb = args.cpu_baseline_frames
+    if rank == 0 and world == 1 and nb != 0:
+        from oracle import pyoracle as po
+        cores = os.cpu_count() or 1
+        if nb < 0:
+            nb = max(4, min(12, args.warmup + args.steps))
+        ocfg = po.config_from(cfg, cores)
+        ora = po.OracleMap(ocfg)
+        osen = ora.make_sensor(W, H, s.fx, s.fy, s.cx, s.cy, 0.1, 5.0)
+        tc = 0.0
+        upd = 0
+        # same stream, first nb frames (includes the allocation-heavy first frame, like the GPU warm-up)
+        skip = min(2, nb - 1)
+        for i in range(nb):
+            fr = frames_host[i]
+            c0 = time.perf_counter()
+            dyn = None
+            if not args.no_motion:
+                _, dyn, _ = ora.detect_motion(osen, fr["stamp"], fr["pose"], fr["depth"])
+            stc = ora.integrate(osen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"], mask=dyn)
+            ora.update_tracking(fr["stamp"])
+            if args.output_every > 0 and (i + 1) % args.output_every == 0:
+                ora.generate_mesh(True, True)
+                ora.reset_inactive()
+                ora.clear_updated()
+            c1 = time.perf_counter()
+            if i >= skip:
+                tc += c1 - c0
+                upd += stc["n_updated_voxels"]
+        cpu_fps = (nb - skip) / tc
+        out["cpu_baseline"] = {"value": cpu_fps, "unit": "frames/s", "cores": cores, "kind": "port",
+                               "sample": "frames %d..%d of the same stream (CPU restatement of the reference path, "
+                                         "%d threads; reference itself not buildable offline)" % (skip, nb - 1, cores),
+                               "mvoxel_updates_per_s": 1e-6 * upd / tc}
+        out["speedup_vs_cpu"] = fps / cpu_fps
+
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,6 +116,10 @@ typedef struct khr_stats {
   uint64_t n_mesh_blocks;      /* last generate_mesh */
   uint64_t n_mesh_vertices;
   uint64_t pool_exhausted;     /* non-zero if an allocation was dropped for lack of pool slots */
+  uint64_t cum_updated_voxels; /* totals over all khr_integrate calls since khr_create */
+  uint64_t cum_band_voxels;
+  uint64_t cum_visited_voxels;
+  uint64_t cum_integrate_calls;
 } khr_stats;
 
 typedef struct khr_ctx khr_ctx;

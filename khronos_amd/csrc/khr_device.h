@@ -36,7 +36,7 @@ enum Counter : int {
   C_N_MESH,
   C_COUNT = 16
 };
-enum Stat64 : int { S_UPD = 0, S_BAND, S_MESH_VERTS, S_PRUNED, S_COUNT = 8 };
+enum Stat64 : int { S_UPD = 0, S_BAND, S_MESH_VERTS, S_PRUNED, S_CUM_UPD, S_CUM_BAND, S_CUM_VISITED, S_CUM_CALLS, S_COUNT = 8 };
 
 struct MeshDesc {
   uint32_t offset;  // first vertex in the mesh vertex buffer

@@ -115,6 +115,21 @@ __global__ __launch_bounds__(256) void k_alloc_visible(DevMap m, DevParams p, De
   if (emit) work[widx] = slot;
 }
 
+// per-call counter reset; the previous call's statistics are folded into cumulative totals so that a
+// benchmark can read N_upd / N_band sums once, outside its timed region.
+__global__ void k_begin_integrate(DevMap m, int nvox) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    m.stats[S_CUM_UPD] += m.stats[S_UPD];
+    m.stats[S_CUM_BAND] += m.stats[S_BAND];
+    m.stats[S_CUM_VISITED] += static_cast<unsigned long long>(m.counters[C_N_VISIBLE]) * nvox;
+    m.stats[S_CUM_CALLS] += 1ull;
+    m.stats[S_UPD] = 0ull;
+    m.stats[S_BAND] = 0ull;
+    m.counters[C_N_VISIBLE] = 0u;
+    m.counters[C_N_NEW] = 0u;
+  }
+}
+
 // explicit allocation of a list of block indices (VolumetricMap::allocateBlock)
 __global__ __launch_bounds__(256) void k_alloc_list(DevMap m, const int* __restrict__ idx, int n,
                                                    uint32_t* __restrict__ new_list) {

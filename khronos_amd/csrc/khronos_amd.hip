@@ -581,8 +581,7 @@ int khr_integrate(khr_ctx* c, int slot, int allocate_blocks, int use_mask, int o
   const DevFrame f = makeDevFrame(c, s);
   DevMap& m = c->m;
   // reset per-call counters
-  HIP_TRY(hipMemsetAsync(&m.counters[C_N_VISIBLE], 0, sizeof(uint32_t) * 2, c->stream));  // N_VISIBLE, N_NEW
-  HIP_TRY(hipMemsetAsync(&m.stats[S_UPD], 0, sizeof(unsigned long long) * 2, c->stream));
+  hipLaunchKernelGGL(k_begin_integrate, dim3(1), dim3(64), 0, c->stream, m, c->p.nvox);
   if (allocate_blocks) {
     ScopedTimer tm(c, 3);
     const DevFrustum fr = makeFrustum(c, f);
@@ -981,6 +980,10 @@ int khr_get_stats(khr_ctx* c, khr_stats* out) {
   s.n_band_voxels = st[S_BAND];
   s.n_tracking_updated_blocks = c->h_counters[C_N_EF];
   s.pool_exhausted = c->h_counters[C_POOL_EXHAUSTED];
+  s.cum_updated_voxels = st[S_CUM_UPD] + st[S_UPD];
+  s.cum_band_voxels = st[S_CUM_BAND] + st[S_BAND];
+  s.cum_visited_voxels = st[S_CUM_VISITED] + s.n_visited_voxels;
+  s.cum_integrate_calls = st[S_CUM_CALLS];
   *out = s;
   return KHR_OK;
 }

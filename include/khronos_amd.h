@@ -82,6 +82,8 @@ typedef struct khr_config {
   uint32_t max_frame_pixels;  /* largest W*H that will be uploaded */
   uint32_t num_frame_slots;   /* device-resident frame ring (FrameDataBuffer role, frame_data_buffer.h:52-100) */
   uint64_t max_mesh_vertices; /* capacity of the mesh vertex buffer */
+  uint32_t max_band_records;  /* capacity of the per-frame in-band voxel list (0 = 4 * max_frame_pixels) */
+  int32_t disable_culling;    /* 1 = visit every frustum block in the TSDF kernel (A/B switch; results identical) */
   /* placement */
   int32_t device;     /* HIP device ordinal */
   int32_t rank;       /* owner-computes sharding: this context integrates blocks with owner == rank */
@@ -120,6 +122,8 @@ typedef struct khr_stats {
   uint64_t cum_band_voxels;
   uint64_t cum_visited_voxels;
   uint64_t cum_integrate_calls;
+  uint64_t n_tsdf_blocks;      /* last integrate: blocks left after conservative culling */
+  uint64_t band_overflow;      /* non-zero if in-band records were dropped (raise max_band_records) */
 } khr_stats;
 
 typedef struct khr_ctx khr_ctx;
@@ -194,8 +198,11 @@ int64_t khr_download_mesh(khr_ctx* ctx, float* points, uint8_t* colors_rgba, uin
 
 /* -- measurement ------------------------------------------------------------------------------- */
 /* HIP-event timing of the kernels launched on the context stream. which: 0 tsdf update,
- * 1 tracking update, 2 ever-free, 3 block allocation+init, 4 motion pixels, 5 mesh, 6 parse input.
+ * 1 tracking update, 2 ever-free, 3 block allocation+init, 4 motion pixels, 5 mesh, 6 parse input,
+ * 7 band (colour / label) update.
  * Accumulates between khr_timing_reset calls; returns total ms and launch count. */
+/* development probe (KHR_DEBUG & 8): per-workgroup timestamps of the last k_tsdf_update launch */
+int khr_debug_read(khr_ctx* ctx, unsigned long long* out, int64_t n);
 int khr_timing_enable(khr_ctx* ctx, int enable);
 int khr_timing_reset(khr_ctx* ctx);
 int khr_timing_get(khr_ctx* ctx, int which, double* total_ms, uint64_t* launches);

@@ -30,7 +30,7 @@ class KhrConfig(C.Structure):
         ("md_max_range", C.c_float), ("md_min_z_coordinate", C.c_float),
         ("mesh_min_weight", C.c_float),
         ("max_blocks", C.c_uint32), ("max_frame_pixels", C.c_uint32), ("num_frame_slots", C.c_uint32),
-        ("max_mesh_vertices", C.c_uint64),
+        ("max_mesh_vertices", C.c_uint64), ("max_band_records", C.c_uint32), ("disable_culling", C.c_int32),
         ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
     ]
 
@@ -49,7 +49,7 @@ class KhrStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "n_allocated_blocks", "n_visible_blocks", "n_new_blocks", "n_visited_voxels", "n_updated_voxels",
         "n_band_voxels", "n_tracking_updated_blocks", "n_seeds", "n_mesh_blocks", "n_mesh_vertices",
-        "pool_exhausted", "cum_updated_voxels", "cum_band_voxels", "cum_visited_voxels", "cum_integrate_calls")]
+        "pool_exhausted", "cum_updated_voxels", "cum_band_voxels", "cum_visited_voxels", "cum_integrate_calls", "n_tsdf_blocks", "band_overflow")]
 
 
 # every symbol include/khronos_amd.h declares (tests check the library exports all of them)
@@ -59,7 +59,7 @@ EXPORTS = [
     "khr_detect_motion", "khr_generate_mesh", "khr_reset_inactive", "khr_mark_all_inactive", "khr_clear_updated",
     "khr_allocate_blocks", "khr_object_prune", "khr_get_stats", "khr_num_blocks", "khr_block_indices",
     "khr_download_block", "khr_mesh_num_vertices", "khr_download_mesh", "khr_timing_enable", "khr_timing_reset",
-    "khr_timing_get",
+    "khr_timing_get", "khr_debug_read",
 ]
 
 _lib = None
@@ -111,6 +111,7 @@ def load_library():
     lib.khr_mesh_num_vertices.restype = i64
     lib.khr_download_mesh.argtypes = [vp, vp, vp, vp, vp, vp, i64]
     lib.khr_download_mesh.restype = i64
+    lib.khr_debug_read.argtypes = [vp, vp, i64]
     lib.khr_timing_enable.argtypes = [vp, i32]
     lib.khr_timing_reset.argtypes = [vp]
     lib.khr_timing_get.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64)]
@@ -135,7 +136,7 @@ def _ptr(a):
 class FusionContext:
     """Thin object wrapper over a khr_ctx (one per GPU / per map)."""
 
-    TIMERS = {"tsdf": 0, "tracking": 1, "ever_free": 2, "alloc": 3, "motion_pixels": 4, "mesh": 5, "parse": 6}
+    TIMERS = {"tsdf": 0, "tracking": 1, "ever_free": 2, "alloc": 3, "motion_pixels": 4, "mesh": 5, "parse": 6, "band": 7}
 
     def __init__(self, cfg):
         self.lib = load_library()

@@ -34,6 +34,10 @@ enum Counter : int {
   C_N_REMOVED,
   C_N_SEEDS,
   C_N_MESH,
+  C_N_BAND,          // in-band records of the last integrate
+  C_N_TSDF,          // non-culled work list length of the last integrate
+  C_BAND_OVERFLOW,
+  C_TSDF_CURSOR,     // dynamic work cursor of k_tsdf_update
   C_COUNT = 16
 };
 enum Stat64 : int { S_UPD = 0, S_BAND, S_MESH_VERTS, S_PRUNED, S_CUM_UPD, S_CUM_BAND, S_CUM_VISITED, S_CUM_CALLS, S_COUNT = 8 };
@@ -76,6 +80,7 @@ struct DevParams {
   int nn;
   float mesh_min_weight;
   int rank, world;
+  int dbg;  // ablation switches (env KHR_DEBUG), 0 in production
 };
 
 struct DevFrame {

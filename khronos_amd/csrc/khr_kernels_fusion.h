@@ -5,6 +5,8 @@
 
 namespace khr {
 
+constexpr int kBandShards = 16;  // the in-band record list is split in shards (one atomic cursor each)
+
 // ----------------------------------------------------------------------------------------------
 // k_parse_input: hydra::conversions::parseInputPacket role (active_window.cpp:275).
 // depth -> range image (z-depth or ray length), rgb u8x3 -> rgba8 (one aligned 4-byte gather per
@@ -33,6 +35,22 @@ __global__ __launch_bounds__(256) void k_parse_input(const float* __restrict__ d
                        (static_cast<uint32_t>(rgb[3 * i + 2]) << 16) | 0xff000000u;
     rgba[i] = c;
   }
+}
+
+// coarse max-range image: one value per 16x16 pixel tile (block-level culling in k_alloc_visible).
+constexpr int kTile = 16;
+__global__ __launch_bounds__(256) void k_range_tiles(const float* __restrict__ range, int W, int H,
+                                                    float* __restrict__ tile_max, int tw) {
+  const int tx = blockIdx.x % tw, ty = blockIdx.x / tw;
+  const int u = tx * kTile + (threadIdx.x & 15), v = ty * kTile + (threadIdx.x >> 4);
+  float r = 0.f;
+  if (u < W && v < H) r = range[v * W + u];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) r = fmaxf(r, __shfl_down(r, o));
+  __shared__ float s[4];
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = r;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_max[blockIdx.x] = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
 }
 
 // world-frame vertex map on demand (InputData::vertex_map)
@@ -117,7 +135,8 @@ __global__ __launch_bounds__(256) void k_alloc_visible(DevMap m, DevParams p, De
 
 // per-call counter reset; the previous call's statistics are folded into cumulative totals so that a
 // benchmark can read N_upd / N_band sums once, outside its timed region.
-__global__ void k_begin_integrate(DevMap m, int nvox) {
+__global__ void k_begin_integrate(DevMap m, int nvox, uint32_t* band_count) {
+  if (blockIdx.x == 0 && threadIdx.x < kBandShards) band_count[threadIdx.x * 32] = 0u;
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     m.stats[S_CUM_UPD] += m.stats[S_UPD];
     m.stats[S_CUM_BAND] += m.stats[S_BAND];
@@ -127,6 +146,88 @@ __global__ void k_begin_integrate(DevMap m, int nvox) {
     m.stats[S_BAND] = 0ull;
     m.counters[C_N_VISIBLE] = 0u;
     m.counters[C_N_NEW] = 0u;
+    m.counters[C_N_TSDF] = 0u;
+    m.counters[C_TSDF_CURSOR] = 0u;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_cull_blocks: exact, conservative block culling.  Every frustum block stays allocated and listed in
+// `work` (block index sets are unchanged), but a block is left out of the TSDF work list when NO voxel
+// of it can produce a valid measurement: all voxels behind the camera / out of range / projecting
+// outside the image, or the largest range value under the block's projected footprint (16x16-pixel
+// max tiles) is smaller than the block's nearest voxel range minus the truncation distance (then every
+// sdf < -trunc).  One wave per block: the 64 lanes scan the footprint's tiles and max-reduce.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cull_blocks(DevMap m, DevParams p, DevFrame f,
+                                                    const uint32_t* __restrict__ work,
+                                                    uint32_t* __restrict__ work_tsdf,
+                                                    const float* __restrict__ tile_max, int tw, int th) {
+  // each workgroup tests kPerWg blocks (one wave per block, 4 rounds), gathers the survivors in LDS and
+  // appends them with ONE atomic (hot-address atomics are expensive, see k_tsdf_update)
+  constexpr int kPerWg = 16;
+  __shared__ uint32_t s_keep[kPerWg];
+  __shared__ uint32_t s_nkeep, s_off;
+  const uint32_t n = m.counters[C_N_VISIBLE];
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t base = blockIdx.x * kPerWg; base < n; base += gridDim.x * kPerWg) {
+  if (threadIdx.x == 0) s_nkeep = 0;
+  __syncthreads();
+  for (uint32_t wi = base + (threadIdx.x >> 6); wi < min(n, base + kPerWg); wi += 4) {
+    const uint32_t slot = work[wi];
+    const int4 bi = m.blk_index[slot];
+    bool keep = true;
+    if (tile_max) {
+      const float margin = 1e-3f;
+      const float lo[3] = {static_cast<float>(bi.x) * p.bs + 0.5f * p.vs, static_cast<float>(bi.y) * p.bs + 0.5f * p.vs,
+                           static_cast<float>(bi.z) * p.bs + 0.5f * p.vs};
+      const float ext = p.bs - p.vs;
+      float zmin = 1e30f, zmax = -1e30f, umin = 1e30f, umax = -1e30f, vmin = 1e30f, vmax = -1e30f;
+      float pcs[8][3];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        xform(f.R, f.t, lo[0] + ((k & 1) ? ext : 0.f), lo[1] + ((k & 2) ? ext : 0.f), lo[2] + ((k & 4) ? ext : 0.f), pcs[k]);
+        zmin = fminf(zmin, pcs[k][2]);
+        zmax = fmaxf(zmax, pcs[k][2]);
+      }
+      // voxel_range >= z in both range modes; z is affine in the voxel position => extremes at corners
+      if (zmax <= -margin) keep = false;              // every voxel behind the camera
+      if (zmin > f.max_range + margin) keep = false;  // every voxel beyond max range
+      if (p.range_mode == 0 && zmax < f.min_range - margin) keep = false;
+      if (keep && zmin > 0.05f) {  // wave-uniform
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float u = (pcs[k][0] * f.fx) / pcs[k][2] + f.cx, v = (pcs[k][1] * f.fy) / pcs[k][2] + f.cy;
+          umin = fminf(umin, u); umax = fmaxf(umax, u);
+          vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+        }
+        // the projection of a convex box in front of the camera lies in the hull of its projected corners
+        if (umax < -1.f || vmax < -1.f || umin > static_cast<float>(f.W) || vmin > static_cast<float>(f.H)) {
+          keep = false;
+        } else {
+          const int tx0 = max(0, (static_cast<int>(floorf(umin)) - 1) / kTile);
+          const int ty0 = max(0, (static_cast<int>(floorf(vmin)) - 1) / kTile);
+          const int tx1 = min(tw - 1, (static_cast<int>(ceilf(umax)) + 2) / kTile);
+          const int ty1 = min(th - 1, (static_cast<int>(ceilf(vmax)) + 2) / kTile);
+          if (tx1 >= tx0 && ty1 >= ty0) {
+            const int nx = tx1 - tx0 + 1, nt = nx * (ty1 - ty0 + 1);
+            float mr = 0.f;
+            for (int t = lane; t < nt; t += 64) mr = fmaxf(mr, tile_max[(ty0 + t / nx) * tw + tx0 + t % nx]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mr = fmaxf(mr, __shfl_xor(mr, o));
+            // distance_to_surface <= max of the 4 interpolated ranges <= mr; sdf = it - voxel_range
+            if (mr < zmin - p.trunc - margin) keep = false;
+          }
+        }
+      }
+    }
+    if (lane == 0 && keep) s_keep[atomicAdd(&s_nkeep, 1u)] = slot;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) s_off = s_nkeep ? atomicAdd(&m.counters[C_N_TSDF], s_nkeep) : 0u;
+  __syncthreads();
+  if (threadIdx.x < s_nkeep) work_tsdf[s_off + threadIdx.x] = s_keep[threadIdx.x];
+  __syncthreads();
   }
 }
 
@@ -208,178 +309,402 @@ __global__ __launch_bounds__(256) void k_init_blocks(DevMap m, DevParams p, cons
 }
 
 // ----------------------------------------------------------------------------------------------
-// k_tsdf_update: the per-voxel loop of hydra::ProjectiveIntegrator (call active_window.cpp:210; label
-// hook object_integrator.cpp:58-81; ASSUMPTIONS.md A.3).  One workgroup (256 threads = 4 waves) per
-// visible block; lane l of a wave owns voxels whose linear index is congruent to its thread id, so
-// every per-field access of a wave is a contiguous 256-byte (f32) / 512-byte (u64) segment.
-// The work list is walked XCD-aware: workgroup b runs on XCD b%8, and is given a contiguous eighth
-// of the (spatially ordered) work list so that each XCD's L2 keeps one band of the images.
+// Projective TSDF / label update = the per-voxel loop of hydra::ProjectiveIntegrator (call
+// active_window.cpp:210; label hook object_integrator.cpp:58-81; ASSUMPTIONS.md A.3), split in two
+// kernels so that every wave does uniform work:
+//
+//  k_tsdf_update  one workgroup (256 threads) per visible, non-culled block, the 16^3 block staged in LDS:
+//    pass 1  thread <-> voxel (lanes along x,y so a wave's 64 image footprints are neighbours):
+//            project, 4 range gathers, sdf / weight -> measurement tile in LDS (8 B per voxel); in-band
+//            voxels are appended as 24-byte records to a global list (wave-aggregated atomic).
+//    pass 2  thread <-> 4 consecutive voxels: 16-byte ds_read of the measurement tile, 16-byte
+//            global load / store of distance and weight (running weighted average), 8-byte
+//            last_observed stores.  Blocks are never read unless a voxel of the float4 group is valid.
+//  k_band_update  one thread per in-band record, dense lanes: colour blend, mask-free label lookup,
+//            K likelihoods (8 independent loads in flight per chunk), arg-max label.
 // ----------------------------------------------------------------------------------------------
-template <int VPS>
-__global__ __launch_bounds__(256) void k_tsdf_update(DevMap m, DevParams p, DevFrame f,
-                                                    const uint32_t* __restrict__ work,
-                                                    const uint32_t* __restrict__ n_work, int use_mask, int object_id) {
+struct BandRec {
+  uint32_t slot;
+  uint32_t lin_mode;  // bits 0..15 linear voxel index, bit 16 = nearest-neighbour interpolation
+  float w;            // measurement weight
+};
+
+
+__device__ inline void interpPixels(float u, float v, int W, int H, int* px, float* du, float* dv) {
+  const int u0 = static_cast<int>(floorf(u)), v0 = static_cast<int>(floorf(v));
+  const int u1 = min(u0 + 1, W - 1), v1 = min(v0 + 1, H - 1);
+  *du = u - static_cast<float>(u0);
+  *dv = v - static_cast<float>(v0);
+  px[0] = v0 * W + u0;
+  px[1] = v1 * W + u0;
+  px[2] = v0 * W + u1;
+  px[3] = v1 * W + u1;
+}
+
+__device__ inline int interpWeights(float du, float dv, bool use_nearest, float* w4) {
+  int best;
+  if (use_nearest) {
+    const int nearest = (du >= 0.5f ? 2 : 0) + (dv >= 0.5f ? 1 : 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w4[k] = (k == nearest) ? 1.f : 0.f;
+    best = nearest;
+  } else {
+    w4[0] = (1.f - du) * (1.f - dv);
+    w4[1] = (1.f - du) * dv;
+    w4[2] = du * (1.f - dv);
+    w4[3] = du * dv;
+    best = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (w4[k] > w4[best]) best = k;
+  }
+  return best;
+}
+
+// slim argument block of k_tsdf_update (keeps the kernel's SGPR footprint small)
+struct TsdfArgs {
+  const int4* blk_index;
+  uint32_t* blk_flags;
+  float* dist;
+  float* weight;
+  uint64_t* last_obs;
+  unsigned long long* stats;
+  uint32_t* counters;
+  const float* range;
+  const int32_t* dyn;
+  int W, H;
+  float fx, fy, cx, cy, min_range, max_range;
+  float R[9], t[3];
+  uint64_t stamp;
+  float vs, bs, trunc, dropoff_eps, max_weight, adaptive_diff;
+  int interp, range_mode, use_dropoff, const_weight, with_tracking, use_mask, dbg;
+  unsigned long long* dbg_buf;  // ablation / timing probe (KHR_DEBUG & 8)
+  uint32_t* wg_stats;           // per-workgroup {n_upd, n_band} partial sums
+};
+
+// FAST = the reference default configuration (z-depth range, adaptive interpolation, weight drop-off,
+// no constant weight, no debug switches) resolved at compile time; the generic instantiation reads the
+// switches from the argument block.
+template <int VPS, int CHUNKS, bool FAST>
+__global__ __launch_bounds__(256) void k_tsdf_update(TsdfArgs a, const uint32_t* __restrict__ work,
+                                                    const uint32_t* __restrict__ n_work,
+                                                    BandRec* __restrict__ band, uint32_t shard_cap,
+                                                    uint32_t* __restrict__ band_count) {
   constexpr int NV = VPS * VPS * VPS;
-  const uint32_t n = *n_work;
-  const uint32_t xcd = blockIdx.x & 7u, j0 = blockIdx.x >> 3, jstride = gridDim.x >> 3;
-  const uint32_t chunk = (n + 7u) >> 3;
-  const uint32_t begin = xcd * chunk, end = min(n, begin + chunk);
+  constexpr int CV = NV / CHUNKS;  // voxels staged in LDS at a time (a z-slab of the block)
+  constexpr int PER = CV / 256;    // voxels per thread in pass 2 (consecutive)
+  static_assert(CV % 256 == 0, "chunk must be a multiple of the workgroup size");
+  __shared__ __attribute__((aligned(16))) float s_sdf[CV];
+  __shared__ __attribute__((aligned(16))) float s_w[CV];
+  __shared__ __attribute__((aligned(16))) uint8_t s_flag[CV];  // bit0 in band, bit1 nearest interpolation
+  __shared__ uint32_t s_wsum[4];
+  __shared__ uint32_t s_base;
+  const uint32_t n = *n_work * CHUNKS;  // work item = one z-slab (chunk) of a block
+  const int range_mode = FAST ? 0 : a.range_mode;
+  const int interp = FAST ? 2 : a.interp;
+  const bool use_dropoff = FAST ? true : (a.use_dropoff != 0);
+  const bool const_weight = FAST ? false : (a.const_weight != 0);
+  const int dbg = FAST ? 0 : a.dbg;
+  const float Wf = static_cast<float>(a.W), Hf = static_cast<float>(a.H);
   uint32_t n_upd = 0, n_band = 0;
-  for (uint32_t wi = begin + j0; wi < end; wi += jstride) {
-    const size_t slot = work[wi];
-    const int4 bi = m.blk_index[slot];
-    const float ox = static_cast<float>(bi.x) * p.bs, oy = static_cast<float>(bi.y) * p.bs,
-                oz = static_cast<float>(bi.z) * p.bs;
-    float* __restrict__ dist = m.dist + slot * NV;
-    float* __restrict__ wgt = m.weight + slot * NV;
-    uint32_t* __restrict__ col = m.color + slot * NV;
-    uint64_t* __restrict__ lobs = m.last_obs + slot * NV;
-    uint8_t* __restrict__ vfl = m.vflags + slot * NV;
-    uint32_t* __restrict__ slab = m.sem_label + slot * NV;
-    float* __restrict__ lik = m.lik + slot * static_cast<size_t>(p.K) * NV;
-    bool any = false;
-    for (int lin = threadIdx.x; lin < NV; lin += 256) {
+  // static striding over the work items: a single hot atomic address sustains only ~90 ops/us on
+  // gfx950, so neither a dynamic work cursor nor per-wave statistics atomics are used here.
+  for (uint32_t wi = blockIdx.x; wi < n; wi += gridDim.x) {
+    const unsigned long long t_start = (dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long t_p1 = 0, t_rec = 0;
+    const size_t slot = work[wi / CHUNKS];
+    const int chunk = static_cast<int>(wi % CHUNKS);
+    const int4 bi = a.blk_index[slot];
+    const float ox = static_cast<float>(bi.x) * a.bs, oy = static_cast<float>(bi.y) * a.bs,
+                oz = static_cast<float>(bi.z) * a.bs;
+    const int cbase = chunk * CV;
+    uint32_t any = 0;
+    // ---- pass 1: measurement per voxel -> LDS (branch-free; invalid lanes are masked by `ok`) ----
+#pragma unroll 2
+    for (int cl = threadIdx.x; cl < CV; cl += 256) {
+      const int lin = cbase + cl;
       const int ix = lin % VPS, iy = (lin / VPS) % VPS, iz = lin / (VPS * VPS);
-      const float px = ox + (static_cast<float>(ix) + 0.5f) * p.vs;
-      const float py = oy + (static_cast<float>(iy) + 0.5f) * p.vs;
-      const float pz = oz + (static_cast<float>(iz) + 0.5f) * p.vs;
+      const float px = ox + (static_cast<float>(ix) + 0.5f) * a.vs;
+      const float py = oy + (static_cast<float>(iy) + 0.5f) * a.vs;
+      const float pz = oz + (static_cast<float>(iz) + 0.5f) * a.vs;
       float pc[3];
-      xform(f.R, f.t, px, py, pz, pc);
-      if (pc[2] <= 0.f) continue;
+      xform(a.R, a.t, px, py, pz, pc);
+      bool ok = pc[2] > 0.f;
       const float voxel_range =
-          p.range_mode == 0 ? pc[2] : sqrtf((pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2]);
-      if (voxel_range < f.min_range || voxel_range > f.max_range) continue;
-      const float u = (pc[0] * f.fx) / pc[2] + f.cx;
-      if (ceilf(u) >= static_cast<float>(f.W) || floorf(u) < 0.f) continue;
-      const float v = (pc[1] * f.fy) / pc[2] + f.cy;
-      if (ceilf(v) >= static_cast<float>(f.H) || floorf(v) < 0.f) continue;
-      // interpolation weights
-      const int u0 = static_cast<int>(floorf(u)), v0 = static_cast<int>(floorf(v));
-      const int u1 = min(u0 + 1, f.W - 1), v1 = min(v0 + 1, f.H - 1);
-      const float du = u - static_cast<float>(u0), dv = v - static_cast<float>(v0);
-      const int px4[4] = {v0 * f.W + u0, v1 * f.W + u0, v0 * f.W + u1, v1 * f.W + u1};
+          range_mode == 0 ? pc[2] : sqrtf((pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2]);
+      ok = ok && !(voxel_range < a.min_range || voxel_range > a.max_range);
+      const float u = (pc[0] * a.fx) / pc[2] + a.cx;
+      ok = ok && !(ceilf(u) >= Wf || floorf(u) < 0.f);
+      const float v = (pc[1] * a.fy) / pc[2] + a.cy;
+      ok = ok && !(ceilf(v) >= Hf || floorf(v) < 0.f);
+      // clamp the coordinates of invalid lanes so that the gathers stay inside the image
+      const float uc = ok ? u : 0.f, vc = ok ? v : 0.f;
+      int px4[4];
+      float du, dv;
+      interpPixels(uc, vc, a.W, a.H, px4, &du, &dv);
       float r4[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) r4[k] = f.range[px4[k]];
-      const int nearest = (du >= 0.5f ? 2 : 0) + (dv >= 0.5f ? 1 : 0);
-      bool use_nearest = p.interp == 0;
-      if (p.interp == 2) {
+      for (int k = 0; k < 4; ++k) r4[k] = a.range[(dbg & 4) ? k : px4[k]];
+      bool use_nearest = interp == 0;
+      if (interp == 2) {
         const float mn = fminf(fminf(r4[0], r4[1]), fminf(r4[2], r4[3]));
         const float mx = fmaxf(fmaxf(r4[0], r4[1]), fmaxf(r4[2], r4[3]));
-        if (mx - mn > p.adaptive_diff) use_nearest = true;
+        use_nearest = use_nearest || (mx - mn > a.adaptive_diff);
       }
       float w4[4];
-      int best;
-      if (use_nearest) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) w4[k] = (k == nearest) ? 1.f : 0.f;
-        best = nearest;
-      } else {
-        w4[0] = (1.f - du) * (1.f - dv);
-        w4[1] = (1.f - du) * dv;
-        w4[2] = du * (1.f - dv);
-        w4[3] = du * dv;
-        best = 0;
-#pragma unroll
-        for (int k = 1; k < 4; ++k)
-          if (w4[k] > w4[best]) best = k;
-      }
+      const int best = interpWeights(du, dv, use_nearest, w4);
       const float dist_surface = ((w4[0] * r4[0] + w4[1] * r4[1]) + w4[2] * r4[2]) + w4[3] * r4[3];
-      if (!(dist_surface >= f.min_range) || dist_surface > f.max_range) continue;
+      ok = ok && (dist_surface >= a.min_range) && !(dist_surface > a.max_range);
       const float sdf = dist_surface - voxel_range;
-      if (sdf < -p.trunc) continue;
-      const bool in_band = fabsf(sdf) < p.trunc;
-      const int best_px = px4[best];
-      int label = -1;
-      bool have_label = false;
-      if (in_band) {
-        if (use_mask && f.dyn[best_px] != 0) continue;
-        if (p.sem_mode == 1) {
-          if (object_id >= 0 && f.obj) {
-            label = (f.obj[best_px] == object_id) ? 1 : 0;
-            have_label = true;
-          }
-        } else if (f.has_label) {
-          label = f.label[best_px];
-          have_label = true;
+      ok = ok && !(sdf < -a.trunc);
+      bool in_band = ok && (fabsf(sdf) < a.trunc);
+      if (a.use_mask) {
+        const int bpx = best == 0 ? px4[0] : (best == 1 ? px4[1] : (best == 2 ? px4[2] : px4[3]));
+        if (in_band && a.dyn[bpx] != 0) {
+          ok = false;
+          in_band = false;
         }
       }
-      const float q = p.vs / pc[2];
-      float w = (f.fx * f.fy) * (q * q);
-      if (!p.const_weight) w = w / (pc[2] * pc[2]);
-      if (p.use_dropoff && sdf < -p.dropoff_eps) {
-        w = w * ((p.trunc + sdf) / (p.trunc - p.dropoff_eps));
-        w = fmaxf(w, 0.f);
+      const float q = a.vs / pc[2];
+      float w = (a.fx * a.fy) * (q * q);
+      if (!const_weight) w = w / (pc[2] * pc[2]);
+      if (use_dropoff) {
+        const float wd = fmaxf(w * ((a.trunc + sdf) / (a.trunc - a.dropoff_eps)), 0.f);
+        w = (sdf < -a.dropoff_eps) ? wd : w;
       }
-      if (!(w > 0.f)) continue;
-
-      const float d_old = dist[lin], w_old = wgt[lin];
-      const float sdf_c = fmaxf(fminf(p.trunc, sdf), -p.trunc);
-      const float d_new = (d_old * w_old + sdf_c * w) / (w_old + w);
-      const float w_new = fminf(w_old + w, p.max_weight);
-      dist[lin] = d_new;
-      wgt[lin] = w_new;
-      if (p.with_tracking) lobs[lin] = f.stamp;
-      ++n_upd;
-      any = true;
-      if (in_band) {
-        ++n_band;
-        if (f.has_color) {
-          float a[3] = {0.f, 0.f, 0.f};
+      ok = ok && (w > 0.f);
+      in_band = in_band && ok;
+      const float meas_w = ok ? w : 0.f;
+      s_sdf[cl] = fmaxf(fminf(a.trunc, sdf), -a.trunc);
+      s_w[cl] = meas_w;
+      s_flag[cl] = static_cast<uint8_t>((in_band ? 1 : 0) | (use_nearest ? 2 : 0));
+      n_upd += ok ? 1u : 0u;
+      n_band += in_band ? 1u : 0u;
+      any |= ok ? 1u : 0u;
+    }
+    const int any_blk = __syncthreads_or(static_cast<int>(any));
+    if (dbg & 8) t_p1 = __builtin_amdgcn_s_memtime();
+    // ---- in-band records: block-wide exclusive scan, ONE atomic per workgroup ------------------
+    if (any_blk && !(dbg & 2)) {
+      uint32_t cnt = 0;
+      if (PER >= 4) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const uint32_t c = f.rgba[px4[k]];
-            a[0] = a[0] + w4[k] * static_cast<float>(c & 0xffu);
-            a[1] = a[1] + w4[k] * static_cast<float>((c >> 8) & 0xffu);
-            a[2] = a[2] + w4[k] * static_cast<float>((c >> 16) & 0xffu);
-          }
-          const uint32_t co = col[lin];
-          const float tot = w_new + w;
-          uint32_t out = 0xff000000u;
+        for (int j = 0; j < PER / 4; ++j)
+          cnt += __popc(reinterpret_cast<const uint32_t*>(s_flag)[threadIdx.x * (PER / 4) + j] & 0x01010101u);
+      } else {
 #pragma unroll
-          for (int ch = 0; ch < 3; ++ch) {
-            const float cn = static_cast<float>(toU8(a[ch]));
-            const float cv = static_cast<float>((co >> (8 * ch)) & 0xffu);
-            out |= static_cast<uint32_t>(toU8((cv * w_new + cn * w) / tot)) << (8 * ch);
-          }
-          col[lin] = out;
-        }
-        if (p.with_semantics && have_label && label >= 0 && label < p.K) {
-          const uint8_t fl = vfl[lin];
-          const bool empty = !(fl & VOX_SEM_VALID);
-          int bestk = 0;
-          float bestv = 0.f;
-          for (int k = 0; k < p.K; ++k) {
-            float l = empty ? 0.f : lik[static_cast<size_t>(k) * NV + lin];
-            if (p.sem_mode == 1) {
-              if (k == label) l += 1.f;
+        for (int j = 0; j < PER; ++j) cnt += s_flag[threadIdx.x * PER + j] & 1u;
+      }
+      uint32_t incl = cnt;  // wave inclusive scan
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if ((threadIdx.x & 63) >= static_cast<uint32_t>(o)) incl += t;
+      }
+      if ((threadIdx.x & 63) == 63) s_wsum[threadIdx.x >> 6] = incl;
+      __syncthreads();
+      const uint32_t wv = threadIdx.x >> 6;
+      uint32_t woff = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) woff += (static_cast<uint32_t>(k) < wv) ? s_wsum[k] : 0u;
+      const uint32_t total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+      const uint32_t shard = blockIdx.x & (kBandShards - 1);
+      if (threadIdx.x == 0) s_base = total ? atomicAdd(&band_count[shard * 32], total) : 0u;
+      __syncthreads();
+      if (cnt) {
+        uint32_t pos = s_base + woff + incl - cnt;
+        BandRec* __restrict__ dst = band + static_cast<size_t>(shard) * shard_cap;
+        bool overflow = false;
+        for (int j = 0; j < PER; ++j) {
+          const int cl = threadIdx.x * PER + j;
+          const uint8_t fl = s_flag[cl];
+          if (fl & 1) {
+            if (pos < shard_cap) {
+              BandRec r;
+              r.slot = static_cast<uint32_t>(slot);
+              r.lin_mode = static_cast<uint32_t>(cbase + cl) | ((fl & 2) ? 0x10000u : 0u);
+              r.w = s_w[cl];
+              dst[pos] = r;
             } else {
-              l += (k == label) ? p.log_match : p.log_nomatch;
+              overflow = true;
             }
-            if (p.sem_mode == 0 || k == label || empty) lik[static_cast<size_t>(k) * NV + lin] = l;
-            if (k == 0 || l > bestv) {
-              bestv = l;
-              bestk = k;
-            }
+            ++pos;
           }
-          if (empty) vfl[lin] = fl | VOX_SEM_VALID;
-          slab[lin] = static_cast<uint32_t>(bestk);
         }
+        if (overflow) atomicAdd(&a.counters[C_BAND_OVERFLOW], 1u);
       }
     }
-    if (__syncthreads_or(any ? 1 : 0)) {
-      if (threadIdx.x == 0) m.blk_flags[slot] |= (BLK_UPDATED | BLK_MESH_UPDATED | BLK_TRACKING_UPDATED);
+    if (dbg & 8) t_rec = __builtin_amdgcn_s_memtime();
+    // ---- pass 2: vectorised running-average update of the voxel arrays -----------------------
+    if (any_blk && !(dbg & 1)) {
+      float4* __restrict__ dist4 = reinterpret_cast<float4*>(a.dist + slot * NV + cbase);
+      float4* __restrict__ wgt4 = reinterpret_cast<float4*>(a.weight + slot * NV + cbase);
+      uint64_t* __restrict__ lobs = a.last_obs + slot * NV + cbase;
+      for (int g = threadIdx.x; g < CV / 4; g += 256) {
+        const float4 mw = reinterpret_cast<const float4*>(s_w)[g];
+        if (!(mw.x > 0.f || mw.y > 0.f || mw.z > 0.f || mw.w > 0.f)) continue;
+        const float4 ms = reinterpret_cast<const float4*>(s_sdf)[g];
+        float4 d = dist4[g], w = wgt4[g];
+        if (mw.x > 0.f) { d.x = (d.x * w.x + ms.x * mw.x) / (w.x + mw.x); w.x = fminf(w.x + mw.x, a.max_weight); }
+        if (mw.y > 0.f) { d.y = (d.y * w.y + ms.y * mw.y) / (w.y + mw.y); w.y = fminf(w.y + mw.y, a.max_weight); }
+        if (mw.z > 0.f) { d.z = (d.z * w.z + ms.z * mw.z) / (w.z + mw.z); w.z = fminf(w.z + mw.z, a.max_weight); }
+        if (mw.w > 0.f) { d.w = (d.w * w.w + ms.w * mw.w) / (w.w + mw.w); w.w = fminf(w.w + mw.w, a.max_weight); }
+        dist4[g] = d;
+        wgt4[g] = w;
+        if (a.with_tracking) {
+          if (mw.x > 0.f) lobs[4 * g] = a.stamp;
+          if (mw.y > 0.f) lobs[4 * g + 1] = a.stamp;
+          if (mw.z > 0.f) lobs[4 * g + 2] = a.stamp;
+          if (mw.w > 0.f) lobs[4 * g + 3] = a.stamp;
+        }
+      }
+      if (threadIdx.x == 0) {
+        if (CHUNKS == 1) a.blk_flags[slot] |= (BLK_UPDATED | BLK_MESH_UPDATED | BLK_TRACKING_UPDATED);
+        else atomicOr(&a.blk_flags[slot], BLK_UPDATED | BLK_MESH_UPDATED | BLK_TRACKING_UPDATED);
+      }
+    }
+    __syncthreads();  // LDS tile is reused by the next work item of this workgroup
+    if ((dbg & 8) && (threadIdx.x & 63) == 0 && wi < 4096) {
+      unsigned long long* o = a.dbg_buf + (static_cast<size_t>(wi) * 4 + (threadIdx.x >> 6)) * 8;
+      o[0] = t_start;
+      o[1] = t_p1;
+      o[2] = t_rec;
+      o[3] = __builtin_amdgcn_s_memtime();
+      o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+      o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+      o[6] = blockIdx.x;
+      o[7] = any_blk;
     }
   }
-  // statistics: wave reduce, one atomic per wave
+  // statistics: wave reduce -> LDS -> one plain store per workgroup (summed by k_band_update)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     n_upd += __shfl_down(n_upd, o);
     n_band += __shfl_down(n_band, o);
   }
-  if ((threadIdx.x & 63) == 0 && (n_upd | n_band)) {
-    atomicAdd(&m.stats[S_UPD], static_cast<unsigned long long>(n_upd));
-    atomicAdd(&m.stats[S_BAND], static_cast<unsigned long long>(n_band));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    s_wsum[threadIdx.x >> 6] = n_upd;
+    reinterpret_cast<uint32_t*>(s_sdf)[threadIdx.x >> 6] = n_band;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a.wg_stats[2 * blockIdx.x] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    const uint32_t* sb = reinterpret_cast<const uint32_t*>(s_sdf);
+    a.wg_stats[2 * blockIdx.x + 1] = sb[0] + sb[1] + sb[2] + sb[3];
+  }
+}
+
+template <int VPS>
+__global__ __launch_bounds__(256) void k_band_update(DevMap m, DevParams p, DevFrame f,
+                                                    const BandRec* __restrict__ band, uint32_t shard_cap,
+                                                    const uint32_t* __restrict__ band_count, int object_id,
+                                                    const uint32_t* __restrict__ wg_stats, int n_wg) {
+  constexpr int NV = VPS * VPS * VPS;
+  if (blockIdx.x == 0 && blockIdx.y == 0) {  // fold k_tsdf_update's per-workgroup statistics
+    unsigned long long u = 0, b = 0;
+    for (int i = threadIdx.x; i < n_wg; i += blockDim.x) {
+      u += wg_stats[2 * i];
+      b += wg_stats[2 * i + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      u += __shfl_down(u, o);
+      b += __shfl_down(b, o);
+    }
+    if ((threadIdx.x & 63) == 0 && (u | b)) {
+      atomicAdd(&m.stats[S_UPD], u);
+      atomicAdd(&m.stats[S_BAND], b);
+    }
+  }
+  const uint32_t shard = blockIdx.y;
+  const uint32_t n = min(band_count[shard * 32], shard_cap);
+  const BandRec* __restrict__ src = band + static_cast<size_t>(shard) * shard_cap;
+  for (uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x; ri < n; ri += gridDim.x * blockDim.x) {
+    const BandRec r = src[ri];
+    const size_t slot = r.slot;
+    const int lin = static_cast<int>(r.lin_mode & 0xffffu);
+    const bool use_nearest = (r.lin_mode & 0x10000u) != 0;
+    // re-project the voxel centre (same expressions as k_tsdf_update pass 1 => identical u, v)
+    const int4 bi = m.blk_index[slot];
+    const int ix = lin % VPS, iy = (lin / VPS) % VPS, iz = lin / (VPS * VPS);
+    const float pwx = static_cast<float>(bi.x) * p.bs + (static_cast<float>(ix) + 0.5f) * p.vs;
+    const float pwy = static_cast<float>(bi.y) * p.bs + (static_cast<float>(iy) + 0.5f) * p.vs;
+    const float pwz = static_cast<float>(bi.z) * p.bs + (static_cast<float>(iz) + 0.5f) * p.vs;
+    float pc[3];
+    xform(f.R, f.t, pwx, pwy, pwz, pc);
+    const float u = (pc[0] * f.fx) / pc[2] + f.cx;
+    const float v = (pc[1] * f.fy) / pc[2] + f.cy;
+    int px4[4];
+    float du, dv, w4[4];
+    interpPixels(u, v, f.W, f.H, px4, &du, &dv);
+    const int best = interpWeights(du, dv, use_nearest, w4);
+    const int best_px = px4[best];
+    const float w = r.w;
+    if (f.has_color) {
+      float a[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t c = f.rgba[px4[k]];
+        a[0] = a[0] + w4[k] * static_cast<float>(c & 0xffu);
+        a[1] = a[1] + w4[k] * static_cast<float>((c >> 8) & 0xffu);
+        a[2] = a[2] + w4[k] * static_cast<float>((c >> 16) & 0xffu);
+      }
+      const float w_new = m.weight[slot * NV + lin];  // voxel weight after the k_tsdf_update pass
+      const uint32_t co = m.color[slot * NV + lin];
+      const float tot = w_new + w;
+      uint32_t out = 0xff000000u;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float cn = static_cast<float>(toU8(a[ch]));
+        const float cv = static_cast<float>((co >> (8 * ch)) & 0xffu);
+        out |= static_cast<uint32_t>(toU8((cv * w_new + cn * w) / tot)) << (8 * ch);
+      }
+      m.color[slot * NV + lin] = out;
+    }
+    int label = -1;
+    bool have_label = false;
+    if (p.sem_mode == 1) {
+      if (object_id >= 0 && f.obj) {
+        label = (f.obj[best_px] == object_id) ? 1 : 0;
+        have_label = true;
+      }
+    } else if (f.has_label) {
+      label = f.label[best_px];
+      have_label = true;
+    }
+    if (p.with_semantics && have_label && label >= 0 && label < p.K) {
+      uint8_t* vfl = m.vflags + slot * NV;
+      float* __restrict__ lik = m.lik + slot * static_cast<size_t>(p.K) * NV;
+      const uint8_t fl = vfl[lin];
+      const bool empty = !(fl & VOX_SEM_VALID);
+      int bestk = 0;
+      float bestv = 0.f;
+      for (int k0 = 0; k0 < p.K; k0 += 8) {
+        float l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          l[j] = (!empty && k0 + j < p.K) ? lik[static_cast<size_t>(k0 + j) * NV + lin] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = k0 + j;
+          if (k < p.K) {
+            if (p.sem_mode == 1) {
+              if (k == label) l[j] += 1.f;
+            } else {
+              l[j] += (k == label) ? p.log_match : p.log_nomatch;
+            }
+            if (p.sem_mode == 0 || k == label || empty) lik[static_cast<size_t>(k) * NV + lin] = l[j];
+            if (k == 0 || l[j] > bestv) {
+              bestv = l[j];
+              bestk = k;
+            }
+          }
+        }
+      }
+      if (empty) vfl[lin] = fl | VOX_SEM_VALID;
+      m.sem_label[slot * NV + lin] = static_cast<uint32_t>(bestk);
+    }
   }
 }
 
@@ -391,8 +716,7 @@ __global__ __launch_bounds__(256) void k_tsdf_update(DevMap m, DevParams p, DevF
 //    stencil (and the multi-GPU halo exchange) consumes instead of re-reading 17 B per neighbour voxel.
 // ----------------------------------------------------------------------------------------------
 template <int VPS>
-__global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, uint64_t stamp,
-                                                        uint32_t* __restrict__ ef_list) {
+__global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, uint64_t stamp) {
   constexpr int NV = VPS * VPS * VPS;
   const uint32_t n_slots = m.counters[C_MAX_SLOT];
   const double now = toSeconds(stamp);
@@ -433,7 +757,6 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
     if (threadIdx.x == 0) {
       uint32_t nf = (fl & ~(BLK_TRACKING_UPDATED | BLK_HAS_ACTIVE)) | (act ? BLK_HAS_ACTIVE : 0u);
       m.blk_flags[s] = nf;
-      if (fl & BLK_TRACKING_UPDATED) ef_list[atomicAdd(&m.counters[C_N_EF], 1u)] = s;
     }
   }
 }

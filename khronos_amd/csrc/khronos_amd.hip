@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <functional>
 #include <map>
 #include <string>
@@ -54,6 +55,8 @@ struct FrameSlot {
   int32_t* dyn = nullptr;
   int32_t* obj = nullptr;
   uint8_t* rgb_staging = nullptr;
+  float* tile_max = nullptr;
+  int tw = 0, th = 0;
   khr_sensor sensor{};
   khr_frame meta{};
   bool valid = false, has_color = false, has_label = false, has_obj = false;
@@ -82,6 +85,12 @@ struct khr_ctx {
   uint32_t* d_work = nullptr;
   uint32_t* d_new = nullptr;
   uint32_t* d_ef = nullptr;
+  uint32_t* d_work_tsdf = nullptr;
+  BandRec* d_band = nullptr;
+  uint32_t band_cap = 0;
+  uint32_t* d_band_count = nullptr;
+  unsigned long long* d_dbg = nullptr;
+  uint32_t* d_wg_stats = nullptr;
   int4* d_removed = nullptr;
   int* d_idx_staging = nullptr;
   // motion detection scratch
@@ -260,8 +269,10 @@ int dispatchVps(khr_ctx* c, F&& f) {
   return fail(KHR_EINVAL, "voxels_per_side must be 8 or 16");
 }
 
-constexpr int kTsdfGrid = 8192;   // multiple of 8 (XCD-aware walk)
+int kTsdfGrid = 4096;   // persistent grid: 256 CUs x 4 resident workgroups (LDS-limited)
+int kTsdfChunks = 4;
 constexpr int kStreamGrid = 4096;
+constexpr int kBandGrid = 2048;
 
 }  // namespace
 
@@ -367,6 +378,9 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   p.mesh_min_weight = cfg->mesh_min_weight;
   p.rank = cfg->rank;
   p.world = cfg->world_size;
+  p.dbg = std::getenv("KHR_DEBUG") ? std::atoi(std::getenv("KHR_DEBUG")) : 0;
+  if (std::getenv("KHR_TSDF_GRID")) kTsdfGrid = std::min(16384, std::atoi(std::getenv("KHR_TSDF_GRID")));
+  if (std::getenv("KHR_TSDF_CHUNKS")) kTsdfChunks = std::atoi(std::getenv("KHR_TSDF_CHUNKS"));
 
   DevMap& m = c->m;
   const size_t cap = cfg->max_blocks, nv = p.nvox;
@@ -396,6 +410,13 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &c->d_work, cap));
   A(devAlloc(c, &c->d_new, cap));
   A(devAlloc(c, &c->d_ef, cap));
+  A(devAlloc(c, &c->d_work_tsdf, cap));
+  c->band_cap = cfg->max_band_records ? cfg->max_band_records : 4u * cfg->max_frame_pixels;
+  c->band_cap = (c->band_cap / kBandShards + 1) * kBandShards;
+  A(devAlloc(c, &c->d_band, c->band_cap, false));
+  A(devAlloc(c, &c->d_band_count, kBandShards * 32));
+  A(devAlloc(c, &c->d_dbg, 4096 * 4 * 8));
+  A(devAlloc(c, &c->d_wg_stats, 2 * 16384));
   A(devAlloc(c, &c->d_removed, cap));
   A(devAlloc(c, &c->d_mesh_count, cap + 1));
   A(devAlloc(c, &c->d_mesh_offset, cap + 1));
@@ -441,6 +462,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     A(devAlloc(c, &s.dyn, npx));
     A(devAlloc(c, &s.obj, npx));
     A(devAlloc(c, &s.rgb_staging, npx * 3, false));
+    A(devAlloc(c, &s.tile_max, npx / 16 + 64, false));
   }
   if (rc != KHR_OK) {
     khr_destroy(c);
@@ -534,6 +556,10 @@ int khr_upload_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fram
   HIP_TRY(hipMemsetAsync(s.dyn, 0, n * sizeof(int32_t), c->stream));
   hipLaunchKernelGGL(k_parse_input, dim3(gridFor(n)), dim3(256), 0, c->stream, s.depth, rgb_dev, s.range, s.rgba,
                      sensor->width, sensor->height, sensor->fx, sensor->fy, sensor->cx, sensor->cy, c->p.range_mode);
+  s.tw = (sensor->width + kTile - 1) / kTile;
+  s.th = (sensor->height + kTile - 1) / kTile;
+  hipLaunchKernelGGL(k_range_tiles, dim3(s.tw * s.th), dim3(256), 0, c->stream, s.range, sensor->width, sensor->height,
+                     s.tile_max, s.tw);
   HIP_TRY(hipGetLastError());
   if (!on_device) HIP_TRY(hipStreamSynchronize(c->stream));  // caller buffers may be reused after return
   s.valid = true;
@@ -581,7 +607,9 @@ int khr_integrate(khr_ctx* c, int slot, int allocate_blocks, int use_mask, int o
   const DevFrame f = makeDevFrame(c, s);
   DevMap& m = c->m;
   // reset per-call counters
-  hipLaunchKernelGGL(k_begin_integrate, dim3(1), dim3(64), 0, c->stream, m, c->p.nvox);
+  hipLaunchKernelGGL(k_begin_integrate, dim3(1), dim3(64), 0, c->stream, m, c->p.nvox, c->d_band_count);
+  const uint32_t* tsdf_work = c->d_work;
+  const uint32_t* tsdf_count = &m.counters[C_N_VISIBLE];
   if (allocate_blocks) {
     ScopedTimer tm(c, 3);
     const DevFrustum fr = makeFrustum(c, f);
@@ -589,20 +617,60 @@ int khr_integrate(khr_ctx* c, int slot, int allocate_blocks, int use_mask, int o
     const size_t total = static_cast<size_t>(S) * S * S;
     hipLaunchKernelGGL(k_alloc_visible, dim3(gridFor(total)), dim3(256), 0, c->stream, m, c->p, f, fr, c->d_work, c->d_new);
     hipLaunchKernelGGL(k_init_blocks, dim3(2048), dim3(256), 0, c->stream, m, c->p, c->d_new);
+    hipLaunchKernelGGL(k_cull_blocks, dim3(1024), dim3(256), 0, c->stream, m, c->p, f, c->d_work, c->d_work_tsdf,
+                       c->cfg.disable_culling ? nullptr : s.tile_max, s.tw, s.th);
     c->host_index_valid = false;
+    tsdf_work = c->d_work_tsdf;
+    tsdf_count = &m.counters[C_N_TSDF];
   } else {
     hipLaunchKernelGGL(k_list_live, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_work,
                        &m.counters[C_N_VISIBLE], 0u);
   }
-  {
-    ScopedTimer tm(c, 0);
-    int rc = dispatchVps(c, [&](auto vps) {
-      hipLaunchKernelGGL((k_tsdf_update<decltype(vps)::value>), dim3(kTsdfGrid), dim3(256), 0, c->stream, m, c->p, f,
-                         c->d_work, &m.counters[C_N_VISIBLE], use_mask, object_id);
-      return KHR_OK;
-    });
-    if (rc) return rc;
-  }
+  int rc = dispatchVps(c, [&](auto vps) {
+    constexpr int V = decltype(vps)::value;
+    {
+      ScopedTimer tm(c, 0);
+      TsdfArgs a{};
+      a.blk_index = m.blk_index; a.blk_flags = m.blk_flags; a.dist = m.dist; a.weight = m.weight;
+      a.last_obs = m.last_obs; a.stats = m.stats; a.counters = m.counters;
+      a.range = f.range; a.dyn = f.dyn; a.W = f.W; a.H = f.H;
+      a.fx = f.fx; a.fy = f.fy; a.cx = f.cx; a.cy = f.cy; a.min_range = f.min_range; a.max_range = f.max_range;
+      std::memcpy(a.R, f.R, sizeof(a.R));
+      std::memcpy(a.t, f.t, sizeof(a.t));
+      a.stamp = f.stamp;
+      a.vs = c->p.vs; a.bs = c->p.bs; a.trunc = c->p.trunc; a.dropoff_eps = c->p.dropoff_eps;
+      a.max_weight = c->p.max_weight; a.adaptive_diff = c->p.adaptive_diff;
+      a.interp = c->p.interp; a.range_mode = c->p.range_mode; a.use_dropoff = c->p.use_dropoff;
+      a.const_weight = c->p.const_weight; a.with_tracking = c->p.with_tracking; a.use_mask = use_mask; a.dbg = c->p.dbg; a.dbg_buf = c->d_dbg; a.wg_stats = c->d_wg_stats;
+      // CHUNKS = z-slabs of the block staged in LDS at a time (LDS per workgroup = 9 B * nvox / CHUNKS)
+      const bool fast = a.range_mode == 0 && a.interp == 2 && a.use_dropoff && !a.const_weight && a.dbg == 0;
+      auto launch = [&](auto chunks) {
+        constexpr int CH = decltype(chunks)::value;
+        if (fast)
+          hipLaunchKernelGGL((k_tsdf_update<V, CH, true>), dim3(kTsdfGrid), dim3(256), 0, c->stream, a, tsdf_work,
+                             tsdf_count, c->d_band, c->band_cap / kBandShards, c->d_band_count);
+        else
+          hipLaunchKernelGGL((k_tsdf_update<V, CH, false>), dim3(kTsdfGrid), dim3(256), 0, c->stream, a, tsdf_work,
+                             tsdf_count, c->d_band, c->band_cap / kBandShards, c->d_band_count);
+      };
+      if (V == 8) {
+        launch(std::integral_constant<int, 1>());
+      } else {
+        switch (kTsdfChunks) {
+          case 1: launch(std::integral_constant<int, 1>()); break;
+          case 2: launch(std::integral_constant<int, 2>()); break;
+          default: launch(std::integral_constant<int, (V == 16 ? 4 : 1)>()); break;
+        }
+      }
+    }
+    {
+      ScopedTimer tm(c, 7);
+      hipLaunchKernelGGL((k_band_update<V>), dim3(kBandGrid / kBandShards, kBandShards), dim3(256), 0, c->stream, m, c->p, f,
+                         c->d_band, c->band_cap / kBandShards, c->d_band_count, object_id, c->d_wg_stats, kTsdfGrid);
+    }
+    return KHR_OK;
+  });
+  if (rc) return rc;
   HIP_TRY(hipGetLastError());
   return KHR_OK;
 }
@@ -614,10 +682,12 @@ int khr_update_tracking(khr_ctx* c, uint64_t stamp) {
   DevMap& m = c->m;
   HIP_TRY(hipMemsetAsync(&m.counters[C_N_EF], 0, sizeof(uint32_t), c->stream));
   return dispatchVps(c, [&](auto vps) {
+    hipLaunchKernelGGL(k_list_live, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_ef, &m.counters[C_N_EF],
+                       BLK_TRACKING_UPDATED);
     {
       ScopedTimer tm(c, 1);
       hipLaunchKernelGGL((k_tracking_update<decltype(vps)::value>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p,
-                         stamp, c->d_ef);
+                         stamp);
     }
     {
       ScopedTimer tm(c, 2);
@@ -980,6 +1050,8 @@ int khr_get_stats(khr_ctx* c, khr_stats* out) {
   s.n_band_voxels = st[S_BAND];
   s.n_tracking_updated_blocks = c->h_counters[C_N_EF];
   s.pool_exhausted = c->h_counters[C_POOL_EXHAUSTED];
+  s.n_tsdf_blocks = c->h_counters[C_N_TSDF];
+  s.band_overflow = c->h_counters[C_BAND_OVERFLOW];
   s.cum_updated_voxels = st[S_CUM_UPD] + st[S_UPD];
   s.cum_band_voxels = st[S_CUM_BAND] + st[S_BAND];
   s.cum_visited_voxels = st[S_CUM_VISITED] + s.n_visited_voxels;
@@ -1097,6 +1169,13 @@ int64_t khr_download_mesh(khr_ctx* c, float* points, uint8_t* colors_rgba, uint3
     n += d.count;
   }
   return n;
+}
+
+int khr_debug_read(khr_ctx* c, unsigned long long* out, int64_t n) {
+  if (!c || !out) return fail(KHR_EINVAL, "null argument");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(out, c->d_dbg, sizeof(unsigned long long) * std::min<int64_t>(n, 4096 * 4 * 8), hipMemcpyDeviceToHost));
+  return KHR_OK;
 }
 
 int khr_timing_enable(khr_ctx* c, int enable) {

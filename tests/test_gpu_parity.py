@@ -125,3 +125,25 @@ def test_sharded_union_equals_unsharded():
     for idx in a[::9]:
         g, h = c0.download_block(idx), ctx.download_block(idx)
         assert np.array_equal(g["distance"], h["distance"]) and np.array_equal(g["weight"], h["weight"])
+
+
+def test_culling_is_exact():
+    """conservative block culling must not change a single voxel (A/B switch disable_culling)."""
+    cfg, ctx, ora, s, sen, osen = make_pair(width=320, height=240)
+    _, ctx2, _, _, _, _ = make_pair(width=320, height=240, disable_culling=1)
+    for i in range(4):
+        fr = s.render(i)
+        for c in (ctx, ctx2):
+            slot = c.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+            c.integrate(slot)
+            c.update_tracking(fr["stamp"])
+    sa, sb = ctx.stats(), ctx2.stats()
+    assert sa["n_tsdf_blocks"] < sb["n_tsdf_blocks"] == sb["n_visible_blocks"] == sa["n_visible_blocks"]
+    assert sa["n_updated_voxels"] == sb["n_updated_voxels"] and sa["n_band_voxels"] == sb["n_band_voxels"]
+    assert sa["band_overflow"] == 0
+    idx = ctx.block_indices()
+    assert np.array_equal(idx, ctx2.block_indices())
+    for b in idx:
+        g, h = ctx.download_block(b), ctx2.download_block(b)
+        for k in ("distance", "weight", "color", "last_observed", "flags", "sem_label", "likelihoods"):
+            assert np.array_equal(g[k], h[k]), (k, b)

@@ -126,18 +126,18 @@ def main():
             cams = [(g_depth[r], g_rgb[r], g_label[r], poses[i][r]) for r in range(world)]
         else:
             cams = [(d_depth[i], d_rgb[i], d_label[i], poses[i][0])]
-        for (dep, rgb, lab, pose) in cams:
-            slot = ctx.upload_frame_device(sensor, stamps[i], pose, dep.data_ptr(), rgb.data_ptr(), lab.data_ptr())
-            use_mask = False
+        out_now = args.output_every > 0 and (i + 1) % args.output_every == 0
+        for ci, (dep, rgb, lab, pose) in enumerate(cams):
+            flags = 0
             if not args.no_motion and world == 1:
-                ctx.detect_motion(slot)
-                use_mask = True
-            ctx.integrate(slot, allocate_blocks=True, use_mask=use_mask)
-        ctx.update_tracking(stamps[i])
-        if args.output_every > 0 and (i + 1) % args.output_every == 0:
-            ctx.generate_mesh(True, True)
-            ctx.reset_inactive()
-            ctx.clear_updated()
+                flags |= ctx.PF_MOTION
+            last = ci == len(cams) - 1
+            if last:
+                flags |= ctx.PF_TRACKING  # TrackingIntegrator::updateBlocks once per tick, after all cameras
+                if out_now:
+                    flags |= ctx.PF_OUTPUT
+            fr = ctx.make_frame(stamps[i], pose, dep.data_ptr(), rgb.data_ptr(), lab.data_ptr())
+            ctx.process_frame(sensor, fr, True, flags)
 
     def sync_all():
         torch.cuda.synchronize()

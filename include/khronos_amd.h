@@ -168,6 +168,8 @@ int khr_generate_mesh(khr_ctx* ctx, int only_mesh_updated, int clear_flag);
 /* replaces: TrackingIntegrator::resetInactive (tracking_integrator.cpp:106-131). removed: caller
  * buffer for 3*cap int32 block indices (may be NULL); *n_removed receives the count. */
 int khr_reset_inactive(khr_ctx* ctx, int32_t* removed, int64_t cap, int64_t* n_removed);
+/* block indices archived by the last (possibly asynchronous) khr_reset_inactive; synchronises. */
+int khr_last_removed(khr_ctx* ctx, int32_t* removed, int64_t cap, int64_t* n_removed);
 /* replaces: the has_active_data=false loop of ActiveWindow::finishMapping (active_window.cpp:181-183) */
 int khr_mark_all_inactive(khr_ctx* ctx);
 /* replaces: TsdfBlock::clearUpdated loop (active_window.cpp:169-171) */
@@ -176,6 +178,19 @@ int khr_clear_updated(khr_ctx* ctx);
 int khr_allocate_blocks(khr_ctx* ctx, const int32_t* indices, int64_t n);
 /* replaces: confidence pruning loop of MeshObjectExtractor (mesh_object_extractor.cpp:246-264) */
 int khr_object_prune(khr_ctx* ctx, float min_confidence, float min_observations, int64_t* n_pruned);
+
+/* One ActiveWindow::spinOnce worth of volumetric work in a single call (active_window.cpp:118-174):
+ * upload + normalise the frame, [KHR_PF_MOTION] FreeSpaceMotionDetector + dynamic mask, frustum
+ * allocation + projective integration, [KHR_PF_TRACKING] tracking / ever-free update, [KHR_PF_OUTPUT]
+ * the volumetric part of extractOutputData (mesh of updated blocks, archival, flag clearing; the list of
+ * archived blocks is fetched with khr_last_removed).  The host only waits where the reference's data
+ * flow forces it to (the motion detector's seed count) and that wait is hidden behind block allocation.
+ * Returns the frame slot (>= 0) or a negative error; *n_clusters (may be NULL) = dynamic clusters kept. */
+#define KHR_PF_MOTION 1u
+#define KHR_PF_TRACKING 2u
+#define KHR_PF_OUTPUT 4u
+int khr_process_frame(khr_ctx* ctx, const khr_sensor* sensor, const khr_frame* frame, int on_device, uint32_t flags,
+                      int* n_clusters);
 
 /* -- output / inspection ----------------------------------------------------------------------- */
 int khr_get_stats(khr_ctx* ctx, khr_stats* out);

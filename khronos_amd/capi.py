@@ -59,7 +59,7 @@ EXPORTS = [
     "khr_detect_motion", "khr_generate_mesh", "khr_reset_inactive", "khr_mark_all_inactive", "khr_clear_updated",
     "khr_allocate_blocks", "khr_object_prune", "khr_get_stats", "khr_num_blocks", "khr_block_indices",
     "khr_download_block", "khr_mesh_num_vertices", "khr_download_mesh", "khr_timing_enable", "khr_timing_reset",
-    "khr_timing_get", "khr_debug_read",
+    "khr_timing_get", "khr_debug_read", "khr_last_removed", "khr_process_frame",
 ]
 
 _lib = None
@@ -112,6 +112,8 @@ def load_library():
     lib.khr_download_mesh.argtypes = [vp, vp, vp, vp, vp, vp, i64]
     lib.khr_download_mesh.restype = i64
     lib.khr_debug_read.argtypes = [vp, vp, i64]
+    lib.khr_last_removed.argtypes = [vp, vp, i64, C.POINTER(i64)]
+    lib.khr_process_frame.argtypes = [vp, C.POINTER(KhrSensor), C.POINTER(KhrFrame), i32, C.c_uint32, C.POINTER(i32)]
     lib.khr_timing_enable.argtypes = [vp, i32]
     lib.khr_timing_reset.argtypes = [vp]
     lib.khr_timing_get.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64)]
@@ -205,6 +207,33 @@ class FusionContext:
         f.color = color_ptr or None
         f.label = label_ptr or None
         return self._chk(self.lib.khr_upload_frame(self.h, C.byref(sensor), C.byref(f), 1))
+
+    PF_MOTION, PF_TRACKING, PF_OUTPUT = 1, 2, 4
+
+    def make_frame(self, stamp_ns, world_T_sensor, depth_ptr, color_ptr=0, label_ptr=0):
+        """pre-built khr_frame for device-resident buffers (reusable across process_frame calls)."""
+        f = KhrFrame()
+        f.timestamp_ns = int(stamp_ns)
+        T = np.ascontiguousarray(world_T_sensor, dtype=np.float64).reshape(16)
+        for i in range(16):
+            f.world_T_sensor[i] = T[i]
+        f.depth = depth_ptr
+        f.color = color_ptr or None
+        f.label = label_ptr or None
+        return f
+
+    def process_frame(self, sensor, frame, on_device=True, flags=3):
+        nc = C.c_int(0)
+        slot = self._chk(self.lib.khr_process_frame(self.h, C.byref(sensor), C.byref(frame), int(on_device), flags,
+                                                    C.byref(nc)))
+        return slot, nc.value
+
+    def last_removed(self):
+        n = C.c_int64(0)
+        cap = int(self.cfg.max_blocks)
+        out = np.zeros((cap, 3), np.int32)
+        self._chk(self.lib.khr_last_removed(self.h, _ptr(out), cap, C.byref(n)))
+        return out[: n.value].copy()
 
     def set_frame_image(self, slot, which, image):
         if image is None:

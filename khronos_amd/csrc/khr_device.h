@@ -37,8 +37,9 @@ enum Counter : int {
   C_N_BAND,          // in-band records of the last integrate
   C_N_TSDF,          // non-culled work list length of the last integrate
   C_BAND_OVERFLOW,
-  C_TSDF_CURSOR,     // dynamic work cursor of k_tsdf_update
-  C_COUNT = 16
+  C_TSDF_CURSOR,     // (unused)
+  C_MESH_OVERFLOW,
+  C_COUNT = 24
 };
 enum Stat64 : int { S_UPD = 0, S_BAND, S_MESH_VERTS, S_PRUNED, S_CUM_UPD, S_CUM_BAND, S_CUM_VISITED, S_CUM_CALLS, S_COUNT = 8 };
 

@@ -96,8 +96,12 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
                                                        const uint32_t* __restrict__ n_work,
                                                        uint32_t* __restrict__ new_count,
                                                        const uint32_t* __restrict__ new_offset, MeshBuffers out,
-                                                       int clear_flag) {
+                                                       int clear_flag, uint32_t max_vertices) {
   constexpr int NV = VPS * VPS * VPS;
+  if (EMIT && new_offset[m.capacity] > max_vertices) {  // vertex buffer too small: flag, write nothing
+    if (blockIdx.x == 0 && threadIdx.x == 0) m.counters[C_MESH_OVERFLOW] = 1u;
+    return;
+  }
   constexpr int T = VPS + 1;
   __shared__ float s_d[T * T * T];
   __shared__ float s_w[T * T * T];
@@ -240,7 +244,8 @@ __global__ __launch_bounds__(256) void k_mesh_carry_counts(DevMap m, uint32_t* _
 // one workgroup per slot (grid-stride); `regen` marks slots that pass 2 rewrites.
 __global__ __launch_bounds__(256) void k_mesh_move(DevMap m, const uint8_t* __restrict__ regen,
                                                   const uint32_t* __restrict__ new_offset, MeshBuffers src,
-                                                  MeshBuffers dst) {
+                                                  MeshBuffers dst, uint32_t max_vertices) {
+  if (new_offset[m.capacity] > max_vertices) return;
   const uint32_t n_slots = m.counters[C_MAX_SLOT];
   for (uint32_t s = blockIdx.x; s < n_slots; s += gridDim.x) {
     if (!(m.blk_flags[s] & BLK_LIVE) || regen[s]) continue;
@@ -293,7 +298,14 @@ __global__ __launch_bounds__(256) void k_reset_inactive(DevMap m, int4* __restri
 }
 
 // rebuild the hash table from live slots after removals (single pass; keys were reset to empty)
+__global__ __launch_bounds__(256) void k_rehash_clear(DevMap m) {
+  if (m.counters[C_N_REMOVED] == 0u) return;  // nothing was removed: keep the table
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= m.ht_mask) m.ht_keys[i] = kEmptyKey;
+}
+
 __global__ __launch_bounds__(256) void k_rehash(DevMap m) {
+  if (m.counters[C_N_REMOVED] == 0u) return;
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= m.counters[C_MAX_SLOT]) return;
   if (!(m.blk_flags[s] & BLK_LIVE)) return;
@@ -303,6 +315,7 @@ __global__ __launch_bounds__(256) void k_rehash(DevMap m) {
 
 // rebuild the free list: ordered compaction of non-live slots (single workgroup, ballot prefix sums)
 __global__ __launch_bounds__(1024) void k_rebuild_free_list(DevMap m) {
+  if (m.counters[C_N_REMOVED] == 0u) return;
   __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_base;
   if (threadIdx.x == 0) s_base = 0;

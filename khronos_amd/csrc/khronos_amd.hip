@@ -91,6 +91,10 @@ struct khr_ctx {
   uint32_t* d_band_count = nullptr;
   unsigned long long* d_dbg = nullptr;
   uint32_t* d_wg_stats = nullptr;
+  uint32_t* h_pinned = nullptr;  // [0] seed pixels of the last motion pass, [1] removed count
+  hipEvent_t ev_seed = nullptr;
+  uint32_t last_removed = 0;
+  bool removed_pending = false;
   int4* d_removed = nullptr;
   int* d_idx_staging = nullptr;
   // motion detection scratch
@@ -107,6 +111,7 @@ struct khr_ctx {
   uint8_t* d_regen = nullptr;
   uint32_t* d_mesh_nwork = nullptr;
   uint64_t mesh_total = 0;
+  bool mesh_stale = false;
   // host mirrors
   std::vector<uint32_t> h_counters;
   khr_stats stats{};
@@ -349,6 +354,11 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     return fail(KHR_EDEVICE, "hipStreamCreate failed");
   }
   c->own_stream = true;
+  if (hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), 64, hipHostMallocDefault) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_seed, hipEventDisableTiming) != hipSuccess) {
+    delete c;
+    return fail(KHR_EDEVICE, "pinned scratch / event creation failed");
+  }
 
   DevParams& p = c->p;
   p.vs = cfg->voxel_size;
@@ -495,6 +505,8 @@ void khr_destroy(khr_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   resolveTimers(c);
   for (void* p : c->allocs) hipFree(p);
+  if (c->h_pinned) hipHostFree(c->h_pinned);
+  if (c->ev_seed) hipEventDestroy(c->ev_seed);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -600,16 +612,11 @@ int khr_download_frame(khr_ctx* c, int slot, float* range, float* vertex_map, in
   return KHR_OK;
 }
 
-int khr_integrate(khr_ctx* c, int slot, int allocate_blocks, int use_mask, int object_id) {
-  if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
-  HIP_TRY(hipSetDevice(c->device));
-  FrameSlot& s = c->slots[slot];
-  const DevFrame f = makeDevFrame(c, s);
+// block allocation + culling of one integrate call (independent of the dynamic mask)
+static int integrateAlloc(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allocate_blocks) {
   DevMap& m = c->m;
   // reset per-call counters
   hipLaunchKernelGGL(k_begin_integrate, dim3(1), dim3(64), 0, c->stream, m, c->p.nvox, c->d_band_count);
-  const uint32_t* tsdf_work = c->d_work;
-  const uint32_t* tsdf_count = &m.counters[C_N_VISIBLE];
   if (allocate_blocks) {
     ScopedTimer tm(c, 3);
     const DevFrustum fr = makeFrustum(c, f);
@@ -620,12 +627,21 @@ int khr_integrate(khr_ctx* c, int slot, int allocate_blocks, int use_mask, int o
     hipLaunchKernelGGL(k_cull_blocks, dim3(1024), dim3(256), 0, c->stream, m, c->p, f, c->d_work, c->d_work_tsdf,
                        c->cfg.disable_culling ? nullptr : s.tile_max, s.tw, s.th);
     c->host_index_valid = false;
-    tsdf_work = c->d_work_tsdf;
-    tsdf_count = &m.counters[C_N_TSDF];
   } else {
     hipLaunchKernelGGL(k_list_live, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_work,
                        &m.counters[C_N_VISIBLE], 0u);
   }
+  HIP_TRY(hipGetLastError());
+  return KHR_OK;
+}
+
+// TSDF + band update kernels of one integrate call
+static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allocate_blocks, int use_mask,
+                           int object_id) {
+  DevMap& m = c->m;
+  (void)s;
+  const uint32_t* tsdf_work = allocate_blocks ? c->d_work_tsdf : c->d_work;
+  const uint32_t* tsdf_count = allocate_blocks ? &m.counters[C_N_TSDF] : &m.counters[C_N_VISIBLE];
   int rc = dispatchVps(c, [&](auto vps) {
     constexpr int V = decltype(vps)::value;
     {
@@ -675,6 +691,16 @@ int khr_integrate(khr_ctx* c, int slot, int allocate_blocks, int use_mask, int o
   return KHR_OK;
 }
 
+int khr_integrate(khr_ctx* c, int slot, int allocate_blocks, int use_mask, int object_id) {
+  if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
+  HIP_TRY(hipSetDevice(c->device));
+  FrameSlot& s = c->slots[slot];
+  const DevFrame f = makeDevFrame(c, s);
+  int rc = integrateAlloc(c, s, f, allocate_blocks);
+  if (rc) return rc;
+  return integrateUpdate(c, s, f, allocate_blocks, use_mask, object_id);
+}
+
 int khr_update_tracking(khr_ctx* c, uint64_t stamp) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
   if (!c->cfg.with_tracking) return KHR_OK;
@@ -701,14 +727,14 @@ int khr_update_tracking(khr_ctx* c, uint64_t stamp) {
 // ---------------------------------------------------------------------------------------------
 // motion detection: device pixel pass + sort / run-length encode, host graph walk, device paint
 // ---------------------------------------------------------------------------------------------
-int khr_detect_motion(khr_ctx* c, int slot) {
-  if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
-  HIP_TRY(hipSetDevice(c->device));
-  FrameSlot& s = c->slots[slot];
+// motion detection, part 1: per-pixel pass; the seed-pixel count travels to pinned host memory
+// asynchronously so that other kernels can be queued behind it before the host has to look at it
+static int motionLaunch(khr_ctx* c, FrameSlot& s) {
   const size_t n = static_cast<size_t>(s.sensor.width) * s.sensor.height;
   HIP_TRY(hipMemsetAsync(s.dyn, 0, n * sizeof(int32_t), c->stream));
   c->stats.n_seeds = 0;
-  if (!c->cfg.with_tracking) return 0;
+  c->h_pinned[0] = 0;
+  if (!c->cfg.with_tracking) return KHR_OK;
   DevMap& m = c->m;
   const DevFrame f = makeDevFrame(c, s);
   // free_space_motion_detector.cpp:80
@@ -719,10 +745,21 @@ int khr_detect_motion(khr_ctx* c, int slot) {
     hipLaunchKernelGGL(k_motion_pixels, dim3(gridFor(n)), dim3(256), 0, c->stream, m, c->p, f, c->cfg.md_max_range,
                        min_z_world, c->d_keys, c->d_pix);
   }
-  uint32_t n_seed_px = 0;
-  HIP_TRY(hipMemcpyAsync(&n_seed_px, &m.counters[C_N_SEEDS], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  if (n_seed_px == 0) return 0;  // no seeds => no clusters (clusterDynamicVoxels loops over seeds only)
+  HIP_TRY(hipMemcpyAsync(&c->h_pinned[0], &m.counters[C_N_SEEDS], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipEventRecord(c->ev_seed, c->stream));
+  return KHR_OK;
+}
+
+// motion detection, part 2: wait for the seed count; without seeds there are no clusters
+// (clusterDynamicVoxels loops over seeds only); otherwise sort / run-length encode the pixel keys,
+// walk the seed graph on the host and paint the dynamic image.  Returns the number of clusters.
+static int motionFinish(khr_ctx* c, FrameSlot& s) {
+  if (!c->cfg.with_tracking) return 0;
+  const size_t n = static_cast<size_t>(s.sensor.width) * s.sensor.height;
+  DevMap& m = c->m;
+  (void)m;
+  HIP_TRY(hipEventSynchronize(c->ev_seed));
+  if (c->h_pinned[0] == 0) return 0;
 
   size_t tb = c->cub_temp_bytes;
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->d_cub_temp, tb, c->d_keys, c->d_keys_sorted, c->d_pix, c->d_pix_sorted,
@@ -892,6 +929,15 @@ int khr_detect_motion(khr_ctx* c, int slot) {
   return n_out;
 }
 
+int khr_detect_motion(khr_ctx* c, int slot) {
+  if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
+  HIP_TRY(hipSetDevice(c->device));
+  FrameSlot& s = c->slots[slot];
+  int rc = motionLaunch(c, s);
+  if (rc) return rc;
+  return motionFinish(c, s);
+}
+
 int khr_generate_mesh(khr_ctx* c, int only_mesh_updated, int clear_flag) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
   HIP_TRY(hipSetDevice(c->device));
@@ -906,40 +952,29 @@ int khr_generate_mesh(khr_ctx* c, int only_mesh_updated, int clear_flag) {
   hipLaunchKernelGGL(k_mesh_carry_counts, dim3(gridFor(cap)), dim3(256), 0, c->stream, m, c->d_mesh_count);
   hipLaunchKernelGGL(k_mark_regen, dim3(gridFor(cap)), dim3(256), 0, c->stream, c->d_work, c->d_mesh_nwork, c->d_regen);
   MeshBuffers src = c->mesh[c->mesh_cur], dst = c->mesh[c->mesh_cur ^ 1];
+  const uint32_t maxv = static_cast<uint32_t>(std::min<uint64_t>(c->cfg.max_mesh_vertices, 0xfffffff0ull));
   int rc = dispatchVps(c, [&](auto vps) {
     constexpr int V = decltype(vps)::value;
     hipLaunchKernelGGL((k_marching_cubes<V, false>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, c->d_work,
-                       c->d_mesh_nwork, c->d_mesh_count, c->d_mesh_offset, dst, clear_flag);
+                       c->d_mesh_nwork, c->d_mesh_count, c->d_mesh_offset, dst, clear_flag, maxv);
     size_t tb = c->cub_temp_bytes;
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->d_cub_temp, tb, c->d_mesh_count, c->d_mesh_offset,
                                              static_cast<int>(cap + 1), c->stream));
-    // capacity check before writing
-    uint32_t total = 0, nwork = 0;
-    HIP_TRY(hipMemcpyAsync(&total, c->d_mesh_offset + cap, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(&nwork, c->d_mesh_nwork, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (total > c->cfg.max_mesh_vertices)
-      return fail(KHR_ENOMEM, "mesh needs %u vertices, max_mesh_vertices=%llu", total,
-                  static_cast<unsigned long long>(c->cfg.max_mesh_vertices));
-    hipLaunchKernelGGL(k_mesh_move, dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->d_regen, c->d_mesh_offset, src, dst);
+    // no host round trip: the capacity check happens on the device (C_MESH_OVERFLOW), totals are read lazily
+    hipLaunchKernelGGL(k_mesh_move, dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->d_regen, c->d_mesh_offset, src, dst, maxv);
     hipLaunchKernelGGL((k_marching_cubes<V, true>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, c->d_work,
-                       c->d_mesh_nwork, c->d_mesh_count, c->d_mesh_offset, dst, clear_flag);
-    c->mesh_total = total;
-    c->stats.n_mesh_blocks = nwork;
-    c->stats.n_mesh_vertices = total;
+                       c->d_mesh_nwork, c->d_mesh_count, c->d_mesh_offset, dst, clear_flag, maxv);
     return KHR_OK;
   });
   if (rc) return rc;
   c->mesh_cur ^= 1;
+  c->mesh_stale = true;
   HIP_TRY(hipGetLastError());
   return KHR_OK;
 }
 
-int khr_reset_inactive(khr_ctx* c, int32_t* removed, int64_t cap, int64_t* n_removed) {
-  if (!c) return fail(KHR_EINVAL, "null ctx");
-  if (n_removed) *n_removed = 0;
-  if (!c->cfg.with_tracking) return KHR_OK;
-  HIP_TRY(hipSetDevice(c->device));
+// archival kernels; no host round trip: the hash table / free list rebuild is conditional on the device
+static int resetInactiveLaunch(khr_ctx* c) {
   DevMap& m = c->m;
   HIP_TRY(hipMemsetAsync(&m.counters[C_N_REMOVED], 0, sizeof(uint32_t), c->stream));
   int rc = dispatchVps(c, [&](auto vps) {
@@ -947,20 +982,24 @@ int khr_reset_inactive(khr_ctx* c, int32_t* removed, int64_t cap, int64_t* n_rem
     return KHR_OK;
   });
   if (rc) return rc;
-  uint32_t n = 0;
-  HIP_TRY(hipMemcpyAsync(&n, &m.counters[C_N_REMOVED], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  if (n_removed) *n_removed = n;
-  if (n == 0) return KHR_OK;
-  // rebuild hash table + free list from the surviving blocks
-  HIP_TRY(hipMemsetAsync(m.ht_keys, 0xff, sizeof(uint64_t) * (static_cast<size_t>(m.ht_mask) + 1), c->stream));
+  hipLaunchKernelGGL(k_rehash_clear, dim3(gridFor(static_cast<size_t>(m.ht_mask) + 1)), dim3(256), 0, c->stream, m);
   hipLaunchKernelGGL(k_rehash, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m);
   hipLaunchKernelGGL(k_rebuild_free_list, dim3(1), dim3(1024), 0, c->stream, m);
   c->host_index_valid = false;
-  if (removed && cap > 0) {
+  c->removed_pending = true;
+  HIP_TRY(hipGetLastError());
+  return KHR_OK;
+}
+
+static int fetchRemoved(khr_ctx* c, int32_t* removed, int64_t cap, int64_t* n_removed) {
+  uint32_t n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, &c->m.counters[C_N_REMOVED], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->removed_pending = false;
+  if (n_removed) *n_removed = n;
+  if (n && removed && cap > 0) {
     std::vector<int4> tmp(n);
-    HIP_TRY(hipMemcpyAsync(tmp.data(), c->d_removed, sizeof(int4) * n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(tmp.data(), c->d_removed, sizeof(int4) * n, hipMemcpyDeviceToHost));
     std::sort(tmp.begin(), tmp.end(), [](const int4& a, const int4& b) {
       return a.x != b.x ? a.x < b.x : (a.y != b.y ? a.y < b.y : a.z < b.z);
     });
@@ -970,8 +1009,55 @@ int khr_reset_inactive(khr_ctx* c, int32_t* removed, int64_t cap, int64_t* n_rem
       removed[3 * i + 2] = tmp[i].z;
     }
   }
-  HIP_TRY(hipGetLastError());
   return KHR_OK;
+}
+
+int khr_reset_inactive(khr_ctx* c, int32_t* removed, int64_t cap, int64_t* n_removed) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  if (n_removed) *n_removed = 0;
+  if (!c->cfg.with_tracking) return KHR_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = resetInactiveLaunch(c);
+  if (rc) return rc;
+  if (!removed && !n_removed) return KHR_OK;  // asynchronous form; fetch later with khr_last_removed
+  return fetchRemoved(c, removed, cap, n_removed);
+}
+
+int khr_last_removed(khr_ctx* c, int32_t* removed, int64_t cap, int64_t* n_removed) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  return fetchRemoved(c, removed, cap, n_removed);
+}
+
+int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame, int on_device, uint32_t flags,
+                      int* n_clusters) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  if (n_clusters) *n_clusters = 0;
+  const int slot = khr_upload_frame(c, sensor, frame, on_device);
+  if (slot < 0) return slot;
+  FrameSlot& s = c->slots[slot];
+  const DevFrame f = makeDevFrame(c, s);
+  const bool motion = (flags & KHR_PF_MOTION) != 0;
+  int rc = KHR_OK;
+  // (1) per-pixel motion pass; its seed count comes back asynchronously ...
+  if (motion && (rc = motionLaunch(c, s))) return rc;
+  // (2) ... while block allocation / culling, which do not depend on the dynamic mask, keep the GPU busy
+  if ((rc = integrateAlloc(c, s, f, 1))) return rc;
+  // (3) host looks at the seed count (clusters only exist when there are seeds)
+  if (motion) {
+    const int nc = motionFinish(c, s);
+    if (nc < 0) return nc;
+    if (n_clusters) *n_clusters = nc;
+  }
+  // (4) TSDF / label update with the dynamic mask, tracking + ever-free
+  if ((rc = integrateUpdate(c, s, f, 1, motion ? 1 : 0, -1))) return rc;
+  if ((flags & KHR_PF_TRACKING) && (rc = khr_update_tracking(c, frame->timestamp_ns))) return rc;
+  // (5) output cadence (ActiveWindow::extractOutputData, active_window.cpp:217-249 + :169-171)
+  if (flags & KHR_PF_OUTPUT) {
+    if ((rc = khr_generate_mesh(c, 1, 1))) return rc;
+    if (c->cfg.with_tracking && (rc = resetInactiveLaunch(c))) return rc;
+    if ((rc = khr_clear_updated(c))) return rc;
+  }
+  return slot;
 }
 
 int khr_mark_all_inactive(khr_ctx* c) {
@@ -1032,6 +1118,8 @@ int khr_object_prune(khr_ctx* c, float min_confidence, float min_observations, i
   return KHR_OK;
 }
 
+static int refreshMeshTotals(khr_ctx* c);
+
 int khr_get_stats(khr_ctx* c, khr_stats* out) {
   if (!c || !out) return fail(KHR_EINVAL, "null argument");
   int rc = readCounters(c);
@@ -1040,6 +1128,8 @@ int khr_get_stats(khr_ctx* c, khr_stats* out) {
   HIP_TRY(hipMemcpy(st, c->m.stats, sizeof(st), hipMemcpyDeviceToHost));
   // live-block count
   rc = ensureHostIndex(c);
+  if (rc) return rc;
+  rc = refreshMeshTotals(c);
   if (rc) return rc;
   khr_stats s = c->stats;
   s.n_allocated_blocks = c->host_index.size();
@@ -1131,15 +1221,35 @@ int khr_download_block(khr_ctx* c, int32_t bx, int32_t by, int32_t bz, float* di
   return KHR_OK;
 }
 
+static int refreshMeshTotals(khr_ctx* c) {
+  if (!c->mesh_stale) return KHR_OK;
+  uint32_t total = 0, nwork = 0, ovf = 0;
+  HIP_TRY(hipMemcpyAsync(&total, c->d_mesh_offset + c->m.capacity, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(&nwork, c->d_mesh_nwork, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(&ovf, &c->m.counters[C_MESH_OVERFLOW], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (ovf) return fail(KHR_ENOMEM, "mesh needs %u vertices, max_mesh_vertices=%llu", total,
+                       static_cast<unsigned long long>(c->cfg.max_mesh_vertices));
+  c->mesh_total = total;
+  c->stats.n_mesh_blocks = nwork;
+  c->stats.n_mesh_vertices = total;
+  c->mesh_stale = false;
+  return KHR_OK;
+}
+
 int64_t khr_mesh_num_vertices(khr_ctx* c) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
+  int rc = refreshMeshTotals(c);
+  if (rc) return rc;
   return static_cast<int64_t>(c->mesh_total);
 }
 
 int64_t khr_download_mesh(khr_ctx* c, float* points, uint8_t* colors_rgba, uint32_t* labels, uint64_t* first_seen,
                           uint64_t* stamps, int64_t cap) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
-  int rc = ensureHostIndex(c);
+  int rc = refreshMeshTotals(c);
+  if (rc) return rc;
+  rc = ensureHostIndex(c);
   if (rc) return rc;
   const uint32_t nslots = static_cast<uint32_t>(c->host_flags.size());
   std::vector<MeshDesc> desc(nslots);

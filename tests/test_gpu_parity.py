@@ -147,3 +147,32 @@ def test_culling_is_exact():
         g, h = ctx.download_block(b), ctx2.download_block(b)
         for k in ("distance", "weight", "color", "last_observed", "flags", "sem_label", "likelihoods"):
             assert np.array_equal(g[k], h[k]), (k, b)
+
+
+def test_fused_process_frame_equals_stepwise():
+    """khr_process_frame (one call per frame, asynchronous output stage) == the step-by-step calls."""
+    cfg, ctx, ora, s, sen, osen = make_pair(width=320, height=240, temporal_window=0.75)
+    fired = 0
+    for i in range(20):
+        fr = s.render(i)
+        out_now = i % 4 == 3
+        f = ctx.make_frame(fr["stamp"], fr["pose"], 0)
+        depth = np.ascontiguousarray(fr["depth"]); rgb = np.ascontiguousarray(fr["rgb"]); lab = np.ascontiguousarray(fr["label"])
+        f.depth, f.color, f.label = depth.ctypes.data, rgb.ctypes.data, lab.ctypes.data
+        flags = ctx.PF_MOTION | ctx.PF_TRACKING | (ctx.PF_OUTPUT if out_now else 0)
+        slot, nc = ctx.process_frame(sen, f, on_device=False, flags=flags)
+        n_o, dyn_o, _ = ora.detect_motion(osen, fr["stamp"], fr["pose"], fr["depth"])
+        assert nc == n_o
+        fired += nc
+        ora.integrate(osen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"], mask=dyn_o)
+        ora.update_tracking(fr["stamp"])
+        if out_now:
+            ora.generate_mesh(True, True)
+            ro = ora.reset_inactive()
+            ora.clear_updated()
+            assert np.array_equal(ctx.last_removed(), ro)
+            gm, om = ctx.download_mesh(), ora.mesh()
+            assert gm["points"].shape == om["points"].shape
+            assert np.abs(gm["points"] - om["points"]).max() <= TOL if len(om["points"]) else True
+    assert fired > 0
+    compare_maps(ctx, ora, max_blocks=100)

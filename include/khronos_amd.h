@@ -157,6 +157,10 @@ int khr_download_frame(khr_ctx* ctx, int slot, float* range, float* vertex_map, 
  * use_mask: non-zero => pixels with dynamic_image != 0 are not integrated (in-band).
  * object_id >= 0 => binary object label from object_image (object_integrator.cpp:58-81). */
 int khr_integrate(khr_ctx* ctx, int slot, int allocate_blocks, int use_mask, int object_id);
+/* same, reading the frame from a slot of ANOTHER context on the same device: the object mini-maps of
+ * MeshObjectExtractor re-integrate the frames buffered by the active window (mesh_object_extractor.cpp:239-243,
+ * FrameDataBuffer role) without copying them. */
+int khr_integrate_shared(khr_ctx* ctx, khr_ctx* src, int src_slot, int allocate_blocks, int use_mask, int object_id);
 /* replaces: TrackingIntegrator::updateBlocks (tracking_integrator.cpp:71-104) */
 int khr_update_tracking(khr_ctx* ctx, uint64_t timestamp_ns);
 /* replaces: FreeSpaceMotionDetector::processInput (free_space_motion_detector.cpp:73-103).

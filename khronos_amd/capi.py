@@ -59,7 +59,7 @@ EXPORTS = [
     "khr_detect_motion", "khr_generate_mesh", "khr_reset_inactive", "khr_mark_all_inactive", "khr_clear_updated",
     "khr_allocate_blocks", "khr_object_prune", "khr_get_stats", "khr_num_blocks", "khr_block_indices",
     "khr_download_block", "khr_mesh_num_vertices", "khr_download_mesh", "khr_timing_enable", "khr_timing_reset",
-    "khr_timing_get", "khr_debug_read", "khr_last_removed", "khr_process_frame",
+    "khr_timing_get", "khr_debug_read", "khr_last_removed", "khr_process_frame", "khr_integrate_shared",
 ]
 
 _lib = None
@@ -93,6 +93,7 @@ def load_library():
     lib.khr_set_frame_image.argtypes = [vp, i32, i32, vp, i32]
     lib.khr_download_frame.argtypes = [vp, i32, vp, vp, vp]
     lib.khr_integrate.argtypes = [vp, i32, i32, i32, i32]
+    lib.khr_integrate_shared.argtypes = [vp, vp, i32, i32, i32, i32]
     lib.khr_update_tracking.argtypes = [vp, u64]
     lib.khr_detect_motion.argtypes = [vp, i32]
     lib.khr_generate_mesh.argtypes = [vp, i32, i32]

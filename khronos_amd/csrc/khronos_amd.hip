@@ -701,6 +701,19 @@ int khr_integrate(khr_ctx* c, int slot, int allocate_blocks, int use_mask, int o
   return integrateUpdate(c, s, f, allocate_blocks, use_mask, object_id);
 }
 
+int khr_integrate_shared(khr_ctx* c, khr_ctx* src, int src_slot, int allocate_blocks, int use_mask, int object_id) {
+  if (!c || !src || src_slot < 0 || src_slot >= static_cast<int>(src->slots.size()) || !src->slots[src_slot].valid)
+    return fail(KHR_EINVAL, "bad source slot");
+  if (c->device != src->device) return fail(KHR_EINVAL, "contexts live on different devices");
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->stream != src->stream) HIP_TRY(hipStreamSynchronize(src->stream));  // the frame must be complete
+  FrameSlot& s = src->slots[src_slot];
+  const DevFrame f = makeDevFrame(src, s);
+  int rc = integrateAlloc(c, s, f, allocate_blocks);
+  if (rc) return rc;
+  return integrateUpdate(c, s, f, allocate_blocks, use_mask, object_id);
+}
+
 int khr_update_tracking(khr_ctx* c, uint64_t stamp) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
   if (!c->cfg.with_tracking) return KHR_OK;

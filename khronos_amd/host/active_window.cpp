@@ -1,0 +1,563 @@
+// active_window.cpp — host orchestration of the fusion path, mirroring khronos::ActiveWindow
+// (khronos/src/active_window/active_window.cpp:73-286) on top of the C ABI.  See active_window.h.
+#include "active_window.h"
+
+#include <algorithm>
+#include <cmath>
+#include <sstream>
+#include <stdexcept>
+
+namespace khronos {
+
+namespace {
+
+void chk(int rc, const char* what) {
+  if (rc < 0) throw std::runtime_error(std::string(what) + " failed: " + khr_last_error());
+}
+
+int interpolationFromName(const std::string& n) {
+  if (n == "nearest") return 0;
+  if (n == "bilinear") return 1;
+  if (n == "adaptive") return 2;
+  throw std::invalid_argument("interpolation_method must be one of {nearest, bilinear, adaptive}");
+}
+
+}  // namespace
+
+// ---- FrameData ------------------------------------------------------------------------------------------
+std::vector<int32_t> FrameData::dynamicImage() const {
+  std::vector<int32_t> d(static_cast<size_t>(input.sensor.width) * input.sensor.height);
+  chk(khr_download_frame(input.ctx, input.slot, nullptr, nullptr, d.data()), "khr_download_frame");
+  return d;
+}
+
+// ---- FrameDataBuffer (frame_data_buffer.cpp:57-123) ------------------------------------------------------
+FrameDataBuffer::FrameDataBuffer(const Config& cfg) : config(cfg) {
+  if (config.max_buffer_size == 0) throw std::invalid_argument("max_buffer_size must be > 0");  // :52
+}
+
+void FrameDataBuffer::trimBuffer(const Tracks& tracks) {
+  // drop every buffered frame that no track observation refers to any more (:57-86)
+  auto referenced = [&tracks](TimeStamp stamp) {
+    for (const Track& t : tracks)
+      for (const Observation& o : t.observations)
+        if (o.stamp == stamp) return true;
+    return false;
+  };
+  for (auto it = buffer_.begin(); it != buffer_.end();) it = referenced((*it)->input.timestamp_ns) ? it + 1 : buffer_.erase(it);
+  if (!buffer_.empty()) oldest_time_stamp_ = buffer_.front()->input.timestamp_ns;
+}
+
+void FrameDataBuffer::storeData(const FrameData::Ptr& data) {
+  // every n-th frame is appended, the others overwrite the newest entry (:88-109)
+  const bool append = input_counter_ == 0;
+  input_counter_ = (input_counter_ + 1) % std::max(1, config.store_every_n_frames);
+  if (!append) {
+    if (!buffer_.empty()) buffer_.pop_back();
+    buffer_.push_back(data);
+    return;
+  }
+  buffer_.push_back(data);
+  if (buffer_.size() > config.max_buffer_size) {
+    buffer_.pop_front();
+    oldest_time_stamp_ = buffer_.front()->input.timestamp_ns;
+  }
+}
+
+FrameData::Ptr FrameDataBuffer::getData(TimeStamp stamp) const {
+  if (stamp < oldest_time_stamp_) return nullptr;  // :111-123
+  for (const auto& f : buffer_)
+    if (f->input.timestamp_ns == stamp) return f;
+  return nullptr;
+}
+
+// ---- FreeSpaceMotionDetector ---------------------------------------------------------------------------------
+FreeSpaceMotionDetector::FreeSpaceMotionDetector(const Config& cfg) : config(cfg) {
+  // checks of free_space_motion_detector.cpp:63-67
+  if (config.num_threads == 0) throw std::invalid_argument("num_threads must be > 0 (or -1)");
+  if (config.neighbor_connectivity != 6 && config.neighbor_connectivity != 18 && config.neighbor_connectivity != 26)
+    throw std::invalid_argument("neighbor_connectivity must be one of {6, 18, 26}");
+  if (config.max_cluster_size < config.min_cluster_size)
+    throw std::invalid_argument("param 'max_cluster_size' must be >= 'min_cluster_size'");
+  if (!(config.max_range > 0.f)) throw std::invalid_argument("max_range must be > 0");
+}
+
+void FreeSpaceMotionDetector::processInput(const VolumetricMap& map, FrameData& data) {
+  // free_space_motion_detector.cpp:73-103; the parameters were handed to the device context at creation
+  const int n = khr_detect_motion(map.ctx(), data.input.slot);
+  chk(n, "khr_detect_motion");
+  data.num_dynamic_clusters = n;
+}
+
+// ---- MeshObjectExtractor ----------------------------------------------------------------------------------------
+MeshObjectExtractor::MeshObjectExtractor(const Config& cfg, const khr_config& aw_device_config)
+    : config(cfg), device_config_(aw_device_config) {
+  // checks of mesh_object_extractor.cpp:66-75
+  auto in01 = [](float v) { return v >= 0.f && v <= 1.f; };
+  if (!in01(config.min_object_allocation_confidence) || !in01(config.min_object_reconstruction_confidence))
+    throw std::invalid_argument("confidences must be in [0, 1]");
+  if (config.min_object_volume < 0 || config.max_object_volume < config.min_object_volume)
+    throw std::invalid_argument("object volume limits are inconsistent");
+  if (config.min_dynamic_displacement < 0 || config.min_reconstruction_resolution < 0)
+    throw std::invalid_argument("negative displacement / resolution");
+}
+
+float MeshObjectExtractor::objectVoxelSize(const Config& config, const BoundingBox& extent) {
+  // mesh_object_extractor.cpp:201-207
+  if (config.object_reconstruction_resolution < 0.f)
+    return std::max(extent.maxDimension() * -config.object_reconstruction_resolution, config.min_reconstruction_resolution);
+  return config.object_reconstruction_resolution;
+}
+
+void MeshObjectExtractor::objectBlockRange(const BoundingBox& extent, float block_size, int32_t* mn, int32_t* mx) {
+  // centre -/+ the full dimensions (mesh_object_extractor.cpp:220-221), block index = floor(p / block_size)
+  const float inv = 1.f / block_size;
+  for (int i = 0; i < 3; ++i) {
+    mn[i] = static_cast<int32_t>(std::floor((extent.center(i) - extent.dimension(i)) * inv));
+    mx[i] = static_cast<int32_t>(std::floor((extent.center(i) + extent.dimension(i)) * inv));
+  }
+}
+
+std::shared_ptr<KhronosObjectAttributes> MeshObjectExtractor::extractObject(const Track& track, const FrameDataBuffer& frames) {
+  // trackIsValid (mesh_object_extractor.cpp:358-...): confidence gate
+  if (track.confidence <= config.min_object_allocation_confidence) return nullptr;
+  if (track.is_dynamic) return nullptr;  // dynamic tracks are a host-only trajectory summary (:120-172), not built here
+  auto object = extractStaticObject(track, frames);
+  if (!object) return nullptr;
+  object->semantic_label = track.semantic_label;
+  object->first_observed_ns = {track.first_seen};
+  object->last_observed_ns = {track.last_seen};
+  for (int i = 0; i < 3; ++i) object->position[i] = object->bounding_box.center(i);
+  return object;
+}
+
+std::shared_ptr<KhronosObjectAttributes> MeshObjectExtractor::extractStaticObject(const Track& track,
+                                                                                 const FrameDataBuffer& buffer) const {
+  if (config.object_reconstruction_resolution == 0.f) return nullptr;
+  // collectSemanticFrames + computeExtent (mesh_object_extractor.cpp:306-340)
+  std::vector<std::pair<FrameData::Ptr, int>> frames;
+  BoundingBox extent;
+  for (const Observation& o : track.observations) {
+    if (o.semantic_cluster_id == -1) continue;
+    FrameData::Ptr f = buffer.getData(o.stamp);
+    if (!f) continue;
+    frames.emplace_back(f, o.semantic_cluster_id);
+    for (const auto& cl : f->semantic_clusters)
+      if (cl.id == o.semantic_cluster_id) {
+        extent.merge(cl.bounding_box);
+        break;
+      }
+  }
+  if (frames.empty()) return nullptr;
+  if (extent.volume() < config.min_object_volume) return nullptr;
+
+  // private map (mesh_object_extractor.cpp:201-215): vps 8, truncation 2 voxels, binary semantics, no tracking
+  khr_config oc = device_config_;
+  oc.voxel_size = objectVoxelSize(config, extent);
+  if (!(oc.voxel_size > 0.f)) return nullptr;  // config::isValid(map_config)
+  oc.voxels_per_side = 8;
+  oc.truncation_distance = oc.voxel_size * 2;
+  oc.with_semantics = 1;
+  oc.with_tracking = 0;
+  oc.num_labels = 2;
+  oc.semantic_mode = 1;
+  oc.num_frame_slots = 1;
+  oc.max_frame_pixels = 4;
+  oc.max_band_records = device_config_.max_band_records ? device_config_.max_band_records : 4u * device_config_.max_frame_pixels;
+  oc.rank = 0;
+  oc.world_size = 1;
+  int32_t mn[3], mx[3];
+  objectBlockRange(extent, oc.voxel_size * 8.f, mn, mx);
+  std::vector<int32_t> idx;
+  for (int x = mn[0]; x <= mx[0]; ++x)
+    for (int y = mn[1]; y <= mx[1]; ++y)
+      for (int z = mn[2]; z <= mx[2]; ++z) {
+        idx.push_back(x);
+        idx.push_back(y);
+        idx.push_back(z);
+      }
+  const size_t n_blocks = idx.size() / 3;
+  if (n_blocks > config.max_object_blocks) return nullptr;
+  oc.max_blocks = static_cast<uint32_t>(n_blocks + 1);
+  oc.max_mesh_vertices = std::max<uint64_t>(1u << 16, n_blocks * 512ull * 15ull / 4);
+  khr_ctx* octx = nullptr;
+  chk(khr_create(&oc, &octx), "khr_create(object map)");
+  std::shared_ptr<KhronosObjectAttributes> object;
+  try {
+    chk(khr_allocate_blocks(octx, idx.data(), static_cast<int64_t>(n_blocks)), "khr_allocate_blocks");  // :218-228
+    // projective re-integration of every buffered frame with the binary object label (:239-243)
+    for (const auto& fr : frames)
+      chk(khr_integrate_shared(octx, fr.first->input.ctx, fr.first->input.slot, /*allocate=*/0, /*use_mask=*/0, fr.second),
+          "khr_integrate_shared");
+    // erase low-confidence voxels (:246-264)
+    int64_t pruned = 0;
+    if (!config.visualize_classification)
+      chk(khr_object_prune(octx, config.min_object_reconstruction_confidence, config.min_object_reconstruction_observations, &pruned),
+          "khr_object_prune");
+    chk(khr_generate_mesh(octx, 1, 0), "khr_generate_mesh");  // :267
+    object = std::make_shared<KhronosObjectAttributes>();
+    const int64_t nv = khr_mesh_num_vertices(octx);
+    chk(static_cast<int>(nv < 0 ? nv : 0), "khr_mesh_num_vertices");
+    hydra::Mesh& mesh = object->mesh;
+    mesh.points.resize(3 * nv);
+    mesh.colors.resize(4 * nv);
+    mesh.labels.resize(nv);
+    mesh.first_seen_stamps.resize(nv);
+    mesh.stamps.resize(nv);
+    if (nv > 0)
+      chk(static_cast<int>(std::min<int64_t>(0, khr_download_mesh(octx, mesh.points.data(), mesh.colors.data(), mesh.labels.data(),
+                                                                    mesh.first_seen_stamps.data(), mesh.stamps.data(), nv))),
+          "khr_download_mesh");
+  } catch (...) {
+    khr_destroy(octx);
+    throw;
+  }
+  khr_destroy(octx);
+
+  if (object->mesh.numVertices() == 0 && config.only_extract_reconstructed_objects) return nullptr;  // :271-275
+  if (object->mesh.numVertices() == 0) {
+    object->bounding_box = extent;
+  } else {
+    BoundingBox bb;
+    for (size_t i = 0; i < object->mesh.numVertices(); ++i) bb.include(&object->mesh.points[3 * i]);
+    object->bounding_box = bb;
+  }
+  const float vol = object->bounding_box.volume();
+  if (vol > config.max_object_volume || vol < config.min_object_volume) return nullptr;  // :283-292
+  // move the mesh to the bounding-box frame (:299-302)
+  for (size_t i = 0; i < object->mesh.numVertices(); ++i)
+    for (int d = 0; d < 3; ++d) object->mesh.points[3 * i + d] -= object->bounding_box.center(d);
+  return object;
+}
+
+// ---- ActiveWindow::Config --------------------------------------------------------------------------------------
+ActiveWindow::Config ActiveWindow::Config::fromYaml(const khronos_amd::YamlNode& n) {
+  Config c;
+  n.read("verbosity", c.verbosity);
+  n.read("min_output_separation", c.min_output_separation);
+  n.read("detach_object_extraction", c.detach_object_extraction);
+  if (const auto* m = n.find("volumetric_map")) {
+    m->read("voxel_size", c.volumetric_map.voxel_size);
+    m->read("truncation_distance", c.volumetric_map.truncation_distance);
+    m->read("voxels_per_side", c.volumetric_map.voxels_per_side);
+    m->read("with_semantics", c.volumetric_map.with_semantics);
+    m->read("with_tracking", c.volumetric_map.with_tracking);
+  }
+  if (const auto* m = n.find("projective_integrator")) {
+    m->read("verbosity", c.projective_integrator.verbosity);
+    m->read("use_weight_dropoff", c.projective_integrator.use_weight_dropoff);
+    m->read("weight_dropoff_epsilon", c.projective_integrator.weight_dropoff_epsilon);
+    m->read("use_constant_weight", c.projective_integrator.use_constant_weight);
+    m->read("max_weight", c.projective_integrator.max_weight);
+    m->read("interpolation_method", c.projective_integrator.interpolation_method);
+    m->read("num_threads", c.projective_integrator.num_threads);
+    if (const auto* si = m->find("semantic_integrator")) si->read("label_confidence", c.projective_integrator.label_confidence);
+  }
+  if (const auto* m = n.find("tracking_integrator")) {
+    auto& t = c.tracking_integrator;
+    m->read("verbosity", t.verbosity);
+    m->read("temporal_buffer", t.temporal_buffer);
+    m->read("burn_in_period", t.burn_in_period);
+    m->read("tsdf_occupancy_threshold", t.tsdf_occupancy_threshold);
+    m->read("neighbor_connectivity", t.neighbor_connectivity);
+    m->read("temporal_window", t.temporal_window);
+    m->read("num_threads", t.num_threads);
+  }
+  if (const auto* m = n.find("motion_detector")) {
+    m->read("type", c.motion_detector_type);
+    auto& d = const_cast<FreeSpaceMotionDetector::Config&>(c.motion_detector);
+    m->read("verbosity", d.verbosity);
+    m->read("neighbor_connectivity", d.neighbor_connectivity);
+    m->read("min_cluster_size", d.min_cluster_size);
+    m->read("max_cluster_size", d.max_cluster_size);
+    m->read("min_separation_distance", d.min_separation_distance);
+    m->read("max_range", d.max_range);
+    m->read("min_z_coordinate", d.min_z_coordinate);
+    m->read("num_threads", d.num_threads);
+  }
+  if (const auto* m = n.find("object_detector")) m->read("type", c.object_detector_type);
+  if (const auto* m = n.find("tracker")) m->read("type", c.tracker_type);
+  if (const auto* m = n.find("object_extractor")) {
+    m->read("type", c.object_extractor_type);
+    auto& e = const_cast<MeshObjectExtractor::Config&>(c.object_extractor);
+    m->read("verbosity", e.verbosity);
+    m->read("min_object_allocation_confidence", e.min_object_allocation_confidence);
+    m->read("min_object_volume", e.min_object_volume);
+    m->read("max_object_volume", e.max_object_volume);
+    m->read("only_extract_reconstructed_objects", e.only_extract_reconstructed_objects);
+    m->read("min_dynamic_displacement", e.min_dynamic_displacement);
+    m->read("min_object_reconstruction_confidence", e.min_object_reconstruction_confidence);
+    m->read("min_object_reconstruction_observations", e.min_object_reconstruction_observations);
+    m->read("object_reconstruction_resolution", e.object_reconstruction_resolution);
+    m->read("min_reconstruction_resolution", e.min_reconstruction_resolution);
+    m->read("visualize_classification", e.visualize_classification);
+  }
+  if (const auto* m = n.find("extraction_worker")) {
+    m->read("num_workers", c.extraction_worker.num_workers);
+    m->read("poll_time_us", c.extraction_worker.poll_time_us);
+    m->read("verbosity", c.extraction_worker.verbosity);
+  }
+  if (const auto* m = n.find("mesh_integrator")) m->read("min_weight", c.mesh_integrator.min_weight);
+  if (const auto* m = n.find("frame_data_buffer")) {
+    auto& b = const_cast<FrameDataBuffer::Config&>(c.frame_data_buffer);
+    m->read("max_buffer_size", b.max_buffer_size);
+    m->read("store_every_n_frames", b.store_every_n_frames);
+  }
+  if (const auto* m = n.find("device")) {  // extension block (not in the reference): HBM sizing / placement
+    m->read("num_labels", c.num_labels);
+    int v = static_cast<int>(c.max_blocks);
+    m->read("max_blocks", v);
+    c.max_blocks = static_cast<uint32_t>(v);
+    v = static_cast<int>(c.max_frame_pixels);
+    m->read("max_frame_pixels", v);
+    c.max_frame_pixels = static_cast<uint32_t>(v);
+    m->read("device", c.device);
+    m->read("rank", c.rank);
+    m->read("world_size", c.world_size);
+  }
+  return c;
+}
+
+ActiveWindow::Config ActiveWindow::Config::fromYamlString(const std::string& text) {
+  const khronos_amd::YamlNode root = khronos_amd::parseYaml(text);
+  const khronos_amd::YamlNode* aw = root.find("active_window");
+  Config c = fromYaml(aw ? *aw : root);
+  if (aw) {
+    std::string type;
+    aw->read("type", type);
+    if (!type.empty() && type != "ActiveWindow") throw std::invalid_argument("active_window.type must be 'ActiveWindow'");
+  }
+  return c;
+}
+
+void ActiveWindow::Config::checkValid() const {
+  const auto& t = tracking_integrator;  // tracking_integrator.cpp:61-65
+  if (t.neighbor_connectivity != 6 && t.neighbor_connectivity != 18 && t.neighbor_connectivity != 26)
+    throw std::invalid_argument("tracking_integrator.neighbor_connectivity must be one of {6, 18, 26}");
+  if (t.num_threads == 0) throw std::invalid_argument("tracking_integrator.num_threads must be >= 1 (or -1)");
+  if (!(t.temporal_buffer > 0)) throw std::invalid_argument("tracking_integrator.temporal_buffer must be > 0");
+  if (t.tsdf_occupancy_threshold == 0) throw std::invalid_argument("tracking_integrator.tsdf_occupancy_threshold must be != 0");
+  if (!(t.temporal_window > 0)) throw std::invalid_argument("tracking_integrator.temporal_window must be > 0");
+  if (!(volumetric_map.voxel_size > 0) || !(volumetric_map.truncation_distance > 0))
+    throw std::invalid_argument("volumetric_map.voxel_size / truncation_distance must be > 0");
+  if (volumetric_map.voxels_per_side != 16 && volumetric_map.voxels_per_side != 8)
+    throw std::invalid_argument("volumetric_map.voxels_per_side must be 8 or 16 on this device backend");
+  if (!motion_detector_type.empty() && motion_detector_type != "FreeSpaceMotionDetector")
+    throw std::invalid_argument("unknown motion_detector type '" + motion_detector_type + "'");
+  if (!object_extractor_type.empty() && object_extractor_type != "MeshObjectExtractor")
+    throw std::invalid_argument("unknown object_extractor type '" + object_extractor_type + "'");
+  interpolationFromName(projective_integrator.interpolation_method);
+}
+
+// ---- ActiveWindow ------------------------------------------------------------------------------------------------
+ActiveWindow::ActiveWindow(const Config& cfg) : config(cfg), frame_data_buffer_(cfg.frame_data_buffer) {
+  config.checkValid();
+  khr_config& d = device_config_;
+  khr_default_config(&d);
+  d.voxel_size = config.volumetric_map.voxel_size;
+  d.voxels_per_side = config.volumetric_map.voxels_per_side;
+  d.truncation_distance = config.volumetric_map.truncation_distance;
+  d.with_semantics = config.volumetric_map.with_semantics;
+  d.with_tracking = config.volumetric_map.with_tracking;
+  d.num_labels = config.num_labels;
+  d.use_weight_dropoff = config.projective_integrator.use_weight_dropoff;
+  d.weight_dropoff_epsilon = config.projective_integrator.weight_dropoff_epsilon;
+  d.use_constant_weight = config.projective_integrator.use_constant_weight;
+  d.max_weight = config.projective_integrator.max_weight;
+  d.interpolation_method = interpolationFromName(config.projective_integrator.interpolation_method);
+  d.label_confidence = config.projective_integrator.label_confidence;
+  d.temporal_buffer = config.tracking_integrator.temporal_buffer;
+  d.tsdf_occupancy_threshold = config.tracking_integrator.tsdf_occupancy_threshold;
+  d.neighbor_connectivity = config.tracking_integrator.neighbor_connectivity;
+  d.temporal_window = config.tracking_integrator.temporal_window;
+  d.md_neighbor_connectivity = config.motion_detector.neighbor_connectivity;
+  d.md_min_cluster_size = config.motion_detector.min_cluster_size;
+  d.md_max_cluster_size = config.motion_detector.max_cluster_size;
+  d.md_min_separation_distance = config.motion_detector.min_separation_distance;
+  d.md_max_range = config.motion_detector.max_range;
+  d.md_min_z_coordinate = config.motion_detector.min_z_coordinate;
+  d.mesh_min_weight = config.mesh_integrator.min_weight;
+  d.max_blocks = config.max_blocks;
+  d.max_frame_pixels = config.max_frame_pixels;
+  d.max_mesh_vertices = config.max_mesh_vertices;
+  // with an object extractor the buffered frames stay resident in the device ring (FrameDataBuffer role)
+  d.num_frame_slots = config.object_extractor_type.empty() ? 2u : static_cast<uint32_t>(config.frame_data_buffer.max_buffer_size + 1);
+  d.device = config.device;
+  d.rank = config.rank;
+  d.world_size = config.world_size;
+  chk(khr_create(&d, &ctx_), "khr_create");
+  map_ = VolumetricMap(config.volumetric_map, ctx_);
+
+  // member processors as specified in the config; absent ones are the no-op bases (active_window.cpp:83-99)
+  if (config.motion_detector_type == "FreeSpaceMotionDetector")
+    motion_detector_ = std::make_unique<FreeSpaceMotionDetector>(config.motion_detector);
+  else
+    motion_detector_ = std::make_unique<MotionDetector>();
+  object_detector_ = std::make_unique<ObjectDetector>();
+  tracker_ = std::make_unique<Tracker>();
+  if (config.object_extractor_type == "MeshObjectExtractor")
+    object_extractor_ = std::make_unique<MeshObjectExtractor>(config.object_extractor, d);
+}
+
+ActiveWindow::~ActiveWindow() {
+  if (ctx_) khr_destroy(ctx_);
+}
+
+std::string ActiveWindow::printInfo() const {
+  std::ostringstream o;
+  o << "ActiveWindow::Config: voxel_size=" << config.volumetric_map.voxel_size
+    << " truncation_distance=" << config.volumetric_map.truncation_distance
+    << " voxels_per_side=" << config.volumetric_map.voxels_per_side << " with_semantics=" << config.volumetric_map.with_semantics
+    << " min_output_separation=" << config.min_output_separation << " motion_detector='" << config.motion_detector_type
+    << "' object_extractor='" << config.object_extractor_type << "' temporal_window=" << config.tracking_integrator.temporal_window
+    << " sinks=" << sinks_.size();
+  return o.str();
+}
+
+void ActiveWindow::addKhronosSink(const KhronosSink& sink) {
+  if (sink) sinks_.push_back(sink);
+}
+
+std::shared_ptr<FrameData> ActiveWindow::createData(const hydra::InputPacket& input) const {
+  // active_window.cpp:268-286: normalise the packet (device: range image, rgba, tiles) and allocate the
+  // dynamic / object images (zeroed in the frame slot)
+  auto data = std::make_shared<FrameData>();
+  InputData& in = data->input;
+  in.timestamp_ns = input.timestamp_ns;
+  std::memcpy(in.world_T_body, input.world_T_body, sizeof(in.world_T_body));
+  hydra::mul4(input.world_T_body, input.body_T_sensor, in.world_T_sensor);
+  in.sensor = input.sensor;
+  in.ctx = ctx_;
+  khr_sensor s{input.sensor.width, input.sensor.height, input.sensor.fx, input.sensor.fy, input.sensor.cx, input.sensor.cy,
+               input.sensor.min_range, input.sensor.max_range};
+  khr_frame f{};
+  f.timestamp_ns = input.timestamp_ns;
+  std::memcpy(f.world_T_sensor, in.world_T_sensor, sizeof(f.world_T_sensor));
+  f.depth = input.depth;
+  f.color = input.color;
+  f.label = input.labels;
+  in.slot = khr_upload_frame(ctx_, &s, &f, input.on_device ? 1 : 0);
+  if (in.slot < 0) return nullptr;  // "Input packet preprocessing failed. Skipping frame." (:276-279)
+  return data;
+}
+
+void ActiveWindow::updateMap(const FrameData& data) {
+  // active_window.cpp:203-215: mask = dynamic_image != 0, integrate with allocation, then tracking update
+  chk(khr_integrate(ctx_, data.input.slot, /*allocate=*/1, /*use_mask=*/1, /*object_id=*/-1), "khr_integrate");
+  chk(khr_update_tracking(ctx_, data.input.timestamp_ns), "khr_update_tracking");
+}
+
+hydra::ActiveWindowOutput::Ptr ActiveWindow::spinOnce(const hydra::InputPacket& input) {
+  std::lock_guard<std::mutex> lock(mutex_);
+  latest_stamp_ = input.timestamp_ns;
+  // Reference order (active_window.cpp:124-137): data -> motion -> objects -> tracker -> updateMap.  The object
+  // detector and tracker are host plugins that neither read nor write what the integration reads, so the
+  // device work (normalise, motion detection, integration, tracking) is queued first and they run while the
+  // GPU is busy.
+  std::shared_ptr<FrameData> data;
+  const bool plain_motion = !motion_detector_->isDeviceBacked() && config.motion_detector_type.empty();
+  if (motion_detector_->isDeviceBacked() || plain_motion) {
+    // fused device step (khr_process_frame): the motion detector's host round trip hides behind allocation
+    data = std::make_shared<FrameData>();
+    InputData& in = data->input;
+    in.timestamp_ns = input.timestamp_ns;
+    std::memcpy(in.world_T_body, input.world_T_body, sizeof(in.world_T_body));
+    hydra::mul4(input.world_T_body, input.body_T_sensor, in.world_T_sensor);
+    in.sensor = input.sensor;
+    in.ctx = ctx_;
+    khr_sensor s{input.sensor.width, input.sensor.height, input.sensor.fx, input.sensor.fy, input.sensor.cx, input.sensor.cy,
+                 input.sensor.min_range, input.sensor.max_range};
+    khr_frame f{};
+    f.timestamp_ns = input.timestamp_ns;
+    std::memcpy(f.world_T_sensor, in.world_T_sensor, sizeof(f.world_T_sensor));
+    f.depth = input.depth;
+    f.color = input.color;
+    f.label = input.labels;
+    const uint32_t flags = KHR_PF_TRACKING | (motion_detector_->isDeviceBacked() ? KHR_PF_MOTION : 0u);
+    int n_clusters = 0;
+    in.slot = khr_process_frame(ctx_, &s, &f, input.on_device ? 1 : 0, flags, &n_clusters);
+    if (in.slot < 0) return nullptr;  // "Input packet preprocessing failed. Skipping frame." (:276-279)
+    data->num_dynamic_clusters = n_clusters;
+  } else {
+    data = createData(input);
+    if (!data) return nullptr;  // the reference dereferences unconditionally here (latent crash)
+    motion_detector_->processInput(map_, *data);
+    updateMap(*data);
+  }
+  object_detector_->processInput(map_, *data);
+  tracker_->processInput(*data);
+
+  frame_data_buffer_.trimBuffer(tracker_->getTracks());
+  frame_data_buffer_.storeData(data);
+  ++num_frames_processed_;
+  for (const auto& sink : sinks_) sink(*data, map_, tracker_->getTracks());
+
+  if (last_full_upated_ + fromSeconds(config.min_output_separation) > latest_stamp_) return nullptr;  // :158-160
+  auto output = extractOutputData(*data, config.detach_object_extraction);
+  output->sensor_data = std::make_shared<InputData>(data->input);
+  last_full_upated_ = latest_stamp_;
+  chk(khr_clear_updated(ctx_), "khr_clear_updated");  // :169-171
+  return output;
+}
+
+hydra::ActiveWindowOutput::Ptr ActiveWindow::extractOutputData(const FrameData& data, bool /*threaded*/) {
+  // active_window.cpp:217-249
+  chk(khr_generate_mesh(ctx_, 1, 1), "khr_generate_mesh");
+  auto output = std::make_shared<hydra::ActiveWindowOutput>();
+  output->timestamp_ns = data.input.timestamp_ns;
+  for (int r = 0; r < 3; ++r) {
+    output->world_t_body[r] = data.input.world_T_body[4 * r + 3];
+    for (int c = 0; c < 3; ++c) output->world_R_body[3 * r + c] = data.input.world_T_body[4 * r + c];
+  }
+  output->map_ctx = ctx_;
+  output->updated_blocks = map_.allocatedBlockIndices(/*only_updated=*/true);  // cloneUpdated role
+  // archive after cloning / meshing (:231-237)
+  if (config.volumetric_map.with_tracking) {
+    std::vector<int32_t> removed(3 * static_cast<size_t>(config.max_blocks));
+    int64_t n = 0;
+    chk(khr_reset_inactive(ctx_, removed.data(), config.max_blocks, &n), "khr_reset_inactive");
+    output->archived_mesh_indices.resize(static_cast<size_t>(n));
+    for (int64_t i = 0; i < n; ++i) output->archived_mesh_indices[i] = {removed[3 * i], removed[3 * i + 1], removed[3 * i + 2]};
+  }
+  extractInactiveObjects(*output);
+  return output;
+}
+
+void ActiveWindow::extractInactiveObjects(hydra::ActiveWindowOutput& output) {
+  // active_window.cpp:251-266: inactive tracks leave the tracker and are handed to the extractor.  The
+  // reference runs extraction on detached worker threads (object_worker_pool.cpp:115-146); here it runs in
+  // line on the device (one mini-map context per object).
+  Tracks& tracks = tracker_->getTracks();
+  for (auto it = tracks.begin(); it != tracks.end();) {
+    if (it->is_active) {
+      ++it;
+      continue;
+    }
+    if (object_extractor_) {
+      auto obj = object_extractor_->extractObject(*it, frame_data_buffer_);
+      if (obj) output.graph_update.push_back(obj);
+    }
+    it = tracks.erase(it);
+  }
+}
+
+void ActiveWindow::finishMapping() {
+  std::lock_guard<std::mutex> lock(mutex_);
+  // active_window.cpp:176-189: everything inactive, then a blocking output extraction
+  chk(khr_mark_all_inactive(ctx_), "khr_mark_all_inactive");
+  for (Track& t : tracker_->getTracks()) t.is_active = false;
+  if (!frame_data_buffer_.empty()) extractOutputData(frame_data_buffer_.getLatestData(), false);
+}
+
+std::vector<std::shared_ptr<KhronosObjectAttributes>> ActiveWindow::extractObjects() {
+  std::vector<std::shared_ptr<KhronosObjectAttributes>> result;
+  std::lock_guard<std::mutex> lock(mutex_);
+  if (!object_extractor_) return result;
+  for (const Track& t : tracker_->getTracks()) {  // active_window.cpp:191-201
+    auto obj = object_extractor_->extractObject(t, frame_data_buffer_);
+    if (obj) result.push_back(obj);
+  }
+  return result;
+}
+
+}  // namespace khronos

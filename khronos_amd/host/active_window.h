@@ -1,0 +1,260 @@
+// active_window.h — host-side mirror of the reference's plugin surface for the fusion path:
+//   khronos::ActiveWindow                     khronos/include/khronos/active_window/active_window.h:67-193
+//   khronos::TrackingIntegrator::Config       .../integration/tracking_integrator.h:59-83
+//   khronos::MotionDetector / FreeSpaceMotionDetector   .../motion_detection/*.h
+//   khronos::ObjectDetector, Tracker (no-op bases)      .../object_detection/object_detector.h, tracking/tracker.h
+//   khronos::MeshObjectExtractor (static objects)       .../object_extraction/mesh_object_extractor.h:59-165
+//   khronos::FrameData / FrameDataBuffer / Track        .../data/*.h
+// Same class names, config keys, method names and call order; the volumetric work goes through the C ABI in
+// include/khronos_amd.h to the gfx950 kernels, the map lives in HBM.  Hydra types are the stand-ins of
+// hydra_compat.h.  Config errors throw std::invalid_argument (the reference aborts in config::checkValid).
+#pragma once
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "hydra_compat.h"
+#include "mini_yaml.h"
+
+namespace khronos {
+
+using hydra::BlockIndex;
+using hydra::BlockIndices;
+using hydra::BoundingBox;
+using hydra::fromSeconds;
+using hydra::InputData;
+using hydra::KhronosObjectAttributes;
+using hydra::TimeStamp;
+using hydra::toSeconds;
+using hydra::VolumetricMap;
+
+// ---- data (khronos/include/khronos/active_window/data/) -------------------------------------------------
+struct MeasurementCluster {  // measurement_clusters.h:63-80
+  int id = 0;
+  size_t num_pixels = 0;
+  BoundingBox bounding_box;
+};
+
+struct FrameData {  // frame_data.h:59-83
+  using Ptr = std::shared_ptr<FrameData>;
+  InputData input;
+  std::vector<MeasurementCluster> dynamic_clusters;
+  std::vector<MeasurementCluster> semantic_clusters;
+  // dynamic_image / object_image live in the device frame slot `input.slot`; host copies on demand
+  std::vector<int32_t> dynamicImage() const;
+  int num_dynamic_clusters = 0;
+};
+
+struct Observation {  // track.h
+  TimeStamp stamp = 0;
+  int semantic_cluster_id = -1;
+  int dynamic_cluster_id = -1;
+};
+
+struct Track {  // track.h:51-111 (fields used by the active window)
+  int id = 0;
+  bool is_active = true;
+  bool is_dynamic = false;
+  float confidence = 0.f;
+  TimeStamp first_seen = 0, last_seen = 0;
+  int semantic_label = -1;
+  BoundingBox last_bounding_box;
+  std::vector<Observation> observations;
+};
+using Tracks = std::vector<Track>;
+
+class FrameDataBuffer {  // frame_data_buffer.h:52-100, frame_data_buffer.cpp:57-123
+ public:
+  struct Config {
+    size_t max_buffer_size = 300;
+    int store_every_n_frames = 1;
+  } const config;
+  explicit FrameDataBuffer(const Config& config);
+  void trimBuffer(const Tracks& tracks);
+  void storeData(const FrameData::Ptr& data);
+  FrameData::Ptr getData(TimeStamp stamp) const;
+  const FrameData& getLatestData() const { return *buffer_.back(); }
+  size_t size() const { return buffer_.size(); }
+  bool empty() const { return buffer_.empty(); }
+
+ private:
+  std::deque<FrameData::Ptr> buffer_;
+  int input_counter_ = 0;
+  TimeStamp oldest_time_stamp_ = 0;
+};
+
+// ---- processors ---------------------------------------------------------------------------------------------
+struct TrackingIntegrator {
+  struct Config {  // tracking_integrator.h:59-83, checks tracking_integrator.cpp:61-65
+    int verbosity = 0;
+    float temporal_buffer = 1.f;
+    float burn_in_period = 1.f;
+    float tsdf_occupancy_threshold = -1.5f;
+    int neighbor_connectivity = 18;
+    float temporal_window = 3.f;
+    int num_threads = -1;  // accepted for compatibility; the update is one kernel launch
+  };
+};
+
+class MotionDetector {  // motion_detector.h:49-69: the base class is a no-op
+ public:
+  virtual ~MotionDetector() = default;
+  virtual void processInput(const VolumetricMap& /*map*/, FrameData& /*data*/) {}
+  virtual bool isDeviceBacked() const { return false; }
+};
+
+class FreeSpaceMotionDetector : public MotionDetector {  // free_space_motion_detector.h:72-197
+ public:
+  struct Config {
+    int verbosity = 0;
+    int neighbor_connectivity = 26;
+    int min_cluster_size = 0;
+    int max_cluster_size = 1000000;
+    float min_separation_distance = 1.f;
+    float max_range = 10000.f;
+    float min_z_coordinate = -10000.f;
+    int num_threads = -1;
+  } const config;
+  explicit FreeSpaceMotionDetector(const Config& config);
+  void processInput(const VolumetricMap& map, FrameData& data) override;
+  bool isDeviceBacked() const override { return true; }
+};
+
+class ObjectDetector {  // object_detector.h: no-op base
+ public:
+  virtual ~ObjectDetector() = default;
+  virtual void processInput(const VolumetricMap& /*map*/, FrameData& /*data*/) {}
+};
+
+class Tracker {  // tracker.h:49-69: no-op base that only owns the track list
+ public:
+  virtual ~Tracker() = default;
+  virtual void processInput(FrameData& /*data*/) {}
+  Tracks& getTracks() { return tracks_; }
+  const Tracks& getTracks() const { return tracks_; }
+
+ protected:
+  Tracks tracks_;
+};
+
+class ObjectExtractor {  // object_extractor.h
+ public:
+  virtual ~ObjectExtractor() = default;
+  virtual std::shared_ptr<KhronosObjectAttributes> extractObject(const Track& track, const FrameDataBuffer& frames) = 0;
+};
+
+class MeshObjectExtractor : public ObjectExtractor {  // mesh_object_extractor.h:59-165
+ public:
+  struct Config {
+    int verbosity = 0;
+    float min_object_allocation_confidence = 0.5f;
+    float min_object_volume = 0.1f;
+    float max_object_volume = 4.0f;
+    bool only_extract_reconstructed_objects = false;
+    float min_dynamic_displacement = 0.2f;
+    float min_object_reconstruction_confidence = 0.5f;
+    float min_object_reconstruction_observations = 10.f;
+    float object_reconstruction_resolution = -0.02f;
+    float min_reconstruction_resolution = 0.f;
+    bool visualize_classification = false;
+    uint32_t max_object_blocks = 32768;  // device pool of the object mini-map
+  } const config;
+  MeshObjectExtractor(const Config& config, const khr_config& aw_device_config);
+  std::shared_ptr<KhronosObjectAttributes> extractObject(const Track& track, const FrameDataBuffer& frames) override;
+  // a13: MeshObjectExtractor::extractStaticObject (mesh_object_extractor.cpp:174-304)
+  std::shared_ptr<KhronosObjectAttributes> extractStaticObject(const Track& track, const FrameDataBuffer& frames) const;
+  // sizing of the private map (mesh_object_extractor.cpp:201-228): voxel size and block range
+  static float objectVoxelSize(const Config& config, const BoundingBox& extent);
+  static void objectBlockRange(const BoundingBox& extent, float block_size, int32_t* min_idx, int32_t* max_idx);
+
+ private:
+  khr_config device_config_;
+};
+
+// ---- the module -------------------------------------------------------------------------------------------------
+class ActiveWindow {
+ public:
+  using KhronosSink = std::function<void(const FrameData&, const VolumetricMap&, const Tracks&)>;
+
+  struct Config {  // active_window.h:72-96 + declare_config active_window.cpp:50-71
+    int verbosity = 0;
+    float min_output_separation = 0.0f;
+    bool detach_object_extraction = true;
+    VolumetricMap::Config volumetric_map;  // base hydra::ActiveWindowModule::Config(false, true)
+    struct ProjectiveIntegrator {
+      int verbosity = 0;
+      bool use_weight_dropoff = true;
+      float weight_dropoff_epsilon = -1.f;
+      bool use_constant_weight = false;
+      float max_weight = 1e5f;
+      std::string interpolation_method = "adaptive";
+      int num_threads = -1;
+      float label_confidence = 0.9f;
+    } projective_integrator;
+    TrackingIntegrator::Config tracking_integrator;
+    std::string motion_detector_type;    // "" = none, "FreeSpaceMotionDetector"
+    FreeSpaceMotionDetector::Config motion_detector;
+    std::string object_detector_type;    // host plugins of SURVEY.md §8(f3); "" = none
+    std::string tracker_type;
+    std::string object_extractor_type;   // "" = none, "MeshObjectExtractor"
+    MeshObjectExtractor::Config object_extractor;
+    struct ExtractionWorker { int num_workers = 2; int poll_time_us = 1000; int verbosity = 0; } extraction_worker;
+    struct MeshIntegrator { float min_weight = 1e-4f; } mesh_integrator;
+    FrameDataBuffer::Config frame_data_buffer;
+    // device-side sizing (no reference equivalent)
+    int num_labels = 20;
+    uint32_t max_blocks = 16384;
+    uint32_t max_frame_pixels = 1280 * 720;
+    uint64_t max_mesh_vertices = 8u << 20;
+    int device = 0, rank = 0, world_size = 1;
+
+    // parse the `active_window:` mapping of a Khronos mapper YAML (same keys as uHumans2.yaml:35-100)
+    static Config fromYaml(const khronos_amd::YamlNode& active_window_node);
+    static Config fromYamlString(const std::string& yaml_text);
+    void checkValid() const;  // throws std::invalid_argument
+  } const config;
+
+  explicit ActiveWindow(const Config& config);
+  virtual ~ActiveWindow();
+
+  std::string printInfo() const;
+  // access (not thread-safe, as in the reference)
+  VolumetricMap& getMap() { return map_; }
+  const VolumetricMap& getMap() const { return map_; }
+  const FrameData& getLatestFrameData() const { return frame_data_buffer_.getLatestData(); }
+  const Tracks& getTracks() const { return tracker_->getTracks(); }
+  void addKhronosSink(const KhronosSink& sink);
+  void setObjectDetector(std::unique_ptr<ObjectDetector> d) { object_detector_ = std::move(d); }
+  void setTracker(std::unique_ptr<Tracker> t) { tracker_ = std::move(t); }
+
+  void finishMapping();
+  std::vector<std::shared_ptr<KhronosObjectAttributes>> extractObjects();
+
+  // protected in the reference (called by the Hydra module thread); public here for the driver
+  hydra::ActiveWindowOutput::Ptr spinOnce(const hydra::InputPacket& input);
+
+ protected:
+  std::shared_ptr<FrameData> createData(const hydra::InputPacket& input) const;
+  void updateMap(const FrameData& data);
+  hydra::ActiveWindowOutput::Ptr extractOutputData(const FrameData& data, bool threaded);
+  void extractInactiveObjects(hydra::ActiveWindowOutput& output);
+
+  khr_ctx* ctx_ = nullptr;
+  khr_config device_config_{};
+  VolumetricMap map_;
+  std::unique_ptr<MotionDetector> motion_detector_;
+  std::unique_ptr<ObjectDetector> object_detector_;
+  std::unique_ptr<Tracker> tracker_;
+  std::unique_ptr<ObjectExtractor> object_extractor_;
+  std::mutex mutex_;
+  std::vector<KhronosSink> sinks_;
+  FrameDataBuffer frame_data_buffer_;
+  TimeStamp latest_stamp_ = 0;
+  TimeStamp last_full_upated_ = 0;
+  size_t num_frames_processed_ = 0;
+};
+
+}  // namespace khronos

@@ -1,0 +1,160 @@
+// aw_demo.cpp — drives khronos::ActiveWindow (host mirror) over a synthetic stream, the way the Hydra module
+// thread drives the reference (spinOnce per InputPacket, finishMapping at shutdown), and prints a JSON
+// summary that tests/test_gpu_host.py compares with the step-wise C-ABI path and the oracle.
+// usage: aw_demo <config.yaml> <width> <height> <frames> [object_label]
+#include <cinttypes>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "active_window.h"
+
+extern "C" {
+void* synth_create(uint32_t seed, int num_static, int with_mover);
+void synth_destroy(void* s);
+void synth_render(void* sp, int W, int H, float fx, float fy, float cx, float cy, const double* T, double t_sec,
+                  float max_depth, float noise_sigma_rel, uint32_t noise_seed, float* depth, uint8_t* rgb, int32_t* label,
+                  int num_threads);
+}
+
+using namespace khronos;
+
+// test stand-in for the instance-forwarding object detector + id tracker (the real
+// ConnectedSemantics / MaxIoUTracker are host plugins that are not part of the device path): pixels carrying
+// `label` become semantic cluster 1 of the frame (object_image = 1 there), with the bounding box of their
+// world-frame vertices, and one track collects them.
+struct LabelObjectDetector : ObjectDetector {
+  int label;
+  const int32_t* current_labels = nullptr;
+  explicit LabelObjectDetector(int l) : label(l) {}
+  void processInput(const VolumetricMap& map, FrameData& data) override {
+    const size_t n = static_cast<size_t>(data.input.sensor.width) * data.input.sensor.height;
+    std::vector<int32_t> obj(n, 0);
+    const std::vector<float> vm = data.input.vertexMap();
+    const std::vector<float> range = data.input.rangeImage();
+    MeasurementCluster cl;
+    cl.id = 1;
+    for (size_t i = 0; i < n; ++i)
+      if (current_labels[i] == label && range[i] > 0.f) {
+        obj[i] = 1;
+        cl.bounding_box.include(&vm[3 * i]);
+        ++cl.num_pixels;
+      }
+    khr_set_frame_image(map.ctx(), data.input.slot, /*object image*/ 1, obj.data(), 0);
+    if (cl.num_pixels > 0) data.semantic_clusters.push_back(cl);
+  }
+};
+
+struct SingleTrackTracker : Tracker {
+  void processInput(FrameData& data) override {
+    if (data.semantic_clusters.empty()) return;
+    if (tracks_.empty()) {
+      Track t;
+      t.id = 0;
+      t.first_seen = data.input.timestamp_ns;
+      t.semantic_label = 1;
+      tracks_.push_back(t);
+    }
+    Track& t = tracks_[0];
+    t.last_seen = data.input.timestamp_ns;
+    t.observations.push_back({data.input.timestamp_ns, 1, -1});
+    t.confidence = std::min(1.f, static_cast<float>(t.observations.size()) / 4.f);
+  }
+};
+
+static void circlePose(double t, double* T) {
+  const double th = 2.0 * M_PI * t / 10.0, yaw = th + M_PI / 2;
+  const double f[3] = {std::cos(yaw), std::sin(yaw), 0}, r[3] = {f[1], -f[0], 0}, d[3] = {0, 0, -1};
+  const double p[3] = {1.5 * std::cos(th), 1.5 * std::sin(th), 1.5};
+  for (int i = 0; i < 3; ++i) {
+    T[4 * i + 0] = r[i];
+    T[4 * i + 1] = d[i];
+    T[4 * i + 2] = f[i];
+    T[4 * i + 3] = p[i];
+  }
+  T[12] = T[13] = T[14] = 0;
+  T[15] = 1;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 5) {
+    std::fprintf(stderr, "usage: aw_demo <config.yaml> <width> <height> <frames> [object_label]\n");
+    return 2;
+  }
+  std::ifstream in(argv[1]);
+  std::stringstream ss;
+  ss << in.rdbuf();
+  const int W = std::atoi(argv[2]), H = std::atoi(argv[3]), N = std::atoi(argv[4]);
+  const int object_label = argc > 5 ? std::atoi(argv[5]) : -1;
+  try {
+    ActiveWindow::Config cfg = ActiveWindow::Config::fromYamlString(ss.str());
+    cfg.max_frame_pixels = static_cast<uint32_t>(W) * H;
+    ActiveWindow aw(cfg);
+    LabelObjectDetector* det = nullptr;
+    if (object_label >= 0) {
+      auto d = std::make_unique<LabelObjectDetector>(object_label);
+      det = d.get();
+      aw.setObjectDetector(std::move(d));
+      aw.setTracker(std::make_unique<SingleTrackTracker>());
+    }
+    int sink_calls = 0;
+    aw.addKhronosSink([&](const FrameData&, const VolumetricMap&, const Tracks&) { ++sink_calls; });
+
+    void* scene = synth_create(1234, 12, 1);
+    std::vector<float> depth(static_cast<size_t>(W) * H);
+    std::vector<uint8_t> rgb(static_cast<size_t>(W) * H * 3);
+    std::vector<int32_t> label(static_cast<size_t>(W) * H);
+    std::printf("{\"info\": \"%s\", \"outputs\": [", aw.printInfo().c_str());
+    int n_out = 0;
+    size_t total_dyn_clusters = 0;
+    for (int i = 0; i < N; ++i) {
+      hydra::InputPacket pkt;
+      pkt.timestamp_ns = static_cast<uint64_t>(std::llround((1.0 + 0.1 * i) * 1e9));
+      circlePose(0.1 * i, pkt.world_T_body);
+      pkt.sensor = {W, H, W / 2.f, W / 2.f, W / 2.f, H / 2.f, 0.1f, 5.f};
+      synth_render(scene, W, H, pkt.sensor.fx, pkt.sensor.fy, pkt.sensor.cx, pkt.sensor.cy, pkt.world_T_body, 0.1 * i, 5.f, 0.f,
+                   1234u + 7919u * i, depth.data(), rgb.data(), label.data(), 0);
+      pkt.depth = depth.data();
+      pkt.color = rgb.data();
+      pkt.labels = label.data();
+      if (det) det->current_labels = label.data();
+      auto out = aw.spinOnce(pkt);
+      total_dyn_clusters += aw.getLatestFrameData().num_dynamic_clusters;
+      if (out) {
+        std::printf("%s{\"stamp\": %" PRIu64 ", \"updated\": %zu, \"archived\": %zu}", n_out ? ", " : "", out->timestamp_ns,
+                    out->updated_blocks.size(), out->archived_mesh_indices.size());
+        ++n_out;
+      }
+    }
+    // map checksum in sorted block order
+    double checksum = 0;
+    size_t n_blocks = aw.getMap().numBlocks();
+    hydra::ActiveWindowOutput probe;
+    probe.map_ctx = aw.getMap().ctx();
+    for (const auto& idx : aw.getMap().allocatedBlockIndices()) {
+      const hydra::BlockCopy b = probe.cloneBlock(idx);
+      for (size_t k = 0; k < b.distance.size(); ++k) checksum += static_cast<double>(b.distance[k]) * b.weight[k];
+    }
+    const size_t n_tracks_before = aw.getTracks().size();
+    auto objects = aw.extractObjects();
+    std::printf("], \"n_outputs\": %d, \"sink_calls\": %d, \"dynamic_clusters\": %zu, \"n_blocks\": %zu, \"checksum\": %.9g, "
+                "\"tracks\": %zu, \"objects\": [",
+                n_out, sink_calls, total_dyn_clusters, n_blocks, checksum, n_tracks_before);
+    for (size_t k = 0; k < objects.size(); ++k) {
+      const auto& o = *objects[k];
+      std::printf("%s{\"vertices\": %zu, \"bbox_min\": [%.6f, %.6f, %.6f], \"bbox_max\": [%.6f, %.6f, %.6f]}", k ? ", " : "",
+                  o.mesh.numVertices(), o.bounding_box.min[0], o.bounding_box.min[1], o.bounding_box.min[2], o.bounding_box.max[0],
+                  o.bounding_box.max[1], o.bounding_box.max[2]);
+    }
+    aw.finishMapping();
+    std::printf("], \"blocks_after_finish\": %zu}\n", aw.getMap().numBlocks());
+    synth_destroy(scene);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "aw_demo: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -1,0 +1,177 @@
+// hydra_compat.h — minimal stand-ins for the Hydra / spark_dsg types that appear in the signature of
+// khronos::ActiveWindow (khronos/include/khronos/active_window/active_window.h:67-193).  Hydra is an
+// un-vendored dependency of the reference (install/https.rosinstall:5-8) and is not available offline; in
+// a real integration these are the genuine Hydra types and this header disappears.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/khronos_amd.h"
+
+namespace hydra {
+
+using TimeStamp = uint64_t;
+inline double toSeconds(TimeStamp t) { return static_cast<double>(t) / 1e9; }
+inline TimeStamp fromSeconds(double s) { return static_cast<TimeStamp>(s * 1e9); }
+
+using BlockIndex = std::array<int32_t, 3>;
+using BlockIndices = std::vector<BlockIndex>;
+
+struct Sensor {
+  int width = 0, height = 0;
+  float fx = 0, fy = 0, cx = 0, cy = 0;
+  float min_range = 0.1f, max_range = 5.f;
+};
+
+// hydra::InputPacket role: raw sensor frame + pose.  Row-major 4x4 doubles (Eigen::Isometry3d role).
+struct InputPacket {
+  TimeStamp timestamp_ns = 0;
+  double world_T_body[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  double body_T_sensor[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  Sensor sensor;
+  const float* depth = nullptr;     // H*W metres
+  const uint8_t* color = nullptr;   // H*W*3
+  const int32_t* labels = nullptr;  // H*W
+  bool on_device = false;           // buffers are HBM-resident on the context's device
+};
+
+inline void mul4(const double* a, const double* b, double* o) {
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) {
+      double s = 0;
+      for (int k = 0; k < 4; ++k) s += a[4 * r + k] * b[4 * k + c];
+      o[4 * r + c] = s;
+    }
+}
+
+// hydra::InputData role (fields SURVEY.md A.2).  The normalised images live in a device frame slot of the
+// fusion context; host copies are fetched on demand.
+struct InputData {
+  TimeStamp timestamp_ns = 0;
+  double world_T_body[16];
+  double world_T_sensor[16];
+  Sensor sensor;
+  khr_ctx* ctx = nullptr;
+  int slot = -1;  // device frame slot
+  const Sensor& getSensor() const { return sensor; }
+  const double* getSensorPose() const { return world_T_sensor; }
+  // host copies (range image H*W, world-frame vertex map H*W*3)
+  std::vector<float> rangeImage() const {
+    std::vector<float> r(static_cast<size_t>(sensor.width) * sensor.height);
+    khr_download_frame(ctx, slot, r.data(), nullptr, nullptr);
+    return r;
+  }
+  std::vector<float> vertexMap() const {
+    std::vector<float> v(static_cast<size_t>(sensor.width) * sensor.height * 3);
+    khr_download_frame(ctx, slot, nullptr, v.data(), nullptr);
+    return v;
+  }
+};
+
+// hydra::VolumetricMap role: here a handle on the HBM-resident map of a fusion context.
+class VolumetricMap {
+ public:
+  struct Config {
+    float voxel_size = 0.1f;
+    int voxels_per_side = 16;
+    float truncation_distance = 0.3f;
+    bool with_semantics = false;
+    bool with_tracking = true;
+  } config;
+
+  VolumetricMap() = default;
+  VolumetricMap(const Config& cfg, khr_ctx* ctx) : config(cfg), ctx_(ctx) {}
+  bool hasSemantics() const { return config.with_semantics; }
+  float blockSize() const { return config.voxel_size * static_cast<float>(config.voxels_per_side); }
+  khr_ctx* ctx() const { return ctx_; }
+  size_t numBlocks() const { return static_cast<size_t>(khr_num_blocks(ctx_)); }
+  // TsdfLayer::allocatedBlockIndices / blockIndicesWithCondition(updated) role (sorted)
+  BlockIndices allocatedBlockIndices(bool only_updated = false) const {
+    const int64_t n = khr_block_indices(ctx_, nullptr, 0, only_updated);
+    BlockIndices out(static_cast<size_t>(n > 0 ? n : 0));
+    if (n > 0) khr_block_indices(ctx_, out[0].data(), n, only_updated);
+    return out;
+  }
+
+ private:
+  khr_ctx* ctx_ = nullptr;
+};
+
+// a voxel block copied to the host (VolumetricMap::cloneUpdated role, active_window.cpp:229)
+struct BlockCopy {
+  BlockIndex index;
+  std::vector<float> distance, weight;
+  std::vector<uint8_t> color;  // rgba
+  std::vector<uint64_t> last_observed, last_occupied;
+  std::vector<uint8_t> flags;
+  std::vector<uint32_t> semantic_label;
+  uint8_t block_flags = 0;
+};
+
+struct Mesh {
+  std::vector<float> points;    // 3 per vertex
+  std::vector<uint8_t> colors;  // rgba per vertex
+  std::vector<uint32_t> labels;
+  std::vector<uint64_t> first_seen_stamps, stamps;
+  size_t numVertices() const { return labels.size(); }
+};
+
+struct BoundingBox {
+  float min[3] = {0, 0, 0}, max[3] = {0, 0, 0};
+  bool valid = false;
+  void merge(const BoundingBox& o) {
+    if (!o.valid) return;
+    if (!valid) { *this = o; return; }
+    for (int i = 0; i < 3; ++i) { min[i] = o.min[i] < min[i] ? o.min[i] : min[i]; max[i] = o.max[i] > max[i] ? o.max[i] : max[i]; }
+  }
+  void include(const float* p) {
+    if (!valid) { for (int i = 0; i < 3; ++i) min[i] = max[i] = p[i]; valid = true; return; }
+    for (int i = 0; i < 3; ++i) { if (p[i] < min[i]) min[i] = p[i]; if (p[i] > max[i]) max[i] = p[i]; }
+  }
+  float dimension(int i) const { return max[i] - min[i]; }
+  float center(int i) const { return 0.5f * (min[i] + max[i]); }
+  float volume() const { return valid ? dimension(0) * dimension(1) * dimension(2) : 0.f; }
+  float maxDimension() const { float m = dimension(0); for (int i = 1; i < 3; ++i) if (dimension(i) > m) m = dimension(i); return m; }
+};
+
+// spark_dsg::KhronosObjectAttributes role (fields set at mesh_object_extractor.cpp:81-118,268-302)
+struct KhronosObjectAttributes {
+  Mesh mesh;
+  BoundingBox bounding_box;
+  int semantic_label = -1;
+  std::vector<TimeStamp> first_observed_ns, last_observed_ns;
+  double position[3] = {0, 0, 0};
+};
+
+// hydra::ActiveWindowOutput role (fields set at active_window.cpp:225-247)
+struct ActiveWindowOutput {
+  using Ptr = std::shared_ptr<ActiveWindowOutput>;
+  TimeStamp timestamp_ns = 0;
+  double world_t_body[3] = {0, 0, 0};
+  double world_R_body[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  BlockIndices archived_mesh_indices;
+  BlockIndices updated_blocks;  // setMap(map.cloneUpdated()): indices now, voxel payload fetched lazily
+  khr_ctx* map_ctx = nullptr;
+  std::shared_ptr<InputData> sensor_data;
+  std::vector<std::shared_ptr<KhronosObjectAttributes>> graph_update;  // LayerUpdate(2) role
+  // deep copy of one updated block (the reference clones all of them eagerly, which on a GPU-resident map
+  // would put a D2H copy of every updated block on the critical path; SURVEY.md §7 "Output cadence & PCIe")
+  BlockCopy cloneBlock(const BlockIndex& idx) const {
+    BlockCopy b;
+    b.index = idx;
+    const size_t n = 4096;
+    b.distance.resize(n); b.weight.resize(n); b.color.resize(4 * n); b.last_observed.resize(n);
+    b.last_occupied.resize(n); b.flags.resize(n); b.semantic_label.resize(n);
+    khr_download_block(map_ctx, idx[0], idx[1], idx[2], b.distance.data(), b.weight.data(), b.color.data(),
+                       b.last_observed.data(), b.last_occupied.data(), b.flags.data(), b.semantic_label.data(), nullptr,
+                       &b.block_flags);
+    return b;
+  }
+};
+
+}  // namespace hydra

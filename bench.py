@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--cpu-baseline-frames", type=int, default=-1,
                     help="frames of the same stream timed on the CPU oracle (rank 0, N=1); -1 = auto, 0 = skip")
     ap.add_argument("--no-roofline-timers", action="store_true")
+    ap.add_argument("--halo-cap", type=int, default=8192, help="halo records all-gathered per rank and tick (N > 1)")
     return ap.parse_args()
 
 
@@ -114,6 +115,12 @@ def main():
         g_label = [torch.empty_like(d_label[0]) for _ in range(world)]
     torch.cuda.synchronize()
 
+    fusion = None
+    if world > 1:
+        from khronos_amd.distributed import HipShard, ShardedFusion
+        with torch.cuda.stream(stream):
+            fusion = ShardedFusion(HipShard(ctx, sensor, args.halo_cap, dev), dist, world)
+
     def step(i):
         with torch.cuda.stream(stream):
             _step(i)
@@ -127,6 +134,14 @@ def main():
         else:
             cams = [(d_depth[i], d_rgb[i], d_label[i], poses[i][0])]
         out_now = args.output_every > 0 and (i + 1) % args.output_every == 0
+        if world > 1:
+            # sharded tick: integrate all cameras into the owned blocks, tracking, halo all-gather, ever-free
+            fusion.tick(stamps[i], [(pose, dep, rgb, lab) for (dep, rgb, lab, pose) in cams])
+            if out_now:
+                ctx.generate_mesh(True, True)
+                ctx.reset_inactive_async()
+                ctx.clear_updated()
+            return
         for ci, (dep, rgb, lab, pose) in enumerate(cams):
             flags = 0
             if not args.no_motion and world == 1:
@@ -186,7 +201,8 @@ def main():
                                "MotionDetector %s, output extraction every %d frames; %d camera(s)"
                                % (W, H, vs * 100, K, "off" if (args.no_motion or world > 1) else "on",
                                   args.output_every, world),
-                   "parallelism": "hash-range block shard x%d, owner-computes, RCCL all-gather of frames" % world
+                   "parallelism": "hash-range block shard x%d, owner-computes, RCCL all-gather of frames + of 528-B halo records "
+                                  "(ever-free); motion detector and mesh halo not exchanged yet" % world
                    if world > 1 else "single GPU"},
         "mvoxel_updates_per_s": 1e-6 * n_upd_all / dt,
         "voxels": {"visited": n_vis_all, "updated": n_upd_all, "band": n_band_all, "allocated_blocks": st1["n_allocated_blocks"],

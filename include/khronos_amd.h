@@ -163,6 +163,19 @@ int khr_integrate(khr_ctx* ctx, int slot, int allocate_blocks, int use_mask, int
 int khr_integrate_shared(khr_ctx* ctx, khr_ctx* src, int src_slot, int allocate_blocks, int use_mask, int object_id);
 /* replaces: TrackingIntegrator::updateBlocks (tracking_integrator.cpp:71-104) */
 int khr_update_tracking(khr_ctx* ctx, uint64_t timestamp_ns);
+/* The two halves of khr_update_tracking, for multi-GPU runs (phase 1 = per-voxel tracking update over all
+ * blocks, 2 = ever-free stencil, 3 = both).  Between them the ranks exchange halo records: */
+int khr_update_tracking_phase(khr_ctx* ctx, uint64_t timestamp_ns, int phase);
+/* Halo record = 66 x u64 = 528 bytes: [0] packed block index (21 bits per axis, +2^20 bias, x lowest),
+ * [1] 1 = valid, [2..65] the block's 4096 "free-or-ever-free" bits in voxel-linear order.
+ * khr_export_halo writes exactly cap_records records (one per live block of this rank, rest zero) so that a
+ * fixed-size all-gather can ship them; khr_import_halo indexes the records of blocks owned by OTHER ranks
+ * so that the ever-free stencil can read neighbours that live on another GPU (no reference equivalent:
+ * the reference is single-process).  The collective itself is the host's job (RCCL via torch.distributed
+ * in bench.py / khronos_amd/distributed.py). */
+#define KHR_HALO_RECORD_BYTES 528
+int khr_export_halo(khr_ctx* ctx, void* records, int64_t cap_records, int on_device);
+int khr_import_halo(khr_ctx* ctx, const void* records, int64_t n_records, int on_device);
 /* replaces: FreeSpaceMotionDetector::processInput (free_space_motion_detector.cpp:73-103).
  * Writes the slot's dynamic_image on the device; returns the number of clusters kept (>= 0). */
 int khr_detect_motion(khr_ctx* ctx, int slot);

@@ -59,7 +59,8 @@ EXPORTS = [
     "khr_detect_motion", "khr_generate_mesh", "khr_reset_inactive", "khr_mark_all_inactive", "khr_clear_updated",
     "khr_allocate_blocks", "khr_object_prune", "khr_get_stats", "khr_num_blocks", "khr_block_indices",
     "khr_download_block", "khr_mesh_num_vertices", "khr_download_mesh", "khr_timing_enable", "khr_timing_reset",
-    "khr_timing_get", "khr_debug_read", "khr_last_removed", "khr_process_frame", "khr_integrate_shared",
+    "khr_timing_get", "khr_debug_read", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_update_tracking_phase",
+    "khr_export_halo", "khr_import_halo",
 ]
 
 _lib = None
@@ -95,6 +96,9 @@ def load_library():
     lib.khr_integrate.argtypes = [vp, i32, i32, i32, i32]
     lib.khr_integrate_shared.argtypes = [vp, vp, i32, i32, i32, i32]
     lib.khr_update_tracking.argtypes = [vp, u64]
+    lib.khr_update_tracking_phase.argtypes = [vp, u64, i32]
+    lib.khr_export_halo.argtypes = [vp, vp, i64, i32]
+    lib.khr_import_halo.argtypes = [vp, vp, i64, i32]
     lib.khr_detect_motion.argtypes = [vp, i32]
     lib.khr_generate_mesh.argtypes = [vp, i32, i32]
     lib.khr_reset_inactive.argtypes = [vp, vp, i64, C.POINTER(i64)]
@@ -257,6 +261,30 @@ class FusionContext:
     def update_tracking(self, stamp_ns):
         self._chk(self.lib.khr_update_tracking(self.h, int(stamp_ns)))
 
+    def update_tracking_phase(self, stamp_ns, phase):
+        self._chk(self.lib.khr_update_tracking_phase(self.h, int(stamp_ns), int(phase)))
+
+    HALO_WORDS = 66
+
+    def export_halo(self, cap_records, device_ptr=None):
+        """host numpy [cap, 66] uint64, or write into an HBM buffer given as an integer pointer."""
+        if device_ptr is not None:
+            self._chk(self.lib.khr_export_halo(self.h, C.c_void_p(device_ptr), int(cap_records), 1))
+            return None
+        out = np.zeros((cap_records, self.HALO_WORDS), np.uint64)
+        self._chk(self.lib.khr_export_halo(self.h, _ptr(out), int(cap_records), 0))
+        return out
+
+    def import_halo(self, records=None, n_records=0, device_ptr=None):
+        if device_ptr is not None:
+            self._chk(self.lib.khr_import_halo(self.h, C.c_void_p(device_ptr), int(n_records), 1))
+            return
+        if records is None or len(records) == 0:
+            self._chk(self.lib.khr_import_halo(self.h, None, 0, 0))
+            return
+        records = np.ascontiguousarray(records, dtype=np.uint64).reshape(-1, self.HALO_WORDS)
+        self._chk(self.lib.khr_import_halo(self.h, _ptr(records), records.shape[0], 0))
+
     def detect_motion(self, slot):
         return self._chk(self.lib.khr_detect_motion(self.h, slot))
 
@@ -269,6 +297,10 @@ class FusionContext:
         out = np.zeros((cap, 3), np.int32)
         self._chk(self.lib.khr_reset_inactive(self.h, _ptr(out), cap, C.byref(n)))
         return out[: n.value].copy()
+
+    def reset_inactive_async(self):
+        """no host round trip; the archived indices stay on the device (fetch with last_removed())."""
+        self._chk(self.lib.khr_reset_inactive(self.h, None, 0, None))
 
     def mark_all_inactive(self):
         self._chk(self.lib.khr_mark_all_inactive(self.h))

@@ -769,17 +769,31 @@ __constant__ int8_t c_nbr26[26][3] = {
 
 // ----------------------------------------------------------------------------------------------
 // k_ever_free: TrackingIntegrator::updateBlockEverFree (tracking_integrator.cpp:168-222).  One workgroup
-// per tracking-updated block.  The (VPS+2)^3 "free-or-ever-free" halo tile is staged in LDS from the
-// per-block bit masks of the block and its up-to-26 neighbours (hash lookups by 27 lanes); a missing
-// neighbour block reads as "not free" (:198-202).  A voxel becomes ever_free iff it is free, not yet
-// ever-free, and all nn neighbours are free-or-ever-free.
+// per tracking-updated block.  The 4096-bit "free-or-ever-free" masks of the block and its up-to-26
+// neighbours are copied to LDS with coalesced 8-byte loads (27 hash lookups by 27 lanes; a neighbour that
+// is not in the local map is looked up in the remote halo table filled by khr_import_halo, i.e. blocks
+// owned by other GPUs; a block missing everywhere reads as "not free", :198-202), expanded to a
+// (VPS+2)^3 byte tile, and a voxel becomes ever_free iff it is free, not yet ever-free, and all nn
+// neighbours are free-or-ever-free.
 // ----------------------------------------------------------------------------------------------
+constexpr int kHaloRecWords = 66;  // u64: [0] packed block key, [1] valid, [2..65] 4096 free bits
+
+struct RemoteHalo {
+  const uint64_t* recs;   // nullptr = no remote halo (single GPU)
+  const uint64_t* ht_keys;
+  const uint32_t* ht_vals;
+  uint32_t ht_mask;
+};
+
 template <int VPS>
-__global__ __launch_bounds__(256) void k_ever_free(DevMap m, DevParams p, const uint32_t* __restrict__ ef_list) {
+__global__ __launch_bounds__(256) void k_ever_free(DevMap m, DevParams p, const uint32_t* __restrict__ ef_list,
+                                                  RemoteHalo rh) {
   constexpr int NV = VPS * VPS * VPS;
+  constexpr int NW = NV / 64;
   constexpr int T = VPS + 2;
   __shared__ uint8_t tile[T * T * T];
-  __shared__ uint32_t nslot[27];
+  __shared__ uint64_t s_bits[27][NW];
+  __shared__ const uint64_t* s_src[27];
   const uint32_t n = m.counters[C_N_EF];
   for (uint32_t b = blockIdx.x; b < n; b += gridDim.x) {
     const size_t slot = ef_list[b];
@@ -787,8 +801,29 @@ __global__ __launch_bounds__(256) void k_ever_free(DevMap m, DevParams p, const 
     __syncthreads();
     if (threadIdx.x < 27) {
       const int dx = threadIdx.x % 3 - 1, dy = (threadIdx.x / 3) % 3 - 1, dz = threadIdx.x / 9 - 1;
-      nslot[threadIdx.x] = (threadIdx.x == 13) ? static_cast<uint32_t>(slot)
-                                               : htLookup(m, packKey(bi.x + dx, bi.y + dy, bi.z + dz));
+      const uint64_t key = packKey(bi.x + dx, bi.y + dy, bi.z + dz);
+      const uint32_t ns = (threadIdx.x == 13) ? static_cast<uint32_t>(slot) : htLookup(m, key);
+      const uint64_t* src = nullptr;
+      if (ns != kInvalidSlot) {
+        src = m.freebits + static_cast<size_t>(ns) * NW;
+      } else if (rh.recs) {
+        uint32_t h = hashKey(key) & rh.ht_mask;
+        while (true) {
+          const uint64_t k = rh.ht_keys[h];
+          if (k == key) {
+            src = rh.recs + static_cast<size_t>(rh.ht_vals[h]) * kHaloRecWords + 2;
+            break;
+          }
+          if (k == kEmptyKey) break;
+          h = (h + 1) & rh.ht_mask;
+        }
+      }
+      s_src[threadIdx.x] = src;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 27 * NW; i += 256) {
+      const uint64_t* src = s_src[i / NW];
+      s_bits[i / NW][i % NW] = src ? src[i % NW] : 0ull;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < T * T * T; c += 256) {
@@ -798,29 +833,75 @@ __global__ __launch_bounds__(256) void k_ever_free(DevMap m, DevParams p, const 
       if (x < 0) { x += VPS; sx = 0; } else if (x >= VPS) { x -= VPS; sx = 2; }
       if (y < 0) { y += VPS; sy = 0; } else if (y >= VPS) { y -= VPS; sy = 2; }
       if (z < 0) { z += VPS; sz = 0; } else if (z >= VPS) { z -= VPS; sz = 2; }
-      const uint32_t ns = nslot[sx + 3 * sy + 9 * sz];
-      uint8_t fbit = 0;
-      if (ns != kInvalidSlot) {
-        const int lin = x + VPS * (y + VPS * z);
-        fbit = (m.freebits[static_cast<size_t>(ns) * (NV / 64) + (lin >> 6)] >> (lin & 63)) & 1ull;
-      }
-      tile[c] = fbit;
+      const int lin = x + VPS * (y + VPS * z);
+      tile[c] = static_cast<uint8_t>((s_bits[sx + 3 * sy + 9 * sz][lin >> 6] >> (lin & 63)) & 1ull);
     }
     __syncthreads();
     uint8_t* __restrict__ vfl = m.vflags + slot * NV;
     for (int lin = threadIdx.x; lin < NV; lin += 256) {
       const int ix = lin % VPS, iy = (lin / VPS) % VPS, iz = lin / (VPS * VPS);
-      const uint8_t v = vfl[lin];
       const int c0 = (ix + 1) + T * ((iy + 1) + T * (iz + 1));
-      // free && !ever_free : the tile bit is (ever_free || free), so with ever_free clear it means free
-      if ((v & VOX_EVER_FREE) || !tile[c0]) continue;
+      if (!tile[c0]) continue;  // not free (and not ever-free)
       bool ok = true;
       for (int k = 0; k < p.nn; ++k) {
         const int c = c0 + c_nbr26[k][0] + T * (c_nbr26[k][1] + T * c_nbr26[k][2]);
         ok = ok && tile[c];
       }
-      if (ok) vfl[lin] = v | VOX_EVER_FREE;
+      if (!ok) continue;
+      // the tile bit is (ever_free || free): only voxels that are not yet ever-free need the store
+      const uint8_t v = vfl[lin];
+      if (!(v & VOX_EVER_FREE)) vfl[lin] = v | VOX_EVER_FREE;
     }
+  }
+}
+
+// halo export: one record per listed block (list compacted by k_list_live); the rest of the buffer is zeroed
+template <int VPS>
+__global__ __launch_bounds__(256) void k_export_halo(DevMap m, const uint32_t* __restrict__ list,
+                                                    const uint32_t* __restrict__ n_list, uint64_t* __restrict__ recs,
+                                                    uint32_t cap) {
+  constexpr int NW = VPS * VPS * VPS / 64;
+  const uint32_t n = min(*n_list, cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && *n_list > cap) atomicAdd(&m.counters[C_POOL_EXHAUSTED], 1u);
+  const uint32_t total = cap * kHaloRecWords;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const uint32_t r = i / kHaloRecWords, w = i % kHaloRecWords;
+    uint64_t v = 0ull;
+    if (r < n) {
+      const uint32_t slot = list[r];
+      if (w == 0) {
+        const int4 bi = m.blk_index[slot];
+        v = packKey(bi.x, bi.y, bi.z);
+      } else if (w == 1) {
+        v = 1ull;
+      } else if (w - 2 < NW) {
+        v = m.freebits[static_cast<size_t>(slot) * NW + (w - 2)];
+      }
+    }
+    recs[i] = v;
+  }
+}
+
+// halo import: index the records of blocks owned by OTHER ranks in an open-addressing table
+__global__ __launch_bounds__(256) void k_import_halo(const uint64_t* __restrict__ recs, uint32_t n_total, int rank,
+                                                    int world, uint64_t* __restrict__ ht_keys,
+                                                    uint32_t* __restrict__ ht_vals, uint32_t ht_mask) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_total) return;
+  if (recs[static_cast<size_t>(r) * kHaloRecWords + 1] != 1ull) return;
+  const uint64_t key = recs[static_cast<size_t>(r) * kHaloRecWords];
+  int x, y, z;
+  unpackKey(key, &x, &y, &z);
+  if (ownerOf(x, y, z, world) == rank) return;
+  uint32_t h = hashKey(key) & ht_mask;
+  while (true) {
+    const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&ht_keys[h]),
+                                              static_cast<unsigned long long>(kEmptyKey), static_cast<unsigned long long>(key));
+    if (prev == kEmptyKey) {
+      ht_vals[h] = r;
+      return;
+    }
+    h = (h + 1) & ht_mask;
   }
 }
 

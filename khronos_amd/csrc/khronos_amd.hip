@@ -91,6 +91,11 @@ struct khr_ctx {
   uint32_t* d_band_count = nullptr;
   unsigned long long* d_dbg = nullptr;
   uint32_t* d_wg_stats = nullptr;
+  // remote halo (multi-GPU): records gathered from the other ranks + their index
+  uint64_t* d_halo_recs = nullptr;
+  uint64_t* d_halo_keys = nullptr;
+  uint32_t* d_halo_vals = nullptr;
+  uint32_t halo_cap_total = 0, halo_mask = 0, halo_n = 0;
   uint32_t* h_pinned = nullptr;  // [0] seed pixels of the last motion pass, [1] removed count
   hipEvent_t ev_seed = nullptr;
   uint32_t last_removed = 0;
@@ -505,6 +510,7 @@ void khr_destroy(khr_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   resolveTimers(c);
   for (void* p : c->allocs) hipFree(p);
+  if (c->d_halo_recs) { hipFree(c->d_halo_recs); hipFree(c->d_halo_keys); hipFree(c->d_halo_vals); }
   if (c->h_pinned) hipHostFree(c->h_pinned);
   if (c->ev_seed) hipEventDestroy(c->ev_seed);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -714,27 +720,105 @@ int khr_integrate_shared(khr_ctx* c, khr_ctx* src, int src_slot, int allocate_bl
   return integrateUpdate(c, s, f, allocate_blocks, use_mask, object_id);
 }
 
-int khr_update_tracking(khr_ctx* c, uint64_t stamp) {
-  if (!c) return fail(KHR_EINVAL, "null ctx");
-  if (!c->cfg.with_tracking) return KHR_OK;
-  HIP_TRY(hipSetDevice(c->device));
+static int trackingPhase(khr_ctx* c, uint64_t stamp, int phase) {
   DevMap& m = c->m;
-  HIP_TRY(hipMemsetAsync(&m.counters[C_N_EF], 0, sizeof(uint32_t), c->stream));
   return dispatchVps(c, [&](auto vps) {
-    hipLaunchKernelGGL(k_list_live, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_ef, &m.counters[C_N_EF],
-                       BLK_TRACKING_UPDATED);
-    {
+    constexpr int V = decltype(vps)::value;
+    if (phase & 1) {
+      HIP_TRY(hipMemsetAsync(&m.counters[C_N_EF], 0, sizeof(uint32_t), c->stream));
+      hipLaunchKernelGGL(k_list_live, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_ef, &m.counters[C_N_EF],
+                         BLK_TRACKING_UPDATED);
       ScopedTimer tm(c, 1);
-      hipLaunchKernelGGL((k_tracking_update<decltype(vps)::value>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p,
-                         stamp);
+      hipLaunchKernelGGL((k_tracking_update<V>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, stamp);
     }
-    {
+    if (phase & 2) {
       ScopedTimer tm(c, 2);
-      hipLaunchKernelGGL((k_ever_free<decltype(vps)::value>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, c->d_ef);
+      RemoteHalo rh{};
+      if (c->halo_n) {
+        rh.recs = c->d_halo_recs;
+        rh.ht_keys = c->d_halo_keys;
+        rh.ht_vals = c->d_halo_vals;
+        rh.ht_mask = c->halo_mask;
+      }
+      hipLaunchKernelGGL((k_ever_free<V>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, c->d_ef, rh);
     }
     HIP_TRY(hipGetLastError());
     return KHR_OK;
   });
+}
+
+int khr_update_tracking(khr_ctx* c, uint64_t stamp) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  if (!c->cfg.with_tracking) return KHR_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  return trackingPhase(c, stamp, 3);
+}
+
+int khr_update_tracking_phase(khr_ctx* c, uint64_t stamp, int phase) {
+  if (!c || phase < 1 || phase > 3) return fail(KHR_EINVAL, "bad argument");
+  if (!c->cfg.with_tracking) return KHR_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  return trackingPhase(c, stamp, phase);
+}
+
+int khr_export_halo(khr_ctx* c, void* records, int64_t cap_records, int on_device) {
+  if (!c || !records || cap_records < 1) return fail(KHR_EINVAL, "bad argument");
+  if (!c->cfg.with_tracking) return fail(KHR_ESTATE, "halo records need the tracking layer");
+  HIP_TRY(hipSetDevice(c->device));
+  DevMap& m = c->m;
+  const size_t bytes = static_cast<size_t>(cap_records) * kHaloRecWords * sizeof(uint64_t);
+  uint64_t* dst = static_cast<uint64_t*>(records);
+  uint64_t* tmp = nullptr;
+  if (!on_device) {
+    HIP_TRY(hipMalloc(&tmp, bytes));
+    dst = tmp;
+  }
+  HIP_TRY(hipMemsetAsync(c->d_mesh_nwork + 1, 0, sizeof(uint32_t), c->stream));
+  hipLaunchKernelGGL(k_list_live, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_work, c->d_mesh_nwork + 1, 0u);
+  int rc = dispatchVps(c, [&](auto vps) {
+    hipLaunchKernelGGL((k_export_halo<decltype(vps)::value>), dim3(1024), dim3(256), 0, c->stream, m, c->d_work,
+                       c->d_mesh_nwork + 1, dst, static_cast<uint32_t>(cap_records));
+    return KHR_OK;
+  });
+  if (rc == KHR_OK && !on_device) {
+    hipError_t e = hipMemcpyAsync(records, tmp, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(KHR_EDEVICE, "halo export copy failed: %s", hipGetErrorString(e));
+  }
+  if (tmp) {
+    hipStreamSynchronize(c->stream);
+    hipFree(tmp);
+  }
+  return rc;
+}
+
+int khr_import_halo(khr_ctx* c, const void* records, int64_t n_records, int on_device) {
+  if (!c || (!records && n_records > 0) || n_records < 0) return fail(KHR_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  if (n_records == 0) {
+    c->halo_n = 0;
+    return KHR_OK;
+  }
+  if (static_cast<uint64_t>(n_records) > c->halo_cap_total) {  // (re)allocate the remote table
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_halo_recs) { hipFree(c->d_halo_recs); hipFree(c->d_halo_keys); hipFree(c->d_halo_vals); }
+    uint32_t ht = 1;
+    while (ht < static_cast<uint64_t>(n_records) * 4) ht <<= 1;
+    HIP_TRY(hipMalloc(&c->d_halo_recs, static_cast<size_t>(n_records) * kHaloRecWords * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(&c->d_halo_keys, sizeof(uint64_t) * ht));
+    HIP_TRY(hipMalloc(&c->d_halo_vals, sizeof(uint32_t) * ht));
+    c->halo_cap_total = static_cast<uint32_t>(n_records);
+    c->halo_mask = ht - 1;
+  }
+  HIP_TRY(hipMemcpyAsync(c->d_halo_recs, records, static_cast<size_t>(n_records) * kHaloRecWords * sizeof(uint64_t),
+                         on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_halo_keys, 0xff, sizeof(uint64_t) * (static_cast<size_t>(c->halo_mask) + 1), c->stream));
+  hipLaunchKernelGGL(k_import_halo, dim3(gridFor(n_records)), dim3(256), 0, c->stream, c->d_halo_recs,
+                     static_cast<uint32_t>(n_records), c->cfg.rank, c->cfg.world_size, c->d_halo_keys, c->d_halo_vals, c->halo_mask);
+  HIP_TRY(hipGetLastError());
+  if (!on_device) HIP_TRY(hipStreamSynchronize(c->stream));
+  c->halo_n = static_cast<uint32_t>(n_records);
+  return KHR_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

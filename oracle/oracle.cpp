@@ -180,6 +180,9 @@ struct orc_map {
   int vps, nvox;
   float bs, bs_inv, vs_inv;
   std::unordered_map<I3, std::unique_ptr<Block>, I3Hash> blocks;
+  // free-or-ever-free bit masks of blocks owned by other ranks (multi-GPU halo)
+  std::unordered_map<I3, std::vector<uint64_t>, I3Hash> halo;
+  std::vector<Block*> ef_work;  // tracking-updated blocks collected by phase 1
 
   Block* find(const I3& i) const {
     auto it = blocks.find(i);
@@ -552,9 +555,10 @@ int orc_integrate(orc_map* m, const orc_sensor* s, const orc_frame* f, int alloc
   return 0;
 }
 
-int orc_update_tracking(orc_map* m, uint64_t stamp) {
+int orc_update_tracking_phase(orc_map* m, uint64_t stamp, int phase) {
   const orc_config& c = m->cfg;
   if (!c.with_tracking) return 0;
+  if (phase & 1) {
   // tracking_integrator.cpp:75-77
   std::vector<Block*> all, updated;
   for (auto& kv : m->blocks) {
@@ -580,6 +584,10 @@ int orc_update_tracking(orc_map* m, uint64_t stamp) {
     }
     b.has_active_data = active_any;
   });
+  m->ef_work = updated;
+  }
+  if (!(phase & 2)) return 0;
+  const std::vector<Block*>& updated = m->ef_work;
   // updateBlockEverFree: tracking_integrator.cpp:168-222
   const int nn = c.neighbor_connectivity;
   const int vps = m->vps;
@@ -599,7 +607,13 @@ int orc_update_tracking(orc_map* m, uint64_t stamp) {
             if (ny < 0) { ny += vps; nb.y--; } else if (ny >= vps) { ny -= vps; nb.y++; }
             if (nz < 0) { nz += vps; nb.z--; } else if (nz >= vps) { nz -= vps; nb.z++; }
             const Block* nblk = (nb == b.index) ? &b : m->find(nb);
-            if (!nblk) { bad = true; break; }
+            if (!nblk) {
+              // not in this rank's shard: consult the halo records of the other ranks (absent => missing block)
+              auto hit = m->halo.find(nb);
+              const int nl = nx + vps * (ny + vps * nz);
+              if (hit == m->halo.end() || !((hit->second[nl >> 6] >> (nl & 63)) & 1ull)) bad = true;
+              continue;
+            }
             const TrackingVoxel& nv = nblk->tracking[nx + vps * (ny + vps * nz)];
             if (nv.ever_free) continue;
             if (!voxelIsFree(c, nv, stamp)) bad = true;
@@ -608,6 +622,45 @@ int orc_update_tracking(orc_map* m, uint64_t stamp) {
         }
   });
   return 0;
+}
+
+int orc_update_tracking(orc_map* m, uint64_t stamp) { return orc_update_tracking_phase(m, stamp, 3); }
+
+static inline uint64_t packBlockKey(const I3& b) {
+  return (static_cast<uint64_t>(static_cast<uint32_t>(b.x + (1 << 20)) & 0x1fffffu)) |
+         (static_cast<uint64_t>(static_cast<uint32_t>(b.y + (1 << 20)) & 0x1fffffu) << 21) |
+         (static_cast<uint64_t>(static_cast<uint32_t>(b.z + (1 << 20)) & 0x1fffffu) << 42);
+}
+
+// halo record: 66 x u64 = [packed block index, valid, 64 words of free-or-ever-free bits] (khronos_amd.h)
+int64_t orc_export_halo(orc_map* m, uint64_t stamp, uint64_t* recs, int64_t cap) {
+  std::memset(recs, 0, sizeof(uint64_t) * 66 * static_cast<size_t>(cap));
+  int64_t n = 0;
+  for (const I3& idx : m->sortedIndices()) {
+    if (n >= cap) return -1;
+    const Block* b = m->find(idx);
+    uint64_t* r = recs + 66 * n;
+    r[0] = packBlockKey(idx);
+    r[1] = 1;
+    for (int i = 0; i < m->nvox; ++i) {
+      const TrackingVoxel& v = b->tracking[i];
+      if (v.ever_free || voxelIsFree(m->cfg, v, stamp)) r[2 + (i >> 6)] |= 1ull << (i & 63);
+    }
+    ++n;
+  }
+  return n;
+}
+
+void orc_import_halo(orc_map* m, const uint64_t* recs, int64_t n) {
+  m->halo.clear();
+  for (int64_t i = 0; i < n; ++i) {
+    const uint64_t* r = recs + 66 * i;
+    if (r[1] != 1) continue;
+    const I3 b = {static_cast<int32_t>(r[0] & 0x1fffffu) - (1 << 20), static_cast<int32_t>((r[0] >> 21) & 0x1fffffu) - (1 << 20),
+                  static_cast<int32_t>((r[0] >> 42) & 0x1fffffu) - (1 << 20)};
+    if (ownerOf(b, m->cfg.world_size) == m->cfg.rank) continue;
+    m->halo[b] = std::vector<uint64_t>(r + 2, r + 66);
+  }
 }
 
 int64_t orc_reset_inactive(orc_map* m, int32_t* removed, int64_t cap) {

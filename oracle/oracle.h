@@ -103,6 +103,12 @@ int orc_integrate(orc_map* m, const orc_sensor* s, const orc_frame* f, int alloc
 /* TrackingIntegrator::updateBlocks (tracking_integrator.cpp:71-104) */
 int orc_update_tracking(orc_map* m, uint64_t timestamp_ns);
 
+/* multi-GPU emulation: phase 1 = tracking update, 2 = ever-free pass, 3 = both; halo
+ * records as in include/khronos_amd.h (66 x u64 per block) */
+int orc_update_tracking_phase(orc_map* m, uint64_t timestamp_ns, int phase);
+int64_t orc_export_halo(orc_map* m, uint64_t timestamp_ns, uint64_t* records, int64_t cap);
+void orc_import_halo(orc_map* m, const uint64_t* records, int64_t n);
+
 /* TrackingIntegrator::resetInactive (tracking_integrator.cpp:106-131); returns count, fills
  * removed[3*i..] up to cap entries */
 int64_t orc_reset_inactive(orc_map* m, int32_t* removed, int64_t cap);

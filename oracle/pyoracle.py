@@ -66,6 +66,11 @@ def load():
     lib.orc_parse_input.restype = None
     lib.orc_integrate.argtypes = [vp, C.POINTER(OrcSensor), C.POINTER(OrcFrame), i32, C.POINTER(OrcStats)]
     lib.orc_update_tracking.argtypes = [vp, C.c_uint64]
+    lib.orc_update_tracking_phase.argtypes = [vp, C.c_uint64, i32]
+    lib.orc_export_halo.argtypes = [vp, C.c_uint64, vp, i64]
+    lib.orc_export_halo.restype = i64
+    lib.orc_import_halo.argtypes = [vp, vp, i64]
+    lib.orc_import_halo.restype = None
     lib.orc_reset_inactive.argtypes = [vp, vp, i64]
     lib.orc_reset_inactive.restype = i64
     lib.orc_mark_all_inactive.argtypes = [vp]
@@ -169,6 +174,19 @@ class OracleMap:
 
     def update_tracking(self, stamp_ns):
         self.lib.orc_update_tracking(self.h, int(stamp_ns))
+
+    def update_tracking_phase(self, stamp_ns, phase):
+        self.lib.orc_update_tracking_phase(self.h, int(stamp_ns), int(phase))
+
+    def export_halo(self, stamp_ns, cap_records):
+        out = np.zeros((cap_records, 66), np.uint64)
+        n = self.lib.orc_export_halo(self.h, int(stamp_ns), _ptr(out), int(cap_records))
+        assert n >= 0, "halo capacity too small"
+        return out
+
+    def import_halo(self, records):
+        records = np.ascontiguousarray(records, dtype=np.uint64).reshape(-1, 66)
+        self.lib.orc_import_halo(self.h, _ptr(records), records.shape[0])
 
     def detect_motion(self, sensor, stamp_ns, T, depth):
         f, keep = self._frame(stamp_ns, T, depth)

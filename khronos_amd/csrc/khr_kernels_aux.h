@@ -16,7 +16,7 @@ constexpr uint64_t kSeedBit = 1ull << 63;
 // one thread per pixel: range / z gates, world vertex from depth + pose, tracking-block lookup, voxel
 // index, ever-free test.  Emits a 64-bit sort key per pixel: packed global voxel index (63 bits) with
 // the seed flag in bit 63; ~0 for pixels that are skipped.  The per-voxel pixel lists of the reference
-// (nested hash maps) are recovered by a device radix sort + run-length encode of these keys.
+// (nested hash maps) are grouped by the device voxel hash tables below (k_md_*).
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_motion_pixels(DevMap m, DevParams p, DevFrame f, float md_max_range,
                                                       float min_z_world, uint64_t* __restrict__ keys,
@@ -58,22 +58,123 @@ __global__ __launch_bounds__(256) void k_motion_pixels(DevMap m, DevParams p, De
     atomicAdd(&m.counters[C_N_SEEDS], static_cast<uint32_t>(__popcll(b)));
 }
 
-// paint FrameData::dynamic_image (writeClustersToData, free_space_motion_detector.cpp:381-399):
-// sorted pixel j belongs to run (unique voxel) run_of[j]; run r carries the id of the last cluster that
-// contains it (0 = none).  One thread per sorted pixel; binary search of the run offsets.
-__global__ __launch_bounds__(256) void k_paint_dynamic(const uint32_t* __restrict__ sorted_pix,
-                                                      const uint32_t* __restrict__ run_offsets, int n_runs,
-                                                      const int32_t* __restrict__ run_id, int n_valid,
-                                                      int32_t* __restrict__ dyn) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_valid) return;
-  int lo = 0, hi = n_runs - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (run_offsets[mid] <= static_cast<uint32_t>(j)) lo = mid; else hi = mid - 1;
+// ----------------------------------------------------------------------------------------------
+// Seed-frame pipeline of the motion detector (clusterDynamicVoxels inputs, free_space_motion_detector.cpp
+// :205-272).  The reference's nested hash maps voxel -> pixels become two device hash tables keyed by the
+// packed global voxel index: the SEED voxels (ever-free voxels hit by a pixel) and the BOUNDARY voxels
+// (occupied non-seed voxels adjacent to a seed, the only non-seed voxels clustering ever touches), each
+// with its pixel count.  A device kernel resolves the neighbours of every seed to compact ids, the host
+// walks the (tiny) seed graph on ids only, and k_md_paint writes FrameData::dynamic_image by hash lookup.
+// ----------------------------------------------------------------------------------------------
+struct VoxTable {
+  uint64_t* keys;    // kEmptyKey = free
+  uint32_t* counts;  // pixels in the voxel
+  uint32_t* ids;     // compact id (after k_md_compact)
+  uint32_t mask;
+};
+
+__device__ inline int voxFind(const VoxTable& t, uint64_t key) {
+  uint32_t h = hashKey(key) & t.mask;
+  while (true) {
+    const uint64_t k = t.keys[h];
+    if (k == key) return static_cast<int>(h);
+    if (k == kEmptyKey) return -1;
+    h = (h + 1) & t.mask;
   }
-  const int id = run_id[lo];
-  if (id) dyn[sorted_pix[j]] = id;
+}
+
+__device__ inline uint32_t voxInsert(const VoxTable& t, uint64_t key) {
+  uint32_t h = hashKey(key) & t.mask;
+  while (true) {
+    const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&t.keys[h]),
+                                              static_cast<unsigned long long>(kEmptyKey), static_cast<unsigned long long>(key));
+    if (prev == kEmptyKey || prev == key) return h;
+    h = (h + 1) & t.mask;
+  }
+}
+
+__constant__ int8_t c_md_nbr26[26][3] = {
+    {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1},
+    {-1, -1, 0}, {-1, 1, 0}, {1, -1, 0}, {1, 1, 0}, {-1, 0, -1}, {-1, 0, 1}, {1, 0, -1}, {1, 0, 1},
+    {0, -1, -1}, {0, -1, 1}, {0, 1, -1}, {0, 1, 1},
+    {-1, -1, -1}, {-1, -1, 1}, {-1, 1, -1}, {-1, 1, 1}, {1, -1, -1}, {1, -1, 1}, {1, 1, -1}, {1, 1, 1}};
+
+__device__ inline uint64_t neighbourKey(uint64_t key, int k) {
+  int x, y, z;
+  unpackKey(key, &x, &y, &z);
+  return packKey(x + c_md_nbr26[k][0], y + c_md_nbr26[k][1], z + c_md_nbr26[k][2]);
+}
+
+__global__ __launch_bounds__(256) void k_md_seed_insert(const uint64_t* __restrict__ keys, int n, VoxTable seeds) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = keys[i];
+  if (k == ~0ull || !(k & kSeedBit)) return;
+  atomicAdd(&seeds.counts[voxInsert(seeds, k & ~kSeedBit)], 1u);
+}
+
+__global__ __launch_bounds__(256) void k_md_boundary_insert(const uint64_t* __restrict__ keys, int n, VoxTable seeds,
+                                                           VoxTable bnd, int nn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = keys[i];
+  if (k == ~0ull || (k & kSeedBit)) return;
+  bool adjacent = false;
+  for (int j = 0; j < nn && !adjacent; ++j) adjacent = voxFind(seeds, neighbourKey(k, j)) >= 0;
+  if (adjacent) atomicAdd(&bnd.counts[voxInsert(bnd, k)], 1u);
+}
+
+// occupied table slots -> compact lists (ids are arbitrary but stable for the rest of the frame)
+__global__ __launch_bounds__(256) void k_md_compact(VoxTable t, uint64_t* __restrict__ list_keys,
+                                                   uint32_t* __restrict__ list_counts, uint32_t* __restrict__ n_out,
+                                                   uint32_t cap) {
+  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool used = h <= t.mask && t.keys[h] != kEmptyKey;
+  const uint32_t id = waveAggInc(n_out, used);
+  if (used && id < cap) {
+    list_keys[id] = t.keys[h];
+    list_counts[id] = t.counts[h];
+    t.ids[h] = id;
+  }
+}
+
+// adj[s * nn + j]: bit 31 set = neighbour is seed id (low bits), else boundary id, 0xffffffff = none
+__global__ __launch_bounds__(256) void k_md_adjacency(const uint64_t* __restrict__ seed_keys,
+                                                     const uint32_t* __restrict__ n_seeds, VoxTable seeds, VoxTable bnd,
+                                                     int nn, uint32_t cap, uint32_t* __restrict__ adj) {
+  const uint32_t ns = min(*n_seeds, cap);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns * nn; i += gridDim.x * blockDim.x) {
+    const uint32_t s = i / nn, j = i % nn;
+    const uint64_t nk = neighbourKey(seed_keys[s], static_cast<int>(j));
+    uint32_t out = 0xffffffffu;
+    const int hs = voxFind(seeds, nk);
+    if (hs >= 0) {
+      out = 0x80000000u | seeds.ids[hs];
+    } else {
+      const int hb = voxFind(bnd, nk);
+      if (hb >= 0) out = bnd.ids[hb];
+    }
+    adj[i] = out;
+  }
+}
+
+// writeClustersToData (free_space_motion_detector.cpp:381-399): cluster id of the pixel's voxel (0 = none)
+__global__ __launch_bounds__(256) void k_md_paint(const uint64_t* __restrict__ keys, int n, VoxTable seeds, VoxTable bnd,
+                                                 const int32_t* __restrict__ seed_final,
+                                                 const int32_t* __restrict__ bnd_final, int32_t* __restrict__ dyn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = keys[i];
+  if (k == ~0ull) return;
+  int id = 0;
+  if (k & kSeedBit) {
+    const int h = voxFind(seeds, k & ~kSeedBit);
+    if (h >= 0) id = seed_final[seeds.ids[h]];
+  } else {
+    const int h = voxFind(bnd, k);
+    if (h >= 0) id = bnd_final[bnd.ids[h]];
+  }
+  if (id) dyn[i] = id;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -110,6 +211,13 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
   const uint32_t n = *n_work;
   for (uint32_t b = blockIdx.x; b < n; b += gridDim.x) {
     const size_t slot = work[b];
+    if (EMIT && new_count[slot] == 0u) {  // most mesh-updated blocks contain no surface: nothing to stage
+      if (threadIdx.x == 0) {
+        m.mesh_desc[slot] = MeshDesc{new_offset[slot], 0u};
+        if (clear_flag) m.blk_flags[slot] &= ~BLK_MESH_UPDATED;
+      }
+      continue;
+    }
     const int4 bi = m.blk_index[slot];
     __syncthreads();
     if (threadIdx.x < 8) {

@@ -8,43 +8,44 @@ namespace khr {
 constexpr int kBandShards = 16;  // the in-band record list is split in shards (one atomic cursor each)
 
 // ----------------------------------------------------------------------------------------------
-// k_parse_input: hydra::conversions::parseInputPacket role (active_window.cpp:275).
-// depth -> range image (z-depth or ray length), rgb u8x3 -> rgba8 (one aligned 4-byte gather per
-// pixel in the update kernel).  One thread per pixel, coalesced.
+// k_frame_ingest: hydra::conversions::parseInputPacket + FrameData allocation role
+// (active_window.cpp:268-286) in ONE pass over the frame: one workgroup per 16x16-pixel tile reads the
+// caller's depth / rgb / label once and writes the frame slot: depth copy, range image (z-depth or ray
+// length), rgb u8x3 -> rgba8 (one aligned 4-byte gather per pixel later), label copy, zeroed
+// dynamic_image, and the tile's max range (block culling).  Also resets the per-frame counters.
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_parse_input(const float* __restrict__ depth,
-                                                    const uint8_t* __restrict__ rgb, float* __restrict__ range,
-                                                    uint32_t* __restrict__ rgba, int W, int H, float fx, float fy,
-                                                    float cx, float cy, int range_mode) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= W * H) return;
-  const float d = depth[i];
-  float r = 0.f;
-  if (d > 0.f && isfinite(d)) {
-    if (range_mode == 0) {
-      r = d;
-    } else {
-      const int u = i % W, v = i / W;
-      const float x = (static_cast<float>(u) - cx) / fx, y = (static_cast<float>(v) - cy) / fy;
-      r = d * sqrtf((x * x + y * y) + 1.f);
-    }
-  }
-  range[i] = r;
-  if (rgb) {
-    const uint32_t c = static_cast<uint32_t>(rgb[3 * i]) | (static_cast<uint32_t>(rgb[3 * i + 1]) << 8) |
-                       (static_cast<uint32_t>(rgb[3 * i + 2]) << 16) | 0xff000000u;
-    rgba[i] = c;
-  }
-}
-
-// coarse max-range image: one value per 16x16 pixel tile (block-level culling in k_alloc_visible).
 constexpr int kTile = 16;
-__global__ __launch_bounds__(256) void k_range_tiles(const float* __restrict__ range, int W, int H,
-                                                    float* __restrict__ tile_max, int tw) {
+__global__ __launch_bounds__(256) void k_frame_ingest(const float* __restrict__ depth_in,
+                                                     const uint8_t* __restrict__ rgb_in,
+                                                     const int32_t* __restrict__ label_in, float* __restrict__ depth,
+                                                     float* __restrict__ range, uint32_t* __restrict__ rgba,
+                                                     int32_t* __restrict__ label, int32_t* __restrict__ dyn,
+                                                     float* __restrict__ tile_max, int tw, int W, int H, float fx,
+                                                     float fy, float cx, float cy, int range_mode,
+                                                     uint32_t* __restrict__ counters) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) counters[C_N_SEEDS] = 0u;
   const int tx = blockIdx.x % tw, ty = blockIdx.x / tw;
   const int u = tx * kTile + (threadIdx.x & 15), v = ty * kTile + (threadIdx.x >> 4);
   float r = 0.f;
-  if (u < W && v < H) r = range[v * W + u];
+  if (u < W && v < H) {
+    const int i = v * W + u;
+    const float d = depth_in[i];
+    if (d > 0.f && isfinite(d)) {
+      if (range_mode == 0) {
+        r = d;
+      } else {
+        const float x = (static_cast<float>(u) - cx) / fx, y = (static_cast<float>(v) - cy) / fy;
+        r = d * sqrtf((x * x + y * y) + 1.f);
+      }
+    }
+    depth[i] = d;
+    range[i] = r;
+    dyn[i] = 0;
+    if (rgb_in)
+      rgba[i] = static_cast<uint32_t>(rgb_in[3 * i]) | (static_cast<uint32_t>(rgb_in[3 * i + 1]) << 8) |
+                (static_cast<uint32_t>(rgb_in[3 * i + 2]) << 16) | 0xff000000u;
+    if (label_in) label[i] = label_in[i];
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) r = fmaxf(r, __shfl_down(r, o));
   __shared__ float s[4];
@@ -148,6 +149,7 @@ __global__ void k_begin_integrate(DevMap m, int nvox, uint32_t* band_count) {
     m.counters[C_N_NEW] = 0u;
     m.counters[C_N_TSDF] = 0u;
     m.counters[C_TSDF_CURSOR] = 0u;
+    m.counters[C_N_EF] = 0u;
   }
 }
 
@@ -385,6 +387,13 @@ struct TsdfArgs {
 // FAST = the reference default configuration (z-depth range, adaptive interpolation, weight drop-off,
 // no constant weight, no debug switches) resolved at compile time; the generic instantiation reads the
 // switches from the argument block.
+// workgroup barrier that orders LDS only: s_waitcnt lgkmcnt(0) + s_barrier.  HIP's __syncthreads() also
+// drains vmcnt, which would stall a workgroup until its pass-2 global stores are acknowledged.
+__device__ inline void ldsBarrier() {
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // vmcnt = 63 (no wait), expcnt = 7, lgkmcnt = 0
+  __builtin_amdgcn_s_barrier();
+}
+
 template <int VPS, int CHUNKS, bool FAST>
 __global__ __launch_bounds__(256) void k_tsdf_update(TsdfArgs a, const uint32_t* __restrict__ work,
                                                     const uint32_t* __restrict__ n_work,
@@ -399,6 +408,7 @@ __global__ __launch_bounds__(256) void k_tsdf_update(TsdfArgs a, const uint32_t*
   __shared__ __attribute__((aligned(16))) uint8_t s_flag[CV];  // bit0 in band, bit1 nearest interpolation
   __shared__ uint32_t s_wsum[4];
   __shared__ uint32_t s_base;
+  __shared__ uint32_t s_any[4];
   const uint32_t n = *n_work * CHUNKS;  // work item = one z-slab (chunk) of a block
   const int range_mode = FAST ? 0 : a.range_mode;
   const int interp = FAST ? 2 : a.interp;
@@ -418,6 +428,20 @@ __global__ __launch_bounds__(256) void k_tsdf_update(TsdfArgs a, const uint32_t*
     const float ox = static_cast<float>(bi.x) * a.bs, oy = static_cast<float>(bi.y) * a.bs,
                 oz = static_cast<float>(bi.z) * a.bs;
     const int cbase = chunk * CV;
+    // prefetch this thread's distance / weight vectors now: their HBM latency hides under pass 1
+    // (pass 2 maps thread <-> 4 consecutive voxels, group g = threadIdx.x + 256 * i)
+    constexpr int PER4 = CV / 1024 > 0 ? CV / 1024 : 1;
+    float4* __restrict__ dist4 = reinterpret_cast<float4*>(a.dist + slot * NV + cbase);
+    float4* __restrict__ wgt4 = reinterpret_cast<float4*>(a.weight + slot * NV + cbase);
+    float4 d_pre[PER4], w_pre[PER4];
+#pragma unroll
+    for (int i = 0; i < PER4; ++i) {
+      const int g = threadIdx.x + 256 * i;
+      if (g < CV / 4) {
+        d_pre[i] = dist4[g];
+        w_pre[i] = wgt4[g];
+      }
+    }
     uint32_t any = 0;
     // ---- pass 1: measurement per voxel -> LDS (branch-free; invalid lanes are masked by `ok`) ----
 #pragma unroll 2
@@ -437,30 +461,58 @@ __global__ __launch_bounds__(256) void k_tsdf_update(TsdfArgs a, const uint32_t*
       ok = ok && !(ceilf(u) >= Wf || floorf(u) < 0.f);
       const float v = (pc[1] * a.fy) / pc[2] + a.cy;
       ok = ok && !(ceilf(v) >= Hf || floorf(v) < 0.f);
+      // whole wave invalid (block partly outside the image / range): nothing to gather
+      if (!__any(ok)) {
+        s_sdf[cl] = 0.f;
+        s_w[cl] = 0.f;
+        s_flag[cl] = 0;
+        continue;
+      }
       // clamp the coordinates of invalid lanes so that the gathers stay inside the image
       const float uc = ok ? u : 0.f, vc = ok ? v : 0.f;
-      int px4[4];
-      float du, dv;
-      interpPixels(uc, vc, a.W, a.H, px4, &du, &dv);
+      const int u0 = static_cast<int>(floorf(uc)), v0 = static_cast<int>(floorf(vc));
+      const int u1 = min(u0 + 1, a.W - 1), v1 = min(v0 + 1, a.H - 1);
+      const float du = uc - static_cast<float>(u0), dv = vc - static_cast<float>(v0);
+      // pixel order: (u0,v0) (u0,v1) (u1,v0) (u1,v1); 32-bit element offsets from the scalar base pointer
+      const uint32_t row0 = static_cast<uint32_t>(v0 * a.W), row1 = static_cast<uint32_t>(v1 * a.W);
+      const uint32_t o0 = row0 + static_cast<uint32_t>(u0), o1 = row1 + static_cast<uint32_t>(u0),
+                     o2 = row0 + static_cast<uint32_t>(u1), o3 = row1 + static_cast<uint32_t>(u1);
       float r4[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) r4[k] = a.range[(dbg & 4) ? k : px4[k]];
+      if (dbg & 4) {
+        r4[0] = a.range[0]; r4[1] = a.range[1]; r4[2] = a.range[2]; r4[3] = a.range[3];
+      } else {
+        r4[0] = a.range[o0]; r4[1] = a.range[o1]; r4[2] = a.range[o2]; r4[3] = a.range[o3];
+      }
       bool use_nearest = interp == 0;
       if (interp == 2) {
         const float mn = fminf(fminf(r4[0], r4[1]), fminf(r4[2], r4[3]));
         const float mx = fmaxf(fmaxf(r4[0], r4[1]), fmaxf(r4[2], r4[3]));
         use_nearest = use_nearest || (mx - mn > a.adaptive_diff);
       }
-      float w4[4];
-      const int best = interpWeights(du, dv, use_nearest, w4);
-      const float dist_surface = ((w4[0] * r4[0] + w4[1] * r4[1]) + w4[2] * r4[2]) + w4[3] * r4[3];
+      // interpolateRange: bilinear sum, or the one-hot nearest sample (1*r + 0*.. == r for finite ranges)
+      const bool hi_u = du >= 0.5f, hi_v = dv >= 0.5f;
+      const float r_near = hi_u ? (hi_v ? r4[3] : r4[2]) : (hi_v ? r4[1] : r4[0]);
+      const float w0 = (1.f - du) * (1.f - dv), w1 = (1.f - du) * dv, w2 = du * (1.f - dv), w3 = du * dv;
+      const float r_bil = ((w0 * r4[0] + w1 * r4[1]) + w2 * r4[2]) + w3 * r4[3];
+      const float dist_surface = use_nearest ? r_near : r_bil;
       ok = ok && (dist_surface >= a.min_range) && !(dist_surface > a.max_range);
       const float sdf = dist_surface - voxel_range;
       ok = ok && !(sdf < -a.trunc);
       bool in_band = ok && (fabsf(sdf) < a.trunc);
-      if (a.use_mask) {
-        const int bpx = best == 0 ? px4[0] : (best == 1 ? px4[1] : (best == 2 ? px4[2] : px4[3]));
-        if (in_band && a.dyn[bpx] != 0) {
+      if (a.use_mask && in_band) {
+        // interpolateID(mask): pixel of the largest weight (first maximum)
+        int best;
+        if (use_nearest) {
+          best = (hi_u ? 2 : 0) + (hi_v ? 1 : 0);
+        } else {
+          best = 0;
+          float bw = w0;
+          if (w1 > bw) { bw = w1; best = 1; }
+          if (w2 > bw) { bw = w2; best = 2; }
+          if (w3 > bw) { bw = w3; best = 3; }
+        }
+        const uint32_t bpx = best == 0 ? o0 : (best == 1 ? o1 : (best == 2 ? o2 : o3));
+        if (a.dyn[bpx] != 0) {
           ok = false;
           in_band = false;
         }
@@ -468,9 +520,8 @@ __global__ __launch_bounds__(256) void k_tsdf_update(TsdfArgs a, const uint32_t*
       const float q = a.vs / pc[2];
       float w = (a.fx * a.fy) * (q * q);
       if (!const_weight) w = w / (pc[2] * pc[2]);
-      if (use_dropoff) {
-        const float wd = fmaxf(w * ((a.trunc + sdf) / (a.trunc - a.dropoff_eps)), 0.f);
-        w = (sdf < -a.dropoff_eps) ? wd : w;
+      if (use_dropoff && sdf < -a.dropoff_eps) {  // only lanes behind the surface pay for this division
+        w = fmaxf(w * ((a.trunc + sdf) / (a.trunc - a.dropoff_eps)), 0.f);
       }
       ok = ok && (w > 0.f);
       in_band = in_band && ok;
@@ -482,7 +533,10 @@ __global__ __launch_bounds__(256) void k_tsdf_update(TsdfArgs a, const uint32_t*
       n_band += in_band ? 1u : 0u;
       any |= ok ? 1u : 0u;
     }
-    const int any_blk = __syncthreads_or(static_cast<int>(any));
+    if ((threadIdx.x & 63) == 0) s_any[threadIdx.x >> 6] = 0u;
+    if (__any(any != 0u) && (threadIdx.x & 63) == 0) s_any[threadIdx.x >> 6] = 1u;
+    ldsBarrier();
+    const int any_blk = static_cast<int>(s_any[0] | s_any[1] | s_any[2] | s_any[3]);
     if (dbg & 8) t_p1 = __builtin_amdgcn_s_memtime();
     // ---- in-band records: block-wide exclusive scan, ONE atomic per workgroup ------------------
     if (any_blk && !(dbg & 2)) {
@@ -502,7 +556,7 @@ __global__ __launch_bounds__(256) void k_tsdf_update(TsdfArgs a, const uint32_t*
         if ((threadIdx.x & 63) >= static_cast<uint32_t>(o)) incl += t;
       }
       if ((threadIdx.x & 63) == 63) s_wsum[threadIdx.x >> 6] = incl;
-      __syncthreads();
+      ldsBarrier();
       const uint32_t wv = threadIdx.x >> 6;
       uint32_t woff = 0;
 #pragma unroll
@@ -510,7 +564,7 @@ __global__ __launch_bounds__(256) void k_tsdf_update(TsdfArgs a, const uint32_t*
       const uint32_t total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
       const uint32_t shard = blockIdx.x & (kBandShards - 1);
       if (threadIdx.x == 0) s_base = total ? atomicAdd(&band_count[shard * 32], total) : 0u;
-      __syncthreads();
+      ldsBarrier();
       if (cnt) {
         uint32_t pos = s_base + woff + incl - cnt;
         BandRec* __restrict__ dst = band + static_cast<size_t>(shard) * shard_cap;
@@ -537,14 +591,15 @@ __global__ __launch_bounds__(256) void k_tsdf_update(TsdfArgs a, const uint32_t*
     if (dbg & 8) t_rec = __builtin_amdgcn_s_memtime();
     // ---- pass 2: vectorised running-average update of the voxel arrays -----------------------
     if (any_blk && !(dbg & 1)) {
-      float4* __restrict__ dist4 = reinterpret_cast<float4*>(a.dist + slot * NV + cbase);
-      float4* __restrict__ wgt4 = reinterpret_cast<float4*>(a.weight + slot * NV + cbase);
       uint64_t* __restrict__ lobs = a.last_obs + slot * NV + cbase;
-      for (int g = threadIdx.x; g < CV / 4; g += 256) {
+#pragma unroll
+      for (int i = 0; i < PER4; ++i) {
+        const int g = threadIdx.x + 256 * i;
+        if (g >= CV / 4) continue;
         const float4 mw = reinterpret_cast<const float4*>(s_w)[g];
         if (!(mw.x > 0.f || mw.y > 0.f || mw.z > 0.f || mw.w > 0.f)) continue;
         const float4 ms = reinterpret_cast<const float4*>(s_sdf)[g];
-        float4 d = dist4[g], w = wgt4[g];
+        float4 d = d_pre[i], w = w_pre[i];
         if (mw.x > 0.f) { d.x = (d.x * w.x + ms.x * mw.x) / (w.x + mw.x); w.x = fminf(w.x + mw.x, a.max_weight); }
         if (mw.y > 0.f) { d.y = (d.y * w.y + ms.y * mw.y) / (w.y + mw.y); w.y = fminf(w.y + mw.y, a.max_weight); }
         if (mw.z > 0.f) { d.z = (d.z * w.z + ms.z * mw.z) / (w.z + mw.z); w.z = fminf(w.z + mw.z, a.max_weight); }
@@ -563,7 +618,7 @@ __global__ __launch_bounds__(256) void k_tsdf_update(TsdfArgs a, const uint32_t*
         else atomicOr(&a.blk_flags[slot], BLK_UPDATED | BLK_MESH_UPDATED | BLK_TRACKING_UPDATED);
       }
     }
-    __syncthreads();  // LDS tile is reused by the next work item of this workgroup
+    ldsBarrier();  // LDS tile is reused by the next work item of this workgroup
     if ((dbg & 8) && (threadIdx.x & 63) == 0 && wi < 4096) {
       unsigned long long* o = a.dbg_buf + (static_cast<size_t>(wi) * 4 + (threadIdx.x >> 6)) * 8;
       o[0] = t_start;
@@ -726,32 +781,60 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
     const uint32_t fl = m.blk_flags[s];
     if (!(fl & BLK_LIVE)) continue;  // uniform per workgroup
     const size_t slot = s;
-    const float* __restrict__ dist = m.dist + slot * NV;
-    const uint64_t* __restrict__ lobs = m.last_obs + slot * NV;
-    uint64_t* __restrict__ locc = m.last_occ + slot * NV;
-    uint8_t* __restrict__ vfl = m.vflags + slot * NV;
+    // thread <-> 4 consecutive voxels: 16-byte loads of distance / flags, 2 x 16-byte of the stamps
+    const float4* __restrict__ dist4 = reinterpret_cast<const float4*>(m.dist + slot * NV);
+    const ulonglong2* __restrict__ lobs2 = reinterpret_cast<const ulonglong2*>(m.last_obs + slot * NV);
+    ulonglong2* __restrict__ locc2 = reinterpret_cast<ulonglong2*>(m.last_occ + slot * NV);
+    uint32_t* __restrict__ vfl4 = reinterpret_cast<uint32_t*>(m.vflags + slot * NV);
     uint64_t* __restrict__ fb = m.freebits + slot * (NV / 64);
     bool any_active = false;
-    for (int lin = threadIdx.x; lin < NV; lin += 256) {
-      const float d = dist[lin];
-      const uint64_t lo = lobs[lin];
-      uint8_t v = vfl[lin];
-      uint64_t occ;
-      if (d < p.occ_thr) {
-        occ = stamp;
-        locc[lin] = stamp;
-      } else {
-        occ = locc[lin];
+    for (int g = threadIdx.x; g < NV / 4; g += 256) {
+      const float4 d = dist4[g];
+      const ulonglong2 oa = lobs2[2 * g], ob = lobs2[2 * g + 1];
+      const uint32_t v4 = vfl4[g];
+      const float dd[4] = {d.x, d.y, d.z, d.w};
+      const uint64_t lo[4] = {oa.x, oa.y, ob.x, ob.y};
+      bool occ[4];
+      bool all_occ = true, none_occ = true;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        occ[k] = dd[k] < p.occ_thr;
+        all_occ = all_occ && occ[k];
+        none_occ = none_occ && !occ[k];
       }
-      const bool was_active = v & VOX_ACTIVE;
-      const bool active = toSeconds(lo) >= t_active;
-      uint8_t nv = static_cast<uint8_t>((v & ~VOX_ACTIVE) | (active ? VOX_ACTIVE : 0));
-      if (was_active && !active) nv |= VOX_TO_REMOVE;
-      if (nv != v) vfl[lin] = nv;
-      any_active |= active;
-      const bool is_free = (toSeconds(occ) < t_free) && (lo != 0ull);
-      const unsigned long long bits = __ballot((nv & VOX_EVER_FREE) || is_free);
-      if ((threadIdx.x & 63) == 0) fb[lin >> 6] = bits;
+      // last_occupied: read only where some voxel of the pair is NOT occupied, write only where one is
+      ulonglong2 ca = make_ulonglong2(stamp, stamp), cb = ca;
+      if (!(occ[0] && occ[1])) ca = locc2[2 * g];
+      if (!(occ[2] && occ[3])) cb = locc2[2 * g + 1];
+      uint64_t oc[4] = {ca.x, ca.y, cb.x, cb.y};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (occ[k]) oc[k] = stamp;
+      if (occ[0] || occ[1]) locc2[2 * g] = make_ulonglong2(oc[0], oc[1]);
+      if (occ[2] || occ[3]) locc2[2 * g + 1] = make_ulonglong2(oc[2], oc[3]);
+      uint32_t nv4 = 0, freebits4 = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint8_t v = static_cast<uint8_t>(v4 >> (8 * k));
+        const bool was_active = v & VOX_ACTIVE;
+        const bool active = toSeconds(lo[k]) >= t_active;
+        uint8_t nv = static_cast<uint8_t>((v & ~VOX_ACTIVE) | (active ? VOX_ACTIVE : 0));
+        if (was_active && !active) nv |= VOX_TO_REMOVE;
+        any_active |= active;
+        const bool is_free = (toSeconds(oc[k]) < t_free) && (lo[k] != 0ull);
+        if ((nv & VOX_EVER_FREE) || is_free) freebits4 |= 1u << k;
+        nv4 |= static_cast<uint32_t>(nv) << (8 * k);
+      }
+      if (nv4 != v4) vfl4[g] = nv4;
+      // 4 bits per lane -> 64-bit words: 16 consecutive lanes form one word (OR-reduce over the group)
+      uint64_t w = static_cast<uint64_t>(freebits4) << (4 * (threadIdx.x & 15));
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const uint32_t lo32 = __shfl_xor(static_cast<uint32_t>(w), o);
+        const uint32_t hi32 = __shfl_xor(static_cast<uint32_t>(w >> 32), o);
+        w |= (static_cast<uint64_t>(hi32) << 32) | lo32;
+      }
+      if ((threadIdx.x & 15) == 0) fb[g >> 4] = w;
     }
     const int act = __syncthreads_or(any_active ? 1 : 0);
     if (threadIdx.x == 0) {
@@ -791,7 +874,8 @@ __global__ __launch_bounds__(256) void k_ever_free(DevMap m, DevParams p, const 
   constexpr int NV = VPS * VPS * VPS;
   constexpr int NW = NV / 64;
   constexpr int T = VPS + 2;
-  __shared__ uint8_t tile[T * T * T];
+  // one (VPS+2)-bit row per (y, z) of the halo tile: bit (x+1) = free-or-ever-free of voxel x of that row
+  __shared__ uint32_t s_row[T * T];
   __shared__ uint64_t s_bits[27][NW];
   __shared__ const uint64_t* s_src[27];
   const uint32_t n = m.counters[C_N_EF];
@@ -826,31 +910,51 @@ __global__ __launch_bounds__(256) void k_ever_free(DevMap m, DevParams p, const 
       s_bits[i / NW][i % NW] = src ? src[i % NW] : 0ull;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < T * T * T; c += 256) {
-      const int tx = c % T, ty = (c / T) % T, tz = c / (T * T);
-      int x = tx - 1, y = ty - 1, z = tz - 1;
-      int sx = 1, sy = 1, sz = 1;
-      if (x < 0) { x += VPS; sx = 0; } else if (x >= VPS) { x -= VPS; sx = 2; }
+    // assemble the rows: row (ty, tz) of the tile = voxels x = -1 .. VPS of (y, z) = (ty-1, tz-1)
+    for (int r = threadIdx.x; r < T * T; r += 256) {
+      const int ty = r % T, tz = r / T;
+      int y = ty - 1, z = tz - 1, sy = 1, sz = 1;
       if (y < 0) { y += VPS; sy = 0; } else if (y >= VPS) { y -= VPS; sy = 2; }
       if (z < 0) { z += VPS; sz = 0; } else if (z >= VPS) { z -= VPS; sz = 2; }
-      const int lin = x + VPS * (y + VPS * z);
-      tile[c] = static_cast<uint8_t>((s_bits[sx + 3 * sy + 9 * sz][lin >> 6] >> (lin & 63)) & 1ull);
+      const int lin0 = VPS * (y + VPS * z);  // voxel x = 0 of the row; a row never straddles a 64-bit word
+      const uint32_t mid = static_cast<uint32_t>((s_bits[1 + 3 * sy + 9 * sz][lin0 >> 6] >> (lin0 & 63)) & ((1u << VPS) - 1u));
+      const uint32_t left = static_cast<uint32_t>((s_bits[0 + 3 * sy + 9 * sz][(lin0 + VPS - 1) >> 6] >> ((lin0 + VPS - 1) & 63)) & 1u);
+      const uint32_t right = static_cast<uint32_t>((s_bits[2 + 3 * sy + 9 * sz][lin0 >> 6] >> (lin0 & 63)) & 1u);
+      s_row[r] = left | (mid << 1) | (right << (VPS + 1));
     }
     __syncthreads();
+    // one thread per row of the block: AND of the (shifted) neighbour rows, by connectivity
     uint8_t* __restrict__ vfl = m.vflags + slot * NV;
-    for (int lin = threadIdx.x; lin < NV; lin += 256) {
-      const int ix = lin % VPS, iy = (lin / VPS) % VPS, iz = lin / (VPS * VPS);
-      const int c0 = (ix + 1) + T * ((iy + 1) + T * (iz + 1));
-      if (!tile[c0]) continue;  // not free (and not ever-free)
-      bool ok = true;
-      for (int k = 0; k < p.nn; ++k) {
-        const int c = c0 + c_nbr26[k][0] + T * (c_nbr26[k][1] + T * c_nbr26[k][2]);
-        ok = ok && tile[c];
+    for (int r = threadIdx.x; r < VPS * VPS; r += 256) {
+      const int iy = r % VPS, iz = r / VPS;
+      const int c = (iy + 1) + T * (iz + 1);
+      const uint32_t self = s_row[c];
+      uint32_t ok = self & (self >> 1) & (self << 1);  // (+-1, 0, 0)
+      // rows with one of (dy, dz) non-zero: faces (dx = 0) and, for 18 / 26, edges (dx = +-1)
+      const uint32_t f1[4] = {s_row[c - 1], s_row[c + 1], s_row[c - T], s_row[c + T]};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ok &= f1[k];
+        if (p.nn >= 18) ok &= (f1[k] >> 1) & (f1[k] << 1);
       }
-      if (!ok) continue;
-      // the tile bit is (ever_free || free): only voxels that are not yet ever-free need the store
-      const uint8_t v = vfl[lin];
-      if (!(v & VOX_EVER_FREE)) vfl[lin] = v | VOX_EVER_FREE;
+      if (p.nn >= 18) {
+        // rows with both dy and dz non-zero: edges (dx = 0) and, for 26, corners (dx = +-1)
+        const uint32_t f2[4] = {s_row[c - 1 - T], s_row[c + 1 - T], s_row[c - 1 + T], s_row[c + 1 + T]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          ok &= f2[k];
+          if (p.nn == 26) ok &= (f2[k] >> 1) & (f2[k] << 1);
+        }
+      }
+      uint32_t cand = (ok >> 1) & ((1u << VPS) - 1u);  // bit x set <=> voxel (x, iy, iz) may become ever-free
+      // the row bit is (ever_free || free): only voxels that are not yet ever-free need the store
+      const int base = VPS * (iy + VPS * iz);
+      while (cand) {
+        const int x = __ffs(cand) - 1;
+        cand &= cand - 1u;
+        const uint8_t v = vfl[base + x];
+        if (!(v & VOX_EVER_FREE)) vfl[base + x] = v | VOX_EVER_FREE;
+      }
     }
   }
 }

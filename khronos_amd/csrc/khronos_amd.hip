@@ -103,11 +103,19 @@ struct khr_ctx {
   int4* d_removed = nullptr;
   int* d_idx_staging = nullptr;
   // motion detection scratch
-  uint64_t *d_keys = nullptr, *d_keys_sorted = nullptr, *d_unique = nullptr;
-  uint32_t *d_pix = nullptr, *d_pix_sorted = nullptr, *d_counts = nullptr, *d_num_runs = nullptr,
-           *d_run_offsets = nullptr;
-  int32_t* d_run_id = nullptr;
+  uint64_t* d_keys = nullptr;
+  uint32_t* d_pix = nullptr;
   void* d_cub_temp = nullptr;
+  // motion detector voxel tables (seed table followed by boundary table) and compact lists
+  uint64_t* d_md_keys = nullptr;
+  uint32_t *d_md_counts = nullptr, *d_md_ids = nullptr, *d_md_n = nullptr, *d_md_adj = nullptr;
+  uint64_t *d_md_seed_keys = nullptr, *d_md_bnd_keys = nullptr;
+  uint32_t *d_md_seed_counts = nullptr, *d_md_bnd_counts = nullptr;
+  int32_t *d_md_seed_final = nullptr, *d_md_bnd_final = nullptr;
+  uint32_t md_mask = 0, md_list_cap = 0;
+  std::vector<uint64_t> h_md_seed_keys, h_md_bnd_keys;
+  std::vector<uint32_t> h_md_seed_counts, h_md_bnd_counts, h_md_adj;
+  std::vector<int32_t> h_md_seed_final, h_md_bnd_final;
   size_t cub_temp_bytes = 0;
   // mesh
   MeshBuffers mesh[2]{};
@@ -126,6 +134,7 @@ struct khr_ctx {
   // timing
   bool timing = false;
   std::vector<TimingRec> pending;
+  std::vector<hipEvent_t> event_pool;
   double t_ms[kNumTimers] = {0};
   uint64_t t_n[kNumTimers] = {0};
 };
@@ -138,8 +147,18 @@ struct ScopedTimer {
   hipEvent_t a = nullptr, b = nullptr;
   ScopedTimer(khr_ctx* ctx, int w) : c(ctx), which(w) {
     if (c->timing) {
-      hipEventCreate(&a);
-      hipEventCreate(&b);
+      auto get = [&]() {
+        hipEvent_t e = nullptr;
+        if (!c->event_pool.empty()) {
+          e = c->event_pool.back();
+          c->event_pool.pop_back();
+        } else {
+          hipEventCreate(&e);
+        }
+        return e;
+      };
+      a = get();
+      b = get();
       hipEventRecord(a, c->stream);
     }
   }
@@ -158,8 +177,8 @@ void resolveTimers(khr_ctx* c) {
     hipEventElapsedTime(&ms, r.a, r.b);
     c->t_ms[r.which] += ms;
     c->t_n[r.which] += 1;
-    hipEventDestroy(r.a);
-    hipEventDestroy(r.b);
+    c->event_pool.push_back(r.a);
+    c->event_pool.push_back(r.b);
   }
   c->pending.clear();
 }
@@ -439,24 +458,29 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &c->d_mesh_nwork, 4));
   const size_t npx = cfg->max_frame_pixels;
   A(devAlloc(c, &c->d_keys, npx, false));
-  A(devAlloc(c, &c->d_keys_sorted, npx, false));
-  A(devAlloc(c, &c->d_unique, npx, false));
   A(devAlloc(c, &c->d_pix, npx, false));
-  A(devAlloc(c, &c->d_pix_sorted, npx, false));
-  A(devAlloc(c, &c->d_counts, npx, false));
-  A(devAlloc(c, &c->d_run_offsets, npx, false));
-  A(devAlloc(c, &c->d_run_id, npx, false));
-  A(devAlloc(c, &c->d_num_runs, 4));
+  {
+    // voxel tables: every pixel can at most open one voxel; 2x slots keep probing short
+    uint32_t ts = 1;
+    while (ts < 2 * npx) ts <<= 1;
+    c->md_mask = ts - 1;
+    c->md_list_cap = static_cast<uint32_t>(std::min<size_t>(npx, 1u << 20));
+    A(devAlloc(c, &c->d_md_keys, 2 * static_cast<size_t>(ts), false));
+    A(devAlloc(c, &c->d_md_counts, 2 * static_cast<size_t>(ts), false));
+    A(devAlloc(c, &c->d_md_ids, 2 * static_cast<size_t>(ts), false));
+    A(devAlloc(c, &c->d_md_n, 4));
+    A(devAlloc(c, &c->d_md_seed_keys, c->md_list_cap, false));
+    A(devAlloc(c, &c->d_md_bnd_keys, c->md_list_cap, false));
+    A(devAlloc(c, &c->d_md_seed_counts, c->md_list_cap, false));
+    A(devAlloc(c, &c->d_md_bnd_counts, c->md_list_cap, false));
+    A(devAlloc(c, &c->d_md_seed_final, c->md_list_cap, false));
+    A(devAlloc(c, &c->d_md_bnd_final, c->md_list_cap, false));
+    A(devAlloc(c, &c->d_md_adj, static_cast<size_t>(c->md_list_cap) * 26, false));
+  }
   if (rc == KHR_OK) {
-    size_t t1 = 0, t2 = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, t1, c->d_keys, c->d_keys_sorted, c->d_pix, c->d_pix_sorted,
-                                       static_cast<int>(npx), 0, 64, c->stream);
-    hipcub::DeviceRunLengthEncode::Encode(nullptr, t2, c->d_keys_sorted, c->d_unique, c->d_counts, c->d_num_runs,
-                                          static_cast<int>(npx), c->stream);
     size_t t3 = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, t3, c->d_mesh_count, c->d_mesh_offset, static_cast<int>(cap + 1),
-                                     c->stream);
-    c->cub_temp_bytes = std::max(std::max(t1, t2), t3) + 256;
+    hipcub::DeviceScan::ExclusiveSum(nullptr, t3, c->d_mesh_count, c->d_mesh_offset, static_cast<int>(cap + 1), c->stream);
+    c->cub_temp_bytes = t3 + 256;
     uint8_t* tmp = nullptr;
     A(devAlloc(c, &tmp, c->cub_temp_bytes, false));
     c->d_cub_temp = tmp;
@@ -509,6 +533,7 @@ void khr_destroy(khr_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   resolveTimers(c);
+  for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
   for (void* p : c->allocs) hipFree(p);
   if (c->d_halo_recs) { hipFree(c->d_halo_recs); hipFree(c->d_halo_keys); hipFree(c->d_halo_vals); }
   if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -560,24 +585,26 @@ int khr_upload_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fram
   s.has_label = frame->label != nullptr;
   s.has_obj = false;
   ScopedTimer tm(c, 6);
-  HIP_TRY(hipMemcpyAsync(s.depth, frame->depth, n * sizeof(float), kind, c->stream));
-  const uint8_t* rgb_dev = nullptr;
-  if (frame->color) {
-    if (on_device) {
-      rgb_dev = frame->color;
-    } else {
+  const float* depth_src = frame->depth;
+  const uint8_t* rgb_src = frame->color;
+  const int32_t* label_src = frame->label;
+  if (!on_device) {  // host buffers: stage them in the slot, the ingest kernel then works in place
+    HIP_TRY(hipMemcpyAsync(s.depth, frame->depth, n * sizeof(float), kind, c->stream));
+    depth_src = s.depth;
+    if (frame->color) {
       HIP_TRY(hipMemcpyAsync(s.rgb_staging, frame->color, n * 3, kind, c->stream));
-      rgb_dev = s.rgb_staging;
+      rgb_src = s.rgb_staging;
+    }
+    if (frame->label) {
+      HIP_TRY(hipMemcpyAsync(s.label, frame->label, n * sizeof(int32_t), kind, c->stream));
+      label_src = s.label;
     }
   }
-  if (frame->label) HIP_TRY(hipMemcpyAsync(s.label, frame->label, n * sizeof(int32_t), kind, c->stream));
-  HIP_TRY(hipMemsetAsync(s.dyn, 0, n * sizeof(int32_t), c->stream));
-  hipLaunchKernelGGL(k_parse_input, dim3(gridFor(n)), dim3(256), 0, c->stream, s.depth, rgb_dev, s.range, s.rgba,
-                     sensor->width, sensor->height, sensor->fx, sensor->fy, sensor->cx, sensor->cy, c->p.range_mode);
   s.tw = (sensor->width + kTile - 1) / kTile;
   s.th = (sensor->height + kTile - 1) / kTile;
-  hipLaunchKernelGGL(k_range_tiles, dim3(s.tw * s.th), dim3(256), 0, c->stream, s.range, sensor->width, sensor->height,
-                     s.tile_max, s.tw);
+  hipLaunchKernelGGL(k_frame_ingest, dim3(s.tw * s.th), dim3(256), 0, c->stream, depth_src, rgb_src, label_src, s.depth,
+                     s.range, s.rgba, s.label, s.dyn, s.tile_max, s.tw, sensor->width, sensor->height, sensor->fx, sensor->fy,
+                     sensor->cx, sensor->cy, c->p.range_mode, c->m.counters);
   HIP_TRY(hipGetLastError());
   if (!on_device) HIP_TRY(hipStreamSynchronize(c->stream));  // caller buffers may be reused after return
   s.valid = true;
@@ -826,9 +853,12 @@ int khr_import_halo(khr_ctx* c, const void* records, int64_t n_records, int on_d
 // ---------------------------------------------------------------------------------------------
 // motion detection, part 1: per-pixel pass; the seed-pixel count travels to pinned host memory
 // asynchronously so that other kernels can be queued behind it before the host has to look at it
-static int motionLaunch(khr_ctx* c, FrameSlot& s) {
+static int motionLaunch(khr_ctx* c, FrameSlot& s, bool fresh_slot) {
   const size_t n = static_cast<size_t>(s.sensor.width) * s.sensor.height;
-  HIP_TRY(hipMemsetAsync(s.dyn, 0, n * sizeof(int32_t), c->stream));
+  if (!fresh_slot) {  // a slot that was just ingested already has a zero dynamic image and seed counter
+    HIP_TRY(hipMemsetAsync(s.dyn, 0, n * sizeof(int32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(&c->m.counters[C_N_SEEDS], 0, sizeof(uint32_t), c->stream));
+  }
   c->stats.n_seeds = 0;
   c->h_pinned[0] = 0;
   if (!c->cfg.with_tracking) return KHR_OK;
@@ -836,7 +866,6 @@ static int motionLaunch(khr_ctx* c, FrameSlot& s) {
   const DevFrame f = makeDevFrame(c, s);
   // free_space_motion_detector.cpp:80
   const float min_z_world = static_cast<float>(s.meta.world_T_sensor[11] + static_cast<double>(c->cfg.md_min_z_coordinate));
-  HIP_TRY(hipMemsetAsync(&m.counters[C_N_SEEDS], 0, sizeof(uint32_t), c->stream));
   {
     ScopedTimer tm(c, 4);
     hipLaunchKernelGGL(k_motion_pixels, dim3(gridFor(n)), dim3(256), 0, c->stream, m, c->p, f, c->cfg.md_max_range,
@@ -852,102 +881,98 @@ static int motionLaunch(khr_ctx* c, FrameSlot& s) {
 // walk the seed graph on the host and paint the dynamic image.  Returns the number of clusters.
 static int motionFinish(khr_ctx* c, FrameSlot& s) {
   if (!c->cfg.with_tracking) return 0;
-  const size_t n = static_cast<size_t>(s.sensor.width) * s.sensor.height;
-  DevMap& m = c->m;
-  (void)m;
+  const int n = s.sensor.width * s.sensor.height;
   HIP_TRY(hipEventSynchronize(c->ev_seed));
   if (c->h_pinned[0] == 0) return 0;
 
-  size_t tb = c->cub_temp_bytes;
-  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->d_cub_temp, tb, c->d_keys, c->d_keys_sorted, c->d_pix, c->d_pix_sorted,
-                                             static_cast<int>(n), 0, 64, c->stream));
-  tb = c->cub_temp_bytes;
-  HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(c->d_cub_temp, tb, c->d_keys_sorted, c->d_unique, c->d_counts,
-                                                c->d_num_runs, static_cast<int>(n), c->stream));
-  uint32_t n_runs = 0;
-  HIP_TRY(hipMemcpyAsync(&n_runs, c->d_num_runs, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  // ---- device: seed / boundary voxel tables, compact lists, seed adjacency ------------------------
+  const int nn = c->cfg.md_neighbor_connectivity;
+  const size_t tsize = static_cast<size_t>(c->md_mask) + 1;
+  VoxTable seeds{c->d_md_keys, c->d_md_counts, c->d_md_ids, c->md_mask};
+  VoxTable bnd{c->d_md_keys + tsize, c->d_md_counts + tsize, c->d_md_ids + tsize, c->md_mask};
+  HIP_TRY(hipMemsetAsync(c->d_md_keys, 0xff, sizeof(uint64_t) * 2 * tsize, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_md_counts, 0, sizeof(uint32_t) * 2 * tsize, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_md_n, 0, sizeof(uint32_t) * 2, c->stream));
+  hipLaunchKernelGGL(k_md_seed_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds);
+  hipLaunchKernelGGL(k_md_boundary_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds, bnd, nn);
+  const uint32_t cap = c->md_list_cap;
+  hipLaunchKernelGGL(k_md_compact, dim3(gridFor(tsize)), dim3(256), 0, c->stream, seeds, c->d_md_seed_keys,
+                     c->d_md_seed_counts, c->d_md_n, cap);
+  hipLaunchKernelGGL(k_md_compact, dim3(gridFor(tsize)), dim3(256), 0, c->stream, bnd, c->d_md_bnd_keys, c->d_md_bnd_counts,
+                     c->d_md_n + 1, cap);
+  hipLaunchKernelGGL(k_md_adjacency, dim3(1024), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_n, seeds, bnd, nn, cap,
+                     c->d_md_adj);
+  uint32_t cnt[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(cnt, c->d_md_n, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  std::vector<uint64_t> keys(n_runs);
-  std::vector<uint32_t> counts(n_runs);
-  HIP_TRY(hipMemcpyAsync(keys.data(), c->d_unique, sizeof(uint64_t) * n_runs, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(counts.data(), c->d_counts, sizeof(uint32_t) * n_runs, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  if (n_runs && keys[n_runs - 1] == ~0ull) --n_runs;  // skipped pixels sort last
-  // runs are sorted by key: [non-seed voxels ascending][seed voxels ascending]
-  uint32_t first_seed = n_runs;
-  {
-    auto it = std::lower_bound(keys.begin(), keys.begin() + n_runs, kSeedBit);
-    first_seed = static_cast<uint32_t>(it - keys.begin());
+  const uint32_t S = cnt[0], B = cnt[1];
+  if (S > cap || B > cap) return fail(KHR_ENOMEM, "motion detector: %u seed / %u boundary voxels exceed the list capacity %u", S, B, cap);
+  c->stats.n_seeds = S;
+  std::vector<uint64_t>& sk = c->h_md_seed_keys;
+  std::vector<uint64_t>& bk = c->h_md_bnd_keys;
+  std::vector<uint32_t>&sc = c->h_md_seed_counts, &bc = c->h_md_bnd_counts, &adj = c->h_md_adj;
+  sk.resize(S); sc.resize(S); adj.resize(static_cast<size_t>(S) * nn); bk.resize(B); bc.resize(B);
+  HIP_TRY(hipMemcpyAsync(sk.data(), c->d_md_seed_keys, sizeof(uint64_t) * S, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(sc.data(), c->d_md_seed_counts, sizeof(uint32_t) * S, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(adj.data(), c->d_md_adj, sizeof(uint32_t) * S * nn, hipMemcpyDeviceToHost, c->stream));
+  if (B) {
+    HIP_TRY(hipMemcpyAsync(bk.data(), c->d_md_bnd_keys, sizeof(uint64_t) * B, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(bc.data(), c->d_md_bnd_counts, sizeof(uint32_t) * B, hipMemcpyDeviceToHost, c->stream));
   }
-  std::vector<uint32_t> offsets(n_runs + 1, 0);
-  for (uint32_t i = 0; i < n_runs; ++i) offsets[i + 1] = offsets[i] + counts[i];
-  const uint32_t n_valid = offsets[n_runs];
-  const uint32_t n_seed_vox = n_runs - first_seed;
-  c->stats.n_seeds = n_seed_vox;
+  HIP_TRY(hipStreamSynchronize(c->stream));
 
-  auto findRun = [&](uint64_t k, bool seed) -> int {
-    const uint64_t kk = seed ? (k | kSeedBit) : k;
-    auto b = keys.begin() + (seed ? first_seed : 0), e = keys.begin() + (seed ? n_runs : first_seed);
-    auto it = std::lower_bound(b, e, kk);
-    return (it != e && *it == kk) ? static_cast<int>(it - keys.begin()) : -1;
-  };
+  // ---- host: the seed-graph walk on compact ids (sequential in the reference too) ---------------
   struct G { int64_t x, y, z; };
   auto unpack = [](uint64_t k) {
     int x, y, z;
-    unpackKey(k & ~kSeedBit, &x, &y, &z);
+    unpackKey(k, &x, &y, &z);
     return G{x, y, z};
   };
   // canonical seed order: ascending (x, y, z) (ASSUMPTIONS.md C.1)
-  std::vector<uint32_t> seed_runs(n_seed_vox);
-  for (uint32_t i = 0; i < n_seed_vox; ++i) seed_runs[i] = first_seed + i;
-  std::sort(seed_runs.begin(), seed_runs.end(), [&](uint32_t a, uint32_t b) {
-    const G ga = unpack(keys[a]), gb = unpack(keys[b]);
+  std::vector<uint32_t> order(S);
+  std::vector<G> sg(S);
+  for (uint32_t i = 0; i < S; ++i) {
+    order[i] = i;
+    sg[i] = unpack(sk[i]);
+  }
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    const G &ga = sg[a], &gb = sg[b];
     return ga.x != gb.x ? ga.x < gb.x : (ga.y != gb.y ? ga.y < gb.y : ga.z < gb.z);
   });
-  static const int kOff[26][3] = {
-      {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1},
-      {-1, -1, 0}, {-1, 1, 0}, {1, -1, 0}, {1, 1, 0}, {-1, 0, -1}, {-1, 0, 1}, {1, 0, -1}, {1, 0, 1},
-      {0, -1, -1}, {0, -1, 1}, {0, 1, -1}, {0, 1, 1},
-      {-1, -1, -1}, {-1, -1, 1}, {-1, 1, -1}, {-1, 1, 1}, {1, -1, -1}, {1, -1, 1}, {1, 1, -1}, {1, 1, 1}};
   struct Cluster {
-    uint64_t n_pixels = 0;          // with the duplicates the reference produces (:255-265)
-    std::vector<uint32_t> runs;     // voxel set (run indices)
+    uint64_t n_pixels = 0;        // with the duplicates the reference produces (:255-265)
+    std::vector<uint32_t> seeds;  // seed ids
+    std::vector<uint32_t> bnds;   // boundary ids (unique)
     int64_t lo[3], hi[3];
   };
   std::vector<Cluster> clusters;
-  std::vector<uint8_t> closed(n_runs, 0);
-  const int nn = c->cfg.md_neighbor_connectivity;
+  std::vector<uint8_t> closed(S, 0);
   // clusterDynamicVoxels (free_space_motion_detector.cpp:205-272)
-  for (uint32_t sr : seed_runs) {
-    if (closed[sr]) continue;
-    std::vector<uint32_t> stack = {sr};
+  std::vector<uint32_t> stack;
+  for (uint32_t s0 : order) {
+    if (closed[s0]) continue;
+    stack.assign(1, s0);
     Cluster cl;
     while (!stack.empty()) {
       const uint32_t r = stack.back();
       stack.pop_back();
       if (closed[r]) continue;
       closed[r] = 1;
-      cl.n_pixels += counts[r];
-      cl.runs.push_back(r);
-      const G g = unpack(keys[r]);
+      cl.n_pixels += sc[r];
+      cl.seeds.push_back(r);
       for (int k = 0; k < nn; ++k) {
-        const uint64_t nk = packKey(static_cast<int>(g.x + kOff[k][0]), static_cast<int>(g.y + kOff[k][1]),
-                                    static_cast<int>(g.z + kOff[k][2]));
-        const int sn = findRun(nk, true);
-        if (sn >= 0) {
-          stack.push_back(static_cast<uint32_t>(sn));
+        const uint32_t a = adj[static_cast<size_t>(r) * nn + k];
+        if (a == 0xffffffffu) continue;
+        if (a & 0x80000000u) {
+          stack.push_back(a & 0x7fffffffu);
         } else {
-          const int on = findRun(nk, false);
-          if (on >= 0) {
-            cl.n_pixels += counts[on];
-            cl.runs.push_back(static_cast<uint32_t>(on));
-            closed[on] = 1;
-          }
+          cl.n_pixels += bc[a];  // appended once per adjacent expanded seed
+          cl.bnds.push_back(a);
         }
       }
     }
-    std::sort(cl.runs.begin(), cl.runs.end());
-    cl.runs.erase(std::unique(cl.runs.begin(), cl.runs.end()), cl.runs.end());
+    std::sort(cl.bnds.begin(), cl.bnds.end());
+    cl.bnds.erase(std::unique(cl.bnds.begin(), cl.bnds.end()), cl.bnds.end());
     clusters.push_back(std::move(cl));
   }
   const size_t nc = clusters.size();
@@ -955,9 +980,9 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
   for (size_t i = 0; i < nc; ++i) {
     Cluster& cl = clusters[i];
     for (int d = 0; d < 3; ++d) { cl.lo[d] = INT64_MAX; cl.hi[d] = INT64_MIN; }
-    for (uint32_t r : cl.runs) {
-      const G g = unpack(keys[r]);
-      vox[i].push_back(g);
+    for (uint32_t r : cl.seeds) vox[i].push_back(sg[r]);
+    for (uint32_t r : cl.bnds) vox[i].push_back(unpack(bk[r]));
+    for (const G& g : vox[i]) {
       const int64_t v[3] = {g.x, g.y, g.z};
       for (int d = 0; d < 3; ++d) { cl.lo[d] = std::min(cl.lo[d], v[d]); cl.hi[d] = std::max(cl.hi[d], v[d]); }
     }
@@ -1001,27 +1026,32 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
     for (size_t i : idx) {
       if (i == cur) continue;
       clusters[cur].n_pixels += clusters[i].n_pixels;
-      clusters[cur].runs.insert(clusters[cur].runs.end(), clusters[i].runs.begin(), clusters[i].runs.end());
+      clusters[cur].seeds.insert(clusters[cur].seeds.end(), clusters[i].seeds.begin(), clusters[i].seeds.end());
+      clusters[cur].bnds.insert(clusters[cur].bnds.end(), clusters[i].bnds.begin(), clusters[i].bnds.end());
     }
     keep[cur] = 1;
   }
-  // applyClusterLevelFilters (:365-379) + writeClustersToData (:381-399)
-  std::vector<int32_t> run_id(n_runs, 0);
+  // applyClusterLevelFilters (:365-379) + writeClustersToData (:381-399): later clusters overwrite earlier ones
+  std::vector<int32_t>&seed_final = c->h_md_seed_final, &bnd_final = c->h_md_bnd_final;
+  seed_final.assign(S, 0);
+  bnd_final.assign(std::max<uint32_t>(B, 1), 0);
   int id = 1, n_out = 0;
   for (size_t ci = 0; ci < nc; ++ci) {
     if (!keep[ci]) continue;
     const int size = static_cast<int>(clusters[ci].n_pixels);
     if (size < c->cfg.md_min_cluster_size || size > c->cfg.md_max_cluster_size) continue;
-    for (uint32_t r : clusters[ci].runs) run_id[r] = id;
+    for (uint32_t r : clusters[ci].seeds) seed_final[r] = id;
+    for (uint32_t r : clusters[ci].bnds) bnd_final[r] = id;
     if (id < 255) ++id;
     ++n_out;
   }
-  if (n_out > 0 && n_valid > 0) {
-    HIP_TRY(hipMemcpyAsync(c->d_run_offsets, offsets.data(), sizeof(uint32_t) * n_runs, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_run_id, run_id.data(), sizeof(int32_t) * n_runs, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_paint_dynamic, dim3(gridFor(n_valid)), dim3(256), 0, c->stream, c->d_pix_sorted,
-                       c->d_run_offsets, static_cast<int>(n_runs), c->d_run_id, static_cast<int>(n_valid), s.dyn);
-    HIP_TRY(hipStreamSynchronize(c->stream));  // host vectors go out of scope
+  if (n_out > 0) {
+    // the host vectors are context members, so the asynchronous upload may outlive this call
+    HIP_TRY(hipMemcpyAsync(c->d_md_seed_final, seed_final.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, c->stream));
+    if (B) HIP_TRY(hipMemcpyAsync(c->d_md_bnd_final, bnd_final.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_md_paint, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds, bnd, c->d_md_seed_final,
+                       c->d_md_bnd_final, s.dyn);
+    HIP_TRY(hipGetLastError());
   }
   return n_out;
 }
@@ -1030,7 +1060,7 @@ int khr_detect_motion(khr_ctx* c, int slot) {
   if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
   HIP_TRY(hipSetDevice(c->device));
   FrameSlot& s = c->slots[slot];
-  int rc = motionLaunch(c, s);
+  int rc = motionLaunch(c, s, false);
   if (rc) return rc;
   return motionFinish(c, s);
 }
@@ -1136,7 +1166,7 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   const bool motion = (flags & KHR_PF_MOTION) != 0;
   int rc = KHR_OK;
   // (1) per-pixel motion pass; its seed count comes back asynchronously ...
-  if (motion && (rc = motionLaunch(c, s))) return rc;
+  if (motion && (rc = motionLaunch(c, s, true))) return rc;
   // (2) ... while block allocation / culling, which do not depend on the dynamic mask, keep the GPU busy
   if ((rc = integrateAlloc(c, s, f, 1))) return rc;
   // (3) host looks at the seed count (clusters only exist when there are seeds)

@@ -17,12 +17,19 @@ for i in range(12):
     ctx.integrate(slot)
     ctx.update_tracking(fr["stamp"])
 st = ctx.stats()
-n = st["n_tsdf_blocks"]
+n = min(4096, st["n_tsdf_blocks"] * 4)
 buf = np.zeros(4096 * 4 * 8, np.uint64)
 ctx.lib.khr_debug_read(ctx.h, buf.ctypes.data, buf.size)
 d = buf.reshape(4096, 4, 8)[:n].astype(np.int64)
-t0 = d[:, :, 0].min()
-start, p1, rec, end = [(d[:, :, k] - t0) for k in range(4)]
+xcc_all = d[:, 0, 5] & 0xf
+start = np.zeros((n, 4), np.int64); p1 = start.copy(); rec = start.copy(); end = start.copy()
+for x in range(8):
+    sel = xcc_all == x
+    if not sel.any():
+        continue
+    t0 = d[sel][:, :, 0].min()
+    for arr, k in ((start, 0), (p1, 1), (rec, 2), (end, 3)):
+        arr[sel] = d[sel][:, :, k] - t0
 print("blocks", n, "kernel span (cycles, s_memtime @100MHz?)", end.max())
 print("wave start  min/med/max", start.min(), np.median(start), start.max())
 print("wave dur    min/med/max", (end - start).min(), np.median(end - start), (end - start).max())

@@ -6,8 +6,10 @@
 namespace khr {
 
 #include "mc_table.inc"  // kMcTriTable / kMcNumTris (host copies)
-__constant__ int8_t c_mc_tri[256][16];
-__constant__ uint8_t c_mc_ntri[256];
+// marching-cubes tables live in global memory and are staged in LDS per workgroup: they are indexed by the
+// per-lane case number, and divergent __constant__ reads serialise (waterfall loop).
+__device__ int8_t g_mc_tri[256][16];
+__device__ uint8_t g_mc_ntri[256];
 
 constexpr uint64_t kSeedBit = 1ull << 63;
 
@@ -208,7 +210,16 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
   __shared__ float s_w[T * T * T];
   __shared__ uint32_t s_nslot[8];
   __shared__ uint32_t s_scan[256];
+  __shared__ uint8_t s_ntri[256];
+  __shared__ uint16_t s_toff[EMIT ? VPS * VPS * VPS : 2];
+  __shared__ uint8_t s_case[EMIT ? VPS * VPS * VPS : 4];
+  __shared__ int8_t s_tri[EMIT ? 256 * 16 : 16];
   const uint32_t n = *n_work;
+  if (blockIdx.x < n) {
+    s_ntri[threadIdx.x] = g_mc_ntri[threadIdx.x];
+    if (EMIT)
+      reinterpret_cast<uint4*>(s_tri)[threadIdx.x] = reinterpret_cast<const uint4*>(&g_mc_tri[0][0])[threadIdx.x];
+  }
   for (uint32_t b = blockIdx.x; b < n; b += gridDim.x) {
     const size_t slot = work[b];
     if (EMIT && new_count[slot] == 0u) {  // most mesh-updated blocks contain no surface: nothing to stage
@@ -268,7 +279,7 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
       }
       if (!ok) index = 0;
       cases[j] = index;
-      cnt[j] = 3u * c_mc_ntri[index];
+      cnt[j] = 3u * s_ntri[index];
       tsum += cnt[j];
     }
     // block exclusive scan of tsum
@@ -282,7 +293,7 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
       __syncthreads();
     }
     const uint32_t total = s_scan[255];
-    uint32_t base = s_scan[threadIdx.x] - tsum;
+    const uint32_t base = s_scan[threadIdx.x] - tsum;
     if (!EMIT) {
       if (threadIdx.x == 0) new_count[slot] = total;
     } else {
@@ -291,50 +302,68 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
         m.mesh_desc[slot] = MeshDesc{boff, total};
         if (clear_flag) m.blk_flags[slot] &= ~BLK_MESH_UPDATED;
       }
+      // per-cube triangle offsets + case numbers -> LDS, then the block's triangles are dealt out to the
+      // threads round-robin (a thread that owns a row of surface cubes would otherwise emit ~100 vertices
+      // one after the other, each behind dependent attribute loads)
+      {
+        uint32_t o = base / 3u;
 #pragma unroll
-      for (int j = 0; j < PER; ++j) {
-        if (cnt[j] == 0) continue;
-        const int lin = threadIdx.x * PER + j;
+        for (int j = 0; j < PER; ++j) {
+          const int lin = threadIdx.x * PER + j;
+          s_toff[lin] = static_cast<uint16_t>(o);
+          s_case[lin] = static_cast<uint8_t>(cases[j]);
+          o += cnt[j] / 3u;
+        }
+      }
+      __syncthreads();
+      const uint32_t n_tri = total / 3u;
+      for (uint32_t tri = threadIdx.x; tri < n_tri; tri += 256) {
+        // largest lin with s_toff[lin] <= tri and a non-empty cube: binary search, then skip empty cubes
+        int lo = 0, hi = NV - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (s_toff[mid] <= tri) lo = mid; else hi = mid - 1;
+        }
+        const int lin = lo;  // cubes after lo with the same offset are empty, cubes before share it only if empty
+        const int index = s_case[lin];
+        const int col = 3 * static_cast<int>(tri - s_toff[lin]);
         const int ix = lin % VPS, iy = (lin / VPS) % VPS, iz = lin / (VPS * VPS);
-        const int index = cases[j];
-        for (int col = 0; c_mc_tri[index][col] != -1; col += 3) {
-          for (int kk = 2; kk >= 0; --kk) {
-            const int e = c_mc_tri[index][col + kk];
-            // edge endpoints
-            const int ea = (e < 8) ? e : (e - 8);
-            const int eb = (e < 4) ? ((e + 1) & 3) : (e < 8 ? 4 + ((e - 4 + 1) & 3) : e - 4);
-            const int ax = (ea == 1 || ea == 2 || ea == 5 || ea == 6), ay = (ea == 2 || ea == 3 || ea == 6 || ea == 7),
-                      az = ea >= 4;
-            const int bx = (eb == 1 || eb == 2 || eb == 5 || eb == 6), by = (eb == 2 || eb == 3 || eb == 6 || eb == 7),
-                      bz = eb >= 4;
-            const float s0 = s_d[(ix + ax) + T * ((iy + ay) + T * (iz + az))];
-            const float s1 = s_d[(ix + bx) + T * ((iy + by) + T * (iz + bz))];
-            const float diff = s0 - s1;
-            float t = 0.5f;
-            if (fabsf(diff) >= 1e-6f) t = s0 / diff;
-            const float p0x = ox + (static_cast<float>(ix + ax) + 0.5f) * p.vs;
-            const float p0y = oy + (static_cast<float>(iy + ay) + 0.5f) * p.vs;
-            const float p0z = oz + (static_cast<float>(iz + az) + 0.5f) * p.vs;
-            const float p1x = ox + (static_cast<float>(ix + bx) + 0.5f) * p.vs;
-            const float p1y = oy + (static_cast<float>(iy + by) + 0.5f) * p.vs;
-            const float p1z = oz + (static_cast<float>(iz + bz) + 0.5f) * p.vs;
-            const size_t vo = static_cast<size_t>(boff) + base;
-            out.points[3 * vo] = p0x + t * (p1x - p0x);
-            out.points[3 * vo + 1] = p0y + t * (p1y - p0y);
-            out.points[3 * vo + 2] = p0z + t * (p1z - p0z);
-            // attributes of the nearer endpoint voxel
-            const int sx = (t <= 0.5f) ? ix + ax : ix + bx, sy = (t <= 0.5f) ? iy + ay : iy + by,
-                      sz = (t <= 0.5f) ? iz + az : iz + bz;
-            int lx = sx, ly = sy, lz = sz, sel = 0;
-            if (lx >= VPS) { lx -= VPS; sel |= 1; }
-            if (ly >= VPS) { ly -= VPS; sel |= 2; }
-            if (lz >= VPS) { lz -= VPS; sel |= 4; }
-            const size_t so = static_cast<size_t>(s_nslot[sel]) * NV + (lx + VPS * (ly + VPS * lz));
-            out.colors[vo] = m.color[so];
-            out.labels[vo] = p.with_semantics ? m.sem_label[so] : 0u;
-            out.stamps[vo] = p.with_tracking ? m.last_obs[so] : 0ull;
-            ++base;
-          }
+#pragma unroll
+        for (int kk = 2; kk >= 0; --kk) {
+          const int e = s_tri[index * 16 + col + kk];
+          // edge endpoints
+          const int ea = (e < 8) ? e : (e - 8);
+          const int eb = (e < 4) ? ((e + 1) & 3) : (e < 8 ? 4 + ((e - 4 + 1) & 3) : e - 4);
+          const int ax = (ea == 1 || ea == 2 || ea == 5 || ea == 6), ay = (ea == 2 || ea == 3 || ea == 6 || ea == 7),
+                    az = ea >= 4;
+          const int bx = (eb == 1 || eb == 2 || eb == 5 || eb == 6), by = (eb == 2 || eb == 3 || eb == 6 || eb == 7),
+                    bz = eb >= 4;
+          const float s0 = s_d[(ix + ax) + T * ((iy + ay) + T * (iz + az))];
+          const float s1 = s_d[(ix + bx) + T * ((iy + by) + T * (iz + bz))];
+          const float diff = s0 - s1;
+          float t = 0.5f;
+          if (fabsf(diff) >= 1e-6f) t = s0 / diff;
+          const float p0x = ox + (static_cast<float>(ix + ax) + 0.5f) * p.vs;
+          const float p0y = oy + (static_cast<float>(iy + ay) + 0.5f) * p.vs;
+          const float p0z = oz + (static_cast<float>(iz + az) + 0.5f) * p.vs;
+          const float p1x = ox + (static_cast<float>(ix + bx) + 0.5f) * p.vs;
+          const float p1y = oy + (static_cast<float>(iy + by) + 0.5f) * p.vs;
+          const float p1z = oz + (static_cast<float>(iz + bz) + 0.5f) * p.vs;
+          const size_t vo = static_cast<size_t>(boff) + 3u * tri + static_cast<uint32_t>(2 - kk);
+          out.points[3 * vo] = p0x + t * (p1x - p0x);
+          out.points[3 * vo + 1] = p0y + t * (p1y - p0y);
+          out.points[3 * vo + 2] = p0z + t * (p1z - p0z);
+          // attributes of the nearer endpoint voxel
+          const int sx = (t <= 0.5f) ? ix + ax : ix + bx, sy = (t <= 0.5f) ? iy + ay : iy + by,
+                    sz = (t <= 0.5f) ? iz + az : iz + bz;
+          int lx = sx, ly = sy, lz = sz, sel = 0;
+          if (lx >= VPS) { lx -= VPS; sel |= 1; }
+          if (ly >= VPS) { ly -= VPS; sel |= 2; }
+          if (lz >= VPS) { lz -= VPS; sel |= 4; }
+          const size_t so = static_cast<size_t>(s_nslot[sel]) * NV + (lx + VPS * (ly + VPS * lz));
+          out.colors[vo] = m.color[so];
+          out.labels[vo] = p.with_semantics ? m.sem_label[so] : 0u;
+          out.stamps[vo] = p.with_tracking ? m.last_obs[so] : 0ull;
         }
       }
     }
@@ -393,8 +422,12 @@ __global__ __launch_bounds__(256) void k_reset_inactive(DevMap m, int4* __restri
     if (!(fl & BLK_LIVE)) continue;
     bool all_remove = true;
     if (fl & BLK_HAS_ACTIVE) {
-      const uint8_t* vfl = m.vflags + static_cast<size_t>(s) * NV;
-      for (int lin = threadIdx.x; lin < NV; lin += 256) all_remove = all_remove && (vfl[lin] & VOX_TO_REMOVE);
+      const uint4* vfl = reinterpret_cast<const uint4*>(m.vflags + static_cast<size_t>(s) * NV);
+      const uint32_t bit = VOX_TO_REMOVE * 0x01010101u;
+      for (int g = threadIdx.x; g < NV / 16; g += 256) {
+        const uint4 v = vfl[g];
+        all_remove = all_remove && ((v.x & v.y & v.z & v.w & bit) == bit);
+      }
     }
     const int keep = __syncthreads_or(all_remove ? 0 : 1);
     if (threadIdx.x == 0 && (!(fl & BLK_HAS_ACTIVE) || !keep)) {
@@ -421,37 +454,24 @@ __global__ __launch_bounds__(256) void k_rehash(DevMap m) {
   htInsertUnique(m, packKey(bi.x, bi.y, bi.z), s);
 }
 
-// rebuild the free list: ordered compaction of non-live slots (single workgroup, ballot prefix sums)
-__global__ __launch_bounds__(1024) void k_rebuild_free_list(DevMap m) {
+// rebuild the free list after removals: (unordered) compaction of the non-live slots, one wave-aggregated
+// atomic per wave; k_free_list_begin / _end reset and publish the counters
+__global__ void k_free_list_begin(DevMap m) {
   if (m.counters[C_N_REMOVED] == 0u) return;
-  __shared__ uint32_t s_wave[16];
-  __shared__ uint32_t s_base;
-  if (threadIdx.x == 0) s_base = 0;
-  __syncthreads();
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t live_total = 0;
-  for (uint32_t start = 0; start < m.capacity; start += 1024) {
-    const uint32_t s = start + threadIdx.x;
-    const bool is_free = s < m.capacity && !(m.blk_flags[s] & BLK_LIVE);
-    const unsigned long long b = __ballot(is_free);
-    if (lane == 0) s_wave[wave] = __popcll(b);
-    __syncthreads();
-    uint32_t off = s_base;
-    for (uint32_t w = 0; w < wave; ++w) off += s_wave[w];
-    if (is_free) m.free_slots[off + __popcll(b & ((1ull << lane) - 1ull))] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t t = 0;
-      for (int w = 0; w < 16; ++w) t += s_wave[w];
-      s_base += t;
-    }
-    __syncthreads();
-  }
-  (void)live_total;
-  if (threadIdx.x == 0) {
-    m.counters[C_N_FREE] = s_base;
-    m.counters[C_FREE_HEAD] = 0;
-    m.counters[C_N_LIVE] = m.capacity - s_base;
+  if (threadIdx.x == 0 && blockIdx.x == 0) m.counters[C_N_FREE] = 0u;
+}
+__global__ __launch_bounds__(256) void k_free_list_fill(DevMap m) {
+  if (m.counters[C_N_REMOVED] == 0u) return;
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool is_free = s < m.capacity && !(m.blk_flags[s] & BLK_LIVE);
+  const uint32_t idx = waveAggInc(&m.counters[C_N_FREE], is_free);
+  if (is_free) m.free_slots[idx] = s;
+}
+__global__ void k_free_list_end(DevMap m) {
+  if (m.counters[C_N_REMOVED] == 0u) return;
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    m.counters[C_FREE_HEAD] = 0u;
+    m.counters[C_N_LIVE] = m.capacity - m.counters[C_N_FREE];
   }
 }
 

@@ -516,8 +516,8 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     uint32_t ctr[C_COUNT] = {0};
     ctr[C_N_FREE] = static_cast<uint32_t>(cap);
     if (e == hipSuccess) e = hipMemcpyAsync(m.counters, ctr, sizeof(ctr), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_mc_tri), kMcTriTable, sizeof(kMcTriTable));
-    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_mc_ntri), kMcNumTris, sizeof(kMcNumTris));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_mc_tri), kMcTriTable, sizeof(kMcTriTable));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_mc_ntri), kMcNumTris, sizeof(kMcNumTris));
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   }
   if (e != hipSuccess) {
@@ -1111,7 +1111,9 @@ static int resetInactiveLaunch(khr_ctx* c) {
   if (rc) return rc;
   hipLaunchKernelGGL(k_rehash_clear, dim3(gridFor(static_cast<size_t>(m.ht_mask) + 1)), dim3(256), 0, c->stream, m);
   hipLaunchKernelGGL(k_rehash, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m);
-  hipLaunchKernelGGL(k_rebuild_free_list, dim3(1), dim3(1024), 0, c->stream, m);
+  hipLaunchKernelGGL(k_free_list_begin, dim3(1), dim3(64), 0, c->stream, m);
+  hipLaunchKernelGGL(k_free_list_fill, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m);
+  hipLaunchKernelGGL(k_free_list_end, dim3(1), dim3(64), 0, c->stream, m);
   c->host_index_valid = false;
   c->removed_pending = true;
   HIP_TRY(hipGetLastError());

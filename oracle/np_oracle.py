@@ -1,0 +1,106 @@
+"""Second, independent restatement (numpy, vectorised) of the per-voxel projective TSDF / semantic update and
+of updateTrackingDuration, used ONLY to cross-check oracle.cpp (N-version check; the reference ships no golden
+vectors).  Follows ASSUMPTIONS.md A.1-A.4 and tracking_integrator.cpp:224-246.
+TEST INFRASTRUCTURE ONLY."""
+import numpy as np
+
+f32 = np.float32
+
+
+def make_pose(T):
+    T = np.asarray(T, np.float64).reshape(4, 4)
+    R = T[:3, :3].T.astype(f32)
+    t = (-(T[:3, :3].T @ T[:3, 3])).astype(f32)  # NB: the oracle sums column-wise left to right
+    t = np.array([-(T[0, r] * T[0, 3] + T[1, r] * T[1, 3] + T[2, r] * T[2, 3]) for r in range(3)], np.float64).astype(f32)
+    return R, t
+
+
+def integrate_block(cfg, sensor, T, depth, label, block_index, dist, weight, lik, sem_valid, sem_label, last_obs, stamp):
+    """updates the arrays of one 16^3 block in place; returns (n_upd, n_band)."""
+    vps = cfg["voxels_per_side"]
+    vs, trunc = f32(cfg["voxel_size"]), f32(cfg["truncation_distance"])
+    bs = vs * f32(vps)
+    W, H = sensor["width"], sensor["height"]
+    fx, fy, cx, cy = (f32(sensor[k]) for k in ("fx", "fy", "cx", "cy"))
+    mn, mx = f32(sensor["min_range"]), f32(sensor["max_range"])
+    R, t = make_pose(T)
+    ix, iy, iz = np.meshgrid(np.arange(vps), np.arange(vps), np.arange(vps), indexing="ij")
+    lin = (ix + vps * (iy + vps * iz)).ravel()
+    order = np.argsort(lin)
+    ix, iy, iz = ix.ravel()[order], iy.ravel()[order], iz.ravel()[order]
+    o = np.asarray(block_index, np.int64).astype(f32) * bs
+    px = o[0] + (ix.astype(f32) + f32(0.5)) * vs
+    py = o[1] + (iy.astype(f32) + f32(0.5)) * vs
+    pz = o[2] + (iz.astype(f32) + f32(0.5)) * vs
+    pc = [((R[r, 0] * px + R[r, 1] * py) + R[r, 2] * pz) + t[r] for r in range(3)]
+    z = pc[2]
+    ok = z > 0
+    with np.errstate(all="ignore"):
+        zs = np.where(ok, z, f32(1))
+        ok &= ~((zs < mn) | (zs > mx))
+        u = (pc[0] * fx) / zs + cx
+        v = (pc[1] * fy) / zs + cy
+        ok &= ~((np.ceil(u) >= W) | (np.floor(u) < 0)) & ~((np.ceil(v) >= H) | (np.floor(v) < 0))
+        uc, vc = np.where(ok, u, f32(0)), np.where(ok, v, f32(0))
+        u0, v0 = np.floor(uc).astype(np.int64), np.floor(vc).astype(np.int64)
+        u1, v1 = np.minimum(u0 + 1, W - 1), np.minimum(v0 + 1, H - 1)
+        du, dv = uc - u0.astype(f32), vc - v0.astype(f32)
+        rng = np.where((depth > 0) & np.isfinite(depth), depth, f32(0)).astype(f32)
+        pxs = [(v0, u0), (v1, u0), (v0, u1), (v1, u1)]
+        r4 = [rng[a, b] for a, b in pxs]
+        w4 = [(f32(1) - du) * (f32(1) - dv), (f32(1) - du) * dv, du * (f32(1) - dv), du * dv]
+        mode = cfg["interpolation_method"]
+        nearest = np.zeros(len(lin), bool) if mode != 0 else np.ones(len(lin), bool)
+        if mode == 2:
+            nearest |= (np.maximum.reduce(r4) - np.minimum.reduce(r4)) > f32(cfg["adaptive_max_range_difference"])
+        near_idx = np.where(du >= 0.5, 2, 0) + np.where(dv >= 0.5, 1, 0)
+        r_near = np.choose(near_idx, r4)
+        r_bil = ((w4[0] * r4[0] + w4[1] * r4[1]) + w4[2] * r4[2]) + w4[3] * r4[3]
+        ds = np.where(nearest, r_near, r_bil)
+        ok &= (ds >= mn) & ~(ds > mx)
+        sdf = ds - zs
+        ok &= ~(sdf < -trunc)
+        band = ok & (np.abs(sdf) < trunc)
+        q = vs / zs
+        w = (fx * fy) * (q * q)
+        w = w / (zs * zs)
+        eps = f32(cfg["weight_dropoff_epsilon"]) if cfg["weight_dropoff_epsilon"] > 0 else f32(cfg["weight_dropoff_epsilon"]) * -vs
+        wd = np.maximum(w * ((trunc + sdf) / (trunc - eps)), f32(0))
+        w = np.where(sdf < -eps, wd, w)
+        ok &= w > 0
+        band &= ok
+        sdf_c = np.maximum(np.minimum(trunc, sdf), -trunc)
+        d_new = (dist * weight + sdf_c * w) / (weight + w)
+        w_new = np.minimum(weight + w, f32(cfg["max_weight"]))
+    dist[ok] = d_new[ok]
+    weight[ok] = w_new[ok]
+    last_obs[ok] = stamp
+    if label is not None and cfg["with_semantics"]:
+        K = cfg["num_labels"]
+        best = np.where(nearest, near_idx, np.argmax(np.stack(w4), axis=0))  # first maximum
+        bv = np.choose(best, [p[0] for p in pxs])
+        bu = np.choose(best, [p[1] for p in pxs])
+        lab = label[bv, bu]
+        sel = band & (lab >= 0) & (lab < K)
+        lm = np.log(f32(cfg["label_confidence"]))
+        ln = np.log((f32(1) - f32(cfg["label_confidence"])) / f32(K - 1))
+        idx = np.flatnonzero(sel)
+        lik[:, idx[~sem_valid[idx]]] = 0
+        add = np.full((K, len(idx)), ln, f32)
+        add[lab[idx], np.arange(len(idx))] = lm
+        lik[:, idx] = lik[:, idx] + add
+        sem_valid[idx] = True
+        sem_label[idx] = np.argmax(lik[:, idx], axis=0)
+    return int(ok.sum()), int(band.sum())
+
+
+def tracking_block(cfg, dist, last_obs, last_occ, flags, stamp):
+    """updateTrackingDuration over one block (tracking_integrator.cpp:224-246); flags bit0 active, bit2 to_remove."""
+    thr = f32(cfg["tsdf_occupancy_threshold"])
+    thr = thr * -f32(cfg["voxel_size"]) if thr < 0 else thr
+    last_occ[dist < thr] = stamp
+    was = (flags & 1) > 0
+    act = (last_obs.astype(np.float64) / 1e9) >= (np.float64(stamp) / 1e9 - np.float64(f32(cfg["temporal_window"])))
+    flags[:] = (flags & ~np.uint8(1)) | act.astype(np.uint8)
+    flags[was & ~act] |= 4
+    return bool(act.any())

@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--cpu-baseline-frames", type=int, default=-1,
                     help="frames of the same stream timed on the CPU oracle (rank 0, N=1); -1 = auto, 0 = skip")
     ap.add_argument("--no-roofline-timers", action="store_true")
+    ap.add_argument("--all-timers", action="store_true", help="HIP-event timers on every kernel group (slower host path)")
     ap.add_argument("--frame-times", action="store_true", help="debug: synchronise and print per-frame wall times")
     ap.add_argument("--halo-cap", type=int, default=8192, help="halo records all-gathered per rank and tick (N > 1)")
     return ap.parse_args()
@@ -177,7 +178,9 @@ def main():
     st0 = ctx.stats()
     if not args.no_roofline_timers:
         ctx.timing_reset()
-        ctx.timing_enable(True)
+        # default: only the two update kernels carry HIP events (each timed launch costs host time);
+        # --all-timers adds the per-kernel breakdown
+        ctx.timing_enable(True, None if args.all_timers else ("tsdf", "band"))
     t0 = time.perf_counter()
     ft = []
     for i in range(args.warmup, n_total):

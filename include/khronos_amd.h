@@ -232,6 +232,7 @@ int64_t khr_download_mesh(khr_ctx* ctx, float* points, uint8_t* colors_rgba, uin
 /* HIP-event timing of the kernels launched on the context stream. which: 0 tsdf update,
  * 1 tracking update, 2 ever-free, 3 block allocation+init, 4 motion pixels, 5 mesh, 6 parse input,
  * 7 band (colour / label) update.
+ * `enable` is a bit mask of timers (bit i = timer i; 0 = off, 0xff = all).
  * Accumulates between khr_timing_reset calls; returns total ms and launch count. */
 /* development probe (KHR_DEBUG & 8): per-workgroup timestamps of the last k_tsdf_update launch */
 int khr_debug_read(khr_ctx* ctx, unsigned long long* out, int64_t n);

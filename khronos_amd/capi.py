@@ -358,8 +358,12 @@ class FusionContext:
         k = self._chk(self.lib.khr_download_mesh(self.h, _ptr(pts), _ptr(col), _ptr(lab), _ptr(fs), _ptr(st), max(n, 1)))
         return {"points": pts[:k], "colors": col[:k], "labels": lab[:k], "first_seen": fs[:k], "stamps": st[:k]}
 
-    def timing_enable(self, on=True):
-        self._chk(self.lib.khr_timing_enable(self.h, int(on)))
+    def timing_enable(self, on=True, names=None):
+        """on=True: all timers, or only those in `names`."""
+        mask = 0
+        if on:
+            mask = 0xFF if names is None else sum(1 << self.TIMERS[n] for n in names)
+        self._chk(self.lib.khr_timing_enable(self.h, mask))
 
     def timing_reset(self):
         self._chk(self.lib.khr_timing_reset(self.h))

@@ -132,7 +132,7 @@ struct khr_ctx {
   std::map<std::array<int32_t, 3>, uint32_t> host_index;
   std::vector<uint32_t> host_flags;
   // timing
-  bool timing = false;
+  uint32_t timing = 0;  // bit i = timer i enabled
   std::vector<TimingRec> pending;
   std::vector<hipEvent_t> event_pool;
   double t_ms[kNumTimers] = {0};
@@ -145,8 +145,10 @@ struct ScopedTimer {
   khr_ctx* c;
   int which;
   hipEvent_t a = nullptr, b = nullptr;
+  bool on = false;
   ScopedTimer(khr_ctx* ctx, int w) : c(ctx), which(w) {
-    if (c->timing) {
+    on = (c->timing >> w) & 1u;
+    if (on) {
       auto get = [&]() {
         hipEvent_t e = nullptr;
         if (!c->event_pool.empty()) {
@@ -163,7 +165,7 @@ struct ScopedTimer {
     }
   }
   ~ScopedTimer() {
-    if (c->timing) {
+    if (on) {
       hipEventRecord(b, c->stream);
       c->pending.push_back({which, a, b});
     }
@@ -1419,7 +1421,7 @@ int khr_debug_read(khr_ctx* c, unsigned long long* out, int64_t n) {
 
 int khr_timing_enable(khr_ctx* c, int enable) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
-  c->timing = enable != 0;
+  c->timing = static_cast<uint32_t>(enable);
   return KHR_OK;
 }
 int khr_timing_reset(khr_ctx* c) {

@@ -126,6 +126,17 @@ typedef struct khr_stats {
   uint64_t band_overflow;      /* non-zero if in-band records were dropped (raise max_band_records) */
 } khr_stats;
 
+/* khronos::MeasurementCluster role (measurement_clusters.h:63-80) for dynamic clusters
+ * (FrameData::dynamic_clusters, free_space_motion_detector.cpp:381-399) */
+typedef struct khr_cluster {
+  int32_t id;                  /* value painted into dynamic_image (ids saturate at 255, :390-395) */
+  uint64_t num_pixels_listed;  /* cluster.pixels.size() of the reference (boundary voxels appended once per adjacent
+                                  seed, :255-265) -- the quantity the size filter uses */
+  uint32_t num_pixels_painted; /* pixels that carry this id in dynamic_image (later clusters overwrite earlier ones) */
+  float bbox_min[3], bbox_max[3]; /* world-frame AABB of the painted pixels' vertices (:396-397) */
+  float centroid[3];           /* mean vertex of the painted pixels (utils::computeCentroid role) */
+} khr_cluster;
+
 typedef struct khr_ctx khr_ctx;
 
 /* -- lifetime --------------------------------------------------------------------------------- */
@@ -179,6 +190,9 @@ int khr_import_halo(khr_ctx* ctx, const void* records, int64_t n_records, int on
 /* replaces: FreeSpaceMotionDetector::processInput (free_space_motion_detector.cpp:73-103).
  * Writes the slot's dynamic_image on the device; returns the number of clusters kept (>= 0). */
 int khr_detect_motion(khr_ctx* ctx, int slot);
+/* FrameData::dynamic_clusters of the frame last passed to khr_detect_motion / khr_process_frame.
+ * Returns the number of clusters (writes min(n, cap)); synchronises. */
+int khr_get_dynamic_clusters(khr_ctx* ctx, int slot, khr_cluster* out, int cap);
 /* replaces: hydra::MeshIntegrator::generateMesh(map, only_mesh_updated, clear_flag)
  * (active_window.cpp:223, mesh_object_extractor.cpp:267) */
 int khr_generate_mesh(khr_ctx* ctx, int only_mesh_updated, int clear_flag);

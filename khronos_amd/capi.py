@@ -45,6 +45,11 @@ class KhrFrame(C.Structure):
                 ("color", C.c_void_p), ("label", C.c_void_p)]
 
 
+class KhrCluster(C.Structure):
+    _fields_ = [("id", C.c_int32), ("num_pixels_listed", C.c_uint64), ("num_pixels_painted", C.c_uint32),
+                ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("centroid", C.c_float * 3)]
+
+
 class KhrStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "n_allocated_blocks", "n_visible_blocks", "n_new_blocks", "n_visited_voxels", "n_updated_voxels",
@@ -60,7 +65,7 @@ EXPORTS = [
     "khr_allocate_blocks", "khr_object_prune", "khr_get_stats", "khr_num_blocks", "khr_block_indices",
     "khr_download_block", "khr_mesh_num_vertices", "khr_download_mesh", "khr_timing_enable", "khr_timing_reset",
     "khr_timing_get", "khr_debug_read", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_update_tracking_phase",
-    "khr_export_halo", "khr_import_halo",
+    "khr_export_halo", "khr_import_halo", "khr_get_dynamic_clusters",
 ]
 
 _lib = None
@@ -100,6 +105,7 @@ def load_library():
     lib.khr_export_halo.argtypes = [vp, vp, i64, i32]
     lib.khr_import_halo.argtypes = [vp, vp, i64, i32]
     lib.khr_detect_motion.argtypes = [vp, i32]
+    lib.khr_get_dynamic_clusters.argtypes = [vp, i32, C.POINTER(KhrCluster), i32]
     lib.khr_generate_mesh.argtypes = [vp, i32, i32]
     lib.khr_reset_inactive.argtypes = [vp, vp, i64, C.POINTER(i64)]
     lib.khr_mark_all_inactive.argtypes = [vp]
@@ -287,6 +293,13 @@ class FusionContext:
 
     def detect_motion(self, slot):
         return self._chk(self.lib.khr_detect_motion(self.h, slot))
+
+    def dynamic_clusters(self, slot):
+        arr = (KhrCluster * 255)()
+        n = self._chk(self.lib.khr_get_dynamic_clusters(self.h, slot, arr, 255))
+        return [dict(id=a.id, num_pixels_listed=a.num_pixels_listed, num_pixels_painted=a.num_pixels_painted,
+                     bbox_min=np.array(a.bbox_min[:]), bbox_max=np.array(a.bbox_max[:]), centroid=np.array(a.centroid[:]))
+                for a in arr[:n]]
 
     def generate_mesh(self, only_mesh_updated=True, clear_flag=True):
         self._chk(self.lib.khr_generate_mesh(self.h, int(only_mesh_updated), int(clear_flag)))

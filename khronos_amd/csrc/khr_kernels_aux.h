@@ -1,6 +1,8 @@
 // khr_kernels_aux.h — motion-detector pixel binning / painting, marching cubes, block archival and
 // map housekeeping kernels.  gfx950, wave64.
 #pragma once
+#include <cstring>
+
 #include "khr_device.h"
 
 namespace khr {
@@ -160,10 +162,33 @@ __global__ __launch_bounds__(256) void k_md_adjacency(const uint64_t* __restrict
   }
 }
 
+// per-cluster summary accumulated while painting (MeasurementCluster role, measurement_clusters.h:63-80):
+// painted pixel count, world-frame bounding box of the painted pixels' vertices, vertex sum (centroid)
+struct ClusterAcc {
+  uint32_t n_pixels;
+  int32_t bmin[3], bmax[3];  // floats mapped to order-preserving ints
+  float sum[3];
+};
+__device__ inline int32_t floatToOrdered(float f) {
+  const int32_t i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__host__ __device__ inline float orderedToFloat(int32_t i) {
+  const int32_t j = i >= 0 ? i : i ^ 0x7fffffff;
+  float f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  f = __int_as_float(j);
+#else
+  std::memcpy(&f, &j, sizeof(f));
+#endif
+  return f;
+}
+
 // writeClustersToData (free_space_motion_detector.cpp:381-399): cluster id of the pixel's voxel (0 = none)
 __global__ __launch_bounds__(256) void k_md_paint(const uint64_t* __restrict__ keys, int n, VoxTable seeds, VoxTable bnd,
                                                  const int32_t* __restrict__ seed_final,
-                                                 const int32_t* __restrict__ bnd_final, int32_t* __restrict__ dyn) {
+                                                 const int32_t* __restrict__ bnd_final, int32_t* __restrict__ dyn,
+                                                 DevFrame f, ClusterAcc* __restrict__ acc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t k = keys[i];
@@ -176,7 +201,21 @@ __global__ __launch_bounds__(256) void k_md_paint(const uint64_t* __restrict__ k
     const int h = voxFind(bnd, k);
     if (h >= 0) id = bnd_final[bnd.ids[h]];
   }
-  if (id) dyn[i] = id;
+  if (!id) return;
+  dyn[i] = id;
+  // bounding box / centroid of the cluster from the world-frame vertex of this pixel (:396-397)
+  const float d = f.depth[i];
+  const int u = i % f.W, v = i / f.W;
+  float pw[3];
+  xform(f.Rw, f.tw, ((static_cast<float>(u) - f.cx) / f.fx) * d, ((static_cast<float>(v) - f.cy) / f.fy) * d, d, pw);
+  ClusterAcc* a = acc + id;
+  atomicAdd(&a->n_pixels, 1u);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    atomicMin(&a->bmin[c], floatToOrdered(pw[c]));
+    atomicMax(&a->bmax[c], floatToOrdered(pw[c]));
+    atomicAdd(&a->sum[c], pw[c]);
+  }
 }
 
 // ----------------------------------------------------------------------------------------------

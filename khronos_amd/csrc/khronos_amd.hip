@@ -112,10 +112,14 @@ struct khr_ctx {
   uint64_t *d_md_seed_keys = nullptr, *d_md_bnd_keys = nullptr;
   uint32_t *d_md_seed_counts = nullptr, *d_md_bnd_counts = nullptr;
   int32_t *d_md_seed_final = nullptr, *d_md_bnd_final = nullptr;
+  ClusterAcc* d_md_acc = nullptr;  // [256], index = cluster id
+  std::vector<khr_cluster> last_clusters;
+  int last_cluster_slot = -1;
   uint32_t md_mask = 0, md_list_cap = 0;
   std::vector<uint64_t> h_md_seed_keys, h_md_bnd_keys;
   std::vector<uint32_t> h_md_seed_counts, h_md_bnd_counts, h_md_adj;
   std::vector<int32_t> h_md_seed_final, h_md_bnd_final;
+  std::vector<ClusterAcc> h_md_acc;
   size_t cub_temp_bytes = 0;
   // mesh
   MeshBuffers mesh[2]{};
@@ -478,6 +482,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     A(devAlloc(c, &c->d_md_seed_final, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_bnd_final, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_adj, static_cast<size_t>(c->md_list_cap) * 26, false));
+    A(devAlloc(c, &c->d_md_acc, 256));
   }
   if (rc == KHR_OK) {
     size_t t3 = 0;
@@ -885,6 +890,8 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
   if (!c->cfg.with_tracking) return 0;
   const int n = s.sensor.width * s.sensor.height;
   HIP_TRY(hipEventSynchronize(c->ev_seed));
+  c->last_clusters.clear();
+  c->last_cluster_slot = static_cast<int>(&s - c->slots.data());
   if (c->h_pinned[0] == 0) return 0;
 
   // ---- device: seed / boundary voxel tables, compact lists, seed adjacency ------------------------
@@ -1038,10 +1045,12 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
   seed_final.assign(S, 0);
   bnd_final.assign(std::max<uint32_t>(B, 1), 0);
   int id = 1, n_out = 0;
+  std::vector<std::pair<int, uint64_t>> kept;  // (id, pixel list length incl. duplicates)
   for (size_t ci = 0; ci < nc; ++ci) {
     if (!keep[ci]) continue;
     const int size = static_cast<int>(clusters[ci].n_pixels);
     if (size < c->cfg.md_min_cluster_size || size > c->cfg.md_max_cluster_size) continue;
+    kept.emplace_back(id, clusters[ci].n_pixels);
     for (uint32_t r : clusters[ci].seeds) seed_final[r] = id;
     for (uint32_t r : clusters[ci].bnds) bnd_final[r] = id;
     if (id < 255) ++id;
@@ -1051,9 +1060,25 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
     // the host vectors are context members, so the asynchronous upload may outlive this call
     HIP_TRY(hipMemcpyAsync(c->d_md_seed_final, seed_final.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, c->stream));
     if (B) HIP_TRY(hipMemcpyAsync(c->d_md_bnd_final, bnd_final.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, c->stream));
+    // per-cluster accumulators: count 0, bbox = [+max, -max] in ordered-int form, sums 0
+    {
+      std::vector<ClusterAcc> init(256);
+      for (auto& a : init) {
+        a.n_pixels = 0;
+        for (int d = 0; d < 3; ++d) { a.bmin[d] = INT32_MAX; a.bmax[d] = INT32_MIN; a.sum[d] = 0.f; }
+      }
+      c->h_md_acc = init;
+      HIP_TRY(hipMemcpyAsync(c->d_md_acc, c->h_md_acc.data(), sizeof(ClusterAcc) * 256, hipMemcpyHostToDevice, c->stream));
+    }
     hipLaunchKernelGGL(k_md_paint, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds, bnd, c->d_md_seed_final,
-                       c->d_md_bnd_final, s.dyn);
+                       c->d_md_bnd_final, s.dyn, makeDevFrame(c, s), c->d_md_acc);
     HIP_TRY(hipGetLastError());
+    c->last_clusters.resize(kept.size());
+    for (size_t i = 0; i < kept.size(); ++i) {
+      c->last_clusters[i] = khr_cluster{};
+      c->last_clusters[i].id = kept[i].first;
+      c->last_clusters[i].num_pixels_listed = kept[i].second;
+    }
   }
   return n_out;
 }
@@ -1065,6 +1090,28 @@ int khr_detect_motion(khr_ctx* c, int slot) {
   int rc = motionLaunch(c, s, false);
   if (rc) return rc;
   return motionFinish(c, s);
+}
+
+int khr_get_dynamic_clusters(khr_ctx* c, int slot, khr_cluster* out, int cap) {
+  if (!c || cap < 0 || (!out && cap > 0)) return fail(KHR_EINVAL, "bad argument");
+  if (slot != c->last_cluster_slot) return fail(KHR_ESTATE, "dynamic clusters are kept for the last processed frame only");
+  const int n = static_cast<int>(c->last_clusters.size());
+  if (n == 0) return 0;
+  std::vector<ClusterAcc> acc(256);
+  HIP_TRY(hipMemcpyAsync(acc.data(), c->d_md_acc, sizeof(ClusterAcc) * 256, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n && i < cap; ++i) {
+    khr_cluster k = c->last_clusters[i];
+    const ClusterAcc& a = acc[k.id];
+    k.num_pixels_painted = a.n_pixels;
+    for (int d = 0; d < 3; ++d) {
+      k.bbox_min[d] = a.n_pixels ? orderedToFloat(a.bmin[d]) : 0.f;
+      k.bbox_max[d] = a.n_pixels ? orderedToFloat(a.bmax[d]) : 0.f;
+      k.centroid[d] = a.n_pixels ? a.sum[d] / static_cast<float>(a.n_pixels) : 0.f;
+    }
+    out[i] = k;
+  }
+  return n;
 }
 
 int khr_generate_mesh(khr_ctx* c, int only_mesh_updated, int clear_flag) {

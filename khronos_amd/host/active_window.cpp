@@ -87,6 +87,26 @@ void FreeSpaceMotionDetector::processInput(const VolumetricMap& map, FrameData& 
   const int n = khr_detect_motion(map.ctx(), data.input.slot);
   chk(n, "khr_detect_motion");
   data.num_dynamic_clusters = n;
+  fetchClusters(map, data);
+}
+
+void FreeSpaceMotionDetector::fetchClusters(const VolumetricMap& map, FrameData& data) {
+  data.dynamic_clusters.clear();
+  if (data.num_dynamic_clusters <= 0) return;
+  std::vector<khr_cluster> cl(255);
+  const int n = khr_get_dynamic_clusters(map.ctx(), data.input.slot, cl.data(), 255);
+  chk(n, "khr_get_dynamic_clusters");
+  for (int i = 0; i < n; ++i) {
+    MeasurementCluster m;
+    m.id = cl[i].id;
+    m.num_pixels = cl[i].num_pixels_listed;
+    if (cl[i].num_pixels_painted) {
+      m.bounding_box.include(cl[i].bbox_min);
+      m.bounding_box.include(cl[i].bbox_max);
+    }
+    for (int d = 0; d < 3; ++d) m.centroid[d] = cl[i].centroid[d];
+    data.dynamic_clusters.push_back(m);
+  }
 }
 
 // ---- MeshObjectExtractor ----------------------------------------------------------------------------------------
@@ -121,13 +141,50 @@ void MeshObjectExtractor::objectBlockRange(const BoundingBox& extent, float bloc
 std::shared_ptr<KhronosObjectAttributes> MeshObjectExtractor::extractObject(const Track& track, const FrameDataBuffer& frames) {
   // trackIsValid (mesh_object_extractor.cpp:358-...): confidence gate
   if (track.confidence <= config.min_object_allocation_confidence) return nullptr;
-  if (track.is_dynamic) return nullptr;  // dynamic tracks are a host-only trajectory summary (:120-172), not built here
-  auto object = extractStaticObject(track, frames);
+  auto object = track.is_dynamic ? extractDynamicObject(track, frames) : extractStaticObject(track, frames);
   if (!object) return nullptr;
   object->semantic_label = track.semantic_label;
   object->first_observed_ns = {track.first_seen};
   object->last_observed_ns = {track.last_seen};
   for (int i = 0; i < 3; ++i) object->position[i] = object->bounding_box.center(i);
+  return object;
+}
+
+std::shared_ptr<KhronosObjectAttributes> MeshObjectExtractor::extractDynamicObject(const Track& track,
+                                                                                  const FrameDataBuffer& buffer) const {
+  // mesh_object_extractor.cpp:120-172: per observation the cluster centroid -> trajectory, mean bounding-box extent,
+  // maximal displacement from the first position
+  auto object = std::make_shared<KhronosObjectAttributes>();
+  float extent[3] = {0, 0, 0};
+  float max_displacement = 0.f;
+  for (const Observation& o : track.observations) {
+    if (o.dynamic_cluster_id == -1) continue;
+    const FrameData::Ptr f = buffer.getData(o.stamp);
+    if (!f) continue;
+    const MeasurementCluster* cl = nullptr;
+    for (const auto& c : f->dynamic_clusters)
+      if (c.id == o.dynamic_cluster_id) cl = &c;
+    if (!cl) continue;
+    object->trajectory_positions.push_back({cl->centroid[0], cl->centroid[1], cl->centroid[2]});
+    object->trajectory_timestamps.push_back(o.stamp);
+    float d2 = 0.f;
+    for (int i = 0; i < 3; ++i) {
+      extent[i] += cl->bounding_box.dimension(i);
+      const float d = cl->centroid[i] - object->trajectory_positions.front()[i];
+      d2 += d * d;
+    }
+    max_displacement = std::max(max_displacement, std::sqrt(d2));
+  }
+  if (object->trajectory_positions.empty()) return nullptr;                 // :156-160
+  if (max_displacement < config.min_dynamic_displacement) return nullptr;   // :161-166
+  const float n = static_cast<float>(object->trajectory_positions.size());
+  const auto& c0 = object->trajectory_positions.front();
+  BoundingBox bb;  // BoundingBox(mean extent, first position) (:167-168)
+  const float lo[3] = {c0[0] - 0.5f * extent[0] / n, c0[1] - 0.5f * extent[1] / n, c0[2] - 0.5f * extent[2] / n};
+  const float hi[3] = {c0[0] + 0.5f * extent[0] / n, c0[1] + 0.5f * extent[1] / n, c0[2] + 0.5f * extent[2] / n};
+  bb.include(lo);
+  bb.include(hi);
+  object->bounding_box = bb;
   return object;
 }
 
@@ -478,6 +535,7 @@ hydra::ActiveWindowOutput::Ptr ActiveWindow::spinOnce(const hydra::InputPacket& 
     in.slot = khr_process_frame(ctx_, &s, &f, input.on_device ? 1 : 0, flags, &n_clusters);
     if (in.slot < 0) return nullptr;  // "Input packet preprocessing failed. Skipping frame." (:276-279)
     data->num_dynamic_clusters = n_clusters;
+    if (n_clusters > 0) FreeSpaceMotionDetector::fetchClusters(map_, *data);
   } else {
     data = createData(input);
     if (!data) return nullptr;  // the reference dereferences unconditionally here (latent crash)

@@ -36,6 +36,7 @@ struct MeasurementCluster {  // measurement_clusters.h:63-80
   int id = 0;
   size_t num_pixels = 0;
   BoundingBox bounding_box;
+  float centroid[3] = {0, 0, 0};  // utils::computeCentroid of the cluster's vertices
 };
 
 struct FrameData {  // frame_data.h:59-83
@@ -121,6 +122,8 @@ class FreeSpaceMotionDetector : public MotionDetector {  // free_space_motion_de
   explicit FreeSpaceMotionDetector(const Config& config);
   void processInput(const VolumetricMap& map, FrameData& data) override;
   bool isDeviceBacked() const override { return true; }
+  // FrameData::dynamic_clusters from the device (writeClustersToData, free_space_motion_detector.cpp:381-399)
+  static void fetchClusters(const VolumetricMap& map, FrameData& data);
 };
 
 class ObjectDetector {  // object_detector.h: no-op base
@@ -164,6 +167,8 @@ class MeshObjectExtractor : public ObjectExtractor {  // mesh_object_extractor.h
   } const config;
   MeshObjectExtractor(const Config& config, const khr_config& aw_device_config);
   std::shared_ptr<KhronosObjectAttributes> extractObject(const Track& track, const FrameDataBuffer& frames) override;
+  // MeshObjectExtractor::extractDynamicObject (mesh_object_extractor.cpp:120-172): trajectory summary
+  std::shared_ptr<KhronosObjectAttributes> extractDynamicObject(const Track& track, const FrameDataBuffer& frames) const;
   // a13: MeshObjectExtractor::extractStaticObject (mesh_object_extractor.cpp:174-304)
   std::shared_ptr<KhronosObjectAttributes> extractStaticObject(const Track& track, const FrameDataBuffer& frames) const;
   // sizing of the private map (mesh_object_extractor.cpp:201-228): voxel size and block range

@@ -146,6 +146,9 @@ struct KhronosObjectAttributes {
   int semantic_label = -1;
   std::vector<TimeStamp> first_observed_ns, last_observed_ns;
   double position[3] = {0, 0, 0};
+  // dynamic objects (mesh_object_extractor.cpp:120-172)
+  std::vector<std::array<float, 3>> trajectory_positions;
+  std::vector<TimeStamp> trajectory_timestamps;
 };
 
 // hydra::ActiveWindowOutput role (fields set at active_window.cpp:225-247)

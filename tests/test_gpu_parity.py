@@ -53,6 +53,18 @@ def test_sequence_with_motion_detection():
         assert out["n_gpu"] == out["n_ora"], (i, out["n_gpu"], out["n_ora"])
         assert np.array_equal(out["dyn_gpu"], out["dyn_ora"]), i
         fired += out["n_gpu"]
+        # FrameData::dynamic_clusters (free_space_motion_detector.cpp:381-399): id, pixels, bounding box
+        cl = ctx.dynamic_clusters(out["slot"])
+        assert len(cl) == out["n_gpu"]
+        if cl:
+            fr_i = s.render(i)
+            _, vm = ora.parse_input(osen, fr_i["pose"], fr_i["depth"])
+            for c in cl:
+                m = out["dyn_ora"] == c["id"]
+                assert c["num_pixels_painted"] == int(m.sum()) and c["num_pixels_listed"] >= c["num_pixels_painted"]
+                if m.any():
+                    assert np.array_equal(c["bbox_min"], vm[m].min(0)) and np.array_equal(c["bbox_max"], vm[m].max(0))
+                    assert np.allclose(c["centroid"], vm[m].astype(np.float64).mean(0), atol=1e-3)
     assert fired > 0, "motion detector never fired: scenario does not exercise a9-a11"
     compare_maps(ctx, ora, max_blocks=120)
 

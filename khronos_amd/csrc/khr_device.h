@@ -5,7 +5,7 @@
 // slot as the leading index, so that the 4096 (or 512) voxels of one block are contiguous per field:
 //   dist[slot][nvox] f32 | weight[slot][nvox] f32 | color[slot][nvox] rgba8 | last_obs[slot][nvox] u64
 //   last_occ[slot][nvox] u64 | vflags[slot][nvox] u8 | sem_label[slot][nvox] u32
-//   lik[slot][K][nvox] f32 | freebits[slot][nvox/64] u64
+//   lik[slot][nvox][K] f32 (voxel-major: one contiguous K-float run per voxel) | freebits[slot][nvox/64] u64
 // plus an open-addressing hash table  packed BlockIndex -> slot.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -117,15 +117,24 @@ __global__ __launch_bounds__(256) void k_md_seed_insert(const uint64_t* __restri
   atomicAdd(&seeds.counts[voxInsert(seeds, k & ~kSeedBit)], 1u);
 }
 
-__global__ __launch_bounds__(256) void k_md_boundary_insert(const uint64_t* __restrict__ keys, int n, VoxTable seeds,
-                                                           VoxTable bnd, int nn) {
+// every neighbour of every seed voxel -> the "near a seed" set (S * nn insertions, S is small) ...
+__global__ __launch_bounds__(256) void k_md_near_insert(const uint64_t* __restrict__ seed_keys,
+                                                       const uint32_t* __restrict__ n_seeds, uint32_t cap, int nn,
+                                                       VoxTable near) {
+  const uint32_t ns = min(*n_seeds, cap);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns * nn; i += gridDim.x * blockDim.x)
+    voxInsert(near, neighbourKey(seed_keys[i / nn], static_cast<int>(i % nn)));
+}
+
+// ... so that a non-seed pixel needs ONE lookup to know whether its voxel is adjacent to a seed (the
+// neighbour relation is symmetric); such voxels form the boundary table with their pixel counts
+__global__ __launch_bounds__(256) void k_md_boundary_insert(const uint64_t* __restrict__ keys, int n, VoxTable near,
+                                                           VoxTable bnd) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t k = keys[i];
   if (k == ~0ull || (k & kSeedBit)) return;
-  bool adjacent = false;
-  for (int j = 0; j < nn && !adjacent; ++j) adjacent = voxFind(seeds, neighbourKey(k, j)) >= 0;
-  if (adjacent) atomicAdd(&bnd.counts[voxInsert(bnd, k)], 1u);
+  if (voxFind(near, k) >= 0) atomicAdd(&bnd.counts[voxInsert(bnd, k)], 1u);
 }
 
 // occupied table slots -> compact lists (ids are arbitrary but stable for the rest of the frame)
@@ -190,31 +199,60 @@ __global__ __launch_bounds__(256) void k_md_paint(const uint64_t* __restrict__ k
                                                  const int32_t* __restrict__ bnd_final, int32_t* __restrict__ dyn,
                                                  DevFrame f, ClusterAcc* __restrict__ acc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t k = keys[i];
-  if (k == ~0ull) return;
+  const uint64_t k = i < n ? keys[i] : ~0ull;
   int id = 0;
-  if (k & kSeedBit) {
-    const int h = voxFind(seeds, k & ~kSeedBit);
-    if (h >= 0) id = seed_final[seeds.ids[h]];
-  } else {
-    const int h = voxFind(bnd, k);
-    if (h >= 0) id = bnd_final[bnd.ids[h]];
+  if (k != ~0ull) {
+    if (k & kSeedBit) {
+      const int h = voxFind(seeds, k & ~kSeedBit);
+      if (h >= 0) id = seed_final[seeds.ids[h]];
+    } else {
+      const int h = voxFind(bnd, k);
+      if (h >= 0) id = bnd_final[bnd.ids[h]];
+    }
   }
-  if (!id) return;
-  dyn[i] = id;
-  // bounding box / centroid of the cluster from the world-frame vertex of this pixel (:396-397)
-  const float d = f.depth[i];
-  const int u = i % f.W, v = i / f.W;
-  float pw[3];
-  xform(f.Rw, f.tw, ((static_cast<float>(u) - f.cx) / f.fx) * d, ((static_cast<float>(v) - f.cy) / f.fy) * d, d, pw);
-  ClusterAcc* a = acc + id;
-  atomicAdd(&a->n_pixels, 1u);
+  float pw[3] = {0.f, 0.f, 0.f};
+  if (id) {
+    dyn[i] = id;
+    // world-frame vertex of this pixel (:396-397)
+    const float d = f.depth[i];
+    const int u = i % f.W, v = i / f.W;
+    xform(f.Rw, f.tw, ((static_cast<float>(u) - f.cx) / f.fx) * d, ((static_cast<float>(v) - f.cy) / f.fy) * d, d, pw);
+  }
+  // bounding box / centroid / count per cluster: reduce over the lanes of the wave that share an id first
+  // (a wave almost always sees one cluster), then ONE lane per (wave, id) issues the atomics
+  unsigned long long todo = __ballot(id != 0);
+  while (todo) {
+    const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+    const int cid = __shfl(id, leader);
+    const bool mine = id == cid;
+    const unsigned long long grp = __ballot(mine);
+    todo &= ~grp;
+    float mn[3], mx[3], sm[3];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    atomicMin(&a->bmin[c], floatToOrdered(pw[c]));
-    atomicMax(&a->bmax[c], floatToOrdered(pw[c]));
-    atomicAdd(&a->sum[c], pw[c]);
+    for (int c = 0; c < 3; ++c) {
+      mn[c] = mine ? pw[c] : 3.0e38f;
+      mx[c] = mine ? pw[c] : -3.0e38f;
+      sm[c] = mine ? pw[c] : 0.f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+        mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+        sm[c] += __shfl_xor(sm[c], o);
+      }
+    }
+    if (static_cast<int>(laneId()) == leader) {
+      ClusterAcc* a = acc + cid;
+      atomicAdd(&a->n_pixels, static_cast<uint32_t>(__popcll(grp)));
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        atomicMin(&a->bmin[c], floatToOrdered(mn[c]));
+        atomicMax(&a->bmax[c], floatToOrdered(mx[c]));
+        atomicAdd(&a->sum[c], sm[c]);
+      }
+    }
   }
 }
 
@@ -535,8 +573,8 @@ __global__ __launch_bounds__(256) void k_object_prune(DevMap m, DevParams p, flo
       if (d > 0.f) continue;
       float conf = 0.f;
       if (m.vflags[o + lin] & VOX_SEM_VALID) {
-        const float l0 = m.lik[(static_cast<size_t>(s) * p.K + 0) * NV + lin];
-        const float l1 = m.lik[(static_cast<size_t>(s) * p.K + 1) * NV + lin];
+        const float l0 = m.lik[(static_cast<size_t>(s) * NV + lin) * p.K + 0];
+        const float l1 = m.lik[(static_cast<size_t>(s) * NV + lin) * p.K + 1];
         const float total = l0 + l1;
         conf = total < min_obs ? -1.f : l1 / total;
       }

@@ -730,29 +730,59 @@ __global__ __launch_bounds__(256) void k_band_update(DevMap m, DevParams p, DevF
     }
     if (p.with_semantics && have_label && label >= 0 && label < p.K) {
       uint8_t* vfl = m.vflags + slot * NV;
-      float* __restrict__ lik = m.lik + slot * static_cast<size_t>(p.K) * NV;
+      // likelihoods are voxel-major: lik[slot][voxel][K] -> one contiguous K*4-byte run per record
+      float* __restrict__ lik = m.lik + (slot * NV + lin) * static_cast<size_t>(p.K);
       const uint8_t fl = vfl[lin];
       const bool empty = !(fl & VOX_SEM_VALID);
       int bestk = 0;
       float bestv = 0.f;
-      for (int k0 = 0; k0 < p.K; k0 += 8) {
-        float l[8];
+      if ((p.K & 3) == 0) {
+        // 16-byte loads / stores, 4 labels at a time, up to 8 vectors (32 labels) in flight
+        float4* __restrict__ lik4 = reinterpret_cast<float4*>(lik);
+        for (int k0 = 0; k0 < p.K; k0 += 32) {
+          float4 l4[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          l[j] = (!empty && k0 + j < p.K) ? lik[static_cast<size_t>(k0 + j) * NV + lin] : 0.f;
+          for (int j = 0; j < 8; ++j)
+            l4[j] = (!empty && k0 + 4 * j < p.K) ? lik4[(k0 >> 2) + j] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int k = k0 + j;
-          if (k < p.K) {
-            if (p.sem_mode == 1) {
-              if (k == label) l[j] += 1.f;
-            } else {
-              l[j] += (k == label) ? p.log_match : p.log_nomatch;
+          for (int j = 0; j < 8; ++j) {
+            if (k0 + 4 * j >= p.K) continue;
+            float l[4] = {l4[j].x, l4[j].y, l4[j].z, l4[j].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int k = k0 + 4 * j + q;
+              if (p.sem_mode == 1) {
+                if (k == label) l[q] += 1.f;
+              } else {
+                l[q] += (k == label) ? p.log_match : p.log_nomatch;
+              }
+              if (k == 0 || l[q] > bestv) {
+                bestv = l[q];
+                bestk = k;
+              }
             }
-            if (p.sem_mode == 0 || k == label || empty) lik[static_cast<size_t>(k) * NV + lin] = l[j];
-            if (k == 0 || l[j] > bestv) {
-              bestv = l[j];
-              bestk = k;
+            lik4[(k0 >> 2) + j] = make_float4(l[0], l[1], l[2], l[3]);
+          }
+        }
+      } else {
+        for (int k0 = 0; k0 < p.K; k0 += 8) {
+          float l[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) l[j] = (!empty && k0 + j < p.K) ? lik[k0 + j] : 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            if (k < p.K) {
+              if (p.sem_mode == 1) {
+                if (k == label) l[j] += 1.f;
+              } else {
+                l[j] += (k == label) ? p.log_match : p.log_nomatch;
+              }
+              lik[k] = l[j];
+              if (k == 0 || l[j] > bestv) {
+                bestv = l[j];
+                bestk = k;
+              }
             }
           }
         }
@@ -771,12 +801,13 @@ __global__ __launch_bounds__(256) void k_band_update(DevMap m, DevParams p, DevF
 //    stencil (and the multi-GPU halo exchange) consumes instead of re-reading 17 B per neighbour voxel.
 // ----------------------------------------------------------------------------------------------
 template <int VPS>
-__global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, uint64_t stamp) {
+__global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, uint64_t stamp, uint64_t lim_active,
+                                                        uint64_t lim_free) {
+  // lim_active / lim_free: smallest stamps x with toSeconds(x) >= toSeconds(now) - temporal_window resp.
+  // - temporal_buffer, found on the host with the reference's double arithmetic.  x -> fl(double(x)/1e9) is
+  // monotone, so "toSeconds(x) >= T" is exactly "x >= lim" and the kernel needs no fp64 divisions.
   constexpr int NV = VPS * VPS * VPS;
   const uint32_t n_slots = m.counters[C_MAX_SLOT];
-  const double now = toSeconds(stamp);
-  const double t_active = now - p.temporal_window;
-  const double t_free = now - p.temporal_buffer;
   for (uint32_t s = blockIdx.x; s < n_slots; s += gridDim.x) {
     const uint32_t fl = m.blk_flags[s];
     if (!(fl & BLK_LIVE)) continue;  // uniform per workgroup
@@ -817,11 +848,11 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
       for (int k = 0; k < 4; ++k) {
         const uint8_t v = static_cast<uint8_t>(v4 >> (8 * k));
         const bool was_active = v & VOX_ACTIVE;
-        const bool active = toSeconds(lo[k]) >= t_active;
+        const bool active = lo[k] >= lim_active;
         uint8_t nv = static_cast<uint8_t>((v & ~VOX_ACTIVE) | (active ? VOX_ACTIVE : 0));
         if (was_active && !active) nv |= VOX_TO_REMOVE;
         any_active |= active;
-        const bool is_free = (toSeconds(oc[k]) < t_free) && (lo[k] != 0ull);
+        const bool is_free = (oc[k] < lim_free) && (lo[k] != 0ull);
         if ((nv & VOX_EVER_FREE) || is_free) freebits4 |= 1u << k;
         nv4 |= static_cast<uint32_t>(nv) << (8 * k);
       }

@@ -471,9 +471,9 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     while (ts < 2 * npx) ts <<= 1;
     c->md_mask = ts - 1;
     c->md_list_cap = static_cast<uint32_t>(std::min<size_t>(npx, 1u << 20));
-    A(devAlloc(c, &c->d_md_keys, 2 * static_cast<size_t>(ts), false));
-    A(devAlloc(c, &c->d_md_counts, 2 * static_cast<size_t>(ts), false));
-    A(devAlloc(c, &c->d_md_ids, 2 * static_cast<size_t>(ts), false));
+    A(devAlloc(c, &c->d_md_keys, 3 * static_cast<size_t>(ts), false));
+    A(devAlloc(c, &c->d_md_counts, 3 * static_cast<size_t>(ts), false));
+    A(devAlloc(c, &c->d_md_ids, 3 * static_cast<size_t>(ts), false));
     A(devAlloc(c, &c->d_md_n, 4));
     A(devAlloc(c, &c->d_md_seed_keys, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_bnd_keys, c->md_list_cap, false));
@@ -754,8 +754,25 @@ int khr_integrate_shared(khr_ctx* c, khr_ctx* src, int src_slot, int allocate_bl
   return integrateUpdate(c, s, f, allocate_blocks, use_mask, object_id);
 }
 
+// smallest unsigned x with  double(x) / 1e9 >= T  (T = toSeconds(now) - window, reference arithmetic:
+// tracking_integrator.cpp:238,250).  fl(double(x)/1e9) is non-decreasing in x, so a binary search is exact.
+static uint64_t stampThreshold(double T) {
+  auto sec = [](uint64_t x) { return static_cast<double>(x) / 1e9; };
+  if (sec(0) >= T) return 0;
+  uint64_t lo = 0, hi = ~0ull;  // sec(lo) < T; find the first x with sec(x) >= T (or ~0 if none)
+  if (!(sec(hi) >= T)) return hi;
+  while (hi - lo > 1) {
+    const uint64_t mid = lo + (hi - lo) / 2;
+    if (sec(mid) >= T) hi = mid; else lo = mid;
+  }
+  return hi;
+}
+
 static int trackingPhase(khr_ctx* c, uint64_t stamp, int phase) {
   DevMap& m = c->m;
+  const double now = static_cast<double>(stamp) / 1e9;
+  const uint64_t lim_active = stampThreshold(now - c->p.temporal_window);
+  const uint64_t lim_free = stampThreshold(now - c->p.temporal_buffer);
   return dispatchVps(c, [&](auto vps) {
     constexpr int V = decltype(vps)::value;
     if (phase & 1) {
@@ -763,7 +780,8 @@ static int trackingPhase(khr_ctx* c, uint64_t stamp, int phase) {
       hipLaunchKernelGGL(k_list_live, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_ef, &m.counters[C_N_EF],
                          BLK_TRACKING_UPDATED);
       ScopedTimer tm(c, 1);
-      hipLaunchKernelGGL((k_tracking_update<V>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, stamp);
+      hipLaunchKernelGGL((k_tracking_update<V>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, stamp, lim_active,
+                         lim_free);
     }
     if (phase & 2) {
       ScopedTimer tm(c, 2);
@@ -899,14 +917,16 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
   const size_t tsize = static_cast<size_t>(c->md_mask) + 1;
   VoxTable seeds{c->d_md_keys, c->d_md_counts, c->d_md_ids, c->md_mask};
   VoxTable bnd{c->d_md_keys + tsize, c->d_md_counts + tsize, c->d_md_ids + tsize, c->md_mask};
-  HIP_TRY(hipMemsetAsync(c->d_md_keys, 0xff, sizeof(uint64_t) * 2 * tsize, c->stream));
+  VoxTable near{c->d_md_keys + 2 * tsize, c->d_md_counts + 2 * tsize, c->d_md_ids + 2 * tsize, c->md_mask};
+  HIP_TRY(hipMemsetAsync(c->d_md_keys, 0xff, sizeof(uint64_t) * 3 * tsize, c->stream));
   HIP_TRY(hipMemsetAsync(c->d_md_counts, 0, sizeof(uint32_t) * 2 * tsize, c->stream));
   HIP_TRY(hipMemsetAsync(c->d_md_n, 0, sizeof(uint32_t) * 2, c->stream));
-  hipLaunchKernelGGL(k_md_seed_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds);
-  hipLaunchKernelGGL(k_md_boundary_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds, bnd, nn);
   const uint32_t cap = c->md_list_cap;
+  hipLaunchKernelGGL(k_md_seed_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds);
   hipLaunchKernelGGL(k_md_compact, dim3(gridFor(tsize)), dim3(256), 0, c->stream, seeds, c->d_md_seed_keys,
                      c->d_md_seed_counts, c->d_md_n, cap);
+  hipLaunchKernelGGL(k_md_near_insert, dim3(256), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_n, cap, nn, near);
+  hipLaunchKernelGGL(k_md_boundary_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, near, bnd);
   hipLaunchKernelGGL(k_md_compact, dim3(gridFor(tsize)), dim3(256), 0, c->stream, bnd, c->d_md_bnd_keys, c->d_md_bnd_counts,
                      c->d_md_n + 1, cap);
   hipLaunchKernelGGL(k_md_adjacency, dim3(1024), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_n, seeds, bnd, nn, cap,
@@ -1379,11 +1399,18 @@ int khr_download_block(khr_ctx* c, int32_t bx, int32_t by, int32_t bz, float* di
     if (c->cfg.with_semantics) HIP_TRY(D(sem_label, m.sem_label + slot * nv, nv * 4));
     else std::memset(sem_label, 0, nv * 4);
   }
-  if (likelihoods && c->cfg.with_semantics) HIP_TRY(D(likelihoods, m.lik + slot * nv * c->p.K, nv * c->p.K * 4));
+  std::vector<float> lik_vm;  // device layout is voxel-major [voxel][K]; the API hands out [k][voxel]
+  if (likelihoods && c->cfg.with_semantics) {
+    lik_vm.resize(nv * c->p.K);
+    HIP_TRY(D(lik_vm.data(), m.lik + slot * nv * c->p.K, nv * c->p.K * 4));
+  }
   uint32_t bf = 0;
   if (block_flags) HIP_TRY(D(&bf, m.blk_flags + slot, 4));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (block_flags) *block_flags = static_cast<uint8_t>(bf & 0xfu);
+  if (likelihoods && c->cfg.with_semantics)
+    for (size_t i = 0; i < nv; ++i)
+      for (int k = 0; k < c->p.K; ++k) likelihoods[static_cast<size_t>(k) * nv + i] = lik_vm[i * c->p.K + k];
   // voxels whose semantic entry is still empty carry undefined likelihood storage: report zeros
   if (likelihoods && c->cfg.with_semantics) {
     std::vector<uint8_t> fl(nv);

@@ -132,7 +132,8 @@ def main():
     if world > 1:
         from khronos_amd.distributed import HipShard, ShardedFusion
         with torch.cuda.stream(stream):
-            fusion = ShardedFusion(HipShard(ctx, sensor, args.halo_cap, dev), dist, world)
+            fusion = ShardedFusion(HipShard(ctx, sensor, args.halo_cap, dev, n_cameras=world), dist, world,
+                                   motion=not args.no_motion, count_device=dev if backend == "nccl" else "cpu")
 
     def step(i):
         with torch.cuda.stream(stream):
@@ -222,10 +223,10 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: %dx%d synthetic RGB-D+labels, %g cm voxels, vps 16, K=%d labels, "
                                "MotionDetector %s, output extraction every %d frames; %d camera(s)"
-                               % (W, H, vs * 100, K, "off" if (args.no_motion or world > 1) else "on",
+                               % (W, H, vs * 100, K, "off" if args.no_motion else "on",
                                   args.output_every, world),
                    "parallelism": "hash-range block shard x%d, owner-computes, RCCL all-gather of frames + of 528-B halo records "
-                                  "(ever-free); motion detector and mesh halo not exchanged yet" % world
+                                  "(ever-free), seed-gated all-reduce of per-pixel voxel keys (motion detector); mesh halo not exchanged yet" % world
                    if world > 1 else "single GPU"},
         "mvoxel_updates_per_s": 1e-6 * n_upd_all / dt,
         "voxels": {"visited": n_vis_all, "updated": n_upd_all, "band": n_band_all, "allocated_blocks": st1["n_allocated_blocks"],

@@ -190,6 +190,14 @@ int khr_import_halo(khr_ctx* ctx, const void* records, int64_t n_records, int on
 /* replaces: FreeSpaceMotionDetector::processInput (free_space_motion_detector.cpp:73-103).
  * Writes the slot's dynamic_image on the device; returns the number of clusters kept (>= 0). */
 int khr_detect_motion(khr_ctx* ctx, int slot);
+/* Multi-GPU form of khr_detect_motion (no reference equivalent).  khr_motion_keys runs the per-pixel pass
+ * (setUpPointMapPart, free_space_motion_detector.cpp:158-203) against THIS rank's shard of the map and writes
+ * one u64 per pixel: the packed global voxel index with the ever-free (seed) flag in bit 63, or 0 if the pixel
+ * is skipped or falls into a block this rank does not own; *n_seed_pixels = seed pixels seen by this rank.
+ * Exactly one rank owns the block a pixel falls into, so a sum all-reduce over the ranks assembles the full
+ * key image; khr_detect_motion_from_keys then clusters and paints from it (identical on every rank). */
+int khr_motion_keys(khr_ctx* ctx, int slot, void* keys_out, int on_device, uint32_t* n_seed_pixels);
+int khr_detect_motion_from_keys(khr_ctx* ctx, int slot, const void* keys, int on_device);
 /* FrameData::dynamic_clusters of the frame last passed to khr_detect_motion / khr_process_frame.
  * Returns the number of clusters (writes min(n, cap)); synchronises. */
 int khr_get_dynamic_clusters(khr_ctx* ctx, int slot, khr_cluster* out, int cap);

@@ -65,7 +65,8 @@ EXPORTS = [
     "khr_allocate_blocks", "khr_object_prune", "khr_get_stats", "khr_num_blocks", "khr_block_indices",
     "khr_download_block", "khr_mesh_num_vertices", "khr_download_mesh", "khr_timing_enable", "khr_timing_reset",
     "khr_timing_get", "khr_debug_read", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_update_tracking_phase",
-    "khr_export_halo", "khr_import_halo", "khr_get_dynamic_clusters",
+    "khr_export_halo", "khr_import_halo", "khr_get_dynamic_clusters", "khr_motion_keys",
+    "khr_detect_motion_from_keys",
 ]
 
 _lib = None
@@ -105,6 +106,8 @@ def load_library():
     lib.khr_export_halo.argtypes = [vp, vp, i64, i32]
     lib.khr_import_halo.argtypes = [vp, vp, i64, i32]
     lib.khr_detect_motion.argtypes = [vp, i32]
+    lib.khr_motion_keys.argtypes = [vp, i32, vp, i32, C.POINTER(C.c_uint32)]
+    lib.khr_detect_motion_from_keys.argtypes = [vp, i32, vp, i32]
     lib.khr_get_dynamic_clusters.argtypes = [vp, i32, C.POINTER(KhrCluster), i32]
     lib.khr_generate_mesh.argtypes = [vp, i32, i32]
     lib.khr_reset_inactive.argtypes = [vp, vp, i64, C.POINTER(i64)]
@@ -293,6 +296,22 @@ class FusionContext:
 
     def detect_motion(self, slot):
         return self._chk(self.lib.khr_detect_motion(self.h, slot))
+
+    def motion_keys(self, slot, shape=None, device_ptr=None):
+        """per-pixel voxel keys of this rank's shard (0 = not mine / skipped); returns (keys or None, n_seed_pixels)."""
+        ns = C.c_uint32(0)
+        if device_ptr is not None:
+            self._chk(self.lib.khr_motion_keys(self.h, slot, C.c_void_p(device_ptr), 1, C.byref(ns)))
+            return None, ns.value
+        out = np.zeros(shape, np.uint64)
+        self._chk(self.lib.khr_motion_keys(self.h, slot, _ptr(out), 0, C.byref(ns)))
+        return out, ns.value
+
+    def detect_motion_from_keys(self, slot, keys=None, device_ptr=None):
+        if device_ptr is not None:
+            return self._chk(self.lib.khr_detect_motion_from_keys(self.h, slot, C.c_void_p(device_ptr), 1))
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        return self._chk(self.lib.khr_detect_motion_from_keys(self.h, slot, _ptr(keys), 0))
 
     def dynamic_clusters(self, slot):
         arr = (KhrCluster * 255)()

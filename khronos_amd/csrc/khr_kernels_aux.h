@@ -62,6 +62,25 @@ __global__ __launch_bounds__(256) void k_motion_pixels(DevMap m, DevParams p, De
     atomicAdd(&m.counters[C_N_SEEDS], static_cast<uint32_t>(__popcll(b)));
 }
 
+// key exchange for sharded maps (multi-GPU): non-owned / skipped pixels travel as 0 so that an all-reduce
+// (sum) over the ranks assembles the full key image (exactly one rank owns the block a pixel falls in)
+__global__ __launch_bounds__(256) void k_md_keys_export(const uint64_t* __restrict__ keys, int n, uint64_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = keys[i] == ~0ull ? 0ull : keys[i];
+}
+__global__ __launch_bounds__(256) void k_md_keys_import(const uint64_t* __restrict__ in, int n, uint64_t* __restrict__ keys,
+                                                       uint32_t* __restrict__ n_seed_px) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t k = ~0ull;
+  if (i < n) {
+    k = in[i] == 0ull ? ~0ull : in[i];
+    keys[i] = k;
+  }
+  const unsigned long long b = __ballot(k != ~0ull && (k & kSeedBit));
+  if (b && laneId() == static_cast<uint32_t>(__ffsll(static_cast<long long>(b)) - 1))
+    atomicAdd(n_seed_px, static_cast<uint32_t>(__popcll(b)));
+}
+
 // ----------------------------------------------------------------------------------------------
 // Seed-frame pipeline of the motion detector (clusterDynamicVoxels inputs, free_space_motion_detector.cpp
 // :205-272).  The reference's nested hash maps voxel -> pixels become two device hash tables keyed by the

@@ -1112,6 +1112,56 @@ int khr_detect_motion(khr_ctx* c, int slot) {
   return motionFinish(c, s);
 }
 
+int khr_motion_keys(khr_ctx* c, int slot, void* keys_out, int on_device, uint32_t* n_seed_pixels) {
+  if (!c || !keys_out || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  FrameSlot& s = c->slots[slot];
+  const int n = s.sensor.width * s.sensor.height;
+  int rc = motionLaunch(c, s, false);
+  if (rc) return rc;
+  uint64_t* dst = static_cast<uint64_t*>(keys_out);
+  uint64_t* tmp = nullptr;
+  if (!on_device) {
+    HIP_TRY(hipMalloc(&tmp, sizeof(uint64_t) * n));
+    dst = tmp;
+  }
+  hipLaunchKernelGGL(k_md_keys_export, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, dst);
+  if (!on_device) {
+    hipError_t e = hipMemcpyAsync(keys_out, tmp, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(tmp);
+    if (e != hipSuccess) return fail(KHR_EDEVICE, "key export failed: %s", hipGetErrorString(e));
+  }
+  HIP_TRY(hipEventSynchronize(c->ev_seed));
+  if (n_seed_pixels) *n_seed_pixels = c->h_pinned[0];
+  return KHR_OK;
+}
+
+int khr_detect_motion_from_keys(khr_ctx* c, int slot, const void* keys, int on_device) {
+  if (!c || !keys || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  FrameSlot& s = c->slots[slot];
+  const int n = s.sensor.width * s.sensor.height;
+  const uint64_t* src = static_cast<const uint64_t*>(keys);
+  uint64_t* tmp = nullptr;
+  if (!on_device) {
+    HIP_TRY(hipMalloc(&tmp, sizeof(uint64_t) * n));
+    HIP_TRY(hipMemcpyAsync(tmp, keys, sizeof(uint64_t) * n, hipMemcpyHostToDevice, c->stream));
+    src = tmp;
+  }
+  HIP_TRY(hipMemsetAsync(s.dyn, 0, sizeof(int32_t) * n, c->stream));
+  HIP_TRY(hipMemsetAsync(&c->m.counters[C_N_SEEDS], 0, sizeof(uint32_t), c->stream));
+  hipLaunchKernelGGL(k_md_keys_import, dim3(gridFor(n)), dim3(256), 0, c->stream, src, n, c->d_keys, &c->m.counters[C_N_SEEDS]);
+  HIP_TRY(hipMemcpyAsync(&c->h_pinned[0], &c->m.counters[C_N_SEEDS], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipEventRecord(c->ev_seed, c->stream));
+  const int nc = motionFinish(c, s);
+  if (tmp) {
+    hipStreamSynchronize(c->stream);
+    hipFree(tmp);
+  }
+  return nc;
+}
+
 int khr_get_dynamic_clusters(khr_ctx* c, int slot, khr_cluster* out, int cap) {
   if (!c || cap < 0 || (!out && cap > 0)) return fail(KHR_EINVAL, "bad argument");
   if (slot != c->last_cluster_slot) return fail(KHR_ESTATE, "dynamic clusters are kept for the last processed frame only");

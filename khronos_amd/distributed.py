@@ -1,10 +1,16 @@
 """Multi-GPU tick orchestration: one process per GPU, the block map sharded by contiguous
-hash range, owner-computes.  Per tick the ranks (1) all-gather the camera frames, (2) integrate every frame
-into the blocks they own, (3) run the per-voxel tracking update, (4) all-gather fixed-size halo records
-(528 B per live block: key + 4096 free-or-ever-free bits), (5) run the ever-free stencil with remote
-neighbours served from the gathered records.  The collectives are torch.distributed calls (backend `nccl` =
-RCCL over xGMI on the GPUs, `gloo` in the CPU tests); the shard itself is any object with the small
-interface below (HipShard here; the tests plug the CPU oracle in to check the protocol).
+hash range, owner-computes.  Per tick the ranks
+  (1) all-gather the camera frames (done by the caller),
+  (2) run the motion detector's per-pixel pass on their shard; a small all-reduce of the seed-pixel counts
+      decides which cameras need the (rare) sum all-reduce of the per-pixel voxel keys, after which every rank
+      clusters and paints the identical dynamic image,
+  (3) integrate every frame into the blocks they own (with the dynamic mask),
+  (4) run the per-voxel tracking update,
+  (5) all-gather fixed-size halo records (528 B per live block: key + 4096 free-or-ever-free bits),
+  (6) run the ever-free stencil with remote neighbours served from the gathered records.
+The collectives are torch.distributed calls (backend `nccl` = RCCL over xGMI on the GPUs, `gloo` in the CPU
+tests); the shard itself is any object with the small interface below (HipShard here; the tests plug the CPU
+oracle in to check the protocol).
 """
 import numpy as np
 import torch
@@ -13,16 +19,27 @@ HALO_WORDS = 66
 
 
 class HipShard:
-    """Shard backend over a khronos_amd.FusionContext; halo buffers are HBM-resident torch tensors."""
+    """Shard backend over a khronos_amd.FusionContext; exchange buffers are HBM-resident torch tensors."""
 
-    def __init__(self, ctx, sensor, halo_cap, device):
+    def __init__(self, ctx, sensor, halo_cap, device, n_cameras=1):
         self.ctx, self.sensor, self.halo_cap, self.device = ctx, sensor, halo_cap, device
         self.send = torch.zeros((halo_cap, HALO_WORDS), dtype=torch.int64, device=device)
+        n = sensor.width * sensor.height
+        self.keys = [torch.zeros(n, dtype=torch.int64, device=device) for _ in range(n_cameras)]
 
-    def integrate(self, stamp, pose, depth, rgb, label):
-        """depth / rgb / label: device tensors."""
-        slot = self.ctx.upload_frame_device(self.sensor, stamp, pose, depth.data_ptr(), rgb.data_ptr(), label.data_ptr())
-        self.ctx.integrate(slot, allocate_blocks=True, use_mask=False)
+    def upload(self, cam, stamp, pose, depth, rgb, label):
+        """depth / rgb / label: device tensors.  Returns the frame slot."""
+        return self.ctx.upload_frame_device(self.sensor, stamp, pose, depth.data_ptr(), rgb.data_ptr(), label.data_ptr())
+
+    def motion_keys(self, cam, slot):
+        _, n_seed = self.ctx.motion_keys(slot, device_ptr=self.keys[cam].data_ptr())
+        return self.keys[cam], n_seed
+
+    def motion_finish(self, cam, slot, keys):
+        return self.ctx.detect_motion_from_keys(slot, device_ptr=keys.data_ptr())
+
+    def integrate(self, cam, slot, use_mask):
+        self.ctx.integrate(slot, allocate_blocks=True, use_mask=use_mask)
 
     def tracking_phase(self, stamp, phase):
         self.ctx.update_tracking_phase(stamp, phase)
@@ -36,9 +53,11 @@ class HipShard:
 
 
 class ShardedFusion:
-    def __init__(self, shard, dist=None, world_size=1):
-        self.shard, self.dist, self.world = shard, dist, world_size
+    def __init__(self, shard, dist=None, world_size=1, motion=True, count_device="cpu"):
+        self.shard, self.dist, self.world, self.motion = shard, dist, world_size, motion
+        self.count_device = count_device
         self._recv = None
+        self.clusters_last_tick = []
 
     def all_gather(self, t):
         if self.dist is None or self.world == 1:
@@ -50,8 +69,25 @@ class ShardedFusion:
 
     def tick(self, stamp, cameras):
         """cameras: list of (pose, depth, rgb, label) for ALL cameras of the rig (already gathered)."""
-        for pose, depth, rgb, label in cameras:
-            self.shard.integrate(stamp, pose, depth, rgb, label)
+        slots = [self.shard.upload(ci, stamp, pose, depth, rgb, label) for ci, (pose, depth, rgb, label) in enumerate(cameras)]
+        self.clusters_last_tick = [0] * len(cameras)
+        if self.motion:
+            keys, counts = [], []
+            for ci, slot in enumerate(slots):
+                k, n = self.shard.motion_keys(ci, slot)
+                keys.append(k)
+                counts.append(n)
+            cnt = torch.tensor(counts, dtype=torch.int64, device=self.count_device)
+            if self.dist is not None and self.world > 1:
+                self.dist.all_reduce(cnt)  # which cameras have seeds anywhere
+            for ci, slot in enumerate(slots):
+                if int(cnt[ci]) == 0:
+                    continue  # no seeds on any rank => no clusters, empty dynamic image
+                if self.dist is not None and self.world > 1:
+                    self.dist.all_reduce(keys[ci])  # exactly one non-zero contribution per pixel
+                self.clusters_last_tick[ci] = self.shard.motion_finish(ci, slot, keys[ci])
+        for ci, slot in enumerate(slots):
+            self.shard.integrate(ci, slot, use_mask=self.motion)
         self.shard.tracking_phase(stamp, 1)
         if self.world > 1:
             self.shard.import_halo(self.all_gather(self.shard.export_halo(stamp)))

@@ -752,27 +752,28 @@ int orc_get_block(const orc_map* m, int32_t bx, int32_t by, int32_t bz, float* d
 // ---------------------------------------------------------------------------------------------
 // FreeSpaceMotionDetector (free_space_motion_detector.cpp:73-399)
 // ---------------------------------------------------------------------------------------------
-int orc_detect_motion(orc_map* m, const orc_sensor* s, const orc_frame* f, int32_t* dynamic_image_out,
-                      int64_t* n_seeds_out) {
+static inline uint64_t packVoxelKey(int64_t x, int64_t y, int64_t z) {
+  return (static_cast<uint64_t>(static_cast<uint32_t>(x + (1 << 20)) & 0x1fffffu)) |
+         (static_cast<uint64_t>(static_cast<uint32_t>(y + (1 << 20)) & 0x1fffffu) << 21) |
+         (static_cast<uint64_t>(static_cast<uint32_t>(z + (1 << 20)) & 0x1fffffu) << 42);
+}
+
+// stage 1: setUpPointMap(Part) (free_space_motion_detector.cpp:105-203) against THIS shard of the map: one
+// key per pixel = packed global voxel index, bit 63 = the voxel is ever-free (seed); 0 = skipped / not in
+// this shard (multi-GPU key exchange format of include/khronos_amd.h)
+void orc_motion_keys(orc_map* m, const orc_sensor* s, const orc_frame* f, uint64_t* keys_out) {
   const orc_config& c = m->cfg;
   const int W = s->width, H = s->height;
-  std::memset(dynamic_image_out, 0, sizeof(int32_t) * W * H);
   std::vector<float> range(static_cast<size_t>(W) * H), vertex(static_cast<size_t>(W) * H * 3);
   orc_parse_input(&c, s, f->world_T_sensor, f->depth, range.data(), vertex.data());
-  const Pose pose = makePose(f->world_T_sensor);
   // :80  min_z_world_ = sensor z + min_z_coordinate
   const float min_z_world =
       static_cast<float>(f->world_T_sensor[11] + static_cast<double>(c.md_min_z_coordinate));
-  (void)pose;
-
-  // setUpPointMap(Part) :105-203. Column stripes + merge are order-only; the canonical result is a
-  // map voxel -> pixels in (stripe, v, u) order.  We use a single ordered map keyed by global index.
-  std::unordered_map<L3, std::vector<int32_t>, L3Hash> point_map;  // pixel = v*W+u
-  std::unordered_set<L3, L3Hash> seeds;
   const int vps = m->vps;
   for (int v = 0; v < H; ++v) {
     for (int u = 0; u < W; ++u) {
       const int i = v * W + u;
+      keys_out[i] = 0;
       const float r = range[i];
       if (r <= 0.f || r > c.md_max_range) continue;  // :169-172
       const float* p = &vertex[3 * i];
@@ -790,11 +791,28 @@ int orc_detect_motion(orc_map* m, const orc_sensor* s, const orc_frame* f, int32
       // :192-197 invalid voxel index (float rounding at block border): the pixel lands in a map entry
       // that can never be addressed by keyFromGlobalIndex => equivalent to dropping it.
       if (vx < 0 || vy < 0 || vz < 0 || vx >= vps || vy >= vps || vz >= vps) continue;
-      const L3 g = {static_cast<int64_t>(bi.x) * vps + vx, static_cast<int64_t>(bi.y) * vps + vy,
-                    static_cast<int64_t>(bi.z) * vps + vz};
-      point_map[g].push_back(i);
-      if (b->tracking[vx + vps * (vy + vps * vz)].ever_free) seeds.insert(g);  // :198-201
+      uint64_t key = packVoxelKey(static_cast<int64_t>(bi.x) * vps + vx, static_cast<int64_t>(bi.y) * vps + vy,
+                                  static_cast<int64_t>(bi.z) * vps + vz);
+      if (b->tracking[vx + vps * (vy + vps * vz)].ever_free) key |= 1ull << 63;  // :198-201
+      keys_out[i] = key;
     }
+  }
+}
+
+// stage 2: clustering, merging, filtering and painting from the (complete) key image
+int orc_detect_motion_from_keys(orc_map* m, int W, int H, const uint64_t* keys, int32_t* dynamic_image_out,
+                                int64_t* n_seeds_out) {
+  const orc_config& c = m->cfg;
+  std::memset(dynamic_image_out, 0, sizeof(int32_t) * W * H);
+  std::unordered_map<L3, std::vector<int32_t>, L3Hash> point_map;  // pixel = v*W+u, in (v, u) order
+  std::unordered_set<L3, L3Hash> seeds;
+  for (int i = 0; i < W * H; ++i) {
+    const uint64_t k = keys[i];
+    if (k == 0) continue;
+    const L3 g = {static_cast<int64_t>(k & 0x1fffffu) - (1 << 20), static_cast<int64_t>((k >> 21) & 0x1fffffu) - (1 << 20),
+                  static_cast<int64_t>((k >> 42) & 0x1fffffu) - (1 << 20)};
+    point_map[g].push_back(i);
+    if (k >> 63) seeds.insert(g);
   }
   if (n_seeds_out) *n_seeds_out = static_cast<int64_t>(seeds.size());
 
@@ -903,6 +921,13 @@ int orc_detect_motion(orc_map* m, const orc_sensor* s, const orc_frame* f, int32
     ++n_out;
   }
   return n_out;
+}
+
+int orc_detect_motion(orc_map* m, const orc_sensor* s, const orc_frame* f, int32_t* dynamic_image_out,
+                      int64_t* n_seeds_out) {
+  std::vector<uint64_t> keys(static_cast<size_t>(s->width) * s->height);
+  orc_motion_keys(m, s, f, keys.data());
+  return orc_detect_motion_from_keys(m, s->width, s->height, keys.data(), dynamic_image_out, n_seeds_out);
 }
 
 // ---------------------------------------------------------------------------------------------

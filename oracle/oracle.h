@@ -124,6 +124,11 @@ void orc_clear_updated(orc_map* m);
 int orc_detect_motion(orc_map* m, const orc_sensor* s, const orc_frame* f, int32_t* dynamic_image_out,
                       int64_t* n_seeds_out);
 
+/* the two stages of orc_detect_motion, for the multi-GPU key exchange (format: include/khronos_amd.h) */
+void orc_motion_keys(orc_map* m, const orc_sensor* s, const orc_frame* f, uint64_t* keys_out);
+int orc_detect_motion_from_keys(orc_map* m, int W, int H, const uint64_t* keys, int32_t* dynamic_image_out,
+                                int64_t* n_seeds_out);
+
 /* hydra::MeshIntegrator::generateMesh (calls active_window.cpp:223, mesh_object_extractor.cpp:267).
  * Mesh is kept inside the map per block. returns #mesh blocks regenerated. */
 int64_t orc_generate_mesh(orc_map* m, int only_mesh_updated, int clear_flag);

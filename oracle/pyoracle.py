@@ -78,6 +78,9 @@ def load():
     lib.orc_clear_updated.argtypes = [vp]
     lib.orc_clear_updated.restype = None
     lib.orc_detect_motion.argtypes = [vp, C.POINTER(OrcSensor), C.POINTER(OrcFrame), vp, C.POINTER(i64)]
+    lib.orc_motion_keys.argtypes = [vp, C.POINTER(OrcSensor), C.POINTER(OrcFrame), vp]
+    lib.orc_motion_keys.restype = None
+    lib.orc_detect_motion_from_keys.argtypes = [vp, i32, i32, vp, vp, C.POINTER(i64)]
     lib.orc_generate_mesh.argtypes = [vp, i32, i32]
     lib.orc_generate_mesh.restype = i64
     lib.orc_mesh_num_vertices.argtypes = [vp]
@@ -193,6 +196,20 @@ class OracleMap:
         dyn = np.zeros((sensor.height, sensor.width), np.int32)
         ns = C.c_int64(0)
         n = self.lib.orc_detect_motion(self.h, C.byref(sensor), C.byref(f), _ptr(dyn), C.byref(ns))
+        return n, dyn, ns.value
+
+    def motion_keys(self, sensor, stamp_ns, T, depth):
+        f, keep = self._frame(stamp_ns, T, depth)
+        keys = np.zeros((sensor.height, sensor.width), np.uint64)
+        self.lib.orc_motion_keys(self.h, C.byref(sensor), C.byref(f), _ptr(keys))
+        return keys
+
+    def detect_motion_from_keys(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        h, w = keys.shape
+        dyn = np.zeros((h, w), np.int32)
+        ns = C.c_int64(0)
+        n = self.lib.orc_detect_motion_from_keys(self.h, w, h, _ptr(keys), _ptr(dyn), C.byref(ns))
         return n, dyn, ns.value
 
     def generate_mesh(self, only_mesh_updated=True, clear_flag=True):

@@ -17,15 +17,35 @@ from khronos_amd.synth import SyntheticStream  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
 from test_cpu_oracle import _cfg  # noqa: E402
 
-W, H, N_FRAMES, HALO_CAP = 160, 120, 14, 1024
+W, H, N_FRAMES, HALO_CAP = 160, 120, 22, 1024
 
 
 class OracleShard:
+    """khronos_amd.distributed shard interface on top of the CPU oracle (frames kept per camera slot)."""
+
     def __init__(self, omap, sensor, halo_cap):
         self.m, self.sensor, self.halo_cap = omap, sensor, halo_cap
+        self.frames, self.dyn = {}, {}
 
-    def integrate(self, stamp, pose, depth, rgb, label):
-        self.m.integrate(self.sensor, stamp, pose, depth.numpy(), rgb.numpy(), label.numpy())
+    def upload(self, cam, stamp, pose, depth, rgb, label):
+        self.frames[cam] = (stamp, pose, depth.numpy(), rgb.numpy(), label.numpy())
+        self.dyn[cam] = None
+        return cam
+
+    def motion_keys(self, cam, slot):
+        stamp, pose, depth, _, _ = self.frames[cam]
+        keys = self.m.motion_keys(self.sensor, stamp, pose, depth)
+        return torch.from_numpy(keys.view(np.int64).reshape(-1)), int((keys >> np.uint64(63)).sum())
+
+    def motion_finish(self, cam, slot, keys):
+        h, w = self.sensor.height, self.sensor.width
+        n, dyn, _ = self.m.detect_motion_from_keys(keys.numpy().view(np.uint64).reshape(h, w))
+        self.dyn[cam] = dyn
+        return n
+
+    def integrate(self, cam, slot, use_mask):
+        stamp, pose, depth, rgb, label = self.frames[cam]
+        self.m.integrate(self.sensor, stamp, pose, depth, rgb, label, mask=self.dyn[cam] if use_mask else None)
 
     def tracking_phase(self, stamp, phase):
         self.m.update_tracking_phase(stamp, phase)
@@ -42,9 +62,11 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     s = SyntheticStream(W, H, threads=1)
     sen = po.OrcSensor(W, H, s.fx, s.fy, s.cx, s.cy, 0.1, 5.0)
-    shard = po.OracleMap(_cfg(rank=rank, world_size=world, voxel_size=0.2, truncation_distance=0.4))
-    full = po.OracleMap(_cfg(voxel_size=0.2, truncation_distance=0.4))
+    kw = dict(voxel_size=0.1, truncation_distance=0.3, md_min_cluster_size=5, md_min_separation_distance=2.0, md_max_range=5.0)
+    shard = po.OracleMap(_cfg(rank=rank, world_size=world, **kw))
+    full = po.OracleMap(_cfg(**kw))
     fusion = ShardedFusion(OracleShard(shard, sen, HALO_CAP), dist, world)
+    clusters_total = 0
     for i in range(N_FRAMES):
         # rank r renders camera r of the rig; the frames are all-gathered like in bench.py
         yaw = 2 * np.pi * rank / world
@@ -58,9 +80,14 @@ def main():
         cams = [(s.pose(i, yaw_offset=2 * np.pi * r / world), gathered[0][r], gathered[1][r], gathered[2][r])
                 for r in range(world)]
         fusion.tick(fr["stamp"], cams)
-        for pose, d, c, l in cams:
-            full.integrate(sen, fr["stamp"], pose, d.numpy(), c.numpy(), l.numpy())
+        n_full = []
+        for pose, d, c, l in cams:  # reference order: motion detection, then integration with the mask
+            n, dyn, _ = full.detect_motion(sen, fr["stamp"], pose, d.numpy())
+            n_full.append(n)
+            full.integrate(sen, fr["stamp"], pose, d.numpy(), c.numpy(), l.numpy(), mask=dyn)
         full.update_tracking(fr["stamp"])
+        assert fusion.clusters_last_tick == n_full, (i, fusion.clusters_last_tick, n_full)
+        clusters_total += sum(n_full)
     # every block of the shard equals the unsharded block, field by field (incl. ever_free bits)
     mine = shard.block_indices()
     all_idx = full.block_indices()
@@ -77,8 +104,9 @@ def main():
     tot = torch.tensor([ef], dtype=torch.int64)
     dist.all_reduce(tot)
     assert int(tot) > 0, "ever-free never fired: the halo path was not exercised"
+    assert clusters_total > 0, "motion detector never fired: the key exchange was not exercised"
     if rank == 0:
-        print("DIST_OK blocks=%d ever_free=%d" % (len(all_idx), int(tot)))
+        print("DIST_OK blocks=%d ever_free=%d clusters=%d" % (len(all_idx), int(tot), clusters_total))
     dist.destroy_process_group()
 
 

@@ -236,3 +236,44 @@ def test_two_shards_with_halo_exchange_equal_unsharded():
     og = rg[np.argsort(rg[:n, 0])]
     oo = ro[np.argsort(ro[:n, 0])]
     assert np.array_equal(og[:n], oo[:n])
+
+
+def test_two_shards_motion_key_exchange():
+    """sharded motion detection: per-shard voxel keys summed over the ranks == unsharded keys, and clustering
+    from the summed keys paints the same dynamic image on every shard as the unsharded detector."""
+    cfg, ctx, ora, s, sen, osen = make_pair(width=320, height=240)
+    _, c0, _, _, _, _ = make_pair(width=320, height=240, rank=0, world_size=2)
+    _, c1, _, _, _, _ = make_pair(width=320, height=240, rank=1, world_size=2)
+    fired = 0
+    for i in range(20):
+        fr = s.render(i)
+        slot = ctx.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+        n_full = ctx.detect_motion(slot)
+        dyn_full = ctx.download_frame(slot, fr["depth"].shape, range_image=False, dynamic_image=True)[2]
+        ctx.integrate(slot, use_mask=True)
+        ctx.update_tracking(fr["stamp"])
+        slots, keys, seeds = [], [], []
+        for c in (c0, c1):
+            sl = c.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+            k, n = c.motion_keys(sl, shape=fr["depth"].shape)
+            slots.append(sl); keys.append(k); seeds.append(n)
+        assert not np.any((keys[0] != 0) & (keys[1] != 0)), "a pixel is owned by exactly one rank"
+        total = keys[0] + keys[1]  # the all-reduce (sum)
+        for c, sl in zip((c0, c1), slots):
+            n = c.detect_motion_from_keys(sl, total) if sum(seeds) else 0
+            assert n == n_full, (i, n, n_full)
+            d = c.download_frame(sl, fr["depth"].shape, range_image=False, dynamic_image=True)[2]
+            assert np.array_equal(d, dyn_full), i
+            c.integrate(sl, use_mask=True)
+            c.update_tracking_phase(fr["stamp"], 1)
+        recs = np.concatenate([c0.export_halo(2048), c1.export_halo(2048)])
+        for c in (c0, c1):
+            c.import_halo(recs)
+            c.update_tracking_phase(fr["stamp"], 2)
+        fired += n_full
+    assert fired > 0
+    for c in (c0, c1):
+        for idx in c.block_indices()[::5]:
+            g, h = c.download_block(idx, likelihoods=False), ctx.download_block(idx, likelihoods=False)
+            for k in ("distance", "weight", "flags", "last_observed"):
+                assert np.array_equal(g[k], h[k]), (k, idx)

@@ -243,6 +243,11 @@ int64_t khr_block_indices(khr_ctx* ctx, int32_t* out, int64_t cap, int only_upda
 int khr_download_block(khr_ctx* ctx, int32_t bx, int32_t by, int32_t bz, float* distance, float* weight,
                        uint8_t* color_rgba, uint64_t* last_observed, uint64_t* last_occupied,
                        uint8_t* voxel_flags, uint32_t* sem_label, float* likelihoods, uint8_t* block_flags);
+/* replaces: VolumetricMap::cloneUpdated (active_window.cpp:229) in ONE packed transfer: every block flagged
+ * KHR_BLK_UPDATED, in sorted block order, gathered on the device and copied per field (any pointer may be
+ * NULL; arrays hold cap_blocks * nvox elements, indices 3 * cap_blocks).  Returns the number of blocks. */
+int64_t khr_download_updated(khr_ctx* ctx, int32_t* indices, float* distance, float* weight, uint8_t* color_rgba,
+                             uint64_t* last_observed, uint8_t* voxel_flags, uint32_t* sem_label, int64_t cap_blocks);
 /* mesh produced by the last khr_generate_mesh calls, concatenated over blocks in sorted block order
  * (utils::combineMeshLayer, geometry_utils.cpp:61-86; faces are implicit: vertex 3i,3i+1,3i+2).
  * returns the vertex count, or a negative error if cap is too small. */

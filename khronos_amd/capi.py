@@ -66,7 +66,7 @@ EXPORTS = [
     "khr_download_block", "khr_mesh_num_vertices", "khr_download_mesh", "khr_timing_enable", "khr_timing_reset",
     "khr_timing_get", "khr_debug_read", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_update_tracking_phase",
     "khr_export_halo", "khr_import_halo", "khr_get_dynamic_clusters", "khr_motion_keys",
-    "khr_detect_motion_from_keys",
+    "khr_detect_motion_from_keys", "khr_download_updated",
 ]
 
 _lib = None
@@ -121,6 +121,8 @@ def load_library():
     lib.khr_block_indices.argtypes = [vp, vp, i64, i32]
     lib.khr_block_indices.restype = i64
     lib.khr_download_block.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32] + [vp] * 9
+    lib.khr_download_updated.argtypes = [vp] + [vp] * 7 + [i64]
+    lib.khr_download_updated.restype = i64
     lib.khr_mesh_num_vertices.argtypes = [vp]
     lib.khr_mesh_num_vertices.restype = i64
     lib.khr_download_mesh.argtypes = [vp, vp, vp, vp, vp, vp, i64]
@@ -379,6 +381,19 @@ class FusionContext:
             _ptr(b["likelihoods"]), _ptr(bf)))
         b["block_flags"] = int(bf[0])
         return b
+
+    def download_updated(self):
+        """VolumetricMap::cloneUpdated in one packed transfer."""
+        n = len(self.block_indices(only_updated=True))
+        nv = self.nvox
+        out = {"indices": np.zeros((max(n, 1), 3), np.int32), "distance": np.empty((max(n, 1), nv), np.float32),
+               "weight": np.empty((max(n, 1), nv), np.float32), "color": np.empty((max(n, 1), nv, 4), np.uint8),
+               "last_observed": np.empty((max(n, 1), nv), np.uint64), "flags": np.empty((max(n, 1), nv), np.uint8),
+               "sem_label": np.empty((max(n, 1), nv), np.uint32)}
+        k = self._chk(self.lib.khr_download_updated(self.h, _ptr(out["indices"]), _ptr(out["distance"]), _ptr(out["weight"]),
+                                                    _ptr(out["color"]), _ptr(out["last_observed"]), _ptr(out["flags"]),
+                                                    _ptr(out["sem_label"]), max(n, 1)))
+        return {a: b[:k] for a, b in out.items()}
 
     def download_mesh(self):
         n = self._chk(self.lib.khr_mesh_num_vertices(self.h))

@@ -578,6 +578,35 @@ __global__ __launch_bounds__(256) void k_block_flag_op(DevMap m, uint32_t and_ma
   if (fl & BLK_LIVE) m.blk_flags[s] = (fl & and_mask) | or_mask;
 }
 
+// VolumetricMap::cloneUpdated role (active_window.cpp:229): gather the voxel arrays of a list of blocks into
+// contiguous staging buffers (one D2H per field afterwards).  One workgroup per block, 16-byte copies.
+struct PackOut {
+  float* dist;
+  float* weight;
+  uint32_t* color;
+  uint64_t* last_obs;
+  uint8_t* vflags;
+  uint32_t* sem_label;
+};
+template <int VPS>
+__global__ __launch_bounds__(256) void k_pack_blocks(DevMap m, const uint32_t* __restrict__ slots, int n, PackOut o) {
+  constexpr int NV = VPS * VPS * VPS;
+  for (int b = blockIdx.x; b < n; b += gridDim.x) {
+    const size_t src = static_cast<size_t>(slots[b]) * NV, dst = static_cast<size_t>(b) * NV;
+    auto copy16 = [&](const void* s, void* d, size_t bytes) {
+      const uint4* s4 = reinterpret_cast<const uint4*>(s);
+      uint4* d4 = reinterpret_cast<uint4*>(d);
+      for (size_t i = threadIdx.x; i < bytes / 16; i += 256) d4[i] = s4[i];
+    };
+    if (o.dist) copy16(m.dist + src, o.dist + dst, NV * 4);
+    if (o.weight) copy16(m.weight + src, o.weight + dst, NV * 4);
+    if (o.color) copy16(m.color + src, o.color + dst, NV * 4);
+    if (o.last_obs) copy16(m.last_obs + src, o.last_obs + dst, NV * 8);
+    if (o.vflags) copy16(m.vflags + src, o.vflags + dst, NV);
+    if (o.sem_label) copy16(m.sem_label + src, o.sem_label + dst, NV * 4);
+  }
+}
+
 // MeshObjectExtractor confidence pruning (mesh_object_extractor.cpp:246-264, computeConfidence :342-356)
 template <int VPS>
 __global__ __launch_bounds__(256) void k_object_prune(DevMap m, DevParams p, float min_conf, float min_obs) {

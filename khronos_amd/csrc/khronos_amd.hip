@@ -1492,6 +1492,64 @@ static int refreshMeshTotals(khr_ctx* c) {
   return KHR_OK;
 }
 
+int64_t khr_download_updated(khr_ctx* c, int32_t* indices, float* distance, float* weight, uint8_t* color_rgba,
+                             uint64_t* last_observed, uint8_t* voxel_flags, uint32_t* sem_label, int64_t cap_blocks) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  int rc = ensureHostIndex(c);
+  if (rc) return rc;
+  // updated blocks in sorted index order (std::map iteration)
+  std::vector<uint32_t> slots;
+  std::vector<int32_t> idx;
+  for (auto& kv : c->host_index)
+    if (c->host_flags[kv.second] & BLK_UPDATED) {
+      slots.push_back(kv.second);
+      idx.insert(idx.end(), kv.first.begin(), kv.first.end());
+    }
+  const int64_t n = static_cast<int64_t>(slots.size());
+  if (n > cap_blocks) return fail(KHR_EINVAL, "%lld updated blocks, cap %lld", static_cast<long long>(n), static_cast<long long>(cap_blocks));
+  if (n == 0) return 0;
+  if (indices) std::memcpy(indices, idx.data(), sizeof(int32_t) * idx.size());
+  const size_t nv = c->p.nvox, tot = static_cast<size_t>(n) * nv;
+  const bool trk = c->cfg.with_tracking, sem = c->cfg.with_semantics;
+  // staging: one allocation, carved per field
+  const size_t bytes = tot * ((distance ? 4 : 0) + (weight ? 4 : 0) + (color_rgba ? 4 : 0) + ((last_observed && trk) ? 8 : 0) +
+                              (voxel_flags ? 1 : 0) + ((sem_label && sem) ? 4 : 0)) + sizeof(uint32_t) * n + 256;
+  uint8_t* stage = nullptr;
+  HIP_TRY(hipMalloc(&stage, bytes));
+  uint8_t* cur = stage;
+  auto carve = [&](size_t b) { uint8_t* p = cur; cur += (b + 15) / 16 * 16; return p; };
+  PackOut o{};
+  if (last_observed && trk) o.last_obs = reinterpret_cast<uint64_t*>(carve(tot * 8));
+  if (distance) o.dist = reinterpret_cast<float*>(carve(tot * 4));
+  if (weight) o.weight = reinterpret_cast<float*>(carve(tot * 4));
+  if (color_rgba) o.color = reinterpret_cast<uint32_t*>(carve(tot * 4));
+  if (sem_label && sem) o.sem_label = reinterpret_cast<uint32_t*>(carve(tot * 4));
+  if (voxel_flags) o.vflags = carve(tot);
+  uint32_t* d_slots = reinterpret_cast<uint32_t*>(carve(sizeof(uint32_t) * n));
+  hipError_t e = hipMemcpyAsync(d_slots, slots.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    rc = dispatchVps(c, [&](auto vps) {
+      hipLaunchKernelGGL((k_pack_blocks<decltype(vps)::value>), dim3(static_cast<unsigned>(std::min<int64_t>(n, 4096))), dim3(256), 0,
+                         c->stream, c->m, d_slots, static_cast<int>(n), o);
+      return KHR_OK;
+    });
+    auto D = [&](void* dst, const void* src, size_t b) { if (e == hipSuccess && dst && src) e = hipMemcpyAsync(dst, src, b, hipMemcpyDeviceToHost, c->stream); };
+    D(distance, o.dist, tot * 4);
+    D(weight, o.weight, tot * 4);
+    D(color_rgba, o.color, tot * 4);
+    D(last_observed, o.last_obs, tot * 8);
+    D(voxel_flags, o.vflags, tot);
+    D(sem_label, o.sem_label, tot * 4);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  }
+  hipFree(stage);
+  if (e != hipSuccess) return fail(KHR_EDEVICE, "download_updated failed: %s", hipGetErrorString(e));
+  if (rc) return rc;
+  if (last_observed && !trk) std::memset(last_observed, 0, tot * 8);
+  if (sem_label && !sem) std::memset(sem_label, 0, tot * 4);
+  return n;
+}
+
 int64_t khr_mesh_num_vertices(khr_ctx* c) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
   int rc = refreshMeshTotals(c);

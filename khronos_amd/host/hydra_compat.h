@@ -162,6 +162,24 @@ struct ActiveWindowOutput {
   khr_ctx* map_ctx = nullptr;
   std::shared_ptr<InputData> sensor_data;
   std::vector<std::shared_ptr<KhronosObjectAttributes>> graph_update;  // LayerUpdate(2) role
+  // all updated blocks in one packed transfer (khr_download_updated); distance / weight only here, the
+  // other layers are available through the C ABI call directly
+  std::vector<BlockCopy> cloneUpdatedTsdf() const {
+    const size_t n = updated_blocks.size();
+    std::vector<int32_t> idx(3 * n);
+    std::vector<float> d(n * 4096), w(n * 4096);
+    std::vector<BlockCopy> out;
+    const int64_t k = n ? khr_download_updated(map_ctx, idx.data(), d.data(), w.data(), nullptr, nullptr, nullptr, nullptr,
+                                               static_cast<int64_t>(n)) : 0;
+    for (int64_t i = 0; i < k; ++i) {
+      BlockCopy b;
+      b.index = {idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]};
+      b.distance.assign(d.begin() + i * 4096, d.begin() + (i + 1) * 4096);
+      b.weight.assign(w.begin() + i * 4096, w.begin() + (i + 1) * 4096);
+      out.push_back(std::move(b));
+    }
+    return out;
+  }
   // deep copy of one updated block (the reference clones all of them eagerly, which on a GPU-resident map
   // would put a D2H copy of every updated block on the critical path; SURVEY.md §7 "Output cadence & PCIe")
   BlockCopy cloneBlock(const BlockIndex& idx) const {

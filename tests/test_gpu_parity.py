@@ -82,6 +82,14 @@ def test_mesh_and_archival():
             assert np.array_equal(gm["labels"], om["labels"])
             assert np.array_equal(gm["stamps"], om["stamps"])
             assert np.abs(gm["colors"].astype(int) - om["colors"].astype(int)).max() <= 1
+            # cloneUpdated (active_window.cpp:229) as one packed transfer == the per-block downloads
+            upd = ctx.download_updated()
+            ui = ctx.block_indices(only_updated=True)
+            assert np.array_equal(upd["indices"], ui) and len(ui) > 0
+            for j in range(0, len(ui), 7):
+                b = ctx.download_block(ui[j], likelihoods=False)
+                for k in ("distance", "weight", "color", "last_observed", "flags", "sem_label"):
+                    assert np.array_equal(upd[k][j], b[k]), k
             rg, ro = ctx.reset_inactive(), ora.reset_inactive()
             assert np.array_equal(rg, ro)
             ctx.clear_updated()

@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument("--no-roofline-timers", action="store_true")
     ap.add_argument("--all-timers", action="store_true", help="HIP-event timers on every kernel group (slower host path)")
     ap.add_argument("--frame-times", action="store_true", help="debug: synchronise and print per-frame wall times")
+    ap.add_argument("--mesh-req-cap", type=int, default=16384, help="mesh halo requests all-gathered per rank (N > 1)")
+    ap.add_argument("--mesh-rec-cap", type=int, default=2048, help="mesh halo records all-gathered per rank (N > 1)")
     ap.add_argument("--halo-cap", type=int, default=8192, help="halo records all-gathered per rank and tick (N > 1)")
     return ap.parse_args()
 
@@ -152,9 +154,7 @@ def main():
             # sharded tick: integrate all cameras into the owned blocks, tracking, halo all-gather, ever-free
             fusion.tick(stamps[i], [(pose, dep, rgb, lab) for (dep, rgb, lab, pose) in cams])
             if out_now:
-                ctx.generate_mesh(True, True)
-                ctx.reset_inactive_async()
-                ctx.clear_updated()
+                fusion.output(req_cap=args.mesh_req_cap, rec_cap=args.mesh_rec_cap)
             return
         for ci, (dep, rgb, lab, pose) in enumerate(cams):
             flags = 0
@@ -226,7 +226,7 @@ def main():
                                % (W, H, vs * 100, K, "off" if args.no_motion else "on",
                                   args.output_every, world),
                    "parallelism": "hash-range block shard x%d, owner-computes, RCCL all-gather of frames + of 528-B halo records "
-                                  "(ever-free), seed-gated all-reduce of per-pixel voxel keys (motion detector); mesh halo not exchanged yet" % world
+                                  "(ever-free), seed-gated all-reduce of per-pixel voxel keys (motion detector), request / response all-gather of mesh halo planes" % world
                    if world > 1 else "single GPU"},
         "mvoxel_updates_per_s": 1e-6 * n_upd_all / dt,
         "voxels": {"visited": n_vis_all, "updated": n_upd_all, "band": n_band_all, "allocated_blocks": st1["n_allocated_blocks"],

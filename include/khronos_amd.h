@@ -204,6 +204,20 @@ int khr_get_dynamic_clusters(khr_ctx* ctx, int slot, khr_cluster* out, int cap);
 /* replaces: hydra::MeshIntegrator::generateMesh(map, only_mesh_updated, clear_flag)
  * (active_window.cpp:223, mesh_object_extractor.cpp:267) */
 int khr_generate_mesh(khr_ctx* ctx, int only_mesh_updated, int clear_flag);
+/* Mesh halo for sharded maps (no reference equivalent).  Marching cubes of a block reads the x = 0 / y = 0 /
+ * z = 0 voxel planes of its +x/+y/+z neighbours (7 blocks); with hash-range sharding those usually live on
+ * other ranks.  Per output tick: (1) khr_mesh_halo_requests lists the packed keys of the neighbours of this
+ * rank's mesh-(updated) blocks that are not in the local map (cap entries, 0 = unused; returns the count);
+ * (2) the requests of all ranks are all-gathered; (3) khr_mesh_halo_export answers the requests this rank
+ * owns with fixed-size records (KHR_MESH_HALO_RECORD_BYTES(vps): key, valid, then per plane distance,
+ * weight, colour, label, stamp) and zero-fills the rest of the cap_records buffer; (4) the records are
+ * all-gathered and khr_mesh_halo_import indexes those of other ranks; khr_generate_mesh then treats them
+ * like local neighbours. */
+#define KHR_MESH_HALO_RECORD_BYTES(vps) (4 * (4 + 3 * 6 * (vps) * (vps)))
+int khr_mesh_halo_requests(khr_ctx* ctx, void* keys_out, int64_t cap, int only_mesh_updated, int on_device);
+int khr_mesh_halo_export(khr_ctx* ctx, const void* requests, int64_t n_requests, void* records, int64_t cap_records,
+                         int on_device);
+int khr_mesh_halo_import(khr_ctx* ctx, const void* records, int64_t n_records, int on_device);
 /* replaces: TrackingIntegrator::resetInactive (tracking_integrator.cpp:106-131). removed: caller
  * buffer for 3*cap int32 block indices (may be NULL); *n_removed receives the count. */
 int khr_reset_inactive(khr_ctx* ctx, int32_t* removed, int64_t cap, int64_t* n_removed);

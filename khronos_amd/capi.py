@@ -66,7 +66,8 @@ EXPORTS = [
     "khr_download_block", "khr_mesh_num_vertices", "khr_download_mesh", "khr_timing_enable", "khr_timing_reset",
     "khr_timing_get", "khr_debug_read", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_update_tracking_phase",
     "khr_export_halo", "khr_import_halo", "khr_get_dynamic_clusters", "khr_motion_keys",
-    "khr_detect_motion_from_keys", "khr_download_updated",
+    "khr_detect_motion_from_keys", "khr_download_updated", "khr_mesh_halo_requests", "khr_mesh_halo_export",
+    "khr_mesh_halo_import",
 ]
 
 _lib = None
@@ -121,6 +122,9 @@ def load_library():
     lib.khr_block_indices.argtypes = [vp, vp, i64, i32]
     lib.khr_block_indices.restype = i64
     lib.khr_download_block.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32] + [vp] * 9
+    lib.khr_mesh_halo_requests.argtypes = [vp, vp, i64, i32, i32]
+    lib.khr_mesh_halo_export.argtypes = [vp, vp, i64, vp, i64, i32]
+    lib.khr_mesh_halo_import.argtypes = [vp, vp, i64, i32]
     lib.khr_download_updated.argtypes = [vp] + [vp] * 7 + [i64]
     lib.khr_download_updated.restype = i64
     lib.khr_mesh_num_vertices.argtypes = [vp]
@@ -381,6 +385,36 @@ class FusionContext:
             _ptr(b["likelihoods"]), _ptr(bf)))
         b["block_flags"] = int(bf[0])
         return b
+
+    def mesh_halo_words(self):
+        v = self.cfg.voxels_per_side
+        return 4 + 3 * 6 * v * v
+
+    def mesh_halo_requests(self, cap, only_mesh_updated=True, device_ptr=None):
+        if device_ptr is not None:
+            return None, self._chk(self.lib.khr_mesh_halo_requests(self.h, C.c_void_p(device_ptr), cap, int(only_mesh_updated), 1))
+        out = np.zeros(cap, np.uint64)
+        n = self._chk(self.lib.khr_mesh_halo_requests(self.h, _ptr(out), cap, int(only_mesh_updated), 0))
+        return out, n
+
+    def mesh_halo_export(self, requests, cap_records, req_ptr=None, n_req=0, out_ptr=None):
+        if out_ptr is not None:
+            self._chk(self.lib.khr_mesh_halo_export(self.h, C.c_void_p(req_ptr), n_req, C.c_void_p(out_ptr), cap_records, 1))
+            return None
+        requests = np.ascontiguousarray(requests, dtype=np.uint64).reshape(-1)
+        out = np.zeros((cap_records, self.mesh_halo_words()), np.uint32)
+        self._chk(self.lib.khr_mesh_halo_export(self.h, _ptr(requests), requests.size, _ptr(out), cap_records, 0))
+        return out
+
+    def mesh_halo_import(self, records=None, device_ptr=None, n_records=0):
+        if device_ptr is not None:
+            self._chk(self.lib.khr_mesh_halo_import(self.h, C.c_void_p(device_ptr), n_records, 1))
+            return
+        if records is None or len(records) == 0:
+            self._chk(self.lib.khr_mesh_halo_import(self.h, None, 0, 0))
+            return
+        records = np.ascontiguousarray(records, dtype=np.uint32).reshape(-1, self.mesh_halo_words())
+        self._chk(self.lib.khr_mesh_halo_import(self.h, _ptr(records), records.shape[0], 0))
 
     def download_updated(self):
         """VolumetricMap::cloneUpdated in one packed transfer."""

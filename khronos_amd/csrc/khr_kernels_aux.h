@@ -283,6 +283,57 @@ __global__ __launch_bounds__(256) void k_md_paint(const uint64_t* __restrict__ k
 // offset in voxel-linear order (block-wide prefix sum of per-voxel counts), so the output order is
 // deterministic.
 // ----------------------------------------------------------------------------------------------
+// Mesh halo record (multi-GPU): the three low voxel planes (x = 0, y = 0, z = 0) of a block, i.e.
+// everything a -x / -y / -z neighbour's marching cubes reads from it.  Layout in u32 words:
+//   [0..1] packed block key, [2] valid (1), [3] pad, then per plane p in {X, Y, Z} (PL = VPS*VPS voxels):
+//   dist[PL] f32 | weight[PL] f32 | color[PL] rgba8 | label[PL] u32 | stamp[PL] u64
+// plane X is indexed (y + VPS*z), plane Y (x + VPS*z), plane Z (x + VPS*y).
+template <int VPS>
+struct MeshHalo {
+  static constexpr int PL = VPS * VPS;
+  static constexpr int kPlaneWords = PL * 6;
+  static constexpr int kWords = 4 + 3 * kPlaneWords;
+  // plane and in-plane index of local voxel (x, y, z) of the neighbour reached through `sel`
+  __host__ __device__ static int planeOf(int sel) { return (sel & 1) ? 0 : ((sel & 2) ? 1 : 2); }
+  __host__ __device__ static int indexOf(int sel, int x, int y, int z) {
+    return (sel & 1) ? (y + VPS * z) : ((sel & 2) ? (x + VPS * z) : (x + VPS * y));
+  }
+  __host__ __device__ static const uint32_t* plane(const uint32_t* rec, int pl) { return rec + 4 + pl * kPlaneWords; }
+  __host__ __device__ static float dist(const uint32_t* rec, int pl, int i) {
+    const uint32_t v = plane(rec, pl)[i];
+    float f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    f = __uint_as_float(v);
+#else
+    std::memcpy(&f, &v, 4);
+#endif
+    return f;
+  }
+  __host__ __device__ static float weight(const uint32_t* rec, int pl, int i) {
+    const uint32_t v = plane(rec, pl)[PL + i];
+    float f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    f = __uint_as_float(v);
+#else
+    std::memcpy(&f, &v, 4);
+#endif
+    return f;
+  }
+  __host__ __device__ static uint32_t color(const uint32_t* rec, int pl, int i) { return plane(rec, pl)[2 * PL + i]; }
+  __host__ __device__ static uint32_t label(const uint32_t* rec, int pl, int i) { return plane(rec, pl)[3 * PL + i]; }
+  __host__ __device__ static uint64_t stamp(const uint32_t* rec, int pl, int i) {
+    const uint32_t* p = plane(rec, pl) + 4 * PL + 2 * i;
+    return static_cast<uint64_t>(p[0]) | (static_cast<uint64_t>(p[1]) << 32);
+  }
+};
+
+struct RemoteMeshHalo {
+  const uint32_t* recs;  // nullptr = none
+  const uint64_t* ht_keys;
+  const uint32_t* ht_vals;
+  uint32_t ht_mask;
+};
+
 struct MeshBuffers {
   float* points;       // 3 per vertex
   uint32_t* colors;    // rgba8
@@ -295,8 +346,9 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
                                                        const uint32_t* __restrict__ n_work,
                                                        uint32_t* __restrict__ new_count,
                                                        const uint32_t* __restrict__ new_offset, MeshBuffers out,
-                                                       int clear_flag, uint32_t max_vertices) {
+                                                       int clear_flag, uint32_t max_vertices, RemoteMeshHalo rh) {
   constexpr int NV = VPS * VPS * VPS;
+  using MH = MeshHalo<VPS>;
   if (EMIT && new_offset[m.capacity] > max_vertices) {  // vertex buffer too small: flag, write nothing
     if (blockIdx.x == 0 && threadIdx.x == 0) m.counters[C_MESH_OVERFLOW] = 1u;
     return;
@@ -305,6 +357,7 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
   __shared__ float s_d[T * T * T];
   __shared__ float s_w[T * T * T];
   __shared__ uint32_t s_nslot[8];
+  __shared__ const uint32_t* s_nrec[8];  // halo record of a neighbour owned by another rank (or nullptr)
   __shared__ uint32_t s_scan[256];
   __shared__ uint8_t s_ntri[256];
   __shared__ uint16_t s_toff[EMIT ? VPS * VPS * VPS : 2];
@@ -329,8 +382,23 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
     __syncthreads();
     if (threadIdx.x < 8) {
       const int k = threadIdx.x;
-      s_nslot[k] = k == 0 ? static_cast<uint32_t>(slot)
-                          : htLookup(m, packKey(bi.x + (k & 1), bi.y + ((k >> 1) & 1), bi.z + ((k >> 2) & 1)));
+      const uint64_t key = packKey(bi.x + (k & 1), bi.y + ((k >> 1) & 1), bi.z + ((k >> 2) & 1));
+      const uint32_t ns = k == 0 ? static_cast<uint32_t>(slot) : htLookup(m, key);
+      const uint32_t* rec = nullptr;
+      if (ns == kInvalidSlot && rh.recs) {
+        uint32_t h = hashKey(key) & rh.ht_mask;
+        while (true) {
+          const uint64_t kk = rh.ht_keys[h];
+          if (kk == key) {
+            rec = rh.recs + static_cast<size_t>(rh.ht_vals[h]) * MH::kWords;
+            break;
+          }
+          if (kk == kEmptyKey) break;
+          h = (h + 1) & rh.ht_mask;
+        }
+      }
+      s_nslot[k] = ns;
+      s_nrec[k] = rec;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < T * T * T; c += 256) {
@@ -345,6 +413,10 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
         const size_t o = static_cast<size_t>(ns) * NV + (x + VPS * (y + VPS * z));
         d = m.dist[o];
         w = m.weight[o];
+      } else if (s_nrec[sel]) {
+        const int pl = MH::planeOf(sel), pi = MH::indexOf(sel, x, y, z);
+        d = MH::dist(s_nrec[sel], pl, pi);
+        w = MH::weight(s_nrec[sel], pl, pi);
       }
       s_d[c] = d;
       s_w[c] = w;
@@ -456,13 +528,128 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
           if (lx >= VPS) { lx -= VPS; sel |= 1; }
           if (ly >= VPS) { ly -= VPS; sel |= 2; }
           if (lz >= VPS) { lz -= VPS; sel |= 4; }
-          const size_t so = static_cast<size_t>(s_nslot[sel]) * NV + (lx + VPS * (ly + VPS * lz));
-          out.colors[vo] = m.color[so];
-          out.labels[vo] = p.with_semantics ? m.sem_label[so] : 0u;
-          out.stamps[vo] = p.with_tracking ? m.last_obs[so] : 0ull;
+          if (s_nslot[sel] != kInvalidSlot) {
+            const size_t so = static_cast<size_t>(s_nslot[sel]) * NV + (lx + VPS * (ly + VPS * lz));
+            out.colors[vo] = m.color[so];
+            out.labels[vo] = p.with_semantics ? m.sem_label[so] : 0u;
+            out.stamps[vo] = p.with_tracking ? m.last_obs[so] : 0ull;
+          } else {  // the source voxel lives in a block of another rank: attributes from its halo record
+            const uint32_t* rec = s_nrec[sel];
+            const int pl = MH::planeOf(sel), pi = MH::indexOf(sel, lx, ly, lz);
+            out.colors[vo] = MH::color(rec, pl, pi);
+            out.labels[vo] = p.with_semantics ? MH::label(rec, pl, pi) : 0u;
+            out.stamps[vo] = p.with_tracking ? MH::stamp(rec, pl, pi) : 0ull;
+          }
         }
       }
     }
+  }
+}
+
+// requests: for every block of the mesh work list, the +x/+y/+z neighbours (7) that are not in the local map
+// and belong to another rank
+__global__ __launch_bounds__(256) void k_mesh_halo_requests(DevMap m, DevParams p, const uint32_t* __restrict__ work,
+                                                           const uint32_t* __restrict__ n_work, uint64_t* __restrict__ req,
+                                                           uint32_t cap, uint32_t* __restrict__ n_req) {
+  const uint32_t n = *n_work;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ((n * 7 + 63) / 64) * 64; i += gridDim.x * blockDim.x) {
+    bool want = false;
+    uint64_t key = 0;
+    if (i < n * 7) {
+      const int4 bi = m.blk_index[work[i / 7]];
+      const int k = static_cast<int>(i % 7) + 1;
+      const int x = bi.x + (k & 1), y = bi.y + ((k >> 1) & 1), z = bi.z + ((k >> 2) & 1);
+      key = packKey(x, y, z);
+      want = ownerOf(x, y, z, p.world) != p.rank && htLookup(m, key) == kInvalidSlot;
+    }
+    const uint32_t idx = waveAggInc(n_req, want);
+    if (want && idx < cap) req[idx] = key;
+  }
+}
+
+// owners mark the requested blocks they hold (duplicates collapse on the flag)
+__global__ __launch_bounds__(256) void k_mesh_halo_mark(DevMap m, DevParams p, const uint64_t* __restrict__ req, uint32_t n,
+                                                       uint8_t* __restrict__ flag) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = req[i];
+  if (key == 0ull) return;
+  int x, y, z;
+  unpackKey(key, &x, &y, &z);
+  if (ownerOf(x, y, z, p.world) != p.rank) return;
+  const uint32_t s = htLookup(m, key);
+  if (s != kInvalidSlot) flag[s] = 1;
+}
+
+__global__ __launch_bounds__(256) void k_list_marked(DevMap m, const uint8_t* __restrict__ flag, uint32_t* __restrict__ list,
+                                                    uint32_t* __restrict__ n_out) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool on = s < m.counters[C_MAX_SLOT] && flag[s] && (m.blk_flags[s] & BLK_LIVE);
+  const uint32_t idx = waveAggInc(n_out, on);
+  if (on) list[idx] = s;
+}
+
+// one workgroup per marked block: write its record; records beyond the list are zeroed (valid = 0)
+template <int VPS>
+__global__ __launch_bounds__(256) void k_mesh_halo_export(DevMap m, DevParams p, const uint32_t* __restrict__ list,
+                                                         const uint32_t* __restrict__ n_list, uint32_t* __restrict__ recs,
+                                                         uint32_t cap) {
+  using MH = MeshHalo<VPS>;
+  constexpr int NV = VPS * VPS * VPS, PL = VPS * VPS;
+  const uint32_t n = min(*n_list, cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && *n_list > cap) atomicAdd(&m.counters[C_POOL_EXHAUSTED], 1u);
+  for (uint32_t r = blockIdx.x; r < cap; r += gridDim.x) {
+    uint32_t* rec = recs + static_cast<size_t>(r) * MH::kWords;
+    if (r >= n) {
+      if (threadIdx.x < 4) rec[threadIdx.x] = 0u;
+      continue;
+    }
+    const size_t slot = list[r];
+    if (threadIdx.x == 0) {
+      const int4 bi = m.blk_index[slot];
+      const uint64_t key = packKey(bi.x, bi.y, bi.z);
+      rec[0] = static_cast<uint32_t>(key);
+      rec[1] = static_cast<uint32_t>(key >> 32);
+      rec[2] = 1u;
+      rec[3] = 0u;
+    }
+    for (int t = threadIdx.x; t < 3 * PL; t += 256) {
+      const int pl = t / PL, i = t % PL, a = i % VPS, b = i / VPS;
+      const int lin = pl == 0 ? (0 + VPS * (a + VPS * b)) : (pl == 1 ? (a + VPS * (0 + VPS * b)) : (a + VPS * (b + VPS * 0)));
+      uint32_t* pw = rec + 4 + pl * MH::kPlaneWords;
+      const size_t o = slot * NV + lin;
+      pw[i] = __float_as_uint(m.dist[o]);
+      pw[PL + i] = __float_as_uint(m.weight[o]);
+      pw[2 * PL + i] = m.color[o];
+      pw[3 * PL + i] = p.with_semantics ? m.sem_label[o] : 0u;
+      const uint64_t st = p.with_tracking ? m.last_obs[o] : 0ull;
+      pw[4 * PL + 2 * i] = static_cast<uint32_t>(st);
+      pw[4 * PL + 2 * i + 1] = static_cast<uint32_t>(st >> 32);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mesh_halo_import(const uint32_t* __restrict__ recs, uint32_t n_total, int words,
+                                                         int rank, int world, uint64_t* __restrict__ ht_keys,
+                                                         uint32_t* __restrict__ ht_vals, uint32_t ht_mask) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_total) return;
+  const uint32_t* rec = recs + static_cast<size_t>(r) * words;
+  if (rec[2] != 1u) return;
+  const uint64_t key = static_cast<uint64_t>(rec[0]) | (static_cast<uint64_t>(rec[1]) << 32);
+  int x, y, z;
+  unpackKey(key, &x, &y, &z);
+  if (ownerOf(x, y, z, world) == rank) return;
+  uint32_t h = hashKey(key) & ht_mask;
+  while (true) {
+    const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&ht_keys[h]),
+                                              static_cast<unsigned long long>(kEmptyKey), static_cast<unsigned long long>(key));
+    if (prev == kEmptyKey) {
+      ht_vals[h] = r;
+      return;
+    }
+    if (prev == key) return;  // the same block can be answered to several requesters' gathers only once per rank
+    h = (h + 1) & ht_mask;
   }
 }
 

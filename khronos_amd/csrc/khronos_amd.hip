@@ -96,6 +96,12 @@ struct khr_ctx {
   uint64_t* d_halo_keys = nullptr;
   uint32_t* d_halo_vals = nullptr;
   uint32_t halo_cap_total = 0, halo_mask = 0, halo_n = 0;
+  // remote mesh halo (three low voxel planes of blocks owned by other ranks)
+  uint32_t* d_mh_recs = nullptr;
+  uint64_t* d_mh_keys = nullptr;
+  uint32_t* d_mh_vals = nullptr;
+  uint32_t mh_cap_total = 0, mh_mask = 0, mh_n = 0;
+  uint8_t* d_mh_flag = nullptr;
   uint32_t* h_pinned = nullptr;  // [0] seed pixels of the last motion pass, [1] removed count
   hipEvent_t ev_seed = nullptr;
   uint32_t last_removed = 0;
@@ -461,7 +467,8 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &c->d_mesh_count, cap + 1));
   A(devAlloc(c, &c->d_mesh_offset, cap + 1));
   A(devAlloc(c, &c->d_regen, cap));
-  A(devAlloc(c, &c->d_mesh_nwork, 4));
+  A(devAlloc(c, &c->d_mh_flag, cap));
+  A(devAlloc(c, &c->d_mesh_nwork, 8));
   const size_t npx = cfg->max_frame_pixels;
   A(devAlloc(c, &c->d_keys, npx, false));
   A(devAlloc(c, &c->d_pix, npx, false));
@@ -543,6 +550,7 @@ void khr_destroy(khr_ctx* c) {
   for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
   for (void* p : c->allocs) hipFree(p);
   if (c->d_halo_recs) { hipFree(c->d_halo_recs); hipFree(c->d_halo_keys); hipFree(c->d_halo_vals); }
+  if (c->d_mh_recs) { hipFree(c->d_mh_recs); hipFree(c->d_mh_keys); hipFree(c->d_mh_vals); }
   if (c->h_pinned) hipHostFree(c->h_pinned);
   if (c->ev_seed) hipEventDestroy(c->ev_seed);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -1198,18 +1206,25 @@ int khr_generate_mesh(khr_ctx* c, int only_mesh_updated, int clear_flag) {
   hipLaunchKernelGGL(k_mesh_carry_counts, dim3(gridFor(cap)), dim3(256), 0, c->stream, m, c->d_mesh_count);
   hipLaunchKernelGGL(k_mark_regen, dim3(gridFor(cap)), dim3(256), 0, c->stream, c->d_work, c->d_mesh_nwork, c->d_regen);
   MeshBuffers src = c->mesh[c->mesh_cur], dst = c->mesh[c->mesh_cur ^ 1];
+  RemoteMeshHalo rmh{};
+  if (c->mh_n) {
+    rmh.recs = c->d_mh_recs;
+    rmh.ht_keys = c->d_mh_keys;
+    rmh.ht_vals = c->d_mh_vals;
+    rmh.ht_mask = c->mh_mask;
+  }
   const uint32_t maxv = static_cast<uint32_t>(std::min<uint64_t>(c->cfg.max_mesh_vertices, 0xfffffff0ull));
   int rc = dispatchVps(c, [&](auto vps) {
     constexpr int V = decltype(vps)::value;
     hipLaunchKernelGGL((k_marching_cubes<V, false>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, c->d_work,
-                       c->d_mesh_nwork, c->d_mesh_count, c->d_mesh_offset, dst, clear_flag, maxv);
+                       c->d_mesh_nwork, c->d_mesh_count, c->d_mesh_offset, dst, clear_flag, maxv, rmh);
     size_t tb = c->cub_temp_bytes;
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->d_cub_temp, tb, c->d_mesh_count, c->d_mesh_offset,
                                              static_cast<int>(cap + 1), c->stream));
     // no host round trip: the capacity check happens on the device (C_MESH_OVERFLOW), totals are read lazily
     hipLaunchKernelGGL(k_mesh_move, dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->d_regen, c->d_mesh_offset, src, dst, maxv);
     hipLaunchKernelGGL((k_marching_cubes<V, true>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, c->d_work,
-                       c->d_mesh_nwork, c->d_mesh_count, c->d_mesh_offset, dst, clear_flag, maxv);
+                       c->d_mesh_nwork, c->d_mesh_count, c->d_mesh_offset, dst, clear_flag, maxv, rmh);
     return KHR_OK;
   });
   if (rc) return rc;
@@ -1257,6 +1272,101 @@ static int fetchRemoved(khr_ctx* c, int32_t* removed, int64_t cap, int64_t* n_re
       removed[3 * i + 2] = tmp[i].z;
     }
   }
+  return KHR_OK;
+}
+
+int khr_mesh_halo_requests(khr_ctx* c, void* keys_out, int64_t cap, int only_mesh_updated, int on_device) {
+  if (!c || !keys_out || cap < 1) return fail(KHR_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  DevMap& m = c->m;
+  uint64_t* dst = static_cast<uint64_t*>(keys_out);
+  uint64_t* tmp = nullptr;
+  if (!on_device) {
+    HIP_TRY(hipMalloc(&tmp, sizeof(uint64_t) * cap));
+    dst = tmp;
+  }
+  HIP_TRY(hipMemsetAsync(dst, 0, sizeof(uint64_t) * cap, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_mesh_nwork + 1, 0, sizeof(uint32_t) * 2, c->stream));
+  hipLaunchKernelGGL(k_list_live, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_work, c->d_mesh_nwork + 1,
+                     only_mesh_updated ? BLK_MESH_UPDATED : 0u);
+  hipLaunchKernelGGL(k_mesh_halo_requests, dim3(512), dim3(256), 0, c->stream, m, c->p, c->d_work, c->d_mesh_nwork + 1, dst,
+                     static_cast<uint32_t>(cap), c->d_mesh_nwork + 2);
+  uint32_t n_req = 0;
+  HIP_TRY(hipMemcpyAsync(&n_req, c->d_mesh_nwork + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  if (!on_device) HIP_TRY(hipMemcpyAsync(keys_out, tmp, sizeof(uint64_t) * cap, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (tmp) hipFree(tmp);
+  if (n_req > cap) return fail(KHR_ENOMEM, "%u mesh halo requests exceed the capacity %lld", n_req, static_cast<long long>(cap));
+  return static_cast<int>(n_req);
+}
+
+int khr_mesh_halo_export(khr_ctx* c, const void* requests, int64_t n_requests, void* records, int64_t cap_records, int on_device) {
+  if (!c || !records || cap_records < 1 || n_requests < 0 || (!requests && n_requests > 0)) return fail(KHR_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  DevMap& m = c->m;
+  const size_t words = c->p.vps == 16 ? MeshHalo<16>::kWords : MeshHalo<8>::kWords;
+  const size_t bytes = static_cast<size_t>(cap_records) * words * 4;
+  const uint64_t* req = static_cast<const uint64_t*>(requests);
+  uint64_t* req_tmp = nullptr;
+  uint32_t* dst = static_cast<uint32_t*>(records);
+  uint32_t* rec_tmp = nullptr;
+  if (!on_device) {
+    if (n_requests) {
+      HIP_TRY(hipMalloc(&req_tmp, sizeof(uint64_t) * n_requests));
+      HIP_TRY(hipMemcpyAsync(req_tmp, requests, sizeof(uint64_t) * n_requests, hipMemcpyHostToDevice, c->stream));
+      req = req_tmp;
+    }
+    HIP_TRY(hipMalloc(&rec_tmp, bytes));
+    dst = rec_tmp;
+  }
+  HIP_TRY(hipMemsetAsync(c->d_mh_flag, 0, m.capacity, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_mesh_nwork + 3, 0, sizeof(uint32_t), c->stream));
+  if (n_requests)
+    hipLaunchKernelGGL(k_mesh_halo_mark, dim3(gridFor(n_requests)), dim3(256), 0, c->stream, m, c->p, req,
+                       static_cast<uint32_t>(n_requests), c->d_mh_flag);
+  hipLaunchKernelGGL(k_list_marked, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_mh_flag, c->d_new, c->d_mesh_nwork + 3);
+  int rc = dispatchVps(c, [&](auto vps) {
+    hipLaunchKernelGGL((k_mesh_halo_export<decltype(vps)::value>), dim3(static_cast<unsigned>(std::min<int64_t>(cap_records, 2048))),
+                       dim3(256), 0, c->stream, m, c->p, c->d_new, c->d_mesh_nwork + 3, dst, static_cast<uint32_t>(cap_records));
+    return KHR_OK;
+  });
+  hipError_t e = hipSuccess;
+  if (rc == KHR_OK && !on_device) e = hipMemcpyAsync(records, rec_tmp, bytes, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (req_tmp) hipFree(req_tmp);
+  if (rec_tmp) hipFree(rec_tmp);
+  if (e != hipSuccess) return fail(KHR_EDEVICE, "mesh halo export failed: %s", hipGetErrorString(e));
+  return rc;
+}
+
+int khr_mesh_halo_import(khr_ctx* c, const void* records, int64_t n_records, int on_device) {
+  if (!c || n_records < 0 || (!records && n_records > 0)) return fail(KHR_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  if (n_records == 0) {
+    c->mh_n = 0;
+    return KHR_OK;
+  }
+  const size_t words = c->p.vps == 16 ? MeshHalo<16>::kWords : MeshHalo<8>::kWords;
+  if (static_cast<uint64_t>(n_records) > c->mh_cap_total) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_mh_recs) { hipFree(c->d_mh_recs); hipFree(c->d_mh_keys); hipFree(c->d_mh_vals); }
+    uint32_t ht = 1;
+    while (ht < static_cast<uint64_t>(n_records) * 4) ht <<= 1;
+    HIP_TRY(hipMalloc(&c->d_mh_recs, static_cast<size_t>(n_records) * words * 4));
+    HIP_TRY(hipMalloc(&c->d_mh_keys, sizeof(uint64_t) * ht));
+    HIP_TRY(hipMalloc(&c->d_mh_vals, sizeof(uint32_t) * ht));
+    c->mh_cap_total = static_cast<uint32_t>(n_records);
+    c->mh_mask = ht - 1;
+  }
+  HIP_TRY(hipMemcpyAsync(c->d_mh_recs, records, static_cast<size_t>(n_records) * words * 4,
+                         on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_mh_keys, 0xff, sizeof(uint64_t) * (static_cast<size_t>(c->mh_mask) + 1), c->stream));
+  hipLaunchKernelGGL(k_mesh_halo_import, dim3(gridFor(n_records)), dim3(256), 0, c->stream, c->d_mh_recs,
+                     static_cast<uint32_t>(n_records), static_cast<int>(words), c->cfg.rank, c->cfg.world_size, c->d_mh_keys,
+                     c->d_mh_vals, c->mh_mask);
+  HIP_TRY(hipGetLastError());
+  if (!on_device) HIP_TRY(hipStreamSynchronize(c->stream));
+  c->mh_n = static_cast<uint32_t>(n_records);
   return KHR_OK;
 }
 

@@ -51,6 +51,31 @@ class HipShard:
     def import_halo(self, gathered):
         self.ctx.import_halo(n_records=gathered.shape[0], device_ptr=gathered.data_ptr())
 
+    # -- output stage (mesh halo) --
+    def mesh_requests(self, cap):
+        if getattr(self, "_req", None) is None or self._req.numel() != cap:
+            self._req = torch.zeros(cap, dtype=torch.int64, device=self.device)
+        self.ctx.mesh_halo_requests(cap, True, device_ptr=self._req.data_ptr())
+        return self._req
+
+    def mesh_export(self, all_requests, cap_records):
+        words = self.ctx.mesh_halo_words()
+        if getattr(self, "_rec", None) is None or self._rec.shape[0] != cap_records:
+            self._rec = torch.zeros((cap_records, words), dtype=torch.int32, device=self.device)
+        self.ctx.mesh_halo_export(None, cap_records, req_ptr=all_requests.data_ptr(), n_req=all_requests.numel(),
+                                  out_ptr=self._rec.data_ptr())
+        return self._rec
+
+    def mesh_import(self, gathered):
+        self.ctx.mesh_halo_import(device_ptr=gathered.data_ptr(), n_records=gathered.shape[0])
+
+    def generate_mesh(self):
+        self.ctx.generate_mesh(True, True)
+
+    def archive(self):
+        self.ctx.reset_inactive_async()
+        self.ctx.clear_updated()
+
 
 class ShardedFusion:
     def __init__(self, shard, dist=None, world_size=1, motion=True, count_device="cpu"):
@@ -92,3 +117,14 @@ class ShardedFusion:
         if self.world > 1:
             self.shard.import_halo(self.all_gather(self.shard.export_halo(stamp)))
         self.shard.tracking_phase(stamp, 2)
+
+    def output(self, req_cap=8192, rec_cap=1024):
+        """ActiveWindow::extractOutputData, volumetric part (active_window.cpp:217-249): marching cubes on the
+        mesh-updated blocks with the neighbours' low planes fetched from their owners (request / response
+        all-gathers), then archival and flag clearing."""
+        if self.world > 1:
+            reqs = self.all_gather(self.shard.mesh_requests(req_cap))
+            recs = self.all_gather(self.shard.mesh_export(reqs, rec_cap))
+            self.shard.mesh_import(recs)
+        self.shard.generate_mesh()
+        self.shard.archive()

@@ -183,6 +183,8 @@ struct orc_map {
   // free-or-ever-free bit masks of blocks owned by other ranks (multi-GPU halo)
   std::unordered_map<I3, std::vector<uint64_t>, I3Hash> halo;
   std::vector<Block*> ef_work;  // tracking-updated blocks collected by phase 1
+  // mesh halo: the three low voxel planes of blocks owned by other ranks (record layout: khronos_amd.h)
+  std::unordered_map<I3, std::vector<uint32_t>, I3Hash> mesh_halo;
 
   Block* find(const I3& i) const {
     auto it = blocks.find(i);
@@ -953,16 +955,29 @@ int64_t orc_generate_mesh(orc_map* m, int only_mesh_updated, int clear_flag) {
                 oz = static_cast<float>(b.index.z) * m->bs;
     // neighbour blocks (+x,+y,+z combos)
     const Block* nb[8];
+    const uint32_t* nrec[8];  // halo record of a neighbour that lives on another rank
     for (int k = 0; k < 8; ++k) {
       const I3 ni = {b.index.x + (k & 1), b.index.y + ((k >> 1) & 1), b.index.z + ((k >> 2) & 1)};
       nb[k] = k == 0 ? &b : m->find(ni);
+      nrec[k] = nullptr;
+      if (!nb[k]) {
+        auto it = m->mesh_halo.find(ni);
+        if (it != m->mesh_halo.end()) nrec[k] = it->second.data();
+      }
     }
+    const int PL = vps * vps, PW = PL * 6;
+    auto planeIdx = [&](int sel, int x, int y, int z, int* pl) {
+      *pl = (sel & 1) ? 0 : ((sel & 2) ? 1 : 2);
+      return (sel & 1) ? (y + vps * z) : ((sel & 2) ? (x + vps * z) : (x + vps * y));
+    };
     for (int iz = 0; iz < vps; ++iz)
       for (int iy = 0; iy < vps; ++iy)
         for (int ix = 0; ix < vps; ++ix) {
           float sdf[8], pos[8][3];
           const Block* cb[8];
           int clin[8];
+          const uint32_t* crec[8];
+          int cpl[8];
           bool ok = true;
           for (int k = 0; k < 8 && ok; ++k) {
             int x = ix + kCubeOffsets[k][0], y = iy + kCubeOffsets[k][1], z = iz + kCubeOffsets[k][2];
@@ -971,13 +986,30 @@ int64_t orc_generate_mesh(orc_map* m, int only_mesh_updated, int clear_flag) {
             if (y >= vps) { y -= vps; sel |= 2; }
             if (z >= vps) { z -= vps; sel |= 4; }
             const Block* blk = nb[sel];
-            if (!blk) { ok = false; break; }
+            crec[k] = nullptr;
+            if (!blk) {
+              if (!nrec[sel]) { ok = false; break; }
+              // remote neighbour: distance / weight from its halo record
+              int pl;
+              const int pi = planeIdx(sel, x, y, z, &pl);
+              const uint32_t* pw = nrec[sel] + 4 + pl * PW;
+              float dd, ww;
+              std::memcpy(&dd, &pw[pi], 4);
+              std::memcpy(&ww, &pw[PL + pi], 4);
+              if (!(ww >= c.mesh_min_weight)) { ok = false; break; }
+              sdf[k] = dd;
+              cb[k] = nullptr;
+              crec[k] = nrec[sel];
+              cpl[k] = pl;
+              clin[k] = pi;
+            } else {
             const int lin = x + vps * (y + vps * z);
             const TsdfVoxel& tv = blk->tsdf[lin];
             if (!(tv.weight >= c.mesh_min_weight)) { ok = false; break; }
             sdf[k] = tv.distance;
             cb[k] = blk;
             clin[k] = lin;
+            }
             pos[k][0] = ox + (static_cast<float>(ix + kCubeOffsets[k][0]) + 0.5f) * c.voxel_size;
             pos[k][1] = oy + (static_cast<float>(iy + kCubeOffsets[k][1]) + 0.5f) * c.voxel_size;
             pos[k][2] = oz + (static_cast<float>(iz + kCubeOffsets[k][2]) + 0.5f) * c.voxel_size;
@@ -1010,6 +1042,21 @@ int64_t orc_generate_mesh(orc_map* m, int only_mesh_updated, int clear_flag) {
               mesh.points.push_back(ev[e][2]);
               const Block* sb = cb[esrc[e]];
               const int sl = clin[esrc[e]];
+              if (!sb) {  // vertex attributes from the halo record of the remote source voxel
+                const uint32_t* pw = crec[esrc[e]] + 4 + cpl[esrc[e]] * PW;
+                const uint32_t col = pw[2 * PL + sl];
+                mesh.colors.push_back(col & 0xff);
+                mesh.colors.push_back((col >> 8) & 0xff);
+                mesh.colors.push_back((col >> 16) & 0xff);
+                mesh.colors.push_back((col >> 24) & 0xff);
+                mesh.labels.push_back(c.with_semantics ? pw[3 * PL + sl] : 0u);
+                const uint64_t st = c.with_tracking
+                                        ? (static_cast<uint64_t>(pw[4 * PL + 2 * sl]) | (static_cast<uint64_t>(pw[4 * PL + 2 * sl + 1]) << 32))
+                                        : 0u;
+                mesh.first_seen.push_back(st);
+                mesh.stamps.push_back(st);
+                continue;
+              }
               mesh.colors.push_back(sb->tsdf[sl].r);
               mesh.colors.push_back(sb->tsdf[sl].g);
               mesh.colors.push_back(sb->tsdf[sl].b);
@@ -1024,6 +1071,75 @@ int64_t orc_generate_mesh(orc_map* m, int only_mesh_updated, int clear_flag) {
     if (clear_flag) b.mesh_updated = false;
   });
   return static_cast<int64_t>(work.size());
+}
+
+// ---- mesh halo (multi-GPU emulation; protocol and record layout: include/khronos_amd.h) ----
+int64_t orc_mesh_halo_requests(orc_map* m, int only_mesh_updated, uint64_t* keys_out, int64_t cap) {
+  std::memset(keys_out, 0, sizeof(uint64_t) * cap);
+  int64_t n = 0;
+  for (const I3& idx : m->sortedIndices()) {
+    const Block* b = m->find(idx);
+    if (only_mesh_updated && !b->mesh_updated) continue;
+    for (int k = 1; k < 8; ++k) {
+      const I3 ni = {idx.x + (k & 1), idx.y + ((k >> 1) & 1), idx.z + ((k >> 2) & 1)};
+      if (ownerOf(ni, m->cfg.world_size) == m->cfg.rank || m->find(ni)) continue;
+      if (n < cap) keys_out[n] = packBlockKey(ni);
+      ++n;
+    }
+  }
+  return n;
+}
+
+int64_t orc_mesh_halo_export(orc_map* m, const uint64_t* reqs, int64_t n_req, uint32_t* recs, int64_t cap) {
+  const int vps = m->vps, PL = vps * vps, PW = PL * 6, words = 4 + 3 * PW;
+  std::memset(recs, 0, sizeof(uint32_t) * static_cast<size_t>(words) * cap);
+  std::vector<I3> want;
+  for (int64_t i = 0; i < n_req; ++i) {
+    if (reqs[i] == 0) continue;
+    const I3 b = {static_cast<int32_t>(reqs[i] & 0x1fffffu) - (1 << 20), static_cast<int32_t>((reqs[i] >> 21) & 0x1fffffu) - (1 << 20),
+                  static_cast<int32_t>((reqs[i] >> 42) & 0x1fffffu) - (1 << 20)};
+    if (ownerOf(b, m->cfg.world_size) == m->cfg.rank && m->find(b)) want.push_back(b);
+  }
+  std::sort(want.begin(), want.end());
+  want.erase(std::unique(want.begin(), want.end()), want.end());
+  if (static_cast<int64_t>(want.size()) > cap) return -1;
+  for (size_t r = 0; r < want.size(); ++r) {
+    const Block* b = m->find(want[r]);
+    uint32_t* rec = recs + r * words;
+    const uint64_t key = packBlockKey(want[r]);
+    rec[0] = static_cast<uint32_t>(key);
+    rec[1] = static_cast<uint32_t>(key >> 32);
+    rec[2] = 1;
+    for (int pl = 0; pl < 3; ++pl)
+      for (int i = 0; i < PL; ++i) {
+        const int a = i % vps, bq = i / vps;
+        const int lin = pl == 0 ? (vps * (a + vps * bq)) : (pl == 1 ? (a + vps * vps * bq) : (a + vps * bq));
+        uint32_t* pw = rec + 4 + pl * PW;
+        std::memcpy(&pw[i], &b->tsdf[lin].distance, 4);
+        std::memcpy(&pw[PL + i], &b->tsdf[lin].weight, 4);
+        pw[2 * PL + i] = static_cast<uint32_t>(b->tsdf[lin].r) | (static_cast<uint32_t>(b->tsdf[lin].g) << 8) |
+                         (static_cast<uint32_t>(b->tsdf[lin].b) << 16) | (static_cast<uint32_t>(b->tsdf[lin].a) << 24);
+        pw[3 * PL + i] = m->cfg.with_semantics ? b->semantic[lin].semantic_label : 0u;
+        const uint64_t st = m->cfg.with_tracking ? b->tracking[lin].last_observed : 0u;
+        pw[4 * PL + 2 * i] = static_cast<uint32_t>(st);
+        pw[4 * PL + 2 * i + 1] = static_cast<uint32_t>(st >> 32);
+      }
+  }
+  return static_cast<int64_t>(want.size());
+}
+
+void orc_mesh_halo_import(orc_map* m, const uint32_t* recs, int64_t n) {
+  const int words = 4 + 3 * 6 * m->vps * m->vps;
+  m->mesh_halo.clear();
+  for (int64_t i = 0; i < n; ++i) {
+    const uint32_t* r = recs + static_cast<size_t>(i) * words;
+    if (r[2] != 1) continue;
+    const uint64_t key = static_cast<uint64_t>(r[0]) | (static_cast<uint64_t>(r[1]) << 32);
+    const I3 b = {static_cast<int32_t>(key & 0x1fffffu) - (1 << 20), static_cast<int32_t>((key >> 21) & 0x1fffffu) - (1 << 20),
+                  static_cast<int32_t>((key >> 42) & 0x1fffffu) - (1 << 20)};
+    if (ownerOf(b, m->cfg.world_size) == m->cfg.rank) continue;
+    m->mesh_halo[b] = std::vector<uint32_t>(r, r + words);
+  }
 }
 
 int64_t orc_mesh_num_vertices(orc_map* m) {

@@ -132,6 +132,10 @@ int orc_detect_motion_from_keys(orc_map* m, int W, int H, const uint64_t* keys, 
 /* hydra::MeshIntegrator::generateMesh (calls active_window.cpp:223, mesh_object_extractor.cpp:267).
  * Mesh is kept inside the map per block. returns #mesh blocks regenerated. */
 int64_t orc_generate_mesh(orc_map* m, int only_mesh_updated, int clear_flag);
+/* mesh halo for the multi-GPU emulation (protocol + record layout: include/khronos_amd.h) */
+int64_t orc_mesh_halo_requests(orc_map* m, int only_mesh_updated, uint64_t* keys_out, int64_t cap);
+int64_t orc_mesh_halo_export(orc_map* m, const uint64_t* requests, int64_t n_requests, uint32_t* records, int64_t cap);
+void orc_mesh_halo_import(orc_map* m, const uint32_t* records, int64_t n);
 /* total vertex count of all mesh blocks (3 per face, no de-duplication) */
 int64_t orc_mesh_num_vertices(orc_map* m);
 /* concatenated mesh (utils::combineMeshLayer, geometry_utils.cpp:61-86), blocks in sorted index order */

@@ -83,6 +83,12 @@ def load():
     lib.orc_detect_motion_from_keys.argtypes = [vp, i32, i32, vp, vp, C.POINTER(i64)]
     lib.orc_generate_mesh.argtypes = [vp, i32, i32]
     lib.orc_generate_mesh.restype = i64
+    lib.orc_mesh_halo_requests.argtypes = [vp, i32, vp, i64]
+    lib.orc_mesh_halo_requests.restype = i64
+    lib.orc_mesh_halo_export.argtypes = [vp, vp, i64, vp, i64]
+    lib.orc_mesh_halo_export.restype = i64
+    lib.orc_mesh_halo_import.argtypes = [vp, vp, i64]
+    lib.orc_mesh_halo_import.restype = None
     lib.orc_mesh_num_vertices.argtypes = [vp]
     lib.orc_mesh_num_vertices.restype = i64
     lib.orc_mesh_copy.argtypes = [vp, vp, vp, vp, vp, vp, i64]
@@ -214,6 +220,27 @@ class OracleMap:
 
     def generate_mesh(self, only_mesh_updated=True, clear_flag=True):
         return self.lib.orc_generate_mesh(self.h, int(only_mesh_updated), int(clear_flag))
+
+    def mesh_halo_words(self):
+        v = self.cfg.voxels_per_side
+        return 4 + 3 * 6 * v * v
+
+    def mesh_halo_requests(self, cap, only_mesh_updated=True):
+        out = np.zeros(cap, np.uint64)
+        n = self.lib.orc_mesh_halo_requests(self.h, int(only_mesh_updated), _ptr(out), cap)
+        assert n <= cap, "mesh halo request capacity too small"
+        return out, n
+
+    def mesh_halo_export(self, requests, cap_records):
+        requests = np.ascontiguousarray(requests, dtype=np.uint64).reshape(-1)
+        out = np.zeros((cap_records, self.mesh_halo_words()), np.uint32)
+        n = self.lib.orc_mesh_halo_export(self.h, _ptr(requests), requests.size, _ptr(out), cap_records)
+        assert n >= 0, "mesh halo record capacity too small"
+        return out
+
+    def mesh_halo_import(self, records):
+        records = np.ascontiguousarray(records, dtype=np.uint32).reshape(-1, self.mesh_halo_words())
+        self.lib.orc_mesh_halo_import(self.h, _ptr(records), records.shape[0])
 
     def mesh(self):
         n = self.lib.orc_mesh_num_vertices(self.h)

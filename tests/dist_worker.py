@@ -56,6 +56,22 @@ class OracleShard:
     def import_halo(self, gathered):
         self.m.import_halo(gathered.numpy().view(np.uint64))
 
+    def mesh_requests(self, cap):
+        return torch.from_numpy(self.m.mesh_halo_requests(cap, True)[0].view(np.int64))
+
+    def mesh_export(self, all_requests, cap_records):
+        return torch.from_numpy(self.m.mesh_halo_export(all_requests.numpy().view(np.uint64), cap_records).view(np.int32))
+
+    def mesh_import(self, gathered):
+        self.m.mesh_halo_import(gathered.numpy().view(np.uint32))
+
+    def generate_mesh(self):
+        self.m.generate_mesh(True, True)
+
+    def archive(self):
+        self.removed = self.m.reset_inactive()
+        self.m.clear_updated()
+
 
 def main():
     dist.init_process_group("gloo")
@@ -67,6 +83,7 @@ def main():
     full = po.OracleMap(_cfg(**kw))
     fusion = ShardedFusion(OracleShard(shard, sen, HALO_CAP), dist, world)
     clusters_total = 0
+    mesh_checks = 0
     for i in range(N_FRAMES):
         # rank r renders camera r of the rig; the frames are all-gathered like in bench.py
         yaw = 2 * np.pi * rank / world
@@ -88,6 +105,23 @@ def main():
         full.update_tracking(fr["stamp"])
         assert fusion.clusters_last_tick == n_full, (i, fusion.clusters_last_tick, n_full)
         clusters_total += sum(n_full)
+        if i % 5 == 4:  # output cadence: mesh (with halo), archival, flag clearing
+            fusion.output(req_cap=4096, rec_cap=1024)
+            full.generate_mesh(True, True)
+            removed_full = full.reset_inactive()
+            full.clear_updated()
+            # union of the shards' archived blocks == the unsharded archive
+            cnt = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(cnt, torch.tensor([len(fusion.shard.removed)], dtype=torch.int64))
+            assert sum(int(c) for c in cnt) == len(removed_full), (i, cnt, len(removed_full))
+            # union of the shards' meshes == the unsharded mesh (vertex count and coordinate checksum)
+            mine = shard.mesh()
+            tot = torch.tensor([float(len(mine["points"])), float(mine["points"].astype(np.float64).sum())], dtype=torch.float64)
+            dist.all_reduce(tot)
+            fm = full.mesh()
+            assert int(tot[0]) == len(fm["points"]) and len(fm["points"]) > 0, (i, tot, len(fm["points"]))
+            assert abs(float(tot[1]) - float(fm["points"].astype(np.float64).sum())) < 1e-6 * max(1.0, len(fm["points"]))
+            mesh_checks += 1
     # every block of the shard equals the unsharded block, field by field (incl. ever_free bits)
     mine = shard.block_indices()
     all_idx = full.block_indices()
@@ -105,6 +139,7 @@ def main():
     dist.all_reduce(tot)
     assert int(tot) > 0, "ever-free never fired: the halo path was not exercised"
     assert clusters_total > 0, "motion detector never fired: the key exchange was not exercised"
+    assert mesh_checks >= 3
     if rank == 0:
         print("DIST_OK blocks=%d ever_free=%d clusters=%d" % (len(all_idx), int(tot), clusters_total))
     dist.destroy_process_group()

@@ -285,3 +285,51 @@ def test_two_shards_motion_key_exchange():
             g, h = c.download_block(idx, likelihoods=False), ctx.download_block(idx, likelihoods=False)
             for k in ("distance", "weight", "flags", "last_observed"):
                 assert np.array_equal(g[k], h[k]), (k, idx)
+
+
+def _tri_soup(mesh):
+    t = mesh["points"].reshape(-1, 9)
+    lab = mesh["labels"].reshape(-1, 3)
+    st = mesh["stamps"].reshape(-1, 3)
+    col = mesh["colors"].reshape(-1, 12)
+    order = np.lexsort(t.T[::-1])
+    return t[order], lab[order], st[order], col[order]
+
+
+def test_two_shards_mesh_halo_equals_unsharded():
+    """marching cubes on 2 hash-range shards with the request / response mesh halo == the unsharded mesh
+    (triangle soup incl. colours, labels and stamps of vertices sourced from remote voxels)."""
+    cfg, ctx, ora, s, sen, osen = make_pair()
+    _, c0, _, _, _, _ = make_pair(rank=0, world_size=2)
+    _, c1, _, _, _, _ = make_pair(rank=1, world_size=2)
+    for i in range(6):
+        fr = s.render(i)
+        for c in (ctx, c0, c1):
+            slot = c.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+            c.integrate(slot)
+            c.update_tracking(fr["stamp"])
+        if i % 3 == 2:
+            ctx.generate_mesh(True, True)
+            cap_req, cap_rec = 4096, 1024
+            reqs = []
+            for c in (c0, c1):
+                r, n = c.mesh_halo_requests(cap_req, only_mesh_updated=True)
+                assert 0 < n <= cap_req
+                reqs.append(r)
+            all_req = np.concatenate(reqs)                      # all-gather of the requests
+            recs = np.concatenate([c.mesh_halo_export(all_req, cap_rec) for c in (c0, c1)])  # all-gather of the answers
+            assert (recs[:, 2] == 1).sum() > 0
+            for c in (c0, c1):
+                c.mesh_halo_import(recs)
+                c.generate_mesh(True, True)
+            full = _tri_soup(ctx.download_mesh())
+            parts = [c.download_mesh() for c in (c0, c1)]
+            both = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+            uni = _tri_soup(both)
+            assert full[0].shape == uni[0].shape and full[0].shape[0] > 100
+            for a, b in zip(full, uni):
+                assert np.array_equal(a, b)
+    # without the halo the shards would drop every cube that touches a remote neighbour
+    c0.mesh_halo_import(None)
+    c0.generate_mesh(False, False)
+    assert len(c0.download_mesh()["points"]) < len(parts[0]["points"])

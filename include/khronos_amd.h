@@ -135,7 +135,21 @@ typedef struct khr_cluster {
   uint32_t num_pixels_painted; /* pixels that carry this id in dynamic_image (later clusters overwrite earlier ones) */
   float bbox_min[3], bbox_max[3]; /* world-frame AABB of the painted pixels' vertices (:396-397) */
   float centroid[3];           /* mean vertex of the painted pixels (utils::computeCentroid role) */
+  int32_t semantic_id;         /* SemanticClusterInfo::category_id of a semantic cluster, -1 for dynamic clusters */
 } khr_cluster;
+
+/* khronos::ConnectedSemantics::Config (connected_semantics.h:62-84) plus the part of hydra's label space the
+ * detector reads (LabelSpaceConfig::isObject, connected_semantics.cpp:134,157) */
+typedef struct khr_object_detector_config {
+  int32_t use_full_connectivity; /* 26- / 8-neighbourhood (1) or 6- / 4-neighbourhood (0) */
+  int32_t min_cluster_size;      /* pixels */
+  int32_t max_cluster_size;      /* pixels, <= 0 = unlimited; 3D mode only (:106-109) */
+  int32_t use_3d;                /* 1: region growing on a voxel grid (:79-118), 0: image components (:146-198) */
+  float grid_size;               /* m, 3D mode */
+  float max_range;               /* m, 0 = infinite; 3D mode only (:127-132) */
+  const int32_t* object_labels;  /* label ids for which isObject() holds */
+  int32_t n_object_labels;
+} khr_object_detector_config;
 
 typedef struct khr_ctx khr_ctx;
 
@@ -161,6 +175,8 @@ int khr_set_frame_image(khr_ctx* ctx, int slot, int which, const int32_t* image,
 /* read back the normalised input of a slot (any pointer may be NULL): range f32 H*W, vertex map
  * f32 H*W*3 in world frame, dynamic image i32 H*W */
 int khr_download_frame(khr_ctx* ctx, int slot, float* range, float* vertex_map, int32_t* dynamic_image);
+/* FrameData::dynamic_image (which = 0) or FrameData::object_image (which = 1) of a slot, H*W i32 */
+int khr_download_frame_image(khr_ctx* ctx, int slot, int which, int32_t* image);
 
 /* -- hot path ---------------------------------------------------------------------------------- */
 /* replaces: hydra::maskNonZero + hydra::ProjectiveIntegrator::updateMap(data.input, map, allocate,
@@ -201,6 +217,22 @@ int khr_detect_motion_from_keys(khr_ctx* ctx, int slot, const void* keys, int on
 /* FrameData::dynamic_clusters of the frame last passed to khr_detect_motion / khr_process_frame.
  * Returns the number of clusters (writes min(n, cap)); synchronises. */
 int khr_get_dynamic_clusters(khr_ctx* ctx, int slot, khr_cluster* out, int cap);
+/* -- object detection and track measurements (callers next to the fusion path) -------- */
+/* replaces: ConnectedSemantics construction (connected_semantics.cpp:56-57); allocates the detector's HBM scratch */
+int khr_configure_object_detector(khr_ctx* ctx, const khr_object_detector_config* cfg);
+/* replaces: ConnectedSemantics::processInput (connected_semantics.cpp:59-69): clusters the frame's label image,
+ * writes FrameData::object_image of the slot and returns the number of semantic clusters.  Cluster order where
+ * the reference iterates an unordered map: ASSUMPTIONS.md C.4. */
+int khr_detect_objects(khr_ctx* ctx, int slot);
+/* FrameData::semantic_clusters of the frame last passed to khr_detect_objects (id, category, pixel count,
+ * bounding box of the pixels' vertices, max_iou_tracker.cpp:466-476).  Returns the count (writes min(n, cap)). */
+int khr_get_semantic_clusters(khr_ctx* ctx, int slot, khr_cluster* out, int cap);
+/* replaces: MaxIoUTracker::setupTrackMeasurementVoxels (max_iou_tracker.cpp:478-487) for every cluster of an
+ * id image at once: the distinct (cluster id, voxel) pairs of the slot's dynamic (which = 0) or object (which =
+ * 1) image on a grid of `voxel_size`, sorted by (id, x, y, z).  ids_out[cap], voxels_out[3*cap] (global voxel
+ * indices).  Returns the number of pairs (may exceed cap; min(n, cap) are written) or a negative error. */
+int64_t khr_cluster_voxels(khr_ctx* ctx, int slot, int which, float voxel_size, int32_t* ids_out, int64_t* voxels_out,
+                           int64_t cap);
 /* replaces: hydra::MeshIntegrator::generateMesh(map, only_mesh_updated, clear_flag)
  * (active_window.cpp:223, mesh_object_extractor.cpp:267) */
 int khr_generate_mesh(khr_ctx* ctx, int only_mesh_updated, int clear_flag);

@@ -47,7 +47,14 @@ class KhrFrame(C.Structure):
 
 class KhrCluster(C.Structure):
     _fields_ = [("id", C.c_int32), ("num_pixels_listed", C.c_uint64), ("num_pixels_painted", C.c_uint32),
-                ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("centroid", C.c_float * 3)]
+                ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("centroid", C.c_float * 3),
+                ("semantic_id", C.c_int32)]
+
+
+class KhrObjectDetectorConfig(C.Structure):
+    _fields_ = [("use_full_connectivity", C.c_int32), ("min_cluster_size", C.c_int32), ("max_cluster_size", C.c_int32),
+                ("use_3d", C.c_int32), ("grid_size", C.c_float), ("max_range", C.c_float),
+                ("object_labels", C.POINTER(C.c_int32)), ("n_object_labels", C.c_int32)]
 
 
 class KhrStats(C.Structure):
@@ -67,7 +74,8 @@ EXPORTS = [
     "khr_timing_get", "khr_debug_read", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_update_tracking_phase",
     "khr_export_halo", "khr_import_halo", "khr_get_dynamic_clusters", "khr_motion_keys",
     "khr_detect_motion_from_keys", "khr_download_updated", "khr_mesh_halo_requests", "khr_mesh_halo_export",
-    "khr_mesh_halo_import",
+    "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",
+    "khr_cluster_voxels", "khr_download_frame_image",
 ]
 
 _lib = None
@@ -110,6 +118,12 @@ def load_library():
     lib.khr_motion_keys.argtypes = [vp, i32, vp, i32, C.POINTER(C.c_uint32)]
     lib.khr_detect_motion_from_keys.argtypes = [vp, i32, vp, i32]
     lib.khr_get_dynamic_clusters.argtypes = [vp, i32, C.POINTER(KhrCluster), i32]
+    lib.khr_configure_object_detector.argtypes = [vp, C.POINTER(KhrObjectDetectorConfig)]
+    lib.khr_detect_objects.argtypes = [vp, i32]
+    lib.khr_download_frame_image.argtypes = [vp, i32, i32, vp]
+    lib.khr_get_semantic_clusters.argtypes = [vp, i32, C.POINTER(KhrCluster), i32]
+    lib.khr_cluster_voxels.argtypes = [vp, i32, i32, C.c_float, vp, vp, C.c_int64]
+    lib.khr_cluster_voxels.restype = C.c_int64
     lib.khr_generate_mesh.argtypes = [vp, i32, i32]
     lib.khr_reset_inactive.argtypes = [vp, vp, i64, C.POINTER(i64)]
     lib.khr_mark_all_inactive.argtypes = [vp]
@@ -262,13 +276,17 @@ class FusionContext:
             image = np.ascontiguousarray(image, dtype=np.int32)
             self._chk(self.lib.khr_set_frame_image(self.h, slot, which, _ptr(image), 0))
 
-    def download_frame(self, slot, shape, range_image=True, vertex_map=False, dynamic_image=False):
+    def download_frame(self, slot, shape, range_image=True, vertex_map=False, dynamic_image=False, object_image=False):
         h, w = shape
         r = np.empty((h, w), np.float32) if range_image else None
         v = np.empty((h, w, 3), np.float32) if vertex_map else None
         d = np.empty((h, w), np.int32) if dynamic_image else None
         self._chk(self.lib.khr_download_frame(self.h, slot, _ptr(r), _ptr(v), _ptr(d)))
-        return r, v, d
+        if not object_image:
+            return r, v, d
+        o = np.empty((h, w), np.int32)
+        self._chk(self.lib.khr_download_frame_image(self.h, slot, 1, _ptr(o)))
+        return r, v, d, o
 
     def integrate(self, slot, allocate_blocks=True, use_mask=False, object_id=-1):
         self._chk(self.lib.khr_integrate(self.h, slot, int(allocate_blocks), int(use_mask), int(object_id)))
@@ -325,6 +343,34 @@ class FusionContext:
         return [dict(id=a.id, num_pixels_listed=a.num_pixels_listed, num_pixels_painted=a.num_pixels_painted,
                      bbox_min=np.array(a.bbox_min[:]), bbox_max=np.array(a.bbox_max[:]), centroid=np.array(a.centroid[:]))
                 for a in arr[:n]]
+
+    # -- object detection / track measurements (ConnectedSemantics, MaxIoUTracker voxel sets) --
+    def configure_object_detector(self, object_labels, use_3d=True, grid_size=0.1, max_range=0.0, min_cluster_size=0,
+                                  max_cluster_size=-1, use_full_connectivity=True):
+        labels = np.ascontiguousarray(object_labels, dtype=np.int32)
+        oc = KhrObjectDetectorConfig(int(use_full_connectivity), int(min_cluster_size), int(max_cluster_size), int(use_3d),
+                                     float(grid_size), float(max_range), labels.ctypes.data_as(C.POINTER(C.c_int32)), labels.size)
+        self._chk(self.lib.khr_configure_object_detector(self.h, C.byref(oc)))
+
+    def detect_objects(self, slot):
+        return self._chk(self.lib.khr_detect_objects(self.h, slot))
+
+    def semantic_clusters(self, slot):
+        n = self._chk(self.lib.khr_get_semantic_clusters(self.h, slot, None, 0))
+        arr = (KhrCluster * max(n, 1))()
+        n = self._chk(self.lib.khr_get_semantic_clusters(self.h, slot, arr, n))
+        return [dict(id=a.id, semantic_id=a.semantic_id, num_pixels=a.num_pixels_listed, bbox_min=np.array(a.bbox_min[:]),
+                     bbox_max=np.array(a.bbox_max[:]), centroid=np.array(a.centroid[:])) for a in arr[:n]]
+
+    def cluster_voxels(self, slot, which, voxel_size):
+        """distinct (cluster id, voxel) pairs of the dynamic (which=0) / object (which=1) image: (ids[n], voxels[n,3])."""
+        n = self.lib.khr_cluster_voxels(self.h, slot, which, float(voxel_size), None, None, 0)
+        self._chk(n)
+        ids = np.zeros(max(n, 1), np.int32)
+        vox = np.zeros((max(n, 1), 3), np.int64)
+        n2 = self.lib.khr_cluster_voxels(self.h, slot, which, float(voxel_size), _ptr(ids), _ptr(vox), n)
+        self._chk(n2)
+        return ids[:n], vox[:n]
 
     def generate_mesh(self, only_mesh_updated=True, clear_flag=True):
         self._chk(self.lib.khr_generate_mesh(self.h, int(only_mesh_updated), int(clear_flag)))

@@ -1,0 +1,344 @@
+// khr_kernels_objects.h — device side of the object-detection / track-measurement row:
+//   khronos::ConnectedSemantics::processInput      connected_semantics.cpp:59-198 (3D region growing, 2D components)
+//   khronos::MaxIoUTracker::setupTrackMeasurementVoxels   max_iou_tracker.cpp:478-487 (per-cluster voxel sets)
+// The reference groups pixels in nested hash maps (semantic id -> voxel -> pixels) and grows regions with a host
+// stack.  Here every candidate pixel inserts (group, voxel) into ONE device hash table, the thread that claims a
+// table slot "owns" the voxel, owners link 3D neighbours with a lock-free union-find (atomicMin on the parent
+// array), and the clusters are the union-find roots.  Per-cluster pixel count / AABB / first pixel are reduced
+// per wave before touching memory (a single hot atomic address sustains only ~90 ops/us on gfx950).
+#pragma once
+#include "khr_device.h"
+
+namespace khr {
+
+// ---- (group, voxel) keys -----------------------------------------------------------------------------------------
+// 15-bit group (semantic-label rank or cluster id) and a voxel index RELATIVE to the sensor's voxel, 16 bits per
+// axis: measured points are within sensor range of the camera, so the window (+-32766 voxels) is a sensor-range
+// limit, not a world-extent one.  Pixels without a depth have vertex (0,0,0) (ASSUMPTIONS.md A.2) and fall in the
+// absolute voxel (0,0,0); when that lies outside the window it gets the reserved code (all-zero coordinates),
+// which is adjacent to nothing (valid codes stop at +-32766).
+constexpr int kGvWindow = 32766;
+constexpr uint32_t kGvMaxGroup = 32766;
+constexpr uint32_t kNodeNone = 0xffffffffu, kNodeOwner = 0x80000000u;
+
+__host__ __device__ inline uint64_t gvKey(uint32_t group, int rx, int ry, int rz) {
+  return (static_cast<uint64_t>(group) << 48) | (static_cast<uint64_t>(static_cast<uint32_t>(rx + 32768) & 0xffffu) << 32) |
+         (static_cast<uint64_t>(static_cast<uint32_t>(ry + 32768) & 0xffffu) << 16) |
+         static_cast<uint64_t>(static_cast<uint32_t>(rz + 32768) & 0xffffu);
+}
+__host__ __device__ inline uint64_t gvOriginKey(uint32_t group) { return static_cast<uint64_t>(group) << 48; }
+__host__ __device__ inline bool gvIsOrigin(uint64_t k) { return (k & 0xffffffffffffull) == 0ull; }
+__host__ __device__ inline void gvUnpack(uint64_t k, uint32_t* group, int* rx, int* ry, int* rz) {
+  *group = static_cast<uint32_t>(k >> 48);
+  *rx = static_cast<int>((k >> 32) & 0xffffu) - 32768;
+  *ry = static_cast<int>((k >> 16) & 0xffffu) - 32768;
+  *rz = static_cast<int>(k & 0xffffu) - 32768;
+}
+
+struct GvTable {
+  uint64_t* keys;  // kEmptyKey = free
+  uint32_t mask;
+};
+
+__device__ inline int gvFind(const GvTable& t, uint64_t key) {
+  uint32_t h = hashKey(key) & t.mask;
+  while (true) {
+    const uint64_t k = t.keys[h];
+    if (k == key) return static_cast<int>(h);
+    if (k == kEmptyKey) return -1;
+    h = (h + 1) & t.mask;
+  }
+}
+// returns the slot; *claimed = this thread put the key there
+__device__ inline uint32_t gvInsert(const GvTable& t, uint64_t key, bool* claimed) {
+  uint32_t h = hashKey(key) & t.mask;
+  while (true) {
+    const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&t.keys[h]),
+                                              static_cast<unsigned long long>(kEmptyKey), static_cast<unsigned long long>(key));
+    if (prev == kEmptyKey) { *claimed = true; return h; }
+    if (prev == key) { *claimed = false; return h; }
+    h = (h + 1) & t.mask;
+  }
+}
+
+// world-frame vertex of a pixel as InputData::vertex_map holds it (ASSUMPTIONS.md A.2)
+__device__ inline void pixelVertex(const DevFrame& f, int i, float* pw) {
+  pw[0] = pw[1] = pw[2] = 0.f;
+  if (f.range[i] > 0.f) {
+    const float d = f.depth[i];
+    const int u = i % f.W, v = i / f.W;
+    xform(f.Rw, f.tw, ((static_cast<float>(u) - f.cx) / f.fx) * d, ((static_cast<float>(v) - f.cy) / f.fy) * d, d, pw);
+  }
+}
+
+// spatial_hash::indexFromPoint(point, voxel_size_inv) relative to the window origin `o`; false = outside the window
+__device__ inline bool gvVoxelKey(const float* pw, float inv, int3 o, uint32_t group, bool vertex_is_origin, uint64_t* key) {
+  const int rx = static_cast<int>(floorf(pw[0] * inv)) - o.x, ry = static_cast<int>(floorf(pw[1] * inv)) - o.y,
+            rz = static_cast<int>(floorf(pw[2] * inv)) - o.z;
+  const bool inside = rx >= -kGvWindow && rx <= kGvWindow && ry >= -kGvWindow && ry <= kGvWindow && rz >= -kGvWindow && rz <= kGvWindow;
+  if (inside) {
+    *key = gvKey(group, rx, ry, rz);
+    return true;
+  }
+  if (vertex_is_origin) {
+    *key = gvOriginKey(group);
+    return true;
+  }
+  return false;
+}
+
+// ---- union-find on node ids (table slots in 3D mode, pixel indices in 2D mode) ---------------------------------------
+__device__ inline uint32_t ufLoad(const uint32_t* parent, uint32_t x) { return __atomic_load_n(parent + x, __ATOMIC_RELAXED); }
+__device__ inline uint32_t ufFind(const uint32_t* parent, uint32_t x) {
+  while (true) {
+    const uint32_t p = ufLoad(parent, x);
+    if (p == x) return x;
+    x = p;
+  }
+}
+// link the larger root under the smaller one; retries when another thread moved the root in between
+__device__ inline void ufUnion(uint32_t* parent, uint32_t a, uint32_t b) {
+  while (true) {
+    a = ufFind(parent, a);
+    b = ufFind(parent, b);
+    if (a == b) return;
+    if (a < b) { const uint32_t t = a; a = b; b = t; }
+    const uint32_t old = atomicMin(parent + a, b);
+    if (old == a) return;
+    a = old;
+  }
+}
+
+// sorted object-label list -> rank (the group), -1 = not an object label (LabelSpaceConfig::isObject role)
+__device__ inline int labelRank(const int32_t* __restrict__ labels, int n, int32_t v) {
+  int lo = 0, hi = n - 1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    const int32_t m = labels[mid];
+    if (m == v) return mid;
+    if (m < v) lo = mid + 1; else hi = mid - 1;
+  }
+  return -1;
+}
+
+// ---- ConnectedSemantics, 3D mode ---------------------------------------------------------------------------------------
+// computeCandidateVoxels (connected_semantics.cpp:123-144): one thread per pixel
+__global__ __launch_bounds__(256) void k_obj_insert3d(DevFrame f, const int32_t* __restrict__ obj_labels, int n_labels,
+                                                     float max_range, float inv, int3 origin, GvTable t,
+                                                     uint32_t* __restrict__ parent, uint32_t* __restrict__ pix_node,
+                                                     uint32_t* __restrict__ flags /* [0] window overflow */) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= f.W * f.H) return;
+  uint32_t node = kNodeNone;
+  const int g = labelRank(obj_labels, n_labels, f.label[i]);
+  const float r = f.range[i];
+  if (g >= 0 && !(max_range > 0.f && r > max_range)) {
+    float pw[3];
+    pixelVertex(f, i, pw);
+    uint64_t key;
+    if (gvVoxelKey(pw, inv, origin, static_cast<uint32_t>(g), !(r > 0.f), &key)) {
+      bool claimed;
+      const uint32_t h = gvInsert(t, key, &claimed);
+      if (claimed) parent[h] = h;
+      node = h | (claimed ? kNodeOwner : 0u);
+    } else {
+      atomicOr(&flags[0], 1u);
+    }
+  }
+  pix_node[i] = node;
+}
+
+__constant__ int8_t c_obj_fwd13[13][3] = {{1, 0, 0},  {0, 1, 0},   {0, 0, 1},  {1, 1, 0},  {-1, 1, 0}, {1, 0, 1}, {-1, 0, 1},
+                                          {0, 1, 1},  {0, -1, 1},  {1, 1, 1},  {-1, 1, 1}, {1, -1, 1}, {-1, -1, 1}};
+
+// region growing (:79-98) as union-find: the owner of a voxel links it to its forward neighbours of the same
+// semantic id (the relation is symmetric, so 13 of 26 / 3 of 6 directions cover every pair once)
+__global__ __launch_bounds__(256) void k_obj_union3d(const uint32_t* __restrict__ pix_node, int n, GvTable t,
+                                                    uint32_t* __restrict__ parent, int n_dirs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t node = pix_node[i];
+  if (node == kNodeNone || !(node & kNodeOwner)) return;
+  const uint32_t h = node & ~kNodeOwner;
+  const uint64_t key = t.keys[h];
+  if (gvIsOrigin(key)) return;
+  uint32_t g;
+  int x, y, z;
+  gvUnpack(key, &g, &x, &y, &z);
+  for (int k = 0; k < n_dirs; ++k) {
+    const int nx = x + c_obj_fwd13[k][0], ny = y + c_obj_fwd13[k][1], nz = z + c_obj_fwd13[k][2];
+    if (nx < -kGvWindow || nx > kGvWindow || ny < -kGvWindow || ny > kGvWindow || nz < -kGvWindow || nz > kGvWindow) continue;
+    const int hn = gvFind(t, gvKey(g, nx, ny, nz));
+    if (hn >= 0) ufUnion(parent, h, static_cast<uint32_t>(hn));
+  }
+}
+
+// ---- ConnectedSemantics, 2D mode (semanticClustering2D / growCluster2D, :146-198) ---------------------------------------
+__global__ __launch_bounds__(256) void k_obj_init2d(DevFrame f, const int32_t* __restrict__ obj_labels, int n_labels,
+                                                   uint32_t* __restrict__ parent, uint32_t* __restrict__ pix_node) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= f.W * f.H) return;
+  const bool cand = labelRank(obj_labels, n_labels, f.label[i]) >= 0;
+  parent[i] = static_cast<uint32_t>(i);
+  pix_node[i] = cand ? (static_cast<uint32_t>(i) | kNodeOwner) : kNodeNone;
+}
+
+__global__ __launch_bounds__(256) void k_obj_union2d(DevFrame f, const uint32_t* __restrict__ pix_node,
+                                                    uint32_t* __restrict__ parent, int full) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= f.W * f.H || pix_node[i] == kNodeNone) return;
+  const int u = i % f.W, v = i / f.W;
+  const int32_t lab = f.label[i];
+  // backward half of neighbors4 / neighbors8
+  if (u > 0 && f.label[i - 1] == lab) ufUnion(parent, i, i - 1);
+  if (v > 0) {
+    if (f.label[i - f.W] == lab) ufUnion(parent, i, i - f.W);
+    if (full) {
+      if (u > 0 && f.label[i - f.W - 1] == lab) ufUnion(parent, i, i - f.W - 1);
+      if (u + 1 < f.W && f.label[i - f.W + 1] == lab) ufUnion(parent, i, i - f.W + 1);
+    }
+  }
+}
+
+// ---- shared tail: roots, paint, remap ---------------------------------------------------------------------------------------
+// per-cluster summary (MeasurementCluster role, measurement_clusters.h:63-80)
+struct ObjAcc {
+  uint32_t n_pixels;
+  uint32_t first_cm;         // smallest column-major pixel index u*H+v (the scan order of :147-148)
+  int32_t bmin[3], bmax[3];  // floats mapped to order-preserving ints
+  float sum[3];
+  uint32_t group;            // label rank
+};
+
+__device__ inline int32_t objFloatToOrdered(float f) {
+  const int32_t i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+
+// owners flatten their node to its root; roots take a compact cluster index and initialise its summary
+__global__ __launch_bounds__(256) void k_obj_roots(const uint32_t* __restrict__ pix_node, int n, uint32_t* __restrict__ parent,
+                                                  uint32_t* __restrict__ root_idx, uint32_t* __restrict__ n_roots, uint32_t cap,
+                                                  ObjAcc* __restrict__ acc, const uint64_t* __restrict__ keys3d,
+                                                  const int32_t* __restrict__ label2d, const int32_t* __restrict__ obj_labels,
+                                                  int n_labels) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t node = i < n ? pix_node[i] : kNodeNone;
+  const bool owner = node != kNodeNone && (node & kNodeOwner);
+  const uint32_t h = node & ~kNodeOwner;
+  bool is_root = false;
+  if (owner) {
+    const uint32_t r = ufFind(parent, h);
+    is_root = r == h;
+    if (!is_root) __atomic_store_n(parent + h, r, __ATOMIC_RELAXED);
+  }
+  const uint32_t idx = waveAggInc(n_roots, is_root);
+  if (is_root) {
+    root_idx[h] = idx;
+    if (idx < cap) {
+      ObjAcc a;
+      a.n_pixels = 0;
+      a.first_cm = 0xffffffffu;
+      for (int d = 0; d < 3; ++d) { a.bmin[d] = INT32_MAX; a.bmax[d] = INT32_MIN; a.sum[d] = 0.f; }
+      a.group = keys3d ? static_cast<uint32_t>(keys3d[h] >> 48)
+                       : static_cast<uint32_t>(labelRank(obj_labels, n_labels, label2d[h]));
+      acc[idx] = a;
+    }
+  }
+}
+
+// provisional paint: object_image = cluster index + 1, and the per-cluster summary
+__global__ __launch_bounds__(256) void k_obj_paint(DevFrame f, const uint32_t* __restrict__ pix_node,
+                                                  const uint32_t* __restrict__ parent, const uint32_t* __restrict__ root_idx,
+                                                  uint32_t cap, int32_t* __restrict__ obj, ObjAcc* __restrict__ acc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = f.W * f.H;
+  int id = 0;
+  float pw[3] = {0.f, 0.f, 0.f};
+  uint32_t cm = 0xffffffffu;
+  if (i < n) {
+    const uint32_t node = pix_node[i];
+    if (node != kNodeNone) {
+      const uint32_t h = node & ~kNodeOwner;
+      const uint32_t idx = root_idx[ufFind(parent, h)];
+      if (idx < cap) {
+        id = static_cast<int>(idx) + 1;
+        pixelVertex(f, i, pw);
+        cm = static_cast<uint32_t>(i % f.W) * static_cast<uint32_t>(f.H) + static_cast<uint32_t>(i / f.W);
+      }
+    }
+    obj[i] = id;
+  }
+  unsigned long long todo = __ballot(id != 0);
+  while (todo) {
+    const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+    const int cid = __shfl(id, leader);
+    const bool mine = id == cid;
+    const unsigned long long grp = __ballot(mine);
+    todo &= ~grp;
+    float mn[3], mx[3], sm[3];
+    uint32_t first = mine ? cm : 0xffffffffu;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      mn[c] = mine ? pw[c] : 3.0e38f;
+      mx[c] = mine ? pw[c] : -3.0e38f;
+      sm[c] = mine ? pw[c] : 0.f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      first = min(first, static_cast<uint32_t>(__shfl_xor(static_cast<int>(first), o)));
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+        mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+        sm[c] += __shfl_xor(sm[c], o);
+      }
+    }
+    if (static_cast<int>(laneId()) == leader) {
+      ObjAcc* a = acc + (cid - 1);
+      atomicAdd(&a->n_pixels, static_cast<uint32_t>(__popcll(grp)));
+      atomicMin(&a->first_cm, first);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        atomicMin(&a->bmin[c], objFloatToOrdered(mn[c]));
+        atomicMax(&a->bmax[c], objFloatToOrdered(mx[c]));
+        atomicAdd(&a->sum[c], sm[c]);
+      }
+    }
+  }
+}
+
+// cluster index + 1 -> final cluster id (0 = filtered out)
+__global__ __launch_bounds__(256) void k_obj_remap(int32_t* __restrict__ obj, int n, const int32_t* __restrict__ final_id) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t t = obj[i];
+  if (t) obj[i] = final_id[t - 1];
+}
+
+// ---- per-cluster voxel sets at the tracker's grid (max_iou_tracker.cpp:478-487) ------------------------------------------------
+__global__ __launch_bounds__(256) void k_cluster_voxels(DevFrame f, const int32_t* __restrict__ id_image, float inv, int3 origin,
+                                                       GvTable t, uint64_t* __restrict__ list, uint32_t* __restrict__ n_list,
+                                                       uint32_t cap, uint32_t* __restrict__ flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool claimed = false;
+  uint64_t key = 0;
+  if (i < f.W * f.H) {
+    const int32_t id = id_image[i];
+    if (id > 0) {
+      if (static_cast<uint32_t>(id) > kGvMaxGroup) {
+        atomicOr(&flags[0], 2u);
+      } else {
+        float pw[3];
+        pixelVertex(f, i, pw);
+        if (gvVoxelKey(pw, inv, origin, static_cast<uint32_t>(id), !(f.range[i] > 0.f), &key))
+          gvInsert(t, key, &claimed);
+        else
+          atomicOr(&flags[0], 1u);
+      }
+    }
+  }
+  const uint32_t at = waveAggInc(n_list, claimed);
+  if (claimed && at < cap) list[at] = key;
+}
+
+}  // namespace khr

@@ -23,6 +23,7 @@
 #include "khr_device.h"
 #include "khr_kernels_aux.h"
 #include "khr_kernels_fusion.h"
+#include "khr_kernels_objects.h"
 
 using namespace khr;
 
@@ -127,6 +128,22 @@ struct khr_ctx {
   std::vector<int32_t> h_md_seed_final, h_md_bnd_final;
   std::vector<ClusterAcc> h_md_acc;
   size_t cub_temp_bytes = 0;
+  // object detector / cluster voxel sets (khr_kernels_objects.h); allocated on first use
+  bool obj_configured = false;
+  khr_object_detector_config obj_cfg{};
+  std::vector<int32_t> obj_labels;  // sorted, unique
+  int32_t* d_obj_labels = nullptr;
+  uint64_t* d_gv_keys = nullptr;
+  uint32_t gv_mask = 0;
+  uint32_t *d_gv_parent = nullptr, *d_gv_rootidx = nullptr, *d_gv_node = nullptr, *d_gv_n = nullptr;
+  ObjAcc* d_obj_acc = nullptr;
+  int32_t* d_obj_final = nullptr;
+  uint64_t* d_cv_list = nullptr;
+  uint32_t obj_root_cap = 0;
+  std::vector<ObjAcc> h_obj_acc;
+  std::vector<int32_t> h_obj_final;
+  std::vector<khr_cluster> last_sem_clusters;
+  int last_sem_slot = -1;
   // mesh
   MeshBuffers mesh[2]{};
   int mesh_cur = 0;
@@ -660,6 +677,20 @@ int khr_download_frame(khr_ctx* c, int slot, float* range, float* vertex_map, in
   return KHR_OK;
 }
 
+int khr_download_frame_image(khr_ctx* c, int slot, int which, int32_t* image) {
+  if (!c || !image || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad argument");
+  if (which != 0 && which != 1) return fail(KHR_EINVAL, "which must be 0 (dynamic) or 1 (object)");
+  FrameSlot& s = c->slots[slot];
+  const size_t n = static_cast<size_t>(s.sensor.width) * s.sensor.height;
+  if (which == 1 && !s.has_obj) {  // never written: FrameData::object_image starts as zeros (active_window.cpp:284)
+    std::memset(image, 0, n * sizeof(int32_t));
+    return KHR_OK;
+  }
+  HIP_TRY(hipMemcpyAsync(image, which == 0 ? s.dyn : s.obj, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return KHR_OK;
+}
+
 // block allocation + culling of one integrate call (independent of the dynamic mask)
 static int integrateAlloc(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allocate_blocks) {
   DevMap& m = c->m;
@@ -1106,6 +1137,7 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
       c->last_clusters[i] = khr_cluster{};
       c->last_clusters[i].id = kept[i].first;
       c->last_clusters[i].num_pixels_listed = kept[i].second;
+      c->last_clusters[i].semantic_id = -1;
     }
   }
   return n_out;
@@ -1190,6 +1222,214 @@ int khr_get_dynamic_clusters(khr_ctx* c, int slot, khr_cluster* out, int cap) {
     out[i] = k;
   }
   return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// object detection (ConnectedSemantics role) and per-cluster voxel sets (MaxIoUTracker measurement role)
+// ---------------------------------------------------------------------------------------------
+static int ensureGv(khr_ctx* c) {
+  if (c->d_gv_keys) return KHR_OK;
+  const size_t npx = c->cfg.max_frame_pixels;
+  size_t ts = 1024;
+  while (ts < 2 * npx) ts <<= 1;
+  c->gv_mask = static_cast<uint32_t>(ts - 1);
+  c->obj_root_cap = 1u << 16;
+  int rc = KHR_OK;
+  auto A = [&](int r) { if (rc == KHR_OK) rc = r; };
+  A(devAlloc(c, &c->d_gv_keys, ts, false));
+  A(devAlloc(c, &c->d_gv_parent, ts, false));  // >= npx: also the per-pixel parent array of the 2D mode
+  A(devAlloc(c, &c->d_gv_rootidx, ts, false));
+  A(devAlloc(c, &c->d_gv_node, npx, false));
+  A(devAlloc(c, &c->d_gv_n, 4));
+  A(devAlloc(c, &c->d_obj_acc, c->obj_root_cap, false));
+  A(devAlloc(c, &c->d_obj_final, c->obj_root_cap, false));
+  A(devAlloc(c, &c->d_cv_list, npx, false));
+  return rc;
+}
+
+// voxel of the sensor position on a grid: the origin of the relative voxel window
+static int3 windowOrigin(const DevFrame& f, float inv) {
+  return make_int3(static_cast<int>(std::floor(f.tw[0] * inv)), static_cast<int>(std::floor(f.tw[1] * inv)),
+                   static_cast<int>(std::floor(f.tw[2] * inv)));
+}
+
+int khr_configure_object_detector(khr_ctx* c, const khr_object_detector_config* cfg) {
+  if (!c || !cfg) return fail(KHR_EINVAL, "null argument");
+  if (cfg->n_object_labels < 0 || (cfg->n_object_labels > 0 && !cfg->object_labels)) return fail(KHR_EINVAL, "bad object label list");
+  if (cfg->use_3d && !(cfg->grid_size > 0.f)) return fail(KHR_EINVAL, "grid_size must be > 0");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = ensureGv(c);
+  if (rc) return rc;
+  c->obj_cfg = *cfg;
+  c->obj_labels.assign(cfg->object_labels, cfg->object_labels + cfg->n_object_labels);
+  std::sort(c->obj_labels.begin(), c->obj_labels.end());
+  c->obj_labels.erase(std::unique(c->obj_labels.begin(), c->obj_labels.end()), c->obj_labels.end());
+  if (c->obj_labels.size() > kGvMaxGroup) return fail(KHR_EINVAL, "more than %u object labels", kGvMaxGroup);
+  c->obj_cfg.object_labels = nullptr;
+  c->obj_cfg.n_object_labels = static_cast<int32_t>(c->obj_labels.size());
+  if (c->d_obj_labels) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    hipFree(c->d_obj_labels);
+    c->allocs.erase(std::remove(c->allocs.begin(), c->allocs.end(), static_cast<void*>(c->d_obj_labels)), c->allocs.end());
+    c->d_obj_labels = nullptr;
+  }
+  rc = devAlloc(c, &c->d_obj_labels, c->obj_labels.size(), false);
+  if (rc) return rc;
+  if (!c->obj_labels.empty()) {
+    HIP_TRY(hipMemcpyAsync(c->d_obj_labels, c->obj_labels.data(), sizeof(int32_t) * c->obj_labels.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  c->obj_configured = true;
+  return KHR_OK;
+}
+
+int khr_detect_objects(khr_ctx* c, int slot) {
+  if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
+  if (!c->obj_configured) return fail(KHR_ESTATE, "khr_configure_object_detector has not been called");
+  HIP_TRY(hipSetDevice(c->device));
+  FrameSlot& s = c->slots[slot];
+  const int n = s.sensor.width * s.sensor.height;
+  const khr_object_detector_config& oc = c->obj_cfg;
+  c->last_sem_clusters.clear();
+  c->last_sem_slot = slot;
+  s.has_obj = true;
+  HIP_TRY(hipMemsetAsync(s.obj, 0, sizeof(int32_t) * n, c->stream));
+  const int n_labels = static_cast<int>(c->obj_labels.size());
+  if (!s.has_label || n_labels == 0) return 0;
+  const DevFrame f = makeDevFrame(c, s);
+  GvTable t{c->d_gv_keys, c->gv_mask};
+  HIP_TRY(hipMemsetAsync(c->d_gv_n, 0, sizeof(uint32_t) * 4, c->stream));
+  if (oc.use_3d) {
+    const float inv = 1.f / oc.grid_size;  // connected_semantics.cpp:75
+    HIP_TRY(hipMemsetAsync(c->d_gv_keys, 0xff, sizeof(uint64_t) * (static_cast<size_t>(c->gv_mask) + 1), c->stream));
+    hipLaunchKernelGGL(k_obj_insert3d, dim3(gridFor(n)), dim3(256), 0, c->stream, f, c->d_obj_labels, n_labels, oc.max_range, inv,
+                       windowOrigin(f, inv), t, c->d_gv_parent, c->d_gv_node, c->d_gv_n + 1);
+    hipLaunchKernelGGL(k_obj_union3d, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_gv_node, n, t, c->d_gv_parent,
+                       oc.use_full_connectivity ? 13 : 3);
+  } else {
+    hipLaunchKernelGGL(k_obj_init2d, dim3(gridFor(n)), dim3(256), 0, c->stream, f, c->d_obj_labels, n_labels, c->d_gv_parent, c->d_gv_node);
+    hipLaunchKernelGGL(k_obj_union2d, dim3(gridFor(n)), dim3(256), 0, c->stream, f, c->d_gv_node, c->d_gv_parent,
+                       oc.use_full_connectivity ? 1 : 0);
+  }
+  hipLaunchKernelGGL(k_obj_roots, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_gv_node, n, c->d_gv_parent, c->d_gv_rootidx, c->d_gv_n,
+                     c->obj_root_cap, c->d_obj_acc, oc.use_3d ? c->d_gv_keys : nullptr, s.label, c->d_obj_labels, n_labels);
+  hipLaunchKernelGGL(k_obj_paint, dim3(gridFor(n)), dim3(256), 0, c->stream, f, c->d_gv_node, c->d_gv_parent, c->d_gv_rootidx,
+                     c->obj_root_cap, s.obj, c->d_obj_acc);
+  HIP_TRY(hipGetLastError());
+  uint32_t cnt[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(cnt, c->d_gv_n, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (cnt[1] & 1u) return fail(KHR_EINVAL, "object detector: a measured point lies more than %d grid cells from the sensor", kGvWindow);
+  const uint32_t R = cnt[0];
+  if (R > c->obj_root_cap) return fail(KHR_ENOMEM, "object detector: %u clusters exceed the capacity %u", R, c->obj_root_cap);
+  if (R == 0) return 0;
+  std::vector<ObjAcc>& acc = c->h_obj_acc;
+  acc.resize(R);
+  HIP_TRY(hipMemcpyAsync(acc.data(), c->d_obj_acc, sizeof(ObjAcc) * R, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  // cluster order: 3D mode = by semantic id (std::map, connected_semantics.h:87), then by first pixel in scan order
+  // (ASSUMPTIONS.md C.4); 2D mode = discovery order of the column-major scan (:147-160)
+  std::vector<uint32_t> order(R);
+  for (uint32_t i = 0; i < R; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    if (oc.use_3d && acc[a].group != acc[b].group) return acc[a].group < acc[b].group;
+    return acc[a].first_cm < acc[b].first_cm;
+  });
+  std::vector<int32_t>& fin = c->h_obj_final;
+  fin.assign(R, 0);
+  int next_id = 1;
+  for (uint32_t r : order) {
+    const ObjAcc& a = acc[r];
+    const int size = static_cast<int>(a.n_pixels);
+    int id;
+    if (oc.use_3d) {  // size filter before the id is taken (:104-110)
+      if (size < oc.min_cluster_size || (oc.max_cluster_size > 0 && size > oc.max_cluster_size)) continue;
+      id = next_id++;
+    } else {          // ids are taken by every component, small ones are erased afterwards (filterClusters, :200-216)
+      id = next_id++;
+      if (size < oc.min_cluster_size) continue;
+    }
+    fin[r] = id;
+    khr_cluster k{};
+    k.id = id;
+    k.num_pixels_listed = a.n_pixels;
+    k.num_pixels_painted = a.n_pixels;
+    for (int d = 0; d < 3; ++d) {
+      k.bbox_min[d] = orderedToFloat(a.bmin[d]);
+      k.bbox_max[d] = orderedToFloat(a.bmax[d]);
+      k.centroid[d] = a.sum[d] / static_cast<float>(a.n_pixels);
+    }
+    k.semantic_id = c->obj_labels[a.group];
+    c->last_sem_clusters.push_back(k);
+  }
+  HIP_TRY(hipMemcpyAsync(c->d_obj_final, fin.data(), sizeof(int32_t) * R, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_obj_remap, dim3(gridFor(n)), dim3(256), 0, c->stream, s.obj, n, c->d_obj_final);
+  HIP_TRY(hipGetLastError());
+  return static_cast<int>(c->last_sem_clusters.size());
+}
+
+int khr_get_semantic_clusters(khr_ctx* c, int slot, khr_cluster* out, int cap) {
+  if (!c || cap < 0 || (!out && cap > 0)) return fail(KHR_EINVAL, "bad argument");
+  if (slot != c->last_sem_slot) return fail(KHR_ESTATE, "semantic clusters are kept for the last processed frame only");
+  const int n = static_cast<int>(c->last_sem_clusters.size());
+  for (int i = 0; i < n && i < cap; ++i) out[i] = c->last_sem_clusters[i];
+  return n;
+}
+
+int64_t khr_cluster_voxels(khr_ctx* c, int slot, int which, float voxel_size, int32_t* ids_out, int64_t* voxels_out, int64_t cap) {
+  if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
+  if (!(voxel_size > 0.f) || cap < 0 || (cap > 0 && (!ids_out || !voxels_out)) || (which != 0 && which != 1)) return fail(KHR_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = ensureGv(c);
+  if (rc) return rc;
+  FrameSlot& s = c->slots[slot];
+  if (which == 1 && !s.has_obj) return 0;
+  const int n = s.sensor.width * s.sensor.height;
+  const DevFrame f = makeDevFrame(c, s);
+  const float inv = 1.f / voxel_size;  // spatial_hash::Grid(voxel_size)
+  const int3 origin = windowOrigin(f, inv);
+  GvTable t{c->d_gv_keys, c->gv_mask};
+  HIP_TRY(hipMemsetAsync(c->d_gv_n, 0, sizeof(uint32_t) * 4, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_gv_keys, 0xff, sizeof(uint64_t) * (static_cast<size_t>(c->gv_mask) + 1), c->stream));
+  hipLaunchKernelGGL(k_cluster_voxels, dim3(gridFor(n)), dim3(256), 0, c->stream, f, which == 0 ? s.dyn : s.obj, inv, origin, t,
+                     c->d_cv_list, c->d_gv_n, static_cast<uint32_t>(c->cfg.max_frame_pixels), c->d_gv_n + 1);
+  HIP_TRY(hipGetLastError());
+  uint32_t cnt[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(cnt, c->d_gv_n, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (cnt[1] & 1u) return fail(KHR_EINVAL, "cluster voxels: a measured point lies more than %d voxels from the sensor", kGvWindow);
+  if (cnt[1] & 2u) return fail(KHR_EINVAL, "cluster voxels: cluster id above %u", kGvMaxGroup);
+  const uint32_t N = cnt[0];
+  if (N == 0) return 0;
+  std::vector<uint64_t> keys(N);
+  HIP_TRY(hipMemcpyAsync(keys.data(), c->d_cv_list, sizeof(uint64_t) * N, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  struct E { int32_t id; int64_t v[3]; };
+  std::vector<E> e(N);
+  for (uint32_t i = 0; i < N; ++i) {
+    uint32_t g;
+    int x, y, z;
+    gvUnpack(keys[i], &g, &x, &y, &z);
+    e[i].id = static_cast<int32_t>(g);
+    if (gvIsOrigin(keys[i])) {
+      e[i].v[0] = e[i].v[1] = e[i].v[2] = 0;
+    } else {
+      e[i].v[0] = static_cast<int64_t>(x) + origin.x;
+      e[i].v[1] = static_cast<int64_t>(y) + origin.y;
+      e[i].v[2] = static_cast<int64_t>(z) + origin.z;
+    }
+  }
+  std::sort(e.begin(), e.end(), [](const E& a, const E& b) {
+    if (a.id != b.id) return a.id < b.id;
+    if (a.v[0] != b.v[0]) return a.v[0] < b.v[0];
+    if (a.v[1] != b.v[1]) return a.v[1] < b.v[1];
+    return a.v[2] < b.v[2];
+  });
+  for (int64_t i = 0; i < static_cast<int64_t>(N) && i < cap; ++i) {
+    ids_out[i] = e[i].id;
+    for (int d = 0; d < 3; ++d) voxels_out[3 * i + d] = e[i].v[d];
+  }
+  return static_cast<int64_t>(N);
 }
 
 int khr_generate_mesh(khr_ctx* c, int only_mesh_updated, int clear_flag) {

@@ -10,12 +10,15 @@
 #include "oracle.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cmath>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <thread>
 #include <unordered_map>
 #include <unordered_set>
@@ -692,6 +695,181 @@ void orc_clear_updated(orc_map* m) {
   // TsdfBlock::clearUpdated (active_window.cpp:169-171): clears the 'updated' flag only; mesh_updated is
   // cleared by generateMesh, tracking_updated by the tracking integrator (ASSUMPTIONS.md A.6)
   for (auto& kv : m->blocks) kv.second->updated = false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ConnectedSemantics (connected_semantics.cpp) and the tracker's per-cluster voxel sets
+// ---------------------------------------------------------------------------------------------
+struct ObjCluster {
+  int semantic_id = -1;
+  std::vector<int> pixels;  // linear row-major pixel indices
+  uint32_t first_cm = 0xffffffffu;
+};
+
+static void finishCluster(ObjCluster& c, int W, int H) {
+  for (int i : c.pixels) {
+    const uint32_t cm = static_cast<uint32_t>(i % W) * static_cast<uint32_t>(H) + static_cast<uint32_t>(i / W);
+    c.first_cm = std::min(c.first_cm, cm);
+  }
+}
+
+int orc_detect_objects(const orc_config* cfg, const orc_object_detector_config* oc, const orc_sensor* s, const orc_frame* f,
+                       int32_t* object_image, orc_cluster* clusters_out, int cap) {
+  const int W = s->width, H = s->height;
+  const size_t n = static_cast<size_t>(W) * H;
+  std::fill(object_image, object_image + n, 0);
+  if (!f->label) return 0;
+  std::vector<float> range(n), vertex(3 * n);
+  orc_parse_input(cfg, s, f->world_T_sensor, f->depth, range.data(), vertex.data());
+  std::set<int32_t> object_labels(oc->object_labels, oc->object_labels + oc->n_object_labels);
+  auto isObject = [&](int32_t l) { return object_labels.count(l) != 0; };
+  std::vector<ObjCluster> clusters;
+
+  if (oc->use_3d) {
+    // computeCandidateVoxels (:123-144)
+    const float inv = 1.f / oc->grid_size;
+    std::map<int, std::map<std::array<int64_t, 3>, std::vector<int>>> maps;
+    for (int u = 0; u < W; ++u) {
+      for (int v = 0; v < H; ++v) {
+        const int i = v * W + u;
+        if (oc->max_range > 0.f && range[i] > oc->max_range) continue;
+        const int sem = f->label[i];
+        if (!isObject(sem)) continue;
+        const float* p = &vertex[3 * i];
+        const std::array<int64_t, 3> vox = {static_cast<int64_t>(std::floor(p[0] * inv)), static_cast<int64_t>(std::floor(p[1] * inv)),
+                                            static_cast<int64_t>(std::floor(p[2] * inv))};
+        maps[sem][vox].push_back(i);
+      }
+    }
+    // semanticClustering3D (:71-121): region growing per semantic id
+    const int nn = oc->use_full_connectivity ? 26 : 6;
+    for (auto& sm : maps) {
+      auto& vox_to_pix = sm.second;
+      std::vector<ObjCluster> of_this_id;
+      while (!vox_to_pix.empty()) {
+        ObjCluster c;
+        c.semantic_id = sm.first;
+        std::vector<std::array<int64_t, 3>> stack;
+        auto it0 = vox_to_pix.begin();
+        stack.push_back(it0->first);
+        c.pixels.insert(c.pixels.end(), it0->second.begin(), it0->second.end());
+        vox_to_pix.erase(it0);
+        while (!stack.empty()) {
+          const auto vi = stack.back();
+          stack.pop_back();
+          for (int k = 0; k < nn; ++k) {
+            const std::array<int64_t, 3> nb = {vi[0] + kNeighborOffsets26[k][0], vi[1] + kNeighborOffsets26[k][1],
+                                               vi[2] + kNeighborOffsets26[k][2]};
+            auto it = vox_to_pix.find(nb);
+            if (it == vox_to_pix.end()) continue;
+            stack.push_back(it->first);
+            c.pixels.insert(c.pixels.end(), it->second.begin(), it->second.end());
+            vox_to_pix.erase(it);
+          }
+        }
+        finishCluster(c, W, H);
+        of_this_id.push_back(std::move(c));
+      }
+      // ASSUMPTIONS.md C.4: the start voxel comes from an unordered map in the reference; canonical order here
+      std::sort(of_this_id.begin(), of_this_id.end(), [](const ObjCluster& a, const ObjCluster& b) { return a.first_cm < b.first_cm; });
+      for (auto& c : of_this_id) {
+        const int size = static_cast<int>(c.pixels.size());
+        if (size < oc->min_cluster_size || (oc->max_cluster_size > 0 && size > oc->max_cluster_size)) continue;  // :104-110
+        clusters.push_back(std::move(c));
+      }
+    }
+    for (size_t k = 0; k < clusters.size(); ++k)
+      for (int i : clusters[k].pixels) object_image[i] = static_cast<int32_t>(k + 1);  // :111-116
+  } else {
+    // semanticClustering2D + growCluster2D (:146-198)
+    std::vector<int32_t> ids_all;  // id of every grown cluster, before filtering
+    for (int u = 0; u < W; ++u) {
+      for (int v = 0; v < H; ++v) {
+        if (object_image[v * W + u] != 0) continue;
+        const int sem = f->label[v * W + u];
+        if (!isObject(sem)) continue;
+        ObjCluster c;
+        c.semantic_id = sem;
+        const int32_t id = static_cast<int32_t>(clusters.size() + 1);
+        std::vector<std::pair<int, int>> stack{{u, v}};
+        c.pixels.push_back(v * W + u);
+        object_image[v * W + u] = id;
+        while (!stack.empty()) {
+          const auto px = stack.back();
+          stack.pop_back();
+          for (int dv = -1; dv <= 1; ++dv)
+            for (int du = -1; du <= 1; ++du) {
+              if (du == 0 && dv == 0) continue;
+              if (!oc->use_full_connectivity && du != 0 && dv != 0) continue;
+              const int nu = px.first + du, nv = px.second + dv;
+              if (nu < 0 || nv < 0 || nu >= W || nv >= H) continue;
+              if (object_image[nv * W + nu] != 0) continue;
+              if (f->label[nv * W + nu] != sem) continue;
+              c.pixels.push_back(nv * W + nu);
+              object_image[nv * W + nu] = id;
+              stack.push_back({nu, nv});
+            }
+        }
+        finishCluster(c, W, H);
+        clusters.push_back(std::move(c));
+      }
+    }
+    // filterClusters (:200-216): ids of the survivors are kept
+    std::vector<ObjCluster> kept;
+    std::vector<int32_t> kept_ids;
+    for (size_t k = 0; k < clusters.size(); ++k) {
+      if (static_cast<int>(clusters[k].pixels.size()) < oc->min_cluster_size) {
+        for (int i : clusters[k].pixels) object_image[i] = 0;
+      } else {
+        kept_ids.push_back(static_cast<int32_t>(k + 1));
+        kept.push_back(std::move(clusters[k]));
+      }
+    }
+    clusters = std::move(kept);
+    for (size_t k = 0; k < clusters.size() && static_cast<int>(k) < cap; ++k) clusters_out[k].id = kept_ids[k];
+  }
+  for (size_t k = 0; k < clusters.size() && static_cast<int>(k) < cap; ++k) {
+    orc_cluster& o = clusters_out[k];
+    if (oc->use_3d) o.id = static_cast<int32_t>(k + 1);
+    o.semantic_id = clusters[k].semantic_id;
+    o.num_pixels = clusters[k].pixels.size();
+    double sum[3] = {0, 0, 0};
+    for (int d = 0; d < 3; ++d) { o.bbox_min[d] = 3.0e38f; o.bbox_max[d] = -3.0e38f; }
+    for (int i : clusters[k].pixels)
+      for (int d = 0; d < 3; ++d) {
+        const float x = vertex[3 * i + d];
+        o.bbox_min[d] = std::min(o.bbox_min[d], x);
+        o.bbox_max[d] = std::max(o.bbox_max[d], x);
+        sum[d] += x;
+      }
+    for (int d = 0; d < 3; ++d) o.centroid[d] = static_cast<float>(sum[d] / static_cast<double>(o.num_pixels));
+  }
+  return static_cast<int>(clusters.size());
+}
+
+int64_t orc_cluster_voxels(const orc_config* cfg, const orc_sensor* s, const orc_frame* f, const int32_t* id_image, float voxel_size,
+                           int32_t* ids_out, int64_t* voxels_out, int64_t cap) {
+  const int W = s->width, H = s->height;
+  const size_t n = static_cast<size_t>(W) * H;
+  std::vector<float> vertex(3 * n);
+  orc_parse_input(cfg, s, f->world_T_sensor, f->depth, nullptr, vertex.data());
+  const float inv = 1.f / voxel_size;  // spatial_hash::Grid
+  std::set<std::array<int64_t, 4>> pairs;
+  for (size_t i = 0; i < n; ++i) {
+    if (id_image[i] <= 0) continue;
+    const float* p = &vertex[3 * i];
+    pairs.insert({static_cast<int64_t>(id_image[i]), static_cast<int64_t>(std::floor(p[0] * inv)),
+                  static_cast<int64_t>(std::floor(p[1] * inv)), static_cast<int64_t>(std::floor(p[2] * inv))});
+  }
+  int64_t k = 0;
+  for (const auto& e : pairs) {
+    if (k < cap) {
+      ids_out[k] = static_cast<int32_t>(e[0]);
+      for (int d = 0; d < 3; ++d) voxels_out[3 * k + d] = e[d + 1];
+    }
+    ++k;
+  }
+  return k;
 }
 
 void orc_allocate_block(orc_map* m, int32_t bx, int32_t by, int32_t bz) { m->allocate({bx, by, bz}); }

@@ -145,6 +145,33 @@ int64_t orc_mesh_copy(orc_map* m, float* points /*3n*/, uint8_t* colors /*4n*/, 
 /* MeshObjectExtractor confidence pruning (mesh_object_extractor.cpp:246-264,342-356) */
 int64_t orc_object_prune(orc_map* m, float min_confidence, float min_observations);
 
+/* khronos::ConnectedSemantics (connected_semantics.cpp:59-216).  object_labels = the ids for which hydra's
+ * LabelSpaceConfig::isObject holds.  Cluster order where the reference iterates an unordered map:
+ * ASSUMPTIONS.md C.4 (3D: by semantic id, then by first pixel in the column-major scan order). */
+typedef struct orc_object_detector_config {
+  int32_t use_full_connectivity;
+  int32_t min_cluster_size;
+  int32_t max_cluster_size;
+  int32_t use_3d;
+  float grid_size;
+  float max_range;
+  const int32_t* object_labels;
+  int32_t n_object_labels;
+} orc_object_detector_config;
+typedef struct orc_cluster {
+  int32_t id;
+  int32_t semantic_id;
+  uint64_t num_pixels;
+  float bbox_min[3], bbox_max[3]; /* BoundingBox(VertexMapAdaptor(pixels, vertex_map)), max_iou_tracker.cpp:466-476 */
+  float centroid[3];              /* mean vertex (double accumulation) */
+} orc_cluster;
+int orc_detect_objects(const orc_config* cfg, const orc_object_detector_config* oc, const orc_sensor* s,
+                       const orc_frame* f, int32_t* object_image_out, orc_cluster* clusters_out, int cap);
+/* MaxIoUTracker::setupTrackMeasurementVoxels (max_iou_tracker.cpp:478-487) for all clusters of an id image:
+ * distinct (id, voxel) pairs sorted by (id, x, y, z); returns the count */
+int64_t orc_cluster_voxels(const orc_config* cfg, const orc_sensor* s, const orc_frame* f, const int32_t* id_image,
+                           float voxel_size, int32_t* ids_out, int64_t* voxels_out, int64_t cap);
+
 /* explicit allocation (mesh_object_extractor.cpp:218-228) */
 void orc_allocate_block(orc_map* m, int32_t bx, int32_t by, int32_t bz);
 

@@ -38,6 +38,17 @@ class OrcFrame(C.Structure):
                 ("object_id", C.c_int32)]
 
 
+class OrcObjectDetectorConfig(C.Structure):
+    _fields_ = [("use_full_connectivity", C.c_int32), ("min_cluster_size", C.c_int32), ("max_cluster_size", C.c_int32),
+                ("use_3d", C.c_int32), ("grid_size", C.c_float), ("max_range", C.c_float),
+                ("object_labels", C.POINTER(C.c_int32)), ("n_object_labels", C.c_int32)]
+
+
+class OrcCluster(C.Structure):
+    _fields_ = [("id", C.c_int32), ("semantic_id", C.c_int32), ("num_pixels", C.c_uint64), ("bbox_min", C.c_float * 3),
+                ("bbox_max", C.c_float * 3), ("centroid", C.c_float * 3)]
+
+
 class OrcStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_visible_blocks", "n_new_blocks", "n_visited_voxels",
                                           "n_updated_voxels", "n_band_voxels")]
@@ -81,6 +92,10 @@ def load():
     lib.orc_motion_keys.argtypes = [vp, C.POINTER(OrcSensor), C.POINTER(OrcFrame), vp]
     lib.orc_motion_keys.restype = None
     lib.orc_detect_motion_from_keys.argtypes = [vp, i32, i32, vp, vp, C.POINTER(i64)]
+    lib.orc_detect_objects.argtypes = [C.POINTER(OrcConfig), C.POINTER(OrcObjectDetectorConfig), C.POINTER(OrcSensor),
+                                       C.POINTER(OrcFrame), vp, C.POINTER(OrcCluster), i32]
+    lib.orc_cluster_voxels.argtypes = [C.POINTER(OrcConfig), C.POINTER(OrcSensor), C.POINTER(OrcFrame), vp, C.c_float, vp, vp, i64]
+    lib.orc_cluster_voxels.restype = i64
     lib.orc_generate_mesh.argtypes = [vp, i32, i32]
     lib.orc_generate_mesh.restype = i64
     lib.orc_mesh_halo_requests.argtypes = [vp, i32, vp, i64]
@@ -217,6 +232,29 @@ class OracleMap:
         ns = C.c_int64(0)
         n = self.lib.orc_detect_motion_from_keys(self.h, w, h, _ptr(keys), _ptr(dyn), C.byref(ns))
         return n, dyn, ns.value
+
+    def detect_objects(self, sensor, stamp_ns, T, depth, label, object_labels, use_3d=True, grid_size=0.1, max_range=0.0,
+                       min_cluster_size=0, max_cluster_size=-1, use_full_connectivity=True, cap=65536):
+        """ConnectedSemantics::processInput: (n, object_image, clusters)."""
+        f, keep = self._frame(stamp_ns, T, depth, label=label)
+        labels = np.ascontiguousarray(object_labels, dtype=np.int32)
+        oc = OrcObjectDetectorConfig(int(use_full_connectivity), int(min_cluster_size), int(max_cluster_size), int(use_3d),
+                                     float(grid_size), float(max_range), labels.ctypes.data_as(C.POINTER(C.c_int32)), labels.size)
+        img = np.zeros((sensor.height, sensor.width), np.int32)
+        arr = (OrcCluster * cap)()
+        n = self.lib.orc_detect_objects(C.byref(self.cfg), C.byref(oc), C.byref(sensor), C.byref(f), _ptr(img), arr, cap)
+        cl = [dict(id=a.id, semantic_id=a.semantic_id, num_pixels=a.num_pixels, bbox_min=np.array(a.bbox_min[:]),
+                   bbox_max=np.array(a.bbox_max[:]), centroid=np.array(a.centroid[:])) for a in arr[:min(n, cap)]]
+        return n, img, cl
+
+    def cluster_voxels(self, sensor, stamp_ns, T, depth, id_image, voxel_size):
+        f, keep = self._frame(stamp_ns, T, depth)
+        img = np.ascontiguousarray(id_image, dtype=np.int32)
+        n = self.lib.orc_cluster_voxels(C.byref(self.cfg), C.byref(sensor), C.byref(f), _ptr(img), float(voxel_size), None, None, 0)
+        ids = np.zeros(max(n, 1), np.int32)
+        vox = np.zeros((max(n, 1), 3), np.int64)
+        self.lib.orc_cluster_voxels(C.byref(self.cfg), C.byref(sensor), C.byref(f), _ptr(img), float(voxel_size), _ptr(ids), _ptr(vox), n)
+        return ids[:n], vox[:n]
 
     def generate_mesh(self, only_mesh_updated=True, clear_flag=True):
         return self.lib.orc_generate_mesh(self.h, int(only_mesh_updated), int(clear_flag))

@@ -143,7 +143,10 @@ std::shared_ptr<KhronosObjectAttributes> MeshObjectExtractor::extractObject(cons
   if (track.confidence <= config.min_object_allocation_confidence) return nullptr;
   auto object = track.is_dynamic ? extractDynamicObject(track, frames) : extractStaticObject(track, frames);
   if (!object) return nullptr;
-  object->semantic_label = track.semantic_label;
+  if (track.semantics) {  // mesh_object_extractor.cpp:96-99
+    object->semantic_label = track.semantics->category_id;
+    object->semantic_feature = track.semantics->feature;
+  }
   object->first_observed_ns = {track.first_seen};
   object->last_observed_ns = {track.last_seen};
   for (int i = 0; i < 3; ++i) object->position[i] = object->bounding_box.center(i);
@@ -332,8 +335,14 @@ ActiveWindow::Config ActiveWindow::Config::fromYaml(const khronos_amd::YamlNode&
     m->read("min_z_coordinate", d.min_z_coordinate);
     m->read("num_threads", d.num_threads);
   }
-  if (const auto* m = n.find("object_detector")) m->read("type", c.object_detector_type);
-  if (const auto* m = n.find("tracker")) m->read("type", c.tracker_type);
+  if (const auto* m = n.find("object_detector")) {
+    m->read("type", c.object_detector_type);
+    c.object_detector = ConnectedSemantics::Config::fromYaml(*m);
+  }
+  if (const auto* m = n.find("tracker")) {
+    m->read("type", c.tracker_type);
+    c.tracker = MaxIoUTracker::Config::fromYaml(*m);
+  }
   if (const auto* m = n.find("object_extractor")) {
     m->read("type", c.object_extractor_type);
     auto& e = const_cast<MeshObjectExtractor::Config&>(c.object_extractor);
@@ -403,6 +412,11 @@ void ActiveWindow::Config::checkValid() const {
     throw std::invalid_argument("unknown motion_detector type '" + motion_detector_type + "'");
   if (!object_extractor_type.empty() && object_extractor_type != "MeshObjectExtractor")
     throw std::invalid_argument("unknown object_extractor type '" + object_extractor_type + "'");
+  if (!object_detector_type.empty() && object_detector_type != "ConnectedSemantics")
+    throw std::invalid_argument("unknown object_detector type '" + object_detector_type +
+                                "' (InstanceForwarding needs open-set label features, which this backend does not carry)");
+  if (!tracker_type.empty() && tracker_type != "MaxIouTracker" && tracker_type != "ExternalTracker")
+    throw std::invalid_argument("unknown tracker type '" + tracker_type + "'");
   interpolationFromName(projective_integrator.interpolation_method);
 }
 
@@ -450,8 +464,21 @@ ActiveWindow::ActiveWindow(const Config& cfg) : config(cfg), frame_data_buffer_(
     motion_detector_ = std::make_unique<FreeSpaceMotionDetector>(config.motion_detector);
   else
     motion_detector_ = std::make_unique<MotionDetector>();
-  object_detector_ = std::make_unique<ObjectDetector>();
-  tracker_ = std::make_unique<Tracker>();
+  if (config.object_detector_type == "ConnectedSemantics")
+    object_detector_ = std::make_unique<ConnectedSemantics>(config.object_detector, map_);
+  else
+    object_detector_ = std::make_unique<ObjectDetector>();
+  if (config.tracker_type == "MaxIouTracker") {
+    tracker_ = std::make_unique<MaxIoUTracker>(config.tracker);
+  } else if (config.tracker_type == "ExternalTracker") {
+    ExternalTracker::Config ec;
+    ec.verbosity = config.tracker.verbosity;
+    ec.temporal_window = config.tracker.temporal_window;
+    ec.min_num_observations = config.tracker.min_num_observations;
+    tracker_ = std::make_unique<ExternalTracker>(ec);
+  } else {
+    tracker_ = std::make_unique<Tracker>();
+  }
   if (config.object_extractor_type == "MeshObjectExtractor")
     object_extractor_ = std::make_unique<MeshObjectExtractor>(config.object_extractor, d);
 }

@@ -13,7 +13,9 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <optional>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "hydra_compat.h"
@@ -32,11 +34,22 @@ using hydra::toSeconds;
 using hydra::VolumetricMap;
 
 // ---- data (khronos/include/khronos/active_window/data/) -------------------------------------------------
+using GlobalIndex = std::array<int64_t, 3>;  // spatial_hash::GlobalIndex role
+
+struct SemanticClusterInfo {  // measurement_clusters.h:48-58
+  int category_id = -1;
+  std::vector<float> feature = {0.f};  // FeatureVector::Zero(1, 1) = "no open-set feature"
+  explicit SemanticClusterInfo(int category) : category_id(category) {}
+  SemanticClusterInfo(int category, std::vector<float> f) : category_id(category), feature(std::move(f)) {}
+};
+
 struct MeasurementCluster {  // measurement_clusters.h:63-80
   int id = 0;
-  size_t num_pixels = 0;
+  size_t num_pixels = 0;            // pixels.size(); the pixel list itself stays in the device id image
   BoundingBox bounding_box;
-  float centroid[3] = {0, 0, 0};  // utils::computeCentroid of the cluster's vertices
+  float centroid[3] = {0, 0, 0};    // utils::computeCentroid of the cluster's vertices
+  std::vector<GlobalIndex> voxels;  // GlobalIndexSet role, kept sorted by (x, y, z)
+  std::optional<SemanticClusterInfo> semantics;
 };
 
 struct FrameData {  // frame_data.h:59-83
@@ -55,15 +68,20 @@ struct Observation {  // track.h
   int dynamic_cluster_id = -1;
 };
 
-struct Track {  // track.h:51-111 (fields used by the active window)
+struct Track {  // track.h:72-111
   int id = 0;
   bool is_active = true;
   bool is_dynamic = false;
   float confidence = 0.f;
   TimeStamp first_seen = 0, last_seen = 0;
-  int semantic_label = -1;
   BoundingBox last_bounding_box;
+  std::vector<GlobalIndex> last_voxels;  // sorted
+  float last_voxel_size = 0.f;
+  float last_centroid[3] = {0, 0, 0};
+  std::optional<SemanticClusterInfo> semantics;
+  size_t num_features = 0;
   std::vector<Observation> observations;
+  void updateSemantics(const std::optional<SemanticClusterInfo>& other);  // track.cpp:42-70
 };
 using Tracks = std::vector<Track>;
 
@@ -143,6 +161,82 @@ class Tracker {  // tracker.h:49-69: no-op base that only owns the track list
   Tracks tracks_;
 };
 
+// khronos::ConnectedSemantics (connected_semantics.h:59-164): the clustering runs on the device
+// (khr_detect_objects), the class carries the config and fills FrameData::semantic_clusters
+class ConnectedSemantics : public ObjectDetector {
+ public:
+  struct Config {  // connected_semantics.h:62-84, declare_config connected_semantics.cpp:44-54
+    int verbosity = 0;
+    bool use_full_connectivity = true;
+    int min_cluster_size = 0;
+    int max_cluster_size = -1;
+    bool use_3d = true;
+    float grid_size = 0.1f;
+    float max_range = 0.f;
+    // hydra's label space (GlobalInfo::getLabelSpaceConfig().isObject, connected_semantics.cpp:134,157)
+    std::vector<int> object_labels;
+    static Config fromYaml(const khronos_amd::YamlNode& node);
+  } const config;
+  ConnectedSemantics(const Config& config, const VolumetricMap& map);
+  void processInput(const VolumetricMap& map, FrameData& data) override;
+};
+
+// khronos::MaxIoUTracker (max_iou_tracker.h:60-214, max_iou_tracker.cpp).  The per-cluster voxel sets come from
+// the device (khr_cluster_voxels); the association logic is host code as in the reference.
+class MaxIoUTracker : public Tracker {
+ public:
+  struct Config {  // max_iou_tracker.h:63-101, checks max_iou_tracker.cpp:143-147
+    int verbosity = 0;
+    enum class SemanticAssociation { kAssignCluster, kAssignTrack } semantic_association = SemanticAssociation::kAssignCluster;
+    float min_semantic_iou = 0.5f;
+    float min_cosine_sim = 0.0f;
+    float min_cross_iou = 0.5f;
+    float max_dynamic_distance = 1.f;
+    float temporal_window = 3.f;
+    int min_num_observations = 20;
+    enum class TrackBy { kPixels, kVoxels, kBouningBox } track_by = TrackBy::kPixels;
+    float voxel_size = 0.1f;
+    static Config fromYaml(const khronos_amd::YamlNode& node);
+  } const config;
+  explicit MaxIoUTracker(const Config& config);
+  void processInput(FrameData& data) override;
+
+  // the steps of processInput (public as in the reference)
+  void setupTrackMeasurements(FrameData& data) const;
+  void associateTracks(const FrameData& data);
+  void associateDynamicTracks(const FrameData& data);
+  void associateSemanticTracks(const FrameData& data);
+  void assignClustersToStaticTrack(const FrameData& data, std::unordered_set<int>& associated_objects);
+  void assignStaticTracksToCluster(const FrameData& data, std::unordered_set<int>& associated_objects);
+  void updateTrackingDuration();
+  Track& addNewTrack(const MeasurementCluster& observation, bool is_dynamic);
+  void updateTrack(const MeasurementCluster& observation, Track& track, bool is_observation_dynamic) const;
+  void computeCentroid(const MeasurementCluster& cluster, float* centroid) const;
+  float computeIoU(const MeasurementCluster& cluster, const Track& track) const;
+  static float computeIoUVoxels(const std::vector<GlobalIndex>& cluster_voxels, const std::vector<GlobalIndex>& track_voxels);
+  static float computeIoUBoundingBox(const BoundingBox& a, const BoundingBox& b);
+
+ private:
+  TimeStamp processing_stamp_ = 0;
+  int current_track_id_ = 0;
+};
+
+// khronos::ExternalTracker (external_tracker.cpp:59-143): tracks follow externally provided cluster ids
+class ExternalTracker : public Tracker {
+ public:
+  struct Config {
+    int verbosity = 0;
+    float temporal_window = 3.f;
+    int min_num_observations = 20;
+    static Config fromYaml(const khronos_amd::YamlNode& node);
+  } const config;
+  explicit ExternalTracker(const Config& config);
+  void processInput(FrameData& data) override;
+
+ private:
+  TimeStamp processing_stamp_ = 0;
+};
+
 class ObjectExtractor {  // object_extractor.h
  public:
   virtual ~ObjectExtractor() = default;
@@ -202,8 +296,10 @@ class ActiveWindow {
     TrackingIntegrator::Config tracking_integrator;
     std::string motion_detector_type;    // "" = none, "FreeSpaceMotionDetector"
     FreeSpaceMotionDetector::Config motion_detector;
-    std::string object_detector_type;    // host plugins of SURVEY.md §8(f3); "" = none
-    std::string tracker_type;
+    std::string object_detector_type;    // "" = none, "ConnectedSemantics"
+    ConnectedSemantics::Config object_detector;
+    std::string tracker_type;            // "" = none, "MaxIouTracker", "ExternalTracker"
+    MaxIoUTracker::Config tracker;
     std::string object_extractor_type;   // "" = none, "MeshObjectExtractor"
     MeshObjectExtractor::Config object_extractor;
     struct ExtractionWorker { int num_workers = 2; int poll_time_us = 1000; int verbosity = 0; } extraction_worker;

@@ -2,6 +2,7 @@
 // thread drives the reference (spinOnce per InputPacket, finishMapping at shutdown), and prints a JSON
 // summary that tests/test_gpu_host.py compares with the step-wise C-ABI path and the oracle.
 // usage: aw_demo <config.yaml> <width> <height> <frames> [object_label]
+//   object_label >= 0: the stand-in detector / tracker below; otherwise the plugins named in the config
 #include <cinttypes>
 #include <cmath>
 #include <cstdio>
@@ -55,7 +56,7 @@ struct SingleTrackTracker : Tracker {
       Track t;
       t.id = 0;
       t.first_seen = data.input.timestamp_ns;
-      t.semantic_label = 1;
+      t.semantics = SemanticClusterInfo(1);
       tracks_.push_back(t);
     }
     Track& t = tracks_[0];
@@ -109,7 +110,7 @@ int main(int argc, char** argv) {
     std::vector<int32_t> label(static_cast<size_t>(W) * H);
     std::printf("{\"info\": \"%s\", \"outputs\": [", aw.printInfo().c_str());
     int n_out = 0;
-    size_t total_dyn_clusters = 0;
+    size_t total_dyn_clusters = 0, total_sem_clusters = 0;
     for (int i = 0; i < N; ++i) {
       hydra::InputPacket pkt;
       pkt.timestamp_ns = static_cast<uint64_t>(std::llround((1.0 + 0.1 * i) * 1e9));
@@ -123,9 +124,10 @@ int main(int argc, char** argv) {
       if (det) det->current_labels = label.data();
       auto out = aw.spinOnce(pkt);
       total_dyn_clusters += aw.getLatestFrameData().num_dynamic_clusters;
+      total_sem_clusters += aw.getLatestFrameData().semantic_clusters.size();
       if (out) {
-        std::printf("%s{\"stamp\": %" PRIu64 ", \"updated\": %zu, \"archived\": %zu}", n_out ? ", " : "", out->timestamp_ns,
-                    out->updated_blocks.size(), out->archived_mesh_indices.size());
+        std::printf("%s{\"stamp\": %" PRIu64 ", \"updated\": %zu, \"archived\": %zu, \"objects\": %zu}", n_out ? ", " : "", out->timestamp_ns,
+                    out->updated_blocks.size(), out->archived_mesh_indices.size(), out->graph_update.size());
         ++n_out;
       }
     }
@@ -139,14 +141,23 @@ int main(int argc, char** argv) {
       for (size_t k = 0; k < b.distance.size(); ++k) checksum += static_cast<double>(b.distance[k]) * b.weight[k];
     }
     const size_t n_tracks_before = aw.getTracks().size();
+    std::string track_json = "[";
+    for (const Track& t : aw.getTracks()) {
+      char buf[256];
+      std::snprintf(buf, sizeof(buf), "%s{\"id\": %d, \"dyn\": %d, \"active\": %d, \"conf\": %.9g, \"cat\": %d, \"n_obs\": %zu, \"first\": %" PRIu64
+                    ", \"last\": %" PRIu64 "}", track_json.size() > 1 ? ", " : "", t.id, int(t.is_dynamic), int(t.is_active), t.confidence,
+                    t.semantics ? t.semantics->category_id : -1, t.observations.size(), t.first_seen, t.last_seen);
+      track_json += buf;
+    }
+    track_json += "]";
     auto objects = aw.extractObjects();
     std::printf("], \"n_outputs\": %d, \"sink_calls\": %d, \"dynamic_clusters\": %zu, \"n_blocks\": %zu, \"checksum\": %.9g, "
-                "\"tracks\": %zu, \"objects\": [",
-                n_out, sink_calls, total_dyn_clusters, n_blocks, checksum, n_tracks_before);
+                "\"tracks\": %zu, \"track_list\": %s, \"semantic_clusters\": %zu, \"objects\": [",
+                n_out, sink_calls, total_dyn_clusters, n_blocks, checksum, n_tracks_before, track_json.c_str(), total_sem_clusters);
     for (size_t k = 0; k < objects.size(); ++k) {
       const auto& o = *objects[k];
-      std::printf("%s{\"vertices\": %zu, \"bbox_min\": [%.6f, %.6f, %.6f], \"bbox_max\": [%.6f, %.6f, %.6f]}", k ? ", " : "",
-                  o.mesh.numVertices(), o.bounding_box.min[0], o.bounding_box.min[1], o.bounding_box.min[2], o.bounding_box.max[0],
+      std::printf("%s{\"label\": %d, \"dynamic\": %d, \"vertices\": %zu, \"bbox_min\": [%.6f, %.6f, %.6f], \"bbox_max\": [%.6f, %.6f, %.6f]}", k ? ", " : "",
+                  o.semantic_label, int(!o.trajectory_positions.empty()), o.mesh.numVertices(), o.bounding_box.min[0], o.bounding_box.min[1], o.bounding_box.min[2], o.bounding_box.max[0],
                   o.bounding_box.max[1], o.bounding_box.max[2]);
     }
     aw.finishMapping();

@@ -1,9 +1,12 @@
 // host_selftest.cpp — GPU-free checks of the host-side logic (run by tests/test_cpu_host.py):
 // YAML-subset loader against the reference's mapper config keys, config validation, FrameDataBuffer
 // store / trim known answers (frame_data_buffer.cpp:57-123), object-map sizing (mesh_object_extractor.cpp:201-228).
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
+#include <iostream>
 #include <sstream>
 
 #include "active_window.h"
@@ -24,7 +27,83 @@ static FrameData::Ptr frame(uint64_t stamp) {
   return f;
 }
 
+// Tracker replay (tests/test_cpu_host.py): a scenario of frames with semantic / dynamic clusters (voxel sets and
+// boxes given) on stdin, the track list after every frame as JSON lines on stdout.  Format:
+//   C <tracker> <track_by> <association> <min_semantic_iou> <min_cosine_sim> <min_cross_iou> <max_dynamic_distance>
+//     <temporal_window> <min_num_observations> <voxel_size>
+//   F <stamp>  |  S <id> <category> <min3> <max3> <nvox> <xyz>*  |  D <id> <min3> <max3> <nvox> <xyz>*  |  E (end of frame)
+static int trackerReplay() {
+  std::unique_ptr<Tracker> tracker;
+  auto data = std::make_shared<FrameData>();
+  std::string tok;
+  auto readCluster = [&](bool semantic) {
+    MeasurementCluster c;
+    std::cin >> c.id;
+    if (semantic) {
+      int cat;
+      std::cin >> cat;
+      c.semantics = SemanticClusterInfo(cat);
+    }
+    float lo[3], hi[3];
+    for (float& v : lo) std::cin >> v;
+    for (float& v : hi) std::cin >> v;
+    c.bounding_box.include(lo);
+    c.bounding_box.include(hi);
+    size_t n;
+    std::cin >> n;
+    c.voxels.resize(n);
+    for (auto& v : c.voxels) std::cin >> v[0] >> v[1] >> v[2];
+    std::sort(c.voxels.begin(), c.voxels.end());
+    c.num_pixels = n;
+    return c;
+  };
+  while (std::cin >> tok) {
+    if (tok == "C") {
+      std::string kind, by, assoc;
+      MaxIoUTracker::Config c;
+      std::cin >> kind >> by >> assoc >> c.min_semantic_iou >> c.min_cosine_sim >> c.min_cross_iou >> c.max_dynamic_distance >>
+          c.temporal_window >> c.min_num_observations >> c.voxel_size;
+      c.track_by = by == "voxels" ? MaxIoUTracker::Config::TrackBy::kVoxels : MaxIoUTracker::Config::TrackBy::kBouningBox;
+      c.semantic_association = assoc == "assign_track" ? MaxIoUTracker::Config::SemanticAssociation::kAssignTrack
+                                                       : MaxIoUTracker::Config::SemanticAssociation::kAssignCluster;
+      if (kind == "external") {
+        ExternalTracker::Config e;
+        e.temporal_window = c.temporal_window;
+        e.min_num_observations = c.min_num_observations;
+        tracker = std::make_unique<ExternalTracker>(e);
+      } else {
+        tracker = std::make_unique<MaxIoUTracker>(c);
+      }
+    } else if (tok == "F") {
+      data = std::make_shared<FrameData>();
+      std::cin >> data->input.timestamp_ns;
+    } else if (tok == "S") {
+      data->semantic_clusters.push_back(readCluster(true));
+    } else if (tok == "D") {
+      data->dynamic_clusters.push_back(readCluster(false));
+    } else if (tok == "E") {
+      tracker->processInput(*data);
+      std::printf("[");
+      bool first = true;
+      for (const Track& t : tracker->getTracks()) {
+        const Observation& o = t.observations.back();
+        std::printf("%s{\"id\": %d, \"dyn\": %d, \"active\": %d, \"conf\": %.9g, \"first\": %llu, \"last\": %llu, \"cat\": %d, "
+                    "\"n_obs\": %zu, \"obs\": [%llu, %d, %d], \"n_vox\": %zu, \"centroid\": [%.9g, %.9g, %.9g]}",
+                    first ? "" : ", ", t.id, int(t.is_dynamic), int(t.is_active), t.confidence,
+                    static_cast<unsigned long long>(t.first_seen), static_cast<unsigned long long>(t.last_seen),
+                    t.semantics ? t.semantics->category_id : -1, t.observations.size(), static_cast<unsigned long long>(o.stamp),
+                    o.semantic_cluster_id, o.dynamic_cluster_id, t.last_voxels.size(), t.last_centroid[0], t.last_centroid[1],
+                    t.last_centroid[2]);
+        first = false;
+      }
+      std::printf("]\n");
+    }
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && std::strcmp(argv[1], "--tracker") == 0) return trackerReplay();
   // ---- YAML ----
   if (argc > 1) {
     std::ifstream in(argv[1]);
@@ -95,6 +174,29 @@ int main(int argc, char** argv) {
     MeshObjectExtractor::objectBlockRange(e, 0.16f, mn, mx);  // centre -/+ FULL dimensions (2x the box)
     CHECK(mn[2] == static_cast<int32_t>(std::floor((0.5f - 1.0f) / 0.16f)) && mx[2] == static_cast<int32_t>(std::floor(1.5f / 0.16f)));
     CHECK(mn[0] == static_cast<int32_t>(std::floor((1.25f - 0.5f) * (1.f / 0.16f))));
+  }
+  // ---- MaxIoUTracker pieces (max_iou_tracker.cpp:565-576, track.cpp:42-70) ----
+  {
+    const std::vector<GlobalIndex> a = {{0, 0, 0}, {0, 0, 1}, {1, 0, 0}}, b = {{0, 0, 1}, {1, 0, 0}, {2, 2, 2}, {3, 0, 0}};
+    CHECK(MaxIoUTracker::computeIoUVoxels(a, b) == 2.f / 5.f);
+    CHECK(MaxIoUTracker::computeIoUVoxels(a, a) == 1.f);
+    BoundingBox p, q;
+    const float p0[3] = {0, 0, 0}, p1[3] = {2, 2, 2}, q0[3] = {1, 1, 1}, q1[3] = {3, 3, 3};
+    p.include(p0); p.include(p1); q.include(q0); q.include(q1);
+    CHECK(MaxIoUTracker::computeIoUBoundingBox(p, q) == 1.f / 15.f);
+    Track t;
+    t.updateSemantics(SemanticClusterInfo(3));
+    CHECK(t.semantics && t.semantics->category_id == 3 && t.num_features == 0);
+    t.updateSemantics(SemanticClusterInfo(3, {1.f, 0.f}));
+    CHECK(t.num_features == 1 && t.semantics->feature.size() == 2);
+    t.updateSemantics(SemanticClusterInfo(3, {0.f, 1.f}));
+    CHECK(t.num_features == 2 && t.semantics->feature[0] == 0.5f && t.semantics->feature[1] == 0.5f);
+    t.updateSemantics(SemanticClusterInfo(3));  // a feature is never replaced by "no feature"
+    CHECK(t.num_features == 2 && t.semantics->feature.size() == 2);
+    bool threw = false;
+    try { MaxIoUTracker::Config c; c.track_by = MaxIoUTracker::Config::TrackBy::kVoxels; c.min_cross_iou = 1.5f; MaxIoUTracker m(c); }
+    catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
   }
   std::printf("host selftest ok\n");
   return 0;

@@ -144,6 +144,7 @@ struct KhronosObjectAttributes {
   Mesh mesh;
   BoundingBox bounding_box;
   int semantic_label = -1;
+  std::vector<float> semantic_feature;
   std::vector<TimeStamp> first_observed_ns, last_observed_ns;
   double position[3] = {0, 0, 0};
   // dynamic objects (mesh_object_extractor.cpp:120-172)

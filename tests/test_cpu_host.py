@@ -86,3 +86,111 @@ def test_yaml_loader_on_reference_file_when_present():
     got = _parse(REF_CFG)
     for k, v in EXPECT.items():
         assert got[k] == (v if isinstance(v, str) else __import__("pytest").approx(v, rel=1e-6)), k
+
+
+# ---- tracker plugins: C++ host restatement vs an independent Python restatement on random scenarios ----------
+def _scenario(rng, n_frames, with_dynamic):
+    """blobs of voxels drifting on a 0.2 m grid: some persist (static objects), one moves (dynamic), some flicker."""
+    import numpy as np
+    frames = []
+    blobs = []
+    for k in range(5):
+        c = rng.integers(-10, 10, 3)
+        ext = rng.integers(1, 4, 3)
+        blobs.append(dict(center=c, ext=ext, cat=int(rng.integers(7, 10)), p_seen=float(rng.uniform(0.6, 1.0))))
+    mover = np.array([0.0, 0.0, 2.0])
+    for i in range(n_frames):
+        stamp = 1_000_000_000 + i * 100_000_000
+        sem, dyn = [], []
+        next_id = 1
+        for b in blobs:
+            if rng.uniform() > b["p_seen"]:
+                continue
+            jitter = rng.integers(-1, 2, 3) if rng.uniform() < 0.3 else np.zeros(3, int)
+            lo = b["center"] - b["ext"] + jitter
+            hi = b["center"] + b["ext"] + jitter
+            vox = {(int(x), int(y), int(z)) for x in range(lo[0], hi[0] + 1) for y in range(lo[1], hi[1] + 1) for z in range(lo[2], hi[2] + 1)
+                   if rng.uniform() < 0.9}
+            if not vox:
+                continue
+            box = (np.array(lo, np.float32) * np.float32(0.2), (np.array(hi, np.float32) + 1) * np.float32(0.2))
+            sem.append(dict(id=next_id, category=b["cat"], voxels=vox, box=box))
+            next_id += 1
+        rng.shuffle(sem)
+        for k, c in enumerate(sem):
+            c["id"] = k + 1
+        if with_dynamic and i % 7 != 3:
+            mover = mover + np.array([0.35, 0.1, 0.0])
+            c0 = np.floor(mover / 0.2).astype(int)
+            vox = {(int(c0[0] + x), int(c0[1] + y), int(c0[2] + z)) for x in range(-1, 2) for y in range(-1, 2) for z in range(-2, 3)}
+            box = ((c0 - [1, 1, 2]).astype(np.float32) * np.float32(0.2), (c0 + [2, 2, 3]).astype(np.float32) * np.float32(0.2))
+            dyn.append(dict(id=1, voxels=vox, box=box))
+            if i % 5 == 0:  # the semantic detector sees the mover too
+                sem.append(dict(id=len(sem) + 1, category=19, voxels=set(list(vox)[: len(vox) * 3 // 4]), box=box))
+        frames.append((stamp, sem, dyn))
+    return frames
+
+
+def _encode(kind, cfg, frames):
+    lines = ["C %s %s %s %r %r %r %r %r %d %r" % (kind, cfg["track_by"], cfg["association"], cfg["min_semantic_iou"], 0.0, cfg["min_cross_iou"],
+                                                   cfg["max_dynamic_distance"], cfg["temporal_window"], cfg["min_num_observations"], cfg["voxel_size"])]
+
+    def cl(tag, c, semantic):
+        v = sorted(c["voxels"])
+        head = "%s %d " % (tag, c["id"]) + ("%d " % c["category"] if semantic else "")
+        return head + " ".join(repr(float(x)) for x in list(c["box"][0]) + list(c["box"][1])) + " %d " % len(v) + " ".join("%d %d %d" % t for t in v)
+    for stamp, sem, dyn in frames:
+        lines.append("F %d" % stamp)
+        lines += [cl("S", c, True) for c in sem] + [cl("D", c, False) for c in dyn]
+        lines.append("E")
+    return "\n".join(lines) + "\n"
+
+
+def _tracks_json(tr):
+    return [dict(id=t.id, dyn=int(t.is_dynamic), active=int(t.is_active), conf=float(t.confidence), first=t.first_seen, last=t.last_seen,
+                 cat=t.category if t.has_semantics else -1, n_obs=len(t.observations), obs=list(t.observations[-1]), n_vox=len(t.last_voxels),
+                 centroid=[float(x) for x in t.last_centroid]) for t in tr.tracks]
+
+
+def test_tracker_plugins_match_independent_restatement():
+    import numpy as np
+    import pytest
+    import py_tracker
+    cases = [
+        ("maxiou", dict(track_by="voxels", association="assign_cluster", min_semantic_iou=0.25, min_cross_iou=0.1, max_dynamic_distance=1.0,
+                        temporal_window=0.55, min_num_observations=4, voxel_size=0.2), True),
+        ("maxiou", dict(track_by="voxels", association="assign_track", min_semantic_iou=0.25, min_cross_iou=0.1, max_dynamic_distance=0.5,
+                        temporal_window=0.35, min_num_observations=15, voxel_size=0.2), True),
+        ("maxiou", dict(track_by="bounding_box", association="assign_cluster", min_semantic_iou=0.3, min_cross_iou=0.2, max_dynamic_distance=1.0,
+                        temporal_window=1.0, min_num_observations=3, voxel_size=0.2), True),
+        ("external", dict(track_by="voxels", association="assign_cluster", min_semantic_iou=0.5, min_cross_iou=0.5, max_dynamic_distance=1.0,
+                          temporal_window=0.45, min_num_observations=5, voxel_size=0.2), False),
+    ]
+    for seed, (kind, cfg, with_dyn) in enumerate(cases):
+        rng = np.random.default_rng(100 + seed)
+        frames = _scenario(rng, 40, with_dyn)
+        out = subprocess.run([SELFTEST, "--tracker"], input=_encode(kind, cfg, frames), capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        got = [json.loads(l) for l in out.stdout.strip().splitlines()]
+        if kind == "external":
+            ref = py_tracker.ExternalTracker(cfg["temporal_window"], cfg["min_num_observations"])
+        else:
+            ref = py_tracker.MaxIoUTracker(cfg["track_by"], cfg["association"], cfg["min_semantic_iou"], 0.0, cfg["min_cross_iou"],
+                                           cfg["max_dynamic_distance"], cfg["temporal_window"], cfg["min_num_observations"], cfg["voxel_size"])
+        assert len(got) == len(frames)
+        n_tracks_max = 0
+        for (stamp, sem, dyn), g in zip(frames, got):
+            ref.process(stamp, sem, dyn)
+            want = _tracks_json(ref)
+            assert len(g) == len(want), (kind, stamp)
+            for a, b in zip(g, want):
+                for k in ("id", "dyn", "active", "first", "last", "cat", "n_obs", "obs"):
+                    assert a[k] == b[k], (kind, stamp, k, a, b)
+                assert a["conf"] == pytest.approx(b["conf"], rel=1e-6)
+                if kind != "external" and cfg["track_by"] == "voxels":
+                    assert a["n_vox"] == b["n_vox"]
+                assert a["centroid"] == pytest.approx(b["centroid"], rel=1e-6, abs=1e-6)
+            n_tracks_max = max(n_tracks_max, len(g))
+        assert n_tracks_max >= 4
+        if kind == "maxiou":
+            assert any(t["dyn"] for t in got[-1]) and any(not t["active"] for t in got[-1])

@@ -99,7 +99,7 @@ def test_active_window_host_mirror(tmp_path):
             upd = len(ctx.block_indices(only_updated=True))
             arch = len(ctx.reset_inactive())
             ctx.clear_updated()
-            outputs.append({"stamp": fr["stamp"], "updated": upd, "archived": arch})
+            outputs.append({"stamp": fr["stamp"], "updated": upd, "archived": arch, "objects": 0})
             last_full = fr["stamp"]
     assert res["outputs"] == outputs
     assert res["dynamic_clusters"] == dyn_total
@@ -153,3 +153,87 @@ def test_config_errors_are_loud(tmp_path):
     p.write_text(bad)
     out = subprocess.run([DEMO, str(p), "64", "48", "1"], capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "temporal_window must be > 0" in out.stderr
+
+
+PLUGIN_YAML = YAML.replace("""  object_extractor:""", """  object_detector:
+    type: "ConnectedSemantics"
+    min_cluster_size: 50 # pixels
+    use_full_connectivity: true
+    use_3d: true
+    grid_size: 0.1 # m
+    max_range: *max_range
+    object_labels: [7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19]
+  tracker:
+    type: "MaxIouTracker"
+    track_by: "voxels"
+    min_semantic_iou: 0.25
+    min_cross_iou: 0.1
+    voxel_size: 0.2 # m
+    temporal_window: *temporal_window
+    min_num_observations: 3
+  object_extractor:""")
+
+
+def test_active_window_with_detector_and_tracker_plugins(tmp_path):
+    """ConnectedSemantics + MaxIouTracker configured from YAML (uHumans2.yaml:60-77 keys) inside the C++ ActiveWindow
+    against the step-wise C ABI (device clustering / voxel sets) + the independent Python tracker restatement."""
+    import py_tracker
+    n_frames = 24
+    cfgp = tmp_path / "aw_plugins.yaml"
+    cfgp.write_text(PLUGIN_YAML)
+    out = subprocess.run([DEMO, str(cfgp), str(W), str(H), str(n_frames)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+
+    cfg, ctx, ora, s, sen, osen = make_pair(width=W, height=H, temporal_window=0.75, truncation_distance=0.3,
+                                            md_min_cluster_size=20, md_min_separation_distance=2.0, md_max_range=5.0)
+    ctx.configure_object_detector(list(range(7, 20)), use_3d=True, grid_size=0.1, max_range=5.0, min_cluster_size=50,
+                                  use_full_connectivity=True)
+    trk = py_tracker.MaxIoUTracker("voxels", "assign_cluster", 0.25, 0.0, 0.1, 1.0, 0.75, 3, 0.2)
+    last_full, sem_total, removed_total, per_output_removed = 0, 0, 0, []
+    for i in range(n_frames):
+        fr = s.render(i)
+        slot = ctx.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+        nd = ctx.detect_motion(slot)
+        ctx.integrate(slot, allocate_blocks=True, use_mask=True)
+        ctx.update_tracking(fr["stamp"])
+        ns = ctx.detect_objects(slot)
+        sem_total += ns
+        sem, dyn = [], []
+        if ns:
+            ids, vox = ctx.cluster_voxels(slot, 1, 0.2)
+            for c in ctx.semantic_clusters(slot):
+                v = {tuple(int(x) for x in r) for r in vox[ids == c["id"]]}
+                sem.append(dict(id=c["id"], category=c["semantic_id"], voxels=v, box=(c["bbox_min"], c["bbox_max"])))
+        if nd:
+            ids, vox = ctx.cluster_voxels(slot, 0, 0.2)
+            for c in ctx.dynamic_clusters(slot):
+                v = {tuple(int(x) for x in r) for r in vox[ids == c["id"]]}
+                dyn.append(dict(id=c["id"], voxels=v, box=(c["bbox_min"], c["bbox_max"])))
+        trk.process(fr["stamp"], sem, dyn)
+        if not (last_full + int(float(np.float32(0.4)) * 1e9) > fr["stamp"]):
+            ctx.generate_mesh(True, True)
+            ctx.reset_inactive()
+            ctx.clear_updated()
+            last_full = fr["stamp"]
+            # extractInactiveObjects (active_window.cpp:251-266): inactive tracks leave the tracker
+            gone = [t for t in trk.tracks if not t.is_active]
+            trk.tracks = [t for t in trk.tracks if t.is_active]
+            removed_total += len(gone)
+            per_output_removed.append(len(gone))
+    assert res["semantic_clusters"] == sem_total > 20
+    want = [dict(id=t.id, dyn=int(t.is_dynamic), active=int(t.is_active), cat=t.category if t.has_semantics else -1,
+                 n_obs=len(t.observations), first=t.first_seen, last=t.last_seen) for t in trk.tracks]
+    got = [{k: t[k] for k in ("id", "dyn", "active", "cat", "n_obs", "first", "last")} for t in res["track_list"]]
+    assert got == want
+    assert len(want) >= 3 and removed_total >= 1
+    for t, r in zip(res["track_list"], trk.tracks):
+        assert t["conf"] == pytest.approx(float(r.confidence), rel=1e-6)
+    # objects handed out with the outputs never exceed the tracks that left the tracker at that tick
+    assert [o["objects"] <= n for o, n in zip(res["outputs"], per_output_removed)] == [True] * len(per_output_removed)
+    # objects extracted from the remaining tracks: static ones carry their track's category and a mesh
+    assert len(res["objects"]) >= 1
+    cats = {t.category for t in trk.tracks if t.has_semantics}
+    for o in res["objects"]:
+        if not o["dynamic"]:
+            assert o["label"] in cats and o["vertices"] > 0

@@ -18,8 +18,13 @@ constexpr uint32_t kInvalidSlot = 0xffffffffu;
 
 // block flag bits 0..3 are the public KHR_BLK_* bits
 constexpr uint32_t BLK_UPDATED = 1u, BLK_MESH_UPDATED = 2u, BLK_TRACKING_UPDATED = 4u, BLK_HAS_ACTIVE = 8u,
-                   BLK_LIVE = 16u;
+                   BLK_LIVE = 16u,
+                   BLK_TRACK_DIRTY = 32u;  // internal: the tracking pass may not skip this block (k_tracking_update)
 constexpr uint8_t VOX_ACTIVE = 1, VOX_EVER_FREE = 2, VOX_TO_REMOVE = 4, VOX_SEM_VALID = 8;
+// internal (masked out of every download): the voxel was occupied at the last tracking pass, i.e. its
+// last_occupied stamp IS that pass's stamp and the stored value is stale (k_tracking_update)
+constexpr uint8_t VOX_OCC = 16;
+constexpr uint8_t VOX_PUBLIC_MASK = 0x0f;
 
 enum Counter : int {
   C_FREE_HEAD = 0,   // cursor into free_slots
@@ -60,6 +65,7 @@ struct DevMap {
   uint32_t* color;
   uint64_t* last_obs;
   uint64_t* last_occ;
+  uint64_t* trk_lim;  // [slot][2]: earliest last_observed of an active voxel, earliest last_occupied of a not-yet-free one
   uint8_t* vflags;
   uint32_t* sem_label;
   float* lik;

@@ -789,7 +789,15 @@ __global__ __launch_bounds__(256) void k_pack_blocks(DevMap m, const uint32_t* _
     if (o.weight) copy16(m.weight + src, o.weight + dst, NV * 4);
     if (o.color) copy16(m.color + src, o.color + dst, NV * 4);
     if (o.last_obs) copy16(m.last_obs + src, o.last_obs + dst, NV * 8);
-    if (o.vflags) copy16(m.vflags + src, o.vflags + dst, NV);
+    if (o.vflags) {  // public flag bits only
+      const uint4* s4 = reinterpret_cast<const uint4*>(m.vflags + src);
+      uint4* d4 = reinterpret_cast<uint4*>(o.vflags + dst);
+      const uint32_t pm = VOX_PUBLIC_MASK * 0x01010101u;
+      for (size_t i = threadIdx.x; i < NV / 16; i += 256) {
+        const uint4 v = s4[i];
+        d4[i] = make_uint4(v.x & pm, v.y & pm, v.z & pm, v.w & pm);
+      }
+    }
     if (o.sem_label) copy16(m.sem_label + src, o.sem_label + dst, NV * 4);
   }
 }

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_alloc_visible(DevMap m, DevParams p, De
       slot = m.free_slots[fidx];
       got = true;
       m.blk_index[slot] = make_int4(bx, by, bz, 0);
-      m.blk_flags[slot] = BLK_LIVE;
+      m.blk_flags[slot] = BLK_LIVE | BLK_TRACK_DIRTY;
       m.mesh_desc[slot] = MeshDesc{0u, 0u};
       htInsertUnique(m, key, slot);
       atomicMax(&m.counters[C_MAX_SLOT], slot + 1);
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void k_alloc_list(DevMap m, const int* __restr
       slot = m.free_slots[fidx];
       got = true;
       m.blk_index[slot] = make_int4(bx, by, bz, 0);
-      m.blk_flags[slot] = BLK_LIVE;
+      m.blk_flags[slot] = BLK_LIVE | BLK_TRACK_DIRTY;
       m.mesh_desc[slot] = MeshDesc{0u, 0u};
       htInsertUnique(m, packKey(bx, by, bz), slot);
       atomicMax(&m.counters[C_MAX_SLOT], slot + 1);
@@ -795,65 +795,87 @@ __global__ __launch_bounds__(256) void k_band_update(DevMap m, DevParams p, DevF
 
 // ----------------------------------------------------------------------------------------------
 // k_tracking_update: TrackingIntegrator::updateBlockTracking + updateTrackingDuration
-// (tracking_integrator.cpp:133-166, 224-246) over ALL live blocks.  Pure stream.  Also emits
-//  - the ever-free work list (blocks whose tracking_updated flag was set, :76-77) and clears the flag (:146)
-//  - a per-block bit mask  free-or-ever-free = ever_free || voxelIsFree  (:248-252) that the ever-free
-//    stencil (and the multi-GPU halo exchange) consumes instead of re-reading 17 B per neighbour voxel.
+// (tracking_integrator.cpp:133-166, 224-246) over ALL live blocks.  Also clears the tracking_updated flag
+// (:146) and emits a per-block bit mask  free-or-ever-free = ever_free || voxelIsFree  (:248-252) that the
+// ever-free stencil (and the multi-GPU halo exchange) consumes instead of re-reading 17 B per neighbour voxel.
+//
+// The reference touches every voxel of every block on every frame; two exact shortcuts remove most of that:
+//  * lazy last_occupied: an occupied voxel's stamp is by definition the stamp of the latest pass, so it is not
+//    stored per frame.  The voxel carries VOX_OCC instead; when it stops being occupied the previous pass's
+//    stamp is written once.  Downloads materialise the value (khr_download_block).
+//  * block skip: for a block the integrator has not touched since its last full pass, distance and
+//    last_observed are unchanged, so nothing can change until lim_active passes the earliest last_observed of
+//    an active voxel (active -> inactive, to_remove) or lim_free passes the earliest last_occupied of a voxel
+//    that is not yet free (free bit 0 -> 1); both minima are kept per block.  Stamps going backwards, freshly
+//    allocated blocks and khr_mark_all_inactive force a full pass (force_full / BLK_TRACK_DIRTY).
 // ----------------------------------------------------------------------------------------------
 template <int VPS>
-__global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, uint64_t stamp, uint64_t lim_active,
-                                                        uint64_t lim_free) {
+__global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, uint64_t stamp, uint64_t prev_stamp,
+                                                        uint64_t lim_active, uint64_t lim_free, int force_full) {
   // lim_active / lim_free: smallest stamps x with toSeconds(x) >= toSeconds(now) - temporal_window resp.
   // - temporal_buffer, found on the host with the reference's double arithmetic.  x -> fl(double(x)/1e9) is
   // monotone, so "toSeconds(x) >= T" is exactly "x >= lim" and the kernel needs no fp64 divisions.
   constexpr int NV = VPS * VPS * VPS;
+  __shared__ uint64_t s_min[2][4];
   const uint32_t n_slots = m.counters[C_MAX_SLOT];
   for (uint32_t s = blockIdx.x; s < n_slots; s += gridDim.x) {
     const uint32_t fl = m.blk_flags[s];
     if (!(fl & BLK_LIVE)) continue;  // uniform per workgroup
+    if (!force_full && !(fl & (BLK_TRACKING_UPDATED | BLK_TRACK_DIRTY))) {
+      const ulonglong2 lim = reinterpret_cast<const ulonglong2*>(m.trk_lim)[s];
+      if (lim_active <= lim.x && lim_free <= lim.y) continue;  // nothing in this block can change
+    }
     const size_t slot = s;
     // thread <-> 4 consecutive voxels: 16-byte loads of distance / flags, 2 x 16-byte of the stamps
     const float4* __restrict__ dist4 = reinterpret_cast<const float4*>(m.dist + slot * NV);
     const ulonglong2* __restrict__ lobs2 = reinterpret_cast<const ulonglong2*>(m.last_obs + slot * NV);
-    ulonglong2* __restrict__ locc2 = reinterpret_cast<ulonglong2*>(m.last_occ + slot * NV);
+    uint64_t* __restrict__ locc = m.last_occ + slot * NV;
     uint32_t* __restrict__ vfl4 = reinterpret_cast<uint32_t*>(m.vflags + slot * NV);
     uint64_t* __restrict__ fb = m.freebits + slot * (NV / 64);
     bool any_active = false;
+    uint64_t a_min = ~0ull, f_min = ~0ull;
     for (int g = threadIdx.x; g < NV / 4; g += 256) {
       const float4 d = dist4[g];
       const ulonglong2 oa = lobs2[2 * g], ob = lobs2[2 * g + 1];
       const uint32_t v4 = vfl4[g];
       const float dd[4] = {d.x, d.y, d.z, d.w};
       const uint64_t lo[4] = {oa.x, oa.y, ob.x, ob.y};
-      bool occ[4];
-      bool all_occ = true, none_occ = true;
+      bool occ[4], was_occ[4], need[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
+        const uint8_t v = static_cast<uint8_t>(v4 >> (8 * k));
         occ[k] = dd[k] < p.occ_thr;
-        all_occ = all_occ && occ[k];
-        none_occ = none_occ && !occ[k];
+        was_occ[k] = v & VOX_OCC;
+        // the stored stamp matters only for a voxel that is not occupied, was not occupied at the previous pass
+        // and is not ever-free yet (an ever-free voxel's free bit is 1 whatever its stamps say)
+        need[k] = !occ[k] && !was_occ[k] && !(v & VOX_EVER_FREE);
       }
-      // last_occupied: read only where some voxel of the pair is NOT occupied, write only where one is
-      ulonglong2 ca = make_ulonglong2(stamp, stamp), cb = ca;
-      if (!(occ[0] && occ[1])) ca = locc2[2 * g];
-      if (!(occ[2] && occ[3])) cb = locc2[2 * g + 1];
-      uint64_t oc[4] = {ca.x, ca.y, cb.x, cb.y};
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (occ[k]) oc[k] = stamp;
-      if (occ[0] || occ[1]) locc2[2 * g] = make_ulonglong2(oc[0], oc[1]);
-      if (occ[2] || occ[3]) locc2[2 * g + 1] = make_ulonglong2(oc[2], oc[3]);
+      ulonglong2 ca = make_ulonglong2(0ull, 0ull), cb = ca;
+      if (need[0] || need[1]) ca = reinterpret_cast<const ulonglong2*>(locc)[2 * g];
+      if (need[2] || need[3]) cb = reinterpret_cast<const ulonglong2*>(locc)[2 * g + 1];
+      const uint64_t stored[4] = {ca.x, ca.y, cb.x, cb.y};
       uint32_t nv4 = 0, freebits4 = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const uint8_t v = static_cast<uint8_t>(v4 >> (8 * k));
+        // last_occupied after this pass (tracking_integrator.cpp:140-143)
+        uint64_t oc = stored[k];
+        if (occ[k]) {
+          oc = stamp;
+        } else if (was_occ[k]) {
+          oc = prev_stamp;  // occupied until the previous pass: materialise its stamp once
+          locc[4 * g + k] = prev_stamp;
+        }
         const bool was_active = v & VOX_ACTIVE;
         const bool active = lo[k] >= lim_active;
-        uint8_t nv = static_cast<uint8_t>((v & ~VOX_ACTIVE) | (active ? VOX_ACTIVE : 0));
+        uint8_t nv = static_cast<uint8_t>((v & ~(VOX_ACTIVE | VOX_OCC)) | (active ? VOX_ACTIVE : 0) | (occ[k] ? VOX_OCC : 0));
         if (was_active && !active) nv |= VOX_TO_REMOVE;
         any_active |= active;
-        const bool is_free = (oc[k] < lim_free) && (lo[k] != 0ull);
-        if ((nv & VOX_EVER_FREE) || is_free) freebits4 |= 1u << k;
+        if (active) a_min = lo[k] < a_min ? lo[k] : a_min;
+        const bool ever = nv & VOX_EVER_FREE;
+        const bool is_free = !ever && (oc < lim_free) && (lo[k] != 0ull);  // only evaluated where it decides the bit
+        if (ever || is_free) freebits4 |= 1u << k;
+        if (!occ[k] && !ever && !is_free && lo[k] != 0ull) f_min = oc < f_min ? oc : f_min;
         nv4 |= static_cast<uint32_t>(nv) << (8 * k);
       }
       if (nv4 != v4) vfl4[g] = nv4;
@@ -867,11 +889,33 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
       }
       if ((threadIdx.x & 15) == 0) fb[g >> 4] = w;
     }
+    // block-wide minima of the two thresholds at which this block has to be looked at again
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t a2 = (static_cast<uint64_t>(__shfl_xor(static_cast<uint32_t>(a_min >> 32), o)) << 32) |
+                          __shfl_xor(static_cast<uint32_t>(a_min), o);
+      const uint64_t f2 = (static_cast<uint64_t>(__shfl_xor(static_cast<uint32_t>(f_min >> 32), o)) << 32) |
+                          __shfl_xor(static_cast<uint32_t>(f_min), o);
+      a_min = a2 < a_min ? a2 : a_min;
+      f_min = f2 < f_min ? f2 : f_min;
+    }
+    if ((threadIdx.x & 63) == 0) {
+      s_min[0][threadIdx.x >> 6] = a_min;
+      s_min[1][threadIdx.x >> 6] = f_min;
+    }
     const int act = __syncthreads_or(any_active ? 1 : 0);
     if (threadIdx.x == 0) {
-      uint32_t nf = (fl & ~(BLK_TRACKING_UPDATED | BLK_HAS_ACTIVE)) | (act ? BLK_HAS_ACTIVE : 0u);
+      uint64_t a = s_min[0][0], f = s_min[1][0];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        a = s_min[0][w] < a ? s_min[0][w] : a;
+        f = s_min[1][w] < f ? s_min[1][w] : f;
+      }
+      reinterpret_cast<ulonglong2*>(m.trk_lim)[s] = make_ulonglong2(a, f);
+      const uint32_t nf = (fl & ~(BLK_TRACKING_UPDATED | BLK_HAS_ACTIVE | BLK_TRACK_DIRTY)) | (act ? BLK_HAS_ACTIVE : 0u);
       m.blk_flags[s] = nf;
     }
+    __syncthreads();  // s_min is reused by the next block of this workgroup
   }
 }
 

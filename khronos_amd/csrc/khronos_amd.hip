@@ -106,6 +106,7 @@ struct khr_ctx {
   uint32_t* h_pinned = nullptr;  // [0] seed pixels of the last motion pass, [1] removed count
   hipEvent_t ev_seed = nullptr;
   uint32_t last_removed = 0;
+  uint64_t last_track_stamp = 0;  // stamp of the latest tracking pass = last_occupied of every VOX_OCC voxel
   bool removed_pending = false;
   int4* d_removed = nullptr;
   int* d_idx_staging = nullptr;
@@ -465,6 +466,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &m.lik, cfg->with_semantics ? cap * nv * p.K : 1, false));
   A(devAlloc(c, &m.last_obs, cfg->with_tracking ? cap * nv : 1, false));
   A(devAlloc(c, &m.last_occ, cfg->with_tracking ? cap * nv : 1, false));
+  A(devAlloc(c, &m.trk_lim, cfg->with_tracking ? cap * 2 : 2));
   A(devAlloc(c, &m.freebits, cfg->with_tracking ? cap * (nv / 64) : 1, false));
   A(devAlloc(c, &m.free_slots, cap, false));
   A(devAlloc(c, &m.counters, C_COUNT));
@@ -819,8 +821,11 @@ static int trackingPhase(khr_ctx* c, uint64_t stamp, int phase) {
       hipLaunchKernelGGL(k_list_live, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_ef, &m.counters[C_N_EF],
                          BLK_TRACKING_UPDATED);
       ScopedTimer tm(c, 1);
-      hipLaunchKernelGGL((k_tracking_update<V>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, stamp, lim_active,
-                         lim_free);
+      // stamps going backwards void the per-block skip thresholds (they assume monotone limits)
+      const int force_full = stamp < c->last_track_stamp || c->cfg.disable_culling ? 1 : 0;
+      hipLaunchKernelGGL((k_tracking_update<V>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, stamp, c->last_track_stamp,
+                         lim_active, lim_free, force_full);
+      c->last_track_stamp = stamp;
     }
     if (phase & 2) {
       ScopedTimer tm(c, 2);
@@ -1660,7 +1665,7 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
 
 int khr_mark_all_inactive(khr_ctx* c) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
-  hipLaunchKernelGGL(k_block_flag_op, dim3(gridFor(c->m.capacity)), dim3(256), 0, c->stream, c->m, ~BLK_HAS_ACTIVE, 0u);
+  hipLaunchKernelGGL(k_block_flag_op, dim3(gridFor(c->m.capacity)), dim3(256), 0, c->stream, c->m, ~BLK_HAS_ACTIVE, BLK_TRACK_DIRTY);
   HIP_TRY(hipGetLastError());
   c->host_index_valid = false;
   return KHR_OK;
@@ -1786,7 +1791,11 @@ int khr_download_block(khr_ctx* c, int32_t bx, int32_t by, int32_t bz, float* di
   if (distance) HIP_TRY(D(distance, m.dist + slot * nv, nv * 4));
   if (weight) HIP_TRY(D(weight, m.weight + slot * nv, nv * 4));
   if (color_rgba) HIP_TRY(D(color_rgba, m.color + slot * nv, nv * 4));
-  if (voxel_flags) HIP_TRY(D(voxel_flags, m.vflags + slot * nv, nv));
+  std::vector<uint8_t> raw_flags;
+  if (voxel_flags || (last_occupied && c->cfg.with_tracking)) {
+    raw_flags.resize(nv);
+    HIP_TRY(D(raw_flags.data(), m.vflags + slot * nv, nv));
+  }
   if (last_observed) {
     if (c->cfg.with_tracking) HIP_TRY(D(last_observed, m.last_obs + slot * nv, nv * 8));
     else std::memset(last_observed, 0, nv * 8);
@@ -1808,6 +1817,12 @@ int khr_download_block(khr_ctx* c, int32_t bx, int32_t by, int32_t bz, float* di
   if (block_flags) HIP_TRY(D(&bf, m.blk_flags + slot, 4));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (block_flags) *block_flags = static_cast<uint8_t>(bf & 0xfu);
+  // lazily stored last_occupied (k_tracking_update): an occupied voxel's stamp is the latest pass's stamp
+  if (last_occupied && c->cfg.with_tracking)
+    for (size_t i = 0; i < nv; ++i)
+      if (raw_flags[i] & VOX_OCC) last_occupied[i] = c->last_track_stamp;
+  if (voxel_flags)
+    for (size_t i = 0; i < nv; ++i) voxel_flags[i] = raw_flags[i] & VOX_PUBLIC_MASK;
   if (likelihoods && c->cfg.with_semantics)
     for (size_t i = 0; i < nv; ++i)
       for (int k = 0; k < c->p.K; ++k) likelihoods[static_cast<size_t>(k) * nv + i] = lik_vm[i * c->p.K + k];

@@ -165,8 +165,68 @@ def test_culling_is_exact():
     assert np.array_equal(idx, ctx2.block_indices())
     for b in idx:
         g, h = ctx.download_block(b), ctx2.download_block(b)
-        for k in ("distance", "weight", "color", "last_observed", "flags", "sem_label", "likelihoods"):
+        for k in ("distance", "weight", "color", "last_observed", "last_occupied", "flags", "sem_label", "likelihoods"):
             assert np.array_equal(g[k], h[k]), (k, b)
+
+
+def test_tracking_shortcuts_are_exact():
+    """the tracking pass stores an occupied voxel's last_occupied lazily and skips blocks in which provably nothing can
+    change (k_tracking_update); every path around those shortcuts against the oracle, which touches every voxel:
+    blocks leaving the view and ageing out, passes without integration, khr_mark_all_inactive, stamps going backwards,
+    and the A/B context (disable_culling = every block every pass)."""
+    cfg, ctx, ora, s, sen, osen = make_pair(width=160, height=120, temporal_window=0.6, temporal_buffer=0.3)
+    _, ctx2, _, _, _, _ = make_pair(width=160, height=120, temporal_window=0.6, temporal_buffer=0.3, disable_culling=1)
+
+    def both_equal():
+        compare_maps(ctx, ora, max_blocks=60, rng=np.random.default_rng(3), check_lik=False)
+        idx = ctx.block_indices()
+        assert np.array_equal(idx, ctx2.block_indices())
+        for b in idx[:: max(1, len(idx) // 40)]:
+            g, h = ctx.download_block(b, likelihoods=False), ctx2.download_block(b, likelihoods=False)
+            for k in ("last_observed", "last_occupied", "flags", "block_flags"):
+                assert np.array_equal(g[k], h[k]), (k, b)
+
+    def track(stamp):
+        ctx.update_tracking(stamp)
+        ctx2.update_tracking(stamp)
+        ora.update_tracking(stamp)
+
+    stamp = 0
+    for i in range(14):  # the camera turns quickly: blocks leave the view, deactivate and become free while untouched
+        fr = s.render(i, yaw_offset=0.35 * i)
+        stamp = fr["stamp"]
+        for c in (ctx, ctx2):
+            slot = c.upload_frame(sen, stamp, fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+            c.integrate(slot)
+        ora.integrate(osen, stamp, fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+        track(stamp)
+        if i % 3 == 2:
+            both_equal()
+    for k in range(12):  # tracking passes without any integration: everything ages
+        stamp += 100_000_000
+        track(stamp)
+        if k % 4 == 3:
+            both_equal()
+    # finishMapping-style inactivation in the middle of a run, then more passes
+    ctx.mark_all_inactive(); ctx2.mark_all_inactive(); ora.mark_all_inactive()
+    both_equal()
+    fr = s.render(30, yaw_offset=0.2)
+    stamp += 100_000_000
+    for c in (ctx, ctx2):
+        slot = c.upload_frame(sen, stamp, fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+        c.integrate(slot)
+    ora.integrate(osen, stamp, fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+    track(stamp)
+    both_equal()
+    # time going backwards (a re-played stamp) and forwards again
+    track(stamp - 450_000_000)
+    both_equal()
+    track(stamp + 50_000_000)
+    both_equal()
+    # archival still sees the same blocks
+    removed = np.asarray(ctx.reset_inactive())
+    assert np.array_equal(removed, np.asarray(ora.reset_inactive())) and np.array_equal(removed, np.asarray(ctx2.reset_inactive()))
+    both_equal()
 
 
 def test_fused_process_frame_equals_stepwise():

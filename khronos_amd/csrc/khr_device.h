@@ -198,4 +198,38 @@ __device__ inline uint8_t toU8(float f) {
   return static_cast<uint8_t>(r);
 }
 
+// ---- lock-free union-find on compact node ids (object detector, motion-cluster components) ----------------------
+// ECL-CC style (Jaiganesh & Burtscher): parents only ever decrease, a find halves the path it walks (each step
+// re-points a node at its grandparent, which is still an ancestor whatever other threads do), and a union hooks
+// the larger root under the smaller one with a CAS that only succeeds while the node is still a root.
+__device__ inline uint32_t ufLoad(const uint32_t* parent, uint32_t x) { return __atomic_load_n(parent + x, __ATOMIC_RELAXED); }
+__device__ inline uint32_t ufFind(uint32_t* parent, uint32_t x) {
+  uint32_t p = ufLoad(parent, x);
+  while (p != x) {
+    const uint32_t gp = ufLoad(parent, p);
+    if (gp != p) atomicMin(parent + x, gp);  // monotone: never undoes a smaller value another thread wrote
+    x = p;
+    p = gp;
+  }
+  return x;
+}
+// read-only variant for passes that run after all unions are done
+__device__ inline uint32_t ufFind(const uint32_t* parent, uint32_t x) {
+  while (true) {
+    const uint32_t p = ufLoad(parent, x);
+    if (p == x) return x;
+    x = p;
+  }
+}
+__device__ inline void ufUnion(uint32_t* parent, uint32_t a, uint32_t b) {
+  a = ufFind(parent, a);
+  b = ufFind(parent, b);
+  while (a != b) {
+    if (a < b) { const uint32_t t = a; a = b; b = t; }  // a = larger root, hooks under b
+    const uint32_t old = atomicCAS(parent + a, a, b);
+    if (old == a) return;
+    a = ufFind(parent, old);  // somebody else hooked a in the meantime: continue from its new root
+  }
+}
+
 }  // namespace khr

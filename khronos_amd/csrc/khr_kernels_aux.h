@@ -128,12 +128,24 @@ __device__ inline uint64_t neighbourKey(uint64_t key, int k) {
   return packKey(x + c_md_nbr26[k][0], y + c_md_nbr26[k][1], z + c_md_nbr26[k][2]);
 }
 
+// lanes of a wave that hold the same voxel key (neighbouring pixels usually do) insert / count once: the table
+// slot of a large voxel would otherwise take one CAS and one atomicAdd per pixel on a single address
+__device__ inline void voxInsertCounted(const VoxTable& t, bool has, uint64_t key) {
+  unsigned long long todo = __ballot(has);
+  while (todo) {
+    const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+    const uint32_t klo = __shfl(static_cast<uint32_t>(key), leader), khi = __shfl(static_cast<uint32_t>(key >> 32), leader);
+    const uint64_t lk = (static_cast<uint64_t>(khi) << 32) | klo;
+    const unsigned long long grp = __ballot(has && key == lk);
+    todo &= ~grp;
+    if (static_cast<int>(laneId()) == leader) atomicAdd(&t.counts[voxInsert(t, lk)], static_cast<uint32_t>(__popcll(grp)));
+  }
+}
+
 __global__ __launch_bounds__(256) void k_md_seed_insert(const uint64_t* __restrict__ keys, int n, VoxTable seeds) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t k = keys[i];
-  if (k == ~0ull || !(k & kSeedBit)) return;
-  atomicAdd(&seeds.counts[voxInsert(seeds, k & ~kSeedBit)], 1u);
+  const uint64_t k = i < n ? keys[i] : ~0ull;
+  voxInsertCounted(seeds, k != ~0ull && (k & kSeedBit), k & ~kSeedBit);
 }
 
 // every neighbour of every seed voxel -> the "near a seed" set (S * nn insertions, S is small) ...
@@ -150,10 +162,9 @@ __global__ __launch_bounds__(256) void k_md_near_insert(const uint64_t* __restri
 __global__ __launch_bounds__(256) void k_md_boundary_insert(const uint64_t* __restrict__ keys, int n, VoxTable near,
                                                            VoxTable bnd) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t k = keys[i];
-  if (k == ~0ull || (k & kSeedBit)) return;
-  if (voxFind(near, k) >= 0) atomicAdd(&bnd.counts[voxInsert(bnd, k)], 1u);
+  const uint64_t k = i < n ? keys[i] : ~0ull;
+  const bool cand = k != ~0ull && !(k & kSeedBit) && voxFind(near, k) >= 0;
+  voxInsertCounted(bnd, cand, k);
 }
 
 // occupied table slots -> compact lists (ids are arbitrary but stable for the rest of the frame)
@@ -190,6 +201,219 @@ __global__ __launch_bounds__(256) void k_md_adjacency(const uint64_t* __restrict
   }
 }
 
+// ---- connected components of the seed graph on the device (clusterDynamicVoxels, :205-272) -------------------------
+// The seed-graph walk only decides which seeds belong together; everything the later stages need per component
+// is an order-free reduction: the first seed in the canonical (x, y, z) order (= the position of the cluster in the
+// reference's visiting order, ASSUMPTIONS.md C.1), the length of the cluster's pixel list (seed pixels + the pixels
+// of every adjacent boundary voxel once per adjacent seed, :255-265) and the voxel bounding box (merge pre-test).
+struct CompAcc {
+  unsigned long long n_pixels;
+  unsigned long long min_key;  // canonical-order key of the first seed
+  int32_t lo[3], hi[3];
+  uint32_t root, pad;
+};
+__device__ inline unsigned long long canonKey(uint64_t packed) {
+  int x, y, z;
+  unpackKey(packed, &x, &y, &z);
+  return (static_cast<unsigned long long>(x + (1 << 20)) << 42) | (static_cast<unsigned long long>(y + (1 << 20)) << 21) |
+         static_cast<unsigned long long>(z + (1 << 20));
+}
+
+// Components for the usual case (a few thousand seeds): ONE workgroup, labels in LDS, min-label propagation over
+// the adjacency with pointer jumping until nothing changes.  No global atomics at all -- with one big moving
+// object every union of the lock-free version below fights over the same few roots (hot-address CAS, ~80 us),
+// while this converges in a handful of LDS rounds.  Writes parent[s] = smallest compact id of s's component.
+constexpr uint32_t kCompLds = 12288;
+__global__ __launch_bounds__(1024) void k_md_comp_lds(const uint32_t* __restrict__ adj, const uint32_t* __restrict__ n_seeds, uint32_t cap,
+                                                     int nn, uint32_t* __restrict__ parent, CompAcc* __restrict__ acc, uint32_t lds_max) {
+  __shared__ uint32_t lab[kCompLds];
+  const uint32_t ns = min(*n_seeds, cap);
+  if (ns > lds_max) return;  // k_md_comp_init / jump / union take over
+  for (uint32_t s = threadIdx.x; s < ns; s += 1024) {
+    lab[s] = s;
+    CompAcc a;
+    a.n_pixels = 0ull;
+    a.min_key = ~0ull;
+    for (int d = 0; d < 3; ++d) { a.lo[d] = INT32_MAX; a.hi[d] = INT32_MIN; }
+    a.root = s;
+    a.pad = 0;
+    acc[s] = a;
+  }
+  __syncthreads();
+  const uint32_t ne = ns * static_cast<uint32_t>(nn);
+  while (true) {
+    bool changed = false;
+    // hooking (Shiloach-Vishkin style): an edge whose ends carry different labels lowers the label of s AND of s's
+    // current representative, so whole trees move per round instead of one node per round
+    for (uint32_t e = threadIdx.x; e < ne; e += 1024) {
+      const uint32_t a = adj[e];
+      if (a == 0xffffffffu || !(a & 0x80000000u)) continue;
+      const uint32_t s = e / nn, lt = lab[a & 0x7fffffffu], ls = lab[s];
+      if (lt < ls) {
+        atomicMin(&lab[ls], lt);
+        atomicMin(&lab[s], lt);
+        changed = true;
+      }
+    }
+    __syncthreads();
+    // pointer jumping to the current root (labels only decrease and lab[x] <= x, so the walk terminates)
+    for (uint32_t s = threadIdx.x; s < ns; s += 1024) {
+      uint32_t l = lab[s], ll = lab[l];
+      if (ll < l) {
+        do {
+          l = ll;
+          ll = lab[l];
+        } while (ll < l);
+        lab[s] = l;  // only this thread writes lab[s] in this phase (concurrent readers see an ancestor either way)
+        changed = true;
+      }
+    }
+    if (!__syncthreads_or(changed ? 1 : 0)) break;
+  }
+  for (uint32_t s = threadIdx.x; s < ns; s += 1024) parent[s] = lab[s];
+}
+
+__global__ __launch_bounds__(256) void k_md_comp_init(const uint32_t* __restrict__ adj, const uint32_t* __restrict__ n_seeds, uint32_t cap,
+                                                     int nn, uint32_t* __restrict__ parent, CompAcc* __restrict__ acc, uint32_t lds_max) {
+  const uint32_t ns = min(*n_seeds, cap);
+  if (ns <= lds_max) return;  // done by k_md_comp_lds
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < ns; s += gridDim.x * blockDim.x) {
+    // start from a forest instead of singletons: hook every seed under its smallest smaller seed neighbour
+    // (parents strictly decrease, so there are no cycles); most unions then find equal roots and do no atomics
+    uint32_t p = s;
+    for (int j = 0; j < nn; ++j) {
+      const uint32_t a = adj[static_cast<size_t>(s) * nn + j];
+      if (a != 0xffffffffu && (a & 0x80000000u)) p = min(p, a & 0x7fffffffu);
+    }
+    parent[s] = p;
+    CompAcc a;
+    a.n_pixels = 0ull;
+    a.min_key = ~0ull;
+    for (int d = 0; d < 3; ++d) { a.lo[d] = INT32_MAX; a.hi[d] = INT32_MIN; }
+    a.root = s;
+    a.pad = 0;
+    acc[s] = a;
+  }
+}
+
+// flatten the initial forest (no unions are in flight): afterwards a find is one hop, so the union pass spends its
+// dependent-load latency only on edges that really join two trees
+__global__ __launch_bounds__(256) void k_md_comp_jump(const uint32_t* __restrict__ n_seeds, uint32_t cap, uint32_t* __restrict__ parent,
+                                                     uint32_t lds_max) {
+  const uint32_t ns = min(*n_seeds, cap);
+  if (ns <= lds_max) return;
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < ns; s += gridDim.x * blockDim.x) {
+    uint32_t p = ufLoad(parent, s);
+    while (true) {
+      const uint32_t gp = ufLoad(parent, p);
+      if (gp == p) break;
+      p = gp;
+    }
+    __atomic_store_n(parent + s, p, __ATOMIC_RELAXED);  // any ancestor is a valid parent
+  }
+}
+
+__global__ __launch_bounds__(256) void k_md_comp_union(const uint32_t* __restrict__ adj, const uint32_t* __restrict__ n_seeds,
+                                                      uint32_t cap, int nn, uint32_t* __restrict__ parent, uint32_t lds_max) {
+  const uint32_t ns = min(*n_seeds, cap);
+  if (ns <= lds_max) return;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns * nn; i += gridDim.x * blockDim.x) {
+    const uint32_t a = adj[i], s = i / nn;
+    // the relation is symmetric: every edge is handled from its larger end
+    if (a != 0xffffffffu && (a & 0x80000000u) && (a & 0x7fffffffu) < s) ufUnion(parent, s, a & 0x7fffffffu);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_md_comp_reduce(const uint64_t* __restrict__ seed_keys, const uint32_t* __restrict__ seed_counts,
+                                                       const uint64_t* __restrict__ bnd_keys, const uint32_t* __restrict__ bnd_counts,
+                                                       const uint32_t* __restrict__ adj, const uint32_t* __restrict__ n_seeds,
+                                                       uint32_t cap, int nn, uint32_t* __restrict__ parent, CompAcc* __restrict__ acc) {
+  const uint32_t ns = min(*n_seeds, cap);
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool on = s < ns;
+  uint32_t r = 0xffffffffu;
+  unsigned long long px = 0ull, key = ~0ull;
+  int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+  if (on) {
+    r = ufFind(parent, s);
+    if (r != s) __atomic_store_n(parent + s, r, __ATOMIC_RELAXED);
+    const uint64_t k = seed_keys[s];
+    key = canonKey(k);
+    px = seed_counts[s];
+    int v[3];
+    unpackKey(k, &v[0], &v[1], &v[2]);
+    for (int d = 0; d < 3; ++d) lo[d] = hi[d] = v[d];
+    for (int j = 0; j < nn; ++j) {
+      const uint32_t a = adj[static_cast<size_t>(s) * nn + j];
+      if (a == 0xffffffffu || (a & 0x80000000u)) continue;
+      px += bnd_counts[a];
+      unpackKey(bnd_keys[a], &v[0], &v[1], &v[2]);
+      for (int d = 0; d < 3; ++d) { lo[d] = min(lo[d], v[d]); hi[d] = max(hi[d], v[d]); }
+    }
+  }
+  // seeds of one wave mostly share a component: reduce per root first, one lane issues the atomics
+  unsigned long long todo = __ballot(on);
+  while (todo) {
+    const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+    const uint32_t lr = __shfl(r, leader);
+    const bool mine = on && r == lr;
+    const unsigned long long grp = __ballot(mine);
+    todo &= ~grp;
+    unsigned long long p2 = mine ? px : 0ull, k2 = mine ? key : ~0ull;
+    int l2[3], h2[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { l2[d] = mine ? lo[d] : INT32_MAX; h2[d] = mine ? hi[d] : INT32_MIN; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long po = (static_cast<unsigned long long>(__shfl_xor(static_cast<uint32_t>(p2 >> 32), o)) << 32) |
+                                    __shfl_xor(static_cast<uint32_t>(p2), o);
+      const unsigned long long ko = (static_cast<unsigned long long>(__shfl_xor(static_cast<uint32_t>(k2 >> 32), o)) << 32) |
+                                    __shfl_xor(static_cast<uint32_t>(k2), o);
+      p2 += po;
+      k2 = ko < k2 ? ko : k2;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { l2[d] = min(l2[d], __shfl_xor(l2[d], o)); h2[d] = max(h2[d], __shfl_xor(h2[d], o)); }
+    }
+    if (static_cast<int>(laneId()) == leader) {
+      CompAcc* a = acc + lr;
+      atomicAdd(&a->n_pixels, p2);
+      atomicMin(&a->min_key, k2);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { atomicMin(&a->lo[d], l2[d]); atomicMax(&a->hi[d], h2[d]); }
+    }
+  }
+}
+
+// roots -> compact component records (head[2] = count; the first records ride in the same small download)
+__global__ __launch_bounds__(256) void k_md_comp_roots(const uint32_t* __restrict__ n_seeds, uint32_t cap, const uint32_t* __restrict__ parent,
+                                                      const CompAcc* __restrict__ acc, uint32_t* __restrict__ root_idx,
+                                                      uint32_t* __restrict__ n_roots, CompAcc* __restrict__ out, uint32_t out_cap) {
+  const uint32_t ns = min(*n_seeds, cap);
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool is_root = s < ns && parent[s] == s;
+  const uint32_t idx = waveAggInc(n_roots, is_root);
+  if (is_root) {
+    root_idx[s] = idx;
+    if (idx < out_cap) out[idx] = acc[s];
+  }
+}
+
+// final ids: a seed takes its component's id; a boundary voxel the id of the LAST cluster that lists it (:388-389;
+// ids grow with the painting order, so that is the maximum over the adjacent seeds' components)
+__global__ __launch_bounds__(256) void k_md_comp_finals(const uint32_t* __restrict__ adj, const uint32_t* __restrict__ n_seeds, uint32_t cap,
+                                                       int nn, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ root_idx,
+                                                       const int32_t* __restrict__ comp_final, int32_t* __restrict__ seed_final,
+                                                       int32_t* __restrict__ bnd_final) {
+  const uint32_t ns = min(*n_seeds, cap);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns * nn; i += gridDim.x * blockDim.x) {
+    const uint32_t s = i / nn, j = i % nn;
+    const int32_t f = comp_final[root_idx[parent[s]]];
+    if (j == 0) seed_final[s] = f;
+    const uint32_t a = adj[i];
+    if (f && a != 0xffffffffu && !(a & 0x80000000u)) atomicMax(&bnd_final[a], f);
+  }
+}
+
 // per-cluster summary accumulated while painting (MeasurementCluster role, measurement_clusters.h:63-80):
 // painted pixel count, world-frame bounding box of the painted pixels' vertices, vertex sum (centroid)
 struct ClusterAcc {
@@ -215,30 +439,52 @@ __host__ __device__ inline float orderedToFloat(int32_t i) {
 // writeClustersToData (free_space_motion_detector.cpp:381-399): cluster id of the pixel's voxel (0 = none)
 __global__ __launch_bounds__(256) void k_md_paint(const uint64_t* __restrict__ keys, int n, VoxTable seeds, VoxTable bnd,
                                                  const int32_t* __restrict__ seed_final,
-                                                 const int32_t* __restrict__ bnd_final, int32_t* __restrict__ dyn,
-                                                 DevFrame f, ClusterAcc* __restrict__ acc) {
+                                                 const int32_t* __restrict__ bnd_final, int32_t* __restrict__ dyn) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t k = i < n ? keys[i] : ~0ull;
+  if (i >= n) return;
+  const uint64_t k = keys[i];
+  if (k == ~0ull) return;
   int id = 0;
-  if (k != ~0ull) {
-    if (k & kSeedBit) {
-      const int h = voxFind(seeds, k & ~kSeedBit);
-      if (h >= 0) id = seed_final[seeds.ids[h]];
-    } else {
-      const int h = voxFind(bnd, k);
-      if (h >= 0) id = bnd_final[bnd.ids[h]];
+  if (k & kSeedBit) {
+    const int h = voxFind(seeds, k & ~kSeedBit);
+    if (h >= 0) id = seed_final[seeds.ids[h]];
+  } else {
+    const int h = voxFind(bnd, k);
+    if (h >= 0) id = bnd_final[bnd.ids[h]];
+  }
+  if (id) dyn[i] = id;
+}
+
+// Per-cluster summary of an id image (ids 1..255), on demand: painted pixel count, AABB and sum of the pixels'
+// world-frame vertices (the tracker's bounding boxes, max_iou_tracker.cpp:466-476).  One workgroup per 32x32
+// pixel tile: lanes of a wave that share an id reduce with shuffles, wave leaders accumulate in an 8-entry LDS
+// table, and only the tile's distinct ids touch global memory -- a cluster's pixels would otherwise serialise
+// thousands of atomics on one address.
+constexpr int kAccTile = 32, kAccSlots = 8;
+__global__ __launch_bounds__(1024) void k_cluster_summary(DevFrame f, const int32_t* __restrict__ img,
+                                                         ClusterAcc* __restrict__ acc) {
+  __shared__ int s_id[kAccSlots];
+  __shared__ ClusterAcc s_acc[kAccSlots];
+  if (threadIdx.x < kAccSlots) {
+    s_id[threadIdx.x] = 0;
+    ClusterAcc a;
+    a.n_pixels = 0;
+    for (int d = 0; d < 3; ++d) { a.bmin[d] = INT32_MAX; a.bmax[d] = INT32_MIN; a.sum[d] = 0.f; }
+    s_acc[threadIdx.x] = a;
+  }
+  __syncthreads();
+  const int tiles_x = (f.W + kAccTile - 1) / kAccTile;
+  const int u = (blockIdx.x % tiles_x) * kAccTile + (threadIdx.x & 31), v = (blockIdx.x / tiles_x) * kAccTile + (threadIdx.x >> 5);
+  int id = 0;
+  float pw[3] = {0.f, 0.f, 0.f};
+  if (u < f.W && v < f.H) {
+    const int i = v * f.W + u;
+    id = img[i];
+    if (id) {
+      const float d = f.depth[i];  // world-frame vertex of this pixel (:396-397)
+      xform(f.Rw, f.tw, ((static_cast<float>(u) - f.cx) / f.fx) * d, ((static_cast<float>(v) - f.cy) / f.fy) * d, d, pw);
     }
   }
-  float pw[3] = {0.f, 0.f, 0.f};
-  if (id) {
-    dyn[i] = id;
-    // world-frame vertex of this pixel (:396-397)
-    const float d = f.depth[i];
-    const int u = i % f.W, v = i / f.W;
-    xform(f.Rw, f.tw, ((static_cast<float>(u) - f.cx) / f.fx) * d, ((static_cast<float>(v) - f.cy) / f.fy) * d, d, pw);
-  }
-  // bounding box / centroid / count per cluster: reduce over the lanes of the wave that share an id first
-  // (a wave almost always sees one cluster), then ONE lane per (wave, id) issues the atomics
   unsigned long long todo = __ballot(id != 0);
   while (todo) {
     const int leader = __ffsll(static_cast<long long>(todo)) - 1;
@@ -263,7 +509,16 @@ __global__ __launch_bounds__(256) void k_md_paint(const uint64_t* __restrict__ k
       }
     }
     if (static_cast<int>(laneId()) == leader) {
+      // claim / find the LDS slot of this id; a tile with more than kAccSlots ids falls through to global memory
       ClusterAcc* a = acc + cid;
+      for (int k = 0; k < kAccSlots; ++k) {
+        const int h = (cid + k) & (kAccSlots - 1);
+        const int prev = atomicCAS(&s_id[h], 0, cid);
+        if (prev == 0 || prev == cid) {
+          a = &s_acc[h];
+          break;
+        }
+      }
       atomicAdd(&a->n_pixels, static_cast<uint32_t>(__popcll(grp)));
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -271,6 +526,18 @@ __global__ __launch_bounds__(256) void k_md_paint(const uint64_t* __restrict__ k
         atomicMax(&a->bmax[c], floatToOrdered(mx[c]));
         atomicAdd(&a->sum[c], sm[c]);
       }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kAccSlots && s_id[threadIdx.x]) {
+    const ClusterAcc& l = s_acc[threadIdx.x];
+    ClusterAcc* a = acc + s_id[threadIdx.x];
+    atomicAdd(&a->n_pixels, l.n_pixels);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      atomicMin(&a->bmin[c], l.bmin[c]);
+      atomicMax(&a->bmax[c], l.bmax[c]);
+      atomicAdd(&a->sum[c], l.sum[c]);
     }
   }
 }

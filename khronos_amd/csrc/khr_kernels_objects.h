@@ -87,27 +87,7 @@ __device__ inline bool gvVoxelKey(const float* pw, float inv, int3 o, uint32_t g
   return false;
 }
 
-// ---- union-find on node ids (table slots in 3D mode, pixel indices in 2D mode) ---------------------------------------
-__device__ inline uint32_t ufLoad(const uint32_t* parent, uint32_t x) { return __atomic_load_n(parent + x, __ATOMIC_RELAXED); }
-__device__ inline uint32_t ufFind(const uint32_t* parent, uint32_t x) {
-  while (true) {
-    const uint32_t p = ufLoad(parent, x);
-    if (p == x) return x;
-    x = p;
-  }
-}
-// link the larger root under the smaller one; retries when another thread moved the root in between
-__device__ inline void ufUnion(uint32_t* parent, uint32_t a, uint32_t b) {
-  while (true) {
-    a = ufFind(parent, a);
-    b = ufFind(parent, b);
-    if (a == b) return;
-    if (a < b) { const uint32_t t = a; a = b; b = t; }
-    const uint32_t old = atomicMin(parent + a, b);
-    if (old == a) return;
-    a = old;
-  }
-}
+// union-find on node ids (table slots in 3D mode, pixel indices in 2D mode): ufFind / ufUnion of khr_device.h
 
 // sorted object-label list -> rank (the group), -1 = not an object label (LabelSpaceConfig::isObject role)
 __device__ inline int labelRank(const int32_t* __restrict__ labels, int n, int32_t v) {

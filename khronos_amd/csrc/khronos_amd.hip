@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -69,6 +70,7 @@ struct TimingRec {
 };
 
 constexpr int kNumTimers = 8;
+constexpr uint32_t kCompCap = 1024, kCompHead = 64;  // motion-cluster components: record capacity / records in the first download
 
 }  // namespace
 
@@ -121,6 +123,13 @@ struct khr_ctx {
   uint32_t *d_md_seed_counts = nullptr, *d_md_bnd_counts = nullptr;
   int32_t *d_md_seed_final = nullptr, *d_md_bnd_final = nullptr;
   ClusterAcc* d_md_acc = nullptr;  // [256], index = cluster id
+  // device components of the seed graph: head = {S, B, R, 0} followed by the component records
+  uint32_t *d_md_parent = nullptr, *d_md_rootidx = nullptr;
+  CompAcc* d_md_comp_acc = nullptr;
+  int32_t* d_md_comp_final = nullptr;
+  uint8_t* h_md_head = nullptr;  // pinned mirror of the head + records, then the final ids going back
+  bool md_host_walk = false;     // KHR_MD_HOST_WALK=1: always cluster on the host (A/B switch, results identical)
+  uint32_t md_lds_max = kCompLds;  // KHR_MD_LDS_MAX=n: seed count up to which the single-workgroup LDS labelling is used
   std::vector<khr_cluster> last_clusters;
   int last_cluster_slot = -1;
   uint32_t md_mask = 0, md_list_cap = 0;
@@ -500,7 +509,18 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     A(devAlloc(c, &c->d_md_keys, 3 * static_cast<size_t>(ts), false));
     A(devAlloc(c, &c->d_md_counts, 3 * static_cast<size_t>(ts), false));
     A(devAlloc(c, &c->d_md_ids, 3 * static_cast<size_t>(ts), false));
-    A(devAlloc(c, &c->d_md_n, 4));
+    {
+      uint8_t* head = nullptr;
+      A(devAlloc(c, &head, 16 + sizeof(CompAcc) * kCompCap));
+      c->d_md_n = reinterpret_cast<uint32_t*>(head);
+    }
+    A(devAlloc(c, &c->d_md_parent, c->md_list_cap, false));
+    A(devAlloc(c, &c->d_md_rootidx, c->md_list_cap, false));
+    A(devAlloc(c, &c->d_md_comp_acc, c->md_list_cap, false));
+    A(devAlloc(c, &c->d_md_comp_final, kCompCap));
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_md_head), 16 + sizeof(CompAcc) * kCompCap, hipHostMallocDefault) != hipSuccess) A(KHR_ENOMEM);
+    c->md_host_walk = std::getenv("KHR_MD_HOST_WALK") != nullptr;
+    if (const char* e = std::getenv("KHR_MD_LDS_MAX")) c->md_lds_max = std::min<uint32_t>(kCompLds, static_cast<uint32_t>(std::atoi(e)));
     A(devAlloc(c, &c->d_md_seed_keys, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_bnd_keys, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_seed_counts, c->md_list_cap, false));
@@ -951,7 +971,16 @@ static int motionLaunch(khr_ctx* c, FrameSlot& s, bool fresh_slot) {
 static int motionFinish(khr_ctx* c, FrameSlot& s) {
   if (!c->cfg.with_tracking) return 0;
   const int n = s.sensor.width * s.sensor.height;
+  static const bool md_timing = std::getenv("KHR_MD_TIMING") != nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!md_timing) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[md] %s %.1f us\n", what, std::chrono::duration<double, std::micro>(t1 - t0).count());
+    t0 = t1;
+  };
   HIP_TRY(hipEventSynchronize(c->ev_seed));
+  lap("wait seed count");
   c->last_clusters.clear();
   c->last_cluster_slot = static_cast<int>(&s - c->slots.data());
   if (c->h_pinned[0] == 0) return 0;
@@ -964,7 +993,7 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
   VoxTable near{c->d_md_keys + 2 * tsize, c->d_md_counts + 2 * tsize, c->d_md_ids + 2 * tsize, c->md_mask};
   HIP_TRY(hipMemsetAsync(c->d_md_keys, 0xff, sizeof(uint64_t) * 3 * tsize, c->stream));
   HIP_TRY(hipMemsetAsync(c->d_md_counts, 0, sizeof(uint32_t) * 2 * tsize, c->stream));
-  HIP_TRY(hipMemsetAsync(c->d_md_n, 0, sizeof(uint32_t) * 2, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_md_n, 0, sizeof(uint32_t) * 4, c->stream));
   const uint32_t cap = c->md_list_cap;
   hipLaunchKernelGGL(k_md_seed_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds);
   hipLaunchKernelGGL(k_md_compact, dim3(gridFor(tsize)), dim3(256), 0, c->stream, seeds, c->d_md_seed_keys,
@@ -975,11 +1004,88 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
                      c->d_md_n + 1, cap);
   hipLaunchKernelGGL(k_md_adjacency, dim3(1024), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_n, seeds, bnd, nn, cap,
                      c->d_md_adj);
-  uint32_t cnt[2] = {0, 0};
-  HIP_TRY(hipMemcpyAsync(cnt, c->d_md_n, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+  // connected components of the seed graph + their order-free summaries, on the device
+  const uint32_t seed_px = std::min<uint32_t>(c->h_pinned[0], cap);  // #seed voxels <= #seed pixels
+  CompAcc* d_comp_out = reinterpret_cast<CompAcc*>(reinterpret_cast<uint8_t*>(c->d_md_n) + 16);
+  hipLaunchKernelGGL(k_md_comp_lds, dim3(1), dim3(1024), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->d_md_comp_acc, c->md_lds_max);
+  hipLaunchKernelGGL(k_md_comp_init, dim3(64), dim3(256), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->d_md_comp_acc,
+                     c->md_lds_max);
+  hipLaunchKernelGGL(k_md_comp_jump, dim3(64), dim3(256), 0, c->stream, c->d_md_n, cap, c->d_md_parent, c->md_lds_max);
+  hipLaunchKernelGGL(k_md_comp_union, dim3(1024), dim3(256), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->md_lds_max);
+  hipLaunchKernelGGL(k_md_comp_reduce, dim3(gridFor(seed_px)), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_seed_counts,
+                     c->d_md_bnd_keys, c->d_md_bnd_counts, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->d_md_comp_acc);
+  hipLaunchKernelGGL(k_md_comp_roots, dim3(gridFor(seed_px)), dim3(256), 0, c->stream, c->d_md_n, cap, c->d_md_parent, c->d_md_comp_acc,
+                     c->d_md_rootidx, c->d_md_n + 2, d_comp_out, kCompCap);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(c->h_md_head, c->d_md_n, 16 + sizeof(CompAcc) * kCompHead, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  const uint32_t S = cnt[0], B = cnt[1];
+  lap("tables + adjacency + components + head sync");
+  const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c->h_md_head);
+  const uint32_t S = cnt[0], B = cnt[1], R = cnt[2];
   if (S > cap || B > cap) return fail(KHR_ENOMEM, "motion detector: %u seed / %u boundary voxels exceed the list capacity %u", S, B, cap);
+  if (R <= kCompCap && !c->md_host_walk) {
+    if (R > kCompHead) {
+      HIP_TRY(hipMemcpyAsync(c->h_md_head, c->d_md_n, 16 + sizeof(CompAcc) * R, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    const CompAcc* comp = reinterpret_cast<const CompAcc*>(c->h_md_head + 16);
+    // cluster order = order in which the walk meets the first seed of each component (ASSUMPTIONS.md C.1)
+    std::vector<uint32_t> order(R);
+    for (uint32_t i = 0; i < R; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return comp[a].min_key < comp[b].min_key; });
+    // mergeClusters (:274-355) can only join clusters whose voxel boxes come closer than min_separation_distance:
+    // the box gap is a lower bound of every pairwise voxel distance.  If no pair qualifies, nothing merges and the
+    // clusters are the components; otherwise the exact voxel-pair test runs on the host path below.
+    const float sep = c->cfg.md_min_separation_distance;
+    bool may_merge = false;
+    for (uint32_t i = 0; i < R && !may_merge; ++i)
+      for (uint32_t j = i + 1; j < R; ++j) {
+        int64_t gap2 = 0;
+        for (int d = 0; d < 3; ++d) {
+          const int64_t gp = std::max<int64_t>(0, std::max<int64_t>(static_cast<int64_t>(comp[i].lo[d]) - comp[j].hi[d],
+                                                                       static_cast<int64_t>(comp[j].lo[d]) - comp[i].hi[d]));
+          gap2 += gp * gp;
+        }
+        if (static_cast<float>(static_cast<int64_t>(std::sqrt(static_cast<double>(gap2)))) < sep) {
+          may_merge = true;
+          break;
+        }
+      }
+    if (!may_merge) {
+      c->stats.n_seeds = S;
+      // applyClusterLevelFilters (:365-379) + ids of writeClustersToData (:381-399)
+      int32_t* fin = reinterpret_cast<int32_t*>(c->h_md_head);  // the records are no longer needed once ids are taken
+      std::vector<std::pair<int, uint64_t>> kept;
+      std::vector<int32_t> tmp(R, 0);
+      int id = 1;
+      for (uint32_t r : order) {
+        const int size = static_cast<int>(comp[r].n_pixels);
+        if (size < c->cfg.md_min_cluster_size || size > c->cfg.md_max_cluster_size) continue;
+        kept.emplace_back(id, comp[r].n_pixels);
+        tmp[r] = id;
+        if (id < 255) ++id;
+      }
+      lap("component order + filter");
+      if (kept.empty()) return 0;
+      std::memcpy(fin, tmp.data(), sizeof(int32_t) * R);
+      HIP_TRY(hipMemcpyAsync(c->d_md_comp_final, fin, sizeof(int32_t) * R, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipMemsetAsync(c->d_md_bnd_final, 0, sizeof(int32_t) * std::max<uint32_t>(B, 1), c->stream));
+      hipLaunchKernelGGL(k_md_comp_finals, dim3(1024), dim3(256), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent,
+                         c->d_md_rootidx, c->d_md_comp_final, c->d_md_seed_final, c->d_md_bnd_final);
+      hipLaunchKernelGGL(k_md_paint, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds, bnd, c->d_md_seed_final,
+                         c->d_md_bnd_final, s.dyn);
+      HIP_TRY(hipGetLastError());
+      c->last_clusters.resize(kept.size());
+      for (size_t i = 0; i < kept.size(); ++i) {
+        c->last_clusters[i] = khr_cluster{};
+        c->last_clusters[i].id = kept[i].first;
+        c->last_clusters[i].num_pixels_listed = kept[i].second;
+        c->last_clusters[i].semantic_id = -1;
+      }
+      lap("finals + paint launch");
+      return static_cast<int>(kept.size());
+    }
+  }
   c->stats.n_seeds = S;
   std::vector<uint64_t>& sk = c->h_md_seed_keys;
   std::vector<uint64_t>& bk = c->h_md_bnd_keys;
@@ -994,6 +1100,7 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
 
+  lap("list download");
   // ---- host: the seed-graph walk on compact ids (sequential in the reference too) ---------------
   struct G { int64_t x, y, z; };
   auto unpack = [](uint64_t k) {
@@ -1048,6 +1155,7 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
     cl.bnds.erase(std::unique(cl.bnds.begin(), cl.bnds.end()), cl.bnds.end());
     clusters.push_back(std::move(cl));
   }
+  lap("graph walk");
   const size_t nc = clusters.size();
   std::vector<std::vector<G>> vox(nc);
   for (size_t i = 0; i < nc; ++i) {
@@ -1104,6 +1212,7 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
     }
     keep[cur] = 1;
   }
+  lap("merge");
   // applyClusterLevelFilters (:365-379) + writeClustersToData (:381-399): later clusters overwrite earlier ones
   std::vector<int32_t>&seed_final = c->h_md_seed_final, &bnd_final = c->h_md_bnd_final;
   seed_final.assign(S, 0);
@@ -1124,18 +1233,8 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
     // the host vectors are context members, so the asynchronous upload may outlive this call
     HIP_TRY(hipMemcpyAsync(c->d_md_seed_final, seed_final.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, c->stream));
     if (B) HIP_TRY(hipMemcpyAsync(c->d_md_bnd_final, bnd_final.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, c->stream));
-    // per-cluster accumulators: count 0, bbox = [+max, -max] in ordered-int form, sums 0
-    {
-      std::vector<ClusterAcc> init(256);
-      for (auto& a : init) {
-        a.n_pixels = 0;
-        for (int d = 0; d < 3; ++d) { a.bmin[d] = INT32_MAX; a.bmax[d] = INT32_MIN; a.sum[d] = 0.f; }
-      }
-      c->h_md_acc = init;
-      HIP_TRY(hipMemcpyAsync(c->d_md_acc, c->h_md_acc.data(), sizeof(ClusterAcc) * 256, hipMemcpyHostToDevice, c->stream));
-    }
     hipLaunchKernelGGL(k_md_paint, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds, bnd, c->d_md_seed_final,
-                       c->d_md_bnd_final, s.dyn, makeDevFrame(c, s), c->d_md_acc);
+                       c->d_md_bnd_final, s.dyn);
     HIP_TRY(hipGetLastError());
     c->last_clusters.resize(kept.size());
     for (size_t i = 0; i < kept.size(); ++i) {
@@ -1145,6 +1244,7 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
       c->last_clusters[i].semantic_id = -1;
     }
   }
+  lap("filter + paint launch");
   return n_out;
 }
 
@@ -1212,7 +1312,16 @@ int khr_get_dynamic_clusters(khr_ctx* c, int slot, khr_cluster* out, int cap) {
   if (slot != c->last_cluster_slot) return fail(KHR_ESTATE, "dynamic clusters are kept for the last processed frame only");
   const int n = static_cast<int>(c->last_clusters.size());
   if (n == 0) return 0;
-  std::vector<ClusterAcc> acc(256);
+  // the summary (the tracker's bounding boxes, max_iou_tracker.cpp:466-476) is computed when somebody asks
+  FrameSlot& s = c->slots[slot];
+  std::vector<ClusterAcc>& acc = c->h_md_acc;
+  acc.assign(256, ClusterAcc{});
+  for (auto& a : acc)
+    for (int d = 0; d < 3; ++d) { a.bmin[d] = INT32_MAX; a.bmax[d] = INT32_MIN; }
+  HIP_TRY(hipMemcpyAsync(c->d_md_acc, acc.data(), sizeof(ClusterAcc) * 256, hipMemcpyHostToDevice, c->stream));
+  const int tiles = ((s.sensor.width + kAccTile - 1) / kAccTile) * ((s.sensor.height + kAccTile - 1) / kAccTile);
+  hipLaunchKernelGGL(k_cluster_summary, dim3(tiles), dim3(1024), 0, c->stream, makeDevFrame(c, s), s.dyn, c->d_md_acc);
+  HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(acc.data(), c->d_md_acc, sizeof(ClusterAcc) * 256, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   for (int i = 0; i < n && i < cap; ++i) {

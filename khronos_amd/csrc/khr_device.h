@@ -44,6 +44,8 @@ enum Counter : int {
   C_BAND_OVERFLOW,
   C_TSDF_CURSOR,     // (unused)
   C_MESH_OVERFLOW,
+  C_N_EF2,           // second ever-free list length: the tracking pass alternates and zeroes the other one
+  C_MP_DONE,         // finished workgroups of k_motion_pixels (the last one publishes the seed count)
   C_COUNT = 24
 };
 enum Stat64 : int { S_UPD = 0, S_BAND, S_MESH_VERTS, S_PRUNED, S_CUM_UPD, S_CUM_BAND, S_CUM_VISITED, S_CUM_CALLS, S_COUNT = 8 };
@@ -196,6 +198,16 @@ __device__ inline uint8_t toU8(float f) {
   float r = floorf(f + 0.5f);
   r = fminf(255.f, fmaxf(0.f, r));
   return static_cast<uint8_t>(r);
+}
+
+// The seed-pixel count goes to pinned host memory from the FIRST thread of the next kernel in the stream (count, then
+// the ticket the host spins on): no copy command, no event, no barrier packet.  (A completion counter inside
+// k_motion_pixels would be one more hot atomic address: 3600 workgroups ~ 40 us.)
+__device__ inline void publishSeedCount(const DevMap& m, volatile uint32_t* host_seed, uint32_t ticket) {
+  host_seed[0] = atomicAdd(&m.counters[C_N_SEEDS], 0u);
+  __threadfence_system();
+  host_seed[1] = ticket;
+  __threadfence_system();
 }
 
 // ---- lock-free union-find on compact node ids (object detector, motion-cluster components) ----------------------

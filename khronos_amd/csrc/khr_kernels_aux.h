@@ -23,12 +23,11 @@ constexpr uint64_t kSeedBit = 1ull << 63;
 // (nested hash maps) are grouped by the device voxel hash tables below (k_md_*).
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_motion_pixels(DevMap m, DevParams p, DevFrame f, float md_max_range,
-                                                      float min_z_world, uint64_t* __restrict__ keys,
-                                                      uint32_t* __restrict__ pix) {
+                                                      float min_z_world, uint64_t* __restrict__ keys) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= f.W * f.H) return;
+  const bool in = i < f.W * f.H;
   uint64_t key = ~0ull;
-  const float r = f.range[i];
+  const float r = in ? f.range[i] : 0.f;
   if (r > 0.f && !(r > md_max_range)) {
     const float d = f.depth[i];
     const int u = i % f.W, v = i / f.W;
@@ -54,12 +53,15 @@ __global__ __launch_bounds__(256) void k_motion_pixels(DevMap m, DevParams p, De
       }
     }
   }
-  keys[i] = key;
-  pix[i] = static_cast<uint32_t>(i);
+  if (in) keys[i] = key;
   const bool seed = (key != ~0ull) && (key & kSeedBit);
   const unsigned long long b = __ballot(seed);
   if (b && laneId() == static_cast<uint32_t>(__ffsll(static_cast<long long>(b)) - 1))
     atomicAdd(&m.counters[C_N_SEEDS], static_cast<uint32_t>(__popcll(b)));
+}
+
+__global__ void k_publish_seed(DevMap m, volatile uint32_t* host_seed, uint32_t ticket) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) publishSeedCount(m, host_seed, ticket);
 }
 
 // key exchange for sharded maps (multi-GPU): non-owned / skipped pixels travel as 0 so that an all-reduce

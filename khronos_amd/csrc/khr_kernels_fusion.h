@@ -15,15 +15,17 @@ constexpr int kBandShards = 16;  // the in-band record list is split in shards (
 // dynamic_image, and the tile's max range (block culling).  Also resets the per-frame counters.
 // ----------------------------------------------------------------------------------------------
 constexpr int kTile = 16;
+__device__ inline void beginIntegrate(DevMap m, int nvox, uint32_t* band_count);
 __global__ __launch_bounds__(256) void k_frame_ingest(const float* __restrict__ depth_in,
                                                      const uint8_t* __restrict__ rgb_in,
                                                      const int32_t* __restrict__ label_in, float* __restrict__ depth,
                                                      float* __restrict__ range, uint32_t* __restrict__ rgba,
                                                      int32_t* __restrict__ label, int32_t* __restrict__ dyn,
                                                      float* __restrict__ tile_max, int tw, int W, int H, float fx,
-                                                     float fy, float cx, float cy, int range_mode,
-                                                     uint32_t* __restrict__ counters) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) counters[C_N_SEEDS] = 0u;
+                                                     float fy, float cx, float cy, int range_mode, DevMap m, int nvox,
+                                                     uint32_t* __restrict__ band_count, int do_begin) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) m.counters[C_N_SEEDS] = 0u;
+  if (do_begin && blockIdx.x == 0) beginIntegrate(m, nvox, band_count);  // khr_process_frame: saves a launch
   const int tx = blockIdx.x % tw, ty = blockIdx.x / tw;
   const int u = tx * kTile + (threadIdx.x & 15), v = ty * kTile + (threadIdx.x >> 4);
   float r = 0.f;
@@ -79,7 +81,10 @@ __global__ __launch_bounds__(256) void k_vertex_map(DevFrame f, float* __restric
 // inserted with a 64-bit CAS.  Candidates are unique, so no two threads insert the same key.
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_alloc_visible(DevMap m, DevParams p, DevFrame f, DevFrustum fr,
-                                                      uint32_t* __restrict__ work, uint32_t* __restrict__ new_list) {
+                                                      uint32_t* __restrict__ work, uint32_t* __restrict__ new_list,
+                                                      volatile uint32_t* host_seed, uint32_t seed_ticket) {
+  // khr_process_frame: this is the first kernel behind k_motion_pixels, whose seed count the host is waiting for
+  if (seed_ticket && blockIdx.x == 0 && threadIdx.x == 0) publishSeedCount(m, host_seed, seed_ticket);
   const int S = 2 * fr.n_steps + 1;
   const int total = S * S * S;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -136,9 +141,9 @@ __global__ __launch_bounds__(256) void k_alloc_visible(DevMap m, DevParams p, De
 
 // per-call counter reset; the previous call's statistics are folded into cumulative totals so that a
 // benchmark can read N_upd / N_band sums once, outside its timed region.
-__global__ void k_begin_integrate(DevMap m, int nvox, uint32_t* band_count) {
-  if (blockIdx.x == 0 && threadIdx.x < kBandShards) band_count[threadIdx.x * 32] = 0u;
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
+__device__ inline void beginIntegrate(DevMap m, int nvox, uint32_t* band_count) {
+  if (threadIdx.x < kBandShards) band_count[threadIdx.x * 32] = 0u;
+  if (threadIdx.x == 0) {
     m.stats[S_CUM_UPD] += m.stats[S_UPD];
     m.stats[S_CUM_BAND] += m.stats[S_BAND];
     m.stats[S_CUM_VISITED] += static_cast<unsigned long long>(m.counters[C_N_VISIBLE]) * nvox;
@@ -149,8 +154,10 @@ __global__ void k_begin_integrate(DevMap m, int nvox, uint32_t* band_count) {
     m.counters[C_N_NEW] = 0u;
     m.counters[C_N_TSDF] = 0u;
     m.counters[C_TSDF_CURSOR] = 0u;
-    m.counters[C_N_EF] = 0u;
   }
+}
+__global__ void k_begin_integrate(DevMap m, int nvox, uint32_t* band_count) {
+  if (blockIdx.x == 0) beginIntegrate(m, nvox, band_count);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -811,16 +818,21 @@ __global__ __launch_bounds__(256) void k_band_update(DevMap m, DevParams p, DevF
 // ----------------------------------------------------------------------------------------------
 template <int VPS>
 __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, uint64_t stamp, uint64_t prev_stamp,
-                                                        uint64_t lim_active, uint64_t lim_free, int force_full) {
+                                                        uint64_t lim_active, uint64_t lim_free, int force_full,
+                                                        uint32_t* __restrict__ ef_list, uint32_t* __restrict__ ef_count,
+                                                        uint32_t* __restrict__ ef_count_next) {
   // lim_active / lim_free: smallest stamps x with toSeconds(x) >= toSeconds(now) - temporal_window resp.
   // - temporal_buffer, found on the host with the reference's double arithmetic.  x -> fl(double(x)/1e9) is
   // monotone, so "toSeconds(x) >= T" is exactly "x >= lim" and the kernel needs no fp64 divisions.
   constexpr int NV = VPS * VPS * VPS;
   __shared__ uint64_t s_min[2][4];
   const uint32_t n_slots = m.counters[C_MAX_SLOT];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *ef_count_next = 0u;  // the list of the NEXT pass (the two counters alternate)
   for (uint32_t s = blockIdx.x; s < n_slots; s += gridDim.x) {
     const uint32_t fl = m.blk_flags[s];
     if (!(fl & BLK_LIVE)) continue;  // uniform per workgroup
+    // ever-free work list: the blocks the integrator touched (tracking_integrator.cpp:76-77); order is irrelevant
+    if (threadIdx.x == 0 && (fl & BLK_TRACKING_UPDATED)) ef_list[atomicAdd(ef_count, 1u)] = s;
     if (!force_full && !(fl & (BLK_TRACKING_UPDATED | BLK_TRACK_DIRTY))) {
       const ulonglong2 lim = reinterpret_cast<const ulonglong2*>(m.trk_lim)[s];
       if (lim_active <= lim.x && lim_free <= lim.y) continue;  // nothing in this block can change
@@ -945,7 +957,7 @@ struct RemoteHalo {
 
 template <int VPS>
 __global__ __launch_bounds__(256) void k_ever_free(DevMap m, DevParams p, const uint32_t* __restrict__ ef_list,
-                                                  RemoteHalo rh) {
+                                                  const uint32_t* __restrict__ ef_count, RemoteHalo rh) {
   constexpr int NV = VPS * VPS * VPS;
   constexpr int NW = NV / 64;
   constexpr int T = VPS + 2;
@@ -953,7 +965,7 @@ __global__ __launch_bounds__(256) void k_ever_free(DevMap m, DevParams p, const 
   __shared__ uint32_t s_row[T * T];
   __shared__ uint64_t s_bits[27][NW];
   __shared__ const uint64_t* s_src[27];
-  const uint32_t n = m.counters[C_N_EF];
+  const uint32_t n = *ef_count;
   for (uint32_t b = blockIdx.x; b < n; b += gridDim.x) {
     const size_t slot = ef_list[b];
     const int4 bi = m.blk_index[slot];

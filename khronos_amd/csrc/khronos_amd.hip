@@ -105,7 +105,14 @@ struct khr_ctx {
   uint32_t* d_mh_vals = nullptr;
   uint32_t mh_cap_total = 0, mh_mask = 0, mh_n = 0;
   uint8_t* d_mh_flag = nullptr;
-  uint32_t* h_pinned = nullptr;  // [0] seed pixels of the last motion pass, [1] removed count
+  uint32_t* h_pinned = nullptr;  // [0] seed pixels of the last motion pass, [1] removed count, [2] count / [3] ticket written by
+                                 // k_motion_pixels (zero-copy)
+  uint32_t* d_pinned = nullptr;  // device view of h_pinned
+  uint32_t seed_ticket = 0;
+  bool seed_publish_pending = false;
+  bool seed_by_ticket = false;   // motionFinish waits for the ticket (k_motion_pixels) instead of ev_seed (key import)
+  bool begin_in_ingest = false, begun = false;  // khr_process_frame folds k_begin_integrate into k_frame_ingest
+  int ef_parity = 0, ef_cur = 0;  // which of C_N_EF / C_N_EF2 the next / the latest tracking pass fills
   hipEvent_t ev_seed = nullptr;
   uint32_t last_removed = 0;
   uint64_t last_track_stamp = 0;  // stamp of the latest tracking pass = last_occupied of every VOX_OCC voxel
@@ -422,6 +429,11 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     delete c;
     return fail(KHR_EDEVICE, "pinned scratch / event creation failed");
   }
+  std::memset(c->h_pinned, 0, 64);
+  if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_pinned), c->h_pinned, 0) != hipSuccess) {
+    delete c;
+    return fail(KHR_EDEVICE, "hipHostGetDevicePointer failed");
+  }
 
   DevParams& p = c->p;
   p.vs = cfg->voxel_size;
@@ -658,8 +670,10 @@ int khr_upload_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fram
   s.th = (sensor->height + kTile - 1) / kTile;
   hipLaunchKernelGGL(k_frame_ingest, dim3(s.tw * s.th), dim3(256), 0, c->stream, depth_src, rgb_src, label_src, s.depth,
                      s.range, s.rgba, s.label, s.dyn, s.tile_max, s.tw, sensor->width, sensor->height, sensor->fx, sensor->fy,
-                     sensor->cx, sensor->cy, c->p.range_mode, c->m.counters);
+                     sensor->cx, sensor->cy, c->p.range_mode, c->m, c->p.nvox, c->d_band_count, c->begin_in_ingest ? 1 : 0);
   HIP_TRY(hipGetLastError());
+  c->begun = c->begin_in_ingest;
+  c->begin_in_ingest = false;
   if (!on_device) HIP_TRY(hipStreamSynchronize(c->stream));  // caller buffers may be reused after return
   s.valid = true;
   return slot;
@@ -716,14 +730,17 @@ int khr_download_frame_image(khr_ctx* c, int slot, int which, int32_t* image) {
 // block allocation + culling of one integrate call (independent of the dynamic mask)
 static int integrateAlloc(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allocate_blocks) {
   DevMap& m = c->m;
-  // reset per-call counters
-  hipLaunchKernelGGL(k_begin_integrate, dim3(1), dim3(64), 0, c->stream, m, c->p.nvox, c->d_band_count);
+  // reset per-call counters (already done by k_frame_ingest inside khr_process_frame)
+  if (!c->begun) hipLaunchKernelGGL(k_begin_integrate, dim3(1), dim3(64), 0, c->stream, m, c->p.nvox, c->d_band_count);
+  c->begun = false;
   if (allocate_blocks) {
     ScopedTimer tm(c, 3);
     const DevFrustum fr = makeFrustum(c, f);
     const int S = 2 * fr.n_steps + 1;
     const size_t total = static_cast<size_t>(S) * S * S;
-    hipLaunchKernelGGL(k_alloc_visible, dim3(gridFor(total)), dim3(256), 0, c->stream, m, c->p, f, fr, c->d_work, c->d_new);
+    hipLaunchKernelGGL(k_alloc_visible, dim3(gridFor(total)), dim3(256), 0, c->stream, m, c->p, f, fr, c->d_work, c->d_new,
+                       c->d_pinned + 2, c->seed_publish_pending ? c->seed_ticket : 0u);
+    c->seed_publish_pending = false;
     hipLaunchKernelGGL(k_init_blocks, dim3(2048), dim3(256), 0, c->stream, m, c->p, c->d_new);
     hipLaunchKernelGGL(k_cull_blocks, dim3(1024), dim3(256), 0, c->stream, m, c->p, f, c->d_work, c->d_work_tsdf,
                        c->cfg.disable_culling ? nullptr : s.tile_max, s.tw, s.th);
@@ -837,14 +854,18 @@ static int trackingPhase(khr_ctx* c, uint64_t stamp, int phase) {
   return dispatchVps(c, [&](auto vps) {
     constexpr int V = decltype(vps)::value;
     if (phase & 1) {
-      HIP_TRY(hipMemsetAsync(&m.counters[C_N_EF], 0, sizeof(uint32_t), c->stream));
-      hipLaunchKernelGGL(k_list_live, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_ef, &m.counters[C_N_EF],
-                         BLK_TRACKING_UPDATED);
+      // the ever-free work list is gathered by the tracking pass itself; the two list counters alternate and each
+      // pass zeroes the other one, so no memset / compaction launch is needed
+      const int cur = c->ef_parity;
+      c->ef_parity ^= 1;
+      c->ef_cur = cur;
+      uint32_t* const ef_count = &m.counters[cur ? C_N_EF2 : C_N_EF];
+      uint32_t* const ef_next = &m.counters[cur ? C_N_EF : C_N_EF2];
       ScopedTimer tm(c, 1);
       // stamps going backwards void the per-block skip thresholds (they assume monotone limits)
       const int force_full = stamp < c->last_track_stamp || c->cfg.disable_culling ? 1 : 0;
       hipLaunchKernelGGL((k_tracking_update<V>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, stamp, c->last_track_stamp,
-                         lim_active, lim_free, force_full);
+                         lim_active, lim_free, force_full, c->d_ef, ef_count, ef_next);
       c->last_track_stamp = stamp;
     }
     if (phase & 2) {
@@ -856,7 +877,8 @@ static int trackingPhase(khr_ctx* c, uint64_t stamp, int phase) {
         rh.ht_vals = c->d_halo_vals;
         rh.ht_mask = c->halo_mask;
       }
-      hipLaunchKernelGGL((k_ever_free<V>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, c->d_ef, rh);
+      hipLaunchKernelGGL((k_ever_free<V>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, c->d_ef,
+                         &m.counters[c->ef_cur ? C_N_EF2 : C_N_EF], rh);
     }
     HIP_TRY(hipGetLastError());
     return KHR_OK;
@@ -950,6 +972,7 @@ static int motionLaunch(khr_ctx* c, FrameSlot& s, bool fresh_slot) {
   }
   c->stats.n_seeds = 0;
   c->h_pinned[0] = 0;
+  c->seed_by_ticket = false;
   if (!c->cfg.with_tracking) return KHR_OK;
   DevMap& m = c->m;
   const DevFrame f = makeDevFrame(c, s);
@@ -957,17 +980,45 @@ static int motionLaunch(khr_ctx* c, FrameSlot& s, bool fresh_slot) {
   const float min_z_world = static_cast<float>(s.meta.world_T_sensor[11] + static_cast<double>(c->cfg.md_min_z_coordinate));
   {
     ScopedTimer tm(c, 4);
+    ++c->seed_ticket;
+    if (c->seed_ticket == 0) ++c->seed_ticket;
     hipLaunchKernelGGL(k_motion_pixels, dim3(gridFor(n)), dim3(256), 0, c->stream, m, c->p, f, c->cfg.md_max_range,
-                       min_z_world, c->d_keys, c->d_pix);
+                       min_z_world, c->d_keys);
   }
-  HIP_TRY(hipMemcpyAsync(&c->h_pinned[0], &m.counters[C_N_SEEDS], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipEventRecord(c->ev_seed, c->stream));
+  HIP_TRY(hipGetLastError());
+  c->seed_by_ticket = true;
+  c->seed_publish_pending = true;  // the next kernel in the stream (k_alloc_visible or k_publish_seed) writes it to the host
   return KHR_OK;
 }
 
 // motion detection, part 2: wait for the seed count; without seeds there are no clusters
 // (clusterDynamicVoxels loops over seeds only); otherwise sort / run-length encode the pixel keys,
 // walk the seed graph on the host and paint the dynamic image.  Returns the number of clusters.
+// the seed-pixel count of the latest pixel pass: either the ticket k_motion_pixels' last workgroup writes into pinned
+// memory (spin; the stream keeps running), or the event behind the asynchronous copy of the key-import path
+static int waitSeedCount(khr_ctx* c) {
+  if (!c->seed_by_ticket) {
+    HIP_TRY(hipEventSynchronize(c->ev_seed));
+    return KHR_OK;
+  }
+  if (c->seed_publish_pending) {
+    hipLaunchKernelGGL(k_publish_seed, dim3(1), dim3(1), 0, c->stream, c->m, c->d_pinned + 2, c->seed_ticket);
+    HIP_TRY(hipGetLastError());
+    c->seed_publish_pending = false;
+  }
+  volatile uint32_t* hp = c->h_pinned;
+  uint64_t spins = 0;
+  while (hp[3] != c->seed_ticket) {
+    if ((++spins & 0xffffu) == 0) {  // every ~65k polls: is the stream still alive?
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) return fail(KHR_EDEVICE, "stream failed while waiting for the seed count: %s", hipGetErrorString(q));
+      if (q == hipSuccess && hp[3] != c->seed_ticket) return fail(KHR_EDEVICE, "seed count was never published");
+    }
+  }
+  c->h_pinned[0] = hp[2];
+  return KHR_OK;
+}
+
 static int motionFinish(khr_ctx* c, FrameSlot& s) {
   if (!c->cfg.with_tracking) return 0;
   const int n = s.sensor.width * s.sensor.height;
@@ -979,7 +1030,7 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
     std::fprintf(stderr, "[md] %s %.1f us\n", what, std::chrono::duration<double, std::micro>(t1 - t0).count());
     t0 = t1;
   };
-  HIP_TRY(hipEventSynchronize(c->ev_seed));
+  { const int rcw = waitSeedCount(c); if (rcw) return rcw; }
   lap("wait seed count");
   c->last_clusters.clear();
   c->last_cluster_slot = static_cast<int>(&s - c->slots.data());
@@ -1277,7 +1328,7 @@ int khr_motion_keys(khr_ctx* c, int slot, void* keys_out, int on_device, uint32_
     hipFree(tmp);
     if (e != hipSuccess) return fail(KHR_EDEVICE, "key export failed: %s", hipGetErrorString(e));
   }
-  HIP_TRY(hipEventSynchronize(c->ev_seed));
+  { const int rcw = waitSeedCount(c); if (rcw) return rcw; }
   if (n_seed_pixels) *n_seed_pixels = c->h_pinned[0];
   return KHR_OK;
 }
@@ -1299,6 +1350,7 @@ int khr_detect_motion_from_keys(khr_ctx* c, int slot, const void* keys, int on_d
   hipLaunchKernelGGL(k_md_keys_import, dim3(gridFor(n)), dim3(256), 0, c->stream, src, n, c->d_keys, &c->m.counters[C_N_SEEDS]);
   HIP_TRY(hipMemcpyAsync(&c->h_pinned[0], &c->m.counters[C_N_SEEDS], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipEventRecord(c->ev_seed, c->stream));
+  c->seed_by_ticket = false;
   const int nc = motionFinish(c, s);
   if (tmp) {
     hipStreamSynchronize(c->stream);
@@ -1744,7 +1796,9 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
                       int* n_clusters) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
   if (n_clusters) *n_clusters = 0;
+  c->begin_in_ingest = true;
   const int slot = khr_upload_frame(c, sensor, frame, on_device);
+  c->begin_in_ingest = false;
   if (slot < 0) return slot;
   FrameSlot& s = c->slots[slot];
   const DevFrame f = makeDevFrame(c, s);
@@ -1850,7 +1904,7 @@ int khr_get_stats(khr_ctx* c, khr_stats* out) {
   s.n_visited_voxels = static_cast<uint64_t>(c->h_counters[C_N_VISIBLE]) * c->p.nvox;
   s.n_updated_voxels = st[S_UPD];
   s.n_band_voxels = st[S_BAND];
-  s.n_tracking_updated_blocks = c->h_counters[C_N_EF];
+  s.n_tracking_updated_blocks = c->h_counters[c->ef_cur ? C_N_EF2 : C_N_EF];
   s.pool_exhausted = c->h_counters[C_POOL_EXHAUSTED];
   s.n_tsdf_blocks = c->h_counters[C_N_TSDF];
   s.band_overflow = c->h_counters[C_BAND_OVERFLOW];

@@ -29,5 +29,5 @@ PY
 python -c "
 import json
 for f in ('bench_full','bench_alltimers'):
-    d=json.load(open('$R/gpurun_out/%s.json'%f)); print(f, round(d['value']), d['ms_per_step'], d['roofline']['frac'], d['roofline_band']['frac'], d.get('cpu_baseline'), d.get('speedup_vs_cpu')); print({k:(round(1e3*v['ms_total']/max(1,v['launches']),1)) for k,v in d['kernel_ms'].items()})"
+    d=json.load(open('$R/gpurun_out/%s.json'%f)); print(f, round(d['value']), d['ms_per_step'], d['roofline']['frac'], d.get('roofline_band',{}).get('frac'), d.get('cpu_baseline'), d.get('speedup_vs_cpu')); print({k:(round(1e3*v['ms_total']/max(1,v['launches']),1)) for k,v in d['kernel_ms'].items()})"
 head -16 $R/gpurun_out/prof_stats/r01_kernel_stats.csv | cut -c1-150

@@ -231,7 +231,8 @@ def main():
         "mvoxel_updates_per_s": 1e-6 * n_upd_all / dt,
         "voxels": {"visited": n_vis_all, "updated": n_upd_all, "band": n_band_all, "allocated_blocks": st1["n_allocated_blocks"],
                    "last_frame_visible_blocks": st1["n_visible_blocks"], "last_frame_tsdf_blocks": st1["n_tsdf_blocks"],
-                   "band_overflow": st1["band_overflow"]},
+                   "band_overflow": st1["band_overflow"], "last_frame_tracking_blocks": st1["n_tracking_processed_blocks"],
+                   "last_frame_touched_blocks": st1["n_tracking_updated_blocks"]},
     }
 
     # ---- roofline of the dominant kernel (k_tsdf_update), from HIP events on the kernel's stream ----

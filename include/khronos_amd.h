@@ -124,6 +124,7 @@ typedef struct khr_stats {
   uint64_t cum_integrate_calls;
   uint64_t n_tsdf_blocks;      /* last integrate: blocks left after conservative culling */
   uint64_t band_overflow;      /* non-zero if in-band records were dropped (raise max_band_records) */
+  uint64_t n_tracking_processed_blocks; /* blocks the last tracking pass had to visit (the rest provably cannot change) */
 } khr_stats;
 
 /* khronos::MeasurementCluster role (measurement_clusters.h:63-80) for dynamic clusters

@@ -61,7 +61,8 @@ class KhrStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "n_allocated_blocks", "n_visible_blocks", "n_new_blocks", "n_visited_voxels", "n_updated_voxels",
         "n_band_voxels", "n_tracking_updated_blocks", "n_seeds", "n_mesh_blocks", "n_mesh_vertices",
-        "pool_exhausted", "cum_updated_voxels", "cum_band_voxels", "cum_visited_voxels", "cum_integrate_calls", "n_tsdf_blocks", "band_overflow")]
+        "pool_exhausted", "cum_updated_voxels", "cum_band_voxels", "cum_visited_voxels", "cum_integrate_calls", "n_tsdf_blocks", "band_overflow",
+        "n_tracking_processed_blocks")]
 
 
 # every symbol include/khronos_amd.h declares (tests check the library exports all of them)

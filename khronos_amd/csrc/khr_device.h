@@ -44,7 +44,10 @@ enum Counter : int {
   C_BAND_OVERFLOW,
   C_TSDF_CURSOR,     // (unused)
   C_MESH_OVERFLOW,
-  C_N_EF2,           // second ever-free list length: the tracking pass alternates and zeroes the other one
+  C_N_PROC,          // tracking pass: blocks that need the full pass (pair 0: C_N_PROC, C_N_EF_A)
+  C_N_EF_A,
+  C_N_PROC2,         // pair 1 (the pairs alternate; each pass zeroes the other pair)
+  C_N_EF2,
   C_MP_DONE,         // finished workgroups of k_motion_pixels (the last one publishes the seed count)
   C_COUNT = 24
 };

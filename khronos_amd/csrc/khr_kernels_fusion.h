@@ -815,28 +815,51 @@ __global__ __launch_bounds__(256) void k_band_update(DevMap m, DevParams p, DevF
 //    an active voxel (active -> inactive, to_remove) or lim_free passes the earliest last_occupied of a voxel
 //    that is not yet free (free bit 0 -> 1); both minima are kept per block.  Stamps going backwards, freshly
 //    allocated blocks and khr_mark_all_inactive force a full pass (force_full / BLK_TRACK_DIRTY).
+//    k_tracking_select (one thread per pool slot) applies the test and compacts the blocks to visit; this kernel
+//    runs one workgroup per listed block (a workgroup per pool slot costs ~15 us in dispatch + dependent loads
+//    before the first useful byte).
 // ----------------------------------------------------------------------------------------------
+// work lists of the tracking pass, one thread per pool slot: `proc` = live blocks that need the full pass (touched by the
+// integrator, dirty, or one of the two skip thresholds crossed), `ef_list` = blocks the integrator touched (the
+// ever-free work list, tracking_integrator.cpp:76-77).  Wave-aggregated appends; the counters of the NEXT pass
+// (cnt_next[0..1], the pairs alternate) are zeroed here so that no memset launch is needed.
+__global__ __launch_bounds__(256) void k_tracking_select(DevMap m, uint64_t lim_active, uint64_t lim_free, int force_full,
+                                                        uint32_t* __restrict__ proc, uint32_t* __restrict__ ef_list,
+                                                        uint32_t* __restrict__ cnt /* [0] proc, [1] ef */,
+                                                        uint32_t* __restrict__ cnt_next) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s == 0) { cnt_next[0] = 0u; cnt_next[1] = 0u; }
+  bool need = false, touched = false;
+  if (s < m.counters[C_MAX_SLOT]) {
+    const uint32_t fl = m.blk_flags[s];
+    if (fl & BLK_LIVE) {
+      touched = fl & BLK_TRACKING_UPDATED;
+      need = force_full || (fl & (BLK_TRACKING_UPDATED | BLK_TRACK_DIRTY));
+      if (!need) {
+        const ulonglong2 lim = reinterpret_cast<const ulonglong2*>(m.trk_lim)[s];
+        need = !(lim_active <= lim.x && lim_free <= lim.y);  // otherwise nothing in this block can change
+      }
+    }
+  }
+  const uint32_t ip = waveAggInc(&cnt[0], need);
+  if (need) proc[ip] = s;
+  const uint32_t ie = waveAggInc(&cnt[1], touched);
+  if (touched) ef_list[ie] = s;
+}
+
 template <int VPS>
 __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, uint64_t stamp, uint64_t prev_stamp,
-                                                        uint64_t lim_active, uint64_t lim_free, int force_full,
-                                                        uint32_t* __restrict__ ef_list, uint32_t* __restrict__ ef_count,
-                                                        uint32_t* __restrict__ ef_count_next) {
+                                                        uint64_t lim_active, uint64_t lim_free,
+                                                        const uint32_t* __restrict__ proc, const uint32_t* __restrict__ n_proc) {
   // lim_active / lim_free: smallest stamps x with toSeconds(x) >= toSeconds(now) - temporal_window resp.
   // - temporal_buffer, found on the host with the reference's double arithmetic.  x -> fl(double(x)/1e9) is
   // monotone, so "toSeconds(x) >= T" is exactly "x >= lim" and the kernel needs no fp64 divisions.
   constexpr int NV = VPS * VPS * VPS;
   __shared__ uint64_t s_min[2][4];
-  const uint32_t n_slots = m.counters[C_MAX_SLOT];
-  if (blockIdx.x == 0 && threadIdx.x == 0) *ef_count_next = 0u;  // the list of the NEXT pass (the two counters alternate)
-  for (uint32_t s = blockIdx.x; s < n_slots; s += gridDim.x) {
+  const uint32_t n = *n_proc;
+  for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const uint32_t s = proc[i];
     const uint32_t fl = m.blk_flags[s];
-    if (!(fl & BLK_LIVE)) continue;  // uniform per workgroup
-    // ever-free work list: the blocks the integrator touched (tracking_integrator.cpp:76-77); order is irrelevant
-    if (threadIdx.x == 0 && (fl & BLK_TRACKING_UPDATED)) ef_list[atomicAdd(ef_count, 1u)] = s;
-    if (!force_full && !(fl & (BLK_TRACKING_UPDATED | BLK_TRACK_DIRTY))) {
-      const ulonglong2 lim = reinterpret_cast<const ulonglong2*>(m.trk_lim)[s];
-      if (lim_active <= lim.x && lim_free <= lim.y) continue;  // nothing in this block can change
-    }
     const size_t slot = s;
     // thread <-> 4 consecutive voxels: 16-byte loads of distance / flags, 2 x 16-byte of the stamps
     const float4* __restrict__ dist4 = reinterpret_cast<const float4*>(m.dist + slot * NV);
@@ -846,48 +869,74 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
     uint64_t* __restrict__ fb = m.freebits + slot * (NV / 64);
     bool any_active = false;
     uint64_t a_min = ~0ull, f_min = ~0ull;
-    for (int g = threadIdx.x; g < NV / 4; g += 256) {
-      const float4 d = dist4[g];
-      const ulonglong2 oa = lobs2[2 * g], ob = lobs2[2 * g + 1];
-      const uint32_t v4 = vfl4[g];
-      const float dd[4] = {d.x, d.y, d.z, d.w};
-      const uint64_t lo[4] = {oa.x, oa.y, ob.x, ob.y};
-      bool occ[4], was_occ[4], need[4];
+    // A block is 1024 groups of 4 voxels = 4 groups per thread (VPS 16).  All loads of a round are issued before the
+    // first use: the pass is latency bound (one workgroup per touched block, a few dependent round trips each), so the
+    // 4 x 52 B of distance / last_observed / flags travel together, then the last_occupied pairs that are needed.
+    constexpr int G = NV / 4 / 256 > 0 ? NV / 4 / 256 : 1;
+    float4 d_[G];
+    ulonglong2 oa_[G], ob_[G], ca_[G], cb_[G];
+    uint32_t v4_[G];
+    uint32_t need_[G];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint8_t v = static_cast<uint8_t>(v4 >> (8 * k));
-        occ[k] = dd[k] < p.occ_thr;
-        was_occ[k] = v & VOX_OCC;
-        // the stored stamp matters only for a voxel that is not occupied, was not occupied at the previous pass
-        // and is not ever-free yet (an ever-free voxel's free bit is 1 whatever its stamps say)
-        need[k] = !occ[k] && !was_occ[k] && !(v & VOX_EVER_FREE);
+    for (int q = 0; q < G; ++q) {
+      const int g = threadIdx.x + 256 * q;
+      if (g < NV / 4) {
+        d_[q] = dist4[g];
+        oa_[q] = lobs2[2 * g];
+        ob_[q] = lobs2[2 * g + 1];
+        v4_[q] = vfl4[g];
       }
-      ulonglong2 ca = make_ulonglong2(0ull, 0ull), cb = ca;
-      if (need[0] || need[1]) ca = reinterpret_cast<const ulonglong2*>(locc)[2 * g];
-      if (need[2] || need[3]) cb = reinterpret_cast<const ulonglong2*>(locc)[2 * g + 1];
-      const uint64_t stored[4] = {ca.x, ca.y, cb.x, cb.y};
+    }
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      const int g = threadIdx.x + 256 * q;
+      need_[q] = 0u;
+      ca_[q] = make_ulonglong2(0ull, 0ull);
+      cb_[q] = ca_[q];
+      if (g < NV / 4) {
+        const float dd[4] = {d_[q].x, d_[q].y, d_[q].z, d_[q].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint8_t v = static_cast<uint8_t>(v4_[q] >> (8 * k));
+          // the stored stamp matters only for a voxel that is not occupied, was not occupied at the previous pass
+          // and is not ever-free yet (an ever-free voxel's free bit is 1 whatever its stamps say)
+          if (!(dd[k] < p.occ_thr) && !(v & VOX_OCC) && !(v & VOX_EVER_FREE)) need_[q] |= 1u << k;
+        }
+        if (need_[q] & 3u) ca_[q] = reinterpret_cast<const ulonglong2*>(locc)[2 * g];
+        if (need_[q] & 12u) cb_[q] = reinterpret_cast<const ulonglong2*>(locc)[2 * g + 1];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      const int g = threadIdx.x + 256 * q;
+      if (g >= NV / 4) continue;
+      const uint32_t v4 = v4_[q];
+      const float dd[4] = {d_[q].x, d_[q].y, d_[q].z, d_[q].w};
+      const uint64_t lo[4] = {oa_[q].x, oa_[q].y, ob_[q].x, ob_[q].y};
+      const uint64_t stored[4] = {ca_[q].x, ca_[q].y, cb_[q].x, cb_[q].y};
       uint32_t nv4 = 0, freebits4 = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const uint8_t v = static_cast<uint8_t>(v4 >> (8 * k));
+        const bool occ = dd[k] < p.occ_thr, was_occ = v & VOX_OCC;
         // last_occupied after this pass (tracking_integrator.cpp:140-143)
         uint64_t oc = stored[k];
-        if (occ[k]) {
+        if (occ) {
           oc = stamp;
-        } else if (was_occ[k]) {
+        } else if (was_occ) {
           oc = prev_stamp;  // occupied until the previous pass: materialise its stamp once
           locc[4 * g + k] = prev_stamp;
         }
         const bool was_active = v & VOX_ACTIVE;
         const bool active = lo[k] >= lim_active;
-        uint8_t nv = static_cast<uint8_t>((v & ~(VOX_ACTIVE | VOX_OCC)) | (active ? VOX_ACTIVE : 0) | (occ[k] ? VOX_OCC : 0));
+        uint8_t nv = static_cast<uint8_t>((v & ~(VOX_ACTIVE | VOX_OCC)) | (active ? VOX_ACTIVE : 0) | (occ ? VOX_OCC : 0));
         if (was_active && !active) nv |= VOX_TO_REMOVE;
         any_active |= active;
         if (active) a_min = lo[k] < a_min ? lo[k] : a_min;
         const bool ever = nv & VOX_EVER_FREE;
         const bool is_free = !ever && (oc < lim_free) && (lo[k] != 0ull);  // only evaluated where it decides the bit
         if (ever || is_free) freebits4 |= 1u << k;
-        if (!occ[k] && !ever && !is_free && lo[k] != 0ull) f_min = oc < f_min ? oc : f_min;
+        if (!occ && !ever && !is_free && lo[k] != 0ull) f_min = oc < f_min ? oc : f_min;
         nv4 |= static_cast<uint32_t>(nv) << (8 * k);
       }
       if (nv4 != v4) vfl4[g] = nv4;

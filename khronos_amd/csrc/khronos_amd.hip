@@ -88,6 +88,7 @@ struct khr_ctx {
   uint32_t* d_work = nullptr;
   uint32_t* d_new = nullptr;
   uint32_t* d_ef = nullptr;
+  uint32_t* d_trk_proc = nullptr;
   uint32_t* d_work_tsdf = nullptr;
   BandRec* d_band = nullptr;
   uint32_t band_cap = 0;
@@ -496,6 +497,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &c->d_work, cap));
   A(devAlloc(c, &c->d_new, cap));
   A(devAlloc(c, &c->d_ef, cap));
+  A(devAlloc(c, &c->d_trk_proc, cap));
   A(devAlloc(c, &c->d_work_tsdf, cap));
   c->band_cap = cfg->max_band_records ? cfg->max_band_records : 4u * cfg->max_frame_pixels;
   c->band_cap = (c->band_cap / kBandShards + 1) * kBandShards;
@@ -859,13 +861,15 @@ static int trackingPhase(khr_ctx* c, uint64_t stamp, int phase) {
       const int cur = c->ef_parity;
       c->ef_parity ^= 1;
       c->ef_cur = cur;
-      uint32_t* const ef_count = &m.counters[cur ? C_N_EF2 : C_N_EF];
-      uint32_t* const ef_next = &m.counters[cur ? C_N_EF : C_N_EF2];
+      uint32_t* const cnt = &m.counters[cur ? C_N_PROC2 : C_N_PROC];
+      uint32_t* const cnt_next = &m.counters[cur ? C_N_PROC : C_N_PROC2];
       ScopedTimer tm(c, 1);
       // stamps going backwards void the per-block skip thresholds (they assume monotone limits)
       const int force_full = stamp < c->last_track_stamp || c->cfg.disable_culling ? 1 : 0;
-      hipLaunchKernelGGL((k_tracking_update<V>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, stamp, c->last_track_stamp,
-                         lim_active, lim_free, force_full, c->d_ef, ef_count, ef_next);
+      hipLaunchKernelGGL(k_tracking_select, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, lim_active, lim_free, force_full,
+                         c->d_trk_proc, c->d_ef, cnt, cnt_next);
+      hipLaunchKernelGGL((k_tracking_update<V>), dim3(1024), dim3(256), 0, c->stream, m, c->p, stamp, c->last_track_stamp, lim_active,
+                         lim_free, c->d_trk_proc, cnt);
       c->last_track_stamp = stamp;
     }
     if (phase & 2) {
@@ -878,7 +882,7 @@ static int trackingPhase(khr_ctx* c, uint64_t stamp, int phase) {
         rh.ht_mask = c->halo_mask;
       }
       hipLaunchKernelGGL((k_ever_free<V>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, c->d_ef,
-                         &m.counters[c->ef_cur ? C_N_EF2 : C_N_EF], rh);
+                         &m.counters[c->ef_cur ? C_N_EF2 : C_N_EF_A], rh);
     }
     HIP_TRY(hipGetLastError());
     return KHR_OK;
@@ -1904,10 +1908,11 @@ int khr_get_stats(khr_ctx* c, khr_stats* out) {
   s.n_visited_voxels = static_cast<uint64_t>(c->h_counters[C_N_VISIBLE]) * c->p.nvox;
   s.n_updated_voxels = st[S_UPD];
   s.n_band_voxels = st[S_BAND];
-  s.n_tracking_updated_blocks = c->h_counters[c->ef_cur ? C_N_EF2 : C_N_EF];
+  s.n_tracking_updated_blocks = c->h_counters[c->ef_cur ? C_N_EF2 : C_N_EF_A];
   s.pool_exhausted = c->h_counters[C_POOL_EXHAUSTED];
   s.n_tsdf_blocks = c->h_counters[C_N_TSDF];
   s.band_overflow = c->h_counters[C_BAND_OVERFLOW];
+  s.n_tracking_processed_blocks = c->h_counters[c->ef_cur ? C_N_PROC2 : C_N_PROC];
   s.cum_updated_voxels = st[S_CUM_UPD] + st[S_UPD];
   s.cum_band_voxels = st[S_CUM_BAND] + st[S_BAND];
   s.cum_visited_voxels = st[S_CUM_VISITED] + s.n_visited_voxels;

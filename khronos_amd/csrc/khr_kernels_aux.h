@@ -922,6 +922,30 @@ __global__ __launch_bounds__(256) void k_mesh_halo_import(const uint32_t* __rest
   }
 }
 
+// mesh work list + everything that hangs on it, one thread per pool slot (s in [0, capacity]): the blocks to
+// (re)generate (generateMesh(map, only_mesh_updated, ...)), their `regen` marks, and the carried-over vertex counts
+// of the blocks that keep their mesh (regenerated blocks get their count from the counting pass)
+__global__ __launch_bounds__(256) void k_mesh_prepare(DevMap m, uint32_t require_flags, uint32_t* __restrict__ work,
+                                                     uint32_t* __restrict__ n_work, uint8_t* __restrict__ regen,
+                                                     uint32_t* __restrict__ new_count) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  bool listed = false;
+  uint32_t count = 0u;
+  if (s < m.counters[C_MAX_SLOT]) {
+    const uint32_t fl = m.blk_flags[s];
+    if (fl & BLK_LIVE) {
+      listed = (fl & require_flags) == require_flags;
+      count = m.mesh_desc[s].count;
+    }
+  }
+  const uint32_t idx = waveAggInc(n_work, listed);
+  if (listed) work[idx] = s;
+  if (s <= m.capacity) {
+    if (s < m.capacity) regen[s] = listed ? 1 : 0;
+    new_count[s] = count;
+  }
+}
+
 // blocks that keep their mesh: carry old count over to the new count array
 __global__ __launch_bounds__(256) void k_mesh_carry_counts(DevMap m, uint32_t* __restrict__ new_count) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -990,41 +1014,30 @@ __global__ __launch_bounds__(256) void k_reset_inactive(DevMap m, int4* __restri
   }
 }
 
-// rebuild the hash table from live slots after removals (single pass; keys were reset to empty)
+// After removals the hash table and the free list are rebuilt from the slot flags, conditionally on the device
+// (nothing removed = nothing to do): k_rehash_clear empties the table and resets the free-list counters,
+// k_rehash re-inserts the live slots and gathers the free ones (unordered compaction, one atomic per wave).
 __global__ __launch_bounds__(256) void k_rehash_clear(DevMap m) {
   if (m.counters[C_N_REMOVED] == 0u) return;  // nothing was removed: keep the table
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i <= m.ht_mask) m.ht_keys[i] = kEmptyKey;
+  if (i == 0) {
+    m.counters[C_N_FREE] = 0u;
+    m.counters[C_FREE_HEAD] = 0u;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_rehash(DevMap m) {
   if (m.counters[C_N_REMOVED] == 0u) return;
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= m.counters[C_MAX_SLOT]) return;
-  if (!(m.blk_flags[s] & BLK_LIVE)) return;
-  const int4 bi = m.blk_index[s];
-  htInsertUnique(m, packKey(bi.x, bi.y, bi.z), s);
-}
-
-// rebuild the free list after removals: (unordered) compaction of the non-live slots, one wave-aggregated
-// atomic per wave; k_free_list_begin / _end reset and publish the counters
-__global__ void k_free_list_begin(DevMap m) {
-  if (m.counters[C_N_REMOVED] == 0u) return;
-  if (threadIdx.x == 0 && blockIdx.x == 0) m.counters[C_N_FREE] = 0u;
-}
-__global__ __launch_bounds__(256) void k_free_list_fill(DevMap m) {
-  if (m.counters[C_N_REMOVED] == 0u) return;
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool is_free = s < m.capacity && !(m.blk_flags[s] & BLK_LIVE);
+  const bool live = s < m.counters[C_MAX_SLOT] && (m.blk_flags[s] & BLK_LIVE);
+  if (live) {
+    const int4 bi = m.blk_index[s];
+    htInsertUnique(m, packKey(bi.x, bi.y, bi.z), s);
+  }
+  const bool is_free = s < m.capacity && !live;
   const uint32_t idx = waveAggInc(&m.counters[C_N_FREE], is_free);
   if (is_free) m.free_slots[idx] = s;
-}
-__global__ void k_free_list_end(DevMap m) {
-  if (m.counters[C_N_REMOVED] == 0u) return;
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    m.counters[C_FREE_HEAD] = 0u;
-    m.counters[C_N_LIVE] = m.capacity - m.counters[C_N_FREE];
-  }
 }
 
 __global__ __launch_bounds__(256) void k_block_flag_op(DevMap m, uint32_t and_mask, uint32_t or_mask) {

@@ -1609,12 +1609,8 @@ int khr_generate_mesh(khr_ctx* c, int only_mesh_updated, int clear_flag) {
   const size_t cap = m.capacity;
   ScopedTimer tm(c, 5);
   HIP_TRY(hipMemsetAsync(c->d_mesh_nwork, 0, sizeof(uint32_t), c->stream));
-  HIP_TRY(hipMemsetAsync(c->d_regen, 0, cap, c->stream));
-  HIP_TRY(hipMemsetAsync(c->d_mesh_count, 0, sizeof(uint32_t) * (cap + 1), c->stream));
-  hipLaunchKernelGGL(k_list_live, dim3(gridFor(cap)), dim3(256), 0, c->stream, m, c->d_work, c->d_mesh_nwork,
-                     only_mesh_updated ? BLK_MESH_UPDATED : 0u);
-  hipLaunchKernelGGL(k_mesh_carry_counts, dim3(gridFor(cap)), dim3(256), 0, c->stream, m, c->d_mesh_count);
-  hipLaunchKernelGGL(k_mark_regen, dim3(gridFor(cap)), dim3(256), 0, c->stream, c->d_work, c->d_mesh_nwork, c->d_regen);
+  hipLaunchKernelGGL(k_mesh_prepare, dim3(gridFor(cap + 1)), dim3(256), 0, c->stream, m, only_mesh_updated ? BLK_MESH_UPDATED : 0u,
+                     c->d_work, c->d_mesh_nwork, c->d_regen, c->d_mesh_count);
   MeshBuffers src = c->mesh[c->mesh_cur], dst = c->mesh[c->mesh_cur ^ 1];
   RemoteMeshHalo rmh{};
   if (c->mh_n) {
@@ -1655,9 +1651,6 @@ static int resetInactiveLaunch(khr_ctx* c) {
   if (rc) return rc;
   hipLaunchKernelGGL(k_rehash_clear, dim3(gridFor(static_cast<size_t>(m.ht_mask) + 1)), dim3(256), 0, c->stream, m);
   hipLaunchKernelGGL(k_rehash, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m);
-  hipLaunchKernelGGL(k_free_list_begin, dim3(1), dim3(64), 0, c->stream, m);
-  hipLaunchKernelGGL(k_free_list_fill, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m);
-  hipLaunchKernelGGL(k_free_list_end, dim3(1), dim3(64), 0, c->stream, m);
   c->host_index_valid = false;
   c->removed_pending = true;
   HIP_TRY(hipGetLastError());

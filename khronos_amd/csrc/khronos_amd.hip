@@ -4,6 +4,7 @@
 // sequentially (free_space_motion_detector.cpp:205-379).  There is deliberately NO CPU fallback for any
 // kernel: without a HIP device khr_create fails.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -216,6 +217,30 @@ struct ScopedTimer {
     }
   }
 };
+
+// Single-kernel timers use the start / stop events of the dispatch packet itself (hipExtLaunchKernelGGL): the same
+// begin / end timestamps rocprofv3 reports, and no extra barrier packets in the stream.  ScopedTimer (event records
+// around a group of launches) costs ~5 us of stream time per bracket.
+hipEvent_t takeEvent(khr_ctx* c) {
+  hipEvent_t e = nullptr;
+  if (!c->event_pool.empty()) {
+    e = c->event_pool.back();
+    c->event_pool.pop_back();
+  } else {
+    hipEventCreate(&e);
+  }
+  return e;
+}
+#define KHR_LAUNCH_TIMED(which, kernel, grid, block, ...)                                              \
+  do {                                                                                                 \
+    if ((c->timing >> (which)) & 1u) {                                                                 \
+      hipEvent_t ev_a = takeEvent(c), ev_b = takeEvent(c);                                             \
+      hipExtLaunchKernelGGL(kernel, grid, block, 0, c->stream, ev_a, ev_b, 0, __VA_ARGS__);            \
+      c->pending.push_back({(which), ev_a, ev_b});                                                     \
+    } else {                                                                                           \
+      hipLaunchKernelGGL(kernel, grid, block, 0, c->stream, __VA_ARGS__);                              \
+    }                                                                                                  \
+  } while (0)
 
 void resolveTimers(khr_ctx* c) {
   for (auto& r : c->pending) {
@@ -765,7 +790,6 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
   int rc = dispatchVps(c, [&](auto vps) {
     constexpr int V = decltype(vps)::value;
     {
-      ScopedTimer tm(c, 0);
       TsdfArgs a{};
       a.blk_index = m.blk_index; a.blk_flags = m.blk_flags; a.dist = m.dist; a.weight = m.weight;
       a.last_obs = m.last_obs; a.stats = m.stats; a.counters = m.counters;
@@ -783,11 +807,11 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
       auto launch = [&](auto chunks) {
         constexpr int CH = decltype(chunks)::value;
         if (fast)
-          hipLaunchKernelGGL((k_tsdf_update<V, CH, true>), dim3(kTsdfGrid), dim3(256), 0, c->stream, a, tsdf_work,
-                             tsdf_count, c->d_band, c->band_cap / kBandShards, c->d_band_count);
+          KHR_LAUNCH_TIMED(0, (k_tsdf_update<V, CH, true>), dim3(kTsdfGrid), dim3(256), a, tsdf_work, tsdf_count, c->d_band,
+                           c->band_cap / kBandShards, c->d_band_count);
         else
-          hipLaunchKernelGGL((k_tsdf_update<V, CH, false>), dim3(kTsdfGrid), dim3(256), 0, c->stream, a, tsdf_work,
-                             tsdf_count, c->d_band, c->band_cap / kBandShards, c->d_band_count);
+          KHR_LAUNCH_TIMED(0, (k_tsdf_update<V, CH, false>), dim3(kTsdfGrid), dim3(256), a, tsdf_work, tsdf_count, c->d_band,
+                           c->band_cap / kBandShards, c->d_band_count);
       };
       if (V == 8) {
         launch(std::integral_constant<int, 1>());
@@ -799,11 +823,8 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
         }
       }
     }
-    {
-      ScopedTimer tm(c, 7);
-      hipLaunchKernelGGL((k_band_update<V>), dim3(kBandGrid / kBandShards, kBandShards), dim3(256), 0, c->stream, m, c->p, f,
-                         c->d_band, c->band_cap / kBandShards, c->d_band_count, object_id, c->d_wg_stats, kTsdfGrid);
-    }
+    KHR_LAUNCH_TIMED(7, (k_band_update<V>), dim3(kBandGrid / kBandShards, kBandShards), dim3(256), m, c->p, f, c->d_band,
+                     c->band_cap / kBandShards, c->d_band_count, object_id, c->d_wg_stats, kTsdfGrid);
     return KHR_OK;
   });
   if (rc) return rc;

@@ -314,6 +314,30 @@ int khr_timing_enable(khr_ctx* ctx, int enable);
 int khr_timing_reset(khr_ctx* ctx);
 int khr_timing_get(khr_ctx* ctx, int which, double* total_ms, uint64_t* launches);
 
+/* -- ray verification (backend change detection) ------------------------------------------
+ * replaces: khronos::RayVerificator (khronos/src/backend/change_detection/ray_verificator.cpp).  A ray is one
+ * (sensor position, mesh vertex, timestamp) measurement.  Rays are marched through a block grid once
+ * (addRayToHash, :327-349); a query point is tested against every ray that crossed its block (check, :66-145) and
+ * returns the timestamps of the rays that saw it (present) or saw through it (absent).  The reference reads
+ * sources / targets out of the scene graph (RayLookup); here the caller passes them as arrays. */
+typedef struct khr_rayver khr_rayver;
+/* RayVerificator::Config {block_size, radial_tolerance, depth_tolerance} with the checks of :59-61 */
+int khr_rv_create(float block_size, float radial_tolerance, float depth_tolerance, int device, khr_rayver** out);
+void khr_rv_destroy(khr_rayver* rv);
+/* setDsg(): forget all rays */
+int khr_rv_clear(khr_rayver* rv);
+/* addVertices() / addRayToHash(): append n rays (stamps[n], sources[3n], targets[3n], host memory) and index them */
+int khr_rv_add_rays(khr_rayver* rv, int64_t n, const uint64_t* stamps, const float* sources, const float* targets);
+int64_t khr_rv_num_rays(khr_rayver* rv);
+int64_t khr_rv_num_pairs(khr_rayver* rv); /* distinct (block, ray) entries of the index */
+/* check() for m points at once: points[3m], earliest[m], latest[m] (inclusive stamp window per point).  Writes the
+ * per-point counts (may be NULL) and the totals; the stamps themselves are fetched with khr_rv_check_stamps:
+ * present_stamps[total_present] / absent_stamps[total_absent], grouped by point in query order, within a point in
+ * ascending ray order (the reference iterates an unordered set; ASSUMPTIONS.md C.5). */
+int khr_rv_check(khr_rayver* rv, int64_t m, const float* points, const uint64_t* earliest, const uint64_t* latest,
+                 uint32_t* n_present, uint32_t* n_absent, uint64_t* total_present, uint64_t* total_absent);
+int khr_rv_check_stamps(khr_rayver* rv, uint64_t* present_stamps, uint64_t* absent_stamps);
+
 #ifdef __cplusplus
 }
 #endif

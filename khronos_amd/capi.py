@@ -77,6 +77,8 @@ EXPORTS = [
     "khr_detect_motion_from_keys", "khr_download_updated", "khr_mesh_halo_requests", "khr_mesh_halo_export",
     "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",
     "khr_cluster_voxels", "khr_download_frame_image",
+    "khr_rv_create", "khr_rv_destroy", "khr_rv_clear", "khr_rv_add_rays", "khr_rv_num_rays", "khr_rv_num_pairs", "khr_rv_check",
+    "khr_rv_check_stamps",
 ]
 
 _lib = None
@@ -122,6 +124,17 @@ def load_library():
     lib.khr_configure_object_detector.argtypes = [vp, C.POINTER(KhrObjectDetectorConfig)]
     lib.khr_detect_objects.argtypes = [vp, i32]
     lib.khr_download_frame_image.argtypes = [vp, i32, i32, vp]
+    lib.khr_rv_create.argtypes = [C.c_float, C.c_float, C.c_float, i32, C.POINTER(vp)]
+    lib.khr_rv_destroy.argtypes = [vp]
+    lib.khr_rv_destroy.restype = None
+    lib.khr_rv_clear.argtypes = [vp]
+    lib.khr_rv_add_rays.argtypes = [vp, C.c_int64, vp, vp, vp]
+    lib.khr_rv_num_rays.argtypes = [vp]
+    lib.khr_rv_num_rays.restype = C.c_int64
+    lib.khr_rv_num_pairs.argtypes = [vp]
+    lib.khr_rv_num_pairs.restype = C.c_int64
+    lib.khr_rv_check.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.khr_rv_check_stamps.argtypes = [vp, vp, vp]
     lib.khr_get_semantic_clusters.argtypes = [vp, i32, C.POINTER(KhrCluster), i32]
     lib.khr_cluster_voxels.argtypes = [vp, i32, i32, C.c_float, vp, vp, C.c_int64]
     lib.khr_cluster_voxels.restype = C.c_int64
@@ -500,3 +513,60 @@ class FusionContext:
         ms, n = C.c_double(0), C.c_uint64(0)
         self._chk(self.lib.khr_timing_get(self.h, self.TIMERS[name], C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class RayVerificator:
+    """ctypes wrapper of the khr_rv_* calls (khronos::RayVerificator on the device, SURVEY.md section 8 f4)."""
+
+    def __init__(self, block_size=1.0, radial_tolerance=0.1, depth_tolerance=0.1, device=0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        rc = self.lib.khr_rv_create(float(block_size), float(radial_tolerance), float(depth_tolerance), int(device), C.byref(self.h))
+        if rc < 0:
+            raise KhronosAmdError("khr_rv_create failed (%d): %s" % (rc, self.lib.khr_last_error().decode()))
+
+    def close(self):
+        if self.h:
+            self.lib.khr_rv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise KhronosAmdError("khr_rv call failed (%d): %s" % (rc, self.lib.khr_last_error().decode()))
+        return rc
+
+    def clear(self):
+        self._chk(self.lib.khr_rv_clear(self.h))
+
+    def add_rays(self, stamps, sources, targets):
+        st = np.ascontiguousarray(stamps, dtype=np.uint64)
+        sr = np.ascontiguousarray(sources, dtype=np.float32).reshape(-1, 3)
+        tg = np.ascontiguousarray(targets, dtype=np.float32).reshape(-1, 3)
+        assert st.size == sr.shape[0] == tg.shape[0]
+        self._chk(self.lib.khr_rv_add_rays(self.h, st.size, _ptr(st), _ptr(sr), _ptr(tg)))
+
+    def num_rays(self):
+        return self._chk(self.lib.khr_rv_num_rays(self.h))
+
+    def num_pairs(self):
+        return self._chk(self.lib.khr_rv_num_pairs(self.h))
+
+    def check(self, points, earliest, latest):
+        """-> (n_present[m], n_absent[m], present_stamps, absent_stamps); stamps grouped by point in query order."""
+        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        m = pts.shape[0]
+        t0 = np.ascontiguousarray(np.broadcast_to(np.asarray(earliest, np.uint64), (m,)))
+        t1 = np.ascontiguousarray(np.broadcast_to(np.asarray(latest, np.uint64), (m,)))
+        npres, nabs = np.zeros(max(m, 1), np.uint32), np.zeros(max(m, 1), np.uint32)
+        tp, ta = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self.lib.khr_rv_check(self.h, m, _ptr(pts), _ptr(t0), _ptr(t1), _ptr(npres), _ptr(nabs), C.byref(tp), C.byref(ta)))
+        pres, absn = np.zeros(max(tp.value, 1), np.uint64), np.zeros(max(ta.value, 1), np.uint64)
+        if m:
+            self._chk(self.lib.khr_rv_check_stamps(self.h, _ptr(pres), _ptr(absn)))
+        return npres[:m], nabs[:m], pres[:tp.value], absn[:ta.value]

@@ -379,6 +379,9 @@ constexpr int kBandGrid = 2048;
 
 extern "C" {
 
+// other translation units of the library (khr_rayver.hip) report through the same per-thread error text
+extern "C" void khr_set_last_error(const char* text) { g_last_error = text ? text : ""; }
+
 const char* khr_last_error(void) { return g_last_error.c_str(); }
 
 void khr_default_config(khr_config* cfg) {

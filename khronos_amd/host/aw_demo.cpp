@@ -12,6 +12,7 @@
 #include <sstream>
 
 #include "active_window.h"
+#include "ray_verificator.h"
 
 extern "C" {
 void* synth_create(uint32_t seed, int num_static, int with_mover);
@@ -80,7 +81,74 @@ static void circlePose(double t, double* T) {
   T[15] = 1;
 }
 
+// aw_demo --rayver <policy>: drives khronos::RayVerificator (host mirror over the device index) with a scenario from
+// stdin and prints the check results as JSON lines (tests/test_gpu_host.py compares them with the oracle).
+//   P <n> then n lines "<stamp> x y z"          agent poses (sorted by time)
+//   V <n> then n lines "<first> <last> x y z"   mesh vertices; every P / V block is followed by an update
+//   Q <n> then n lines "<earliest> <latest> x y z"
+static int rayverDemo(const char* policy) {
+  RayVerificator::Config cfg;
+  const char* names[] = {"First", "Last", "FirstAndLast", "Middle", "All"};
+  for (int i = 0; i < 5; ++i)
+    if (std::string(policy) == names[i]) cfg.ray_policy = static_cast<RayVerificator::Config::RayPolicy>(i);
+  std::cin >> cfg.block_size >> cfg.radial_tolerance >> cfg.depth_tolerance >> cfg.active_window_duration;
+  RayVerificator rv(cfg);
+  std::vector<uint64_t> pose_stamps, first_seen, last_seen;
+  std::vector<float> pose_pos, vertices;
+  std::string tok;
+  while (std::cin >> tok) {
+    size_t n = 0;
+    std::cin >> n;
+    if (tok == "P") {
+      for (size_t i = 0; i < n; ++i) {
+        uint64_t t; float x, y, z;
+        std::cin >> t >> x >> y >> z;
+        pose_stamps.push_back(t);
+        pose_pos.insert(pose_pos.end(), {x, y, z});
+      }
+    } else if (tok == "V") {
+      for (size_t i = 0; i < n; ++i) {
+        uint64_t a, b; float x, y, z;
+        std::cin >> a >> b >> x >> y >> z;
+        first_seen.push_back(a);
+        last_seen.push_back(b);
+        vertices.insert(vertices.end(), {x, y, z});
+      }
+      rv.updateData(pose_stamps, pose_pos, vertices, first_seen, last_seen);
+    } else if (tok == "Q") {
+      std::vector<float> pts;
+      std::vector<uint64_t> t0, t1;
+      for (size_t i = 0; i < n; ++i) {
+        uint64_t a, b; float x, y, z;
+        std::cin >> a >> b >> x >> y >> z;
+        t0.push_back(a);
+        t1.push_back(b);
+        pts.insert(pts.end(), {x, y, z});
+      }
+      const auto res = rv.checkMany(pts, t0, t1);
+      std::printf("{\"rays\": %zu, \"results\": [", rv.numRays());
+      for (size_t i = 0; i < res.size(); ++i) {
+        std::printf("%s{\"present\": [", i ? ", " : "");
+        for (size_t k = 0; k < res[i].present.size(); ++k) std::printf("%s%" PRIu64, k ? ", " : "", res[i].present[k]);
+        std::printf("], \"absent\": [");
+        for (size_t k = 0; k < res[i].absent.size(); ++k) std::printf("%s%" PRIu64, k ? ", " : "", res[i].absent[k]);
+        std::printf("]}");
+      }
+      std::printf("]}\n");
+    }
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 3 && std::string(argv[1]) == "--rayver") {
+    try {
+      return rayverDemo(argv[2]);
+    } catch (const std::exception& e) {
+      std::fprintf(stderr, "aw_demo: %s\n", e.what());
+      return 1;
+    }
+  }
   if (argc < 5) {
     std::fprintf(stderr, "usage: aw_demo <config.yaml> <width> <height> <frames> [object_label]\n");
     return 2;

@@ -872,6 +872,97 @@ int64_t orc_cluster_voxels(const orc_config* cfg, const orc_sensor* s, const orc
   return k;
 }
 
+// ---------------------------------------------------------------------------------------------
+// RayVerificator (khronos/src/backend/change_detection/ray_verificator.cpp)
+// ---------------------------------------------------------------------------------------------
+struct orc_rayver {
+  float block_size, inv, radial_tol, depth_tol;
+  std::vector<uint64_t> stamp;
+  std::vector<std::array<float, 3>> src, tgt;
+  std::map<std::array<int64_t, 3>, std::set<size_t>> block_seen_by_rays;  // ordered containers: ascending ray index
+};
+
+static inline std::array<float, 3> rvSub(const std::array<float, 3>& a, const std::array<float, 3>& b) {
+  return {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
+}
+static inline float rvDot(const std::array<float, 3>& a, const std::array<float, 3>& b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+static inline float rvNorm(const std::array<float, 3>& a) { return std::sqrt(rvDot(a, a)); }
+
+orc_rayver* orc_rv_create(float block_size, float radial_tolerance, float depth_tolerance) {
+  auto* rv = new orc_rayver();
+  rv->block_size = block_size;
+  rv->inv = 1.f / block_size;
+  rv->radial_tol = radial_tolerance;
+  rv->depth_tol = depth_tolerance;
+  return rv;
+}
+void orc_rv_destroy(orc_rayver* rv) { delete rv; }
+
+void orc_rv_add_rays(orc_rayver* rv, int64_t n, const uint64_t* stamps, const float* sources, const float* targets) {
+  for (int64_t i = 0; i < n; ++i) {
+    rv->stamp.push_back(stamps[i]);
+    rv->src.push_back({sources[3 * i], sources[3 * i + 1], sources[3 * i + 2]});
+    rv->tgt.push_back({targets[3 * i], targets[3 * i + 1], targets[3 * i + 2]});
+    const size_t ray_index = rv->stamp.size() - 1;
+    // addRayToHash (:327-349)
+    const auto& source = rv->src.back();
+    const auto d = rvSub(rv->tgt.back(), source);
+    const float max_depth = rvNorm(d);
+    if (!std::isfinite(max_depth) || !(max_depth > 0.f)) continue;  // reference: endless march / NaN block index (undefined)
+    const std::array<float, 3> direction = {d[0] / max_depth, d[1] / max_depth, d[2] / max_depth};
+    const float ray_step = rv->block_size / 4;
+    float ray_distance = 0.f;
+    while (ray_distance <= max_depth) {
+      ray_distance += ray_step;
+      const std::array<float, 3> p = {source[0] + ray_distance * direction[0], source[1] + ray_distance * direction[1],
+                                      source[2] + ray_distance * direction[2]};
+      const std::array<int64_t, 3> index = {static_cast<int64_t>(std::floor(p[0] * rv->inv)), static_cast<int64_t>(std::floor(p[1] * rv->inv)),
+                                            static_cast<int64_t>(std::floor(p[2] * rv->inv))};
+      rv->block_seen_by_rays[index].insert(ray_index);
+    }
+  }
+}
+
+int64_t orc_rv_num_pairs(const orc_rayver* rv) {
+  int64_t n = 0;
+  for (const auto& kv : rv->block_seen_by_rays) n += static_cast<int64_t>(kv.second.size());
+  return n;
+}
+
+void orc_rv_check(const orc_rayver* rv, const float* pt, uint64_t earliest, uint64_t latest, uint64_t* present, int64_t cap_present,
+                  int64_t* n_present, uint64_t* absent, int64_t cap_absent, int64_t* n_absent) {
+  // check (:66-145)
+  *n_present = 0;
+  *n_absent = 0;
+  const std::array<float, 3> point = {pt[0], pt[1], pt[2]};
+  const std::array<int64_t, 3> index = {static_cast<int64_t>(std::floor(point[0] * rv->inv)), static_cast<int64_t>(std::floor(point[1] * rv->inv)),
+                                        static_cast<int64_t>(std::floor(point[2] * rv->inv))};
+  const auto it = rv->block_seen_by_rays.find(index);
+  if (it == rv->block_seen_by_rays.end()) return;
+  for (size_t ray_index : it->second) {
+    const uint64_t ts = rv->stamp[ray_index];
+    if (ts < earliest || ts > latest) continue;
+    const auto& source = rv->src[ray_index];
+    const auto& vertex = rv->tgt[ray_index];
+    const auto ps = rvSub(point, source);
+    const float depth = rvNorm(ps);
+    const std::array<float, 3> direction = {ps[0] / depth, ps[1] / depth, ps[2] / depth};
+    const auto sv = rvSub(source, vertex);
+    const std::array<float, 3> cr = {ps[1] * sv[2] - ps[2] * sv[1], ps[2] * sv[0] - ps[0] * sv[2], ps[0] * sv[1] - ps[1] * sv[0]};
+    const float radial_distance = rvNorm(cr) / depth;
+    if (radial_distance > rv->radial_tol) continue;
+    const float depth_distance = rvDot(rvSub(vertex, source), direction);
+    if (depth - depth_distance > rv->depth_tol) continue;
+    if (depth_distance - depth > rv->depth_tol) {
+      if (*n_absent < cap_absent) absent[*n_absent] = ts;
+      ++*n_absent;
+    } else {
+      if (*n_present < cap_present) present[*n_present] = ts;
+      ++*n_present;
+    }
+  }
+}
+
 void orc_allocate_block(orc_map* m, int32_t bx, int32_t by, int32_t bz) { m->allocate({bx, by, bz}); }
 
 int64_t orc_num_blocks(const orc_map* m) { return static_cast<int64_t>(m->blocks.size()); }

@@ -172,6 +172,17 @@ int orc_detect_objects(const orc_config* cfg, const orc_object_detector_config* 
 int64_t orc_cluster_voxels(const orc_config* cfg, const orc_sensor* s, const orc_frame* f, const int32_t* id_image,
                            float voxel_size, int32_t* ids_out, int64_t* voxels_out, int64_t cap);
 
+/* khronos::RayVerificator (khronos/src/backend/change_detection/ray_verificator.cpp): rays given as arrays
+ * (the reference looks sources / targets up in the scene graph).  check() output in ascending ray order
+ * (ASSUMPTIONS.md C.5). */
+typedef struct orc_rayver orc_rayver;
+orc_rayver* orc_rv_create(float block_size, float radial_tolerance, float depth_tolerance);
+void orc_rv_destroy(orc_rayver* rv);
+void orc_rv_add_rays(orc_rayver* rv, int64_t n, const uint64_t* stamps, const float* sources, const float* targets);
+int64_t orc_rv_num_pairs(const orc_rayver* rv);
+void orc_rv_check(const orc_rayver* rv, const float* point, uint64_t earliest, uint64_t latest, uint64_t* present,
+                  int64_t cap_present, int64_t* n_present, uint64_t* absent, int64_t cap_absent, int64_t* n_absent);
+
 /* explicit allocation (mesh_object_extractor.cpp:218-228) */
 void orc_allocate_block(orc_map* m, int32_t bx, int32_t by, int32_t bz);
 

@@ -96,6 +96,16 @@ def load():
                                        C.POINTER(OrcFrame), vp, C.POINTER(OrcCluster), i32]
     lib.orc_cluster_voxels.argtypes = [C.POINTER(OrcConfig), C.POINTER(OrcSensor), C.POINTER(OrcFrame), vp, C.c_float, vp, vp, i64]
     lib.orc_cluster_voxels.restype = i64
+    lib.orc_rv_create.argtypes = [C.c_float, C.c_float, C.c_float]
+    lib.orc_rv_create.restype = vp
+    lib.orc_rv_destroy.argtypes = [vp]
+    lib.orc_rv_destroy.restype = None
+    lib.orc_rv_add_rays.argtypes = [vp, i64, vp, vp, vp]
+    lib.orc_rv_add_rays.restype = None
+    lib.orc_rv_num_pairs.argtypes = [vp]
+    lib.orc_rv_num_pairs.restype = i64
+    lib.orc_rv_check.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64)]
+    lib.orc_rv_check.restype = None
     lib.orc_generate_mesh.argtypes = [vp, i32, i32]
     lib.orc_generate_mesh.restype = i64
     lib.orc_mesh_halo_requests.argtypes = [vp, i32, vp, i64]
@@ -336,3 +346,48 @@ class OracleMap:
             raise KeyError(tuple(idx))
         b["block_flags"] = int(bf[0])
         return b
+
+
+class OracleRayVerificator:
+    """CPU restatement of khronos::RayVerificator (test infrastructure)."""
+
+    def __init__(self, block_size=1.0, radial_tolerance=0.1, depth_tolerance=0.1):
+        self.lib = load()
+        self.h = self.lib.orc_rv_create(float(block_size), float(radial_tolerance), float(depth_tolerance))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.orc_rv_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def add_rays(self, stamps, sources, targets):
+        st = np.ascontiguousarray(stamps, dtype=np.uint64)
+        sr = np.ascontiguousarray(sources, dtype=np.float32).reshape(-1, 3)
+        tg = np.ascontiguousarray(targets, dtype=np.float32).reshape(-1, 3)
+        self.lib.orc_rv_add_rays(self.h, st.size, _ptr(st), _ptr(sr), _ptr(tg))
+
+    def num_pairs(self):
+        return self.lib.orc_rv_num_pairs(self.h)
+
+    def check_one(self, point, earliest=0, latest=2 ** 64 - 1, cap=1 << 16):
+        p = np.ascontiguousarray(point, dtype=np.float32)
+        pres, absn = np.zeros(cap, np.uint64), np.zeros(cap, np.uint64)
+        n_p, n_a = C.c_int64(0), C.c_int64(0)
+        self.lib.orc_rv_check(self.h, _ptr(p), int(earliest), int(latest), _ptr(pres), cap, C.byref(n_p), _ptr(absn), cap, C.byref(n_a))
+        assert n_p.value <= cap and n_a.value <= cap
+        return pres[: n_p.value].copy(), absn[: n_a.value].copy()
+
+    def check(self, points, earliest, latest):
+        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        m = pts.shape[0]
+        t0 = np.broadcast_to(np.asarray(earliest, np.uint64), (m,))
+        t1 = np.broadcast_to(np.asarray(latest, np.uint64), (m,))
+        npres, nabs, pres, absn = [], [], [], []
+        for i in range(m):
+            a, b = self.check_one(pts[i], int(t0[i]), int(t1[i]))
+            npres.append(len(a)); nabs.append(len(b)); pres.append(a); absn.append(b)
+        cat = lambda l: np.concatenate(l) if l else np.zeros(0, np.uint64)
+        return np.array(npres, np.uint32), np.array(nabs, np.uint32), cat(pres), cat(absn)

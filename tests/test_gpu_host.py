@@ -237,3 +237,80 @@ def test_active_window_with_detector_and_tracker_plugins(tmp_path):
     for o in res["objects"]:
         if not o["dynamic"]:
             assert o["label"] in cats and o["vertices"] > 0
+
+
+def _vertex_sources(policy, stamps, first, last):
+    """Python restatement of RayVerificator::computeVertexSources (ray_verificator.cpp:266-325), deterministic policies."""
+    import bisect
+    out = set()
+    n = len(stamps)
+    if policy in ("First", "FirstAndLast"):
+        i = bisect.bisect_right(stamps, first)
+        if i < n:
+            out.add(i)
+    if policy in ("Last", "FirstAndLast"):
+        i = bisect.bisect_left(stamps, last)
+        if i < n:
+            out.add(i)
+    if policy == "Middle":
+        i = bisect.bisect_left(stamps, (last + first) // 2)
+        if i < n:
+            out.add(i)
+    if policy == "All":
+        out.update(range(bisect.bisect_right(stamps, first), bisect.bisect_left(stamps, last)))
+    return sorted(out)
+
+
+@pytest.mark.parametrize("policy", ["Middle", "FirstAndLast", "All", "First", "Last"])
+def test_ray_verificator_host_mirror(policy):
+    """C++ khronos::RayVerificator mirror (pose / mesh arrays -> rays by policy -> device index -> check) against the
+    oracle fed with the rays a Python restatement of computeVertexSources selects."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(5)
+    T = 1_000_000_000
+    n_poses = 30
+    pose_t = [(1 + k) * T // 2 for k in range(n_poses)]
+    th = np.linspace(0, 2 * np.pi, n_poses, endpoint=False)
+    pose_p = np.stack([1.5 * np.cos(th), 1.5 * np.sin(th), np.full(n_poses, 1.5)], 1).astype(np.float32)
+    window = 1.0  # active_window_duration [s]: last_seen stamps are shifted back by it (ray_verificator.cpp:232-237)
+
+    def verts(n):
+        p = rng.uniform([-4, -3, 0], [4, 3, 3], (n, 3)).astype(np.float32)
+        p[:, rng.integers(0, 3)] = np.float32(-3.0)
+        a = rng.integers(0, n_poses - 6, n)
+        first = np.array([pose_t[i] for i in a], np.int64) + rng.integers(-T // 4, T // 4, n)
+        last = first + rng.integers(0, 5 * T, n) + int(window * 1e9)
+        return p, np.maximum(first, 0), last
+
+    lines = ["1.0 0.1 0.1 %r" % window]
+    ora = po.OracleRayVerificator(1.0, 0.1, 0.1)
+    all_p = []
+    for batch, (npose, nv) in enumerate([(18, 250), (30, 250)]):
+        lo = 0 if batch == 0 else 18
+        lines.append("P %d" % (npose - lo))
+        lines += ["%d %r %r %r" % (pose_t[i], *map(float, pose_p[i])) for i in range(lo, npose)]
+        p, first, last = verts(nv)
+        all_p.append(p)
+        lines.append("V %d" % nv)
+        lines += ["%d %d %r %r %r" % (first[i], last[i], *map(float, p[i])) for i in range(nv)]
+        st, sr, tg = [], [], []
+        for i in range(nv):
+            for s in _vertex_sources(policy, pose_t[:npose], int(first[i]), int(last[i]) - int(np.float32(window) * 1e9)):
+                st.append(pose_t[s]); sr.append(pose_p[s]); tg.append(p[i])
+        if st:
+            ora.add_rays(st, sr, tg)
+    pts = np.concatenate(all_p)[::3]
+    q = np.concatenate([pts, 0.5 * (pts + pose_p[rng.integers(0, n_poses, len(pts))])]).astype(np.float32)
+    t0 = rng.integers(0, 6, len(q)) * T
+    t1 = t0 + rng.integers(1, 12, len(q)) * T
+    lines.append("Q %d" % len(q))
+    lines += ["%d %d %r %r %r" % (t0[i], t1[i], *map(float, q[i])) for i in range(len(q))]
+    out = subprocess.run([DEMO, "--rayver", policy], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    n_hits = 0
+    for i, r in enumerate(res["results"]):
+        pres, absn = ora.check_one(q[i], int(t0[i]), int(t1[i]))
+        assert r["present"] == [int(x) for x in pres] and r["absent"] == [int(x) for x in absn], i
+        n_hits += len(pres) + len(absn)
+    assert res["rays"] > 300 and n_hits > 20

@@ -1,0 +1,89 @@
+"""GPU parity for the ray verificator: khr_rv_* against the oracle restatement of
+khronos::RayVerificator, bit-exact (counts and timestamp lists in ascending ray order)."""
+import numpy as np
+import pytest
+
+from khronos_amd import RayVerificator
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+T = 1_000_000_000
+
+
+def _scene(rng, n_poses, n_per_pose):
+    """sensor positions on a circle inside an 8 x 6 x 3 m room; every pose sees points on the walls / floor."""
+    stamps, src, tgt = [], [], []
+    for k in range(n_poses):
+        th = 2 * np.pi * k / n_poses
+        s = np.array([1.5 * np.cos(th), 1.5 * np.sin(th), 1.5], np.float32)
+        d = rng.normal(size=(n_per_pose, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        # distance to the room box [-4,4] x [-3,3] x [0,3]
+        lo, hi = np.array([-4, -3, 0], np.float32), np.array([4, 3, 3], np.float32)
+        with np.errstate(divide="ignore"):
+            t = np.where(d > 0, (hi - s) / d, (lo - s) / d)
+        dist = np.minimum(t.min(1), 5.0).astype(np.float32)
+        p = (s + d * dist[:, None]).astype(np.float32)
+        stamps += [np.full(n_per_pose, (1 + k) * T, np.uint64)]
+        src += [np.repeat(s[None], n_per_pose, 0)]
+        tgt += [p]
+    return np.concatenate(stamps), np.concatenate(src), np.concatenate(tgt)
+
+
+def _compare(dev, ora, pts, t0, t1):
+    g = dev.check(pts, t0, t1)
+    o = ora.check(pts, t0, t1)
+    for a, b, name in zip(g, o, ("n_present", "n_absent", "present", "absent")):
+        assert a.shape == b.shape and np.array_equal(a, b), name
+    return g
+
+
+@pytest.mark.parametrize("block_size,radial,depth", [(1.0, 0.1, 0.1), (0.5, 0.05, 0.2), (2.0, 0.3, 0.05)])
+def test_rayver_parity(block_size, radial, depth):
+    rng = np.random.default_rng(11)
+    st, src, tgt = _scene(rng, 12, 400)
+    dev, ora = RayVerificator(block_size, radial, depth), po.OracleRayVerificator(block_size, radial, depth)
+    # two batches: the index is extended, not rebuilt from scratch by the caller
+    half = len(st) // 2
+    for sl in (slice(0, half), slice(half, None)):
+        dev.add_rays(st[sl], src[sl], tgt[sl])
+        ora.add_rays(st[sl], src[sl], tgt[sl])
+        assert dev.num_pairs() == ora.num_pairs() > 0
+    assert dev.num_rays() == len(st)
+    # queries: measured surface points (present by their own ray, absent / occluded for others), points half-way along
+    # rays (absent), random points, points outside everything
+    sel = rng.choice(len(st), 300, replace=False)
+    pts = np.concatenate([tgt[sel], 0.5 * (src[sel] + tgt[sel]), rng.uniform([-4, -3, 0], [4, 3, 3], (300, 3)).astype(np.float32),
+                          np.array([[50.0, 50.0, 50.0], [-7.5, 0.0, 1.0]], np.float32)]).astype(np.float32)
+    g = _compare(dev, ora, pts, 0, 2 ** 64 - 1)
+    assert g[0].sum() > 300 and g[1].sum() > 300
+    # per-point time windows (ray_background_change_detector.cpp:92 / ray_object_change_detector.cpp:127-134)
+    t0 = rng.integers(0, 8, len(pts)).astype(np.uint64) * T
+    t1 = t0 + rng.integers(0, 6, len(pts)).astype(np.uint64) * T
+    _compare(dev, ora, pts, t0, t1)
+    # setDsg(): start over
+    dev.clear()
+    assert dev.num_rays() == 0 and dev.num_pairs() == 0
+    n_p, n_a, pres, absn = dev.check(pts[:10], 0, 2 ** 64 - 1)
+    assert n_p.sum() == 0 and n_a.sum() == 0 and len(pres) == 0 and len(absn) == 0
+
+
+def test_rayver_edge_cases():
+    dev, ora = RayVerificator(1.0, 0.1, 0.1), po.OracleRayVerificator(1.0, 0.1, 0.1)
+    assert dev.check(np.zeros((3, 3), np.float32), 0, 1)[0].sum() == 0  # no rays yet
+    # zero-length ray (left out of the index), axis-parallel rays on block borders, negative coordinates, many rays in one block
+    st = np.arange(1, 203, dtype=np.uint64) * T
+    src = np.zeros((202, 3), np.float32)
+    tgt = np.zeros((202, 3), np.float32)
+    tgt[1] = [3.0, 0.0, 0.0]
+    tgt[2:] = np.stack([np.full(200, -2.0), np.linspace(-0.4, 0.4, 200), np.full(200, -1.0)], 1)
+    dev.add_rays(st, src, tgt)
+    ora.add_rays(st, src, tgt)
+    assert dev.num_pairs() == ora.num_pairs()
+    pts = np.concatenate([tgt, 0.5 * tgt, [[1.0, 0.0, 0.0], [2.0, 0.0, 0.0], [-1.0, 0.0, -0.5]]]).astype(np.float32)
+    g = _compare(dev, ora, pts, 0, 2 ** 64 - 1)
+    assert g[0].max() > 5  # neighbouring rays of the fan agree on their end points
+    with pytest.raises(Exception):
+        RayVerificator(0.0, 0.1, 0.1)
+    with pytest.raises(Exception):
+        RayVerificator(1.0, 0.1, -1.0)

@@ -104,9 +104,12 @@ __global__ __launch_bounds__(256) void k_rv_check(const float* __restrict__ pts,
                                                  float radial_tol, float depth_tol, uint32_t* __restrict__ n_present,
                                                  uint32_t* __restrict__ n_absent, const uint32_t* __restrict__ off_present,
                                                  const uint32_t* __restrict__ off_absent, uint64_t* __restrict__ out_present,
-                                                 uint64_t* __restrict__ out_absent) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= m) return;
+                                                 uint64_t* __restrict__ out_absent, const uint32_t* __restrict__ order) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= m) return;
+  // queries are visited in block-key order: the lanes of a wave then sweep the same ray segment (uniform, cached loads)
+  // instead of 64 unrelated ones; results go to the query's own slot, so the output order is the caller's
+  const uint32_t q = order[tid];
   const V3 point = {pts[3 * q], pts[3 * q + 1], pts[3 * q + 2]};
   const uint64_t key = blockKeyOf(point, inv);
   // first pair of the block (lower bound)
@@ -142,6 +145,14 @@ __global__ __launch_bounds__(256) void k_rv_check(const float* __restrict__ pts,
     n_present[q] = np;
     n_absent[q] = na;
   }
+}
+
+__global__ __launch_bounds__(256) void k_rv_query_keys(const float* __restrict__ pts, uint32_t m, float inv, uint64_t* __restrict__ keys,
+                                                      uint32_t* __restrict__ idx) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= m) return;
+  keys[q] = blockKeyOf({pts[3 * q], pts[3 * q + 1], pts[3 * q + 2]}, inv);
+  idx[q] = q;
 }
 
 template <typename T>
@@ -190,6 +201,8 @@ struct khr_rayver {
   uint32_t* d_oa = nullptr; size_t cap_oa = 0;
   uint64_t* d_outp = nullptr; size_t cap_outp = 0;
   uint64_t* d_outa = nullptr; size_t cap_outa = 0;
+  uint64_t* d_qkey[2] = {nullptr, nullptr}; size_t cap_qkey[2] = {0, 0};
+  uint32_t* d_qidx[2] = {nullptr, nullptr}; size_t cap_qidx[2] = {0, 0};
   size_t last_m = 0;
   uint64_t last_present = 0, last_absent = 0;
 };
@@ -230,7 +243,9 @@ void khr_rv_destroy(khr_rayver* rv) {
                   static_cast<void*>(rv->d_vals[1]), static_cast<void*>(rv->d_u32a), static_cast<void*>(rv->d_u32b), rv->d_temp,
                   static_cast<void*>(rv->d_pts), static_cast<void*>(rv->d_t0), static_cast<void*>(rv->d_t1),
                   static_cast<void*>(rv->d_np), static_cast<void*>(rv->d_na), static_cast<void*>(rv->d_op),
-                  static_cast<void*>(rv->d_oa), static_cast<void*>(rv->d_outp), static_cast<void*>(rv->d_outa)})
+                  static_cast<void*>(rv->d_oa), static_cast<void*>(rv->d_outp), static_cast<void*>(rv->d_outa),
+                  static_cast<void*>(rv->d_qkey[0]), static_cast<void*>(rv->d_qkey[1]), static_cast<void*>(rv->d_qidx[0]),
+                  static_cast<void*>(rv->d_qidx[1])})
     if (p) hipFree(p);
   hipStreamDestroy(rv->stream);
   delete rv;
@@ -354,9 +369,31 @@ int khr_rv_check(khr_rayver* rv, int64_t m, const float* points, const uint64_t*
   RV_TRY(hipMemsetAsync(rv->d_np + M, 0, sizeof(uint32_t), rv->stream));
   RV_TRY(hipMemsetAsync(rv->d_na + M, 0, sizeof(uint32_t), rv->stream));
   const int grid = static_cast<int>((M + 255) / 256);
+  // visit order: queries sorted by block key
+  for (int b = 0; b < 2; ++b) {
+    if ((rc = growBuffer(&rv->d_qkey[b], &rv->cap_qkey[b], M, 0, rv->stream))) return rc;
+    if ((rc = growBuffer(&rv->d_qidx[b], &rv->cap_qidx[b], M, 0, rv->stream))) return rc;
+  }
+  hipLaunchKernelGGL(k_rv_query_keys, dim3(grid), dim3(256), 0, rv->stream, rv->d_pts, static_cast<uint32_t>(M), rv->inv, rv->d_qkey[0],
+                     rv->d_qidx[0]);
+  {
+    size_t tb = 0;
+    RV_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, rv->d_qkey[0], rv->d_qkey[1], rv->d_qidx[0], rv->d_qidx[1], static_cast<int>(M),
+                                              0, 63, rv->stream));
+    if (tb > rv->cap_temp) {
+      if (rv->d_temp) hipFree(rv->d_temp);
+      rv->d_temp = nullptr;
+      rv->cap_temp = 0;
+      RV_TRY(hipMalloc(&rv->d_temp, tb));
+      rv->cap_temp = tb;
+    }
+    tb = rv->cap_temp;
+    RV_TRY(hipcub::DeviceRadixSort::SortPairs(rv->d_temp, tb, rv->d_qkey[0], rv->d_qkey[1], rv->d_qidx[0], rv->d_qidx[1], static_cast<int>(M),
+                                              0, 63, rv->stream));
+  }
   hipLaunchKernelGGL((k_rv_check<false>), dim3(grid), dim3(256), 0, rv->stream, rv->d_pts, rv->d_t0, rv->d_t1, static_cast<uint32_t>(M),
                      rv->d_keys[0], rv->d_vals[0], static_cast<uint32_t>(rv->n_pairs), rv->d_stamp, rv->d_src, rv->d_tgt, rv->inv,
-                     rv->radial_tol, rv->depth_tol, rv->d_np, rv->d_na, nullptr, nullptr, nullptr, nullptr);
+                     rv->radial_tol, rv->depth_tol, rv->d_np, rv->d_na, nullptr, nullptr, nullptr, nullptr, rv->d_qidx[1]);
   RV_TRY(hipGetLastError());
   for (int which = 0; which < 2; ++which) {
     size_t tb = 0;
@@ -399,7 +436,7 @@ int khr_rv_check_stamps(khr_rayver* rv, uint64_t* present_stamps, uint64_t* abse
   const int grid = static_cast<int>((M + 255) / 256);
   hipLaunchKernelGGL((k_rv_check<true>), dim3(grid), dim3(256), 0, rv->stream, rv->d_pts, rv->d_t0, rv->d_t1, static_cast<uint32_t>(M),
                      rv->d_keys[0], rv->d_vals[0], static_cast<uint32_t>(rv->n_pairs), rv->d_stamp, rv->d_src, rv->d_tgt, rv->inv,
-                     rv->radial_tol, rv->depth_tol, nullptr, nullptr, rv->d_op, rv->d_oa, rv->d_outp, rv->d_outa);
+                     rv->radial_tol, rv->depth_tol, nullptr, nullptr, rv->d_op, rv->d_oa, rv->d_outp, rv->d_outa, rv->d_qidx[1]);
   RV_TRY(hipGetLastError());
   if (rv->last_present) RV_TRY(hipMemcpyAsync(present_stamps, rv->d_outp, sizeof(uint64_t) * rv->last_present, hipMemcpyDeviceToHost, rv->stream));
   if (rv->last_absent) RV_TRY(hipMemcpyAsync(absent_stamps, rv->d_outa, sizeof(uint64_t) * rv->last_absent, hipMemcpyDeviceToHost, rv->stream));

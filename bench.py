@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--max-blocks", type=int, default=40960)
     ap.add_argument("--output-every", type=int, default=4)
     ap.add_argument("--no-motion", action="store_true")
+    ap.add_argument("--no-objects", action="store_true",
+                    help="leave out the object half of the active window (ConnectedSemantics, MaxIoUTracker, MeshObjectExtractor)")
+    ap.add_argument("--buffer-frames", type=int, default=100, help="frame_data_buffer.max_buffer_size (frames kept in HBM per camera)")
     ap.add_argument("--cpu-baseline-frames", type=int, default=-1,
                     help="frames of the same stream timed on the CPU oracle (rank 0, N=1); -1 = auto, 0 = skip")
     ap.add_argument("--no-roofline-timers", action="store_true")
@@ -53,6 +56,49 @@ def parse_args():
     ap.add_argument("--mesh-rec-cap", type=int, default=2048, help="mesh halo records all-gathered per rank (N > 1)")
     ap.add_argument("--halo-cap", type=int, default=8192, help="halo records all-gathered per rank and tick (N > 1)")
     return ap.parse_args()
+
+
+# `active_window:` YAML of the object half (keys and values of khronos_ros/config/mapper/uHumans2.yaml:35-100; the
+# object labels are the scene's primitives, the mover included)
+OBJECT_YAML = """
+active_window:
+  type: "ActiveWindow"
+  min_output_separation: 0.4
+  frame_data_buffer:
+    max_buffer_size: %(buf)d
+    store_every_n_frames: 1
+  volumetric_map:
+    voxel_size: %(vs)r
+    truncation_distance: %(trunc)r
+    voxels_per_side: 16
+    with_semantics: true
+  object_detector:
+    type: "ConnectedSemantics"
+    min_cluster_size: 50
+    use_full_connectivity: true
+    use_3d: true
+    grid_size: 0.1
+    max_range: 5
+    object_labels: [7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19]
+  tracker:
+    type: "MaxIouTracker"
+    track_by: "voxels"
+    min_semantic_iou: 0.25
+    min_cross_iou: 0.1
+    voxel_size: 0.2
+    temporal_window: 3
+    min_num_observations: 15
+  object_extractor:
+    type: MeshObjectExtractor
+    min_object_allocation_confidence: 0.5
+    min_object_volume: 0.005
+    max_object_volume: 10.0
+    min_dynamic_displacement: 1
+    only_extract_reconstructed_objects: true
+    min_object_reconstruction_confidence: 0.5
+    min_object_reconstruction_observations: 0
+    object_reconstruction_resolution: -0.02
+"""
 
 
 def main():
@@ -93,7 +139,9 @@ def main():
     n_total = args.warmup + args.steps
     cfg = default_config(
         voxel_size=vs, truncation_distance=3.0 * vs, voxels_per_side=16, with_semantics=1, with_tracking=1,
-        num_labels=K, max_blocks=args.max_blocks, max_frame_pixels=W * H, num_frame_slots=max(2, world),
+        num_labels=K, max_blocks=args.max_blocks, max_frame_pixels=W * H,
+        # buffered frames stay resident in the device ring (FrameDataBuffer role); every rank holds all cameras' frames
+        num_frame_slots=max(2, world) if args.no_objects else world * (args.buffer_frames + 1),
         max_mesh_vertices=48 << 20,
         # khronos_ros/config/mapper/uHumans2.yaml:52-57
         md_min_cluster_size=500, md_min_separation_distance=2.0, md_max_range=5.0,
@@ -102,6 +150,13 @@ def main():
     # one explicit (non-default) HIP stream shared by torch / RCCL and the fusion kernels
     stream = torch.cuda.Stream(device=local_rank)
     ctx.set_stream(stream.cuda_stream)
+
+    # object half of the active window: the reference plugins configured as in khronos_ros/config/mapper/uHumans2.yaml:60-100
+    # (object labels = the scene's primitives 7..19; this rank's own camera is detected / tracked / extracted here)
+    pipe = None
+    if not args.no_objects:
+        from khronos_amd.host_capi import ObjectPipeline
+        pipe = ObjectPipeline(ctx, OBJECT_YAML % dict(vs=args.voxel_size, trunc=3 * args.voxel_size, buf=args.buffer_frames))
 
     # ---- synthetic input, rendered before the timed region, resident in HBM ----------------------
     s = SyntheticStream(W, H, seed=1234)
@@ -152,20 +207,36 @@ def main():
         out_now = args.output_every > 0 and (i + 1) % args.output_every == 0
         if world > 1:
             # sharded tick: integrate all cameras into the owned blocks, tracking, halo all-gather, ever-free
-            fusion.tick(stamps[i], [(pose, dep, rgb, lab) for (dep, rgb, lab, pose) in cams])
+            slots = fusion.tick(stamps[i], [(pose, dep, rgb, lab) for (dep, rgb, lab, pose) in cams])
+            if pipe is not None:  # owner-computes for objects: each rank handles its own camera
+                pipe.finish_frame()  # tracker association of the previous tick, while this tick's kernels run
+                pipe.launch_frame(slots[rank], stamps[i], poses[i][rank], sensor, fusion.clusters_last_tick[rank])
             if out_now:
                 fusion.output(req_cap=args.mesh_req_cap, rec_cap=args.mesh_rec_cap)
+                if pipe is not None:
+                    obj_stats[0] += pipe.extract_inactive()[0]
             return
         for ci, (dep, rgb, lab, pose) in enumerate(cams):
             flags = 0
             if not args.no_motion and world == 1:
                 flags |= ctx.PF_MOTION
+            if pipe is not None:
+                flags |= ctx.PF_OBJECTS
             last = ci == len(cams) - 1
             if last:
                 flags |= ctx.PF_TRACKING  # TrackingIntegrator::updateBlocks once per tick, after all cameras
                 if out_now:
                     flags |= ctx.PF_OUTPUT
-            ctx.process_frame(sensor, frame_desc[i], True, flags)
+            slot, n_dyn = ctx.process_frame(sensor, frame_desc[i], True, flags)
+            if pipe is not None:
+                # software pipeline: the tracker association of the previous frame runs on the host while this frame's
+                # kernels execute; this frame's voxel-set passes are queued behind them and collected next time
+                pipe.finish_frame()
+                pipe.launch_frame(slot, stamps[i], pose, sensor, n_dyn)
+                if last and out_now:
+                    obj_stats[0] += pipe.extract_inactive()[0]
+
+    obj_stats = [0]
 
     def sync_all():
         torch.cuda.synchronize()
@@ -194,6 +265,8 @@ def main():
             ft.append((i, round(1e6 * (time.perf_counter() - tf)), ctx.stats()["n_seeds"]))
     if args.frame_times and rank == 0:
         print("frame_times(us, seeds):", ft, file=sys.stderr)
+    if pipe is not None:
+        pipe.finish_frame()
     sync_all()
     dt = time.perf_counter() - t0
     ctx.timing_enable(False)
@@ -222,13 +295,17 @@ def main():
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: %dx%d synthetic RGB-D+labels, %g cm voxels, vps 16, K=%d labels, "
-                               "MotionDetector %s, output extraction every %d frames; %d camera(s)"
+                               "MotionDetector %s, object detection / tracking / extraction %s, output (mesh, archival, object "
+                               "extraction) every %d frames; %d camera(s)"
                                % (W, H, vs * 100, K, "off" if args.no_motion else "on",
+                                  "off" if args.no_objects else "on (ConnectedSemantics, MaxIoUTracker, MeshObjectExtractor)",
                                   args.output_every, world),
                    "parallelism": "hash-range block shard x%d, owner-computes, RCCL all-gather of frames + of 528-B halo records "
                                   "(ever-free), seed-gated all-reduce of per-pixel voxel keys (motion detector), request / response all-gather of mesh halo planes" % world
                    if world > 1 else "single GPU"},
         "mvoxel_updates_per_s": 1e-6 * n_upd_all / dt,
+        "objects": None if pipe is None else {"tracks_at_end": pipe.num_tracks(), "buffered_frames": pipe.num_buffered_frames(),
+                                              "objects_extracted": obj_stats[0]},
         "voxels": {"visited": n_vis_all, "updated": n_upd_all, "band": n_band_all, "allocated_blocks": st1["n_allocated_blocks"],
                    "last_frame_visible_blocks": st1["n_visible_blocks"], "last_frame_tsdf_blocks": st1["n_tsdf_blocks"],
                    "band_overflow": st1["band_overflow"], "last_frame_tracking_blocks": st1["n_tracking_processed_blocks"],

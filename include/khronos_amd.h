@@ -164,6 +164,8 @@ int khr_set_stream(khr_ctx* ctx, void* hip_stream);
 int khr_sync(khr_ctx* ctx);
 /* fill a config with the reference defaults */
 void khr_default_config(khr_config* cfg);
+/* the config a context was created with (VolumetricMap::config role) */
+int khr_get_config(khr_ctx* ctx, khr_config* out);
 
 /* -- input ------------------------------------------------------------------------------------- */
 /* replaces: hydra::conversions::parseInputPacket + FrameData allocation (active_window.cpp:268-286).
@@ -234,6 +236,11 @@ int khr_get_semantic_clusters(khr_ctx* ctx, int slot, khr_cluster* out, int cap)
  * indices).  Returns the number of pairs (may exceed cap; min(n, cap) are written) or a negative error. */
 int64_t khr_cluster_voxels(khr_ctx* ctx, int slot, int which, float voxel_size, int32_t* ids_out, int64_t* voxels_out,
                            int64_t cap);
+/* the same in two halves, so that the next frame's kernels can be queued before the host waits for the sets: _launch
+ * enqueues the pass and an asynchronous copy to pinned memory (one request per `which` may be outstanding), _fetch
+ * waits for it and decodes (same output as khr_cluster_voxels). */
+int khr_cluster_voxels_launch(khr_ctx* ctx, int slot, int which, float voxel_size);
+int64_t khr_cluster_voxels_fetch(khr_ctx* ctx, int which, int32_t* ids_out, int64_t* voxels_out, int64_t cap);
 /* replaces: hydra::MeshIntegrator::generateMesh(map, only_mesh_updated, clear_flag)
  * (active_window.cpp:223, mesh_object_extractor.cpp:267) */
 int khr_generate_mesh(khr_ctx* ctx, int only_mesh_updated, int clear_flag);
@@ -275,6 +282,9 @@ int khr_object_prune(khr_ctx* ctx, float min_confidence, float min_observations,
 #define KHR_PF_MOTION 1u
 #define KHR_PF_TRACKING 2u
 #define KHR_PF_OUTPUT 4u
+#define KHR_PF_OBJECTS 8u /* ConnectedSemantics on the frame (khr_configure_object_detector first): its kernels are queued
+                             right after the ingest and its host part runs once the frame's other kernels are queued;
+                             khr_detect_objects / khr_get_semantic_clusters then return the cached result */
 int khr_process_frame(khr_ctx* ctx, const khr_sensor* sensor, const khr_frame* frame, int on_device, uint32_t flags,
                       int* n_clusters);
 

@@ -78,7 +78,7 @@ EXPORTS = [
     "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",
     "khr_cluster_voxels", "khr_download_frame_image",
     "khr_rv_create", "khr_rv_destroy", "khr_rv_clear", "khr_rv_add_rays", "khr_rv_num_rays", "khr_rv_num_pairs", "khr_rv_check",
-    "khr_rv_check_stamps",
+    "khr_rv_check_stamps", "khr_get_config", "khr_cluster_voxels_launch", "khr_cluster_voxels_fetch",
 ]
 
 _lib = None
@@ -135,6 +135,10 @@ def load_library():
     lib.khr_rv_num_pairs.restype = C.c_int64
     lib.khr_rv_check.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.khr_rv_check_stamps.argtypes = [vp, vp, vp]
+    lib.khr_get_config.argtypes = [vp, vp]
+    lib.khr_cluster_voxels_launch.argtypes = [vp, i32, i32, C.c_float]
+    lib.khr_cluster_voxels_fetch.argtypes = [vp, i32, vp, vp, C.c_int64]
+    lib.khr_cluster_voxels_fetch.restype = C.c_int64
     lib.khr_get_semantic_clusters.argtypes = [vp, i32, C.POINTER(KhrCluster), i32]
     lib.khr_cluster_voxels.argtypes = [vp, i32, i32, C.c_float, vp, vp, C.c_int64]
     lib.khr_cluster_voxels.restype = C.c_int64
@@ -256,6 +260,7 @@ class FusionContext:
         f.label = label_ptr or None
         return self._chk(self.lib.khr_upload_frame(self.h, C.byref(sensor), C.byref(f), 1))
 
+    PF_OBJECTS = 8
     PF_MOTION, PF_TRACKING, PF_OUTPUT = 1, 2, 4
 
     def make_frame(self, stamp_ns, world_T_sensor, depth_ptr, color_ptr=0, label_ptr=0):

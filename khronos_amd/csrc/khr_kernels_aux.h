@@ -60,6 +60,20 @@ __global__ __launch_bounds__(256) void k_motion_pixels(DevMap m, DevParams p, De
     atomicAdd(&m.counters[C_N_SEEDS], static_cast<uint32_t>(__popcll(b)));
 }
 
+// Small result blocks (counters + the first records) go to pinned host memory with ONE workgroup of plain stores,
+// followed by a ticket the host spins on: a copy command plus an event cost ~15 us of stream time in barrier
+// packets, this costs a ~5 us kernel and nothing else.
+__global__ __launch_bounds__(1024) void k_publish(const uint32_t* __restrict__ src, volatile uint32_t* __restrict__ dst_host,
+                                                 uint32_t n_words, volatile uint32_t* __restrict__ ticket_host, uint32_t ticket) {
+  for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) dst_host[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *ticket_host = ticket;
+    __threadfence_system();
+  }
+}
+
 __global__ void k_publish_seed(DevMap m, volatile uint32_t* host_seed, uint32_t ticket) {
   if (blockIdx.x == 0 && threadIdx.x == 0) publishSeedCount(m, host_seed, ticket);
 }

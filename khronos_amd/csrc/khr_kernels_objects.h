@@ -61,6 +61,38 @@ __device__ inline uint32_t gvInsert(const GvTable& t, uint64_t key, bool* claime
   }
 }
 
+// Lanes of a wave that hold the same key (neighbouring pixels mostly fall in the same voxel) insert ONCE: a 10 cm voxel
+// at 1 m range covers thousands of pixels, and one CAS per pixel on its table slot serialises on a single address
+// (~90 ops/us).  Returns the slot for every participating lane; *claimed is set on exactly one lane per new key.
+__device__ inline uint32_t gvInsertWave(const GvTable& t, bool has, uint64_t key, bool* claimed) {
+  uint32_t slot = 0;
+  *claimed = false;
+  unsigned long long todo = __ballot(has);
+  while (todo) {
+    const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+    const uint32_t klo = __shfl(static_cast<uint32_t>(key), leader), khi = __shfl(static_cast<uint32_t>(key >> 32), leader);
+    const uint64_t lk = (static_cast<uint64_t>(khi) << 32) | klo;
+    const bool mine = has && key == lk;
+    todo &= ~__ballot(mine);
+    uint32_t h = 0;
+    bool cl = false;
+    if (static_cast<int>(laneId()) == leader) h = gvInsert(t, lk, &cl);
+    h = __shfl(h, leader);
+    if (mine) slot = h;
+    if (static_cast<int>(laneId()) == leader) *claimed = cl;
+  }
+  return slot;
+}
+
+// empty the (group, voxel) table and zero the 4 request counters in one launch (two memset commands otherwise)
+__global__ __launch_bounds__(256) void k_gv_clear(uint64_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ counters) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  // 16 bytes per thread
+  if (2 * i + 1 < n) reinterpret_cast<ulonglong2*>(keys)[i] = make_ulonglong2(kEmptyKey, kEmptyKey);
+  else if (2 * i < n) keys[2 * i] = kEmptyKey;
+  if (i < 4) counters[i] = 0u;
+}
+
 // world-frame vertex of a pixel as InputData::vertex_map holds it (ASSUMPTIONS.md A.2)
 __device__ inline void pixelVertex(const DevFrame& f, int i, float* pw) {
   pw[0] = pw[1] = pw[2] = 0.f;
@@ -108,24 +140,23 @@ __global__ __launch_bounds__(256) void k_obj_insert3d(DevFrame f, const int32_t*
                                                      uint32_t* __restrict__ parent, uint32_t* __restrict__ pix_node,
                                                      uint32_t* __restrict__ flags /* [0] window overflow */) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= f.W * f.H) return;
-  uint32_t node = kNodeNone;
-  const int g = labelRank(obj_labels, n_labels, f.label[i]);
-  const float r = f.range[i];
-  if (g >= 0 && !(max_range > 0.f && r > max_range)) {
-    float pw[3];
-    pixelVertex(f, i, pw);
-    uint64_t key;
-    if (gvVoxelKey(pw, inv, origin, static_cast<uint32_t>(g), !(r > 0.f), &key)) {
-      bool claimed;
-      const uint32_t h = gvInsert(t, key, &claimed);
-      if (claimed) parent[h] = h;
-      node = h | (claimed ? kNodeOwner : 0u);
-    } else {
-      atomicOr(&flags[0], 1u);
+  const bool in = i < f.W * f.H;
+  bool has = false;
+  uint64_t key = 0;
+  if (in) {
+    const int g = labelRank(obj_labels, n_labels, f.label[i]);
+    const float r = f.range[i];
+    if (g >= 0 && !(max_range > 0.f && r > max_range)) {
+      float pw[3];
+      pixelVertex(f, i, pw);
+      has = gvVoxelKey(pw, inv, origin, static_cast<uint32_t>(g), !(r > 0.f), &key);
+      if (!has) atomicOr(&flags[0], 1u);
     }
   }
-  pix_node[i] = node;
+  bool claimed;
+  const uint32_t h = gvInsertWave(t, has, key, &claimed);
+  if (claimed) parent[h] = h;
+  if (in) pix_node[i] = has ? (h | (claimed ? kNodeOwner : 0u)) : kNodeNone;
 }
 
 __constant__ int8_t c_obj_fwd13[13][3] = {{1, 0, 0},  {0, 1, 0},   {0, 0, 1},  {1, 1, 0},  {-1, 1, 0}, {1, 0, 1}, {-1, 0, 1},
@@ -226,24 +257,39 @@ __global__ __launch_bounds__(256) void k_obj_roots(const uint32_t* __restrict__ 
   }
 }
 
-// provisional paint: object_image = cluster index + 1, and the per-cluster summary
-__global__ __launch_bounds__(256) void k_obj_paint(DevFrame f, const uint32_t* __restrict__ pix_node,
-                                                  const uint32_t* __restrict__ parent, const uint32_t* __restrict__ root_idx,
-                                                  uint32_t cap, int32_t* __restrict__ obj, ObjAcc* __restrict__ acc) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = f.W * f.H;
+// provisional paint: object_image = cluster index + 1, and the per-cluster summary.  One workgroup per 32x32-pixel tile:
+// lanes of a wave that share a cluster reduce with shuffles, wave leaders accumulate in a small LDS table, and only the
+// tile's distinct clusters touch global memory (a big cluster would otherwise take thousands of atomics on one record).
+constexpr int kObjTile = 32, kObjSlots = 16;
+__global__ __launch_bounds__(1024) void k_obj_paint(DevFrame f, const uint32_t* __restrict__ pix_node,
+                                                   const uint32_t* __restrict__ parent, const uint32_t* __restrict__ root_idx,
+                                                   uint32_t cap, int32_t* __restrict__ obj, ObjAcc* __restrict__ acc) {
+  __shared__ int s_id[kObjSlots];
+  __shared__ ObjAcc s_acc[kObjSlots];
+  if (threadIdx.x < kObjSlots) {
+    s_id[threadIdx.x] = 0;
+    ObjAcc a;
+    a.n_pixels = 0;
+    a.first_cm = 0xffffffffu;
+    for (int d = 0; d < 3; ++d) { a.bmin[d] = INT32_MAX; a.bmax[d] = INT32_MIN; a.sum[d] = 0.f; }
+    a.group = 0;
+    s_acc[threadIdx.x] = a;
+  }
+  __syncthreads();
+  const int tiles_x = (f.W + kObjTile - 1) / kObjTile;
+  const int u = (blockIdx.x % tiles_x) * kObjTile + (threadIdx.x & 31), v = (blockIdx.x / tiles_x) * kObjTile + (threadIdx.x >> 5);
   int id = 0;
   float pw[3] = {0.f, 0.f, 0.f};
   uint32_t cm = 0xffffffffu;
-  if (i < n) {
+  if (u < f.W && v < f.H) {
+    const int i = v * f.W + u;
     const uint32_t node = pix_node[i];
     if (node != kNodeNone) {
-      const uint32_t h = node & ~kNodeOwner;
-      const uint32_t idx = root_idx[ufFind(parent, h)];
+      const uint32_t idx = root_idx[ufFind(parent, node & ~kNodeOwner)];
       if (idx < cap) {
         id = static_cast<int>(idx) + 1;
         pixelVertex(f, i, pw);
-        cm = static_cast<uint32_t>(i % f.W) * static_cast<uint32_t>(f.H) + static_cast<uint32_t>(i / f.W);
+        cm = static_cast<uint32_t>(u) * static_cast<uint32_t>(f.H) + static_cast<uint32_t>(v);
       }
     }
     obj[i] = id;
@@ -274,7 +320,15 @@ __global__ __launch_bounds__(256) void k_obj_paint(DevFrame f, const uint32_t* _
       }
     }
     if (static_cast<int>(laneId()) == leader) {
-      ObjAcc* a = acc + (cid - 1);
+      ObjAcc* a = acc + (cid - 1);  // fall-back: straight to global memory when the tile holds more than kObjSlots clusters
+      for (int k = 0; k < kObjSlots; ++k) {
+        const int h = (cid + k) & (kObjSlots - 1);
+        const int prev = atomicCAS(&s_id[h], 0, cid);
+        if (prev == 0 || prev == cid) {
+          a = &s_acc[h];
+          break;
+        }
+      }
       atomicAdd(&a->n_pixels, static_cast<uint32_t>(__popcll(grp)));
       atomicMin(&a->first_cm, first);
 #pragma unroll
@@ -283,6 +337,19 @@ __global__ __launch_bounds__(256) void k_obj_paint(DevFrame f, const uint32_t* _
         atomicMax(&a->bmax[c], objFloatToOrdered(mx[c]));
         atomicAdd(&a->sum[c], sm[c]);
       }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kObjSlots && s_id[threadIdx.x]) {
+    const ObjAcc& l = s_acc[threadIdx.x];
+    ObjAcc* a = acc + (s_id[threadIdx.x] - 1);
+    atomicAdd(&a->n_pixels, l.n_pixels);
+    atomicMin(&a->first_cm, l.first_cm);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      atomicMin(&a->bmin[c], l.bmin[c]);
+      atomicMax(&a->bmax[c], l.bmax[c]);
+      atomicAdd(&a->sum[c], l.sum[c]);
     }
   }
 }
@@ -300,7 +367,7 @@ __global__ __launch_bounds__(256) void k_cluster_voxels(DevFrame f, const int32_
                                                        GvTable t, uint64_t* __restrict__ list, uint32_t* __restrict__ n_list,
                                                        uint32_t cap, uint32_t* __restrict__ flags) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool claimed = false;
+  bool has = false;
   uint64_t key = 0;
   if (i < f.W * f.H) {
     const int32_t id = id_image[i];
@@ -310,15 +377,17 @@ __global__ __launch_bounds__(256) void k_cluster_voxels(DevFrame f, const int32_
       } else {
         float pw[3];
         pixelVertex(f, i, pw);
-        if (gvVoxelKey(pw, inv, origin, static_cast<uint32_t>(id), !(f.range[i] > 0.f), &key))
-          gvInsert(t, key, &claimed);
-        else
-          atomicOr(&flags[0], 1u);
+        has = gvVoxelKey(pw, inv, origin, static_cast<uint32_t>(id), !(f.range[i] > 0.f), &key);
+        if (!has) atomicOr(&flags[0], 1u);
       }
     }
   }
+  bool claimed;
+  const uint32_t h = gvInsertWave(t, has, key, &claimed);
+  (void)h;
+  const uint64_t my_key = key;  // the claiming lane is the leader of its own key group
   const uint32_t at = waveAggInc(n_list, claimed);
-  if (claimed && at < cap) list[at] = key;
+  if (claimed && at < cap) list[at] = my_key;
 }
 
 }  // namespace khr

@@ -62,7 +62,9 @@ struct FrameSlot {
   int tw = 0, th = 0;
   khr_sensor sensor{};
   khr_frame meta{};
-  bool valid = false, has_color = false, has_label = false, has_obj = false;
+  bool valid = false, has_color = false, has_label = false, has_obj = false, objects_done = false;
+  std::vector<khr_cluster> sem_clusters;  // semantic clusters of the frame in this slot (khr_detect_objects)
+  std::vector<khr_cluster> clusters;  // dynamic clusters of the frame in this slot (ids, listed pixel counts)
 };
 
 struct TimingRec {
@@ -71,6 +73,8 @@ struct TimingRec {
 };
 
 constexpr int kNumTimers = 8;
+constexpr uint32_t kObjHead = 512;   // cluster records in the first download of the object detector
+constexpr uint32_t kCvHead = 8192;   // (cluster, voxel) keys in the first download of a voxel-set request
 constexpr uint32_t kCompCap = 1024, kCompHead = 64;  // motion-cluster components: record capacity / records in the first download
 
 }  // namespace
@@ -139,8 +143,6 @@ struct khr_ctx {
   uint8_t* h_md_head = nullptr;  // pinned mirror of the head + records, then the final ids going back
   bool md_host_walk = false;     // KHR_MD_HOST_WALK=1: always cluster on the host (A/B switch, results identical)
   uint32_t md_lds_max = kCompLds;  // KHR_MD_LDS_MAX=n: seed count up to which the single-workgroup LDS labelling is used
-  std::vector<khr_cluster> last_clusters;
-  int last_cluster_slot = -1;
   uint32_t md_mask = 0, md_list_cap = 0;
   std::vector<uint64_t> h_md_seed_keys, h_md_bnd_keys;
   std::vector<uint32_t> h_md_seed_counts, h_md_bnd_counts, h_md_adj;
@@ -159,10 +161,19 @@ struct khr_ctx {
   int32_t* d_obj_final = nullptr;
   uint64_t* d_cv_list = nullptr;
   uint32_t obj_root_cap = 0;
-  std::vector<ObjAcc> h_obj_acc;
-  std::vector<int32_t> h_obj_final;
-  std::vector<khr_cluster> last_sem_clusters;
-  int last_sem_slot = -1;
+  uint8_t* h_obj_head = nullptr;   // pinned: {roots, flags, -, -} + the cluster records (first download kObjHead of them)
+  hipEvent_t ev_obj = nullptr;
+  int obj_pending_slot = -1;       // objectsLaunch issued, objectsFinish outstanding
+  // asynchronous per-cluster voxel sets, one request per id image (0 dynamic, 1 object)
+  uint32_t* d_cv_n[2] = {nullptr, nullptr};
+  uint64_t* d_cv_keys[2] = {nullptr, nullptr};
+  uint8_t* h_cv[2] = {nullptr, nullptr};  // pinned: {count, flags, -, -} + keys
+  uint8_t* d_cv_host[2] = {nullptr, nullptr};  // device views of h_cv / h_obj_head
+  uint8_t* d_obj_head_host = nullptr;
+  hipEvent_t ev_cv[2] = {nullptr, nullptr};
+  int cv_pending_slot[2] = {-1, -1};
+  uint32_t obj_ticket = 0, cv_ticket[2] = {0, 0};  // h_pinned[4] / [5], [6]
+  int3 cv_origin[2]{};
   // mesh
   MeshBuffers mesh[2]{};
   int mesh_cur = 0;
@@ -421,6 +432,12 @@ void khr_default_config(khr_config* cfg) {
   cfg->world_size = 1;
 }
 
+int khr_get_config(khr_ctx* c, khr_config* out) {
+  if (!c || !out) return fail(KHR_EINVAL, "null argument");
+  *out = c->cfg;
+  return KHR_OK;
+}
+
 int khr_create(const khr_config* cfg, khr_ctx** out) {
   if (!cfg || !out) return fail(KHR_EINVAL, "null argument");
   *out = nullptr;
@@ -633,6 +650,12 @@ void khr_destroy(khr_ctx* c) {
   if (c->d_halo_recs) { hipFree(c->d_halo_recs); hipFree(c->d_halo_keys); hipFree(c->d_halo_vals); }
   if (c->d_mh_recs) { hipFree(c->d_mh_recs); hipFree(c->d_mh_keys); hipFree(c->d_mh_vals); }
   if (c->h_pinned) hipHostFree(c->h_pinned);
+  if (c->h_obj_head) hipHostFree(c->h_obj_head);
+  if (c->ev_obj) hipEventDestroy(c->ev_obj);
+  for (int w = 0; w < 2; ++w) {
+    if (c->h_cv[w]) hipHostFree(c->h_cv[w]);
+    if (c->ev_cv[w]) hipEventDestroy(c->ev_cv[w]);
+  }
   if (c->ev_seed) hipEventDestroy(c->ev_seed);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -680,6 +703,9 @@ int khr_upload_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fram
   s.has_color = frame->color != nullptr;
   s.has_label = frame->label != nullptr;
   s.has_obj = false;
+  s.objects_done = false;
+  s.clusters.clear();
+  s.sem_clusters.clear();
   ScopedTimer tm(c, 6);
   const float* depth_src = frame->depth;
   const uint8_t* rgb_src = frame->color;
@@ -1047,6 +1073,21 @@ static int waitSeedCount(khr_ctx* c) {
   return KHR_OK;
 }
 
+// spin on a ticket word in pinned memory (written by k_publish); keeps an eye on the stream so that a failed launch
+// cannot hang the host
+static int waitTicket(khr_ctx* c, int word, uint32_t ticket, const char* what) {
+  volatile uint32_t* hp = c->h_pinned;
+  uint64_t spins = 0;
+  while (hp[word] != ticket) {
+    if ((++spins & 0xffffu) == 0) {
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) return fail(KHR_EDEVICE, "stream failed while waiting for %s: %s", what, hipGetErrorString(q));
+      if (q == hipSuccess && hp[word] != ticket) return fail(KHR_EDEVICE, "%s was never published", what);
+    }
+  }
+  return KHR_OK;
+}
+
 static int motionFinish(khr_ctx* c, FrameSlot& s) {
   if (!c->cfg.with_tracking) return 0;
   const int n = s.sensor.width * s.sensor.height;
@@ -1060,8 +1101,7 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
   };
   { const int rcw = waitSeedCount(c); if (rcw) return rcw; }
   lap("wait seed count");
-  c->last_clusters.clear();
-  c->last_cluster_slot = static_cast<int>(&s - c->slots.data());
+  s.clusters.clear();
   if (c->h_pinned[0] == 0) return 0;
 
   // ---- device: seed / boundary voxel tables, compact lists, seed adjacency ------------------------
@@ -1154,12 +1194,12 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
       hipLaunchKernelGGL(k_md_paint, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds, bnd, c->d_md_seed_final,
                          c->d_md_bnd_final, s.dyn);
       HIP_TRY(hipGetLastError());
-      c->last_clusters.resize(kept.size());
+      s.clusters.resize(kept.size());
       for (size_t i = 0; i < kept.size(); ++i) {
-        c->last_clusters[i] = khr_cluster{};
-        c->last_clusters[i].id = kept[i].first;
-        c->last_clusters[i].num_pixels_listed = kept[i].second;
-        c->last_clusters[i].semantic_id = -1;
+        s.clusters[i] = khr_cluster{};
+        s.clusters[i].id = kept[i].first;
+        s.clusters[i].num_pixels_listed = kept[i].second;
+        s.clusters[i].semantic_id = -1;
       }
       lap("finals + paint launch");
       return static_cast<int>(kept.size());
@@ -1315,12 +1355,12 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
     hipLaunchKernelGGL(k_md_paint, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds, bnd, c->d_md_seed_final,
                        c->d_md_bnd_final, s.dyn);
     HIP_TRY(hipGetLastError());
-    c->last_clusters.resize(kept.size());
+    s.clusters.resize(kept.size());
     for (size_t i = 0; i < kept.size(); ++i) {
-      c->last_clusters[i] = khr_cluster{};
-      c->last_clusters[i].id = kept[i].first;
-      c->last_clusters[i].num_pixels_listed = kept[i].second;
-      c->last_clusters[i].semantic_id = -1;
+      s.clusters[i] = khr_cluster{};
+      s.clusters[i].id = kept[i].first;
+      s.clusters[i].num_pixels_listed = kept[i].second;
+      s.clusters[i].semantic_id = -1;
     }
   }
   lap("filter + paint launch");
@@ -1389,8 +1429,8 @@ int khr_detect_motion_from_keys(khr_ctx* c, int slot, const void* keys, int on_d
 
 int khr_get_dynamic_clusters(khr_ctx* c, int slot, khr_cluster* out, int cap) {
   if (!c || cap < 0 || (!out && cap > 0)) return fail(KHR_EINVAL, "bad argument");
-  if (slot != c->last_cluster_slot) return fail(KHR_ESTATE, "dynamic clusters are kept for the last processed frame only");
-  const int n = static_cast<int>(c->last_clusters.size());
+  if (slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
+  const int n = static_cast<int>(c->slots[slot].clusters.size());
   if (n == 0) return 0;
   // the summary (the tracker's bounding boxes, max_iou_tracker.cpp:466-476) is computed when somebody asks
   FrameSlot& s = c->slots[slot];
@@ -1405,7 +1445,7 @@ int khr_get_dynamic_clusters(khr_ctx* c, int slot, khr_cluster* out, int cap) {
   HIP_TRY(hipMemcpyAsync(acc.data(), c->d_md_acc, sizeof(ClusterAcc) * 256, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   for (int i = 0; i < n && i < cap; ++i) {
-    khr_cluster k = c->last_clusters[i];
+    khr_cluster k = s.clusters[i];
     const ClusterAcc& a = acc[k.id];
     k.num_pixels_painted = a.n_pixels;
     for (int d = 0; d < 3; ++d) {
@@ -1434,10 +1474,28 @@ static int ensureGv(khr_ctx* c) {
   A(devAlloc(c, &c->d_gv_parent, ts, false));  // >= npx: also the per-pixel parent array of the 2D mode
   A(devAlloc(c, &c->d_gv_rootidx, ts, false));
   A(devAlloc(c, &c->d_gv_node, npx, false));
-  A(devAlloc(c, &c->d_gv_n, 4));
-  A(devAlloc(c, &c->d_obj_acc, c->obj_root_cap, false));
+  {
+    // counters and cluster records are contiguous: one small copy brings both to the host
+    uint8_t* head = nullptr;
+    A(devAlloc(c, &head, 16 + sizeof(ObjAcc) * c->obj_root_cap));
+    c->d_gv_n = reinterpret_cast<uint32_t*>(head);
+    c->d_obj_acc = head ? reinterpret_cast<ObjAcc*>(head + 16) : nullptr;
+  }
   A(devAlloc(c, &c->d_obj_final, c->obj_root_cap, false));
-  A(devAlloc(c, &c->d_cv_list, npx, false));
+  for (int w = 0; w < 2; ++w) {
+    uint8_t* head = nullptr;
+    A(devAlloc(c, &head, 16 + sizeof(uint64_t) * npx));
+    c->d_cv_n[w] = reinterpret_cast<uint32_t*>(head);
+    c->d_cv_keys[w] = head ? reinterpret_cast<uint64_t*>(head + 16) : nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_cv[w]), 16 + sizeof(uint64_t) * npx, hipHostMallocDefault) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_cv_host[w]), c->h_cv[w], 0) != hipSuccess)
+      A(KHR_ENOMEM);
+    if (hipEventCreateWithFlags(&c->ev_cv[w], hipEventDisableTiming) != hipSuccess) A(KHR_EDEVICE);
+  }
+  if (hipHostMalloc(reinterpret_cast<void**>(&c->h_obj_head), 16 + sizeof(ObjAcc) * c->obj_root_cap, hipHostMallocDefault) != hipSuccess ||
+      hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_obj_head_host), c->h_obj_head, 0) != hipSuccess)
+    A(KHR_ENOMEM);
+  if (hipEventCreateWithFlags(&c->ev_obj, hipEventDisableTiming) != hipSuccess) A(KHR_EDEVICE);
   return rc;
 }
 
@@ -1477,50 +1535,78 @@ int khr_configure_object_detector(khr_ctx* c, const khr_object_detector_config* 
   return KHR_OK;
 }
 
-int khr_detect_objects(khr_ctx* c, int slot) {
-  if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
-  if (!c->obj_configured) return fail(KHR_ESTATE, "khr_configure_object_detector has not been called");
-  HIP_TRY(hipSetDevice(c->device));
+// ConnectedSemantics, part 1: everything up to the per-cluster records, and their copy to pinned memory.  No host
+// wait: khr_process_frame issues this right after the frame ingest and looks at the records when the rest of the
+// frame's kernels are queued.
+static int objectsLaunch(khr_ctx* c, int slot) {
   FrameSlot& s = c->slots[slot];
   const int n = s.sensor.width * s.sensor.height;
   const khr_object_detector_config& oc = c->obj_cfg;
-  c->last_sem_clusters.clear();
-  c->last_sem_slot = slot;
+  s.sem_clusters.clear();
+  s.objects_done = false;
   s.has_obj = true;
-  HIP_TRY(hipMemsetAsync(s.obj, 0, sizeof(int32_t) * n, c->stream));
+  c->obj_pending_slot = -1;
   const int n_labels = static_cast<int>(c->obj_labels.size());
-  if (!s.has_label || n_labels == 0) return 0;
+  if (!s.has_label || n_labels == 0) {
+    HIP_TRY(hipMemsetAsync(s.obj, 0, sizeof(int32_t) * n, c->stream));
+    s.objects_done = true;
+    return KHR_OK;
+  }
   const DevFrame f = makeDevFrame(c, s);
   GvTable t{c->d_gv_keys, c->gv_mask};
-  HIP_TRY(hipMemsetAsync(c->d_gv_n, 0, sizeof(uint32_t) * 4, c->stream));
+  const uint32_t tsize = c->gv_mask + 1;
+  // (the object image needs no clearing: the paint pass writes every pixel)
   if (oc.use_3d) {
     const float inv = 1.f / oc.grid_size;  // connected_semantics.cpp:75
-    HIP_TRY(hipMemsetAsync(c->d_gv_keys, 0xff, sizeof(uint64_t) * (static_cast<size_t>(c->gv_mask) + 1), c->stream));
+    hipLaunchKernelGGL(k_gv_clear, dim3(gridFor(tsize / 2)), dim3(256), 0, c->stream, c->d_gv_keys, tsize, c->d_gv_n);
     hipLaunchKernelGGL(k_obj_insert3d, dim3(gridFor(n)), dim3(256), 0, c->stream, f, c->d_obj_labels, n_labels, oc.max_range, inv,
                        windowOrigin(f, inv), t, c->d_gv_parent, c->d_gv_node, c->d_gv_n + 1);
     hipLaunchKernelGGL(k_obj_union3d, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_gv_node, n, t, c->d_gv_parent,
                        oc.use_full_connectivity ? 13 : 3);
   } else {
+    HIP_TRY(hipMemsetAsync(c->d_gv_n, 0, sizeof(uint32_t) * 4, c->stream));
     hipLaunchKernelGGL(k_obj_init2d, dim3(gridFor(n)), dim3(256), 0, c->stream, f, c->d_obj_labels, n_labels, c->d_gv_parent, c->d_gv_node);
     hipLaunchKernelGGL(k_obj_union2d, dim3(gridFor(n)), dim3(256), 0, c->stream, f, c->d_gv_node, c->d_gv_parent,
                        oc.use_full_connectivity ? 1 : 0);
   }
   hipLaunchKernelGGL(k_obj_roots, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_gv_node, n, c->d_gv_parent, c->d_gv_rootidx, c->d_gv_n,
                      c->obj_root_cap, c->d_obj_acc, oc.use_3d ? c->d_gv_keys : nullptr, s.label, c->d_obj_labels, n_labels);
-  hipLaunchKernelGGL(k_obj_paint, dim3(gridFor(n)), dim3(256), 0, c->stream, f, c->d_gv_node, c->d_gv_parent, c->d_gv_rootidx,
+  const int obj_tiles = ((s.sensor.width + kObjTile - 1) / kObjTile) * ((s.sensor.height + kObjTile - 1) / kObjTile);
+  hipLaunchKernelGGL(k_obj_paint, dim3(obj_tiles), dim3(1024), 0, c->stream, f, c->d_gv_node, c->d_gv_parent, c->d_gv_rootidx,
                      c->obj_root_cap, s.obj, c->d_obj_acc);
   HIP_TRY(hipGetLastError());
-  uint32_t cnt[2] = {0, 0};
-  HIP_TRY(hipMemcpyAsync(cnt, c->d_gv_n, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (++c->obj_ticket == 0) ++c->obj_ticket;
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, c->stream, c->d_gv_n, reinterpret_cast<uint32_t*>(c->d_obj_head_host),
+                     static_cast<uint32_t>((16 + sizeof(ObjAcc) * kObjHead) / 4), c->d_pinned + 4, c->obj_ticket);
+  HIP_TRY(hipGetLastError());
+  c->obj_pending_slot = slot;
+  return KHR_OK;
+}
+
+// ConnectedSemantics, part 2: order / filter the clusters on the host, remap the provisional ids.  Returns the
+// number of semantic clusters.
+static int objectsFinish(khr_ctx* c, int slot) {
+  FrameSlot& s = c->slots[slot];
+  if (s.objects_done) return static_cast<int>(s.sem_clusters.size());
+  if (c->obj_pending_slot != slot) return fail(KHR_ESTATE, "object detection was not launched for this slot");
+  c->obj_pending_slot = -1;
+  const int n = s.sensor.width * s.sensor.height;
+  const khr_object_detector_config& oc = c->obj_cfg;
+  {
+    const int rcw = waitTicket(c, 4, c->obj_ticket, "the object detector's cluster records");
+    if (rcw) return rcw;
+  }
+  const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c->h_obj_head);
   if (cnt[1] & 1u) return fail(KHR_EINVAL, "object detector: a measured point lies more than %d grid cells from the sensor", kGvWindow);
   const uint32_t R = cnt[0];
   if (R > c->obj_root_cap) return fail(KHR_ENOMEM, "object detector: %u clusters exceed the capacity %u", R, c->obj_root_cap);
+  s.objects_done = true;
   if (R == 0) return 0;
-  std::vector<ObjAcc>& acc = c->h_obj_acc;
-  acc.resize(R);
-  HIP_TRY(hipMemcpyAsync(acc.data(), c->d_obj_acc, sizeof(ObjAcc) * R, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (R > kObjHead) {
+    HIP_TRY(hipMemcpyAsync(c->h_obj_head, c->d_gv_n, 16 + sizeof(ObjAcc) * R, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  const ObjAcc* acc = reinterpret_cast<const ObjAcc*>(c->h_obj_head + 16);
   // cluster order: 3D mode = by semantic id (std::map, connected_semantics.h:87), then by first pixel in scan order
   // (ASSUMPTIONS.md C.4); 2D mode = discovery order of the column-major scan (:147-160)
   std::vector<uint32_t> order(R);
@@ -1529,8 +1615,7 @@ int khr_detect_objects(khr_ctx* c, int slot) {
     if (oc.use_3d && acc[a].group != acc[b].group) return acc[a].group < acc[b].group;
     return acc[a].first_cm < acc[b].first_cm;
   });
-  std::vector<int32_t>& fin = c->h_obj_final;
-  fin.assign(R, 0);
+  std::vector<int32_t> fin(R, 0);
   int next_id = 1;
   for (uint32_t r : order) {
     const ObjAcc& a = acc[r];
@@ -1554,50 +1639,89 @@ int khr_detect_objects(khr_ctx* c, int slot) {
       k.centroid[d] = a.sum[d] / static_cast<float>(a.n_pixels);
     }
     k.semantic_id = c->obj_labels[a.group];
-    c->last_sem_clusters.push_back(k);
+    s.sem_clusters.push_back(k);
   }
-  HIP_TRY(hipMemcpyAsync(c->d_obj_final, fin.data(), sizeof(int32_t) * R, hipMemcpyHostToDevice, c->stream));
+  // the records are consumed: the pinned block now carries the final ids to the device
+  std::memcpy(c->h_obj_head, fin.data(), sizeof(int32_t) * R);
+  HIP_TRY(hipMemcpyAsync(c->d_obj_final, c->h_obj_head, sizeof(int32_t) * R, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_obj_remap, dim3(gridFor(n)), dim3(256), 0, c->stream, s.obj, n, c->d_obj_final);
   HIP_TRY(hipGetLastError());
-  return static_cast<int>(c->last_sem_clusters.size());
+  return static_cast<int>(s.sem_clusters.size());
+}
+
+int khr_detect_objects(khr_ctx* c, int slot) {
+  if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
+  if (!c->obj_configured) return fail(KHR_ESTATE, "khr_configure_object_detector has not been called");
+  HIP_TRY(hipSetDevice(c->device));
+  FrameSlot& s = c->slots[slot];
+  if (s.objects_done) return static_cast<int>(s.sem_clusters.size());  // already done inside khr_process_frame
+  if (c->obj_pending_slot != slot) {
+    const int rc = objectsLaunch(c, slot);
+    if (rc) return rc;
+  }
+  return objectsFinish(c, slot);
 }
 
 int khr_get_semantic_clusters(khr_ctx* c, int slot, khr_cluster* out, int cap) {
   if (!c || cap < 0 || (!out && cap > 0)) return fail(KHR_EINVAL, "bad argument");
-  if (slot != c->last_sem_slot) return fail(KHR_ESTATE, "semantic clusters are kept for the last processed frame only");
-  const int n = static_cast<int>(c->last_sem_clusters.size());
-  for (int i = 0; i < n && i < cap; ++i) out[i] = c->last_sem_clusters[i];
+  if (slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
+  const FrameSlot& s = c->slots[slot];
+  if (!s.objects_done) return fail(KHR_ESTATE, "khr_detect_objects has not run for this frame");
+  const int n = static_cast<int>(s.sem_clusters.size());
+  for (int i = 0; i < n && i < cap; ++i) out[i] = s.sem_clusters[i];
   return n;
 }
 
-int64_t khr_cluster_voxels(khr_ctx* c, int slot, int which, float voxel_size, int32_t* ids_out, int64_t* voxels_out, int64_t cap) {
+int khr_cluster_voxels_launch(khr_ctx* c, int slot, int which, float voxel_size) {
   if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
-  if (!(voxel_size > 0.f) || cap < 0 || (cap > 0 && (!ids_out || !voxels_out)) || (which != 0 && which != 1)) return fail(KHR_EINVAL, "bad argument");
+  if (!(voxel_size > 0.f) || (which != 0 && which != 1)) return fail(KHR_EINVAL, "bad argument");
   HIP_TRY(hipSetDevice(c->device));
   int rc = ensureGv(c);
   if (rc) return rc;
   FrameSlot& s = c->slots[slot];
-  if (which == 1 && !s.has_obj) return 0;
+  c->cv_pending_slot[which] = slot;
+  uint32_t* hc = reinterpret_cast<uint32_t*>(c->h_cv[which]);
+  if (which == 1 && !s.has_obj) {  // no object image: nothing to look at
+    hc[0] = hc[1] = 0;
+    c->cv_ticket[which] = c->h_pinned[5 + which];  // nothing in flight: the fetch sees the current ticket
+    return KHR_OK;
+  }
   const int n = s.sensor.width * s.sensor.height;
   const DevFrame f = makeDevFrame(c, s);
   const float inv = 1.f / voxel_size;  // spatial_hash::Grid(voxel_size)
-  const int3 origin = windowOrigin(f, inv);
+  c->cv_origin[which] = windowOrigin(f, inv);
   GvTable t{c->d_gv_keys, c->gv_mask};
-  HIP_TRY(hipMemsetAsync(c->d_gv_n, 0, sizeof(uint32_t) * 4, c->stream));
-  HIP_TRY(hipMemsetAsync(c->d_gv_keys, 0xff, sizeof(uint64_t) * (static_cast<size_t>(c->gv_mask) + 1), c->stream));
-  hipLaunchKernelGGL(k_cluster_voxels, dim3(gridFor(n)), dim3(256), 0, c->stream, f, which == 0 ? s.dyn : s.obj, inv, origin, t,
-                     c->d_cv_list, c->d_gv_n, static_cast<uint32_t>(c->cfg.max_frame_pixels), c->d_gv_n + 1);
+  const uint32_t tsize = c->gv_mask + 1;
+  hipLaunchKernelGGL(k_gv_clear, dim3(gridFor(tsize / 2)), dim3(256), 0, c->stream, c->d_gv_keys, tsize, c->d_cv_n[which]);
+  hipLaunchKernelGGL(k_cluster_voxels, dim3(gridFor(n)), dim3(256), 0, c->stream, f, which == 0 ? s.dyn : s.obj, inv, c->cv_origin[which], t,
+                     c->d_cv_keys[which], c->d_cv_n[which], static_cast<uint32_t>(c->cfg.max_frame_pixels), c->d_cv_n[which] + 1);
   HIP_TRY(hipGetLastError());
-  uint32_t cnt[2] = {0, 0};
-  HIP_TRY(hipMemcpyAsync(cnt, c->d_gv_n, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (++c->cv_ticket[which] == 0) ++c->cv_ticket[which];
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, c->stream, c->d_cv_n[which], reinterpret_cast<uint32_t*>(c->d_cv_host[which]),
+                     static_cast<uint32_t>((16 + sizeof(uint64_t) * std::min<size_t>(kCvHead, c->cfg.max_frame_pixels)) / 4),
+                     c->d_pinned + 5 + which, c->cv_ticket[which]);
+  HIP_TRY(hipGetLastError());
+  return KHR_OK;
+}
+
+int64_t khr_cluster_voxels_fetch(khr_ctx* c, int which, int32_t* ids_out, int64_t* voxels_out, int64_t cap) {
+  if (!c || (which != 0 && which != 1) || cap < 0 || (cap > 0 && (!ids_out || !voxels_out))) return fail(KHR_EINVAL, "bad argument");
+  if (c->cv_pending_slot[which] < 0) return fail(KHR_ESTATE, "khr_cluster_voxels_launch has not been called");
+  {
+    const int rcw = waitTicket(c, 5 + which, c->cv_ticket[which], "the cluster voxel sets");
+    if (rcw) return rcw;
+  }
+  const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c->h_cv[which]);
   if (cnt[1] & 1u) return fail(KHR_EINVAL, "cluster voxels: a measured point lies more than %d voxels from the sensor", kGvWindow);
   if (cnt[1] & 2u) return fail(KHR_EINVAL, "cluster voxels: cluster id above %u", kGvMaxGroup);
   const uint32_t N = cnt[0];
   if (N == 0) return 0;
-  std::vector<uint64_t> keys(N);
-  HIP_TRY(hipMemcpyAsync(keys.data(), c->d_cv_list, sizeof(uint64_t) * N, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (N > kCvHead) {
+    HIP_TRY(hipMemcpyAsync(c->h_cv[which], c->d_cv_n[which], 16 + sizeof(uint64_t) * N, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  const uint64_t* keys = reinterpret_cast<const uint64_t*>(c->h_cv[which] + 16);
+  const int3 origin = c->cv_origin[which];
   struct E { int32_t id; int64_t v[3]; };
   std::vector<E> e(N);
   for (uint32_t i = 0; i < N; ++i) {
@@ -1624,6 +1748,13 @@ int64_t khr_cluster_voxels(khr_ctx* c, int slot, int which, float voxel_size, in
     for (int d = 0; d < 3; ++d) voxels_out[3 * i + d] = e[i].v[d];
   }
   return static_cast<int64_t>(N);
+}
+
+int64_t khr_cluster_voxels(khr_ctx* c, int slot, int which, float voxel_size, int32_t* ids_out, int64_t* voxels_out, int64_t cap) {
+  if (cap < 0 || (cap > 0 && (!ids_out || !voxels_out))) return fail(KHR_EINVAL, "bad argument");
+  const int rc = khr_cluster_voxels_launch(c, slot, which, voxel_size);
+  if (rc) return rc;
+  return khr_cluster_voxels_fetch(c, which, ids_out, voxels_out, cap);
 }
 
 int khr_generate_mesh(khr_ctx* c, int only_mesh_updated, int clear_flag) {
@@ -1824,7 +1955,14 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   FrameSlot& s = c->slots[slot];
   const DevFrame f = makeDevFrame(c, s);
   const bool motion = (flags & KHR_PF_MOTION) != 0;
+  const bool objects = (flags & KHR_PF_OBJECTS) != 0;
   int rc = KHR_OK;
+  // (0) object detection kernels first (they only read the frame): their cluster records reach the host while the
+  //     volumetric kernels run, and are looked at in (6)
+  if (objects) {
+    if (!c->obj_configured) return fail(KHR_ESTATE, "KHR_PF_OBJECTS needs khr_configure_object_detector");
+    if ((rc = objectsLaunch(c, slot))) return rc;
+  }
   // (1) per-pixel motion pass; its seed count comes back asynchronously ...
   if (motion && (rc = motionLaunch(c, s, true))) return rc;
   // (2) ... while block allocation / culling, which do not depend on the dynamic mask, keep the GPU busy
@@ -1843,6 +1981,11 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
     if ((rc = khr_generate_mesh(c, 1, 1))) return rc;
     if (c->cfg.with_tracking && (rc = resetInactiveLaunch(c))) return rc;
     if ((rc = khr_clear_updated(c))) return rc;
+  }
+  // (6) ConnectedSemantics, host part (the records arrived long ago) + id remap queued behind everything else
+  if (objects) {
+    const int ns = objectsFinish(c, slot);
+    if (ns < 0) return ns;
   }
   return slot;
 }

@@ -117,6 +117,7 @@ class ShardedFusion:
         if self.world > 1:
             self.shard.import_halo(self.all_gather(self.shard.export_halo(stamp)))
         self.shard.tracking_phase(stamp, 2)
+        return slots
 
     def output(self, req_cap=8192, rec_cap=1024):
         """ActiveWindow::extractOutputData, volumetric part (active_window.cpp:217-249): marching cubes on the

@@ -201,8 +201,15 @@ class MaxIoUTracker : public Tracker {
   explicit MaxIoUTracker(const Config& config);
   void processInput(FrameData& data) override;
 
+  // processInput in two halves for callers that queue the next frame's device work in between (object_pipeline.cpp):
+  // beginInput enqueues the voxel-set passes, completeInput waits for them and runs the association
+  void beginInput(FrameData& data);
+  void completeInput(FrameData& data);
+
   // the steps of processInput (public as in the reference)
   void setupTrackMeasurements(FrameData& data) const;
+  void launchTrackMeasurements(FrameData& data) const;
+  void finishTrackMeasurements(FrameData& data) const;
   void associateTracks(const FrameData& data);
   void associateDynamicTracks(const FrameData& data);
   void associateSemanticTracks(const FrameData& data);
@@ -219,6 +226,8 @@ class MaxIoUTracker : public Tracker {
  private:
   TimeStamp processing_stamp_ = 0;
   int current_track_id_ = 0;
+  mutable std::vector<int32_t> scratch_ids_;
+  mutable std::vector<int64_t> scratch_voxels_;
 };
 
 // khronos::ExternalTracker (external_tracker.cpp:59-143): tracks follow externally provided cluster ids

@@ -1,0 +1,194 @@
+// object_pipeline.cpp — the object half of khronos::ActiveWindow::spinOnce as a C API for bindings (bench.py, the
+// sharded multi-GPU driver): object detector -> tracker -> frame buffer per frame (active_window.cpp:130-145) and
+// extraction of the tracks that left the window at output cadence (extractInactiveObjects, :251-266).  It is built
+// from the same `active_window:` YAML as the ActiveWindow class and runs on a fusion context's frame slots; the
+// volumetric half of spinOnce is khr_process_frame (single GPU) or the sharded tick (multi GPU, where the halo
+// exchanges are RCCL collectives driven from Python).
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "active_window.h"
+
+using namespace khronos;
+
+struct kop_handle {
+  ActiveWindow::Config config;
+  khr_ctx* ctx = nullptr;
+  VolumetricMap map;
+  std::unique_ptr<ObjectDetector> detector;
+  std::unique_ptr<Tracker> tracker;
+  std::unique_ptr<ObjectExtractor> extractor;
+  std::unique_ptr<FrameDataBuffer> buffer;
+  std::vector<std::shared_ptr<KhronosObjectAttributes>> last_objects;
+  std::shared_ptr<FrameData> pending;  // kop_launch_frame done, kop_finish_frame outstanding
+};
+
+namespace {
+void setErr(char* err, int n, const std::string& s) {
+  if (err && n > 0) {
+    std::strncpy(err, s.c_str(), static_cast<size_t>(n) - 1);
+    err[n - 1] = 0;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+kop_handle* kop_create(khr_ctx* ctx, const char* yaml_text, char* err, int err_len) {
+  if (!ctx || !yaml_text) {
+    setErr(err, err_len, "null argument");
+    return nullptr;
+  }
+  try {
+    auto h = std::make_unique<kop_handle>();
+    h->config = ActiveWindow::Config::fromYamlString(yaml_text);
+    h->config.checkValid();
+    h->ctx = ctx;
+    h->map = VolumetricMap(h->config.volumetric_map, ctx);
+    const auto& c = h->config;
+    if (c.object_detector_type == "ConnectedSemantics") h->detector = std::make_unique<ConnectedSemantics>(c.object_detector, h->map);
+    else h->detector = std::make_unique<ObjectDetector>();
+    if (c.tracker_type == "MaxIouTracker") {
+      h->tracker = std::make_unique<MaxIoUTracker>(c.tracker);
+    } else if (c.tracker_type == "ExternalTracker") {
+      ExternalTracker::Config ec;
+      ec.temporal_window = c.tracker.temporal_window;
+      ec.min_num_observations = c.tracker.min_num_observations;
+      h->tracker = std::make_unique<ExternalTracker>(ec);
+    } else {
+      h->tracker = std::make_unique<Tracker>();
+    }
+    if (c.object_extractor_type == "MeshObjectExtractor") {
+      khr_config dc{};
+      if (khr_get_config(ctx, &dc) < 0) throw std::runtime_error(khr_last_error());
+      h->extractor = std::make_unique<MeshObjectExtractor>(c.object_extractor, dc);
+    }
+    h->buffer = std::make_unique<FrameDataBuffer>(c.frame_data_buffer);
+    return h.release();
+  } catch (const std::exception& e) {
+    setErr(err, err_len, e.what());
+    return nullptr;
+  }
+}
+
+void kop_destroy(kop_handle* h) { delete h; }
+
+// The per-frame work in two halves so that the caller can queue the next frame's device work in between:
+// kop_launch_frame = object_detector_->processInput + the tracker's measurement passes (enqueued, not awaited);
+// kop_finish_frame = tracker association, trimBuffer, storeData (active_window.cpp:130-145).  Returns the track count.
+int kop_finish_frame(kop_handle* h, char* err, int err_len) {
+  if (!h) return KHR_EINVAL;
+  try {
+    if (h->pending) {
+      std::shared_ptr<FrameData> data = h->pending;
+      h->pending.reset();
+      if (auto* iou = dynamic_cast<MaxIoUTracker*>(h->tracker.get())) iou->completeInput(*data);
+      else h->tracker->processInput(*data);
+      h->buffer->trimBuffer(h->tracker->getTracks());
+      h->buffer->storeData(data);
+    }
+    return static_cast<int>(h->tracker->getTracks().size());
+  } catch (const std::exception& e) {
+    setErr(err, err_len, e.what());
+    return KHR_EDEVICE;
+  }
+}
+
+int kop_launch_frame(kop_handle* h, int slot, uint64_t stamp_ns, const double* world_T_sensor, const khr_sensor* sensor,
+                     int n_dynamic_clusters, char* err, int err_len) {
+  if (!h || !world_T_sensor || !sensor) return KHR_EINVAL;
+  if (h->pending) {
+    const int rc = kop_finish_frame(h, err, err_len);
+    if (rc < 0) return rc;
+  }
+  try {
+    auto data = std::make_shared<FrameData>();
+    InputData& in = data->input;
+    in.timestamp_ns = stamp_ns;
+    std::memcpy(in.world_T_sensor, world_T_sensor, sizeof(in.world_T_sensor));
+    std::memcpy(in.world_T_body, world_T_sensor, sizeof(in.world_T_body));
+    in.sensor = {sensor->width, sensor->height, sensor->fx, sensor->fy, sensor->cx, sensor->cy, sensor->min_range, sensor->max_range};
+    in.ctx = h->ctx;
+    in.slot = slot;
+    data->num_dynamic_clusters = n_dynamic_clusters;
+    if (n_dynamic_clusters > 0) FreeSpaceMotionDetector::fetchClusters(h->map, *data);
+    h->detector->processInput(h->map, *data);  // cached when khr_process_frame ran with KHR_PF_OBJECTS
+    if (auto* iou = dynamic_cast<MaxIoUTracker*>(h->tracker.get())) iou->beginInput(*data);
+    h->pending = data;
+    return KHR_OK;
+  } catch (const std::exception& e) {
+    setErr(err, err_len, e.what());
+    return KHR_EDEVICE;
+  }
+}
+
+int kop_process_frame(kop_handle* h, int slot, uint64_t stamp_ns, const double* world_T_sensor, const khr_sensor* sensor,
+                      int n_dynamic_clusters, char* err, int err_len) {
+  const int rc = kop_launch_frame(h, slot, stamp_ns, world_T_sensor, sensor, n_dynamic_clusters, err, err_len);
+  if (rc < 0) return rc;
+  return kop_finish_frame(h, err, err_len);
+}
+
+// extractInactiveObjects: inactive tracks leave the tracker and go through the extractor.  Returns the number of
+// extracted objects; *n_removed = tracks removed, *n_vertices = mesh vertices of the extracted objects.
+int kop_extract_inactive(kop_handle* h, int* n_removed, uint64_t* n_vertices, char* err, int err_len) {
+  if (!h) return KHR_EINVAL;
+  if (n_removed) *n_removed = 0;
+  if (n_vertices) *n_vertices = 0;
+  if (h->pending) {
+    const int rc = kop_finish_frame(h, err, err_len);
+    if (rc < 0) return rc;
+  }
+  try {
+    h->last_objects.clear();
+    Tracks& tracks = h->tracker->getTracks();
+    for (auto it = tracks.begin(); it != tracks.end();) {
+      if (it->is_active) {
+        ++it;
+        continue;
+      }
+      if (h->extractor) {
+        auto obj = h->extractor->extractObject(*it, *h->buffer);
+        if (obj) {
+          if (n_vertices) *n_vertices += obj->mesh.numVertices();
+          h->last_objects.push_back(obj);
+        }
+      }
+      if (n_removed) ++*n_removed;
+      it = tracks.erase(it);
+    }
+    return static_cast<int>(h->last_objects.size());
+  } catch (const std::exception& e) {
+    setErr(err, err_len, e.what());
+    return KHR_EDEVICE;
+  }
+}
+
+int kop_num_tracks(kop_handle* h) { return h ? static_cast<int>(h->tracker->getTracks().size()) : KHR_EINVAL; }
+int kop_num_buffered_frames(kop_handle* h) { return h ? static_cast<int>(h->buffer->size()) : KHR_EINVAL; }
+
+// tracks as flat records: id, is_dynamic, is_active, category, n_observations, first_seen, last_seen, confidence * 1e6
+int kop_get_tracks(kop_handle* h, int64_t* out /* 8 per track */, int cap) {
+  if (!h) return KHR_EINVAL;
+  const Tracks& tracks = h->tracker->getTracks();
+  int n = 0;
+  for (const Track& t : tracks) {
+    if (n < cap && out) {
+      int64_t* o = out + 8 * n;
+      o[0] = t.id;
+      o[1] = t.is_dynamic;
+      o[2] = t.is_active;
+      o[3] = t.semantics ? t.semantics->category_id : -1;
+      o[4] = static_cast<int64_t>(t.observations.size());
+      o[5] = static_cast<int64_t>(t.first_seen);
+      o[6] = static_cast<int64_t>(t.last_seen);
+      o[7] = static_cast<int64_t>(static_cast<double>(t.confidence) * 1e6 + 0.5);
+    }
+    ++n;
+  }
+  return n;
+}
+
+}  // extern "C"

@@ -158,34 +158,61 @@ MaxIoUTracker::MaxIoUTracker(const Config& cfg) : config(cfg) {
 }
 
 void MaxIoUTracker::processInput(FrameData& data) {
-  processing_stamp_ = data.input.timestamp_ns;  // max_iou_tracker.cpp:187-203
-  setupTrackMeasurements(data);
+  beginInput(data);  // max_iou_tracker.cpp:187-203
+  completeInput(data);
+}
+
+void MaxIoUTracker::beginInput(FrameData& data) { launchTrackMeasurements(data); }
+
+void MaxIoUTracker::completeInput(FrameData& data) {
+  processing_stamp_ = data.input.timestamp_ns;
+  finishTrackMeasurements(data);
   associateTracks(data);
   updateTrackingDuration();
 }
 
 void MaxIoUTracker::setupTrackMeasurements(FrameData& data) const {
-  // max_iou_tracker.cpp:464-487.  Bounding boxes arrive with the clusters (device reduction); the voxel sets of
-  // ALL clusters of an id image are one device pass.  Without a device frame (unit tests) the clusters are used
-  // as given.
+  launchTrackMeasurements(data);
+  finishTrackMeasurements(data);
+}
+
+// max_iou_tracker.cpp:464-487.  Bounding boxes arrive with the clusters (device reduction); the voxel sets of ALL
+// clusters of an id image are one device pass, enqueued here and collected in finishTrackMeasurements.  Without a
+// device frame (unit tests) the clusters are used as given.
+void MaxIoUTracker::launchTrackMeasurements(FrameData& data) const {
+  if (config.track_by != Config::TrackBy::kVoxels || !data.input.ctx || data.input.slot < 0) return;
+  if (!data.semantic_clusters.empty())
+    chk(khr_cluster_voxels_launch(data.input.ctx, data.input.slot, 1, config.voxel_size), "khr_cluster_voxels_launch");
+  if (!data.dynamic_clusters.empty())
+    chk(khr_cluster_voxels_launch(data.input.ctx, data.input.slot, 0, config.voxel_size), "khr_cluster_voxels_launch");
+}
+
+void MaxIoUTracker::finishTrackMeasurements(FrameData& data) const {
   if (config.track_by != Config::TrackBy::kVoxels || !data.input.ctx || data.input.slot < 0) return;
   auto fill = [&](std::vector<MeasurementCluster>& clusters, int which) {
     for (auto& c : clusters) c.voxels.clear();
     if (clusters.empty()) return;
-    int64_t n = khr_cluster_voxels(data.input.ctx, data.input.slot, which, config.voxel_size, nullptr, nullptr, 0);
-    chk(static_cast<int>(std::min<int64_t>(n, 0)), "khr_cluster_voxels");
-    if (n == 0) return;
-    std::vector<int32_t> ids(static_cast<size_t>(n));
-    std::vector<int64_t> vox(static_cast<size_t>(3 * n));
-    n = khr_cluster_voxels(data.input.ctx, data.input.slot, which, config.voxel_size, ids.data(), vox.data(), n);
-    chk(static_cast<int>(std::min<int64_t>(n, 0)), "khr_cluster_voxels");
+    if (scratch_ids_.empty()) {
+      scratch_ids_.resize(1u << 16);
+      scratch_voxels_.resize(3u << 16);
+    }
+    int64_t n = khr_cluster_voxels_fetch(data.input.ctx, which, scratch_ids_.data(), scratch_voxels_.data(),
+                                         static_cast<int64_t>(scratch_ids_.size()));
+    chk(static_cast<int>(std::min<int64_t>(n, 0)), "khr_cluster_voxels_fetch");
+    if (n > static_cast<int64_t>(scratch_ids_.size())) {
+      scratch_ids_.resize(static_cast<size_t>(n));
+      scratch_voxels_.resize(static_cast<size_t>(3 * n));
+      n = khr_cluster_voxels_fetch(data.input.ctx, which, scratch_ids_.data(), scratch_voxels_.data(), n);
+      chk(static_cast<int>(std::min<int64_t>(n, 0)), "khr_cluster_voxels_fetch");
+    }
     // pairs are sorted by (id, x, y, z)
+    const auto ib = scratch_ids_.begin(), ie = scratch_ids_.begin() + n;
     for (auto& c : clusters) {
-      const auto lo = std::lower_bound(ids.begin(), ids.end(), c.id), hi = std::upper_bound(ids.begin(), ids.end(), c.id);
+      const auto lo = std::lower_bound(ib, ie, c.id), hi = std::upper_bound(ib, ie, c.id);
       c.voxels.reserve(static_cast<size_t>(hi - lo));
       for (auto it = lo; it != hi; ++it) {
-        const size_t k = static_cast<size_t>(it - ids.begin());
-        c.voxels.push_back({vox[3 * k], vox[3 * k + 1], vox[3 * k + 2]});
+        const size_t k = static_cast<size_t>(it - ib);
+        c.voxels.push_back({scratch_voxels_[3 * k], scratch_voxels_[3 * k + 1], scratch_voxels_[3 * k + 2]});
       }
     }
   };

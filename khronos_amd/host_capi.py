@@ -1,0 +1,104 @@
+"""ctypes binding of the object half of the active window (khronos_amd/host/object_pipeline.cpp): object detector ->
+tracker -> frame buffer per frame and extraction of the tracks that left the window, on a FusionContext's frame
+slots.  The classes behind it are the C++ mirrors of the reference plugins (khronos_amd/host/)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .capi import KhrSensor, KhronosAmdError, load_library
+
+HOST_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libkhronos_amd_host.so")
+_host = None
+
+
+def load_host_library():
+    global _host
+    if _host is not None:
+        return _host
+    load_library()  # libkhronos_amd.so first (the host library links against it)
+    if not os.path.exists(HOST_LIB_PATH):
+        raise KhronosAmdError("host library %s is missing: run __graft_entry__.build()" % HOST_LIB_PATH)
+    lib = C.CDLL(HOST_LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, i32 = C.c_void_p, C.c_int32
+    lib.kop_create.argtypes = [vp, C.c_char_p, C.c_char_p, i32]
+    lib.kop_create.restype = vp
+    lib.kop_destroy.argtypes = [vp]
+    lib.kop_destroy.restype = None
+    lib.kop_process_frame.argtypes = [vp, i32, C.c_uint64, vp, C.POINTER(KhrSensor), i32, C.c_char_p, i32]
+    lib.kop_launch_frame.argtypes = [vp, i32, C.c_uint64, vp, C.POINTER(KhrSensor), i32, C.c_char_p, i32]
+    lib.kop_finish_frame.argtypes = [vp, C.c_char_p, i32]
+    lib.kop_extract_inactive.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_uint64), C.c_char_p, i32]
+    lib.kop_num_tracks.argtypes = [vp]
+    lib.kop_num_buffered_frames.argtypes = [vp]
+    lib.kop_get_tracks.argtypes = [vp, vp, i32]
+    _host = lib
+    return lib
+
+
+class ObjectPipeline:
+    """ConnectedSemantics / MaxIoUTracker / MeshObjectExtractor (as configured in the `active_window:` YAML) running on
+    the frame slots of `ctx` (a FusionContext whose num_frame_slots covers frame_data_buffer.max_buffer_size + 1)."""
+
+    def __init__(self, ctx, yaml_text):
+        self.lib = load_host_library()
+        self.ctx = ctx
+        self._err = C.create_string_buffer(512)
+        self.h = self.lib.kop_create(ctx.h, yaml_text.encode(), self._err, 512)
+        if not self.h:
+            raise KhronosAmdError("kop_create failed: %s" % self._err.value.decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.kop_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def process_frame(self, slot, stamp_ns, world_T_sensor, sensor, n_dynamic_clusters=0):
+        T = np.ascontiguousarray(world_T_sensor, dtype=np.float64).reshape(16)
+        n = self.lib.kop_process_frame(self.h, int(slot), int(stamp_ns), T.ctypes.data, C.byref(sensor), int(n_dynamic_clusters),
+                                       self._err, 512)
+        if n < 0:
+            raise KhronosAmdError("kop_process_frame failed (%d): %s" % (n, self._err.value.decode()))
+        return n
+
+    def launch_frame(self, slot, stamp_ns, world_T_sensor, sensor, n_dynamic_clusters=0):
+        """first half of process_frame: detector + the tracker's device passes are queued, nothing is awaited"""
+        T = np.ascontiguousarray(world_T_sensor, dtype=np.float64).reshape(16)
+        rc = self.lib.kop_launch_frame(self.h, int(slot), int(stamp_ns), T.ctypes.data, C.byref(sensor), int(n_dynamic_clusters),
+                                       self._err, 512)
+        if rc < 0:
+            raise KhronosAmdError("kop_launch_frame failed (%d): %s" % (rc, self._err.value.decode()))
+
+    def finish_frame(self):
+        """second half: tracker association + frame buffer for the launched frame (no-op without one); -> track count"""
+        n = self.lib.kop_finish_frame(self.h, self._err, 512)
+        if n < 0:
+            raise KhronosAmdError("kop_finish_frame failed (%d): %s" % (n, self._err.value.decode()))
+        return n
+
+    def extract_inactive(self):
+        """-> (objects extracted, tracks removed, mesh vertices of the extracted objects)"""
+        nr, nv = C.c_int32(0), C.c_uint64(0)
+        n = self.lib.kop_extract_inactive(self.h, C.byref(nr), C.byref(nv), self._err, 512)
+        if n < 0:
+            raise KhronosAmdError("kop_extract_inactive failed (%d): %s" % (n, self._err.value.decode()))
+        return n, nr.value, nv.value
+
+    def num_tracks(self):
+        return self.lib.kop_num_tracks(self.h)
+
+    def num_buffered_frames(self):
+        return self.lib.kop_num_buffered_frames(self.h)
+
+    def tracks(self):
+        n = self.lib.kop_get_tracks(self.h, None, 0)
+        out = np.zeros((max(n, 1), 8), np.int64)
+        n = self.lib.kop_get_tracks(self.h, out.ctypes.data, n)
+        return [dict(id=int(r[0]), dyn=int(r[1]), active=int(r[2]), cat=int(r[3]), n_obs=int(r[4]), first=int(r[5]), last=int(r[6]),
+                     conf=r[7] / 1e6) for r in out[:n]]

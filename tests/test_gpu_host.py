@@ -314,3 +314,61 @@ def test_ray_verificator_host_mirror(policy):
         assert r["present"] == [int(x) for x in pres] and r["absent"] == [int(x) for x in absn], i
         n_hits += len(pres) + len(absn)
     assert res["rays"] > 300 and n_hits > 20
+
+
+def test_object_pipeline_c_api_matches_replica():
+    """kop_* (detector -> tracker -> buffer -> extraction on a FusionContext's frame slots, the form bench.py and the
+    sharded driver use) against the step-wise device calls + the independent Python tracker."""
+    import py_tracker
+    from khronos_amd.host_capi import ObjectPipeline
+    n_frames = 24
+    cfg, ctx, ora, s, sen, osen = make_pair(width=W, height=H, temporal_window=0.75, truncation_distance=0.3, md_min_cluster_size=20,
+                                            md_min_separation_distance=2.0, md_max_range=5.0, num_frame_slots=41)
+    _, ctx2, _, _, _, _ = make_pair(width=W, height=H, temporal_window=0.75, truncation_distance=0.3, md_min_cluster_size=20,
+                                    md_min_separation_distance=2.0, md_max_range=5.0)
+    pipe = ObjectPipeline(ctx, PLUGIN_YAML)
+    ctx2.configure_object_detector(list(range(7, 20)), use_3d=True, grid_size=0.1, max_range=5.0, min_cluster_size=50,
+                                   use_full_connectivity=True)
+    trk = py_tracker.MaxIoUTracker("voxels", "assign_cluster", 0.25, 0.0, 0.1, 1.0, 0.75, 3, 0.2)
+    n_obj_total, removed_total = 0, 0
+    for i in range(n_frames):
+        fr = s.render(i)
+        out_now = i % 4 == 3
+        # product path: fused volumetric step, then the object half
+        f = ctx.make_frame(fr["stamp"], fr["pose"], 0)
+        depth = np.ascontiguousarray(fr["depth"]); rgb = np.ascontiguousarray(fr["rgb"]); lab = np.ascontiguousarray(fr["label"])
+        f.depth, f.color, f.label = depth.ctypes.data, rgb.ctypes.data, lab.ctypes.data
+        slot, nc = ctx.process_frame(sen, f, on_device=False, flags=ctx.PF_MOTION | ctx.PF_TRACKING | (ctx.PF_OUTPUT if out_now else 0))
+        n_tracks = pipe.process_frame(slot, fr["stamp"], fr["pose"], sen, nc)
+        # replica
+        slot2 = ctx2.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+        nd = ctx2.detect_motion(slot2)
+        assert nd == nc
+        ctx2.integrate(slot2, allocate_blocks=True, use_mask=True)
+        ctx2.update_tracking(fr["stamp"])
+        ns = ctx2.detect_objects(slot2)
+        sem, dyn = [], []
+        if ns:
+            ids, vox = ctx2.cluster_voxels(slot2, 1, 0.2)
+            for c in ctx2.semantic_clusters(slot2):
+                sem.append(dict(id=c["id"], category=c["semantic_id"], voxels={tuple(int(x) for x in r) for r in vox[ids == c["id"]]},
+                                box=(c["bbox_min"], c["bbox_max"])))
+        if nd:
+            ids, vox = ctx2.cluster_voxels(slot2, 0, 0.2)
+            for c in ctx2.dynamic_clusters(slot2):
+                dyn.append(dict(id=c["id"], voxels={tuple(int(x) for x in r) for r in vox[ids == c["id"]]}, box=(c["bbox_min"], c["bbox_max"])))
+        trk.process(fr["stamp"], sem, dyn)
+        assert n_tracks == len(trk.tracks)
+        if out_now:
+            ctx2.generate_mesh(True, True); ctx2.reset_inactive(); ctx2.clear_updated()
+            n_obj, n_rm, n_vert = pipe.extract_inactive()
+            gone = [t for t in trk.tracks if not t.is_active]
+            trk.tracks = [t for t in trk.tracks if t.is_active]
+            assert n_rm == len(gone) and n_obj <= n_rm
+            n_obj_total += n_obj
+            removed_total += n_rm
+    got = [{k: t[k] for k in ("id", "dyn", "active", "cat", "n_obs", "first", "last")} for t in pipe.tracks()]
+    want = [dict(id=t.id, dyn=int(t.is_dynamic), active=int(t.is_active), cat=t.category if t.has_semantics else -1,
+                 n_obs=len(t.observations), first=t.first_seen, last=t.last_seen) for t in trk.tracks]
+    assert got == want and len(want) >= 3 and removed_total >= 1
+    assert pipe.num_buffered_frames() <= 40

@@ -1577,7 +1577,7 @@ static int objectsLaunch(khr_ctx* c, int slot) {
   HIP_TRY(hipGetLastError());
   if (++c->obj_ticket == 0) ++c->obj_ticket;
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, c->stream, c->d_gv_n, reinterpret_cast<uint32_t*>(c->d_obj_head_host),
-                     static_cast<uint32_t>((16 + sizeof(ObjAcc) * kObjHead) / 4), c->d_pinned + 4, c->obj_ticket);
+                     static_cast<uint32_t>(sizeof(ObjAcc) / 4), kObjHead, c->d_pinned + 4, c->obj_ticket);
   HIP_TRY(hipGetLastError());
   c->obj_pending_slot = slot;
   return KHR_OK;
@@ -1698,8 +1698,8 @@ int khr_cluster_voxels_launch(khr_ctx* c, int slot, int which, float voxel_size)
   HIP_TRY(hipGetLastError());
   if (++c->cv_ticket[which] == 0) ++c->cv_ticket[which];
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, c->stream, c->d_cv_n[which], reinterpret_cast<uint32_t*>(c->d_cv_host[which]),
-                     static_cast<uint32_t>((16 + sizeof(uint64_t) * std::min<size_t>(kCvHead, c->cfg.max_frame_pixels)) / 4),
-                     c->d_pinned + 5 + which, c->cv_ticket[which]);
+                     2u, static_cast<uint32_t>(std::min<size_t>(kCvHead, c->cfg.max_frame_pixels)), c->d_pinned + 5 + which,
+                     c->cv_ticket[which]);
   HIP_TRY(hipGetLastError());
   return KHR_OK;
 }

@@ -357,8 +357,9 @@ class FusionContext:
         return self._chk(self.lib.khr_detect_motion_from_keys(self.h, slot, _ptr(keys), 0))
 
     def dynamic_clusters(self, slot):
-        arr = (KhrCluster * 255)()
-        n = self._chk(self.lib.khr_get_dynamic_clusters(self.h, slot, arr, 255))
+        n = self._chk(self.lib.khr_get_dynamic_clusters(self.h, slot, None, 0))
+        arr = (KhrCluster * max(n, 1))()
+        n = self._chk(self.lib.khr_get_dynamic_clusters(self.h, slot, arr, n))
         return [dict(id=a.id, num_pixels_listed=a.num_pixels_listed, num_pixels_painted=a.num_pixels_painted,
                      bbox_min=np.array(a.bbox_min[:]), bbox_max=np.array(a.bbox_max[:]), centroid=np.array(a.centroid[:]))
                 for a in arr[:n]]

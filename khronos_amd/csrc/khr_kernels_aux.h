@@ -117,22 +117,26 @@ struct VoxTable {
 
 __device__ inline int voxFind(const VoxTable& t, uint64_t key) {
   uint32_t h = hashKey(key) & t.mask;
-  while (true) {
+  for (uint32_t probes = 0; probes <= t.mask; ++probes) {
     const uint64_t k = t.keys[h];
     if (k == key) return static_cast<int>(h);
     if (k == kEmptyKey) return -1;
     h = (h + 1) & t.mask;
   }
+  return -1;
 }
 
+// bounded: a full table returns kInvalidSlot instead of probing forever (callers size their tables so that this
+// cannot happen and treat it as an error)
 __device__ inline uint32_t voxInsert(const VoxTable& t, uint64_t key) {
   uint32_t h = hashKey(key) & t.mask;
-  while (true) {
+  for (uint32_t probes = 0; probes <= t.mask; ++probes) {
     const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&t.keys[h]),
                                               static_cast<unsigned long long>(kEmptyKey), static_cast<unsigned long long>(key));
     if (prev == kEmptyKey || prev == key) return h;
     h = (h + 1) & t.mask;
   }
+  return kInvalidSlot;
 }
 
 __constant__ int8_t c_md_nbr26[26][3] = {
@@ -157,7 +161,10 @@ __device__ inline void voxInsertCounted(const VoxTable& t, bool has, uint64_t ke
     const uint64_t lk = (static_cast<uint64_t>(khi) << 32) | klo;
     const unsigned long long grp = __ballot(has && key == lk);
     todo &= ~grp;
-    if (static_cast<int>(laneId()) == leader) atomicAdd(&t.counts[voxInsert(t, lk)], static_cast<uint32_t>(__popcll(grp)));
+    if (static_cast<int>(laneId()) == leader) {
+      const uint32_t h = voxInsert(t, lk);
+      if (h != kInvalidSlot) atomicAdd(&t.counts[h], static_cast<uint32_t>(__popcll(grp)));
+    }
   }
 }
 
@@ -170,19 +177,29 @@ __global__ __launch_bounds__(256) void k_md_seed_insert(const uint64_t* __restri
 // every neighbour of every seed voxel -> the "near a seed" set (S * nn insertions, S is small) ...
 __global__ __launch_bounds__(256) void k_md_near_insert(const uint64_t* __restrict__ seed_keys,
                                                        const uint32_t* __restrict__ n_seeds, uint32_t cap, int nn,
-                                                       VoxTable near) {
+                                                       VoxTable near, uint32_t* __restrict__ overflow) {
   const uint32_t ns = min(*n_seeds, cap);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns * nn; i += gridDim.x * blockDim.x)
-    voxInsert(near, neighbourKey(seed_keys[i / nn], static_cast<int>(i % nn)));
+    if (voxInsert(near, neighbourKey(seed_keys[i / nn], static_cast<int>(i % nn))) == kInvalidSlot) atomicOr(overflow, 1u);
 }
 
 // ... so that a non-seed pixel needs ONE lookup to know whether its voxel is adjacent to a seed (the
 // neighbour relation is symmetric); such voxels form the boundary table with their pixel counts
 __global__ __launch_bounds__(256) void k_md_boundary_insert(const uint64_t* __restrict__ keys, int n, VoxTable near,
-                                                           VoxTable bnd) {
+                                                           VoxTable bnd, VoxTable seeds, int nn, int direct) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t k = i < n ? keys[i] : ~0ull;
-  const bool cand = k != ~0ull && !(k & kSeedBit) && voxFind(near, k) >= 0;
+  bool cand = k != ~0ull && !(k & kSeedBit);
+  if (cand) {
+    if (!direct) {
+      cand = voxFind(near, k) >= 0;
+    } else {
+      // frames with so many seed pixels that 26 neighbours per seed might not fit the `near` table: look the
+      // neighbours up in the seed table instead (26 lookups per pixel, no table that can fill up)
+      cand = false;
+      for (int j = 0; j < nn && !cand; ++j) cand = voxFind(seeds, neighbourKey(k, j)) >= 0;
+    }
+  }
   voxInsertCounted(bnd, cand, k);
 }
 

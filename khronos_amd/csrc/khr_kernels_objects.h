@@ -42,14 +42,15 @@ struct GvTable {
 
 __device__ inline int gvFind(const GvTable& t, uint64_t key) {
   uint32_t h = hashKey(key) & t.mask;
-  while (true) {
+  for (uint32_t probes = 0; probes <= t.mask; ++probes) {
     const uint64_t k = t.keys[h];
     if (k == key) return static_cast<int>(h);
     if (k == kEmptyKey) return -1;
     h = (h + 1) & t.mask;
   }
+  return -1;
 }
-// returns the slot; *claimed = this thread put the key there
+// returns the slot; *claimed = this thread put the key there (the table has 2 slots per pixel, so it cannot fill up)
 __device__ inline uint32_t gvInsert(const GvTable& t, uint64_t key, bool* claimed) {
   uint32_t h = hashKey(key) & t.mask;
   while (true) {

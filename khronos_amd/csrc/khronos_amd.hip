@@ -1117,8 +1117,12 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
   hipLaunchKernelGGL(k_md_seed_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds);
   hipLaunchKernelGGL(k_md_compact, dim3(gridFor(tsize)), dim3(256), 0, c->stream, seeds, c->d_md_seed_keys,
                      c->d_md_seed_counts, c->d_md_n, cap);
-  hipLaunchKernelGGL(k_md_near_insert, dim3(256), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_n, cap, nn, near);
-  hipLaunchKernelGGL(k_md_boundary_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, near, bnd);
+  // the `near` table takes up to nn entries per seed voxel (#seed voxels <= #seed pixels); when that could fill it,
+  // the boundary test looks the neighbours up in the seed table directly
+  const int direct = static_cast<double>(nn) * c->h_pinned[0] > 0.7 * static_cast<double>(tsize) ? 1 : 0;
+  if (!direct)
+    hipLaunchKernelGGL(k_md_near_insert, dim3(256), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_n, cap, nn, near, c->d_md_n + 3);
+  hipLaunchKernelGGL(k_md_boundary_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, near, bnd, seeds, nn, direct);
   hipLaunchKernelGGL(k_md_compact, dim3(gridFor(tsize)), dim3(256), 0, c->stream, bnd, c->d_md_bnd_keys, c->d_md_bnd_counts,
                      c->d_md_n + 1, cap);
   hipLaunchKernelGGL(k_md_adjacency, dim3(1024), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_n, seeds, bnd, nn, cap,
@@ -1141,6 +1145,7 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
   lap("tables + adjacency + components + head sync");
   const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c->h_md_head);
   const uint32_t S = cnt[0], B = cnt[1], R = cnt[2];
+  if (cnt[3]) return fail(KHR_ENOMEM, "motion detector: neighbour table overflow (%u seed voxels)", S);
   if (S > cap || B > cap) return fail(KHR_ENOMEM, "motion detector: %u seed / %u boundary voxels exceed the list capacity %u", S, B, cap);
   if (R <= kCompCap && !c->md_host_walk) {
     if (R > kCompHead) {

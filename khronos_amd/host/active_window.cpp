@@ -93,10 +93,11 @@ void FreeSpaceMotionDetector::processInput(const VolumetricMap& map, FrameData& 
 void FreeSpaceMotionDetector::fetchClusters(const VolumetricMap& map, FrameData& data) {
   data.dynamic_clusters.clear();
   if (data.num_dynamic_clusters <= 0) return;
-  std::vector<khr_cluster> cl(255);
-  const int n = khr_get_dynamic_clusters(map.ctx(), data.input.slot, cl.data(), 255);
+  // ids saturate at 255 but the cluster list does not (free_space_motion_detector.cpp:384-395)
+  std::vector<khr_cluster> cl(static_cast<size_t>(std::max(data.num_dynamic_clusters, 1)));
+  const int n = khr_get_dynamic_clusters(map.ctx(), data.input.slot, cl.data(), static_cast<int>(cl.size()));
   chk(n, "khr_get_dynamic_clusters");
-  for (int i = 0; i < n; ++i) {
+  for (int i = 0; i < n && i < static_cast<int>(cl.size()); ++i) {
     MeasurementCluster m;
     m.id = cl[i].id;
     m.num_pixels = cl[i].num_pixels_listed;

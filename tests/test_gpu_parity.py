@@ -404,3 +404,44 @@ def test_two_shards_mesh_halo_equals_unsharded():
     c0.mesh_halo_import(None)
     c0.generate_mesh(False, False)
     assert len(c0.download_mesh()["points"]) < len(parts[0]["points"])
+
+
+@pytest.mark.parametrize("mode", ["lds", "global", "host"])
+def test_motion_clustering_from_key_images(mode, monkeypatch):
+    """the clustering half of the motion detector on hand-made voxel-key images (no map involved): duplicate boundary
+    counts, truncated-norm merging, 300 clusters (ids saturate at 255), 1500 components (more than the device record
+    capacity: host path), shared boundary voxels with zero separation — device vs oracle, every clustering mode."""
+    from test_cpu_motion_kat import _image, key
+    if mode == "host":
+        monkeypatch.setenv("KHR_MD_HOST_WALK", "1")
+    if mode == "global":
+        monkeypatch.setenv("KHR_MD_LDS_MAX", "0")
+    W, H = 128, 64
+    rng = np.random.default_rng(8)
+    cases = []
+    cases.append(([(key(0, 0, 0, True), 3), (key(1, 0, 0, True), 3), (key(0, 1, 0), 5)], dict(md_min_cluster_size=16, md_min_separation_distance=0.5)))
+    cases.append(([(key(0, 0, 0, True), 4), (key(2, 2, 2, True), 4)], dict(md_min_cluster_size=1, md_min_separation_distance=3.2)))
+    cases.append(([(key(4 * i, 0, 0, True), 3) for i in range(300)], dict(md_min_cluster_size=1, md_min_separation_distance=1.0)))
+    cases.append(([(key(3 * (i % 40), 3 * (i // 40), 7, True), 2) for i in range(1500)], dict(md_min_cluster_size=1, md_min_separation_distance=1.0)))
+    cases.append(([(key(0, 0, 0, True), 3), (key(2, 0, 0, True), 3), (key(1, 0, 0), 5)], dict(md_min_cluster_size=1, md_min_separation_distance=0.0)))
+    # random blobs: seeds and occupied voxels scattered in a 12^3 cube, 1..6 pixels each
+    vox = rng.integers(0, 12, (400, 3))
+    vox = np.unique(vox, axis=0)
+    runs = [(key(int(v[0]), int(v[1]), int(v[2]), bool(rng.uniform() < 0.35)), int(rng.integers(1, 7))) for v in vox]
+    cases.append((runs, dict(md_min_cluster_size=4, md_min_separation_distance=1.0)))
+    cases.append((runs, dict(md_min_cluster_size=1, md_min_separation_distance=2.5, md_neighbor_connectivity=6)))
+    for runs, kw in cases:
+        cfg, ctx, ora, s, sen, osen = make_pair(width=W, height=H, **kw)
+        img, _ = _image(W, H, runs)
+        # a frame slot to paint into (its content is irrelevant: the keys are given)
+        fr = s.render(0)
+        slot = ctx.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+        n_g = ctx.detect_motion_from_keys(slot, img)
+        n_o, dyn_o, _ = ora.detect_motion_from_keys(img)
+        dyn_g = ctx.download_frame(slot, (H, W), range_image=False, dynamic_image=True)[2]
+        assert n_g == n_o, (kw, n_g, n_o)
+        assert np.array_equal(dyn_g, dyn_o), kw
+        cl = ctx.dynamic_clusters(slot)
+        assert len(cl) == n_g
+        for c in cl[:50]:
+            assert c["num_pixels_painted"] == int((dyn_o == c["id"]).sum()) or c["id"] == 255

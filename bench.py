@@ -175,9 +175,20 @@ def main():
         stamps.append(fr["stamp"])
         poses.append([s.pose(i, yaw_offset=2.0 * math.pi * r / world) for r in range(world)])
     if world > 1:
-        g_depth = [torch.empty_like(d_depth[0]) for _ in range(world)]
-        g_rgb = [torch.empty_like(d_rgb[0]) for _ in range(world)]
-        g_label = [torch.empty_like(d_label[0]) for _ in range(world)]
+        # one packed buffer per frame (depth f32 | label i32 | rgb u8x3) so that a tick needs ONE frame all-gather
+        npx = W * H
+        packed = []
+        for i in range(n_total):
+            pk = torch.empty(11 * npx, dtype=torch.uint8, device=dev)
+            pk[: 4 * npx] = d_depth[i].view(torch.uint8).reshape(-1)
+            pk[4 * npx: 8 * npx] = d_label[i].view(torch.uint8).reshape(-1)
+            pk[8 * npx:] = d_rgb[i].reshape(-1)
+            packed.append(pk)
+        g_flat = torch.empty(world * 11 * npx, dtype=torch.uint8, device=dev)  # flat: the concatenated form every backend accepts
+        g_packed = g_flat.view(world, 11 * npx)
+        g_depth = [g_packed[r, : 4 * npx].view(torch.float32).view(H, W) for r in range(world)]
+        g_label = [g_packed[r, 4 * npx: 8 * npx].view(torch.int32).view(H, W) for r in range(world)]
+        g_rgb = [g_packed[r, 8 * npx:].view(H, W, 3) for r in range(world)]
     torch.cuda.synchronize()
 
     # input descriptors (khr_frame: stamp, pose, HBM pointers) are built before the timed region
@@ -198,9 +209,7 @@ def main():
 
     def _step(i):
         if world > 1:
-            dist.all_gather(g_depth, d_depth[i])
-            dist.all_gather(g_rgb, d_rgb[i])
-            dist.all_gather(g_label, d_label[i])
+            dist.all_gather_into_tensor(g_flat, packed[i])
             cams = [(g_depth[r], g_rgb[r], g_label[r], poses[i][r]) for r in range(world)]
         else:
             cams = [(d_depth[i], d_rgb[i], d_label[i], poses[i][0])]
@@ -300,7 +309,7 @@ def main():
                                % (W, H, vs * 100, K, "off" if args.no_motion else "on",
                                   "off" if args.no_objects else "on (ConnectedSemantics, MaxIoUTracker, MeshObjectExtractor)",
                                   args.output_every, world),
-                   "parallelism": "hash-range block shard x%d, owner-computes, RCCL all-gather of frames + of 528-B halo records "
+                   "parallelism": "hash-range block shard x%d, owner-computes, RCCL all-gather of packed frames + of 528-B halo records "
                                   "(ever-free), seed-gated all-reduce of per-pixel voxel keys (motion detector), request / response all-gather of mesh halo planes" % world
                    if world > 1 else "single GPU"},
         "mvoxel_updates_per_s": 1e-6 * n_upd_all / dt,

@@ -87,10 +87,16 @@ class ShardedFusion:
     def all_gather(self, t):
         if self.dist is None or self.world == 1:
             return t
-        if self._recv is None or self._recv[0].shape != t.shape or self._recv[0].device != t.device:
-            self._recv = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(self._recv, t)
-        return torch.cat(self._recv, dim=0)
+        # one contiguous receive buffer per (shape, dtype): the collective writes into it directly (no list + cat copy)
+        key = (tuple(t.shape), t.dtype, t.device)
+        if self._recv is None:
+            self._recv = {}
+        out = self._recv.get(key)
+        if out is None:
+            out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            self._recv[key] = out
+        self.dist.all_gather_into_tensor(out, t.contiguous())
+        return out
 
     def tick(self, stamp, cameras):
         """cameras: list of (pose, depth, rgb, label) for ALL cameras of the rig (already gathered)."""

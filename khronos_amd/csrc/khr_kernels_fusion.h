@@ -451,15 +451,32 @@ __global__ __launch_bounds__(256) void k_tsdf_update(TsdfArgs a, const uint32_t*
     }
     uint32_t any = 0;
     // ---- pass 1: measurement per voxel -> LDS (branch-free; invalid lanes are masked by `ok`) ----
+    // A thread's voxels of one work item differ only in z (the stride 256 is a multiple of VPS * VPS for VPS = 16 and
+    // of VPS for VPS = 8), so the x / y parts of the transform -- (R[3c] * px + R[3c+1] * py), the first addition of
+    // xform() -- are computed once per work item; the remaining operations keep xform()'s order, bit for bit.
+    constexpr bool kHoistXY = (256 % (VPS * VPS)) == 0;
+    float pxy[3] = {0.f, 0.f, 0.f};
+    if (kHoistXY) {
+      const int lin0 = cbase + static_cast<int>(threadIdx.x);
+      const float px = ox + (static_cast<float>(lin0 % VPS) + 0.5f) * a.vs;
+      const float py = oy + (static_cast<float>((lin0 / VPS) % VPS) + 0.5f) * a.vs;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pxy[c] = a.R[3 * c] * px + a.R[3 * c + 1] * py;
+    }
 #pragma unroll 2
     for (int cl = threadIdx.x; cl < CV; cl += 256) {
       const int lin = cbase + cl;
       const int ix = lin % VPS, iy = (lin / VPS) % VPS, iz = lin / (VPS * VPS);
-      const float px = ox + (static_cast<float>(ix) + 0.5f) * a.vs;
-      const float py = oy + (static_cast<float>(iy) + 0.5f) * a.vs;
       const float pz = oz + (static_cast<float>(iz) + 0.5f) * a.vs;
       float pc[3];
-      xform(a.R, a.t, px, py, pz, pc);
+      if (kHoistXY) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pc[c] = (pxy[c] + a.R[3 * c + 2] * pz) + a.t[c];
+      } else {
+        const float px = ox + (static_cast<float>(ix) + 0.5f) * a.vs;
+        const float py = oy + (static_cast<float>(iy) + 0.5f) * a.vs;
+        xform(a.R, a.t, px, py, pz, pc);
+      }
       bool ok = pc[2] > 0.f;
       const float voxel_range =
           range_mode == 0 ? pc[2] : sqrtf((pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2]);

@@ -134,12 +134,22 @@ __device__ inline int labelRank(const int32_t* __restrict__ labels, int n, int32
   return -1;
 }
 
+// per-cluster summary (MeasurementCluster role, measurement_clusters.h:63-80)
+struct ObjAcc {
+  uint32_t n_pixels;
+  uint32_t first_cm;         // smallest column-major pixel index u*H+v (the scan order of :147-148)
+  int32_t bmin[3], bmax[3];  // floats mapped to order-preserving ints
+  float sum[3];
+  uint32_t group;            // label rank
+};
+
 // ---- ConnectedSemantics, 3D mode ---------------------------------------------------------------------------------------
 // computeCandidateVoxels (connected_semantics.cpp:123-144): one thread per pixel
 __global__ __launch_bounds__(256) void k_obj_insert3d(DevFrame f, const int32_t* __restrict__ obj_labels, int n_labels,
                                                      float max_range, float inv, int3 origin, GvTable t,
                                                      uint32_t* __restrict__ parent, uint32_t* __restrict__ pix_node,
-                                                     uint32_t* __restrict__ flags /* [0] window overflow */) {
+                                                     uint32_t* __restrict__ flags /* [0] window overflow */,
+                                                     uint32_t* __restrict__ owners, uint32_t* __restrict__ n_owners) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in = i < f.W * f.H;
   bool has = false;
@@ -156,33 +166,73 @@ __global__ __launch_bounds__(256) void k_obj_insert3d(DevFrame f, const int32_t*
   }
   bool claimed;
   const uint32_t h = gvInsertWave(t, has, key, &claimed);
-  if (claimed) parent[h] = h;
+  // the claimed slots (one per distinct voxel) form the work list of the union / root passes and of the table reset
+  const uint32_t at = waveAggInc(n_owners, claimed);
+  if (claimed) {
+    parent[h] = h;
+    owners[at] = h;
+  }
   if (in) pix_node[i] = has ? (h | (claimed ? kNodeOwner : 0u)) : kNodeNone;
 }
 
 __constant__ int8_t c_obj_fwd13[13][3] = {{1, 0, 0},  {0, 1, 0},   {0, 0, 1},  {1, 1, 0},  {-1, 1, 0}, {1, 0, 1}, {-1, 0, 1},
                                           {0, 1, 1},  {0, -1, 1},  {1, 1, 1},  {-1, 1, 1}, {1, -1, 1}, {-1, -1, 1}};
 
-// region growing (:79-98) as union-find: the owner of a voxel links it to its forward neighbours of the same
-// semantic id (the relation is symmetric, so 13 of 26 / 3 of 6 directions cover every pair once)
-__global__ __launch_bounds__(256) void k_obj_union3d(const uint32_t* __restrict__ pix_node, int n, GvTable t,
+// region growing (:79-98) as union-find: every voxel is linked to its forward neighbours of the same semantic id (the
+// relation is symmetric, so 13 of 26 / 3 of 6 directions cover every pair once).  One thread per (voxel, direction):
+// the table lookups of a voxel run in parallel instead of as one latency chain.
+__global__ __launch_bounds__(256) void k_obj_union3d(const uint32_t* __restrict__ owners, const uint32_t* __restrict__ n_owners, GvTable t,
                                                     uint32_t* __restrict__ parent, int n_dirs) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t node = pix_node[i];
-  if (node == kNodeNone || !(node & kNodeOwner)) return;
-  const uint32_t h = node & ~kNodeOwner;
-  const uint64_t key = t.keys[h];
-  if (gvIsOrigin(key)) return;
-  uint32_t g;
-  int x, y, z;
-  gvUnpack(key, &g, &x, &y, &z);
-  for (int k = 0; k < n_dirs; ++k) {
+  const uint32_t total = *n_owners * static_cast<uint32_t>(n_dirs);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const uint32_t h = owners[i / n_dirs];
+    const int k = static_cast<int>(i % n_dirs);
+    const uint64_t key = t.keys[h];
+    if (gvIsOrigin(key)) continue;
+    uint32_t g;
+    int x, y, z;
+    gvUnpack(key, &g, &x, &y, &z);
     const int nx = x + c_obj_fwd13[k][0], ny = y + c_obj_fwd13[k][1], nz = z + c_obj_fwd13[k][2];
     if (nx < -kGvWindow || nx > kGvWindow || ny < -kGvWindow || ny > kGvWindow || nz < -kGvWindow || nz > kGvWindow) continue;
     const int hn = gvFind(t, gvKey(g, nx, ny, nz));
     if (hn >= 0) ufUnion(parent, h, static_cast<uint32_t>(hn));
   }
+}
+
+// 3D mode: the voxels flatten to their roots; roots take a compact cluster index and initialise its summary
+__global__ __launch_bounds__(256) void k_obj_roots3d(const uint32_t* __restrict__ owners, const uint32_t* __restrict__ n_owners,
+                                                    uint32_t* __restrict__ parent, uint32_t* __restrict__ root_idx,
+                                                    uint32_t* __restrict__ n_roots, uint32_t cap, ObjAcc* __restrict__ acc,
+                                                    const uint64_t* __restrict__ keys) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool on = i < *n_owners;
+  uint32_t h = 0;
+  bool is_root = false;
+  if (on) {
+    h = owners[i];
+    const uint32_t r = ufFind(parent, h);
+    is_root = r == h;
+    if (!is_root) __atomic_store_n(parent + h, r, __ATOMIC_RELAXED);
+  }
+  const uint32_t idx = waveAggInc(n_roots, is_root);
+  if (is_root) {
+    root_idx[h] = idx;
+    if (idx < cap) {
+      ObjAcc a;
+      a.n_pixels = 0;
+      a.first_cm = 0xffffffffu;
+      for (int d = 0; d < 3; ++d) { a.bmin[d] = INT32_MAX; a.bmax[d] = INT32_MIN; a.sum[d] = 0.f; }
+      a.group = static_cast<uint32_t>(keys[h] >> 48);
+      acc[idx] = a;
+    }
+  }
+}
+
+// give the table back empty: only the slots this frame used are touched (a full clear is 16 MB at 720p)
+__global__ __launch_bounds__(256) void k_gv_release(const uint32_t* __restrict__ slots, const uint32_t* __restrict__ n_slots,
+                                                   uint64_t* __restrict__ keys) {
+  const uint32_t n = *n_slots;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) keys[slots[i]] = kEmptyKey;
 }
 
 // ---- ConnectedSemantics, 2D mode (semanticClustering2D / growCluster2D, :146-198) ---------------------------------------
@@ -213,15 +263,6 @@ __global__ __launch_bounds__(256) void k_obj_union2d(DevFrame f, const uint32_t*
 }
 
 // ---- shared tail: roots, paint, remap ---------------------------------------------------------------------------------------
-// per-cluster summary (MeasurementCluster role, measurement_clusters.h:63-80)
-struct ObjAcc {
-  uint32_t n_pixels;
-  uint32_t first_cm;         // smallest column-major pixel index u*H+v (the scan order of :147-148)
-  int32_t bmin[3], bmax[3];  // floats mapped to order-preserving ints
-  float sum[3];
-  uint32_t group;            // label rank
-};
-
 __device__ inline int32_t objFloatToOrdered(float f) {
   const int32_t i = __float_as_int(f);
   return i >= 0 ? i : i ^ 0x7fffffff;
@@ -366,7 +407,7 @@ __global__ __launch_bounds__(256) void k_obj_remap(int32_t* __restrict__ obj, in
 // ---- per-cluster voxel sets at the tracker's grid (max_iou_tracker.cpp:478-487) ------------------------------------------------
 __global__ __launch_bounds__(256) void k_cluster_voxels(DevFrame f, const int32_t* __restrict__ id_image, float inv, int3 origin,
                                                        GvTable t, uint64_t* __restrict__ list, uint32_t* __restrict__ n_list,
-                                                       uint32_t cap, uint32_t* __restrict__ flags) {
+                                                       uint32_t cap, uint32_t* __restrict__ flags, uint32_t* __restrict__ slots) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool has = false;
   uint64_t key = 0;
@@ -385,10 +426,12 @@ __global__ __launch_bounds__(256) void k_cluster_voxels(DevFrame f, const int32_
   }
   bool claimed;
   const uint32_t h = gvInsertWave(t, has, key, &claimed);
-  (void)h;
   const uint64_t my_key = key;  // the claiming lane is the leader of its own key group
   const uint32_t at = waveAggInc(n_list, claimed);
-  if (claimed && at < cap) list[at] = my_key;
+  if (claimed && at < cap) {
+    list[at] = my_key;
+    slots[at] = h;
+  }
 }
 
 }  // namespace khr

@@ -161,6 +161,8 @@ struct khr_ctx {
   int32_t* d_obj_final = nullptr;
   uint64_t* d_cv_list = nullptr;
   uint32_t obj_root_cap = 0;
+  uint32_t* d_gv_owners = nullptr;  // table slots claimed by the current request (work list + table reset)
+  bool gv_clean = false;            // the (group, voxel) table is empty (every request gives it back empty)
   uint8_t* h_obj_head = nullptr;   // pinned: {roots, flags, -, -} + the cluster records (first download kObjHead of them)
   hipEvent_t ev_obj = nullptr;
   int obj_pending_slot = -1;       // objectsLaunch issued, objectsFinish outstanding
@@ -1479,6 +1481,7 @@ static int ensureGv(khr_ctx* c) {
   A(devAlloc(c, &c->d_gv_parent, ts, false));  // >= npx: also the per-pixel parent array of the 2D mode
   A(devAlloc(c, &c->d_gv_rootidx, ts, false));
   A(devAlloc(c, &c->d_gv_node, npx, false));
+  A(devAlloc(c, &c->d_gv_owners, npx, false));
   {
     // counters and cluster records are contiguous: one small copy brings both to the host
     uint8_t* head = nullptr;
@@ -1563,19 +1566,26 @@ static int objectsLaunch(khr_ctx* c, int slot) {
   // (the object image needs no clearing: the paint pass writes every pixel)
   if (oc.use_3d) {
     const float inv = 1.f / oc.grid_size;  // connected_semantics.cpp:75
-    hipLaunchKernelGGL(k_gv_clear, dim3(gridFor(tsize / 2)), dim3(256), 0, c->stream, c->d_gv_keys, tsize, c->d_gv_n);
+    if (!c->gv_clean) hipLaunchKernelGGL(k_gv_clear, dim3(gridFor(tsize / 2)), dim3(256), 0, c->stream, c->d_gv_keys, tsize, c->d_gv_n);
+    else HIP_TRY(hipMemsetAsync(c->d_gv_n, 0, sizeof(uint32_t) * 4, c->stream));
+    c->gv_clean = false;
     hipLaunchKernelGGL(k_obj_insert3d, dim3(gridFor(n)), dim3(256), 0, c->stream, f, c->d_obj_labels, n_labels, oc.max_range, inv,
-                       windowOrigin(f, inv), t, c->d_gv_parent, c->d_gv_node, c->d_gv_n + 1);
-    hipLaunchKernelGGL(k_obj_union3d, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_gv_node, n, t, c->d_gv_parent,
+                       windowOrigin(f, inv), t, c->d_gv_parent, c->d_gv_node, c->d_gv_n + 1, c->d_gv_owners, c->d_gv_n + 2);
+    hipLaunchKernelGGL(k_obj_union3d, dim3(1024), dim3(256), 0, c->stream, c->d_gv_owners, c->d_gv_n + 2, t, c->d_gv_parent,
                        oc.use_full_connectivity ? 13 : 3);
+    hipLaunchKernelGGL(k_obj_roots3d, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_gv_owners, c->d_gv_n + 2, c->d_gv_parent,
+                       c->d_gv_rootidx, c->d_gv_n, c->obj_root_cap, c->d_obj_acc, c->d_gv_keys);
+    // the keys are not needed any more (the paint pass goes through pix_node -> parent -> root_idx)
+    hipLaunchKernelGGL(k_gv_release, dim3(256), dim3(256), 0, c->stream, c->d_gv_owners, c->d_gv_n + 2, c->d_gv_keys);
+    c->gv_clean = true;
   } else {
     HIP_TRY(hipMemsetAsync(c->d_gv_n, 0, sizeof(uint32_t) * 4, c->stream));
     hipLaunchKernelGGL(k_obj_init2d, dim3(gridFor(n)), dim3(256), 0, c->stream, f, c->d_obj_labels, n_labels, c->d_gv_parent, c->d_gv_node);
     hipLaunchKernelGGL(k_obj_union2d, dim3(gridFor(n)), dim3(256), 0, c->stream, f, c->d_gv_node, c->d_gv_parent,
                        oc.use_full_connectivity ? 1 : 0);
+    hipLaunchKernelGGL(k_obj_roots, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_gv_node, n, c->d_gv_parent, c->d_gv_rootidx, c->d_gv_n,
+                       c->obj_root_cap, c->d_obj_acc, nullptr, s.label, c->d_obj_labels, n_labels);
   }
-  hipLaunchKernelGGL(k_obj_roots, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_gv_node, n, c->d_gv_parent, c->d_gv_rootidx, c->d_gv_n,
-                     c->obj_root_cap, c->d_obj_acc, oc.use_3d ? c->d_gv_keys : nullptr, s.label, c->d_obj_labels, n_labels);
   const int obj_tiles = ((s.sensor.width + kObjTile - 1) / kObjTile) * ((s.sensor.height + kObjTile - 1) / kObjTile);
   hipLaunchKernelGGL(k_obj_paint, dim3(obj_tiles), dim3(1024), 0, c->stream, f, c->d_gv_node, c->d_gv_parent, c->d_gv_rootidx,
                      c->obj_root_cap, s.obj, c->d_obj_acc);
@@ -1697,9 +1707,14 @@ int khr_cluster_voxels_launch(khr_ctx* c, int slot, int which, float voxel_size)
   c->cv_origin[which] = windowOrigin(f, inv);
   GvTable t{c->d_gv_keys, c->gv_mask};
   const uint32_t tsize = c->gv_mask + 1;
-  hipLaunchKernelGGL(k_gv_clear, dim3(gridFor(tsize / 2)), dim3(256), 0, c->stream, c->d_gv_keys, tsize, c->d_cv_n[which]);
+  if (!c->gv_clean) hipLaunchKernelGGL(k_gv_clear, dim3(gridFor(tsize / 2)), dim3(256), 0, c->stream, c->d_gv_keys, tsize, c->d_cv_n[which]);
+  else HIP_TRY(hipMemsetAsync(c->d_cv_n[which], 0, sizeof(uint32_t) * 4, c->stream));
+  c->gv_clean = false;
   hipLaunchKernelGGL(k_cluster_voxels, dim3(gridFor(n)), dim3(256), 0, c->stream, f, which == 0 ? s.dyn : s.obj, inv, c->cv_origin[which], t,
-                     c->d_cv_keys[which], c->d_cv_n[which], static_cast<uint32_t>(c->cfg.max_frame_pixels), c->d_cv_n[which] + 1);
+                     c->d_cv_keys[which], c->d_cv_n[which], static_cast<uint32_t>(c->cfg.max_frame_pixels), c->d_cv_n[which] + 1,
+                     c->d_gv_owners);
+  hipLaunchKernelGGL(k_gv_release, dim3(256), dim3(256), 0, c->stream, c->d_gv_owners, c->d_cv_n[which], c->d_gv_keys);
+  c->gv_clean = true;
   HIP_TRY(hipGetLastError());
   if (++c->cv_ticket[which] == 0) ++c->cv_ticket[which];
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, c->stream, c->d_cv_n[which], reinterpret_cast<uint32_t*>(c->d_cv_host[which]),

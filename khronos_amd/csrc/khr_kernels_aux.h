@@ -65,12 +65,14 @@ __global__ __launch_bounds__(256) void k_motion_pixels(DevMap m, DevParams p, De
 // packets, this costs a ~5 us kernel and nothing else.
 __global__ __launch_bounds__(1024) void k_publish(const uint32_t* __restrict__ src, volatile uint32_t* __restrict__ dst_host,
                                                  uint32_t rec_words, uint32_t max_recs, volatile uint32_t* __restrict__ ticket_host,
-                                                 uint32_t ticket) {
-  // block layout: 4 counter words (word 0 = number of records) + the records; only the records that exist travel
+                                                 uint32_t ticket, uint32_t* __restrict__ counters_to_zero) {
+  // block layout: 4 counter words (word 0 = number of records) + the records; only the records that exist travel.
+  // The counters are zeroed afterwards: the next request of this kind starts clean without a memset command.
   const uint32_t n_words = 4u + min(src[0], max_recs) * rec_words;
   for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) dst_host[i] = src[i];
   __threadfence_system();
   __syncthreads();
+  if (threadIdx.x < 4) counters_to_zero[threadIdx.x] = 0u;
   if (threadIdx.x == 0) {
     *ticket_host = ticket;
     __threadfence_system();

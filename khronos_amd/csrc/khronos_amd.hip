@@ -163,6 +163,7 @@ struct khr_ctx {
   uint32_t obj_root_cap = 0;
   uint32_t* d_gv_owners = nullptr;  // table slots claimed by the current request (work list + table reset)
   bool gv_clean = false;            // the (group, voxel) table is empty (every request gives it back empty)
+  bool gv_counters_clean[3] = {false, false, false};  // request counters zeroed by their last k_publish: detect, voxels 0 / 1
   uint8_t* h_obj_head = nullptr;   // pinned: {roots, flags, -, -} + the cluster records (first download kObjHead of them)
   hipEvent_t ev_obj = nullptr;
   int obj_pending_slot = -1;       // objectsLaunch issued, objectsFinish outstanding
@@ -1566,9 +1567,11 @@ static int objectsLaunch(khr_ctx* c, int slot) {
   // (the object image needs no clearing: the paint pass writes every pixel)
   if (oc.use_3d) {
     const float inv = 1.f / oc.grid_size;  // connected_semantics.cpp:75
+    // (the counters were zeroed by the k_publish of the previous request, unless that one never got that far)
     if (!c->gv_clean) hipLaunchKernelGGL(k_gv_clear, dim3(gridFor(tsize / 2)), dim3(256), 0, c->stream, c->d_gv_keys, tsize, c->d_gv_n);
-    else HIP_TRY(hipMemsetAsync(c->d_gv_n, 0, sizeof(uint32_t) * 4, c->stream));
+    else if (!c->gv_counters_clean[0]) HIP_TRY(hipMemsetAsync(c->d_gv_n, 0, sizeof(uint32_t) * 4, c->stream));
     c->gv_clean = false;
+    c->gv_counters_clean[0] = false;
     hipLaunchKernelGGL(k_obj_insert3d, dim3(gridFor(n)), dim3(256), 0, c->stream, f, c->d_obj_labels, n_labels, oc.max_range, inv,
                        windowOrigin(f, inv), t, c->d_gv_parent, c->d_gv_node, c->d_gv_n + 1, c->d_gv_owners, c->d_gv_n + 2);
     hipLaunchKernelGGL(k_obj_union3d, dim3(1024), dim3(256), 0, c->stream, c->d_gv_owners, c->d_gv_n + 2, t, c->d_gv_parent,
@@ -1592,8 +1595,9 @@ static int objectsLaunch(khr_ctx* c, int slot) {
   HIP_TRY(hipGetLastError());
   if (++c->obj_ticket == 0) ++c->obj_ticket;
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, c->stream, c->d_gv_n, reinterpret_cast<uint32_t*>(c->d_obj_head_host),
-                     static_cast<uint32_t>(sizeof(ObjAcc) / 4), kObjHead, c->d_pinned + 4, c->obj_ticket);
+                     static_cast<uint32_t>(sizeof(ObjAcc) / 4), kObjHead, c->d_pinned + 4, c->obj_ticket, c->d_gv_n);
   HIP_TRY(hipGetLastError());
+  c->gv_counters_clean[0] = oc.use_3d != 0;  // (the 2D path resets them itself)
   c->obj_pending_slot = slot;
   return KHR_OK;
 }
@@ -1708,8 +1712,9 @@ int khr_cluster_voxels_launch(khr_ctx* c, int slot, int which, float voxel_size)
   GvTable t{c->d_gv_keys, c->gv_mask};
   const uint32_t tsize = c->gv_mask + 1;
   if (!c->gv_clean) hipLaunchKernelGGL(k_gv_clear, dim3(gridFor(tsize / 2)), dim3(256), 0, c->stream, c->d_gv_keys, tsize, c->d_cv_n[which]);
-  else HIP_TRY(hipMemsetAsync(c->d_cv_n[which], 0, sizeof(uint32_t) * 4, c->stream));
+  else if (!c->gv_counters_clean[1 + which]) HIP_TRY(hipMemsetAsync(c->d_cv_n[which], 0, sizeof(uint32_t) * 4, c->stream));
   c->gv_clean = false;
+  c->gv_counters_clean[1 + which] = false;
   hipLaunchKernelGGL(k_cluster_voxels, dim3(gridFor(n)), dim3(256), 0, c->stream, f, which == 0 ? s.dyn : s.obj, inv, c->cv_origin[which], t,
                      c->d_cv_keys[which], c->d_cv_n[which], static_cast<uint32_t>(c->cfg.max_frame_pixels), c->d_cv_n[which] + 1,
                      c->d_gv_owners);
@@ -1719,8 +1724,9 @@ int khr_cluster_voxels_launch(khr_ctx* c, int slot, int which, float voxel_size)
   if (++c->cv_ticket[which] == 0) ++c->cv_ticket[which];
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, c->stream, c->d_cv_n[which], reinterpret_cast<uint32_t*>(c->d_cv_host[which]),
                      2u, static_cast<uint32_t>(std::min<size_t>(kCvHead, c->cfg.max_frame_pixels)), c->d_pinned + 5 + which,
-                     c->cv_ticket[which]);
+                     c->cv_ticket[which], c->d_cv_n[which]);
   HIP_TRY(hipGetLastError());
+  c->gv_counters_clean[1 + which] = true;
   return KHR_OK;
 }
 

@@ -580,6 +580,27 @@ __global__ __launch_bounds__(1024) void k_cluster_summary(DevFrame f, const int3
   }
 }
 
+// the per-cluster summaries of a frame go to pinned host memory right behind the paint pass (ticket as in k_publish) and
+// the device copy is reset to the reduction identities for the next frame
+__global__ __launch_bounds__(256) void k_publish_cluster_acc(ClusterAcc* __restrict__ acc, volatile uint32_t* __restrict__ dst_host,
+                                                            uint32_t n_ids, volatile uint32_t* __restrict__ ticket_host, uint32_t ticket) {
+  constexpr uint32_t W = sizeof(ClusterAcc) / 4;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(acc);
+  for (uint32_t i = threadIdx.x; i < n_ids * W; i += blockDim.x) dst_host[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < n_ids; k += blockDim.x) {
+    ClusterAcc a;
+    a.n_pixels = 0;
+    for (int d = 0; d < 3; ++d) { a.bmin[d] = INT32_MAX; a.bmax[d] = INT32_MIN; a.sum[d] = 0.f; }
+    acc[k] = a;
+  }
+  if (threadIdx.x == 0) {
+    *ticket_host = ticket;
+    __threadfence_system();
+  }
+}
+
 // ----------------------------------------------------------------------------------------------
 // Marching cubes (hydra::MeshIntegrator::generateMesh, ASSUMPTIONS.md A.5).  One workgroup per block;
 // the (VPS+1)^3 distance / weight tile (block + the +x/+y/+z faces, edges and corner of up to 7

@@ -148,6 +148,10 @@ struct khr_ctx {
   std::vector<uint32_t> h_md_seed_counts, h_md_bnd_counts, h_md_adj;
   std::vector<int32_t> h_md_seed_final, h_md_bnd_final;
   std::vector<ClusterAcc> h_md_acc;
+  ClusterAcc* h_md_acc_pinned = nullptr;   // summaries of the latest seed frame (k_publish_cluster_acc), ticket h_pinned[7]
+  ClusterAcc* d_md_acc_host = nullptr;     // device view of it
+  uint32_t md_acc_ticket = 0;
+  int md_acc_slot = -1;                    // the frame slot the published summaries belong to
   size_t cub_temp_bytes = 0;
   // object detector / cluster voxel sets (khr_kernels_objects.h); allocated on first use
   bool obj_configured = false;
@@ -591,6 +595,17 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     A(devAlloc(c, &c->d_md_bnd_final, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_adj, static_cast<size_t>(c->md_list_cap) * 26, false));
     A(devAlloc(c, &c->d_md_acc, 256));
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_md_acc_pinned), sizeof(ClusterAcc) * 256, hipHostMallocDefault) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_md_acc_host), c->h_md_acc_pinned, 0) != hipSuccess)
+      A(KHR_ENOMEM);
+    {
+      std::vector<ClusterAcc> init(256);
+      for (auto& a : init) {
+        a.n_pixels = 0;
+        for (int d = 0; d < 3; ++d) { a.bmin[d] = INT32_MAX; a.bmax[d] = INT32_MIN; a.sum[d] = 0.f; }
+      }
+      if (rc == KHR_OK && hipMemcpy(c->d_md_acc, init.data(), sizeof(ClusterAcc) * 256, hipMemcpyHostToDevice) != hipSuccess) A(KHR_EDEVICE);
+    }
   }
   if (rc == KHR_OK) {
     size_t t3 = 0;
@@ -654,6 +669,7 @@ void khr_destroy(khr_ctx* c) {
   if (c->d_mh_recs) { hipFree(c->d_mh_recs); hipFree(c->d_mh_keys); hipFree(c->d_mh_vals); }
   if (c->h_pinned) hipHostFree(c->h_pinned);
   if (c->h_obj_head) hipHostFree(c->h_obj_head);
+  if (c->h_md_acc_pinned) hipHostFree(c->h_md_acc_pinned);
   if (c->ev_obj) hipEventDestroy(c->ev_obj);
   for (int w = 0; w < 2; ++w) {
     if (c->h_cv[w]) hipHostFree(c->h_cv[w]);
@@ -1091,6 +1107,19 @@ static int waitTicket(khr_ctx* c, int word, uint32_t ticket, const char* what) {
   return KHR_OK;
 }
 
+// per-cluster summaries (pixel count, AABB, vertex sum) of the freshly painted dynamic image, queued behind the paint pass
+// and published to pinned memory; khr_get_dynamic_clusters only has to wait for the ticket
+static int clusterSummaryLaunch(khr_ctx* c, FrameSlot& s, int max_id) {
+  const int tiles = ((s.sensor.width + kAccTile - 1) / kAccTile) * ((s.sensor.height + kAccTile - 1) / kAccTile);
+  hipLaunchKernelGGL(k_cluster_summary, dim3(tiles), dim3(1024), 0, c->stream, makeDevFrame(c, s), s.dyn, c->d_md_acc);
+  if (++c->md_acc_ticket == 0) ++c->md_acc_ticket;
+  hipLaunchKernelGGL(k_publish_cluster_acc, dim3(1), dim3(256), 0, c->stream, c->d_md_acc, reinterpret_cast<uint32_t*>(c->d_md_acc_host),
+                     static_cast<uint32_t>(std::min(max_id + 1, 256)), c->d_pinned + 7, c->md_acc_ticket);
+  HIP_TRY(hipGetLastError());
+  c->md_acc_slot = static_cast<int>(&s - c->slots.data());
+  return KHR_OK;
+}
+
 static int motionFinish(khr_ctx* c, FrameSlot& s) {
   if (!c->cfg.with_tracking) return 0;
   const int n = s.sensor.width * s.sensor.height;
@@ -1202,6 +1231,10 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
       hipLaunchKernelGGL(k_md_paint, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds, bnd, c->d_md_seed_final,
                          c->d_md_bnd_final, s.dyn);
       HIP_TRY(hipGetLastError());
+      {
+        const int rcs = clusterSummaryLaunch(c, s, kept.back().first);
+        if (rcs) return rcs;
+      }
       s.clusters.resize(kept.size());
       for (size_t i = 0; i < kept.size(); ++i) {
         s.clusters[i] = khr_cluster{};
@@ -1363,6 +1396,10 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
     hipLaunchKernelGGL(k_md_paint, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds, bnd, c->d_md_seed_final,
                        c->d_md_bnd_final, s.dyn);
     HIP_TRY(hipGetLastError());
+    {
+      const int rcs = clusterSummaryLaunch(c, s, kept.back().first);
+      if (rcs) return rcs;
+    }
     s.clusters.resize(kept.size());
     for (size_t i = 0; i < kept.size(); ++i) {
       s.clusters[i] = khr_cluster{};
@@ -1440,18 +1477,19 @@ int khr_get_dynamic_clusters(khr_ctx* c, int slot, khr_cluster* out, int cap) {
   if (slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
   const int n = static_cast<int>(c->slots[slot].clusters.size());
   if (n == 0) return 0;
-  // the summary (the tracker's bounding boxes, max_iou_tracker.cpp:466-476) is computed when somebody asks
+  // the summaries (the tracker's bounding boxes, max_iou_tracker.cpp:466-476) were queued behind the paint pass and
+  // published to pinned memory; for an older slot (only the latest frame's are kept) they are recomputed here
   FrameSlot& s = c->slots[slot];
-  std::vector<ClusterAcc>& acc = c->h_md_acc;
-  acc.assign(256, ClusterAcc{});
-  for (auto& a : acc)
-    for (int d = 0; d < 3; ++d) { a.bmin[d] = INT32_MAX; a.bmax[d] = INT32_MIN; }
-  HIP_TRY(hipMemcpyAsync(c->d_md_acc, acc.data(), sizeof(ClusterAcc) * 256, hipMemcpyHostToDevice, c->stream));
-  const int tiles = ((s.sensor.width + kAccTile - 1) / kAccTile) * ((s.sensor.height + kAccTile - 1) / kAccTile);
-  hipLaunchKernelGGL(k_cluster_summary, dim3(tiles), dim3(1024), 0, c->stream, makeDevFrame(c, s), s.dyn, c->d_md_acc);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(acc.data(), c->d_md_acc, sizeof(ClusterAcc) * 256, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  const ClusterAcc* acc = c->h_md_acc_pinned;
+  if (c->md_acc_slot == slot) {
+    const int rcw = waitTicket(c, 7, c->md_acc_ticket, "the dynamic cluster summaries");
+    if (rcw) return rcw;
+  } else {
+    const int rcs = clusterSummaryLaunch(c, s, 255);
+    if (rcs) return rcs;
+    const int rcw = waitTicket(c, 7, c->md_acc_ticket, "the dynamic cluster summaries");
+    if (rcw) return rcw;
+  }
   for (int i = 0; i < n && i < cap; ++i) {
     khr_cluster k = s.clusters[i];
     const ClusterAcc& a = acc[k.id];

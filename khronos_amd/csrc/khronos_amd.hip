@@ -273,6 +273,17 @@ void resolveTimers(khr_ctx* c) {
   c->pending.clear();
 }
 
+// temporary device buffer of the host-pointer variants of the exchange calls (tests / non-RCCL callers): freed on
+// every exit path; hipFree waits for the device, so work still using the buffer is finished first
+struct DevTemp {
+  void* p = nullptr;
+  ~DevTemp() {
+    if (p) hipFree(p);
+  }
+  template <typename T>
+  T* as() const { return static_cast<T*>(p); }
+};
+
 template <typename T>
 int devAlloc(khr_ctx* c, T** out, size_t count, bool zero = true) {
   void* p = nullptr;
@@ -776,13 +787,12 @@ int khr_download_frame(khr_ctx* c, int slot, float* range, float* vertex_map, in
   if (range) HIP_TRY(hipMemcpyAsync(range, s.range, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   if (dynamic_image) HIP_TRY(hipMemcpyAsync(dynamic_image, s.dyn, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   if (vertex_map) {
-    float* d_v = nullptr;
-    HIP_TRY(hipMalloc(&d_v, n * 3 * sizeof(float)));
+    DevTemp tmpv;
+    HIP_TRY(hipMalloc(&tmpv.p, n * 3 * sizeof(float)));
+    float* d_v = tmpv.as<float>();
     hipLaunchKernelGGL(k_vertex_map, dim3(gridFor(n)), dim3(256), 0, c->stream, makeDevFrame(c, s), d_v);
-    hipError_t e = hipMemcpyAsync(vertex_map, d_v, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-    hipStreamSynchronize(c->stream);
-    hipFree(d_v);
-    if (e != hipSuccess) return fail(KHR_EDEVICE, "vertex map download failed");
+    HIP_TRY(hipMemcpyAsync(vertex_map, d_v, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
   return KHR_OK;
@@ -979,10 +989,11 @@ int khr_export_halo(khr_ctx* c, void* records, int64_t cap_records, int on_devic
   DevMap& m = c->m;
   const size_t bytes = static_cast<size_t>(cap_records) * kHaloRecWords * sizeof(uint64_t);
   uint64_t* dst = static_cast<uint64_t*>(records);
+  DevTemp holder;
   uint64_t* tmp = nullptr;
   if (!on_device) {
-    HIP_TRY(hipMalloc(&tmp, bytes));
-    dst = tmp;
+    HIP_TRY(hipMalloc(&holder.p, bytes));
+    dst = tmp = holder.as<uint64_t>();
   }
   HIP_TRY(hipMemsetAsync(c->d_mesh_nwork + 1, 0, sizeof(uint32_t), c->stream));
   hipLaunchKernelGGL(k_list_live, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_work, c->d_mesh_nwork + 1, 0u);
@@ -995,10 +1006,6 @@ int khr_export_halo(khr_ctx* c, void* records, int64_t cap_records, int on_devic
     hipError_t e = hipMemcpyAsync(records, tmp, bytes, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) rc = fail(KHR_EDEVICE, "halo export copy failed: %s", hipGetErrorString(e));
-  }
-  if (tmp) {
-    hipStreamSynchronize(c->stream);
-    hipFree(tmp);
   }
   return rc;
 }
@@ -1429,17 +1436,15 @@ int khr_motion_keys(khr_ctx* c, int slot, void* keys_out, int on_device, uint32_
   int rc = motionLaunch(c, s, false);
   if (rc) return rc;
   uint64_t* dst = static_cast<uint64_t*>(keys_out);
-  uint64_t* tmp = nullptr;
+  DevTemp holder;
   if (!on_device) {
-    HIP_TRY(hipMalloc(&tmp, sizeof(uint64_t) * n));
-    dst = tmp;
+    HIP_TRY(hipMalloc(&holder.p, sizeof(uint64_t) * n));
+    dst = holder.as<uint64_t>();
   }
   hipLaunchKernelGGL(k_md_keys_export, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, dst);
   if (!on_device) {
-    hipError_t e = hipMemcpyAsync(keys_out, tmp, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(tmp);
-    if (e != hipSuccess) return fail(KHR_EDEVICE, "key export failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpyAsync(keys_out, dst, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
   }
   { const int rcw = waitSeedCount(c); if (rcw) return rcw; }
   if (n_seed_pixels) *n_seed_pixels = c->h_pinned[0];
@@ -1452,11 +1457,11 @@ int khr_detect_motion_from_keys(khr_ctx* c, int slot, const void* keys, int on_d
   FrameSlot& s = c->slots[slot];
   const int n = s.sensor.width * s.sensor.height;
   const uint64_t* src = static_cast<const uint64_t*>(keys);
-  uint64_t* tmp = nullptr;
+  DevTemp holder;  // (freed when this call returns; hipFree waits for the kernels that read it)
   if (!on_device) {
-    HIP_TRY(hipMalloc(&tmp, sizeof(uint64_t) * n));
-    HIP_TRY(hipMemcpyAsync(tmp, keys, sizeof(uint64_t) * n, hipMemcpyHostToDevice, c->stream));
-    src = tmp;
+    HIP_TRY(hipMalloc(&holder.p, sizeof(uint64_t) * n));
+    HIP_TRY(hipMemcpyAsync(holder.p, keys, sizeof(uint64_t) * n, hipMemcpyHostToDevice, c->stream));
+    src = holder.as<uint64_t>();
   }
   HIP_TRY(hipMemsetAsync(s.dyn, 0, sizeof(int32_t) * n, c->stream));
   HIP_TRY(hipMemsetAsync(&c->m.counters[C_N_SEEDS], 0, sizeof(uint32_t), c->stream));
@@ -1464,12 +1469,7 @@ int khr_detect_motion_from_keys(khr_ctx* c, int slot, const void* keys, int on_d
   HIP_TRY(hipMemcpyAsync(&c->h_pinned[0], &c->m.counters[C_N_SEEDS], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipEventRecord(c->ev_seed, c->stream));
   c->seed_by_ticket = false;
-  const int nc = motionFinish(c, s);
-  if (tmp) {
-    hipStreamSynchronize(c->stream);
-    hipFree(tmp);
-  }
-  return nc;
+  return motionFinish(c, s);
 }
 
 int khr_get_dynamic_clusters(khr_ctx* c, int slot, khr_cluster* out, int cap) {
@@ -1902,10 +1902,11 @@ int khr_mesh_halo_requests(khr_ctx* c, void* keys_out, int64_t cap, int only_mes
   HIP_TRY(hipSetDevice(c->device));
   DevMap& m = c->m;
   uint64_t* dst = static_cast<uint64_t*>(keys_out);
+  DevTemp holder;
   uint64_t* tmp = nullptr;
   if (!on_device) {
-    HIP_TRY(hipMalloc(&tmp, sizeof(uint64_t) * cap));
-    dst = tmp;
+    HIP_TRY(hipMalloc(&holder.p, sizeof(uint64_t) * cap));
+    dst = tmp = holder.as<uint64_t>();
   }
   HIP_TRY(hipMemsetAsync(dst, 0, sizeof(uint64_t) * cap, c->stream));
   HIP_TRY(hipMemsetAsync(c->d_mesh_nwork + 1, 0, sizeof(uint32_t) * 2, c->stream));
@@ -1917,7 +1918,6 @@ int khr_mesh_halo_requests(khr_ctx* c, void* keys_out, int64_t cap, int only_mes
   HIP_TRY(hipMemcpyAsync(&n_req, c->d_mesh_nwork + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   if (!on_device) HIP_TRY(hipMemcpyAsync(keys_out, tmp, sizeof(uint64_t) * cap, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (tmp) hipFree(tmp);
   if (n_req > cap) return fail(KHR_ENOMEM, "%u mesh halo requests exceed the capacity %lld", n_req, static_cast<long long>(cap));
   return static_cast<int>(n_req);
 }
@@ -1929,17 +1929,17 @@ int khr_mesh_halo_export(khr_ctx* c, const void* requests, int64_t n_requests, v
   const size_t words = c->p.vps == 16 ? MeshHalo<16>::kWords : MeshHalo<8>::kWords;
   const size_t bytes = static_cast<size_t>(cap_records) * words * 4;
   const uint64_t* req = static_cast<const uint64_t*>(requests);
-  uint64_t* req_tmp = nullptr;
   uint32_t* dst = static_cast<uint32_t*>(records);
+  DevTemp req_holder, rec_holder;
   uint32_t* rec_tmp = nullptr;
   if (!on_device) {
     if (n_requests) {
-      HIP_TRY(hipMalloc(&req_tmp, sizeof(uint64_t) * n_requests));
-      HIP_TRY(hipMemcpyAsync(req_tmp, requests, sizeof(uint64_t) * n_requests, hipMemcpyHostToDevice, c->stream));
-      req = req_tmp;
+      HIP_TRY(hipMalloc(&req_holder.p, sizeof(uint64_t) * n_requests));
+      HIP_TRY(hipMemcpyAsync(req_holder.p, requests, sizeof(uint64_t) * n_requests, hipMemcpyHostToDevice, c->stream));
+      req = req_holder.as<uint64_t>();
     }
-    HIP_TRY(hipMalloc(&rec_tmp, bytes));
-    dst = rec_tmp;
+    HIP_TRY(hipMalloc(&rec_holder.p, bytes));
+    dst = rec_tmp = rec_holder.as<uint32_t>();
   }
   HIP_TRY(hipMemsetAsync(c->d_mh_flag, 0, m.capacity, c->stream));
   HIP_TRY(hipMemsetAsync(c->d_mesh_nwork + 3, 0, sizeof(uint32_t), c->stream));
@@ -1955,8 +1955,6 @@ int khr_mesh_halo_export(khr_ctx* c, const void* requests, int64_t n_requests, v
   hipError_t e = hipSuccess;
   if (rc == KHR_OK && !on_device) e = hipMemcpyAsync(records, rec_tmp, bytes, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  if (req_tmp) hipFree(req_tmp);
-  if (rec_tmp) hipFree(rec_tmp);
   if (e != hipSuccess) return fail(KHR_EDEVICE, "mesh halo export failed: %s", hipGetErrorString(e));
   return rc;
 }

@@ -141,7 +141,7 @@ def main():
         voxel_size=vs, truncation_distance=3.0 * vs, voxels_per_side=16, with_semantics=1, with_tracking=1,
         num_labels=K, max_blocks=args.max_blocks, max_frame_pixels=W * H,
         # buffered frames stay resident in the device ring (FrameDataBuffer role); every rank holds all cameras' frames
-        num_frame_slots=max(2, world) if args.no_objects else world * (args.buffer_frames + 1),
+        num_frame_slots=max(2, world) if args.no_objects else world * (args.buffer_frames + 1) + 64,  # + frames held by detached extractions
         max_mesh_vertices=48 << 20,
         # khronos_ros/config/mapper/uHumans2.yaml:52-57
         md_min_cluster_size=500, md_min_separation_distance=2.0, md_max_range=5.0,
@@ -223,7 +223,11 @@ def main():
             if out_now:
                 fusion.output(req_cap=args.mesh_req_cap, rec_cap=args.mesh_rec_cap)
                 if pipe is not None:
-                    obj_stats[0] += pipe.extract_inactive()[0]
+                    t_e = time.perf_counter()
+                    n_obj, n_rm, _ = pipe.extract_inactive()
+                    obj_stats[0] += n_obj
+                    obj_stats[1] += n_rm
+                    obj_stats[2] += time.perf_counter() - t_e
             return
         for ci, (dep, rgb, lab, pose) in enumerate(cams):
             flags = 0
@@ -243,9 +247,13 @@ def main():
                 pipe.finish_frame()
                 pipe.launch_frame(slot, stamps[i], pose, sensor, n_dyn)
                 if last and out_now:
-                    obj_stats[0] += pipe.extract_inactive()[0]
+                    t_e = time.perf_counter()
+                    n_obj, n_rm, _ = pipe.extract_inactive()
+                    obj_stats[0] += n_obj
+                    obj_stats[1] += n_rm
+                    obj_stats[2] += time.perf_counter() - t_e
 
-    obj_stats = [0]
+    obj_stats = [0, 0, 0.0]  # objects extracted, tracks removed, seconds spent in extraction (timed region and warm-up)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -276,6 +284,7 @@ def main():
         print("frame_times(us, seeds):", ft, file=sys.stderr)
     if pipe is not None:
         pipe.finish_frame()
+        obj_stats[0] += pipe.join()  # detached object extractions still running on the worker thread / its stream
     sync_all()
     dt = time.perf_counter() - t0
     ctx.timing_enable(False)
@@ -314,7 +323,8 @@ def main():
                    if world > 1 else "single GPU"},
         "mvoxel_updates_per_s": 1e-6 * n_upd_all / dt,
         "objects": None if pipe is None else {"tracks_at_end": pipe.num_tracks(), "buffered_frames": pipe.num_buffered_frames(),
-                                              "objects_extracted": obj_stats[0]},
+                                              "objects_extracted": obj_stats[0], "tracks_removed": obj_stats[1],
+                                              "extraction_ms_total": 1e3 * obj_stats[2]},
         "voxels": {"visited": n_vis_all, "updated": n_upd_all, "band": n_band_all, "allocated_blocks": st1["n_allocated_blocks"],
                    "last_frame_visible_blocks": st1["n_visible_blocks"], "last_frame_tsdf_blocks": st1["n_tsdf_blocks"],
                    "band_overflow": st1["band_overflow"], "last_frame_tracking_blocks": st1["n_tracking_processed_blocks"],

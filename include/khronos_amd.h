@@ -164,6 +164,19 @@ int khr_set_stream(khr_ctx* ctx, void* hip_stream);
 int khr_sync(khr_ctx* ctx);
 /* fill a config with the reference defaults */
 void khr_default_config(khr_config* cfg);
+/* empty the map and give it a new metric resolution, keeping every allocation: what constructing a fresh
+ * hydra::VolumetricMap per object does in the reference (mesh_object_extractor.cpp:201-215) without the cost of
+ * re-creating the HBM pool.  Capacities, voxels_per_side, layers and integrator switches stay as created. */
+int khr_reset_map(khr_ctx* ctx, float voxel_size, float truncation_distance);
+/* frame slots are a ring: khr_upload_frame / khr_process_frame take the next slot nobody retains.  Whoever keeps a frame
+ * (FrameDataBuffer entries, a detached object extraction that re-integrates it) retains its slot and releases it when done;
+ * thread-safe.  KHR_ENOMEM from the upload calls when every slot is retained. */
+int khr_retain_slot(khr_ctx* ctx, int slot);
+int khr_release_slot(khr_ctx* ctx, int slot);
+/* device-side ordering between two contexts: everything queued so far on `other`'s stream happens before anything queued on
+ * `ctx`'s stream from now on (event + stream wait, no host wait).  After it khr_integrate_shared(ctx, other, ...) does not
+ * synchronise the host with `other` any more; the declaration lasts until khr_reset_map(ctx). */
+int khr_depend_on(khr_ctx* ctx, khr_ctx* other);
 /* the config a context was created with (VolumetricMap::config role) */
 int khr_get_config(khr_ctx* ctx, khr_config* out);
 

@@ -78,7 +78,7 @@ EXPORTS = [
     "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",
     "khr_cluster_voxels", "khr_download_frame_image",
     "khr_rv_create", "khr_rv_destroy", "khr_rv_clear", "khr_rv_add_rays", "khr_rv_num_rays", "khr_rv_num_pairs", "khr_rv_check",
-    "khr_rv_check_stamps", "khr_get_config", "khr_cluster_voxels_launch", "khr_cluster_voxels_fetch",
+    "khr_rv_check_stamps", "khr_get_config", "khr_cluster_voxels_launch", "khr_cluster_voxels_fetch", "khr_reset_map", "khr_depend_on", "khr_retain_slot", "khr_release_slot",
 ]
 
 _lib = None
@@ -136,6 +136,10 @@ def load_library():
     lib.khr_rv_check.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.khr_rv_check_stamps.argtypes = [vp, vp, vp]
     lib.khr_get_config.argtypes = [vp, vp]
+    lib.khr_reset_map.argtypes = [vp, C.c_float, C.c_float]
+    lib.khr_depend_on.argtypes = [vp, vp]
+    lib.khr_retain_slot.argtypes = [vp, i32]
+    lib.khr_release_slot.argtypes = [vp, i32]
     lib.khr_cluster_voxels_launch.argtypes = [vp, i32, i32, C.c_float]
     lib.khr_cluster_voxels_fetch.argtypes = [vp, i32, vp, vp, C.c_int64]
     lib.khr_cluster_voxels_fetch.restype = C.c_int64
@@ -203,6 +207,10 @@ class FusionContext:
         self.nvox = cfg.voxels_per_side ** 3
 
     def close(self):
+        # objects that hold frame slots of this context (host_capi.ObjectPipeline) go first
+        for d in list(getattr(self, "_dependents", [])):
+            d.close()
+        self._dependents = []
         if getattr(self, "h", None):
             self.lib.khr_destroy(self.h)
             self.h = None
@@ -408,6 +416,11 @@ class FusionContext:
 
     def mark_all_inactive(self):
         self._chk(self.lib.khr_mark_all_inactive(self.h))
+
+    def reset_map(self, voxel_size, truncation_distance):
+        """empty map at a new resolution, allocations kept (object mini-maps are reused between objects)"""
+        self._chk(self.lib.khr_reset_map(self.h, float(voxel_size), float(truncation_distance)))
+        self.cfg.voxel_size, self.cfg.truncation_distance = float(voxel_size), float(truncation_distance)
 
     def clear_updated(self):
         self._chk(self.lib.khr_clear_updated(self.h))

@@ -1097,6 +1097,19 @@ __global__ __launch_bounds__(256) void k_rehash(DevMap m) {
   if (is_free) m.free_slots[idx] = s;
 }
 
+// khr_reset_map: back to the freshly created state (no block, empty hash, identity free list, zero counters / statistics)
+__global__ __launch_bounds__(256) void k_reset_map(DevMap m) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= m.ht_mask) m.ht_keys[i] = kEmptyKey;
+  if (i < m.capacity) {
+    m.blk_flags[i] = 0u;
+    m.mesh_desc[i] = MeshDesc{0u, 0u};
+    m.free_slots[i] = i;
+  }
+  if (i < C_COUNT) m.counters[i] = i == C_N_FREE ? m.capacity : 0u;
+  if (i < S_COUNT) m.stats[i] = 0ull;
+}
+
 __global__ __launch_bounds__(256) void k_block_flag_op(DevMap m, uint32_t and_mask, uint32_t or_mask) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= m.counters[C_MAX_SLOT]) return;

@@ -9,7 +9,9 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
+#include <memory>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -89,6 +91,7 @@ struct khr_ctx {
   std::vector<void*> allocs;
   std::vector<FrameSlot> slots;
   int next_slot = 0;
+  std::unique_ptr<std::atomic<int>[]> slot_leases;  // khr_retain_slot: frames somebody still reads are not overwritten
   // work lists
   uint32_t* d_work = nullptr;
   uint32_t* d_new = nullptr;
@@ -121,6 +124,8 @@ struct khr_ctx {
   int ef_parity = 0, ef_cur = 0;  // which of C_N_EF / C_N_EF2 the next / the latest tracking pass fills
   hipEvent_t ev_seed = nullptr;
   uint32_t last_removed = 0;
+  khr_ctx* dep_src = nullptr;     // khr_depend_on: this context's stream already waits for that context's earlier work
+  hipEvent_t ev_dep = nullptr;
   uint64_t last_track_stamp = 0;  // stamp of the latest tracking pass = last_occupied of every VOX_OCC voxel
   bool removed_pending = false;
   int4* d_removed = nullptr;
@@ -450,6 +455,77 @@ void khr_default_config(khr_config* cfg) {
   cfg->world_size = 1;
 }
 
+// the voxel-size dependent part of DevParams (khr_create, khr_reset_map)
+static void deriveMetricParams(const khr_config& cfg, DevParams& p) {
+  p.vs = cfg.voxel_size;
+  p.vs_inv = 1.f / cfg.voxel_size;
+  p.bs = cfg.voxel_size * static_cast<float>(cfg.voxels_per_side);
+  p.bs_inv = 1.f / p.bs;
+  p.trunc = cfg.truncation_distance;
+  p.dropoff_eps = cfg.weight_dropoff_epsilon > 0.f ? cfg.weight_dropoff_epsilon : cfg.weight_dropoff_epsilon * -cfg.voxel_size;
+  p.occ_thr = cfg.tsdf_occupancy_threshold < 0 ? cfg.tsdf_occupancy_threshold * -cfg.voxel_size : cfg.tsdf_occupancy_threshold;
+}
+
+int khr_retain_slot(khr_ctx* c, int slot) {
+  if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size())) return fail(KHR_EINVAL, "bad slot");
+  c->slot_leases[slot].fetch_add(1, std::memory_order_acq_rel);
+  return KHR_OK;
+}
+
+int khr_release_slot(khr_ctx* c, int slot) {
+  if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size())) return fail(KHR_EINVAL, "bad slot");
+  if (c->slot_leases[slot].fetch_sub(1, std::memory_order_acq_rel) <= 0) {
+    c->slot_leases[slot].store(0);
+    return fail(KHR_ESTATE, "slot %d was not retained", slot);
+  }
+  return KHR_OK;
+}
+
+int khr_depend_on(khr_ctx* c, khr_ctx* other) {
+  if (!c || !other) return fail(KHR_EINVAL, "null ctx");
+  if (c->device != other->device) return fail(KHR_EINVAL, "contexts live on different devices");
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->stream == other->stream) {
+    c->dep_src = other;
+    return KHR_OK;
+  }
+  if (!c->ev_dep) HIP_TRY(hipEventCreateWithFlags(&c->ev_dep, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(c->ev_dep, other->stream));
+  HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_dep, 0));
+  c->dep_src = other;
+  return KHR_OK;
+}
+
+int khr_reset_map(khr_ctx* c, float voxel_size, float truncation_distance) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  if (!(voxel_size > 0.f) || !(truncation_distance > 0.f)) return fail(KHR_EINVAL, "voxel_size / truncation_distance must be > 0");
+  HIP_TRY(hipSetDevice(c->device));
+  c->cfg.voxel_size = voxel_size;
+  c->cfg.truncation_distance = truncation_distance;
+  deriveMetricParams(c->cfg, c->p);
+  const size_t n = std::max<size_t>(static_cast<size_t>(c->m.ht_mask) + 1, c->m.capacity);
+  hipLaunchKernelGGL(k_reset_map, dim3(gridFor(n)), dim3(256), 0, c->stream, c->m);
+  HIP_TRY(hipGetLastError());
+  c->mesh_cur = 0;
+  c->mesh_total = 0;
+  c->mesh_stale = false;
+  c->host_index_valid = false;
+  c->last_removed = 0;
+  c->removed_pending = false;
+  c->last_track_stamp = 0;
+  c->dep_src = nullptr;
+  c->halo_n = 0;
+  c->mh_n = 0;
+  c->stats = khr_stats{};
+  for (auto& s : c->slots) {
+    s.valid = false;
+    s.clusters.clear();
+    s.sem_clusters.clear();
+  }
+  for (size_t i = 0; i < c->slots.size(); ++i) c->slot_leases[i].store(0);
+  return KHR_OK;
+}
+
 int khr_get_config(khr_ctx* c, khr_config* out) {
   if (!c || !out) return fail(KHR_EINVAL, "null argument");
   *out = c->cfg;
@@ -500,13 +576,9 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   }
 
   DevParams& p = c->p;
-  p.vs = cfg->voxel_size;
-  p.vs_inv = 1.f / cfg->voxel_size;
+  deriveMetricParams(*cfg, p);
   p.vps = cfg->voxels_per_side;
   p.nvox = p.vps * p.vps * p.vps;
-  p.bs = cfg->voxel_size * static_cast<float>(cfg->voxels_per_side);
-  p.bs_inv = 1.f / p.bs;
-  p.trunc = cfg->truncation_distance;
   p.K = cfg->with_semantics ? cfg->num_labels : 1;
   p.with_semantics = cfg->with_semantics;
   p.with_tracking = cfg->with_tracking;
@@ -515,12 +587,10 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   p.interp = cfg->interpolation_method;
   p.range_mode = cfg->range_mode;
   p.sem_mode = cfg->semantic_mode;
-  p.dropoff_eps = cfg->weight_dropoff_epsilon > 0.f ? cfg->weight_dropoff_epsilon : cfg->weight_dropoff_epsilon * -cfg->voxel_size;
   p.max_weight = cfg->max_weight;
   p.adaptive_diff = cfg->adaptive_max_range_difference;
   p.log_match = std::log(cfg->label_confidence);
   p.log_nomatch = cfg->num_labels > 1 ? std::log((1.f - cfg->label_confidence) / static_cast<float>(cfg->num_labels - 1)) : 0.f;
-  p.occ_thr = cfg->tsdf_occupancy_threshold < 0 ? cfg->tsdf_occupancy_threshold * -cfg->voxel_size : cfg->tsdf_occupancy_threshold;
   p.temporal_buffer = static_cast<double>(cfg->temporal_buffer);
   p.temporal_window = static_cast<double>(cfg->temporal_window);
   p.nn = cfg->neighbor_connectivity;
@@ -633,6 +703,8 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     A(devAlloc(c, &c->mesh[b].stamps, cfg->max_mesh_vertices, false));
   }
   c->slots.resize(cfg->num_frame_slots);
+  c->slot_leases.reset(new std::atomic<int>[cfg->num_frame_slots]);
+  for (uint32_t i = 0; i < cfg->num_frame_slots; ++i) c->slot_leases[i].store(0);
   for (auto& s : c->slots) {
     if (rc != KHR_OK) break;
     A(devAlloc(c, &s.depth, npx, false));
@@ -687,6 +759,7 @@ void khr_destroy(khr_ctx* c) {
     if (c->ev_cv[w]) hipEventDestroy(c->ev_cv[w]);
   }
   if (c->ev_seed) hipEventDestroy(c->ev_seed);
+  if (c->ev_dep) hipEventDestroy(c->ev_dep);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -721,8 +794,16 @@ int khr_upload_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fram
   if (!(sensor->fx > 0.f) || !(sensor->fy > 0.f) || !(sensor->max_range > sensor->min_range))
     return fail(KHR_EINVAL, "bad intrinsics / range");
   HIP_TRY(hipSetDevice(c->device));
-  const int slot = c->next_slot;
-  c->next_slot = (c->next_slot + 1) % static_cast<int>(c->slots.size());
+  // next slot of the ring that nobody holds (khr_retain_slot): buffered frames and frames a detached extraction still reads
+  // stay intact however far the stream has advanced
+  const int n_slots = static_cast<int>(c->slots.size());
+  int slot = -1;
+  for (int k = 0; k < n_slots && slot < 0; ++k) {
+    const int cand = (c->next_slot + k) % n_slots;
+    if (c->slot_leases[cand].load(std::memory_order_acquire) == 0) slot = cand;
+  }
+  if (slot < 0) return fail(KHR_ENOMEM, "all %d frame slots are retained (raise num_frame_slots)", n_slots);
+  c->next_slot = (slot + 1) % n_slots;
   FrameSlot& s = c->slots[slot];
   const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   s.sensor = *sensor;
@@ -905,7 +986,8 @@ int khr_integrate_shared(khr_ctx* c, khr_ctx* src, int src_slot, int allocate_bl
     return fail(KHR_EINVAL, "bad source slot");
   if (c->device != src->device) return fail(KHR_EINVAL, "contexts live on different devices");
   HIP_TRY(hipSetDevice(c->device));
-  if (c->stream != src->stream) HIP_TRY(hipStreamSynchronize(src->stream));  // the frame must be complete
+  // the frame must be complete: either the caller declared the dependency on the device (khr_depend_on) or the host waits
+  if (c->stream != src->stream && c->dep_src != src) HIP_TRY(hipStreamSynchronize(src->stream));
   FrameSlot& s = src->slots[src_slot];
   const DevFrame f = makeDevFrame(src, s);
   int rc = integrateAlloc(c, s, f, allocate_blocks);
@@ -1089,6 +1171,7 @@ static int waitSeedCount(khr_ctx* c) {
   volatile uint32_t* hp = c->h_pinned;
   uint64_t spins = 0;
   while (hp[3] != c->seed_ticket) {
+    __builtin_ia32_pause();
     if ((++spins & 0xffffu) == 0) {  // every ~65k polls: is the stream still alive?
       const hipError_t q = hipStreamQuery(c->stream);
       if (q != hipSuccess && q != hipErrorNotReady) return fail(KHR_EDEVICE, "stream failed while waiting for the seed count: %s", hipGetErrorString(q));
@@ -1105,6 +1188,7 @@ static int waitTicket(khr_ctx* c, int word, uint32_t ticket, const char* what) {
   volatile uint32_t* hp = c->h_pinned;
   uint64_t spins = 0;
   while (hp[word] != ticket) {
+    __builtin_ia32_pause();
     if ((++spins & 0xffffu) == 0) {
       const hipError_t q = hipStreamQuery(c->stream);
       if (q != hipSuccess && q != hipErrorNotReady) return fail(KHR_EDEVICE, "stream failed while waiting for %s: %s", what, hipGetErrorString(q));

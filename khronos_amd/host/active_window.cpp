@@ -123,6 +123,10 @@ MeshObjectExtractor::MeshObjectExtractor(const Config& cfg, const khr_config& aw
     throw std::invalid_argument("negative displacement / resolution");
 }
 
+MeshObjectExtractor::~MeshObjectExtractor() {
+  if (object_ctx_) khr_destroy(object_ctx_);
+}
+
 float MeshObjectExtractor::objectVoxelSize(const Config& config, const BoundingBox& extent) {
   // mesh_object_extractor.cpp:201-207
   if (config.object_reconstruction_resolution < 0.f)
@@ -239,10 +243,20 @@ std::shared_ptr<KhronosObjectAttributes> MeshObjectExtractor::extractStaticObjec
       }
   const size_t n_blocks = idx.size() / 3;
   if (n_blocks > config.max_object_blocks) return nullptr;
-  oc.max_blocks = static_cast<uint32_t>(n_blocks + 1);
-  oc.max_mesh_vertices = std::max<uint64_t>(1u << 16, n_blocks * 512ull * 15ull / 4);
-  khr_ctx* octx = nullptr;
-  chk(khr_create(&oc, &octx), "khr_create(object map)");
+  if (!object_ctx_ || n_blocks + 1 > object_ctx_blocks_) {
+    if (object_ctx_) khr_destroy(object_ctx_);
+    object_ctx_ = nullptr;
+    oc.max_blocks = static_cast<uint32_t>(std::max<size_t>({n_blocks + 1, 2 * static_cast<size_t>(object_ctx_blocks_), 4096}));
+    oc.max_mesh_vertices = std::max<uint64_t>(1u << 16, static_cast<uint64_t>(oc.max_blocks) * 512ull * 15ull / 4);
+    chk(khr_create(&oc, &object_ctx_), "khr_create(object map)");
+    object_ctx_blocks_ = oc.max_blocks;
+  } else {
+    chk(khr_reset_map(object_ctx_, oc.voxel_size, oc.truncation_distance), "khr_reset_map(object map)");
+  }
+  khr_ctx* octx = object_ctx_;
+  // the buffered frames were written on the active window's stream: one device-side dependency instead of a host wait per
+  // re-integrated frame (the extraction may run on a worker thread while the window keeps queueing frames)
+  chk(khr_depend_on(octx, frames.front().first->input.ctx), "khr_depend_on");
   std::shared_ptr<KhronosObjectAttributes> object;
   try {
     chk(khr_allocate_blocks(octx, idx.data(), static_cast<int64_t>(n_blocks)), "khr_allocate_blocks");  // :218-228
@@ -270,10 +284,11 @@ std::shared_ptr<KhronosObjectAttributes> MeshObjectExtractor::extractStaticObjec
                                                                     mesh.first_seen_stamps.data(), mesh.stamps.data(), nv))),
           "khr_download_mesh");
   } catch (...) {
-    khr_destroy(octx);
+    khr_destroy(object_ctx_);  // unknown state: start from a fresh context next time
+    object_ctx_ = nullptr;
+    object_ctx_blocks_ = 0;
     throw;
   }
-  khr_destroy(octx);
 
   if (object->mesh.numVertices() == 0 && config.only_extract_reconstructed_objects) return nullptr;  // :271-275
   if (object->mesh.numVertices() == 0) {
@@ -326,7 +341,7 @@ ActiveWindow::Config ActiveWindow::Config::fromYaml(const khronos_amd::YamlNode&
   }
   if (const auto* m = n.find("motion_detector")) {
     m->read("type", c.motion_detector_type);
-    auto& d = const_cast<FreeSpaceMotionDetector::Config&>(c.motion_detector);
+    auto& d = c.motion_detector;
     m->read("verbosity", d.verbosity);
     m->read("neighbor_connectivity", d.neighbor_connectivity);
     m->read("min_cluster_size", d.min_cluster_size);
@@ -346,7 +361,7 @@ ActiveWindow::Config ActiveWindow::Config::fromYaml(const khronos_amd::YamlNode&
   }
   if (const auto* m = n.find("object_extractor")) {
     m->read("type", c.object_extractor_type);
-    auto& e = const_cast<MeshObjectExtractor::Config&>(c.object_extractor);
+    auto& e = c.object_extractor;
     m->read("verbosity", e.verbosity);
     m->read("min_object_allocation_confidence", e.min_object_allocation_confidence);
     m->read("min_object_volume", e.min_object_volume);
@@ -366,7 +381,7 @@ ActiveWindow::Config ActiveWindow::Config::fromYaml(const khronos_amd::YamlNode&
   }
   if (const auto* m = n.find("mesh_integrator")) m->read("min_weight", c.mesh_integrator.min_weight);
   if (const auto* m = n.find("frame_data_buffer")) {
-    auto& b = const_cast<FrameDataBuffer::Config&>(c.frame_data_buffer);
+    auto& b = c.frame_data_buffer;
     m->read("max_buffer_size", b.max_buffer_size);
     m->read("store_every_n_frames", b.store_every_n_frames);
   }
@@ -485,6 +500,10 @@ ActiveWindow::ActiveWindow(const Config& cfg) : config(cfg), frame_data_buffer_(
 }
 
 ActiveWindow::~ActiveWindow() {
+  // buffered frames hold leases on frame slots of the context: they go first (frames a sink copied must not outlive the
+  // window either)
+  frame_data_buffer_.clear();
+  object_extractor_.reset();
   if (ctx_) khr_destroy(ctx_);
 }
 
@@ -523,6 +542,7 @@ std::shared_ptr<FrameData> ActiveWindow::createData(const hydra::InputPacket& in
   f.label = input.labels;
   in.slot = khr_upload_frame(ctx_, &s, &f, input.on_device ? 1 : 0);
   if (in.slot < 0) return nullptr;  // "Input packet preprocessing failed. Skipping frame." (:276-279)
+  in.retainSlot();
   return data;
 }
 
@@ -562,6 +582,7 @@ hydra::ActiveWindowOutput::Ptr ActiveWindow::spinOnce(const hydra::InputPacket& 
     int n_clusters = 0;
     in.slot = khr_process_frame(ctx_, &s, &f, input.on_device ? 1 : 0, flags, &n_clusters);
     if (in.slot < 0) return nullptr;  // "Input packet preprocessing failed. Skipping frame." (:276-279)
+    in.retainSlot();
     data->num_dynamic_clusters = n_clusters;
     if (n_clusters > 0) FreeSpaceMotionDetector::fetchClusters(map_, *data);
   } else {

@@ -98,6 +98,7 @@ class FrameDataBuffer {  // frame_data_buffer.h:52-100, frame_data_buffer.cpp:57
   const FrameData& getLatestData() const { return *buffer_.back(); }
   size_t size() const { return buffer_.size(); }
   bool empty() const { return buffer_.empty(); }
+  void clear() { buffer_.clear(); }
 
  private:
   std::deque<FrameData::Ptr> buffer_;
@@ -269,6 +270,9 @@ class MeshObjectExtractor : public ObjectExtractor {  // mesh_object_extractor.h
     uint32_t max_object_blocks = 32768;  // device pool of the object mini-map
   } const config;
   MeshObjectExtractor(const Config& config, const khr_config& aw_device_config);
+  ~MeshObjectExtractor() override;
+  MeshObjectExtractor(const MeshObjectExtractor&) = delete;
+  MeshObjectExtractor& operator=(const MeshObjectExtractor&) = delete;
   std::shared_ptr<KhronosObjectAttributes> extractObject(const Track& track, const FrameDataBuffer& frames) override;
   // MeshObjectExtractor::extractDynamicObject (mesh_object_extractor.cpp:120-172): trajectory summary
   std::shared_ptr<KhronosObjectAttributes> extractDynamicObject(const Track& track, const FrameDataBuffer& frames) const;
@@ -280,6 +284,10 @@ class MeshObjectExtractor : public ObjectExtractor {  // mesh_object_extractor.h
 
  private:
   khr_config device_config_;
+  // the object mini-map is one device context that is emptied and re-scaled per object (khr_reset_map) instead of a
+  // new VolumetricMap per object: creating / destroying an HBM pool costs milliseconds, the reset one small kernel
+  mutable khr_ctx* object_ctx_ = nullptr;
+  mutable uint32_t object_ctx_blocks_ = 0;
 };
 
 // ---- the module -------------------------------------------------------------------------------------------------

@@ -58,6 +58,15 @@ struct InputData {
   Sensor sensor;
   khr_ctx* ctx = nullptr;
   int slot = -1;  // device frame slot
+  // keeps the slot out of the ring for as long as any copy of this InputData lives (the shared_ptr<FrameData> ownership of
+  // the reference: buffer entries and extraction workers keep frames alive, active_window.cpp:261-263)
+  std::shared_ptr<void> slot_lease;
+  void retainSlot() {
+    if (!ctx || slot < 0 || khr_retain_slot(ctx, slot) < 0) return;
+    khr_ctx* c = ctx;
+    const int s = slot;
+    slot_lease = std::shared_ptr<void>(nullptr, [c, s](void*) { khr_release_slot(c, s); });
+  }
   const Sensor& getSensor() const { return sensor; }
   const double* getSensorPose() const { return world_T_sensor; }
   // host copies (range image H*W, world-frame vertex map H*W*3)

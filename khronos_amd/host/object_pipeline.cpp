@@ -4,10 +4,14 @@
 // from the same `active_window:` YAML as the ActiveWindow class and runs on a fusion context's frame slots; the
 // volumetric half of spinOnce is khr_process_frame (single GPU) or the sharded tick (multi GPU, where the halo
 // exchanges are RCCL collectives driven from Python).
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 
 #include "active_window.h"
 
@@ -23,6 +27,65 @@ struct kop_handle {
   std::unique_ptr<FrameDataBuffer> buffer;
   std::vector<std::shared_ptr<KhronosObjectAttributes>> last_objects;
   std::shared_ptr<FrameData> pending;  // kop_launch_frame done, kop_finish_frame outstanding
+
+  // detached extraction (ObjectWorkerPool role, object_worker_pool.cpp:56-146): one worker thread takes the tracks that
+  // left the window together with a snapshot of the frame buffer (shared frames outlive trimming, active_window.cpp:261-263)
+  // and runs the extractor on its own device context / stream while the window keeps processing frames
+  struct Job {
+    Track track;
+    std::shared_ptr<const FrameDataBuffer> frames;
+  };
+  std::thread worker;
+  std::mutex mu;
+  std::condition_variable cv, cv_idle;
+  std::deque<Job> jobs;
+  bool stop = false, busy = false;
+  std::vector<std::shared_ptr<KhronosObjectAttributes>> finished;  // not yet handed out
+  uint64_t finished_vertices = 0;
+  std::string worker_error;
+
+  ~kop_handle() {
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    if (worker.joinable()) worker.join();
+    // frames hold leases on slots of `ctx`, which the caller destroys after this handle
+    pending.reset();
+    jobs.clear();
+    buffer.reset();
+  }
+  void workerLoop() {
+    while (true) {
+      Job job;
+      {
+        std::unique_lock<std::mutex> lock(mu);
+        cv.wait(lock, [&] { return stop || !jobs.empty(); });
+        if (jobs.empty()) return;  // stop requested and nothing left
+        job = std::move(jobs.front());
+        jobs.pop_front();
+        busy = true;
+      }
+      std::shared_ptr<KhronosObjectAttributes> obj;
+      std::string err;
+      try {
+        obj = extractor->extractObject(job.track, *job.frames);
+      } catch (const std::exception& e) {
+        err = e.what();
+      }
+      {
+        std::lock_guard<std::mutex> lock(mu);
+        if (obj) {
+          finished_vertices += obj->mesh.numVertices();
+          finished.push_back(obj);
+        }
+        if (!err.empty()) worker_error = err;
+        busy = false;
+      }
+      cv_idle.notify_all();
+    }
+  }
 };
 
 namespace {
@@ -112,6 +175,7 @@ int kop_launch_frame(kop_handle* h, int slot, uint64_t stamp_ns, const double* w
     in.sensor = {sensor->width, sensor->height, sensor->fx, sensor->fy, sensor->cx, sensor->cy, sensor->min_range, sensor->max_range};
     in.ctx = h->ctx;
     in.slot = slot;
+    in.retainSlot();
     data->num_dynamic_clusters = n_dynamic_clusters;
     if (n_dynamic_clusters > 0) FreeSpaceMotionDetector::fetchClusters(h->map, *data);
     h->detector->processInput(h->map, *data);  // cached when khr_process_frame ran with KHR_PF_OBJECTS
@@ -131,8 +195,10 @@ int kop_process_frame(kop_handle* h, int slot, uint64_t stamp_ns, const double* 
   return kop_finish_frame(h, err, err_len);
 }
 
-// extractInactiveObjects: inactive tracks leave the tracker and go through the extractor.  Returns the number of
-// extracted objects; *n_removed = tracks removed, *n_vertices = mesh vertices of the extracted objects.
+// extractInactiveObjects (active_window.cpp:251-266): inactive tracks leave the tracker and go to the extractor -- on the
+// worker thread when `detach_object_extraction` is set (the reference's default), in line otherwise.  Returns the number
+// of objects handed out with this call (detached: the extractions that finished since the last call, like
+// ObjectWorkerPool::getFinishedExtractions); *n_removed = tracks removed now, *n_vertices = mesh vertices of those objects.
 int kop_extract_inactive(kop_handle* h, int* n_removed, uint64_t* n_vertices, char* err, int err_len) {
   if (!h) return KHR_EINVAL;
   if (n_removed) *n_removed = 0;
@@ -144,12 +210,21 @@ int kop_extract_inactive(kop_handle* h, int* n_removed, uint64_t* n_vertices, ch
   try {
     h->last_objects.clear();
     Tracks& tracks = h->tracker->getTracks();
+    const bool detach = h->config.detach_object_extraction && h->extractor;
+    std::shared_ptr<const FrameDataBuffer> snapshot;
     for (auto it = tracks.begin(); it != tracks.end();) {
       if (it->is_active) {
         ++it;
         continue;
       }
-      if (h->extractor) {
+      if (detach) {
+        if (!snapshot) snapshot = std::make_shared<const FrameDataBuffer>(*h->buffer);
+        {
+          std::lock_guard<std::mutex> lock(h->mu);
+          h->jobs.push_back({std::move(*it), snapshot});
+        }
+        h->cv.notify_one();
+      } else if (h->extractor) {
         auto obj = h->extractor->extractObject(*it, *h->buffer);
         if (obj) {
           if (n_vertices) *n_vertices += obj->mesh.numVertices();
@@ -159,11 +234,32 @@ int kop_extract_inactive(kop_handle* h, int* n_removed, uint64_t* n_vertices, ch
       if (n_removed) ++*n_removed;
       it = tracks.erase(it);
     }
+    if (detach) {
+      if (!h->worker.joinable()) h->worker = std::thread([h] { h->workerLoop(); });
+      std::lock_guard<std::mutex> lock(h->mu);
+      if (!h->worker_error.empty()) throw std::runtime_error("object extraction worker: " + h->worker_error);
+      h->last_objects.swap(h->finished);
+      h->finished.clear();
+      if (n_vertices) *n_vertices = h->finished_vertices;
+      h->finished_vertices = 0;
+    }
     return static_cast<int>(h->last_objects.size());
   } catch (const std::exception& e) {
     setErr(err, err_len, e.what());
     return KHR_EDEVICE;
   }
+}
+
+// wait for the detached extractions (ObjectWorkerPool::join role); returns the number of finished objects not handed out yet
+int kop_join(kop_handle* h, char* err, int err_len) {
+  if (!h) return KHR_EINVAL;
+  std::unique_lock<std::mutex> lock(h->mu);
+  h->cv_idle.wait(lock, [&] { return h->jobs.empty() && !h->busy; });
+  if (!h->worker_error.empty()) {
+    setErr(err, err_len, "object extraction worker: " + h->worker_error);
+    return KHR_EDEVICE;
+  }
+  return static_cast<int>(h->finished.size());
 }
 
 int kop_num_tracks(kop_handle* h) { return h ? static_cast<int>(h->tracker->getTracks().size()) : KHR_EINVAL; }

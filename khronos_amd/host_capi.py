@@ -29,6 +29,7 @@ def load_host_library():
     lib.kop_launch_frame.argtypes = [vp, i32, C.c_uint64, vp, C.POINTER(KhrSensor), i32, C.c_char_p, i32]
     lib.kop_finish_frame.argtypes = [vp, C.c_char_p, i32]
     lib.kop_extract_inactive.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_uint64), C.c_char_p, i32]
+    lib.kop_join.argtypes = [vp, C.c_char_p, i32]
     lib.kop_num_tracks.argtypes = [vp]
     lib.kop_num_buffered_frames.argtypes = [vp]
     lib.kop_get_tracks.argtypes = [vp, vp, i32]
@@ -47,6 +48,9 @@ class ObjectPipeline:
         self.h = self.lib.kop_create(ctx.h, yaml_text.encode(), self._err, 512)
         if not self.h:
             raise KhronosAmdError("kop_create failed: %s" % self._err.value.decode())
+        if not hasattr(ctx, "_dependents"):
+            ctx._dependents = []
+        ctx._dependents.append(self)  # FusionContext.close() closes us first: our frames hold slot leases on it
 
     def close(self):
         if getattr(self, "h", None):
@@ -89,6 +93,13 @@ class ObjectPipeline:
         if n < 0:
             raise KhronosAmdError("kop_extract_inactive failed (%d): %s" % (n, self._err.value.decode()))
         return n, nr.value, nv.value
+
+    def join(self):
+        """wait for detached extractions; -> finished objects that were not handed out by extract_inactive() yet"""
+        n = self.lib.kop_join(self.h, self._err, 512)
+        if n < 0:
+            raise KhronosAmdError("kop_join failed (%d): %s" % (n, self._err.value.decode()))
+        return n
 
     def num_tracks(self):
         return self.lib.kop_num_tracks(self.h)

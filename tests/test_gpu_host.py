@@ -361,14 +361,16 @@ def test_object_pipeline_c_api_matches_replica():
         assert n_tracks == len(trk.tracks)
         if out_now:
             ctx2.generate_mesh(True, True); ctx2.reset_inactive(); ctx2.clear_updated()
-            n_obj, n_rm, n_vert = pipe.extract_inactive()
+            n_obj, n_rm, n_vert = pipe.extract_inactive()  # detached: objects of earlier batches arrive with later calls
             gone = [t for t in trk.tracks if not t.is_active]
             trk.tracks = [t for t in trk.tracks if t.is_active]
-            assert n_rm == len(gone) and n_obj <= n_rm
+            assert n_rm == len(gone)
             n_obj_total += n_obj
             removed_total += n_rm
     got = [{k: t[k] for k in ("id", "dyn", "active", "cat", "n_obs", "first", "last")} for t in pipe.tracks()]
     want = [dict(id=t.id, dyn=int(t.is_dynamic), active=int(t.is_active), cat=t.category if t.has_semantics else -1,
                  n_obs=len(t.observations), first=t.first_seen, last=t.last_seen) for t in trk.tracks]
     assert got == want and len(want) >= 3 and removed_total >= 1
+    n_obj_total += pipe.join()
+    assert n_obj_total <= removed_total
     assert pipe.num_buffered_frames() <= 40

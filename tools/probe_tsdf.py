@@ -1,5 +1,5 @@
 """development probe: per-workgroup timeline of k_tsdf_update (KHR_DEBUG=8)."""
-import os, sys
+import os, sys, time
 os.environ.setdefault("KHR_DEBUG", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,7 +11,12 @@ cfg = default_config(voxel_size=vs, truncation_distance=3 * vs, with_semantics=1
 ctx = FusionContext(cfg)
 s = SyntheticStream(W, H)
 sen = ctx.make_sensor(W, H, s.fx, s.fy, s.cx, s.cy)
+ctx.timing_enable(True, ["tsdf"])
 for i in range(12):
+    if i == 6:
+        ctx.timing_reset()
+    if i == 11:
+        ctx.stats(); time.sleep(0.05)  # isolate the last launch in time
     fr = s.render(i)
     slot = ctx.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
     ctx.integrate(slot)
@@ -21,6 +26,19 @@ n = min(4096, st["n_tsdf_blocks"] * 4)
 buf = np.zeros(4096 * 4 * 8, np.uint64)
 ctx.lib.khr_debug_read(ctx.h, buf.ctypes.data, buf.size)
 d = buf.reshape(4096, 4, 8)[:n].astype(np.int64)
+# keep the entries of the LAST launch only (earlier frames had more work items; their probes are stale)
+xcc0 = d[:, 0, 5] & 0xf
+keep = np.zeros(len(d), bool)
+for x in range(8):
+    sel = xcc0 == x
+    if sel.any():
+        last = d[sel, 0, 3].max()  # the latest end on this XCD belongs to the last launch
+        keep |= sel & (last - d[:, 0, 0] < 5_000_000)
+print("entries", n, "of the last launch", int(keep.sum()))
+d = d[keep]
+n = len(d)
+ms, cnt = ctx.timing_get("tsdf")
+print("k_tsdf_update by its dispatch events: %.1f us avg over %d launches" % (1e3 * ms / max(cnt, 1), cnt))
 xcc_all = d[:, 0, 5] & 0xf
 start = np.zeros((n, 4), np.int64); p1 = start.copy(); rec = start.copy(); end = start.copy()
 for x in range(8):

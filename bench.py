@@ -54,6 +54,9 @@ def parse_args():
     ap.add_argument("--frame-times", action="store_true", help="debug: synchronise and print per-frame wall times")
     ap.add_argument("--mesh-req-cap", type=int, default=16384, help="mesh halo requests all-gathered per rank (N > 1)")
     ap.add_argument("--mesh-rec-cap", type=int, default=2048, help="mesh halo records all-gathered per rank (N > 1)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="development: ONE process plays rank 0 of an N-rank sharded run (all N cameras rendered locally, no "
+                         "collectives) to measure the per-rank tick cost on a 1-GPU box; the JSON line is marked emulation")
     ap.add_argument("--halo-cap", type=int, default=8192, help="halo records all-gathered per rank and tick (N > 1)")
     return ap.parse_args()
 
@@ -126,6 +129,10 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    emu = args.emulate_world if (args.emulate_world > 1 and world == 1) else 0
+    if emu:
+        world = emu  # shard parameters, cameras and tick structure of an N-rank run; dist stays None
+
     import __graft_entry__ as entry
     if rank == 0:
         entry.build()
@@ -165,16 +172,21 @@ def main():
     frames_host = []
     dev = torch.device("cuda", local_rank)
     d_depth, d_rgb, d_label, poses, stamps = [], [], [], [], []
+    emu_cams = []
     for i in range(n_total):
         fr = s.render(i, yaw_offset=yaw)
         if rank == 0 and world == 1:
             frames_host.append(fr)
+        if emu:
+            others = [s.render(i, yaw_offset=2.0 * math.pi * r / world) for r in range(1, world)]
+            emu_cams.append([(torch.from_numpy(o["depth"]).to(dev), torch.from_numpy(o["rgb"]).to(dev),
+                              torch.from_numpy(o["label"]).to(dev)) for o in others])
         d_depth.append(torch.from_numpy(fr["depth"]).to(dev))
         d_rgb.append(torch.from_numpy(fr["rgb"]).to(dev))
         d_label.append(torch.from_numpy(fr["label"]).to(dev))
         stamps.append(fr["stamp"])
         poses.append([s.pose(i, yaw_offset=2.0 * math.pi * r / world) for r in range(world)])
-    if world > 1:
+    if world > 1 and not emu:
         # one packed buffer per frame (depth f32 | label i32 | rgb u8x3) so that a tick needs ONE frame all-gather
         npx = W * H
         packed = []
@@ -184,11 +196,25 @@ def main():
             pk[4 * npx: 8 * npx] = d_label[i].view(torch.uint8).reshape(-1)
             pk[8 * npx:] = d_rgb[i].reshape(-1)
             packed.append(pk)
-        g_flat = torch.empty(world * 11 * npx, dtype=torch.uint8, device=dev)  # flat: the concatenated form every backend accepts
-        g_packed = g_flat.view(world, 11 * npx)
-        g_depth = [g_packed[r, : 4 * npx].view(torch.float32).view(H, W) for r in range(world)]
-        g_label = [g_packed[r, 4 * npx: 8 * npx].view(torch.int32).view(H, W) for r in range(world)]
-        g_rgb = [g_packed[r, 8 * npx:].view(H, W, 3) for r in range(world)]
+        # two receive buffers: the all-gather of tick i + 1 runs on its own stream while tick i is fused (the frames of a
+        # tick do not depend on the map, so the exchange is off the critical path as long as it is shorter than a tick)
+        g_flat, g_depth, g_label, g_rgb = [], [], [], []
+        for _b in range(2):
+            gf = torch.empty(world * 11 * npx, dtype=torch.uint8, device=dev)  # flat: the concatenated form every backend accepts
+            gp = gf.view(world, 11 * npx)
+            g_flat.append(gf)
+            g_depth.append([gp[r, : 4 * npx].view(torch.float32).view(H, W) for r in range(world)])
+            g_label.append([gp[r, 4 * npx: 8 * npx].view(torch.int32).view(H, W) for r in range(world)])
+            g_rgb.append([gp[r, 8 * npx:].view(H, W, 3) for r in range(world)])
+        comm_stream = torch.cuda.Stream(device=local_rank)
+        gather_work = {}
+
+        def issue_gather(i):
+            if i >= n_total or i in gather_work:
+                return
+            comm_stream.wait_stream(stream)  # the buffer's previous reader (tick i - 2) has been queued on `stream`
+            with torch.cuda.stream(comm_stream):
+                gather_work[i] = dist.all_gather_into_tensor(g_flat[i % 2], packed[i], async_op=True)
     torch.cuda.synchronize()
 
     # input descriptors (khr_frame: stamp, pose, HBM pointers) are built before the timed region
@@ -208,9 +234,16 @@ def main():
             _step(i)
 
     def _step(i):
-        if world > 1:
-            dist.all_gather_into_tensor(g_flat, packed[i])
-            cams = [(g_depth[r], g_rgb[r], g_label[r], poses[i][r]) for r in range(world)]
+        if emu:
+            cams = [(d_depth[i], d_rgb[i], d_label[i], poses[i][0])] + [
+                (dep, rgb, lab, poses[i][r + 1]) for r, (dep, rgb, lab) in enumerate(emu_cams[i])]
+        elif world > 1:
+            issue_gather(i)
+            gather_work.pop(i).wait()  # `stream` waits for this tick's frames
+            stream.wait_stream(comm_stream)
+            issue_gather(i + 1)        # next tick's frames travel while this tick is fused
+            b = i % 2
+            cams = [(g_depth[b][r], g_rgb[b][r], g_label[b][r], poses[i][r]) for r in range(world)]
         else:
             cams = [(d_depth[i], d_rgb[i], d_label[i], poses[i][0])]
         out_now = args.output_every > 0 and (i + 1) % args.output_every == 0
@@ -309,7 +342,7 @@ def main():
     fps = frames / dt
     out = {
         "metric": "active-window frames/sec (+ Mvoxel-updates/sec) at %dx%d RGB-D+labels, %g cm voxels" % (W, H, vs * 100),
-        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": fps, "unit": "frames/s", "n_gpus": 1 if emu else world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: %dx%d synthetic RGB-D+labels, %g cm voxels, vps 16, K=%d labels, "
@@ -318,10 +351,13 @@ def main():
                                % (W, H, vs * 100, K, "off" if args.no_motion else "on",
                                   "off" if args.no_objects else "on (ConnectedSemantics, MaxIoUTracker, MeshObjectExtractor)",
                                   args.output_every, world),
-                   "parallelism": "hash-range block shard x%d, owner-computes, RCCL all-gather of packed frames + of 528-B halo records "
+                   "parallelism": "hash-range block shard x%d, owner-computes, RCCL all-gather of packed frames (prefetched one tick ahead on its own stream) + of 528-B halo records "
                                   "(ever-free), seed-gated all-reduce of per-pixel voxel keys (motion detector), request / response all-gather of mesh halo planes" % world
                    if world > 1 else "single GPU"},
         "mvoxel_updates_per_s": 1e-6 * n_upd_all / dt,
+        **({"emulation": "rank 0 of a %d-rank sharded run played by one process, no collectives: `value` is what the job would reach "
+                         "if communication were free and all ranks were as loaded as rank 0 -- NOT a measured N-GPU number" % world}
+           if emu else {}),
         "objects": None if pipe is None else {"tracks_at_end": pipe.num_tracks(), "buffered_frames": pipe.num_buffered_frames(),
                                               "objects_extracted": obj_stats[0], "tracks_removed": obj_stats[1],
                                               "extraction_ms_total": 1e3 * obj_stats[2]},

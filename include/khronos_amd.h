@@ -325,6 +325,28 @@ int64_t khr_mesh_num_vertices(khr_ctx* ctx);
 int64_t khr_download_mesh(khr_ctx* ctx, float* points, uint8_t* colors_rgba, uint32_t* labels,
                           uint64_t* first_seen, uint64_t* stamps, int64_t cap);
 
+/* ---- tick path: the camera frames of ONE tick batched (sharded multi-camera runs) ------------------------------------
+ * In a hash-range sharded run every rank sees every camera frame, so the per-camera work of a
+ * rank is what does not shrink with the rank count.  These two calls are khr_upload_frame / khr_integrate for n_frames
+ * frames of the same sensor with the per-camera launches folded together; results are identical to the per-frame calls
+ * made in camera order (reference call order per frame: active_window.cpp:189-215).
+ *
+ * khr_tick_ingest: ingest n_frames frames (DEVICE pointers in khr_frame) in one launch; slots_out[i] = frame slot.
+ *   count_seeds != 0: the motion detector's per-pixel seed test (free_space_motion_detector.cpp:158-203) runs in the
+ *   same pass against this shard's blocks.  n_seed_pixels (host, may be NULL) receives camera i's count and makes the
+ *   call wait for it; with NULL nothing waits and khr_tick_seed_counts collects the counts later, after more work has
+ *   been queued.  seed_counts_device (device int64[n_frames], may be NULL) receives the same counts on the device, as
+ *   the operand of the ranks' count all-reduce.  The voxel keys of a camera are only needed when some rank reports
+ *   seeds: khr_motion_keys(slot) then produces them.
+ * khr_tick_integrate: phases bit 0 = block allocation for every frame + one initialisation + one culling launch
+ *   (independent of the motion masks: queue it before collecting the seed counts), bit 1 = the TSDF / band update
+ *   kernels frame by frame in the order given (use_mask / object_id as khr_integrate).  Split phases take at most 8
+ *   frames per call. */
+int khr_tick_ingest(khr_ctx* ctx, const khr_sensor* sensor, const khr_frame* frames, int n_frames, int count_seeds,
+                    int* slots_out, uint32_t* n_seed_pixels, int64_t* seed_counts_device);
+int khr_tick_seed_counts(khr_ctx* ctx, uint32_t* n_seed_pixels, int n_frames);
+int khr_tick_integrate(khr_ctx* ctx, const int* slots, int n_frames, int use_mask, int object_id, int phases);
+
 /* -- measurement ------------------------------------------------------------------------------- */
 /* HIP-event timing of the kernels launched on the context stream. which: 0 tsdf update,
  * 1 tracking update, 2 ever-free, 3 block allocation+init, 4 motion pixels, 5 mesh, 6 parse input,

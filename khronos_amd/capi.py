@@ -72,7 +72,7 @@ EXPORTS = [
     "khr_detect_motion", "khr_generate_mesh", "khr_reset_inactive", "khr_mark_all_inactive", "khr_clear_updated",
     "khr_allocate_blocks", "khr_object_prune", "khr_get_stats", "khr_num_blocks", "khr_block_indices",
     "khr_download_block", "khr_mesh_num_vertices", "khr_download_mesh", "khr_timing_enable", "khr_timing_reset",
-    "khr_timing_get", "khr_debug_read", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_update_tracking_phase",
+    "khr_timing_get", "khr_debug_read", "khr_tick_ingest", "khr_tick_integrate", "khr_tick_seed_counts", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_update_tracking_phase",
     "khr_export_halo", "khr_import_halo", "khr_get_dynamic_clusters", "khr_motion_keys",
     "khr_detect_motion_from_keys", "khr_download_updated", "khr_mesh_halo_requests", "khr_mesh_halo_export",
     "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",
@@ -168,6 +168,9 @@ def load_library():
     lib.khr_download_mesh.argtypes = [vp, vp, vp, vp, vp, vp, i64]
     lib.khr_download_mesh.restype = i64
     lib.khr_debug_read.argtypes = [vp, vp, i64]
+    lib.khr_tick_ingest.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
+    lib.khr_tick_seed_counts.argtypes = [vp, vp, i32]
+    lib.khr_tick_integrate.argtypes = [vp, vp, i32, i32, i32, i32]
     lib.khr_last_removed.argtypes = [vp, vp, i64, C.POINTER(i64)]
     lib.khr_process_frame.argtypes = [vp, C.POINTER(KhrSensor), C.POINTER(KhrFrame), i32, C.c_uint32, C.POINTER(i32)]
     lib.khr_timing_enable.argtypes = [vp, i32]
@@ -267,6 +270,27 @@ class FusionContext:
         f.color = color_ptr or None
         f.label = label_ptr or None
         return self._chk(self.lib.khr_upload_frame(self.h, C.byref(sensor), C.byref(f), 1))
+
+    def tick_ingest(self, sensor, frames, count_seeds=True, want_counts=True, counts_device_ptr=0):
+        """khr_tick_ingest: `frames` = list of KhrFrame with DEVICE pointers (make_frame).  Returns (slots, seed counts or
+        None); want_counts=False does not wait (tick_seed_counts collects later); counts_device_ptr: device int64[n]."""
+        n = len(frames)
+        arr = (KhrFrame * n)(*frames)
+        slots = (C.c_int * n)()
+        counts = (C.c_uint32 * n)() if want_counts else None
+        self._chk(self.lib.khr_tick_ingest(self.h, C.byref(sensor), arr, n, 1 if count_seeds else 0, slots, counts,
+                                           C.c_void_p(counts_device_ptr or None)))
+        return list(slots), (list(counts) if want_counts else None)
+
+    def tick_seed_counts(self, n):
+        counts = (C.c_uint32 * n)()
+        self._chk(self.lib.khr_tick_seed_counts(self.h, counts, n))
+        return list(counts)
+
+    def tick_integrate(self, slots, use_mask=False, object_id=-1, phases=3):
+        n = len(slots)
+        arr = (C.c_int * n)(*[int(x) for x in slots])
+        self._chk(self.lib.khr_tick_integrate(self.h, arr, n, 1 if use_mask else 0, int(object_id), int(phases)))
 
     PF_OBJECTS = 8
     PF_MOTION, PF_TRACKING, PF_OUTPUT = 1, 2, 4

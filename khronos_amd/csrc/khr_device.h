@@ -63,7 +63,7 @@ struct DevMap {
   uint32_t* ht_vals;
   uint32_t ht_mask;
   uint32_t capacity;
-  int4* blk_index;      // x,y,z,unused
+  int4* blk_index;      // x, y, z, allocation epoch (tick path; 0 otherwise)
   uint32_t* blk_flags;
   float* dist;
   float* weight;
@@ -178,6 +178,43 @@ __device__ inline void xform(const float* R, const float* t, float x, float y, f
   o[0] = ((R[0] * x + R[1] * y) + R[2] * z) + t[0];
   o[1] = ((R[3] * x + R[4] * y) + R[5] * z) + t[1];
   o[2] = ((R[6] * x + R[7] * y) + R[8] * z) + t[2];
+}
+
+// FreeSpaceMotionDetector::setUpPointMapPart for one pixel (free_space_motion_detector.cpp:158-203): range / z gates,
+// world vertex from depth + pose, tracking-block lookup, voxel index, ever-free test.  Returns the packed global voxel
+// index with the seed flag in bit 63, ~0 for skipped pixels.  (r, d) = the frame slot's range / depth of pixel (u, v).
+constexpr uint64_t kSeedFlag = 1ull << 63;
+__device__ inline uint64_t motionPixelKey(const DevMap& m, const DevParams& p, float r, float d, int u, int v, float fx,
+                                          float fy, float cx, float cy, const float* Rw, const float* tw,
+                                          float md_max_range, float min_z_world, int ignore_epoch = 0) {
+  uint64_t key = ~0ull;
+  if (r > 0.f && !(r > md_max_range)) {
+    const float x = ((static_cast<float>(u) - cx) / fx) * d;
+    const float y = ((static_cast<float>(v) - cy) / fy) * d;
+    float pw[3];
+    xform(Rw, tw, x, y, d, pw);
+    if (!(pw[2] < min_z_world)) {
+      const int bx = static_cast<int>(floorf(pw[0] * p.bs_inv)), by = static_cast<int>(floorf(pw[1] * p.bs_inv)),
+                bz = static_cast<int>(floorf(pw[2] * p.bs_inv));
+      uint32_t slot = htLookup(m, packKey(bx, by, bz));
+      // tick path: blocks the current tick has just allocated (blk_index.w = allocation epoch) did not exist when the
+      // reference would have run the detector (before the frame's integration): not there yet
+      if (slot != kInvalidSlot && ignore_epoch != 0 && m.blk_index[slot].w == ignore_epoch) slot = kInvalidSlot;
+      if (slot != kInvalidSlot) {
+        const float ox = static_cast<float>(bx) * p.bs, oy = static_cast<float>(by) * p.bs,
+                    oz = static_cast<float>(bz) * p.bs;
+        const int vx = static_cast<int>(floorf((pw[0] - ox) * p.vs_inv));
+        const int vy = static_cast<int>(floorf((pw[1] - oy) * p.vs_inv));
+        const int vz = static_cast<int>(floorf((pw[2] - oz) * p.vs_inv));
+        if (vx >= 0 && vy >= 0 && vz >= 0 && vx < p.vps && vy < p.vps && vz < p.vps) {
+          key = packKey(bx * p.vps + vx, by * p.vps + vy, bz * p.vps + vz);
+          const int lin = vx + p.vps * (vy + p.vps * vz);
+          if (m.vflags[static_cast<size_t>(slot) * p.nvox + lin] & VOX_EVER_FREE) key |= kSeedFlag;
+        }
+      }
+    }
+  }
+  return key;
 }
 
 __device__ inline double toSeconds(uint64_t ns) { return static_cast<double>(ns) / 1e9; }

@@ -13,7 +13,7 @@ namespace khr {
 __device__ int8_t g_mc_tri[256][16];
 __device__ uint8_t g_mc_ntri[256];
 
-constexpr uint64_t kSeedBit = 1ull << 63;
+constexpr uint64_t kSeedBit = kSeedFlag;
 
 // ----------------------------------------------------------------------------------------------
 // k_motion_pixels: FreeSpaceMotionDetector::setUpPointMapPart (free_space_motion_detector.cpp:158-203),
@@ -23,36 +23,13 @@ constexpr uint64_t kSeedBit = 1ull << 63;
 // (nested hash maps) are grouped by the device voxel hash tables below (k_md_*).
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_motion_pixels(DevMap m, DevParams p, DevFrame f, float md_max_range,
-                                                      float min_z_world, uint64_t* __restrict__ keys) {
+                                                      float min_z_world, uint64_t* __restrict__ keys, int ignore_epoch) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in = i < f.W * f.H;
   uint64_t key = ~0ull;
-  const float r = in ? f.range[i] : 0.f;
-  if (r > 0.f && !(r > md_max_range)) {
-    const float d = f.depth[i];
-    const int u = i % f.W, v = i / f.W;
-    const float x = ((static_cast<float>(u) - f.cx) / f.fx) * d;
-    const float y = ((static_cast<float>(v) - f.cy) / f.fy) * d;
-    float pw[3];
-    xform(f.Rw, f.tw, x, y, d, pw);
-    if (!(pw[2] < min_z_world)) {
-      const int bx = static_cast<int>(floorf(pw[0] * p.bs_inv)), by = static_cast<int>(floorf(pw[1] * p.bs_inv)),
-                bz = static_cast<int>(floorf(pw[2] * p.bs_inv));
-      const uint32_t slot = htLookup(m, packKey(bx, by, bz));
-      if (slot != kInvalidSlot) {
-        const float ox = static_cast<float>(bx) * p.bs, oy = static_cast<float>(by) * p.bs,
-                    oz = static_cast<float>(bz) * p.bs;
-        const int vx = static_cast<int>(floorf((pw[0] - ox) * p.vs_inv));
-        const int vy = static_cast<int>(floorf((pw[1] - oy) * p.vs_inv));
-        const int vz = static_cast<int>(floorf((pw[2] - oz) * p.vs_inv));
-        if (vx >= 0 && vy >= 0 && vz >= 0 && vx < p.vps && vy < p.vps && vz < p.vps) {
-          key = packKey(bx * p.vps + vx, by * p.vps + vy, bz * p.vps + vz);
-          const int lin = vx + p.vps * (vy + p.vps * vz);
-          if (m.vflags[static_cast<size_t>(slot) * p.nvox + lin] & VOX_EVER_FREE) key |= kSeedBit;
-        }
-      }
-    }
-  }
+  if (in)
+    key = motionPixelKey(m, p, f.range[i], f.depth[i], i % f.W, i / f.W, f.fx, f.fy, f.cx, f.cy, f.Rw, f.tw, md_max_range,
+                         min_z_world, ignore_epoch);
   if (in) keys[i] = key;
   const bool seed = (key != ~0ull) && (key & kSeedBit);
   const unsigned long long b = __ballot(seed);

@@ -15,23 +15,21 @@ constexpr int kBandShards = 16;  // the in-band record list is split in shards (
 // dynamic_image, and the tile's max range (block culling).  Also resets the per-frame counters.
 // ----------------------------------------------------------------------------------------------
 constexpr int kTile = 16;
+constexpr int kMaxTick = 8;  // camera frames batched per launch in the tick path (khr_tick_*)
 __device__ inline void beginIntegrate(DevMap m, int nvox, uint32_t* band_count);
-__global__ __launch_bounds__(256) void k_frame_ingest(const float* __restrict__ depth_in,
-                                                     const uint8_t* __restrict__ rgb_in,
-                                                     const int32_t* __restrict__ label_in, float* __restrict__ depth,
-                                                     float* __restrict__ range, uint32_t* __restrict__ rgba,
-                                                     int32_t* __restrict__ label, int32_t* __restrict__ dyn,
-                                                     float* __restrict__ tile_max, int tw, int W, int H, float fx,
-                                                     float fy, float cx, float cy, int range_mode, DevMap m, int nvox,
-                                                     uint32_t* __restrict__ band_count, int do_begin) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) m.counters[C_N_SEEDS] = 0u;
-  if (do_begin && blockIdx.x == 0) beginIntegrate(m, nvox, band_count);  // khr_process_frame: saves a launch
-  const int tx = blockIdx.x % tw, ty = blockIdx.x / tw;
+
+// one 16x16-pixel tile of one frame; returns this thread's (depth, range) for callers that go on with the pixel
+__device__ inline void ingestTile(const float* __restrict__ depth_in, const uint8_t* __restrict__ rgb_in,
+                                  const int32_t* __restrict__ label_in, float* __restrict__ depth, float* __restrict__ range,
+                                  uint32_t* __restrict__ rgba, int32_t* __restrict__ label, int32_t* __restrict__ dyn,
+                                  float* __restrict__ tile_max, int tile, int tw, int W, int H, float fx, float fy, float cx,
+                                  float cy, int range_mode, float* d_out, float* r_out) {
+  const int tx = tile % tw, ty = tile / tw;
   const int u = tx * kTile + (threadIdx.x & 15), v = ty * kTile + (threadIdx.x >> 4);
-  float r = 0.f;
+  float r = 0.f, d = 0.f;
   if (u < W && v < H) {
     const int i = v * W + u;
-    const float d = depth_in[i];
+    d = depth_in[i];
     if (d > 0.f && isfinite(d)) {
       if (range_mode == 0) {
         r = d;
@@ -48,12 +46,84 @@ __global__ __launch_bounds__(256) void k_frame_ingest(const float* __restrict__ 
                 (static_cast<uint32_t>(rgb_in[3 * i + 2]) << 16) | 0xff000000u;
     if (label_in) label[i] = label_in[i];
   }
+  *d_out = d;
+  *r_out = r;
+  float rm = r;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) r = fmaxf(r, __shfl_down(r, o));
+  for (int o = 32; o > 0; o >>= 1) rm = fmaxf(rm, __shfl_down(rm, o));
   __shared__ float s[4];
-  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = r;
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = rm;
   __syncthreads();
-  if (threadIdx.x == 0) tile_max[blockIdx.x] = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+  if (threadIdx.x == 0) tile_max[tile] = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+}
+
+__global__ __launch_bounds__(256) void k_frame_ingest(const float* __restrict__ depth_in,
+                                                     const uint8_t* __restrict__ rgb_in,
+                                                     const int32_t* __restrict__ label_in, float* __restrict__ depth,
+                                                     float* __restrict__ range, uint32_t* __restrict__ rgba,
+                                                     int32_t* __restrict__ label, int32_t* __restrict__ dyn,
+                                                     float* __restrict__ tile_max, int tw, int W, int H, float fx,
+                                                     float fy, float cx, float cy, int range_mode, DevMap m, int nvox,
+                                                     uint32_t* __restrict__ band_count, int do_begin) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) m.counters[C_N_SEEDS] = 0u;
+  if (do_begin && blockIdx.x == 0) beginIntegrate(m, nvox, band_count);  // khr_process_frame: saves a launch
+  float d, r;
+  ingestTile(depth_in, rgb_in, label_in, depth, range, rgba, label, dyn, tile_max, blockIdx.x, tw, W, H, fx, fy, cx, cy,
+             range_mode, &d, &r);
+}
+
+// The camera frames of one tick in one launch (blockIdx.y = camera): k_frame_ingest for each, and -- count_seeds -- the
+// motion detector's seed test of every pixel against this shard's blocks in the same pass.  In a sharded run the voxel
+// keys of a camera are only needed when SOME rank has seeds for it (rare), so the common case costs no key image, no
+// second pass over the frame and no per-camera launches; khr_motion_keys produces the keys when they are needed.
+struct TickIngest {
+  const float* depth_in[kMaxTick];
+  const uint8_t* rgb_in[kMaxTick];
+  const int32_t* label_in[kMaxTick];
+  float* depth[kMaxTick];
+  float* range[kMaxTick];
+  uint32_t* rgba[kMaxTick];
+  int32_t* label[kMaxTick];
+  int32_t* dyn[kMaxTick];
+  float* tile_max[kMaxTick];
+  float Rw[kMaxTick][9], tw[kMaxTick][3], min_z_world[kMaxTick];
+};
+__global__ __launch_bounds__(256) void k_tick_ingest(TickIngest t, int tw, int W, int H, float fx, float fy, float cx, float cy,
+                                                    int range_mode, DevMap m, DevParams p, float md_max_range, int count_seeds,
+                                                    uint32_t* __restrict__ seed_counts) {
+  const int cam = blockIdx.y;
+  if (blockIdx.x == 0 && cam == 0 && threadIdx.x == 0) m.counters[C_N_SEEDS] = 0u;
+  float d, r;
+  ingestTile(t.depth_in[cam], t.rgb_in[cam], t.label_in[cam], t.depth[cam], t.range[cam], t.rgba[cam], t.label[cam], t.dyn[cam],
+             t.tile_max[cam], blockIdx.x, tw, W, H, fx, fy, cx, cy, range_mode, &d, &r);
+  if (!count_seeds) return;
+  const int u = (blockIdx.x % tw) * kTile + (threadIdx.x & 15), v = (blockIdx.x / tw) * kTile + (threadIdx.x >> 4);
+  bool seed = false;
+  if (u < W && v < H) {
+    const uint64_t key = motionPixelKey(m, p, r, d, u, v, fx, fy, cx, cy, t.Rw[cam], t.tw[cam], md_max_range, t.min_z_world[cam]);
+    seed = key != ~0ull && (key & kSeedFlag);
+  }
+  const unsigned long long b = __ballot(seed);
+  if (b && laneId() == static_cast<uint32_t>(__ffsll(static_cast<long long>(b)) - 1))
+    atomicAdd(&seed_counts[cam], static_cast<uint32_t>(__popcll(b)));
+}
+
+// per-camera counts of a tick -> pinned host memory + ticket (one workgroup, plain stores); the device copies are
+// zeroed for the next tick
+__global__ void k_tick_publish(uint32_t* __restrict__ counts, int n, volatile uint32_t* __restrict__ host_counts,
+                               volatile uint32_t* __restrict__ host_ticket, uint32_t ticket, long long* __restrict__ dev_counts) {
+  if (threadIdx.x < static_cast<uint32_t>(n)) {
+    const uint32_t v = atomicAdd(&counts[threadIdx.x], 0u);
+    host_counts[threadIdx.x] = v;
+    if (dev_counts) dev_counts[threadIdx.x] = static_cast<long long>(v);  // operand of the ranks' count all-reduce
+    counts[threadIdx.x] = 0u;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *host_ticket = ticket;
+    __threadfence_system();
+  }
 }
 
 // world-frame vertex map on demand (InputData::vertex_map)
@@ -82,7 +152,10 @@ __global__ __launch_bounds__(256) void k_vertex_map(DevFrame f, float* __restric
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_alloc_visible(DevMap m, DevParams p, DevFrame f, DevFrustum fr,
                                                       uint32_t* __restrict__ work, uint32_t* __restrict__ new_list,
-                                                      volatile uint32_t* host_seed, uint32_t seed_ticket) {
+                                                      volatile uint32_t* host_seed, uint32_t seed_ticket,
+                                                      uint32_t* __restrict__ list_count, int epoch) {
+  // list_count: cursor of `work`.  The tick path (khr_tick_integrate) keeps one list per camera and lets
+  // counters[C_N_VISIBLE] run on as the tick's total (statistics).
   // khr_process_frame: this is the first kernel behind k_motion_pixels, whose seed count the host is waiting for
   if (seed_ticket && blockIdx.x == 0 && threadIdx.x == 0) publishSeedCount(m, host_seed, seed_ticket);
   const int S = 2 * fr.n_steps + 1;
@@ -122,7 +195,7 @@ __global__ __launch_bounds__(256) void k_alloc_visible(DevMap m, DevParams p, De
     if (fidx < m.counters[C_N_FREE]) {
       slot = m.free_slots[fidx];
       got = true;
-      m.blk_index[slot] = make_int4(bx, by, bz, 0);
+      m.blk_index[slot] = make_int4(bx, by, bz, epoch);
       m.blk_flags[slot] = BLK_LIVE | BLK_TRACK_DIRTY;
       m.mesh_desc[slot] = MeshDesc{0u, 0u};
       htInsertUnique(m, key, slot);
@@ -135,8 +208,9 @@ __global__ __launch_bounds__(256) void k_alloc_visible(DevMap m, DevParams p, De
   const uint32_t nidx = waveAggInc(&m.counters[C_N_NEW], got);
   if (got) new_list[nidx] = slot;
   const bool emit = visible && slot != kInvalidSlot;
-  const uint32_t widx = waveAggInc(&m.counters[C_N_VISIBLE], emit);
+  const uint32_t widx = waveAggInc(list_count, emit);
   if (emit) work[widx] = slot;
+  if (list_count != &m.counters[C_N_VISIBLE]) waveAggInc(&m.counters[C_N_VISIBLE], emit);
 }
 
 // per-call counter reset; the previous call's statistics are folded into cumulative totals so that a
@@ -159,6 +233,14 @@ __device__ inline void beginIntegrate(DevMap m, int nvox, uint32_t* band_count) 
 __global__ void k_begin_integrate(DevMap m, int nvox, uint32_t* band_count) {
   if (blockIdx.x == 0) beginIntegrate(m, nvox, band_count);
 }
+// tick path: one begin for all cameras of the tick (both record-cursor sets, the per-camera list counters)
+__global__ void k_tick_begin(DevMap m, int nvox, uint32_t* band_count, uint32_t* band_count2, uint32_t* tick_counts,
+                             uint32_t extra_calls) {
+  beginIntegrate(m, nvox, band_count);
+  if (threadIdx.x < kBandShards) band_count2[threadIdx.x * 32] = 0u;
+  if (threadIdx.x < 2 * kMaxTick) tick_counts[threadIdx.x] = 0u;
+  if (threadIdx.x == 0) m.stats[S_CUM_CALLS] += extra_calls;
+}
 
 // ----------------------------------------------------------------------------------------------
 // k_cull_blocks: exact, conservative block culling.  Every frustum block stays allocated and listed in
@@ -168,16 +250,15 @@ __global__ void k_begin_integrate(DevMap m, int nvox, uint32_t* band_count) {
 // max tiles) is smaller than the block's nearest voxel range minus the truncation distance (then every
 // sdf < -trunc).  One wave per block: the 64 lanes scan the footprint's tiles and max-reduce.
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cull_blocks(DevMap m, DevParams p, DevFrame f,
-                                                    const uint32_t* __restrict__ work,
-                                                    uint32_t* __restrict__ work_tsdf,
-                                                    const float* __restrict__ tile_max, int tw, int th) {
+__device__ inline void cullBlocks(const DevMap& m, const DevParams& p, const DevFrame& f, const uint32_t* __restrict__ work,
+                                  const uint32_t* __restrict__ n_work, uint32_t* __restrict__ work_tsdf,
+                                  uint32_t* __restrict__ n_tsdf, const float* __restrict__ tile_max, int tw, int th) {
   // each workgroup tests kPerWg blocks (one wave per block, 4 rounds), gathers the survivors in LDS and
   // appends them with ONE atomic (hot-address atomics are expensive, see k_tsdf_update)
   constexpr int kPerWg = 16;
   __shared__ uint32_t s_keep[kPerWg];
   __shared__ uint32_t s_nkeep, s_off;
-  const uint32_t n = m.counters[C_N_VISIBLE];
+  const uint32_t n = *n_work;
   const uint32_t lane = threadIdx.x & 63;
   for (uint32_t base = blockIdx.x * kPerWg; base < n; base += gridDim.x * kPerWg) {
   if (threadIdx.x == 0) s_nkeep = 0;
@@ -233,11 +314,36 @@ __global__ __launch_bounds__(256) void k_cull_blocks(DevMap m, DevParams p, DevF
     if (lane == 0 && keep) s_keep[atomicAdd(&s_nkeep, 1u)] = slot;
   }
   __syncthreads();
-  if (threadIdx.x == 0) s_off = s_nkeep ? atomicAdd(&m.counters[C_N_TSDF], s_nkeep) : 0u;
+  if (threadIdx.x == 0) {
+    s_off = s_nkeep ? atomicAdd(n_tsdf, s_nkeep) : 0u;
+    if (s_nkeep && n_tsdf != &m.counters[C_N_TSDF]) atomicAdd(&m.counters[C_N_TSDF], s_nkeep);  // tick total (statistics)
+  }
   __syncthreads();
   if (threadIdx.x < s_nkeep) work_tsdf[s_off + threadIdx.x] = s_keep[threadIdx.x];
   __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(256) void k_cull_blocks(DevMap m, DevParams p, DevFrame f,
+                                                    const uint32_t* __restrict__ work,
+                                                    uint32_t* __restrict__ work_tsdf,
+                                                    const float* __restrict__ tile_max, int tw, int th) {
+  cullBlocks(m, p, f, work, &m.counters[C_N_VISIBLE], work_tsdf, &m.counters[C_N_TSDF], tile_max, tw, th);
+}
+
+// the cameras of a tick in one launch (blockIdx.y = camera): per-camera visible lists -> per-camera TSDF lists.
+// tick_counts[2 * cam] = visible, [2 * cam + 1] = non-culled.
+struct TickFrames {
+  DevFrame f[kMaxTick];
+  const float* tile_max[kMaxTick];
+};
+__global__ __launch_bounds__(256) void k_tick_cull(DevMap m, DevParams p, TickFrames t, const uint32_t* __restrict__ work,
+                                                  uint32_t* __restrict__ work_tsdf, uint32_t list_stride,
+                                                  uint32_t* __restrict__ tick_counts, int use_tiles, int tw, int th) {
+  const int cam = blockIdx.y;
+  cullBlocks(m, p, t.f[cam], work + static_cast<size_t>(cam) * list_stride, &tick_counts[2 * cam],
+             work_tsdf + static_cast<size_t>(cam) * list_stride, &tick_counts[2 * cam + 1], use_tiles ? t.tile_max[cam] : nullptr, tw,
+             th);
 }
 
 // explicit allocation of a list of block indices (VolumetricMap::allocateBlock)
@@ -678,8 +784,11 @@ template <int VPS>
 __global__ __launch_bounds__(256) void k_band_update(DevMap m, DevParams p, DevFrame f,
                                                     const BandRec* __restrict__ band, uint32_t shard_cap,
                                                     const uint32_t* __restrict__ band_count, int object_id,
-                                                    const uint32_t* __restrict__ wg_stats, int n_wg) {
+                                                    const uint32_t* __restrict__ wg_stats, int n_wg,
+                                                    uint32_t* __restrict__ band_count_next) {
   constexpr int NV = VPS * VPS * VPS;
+  // tick path: the record cursors alternate between two sets; the set of the NEXT camera's k_tsdf_update is idle now
+  if (band_count_next && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kBandShards) band_count_next[threadIdx.x * 32] = 0u;
   if (blockIdx.x == 0 && blockIdx.y == 0) {  // fold k_tsdf_update's per-workgroup statistics
     unsigned long long u = 0, b = 0;
     for (int i = threadIdx.x; i < n_wg; i += blockDim.x) {
@@ -720,17 +829,44 @@ __global__ __launch_bounds__(256) void k_band_update(DevMap m, DevParams p, DevF
     const int best = interpWeights(du, dv, use_nearest, w4);
     const int best_px = px4[best];
     const float w = r.w;
+    // every load of this record is issued here, before the first store: the colour / label / likelihood reads depend
+    // only on the record and the block index, and a store in between would fence them (the arrays may alias as far as
+    // the compiler knows), turning one round trip to memory into three
+    const bool do_sem = p.with_semantics && ((p.sem_mode == 1) ? (object_id >= 0 && f.obj != nullptr) : (f.has_label != 0));
+    const bool vec_lik = do_sem && (p.K & 3) == 0 && p.K <= 32;
+    uint32_t c4[4] = {0u, 0u, 0u, 0u};
+    float w_new = 0.f;
+    uint32_t co = 0u;
+    if (f.has_color) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) c4[k] = f.rgba[px4[k]];
+      w_new = m.weight[slot * NV + lin];  // voxel weight after the k_tsdf_update pass
+      co = m.color[slot * NV + lin];
+    }
+    int label = -1;
+    uint8_t fl = 0;
+    float4 l4[8];
+    uint8_t* vfl = m.vflags + slot * NV;
+    // likelihoods are voxel-major: lik[slot][voxel][K] -> one contiguous K*4-byte run per record
+    float* __restrict__ lik = m.lik + (slot * NV + lin) * static_cast<size_t>(p.K);
+    float4* __restrict__ lik4 = reinterpret_cast<float4*>(lik);
+    if (do_sem) {
+      label = (p.sem_mode == 1) ? ((f.obj[best_px] == object_id) ? 1 : 0) : f.label[best_px];
+      fl = vfl[lin];
+      if (vec_lik) {  // a voxel without VOX_SEM_VALID holds no likelihoods yet: what is loaded is replaced by zeros below
+#pragma unroll
+        for (int j = 0; j < 8; ++j) l4[j] = (4 * j < p.K) ? lik4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
     if (f.has_color) {
       float a[3] = {0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const uint32_t c = f.rgba[px4[k]];
+        const uint32_t c = c4[k];
         a[0] = a[0] + w4[k] * static_cast<float>(c & 0xffu);
         a[1] = a[1] + w4[k] * static_cast<float>((c >> 8) & 0xffu);
         a[2] = a[2] + w4[k] * static_cast<float>((c >> 16) & 0xffu);
       }
-      const float w_new = m.weight[slot * NV + lin];  // voxel weight after the k_tsdf_update pass
-      const uint32_t co = m.color[slot * NV + lin];
       const float tot = w_new + w;
       uint32_t out = 0xff000000u;
 #pragma unroll
@@ -741,52 +877,31 @@ __global__ __launch_bounds__(256) void k_band_update(DevMap m, DevParams p, DevF
       }
       m.color[slot * NV + lin] = out;
     }
-    int label = -1;
-    bool have_label = false;
-    if (p.sem_mode == 1) {
-      if (object_id >= 0 && f.obj) {
-        label = (f.obj[best_px] == object_id) ? 1 : 0;
-        have_label = true;
-      }
-    } else if (f.has_label) {
-      label = f.label[best_px];
-      have_label = true;
-    }
-    if (p.with_semantics && have_label && label >= 0 && label < p.K) {
-      uint8_t* vfl = m.vflags + slot * NV;
-      // likelihoods are voxel-major: lik[slot][voxel][K] -> one contiguous K*4-byte run per record
-      float* __restrict__ lik = m.lik + (slot * NV + lin) * static_cast<size_t>(p.K);
-      const uint8_t fl = vfl[lin];
+    if (do_sem && label >= 0 && label < p.K) {
       const bool empty = !(fl & VOX_SEM_VALID);
       int bestk = 0;
       float bestv = 0.f;
-      if ((p.K & 3) == 0) {
-        // 16-byte loads / stores, 4 labels at a time, up to 8 vectors (32 labels) in flight
-        float4* __restrict__ lik4 = reinterpret_cast<float4*>(lik);
-        for (int k0 = 0; k0 < p.K; k0 += 32) {
-          float4 l4[8];
+      if (vec_lik) {
+        // 16-byte loads / stores, 4 labels at a time, up to 8 vectors (32 labels)
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            l4[j] = (!empty && k0 + 4 * j < p.K) ? lik4[(k0 >> 2) + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < 8; ++j) {
+          if (4 * j >= p.K) continue;
+          float l[4] = {l4[j].x, l4[j].y, l4[j].z, l4[j].w};
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if (k0 + 4 * j >= p.K) continue;
-            float l[4] = {l4[j].x, l4[j].y, l4[j].z, l4[j].w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int k = k0 + 4 * j + q;
-              if (p.sem_mode == 1) {
-                if (k == label) l[q] += 1.f;
-              } else {
-                l[q] += (k == label) ? p.log_match : p.log_nomatch;
-              }
-              if (k == 0 || l[q] > bestv) {
-                bestv = l[q];
-                bestk = k;
-              }
+          for (int q = 0; q < 4; ++q) {
+            const int k = 4 * j + q;
+            if (empty) l[q] = 0.f;
+            if (p.sem_mode == 1) {
+              if (k == label) l[q] += 1.f;
+            } else {
+              l[q] += (k == label) ? p.log_match : p.log_nomatch;
             }
-            lik4[(k0 >> 2) + j] = make_float4(l[0], l[1], l[2], l[3]);
+            if (k == 0 || l[q] > bestv) {
+              bestv = l[q];
+              bestk = k;
+            }
           }
+          lik4[j] = make_float4(l[0], l[1], l[2], l[3]);
         }
       } else {
         for (int k0 = 0; k0 < p.K; k0 += 8) {

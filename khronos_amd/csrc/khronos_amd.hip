@@ -65,6 +65,7 @@ struct FrameSlot {
   khr_sensor sensor{};
   khr_frame meta{};
   bool valid = false, has_color = false, has_label = false, has_obj = false, objects_done = false;
+  bool dyn_clean = false;  // the dynamic image is all zero (fresh from ingest, nothing painted yet)
   std::vector<khr_cluster> sem_clusters;  // semantic clusters of the frame in this slot (khr_detect_objects)
   std::vector<khr_cluster> clusters;  // dynamic clusters of the frame in this slot (ids, listed pixel counts)
 };
@@ -98,6 +99,21 @@ struct khr_ctx {
   uint32_t* d_ef = nullptr;
   uint32_t* d_trk_proc = nullptr;
   uint32_t* d_work_tsdf = nullptr;
+  // tick path (khr_tick_*): per-camera work lists [kMaxTick][capacity], {visible, non-culled} counts, seed counts,
+  // second record-cursor set, pinned result block (kMaxTick counts + ticket)
+  uint32_t* d_tick_work = nullptr;
+  uint32_t* d_tick_tsdf = nullptr;
+  uint32_t* d_tick_counts = nullptr;
+  uint32_t* d_tick_seeds = nullptr;
+  uint32_t* d_band_count2 = nullptr;
+  uint32_t* h_tick = nullptr;
+  uint32_t* d_tick_host = nullptr;
+  uint32_t tick_ticket = 0;
+  std::vector<uint32_t> tick_seed_host;  // seed counts of the latest khr_tick_ingest (collected lazily)
+  int tick_seed_n = 0, tick_seed_collected = 0;
+  // between the allocation and the update phase of a tick: the epoch the tick's new blocks carry (the motion detector
+  // must not see them: in reference order it runs before the frames are integrated); 0 otherwise
+  int tick_epoch = 0, motion_ignore_epoch = 0;
   BandRec* d_band = nullptr;
   uint32_t band_cap = 0;
   uint32_t* d_band_count = nullptr;
@@ -105,6 +121,7 @@ struct khr_ctx {
   uint32_t* d_wg_stats = nullptr;
   // remote halo (multi-GPU): records gathered from the other ranks + their index
   uint64_t* d_halo_recs = nullptr;
+  const uint64_t* halo_view = nullptr;  // records in use: d_halo_recs, or the caller's device buffer (imported in place)
   uint64_t* d_halo_keys = nullptr;
   uint32_t* d_halo_vals = nullptr;
   uint32_t halo_cap_total = 0, halo_mask = 0, halo_n = 0;
@@ -405,7 +422,7 @@ int dispatchVps(khr_ctx* c, F&& f) {
 }
 
 int kTsdfGrid = 4096;   // persistent grid: 256 CUs x 4 resident workgroups (LDS-limited)
-int kTsdfChunks = 4;
+int kTsdfChunks = 0;    // 0 = by world size (4 / 8 / 16 z-slabs per block); env KHR_TSDF_CHUNKS
 constexpr int kStreamGrid = 4096;
 constexpr int kBandGrid = 2048;
 
@@ -751,6 +768,7 @@ void khr_destroy(khr_ctx* c) {
   if (c->d_halo_recs) { hipFree(c->d_halo_recs); hipFree(c->d_halo_keys); hipFree(c->d_halo_vals); }
   if (c->d_mh_recs) { hipFree(c->d_mh_recs); hipFree(c->d_mh_keys); hipFree(c->d_mh_vals); }
   if (c->h_pinned) hipHostFree(c->h_pinned);
+  if (c->h_tick) hipHostFree(c->h_tick);
   if (c->h_obj_head) hipHostFree(c->h_obj_head);
   if (c->h_md_acc_pinned) hipHostFree(c->h_md_acc_pinned);
   if (c->ev_obj) hipEventDestroy(c->ev_obj);
@@ -786,6 +804,19 @@ int khr_sync(khr_ctx* c) {
   return KHR_OK;
 }
 
+// next slot of the frame ring that nobody holds
+static int acquireSlot(khr_ctx* c) {
+  const int n_slots = static_cast<int>(c->slots.size());
+  int slot = -1;
+  for (int k = 0; k < n_slots && slot < 0; ++k) {
+    const int cand = (c->next_slot + k) % n_slots;
+    if (c->slot_leases[cand].load(std::memory_order_acquire) == 0) slot = cand;
+  }
+  if (slot < 0) return fail(KHR_ENOMEM, "all %d frame slots are retained (raise num_frame_slots)", n_slots);
+  c->next_slot = (slot + 1) % n_slots;
+  return slot;
+}
+
 int khr_upload_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame, int on_device) {
   if (!c || !sensor || !frame || !frame->depth) return fail(KHR_EINVAL, "null argument");
   const size_t n = static_cast<size_t>(sensor->width) * sensor->height;
@@ -796,14 +827,8 @@ int khr_upload_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fram
   HIP_TRY(hipSetDevice(c->device));
   // next slot of the ring that nobody holds (khr_retain_slot): buffered frames and frames a detached extraction still reads
   // stay intact however far the stream has advanced
-  const int n_slots = static_cast<int>(c->slots.size());
-  int slot = -1;
-  for (int k = 0; k < n_slots && slot < 0; ++k) {
-    const int cand = (c->next_slot + k) % n_slots;
-    if (c->slot_leases[cand].load(std::memory_order_acquire) == 0) slot = cand;
-  }
-  if (slot < 0) return fail(KHR_ENOMEM, "all %d frame slots are retained (raise num_frame_slots)", n_slots);
-  c->next_slot = (slot + 1) % n_slots;
+  const int slot = acquireSlot(c);
+  if (slot < 0) return slot;
   FrameSlot& s = c->slots[slot];
   const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   s.sensor = *sensor;
@@ -843,6 +868,7 @@ int khr_upload_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fram
   c->begin_in_ingest = false;
   if (!on_device) HIP_TRY(hipStreamSynchronize(c->stream));  // caller buffers may be reused after return
   s.valid = true;
+  s.dyn_clean = true;
   return slot;
 }
 
@@ -858,6 +884,7 @@ int khr_set_frame_image(khr_ctx* c, int slot, int which, const int32_t* image, i
     HIP_TRY(hipMemsetAsync(dst, 0, n * sizeof(int32_t), c->stream));
   }
   if (which == 1) s.has_obj = image != nullptr;
+  if (which == 0) s.dyn_clean = image == nullptr;
   return KHR_OK;
 }
 
@@ -905,7 +932,7 @@ static int integrateAlloc(khr_ctx* c, FrameSlot& s, const DevFrame& f, int alloc
     const int S = 2 * fr.n_steps + 1;
     const size_t total = static_cast<size_t>(S) * S * S;
     hipLaunchKernelGGL(k_alloc_visible, dim3(gridFor(total)), dim3(256), 0, c->stream, m, c->p, f, fr, c->d_work, c->d_new,
-                       c->d_pinned + 2, c->seed_publish_pending ? c->seed_ticket : 0u);
+                       c->d_pinned + 2, c->seed_publish_pending ? c->seed_ticket : 0u, &m.counters[C_N_VISIBLE], 0);
     c->seed_publish_pending = false;
     hipLaunchKernelGGL(k_init_blocks, dim3(2048), dim3(256), 0, c->stream, m, c->p, c->d_new);
     hipLaunchKernelGGL(k_cull_blocks, dim3(1024), dim3(256), 0, c->stream, m, c->p, f, c->d_work, c->d_work_tsdf,
@@ -920,12 +947,27 @@ static int integrateAlloc(khr_ctx* c, FrameSlot& s, const DevFrame& f, int alloc
 }
 
 // TSDF + band update kernels of one integrate call
+// tick path: the camera's own work list and the alternating record-cursor set
+struct UpdateLists {
+  const uint32_t* tsdf_work = nullptr;
+  const uint32_t* tsdf_count = nullptr;
+  uint32_t* band_count = nullptr;
+  uint32_t* band_count_next = nullptr;
+};
 static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allocate_blocks, int use_mask,
-                           int object_id) {
+                           int object_id, const UpdateLists* lists = nullptr) {
   DevMap& m = c->m;
   (void)s;
   const uint32_t* tsdf_work = allocate_blocks ? c->d_work_tsdf : c->d_work;
   const uint32_t* tsdf_count = allocate_blocks ? &m.counters[C_N_TSDF] : &m.counters[C_N_VISIBLE];
+  uint32_t* band_count = c->d_band_count;
+  uint32_t* band_count_next = nullptr;
+  if (lists) {
+    tsdf_work = lists->tsdf_work;
+    tsdf_count = lists->tsdf_count;
+    band_count = lists->band_count;
+    band_count_next = lists->band_count_next;
+  }
   int rc = dispatchVps(c, [&](auto vps) {
     constexpr int V = decltype(vps)::value;
     {
@@ -947,23 +989,29 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
         constexpr int CH = decltype(chunks)::value;
         if (fast)
           KHR_LAUNCH_TIMED(0, (k_tsdf_update<V, CH, true>), dim3(kTsdfGrid), dim3(256), a, tsdf_work, tsdf_count, c->d_band,
-                           c->band_cap / kBandShards, c->d_band_count);
+                           c->band_cap / kBandShards, band_count);
         else
           KHR_LAUNCH_TIMED(0, (k_tsdf_update<V, CH, false>), dim3(kTsdfGrid), dim3(256), a, tsdf_work, tsdf_count, c->d_band,
-                           c->band_cap / kBandShards, c->d_band_count);
+                           c->band_cap / kBandShards, band_count);
       };
       if (V == 8) {
         launch(std::integral_constant<int, 1>());
       } else {
-        switch (kTsdfChunks) {
+        // a shard of a sharded map sees 1 / world of every frame's blocks: smaller z-slabs keep the work-item count
+        // (and with it the number of busy CUs) up and the per-item latency chain short
+        int chunks = kTsdfChunks;
+        if (chunks == 0) chunks = c->cfg.world_size >= 4 ? 16 : (c->cfg.world_size >= 2 ? 8 : 4);
+        switch (chunks) {
           case 1: launch(std::integral_constant<int, 1>()); break;
           case 2: launch(std::integral_constant<int, 2>()); break;
+          case 8: launch(std::integral_constant<int, (V == 16 ? 8 : 1)>()); break;
+          case 16: launch(std::integral_constant<int, (V == 16 ? 16 : 1)>()); break;
           default: launch(std::integral_constant<int, (V == 16 ? 4 : 1)>()); break;
         }
       }
     }
     KHR_LAUNCH_TIMED(7, (k_band_update<V>), dim3(kBandGrid / kBandShards, kBandShards), dim3(256), m, c->p, f, c->d_band,
-                     c->band_cap / kBandShards, c->d_band_count, object_id, c->d_wg_stats, kTsdfGrid);
+                     c->band_cap / kBandShards, band_count, object_id, c->d_wg_stats, kTsdfGrid, band_count_next);
     return KHR_OK;
   });
   if (rc) return rc;
@@ -1037,7 +1085,7 @@ static int trackingPhase(khr_ctx* c, uint64_t stamp, int phase) {
       ScopedTimer tm(c, 2);
       RemoteHalo rh{};
       if (c->halo_n) {
-        rh.recs = c->d_halo_recs;
+        rh.recs = c->halo_view;
         rh.ht_keys = c->d_halo_keys;
         rh.ht_vals = c->d_halo_vals;
         rh.ht_mask = c->halo_mask;
@@ -1062,6 +1110,191 @@ int khr_update_tracking_phase(khr_ctx* c, uint64_t stamp, int phase) {
   if (!c->cfg.with_tracking) return KHR_OK;
   HIP_TRY(hipSetDevice(c->device));
   return trackingPhase(c, stamp, phase);
+}
+
+// ---------------------------------------------------------------------------------------------
+// tick path: the camera frames of one tick batched (sharded multi-camera runs).  Every rank of a
+// sharded run sees every camera, so what a rank does PER CAMERA is the part that does not shrink with the number of
+// ranks: one ingest launch for all cameras with the motion detector's seed test folded in, one host wait per tick,
+// allocation per camera but ONE block initialisation and ONE culling launch, then the update kernels per camera.
+// ---------------------------------------------------------------------------------------------
+// spin on a word of pinned memory a one-workgroup publish kernel writes (the stream keeps running)
+static int waitWord(khr_ctx* c, volatile uint32_t* w, uint32_t ticket, const char* what) {
+  uint64_t spins = 0;
+  while (*w != ticket) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xffffu) == 0) {
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) return fail(KHR_EDEVICE, "stream failed while waiting for %s: %s", what, hipGetErrorString(q));
+      if (q == hipSuccess && *w != ticket) return fail(KHR_EDEVICE, "%s was never published", what);
+    }
+  }
+  return KHR_OK;
+}
+
+static int ensureTick(khr_ctx* c) {
+  if (c->d_tick_work) return KHR_OK;
+  const size_t cap = c->m.capacity;
+  int rc = devAlloc(c, &c->d_tick_work, cap * kMaxTick, false);
+  if (!rc) rc = devAlloc(c, &c->d_tick_tsdf, cap * kMaxTick, false);
+  if (!rc) rc = devAlloc(c, &c->d_tick_counts, 2 * kMaxTick + 32);
+  if (!rc) rc = devAlloc(c, &c->d_tick_seeds, kMaxTick + 32);
+  if (!rc) rc = devAlloc(c, &c->d_band_count2, kBandShards * 32);
+  if (rc) return rc;
+  if (hipHostMalloc(reinterpret_cast<void**>(&c->h_tick), 256, hipHostMallocDefault) != hipSuccess)
+    return fail(KHR_ENOMEM, "pinned tick block");
+  std::memset(c->h_tick, 0, 256);
+  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_tick_host), c->h_tick, 0));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the zero-fills above
+  return KHR_OK;
+}
+
+int khr_tick_ingest(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frames, int n_frames, int count_seeds,
+                    int* slots_out, uint32_t* n_seed_pixels, int64_t* seed_counts_device) {
+  if (!c || !sensor || !frames || !slots_out || n_frames < 1) return fail(KHR_EINVAL, "bad argument");
+  const size_t n = static_cast<size_t>(sensor->width) * sensor->height;
+  if (sensor->width < 2 || sensor->height < 2 || n > c->cfg.max_frame_pixels)
+    return fail(KHR_EINVAL, "frame %dx%d exceeds max_frame_pixels=%u", sensor->width, sensor->height, c->cfg.max_frame_pixels);
+  if (!(sensor->fx > 0.f) || !(sensor->fy > 0.f) || !(sensor->max_range > sensor->min_range))
+    return fail(KHR_EINVAL, "bad intrinsics / range");
+  if (static_cast<size_t>(n_frames) > c->slots.size()) return fail(KHR_EINVAL, "more frames than frame slots (num_frame_slots)");
+  for (int i = 0; i < n_frames; ++i)
+    if (!frames[i].depth) return fail(KHR_EINVAL, "frame %d has no depth image", i);
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = ensureTick(c);
+  if (rc) return rc;
+  count_seeds = count_seeds && c->cfg.with_tracking;
+  c->tick_seed_host.assign(n_frames, 0u);
+  c->tick_seed_collected = 0;
+  const int tw = (sensor->width + kTile - 1) / kTile, th = (sensor->height + kTile - 1) / kTile;
+  ScopedTimer tm(c, 6);
+  for (int base = 0; base < n_frames; base += kMaxTick) {
+    const int nb = std::min(kMaxTick, n_frames - base);
+    TickIngest t{};
+    for (int k = 0; k < nb; ++k) {
+      const khr_frame& fr = frames[base + k];
+      const int slot = acquireSlot(c);
+      if (slot < 0) return slot;
+      FrameSlot& s = c->slots[slot];
+      s.sensor = *sensor;
+      s.meta = fr;
+      s.meta.depth = nullptr;
+      s.meta.color = nullptr;
+      s.meta.label = nullptr;
+      s.has_color = fr.color != nullptr;
+      s.has_label = fr.label != nullptr;
+      s.has_obj = false;
+      s.objects_done = false;
+      s.clusters.clear();
+      s.sem_clusters.clear();
+      s.tw = tw;
+      s.th = th;
+      s.valid = true;
+      s.dyn_clean = true;
+      slots_out[base + k] = slot;
+      t.depth_in[k] = fr.depth; t.rgb_in[k] = fr.color; t.label_in[k] = fr.label;
+      t.depth[k] = s.depth; t.range[k] = s.range; t.rgba[k] = s.rgba; t.label[k] = s.label; t.dyn[k] = s.dyn;
+      t.tile_max[k] = s.tile_max;
+      float R[9], tt[3];
+      makePose(fr.world_T_sensor, R, tt, t.Rw[k], t.tw[k]);
+      t.min_z_world[k] = static_cast<float>(fr.world_T_sensor[11] + static_cast<double>(c->cfg.md_min_z_coordinate));
+    }
+    hipLaunchKernelGGL(k_tick_ingest, dim3(tw * th, nb), dim3(256), 0, c->stream, t, tw, sensor->width, sensor->height, sensor->fx,
+                       sensor->fy, sensor->cx, sensor->cy, c->p.range_mode, c->m, c->p, c->cfg.md_max_range, count_seeds ? 1 : 0,
+                       c->d_tick_seeds);
+    if (count_seeds) {
+      ++c->tick_ticket;
+      if (c->tick_ticket == 0) ++c->tick_ticket;
+      hipLaunchKernelGGL(k_tick_publish, dim3(1), dim3(64), 0, c->stream, c->d_tick_seeds, nb,
+                         c->d_tick_host, c->d_tick_host + 32, c->tick_ticket,
+                         seed_counts_device ? reinterpret_cast<long long*>(seed_counts_device) + base : nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    // one result block: a tick of one batch may be collected later (khr_tick_seed_counts), more batches are collected
+    // as they go
+    if (count_seeds && (n_seed_pixels || n_frames > kMaxTick)) {
+      rc = waitWord(c, &c->h_tick[32], c->tick_ticket, "tick seed counts");
+      if (rc) return rc;
+      for (int k = 0; k < nb; ++k) c->tick_seed_host[base + k] = c->h_tick[k];
+      c->tick_seed_collected = base + nb;
+    }
+  }
+  c->tick_seed_n = count_seeds ? n_frames : 0;
+  if (count_seeds && n_seed_pixels) std::memcpy(n_seed_pixels, c->tick_seed_host.data(), sizeof(uint32_t) * n_frames);
+  if (!count_seeds && n_seed_pixels) std::memset(n_seed_pixels, 0, sizeof(uint32_t) * n_frames);
+  if (!count_seeds && seed_counts_device) HIP_TRY(hipMemsetAsync(seed_counts_device, 0, sizeof(int64_t) * n_frames, c->stream));
+  c->begun = false;
+  c->begin_in_ingest = false;
+  return KHR_OK;
+}
+
+int khr_tick_seed_counts(khr_ctx* c, uint32_t* n_seed_pixels, int n_frames) {
+  if (!c || !n_seed_pixels || n_frames < 0) return fail(KHR_EINVAL, "bad argument");
+  if (n_frames > static_cast<int>(c->tick_seed_host.size())) return fail(KHR_ESTATE, "no khr_tick_ingest of that many frames");
+  if (c->tick_seed_n && c->tick_seed_collected < c->tick_seed_n) {  // the last batch's block has not been read yet
+    const int rc = waitWord(c, &c->h_tick[32], c->tick_ticket, "tick seed counts");
+    if (rc) return rc;
+    for (int k = 0; k < c->tick_seed_n; ++k) c->tick_seed_host[k] = c->h_tick[k];
+    c->tick_seed_collected = c->tick_seed_n;
+  }
+  std::memcpy(n_seed_pixels, c->tick_seed_host.data(), sizeof(uint32_t) * n_frames);
+  return KHR_OK;
+}
+
+int khr_tick_integrate(khr_ctx* c, const int* slots, int n_frames, int use_mask, int object_id, int phases) {
+  if (!c || !slots || n_frames < 1 || (phases & 3) == 0) return fail(KHR_EINVAL, "bad argument");
+  if ((phases & 3) != 3 && n_frames > kMaxTick) return fail(KHR_EINVAL, "split phases take at most %d frames", kMaxTick);
+  for (int i = 0; i < n_frames; ++i)
+    if (slots[i] < 0 || slots[i] >= static_cast<int>(c->slots.size()) || !c->slots[slots[i]].valid) return fail(KHR_EINVAL, "bad slot");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = ensureTick(c);
+  if (rc) return rc;
+  DevMap& m = c->m;
+  const uint32_t cap = m.capacity;
+  for (int base = 0; base < n_frames; base += kMaxTick) {
+    const int nb = std::min(kMaxTick, n_frames - base);
+    TickFrames t{};
+    for (int k = 0; k < nb; ++k) {
+      FrameSlot& s = c->slots[slots[base + k]];
+      t.f[k] = makeDevFrame(c, s);
+      t.tile_max[k] = s.tile_max;
+    }
+    if (phases & 1) {
+      if (++c->tick_epoch <= 0) c->tick_epoch = 1;
+      c->motion_ignore_epoch = c->tick_epoch;
+      if (std::getenv("KHR_DEBUG_TICK_NO_EPOCH")) c->motion_ignore_epoch = 0;  // test hook: shows that the epoch matters
+      hipLaunchKernelGGL(k_tick_begin, dim3(1), dim3(64), 0, c->stream, m, c->p.nvox, c->d_band_count, c->d_band_count2,
+                         c->d_tick_counts, static_cast<uint32_t>(nb - 1));
+      c->begun = false;
+      ScopedTimer tm(c, 3);
+      for (int k = 0; k < nb; ++k) {
+        const DevFrustum fr = makeFrustum(c, t.f[k]);
+        const int S = 2 * fr.n_steps + 1;
+        const size_t total = static_cast<size_t>(S) * S * S;
+        hipLaunchKernelGGL(k_alloc_visible, dim3(gridFor(total)), dim3(256), 0, c->stream, m, c->p, t.f[k], fr,
+                           c->d_tick_work + static_cast<size_t>(k) * cap, c->d_new, c->d_pinned + 2, 0u, &c->d_tick_counts[2 * k],
+                           c->motion_ignore_epoch);
+      }
+      hipLaunchKernelGGL(k_init_blocks, dim3(2048), dim3(256), 0, c->stream, m, c->p, c->d_new);
+      const FrameSlot& s0 = c->slots[slots[base]];
+      hipLaunchKernelGGL(k_tick_cull, dim3(256, nb), dim3(256), 0, c->stream, m, c->p, t, c->d_tick_work, c->d_tick_tsdf, cap,
+                         c->d_tick_counts, c->cfg.disable_culling ? 0 : 1, s0.tw, s0.th);
+      c->host_index_valid = false;
+      HIP_TRY(hipGetLastError());
+    }
+    for (int k = 0; k < nb && (phases & 2); ++k) {
+      FrameSlot& s = c->slots[slots[base + k]];
+      UpdateLists lists;
+      lists.tsdf_work = c->d_tick_tsdf + static_cast<size_t>(k) * cap;
+      lists.tsdf_count = &c->d_tick_counts[2 * k + 1];
+      lists.band_count = (k & 1) ? c->d_band_count2 : c->d_band_count;
+      lists.band_count_next = (k & 1) ? c->d_band_count : c->d_band_count2;
+      rc = integrateUpdate(c, s, t.f[k], 1, use_mask, object_id, &lists);
+      if (rc) return rc;
+    }
+    if (phases & 2) c->motion_ignore_epoch = 0;
+  }
+  return KHR_OK;
 }
 
 int khr_export_halo(khr_ctx* c, void* records, int64_t cap_records, int on_device) {
@@ -1110,10 +1343,17 @@ int khr_import_halo(khr_ctx* c, const void* records, int64_t n_records, int on_d
     c->halo_cap_total = static_cast<uint32_t>(n_records);
     c->halo_mask = ht - 1;
   }
-  HIP_TRY(hipMemcpyAsync(c->d_halo_recs, records, static_cast<size_t>(n_records) * kHaloRecWords * sizeof(uint64_t),
-                         on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+  // device records are used where they lie (the caller keeps the buffer until the next khr_update_tracking_phase(.., 2)
+  // has been queued: stream order does the rest); host records are staged
+  if (on_device) {
+    c->halo_view = static_cast<const uint64_t*>(records);
+  } else {
+    HIP_TRY(hipMemcpyAsync(c->d_halo_recs, records, static_cast<size_t>(n_records) * kHaloRecWords * sizeof(uint64_t),
+                           hipMemcpyHostToDevice, c->stream));
+    c->halo_view = c->d_halo_recs;
+  }
   HIP_TRY(hipMemsetAsync(c->d_halo_keys, 0xff, sizeof(uint64_t) * (static_cast<size_t>(c->halo_mask) + 1), c->stream));
-  hipLaunchKernelGGL(k_import_halo, dim3(gridFor(n_records)), dim3(256), 0, c->stream, c->d_halo_recs,
+  hipLaunchKernelGGL(k_import_halo, dim3(gridFor(n_records)), dim3(256), 0, c->stream, c->halo_view,
                      static_cast<uint32_t>(n_records), c->cfg.rank, c->cfg.world_size, c->d_halo_keys, c->d_halo_vals, c->halo_mask);
   HIP_TRY(hipGetLastError());
   if (!on_device) HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1129,7 +1369,7 @@ int khr_import_halo(khr_ctx* c, const void* records, int64_t n_records, int on_d
 static int motionLaunch(khr_ctx* c, FrameSlot& s, bool fresh_slot) {
   const size_t n = static_cast<size_t>(s.sensor.width) * s.sensor.height;
   if (!fresh_slot) {  // a slot that was just ingested already has a zero dynamic image and seed counter
-    HIP_TRY(hipMemsetAsync(s.dyn, 0, n * sizeof(int32_t), c->stream));
+    if (!s.dyn_clean) HIP_TRY(hipMemsetAsync(s.dyn, 0, n * sizeof(int32_t), c->stream));
     HIP_TRY(hipMemsetAsync(&c->m.counters[C_N_SEEDS], 0, sizeof(uint32_t), c->stream));
   }
   c->stats.n_seeds = 0;
@@ -1145,7 +1385,7 @@ static int motionLaunch(khr_ctx* c, FrameSlot& s, bool fresh_slot) {
     ++c->seed_ticket;
     if (c->seed_ticket == 0) ++c->seed_ticket;
     hipLaunchKernelGGL(k_motion_pixels, dim3(gridFor(n)), dim3(256), 0, c->stream, m, c->p, f, c->cfg.md_max_range,
-                       min_z_world, c->d_keys);
+                       min_z_world, c->d_keys, c->motion_ignore_epoch);
   }
   HIP_TRY(hipGetLastError());
   c->seed_by_ticket = true;
@@ -1226,6 +1466,7 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
   lap("wait seed count");
   s.clusters.clear();
   if (c->h_pinned[0] == 0) return 0;
+  s.dyn_clean = false;  // clusters may be painted from here on
 
   // ---- device: seed / boundary voxel tables, compact lists, seed adjacency ------------------------
   const int nn = c->cfg.md_neighbor_connectivity;
@@ -1321,6 +1562,7 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
                          c->d_md_rootidx, c->d_md_comp_final, c->d_md_seed_final, c->d_md_bnd_final);
       hipLaunchKernelGGL(k_md_paint, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds, bnd, c->d_md_seed_final,
                          c->d_md_bnd_final, s.dyn);
+      s.dyn_clean = false;
       HIP_TRY(hipGetLastError());
       {
         const int rcs = clusterSummaryLaunch(c, s, kept.back().first);
@@ -1486,6 +1728,7 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
     if (B) HIP_TRY(hipMemcpyAsync(c->d_md_bnd_final, bnd_final.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_md_paint, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds, bnd, c->d_md_seed_final,
                        c->d_md_bnd_final, s.dyn);
+    s.dyn_clean = false;
     HIP_TRY(hipGetLastError());
     {
       const int rcs = clusterSummaryLaunch(c, s, kept.back().first);
@@ -1547,7 +1790,8 @@ int khr_detect_motion_from_keys(khr_ctx* c, int slot, const void* keys, int on_d
     HIP_TRY(hipMemcpyAsync(holder.p, keys, sizeof(uint64_t) * n, hipMemcpyHostToDevice, c->stream));
     src = holder.as<uint64_t>();
   }
-  HIP_TRY(hipMemsetAsync(s.dyn, 0, sizeof(int32_t) * n, c->stream));
+  if (!s.dyn_clean) HIP_TRY(hipMemsetAsync(s.dyn, 0, sizeof(int32_t) * n, c->stream));
+  s.dyn_clean = true;
   HIP_TRY(hipMemsetAsync(&c->m.counters[C_N_SEEDS], 0, sizeof(uint32_t), c->stream));
   hipLaunchKernelGGL(k_md_keys_import, dim3(gridFor(n)), dim3(256), 0, c->stream, src, n, c->d_keys, &c->m.counters[C_N_SEEDS]);
   HIP_TRY(hipMemcpyAsync(&c->h_pinned[0], &c->m.counters[C_N_SEEDS], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));

@@ -31,6 +31,24 @@ class HipShard:
         """depth / rgb / label: device tensors.  Returns the frame slot."""
         return self.ctx.upload_frame_device(self.sensor, stamp, pose, depth.data_ptr(), rgb.data_ptr(), label.data_ptr())
 
+    # -- the cameras of a tick batched (khr_tick_ingest / khr_tick_integrate) --
+    MAX_SPLIT = 8  # frames per split-phase call (khronos_amd.h)
+
+    def tick_ingest(self, stamp, cameras, count_seeds, wait=True):
+        """wait=False: nothing blocks; the counts land in self.seed_counts_dev (device int64) and tick_seed_counts()."""
+        frames = [self.ctx.make_frame(stamp, pose, depth.data_ptr(), rgb.data_ptr(), label.data_ptr())
+                  for (pose, depth, rgb, label) in cameras]
+        if getattr(self, "seed_counts_dev", None) is None or self.seed_counts_dev.numel() != len(frames):
+            self.seed_counts_dev = torch.zeros(len(frames), dtype=torch.int64, device=self.device)
+        return self.ctx.tick_ingest(self.sensor, frames, count_seeds=count_seeds, want_counts=count_seeds and wait,
+                                    counts_device_ptr=self.seed_counts_dev.data_ptr())
+
+    def tick_seed_counts(self, n):
+        return self.ctx.tick_seed_counts(n)
+
+    def tick_integrate(self, slots, use_mask, phases=3):
+        self.ctx.tick_integrate(slots, use_mask=use_mask, phases=phases)
+
     def motion_keys(self, cam, slot):
         _, n_seed = self.ctx.motion_keys(slot, device_ptr=self.keys[cam].data_ptr())
         return self.keys[cam], n_seed
@@ -100,25 +118,52 @@ class ShardedFusion:
 
     def tick(self, stamp, cameras):
         """cameras: list of (pose, depth, rgb, label) for ALL cameras of the rig (already gathered)."""
-        slots = [self.shard.upload(ci, stamp, pose, depth, rgb, label) for ci, (pose, depth, rgb, label) in enumerate(cameras)]
+        batched = hasattr(self.shard, "tick_ingest")  # HipShard: per-camera launches folded together
+        split = batched and len(cameras) <= self.shard.MAX_SPLIT
         self.clusters_last_tick = [0] * len(cameras)
+        counts = None
+        if batched:
+            # nothing waits here: allocation / culling (independent of the motion masks) is queued behind the ingest, so the
+            # device has work while the host collects and exchanges the seed counts
+            slots, counts = self.shard.tick_ingest(stamp, cameras, self.motion, wait=not split)
+            if split:
+                self.shard.tick_integrate(slots, use_mask=self.motion, phases=1)
+        else:
+            slots = [self.shard.upload(ci, stamp, pose, depth, rgb, label) for ci, (pose, depth, rgb, label) in enumerate(cameras)]
         if self.motion:
-            keys, counts = [], []
+            keys = [None] * len(cameras)
+            if not batched:
+                counts = []
+                for ci, slot in enumerate(slots):
+                    keys[ci], n = self.shard.motion_keys(ci, slot)
+                    counts.append(n)
+            exchange = self.dist is not None and self.world > 1
+            if exchange and split and self.count_device != "cpu":
+                cnt = self.shard.seed_counts_dev  # written by the ingest's publish kernel: no host -> device copy
+                self.dist.all_reduce(cnt)
+                cnt = cnt.tolist()
+            else:
+                if split:
+                    counts = self.shard.tick_seed_counts(len(cameras))
+                if exchange:
+                    cnt = torch.tensor(counts, dtype=torch.int64, device=self.count_device)
+                    self.dist.all_reduce(cnt)  # which cameras have seeds anywhere
+                    cnt = cnt.tolist()
+                else:
+                    cnt = list(counts)
             for ci, slot in enumerate(slots):
-                k, n = self.shard.motion_keys(ci, slot)
-                keys.append(k)
-                counts.append(n)
-            cnt = torch.tensor(counts, dtype=torch.int64, device=self.count_device)
-            if self.dist is not None and self.world > 1:
-                self.dist.all_reduce(cnt)  # which cameras have seeds anywhere
-            for ci, slot in enumerate(slots):
-                if int(cnt[ci]) == 0:
+                if cnt[ci] == 0:
                     continue  # no seeds on any rank => no clusters, empty dynamic image
-                if self.dist is not None and self.world > 1:
+                if keys[ci] is None:  # batched ingest only counted: the voxel keys are produced when somebody has seeds
+                    keys[ci], _ = self.shard.motion_keys(ci, slot)
+                if exchange:
                     self.dist.all_reduce(keys[ci])  # exactly one non-zero contribution per pixel
                 self.clusters_last_tick[ci] = self.shard.motion_finish(ci, slot, keys[ci])
-        for ci, slot in enumerate(slots):
-            self.shard.integrate(ci, slot, use_mask=self.motion)
+        if batched:
+            self.shard.tick_integrate(slots, use_mask=self.motion, phases=2 if split else 3)
+        else:
+            for ci, slot in enumerate(slots):
+                self.shard.integrate(ci, slot, use_mask=self.motion)
         self.shard.tracking_phase(stamp, 1)
         if self.world > 1:
             self.shard.import_halo(self.all_gather(self.shard.export_halo(stamp)))

@@ -73,3 +73,28 @@ def compare_maps(ctx, ora, max_blocks=None, rng=None, check_lik=True):
     assert worst["lik"] <= TOL * 10, worst  # log-likelihood sums grow with observations
     assert worst["color"] <= 1, worst
     return worst, len(gi)
+
+
+class DeviceArray:
+    """a numpy array copied to HBM through the HIP runtime the library itself is linked against (ctypes); for tests of the
+    device-pointer entry points that must not pull a second HIP runtime (torch's) into the process."""
+    _hip = None
+
+    def __init__(self, arr):
+        import ctypes as C
+        if DeviceArray._hip is None:
+            DeviceArray._hip = C.CDLL("libamdhip64.so")
+        arr = np.ascontiguousarray(arr)
+        self.ptr = C.c_void_p()
+        rc = self._hip.hipMalloc(C.byref(self.ptr), C.c_size_t(arr.nbytes))
+        assert rc == 0, rc
+        rc = self._hip.hipMemcpy(self.ptr, C.c_void_p(arr.ctypes.data), C.c_size_t(arr.nbytes), 1)
+        assert rc == 0, rc
+
+    def data_ptr(self):
+        return self.ptr.value
+
+    def free(self):
+        if self.ptr:
+            self._hip.hipFree(self.ptr)
+            self.ptr = None

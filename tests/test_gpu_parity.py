@@ -445,3 +445,77 @@ def test_motion_clustering_from_key_images(mode, monkeypatch):
         assert len(cl) == n_g
         for c in cl[:50]:
             assert c["num_pixels_painted"] == int((dyn_o == c["id"]).sum()) or c["id"] == 255
+
+
+def test_tick_path_equals_per_frame_calls():
+    """khr_tick_ingest / khr_tick_integrate (the cameras of a tick batched: one ingest launch with the seed test folded
+    in, one block initialisation, one culling launch) == khr_upload_frame / khr_motion_keys / khr_integrate frame by
+    frame in camera order, bit for bit; on a shard (rank 0 of 2) and unsharded, with overlapping cameras (blocks seen
+    and newly allocated by several cameras of the same tick) and more cameras than one batch holds."""
+    from common import DeviceArray
+    for world, n_cam, n_ticks in ((2, 3, 18), (1, 9, 2)):
+        kw = dict(width=160, height=120, rank=0, world_size=world, num_frame_slots=2 * n_cam, temporal_window=0.6,
+                  temporal_buffer=0.3)
+        cfg, a, _, s, sen, _ = make_pair(**kw)
+        _, b, _, _, sen_b, _ = make_pair(**kw)
+        seeds_seen = 0
+        for tick in range(n_ticks):
+            # the rig keeps turning: every tick allocates blocks, some of them under pixels of a seed frame (the motion
+            # detector must not see those yet: allocation epoch)
+            frs = [s.render(tick, yaw_offset=0.3 * k + 0.12 * tick) for k in range(n_cam)]
+            stamp = frs[0]["stamp"]
+            tens = [(DeviceArray(f["depth"]), DeviceArray(f["rgb"]), DeviceArray(f["label"])) for f in frs]
+            # per-frame calls
+            slots_a, seeds_a, keys_a = [], [], []
+            for f, (d, c, l) in zip(frs, tens):
+                sl = a.upload_frame_device(sen, stamp, f["pose"], d.data_ptr(), c.data_ptr(), l.data_ptr())
+                k, n = a.motion_keys(sl, shape=f["depth"].shape)
+                keys_a.append(k)
+                if n:
+                    a.detect_motion_from_keys(sl, k)
+                slots_a.append(sl)
+                seeds_a.append(n)
+            for sl in slots_a:
+                a.integrate(sl, use_mask=True)
+            a.update_tracking(stamp)
+            # tick calls
+            frames = [b.make_frame(stamp, f["pose"], d.data_ptr(), c.data_ptr(), l.data_ptr()) for f, (d, c, l) in zip(frs, tens)]
+            if n_cam <= 8:  # split phases: nothing waits in the ingest, allocation / culling queued before the counts are read
+                slots_b, none = b.tick_ingest(sen_b, frames, count_seeds=True, want_counts=False)
+                assert none is None
+                b.tick_integrate(slots_b, phases=1)
+                seeds_b = b.tick_seed_counts(n_cam)
+            else:
+                slots_b, seeds_b = b.tick_ingest(sen_b, frames, count_seeds=True)
+            assert seeds_b == seeds_a, (tick, seeds_a, seeds_b)
+            for ci, (sl, f, n) in enumerate(zip(slots_b, frs, seeds_b)):
+                # (keys of every camera, not only of those with seeds: the blocks phase 1 has just allocated must be
+                # invisible to the pixel pass, as they are in the per-frame order)
+                k, n2 = b.motion_keys(sl, shape=f["depth"].shape)
+                assert n2 == n and np.array_equal(k, keys_a[ci]), (tick, ci)
+                if n:
+                    b.detect_motion_from_keys(sl, k)
+            b.tick_integrate(slots_b, use_mask=True, phases=2 if n_cam <= 8 else 3)
+            b.update_tracking(stamp)
+            seeds_seen += sum(seeds_a)
+            a.sync(); b.sync()
+            for t3 in tens:
+                for t in t3:
+                    t.free()
+            for sa, sb, f in zip(slots_a, slots_b, frs):
+                ra, _, da = a.download_frame(sa, f["depth"].shape, range_image=True, dynamic_image=True)
+                rb, _, db = b.download_frame(sb, f["depth"].shape, range_image=True, dynamic_image=True)
+                assert np.array_equal(ra, rb) and np.array_equal(da, db)
+        sa, sb = a.stats(), b.stats()
+        for k in ("cum_updated_voxels", "cum_band_voxels", "cum_visited_voxels", "cum_integrate_calls", "n_allocated_blocks"):
+            assert sa[k] == sb[k], (k, sa[k], sb[k])
+        assert sb["band_overflow"] == 0
+        idx = a.block_indices()
+        assert len(idx) > 20 and np.array_equal(idx, b.block_indices())
+        for bi in idx[:: max(1, len(idx) // 60)]:
+            g, h = a.download_block(bi), b.download_block(bi)
+            for k in ("distance", "weight", "color", "last_observed", "last_occupied", "flags", "block_flags", "sem_label",
+                      "likelihoods"):
+                assert np.array_equal(g[k], h[k]), (world, k, bi)
+        assert world == 1 or seeds_seen > 0
+        a.close(); b.close()

@@ -789,9 +789,12 @@ __global__ __launch_bounds__(256) void k_band_update(DevMap m, DevParams p, DevF
   constexpr int NV = VPS * VPS * VPS;
   // tick path: the record cursors alternate between two sets; the set of the NEXT camera's k_tsdf_update is idle now
   if (band_count_next && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kBandShards) band_count_next[threadIdx.x * 32] = 0u;
-  if (blockIdx.x == 0 && blockIdx.y == 0) {  // fold k_tsdf_update's per-workgroup statistics
+  if (blockIdx.x == 0) {
+    // fold k_tsdf_update's per-workgroup statistics: the first workgroup of every shard takes a slice, one entry pair per
+    // thread and round (a single workgroup walking all 4096 pairs was a serial chain of ~16 load latencies: the kernel's
+    // whole fixed cost)
     unsigned long long u = 0, b = 0;
-    for (int i = threadIdx.x; i < n_wg; i += blockDim.x) {
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n_wg; i += gridDim.y * blockDim.x) {
       u += wg_stats[2 * i];
       b += wg_stats[2 * i + 1];
     }

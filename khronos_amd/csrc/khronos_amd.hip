@@ -66,6 +66,7 @@ struct FrameSlot {
   khr_frame meta{};
   bool valid = false, has_color = false, has_label = false, has_obj = false, objects_done = false;
   bool dyn_clean = false;  // the dynamic image is all zero (fresh from ingest, nothing painted yet)
+  bool aux_used = false;   // kernels of the auxiliary stream have read / written this slot since its ingest
   std::vector<khr_cluster> sem_clusters;  // semantic clusters of the frame in this slot (khr_detect_objects)
   std::vector<khr_cluster> clusters;  // dynamic clusters of the frame in this slot (ids, listed pixel counts)
 };
@@ -89,6 +90,11 @@ struct khr_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // second stream for the object detector / voxel-set kernels: they only read the frame, so they run beside the
+  // volumetric kernels of the same frame instead of in front of them.  ev_aux orders it behind the main stream where
+  // it has to be (the frame's ingest, a painted dynamic image), ev_aux_done orders consumers of the object image behind it.
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_aux = nullptr, ev_aux_done = nullptr;
   std::vector<void*> allocs;
   std::vector<FrameSlot> slots;
   int next_slot = 0;
@@ -503,12 +509,17 @@ int khr_depend_on(khr_ctx* c, khr_ctx* other) {
   if (c->device != other->device) return fail(KHR_EINVAL, "contexts live on different devices");
   HIP_TRY(hipSetDevice(c->device));
   if (c->stream == other->stream) {
+    HIP_TRY(hipEventRecord(other->ev_aux_done, other->aux_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, other->ev_aux_done, 0));
     c->dep_src = other;
     return KHR_OK;
   }
   if (!c->ev_dep) HIP_TRY(hipEventCreateWithFlags(&c->ev_dep, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(c->ev_dep, other->stream));
   HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_dep, 0));
+  // ... and behind its object detector (the object images of its frame slots)
+  HIP_TRY(hipEventRecord(other->ev_aux_done, other->aux_stream));
+  HIP_TRY(hipStreamWaitEvent(c->stream, other->ev_aux_done, 0));
   c->dep_src = other;
   return KHR_OK;
 }
@@ -581,6 +592,12 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     return fail(KHR_EDEVICE, "hipStreamCreate failed");
   }
   c->own_stream = true;
+  if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_aux_done, hipEventDisableTiming) != hipSuccess) {
+    delete c;
+    return fail(KHR_EDEVICE, "auxiliary stream / event creation failed");
+  }
   if (hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), 64, hipHostMallocDefault) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_seed, hipEventDisableTiming) != hipSuccess) {
     delete c;
@@ -762,6 +779,7 @@ void khr_destroy(khr_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
   resolveTimers(c);
   for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
   for (void* p : c->allocs) hipFree(p);
@@ -778,6 +796,9 @@ void khr_destroy(khr_ctx* c) {
   }
   if (c->ev_seed) hipEventDestroy(c->ev_seed);
   if (c->ev_dep) hipEventDestroy(c->ev_dep);
+  if (c->ev_aux) hipEventDestroy(c->ev_aux);
+  if (c->ev_aux_done) hipEventDestroy(c->ev_aux_done);
+  if (c->aux_stream) hipStreamDestroy(c->aux_stream);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -785,6 +806,7 @@ void khr_destroy(khr_ctx* c) {
 int khr_set_stream(khr_ctx* c, void* hip_stream) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
   HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipStreamSynchronize(c->aux_stream));
   if (c->own_stream) {
     hipStreamDestroy(c->stream);
     c->own_stream = false;
@@ -801,6 +823,15 @@ int khr_set_stream(khr_ctx* c, void* hip_stream) {
 int khr_sync(khr_ctx* c) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
   HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipStreamSynchronize(c->aux_stream));
+  return KHR_OK;
+}
+
+// the auxiliary stream continues behind everything queued on the main stream so far (a frame's ingest, a painted
+// dynamic image)
+static int auxAfterMain(khr_ctx* c) {
+  HIP_TRY(hipEventRecord(c->ev_aux, c->stream));
+  HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_aux, 0));
   return KHR_OK;
 }
 
@@ -814,6 +845,10 @@ static int acquireSlot(khr_ctx* c) {
   }
   if (slot < 0) return fail(KHR_ENOMEM, "all %d frame slots are retained (raise num_frame_slots)", n_slots);
   c->next_slot = (slot + 1) % n_slots;
+  if (c->slots[slot].aux_used) {  // the object detector may still be reading the previous occupant (tiny rings only)
+    if (hipStreamQuery(c->aux_stream) != hipSuccess) HIP_TRY(hipStreamSynchronize(c->aux_stream));
+    c->slots[slot].aux_used = false;
+  }
   return slot;
 }
 
@@ -885,6 +920,10 @@ int khr_set_frame_image(khr_ctx* c, int slot, int which, const int32_t* image, i
   }
   if (which == 1) s.has_obj = image != nullptr;
   if (which == 0) s.dyn_clean = image == nullptr;
+  if (which == 1) {  // an object image written here is read by kernels of the auxiliary stream (voxel sets)
+    const int rca = auxAfterMain(c);
+    if (rca) return rca;
+  }
   return KHR_OK;
 }
 
@@ -915,6 +954,7 @@ int khr_download_frame_image(khr_ctx* c, int slot, int which, int32_t* image) {
     std::memset(image, 0, n * sizeof(int32_t));
     return KHR_OK;
   }
+  if (which == 1) HIP_TRY(hipStreamSynchronize(c->aux_stream));  // painted / remapped by the object detector's stream
   HIP_TRY(hipMemcpyAsync(image, which == 0 ? s.dyn : s.obj, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return KHR_OK;
@@ -1024,6 +1064,10 @@ int khr_integrate(khr_ctx* c, int slot, int allocate_blocks, int use_mask, int o
   HIP_TRY(hipSetDevice(c->device));
   FrameSlot& s = c->slots[slot];
   const DevFrame f = makeDevFrame(c, s);
+  if (object_id >= 0 && s.has_obj) {  // the object image comes from the auxiliary stream
+    HIP_TRY(hipEventRecord(c->ev_aux_done, c->aux_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_aux_done, 0));
+  }
   int rc = integrateAlloc(c, s, f, allocate_blocks);
   if (rc) return rc;
   return integrateUpdate(c, s, f, allocate_blocks, use_mask, object_id);
@@ -1035,7 +1079,10 @@ int khr_integrate_shared(khr_ctx* c, khr_ctx* src, int src_slot, int allocate_bl
   if (c->device != src->device) return fail(KHR_EINVAL, "contexts live on different devices");
   HIP_TRY(hipSetDevice(c->device));
   // the frame must be complete: either the caller declared the dependency on the device (khr_depend_on) or the host waits
-  if (c->stream != src->stream && c->dep_src != src) HIP_TRY(hipStreamSynchronize(src->stream));
+  if (c->dep_src != src) {
+    if (c->stream != src->stream) HIP_TRY(hipStreamSynchronize(src->stream));
+    HIP_TRY(hipStreamSynchronize(src->aux_stream));
+  }
   FrameSlot& s = src->slots[src_slot];
   const DevFrame f = makeDevFrame(src, s);
   int rc = integrateAlloc(c, s, f, allocate_blocks);
@@ -1424,13 +1471,14 @@ static int waitSeedCount(khr_ctx* c) {
 
 // spin on a ticket word in pinned memory (written by k_publish); keeps an eye on the stream so that a failed launch
 // cannot hang the host
-static int waitTicket(khr_ctx* c, int word, uint32_t ticket, const char* what) {
+static int waitTicket(khr_ctx* c, int word, uint32_t ticket, const char* what, hipStream_t stream = nullptr) {
   volatile uint32_t* hp = c->h_pinned;
   uint64_t spins = 0;
+  if (!stream) stream = c->stream;
   while (hp[word] != ticket) {
     __builtin_ia32_pause();
     if ((++spins & 0xffffu) == 0) {
-      const hipError_t q = hipStreamQuery(c->stream);
+      const hipError_t q = hipStreamQuery(stream);
       if (q != hipSuccess && q != hipErrorNotReady) return fail(KHR_EDEVICE, "stream failed while waiting for %s: %s", what, hipGetErrorString(q));
       if (q == hipSuccess && hp[word] != ticket) return fail(KHR_EDEVICE, "%s was never published", what);
     }
@@ -1871,6 +1919,7 @@ static int ensureGv(khr_ctx* c) {
       hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_obj_head_host), c->h_obj_head, 0) != hipSuccess)
     A(KHR_ENOMEM);
   if (hipEventCreateWithFlags(&c->ev_obj, hipEventDisableTiming) != hipSuccess) A(KHR_EDEVICE);
+  if (rc == KHR_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = KHR_EDEVICE;  // zero-fills above vs the auxiliary stream
   return rc;
 }
 
@@ -1920,10 +1969,11 @@ static int objectsLaunch(khr_ctx* c, int slot) {
   s.sem_clusters.clear();
   s.objects_done = false;
   s.has_obj = true;
+  s.aux_used = true;
   c->obj_pending_slot = -1;
   const int n_labels = static_cast<int>(c->obj_labels.size());
   if (!s.has_label || n_labels == 0) {
-    HIP_TRY(hipMemsetAsync(s.obj, 0, sizeof(int32_t) * n, c->stream));
+    HIP_TRY(hipMemsetAsync(s.obj, 0, sizeof(int32_t) * n, c->aux_stream));
     s.objects_done = true;
     return KHR_OK;
   }
@@ -1934,33 +1984,33 @@ static int objectsLaunch(khr_ctx* c, int slot) {
   if (oc.use_3d) {
     const float inv = 1.f / oc.grid_size;  // connected_semantics.cpp:75
     // (the counters were zeroed by the k_publish of the previous request, unless that one never got that far)
-    if (!c->gv_clean) hipLaunchKernelGGL(k_gv_clear, dim3(gridFor(tsize / 2)), dim3(256), 0, c->stream, c->d_gv_keys, tsize, c->d_gv_n);
-    else if (!c->gv_counters_clean[0]) HIP_TRY(hipMemsetAsync(c->d_gv_n, 0, sizeof(uint32_t) * 4, c->stream));
+    if (!c->gv_clean) hipLaunchKernelGGL(k_gv_clear, dim3(gridFor(tsize / 2)), dim3(256), 0, c->aux_stream, c->d_gv_keys, tsize, c->d_gv_n);
+    else if (!c->gv_counters_clean[0]) HIP_TRY(hipMemsetAsync(c->d_gv_n, 0, sizeof(uint32_t) * 4, c->aux_stream));
     c->gv_clean = false;
     c->gv_counters_clean[0] = false;
-    hipLaunchKernelGGL(k_obj_insert3d, dim3(gridFor(n)), dim3(256), 0, c->stream, f, c->d_obj_labels, n_labels, oc.max_range, inv,
+    hipLaunchKernelGGL(k_obj_insert3d, dim3(gridFor(n)), dim3(256), 0, c->aux_stream, f, c->d_obj_labels, n_labels, oc.max_range, inv,
                        windowOrigin(f, inv), t, c->d_gv_parent, c->d_gv_node, c->d_gv_n + 1, c->d_gv_owners, c->d_gv_n + 2);
-    hipLaunchKernelGGL(k_obj_union3d, dim3(1024), dim3(256), 0, c->stream, c->d_gv_owners, c->d_gv_n + 2, t, c->d_gv_parent,
+    hipLaunchKernelGGL(k_obj_union3d, dim3(1024), dim3(256), 0, c->aux_stream, c->d_gv_owners, c->d_gv_n + 2, t, c->d_gv_parent,
                        oc.use_full_connectivity ? 13 : 3);
-    hipLaunchKernelGGL(k_obj_roots3d, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_gv_owners, c->d_gv_n + 2, c->d_gv_parent,
+    hipLaunchKernelGGL(k_obj_roots3d, dim3(gridFor(n)), dim3(256), 0, c->aux_stream, c->d_gv_owners, c->d_gv_n + 2, c->d_gv_parent,
                        c->d_gv_rootidx, c->d_gv_n, c->obj_root_cap, c->d_obj_acc, c->d_gv_keys);
     // the keys are not needed any more (the paint pass goes through pix_node -> parent -> root_idx)
-    hipLaunchKernelGGL(k_gv_release, dim3(256), dim3(256), 0, c->stream, c->d_gv_owners, c->d_gv_n + 2, c->d_gv_keys);
+    hipLaunchKernelGGL(k_gv_release, dim3(256), dim3(256), 0, c->aux_stream, c->d_gv_owners, c->d_gv_n + 2, c->d_gv_keys);
     c->gv_clean = true;
   } else {
-    HIP_TRY(hipMemsetAsync(c->d_gv_n, 0, sizeof(uint32_t) * 4, c->stream));
-    hipLaunchKernelGGL(k_obj_init2d, dim3(gridFor(n)), dim3(256), 0, c->stream, f, c->d_obj_labels, n_labels, c->d_gv_parent, c->d_gv_node);
-    hipLaunchKernelGGL(k_obj_union2d, dim3(gridFor(n)), dim3(256), 0, c->stream, f, c->d_gv_node, c->d_gv_parent,
+    HIP_TRY(hipMemsetAsync(c->d_gv_n, 0, sizeof(uint32_t) * 4, c->aux_stream));
+    hipLaunchKernelGGL(k_obj_init2d, dim3(gridFor(n)), dim3(256), 0, c->aux_stream, f, c->d_obj_labels, n_labels, c->d_gv_parent, c->d_gv_node);
+    hipLaunchKernelGGL(k_obj_union2d, dim3(gridFor(n)), dim3(256), 0, c->aux_stream, f, c->d_gv_node, c->d_gv_parent,
                        oc.use_full_connectivity ? 1 : 0);
-    hipLaunchKernelGGL(k_obj_roots, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_gv_node, n, c->d_gv_parent, c->d_gv_rootidx, c->d_gv_n,
+    hipLaunchKernelGGL(k_obj_roots, dim3(gridFor(n)), dim3(256), 0, c->aux_stream, c->d_gv_node, n, c->d_gv_parent, c->d_gv_rootidx, c->d_gv_n,
                        c->obj_root_cap, c->d_obj_acc, nullptr, s.label, c->d_obj_labels, n_labels);
   }
   const int obj_tiles = ((s.sensor.width + kObjTile - 1) / kObjTile) * ((s.sensor.height + kObjTile - 1) / kObjTile);
-  hipLaunchKernelGGL(k_obj_paint, dim3(obj_tiles), dim3(1024), 0, c->stream, f, c->d_gv_node, c->d_gv_parent, c->d_gv_rootidx,
+  hipLaunchKernelGGL(k_obj_paint, dim3(obj_tiles), dim3(1024), 0, c->aux_stream, f, c->d_gv_node, c->d_gv_parent, c->d_gv_rootidx,
                      c->obj_root_cap, s.obj, c->d_obj_acc);
   HIP_TRY(hipGetLastError());
   if (++c->obj_ticket == 0) ++c->obj_ticket;
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, c->stream, c->d_gv_n, reinterpret_cast<uint32_t*>(c->d_obj_head_host),
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, c->aux_stream, c->d_gv_n, reinterpret_cast<uint32_t*>(c->d_obj_head_host),
                      static_cast<uint32_t>(sizeof(ObjAcc) / 4), kObjHead, c->d_pinned + 4, c->obj_ticket, c->d_gv_n);
   HIP_TRY(hipGetLastError());
   c->gv_counters_clean[0] = oc.use_3d != 0;  // (the 2D path resets them itself)
@@ -1978,7 +2028,7 @@ static int objectsFinish(khr_ctx* c, int slot) {
   const int n = s.sensor.width * s.sensor.height;
   const khr_object_detector_config& oc = c->obj_cfg;
   {
-    const int rcw = waitTicket(c, 4, c->obj_ticket, "the object detector's cluster records");
+    const int rcw = waitTicket(c, 4, c->obj_ticket, "the object detector's cluster records", c->aux_stream);
     if (rcw) return rcw;
   }
   const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c->h_obj_head);
@@ -1988,8 +2038,8 @@ static int objectsFinish(khr_ctx* c, int slot) {
   s.objects_done = true;
   if (R == 0) return 0;
   if (R > kObjHead) {
-    HIP_TRY(hipMemcpyAsync(c->h_obj_head, c->d_gv_n, 16 + sizeof(ObjAcc) * R, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_obj_head, c->d_gv_n, 16 + sizeof(ObjAcc) * R, hipMemcpyDeviceToHost, c->aux_stream));
+    HIP_TRY(hipStreamSynchronize(c->aux_stream));
   }
   const ObjAcc* acc = reinterpret_cast<const ObjAcc*>(c->h_obj_head + 16);
   // cluster order: 3D mode = by semantic id (std::map, connected_semantics.h:87), then by first pixel in scan order
@@ -2028,8 +2078,8 @@ static int objectsFinish(khr_ctx* c, int slot) {
   }
   // the records are consumed: the pinned block now carries the final ids to the device
   std::memcpy(c->h_obj_head, fin.data(), sizeof(int32_t) * R);
-  HIP_TRY(hipMemcpyAsync(c->d_obj_final, c->h_obj_head, sizeof(int32_t) * R, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_obj_remap, dim3(gridFor(n)), dim3(256), 0, c->stream, s.obj, n, c->d_obj_final);
+  HIP_TRY(hipMemcpyAsync(c->d_obj_final, c->h_obj_head, sizeof(int32_t) * R, hipMemcpyHostToDevice, c->aux_stream));
+  hipLaunchKernelGGL(k_obj_remap, dim3(gridFor(n)), dim3(256), 0, c->aux_stream, s.obj, n, c->d_obj_final);
   HIP_TRY(hipGetLastError());
   return static_cast<int>(s.sem_clusters.size());
 }
@@ -2041,7 +2091,8 @@ int khr_detect_objects(khr_ctx* c, int slot) {
   FrameSlot& s = c->slots[slot];
   if (s.objects_done) return static_cast<int>(s.sem_clusters.size());  // already done inside khr_process_frame
   if (c->obj_pending_slot != slot) {
-    const int rc = objectsLaunch(c, slot);
+    int rc = auxAfterMain(c);  // the slot's ingest (and whatever else the caller queued) comes first
+    if (!rc) rc = objectsLaunch(c, slot);
     if (rc) return rc;
   }
   return objectsFinish(c, slot);
@@ -2074,21 +2125,26 @@ int khr_cluster_voxels_launch(khr_ctx* c, int slot, int which, float voxel_size)
   const int n = s.sensor.width * s.sensor.height;
   const DevFrame f = makeDevFrame(c, s);
   const float inv = 1.f / voxel_size;  // spatial_hash::Grid(voxel_size)
+  if (which == 0) {  // the dynamic image is painted on the main stream
+    rc = auxAfterMain(c);
+    if (rc) return rc;
+  }
+  s.aux_used = true;
   c->cv_origin[which] = windowOrigin(f, inv);
   GvTable t{c->d_gv_keys, c->gv_mask};
   const uint32_t tsize = c->gv_mask + 1;
-  if (!c->gv_clean) hipLaunchKernelGGL(k_gv_clear, dim3(gridFor(tsize / 2)), dim3(256), 0, c->stream, c->d_gv_keys, tsize, c->d_cv_n[which]);
-  else if (!c->gv_counters_clean[1 + which]) HIP_TRY(hipMemsetAsync(c->d_cv_n[which], 0, sizeof(uint32_t) * 4, c->stream));
+  if (!c->gv_clean) hipLaunchKernelGGL(k_gv_clear, dim3(gridFor(tsize / 2)), dim3(256), 0, c->aux_stream, c->d_gv_keys, tsize, c->d_cv_n[which]);
+  else if (!c->gv_counters_clean[1 + which]) HIP_TRY(hipMemsetAsync(c->d_cv_n[which], 0, sizeof(uint32_t) * 4, c->aux_stream));
   c->gv_clean = false;
   c->gv_counters_clean[1 + which] = false;
-  hipLaunchKernelGGL(k_cluster_voxels, dim3(gridFor(n)), dim3(256), 0, c->stream, f, which == 0 ? s.dyn : s.obj, inv, c->cv_origin[which], t,
+  hipLaunchKernelGGL(k_cluster_voxels, dim3(gridFor(n)), dim3(256), 0, c->aux_stream, f, which == 0 ? s.dyn : s.obj, inv, c->cv_origin[which], t,
                      c->d_cv_keys[which], c->d_cv_n[which], static_cast<uint32_t>(c->cfg.max_frame_pixels), c->d_cv_n[which] + 1,
                      c->d_gv_owners);
-  hipLaunchKernelGGL(k_gv_release, dim3(256), dim3(256), 0, c->stream, c->d_gv_owners, c->d_cv_n[which], c->d_gv_keys);
+  hipLaunchKernelGGL(k_gv_release, dim3(256), dim3(256), 0, c->aux_stream, c->d_gv_owners, c->d_cv_n[which], c->d_gv_keys);
   c->gv_clean = true;
   HIP_TRY(hipGetLastError());
   if (++c->cv_ticket[which] == 0) ++c->cv_ticket[which];
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, c->stream, c->d_cv_n[which], reinterpret_cast<uint32_t*>(c->d_cv_host[which]),
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, c->aux_stream, c->d_cv_n[which], reinterpret_cast<uint32_t*>(c->d_cv_host[which]),
                      2u, static_cast<uint32_t>(std::min<size_t>(kCvHead, c->cfg.max_frame_pixels)), c->d_pinned + 5 + which,
                      c->cv_ticket[which], c->d_cv_n[which]);
   HIP_TRY(hipGetLastError());
@@ -2100,7 +2156,7 @@ int64_t khr_cluster_voxels_fetch(khr_ctx* c, int which, int32_t* ids_out, int64_
   if (!c || (which != 0 && which != 1) || cap < 0 || (cap > 0 && (!ids_out || !voxels_out))) return fail(KHR_EINVAL, "bad argument");
   if (c->cv_pending_slot[which] < 0) return fail(KHR_ESTATE, "khr_cluster_voxels_launch has not been called");
   {
-    const int rcw = waitTicket(c, 5 + which, c->cv_ticket[which], "the cluster voxel sets");
+    const int rcw = waitTicket(c, 5 + which, c->cv_ticket[which], "the cluster voxel sets", c->aux_stream);
     if (rcw) return rcw;
   }
   const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c->h_cv[which]);
@@ -2109,8 +2165,8 @@ int64_t khr_cluster_voxels_fetch(khr_ctx* c, int which, int32_t* ids_out, int64_
   const uint32_t N = cnt[0];
   if (N == 0) return 0;
   if (N > kCvHead) {
-    HIP_TRY(hipMemcpyAsync(c->h_cv[which], c->d_cv_n[which], 16 + sizeof(uint64_t) * N, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_cv[which], c->d_cv_n[which], 16 + sizeof(uint64_t) * N, hipMemcpyDeviceToHost, c->aux_stream));
+    HIP_TRY(hipStreamSynchronize(c->aux_stream));
   }
   const uint64_t* keys = reinterpret_cast<const uint64_t*>(c->h_cv[which] + 16);
   const int3 origin = c->cv_origin[which];
@@ -2351,6 +2407,7 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   //     volumetric kernels run, and are looked at in (6)
   if (objects) {
     if (!c->obj_configured) return fail(KHR_ESTATE, "KHR_PF_OBJECTS needs khr_configure_object_detector");
+    if ((rc = auxAfterMain(c))) return rc;  // behind this frame's ingest, beside everything that follows
     if ((rc = objectsLaunch(c, slot))) return rc;
   }
   // (1) per-pixel motion pass; its seed count comes back asynchronously ...

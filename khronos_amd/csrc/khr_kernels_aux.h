@@ -147,6 +147,18 @@ __device__ inline void voxInsertCounted(const VoxTable& t, bool has, uint64_t ke
   }
 }
 
+// one launch instead of three memsets: keys of the three tables = empty, counts of the first two = 0, list counters = 0
+__global__ __launch_bounds__(256) void k_md_clear(uint64_t* __restrict__ keys, uint32_t* __restrict__ counts, uint32_t tsize,
+                                                 uint32_t* __restrict__ n4) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  ulonglong2* k2 = reinterpret_cast<ulonglong2*>(keys);
+  for (uint32_t i = t0; i < 3u * (tsize / 2); i += stride) k2[i] = make_ulonglong2(~0ull, ~0ull);
+  uint4* c4 = reinterpret_cast<uint4*>(counts);
+  for (uint32_t i = t0; i < 2u * (tsize / 4); i += stride) c4[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (t0 < 4) n4[t0] = 0u;
+}
+
 __global__ __launch_bounds__(256) void k_md_seed_insert(const uint64_t* __restrict__ keys, int n, VoxTable seeds) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t k = i < n ? keys[i] : ~0ull;
@@ -185,7 +197,7 @@ __global__ __launch_bounds__(256) void k_md_boundary_insert(const uint64_t* __re
 // occupied table slots -> compact lists (ids are arbitrary but stable for the rest of the frame)
 __global__ __launch_bounds__(256) void k_md_compact(VoxTable t, uint64_t* __restrict__ list_keys,
                                                    uint32_t* __restrict__ list_counts, uint32_t* __restrict__ n_out,
-                                                   uint32_t cap) {
+                                                   uint32_t cap, int32_t* __restrict__ zero_per_entry) {
   const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
   const bool used = h <= t.mask && t.keys[h] != kEmptyKey;
   const uint32_t id = waveAggInc(n_out, used);
@@ -193,6 +205,7 @@ __global__ __launch_bounds__(256) void k_md_compact(VoxTable t, uint64_t* __rest
     list_keys[id] = t.keys[h];
     list_counts[id] = t.counts[h];
     t.ids[h] = id;
+    if (zero_per_entry) zero_per_entry[id] = 0;  // final ids of the boundary voxels start at "none" (k_md_comp_finals raises them)
   }
 }
 
@@ -415,14 +428,19 @@ __global__ __launch_bounds__(256) void k_md_comp_roots(const uint32_t* __restric
 
 // final ids: a seed takes its component's id; a boundary voxel the id of the LAST cluster that lists it (:388-389;
 // ids grow with the painting order, so that is the maximum over the adjacent seeds' components)
+constexpr int kCompInline = 64;  // final ids of up to this many components travel as a kernel argument (no copy command)
+struct CompFinals {
+  int32_t id[kCompInline];
+};
 __global__ __launch_bounds__(256) void k_md_comp_finals(const uint32_t* __restrict__ adj, const uint32_t* __restrict__ n_seeds, uint32_t cap,
                                                        int nn, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ root_idx,
-                                                       const int32_t* __restrict__ comp_final, int32_t* __restrict__ seed_final,
+                                                       const int32_t* __restrict__ comp_final, CompFinals inl, int32_t* __restrict__ seed_final,
                                                        int32_t* __restrict__ bnd_final) {
   const uint32_t ns = min(*n_seeds, cap);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns * nn; i += gridDim.x * blockDim.x) {
     const uint32_t s = i / nn, j = i % nn;
-    const int32_t f = comp_final[root_idx[parent[s]]];
+    const uint32_t ri = root_idx[parent[s]];
+    const int32_t f = comp_final ? comp_final[ri] : inl.id[ri];
     if (j == 0) seed_final[s] = f;
     const uint32_t a = adj[i];
     if (f && a != 0xffffffffu && !(a & 0x80000000u)) atomicMax(&bnd_final[a], f);

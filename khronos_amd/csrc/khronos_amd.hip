@@ -172,6 +172,9 @@ struct khr_ctx {
   bool md_host_walk = false;     // KHR_MD_HOST_WALK=1: always cluster on the host (A/B switch, results identical)
   uint32_t md_lds_max = kCompLds;  // KHR_MD_LDS_MAX=n: seed count up to which the single-workgroup LDS labelling is used
   uint32_t md_mask = 0, md_list_cap = 0;
+  uint32_t md_head_ticket = 0;      // h_pinned[8]
+  uint8_t* d_md_head_host = nullptr;  // device view of h_md_head
+  uint32_t* d_md_scratch4 = nullptr;  // 4 words k_publish may zero
   std::vector<uint64_t> h_md_seed_keys, h_md_bnd_keys;
   std::vector<uint32_t> h_md_seed_counts, h_md_bnd_counts, h_md_adj;
   std::vector<int32_t> h_md_seed_final, h_md_bnd_final;
@@ -699,7 +702,10 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     A(devAlloc(c, &c->d_md_rootidx, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_comp_acc, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_comp_final, kCompCap));
-    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_md_head), 16 + sizeof(CompAcc) * kCompCap, hipHostMallocDefault) != hipSuccess) A(KHR_ENOMEM);
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_md_head), 16 + sizeof(CompAcc) * kCompCap, hipHostMallocDefault) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_md_head_host), c->h_md_head, 0) != hipSuccess)
+      A(KHR_ENOMEM);
+    A(devAlloc(c, &c->d_md_scratch4, 8));
     c->md_host_walk = std::getenv("KHR_MD_HOST_WALK") != nullptr;
     if (const char* e = std::getenv("KHR_MD_LDS_MAX")) c->md_lds_max = std::min<uint32_t>(kCompLds, static_cast<uint32_t>(std::atoi(e)));
     A(devAlloc(c, &c->d_md_seed_keys, c->md_list_cap, false));
@@ -1518,17 +1524,25 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
 
   // ---- device: seed / boundary voxel tables, compact lists, seed adjacency ------------------------
   const int nn = c->cfg.md_neighbor_connectivity;
-  const size_t tsize = static_cast<size_t>(c->md_mask) + 1;
-  VoxTable seeds{c->d_md_keys, c->d_md_counts, c->d_md_ids, c->md_mask};
-  VoxTable bnd{c->d_md_keys + tsize, c->d_md_counts + tsize, c->d_md_ids + tsize, c->md_mask};
-  VoxTable near{c->d_md_keys + 2 * tsize, c->d_md_counts + 2 * tsize, c->d_md_ids + 2 * tsize, c->md_mask};
-  HIP_TRY(hipMemsetAsync(c->d_md_keys, 0xff, sizeof(uint64_t) * 3 * tsize, c->stream));
-  HIP_TRY(hipMemsetAsync(c->d_md_counts, 0, sizeof(uint32_t) * 2 * tsize, c->stream));
-  HIP_TRY(hipMemsetAsync(c->d_md_n, 0, sizeof(uint32_t) * 4, c->stream));
+  // table size for THIS frame: #seed voxels <= #seed pixels (known), boundary / near voxels <= nn per seed voxel; the
+  // allocation covers the worst case (every pixel its own voxel), a typical seed frame needs 1 / 8 of it -- and the
+  // clear and the two compaction passes walk the whole table
+  uint32_t mask = c->md_mask;
+  {
+    const uint64_t need = 4ull * static_cast<uint64_t>(nn) * std::max<uint32_t>(c->h_pinned[0], 1u);
+    uint32_t ts = 1u << 14;
+    while (ts < need && ts - 1 < c->md_mask) ts <<= 1;
+    mask = std::min(ts - 1, c->md_mask);
+  }
+  const size_t tsize = static_cast<size_t>(mask) + 1;
+  VoxTable seeds{c->d_md_keys, c->d_md_counts, c->d_md_ids, mask};
+  VoxTable bnd{c->d_md_keys + tsize, c->d_md_counts + tsize, c->d_md_ids + tsize, mask};
+  VoxTable near{c->d_md_keys + 2 * tsize, c->d_md_counts + 2 * tsize, c->d_md_ids + 2 * tsize, mask};
+  hipLaunchKernelGGL(k_md_clear, dim3(1024), dim3(256), 0, c->stream, c->d_md_keys, c->d_md_counts, static_cast<uint32_t>(tsize), c->d_md_n);
   const uint32_t cap = c->md_list_cap;
   hipLaunchKernelGGL(k_md_seed_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds);
   hipLaunchKernelGGL(k_md_compact, dim3(gridFor(tsize)), dim3(256), 0, c->stream, seeds, c->d_md_seed_keys,
-                     c->d_md_seed_counts, c->d_md_n, cap);
+                     c->d_md_seed_counts, c->d_md_n, cap, nullptr);
   // the `near` table takes up to nn entries per seed voxel (#seed voxels <= #seed pixels); when that could fill it,
   // the boundary test looks the neighbours up in the seed table directly
   const int direct = static_cast<double>(nn) * c->h_pinned[0] > 0.7 * static_cast<double>(tsize) ? 1 : 0;
@@ -1536,24 +1550,33 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
     hipLaunchKernelGGL(k_md_near_insert, dim3(256), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_n, cap, nn, near, c->d_md_n + 3);
   hipLaunchKernelGGL(k_md_boundary_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, near, bnd, seeds, nn, direct);
   hipLaunchKernelGGL(k_md_compact, dim3(gridFor(tsize)), dim3(256), 0, c->stream, bnd, c->d_md_bnd_keys, c->d_md_bnd_counts,
-                     c->d_md_n + 1, cap);
+                     c->d_md_n + 1, cap, c->d_md_bnd_final);
   hipLaunchKernelGGL(k_md_adjacency, dim3(1024), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_n, seeds, bnd, nn, cap,
                      c->d_md_adj);
   // connected components of the seed graph + their order-free summaries, on the device
   const uint32_t seed_px = std::min<uint32_t>(c->h_pinned[0], cap);  // #seed voxels <= #seed pixels
   CompAcc* d_comp_out = reinterpret_cast<CompAcc*>(reinterpret_cast<uint8_t*>(c->d_md_n) + 16);
   hipLaunchKernelGGL(k_md_comp_lds, dim3(1), dim3(1024), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->d_md_comp_acc, c->md_lds_max);
-  hipLaunchKernelGGL(k_md_comp_init, dim3(64), dim3(256), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->d_md_comp_acc,
-                     c->md_lds_max);
-  hipLaunchKernelGGL(k_md_comp_jump, dim3(64), dim3(256), 0, c->stream, c->d_md_n, cap, c->d_md_parent, c->md_lds_max);
-  hipLaunchKernelGGL(k_md_comp_union, dim3(1024), dim3(256), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->md_lds_max);
+  if (seed_px > c->md_lds_max) {  // (#seed voxels <= #seed pixels: otherwise the single-workgroup kernel has done it)
+    hipLaunchKernelGGL(k_md_comp_init, dim3(64), dim3(256), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->d_md_comp_acc,
+                       c->md_lds_max);
+    hipLaunchKernelGGL(k_md_comp_jump, dim3(64), dim3(256), 0, c->stream, c->d_md_n, cap, c->d_md_parent, c->md_lds_max);
+    hipLaunchKernelGGL(k_md_comp_union, dim3(1024), dim3(256), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->md_lds_max);
+  }
   hipLaunchKernelGGL(k_md_comp_reduce, dim3(gridFor(seed_px)), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_seed_counts,
                      c->d_md_bnd_keys, c->d_md_bnd_counts, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->d_md_comp_acc);
   hipLaunchKernelGGL(k_md_comp_roots, dim3(gridFor(seed_px)), dim3(256), 0, c->stream, c->d_md_n, cap, c->d_md_parent, c->d_md_comp_acc,
                      c->d_md_rootidx, c->d_md_n + 2, d_comp_out, kCompCap);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(c->h_md_head, c->d_md_n, 16 + sizeof(CompAcc) * kCompHead, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  // counters + the first component records -> pinned memory by a one-workgroup kernel, the host spins on the ticket
+  if (++c->md_head_ticket == 0) ++c->md_head_ticket;
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, c->stream, c->d_md_n, reinterpret_cast<uint32_t*>(c->d_md_head_host),
+                     static_cast<uint32_t>(sizeof(CompAcc) / 4), kCompHead, c->d_pinned + 8, c->md_head_ticket, c->d_md_scratch4);
+  HIP_TRY(hipGetLastError());
+  {
+    const int rcw = waitTicket(c, 8, c->md_head_ticket, "the motion detector's component records");
+    if (rcw) return rcw;
+  }
   lap("tables + adjacency + components + head sync");
   const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c->h_md_head);
   const uint32_t S = cnt[0], B = cnt[1], R = cnt[2];
@@ -1603,11 +1626,18 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
       }
       lap("component order + filter");
       if (kept.empty()) return 0;
-      std::memcpy(fin, tmp.data(), sizeof(int32_t) * R);
-      HIP_TRY(hipMemcpyAsync(c->d_md_comp_final, fin, sizeof(int32_t) * R, hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(hipMemsetAsync(c->d_md_bnd_final, 0, sizeof(int32_t) * std::max<uint32_t>(B, 1), c->stream));
+      CompFinals inl{};
+      const int32_t* fin_dev = nullptr;
+      if (R <= static_cast<uint32_t>(kCompInline)) {  // the ids travel in the kernel arguments
+        for (uint32_t i = 0; i < R; ++i) inl.id[i] = tmp[i];
+      } else {
+        std::memcpy(fin, tmp.data(), sizeof(int32_t) * R);
+        HIP_TRY(hipMemcpyAsync(c->d_md_comp_final, fin, sizeof(int32_t) * R, hipMemcpyHostToDevice, c->stream));
+        fin_dev = c->d_md_comp_final;
+      }
+      // (the boundary voxels' final ids were zeroed by the compaction pass)
       hipLaunchKernelGGL(k_md_comp_finals, dim3(1024), dim3(256), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent,
-                         c->d_md_rootidx, c->d_md_comp_final, c->d_md_seed_final, c->d_md_bnd_final);
+                         c->d_md_rootidx, fin_dev, inl, c->d_md_seed_final, c->d_md_bnd_final);
       hipLaunchKernelGGL(k_md_paint, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds, bnd, c->d_md_seed_final,
                          c->d_md_bnd_final, s.dyn);
       s.dyn_clean = false;

@@ -149,7 +149,7 @@ __device__ inline void voxInsertCounted(const VoxTable& t, bool has, uint64_t ke
 
 // one launch instead of three memsets: keys of the three tables = empty, counts of the first two = 0, list counters = 0
 __global__ __launch_bounds__(256) void k_md_clear(uint64_t* __restrict__ keys, uint32_t* __restrict__ counts, uint32_t tsize,
-                                                 uint32_t* __restrict__ n4) {
+                                                 uint32_t* __restrict__ n4, int32_t* __restrict__ aabb) {
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x;
   ulonglong2* k2 = reinterpret_cast<ulonglong2*>(keys);
@@ -157,6 +157,8 @@ __global__ __launch_bounds__(256) void k_md_clear(uint64_t* __restrict__ keys, u
   uint4* c4 = reinterpret_cast<uint4*>(counts);
   for (uint32_t i = t0; i < 2u * (tsize / 4); i += stride) c4[i] = make_uint4(0u, 0u, 0u, 0u);
   if (t0 < 4) n4[t0] = 0u;
+  if (t0 < 6) aabb[t0] = t0 < 3 ? INT32_MAX : INT32_MIN;  // voxel box of the seed voxels (k_md_near_insert)
+  if (t0 == 7) aabb[7] = 0;                                // seed-seed edge count (k_md_adjacency)
 }
 
 __global__ __launch_bounds__(256) void k_md_seed_insert(const uint64_t* __restrict__ keys, int n, VoxTable seeds) {
@@ -168,19 +170,64 @@ __global__ __launch_bounds__(256) void k_md_seed_insert(const uint64_t* __restri
 // every neighbour of every seed voxel -> the "near a seed" set (S * nn insertions, S is small) ...
 __global__ __launch_bounds__(256) void k_md_near_insert(const uint64_t* __restrict__ seed_keys,
                                                        const uint32_t* __restrict__ n_seeds, uint32_t cap, int nn,
-                                                       VoxTable near, uint32_t* __restrict__ overflow) {
+                                                       VoxTable near, uint32_t* __restrict__ overflow, int32_t* __restrict__ aabb) {
   const uint32_t ns = min(*n_seeds, cap);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns * nn; i += gridDim.x * blockDim.x)
-    if (voxInsert(near, neighbourKey(seed_keys[i / nn], static_cast<int>(i % nn))) == kInvalidSlot) atomicOr(overflow, 1u);
+  // the table takes up to nn entries per seed VOXEL (known here, not on the host, which only has the pixel count); when
+  // that could fill it, the boundary pass looks the neighbours up in the seed table instead (aabb[6] = direct mode)
+  const bool direct = static_cast<float>(nn) * static_cast<float>(ns) > 0.7f * (static_cast<float>(near.mask) + 1.f);
+  if (blockIdx.x == 0 && threadIdx.x == 0) aabb[6] = direct ? 1 : 0;
+  int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns * nn; i += gridDim.x * blockDim.x) {
+    const uint64_t sk = seed_keys[i / nn];
+    if (!direct && voxInsert(near, neighbourKey(sk, static_cast<int>(i % nn))) == kInvalidSlot) atomicOr(overflow, 1u);
+    if (i % nn == 0) {
+      int v[3];
+      unpackKey(sk, &v[0], &v[1], &v[2]);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { lo[d] = min(lo[d], v[d]); hi[d] = max(hi[d], v[d]); }
+    }
+  }
+  // voxel box of all seeds: lets the per-pixel boundary pass drop every pixel that cannot touch a seed without a
+  // table lookup.  Workgroup reduction first: 6 atomics per workgroup, not per wave.
+  __shared__ int s_box[6][4];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[d] = min(lo[d], __shfl_xor(lo[d], o));
+      hi[d] = max(hi[d], __shfl_xor(hi[d], o));
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { s_box[d][threadIdx.x >> 6] = lo[d]; s_box[3 + d][threadIdx.x >> 6] = hi[d]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int d = threadIdx.x;
+    int v = s_box[d][0];
+    for (int w = 1; w < 4; ++w) v = d < 3 ? min(v, s_box[d][w]) : max(v, s_box[d][w]);
+    if (d < 3) { if (v != INT32_MAX) atomicMin(&aabb[d], v); }
+    else if (v != INT32_MIN) atomicMax(&aabb[d], v);
+  }
 }
 
 // ... so that a non-seed pixel needs ONE lookup to know whether its voxel is adjacent to a seed (the
 // neighbour relation is symmetric); such voxels form the boundary table with their pixel counts
 __global__ __launch_bounds__(256) void k_md_boundary_insert(const uint64_t* __restrict__ keys, int n, VoxTable near,
-                                                           VoxTable bnd, VoxTable seeds, int nn, int direct) {
+                                                           VoxTable bnd, VoxTable seeds, int nn, int direct,
+                                                           const int32_t* __restrict__ aabb) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t k = i < n ? keys[i] : ~0ull;
   bool cand = k != ~0ull && !(k & kSeedBit);
+  direct = direct || aabb[6];
+  if (cand) {
+    // a voxel adjacent to a seed lies in the seeds' voxel box grown by one: everything else (nearly every pixel of the
+    // frame) is dropped here instead of by a miss in a 16 MB table
+    int x, y, z;
+    unpackKey(k, &x, &y, &z);
+    cand = x >= aabb[0] - 1 && y >= aabb[1] - 1 && z >= aabb[2] - 1 && x <= aabb[3] + 1 && y <= aabb[4] + 1 && z <= aabb[5] + 1;
+  }
   if (cand) {
     if (!direct) {
       cand = voxFind(near, k) >= 0;
@@ -212,20 +259,46 @@ __global__ __launch_bounds__(256) void k_md_compact(VoxTable t, uint64_t* __rest
 // adj[s * nn + j]: bit 31 set = neighbour is seed id (low bits), else boundary id, 0xffffffff = none
 __global__ __launch_bounds__(256) void k_md_adjacency(const uint64_t* __restrict__ seed_keys,
                                                      const uint32_t* __restrict__ n_seeds, VoxTable seeds, VoxTable bnd,
-                                                     int nn, uint32_t cap, uint32_t* __restrict__ adj) {
+                                                     int nn, uint32_t cap, uint32_t* __restrict__ adj,
+                                                     uint32_t* __restrict__ edges, uint32_t edge_cap, uint32_t* __restrict__ n_edges) {
+  // also emits the seed-seed edges (larger id -> smaller id, packed (s << 16) | t for s < 65536) as a dense list: the
+  // component kernel then reads ~1 / 4 of the adjacency's entries, coalesced, instead of scanning all of them in one
+  // workgroup.  One list append per workgroup and round (workgroup scan), not per wave.
+  __shared__ uint32_t s_cnt[4], s_base;
   const uint32_t ns = min(*n_seeds, cap);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns * nn; i += gridDim.x * blockDim.x) {
-    const uint32_t s = i / nn, j = i % nn;
-    const uint64_t nk = neighbourKey(seed_keys[s], static_cast<int>(j));
-    uint32_t out = 0xffffffffu;
-    const int hs = voxFind(seeds, nk);
-    if (hs >= 0) {
-      out = 0x80000000u | seeds.ids[hs];
-    } else {
-      const int hb = voxFind(bnd, nk);
-      if (hb >= 0) out = bnd.ids[hb];
+  const uint32_t total = ns * nn;
+  const uint32_t rounds = (total + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
+  for (uint32_t r = 0; r < rounds; ++r) {
+    const uint32_t i = (r * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    uint32_t out = 0xffffffffu, s = 0;
+    if (i < total) {
+      s = i / nn;
+      const uint32_t j = i % nn;
+      const uint64_t nk = neighbourKey(seed_keys[s], static_cast<int>(j));
+      const int hs = voxFind(seeds, nk);
+      if (hs >= 0) {
+        out = 0x80000000u | seeds.ids[hs];
+      } else {
+        const int hb = voxFind(bnd, nk);
+        if (hb >= 0) out = bnd.ids[hb];
+      }
+      adj[i] = out;
     }
-    adj[i] = out;
+    const bool is_edge = out != 0xffffffffu && (out & 0x80000000u) && (out & 0x7fffffffu) < s && s < 65536u;
+    const unsigned long long b = __ballot(is_edge);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = static_cast<uint32_t>(__popcll(b));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+      s_base = tot ? atomicAdd(n_edges, tot) : 0u;
+    }
+    __syncthreads();
+    if (is_edge) {
+      uint32_t pos = s_base + static_cast<uint32_t>(__popcll(b & ((1ull << laneId()) - 1ull)));
+      for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) pos += s_cnt[w];
+      if (pos < edge_cap) edges[pos] = (s << 16) | (out & 0x7fffffffu);
+    }
+    __syncthreads();
   }
 }
 
@@ -253,9 +326,12 @@ __device__ inline unsigned long long canonKey(uint64_t packed) {
 // while this converges in a handful of LDS rounds.  Writes parent[s] = smallest compact id of s's component.
 constexpr uint32_t kCompLds = 12288;
 __global__ __launch_bounds__(1024) void k_md_comp_lds(const uint32_t* __restrict__ adj, const uint32_t* __restrict__ n_seeds, uint32_t cap,
-                                                     int nn, uint32_t* __restrict__ parent, CompAcc* __restrict__ acc, uint32_t lds_max) {
+                                                     int nn, uint32_t* __restrict__ parent, CompAcc* __restrict__ acc, uint32_t lds_max,
+                                                     const uint32_t* __restrict__ edges, uint32_t edge_cap,
+                                                     const uint32_t* __restrict__ n_edges_p, unsigned long long* __restrict__ probe) {
   __shared__ uint32_t lab[kCompLds];
   const uint32_t ns = min(*n_seeds, cap);
+  if (probe && threadIdx.x == 0) { probe[0] = __builtin_amdgcn_s_memtime(); probe[6] = ns; }
   if (ns > lds_max) return;  // k_md_comp_init / jump / union take over
   for (uint32_t s = threadIdx.x; s < ns; s += 1024) {
     lab[s] = s;
@@ -268,37 +344,57 @@ __global__ __launch_bounds__(1024) void k_md_comp_lds(const uint32_t* __restrict
     acc[s] = a;
   }
   __syncthreads();
-  const uint32_t ne = ns * static_cast<uint32_t>(nn);
-  while (true) {
-    bool changed = false;
-    // hooking (Shiloach-Vishkin style): an edge whose ends carry different labels lowers the label of s AND of s's
-    // current representative, so whole trees move per round instead of one node per round
-    for (uint32_t e = threadIdx.x; e < ne; e += 1024) {
-      const uint32_t a = adj[e];
-      if (a == 0xffffffffu || !(a & 0x80000000u)) continue;
-      const uint32_t s = e / nn, lt = lab[a & 0x7fffffffu], ls = lab[s];
-      if (lt < ls) {
-        atomicMin(&lab[ls], lt);
-        atomicMin(&lab[s], lt);
-        changed = true;
-      }
+  if (probe && threadIdx.x == 0) probe[1] = __builtin_amdgcn_s_memtime();
+  // Union-find in LDS (ECL-CC scheme, cf. ufFind / ufUnion in khr_device.h): parents only decrease, the larger root is
+  // hooked under the smaller one with a CAS, finds halve the path they walk; the root of a tree is its smallest id, as
+  // the callers expect.  ONE pass over the seed-seed edge list k_md_adjacency wrote (the label-propagation rounds this
+  // replaces grew with the diameter of the moving object's surface, and 48 unrolled copies of the union code ran at the
+  // speed of the instruction cache): loops stay rolled, loads come in batches of 4.
+  auto find = [&](uint32_t x) {
+    uint32_t p = lab[x];
+    while (p != x) {
+      const uint32_t gp = lab[p];
+      if (gp != p) atomicMin(&lab[x], gp);
+      x = p;
+      p = gp;
     }
-    __syncthreads();
-    // pointer jumping to the current root (labels only decrease and lab[x] <= x, so the walk terminates)
-    for (uint32_t s = threadIdx.x; s < ns; s += 1024) {
-      uint32_t l = lab[s], ll = lab[l];
-      if (ll < l) {
-        do {
-          l = ll;
-          ll = lab[l];
-        } while (ll < l);
-        lab[s] = l;  // only this thread writes lab[s] in this phase (concurrent readers see an ancestor either way)
-        changed = true;
-      }
+    return x;
+  };
+  auto unite = [&](uint32_t x, uint32_t y) {
+    x = find(x);
+    y = find(y);
+    while (x != y) {
+      if (x < y) { const uint32_t t = x; x = y; y = t; }  // x = larger root, hooks under y
+      const uint32_t old = atomicCAS(&lab[x], x, y);
+      if (old == x) return;
+      x = find(old);
     }
-    if (!__syncthreads_or(changed ? 1 : 0)) break;
+  };
+  const uint32_t n_all = *n_edges_p;
+  const uint32_t n_edges = min(n_all, edge_cap);
+  for (uint32_t base = threadIdx.x; base < n_edges; base += 4096) {
+    uint32_t ed[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ed[k] = base + 1024u * k < n_edges ? edges[base + 1024u * k] : 0u;  // (0 -> 0): no-op
+    for (int k = 0; k < 4; ++k)
+      if (ed[k]) unite(ed[k] >> 16, ed[k] & 0xffffu);
   }
-  for (uint32_t s = threadIdx.x; s < ns; s += 1024) parent[s] = lab[s];
+  if (n_all > edge_cap) {  // more edges than the list holds (never seen): everything straight from the adjacency
+    const uint32_t ne = ns * static_cast<uint32_t>(nn);
+    for (uint32_t e = threadIdx.x; e < ne; e += 1024) {
+      const uint32_t av = adj[e];
+      const uint32_t s = e / nn, t = av & 0x7fffffffu;
+      if (av != 0xffffffffu && (av & 0x80000000u) && t < s) unite(s, t);
+    }
+  }
+  __syncthreads();
+  if (probe && threadIdx.x == 0) probe[4] = __builtin_amdgcn_s_memtime();
+  for (uint32_t s = threadIdx.x; s < ns; s += 1024) {  // flatten (no unions in flight)
+    uint32_t r = s;
+    while (lab[r] != r) r = lab[r];
+    parent[s] = r;
+  }
+  if (probe && threadIdx.x == 0) { probe[5] = __builtin_amdgcn_s_memtime(); probe[3] = n_edges; probe[2] = probe[1]; }
 }
 
 __global__ __launch_bounds__(256) void k_md_comp_init(const uint32_t* __restrict__ adj, const uint32_t* __restrict__ n_seeds, uint32_t cap,

@@ -174,6 +174,7 @@ struct khr_ctx {
   uint32_t md_mask = 0, md_list_cap = 0;
   uint32_t md_head_ticket = 0;      // h_pinned[8]
   uint8_t* d_md_head_host = nullptr;  // device view of h_md_head
+  uint32_t* d_md_edges = nullptr;     // seed-seed edge list of the latest seed frame (k_md_adjacency -> k_md_comp_lds)
   uint32_t* d_md_scratch4 = nullptr;  // 4 words k_publish may zero
   std::vector<uint64_t> h_md_seed_keys, h_md_bnd_keys;
   std::vector<uint32_t> h_md_seed_counts, h_md_bnd_counts, h_md_adj;
@@ -700,12 +701,13 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     }
     A(devAlloc(c, &c->d_md_parent, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_rootidx, c->md_list_cap, false));
+    A(devAlloc(c, &c->d_md_edges, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_comp_acc, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_comp_final, kCompCap));
     if (hipHostMalloc(reinterpret_cast<void**>(&c->h_md_head), 16 + sizeof(CompAcc) * kCompCap, hipHostMallocDefault) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_md_head_host), c->h_md_head, 0) != hipSuccess)
       A(KHR_ENOMEM);
-    A(devAlloc(c, &c->d_md_scratch4, 8));
+    A(devAlloc(c, &c->d_md_scratch4, 16));  // [0..3] words k_publish may zero, [8..13] voxel box of the seed voxels
     c->md_host_walk = std::getenv("KHR_MD_HOST_WALK") != nullptr;
     if (const char* e = std::getenv("KHR_MD_LDS_MAX")) c->md_lds_max = std::min<uint32_t>(kCompLds, static_cast<uint32_t>(std::atoi(e)));
     A(devAlloc(c, &c->d_md_seed_keys, c->md_list_cap, false));
@@ -1538,25 +1540,31 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
   VoxTable seeds{c->d_md_keys, c->d_md_counts, c->d_md_ids, mask};
   VoxTable bnd{c->d_md_keys + tsize, c->d_md_counts + tsize, c->d_md_ids + tsize, mask};
   VoxTable near{c->d_md_keys + 2 * tsize, c->d_md_counts + 2 * tsize, c->d_md_ids + 2 * tsize, mask};
-  hipLaunchKernelGGL(k_md_clear, dim3(1024), dim3(256), 0, c->stream, c->d_md_keys, c->d_md_counts, static_cast<uint32_t>(tsize), c->d_md_n);
+  hipLaunchKernelGGL(k_md_clear, dim3(1024), dim3(256), 0, c->stream, c->d_md_keys, c->d_md_counts, static_cast<uint32_t>(tsize), c->d_md_n,
+                     reinterpret_cast<int32_t*>(c->d_md_scratch4) + 8);
   const uint32_t cap = c->md_list_cap;
   hipLaunchKernelGGL(k_md_seed_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds);
   hipLaunchKernelGGL(k_md_compact, dim3(gridFor(tsize)), dim3(256), 0, c->stream, seeds, c->d_md_seed_keys,
                      c->d_md_seed_counts, c->d_md_n, cap, nullptr);
-  // the `near` table takes up to nn entries per seed voxel (#seed voxels <= #seed pixels); when that could fill it,
-  // the boundary test looks the neighbours up in the seed table directly
-  const int direct = static_cast<double>(nn) * c->h_pinned[0] > 0.7 * static_cast<double>(tsize) ? 1 : 0;
-  if (!direct)
-    hipLaunchKernelGGL(k_md_near_insert, dim3(256), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_n, cap, nn, near, c->d_md_n + 3);
-  hipLaunchKernelGGL(k_md_boundary_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, near, bnd, seeds, nn, direct);
+  // (whether the `near` table can hold nn entries per seed voxel is decided on the device, which knows the voxel count)
+  const int direct = 0;
+  hipLaunchKernelGGL(k_md_near_insert, dim3(256), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_n, cap, nn, near, c->d_md_n + 3,
+                     reinterpret_cast<int32_t*>(c->d_md_scratch4) + 8);
+  hipLaunchKernelGGL(k_md_boundary_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, near, bnd, seeds, nn, direct,
+                     reinterpret_cast<const int32_t*>(c->d_md_scratch4) + 8);
   hipLaunchKernelGGL(k_md_compact, dim3(gridFor(tsize)), dim3(256), 0, c->stream, bnd, c->d_md_bnd_keys, c->d_md_bnd_counts,
                      c->d_md_n + 1, cap, c->d_md_bnd_final);
+  // (the edge list shares the buffer of the lock-free path's root index: only one of the two component paths runs)
+  const uint32_t edge_cap = cap;
+  uint32_t* const d_edges = c->d_md_edges;
+  uint32_t* const d_n_edges = c->d_md_scratch4 + 15;
   hipLaunchKernelGGL(k_md_adjacency, dim3(1024), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_n, seeds, bnd, nn, cap,
-                     c->d_md_adj);
+                     c->d_md_adj, d_edges, edge_cap, d_n_edges);
   // connected components of the seed graph + their order-free summaries, on the device
   const uint32_t seed_px = std::min<uint32_t>(c->h_pinned[0], cap);  // #seed voxels <= #seed pixels
   CompAcc* d_comp_out = reinterpret_cast<CompAcc*>(reinterpret_cast<uint8_t*>(c->d_md_n) + 16);
-  hipLaunchKernelGGL(k_md_comp_lds, dim3(1), dim3(1024), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->d_md_comp_acc, c->md_lds_max);
+  hipLaunchKernelGGL(k_md_comp_lds, dim3(1), dim3(1024), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->d_md_comp_acc, c->md_lds_max,
+                     d_edges, edge_cap, d_n_edges, (c->p.dbg & 16) ? c->d_dbg : nullptr);
   if (seed_px > c->md_lds_max) {  // (#seed voxels <= #seed pixels: otherwise the single-workgroup kernel has done it)
     hipLaunchKernelGGL(k_md_comp_init, dim3(64), dim3(256), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->d_md_comp_acc,
                        c->md_lds_max);

@@ -273,12 +273,19 @@ def main():
                 flags |= ctx.PF_TRACKING  # TrackingIntegrator::updateBlocks once per tick, after all cameras
                 if out_now:
                     flags |= ctx.PF_OUTPUT
+            _t0 = time.perf_counter()
             slot, n_dyn = ctx.process_frame(sensor, frame_desc[i], True, flags)
+            _t1 = time.perf_counter()
+            host_t[0] += _t1 - _t0
             if pipe is not None:
                 # software pipeline: the tracker association of the previous frame runs on the host while this frame's
                 # kernels execute; this frame's voxel-set passes are queued behind them and collected next time
                 pipe.finish_frame()
+                _t2 = time.perf_counter()
                 pipe.launch_frame(slot, stamps[i], pose, sensor, n_dyn)
+                _t3 = time.perf_counter()
+                host_t[1] += _t2 - _t1
+                host_t[2] += _t3 - _t2
                 if last and out_now:
                     t_e = time.perf_counter()
                     n_obj, n_rm, _ = pipe.extract_inactive()
@@ -286,6 +293,7 @@ def main():
                     obj_stats[1] += n_rm
                     obj_stats[2] += time.perf_counter() - t_e
 
+    host_t = [0.0, 0.0, 0.0]  # host seconds in process_frame / finish_frame / launch_frame (incl. warm-up)
     obj_stats = [0, 0, 0.0]  # objects extracted, tracks removed, seconds spent in extraction (timed region and warm-up)
 
     def sync_all():
@@ -313,6 +321,9 @@ def main():
         if args.frame_times:
             torch.cuda.synchronize()
             ft.append((i, round(1e6 * (time.perf_counter() - tf)), ctx.stats()["n_seeds"]))
+    if os.environ.get("KHR_BENCH_HOST_TIMES") and rank == 0:
+        print("host us/frame: process_frame %.1f finish_frame %.1f launch_frame %.1f" % tuple(1e6 * t / max(1, n_total) for t in host_t),
+              file=sys.stderr)
     if args.frame_times and rank == 0:
         print("frame_times(us, seeds):", ft, file=sys.stderr)
     if pipe is not None:

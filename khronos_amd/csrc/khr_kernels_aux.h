@@ -132,7 +132,7 @@ __device__ inline uint64_t neighbourKey(uint64_t key, int k) {
 
 // lanes of a wave that hold the same voxel key (neighbouring pixels usually do) insert / count once: the table
 // slot of a large voxel would otherwise take one CAS and one atomicAdd per pixel on a single address
-__device__ inline void voxInsertCounted(const VoxTable& t, bool has, uint64_t key) {
+__device__ inline void voxInsertCounted(const VoxTable& t, bool has, uint64_t key, uint32_t* overflow = nullptr) {
   unsigned long long todo = __ballot(has);
   while (todo) {
     const int leader = __ffsll(static_cast<long long>(todo)) - 1;
@@ -143,6 +143,7 @@ __device__ inline void voxInsertCounted(const VoxTable& t, bool has, uint64_t ke
     if (static_cast<int>(laneId()) == leader) {
       const uint32_t h = voxInsert(t, lk);
       if (h != kInvalidSlot) atomicAdd(&t.counts[h], static_cast<uint32_t>(__popcll(grp)));
+      else if (overflow) atomicOr(overflow, 1u);  // table full: the host repeats the frame with the full-size tables
     }
   }
 }
@@ -161,10 +162,11 @@ __global__ __launch_bounds__(256) void k_md_clear(uint64_t* __restrict__ keys, u
   if (t0 == 7) aabb[7] = 0;                                // seed-seed edge count (k_md_adjacency)
 }
 
-__global__ __launch_bounds__(256) void k_md_seed_insert(const uint64_t* __restrict__ keys, int n, VoxTable seeds) {
+__global__ __launch_bounds__(256) void k_md_seed_insert(const uint64_t* __restrict__ keys, int n, VoxTable seeds,
+                                                       uint32_t* __restrict__ overflow) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t k = i < n ? keys[i] : ~0ull;
-  voxInsertCounted(seeds, k != ~0ull && (k & kSeedBit), k & ~kSeedBit);
+  voxInsertCounted(seeds, k != ~0ull && (k & kSeedBit), k & ~kSeedBit, overflow);
 }
 
 // every neighbour of every seed voxel -> the "near a seed" set (S * nn insertions, S is small) ...
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void k_md_near_insert(const uint64_t* __restri
 // neighbour relation is symmetric); such voxels form the boundary table with their pixel counts
 __global__ __launch_bounds__(256) void k_md_boundary_insert(const uint64_t* __restrict__ keys, int n, VoxTable near,
                                                            VoxTable bnd, VoxTable seeds, int nn, int direct,
-                                                           const int32_t* __restrict__ aabb) {
+                                                           const int32_t* __restrict__ aabb, uint32_t* __restrict__ overflow) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t k = i < n ? keys[i] : ~0ull;
   bool cand = k != ~0ull && !(k & kSeedBit);
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256) void k_md_boundary_insert(const uint64_t* __re
       for (int j = 0; j < nn && !cand; ++j) cand = voxFind(seeds, neighbourKey(k, j)) >= 0;
     }
   }
-  voxInsertCounted(bnd, cand, k);
+  voxInsertCounted(bnd, cand, k, overflow);
 }
 
 // occupied table slots -> compact lists (ids are arbitrary but stable for the rest of the frame)

@@ -173,6 +173,7 @@ struct khr_ctx {
   uint32_t md_lds_max = kCompLds;  // KHR_MD_LDS_MAX=n: seed count up to which the single-workgroup LDS labelling is used
   uint32_t md_mask = 0, md_list_cap = 0;
   uint32_t md_head_ticket = 0;      // h_pinned[8]
+  uint32_t md_last_seeds = 0;       // seed voxels of the previous seed frame (predicts which component path is needed)
   uint8_t* d_md_head_host = nullptr;  // device view of h_md_head
   uint32_t* d_md_edges = nullptr;     // seed-seed edge list of the latest seed frame (k_md_adjacency -> k_md_comp_lds)
   uint32_t* d_md_scratch4 = nullptr;  // 4 words k_publish may zero
@@ -1526,67 +1527,84 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
 
   // ---- device: seed / boundary voxel tables, compact lists, seed adjacency ------------------------
   const int nn = c->cfg.md_neighbor_connectivity;
-  // table size for THIS frame: #seed voxels <= #seed pixels (known), boundary / near voxels <= nn per seed voxel; the
-  // allocation covers the worst case (every pixel its own voxel), a typical seed frame needs 1 / 8 of it -- and the
-  // clear and the two compaction passes walk the whole table
-  uint32_t mask = c->md_mask;
-  {
-    const uint64_t need = 4ull * static_cast<uint64_t>(nn) * std::max<uint32_t>(c->h_pinned[0], 1u);
-    uint32_t ts = 1u << 14;
-    while (ts < need && ts - 1 < c->md_mask) ts <<= 1;
-    mask = std::min(ts - 1, c->md_mask);
-  }
-  const size_t tsize = static_cast<size_t>(mask) + 1;
-  VoxTable seeds{c->d_md_keys, c->d_md_counts, c->d_md_ids, mask};
-  VoxTable bnd{c->d_md_keys + tsize, c->d_md_counts + tsize, c->d_md_ids + tsize, mask};
-  VoxTable near{c->d_md_keys + 2 * tsize, c->d_md_counts + 2 * tsize, c->d_md_ids + 2 * tsize, mask};
-  hipLaunchKernelGGL(k_md_clear, dim3(1024), dim3(256), 0, c->stream, c->d_md_keys, c->d_md_counts, static_cast<uint32_t>(tsize), c->d_md_n,
-                     reinterpret_cast<int32_t*>(c->d_md_scratch4) + 8);
+  // Table size for THIS frame.  The allocation covers the worst case (every pixel its own voxel: 2 M slots at 720p), and the
+  // clear and the two compaction passes walk the whole table; a seed frame has ~20 pixels per seed voxel, so the
+  // optimistic size is 2 slots per seed PIXEL (the seed table can then never fill up).  The near / boundary tables
+  // (<= nn entries per seed voxel) may: the near table switches itself to direct mode on the device, a full boundary
+  // table raises the overflow flag and the frame is repeated with the full-size tables.  Likewise the lock-free
+  // component kernels (for more than 12 k seed voxels) are only queued when the previous seed frame came close to
+  // needing them; a frame that needs them unexpectedly is repeated.
   const uint32_t cap = c->md_list_cap;
-  hipLaunchKernelGGL(k_md_seed_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds);
-  hipLaunchKernelGGL(k_md_compact, dim3(gridFor(tsize)), dim3(256), 0, c->stream, seeds, c->d_md_seed_keys,
-                     c->d_md_seed_counts, c->d_md_n, cap, nullptr);
-  // (whether the `near` table can hold nn entries per seed voxel is decided on the device, which knows the voxel count)
-  const int direct = 0;
-  hipLaunchKernelGGL(k_md_near_insert, dim3(256), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_n, cap, nn, near, c->d_md_n + 3,
-                     reinterpret_cast<int32_t*>(c->d_md_scratch4) + 8);
-  hipLaunchKernelGGL(k_md_boundary_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, near, bnd, seeds, nn, direct,
-                     reinterpret_cast<const int32_t*>(c->d_md_scratch4) + 8);
-  hipLaunchKernelGGL(k_md_compact, dim3(gridFor(tsize)), dim3(256), 0, c->stream, bnd, c->d_md_bnd_keys, c->d_md_bnd_counts,
-                     c->d_md_n + 1, cap, c->d_md_bnd_final);
-  // (the edge list shares the buffer of the lock-free path's root index: only one of the two component paths runs)
-  const uint32_t edge_cap = cap;
-  uint32_t* const d_edges = c->d_md_edges;
-  uint32_t* const d_n_edges = c->d_md_scratch4 + 15;
-  hipLaunchKernelGGL(k_md_adjacency, dim3(1024), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_n, seeds, bnd, nn, cap,
-                     c->d_md_adj, d_edges, edge_cap, d_n_edges);
-  // connected components of the seed graph + their order-free summaries, on the device
   const uint32_t seed_px = std::min<uint32_t>(c->h_pinned[0], cap);  // #seed voxels <= #seed pixels
   CompAcc* d_comp_out = reinterpret_cast<CompAcc*>(reinterpret_cast<uint8_t*>(c->d_md_n) + 16);
-  hipLaunchKernelGGL(k_md_comp_lds, dim3(1), dim3(1024), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->d_md_comp_acc, c->md_lds_max,
-                     d_edges, edge_cap, d_n_edges, (c->p.dbg & 16) ? c->d_dbg : nullptr);
-  if (seed_px > c->md_lds_max) {  // (#seed voxels <= #seed pixels: otherwise the single-workgroup kernel has done it)
-    hipLaunchKernelGGL(k_md_comp_init, dim3(64), dim3(256), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->d_md_comp_acc,
-                       c->md_lds_max);
-    hipLaunchKernelGGL(k_md_comp_jump, dim3(64), dim3(256), 0, c->stream, c->d_md_n, cap, c->d_md_parent, c->md_lds_max);
-    hipLaunchKernelGGL(k_md_comp_union, dim3(1024), dim3(256), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->md_lds_max);
-  }
-  hipLaunchKernelGGL(k_md_comp_reduce, dim3(gridFor(seed_px)), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_seed_counts,
-                     c->d_md_bnd_keys, c->d_md_bnd_counts, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->d_md_comp_acc);
-  hipLaunchKernelGGL(k_md_comp_roots, dim3(gridFor(seed_px)), dim3(256), 0, c->stream, c->d_md_n, cap, c->d_md_parent, c->d_md_comp_acc,
-                     c->d_md_rootidx, c->d_md_n + 2, d_comp_out, kCompCap);
-  HIP_TRY(hipGetLastError());
-  // counters + the first component records -> pinned memory by a one-workgroup kernel, the host spins on the ticket
-  if (++c->md_head_ticket == 0) ++c->md_head_ticket;
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, c->stream, c->d_md_n, reinterpret_cast<uint32_t*>(c->d_md_head_host),
-                     static_cast<uint32_t>(sizeof(CompAcc) / 4), kCompHead, c->d_pinned + 8, c->md_head_ticket, c->d_md_scratch4);
-  HIP_TRY(hipGetLastError());
+  uint32_t mask = c->md_mask;
   {
-    const int rcw = waitTicket(c, 8, c->md_head_ticket, "the motion detector's component records");
-    if (rcw) return rcw;
+    uint32_t ts = 1u << 14;
+    while (ts < 2ull * std::max<uint32_t>(c->h_pinned[0], 1u) && ts - 1 < c->md_mask) ts <<= 1;
+    if (const char* e = std::getenv("KHR_MD_TABLE_LOG2")) ts = 1u << std::min(30, std::max(4, std::atoi(e)));  // test hook: forces the repeat
+    mask = std::min(ts - 1, c->md_mask);
   }
-  lap("tables + adjacency + components + head sync");
+  bool with_global = c->md_host_walk || 2u * c->md_last_seeds > c->md_lds_max || c->md_lds_max < kCompLds;
+  if (std::getenv("KHR_MD_NO_PREDICT")) with_global = false;  // test hook: the lock-free path only after a repeat
+  VoxTable seeds{}, bnd{}, near{};
   const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c->h_md_head);
+  for (int attempt = 0;; ++attempt) {
+    const size_t tsize = static_cast<size_t>(mask) + 1;
+    seeds = VoxTable{c->d_md_keys, c->d_md_counts, c->d_md_ids, mask};
+    bnd = VoxTable{c->d_md_keys + tsize, c->d_md_counts + tsize, c->d_md_ids + tsize, mask};
+    near = VoxTable{c->d_md_keys + 2 * tsize, c->d_md_counts + 2 * tsize, c->d_md_ids + 2 * tsize, mask};
+    int32_t* const d_box = reinterpret_cast<int32_t*>(c->d_md_scratch4) + 8;  // [0..5] seed voxel box, [6] direct mode, [7] edge count
+    hipLaunchKernelGGL(k_md_clear, dim3(1024), dim3(256), 0, c->stream, c->d_md_keys, c->d_md_counts, static_cast<uint32_t>(tsize), c->d_md_n, d_box);
+    hipLaunchKernelGGL(k_md_seed_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds, c->d_md_n + 3);
+    hipLaunchKernelGGL(k_md_compact, dim3(gridFor(tsize)), dim3(256), 0, c->stream, seeds, c->d_md_seed_keys,
+                       c->d_md_seed_counts, c->d_md_n, cap, nullptr);
+    // (whether the `near` table can hold nn entries per seed voxel is decided on the device, which knows the voxel count)
+    hipLaunchKernelGGL(k_md_near_insert, dim3(256), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_n, cap, nn, near, c->d_md_n + 3, d_box);
+    hipLaunchKernelGGL(k_md_boundary_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, near, bnd, seeds, nn, 0, d_box,
+                       c->d_md_n + 3);
+    hipLaunchKernelGGL(k_md_compact, dim3(gridFor(tsize)), dim3(256), 0, c->stream, bnd, c->d_md_bnd_keys, c->d_md_bnd_counts,
+                       c->d_md_n + 1, cap, c->d_md_bnd_final);
+    const uint32_t edge_cap = cap;
+    uint32_t* const d_n_edges = c->d_md_scratch4 + 15;
+    hipLaunchKernelGGL(k_md_adjacency, dim3(1024), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_n, seeds, bnd, nn, cap,
+                       c->d_md_adj, c->d_md_edges, edge_cap, d_n_edges);
+    // connected components of the seed graph + their order-free summaries, on the device
+    hipLaunchKernelGGL(k_md_comp_lds, dim3(1), dim3(1024), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->d_md_comp_acc,
+                       c->md_lds_max, c->d_md_edges, edge_cap, d_n_edges, (c->p.dbg & 16) ? c->d_dbg : nullptr);
+    if (with_global) {
+      hipLaunchKernelGGL(k_md_comp_init, dim3(64), dim3(256), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->d_md_comp_acc,
+                         c->md_lds_max);
+      hipLaunchKernelGGL(k_md_comp_jump, dim3(64), dim3(256), 0, c->stream, c->d_md_n, cap, c->d_md_parent, c->md_lds_max);
+      hipLaunchKernelGGL(k_md_comp_union, dim3(1024), dim3(256), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->md_lds_max);
+    }
+    hipLaunchKernelGGL(k_md_comp_reduce, dim3(gridFor(seed_px)), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_seed_counts,
+                       c->d_md_bnd_keys, c->d_md_bnd_counts, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->d_md_comp_acc);
+    hipLaunchKernelGGL(k_md_comp_roots, dim3(gridFor(seed_px)), dim3(256), 0, c->stream, c->d_md_n, cap, c->d_md_parent, c->d_md_comp_acc,
+                       c->d_md_rootidx, c->d_md_n + 2, d_comp_out, kCompCap);
+    HIP_TRY(hipGetLastError());
+    // counters + the first component records -> pinned memory by a one-workgroup kernel, the host spins on the ticket
+    if (++c->md_head_ticket == 0) ++c->md_head_ticket;
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, c->stream, c->d_md_n, reinterpret_cast<uint32_t*>(c->d_md_head_host),
+                       static_cast<uint32_t>(sizeof(CompAcc) / 4), kCompHead, c->d_pinned + 8, c->md_head_ticket, c->d_md_scratch4);
+    HIP_TRY(hipGetLastError());
+    {
+      const int rcw = waitTicket(c, 8, c->md_head_ticket, "the motion detector's component records");
+      if (rcw) return rcw;
+    }
+    if (attempt < 2) {
+      if (cnt[3] && mask < c->md_mask) {  // a table filled up: once more with the worst-case size
+        mask = c->md_mask;
+        continue;
+      }
+      if (cnt[0] > c->md_lds_max && !with_global) {  // more seed voxels than the single-workgroup kernel takes
+        with_global = true;
+        continue;
+      }
+    }
+    break;
+  }
+  c->md_last_seeds = cnt[0];
+  lap("tables + adjacency + components + head sync");
   const uint32_t S = cnt[0], B = cnt[1], R = cnt[2];
   if (cnt[3]) return fail(KHR_ENOMEM, "motion detector: neighbour table overflow (%u seed voxels)", S);
   if (S > cap || B > cap) return fail(KHR_ENOMEM, "motion detector: %u seed / %u boundary voxels exceed the list capacity %u", S, B, cap);

@@ -47,7 +47,8 @@ def test_sequence_tsdf_tracking(interp):
 
 @pytest.mark.parametrize("mode,sep,noise,min_size", [("lds", 2.0, 0.0, 20), ("host", 2.0, 0.0, 20), ("global", 2.0, 0.0, 20),
                                                        ("lds", 1.0, 0.01, 3), ("host", 1.0, 0.01, 3), ("global", 1.0, 0.01, 3),
-                                                       ("lds", 12.0, 0.01, 3), ("lds", 40.0, 0.005, 10)])
+                                                       ("lds", 12.0, 0.01, 3), ("lds", 40.0, 0.005, 10),
+                                                       ("repeat-tables", 2.0, 0.0, 20), ("repeat-global", 1.0, 0.01, 3)])
 def test_sequence_with_motion_detection(mode, sep, noise, min_size, monkeypatch):
     """the three ways the seed graph is clustered -- one workgroup in LDS (default), lock-free union-find in global memory
     (large seed counts; forced with KHR_MD_LDS_MAX=0) and the host walk (KHR_MD_HOST_WALK=1, and automatically whenever
@@ -56,6 +57,13 @@ def test_sequence_with_motion_detection(mode, sep, noise, min_size, monkeypatch)
         monkeypatch.setenv("KHR_MD_HOST_WALK", "1")
     if mode == "global":
         monkeypatch.setenv("KHR_MD_LDS_MAX", "0")
+    # the optimistic first attempt of a seed frame (small voxel tables, single-workgroup components only) and its repeat:
+    # tables far too small -> overflow flag -> full-size tables; more seed voxels than the LDS kernel takes -> lock-free path
+    if mode == "repeat-tables":
+        monkeypatch.setenv("KHR_MD_TABLE_LOG2", "6")
+    if mode == "repeat-global":
+        monkeypatch.setenv("KHR_MD_LDS_MAX", "8")
+        monkeypatch.setenv("KHR_MD_NO_PREDICT", "1")
     cfg, ctx, ora, s, sen, osen = make_pair(width=320, height=240, md_min_separation_distance=sep, md_min_cluster_size=min_size,
                                             stream_kw=dict(noise=noise))
     fired = 0

@@ -32,9 +32,9 @@ __global__ __launch_bounds__(256) void k_motion_pixels(DevMap m, DevParams p, De
                          min_z_world, ignore_epoch);
   if (in) keys[i] = key;
   const bool seed = (key != ~0ull) && (key & kSeedBit);
-  const unsigned long long b = __ballot(seed);
-  if (b && laneId() == static_cast<uint32_t>(__ffsll(static_cast<long long>(b)) - 1))
-    atomicAdd(&m.counters[C_N_SEEDS], static_cast<uint32_t>(__popcll(b)));
+  // seed pixels come in patches (a moving object): one counter update per workgroup, not per wave
+  const int any = __syncthreads_count(seed ? 1 : 0);
+  if (any && threadIdx.x == 0) atomicAdd(&m.counters[C_N_SEEDS], static_cast<uint32_t>(any));
 }
 
 // Small result blocks (counters + the first records) go to pinned host memory with ONE workgroup of plain stores,
@@ -247,14 +247,28 @@ __global__ __launch_bounds__(256) void k_md_boundary_insert(const uint64_t* __re
 __global__ __launch_bounds__(256) void k_md_compact(VoxTable t, uint64_t* __restrict__ list_keys,
                                                    uint32_t* __restrict__ list_counts, uint32_t* __restrict__ n_out,
                                                    uint32_t cap, int32_t* __restrict__ zero_per_entry) {
+  // one list append per WORKGROUP (workgroup scan): the entries are scattered over the table, so nearly every wave has one
+  // or two, and an append per wave was ~1000 atomics on one address (~10 us)
+  __shared__ uint32_t s_cnt[4], s_base;
   const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
   const bool used = h <= t.mask && t.keys[h] != kEmptyKey;
-  const uint32_t id = waveAggInc(n_out, used);
-  if (used && id < cap) {
-    list_keys[id] = t.keys[h];
-    list_counts[id] = t.counts[h];
-    t.ids[h] = id;
-    if (zero_per_entry) zero_per_entry[id] = 0;  // final ids of the boundary voxels start at "none" (k_md_comp_finals raises them)
+  const unsigned long long b = __ballot(used);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = static_cast<uint32_t>(__popcll(b));
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    s_base = tot ? atomicAdd(n_out, tot) : 0u;
+  }
+  __syncthreads();
+  if (used) {
+    uint32_t id = s_base + static_cast<uint32_t>(__popcll(b & ((1ull << laneId()) - 1ull)));
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) id += s_cnt[w];
+    if (id < cap) {
+      list_keys[id] = t.keys[h];
+      list_counts[id] = t.counts[h];
+      t.ids[h] = id;
+      if (zero_per_entry) zero_per_entry[id] = 0;  // final ids of the boundary voxels start at "none" (k_md_comp_finals raises them)
+    }
   }
 }
 
@@ -469,11 +483,23 @@ __global__ __launch_bounds__(256) void k_md_comp_reduce(const uint64_t* __restri
     int v[3];
     unpackKey(k, &v[0], &v[1], &v[2]);
     for (int d = 0; d < 3; ++d) lo[d] = hi[d] = v[d];
-    for (int j = 0; j < nn; ++j) {
-      const uint32_t a = adj[static_cast<size_t>(s) * nn + j];
-      if (a == 0xffffffffu || (a & 0x80000000u)) continue;
-      px += bnd_counts[a];
-      unpackKey(bnd_keys[a], &v[0], &v[1], &v[2]);
+    // two round trips instead of 2 * nn: all adjacency entries of the seed first, then the boundary records they name
+    uint32_t av[26];
+#pragma unroll
+    for (int j = 0; j < 26; ++j) av[j] = j < nn ? adj[static_cast<size_t>(s) * nn + j] : 0xffffffffu;
+    uint32_t bc[26];
+    uint64_t bk[26];
+#pragma unroll
+    for (int j = 0; j < 26; ++j) {
+      const bool is_b = av[j] != 0xffffffffu && !(av[j] & 0x80000000u);
+      bc[j] = is_b ? bnd_counts[av[j]] : 0u;
+      bk[j] = is_b ? bnd_keys[av[j]] : k;  // (the seed's own voxel: no effect on the box)
+    }
+#pragma unroll
+    for (int j = 0; j < 26; ++j) {
+      px += bc[j];
+      unpackKey(bk[j], &v[0], &v[1], &v[2]);
+#pragma unroll
       for (int d = 0; d < 3; ++d) { lo[d] = min(lo[d], v[d]); hi[d] = max(hi[d], v[d]); }
     }
   }

@@ -193,6 +193,10 @@ int khr_set_frame_image(khr_ctx* ctx, int slot, int which, const int32_t* image,
 int khr_download_frame(khr_ctx* ctx, int slot, float* range, float* vertex_map, int32_t* dynamic_image);
 /* FrameData::dynamic_image (which = 0) or FrameData::object_image (which = 1) of a slot, H*W i32 */
 int khr_download_frame_image(khr_ctx* ctx, int slot, int which, int32_t* image);
+/* The same image into a DEVICE buffer (width * height int32), asynchronously on the context stream: the operand of a
+ * broadcast when one rank of a sharded run clusters a camera's motion for all (khronos_amd/distributed.py); the
+ * receivers paint it with khr_set_frame_image(.., on_device = 1). */
+int khr_copy_frame_image(khr_ctx* ctx, int slot, int which, void* device_dst);
 
 /* -- hot path ---------------------------------------------------------------------------------- */
 /* replaces: hydra::maskNonZero + hydra::ProjectiveIntegrator::updateMap(data.input, map, allocate,

@@ -72,7 +72,7 @@ EXPORTS = [
     "khr_detect_motion", "khr_generate_mesh", "khr_reset_inactive", "khr_mark_all_inactive", "khr_clear_updated",
     "khr_allocate_blocks", "khr_object_prune", "khr_get_stats", "khr_num_blocks", "khr_block_indices",
     "khr_download_block", "khr_mesh_num_vertices", "khr_download_mesh", "khr_timing_enable", "khr_timing_reset",
-    "khr_timing_get", "khr_debug_read", "khr_tick_ingest", "khr_tick_integrate", "khr_tick_seed_counts", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_update_tracking_phase",
+    "khr_timing_get", "khr_debug_read", "khr_tick_ingest", "khr_tick_integrate", "khr_tick_seed_counts", "khr_copy_frame_image", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_update_tracking_phase",
     "khr_export_halo", "khr_import_halo", "khr_get_dynamic_clusters", "khr_motion_keys",
     "khr_detect_motion_from_keys", "khr_download_updated", "khr_mesh_halo_requests", "khr_mesh_halo_export",
     "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",
@@ -170,6 +170,7 @@ def load_library():
     lib.khr_debug_read.argtypes = [vp, vp, i64]
     lib.khr_tick_ingest.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     lib.khr_tick_seed_counts.argtypes = [vp, vp, i32]
+    lib.khr_copy_frame_image.argtypes = [vp, i32, i32, vp]
     lib.khr_tick_integrate.argtypes = [vp, vp, i32, i32, i32, i32]
     lib.khr_last_removed.argtypes = [vp, vp, i64, C.POINTER(i64)]
     lib.khr_process_frame.argtypes = [vp, C.POINTER(KhrSensor), C.POINTER(KhrFrame), i32, C.c_uint32, C.POINTER(i32)]
@@ -282,6 +283,10 @@ class FusionContext:
                                            C.c_void_p(counts_device_ptr or None)))
         return list(slots), (list(counts) if want_counts else None)
 
+    def copy_frame_image(self, slot, which, device_ptr):
+        """dynamic (0) / object (1) image of a frame slot into a device buffer (int32, W*H), asynchronously."""
+        self._chk(self.lib.khr_copy_frame_image(self.h, int(slot), int(which), C.c_void_p(device_ptr)))
+
     def tick_seed_counts(self, n):
         counts = (C.c_uint32 * n)()
         self._chk(self.lib.khr_tick_seed_counts(self.h, counts, n))
@@ -320,8 +325,10 @@ class FusionContext:
         self._chk(self.lib.khr_last_removed(self.h, _ptr(out), cap, C.byref(n)))
         return out[: n.value].copy()
 
-    def set_frame_image(self, slot, which, image):
-        if image is None:
+    def set_frame_image(self, slot, which, image, device_ptr=None):
+        if device_ptr is not None:  # device buffer (int32, W*H)
+            self._chk(self.lib.khr_set_frame_image(self.h, slot, which, C.c_void_p(device_ptr), 1))
+        elif image is None:
             self._chk(self.lib.khr_set_frame_image(self.h, slot, which, None, 0))
         else:
             image = np.ascontiguousarray(image, dtype=np.int32)

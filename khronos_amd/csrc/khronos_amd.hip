@@ -954,6 +954,24 @@ int khr_download_frame(khr_ctx* c, int slot, float* range, float* vertex_map, in
   return KHR_OK;
 }
 
+int khr_copy_frame_image(khr_ctx* c, int slot, int which, void* device_dst) {
+  if (!c || !device_dst || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad argument");
+  if (which != 0 && which != 1) return fail(KHR_EINVAL, "which must be 0 (dynamic) or 1 (object)");
+  HIP_TRY(hipSetDevice(c->device));
+  FrameSlot& s = c->slots[slot];
+  const size_t n = static_cast<size_t>(s.sensor.width) * s.sensor.height;
+  if (which == 1 && !s.has_obj) {
+    HIP_TRY(hipMemsetAsync(device_dst, 0, n * sizeof(int32_t), c->stream));
+    return KHR_OK;
+  }
+  if (which == 1) {  // painted / remapped by the object detector's stream
+    HIP_TRY(hipEventRecord(c->ev_aux_done, c->aux_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_aux_done, 0));
+  }
+  HIP_TRY(hipMemcpyAsync(device_dst, which == 0 ? s.dyn : s.obj, n * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+  return KHR_OK;
+}
+
 int khr_download_frame_image(khr_ctx* c, int slot, int which, int32_t* image) {
   if (!c || !image || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad argument");
   if (which != 0 && which != 1) return fail(KHR_EINVAL, "which must be 0 (dynamic) or 1 (object)");

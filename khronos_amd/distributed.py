@@ -56,6 +56,28 @@ class HipShard:
     def motion_finish(self, cam, slot, keys):
         return self.ctx.detect_motion_from_keys(slot, device_ptr=keys.data_ptr())
 
+    # -- one rank clusters a camera's motion for all (ShardedFusion, shard_motion) --
+    def _image_buffer(self, cam):
+        n = self.sensor.width * self.sensor.height
+        if getattr(self, "_dyn_bufs", None) is None:
+            self._dyn_bufs = {}
+        if cam not in self._dyn_bufs:
+            self._dyn_bufs[cam] = torch.zeros(n + 1, dtype=torch.int32, device=self.device)
+        return self._dyn_bufs[cam]
+
+    def dynamic_image(self, cam, slot, n_clusters):
+        """the painted dynamic image of `slot` + the cluster count in the last element (device int32 tensor)."""
+        buf = self._image_buffer(cam)
+        self.ctx.copy_frame_image(slot, 0, buf.data_ptr())
+        buf[-1:] = n_clusters
+        return buf
+
+    def image_buffer(self, cam, slot):
+        return self._image_buffer(cam)
+
+    def set_dynamic_image(self, cam, slot, img):
+        self.ctx.set_frame_image(slot, 0, None, device_ptr=img.data_ptr())
+
     def integrate(self, cam, slot, use_mask):
         self.ctx.integrate(slot, allocate_blocks=True, use_mask=use_mask)
 
@@ -96,9 +118,14 @@ class HipShard:
 
 
 class ShardedFusion:
-    def __init__(self, shard, dist=None, world_size=1, motion=True, count_device="cpu"):
+    def __init__(self, shard, dist=None, world_size=1, motion=True, count_device="cpu", shard_motion=True):
+        """shard_motion: the clustering of a camera's motion (seed graph, components, painting: the part of the detector
+        that works on the assembled key image, not on the map) runs on the camera's home rank only, which broadcasts the
+        painted dynamic image; otherwise every rank clusters every camera's identical key image."""
         self.shard, self.dist, self.world, self.motion = shard, dist, world_size, motion
         self.count_device = count_device
+        self.shard_motion = shard_motion and hasattr(shard, "dynamic_image")
+        self.rank = dist.get_rank() if (dist is not None and world_size > 1) else 0
         self._recv = None
         self.clusters_last_tick = []
 
@@ -154,11 +181,31 @@ class ShardedFusion:
             for ci, slot in enumerate(slots):
                 if cnt[ci] == 0:
                     continue  # no seeds on any rank => no clusters, empty dynamic image
+                home = ci % self.world
                 if keys[ci] is None:  # batched ingest only counted: the voxel keys are produced when somebody has seeds
                     keys[ci], _ = self.shard.motion_keys(ci, slot)
+                if not self.shard_motion:
+                    if exchange:
+                        self.dist.all_reduce(keys[ci])  # exactly one non-zero contribution per pixel
+                    self.clusters_last_tick[ci] = self.shard.motion_finish(ci, slot, keys[ci])
+                    continue
+                # the camera's home rank assembles the key image, clusters it and paints; everybody else receives the
+                # painted image (+ the cluster count in its last element) -- the clustering is the one stage of a tick
+                # that every rank would otherwise repeat for every camera
                 if exchange:
-                    self.dist.all_reduce(keys[ci])  # exactly one non-zero contribution per pixel
-                self.clusters_last_tick[ci] = self.shard.motion_finish(ci, slot, keys[ci])
+                    self.dist.reduce(keys[ci], dst=home)
+                if self.rank == home:
+                    n = self.shard.motion_finish(ci, slot, keys[ci])
+                    self.clusters_last_tick[ci] = n
+                    img = self.shard.dynamic_image(ci, slot, n) if exchange else None
+                else:
+                    img = self.shard.image_buffer(ci, slot)
+                if exchange:
+                    self.dist.broadcast(img, src=home)
+                    if self.rank != home:
+                        self.shard.set_dynamic_image(ci, slot, img[:-1])
+                        # (the count of a foreign camera is only read where that costs no device round trip)
+                        self.clusters_last_tick[ci] = int(img[-1]) if img.device.type == "cpu" else None
         if batched:
             self.shard.tick_integrate(slots, use_mask=self.motion, phases=2 if split else 3)
         else:

@@ -43,6 +43,15 @@ class OracleShard:
         self.dyn[cam] = dyn
         return n
 
+    def dynamic_image(self, cam, slot, n_clusters):
+        return torch.from_numpy(np.concatenate([self.dyn[cam].reshape(-1).astype(np.int32), np.array([n_clusters], np.int32)]))
+
+    def image_buffer(self, cam, slot):
+        return torch.zeros(self.sensor.height * self.sensor.width + 1, dtype=torch.int32)
+
+    def set_dynamic_image(self, cam, slot, img):
+        self.dyn[cam] = img.numpy().reshape(self.sensor.height, self.sensor.width).astype(np.int32)
+
     def integrate(self, cam, slot, use_mask):
         stamp, pose, depth, rgb, label = self.frames[cam]
         self.m.integrate(self.sensor, stamp, pose, depth, rgb, label, mask=self.dyn[cam] if use_mask else None)

@@ -252,7 +252,8 @@ __global__ void k_tick_begin(DevMap m, int nvox, uint32_t* band_count, uint32_t*
 // ----------------------------------------------------------------------------------------------
 __device__ inline void cullBlocks(const DevMap& m, const DevParams& p, const DevFrame& f, const uint32_t* __restrict__ work,
                                   const uint32_t* __restrict__ n_work, uint32_t* __restrict__ work_tsdf,
-                                  uint32_t* __restrict__ n_tsdf, const float* __restrict__ tile_max, int tw, int th) {
+                                  uint32_t* __restrict__ n_tsdf, const float* __restrict__ tile_max, int tw, int th,
+                                  uint32_t bid, uint32_t nblk) {
   // each workgroup tests kPerWg blocks (one wave per block, 4 rounds), gathers the survivors in LDS and
   // appends them with ONE atomic (hot-address atomics are expensive, see k_tsdf_update)
   constexpr int kPerWg = 16;
@@ -260,7 +261,7 @@ __device__ inline void cullBlocks(const DevMap& m, const DevParams& p, const Dev
   __shared__ uint32_t s_nkeep, s_off;
   const uint32_t n = *n_work;
   const uint32_t lane = threadIdx.x & 63;
-  for (uint32_t base = blockIdx.x * kPerWg; base < n; base += gridDim.x * kPerWg) {
+  for (uint32_t base = bid * kPerWg; base < n; base += nblk * kPerWg) {
   if (threadIdx.x == 0) s_nkeep = 0;
   __syncthreads();
   for (uint32_t wi = base + (threadIdx.x >> 6); wi < min(n, base + kPerWg); wi += 4) {
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256) void k_cull_blocks(DevMap m, DevParams p, DevF
                                                     const uint32_t* __restrict__ work,
                                                     uint32_t* __restrict__ work_tsdf,
                                                     const float* __restrict__ tile_max, int tw, int th) {
-  cullBlocks(m, p, f, work, &m.counters[C_N_VISIBLE], work_tsdf, &m.counters[C_N_TSDF], tile_max, tw, th);
+  cullBlocks(m, p, f, work, &m.counters[C_N_VISIBLE], work_tsdf, &m.counters[C_N_TSDF], tile_max, tw, th, blockIdx.x, gridDim.x);
 }
 
 // the cameras of a tick in one launch (blockIdx.y = camera): per-camera visible lists -> per-camera TSDF lists.
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(256) void k_tick_cull(DevMap m, DevParams p, TickFr
   const int cam = blockIdx.y;
   cullBlocks(m, p, t.f[cam], work + static_cast<size_t>(cam) * list_stride, &tick_counts[2 * cam],
              work_tsdf + static_cast<size_t>(cam) * list_stride, &tick_counts[2 * cam + 1], use_tiles ? t.tile_max[cam] : nullptr, tw,
-             th);
+             th, blockIdx.x, gridDim.x);
 }
 
 // explicit allocation of a list of block indices (VolumetricMap::allocateBlock)
@@ -392,10 +393,11 @@ __global__ __launch_bounds__(256) void k_list_live(DevMap m, uint32_t* __restric
 }
 
 // zero-initialise freshly allocated blocks.  One workgroup per block, 16-byte stores.
-__global__ __launch_bounds__(256) void k_init_blocks(DevMap m, DevParams p, const uint32_t* __restrict__ new_list) {
+__device__ inline void initBlocks(const DevMap& m, const DevParams& p, const uint32_t* __restrict__ new_list, uint32_t bid,
+                                  uint32_t nblk) {
   const uint32_t n = m.counters[C_N_NEW];
   const int nv = p.nvox;
-  for (uint32_t b = blockIdx.x; b < n; b += gridDim.x) {
+  for (uint32_t b = bid; b < n; b += nblk) {
     const size_t slot = new_list[b];
     const uint4 z = make_uint4(0, 0, 0, 0);
     uint4* d4 = reinterpret_cast<uint4*>(m.dist + slot * nv);
@@ -421,6 +423,22 @@ __global__ __launch_bounds__(256) void k_init_blocks(DevMap m, DevParams p, cons
       for (int i = threadIdx.x; i < nv / 64; i += blockDim.x) fb[i] = 0ull;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_init_blocks(DevMap m, DevParams p, const uint32_t* __restrict__ new_list) {
+  initBlocks(m, p, new_list, blockIdx.x, gridDim.x);
+}
+
+// block initialisation and culling of one frame in one launch: both only depend on the allocation pass (culling reads
+// block indices and the frame's range tiles, never voxels), and as separate launches each paid the ~5 us launch floor.
+// The first `n_cull` workgroups cull, the rest initialise.
+__global__ __launch_bounds__(256) void k_init_cull(DevMap m, DevParams p, DevFrame f, const uint32_t* __restrict__ new_list,
+                                                  const uint32_t* __restrict__ work, uint32_t* __restrict__ work_tsdf,
+                                                  const float* __restrict__ tile_max, int tw, int th, uint32_t n_cull) {
+  if (blockIdx.x < n_cull)
+    cullBlocks(m, p, f, work, &m.counters[C_N_VISIBLE], work_tsdf, &m.counters[C_N_TSDF], tile_max, tw, th, blockIdx.x, n_cull);
+  else
+    initBlocks(m, p, new_list, blockIdx.x - n_cull, gridDim.x - n_cull);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -977,12 +995,19 @@ __global__ __launch_bounds__(256) void k_tracking_select(DevMap m, uint64_t lim_
     }
   }
   const uint32_t ip = waveAggInc(&cnt[0], need);
-  if (need) proc[ip] = s;
+  if (need) {
+    proc[ip] = s;
+    // k_tracking_update works on a block in several independent pieces: they meet in these words with atomicMin / atomicOr
+    reinterpret_cast<ulonglong2*>(m.trk_lim)[s] = make_ulonglong2(~0ull, ~0ull);
+    m.blk_flags[s] = m.blk_flags[s] & ~(BLK_TRACKING_UPDATED | BLK_HAS_ACTIVE | BLK_TRACK_DIRTY);
+  }
   const uint32_t ie = waveAggInc(&cnt[1], touched);
   if (touched) ef_list[ie] = s;
 }
 
-template <int VPS>
+// CH = pieces per block (work item = one piece): a frame touches a few hundred blocks, one workgroup per block left the
+// CUs with two resident workgroups each and every phase of the pass (loads -> last_occupied loads -> stores) exposed.
+template <int VPS, int CH>
 __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, uint64_t stamp, uint64_t prev_stamp,
                                                         uint64_t lim_active, uint64_t lim_free,
                                                         const uint32_t* __restrict__ proc, const uint32_t* __restrict__ n_proc) {
@@ -991,10 +1016,10 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
   // monotone, so "toSeconds(x) >= T" is exactly "x >= lim" and the kernel needs no fp64 divisions.
   constexpr int NV = VPS * VPS * VPS;
   __shared__ uint64_t s_min[2][4];
-  const uint32_t n = *n_proc;
-  for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-    const uint32_t s = proc[i];
-    const uint32_t fl = m.blk_flags[s];
+  const uint32_t n = *n_proc * CH;
+  for (uint32_t wi = blockIdx.x; wi < n; wi += gridDim.x) {
+    const uint32_t s = proc[wi / CH];
+    const int g0 = static_cast<int>(wi % CH) * (NV / 4 / CH);  // first group of 4 voxels of this piece
     const size_t slot = s;
     // thread <-> 4 consecutive voxels: 16-byte loads of distance / flags, 2 x 16-byte of the stamps
     const float4* __restrict__ dist4 = reinterpret_cast<const float4*>(m.dist + slot * NV);
@@ -1007,15 +1032,16 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
     // A block is 1024 groups of 4 voxels = 4 groups per thread (VPS 16).  All loads of a round are issued before the
     // first use: the pass is latency bound (one workgroup per touched block, a few dependent round trips each), so the
     // 4 x 52 B of distance / last_observed / flags travel together, then the last_occupied pairs that are needed.
-    constexpr int G = NV / 4 / 256 > 0 ? NV / 4 / 256 : 1;
+    constexpr int G = NV / 4 / CH / 256 > 0 ? NV / 4 / CH / 256 : 1;
+    constexpr int GEND = NV / 4 / CH;  // groups per piece
     float4 d_[G];
     ulonglong2 oa_[G], ob_[G], ca_[G], cb_[G];
     uint32_t v4_[G];
     uint32_t need_[G];
 #pragma unroll
     for (int q = 0; q < G; ++q) {
-      const int g = threadIdx.x + 256 * q;
-      if (g < NV / 4) {
+      const int gl = threadIdx.x + 256 * q, g = g0 + gl;
+      if (gl < GEND) {
         d_[q] = dist4[g];
         oa_[q] = lobs2[2 * g];
         ob_[q] = lobs2[2 * g + 1];
@@ -1024,11 +1050,11 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
     }
 #pragma unroll
     for (int q = 0; q < G; ++q) {
-      const int g = threadIdx.x + 256 * q;
+      const int gl = threadIdx.x + 256 * q, g = g0 + gl;
       need_[q] = 0u;
       ca_[q] = make_ulonglong2(0ull, 0ull);
       cb_[q] = ca_[q];
-      if (g < NV / 4) {
+      if (gl < GEND) {
         const float dd[4] = {d_[q].x, d_[q].y, d_[q].z, d_[q].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1043,8 +1069,8 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
     }
 #pragma unroll
     for (int q = 0; q < G; ++q) {
-      const int g = threadIdx.x + 256 * q;
-      if (g >= NV / 4) continue;
+      const int gl = threadIdx.x + 256 * q, g = g0 + gl;
+      if (gl >= GEND) continue;
       const uint32_t v4 = v4_[q];
       const float dd[4] = {d_[q].x, d_[q].y, d_[q].z, d_[q].w};
       const uint64_t lo[4] = {oa_[q].x, oa_[q].y, ob_[q].x, ob_[q].y};
@@ -1107,9 +1133,11 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
         a = s_min[0][w] < a ? s_min[0][w] : a;
         f = s_min[1][w] < f ? s_min[1][w] : f;
       }
-      reinterpret_cast<ulonglong2*>(m.trk_lim)[s] = make_ulonglong2(a, f);
-      const uint32_t nf = (fl & ~(BLK_TRACKING_UPDATED | BLK_HAS_ACTIVE | BLK_TRACK_DIRTY)) | (act ? BLK_HAS_ACTIVE : 0u);
-      m.blk_flags[s] = nf;
+      // (k_tracking_select reset the two thresholds to ~0 and cleared the flags of this block)
+      unsigned long long* lim = reinterpret_cast<unsigned long long*>(m.trk_lim) + 2 * static_cast<size_t>(s);
+      if (a != ~0ull) atomicMin(&lim[0], static_cast<unsigned long long>(a));
+      if (f != ~0ull) atomicMin(&lim[1], static_cast<unsigned long long>(f));
+      if (act) atomicOr(&m.blk_flags[s], BLK_HAS_ACTIVE);
     }
     __syncthreads();  // s_min is reused by the next block of this workgroup
   }

@@ -1001,9 +1001,8 @@ static int integrateAlloc(khr_ctx* c, FrameSlot& s, const DevFrame& f, int alloc
     hipLaunchKernelGGL(k_alloc_visible, dim3(gridFor(total)), dim3(256), 0, c->stream, m, c->p, f, fr, c->d_work, c->d_new,
                        c->d_pinned + 2, c->seed_publish_pending ? c->seed_ticket : 0u, &m.counters[C_N_VISIBLE], 0);
     c->seed_publish_pending = false;
-    hipLaunchKernelGGL(k_init_blocks, dim3(2048), dim3(256), 0, c->stream, m, c->p, c->d_new);
-    hipLaunchKernelGGL(k_cull_blocks, dim3(1024), dim3(256), 0, c->stream, m, c->p, f, c->d_work, c->d_work_tsdf,
-                       c->cfg.disable_culling ? nullptr : s.tile_max, s.tw, s.th);
+    hipLaunchKernelGGL(k_init_cull, dim3(1024 + 1024), dim3(256), 0, c->stream, m, c->p, f, c->d_new, c->d_work, c->d_work_tsdf,
+                       c->cfg.disable_culling ? nullptr : s.tile_max, s.tw, s.th, 1024u);
     c->host_index_valid = false;
   } else {
     hipLaunchKernelGGL(k_list_live, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_work,
@@ -1151,8 +1150,8 @@ static int trackingPhase(khr_ctx* c, uint64_t stamp, int phase) {
       const int force_full = stamp < c->last_track_stamp || c->cfg.disable_culling ? 1 : 0;
       hipLaunchKernelGGL(k_tracking_select, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, lim_active, lim_free, force_full,
                          c->d_trk_proc, c->d_ef, cnt, cnt_next);
-      hipLaunchKernelGGL((k_tracking_update<V>), dim3(1024), dim3(256), 0, c->stream, m, c->p, stamp, c->last_track_stamp, lim_active,
-                         lim_free, c->d_trk_proc, cnt);
+      hipLaunchKernelGGL((k_tracking_update<V, (V == 16 ? 4 : 1)>), dim3(V == 16 ? 4096 : 1024), dim3(256), 0, c->stream, m, c->p, stamp,
+                         c->last_track_stamp, lim_active, lim_free, c->d_trk_proc, cnt);
       c->last_track_stamp = stamp;
     }
     if (phase & 2) {

@@ -1248,6 +1248,8 @@ int khr_tick_ingest(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame
       const khr_frame& fr = frames[base + k];
       const int slot = acquireSlot(c);
       if (slot < 0) return slot;
+      for (int j = 0; j < base + k; ++j)  // the ring wrapped around retained slots: this tick would overwrite itself
+        if (slots_out[j] == slot) return fail(KHR_ENOMEM, "not enough free frame slots for a tick of %d frames (raise num_frame_slots)", n_frames);
       FrameSlot& s = c->slots[slot];
       s.sensor = *sensor;
       s.meta = fr;
@@ -1317,8 +1319,11 @@ int khr_tick_seed_counts(khr_ctx* c, uint32_t* n_seed_pixels, int n_frames) {
 int khr_tick_integrate(khr_ctx* c, const int* slots, int n_frames, int use_mask, int object_id, int phases) {
   if (!c || !slots || n_frames < 1 || (phases & 3) == 0) return fail(KHR_EINVAL, "bad argument");
   if ((phases & 3) != 3 && n_frames > kMaxTick) return fail(KHR_EINVAL, "split phases take at most %d frames", kMaxTick);
-  for (int i = 0; i < n_frames; ++i)
+  for (int i = 0; i < n_frames; ++i) {
     if (slots[i] < 0 || slots[i] >= static_cast<int>(c->slots.size()) || !c->slots[slots[i]].valid) return fail(KHR_EINVAL, "bad slot");
+    const khr_sensor &a = c->slots[slots[i]].sensor, &b = c->slots[slots[0]].sensor;
+    if (a.width != b.width || a.height != b.height) return fail(KHR_EINVAL, "the frames of a tick must come from sensors of one image size");
+  }
   HIP_TRY(hipSetDevice(c->device));
   int rc = ensureTick(c);
   if (rc) return rc;

@@ -148,7 +148,7 @@ struct khr_ctx {
   hipEvent_t ev_seed = nullptr;
   uint32_t last_removed = 0;
   khr_ctx* dep_src = nullptr;     // khr_depend_on: this context's stream already waits for that context's earlier work
-  hipEvent_t ev_dep = nullptr;
+  hipEvent_t ev_dep = nullptr, ev_dep_aux = nullptr;
   uint64_t last_track_stamp = 0;  // stamp of the latest tracking pass = last_occupied of every VOX_OCC voxel
   bool removed_pending = false;
   int4* d_removed = nullptr;
@@ -173,6 +173,8 @@ struct khr_ctx {
   uint32_t md_lds_max = kCompLds;  // KHR_MD_LDS_MAX=n: seed count up to which the single-workgroup LDS labelling is used
   uint32_t md_mask = 0, md_list_cap = 0;
   uint32_t md_head_ticket = 0;      // h_pinned[8]
+  bool md_defer_summary = false;    // clusterSummaryLaunch only notes the request (md_summary_pending = largest id)
+  int md_summary_pending = -1;
   uint32_t md_last_seeds = 0;       // seed voxels of the previous seed frame (predicts which component path is needed)
   uint8_t* d_md_head_host = nullptr;  // device view of h_md_head
   uint32_t* d_md_edges = nullptr;     // seed-seed edge list of the latest seed frame (k_md_adjacency -> k_md_comp_lds)
@@ -513,9 +515,12 @@ int khr_depend_on(khr_ctx* c, khr_ctx* other) {
   if (!c || !other) return fail(KHR_EINVAL, "null ctx");
   if (c->device != other->device) return fail(KHR_EINVAL, "contexts live on different devices");
   HIP_TRY(hipSetDevice(c->device));
+  // (events owned by the DEPENDENT context: khr_depend_on may be called from a worker thread while the other context's
+  // own thread keeps using its events)
+  if (!c->ev_dep_aux) HIP_TRY(hipEventCreateWithFlags(&c->ev_dep_aux, hipEventDisableTiming));
   if (c->stream == other->stream) {
-    HIP_TRY(hipEventRecord(other->ev_aux_done, other->aux_stream));
-    HIP_TRY(hipStreamWaitEvent(c->stream, other->ev_aux_done, 0));
+    HIP_TRY(hipEventRecord(c->ev_dep_aux, other->aux_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_dep_aux, 0));
     c->dep_src = other;
     return KHR_OK;
   }
@@ -523,8 +528,8 @@ int khr_depend_on(khr_ctx* c, khr_ctx* other) {
   HIP_TRY(hipEventRecord(c->ev_dep, other->stream));
   HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_dep, 0));
   // ... and behind its object detector (the object images of its frame slots)
-  HIP_TRY(hipEventRecord(other->ev_aux_done, other->aux_stream));
-  HIP_TRY(hipStreamWaitEvent(c->stream, other->ev_aux_done, 0));
+  HIP_TRY(hipEventRecord(c->ev_dep_aux, other->aux_stream));
+  HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_dep_aux, 0));
   c->dep_src = other;
   return KHR_OK;
 }
@@ -805,6 +810,7 @@ void khr_destroy(khr_ctx* c) {
   }
   if (c->ev_seed) hipEventDestroy(c->ev_seed);
   if (c->ev_dep) hipEventDestroy(c->ev_dep);
+  if (c->ev_dep_aux) hipEventDestroy(c->ev_dep_aux);
   if (c->ev_aux) hipEventDestroy(c->ev_aux);
   if (c->ev_aux_done) hipEventDestroy(c->ev_aux_done);
   if (c->aux_stream) hipStreamDestroy(c->aux_stream);
@@ -1520,6 +1526,10 @@ static int waitTicket(khr_ctx* c, int word, uint32_t ticket, const char* what, h
 // per-cluster summaries (pixel count, AABB, vertex sum) of the freshly painted dynamic image, queued behind the paint pass
 // and published to pinned memory; khr_get_dynamic_clusters only has to wait for the ticket
 static int clusterSummaryLaunch(khr_ctx* c, FrameSlot& s, int max_id) {
+  if (c->md_defer_summary) {  // khr_process_frame queues the update kernels first: nothing on the frame's critical path reads the summaries
+    c->md_summary_pending = max_id;
+    return KHR_OK;
+  }
   const int tiles = ((s.sensor.width + kAccTile - 1) / kAccTile) * ((s.sensor.height + kAccTile - 1) / kAccTile);
   hipLaunchKernelGGL(k_cluster_summary, dim3(tiles), dim3(1024), 0, c->stream, makeDevFrame(c, s), s.dyn, c->d_md_acc);
   if (++c->md_acc_ticket == 0) ++c->md_acc_ticket;
@@ -2494,12 +2504,20 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   if ((rc = integrateAlloc(c, s, f, 1))) return rc;
   // (3) host looks at the seed count (clusters only exist when there are seeds)
   if (motion) {
+    c->md_defer_summary = true;
+    c->md_summary_pending = -1;
     const int nc = motionFinish(c, s);
+    c->md_defer_summary = false;
     if (nc < 0) return nc;
     if (n_clusters) *n_clusters = nc;
   }
   // (4) TSDF / label update with the dynamic mask, tracking + ever-free
   if ((rc = integrateUpdate(c, s, f, 1, motion ? 1 : 0, -1))) return rc;
+  if (c->md_summary_pending >= 0) {  // the dynamic clusters' summaries, behind the update kernels
+    const int pend = c->md_summary_pending;
+    c->md_summary_pending = -1;
+    if ((rc = clusterSummaryLaunch(c, s, pend))) return rc;
+  }
   if ((flags & KHR_PF_TRACKING) && (rc = khr_update_tracking(c, frame->timestamp_ns))) return rc;
   // (5) output cadence (ActiveWindow::extractOutputData, active_window.cpp:217-249 + :169-171)
   if (flags & KHR_PF_OUTPUT) {

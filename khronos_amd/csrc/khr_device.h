@@ -250,6 +250,26 @@ __device__ inline void publishSeedCount(const DevMap& m, volatile uint32_t* host
   __threadfence_system();
 }
 
+constexpr int kBandShards = 16;  // the in-band record list is split in shards (one atomic cursor each)
+
+// per-call counter reset; the previous call's statistics are folded into cumulative totals so that a
+// benchmark can read N_upd / N_band sums once, outside its timed region.
+__device__ inline void beginIntegrate(DevMap m, int nvox, uint32_t* band_count) {
+  if (threadIdx.x < kBandShards) band_count[threadIdx.x * 32] = 0u;
+  if (threadIdx.x == 0) {
+    m.stats[S_CUM_UPD] += m.stats[S_UPD];
+    m.stats[S_CUM_BAND] += m.stats[S_BAND];
+    m.stats[S_CUM_VISITED] += static_cast<unsigned long long>(m.counters[C_N_VISIBLE]) * nvox;
+    m.stats[S_CUM_CALLS] += 1ull;
+    m.stats[S_UPD] = 0ull;
+    m.stats[S_BAND] = 0ull;
+    m.counters[C_N_VISIBLE] = 0u;
+    m.counters[C_N_NEW] = 0u;
+    m.counters[C_N_TSDF] = 0u;
+    m.counters[C_TSDF_CURSOR] = 0u;
+  }
+}
+
 // ---- lock-free union-find on compact node ids (object detector, motion-cluster components) ----------------------
 // ECL-CC style (Jaiganesh & Burtscher): parents only ever decrease, a find halves the path it walks (each step
 // re-points a node at its grandparent, which is still an ancestor whatever other threads do), and a union hooks

@@ -23,7 +23,11 @@ constexpr uint64_t kSeedBit = kSeedFlag;
 // (nested hash maps) are grouped by the device voxel hash tables below (k_md_*).
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_motion_pixels(DevMap m, DevParams p, DevFrame f, float md_max_range,
-                                                      float min_z_world, uint64_t* __restrict__ keys, int ignore_epoch) {
+                                                      float min_z_world, uint64_t* __restrict__ keys, int ignore_epoch,
+                                                      uint32_t* __restrict__ begin_band_count) {
+  // khr_process_frame with the ingest on the auxiliary stream: the per-frame counter reset rides here (first kernel of the
+  // frame on the main stream; the allocation pass, which uses the counters, comes next)
+  if (begin_band_count && blockIdx.x == 0) beginIntegrate(m, p.nvox, begin_band_count);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in = i < f.W * f.H;
   uint64_t key = ~0ull;

@@ -5,7 +5,6 @@
 
 namespace khr {
 
-constexpr int kBandShards = 16;  // the in-band record list is split in shards (one atomic cursor each)
 
 // ----------------------------------------------------------------------------------------------
 // k_frame_ingest: hydra::conversions::parseInputPacket + FrameData allocation role
@@ -16,7 +15,6 @@ constexpr int kBandShards = 16;  // the in-band record list is split in shards (
 // ----------------------------------------------------------------------------------------------
 constexpr int kTile = 16;
 constexpr int kMaxTick = 8;  // camera frames batched per launch in the tick path (khr_tick_*)
-__device__ inline void beginIntegrate(DevMap m, int nvox, uint32_t* band_count);
 
 // one 16x16-pixel tile of one frame; returns this thread's (depth, range) for callers that go on with the pixel
 __device__ inline void ingestTile(const float* __restrict__ depth_in, const uint8_t* __restrict__ rgb_in,
@@ -213,23 +211,6 @@ __global__ __launch_bounds__(256) void k_alloc_visible(DevMap m, DevParams p, De
   if (list_count != &m.counters[C_N_VISIBLE]) waveAggInc(&m.counters[C_N_VISIBLE], emit);
 }
 
-// per-call counter reset; the previous call's statistics are folded into cumulative totals so that a
-// benchmark can read N_upd / N_band sums once, outside its timed region.
-__device__ inline void beginIntegrate(DevMap m, int nvox, uint32_t* band_count) {
-  if (threadIdx.x < kBandShards) band_count[threadIdx.x * 32] = 0u;
-  if (threadIdx.x == 0) {
-    m.stats[S_CUM_UPD] += m.stats[S_UPD];
-    m.stats[S_CUM_BAND] += m.stats[S_BAND];
-    m.stats[S_CUM_VISITED] += static_cast<unsigned long long>(m.counters[C_N_VISIBLE]) * nvox;
-    m.stats[S_CUM_CALLS] += 1ull;
-    m.stats[S_UPD] = 0ull;
-    m.stats[S_BAND] = 0ull;
-    m.counters[C_N_VISIBLE] = 0u;
-    m.counters[C_N_NEW] = 0u;
-    m.counters[C_N_TSDF] = 0u;
-    m.counters[C_TSDF_CURSOR] = 0u;
-  }
-}
 __global__ void k_begin_integrate(DevMap m, int nvox, uint32_t* band_count) {
   if (blockIdx.x == 0) beginIntegrate(m, nvox, band_count);
 }

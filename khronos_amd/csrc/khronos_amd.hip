@@ -66,7 +66,7 @@ struct FrameSlot {
   khr_frame meta{};
   bool valid = false, has_color = false, has_label = false, has_obj = false, objects_done = false;
   bool dyn_clean = false;  // the dynamic image is all zero (fresh from ingest, nothing painted yet)
-  bool aux_used = false;   // kernels of the auxiliary stream have read / written this slot since its ingest
+  uint64_t aux_seq = 0;    // sequence number of the last auxiliary-stream batch that read / wrote this slot (0 = none)
   std::vector<khr_cluster> sem_clusters;  // semantic clusters of the frame in this slot (khr_detect_objects)
   std::vector<khr_cluster> clusters;  // dynamic clusters of the frame in this slot (ids, listed pixel counts)
 };
@@ -95,6 +95,9 @@ struct khr_ctx {
   // it has to be (the frame's ingest, a painted dynamic image), ev_aux_done orders consumers of the object image behind it.
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_aux = nullptr, ev_aux_done = nullptr;
+  // batches queued on the auxiliary stream are numbered; aux_seq_done = the latest one the host KNOWS to be complete
+  // (a ticket it waited for, an idle stream): a frame slot is only re-ingested when its last batch is
+  uint64_t aux_seq_issued = 0, aux_seq_done = 0, obj_seq = 0, cv_seq[2] = {0, 0};
   std::vector<void*> allocs;
   std::vector<FrameSlot> slots;
   int next_slot = 0;
@@ -144,6 +147,8 @@ struct khr_ctx {
   bool seed_publish_pending = false;
   bool seed_by_ticket = false;   // motionFinish waits for the ticket (k_motion_pixels) instead of ev_seed (key import)
   bool begin_in_ingest = false, begun = false;  // khr_process_frame folds k_begin_integrate into k_frame_ingest
+  hipStream_t ingest_stream = nullptr;           // khr_process_frame: ingest on the auxiliary stream (set around khr_upload_frame)
+  bool early_ingest = true;                      // env KHR_NO_EARLY_INGEST=1 turns it off
   int ef_parity = 0, ef_cur = 0;  // which of C_N_EF / C_N_EF2 the next / the latest tracking pass fills
   hipEvent_t ev_seed = nullptr;
   uint32_t last_removed = 0;
@@ -246,7 +251,7 @@ struct ScopedTimer {
   hipEvent_t a = nullptr, b = nullptr;
   bool on = false;
   ScopedTimer(khr_ctx* ctx, int w) : c(ctx), which(w) {
-    on = (c->timing >> w) & 1u;
+    on = w >= 0 && ((c->timing >> w) & 1u);
     if (on) {
       auto get = [&]() {
         hipEvent_t e = nullptr;
@@ -644,6 +649,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   p.dbg = std::getenv("KHR_DEBUG") ? std::atoi(std::getenv("KHR_DEBUG")) : 0;
   if (std::getenv("KHR_TSDF_GRID")) kTsdfGrid = std::min(16384, std::atoi(std::getenv("KHR_TSDF_GRID")));
   if (std::getenv("KHR_TSDF_CHUNKS")) kTsdfChunks = std::atoi(std::getenv("KHR_TSDF_CHUNKS"));
+  if (std::getenv("KHR_NO_EARLY_INGEST")) c->early_ingest = false;
 
   DevMap& m = c->m;
   const size_t cap = cfg->max_blocks, nv = p.nvox;
@@ -860,10 +866,12 @@ static int acquireSlot(khr_ctx* c) {
   }
   if (slot < 0) return fail(KHR_ENOMEM, "all %d frame slots are retained (raise num_frame_slots)", n_slots);
   c->next_slot = (slot + 1) % n_slots;
-  if (c->slots[slot].aux_used) {  // the object detector may still be reading the previous occupant (tiny rings only)
+  if (c->slots[slot].aux_seq > c->aux_seq_done) {  // the auxiliary stream may still be reading the previous occupant (tiny rings only)
+    const uint64_t upto = c->aux_seq_issued;
     if (hipStreamQuery(c->aux_stream) != hipSuccess) HIP_TRY(hipStreamSynchronize(c->aux_stream));
-    c->slots[slot].aux_used = false;
+    c->aux_seq_done = upto;
   }
+  c->slots[slot].aux_seq = 0;
   return slot;
 }
 
@@ -892,7 +900,8 @@ int khr_upload_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fram
   s.objects_done = false;
   s.clusters.clear();
   s.sem_clusters.clear();
-  ScopedTimer tm(c, 6);
+  hipStream_t ist = (on_device && c->ingest_stream) ? c->ingest_stream : c->stream;
+  ScopedTimer tm(c, ist == c->stream ? 6 : -1);
   const float* depth_src = frame->depth;
   const uint8_t* rgb_src = frame->color;
   const int32_t* label_src = frame->label;
@@ -910,7 +919,7 @@ int khr_upload_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fram
   }
   s.tw = (sensor->width + kTile - 1) / kTile;
   s.th = (sensor->height + kTile - 1) / kTile;
-  hipLaunchKernelGGL(k_frame_ingest, dim3(s.tw * s.th), dim3(256), 0, c->stream, depth_src, rgb_src, label_src, s.depth,
+  hipLaunchKernelGGL(k_frame_ingest, dim3(s.tw * s.th), dim3(256), 0, ist, depth_src, rgb_src, label_src, s.depth,
                      s.range, s.rgba, s.label, s.dyn, s.tile_max, s.tw, sensor->width, sensor->height, sensor->fx, sensor->fy,
                      sensor->cx, sensor->cy, c->p.range_mode, c->m, c->p.nvox, c->d_band_count, c->begin_in_ingest ? 1 : 0);
   HIP_TRY(hipGetLastError());
@@ -1450,7 +1459,7 @@ int khr_import_halo(khr_ctx* c, const void* records, int64_t n_records, int on_d
 // ---------------------------------------------------------------------------------------------
 // motion detection, part 1: per-pixel pass; the seed-pixel count travels to pinned host memory
 // asynchronously so that other kernels can be queued behind it before the host has to look at it
-static int motionLaunch(khr_ctx* c, FrameSlot& s, bool fresh_slot) {
+static int motionLaunch(khr_ctx* c, FrameSlot& s, bool fresh_slot, bool do_begin = false) {
   const size_t n = static_cast<size_t>(s.sensor.width) * s.sensor.height;
   if (!fresh_slot) {  // a slot that was just ingested already has a zero dynamic image and seed counter
     if (!s.dyn_clean) HIP_TRY(hipMemsetAsync(s.dyn, 0, n * sizeof(int32_t), c->stream));
@@ -1469,7 +1478,8 @@ static int motionLaunch(khr_ctx* c, FrameSlot& s, bool fresh_slot) {
     ++c->seed_ticket;
     if (c->seed_ticket == 0) ++c->seed_ticket;
     hipLaunchKernelGGL(k_motion_pixels, dim3(gridFor(n)), dim3(256), 0, c->stream, m, c->p, f, c->cfg.md_max_range,
-                       min_z_world, c->d_keys, c->motion_ignore_epoch);
+                       min_z_world, c->d_keys, c->motion_ignore_epoch, do_begin ? c->d_band_count : nullptr);
+    if (do_begin) c->begun = true;
   }
   HIP_TRY(hipGetLastError());
   c->seed_by_ticket = true;
@@ -2057,7 +2067,7 @@ static int objectsLaunch(khr_ctx* c, int slot) {
   s.sem_clusters.clear();
   s.objects_done = false;
   s.has_obj = true;
-  s.aux_used = true;
+  s.aux_seq = c->obj_seq = ++c->aux_seq_issued;
   c->obj_pending_slot = -1;
   const int n_labels = static_cast<int>(c->obj_labels.size());
   if (!s.has_label || n_labels == 0) {
@@ -2118,6 +2128,7 @@ static int objectsFinish(khr_ctx* c, int slot) {
   {
     const int rcw = waitTicket(c, 4, c->obj_ticket, "the object detector's cluster records", c->aux_stream);
     if (rcw) return rcw;
+    c->aux_seq_done = std::max(c->aux_seq_done, c->obj_seq);
   }
   const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c->h_obj_head);
   if (cnt[1] & 1u) return fail(KHR_EINVAL, "object detector: a measured point lies more than %d grid cells from the sensor", kGvWindow);
@@ -2217,7 +2228,7 @@ int khr_cluster_voxels_launch(khr_ctx* c, int slot, int which, float voxel_size)
     rc = auxAfterMain(c);
     if (rc) return rc;
   }
-  s.aux_used = true;
+  s.aux_seq = c->cv_seq[which] = ++c->aux_seq_issued;
   c->cv_origin[which] = windowOrigin(f, inv);
   GvTable t{c->d_gv_keys, c->gv_mask};
   const uint32_t tsize = c->gv_mask + 1;
@@ -2245,6 +2256,7 @@ int64_t khr_cluster_voxels_fetch(khr_ctx* c, int which, int32_t* ids_out, int64_
   if (c->cv_pending_slot[which] < 0) return fail(KHR_ESTATE, "khr_cluster_voxels_launch has not been called");
   {
     const int rcw = waitTicket(c, 5 + which, c->cv_ticket[which], "the cluster voxel sets", c->aux_stream);
+    if (!rcw) c->aux_seq_done = std::max(c->aux_seq_done, c->cv_seq[which]);
     if (rcw) return rcw;
   }
   const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c->h_cv[which]);
@@ -2482,24 +2494,37 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
                       int* n_clusters) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
   if (n_clusters) *n_clusters = 0;
-  c->begin_in_ingest = true;
+  const bool motion = (flags & KHR_PF_MOTION) != 0;
+  const bool objects = (flags & KHR_PF_OBJECTS) != 0;
+  // The ingest only writes the frame slot, so it runs on the auxiliary stream: queued as soon as this call starts, it
+  // executes beside the tail of the previous frame (tracking, ever-free, output) instead of after it.  Only with the
+  // motion detector on: its per-frame host wait is what keeps the host from queueing frames whose slot an earlier
+  // frame still reads.  The per-frame counter reset moves to the first main-stream kernel (k_motion_pixels).
+  const bool early = c->early_ingest && on_device && motion && c->cfg.with_tracking && c->slots.size() >= 2;
+  c->begin_in_ingest = !early;
+  c->ingest_stream = early ? c->aux_stream : nullptr;
   const int slot = khr_upload_frame(c, sensor, frame, on_device);
+  c->ingest_stream = nullptr;
   c->begin_in_ingest = false;
   if (slot < 0) return slot;
   FrameSlot& s = c->slots[slot];
   const DevFrame f = makeDevFrame(c, s);
-  const bool motion = (flags & KHR_PF_MOTION) != 0;
-  const bool objects = (flags & KHR_PF_OBJECTS) != 0;
   int rc = KHR_OK;
+  if (early) {
+    c->begun = false;
+    s.aux_seq = ++c->aux_seq_issued;
+    HIP_TRY(hipEventRecord(c->ev_aux_done, c->aux_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_aux_done, 0));
+  }
   // (0) object detection kernels first (they only read the frame): their cluster records reach the host while the
   //     volumetric kernels run, and are looked at in (6)
   if (objects) {
     if (!c->obj_configured) return fail(KHR_ESTATE, "KHR_PF_OBJECTS needs khr_configure_object_detector");
-    if ((rc = auxAfterMain(c))) return rc;  // behind this frame's ingest, beside everything that follows
+    if (!early && (rc = auxAfterMain(c))) return rc;  // behind this frame's ingest (early: same stream, in order)
     if ((rc = objectsLaunch(c, slot))) return rc;
   }
   // (1) per-pixel motion pass; its seed count comes back asynchronously ...
-  if (motion && (rc = motionLaunch(c, s, true))) return rc;
+  if (motion && (rc = motionLaunch(c, s, true, early))) return rc;
   // (2) ... while block allocation / culling, which do not depend on the dynamic mask, keep the GPU busy
   if ((rc = integrateAlloc(c, s, f, 1))) return rc;
   // (3) host looks at the seed count (clusters only exist when there are seeds)

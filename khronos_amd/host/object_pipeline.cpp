@@ -14,6 +14,7 @@
 #include <thread>
 
 #include "active_window.h"
+#include "ray_verificator.h"
 
 using namespace khronos;
 
@@ -285,6 +286,30 @@ int kop_get_tracks(kop_handle* h, int64_t* out /* 8 per track */, int cap) {
     ++n;
   }
   return n;
+}
+
+// RayChangeDetector::detectChanges for bindings that do not go through the C++ class (and for the CPU tests): one point's
+// presence / absence observations -> out[0] = closest_absent, out[1] = furthest_persistent; return value bit 0 / bit 1 =
+// which of the two exist, < 0 on a bad configuration.
+int khr_host_detect_changes(const uint64_t* present, int64_t n_present, const uint64_t* absent, int64_t n_absent,
+                            float temporal_resolution, int64_t window_size, int use_relative_confidence, float absence_confidence,
+                            float presence_confidence, int forward, uint64_t* out) {
+  if ((n_present > 0 && !present) || (n_absent > 0 && !absent) || n_present < 0 || n_absent < 0 || !out || window_size < 0) return KHR_EINVAL;
+  try {
+    khronos::RayChangeDetector::Config cfg;
+    cfg.temporal_resolution = temporal_resolution;
+    cfg.window_size = static_cast<size_t>(window_size);
+    cfg.use_relative_confidence = use_relative_confidence != 0;
+    cfg.absence_confidence = absence_confidence;
+    cfg.presence_confidence = presence_confidence;
+    const khronos::RayChangeDetector det(cfg);
+    const auto r = det.detectChanges(present, static_cast<size_t>(n_present), absent, static_cast<size_t>(n_absent), forward != 0);
+    out[0] = r.closest_absent.value_or(0);
+    out[1] = r.furthest_persistent.value_or(0);
+    return (r.closest_absent ? 1 : 0) | (r.furthest_persistent ? 2 : 0);
+  } catch (const std::exception&) {
+    return KHR_EINVAL;
+  }
 }
 
 }  // extern "C"

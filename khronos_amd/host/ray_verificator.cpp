@@ -147,4 +147,87 @@ RayVerificator::CheckResult RayVerificator::check(const float* point, uint64_t e
   return checkMany({point[0], point[1], point[2]}, {earliest}, {latest})[0];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// RayChangeDetector (ray_change_detector.cpp)
+// ---------------------------------------------------------------------------------------------------------------------
+RayChangeDetector::Config RayChangeDetector::Config::fromYaml(const khronos_amd::YamlNode& m) {
+  Config c;
+  m.read("verbosity", c.verbosity);
+  m.read("temporal_resolution", c.temporal_resolution);
+  int w = static_cast<int>(c.window_size);
+  m.read("window_size", w);
+  if (w < 0) throw std::invalid_argument("window_size must be > 0");
+  c.window_size = static_cast<size_t>(w);
+  m.read("use_relative_confidence", c.use_relative_confidence);
+  m.read("absence_confidence", c.absence_confidence);
+  m.read("presence_confidence", c.presence_confidence);
+  return c;
+}
+
+void RayChangeDetector::Config::checkValid() const {  // ray_change_detector.cpp:51-60
+  if (!(temporal_resolution > 0.f)) throw std::invalid_argument("RayChangeDetector: temporal_resolution must be > 0");
+  if (!(window_size > 0)) throw std::invalid_argument("RayChangeDetector: window_size must be > 0");
+  if (use_relative_confidence) {
+    if (!(absence_confidence >= 0.f && absence_confidence <= 1.f)) throw std::invalid_argument("RayChangeDetector: absence_confidence must be in [0, 1]");
+    if (!(presence_confidence >= 0.f && presence_confidence <= 1.f)) throw std::invalid_argument("RayChangeDetector: presence_confidence must be in [0, 1]");
+  } else {
+    if (!(absence_confidence > 0.f)) throw std::invalid_argument("RayChangeDetector: absence_confidence must be > 0");
+    if (!(presence_confidence > 0.f)) throw std::invalid_argument("RayChangeDetector: presence_confidence must be > 0");
+  }
+}
+
+static const RayChangeDetector::Config& validated(const RayChangeDetector::Config& c) {
+  c.checkValid();
+  return c;
+}
+
+// resolution_ns_(config.temporal_resolution * 1e9): float * double -> double -> uint64_t (ray_change_detector.cpp:63-64)
+RayChangeDetector::RayChangeDetector(const Config& cfg)
+    : config(validated(cfg)), resolution_ns_(static_cast<uint64_t>(static_cast<double>(cfg.temporal_resolution) * 1e9)) {}
+
+RayChangeDetector::ChangeResult RayChangeDetector::detectChanges(const RayVerificator::CheckResult& check, bool forward) const {
+  return detectChanges(check.present.data(), check.present.size(), check.absent.data(), check.absent.size(), forward);
+}
+
+RayChangeDetector::ChangeResult RayChangeDetector::detectChanges(const uint64_t* present, size_t n_present, const uint64_t* absent,
+                                                                 size_t n_absent, bool forward) const {
+  // series[time_index] = {num_present, num_absent} (:72-81)
+  std::unordered_map<size_t, std::pair<unsigned, unsigned>> series;
+  for (size_t i = 0; i < n_present; ++i) series[present[i] / resolution_ns_].first++;
+  for (size_t i = 0; i < n_absent; ++i) series[absent[i] / resolution_ns_].second++;
+  // directional list of the occupied bins (:83-93)
+  std::vector<size_t> idx;
+  idx.reserve(series.size());
+  for (const auto& kv : series) idx.push_back(kv.first);
+  if (forward) std::sort(idx.begin(), idx.end());
+  else std::sort(idx.begin(), idx.end(), std::greater<size_t>());
+  ChangeResult result;
+  for (const size_t ti : idx) {
+    // the window always extends towards LATER bins, in both directions (:101-107)
+    unsigned np = 0, na = 0;
+    for (size_t i = 0; i < config.window_size; ++i) {
+      const auto it = series.find(ti + i);
+      if (it != series.end()) {
+        np += it->second.first;
+        na += it->second.second;
+      }
+    }
+    if (config.use_relative_confidence) {  // (:110-119)
+      const float absence = na / static_cast<float>(np + na);
+      if (absence > config.absence_confidence) {
+        result.closest_absent = ti * resolution_ns_;
+        return result;  // once an absence is found the search stops
+      }
+      if (1.f - absence > config.presence_confidence) result.furthest_persistent = ti * resolution_ns_;
+    } else {  // (:120-129) counts against float thresholds
+      if (na > config.absence_confidence) {
+        result.closest_absent = ti * resolution_ns_;
+        return result;
+      }
+      if (np > config.presence_confidence) result.furthest_persistent = ti * resolution_ns_;
+    }
+  }
+  return result;
+}
+
 }  // namespace khronos

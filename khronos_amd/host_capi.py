@@ -33,8 +33,25 @@ def load_host_library():
     lib.kop_num_tracks.argtypes = [vp]
     lib.kop_num_buffered_frames.argtypes = [vp]
     lib.kop_get_tracks.argtypes = [vp, vp, i32]
+    lib.khr_host_detect_changes.argtypes = [vp, C.c_int64, vp, C.c_int64, C.c_float, C.c_int64, i32, C.c_float, C.c_float, i32, vp]
     _host = lib
     return lib
+
+
+def detect_changes(present, absent, forward, temporal_resolution=1.0, window_size=5, use_relative_confidence=True,
+                   absence_confidence=0.5, presence_confidence=0.5):
+    """khronos::RayChangeDetector::detectChanges (host mirror, khronos_amd/host/ray_verificator.cpp) for one point:
+    returns (closest_absent or None, furthest_persistent or None)."""
+    lib = load_host_library()
+    p = np.ascontiguousarray(present, dtype=np.uint64)
+    a = np.ascontiguousarray(absent, dtype=np.uint64)
+    out = np.zeros(2, np.uint64)
+    rc = lib.khr_host_detect_changes(p.ctypes.data if p.size else None, p.size, a.ctypes.data if a.size else None, a.size,
+                                     float(temporal_resolution), int(window_size), 1 if use_relative_confidence else 0,
+                                     float(absence_confidence), float(presence_confidence), 1 if forward else 0, out.ctypes.data)
+    if rc < 0:
+        raise KhronosAmdError("khr_host_detect_changes failed (%d): bad configuration" % rc)
+    return (int(out[0]) if rc & 1 else None, int(out[1]) if rc & 2 else None)
 
 
 class ObjectPipeline:

@@ -391,3 +391,40 @@ class OracleRayVerificator:
             npres.append(len(a)); nabs.append(len(b)); pres.append(a); absn.append(b)
         cat = lambda l: np.concatenate(l) if l else np.zeros(0, np.uint64)
         return np.array(npres, np.uint32), np.array(nabs, np.uint32), cat(pres), cat(absn)
+
+
+def detect_changes(present, absent, forward, temporal_resolution=1.0, window_size=5, use_relative_confidence=True,
+                   absence_confidence=0.5, presence_confidence=0.5):
+    """CPU restatement of khronos::RayChangeDetector::detectChanges (khronos/src/backend/change_detection/
+    ray_change_detector.cpp:66-133; configuration :40-64): time-bin majority vote over one point's presence / absence
+    observations.  TEST INFRASTRUCTURE ONLY.  Returns (closest_absent or None, furthest_persistent or None)."""
+    # resolution_ns_(config.temporal_resolution * 1e9): float * double -> uint64 (:63-64)
+    res = int(np.float64(np.float32(temporal_resolution)) * 1e9)
+    series = {}
+    for t in present:  # :74-77
+        e = series.setdefault(int(t) // res, [0, 0])
+        e[0] += 1
+    for t in absent:   # :78-81
+        e = series.setdefault(int(t) // res, [0, 0])
+        e[1] += 1
+    closest_absent = furthest_persistent = None
+    ac, pc = np.float32(absence_confidence), np.float32(presence_confidence)
+    for ti in sorted(series, reverse=not forward):  # :83-93
+        n_p = n_a = 0
+        for i in range(window_size):  # :101-107: the window always extends towards later bins
+            e = series.get(ti + i)
+            if e is not None:
+                n_p += e[0]
+                n_a += e[1]
+        if use_relative_confidence:  # :110-119
+            conf = np.float32(n_a) / np.float32(n_p + n_a)
+            if conf > ac:
+                return ti * res, furthest_persistent
+            if np.float32(1.0) - conf > pc:
+                furthest_persistent = ti * res
+        else:                        # :120-129
+            if np.float32(n_a) > ac:
+                return ti * res, furthest_persistent
+            if np.float32(n_p) > pc:
+                furthest_persistent = ti * res
+    return closest_absent, furthest_persistent

@@ -1,5 +1,6 @@
 """Oracle known-answer tests for khronos::RayVerificator (ray_verificator.cpp:66-145, 327-349)."""
 import numpy as np
+import pytest
 
 from oracle import pyoracle as po
 
@@ -57,3 +58,65 @@ def test_results_come_in_ray_order_and_rays_accumulate():
     assert list(absn) == [7 * T] and list(pres) == [9 * T]
     pres, absn = rv.check_one([1.5, 0.5, 0.5])
     assert list(absn) == [7 * T, 9 * T] and list(pres) == [3 * T]  # ascending ray index, not ascending time
+
+
+# ---- RayChangeDetector::detectChanges (time-bin vote over the check results; pure host logic) -----------------------------
+S = 1_000_000_000
+
+
+def _both(present, absent, forward, **kw):
+    from khronos_amd.host_capi import detect_changes
+    got = detect_changes(present, absent, forward, **kw)
+    ref = po.detect_changes(present, absent, forward, **kw)
+    assert got == ref, (got, ref, kw)
+    return got
+
+
+def test_change_detector_known_answers():
+    """hand-derived cases of ray_change_detector.cpp:66-133 (defaults: 1 s bins, window 5, relative confidences 0.5)."""
+    # nothing observed: neither result exists
+    assert _both([], [], True) == (None, None)
+    # only presence, three bins: the LAST bin visited in the search direction is the furthest persistent one
+    assert _both([1 * S, 2 * S + 5, 9 * S], [], True) == (None, 9 * S)
+    assert _both([1 * S, 2 * S + 5, 9 * S], [], False) == (None, 1 * S)
+    # an absent majority stops the search; what was persistent before it stays
+    assert _both([1 * S, 1 * S + 7], [20 * S, 20 * S + 1, 21 * S], True) == (20 * S, 1 * S)
+    # backwards the absent bins come first: no persistent observation is reported at all
+    assert _both([1 * S, 1 * S + 7], [20 * S, 20 * S + 1, 21 * S], False) == (21 * S, None)
+    # the window looks at LATER bins in both directions: bin 3 sees the absences of bins 4..7, bin 8 does not see bin 3
+    assert _both([3 * S], [4 * S, 5 * S], True) == (3 * S, None)
+    assert _both([8 * S], [3 * S, 3 * S + 1], False) == (3 * S, 8 * S)
+    # a tie is neither absent (> 0.5) nor present (> 0.5)
+    assert _both([3 * S], [3 * S + 1], True) == (None, None)
+    # count mode: thresholds are counts compared with '>'
+    kw = dict(use_relative_confidence=False, absence_confidence=2.0, presence_confidence=1.0)
+    assert _both([1 * S, 1 * S + 1], [9 * S, 9 * S + 1], True, **kw) == (None, 1 * S)
+    assert _both([1 * S, 1 * S + 1], [9 * S, 9 * S + 1, 9 * S + 2], True, **kw) == (9 * S, 1 * S)
+    # temporal_resolution 0.1 s is 0.1f * 1e9 = 100000001 ns per bin (float -> double -> integer)
+    assert _both([100000001], [], True, temporal_resolution=0.1, window_size=1) == (None, 100000001)
+    assert _both([100000000], [], True, temporal_resolution=0.1, window_size=1) == (None, 0)
+
+
+def test_change_detector_matches_restatement_on_random_series():
+    rng = np.random.default_rng(11)
+    for trial in range(300):
+        n_p, n_a = int(rng.integers(0, 40)), int(rng.integers(0, 40))
+        span = int(rng.integers(1, 30)) * S
+        present = rng.integers(0, span, n_p).astype(np.uint64)
+        absent = rng.integers(0, span, n_a).astype(np.uint64)
+        kw = dict(temporal_resolution=float(rng.choice([0.1, 0.5, 1.0, 2.5])), window_size=int(rng.integers(1, 8)))
+        if trial % 2:
+            kw.update(use_relative_confidence=False, absence_confidence=float(rng.integers(1, 6)), presence_confidence=float(rng.integers(1, 6)))
+        else:
+            kw.update(absence_confidence=float(rng.uniform(0.1, 0.9)), presence_confidence=float(rng.uniform(0.1, 0.9)))
+        for forward in (True, False):
+            _both(present, absent, forward, **kw)
+
+
+def test_change_detector_rejects_bad_configuration():
+    from khronos_amd import KhronosAmdError
+    from khronos_amd.host_capi import detect_changes
+    for kw in (dict(temporal_resolution=0.0), dict(window_size=0), dict(absence_confidence=1.5),
+               dict(use_relative_confidence=False, presence_confidence=0.0)):
+        with pytest.raises(KhronosAmdError):
+            detect_changes([1], [2], True, **kw)

@@ -386,6 +386,15 @@ int64_t khr_rv_num_pairs(khr_rayver* rv); /* distinct (block, ray) entries of th
 int khr_rv_check(khr_rayver* rv, int64_t m, const float* points, const uint64_t* earliest, const uint64_t* latest,
                  uint32_t* n_present, uint32_t* n_absent, uint64_t* total_present, uint64_t* total_absent);
 int khr_rv_check_stamps(khr_rayver* rv, uint64_t* present_stamps, uint64_t* absent_stamps);
+/* khronos::RayChangeDetector::detectChanges (ray_change_detector.cpp:66-133, configuration checks :51-60) for every
+ * point of the latest khr_rv_check, on the device: the time-bin majority vote over the point's presence / absence
+ * observations, so that two stamps and a flag byte per point come back instead of the stamp lists.  forward: per point,
+ * != 0 = search towards the future (NULL: forward_all > 0 all forward, < 0 all backward).  flags[i]: bit 0
+ * closest_absent[i] exists, bit 1 furthest_persistent[i] exists, bit 7 the point's observations span more than 2048
+ * time bins (vote on its khr_rv_check_stamps lists with the host mirror, khronos_amd/host/ray_verificator.h). */
+int khr_rv_detect_changes(khr_rayver* rv, float temporal_resolution, int64_t window_size, int use_relative_confidence,
+                          float absence_confidence, float presence_confidence, const uint8_t* forward, int forward_all,
+                          uint64_t* closest_absent, uint64_t* furthest_persistent, uint8_t* flags);
 
 #ifdef __cplusplus
 }

@@ -72,7 +72,7 @@ EXPORTS = [
     "khr_detect_motion", "khr_generate_mesh", "khr_reset_inactive", "khr_mark_all_inactive", "khr_clear_updated",
     "khr_allocate_blocks", "khr_object_prune", "khr_get_stats", "khr_num_blocks", "khr_block_indices",
     "khr_download_block", "khr_mesh_num_vertices", "khr_download_mesh", "khr_timing_enable", "khr_timing_reset",
-    "khr_timing_get", "khr_debug_read", "khr_tick_ingest", "khr_tick_integrate", "khr_tick_seed_counts", "khr_copy_frame_image", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_update_tracking_phase",
+    "khr_timing_get", "khr_debug_read", "khr_tick_ingest", "khr_tick_integrate", "khr_tick_seed_counts", "khr_copy_frame_image", "khr_rv_detect_changes", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_update_tracking_phase",
     "khr_export_halo", "khr_import_halo", "khr_get_dynamic_clusters", "khr_motion_keys",
     "khr_detect_motion_from_keys", "khr_download_updated", "khr_mesh_halo_requests", "khr_mesh_halo_export",
     "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",
@@ -135,6 +135,7 @@ def load_library():
     lib.khr_rv_num_pairs.restype = C.c_int64
     lib.khr_rv_check.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.khr_rv_check_stamps.argtypes = [vp, vp, vp]
+    lib.khr_rv_detect_changes.argtypes = [vp, C.c_float, C.c_int64, i32, C.c_float, C.c_float, vp, i32, vp, vp, vp]
     lib.khr_get_config.argtypes = [vp, vp]
     lib.khr_reset_map.argtypes = [vp, C.c_float, C.c_float]
     lib.khr_depend_on.argtypes = [vp, vp]
@@ -620,3 +621,25 @@ class RayVerificator:
         if m:
             self._chk(self.lib.khr_rv_check_stamps(self.h, _ptr(pres), _ptr(absn)))
         return npres[:m], nabs[:m], pres[:tp.value], absn[:ta.value]
+
+    def check_and_vote(self, points, earliest, latest, forward, temporal_resolution=1.0, window_size=5,
+                       use_relative_confidence=True, absence_confidence=0.5, presence_confidence=0.5):
+        """khr_rv_check + khr_rv_detect_changes: RayVerificator::check and RayChangeDetector::detectChanges for all points
+        without the stamp lists leaving the device.  forward: bool or per-point array.
+        -> (closest_absent[m], furthest_persistent[m], flags[m]) (flags: bit 0 / bit 1 = exists, bit 7 = vote on the host)."""
+        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        m = pts.shape[0]
+        t0 = np.ascontiguousarray(np.broadcast_to(np.asarray(earliest, np.uint64), (m,)))
+        t1 = np.ascontiguousarray(np.broadcast_to(np.asarray(latest, np.uint64), (m,)))
+        tp, ta = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self.lib.khr_rv_check(self.h, m, _ptr(pts), _ptr(t0), _ptr(t1), None, None, C.byref(tp), C.byref(ta)))
+        ca, fp, fl = np.zeros(max(m, 1), np.uint64), np.zeros(max(m, 1), np.uint64), np.zeros(max(m, 1), np.uint8)
+        if m:
+            if np.isscalar(forward) or isinstance(forward, (bool, np.bool_)):
+                fwd, fall = None, (1 if forward else -1)
+            else:
+                fwd, fall = np.ascontiguousarray(np.asarray(forward).astype(np.uint8)), 0
+            self._chk(self.lib.khr_rv_detect_changes(self.h, float(temporal_resolution), int(window_size), 1 if use_relative_confidence else 0,
+                                                     float(absence_confidence), float(presence_confidence), _ptr(fwd) if fwd is not None else None,
+                                                     fall, _ptr(ca), _ptr(fp), _ptr(fl)))
+        return ca[:m], fp[:m], fl[:m]

@@ -175,6 +175,9 @@ int growBuffer(T** buf, size_t* cap, size_t need, size_t keep, hipStream_t strea
 
 }  // namespace
 
+struct khr_rayver;
+static int fillStamps(khr_rayver* rv);
+
 struct khr_rayver {
   float block_size = 1.f, inv = 1.f, radial_tol = 0.1f, depth_tol = 0.1f;
   int device = 0;
@@ -205,7 +208,129 @@ struct khr_rayver {
   uint32_t* d_qidx[2] = {nullptr, nullptr}; size_t cap_qidx[2] = {0, 0};
   size_t last_m = 0;
   uint64_t last_present = 0, last_absent = 0;
+  bool stamps_filled = false;  // d_outp / d_outa hold the stamp lists of the latest check
+  // khr_rv_detect_changes
+  uint8_t* d_fwd = nullptr; size_t cap_fwd = 0;
+  uint64_t* d_vote = nullptr; size_t cap_vote = 0;  // [2 * m] closest_absent, furthest_persistent
+  uint8_t* d_vflags = nullptr; size_t cap_vflags = 0;
 };
+
+// the stamp lists of the latest khr_rv_check, materialised on the device (per point at the offsets of the exclusive sums)
+static int fillStamps(khr_rayver* rv) {
+  if (rv->stamps_filled) return KHR_OK;
+  int rc = KHR_OK;
+  if ((rc = growBuffer(&rv->d_outp, &rv->cap_outp, std::max<size_t>(rv->last_present, 1), 0, rv->stream))) return rc;
+  if ((rc = growBuffer(&rv->d_outa, &rv->cap_outa, std::max<size_t>(rv->last_absent, 1), 0, rv->stream))) return rc;
+  const size_t M = rv->last_m;
+  const int grid = static_cast<int>((M + 255) / 256);
+  hipLaunchKernelGGL((k_rv_check<true>), dim3(grid), dim3(256), 0, rv->stream, rv->d_pts, rv->d_t0, rv->d_t1, static_cast<uint32_t>(M),
+                     rv->d_keys[0], rv->d_vals[0], static_cast<uint32_t>(rv->n_pairs), rv->d_stamp, rv->d_src, rv->d_tgt, rv->inv,
+                     rv->radial_tol, rv->depth_tol, nullptr, nullptr, rv->d_op, rv->d_oa, rv->d_outp, rv->d_outa, rv->d_qidx[1]);
+  RV_TRY(hipGetLastError());
+  rv->stamps_filled = true;
+  return KHR_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// k_rv_vote: khronos::RayChangeDetector::detectChanges (ray_change_detector.cpp:66-133) for every point of a check, one
+// wave per point.  The presence / absence stamps of a point are binned (stamp / resolution) into an LDS histogram over
+// the point's own bin range, window sums come from an inclusive scan, and the directional walk over the occupied bins
+// ("first bin whose window votes absent ends the search, the last bin before it whose window votes present is the
+// furthest persistent one") becomes two wave reductions.  flags: bit 0 closest_absent exists, bit 1 furthest_persistent
+// exists, bit 7 the point's observations span more bins than the histogram holds (the caller votes on the host).
+// ----------------------------------------------------------------------------------------------------------------------
+constexpr int kVoteBins = 2048;
+__global__ __launch_bounds__(64) void k_rv_vote(const uint32_t* __restrict__ op, const uint32_t* __restrict__ oa,
+                                               const uint64_t* __restrict__ sp, const uint64_t* __restrict__ sa, uint32_t m,
+                                               uint64_t res_ns, uint32_t window, int relative, float absence_conf, float presence_conf,
+                                               const uint8_t* __restrict__ fwd, int fwd_all, uint64_t* __restrict__ out,
+                                               uint8_t* __restrict__ flags) {
+  __shared__ uint32_t hp[kVoteBins], ha[kVoteBins];  // counts per bin, then inclusive prefix sums
+  const uint32_t i = blockIdx.x, lane = threadIdx.x;
+  if (i >= m) return;
+  const uint32_t p0 = op[i], p1 = op[i + 1], a0 = oa[i], a1 = oa[i + 1];
+  if (p0 == p1 && a0 == a1) {  // nothing observed: neither result exists
+    if (lane == 0) { flags[i] = 0; out[2 * i] = 0; out[2 * i + 1] = 0; }
+    return;
+  }
+  uint64_t bmin = ~0ull, bmax = 0ull;
+  for (uint32_t k = p0 + lane; k < p1; k += 64) { const uint64_t b = sp[k] / res_ns; bmin = b < bmin ? b : bmin; bmax = b > bmax ? b : bmax; }
+  for (uint32_t k = a0 + lane; k < a1; k += 64) { const uint64_t b = sa[k] / res_ns; bmin = b < bmin ? b : bmin; bmax = b > bmax ? b : bmax; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint64_t lo = (static_cast<uint64_t>(__shfl_xor(static_cast<uint32_t>(bmin >> 32), o)) << 32) | __shfl_xor(static_cast<uint32_t>(bmin), o);
+    const uint64_t hi = (static_cast<uint64_t>(__shfl_xor(static_cast<uint32_t>(bmax >> 32), o)) << 32) | __shfl_xor(static_cast<uint32_t>(bmax), o);
+    bmin = lo < bmin ? lo : bmin;
+    bmax = hi > bmax ? hi : bmax;
+  }
+  if (bmax - bmin >= static_cast<uint64_t>(kVoteBins)) {
+    if (lane == 0) { flags[i] = 0x80; out[2 * i] = 0; out[2 * i + 1] = 0; }
+    return;
+  }
+  const int R = static_cast<int>(bmax - bmin) + 1;
+  for (int j = lane; j < R; j += 64) { hp[j] = 0u; ha[j] = 0u; }
+  __syncthreads();
+  for (uint32_t k = p0 + lane; k < p1; k += 64) atomicAdd(&hp[static_cast<int>(sp[k] / res_ns - bmin)], 1u);
+  for (uint32_t k = a0 + lane; k < a1; k += 64) atomicAdd(&ha[static_cast<int>(sa[k] / res_ns - bmin)], 1u);
+  __syncthreads();
+  // occupied flags live in bit 31 of the prefix arrays' source: keep the raw counts of this lane's bins in registers per
+  // round instead -- inclusive scan in rounds of 64 bins with a carry
+  uint32_t carry_p = 0, carry_a = 0;
+  for (int base = 0; base < R; base += 64) {
+    const int j = base + lane;
+    uint32_t vp = j < R ? hp[j] : 0u, va = j < R ? ha[j] : 0u;
+    const uint32_t occupied = (vp | va) ? 0x80000000u : 0u;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t tp = __shfl_up(vp, o), ta = __shfl_up(va, o);
+      if (static_cast<int>(lane) >= o) { vp += tp; va += ta; }
+    }
+    vp += carry_p;
+    va += carry_a;
+    if (j < R) { hp[j] = vp; ha[j] = va | occupied; }  // (counts stay far below 2^31)
+    carry_p = __shfl(vp, 63);
+    carry_a = __shfl(va, 63);
+  }
+  __syncthreads();
+  const bool forward = fwd_all ? (fwd_all > 0) : (fwd[i] != 0);
+  // pass 1: the first bin (in search direction) whose window votes absent
+  int jA = forward ? INT32_MAX : -1;
+  for (int base = 0; base < R; base += 64) {
+    const int j = base + lane;
+    if (j < R && (ha[j] & 0x80000000u)) {
+      const int e = min(j + static_cast<int>(window) - 1, R - 1);
+      const uint32_t np = hp[e] - (j ? hp[j - 1] : 0u);
+      const uint32_t na = (ha[e] & 0x7fffffffu) - (j ? (ha[j - 1] & 0x7fffffffu) : 0u);
+      const bool absent = relative ? (static_cast<float>(na) / static_cast<float>(np + na) > absence_conf) : (static_cast<float>(na) > absence_conf);
+      if (absent) jA = forward ? min(jA, j) : max(jA, j);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(jA, o); jA = forward ? min(jA, t) : max(jA, t); }
+  // pass 2: the last bin before it whose window votes present
+  int jF = forward ? -1 : INT32_MAX;
+  for (int base = 0; base < R; base += 64) {
+    const int j = base + lane;
+    const bool before = forward ? (j < jA) : (j > jA);
+    if (j < R && before && (ha[j] & 0x80000000u)) {
+      const int e = min(j + static_cast<int>(window) - 1, R - 1);
+      const uint32_t np = hp[e] - (j ? hp[j - 1] : 0u);
+      const uint32_t na = (ha[e] & 0x7fffffffu) - (j ? (ha[j - 1] & 0x7fffffffu) : 0u);
+      const bool present = relative ? (1.f - static_cast<float>(na) / static_cast<float>(np + na) > presence_conf)
+                                    : (static_cast<float>(np) > presence_conf);
+      if (present) jF = forward ? max(jF, j) : min(jF, j);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(jF, o); jF = forward ? max(jF, t) : min(jF, t); }
+  if (lane == 0) {
+    const bool hasA = forward ? (jA != INT32_MAX) : (jA >= 0);
+    const bool hasF = forward ? (jF >= 0) : (jF != INT32_MAX);
+    out[2 * i] = hasA ? (bmin + static_cast<uint64_t>(jA)) * res_ns : 0ull;
+    out[2 * i + 1] = hasF ? (bmin + static_cast<uint64_t>(jF)) * res_ns : 0ull;
+    flags[i] = static_cast<uint8_t>((hasA ? 1 : 0) | (hasF ? 2 : 0));
+  }
+}
 
 extern "C" {
 
@@ -245,7 +370,8 @@ void khr_rv_destroy(khr_rayver* rv) {
                   static_cast<void*>(rv->d_np), static_cast<void*>(rv->d_na), static_cast<void*>(rv->d_op),
                   static_cast<void*>(rv->d_oa), static_cast<void*>(rv->d_outp), static_cast<void*>(rv->d_outa),
                   static_cast<void*>(rv->d_qkey[0]), static_cast<void*>(rv->d_qkey[1]), static_cast<void*>(rv->d_qidx[0]),
-                  static_cast<void*>(rv->d_qidx[1])})
+                  static_cast<void*>(rv->d_qidx[1]), static_cast<void*>(rv->d_fwd), static_cast<void*>(rv->d_vote),
+                  static_cast<void*>(rv->d_vflags)})
     if (p) hipFree(p);
   hipStreamDestroy(rv->stream);
   delete rv;
@@ -259,6 +385,7 @@ int khr_rv_clear(khr_rayver* rv) {
   rv->n_rays = 0;
   rv->n_pairs = 0;
   rv->last_m = 0;
+  rv->stamps_filled = false;
   return KHR_OK;
 }
 
@@ -351,6 +478,7 @@ int khr_rv_check(khr_rayver* rv, int64_t m, const float* points, const uint64_t*
   if (total_absent) *total_absent = 0;
   rv->last_m = 0;
   rv->last_present = rv->last_absent = 0;
+  rv->stamps_filled = false;
   if (m == 0) return KHR_OK;
   if (m > 0xfffffff0ll) return rvFail(KHR_EINVAL, "too many query points");
   RV_TRY(hipSetDevice(rv->device));
@@ -430,17 +558,52 @@ int khr_rv_check_stamps(khr_rayver* rv, uint64_t* present_stamps, uint64_t* abse
   if ((rv->last_present && !present_stamps) || (rv->last_absent && !absent_stamps)) return rvFail(KHR_EINVAL, "null output buffer");
   RV_TRY(hipSetDevice(rv->device));
   int rc = KHR_OK;
-  if ((rc = growBuffer(&rv->d_outp, &rv->cap_outp, std::max<size_t>(rv->last_present, 1), 0, rv->stream))) return rc;
-  if ((rc = growBuffer(&rv->d_outa, &rv->cap_outa, std::max<size_t>(rv->last_absent, 1), 0, rv->stream))) return rc;
-  const size_t M = rv->last_m;
-  const int grid = static_cast<int>((M + 255) / 256);
-  hipLaunchKernelGGL((k_rv_check<true>), dim3(grid), dim3(256), 0, rv->stream, rv->d_pts, rv->d_t0, rv->d_t1, static_cast<uint32_t>(M),
-                     rv->d_keys[0], rv->d_vals[0], static_cast<uint32_t>(rv->n_pairs), rv->d_stamp, rv->d_src, rv->d_tgt, rv->inv,
-                     rv->radial_tol, rv->depth_tol, nullptr, nullptr, rv->d_op, rv->d_oa, rv->d_outp, rv->d_outa, rv->d_qidx[1]);
-  RV_TRY(hipGetLastError());
+  if ((rc = fillStamps(rv))) return rc;
   if (rv->last_present) RV_TRY(hipMemcpyAsync(present_stamps, rv->d_outp, sizeof(uint64_t) * rv->last_present, hipMemcpyDeviceToHost, rv->stream));
   if (rv->last_absent) RV_TRY(hipMemcpyAsync(absent_stamps, rv->d_outa, sizeof(uint64_t) * rv->last_absent, hipMemcpyDeviceToHost, rv->stream));
   RV_TRY(hipStreamSynchronize(rv->stream));
+  return KHR_OK;
+}
+
+int khr_rv_detect_changes(khr_rayver* rv, float temporal_resolution, int64_t window_size, int use_relative_confidence,
+                          float absence_confidence, float presence_confidence, const uint8_t* forward, int forward_all,
+                          uint64_t* closest_absent, uint64_t* furthest_persistent, uint8_t* flags) {
+  if (!rv || !closest_absent || !furthest_persistent || !flags) return rvFail(KHR_EINVAL, "null argument");
+  if (rv->last_m == 0) return rvFail(KHR_ESTATE, "khr_rv_check has not been called");
+  if (!forward && forward_all == 0) return rvFail(KHR_EINVAL, "no search direction given");
+  // configuration checks of ray_change_detector.cpp:51-60
+  if (!(temporal_resolution > 0.f) || window_size <= 0) return rvFail(KHR_EINVAL, "temporal_resolution and window_size must be > 0");
+  if (use_relative_confidence) {
+    if (!(absence_confidence >= 0.f && absence_confidence <= 1.f && presence_confidence >= 0.f && presence_confidence <= 1.f))
+      return rvFail(KHR_EINVAL, "relative confidences must be in [0, 1]");
+  } else if (!(absence_confidence > 0.f && presence_confidence > 0.f)) {
+    return rvFail(KHR_EINVAL, "count confidences must be > 0");
+  }
+  const uint64_t res_ns = static_cast<uint64_t>(static_cast<double>(temporal_resolution) * 1e9);  // :63-64
+  if (res_ns == 0) return rvFail(KHR_EINVAL, "temporal_resolution below 1 ns");
+  RV_TRY(hipSetDevice(rv->device));
+  int rc = fillStamps(rv);
+  if (rc) return rc;
+  const size_t M = rv->last_m;
+  if ((rc = growBuffer(&rv->d_vote, &rv->cap_vote, 2 * M, 0, rv->stream))) return rc;
+  if ((rc = growBuffer(&rv->d_vflags, &rv->cap_vflags, M, 0, rv->stream))) return rc;
+  if (forward) {
+    if ((rc = growBuffer(&rv->d_fwd, &rv->cap_fwd, M, 0, rv->stream))) return rc;
+    RV_TRY(hipMemcpyAsync(rv->d_fwd, forward, M, hipMemcpyHostToDevice, rv->stream));
+  }
+  hipLaunchKernelGGL(k_rv_vote, dim3(static_cast<uint32_t>(M)), dim3(64), 0, rv->stream, rv->d_op, rv->d_oa, rv->d_outp, rv->d_outa,
+                     static_cast<uint32_t>(M), res_ns, static_cast<uint32_t>(std::min<int64_t>(window_size, 1 << 30)), use_relative_confidence ? 1 : 0,
+                     absence_confidence, presence_confidence, forward ? rv->d_fwd : nullptr, forward ? 0 : (forward_all > 0 ? 1 : -1), rv->d_vote,
+                     rv->d_vflags);
+  RV_TRY(hipGetLastError());
+  std::vector<uint64_t> tmp(2 * M);
+  RV_TRY(hipMemcpyAsync(tmp.data(), rv->d_vote, sizeof(uint64_t) * 2 * M, hipMemcpyDeviceToHost, rv->stream));
+  RV_TRY(hipMemcpyAsync(flags, rv->d_vflags, M, hipMemcpyDeviceToHost, rv->stream));
+  RV_TRY(hipStreamSynchronize(rv->stream));
+  for (size_t i = 0; i < M; ++i) {
+    closest_absent[i] = tmp[2 * i];
+    furthest_persistent[i] = tmp[2 * i + 1];
+  }
   return KHR_OK;
 }
 

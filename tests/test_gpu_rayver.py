@@ -87,3 +87,43 @@ def test_rayver_edge_cases():
         RayVerificator(0.0, 0.1, 0.1)
     with pytest.raises(Exception):
         RayVerificator(1.0, 0.1, -1.0)
+
+
+@pytest.mark.parametrize("relative", [True, False])
+def test_device_vote_equals_restatement(relative):
+    """khr_rv_detect_changes (RayChangeDetector::detectChanges on the device, one wave per point) against the oracle
+    restatement applied to the stamp lists of khr_rv_check_stamps, point by point: both search directions, several
+    resolutions and windows, relative and count confidences; a span of more than 2048 bins raises the host-fallback flag."""
+    rng = np.random.default_rng(5)
+    st, src, tgt = _scene(rng, 40, 300)  # stamps 1 .. 40 s
+    dev = RayVerificator(1.0, 0.1, 0.1)
+    dev.add_rays(st, src, tgt)
+    sel = rng.choice(len(st), 200, replace=False)
+    pts = np.concatenate([tgt[sel], 0.5 * (src[sel] + tgt[sel]), rng.uniform([-4, -3, 0], [4, 3, 3], (200, 3)).astype(np.float32),
+                          np.array([[50.0, 50.0, 50.0]], np.float32)]).astype(np.float32)
+    m = len(pts)
+    n_p, n_a, pres, absn = dev.check(pts, 0, 2 ** 64 - 1)
+    op = np.concatenate([[0], np.cumsum(n_p.astype(np.int64))]).astype(np.int64)
+    oa = np.concatenate([[0], np.cumsum(n_a.astype(np.int64))]).astype(np.int64)
+    fwd = rng.integers(0, 2, m).astype(bool)
+    some = 0
+    for res, window in ((1.0, 5), (0.5, 3), (2.5, 1), (0.1, 8)):
+        kw = dict(temporal_resolution=res, window_size=window)
+        if relative:
+            kw.update(absence_confidence=0.4, presence_confidence=0.55)
+        else:
+            kw.update(use_relative_confidence=False, absence_confidence=2.0, presence_confidence=3.0)
+        for direction in (fwd, True, False):
+            ca, fp, fl = dev.check_and_vote(pts, 0, 2 ** 64 - 1, direction, **kw)
+            assert not (fl & 0x80).any()
+            for i in range(m):
+                f = bool(direction[i]) if not isinstance(direction, bool) else direction
+                ref = po.detect_changes(pres[op[i]:op[i + 1]], absn[oa[i]:oa[i + 1]], f, **kw)
+                got = (int(ca[i]) if fl[i] & 1 else None, int(fp[i]) if fl[i] & 2 else None)
+                assert got == ref, (i, f, kw, got, ref)
+                some += ref[0] is not None or ref[1] is not None
+    assert some > 500
+    # 1 ms bins over 39 s of observations: more bins than the histogram holds -> flag, no result
+    ca, fp, fl = dev.check_and_vote(pts, 0, 2 ** 64 - 1, True, temporal_resolution=0.001)
+    multi = (n_p + n_a) > 1
+    assert (fl[multi] & 0x80).any() and not (fl[~(fl & 0x80).astype(bool)] & 0x80).any()

@@ -82,6 +82,18 @@ def row_f4(n_poses=200, per_pose=5000, n_query=200000):
     t = time.perf_counter()
     g = dev.check(q, 0, 2 ** 64 - 1)
     t_check = time.perf_counter() - t
+    # the same points with the change detector's vote on the device: no stamp lists leave HBM
+    dev.check_and_vote(q[:1000], 0, 2 ** 64 - 1, True)
+    t = time.perf_counter()
+    v = dev.check_and_vote(q, 0, 2 ** 64 - 1, True)
+    t_vote = time.perf_counter() - t
+    # (spot check against the host restatement of the vote on the downloaded lists)
+    op = np.concatenate([[0], np.cumsum(g[0].astype(np.int64))])
+    oa = np.concatenate([[0], np.cumsum(g[1].astype(np.int64))])
+    for i in range(0, n_query, max(1, n_query // 500)):
+        ref = po.detect_changes(g[2][op[i]:op[i + 1]], g[3][oa[i]:oa[i + 1]], True)
+        got = (int(v[0][i]) if v[2][i] & 1 else None, int(v[1][i]) if v[2][i] & 2 else None)
+        assert got == ref, (i, got, ref)
     # CPU oracle on a bounded sample
     ora = po.OracleRayVerificator(1.0, 0.1, 0.1)
     t = time.perf_counter()
@@ -98,8 +110,10 @@ def row_f4(n_poses=200, per_pose=5000, n_query=200000):
                 len(stamps), n_poses, per_pose, n_query),
             "index_pairs": dev.num_pairs(), "build_ms": 1e3 * t_build, "cpu_build_ms": 1e3 * t_cpu_build,
             "check_ms": 1e3 * t_check, "check_points_per_s": n_query / t_check, "matches_returned": tests,
+            "check_and_vote_ms": 1e3 * t_vote, "check_and_vote_points_per_s": n_query / t_vote,
             "cpu_check_points_per_s": ns / t_cpu_check, "cpu": "oracle, 1 thread, %d-point sample" % ns,
-            "note": "check time includes H2D of the points and D2H of counts + stamp lists"}
+            "note": "check time includes H2D of the points and D2H of counts + stamp lists; check_and_vote = khr_rv_check + "
+                    "khr_rv_detect_changes (RayChangeDetector::detectChanges on the device, 17 B per point back)"}
 
 
 if __name__ == "__main__":

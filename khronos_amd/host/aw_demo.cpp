@@ -135,6 +135,29 @@ static int rayverDemo(const char* policy) {
         std::printf("]}");
       }
       std::printf("]}\n");
+    } else if (tok == "C") {  // C <n> <resolution> <window> <relative> <absence> <presence>, then n lines "<forward> <earliest> <latest> x y z"
+      RayChangeDetector::Config dc;
+      int rel = 1;
+      std::cin >> dc.temporal_resolution >> dc.window_size >> rel >> dc.absence_confidence >> dc.presence_confidence;
+      dc.use_relative_confidence = rel != 0;
+      const RayChangeDetector det(dc);
+      std::vector<float> pts;
+      std::vector<uint64_t> t0, t1;
+      std::vector<uint8_t> fwd;
+      for (size_t i = 0; i < n; ++i) {
+        int f; uint64_t a, b; float x, y, z;
+        std::cin >> f >> a >> b >> x >> y >> z;
+        fwd.push_back(static_cast<uint8_t>(f));
+        t0.push_back(a);
+        t1.push_back(b);
+        pts.insert(pts.end(), {x, y, z});
+      }
+      const auto res = det.detectChangesMany(rv, pts, t0, t1, fwd);
+      std::printf("{\"changes\": [");
+      for (size_t i = 0; i < res.size(); ++i)
+        std::printf("%s[%lld, %lld]", i ? ", " : "", res[i].closest_absent ? static_cast<long long>(*res[i].closest_absent) : -1ll,
+                    res[i].furthest_persistent ? static_cast<long long>(*res[i].furthest_persistent) : -1ll);
+      std::printf("]}\n");
     }
   }
   return 0;

@@ -230,4 +230,33 @@ RayChangeDetector::ChangeResult RayChangeDetector::detectChanges(const uint64_t*
   return result;
 }
 
+std::vector<RayChangeDetector::ChangeResult> RayChangeDetector::detectChangesMany(const RayVerificator& verificator,
+                                                                                 const std::vector<float>& points,
+                                                                                 const std::vector<uint64_t>& earliest,
+                                                                                 const std::vector<uint64_t>& latest,
+                                                                                 const std::vector<uint8_t>& forward) const {
+  const size_t m = earliest.size();
+  if (points.size() != 3 * m || latest.size() != m || forward.size() != m) throw std::invalid_argument("query arrays have inconsistent sizes");
+  std::vector<ChangeResult> out(m);
+  if (m == 0) return out;
+  uint64_t tp = 0, ta = 0;
+  chk(khr_rv_check(verificator.handle(), static_cast<int64_t>(m), points.data(), earliest.data(), latest.data(), nullptr, nullptr, &tp, &ta),
+      "khr_rv_check");
+  std::vector<uint64_t> ca(m), fp(m);
+  std::vector<uint8_t> fl(m);
+  chk(khr_rv_detect_changes(verificator.handle(), config.temporal_resolution, static_cast<int64_t>(config.window_size),
+                            config.use_relative_confidence ? 1 : 0, config.absence_confidence, config.presence_confidence, forward.data(), 0,
+                            ca.data(), fp.data(), fl.data()),
+      "khr_rv_detect_changes");
+  for (size_t i = 0; i < m; ++i) {
+    if (fl[i] & 0x80) {  // too many time bins for the device histogram: vote here on the point's own lists
+      out[i] = detectChanges(verificator.check(&points[3 * i], earliest[i], latest[i]), forward[i] != 0);
+      continue;
+    }
+    if (fl[i] & 1) out[i].closest_absent = ca[i];
+    if (fl[i] & 2) out[i].furthest_persistent = fp[i];
+  }
+  return out;
+}
+
 }  // namespace khronos

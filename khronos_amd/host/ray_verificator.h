@@ -55,6 +55,7 @@ class RayVerificator {
                                      const std::vector<uint64_t>& latest) const;
 
   size_t numRays() const;
+  khr_rayver* handle() const { return rv_; }  // the device index (for RayChangeDetector::detectChangesMany)
   // computeVertexSources (ray_verificator.cpp:266-325): indices into the pose list
   std::unordered_set<size_t> computeVertexSources(uint64_t first_seen, uint64_t last_seen);
 
@@ -94,6 +95,14 @@ class RayChangeDetector {
   // detectChanges (ray_change_detector.cpp:66-133)
   ChangeResult detectChanges(const RayVerificator::CheckResult& check, bool forward) const;
   ChangeResult detectChanges(const uint64_t* present, size_t n_present, const uint64_t* absent, size_t n_absent, bool forward) const;
+
+  // check + detectChanges for many points in one device pass (khr_rv_check + khr_rv_detect_changes): what the loops of
+  // ray_background_change_detector.cpp:92-103 / ray_object_change_detector.cpp:127-160 do point by point.  forward[i] != 0:
+  // search towards the future.  Points whose observations span more time bins than the device histogram holds are
+  // voted on here from their stamp lists.
+  std::vector<ChangeResult> detectChangesMany(const RayVerificator& verificator, const std::vector<float>& points,
+                                              const std::vector<uint64_t>& earliest, const std::vector<uint64_t>& latest,
+                                              const std::vector<uint8_t>& forward) const;
 
  protected:
   const uint64_t resolution_ns_;

@@ -305,9 +305,27 @@ def test_ray_verificator_host_mirror(policy):
     t1 = t0 + rng.integers(1, 12, len(q)) * T
     lines.append("Q %d" % len(q))
     lines += ["%d %d %r %r %r" % (t0[i], t1[i], *map(float, q[i])) for i in range(len(q))]
+    # RayChangeDetector::detectChangesMany (check + time-bin vote in one device pass; 0.002 s bins force the host fallback
+    # for points seen over more than 2048 bins)
+    fwd = rng.integers(0, 2, len(q))
+    votes = [(1.0, 3, 1, 0.4, 0.5), (0.002, 400, 0, 1.0, 1.0)]
+    for v in votes:
+        lines.append("C %d %r %d %d %r %r" % ((len(q),) + v))
+        lines += ["%d %d %d %r %r %r" % (fwd[i], t0[i], t1[i], *map(float, q[i])) for i in range(len(q))]
     out = subprocess.run([DEMO, "--rayver", policy], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
-    res = json.loads(out.stdout.strip().splitlines()[-1])
+    outs = out.stdout.strip().splitlines()
+    n_votes = 0
+    for v, line in zip(votes, outs[-len(votes):]):
+        ch = json.loads(line)["changes"]
+        for i in range(len(q)):
+            pres, absn = ora.check_one(q[i], int(t0[i]), int(t1[i]))
+            ref = po.detect_changes(pres, absn, bool(fwd[i]), temporal_resolution=v[0], window_size=v[1], use_relative_confidence=bool(v[2]),
+                                    absence_confidence=v[3], presence_confidence=v[4])
+            assert ch[i] == [-1 if ref[0] is None else ref[0], -1 if ref[1] is None else ref[1]], (v, i, ch[i], ref)
+            n_votes += ref[0] is not None or ref[1] is not None
+    assert n_votes > 10
+    res = json.loads(outs[-len(votes) - 1])
     n_hits = 0
     for i, r in enumerate(res["results"]):
         pres, absn = ora.check_one(q[i], int(t0[i]), int(t1[i]))

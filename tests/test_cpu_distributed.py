@@ -7,11 +7,16 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_sharded_fusion_equals_unsharded():
+import pytest
+
+
+@pytest.mark.parametrize("world,port", [(2, 29731), (3, 29733)])
+def test_sharded_fusion_equals_unsharded(world, port):
+    """2 ranks, and 3 (a camera's home rank for the motion clustering is no longer "the other one"; three-way halos)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "tests", "dist_worker.py")]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "DIST_OK" in out.stdout
 

@@ -263,7 +263,7 @@ def main():
                     obj_stats[2] += time.perf_counter() - t_e
             return
         for ci, (dep, rgb, lab, pose) in enumerate(cams):
-            flags = 0
+            flags = ctx.PF_INPUT_READY  # the synthetic frames are resident and complete before the timed region
             if not args.no_motion and world == 1:
                 flags |= ctx.PF_MOTION
             if pipe is not None:

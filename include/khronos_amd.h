@@ -302,6 +302,10 @@ int khr_object_prune(khr_ctx* ctx, float min_confidence, float min_observations,
 #define KHR_PF_OBJECTS 8u /* ConnectedSemantics on the frame (khr_configure_object_detector first): its kernels are queued
                              right after the ingest and its host part runs once the frame's other kernels are queued;
                              khr_detect_objects / khr_get_semantic_clusters then return the cached result */
+#define KHR_PF_INPUT_READY 16u /* on_device frames only: the input buffers are COMPLETE when the call is made (nothing still
+                                  queued on the context's stream writes them).  The ingest then runs on the context's second
+                                  stream beside the previous frame's tail instead of behind it.  Without the flag the ingest is
+                                  ordered behind everything queued on the context's stream, as every other call is. */
 int khr_process_frame(khr_ctx* ctx, const khr_sensor* sensor, const khr_frame* frame, int on_device, uint32_t flags,
                       int* n_clusters);
 

@@ -299,6 +299,7 @@ class FusionContext:
         self._chk(self.lib.khr_tick_integrate(self.h, arr, n, 1 if use_mask else 0, int(object_id), int(phases)))
 
     PF_OBJECTS = 8
+    PF_INPUT_READY = 16  # device inputs are complete at call time: the ingest may run ahead on the second stream
     PF_MOTION, PF_TRACKING, PF_OUTPUT = 1, 2, 4
 
     def make_frame(self, stamp_ns, world_T_sensor, depth_ptr, color_ptr=0, label_ptr=0):

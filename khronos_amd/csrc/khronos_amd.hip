@@ -2496,11 +2496,12 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   if (n_clusters) *n_clusters = 0;
   const bool motion = (flags & KHR_PF_MOTION) != 0;
   const bool objects = (flags & KHR_PF_OBJECTS) != 0;
-  // The ingest only writes the frame slot, so it runs on the auxiliary stream: queued as soon as this call starts, it
+  // KHR_PF_INPUT_READY (the caller's buffers are complete): the ingest only writes the frame slot, so it runs on the
+  // auxiliary stream: queued as soon as this call starts, it
   // executes beside the tail of the previous frame (tracking, ever-free, output) instead of after it.  Only with the
   // motion detector on: its per-frame host wait is what keeps the host from queueing frames whose slot an earlier
   // frame still reads.  The per-frame counter reset moves to the first main-stream kernel (k_motion_pixels).
-  const bool early = c->early_ingest && on_device && motion && c->cfg.with_tracking && c->slots.size() >= 2;
+  const bool early = c->early_ingest && (flags & KHR_PF_INPUT_READY) && on_device && motion && c->cfg.with_tracking && c->slots.size() >= 2;
   c->begin_in_ingest = !early;
   c->ingest_stream = early ? c->aux_stream : nullptr;
   const int slot = khr_upload_frame(c, sensor, frame, on_device);

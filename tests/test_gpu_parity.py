@@ -248,18 +248,30 @@ def test_tracking_shortcuts_are_exact():
     both_equal()
 
 
-def test_fused_process_frame_equals_stepwise():
-    """khr_process_frame (one call per frame, asynchronous output stage) == the step-by-step calls."""
-    cfg, ctx, ora, s, sen, osen = make_pair(width=320, height=240, temporal_window=0.75)
+@pytest.mark.parametrize("inputs", ["host", "device", "device-ready"])
+def test_fused_process_frame_equals_stepwise(inputs):
+    """khr_process_frame (one call per frame, asynchronous output stage) == the step-by-step calls; with host buffers, with
+    device buffers, and with device buffers declared complete (KHR_PF_INPUT_READY: the ingest runs ahead on the context's
+    second stream and the per-frame counter reset moves into the motion detector's pixel pass)."""
+    from common import DeviceArray
+    cfg, ctx, ora, s, sen, osen = make_pair(width=320, height=240, temporal_window=0.75, num_frame_slots=3)
     fired = 0
+    held = []
     for i in range(20):
         fr = s.render(i)
         out_now = i % 4 == 3
         f = ctx.make_frame(fr["stamp"], fr["pose"], 0)
         depth = np.ascontiguousarray(fr["depth"]); rgb = np.ascontiguousarray(fr["rgb"]); lab = np.ascontiguousarray(fr["label"])
-        f.depth, f.color, f.label = depth.ctypes.data, rgb.ctypes.data, lab.ctypes.data
         flags = ctx.PF_MOTION | ctx.PF_TRACKING | (ctx.PF_OUTPUT if out_now else 0)
-        slot, nc = ctx.process_frame(sen, f, on_device=False, flags=flags)
+        if inputs == "host":
+            f.depth, f.color, f.label = depth.ctypes.data, rgb.ctypes.data, lab.ctypes.data
+        else:
+            dev = [DeviceArray(depth), DeviceArray(rgb), DeviceArray(lab)]  # (hipMemcpy: complete when it returns)
+            held.append(dev)
+            f.depth, f.color, f.label = (d.data_ptr() for d in dev)
+            if inputs == "device-ready":
+                flags |= ctx.PF_INPUT_READY
+        slot, nc = ctx.process_frame(sen, f, on_device=inputs != "host", flags=flags)
         n_o, dyn_o, _ = ora.detect_motion(osen, fr["stamp"], fr["pose"], fr["depth"])
         assert nc == n_o
         fired += nc
@@ -275,6 +287,10 @@ def test_fused_process_frame_equals_stepwise():
             assert np.abs(gm["points"] - om["points"]).max() <= TOL if len(om["points"]) else True
     assert fired > 0
     compare_maps(ctx, ora, max_blocks=100)
+    ctx.sync()
+    for dev in held:
+        for d in dev:
+            d.free()
 
 
 def test_two_shards_with_halo_exchange_equal_unsharded():

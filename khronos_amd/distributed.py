@@ -1,10 +1,12 @@
 """Multi-GPU tick orchestration: one process per GPU, the block map sharded by contiguous
 hash range, owner-computes.  Per tick the ranks
-  (1) all-gather the camera frames (done by the caller),
-  (2) run the motion detector's per-pixel pass on their shard; a small all-reduce of the seed-pixel counts
-      decides which cameras need the (rare) sum all-reduce of the per-pixel voxel keys, after which every rank
-      clusters and paints the identical dynamic image,
-  (3) integrate every frame into the blocks they own (with the dynamic mask),
+  (1) all-gather the camera frames (done by the caller; bench.py prefetches the next tick's gather on its own stream),
+  (2) ingest all cameras in one launch; the motion detector's seed test runs in the same pass on each rank's shard, and a
+      small all-reduce of the per-camera seed-pixel counts decides which cameras need more: for those the per-pixel voxel
+      keys are reduced to the camera's home rank, which clusters them, paints the dynamic image and broadcasts it
+      (shard_motion=False: the keys are all-reduced and every rank clusters the identical image),
+  (3) allocate / cull for every frame (queued before the count exchange: it does not depend on the masks), then integrate
+      every frame into the blocks they own (with the dynamic mask),
   (4) run the per-voxel tracking update,
   (5) all-gather fixed-size halo records (528 B per live block: key + 4096 free-or-ever-free bits),
   (6) run the ever-free stencil with remote neighbours served from the gathered records.

@@ -7,9 +7,15 @@ integration (with the dynamic mask) -> tracking + ever-free update, and every `-
 the output extraction (marching cubes on updated blocks, archival of inactive blocks, flag clearing;
 active_window.cpp:217-249 at uHumans2's min_output_separation = 0.4 s).
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 1280x720 RGB-D + labels,
-2 cm voxels, truncation 6 cm, 16^3 blocks, K = 20 labels, MotionDetector on.  Frames are rendered on the
-host BEFORE the timed region and are resident in HBM when it starts.
+Workloads (`--config`, BASELINE.json `configs`; explicit --width / --voxel-size / ... override a preset):
+  c3 (default, the configuration the metric is quoted on): 1280x720 RGB-D + labels, 2 cm voxels, truncation 6 cm,
+     K = 20 labels, MotionDetector + object detection / tracking / extraction on, output every 4th frame (0.4 s).
+  c2: 640x480, 5 cm voxels, truncation 15 cm, static background TSDF only (khronos_ros/config/mapper/ground_truth.yaml:56-94:
+     no motion detector, no object detector, min_output_separation 0 = mesh + archival every frame).
+  c1: 640x480, 5 cm voxels, the projective integrator alone (allocation + TSDF / label update of each frame).
+Frames are rendered on the host BEFORE the timed region and are resident in HBM when it starts.  `--preroll` frames are
+fused before the warm-up so that the timed steps run on a map / track set in steady state (tracks old enough to leave
+the window and be extracted).
 
 N > 1 (one process per GPU, launched by torch.distributed.run): rank r owns camera r of an N-camera rig
 and the hash-range shard r of the block map; every tick the N camera frames are all-gathered over RCCL
@@ -37,15 +43,23 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--width", type=int, default=1280)
-    ap.add_argument("--height", type=int, default=720)
-    ap.add_argument("--voxel-size", type=float, default=0.02)
+    ap.add_argument("--config", choices=["c1", "c2", "c3"], default="c3", help="BASELINE.json workload preset (see module docstring)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--voxel-size", type=float, default=None)
     ap.add_argument("--num-labels", type=int, default=20)
     ap.add_argument("--max-blocks", type=int, default=40960)
-    ap.add_argument("--output-every", type=int, default=4)
-    ap.add_argument("--no-motion", action="store_true")
-    ap.add_argument("--no-objects", action="store_true",
+    ap.add_argument("--output-every", type=int, default=None)
+    ap.add_argument("--no-motion", action="store_true", default=None)
+    ap.add_argument("--no-objects", action="store_true", default=None,
                     help="leave out the object half of the active window (ConnectedSemantics, MaxIoUTracker, MeshObjectExtractor)")
+    ap.add_argument("--no-tracking", action="store_true", default=None, help="leave out TrackingIntegrator::updateBlocks (c1)")
+    ap.add_argument("--preroll", type=int, default=None,
+                    help="frames fused before the warm-up (untimed): brings the map and the tracker to steady state; default 60 for c3, 0 otherwise")
+    ap.add_argument("--latency-frames", type=int, default=8,
+                    help="frames after the timed region that are run with a device synchronisation after each: per-frame latency "
+                         "(the reference's active_window/all scope) beside the pipelined throughput; 0 = skip")
+    ap.add_argument("--exact", action="store_true", help="khr_config.exact_arithmetic = 1 (values bit-identical to the CPU restatement)")
     ap.add_argument("--buffer-frames", type=int, default=100, help="frame_data_buffer.max_buffer_size (frames kept in HBM per camera)")
     ap.add_argument("--cpu-baseline-frames", type=int, default=-1,
                     help="frames of the same stream timed on the CPU oracle (rank 0, N=1); -1 = auto, 0 = skip")
@@ -58,7 +72,14 @@ def parse_args():
                     help="development: ONE process plays rank 0 of an N-rank sharded run (all N cameras rendered locally, no "
                          "collectives) to measure the per-rank tick cost on a 1-GPU box; the JSON line is marked emulation")
     ap.add_argument("--halo-cap", type=int, default=8192, help="halo records all-gathered per rank and tick (N > 1)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    preset = {"c3": dict(width=1280, height=720, voxel_size=0.02, output_every=4, no_motion=False, no_objects=False, no_tracking=False, preroll=60),
+              "c2": dict(width=640, height=480, voxel_size=0.05, output_every=1, no_motion=True, no_objects=True, no_tracking=False, preroll=0),
+              "c1": dict(width=640, height=480, voxel_size=0.05, output_every=0, no_motion=True, no_objects=True, no_tracking=True, preroll=0)}[a.config]
+    for k, v in preset.items():
+        if getattr(a, k) is None:
+            setattr(a, k, v)
+    return a
 
 
 # `active_window:` YAML of the object half (keys and values of khronos_ros/config/mapper/uHumans2.yaml:35-100; the
@@ -143,9 +164,17 @@ def main():
 
     W, H, vs = args.width, args.height, args.voxel_size
     K = args.num_labels
-    n_total = args.warmup + args.steps
+    # stream layout: [pre-roll | warm-up | timed steps | latency frames]; only world == 1 runs pre-roll / latency frames
+    pre = args.preroll if world == 1 else 0
+    lat = args.latency_frames if (world == 1 and not args.frame_times) else 0
+    w0 = pre                      # first warm-up frame
+    t0i = pre + args.warmup       # first timed frame
+    t1i = t0i + args.steps        # first latency frame
+    n_total = t1i + lat
+    trunc = 3.0 * vs
     cfg = default_config(
-        voxel_size=vs, truncation_distance=3.0 * vs, voxels_per_side=16, with_semantics=1, with_tracking=1,
+        voxel_size=vs, truncation_distance=trunc, voxels_per_side=16, with_semantics=1, with_tracking=1,
+        exact_arithmetic=1 if args.exact else 0,
         num_labels=K, max_blocks=args.max_blocks, max_frame_pixels=W * H,
         # buffered frames stay resident in the device ring (FrameDataBuffer role); every rank holds all cameras' frames
         num_frame_slots=max(2, world) if args.no_objects else world * (args.buffer_frames + 1) + 64,  # + frames held by detached extractions
@@ -270,7 +299,8 @@ def main():
                 flags |= ctx.PF_OBJECTS
             last = ci == len(cams) - 1
             if last:
-                flags |= ctx.PF_TRACKING  # TrackingIntegrator::updateBlocks once per tick, after all cameras
+                if not args.no_tracking:
+                    flags |= ctx.PF_TRACKING  # TrackingIntegrator::updateBlocks once per tick, after all cameras
                 if out_now:
                     flags |= ctx.PF_OUTPUT
             _t0 = time.perf_counter()
@@ -302,9 +332,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(t0i):  # pre-roll + warm-up, untimed
         step(i)
     sync_all()
+    obj_before = list(obj_stats)
+    if pipe is not None:
+        obj_before[0] += 0  # (detached extractions finishing later are attributed to the region that joins them)
     st0 = ctx.stats()
     if not args.no_roofline_timers:
         ctx.timing_reset()
@@ -313,7 +346,7 @@ def main():
         ctx.timing_enable(True, None if args.all_timers else ("tsdf",))  # HIP events cost a barrier packet each: only the roofline kernel
     t0 = time.perf_counter()
     ft = []
-    for i in range(args.warmup, n_total):
+    for i in range(t0i, t1i):
         if args.frame_times:
             torch.cuda.synchronize()
             tf = time.perf_counter()
@@ -333,6 +366,23 @@ def main():
     dt = time.perf_counter() - t0
     ctx.timing_enable(False)
     st1 = ctx.stats()
+    obj_timed = [obj_stats[k] - obj_before[k] for k in range(3)]
+    # per-frame latency: the same steps with a device synchronisation after each (the reference's active_window/all scope
+    # is a per-frame wall time; `value` above is pipelined throughput: the host queues frame i + 1 while frame i executes)
+    lat_ms = None
+    if lat > 0:
+        tl = []
+        for i in range(t1i, n_total):
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            step(i)
+            if pipe is not None:
+                pipe.finish_frame()
+            torch.cuda.synchronize()
+            tl.append(1e3 * (time.perf_counter() - ta))
+        if pipe is not None:
+            pipe.join()
+        lat_ms = {"mean": float(np.mean(tl)), "min": float(np.min(tl)), "max": float(np.max(tl)), "frames": len(tl)}
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -350,18 +400,29 @@ def main():
         n_upd_all, n_band_all, n_vis_all = float(n_upd), float(n_band), float(n_vis)
 
     frames = args.steps * world  # camera frames fused by the whole job
+    # the label names a BASELINE config only when the arguments ARE that config
+    ref = {"c3": (1280, 720, 0.02, 4, False, False, False), "c2": (640, 480, 0.05, 1, True, True, False),
+           "c1": (640, 480, 0.05, 0, True, True, True)}[args.config]
+    preset_matches = (W, H, vs, args.output_every, bool(args.no_motion), bool(args.no_objects), bool(args.no_tracking)) == ref and K == 20
+    preset_name = ({"c3": "BASELINE configs[2]: ", "c2": "BASELINE configs[1] (synthetic stand-in for the tesse_cd_office replay): ",
+                    "c1": "BASELINE configs[0] (projective integrator alone): "}[args.config]) if preset_matches else "custom: "
     fps = frames / dt
     out = {
         "metric": "active-window frames/sec (+ Mvoxel-updates/sec) at %dx%d RGB-D+labels, %g cm voxels" % (W, H, vs * 100),
+        "latency_ms_per_frame": lat_ms,
         "value": fps, "unit": "frames/s", "n_gpus": 1 if emu else world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2]: %dx%d synthetic RGB-D+labels, %g cm voxels, vps 16, K=%d labels, "
-                               "MotionDetector %s, object detection / tracking / extraction %s, output (mesh, archival, object "
-                               "extraction) every %d frames; %d camera(s)"
-                               % (W, H, vs * 100, K, "off" if args.no_motion else "on",
+        "config": {"workload": "%s%dx%d synthetic RGB-D+labels, %g cm voxels, truncation %g cm, vps 16, K=%d labels, "
+                               "MotionDetector %s, tracking integrator %s, object detection / tracking / extraction %s, %s; %d camera(s); "
+                               "%d pre-roll + %d warm-up frames before the timed steps; %s arithmetic"
+                               % (preset_name, W, H, vs * 100, trunc * 100, K, "off" if args.no_motion else "on",
+                                  "off" if args.no_tracking else "on",
                                   "off" if args.no_objects else "on (ConnectedSemantics, MaxIoUTracker, MeshObjectExtractor)",
-                                  args.output_every, world),
+                                  ("output (mesh, archival%s) every %d frame(s)" % ("" if args.no_objects else ", object extraction", args.output_every))
+                                  if args.output_every > 0 else "no output stage", world, pre, args.warmup,
+                                  "exact" if args.exact else "fast (decisions exact, values ~1e-6)"),
+                   "preset": args.config if preset_matches else None,
                    "parallelism": "hash-range block shard x%d, owner-computes, RCCL all-gather of packed frames (prefetched one tick ahead on its own stream) + of 528-B halo records "
                                   "(ever-free), seed-gated all-reduce of per-pixel voxel keys (motion detector), request / response all-gather of mesh halo planes" % world
                    if world > 1 else "single GPU"},
@@ -370,47 +431,49 @@ def main():
                          "if communication were free and all ranks were as loaded as rank 0 -- NOT a measured N-GPU number" % world}
            if emu else {}),
         "objects": None if pipe is None else {"tracks_at_end": pipe.num_tracks(), "buffered_frames": pipe.num_buffered_frames(),
-                                              "objects_extracted": obj_stats[0], "tracks_removed": obj_stats[1],
-                                              "extraction_ms_total": 1e3 * obj_stats[2]},
+                                              "objects_extracted": obj_timed[0], "tracks_removed": obj_timed[1],
+                                              "extraction_ms_total": 1e3 * obj_timed[2],
+                                              "objects_extracted_before_timed_region": obj_before[0]},
         "voxels": {"visited": n_vis_all, "updated": n_upd_all, "band": n_band_all, "allocated_blocks": st1["n_allocated_blocks"],
                    "last_frame_visible_blocks": st1["n_visible_blocks"], "last_frame_tsdf_blocks": st1["n_tsdf_blocks"],
                    "band_overflow": st1["band_overflow"], "last_frame_tracking_blocks": st1["n_tracking_processed_blocks"],
                    "last_frame_touched_blocks": st1["n_tracking_updated_blocks"]},
     }
 
-    # ---- roofline of the dominant kernel (k_tsdf_update), from HIP events on the kernel's stream ----
+    # ---- roofline of the dominant kernel (k_fuse: the fused TSDF / colour / label update), from HIP events on the
+    #      kernel's own dispatch packets (hipExtLaunchKernelGGL start / stop events on the kernel's stream) ----
     if not args.no_roofline_timers and rank == 0:
         ms, launches = ctx.timing_get("tsdf")
-        # ALGORITHMIC bytes: 24 B per updated voxel (R+W distance, weight; W last_observed)
-        # + (12 + 8K) B per in-band voxel (R+W colour, R+W K likelihoods, W label) + 15 B per pixel (images once)
-        # The update is two kernels: k_tsdf_update (distance / weight / last_observed + range image) and
-        # k_band_update (colour, likelihoods, label + rgb / label / mask images); the roofline object is for
-        # the dominant one, k_tsdf_update, the other is reported in "roofline_band".
-        bytes_total = 24.0 * n_upd + 4.0 * W * H * max(1, launches)
+        nl = max(1, launches)
+        # ALGORITHMIC bytes of the TSDF-update kernel, SURVEY.md section 8(d):
+        #   24 B per updated voxel (R+W distance, R+W weight, W last_observed)
+        # + (12 + 8K) B per in-band voxel (R+W colour, R+W K likelihoods, W label)
+        # + the images once per launch: depth 4 + label 4 + rgb 3 (+ mask 4 with the motion detector) B per pixel
+        px_bytes = 11.0 + (0.0 if args.no_motion else 4.0)
+        bytes_total = 24.0 * n_upd + (12.0 + 8.0 * K) * n_band + px_bytes * W * H * nl
         achieved = bytes_total / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        ms_b, launches_b = ctx.timing_get("band")
-        bytes_b = (12.0 + 8.0 * K) * n_band + 11.0 * W * H * max(1, launches_b)
-        ach_b = bytes_b / (ms_b * 1e-3) / 1e9 if ms_b > 0 else 0.0
-        if launches_b > 0:  # --all-timers
-            out["roofline_band"] = {"kernel": "k_band_update", "bound": "hbm", "achieved": ach_b, "peak": 8000.0,
-                                    "unit": "GB/s", "frac": ach_b / 8000.0, "avg_launch_us": 1e3 * ms_b / max(1, launches_b),
-                                    "algorithmic_bytes_per_launch": bytes_b / max(1, launches_b)}
-            out["tsdf_step_GBps"] = (bytes_total + bytes_b) / ((ms + ms_b) * 1e-3) / 1e9 if (ms + ms_b) > 0 else 0.0
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_tsdf_update_bytes_per_launch")
+                tj = json.load(open(tpath))
+                if tj.get("kernel") == "k_fuse" and tj.get("workload") == [W, H, vs]:
+                    traffic = tj.get("k_fuse_bytes_per_launch")
+                    traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, %s; NOT measured in this run)" % tj.get("collected", "?")
             except Exception:
                 traffic = None
-        out["roofline"] = {"kernel": "k_tsdf_update", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
-                           "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                           "avg_launch_us": 1e3 * ms / max(1, launches), "launches": launches,
-                           "algorithmic_bytes_per_launch": bytes_total / max(1, launches)}
+        out["roofline"] = {"kernel": "k_fuse", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
+                           "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                           "avg_launch_us": 1e3 * ms / nl, "launches": launches,
+                           "algorithmic_bytes_per_launch": bytes_total / nl,
+                           "algorithmic_bytes": "24 B x N_upd + (12 + 8K) B x N_band + %g B x W x H per launch (SURVEY.md 8(d))" % px_bytes,
+                           "frac_of_measured_copy_peak_6290": achieved / 6290.0}
+        # Mvoxel-updates/s = N_upd / sum of the TSDF-update step's time (the whole-frame figure is above)
+        out["mvoxel_updates_per_s_tsdf_step"] = 1e-6 * n_upd / (ms * 1e-3) if ms > 0 else None
         kern = {}
-        for name in ("tsdf", "band", "tracking", "ever_free", "alloc", "motion_pixels", "mesh", "parse"):
+        for name in ("tsdf", "tracking", "ever_free", "alloc", "motion_pixels", "mesh", "parse"):
             m_, n_ = ctx.timing_get(name)
-            kern[name] = {"ms_total": m_, "launches": n_}
+            kern["fuse" if name == "tsdf" else name] = {"ms_total": m_, "launches": n_}
         out["kernel_ms"] = kern
 
     # ---- CPU baseline: the oracle on a bounded sample of the same stream (rank 0, N = 1 only) ----
@@ -419,7 +482,7 @@ def main():
         from oracle import pyoracle as po
         cores = os.cpu_count() or 1
         if nb < 0:
-            nb = max(4, min(12, args.warmup + args.steps))
+            nb = max(4, min(12, args.warmup + args.steps)) if args.config == "c3" else 24
         ocfg = po.config_from(cfg, cores)
         ora = po.OracleMap(ocfg)
         osen = ora.make_sensor(W, H, s.fx, s.fy, s.cx, s.cy, 0.1, 5.0)
@@ -434,7 +497,8 @@ def main():
             if not args.no_motion:
                 _, dyn, _ = ora.detect_motion(osen, fr["stamp"], fr["pose"], fr["depth"])
             stc = ora.integrate(osen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"], mask=dyn)
-            ora.update_tracking(fr["stamp"])
+            if not args.no_tracking:
+                ora.update_tracking(fr["stamp"])
             if pipe is not None:
                 # object half on the CPU: ConnectedSemantics + the tracker's voxel sets (single-threaded in the reference
                 # too); the association itself is negligible and not timed
@@ -445,7 +509,8 @@ def main():
                     ora.cluster_voxels(osen, fr["stamp"], fr["pose"], fr["depth"], dyn, 0.2)
             if args.output_every > 0 and (i + 1) % args.output_every == 0:
                 ora.generate_mesh(True, True)
-                ora.reset_inactive()
+                if not args.no_tracking:
+                    ora.reset_inactive()
                 ora.clear_updated()
             c1 = time.perf_counter()
             if i >= skip:

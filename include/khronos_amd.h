@@ -82,12 +82,17 @@ typedef struct khr_config {
   uint32_t max_frame_pixels;  /* largest W*H that will be uploaded */
   uint32_t num_frame_slots;   /* device-resident frame ring (FrameDataBuffer role, frame_data_buffer.h:52-100) */
   uint64_t max_mesh_vertices; /* capacity of the mesh vertex buffer */
-  uint32_t max_band_records;  /* capacity of the per-frame in-band voxel list (0 = 4 * max_frame_pixels) */
+  uint32_t max_band_records;  /* unused since the fused update kernel (in-band voxels never leave the wave); kept for layout */
   int32_t disable_culling;    /* 1 = visit every frustum block in the TSDF kernel (A/B switch; results identical) */
   /* placement */
   int32_t device;     /* HIP device ordinal */
   int32_t rank;       /* owner-computes sharding: this context integrates blocks with owner == rank */
   int32_t world_size; /* 1 = unsharded */
+  /* arithmetic of the voxel update: 0 (default) = every decision (validity, band membership, interpolation mode, mask,
+   * weight > 0) exactly as the CPU restatement, measurement weight and running average with contracted FMAs and
+   * v_rcp_f32 (values within ~1e-6 relative of the restatement); 1 = values bit-identical to the restatement as well
+   * (golden fixtures, A/B tests). */
+  int32_t exact_arithmetic;
 } khr_config;
 
 typedef struct khr_sensor {
@@ -123,7 +128,7 @@ typedef struct khr_stats {
   uint64_t cum_visited_voxels;
   uint64_t cum_integrate_calls;
   uint64_t n_tsdf_blocks;      /* last integrate: blocks left after conservative culling */
-  uint64_t band_overflow;      /* non-zero if in-band records were dropped (raise max_band_records) */
+  uint64_t band_overflow;      /* always 0 (the fused update kernel keeps no global record list) */
   uint64_t n_tracking_processed_blocks; /* blocks the last tracking pass had to visit (the rest provably cannot change) */
 } khr_stats;
 
@@ -356,9 +361,9 @@ int khr_tick_seed_counts(khr_ctx* ctx, uint32_t* n_seed_pixels, int n_frames);
 int khr_tick_integrate(khr_ctx* ctx, const int* slots, int n_frames, int use_mask, int object_id, int phases);
 
 /* -- measurement ------------------------------------------------------------------------------- */
-/* HIP-event timing of the kernels launched on the context stream. which: 0 tsdf update,
- * 1 tracking update, 2 ever-free, 3 block allocation+init, 4 motion pixels, 5 mesh, 6 parse input,
- * 7 band (colour / label) update.
+/* HIP-event timing of the kernels launched on the context stream. which: 0 fused TSDF / colour / label update
+ * (k_fuse), 1 tracking update, 2 ever-free, 3 block allocation+init, 4 motion pixels, 5 mesh, 6 parse input,
+ * 7 unused (the band update is part of k_fuse).
  * `enable` is a bit mask of timers (bit i = timer i; 0 = off, 0xff = all).
  * Accumulates between khr_timing_reset calls; returns total ms and launch count. */
 /* development probe (KHR_DEBUG & 8): per-workgroup timestamps of the last k_tsdf_update launch */

@@ -51,7 +51,7 @@ enum Counter : int {
   C_MP_DONE,         // finished workgroups of k_motion_pixels (the last one publishes the seed count)
   C_COUNT = 24
 };
-enum Stat64 : int { S_UPD = 0, S_BAND, S_MESH_VERTS, S_PRUNED, S_CUM_UPD, S_CUM_BAND, S_CUM_VISITED, S_CUM_CALLS, S_COUNT = 8 };
+enum Stat64 : int { S_UPD = 0 /* unused */, S_BAND /* unused */, S_MESH_VERTS, S_PRUNED, S_CUM_UPD, S_CUM_BAND, S_CUM_VISITED, S_CUM_CALLS, S_COUNT = 8 };
 
 struct MeshDesc {
   uint32_t offset;  // first vertex in the mesh vertex buffer
@@ -250,23 +250,36 @@ __device__ inline void publishSeedCount(const DevMap& m, volatile uint32_t* host
   __threadfence_system();
 }
 
-constexpr int kBandShards = 16;  // the in-band record list is split in shards (one atomic cursor each)
+constexpr int kFuseStatSlots = 2048;  // upper bound of k_fuse's grid: one {n_upd, n_band} statistics slot per workgroup
 
-// per-call counter reset; the previous call's statistics are folded into cumulative totals so that a
-// benchmark can read N_upd / N_band sums once, outside its timed region.
-__device__ inline void beginIntegrate(DevMap m, int nvox, uint32_t* band_count) {
-  if (threadIdx.x < kBandShards) band_count[threadIdx.x * 32] = 0u;
+// per-call counter reset (one workgroup, any size).  k_fuse leaves its statistics as per-workgroup partial sums in
+// wg_stats; they are folded into the cumulative totals here, so that a benchmark can read N_upd / N_band sums once,
+// outside its timed region (khr_get_stats adds the slots that have not been folded yet).
+__device__ inline void beginIntegrate(DevMap m, int nvox, uint32_t* wg_stats) {
+  unsigned long long u = 0, b = 0;
+  uint2* __restrict__ st = reinterpret_cast<uint2*>(wg_stats);
+#pragma unroll 4
+  for (int i = threadIdx.x; i < kFuseStatSlots; i += blockDim.x) {
+    const uint2 v = st[i];
+    u += v.x;
+    b += v.y;
+    if (v.x | v.y) st[i] = make_uint2(0u, 0u);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    u += __shfl_down(u, o);
+    b += __shfl_down(b, o);
+  }
+  if ((threadIdx.x & 63) == 0 && (u | b)) {
+    atomicAdd(&m.stats[S_CUM_UPD], u);
+    atomicAdd(&m.stats[S_CUM_BAND], b);
+  }
   if (threadIdx.x == 0) {
-    m.stats[S_CUM_UPD] += m.stats[S_UPD];
-    m.stats[S_CUM_BAND] += m.stats[S_BAND];
     m.stats[S_CUM_VISITED] += static_cast<unsigned long long>(m.counters[C_N_VISIBLE]) * nvox;
     m.stats[S_CUM_CALLS] += 1ull;
-    m.stats[S_UPD] = 0ull;
-    m.stats[S_BAND] = 0ull;
     m.counters[C_N_VISIBLE] = 0u;
     m.counters[C_N_NEW] = 0u;
     m.counters[C_N_TSDF] = 0u;
-    m.counters[C_TSDF_CURSOR] = 0u;
   }
 }
 

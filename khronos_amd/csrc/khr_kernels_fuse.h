@@ -1,0 +1,445 @@
+// khr_kernels_fuse.h — k_fuse: the per-voxel loop of hydra::ProjectiveIntegrator::updateMap (call
+// active_window.cpp:210; label hook object_integrator.cpp:58-81; ASSUMPTIONS.md A.3 / A.4) as ONE kernel:
+// projective TSDF update (distance, weight, last_observed) and, for the voxels inside the truncation band,
+// colour blend + semantic likelihoods + arg-max label.  gfx950, wave64.
+//
+// Shape:
+//  * a WAVE is the unit of work: it owns 64 voxels of an x-y patch of a block (16 x 4 voxels for 16^3 blocks, the
+//    whole 8 x 8 slice for 8^3 blocks) and walks them through a range of z.  The 64 voxels are consecutive in every
+//    per-voxel array, so each load / store of the wave is one contiguous 256-byte (512 for the stamps) segment, and
+//    their 64 image footprints are neighbours.  Waves never talk to each other: no workgroup barrier, no atomics on
+//    the voxel path, results stay in registers between the measurement and the read-modify-write.
+//  * the x / y part of the voxel-centre transform is computed once per wave item, each z step adds the z part
+//    (same operation order as the reference restatement, so the projected pixel is bit-identical);
+//  * the four range samples of a voxel arrive as two 8-byte gathers (the pixel pairs (u0, v0)-(u0+1, v0) and
+//    (u0, v1)-(u0+1, v1)); distance / weight are loaded as soon as the voxel is known to project into the image, i.e.
+//    together with the gathers, and only for such voxels;
+//  * every DECISION (in front of the camera, in range, in the image, interpolation mode, sdf >= -truncation, inside the
+//    band, dynamic mask, weight > 0) is evaluated with the reference's operations in the reference's order; the
+//    divisions behind them share one refined reciprocal of the voxel depth and use the correctly rounded
+//    rcp-Newton-FMA sequence (what hipcc emits for `/`, minus the scaling steps that are unnecessary for depths in
+//    [min_range, max_range]).  EXACT = false relaxes only VALUES: measurement weight and running average use
+//    contracted FMAs and v_rcp_f32 (relative error ~1e-6, far inside the 1e-4 the path promises);
+//    EXACT = true keeps them bit-identical to the CPU oracle (khr_config.exact_arithmetic, golden tests);
+//  * in-band voxels (a few per cent) are compacted with a ballot into a per-wave LDS list {voxel, mode, weights, u, v}
+//    and worked off DENSELY by the same wave (lane <-> record): colour, label lookup, K likelihoods with all loads
+//    issued before the first store.  No global record list, no second launch, no list atomics.
+//  * statistics leave the kernel as one plain read-modify-write per workgroup on its own slot of wg_stats
+//    (hot-address atomics sustain only ~90 ops/us on gfx950); beginIntegrate / khr_get_stats fold them.
+#pragma once
+#include "khr_device.h"
+
+namespace khr {
+
+__device__ inline void interpPixels(float u, float v, int W, int H, int* px, float* du, float* dv) {
+  const int u0 = static_cast<int>(floorf(u)), v0 = static_cast<int>(floorf(v));
+  const int u1 = min(u0 + 1, W - 1), v1 = min(v0 + 1, H - 1);
+  *du = u - static_cast<float>(u0);
+  *dv = v - static_cast<float>(v0);
+  px[0] = v0 * W + u0;
+  px[1] = v1 * W + u0;
+  px[2] = v0 * W + u1;
+  px[3] = v1 * W + u1;
+}
+
+__device__ inline int interpWeights(float du, float dv, bool use_nearest, float* w4) {
+  int best;
+  if (use_nearest) {
+    const int nearest = (du >= 0.5f ? 2 : 0) + (dv >= 0.5f ? 1 : 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w4[k] = (k == nearest) ? 1.f : 0.f;
+    best = nearest;
+  } else {
+    w4[0] = (1.f - du) * (1.f - dv);
+    w4[1] = (1.f - du) * dv;
+    w4[2] = du * (1.f - dv);
+    w4[3] = du * dv;
+    best = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (w4[k] > w4[best]) best = k;
+  }
+  return best;
+}
+
+// y ~ 1 / b: v_rcp_f32 (1 ulp) + one Newton step.  For normal b this is the reciprocal hipcc's IEEE division uses.
+__device__ inline float rcpRefined(float b) {
+  const float y = __builtin_amdgcn_rcpf(b);
+  const float e = __builtin_fmaf(-b, y, 1.f);
+  return __builtin_fmaf(e, y, y);
+}
+// correctly rounded a / b from y = rcpRefined(b): the quotient / residual steps of hipcc's expansion of an IEEE f32
+// division (v_div_scale / v_div_fmas / v_div_fixup only matter for operands near the ends of the exponent range)
+__device__ inline float divExact(float a, float b, float y) {
+  float q = a * y;
+  float r = __builtin_fmaf(-b, q, a);
+  q = __builtin_fmaf(r, y, q);
+  r = __builtin_fmaf(-b, q, a);
+  return __builtin_fmaf(r, y, q);
+}
+
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));  // two adjacent pixels, 4-byte aligned
+
+struct FuseArgs {
+  // map
+  const int4* blk_index;
+  uint32_t* blk_flags;
+  float* dist;
+  float* weight;
+  uint64_t* last_obs;
+  uint32_t* color;
+  uint8_t* vflags;
+  uint32_t* sem_label;
+  float* lik;
+  uint32_t* wg_stats;  // [2 * gridDim.x]: {n_upd, n_band} accumulated per workgroup slot
+  // frame
+  const float* range;
+  const int32_t* dyn;
+  const uint32_t* rgba;
+  const int32_t* label;
+  const int32_t* obj;
+  int W, H;
+  float fx, fy, cx, cy, min_range, max_range;
+  float R[9], t[3];
+  uint64_t stamp;
+  // parameters
+  float vs, bs, trunc, dropoff_eps, max_weight, adaptive_diff, log_match, log_nomatch;
+  int interp, range_mode, use_dropoff, const_weight, with_tracking, use_mask;
+  int K, sem_mode, do_sem, has_color, object_id;
+};
+
+constexpr int kFuseCap = 192;        // in-band records a wave collects before it works them off
+
+// colour / label / likelihood update of one in-band voxel (the body of updateVoxel for |sdf| < truncation)
+// `a` points into the kernel-argument segment: the fields only this phase needs (image / layer pointers, label
+// parameters) are scalar loads issued here, instead of ~40 SGPRs kept alive through the voxel loop.
+typedef const FuseArgs __attribute__((address_space(4))) * FuseArgsK;
+constexpr int kLikVec = 5;  // float4 likelihood vectors a lane holds at once (K = 20 in one round trip)
+template <int VPS>
+__device__ inline void fuseBandRecord(FuseArgsK ka, size_t slot, uint32_t lin_mode, float w, float w_new, float u, float v) {
+  constexpr int NV = VPS * VPS * VPS;
+  const FuseArgs __attribute__((address_space(4)))& a = *ka;
+  const uint32_t lin = lin_mode & 0xffffu;
+  const bool use_nearest = (lin_mode & 0x10000u) != 0;
+  const int K = a.K;
+  // block bases are wave-uniform (SGPRs), the voxel adds a 32-bit byte offset
+  char* const color_b = reinterpret_cast<char*>(a.color + slot * NV);
+  char* const vfl_b = reinterpret_cast<char*>(a.vflags + slot * NV);
+  char* const lab_b = reinterpret_cast<char*>(a.sem_label + slot * NV);
+  char* const lik_b = reinterpret_cast<char*>(a.lik + slot * NV * static_cast<size_t>(K));  // voxel-major: K floats per voxel
+  const uint32_t lik_o = lin * static_cast<uint32_t>(K) * 4u;
+  int px4[4];
+  float du, dv, w4[4];
+  interpPixels(u, v, a.W, a.H, px4, &du, &dv);
+  const int best = interpWeights(du, dv, use_nearest, w4);
+  const uint32_t best_o = static_cast<uint32_t>(px4[best]) * 4u;
+  if (a.has_color) {
+    const char* const rgba_b = reinterpret_cast<const char*>(a.rgba);
+    uint32_t c4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c4[k] = *reinterpret_cast<const uint32_t*>(rgba_b + static_cast<uint32_t>(px4[k]) * 4u);
+    const uint32_t co = *reinterpret_cast<const uint32_t*>(color_b + lin * 4u);
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t c = c4[k];
+      acc[0] = acc[0] + w4[k] * static_cast<float>(c & 0xffu);
+      acc[1] = acc[1] + w4[k] * static_cast<float>((c >> 8) & 0xffu);
+      acc[2] = acc[2] + w4[k] * static_cast<float>((c >> 16) & 0xffu);
+    }
+    const float tot = w_new + w;
+    const float ytot = rcpRefined(tot);
+    uint32_t out = 0xff000000u;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float cn = static_cast<float>(toU8(acc[ch]));
+      const float cv = static_cast<float>((co >> (8 * ch)) & 0xffu);
+      out |= static_cast<uint32_t>(toU8(divExact(cv * w_new + cn * w, tot, ytot))) << (8 * ch);
+    }
+    *reinterpret_cast<uint32_t*>(color_b + lin * 4u) = out;
+  }
+  if (!a.do_sem) return;
+  const int label = (a.sem_mode == 1) ? ((*reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.obj) + best_o) == a.object_id) ? 1 : 0)
+                                      : *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.label) + best_o);
+  const uint8_t fl = *reinterpret_cast<const uint8_t*>(vfl_b + lin);
+  if (label < 0 || label >= K) return;
+  // a voxel without VOX_SEM_VALID holds no likelihoods yet: what is loaded is replaced by zeros
+  const bool empty = !(fl & VOX_SEM_VALID);
+  const float add_hit = (a.sem_mode == 1) ? 1.f : a.log_match, add_miss = (a.sem_mode == 1) ? 0.f : a.log_nomatch;
+  int bestk = 0;
+  float bestv = 0.f;
+  if ((K & 3) == 0) {
+    // 16-byte loads / stores, kLikVec vectors per round: every load of a round is issued before its first store
+    for (int j0 = 0; j0 < K / 4; j0 += kLikVec) {
+      float4 l4[kLikVec];
+#pragma unroll
+      for (int j = 0; j < kLikVec; ++j)
+        if (j0 + j < K / 4) l4[j] = *reinterpret_cast<const float4*>(lik_b + lik_o + static_cast<uint32_t>(j0 + j) * 16u);
+#pragma unroll
+      for (int j = 0; j < kLikVec; ++j) {
+        if (j0 + j >= K / 4) continue;
+        float l[4] = {l4[j].x, l4[j].y, l4[j].z, l4[j].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k = 4 * (j0 + j) + q;
+          if (empty) l[q] = 0.f;
+          if (a.sem_mode == 1) {
+            if (k == label) l[q] += 1.f;
+          } else {
+            l[q] += (k == label) ? add_hit : add_miss;
+          }
+          if (k == 0 || l[q] > bestv) {
+            bestv = l[q];
+            bestk = k;
+          }
+        }
+        *reinterpret_cast<float4*>(lik_b + lik_o + static_cast<uint32_t>(j0 + j) * 16u) = make_float4(l[0], l[1], l[2], l[3]);
+      }
+    }
+  } else {
+    float* __restrict__ lik = reinterpret_cast<float*>(lik_b + lik_o);
+    for (int k0 = 0; k0 < K; k0 += 8) {
+      float l[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) l[j] = (!empty && k0 + j < K) ? lik[k0 + j] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        if (k < K) {
+          if (a.sem_mode == 1) {
+            if (k == label) l[j] += 1.f;
+          } else {
+            l[j] += (k == label) ? add_hit : add_miss;
+          }
+          lik[k] = l[j];
+          if (k == 0 || l[j] > bestv) {
+            bestv = l[j];
+            bestk = k;
+          }
+        }
+      }
+    }
+  }
+  if (empty) *reinterpret_cast<uint8_t*>(vfl_b + lin) = fl | VOX_SEM_VALID;
+  *reinterpret_cast<uint32_t*>(lab_b + lin * 4u) = static_cast<uint32_t>(bestk);
+}
+
+// DEFCFG = the reference default switches (z-depth range, adaptive interpolation, weight drop-off, no constant
+// weight) resolved at compile time; otherwise they are read from the argument block.
+// ZSPLIT = wave items per x-y patch (a wave walks VPS / ZSPLIT z steps).
+// MINW = resident waves per SIMD the register allocation is held to (__launch_bounds__; 1 = unconstrained).
+template <int VPS, int ZSPLIT, bool DEFCFG, bool EXACT, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, const uint32_t* __restrict__ work,
+                                              const uint32_t* __restrict__ n_work) {
+  constexpr int NV = VPS * VPS * VPS;
+  constexpr int SL = VPS * VPS;        // voxels per z slice
+  constexpr int PATCHES = SL / 64;     // 64-voxel x-y patches per slice
+  constexpr int ZR = VPS / ZSPLIT;     // z steps per wave item
+  constexpr int WPB = PATCHES * ZSPLIT;  // wave items per block
+  constexpr int G = WPB / 4 > 0 ? WPB / 4 : 1;  // workgroup items that share a block: kept on one XCD (same range-image footprint)
+  static_assert(SL % 64 == 0 && VPS % ZSPLIT == 0, "bad block shape");
+  // per-wave record list, one LDS base per wave: field f of record r at s_rec[wave][f][r] (0 voxel | mode, 1 measurement
+  // weight, 2 voxel weight after the update, 3 u, 4 v), so the five stores of a record differ by immediate offsets
+  __shared__ uint32_t s_rec[4][5][kFuseCap];
+  __shared__ uint32_t s_stat[4][2];
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int lane = static_cast<int>(threadIdx.x & 63);
+  const int range_mode = DEFCFG ? 0 : a.range_mode;
+  const int interp = DEFCFG ? 2 : a.interp;
+  const bool use_dropoff = DEFCFG ? true : (a.use_dropoff != 0);
+  const bool const_weight = DEFCFG ? false : (a.const_weight != 0);
+  const float Wm1 = static_cast<float>(a.W - 1), Hm1 = static_cast<float>(a.H - 1);
+  const float fxfy = a.fx * a.fy;
+  const float den = a.trunc - a.dropoff_eps;  // weight drop-off denominator (uniform)
+  const float yden = rcpRefined(den);
+  const uint32_t n_items = *n_work * WPB;     // wave items
+  const uint32_t n_wg = (n_items + 3) / 4;    // workgroup items
+  const uint32_t n_wg_pad = (n_wg + 8 * G - 1) / (8 * G) * (8 * G);
+  uint32_t n_upd = 0, n_band = 0;
+  for (uint32_t b = blockIdx.x; b < n_wg_pad; b += gridDim.x) {
+    // workgroup b runs on XCD b % 8: the G items of a block go to the same XCD
+    const uint32_t x = b & 7u, q = b >> 3;
+    const uint32_t j = (q / G) * (8 * G) + x * G + (q % G);
+    const uint32_t wi = j * 4 + static_cast<uint32_t>(wave);
+    if (wi >= n_items) continue;
+    const size_t slot = work[wi / WPB];
+    const int sub = static_cast<int>(wi % WPB);
+    const int patch = sub % PATCHES, z0 = (sub / PATCHES) * ZR;
+    const int4 bi = a.blk_index[slot];
+    const float ox = static_cast<float>(bi.x) * a.bs, oy = static_cast<float>(bi.y) * a.bs, oz = static_cast<float>(bi.z) * a.bs;
+    const int lin_xy = patch * 64 + lane;
+    const int ix = lin_xy % VPS, iy = lin_xy / VPS;
+    const float px = ox + (static_cast<float>(ix) + 0.5f) * a.vs;
+    const float py = oy + (static_cast<float>(iy) + 0.5f) * a.vs;
+    float pxy[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pxy[c] = a.R[3 * c] * px + a.R[3 * c + 1] * py;
+    // per-item bases in SGPRs + 32-bit unsigned byte offsets per lane: the loads / stores take the
+    // `global_* v, v_off, s[base]` form (no 64-bit address arithmetic in VGPRs)
+    char* const dist_b = reinterpret_cast<char*>(a.dist + slot * NV);
+    char* const wgt_b = reinterpret_cast<char*>(a.weight + slot * NV);
+    char* const lobs_b = reinterpret_cast<char*>(a.last_obs + slot * NV);
+    const char* const range_b = reinterpret_cast<const char*>(a.range);
+    const uint32_t W4 = static_cast<uint32_t>(a.W) * 4u;
+    uint32_t cnt = 0;       // records waiting in this wave's LDS list
+    bool touched = false;   // wave-uniform: some voxel of this item was updated
+    for (int zi = 0; zi < ZR; ++zi) {
+      const int iz = z0 + zi;
+      const uint32_t lin = static_cast<uint32_t>(lin_xy + iz * SL);
+      const float pz = oz + (static_cast<float>(iz) + 0.5f) * a.vs;
+      float pc[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pc[c] = (pxy[c] + a.R[3 * c + 2] * pz) + a.t[c];
+      bool ok = pc[2] > 0.f;
+      const float voxel_range = range_mode == 0 ? pc[2] : sqrtf((pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2]);
+      ok = ok && !(voxel_range < a.min_range || voxel_range > a.max_range);
+      const float yz = rcpRefined(pc[2]);
+      const float u = divExact(pc[0] * a.fx, pc[2], yz) + a.cx;
+      const float v = divExact(pc[1] * a.fy, pc[2], yz) + a.cy;
+      // ceil(u) >= W || floor(u) < 0  <=>  u > W - 1 || u < 0  (W - 1 is an integer-valued float); x - y >= 0 <=> x >= y
+      // holds exactly in IEEE arithmetic, so the four tests are one min3 / min / compare
+      ok = ok && (fminf(fminf(u, v), fminf(Wm1 - u, Hm1 - v)) >= 0.f);
+      if (__builtin_amdgcn_ballot_w64(ok) != 0ull) {
+        // invalid lanes gather pixel (0, 0); valid lanes have 0 <= u <= W - 1, so floor == truncation
+        const float uc = ok ? u : 0.f, vc = ok ? v : 0.f;
+        const uint32_t u0 = static_cast<uint32_t>(static_cast<int>(uc)), v0 = static_cast<uint32_t>(static_cast<int>(vc));
+        const uint32_t v1 = min(v0 + 1u, static_cast<uint32_t>(a.H - 1));
+        const float du = __builtin_amdgcn_fractf(uc), dv = __builtin_amdgcn_fractf(vc);  // x - floor(x), exact for x >= 0
+        const uint32_t o0 = v0 * W4 + u0 * 4u, o1 = v1 * W4 + u0 * 4u;  // byte offsets of (u0, v0), (u0, v1)
+        const f2u ra = *reinterpret_cast<const f2u*>(range_b + o0);  // (u0, v0), (u0 + 1, v0)
+        const f2u rb = *reinterpret_cast<const f2u*>(range_b + o1);  // (u0, v1), (u0 + 1, v1)
+        float d_old = 0.f, w_old = 0.f;
+        if (ok) {
+          d_old = *reinterpret_cast<const float*>(dist_b + lin * 4u);
+          w_old = *reinterpret_cast<const float*>(wgt_b + lin * 4u);
+        }
+        // pixel order of the reference: (u0,v0) (u0,v1) (u1,v0) (u1,v1) with u1 = min(u0 + 1, W - 1)
+        const bool last_col = u0 >= static_cast<uint32_t>(a.W - 1);
+        const float r0 = ra.x, r1 = rb.x, r2 = last_col ? ra.x : ra.y, r3 = last_col ? rb.x : rb.y;
+        bool use_nearest = interp == 0;
+        if (interp == 2) {
+          const float mn = fminf(fminf(r0, r1), fminf(r2, r3));
+          const float mx = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+          use_nearest = use_nearest || (mx - mn > a.adaptive_diff);
+        }
+        const bool hi_u = du >= 0.5f, hi_v = dv >= 0.5f;
+        const float r_near = hi_u ? (hi_v ? r3 : r2) : (hi_v ? r1 : r0);
+        const float omu = 1.f - du, omv = 1.f - dv;
+        const float w0 = omu * omv, w1 = omu * dv, w2 = du * omv, w3 = du * dv;
+        const float r_bil = ((w0 * r0 + w1 * r1) + w2 * r2) + w3 * r3;
+        const float dist_surface = use_nearest ? r_near : r_bil;
+        ok = ok && (dist_surface >= a.min_range) && !(dist_surface > a.max_range);
+        const float sdf = dist_surface - voxel_range;
+        ok = ok && !(sdf < -a.trunc);
+        bool in_band = ok && (fabsf(sdf) < a.trunc);
+        if (__builtin_expect(a.use_mask && __builtin_amdgcn_ballot_w64(in_band) != 0ull, 0)) {
+          // interpolateID(mask): pixel of the largest weight (first maximum)
+          int best;
+          if (use_nearest) {
+            best = (hi_u ? 2 : 0) + (hi_v ? 1 : 0);
+          } else {
+            best = 0;
+            float bw = w0;
+            if (w1 > bw) { bw = w1; best = 1; }
+            if (w2 > bw) { bw = w2; best = 2; }
+            if (w3 > bw) { bw = w3; best = 3; }
+          }
+          const uint32_t uo = ((best & 2) && !last_col) ? 4u : 0u;
+          const uint32_t bo = ((best & 1) ? o1 : o0) + uo;
+          if (in_band && *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.dyn) + bo) != 0) {
+            ok = false;
+            in_band = false;
+          }
+        }
+        if (__builtin_amdgcn_ballot_w64(ok) != 0ull) {
+          // measurement weight (computeWeight): fx fy vs^2 / z^4, linear drop-off behind the surface
+          float w;
+          if (EXACT) {
+            const float qd = divExact(a.vs, pc[2], yz);
+            w = fxfy * (qd * qd);
+            if (!const_weight) {
+              const float z2 = pc[2] * pc[2];
+              w = divExact(w, z2, rcpRefined(z2));
+            }
+            if (use_dropoff && sdf < -a.dropoff_eps) w = fmaxf(w * divExact(a.trunc + sdf, den, yden), 0.f);
+          } else {
+            const float qd = a.vs * yz;
+            w = fxfy * (qd * qd);
+            if (!const_weight) w = w * (yz * yz);
+            if (use_dropoff && sdf < -a.dropoff_eps) w = fmaxf(w * ((a.trunc + sdf) * yden), 0.f);
+          }
+          // w > 0 is the same decision in both modes: the factors are positive normal numbers far from underflow, so
+          // the product is zero exactly when trunc + sdf == 0
+          ok = ok && (w > 0.f);
+          in_band = in_band && ok;
+          const float sdf_c = fmaxf(fminf(a.trunc, sdf), -a.trunc);
+          const float tot = w_old + w;
+          float d_new;
+          if (EXACT) {
+            d_new = divExact(d_old * w_old + sdf_c * w, tot, rcpRefined(tot));
+          } else {
+            d_new = __builtin_fmaf(d_old, w_old, sdf_c * w) * __builtin_amdgcn_rcpf(tot);
+          }
+          const float w_new = fminf(tot, a.max_weight);
+          if (ok) {
+            *reinterpret_cast<float*>(dist_b + lin * 4u) = d_new;
+            *reinterpret_cast<float*>(wgt_b + lin * 4u) = w_new;
+            if (a.with_tracking) *reinterpret_cast<uint64_t*>(lobs_b + lin * 8u) = a.stamp;
+          }
+          const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(ok), m_band = __builtin_amdgcn_ballot_w64(in_band);
+          n_upd += static_cast<uint32_t>(__popcll(m_ok));
+          touched = touched || (m_ok != 0ull);
+          if (m_band) {
+            n_band += static_cast<uint32_t>(__popcll(m_band));
+            if (in_band) {
+              const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m_band >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m_band), 0u));
+              uint32_t* const rec = &s_rec[wave][0][pos];
+              rec[0] = lin | (use_nearest ? 0x10000u : 0u);
+              rec[kFuseCap] = __float_as_uint(w);
+              rec[2 * kFuseCap] = __float_as_uint(w_new);
+              rec[3 * kFuseCap] = __float_as_uint(u);
+              rec[4 * kFuseCap] = __float_as_uint(v);
+            }
+            cnt += static_cast<uint32_t>(__popcll(m_band));
+          }
+        }
+      }
+      // work the list off when the next z step might not fit, and at the end of the item (a cold block: the hint keeps
+      // the register allocator from favouring its values over the voxel loop's)
+      if (__builtin_expect(cnt > static_cast<uint32_t>(kFuseCap - 64) || (zi == ZR - 1 && cnt > 0u), 0)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // explicit kernel arguments start at offset 0 of the kernarg segment; the empty asm keeps the loads of the band
+        // phase's arguments from being hoisted out of this block (and their registers out of the voxel loop)
+        FuseArgsK ka = (FuseArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        for (uint32_t r = static_cast<uint32_t>(lane); r < cnt; r += 64u) {
+          const uint32_t* const rec = &s_rec[wave][0][r];
+          fuseBandRecord<VPS>(ka, slot, rec[0], __uint_as_float(rec[kFuseCap]), __uint_as_float(rec[2 * kFuseCap]),
+                              __uint_as_float(rec[3 * kFuseCap]), __uint_as_float(rec[4 * kFuseCap]));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        cnt = 0u;
+      }
+    }
+    if (touched && lane == 0) atomicOr(&a.blk_flags[slot], BLK_UPDATED | BLK_MESH_UPDATED | BLK_TRACKING_UPDATED);
+  }
+  // statistics: one read-modify-write per workgroup on its own slot (folded by beginIntegrate / khr_get_stats)
+  if (lane == 0) {
+    s_stat[wave][0] = n_upd;
+    s_stat[wave][1] = n_band;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t su = s_stat[0][0] + s_stat[1][0] + s_stat[2][0] + s_stat[3][0];
+    const uint32_t sb = s_stat[0][1] + s_stat[1][1] + s_stat[2][1] + s_stat[3][1];
+    if (su | sb) {
+      a.wg_stats[2 * blockIdx.x] += su;
+      a.wg_stats[2 * blockIdx.x + 1] += sb;
+    }
+  }
+}
+
+}  // namespace khr

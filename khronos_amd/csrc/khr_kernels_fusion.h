@@ -62,9 +62,9 @@ __global__ __launch_bounds__(256) void k_frame_ingest(const float* __restrict__ 
                                                      int32_t* __restrict__ label, int32_t* __restrict__ dyn,
                                                      float* __restrict__ tile_max, int tw, int W, int H, float fx,
                                                      float fy, float cx, float cy, int range_mode, DevMap m, int nvox,
-                                                     uint32_t* __restrict__ band_count, int do_begin) {
+                                                     uint32_t* __restrict__ wg_stats, int do_begin) {
   if (blockIdx.x == 0 && threadIdx.x == 0) m.counters[C_N_SEEDS] = 0u;
-  if (do_begin && blockIdx.x == 0) beginIntegrate(m, nvox, band_count);  // khr_process_frame: saves a launch
+  if (do_begin && blockIdx.x == 0) beginIntegrate(m, nvox, wg_stats);  // khr_process_frame: saves a launch
   float d, r;
   ingestTile(depth_in, rgb_in, label_in, depth, range, rgba, label, dyn, tile_max, blockIdx.x, tw, W, H, fx, fy, cx, cy,
              range_mode, &d, &r);
@@ -211,14 +211,12 @@ __global__ __launch_bounds__(256) void k_alloc_visible(DevMap m, DevParams p, De
   if (list_count != &m.counters[C_N_VISIBLE]) waveAggInc(&m.counters[C_N_VISIBLE], emit);
 }
 
-__global__ void k_begin_integrate(DevMap m, int nvox, uint32_t* band_count) {
-  if (blockIdx.x == 0) beginIntegrate(m, nvox, band_count);
+__global__ void k_begin_integrate(DevMap m, int nvox, uint32_t* wg_stats) {
+  if (blockIdx.x == 0) beginIntegrate(m, nvox, wg_stats);
 }
-// tick path: one begin for all cameras of the tick (both record-cursor sets, the per-camera list counters)
-__global__ void k_tick_begin(DevMap m, int nvox, uint32_t* band_count, uint32_t* band_count2, uint32_t* tick_counts,
-                             uint32_t extra_calls) {
-  beginIntegrate(m, nvox, band_count);
-  if (threadIdx.x < kBandShards) band_count2[threadIdx.x * 32] = 0u;
+// tick path: one begin for all cameras of the tick (the per-camera list counters)
+__global__ void k_tick_begin(DevMap m, int nvox, uint32_t* wg_stats, uint32_t* tick_counts, uint32_t extra_calls) {
+  beginIntegrate(m, nvox, wg_stats);
   if (threadIdx.x < 2 * kMaxTick) tick_counts[threadIdx.x] = 0u;
   if (threadIdx.x == 0) m.stats[S_CUM_CALLS] += extra_calls;
 }
@@ -420,518 +418,6 @@ __global__ __launch_bounds__(256) void k_init_cull(DevMap m, DevParams p, DevFra
     cullBlocks(m, p, f, work, &m.counters[C_N_VISIBLE], work_tsdf, &m.counters[C_N_TSDF], tile_max, tw, th, blockIdx.x, n_cull);
   else
     initBlocks(m, p, new_list, blockIdx.x - n_cull, gridDim.x - n_cull);
-}
-
-// ----------------------------------------------------------------------------------------------
-// Projective TSDF / label update = the per-voxel loop of hydra::ProjectiveIntegrator (call
-// active_window.cpp:210; label hook object_integrator.cpp:58-81; ASSUMPTIONS.md A.3), split in two
-// kernels so that every wave does uniform work:
-//
-//  k_tsdf_update  one workgroup (256 threads) per visible, non-culled block, the 16^3 block staged in LDS:
-//    pass 1  thread <-> voxel (lanes along x,y so a wave's 64 image footprints are neighbours):
-//            project, 4 range gathers, sdf / weight -> measurement tile in LDS (8 B per voxel); in-band
-//            voxels are appended as 24-byte records to a global list (wave-aggregated atomic).
-//    pass 2  thread <-> 4 consecutive voxels: 16-byte ds_read of the measurement tile, 16-byte
-//            global load / store of distance and weight (running weighted average), 8-byte
-//            last_observed stores.  Blocks are never read unless a voxel of the float4 group is valid.
-//  k_band_update  one thread per in-band record, dense lanes: colour blend, mask-free label lookup,
-//            K likelihoods (8 independent loads in flight per chunk), arg-max label.
-// ----------------------------------------------------------------------------------------------
-struct BandRec {
-  uint32_t slot;
-  uint32_t lin_mode;  // bits 0..15 linear voxel index, bit 16 = nearest-neighbour interpolation
-  float w;            // measurement weight
-};
-
-
-__device__ inline void interpPixels(float u, float v, int W, int H, int* px, float* du, float* dv) {
-  const int u0 = static_cast<int>(floorf(u)), v0 = static_cast<int>(floorf(v));
-  const int u1 = min(u0 + 1, W - 1), v1 = min(v0 + 1, H - 1);
-  *du = u - static_cast<float>(u0);
-  *dv = v - static_cast<float>(v0);
-  px[0] = v0 * W + u0;
-  px[1] = v1 * W + u0;
-  px[2] = v0 * W + u1;
-  px[3] = v1 * W + u1;
-}
-
-__device__ inline int interpWeights(float du, float dv, bool use_nearest, float* w4) {
-  int best;
-  if (use_nearest) {
-    const int nearest = (du >= 0.5f ? 2 : 0) + (dv >= 0.5f ? 1 : 0);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) w4[k] = (k == nearest) ? 1.f : 0.f;
-    best = nearest;
-  } else {
-    w4[0] = (1.f - du) * (1.f - dv);
-    w4[1] = (1.f - du) * dv;
-    w4[2] = du * (1.f - dv);
-    w4[3] = du * dv;
-    best = 0;
-#pragma unroll
-    for (int k = 1; k < 4; ++k)
-      if (w4[k] > w4[best]) best = k;
-  }
-  return best;
-}
-
-// slim argument block of k_tsdf_update (keeps the kernel's SGPR footprint small)
-struct TsdfArgs {
-  const int4* blk_index;
-  uint32_t* blk_flags;
-  float* dist;
-  float* weight;
-  uint64_t* last_obs;
-  unsigned long long* stats;
-  uint32_t* counters;
-  const float* range;
-  const int32_t* dyn;
-  int W, H;
-  float fx, fy, cx, cy, min_range, max_range;
-  float R[9], t[3];
-  uint64_t stamp;
-  float vs, bs, trunc, dropoff_eps, max_weight, adaptive_diff;
-  int interp, range_mode, use_dropoff, const_weight, with_tracking, use_mask, dbg;
-  unsigned long long* dbg_buf;  // ablation / timing probe (KHR_DEBUG & 8)
-  uint32_t* wg_stats;           // per-workgroup {n_upd, n_band} partial sums
-};
-
-// FAST = the reference default configuration (z-depth range, adaptive interpolation, weight drop-off,
-// no constant weight, no debug switches) resolved at compile time; the generic instantiation reads the
-// switches from the argument block.
-// workgroup barrier that orders LDS only: s_waitcnt lgkmcnt(0) + s_barrier.  HIP's __syncthreads() also
-// drains vmcnt, which would stall a workgroup until its pass-2 global stores are acknowledged.
-__device__ inline void ldsBarrier() {
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // vmcnt = 63 (no wait), expcnt = 7, lgkmcnt = 0
-  __builtin_amdgcn_s_barrier();
-}
-
-template <int VPS, int CHUNKS, bool FAST>
-__global__ __launch_bounds__(256) void k_tsdf_update(TsdfArgs a, const uint32_t* __restrict__ work,
-                                                    const uint32_t* __restrict__ n_work,
-                                                    BandRec* __restrict__ band, uint32_t shard_cap,
-                                                    uint32_t* __restrict__ band_count) {
-  constexpr int NV = VPS * VPS * VPS;
-  constexpr int CV = NV / CHUNKS;  // voxels staged in LDS at a time (a z-slab of the block)
-  constexpr int PER = CV / 256;    // voxels per thread in pass 2 (consecutive)
-  static_assert(CV % 256 == 0, "chunk must be a multiple of the workgroup size");
-  __shared__ __attribute__((aligned(16))) float s_sdf[CV];
-  __shared__ __attribute__((aligned(16))) float s_w[CV];
-  __shared__ __attribute__((aligned(16))) uint8_t s_flag[CV];  // bit0 in band, bit1 nearest interpolation
-  __shared__ uint32_t s_wsum[4];
-  __shared__ uint32_t s_base;
-  __shared__ uint32_t s_any[4];
-  const uint32_t n = *n_work * CHUNKS;  // work item = one z-slab (chunk) of a block
-  const int range_mode = FAST ? 0 : a.range_mode;
-  const int interp = FAST ? 2 : a.interp;
-  const bool use_dropoff = FAST ? true : (a.use_dropoff != 0);
-  const bool const_weight = FAST ? false : (a.const_weight != 0);
-  const int dbg = FAST ? 0 : a.dbg;
-  const float Wf = static_cast<float>(a.W), Hf = static_cast<float>(a.H);
-  uint32_t n_upd = 0, n_band = 0;
-  // static striding over the work items: a single hot atomic address sustains only ~90 ops/us on
-  // gfx950, so neither a dynamic work cursor nor per-wave statistics atomics are used here.
-  for (uint32_t wi = blockIdx.x; wi < n; wi += gridDim.x) {
-    const unsigned long long t_start = (dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
-    unsigned long long t_p1 = 0, t_rec = 0;
-    const size_t slot = work[wi / CHUNKS];
-    const int chunk = static_cast<int>(wi % CHUNKS);
-    const int4 bi = a.blk_index[slot];
-    const float ox = static_cast<float>(bi.x) * a.bs, oy = static_cast<float>(bi.y) * a.bs,
-                oz = static_cast<float>(bi.z) * a.bs;
-    const int cbase = chunk * CV;
-    // prefetch this thread's distance / weight vectors now: their HBM latency hides under pass 1
-    // (pass 2 maps thread <-> 4 consecutive voxels, group g = threadIdx.x + 256 * i)
-    constexpr int PER4 = CV / 1024 > 0 ? CV / 1024 : 1;
-    float4* __restrict__ dist4 = reinterpret_cast<float4*>(a.dist + slot * NV + cbase);
-    float4* __restrict__ wgt4 = reinterpret_cast<float4*>(a.weight + slot * NV + cbase);
-    float4 d_pre[PER4], w_pre[PER4];
-#pragma unroll
-    for (int i = 0; i < PER4; ++i) {
-      const int g = threadIdx.x + 256 * i;
-      if (g < CV / 4) {
-        d_pre[i] = dist4[g];
-        w_pre[i] = wgt4[g];
-      }
-    }
-    uint32_t any = 0;
-    // ---- pass 1: measurement per voxel -> LDS (branch-free; invalid lanes are masked by `ok`) ----
-    // A thread's voxels of one work item differ only in z (the stride 256 is a multiple of VPS * VPS for VPS = 16 and
-    // of VPS for VPS = 8), so the x / y parts of the transform -- (R[3c] * px + R[3c+1] * py), the first addition of
-    // xform() -- are computed once per work item; the remaining operations keep xform()'s order, bit for bit.
-    constexpr bool kHoistXY = (256 % (VPS * VPS)) == 0;
-    float pxy[3] = {0.f, 0.f, 0.f};
-    if (kHoistXY) {
-      const int lin0 = cbase + static_cast<int>(threadIdx.x);
-      const float px = ox + (static_cast<float>(lin0 % VPS) + 0.5f) * a.vs;
-      const float py = oy + (static_cast<float>((lin0 / VPS) % VPS) + 0.5f) * a.vs;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) pxy[c] = a.R[3 * c] * px + a.R[3 * c + 1] * py;
-    }
-#pragma unroll 2
-    for (int cl = threadIdx.x; cl < CV; cl += 256) {
-      const int lin = cbase + cl;
-      const int ix = lin % VPS, iy = (lin / VPS) % VPS, iz = lin / (VPS * VPS);
-      const float pz = oz + (static_cast<float>(iz) + 0.5f) * a.vs;
-      float pc[3];
-      if (kHoistXY) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) pc[c] = (pxy[c] + a.R[3 * c + 2] * pz) + a.t[c];
-      } else {
-        const float px = ox + (static_cast<float>(ix) + 0.5f) * a.vs;
-        const float py = oy + (static_cast<float>(iy) + 0.5f) * a.vs;
-        xform(a.R, a.t, px, py, pz, pc);
-      }
-      bool ok = pc[2] > 0.f;
-      const float voxel_range =
-          range_mode == 0 ? pc[2] : sqrtf((pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2]);
-      ok = ok && !(voxel_range < a.min_range || voxel_range > a.max_range);
-      const float u = (pc[0] * a.fx) / pc[2] + a.cx;
-      ok = ok && !(ceilf(u) >= Wf || floorf(u) < 0.f);
-      const float v = (pc[1] * a.fy) / pc[2] + a.cy;
-      ok = ok && !(ceilf(v) >= Hf || floorf(v) < 0.f);
-      // whole wave invalid (block partly outside the image / range): nothing to gather
-      if (!__any(ok)) {
-        s_sdf[cl] = 0.f;
-        s_w[cl] = 0.f;
-        s_flag[cl] = 0;
-        continue;
-      }
-      // clamp the coordinates of invalid lanes so that the gathers stay inside the image
-      const float uc = ok ? u : 0.f, vc = ok ? v : 0.f;
-      const int u0 = static_cast<int>(floorf(uc)), v0 = static_cast<int>(floorf(vc));
-      const int u1 = min(u0 + 1, a.W - 1), v1 = min(v0 + 1, a.H - 1);
-      const float du = uc - static_cast<float>(u0), dv = vc - static_cast<float>(v0);
-      // pixel order: (u0,v0) (u0,v1) (u1,v0) (u1,v1); 32-bit element offsets from the scalar base pointer
-      const uint32_t row0 = static_cast<uint32_t>(v0 * a.W), row1 = static_cast<uint32_t>(v1 * a.W);
-      const uint32_t o0 = row0 + static_cast<uint32_t>(u0), o1 = row1 + static_cast<uint32_t>(u0),
-                     o2 = row0 + static_cast<uint32_t>(u1), o3 = row1 + static_cast<uint32_t>(u1);
-      float r4[4];
-      if (dbg & 4) {
-        r4[0] = a.range[0]; r4[1] = a.range[1]; r4[2] = a.range[2]; r4[3] = a.range[3];
-      } else {
-        r4[0] = a.range[o0]; r4[1] = a.range[o1]; r4[2] = a.range[o2]; r4[3] = a.range[o3];
-      }
-      bool use_nearest = interp == 0;
-      if (interp == 2) {
-        const float mn = fminf(fminf(r4[0], r4[1]), fminf(r4[2], r4[3]));
-        const float mx = fmaxf(fmaxf(r4[0], r4[1]), fmaxf(r4[2], r4[3]));
-        use_nearest = use_nearest || (mx - mn > a.adaptive_diff);
-      }
-      // interpolateRange: bilinear sum, or the one-hot nearest sample (1*r + 0*.. == r for finite ranges)
-      const bool hi_u = du >= 0.5f, hi_v = dv >= 0.5f;
-      const float r_near = hi_u ? (hi_v ? r4[3] : r4[2]) : (hi_v ? r4[1] : r4[0]);
-      const float w0 = (1.f - du) * (1.f - dv), w1 = (1.f - du) * dv, w2 = du * (1.f - dv), w3 = du * dv;
-      const float r_bil = ((w0 * r4[0] + w1 * r4[1]) + w2 * r4[2]) + w3 * r4[3];
-      const float dist_surface = use_nearest ? r_near : r_bil;
-      ok = ok && (dist_surface >= a.min_range) && !(dist_surface > a.max_range);
-      const float sdf = dist_surface - voxel_range;
-      ok = ok && !(sdf < -a.trunc);
-      bool in_band = ok && (fabsf(sdf) < a.trunc);
-      if (a.use_mask && in_band) {
-        // interpolateID(mask): pixel of the largest weight (first maximum)
-        int best;
-        if (use_nearest) {
-          best = (hi_u ? 2 : 0) + (hi_v ? 1 : 0);
-        } else {
-          best = 0;
-          float bw = w0;
-          if (w1 > bw) { bw = w1; best = 1; }
-          if (w2 > bw) { bw = w2; best = 2; }
-          if (w3 > bw) { bw = w3; best = 3; }
-        }
-        const uint32_t bpx = best == 0 ? o0 : (best == 1 ? o1 : (best == 2 ? o2 : o3));
-        if (a.dyn[bpx] != 0) {
-          ok = false;
-          in_band = false;
-        }
-      }
-      const float q = a.vs / pc[2];
-      float w = (a.fx * a.fy) * (q * q);
-      if (!const_weight) w = w / (pc[2] * pc[2]);
-      if (use_dropoff && sdf < -a.dropoff_eps) {  // only lanes behind the surface pay for this division
-        w = fmaxf(w * ((a.trunc + sdf) / (a.trunc - a.dropoff_eps)), 0.f);
-      }
-      ok = ok && (w > 0.f);
-      in_band = in_band && ok;
-      const float meas_w = ok ? w : 0.f;
-      s_sdf[cl] = fmaxf(fminf(a.trunc, sdf), -a.trunc);
-      s_w[cl] = meas_w;
-      s_flag[cl] = static_cast<uint8_t>((in_band ? 1 : 0) | (use_nearest ? 2 : 0));
-      n_upd += ok ? 1u : 0u;
-      n_band += in_band ? 1u : 0u;
-      any |= ok ? 1u : 0u;
-    }
-    if ((threadIdx.x & 63) == 0) s_any[threadIdx.x >> 6] = 0u;
-    if (__any(any != 0u) && (threadIdx.x & 63) == 0) s_any[threadIdx.x >> 6] = 1u;
-    ldsBarrier();
-    const int any_blk = static_cast<int>(s_any[0] | s_any[1] | s_any[2] | s_any[3]);
-    if (dbg & 8) t_p1 = __builtin_amdgcn_s_memtime();
-    // ---- in-band records: block-wide exclusive scan, ONE atomic per workgroup ------------------
-    if (any_blk && !(dbg & 2)) {
-      uint32_t cnt = 0;
-      if (PER >= 4) {
-#pragma unroll
-        for (int j = 0; j < PER / 4; ++j)
-          cnt += __popc(reinterpret_cast<const uint32_t*>(s_flag)[threadIdx.x * (PER / 4) + j] & 0x01010101u);
-      } else {
-#pragma unroll
-        for (int j = 0; j < PER; ++j) cnt += s_flag[threadIdx.x * PER + j] & 1u;
-      }
-      uint32_t incl = cnt;  // wave inclusive scan
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o);
-        if ((threadIdx.x & 63) >= static_cast<uint32_t>(o)) incl += t;
-      }
-      if ((threadIdx.x & 63) == 63) s_wsum[threadIdx.x >> 6] = incl;
-      ldsBarrier();
-      const uint32_t wv = threadIdx.x >> 6;
-      uint32_t woff = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) woff += (static_cast<uint32_t>(k) < wv) ? s_wsum[k] : 0u;
-      const uint32_t total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-      const uint32_t shard = blockIdx.x & (kBandShards - 1);
-      if (threadIdx.x == 0) s_base = total ? atomicAdd(&band_count[shard * 32], total) : 0u;
-      ldsBarrier();
-      if (cnt) {
-        uint32_t pos = s_base + woff + incl - cnt;
-        BandRec* __restrict__ dst = band + static_cast<size_t>(shard) * shard_cap;
-        bool overflow = false;
-        for (int j = 0; j < PER; ++j) {
-          const int cl = threadIdx.x * PER + j;
-          const uint8_t fl = s_flag[cl];
-          if (fl & 1) {
-            if (pos < shard_cap) {
-              BandRec r;
-              r.slot = static_cast<uint32_t>(slot);
-              r.lin_mode = static_cast<uint32_t>(cbase + cl) | ((fl & 2) ? 0x10000u : 0u);
-              r.w = s_w[cl];
-              dst[pos] = r;
-            } else {
-              overflow = true;
-            }
-            ++pos;
-          }
-        }
-        if (overflow) atomicAdd(&a.counters[C_BAND_OVERFLOW], 1u);
-      }
-    }
-    if (dbg & 8) t_rec = __builtin_amdgcn_s_memtime();
-    // ---- pass 2: vectorised running-average update of the voxel arrays -----------------------
-    if (any_blk && !(dbg & 1)) {
-      uint64_t* __restrict__ lobs = a.last_obs + slot * NV + cbase;
-#pragma unroll
-      for (int i = 0; i < PER4; ++i) {
-        const int g = threadIdx.x + 256 * i;
-        if (g >= CV / 4) continue;
-        const float4 mw = reinterpret_cast<const float4*>(s_w)[g];
-        if (!(mw.x > 0.f || mw.y > 0.f || mw.z > 0.f || mw.w > 0.f)) continue;
-        const float4 ms = reinterpret_cast<const float4*>(s_sdf)[g];
-        float4 d = d_pre[i], w = w_pre[i];
-        if (mw.x > 0.f) { d.x = (d.x * w.x + ms.x * mw.x) / (w.x + mw.x); w.x = fminf(w.x + mw.x, a.max_weight); }
-        if (mw.y > 0.f) { d.y = (d.y * w.y + ms.y * mw.y) / (w.y + mw.y); w.y = fminf(w.y + mw.y, a.max_weight); }
-        if (mw.z > 0.f) { d.z = (d.z * w.z + ms.z * mw.z) / (w.z + mw.z); w.z = fminf(w.z + mw.z, a.max_weight); }
-        if (mw.w > 0.f) { d.w = (d.w * w.w + ms.w * mw.w) / (w.w + mw.w); w.w = fminf(w.w + mw.w, a.max_weight); }
-        dist4[g] = d;
-        wgt4[g] = w;
-        if (a.with_tracking) {
-          if (mw.x > 0.f) lobs[4 * g] = a.stamp;
-          if (mw.y > 0.f) lobs[4 * g + 1] = a.stamp;
-          if (mw.z > 0.f) lobs[4 * g + 2] = a.stamp;
-          if (mw.w > 0.f) lobs[4 * g + 3] = a.stamp;
-        }
-      }
-      if (threadIdx.x == 0) {
-        if (CHUNKS == 1) a.blk_flags[slot] |= (BLK_UPDATED | BLK_MESH_UPDATED | BLK_TRACKING_UPDATED);
-        else atomicOr(&a.blk_flags[slot], BLK_UPDATED | BLK_MESH_UPDATED | BLK_TRACKING_UPDATED);
-      }
-    }
-    ldsBarrier();  // LDS tile is reused by the next work item of this workgroup
-    if ((dbg & 8) && (threadIdx.x & 63) == 0 && wi < 4096) {
-      unsigned long long* o = a.dbg_buf + (static_cast<size_t>(wi) * 4 + (threadIdx.x >> 6)) * 8;
-      o[0] = t_start;
-      o[1] = t_p1;
-      o[2] = t_rec;
-      o[3] = __builtin_amdgcn_s_memtime();
-      o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
-      o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
-      o[6] = blockIdx.x;
-      o[7] = any_blk;
-    }
-  }
-  // statistics: wave reduce -> LDS -> one plain store per workgroup (summed by k_band_update)
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    n_upd += __shfl_down(n_upd, o);
-    n_band += __shfl_down(n_band, o);
-  }
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) {
-    s_wsum[threadIdx.x >> 6] = n_upd;
-    reinterpret_cast<uint32_t*>(s_sdf)[threadIdx.x >> 6] = n_band;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    a.wg_stats[2 * blockIdx.x] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-    const uint32_t* sb = reinterpret_cast<const uint32_t*>(s_sdf);
-    a.wg_stats[2 * blockIdx.x + 1] = sb[0] + sb[1] + sb[2] + sb[3];
-  }
-}
-
-template <int VPS>
-__global__ __launch_bounds__(256) void k_band_update(DevMap m, DevParams p, DevFrame f,
-                                                    const BandRec* __restrict__ band, uint32_t shard_cap,
-                                                    const uint32_t* __restrict__ band_count, int object_id,
-                                                    const uint32_t* __restrict__ wg_stats, int n_wg,
-                                                    uint32_t* __restrict__ band_count_next) {
-  constexpr int NV = VPS * VPS * VPS;
-  // tick path: the record cursors alternate between two sets; the set of the NEXT camera's k_tsdf_update is idle now
-  if (band_count_next && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kBandShards) band_count_next[threadIdx.x * 32] = 0u;
-  if (blockIdx.x == 0) {
-    // fold k_tsdf_update's per-workgroup statistics: the first workgroup of every shard takes a slice, one entry pair per
-    // thread and round (a single workgroup walking all 4096 pairs was a serial chain of ~16 load latencies: the kernel's
-    // whole fixed cost)
-    unsigned long long u = 0, b = 0;
-    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n_wg; i += gridDim.y * blockDim.x) {
-      u += wg_stats[2 * i];
-      b += wg_stats[2 * i + 1];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      u += __shfl_down(u, o);
-      b += __shfl_down(b, o);
-    }
-    if ((threadIdx.x & 63) == 0 && (u | b)) {
-      atomicAdd(&m.stats[S_UPD], u);
-      atomicAdd(&m.stats[S_BAND], b);
-    }
-  }
-  const uint32_t shard = blockIdx.y;
-  const uint32_t n = min(band_count[shard * 32], shard_cap);
-  const BandRec* __restrict__ src = band + static_cast<size_t>(shard) * shard_cap;
-  for (uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x; ri < n; ri += gridDim.x * blockDim.x) {
-    const BandRec r = src[ri];
-    const size_t slot = r.slot;
-    const int lin = static_cast<int>(r.lin_mode & 0xffffu);
-    const bool use_nearest = (r.lin_mode & 0x10000u) != 0;
-    // re-project the voxel centre (same expressions as k_tsdf_update pass 1 => identical u, v)
-    const int4 bi = m.blk_index[slot];
-    const int ix = lin % VPS, iy = (lin / VPS) % VPS, iz = lin / (VPS * VPS);
-    const float pwx = static_cast<float>(bi.x) * p.bs + (static_cast<float>(ix) + 0.5f) * p.vs;
-    const float pwy = static_cast<float>(bi.y) * p.bs + (static_cast<float>(iy) + 0.5f) * p.vs;
-    const float pwz = static_cast<float>(bi.z) * p.bs + (static_cast<float>(iz) + 0.5f) * p.vs;
-    float pc[3];
-    xform(f.R, f.t, pwx, pwy, pwz, pc);
-    const float u = (pc[0] * f.fx) / pc[2] + f.cx;
-    const float v = (pc[1] * f.fy) / pc[2] + f.cy;
-    int px4[4];
-    float du, dv, w4[4];
-    interpPixels(u, v, f.W, f.H, px4, &du, &dv);
-    const int best = interpWeights(du, dv, use_nearest, w4);
-    const int best_px = px4[best];
-    const float w = r.w;
-    // every load of this record is issued here, before the first store: the colour / label / likelihood reads depend
-    // only on the record and the block index, and a store in between would fence them (the arrays may alias as far as
-    // the compiler knows), turning one round trip to memory into three
-    const bool do_sem = p.with_semantics && ((p.sem_mode == 1) ? (object_id >= 0 && f.obj != nullptr) : (f.has_label != 0));
-    const bool vec_lik = do_sem && (p.K & 3) == 0 && p.K <= 32;
-    uint32_t c4[4] = {0u, 0u, 0u, 0u};
-    float w_new = 0.f;
-    uint32_t co = 0u;
-    if (f.has_color) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) c4[k] = f.rgba[px4[k]];
-      w_new = m.weight[slot * NV + lin];  // voxel weight after the k_tsdf_update pass
-      co = m.color[slot * NV + lin];
-    }
-    int label = -1;
-    uint8_t fl = 0;
-    float4 l4[8];
-    uint8_t* vfl = m.vflags + slot * NV;
-    // likelihoods are voxel-major: lik[slot][voxel][K] -> one contiguous K*4-byte run per record
-    float* __restrict__ lik = m.lik + (slot * NV + lin) * static_cast<size_t>(p.K);
-    float4* __restrict__ lik4 = reinterpret_cast<float4*>(lik);
-    if (do_sem) {
-      label = (p.sem_mode == 1) ? ((f.obj[best_px] == object_id) ? 1 : 0) : f.label[best_px];
-      fl = vfl[lin];
-      if (vec_lik) {  // a voxel without VOX_SEM_VALID holds no likelihoods yet: what is loaded is replaced by zeros below
-#pragma unroll
-        for (int j = 0; j < 8; ++j) l4[j] = (4 * j < p.K) ? lik4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    if (f.has_color) {
-      float a[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t c = c4[k];
-        a[0] = a[0] + w4[k] * static_cast<float>(c & 0xffu);
-        a[1] = a[1] + w4[k] * static_cast<float>((c >> 8) & 0xffu);
-        a[2] = a[2] + w4[k] * static_cast<float>((c >> 16) & 0xffu);
-      }
-      const float tot = w_new + w;
-      uint32_t out = 0xff000000u;
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        const float cn = static_cast<float>(toU8(a[ch]));
-        const float cv = static_cast<float>((co >> (8 * ch)) & 0xffu);
-        out |= static_cast<uint32_t>(toU8((cv * w_new + cn * w) / tot)) << (8 * ch);
-      }
-      m.color[slot * NV + lin] = out;
-    }
-    if (do_sem && label >= 0 && label < p.K) {
-      const bool empty = !(fl & VOX_SEM_VALID);
-      int bestk = 0;
-      float bestv = 0.f;
-      if (vec_lik) {
-        // 16-byte loads / stores, 4 labels at a time, up to 8 vectors (32 labels)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (4 * j >= p.K) continue;
-          float l[4] = {l4[j].x, l4[j].y, l4[j].z, l4[j].w};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int k = 4 * j + q;
-            if (empty) l[q] = 0.f;
-            if (p.sem_mode == 1) {
-              if (k == label) l[q] += 1.f;
-            } else {
-              l[q] += (k == label) ? p.log_match : p.log_nomatch;
-            }
-            if (k == 0 || l[q] > bestv) {
-              bestv = l[q];
-              bestk = k;
-            }
-          }
-          lik4[j] = make_float4(l[0], l[1], l[2], l[3]);
-        }
-      } else {
-        for (int k0 = 0; k0 < p.K; k0 += 8) {
-          float l[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) l[j] = (!empty && k0 + j < p.K) ? lik[k0 + j] : 0.f;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int k = k0 + j;
-            if (k < p.K) {
-              if (p.sem_mode == 1) {
-                if (k == label) l[j] += 1.f;
-              } else {
-                l[j] += (k == label) ? p.log_match : p.log_nomatch;
-              }
-              lik[k] = l[j];
-              if (k == 0 || l[j] > bestv) {
-                bestv = l[j];
-                bestk = k;
-              }
-            }
-          }
-        }
-      }
-      if (empty) vfl[lin] = fl | VOX_SEM_VALID;
-      m.sem_label[slot * NV + lin] = static_cast<uint32_t>(bestk);
-    }
-  }
 }
 
 // ----------------------------------------------------------------------------------------------

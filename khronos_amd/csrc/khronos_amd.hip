@@ -27,6 +27,7 @@
 #include "khr_device.h"
 #include "khr_kernels_aux.h"
 #include "khr_kernels_fusion.h"
+#include "khr_kernels_fuse.h"
 #include "khr_kernels_objects.h"
 
 using namespace khr;
@@ -114,7 +115,6 @@ struct khr_ctx {
   uint32_t* d_tick_tsdf = nullptr;
   uint32_t* d_tick_counts = nullptr;
   uint32_t* d_tick_seeds = nullptr;
-  uint32_t* d_band_count2 = nullptr;
   uint32_t* h_tick = nullptr;
   uint32_t* d_tick_host = nullptr;
   uint32_t tick_ticket = 0;
@@ -123,9 +123,6 @@ struct khr_ctx {
   // between the allocation and the update phase of a tick: the epoch the tick's new blocks carry (the motion detector
   // must not see them: in reference order it runs before the frames are integrated); 0 otherwise
   int tick_epoch = 0, motion_ignore_epoch = 0;
-  BandRec* d_band = nullptr;
-  uint32_t band_cap = 0;
-  uint32_t* d_band_count = nullptr;
   unsigned long long* d_dbg = nullptr;
   uint32_t* d_wg_stats = nullptr;
   // remote halo (multi-GPU): records gathered from the other ranks + their index
@@ -439,10 +436,11 @@ int dispatchVps(khr_ctx* c, F&& f) {
   return fail(KHR_EINVAL, "voxels_per_side must be 8 or 16");
 }
 
-int kTsdfGrid = 4096;   // persistent grid: 256 CUs x 4 resident workgroups (LDS-limited)
-int kTsdfChunks = 0;    // 0 = by world size (4 / 8 / 16 z-slabs per block); env KHR_TSDF_CHUNKS
+int kFuseGrid = 0;      // 0 = resident workgroups of the instantiation (occupancy query) x CUs; env KHR_FUSE_GRID
+int kFuseZsplit = 0;    // 0 = by world size (wave items per x-y patch of a block: 2 / 4 / 8); env KHR_FUSE_ZSPLIT
+int kFuseExact = -1;    // -1 = khr_config.exact_arithmetic; env KHR_FUSE_EXACT=0/1 overrides (A/B switch)
+int kFuseMinw = 0;      // env KHR_FUSE_MINW: register budget of the default instantiation (1 none, 7, 8 waves / SIMD)
 constexpr int kStreamGrid = 4096;
-constexpr int kBandGrid = 2048;
 
 }  // namespace
 
@@ -488,6 +486,7 @@ void khr_default_config(khr_config* cfg) {
   cfg->device = 0;
   cfg->rank = 0;
   cfg->world_size = 1;
+  cfg->exact_arithmetic = 0;
 }
 
 // the voxel-size dependent part of DevParams (khr_create, khr_reset_map)
@@ -647,8 +646,10 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   p.rank = cfg->rank;
   p.world = cfg->world_size;
   p.dbg = std::getenv("KHR_DEBUG") ? std::atoi(std::getenv("KHR_DEBUG")) : 0;
-  if (std::getenv("KHR_TSDF_GRID")) kTsdfGrid = std::min(16384, std::atoi(std::getenv("KHR_TSDF_GRID")));
-  if (std::getenv("KHR_TSDF_CHUNKS")) kTsdfChunks = std::atoi(std::getenv("KHR_TSDF_CHUNKS"));
+  if (std::getenv("KHR_FUSE_GRID")) kFuseGrid = std::max(8, std::min(kFuseStatSlots, std::atoi(std::getenv("KHR_FUSE_GRID"))));
+  if (std::getenv("KHR_FUSE_ZSPLIT")) kFuseZsplit = std::atoi(std::getenv("KHR_FUSE_ZSPLIT"));
+  if (std::getenv("KHR_FUSE_EXACT")) kFuseExact = std::atoi(std::getenv("KHR_FUSE_EXACT")) ? 1 : 0;
+  if (std::getenv("KHR_FUSE_MINW")) kFuseMinw = std::atoi(std::getenv("KHR_FUSE_MINW"));
   if (std::getenv("KHR_NO_EARLY_INGEST")) c->early_ingest = false;
 
   DevMap& m = c->m;
@@ -682,12 +683,8 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &c->d_ef, cap));
   A(devAlloc(c, &c->d_trk_proc, cap));
   A(devAlloc(c, &c->d_work_tsdf, cap));
-  c->band_cap = cfg->max_band_records ? cfg->max_band_records : 4u * cfg->max_frame_pixels;
-  c->band_cap = (c->band_cap / kBandShards + 1) * kBandShards;
-  A(devAlloc(c, &c->d_band, c->band_cap, false));
-  A(devAlloc(c, &c->d_band_count, kBandShards * 32));
   A(devAlloc(c, &c->d_dbg, 4096 * 4 * 8));
-  A(devAlloc(c, &c->d_wg_stats, 2 * 16384));
+  A(devAlloc(c, &c->d_wg_stats, 2 * kFuseStatSlots));
   A(devAlloc(c, &c->d_removed, cap));
   A(devAlloc(c, &c->d_mesh_count, cap + 1));
   A(devAlloc(c, &c->d_mesh_offset, cap + 1));
@@ -762,7 +759,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   for (auto& s : c->slots) {
     if (rc != KHR_OK) break;
     A(devAlloc(c, &s.depth, npx, false));
-    A(devAlloc(c, &s.range, npx, false));
+    A(devAlloc(c, &s.range, npx + 4, false));  // + pad: k_fuse gathers pixel pairs (u0, u0 + 1) with one 8-byte load
     A(devAlloc(c, &s.rgba, npx, false));
     A(devAlloc(c, &s.label, npx, false));
     A(devAlloc(c, &s.dyn, npx));
@@ -921,7 +918,7 @@ int khr_upload_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fram
   s.th = (sensor->height + kTile - 1) / kTile;
   hipLaunchKernelGGL(k_frame_ingest, dim3(s.tw * s.th), dim3(256), 0, ist, depth_src, rgb_src, label_src, s.depth,
                      s.range, s.rgba, s.label, s.dyn, s.tile_max, s.tw, sensor->width, sensor->height, sensor->fx, sensor->fy,
-                     sensor->cx, sensor->cy, c->p.range_mode, c->m, c->p.nvox, c->d_band_count, c->begin_in_ingest ? 1 : 0);
+                     sensor->cx, sensor->cy, c->p.range_mode, c->m, c->p.nvox, c->d_wg_stats, c->begin_in_ingest ? 1 : 0);
   HIP_TRY(hipGetLastError());
   c->begun = c->begin_in_ingest;
   c->begin_in_ingest = false;
@@ -1006,7 +1003,7 @@ int khr_download_frame_image(khr_ctx* c, int slot, int which, int32_t* image) {
 static int integrateAlloc(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allocate_blocks) {
   DevMap& m = c->m;
   // reset per-call counters (already done by k_frame_ingest inside khr_process_frame)
-  if (!c->begun) hipLaunchKernelGGL(k_begin_integrate, dim3(1), dim3(64), 0, c->stream, m, c->p.nvox, c->d_band_count);
+  if (!c->begun) hipLaunchKernelGGL(k_begin_integrate, dim3(1), dim3(256), 0, c->stream, m, c->p.nvox, c->d_wg_stats);
   c->begun = false;
   if (allocate_blocks) {
     ScopedTimer tm(c, 3);
@@ -1027,72 +1024,93 @@ static int integrateAlloc(khr_ctx* c, FrameSlot& s, const DevFrame& f, int alloc
   return KHR_OK;
 }
 
-// TSDF + band update kernels of one integrate call
-// tick path: the camera's own work list and the alternating record-cursor set
+// the fused TSDF / colour / label update kernel of one integrate call (k_fuse)
+// tick path: the camera's own work list
 struct UpdateLists {
   const uint32_t* tsdf_work = nullptr;
   const uint32_t* tsdf_count = nullptr;
-  uint32_t* band_count = nullptr;
-  uint32_t* band_count_next = nullptr;
 };
+
+// resident workgroups of a k_fuse instantiation x CUs, rounded down to whole XCD rounds (the grid is persistent: static
+// striding over the work items, so workgroups beyond residency would only add a tail)
+static int fuseGrid(khr_ctx* c, const void* kernel, int group) {
+  if (kFuseGrid > 0) return std::max(8 * group, kFuseGrid / (8 * group) * (8 * group));
+  static std::map<const void*, int> cache;
+  const void* key = kernel;
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int per_cu = 0, cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  per_cu = std::min(per_cu, 8);
+  int grid = std::min(kFuseStatSlots, per_cu * cus);
+  grid = std::max(8 * group, grid / (8 * group) * (8 * group));
+  cache[key] = grid;
+  return grid;
+}
+
 static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allocate_blocks, int use_mask,
                            int object_id, const UpdateLists* lists = nullptr) {
   DevMap& m = c->m;
-  (void)s;
   const uint32_t* tsdf_work = allocate_blocks ? c->d_work_tsdf : c->d_work;
   const uint32_t* tsdf_count = allocate_blocks ? &m.counters[C_N_TSDF] : &m.counters[C_N_VISIBLE];
-  uint32_t* band_count = c->d_band_count;
-  uint32_t* band_count_next = nullptr;
   if (lists) {
     tsdf_work = lists->tsdf_work;
     tsdf_count = lists->tsdf_count;
-    band_count = lists->band_count;
-    band_count_next = lists->band_count_next;
   }
+  FuseArgs a{};
+  a.blk_index = m.blk_index; a.blk_flags = m.blk_flags; a.dist = m.dist; a.weight = m.weight; a.last_obs = m.last_obs;
+  a.color = m.color; a.vflags = m.vflags; a.sem_label = m.sem_label; a.lik = m.lik; a.wg_stats = c->d_wg_stats;
+  a.range = f.range; a.dyn = f.dyn; a.rgba = f.rgba; a.label = f.label; a.obj = f.obj;
+  a.W = f.W; a.H = f.H; a.fx = f.fx; a.fy = f.fy; a.cx = f.cx; a.cy = f.cy; a.min_range = f.min_range; a.max_range = f.max_range;
+  std::memcpy(a.R, f.R, sizeof(a.R));
+  std::memcpy(a.t, f.t, sizeof(a.t));
+  a.stamp = f.stamp;
+  a.vs = c->p.vs; a.bs = c->p.bs; a.trunc = c->p.trunc; a.dropoff_eps = c->p.dropoff_eps; a.max_weight = c->p.max_weight;
+  a.adaptive_diff = c->p.adaptive_diff; a.log_match = c->p.log_match; a.log_nomatch = c->p.log_nomatch;
+  a.interp = c->p.interp; a.range_mode = c->p.range_mode; a.use_dropoff = c->p.use_dropoff; a.const_weight = c->p.const_weight;
+  a.with_tracking = c->p.with_tracking;
+  // a dynamic image nobody has painted since the ingest is all zero: the mask cannot reject anything
+  a.use_mask = (use_mask && !s.dyn_clean) ? 1 : 0;
+  a.K = c->p.K; a.sem_mode = c->p.sem_mode; a.has_color = f.has_color; a.object_id = object_id;
+  a.do_sem = (c->p.with_semantics && ((c->p.sem_mode == 1) ? (object_id >= 0 && f.obj != nullptr) : (f.has_label != 0))) ? 1 : 0;
+  const bool defcfg = a.range_mode == 0 && a.interp == 2 && a.use_dropoff && !a.const_weight;
+  const bool exact = kFuseExact >= 0 ? kFuseExact != 0 : c->cfg.exact_arithmetic != 0;
   int rc = dispatchVps(c, [&](auto vps) {
     constexpr int V = decltype(vps)::value;
-    {
-      TsdfArgs a{};
-      a.blk_index = m.blk_index; a.blk_flags = m.blk_flags; a.dist = m.dist; a.weight = m.weight;
-      a.last_obs = m.last_obs; a.stats = m.stats; a.counters = m.counters;
-      a.range = f.range; a.dyn = f.dyn; a.W = f.W; a.H = f.H;
-      a.fx = f.fx; a.fy = f.fy; a.cx = f.cx; a.cy = f.cy; a.min_range = f.min_range; a.max_range = f.max_range;
-      std::memcpy(a.R, f.R, sizeof(a.R));
-      std::memcpy(a.t, f.t, sizeof(a.t));
-      a.stamp = f.stamp;
-      a.vs = c->p.vs; a.bs = c->p.bs; a.trunc = c->p.trunc; a.dropoff_eps = c->p.dropoff_eps;
-      a.max_weight = c->p.max_weight; a.adaptive_diff = c->p.adaptive_diff;
-      a.interp = c->p.interp; a.range_mode = c->p.range_mode; a.use_dropoff = c->p.use_dropoff;
-      a.const_weight = c->p.const_weight; a.with_tracking = c->p.with_tracking; a.use_mask = use_mask; a.dbg = c->p.dbg; a.dbg_buf = c->d_dbg; a.wg_stats = c->d_wg_stats;
-      // CHUNKS = z-slabs of the block staged in LDS at a time (LDS per workgroup = 9 B * nvox / CHUNKS)
-      const bool fast = a.range_mode == 0 && a.interp == 2 && a.use_dropoff && !a.const_weight && a.dbg == 0;
-      auto launch = [&](auto chunks) {
-        constexpr int CH = decltype(chunks)::value;
-        if (fast)
-          KHR_LAUNCH_TIMED(0, (k_tsdf_update<V, CH, true>), dim3(kTsdfGrid), dim3(256), a, tsdf_work, tsdf_count, c->d_band,
-                           c->band_cap / kBandShards, band_count);
-        else
-          KHR_LAUNCH_TIMED(0, (k_tsdf_update<V, CH, false>), dim3(kTsdfGrid), dim3(256), a, tsdf_work, tsdf_count, c->d_band,
-                           c->band_cap / kBandShards, band_count);
+    auto launch = [&](auto zsplit) {
+      constexpr int ZS = decltype(zsplit)::value;
+      constexpr int G = (V * V / 64) * ZS / 4 > 0 ? (V * V / 64) * ZS / 4 : 1;
+      auto go = [&](auto kern) {
+        const int grid = fuseGrid(c, reinterpret_cast<const void*>(kern), G);
+        KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(256), a, tsdf_work, tsdf_count);
       };
-      if (V == 8) {
-        launch(std::integral_constant<int, 1>());
+      // non-default switches are test configurations: they always run the bit-exact arithmetic
+      if (defcfg && !exact) {
+        if (V == 16 && kFuseMinw == 8) go(&k_fuse<V, ZS, true, false, (V == 16 ? 8 : 1)>);
+        else if (V == 16 && kFuseMinw == 7) go(&k_fuse<V, ZS, true, false, (V == 16 ? 7 : 1)>);
+        else go(&k_fuse<V, ZS, true, false, 1>);
+      } else if (defcfg) {
+        go(&k_fuse<V, ZS, true, true, 1>);
       } else {
-        // a shard of a sharded map sees 1 / world of every frame's blocks: smaller z-slabs keep the work-item count
-        // (and with it the number of busy CUs) up and the per-item latency chain short
-        int chunks = kTsdfChunks;
-        if (chunks == 0) chunks = c->cfg.world_size >= 4 ? 16 : (c->cfg.world_size >= 2 ? 8 : 4);
-        switch (chunks) {
-          case 1: launch(std::integral_constant<int, 1>()); break;
-          case 2: launch(std::integral_constant<int, 2>()); break;
-          case 8: launch(std::integral_constant<int, (V == 16 ? 8 : 1)>()); break;
-          case 16: launch(std::integral_constant<int, (V == 16 ? 16 : 1)>()); break;
-          default: launch(std::integral_constant<int, (V == 16 ? 4 : 1)>()); break;
-        }
+        go(&k_fuse<V, ZS, false, true, 1>);
+      }
+    };
+    // a shard of a sharded map sees 1 / world of every frame's blocks: shorter z ranges per wave keep the number of
+    // wave items (and with it the number of busy SIMDs) up
+    int zs = kFuseZsplit;
+    if (zs == 0) zs = c->cfg.world_size >= 4 ? 8 : (c->cfg.world_size >= 2 ? 4 : 2);
+    if (V == 8) {
+      launch(std::integral_constant<int, 4>());
+    } else {
+      switch (zs) {
+        case 1: launch(std::integral_constant<int, (V == 16 ? 1 : 4)>()); break;
+        case 4: launch(std::integral_constant<int, 4>()); break;
+        case 8: launch(std::integral_constant<int, (V == 16 ? 8 : 4)>()); break;
+        default: launch(std::integral_constant<int, (V == 16 ? 2 : 4)>()); break;
       }
     }
-    KHR_LAUNCH_TIMED(7, (k_band_update<V>), dim3(kBandGrid / kBandShards, kBandShards), dim3(256), m, c->p, f, c->d_band,
-                     c->band_cap / kBandShards, band_count, object_id, c->d_wg_stats, kTsdfGrid, band_count_next);
     return KHR_OK;
   });
   if (rc) return rc;
@@ -1227,7 +1245,6 @@ static int ensureTick(khr_ctx* c) {
   if (!rc) rc = devAlloc(c, &c->d_tick_tsdf, cap * kMaxTick, false);
   if (!rc) rc = devAlloc(c, &c->d_tick_counts, 2 * kMaxTick + 32);
   if (!rc) rc = devAlloc(c, &c->d_tick_seeds, kMaxTick + 32);
-  if (!rc) rc = devAlloc(c, &c->d_band_count2, kBandShards * 32);
   if (rc) return rc;
   if (hipHostMalloc(reinterpret_cast<void**>(&c->h_tick), 256, hipHostMallocDefault) != hipSuccess)
     return fail(KHR_ENOMEM, "pinned tick block");
@@ -1356,8 +1373,8 @@ int khr_tick_integrate(khr_ctx* c, const int* slots, int n_frames, int use_mask,
       if (++c->tick_epoch <= 0) c->tick_epoch = 1;
       c->motion_ignore_epoch = c->tick_epoch;
       if (std::getenv("KHR_DEBUG_TICK_NO_EPOCH")) c->motion_ignore_epoch = 0;  // test hook: shows that the epoch matters
-      hipLaunchKernelGGL(k_tick_begin, dim3(1), dim3(64), 0, c->stream, m, c->p.nvox, c->d_band_count, c->d_band_count2,
-                         c->d_tick_counts, static_cast<uint32_t>(nb - 1));
+      hipLaunchKernelGGL(k_tick_begin, dim3(1), dim3(256), 0, c->stream, m, c->p.nvox, c->d_wg_stats, c->d_tick_counts,
+                         static_cast<uint32_t>(nb - 1));
       c->begun = false;
       ScopedTimer tm(c, 3);
       for (int k = 0; k < nb; ++k) {
@@ -1380,8 +1397,6 @@ int khr_tick_integrate(khr_ctx* c, const int* slots, int n_frames, int use_mask,
       UpdateLists lists;
       lists.tsdf_work = c->d_tick_tsdf + static_cast<size_t>(k) * cap;
       lists.tsdf_count = &c->d_tick_counts[2 * k + 1];
-      lists.band_count = (k & 1) ? c->d_band_count2 : c->d_band_count;
-      lists.band_count_next = (k & 1) ? c->d_band_count : c->d_band_count2;
       rc = integrateUpdate(c, s, t.f[k], 1, use_mask, object_id, &lists);
       if (rc) return rc;
     }
@@ -1478,7 +1493,7 @@ static int motionLaunch(khr_ctx* c, FrameSlot& s, bool fresh_slot, bool do_begin
     ++c->seed_ticket;
     if (c->seed_ticket == 0) ++c->seed_ticket;
     hipLaunchKernelGGL(k_motion_pixels, dim3(gridFor(n)), dim3(256), 0, c->stream, m, c->p, f, c->cfg.md_max_range,
-                       min_z_world, c->d_keys, c->motion_ignore_epoch, do_begin ? c->d_band_count : nullptr);
+                       min_z_world, c->d_keys, c->motion_ignore_epoch, do_begin ? c->d_wg_stats : nullptr);
     if (do_begin) c->begun = true;
   }
   HIP_TRY(hipGetLastError());
@@ -2635,15 +2650,23 @@ int khr_get_stats(khr_ctx* c, khr_stats* out) {
   s.n_visible_blocks = c->h_counters[C_N_VISIBLE];
   s.n_new_blocks = c->h_counters[C_N_NEW];
   s.n_visited_voxels = static_cast<uint64_t>(c->h_counters[C_N_VISIBLE]) * c->p.nvox;
-  s.n_updated_voxels = st[S_UPD];
-  s.n_band_voxels = st[S_BAND];
+  // k_fuse's per-workgroup partial sums since the last per-call reset (beginIntegrate folds them into the totals)
+  std::vector<uint32_t> wgs(2 * kFuseStatSlots);
+  HIP_TRY(hipMemcpy(wgs.data(), c->d_wg_stats, sizeof(uint32_t) * wgs.size(), hipMemcpyDeviceToHost));
+  uint64_t cur_upd = 0, cur_band = 0;
+  for (int i = 0; i < kFuseStatSlots; ++i) {
+    cur_upd += wgs[2 * i];
+    cur_band += wgs[2 * i + 1];
+  }
+  s.n_updated_voxels = cur_upd;
+  s.n_band_voxels = cur_band;
   s.n_tracking_updated_blocks = c->h_counters[c->ef_cur ? C_N_EF2 : C_N_EF_A];
   s.pool_exhausted = c->h_counters[C_POOL_EXHAUSTED];
   s.n_tsdf_blocks = c->h_counters[C_N_TSDF];
-  s.band_overflow = c->h_counters[C_BAND_OVERFLOW];
+  s.band_overflow = 0;  // the fused update kernel keeps no global record list
   s.n_tracking_processed_blocks = c->h_counters[c->ef_cur ? C_N_PROC2 : C_N_PROC];
-  s.cum_updated_voxels = st[S_CUM_UPD] + st[S_UPD];
-  s.cum_band_voxels = st[S_CUM_BAND] + st[S_BAND];
+  s.cum_updated_voxels = st[S_CUM_UPD] + cur_upd;
+  s.cum_band_voxels = st[S_CUM_BAND] + cur_band;
   s.cum_visited_voxels = st[S_CUM_VISITED] + s.n_visited_voxels;
   s.cum_integrate_calls = st[S_CUM_CALLS];
   *out = s;

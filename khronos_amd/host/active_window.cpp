@@ -228,7 +228,7 @@ std::shared_ptr<KhronosObjectAttributes> MeshObjectExtractor::extractStaticObjec
   oc.semantic_mode = 1;
   oc.num_frame_slots = 1;
   oc.max_frame_pixels = 4;
-  oc.max_band_records = device_config_.max_band_records ? device_config_.max_band_records : 4u * device_config_.max_frame_pixels;
+  oc.exact_arithmetic = device_config_.exact_arithmetic;
   oc.rank = 0;
   oc.world_size = 1;
   int32_t mn[3], mx[3];
@@ -396,6 +396,7 @@ ActiveWindow::Config ActiveWindow::Config::fromYaml(const khronos_amd::YamlNode&
     m->read("device", c.device);
     m->read("rank", c.rank);
     m->read("world_size", c.world_size);
+    m->read("exact_arithmetic", c.exact_arithmetic);
   }
   return c;
 }
@@ -472,6 +473,7 @@ ActiveWindow::ActiveWindow(const Config& cfg) : config(cfg), frame_data_buffer_(
   d.device = config.device;
   d.rank = config.rank;
   d.world_size = config.world_size;
+  d.exact_arithmetic = config.exact_arithmetic;
   chk(khr_create(&d, &ctx_), "khr_create");
   map_ = VolumetricMap(config.volumetric_map, ctx_);
 

@@ -328,6 +328,7 @@ class ActiveWindow {
     uint32_t max_frame_pixels = 1280 * 720;
     uint64_t max_mesh_vertices = 8u << 20;
     int device = 0, rank = 0, world_size = 1;
+    int exact_arithmetic = 0;  // khr_config.exact_arithmetic: voxel values bit-identical to the CPU restatement
 
     // parse the `active_window:` mapping of a Khronos mapper YAML (same keys as uHumans2.yaml:35-100)
     static Config fromYaml(const khronos_amd::YamlNode& active_window_node);

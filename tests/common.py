@@ -8,12 +8,19 @@ from oracle import pyoracle as po
 
 # the float tolerance BASELINE.json states (per-voxel SDF / weight / label within 1e-4)
 TOL = 1e-4
+# arithmetic mode of the contexts make_pair creates (khr_config.exact_arithmetic); the `arith` fixture (conftest.py) runs a
+# test under both.  1: voxel values bit-identical to the oracle (every comparison below is exact).  0 (product default):
+# every decision of the integrator is still exact, distance / weight carry ~1e-6 relative error, so the few later decisions
+# that read those VALUES (occupied = distance < threshold, colour rounding) may differ on voxels that sit on the
+# threshold to within that error; such voxels are counted and bounded, not ignored.
+EXACT = 0
 
 
 def make_pair(width=320, height=240, seed=1234, stream_kw=None, **cfg_kw):
     kw = dict(voxel_size=0.1, truncation_distance=0.3, with_semantics=1, with_tracking=1, max_blocks=4096,
               max_frame_pixels=width * height, md_min_cluster_size=20, md_min_separation_distance=2.0, md_max_range=5.0)
     kw.update(cfg_kw)
+    kw.setdefault("exact_arithmetic", EXACT)
     cfg = default_config(**kw)
     ctx = FusionContext(cfg)
     ora = po.OracleMap(po.config_from(cfg, 0))
@@ -44,8 +51,18 @@ def step_both(ctx, ora, sen, osen, fr, motion=False, track=True, use_color=True,
     return out
 
 
-def compare_maps(ctx, ora, max_blocks=None, rng=None, check_lik=True):
-    """Block index sets bit-exact; per-voxel fields within TOL (integers / flags exact)."""
+def occupancy_threshold(cfg):
+    """tracking_integrator.cpp:136-138: negative = multiple of the voxel size"""
+    t = cfg.tsdf_occupancy_threshold
+    return -t * cfg.voxel_size if t < 0 else t
+
+
+def compare_maps(ctx, ora, max_blocks=None, rng=None, check_lik=True, cfg=None, exact=None):
+    """Block index sets bit-exact; per-voxel fields within TOL; labels and last_observed exact.  exact arithmetic: every
+    field bit-identical.  Fast arithmetic: last_occupied / tracking flags derive from `distance < threshold`, a decision
+    on a VALUE that carries ~1e-7 of error, so a voxel sitting on the threshold may differ; mismatches are counted in
+    worst["borderline"] and bounded by 1e-5 of the compared voxels (expected: 0 at test sizes)."""
+    exact = bool(EXACT) if exact is None else exact
     gi, oi = ctx.block_indices(), ora.block_indices()
     assert gi.shape == oi.shape, (gi.shape, oi.shape)
     assert (gi == oi).all(), "block index sets differ"
@@ -53,25 +70,38 @@ def compare_maps(ctx, ora, max_blocks=None, rng=None, check_lik=True):
     if max_blocks is not None and len(gi) > max_blocks:
         rng = rng or np.random.default_rng(0)
         sel = np.sort(rng.choice(len(gi), max_blocks, replace=False))
-    worst = {"distance": 0.0, "weight_rel": 0.0, "lik": 0.0, "color": 0}
+    worst = {"distance": 0.0, "weight_rel": 0.0, "lik": 0.0, "color": 0, "borderline": 0, "voxels": 0, "color_off_by_one": 0}
     for i in sel:
         idx = gi[i]
         g, o = ctx.download_block(idx), ora.get_block(idx)
+        worst["voxels"] += g["distance"].size
         worst["distance"] = max(worst["distance"], float(np.abs(g["distance"] - o["distance"]).max()))
         wr = np.abs(g["weight"] - o["weight"]) / np.maximum(1.0, np.abs(o["weight"]))
         worst["weight_rel"] = max(worst["weight_rel"], float(wr.max()))
-        worst["color"] = max(worst["color"], int(np.abs(g["color"].astype(int) - o["color"].astype(int)).max()))
+        cd = np.abs(g["color"].astype(int) - o["color"].astype(int))
+        worst["color"] = max(worst["color"], int(cd.max()))
+        worst["color_off_by_one"] += int((cd.max(axis=-1) > 0).sum()) if cd.ndim > 1 else int((cd > 0).sum())
         assert (g["last_observed"] == o["last_observed"]).all(), ("last_observed", idx)
-        assert (g["last_occupied"] == o["last_occupied"]).all(), ("last_occupied", idx)
-        assert (g["flags"] == o["flags"]).all(), ("flags", idx, np.flatnonzero(g["flags"] != o["flags"])[:8])
         assert (g["sem_label"] == o["sem_label"]).all(), ("sem_label", idx)
-        assert g["block_flags"] == o["block_flags"], ("block_flags", idx, g["block_flags"], o["block_flags"])
+        if exact:
+            assert np.array_equal(g["distance"], o["distance"]), ("distance not bit-exact", idx)
+            assert np.array_equal(g["weight"], o["weight"]), ("weight not bit-exact", idx)
+            assert (g["color"] == o["color"]).all(), ("color", idx)
+            assert (g["last_occupied"] == o["last_occupied"]).all(), ("last_occupied", idx)
+            assert (g["flags"] == o["flags"]).all(), ("flags", idx, np.flatnonzero(g["flags"] != o["flags"])[:8])
+            assert g["block_flags"] == o["block_flags"], ("block_flags", idx, g["block_flags"], o["block_flags"])
+        else:
+            bad = (g["last_occupied"] != o["last_occupied"]) | (g["flags"] != o["flags"])
+            worst["borderline"] += int(bad.sum())
+            if g["block_flags"] != o["block_flags"]:
+                worst["borderline"] += 1
         if check_lik and g["likelihoods"] is not None:
             worst["lik"] = max(worst["lik"], float(np.abs(g["likelihoods"] - o["likelihoods"]).max()))
     assert worst["distance"] <= TOL, worst
     assert worst["weight_rel"] <= TOL, worst
     assert worst["lik"] <= TOL * 10, worst  # log-likelihood sums grow with observations
     assert worst["color"] <= 1, worst
+    assert worst["borderline"] <= max(2, int(1e-5 * worst["voxels"])), worst
     return worst, len(gi)
 
 

@@ -14,9 +14,18 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session", autouse=True)
 def _built():
-    """Make sure the native artefacts exist (no-op when already built)."""
+    """Build the native artefacts; build() is mtime-gated, so this is a no-op when they are newer than their sources
+    (lib/ is git-ignored: running against stale binaries after a source edit must not be possible)."""
     import __graft_entry__ as g
-    if not (os.path.exists(os.path.join(ROOT, "khronos_amd", "lib", "libkhronos_amd.so"))
-            and os.path.exists(os.path.join(ROOT, "khronos_amd", "lib", "libkhr_synth.so"))
-            and os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so"))):
-        g.build()
+    g.build()
+
+
+@pytest.fixture(params=["fast", "exact"])
+def arith(request):
+    """Runs a parity test under both arithmetic modes of the voxel update (khr_config.exact_arithmetic): `fast` = the
+    product default (decisions exact, values within TOL), `exact` = values bit-identical to the oracle as well."""
+    import common
+    prev = common.EXACT
+    common.EXACT = 1 if request.param == "exact" else 0
+    yield request.param
+    common.EXACT = prev

@@ -7,6 +7,12 @@ from common import TOL, compare_maps, make_pair, step_both
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _both_arithmetic_modes(arith):
+    """every test of this module runs with the product's fast arithmetic and with exact_arithmetic = 1 (conftest.arith)"""
+    yield
+
+
 def test_single_frame_tsdf_semantics():
     cfg, ctx, ora, s, sen, osen = make_pair()
     fr = s.render(0)

@@ -106,6 +106,8 @@ struct FuseArgs {
   float vs, bs, trunc, dropoff_eps, max_weight, adaptive_diff, log_match, log_nomatch;
   int interp, range_mode, use_dropoff, const_weight, with_tracking, use_mask;
   int K, sem_mode, do_sem, has_color, object_id;
+  int dbg;  // ablation switches of the DBG instantiation (env KHR_FUSE_DBG): 1 no band phase, 2 no voxel stores,
+            // 4 no distance / weight loads, 8 range gathers from a fixed address, 16 geometry only
 };
 
 constexpr int kFuseCap = 192;        // in-band records a wave collects before it works them off
@@ -228,7 +230,7 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, size_t slot, uint32_t lin_mo
 // weight) resolved at compile time; otherwise they are read from the argument block.
 // ZSPLIT = wave items per x-y patch (a wave walks VPS / ZSPLIT z steps).
 // MINW = resident waves per SIMD the register allocation is held to (__launch_bounds__; 1 = unconstrained).
-template <int VPS, int ZSPLIT, bool DEFCFG, bool EXACT, int MINW>
+template <int VPS, int ZSPLIT, bool DEFCFG, bool EXACT, int MINW, bool DBG = false>
 __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, const uint32_t* __restrict__ work,
                                               const uint32_t* __restrict__ n_work) {
   constexpr int NV = VPS * VPS * VPS;
@@ -256,6 +258,7 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, const uint32_t* 
   const uint32_t n_wg = (n_items + 3) / 4;    // workgroup items
   const uint32_t n_wg_pad = (n_wg + 8 * G - 1) / (8 * G) * (8 * G);
   uint32_t n_upd = 0, n_band = 0;
+  const int dbg = DBG ? a.dbg : 0;
   for (uint32_t b = blockIdx.x; b < n_wg_pad; b += gridDim.x) {
     // workgroup b runs on XCD b % 8: the G items of a block go to the same XCD
     const uint32_t x = b & 7u, q = b >> 3;
@@ -299,17 +302,22 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, const uint32_t* 
       // ceil(u) >= W || floor(u) < 0  <=>  u > W - 1 || u < 0  (W - 1 is an integer-valued float); x - y >= 0 <=> x >= y
       // holds exactly in IEEE arithmetic, so the four tests are one min3 / min / compare
       ok = ok && (fminf(fminf(u, v), fminf(Wm1 - u, Hm1 - v)) >= 0.f);
+      if (DBG && (dbg & 16)) {
+        n_upd += static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(ok)));
+        continue;
+      }
       if (__builtin_amdgcn_ballot_w64(ok) != 0ull) {
         // invalid lanes gather pixel (0, 0); valid lanes have 0 <= u <= W - 1, so floor == truncation
         const float uc = ok ? u : 0.f, vc = ok ? v : 0.f;
         const uint32_t u0 = static_cast<uint32_t>(static_cast<int>(uc)), v0 = static_cast<uint32_t>(static_cast<int>(vc));
         const uint32_t v1 = min(v0 + 1u, static_cast<uint32_t>(a.H - 1));
         const float du = __builtin_amdgcn_fractf(uc), dv = __builtin_amdgcn_fractf(vc);  // x - floor(x), exact for x >= 0
-        const uint32_t o0 = v0 * W4 + u0 * 4u, o1 = v1 * W4 + u0 * 4u;  // byte offsets of (u0, v0), (u0, v1)
+        uint32_t o0 = v0 * W4 + u0 * 4u, o1 = v1 * W4 + u0 * 4u;  // byte offsets of (u0, v0), (u0, v1)
+        if (DBG && (dbg & 8)) { o0 = static_cast<uint32_t>(lane) * 8u; o1 = o0 + W4; }
         const f2u ra = *reinterpret_cast<const f2u*>(range_b + o0);  // (u0, v0), (u0 + 1, v0)
         const f2u rb = *reinterpret_cast<const f2u*>(range_b + o1);  // (u0, v1), (u0 + 1, v1)
         float d_old = 0.f, w_old = 0.f;
-        if (ok) {
+        if (ok && !(DBG && (dbg & 4))) {
           d_old = *reinterpret_cast<const float*>(dist_b + lin * 4u);
           w_old = *reinterpret_cast<const float*>(wgt_b + lin * 4u);
         }
@@ -381,7 +389,7 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, const uint32_t* 
             d_new = __builtin_fmaf(d_old, w_old, sdf_c * w) * __builtin_amdgcn_rcpf(tot);
           }
           const float w_new = fminf(tot, a.max_weight);
-          if (ok) {
+          if (ok && !(DBG && (dbg & 2))) {
             *reinterpret_cast<float*>(dist_b + lin * 4u) = d_new;
             *reinterpret_cast<float*>(wgt_b + lin * 4u) = w_new;
             if (a.with_tracking) *reinterpret_cast<uint64_t*>(lobs_b + lin * 8u) = a.stamp;
@@ -407,6 +415,7 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, const uint32_t* 
       }
       // work the list off when the next z step might not fit, and at the end of the item (a cold block: the hint keeps
       // the register allocator from favouring its values over the voxel loop's)
+      if (DBG && (dbg & 1)) cnt = 0u;
       if (__builtin_expect(cnt > static_cast<uint32_t>(kFuseCap - 64) || (zi == ZR - 1 && cnt > 0u), 0)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -440,6 +440,7 @@ int kFuseGrid = 0;      // 0 = resident workgroups of the instantiation (occupan
 int kFuseZsplit = 0;    // 0 = by world size (wave items per x-y patch of a block: 2 / 4 / 8); env KHR_FUSE_ZSPLIT
 int kFuseExact = -1;    // -1 = khr_config.exact_arithmetic; env KHR_FUSE_EXACT=0/1 overrides (A/B switch)
 int kFuseMinw = 0;      // env KHR_FUSE_MINW: register budget of the default instantiation (1 none, 7, 8 waves / SIMD)
+int kFuseDbg = 0;       // env KHR_FUSE_DBG: ablation switches (development; selects the DBG instantiation)
 constexpr int kStreamGrid = 4096;
 
 }  // namespace
@@ -650,6 +651,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   if (std::getenv("KHR_FUSE_ZSPLIT")) kFuseZsplit = std::atoi(std::getenv("KHR_FUSE_ZSPLIT"));
   if (std::getenv("KHR_FUSE_EXACT")) kFuseExact = std::atoi(std::getenv("KHR_FUSE_EXACT")) ? 1 : 0;
   if (std::getenv("KHR_FUSE_MINW")) kFuseMinw = std::atoi(std::getenv("KHR_FUSE_MINW"));
+  if (std::getenv("KHR_FUSE_DBG")) kFuseDbg = std::atoi(std::getenv("KHR_FUSE_DBG"));
   if (std::getenv("KHR_NO_EARLY_INGEST")) c->early_ingest = false;
 
   DevMap& m = c->m;
@@ -1084,10 +1086,15 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
       constexpr int G = (V * V / 64) * ZS / 4 > 0 ? (V * V / 64) * ZS / 4 : 1;
       auto go = [&](auto kern) {
         const int grid = fuseGrid(c, reinterpret_cast<const void*>(kern), G);
+        static bool said = false;
+        if (!said && std::getenv("KHR_VERBOSE")) { said = true; std::fprintf(stderr, "[khr] k_fuse<%d,%d> grid %d\n", V, ZS, grid); }
         KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(256), a, tsdf_work, tsdf_count);
       };
       // non-default switches are test configurations: they always run the bit-exact arithmetic
-      if (defcfg && !exact) {
+      a.dbg = kFuseDbg;
+      if (defcfg && !exact && kFuseDbg && V == 16) {
+        go(&k_fuse<V, ZS, true, false, 1, (V == 16)>);
+      } else if (defcfg && !exact) {
         if (V == 16 && kFuseMinw == 8) go(&k_fuse<V, ZS, true, false, (V == 16 ? 8 : 1)>);
         else if (V == 16 && kFuseMinw == 7) go(&k_fuse<V, ZS, true, false, (V == 16 ? 7 : 1)>);
         else go(&k_fuse<V, ZS, true, false, 1>);

@@ -242,7 +242,7 @@ int main(int argc, char** argv) {
     }
     track_json += "]";
     auto objects = aw.extractObjects();
-    std::printf("], \"n_outputs\": %d, \"sink_calls\": %d, \"dynamic_clusters\": %zu, \"n_blocks\": %zu, \"checksum\": %.9g, "
+    std::printf("], \"n_outputs\": %d, \"sink_calls\": %d, \"dynamic_clusters\": %zu, \"n_blocks\": %zu, \"checksum\": %.17g, "
                 "\"tracks\": %zu, \"track_list\": %s, \"semantic_clusters\": %zu, \"objects\": [",
                 n_out, sink_calls, total_dyn_clusters, n_blocks, checksum, n_tracks_before, track_json.c_str(), total_sem_clusters);
     for (size_t k = 0; k < objects.size(); ++k) {

@@ -110,7 +110,7 @@ struct FuseArgs {
             // 4 no distance / weight loads, 8 range gathers from a fixed address, 16 geometry only
 };
 
-constexpr int kFuseCap = 192;        // in-band records a wave collects before it works them off
+constexpr int kFuseCap = 256;        // in-band records a wave collects before it works them off (one 4-z chunk of a patch)
 
 // colour / label / likelihood update of one in-band voxel (the body of updateVoxel for |sdf| < truncation)
 // `a` points into the kernel-argument segment: the fields only this phase needs (image / layer pointers, label
@@ -228,18 +228,32 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, size_t slot, uint32_t lin_mo
 
 // DEFCFG = the reference default switches (z-depth range, adaptive interpolation, weight drop-off, no constant
 // weight) resolved at compile time; otherwise they are read from the argument block.
-// ZSPLIT = wave items per x-y patch (a wave walks VPS / ZSPLIT z steps).
+// ZSPLIT = wave items per x-y patch (a wave walks ZR = VPS / ZSPLIT z steps, ZC of them at a time: the loads of a chunk --
+// range gathers, distance, weight -- are all issued before the first result is needed, so a wave has ZC round trips to
+// memory in flight instead of one).
 // MINW = resident waves per SIMD the register allocation is held to (__launch_bounds__; 1 = unconstrained).
+//
+// Work distribution: wave items are pulled from kFuseQueues atomic cursors (8 per XCD; a hot atomic address sustains
+// only ~90 ops/us on gfx950, and blocks differ a lot in cost -- a block the surface crosses carries ~1500 in-band voxels,
+// a free-space block none -- so static striding left most waves idle for the second half of the launch).  Queue
+// (x, s) serves the items t = 8 k + s, k = 0, 1, ... of the blocks with index = x mod 8; a wave starts on the queue of
+// its XCD (workgroup b runs on XCD b % 8: the waves working on a block then share one L2) and moves on to the other
+// queues of that XCD, then to the other XCDs, when its own is empty.  The next cursor value is fetched while the current
+// item is processed.  The cursors alternate between two sets; a launch zeroes the set the next launch will use.
+constexpr int kFuseQueues = 64;      // 8 XCDs x 8 cursors
+constexpr int kFuseQueueStride = 32;  // uint32 words between cursors (one 128-byte line each)
+
 template <int VPS, int ZSPLIT, bool DEFCFG, bool EXACT, int MINW, bool DBG = false>
 __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, const uint32_t* __restrict__ work,
-                                              const uint32_t* __restrict__ n_work) {
+                                              const uint32_t* __restrict__ n_work, uint32_t* __restrict__ queue,
+                                              uint32_t* __restrict__ queue_next) {
   constexpr int NV = VPS * VPS * VPS;
   constexpr int SL = VPS * VPS;        // voxels per z slice
   constexpr int PATCHES = SL / 64;     // 64-voxel x-y patches per slice
   constexpr int ZR = VPS / ZSPLIT;     // z steps per wave item
+  constexpr int ZC = ZR < 4 ? ZR : 4;  // z steps per chunk (loads in flight together)
   constexpr int WPB = PATCHES * ZSPLIT;  // wave items per block
-  constexpr int G = WPB / 4 > 0 ? WPB / 4 : 1;  // workgroup items that share a block: kept on one XCD (same range-image footprint)
-  static_assert(SL % 64 == 0 && VPS % ZSPLIT == 0, "bad block shape");
+  static_assert(SL % 64 == 0 && VPS % ZSPLIT == 0 && ZR % ZC == 0, "bad block shape");
   // per-wave record list, one LDS base per wave: field f of record r at s_rec[wave][f][r] (0 voxel | mode, 1 measurement
   // weight, 2 voxel weight after the update, 3 u, 4 v), so the five stores of a record differ by immediate offsets
   __shared__ uint32_t s_rec[4][5][kFuseCap];
@@ -254,20 +268,38 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, const uint32_t* 
   const float fxfy = a.fx * a.fy;
   const float den = a.trunc - a.dropoff_eps;  // weight drop-off denominator (uniform)
   const float yden = rcpRefined(den);
-  const uint32_t n_items = *n_work * WPB;     // wave items
-  const uint32_t n_wg = (n_items + 3) / 4;    // workgroup items
-  const uint32_t n_wg_pad = (n_wg + 8 * G - 1) / (8 * G) * (8 * G);
+  const uint32_t n_blocks = *n_work;
   uint32_t n_upd = 0, n_band = 0;
   const int dbg = DBG ? a.dbg : 0;
-  for (uint32_t b = blockIdx.x; b < n_wg_pad; b += gridDim.x) {
-    // workgroup b runs on XCD b % 8: the G items of a block go to the same XCD
-    const uint32_t x = b & 7u, q = b >> 3;
-    const uint32_t j = (q / G) * (8 * G) + x * G + (q % G);
-    const uint32_t wi = j * 4 + static_cast<uint32_t>(wave);
-    if (wi >= n_items) continue;
-    const size_t slot = work[wi / WPB];
-    const int sub = static_cast<int>(wi % WPB);
-    const int patch = sub % PATCHES, z0 = (sub / PATCHES) * ZR;
+  if (blockIdx.x == 0 && threadIdx.x < kFuseQueues) queue_next[threadIdx.x * kFuseQueueStride] = 0u;
+  // this wave's home queue: one of the 8 cursors of its XCD
+  uint32_t cur_q = (blockIdx.x & 7u) * 8u + ((static_cast<uint32_t>(blockIdx.x >> 3) * 4u + static_cast<uint32_t>(wave)) & 7u);
+  const uint32_t home_q = cur_q;
+  auto fetch = [&](uint32_t qi) -> uint32_t {  // next position of queue qi (lane 0 carries the value)
+    uint32_t k = 0;
+    if (lane == 0) k = atomicAdd(&queue[qi * kFuseQueueStride], 1u);
+    return k;
+  };
+  uint32_t k_next = fetch(cur_q);
+  while (true) {
+    // ---- take the prefetched position; when the queue is exhausted look at all 64 cursors at once (lane <-> queue)
+    //      and move to the nearest one that still has items (own XCD first) ----
+    const uint32_t kq = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(k_next)));
+    const uint32_t t = kq * 8u + (cur_q & 7u);   // item index among the items of the blocks = x (mod 8)
+    const uint32_t blk = (t / WPB) * 8u + (cur_q >> 3);
+    if (blk >= n_blocks) {
+      const uint32_t kk = __hip_atomic_load(&queue[static_cast<uint32_t>(lane) * kFuseQueueStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t tb = ((kk * 8u + (static_cast<uint32_t>(lane) & 7u)) / WPB) * 8u + (static_cast<uint32_t>(lane) >> 3);
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(tb < n_blocks);
+      if (m == 0ull) break;
+      const unsigned long long rot = home_q ? ((m >> home_q) | (m << (64u - home_q))) : m;
+      cur_q = (static_cast<uint32_t>(__builtin_ctzll(rot)) + home_q) & 63u;
+      k_next = fetch(cur_q);
+      continue;
+    }
+    const size_t slot = work[blk];
+    const int sbi = static_cast<int>(t % WPB);
+    const int patch = sbi % PATCHES, z0 = (sbi / PATCHES) * ZR;
     const int4 bi = a.blk_index[slot];
     const float ox = static_cast<float>(bi.x) * a.bs, oy = static_cast<float>(bi.y) * a.bs, oz = static_cast<float>(bi.z) * a.bs;
     const int lin_xy = patch * 64 + lane;
@@ -286,44 +318,78 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, const uint32_t* 
     const uint32_t W4 = static_cast<uint32_t>(a.W) * 4u;
     uint32_t cnt = 0;       // records waiting in this wave's LDS list
     bool touched = false;   // wave-uniform: some voxel of this item was updated
-    for (int zi = 0; zi < ZR; ++zi) {
-      const int iz = z0 + zi;
-      const uint32_t lin = static_cast<uint32_t>(lin_xy + iz * SL);
-      const float pz = oz + (static_cast<float>(iz) + 0.5f) * a.vs;
-      float pc[3];
+    for (int zc = 0; zc < ZR; zc += ZC) {
+      // ---- phase 1: geometry of the chunk's ZC voxels per lane, all their loads issued ----
+      float u_[ZC], v_[ZC], z_[ZC], yz_[ZC], d_[ZC], w_[ZC];
+      f2u ra_[ZC], rb_[ZC];
+      bool ok_[ZC];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) pc[c] = (pxy[c] + a.R[3 * c + 2] * pz) + a.t[c];
-      bool ok = pc[2] > 0.f;
-      const float voxel_range = range_mode == 0 ? pc[2] : sqrtf((pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2]);
-      ok = ok && !(voxel_range < a.min_range || voxel_range > a.max_range);
-      const float yz = rcpRefined(pc[2]);
-      const float u = divExact(pc[0] * a.fx, pc[2], yz) + a.cx;
-      const float v = divExact(pc[1] * a.fy, pc[2], yz) + a.cy;
-      // ceil(u) >= W || floor(u) < 0  <=>  u > W - 1 || u < 0  (W - 1 is an integer-valued float); x - y >= 0 <=> x >= y
-      // holds exactly in IEEE arithmetic, so the four tests are one min3 / min / compare
-      ok = ok && (fminf(fminf(u, v), fminf(Wm1 - u, Hm1 - v)) >= 0.f);
-      if (DBG && (dbg & 16)) {
-        n_upd += static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(ok)));
-        continue;
-      }
-      if (__builtin_amdgcn_ballot_w64(ok) != 0ull) {
+      for (int k = 0; k < ZC; ++k) {
+        const int iz = z0 + zc + k;
+        const uint32_t lin = static_cast<uint32_t>(lin_xy + iz * SL);
+        const float pz = oz + (static_cast<float>(iz) + 0.5f) * a.vs;
+        float pc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pc[c] = (pxy[c] + a.R[3 * c + 2] * pz) + a.t[c];
+        bool ok = pc[2] > 0.f;
+        // (ray-length mode: the range test needs the voxel's full range; recomputed in phase 2)
+        const float voxel_range = range_mode == 0 ? pc[2] : sqrtf((pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2]);
+        ok = ok && !(voxel_range < a.min_range || voxel_range > a.max_range);
+        const float yz = rcpRefined(pc[2]);
+        const float u = divExact(pc[0] * a.fx, pc[2], yz) + a.cx;
+        const float v = divExact(pc[1] * a.fy, pc[2], yz) + a.cy;
+        // ceil(u) >= W || floor(u) < 0  <=>  u > W - 1 || u < 0  (W - 1 is an integer-valued float); x - y >= 0 <=> x >= y
+        // holds exactly in IEEE arithmetic, so the four tests are one min3 / min / compare
+        ok = ok && (fminf(fminf(u, v), fminf(Wm1 - u, Hm1 - v)) >= 0.f);
         // invalid lanes gather pixel (0, 0); valid lanes have 0 <= u <= W - 1, so floor == truncation
         const float uc = ok ? u : 0.f, vc = ok ? v : 0.f;
         const uint32_t u0 = static_cast<uint32_t>(static_cast<int>(uc)), v0 = static_cast<uint32_t>(static_cast<int>(vc));
         const uint32_t v1 = min(v0 + 1u, static_cast<uint32_t>(a.H - 1));
-        const float du = __builtin_amdgcn_fractf(uc), dv = __builtin_amdgcn_fractf(vc);  // x - floor(x), exact for x >= 0
         uint32_t o0 = v0 * W4 + u0 * 4u, o1 = v1 * W4 + u0 * 4u;  // byte offsets of (u0, v0), (u0, v1)
         if (DBG && (dbg & 8)) { o0 = static_cast<uint32_t>(lane) * 8u; o1 = o0 + W4; }
-        const f2u ra = *reinterpret_cast<const f2u*>(range_b + o0);  // (u0, v0), (u0 + 1, v0)
-        const f2u rb = *reinterpret_cast<const f2u*>(range_b + o1);  // (u0, v1), (u0 + 1, v1)
-        float d_old = 0.f, w_old = 0.f;
+        ra_[k] = *reinterpret_cast<const f2u*>(range_b + o0);  // (u0, v0), (u0 + 1, v0)
+        rb_[k] = *reinterpret_cast<const f2u*>(range_b + o1);  // (u0, v1), (u0 + 1, v1)
+        d_[k] = 0.f;
+        w_[k] = 0.f;
         if (ok && !(DBG && (dbg & 4))) {
-          d_old = *reinterpret_cast<const float*>(dist_b + lin * 4u);
-          w_old = *reinterpret_cast<const float*>(wgt_b + lin * 4u);
+          d_[k] = *reinterpret_cast<const float*>(dist_b + lin * 4u);
+          w_[k] = *reinterpret_cast<const float*>(wgt_b + lin * 4u);
         }
+        u_[k] = uc;
+        v_[k] = vc;
+        z_[k] = range_mode == 0 ? pc[2] : voxel_range;
+        yz_[k] = yz;
+        ok_[k] = ok;
+      }
+      // the cursor for the next round is fetched here, BEHIND the chunk's loads: vmcnt retires in order, so an atomic
+      // issued in front of them would have to come back before the first range sample could be used
+      if (zc == 0) k_next = fetch(cur_q);
+      // ---- phase 2: measurement, decisions, read-modify-write ----
+#pragma unroll
+      for (int k = 0; k < ZC; ++k) {
+        bool ok = ok_[k];
+        if (DBG && (dbg & 16)) {
+          n_upd += static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(ok)));
+          continue;
+        }
+        if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
+        const int iz = z0 + zc + k;
+        const uint32_t lin = static_cast<uint32_t>(lin_xy + iz * SL);
+        const float uc = u_[k], vc = v_[k], voxel_range = z_[k], yz = yz_[k];
+        // range_mode 0: voxel_range is the voxel's depth; ray-length mode needs the depth again for the weight
+        float depth = voxel_range;
+        if (range_mode != 0) {
+          const float pz = oz + (static_cast<float>(iz) + 0.5f) * a.vs;
+          depth = (pxy[2] + a.R[8] * pz) + a.t[2];
+        }
+        const uint32_t u0 = static_cast<uint32_t>(static_cast<int>(uc)), v0 = static_cast<uint32_t>(static_cast<int>(vc));
+        const uint32_t v1 = min(v0 + 1u, static_cast<uint32_t>(a.H - 1));
+        const float du = __builtin_amdgcn_fractf(uc), dv = __builtin_amdgcn_fractf(vc);  // x - floor(x), exact for x >= 0
+        const uint32_t o0 = v0 * W4 + u0 * 4u, o1 = v1 * W4 + u0 * 4u;
+        const float d_old = d_[k], w_old = w_[k];
         // pixel order of the reference: (u0,v0) (u0,v1) (u1,v0) (u1,v1) with u1 = min(u0 + 1, W - 1)
         const bool last_col = u0 >= static_cast<uint32_t>(a.W - 1);
-        const float r0 = ra.x, r1 = rb.x, r2 = last_col ? ra.x : ra.y, r3 = last_col ? rb.x : rb.y;
+        const float r0 = ra_[k].x, r1 = rb_[k].x, r2 = last_col ? ra_[k].x : ra_[k].y, r3 = last_col ? rb_[k].x : rb_[k].y;
         bool use_nearest = interp == 0;
         if (interp == 2) {
           const float mn = fminf(fminf(r0, r1), fminf(r2, r3));
@@ -359,64 +425,63 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, const uint32_t* 
             in_band = false;
           }
         }
-        if (__builtin_amdgcn_ballot_w64(ok) != 0ull) {
-          // measurement weight (computeWeight): fx fy vs^2 / z^4, linear drop-off behind the surface
-          float w;
-          if (EXACT) {
-            const float qd = divExact(a.vs, pc[2], yz);
-            w = fxfy * (qd * qd);
-            if (!const_weight) {
-              const float z2 = pc[2] * pc[2];
-              w = divExact(w, z2, rcpRefined(z2));
-            }
-            if (use_dropoff && sdf < -a.dropoff_eps) w = fmaxf(w * divExact(a.trunc + sdf, den, yden), 0.f);
-          } else {
-            const float qd = a.vs * yz;
-            w = fxfy * (qd * qd);
-            if (!const_weight) w = w * (yz * yz);
-            if (use_dropoff && sdf < -a.dropoff_eps) w = fmaxf(w * ((a.trunc + sdf) * yden), 0.f);
+        if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
+        // measurement weight (computeWeight): fx fy vs^2 / z^4, linear drop-off behind the surface
+        float w;
+        if (EXACT) {
+          const float qd = divExact(a.vs, depth, yz);
+          w = fxfy * (qd * qd);
+          if (!const_weight) {
+            const float z2 = depth * depth;
+            w = divExact(w, z2, rcpRefined(z2));
           }
-          // w > 0 is the same decision in both modes: the factors are positive normal numbers far from underflow, so
-          // the product is zero exactly when trunc + sdf == 0
-          ok = ok && (w > 0.f);
-          in_band = in_band && ok;
-          const float sdf_c = fmaxf(fminf(a.trunc, sdf), -a.trunc);
-          const float tot = w_old + w;
-          float d_new;
-          if (EXACT) {
-            d_new = divExact(d_old * w_old + sdf_c * w, tot, rcpRefined(tot));
-          } else {
-            d_new = __builtin_fmaf(d_old, w_old, sdf_c * w) * __builtin_amdgcn_rcpf(tot);
+          if (use_dropoff && sdf < -a.dropoff_eps) w = fmaxf(w * divExact(a.trunc + sdf, den, yden), 0.f);
+        } else {
+          const float qd = a.vs * yz;
+          w = fxfy * (qd * qd);
+          if (!const_weight) w = w * (yz * yz);
+          if (use_dropoff && sdf < -a.dropoff_eps) w = fmaxf(w * ((a.trunc + sdf) * yden), 0.f);
+        }
+        // w > 0 is the same decision in both modes: the factors are positive normal numbers far from underflow, so
+        // the product is zero exactly when trunc + sdf == 0
+        ok = ok && (w > 0.f);
+        in_band = in_band && ok;
+        const float sdf_c = fmaxf(fminf(a.trunc, sdf), -a.trunc);
+        const float tot = w_old + w;
+        float d_new;
+        if (EXACT) {
+          d_new = divExact(d_old * w_old + sdf_c * w, tot, rcpRefined(tot));
+        } else {
+          d_new = __builtin_fmaf(d_old, w_old, sdf_c * w) * __builtin_amdgcn_rcpf(tot);
+        }
+        const float w_new = fminf(tot, a.max_weight);
+        if (ok && !(DBG && (dbg & 2))) {
+          *reinterpret_cast<float*>(dist_b + lin * 4u) = d_new;
+          *reinterpret_cast<float*>(wgt_b + lin * 4u) = w_new;
+          if (a.with_tracking) *reinterpret_cast<uint64_t*>(lobs_b + lin * 8u) = a.stamp;
+        }
+        const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(ok), m_band = __builtin_amdgcn_ballot_w64(in_band);
+        n_upd += static_cast<uint32_t>(__popcll(m_ok));
+        touched = touched || (m_ok != 0ull);
+        if (m_band) {
+          n_band += static_cast<uint32_t>(__popcll(m_band));
+          if (in_band) {
+            const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m_band >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m_band), 0u));
+            uint32_t* const rec = &s_rec[wave][0][pos];
+            rec[0] = lin | (use_nearest ? 0x10000u : 0u);
+            rec[kFuseCap] = __float_as_uint(w);
+            rec[2 * kFuseCap] = __float_as_uint(w_new);
+            rec[3 * kFuseCap] = __float_as_uint(uc);
+            rec[4 * kFuseCap] = __float_as_uint(vc);
           }
-          const float w_new = fminf(tot, a.max_weight);
-          if (ok && !(DBG && (dbg & 2))) {
-            *reinterpret_cast<float*>(dist_b + lin * 4u) = d_new;
-            *reinterpret_cast<float*>(wgt_b + lin * 4u) = w_new;
-            if (a.with_tracking) *reinterpret_cast<uint64_t*>(lobs_b + lin * 8u) = a.stamp;
-          }
-          const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(ok), m_band = __builtin_amdgcn_ballot_w64(in_band);
-          n_upd += static_cast<uint32_t>(__popcll(m_ok));
-          touched = touched || (m_ok != 0ull);
-          if (m_band) {
-            n_band += static_cast<uint32_t>(__popcll(m_band));
-            if (in_band) {
-              const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m_band >> 32),
-                                                                  __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m_band), 0u));
-              uint32_t* const rec = &s_rec[wave][0][pos];
-              rec[0] = lin | (use_nearest ? 0x10000u : 0u);
-              rec[kFuseCap] = __float_as_uint(w);
-              rec[2 * kFuseCap] = __float_as_uint(w_new);
-              rec[3 * kFuseCap] = __float_as_uint(u);
-              rec[4 * kFuseCap] = __float_as_uint(v);
-            }
-            cnt += static_cast<uint32_t>(__popcll(m_band));
-          }
+          cnt += static_cast<uint32_t>(__popcll(m_band));
         }
       }
-      // work the list off when the next z step might not fit, and at the end of the item (a cold block: the hint keeps
+      // work the list off when the next chunk might not fit, and at the end of the item (a cold block: the hint keeps
       // the register allocator from favouring its values over the voxel loop's)
       if (DBG && (dbg & 1)) cnt = 0u;
-      if (__builtin_expect(cnt > static_cast<uint32_t>(kFuseCap - 64) || (zi == ZR - 1 && cnt > 0u), 0)) {
+      if (__builtin_expect(cnt > static_cast<uint32_t>(kFuseCap - 64 * ZC) || (zc + ZC >= ZR && cnt > 0u), 0)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // explicit kernel arguments start at offset 0 of the kernarg segment; the empty asm keeps the loads of the band

@@ -125,6 +125,8 @@ struct khr_ctx {
   int tick_epoch = 0, motion_ignore_epoch = 0;
   unsigned long long* d_dbg = nullptr;
   uint32_t* d_wg_stats = nullptr;
+  uint32_t* d_fuse_queue = nullptr;  // two sets of k_fuse's work cursors (a launch zeroes the set of the next one)
+  uint32_t fuse_seq = 0;
   // remote halo (multi-GPU): records gathered from the other ranks + their index
   uint64_t* d_halo_recs = nullptr;
   const uint64_t* halo_view = nullptr;  // records in use: d_halo_recs, or the caller's device buffer (imported in place)
@@ -439,7 +441,7 @@ int dispatchVps(khr_ctx* c, F&& f) {
 int kFuseGrid = 0;      // 0 = resident workgroups of the instantiation (occupancy query) x CUs; env KHR_FUSE_GRID
 int kFuseZsplit = 0;    // 0 = by world size (wave items per x-y patch of a block: 2 / 4 / 8); env KHR_FUSE_ZSPLIT
 int kFuseExact = -1;    // -1 = khr_config.exact_arithmetic; env KHR_FUSE_EXACT=0/1 overrides (A/B switch)
-int kFuseMinw = 0;      // env KHR_FUSE_MINW: register budget of the default instantiation (1 none, 7, 8 waves / SIMD)
+int kFuseMinw = 0;      // env KHR_FUSE_MINW: register budget of the default instantiation (1 none, 4, 6 waves / SIMD)
 int kFuseDbg = 0;       // env KHR_FUSE_DBG: ablation switches (development; selects the DBG instantiation)
 constexpr int kStreamGrid = 4096;
 
@@ -687,6 +689,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &c->d_work_tsdf, cap));
   A(devAlloc(c, &c->d_dbg, 4096 * 4 * 8));
   A(devAlloc(c, &c->d_wg_stats, 2 * kFuseStatSlots));
+  A(devAlloc(c, &c->d_fuse_queue, 2 * kFuseQueues * kFuseQueueStride));
   A(devAlloc(c, &c->d_removed, cap));
   A(devAlloc(c, &c->d_mesh_count, cap + 1));
   A(devAlloc(c, &c->d_mesh_offset, cap + 1));
@@ -1083,20 +1086,23 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
     constexpr int V = decltype(vps)::value;
     auto launch = [&](auto zsplit) {
       constexpr int ZS = decltype(zsplit)::value;
-      constexpr int G = (V * V / 64) * ZS / 4 > 0 ? (V * V / 64) * ZS / 4 : 1;
+      constexpr int G = 1;
       auto go = [&](auto kern) {
         const int grid = fuseGrid(c, reinterpret_cast<const void*>(kern), G);
         static bool said = false;
         if (!said && std::getenv("KHR_VERBOSE")) { said = true; std::fprintf(stderr, "[khr] k_fuse<%d,%d> grid %d\n", V, ZS, grid); }
-        KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(256), a, tsdf_work, tsdf_count);
+        uint32_t* const q_cur = c->d_fuse_queue + (c->fuse_seq & 1u) * (kFuseQueues * kFuseQueueStride);
+        uint32_t* const q_next = c->d_fuse_queue + ((c->fuse_seq + 1u) & 1u) * (kFuseQueues * kFuseQueueStride);
+        ++c->fuse_seq;
+        KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(256), a, tsdf_work, tsdf_count, q_cur, q_next);
       };
       // non-default switches are test configurations: they always run the bit-exact arithmetic
       a.dbg = kFuseDbg;
       if (defcfg && !exact && kFuseDbg && V == 16) {
         go(&k_fuse<V, ZS, true, false, 1, (V == 16)>);
       } else if (defcfg && !exact) {
-        if (V == 16 && kFuseMinw == 8) go(&k_fuse<V, ZS, true, false, (V == 16 ? 8 : 1)>);
-        else if (V == 16 && kFuseMinw == 7) go(&k_fuse<V, ZS, true, false, (V == 16 ? 7 : 1)>);
+        if (V == 16 && kFuseMinw == 6) go(&k_fuse<V, ZS, true, false, (V == 16 ? 6 : 1)>);
+        else if (V == 16 && kFuseMinw == 4) go(&k_fuse<V, ZS, true, false, (V == 16 ? 4 : 1)>);
         else go(&k_fuse<V, ZS, true, false, 1>);
       } else if (defcfg) {
         go(&k_fuse<V, ZS, true, true, 1>);

@@ -49,6 +49,8 @@ enum Counter : int {
   C_N_PROC2,         // pair 1 (the pairs alternate; each pass zeroes the other pair)
   C_N_EF2,
   C_MP_DONE,         // finished workgroups of k_motion_pixels (the last one publishes the seed count)
+  C_N_TSDF_HEAVY,    // update list of the last integrate: heavy blocks (front of the descriptor list) ...
+  C_N_TSDF_LIGHT,    // ... and the others (back of the list); the two are adjacent (FuseList::counts)
   C_COUNT = 24
 };
 enum Stat64 : int { S_UPD = 0 /* unused */, S_BAND /* unused */, S_MESH_VERTS, S_PRUNED, S_CUM_UPD, S_CUM_BAND, S_CUM_VISITED, S_CUM_CALLS, S_COUNT = 8 };
@@ -75,10 +77,21 @@ struct DevMap {
   uint32_t* sem_label;
   float* lik;
   uint64_t* freebits;
+  uint16_t* blk_band;   // [slot][32]: in-band voxels of each wave item of the block at its latest update (k_fuse -> culling pass)
   uint32_t* free_slots;
   uint32_t* counters;             // Counter
   unsigned long long* stats;      // Stat64
   MeshDesc* mesh_desc;            // per slot
+};
+
+// Update list of k_fuse (written by the culling pass, khr_kernels_fusion.h): block descriptors {slot, block index}, the
+// blocks that reported >= kHeavyBand in-band voxels at their previous update from the front, the others from the back.
+constexpr uint32_t kHeavyBand = 128;
+constexpr int kBandSlots = 32;  // per-block entries of DevMap::blk_band (one per wave item of the block)
+struct FuseList {
+  uint4* desc;       // [cap]
+  uint32_t cap;
+  uint32_t* counts;  // [0] heavy (front), [1] light (back)
 };
 
 struct DevParams {
@@ -280,6 +293,8 @@ __device__ inline void beginIntegrate(DevMap m, int nvox, uint32_t* wg_stats) {
     m.counters[C_N_VISIBLE] = 0u;
     m.counters[C_N_NEW] = 0u;
     m.counters[C_N_TSDF] = 0u;
+    m.counters[C_N_TSDF_HEAVY] = 0u;
+    m.counters[C_N_TSDF_LIGHT] = 0u;
   }
 }
 

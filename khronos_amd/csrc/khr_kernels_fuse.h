@@ -92,6 +92,7 @@ struct FuseArgs {
   uint32_t* sem_label;
   float* lik;
   uint32_t* wg_stats;  // [2 * gridDim.x]: {n_upd, n_band} accumulated per workgroup slot
+  uint16_t* blk_band;  // [slot][kBandSlots]: in-band voxels of each wave item at this update
   // frame
   const float* range;
   const int32_t* dyn;
@@ -106,6 +107,7 @@ struct FuseArgs {
   float vs, bs, trunc, dropoff_eps, max_weight, adaptive_diff, log_match, log_nomatch;
   int interp, range_mode, use_dropoff, const_weight, with_tracking, use_mask;
   int K, sem_mode, do_sem, has_color, object_id;
+  unsigned long long* dbg_buf;  // DBG & 64: per-wave timeline {start, end, band cycles, items, rounds, records, max item cycles, hw id}
   int dbg;  // ablation switches of the DBG instantiation (env KHR_FUSE_DBG): 1 no band phase, 2 no voxel stores,
             // 4 no distance / weight loads, 8 range gathers from a fixed address, 16 geometry only
 };
@@ -233,20 +235,14 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, size_t slot, uint32_t lin_mo
 // memory in flight instead of one).
 // MINW = resident waves per SIMD the register allocation is held to (__launch_bounds__; 1 = unconstrained).
 //
-// Work distribution: wave items are pulled from kFuseQueues atomic cursors (8 per XCD; a hot atomic address sustains
-// only ~90 ops/us on gfx950, and blocks differ a lot in cost -- a block the surface crosses carries ~1500 in-band voxels,
-// a free-space block none -- so static striding left most waves idle for the second half of the launch).  Queue
-// (x, s) serves the items t = 8 k + s, k = 0, 1, ... of the blocks with index = x mod 8; a wave starts on the queue of
-// its XCD (workgroup b runs on XCD b % 8: the waves working on a block then share one L2) and moves on to the other
-// queues of that XCD, then to the other XCDs, when its own is empty.  The next cursor value is fetched while the current
-// item is processed.  The cursors alternate between two sets; a launch zeroes the set the next launch will use.
-constexpr int kFuseQueues = 64;      // 8 XCDs x 8 cursors
-constexpr int kFuseQueueStride = 32;  // uint32 words between cursors (one 128-byte line each)
-
+// Work distribution: the grid is persistent (resident workgroups only) and wave g takes the items g, g + n_waves, ... of
+// the descriptor list the culling pass wrote HEAVY BLOCKS FIRST (FuseList, khr_kernels_fusion.h): blocks differ a lot in
+// cost -- a block the surface crosses carries ~1500 in-band voxels, a free-space block none -- and dealing the sorted list
+// round-robin gives every wave its share of the expensive ones.  (Dynamic distribution is not an option: 20 k returning
+// atomics per launch cost more than the whole kernel on gfx950, measured.)  The descriptor {slot, block index} of a wave's
+// next item is loaded while the current item is processed, so an item starts without a dependent round trip.
 template <int VPS, int ZSPLIT, bool DEFCFG, bool EXACT, int MINW, bool DBG = false>
-__global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, const uint32_t* __restrict__ work,
-                                              const uint32_t* __restrict__ n_work, uint32_t* __restrict__ queue,
-                                              uint32_t* __restrict__ queue_next) {
+__global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
   constexpr int NV = VPS * VPS * VPS;
   constexpr int SL = VPS * VPS;        // voxels per z slice
   constexpr int PATCHES = SL / 64;     // 64-voxel x-y patches per slice
@@ -268,39 +264,32 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, const uint32_t* 
   const float fxfy = a.fx * a.fy;
   const float den = a.trunc - a.dropoff_eps;  // weight drop-off denominator (uniform)
   const float yden = rcpRefined(den);
-  const uint32_t n_blocks = *n_work;
+  const uint32_t n_heavy = list.counts[0], n_blocks = n_heavy + list.counts[1];
   uint32_t n_upd = 0, n_band = 0;
   const int dbg = DBG ? a.dbg : 0;
-  if (blockIdx.x == 0 && threadIdx.x < kFuseQueues) queue_next[threadIdx.x * kFuseQueueStride] = 0u;
-  // this wave's home queue: one of the 8 cursors of its XCD
-  uint32_t cur_q = (blockIdx.x & 7u) * 8u + ((static_cast<uint32_t>(blockIdx.x >> 3) * 4u + static_cast<uint32_t>(wave)) & 7u);
-  const uint32_t home_q = cur_q;
-  auto fetch = [&](uint32_t qi) -> uint32_t {  // next position of queue qi (lane 0 carries the value)
-    uint32_t k = 0;
-    if (lane == 0) k = atomicAdd(&queue[qi * kFuseQueueStride], 1u);
-    return k;
+  const uint32_t n_items = n_blocks * WPB, n_waves = gridDim.x * 4u;
+  // descriptor of block b of the list: heavy blocks from the front, the others from the back
+  auto descOf = [&](uint32_t item) -> uint4 {
+    const uint32_t b = item / WPB;
+    return list.desc[b < n_heavy ? b : list.cap - 1u - (b - n_heavy)];
   };
-  uint32_t k_next = fetch(cur_q);
-  while (true) {
-    // ---- take the prefetched position; when the queue is exhausted look at all 64 cursors at once (lane <-> queue)
-    //      and move to the nearest one that still has items (own XCD first) ----
-    const uint32_t kq = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(k_next)));
-    const uint32_t t = kq * 8u + (cur_q & 7u);   // item index among the items of the blocks = x (mod 8)
-    const uint32_t blk = (t / WPB) * 8u + (cur_q >> 3);
-    if (blk >= n_blocks) {
-      const uint32_t kk = __hip_atomic_load(&queue[static_cast<uint32_t>(lane) * kFuseQueueStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t tb = ((kk * 8u + (static_cast<uint32_t>(lane) & 7u)) / WPB) * 8u + (static_cast<uint32_t>(lane) >> 3);
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(tb < n_blocks);
-      if (m == 0ull) break;
-      const unsigned long long rot = home_q ? ((m >> home_q) | (m << (64u - home_q))) : m;
-      cur_q = (static_cast<uint32_t>(__builtin_ctzll(rot)) + home_q) & 63u;
-      k_next = fetch(cur_q);
-      continue;
-    }
-    const size_t slot = work[blk];
-    const int sbi = static_cast<int>(t % WPB);
+  uint32_t item = blockIdx.x * 4u + static_cast<uint32_t>(wave);
+  uint4 d_next = make_uint4(0u, 0u, 0u, 0u);
+  if (item < n_items) d_next = descOf(item);
+  const unsigned long long tw0 = (DBG && (dbg & 64)) ? __builtin_amdgcn_s_memtime() : 0ull;
+  unsigned long long t_band = 0, t_item_max = 0;
+  uint32_t c_items = 0, c_rounds = 0, c_recs = 0;
+  while (item < n_items) {
+    const unsigned long long ti0 = (DBG && (dbg & 64)) ? __builtin_amdgcn_s_memtime() : 0ull;
+    const size_t slot = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(d_next.x)));
+    int4 bi;
+    bi.x = __builtin_amdgcn_readfirstlane(static_cast<int>(d_next.y));
+    bi.y = __builtin_amdgcn_readfirstlane(static_cast<int>(d_next.z));
+    bi.z = __builtin_amdgcn_readfirstlane(static_cast<int>(d_next.w));
+    const int sbi = static_cast<int>(item % WPB);
     const int patch = sbi % PATCHES, z0 = (sbi / PATCHES) * ZR;
-    const int4 bi = a.blk_index[slot];
+    const uint32_t item_next = item + n_waves;
+    uint32_t item_band = 0;
     const float ox = static_cast<float>(bi.x) * a.bs, oy = static_cast<float>(bi.y) * a.bs, oz = static_cast<float>(bi.z) * a.bs;
     const int lin_xy = patch * 64 + lane;
     const int ix = lin_xy % VPS, iy = lin_xy / VPS;
@@ -361,9 +350,9 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, const uint32_t* 
         yz_[k] = yz;
         ok_[k] = ok;
       }
-      // the cursor for the next round is fetched here, BEHIND the chunk's loads: vmcnt retires in order, so an atomic
-      // issued in front of them would have to come back before the first range sample could be used
-      if (zc == 0) k_next = fetch(cur_q);
+      // the next item's descriptor is loaded here, BEHIND the chunk's loads (vmcnt retires in order: issued in front of them
+      // it would have to come back before the first range sample could be used)
+      if (zc == 0 && item_next < n_items) d_next = descOf(item_next);
       // ---- phase 2: measurement, decisions, read-modify-write ----
 #pragma unroll
       for (int k = 0; k < ZC; ++k) {
@@ -465,6 +454,7 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, const uint32_t* 
         touched = touched || (m_ok != 0ull);
         if (m_band) {
           n_band += static_cast<uint32_t>(__popcll(m_band));
+          item_band += static_cast<uint32_t>(__popcll(m_band));
           if (in_band) {
             const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m_band >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m_band), 0u));
@@ -482,6 +472,8 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, const uint32_t* 
       // the register allocator from favouring its values over the voxel loop's)
       if (DBG && (dbg & 1)) cnt = 0u;
       if (__builtin_expect(cnt > static_cast<uint32_t>(kFuseCap - 64 * ZC) || (zc + ZC >= ZR && cnt > 0u), 0)) {
+        const unsigned long long tb0 = (DBG && (dbg & 64)) ? __builtin_amdgcn_s_memtime() : 0ull;
+        if (DBG) { c_rounds += (cnt + 63u) / 64u; c_recs += cnt; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // explicit kernel arguments start at offset 0 of the kernarg segment; the empty asm keeps the loads of the band
@@ -495,10 +487,34 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, const uint32_t* 
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (DBG && (dbg & 64)) {
+          __builtin_amdgcn_s_waitcnt(0);  // the phase's stores included
+          t_band += __builtin_amdgcn_s_memtime() - tb0;
+        }
         cnt = 0u;
       }
     }
-    if (touched && lane == 0) atomicOr(&a.blk_flags[slot], BLK_UPDATED | BLK_MESH_UPDATED | BLK_TRACKING_UPDATED);
+    if (lane == 0) {
+      if (touched && !(DBG && (dbg & 128))) atomicOr(&a.blk_flags[slot], BLK_UPDATED | BLK_MESH_UPDATED | BLK_TRACKING_UPDATED);
+      a.blk_band[slot * kBandSlots + (sbi & (kBandSlots - 1))] = static_cast<uint16_t>(min(item_band, 65535u));  // next frame's culling pass sorts by it
+    }
+    item = item_next;
+    if (DBG && (dbg & 64)) {
+      const unsigned long long dt = __builtin_amdgcn_s_memtime() - ti0;
+      t_item_max = dt > t_item_max ? dt : t_item_max;
+      ++c_items;
+    }
+  }
+  if (DBG && (dbg & 64) && lane == 0) {
+    unsigned long long* o = a.dbg_buf + (static_cast<size_t>(blockIdx.x) * 4 + wave) * 8;
+    o[0] = tw0;
+    o[1] = __builtin_amdgcn_s_memtime();
+    o[2] = t_band;
+    o[3] = c_items;
+    o[4] = c_rounds;
+    o[5] = c_recs;
+    o[6] = t_item_max;
+    o[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((31 << 11) | 20)) << 32);
   }
   // statistics: one read-modify-write per workgroup on its own slot (folded by beginIntegrate / khr_get_stats)
   if (lane == 0) {

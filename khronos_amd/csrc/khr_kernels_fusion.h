@@ -217,7 +217,7 @@ __global__ void k_begin_integrate(DevMap m, int nvox, uint32_t* wg_stats) {
 // tick path: one begin for all cameras of the tick (the per-camera list counters)
 __global__ void k_tick_begin(DevMap m, int nvox, uint32_t* wg_stats, uint32_t* tick_counts, uint32_t extra_calls) {
   beginIntegrate(m, nvox, wg_stats);
-  if (threadIdx.x < 2 * kMaxTick) tick_counts[threadIdx.x] = 0u;
+  if (threadIdx.x < 4 * kMaxTick) tick_counts[threadIdx.x] = 0u;
   if (threadIdx.x == 0) m.stats[S_CUM_CALLS] += extra_calls;
 }
 
@@ -229,15 +229,21 @@ __global__ void k_tick_begin(DevMap m, int nvox, uint32_t* wg_stats, uint32_t* t
 // max tiles) is smaller than the block's nearest voxel range minus the truncation distance (then every
 // sdf < -trunc).  One wave per block: the 64 lanes scan the footprint's tiles and max-reduce.
 // ----------------------------------------------------------------------------------------------
+// The survivors leave as DESCRIPTORS {slot, block index} of the update kernel (k_fuse), heavy blocks first: a block whose
+// items reported >= kHeavyBand in-band voxels at its previous update (m.blk_band, written by k_fuse) goes to the front of
+// the list (positions 0 .. n_heavy - 1), the others to the back (cap - 1 downwards).  k_fuse deals the items round-robin
+// to its waves, so every wave gets its share of the expensive blocks (a block the surface crosses carries ~1500 in-band
+// voxels = colour + label + K likelihood updates, a free-space block none) instead of a random number of them.
 __device__ inline void cullBlocks(const DevMap& m, const DevParams& p, const DevFrame& f, const uint32_t* __restrict__ work,
-                                  const uint32_t* __restrict__ n_work, uint32_t* __restrict__ work_tsdf,
+                                  const uint32_t* __restrict__ n_work, FuseList out,
                                   uint32_t* __restrict__ n_tsdf, const float* __restrict__ tile_max, int tw, int th,
                                   uint32_t bid, uint32_t nblk) {
   // each workgroup tests kPerWg blocks (one wave per block, 4 rounds), gathers the survivors in LDS and
-  // appends them with ONE atomic (hot-address atomics are expensive, see k_tsdf_update)
+  // appends them with one atomic per list (hot-address atomics are expensive)
   constexpr int kPerWg = 16;
-  __shared__ uint32_t s_keep[kPerWg];
-  __shared__ uint32_t s_nkeep, s_off;
+  __shared__ uint4 s_keep[kPerWg];
+  __shared__ uint32_t s_heavy[kPerWg];
+  __shared__ uint32_t s_nkeep, s_off_h, s_off_l, s_nh;
   const uint32_t n = *n_work;
   const uint32_t lane = threadIdx.x & 63;
   for (uint32_t base = bid * kPerWg; base < n; base += nblk * kPerWg) {
@@ -291,24 +297,44 @@ __device__ inline void cullBlocks(const DevMap& m, const DevParams& p, const Dev
         }
       }
     }
-    if (lane == 0 && keep) s_keep[atomicAdd(&s_nkeep, 1u)] = slot;
+    if (keep) {  // wave-uniform
+      // in-band voxels of the block's items at its previous update
+      uint32_t band = lane < kBandSlots ? m.blk_band[static_cast<size_t>(slot) * kBandSlots + lane] : 0u;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) band += __shfl_xor(band, o);
+      if (lane == 0) {
+        const uint32_t k = atomicAdd(&s_nkeep, 1u);
+        s_keep[k] = make_uint4(slot, static_cast<uint32_t>(bi.x), static_cast<uint32_t>(bi.y), static_cast<uint32_t>(bi.z));
+        s_heavy[k] = band >= kHeavyBand ? 1u : 0u;
+      }
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    s_off = s_nkeep ? atomicAdd(n_tsdf, s_nkeep) : 0u;
-    if (s_nkeep && n_tsdf != &m.counters[C_N_TSDF]) atomicAdd(&m.counters[C_N_TSDF], s_nkeep);  // tick total (statistics)
+    uint32_t nh = 0;
+    for (uint32_t k = 0; k < s_nkeep; ++k) nh += s_heavy[k];
+    s_nh = nh;
+    s_off_h = nh ? atomicAdd(&out.counts[0], nh) : 0u;
+    s_off_l = (s_nkeep - nh) ? atomicAdd(&out.counts[1], s_nkeep - nh) : 0u;
+    if (s_nkeep) atomicAdd(n_tsdf, s_nkeep);  // total (statistics)
   }
   __syncthreads();
-  if (threadIdx.x < s_nkeep) work_tsdf[s_off + threadIdx.x] = s_keep[threadIdx.x];
+  if (threadIdx.x < s_nkeep) {
+    // position among this workgroup's heavy / light survivors
+    uint32_t before_h = 0;
+    for (uint32_t k = 0; k < threadIdx.x; ++k) before_h += s_heavy[k];
+    const bool heavy = s_heavy[threadIdx.x] != 0u;
+    const uint32_t pos = heavy ? s_off_h + before_h : out.cap - 1u - (s_off_l + (threadIdx.x - before_h));
+    out.desc[pos] = s_keep[threadIdx.x];
+  }
   __syncthreads();
   }
 }
 
 __global__ __launch_bounds__(256) void k_cull_blocks(DevMap m, DevParams p, DevFrame f,
-                                                    const uint32_t* __restrict__ work,
-                                                    uint32_t* __restrict__ work_tsdf,
+                                                    const uint32_t* __restrict__ work, FuseList out,
                                                     const float* __restrict__ tile_max, int tw, int th) {
-  cullBlocks(m, p, f, work, &m.counters[C_N_VISIBLE], work_tsdf, &m.counters[C_N_TSDF], tile_max, tw, th, blockIdx.x, gridDim.x);
+  cullBlocks(m, p, f, work, &m.counters[C_N_VISIBLE], out, &m.counters[C_N_TSDF], tile_max, tw, th, blockIdx.x, gridDim.x);
 }
 
 // the cameras of a tick in one launch (blockIdx.y = camera): per-camera visible lists -> per-camera TSDF lists.
@@ -318,12 +344,13 @@ struct TickFrames {
   const float* tile_max[kMaxTick];
 };
 __global__ __launch_bounds__(256) void k_tick_cull(DevMap m, DevParams p, TickFrames t, const uint32_t* __restrict__ work,
-                                                  uint32_t* __restrict__ work_tsdf, uint32_t list_stride,
+                                                  uint4* __restrict__ desc, uint32_t list_stride,
                                                   uint32_t* __restrict__ tick_counts, int use_tiles, int tw, int th) {
+  // tick_counts: [2 * cam] visible, [2 * cam + 1] non-culled (statistics), [2 * kMaxTick + 2 * cam + {0, 1}] heavy / light
   const int cam = blockIdx.y;
-  cullBlocks(m, p, t.f[cam], work + static_cast<size_t>(cam) * list_stride, &tick_counts[2 * cam],
-             work_tsdf + static_cast<size_t>(cam) * list_stride, &tick_counts[2 * cam + 1], use_tiles ? t.tile_max[cam] : nullptr, tw,
-             th, blockIdx.x, gridDim.x);
+  FuseList out{desc + static_cast<size_t>(cam) * list_stride, list_stride, &tick_counts[2 * kMaxTick + 2 * cam]};
+  cullBlocks(m, p, t.f[cam], work + static_cast<size_t>(cam) * list_stride, &tick_counts[2 * cam], out, &tick_counts[2 * cam + 1],
+             use_tiles ? t.tile_max[cam] : nullptr, tw, th, blockIdx.x, gridDim.x);
 }
 
 // explicit allocation of a list of block indices (VolumetricMap::allocateBlock)
@@ -360,7 +387,7 @@ __global__ __launch_bounds__(256) void k_alloc_list(DevMap m, const int* __restr
 
 // all live blocks -> work list (updateMap(allocate=false): "blocks = all allocated")
 __global__ __launch_bounds__(256) void k_list_live(DevMap m, uint32_t* __restrict__ work, uint32_t* counter,
-                                                  uint32_t require_flags) {
+                                                  uint32_t require_flags, FuseList out = FuseList{nullptr, 0u, nullptr}) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   bool live = false;
   if (s < m.counters[C_MAX_SLOT]) {
@@ -369,6 +396,13 @@ __global__ __launch_bounds__(256) void k_list_live(DevMap m, uint32_t* __restric
   }
   const uint32_t idx = waveAggInc(counter, live);
   if (live) work[idx] = s;
+  if (out.desc) {  // the same list as descriptors of the update kernel (all "light": stored from the back)
+    const uint32_t j = waveAggInc(&out.counts[1], live);
+    if (live) {
+      const int4 bi = m.blk_index[s];
+      out.desc[out.cap - 1u - j] = make_uint4(s, static_cast<uint32_t>(bi.x), static_cast<uint32_t>(bi.y), static_cast<uint32_t>(bi.z));
+    }
+  }
 }
 
 // zero-initialise freshly allocated blocks.  One workgroup per block, 16-byte stores.
@@ -391,6 +425,7 @@ __device__ inline void initBlocks(const DevMap& m, const DevParams& p, const uin
     }
     uint4* f4 = reinterpret_cast<uint4*>(m.vflags + slot * nv);
     for (int i = threadIdx.x; i < nv / 16; i += blockDim.x) f4[i] = z;
+    if (threadIdx.x < kBandSlots) m.blk_band[slot * kBandSlots + threadIdx.x] = 0;
     if (p.with_tracking) {
       uint4* o4 = reinterpret_cast<uint4*>(m.last_obs + slot * nv);
       uint4* q4 = reinterpret_cast<uint4*>(m.last_occ + slot * nv);
@@ -412,10 +447,10 @@ __global__ __launch_bounds__(256) void k_init_blocks(DevMap m, DevParams p, cons
 // block indices and the frame's range tiles, never voxels), and as separate launches each paid the ~5 us launch floor.
 // The first `n_cull` workgroups cull, the rest initialise.
 __global__ __launch_bounds__(256) void k_init_cull(DevMap m, DevParams p, DevFrame f, const uint32_t* __restrict__ new_list,
-                                                  const uint32_t* __restrict__ work, uint32_t* __restrict__ work_tsdf,
+                                                  const uint32_t* __restrict__ work, FuseList out,
                                                   const float* __restrict__ tile_max, int tw, int th, uint32_t n_cull) {
   if (blockIdx.x < n_cull)
-    cullBlocks(m, p, f, work, &m.counters[C_N_VISIBLE], work_tsdf, &m.counters[C_N_TSDF], tile_max, tw, th, blockIdx.x, n_cull);
+    cullBlocks(m, p, f, work, &m.counters[C_N_VISIBLE], out, &m.counters[C_N_TSDF], tile_max, tw, th, blockIdx.x, n_cull);
   else
     initBlocks(m, p, new_list, blockIdx.x - n_cull, gridDim.x - n_cull);
 }

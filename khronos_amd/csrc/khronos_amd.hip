@@ -108,11 +108,9 @@ struct khr_ctx {
   uint32_t* d_new = nullptr;
   uint32_t* d_ef = nullptr;
   uint32_t* d_trk_proc = nullptr;
-  uint32_t* d_work_tsdf = nullptr;
   // tick path (khr_tick_*): per-camera work lists [kMaxTick][capacity], {visible, non-culled} counts, seed counts,
   // second record-cursor set, pinned result block (kMaxTick counts + ticket)
   uint32_t* d_tick_work = nullptr;
-  uint32_t* d_tick_tsdf = nullptr;
   uint32_t* d_tick_counts = nullptr;
   uint32_t* d_tick_seeds = nullptr;
   uint32_t* h_tick = nullptr;
@@ -125,8 +123,8 @@ struct khr_ctx {
   int tick_epoch = 0, motion_ignore_epoch = 0;
   unsigned long long* d_dbg = nullptr;
   uint32_t* d_wg_stats = nullptr;
-  uint32_t* d_fuse_queue = nullptr;  // two sets of k_fuse's work cursors (a launch zeroes the set of the next one)
-  uint32_t fuse_seq = 0;
+  uint4* d_work4 = nullptr;       // update list of k_fuse (descriptors, heavy blocks first; FuseList)
+  uint4* d_tick_work4 = nullptr;  // tick path: one list per camera
   // remote halo (multi-GPU): records gathered from the other ranks + their index
   uint64_t* d_halo_recs = nullptr;
   const uint64_t* halo_view = nullptr;  // records in use: d_halo_recs, or the caller's device buffer (imported in place)
@@ -686,10 +684,10 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &c->d_new, cap));
   A(devAlloc(c, &c->d_ef, cap));
   A(devAlloc(c, &c->d_trk_proc, cap));
-  A(devAlloc(c, &c->d_work_tsdf, cap));
   A(devAlloc(c, &c->d_dbg, 4096 * 4 * 8));
   A(devAlloc(c, &c->d_wg_stats, 2 * kFuseStatSlots));
-  A(devAlloc(c, &c->d_fuse_queue, 2 * kFuseQueues * kFuseQueueStride));
+  A(devAlloc(c, &c->d_work4, cap, false));
+  A(devAlloc(c, &m.blk_band, cap * kBandSlots));
   A(devAlloc(c, &c->d_removed, cap));
   A(devAlloc(c, &c->d_mesh_count, cap + 1));
   A(devAlloc(c, &c->d_mesh_offset, cap + 1));
@@ -1018,12 +1016,13 @@ static int integrateAlloc(khr_ctx* c, FrameSlot& s, const DevFrame& f, int alloc
     hipLaunchKernelGGL(k_alloc_visible, dim3(gridFor(total)), dim3(256), 0, c->stream, m, c->p, f, fr, c->d_work, c->d_new,
                        c->d_pinned + 2, c->seed_publish_pending ? c->seed_ticket : 0u, &m.counters[C_N_VISIBLE], 0);
     c->seed_publish_pending = false;
-    hipLaunchKernelGGL(k_init_cull, dim3(1024 + 1024), dim3(256), 0, c->stream, m, c->p, f, c->d_new, c->d_work, c->d_work_tsdf,
+    hipLaunchKernelGGL(k_init_cull, dim3(1024 + 1024), dim3(256), 0, c->stream, m, c->p, f, c->d_new, c->d_work,
+                       FuseList{c->d_work4, m.capacity, &m.counters[C_N_TSDF_HEAVY]},
                        c->cfg.disable_culling ? nullptr : s.tile_max, s.tw, s.th, 1024u);
     c->host_index_valid = false;
   } else {
     hipLaunchKernelGGL(k_list_live, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_work,
-                       &m.counters[C_N_VISIBLE], 0u);
+                       &m.counters[C_N_VISIBLE], 0u, FuseList{c->d_work4, m.capacity, &m.counters[C_N_TSDF_HEAVY]});
   }
   HIP_TRY(hipGetLastError());
   return KHR_OK;
@@ -1032,8 +1031,7 @@ static int integrateAlloc(khr_ctx* c, FrameSlot& s, const DevFrame& f, int alloc
 // the fused TSDF / colour / label update kernel of one integrate call (k_fuse)
 // tick path: the camera's own work list
 struct UpdateLists {
-  const uint32_t* tsdf_work = nullptr;
-  const uint32_t* tsdf_count = nullptr;
+  FuseList list{nullptr, 0u, nullptr};
 };
 
 // resident workgroups of a k_fuse instantiation x CUs, rounded down to whole XCD rounds (the grid is persistent: static
@@ -1058,15 +1056,13 @@ static int fuseGrid(khr_ctx* c, const void* kernel, int group) {
 static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allocate_blocks, int use_mask,
                            int object_id, const UpdateLists* lists = nullptr) {
   DevMap& m = c->m;
-  const uint32_t* tsdf_work = allocate_blocks ? c->d_work_tsdf : c->d_work;
-  const uint32_t* tsdf_count = allocate_blocks ? &m.counters[C_N_TSDF] : &m.counters[C_N_VISIBLE];
-  if (lists) {
-    tsdf_work = lists->tsdf_work;
-    tsdf_count = lists->tsdf_count;
-  }
+  (void)allocate_blocks;
+  FuseList list{c->d_work4, m.capacity, &m.counters[C_N_TSDF_HEAVY]};
+  if (lists) list = lists->list;
   FuseArgs a{};
   a.blk_index = m.blk_index; a.blk_flags = m.blk_flags; a.dist = m.dist; a.weight = m.weight; a.last_obs = m.last_obs;
   a.color = m.color; a.vflags = m.vflags; a.sem_label = m.sem_label; a.lik = m.lik; a.wg_stats = c->d_wg_stats;
+  a.blk_band = m.blk_band;
   a.range = f.range; a.dyn = f.dyn; a.rgba = f.rgba; a.label = f.label; a.obj = f.obj;
   a.W = f.W; a.H = f.H; a.fx = f.fx; a.fy = f.fy; a.cx = f.cx; a.cy = f.cy; a.min_range = f.min_range; a.max_range = f.max_range;
   std::memcpy(a.R, f.R, sizeof(a.R));
@@ -1091,13 +1087,11 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
         const int grid = fuseGrid(c, reinterpret_cast<const void*>(kern), G);
         static bool said = false;
         if (!said && std::getenv("KHR_VERBOSE")) { said = true; std::fprintf(stderr, "[khr] k_fuse<%d,%d> grid %d\n", V, ZS, grid); }
-        uint32_t* const q_cur = c->d_fuse_queue + (c->fuse_seq & 1u) * (kFuseQueues * kFuseQueueStride);
-        uint32_t* const q_next = c->d_fuse_queue + ((c->fuse_seq + 1u) & 1u) * (kFuseQueues * kFuseQueueStride);
-        ++c->fuse_seq;
-        KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(256), a, tsdf_work, tsdf_count, q_cur, q_next);
+        KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(256), a, list);
       };
       // non-default switches are test configurations: they always run the bit-exact arithmetic
       a.dbg = kFuseDbg;
+      a.dbg_buf = c->d_dbg;
       if (defcfg && !exact && kFuseDbg && V == 16) {
         go(&k_fuse<V, ZS, true, false, 1, (V == 16)>);
       } else if (defcfg && !exact) {
@@ -1255,8 +1249,8 @@ static int ensureTick(khr_ctx* c) {
   if (c->d_tick_work) return KHR_OK;
   const size_t cap = c->m.capacity;
   int rc = devAlloc(c, &c->d_tick_work, cap * kMaxTick, false);
-  if (!rc) rc = devAlloc(c, &c->d_tick_tsdf, cap * kMaxTick, false);
-  if (!rc) rc = devAlloc(c, &c->d_tick_counts, 2 * kMaxTick + 32);
+  if (!rc) rc = devAlloc(c, &c->d_tick_work4, cap * kMaxTick, false);
+  if (!rc) rc = devAlloc(c, &c->d_tick_counts, 4 * kMaxTick + 32);
   if (!rc) rc = devAlloc(c, &c->d_tick_seeds, kMaxTick + 32);
   if (rc) return rc;
   if (hipHostMalloc(reinterpret_cast<void**>(&c->h_tick), 256, hipHostMallocDefault) != hipSuccess)
@@ -1400,7 +1394,7 @@ int khr_tick_integrate(khr_ctx* c, const int* slots, int n_frames, int use_mask,
       }
       hipLaunchKernelGGL(k_init_blocks, dim3(2048), dim3(256), 0, c->stream, m, c->p, c->d_new);
       const FrameSlot& s0 = c->slots[slots[base]];
-      hipLaunchKernelGGL(k_tick_cull, dim3(256, nb), dim3(256), 0, c->stream, m, c->p, t, c->d_tick_work, c->d_tick_tsdf, cap,
+      hipLaunchKernelGGL(k_tick_cull, dim3(256, nb), dim3(256), 0, c->stream, m, c->p, t, c->d_tick_work, c->d_tick_work4, cap,
                          c->d_tick_counts, c->cfg.disable_culling ? 0 : 1, s0.tw, s0.th);
       c->host_index_valid = false;
       HIP_TRY(hipGetLastError());
@@ -1408,8 +1402,7 @@ int khr_tick_integrate(khr_ctx* c, const int* slots, int n_frames, int use_mask,
     for (int k = 0; k < nb && (phases & 2); ++k) {
       FrameSlot& s = c->slots[slots[base + k]];
       UpdateLists lists;
-      lists.tsdf_work = c->d_tick_tsdf + static_cast<size_t>(k) * cap;
-      lists.tsdf_count = &c->d_tick_counts[2 * k + 1];
+      lists.list = FuseList{c->d_tick_work4 + static_cast<size_t>(k) * cap, cap, &c->d_tick_counts[2 * kMaxTick + 2 * k]};
       rc = integrateUpdate(c, s, t.f[k], 1, use_mask, object_id, &lists);
       if (rc) return rc;
     }

@@ -1,0 +1,49 @@
+"""development probe: per-wave timeline of the last k_fuse launch (KHR_FUSE_DBG=64 selects the instrumented instantiation)."""
+import os, sys
+os.environ.setdefault("KHR_FUSE_DBG", "64")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from khronos_amd import FusionContext, default_config
+from khronos_amd.synth import SyntheticStream
+
+W, H, vs = 1280, 720, 0.02
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 26
+cfg = default_config(voxel_size=vs, truncation_distance=3 * vs, with_semantics=1, with_tracking=1, num_labels=20, max_blocks=40960,
+                     max_frame_pixels=W * H)
+ctx = FusionContext(cfg)
+s = SyntheticStream(W, H, seed=1234)
+sen = ctx.make_sensor(W, H, s.fx, s.fy, s.cx, s.cy, 0.1, 5.0)
+for i in range(n):
+    fr = s.render(i)
+    slot = ctx.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+    ctx.integrate(slot)
+    ctx.update_tracking(fr["stamp"])
+ctx.sync()
+st = ctx.stats()
+buf = np.zeros(4096 * 4 * 8, np.uint64)
+ctx.lib.khr_debug_read(ctx.h, buf.ctypes.data, buf.size)
+b = buf.reshape(-1, 8)
+b = b[b[:, 1] > 0]
+t0 = b[:, 0].min()
+start = (b[:, 0] - t0).astype(np.float64)
+end = (b[:, 1] - t0).astype(np.float64)
+dur = end - start
+band = b[:, 2].astype(np.float64)
+items, rounds, recs, imax = b[:, 3], b[:, 4], b[:, 5], b[:, 6].astype(np.float64)
+F = 2100.0  # s_memtime ticks per us: the counter runs at about the shader clock on gfx950 (durations only: XCDs have different bases)
+print("tsdf blocks", st["n_tsdf_blocks"], "n_upd", st["n_updated_voxels"], "n_band", st["n_band_voxels"])
+print("waves", len(b))
+q = [0, 10, 50, 90, 99, 100]
+print("dur    pct", np.percentile(dur, q) / F, "mean", dur.mean() / F)
+print("band   pct", np.percentile(band, q) / F, "mean", band.mean() / F)
+print("items  pct", np.percentile(items, q), "rounds pct", np.percentile(rounds, q), "recs total", recs.sum())
+print("max item pct", np.percentile(imax, q) / F)
+tr = rounds > 0
+if tr.any():
+    print("band ticks per round (waves with rounds): mean", (band[tr] / rounds[tr]).mean() / F, "us; pct", np.percentile(band[tr] / rounds[tr], q) / F)
+nb = dur - band
+print("non-band per item: mean", (nb / np.maximum(items, 1)).mean() / F, "us")
+late = np.argsort(dur)[-8:]
+for i in late:
+    print("longest waves: dur %.1f band %.1f items %d rounds %d recs %d maxitem %.1f" % (dur[i] / F, band[i] / F, items[i], rounds[i], recs[i], imax[i] / F))

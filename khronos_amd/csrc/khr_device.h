@@ -49,9 +49,11 @@ enum Counter : int {
   C_N_PROC2,         // pair 1 (the pairs alternate; each pass zeroes the other pair)
   C_N_EF2,
   C_MP_DONE,         // finished workgroups of k_motion_pixels (the last one publishes the seed count)
-  C_N_TSDF_HEAVY,    // update list of the last integrate: heavy blocks (front of the descriptor list) ...
-  C_N_TSDF_LIGHT,    // ... and the others (back of the list); the two are adjacent (FuseList::counts)
-  C_COUNT = 24
+  C_N_ITEMS0,        // update list of the last integrate: wave items per cost class (FuseList::counts, 4 adjacent words)
+  C_N_ITEMS1,
+  C_N_ITEMS2,
+  C_N_ITEMS3,
+  C_COUNT = 32
 };
 enum Stat64 : int { S_UPD = 0 /* unused */, S_BAND /* unused */, S_MESH_VERTS, S_PRUNED, S_CUM_UPD, S_CUM_BAND, S_CUM_VISITED, S_CUM_CALLS, S_COUNT = 8 };
 
@@ -84,15 +86,23 @@ struct DevMap {
   MeshDesc* mesh_desc;            // per slot
 };
 
-// Update list of k_fuse (written by the culling pass, khr_kernels_fusion.h): block descriptors {slot, block index}, the
-// blocks that reported >= kHeavyBand in-band voxels at their previous update from the front, the others from the back.
-constexpr uint32_t kHeavyBand = 128;
+// Update list of k_fuse, written by the culling pass (khr_kernels_fusion.h): one descriptor {slot | item << 24, block
+// index} per WAVE ITEM of every block to update, grouped by the item's expected cost = the in-band voxels it reported at
+// its previous update (DevMap::blk_band): class 0 (> 128, three or four band rounds) from the front of `a`, class 1
+// (65 .. 128) from the back of `a`, class 2 (1 .. 64) from the front of `b`, class 3 (none) from the back of `b`.
+// k_fuse deals the items in class order round-robin to its waves, so every wave gets its share of the expensive ones.
 constexpr int kBandSlots = 32;  // per-block entries of DevMap::blk_band (one per wave item of the block)
 struct FuseList {
-  uint4* desc;       // [cap]
-  uint32_t cap;
-  uint32_t* counts;  // [0] heavy (front), [1] light (back)
+  uint4* a;
+  uint4* b;
+  uint32_t cap;      // descriptors per array
+  uint32_t* counts;  // [4] items per class
 };
+__device__ inline uint32_t fuseClass(uint32_t band) { return band > 128u ? 0u : (band > 64u ? 1u : (band > 0u ? 2u : 3u)); }
+__device__ inline uint4* fuseDescPtr(const FuseList& l, uint32_t cls, uint32_t pos) {
+  uint4* const arr = cls < 2u ? l.a : l.b;
+  return arr + ((cls & 1u) ? l.cap - 1u - pos : pos);
+}
 
 struct DevParams {
   float vs, vs_inv, bs, bs_inv, trunc;
@@ -293,8 +303,10 @@ __device__ inline void beginIntegrate(DevMap m, int nvox, uint32_t* wg_stats) {
     m.counters[C_N_VISIBLE] = 0u;
     m.counters[C_N_NEW] = 0u;
     m.counters[C_N_TSDF] = 0u;
-    m.counters[C_N_TSDF_HEAVY] = 0u;
-    m.counters[C_N_TSDF_LIGHT] = 0u;
+    m.counters[C_N_ITEMS0] = 0u;
+    m.counters[C_N_ITEMS1] = 0u;
+    m.counters[C_N_ITEMS2] = 0u;
+    m.counters[C_N_ITEMS3] = 0u;
   }
 }
 

@@ -119,13 +119,16 @@ constexpr int kFuseCap = 256;        // in-band records a wave collects before i
 // parameters) are scalar loads issued here, instead of ~40 SGPRs kept alive through the voxel loop.
 typedef const FuseArgs __attribute__((address_space(4))) * FuseArgsK;
 constexpr int kLikVec = 5;  // float4 likelihood vectors a lane holds at once (K = 20 in one round trip)
-template <int VPS>
-__device__ inline void fuseBandRecord(FuseArgsK ka, size_t slot, uint32_t lin_mode, float w, float w_new, float u, float v) {
+template <int VPS, bool DBG = false>
+__device__ inline void fuseBandRecord(FuseArgsK ka, size_t slot, uint32_t lin_mode, float w, float w_new, float u, float v,
+                                      unsigned long long* tacc = nullptr) {
+  (void)tacc;
   constexpr int NV = VPS * VPS * VPS;
   const FuseArgs __attribute__((address_space(4)))& a = *ka;
   const uint32_t lin = lin_mode & 0xffffu;
   const bool use_nearest = (lin_mode & 0x10000u) != 0;
   const int K = a.K;
+  const bool has_color = a.has_color != 0, do_sem = a.do_sem != 0, vec = (K & 3) == 0;
   // block bases are wave-uniform (SGPRs), the voxel adds a 32-bit byte offset
   char* const color_b = reinterpret_cast<char*>(a.color + slot * NV);
   char* const vfl_b = reinterpret_cast<char*>(a.vflags + slot * NV);
@@ -137,12 +140,29 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, size_t slot, uint32_t lin_mo
   interpPixels(u, v, a.W, a.H, px4, &du, &dv);
   const int best = interpWeights(du, dv, use_nearest, w4);
   const uint32_t best_o = static_cast<uint32_t>(px4[best]) * 4u;
-  if (a.has_color) {
+  // ---- every load of the record is issued here, before the first store: a memory round trip costs 1.5 - 2 us under
+  //      this kernel's load and vmcnt retires in order, so each load placed behind a store waits for that store too ----
+  uint32_t c4[4] = {0u, 0u, 0u, 0u}, co = 0u;
+  if (has_color) {
     const char* const rgba_b = reinterpret_cast<const char*>(a.rgba);
-    uint32_t c4[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) c4[k] = *reinterpret_cast<const uint32_t*>(rgba_b + static_cast<uint32_t>(px4[k]) * 4u);
-    const uint32_t co = *reinterpret_cast<const uint32_t*>(color_b + lin * 4u);
+    co = *reinterpret_cast<const uint32_t*>(color_b + lin * 4u);
+  }
+  int label = -1;
+  uint8_t fl = 0;
+  float4 l4[kLikVec];
+  if (do_sem) {
+    label = (a.sem_mode == 1) ? ((*reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.obj) + best_o) == a.object_id) ? 1 : 0)
+                              : *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.label) + best_o);
+    fl = *reinterpret_cast<const uint8_t*>(vfl_b + lin);
+    if (vec) {  // a voxel without VOX_SEM_VALID holds no likelihoods yet: what is loaded is replaced by zeros below
+#pragma unroll
+      for (int j = 0; j < kLikVec; ++j)
+        l4[j] = (j < K / 4) ? *reinterpret_cast<const float4*>(lik_b + lik_o + static_cast<uint32_t>(j) * 16u) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  if (has_color) {
     float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -162,23 +182,19 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, size_t slot, uint32_t lin_mo
     }
     *reinterpret_cast<uint32_t*>(color_b + lin * 4u) = out;
   }
-  if (!a.do_sem) return;
-  const int label = (a.sem_mode == 1) ? ((*reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.obj) + best_o) == a.object_id) ? 1 : 0)
-                                      : *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.label) + best_o);
-  const uint8_t fl = *reinterpret_cast<const uint8_t*>(vfl_b + lin);
-  if (label < 0 || label >= K) return;
-  // a voxel without VOX_SEM_VALID holds no likelihoods yet: what is loaded is replaced by zeros
+  if (!do_sem || label < 0 || label >= K) return;
   const bool empty = !(fl & VOX_SEM_VALID);
   const float add_hit = (a.sem_mode == 1) ? 1.f : a.log_match, add_miss = (a.sem_mode == 1) ? 0.f : a.log_nomatch;
   int bestk = 0;
   float bestv = 0.f;
-  if ((K & 3) == 0) {
-    // 16-byte loads / stores, kLikVec vectors per round: every load of a round is issued before its first store
+  if (vec) {
+    // 16-byte loads / stores, kLikVec vectors per round (the first round's loads are already under way)
     for (int j0 = 0; j0 < K / 4; j0 += kLikVec) {
-      float4 l4[kLikVec];
+      if (j0 > 0) {
 #pragma unroll
-      for (int j = 0; j < kLikVec; ++j)
-        if (j0 + j < K / 4) l4[j] = *reinterpret_cast<const float4*>(lik_b + lik_o + static_cast<uint32_t>(j0 + j) * 16u);
+        for (int j = 0; j < kLikVec; ++j)
+          if (j0 + j < K / 4) l4[j] = *reinterpret_cast<const float4*>(lik_b + lik_o + static_cast<uint32_t>(j0 + j) * 16u);
+      }
 #pragma unroll
       for (int j = 0; j < kLikVec; ++j) {
         if (j0 + j >= K / 4) continue;
@@ -187,11 +203,7 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, size_t slot, uint32_t lin_mo
         for (int q = 0; q < 4; ++q) {
           const int k = 4 * (j0 + j) + q;
           if (empty) l[q] = 0.f;
-          if (a.sem_mode == 1) {
-            if (k == label) l[q] += 1.f;
-          } else {
-            l[q] += (k == label) ? add_hit : add_miss;
-          }
+          l[q] += (k == label) ? add_hit : add_miss;
           if (k == 0 || l[q] > bestv) {
             bestv = l[q];
             bestk = k;
@@ -210,11 +222,7 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, size_t slot, uint32_t lin_mo
       for (int j = 0; j < 8; ++j) {
         const int k = k0 + j;
         if (k < K) {
-          if (a.sem_mode == 1) {
-            if (k == label) l[j] += 1.f;
-          } else {
-            l[j] += (k == label) ? add_hit : add_miss;
-          }
+          l[j] += (k == label) ? add_hit : add_miss;
           lik[k] = l[j];
           if (k == 0 || l[j] > bestv) {
             bestv = l[j];
@@ -236,9 +244,9 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, size_t slot, uint32_t lin_mo
 // MINW = resident waves per SIMD the register allocation is held to (__launch_bounds__; 1 = unconstrained).
 //
 // Work distribution: the grid is persistent (resident workgroups only) and wave g takes the items g, g + n_waves, ... of
-// the descriptor list the culling pass wrote HEAVY BLOCKS FIRST (FuseList, khr_kernels_fusion.h): blocks differ a lot in
-// cost -- a block the surface crosses carries ~1500 in-band voxels, a free-space block none -- and dealing the sorted list
-// round-robin gives every wave its share of the expensive ones.  (Dynamic distribution is not an option: 20 k returning
+// the descriptor list the culling pass wrote MOST EXPENSIVE ITEMS FIRST (FuseList, khr_device.h): items differ a lot in
+// cost -- a block the surface crosses carries ~1500 in-band voxels (colour + label + K likelihood updates each), a
+// free-space block none -- and dealing the sorted list round-robin gives every wave its share of the expensive ones.  (Dynamic distribution is not an option: 20 k returning
 // atomics per launch cost more than the whole kernel on gfx950, measured.)  The descriptor {slot, block index} of a wave's
 // next item is loaded while the current item is processed, so an item starts without a dependent round trip.
 template <int VPS, int ZSPLIT, bool DEFCFG, bool EXACT, int MINW, bool DBG = false>
@@ -264,29 +272,33 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
   const float fxfy = a.fx * a.fy;
   const float den = a.trunc - a.dropoff_eps;  // weight drop-off denominator (uniform)
   const float yden = rcpRefined(den);
-  const uint32_t n_heavy = list.counts[0], n_blocks = n_heavy + list.counts[1];
+  const uint32_t nc0 = list.counts[0], nc1 = nc0 + list.counts[1], nc2 = nc1 + list.counts[2], n_items = nc2 + list.counts[3];
   uint32_t n_upd = 0, n_band = 0;
   const int dbg = DBG ? a.dbg : 0;
-  const uint32_t n_items = n_blocks * WPB, n_waves = gridDim.x * 4u;
-  // descriptor of block b of the list: heavy blocks from the front, the others from the back
-  auto descOf = [&](uint32_t item) -> uint4 {
-    const uint32_t b = item / WPB;
-    return list.desc[b < n_heavy ? b : list.cap - 1u - (b - n_heavy)];
+  const uint32_t n_waves = gridDim.x * 4u;
+  // descriptor of item i in deal order: class 0, 1, 2, 3 (FuseList)
+  auto descOf = [&](uint32_t i) -> uint4 {
+    if (i < nc0) return list.a[i];
+    if (i < nc1) return list.a[list.cap - 1u - (i - nc0)];
+    if (i < nc2) return list.b[i - nc1];
+    return list.b[list.cap - 1u - (i - nc2)];
   };
   uint32_t item = blockIdx.x * 4u + static_cast<uint32_t>(wave);
   uint4 d_next = make_uint4(0u, 0u, 0u, 0u);
   if (item < n_items) d_next = descOf(item);
   const unsigned long long tw0 = (DBG && (dbg & 64)) ? __builtin_amdgcn_s_memtime() : 0ull;
   unsigned long long t_band = 0, t_item_max = 0;
+  unsigned long long tacc[4] = {0, 0, 0, 0};  // DBG: band round split {colour part, label / flag loads, likelihood loads, whole label part}
   uint32_t c_items = 0, c_rounds = 0, c_recs = 0;
   while (item < n_items) {
     const unsigned long long ti0 = (DBG && (dbg & 64)) ? __builtin_amdgcn_s_memtime() : 0ull;
-    const size_t slot = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(d_next.x)));
+    const uint32_t dx = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(d_next.x)));
+    const size_t slot = dx & 0xffffffu;
     int4 bi;
     bi.x = __builtin_amdgcn_readfirstlane(static_cast<int>(d_next.y));
     bi.y = __builtin_amdgcn_readfirstlane(static_cast<int>(d_next.z));
     bi.z = __builtin_amdgcn_readfirstlane(static_cast<int>(d_next.w));
-    const int sbi = static_cast<int>(item % WPB);
+    const int sbi = static_cast<int>(dx >> 24);
     const int patch = sbi % PATCHES, z0 = (sbi / PATCHES) * ZR;
     const uint32_t item_next = item + n_waves;
     uint32_t item_band = 0;
@@ -482,8 +494,8 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
         asm volatile("" : "+s"(ka));
         for (uint32_t r = static_cast<uint32_t>(lane); r < cnt; r += 64u) {
           const uint32_t* const rec = &s_rec[wave][0][r];
-          fuseBandRecord<VPS>(ka, slot, rec[0], __uint_as_float(rec[kFuseCap]), __uint_as_float(rec[2 * kFuseCap]),
-                              __uint_as_float(rec[3 * kFuseCap]), __uint_as_float(rec[4 * kFuseCap]));
+          fuseBandRecord<VPS, DBG>(ka, slot, rec[0], __uint_as_float(rec[kFuseCap]), __uint_as_float(rec[2 * kFuseCap]),
+                                   __uint_as_float(rec[3 * kFuseCap]), __uint_as_float(rec[4 * kFuseCap]), tacc);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -514,7 +526,10 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
     o[4] = c_rounds;
     o[5] = c_recs;
     o[6] = t_item_max;
-    o[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((31 << 11) | 20)) << 32);
+    o[7] = (tacc[0] & 0xffffull) | ((tacc[1] >> 4 & 0xffffull) << 16) | ((tacc[2] >> 4 & 0xffffull) << 32) | ((tacc[3] >> 4 & 0xffffull) << 48);
+    o[7] = 0;
+    unsigned long long* o2 = a.dbg_buf + 4096 * 4 * 8 + (static_cast<size_t>(blockIdx.x) * 4 + wave) * 4;
+    o2[0] = tacc[0]; o2[1] = tacc[1]; o2[2] = tacc[2]; o2[3] = tacc[3];
   }
   // statistics: one read-modify-write per workgroup on its own slot (folded by beginIntegrate / khr_get_stats)
   if (lane == 0) {

@@ -217,7 +217,7 @@ __global__ void k_begin_integrate(DevMap m, int nvox, uint32_t* wg_stats) {
 // tick path: one begin for all cameras of the tick (the per-camera list counters)
 __global__ void k_tick_begin(DevMap m, int nvox, uint32_t* wg_stats, uint32_t* tick_counts, uint32_t extra_calls) {
   beginIntegrate(m, nvox, wg_stats);
-  if (threadIdx.x < 4 * kMaxTick) tick_counts[threadIdx.x] = 0u;
+  if (threadIdx.x < 6 * kMaxTick) tick_counts[threadIdx.x] = 0u;
   if (threadIdx.x == 0) m.stats[S_CUM_CALLS] += extra_calls;
 }
 
@@ -229,25 +229,22 @@ __global__ void k_tick_begin(DevMap m, int nvox, uint32_t* wg_stats, uint32_t* t
 // max tiles) is smaller than the block's nearest voxel range minus the truncation distance (then every
 // sdf < -trunc).  One wave per block: the 64 lanes scan the footprint's tiles and max-reduce.
 // ----------------------------------------------------------------------------------------------
-// The survivors leave as DESCRIPTORS {slot, block index} of the update kernel (k_fuse), heavy blocks first: a block whose
-// items reported >= kHeavyBand in-band voxels at its previous update (m.blk_band, written by k_fuse) goes to the front of
-// the list (positions 0 .. n_heavy - 1), the others to the back (cap - 1 downwards).  k_fuse deals the items round-robin
-// to its waves, so every wave gets its share of the expensive blocks (a block the surface crosses carries ~1500 in-band
-// voxels = colour + label + K likelihood updates, a free-space block none) instead of a random number of them.
+// The survivors leave as the wave-item descriptors of the update kernel, grouped by expected cost (FuseList, khr_device.h).
 __device__ inline void cullBlocks(const DevMap& m, const DevParams& p, const DevFrame& f, const uint32_t* __restrict__ work,
-                                  const uint32_t* __restrict__ n_work, FuseList out,
+                                  const uint32_t* __restrict__ n_work, FuseList out, uint32_t wpb,
                                   uint32_t* __restrict__ n_tsdf, const float* __restrict__ tile_max, int tw, int th,
                                   uint32_t bid, uint32_t nblk) {
-  // each workgroup tests kPerWg blocks (one wave per block, 4 rounds), gathers the survivors in LDS and
-  // appends them with one atomic per list (hot-address atomics are expensive)
+  // each workgroup tests kPerWg blocks (one wave per block, 4 rounds), gathers the survivors' items in LDS and
+  // appends them with one atomic per class (hot-address atomics are expensive)
   constexpr int kPerWg = 16;
-  __shared__ uint4 s_keep[kPerWg];
-  __shared__ uint32_t s_heavy[kPerWg];
-  __shared__ uint32_t s_nkeep, s_off_h, s_off_l, s_nh;
+  __shared__ uint4 s_blk[kPerWg];                     // {slot, block index} of the survivors
+  __shared__ uint16_t s_item[4][kPerWg * kBandSlots];  // per class: survivor << 8 | item
+  __shared__ uint32_t s_nkeep, s_ccnt[4], s_off[4];
   const uint32_t n = *n_work;
   const uint32_t lane = threadIdx.x & 63;
   for (uint32_t base = bid * kPerWg; base < n; base += nblk * kPerWg) {
   if (threadIdx.x == 0) s_nkeep = 0;
+  if (threadIdx.x < 4) s_ccnt[threadIdx.x] = 0;
   __syncthreads();
   for (uint32_t wi = base + (threadIdx.x >> 6); wi < min(n, base + kPerWg); wi += 4) {
     const uint32_t slot = work[wi];
@@ -298,43 +295,39 @@ __device__ inline void cullBlocks(const DevMap& m, const DevParams& p, const Dev
       }
     }
     if (keep) {  // wave-uniform
-      // in-band voxels of the block's items at its previous update
-      uint32_t band = lane < kBandSlots ? m.blk_band[static_cast<size_t>(slot) * kBandSlots + lane] : 0u;
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) band += __shfl_xor(band, o);
+      uint32_t kslot = 0;
       if (lane == 0) {
-        const uint32_t k = atomicAdd(&s_nkeep, 1u);
-        s_keep[k] = make_uint4(slot, static_cast<uint32_t>(bi.x), static_cast<uint32_t>(bi.y), static_cast<uint32_t>(bi.z));
-        s_heavy[k] = band >= kHeavyBand ? 1u : 0u;
+        kslot = atomicAdd(&s_nkeep, 1u);
+        s_blk[kslot] = make_uint4(slot, static_cast<uint32_t>(bi.x), static_cast<uint32_t>(bi.y), static_cast<uint32_t>(bi.z));
+      }
+      kslot = __shfl(kslot, 0);
+      if (lane < wpb) {  // lane <-> wave item of the block: class by the in-band voxels of its previous update
+        const uint32_t cls = fuseClass(m.blk_band[static_cast<size_t>(slot) * kBandSlots + lane]);
+        s_item[cls][atomicAdd(&s_ccnt[cls], 1u)] = static_cast<uint16_t>((kslot << 8) | lane);
       }
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t nh = 0;
-    for (uint32_t k = 0; k < s_nkeep; ++k) nh += s_heavy[k];
-    s_nh = nh;
-    s_off_h = nh ? atomicAdd(&out.counts[0], nh) : 0u;
-    s_off_l = (s_nkeep - nh) ? atomicAdd(&out.counts[1], s_nkeep - nh) : 0u;
-    if (s_nkeep) atomicAdd(n_tsdf, s_nkeep);  // total (statistics)
-  }
+  if (threadIdx.x < 4) s_off[threadIdx.x] = s_ccnt[threadIdx.x] ? atomicAdd(&out.counts[threadIdx.x], s_ccnt[threadIdx.x]) : 0u;
+  if (threadIdx.x == 0 && s_nkeep) atomicAdd(n_tsdf, s_nkeep);  // blocks (statistics)
   __syncthreads();
-  if (threadIdx.x < s_nkeep) {
-    // position among this workgroup's heavy / light survivors
-    uint32_t before_h = 0;
-    for (uint32_t k = 0; k < threadIdx.x; ++k) before_h += s_heavy[k];
-    const bool heavy = s_heavy[threadIdx.x] != 0u;
-    const uint32_t pos = heavy ? s_off_h + before_h : out.cap - 1u - (s_off_l + (threadIdx.x - before_h));
-    out.desc[pos] = s_keep[threadIdx.x];
+#pragma unroll
+  for (uint32_t cls = 0; cls < 4; ++cls) {
+    for (uint32_t i = threadIdx.x; i < s_ccnt[cls]; i += blockDim.x) {
+      const uint32_t it = s_item[cls][i];
+      uint4 d = s_blk[it >> 8];
+      d.x |= (it & 0xffu) << 24;
+      *fuseDescPtr(out, cls, s_off[cls] + i) = d;
+    }
   }
   __syncthreads();
   }
 }
 
 __global__ __launch_bounds__(256) void k_cull_blocks(DevMap m, DevParams p, DevFrame f,
-                                                    const uint32_t* __restrict__ work, FuseList out,
+                                                    const uint32_t* __restrict__ work, FuseList out, uint32_t wpb,
                                                     const float* __restrict__ tile_max, int tw, int th) {
-  cullBlocks(m, p, f, work, &m.counters[C_N_VISIBLE], out, &m.counters[C_N_TSDF], tile_max, tw, th, blockIdx.x, gridDim.x);
+  cullBlocks(m, p, f, work, &m.counters[C_N_VISIBLE], out, wpb, &m.counters[C_N_TSDF], tile_max, tw, th, blockIdx.x, gridDim.x);
 }
 
 // the cameras of a tick in one launch (blockIdx.y = camera): per-camera visible lists -> per-camera TSDF lists.
@@ -344,12 +337,14 @@ struct TickFrames {
   const float* tile_max[kMaxTick];
 };
 __global__ __launch_bounds__(256) void k_tick_cull(DevMap m, DevParams p, TickFrames t, const uint32_t* __restrict__ work,
-                                                  uint4* __restrict__ desc, uint32_t list_stride,
+                                                  uint32_t list_stride, uint4* __restrict__ desc, uint32_t desc_stride, uint32_t wpb,
                                                   uint32_t* __restrict__ tick_counts, int use_tiles, int tw, int th) {
-  // tick_counts: [2 * cam] visible, [2 * cam + 1] non-culled (statistics), [2 * kMaxTick + 2 * cam + {0, 1}] heavy / light
+  // tick_counts: [2 * cam] visible, [2 * cam + 1] non-culled (statistics), [2 * kMaxTick + 4 * cam + cls] items per class;
+  // descriptors of camera cam: arrays a, b = desc + (2 cam, 2 cam + 1) * desc_stride
   const int cam = blockIdx.y;
-  FuseList out{desc + static_cast<size_t>(cam) * list_stride, list_stride, &tick_counts[2 * kMaxTick + 2 * cam]};
-  cullBlocks(m, p, t.f[cam], work + static_cast<size_t>(cam) * list_stride, &tick_counts[2 * cam], out, &tick_counts[2 * cam + 1],
+  FuseList out{desc + static_cast<size_t>(2 * cam) * desc_stride, desc + static_cast<size_t>(2 * cam + 1) * desc_stride, desc_stride,
+               &tick_counts[2 * kMaxTick + 4 * cam]};
+  cullBlocks(m, p, t.f[cam], work + static_cast<size_t>(cam) * list_stride, &tick_counts[2 * cam], out, wpb, &tick_counts[2 * cam + 1],
              use_tiles ? t.tile_max[cam] : nullptr, tw, th, blockIdx.x, gridDim.x);
 }
 
@@ -387,7 +382,8 @@ __global__ __launch_bounds__(256) void k_alloc_list(DevMap m, const int* __restr
 
 // all live blocks -> work list (updateMap(allocate=false): "blocks = all allocated")
 __global__ __launch_bounds__(256) void k_list_live(DevMap m, uint32_t* __restrict__ work, uint32_t* counter,
-                                                  uint32_t require_flags, FuseList out = FuseList{nullptr, 0u, nullptr}) {
+                                                  uint32_t require_flags, FuseList out = FuseList{nullptr, nullptr, 0u, nullptr},
+                                                  uint32_t wpb = 0u) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   bool live = false;
   if (s < m.counters[C_MAX_SLOT]) {
@@ -396,11 +392,20 @@ __global__ __launch_bounds__(256) void k_list_live(DevMap m, uint32_t* __restric
   }
   const uint32_t idx = waveAggInc(counter, live);
   if (live) work[idx] = s;
-  if (out.desc) {  // the same list as descriptors of the update kernel (all "light": stored from the back)
-    const uint32_t j = waveAggInc(&out.counts[1], live);
-    if (live) {
-      const int4 bi = m.blk_index[s];
-      out.desc[out.cap - 1u - j] = make_uint4(s, static_cast<uint32_t>(bi.x), static_cast<uint32_t>(bi.y), static_cast<uint32_t>(bi.z));
+  if (out.a) {  // the same blocks as wave-item descriptors of the update kernel (no cost classes: all class 3)
+    const unsigned long long mask = __ballot(live);
+    if (mask) {
+      const uint32_t lane = laneId();
+      const int leader = __ffsll(static_cast<long long>(mask)) - 1;
+      uint32_t base = 0;
+      if (lane == static_cast<uint32_t>(leader)) base = atomicAdd(&out.counts[3], static_cast<uint32_t>(__popcll(mask)) * wpb);
+      base = __shfl(base, leader) + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull))) * wpb;
+      if (live) {
+        const int4 bi = m.blk_index[s];
+        for (uint32_t it = 0; it < wpb; ++it)
+          *fuseDescPtr(out, 3u, base + it) =
+              make_uint4(s | (it << 24), static_cast<uint32_t>(bi.x), static_cast<uint32_t>(bi.y), static_cast<uint32_t>(bi.z));
+      }
     }
   }
 }
@@ -447,10 +452,10 @@ __global__ __launch_bounds__(256) void k_init_blocks(DevMap m, DevParams p, cons
 // block indices and the frame's range tiles, never voxels), and as separate launches each paid the ~5 us launch floor.
 // The first `n_cull` workgroups cull, the rest initialise.
 __global__ __launch_bounds__(256) void k_init_cull(DevMap m, DevParams p, DevFrame f, const uint32_t* __restrict__ new_list,
-                                                  const uint32_t* __restrict__ work, FuseList out,
+                                                  const uint32_t* __restrict__ work, FuseList out, uint32_t wpb,
                                                   const float* __restrict__ tile_max, int tw, int th, uint32_t n_cull) {
   if (blockIdx.x < n_cull)
-    cullBlocks(m, p, f, work, &m.counters[C_N_VISIBLE], out, &m.counters[C_N_TSDF], tile_max, tw, th, blockIdx.x, n_cull);
+    cullBlocks(m, p, f, work, &m.counters[C_N_VISIBLE], out, wpb, &m.counters[C_N_TSDF], tile_max, tw, th, blockIdx.x, n_cull);
   else
     initBlocks(m, p, new_list, blockIdx.x - n_cull, gridDim.x - n_cull);
 }

@@ -123,8 +123,11 @@ struct khr_ctx {
   int tick_epoch = 0, motion_ignore_epoch = 0;
   unsigned long long* d_dbg = nullptr;
   uint32_t* d_wg_stats = nullptr;
-  uint4* d_work4 = nullptr;       // update list of k_fuse (descriptors, heavy blocks first; FuseList)
-  uint4* d_tick_work4 = nullptr;  // tick path: one list per camera
+  uint4* d_work4 = nullptr;       // update list of k_fuse: two descriptor arrays of item_cap entries (FuseList)
+  uint4* d_tick_work4 = nullptr;  // tick path: two arrays per camera
+  uint32_t item_cap = 0;          // max_blocks x wave items per block
+  uint32_t wpb = 0;               // wave items per block of this context's k_fuse instantiation
+  int fuse_zsplit = 2;            // z ranges per x-y patch of that instantiation
   // remote halo (multi-GPU): records gathered from the other ranks + their index
   uint64_t* d_halo_recs = nullptr;
   const uint64_t* halo_view = nullptr;  // records in use: d_halo_recs, or the caller's device buffer (imported in place)
@@ -684,9 +687,18 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &c->d_new, cap));
   A(devAlloc(c, &c->d_ef, cap));
   A(devAlloc(c, &c->d_trk_proc, cap));
-  A(devAlloc(c, &c->d_dbg, 4096 * 4 * 8));
+  A(devAlloc(c, &c->d_dbg, 4096 * 4 * 12));
   A(devAlloc(c, &c->d_wg_stats, 2 * kFuseStatSlots));
-  A(devAlloc(c, &c->d_work4, cap, false));
+  {
+    int zs = kFuseZsplit;
+    if (zs == 0) zs = cfg->world_size >= 4 ? 8 : (cfg->world_size >= 2 ? 4 : 2);
+    if (zs != 1 && zs != 2 && zs != 4 && zs != 8) zs = 2;
+    if (cfg->voxels_per_side == 8) zs = 4;
+    c->fuse_zsplit = zs;
+    c->wpb = static_cast<uint32_t>((cfg->voxels_per_side * cfg->voxels_per_side / 64) * zs);
+    c->item_cap = static_cast<uint32_t>(cap) * c->wpb;
+  }
+  A(devAlloc(c, &c->d_work4, 2 * static_cast<size_t>(c->item_cap), false));
   A(devAlloc(c, &m.blk_band, cap * kBandSlots));
   A(devAlloc(c, &c->d_removed, cap));
   A(devAlloc(c, &c->d_mesh_count, cap + 1));
@@ -1017,12 +1029,13 @@ static int integrateAlloc(khr_ctx* c, FrameSlot& s, const DevFrame& f, int alloc
                        c->d_pinned + 2, c->seed_publish_pending ? c->seed_ticket : 0u, &m.counters[C_N_VISIBLE], 0);
     c->seed_publish_pending = false;
     hipLaunchKernelGGL(k_init_cull, dim3(1024 + 1024), dim3(256), 0, c->stream, m, c->p, f, c->d_new, c->d_work,
-                       FuseList{c->d_work4, m.capacity, &m.counters[C_N_TSDF_HEAVY]},
+                       FuseList{c->d_work4, c->d_work4 + c->item_cap, c->item_cap, &m.counters[C_N_ITEMS0]}, c->wpb,
                        c->cfg.disable_culling ? nullptr : s.tile_max, s.tw, s.th, 1024u);
     c->host_index_valid = false;
   } else {
     hipLaunchKernelGGL(k_list_live, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_work,
-                       &m.counters[C_N_VISIBLE], 0u, FuseList{c->d_work4, m.capacity, &m.counters[C_N_TSDF_HEAVY]});
+                       &m.counters[C_N_VISIBLE], 0u, FuseList{c->d_work4, c->d_work4 + c->item_cap, c->item_cap, &m.counters[C_N_ITEMS0]},
+                       c->wpb);
   }
   HIP_TRY(hipGetLastError());
   return KHR_OK;
@@ -1031,7 +1044,7 @@ static int integrateAlloc(khr_ctx* c, FrameSlot& s, const DevFrame& f, int alloc
 // the fused TSDF / colour / label update kernel of one integrate call (k_fuse)
 // tick path: the camera's own work list
 struct UpdateLists {
-  FuseList list{nullptr, 0u, nullptr};
+  FuseList list{nullptr, nullptr, 0u, nullptr};
 };
 
 // resident workgroups of a k_fuse instantiation x CUs, rounded down to whole XCD rounds (the grid is persistent: static
@@ -1057,7 +1070,7 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
                            int object_id, const UpdateLists* lists = nullptr) {
   DevMap& m = c->m;
   (void)allocate_blocks;
-  FuseList list{c->d_work4, m.capacity, &m.counters[C_N_TSDF_HEAVY]};
+  FuseList list{c->d_work4, c->d_work4 + c->item_cap, c->item_cap, &m.counters[C_N_ITEMS0]};
   if (lists) list = lists->list;
   FuseArgs a{};
   a.blk_index = m.blk_index; a.blk_flags = m.blk_flags; a.dist = m.dist; a.weight = m.weight; a.last_obs = m.last_obs;
@@ -1106,8 +1119,7 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
     };
     // a shard of a sharded map sees 1 / world of every frame's blocks: shorter z ranges per wave keep the number of
     // wave items (and with it the number of busy SIMDs) up
-    int zs = kFuseZsplit;
-    if (zs == 0) zs = c->cfg.world_size >= 4 ? 8 : (c->cfg.world_size >= 2 ? 4 : 2);
+    const int zs = c->fuse_zsplit;
     if (V == 8) {
       launch(std::integral_constant<int, 4>());
     } else {
@@ -1249,8 +1261,8 @@ static int ensureTick(khr_ctx* c) {
   if (c->d_tick_work) return KHR_OK;
   const size_t cap = c->m.capacity;
   int rc = devAlloc(c, &c->d_tick_work, cap * kMaxTick, false);
-  if (!rc) rc = devAlloc(c, &c->d_tick_work4, cap * kMaxTick, false);
-  if (!rc) rc = devAlloc(c, &c->d_tick_counts, 4 * kMaxTick + 32);
+  if (!rc) rc = devAlloc(c, &c->d_tick_work4, 2 * static_cast<size_t>(c->item_cap) * kMaxTick, false);
+  if (!rc) rc = devAlloc(c, &c->d_tick_counts, 6 * kMaxTick + 32);
   if (!rc) rc = devAlloc(c, &c->d_tick_seeds, kMaxTick + 32);
   if (rc) return rc;
   if (hipHostMalloc(reinterpret_cast<void**>(&c->h_tick), 256, hipHostMallocDefault) != hipSuccess)
@@ -1394,7 +1406,7 @@ int khr_tick_integrate(khr_ctx* c, const int* slots, int n_frames, int use_mask,
       }
       hipLaunchKernelGGL(k_init_blocks, dim3(2048), dim3(256), 0, c->stream, m, c->p, c->d_new);
       const FrameSlot& s0 = c->slots[slots[base]];
-      hipLaunchKernelGGL(k_tick_cull, dim3(256, nb), dim3(256), 0, c->stream, m, c->p, t, c->d_tick_work, c->d_tick_work4, cap,
+      hipLaunchKernelGGL(k_tick_cull, dim3(256, nb), dim3(256), 0, c->stream, m, c->p, t, c->d_tick_work, cap, c->d_tick_work4, c->item_cap, c->wpb,
                          c->d_tick_counts, c->cfg.disable_culling ? 0 : 1, s0.tw, s0.th);
       c->host_index_valid = false;
       HIP_TRY(hipGetLastError());
@@ -1402,7 +1414,8 @@ int khr_tick_integrate(khr_ctx* c, const int* slots, int n_frames, int use_mask,
     for (int k = 0; k < nb && (phases & 2); ++k) {
       FrameSlot& s = c->slots[slots[base + k]];
       UpdateLists lists;
-      lists.list = FuseList{c->d_tick_work4 + static_cast<size_t>(k) * cap, cap, &c->d_tick_counts[2 * kMaxTick + 2 * k]};
+      lists.list = FuseList{c->d_tick_work4 + static_cast<size_t>(2 * k) * c->item_cap, c->d_tick_work4 + static_cast<size_t>(2 * k + 1) * c->item_cap,
+                            c->item_cap, &c->d_tick_counts[2 * kMaxTick + 4 * k]};
       rc = integrateUpdate(c, s, t.f[k], 1, use_mask, object_id, &lists);
       if (rc) return rc;
     }
@@ -2888,7 +2901,7 @@ int64_t khr_download_mesh(khr_ctx* c, float* points, uint8_t* colors_rgba, uint3
 int khr_debug_read(khr_ctx* c, unsigned long long* out, int64_t n) {
   if (!c || !out) return fail(KHR_EINVAL, "null argument");
   HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(hipMemcpy(out, c->d_dbg, sizeof(unsigned long long) * std::min<int64_t>(n, 4096 * 4 * 8), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, c->d_dbg, sizeof(unsigned long long) * std::min<int64_t>(n, 4096 * 4 * 12), hipMemcpyDeviceToHost));
   return KHR_OK;
 }
 

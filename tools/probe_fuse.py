@@ -21,9 +21,10 @@ for i in range(n):
     ctx.update_tracking(fr["stamp"])
 ctx.sync()
 st = ctx.stats()
-buf = np.zeros(4096 * 4 * 8, np.uint64)
+buf = np.zeros(4096 * 4 * 12, np.uint64)
 ctx.lib.khr_debug_read(ctx.h, buf.ctypes.data, buf.size)
-b = buf.reshape(-1, 8)
+b = buf[:4096 * 4 * 8].reshape(-1, 8)
+acc = buf[4096 * 4 * 8:].reshape(-1, 4)[b[:, 1] > 0].astype(np.float64)
 b = b[b[:, 1] > 0]
 t0 = b[:, 0].min()
 start = (b[:, 0] - t0).astype(np.float64)
@@ -47,3 +48,7 @@ print("non-band per item: mean", (nb / np.maximum(items, 1)).mean() / F, "us")
 late = np.argsort(dur)[-8:]
 for i in late:
     print("longest waves: dur %.1f band %.1f items %d rounds %d recs %d maxitem %.1f" % (dur[i] / F, band[i] / F, items[i], rounds[i], recs[i], imax[i] / F))
+
+if tr.any():
+    per = acc[tr] / rounds[tr][:, None] / F
+    print("per band round (us): colour part %.2f | label/flag loads %.2f | likelihood loads %.2f | whole label part %.2f" % tuple(per.mean(0)))

@@ -238,26 +238,42 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, size_t slot, uint32_t lin_mo
 
 // DEFCFG = the reference default switches (z-depth range, adaptive interpolation, weight drop-off, no constant
 // weight) resolved at compile time; otherwise they are read from the argument block.
-// ZSPLIT = wave items per x-y patch (a wave walks ZR = VPS / ZSPLIT z steps, ZC of them at a time: the loads of a chunk --
-// range gathers, distance, weight -- are all issued before the first result is needed, so a wave has ZC round trips to
-// memory in flight instead of one).
+// ZSPLIT = wave items per x-y patch: a wave item is 64 voxels of an x-y patch times ZR = VPS / ZSPLIT (2 or 4) z steps.
 // MINW = resident waves per SIMD the register allocation is held to (__launch_bounds__; 1 = unconstrained).
 //
 // Work distribution: the grid is persistent (resident workgroups only) and wave g takes the items g, g + n_waves, ... of
 // the descriptor list the culling pass wrote MOST EXPENSIVE ITEMS FIRST (FuseList, khr_device.h): items differ a lot in
 // cost -- a block the surface crosses carries ~1500 in-band voxels (colour + label + K likelihood updates each), a
-// free-space block none -- and dealing the sorted list round-robin gives every wave its share of the expensive ones.  (Dynamic distribution is not an option: 20 k returning
-// atomics per launch cost more than the whole kernel on gfx950, measured.)  The descriptor {slot, block index} of a wave's
-// next item is loaded while the current item is processed, so an item starts without a dependent round trip.
+// free-space block none -- and dealing the sorted list round-robin gives every wave its share of the expensive ones.
+// (Dynamic distribution is not an option: 20 k returning atomics per launch cost more than the whole kernel on gfx950,
+// measured.)
+//
+// Software pipeline: a memory round trip costs 1.5 - 2 us under this kernel's load and gfx950 retires vmcnt in order, so a
+// load issued behind a store also waits for that store.  The loop therefore runs one item AHEAD with its loads: phase 1
+// of item n + 1 (geometry, range gathers, distance / weight loads: 4 ZR loads per lane) is issued BEFORE phase 2 of item n
+// (measurement, decisions, stores, in-band records) and before item n's band rounds.  When item n + 1 is computed its
+// loads are older than every store in flight, and their latency is hidden behind item n's arithmetic and band work.
+template <int VPS, int ZR>
+struct FuseItem {
+  // wave-uniform
+  size_t slot;
+  int z0, sbi;
+  float oz, pxy2;  // block origin z; x-y part of the depth row (ray-length mode recomputes the depth in phase 2)
+  // per lane
+  int lin_xy;
+  float u[ZR], v[ZR], z[ZR], yz[ZR], d[ZR], w[ZR];
+  f2u ra[ZR], rb[ZR];
+  bool ok[ZR];
+};
+
 template <int VPS, int ZSPLIT, bool DEFCFG, bool EXACT, int MINW, bool DBG = false>
 __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
   constexpr int NV = VPS * VPS * VPS;
   constexpr int SL = VPS * VPS;        // voxels per z slice
   constexpr int PATCHES = SL / 64;     // 64-voxel x-y patches per slice
   constexpr int ZR = VPS / ZSPLIT;     // z steps per wave item
-  constexpr int ZC = ZR < 4 ? ZR : 4;  // z steps per chunk (loads in flight together)
-  constexpr int WPB = PATCHES * ZSPLIT;  // wave items per block
-  static_assert(SL % 64 == 0 && VPS % ZSPLIT == 0 && ZR % ZC == 0, "bad block shape");
+  static_assert(SL % 64 == 0 && VPS % ZSPLIT == 0 && (ZR == 2 || ZR == 4), "bad block shape");
+  static_assert(64 * ZR <= kFuseCap, "record list must hold one item");
   // per-wave record list, one LDS base per wave: field f of record r at s_rec[wave][f][r] (0 voxel | mode, 1 measurement
   // weight, 2 voxel weight after the update, 3 u, 4 v), so the five stores of a record differ by immediate offsets
   __shared__ uint32_t s_rec[4][5][kFuseCap];
@@ -272,6 +288,8 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
   const float fxfy = a.fx * a.fy;
   const float den = a.trunc - a.dropoff_eps;  // weight drop-off denominator (uniform)
   const float yden = rcpRefined(den);
+  const char* const range_b = reinterpret_cast<const char*>(a.range);
+  const uint32_t W4 = static_cast<uint32_t>(a.W) * 4u;
   const uint32_t nc0 = list.counts[0], nc1 = nc0 + list.counts[1], nc2 = nc1 + list.counts[2], n_items = nc2 + list.counts[3];
   uint32_t n_upd = 0, n_band = 0;
   const int dbg = DBG ? a.dbg : 0;
@@ -283,239 +301,242 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
     if (i < nc2) return list.b[i - nc1];
     return list.b[list.cap - 1u - (i - nc2)];
   };
-  uint32_t item = blockIdx.x * 4u + static_cast<uint32_t>(wave);
-  uint4 d_next = make_uint4(0u, 0u, 0u, 0u);
-  if (item < n_items) d_next = descOf(item);
-  const unsigned long long tw0 = (DBG && (dbg & 64)) ? __builtin_amdgcn_s_memtime() : 0ull;
-  unsigned long long t_band = 0, t_item_max = 0;
-  unsigned long long tacc[4] = {0, 0, 0, 0};  // DBG: band round split {colour part, label / flag loads, likelihood loads, whole label part}
-  uint32_t c_items = 0, c_rounds = 0, c_recs = 0;
-  while (item < n_items) {
-    const unsigned long long ti0 = (DBG && (dbg & 64)) ? __builtin_amdgcn_s_memtime() : 0ull;
-    const uint32_t dx = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(d_next.x)));
-    const size_t slot = dx & 0xffffffu;
-    int4 bi;
-    bi.x = __builtin_amdgcn_readfirstlane(static_cast<int>(d_next.y));
-    bi.y = __builtin_amdgcn_readfirstlane(static_cast<int>(d_next.z));
-    bi.z = __builtin_amdgcn_readfirstlane(static_cast<int>(d_next.w));
-    const int sbi = static_cast<int>(dx >> 24);
-    const int patch = sbi % PATCHES, z0 = (sbi / PATCHES) * ZR;
-    const uint32_t item_next = item + n_waves;
-    uint32_t item_band = 0;
-    const float ox = static_cast<float>(bi.x) * a.bs, oy = static_cast<float>(bi.y) * a.bs, oz = static_cast<float>(bi.z) * a.bs;
-    const int lin_xy = patch * 64 + lane;
-    const int ix = lin_xy % VPS, iy = lin_xy / VPS;
+
+  // ---- phase 1: geometry of the item's ZR voxels per lane; all their loads issued ----
+  auto phase1 = [&](FuseItem<VPS, ZR>& it, const uint4 desc) {
+    const uint32_t dx = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(desc.x)));
+    it.slot = dx & 0xffffffu;
+    it.sbi = static_cast<int>(dx >> 24);
+    const int bx = __builtin_amdgcn_readfirstlane(static_cast<int>(desc.y));
+    const int by = __builtin_amdgcn_readfirstlane(static_cast<int>(desc.z));
+    const int bz = __builtin_amdgcn_readfirstlane(static_cast<int>(desc.w));
+    const int patch = it.sbi % PATCHES;
+    it.z0 = (it.sbi / PATCHES) * ZR;
+    const float ox = static_cast<float>(bx) * a.bs, oy = static_cast<float>(by) * a.bs;
+    it.oz = static_cast<float>(bz) * a.bs;
+    it.lin_xy = patch * 64 + lane;
+    const int ix = it.lin_xy % VPS, iy = it.lin_xy / VPS;
     const float px = ox + (static_cast<float>(ix) + 0.5f) * a.vs;
     const float py = oy + (static_cast<float>(iy) + 0.5f) * a.vs;
     float pxy[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) pxy[c] = a.R[3 * c] * px + a.R[3 * c + 1] * py;
+    it.pxy2 = pxy[2];
     // per-item bases in SGPRs + 32-bit unsigned byte offsets per lane: the loads / stores take the
     // `global_* v, v_off, s[base]` form (no 64-bit address arithmetic in VGPRs)
+    const char* const dist_b = reinterpret_cast<const char*>(a.dist + it.slot * NV);
+    const char* const wgt_b = reinterpret_cast<const char*>(a.weight + it.slot * NV);
+#pragma unroll
+    for (int k = 0; k < ZR; ++k) {
+      const int iz = it.z0 + k;
+      const uint32_t lin = static_cast<uint32_t>(it.lin_xy + iz * SL);
+      const float pz = it.oz + (static_cast<float>(iz) + 0.5f) * a.vs;
+      float pc[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pc[c] = (pxy[c] + a.R[3 * c + 2] * pz) + a.t[c];
+      bool ok = pc[2] > 0.f;
+      const float voxel_range = range_mode == 0 ? pc[2] : sqrtf((pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2]);
+      ok = ok && !(voxel_range < a.min_range || voxel_range > a.max_range);
+      const float yz = rcpRefined(pc[2]);
+      const float u = divExact(pc[0] * a.fx, pc[2], yz) + a.cx;
+      const float v = divExact(pc[1] * a.fy, pc[2], yz) + a.cy;
+      // ceil(u) >= W || floor(u) < 0  <=>  u > W - 1 || u < 0  (W - 1 is an integer-valued float); x - y >= 0 <=> x >= y
+      // holds exactly in IEEE arithmetic, so the four tests are one min3 / min / compare
+      ok = ok && (fminf(fminf(u, v), fminf(Wm1 - u, Hm1 - v)) >= 0.f);
+      // invalid lanes gather pixel (0, 0); valid lanes have 0 <= u <= W - 1, so floor == truncation
+      const float uc = ok ? u : 0.f, vc = ok ? v : 0.f;
+      const uint32_t u0 = static_cast<uint32_t>(static_cast<int>(uc)), v0 = static_cast<uint32_t>(static_cast<int>(vc));
+      const uint32_t v1 = min(v0 + 1u, static_cast<uint32_t>(a.H - 1));
+      uint32_t o0 = v0 * W4 + u0 * 4u, o1 = v1 * W4 + u0 * 4u;  // byte offsets of (u0, v0), (u0, v1)
+      if (DBG && (dbg & 8)) { o0 = static_cast<uint32_t>(lane) * 8u; o1 = o0 + W4; }
+      it.ra[k] = *reinterpret_cast<const f2u*>(range_b + o0);  // (u0, v0), (u0 + 1, v0)
+      it.rb[k] = *reinterpret_cast<const f2u*>(range_b + o1);  // (u0, v1), (u0 + 1, v1)
+      it.d[k] = 0.f;
+      it.w[k] = 0.f;
+      if (ok && !(DBG && (dbg & 4))) {
+        it.d[k] = *reinterpret_cast<const float*>(dist_b + lin * 4u);
+        it.w[k] = *reinterpret_cast<const float*>(wgt_b + lin * 4u);
+      }
+      it.u[k] = uc;
+      it.v[k] = vc;
+      it.z[k] = voxel_range;
+      it.yz[k] = yz;
+      it.ok[k] = ok;
+    }
+  };
+
+  uint32_t item = blockIdx.x * 4u + static_cast<uint32_t>(wave);
+  FuseItem<VPS, ZR> cur, nxt;
+  uint4 d_next = make_uint4(0u, 0u, 0u, 0u);
+  if (item < n_items) {
+    phase1(cur, descOf(item));
+    if (item + n_waves < n_items) d_next = descOf(item + n_waves);
+  }
+  const unsigned long long tw0 = (DBG && (dbg & 64)) ? __builtin_amdgcn_s_memtime() : 0ull;
+  unsigned long long t_band = 0, t_item_max = 0;
+  uint32_t c_items = 0, c_rounds = 0, c_recs = 0;
+  while (item < n_items) {
+    const unsigned long long ti0 = (DBG && (dbg & 64)) ? __builtin_amdgcn_s_memtime() : 0ull;
+    // ---- the NEXT item's loads go out first (and the descriptor of the one after it) ----
+    const uint32_t item_next = item + n_waves;
+    const bool have_next = item_next < n_items;
+    if (have_next) {
+      phase1(nxt, d_next);
+      if (item_next + n_waves < n_items) d_next = descOf(item_next + n_waves);
+    }
+    // ---- phase 2 of the current item: measurement, decisions, read-modify-write ----
+    const size_t slot = cur.slot;
     char* const dist_b = reinterpret_cast<char*>(a.dist + slot * NV);
     char* const wgt_b = reinterpret_cast<char*>(a.weight + slot * NV);
     char* const lobs_b = reinterpret_cast<char*>(a.last_obs + slot * NV);
-    const char* const range_b = reinterpret_cast<const char*>(a.range);
-    const uint32_t W4 = static_cast<uint32_t>(a.W) * 4u;
-    uint32_t cnt = 0;       // records waiting in this wave's LDS list
+    uint32_t cnt = 0;       // records in this wave's LDS list
     bool touched = false;   // wave-uniform: some voxel of this item was updated
-    for (int zc = 0; zc < ZR; zc += ZC) {
-      // ---- phase 1: geometry of the chunk's ZC voxels per lane, all their loads issued ----
-      float u_[ZC], v_[ZC], z_[ZC], yz_[ZC], d_[ZC], w_[ZC];
-      f2u ra_[ZC], rb_[ZC];
-      bool ok_[ZC];
 #pragma unroll
-      for (int k = 0; k < ZC; ++k) {
-        const int iz = z0 + zc + k;
-        const uint32_t lin = static_cast<uint32_t>(lin_xy + iz * SL);
-        const float pz = oz + (static_cast<float>(iz) + 0.5f) * a.vs;
-        float pc[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) pc[c] = (pxy[c] + a.R[3 * c + 2] * pz) + a.t[c];
-        bool ok = pc[2] > 0.f;
-        // (ray-length mode: the range test needs the voxel's full range; recomputed in phase 2)
-        const float voxel_range = range_mode == 0 ? pc[2] : sqrtf((pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2]);
-        ok = ok && !(voxel_range < a.min_range || voxel_range > a.max_range);
-        const float yz = rcpRefined(pc[2]);
-        const float u = divExact(pc[0] * a.fx, pc[2], yz) + a.cx;
-        const float v = divExact(pc[1] * a.fy, pc[2], yz) + a.cy;
-        // ceil(u) >= W || floor(u) < 0  <=>  u > W - 1 || u < 0  (W - 1 is an integer-valued float); x - y >= 0 <=> x >= y
-        // holds exactly in IEEE arithmetic, so the four tests are one min3 / min / compare
-        ok = ok && (fminf(fminf(u, v), fminf(Wm1 - u, Hm1 - v)) >= 0.f);
-        // invalid lanes gather pixel (0, 0); valid lanes have 0 <= u <= W - 1, so floor == truncation
-        const float uc = ok ? u : 0.f, vc = ok ? v : 0.f;
-        const uint32_t u0 = static_cast<uint32_t>(static_cast<int>(uc)), v0 = static_cast<uint32_t>(static_cast<int>(vc));
-        const uint32_t v1 = min(v0 + 1u, static_cast<uint32_t>(a.H - 1));
-        uint32_t o0 = v0 * W4 + u0 * 4u, o1 = v1 * W4 + u0 * 4u;  // byte offsets of (u0, v0), (u0, v1)
-        if (DBG && (dbg & 8)) { o0 = static_cast<uint32_t>(lane) * 8u; o1 = o0 + W4; }
-        ra_[k] = *reinterpret_cast<const f2u*>(range_b + o0);  // (u0, v0), (u0 + 1, v0)
-        rb_[k] = *reinterpret_cast<const f2u*>(range_b + o1);  // (u0, v1), (u0 + 1, v1)
-        d_[k] = 0.f;
-        w_[k] = 0.f;
-        if (ok && !(DBG && (dbg & 4))) {
-          d_[k] = *reinterpret_cast<const float*>(dist_b + lin * 4u);
-          w_[k] = *reinterpret_cast<const float*>(wgt_b + lin * 4u);
-        }
-        u_[k] = uc;
-        v_[k] = vc;
-        z_[k] = range_mode == 0 ? pc[2] : voxel_range;
-        yz_[k] = yz;
-        ok_[k] = ok;
+    for (int k = 0; k < ZR; ++k) {
+      bool ok = cur.ok[k];
+      if (DBG && (dbg & 16)) {
+        n_upd += static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(ok)));
+        continue;
       }
-      // the next item's descriptor is loaded here, BEHIND the chunk's loads (vmcnt retires in order: issued in front of them
-      // it would have to come back before the first range sample could be used)
-      if (zc == 0 && item_next < n_items) d_next = descOf(item_next);
-      // ---- phase 2: measurement, decisions, read-modify-write ----
-#pragma unroll
-      for (int k = 0; k < ZC; ++k) {
-        bool ok = ok_[k];
-        if (DBG && (dbg & 16)) {
-          n_upd += static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(ok)));
-          continue;
-        }
-        if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
-        const int iz = z0 + zc + k;
-        const uint32_t lin = static_cast<uint32_t>(lin_xy + iz * SL);
-        const float uc = u_[k], vc = v_[k], voxel_range = z_[k], yz = yz_[k];
-        // range_mode 0: voxel_range is the voxel's depth; ray-length mode needs the depth again for the weight
-        float depth = voxel_range;
-        if (range_mode != 0) {
-          const float pz = oz + (static_cast<float>(iz) + 0.5f) * a.vs;
-          depth = (pxy[2] + a.R[8] * pz) + a.t[2];
-        }
-        const uint32_t u0 = static_cast<uint32_t>(static_cast<int>(uc)), v0 = static_cast<uint32_t>(static_cast<int>(vc));
-        const uint32_t v1 = min(v0 + 1u, static_cast<uint32_t>(a.H - 1));
-        const float du = __builtin_amdgcn_fractf(uc), dv = __builtin_amdgcn_fractf(vc);  // x - floor(x), exact for x >= 0
-        const uint32_t o0 = v0 * W4 + u0 * 4u, o1 = v1 * W4 + u0 * 4u;
-        const float d_old = d_[k], w_old = w_[k];
-        // pixel order of the reference: (u0,v0) (u0,v1) (u1,v0) (u1,v1) with u1 = min(u0 + 1, W - 1)
-        const bool last_col = u0 >= static_cast<uint32_t>(a.W - 1);
-        const float r0 = ra_[k].x, r1 = rb_[k].x, r2 = last_col ? ra_[k].x : ra_[k].y, r3 = last_col ? rb_[k].x : rb_[k].y;
-        bool use_nearest = interp == 0;
-        if (interp == 2) {
-          const float mn = fminf(fminf(r0, r1), fminf(r2, r3));
-          const float mx = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
-          use_nearest = use_nearest || (mx - mn > a.adaptive_diff);
-        }
-        const bool hi_u = du >= 0.5f, hi_v = dv >= 0.5f;
-        const float r_near = hi_u ? (hi_v ? r3 : r2) : (hi_v ? r1 : r0);
-        const float omu = 1.f - du, omv = 1.f - dv;
-        const float w0 = omu * omv, w1 = omu * dv, w2 = du * omv, w3 = du * dv;
-        const float r_bil = ((w0 * r0 + w1 * r1) + w2 * r2) + w3 * r3;
-        const float dist_surface = use_nearest ? r_near : r_bil;
-        ok = ok && (dist_surface >= a.min_range) && !(dist_surface > a.max_range);
-        const float sdf = dist_surface - voxel_range;
-        ok = ok && !(sdf < -a.trunc);
-        bool in_band = ok && (fabsf(sdf) < a.trunc);
-        if (__builtin_expect(a.use_mask && __builtin_amdgcn_ballot_w64(in_band) != 0ull, 0)) {
-          // interpolateID(mask): pixel of the largest weight (first maximum)
-          int best;
-          if (use_nearest) {
-            best = (hi_u ? 2 : 0) + (hi_v ? 1 : 0);
-          } else {
-            best = 0;
-            float bw = w0;
-            if (w1 > bw) { bw = w1; best = 1; }
-            if (w2 > bw) { bw = w2; best = 2; }
-            if (w3 > bw) { bw = w3; best = 3; }
-          }
-          const uint32_t uo = ((best & 2) && !last_col) ? 4u : 0u;
-          const uint32_t bo = ((best & 1) ? o1 : o0) + uo;
-          if (in_band && *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.dyn) + bo) != 0) {
-            ok = false;
-            in_band = false;
-          }
-        }
-        if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
-        // measurement weight (computeWeight): fx fy vs^2 / z^4, linear drop-off behind the surface
-        float w;
-        if (EXACT) {
-          const float qd = divExact(a.vs, depth, yz);
-          w = fxfy * (qd * qd);
-          if (!const_weight) {
-            const float z2 = depth * depth;
-            w = divExact(w, z2, rcpRefined(z2));
-          }
-          if (use_dropoff && sdf < -a.dropoff_eps) w = fmaxf(w * divExact(a.trunc + sdf, den, yden), 0.f);
+      if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
+      const int iz = cur.z0 + k;
+      const uint32_t lin = static_cast<uint32_t>(cur.lin_xy + iz * SL);
+      const float uc = cur.u[k], vc = cur.v[k], voxel_range = cur.z[k], yz = cur.yz[k];
+      // range_mode 0: voxel_range is the voxel's depth; ray-length mode needs the depth again for the weight
+      float depth = voxel_range;
+      if (range_mode != 0) {
+        const float pz = cur.oz + (static_cast<float>(iz) + 0.5f) * a.vs;
+        depth = (cur.pxy2 + a.R[8] * pz) + a.t[2];
+      }
+      const uint32_t u0 = static_cast<uint32_t>(static_cast<int>(uc)), v0 = static_cast<uint32_t>(static_cast<int>(vc));
+      const uint32_t v1 = min(v0 + 1u, static_cast<uint32_t>(a.H - 1));
+      const float du = __builtin_amdgcn_fractf(uc), dv = __builtin_amdgcn_fractf(vc);  // x - floor(x), exact for x >= 0
+      const uint32_t o0 = v0 * W4 + u0 * 4u, o1 = v1 * W4 + u0 * 4u;
+      const float d_old = cur.d[k], w_old = cur.w[k];
+      // pixel order of the reference: (u0,v0) (u0,v1) (u1,v0) (u1,v1) with u1 = min(u0 + 1, W - 1)
+      const bool last_col = u0 >= static_cast<uint32_t>(a.W - 1);
+      const float r0 = cur.ra[k].x, r1 = cur.rb[k].x, r2 = last_col ? cur.ra[k].x : cur.ra[k].y, r3 = last_col ? cur.rb[k].x : cur.rb[k].y;
+      bool use_nearest = interp == 0;
+      if (interp == 2) {
+        const float mn = fminf(fminf(r0, r1), fminf(r2, r3));
+        const float mx = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+        use_nearest = use_nearest || (mx - mn > a.adaptive_diff);
+      }
+      const bool hi_u = du >= 0.5f, hi_v = dv >= 0.5f;
+      const float r_near = hi_u ? (hi_v ? r3 : r2) : (hi_v ? r1 : r0);
+      const float omu = 1.f - du, omv = 1.f - dv;
+      const float w0 = omu * omv, w1 = omu * dv, w2 = du * omv, w3 = du * dv;
+      const float r_bil = ((w0 * r0 + w1 * r1) + w2 * r2) + w3 * r3;
+      const float dist_surface = use_nearest ? r_near : r_bil;
+      ok = ok && (dist_surface >= a.min_range) && !(dist_surface > a.max_range);
+      const float sdf = dist_surface - voxel_range;
+      ok = ok && !(sdf < -a.trunc);
+      bool in_band = ok && (fabsf(sdf) < a.trunc);
+      if (__builtin_expect(a.use_mask && __builtin_amdgcn_ballot_w64(in_band) != 0ull, 0)) {
+        // interpolateID(mask): pixel of the largest weight (first maximum)
+        int best;
+        if (use_nearest) {
+          best = (hi_u ? 2 : 0) + (hi_v ? 1 : 0);
         } else {
-          const float qd = a.vs * yz;
-          w = fxfy * (qd * qd);
-          if (!const_weight) w = w * (yz * yz);
-          if (use_dropoff && sdf < -a.dropoff_eps) w = fmaxf(w * ((a.trunc + sdf) * yden), 0.f);
+          best = 0;
+          float bw = w0;
+          if (w1 > bw) { bw = w1; best = 1; }
+          if (w2 > bw) { bw = w2; best = 2; }
+          if (w3 > bw) { bw = w3; best = 3; }
         }
-        // w > 0 is the same decision in both modes: the factors are positive normal numbers far from underflow, so
-        // the product is zero exactly when trunc + sdf == 0
-        ok = ok && (w > 0.f);
-        in_band = in_band && ok;
-        const float sdf_c = fmaxf(fminf(a.trunc, sdf), -a.trunc);
-        const float tot = w_old + w;
-        float d_new;
-        if (EXACT) {
-          d_new = divExact(d_old * w_old + sdf_c * w, tot, rcpRefined(tot));
-        } else {
-          d_new = __builtin_fmaf(d_old, w_old, sdf_c * w) * __builtin_amdgcn_rcpf(tot);
-        }
-        const float w_new = fminf(tot, a.max_weight);
-        if (ok && !(DBG && (dbg & 2))) {
-          *reinterpret_cast<float*>(dist_b + lin * 4u) = d_new;
-          *reinterpret_cast<float*>(wgt_b + lin * 4u) = w_new;
-          if (a.with_tracking) *reinterpret_cast<uint64_t*>(lobs_b + lin * 8u) = a.stamp;
-        }
-        const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(ok), m_band = __builtin_amdgcn_ballot_w64(in_band);
-        n_upd += static_cast<uint32_t>(__popcll(m_ok));
-        touched = touched || (m_ok != 0ull);
-        if (m_band) {
-          n_band += static_cast<uint32_t>(__popcll(m_band));
-          item_band += static_cast<uint32_t>(__popcll(m_band));
-          if (in_band) {
-            const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m_band >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m_band), 0u));
-            uint32_t* const rec = &s_rec[wave][0][pos];
-            rec[0] = lin | (use_nearest ? 0x10000u : 0u);
-            rec[kFuseCap] = __float_as_uint(w);
-            rec[2 * kFuseCap] = __float_as_uint(w_new);
-            rec[3 * kFuseCap] = __float_as_uint(uc);
-            rec[4 * kFuseCap] = __float_as_uint(vc);
-          }
-          cnt += static_cast<uint32_t>(__popcll(m_band));
+        const uint32_t uo = ((best & 2) && !last_col) ? 4u : 0u;
+        const uint32_t bo = ((best & 1) ? o1 : o0) + uo;
+        if (in_band && *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.dyn) + bo) != 0) {
+          ok = false;
+          in_band = false;
         }
       }
-      // work the list off when the next chunk might not fit, and at the end of the item (a cold block: the hint keeps
-      // the register allocator from favouring its values over the voxel loop's)
-      if (DBG && (dbg & 1)) cnt = 0u;
-      if (__builtin_expect(cnt > static_cast<uint32_t>(kFuseCap - 64 * ZC) || (zc + ZC >= ZR && cnt > 0u), 0)) {
-        const unsigned long long tb0 = (DBG && (dbg & 64)) ? __builtin_amdgcn_s_memtime() : 0ull;
-        if (DBG) { c_rounds += (cnt + 63u) / 64u; c_recs += cnt; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // explicit kernel arguments start at offset 0 of the kernarg segment; the empty asm keeps the loads of the band
-        // phase's arguments from being hoisted out of this block (and their registers out of the voxel loop)
-        FuseArgsK ka = (FuseArgsK)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(ka));
-        for (uint32_t r = static_cast<uint32_t>(lane); r < cnt; r += 64u) {
-          const uint32_t* const rec = &s_rec[wave][0][r];
-          fuseBandRecord<VPS, DBG>(ka, slot, rec[0], __uint_as_float(rec[kFuseCap]), __uint_as_float(rec[2 * kFuseCap]),
-                                   __uint_as_float(rec[3 * kFuseCap]), __uint_as_float(rec[4 * kFuseCap]), tacc);
+      if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
+      // measurement weight (computeWeight): fx fy vs^2 / z^4, linear drop-off behind the surface
+      float w;
+      if (EXACT) {
+        const float qd = divExact(a.vs, depth, yz);
+        w = fxfy * (qd * qd);
+        if (!const_weight) {
+          const float z2 = depth * depth;
+          w = divExact(w, z2, rcpRefined(z2));
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (DBG && (dbg & 64)) {
-          __builtin_amdgcn_s_waitcnt(0);  // the phase's stores included
-          t_band += __builtin_amdgcn_s_memtime() - tb0;
-        }
-        cnt = 0u;
+        if (use_dropoff && sdf < -a.dropoff_eps) w = fmaxf(w * divExact(a.trunc + sdf, den, yden), 0.f);
+      } else {
+        const float qd = a.vs * yz;
+        w = fxfy * (qd * qd);
+        if (!const_weight) w = w * (yz * yz);
+        if (use_dropoff && sdf < -a.dropoff_eps) w = fmaxf(w * ((a.trunc + sdf) * yden), 0.f);
       }
+      // w > 0 is the same decision in both modes: the factors are positive normal numbers far from underflow, so
+      // the product is zero exactly when trunc + sdf == 0
+      ok = ok && (w > 0.f);
+      in_band = in_band && ok;
+      const float sdf_c = fmaxf(fminf(a.trunc, sdf), -a.trunc);
+      const float tot = w_old + w;
+      float d_new;
+      if (EXACT) {
+        d_new = divExact(d_old * w_old + sdf_c * w, tot, rcpRefined(tot));
+      } else {
+        d_new = __builtin_fmaf(d_old, w_old, sdf_c * w) * __builtin_amdgcn_rcpf(tot);
+      }
+      const float w_new = fminf(tot, a.max_weight);
+      if (ok && !(DBG && (dbg & 2))) {
+        *reinterpret_cast<float*>(dist_b + lin * 4u) = d_new;
+        *reinterpret_cast<float*>(wgt_b + lin * 4u) = w_new;
+        if (a.with_tracking) *reinterpret_cast<uint64_t*>(lobs_b + lin * 8u) = a.stamp;
+      }
+      const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(ok), m_band = __builtin_amdgcn_ballot_w64(in_band);
+      n_upd += static_cast<uint32_t>(__popcll(m_ok));
+      touched = touched || (m_ok != 0ull);
+      if (m_band) {
+        n_band += static_cast<uint32_t>(__popcll(m_band));
+        if (in_band) {
+          const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m_band >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m_band), 0u));
+          uint32_t* const rec = &s_rec[wave][0][pos];
+          rec[0] = lin | (use_nearest ? 0x10000u : 0u);
+          rec[kFuseCap] = __float_as_uint(w);
+          rec[2 * kFuseCap] = __float_as_uint(w_new);
+          rec[3 * kFuseCap] = __float_as_uint(uc);
+          rec[4 * kFuseCap] = __float_as_uint(vc);
+        }
+        cnt += static_cast<uint32_t>(__popcll(m_band));
+      }
+    }
+    const uint32_t item_band = cnt;
+    // ---- the item's in-band voxels, densely (lane <-> record).  A cold block: the hint keeps the register allocator
+    //      from favouring its values over the voxel loop's ----
+    if (DBG && (dbg & 1)) cnt = 0u;
+    if (__builtin_expect(cnt > 0u, 0)) {
+      const unsigned long long tb0 = (DBG && (dbg & 64)) ? __builtin_amdgcn_s_memtime() : 0ull;
+      if (DBG) { c_rounds += (cnt + 63u) / 64u; c_recs += cnt; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // explicit kernel arguments start at offset 0 of the kernarg segment; the empty asm keeps the loads of the band
+      // phase's arguments from being hoisted out of this block (and their registers out of the voxel loop)
+      FuseArgsK ka = (FuseArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(ka));
+      for (uint32_t r = static_cast<uint32_t>(lane); r < cnt; r += 64u) {
+        const uint32_t* const rec = &s_rec[wave][0][r];
+        fuseBandRecord<VPS>(ka, slot, rec[0], __uint_as_float(rec[kFuseCap]), __uint_as_float(rec[2 * kFuseCap]),
+                            __uint_as_float(rec[3 * kFuseCap]), __uint_as_float(rec[4 * kFuseCap]));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (DBG && (dbg & 64)) t_band += __builtin_amdgcn_s_memtime() - tb0;
     }
     if (lane == 0) {
       if (touched && !(DBG && (dbg & 128))) atomicOr(&a.blk_flags[slot], BLK_UPDATED | BLK_MESH_UPDATED | BLK_TRACKING_UPDATED);
-      a.blk_band[slot * kBandSlots + (sbi & (kBandSlots - 1))] = static_cast<uint16_t>(min(item_band, 65535u));  // next frame's culling pass sorts by it
+      a.blk_band[slot * kBandSlots + (cur.sbi & (kBandSlots - 1))] = static_cast<uint16_t>(min(item_band, 65535u));  // next frame's culling pass sorts by it
     }
-    item = item_next;
     if (DBG && (dbg & 64)) {
       const unsigned long long dt = __builtin_amdgcn_s_memtime() - ti0;
       t_item_max = dt > t_item_max ? dt : t_item_max;
       ++c_items;
     }
+    item = item_next;
+    if (have_next) cur = nxt;
   }
   if (DBG && (dbg & 64) && lane == 0) {
     unsigned long long* o = a.dbg_buf + (static_cast<size_t>(blockIdx.x) * 4 + wave) * 8;
@@ -526,10 +547,7 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
     o[4] = c_rounds;
     o[5] = c_recs;
     o[6] = t_item_max;
-    o[7] = (tacc[0] & 0xffffull) | ((tacc[1] >> 4 & 0xffffull) << 16) | ((tacc[2] >> 4 & 0xffffull) << 32) | ((tacc[3] >> 4 & 0xffffull) << 48);
     o[7] = 0;
-    unsigned long long* o2 = a.dbg_buf + 4096 * 4 * 8 + (static_cast<size_t>(blockIdx.x) * 4 + wave) * 4;
-    o2[0] = tacc[0]; o2[1] = tacc[1]; o2[2] = tacc[2]; o2[3] = tacc[3];
   }
   // statistics: one read-modify-write per workgroup on its own slot (folded by beginIntegrate / khr_get_stats)
   if (lane == 0) {

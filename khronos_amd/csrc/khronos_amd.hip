@@ -691,8 +691,8 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &c->d_wg_stats, 2 * kFuseStatSlots));
   {
     int zs = kFuseZsplit;
-    if (zs == 0) zs = cfg->world_size >= 4 ? 8 : (cfg->world_size >= 2 ? 4 : 2);
-    if (zs != 1 && zs != 2 && zs != 4 && zs != 8) zs = 2;
+    if (zs == 0) zs = cfg->world_size >= 4 ? 8 : 4;
+    if (zs != 4 && zs != 8) zs = 4;  // a wave item is a 64-voxel patch x 4 (or 2) z steps
     if (cfg->voxels_per_side == 8) zs = 4;
     c->fuse_zsplit = zs;
     c->wpb = static_cast<uint32_t>((cfg->voxels_per_side * cfg->voxels_per_side / 64) * zs);
@@ -1108,7 +1108,7 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
       if (defcfg && !exact && kFuseDbg && V == 16) {
         go(&k_fuse<V, ZS, true, false, 1, (V == 16)>);
       } else if (defcfg && !exact) {
-        if (V == 16 && kFuseMinw == 6) go(&k_fuse<V, ZS, true, false, (V == 16 ? 6 : 1)>);
+        if (V == 16 && kFuseMinw == 5) go(&k_fuse<V, ZS, true, false, (V == 16 ? 5 : 1)>);
         else if (V == 16 && kFuseMinw == 4) go(&k_fuse<V, ZS, true, false, (V == 16 ? 4 : 1)>);
         else go(&k_fuse<V, ZS, true, false, 1>);
       } else if (defcfg) {
@@ -1123,12 +1123,8 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
     if (V == 8) {
       launch(std::integral_constant<int, 4>());
     } else {
-      switch (zs) {
-        case 1: launch(std::integral_constant<int, (V == 16 ? 1 : 4)>()); break;
-        case 4: launch(std::integral_constant<int, 4>()); break;
-        case 8: launch(std::integral_constant<int, (V == 16 ? 8 : 4)>()); break;
-        default: launch(std::integral_constant<int, (V == 16 ? 2 : 4)>()); break;
-      }
+      if (zs == 8) launch(std::integral_constant<int, (V == 16 ? 8 : 4)>());
+      else launch(std::integral_constant<int, 4>());
     }
     return KHR_OK;
   });

@@ -49,6 +49,3 @@ late = np.argsort(dur)[-8:]
 for i in late:
     print("longest waves: dur %.1f band %.1f items %d rounds %d recs %d maxitem %.1f" % (dur[i] / F, band[i] / F, items[i], rounds[i], recs[i], imax[i] / F))
 
-if tr.any():
-    per = acc[tr] / rounds[tr][:, None] / F
-    print("per band round (us): colour part %.2f | label/flag loads %.2f | likelihood loads %.2f | whole label part %.2f" % tuple(per.mean(0)))

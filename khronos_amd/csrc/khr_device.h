@@ -121,7 +121,6 @@ struct DevParams {
 struct DevFrame {
   const float* depth;
   const float* range;
-  const float4* rquad;  // per pixel: the four range samples of an interpolation anchored there (ingestTile)
   const uint32_t* rgba;
   const int32_t* label;
   int32_t* dyn;

@@ -94,7 +94,7 @@ struct FuseArgs {
   uint32_t* wg_stats;  // [2 * gridDim.x]: {n_upd, n_band} accumulated per workgroup slot
   uint16_t* blk_band;  // [slot][kBandSlots]: in-band voxels of each wave item at this update
   // frame
-  const float4* rquad;  // per pixel: the four range samples of an interpolation anchored there
+  const float* range;
   const int32_t* dyn;
   const uint32_t* rgba;
   const int32_t* label;
@@ -238,46 +238,42 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, size_t slot, uint32_t lin_mo
 
 // DEFCFG = the reference default switches (z-depth range, adaptive interpolation, weight drop-off, no constant
 // weight) resolved at compile time; otherwise they are read from the argument block.
+// ZSPLIT = wave items per x-y patch: a wave item is 64 voxels of an x-y patch times ZR = VPS / ZSPLIT (2 or 4) z steps.
 // MINW = resident waves per SIMD the register allocation is held to (__launch_bounds__; 1 = unconstrained).
-//
-// What bounds this kernel on gfx950 is the NUMBER of vector-memory instructions a CU can process (~40 cycles each,
-// coalesced or not: measured by issuing the loads without using them), not bytes and not arithmetic.  Hence:
-//  * a lane owns 4 x-consecutive voxels (16-byte loads / stores of distance and weight, 2 x 16 bytes of last_observed):
-//    a wave item = 256 voxels = one z slice of a 16^3 block (four slices of an 8^3 block);
-//  * the four range samples of a voxel's footprint come from ONE 16-byte gather of the frame's quad image (rquad);
-//  * per 256 voxels: 4 gathers + 2 loads + 4 stores, against 28 instructions with one voxel per lane and pixel pairs.
 //
 // Work distribution: the grid is persistent (resident workgroups only) and wave g takes the items g, g + n_waves, ... of
 // the descriptor list the culling pass wrote MOST EXPENSIVE ITEMS FIRST (FuseList, khr_device.h): items differ a lot in
 // cost -- a block the surface crosses carries ~1500 in-band voxels (colour + label + K likelihood updates each), a
 // free-space block none -- and dealing the sorted list round-robin gives every wave its share of the expensive ones.
-// (Dynamic distribution is not an option: 20 k returning atomics per launch cost more than the whole kernel, measured.)
+// (Dynamic distribution is not an option: 20 k returning atomics per launch cost more than the whole kernel on gfx950,
+// measured.)
 //
 // Software pipeline: a memory round trip costs 1.5 - 2 us under this kernel's load and gfx950 retires vmcnt in order, so a
 // load issued behind a store also waits for that store.  The loop therefore runs one item AHEAD with its loads: phase 1
-// of item n + 1 (geometry, range gathers, distance / weight loads) is issued BEFORE phase 2 of item n (measurement,
-// decisions, stores, in-band records) and before item n's band rounds.
-constexpr int kVL = 4;  // voxels per lane (consecutive in x)
+// of item n + 1 (geometry, range gathers, distance / weight loads: 4 ZR loads per lane) is issued BEFORE phase 2 of item n
+// (measurement, decisions, stores, in-band records) and before item n's band rounds.  When item n + 1 is computed its
+// loads are older than every store in flight, and their latency is hidden behind item n's arithmetic and band work.
+template <int VPS, int ZR>
 struct FuseItem {
   // wave-uniform
   size_t slot;
-  int sbi;
+  int z0, sbi;
+  float oz, pxy2;  // block origin z; x-y part of the depth row (ray-length mode recomputes the depth in phase 2)
   // per lane
-  uint32_t lin0;  // linear index of the lane's first voxel
-  float u[kVL], v[kVL], z[kVL], depth[kVL];
-  float4 q[kVL];  // range samples (u0,v0) (u0,v1) (u1,v0) (u1,v1)
-  float4 d4, w4;
-  bool ok[kVL];
+  int lin_xy;
+  float u[ZR], v[ZR], z[ZR], yz[ZR], d[ZR], w[ZR];
+  f2u ra[ZR], rb[ZR];
+  bool ok[ZR];
 };
 
-template <int VPS, bool DEFCFG, bool EXACT, int MINW, bool DBG = false>
+template <int VPS, int ZSPLIT, bool DEFCFG, bool EXACT, int MINW, bool DBG = false>
 __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
   constexpr int NV = VPS * VPS * VPS;
-  constexpr int SL = VPS * VPS;            // voxels per z slice
-  constexpr int XG = VPS / kVL;            // lanes along x
-  constexpr int ZW = 64 * kVL / SL;        // z slices per wave item (1 for 16^3 blocks, 4 for 8^3)
-  static_assert(VPS % kVL == 0 && (64 * kVL) % SL == 0 && VPS % ZW == 0, "bad block shape");
-  static_assert(64 * kVL <= kFuseCap, "record list must hold one item");
+  constexpr int SL = VPS * VPS;        // voxels per z slice
+  constexpr int PATCHES = SL / 64;     // 64-voxel x-y patches per slice
+  constexpr int ZR = VPS / ZSPLIT;     // z steps per wave item
+  static_assert(SL % 64 == 0 && VPS % ZSPLIT == 0 && (ZR == 2 || ZR == 4), "bad block shape");
+  static_assert(64 * ZR <= kFuseCap, "record list must hold one item");
   // per-wave record list, one LDS base per wave: field f of record r at s_rec[wave][f][r] (0 voxel | mode, 1 measurement
   // weight, 2 voxel weight after the update, 3 u, 4 v), so the five stores of a record differ by immediate offsets
   __shared__ uint32_t s_rec[4][5][kFuseCap];
@@ -292,14 +288,12 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
   const float fxfy = a.fx * a.fy;
   const float den = a.trunc - a.dropoff_eps;  // weight drop-off denominator (uniform)
   const float yden = rcpRefined(den);
-  const char* const quad_b = reinterpret_cast<const char*>(a.rquad);
-  const uint32_t W16 = static_cast<uint32_t>(a.W) * 16u;
+  const char* const range_b = reinterpret_cast<const char*>(a.range);
+  const uint32_t W4 = static_cast<uint32_t>(a.W) * 4u;
   const uint32_t nc0 = list.counts[0], nc1 = nc0 + list.counts[1], nc2 = nc1 + list.counts[2], n_items = nc2 + list.counts[3];
   uint32_t n_upd = 0, n_band = 0;
   const int dbg = DBG ? a.dbg : 0;
   const uint32_t n_waves = gridDim.x * 4u;
-  // lane -> (x group, y, z slice of the item)
-  const int lx = (lane % XG) * kVL, ly = (lane / XG) % VPS, lz = lane / (XG * VPS);
   // descriptor of item i in deal order: class 0, 1, 2, 3 (FuseList)
   auto descOf = [&](uint32_t i) -> uint4 {
     if (i < nc0) return list.a[i];
@@ -308,28 +302,38 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
     return list.b[list.cap - 1u - (i - nc2)];
   };
 
-  // ---- phase 1: geometry of the lane's 4 voxels; their loads issued ----
-  auto phase1 = [&](FuseItem& it, const uint4 desc) {
+  // ---- phase 1: geometry of the item's ZR voxels per lane; all their loads issued ----
+  auto phase1 = [&](FuseItem<VPS, ZR>& it, const uint4 desc) {
     const uint32_t dx = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(desc.x)));
     it.slot = dx & 0xffffffu;
     it.sbi = static_cast<int>(dx >> 24);
     const int bx = __builtin_amdgcn_readfirstlane(static_cast<int>(desc.y));
     const int by = __builtin_amdgcn_readfirstlane(static_cast<int>(desc.z));
     const int bz = __builtin_amdgcn_readfirstlane(static_cast<int>(desc.w));
-    const int iz = it.sbi * ZW + lz;
-    const float ox = static_cast<float>(bx) * a.bs, oy = static_cast<float>(by) * a.bs, oz = static_cast<float>(bz) * a.bs;
-    it.lin0 = static_cast<uint32_t>(lx + VPS * (ly + VPS * iz));
-    const float py = oy + (static_cast<float>(ly) + 0.5f) * a.vs;
-    const float pz = oz + (static_cast<float>(iz) + 0.5f) * a.vs;
+    const int patch = it.sbi % PATCHES;
+    it.z0 = (it.sbi / PATCHES) * ZR;
+    const float ox = static_cast<float>(bx) * a.bs, oy = static_cast<float>(by) * a.bs;
+    it.oz = static_cast<float>(bz) * a.bs;
+    it.lin_xy = patch * 64 + lane;
+    const int ix = it.lin_xy % VPS, iy = it.lin_xy / VPS;
+    const float px = ox + (static_cast<float>(ix) + 0.5f) * a.vs;
+    const float py = oy + (static_cast<float>(iy) + 0.5f) * a.vs;
+    float pxy[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pxy[c] = a.R[3 * c] * px + a.R[3 * c + 1] * py;
+    it.pxy2 = pxy[2];
+    // per-item bases in SGPRs + 32-bit unsigned byte offsets per lane: the loads / stores take the
+    // `global_* v, v_off, s[base]` form (no 64-bit address arithmetic in VGPRs)
     const char* const dist_b = reinterpret_cast<const char*>(a.dist + it.slot * NV);
     const char* const wgt_b = reinterpret_cast<const char*>(a.weight + it.slot * NV);
-    bool any_ok = false;
 #pragma unroll
-    for (int j = 0; j < kVL; ++j) {
-      const float px = ox + (static_cast<float>(lx + j) + 0.5f) * a.vs;
+    for (int k = 0; k < ZR; ++k) {
+      const int iz = it.z0 + k;
+      const uint32_t lin = static_cast<uint32_t>(it.lin_xy + iz * SL);
+      const float pz = it.oz + (static_cast<float>(iz) + 0.5f) * a.vs;
       float pc[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) pc[c] = ((a.R[3 * c] * px + a.R[3 * c + 1] * py) + a.R[3 * c + 2] * pz) + a.t[c];
+      for (int c = 0; c < 3; ++c) pc[c] = (pxy[c] + a.R[3 * c + 2] * pz) + a.t[c];
       bool ok = pc[2] > 0.f;
       const float voxel_range = range_mode == 0 ? pc[2] : sqrtf((pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2]);
       ok = ok && !(voxel_range < a.min_range || voxel_range > a.max_range);
@@ -339,29 +343,30 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
       // ceil(u) >= W || floor(u) < 0  <=>  u > W - 1 || u < 0  (W - 1 is an integer-valued float); x - y >= 0 <=> x >= y
       // holds exactly in IEEE arithmetic, so the four tests are one min3 / min / compare
       ok = ok && (fminf(fminf(u, v), fminf(Wm1 - u, Hm1 - v)) >= 0.f);
-      // invalid voxels gather pixel (0, 0); valid ones have 0 <= u <= W - 1, so floor == truncation
+      // invalid lanes gather pixel (0, 0); valid lanes have 0 <= u <= W - 1, so floor == truncation
       const float uc = ok ? u : 0.f, vc = ok ? v : 0.f;
       const uint32_t u0 = static_cast<uint32_t>(static_cast<int>(uc)), v0 = static_cast<uint32_t>(static_cast<int>(vc));
-      uint32_t o0 = v0 * W16 + u0 * 16u;
-      if (DBG && (dbg & 8)) o0 = static_cast<uint32_t>(lane) * 16u;
-      it.q[j] = *reinterpret_cast<const float4*>(quad_b + o0);
-      it.u[j] = uc;
-      it.v[j] = vc;
-      it.z[j] = voxel_range;
-      it.depth[j] = range_mode == 0 ? 0.f : pc[2];  // (z-depth mode: the range IS the depth)
-      it.ok[j] = ok;
-      any_ok = any_ok || ok;
-    }
-    it.d4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    it.w4 = it.d4;
-    if (any_ok && !(DBG && (dbg & 4))) {
-      it.d4 = *reinterpret_cast<const float4*>(dist_b + it.lin0 * 4u);
-      it.w4 = *reinterpret_cast<const float4*>(wgt_b + it.lin0 * 4u);
+      const uint32_t v1 = min(v0 + 1u, static_cast<uint32_t>(a.H - 1));
+      uint32_t o0 = v0 * W4 + u0 * 4u, o1 = v1 * W4 + u0 * 4u;  // byte offsets of (u0, v0), (u0, v1)
+      if (DBG && (dbg & 8)) { o0 = static_cast<uint32_t>(lane) * 8u; o1 = o0 + W4; }
+      it.ra[k] = *reinterpret_cast<const f2u*>(range_b + o0);  // (u0, v0), (u0 + 1, v0)
+      it.rb[k] = *reinterpret_cast<const f2u*>(range_b + o1);  // (u0, v1), (u0 + 1, v1)
+      it.d[k] = 0.f;
+      it.w[k] = 0.f;
+      if (ok && !(DBG && (dbg & 4))) {
+        it.d[k] = *reinterpret_cast<const float*>(dist_b + lin * 4u);
+        it.w[k] = *reinterpret_cast<const float*>(wgt_b + lin * 4u);
+      }
+      it.u[k] = uc;
+      it.v[k] = vc;
+      it.z[k] = voxel_range;
+      it.yz[k] = yz;
+      it.ok[k] = ok;
     }
   };
 
   uint32_t item = blockIdx.x * 4u + static_cast<uint32_t>(wave);
-  FuseItem cur, nxt;
+  FuseItem<VPS, ZR> cur, nxt;
   uint4 d_next = make_uint4(0u, 0u, 0u, 0u);
   if (item < n_items) {
     phase1(cur, descOf(item));
@@ -385,26 +390,32 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
     char* const wgt_b = reinterpret_cast<char*>(a.weight + slot * NV);
     char* const lobs_b = reinterpret_cast<char*>(a.last_obs + slot * NV);
     uint32_t cnt = 0;       // records in this wave's LDS list
-    float dn[kVL] = {cur.d4.x, cur.d4.y, cur.d4.z, cur.d4.w}, wn[kVL] = {cur.w4.x, cur.w4.y, cur.w4.z, cur.w4.w};
-    bool okf[kVL];
-    bool any_lane = false;
+    bool touched = false;   // wave-uniform: some voxel of this item was updated
 #pragma unroll
-    for (int j = 0; j < kVL; ++j) {
-      bool ok = cur.ok[j];
-      okf[j] = false;
+    for (int k = 0; k < ZR; ++k) {
+      bool ok = cur.ok[k];
       if (DBG && (dbg & 16)) {
         n_upd += static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(ok)));
         continue;
       }
       if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
-      const uint32_t lin = cur.lin0 + static_cast<uint32_t>(j);
-      const float uc = cur.u[j], vc = cur.v[j], voxel_range = cur.z[j];
-      const float depth = range_mode == 0 ? voxel_range : cur.depth[j];
-      const float yz = rcpRefined(depth);  // (the same three instructions as in phase 1: cheaper than carrying the value)
+      const int iz = cur.z0 + k;
+      const uint32_t lin = static_cast<uint32_t>(cur.lin_xy + iz * SL);
+      const float uc = cur.u[k], vc = cur.v[k], voxel_range = cur.z[k], yz = cur.yz[k];
+      // range_mode 0: voxel_range is the voxel's depth; ray-length mode needs the depth again for the weight
+      float depth = voxel_range;
+      if (range_mode != 0) {
+        const float pz = cur.oz + (static_cast<float>(iz) + 0.5f) * a.vs;
+        depth = (cur.pxy2 + a.R[8] * pz) + a.t[2];
+      }
+      const uint32_t u0 = static_cast<uint32_t>(static_cast<int>(uc)), v0 = static_cast<uint32_t>(static_cast<int>(vc));
+      const uint32_t v1 = min(v0 + 1u, static_cast<uint32_t>(a.H - 1));
       const float du = __builtin_amdgcn_fractf(uc), dv = __builtin_amdgcn_fractf(vc);  // x - floor(x), exact for x >= 0
-      const float d_old = dn[j], w_old = wn[j];
-      // pixel order of the reference: (u0,v0) (u0,v1) (u1,v0) (u1,v1), clamped at the image border by the quad image
-      const float r0 = cur.q[j].x, r1 = cur.q[j].y, r2 = cur.q[j].z, r3 = cur.q[j].w;
+      const uint32_t o0 = v0 * W4 + u0 * 4u, o1 = v1 * W4 + u0 * 4u;
+      const float d_old = cur.d[k], w_old = cur.w[k];
+      // pixel order of the reference: (u0,v0) (u0,v1) (u1,v0) (u1,v1) with u1 = min(u0 + 1, W - 1)
+      const bool last_col = u0 >= static_cast<uint32_t>(a.W - 1);
+      const float r0 = cur.ra[k].x, r1 = cur.rb[k].x, r2 = last_col ? cur.ra[k].x : cur.ra[k].y, r3 = last_col ? cur.rb[k].x : cur.rb[k].y;
       bool use_nearest = interp == 0;
       if (interp == 2) {
         const float mn = fminf(fminf(r0, r1), fminf(r2, r3));
@@ -433,9 +444,9 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
           if (w2 > bw) { bw = w2; best = 2; }
           if (w3 > bw) { bw = w3; best = 3; }
         }
-        const int u0 = static_cast<int>(uc), v0 = static_cast<int>(vc);
-        const int ub = (best & 2) ? min(u0 + 1, a.W - 1) : u0, vb = (best & 1) ? min(v0 + 1, a.H - 1) : v0;
-        if (in_band && a.dyn[vb * a.W + ub] != 0) {
+        const uint32_t uo = ((best & 2) && !last_col) ? 4u : 0u;
+        const uint32_t bo = ((best & 1) ? o1 : o0) + uo;
+        if (in_band && *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.dyn) + bo) != 0) {
           ok = false;
           in_band = false;
         }
@@ -470,14 +481,14 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
         d_new = __builtin_fmaf(d_old, w_old, sdf_c * w) * __builtin_amdgcn_rcpf(tot);
       }
       const float w_new = fminf(tot, a.max_weight);
-      if (ok) {  // voxels without a measurement keep the value that was loaded
-        dn[j] = d_new;
-        wn[j] = w_new;
+      if (ok && !(DBG && (dbg & 2))) {
+        *reinterpret_cast<float*>(dist_b + lin * 4u) = d_new;
+        *reinterpret_cast<float*>(wgt_b + lin * 4u) = w_new;
+        if (a.with_tracking) *reinterpret_cast<uint64_t*>(lobs_b + lin * 8u) = a.stamp;
       }
-      okf[j] = ok;
-      any_lane = any_lane || ok;
       const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(ok), m_band = __builtin_amdgcn_ballot_w64(in_band);
       n_upd += static_cast<uint32_t>(__popcll(m_ok));
+      touched = touched || (m_ok != 0ull);
       if (m_band) {
         n_band += static_cast<uint32_t>(__popcll(m_band));
         if (in_band) {
@@ -491,25 +502,6 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
           rec[4 * kFuseCap] = __float_as_uint(vc);
         }
         cnt += static_cast<uint32_t>(__popcll(m_band));
-      }
-    }
-    // ---- stores: 16 bytes of distance and weight per lane (the lane loaded them whenever one of its voxels could be
-    //      valid); last_observed as 2 x 16 bytes when the whole lane is valid, per voxel otherwise ----
-    const bool touched = __builtin_amdgcn_ballot_w64(any_lane) != 0ull;
-    if (any_lane && !(DBG && (dbg & 2))) {
-      *reinterpret_cast<float4*>(dist_b + cur.lin0 * 4u) = make_float4(dn[0], dn[1], dn[2], dn[3]);
-      *reinterpret_cast<float4*>(wgt_b + cur.lin0 * 4u) = make_float4(wn[0], wn[1], wn[2], wn[3]);
-      if (a.with_tracking) {
-        ulonglong2* const lo = reinterpret_cast<ulonglong2*>(lobs_b + cur.lin0 * 8u);
-        if (okf[0] && okf[1] && okf[2] && okf[3]) {
-          lo[0] = make_ulonglong2(a.stamp, a.stamp);
-          lo[1] = make_ulonglong2(a.stamp, a.stamp);
-        } else {
-          uint64_t* const l1 = reinterpret_cast<uint64_t*>(lo);
-#pragma unroll
-          for (int j = 0; j < kVL; ++j)
-            if (okf[j]) l1[j] = a.stamp;
-        }
       }
     }
     const uint32_t item_band = cnt;

@@ -16,27 +16,9 @@ namespace khr {
 constexpr int kTile = 16;
 constexpr int kMaxTick = 8;  // camera frames batched per launch in the tick path (khr_tick_*)
 
-// range value of a depth sample (A.2: z-depth, or ray length in range_mode 1); 0 = invalid
-__device__ inline float rangeOfDepth(float d, int u, int v, float fx, float fy, float cx, float cy, int range_mode) {
-  float r = 0.f;
-  if (d > 0.f && isfinite(d)) {
-    if (range_mode == 0) {
-      r = d;
-    } else {
-      const float x = (static_cast<float>(u) - cx) / fx, y = (static_cast<float>(v) - cy) / fy;
-      r = d * sqrtf((x * x + y * y) + 1.f);
-    }
-  }
-  return r;
-}
-
-// one 16x16-pixel tile of one frame; returns this thread's (depth, range) for callers that go on with the pixel.
-// rquad: the four range samples an interpolation at (u + du, v + dv) reads, in the reference's pixel order
-// (u,v) (u,v1) (u1,v) (u1,v1) with u1 = min(u + 1, W - 1), v1 = min(v + 1, H - 1), as ONE 16-byte element per pixel: the
-// update kernel fetches a voxel's footprint with a single gather (its vector-memory instruction count is what bounds it).
+// one 16x16-pixel tile of one frame; returns this thread's (depth, range) for callers that go on with the pixel
 __device__ inline void ingestTile(const float* __restrict__ depth_in, const uint8_t* __restrict__ rgb_in,
                                   const int32_t* __restrict__ label_in, float* __restrict__ depth, float* __restrict__ range,
-                                  float4* __restrict__ rquad,
                                   uint32_t* __restrict__ rgba, int32_t* __restrict__ label, int32_t* __restrict__ dyn,
                                   float* __restrict__ tile_max, int tile, int tw, int W, int H, float fx, float fy, float cx,
                                   float cy, int range_mode, float* d_out, float* r_out) {
@@ -46,12 +28,14 @@ __device__ inline void ingestTile(const float* __restrict__ depth_in, const uint
   if (u < W && v < H) {
     const int i = v * W + u;
     d = depth_in[i];
-    r = rangeOfDepth(d, u, v, fx, fy, cx, cy, range_mode);
-    const int u1 = min(u + 1, W - 1), v1 = min(v + 1, H - 1);
-    const float r01 = rangeOfDepth(depth_in[v1 * W + u], u, v1, fx, fy, cx, cy, range_mode);
-    const float r10 = rangeOfDepth(depth_in[v * W + u1], u1, v, fx, fy, cx, cy, range_mode);
-    const float r11 = rangeOfDepth(depth_in[v1 * W + u1], u1, v1, fx, fy, cx, cy, range_mode);
-    rquad[i] = make_float4(r, r01, r10, r11);
+    if (d > 0.f && isfinite(d)) {
+      if (range_mode == 0) {
+        r = d;
+      } else {
+        const float x = (static_cast<float>(u) - cx) / fx, y = (static_cast<float>(v) - cy) / fy;
+        r = d * sqrtf((x * x + y * y) + 1.f);
+      }
+    }
     depth[i] = d;
     range[i] = r;
     dyn[i] = 0;
@@ -74,7 +58,7 @@ __device__ inline void ingestTile(const float* __restrict__ depth_in, const uint
 __global__ __launch_bounds__(256) void k_frame_ingest(const float* __restrict__ depth_in,
                                                      const uint8_t* __restrict__ rgb_in,
                                                      const int32_t* __restrict__ label_in, float* __restrict__ depth,
-                                                     float* __restrict__ range, float4* __restrict__ rquad, uint32_t* __restrict__ rgba,
+                                                     float* __restrict__ range, uint32_t* __restrict__ rgba,
                                                      int32_t* __restrict__ label, int32_t* __restrict__ dyn,
                                                      float* __restrict__ tile_max, int tw, int W, int H, float fx,
                                                      float fy, float cx, float cy, int range_mode, DevMap m, int nvox,
@@ -82,7 +66,7 @@ __global__ __launch_bounds__(256) void k_frame_ingest(const float* __restrict__ 
   if (blockIdx.x == 0 && threadIdx.x == 0) m.counters[C_N_SEEDS] = 0u;
   if (do_begin && blockIdx.x == 0) beginIntegrate(m, nvox, wg_stats);  // khr_process_frame: saves a launch
   float d, r;
-  ingestTile(depth_in, rgb_in, label_in, depth, range, rquad, rgba, label, dyn, tile_max, blockIdx.x, tw, W, H, fx, fy, cx, cy,
+  ingestTile(depth_in, rgb_in, label_in, depth, range, rgba, label, dyn, tile_max, blockIdx.x, tw, W, H, fx, fy, cx, cy,
              range_mode, &d, &r);
 }
 
@@ -96,7 +80,6 @@ struct TickIngest {
   const int32_t* label_in[kMaxTick];
   float* depth[kMaxTick];
   float* range[kMaxTick];
-  float4* rquad[kMaxTick];
   uint32_t* rgba[kMaxTick];
   int32_t* label[kMaxTick];
   int32_t* dyn[kMaxTick];
@@ -109,7 +92,7 @@ __global__ __launch_bounds__(256) void k_tick_ingest(TickIngest t, int tw, int W
   const int cam = blockIdx.y;
   if (blockIdx.x == 0 && cam == 0 && threadIdx.x == 0) m.counters[C_N_SEEDS] = 0u;
   float d, r;
-  ingestTile(t.depth_in[cam], t.rgb_in[cam], t.label_in[cam], t.depth[cam], t.range[cam], t.rquad[cam], t.rgba[cam], t.label[cam], t.dyn[cam],
+  ingestTile(t.depth_in[cam], t.rgb_in[cam], t.label_in[cam], t.depth[cam], t.range[cam], t.rgba[cam], t.label[cam], t.dyn[cam],
              t.tile_max[cam], blockIdx.x, tw, W, H, fx, fy, cx, cy, range_mode, &d, &r);
   if (!count_seeds) return;
   const int u = (blockIdx.x % tw) * kTile + (threadIdx.x & 15), v = (blockIdx.x / tw) * kTile + (threadIdx.x >> 4);

@@ -56,7 +56,6 @@ int fail(int code, const char* fmt, ...) {
 struct FrameSlot {
   float* depth = nullptr;
   float* range = nullptr;
-  float4* rquad = nullptr;
   uint32_t* rgba = nullptr;
   int32_t* label = nullptr;
   int32_t* dyn = nullptr;
@@ -128,6 +127,7 @@ struct khr_ctx {
   uint4* d_tick_work4 = nullptr;  // tick path: two arrays per camera
   uint32_t item_cap = 0;          // max_blocks x wave items per block
   uint32_t wpb = 0;               // wave items per block of this context's k_fuse instantiation
+  int fuse_zsplit = 2;            // z ranges per x-y patch of that instantiation
   // remote halo (multi-GPU): records gathered from the other ranks + their index
   uint64_t* d_halo_recs = nullptr;
   const uint64_t* halo_view = nullptr;  // records in use: d_halo_recs, or the caller's device buffer (imported in place)
@@ -365,7 +365,6 @@ DevFrame makeDevFrame(const khr_ctx* c, const FrameSlot& s) {
   DevFrame f{};
   f.depth = s.depth;
   f.range = s.range;
-  f.rquad = s.rquad;
   f.rgba = s.rgba;
   f.label = s.label;
   f.dyn = s.dyn;
@@ -441,6 +440,7 @@ int dispatchVps(khr_ctx* c, F&& f) {
 }
 
 int kFuseGrid = 0;      // 0 = resident workgroups of the instantiation (occupancy query) x CUs; env KHR_FUSE_GRID
+int kFuseZsplit = 0;    // 0 = by world size (wave items per x-y patch of a block: 2 / 4 / 8); env KHR_FUSE_ZSPLIT
 int kFuseExact = -1;    // -1 = khr_config.exact_arithmetic; env KHR_FUSE_EXACT=0/1 overrides (A/B switch)
 int kFuseMinw = 0;      // env KHR_FUSE_MINW: register budget of the default instantiation (1 none, 4, 6 waves / SIMD)
 int kFuseDbg = 0;       // env KHR_FUSE_DBG: ablation switches (development; selects the DBG instantiation)
@@ -651,6 +651,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   p.world = cfg->world_size;
   p.dbg = std::getenv("KHR_DEBUG") ? std::atoi(std::getenv("KHR_DEBUG")) : 0;
   if (std::getenv("KHR_FUSE_GRID")) kFuseGrid = std::max(8, std::min(kFuseStatSlots, std::atoi(std::getenv("KHR_FUSE_GRID"))));
+  if (std::getenv("KHR_FUSE_ZSPLIT")) kFuseZsplit = std::atoi(std::getenv("KHR_FUSE_ZSPLIT"));
   if (std::getenv("KHR_FUSE_EXACT")) kFuseExact = std::atoi(std::getenv("KHR_FUSE_EXACT")) ? 1 : 0;
   if (std::getenv("KHR_FUSE_MINW")) kFuseMinw = std::atoi(std::getenv("KHR_FUSE_MINW"));
   if (std::getenv("KHR_FUSE_DBG")) kFuseDbg = std::atoi(std::getenv("KHR_FUSE_DBG"));
@@ -688,9 +689,15 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &c->d_trk_proc, cap));
   A(devAlloc(c, &c->d_dbg, 4096 * 4 * 12));
   A(devAlloc(c, &c->d_wg_stats, 2 * kFuseStatSlots));
-  // wave items per block of k_fuse: 256 voxels each
-  c->wpb = static_cast<uint32_t>(p.nvox / 256);
-  c->item_cap = static_cast<uint32_t>(cap) * c->wpb;
+  {
+    int zs = kFuseZsplit;
+    if (zs == 0) zs = cfg->world_size >= 4 ? 8 : 4;
+    if (zs != 4 && zs != 8) zs = 4;  // a wave item is a 64-voxel patch x 4 (or 2) z steps
+    if (cfg->voxels_per_side == 8) zs = 4;
+    c->fuse_zsplit = zs;
+    c->wpb = static_cast<uint32_t>((cfg->voxels_per_side * cfg->voxels_per_side / 64) * zs);
+    c->item_cap = static_cast<uint32_t>(cap) * c->wpb;
+  }
   A(devAlloc(c, &c->d_work4, 2 * static_cast<size_t>(c->item_cap), false));
   A(devAlloc(c, &m.blk_band, cap * kBandSlots));
   A(devAlloc(c, &c->d_removed, cap));
@@ -767,8 +774,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   for (auto& s : c->slots) {
     if (rc != KHR_OK) break;
     A(devAlloc(c, &s.depth, npx, false));
-    A(devAlloc(c, &s.range, npx, false));
-    A(devAlloc(c, &s.rquad, npx, false));
+    A(devAlloc(c, &s.range, npx + 4, false));  // + pad: k_fuse gathers pixel pairs (u0, u0 + 1) with one 8-byte load
     A(devAlloc(c, &s.rgba, npx, false));
     A(devAlloc(c, &s.label, npx, false));
     A(devAlloc(c, &s.dyn, npx));
@@ -926,7 +932,7 @@ int khr_upload_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fram
   s.tw = (sensor->width + kTile - 1) / kTile;
   s.th = (sensor->height + kTile - 1) / kTile;
   hipLaunchKernelGGL(k_frame_ingest, dim3(s.tw * s.th), dim3(256), 0, ist, depth_src, rgb_src, label_src, s.depth,
-                     s.range, s.rquad, s.rgba, s.label, s.dyn, s.tile_max, s.tw, sensor->width, sensor->height, sensor->fx, sensor->fy,
+                     s.range, s.rgba, s.label, s.dyn, s.tile_max, s.tw, sensor->width, sensor->height, sensor->fx, sensor->fy,
                      sensor->cx, sensor->cy, c->p.range_mode, c->m, c->p.nvox, c->d_wg_stats, c->begin_in_ingest ? 1 : 0);
   HIP_TRY(hipGetLastError());
   c->begun = c->begin_in_ingest;
@@ -1070,7 +1076,7 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
   a.blk_index = m.blk_index; a.blk_flags = m.blk_flags; a.dist = m.dist; a.weight = m.weight; a.last_obs = m.last_obs;
   a.color = m.color; a.vflags = m.vflags; a.sem_label = m.sem_label; a.lik = m.lik; a.wg_stats = c->d_wg_stats;
   a.blk_band = m.blk_band;
-  a.rquad = f.rquad; a.dyn = f.dyn; a.rgba = f.rgba; a.label = f.label; a.obj = f.obj;
+  a.range = f.range; a.dyn = f.dyn; a.rgba = f.rgba; a.label = f.label; a.obj = f.obj;
   a.W = f.W; a.H = f.H; a.fx = f.fx; a.fy = f.fy; a.cx = f.cx; a.cy = f.cy; a.min_range = f.min_range; a.max_range = f.max_range;
   std::memcpy(a.R, f.R, sizeof(a.R));
   std::memcpy(a.t, f.t, sizeof(a.t));
@@ -1087,25 +1093,38 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
   const bool exact = kFuseExact >= 0 ? kFuseExact != 0 : c->cfg.exact_arithmetic != 0;
   int rc = dispatchVps(c, [&](auto vps) {
     constexpr int V = decltype(vps)::value;
-    auto go = [&](auto kern) {
-      const int grid = fuseGrid(c, reinterpret_cast<const void*>(kern), 1);
-      static bool said = false;
-      if (!said && std::getenv("KHR_VERBOSE")) { said = true; std::fprintf(stderr, "[khr] k_fuse<%d> grid %d\n", V, grid); }
-      KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(256), a, list);
+    auto launch = [&](auto zsplit) {
+      constexpr int ZS = decltype(zsplit)::value;
+      constexpr int G = 1;
+      auto go = [&](auto kern) {
+        const int grid = fuseGrid(c, reinterpret_cast<const void*>(kern), G);
+        static bool said = false;
+        if (!said && std::getenv("KHR_VERBOSE")) { said = true; std::fprintf(stderr, "[khr] k_fuse<%d,%d> grid %d\n", V, ZS, grid); }
+        KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(256), a, list);
+      };
+      // non-default switches are test configurations: they always run the bit-exact arithmetic
+      a.dbg = kFuseDbg;
+      a.dbg_buf = c->d_dbg;
+      if (defcfg && !exact && kFuseDbg && V == 16) {
+        go(&k_fuse<V, ZS, true, false, 1, (V == 16)>);
+      } else if (defcfg && !exact) {
+        if (V == 16 && kFuseMinw == 5) go(&k_fuse<V, ZS, true, false, (V == 16 ? 5 : 1)>);
+        else if (V == 16 && kFuseMinw == 4) go(&k_fuse<V, ZS, true, false, (V == 16 ? 4 : 1)>);
+        else go(&k_fuse<V, ZS, true, false, 1>);
+      } else if (defcfg) {
+        go(&k_fuse<V, ZS, true, true, 1>);
+      } else {
+        go(&k_fuse<V, ZS, false, true, 1>);
+      }
     };
-    a.dbg = kFuseDbg;
-    a.dbg_buf = c->d_dbg;
-    // non-default switches are test configurations: they always run the bit-exact arithmetic
-    if (defcfg && !exact && kFuseDbg && V == 16) {
-      go(&k_fuse<V, true, false, 1, (V == 16)>);
-    } else if (defcfg && !exact) {
-      if (V == 16 && kFuseMinw == 4) go(&k_fuse<V, true, false, (V == 16 ? 4 : 1)>);
-      else if (V == 16 && kFuseMinw == 3) go(&k_fuse<V, true, false, (V == 16 ? 3 : 1)>);
-      else go(&k_fuse<V, true, false, 1>);
-    } else if (defcfg) {
-      go(&k_fuse<V, true, true, 1>);
+    // a shard of a sharded map sees 1 / world of every frame's blocks: shorter z ranges per wave keep the number of
+    // wave items (and with it the number of busy SIMDs) up
+    const int zs = c->fuse_zsplit;
+    if (V == 8) {
+      launch(std::integral_constant<int, 4>());
     } else {
-      go(&k_fuse<V, false, true, 1>);
+      if (zs == 8) launch(std::integral_constant<int, (V == 16 ? 8 : 4)>());
+      else launch(std::integral_constant<int, 4>());
     }
     return KHR_OK;
   });
@@ -1296,7 +1315,7 @@ int khr_tick_ingest(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame
       s.dyn_clean = true;
       slots_out[base + k] = slot;
       t.depth_in[k] = fr.depth; t.rgb_in[k] = fr.color; t.label_in[k] = fr.label;
-      t.depth[k] = s.depth; t.range[k] = s.range; t.rquad[k] = s.rquad; t.rgba[k] = s.rgba; t.label[k] = s.label; t.dyn[k] = s.dyn;
+      t.depth[k] = s.depth; t.range[k] = s.range; t.rgba[k] = s.rgba; t.label[k] = s.label; t.dyn[k] = s.dyn;
       t.tile_max[k] = s.tile_max;
       float R[9], tt[3];
       makePose(fr.world_T_sensor, R, tt, t.Rw[k], t.tw[k]);

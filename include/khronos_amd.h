@@ -213,6 +213,11 @@ int khr_integrate(khr_ctx* ctx, int slot, int allocate_blocks, int use_mask, int
  * MeshObjectExtractor re-integrate the frames buffered by the active window (mesh_object_extractor.cpp:239-243,
  * FrameDataBuffer role) without copying them. */
 int khr_integrate_shared(khr_ctx* ctx, khr_ctx* src, int src_slot, int allocate_blocks, int use_mask, int object_id);
+/* the same for n frames of `src` in the order given (the loop of mesh_object_extractor.cpp:239-243 as ONE call): with
+ * allocate_blocks == 0 the block list and the per-call bookkeeping are set up once for all frames, so that a frame costs
+ * one kernel launch.  object_ids may be NULL (= -1 for every frame).  Results are identical to n khr_integrate_shared calls. */
+int khr_integrate_shared_batch(khr_ctx* ctx, khr_ctx* src, const int* src_slots, const int* object_ids, int n_frames,
+                               int allocate_blocks, int use_mask);
 /* replaces: TrackingIntegrator::updateBlocks (tracking_integrator.cpp:71-104) */
 int khr_update_tracking(khr_ctx* ctx, uint64_t timestamp_ns);
 /* The two halves of khr_update_tracking, for multi-GPU runs (phase 1 = per-voxel tracking update over all

@@ -72,7 +72,7 @@ EXPORTS = [
     "khr_detect_motion", "khr_generate_mesh", "khr_reset_inactive", "khr_mark_all_inactive", "khr_clear_updated",
     "khr_allocate_blocks", "khr_object_prune", "khr_get_stats", "khr_num_blocks", "khr_block_indices",
     "khr_download_block", "khr_mesh_num_vertices", "khr_download_mesh", "khr_timing_enable", "khr_timing_reset",
-    "khr_timing_get", "khr_debug_read", "khr_tick_ingest", "khr_tick_integrate", "khr_tick_seed_counts", "khr_copy_frame_image", "khr_rv_detect_changes", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_update_tracking_phase",
+    "khr_timing_get", "khr_debug_read", "khr_tick_ingest", "khr_tick_integrate", "khr_tick_seed_counts", "khr_copy_frame_image", "khr_rv_detect_changes", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_integrate_shared_batch", "khr_update_tracking_phase",
     "khr_export_halo", "khr_import_halo", "khr_get_dynamic_clusters", "khr_motion_keys",
     "khr_detect_motion_from_keys", "khr_download_updated", "khr_mesh_halo_requests", "khr_mesh_halo_export",
     "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",

@@ -236,7 +236,7 @@ __device__ inline void cullBlocks(const DevMap& m, const DevParams& p, const Dev
                                   uint32_t bid, uint32_t nblk) {
   // each workgroup tests kPerWg blocks (one wave per block, 4 rounds), gathers the survivors' items in LDS and
   // appends them with one atomic per class (hot-address atomics are expensive)
-  constexpr int kPerWg = 16;
+  constexpr int kPerWg = 8;
   __shared__ uint4 s_blk[kPerWg];                     // {slot, block index} of the survivors
   __shared__ uint16_t s_item[4][kPerWg * kBandSlots];  // per class: survivor << 8 | item
   __shared__ uint32_t s_nkeep, s_ccnt[4], s_off[4];

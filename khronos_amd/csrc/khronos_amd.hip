@@ -1164,6 +1164,44 @@ int khr_integrate_shared(khr_ctx* c, khr_ctx* src, int src_slot, int allocate_bl
   return integrateUpdate(c, s, f, allocate_blocks, use_mask, object_id);
 }
 
+int khr_integrate_shared_batch(khr_ctx* c, khr_ctx* src, const int* src_slots, const int* object_ids, int n_frames,
+                               int allocate_blocks, int use_mask) {
+  if (!c || !src || !src_slots || n_frames < 0) return fail(KHR_EINVAL, "bad argument");
+  for (int i = 0; i < n_frames; ++i)
+    if (src_slots[i] < 0 || src_slots[i] >= static_cast<int>(src->slots.size()) || !src->slots[src_slots[i]].valid)
+      return fail(KHR_EINVAL, "bad source slot");
+  if (c->device != src->device) return fail(KHR_EINVAL, "contexts live on different devices");
+  if (n_frames == 0) return KHR_OK;
+  if (allocate_blocks) {  // the frustum differs per frame: nothing to share
+    for (int i = 0; i < n_frames; ++i) {
+      const int rc = khr_integrate_shared(c, src, src_slots[i], 1, use_mask, object_ids ? object_ids[i] : -1);
+      if (rc) return rc;
+    }
+    return KHR_OK;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->dep_src != src) {
+    if (c->stream != src->stream) HIP_TRY(hipStreamSynchronize(src->stream));
+    HIP_TRY(hipStreamSynchronize(src->aux_stream));
+  }
+  // "blocks = all allocated" (updateMap(allocate = false)): one list for all frames; the integrator never allocates or
+  // frees blocks, so it stays valid
+  {
+    FrameSlot& s0 = src->slots[src_slots[0]];
+    const DevFrame f0 = makeDevFrame(src, s0);
+    const int rc = integrateAlloc(c, s0, f0, 0);
+    if (rc) return rc;
+  }
+  for (int i = 0; i < n_frames; ++i) {
+    FrameSlot& s = src->slots[src_slots[i]];
+    const DevFrame f = makeDevFrame(src, s);
+    const int rc = integrateUpdate(c, s, f, 0, use_mask, object_ids ? object_ids[i] : -1);
+    if (rc) return rc;
+  }
+  // (statistics: cum_integrate_calls counts this batch once; the voxel counts cover all its frames)
+  return KHR_OK;
+}
+
 // smallest unsigned x with  double(x) / 1e9 >= T  (T = toSeconds(now) - window, reference arithmetic:
 // tracking_integrator.cpp:238,250).  fl(double(x)/1e9) is non-decreasing in x, so a binary search is exact.
 static uint64_t stampThreshold(double T) {

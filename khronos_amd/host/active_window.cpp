@@ -121,6 +121,34 @@ MeshObjectExtractor::MeshObjectExtractor(const Config& cfg, const khr_config& aw
     throw std::invalid_argument("object volume limits are inconsistent");
   if (config.min_dynamic_displacement < 0 || config.min_reconstruction_resolution < 0)
     throw std::invalid_argument("negative displacement / resolution");
+  // The private object map is created HERE, once (hipMalloc / hipFree synchronise the whole device: creating it at the
+  // first extraction stalled the active window for ~6 ms in the middle of the stream); extractions re-scale and empty it
+  // (khr_reset_map).  It only grows when an object needs more blocks than it holds.
+  if (aw_device_config.max_frame_pixels > 0) {
+    khr_config oc = objectMapConfig(0.05f);
+    oc.max_blocks = 4096;
+    oc.max_mesh_vertices = std::max<uint64_t>(1u << 16, static_cast<uint64_t>(oc.max_blocks) * 512ull * 15ull / 4);
+    if (khr_create(&oc, &object_ctx_) == KHR_OK) object_ctx_blocks_ = oc.max_blocks;
+    else object_ctx_ = nullptr;  // (no device yet: created on first use)
+  }
+}
+
+khr_config MeshObjectExtractor::objectMapConfig(float voxel_size) const {
+  // private map (mesh_object_extractor.cpp:201-215): vps 8, truncation 2 voxels, binary semantics, no tracking
+  khr_config oc = device_config_;
+  oc.voxel_size = voxel_size;
+  oc.voxels_per_side = 8;
+  oc.truncation_distance = oc.voxel_size * 2;
+  oc.with_semantics = 1;
+  oc.with_tracking = 0;
+  oc.num_labels = 2;
+  oc.semantic_mode = 1;
+  oc.num_frame_slots = 1;
+  oc.max_frame_pixels = 4;
+  oc.exact_arithmetic = device_config_.exact_arithmetic;
+  oc.rank = 0;
+  oc.world_size = 1;
+  return oc;
 }
 
 MeshObjectExtractor::~MeshObjectExtractor() {
@@ -216,21 +244,9 @@ std::shared_ptr<KhronosObjectAttributes> MeshObjectExtractor::extractStaticObjec
   if (frames.empty()) return nullptr;
   if (extent.volume() < config.min_object_volume) return nullptr;
 
-  // private map (mesh_object_extractor.cpp:201-215): vps 8, truncation 2 voxels, binary semantics, no tracking
-  khr_config oc = device_config_;
-  oc.voxel_size = objectVoxelSize(config, extent);
-  if (!(oc.voxel_size > 0.f)) return nullptr;  // config::isValid(map_config)
-  oc.voxels_per_side = 8;
-  oc.truncation_distance = oc.voxel_size * 2;
-  oc.with_semantics = 1;
-  oc.with_tracking = 0;
-  oc.num_labels = 2;
-  oc.semantic_mode = 1;
-  oc.num_frame_slots = 1;
-  oc.max_frame_pixels = 4;
-  oc.exact_arithmetic = device_config_.exact_arithmetic;
-  oc.rank = 0;
-  oc.world_size = 1;
+  const float ovs = objectVoxelSize(config, extent);
+  if (!(ovs > 0.f)) return nullptr;  // config::isValid(map_config)
+  khr_config oc = objectMapConfig(ovs);
   int32_t mn[3], mx[3];
   objectBlockRange(extent, oc.voxel_size * 8.f, mn, mx);
   std::vector<int32_t> idx;
@@ -260,10 +276,18 @@ std::shared_ptr<KhronosObjectAttributes> MeshObjectExtractor::extractStaticObjec
   std::shared_ptr<KhronosObjectAttributes> object;
   try {
     chk(khr_allocate_blocks(octx, idx.data(), static_cast<int64_t>(n_blocks)), "khr_allocate_blocks");  // :218-228
-    // projective re-integration of every buffered frame with the binary object label (:239-243)
-    for (const auto& fr : frames)
-      chk(khr_integrate_shared(octx, fr.first->input.ctx, fr.first->input.slot, /*allocate=*/0, /*use_mask=*/0, fr.second),
-          "khr_integrate_shared");
+    // projective re-integration of every buffered frame with the binary object label (:239-243): one call, the block
+    // list and the per-call bookkeeping are set up once for all frames
+    {
+      std::vector<int> slots, ids;
+      for (const auto& fr : frames) {
+        slots.push_back(fr.first->input.slot);
+        ids.push_back(fr.second);
+      }
+      chk(khr_integrate_shared_batch(octx, frames.front().first->input.ctx, slots.data(), ids.data(), static_cast<int>(slots.size()),
+                                     /*allocate=*/0, /*use_mask=*/0),
+          "khr_integrate_shared_batch");
+    }
     // erase low-confidence voxels (:246-264)
     int64_t pruned = 0;
     if (!config.visualize_classification)

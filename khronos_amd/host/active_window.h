@@ -286,6 +286,7 @@ class MeshObjectExtractor : public ObjectExtractor {  // mesh_object_extractor.h
   khr_config device_config_;
   // the object mini-map is one device context that is emptied and re-scaled per object (khr_reset_map) instead of a
   // new VolumetricMap per object: creating / destroying an HBM pool costs milliseconds, the reset one small kernel
+  khr_config objectMapConfig(float voxel_size) const;
   mutable khr_ctx* object_ctx_ = nullptr;
   mutable uint32_t object_ctx_blocks_ = 0;
 };

@@ -421,6 +421,7 @@ ActiveWindow::Config ActiveWindow::Config::fromYaml(const khronos_amd::YamlNode&
     m->read("rank", c.rank);
     m->read("world_size", c.world_size);
     m->read("exact_arithmetic", c.exact_arithmetic);
+    m->read("timing_sync_device", c.timing_sync_device);
   }
   return c;
 }
@@ -499,6 +500,10 @@ ActiveWindow::ActiveWindow(const Config& cfg) : config(cfg), frame_data_buffer_(
   d.world_size = config.world_size;
   d.exact_arithmetic = config.exact_arithmetic;
   chk(khr_create(&d, &ctx_), "khr_create");
+  if (config.timing_sync_device) {
+    khr_ctx* const sc = ctx_;
+    hydra::timing::ElapsedTimeRecorder::instance().sync_device = [sc]() { khr_sync(sc); };
+  }
   map_ = VolumetricMap(config.volumetric_map, ctx_);
 
   // member processors as specified in the config; absent ones are the no-op bases (active_window.cpp:83-99)
@@ -526,6 +531,7 @@ ActiveWindow::ActiveWindow(const Config& cfg) : config(cfg), frame_data_buffer_(
 }
 
 ActiveWindow::~ActiveWindow() {
+  hydra::timing::ElapsedTimeRecorder::instance().sync_device = nullptr;
   // buffered frames hold leases on frame slots of the context: they go first (frames a sink copied must not outlive the
   // window either)
   frame_data_buffer_.clear();
@@ -548,7 +554,10 @@ void ActiveWindow::addKhronosSink(const KhronosSink& sink) {
   if (sink) sinks_.push_back(sink);
 }
 
+using Timer = hydra::timing::ScopedTimer;
+
 std::shared_ptr<FrameData> ActiveWindow::createData(const hydra::InputPacket& input) const {
+  Timer timer("active_window/create_data", latest_stamp_);  // active_window.cpp:269
   // active_window.cpp:268-286: normalise the packet (device: range image, rgba, tiles) and allocate the
   // dynamic / object images (zeroed in the frame slot)
   auto data = std::make_shared<FrameData>();
@@ -574,13 +583,18 @@ std::shared_ptr<FrameData> ActiveWindow::createData(const hydra::InputPacket& in
 
 void ActiveWindow::updateMap(const FrameData& data) {
   // active_window.cpp:203-215: mask = dynamic_image != 0, integrate with allocation, then tracking update
+  Timer timer("active_window/update_map", latest_stamp_, config.timing_sync_device);  // :204
   chk(khr_integrate(ctx_, data.input.slot, /*allocate=*/1, /*use_mask=*/1, /*object_id=*/-1), "khr_integrate");
-  chk(khr_update_tracking(ctx_, data.input.timestamp_ns), "khr_update_tracking");
+  {
+    Timer t2("integration/tracking", data.input.timestamp_ns, config.timing_sync_device);  // tracking_integrator.cpp:72
+    chk(khr_update_tracking(ctx_, data.input.timestamp_ns), "khr_update_tracking");
+  }
 }
 
 hydra::ActiveWindowOutput::Ptr ActiveWindow::spinOnce(const hydra::InputPacket& input) {
   std::lock_guard<std::mutex> lock(mutex_);
   latest_stamp_ = input.timestamp_ns;
+  Timer timer("active_window/all", latest_stamp_, config.timing_sync_device);  // active_window.cpp:121
   // Reference order (active_window.cpp:124-137): data -> motion -> objects -> tracker -> updateMap.  The object
   // detector and tracker are host plugins that neither read nor write what the integration reads, so the
   // device work (normalise, motion detection, integration, tracking) is queued first and they run while the
@@ -606,7 +620,11 @@ hydra::ActiveWindowOutput::Ptr ActiveWindow::spinOnce(const hydra::InputPacket& 
     f.label = input.labels;
     const uint32_t flags = KHR_PF_TRACKING | (motion_detector_->isDeviceBacked() ? KHR_PF_MOTION : 0u);
     int n_clusters = 0;
+    // create_data + motion_detection/all + update_map (+ integration/tracking) of the reference are ONE fused device call
+    // here; the scope is recorded under the reference's outer name
+    Timer t_map("active_window/update_map", latest_stamp_, config.timing_sync_device);
     in.slot = khr_process_frame(ctx_, &s, &f, input.on_device ? 1 : 0, flags, &n_clusters);
+    t_map.stop();
     if (in.slot < 0) return nullptr;  // "Input packet preprocessing failed. Skipping frame." (:276-279)
     in.retainSlot();
     data->num_dynamic_clusters = n_clusters;
@@ -614,16 +632,28 @@ hydra::ActiveWindowOutput::Ptr ActiveWindow::spinOnce(const hydra::InputPacket& 
   } else {
     data = createData(input);
     if (!data) return nullptr;  // the reference dereferences unconditionally here (latent crash)
-    motion_detector_->processInput(map_, *data);
+    {
+      Timer t("motion_detection/all", latest_stamp_, config.timing_sync_device);  // free_space_motion_detector.cpp:75
+      motion_detector_->processInput(map_, *data);
+    }
     updateMap(*data);
   }
-  object_detector_->processInput(map_, *data);
-  tracker_->processInput(*data);
+  {
+    Timer t("object_detection/all", latest_stamp_);  // connected_semantics.cpp:61, instance_forwarding.cpp:75
+    object_detector_->processInput(map_, *data);
+  }
+  {
+    Timer t("tracking/all", latest_stamp_);  // max_iou_tracker.cpp:200, external_tracker.cpp:68
+    tracker_->processInput(*data);
+  }
 
   frame_data_buffer_.trimBuffer(tracker_->getTracks());
   frame_data_buffer_.storeData(data);
   ++num_frames_processed_;
-  for (const auto& sink : sinks_) sink(*data, map_, tracker_->getTracks());
+  {
+    Timer sink_timer("active_window/sinks", latest_stamp_);  // active_window.cpp:152
+    for (const auto& sink : sinks_) sink(*data, map_, tracker_->getTracks());
+  }
 
   if (last_full_upated_ + fromSeconds(config.min_output_separation) > latest_stamp_) return nullptr;  // :158-160
   auto output = extractOutputData(*data, config.detach_object_extraction);
@@ -635,6 +665,7 @@ hydra::ActiveWindowOutput::Ptr ActiveWindow::spinOnce(const hydra::InputPacket& 
 
 hydra::ActiveWindowOutput::Ptr ActiveWindow::extractOutputData(const FrameData& data, bool /*threaded*/) {
   // active_window.cpp:217-249
+  Timer timer("active_window/extract_output", latest_stamp_, config.timing_sync_device);  // :220
   chk(khr_generate_mesh(ctx_, 1, 1), "khr_generate_mesh");
   auto output = std::make_shared<hydra::ActiveWindowOutput>();
   output->timestamp_ns = data.input.timestamp_ns;

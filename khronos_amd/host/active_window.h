@@ -330,6 +330,9 @@ class ActiveWindow {
     uint64_t max_mesh_vertices = 8u << 20;
     int device = 0, rank = 0, world_size = 1;
     int exact_arithmetic = 0;  // khr_config.exact_arithmetic: voxel values bit-identical to the CPU restatement
+    // hydra::timing scopes (hydra_compat.h): wait for the device before a scope that launched device work stops, so that
+    // "active_window/all" is the per-frame latency the reference's timer measures (off: enqueue time only)
+    bool timing_sync_device = false;
 
     // parse the `active_window:` mapping of a Khronos mapper YAML (same keys as uHumans2.yaml:35-100)
     static Config fromYaml(const khronos_amd::YamlNode& active_window_node);

@@ -173,7 +173,7 @@ int main(int argc, char** argv) {
     }
   }
   if (argc < 5) {
-    std::fprintf(stderr, "usage: aw_demo <config.yaml> <width> <height> <frames> [object_label]\n");
+    std::fprintf(stderr, "usage: aw_demo <config.yaml> <width> <height> <frames> [object_label] [timing_stats.csv]\n");
     return 2;
   }
   std::ifstream in(argv[1]);
@@ -252,7 +252,17 @@ int main(int argc, char** argv) {
                   o.bounding_box.max[1], o.bounding_box.max[2]);
     }
     aw.finishMapping();
-    std::printf("], \"blocks_after_finish\": %zu}\n", aw.getMap().numBlocks());
+    std::printf("], \"blocks_after_finish\": %zu", aw.getMap().numBlocks());
+    // timing/stats.csv of the reference's experiment manager (experiment_manager.cpp:251-258), same scope names
+    if (argc > 6) hydra::timing::ElapsedTimeRecorder::instance().logStats(argv[6]);
+    std::printf(", \"timing\": {");
+    bool first_t = true;
+    for (const auto& kv : hydra::timing::ElapsedTimeRecorder::instance().stats()) {
+      std::printf("%s\"%s\": {\"count\": %llu, \"mean_ms\": %.4f}", first_t ? "" : ", ", kv.first.c_str(),
+                  static_cast<unsigned long long>(kv.second.count), 1e3 * kv.second.sum / static_cast<double>(kv.second.count));
+      first_t = false;
+    }
+    std::printf("}}\n");
     synth_destroy(scene);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "aw_demo: %s\n", e.what());

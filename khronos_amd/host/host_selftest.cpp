@@ -198,6 +198,26 @@ int main(int argc, char** argv) {
     catch (const std::invalid_argument&) { threw = true; }
     CHECK(threw);
   }
+  // ---- hydra::timing stand-in: the reference's scope names, stats.csv rows ----
+  {
+    auto& rec = hydra::timing::ElapsedTimeRecorder::instance();
+    rec.reset();
+    rec.record("active_window/all", 0.25);
+    rec.record("active_window/all", 0.75);
+    { hydra::timing::ScopedTimer t("active_window/update_map", 0); }
+    const auto st = rec.stats();
+    CHECK(st.at("active_window/all").count == 2 && st.at("active_window/all").min == 0.25 && st.at("active_window/all").max == 0.75);
+    CHECK(st.at("active_window/all").sum == 1.0 && st.count("active_window/update_map") == 1);
+    const std::string path = "/tmp/khr_selftest_stats.csv";
+    CHECK(rec.logStats(path));
+    std::ifstream f(path);
+    std::string header, row;
+    std::getline(f, header);
+    std::getline(f, row);
+    CHECK(header == "name,mean[s],min[s],max[s],std-dev[s],count");
+    CHECK(row.rfind("active_window/all,0.5,0.25,0.75,", 0) == 0);
+    rec.reset();
+  }
   std::printf("host selftest ok\n");
   return 0;
 }

@@ -3,6 +3,12 @@
 // un-vendored dependency of the reference (install/https.rosinstall:5-8) and is not available offline; in
 // a real integration these are the genuine Hydra types and this header disappears.
 #pragma once
+#include <chrono>
+#include <cmath>
+#include <fstream>
+#include <functional>
+#include <map>
+#include <mutex>
 #include <array>
 #include <cstdint>
 #include <cstring>
@@ -204,5 +210,86 @@ struct ActiveWindowOutput {
     return b;
   }
 };
+
+
+// ---- hydra::timing (ElapsedTimeRecorder / ScopedTimer role) ------------------------------------------------------------
+// The reference brackets its stages with `Timer timer("<scope>", stamp)` (active_window.cpp:121,152,204,220,269;
+// tracking_integrator.cpp:72; free_space_motion_detector.cpp:75; connected_semantics.cpp:61; max_iou_tracker.cpp:200,217)
+// and dumps `timing/stats.csv` at shutdown (khronos_ros/src/experiments/experiment_manager.cpp:251-258).  Same scope
+// names here, so that a CPU-vs-GPU comparison reads the same rows.  The device work of a scope is asynchronous: with
+// `ElapsedTimeRecorder::instance().sync_device = fn` set (the ActiveWindow sets it when config.timing_sync_device is on)
+// a scope's end first waits for the device, which makes "active_window/all" the per-frame latency the reference measures.
+namespace timing {
+struct TimerStats {
+  uint64_t count = 0;
+  double sum = 0.0, sum_sq = 0.0, min = 0.0, max = 0.0, last = 0.0;
+};
+class ElapsedTimeRecorder {
+ public:
+  static ElapsedTimeRecorder& instance() {
+    static ElapsedTimeRecorder r;
+    return r;
+  }
+  void record(const std::string& name, double seconds) {
+    std::lock_guard<std::mutex> lock(mutex_);
+    TimerStats& t = stats_[name];
+    if (t.count == 0) t.min = t.max = seconds;
+    t.min = std::min(t.min, seconds);
+    t.max = std::max(t.max, seconds);
+    t.sum += seconds;
+    t.sum_sq += seconds * seconds;
+    t.last = seconds;
+    ++t.count;
+  }
+  std::map<std::string, TimerStats> stats() const {
+    std::lock_guard<std::mutex> lock(mutex_);
+    return stats_;
+  }
+  void reset() {
+    std::lock_guard<std::mutex> lock(mutex_);
+    stats_.clear();
+  }
+  // "name,mean[s],min[s],max[s],std-dev[s]" rows (ElapsedTimeRecorder::logStats; column set recalled, ASSUMPTIONS.md D.1),
+  // plus the sample count as a last column
+  bool logStats(const std::string& path) const {
+    std::ofstream out(path);
+    if (!out) return false;
+    out << "name,mean[s],min[s],max[s],std-dev[s],count\n";
+    for (const auto& kv : stats()) {
+      const TimerStats& t = kv.second;
+      const double mean = t.count ? t.sum / static_cast<double>(t.count) : 0.0;
+      const double var = t.count > 1 ? std::max(0.0, (t.sum_sq - t.sum * mean) / static_cast<double>(t.count - 1)) : 0.0;
+      out << kv.first << ',' << mean << ',' << t.min << ',' << t.max << ',' << std::sqrt(var) << ',' << t.count << "\n";
+    }
+    return true;
+  }
+  std::function<void()> sync_device;  // optional: called when a timer with `sync` set stops
+  bool disabled = false;
+
+ private:
+  mutable std::mutex mutex_;
+  std::map<std::string, TimerStats> stats_;
+};
+
+class ScopedTimer {
+ public:
+  ScopedTimer(std::string name, uint64_t /*timestamp_ns*/, bool sync = false)
+      : name_(std::move(name)), sync_(sync), start_(std::chrono::steady_clock::now()) {}
+  ~ScopedTimer() { stop(); }
+  void stop() {
+    if (done_) return;
+    done_ = true;
+    ElapsedTimeRecorder& r = ElapsedTimeRecorder::instance();
+    if (r.disabled) return;
+    if (sync_ && r.sync_device) r.sync_device();
+    r.record(name_, std::chrono::duration<double>(std::chrono::steady_clock::now() - start_).count());
+  }
+
+ private:
+  std::string name_;
+  bool sync_, done_ = false;
+  std::chrono::steady_clock::time_point start_;
+};
+}  // namespace timing
 
 }  // namespace hydra

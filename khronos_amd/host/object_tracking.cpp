@@ -221,6 +221,7 @@ void MaxIoUTracker::finishTrackMeasurements(FrameData& data) const {
 }
 
 void MaxIoUTracker::associateTracks(const FrameData& data) {
+  hydra::timing::ScopedTimer timer("tracking/associate", processing_stamp_);  // max_iou_tracker.cpp:217
   associateDynamicTracks(data);   // max_iou_tracker.cpp:205-218
   associateSemanticTracks(data);
 }

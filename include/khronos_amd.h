@@ -268,6 +268,24 @@ int64_t khr_cluster_voxels(khr_ctx* ctx, int slot, int which, float voxel_size, 
  * waits for it and decodes (same output as khr_cluster_voxels). */
 int khr_cluster_voxels_launch(khr_ctx* ctx, int slot, int which, float voxel_size);
 int64_t khr_cluster_voxels_fetch(khr_ctx* ctx, int which, int32_t* ids_out, int64_t* voxels_out, int64_t cap);
+/* replaces: MaxIoUTracker::computeIoUPixels for track_by = pixels (max_iou_tracker.cpp:497-503, 578-600).  A track's
+ * last_points are named by the resident frame slot, id image (0 dynamic, 1 object) and cluster id of its last
+ * observation (the caller retains the slot).  For up to 32 such references: n_points[r] = number of points
+ * (last_points.size()), inter[r * (max_id + 1) + c] = pixels of object-image cluster c of frame `slot` that are hit by a
+ * re-projected point of reference r (the intersection of :595-599).  Synchronises. */
+typedef struct khr_pixel_ref {
+  int32_t slot;
+  int32_t which;
+  int32_t id;
+} khr_pixel_ref;
+int khr_pixel_iou(khr_ctx* ctx, int slot, const khr_pixel_ref* refs, int n_refs, int max_id, uint32_t* n_points, uint32_t* inter);
+/* replaces: InstanceForwarding::extractSemanticClusters (instance_forwarding.cpp:80-149): object_image = label image; one
+ * cluster per non-zero instance id (0 < id <= max_id) from the pixels that are not in `background_ids` (ids whose
+ * open-set feature scored above max_background_score: decided by the caller, sorted ascending, may be NULL) and not
+ * beyond max_range (<= 0: no limit).  out[max_id + 1] receives pixel count, bounding box, centroid per id (num_pixels_listed
+ * == 0: id absent); size / volume filters and the cluster order are the caller's.  Returns the number of ids present. */
+int khr_forward_instances(khr_ctx* ctx, int slot, float max_range, const int32_t* background_ids, int n_background, int max_id,
+                          khr_cluster* out);
 /* replaces: hydra::MeshIntegrator::generateMesh(map, only_mesh_updated, clear_flag)
  * (active_window.cpp:223, mesh_object_extractor.cpp:267) */
 int khr_generate_mesh(khr_ctx* ctx, int only_mesh_updated, int clear_flag);

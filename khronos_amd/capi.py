@@ -72,7 +72,7 @@ EXPORTS = [
     "khr_detect_motion", "khr_generate_mesh", "khr_reset_inactive", "khr_mark_all_inactive", "khr_clear_updated",
     "khr_allocate_blocks", "khr_object_prune", "khr_get_stats", "khr_num_blocks", "khr_block_indices",
     "khr_download_block", "khr_mesh_num_vertices", "khr_download_mesh", "khr_timing_enable", "khr_timing_reset",
-    "khr_timing_get", "khr_debug_read", "khr_tick_ingest", "khr_tick_integrate", "khr_tick_seed_counts", "khr_copy_frame_image", "khr_rv_detect_changes", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_integrate_shared_batch", "khr_update_tracking_phase",
+    "khr_timing_get", "khr_debug_read", "khr_tick_ingest", "khr_tick_integrate", "khr_tick_seed_counts", "khr_copy_frame_image", "khr_rv_detect_changes", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_integrate_shared_batch", "khr_pixel_iou", "khr_forward_instances", "khr_update_tracking_phase",
     "khr_export_halo", "khr_import_halo", "khr_get_dynamic_clusters", "khr_motion_keys",
     "khr_detect_motion_from_keys", "khr_download_updated", "khr_mesh_halo_requests", "khr_mesh_halo_export",
     "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",
@@ -123,6 +123,8 @@ def load_library():
     lib.khr_get_dynamic_clusters.argtypes = [vp, i32, C.POINTER(KhrCluster), i32]
     lib.khr_configure_object_detector.argtypes = [vp, C.POINTER(KhrObjectDetectorConfig)]
     lib.khr_detect_objects.argtypes = [vp, i32]
+    lib.khr_pixel_iou.argtypes = [vp, i32, vp, i32, i32, vp, vp]
+    lib.khr_forward_instances.argtypes = [vp, i32, C.c_float, vp, i32, i32, C.POINTER(KhrCluster)]
     lib.khr_download_frame_image.argtypes = [vp, i32, i32, vp]
     lib.khr_rv_create.argtypes = [C.c_float, C.c_float, C.c_float, i32, C.POINTER(vp)]
     lib.khr_rv_destroy.argtypes = [vp]
@@ -422,6 +424,25 @@ class FusionContext:
         n = self._chk(self.lib.khr_get_semantic_clusters(self.h, slot, arr, n))
         return [dict(id=a.id, semantic_id=a.semantic_id, num_pixels=a.num_pixels_listed, bbox_min=np.array(a.bbox_min[:]),
                      bbox_max=np.array(a.bbox_max[:]), centroid=np.array(a.centroid[:])) for a in arr[:n]]
+
+    def pixel_iou(self, slot, refs, max_id):
+        """MaxIoUTracker track_by = pixels: refs = [(slot, which, id), ...] (<= 32) -> (n_points[r], inter[r, max_id + 1])."""
+        r = np.ascontiguousarray(np.array(refs, np.int32).reshape(-1, 3))
+        n_points = np.zeros(max(len(r), 1), np.uint32)
+        inter = np.zeros((max(len(r), 1), max_id + 1), np.uint32)
+        self._chk(self.lib.khr_pixel_iou(self.h, slot, _ptr(r), len(r), int(max_id), _ptr(n_points), _ptr(inter)))
+        return n_points[:len(r)], inter[:len(r)]
+
+    def forward_instances(self, slot, max_range=0.0, background_ids=(), max_id=255):
+        """InstanceForwarding::extractSemanticClusters: per-id summaries of the label image (ids present only)."""
+        bg = np.ascontiguousarray(sorted(background_ids), dtype=np.int32)
+        arr = (KhrCluster * (max_id + 1))()
+        n = self._chk(self.lib.khr_forward_instances(self.h, slot, float(max_range), _ptr(bg) if bg.size else None, int(bg.size),
+                                                     int(max_id), arr))
+        out = [dict(id=a.id, num_pixels=a.num_pixels_listed, bbox_min=np.array(a.bbox_min[:]), bbox_max=np.array(a.bbox_max[:]),
+                    centroid=np.array(a.centroid[:])) for a in arr if a.num_pixels_listed]
+        assert len(out) == n
+        return out
 
     def cluster_voxels(self, slot, which, voxel_size):
         """distinct (cluster id, voxel) pairs of the dynamic (which=0) / object (which=1) image: (ids[n], voxels[n,3])."""

@@ -434,4 +434,203 @@ __global__ __launch_bounds__(256) void k_cluster_voxels(DevFrame f, const int32_
   }
 }
 
+
+// ---- MaxIoUTracker, track_by = pixels (max_iou_tracker.cpp:497-503, 578-600) --------------------------------------------------
+// A track's last_points are the world vertices of its last observation's pixels; they stay where they are -- in the id
+// image of a resident frame slot -- and are named by (slot, image, cluster id).  computeIoUPixels re-projects them into
+// the CURRENT frame and intersects the pixel set with a cluster's pixels:
+//   k_pix_reproject   one pass over a source frame: pixels carrying a reference id -> vertex -> getSensorPose() * point ->
+//                     camera -> bit `ref` of the target pixel in a W x H word image (std::set<Pixel> semantics: a bit is set
+//                     once however many points land there), and the number of points per reference;
+//   k_pix_intersect   one pass over the current frame: per (cluster id, reference) the number of the cluster's pixels whose
+//                     bit is set.  Lanes of a wave that hold the same cluster reduce with a ballot before the atomic.
+constexpr int kPixRefs = 32;
+struct PixRefs {
+  int n;
+  int32_t id[kPixRefs];   // cluster id in the source image
+  int32_t bit[kPixRefs];  // reference index = bit in the mask word
+};
+struct PixCamera {
+  double T[12];  // rows of InputData::getSensorPose() of the current frame (applied as the reference applies it, :582-588)
+  float fx, fy, cx, cy;
+  int W, H;
+};
+__global__ __launch_bounds__(256) void k_pix_reproject(DevFrame src, const int32_t* __restrict__ id_img, PixRefs refs, PixCamera cam,
+                                                      uint32_t* __restrict__ mask, uint32_t* __restrict__ n_points) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int bit = -1;
+  if (i < src.W * src.H) {
+    const int32_t id = id_img[i];
+    if (id > 0) {
+      for (int k = 0; k < refs.n; ++k)
+        if (refs.id[k] == id) bit = refs.bit[k];
+    }
+  }
+  if (__ballot(bit >= 0) == 0ull) return;
+  if (bit >= 0) {
+    float pw[3];
+    pixelVertex(src, i, pw);
+    // Eigen::Isometry3d * Vector3d, then .cast<float>() (:587-588)
+    const double x = pw[0], y = pw[1], z = pw[2];
+    const float xs = static_cast<float>(cam.T[0] * x + cam.T[1] * y + cam.T[2] * z + cam.T[3]);
+    const float ys = static_cast<float>(cam.T[4] * x + cam.T[5] * y + cam.T[6] * z + cam.T[7]);
+    const float zs = static_cast<float>(cam.T[8] * x + cam.T[9] * y + cam.T[10] * z + cam.T[11]);
+    // Sensor::projectPointToImagePlane(p, int& u, int& v) (un-vendored, ASSUMPTIONS.md A.8): in front of the camera,
+    // pinhole projection, rounded to the nearest pixel, inside the image
+    if (zs > 0.f) {
+      const float uf = (xs * cam.fx) / zs + cam.cx, vf = (ys * cam.fy) / zs + cam.cy;
+      const float ur = roundf(uf), vr = roundf(vf);
+      if (ur >= 0.f && vr >= 0.f && ur < static_cast<float>(cam.W) && vr < static_cast<float>(cam.H))
+        atomicOr(&mask[static_cast<int>(vr) * cam.W + static_cast<int>(ur)], 1u << bit);
+    }
+  }
+  // points per reference (Track::last_points.size()): lanes with the same reference count once per wave
+  unsigned long long todo = __ballot(bit >= 0);
+  while (todo) {
+    const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+    const int b = __shfl(bit, leader);
+    const unsigned long long grp = __ballot(bit == b);
+    todo &= ~grp;
+    if (static_cast<int>(laneId()) == leader) atomicAdd(&n_points[b], static_cast<uint32_t>(__popcll(grp)));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pix_intersect(const int32_t* __restrict__ id_img, const uint32_t* __restrict__ mask, int n,
+                                                      int n_refs, int max_id, uint32_t* __restrict__ inter /* [n_refs][max_id + 1] */) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int32_t c = 0;
+  uint32_t m = 0;
+  if (i < n) {
+    c = id_img[i];
+    if (c > 0 && c <= max_id) m = mask[i];
+    else c = 0;
+  }
+  if (__ballot(m != 0u) == 0ull) return;
+  for (int t = 0; t < n_refs; ++t) {
+    unsigned long long todo = __ballot((m >> t) & 1u);
+    while (todo) {
+      const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+      const int32_t cl = __shfl(c, leader);
+      const unsigned long long grp = __ballot(((m >> t) & 1u) && c == cl);
+      todo &= ~grp;
+      if (static_cast<int>(laneId()) == leader)
+        atomicAdd(&inter[static_cast<size_t>(t) * (max_id + 1) + cl], static_cast<uint32_t>(__popcll(grp)));
+    }
+  }
+}
+
+// ---- InstanceForwarding::extractSemanticClusters (instance_forwarding.cpp:80-149) ------------------------------------------------
+// object_image = label image (every pixel, :83), one cluster per instance id with the pixels that pass the background /
+// range filters; per-cluster pixel count, bounding box, first pixel and vertex sum are reduced per 32 x 32 tile in LDS
+// (k_obj_paint's scheme) into a dense table indexed by the instance id.
+__global__ __launch_bounds__(1024) void k_inst_forward(DevFrame f, int32_t* __restrict__ obj, float max_range,
+                                                      const int32_t* __restrict__ background_ids, int n_background, int max_id,
+                                                      ObjAcc* __restrict__ acc, uint32_t* __restrict__ flags) {
+  __shared__ int s_id[kObjSlots];
+  __shared__ ObjAcc s_acc[kObjSlots];
+  if (threadIdx.x < kObjSlots) {
+    s_id[threadIdx.x] = 0;
+    ObjAcc a;
+    a.n_pixels = 0;
+    a.first_cm = 0xffffffffu;
+    for (int d = 0; d < 3; ++d) { a.bmin[d] = INT32_MAX; a.bmax[d] = INT32_MIN; a.sum[d] = 0.f; }
+    a.group = 0;
+    s_acc[threadIdx.x] = a;
+  }
+  __syncthreads();
+  const int tiles_x = (f.W + kObjTile - 1) / kObjTile;
+  const int u = (blockIdx.x % tiles_x) * kObjTile + (threadIdx.x & 31), v = (blockIdx.x / tiles_x) * kObjTile + (threadIdx.x >> 5);
+  int id = 0;
+  float pw[3] = {0.f, 0.f, 0.f};
+  uint32_t cm = 0xffffffffu;
+  if (u < f.W && v < f.H) {
+    const int i = v * f.W + u;
+    const int32_t lab = f.label[i];
+    obj[i] = lab;  // data.object_image = data.input.label_image (:83): filtered pixels keep their label too
+    bool keep = lab != 0;
+    if (keep && n_background > 0) keep = labelRank(background_ids, n_background, lab) < 0;  // (:93-103, scores taken on the host)
+    if (keep && max_range > 0.f) keep = !(f.range[i] > max_range);                          // (:105-110)
+    if (keep) {
+      if (lab < 0 || lab > max_id) {
+        atomicOr(&flags[0], 1u);  // instance id outside the table: reported, never silently dropped
+      } else {
+        id = lab;
+        pixelVertex(f, i, pw);
+        cm = static_cast<uint32_t>(u) * static_cast<uint32_t>(f.H) + static_cast<uint32_t>(v);
+      }
+    }
+  }
+  unsigned long long todo = __ballot(id != 0);
+  while (todo) {
+    const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+    const int cid = __shfl(id, leader);
+    const bool mine = id == cid;
+    const unsigned long long grp = __ballot(mine);
+    todo &= ~grp;
+    float mn[3], mx[3], sm[3];
+    uint32_t first = mine ? cm : 0xffffffffu;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      mn[c] = mine ? pw[c] : 3.0e38f;
+      mx[c] = mine ? pw[c] : -3.0e38f;
+      sm[c] = mine ? pw[c] : 0.f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      first = min(first, static_cast<uint32_t>(__shfl_xor(static_cast<int>(first), o)));
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+        mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+        sm[c] += __shfl_xor(sm[c], o);
+      }
+    }
+    if (static_cast<int>(laneId()) == leader) {
+      ObjAcc* a = acc + cid;
+      for (int k = 0; k < kObjSlots; ++k) {
+        const int h = (cid + k) & (kObjSlots - 1);
+        const int prev = atomicCAS(&s_id[h], 0, cid);
+        if (prev == 0 || prev == cid) {
+          a = &s_acc[h];
+          break;
+        }
+      }
+      atomicAdd(&a->n_pixels, static_cast<uint32_t>(__popcll(grp)));
+      atomicMin(&a->first_cm, first);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        atomicMin(&a->bmin[c], objFloatToOrdered(mn[c]));
+        atomicMax(&a->bmax[c], objFloatToOrdered(mx[c]));
+        atomicAdd(&a->sum[c], sm[c]);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kObjSlots && s_id[threadIdx.x]) {
+    const ObjAcc& l = s_acc[threadIdx.x];
+    ObjAcc* a = acc + s_id[threadIdx.x];
+    atomicAdd(&a->n_pixels, l.n_pixels);
+    atomicMin(&a->first_cm, l.first_cm);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      atomicMin(&a->bmin[c], l.bmin[c]);
+      atomicMax(&a->bmax[c], l.bmax[c]);
+      atomicAdd(&a->sum[c], l.sum[c]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_inst_clear(ObjAcc* __restrict__ acc, int n, uint32_t* __restrict__ flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) flags[0] = 0u;
+  if (i < n) {
+    ObjAcc a;
+    a.n_pixels = 0;
+    a.first_cm = 0xffffffffu;
+    for (int d = 0; d < 3; ++d) { a.bmin[d] = INT32_MAX; a.bmax[d] = INT32_MIN; a.sum[d] = 0.f; }
+    a.group = 0;
+    acc[i] = a;
+  }
+}
+
 }  // namespace khr

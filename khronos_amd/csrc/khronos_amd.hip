@@ -123,6 +123,10 @@ struct khr_ctx {
   int tick_epoch = 0, motion_ignore_epoch = 0;
   unsigned long long* d_dbg = nullptr;
   uint32_t* d_wg_stats = nullptr;
+  uint32_t* d_pix_scratch = nullptr;  // khr_pixel_iou: mask image + counters (allocated on first use)
+  size_t pix_words = 0;
+  uint8_t* d_inst = nullptr;          // khr_forward_instances: per-id accumulators
+  size_t inst_bytes = 0;
   uint4* d_work4 = nullptr;       // update list of k_fuse: two descriptor arrays of item_cap entries (FuseList)
   uint4* d_tick_work4 = nullptr;  // tick path: two arrays per camera
   uint32_t item_cap = 0;          // max_blocks x wave items per block
@@ -817,6 +821,8 @@ void khr_destroy(khr_ctx* c) {
   for (void* p : c->allocs) hipFree(p);
   if (c->d_halo_recs) { hipFree(c->d_halo_recs); hipFree(c->d_halo_keys); hipFree(c->d_halo_vals); }
   if (c->d_mh_recs) { hipFree(c->d_mh_recs); hipFree(c->d_mh_keys); hipFree(c->d_mh_vals); }
+  if (c->d_pix_scratch) hipFree(c->d_pix_scratch);
+  if (c->d_inst) hipFree(c->d_inst);
   if (c->h_pinned) hipHostFree(c->h_pinned);
   if (c->h_tick) hipHostFree(c->h_tick);
   if (c->h_obj_head) hipHostFree(c->h_obj_head);
@@ -2371,6 +2377,117 @@ int64_t khr_cluster_voxels(khr_ctx* c, int slot, int which, float voxel_size, in
   const int rc = khr_cluster_voxels_launch(c, slot, which, voxel_size);
   if (rc) return rc;
   return khr_cluster_voxels_fetch(c, which, ids_out, voxels_out, cap);
+}
+
+int khr_pixel_iou(khr_ctx* c, int slot, const khr_pixel_ref* refs, int n_refs, int max_id, uint32_t* n_points, uint32_t* inter) {
+  if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
+  if (n_refs < 0 || n_refs > kPixRefs || (n_refs > 0 && (!refs || !n_points || !inter)) || max_id < 1 || max_id > 65535)
+    return fail(KHR_EINVAL, "bad argument (at most %d references per call)", kPixRefs);
+  if (n_refs == 0) return KHR_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  FrameSlot& cur = c->slots[slot];
+  if (!cur.has_obj) return fail(KHR_ESTATE, "the frame has no object image (run the object detector first)");
+  const size_t npx = c->cfg.max_frame_pixels;
+  const size_t words = npx + kPixRefs + static_cast<size_t>(kPixRefs) * (static_cast<size_t>(max_id) + 1);
+  if (c->pix_words < words) {
+    if (c->d_pix_scratch) { HIP_TRY(hipStreamSynchronize(c->stream)); hipFree(c->d_pix_scratch); c->d_pix_scratch = nullptr; }
+    HIP_TRY(hipMalloc(&c->d_pix_scratch, words * sizeof(uint32_t)));
+    c->pix_words = words;
+  }
+  uint32_t* const d_mask = c->d_pix_scratch;
+  uint32_t* const d_np = d_mask + npx;
+  uint32_t* const d_inter = d_np + kPixRefs;
+  const int n = cur.sensor.width * cur.sensor.height;
+  // the object image of this frame and the id images of the source frames come from the auxiliary stream
+  HIP_TRY(hipEventRecord(c->ev_aux_done, c->aux_stream));
+  HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_aux_done, 0));
+  HIP_TRY(hipMemsetAsync(d_mask, 0, words * sizeof(uint32_t), c->stream));
+  PixCamera cam{};
+  for (int k = 0; k < 12; ++k) cam.T[k] = cur.meta.world_T_sensor[k];
+  cam.fx = cur.sensor.fx; cam.fy = cur.sensor.fy; cam.cx = cur.sensor.cx; cam.cy = cur.sensor.cy;
+  cam.W = cur.sensor.width; cam.H = cur.sensor.height;
+  // one pass per distinct (slot, image) among the references
+  std::vector<char> done(static_cast<size_t>(n_refs), 0);
+  for (int a = 0; a < n_refs; ++a) {
+    if (done[a]) continue;
+    const khr_pixel_ref& ra = refs[a];
+    if (ra.slot < 0 || ra.slot >= static_cast<int>(c->slots.size()) || !c->slots[ra.slot].valid || (ra.which != 0 && ra.which != 1))
+      return fail(KHR_EINVAL, "bad reference %d", a);
+    FrameSlot& src = c->slots[ra.slot];
+    if (src.sensor.width != cur.sensor.width || src.sensor.height != cur.sensor.height)
+      return fail(KHR_EINVAL, "reference frames must have the current frame's image size");
+    PixRefs pr{};
+    for (int b = a; b < n_refs; ++b)
+      if (!done[b] && refs[b].slot == ra.slot && refs[b].which == ra.which) {
+        pr.id[pr.n] = refs[b].id;
+        pr.bit[pr.n] = b;
+        ++pr.n;
+        done[b] = 1;
+      }
+    const DevFrame fs = makeDevFrame(c, src);
+    hipLaunchKernelGGL(k_pix_reproject, dim3(gridFor(n)), dim3(256), 0, c->stream, fs, ra.which == 0 ? src.dyn : src.obj, pr, cam,
+                       d_mask, d_np);
+  }
+  hipLaunchKernelGGL(k_pix_intersect, dim3(gridFor(n)), dim3(256), 0, c->stream, cur.obj, d_mask, n, n_refs, max_id, d_inter);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(n_points, d_np, sizeof(uint32_t) * n_refs, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(inter, d_inter, sizeof(uint32_t) * static_cast<size_t>(n_refs) * (static_cast<size_t>(max_id) + 1),
+                         hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return KHR_OK;
+}
+
+int khr_forward_instances(khr_ctx* c, int slot, float max_range, const int32_t* background_ids, int n_background, int max_id,
+                          khr_cluster* out) {
+  if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
+  if (!out || max_id < 1 || max_id > 65535 || n_background < 0 || (n_background > 0 && !background_ids)) return fail(KHR_EINVAL, "bad argument");
+  FrameSlot& s = c->slots[slot];
+  if (!s.has_label) return fail(KHR_ESTATE, "the frame has no label image to forward");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t n_acc = static_cast<size_t>(max_id) + 1;
+  const size_t bytes = sizeof(ObjAcc) * n_acc + 16 + sizeof(int32_t) * static_cast<size_t>(std::max(n_background, 1));
+  if (c->inst_bytes < bytes) {
+    if (c->d_inst) { HIP_TRY(hipStreamSynchronize(c->stream)); hipFree(c->d_inst); c->d_inst = nullptr; }
+    HIP_TRY(hipMalloc(&c->d_inst, bytes));
+    c->inst_bytes = bytes;
+  }
+  ObjAcc* const d_acc = reinterpret_cast<ObjAcc*>(c->d_inst);
+  uint32_t* const d_flags = reinterpret_cast<uint32_t*>(c->d_inst + sizeof(ObjAcc) * n_acc);
+  int32_t* const d_bg = reinterpret_cast<int32_t*>(c->d_inst + sizeof(ObjAcc) * n_acc + 16);
+  if (n_background) HIP_TRY(hipMemcpyAsync(d_bg, background_ids, sizeof(int32_t) * n_background, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_inst_clear, dim3(gridFor(n_acc)), dim3(256), 0, c->stream, d_acc, static_cast<int>(n_acc), d_flags);
+  const DevFrame f = makeDevFrame(c, s);
+  const int tiles = ((f.W + kObjTile - 1) / kObjTile) * ((f.H + kObjTile - 1) / kObjTile);
+  hipLaunchKernelGGL(k_inst_forward, dim3(tiles), dim3(1024), 0, c->stream, f, s.obj, max_range, d_bg, n_background, max_id, d_acc, d_flags);
+  HIP_TRY(hipGetLastError());
+  std::vector<ObjAcc> acc(n_acc);
+  uint32_t flags = 0;
+  HIP_TRY(hipMemcpyAsync(acc.data(), d_acc, sizeof(ObjAcc) * n_acc, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(&flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  s.has_obj = true;
+  s.objects_done = true;
+  s.sem_clusters.clear();
+  if (flags & 1u) return fail(KHR_EINVAL, "an instance id of the label image is outside 1..%d", max_id);
+  int present = 0;
+  for (size_t id = 0; id < n_acc; ++id) {
+    khr_cluster k{};
+    const ObjAcc& a = acc[id];
+    k.id = static_cast<int32_t>(id);
+    k.num_pixels_listed = a.n_pixels;
+    k.num_pixels_painted = a.n_pixels;
+    k.semantic_id = static_cast<int32_t>(id);
+    if (a.n_pixels) {
+      ++present;
+      for (int d = 0; d < 3; ++d) {
+        k.bbox_min[d] = orderedToFloat(a.bmin[d]);
+        k.bbox_max[d] = orderedToFloat(a.bmax[d]);
+        k.centroid[d] = a.sum[d] / static_cast<float>(a.n_pixels);
+      }
+    }
+    out[id] = k;
+  }
+  return present;
 }
 
 int khr_generate_mesh(khr_ctx* c, int only_mesh_updated, int clear_flag) {

@@ -378,6 +378,7 @@ ActiveWindow::Config ActiveWindow::Config::fromYaml(const khronos_amd::YamlNode&
   if (const auto* m = n.find("object_detector")) {
     m->read("type", c.object_detector_type);
     c.object_detector = ConnectedSemantics::Config::fromYaml(*m);
+    c.instance_forwarding = InstanceForwarding::Config::fromYaml(*m);
   }
   if (const auto* m = n.find("tracker")) {
     m->read("type", c.tracker_type);
@@ -454,9 +455,8 @@ void ActiveWindow::Config::checkValid() const {
     throw std::invalid_argument("unknown motion_detector type '" + motion_detector_type + "'");
   if (!object_extractor_type.empty() && object_extractor_type != "MeshObjectExtractor")
     throw std::invalid_argument("unknown object_extractor type '" + object_extractor_type + "'");
-  if (!object_detector_type.empty() && object_detector_type != "ConnectedSemantics")
-    throw std::invalid_argument("unknown object_detector type '" + object_detector_type +
-                                "' (InstanceForwarding needs open-set label features, which this backend does not carry)");
+  if (!object_detector_type.empty() && object_detector_type != "ConnectedSemantics" && object_detector_type != "InstanceForwarding")
+    throw std::invalid_argument("unknown object_detector type '" + object_detector_type + "'");
   if (!tracker_type.empty() && tracker_type != "MaxIouTracker" && tracker_type != "ExternalTracker")
     throw std::invalid_argument("unknown tracker type '" + tracker_type + "'");
   interpolationFromName(projective_integrator.interpolation_method);
@@ -513,6 +513,8 @@ ActiveWindow::ActiveWindow(const Config& cfg) : config(cfg), frame_data_buffer_(
     motion_detector_ = std::make_unique<MotionDetector>();
   if (config.object_detector_type == "ConnectedSemantics")
     object_detector_ = std::make_unique<ConnectedSemantics>(config.object_detector, map_);
+  else if (config.object_detector_type == "InstanceForwarding")
+    object_detector_ = std::make_unique<InstanceForwarding>(config.instance_forwarding);
   else
     object_detector_ = std::make_unique<ObjectDetector>();
   if (config.tracker_type == "MaxIouTracker") {
@@ -575,6 +577,7 @@ std::shared_ptr<FrameData> ActiveWindow::createData(const hydra::InputPacket& in
   f.depth = input.depth;
   f.color = input.color;
   f.label = input.labels;
+  in.label_features = input.label_features;
   in.slot = khr_upload_frame(ctx_, &s, &f, input.on_device ? 1 : 0);
   if (in.slot < 0) return nullptr;  // "Input packet preprocessing failed. Skipping frame." (:276-279)
   in.retainSlot();
@@ -623,6 +626,7 @@ hydra::ActiveWindowOutput::Ptr ActiveWindow::spinOnce(const hydra::InputPacket& 
     // create_data + motion_detection/all + update_map (+ integration/tracking) of the reference are ONE fused device call
     // here; the scope is recorded under the reference's outer name
     Timer t_map("active_window/update_map", latest_stamp_, config.timing_sync_device);
+    in.label_features = input.label_features;
     in.slot = khr_process_frame(ctx_, &s, &f, input.on_device ? 1 : 0, flags, &n_clusters);
     t_map.stop();
     if (in.slot < 0) return nullptr;  // "Input packet preprocessing failed. Skipping frame." (:276-279)

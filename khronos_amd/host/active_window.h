@@ -81,6 +81,14 @@ struct Track {  // track.h:72-111
   std::optional<SemanticClusterInfo> semantics;
   size_t num_features = 0;
   std::vector<Observation> observations;
+  // track_by = pixels: Track::last_points (track.h) are the vertices of the last observation's pixels.  They are not
+  // copied out of HBM: the track names the id image they sit in and keeps that frame slot alive.
+  struct PixelRef {
+    khr_ctx* ctx = nullptr;
+    int slot = -1, which = 0, id = 0;  // which: 0 dynamic image, 1 object image
+    size_t num_points = 0;             // last_points.size()
+    std::shared_ptr<void> lease;       // khr_retain_slot for as long as any copy of the track refers to the frame
+  } last_pixels;
   void updateSemantics(const std::optional<SemanticClusterInfo>& other);  // track.cpp:42-70
 };
 using Tracks = std::vector<Track>;
@@ -182,6 +190,33 @@ class ConnectedSemantics : public ObjectDetector {
   void processInput(const VolumetricMap& map, FrameData& data) override;
 };
 
+// khronos::InstanceForwarding (instance_forwarding.h:57-100, instance_forwarding.cpp:73-149): the instance ids of the label
+// image ARE the clusters.  Pixel grouping and the per-cluster summaries are one device pass (khr_forward_instances); the
+// background filter scores each id's open-set feature against the background prompts on the host (a handful of ids).
+class InstanceForwarding : public ObjectDetector {
+ public:
+  struct Config {
+    int verbosity = 0;
+    float max_range = 0.f;
+    int min_cluster_size = 0;
+    int max_cluster_size = -1;
+    double min_object_volume = 0.0;
+    double max_object_volume = -1.0;
+    double max_background_score = 0.2;
+    // hydra::EmbeddingGroup `background` (prompt embeddings) + hydra::CosineDistance metric: un-vendored, given here as
+    // plain vectors; empty = no background filter (instance_forwarding.cpp:66-71)
+    std::vector<std::vector<float>> background_embeddings;
+    int max_instance_id = 4095;  // size of the device's per-id table (extension)
+    static Config fromYaml(const khronos_amd::YamlNode& node);
+  } const config;
+  explicit InstanceForwarding(const Config& config);
+  void processInput(const VolumetricMap& map, FrameData& data) override;
+  static float bestBackgroundScore(const std::vector<std::vector<float>>& background, const std::vector<float>& feature);
+
+ private:
+  bool filter_by_volume_;
+};
+
 // khronos::MaxIoUTracker (max_iou_tracker.h:60-214, max_iou_tracker.cpp).  The per-cluster voxel sets come from
 // the device (khr_cluster_voxels); the association logic is host code as in the reference.
 class MaxIoUTracker : public Tracker {
@@ -229,6 +264,13 @@ class MaxIoUTracker : public Tracker {
   int current_track_id_ = 0;
   mutable std::vector<int32_t> scratch_ids_;
   mutable std::vector<int64_t> scratch_voxels_;
+  // track_by = pixels: the frame being associated and, per track (index), the intersections of its re-projected points
+  // with every object-image cluster of that frame (khr_pixel_iou)
+  const FrameData* current_ = nullptr;
+  mutable std::vector<std::vector<uint32_t>> pix_inter_;
+  mutable std::vector<uint64_t> pix_key_;  // (track id, last_seen) the row was computed for
+  mutable int pix_max_id_ = 0;
+  void ensurePixelIntersections(size_t track_index) const;
 };
 
 // khronos::ExternalTracker (external_tracker.cpp:59-143): tracks follow externally provided cluster ids
@@ -314,8 +356,9 @@ class ActiveWindow {
     TrackingIntegrator::Config tracking_integrator;
     std::string motion_detector_type;    // "" = none, "FreeSpaceMotionDetector"
     FreeSpaceMotionDetector::Config motion_detector;
-    std::string object_detector_type;    // "" = none, "ConnectedSemantics"
+    std::string object_detector_type;    // "" = none, "ConnectedSemantics", "InstanceForwarding"
     ConnectedSemantics::Config object_detector;
+    InstanceForwarding::Config instance_forwarding;  // read from the same `object_detector` node
     std::string tracker_type;            // "" = none, "MaxIouTracker", "ExternalTracker"
     MaxIoUTracker::Config tracker;
     std::string object_extractor_type;   // "" = none, "MeshObjectExtractor"

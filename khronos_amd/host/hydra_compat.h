@@ -44,6 +44,8 @@ struct InputPacket {
   const uint8_t* color = nullptr;   // H*W*3
   const int32_t* labels = nullptr;  // H*W
   bool on_device = false;           // buffers are HBM-resident on the context's device
+  // open-set features of the instance ids of `labels` (InputData::label_features, used at instance_forwarding.cpp:96,141)
+  std::map<int, std::vector<float>> label_features;
 };
 
 inline void mul4(const double* a, const double* b, double* o) {
@@ -64,6 +66,7 @@ struct InputData {
   Sensor sensor;
   khr_ctx* ctx = nullptr;
   int slot = -1;  // device frame slot
+  std::map<int, std::vector<float>> label_features;  // InputData::label_features
   // keeps the slot out of the ring for as long as any copy of this InputData lives (the shared_ptr<FrameData> ownership of
   // the reference: buffer entries and extraction workers keep frames alive, active_window.cpp:261-263)
   std::shared_ptr<void> slot_lease;

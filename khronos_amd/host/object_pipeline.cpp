@@ -113,6 +113,7 @@ kop_handle* kop_create(khr_ctx* ctx, const char* yaml_text, char* err, int err_l
     h->map = VolumetricMap(h->config.volumetric_map, ctx);
     const auto& c = h->config;
     if (c.object_detector_type == "ConnectedSemantics") h->detector = std::make_unique<ConnectedSemantics>(c.object_detector, h->map);
+    else if (c.object_detector_type == "InstanceForwarding") h->detector = std::make_unique<InstanceForwarding>(c.instance_forwarding);
     else h->detector = std::make_unique<ObjectDetector>();
     if (c.tracker_type == "MaxIouTracker") {
       h->tracker = std::make_unique<MaxIoUTracker>(c.tracker);

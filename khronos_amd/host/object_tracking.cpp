@@ -114,6 +114,83 @@ void ConnectedSemantics::processInput(const VolumetricMap& map, FrameData& data)
   }
 }
 
+// ---- InstanceForwarding -----------------------------------------------------------------------------------------------
+InstanceForwarding::Config InstanceForwarding::Config::fromYaml(const khronos_amd::YamlNode& m) {
+  Config c;  // declare_config, instance_forwarding.cpp:47-61
+  m.read("verbosity", c.verbosity);
+  m.read("max_range", c.max_range);
+  m.read("min_cluster_size", c.min_cluster_size);
+  m.read("max_cluster_size", c.max_cluster_size);
+  m.read("min_object_volume", c.min_object_volume);
+  m.read("max_object_volume", c.max_object_volume);
+  m.read("max_background_score", c.max_background_score);
+  m.read("max_instance_id", c.max_instance_id);
+  return c;
+}
+
+InstanceForwarding::InstanceForwarding(const Config& cfg)
+    : config(cfg), filter_by_volume_(cfg.min_object_volume > 0.0 || cfg.max_object_volume > 0.0) {
+  if (config.max_instance_id < 1 || config.max_instance_id > 65535) throw std::invalid_argument("object_detector.max_instance_id must be in [1, 65535]");
+}
+
+float InstanceForwarding::bestBackgroundScore(const std::vector<std::vector<float>>& background, const std::vector<float>& feature) {
+  // EmbeddingGroup::getBestScore with hydra::CosineDistance (un-vendored, ASSUMPTIONS.md A.9): the largest cosine
+  // similarity between the feature and a background prompt
+  float best = -std::numeric_limits<float>::infinity();
+  for (const auto& b : background) {
+    float dot = 0.f, na = 0.f, nb = 0.f;
+    const size_t n = std::min(b.size(), feature.size());
+    for (size_t i = 0; i < n; ++i) {
+      dot += b[i] * feature[i];
+      na += b[i] * b[i];
+      nb += feature[i] * feature[i];
+    }
+    const float s = dot / (std::sqrt(na) * std::sqrt(nb));
+    if (s > best) best = s;
+  }
+  return best;
+}
+
+void InstanceForwarding::processInput(const VolumetricMap& map, FrameData& data) {
+  // instance_forwarding.cpp:73-149
+  data.semantic_clusters.clear();
+  // background filter (:93-103): an id without a feature, or whose best score exceeds the limit, contributes no pixels.
+  // The ids a label image can carry are bounded by the table size, so "no feature" ids are listed too.
+  std::vector<int32_t> background;
+  if (!config.background_embeddings.empty()) {
+    for (int id = 1; id <= config.max_instance_id; ++id) {
+      const auto f = data.input.label_features.find(id);
+      if (f == data.input.label_features.end() ||
+          static_cast<double>(bestBackgroundScore(config.background_embeddings, f->second)) > config.max_background_score)
+        background.push_back(id);
+    }
+  }
+  std::vector<khr_cluster> table(static_cast<size_t>(config.max_instance_id) + 1);
+  const int n = khr_forward_instances(map.ctx(), data.input.slot, config.max_range, background.empty() ? nullptr : background.data(),
+                                      static_cast<int>(background.size()), config.max_instance_id, table.data());
+  chk(n, "khr_forward_instances");
+  // clusters in ascending id order (the reference iterates an unordered_map, :117; ASSUMPTIONS.md C.4)
+  for (const khr_cluster& k : table) {
+    if (k.num_pixels_listed == 0) continue;
+    const int size = static_cast<int>(k.num_pixels_listed);
+    if (size < config.min_cluster_size || (config.max_cluster_size > 0 && size > config.max_cluster_size)) continue;  // :119-122
+    MeasurementCluster m;
+    m.id = k.id;
+    m.num_pixels = static_cast<size_t>(k.num_pixels_listed);
+    m.bounding_box.include(k.bbox_min);
+    m.bounding_box.include(k.bbox_max);
+    for (int d = 0; d < 3; ++d) m.centroid[d] = k.centroid[d];
+    if (filter_by_volume_) {  // :128-135
+      const double volume = m.bounding_box.volume();
+      if (volume < config.min_object_volume || (config.max_object_volume > 0.0 && volume > config.max_object_volume)) continue;
+    }
+    if (data.input.label_features.empty()) m.semantics = SemanticClusterInfo(k.id);  // closed set (:138-140)
+    const auto f = data.input.label_features.find(k.id);
+    if (f != data.input.label_features.end()) m.semantics = SemanticClusterInfo(k.id, f->second);  // (:142-145)
+    data.semantic_clusters.push_back(std::move(m));
+  }
+}
+
 // ---- MaxIoUTracker ---------------------------------------------------------------------------------------------------------
 MaxIoUTracker::Config MaxIoUTracker::Config::fromYaml(const khronos_amd::YamlNode& m) {
   Config c;
@@ -151,10 +228,6 @@ MaxIoUTracker::MaxIoUTracker(const Config& cfg) : config(cfg) {
   if (!in(config.min_cosine_sim, -1.f, 1.f)) throw std::invalid_argument("tracker.min_cosine_sim must be in [-1, 1]");
   if (!(config.temporal_window > 0.f)) throw std::invalid_argument("tracker.temporal_window must be > 0");
   if (!(config.voxel_size > 0.f)) throw std::invalid_argument("tracker.voxel_size must be > 0");
-  if (config.track_by == Config::TrackBy::kPixels)
-    throw std::invalid_argument(
-        "tracker.track_by 'pixels' is not available on the device backend (per-cluster pixel lists stay in the HBM id "
-        "images); use 'voxels' (all shipped mapper configs) or 'bounding_box'");
 }
 
 void MaxIoUTracker::processInput(FrameData& data) {
@@ -167,7 +240,13 @@ void MaxIoUTracker::beginInput(FrameData& data) { launchTrackMeasurements(data);
 void MaxIoUTracker::completeInput(FrameData& data) {
   processing_stamp_ = data.input.timestamp_ns;
   finishTrackMeasurements(data);
+  current_ = &data;
+  pix_inter_.clear();
+  pix_key_.clear();
+  pix_max_id_ = 0;
+  for (const auto& c : data.semantic_clusters) pix_max_id_ = std::max(pix_max_id_, c.id);
   associateTracks(data);
+  current_ = nullptr;
   updateTrackingDuration();
 }
 
@@ -233,6 +312,11 @@ void MaxIoUTracker::computeCentroid(const MeasurementCluster& cluster, float* ce
     for (int d = 0; d < 3; ++d) centroid[d] = cluster.bounding_box.center(d);
     return;
   }
+  if (config.track_by == Config::TrackBy::kPixels) {
+    // mean of the cluster's vertices (:543-549); reduced on the device with the cluster (float sums in reduction order)
+    for (int d = 0; d < 3; ++d) centroid[d] = cluster.centroid[d];
+    return;
+  }
   // voxels: mean of the voxel centres (grid_.toPoint); summed in sorted voxel order (the reference iterates an
   // unordered set, ASSUMPTIONS.md C.4)
   for (const GlobalIndex& v : cluster.voxels)
@@ -272,7 +356,57 @@ float MaxIoUTracker::computeIoUBoundingBox(const BoundingBox& a, const BoundingB
   return uni > 0.f ? inter / uni : 0.f;
 }
 
+// track_by = pixels: intersections of the re-projected points of tracks_[track_index] with the object-image clusters of the
+// frame being associated (computeIoUPixels, max_iou_tracker.cpp:578-600).  Rows are computed in batches of up to 32 tracks
+// per device call; a track created or updated during this frame's association gets a fresh row on demand.
+void MaxIoUTracker::ensurePixelIntersections(size_t track_index) const {
+  const auto keyOf = [](const Track& t) { return (static_cast<uint64_t>(static_cast<uint32_t>(t.id)) << 40) ^ t.last_seen; };
+  if (pix_inter_.size() < tracks_.size()) {
+    pix_inter_.resize(tracks_.size());
+    pix_key_.resize(tracks_.size(), ~0ull);
+  }
+  const Track& want = tracks_[track_index];
+  if (pix_key_[track_index] == keyOf(want) && !pix_inter_[track_index].empty()) return;
+  if (!current_ || !current_->input.ctx || current_->input.slot < 0 || pix_max_id_ < 1) return;
+  // the wanted track plus every other track whose row is stale, up to the per-call limit
+  std::vector<size_t> batch = {track_index};
+  for (size_t t = 0; t < tracks_.size() && batch.size() < 32; ++t)
+    if (t != track_index && tracks_[t].last_pixels.slot >= 0 && pix_key_[t] != keyOf(tracks_[t])) batch.push_back(t);
+  std::vector<khr_pixel_ref> refs;
+  std::vector<size_t> owners;
+  for (size_t t : batch) {
+    const Track::PixelRef& r = tracks_[t].last_pixels;
+    if (r.slot < 0 || r.ctx != current_->input.ctx) continue;
+    refs.push_back({r.slot, r.which, r.id});
+    owners.push_back(t);
+  }
+  if (refs.empty()) return;
+  const size_t stride = static_cast<size_t>(pix_max_id_) + 1;
+  std::vector<uint32_t> n_points(refs.size()), inter(refs.size() * stride);
+  chk(khr_pixel_iou(current_->input.ctx, current_->input.slot, refs.data(), static_cast<int>(refs.size()), pix_max_id_, n_points.data(),
+                    inter.data()),
+      "khr_pixel_iou");
+  for (size_t k = 0; k < owners.size(); ++k) {
+    pix_inter_[owners[k]].assign(inter.begin() + static_cast<std::ptrdiff_t>(k * stride), inter.begin() + static_cast<std::ptrdiff_t>((k + 1) * stride));
+    pix_inter_[owners[k]].push_back(n_points[k]);  // last entry: last_points.size() as the device counted it
+    pix_key_[owners[k]] = keyOf(tracks_[owners[k]]);
+  }
+}
+
 float MaxIoUTracker::computeIoU(const MeasurementCluster& cluster, const Track& track) const {
+  if (config.track_by == Config::TrackBy::kPixels) {
+    const size_t ti = static_cast<size_t>(&track - tracks_.data());
+    ensurePixelIntersections(ti);
+    float intersection = 0.f;
+    size_t n_points = track.last_pixels.num_points;
+    if (ti < pix_inter_.size() && !pix_inter_[ti].empty()) {
+      const std::vector<uint32_t>& row = pix_inter_[ti];
+      if (cluster.id >= 0 && static_cast<size_t>(cluster.id) + 1 < row.size()) intersection = static_cast<float>(row[static_cast<size_t>(cluster.id)]);
+      n_points = row.back();  // the pixels that carry the id in the source image (dynamic clusters: the painted set)
+    }
+    // intersection / (cluster.pixels.size() + track.last_points.size() - intersection)  (:599)
+    return intersection / (static_cast<float>(cluster.num_pixels + n_points) - intersection);
+  }
   return config.track_by == Config::TrackBy::kVoxels ? computeIoUVoxels(cluster.voxels, track.last_voxels)
                                                      : computeIoUBoundingBox(track.last_bounding_box, cluster.bounding_box);
 }
@@ -412,7 +546,19 @@ Track& MaxIoUTracker::addNewTrack(const MeasurementCluster& observation, bool is
 
 void MaxIoUTracker::updateTrack(const MeasurementCluster& observation, Track& track, bool is_observation_dynamic) const {
   // max_iou_tracker.cpp:502-546
-  if (config.track_by == Config::TrackBy::kVoxels) {
+  if (config.track_by == Config::TrackBy::kPixels) {
+    // track.last_points = the vertices of observation.pixels (:504-510): named, not copied
+    Track::PixelRef r;
+    if (current_ && current_->input.ctx && current_->input.slot >= 0) {
+      r.ctx = current_->input.ctx;
+      r.slot = current_->input.slot;
+      r.which = is_observation_dynamic ? 0 : 1;
+      r.id = observation.id;
+      r.lease = current_->input.slot_lease;  // the frame's own lease object (FrameData keeps the slot; so does this copy)
+    }
+    r.num_points = observation.num_pixels;
+    track.last_pixels = std::move(r);
+  } else if (config.track_by == Config::TrackBy::kVoxels) {
     track.last_voxels = observation.voxels;
     track.last_voxel_size = config.voxel_size;
   }

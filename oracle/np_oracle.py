@@ -104,3 +104,57 @@ def tracking_block(cfg, dist, last_obs, last_occ, flags, stamp):
     flags[:] = (flags & ~np.uint8(1)) | act.astype(np.uint8)
     flags[was & ~act] |= 4
     return bool(act.any())
+
+
+# ---- MaxIoUTracker::computeIoUPixels (max_iou_tracker.cpp:578-600) and InstanceForwarding (instance_forwarding.cpp:80-149) ----
+def reproject_pixels(points, world_T_sensor, fx, fy, cx, cy, W, H):
+    """std::set<Pixel> of :583-593: every point goes through getSensorPose() (AS the reference applies it: the pose is
+    named sensor_T_world there but is world_T_sensor) in double, is cast to float and projected with
+    Sensor::projectPointToImagePlane(p, int& u, int& v) (ASSUMPTIONS.md A.8: z > 0, pinhole, nearest pixel, inside)."""
+    T = np.asarray(world_T_sensor, np.float64).reshape(4, 4)
+    p = np.asarray(points, np.float64).reshape(-1, 3)
+    ps = (p @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+    out = set()
+    f32 = np.float32
+    for x, y, z in ps:
+        if not z > 0:
+            continue
+        uf = f32(f32(f32(x * f32(fx)) / z) + f32(cx))
+        vf = f32(f32(f32(y * f32(fy)) / z) + f32(cy))
+        # std::round: halves away from zero
+        u = float(np.floor(abs(float(uf)) + 0.5) * (1 if uf >= 0 else -1))
+        v = float(np.floor(abs(float(vf)) + 0.5) * (1 if vf >= 0 else -1))
+        if 0 <= u < W and 0 <= v < H:
+            out.add((int(u), int(v)))
+    return out
+
+
+def iou_pixels(cluster_pixels, track_points, world_T_sensor, fx, fy, cx, cy, W, H):
+    """:595-599; cluster_pixels = list of (u, v), track_points = Track::last_points (n, 3)."""
+    rep = reproject_pixels(track_points, world_T_sensor, fx, fy, cx, cy, W, H)
+    inter = np.float32(0)
+    for px in cluster_pixels:
+        if px in rep:
+            inter = np.float32(inter + np.float32(1))
+    return np.float32(inter / np.float32(np.float32(len(cluster_pixels) + len(track_points)) - inter)), int(inter)
+
+
+def forward_instances(label, range_image, vertex_map, max_range=0.0, background_ids=()):
+    """extractSemanticClusters before the size / volume filters: {id: dict(pixels (column-major scan order), bbox)}."""
+    H, W = label.shape
+    bg = set(int(b) for b in background_ids)
+    out = {}
+    for u in range(W):
+        col = label[:, u]
+        for v in np.flatnonzero(col):
+            i = int(col[v])
+            if i in bg:
+                continue
+            if max_range > 0 and range_image[v, u] > max_range:
+                continue
+            out.setdefault(i, []).append((u, int(v)))
+    res = {}
+    for i, px in out.items():
+        pts = np.array([vertex_map[v, u] for (u, v) in px], np.float32)
+        res[i] = dict(id=i, pixels=px, num_pixels=len(px), bbox_min=pts.min(0), bbox_max=pts.max(0))
+    return res

@@ -22,6 +22,7 @@ class Track:
         self.has_semantics = False
         self.observations = []
         self.last_voxels = set()
+        self.last_points = np.zeros((0, 3), f32)  # track_by = pixels
         self.last_box = None
         self.last_centroid = np.zeros(3, f32)
 
@@ -55,17 +56,23 @@ class MaxIoUTracker:
         self.max_dynamic_distance = f32(max_dynamic_distance)
         self.temporal_window, self.min_num_observations, self.voxel_size = temporal_window, min_num_observations, f32(voxel_size)
         self.tracks, self.next_id, self.stamp = [], 0, 0
+        self.cam = None  # track_by = pixels: (world_T_sensor, fx, fy, cx, cy, W, H) of the frame being processed
 
     # -- measurements --
     def centroid(self, c):
         if self.track_by == "bounding_box":
             return (f32(0.5) * (c["box"][0] + c["box"][1])).astype(f32)
+        if self.track_by == "pixels":  # max_iou_tracker.cpp:543-549
+            return (c["points"].astype(np.float64).sum(0) / len(c["points"])).astype(f32)
         s = np.zeros(3, f32)
         for v in sorted(c["voxels"]):
             s = (s + (np.array(v, f32) + f32(0.5)) * self.voxel_size).astype(f32)
         return (s / f32(len(c["voxels"]))).astype(f32)
 
     def iou(self, c, t):
+        if self.track_by == "pixels":
+            from oracle import np_oracle as npo
+            return npo.iou_pixels(c["pixels"], t.last_points, *self.cam)[0]
         if self.track_by == "voxels":
             return iou_voxels(c["voxels"], t.last_voxels)
         return iou_box(t.last_box, c["box"])
@@ -74,6 +81,8 @@ class MaxIoUTracker:
     def update(self, c, t, dynamic):
         if self.track_by == "voxels":
             t.last_voxels = set(c["voxels"])
+        if self.track_by == "pixels":
+            t.last_points = c["points"]
         t.last_box = c["box"]
         if not dynamic and not t.has_semantics and c.get("category") is not None:
             t.has_semantics, t.category = True, c["category"]

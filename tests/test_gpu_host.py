@@ -334,9 +334,11 @@ def test_ray_verificator_host_mirror(policy):
     assert res["rays"] > 300 and n_hits > 20
 
 
-def test_object_pipeline_c_api_matches_replica():
+@pytest.mark.parametrize("track_by", ["voxels", "pixels"])
+def test_object_pipeline_c_api_matches_replica(track_by):
     """kop_* (detector -> tracker -> buffer -> extraction on a FusionContext's frame slots, the form bench.py and the
-    sharded driver use) against the step-wise device calls + the independent Python tracker."""
+    sharded driver use) against the step-wise device calls + the independent Python tracker; with the tracker's voxel sets
+    (the shipped configs) and with track_by = pixels (the reference default: re-projected points, khr_pixel_iou)."""
     import py_tracker
     from khronos_amd.host_capi import ObjectPipeline
     n_frames = 24
@@ -344,10 +346,15 @@ def test_object_pipeline_c_api_matches_replica():
                                             md_min_separation_distance=2.0, md_max_range=5.0, num_frame_slots=41)
     _, ctx2, _, _, _, _ = make_pair(width=W, height=H, temporal_window=0.75, truncation_distance=0.3, md_min_cluster_size=20,
                                     md_min_separation_distance=2.0, md_max_range=5.0)
-    pipe = ObjectPipeline(ctx, PLUGIN_YAML)
+    pipe = ObjectPipeline(ctx, PLUGIN_YAML.replace('track_by: "voxels"', 'track_by: "%s"' % track_by))
     ctx2.configure_object_detector(list(range(7, 20)), use_3d=True, grid_size=0.1, max_range=5.0, min_cluster_size=50,
                                    use_full_connectivity=True)
-    trk = py_tracker.MaxIoUTracker("voxels", "assign_cluster", 0.25, 0.0, 0.1, 1.0, 0.75, 3, 0.2)
+    trk = py_tracker.MaxIoUTracker(track_by, "assign_cluster", 0.25, 0.0, 0.1, 1.0, 0.75, 3, 0.2)
+
+    def pixel_fields(img, cid, vm):  # cluster.pixels / the vertices behind them, from the downloaded id image
+        vs, us = np.nonzero(img == cid)
+        return dict(pixels=list(zip(us.tolist(), vs.tolist())), points=vm[vs, us].astype(np.float32))
+
     n_obj_total, removed_total = 0, 0
     for i in range(n_frames):
         fr = s.render(i)
@@ -366,15 +373,24 @@ def test_object_pipeline_c_api_matches_replica():
         ctx2.update_tracking(fr["stamp"])
         ns = ctx2.detect_objects(slot2)
         sem, dyn = [], []
+        vm = ora.parse_input(osen, fr["pose"], fr["depth"])[1] if track_by == "pixels" else None
         if ns:
             ids, vox = ctx2.cluster_voxels(slot2, 1, 0.2)
+            oimg = np.zeros((H, W), np.int32)
+            ctx2.lib.khr_download_frame_image(ctx2.h, slot2, 1, oimg.ctypes.data)
             for c in ctx2.semantic_clusters(slot2):
                 sem.append(dict(id=c["id"], category=c["semantic_id"], voxels={tuple(int(x) for x in r) for r in vox[ids == c["id"]]},
                                 box=(c["bbox_min"], c["bbox_max"])))
+                if track_by == "pixels":
+                    sem[-1].update(pixel_fields(oimg, c["id"], vm))
         if nd:
             ids, vox = ctx2.cluster_voxels(slot2, 0, 0.2)
+            dimg = ctx2.download_frame(slot2, (H, W), range_image=False, dynamic_image=True)[2]
             for c in ctx2.dynamic_clusters(slot2):
                 dyn.append(dict(id=c["id"], voxels={tuple(int(x) for x in r) for r in vox[ids == c["id"]]}, box=(c["bbox_min"], c["bbox_max"])))
+                if track_by == "pixels":
+                    dyn[-1].update(pixel_fields(dimg, c["id"], vm))
+        trk.cam = (fr["pose"], s.fx, s.fy, s.cx, s.cy, W, H)
         trk.process(fr["stamp"], sem, dyn)
         assert n_tracks == len(trk.tracks)
         if out_now:

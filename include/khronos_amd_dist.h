@@ -1,0 +1,65 @@
+/* khronos_amd_dist.h -- C ABI of the multi-GPU (sharded) active-window tick, libkhronos_amd_host.so.
+ *
+ * TEST-INFRA-FREE product code: RCCL collectives issued from C++ on the fusion context's own HIP stream.  One process per GPU,
+ * one khr_ctx per process created with khr_config.rank / world_size (hash-range block ownership, owner computes).  The
+ * reference has no multi-process mode (khronos/src/active_window/active_window.cpp:118-174 is one thread, one map); what
+ * these calls replace, per rank, is the body of ActiveWindow::spinOnce -> updateMap / extractOutputData
+ * (active_window.cpp:186-260) with the exchanges DESIGN.md section 5 lists between the same steps.
+ *
+ * Rendezvous: rank 0 calls kdist_unique_id and hands the 128 bytes to the other ranks by whatever the launcher offers
+ * (env var, file, MPI, torch store); every rank then calls kdist_create with the same id.  All calls of one handle are
+ * collective: every rank must make the same call sequence.
+ *
+ * Errors: negative khr_status (include/khronos_amd.h), text via khr_last_error().  Exchange buffers are sized at create;
+ * exceeding one is KHR_ENOMEM from kdist_tick / kdist_output, never a silent truncation.
+ */
+#ifndef KHRONOS_AMD_DIST_H_
+#define KHRONOS_AMD_DIST_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "khronos_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kdist_handle kdist_handle;
+
+enum kdist_flags {
+  KDIST_MOTION = 1,          /* run the free-space motion detector (motion_detection/, a8-a11) inside the tick */
+  KDIST_SHARD_MOTION = 2,    /* cluster each camera on its home rank (camera % world) and broadcast the dynamic image;
+                                off: every rank all-reduces the keys and clusters every camera itself */
+  KDIST_ALWAYS_EXCHANGE = 4  /* issue the collectives even when world_size == 1 (single-GPU smoke of the RCCL path) */
+};
+
+/* ncclGetUniqueId: 128 opaque bytes. */
+int kdist_unique_id(char id_out[128]);
+
+/* n_cameras: frames per tick.  halo_cap: ever-free halo records (528 B) a rank may export per tick.  mesh_req_cap /
+ * mesh_rec_cap: marching-cubes halo plane requests / records per output stage.  Takes the context's stream over
+ * (khr_set_stream) for its lifetime.  NULL on failure. */
+kdist_handle* kdist_create(khr_ctx* ctx, const khr_sensor* sensor, int rank, int world_size, const char unique_id[128],
+                           int n_cameras, int64_t halo_cap, int64_t mesh_req_cap, int64_t mesh_rec_cap, uint32_t flags);
+void kdist_destroy(kdist_handle* h);
+
+/* the HIP stream (hipStream_t) every call of this handle is ordered on */
+void* kdist_stream(kdist_handle* h);
+
+/* ncclAllGather of one packed camera frame per rank (device pointer, same byte count on every rank); *gathered_out is a
+ * device buffer of world_size * bytes owned by the handle, valid until the next call. */
+int kdist_gather_frames(kdist_handle* h, const void* packed_local, size_t bytes, void** gathered_out);
+
+/* one tick: every camera's frame (device pointers) into this rank's shard.  slots_out[n]: frame slots; clusters_out[n]:
+ * dynamic clusters per camera (identical on every rank). */
+int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, int* slots_out, int* clusters_out);
+
+/* output stage (extractOutputData): mesh halo exchange, marching cubes over the owned updated blocks, archival of the
+ * blocks that left the window, flag clearing.  Results stay in the context (khr_download_mesh, khr_last_removed). */
+int kdist_output(kdist_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,343 @@
+// sharded_fusion.cpp — the multi-GPU tick of the active window in C++ over RCCL.
+//
+// One process per GPU, one khr_ctx per process (khr_config.rank / world_size: the block map is sharded by contiguous hash
+// range, owner-computes).  This file is the host side north_star asks for ("host code stays C++ ... RCCL ... over xGMI"):
+// the collectives are rccl calls on the context's own HIP stream, so the ActiveWindow drop-in can run sharded without any
+// Python.  khronos_amd/distributed.py keeps the same protocol on torch.distributed for the gloo (CPU, oracle-backed)
+// protocol tests; the two are step-for-step the same sequence of C-ABI calls.
+//
+// Per tick (the reference has no counterpart: it is single-process; call order inside a rank follows
+// active_window.cpp:118-174):
+//   (1) [caller or gatherFrames] the cameras' frames are all-gathered (packed depth | label | rgb, one ncclAllGather);
+//   (2) one ingest launch for all cameras with the motion detector's seed test folded in (khr_tick_ingest); block
+//       allocation + culling are queued right behind it (they do not depend on the dynamic masks);
+//   (3) ncclAllReduce of the per-camera seed-pixel counts (N x int64).  Only for cameras with seeds somewhere: the
+//       per-pixel voxel keys are ncclReduce'd to the camera's home rank (exactly one rank owns a pixel's block, everybody
+//       else contributes 0), which clusters them, paints the dynamic image and ncclBroadcasts it;
+//   (4) the fused TSDF / colour / label update of every camera into the owned blocks, then the tracking pass;
+//   (5) ncclAllGather of the halo records (528 B per live block: key + 4096 free-or-ever-free bits), ever-free stencil.
+// Output stage: request / response all-gathers of the marching-cubes halo planes, then mesh, archival, flag clearing.
+//
+// Exchange buffers are sized once; a rank whose live blocks or requests exceed them is an ERROR (KHR_ENOMEM), never a
+// silent truncation: the device counts overflows (khr_stats.pool_exhausted) and the output stage checks the counter.
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/khronos_amd_dist.h"
+
+extern "C" void khr_set_last_error(const char* text);
+
+namespace {
+
+struct Fail {
+  int code;
+  std::string what;
+};
+
+#define KD_HIP(expr)                                                                                          \
+  do {                                                                                                        \
+    const hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) throw Fail{KHR_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)};        \
+  } while (0)
+#define KD_NCCL(expr)                                                                                         \
+  do {                                                                                                        \
+    const ncclResult_t r_ = (expr);                                                                           \
+    if (r_ != ncclSuccess) throw Fail{KHR_EDEVICE, std::string(#expr) + ": " + ncclGetErrorString(r_)};      \
+  } while (0)
+#define KD_KHR(expr)                                                                                          \
+  do {                                                                                                        \
+    const long long r_ = static_cast<long long>(expr);                                                        \
+    if (r_ < 0) throw Fail{static_cast<int>(r_), std::string(#expr) + ": " + khr_last_error()};              \
+  } while (0)
+
+constexpr int kHaloWords = KHR_HALO_RECORD_BYTES / 8;
+constexpr int kMaxSplit = 8;  // frames per split-phase khr_tick_integrate call (khronos_amd.h)
+
+}  // namespace
+
+struct kdist_handle {
+  khr_ctx* ctx = nullptr;
+  khr_sensor sensor{};
+  int rank = 0, world = 1, n_cameras = 1;
+  bool motion = true, shard_motion = true, always_exchange = false, own_comm = false;
+  ncclComm_t comm = nullptr;
+  hipStream_t stream = nullptr;
+  int64_t halo_cap = 0, req_cap = 0, rec_cap = 0;
+  size_t npx = 0, mesh_words = 0;
+  // exchange buffers (HBM)
+  uint64_t* halo_send = nullptr;
+  uint64_t* halo_recv = nullptr;
+  int64_t* seed_counts = nullptr;             // [n_cameras]
+  std::vector<uint64_t*> keys;                // per camera: per-pixel voxel keys
+  std::vector<int32_t*> dyn_img;              // per camera: painted dynamic image + cluster count in the last element
+  uint64_t *req_send = nullptr, *req_recv = nullptr;
+  uint32_t *rec_send = nullptr, *rec_recv = nullptr;
+  void* frame_recv = nullptr;
+  size_t frame_recv_bytes = 0;
+  std::vector<int> clusters_last_tick;
+  std::vector<void*> allocs;
+
+  bool exchange() const { return world > 1 || always_exchange; }
+  template <typename T>
+  T* alloc(size_t count) {
+    void* p = nullptr;
+    KD_HIP(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    KD_HIP(hipMemsetAsync(p, 0, std::max<size_t>(count, 1) * sizeof(T), stream));
+    allocs.push_back(p);
+    return static_cast<T*>(p);
+  }
+};
+
+namespace {
+int guarded(const char* where, const std::function<int()>& body) {
+  try {
+    return body();
+  } catch (const Fail& f) {
+    khr_set_last_error((std::string(where) + ": " + f.what).c_str());
+    return f.code;
+  } catch (const std::exception& e) {
+    khr_set_last_error((std::string(where) + ": " + e.what()).c_str());
+    return KHR_EINVAL;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+// 128-byte rendezvous token of a new communicator: rank 0 makes it, every rank receives it out of band (MPI, a file, the
+// launcher's environment ...) and passes it to kdist_create
+int kdist_unique_id(char id_out[128]) {
+  return guarded("kdist_unique_id", [&]() {
+    static_assert(sizeof(ncclUniqueId) <= 128, "ncclUniqueId size");
+    ncclUniqueId id;
+    KD_NCCL(ncclGetUniqueId(&id));
+    std::memset(id_out, 0, 128);
+    std::memcpy(id_out, &id, sizeof(id));
+    return KHR_OK;
+  });
+}
+
+// ctx: this rank's fusion context (created with rank / world_size set); its stream becomes the communicator's stream.
+// flags: bit 0 motion detector on, bit 1 home-rank clustering (shard_motion), bit 2 run the collectives even with
+// world_size == 1 (smoke test of the RCCL path on one GPU).
+kdist_handle* kdist_create(khr_ctx* ctx, const khr_sensor* sensor, int rank, int world_size, const char unique_id[128],
+                           int n_cameras, int64_t halo_cap, int64_t mesh_req_cap, int64_t mesh_rec_cap, uint32_t flags) {
+  kdist_handle* h = nullptr;
+  const int rc = guarded("kdist_create", [&]() {
+    if (!ctx || !sensor || rank < 0 || world_size < 1 || rank >= world_size || n_cameras < 1 || halo_cap < 1 || mesh_req_cap < 1 ||
+        mesh_rec_cap < 1)
+      throw Fail{KHR_EINVAL, "bad argument"};
+    khr_config cfg{};
+    KD_KHR(khr_get_config(ctx, &cfg));
+    if (cfg.rank != rank || cfg.world_size != world_size) throw Fail{KHR_EINVAL, "the context was created for another rank / world size"};
+    h = new kdist_handle();
+    h->ctx = ctx;
+    h->sensor = *sensor;
+    h->rank = rank;
+    h->world = world_size;
+    h->n_cameras = n_cameras;
+    h->motion = flags & 1u;
+    h->shard_motion = flags & 2u;
+    h->always_exchange = flags & 4u;
+    h->halo_cap = halo_cap;
+    h->req_cap = mesh_req_cap;
+    h->rec_cap = mesh_rec_cap;
+    h->npx = static_cast<size_t>(sensor->width) * sensor->height;
+    h->mesh_words = KHR_MESH_HALO_RECORD_BYTES(cfg.voxels_per_side) / 4;
+    KD_HIP(hipSetDevice(cfg.device));
+    KD_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    KD_KHR(khr_set_stream(ctx, h->stream));  // fusion kernels and collectives share one stream: stream order is the protocol
+    if (h->exchange()) {
+      if (!unique_id) throw Fail{KHR_EINVAL, "a communicator needs the unique id made by rank 0 (kdist_unique_id)"};
+      ncclUniqueId id;
+      std::memcpy(&id, unique_id, sizeof(id));
+      KD_NCCL(ncclCommInitRank(&h->comm, world_size, id, rank));
+      h->own_comm = true;
+    }
+    const size_t W = static_cast<size_t>(world_size);
+    h->halo_send = h->alloc<uint64_t>(static_cast<size_t>(halo_cap) * kHaloWords);
+    h->halo_recv = h->alloc<uint64_t>(W * static_cast<size_t>(halo_cap) * kHaloWords);
+    h->seed_counts = h->alloc<int64_t>(static_cast<size_t>(n_cameras));
+    h->keys.assign(static_cast<size_t>(n_cameras), nullptr);
+    h->dyn_img.assign(static_cast<size_t>(n_cameras), nullptr);
+    h->req_send = h->alloc<uint64_t>(static_cast<size_t>(mesh_req_cap));
+    h->req_recv = h->alloc<uint64_t>(W * static_cast<size_t>(mesh_req_cap));
+    h->rec_send = h->alloc<uint32_t>(static_cast<size_t>(mesh_rec_cap) * h->mesh_words);
+    h->rec_recv = h->alloc<uint32_t>(W * static_cast<size_t>(mesh_rec_cap) * h->mesh_words);
+    h->clusters_last_tick.assign(static_cast<size_t>(n_cameras), 0);
+    KD_HIP(hipStreamSynchronize(h->stream));
+    return KHR_OK;
+  });
+  if (rc != KHR_OK) {
+    if (h) {
+      for (void* p : h->allocs) (void)hipFree(p);
+      if (h->comm) ncclCommDestroy(h->comm);
+      if (h->stream) {
+        khr_set_stream(ctx, nullptr);
+        (void)hipStreamDestroy(h->stream);
+      }
+      delete h;
+    }
+    return nullptr;
+  }
+  return h;
+}
+
+void kdist_destroy(kdist_handle* h) {
+  if (!h) return;
+  (void)hipStreamSynchronize(h->stream);
+  if (h->own_comm && h->comm) ncclCommDestroy(h->comm);
+  khr_set_stream(h->ctx, nullptr);  // the context goes back to a stream of its own
+  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->frame_recv) (void)hipFree(h->frame_recv);
+  (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+void* kdist_stream(kdist_handle* h) { return h ? static_cast<void*>(h->stream) : nullptr; }
+
+// all-gather of one packed frame per rank (bytes each) into world_size * bytes at *gathered_out (owned by the handle)
+int kdist_gather_frames(kdist_handle* h, const void* packed_local, size_t bytes, void** gathered_out) {
+  return guarded("kdist_gather_frames", [&]() {
+    if (!h || !packed_local || !gathered_out || bytes == 0) throw Fail{KHR_EINVAL, "bad argument"};
+    const size_t need = bytes * static_cast<size_t>(h->world);
+    if (h->frame_recv_bytes < need) {
+      if (h->frame_recv) {
+        KD_HIP(hipStreamSynchronize(h->stream));
+        (void)hipFree(h->frame_recv);
+        h->frame_recv = nullptr;
+      }
+      KD_HIP(hipMalloc(&h->frame_recv, need));
+      h->frame_recv_bytes = need;
+    }
+    if (h->exchange()) {
+      KD_NCCL(ncclAllGather(packed_local, h->frame_recv, bytes, ncclUint8, h->comm, h->stream));
+    } else {
+      KD_HIP(hipMemcpyAsync(h->frame_recv, packed_local, bytes, hipMemcpyDeviceToDevice, h->stream));
+    }
+    *gathered_out = h->frame_recv;
+    return KHR_OK;
+  });
+}
+
+// One tick: frames[n] = ALL cameras of the rig (device pointers, already gathered), in camera order on every rank.
+// slots_out[n] receives the frame slots; clusters_out[n] (may be NULL) the dynamic clusters per camera where this rank
+// knows them without a device round trip (its home cameras; -1 elsewhere).
+int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, int* slots_out, int* clusters_out) {
+  return guarded("kdist_tick", [&]() {
+    if (!h || !frames || !slots_out || n < 1 || n > h->n_cameras) throw Fail{KHR_EINVAL, "bad argument"};
+    khr_ctx* c = h->ctx;
+    const bool split = n <= kMaxSplit;
+    const bool ex = h->exchange();
+    std::vector<uint32_t> host_counts(static_cast<size_t>(n), 0u);
+    for (int i = 0; i < n; ++i) h->clusters_last_tick[static_cast<size_t>(i)] = 0;
+    // (2) ingest + seed test; nothing waits; allocation / culling queued behind it
+    KD_KHR(khr_tick_ingest(c, &h->sensor, frames, n, h->motion ? 1 : 0, slots_out, split ? nullptr : host_counts.data(), h->seed_counts));
+    if (split) KD_KHR(khr_tick_integrate(c, slots_out, n, h->motion ? 1 : 0, -1, 1));
+    if (h->motion) {
+      // (3) which cameras have seeds on some rank
+      std::vector<int64_t> cnt(static_cast<size_t>(n), 0);
+      if (ex && split) {
+        KD_NCCL(ncclAllReduce(h->seed_counts, h->seed_counts, static_cast<size_t>(n), ncclInt64, ncclSum, h->comm, h->stream));
+        KD_HIP(hipMemcpyAsync(cnt.data(), h->seed_counts, sizeof(int64_t) * static_cast<size_t>(n), hipMemcpyDeviceToHost, h->stream));
+        KD_HIP(hipStreamSynchronize(h->stream));
+      } else {
+        if (split) KD_KHR(khr_tick_seed_counts(c, host_counts.data(), n));
+        for (int i = 0; i < n; ++i) cnt[static_cast<size_t>(i)] = host_counts[static_cast<size_t>(i)];
+        if (ex) {
+          KD_HIP(hipMemcpyAsync(h->seed_counts, cnt.data(), sizeof(int64_t) * static_cast<size_t>(n), hipMemcpyHostToDevice, h->stream));
+          KD_NCCL(ncclAllReduce(h->seed_counts, h->seed_counts, static_cast<size_t>(n), ncclInt64, ncclSum, h->comm, h->stream));
+          KD_HIP(hipMemcpyAsync(cnt.data(), h->seed_counts, sizeof(int64_t) * static_cast<size_t>(n), hipMemcpyDeviceToHost, h->stream));
+          KD_HIP(hipStreamSynchronize(h->stream));
+        }
+      }
+      for (int ci = 0; ci < n; ++ci) {
+        if (cnt[static_cast<size_t>(ci)] == 0) continue;  // no seeds anywhere => no clusters, empty dynamic image
+        const int home = ci % h->world;
+        uint64_t*& keys = h->keys[static_cast<size_t>(ci)];
+        if (!keys) keys = h->alloc<uint64_t>(h->npx);
+        uint32_t n_seed = 0;
+        KD_KHR(khr_motion_keys(c, slots_out[ci], keys, 1, &n_seed));
+        if (!h->shard_motion) {
+          if (ex) KD_NCCL(ncclAllReduce(keys, keys, h->npx, ncclUint64, ncclSum, h->comm, h->stream));
+          const int nc = khr_detect_motion_from_keys(c, slots_out[ci], keys, 1);
+          KD_KHR(nc);
+          h->clusters_last_tick[static_cast<size_t>(ci)] = nc;
+          continue;
+        }
+        // the camera's home rank assembles the key image, clusters it and paints; everybody else receives the painted image
+        if (ex) KD_NCCL(ncclReduce(keys, keys, h->npx, ncclUint64, ncclSum, home, h->comm, h->stream));
+        int32_t*& img = h->dyn_img[static_cast<size_t>(ci)];
+        if (ex && !img) img = h->alloc<int32_t>(h->npx + 1);
+        if (h->rank == home) {
+          const int nc = khr_detect_motion_from_keys(c, slots_out[ci], keys, 1);
+          KD_KHR(nc);
+          h->clusters_last_tick[static_cast<size_t>(ci)] = nc;
+          if (ex) {
+            KD_KHR(khr_copy_frame_image(c, slots_out[ci], 0, img));
+            const int32_t nc32 = nc;
+            KD_HIP(hipMemcpyAsync(img + h->npx, &nc32, sizeof(nc32), hipMemcpyHostToDevice, h->stream));
+            KD_HIP(hipStreamSynchronize(h->stream));  // (nc32 lives on this stack frame)
+          }
+        } else {
+          h->clusters_last_tick[static_cast<size_t>(ci)] = -1;
+        }
+        if (ex) {
+          KD_NCCL(ncclBroadcast(img, img, h->npx + 1, ncclInt32, home, h->comm, h->stream));
+          if (h->rank != home) KD_KHR(khr_set_frame_image(c, slots_out[ci], 0, img, 1));
+        }
+      }
+    }
+    // (4) update of every camera, tracking pass
+    KD_KHR(khr_tick_integrate(c, slots_out, n, h->motion ? 1 : 0, -1, split ? 2 : 3));
+    KD_KHR(khr_update_tracking_phase(c, stamp, 1));
+    // (5) halo records of every rank, ever-free stencil
+    if (ex) {
+      KD_KHR(khr_export_halo(c, h->halo_send, h->halo_cap, 1));
+      KD_NCCL(ncclAllGather(h->halo_send, h->halo_recv, static_cast<size_t>(h->halo_cap) * kHaloWords, ncclUint64, h->comm, h->stream));
+      KD_KHR(khr_import_halo(c, h->halo_recv, static_cast<int64_t>(h->world) * h->halo_cap, 1));
+    }
+    KD_KHR(khr_update_tracking_phase(c, stamp, 2));
+    if (clusters_out)
+      for (int i = 0; i < n; ++i) clusters_out[i] = h->clusters_last_tick[static_cast<size_t>(i)];
+    return KHR_OK;
+  });
+}
+
+// ActiveWindow::extractOutputData, volumetric part (active_window.cpp:217-249), sharded: marching cubes on the
+// mesh-updated blocks with the neighbours' low planes fetched from their owners, then archival and flag clearing.
+int kdist_output(kdist_handle* h) {
+  return guarded("kdist_output", [&]() {
+    if (!h) throw Fail{KHR_EINVAL, "null handle"};
+    khr_ctx* c = h->ctx;
+    if (h->exchange()) {
+      KD_KHR(khr_mesh_halo_requests(c, h->req_send, h->req_cap, 1, 1));  // (errors when the requests exceed req_cap)
+      KD_NCCL(ncclAllGather(h->req_send, h->req_recv, static_cast<size_t>(h->req_cap), ncclUint64, h->comm, h->stream));
+      KD_KHR(khr_mesh_halo_export(c, h->req_recv, static_cast<int64_t>(h->world) * h->req_cap, h->rec_send, h->rec_cap, 1));
+      KD_NCCL(ncclAllGather(h->rec_send, h->rec_recv, static_cast<size_t>(h->rec_cap) * h->mesh_words, ncclUint32, h->comm, h->stream));
+      KD_KHR(khr_mesh_halo_import(c, h->rec_recv, static_cast<int64_t>(h->world) * h->rec_cap, 1));
+      // a rank with more live blocks than halo_cap, or more answers than rec_cap, would have truncated its records: the
+      // device counted that (the exchange kernels bump pool_exhausted), and this is where it becomes an error
+      khr_stats st{};
+      KD_KHR(khr_get_stats(c, &st));
+      if (st.pool_exhausted)
+        throw Fail{KHR_ENOMEM, "an exchange buffer was too small (halo_cap / mesh_rec_cap) or the block pool ran out: records were dropped"};
+    }
+    KD_KHR(khr_generate_mesh(c, 1, 1));
+    KD_KHR(khr_reset_inactive(c, nullptr, 0, nullptr));
+    KD_KHR(khr_clear_updated(c));
+    return KHR_OK;
+  });
+}
+
+}  // extern "C"

@@ -33,6 +33,16 @@ def load_host_library():
     lib.kop_num_tracks.argtypes = [vp]
     lib.kop_num_buffered_frames.argtypes = [vp]
     lib.kop_get_tracks.argtypes = [vp, vp, i32]
+    lib.kdist_unique_id.argtypes = [C.c_char_p]
+    lib.kdist_create.argtypes = [vp, C.POINTER(KhrSensor), i32, i32, C.c_char_p, i32, C.c_int64, C.c_int64, C.c_int64, C.c_uint32]
+    lib.kdist_create.restype = vp
+    lib.kdist_destroy.argtypes = [vp]
+    lib.kdist_destroy.restype = None
+    lib.kdist_stream.argtypes = [vp]
+    lib.kdist_stream.restype = vp
+    lib.kdist_gather_frames.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
+    lib.kdist_tick.argtypes = [vp, C.c_uint64, vp, i32, vp, vp]
+    lib.kdist_output.argtypes = [vp]
     lib.khr_host_detect_changes.argtypes = [vp, C.c_int64, vp, C.c_int64, C.c_float, C.c_int64, i32, C.c_float, C.c_float, i32, vp]
     _host = lib
     return lib
@@ -130,3 +140,57 @@ class ObjectPipeline:
         n = self.lib.kop_get_tracks(self.h, out.ctypes.data, n)
         return [dict(id=int(r[0]), dyn=int(r[1]), active=int(r[2]), cat=int(r[3]), n_obs=int(r[4]), first=int(r[5]), last=int(r[6]),
                      conf=r[7] / 1e6) for r in out[:n]]
+
+
+class ShardedFusionHost:
+    """The multi-GPU tick in C++ over RCCL (khronos_amd/host/sharded_fusion.cpp): the same protocol as
+    khronos_amd.distributed.ShardedFusion, with ncclAllGather / ncclAllReduce / ncclReduce / ncclBroadcast on the context's own
+    HIP stream instead of torch.distributed.  unique_id: the 128-byte token rank 0 made with unique_id() (any transport)."""
+    MOTION, SHARD_MOTION, ALWAYS_EXCHANGE = 1, 2, 4
+
+    @staticmethod
+    def unique_id():
+        lib = load_host_library()
+        buf = C.create_string_buffer(128)
+        if lib.kdist_unique_id(buf) < 0:
+            raise KhronosAmdError("kdist_unique_id failed: %s" % load_library().khr_last_error().decode())
+        return buf.raw
+
+    def __init__(self, ctx, sensor, rank, world_size, unique_id, n_cameras, halo_cap=8192, mesh_req_cap=16384, mesh_rec_cap=2048,
+                 motion=True, shard_motion=True, always_exchange=False):
+        self.lib, self.ctx, self.n_cameras = load_host_library(), ctx, n_cameras
+        flags = (self.MOTION if motion else 0) | (self.SHARD_MOTION if shard_motion else 0) | (self.ALWAYS_EXCHANGE if always_exchange else 0)
+        self.h = self.lib.kdist_create(ctx.h, C.byref(sensor), rank, world_size, unique_id, n_cameras, halo_cap, mesh_req_cap, mesh_rec_cap,
+                                       flags)
+        if not self.h:
+            raise KhronosAmdError("kdist_create failed: %s" % load_library().khr_last_error().decode())
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise KhronosAmdError("sharded fusion call failed (%d): %s" % (rc, load_library().khr_last_error().decode()))
+        return rc
+
+    def stream(self):
+        return self.lib.kdist_stream(self.h)
+
+    def gather_frames(self, packed_ptr, nbytes):
+        out = C.c_void_p()
+        self._chk(self.lib.kdist_gather_frames(self.h, packed_ptr, nbytes, C.byref(out)))
+        return out.value
+
+    def tick(self, stamp, frames):
+        """frames: list of KhrFrame (device pointers), all cameras in camera order -> (slots, clusters)."""
+        from .capi import KhrFrame
+        arr = (KhrFrame * len(frames))(*frames)
+        slots = (C.c_int32 * len(frames))()
+        clusters = (C.c_int32 * len(frames))()
+        self._chk(self.lib.kdist_tick(self.h, int(stamp), arr, len(frames), slots, clusters))
+        return list(slots), list(clusters)
+
+    def output(self):
+        self._chk(self.lib.kdist_output(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.kdist_destroy(self.h)
+            self.h = None

@@ -194,3 +194,21 @@ def test_tracker_plugins_match_independent_restatement():
         assert n_tracks_max >= 4
         if kind == "maxiou":
             assert any(t["dyn"] for t in got[-1]) and any(not t["active"] for t in got[-1])
+
+
+def test_host_library_exports_the_sharded_tick_abi():
+    """libkhronos_amd_host.so loads on a CPU-only box and exports every entry point include/khronos_amd_dist.h declares
+    (the RCCL tick; no compute, no communicator is created here)."""
+    import ctypes
+    import re
+    from khronos_amd import host_capi
+    hdr = open(os.path.join(ROOT, "include", "khronos_amd_dist.h")).read()
+    declared = set(re.findall(r"\b(kdist_[a-z_]+)\s*\(", hdr))
+    assert declared == {"kdist_unique_id", "kdist_create", "kdist_destroy", "kdist_stream", "kdist_gather_frames", "kdist_tick",
+                        "kdist_output"}
+    lib = ctypes.CDLL(host_capi.HOST_LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name in declared:
+        assert hasattr(lib, name), name
+    # the loader sets prototypes for all of them
+    lib2 = host_capi.load_host_library()
+    assert lib2.kdist_create.restype is ctypes.c_void_p

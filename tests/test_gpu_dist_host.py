@@ -1,0 +1,57 @@
+"""-m gpu: the C++ / RCCL sharded tick (khronos_amd/host/sharded_fusion.cpp) on ONE GPU: world_size 1 with the collectives
+forced on (ncclAllReduce / ncclReduce / ncclBroadcast / ncclAllGather over a one-rank communicator), against the plain
+single-context path on the same frames.  (The N-rank protocol itself is exercised by tests/test_cpu_distributed.py over gloo
+with the oracle as the shard backend; an N-GPU RCCL run needs an N-GPU node, which only the round driver has.)"""
+import numpy as np
+import pytest
+
+from common import DeviceArray, make_pair
+
+pytestmark = pytest.mark.gpu
+W, H = 320, 240
+
+
+@pytest.mark.parametrize("shard_motion", [True, False])
+def test_cxx_rccl_tick_equals_single_context(shard_motion):
+    from khronos_amd.host_capi import ShardedFusionHost
+    cfg, ctx, ora, s, sen, osen = make_pair(width=W, height=H, temporal_window=0.75, num_frame_slots=4)
+    _, ref, _, _, _, _ = make_pair(width=W, height=H, temporal_window=0.75, num_frame_slots=4)
+    sf = ShardedFusionHost(ctx, sen, 0, 1, ShardedFusionHost.unique_id(), n_cameras=1, halo_cap=4096, mesh_req_cap=4096,
+                           mesh_rec_cap=512, motion=True, shard_motion=shard_motion, always_exchange=True)
+    held, fired = [], 0
+    for i in range(20):
+        fr = s.render(i)
+        dev = [DeviceArray(np.ascontiguousarray(fr[k])) for k in ("depth", "rgb", "label")]
+        held.append(dev)
+        f = ctx.make_frame(fr["stamp"], fr["pose"], dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr())
+        slots, clusters = sf.tick(fr["stamp"], [f])
+        # reference: the plain calls on a second context
+        slot2 = ref.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+        n2 = ref.detect_motion(slot2)
+        ref.integrate(slot2, allocate_blocks=True, use_mask=True)
+        ref.update_tracking(fr["stamp"])
+        assert clusters[0] == n2, (i, clusters, n2)
+        fired += n2
+        d1 = ctx.download_frame(slots[0], (H, W), range_image=False, dynamic_image=True)[2]
+        d2 = ref.download_frame(slot2, (H, W), range_image=False, dynamic_image=True)[2]
+        assert np.array_equal(d1, d2), i
+        if i % 4 == 3:
+            sf.output()
+            ref.generate_mesh(True, True)
+            ref.reset_inactive()
+            ref.clear_updated()
+            m1, m2 = ctx.download_mesh(), ref.download_mesh()
+            assert m1["points"].shape == m2["points"].shape
+    assert fired > 0
+    a, b = ctx.block_indices(), ref.block_indices()
+    assert np.array_equal(a, b) and len(a) > 20
+    for idx in a[::2]:
+        g, h = ctx.download_block(idx), ref.download_block(idx)
+        for k in ("distance", "weight", "color", "last_observed", "last_occupied", "flags", "sem_label"):
+            assert np.array_equal(g[k], h[k]), (k, idx)
+    assert ctx.stats()["pool_exhausted"] == 0
+    sf.close()
+    ctx.sync()
+    for dev in held:
+        for d in dev:
+            d.free()

@@ -71,6 +71,9 @@ def parse_args():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="development: ONE process plays rank 0 of an N-rank sharded run (all N cameras rendered locally, no "
                          "collectives) to measure the per-rank tick cost on a 1-GPU box; the JSON line is marked emulation")
+    ap.add_argument("--dist-host", choices=["cxx", "torch"], default="cxx",
+                    help="N > 1: who issues the tick's collectives: cxx = RCCL from libkhronos_amd_host.so (kdist_*, the product "
+                         "path), torch = khronos_amd/distributed.py over torch.distributed (the protocol test harness)")
     ap.add_argument("--halo-cap", type=int, default=8192, help="halo records all-gathered per rank and tick (N > 1)")
     a = ap.parse_args()
     preset = {"c3": dict(width=1280, height=720, voxel_size=0.02, output_every=4, no_motion=False, no_objects=False, no_tracking=False, preroll=60),
@@ -252,11 +255,41 @@ def main():
         frame_desc = [ctx.make_frame(stamps[i], poses[i][0], d_depth[i].data_ptr(), d_rgb[i].data_ptr(), d_label[i].data_ptr())
                       for i in range(n_total)]
     fusion = None
+    fusion_cxx = None
+    dist_host = "none"
     if world > 1:
-        from khronos_amd.distributed import HipShard, ShardedFusion
-        with torch.cuda.stream(stream):
-            fusion = ShardedFusion(HipShard(ctx, sensor, args.halo_cap, dev, n_cameras=world), dist, world,
-                                   motion=not args.no_motion, count_device=dev if backend == "nccl" else "cpu")
+        if not emu and backend == "nccl" and args.dist_host == "cxx":
+            # the tick's collectives from C++ (RCCL on the context's stream); torch.distributed only carries the 128-byte
+            # rendezvous token and the synthetic frames.  Creation is agreed on collectively: if any rank cannot build
+            # its communicator, every rank falls back to the torch harness below.
+            from khronos_amd.host_capi import ShardedFusionHost
+            tok = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                tok.copy_(torch.frombuffer(bytearray(ShardedFusionHost.unique_id()), dtype=torch.uint8))
+            dist.broadcast(tok, 0)
+            ok = torch.ones(1, dtype=torch.int32, device=dev)
+            try:
+                fusion_cxx = ShardedFusionHost(ctx, sensor, rank, world, bytes(tok.cpu().numpy().tobytes()), n_cameras=world,
+                                               halo_cap=args.halo_cap, mesh_req_cap=args.mesh_req_cap,
+                                               mesh_rec_cap=args.mesh_rec_cap, motion=not args.no_motion, shard_motion=True)
+            except Exception as e:  # noqa: BLE001
+                print("rank %d: kdist_create failed (%s); falling back to --dist-host torch" % (rank, e), file=sys.stderr)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if fusion_cxx is not None:
+                    fusion_cxx.close()
+                fusion_cxx = None
+                ctx.set_stream(stream.cuda_stream)
+            else:
+                stream = torch.cuda.ExternalStream(fusion_cxx.stream(), device=dev)  # the tick's stream, for event ordering
+                dist_host = "cxx"
+        if fusion_cxx is None:
+            from khronos_amd.distributed import HipShard, ShardedFusion
+            with torch.cuda.stream(stream):
+                fusion = ShardedFusion(HipShard(ctx, sensor, args.halo_cap, dev, n_cameras=world), dist, world,
+                                       motion=not args.no_motion, count_device=dev if backend == "nccl" else "cpu")
+            dist_host = "emulated" if emu else "torch"
 
     def step(i):
         with torch.cuda.stream(stream):
@@ -278,12 +311,20 @@ def main():
         out_now = args.output_every > 0 and (i + 1) % args.output_every == 0
         if world > 1:
             # sharded tick: integrate all cameras into the owned blocks, tracking, halo all-gather, ever-free
-            slots = fusion.tick(stamps[i], [(pose, dep, rgb, lab) for (dep, rgb, lab, pose) in cams])
+            if fusion_cxx is not None:
+                slots, clusters = fusion_cxx.tick(stamps[i], [
+                    ctx.make_frame(stamps[i], pose, dep.data_ptr(), rgb.data_ptr(), lab.data_ptr()) for (dep, rgb, lab, pose) in cams])
+            else:
+                slots = fusion.tick(stamps[i], [(pose, dep, rgb, lab) for (dep, rgb, lab, pose) in cams])
+                clusters = fusion.clusters_last_tick
             if pipe is not None:  # owner-computes for objects: each rank handles its own camera
                 pipe.finish_frame()  # tracker association of the previous tick, while this tick's kernels run
-                pipe.launch_frame(slots[rank], stamps[i], poses[i][rank], sensor, fusion.clusters_last_tick[rank])
+                pipe.launch_frame(slots[rank], stamps[i], poses[i][rank], sensor, clusters[rank])
             if out_now:
-                fusion.output(req_cap=args.mesh_req_cap, rec_cap=args.mesh_rec_cap)
+                if fusion_cxx is not None:
+                    fusion_cxx.output()
+                else:
+                    fusion.output(req_cap=args.mesh_req_cap, rec_cap=args.mesh_rec_cap)
                 if pipe is not None:
                     t_e = time.perf_counter()
                     n_obj, n_rm, _ = pipe.extract_inactive()
@@ -425,7 +466,10 @@ def main():
                    "preset": args.config if preset_matches else None,
                    "parallelism": "hash-range block shard x%d, owner-computes, RCCL all-gather of packed frames (prefetched one tick ahead on its own stream) + of 528-B halo records "
                                   "(ever-free), seed-gated all-reduce of per-pixel voxel keys (motion detector), request / response all-gather of mesh halo planes" % world
-                   if world > 1 else "single GPU"},
+                   if world > 1 else "single GPU",
+                   "collectives_issued_by": {"cxx": "libkhronos_amd_host.so (kdist_*: rccl calls on the context's HIP stream)",
+                                             "torch": "khronos_amd/distributed.py (torch.distributed)", "emulated": "none (emulation)",
+                                             "none": None}[dist_host]},
         "mvoxel_updates_per_s": 1e-6 * n_upd_all / dt,
         **({"emulation": "rank 0 of a %d-rank sharded run played by one process, no collectives: `value` is what the job would reach "
                          "if communication were free and all ranks were as loaded as rank 0 -- NOT a measured N-GPU number" % world}

@@ -151,6 +151,7 @@ struct khr_ctx {
   bool seed_publish_pending = false;
   bool seed_by_ticket = false;   // motionFinish waits for the ticket (k_motion_pixels) instead of ev_seed (key import)
   bool begin_in_ingest = false, begun = false;  // khr_process_frame folds k_begin_integrate into k_frame_ingest
+  int last_frame_slot = -1;                      // khr_process_frame: slot of the frame queued last
   hipStream_t ingest_stream = nullptr;           // khr_process_frame: ingest on the auxiliary stream (set around khr_upload_frame)
   bool early_ingest = true;                      // env KHR_NO_EARLY_INGEST=1 turns it off
   int ef_parity = 0, ef_cur = 0;  // which of C_N_EF / C_N_EF2 the next / the latest tracking pass fills
@@ -516,11 +517,12 @@ int khr_retain_slot(khr_ctx* c, int slot) {
 
 int khr_release_slot(khr_ctx* c, int slot) {
   if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size())) return fail(KHR_EINVAL, "bad slot");
-  if (c->slot_leases[slot].fetch_sub(1, std::memory_order_acq_rel) <= 0) {
-    c->slot_leases[slot].store(0);
-    return fail(KHR_ESTATE, "slot %d was not retained", slot);
-  }
-  return KHR_OK;
+  // decrement only while positive (leases are taken and dropped by the frame thread and by detached extraction workers:
+  // an unmatched release must not erase a lease somebody else takes at the same moment)
+  int cur = c->slot_leases[slot].load(std::memory_order_acquire);
+  while (cur > 0)
+    if (c->slot_leases[slot].compare_exchange_weak(cur, cur - 1, std::memory_order_acq_rel, std::memory_order_acquire)) return KHR_OK;
+  return fail(KHR_ESTATE, "slot %d was not retained", slot);
 }
 
 int khr_depend_on(khr_ctx* c, khr_ctx* other) {
@@ -875,6 +877,16 @@ static int auxAfterMain(khr_ctx* c) {
 }
 
 // next slot of the frame ring that nobody holds
+// the slot acquireSlot would hand out next (-1: none free); no side effects
+static int peekSlot(const khr_ctx* c) {
+  const int n_slots = static_cast<int>(c->slots.size());
+  for (int k = 0; k < n_slots; ++k) {
+    const int cand = (c->next_slot + k) % n_slots;
+    if (c->slot_leases[cand].load(std::memory_order_acquire) == 0) return cand;
+  }
+  return -1;
+}
+
 static int acquireSlot(khr_ctx* c) {
   const int n_slots = static_cast<int>(c->slots.size());
   int slot = -1;
@@ -907,6 +919,7 @@ int khr_upload_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fram
   if (slot < 0) return slot;
   FrameSlot& s = c->slots[slot];
   const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  s.valid = false;  // until the ingest is queued: an error below leaves a slot nobody can integrate, not the previous occupant
   s.sensor = *sensor;
   s.meta = *frame;
   s.meta.depth = nullptr;
@@ -1332,15 +1345,28 @@ int khr_tick_ingest(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame
   c->tick_seed_collected = 0;
   const int tw = (sensor->width + kTile - 1) / kTile, th = (sensor->height + kTile - 1) / kTile;
   ScopedTimer tm(c, 6);
+  // all slots of the tick first: nothing of the ring's state is touched unless the whole tick fits
+  const int ring_pos = c->next_slot;
+  for (int i = 0; i < n_frames; ++i) {
+    const int slot = acquireSlot(c);
+    bool wrapped = false;
+    for (int j = 0; j < i && slot >= 0; ++j) wrapped |= slots_out[j] == slot;  // the ring wrapped around retained slots
+    if (slot < 0 || wrapped) {
+      c->next_slot = ring_pos;
+      return slot < 0 ? slot : fail(KHR_ENOMEM, "not enough free frame slots for a tick of %d frames (raise num_frame_slots)", n_frames);
+    }
+    slots_out[i] = slot;
+  }
+  struct Invalidate {  // an error after this point leaves the tick's slots unusable instead of half-written
+    khr_ctx* c; const int* slots; int n; bool armed = true;
+    ~Invalidate() { if (armed) for (int i = 0; i < n; ++i) c->slots[slots[i]].valid = false; }
+  } undo{c, slots_out, n_frames};
   for (int base = 0; base < n_frames; base += kMaxTick) {
     const int nb = std::min(kMaxTick, n_frames - base);
     TickIngest t{};
     for (int k = 0; k < nb; ++k) {
       const khr_frame& fr = frames[base + k];
-      const int slot = acquireSlot(c);
-      if (slot < 0) return slot;
-      for (int j = 0; j < base + k; ++j)  // the ring wrapped around retained slots: this tick would overwrite itself
-        if (slots_out[j] == slot) return fail(KHR_ENOMEM, "not enough free frame slots for a tick of %d frames (raise num_frame_slots)", n_frames);
+      const int slot = slots_out[base + k];
       FrameSlot& s = c->slots[slot];
       s.sensor = *sensor;
       s.meta = fr;
@@ -1357,7 +1383,6 @@ int khr_tick_ingest(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame
       s.th = th;
       s.valid = true;
       s.dyn_clean = true;
-      slots_out[base + k] = slot;
       t.depth_in[k] = fr.depth; t.rgb_in[k] = fr.color; t.label_in[k] = fr.label;
       t.depth[k] = s.depth; t.range[k] = s.range; t.rgba[k] = s.rgba; t.label[k] = s.label; t.dyn[k] = s.dyn;
       t.tile_max[k] = s.tile_max;
@@ -1391,6 +1416,7 @@ int khr_tick_ingest(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame
   if (!count_seeds && seed_counts_device) HIP_TRY(hipMemsetAsync(seed_counts_device, 0, sizeof(int64_t) * n_frames, c->stream));
   c->begun = false;
   c->begin_in_ingest = false;
+  undo.armed = false;
   return KHR_OK;
 }
 
@@ -2686,13 +2712,18 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   // executes beside the tail of the previous frame (tracking, ever-free, output) instead of after it.  Only with the
   // motion detector on: its per-frame host wait is what keeps the host from queueing frames whose slot an earlier
   // frame still reads.  The per-frame counter reset moves to the first main-stream kernel (k_motion_pixels).
-  const bool early = c->early_ingest && (flags & KHR_PF_INPUT_READY) && on_device && motion && c->cfg.with_tracking && c->slots.size() >= 2;
+  // Not when the ring hands back the slot of the frame queued just before (everything else is retained): that frame's
+  // update / summary / tracking kernels may still be running on the main stream, and the auxiliary stream is not ordered
+  // behind them -- the ingest then stays on the main stream.
+  const bool early = c->early_ingest && (flags & KHR_PF_INPUT_READY) && on_device && motion && c->cfg.with_tracking &&
+                     c->slots.size() >= 2 && peekSlot(c) != c->last_frame_slot;
   c->begin_in_ingest = !early;
   c->ingest_stream = early ? c->aux_stream : nullptr;
   const int slot = khr_upload_frame(c, sensor, frame, on_device);
   c->ingest_stream = nullptr;
   c->begin_in_ingest = false;
   if (slot < 0) return slot;
+  c->last_frame_slot = slot;
   FrameSlot& s = c->slots[slot];
   const DevFrame f = makeDevFrame(c, s);
   int rc = KHR_OK;

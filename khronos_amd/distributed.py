@@ -118,6 +118,14 @@ class HipShard:
         self.ctx.reset_inactive_async()
         self.ctx.clear_updated()
 
+    def check_exchange_overflow(self):
+        """the exchange buffers (halo_cap, mesh request / record caps) are fixed-size; a rank that had more to send counted it on
+        the device (khr_stats.pool_exhausted, sticky) instead of sending it.  That is an error, not a result."""
+        n = self.ctx.stats()["pool_exhausted"]
+        if n:
+            raise RuntimeError("sharded fusion: %d exchange / pool overflows (raise halo_cap / mesh_req_cap / mesh_rec_cap / "
+                               "max_blocks): the map of this run is incomplete" % n)
+
 
 class ShardedFusion:
     def __init__(self, shard, dist=None, world_size=1, motion=True, count_device="cpu", shard_motion=True):
@@ -229,3 +237,5 @@ class ShardedFusion:
             self.shard.mesh_import(recs)
         self.shard.generate_mesh()
         self.shard.archive()
+        if hasattr(self.shard, "check_exchange_overflow"):
+            self.shard.check_exchange_overflow()

@@ -24,6 +24,8 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -31,6 +33,7 @@
 #include <functional>
 #include <memory>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/khronos_amd_dist.h"
@@ -44,6 +47,44 @@ struct Fail {
   std::string what;
 };
 
+// RCCL is bound at the first kdist_* call, not at load time: a process that only uses the single-GPU ActiveWindow (or a
+// CPU-only box running the host-logic tests) never maps it, and a process that already carries an RCCL (the soname is
+// shared with PyTorch-ROCm's copy) keeps exactly one.
+struct Rccl {
+  decltype(&::ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&::ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&::ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&::ncclAllGather) AllGather = nullptr;
+  decltype(&::ncclAllReduce) AllReduce = nullptr;
+  decltype(&::ncclReduce) Reduce = nullptr;
+  decltype(&::ncclBroadcast) Broadcast = nullptr;
+  decltype(&::ncclGetErrorString) GetErrorString = nullptr;
+};
+
+const Rccl& rccl() {
+  static const Rccl table = [] {
+    void* lib = nullptr;
+    for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"})
+      if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) throw Fail{KHR_EDEVICE, std::string("RCCL (librccl.so.1) cannot be loaded: ") + dlerror()};
+    Rccl t;
+    auto bind = [&](auto& fn, const char* sym) {
+      fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(lib, sym));
+      if (!fn) throw Fail{KHR_EDEVICE, std::string("librccl has no ") + sym};
+    };
+    bind(t.GetUniqueId, "ncclGetUniqueId");
+    bind(t.CommInitRank, "ncclCommInitRank");
+    bind(t.CommDestroy, "ncclCommDestroy");
+    bind(t.AllGather, "ncclAllGather");
+    bind(t.AllReduce, "ncclAllReduce");
+    bind(t.Reduce, "ncclReduce");
+    bind(t.Broadcast, "ncclBroadcast");
+    bind(t.GetErrorString, "ncclGetErrorString");
+    return t;
+  }();
+  return table;
+}
+
 #define KD_HIP(expr)                                                                                          \
   do {                                                                                                        \
     const hipError_t e_ = (expr);                                                                             \
@@ -52,7 +93,7 @@ struct Fail {
 #define KD_NCCL(expr)                                                                                         \
   do {                                                                                                        \
     const ncclResult_t r_ = (expr);                                                                           \
-    if (r_ != ncclSuccess) throw Fail{KHR_EDEVICE, std::string(#expr) + ": " + ncclGetErrorString(r_)};      \
+    if (r_ != ncclSuccess) throw Fail{KHR_EDEVICE, std::string(#expr) + ": " + rccl().GetErrorString(r_)};      \
   } while (0)
 #define KD_KHR(expr)                                                                                          \
   do {                                                                                                        \
@@ -120,7 +161,7 @@ int kdist_unique_id(char id_out[128]) {
   return guarded("kdist_unique_id", [&]() {
     static_assert(sizeof(ncclUniqueId) <= 128, "ncclUniqueId size");
     ncclUniqueId id;
-    KD_NCCL(ncclGetUniqueId(&id));
+    KD_NCCL(rccl().GetUniqueId(&id));
     std::memset(id_out, 0, 128);
     std::memcpy(id_out, &id, sizeof(id));
     return KHR_OK;
@@ -161,7 +202,7 @@ kdist_handle* kdist_create(khr_ctx* ctx, const khr_sensor* sensor, int rank, int
       if (!unique_id) throw Fail{KHR_EINVAL, "a communicator needs the unique id made by rank 0 (kdist_unique_id)"};
       ncclUniqueId id;
       std::memcpy(&id, unique_id, sizeof(id));
-      KD_NCCL(ncclCommInitRank(&h->comm, world_size, id, rank));
+      KD_NCCL(rccl().CommInitRank(&h->comm, world_size, id, rank));
       h->own_comm = true;
     }
     const size_t W = static_cast<size_t>(world_size);
@@ -181,7 +222,7 @@ kdist_handle* kdist_create(khr_ctx* ctx, const khr_sensor* sensor, int rank, int
   if (rc != KHR_OK) {
     if (h) {
       for (void* p : h->allocs) (void)hipFree(p);
-      if (h->comm) ncclCommDestroy(h->comm);
+      if (h->comm) rccl().CommDestroy(h->comm);
       if (h->stream) {
         khr_set_stream(ctx, nullptr);
         (void)hipStreamDestroy(h->stream);
@@ -196,7 +237,7 @@ kdist_handle* kdist_create(khr_ctx* ctx, const khr_sensor* sensor, int rank, int
 void kdist_destroy(kdist_handle* h) {
   if (!h) return;
   (void)hipStreamSynchronize(h->stream);
-  if (h->own_comm && h->comm) ncclCommDestroy(h->comm);
+  if (h->own_comm && h->comm) rccl().CommDestroy(h->comm);
   khr_set_stream(h->ctx, nullptr);  // the context goes back to a stream of its own
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->frame_recv) (void)hipFree(h->frame_recv);
@@ -221,7 +262,7 @@ int kdist_gather_frames(kdist_handle* h, const void* packed_local, size_t bytes,
       h->frame_recv_bytes = need;
     }
     if (h->exchange()) {
-      KD_NCCL(ncclAllGather(packed_local, h->frame_recv, bytes, ncclUint8, h->comm, h->stream));
+      KD_NCCL(rccl().AllGather(packed_local, h->frame_recv, bytes, ncclUint8, h->comm, h->stream));
     } else {
       KD_HIP(hipMemcpyAsync(h->frame_recv, packed_local, bytes, hipMemcpyDeviceToDevice, h->stream));
     }
@@ -248,7 +289,7 @@ int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, 
       // (3) which cameras have seeds on some rank
       std::vector<int64_t> cnt(static_cast<size_t>(n), 0);
       if (ex && split) {
-        KD_NCCL(ncclAllReduce(h->seed_counts, h->seed_counts, static_cast<size_t>(n), ncclInt64, ncclSum, h->comm, h->stream));
+        KD_NCCL(rccl().AllReduce(h->seed_counts, h->seed_counts, static_cast<size_t>(n), ncclInt64, ncclSum, h->comm, h->stream));
         KD_HIP(hipMemcpyAsync(cnt.data(), h->seed_counts, sizeof(int64_t) * static_cast<size_t>(n), hipMemcpyDeviceToHost, h->stream));
         KD_HIP(hipStreamSynchronize(h->stream));
       } else {
@@ -256,7 +297,7 @@ int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, 
         for (int i = 0; i < n; ++i) cnt[static_cast<size_t>(i)] = host_counts[static_cast<size_t>(i)];
         if (ex) {
           KD_HIP(hipMemcpyAsync(h->seed_counts, cnt.data(), sizeof(int64_t) * static_cast<size_t>(n), hipMemcpyHostToDevice, h->stream));
-          KD_NCCL(ncclAllReduce(h->seed_counts, h->seed_counts, static_cast<size_t>(n), ncclInt64, ncclSum, h->comm, h->stream));
+          KD_NCCL(rccl().AllReduce(h->seed_counts, h->seed_counts, static_cast<size_t>(n), ncclInt64, ncclSum, h->comm, h->stream));
           KD_HIP(hipMemcpyAsync(cnt.data(), h->seed_counts, sizeof(int64_t) * static_cast<size_t>(n), hipMemcpyDeviceToHost, h->stream));
           KD_HIP(hipStreamSynchronize(h->stream));
         }
@@ -269,14 +310,14 @@ int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, 
         uint32_t n_seed = 0;
         KD_KHR(khr_motion_keys(c, slots_out[ci], keys, 1, &n_seed));
         if (!h->shard_motion) {
-          if (ex) KD_NCCL(ncclAllReduce(keys, keys, h->npx, ncclUint64, ncclSum, h->comm, h->stream));
+          if (ex) KD_NCCL(rccl().AllReduce(keys, keys, h->npx, ncclUint64, ncclSum, h->comm, h->stream));
           const int nc = khr_detect_motion_from_keys(c, slots_out[ci], keys, 1);
           KD_KHR(nc);
           h->clusters_last_tick[static_cast<size_t>(ci)] = nc;
           continue;
         }
         // the camera's home rank assembles the key image, clusters it and paints; everybody else receives the painted image
-        if (ex) KD_NCCL(ncclReduce(keys, keys, h->npx, ncclUint64, ncclSum, home, h->comm, h->stream));
+        if (ex) KD_NCCL(rccl().Reduce(keys, keys, h->npx, ncclUint64, ncclSum, home, h->comm, h->stream));
         int32_t*& img = h->dyn_img[static_cast<size_t>(ci)];
         if (ex && !img) img = h->alloc<int32_t>(h->npx + 1);
         if (h->rank == home) {
@@ -293,7 +334,7 @@ int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, 
           h->clusters_last_tick[static_cast<size_t>(ci)] = -1;
         }
         if (ex) {
-          KD_NCCL(ncclBroadcast(img, img, h->npx + 1, ncclInt32, home, h->comm, h->stream));
+          KD_NCCL(rccl().Broadcast(img, img, h->npx + 1, ncclInt32, home, h->comm, h->stream));
           if (h->rank != home) KD_KHR(khr_set_frame_image(c, slots_out[ci], 0, img, 1));
         }
       }
@@ -304,7 +345,7 @@ int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, 
     // (5) halo records of every rank, ever-free stencil
     if (ex) {
       KD_KHR(khr_export_halo(c, h->halo_send, h->halo_cap, 1));
-      KD_NCCL(ncclAllGather(h->halo_send, h->halo_recv, static_cast<size_t>(h->halo_cap) * kHaloWords, ncclUint64, h->comm, h->stream));
+      KD_NCCL(rccl().AllGather(h->halo_send, h->halo_recv, static_cast<size_t>(h->halo_cap) * kHaloWords, ncclUint64, h->comm, h->stream));
       KD_KHR(khr_import_halo(c, h->halo_recv, static_cast<int64_t>(h->world) * h->halo_cap, 1));
     }
     KD_KHR(khr_update_tracking_phase(c, stamp, 2));
@@ -322,9 +363,9 @@ int kdist_output(kdist_handle* h) {
     khr_ctx* c = h->ctx;
     if (h->exchange()) {
       KD_KHR(khr_mesh_halo_requests(c, h->req_send, h->req_cap, 1, 1));  // (errors when the requests exceed req_cap)
-      KD_NCCL(ncclAllGather(h->req_send, h->req_recv, static_cast<size_t>(h->req_cap), ncclUint64, h->comm, h->stream));
+      KD_NCCL(rccl().AllGather(h->req_send, h->req_recv, static_cast<size_t>(h->req_cap), ncclUint64, h->comm, h->stream));
       KD_KHR(khr_mesh_halo_export(c, h->req_recv, static_cast<int64_t>(h->world) * h->req_cap, h->rec_send, h->rec_cap, 1));
-      KD_NCCL(ncclAllGather(h->rec_send, h->rec_recv, static_cast<size_t>(h->rec_cap) * h->mesh_words, ncclUint32, h->comm, h->stream));
+      KD_NCCL(rccl().AllGather(h->rec_send, h->rec_recv, static_cast<size_t>(h->rec_cap) * h->mesh_words, ncclUint32, h->comm, h->stream));
       KD_KHR(khr_mesh_halo_import(c, h->rec_recv, static_cast<int64_t>(h->world) * h->rec_cap, 1));
       // a rank with more live blocks than halo_cap, or more answers than rec_cap, would have truncated its records: the
       // device counted that (the exchange kernels bump pool_exhausted), and this is where it becomes an error

@@ -291,9 +291,14 @@ def main():
                                        motion=not args.no_motion, count_device=dev if backend == "nccl" else "cpu")
             dist_host = "emulated" if emu else "torch"
 
+    _trace = ctx.lib.khr_host_trace  # no-op unless KHR_HOST_TRACE is set
+    _tags = {k: k.encode() for k in ("step_begin", "step_end", "timed_begin", "join_begin", "timed_end")}
+
     def step(i):
+        _trace(_tags["step_begin"])
         with torch.cuda.stream(stream):
             _step(i)
+        _trace(_tags["step_end"])
 
     def _step(i):
         if emu:
@@ -385,6 +390,7 @@ def main():
         # default: only the two update kernels carry HIP events (each timed launch costs host time);
         # --all-timers adds the per-kernel breakdown
         ctx.timing_enable(True, None if args.all_timers else ("tsdf",))  # HIP events cost a barrier packet each: only the roofline kernel
+    _trace(_tags["timed_begin"])
     t0 = time.perf_counter()
     ft = []
     for i in range(t0i, t1i):
@@ -400,11 +406,13 @@ def main():
               file=sys.stderr)
     if args.frame_times and rank == 0:
         print("frame_times(us, seeds):", ft, file=sys.stderr)
+    _trace(_tags["join_begin"])
     if pipe is not None:
         pipe.finish_frame()
         obj_stats[0] += pipe.join()  # detached object extractions still running on the worker thread / its stream
     sync_all()
     dt = time.perf_counter() - t0
+    _trace(_tags["timed_end"])
     ctx.timing_enable(False)
     st1 = ctx.stats()
     obj_timed = [obj_stats[k] - obj_before[k] for k in range(3)]
@@ -480,6 +488,7 @@ def main():
                                               "objects_extracted_before_timed_region": obj_before[0]},
         "voxels": {"visited": n_vis_all, "updated": n_upd_all, "band": n_band_all, "allocated_blocks": st1["n_allocated_blocks"],
                    "last_frame_visible_blocks": st1["n_visible_blocks"], "last_frame_tsdf_blocks": st1["n_tsdf_blocks"],
+                   "last_frame_fuse_items": st1["n_fuse_items"],
                    "band_overflow": st1["band_overflow"], "last_frame_tracking_blocks": st1["n_tracking_processed_blocks"],
                    "last_frame_touched_blocks": st1["n_tracking_updated_blocks"]},
     }

@@ -130,6 +130,8 @@ typedef struct khr_stats {
   uint64_t n_tsdf_blocks;      /* last integrate: blocks left after conservative culling */
   uint64_t band_overflow;      /* always 0 (the fused update kernel keeps no global record list) */
   uint64_t n_tracking_processed_blocks; /* blocks the last tracking pass had to visit (the rest provably cannot change) */
+  uint64_t n_fuse_items;       /* last integrate: wave items (64-voxel x-y patch x 2..4 z steps) the update kernel was given,
+                                  after block- and item-level culling (n_tsdf_blocks * items-per-block before the latter) */
 } khr_stats;
 
 /* khronos::MeasurementCluster role (measurement_clusters.h:63-80) for dynamic clusters
@@ -164,6 +166,11 @@ typedef struct khr_ctx khr_ctx;
 int khr_create(const khr_config* cfg, khr_ctx** out);
 void khr_destroy(khr_ctx* ctx);
 const char* khr_last_error(void);
+
+/* Diagnostic host timeline: with KHR_HOST_TRACE=<file> in the environment every call appends (tag, monotonic ns) and the
+ * file is written at process exit (the library marks its own phases: pf_*, kop_*); a no-op otherwise.  `tag` must stay
+ * valid until exit (string literal). */
+void khr_host_trace(const char* tag);
 /* use an externally owned hipStream_t (e.g. the stream RCCL collectives run on); NULL = own stream */
 int khr_set_stream(khr_ctx* ctx, void* hip_stream);
 int khr_sync(khr_ctx* ctx);

@@ -62,12 +62,12 @@ class KhrStats(C.Structure):
         "n_allocated_blocks", "n_visible_blocks", "n_new_blocks", "n_visited_voxels", "n_updated_voxels",
         "n_band_voxels", "n_tracking_updated_blocks", "n_seeds", "n_mesh_blocks", "n_mesh_vertices",
         "pool_exhausted", "cum_updated_voxels", "cum_band_voxels", "cum_visited_voxels", "cum_integrate_calls", "n_tsdf_blocks", "band_overflow",
-        "n_tracking_processed_blocks")]
+        "n_tracking_processed_blocks", "n_fuse_items")]
 
 
 # every symbol include/khronos_amd.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "khr_create", "khr_destroy", "khr_last_error", "khr_set_stream", "khr_sync", "khr_default_config",
+    "khr_create", "khr_destroy", "khr_last_error", "khr_host_trace", "khr_set_stream", "khr_sync", "khr_default_config",
     "khr_upload_frame", "khr_set_frame_image", "khr_download_frame", "khr_integrate", "khr_update_tracking",
     "khr_detect_motion", "khr_generate_mesh", "khr_reset_inactive", "khr_mark_all_inactive", "khr_clear_updated",
     "khr_allocate_blocks", "khr_object_prune", "khr_get_stats", "khr_num_blocks", "khr_block_indices",
@@ -104,6 +104,8 @@ def load_library():
     lib.khr_destroy.argtypes = [vp]
     lib.khr_destroy.restype = None
     lib.khr_last_error.restype = C.c_char_p
+    lib.khr_host_trace.argtypes = [C.c_char_p]
+    lib.khr_host_trace.restype = None
     lib.khr_set_stream.argtypes = [vp, vp]
     lib.khr_sync.argtypes = [vp]
     lib.khr_default_config.argtypes = [C.POINTER(KhrConfig)]

@@ -239,14 +239,17 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, size_t slot, uint32_t lin_mo
 // DEFCFG = the reference default switches (z-depth range, adaptive interpolation, weight drop-off, no constant
 // weight) resolved at compile time; otherwise they are read from the argument block.
 // ZSPLIT = wave items per x-y patch: a wave item is 64 voxels of an x-y patch times ZR = VPS / ZSPLIT (2 or 4) z steps.
-// MINW = resident waves per SIMD the register allocation is held to (__launch_bounds__; 1 = unconstrained).
 //
-// Work distribution: the grid is persistent (resident workgroups only) and wave g takes the items g, g + n_waves, ... of
-// the descriptor list the culling pass wrote MOST EXPENSIVE ITEMS FIRST (FuseList, khr_device.h): items differ a lot in
-// cost -- a block the surface crosses carries ~1500 in-band voxels (colour + label + K likelihood updates each), a
-// free-space block none -- and dealing the sorted list round-robin gives every wave its share of the expensive ones.
-// (Dynamic distribution is not an option: 20 k returning atomics per launch cost more than the whole kernel on gfx950,
-// measured.)
+// WPW = waves per workgroup.
+//
+// Work distribution: the grid is persistent (resident workgroups only).  The culling pass wrote the descriptor list MOST
+// EXPENSIVE ITEMS FIRST (FuseList, khr_device.h): items differ a lot in cost -- a block the surface crosses carries ~1500
+// in-band voxels (colour + label + K likelihood updates each), a free-space block none.  Workgroup b owns the positions
+// b, b + gridDim.x, b + 2 gridDim.x, ... (every workgroup gets the same mix of the cost classes) and its waves take them
+// from an LDS counter in that order, whoever is free first: longest-processing-time list scheduling inside the
+// workgroup.  With one or two large workgroups per CU the waves of a CU finish together, and the CUs' shares differ by
+// at most one item per class.  (A device-wide queue is not an option: 20 k returning global atomics per launch cost more
+// than the whole kernel on gfx950, measured; an LDS atomic costs ~100 ns and leaves the CU only.)
 //
 // Software pipeline: a memory round trip costs 1.5 - 2 us under this kernel's load and gfx950 retires vmcnt in order, so a
 // load issued behind a store also waits for that store.  The loop therefore runs one item AHEAD with its loads: phase 1
@@ -266,8 +269,8 @@ struct FuseItem {
   bool ok[ZR];
 };
 
-template <int VPS, int ZSPLIT, bool DEFCFG, bool EXACT, int MINW, bool DBG = false>
-__global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
+template <int VPS, int ZSPLIT, bool DEFCFG, bool EXACT, int WPW, bool DBG = false>
+__global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
   constexpr int NV = VPS * VPS * VPS;
   constexpr int SL = VPS * VPS;        // voxels per z slice
   constexpr int PATCHES = SL / 64;     // 64-voxel x-y patches per slice
@@ -276,8 +279,9 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
   static_assert(64 * ZR <= kFuseCap, "record list must hold one item");
   // per-wave record list, one LDS base per wave: field f of record r at s_rec[wave][f][r] (0 voxel | mode, 1 measurement
   // weight, 2 voxel weight after the update, 3 u, 4 v), so the five stores of a record differ by immediate offsets
-  __shared__ uint32_t s_rec[4][5][kFuseCap];
-  __shared__ uint32_t s_stat[4][2];
+  __shared__ uint32_t s_rec[WPW][5][kFuseCap];
+  __shared__ uint32_t s_stat[WPW][2];
+  __shared__ uint32_t s_q;  // the workgroup's item queue: next index into its share of the descriptor list
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int lane = static_cast<int>(threadIdx.x & 63);
   const int range_mode = DEFCFG ? 0 : a.range_mode;
@@ -293,7 +297,16 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
   const uint32_t nc0 = list.counts[0], nc1 = nc0 + list.counts[1], nc2 = nc1 + list.counts[2], n_items = nc2 + list.counts[3];
   uint32_t n_upd = 0, n_band = 0;
   const int dbg = DBG ? a.dbg : 0;
-  const uint32_t n_waves = gridDim.x * 4u;
+  if (threadIdx.x == 0) s_q = 0u;
+  __syncthreads();
+  // next item of this workgroup's share (positions blockIdx.x, blockIdx.x + gridDim.x, ...: every workgroup gets the same
+  // mix of the cost classes), handed to whichever of its waves asks first; wave-uniform result
+  auto pull = [&]() -> uint32_t {
+    uint32_t j = 0u;
+    if (lane == 0) j = atomicAdd(&s_q, 1u);
+    j = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(j)));
+    return blockIdx.x + gridDim.x * j;
+  };
   // descriptor of item i in deal order: class 0, 1, 2, 3 (FuseList)
   auto descOf = [&](uint32_t i) -> uint4 {
     if (i < nc0) return list.a[i];
@@ -365,12 +378,13 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
     }
   };
 
-  uint32_t item = blockIdx.x * 4u + static_cast<uint32_t>(wave);
+  uint32_t item = pull();
+  uint32_t item_next = item < n_items ? pull() : 0xffffffffu;
   FuseItem<VPS, ZR> cur, nxt;
   uint4 d_next = make_uint4(0u, 0u, 0u, 0u);
   if (item < n_items) {
     phase1(cur, descOf(item));
-    if (item + n_waves < n_items) d_next = descOf(item + n_waves);
+    if (item_next < n_items) d_next = descOf(item_next);
   }
   const unsigned long long tw0 = (DBG && (dbg & 64)) ? __builtin_amdgcn_s_memtime() : 0ull;
   unsigned long long t_band = 0, t_item_max = 0;
@@ -378,11 +392,12 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
   while (item < n_items) {
     const unsigned long long ti0 = (DBG && (dbg & 64)) ? __builtin_amdgcn_s_memtime() : 0ull;
     // ---- the NEXT item's loads go out first (and the descriptor of the one after it) ----
-    const uint32_t item_next = item + n_waves;
     const bool have_next = item_next < n_items;
+    uint32_t item_nn = 0xffffffffu;
     if (have_next) {
       phase1(nxt, d_next);
-      if (item_next + n_waves < n_items) d_next = descOf(item_next + n_waves);
+      item_nn = pull();
+      if (item_nn < n_items) d_next = descOf(item_nn);
     }
     // ---- phase 2 of the current item: measurement, decisions, read-modify-write ----
     const size_t slot = cur.slot;
@@ -536,10 +551,11 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
       ++c_items;
     }
     item = item_next;
+    item_next = item_nn;
     if (have_next) cur = nxt;
   }
   if (DBG && (dbg & 64) && lane == 0) {
-    unsigned long long* o = a.dbg_buf + (static_cast<size_t>(blockIdx.x) * 4 + wave) * 8;
+    unsigned long long* o = a.dbg_buf + (static_cast<size_t>(blockIdx.x) * WPW + wave) * 8;
     o[0] = tw0;
     o[1] = __builtin_amdgcn_s_memtime();
     o[2] = t_band;
@@ -556,8 +572,12 @@ __global__ __launch_bounds__(256, MINW) void k_fuse(FuseArgs a, FuseList list) {
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t su = s_stat[0][0] + s_stat[1][0] + s_stat[2][0] + s_stat[3][0];
-    const uint32_t sb = s_stat[0][1] + s_stat[1][1] + s_stat[2][1] + s_stat[3][1];
+    uint32_t su = 0u, sb = 0u;
+#pragma unroll
+    for (int w = 0; w < WPW; ++w) {
+      su += s_stat[w][0];
+      sb += s_stat[w][1];
+    }
     if (su | sb) {
       a.wg_stats[2 * blockIdx.x] += su;
       a.wg_stats[2 * blockIdx.x + 1] += sb;

@@ -12,6 +12,7 @@
 #include <atomic>
 #include <chrono>
 #include <memory>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -151,7 +152,16 @@ struct khr_ctx {
   bool seed_publish_pending = false;
   bool seed_by_ticket = false;   // motionFinish waits for the ticket (k_motion_pixels) instead of ev_seed (key import)
   bool begin_in_ingest = false, begun = false;  // khr_process_frame folds k_begin_integrate into k_frame_ingest
+  uint64_t map_gen = 1, counters_gen = 0;        // block set generation / generation h_counters was read at (mesh download)
   int last_frame_slot = -1;                      // khr_process_frame: slot of the frame queued last
+  // pinned host staging (downloads, block-index uploads): grow-only; one transfer batch in flight per buffer
+  void* h_stage = nullptr;
+  size_t h_stage_bytes = 0;
+  void* h_up = nullptr;                          // upload staging (khr_allocate_blocks) + its device twin
+  size_t h_up_bytes = 0;
+  void* d_up = nullptr;
+  hipEvent_t ev_ingest = nullptr;                // khr_process_frame: this frame's main-stream ingest is queued
+  hipEvent_t ev_up = nullptr;                    // the last upload out of h_up has been consumed
   hipStream_t ingest_stream = nullptr;           // khr_process_frame: ingest on the auxiliary stream (set around khr_upload_frame)
   bool early_ingest = true;                      // env KHR_NO_EARLY_INGEST=1 turns it off
   int ef_parity = 0, ef_cur = 0;  // which of C_N_EF / C_N_EF2 the next / the latest tracking pass fills
@@ -407,6 +417,18 @@ DevFrustum makeFrustum(const khr_ctx* c, const DevFrame& f) {
   return fr;
 }
 
+// grow-only pinned staging; contents are undefined after a call that grows it
+int ensureStage(khr_ctx* c, size_t bytes) {
+  if (bytes <= c->h_stage_bytes) return KHR_OK;
+  if (c->h_stage) HIP_TRY(hipHostFree(c->h_stage));
+  c->h_stage = nullptr;
+  c->h_stage_bytes = 0;
+  const size_t want = std::max<size_t>(bytes + bytes / 2, 1u << 20);
+  if (hipHostMalloc(&c->h_stage, want, hipHostMallocDefault) != hipSuccess) return fail(KHR_ENOMEM, "pinned staging of %zu bytes", want);
+  c->h_stage_bytes = want;
+  return KHR_OK;
+}
+
 int readCounters(khr_ctx* c) {
   c->h_counters.resize(C_COUNT);
   HIP_TRY(hipMemcpyAsync(c->h_counters.data(), c->m.counters, sizeof(uint32_t) * C_COUNT, hipMemcpyDeviceToHost,
@@ -447,7 +469,9 @@ int dispatchVps(khr_ctx* c, F&& f) {
 int kFuseGrid = 0;      // 0 = resident workgroups of the instantiation (occupancy query) x CUs; env KHR_FUSE_GRID
 int kFuseZsplit = 0;    // 0 = by world size (wave items per x-y patch of a block: 2 / 4 / 8); env KHR_FUSE_ZSPLIT
 int kFuseExact = -1;    // -1 = khr_config.exact_arithmetic; env KHR_FUSE_EXACT=0/1 overrides (A/B switch)
-int kFuseMinw = 0;      // env KHR_FUSE_MINW: register budget of the default instantiation (1 none, 4, 6 waves / SIMD)
+int kFuseWpw = 0;       // env KHR_FUSE_WPW: waves per workgroup of the default instantiation (4, 8, 16; 0 = kFuseWpwDefault)
+int kFuseWavesPerCu = 16;  // env KHR_FUSE_WAVES: resident waves per CU the persistent grid is sized for
+constexpr int kFuseWpwDefault = 12;
 int kFuseDbg = 0;       // env KHR_FUSE_DBG: ablation switches (development; selects the DBG instantiation)
 constexpr int kStreamGrid = 4096;
 
@@ -457,6 +481,42 @@ extern "C" {
 
 // other translation units of the library (khr_rayver.hip) report through the same per-thread error text
 extern "C" void khr_set_last_error(const char* text) { g_last_error = text ? text : ""; }
+
+// ---- host timeline (diagnostic; KHR_HOST_TRACE=<file>) --------------------------------------------------------------
+// Marks are (tag, monotonic ns) pairs appended by the thread that passes them; the file is written at process exit.
+// Off (one predictable branch per mark) unless the variable is set.
+namespace {
+struct HostTrace {
+  bool on = false;
+  std::string path;
+  std::mutex mu;
+  std::vector<std::pair<const char*, uint64_t>> marks;
+  HostTrace() {
+    if (const char* e = std::getenv("KHR_HOST_TRACE")) {
+      on = e[0] != 0;
+      path = e;
+      marks.reserve(1 << 20);
+    }
+  }
+  ~HostTrace() {
+    if (!on) return;
+    if (FILE* f = std::fopen(path.c_str(), "w")) {
+      for (const auto& m : marks) std::fprintf(f, "%s %llu\n", m.first, static_cast<unsigned long long>(m.second));
+      std::fclose(f);
+    }
+  }
+};
+HostTrace g_trace;
+}  // namespace
+// tag must outlive the process (string literal / interned)
+extern "C" void khr_host_trace(const char* tag) {
+  if (!g_trace.on) return;
+  const uint64_t t = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(
+                                              std::chrono::steady_clock::now().time_since_epoch()).count());
+  std::lock_guard<std::mutex> lk(g_trace.mu);
+  g_trace.marks.emplace_back(tag, t);
+}
+#define HT(tag) khr_host_trace(tag)
 
 const char* khr_last_error(void) { return g_last_error.c_str(); }
 
@@ -561,7 +621,7 @@ int khr_reset_map(khr_ctx* c, float voxel_size, float truncation_distance) {
   c->mesh_cur = 0;
   c->mesh_total = 0;
   c->mesh_stale = false;
-  c->host_index_valid = false;
+  c->host_index_valid = false, ++c->map_gen;
   c->last_removed = 0;
   c->removed_pending = false;
   c->last_track_stamp = 0;
@@ -659,7 +719,8 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   if (std::getenv("KHR_FUSE_GRID")) kFuseGrid = std::max(8, std::min(kFuseStatSlots, std::atoi(std::getenv("KHR_FUSE_GRID"))));
   if (std::getenv("KHR_FUSE_ZSPLIT")) kFuseZsplit = std::atoi(std::getenv("KHR_FUSE_ZSPLIT"));
   if (std::getenv("KHR_FUSE_EXACT")) kFuseExact = std::atoi(std::getenv("KHR_FUSE_EXACT")) ? 1 : 0;
-  if (std::getenv("KHR_FUSE_MINW")) kFuseMinw = std::atoi(std::getenv("KHR_FUSE_MINW"));
+  if (std::getenv("KHR_FUSE_WPW")) kFuseWpw = std::atoi(std::getenv("KHR_FUSE_WPW"));
+  if (std::getenv("KHR_FUSE_WAVES")) kFuseWavesPerCu = std::max(4, std::atoi(std::getenv("KHR_FUSE_WAVES")));
   if (std::getenv("KHR_FUSE_DBG")) kFuseDbg = std::atoi(std::getenv("KHR_FUSE_DBG"));
   if (std::getenv("KHR_NO_EARLY_INGEST")) c->early_ingest = false;
 
@@ -826,6 +887,11 @@ void khr_destroy(khr_ctx* c) {
   if (c->d_pix_scratch) hipFree(c->d_pix_scratch);
   if (c->d_inst) hipFree(c->d_inst);
   if (c->h_pinned) hipHostFree(c->h_pinned);
+  if (c->h_stage) hipHostFree(c->h_stage);
+  if (c->h_up) hipHostFree(c->h_up);
+  if (c->d_up) hipFree(c->d_up);
+  if (c->ev_up) hipEventDestroy(c->ev_up);
+  if (c->ev_ingest) hipEventDestroy(c->ev_ingest);
   if (c->h_tick) hipHostFree(c->h_tick);
   if (c->h_obj_head) hipHostFree(c->h_obj_head);
   if (c->h_md_acc_pinned) hipHostFree(c->h_md_acc_pinned);
@@ -1050,7 +1116,7 @@ static int integrateAlloc(khr_ctx* c, FrameSlot& s, const DevFrame& f, int alloc
     hipLaunchKernelGGL(k_init_cull, dim3(1024 + 1024), dim3(256), 0, c->stream, m, c->p, f, c->d_new, c->d_work,
                        FuseList{c->d_work4, c->d_work4 + c->item_cap, c->item_cap, &m.counters[C_N_ITEMS0]}, c->wpb,
                        c->cfg.disable_culling ? nullptr : s.tile_max, s.tw, s.th, 1024u);
-    c->host_index_valid = false;
+    c->host_index_valid = false, ++c->map_gen;
   } else {
     hipLaunchKernelGGL(k_list_live, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_work,
                        &m.counters[C_N_VISIBLE], 0u, FuseList{c->d_work4, c->d_work4 + c->item_cap, c->item_cap, &m.counters[C_N_ITEMS0]},
@@ -1068,14 +1134,15 @@ struct UpdateLists {
 
 // resident workgroups of a k_fuse instantiation x CUs, rounded down to whole XCD rounds (the grid is persistent: static
 // striding over the work items, so workgroups beyond residency would only add a tail)
-static int fuseGrid(khr_ctx* c, const void* kernel, int group) {
+static int fuseGrid(khr_ctx* c, const void* kernel, int group, int block) {
   if (kFuseGrid > 0) return std::max(8 * group, kFuseGrid / (8 * group) * (8 * group));
   static std::map<const void*, int> cache;
   const void* key = kernel;
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   int per_cu = 0, cus = 256;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  per_cu = std::min(per_cu, std::max(1, kFuseWavesPerCu / (block / 64)));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   per_cu = std::min(per_cu, 8);
@@ -1115,25 +1182,29 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
     auto launch = [&](auto zsplit) {
       constexpr int ZS = decltype(zsplit)::value;
       constexpr int G = 1;
-      auto go = [&](auto kern) {
-        const int grid = fuseGrid(c, reinterpret_cast<const void*>(kern), G);
+      auto go = [&](auto kern, int wpw) {
+        const int grid = fuseGrid(c, reinterpret_cast<const void*>(kern), G, 64 * wpw);
         static bool said = false;
-        if (!said && std::getenv("KHR_VERBOSE")) { said = true; std::fprintf(stderr, "[khr] k_fuse<%d,%d> grid %d\n", V, ZS, grid); }
-        KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(256), a, list);
+        if (!said && std::getenv("KHR_VERBOSE")) { said = true; std::fprintf(stderr, "[khr] k_fuse<%d,%d> %d waves / workgroup, grid %d\n", V, ZS, wpw, grid); }
+        KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(64 * wpw), a, list);
       };
       // non-default switches are test configurations: they always run the bit-exact arithmetic
       a.dbg = kFuseDbg;
       a.dbg_buf = c->d_dbg;
+      constexpr int WD = kFuseWpwDefault;
       if (defcfg && !exact && kFuseDbg && V == 16) {
-        go(&k_fuse<V, ZS, true, false, 1, (V == 16)>);
+        go(&k_fuse<V, ZS, true, false, WD, (V == 16)>, WD);
       } else if (defcfg && !exact) {
-        if (V == 16 && kFuseMinw == 5) go(&k_fuse<V, ZS, true, false, (V == 16 ? 5 : 1)>);
-        else if (V == 16 && kFuseMinw == 4) go(&k_fuse<V, ZS, true, false, (V == 16 ? 4 : 1)>);
-        else go(&k_fuse<V, ZS, true, false, 1>);
+        if (V == 16 && kFuseWpw == 4) go(&k_fuse<V, ZS, true, false, (V == 16 ? 4 : WD)>, V == 16 ? 4 : WD);
+        else if (V == 16 && kFuseWpw == 8) go(&k_fuse<V, ZS, true, false, (V == 16 ? 8 : WD)>, V == 16 ? 8 : WD);
+        else if (V == 16 && kFuseWpw == 16) go(&k_fuse<V, ZS, true, false, (V == 16 ? 16 : WD)>, V == 16 ? 16 : WD);
+        else if (V == 16 && kFuseWpw == 6) go(&k_fuse<V, ZS, true, false, (V == 16 ? 6 : WD)>, V == 16 ? 6 : WD);
+        else if (V == 16 && kFuseWpw == 12) go(&k_fuse<V, ZS, true, false, (V == 16 ? 12 : WD)>, V == 16 ? 12 : WD);
+        else go(&k_fuse<V, ZS, true, false, WD>, WD);
       } else if (defcfg) {
-        go(&k_fuse<V, ZS, true, true, 1>);
+        go(&k_fuse<V, ZS, true, true, WD>, WD);
       } else {
-        go(&k_fuse<V, ZS, false, true, 1>);
+        go(&k_fuse<V, ZS, false, true, WD>, WD);
       }
     };
     // a shard of a sharded map sees 1 / world of every frame's blocks: shorter z ranges per wave keep the number of
@@ -1474,7 +1545,7 @@ int khr_tick_integrate(khr_ctx* c, const int* slots, int n_frames, int use_mask,
       const FrameSlot& s0 = c->slots[slots[base]];
       hipLaunchKernelGGL(k_tick_cull, dim3(256, nb), dim3(256), 0, c->stream, m, c->p, t, c->d_tick_work, cap, c->d_tick_work4, c->item_cap, c->wpb,
                          c->d_tick_counts, c->cfg.disable_culling ? 0 : 1, s0.tw, s0.th);
-      c->host_index_valid = false;
+      c->host_index_valid = false, ++c->map_gen;
       HIP_TRY(hipGetLastError());
     }
     for (int k = 0; k < nb && (phases & 2); ++k) {
@@ -2565,7 +2636,7 @@ static int resetInactiveLaunch(khr_ctx* c) {
   if (rc) return rc;
   hipLaunchKernelGGL(k_rehash_clear, dim3(gridFor(static_cast<size_t>(m.ht_mask) + 1)), dim3(256), 0, c->stream, m);
   hipLaunchKernelGGL(k_rehash, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m);
-  c->host_index_valid = false;
+  c->host_index_valid = false, ++c->map_gen;
   c->removed_pending = true;
   HIP_TRY(hipGetLastError());
   return KHR_OK;
@@ -2704,6 +2775,7 @@ int khr_last_removed(khr_ctx* c, int32_t* removed, int64_t cap, int64_t* n_remov
 int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame, int on_device, uint32_t flags,
                       int* n_clusters) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
+  HT("pf_enter");
   if (n_clusters) *n_clusters = 0;
   const bool motion = (flags & KHR_PF_MOTION) != 0;
   const bool objects = (flags & KHR_PF_OBJECTS) != 0;
@@ -2733,17 +2805,24 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
     HIP_TRY(hipEventRecord(c->ev_aux_done, c->aux_stream));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_aux_done, 0));
   }
-  // (0) object detection kernels first (they only read the frame): their cluster records reach the host while the
-  //     volumetric kernels run, and are looked at in (6)
-  if (objects) {
-    if (!c->obj_configured) return fail(KHR_ESTATE, "KHR_PF_OBJECTS needs khr_configure_object_detector");
-    if (!early && (rc = auxAfterMain(c))) return rc;  // behind this frame's ingest (early: same stream, in order)
-    if ((rc = objectsLaunch(c, slot))) return rc;
+  if (objects && !c->obj_configured) return fail(KHR_ESTATE, "KHR_PF_OBJECTS needs khr_configure_object_detector");
+  if (objects && !early) {  // main-stream ingest: the object kernels (auxiliary stream) start behind it, not behind (1) - (2)
+    if (!c->ev_ingest) HIP_TRY(hipEventCreateWithFlags(&c->ev_ingest, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->ev_ingest, c->stream));
   }
   // (1) per-pixel motion pass; its seed count comes back asynchronously ...
   if (motion && (rc = motionLaunch(c, s, true, early))) return rc;
   // (2) ... while block allocation / culling, which do not depend on the dynamic mask, keep the GPU busy
   if ((rc = integrateAlloc(c, s, f, 1))) return rc;
+  HT("pf_alloc_launched");
+  // (2b) object detection kernels (they only read the frame) on the auxiliary stream, queued while the host would
+  //      otherwise wait for the seed count: the main stream's next kernels are already in its queue.  Their cluster
+  //      records reach the host while the volumetric kernels run, and are looked at in (6)
+  if (objects) {
+    if (!early) HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_ingest, 0));  // (early: same stream, in order)
+    if ((rc = objectsLaunch(c, slot))) return rc;
+    HT("pf_objects_launched");
+  }
   // (3) host looks at the seed count (clusters only exist when there are seeds)
   if (motion) {
     c->md_defer_summary = true;
@@ -2753,6 +2832,7 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
     if (nc < 0) return nc;
     if (n_clusters) *n_clusters = nc;
   }
+  HT("pf_motion_done");
   // (4) TSDF / label update with the dynamic mask, tracking + ever-free
   if ((rc = integrateUpdate(c, s, f, 1, motion ? 1 : 0, -1))) return rc;
   if (c->md_summary_pending >= 0) {  // the dynamic clusters' summaries, behind the update kernels
@@ -2761,17 +2841,20 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
     if ((rc = clusterSummaryLaunch(c, s, pend))) return rc;
   }
   if ((flags & KHR_PF_TRACKING) && (rc = khr_update_tracking(c, frame->timestamp_ns))) return rc;
+  HT("pf_update_launched");
   // (5) output cadence (ActiveWindow::extractOutputData, active_window.cpp:217-249 + :169-171)
   if (flags & KHR_PF_OUTPUT) {
     if ((rc = khr_generate_mesh(c, 1, 1))) return rc;
     if (c->cfg.with_tracking && (rc = resetInactiveLaunch(c))) return rc;
     if ((rc = khr_clear_updated(c))) return rc;
+    HT("pf_output_launched");
   }
   // (6) ConnectedSemantics, host part (the records arrived long ago) + id remap queued behind everything else
   if (objects) {
     const int ns = objectsFinish(c, slot);
     if (ns < 0) return ns;
   }
+  HT("pf_exit");
   return slot;
 }
 
@@ -2779,7 +2862,7 @@ int khr_mark_all_inactive(khr_ctx* c) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
   hipLaunchKernelGGL(k_block_flag_op, dim3(gridFor(c->m.capacity)), dim3(256), 0, c->stream, c->m, ~BLK_HAS_ACTIVE, BLK_TRACK_DIRTY);
   HIP_TRY(hipGetLastError());
-  c->host_index_valid = false;
+  c->host_index_valid = false, ++c->map_gen;
   return KHR_OK;
 }
 
@@ -2787,7 +2870,7 @@ int khr_clear_updated(khr_ctx* c) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
   hipLaunchKernelGGL(k_block_flag_op, dim3(gridFor(c->m.capacity)), dim3(256), 0, c->stream, c->m, ~BLK_UPDATED, 0u);
   HIP_TRY(hipGetLastError());
-  c->host_index_valid = false;
+  c->host_index_valid = false, ++c->map_gen;
   return KHR_OK;
 }
 
@@ -2800,19 +2883,31 @@ int khr_allocate_blocks(khr_ctx* c, const int32_t* indices, int64_t n) {
   for (int64_t i = 0; i < n; ++i) v[i] = {indices[3 * i], indices[3 * i + 1], indices[3 * i + 2]};
   std::sort(v.begin(), v.end());
   v.erase(std::unique(v.begin(), v.end()), v.end());
-  int* d_idx = nullptr;
-  HIP_TRY(hipMalloc(&d_idx, sizeof(int32_t) * 3 * v.size()));
-  hipError_t e = hipMemcpyAsync(d_idx, v.data(), sizeof(int32_t) * 3 * v.size(), hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(&c->m.counters[C_N_NEW], 0, sizeof(uint32_t), c->stream);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_alloc_list, dim3(gridFor(v.size())), dim3(256), 0, c->stream, c->m, d_idx,
-                       static_cast<int>(v.size()), c->d_new);
-    hipLaunchKernelGGL(k_init_blocks, dim3(2048), dim3(256), 0, c->stream, c->m, c->p, c->d_new);
-    e = hipStreamSynchronize(c->stream);
+  // asynchronous: the indices travel through a pinned buffer + its device twin owned by the context (no hipMalloc /
+  // hipFree, which stall every stream of the device); the buffer is reused only after the previous upload was consumed
+  const size_t bytes = sizeof(int32_t) * 3 * v.size();
+  if (!c->ev_up) HIP_TRY(hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
+  else HIP_TRY(hipEventSynchronize(c->ev_up));
+  if (bytes > c->h_up_bytes) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->h_up) hipHostFree(c->h_up);
+    if (c->d_up) hipFree(c->d_up);
+    c->h_up = c->d_up = nullptr;
+    c->h_up_bytes = 0;
+    const size_t want = std::max<size_t>(2 * bytes, 1u << 16);
+    if (hipHostMalloc(&c->h_up, want, hipHostMallocDefault) != hipSuccess || hipMalloc(&c->d_up, want) != hipSuccess)
+      return fail(KHR_ENOMEM, "block index staging of %zu bytes", want);
+    c->h_up_bytes = want;
   }
-  hipFree(d_idx);
-  c->host_index_valid = false;
-  if (e != hipSuccess) return fail(KHR_EDEVICE, "allocate_blocks failed: %s", hipGetErrorString(e));
+  std::memcpy(c->h_up, v.data(), bytes);
+  HIP_TRY(hipMemcpyAsync(c->d_up, c->h_up, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipEventRecord(c->ev_up, c->stream));
+  HIP_TRY(hipMemsetAsync(&c->m.counters[C_N_NEW], 0, sizeof(uint32_t), c->stream));
+  hipLaunchKernelGGL(k_alloc_list, dim3(gridFor(v.size())), dim3(256), 0, c->stream, c->m, static_cast<const int*>(c->d_up),
+                     static_cast<int>(v.size()), c->d_new);
+  hipLaunchKernelGGL(k_init_blocks, dim3(2048), dim3(256), 0, c->stream, c->m, c->p, c->d_new);
+  HIP_TRY(hipGetLastError());
+  c->host_index_valid = false, ++c->map_gen;
   return KHR_OK;
 }
 
@@ -2826,10 +2921,12 @@ int khr_object_prune(khr_ctx* c, float min_confidence, float min_observations, i
     return KHR_OK;
   });
   if (rc) return rc;
-  unsigned long long np = 0;
-  HIP_TRY(hipMemcpyAsync(&np, &c->m.stats[S_PRUNED], sizeof(np), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  if (n_pruned) *n_pruned = static_cast<int64_t>(np);
+  if (n_pruned) {  // (asynchronous without a count request)
+    unsigned long long np = 0;
+    HIP_TRY(hipMemcpyAsync(&np, &c->m.stats[S_PRUNED], sizeof(np), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *n_pruned = static_cast<int64_t>(np);
+  }
   return KHR_OK;
 }
 
@@ -2864,6 +2961,8 @@ int khr_get_stats(khr_ctx* c, khr_stats* out) {
   s.n_tracking_updated_blocks = c->h_counters[c->ef_cur ? C_N_EF2 : C_N_EF_A];
   s.pool_exhausted = c->h_counters[C_POOL_EXHAUSTED];
   s.n_tsdf_blocks = c->h_counters[C_N_TSDF];
+  s.n_fuse_items = static_cast<uint64_t>(c->h_counters[C_N_ITEMS0]) + c->h_counters[C_N_ITEMS1] + c->h_counters[C_N_ITEMS2] +
+                   c->h_counters[C_N_ITEMS3];
   s.band_overflow = 0;  // the fused update kernel keeps no global record list
   s.n_tracking_processed_blocks = c->h_counters[c->ef_cur ? C_N_PROC2 : C_N_PROC];
   s.cum_updated_voxels = st[S_CUM_UPD] + cur_upd;
@@ -2964,11 +3063,18 @@ int khr_download_block(khr_ctx* c, int32_t bx, int32_t by, int32_t bz, float* di
 
 static int refreshMeshTotals(khr_ctx* c) {
   if (!c->mesh_stale) return KHR_OK;
-  uint32_t total = 0, nwork = 0, ovf = 0;
-  HIP_TRY(hipMemcpyAsync(&total, c->d_mesh_offset + c->m.capacity, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(&nwork, c->d_mesh_nwork, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(&ovf, &c->m.counters[C_MESH_OVERFLOW], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  // one round trip through the pinned block: mesh total, work count and the counter block (C_MESH_OVERFLOW, C_MAX_SLOT)
+  int rcs = ensureStage(c, sizeof(uint32_t) * (C_COUNT + 2));
+  if (rcs) return rcs;
+  uint32_t* hs = static_cast<uint32_t*>(c->h_stage);
+  HIP_TRY(hipMemcpyAsync(hs, c->d_mesh_offset + c->m.capacity, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(hs + 1, c->d_mesh_nwork, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(hs + 2, c->m.counters, sizeof(uint32_t) * C_COUNT, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  const uint32_t total = hs[0], nwork = hs[1];
+  c->h_counters.assign(hs + 2, hs + 2 + C_COUNT);
+  c->counters_gen = c->map_gen;
+  const uint32_t ovf = c->h_counters[C_MESH_OVERFLOW];
   if (ovf) return fail(KHR_ENOMEM, "mesh needs %u vertices, max_mesh_vertices=%llu", total,
                        static_cast<unsigned long long>(c->cfg.max_mesh_vertices));
   c->mesh_total = total;
@@ -3046,35 +3152,59 @@ int64_t khr_mesh_num_vertices(khr_ctx* c) {
 int64_t khr_download_mesh(khr_ctx* c, float* points, uint8_t* colors_rgba, uint32_t* labels, uint64_t* first_seen,
                           uint64_t* stamps, int64_t cap) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
-  int rc = refreshMeshTotals(c);
+  // Two host round trips in all: (1) totals + counters (skipped when they are current), (2) block index, flags, mesh
+  // descriptors and the vertex arrays as one batch of asynchronous copies into the pinned staging buffer.
+  int rc = c->mesh_stale ? refreshMeshTotals(c) : (c->counters_gen == c->map_gen ? KHR_OK : readCounters(c));
   if (rc) return rc;
-  rc = ensureHostIndex(c);
-  if (rc) return rc;
-  const uint32_t nslots = static_cast<uint32_t>(c->host_flags.size());
-  std::vector<MeshDesc> desc(nslots);
-  if (nslots) HIP_TRY(hipMemcpy(desc.data(), c->m.mesh_desc, sizeof(MeshDesc) * nslots, hipMemcpyDeviceToHost));
+  const uint32_t nslots = c->h_counters[C_MAX_SLOT];
+  const size_t all = c->mesh_total;
+  if (static_cast<int64_t>(all) > cap)
+    return fail(KHR_EINVAL, "mesh has %lld vertices, cap %lld", static_cast<long long>(all), static_cast<long long>(cap));
+  const MeshBuffers& mb = c->mesh[c->mesh_cur];
+  auto al = [](size_t b) { return (b + 63) & ~static_cast<size_t>(63); };
+  const size_t o_idx = 0, o_flag = o_idx + al(sizeof(int4) * nslots), o_desc = o_flag + al(sizeof(uint32_t) * nslots);
+  const size_t o_p = o_desc + al(sizeof(MeshDesc) * nslots), o_c = o_p + al(points ? all * 12 : 0);
+  const size_t o_l = o_c + al(colors_rgba ? all * 4 : 0), o_s = o_l + al(labels ? all * 4 : 0);
+  const size_t bytes = o_s + al((first_seen || stamps) ? all * 8 : 0);
+  if ((rc = ensureStage(c, bytes))) return rc;
+  char* st = static_cast<char*>(c->h_stage);
+  if (nslots) {
+    HIP_TRY(hipMemcpyAsync(st + o_idx, c->m.blk_index, sizeof(int4) * nslots, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(st + o_flag, c->m.blk_flags, sizeof(uint32_t) * nslots, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(st + o_desc, c->m.mesh_desc, sizeof(MeshDesc) * nslots, hipMemcpyDeviceToHost, c->stream));
+  }
+  if (all) {
+    if (points) HIP_TRY(hipMemcpyAsync(st + o_p, mb.points, all * 12, hipMemcpyDeviceToHost, c->stream));
+    if (colors_rgba) HIP_TRY(hipMemcpyAsync(st + o_c, mb.colors, all * 4, hipMemcpyDeviceToHost, c->stream));
+    if (labels) HIP_TRY(hipMemcpyAsync(st + o_l, mb.labels, all * 4, hipMemcpyDeviceToHost, c->stream));
+    if (first_seen || stamps) HIP_TRY(hipMemcpyAsync(st + o_s, mb.stamps, all * 8, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const int4* idx = reinterpret_cast<const int4*>(st + o_idx);
+  const uint32_t* flg = reinterpret_cast<const uint32_t*>(st + o_flag);
+  const MeshDesc* desc = reinterpret_cast<const MeshDesc*>(st + o_desc);
+  c->host_flags.assign(flg, flg + nslots);
+  c->host_index.clear();
+  for (uint32_t sl = 0; sl < nslots; ++sl)
+    if (flg[sl] & BLK_LIVE) c->host_index[{idx[sl].x, idx[sl].y, idx[sl].z}] = sl;
+  c->host_index_valid = true;
   int64_t total = 0;
   for (auto& kv : c->host_index) total += desc[kv.second].count;
   if (total > cap) return fail(KHR_EINVAL, "mesh has %lld vertices, cap %lld", static_cast<long long>(total), static_cast<long long>(cap));
   if (total == 0) return 0;
-  const MeshBuffers& mb = c->mesh[c->mesh_cur];
-  const size_t all = c->mesh_total;
-  std::vector<float> hp(points ? all * 3 : 0);
-  std::vector<uint32_t> hc(colors_rgba ? all : 0), hl(labels ? all : 0);
-  std::vector<uint64_t> hs((first_seen || stamps) ? all : 0);
-  if (points) HIP_TRY(hipMemcpy(hp.data(), mb.points, all * 12, hipMemcpyDeviceToHost));
-  if (colors_rgba) HIP_TRY(hipMemcpy(hc.data(), mb.colors, all * 4, hipMemcpyDeviceToHost));
-  if (labels) HIP_TRY(hipMemcpy(hl.data(), mb.labels, all * 4, hipMemcpyDeviceToHost));
-  if (first_seen || stamps) HIP_TRY(hipMemcpy(hs.data(), mb.stamps, all * 8, hipMemcpyDeviceToHost));
+  const float* hp = reinterpret_cast<const float*>(st + o_p);
+  const uint32_t* hc = reinterpret_cast<const uint32_t*>(st + o_c);
+  const uint32_t* hl = reinterpret_cast<const uint32_t*>(st + o_l);
+  const uint64_t* hs = reinterpret_cast<const uint64_t*>(st + o_s);
   int64_t n = 0;
   for (auto& kv : c->host_index) {  // sorted block order (combineMeshLayer iterates the mesh layer)
     const MeshDesc d = desc[kv.second];
     if (!d.count) continue;
-    if (points) std::memcpy(points + 3 * n, hp.data() + 3 * static_cast<size_t>(d.offset), 12ull * d.count);
-    if (colors_rgba) std::memcpy(colors_rgba + 4 * n, hc.data() + d.offset, 4ull * d.count);
-    if (labels) std::memcpy(labels + n, hl.data() + d.offset, 4ull * d.count);
-    if (first_seen) std::memcpy(first_seen + n, hs.data() + d.offset, 8ull * d.count);
-    if (stamps) std::memcpy(stamps + n, hs.data() + d.offset, 8ull * d.count);
+    if (points) std::memcpy(points + 3 * n, hp + 3 * static_cast<size_t>(d.offset), 12ull * d.count);
+    if (colors_rgba) std::memcpy(colors_rgba + 4 * n, hc + d.offset, 4ull * d.count);
+    if (labels) std::memcpy(labels + n, hl + d.offset, 4ull * d.count);
+    if (first_seen) std::memcpy(first_seen + n, hs + d.offset, 8ull * d.count);
+    if (stamps) std::memcpy(stamps + n, hs + d.offset, 8ull * d.count);
     n += d.count;
   }
   return n;

@@ -289,9 +289,8 @@ std::shared_ptr<KhronosObjectAttributes> MeshObjectExtractor::extractStaticObjec
           "khr_integrate_shared_batch");
     }
     // erase low-confidence voxels (:246-264)
-    int64_t pruned = 0;
-    if (!config.visualize_classification)
-      chk(khr_object_prune(octx, config.min_object_reconstruction_confidence, config.min_object_reconstruction_observations, &pruned),
+    if (!config.visualize_classification)  // (no count requested: the call stays asynchronous)
+      chk(khr_object_prune(octx, config.min_object_reconstruction_confidence, config.min_object_reconstruction_observations, nullptr),
           "khr_object_prune");
     chk(khr_generate_mesh(octx, 1, 0), "khr_generate_mesh");  // :267
     object = std::make_shared<KhronosObjectAttributes>();

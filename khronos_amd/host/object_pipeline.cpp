@@ -145,6 +145,8 @@ void kop_destroy(kop_handle* h) { delete h; }
 // kop_finish_frame = tracker association, trimBuffer, storeData (active_window.cpp:130-145).  Returns the track count.
 int kop_finish_frame(kop_handle* h, char* err, int err_len) {
   if (!h) return KHR_EINVAL;
+  khr_host_trace("kop_finish_enter");
+  struct Exit { ~Exit() { khr_host_trace("kop_finish_exit"); } } on_exit;
   try {
     if (h->pending) {
       std::shared_ptr<FrameData> data = h->pending;
@@ -168,6 +170,8 @@ int kop_launch_frame(kop_handle* h, int slot, uint64_t stamp_ns, const double* w
     const int rc = kop_finish_frame(h, err, err_len);
     if (rc < 0) return rc;
   }
+  khr_host_trace("kop_launch_enter");
+  struct Exit { ~Exit() { khr_host_trace("kop_launch_exit"); } } on_exit;
   try {
     auto data = std::make_shared<FrameData>();
     InputData& in = data->input;
@@ -181,6 +185,7 @@ int kop_launch_frame(kop_handle* h, int slot, uint64_t stamp_ns, const double* w
     data->num_dynamic_clusters = n_dynamic_clusters;
     if (n_dynamic_clusters > 0) FreeSpaceMotionDetector::fetchClusters(h->map, *data);
     h->detector->processInput(h->map, *data);  // cached when khr_process_frame ran with KHR_PF_OBJECTS
+    khr_host_trace("kop_launch_detected");
     if (auto* iou = dynamic_cast<MaxIoUTracker*>(h->tracker.get())) iou->beginInput(*data);
     h->pending = data;
     return KHR_OK;
@@ -209,6 +214,8 @@ int kop_extract_inactive(kop_handle* h, int* n_removed, uint64_t* n_vertices, ch
     const int rc = kop_finish_frame(h, err, err_len);
     if (rc < 0) return rc;
   }
+  khr_host_trace("kop_extract_enter");
+  struct Exit { ~Exit() { khr_host_trace("kop_extract_exit"); } } on_exit;
   try {
     h->last_objects.clear();
     Tracks& tracks = h->tracker->getTracks();

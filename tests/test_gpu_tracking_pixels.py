@@ -12,8 +12,10 @@ W, H = 320, 240
 OBJ = list(range(7, 20))
 
 
-def _frame(ctx, ora, osen, sen, s, i, detect=True):
+def _frame(ctx, ora, osen, sen, s, i, detect=True, pose=None):
     fr = s.render(i)
+    if pose is not None:
+        fr["pose"] = pose
     slot = ctx.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
     rng, vm = ora.parse_input(osen, fr["pose"], fr["depth"])
     n, oimg, cl = (0, None, [])
@@ -27,8 +29,13 @@ def _frame(ctx, ora, osen, sen, s, i, detect=True):
 def test_pixel_iou_matches_numpy_restatement():
     cfg, ctx, ora, s, sen, osen = make_pair(width=W, height=H, num_frame_slots=4)
     ctx.configure_object_detector(OBJ, use_3d=True, grid_size=0.1, max_range=5.0, min_cluster_size=50, use_full_connectivity=True)
-    fr0, slot0, _, vm0, oimg0, cl0 = _frame(ctx, ora, osen, sen, s, 8)
-    fr1, slot1, _, _, oimg1, cl1 = _frame(ctx, ora, osen, sen, s, 10)
+    # computeIoUPixels (max_iou_tracker.cpp:578-600) maps the track's WORLD points with getSensorPose() (world_T_sensor, not its
+    # inverse) before projecting them; with a real trajectory almost nothing lands in the image.  A near-identity pose keeps the
+    # quirk and still gives non-empty intersections, so that the counts below are a real check.
+    pose = np.eye(4)
+    pose[:3, 3] = (0.01, -0.02, 0.015)
+    fr0, slot0, _, vm0, oimg0, cl0 = _frame(ctx, ora, osen, sen, s, 8, pose=pose)
+    fr1, slot1, _, _, oimg1, cl1 = _frame(ctx, ora, osen, sen, s, 10, pose=pose)
     assert len(cl0) >= 1 and len(cl1) >= 1
     refs = [(slot0, 1, c["id"]) for c in cl0][:8] + [(slot1, 1, cl1[0]["id"])]  # the last one: a track created in this frame
     max_id = max(c["id"] for c in cl1)

@@ -284,6 +284,13 @@ def main():
             else:
                 stream = torch.cuda.ExternalStream(fusion_cxx.stream(), device=dev)  # the tick's stream, for event ordering
                 dist_host = "cxx"
+        elif emu and args.dist_host == "cxx":
+            from khronos_amd.host_capi import ShardedFusionHost
+            fusion_cxx = ShardedFusionHost(ctx, sensor, 0, world, None, n_cameras=world, halo_cap=args.halo_cap,
+                                           mesh_req_cap=args.mesh_req_cap, mesh_rec_cap=args.mesh_rec_cap, motion=not args.no_motion,
+                                           shard_motion=True, emulate=True)
+            stream = torch.cuda.ExternalStream(fusion_cxx.stream(), device=dev)
+            dist_host = "cxx-emulated"
         if fusion_cxx is None:
             from khronos_amd.distributed import HipShard, ShardedFusion
             with torch.cuda.stream(stream):
@@ -476,7 +483,8 @@ def main():
                                   "(ever-free), seed-gated all-reduce of per-pixel voxel keys (motion detector), request / response all-gather of mesh halo planes" % world
                    if world > 1 else "single GPU",
                    "collectives_issued_by": {"cxx": "libkhronos_amd_host.so (kdist_*: rccl calls on the context's HIP stream)",
-                                             "torch": "khronos_amd/distributed.py (torch.distributed)", "emulated": "none (emulation)",
+                                             "torch": "khronos_amd/distributed.py (torch.distributed)", "emulated": "none (emulation, torch harness)",
+                                             "cxx-emulated": "libkhronos_amd_host.so (kdist_*, KDIST_EMULATE: rank 0 alone, collectives skipped)",
                                              "none": None}[dist_host]},
         "mvoxel_updates_per_s": 1e-6 * n_upd_all / dt,
         **({"emulation": "rank 0 of a %d-rank sharded run played by one process, no collectives: `value` is what the job would reach "

@@ -365,6 +365,16 @@ int64_t khr_download_updated(khr_ctx* ctx, int32_t* indices, float* distance, fl
  * (utils::combineMeshLayer, geometry_utils.cpp:61-86; faces are implicit: vertex 3i,3i+1,3i+2).
  * returns the vertex count, or a negative error if cap is too small. */
 int64_t khr_mesh_num_vertices(khr_ctx* ctx);
+/* the same mesh with ONE host round trip, in two halves so that the caller can size its arrays in between:
+ * khr_fetch_mesh makes the device gather block table + vertex arrays into pinned memory (one launch, one wait) and
+ * returns the vertex count; khr_fetch_mesh_into then copies them, in sorted block order, into the caller's arrays
+ * (no device access; any pointer may be NULL; first_seen == stamps, ASSUMPTIONS.md A.5).  The staged data stay valid
+ * until the next khr_fetch_mesh / khr_download_mesh of this context. */
+typedef struct khr_mesh_view {
+  int64_t num_vertices;
+} khr_mesh_view;
+int64_t khr_fetch_mesh(khr_ctx* ctx, khr_mesh_view* out);
+int khr_fetch_mesh_into(khr_ctx* ctx, float* points, uint8_t* colors_rgba, uint32_t* labels, uint64_t* first_seen, uint64_t* stamps);
 int64_t khr_download_mesh(khr_ctx* ctx, float* points, uint8_t* colors_rgba, uint32_t* labels,
                           uint64_t* first_seen, uint64_t* stamps, int64_t cap);
 

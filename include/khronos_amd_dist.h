@@ -31,7 +31,10 @@ enum kdist_flags {
   KDIST_MOTION = 1,          /* run the free-space motion detector (motion_detection/, a8-a11) inside the tick */
   KDIST_SHARD_MOTION = 2,    /* cluster each camera on its home rank (camera % world) and broadcast the dynamic image;
                                 off: every rank all-reduces the keys and clusters every camera itself */
-  KDIST_ALWAYS_EXCHANGE = 4  /* issue the collectives even when world_size == 1 (single-GPU smoke of the RCCL path) */
+  KDIST_ALWAYS_EXCHANGE = 4, /* issue the collectives even when world_size == 1 (single-GPU smoke of the RCCL path) */
+  KDIST_EMULATE = 8          /* measurement aid: run rank `rank` of `world_size` alone -- no communicator, every collective
+                                skipped, the export / import kernels run on this rank's records only.  The map it builds is
+                                the rank's shard WITHOUT its neighbours' halos: timing only, never a result. */
 };
 
 /* ncclGetUniqueId: 128 opaque bytes. */

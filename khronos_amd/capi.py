@@ -71,7 +71,7 @@ EXPORTS = [
     "khr_upload_frame", "khr_set_frame_image", "khr_download_frame", "khr_integrate", "khr_update_tracking",
     "khr_detect_motion", "khr_generate_mesh", "khr_reset_inactive", "khr_mark_all_inactive", "khr_clear_updated",
     "khr_allocate_blocks", "khr_object_prune", "khr_get_stats", "khr_num_blocks", "khr_block_indices",
-    "khr_download_block", "khr_mesh_num_vertices", "khr_download_mesh", "khr_timing_enable", "khr_timing_reset",
+    "khr_download_block", "khr_mesh_num_vertices", "khr_download_mesh", "khr_fetch_mesh", "khr_fetch_mesh_into", "khr_timing_enable", "khr_timing_reset",
     "khr_timing_get", "khr_debug_read", "khr_tick_ingest", "khr_tick_integrate", "khr_tick_seed_counts", "khr_copy_frame_image", "khr_rv_detect_changes", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_integrate_shared_batch", "khr_pixel_iou", "khr_forward_instances", "khr_update_tracking_phase",
     "khr_export_halo", "khr_import_halo", "khr_get_dynamic_clusters", "khr_motion_keys",
     "khr_detect_motion_from_keys", "khr_download_updated", "khr_mesh_halo_requests", "khr_mesh_halo_export",
@@ -172,6 +172,9 @@ def load_library():
     lib.khr_mesh_num_vertices.restype = i64
     lib.khr_download_mesh.argtypes = [vp, vp, vp, vp, vp, vp, i64]
     lib.khr_download_mesh.restype = i64
+    lib.khr_fetch_mesh.argtypes = [vp, vp]
+    lib.khr_fetch_mesh.restype = i64
+    lib.khr_fetch_mesh_into.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.khr_debug_read.argtypes = [vp, vp, i64]
     lib.khr_tick_ingest.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     lib.khr_tick_seed_counts.argtypes = [vp, vp, i32]
@@ -573,6 +576,19 @@ class FusionContext:
         st = np.empty(max(n, 1), np.uint64)
         k = self._chk(self.lib.khr_download_mesh(self.h, _ptr(pts), _ptr(col), _ptr(lab), _ptr(fs), _ptr(st), max(n, 1)))
         return {"points": pts[:k], "colors": col[:k], "labels": lab[:k], "first_seen": fs[:k], "stamps": st[:k]}
+
+    def fetch_mesh(self):
+        """the same mesh through khr_fetch_mesh / khr_fetch_mesh_into (one host round trip)."""
+        v = C.c_int64(0)
+        n = self._chk(self.lib.khr_fetch_mesh(self.h, C.byref(v)))
+        pts = np.empty((n, 3), np.float32)
+        col = np.empty((n, 4), np.uint8)
+        lab = np.empty(n, np.uint32)
+        fs = np.empty(n, np.uint64)
+        st = np.empty(n, np.uint64)
+        if n:
+            self._chk(self.lib.khr_fetch_mesh_into(self.h, _ptr(pts), _ptr(col), _ptr(lab), _ptr(fs), _ptr(st)))
+        return {"points": pts, "colors": col, "labels": lab, "first_seen": fs, "stamps": st}
 
     def timing_enable(self, on=True, names=None):
         """on=True: all timers, or only those in `names`."""

@@ -19,7 +19,9 @@ constexpr uint32_t kInvalidSlot = 0xffffffffu;
 // block flag bits 0..3 are the public KHR_BLK_* bits
 constexpr uint32_t BLK_UPDATED = 1u, BLK_MESH_UPDATED = 2u, BLK_TRACKING_UPDATED = 4u, BLK_HAS_ACTIVE = 8u,
                    BLK_LIVE = 16u,
-                   BLK_TRACK_DIRTY = 32u;  // internal: the tracking pass may not skip this block (k_tracking_update)
+                   BLK_TRACK_DIRTY = 32u,  // internal: the tracking pass may not skip this block (k_tracking_update)
+                   BLK_ANY_KEEP = 64u;     // internal: some voxel is not to_remove (as of the block's last tracking pass;
+                                           // set at allocation).  resetInactive reads this instead of 4096 voxel flags.
 constexpr uint8_t VOX_ACTIVE = 1, VOX_EVER_FREE = 2, VOX_TO_REMOVE = 4, VOX_SEM_VALID = 8;
 // internal (masked out of every download): the voxel was occupied at the last tracking pass, i.e. its
 // last_occupied stamp IS that pass's stamp and the stored value is stale (k_tracking_update)

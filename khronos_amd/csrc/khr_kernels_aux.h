@@ -1169,29 +1169,71 @@ __global__ __launch_bounds__(256) void k_mark_regen(const uint32_t* __restrict__
 // per live block: all-voxels-to_remove reduction; blocks without active data or fully to_remove are
 // dropped from the pool (flags = 0) and their indices appended to the removed list.
 // ----------------------------------------------------------------------------------------------
+// "All voxels to_remove" is a per-block bit the tracking pass maintains (BLK_ANY_KEEP: voxel flags only change in that
+// pass, and a block it skips has not changed), so this is one thread per pool slot.
 template <int VPS>
 __global__ __launch_bounds__(256) void k_reset_inactive(DevMap m, int4* __restrict__ removed) {
-  constexpr int NV = VPS * VPS * VPS;
   const uint32_t n_slots = m.counters[C_MAX_SLOT];
-  for (uint32_t s = blockIdx.x; s < n_slots; s += gridDim.x) {
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += gridDim.x * blockDim.x) {
     const uint32_t fl = m.blk_flags[s];
     if (!(fl & BLK_LIVE)) continue;
-    bool all_remove = true;
-    if (fl & BLK_HAS_ACTIVE) {
-      const uint4* vfl = reinterpret_cast<const uint4*>(m.vflags + static_cast<size_t>(s) * NV);
-      const uint32_t bit = VOX_TO_REMOVE * 0x01010101u;
-      for (int g = threadIdx.x; g < NV / 16; g += 256) {
-        const uint4 v = vfl[g];
-        all_remove = all_remove && ((v.x & v.y & v.z & v.w & bit) == bit);
-      }
-    }
-    const int keep = __syncthreads_or(all_remove ? 0 : 1);
-    if (threadIdx.x == 0 && (!(fl & BLK_HAS_ACTIVE) || !keep)) {
+    if (!(fl & BLK_HAS_ACTIVE) || !(fl & BLK_ANY_KEEP)) {
       removed[atomicAdd(&m.counters[C_N_REMOVED], 1u)] = m.blk_index[s];
       m.blk_flags[s] = 0u;
       m.mesh_desc[s] = MeshDesc{0u, 0u};
     }
   }
+}
+
+// k_mesh_gather: everything khr_fetch_mesh needs, written by the device straight into pinned host memory in ONE launch
+// (a D2H copy costs ~40-70 us of latency each on this platform, the mesh of an object is a few hundred KB).
+// Layout of dst (32-bit words): header[16] = {total vertices, slots, overflow flag, fits, words needed}, then the
+// regions at the offsets the header's words 8..14 give: block index (4 / slot), flags (1), mesh descriptors (2),
+// points (3 / vertex), colours (1), labels (1), stamps (2).  Nothing but the header is written when cap_words is too small.
+__global__ __launch_bounds__(256) void k_mesh_gather(DevMap m, MeshBuffers mb, const uint32_t* __restrict__ total_ptr,
+                                                    uint32_t* __restrict__ dst, uint64_t cap_words, uint32_t* __restrict__ done_count,
+                                                    uint32_t ticket) {
+  const uint32_t total = *total_ptr, nslots = m.counters[C_MAX_SLOT];
+  auto al = [](uint64_t w) { return (w + 15ull) & ~15ull; };
+  const uint64_t o_idx = 16, o_flag = o_idx + al(4ull * nslots), o_desc = o_flag + al(nslots), o_p = o_desc + al(2ull * nslots);
+  const uint64_t o_c = o_p + al(3ull * total), o_l = o_c + al(total), o_s = o_l + al(total), need = o_s + al(2ull * total);
+  const bool fits = need <= cap_words;
+  if (blockIdx.x == 0 && threadIdx.x < 16) {
+    const uint64_t h[16] = {total, nslots, m.counters[C_MESH_OVERFLOW], fits ? 1ull : 0ull, need, 0, 0, 0,
+                            o_idx, o_flag, o_desc, o_p, o_c, o_l, o_s, 0};
+    if (threadIdx.x < 15) dst[threadIdx.x] = static_cast<uint32_t>(h[threadIdx.x]);
+  }
+  // header word 15 = ticket, written by the workgroup that finishes last, after everybody's data is visible to the host
+  // (the host spins on it: a blocking stream wait costs hundreds of us of wake-up latency)
+  auto finish = [&]() {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t prev = atomicAdd(done_count, 1u);
+      if (prev == gridDim.x - 1) {
+        *done_count = 0u;  // ready for the next launch (stream order)
+        __threadfence_system();
+        __hip_atomic_store(&dst[15], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  };
+  if (!fits) {
+    finish();
+    return;
+  }
+  const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x, nth = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  auto copy = [&](const void* src, uint64_t off, uint64_t words) {
+    const uint32_t* s32 = static_cast<const uint32_t*>(src);
+    for (uint64_t i = tid; i < words; i += nth) dst[off + i] = s32[i];
+  };
+  copy(m.blk_index, o_idx, 4ull * nslots);
+  copy(m.blk_flags, o_flag, nslots);
+  copy(m.mesh_desc, o_desc, 2ull * nslots);
+  copy(mb.points, o_p, 3ull * total);
+  copy(mb.colors, o_c, total);
+  copy(mb.labels, o_l, total);
+  copy(mb.stamps, o_s, 2ull * total);
+  finish();
 }
 
 // After removals the hash table and the free list are rebuilt from the slot flags, conditionally on the device

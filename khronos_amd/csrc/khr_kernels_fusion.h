@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void k_alloc_visible(DevMap m, DevParams p, De
       slot = m.free_slots[fidx];
       got = true;
       m.blk_index[slot] = make_int4(bx, by, bz, epoch);
-      m.blk_flags[slot] = BLK_LIVE | BLK_TRACK_DIRTY;
+      m.blk_flags[slot] = BLK_LIVE | BLK_TRACK_DIRTY | BLK_ANY_KEEP;
       m.mesh_desc[slot] = MeshDesc{0u, 0u};
       htInsertUnique(m, key, slot);
       atomicMax(&m.counters[C_MAX_SLOT], slot + 1);
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void k_alloc_list(DevMap m, const int* __restr
       slot = m.free_slots[fidx];
       got = true;
       m.blk_index[slot] = make_int4(bx, by, bz, 0);
-      m.blk_flags[slot] = BLK_LIVE | BLK_TRACK_DIRTY;
+      m.blk_flags[slot] = BLK_LIVE | BLK_TRACK_DIRTY | BLK_ANY_KEEP;
       m.mesh_desc[slot] = MeshDesc{0u, 0u};
       htInsertUnique(m, packKey(bx, by, bz), slot);
       atomicMax(&m.counters[C_MAX_SLOT], slot + 1);
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void k_tracking_select(DevMap m, uint64_t lim_
     proc[ip] = s;
     // k_tracking_update works on a block in several independent pieces: they meet in these words with atomicMin / atomicOr
     reinterpret_cast<ulonglong2*>(m.trk_lim)[s] = make_ulonglong2(~0ull, ~0ull);
-    m.blk_flags[s] = m.blk_flags[s] & ~(BLK_TRACKING_UPDATED | BLK_HAS_ACTIVE | BLK_TRACK_DIRTY);
+    m.blk_flags[s] = m.blk_flags[s] & ~(BLK_TRACKING_UPDATED | BLK_HAS_ACTIVE | BLK_TRACK_DIRTY | BLK_ANY_KEEP);
   }
   const uint32_t ie = waveAggInc(&cnt[1], touched);
   if (touched) ef_list[ie] = s;
@@ -571,6 +571,7 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
   // monotone, so "toSeconds(x) >= T" is exactly "x >= lim" and the kernel needs no fp64 divisions.
   constexpr int NV = VPS * VPS * VPS;
   __shared__ uint64_t s_min[2][4];
+  __shared__ uint32_t s_bits;  // 1 = some voxel active, 2 = some voxel not to_remove
   const uint32_t n = *n_proc * CH;
   for (uint32_t wi = blockIdx.x; wi < n; wi += gridDim.x) {
     const uint32_t s = proc[wi / CH];
@@ -582,8 +583,9 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
     uint64_t* __restrict__ locc = m.last_occ + slot * NV;
     uint32_t* __restrict__ vfl4 = reinterpret_cast<uint32_t*>(m.vflags + slot * NV);
     uint64_t* __restrict__ fb = m.freebits + slot * (NV / 64);
-    bool any_active = false;
+    bool any_active = false, any_keep = false;
     uint64_t a_min = ~0ull, f_min = ~0ull;
+    if (threadIdx.x == 0) s_bits = 0u;  // (ordered against the previous block's read by the barrier that ends the loop body)
     // A block is 1024 groups of 4 voxels = 4 groups per thread (VPS 16).  All loads of a round are issued before the
     // first use: the pass is latency bound (one workgroup per touched block, a few dependent round trips each), so the
     // 4 x 52 B of distance / last_observed / flags travel together, then the last_occupied pairs that are needed.
@@ -648,6 +650,7 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
         uint8_t nv = static_cast<uint8_t>((v & ~(VOX_ACTIVE | VOX_OCC)) | (active ? VOX_ACTIVE : 0) | (occ ? VOX_OCC : 0));
         if (was_active && !active) nv |= VOX_TO_REMOVE;
         any_active |= active;
+        any_keep |= !(nv & VOX_TO_REMOVE);
         if (active) a_min = lo[k] < a_min ? lo[k] : a_min;
         const bool ever = nv & VOX_EVER_FREE;
         const bool is_free = !ever && (oc < lim_free) && (lo[k] != 0ull);  // only evaluated where it decides the bit
@@ -676,12 +679,16 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
       a_min = a2 < a_min ? a2 : a_min;
       f_min = f2 < f_min ? f2 : f_min;
     }
+    __syncthreads();  // s_bits was cleared by thread 0 above
+    const uint32_t wbits = (__builtin_amdgcn_ballot_w64(any_active) != 0ull ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(any_keep) != 0ull ? 2u : 0u);
     if ((threadIdx.x & 63) == 0) {
       s_min[0][threadIdx.x >> 6] = a_min;
       s_min[1][threadIdx.x >> 6] = f_min;
+      if (wbits) atomicOr(&s_bits, wbits);
     }
-    const int act = __syncthreads_or(any_active ? 1 : 0);
+    __syncthreads();
     if (threadIdx.x == 0) {
+      const uint32_t bits = s_bits;
       uint64_t a = s_min[0][0], f = s_min[1][0];
 #pragma unroll
       for (int w = 1; w < 4; ++w) {
@@ -692,7 +699,7 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
       unsigned long long* lim = reinterpret_cast<unsigned long long*>(m.trk_lim) + 2 * static_cast<size_t>(s);
       if (a != ~0ull) atomicMin(&lim[0], static_cast<unsigned long long>(a));
       if (f != ~0ull) atomicMin(&lim[1], static_cast<unsigned long long>(f));
-      if (act) atomicOr(&m.blk_flags[s], BLK_HAS_ACTIVE);
+      if (bits) atomicOr(&m.blk_flags[s], ((bits & 1u) ? BLK_HAS_ACTIVE : 0u) | ((bits & 2u) ? BLK_ANY_KEEP : 0u));
     }
     __syncthreads();  // s_min is reused by the next block of this workgroup
   }

@@ -152,6 +152,10 @@ struct khr_ctx {
   bool seed_publish_pending = false;
   bool seed_by_ticket = false;   // motionFinish waits for the ticket (k_motion_pixels) instead of ev_seed (key import)
   bool begin_in_ingest = false, begun = false;  // khr_process_frame folds k_begin_integrate into k_frame_ingest
+  uint32_t fetch_ticket = 0;                     // khr_fetch_mesh: completion ticket the gather kernel publishes
+  uint32_t* d_fetch_done = nullptr;              //   + its workgroup completion counter (device)
+  std::vector<uint32_t> fm_order;                // khr_fetch_mesh: slots that carry vertices, in sorted block order
+  size_t fm_total = 0;
   uint64_t map_gen = 1, counters_gen = 0;        // block set generation / generation h_counters was read at (mesh download)
   int last_frame_slot = -1;                      // khr_process_frame: slot of the frame queued last
   // pinned host staging (downloads, block-index uploads): grow-only; one transfer batch in flight per buffer
@@ -688,6 +692,14 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     return fail(KHR_EDEVICE, "pinned scratch / event creation failed");
   }
   std::memset(c->h_pinned, 0, 64);
+  // staging buffers up front: growing them later means hipHostMalloc / hipMalloc in the middle of a run (hundreds of us,
+  // and hipMalloc stalls every stream of the device)
+  c->h_up_bytes = 1u << 16;
+  if (ensureStage(c, 1u << 20) != KHR_OK || hipHostMalloc(&c->h_up, c->h_up_bytes, hipHostMallocDefault) != hipSuccess ||
+      hipMalloc(&c->d_up, c->h_up_bytes) != hipSuccess) {
+    delete c;
+    return fail(KHR_ENOMEM, "pinned staging buffers");
+  }
   if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_pinned), c->h_pinned, 0) != hipSuccess) {
     delete c;
     return fail(KHR_EDEVICE, "hipHostGetDevicePointer failed");
@@ -756,6 +768,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &c->d_trk_proc, cap));
   A(devAlloc(c, &c->d_dbg, 4096 * 4 * 12));
   A(devAlloc(c, &c->d_wg_stats, 2 * kFuseStatSlots));
+  A(devAlloc(c, &c->d_fetch_done, 4));
   {
     int zs = kFuseZsplit;
     if (zs == 0) zs = cfg->world_size >= 4 ? 8 : 4;
@@ -1137,6 +1150,8 @@ struct UpdateLists {
 static int fuseGrid(khr_ctx* c, const void* kernel, int group, int block) {
   if (kFuseGrid > 0) return std::max(8 * group, kFuseGrid / (8 * group) * (8 * group));
   static std::map<const void*, int> cache;
+  static std::mutex cache_mu;  // contexts of different threads (active window + extraction workers) launch concurrently
+  std::lock_guard<std::mutex> lock(cache_mu);
   const void* key = kernel;
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
@@ -2630,7 +2645,7 @@ static int resetInactiveLaunch(khr_ctx* c) {
   DevMap& m = c->m;
   HIP_TRY(hipMemsetAsync(&m.counters[C_N_REMOVED], 0, sizeof(uint32_t), c->stream));
   int rc = dispatchVps(c, [&](auto vps) {
-    hipLaunchKernelGGL((k_reset_inactive<decltype(vps)::value>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->d_removed);
+    hipLaunchKernelGGL((k_reset_inactive<decltype(vps)::value>), dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_removed);
     return KHR_OK;
   });
   if (rc) return rc;
@@ -3208,6 +3223,92 @@ int64_t khr_download_mesh(khr_ctx* c, float* points, uint8_t* colors_rgba, uint3
     n += d.count;
   }
   return n;
+}
+
+// one launch + one host wait: the device gathers index / flags / descriptors / vertex arrays into the pinned staging
+// buffer (k_mesh_gather), the host orders the blocks and hands out views of arrays it owns
+int64_t khr_fetch_mesh(khr_ctx* c, khr_mesh_view* out) {
+  if (!c || !out) return fail(KHR_EINVAL, "null argument");
+  *out = khr_mesh_view{};
+  c->fm_order.clear();
+  c->fm_total = 0;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = ensureStage(c, 1u << 20);
+  if (rc) return rc;
+  const MeshBuffers& mb = c->mesh[c->mesh_cur];
+  const uint32_t* h = static_cast<const uint32_t*>(c->h_stage);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    void* d_stage = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&d_stage, c->h_stage, 0));
+    ++c->fetch_ticket;
+    if (c->fetch_ticket == 0) ++c->fetch_ticket;
+    static_cast<volatile uint32_t*>(c->h_stage)[15] = 0u;
+    hipLaunchKernelGGL(k_mesh_gather, dim3(256), dim3(256), 0, c->stream, c->m, mb, c->d_mesh_offset + c->m.capacity,
+                       static_cast<uint32_t*>(d_stage), static_cast<uint64_t>(c->h_stage_bytes / 4), c->d_fetch_done, c->fetch_ticket);
+    HIP_TRY(hipGetLastError());
+    HT("fetch_launched");
+    if ((rc = waitWord(c, static_cast<volatile uint32_t*>(c->h_stage) + 15, c->fetch_ticket, "mesh gather"))) return rc;
+    HT("fetch_arrived");
+    if (h[2]) return fail(KHR_ENOMEM, "mesh needs %u vertices, max_mesh_vertices=%llu", h[0], static_cast<unsigned long long>(c->cfg.max_mesh_vertices));
+    if (h[3]) break;
+    if (attempt == 1) return fail(KHR_ENOMEM, "mesh staging of %u words", h[4]);
+    const size_t need = static_cast<size_t>(h[4]) * 4;
+    if ((rc = ensureStage(c, need))) return rc;
+    h = static_cast<const uint32_t*>(c->h_stage);
+  }
+  const uint32_t total_dev = h[0], nslots = h[1];
+  c->mesh_total = total_dev;
+  c->stats.n_mesh_vertices = total_dev;
+  c->mesh_stale = false;
+  const int4* idx = reinterpret_cast<const int4*>(h + h[8]);
+  const uint32_t* flg = h + h[9];
+  const MeshDesc* desc = reinterpret_cast<const MeshDesc*>(h + h[10]);
+  const float* hp = reinterpret_cast<const float*>(h + h[11]);
+  const uint32_t* hc = h + h[12];
+  const uint32_t* hl = h + h[13];
+  const uint64_t* hs = reinterpret_cast<const uint64_t*>(h + h[14]);
+  // only the blocks that carry vertices matter, in sorted block order (combineMeshLayer iterates the mesh layer):
+  // a sort of those few, not a map of every live block
+  std::vector<uint32_t> order;
+  size_t total = 0;
+  for (uint32_t sl = 0; sl < nslots; ++sl)
+    if ((flg[sl] & BLK_LIVE) && desc[sl].count) {
+      order.push_back(sl);
+      total += desc[sl].count;
+    }
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    return idx[a].x != idx[b].x ? idx[a].x < idx[b].x : (idx[a].y != idx[b].y ? idx[a].y < idx[b].y : idx[a].z < idx[b].z);
+  });
+  HT("fetch_sorted");
+  c->fm_order.swap(order);
+  c->fm_total = total;
+  out->num_vertices = static_cast<int64_t>(total);
+  return static_cast<int64_t>(total);
+}
+
+// second half of khr_fetch_mesh: the staged vertex arrays, block by block in sorted block order, into the caller's arrays
+// (any pointer may be NULL).  No device access.
+int khr_fetch_mesh_into(khr_ctx* c, float* points, uint8_t* colors_rgba, uint32_t* labels, uint64_t* first_seen, uint64_t* stamps) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  if (!c->h_stage || c->fetch_ticket == 0) return fail(KHR_ESTATE, "no khr_fetch_mesh before khr_fetch_mesh_into");
+  const uint32_t* h = static_cast<const uint32_t*>(c->h_stage);
+  const MeshDesc* desc = reinterpret_cast<const MeshDesc*>(h + h[10]);
+  const float* hp = reinterpret_cast<const float*>(h + h[11]);
+  const uint32_t* hc = h + h[12];
+  const uint32_t* hl = h + h[13];
+  const uint64_t* hs = reinterpret_cast<const uint64_t*>(h + h[14]);
+  size_t n = 0;
+  for (const uint32_t sl : c->fm_order) {
+    const MeshDesc d = desc[sl];
+    if (points) std::memcpy(points + 3 * n, hp + 3 * static_cast<size_t>(d.offset), 12ull * d.count);
+    if (colors_rgba) std::memcpy(colors_rgba + 4 * n, hc + d.offset, 4ull * d.count);
+    if (labels) std::memcpy(labels + n, hl + d.offset, 4ull * d.count);
+    if (first_seen) std::memcpy(first_seen + n, hs + d.offset, 8ull * d.count);
+    if (stamps) std::memcpy(stamps + n, hs + d.offset, 8ull * d.count);
+    n += d.count;
+  }
+  HT("fetch_copied");
+  return KHR_OK;
 }
 
 int khr_debug_read(khr_ctx* c, unsigned long long* out, int64_t n) {

@@ -270,12 +270,14 @@ std::shared_ptr<KhronosObjectAttributes> MeshObjectExtractor::extractStaticObjec
     chk(khr_reset_map(object_ctx_, oc.voxel_size, oc.truncation_distance), "khr_reset_map(object map)");
   }
   khr_ctx* octx = object_ctx_;
+  khr_host_trace("x_ctx_ready");
   // the buffered frames were written on the active window's stream: one device-side dependency instead of a host wait per
   // re-integrated frame (the extraction may run on a worker thread while the window keeps queueing frames)
   chk(khr_depend_on(octx, frames.front().first->input.ctx), "khr_depend_on");
   std::shared_ptr<KhronosObjectAttributes> object;
   try {
     chk(khr_allocate_blocks(octx, idx.data(), static_cast<int64_t>(n_blocks)), "khr_allocate_blocks");  // :218-228
+    khr_host_trace("x_allocated");
     // projective re-integration of every buffered frame with the binary object label (:239-243): one call, the block
     // list and the per-call bookkeeping are set up once for all frames
     {
@@ -288,14 +290,17 @@ std::shared_ptr<KhronosObjectAttributes> MeshObjectExtractor::extractStaticObjec
                                      /*allocate=*/0, /*use_mask=*/0),
           "khr_integrate_shared_batch");
     }
+    khr_host_trace("x_integrated");
     // erase low-confidence voxels (:246-264)
     if (!config.visualize_classification)  // (no count requested: the call stays asynchronous)
       chk(khr_object_prune(octx, config.min_object_reconstruction_confidence, config.min_object_reconstruction_observations, nullptr),
           "khr_object_prune");
     chk(khr_generate_mesh(octx, 1, 0), "khr_generate_mesh");  // :267
+    khr_host_trace("x_mesh_queued");
     object = std::make_shared<KhronosObjectAttributes>();
-    const int64_t nv = khr_mesh_num_vertices(octx);
-    chk(static_cast<int>(nv < 0 ? nv : 0), "khr_mesh_num_vertices");
+    khr_mesh_view view{};
+    const int64_t nv = khr_fetch_mesh(octx, &view);  // one device -> host round trip for the whole object mesh
+    chk(static_cast<int>(nv < 0 ? nv : 0), "khr_fetch_mesh");
     hydra::Mesh& mesh = object->mesh;
     mesh.points.resize(3 * nv);
     mesh.colors.resize(4 * nv);
@@ -303,9 +308,10 @@ std::shared_ptr<KhronosObjectAttributes> MeshObjectExtractor::extractStaticObjec
     mesh.first_seen_stamps.resize(nv);
     mesh.stamps.resize(nv);
     if (nv > 0)
-      chk(static_cast<int>(std::min<int64_t>(0, khr_download_mesh(octx, mesh.points.data(), mesh.colors.data(), mesh.labels.data(),
-                                                                    mesh.first_seen_stamps.data(), mesh.stamps.data(), nv))),
-          "khr_download_mesh");
+      chk(khr_fetch_mesh_into(octx, mesh.points.data(), mesh.colors.data(), mesh.labels.data(), mesh.first_seen_stamps.data(),
+                              mesh.stamps.data()),
+          "khr_fetch_mesh_into");
+    khr_host_trace("x_downloaded");
   } catch (...) {
     khr_destroy(object_ctx_);  // unknown state: start from a fresh context next time
     object_ctx_ = nullptr;

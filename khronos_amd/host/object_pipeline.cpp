@@ -24,23 +24,26 @@ struct kop_handle {
   VolumetricMap map;
   std::unique_ptr<ObjectDetector> detector;
   std::unique_ptr<Tracker> tracker;
-  std::unique_ptr<ObjectExtractor> extractor;
+  std::unique_ptr<ObjectExtractor> extractor;   // in-line extraction + worker 0
+  std::vector<std::unique_ptr<ObjectExtractor>> more_extractors;  // workers 1 .. num_workers - 1 (own device context each)
   std::unique_ptr<FrameDataBuffer> buffer;
   std::vector<std::shared_ptr<KhronosObjectAttributes>> last_objects;
   std::shared_ptr<FrameData> pending;  // kop_launch_frame done, kop_finish_frame outstanding
 
-  // detached extraction (ObjectWorkerPool role, object_worker_pool.cpp:56-146): one worker thread takes the tracks that
-  // left the window together with a snapshot of the frame buffer (shared frames outlive trimming, active_window.cpp:261-263)
-  // and runs the extractor on its own device context / stream while the window keeps processing frames
+  // detached extraction (ObjectWorkerPool role, object_worker_pool.cpp:56-146): extraction_worker.num_workers threads take
+  // the tracks that left the window together with a snapshot of the frame buffer (shared frames outlive trimming,
+  // active_window.cpp:261-263); each runs its own extractor on its own device context / stream while the window keeps
+  // processing frames.  Finished objects are handed out in completion order, like getFinishedExtractions.
   struct Job {
     Track track;
     std::shared_ptr<const FrameDataBuffer> frames;
   };
-  std::thread worker;
+  std::vector<std::thread> workers;
   std::mutex mu;
   std::condition_variable cv, cv_idle;
   std::deque<Job> jobs;
-  bool stop = false, busy = false;
+  bool stop = false;
+  int busy = 0;
   std::vector<std::shared_ptr<KhronosObjectAttributes>> finished;  // not yet handed out
   uint64_t finished_vertices = 0;
   std::string worker_error;
@@ -51,13 +54,14 @@ struct kop_handle {
       stop = true;
     }
     cv.notify_all();
-    if (worker.joinable()) worker.join();
+    for (auto& w : workers)
+      if (w.joinable()) w.join();
     // frames hold leases on slots of `ctx`, which the caller destroys after this handle
     pending.reset();
     jobs.clear();
     buffer.reset();
   }
-  void workerLoop() {
+  void workerLoop(ObjectExtractor* my_extractor) {
     while (true) {
       Job job;
       {
@@ -66,12 +70,14 @@ struct kop_handle {
         if (jobs.empty()) return;  // stop requested and nothing left
         job = std::move(jobs.front());
         jobs.pop_front();
-        busy = true;
+        ++busy;
       }
       std::shared_ptr<KhronosObjectAttributes> obj;
       std::string err;
       try {
-        obj = extractor->extractObject(job.track, *job.frames);
+        khr_host_trace("worker_job_begin");
+        obj = my_extractor->extractObject(job.track, *job.frames);
+        khr_host_trace("worker_job_end");
       } catch (const std::exception& e) {
         err = e.what();
       }
@@ -82,7 +88,7 @@ struct kop_handle {
           finished.push_back(obj);
         }
         if (!err.empty()) worker_error = err;
-        busy = false;
+        --busy;
       }
       cv_idle.notify_all();
     }
@@ -129,6 +135,9 @@ kop_handle* kop_create(khr_ctx* ctx, const char* yaml_text, char* err, int err_l
       khr_config dc{};
       if (khr_get_config(ctx, &dc) < 0) throw std::runtime_error(khr_last_error());
       h->extractor = std::make_unique<MeshObjectExtractor>(c.object_extractor, dc);
+      if (c.detach_object_extraction)
+        for (int w = 1; w < std::max(1, c.extraction_worker.num_workers); ++w)
+          h->more_extractors.push_back(std::make_unique<MeshObjectExtractor>(c.object_extractor, dc));
     }
     h->buffer = std::make_unique<FrameDataBuffer>(c.frame_data_buffer);
     return h.release();
@@ -244,7 +253,13 @@ int kop_extract_inactive(kop_handle* h, int* n_removed, uint64_t* n_vertices, ch
       it = tracks.erase(it);
     }
     if (detach) {
-      if (!h->worker.joinable()) h->worker = std::thread([h] { h->workerLoop(); });
+      if (h->workers.empty()) {
+        h->workers.emplace_back([h] { h->workerLoop(h->extractor.get()); });
+        for (auto& e : h->more_extractors) {
+          ObjectExtractor* ep = e.get();
+          h->workers.emplace_back([h, ep] { h->workerLoop(ep); });
+        }
+      }
       std::lock_guard<std::mutex> lock(h->mu);
       if (!h->worker_error.empty()) throw std::runtime_error("object extraction worker: " + h->worker_error);
       h->last_objects.swap(h->finished);
@@ -263,7 +278,7 @@ int kop_extract_inactive(kop_handle* h, int* n_removed, uint64_t* n_vertices, ch
 int kop_join(kop_handle* h, char* err, int err_len) {
   if (!h) return KHR_EINVAL;
   std::unique_lock<std::mutex> lock(h->mu);
-  h->cv_idle.wait(lock, [&] { return h->jobs.empty() && !h->busy; });
+  h->cv_idle.wait(lock, [&] { return h->jobs.empty() && h->busy == 0; });
   if (!h->worker_error.empty()) {
     setErr(err, err_len, "object extraction worker: " + h->worker_error);
     return KHR_EDEVICE;

@@ -111,6 +111,7 @@ struct kdist_handle {
   khr_sensor sensor{};
   int rank = 0, world = 1, n_cameras = 1;
   bool motion = true, shard_motion = true, always_exchange = false, own_comm = false;
+  bool emulate = false;  // KDIST_EMULATE: the tick of rank `rank` of `world` without the other ranks (no communicator)
   ncclComm_t comm = nullptr;
   hipStream_t stream = nullptr;
   int64_t halo_cap = 0, req_cap = 0, rec_cap = 0;
@@ -129,6 +130,7 @@ struct kdist_handle {
   std::vector<void*> allocs;
 
   bool exchange() const { return world > 1 || always_exchange; }
+  bool net() const { return comm != nullptr; }
   template <typename T>
   T* alloc(size_t count) {
     void* p = nullptr;
@@ -190,6 +192,7 @@ kdist_handle* kdist_create(khr_ctx* ctx, const khr_sensor* sensor, int rank, int
     h->motion = flags & 1u;
     h->shard_motion = flags & 2u;
     h->always_exchange = flags & 4u;
+    h->emulate = flags & 8u;
     h->halo_cap = halo_cap;
     h->req_cap = mesh_req_cap;
     h->rec_cap = mesh_rec_cap;
@@ -198,7 +201,7 @@ kdist_handle* kdist_create(khr_ctx* ctx, const khr_sensor* sensor, int rank, int
     KD_HIP(hipSetDevice(cfg.device));
     KD_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     KD_KHR(khr_set_stream(ctx, h->stream));  // fusion kernels and collectives share one stream: stream order is the protocol
-    if (h->exchange()) {
+    if (h->exchange() && !h->emulate) {
       if (!unique_id) throw Fail{KHR_EINVAL, "a communicator needs the unique id made by rank 0 (kdist_unique_id)"};
       ncclUniqueId id;
       std::memcpy(&id, unique_id, sizeof(id));
@@ -262,6 +265,7 @@ int kdist_gather_frames(kdist_handle* h, const void* packed_local, size_t bytes,
       h->frame_recv_bytes = need;
     }
     if (h->exchange()) {
+      if (!h->net()) throw Fail{KHR_ESTATE, "no communicator (emulation)"};
       KD_NCCL(rccl().AllGather(packed_local, h->frame_recv, bytes, ncclUint8, h->comm, h->stream));
     } else {
       KD_HIP(hipMemcpyAsync(h->frame_recv, packed_local, bytes, hipMemcpyDeviceToDevice, h->stream));
@@ -289,7 +293,7 @@ int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, 
       // (3) which cameras have seeds on some rank
       std::vector<int64_t> cnt(static_cast<size_t>(n), 0);
       if (ex && split) {
-        KD_NCCL(rccl().AllReduce(h->seed_counts, h->seed_counts, static_cast<size_t>(n), ncclInt64, ncclSum, h->comm, h->stream));
+        if (h->net()) KD_NCCL(rccl().AllReduce(h->seed_counts, h->seed_counts, static_cast<size_t>(n), ncclInt64, ncclSum, h->comm, h->stream));
         KD_HIP(hipMemcpyAsync(cnt.data(), h->seed_counts, sizeof(int64_t) * static_cast<size_t>(n), hipMemcpyDeviceToHost, h->stream));
         KD_HIP(hipStreamSynchronize(h->stream));
       } else {
@@ -297,7 +301,7 @@ int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, 
         for (int i = 0; i < n; ++i) cnt[static_cast<size_t>(i)] = host_counts[static_cast<size_t>(i)];
         if (ex) {
           KD_HIP(hipMemcpyAsync(h->seed_counts, cnt.data(), sizeof(int64_t) * static_cast<size_t>(n), hipMemcpyHostToDevice, h->stream));
-          KD_NCCL(rccl().AllReduce(h->seed_counts, h->seed_counts, static_cast<size_t>(n), ncclInt64, ncclSum, h->comm, h->stream));
+          if (h->net()) KD_NCCL(rccl().AllReduce(h->seed_counts, h->seed_counts, static_cast<size_t>(n), ncclInt64, ncclSum, h->comm, h->stream));
           KD_HIP(hipMemcpyAsync(cnt.data(), h->seed_counts, sizeof(int64_t) * static_cast<size_t>(n), hipMemcpyDeviceToHost, h->stream));
           KD_HIP(hipStreamSynchronize(h->stream));
         }
@@ -310,14 +314,14 @@ int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, 
         uint32_t n_seed = 0;
         KD_KHR(khr_motion_keys(c, slots_out[ci], keys, 1, &n_seed));
         if (!h->shard_motion) {
-          if (ex) KD_NCCL(rccl().AllReduce(keys, keys, h->npx, ncclUint64, ncclSum, h->comm, h->stream));
+          if (ex && h->net()) KD_NCCL(rccl().AllReduce(keys, keys, h->npx, ncclUint64, ncclSum, h->comm, h->stream));
           const int nc = khr_detect_motion_from_keys(c, slots_out[ci], keys, 1);
           KD_KHR(nc);
           h->clusters_last_tick[static_cast<size_t>(ci)] = nc;
           continue;
         }
         // the camera's home rank assembles the key image, clusters it and paints; everybody else receives the painted image
-        if (ex) KD_NCCL(rccl().Reduce(keys, keys, h->npx, ncclUint64, ncclSum, home, h->comm, h->stream));
+        if (ex && h->net()) KD_NCCL(rccl().Reduce(keys, keys, h->npx, ncclUint64, ncclSum, home, h->comm, h->stream));
         int32_t*& img = h->dyn_img[static_cast<size_t>(ci)];
         if (ex && !img) img = h->alloc<int32_t>(h->npx + 1);
         if (h->rank == home) {
@@ -334,8 +338,8 @@ int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, 
           h->clusters_last_tick[static_cast<size_t>(ci)] = -1;
         }
         if (ex) {
-          KD_NCCL(rccl().Broadcast(img, img, h->npx + 1, ncclInt32, home, h->comm, h->stream));
-          if (h->rank != home) KD_KHR(khr_set_frame_image(c, slots_out[ci], 0, img, 1));
+          if (h->net()) KD_NCCL(rccl().Broadcast(img, img, h->npx + 1, ncclInt32, home, h->comm, h->stream));
+          if (h->rank != home && h->net()) KD_KHR(khr_set_frame_image(c, slots_out[ci], 0, img, 1));
         }
       }
     }
@@ -345,8 +349,12 @@ int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, 
     // (5) halo records of every rank, ever-free stencil
     if (ex) {
       KD_KHR(khr_export_halo(c, h->halo_send, h->halo_cap, 1));
-      KD_NCCL(rccl().AllGather(h->halo_send, h->halo_recv, static_cast<size_t>(h->halo_cap) * kHaloWords, ncclUint64, h->comm, h->stream));
-      KD_KHR(khr_import_halo(c, h->halo_recv, static_cast<int64_t>(h->world) * h->halo_cap, 1));
+      if (h->net()) {
+        KD_NCCL(rccl().AllGather(h->halo_send, h->halo_recv, static_cast<size_t>(h->halo_cap) * kHaloWords, ncclUint64, h->comm, h->stream));
+        KD_KHR(khr_import_halo(c, h->halo_recv, static_cast<int64_t>(h->world) * h->halo_cap, 1));
+      } else {  // emulation: only this rank's records exist
+        KD_KHR(khr_import_halo(c, h->halo_send, h->halo_cap, 1));
+      }
     }
     KD_KHR(khr_update_tracking_phase(c, stamp, 2));
     if (clusters_out)
@@ -363,10 +371,15 @@ int kdist_output(kdist_handle* h) {
     khr_ctx* c = h->ctx;
     if (h->exchange()) {
       KD_KHR(khr_mesh_halo_requests(c, h->req_send, h->req_cap, 1, 1));  // (errors when the requests exceed req_cap)
-      KD_NCCL(rccl().AllGather(h->req_send, h->req_recv, static_cast<size_t>(h->req_cap), ncclUint64, h->comm, h->stream));
-      KD_KHR(khr_mesh_halo_export(c, h->req_recv, static_cast<int64_t>(h->world) * h->req_cap, h->rec_send, h->rec_cap, 1));
-      KD_NCCL(rccl().AllGather(h->rec_send, h->rec_recv, static_cast<size_t>(h->rec_cap) * h->mesh_words, ncclUint32, h->comm, h->stream));
-      KD_KHR(khr_mesh_halo_import(c, h->rec_recv, static_cast<int64_t>(h->world) * h->rec_cap, 1));
+      if (h->net()) {
+        KD_NCCL(rccl().AllGather(h->req_send, h->req_recv, static_cast<size_t>(h->req_cap), ncclUint64, h->comm, h->stream));
+        KD_KHR(khr_mesh_halo_export(c, h->req_recv, static_cast<int64_t>(h->world) * h->req_cap, h->rec_send, h->rec_cap, 1));
+        KD_NCCL(rccl().AllGather(h->rec_send, h->rec_recv, static_cast<size_t>(h->rec_cap) * h->mesh_words, ncclUint32, h->comm, h->stream));
+        KD_KHR(khr_mesh_halo_import(c, h->rec_recv, static_cast<int64_t>(h->world) * h->rec_cap, 1));
+      } else {  // emulation: requests and answers of this rank only
+        KD_KHR(khr_mesh_halo_export(c, h->req_send, h->req_cap, h->rec_send, h->rec_cap, 1));
+        KD_KHR(khr_mesh_halo_import(c, h->rec_send, h->rec_cap, 1));
+      }
       // a rank with more live blocks than halo_cap, or more answers than rec_cap, would have truncated its records: the
       // device counted that (the exchange kernels bump pool_exhausted), and this is where it becomes an error
       khr_stats st{};

@@ -146,7 +146,7 @@ class ShardedFusionHost:
     """The multi-GPU tick in C++ over RCCL (khronos_amd/host/sharded_fusion.cpp): the same protocol as
     khronos_amd.distributed.ShardedFusion, with ncclAllGather / ncclAllReduce / ncclReduce / ncclBroadcast on the context's own
     HIP stream instead of torch.distributed.  unique_id: the 128-byte token rank 0 made with unique_id() (any transport)."""
-    MOTION, SHARD_MOTION, ALWAYS_EXCHANGE = 1, 2, 4
+    MOTION, SHARD_MOTION, ALWAYS_EXCHANGE, EMULATE = 1, 2, 4, 8
 
     @staticmethod
     def unique_id():
@@ -157,9 +157,10 @@ class ShardedFusionHost:
         return buf.raw
 
     def __init__(self, ctx, sensor, rank, world_size, unique_id, n_cameras, halo_cap=8192, mesh_req_cap=16384, mesh_rec_cap=2048,
-                 motion=True, shard_motion=True, always_exchange=False):
+                 motion=True, shard_motion=True, always_exchange=False, emulate=False):
         self.lib, self.ctx, self.n_cameras = load_host_library(), ctx, n_cameras
-        flags = (self.MOTION if motion else 0) | (self.SHARD_MOTION if shard_motion else 0) | (self.ALWAYS_EXCHANGE if always_exchange else 0)
+        flags = (self.MOTION if motion else 0) | (self.SHARD_MOTION if shard_motion else 0) | (self.ALWAYS_EXCHANGE if always_exchange else 0) | \
+            (self.EMULATE if emulate else 0)
         self.h = self.lib.kdist_create(ctx.h, C.byref(sensor), rank, world_size, unique_id, n_cameras, halo_cap, mesh_req_cap, mesh_rec_cap,
                                        flags)
         if not self.h:

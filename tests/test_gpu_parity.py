@@ -107,6 +107,9 @@ def test_mesh_and_archival():
             assert np.array_equal(gm["labels"], om["labels"])
             assert np.array_equal(gm["stamps"], om["stamps"])
             assert np.abs(gm["colors"].astype(int) - om["colors"].astype(int)).max() <= 1
+            fm = ctx.fetch_mesh()  # the one-round-trip form (khr_fetch_mesh) returns the same arrays
+            for k in ("points", "colors", "labels", "stamps", "first_seen"):
+                assert np.array_equal(fm[k], gm[k]), k
             # cloneUpdated (active_window.cpp:229) as one packed transfer == the per-block downloads
             upd = ctx.download_updated()
             ui = ctx.block_indices(only_updated=True)

@@ -59,7 +59,8 @@ def parse_args():
     ap.add_argument("--latency-frames", type=int, default=8,
                     help="frames after the timed region that are run with a device synchronisation after each: per-frame latency "
                          "(the reference's active_window/all scope) beside the pipelined throughput; 0 = skip")
-    ap.add_argument("--exact", action="store_true", help="khr_config.exact_arithmetic = 1 (values bit-identical to the CPU restatement)")
+    ap.add_argument("--exact", action="store_true", help="(default) khr_config.exact_arithmetic = 1: values bit-identical to the CPU restatement")
+    ap.add_argument("--fast", action="store_true", help="khr_config.exact_arithmetic = 0: decisions exact, distance / weight within ~1e-6 relative")
     ap.add_argument("--buffer-frames", type=int, default=100, help="frame_data_buffer.max_buffer_size (frames kept in HBM per camera)")
     ap.add_argument("--cpu-baseline-frames", type=int, default=-1,
                     help="frames of the same stream timed on the CPU oracle (rank 0, N=1); -1 = auto, 0 = skip")
@@ -177,7 +178,7 @@ def main():
     trunc = 3.0 * vs
     cfg = default_config(
         voxel_size=vs, truncation_distance=trunc, voxels_per_side=16, with_semantics=1, with_tracking=1,
-        exact_arithmetic=1 if args.exact else 0,
+        exact_arithmetic=0 if args.fast else 1,
         num_labels=K, max_blocks=args.max_blocks, max_frame_pixels=W * H,
         # buffered frames stay resident in the device ring (FrameDataBuffer role); every rank holds all cameras' frames
         num_frame_slots=max(2, world) if args.no_objects else world * (args.buffer_frames + 1) + 64,  # + frames held by detached extractions
@@ -477,7 +478,7 @@ def main():
                                   "off" if args.no_objects else "on (ConnectedSemantics, MaxIoUTracker, MeshObjectExtractor)",
                                   ("output (mesh, archival%s) every %d frame(s)" % ("" if args.no_objects else ", object extraction", args.output_every))
                                   if args.output_every > 0 else "no output stage", world, pre, args.warmup,
-                                  "exact" if args.exact else "fast (decisions exact, values ~1e-6)"),
+                                  "fast (decisions exact, values ~1e-6)" if args.fast else "exact (bit-identical to the CPU restatement)"),
                    "preset": args.config if preset_matches else None,
                    "parallelism": "hash-range block shard x%d, owner-computes, RCCL all-gather of packed frames (prefetched one tick ahead on its own stream) + of 528-B halo records "
                                   "(ever-free), seed-gated all-reduce of per-pixel voxel keys (motion detector), request / response all-gather of mesh halo planes" % world

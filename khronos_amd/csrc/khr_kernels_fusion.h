@@ -301,57 +301,70 @@ __device__ inline void cullBlocks(const DevMap& m, const DevParams& p, const Dev
         s_blk[kslot] = make_uint4(slot, static_cast<uint32_t>(bi.x), static_cast<uint32_t>(bi.y), static_cast<uint32_t>(bi.z));
       }
       kslot = __shfl(kslot, 0);
-      if (lane < wpb) {  // lane <-> wave item of the block: class by the in-band voxels of its previous update
-        // the same three tests once more on the item's own voxels (k_fuse: a 64-voxel x-y patch, vps / (wpb / patches)
-        // z steps: a thin slab of the block): behind the camera / out of range, projected outside the image, or
-        // entirely behind the surface by more than the truncation distance.  A culled item has no voxel the update
-        // would touch, so the result is the same and the update kernel issues no loads for it.
-        bool ikeep = true;
-        if (tile_max && (p.dbg & 256) == 0) {
-          const float margin = 1e-3f;
-          const int patches = (p.vps * p.vps) >> 6, rows = 64 / p.vps, zr = p.vps / (static_cast<int>(wpb) / patches);
-          const int y0 = (static_cast<int>(lane) % patches) * rows, z0 = (static_cast<int>(lane) / patches) * zr;
-          const float lo[3] = {static_cast<float>(bi.x) * p.bs + 0.5f * p.vs, static_cast<float>(bi.y) * p.bs + (static_cast<float>(y0) + 0.5f) * p.vs,
-                               static_cast<float>(bi.z) * p.bs + (static_cast<float>(z0) + 0.5f) * p.vs};
-          const float ex[3] = {p.bs - p.vs, static_cast<float>(rows - 1) * p.vs, static_cast<float>(zr - 1) * p.vs};
-          float zmin = 1e30f, zmax = -1e30f, umin = 1e30f, umax = -1e30f, vmin = 1e30f, vmax = -1e30f;
-          float pcs[8][3];
+      // lanes <-> wave items of the block, 64 / wpb lanes per item (they split the item's footprint tiles).
+      // The same three tests once more on the item's own voxels (k_fuse: a 64-voxel x-y patch, vps / (wpb / patches) z
+      // steps: a thin slab of the block): behind the camera / out of range, projected outside the image, or entirely
+      // behind the surface by more than the truncation distance.  A culled item has no voxel the update would touch, so
+      // the result is the same and the update kernel issues no loads for it.
+      const uint32_t lpi = 64u / wpb, item = lane / lpi, sub = lane % lpi;  // wpb is 4, 16 or 32
+      bool ikeep = true;
+      if (tile_max && (p.dbg & 256) == 0) {
+        const float margin = 1e-3f;
+        const int patches = (p.vps * p.vps) >> 6, rows = 64 / p.vps, zr = p.vps / (static_cast<int>(wpb) / patches);
+        const int y0 = (static_cast<int>(item) % patches) * rows, z0 = (static_cast<int>(item) / patches) * zr;
+        const float lo[3] = {static_cast<float>(bi.x) * p.bs + 0.5f * p.vs, static_cast<float>(bi.y) * p.bs + (static_cast<float>(y0) + 0.5f) * p.vs,
+                             static_cast<float>(bi.z) * p.bs + (static_cast<float>(z0) + 0.5f) * p.vs};
+        const float ex[3] = {p.bs - p.vs, static_cast<float>(rows - 1) * p.vs, static_cast<float>(zr - 1) * p.vs};
+        float zmin = 1e30f, zmax = -1e30f, umin = 1e30f, umax = -1e30f, vmin = 1e30f, vmax = -1e30f;
+        float pcs[8][3];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          xform(f.R, f.t, lo[0] + ((k & 1) ? ex[0] : 0.f), lo[1] + ((k & 2) ? ex[1] : 0.f), lo[2] + ((k & 4) ? ex[2] : 0.f), pcs[k]);
+          zmin = fminf(zmin, pcs[k][2]);
+          zmax = fmaxf(zmax, pcs[k][2]);
+        }
+        if (zmax <= -margin) ikeep = false;
+        if (zmin > f.max_range + margin) ikeep = false;
+        if (p.range_mode == 0 && zmax < f.min_range - margin) ikeep = false;
+        if (ikeep && zmin > 0.05f) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            xform(f.R, f.t, lo[0] + ((k & 1) ? ex[0] : 0.f), lo[1] + ((k & 2) ? ex[1] : 0.f), lo[2] + ((k & 4) ? ex[2] : 0.f), pcs[k]);
-            zmin = fminf(zmin, pcs[k][2]);
-            zmax = fmaxf(zmax, pcs[k][2]);
+            // (1-ulp reciprocal: the footprint below is widened by a pixel and more on every side)
+            const float iz = __builtin_amdgcn_rcpf(pcs[k][2]);
+            const float u = (pcs[k][0] * f.fx) * iz + f.cx, v = (pcs[k][1] * f.fy) * iz + f.cy;
+            umin = fminf(umin, u); umax = fmaxf(umax, u);
+            vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
           }
-          if (zmax <= -margin) ikeep = false;
-          if (zmin > f.max_range + margin) ikeep = false;
-          if (p.range_mode == 0 && zmax < f.min_range - margin) ikeep = false;
-          if (ikeep && zmin > 0.05f) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const float u = (pcs[k][0] * f.fx) / pcs[k][2] + f.cx, v = (pcs[k][1] * f.fy) / pcs[k][2] + f.cy;
-              umin = fminf(umin, u); umax = fmaxf(umax, u);
-              vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
-            }
-            if (umax < -1.f || vmax < -1.f || umin > static_cast<float>(f.W) || vmin > static_cast<float>(f.H)) {
-              ikeep = false;
-            } else {
-              const int tx0 = max(0, (static_cast<int>(floorf(umin)) - 1) / kTile);
-              const int ty0 = max(0, (static_cast<int>(floorf(vmin)) - 1) / kTile);
-              const int tx1 = min(tw - 1, (static_cast<int>(ceilf(umax)) + 2) / kTile);
-              const int ty1 = min(th - 1, (static_cast<int>(ceilf(vmax)) + 2) / kTile);
-              const int nx = tx1 - tx0 + 1, nt = nx * (ty1 - ty0 + 1);
-              if (tx1 >= tx0 && ty1 >= ty0 && nt <= 24) {  // (a slab right in front of the camera covers many tiles: keep it)
-                float mr = 0.f;
-                for (int t = 0; t < nt; ++t) mr = fmaxf(mr, tile_max[(ty0 + t / nx) * tw + tx0 + t % nx]);
-                if (mr < zmin - p.trunc - margin) ikeep = false;
+          if (umax < -2.f || vmax < -2.f || umin > static_cast<float>(f.W) + 1.f || vmin > static_cast<float>(f.H) + 1.f) {
+            ikeep = false;
+          } else {
+            const int tx0 = max(0, (static_cast<int>(floorf(umin)) - 2) / kTile);
+            const int ty0 = max(0, (static_cast<int>(floorf(vmin)) - 2) / kTile);
+            const int tx1 = min(tw - 1, (static_cast<int>(ceilf(umax)) + 3) / kTile);
+            const int ty1 = min(th - 1, (static_cast<int>(ceilf(vmax)) + 3) / kTile);
+            const int nx = tx1 - tx0 + 1, nt = nx * (ty1 - ty0 + 1);
+            if (tx1 >= tx0 && ty1 >= ty0 && nt <= 16 * static_cast<int>(lpi)) {  // (a slab right in front of the camera covers many tiles: keep it)
+              // the item's lanes split the tiles; two independent accumulators keep two loads in flight per lane
+              float m0 = 0.f, m1 = 0.f;
+              int t = static_cast<int>(sub);
+              for (; t + static_cast<int>(lpi) < nt; t += 2 * static_cast<int>(lpi)) {
+                const int t2 = t + static_cast<int>(lpi);
+                const float a = tile_max[(ty0 + t / nx) * tw + tx0 + t % nx];
+                const float b = tile_max[(ty0 + t2 / nx) * tw + tx0 + t2 % nx];
+                m0 = fmaxf(m0, a);
+                m1 = fmaxf(m1, b);
               }
+              if (t < nt) m0 = fmaxf(m0, tile_max[(ty0 + t / nx) * tw + tx0 + t % nx]);
+              float mr = fmaxf(m0, m1);
+              for (uint32_t o = 1; o < lpi; o <<= 1) mr = fmaxf(mr, __shfl_xor(mr, static_cast<int>(o)));
+              if (mr < zmin - p.trunc - margin) ikeep = false;
             }
           }
         }
-        if (ikeep) {
-          const uint32_t cls = fuseClass(m.blk_band[static_cast<size_t>(slot) * kBandSlots + lane]);
-          s_item[cls][atomicAdd(&s_ccnt[cls], 1u)] = static_cast<uint16_t>((kslot << 8) | lane);
-        }
+      }
+      if (ikeep && sub == 0) {
+        const uint32_t cls = fuseClass(m.blk_band[static_cast<size_t>(slot) * kBandSlots + item]);
+        s_item[cls][atomicAdd(&s_ccnt[cls], 1u)] = static_cast<uint16_t>((kslot << 8) | item);
       }
     }
   }

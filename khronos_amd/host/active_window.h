@@ -372,7 +372,7 @@ class ActiveWindow {
     uint32_t max_frame_pixels = 1280 * 720;
     uint64_t max_mesh_vertices = 8u << 20;
     int device = 0, rank = 0, world_size = 1;
-    int exact_arithmetic = 0;  // khr_config.exact_arithmetic: voxel values bit-identical to the CPU restatement
+    int exact_arithmetic = 1;  // khr_config.exact_arithmetic: 1 = voxel values bit-identical to the CPU restatement (default), 0 = relaxed values
     // hydra::timing scopes (hydra_compat.h): wait for the device before a scope that launched device work stops, so that
     // "active_window/all" is the per-frame latency the reference's timer measures (off: enqueue time only)
     bool timing_sync_device = false;

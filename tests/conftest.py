@@ -23,7 +23,7 @@ def _built():
 @pytest.fixture(params=["fast", "exact"])
 def arith(request):
     """Runs a parity test under both arithmetic modes of the voxel update (khr_config.exact_arithmetic): `fast` = the
-    product default (decisions exact, values within TOL), `exact` = values bit-identical to the oracle as well."""
+    relaxed option (decisions exact, values within TOL), `exact` = the product default: values bit-identical to the oracle as well."""
     import common
     prev = common.EXACT
     common.EXACT = 1 if request.param == "exact" else 0

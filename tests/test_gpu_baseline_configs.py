@@ -8,7 +8,7 @@ run 320x240 at 10 cm so that the oracle finishes in seconds):
            rate, ~2700 frustum blocks per frame
 
 Each configuration is fused once by the oracle (all host cores) and by the HIP path in both arithmetic modes
-(khr_config.exact_arithmetic = 0 product default / 1 bit-exact values).  Checked: block index sets bit-exact, per-frame
+(khr_config.exact_arithmetic = 1 product default: bit-exact values / 0 relaxed values).  Checked: block index sets bit-exact, per-frame
 statistics (visible / new blocks, N_upd, N_band) equal, dynamic images and cluster counts equal, archived block lists equal,
 mesh vertex counts equal and positions within TOL, and on a >= 200-block sample distance / weight within TOL (bit-exact
 in exact mode), labels / last_observed exact, flags / last_occupied exact (fast mode: borderline count reported, bounded).

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _both_arithmetic_modes(arith):
-    """every test of this module runs with the product's fast arithmetic and with exact_arithmetic = 1 (conftest.arith)"""
+    """every test of this module runs with exact_arithmetic = 1 (product default) and with the relaxed arithmetic (conftest.arith)"""
     yield
 
 

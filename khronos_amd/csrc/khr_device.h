@@ -20,8 +20,11 @@ constexpr uint32_t kInvalidSlot = 0xffffffffu;
 constexpr uint32_t BLK_UPDATED = 1u, BLK_MESH_UPDATED = 2u, BLK_TRACKING_UPDATED = 4u, BLK_HAS_ACTIVE = 8u,
                    BLK_LIVE = 16u,
                    BLK_TRACK_DIRTY = 32u,  // internal: the tracking pass may not skip this block (k_tracking_update)
-                   BLK_ANY_KEEP = 64u;     // internal: some voxel is not to_remove (as of the block's last tracking pass;
+                   BLK_ANY_KEEP = 64u,     // internal: some voxel is not to_remove (as of the block's last tracking pass;
                                            // set at allocation).  resetInactive reads this instead of 4096 voxel flags.
+                   BLK_HAS_NEG = 128u;     // internal: the update kernel has written a negative distance into this block at
+                                           // some point (never cleared while the block lives: a superset of "has one
+                                           // now").  Marching cubes skips blocks that cannot contain a sign change.
 constexpr uint8_t VOX_ACTIVE = 1, VOX_EVER_FREE = 2, VOX_TO_REMOVE = 4, VOX_SEM_VALID = 8;
 // internal (masked out of every download): the voxel was occupied at the last tracking pass, i.e. its
 // last_occupied stamp IS that pass's stamp and the stored value is stale (k_tracking_update)

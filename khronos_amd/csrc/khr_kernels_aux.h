@@ -807,6 +807,7 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
   __shared__ float s_w[T * T * T];
   __shared__ uint32_t s_nslot[8];
   __shared__ const uint32_t* s_nrec[8];  // halo record of a neighbour owned by another rank (or nullptr)
+  __shared__ uint32_t s_may_cross;       // some block of the 2 x 2 x 2 neighbourhood may hold a negative distance
   __shared__ uint32_t s_scan[256];
   __shared__ uint8_t s_ntri[256];
   __shared__ uint16_t s_toff[EMIT ? VPS * VPS * VPS : 2];
@@ -828,6 +829,7 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
       continue;
     }
     const int4 bi = m.blk_index[slot];
+    if (threadIdx.x == 0) s_may_cross = 0u;
     __syncthreads();
     if (threadIdx.x < 8) {
       const int k = threadIdx.x;
@@ -848,8 +850,17 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
       }
       s_nslot[k] = ns;
       s_nrec[k] = rec;
+      // a remote neighbour's record says nothing about signs: assume it may cross
+      if (rec || (ns != kInvalidSlot && (m.blk_flags[ns] & BLK_HAS_NEG))) atomicOr(&s_may_cross, 1u);
     }
     __syncthreads();
+    if (!EMIT && s_may_cross == 0u && (p.dbg & 512) == 0) {
+      // no negative distance anywhere in the cubes' corner lattice => every cube index is 0 => no triangle (most
+      // mesh-updated blocks are free space): nothing to stage
+      if (threadIdx.x == 0) new_count[slot] = 0u;
+      __syncthreads();  // everybody has read s_may_cross before thread 0 clears it for the next block
+      continue;
+    }
     for (int c = threadIdx.x; c < T * T * T; c += 256) {
       int x = c % T, y = (c / T) % T, z = c / (T * T);
       int sel = 0;

@@ -406,6 +406,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
     char* const lobs_b = reinterpret_cast<char*>(a.last_obs + slot * NV);
     uint32_t cnt = 0;       // records in this wave's LDS list
     bool touched = false;   // wave-uniform: some voxel of this item was updated
+    bool wrote_neg = false; // wave-uniform: some updated voxel now holds a negative distance
 #pragma unroll
     for (int k = 0; k < ZR; ++k) {
       bool ok = cur.ok[k];
@@ -504,6 +505,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
       const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(ok), m_band = __builtin_amdgcn_ballot_w64(in_band);
       n_upd += static_cast<uint32_t>(__popcll(m_ok));
       touched = touched || (m_ok != 0ull);
+      wrote_neg = wrote_neg || (__builtin_amdgcn_ballot_w64(ok && d_new < 0.f) != 0ull);
       if (m_band) {
         n_band += static_cast<uint32_t>(__popcll(m_band));
         if (in_band) {
@@ -542,7 +544,8 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
       if (DBG && (dbg & 64)) t_band += __builtin_amdgcn_s_memtime() - tb0;
     }
     if (lane == 0) {
-      if (touched && !(DBG && (dbg & 128))) atomicOr(&a.blk_flags[slot], BLK_UPDATED | BLK_MESH_UPDATED | BLK_TRACKING_UPDATED);
+      if (touched && !(DBG && (dbg & 128)))
+        atomicOr(&a.blk_flags[slot], BLK_UPDATED | BLK_MESH_UPDATED | BLK_TRACKING_UPDATED | (wrote_neg ? BLK_HAS_NEG : 0u));
       a.blk_band[slot * kBandSlots + (cur.sbi & (kBandSlots - 1))] = static_cast<uint16_t>(min(item_band, 65535u));  // next frame's culling pass sorts by it
     }
     if (DBG && (dbg & 64)) {

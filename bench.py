@@ -259,7 +259,7 @@ def main():
     fusion_cxx = None
     dist_host = "none"
     if world > 1:
-        if not emu and backend == "nccl" and args.dist_host == "cxx":
+        if not emu and args.dist_host == "cxx":  # (the token and the agreement below travel over whatever backend torch.distributed uses)
             # the tick's collectives from C++ (RCCL on the context's stream); torch.distributed only carries the 128-byte
             # rendezvous token and the synthetic frames.  Creation is agreed on collectively: if any rank cannot build
             # its communicator, every rank falls back to the torch harness below.

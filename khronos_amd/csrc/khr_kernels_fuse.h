@@ -301,11 +301,16 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
   __syncthreads();
   // next item of this workgroup's share (positions blockIdx.x, blockIdx.x + gridDim.x, ...: every workgroup gets the same
   // mix of the cost classes), handed to whichever of its waves asks first; wave-uniform result
+  // XCD-aware share: workgroup b runs on XCD b % 8 (round-robin dispatch), so its first position is
+  // (b % 8) * (grid / 8) + b / 8: list positions that are neighbours -- the items of one block, blocks that are neighbours
+  // in the visible list -- land on workgroups of the SAME XCD and share its L2 for the image rows and voxel lines they
+  // have in common.  (grid is a multiple of 8.)
+  const uint32_t first = (dbg & 512) ? blockIdx.x : (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   auto pull = [&]() -> uint32_t {
     uint32_t j = 0u;
     if (lane == 0) j = atomicAdd(&s_q, 1u);
     j = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(j)));
-    return blockIdx.x + gridDim.x * j;
+    return first + gridDim.x * j;
   };
   // descriptor of item i in deal order: class 0, 1, 2, 3 (FuseList)
   auto descOf = [&](uint32_t i) -> uint4 {

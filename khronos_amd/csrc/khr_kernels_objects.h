@@ -403,6 +403,21 @@ __global__ __launch_bounds__(256) void k_obj_remap(int32_t* __restrict__ obj, in
   const int32_t t = obj[i];
   if (t) obj[i] = final_id[t - 1];
 }
+// the same with the table in the kernel arguments (a frame has tens of components): no host -> device copy command in the
+// stream (a 1 KB copy costs ~20 us of stream time)
+constexpr int kRemapTab = 256;
+struct RemapTab {
+  int32_t v[kRemapTab];
+};
+__global__ __launch_bounds__(256) void k_obj_remap_tab(int32_t* __restrict__ obj, int n, RemapTab tab) {
+  __shared__ int32_t s_tab[kRemapTab];
+  s_tab[threadIdx.x] = tab.v[threadIdx.x];
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t t = obj[i];
+  if (t) obj[i] = s_tab[t - 1];
+}
 
 // ---- per-cluster voxel sets at the tracker's grid (max_iou_tracker.cpp:478-487) ------------------------------------------------
 __global__ __launch_bounds__(256) void k_cluster_voxels(DevFrame f, const int32_t* __restrict__ id_image, float inv, int3 origin,

@@ -2362,9 +2362,15 @@ static int objectsFinish(khr_ctx* c, int slot) {
     s.sem_clusters.push_back(k);
   }
   // the records are consumed: the pinned block now carries the final ids to the device
-  std::memcpy(c->h_obj_head, fin.data(), sizeof(int32_t) * R);
-  HIP_TRY(hipMemcpyAsync(c->d_obj_final, c->h_obj_head, sizeof(int32_t) * R, hipMemcpyHostToDevice, c->aux_stream));
-  hipLaunchKernelGGL(k_obj_remap, dim3(gridFor(n)), dim3(256), 0, c->aux_stream, s.obj, n, c->d_obj_final);
+  if (R <= static_cast<uint32_t>(kRemapTab)) {  // the usual case: the table rides in the kernel arguments
+    RemapTab tab{};
+    std::memcpy(tab.v, fin.data(), sizeof(int32_t) * R);
+    hipLaunchKernelGGL(k_obj_remap_tab, dim3(gridFor(n)), dim3(256), 0, c->aux_stream, s.obj, n, tab);
+  } else {
+    std::memcpy(c->h_obj_head, fin.data(), sizeof(int32_t) * R);
+    HIP_TRY(hipMemcpyAsync(c->d_obj_final, c->h_obj_head, sizeof(int32_t) * R, hipMemcpyHostToDevice, c->aux_stream));
+    hipLaunchKernelGGL(k_obj_remap, dim3(gridFor(n)), dim3(256), 0, c->aux_stream, s.obj, n, c->d_obj_final);
+  }
   HIP_TRY(hipGetLastError());
   return static_cast<int>(s.sem_clusters.size());
 }

@@ -120,6 +120,8 @@ struct kdist_handle {
   uint64_t* halo_send = nullptr;
   uint64_t* halo_recv = nullptr;
   int64_t* seed_counts = nullptr;             // [n_cameras]
+  int64_t* h_seed_counts = nullptr;           // pinned mirror of the reduced counts
+  hipEvent_t ev_counts = nullptr;             // ... have arrived
   std::vector<uint64_t*> keys;                // per camera: per-pixel voxel keys
   std::vector<int32_t*> dyn_img;              // per camera: painted dynamic image + cluster count in the last element
   uint64_t *req_send = nullptr, *req_recv = nullptr;
@@ -212,6 +214,8 @@ kdist_handle* kdist_create(khr_ctx* ctx, const khr_sensor* sensor, int rank, int
     h->halo_send = h->alloc<uint64_t>(static_cast<size_t>(halo_cap) * kHaloWords);
     h->halo_recv = h->alloc<uint64_t>(W * static_cast<size_t>(halo_cap) * kHaloWords);
     h->seed_counts = h->alloc<int64_t>(static_cast<size_t>(n_cameras));
+    KD_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_seed_counts), sizeof(int64_t) * static_cast<size_t>(n_cameras), hipHostMallocDefault));
+    KD_HIP(hipEventCreateWithFlags(&h->ev_counts, hipEventDisableTiming));
     h->keys.assign(static_cast<size_t>(n_cameras), nullptr);
     h->dyn_img.assign(static_cast<size_t>(n_cameras), nullptr);
     h->req_send = h->alloc<uint64_t>(static_cast<size_t>(mesh_req_cap));
@@ -244,6 +248,8 @@ void kdist_destroy(kdist_handle* h) {
   khr_set_stream(h->ctx, nullptr);  // the context goes back to a stream of its own
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->frame_recv) (void)hipFree(h->frame_recv);
+  if (h->h_seed_counts) (void)hipHostFree(h->h_seed_counts);
+  if (h->ev_counts) (void)hipEventDestroy(h->ev_counts);
   (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -288,20 +294,27 @@ int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, 
     for (int i = 0; i < n; ++i) h->clusters_last_tick[static_cast<size_t>(i)] = 0;
     // (2) ingest + seed test; nothing waits; allocation / culling queued behind it
     KD_KHR(khr_tick_ingest(c, &h->sensor, frames, n, h->motion ? 1 : 0, slots_out, split ? nullptr : host_counts.data(), h->seed_counts));
+    // the count exchange goes out right behind the ingest, BEFORE allocation / culling are queued: the host then learns
+    // which cameras have seeds while the device still works on those, and queues the update launches without a gap
+    const bool early_counts = h->motion && split && h->net();
+    if (early_counts) {
+      KD_NCCL(rccl().AllReduce(h->seed_counts, h->seed_counts, static_cast<size_t>(n), ncclInt64, ncclSum, h->comm, h->stream));
+      KD_HIP(hipMemcpyAsync(h->h_seed_counts, h->seed_counts, sizeof(int64_t) * static_cast<size_t>(n), hipMemcpyDeviceToHost, h->stream));
+      KD_HIP(hipEventRecord(h->ev_counts, h->stream));
+    }
     if (split) KD_KHR(khr_tick_integrate(c, slots_out, n, h->motion ? 1 : 0, -1, 1));
     if (h->motion) {
       // (3) which cameras have seeds on some rank
       std::vector<int64_t> cnt(static_cast<size_t>(n), 0);
-      if (ex && split) {
-        if (h->net()) KD_NCCL(rccl().AllReduce(h->seed_counts, h->seed_counts, static_cast<size_t>(n), ncclInt64, ncclSum, h->comm, h->stream));
-        KD_HIP(hipMemcpyAsync(cnt.data(), h->seed_counts, sizeof(int64_t) * static_cast<size_t>(n), hipMemcpyDeviceToHost, h->stream));
-        KD_HIP(hipStreamSynchronize(h->stream));
+      if (early_counts) {
+        KD_HIP(hipEventSynchronize(h->ev_counts));
+        for (int i = 0; i < n; ++i) cnt[static_cast<size_t>(i)] = h->h_seed_counts[i];
       } else {
-        if (split) KD_KHR(khr_tick_seed_counts(c, host_counts.data(), n));
+        if (split) KD_KHR(khr_tick_seed_counts(c, host_counts.data(), n));  // (pinned ticket of the ingest's publish kernel: no stream wait)
         for (int i = 0; i < n; ++i) cnt[static_cast<size_t>(i)] = host_counts[static_cast<size_t>(i)];
-        if (ex) {
+        if (ex && h->net()) {
           KD_HIP(hipMemcpyAsync(h->seed_counts, cnt.data(), sizeof(int64_t) * static_cast<size_t>(n), hipMemcpyHostToDevice, h->stream));
-          if (h->net()) KD_NCCL(rccl().AllReduce(h->seed_counts, h->seed_counts, static_cast<size_t>(n), ncclInt64, ncclSum, h->comm, h->stream));
+          KD_NCCL(rccl().AllReduce(h->seed_counts, h->seed_counts, static_cast<size_t>(n), ncclInt64, ncclSum, h->comm, h->stream));
           KD_HIP(hipMemcpyAsync(cnt.data(), h->seed_counts, sizeof(int64_t) * static_cast<size_t>(n), hipMemcpyDeviceToHost, h->stream));
           KD_HIP(hipStreamSynchronize(h->stream));
         }

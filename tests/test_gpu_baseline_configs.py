@@ -72,6 +72,10 @@ def _run(width, height, vs, trunc, n_frames, motion, out_every, max_blocks, exac
             if len(om["points"]):
                 assert np.abs(gm["points"] - om["points"]).max() <= TOL
                 assert np.array_equal(gm["labels"], om["labels"])
+                if i + 1 == out_every:  # khr_fetch_mesh on a mesh far larger than its initial staging buffer (the retry path)
+                    fm = ctx.fetch_mesh()
+                    for k in ("points", "colors", "labels", "stamps"):
+                        assert np.array_equal(fm[k], gm[k]), k
             assert np.array_equal(ctx.reset_inactive(), ora.reset_inactive()), i
             ctx.clear_updated()
             ora.clear_updated()

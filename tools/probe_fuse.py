@@ -1,6 +1,7 @@
 """development probe: per-wave timeline of the last k_fuse launch (KHR_FUSE_DBG=64 selects the instrumented instantiation)."""
 import os, sys
 os.environ.setdefault("KHR_FUSE_DBG", "64")
+os.environ.setdefault("KHR_FUSE_EXACT", "0")  # the instrumented instantiation is the relaxed-arithmetic one
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
@@ -49,3 +50,25 @@ late = np.argsort(dur)[-8:]
 for i in late:
     print("longest waves: dur %.1f band %.1f items %d rounds %d recs %d maxitem %.1f" % (dur[i] / F, band[i] / F, items[i], rounds[i], recs[i], imax[i] / F))
 
+
+# ---- per-workgroup view (LDS item queue: WPW waves per workgroup, one workgroup per CU) ----
+WPW = int(os.environ.get("KHR_PROBE_WPW", "12"))
+nwg = len(dur) // WPW
+if nwg * WPW == len(dur):
+    dw = dur.reshape(nwg, WPW) / F
+    iw = items.reshape(nwg, WPW)
+    rw = rounds.reshape(nwg, WPW)
+    wg_max = dw.max(1)
+    wg_mean = dw.mean(1)
+    print("workgroups", nwg, "per-WG max dur pct", np.percentile(wg_max, q), "mean of per-WG mean", wg_mean.mean())
+    print("per-WG (max - min) wave dur pct", np.percentile(dw.max(1) - dw.min(1), q))
+    print("per-WG items pct", np.percentile(iw.sum(1), q), "rounds pct", np.percentile(rw.sum(1), q))
+    xcd = np.arange(nwg) % 8
+    for x in range(8):
+        print("xcd", x, "mean WG max dur %.1f" % wg_max[xcd == x].mean(), "items %.1f rounds %.1f" % (iw[xcd == x].sum(1).mean(), rw[xcd == x].sum(1).mean()))
+    worst = np.argsort(wg_max)[-5:]
+    for w in worst:
+        print("slowest WG %d (xcd %d): max %.1f mean %.1f items %d rounds %d" % (w, w % 8, wg_max[w], wg_mean[w], iw[w].sum(), rw[w].sum()))
+    best = np.argsort(wg_max)[:3]
+    for w in best:
+        print("fastest WG %d (xcd %d): max %.1f mean %.1f items %d rounds %d" % (w, w % 8, wg_max[w], wg_mean[w], iw[w].sum(), rw[w].sum()))

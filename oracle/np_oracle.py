@@ -158,3 +158,54 @@ def forward_instances(label, range_image, vertex_map, max_range=0.0, background_
         pts = np.array([vertex_map[v, u] for (u, v) in px], np.float32)
         res[i] = dict(id=i, pixels=px, num_pixels=len(px), bbox_min=pts.min(0), bbox_max=pts.max(0))
     return res
+
+
+# ---- TrackingIntegrator::updateBlockEverFree (tracking_integrator.cpp:168-222) over a whole map ----
+def _neighbour_offsets(nn):
+    faces = [(-1, 0, 0), (1, 0, 0), (0, -1, 0), (0, 1, 0), (0, 0, -1), (0, 0, 1)]
+    edges = [(dx, dy, dz) for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1) if abs(dx) + abs(dy) + abs(dz) == 2]
+    corners = [(dx, dy, dz) for dx in (-1, 1) for dy in (-1, 1) for dz in (-1, 1)]
+    return {6: faces, 18: faces + edges, 26: faces + edges + corners}[nn]  # the RESULT does not depend on the order
+
+
+def voxel_is_free(cfg, last_occ, last_obs, stamp):
+    """voxelIsFree (:248-252): last_occupied strictly older than temporal_buffer (double seconds) and observed at all."""
+    return ((last_occ.astype(np.float64) / 1e9) < (np.float64(stamp) / 1e9 - np.float64(f32(cfg["temporal_buffer"])))) & (last_obs != 0)
+
+
+def ever_free_pass(cfg, blocks, updated, stamp):
+    """blocks: {(bx, by, bz): dict(last_obs, last_occ, flags)} (flat arrays, x fastest; flags bit1 = ever_free);
+    updated: the block indices the integrator touched in this frame.  Sets the ever_free bit where the voxel is free and all
+    `neighbor_connectivity` neighbours are ever-free or free; a neighbour in a block that does not exist fails the test.
+    (The reference reads neighbours' ever_free while other threads set it; the outcome is the same either way because a
+    voxel that becomes ever-free in this pass is free, ASSUMPTIONS.md B.)"""
+    vps = cfg["voxels_per_side"]
+    offs = _neighbour_offsets(cfg["neighbor_connectivity"])
+    # free-or-ever-free volume of every block BEFORE the pass, as (z, y, x) cubes
+    F, free = {}, {}
+    for b, d in blocks.items():
+        fr = voxel_is_free(cfg, d["last_occ"], d["last_obs"], stamp)
+        free[b] = fr
+        F[b] = (((d["flags"] & 2) > 0) | fr).reshape(vps, vps, vps)
+    for b in updated:
+        d = blocks[b]
+        pad = np.zeros((vps + 2, vps + 2, vps + 2), bool)  # missing block => False
+        for dz in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    nb = (b[0] + dx, b[1] + dy, b[2] + dz)
+                    if nb not in F:
+                        continue
+                    src = F[nb]
+                    zs = slice(0, 1) if dz == 1 else (slice(vps - 1, vps) if dz == -1 else slice(0, vps))
+                    ys = slice(0, 1) if dy == 1 else (slice(vps - 1, vps) if dy == -1 else slice(0, vps))
+                    xs = slice(0, 1) if dx == 1 else (slice(vps - 1, vps) if dx == -1 else slice(0, vps))
+                    zd = slice(vps + 1, vps + 2) if dz == 1 else (slice(0, 1) if dz == -1 else slice(1, vps + 1))
+                    yd = slice(vps + 1, vps + 2) if dy == 1 else (slice(0, 1) if dy == -1 else slice(1, vps + 1))
+                    xd = slice(vps + 1, vps + 2) if dx == 1 else (slice(0, 1) if dx == -1 else slice(1, vps + 1))
+                    pad[zd, yd, xd] = src[zs, ys, xs]
+        ok = np.ones((vps, vps, vps), bool)
+        for (dx, dy, dz) in offs:
+            ok &= pad[1 + dz:1 + dz + vps, 1 + dy:1 + dy + vps, 1 + dx:1 + dx + vps]
+        new = free[b].reshape(vps, vps, vps) & ok
+        d["flags"][new.ravel()] |= 2

@@ -53,3 +53,163 @@ def test_numpy_restatement_matches_oracle(interp):
         # tracking flags agree where the block existed for all 3 frames (always true here: the camera barely moves)
         assert np.array_equal(flags & 5, o["flags"] & 5), b
     assert checked_band > 100
+
+
+@pytest.mark.parametrize("nn", [6, 18, 26])
+def test_numpy_ever_free_stencil_matches_oracle(nn):
+    """Row a7 (updateBlockEverFree) N-version: the whole map in numpy -- per-block integration + tracking duration
+    (np_oracle.integrate_block / tracking_block) and the ever-free stencil over the neighbouring blocks
+    (np_oracle.ever_free_pass) -- against oracle.cpp, frame by frame; flags active / ever_free / to_remove bit for bit."""
+    W, H = 96, 72
+    s = SyntheticStream(W, H, threads=1)
+    sen = po.OrcSensor(W, H, s.fx, s.fy, s.cx, s.cy, 0.1, 5.0)
+    sensor = dict(width=W, height=H, fx=s.fx, fy=s.fy, cx=s.cx, cy=s.cy, min_range=0.1, max_range=5.0)
+    kw = dict(voxel_size=0.2, truncation_distance=0.4, temporal_buffer=0.25, temporal_window=0.55, neighbor_connectivity=nn)
+    cfg = dict(CFG, **kw)
+    ora = po.OracleMap(_cfg(**kw))
+    blocks = {}
+    n_ever = 0
+    for i in range(9):
+        fr = s.render(i)
+        ora.integrate(sen, fr["stamp"], fr["pose"], fr["depth"], None, fr["label"])
+        ora.update_tracking(fr["stamp"])
+        stamp = np.uint64(fr["stamp"])
+        idx = [tuple(int(v) for v in b) for b in ora.block_indices()]  # (allocation is not what this test re-derives)
+        updated = []
+        for b in idx:
+            if b not in blocks:
+                nv = 4096
+                blocks[b] = dict(dist=np.zeros(nv, np.float32), weight=np.zeros(nv, np.float32), lik=np.zeros((20, nv), np.float32),
+                                 valid=np.zeros(nv, bool), lab=np.zeros(nv, np.int64), last_obs=np.zeros(nv, np.uint64),
+                                 last_occ=np.zeros(nv, np.uint64), flags=np.zeros(nv, np.uint8))
+            d = blocks[b]
+            n_upd, _ = npo.integrate_block(cfg, sensor, fr["pose"], fr["depth"], fr["label"], np.array(b), d["dist"], d["weight"],
+                                           d["lik"], d["valid"], d["lab"], d["last_obs"], stamp)
+            if n_upd:
+                updated.append(b)
+        for b in idx:
+            d = blocks[b]
+            npo.tracking_block(cfg, d["dist"], d["last_obs"], d["last_occ"], d["flags"], stamp)
+        npo.ever_free_pass(cfg, {b: blocks[b] for b in idx}, updated, stamp)
+        for b in idx:
+            o = ora.get_block(np.array(b, np.int32))
+            assert np.array_equal(blocks[b]["flags"] & 7, o["flags"] & 7), (i, b)
+            n_ever += int(((o["flags"] & 2) > 0).sum())
+    assert n_ever > 1000, n_ever  # the stencil actually fired
+
+
+def test_marching_cubes_mesh_properties():
+    """Row a14 (MeshIntegrator::generateMesh, voxblox-lineage marching cubes, ASSUMPTIONS.md A.5) checked without a second
+    copy of the 256-case table, from what every correct table must produce:
+      P1 every mesh vertex lies on a lattice edge between two OBSERVED voxel centres of opposite sign (d < 0 vs d >= 0), at
+         the linear zero crossing t = d0 / (d0 - d1) (0.5 when |d0 - d1| < 1e-6);
+      P2 every such edge that belongs to at least one valid cube (8 observed corners, origin voxel in an allocated block)
+         carries a vertex -- a table entry that forgot an edge, or a cube-validity rule that dropped a cube, fails here;
+      P3 the vertex label is the label of one of the edge's two voxels, the nearer one when t is not at the midpoint;
+      P4 vertices come in triangles."""
+    W, H = 96, 72
+    s = SyntheticStream(W, H, threads=1)
+    sen = po.OrcSensor(W, H, s.fx, s.fy, s.cx, s.cy, 0.1, 5.0)
+    vs, vps = 0.1, 16
+    ora = po.OracleMap(_cfg(voxel_size=vs, truncation_distance=0.3))
+    for i in range(4):
+        fr = s.render(i)
+        ora.integrate(sen, fr["stamp"], fr["pose"], fr["depth"], None, fr["label"])
+    ora.generate_mesh(False, False)
+    m = ora.mesh()
+    pts = m["points"].astype(np.float64)
+    assert len(pts) > 3000 and len(pts) % 3 == 0  # P4
+    # global lattice: global voxel index -> (d, w, label)
+    D, Wt, L = {}, {}, {}
+    blocks = [tuple(int(v) for v in b) for b in ora.block_indices()]
+    vox = {}
+    for b in blocks:
+        o = ora.get_block(np.array(b, np.int32), likelihoods=False)
+        vox[b] = (o["distance"].reshape(vps, vps, vps), o["weight"].reshape(vps, vps, vps), o["sem_label"].reshape(vps, vps, vps))  # [z][y][x]
+
+    def at(g):  # g = global voxel index (x, y, z) -> (d, w, label) or None when the block does not exist
+        b = (g[0] // vps, g[1] // vps, g[2] // vps)
+        if b not in vox:
+            return None
+        d, w, l = vox[b]
+        x, y, z = g[0] % vps, g[1] % vps, g[2] % vps
+        return float(d[z, y, x]), float(w[z, y, x]), int(l[z, y, x])
+
+    MINW = 1e-4
+    f32 = np.float32
+    seen_edges = set()
+    checked = 0
+    for p, lab in zip(pts, m["labels"]):
+        g = p / f32(vs) - 0.5
+        r = np.round(g)
+        frac = np.abs(g - r)
+        axis = int(np.argmax(frac))
+        if frac[axis] < 1e-4:   # the crossing sits on a voxel centre: the edge is not identifiable from the position alone
+            continue
+        others = [a for a in range(3) if a != axis]
+        assert all(frac[a] < 1e-3 for a in others), (p, g)  # P1: on a lattice edge
+        v0 = [int(r[0]), int(r[1]), int(r[2])]
+        v0[axis] = int(np.floor(g[axis]))
+        v1 = list(v0)
+        v1[axis] += 1
+        a0, a1 = at(tuple(v0)), at(tuple(v1))
+        assert a0 is not None and a1 is not None, p
+        assert a0[1] >= MINW and a1[1] >= MINW, p  # observed
+        assert (a0[0] < 0.0) != (a1[0] < 0.0), (p, a0, a1)  # opposite sign
+        d0, d1 = f32(a0[0]), f32(a1[0])
+        t = 0.5 if abs(float(d0 - d1)) < 1e-6 else float(d0 / (d0 - d1))
+        assert abs((g[axis] - v0[axis]) - t) < 2e-4, (p, t, g[axis] - v0[axis])  # at the zero crossing
+        if abs(t - 0.5) > 1e-3:
+            assert int(lab) == (a0[2] if t < 0.5 else a1[2]), (p, lab, a0, a1, t)  # P3
+        else:
+            assert int(lab) in (a0[2], a1[2])
+        seen_edges.add((tuple(v0), axis))
+        checked += 1
+    assert checked > 0.9 * len(pts)
+    # P2: every sign-change edge of a valid cube is in the mesh
+    def cube_valid(o):
+        if (o[0] // vps, o[1] // vps, o[2] // vps) not in vox:
+            return False
+        for dz in (0, 1):
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    a = at((o[0] + dx, o[1] + dy, o[2] + dz))
+                    if a is None or not (a[1] >= MINW):
+                        return False
+        return True
+
+    missing = 0
+    n_cross = 0
+    for b in blocks:
+        d, w, _ = vox[b]
+        for axis in range(3):
+            # candidate edges inside the block or towards its +axis neighbour
+            for z in range(vps):
+                for y in range(vps):
+                    for x in range(vps):
+                        if not (w[z, y, x] >= MINW):
+                            continue
+                        g0 = (b[0] * vps + x, b[1] * vps + y, b[2] * vps + z)
+                        g1 = list(g0)
+                        g1[axis] += 1
+                        a1 = at(tuple(g1))
+                        if a1 is None or not (a1[1] >= MINW) or (float(d[z, y, x]) < 0.0) == (a1[0] < 0.0):
+                            continue
+                        o1, o2 = [a for a in range(3) if a != axis]
+                        cubes = []
+                        for s1 in (0, -1):
+                            for s2 in (0, -1):
+                                o = list(g0)
+                                o[o1] += s1
+                                o[o2] += s2
+                                cubes.append(tuple(o))
+                        if not any(cube_valid(o) for o in cubes):
+                            continue
+                        n_cross += 1
+                        d0, d1 = f32(d[z, y, x]), f32(a1[0])
+                        t = 0.5 if abs(float(d0 - d1)) < 1e-6 else float(d0 / (d0 - d1))
+                        if t < 1e-4 or t > 1 - 1e-4:
+                            continue  # (such a vertex was not attributed to an edge above)
+                        if (g0, axis) not in seen_edges:
+                            missing += 1
+    assert n_cross > 1000 and missing == 0, (n_cross, missing)

@@ -1355,7 +1355,10 @@ __global__ __launch_bounds__(256) void k_object_prune(DevMap m, DevParams p, flo
       }
     }
   }
-  if (pruned) atomicAdd(&m.stats[S_PRUNED], static_cast<unsigned long long>(pruned));
+  // one statistics atomic per wave (a hot 64-bit address sustains ~90 atomics / us: per-thread adds were most of this kernel)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) pruned += __shfl_down(pruned, o);
+  if ((threadIdx.x & 63) == 0 && pruned) atomicAdd(&m.stats[S_PRUNED], static_cast<unsigned long long>(pruned));
 }
 
 }  // namespace khr

@@ -3,6 +3,7 @@
 #include "active_window.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <sstream>
 #include <stdexcept>
@@ -533,16 +534,20 @@ ActiveWindow::ActiveWindow(const Config& cfg) : config(cfg), frame_data_buffer_(
   } else {
     tracker_ = std::make_unique<Tracker>();
   }
-  if (config.object_extractor_type == "MeshObjectExtractor")
-    object_extractor_ = std::make_unique<MeshObjectExtractor>(config.object_extractor, d);
+  if (config.object_extractor_type == "MeshObjectExtractor") {
+    const MeshObjectExtractor::Config oec = config.object_extractor;
+    extraction_worker_ = std::make_unique<ObjectWorkerPool>(
+        config.extraction_worker, [oec, d]() -> std::unique_ptr<ObjectExtractor> { return std::make_unique<MeshObjectExtractor>(oec, d); });
+  }
 }
 
 ActiveWindow::~ActiveWindow() {
   hydra::timing::ElapsedTimeRecorder::instance().sync_device = nullptr;
   // buffered frames hold leases on frame slots of the context: they go first (frames a sink copied must not outlive the
   // window either)
+  if (extraction_worker_) extraction_worker_->stop();  // (requests hold copies of the frame buffer: they go with it)
   frame_data_buffer_.clear();
-  object_extractor_.reset();
+  extraction_worker_.reset();
   if (ctx_) khr_destroy(ctx_);
 }
 
@@ -672,7 +677,7 @@ hydra::ActiveWindowOutput::Ptr ActiveWindow::spinOnce(const hydra::InputPacket& 
   return output;
 }
 
-hydra::ActiveWindowOutput::Ptr ActiveWindow::extractOutputData(const FrameData& data, bool /*threaded*/) {
+hydra::ActiveWindowOutput::Ptr ActiveWindow::extractOutputData(const FrameData& data, bool threaded) {
   // active_window.cpp:217-249
   Timer timer("active_window/extract_output", latest_stamp_, config.timing_sync_device);  // :220
   chk(khr_generate_mesh(ctx_, 1, 1), "khr_generate_mesh");
@@ -692,24 +697,26 @@ hydra::ActiveWindowOutput::Ptr ActiveWindow::extractOutputData(const FrameData& 
     output->archived_mesh_indices.resize(static_cast<size_t>(n));
     for (int64_t i = 0; i < n; ++i) output->archived_mesh_indices[i] = {removed[3 * i], removed[3 * i + 1], removed[3 * i + 2]};
   }
-  extractInactiveObjects(*output);
+  // :238-247: inactive tracks go to the worker pool; a blocking call (finishMapping, detach_object_extraction: false) waits
+  // for them; the output carries whatever has finished by now (with detached extraction: objects of earlier outputs too)
+  extractInactiveObjects();
+  if (extraction_worker_) {
+    if (!threaded) extraction_worker_->join();
+    extraction_worker_->fill(output->graph_update);
+  }
   return output;
 }
 
-void ActiveWindow::extractInactiveObjects(hydra::ActiveWindowOutput& output) {
-  // active_window.cpp:251-266: inactive tracks leave the tracker and are handed to the extractor.  The
-  // reference runs extraction on detached worker threads (object_worker_pool.cpp:115-146); here it runs in
-  // line on the device (one mini-map context per object).
+void ActiveWindow::extractInactiveObjects() {
+  // active_window.cpp:251-266: inactive tracks leave the tracker; the track is moved and the frame buffer copied to the
+  // worker (the copy keeps the relevant frames -- and their device frame slots -- alive while the window moves on)
   Tracks& tracks = tracker_->getTracks();
   for (auto it = tracks.begin(); it != tracks.end();) {
     if (it->is_active) {
       ++it;
       continue;
     }
-    if (object_extractor_) {
-      auto obj = object_extractor_->extractObject(*it, frame_data_buffer_);
-      if (obj) output.graph_update.push_back(obj);
-    }
+    if (extraction_worker_) extraction_worker_->submit(latest_stamp_, std::move(*it), frame_data_buffer_);
     it = tracks.erase(it);
   }
 }
@@ -725,12 +732,119 @@ void ActiveWindow::finishMapping() {
 std::vector<std::shared_ptr<KhronosObjectAttributes>> ActiveWindow::extractObjects() {
   std::vector<std::shared_ptr<KhronosObjectAttributes>> result;
   std::lock_guard<std::mutex> lock(mutex_);
-  if (!object_extractor_) return result;
+  if (!extraction_worker_) return result;
   for (const Track& t : tracker_->getTracks()) {  // active_window.cpp:191-201
-    auto obj = object_extractor_->extractObject(t, frame_data_buffer_);
+    auto obj = extraction_worker_->runBlocking(t, frame_data_buffer_);
     if (obj) result.push_back(obj);
   }
   return result;
+}
+
+// ---- ObjectWorkerPool (object_worker_pool.cpp:56-146) ---------------------------------------------------------------
+ObjectWorkerPool::ObjectWorkerPool(const Config& cfg, const ExtractorFactory& make_extractor) : config(cfg) {
+  if (!make_extractor) return;
+  const int n = std::max(1, std::min(kMaxWorkers, cfg.num_workers > 0 ? cfg.num_workers : kMaxWorkers));
+  for (int i = 0; i < n; ++i) extractors_.push_back(make_extractor());
+  for (size_t w = 0; w < extractors_.size(); ++w) workers_.emplace_back([this, w] { workerLoop(w); });
+}
+
+ObjectWorkerPool::~ObjectWorkerPool() { stop(); }
+
+void ObjectWorkerPool::stop() {
+  {
+    std::lock_guard<std::mutex> lock(mutex_);
+    should_shutdown_ = true;
+  }
+  cv_work_.notify_all();
+  for (auto& t : workers_)
+    if (t.joinable()) t.join();
+  workers_.clear();
+  std::lock_guard<std::mutex> lock(mutex_);
+  queue_.clear();  // (frames of unworked requests are released here)
+}
+
+void ObjectWorkerPool::join() {
+  std::unique_lock<std::mutex> lock(mutex_);
+  cv_idle_.wait(lock, [&] { return (queue_.empty() && in_work_ == 0) || should_shutdown_; });
+  if (!error_.empty()) {
+    const std::string e = error_;
+    error_.clear();
+    throw std::runtime_error("object extraction worker: " + e);
+  }
+}
+
+size_t ObjectWorkerPool::numRunning() const {
+  std::lock_guard<std::mutex> lock(mutex_);
+  return queue_.size() + in_work_;
+}
+
+void ObjectWorkerPool::submit(TimeStamp stamp, Track&& track, const FrameDataBuffer& frame_data) {
+  if (extractors_.empty()) return;  // :93-95
+  auto req = std::unique_ptr<Request>(new Request{stamp, std::move(track), frame_data});
+  {
+    std::lock_guard<std::mutex> lock(mutex_);
+    queue_.push_back(std::move(req));
+  }
+  cv_work_.notify_one();
+}
+
+std::shared_ptr<KhronosObjectAttributes> ObjectWorkerPool::runBlocking(const Track& track, const FrameDataBuffer& data) {
+  if (extractors_.empty()) return nullptr;  // :102-104
+  // worker 0's extractor, when that worker is not using it (a device mini-map context serves one extraction at a time)
+  std::lock_guard<std::mutex> lock(blocking_mutex_);
+  return extractors_[0]->extractObject(track, data);
+}
+
+size_t ObjectWorkerPool::fill(std::vector<std::shared_ptr<KhronosObjectAttributes>>& out) {
+  std::lock_guard<std::mutex> lock(mutex_);
+  if (!error_.empty()) {
+    const std::string e = error_;
+    error_.clear();
+    throw std::runtime_error("object extraction worker: " + e);
+  }
+  const size_t n = output_.size();
+  std::move(output_.begin(), output_.end(), std::back_inserter(out));
+  output_.clear();
+  return n;
+}
+
+void ObjectWorkerPool::workerLoop(size_t worker) {
+  while (true) {
+    std::unique_ptr<Request> req;
+    {
+      std::unique_lock<std::mutex> lock(mutex_);
+      cv_work_.wait(lock, [&] { return should_shutdown_ || !queue_.empty(); });
+      if (should_shutdown_) return;
+      req = std::move(queue_.front());
+      queue_.pop_front();
+      ++in_work_;
+    }
+    std::shared_ptr<KhronosObjectAttributes> attrs;
+    std::string err;
+    const auto start = std::chrono::steady_clock::now();
+    try {
+      khr_host_trace("worker_job_begin");
+      if (worker == 0) {
+        std::lock_guard<std::mutex> lock(blocking_mutex_);
+        attrs = extractors_[0]->extractObject(req->track, req->frame_data);
+      } else {
+        attrs = extractors_[worker]->extractObject(req->track, req->frame_data);
+      }
+      khr_host_trace("worker_job_end");
+    } catch (const std::exception& e) {
+      err = e.what();
+    }
+    hydra::timing::ElapsedTimeRecorder::instance().record(
+        "active_window/extract_object", std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count());  // :139
+    req.reset();  // the request's frames (and their device slots) are released before the pool reports idle
+    {
+      std::lock_guard<std::mutex> lock(mutex_);
+      --in_work_;
+      if (attrs) output_.emplace_back(std::move(attrs));
+      if (!err.empty()) error_ = err;
+    }
+    cv_idle_.notify_all();
+  }
 }
 
 }  // namespace khronos

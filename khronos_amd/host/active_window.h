@@ -9,12 +9,14 @@
 // include/khronos_amd.h to the gfx950 kernels, the map lives in HBM.  Hydra types are the stand-ins of
 // hydra_compat.h.  Config errors throw std::invalid_argument (the reference aborts in config::checkValid).
 #pragma once
+#include <condition_variable>
 #include <deque>
 #include <functional>
 #include <memory>
 #include <mutex>
 #include <optional>
 #include <string>
+#include <thread>
 #include <unordered_set>
 #include <vector>
 
@@ -334,6 +336,52 @@ class MeshObjectExtractor : public ObjectExtractor {  // mesh_object_extractor.h
 };
 
 // ---- the module -------------------------------------------------------------------------------------------------
+// khronos::ObjectWorkerPool (object_worker_pool.h / .cpp:56-146): tracks that left the window are submitted together with
+// a copy of the frame buffer (the shared frames stay alive, active_window.cpp:261-263) and extracted on worker threads;
+// finished objects are collected with fill().  The reference starts one detached thread per request, at most
+// `num_workers` at a time, all sharing one extractor; here every worker owns its extractor (= its own device mini-map
+// context and stream), because an extraction re-integrates into that context.
+class ObjectWorkerPool {
+ public:
+  struct Config {
+    int num_workers = 2;      // 0 = as many as the reference would start: capped at kMaxWorkers here
+    int poll_time_us = 1000;  // (the reference polls its queue; this pool blocks on a condition variable)
+    int verbosity = 0;
+  };
+  static constexpr int kMaxWorkers = 4;
+  using ExtractorFactory = std::function<std::unique_ptr<ObjectExtractor>()>;
+
+  ObjectWorkerPool(const Config& config, const ExtractorFactory& make_extractor);
+  ~ObjectWorkerPool();
+  void stop();
+  void join();                 // wait until every submitted request has been worked off
+  size_t numRunning() const;   // requests queued or in work
+  void submit(TimeStamp stamp, Track&& track, const FrameDataBuffer& frame_data);
+  std::shared_ptr<KhronosObjectAttributes> runBlocking(const Track& track, const FrameDataBuffer& data);
+  // moves the finished objects (completion order) to `out`; returns how many
+  size_t fill(std::vector<std::shared_ptr<KhronosObjectAttributes>>& out);
+  bool hasExtractor() const { return !extractors_.empty(); }
+  const Config config;
+
+ private:
+  struct Request {
+    TimeStamp stamp;
+    Track track;
+    FrameDataBuffer frame_data;
+  };
+  void workerLoop(size_t worker);
+  std::vector<std::unique_ptr<ObjectExtractor>> extractors_;  // [0] also serves runBlocking (under blocking_mutex_)
+  std::vector<std::thread> workers_;
+  mutable std::mutex mutex_;
+  std::mutex blocking_mutex_;
+  std::condition_variable cv_work_, cv_idle_;
+  std::deque<std::unique_ptr<Request>> queue_;
+  std::vector<std::shared_ptr<KhronosObjectAttributes>> output_;
+  std::string error_;
+  size_t in_work_ = 0;
+  bool should_shutdown_ = false;
+};
+
 class ActiveWindow {
  public:
   using KhronosSink = std::function<void(const FrameData&, const VolumetricMap&, const Tracks&)>;
@@ -363,7 +411,7 @@ class ActiveWindow {
     MaxIoUTracker::Config tracker;
     std::string object_extractor_type;   // "" = none, "MeshObjectExtractor"
     MeshObjectExtractor::Config object_extractor;
-    struct ExtractionWorker { int num_workers = 2; int poll_time_us = 1000; int verbosity = 0; } extraction_worker;
+    ObjectWorkerPool::Config extraction_worker;
     struct MeshIntegrator { float min_weight = 1e-4f; } mesh_integrator;
     FrameDataBuffer::Config frame_data_buffer;
     // device-side sizing (no reference equivalent)
@@ -406,7 +454,7 @@ class ActiveWindow {
   std::shared_ptr<FrameData> createData(const hydra::InputPacket& input) const;
   void updateMap(const FrameData& data);
   hydra::ActiveWindowOutput::Ptr extractOutputData(const FrameData& data, bool threaded);
-  void extractInactiveObjects(hydra::ActiveWindowOutput& output);
+  void extractInactiveObjects();
 
   khr_ctx* ctx_ = nullptr;
   khr_config device_config_{};
@@ -414,7 +462,7 @@ class ActiveWindow {
   std::unique_ptr<MotionDetector> motion_detector_;
   std::unique_ptr<ObjectDetector> object_detector_;
   std::unique_ptr<Tracker> tracker_;
-  std::unique_ptr<ObjectExtractor> object_extractor_;
+  std::unique_ptr<ObjectWorkerPool> extraction_worker_;  // owns the extractor(s) (active_window.h:189)
   std::mutex mutex_;
   std::vector<KhronosSink> sinks_;
   FrameDataBuffer frame_data_buffer_;

@@ -24,74 +24,17 @@ struct kop_handle {
   VolumetricMap map;
   std::unique_ptr<ObjectDetector> detector;
   std::unique_ptr<Tracker> tracker;
-  std::unique_ptr<ObjectExtractor> extractor;   // in-line extraction + worker 0
-  std::vector<std::unique_ptr<ObjectExtractor>> more_extractors;  // workers 1 .. num_workers - 1 (own device context each)
+  std::unique_ptr<ObjectWorkerPool> pool;  // owns the extractor(s); ObjectWorkerPool role (object_worker_pool.cpp:56-146)
   std::unique_ptr<FrameDataBuffer> buffer;
   std::vector<std::shared_ptr<KhronosObjectAttributes>> last_objects;
   std::shared_ptr<FrameData> pending;  // kop_launch_frame done, kop_finish_frame outstanding
 
-  // detached extraction (ObjectWorkerPool role, object_worker_pool.cpp:56-146): extraction_worker.num_workers threads take
-  // the tracks that left the window together with a snapshot of the frame buffer (shared frames outlive trimming,
-  // active_window.cpp:261-263); each runs its own extractor on its own device context / stream while the window keeps
-  // processing frames.  Finished objects are handed out in completion order, like getFinishedExtractions.
-  struct Job {
-    Track track;
-    std::shared_ptr<const FrameDataBuffer> frames;
-  };
-  std::vector<std::thread> workers;
-  std::mutex mu;
-  std::condition_variable cv, cv_idle;
-  std::deque<Job> jobs;
-  bool stop = false;
-  int busy = 0;
-  std::vector<std::shared_ptr<KhronosObjectAttributes>> finished;  // not yet handed out
-  uint64_t finished_vertices = 0;
-  std::string worker_error;
-
   ~kop_handle() {
-    {
-      std::lock_guard<std::mutex> lock(mu);
-      stop = true;
-    }
-    cv.notify_all();
-    for (auto& w : workers)
-      if (w.joinable()) w.join();
+    if (pool) pool->stop();
     // frames hold leases on slots of `ctx`, which the caller destroys after this handle
     pending.reset();
-    jobs.clear();
     buffer.reset();
-  }
-  void workerLoop(ObjectExtractor* my_extractor) {
-    while (true) {
-      Job job;
-      {
-        std::unique_lock<std::mutex> lock(mu);
-        cv.wait(lock, [&] { return stop || !jobs.empty(); });
-        if (jobs.empty()) return;  // stop requested and nothing left
-        job = std::move(jobs.front());
-        jobs.pop_front();
-        ++busy;
-      }
-      std::shared_ptr<KhronosObjectAttributes> obj;
-      std::string err;
-      try {
-        khr_host_trace("worker_job_begin");
-        obj = my_extractor->extractObject(job.track, *job.frames);
-        khr_host_trace("worker_job_end");
-      } catch (const std::exception& e) {
-        err = e.what();
-      }
-      {
-        std::lock_guard<std::mutex> lock(mu);
-        if (obj) {
-          finished_vertices += obj->mesh.numVertices();
-          finished.push_back(obj);
-        }
-        if (!err.empty()) worker_error = err;
-        --busy;
-      }
-      cv_idle.notify_all();
-    }
+    pool.reset();
   }
 };
 
@@ -134,10 +77,11 @@ kop_handle* kop_create(khr_ctx* ctx, const char* yaml_text, char* err, int err_l
     if (c.object_extractor_type == "MeshObjectExtractor") {
       khr_config dc{};
       if (khr_get_config(ctx, &dc) < 0) throw std::runtime_error(khr_last_error());
-      h->extractor = std::make_unique<MeshObjectExtractor>(c.object_extractor, dc);
-      if (c.detach_object_extraction)
-        for (int w = 1; w < std::max(1, c.extraction_worker.num_workers); ++w)
-          h->more_extractors.push_back(std::make_unique<MeshObjectExtractor>(c.object_extractor, dc));
+      const MeshObjectExtractor::Config oec = c.object_extractor;
+      ObjectWorkerPool::Config pc = c.extraction_worker;
+      if (!c.detach_object_extraction) pc.num_workers = 1;  // blocking extraction needs one extractor
+      h->pool = std::make_unique<ObjectWorkerPool>(
+          pc, [oec, dc]() -> std::unique_ptr<ObjectExtractor> { return std::make_unique<MeshObjectExtractor>(oec, dc); });
     }
     h->buffer = std::make_unique<FrameDataBuffer>(c.frame_data_buffer);
     return h.release();
@@ -228,44 +172,21 @@ int kop_extract_inactive(kop_handle* h, int* n_removed, uint64_t* n_vertices, ch
   try {
     h->last_objects.clear();
     Tracks& tracks = h->tracker->getTracks();
-    const bool detach = h->config.detach_object_extraction && h->extractor;
-    std::shared_ptr<const FrameDataBuffer> snapshot;
+    const TimeStamp stamp = h->buffer->empty() ? 0 : h->buffer->getLatestData().input.timestamp_ns;
     for (auto it = tracks.begin(); it != tracks.end();) {
       if (it->is_active) {
         ++it;
         continue;
       }
-      if (detach) {
-        if (!snapshot) snapshot = std::make_shared<const FrameDataBuffer>(*h->buffer);
-        {
-          std::lock_guard<std::mutex> lock(h->mu);
-          h->jobs.push_back({std::move(*it), snapshot});
-        }
-        h->cv.notify_one();
-      } else if (h->extractor) {
-        auto obj = h->extractor->extractObject(*it, *h->buffer);
-        if (obj) {
-          if (n_vertices) *n_vertices += obj->mesh.numVertices();
-          h->last_objects.push_back(obj);
-        }
-      }
+      if (h->pool) h->pool->submit(stamp, std::move(*it), *h->buffer);  // (the copy of the buffer keeps the frames alive)
       if (n_removed) ++*n_removed;
       it = tracks.erase(it);
     }
-    if (detach) {
-      if (h->workers.empty()) {
-        h->workers.emplace_back([h] { h->workerLoop(h->extractor.get()); });
-        for (auto& e : h->more_extractors) {
-          ObjectExtractor* ep = e.get();
-          h->workers.emplace_back([h, ep] { h->workerLoop(ep); });
-        }
-      }
-      std::lock_guard<std::mutex> lock(h->mu);
-      if (!h->worker_error.empty()) throw std::runtime_error("object extraction worker: " + h->worker_error);
-      h->last_objects.swap(h->finished);
-      h->finished.clear();
-      if (n_vertices) *n_vertices = h->finished_vertices;
-      h->finished_vertices = 0;
+    if (h->pool) {
+      if (!h->config.detach_object_extraction) h->pool->join();
+      h->pool->fill(h->last_objects);
+      if (n_vertices)
+        for (const auto& o : h->last_objects) *n_vertices += o->mesh.numVertices();
     }
     return static_cast<int>(h->last_objects.size());
   } catch (const std::exception& e) {
@@ -277,13 +198,17 @@ int kop_extract_inactive(kop_handle* h, int* n_removed, uint64_t* n_vertices, ch
 // wait for the detached extractions (ObjectWorkerPool::join role); returns the number of finished objects not handed out yet
 int kop_join(kop_handle* h, char* err, int err_len) {
   if (!h) return KHR_EINVAL;
-  std::unique_lock<std::mutex> lock(h->mu);
-  h->cv_idle.wait(lock, [&] { return h->jobs.empty() && h->busy == 0; });
-  if (!h->worker_error.empty()) {
-    setErr(err, err_len, "object extraction worker: " + h->worker_error);
+  if (!h->pool) return 0;
+  try {
+    h->pool->join();
+    std::vector<std::shared_ptr<KhronosObjectAttributes>> done;
+    h->pool->fill(done);
+    std::move(done.begin(), done.end(), std::back_inserter(h->last_objects));
+    return static_cast<int>(done.size());
+  } catch (const std::exception& e) {
+    setErr(err, err_len, e.what());
     return KHR_EDEVICE;
   }
-  return static_cast<int>(h->finished.size());
 }
 
 int kop_num_tracks(kop_handle* h) { return h ? static_cast<int>(h->tracker->getTracks().size()) : KHR_EINVAL; }

@@ -229,8 +229,10 @@ def test_active_window_with_detector_and_tracker_plugins(tmp_path):
     assert len(want) >= 3 and removed_total >= 1
     for t, r in zip(res["track_list"], trk.tracks):
         assert t["conf"] == pytest.approx(float(r.confidence), rel=1e-6)
-    # objects handed out with the outputs never exceed the tracks that left the tracker at that tick
-    assert [o["objects"] <= n for o, n in zip(res["outputs"], per_output_removed)] == [True] * len(per_output_removed)
+    # objects handed out with the outputs never exceed the tracks that have left the tracker by then (extraction is
+    # detached by default, like the reference: an object may arrive with a later output than the one its track left at)
+    got_cum = np.cumsum([o["objects"] for o in res["outputs"]])
+    assert len(got_cum) == len(per_output_removed) and np.all(got_cum <= np.cumsum(per_output_removed))
     # objects extracted from the remaining tracks: static ones carry their track's category and a mesh
     assert len(res["objects"]) >= 1
     cats = {t.category for t in trk.tracks if t.has_semantics}

@@ -2,6 +2,9 @@
 // YAML-subset loader against the reference's mapper config keys, config validation, FrameDataBuffer
 // store / trim known answers (frame_data_buffer.cpp:57-123), object-map sizing (mesh_object_extractor.cpp:201-228).
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -217,6 +220,62 @@ int main(int argc, char** argv) {
     CHECK(header == "name,mean[s],min[s],max[s],std-dev[s],count");
     CHECK(row.rfind("active_window/all,0.5,0.25,0.75,", 0) == 0);
     rec.reset();
+  }
+  // ---- ObjectWorkerPool (object_worker_pool.cpp:56-146) with a device-free extractor ----
+  {
+    struct FakeExtractor : ObjectExtractor {
+      std::atomic<int>* concurrent;
+      std::atomic<int>* peak;
+      explicit FakeExtractor(std::atomic<int>* c, std::atomic<int>* p) : concurrent(c), peak(p) {}
+      std::shared_ptr<KhronosObjectAttributes> extractObject(const Track& track, const FrameDataBuffer&) override {
+        const int now = ++*concurrent;
+        int seen = peak->load();
+        while (now > seen && !peak->compare_exchange_weak(seen, now)) {}
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        --*concurrent;
+        if (track.id % 5 == 4) return nullptr;  // (an extractor may decline a track: confidence gate, empty mesh)
+        auto o = std::make_shared<KhronosObjectAttributes>();
+        o->semantic_label = track.id;
+        return o;
+      }
+    };
+    std::atomic<int> concurrent{0}, peak{0};
+    ObjectWorkerPool::Config pc;
+    pc.num_workers = 3;
+    ObjectWorkerPool pool(pc, [&]() -> std::unique_ptr<ObjectExtractor> { return std::make_unique<FakeExtractor>(&concurrent, &peak); });
+    FrameDataBuffer buffer{FrameDataBuffer::Config{}};
+    for (int i = 0; i < 10; ++i) {
+      Track t;
+      t.id = i;
+      pool.submit(static_cast<TimeStamp>(i), std::move(t), buffer);
+    }
+    Track blocking;
+    blocking.id = 100;
+    const auto direct = pool.runBlocking(blocking, buffer);  // shares extractor 0 with worker 0, serialised
+    CHECK(direct && direct->semantic_label == 100);
+    pool.join();
+    CHECK(pool.numRunning() == 0);
+    std::vector<std::shared_ptr<KhronosObjectAttributes>> out;
+    CHECK(pool.fill(out) == 8);  // ids 4 and 9 were declined
+    std::vector<int> ids;
+    for (const auto& o : out) ids.push_back(o->semantic_label);
+    std::sort(ids.begin(), ids.end());
+    CHECK((ids == std::vector<int>{0, 1, 2, 3, 5, 6, 7, 8}));
+    CHECK(peak.load() >= 2 && peak.load() <= 3);  // several workers at once, never more than num_workers
+    CHECK(pool.fill(out) == 0);
+    // stop with work queued: the pool comes down without running it
+    for (int i = 0; i < 4; ++i) {
+      Track t;
+      t.id = 200 + i;
+      pool.submit(0, std::move(t), buffer);
+    }
+    pool.stop();
+    // no extractor configured: submit / runBlocking are no-ops (:93-95, :102-104)
+    ObjectWorkerPool none(pc, nullptr);
+    Track t2;
+    none.submit(0, std::move(t2), buffer);
+    none.join();
+    CHECK(!none.hasExtractor() && none.runBlocking(blocking, buffer) == nullptr && none.fill(out) == 0);
   }
   std::printf("host selftest ok\n");
   return 0;

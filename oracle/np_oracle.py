@@ -209,3 +209,121 @@ def ever_free_pass(cfg, blocks, updated, stamp):
             ok &= pad[1 + dz:1 + dz + vps, 1 + dy:1 + dy + vps, 1 + dx:1 + dx + vps]
         new = free[b].reshape(vps, vps, vps) & ok
         d["flags"][new.ravel()] |= 2
+
+
+# ---- FreeSpaceMotionDetector (free_space_motion_detector.cpp:73-399), second restatement: plain Python sets / dicts ----
+def motion_point_map(cfg, sensor, T, depth, blocks):
+    """setUpPointMap (:105-203).  blocks: {(bx, by, bz): ever_free bool array [nvox]} of the tracking layer as it is when the
+    detector runs (before the frame is integrated).  Returns (point_map {voxel (x, y, z): [pixel index v * W + u, ...]} in
+    (v, u) order, seeds {voxel}); pixels the reference skips are absent."""
+    vps = cfg["voxels_per_side"]
+    vs = f32(cfg["voxel_size"])
+    bs = vs * f32(vps)
+    bs_inv, vs_inv = f32(1) / bs, f32(1) / vs
+    W, H = sensor["width"], sensor["height"]
+    fx, fy, cx, cy = (f32(sensor[k]) for k in ("fx", "fy", "cx", "cy"))
+    Tm = np.asarray(T, np.float64).reshape(4, 4)
+    Rw, tw = Tm[:3, :3].astype(np.float32), Tm[:3, 3].astype(np.float32)
+    min_z_world = f32(Tm[2, 3] + np.float64(f32(cfg["md_min_z_coordinate"])))  # :80
+    d = np.asarray(depth, np.float32)
+    u, v = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+    valid = (d > 0) & np.isfinite(d)
+    rng = np.where(valid, d, f32(0))  # range_mode 0 (A.2)
+    x = ((u - cx) / fx) * d
+    y = ((v - cy) / fy) * d
+    pw = [((Rw[r, 0] * x + Rw[r, 1] * y) + Rw[r, 2] * d) + tw[r] for r in range(3)]
+    pw = [np.where(valid, c, f32(0)) for c in pw]  # invalid pixels carry the vertex (0, 0, 0) (A.2)
+    keep = (rng > 0) & ~(rng > f32(cfg["md_max_range"])) & ~(pw[2] < min_z_world)  # :169-176
+    bi = [np.floor(c * bs_inv).astype(np.int64) for c in pw]
+    point_map, seeds = {}, set()
+    for vv, uu in zip(*np.nonzero(keep)):
+        b = (int(bi[0][vv, uu]), int(bi[1][vv, uu]), int(bi[2][vv, uu]))
+        ef = blocks.get(b)
+        if ef is None:  # :180 no tracking block
+            continue
+        o = [f32(b[k]) * bs for k in range(3)]
+        vi = [int(np.floor((pw[k][vv, uu] - o[k]) * vs_inv)) for k in range(3)]
+        if min(vi) < 0 or max(vi) >= vps:  # :192-197 (float rounding at a block border): in no voxel
+            continue
+        g = (b[0] * vps + vi[0], b[1] * vps + vi[1], b[2] * vps + vi[2])
+        point_map.setdefault(g, []).append(int(vv) * W + int(uu))
+        if ef[vi[0] + vps * (vi[1] + vps * vi[2])]:
+            seeds.add(g)  # :198-201
+    return point_map, seeds
+
+
+def motion_clusters(cfg, point_map, seeds, W, H):
+    """clusterDynamicVoxels (:205-272) + mergeClusters (:274-355) + applyClusterLevelFilters (:365-379) +
+    writeClustersToData (:381-399).  Returns (number of clusters written, dynamic image)."""
+    offs = _neighbour_offsets(cfg["md_neighbor_connectivity"])
+    closed = set()
+    clusters = []
+    for seed in sorted(seeds):  # C.1: ascending (x, y, z) stands in for the unordered_set order
+        if seed in closed:
+            continue
+        stack, pixels, voxels = [seed], [], set()
+        while stack:
+            g = stack.pop()
+            if g in closed:
+                continue
+            closed.add(g)
+            if g not in point_map:
+                continue
+            pixels += point_map[g]
+            voxels.add(g)
+            for (dx, dy, dz) in offs:
+                ng = (g[0] + dx, g[1] + dy, g[2] + dz)
+                if ng in seeds:
+                    stack.append(ng)
+                elif ng in point_map:  # occupied neighbour: appended once per adjacent seed, no closed-set test (:255-265)
+                    pixels += point_map[ng]
+                    voxels.add(ng)
+                    closed.add(ng)
+        clusters.append([pixels, voxels])
+    n = len(clusters)
+    sep = f32(cfg["md_min_separation_distance"])
+
+    def overlap(a, b):  # checkClusterOverlap: integer norm of the int64 difference, truncated (C.2)
+        for p in clusters[a][1]:
+            for q in clusters[b][1]:
+                n2 = (p[0] - q[0]) ** 2 + (p[1] - q[1]) ** 2 + (p[2] - q[2]) ** 2
+                if f32(int(np.sqrt(np.float64(n2)))) < sep:
+                    return True
+        return False
+
+    ov = [[False] * n for _ in range(n)]
+    for i in range(n):
+        for j in range(i + 1, n):
+            ov[i][j] = ov[j][i] = overlap(i, j)
+    merged, keep = [False] * n, [False] * n
+
+    def connected(ci, out):  # getConnectedClusters: depth-first over the overlap relation, in index order
+        for i in range(n):
+            if not merged[i] and ov[ci][i]:
+                merged[i] = True
+                out.append(i)
+                connected(i, out)
+
+    for cur in range(n):
+        if merged[cur]:
+            continue
+        idx = []
+        connected(cur, idx)
+        for i in idx:
+            if i != cur:
+                clusters[cur][0] += clusters[i][0]
+                clusters[cur][1] |= clusters[i][1]
+        keep[cur] = True
+    dyn = np.zeros(W * H, np.int32)
+    cid, n_out = 1, 0
+    for ci in range(n):
+        if not keep[ci]:
+            continue
+        size = len(clusters[ci][0])
+        if size < cfg["md_min_cluster_size"] or size > cfg["md_max_cluster_size"]:
+            continue
+        dyn[np.array(clusters[ci][0], np.int64)] = cid  # later clusters overwrite earlier ones (:388-389)
+        if cid < 255:
+            cid += 1
+        n_out += 1
+    return n_out, dyn.reshape(H, W)

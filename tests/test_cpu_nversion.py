@@ -213,3 +213,36 @@ def test_marching_cubes_mesh_properties():
                         if (g0, axis) not in seen_edges:
                             missing += 1
     assert n_cross > 1000 and missing == 0, (n_cross, missing)
+
+
+def test_python_motion_detector_matches_oracle():
+    """Rows a9-a11 N-version: the free-space motion detector restated a second time with plain Python sets / dicts
+    (np_oracle.motion_point_map / motion_clusters) from the map state the oracle holds when the detector runs; cluster
+    count and dynamic image equal the oracle's on every frame of a stream with moving objects."""
+    W, H = 160, 120
+    s = SyntheticStream(W, H, threads=1)
+    sen = po.OrcSensor(W, H, s.fx, s.fy, s.cx, s.cy, 0.1, 5.0)
+    sensor = dict(width=W, height=H, fx=s.fx, fy=s.fy, cx=s.cx, cy=s.cy, min_range=0.1, max_range=5.0)
+    kw = dict(temporal_buffer=0.35, temporal_window=0.75, md_min_cluster_size=8, md_max_cluster_size=100000,
+              md_min_separation_distance=2.0, md_max_range=5.0, md_neighbor_connectivity=26)
+    cfg = dict(CFG, md_min_z_coordinate=-10000.0, **kw)
+    ora = po.OracleMap(_cfg(**kw))
+    fired, seed_frames = 0, 0
+    for i in range(16):
+        fr = s.render(i)
+        # the tracking layer as the detector sees it: before this frame is integrated
+        blocks = {}
+        for b in ora.block_indices():
+            o = ora.get_block(b, likelihoods=False)
+            blocks[tuple(int(v) for v in b)] = (o["flags"] & 2) > 0
+        n_o, dyn_o, n_seeds = ora.detect_motion(sen, fr["stamp"], fr["pose"], fr["depth"])
+        pm, seeds = npo.motion_point_map(cfg, sensor, fr["pose"], fr["depth"], blocks)
+        assert len(seeds) == n_seeds, (i, len(seeds), n_seeds)
+        n_p, dyn_p = npo.motion_clusters(cfg, pm, seeds, W, H)
+        assert n_p == n_o, (i, n_p, n_o)
+        assert np.array_equal(dyn_p, dyn_o), i
+        fired += n_o
+        seed_frames += int(n_seeds > 0)
+        ora.integrate(sen, fr["stamp"], fr["pose"], fr["depth"], None, fr["label"], mask=dyn_o)
+        ora.update_tracking(fr["stamp"])
+    assert fired > 0 and seed_frames >= 3, (fired, seed_frames)

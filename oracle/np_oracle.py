@@ -327,3 +327,46 @@ def motion_clusters(cfg, point_map, seeds, W, H):
             cid += 1
         n_out += 1
     return n_out, dyn.reshape(H, W)
+
+
+# ---- frustum allocation of ProjectiveIntegrator::updateMap(allocate_blocks = true) (ASSUMPTIONS.md A.3) ----
+def visible_blocks(cfg, sensor, T):
+    """block indices (n, 3) whose centre passes pointIsInViewFrustum(centre in the sensor frame, 0.8660254 * block_size),
+    vectorised over the (2n + 1)^3 candidate cube around the camera's block; fp32, the operation order of A.3."""
+    vps = cfg["voxels_per_side"]
+    bs = f32(cfg["voxel_size"]) * f32(vps)
+    bs_inv = f32(1) / bs
+    W, H = sensor["width"], sensor["height"]
+    fx, fy, cx, cy = (f32(sensor[k]) for k in ("fx", "fy", "cx", "cy"))
+    max_range = f32(sensor["max_range"])
+    R, t = make_pose(T)
+    Tm = np.asarray(T, np.float64).reshape(4, 4)
+    tw = Tm[:3, 3].astype(np.float32)
+    n = int(np.ceil(max_range * bs_inv)) + 1
+    bc = np.floor(tw * bs_inv).astype(np.int64)
+    xl, xr = (f32(0) - cx) / fx, (f32(W) - cx) / fx
+    yt, yb = (f32(0) - cy) / fy, (f32(H) - cy) / fy
+    tl, tr, bl, br = (np.array(v, np.float32) for v in ((xl, yt, 1), (xr, yt, 1), (xl, yb, 1), (xr, yb, 1)))
+
+    def crossn(a, b):
+        x = a[1] * b[2] - a[2] * b[1]
+        y = a[2] * b[0] - a[0] * b[2]
+        z = a[0] * b[1] - a[1] * b[0]
+        nn = np.sqrt((x * x + y * y) + z * z, dtype=np.float32)
+        return np.array([x / nn, y / nn, z / nn], np.float32)
+
+    normals = [crossn(bl, tl), crossn(tr, br), crossn(tl, tr), crossn(br, bl)]  # left, right, top, bottom (inward)
+    infl = f32(0.8660254) * bs
+    d = np.arange(-n, n + 1, dtype=np.int64)
+    dz, dy, dx = np.meshgrid(d, d, d, indexing="ij")
+    b = np.stack([bc[0] + dx.ravel(), bc[1] + dy.ravel(), bc[2] + dz.ravel()], axis=1)
+    c = (b.astype(np.float32) + f32(0.5)) * bs
+    pc = [((R[r, 0] * c[:, 0] + R[r, 1] * c[:, 1]) + R[r, 2] * c[:, 2]) + t[r] for r in range(3)]
+    ok = ~(pc[2] < -infl)
+    n2 = (pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2]
+    lim = max_range + infl
+    ok &= ~(n2 > lim * lim)
+    for nrm in normals:
+        dd = (pc[0] * nrm[0] + pc[1] * nrm[1]) + pc[2] * nrm[2]
+        ok &= ~(dd < -infl)
+    return b[ok]

@@ -246,3 +246,24 @@ def test_python_motion_detector_matches_oracle():
         ora.integrate(sen, fr["stamp"], fr["pose"], fr["depth"], None, fr["label"], mask=dyn_o)
         ora.update_tracking(fr["stamp"])
     assert fired > 0 and seed_frames >= 3, (fired, seed_frames)
+
+
+def test_numpy_frustum_allocation_matches_oracle():
+    """ASSUMPTIONS.md A.3 allocation (findBlocksInViewFrustum role): the blocks a frame allocates, vectorised in numpy
+    (np_oracle.visible_blocks), against the oracle's loop -- exact index sets along a moving trajectory, two voxel sizes."""
+    W, H = 160, 120
+    s = SyntheticStream(W, H, threads=1)
+    sen = po.OrcSensor(W, H, s.fx, s.fy, s.cx, s.cy, 0.1, 5.0)
+    sensor = dict(width=W, height=H, fx=s.fx, fy=s.fy, cx=s.cx, cy=s.cy, min_range=0.1, max_range=5.0)
+    for vs in (0.1, 0.04):
+        cfg = dict(CFG, voxel_size=vs, truncation_distance=3 * vs)
+        seen = set()
+        ora = po.OracleMap(_cfg(voxel_size=vs, truncation_distance=3 * vs, with_semantics=0, with_tracking=0))
+        for i in (0, 7, 23, 41):
+            fr = s.render(i)
+            so = ora.integrate(sen, fr["stamp"], fr["pose"], fr["depth"], None, None)
+            vis = {tuple(int(v) for v in b) for b in npo.visible_blocks(cfg, sensor, fr["pose"])}
+            assert len(vis) == so["n_visible_blocks"], (vs, i, len(vis), so["n_visible_blocks"])
+            seen |= vis
+            assert seen == {tuple(int(v) for v in b) for b in ora.block_indices()}, (vs, i)
+        assert len(seen) > (100 if vs > 0.05 else 1000)

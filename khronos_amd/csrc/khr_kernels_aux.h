@@ -910,18 +910,27 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
       cnt[j] = 3u * s_ntri[index];
       tsum += cnt[j];
     }
-    // block exclusive scan of tsum
-    s_scan[threadIdx.x] = tsum;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-      uint32_t v = 0;
-      if (threadIdx.x >= static_cast<uint32_t>(off)) v = s_scan[threadIdx.x - off];
-      __syncthreads();
-      s_scan[threadIdx.x] += v;
-      __syncthreads();
+    // block exclusive scan of tsum: inclusive scan inside each wave with shuffles, the four wave totals through LDS (one
+    // barrier instead of the sixteen of a Hillis-Steele scan over 256 threads)
+    uint32_t incl = tsum;
+    {
+      const uint32_t ln = threadIdx.x & 63u;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off);
+        if (ln >= static_cast<uint32_t>(off)) incl += up;
+      }
+      if (ln == 63u) s_scan[threadIdx.x >> 6] = incl;
     }
-    const uint32_t total = s_scan[255];
-    const uint32_t base = s_scan[threadIdx.x] - tsum;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; ++w) {
+      const uint32_t t = s_scan[w];
+      if (w < (threadIdx.x >> 6)) wbase += t;
+      total += t;
+    }
+    const uint32_t base = wbase + incl - tsum;
     if (!EMIT) {
       if (threadIdx.x == 0) new_count[slot] = total;
     } else {

@@ -804,7 +804,8 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
   }
   constexpr int T = VPS + 1;
   __shared__ float s_d[T * T * T];
-  __shared__ float s_w[T * T * T];
+  __shared__ uint8_t s_ok[T * T * T];  // corner observed (weight >= mesh_min_weight): a byte instead of the weight keeps the
+                                       // workgroup's LDS at 25 / 42 KB (count / emit), i.e. 6 / 3 resident workgroups per CU
   __shared__ uint32_t s_nslot[8];
   __shared__ const uint32_t* s_nrec[8];  // halo record of a neighbour owned by another rank (or nullptr)
   __shared__ uint32_t s_may_cross;       // some block of the 2 x 2 x 2 neighbourhood may hold a negative distance
@@ -879,7 +880,7 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
         w = MH::weight(s_nrec[sel], pl, pi);
       }
       s_d[c] = d;
-      s_w[c] = w;
+      s_ok[c] = (w >= p.mesh_min_weight) ? 1 : 0;
     }
     __syncthreads();
     const float ox = static_cast<float>(bi.x) * p.bs, oy = static_cast<float>(bi.y) * p.bs,
@@ -902,7 +903,7 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
         const int cy = iy + ((k == 2 || k == 3 || k == 6 || k == 7) ? 1 : 0);
         const int cz = iz + (k >= 4 ? 1 : 0);
         const int c = cx + T * (cy + T * cz);
-        ok = ok && (s_w[c] >= p.mesh_min_weight);
+        ok = ok && (s_ok[c] != 0);
         if (s_d[c] < 0.f) index |= (1 << k);
       }
       if (!ok) index = 0;

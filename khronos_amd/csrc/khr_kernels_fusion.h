@@ -550,12 +550,13 @@ __global__ __launch_bounds__(256) void k_tracking_select(DevMap m, uint64_t lim_
                                                         uint32_t* __restrict__ cnt_next) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s == 0) { cnt_next[0] = 0u; cnt_next[1] = 0u; }
-  bool need = false, touched = false;
+  bool need = false, touched = false, reload = false;
   if (s < m.counters[C_MAX_SLOT]) {
     const uint32_t fl = m.blk_flags[s];
     if (fl & BLK_LIVE) {
       touched = fl & BLK_TRACKING_UPDATED;
       need = force_full || (fl & (BLK_TRACKING_UPDATED | BLK_TRACK_DIRTY));
+      reload = need;  // the distances may have changed since the block's last pass (integrator, new block, forced pass)
       if (!need) {
         const ulonglong2 lim = reinterpret_cast<const ulonglong2*>(m.trk_lim)[s];
         need = !(lim_active <= lim.x && lim_free <= lim.y);  // otherwise nothing in this block can change
@@ -564,7 +565,8 @@ __global__ __launch_bounds__(256) void k_tracking_select(DevMap m, uint64_t lim_
   }
   const uint32_t ip = waveAggInc(&cnt[0], need);
   if (need) {
-    proc[ip] = s;
+    // bit 31: the pass has to look at the distances; without it a voxel is occupied iff it was at its last pass (VOX_OCC)
+    proc[ip] = s | (reload ? 0x80000000u : 0u);
     // k_tracking_update works on a block in several independent pieces: they meet in these words with atomicMin / atomicOr
     reinterpret_cast<ulonglong2*>(m.trk_lim)[s] = make_ulonglong2(~0ull, ~0ull);
     m.blk_flags[s] = m.blk_flags[s] & ~(BLK_TRACKING_UPDATED | BLK_HAS_ACTIVE | BLK_TRACK_DIRTY | BLK_ANY_KEEP);
@@ -587,7 +589,11 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
   __shared__ uint32_t s_bits;  // 1 = some voxel active, 2 = some voxel not to_remove
   const uint32_t n = *n_proc * CH;
   for (uint32_t wi = blockIdx.x; wi < n; wi += gridDim.x) {
-    const uint32_t s = proc[wi / CH];
+    const uint32_t pe = proc[wi / CH];
+    const uint32_t s = pe & 0x7fffffffu;
+    // a block the integrator has not touched since its last pass has the distances of that pass: occupied == VOX_OCC,
+    // and its 16 KB of distances stay where they are (about half the blocks of a pass are there for their timers only)
+    const bool reload = (pe >> 31) != 0u;
     const int g0 = static_cast<int>(wi % CH) * (NV / 4 / CH);  // first group of 4 voxels of this piece
     const size_t slot = s;
     // thread <-> 4 consecutive voxels: 16-byte loads of distance / flags, 2 x 16-byte of the stamps
@@ -612,7 +618,7 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
     for (int q = 0; q < G; ++q) {
       const int gl = threadIdx.x + 256 * q, g = g0 + gl;
       if (gl < GEND) {
-        d_[q] = dist4[g];
+        d_[q] = reload ? dist4[g] : make_float4(0.f, 0.f, 0.f, 0.f);
         oa_[q] = lobs2[2 * g];
         ob_[q] = lobs2[2 * g + 1];
         v4_[q] = vfl4[g];
@@ -631,7 +637,8 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
           const uint8_t v = static_cast<uint8_t>(v4_[q] >> (8 * k));
           // the stored stamp matters only for a voxel that is not occupied, was not occupied at the previous pass
           // and is not ever-free yet (an ever-free voxel's free bit is 1 whatever its stamps say)
-          if (!(dd[k] < p.occ_thr) && !(v & VOX_OCC) && !(v & VOX_EVER_FREE)) need_[q] |= 1u << k;
+          const bool occ_k = reload ? (dd[k] < p.occ_thr) : ((v & VOX_OCC) != 0);
+          if (!occ_k && !(v & VOX_OCC) && !(v & VOX_EVER_FREE)) need_[q] |= 1u << k;
         }
         if (need_[q] & 3u) ca_[q] = reinterpret_cast<const ulonglong2*>(locc)[2 * g];
         if (need_[q] & 12u) cb_[q] = reinterpret_cast<const ulonglong2*>(locc)[2 * g + 1];
@@ -649,7 +656,8 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const uint8_t v = static_cast<uint8_t>(v4 >> (8 * k));
-        const bool occ = dd[k] < p.occ_thr, was_occ = v & VOX_OCC;
+        const bool was_occ = v & VOX_OCC;
+        const bool occ = reload ? (dd[k] < p.occ_thr) : was_occ;
         // last_occupied after this pass (tracking_integrator.cpp:140-143)
         uint64_t oc = stored[k];
         if (occ) {

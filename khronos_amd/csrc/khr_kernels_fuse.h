@@ -110,6 +110,7 @@ struct FuseArgs {
   unsigned long long* dbg_buf;  // DBG & 64: per-wave timeline {start, end, band cycles, items, rounds, records, max item cycles, hw id}
   int dbg;  // ablation switches of the DBG instantiation (env KHR_FUSE_DBG): 1 no band phase, 2 no voxel stores,
             // 4 no distance / weight loads, 8 range gathers from a fixed address, 16 geometry only
+  int band_mode;  // 0 = lane <-> record (fuseBandRecord, default), 1 = record-cooperative (fuseBandCoop; env KHR_FUSE_BAND)
 };
 
 constexpr int kFuseCap = 256;        // in-band records a wave collects before it works them off (one 4-z chunk of a patch)
@@ -234,6 +235,167 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, size_t slot, uint32_t lin_mo
   }
   if (empty) *reinterpret_cast<uint8_t*>(vfl_b + lin) = fl | VOX_SEM_VALID;
   *reinterpret_cast<uint32_t*>(lab_b + lin * 4u) = static_cast<uint32_t>(bestk);
+}
+
+// ---- record-cooperative band phase (round 3) -----------------------------------------------------------------------
+// The same update as fuseBandRecord for a wave's whole record list, with the memory requests laid out for the L1:
+//  * part A, lane <-> record: colour blend (the four image colours arrive as TWO 8-byte pixel-pair gathers like the range
+//    samples), label lookup, voxel flags;
+//  * part B, K / 4 lanes <-> record: a voxel's K likelihoods are one contiguous row (voxel-major layout), so the K / 4
+//    lanes of a record load / store ONE 16-byte vector each and the wave instruction touches 64 / (K / 4) rows in at most
+//    two cache lines per row -- with lane <-> record every one of the K / 4 vector accesses of a record was a separate
+//    wave instruction with 64 lanes in 64 different lines (12 loads + 7 stores of 4 - 16 bytes per record, 19 line
+//    accesses; now ~6).  The arg-max over a row is a segmented wave reduction (first maximum wins, as the scalar loop);
+//    lane 0 of the segment stores the label.
+// All loads of a 64-record chunk (part A's and part B's) are issued before its first store.  Values and decisions are
+// those of fuseBandRecord bit for bit (same additions on the same operands, same tie-breaking).
+typedef uint32_t u2u __attribute__((ext_vector_type(2), aligned(4)));  // two adjacent rgba8 pixels, 4-byte aligned
+constexpr int kCoopPasses = 6;  // part-B passes whose row vectors are in flight together (K = 20: all six)
+__device__ inline bool fuseBandCoopOk(int K, int sem_mode, int do_sem) {
+  return !do_sem || (sem_mode != 1 && (K & 3) == 0 && K >= 4 && K <= 64);
+}
+template <int VPS, int CAP = kFuseCap>
+__device__ __forceinline__ void fuseBandCoop(FuseArgsK ka, size_t slot, const uint32_t* rec, uint32_t cnt, int lane) {
+  constexpr int NV = VPS * VPS * VPS;
+  const FuseArgs __attribute__((address_space(4)))& a = *ka;
+  const int K = a.K;
+  const bool has_color = a.has_color != 0, do_sem = a.do_sem != 0;
+  const uint32_t lpr = do_sem ? static_cast<uint32_t>(K) >> 2 : 1u;  // lanes per record in part B
+  const uint32_t rpp = 64u / lpr;                                     // records per part-B pass
+  const uint32_t npass = (64u + rpp - 1u) / rpp;
+  const uint32_t rl0 = static_cast<uint32_t>(lane) / lpr, j = static_cast<uint32_t>(lane) - rl0 * lpr;
+  char* const color_b = reinterpret_cast<char*>(a.color + slot * NV);
+  char* const vfl_b = reinterpret_cast<char*>(a.vflags + slot * NV);
+  char* const lab_b = reinterpret_cast<char*>(a.sem_label + slot * NV);
+  char* const lik_b = reinterpret_cast<char*>(a.lik + slot * NV * static_cast<size_t>(K));
+  const uint32_t row_bytes = static_cast<uint32_t>(K) * 4u;
+  const float add_hit = a.log_match, add_miss = a.log_nomatch;
+  // development ablations (env KHR_FUSE_DBG, any instantiation): 1024 no part-A loads, 2048 no likelihood loads,
+  // 4096 no likelihood stores, 8192 no part-A stores
+  const int bdbg = a.dbg;
+  for (uint32_t base = 0; base < cnt; base += 64u) {
+    const uint32_t n_here = min(64u, cnt - base);  // wave-uniform
+    const bool valid = static_cast<uint32_t>(lane) < n_here;
+    const uint32_t r = base + (valid ? static_cast<uint32_t>(lane) : 0u);
+    // ---- part A loads ----
+    const uint32_t lin_mode = rec[r];
+    const float w = __uint_as_float(rec[CAP + r]), w_new = __uint_as_float(rec[2 * CAP + r]);
+    const float u = __uint_as_float(rec[3 * CAP + r]), v = __uint_as_float(rec[4 * CAP + r]);
+    const uint32_t lin = lin_mode & 0xffffu;
+    int px4[4];
+    float du, dv, w4[4];
+    interpPixels(u, v, a.W, a.H, px4, &du, &dv);
+    const int best = interpWeights(du, dv, (lin_mode & 0x10000u) != 0, w4);
+    const bool last_col = px4[2] == px4[0];
+    u2u ca = {0u, 0u}, cb = {0u, 0u};
+    uint32_t co = 0u;
+    if (has_color && valid && !(bdbg & 1024)) {
+      const char* const rgba_b = reinterpret_cast<const char*>(a.rgba);
+      ca = *reinterpret_cast<const u2u*>(rgba_b + static_cast<uint32_t>(px4[0]) * 4u);  // (u0, v0), (u0 + 1, v0)
+      cb = *reinterpret_cast<const u2u*>(rgba_b + static_cast<uint32_t>(px4[1]) * 4u);  // (u0, v1), (u0 + 1, v1)
+      co = *reinterpret_cast<const uint32_t*>(color_b + lin * 4u);
+    }
+    int label = -1;
+    uint8_t fl = 0;
+    if (do_sem && valid) {
+      label = 1;
+      if (!(bdbg & 1024)) {
+        label = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.label) + static_cast<uint32_t>(px4[best]) * 4u);
+        fl = *reinterpret_cast<const uint8_t*>(vfl_b + lin);
+      }
+    }
+    // ---- part B loads: pass p covers the chunk's records p * rpp .. p * rpp + rpp - 1, lane (rl0, j) the j-th vector ----
+    float4 l4[kCoopPasses];
+    uint32_t lin_p[kCoopPasses];  // voxel of the record this lane serves in pass p (~0: none)
+    if (do_sem) {
+#pragma unroll
+      for (int p = 0; p < kCoopPasses; ++p) {
+        const uint32_t rl = static_cast<uint32_t>(p) * rpp + rl0;
+        const bool on = static_cast<uint32_t>(p) < npass && rl0 < rpp && rl < n_here;
+        lin_p[p] = 0xffffffffu;
+        l4[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (on) {
+          lin_p[p] = rec[base + rl] & 0xffffu;
+          if (!(bdbg & 2048)) l4[p] = *reinterpret_cast<const float4*>(lik_b + (lin_p[p] * row_bytes + j * 16u));
+        }
+      }
+    }
+    // ---- part A: colour ----
+    if (has_color && valid) {
+      const uint32_t c4[4] = {ca.x, cb.x, last_col ? ca.x : ca.y, last_col ? cb.x : cb.y};
+      float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t c = c4[k];
+        acc[0] = acc[0] + w4[k] * static_cast<float>(c & 0xffu);
+        acc[1] = acc[1] + w4[k] * static_cast<float>((c >> 8) & 0xffu);
+        acc[2] = acc[2] + w4[k] * static_cast<float>((c >> 16) & 0xffu);
+      }
+      const float tot = w_new + w;
+      const float ytot = rcpRefined(tot);
+      uint32_t out = 0xff000000u;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float cn = static_cast<float>(toU8(acc[ch]));
+        const float cv = static_cast<float>((co >> (8 * ch)) & 0xffu);
+        out |= static_cast<uint32_t>(toU8(divExact(cv * w_new + cn * w, tot, ytot))) << (8 * ch);
+      }
+      if (!(bdbg & 8192)) *reinterpret_cast<uint32_t*>(color_b + lin * 4u) = out;
+    }
+    if (!do_sem) continue;
+    const bool upd = valid && label >= 0 && label < K;
+    const bool empty = !(fl & VOX_SEM_VALID);
+    if (upd && empty && !(bdbg & 8192)) *reinterpret_cast<uint8_t*>(vfl_b + lin) = fl | VOX_SEM_VALID;
+    const uint32_t packed = (upd ? 0x80000000u : 0u) | (empty ? 0x40000000u : 0u) | (static_cast<uint32_t>(label) & 0xffffu);
+    // ---- part B: likelihood rows ----
+    for (uint32_t p0 = 0; p0 < npass; p0 += kCoopPasses) {
+      if (p0 > 0) {  // K > 40: further rounds (their loads queue behind the stores of the previous round)
+#pragma unroll
+        for (int p = 0; p < kCoopPasses; ++p) {
+          const uint32_t rl = (p0 + static_cast<uint32_t>(p)) * rpp + rl0;
+          const bool on = p0 + static_cast<uint32_t>(p) < npass && rl0 < rpp && rl < n_here;
+          lin_p[p] = 0xffffffffu;
+          if (on) {
+            lin_p[p] = rec[base + rl] & 0xffffu;
+            l4[p] = *reinterpret_cast<const float4*>(lik_b + (lin_p[p] * row_bytes + j * 16u));
+          }
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < kCoopPasses; ++p) {
+        if (p0 + static_cast<uint32_t>(p) >= npass) continue;  // wave-uniform
+        const uint32_t rl = (p0 + static_cast<uint32_t>(p)) * rpp + rl0;
+        const uint32_t pk = static_cast<uint32_t>(__shfl(static_cast<int>(packed), static_cast<int>(rl & 63u)));
+        const bool on = lin_p[p] != 0xffffffffu && (pk & 0x80000000u) != 0u;
+        const int lab = static_cast<int>(pk & 0xffffu);
+        const bool emp = (pk & 0x40000000u) != 0u;
+        float l[4] = {l4[p].x, l4[p].y, l4[p].z, l4[p].w};
+        float bv = 0.f;
+        int bk = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k = 4 * static_cast<int>(j) + q;
+          if (emp) l[q] = 0.f;
+          l[q] += (k == lab) ? add_hit : add_miss;
+          if (q == 0 || l[q] > bv) {
+            bv = l[q];
+            bk = k;
+          }
+        }
+        if (on && !(bdbg & 4096)) *reinterpret_cast<float4*>(lik_b + (lin_p[p] * row_bytes + j * 16u)) = make_float4(l[0], l[1], l[2], l[3]);
+        // segmented arg-max over the record's lpr lanes: lane (rl0, j) ends up with the first maximum of j .. lpr - 1
+        for (uint32_t off = 1; off < lpr; off <<= 1) {
+          const float ov = __shfl_down(bv, off);
+          const int ok = __shfl_down(bk, off);
+          if (j + off < lpr && ov > bv) {
+            bv = ov;
+            bk = ok;
+          }
+        }
+        if (on && j == 0u && !(bdbg & 8192)) *reinterpret_cast<uint32_t*>(lab_b + lin_p[p] * 4u) = static_cast<uint32_t>(bk);
+      }
+    }
+  }
 }
 
 // DEFCFG = the reference default switches (z-depth range, adaptive interpolation, weight drop-off, no constant
@@ -539,10 +701,14 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
       // phase's arguments from being hoisted out of this block (and their registers out of the voxel loop)
       FuseArgsK ka = (FuseArgsK)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+s"(ka));
-      for (uint32_t r = static_cast<uint32_t>(lane); r < cnt; r += 64u) {
-        const uint32_t* const rec = &s_rec[wave][0][r];
-        fuseBandRecord<VPS>(ka, slot, rec[0], __uint_as_float(rec[kFuseCap]), __uint_as_float(rec[2 * kFuseCap]),
-                            __uint_as_float(rec[3 * kFuseCap]), __uint_as_float(rec[4 * kFuseCap]));
+      if (ka->band_mode != 0 && fuseBandCoopOk(ka->K, ka->sem_mode, ka->do_sem)) {
+        fuseBandCoop<VPS>(ka, slot, &s_rec[wave][0][0], cnt, lane);
+      } else {
+        for (uint32_t r = static_cast<uint32_t>(lane); r < cnt; r += 64u) {
+          const uint32_t* const rec = &s_rec[wave][0][r];
+          fuseBandRecord<VPS>(ka, slot, rec[0], __uint_as_float(rec[kFuseCap]), __uint_as_float(rec[2 * kFuseCap]),
+                              __uint_as_float(rec[3 * kFuseCap]), __uint_as_float(rec[4 * kFuseCap]));
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -574,6 +740,278 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
     o[7] = 0;
   }
   // statistics: one read-modify-write per workgroup on its own slot (folded by beginIntegrate / khr_get_stats)
+  if (lane == 0) {
+    s_stat[wave][0] = n_upd;
+    s_stat[wave][1] = n_band;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t su = 0u, sb = 0u;
+#pragma unroll
+    for (int w = 0; w < WPW; ++w) {
+      su += s_stat[w][0];
+      sb += s_stat[w][1];
+    }
+    if (su | sb) {
+      a.wg_stats[2 * blockIdx.x] += su;
+      a.wg_stats[2 * blockIdx.x + 1] += sb;
+    }
+  }
+}
+
+// ====================================================================================================================
+// k_fuse2 (round 3): the same update as k_fuse, shaped for thread-level parallelism instead of a per-wave software
+// pipeline.  What the round-2 kernel's ISA and in-kernel timeline showed: with in-order vmcnt a wave
+// that overlaps item n + 1's loads with item n's stores still drains its stores once per item (descriptor wait at the
+// loop top, register copies of the prefetched item at the bottom), the band phase is two more exposed round trips, and
+// 168 VGPRs cap the CU at 12 waves -- each wave spends ~60 % of its life parked on s_waitcnt and the SIMDs sit idle.
+// Here a wave holds ONE item (no prefetch set), the descriptor arrives through the scalar cache (lgkmcnt: not ordered
+// behind the wave's vector stores), the band phase is the record-cooperative form, and the register budget is set by
+// MINW (waves per SIMD the kernel is compiled for) so that 20 - 32 waves per CU are resident: the waits are covered by
+// other waves, not by the wave's own schedule.
+// ====================================================================================================================
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+typedef const u4v __attribute__((address_space(4))) * DescK;
+template <int VPS, int ZSPLIT, bool DEFCFG, bool EXACT, int WPW, int MINW>
+__global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList list) {
+  constexpr int NV = VPS * VPS * VPS;
+  constexpr int SL = VPS * VPS;
+  constexpr int PATCHES = SL / 64;
+  constexpr int ZR = VPS / ZSPLIT;
+  constexpr int CAP = 64 * ZR;  // records of one item
+  static_assert(SL % 64 == 0 && VPS % ZSPLIT == 0 && (ZR == 2 || ZR == 4), "bad block shape");
+  __shared__ uint32_t s_rec[WPW][5][CAP];
+  __shared__ uint32_t s_stat[WPW][2];
+  __shared__ uint32_t s_q;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int lane = static_cast<int>(threadIdx.x & 63);
+  const int range_mode = DEFCFG ? 0 : a.range_mode;
+  const int interp = DEFCFG ? 2 : a.interp;
+  const bool use_dropoff = DEFCFG ? true : (a.use_dropoff != 0);
+  const bool const_weight = DEFCFG ? false : (a.const_weight != 0);
+  const float Wm1 = static_cast<float>(a.W - 1), Hm1 = static_cast<float>(a.H - 1);
+  const float fxfy = a.fx * a.fy;
+  const float den = a.trunc - a.dropoff_eps;
+  const float yden = rcpRefined(den);
+  const char* const range_b = reinterpret_cast<const char*>(a.range);
+  const uint32_t W4 = static_cast<uint32_t>(a.W) * 4u;
+  const uint32_t nc0 = list.counts[0], nc1 = nc0 + list.counts[1], nc2 = nc1 + list.counts[2], n_items = nc2 + list.counts[3];
+  uint32_t n_upd = 0, n_band = 0;
+  if (threadIdx.x == 0) s_q = 0u;
+  __syncthreads();
+  // workgroup b owns the list positions first, first + grid, ... (XCD-aware share as k_fuse); its waves take them from an LDS
+  // counter.  (Tried here and dropped, with numbers in DESIGN.md section 6: queue heads in global memory with work
+  // stealing between workgroups -- 20 k returning global atomics per launch cost 30 us even on 256 different words --
+  // and an oversubscribed, non-persistent grid -- a second round of workgroups costs ~15 us of dispatch.)
+  const uint32_t first = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  auto pull = [&]() -> uint32_t {
+    uint32_t j = 0u;
+    if (lane == 0) j = atomicAdd(&s_q, 1u);
+    j = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(j)));
+    return first + gridDim.x * j;
+  };
+  // descriptor of item i in deal order, through the scalar cache (the list was written by the previous kernel)
+  const DescK la = (DescK)list.a, lb = (DescK)list.b;
+  auto descOf = [&](uint32_t i) -> uint4 {
+    u4v d;
+    if (i < nc0) d = la[i];
+    else if (i < nc1) d = la[list.cap - 1u - (i - nc0)];
+    else if (i < nc2) d = lb[i - nc1];
+    else d = lb[list.cap - 1u - (i - nc2)];
+    return make_uint4(d.x, d.y, d.z, d.w);
+  };
+  uint32_t item = pull();
+  uint4 desc = make_uint4(0u, 0u, 0u, 0u);
+  if (item < n_items) desc = descOf(item);
+  while (item < n_items) {
+    const uint32_t item_next = pull();
+    uint4 d_next = make_uint4(0u, 0u, 0u, 0u);
+    if (item_next < n_items) d_next = descOf(item_next);
+    // ---- phase 1: geometry of the item's ZR voxels per lane; all their loads issued ----
+    const size_t slot = desc.x & 0xffffffu;
+    const int sbi = static_cast<int>(desc.x >> 24);
+    const int bx = static_cast<int>(desc.y), by = static_cast<int>(desc.z), bz = static_cast<int>(desc.w);
+    const int patch = sbi % PATCHES;
+    const int z0 = (sbi / PATCHES) * ZR;
+    const float ox = static_cast<float>(bx) * a.bs, oy = static_cast<float>(by) * a.bs, oz = static_cast<float>(bz) * a.bs;
+    const int lin_xy = patch * 64 + lane;
+    const int ix = lin_xy % VPS, iy = lin_xy / VPS;
+    const float px = ox + (static_cast<float>(ix) + 0.5f) * a.vs;
+    const float py = oy + (static_cast<float>(iy) + 0.5f) * a.vs;
+    float pxy[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pxy[c] = a.R[3 * c] * px + a.R[3 * c + 1] * py;
+    char* const dist_b = reinterpret_cast<char*>(a.dist + slot * NV);
+    char* const wgt_b = reinterpret_cast<char*>(a.weight + slot * NV);
+    char* const lobs_b = reinterpret_cast<char*>(a.last_obs + slot * NV);
+    float uu[ZR], vv[ZR], zz[ZR], yzz[ZR], dd[ZR], ww[ZR];
+    f2u ra[ZR], rb[ZR];
+    bool okk[ZR];
+#pragma unroll
+    for (int k = 0; k < ZR; ++k) {
+      const int iz = z0 + k;
+      const uint32_t lin = static_cast<uint32_t>(lin_xy + iz * SL);
+      const float pz = oz + (static_cast<float>(iz) + 0.5f) * a.vs;
+      float pc[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pc[c] = (pxy[c] + a.R[3 * c + 2] * pz) + a.t[c];
+      bool ok = pc[2] > 0.f;
+      const float voxel_range = range_mode == 0 ? pc[2] : sqrtf((pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2]);
+      ok = ok && !(voxel_range < a.min_range || voxel_range > a.max_range);
+      const float yz = rcpRefined(pc[2]);
+      const float u = divExact(pc[0] * a.fx, pc[2], yz) + a.cx;
+      const float v = divExact(pc[1] * a.fy, pc[2], yz) + a.cy;
+      ok = ok && (fminf(fminf(u, v), fminf(Wm1 - u, Hm1 - v)) >= 0.f);
+      const float uc = ok ? u : 0.f, vc = ok ? v : 0.f;
+      const uint32_t u0 = static_cast<uint32_t>(static_cast<int>(uc)), v0 = static_cast<uint32_t>(static_cast<int>(vc));
+      const uint32_t v1 = min(v0 + 1u, static_cast<uint32_t>(a.H - 1));
+      const uint32_t o0 = v0 * W4 + u0 * 4u, o1 = v1 * W4 + u0 * 4u;
+      ra[k] = *reinterpret_cast<const f2u*>(range_b + o0);
+      rb[k] = *reinterpret_cast<const f2u*>(range_b + o1);
+      dd[k] = 0.f;
+      ww[k] = 0.f;
+      if (ok) {
+        dd[k] = *reinterpret_cast<const float*>(dist_b + lin * 4u);
+        ww[k] = *reinterpret_cast<const float*>(wgt_b + lin * 4u);
+      }
+      uu[k] = uc;
+      vv[k] = vc;
+      zz[k] = voxel_range;
+      yzz[k] = yz;
+      okk[k] = ok;
+    }
+    // ---- phase 2: measurement, decisions, read-modify-write ----
+    uint32_t cnt = 0;
+    bool touched = false, wrote_neg = false;
+#pragma unroll
+    for (int k = 0; k < ZR; ++k) {
+      bool ok = okk[k];
+      if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
+      const int iz = z0 + k;
+      const uint32_t lin = static_cast<uint32_t>(lin_xy + iz * SL);
+      const float uc = uu[k], vc = vv[k], voxel_range = zz[k], yz = yzz[k];
+      float depth = voxel_range;
+      if (range_mode != 0) {
+        const float pz = oz + (static_cast<float>(iz) + 0.5f) * a.vs;
+        depth = (pxy[2] + a.R[8] * pz) + a.t[2];
+      }
+      const uint32_t u0 = static_cast<uint32_t>(static_cast<int>(uc)), v0 = static_cast<uint32_t>(static_cast<int>(vc));
+      const uint32_t v1 = min(v0 + 1u, static_cast<uint32_t>(a.H - 1));
+      const float du = __builtin_amdgcn_fractf(uc), dv = __builtin_amdgcn_fractf(vc);
+      const uint32_t o0 = v0 * W4 + u0 * 4u, o1 = v1 * W4 + u0 * 4u;
+      const float d_old = dd[k], w_old = ww[k];
+      const bool last_col = u0 >= static_cast<uint32_t>(a.W - 1);
+      const float r0 = ra[k].x, r1 = rb[k].x, r2 = last_col ? ra[k].x : ra[k].y, r3 = last_col ? rb[k].x : rb[k].y;
+      bool use_nearest = interp == 0;
+      if (interp == 2) {
+        const float mn = fminf(fminf(r0, r1), fminf(r2, r3));
+        const float mx = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+        use_nearest = use_nearest || (mx - mn > a.adaptive_diff);
+      }
+      const bool hi_u = du >= 0.5f, hi_v = dv >= 0.5f;
+      const float r_near = hi_u ? (hi_v ? r3 : r2) : (hi_v ? r1 : r0);
+      const float omu = 1.f - du, omv = 1.f - dv;
+      const float w0 = omu * omv, w1 = omu * dv, w2 = du * omv, w3 = du * dv;
+      const float r_bil = ((w0 * r0 + w1 * r1) + w2 * r2) + w3 * r3;
+      const float dist_surface = use_nearest ? r_near : r_bil;
+      ok = ok && (dist_surface >= a.min_range) && !(dist_surface > a.max_range);
+      const float sdf = dist_surface - voxel_range;
+      ok = ok && !(sdf < -a.trunc);
+      bool in_band = ok && (fabsf(sdf) < a.trunc);
+      if (__builtin_expect(a.use_mask && __builtin_amdgcn_ballot_w64(in_band) != 0ull, 0)) {
+        int best;
+        if (use_nearest) {
+          best = (hi_u ? 2 : 0) + (hi_v ? 1 : 0);
+        } else {
+          best = 0;
+          float bw = w0;
+          if (w1 > bw) { bw = w1; best = 1; }
+          if (w2 > bw) { bw = w2; best = 2; }
+          if (w3 > bw) { bw = w3; best = 3; }
+        }
+        const uint32_t uo = ((best & 2) && !last_col) ? 4u : 0u;
+        const uint32_t bo = ((best & 1) ? o1 : o0) + uo;
+        if (in_band && *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.dyn) + bo) != 0) {
+          ok = false;
+          in_band = false;
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
+      float w;
+      if (EXACT) {
+        const float qd = divExact(a.vs, depth, yz);
+        w = fxfy * (qd * qd);
+        if (!const_weight) {
+          const float z2 = depth * depth;
+          w = divExact(w, z2, rcpRefined(z2));
+        }
+        if (use_dropoff && sdf < -a.dropoff_eps) w = fmaxf(w * divExact(a.trunc + sdf, den, yden), 0.f);
+      } else {
+        const float qd = a.vs * yz;
+        w = fxfy * (qd * qd);
+        if (!const_weight) w = w * (yz * yz);
+        if (use_dropoff && sdf < -a.dropoff_eps) w = fmaxf(w * ((a.trunc + sdf) * yden), 0.f);
+      }
+      ok = ok && (w > 0.f);
+      in_band = in_band && ok;
+      const float sdf_c = fmaxf(fminf(a.trunc, sdf), -a.trunc);
+      const float tot = w_old + w;
+      float d_new;
+      if (EXACT) {
+        d_new = divExact(d_old * w_old + sdf_c * w, tot, rcpRefined(tot));
+      } else {
+        d_new = __builtin_fmaf(d_old, w_old, sdf_c * w) * __builtin_amdgcn_rcpf(tot);
+      }
+      const float w_new = fminf(tot, a.max_weight);
+      if (ok) {
+        *reinterpret_cast<float*>(dist_b + lin * 4u) = d_new;
+        *reinterpret_cast<float*>(wgt_b + lin * 4u) = w_new;
+        if (a.with_tracking) *reinterpret_cast<uint64_t*>(lobs_b + lin * 8u) = a.stamp;
+      }
+      const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(ok), m_band = __builtin_amdgcn_ballot_w64(in_band);
+      n_upd += static_cast<uint32_t>(__popcll(m_ok));
+      touched = touched || (m_ok != 0ull);
+      wrote_neg = wrote_neg || (__builtin_amdgcn_ballot_w64(ok && d_new < 0.f) != 0ull);
+      if (m_band) {
+        n_band += static_cast<uint32_t>(__popcll(m_band));
+        if (in_band) {
+          const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m_band >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m_band), 0u));
+          uint32_t* const rec = &s_rec[wave][0][pos];
+          rec[0] = lin | (use_nearest ? 0x10000u : 0u);
+          rec[CAP] = __float_as_uint(w);
+          rec[2 * CAP] = __float_as_uint(w_new);
+          rec[3 * CAP] = __float_as_uint(uc);
+          rec[4 * CAP] = __float_as_uint(vc);
+        }
+        cnt += static_cast<uint32_t>(__popcll(m_band));
+      }
+    }
+    // ---- the item's in-band voxels ----
+    if (__builtin_expect(cnt > 0u, 0)) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      FuseArgsK ka = (FuseArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(ka));
+      if (ka->band_mode != 0 && fuseBandCoopOk(ka->K, ka->sem_mode, ka->do_sem)) {
+        fuseBandCoop<VPS, CAP>(ka, slot, &s_rec[wave][0][0], cnt, lane);
+      } else {
+        for (uint32_t r = static_cast<uint32_t>(lane); r < cnt; r += 64u) {
+          const uint32_t* const rec = &s_rec[wave][0][r];
+          fuseBandRecord<VPS>(ka, slot, rec[0], __uint_as_float(rec[CAP]), __uint_as_float(rec[2 * CAP]),
+                              __uint_as_float(rec[3 * CAP]), __uint_as_float(rec[4 * CAP]));
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) {
+      if (touched) atomicOr(&a.blk_flags[slot], BLK_UPDATED | BLK_MESH_UPDATED | BLK_TRACKING_UPDATED | (wrote_neg ? BLK_HAS_NEG : 0u));
+      a.blk_band[slot * kBandSlots + (sbi & (kBandSlots - 1))] = static_cast<uint16_t>(min(cnt, 65535u));
+    }
+    item = item_next;
+    desc = d_next;
+  }
   if (lane == 0) {
     s_stat[wave][0] = n_upd;
     s_stat[wave][1] = n_band;

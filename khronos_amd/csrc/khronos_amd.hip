@@ -477,6 +477,9 @@ int kFuseWpw = 0;       // env KHR_FUSE_WPW: waves per workgroup of the default 
 int kFuseWavesPerCu = 16;  // env KHR_FUSE_WAVES: resident waves per CU the persistent grid is sized for
 constexpr int kFuseWpwDefault = 12;
 int kFuseDbg = 0;       // env KHR_FUSE_DBG: ablation switches (development; selects the DBG instantiation)
+int kFuseVer = 1;       // env KHR_FUSE_V: 1 = k_fuse (per-wave software pipeline), 2 = k_fuse2 (one item per wave, high occupancy)
+int kFuse2Cfg = 0;      // env KHR_FUSE2_CFG: which (waves per workgroup, waves per SIMD) instantiation of k_fuse2
+int kFuseBand = 0;      // env KHR_FUSE_BAND: 0 = lane <-> record (default), 1 = record-cooperative band phase (fuseBandCoop: -41 % L2 write requests, -16 % L1 accesses, same time at 720p / 2 cm, slower on small frames)
 constexpr int kStreamGrid = 4096;
 
 }  // namespace
@@ -734,6 +737,9 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   if (std::getenv("KHR_FUSE_WPW")) kFuseWpw = std::atoi(std::getenv("KHR_FUSE_WPW"));
   if (std::getenv("KHR_FUSE_WAVES")) kFuseWavesPerCu = std::max(4, std::atoi(std::getenv("KHR_FUSE_WAVES")));
   if (std::getenv("KHR_FUSE_DBG")) kFuseDbg = std::atoi(std::getenv("KHR_FUSE_DBG"));
+  if (std::getenv("KHR_FUSE_BAND")) kFuseBand = std::atoi(std::getenv("KHR_FUSE_BAND"));
+  if (std::getenv("KHR_FUSE_V")) kFuseVer = std::atoi(std::getenv("KHR_FUSE_V"));
+  if (std::getenv("KHR_FUSE2_CFG")) kFuse2Cfg = std::atoi(std::getenv("KHR_FUSE2_CFG"));
   if (std::getenv("KHR_NO_EARLY_INGEST")) c->early_ingest = false;
 
   DevMap& m = c->m;
@@ -855,7 +861,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     if (rc != KHR_OK) break;
     A(devAlloc(c, &s.depth, npx, false));
     A(devAlloc(c, &s.range, npx + 4, false));  // + pad: k_fuse gathers pixel pairs (u0, u0 + 1) with one 8-byte load
-    A(devAlloc(c, &s.rgba, npx, false));
+    A(devAlloc(c, &s.rgba, npx + 4, false));   // + pad: the band phase gathers colour pixel pairs like the range samples
     A(devAlloc(c, &s.label, npx, false));
     A(devAlloc(c, &s.dyn, npx));
     A(devAlloc(c, &s.obj, npx));
@@ -1206,8 +1212,40 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
       // non-default switches are test configurations: they always run the bit-exact arithmetic
       a.dbg = kFuseDbg;
       a.dbg_buf = c->d_dbg;
+      a.band_mode = kFuseBand;
       constexpr int WD = kFuseWpwDefault;
-      if (defcfg && !exact && kFuseDbg && V == 16) {
+      if (kFuseVer == 2 && V == 16 && defcfg && exact) {
+        // k_fuse2: (waves per workgroup, waves per SIMD it is compiled for); the grid is what is resident
+        auto go2 = [&](auto kern, int wpw) {
+          static std::map<const void*, int> cache;
+          static std::mutex mu;
+          int grid;
+          {
+            std::lock_guard<std::mutex> lock(mu);
+            auto it = cache.find(reinterpret_cast<const void*>(kern));
+            if (it != cache.end()) {
+              grid = it->second;
+            } else {
+              int per_cu = 0;
+              if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * wpw, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+              hipDeviceProp_t prop;
+              int cus = 256;
+              if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+              grid = std::min(kFuseStatSlots, per_cu * cus) / 8 * 8;
+              if (kFuseGrid > 0) grid = std::max(8, kFuseGrid / 8 * 8);
+              cache[reinterpret_cast<const void*>(kern)] = grid;
+              if (std::getenv("KHR_VERBOSE")) std::fprintf(stderr, "[khr] k_fuse2<%d,%d> %d waves / workgroup, %d workgroups / CU, grid %d\n", V, ZS, wpw, per_cu, grid);
+            }
+          }
+          KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(64 * wpw), a, list);
+        };
+        constexpr int V2 = (V == 16 ? 16 : 16), Z2 = (V == 16 ? ZS : 4);
+        switch (kFuse2Cfg) {
+          case 3: go2(&k_fuse2<V2, Z2, true, true, 10, 5>, 10); break;   // 2 workgroups x 10 waves per CU
+          case 5: go2(&k_fuse2<V2, Z2, true, true, 8, 5>, 8); break;     // 2 x 8
+          default: go2(&k_fuse2<V2, Z2, true, true, 16, 4>, 16); break;  // 1 x 16
+        }
+      } else if (defcfg && !exact && kFuseDbg && V == 16) {
         go(&k_fuse<V, ZS, true, false, WD, (V == 16)>, WD);
       } else if (defcfg && !exact) {
         if (V == 16 && kFuseWpw == 4) go(&k_fuse<V, ZS, true, false, (V == 16 ? 4 : WD)>, V == 16 ? 4 : WD);

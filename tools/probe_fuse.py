@@ -72,3 +72,17 @@ if nwg * WPW == len(dur):
     best = np.argsort(wg_max)[:3]
     for w in best:
         print("fastest WG %d (xcd %d): max %.1f mean %.1f items %d rounds %d" % (w, w % 8, wg_max[w], wg_mean[w], iw[w].sum(), rw[w].sum()))
+
+# ---- round 3: where does the launch time go?  start / end skew and per-XCD end times ----
+print("wave start pct (us after the first wave)", np.percentile(start, q) / F)
+print("wave end   pct", np.percentile(end, q) / F)
+if nwg * WPW == len(dur):
+    sw = (start.reshape(nwg, WPW) / F).min(1)
+    ew = (end.reshape(nwg, WPW) / F).max(1)
+    # (XCDs have different s_memtime bases: compare within an XCD only)
+    for x in range(8):
+        s0 = sw[xcd == x].min()
+        print("xcd %d: WG start spread %.1f us, WG end (rel. to the xcd's first start) pct" % (x, sw[xcd == x].max() - s0),
+              np.round(np.percentile(ew[xcd == x] - s0, q), 1), "records per WG pct", np.percentile(recs.reshape(nwg, WPW).sum(1)[xcd == x], [0, 50, 100]))
+    rsum = recs.reshape(nwg, WPW).sum(1)
+    print("corr(WG max dur, WG records) = %.2f, corr(WG max dur, WG rounds) = %.2f" % (np.corrcoef(wg_max, rsum)[0, 1], np.corrcoef(wg_max, rw.sum(1))[0, 1]))

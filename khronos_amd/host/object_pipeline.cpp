@@ -27,6 +27,8 @@ struct kop_handle {
   std::unique_ptr<ObjectWorkerPool> pool;  // owns the extractor(s); ObjectWorkerPool role (object_worker_pool.cpp:56-146)
   std::unique_ptr<FrameDataBuffer> buffer;
   std::vector<std::shared_ptr<KhronosObjectAttributes>> last_objects;
+  std::vector<std::shared_ptr<KhronosObjectAttributes>> history;  // every object handed out so far (kop_keep_objects)
+  bool keep_history = false;
   std::shared_ptr<FrameData> pending;  // kop_launch_frame done, kop_finish_frame outstanding
 
   ~kop_handle() {
@@ -187,6 +189,7 @@ int kop_extract_inactive(kop_handle* h, int* n_removed, uint64_t* n_vertices, ch
       h->pool->fill(h->last_objects);
       if (n_vertices)
         for (const auto& o : h->last_objects) *n_vertices += o->mesh.numVertices();
+      if (h->keep_history) h->history.insert(h->history.end(), h->last_objects.begin(), h->last_objects.end());
     }
     return static_cast<int>(h->last_objects.size());
   } catch (const std::exception& e) {
@@ -203,12 +206,49 @@ int kop_join(kop_handle* h, char* err, int err_len) {
     h->pool->join();
     std::vector<std::shared_ptr<KhronosObjectAttributes>> done;
     h->pool->fill(done);
+    if (h->keep_history) h->history.insert(h->history.end(), done.begin(), done.end());
+    const int n_done = static_cast<int>(done.size());
     std::move(done.begin(), done.end(), std::back_inserter(h->last_objects));
-    return static_cast<int>(done.size());
+    return n_done;
   } catch (const std::exception& e) {
     setErr(err, err_len, e.what());
     return KHR_EDEVICE;
   }
+}
+
+// The objects handed out so far (what a Khronos sink would have received with the outputs): kept when asked for
+// (parity tests compare every extracted object with the oracle's restatement of the extractor).
+int kop_keep_objects(kop_handle* h, int on) {
+  if (!h) return KHR_EINVAL;
+  h->keep_history = on != 0;
+  if (!on) h->history.clear();
+  return KHR_OK;
+}
+int kop_num_objects(kop_handle* h) { return h ? static_cast<int>(h->history.size()) : KHR_EINVAL; }
+// record of object i: semantic label, vertices, first / last observed stamp, trajectory length, bounding box min / max
+int kop_get_object(kop_handle* h, int i, int64_t* meta /* 5 */, float* bbox /* 6 */) {
+  if (!h || i < 0 || i >= static_cast<int>(h->history.size()) || !meta || !bbox) return KHR_EINVAL;
+  const KhronosObjectAttributes& o = *h->history[i];
+  meta[0] = o.semantic_label;
+  meta[1] = static_cast<int64_t>(o.mesh.numVertices());
+  meta[2] = o.first_observed_ns.empty() ? 0 : static_cast<int64_t>(o.first_observed_ns.front());
+  meta[3] = o.last_observed_ns.empty() ? 0 : static_cast<int64_t>(o.last_observed_ns.front());
+  meta[4] = static_cast<int64_t>(o.trajectory_positions.size());
+  for (int d = 0; d < 3; ++d) {
+    bbox[d] = o.bounding_box.min[d];
+    bbox[3 + d] = o.bounding_box.max[d];
+  }
+  return KHR_OK;
+}
+// mesh of object i (vertices in the bounding-box frame, mesh_object_extractor.cpp:299-302): 3 floats + 1 label per vertex
+int64_t kop_get_object_mesh(kop_handle* h, int i, float* points, uint32_t* labels, int64_t cap) {
+  if (!h || i < 0 || i >= static_cast<int>(h->history.size())) return KHR_EINVAL;
+  const hydra::Mesh& m = h->history[i]->mesh;
+  const int64_t n = static_cast<int64_t>(m.numVertices());
+  if (n > cap) return KHR_EINVAL;
+  if (points && n) std::memcpy(points, m.points.data(), sizeof(float) * 3 * n);
+  if (labels && n) std::memcpy(labels, m.labels.data(), sizeof(uint32_t) * n);
+  return n;
 }
 
 int kop_num_tracks(kop_handle* h) { return h ? static_cast<int>(h->tracker->getTracks().size()) : KHR_EINVAL; }

@@ -33,6 +33,11 @@ def load_host_library():
     lib.kop_num_tracks.argtypes = [vp]
     lib.kop_num_buffered_frames.argtypes = [vp]
     lib.kop_get_tracks.argtypes = [vp, vp, i32]
+    lib.kop_keep_objects.argtypes = [vp, i32]
+    lib.kop_num_objects.argtypes = [vp]
+    lib.kop_get_object.argtypes = [vp, i32, vp, vp]
+    lib.kop_get_object_mesh.argtypes = [vp, i32, vp, vp, C.c_int64]
+    lib.kop_get_object_mesh.restype = C.c_int64
     lib.kdist_unique_id.argtypes = [C.c_char_p]
     lib.kdist_create.argtypes = [vp, C.POINTER(KhrSensor), i32, i32, C.c_char_p, i32, C.c_int64, C.c_int64, C.c_int64, C.c_uint32]
     lib.kdist_create.restype = vp
@@ -127,6 +132,27 @@ class ObjectPipeline:
         if n < 0:
             raise KhronosAmdError("kop_join failed (%d): %s" % (n, self._err.value.decode()))
         return n
+
+    def keep_objects(self, on=True):
+        """keep every object handed out from now on (objects())"""
+        self.lib.kop_keep_objects(self.h, 1 if on else 0)
+
+    def objects(self):
+        """the objects handed out since keep_objects(): label, stamps, bounding box, mesh (bounding-box frame)"""
+        out = []
+        for i in range(self.lib.kop_num_objects(self.h)):
+            meta = np.zeros(5, np.int64)
+            bbox = np.zeros(6, np.float32)
+            if self.lib.kop_get_object(self.h, i, meta.ctypes.data, bbox.ctypes.data) < 0:
+                raise KhronosAmdError("kop_get_object failed")
+            n = int(meta[1])
+            pts = np.zeros((n, 3), np.float32)
+            lab = np.zeros(n, np.uint32)
+            if n and self.lib.kop_get_object_mesh(self.h, i, pts.ctypes.data, lab.ctypes.data, n) != n:
+                raise KhronosAmdError("kop_get_object_mesh failed")
+            out.append(dict(label=int(meta[0]), vertices=n, first_seen=int(meta[2]), last_seen=int(meta[3]), trajectory=int(meta[4]),
+                            bbox_min=bbox[:3].copy(), bbox_max=bbox[3:].copy(), points=pts, labels=lab))
+        return out
 
     def num_tracks(self):
         return self.lib.kop_num_tracks(self.h)

@@ -337,6 +337,8 @@ int khr_object_prune(khr_ctx* ctx, float min_confidence, float min_observations,
 #define KHR_PF_OBJECTS 8u /* ConnectedSemantics on the frame (khr_configure_object_detector first): its kernels are queued
                              right after the ingest and its host part runs once the frame's other kernels are queued;
                              khr_detect_objects / khr_get_semantic_clusters then return the cached result */
+#define KHR_PF_SNAPSHOT 32u /* with KHR_PF_OUTPUT: snapshot of the updated blocks (khr_snapshot_updated, all fields, capacity 8192
+                             * blocks) between meshing and archival; fetch it with khr_take_snapshot */
 #define KHR_PF_INPUT_READY 16u /* on_device frames only: the input buffers are COMPLETE when the call is made (nothing still
                                   queued on the context's stream writes them).  The ingest then runs on the context's second
                                   stream beside the previous frame's tail instead of behind it.  Without the flag the ingest is
@@ -361,6 +363,34 @@ int khr_download_block(khr_ctx* ctx, int32_t bx, int32_t by, int32_t bz, float* 
  * NULL; arrays hold cap_blocks * nvox elements, indices 3 * cap_blocks).  Returns the number of blocks. */
 int64_t khr_download_updated(khr_ctx* ctx, int32_t* indices, float* distance, float* weight, uint8_t* color_rgba,
                              uint64_t* last_observed, uint8_t* voxel_flags, uint32_t* sem_label, int64_t cap_blocks);
+/* replaces: VolumetricMap::cloneUpdated (active_window.cpp:229) with the reference's SNAPSHOT semantics: the voxel arrays
+ * of every block flagged KHR_BLK_UPDATED are copied -- on the device, in stream order, without a host round trip -- into
+ * a snapshot object that keeps its contents however the map changes afterwards (later frames, resetInactive), until it is
+ * released.  The hydra frontend consumes ActiveWindowOutput::map later from a queue; khr_download_updated, which reads the
+ * live map, is only equivalent when called before the next frame.  `fields` = bit mask of KHR_SNAP_*; `cap_blocks` bounds
+ * the snapshot (blocks beyond it are counted and make the download fail with KHR_ENOMEM; 0 = the context's max_blocks).
+ * The arena comes from a per-context pool of released snapshots (hipMalloc only when none fits).
+ * khr_process_frame(KHR_PF_SNAPSHOT | KHR_PF_OUTPUT) takes the snapshot at the reference's place -- after meshing, before
+ * archival and flag clearing -- and khr_take_snapshot hands it out. */
+typedef struct khr_snapshot khr_snapshot;
+#define KHR_SNAP_DISTANCE 1u
+#define KHR_SNAP_WEIGHT 2u
+#define KHR_SNAP_COLOR 4u
+#define KHR_SNAP_LAST_OBSERVED 8u
+#define KHR_SNAP_FLAGS 16u
+#define KHR_SNAP_LABEL 32u
+#define KHR_SNAP_ALL 63u
+int khr_snapshot_updated(khr_ctx* ctx, uint32_t fields, int64_t cap_blocks, khr_snapshot** out);
+/* the snapshot queued by the last khr_process_frame(.. KHR_PF_SNAPSHOT ..); NULL (and KHR_ENOTFOUND) if there is none */
+int khr_take_snapshot(khr_ctx* ctx, khr_snapshot** out);
+/* number of blocks in the snapshot (waits for the device copy to have been queued and counted) */
+int64_t khr_snapshot_num_blocks(khr_snapshot* snap);
+/* copy the snapshot to the host, blocks in sorted index order (any pointer may be NULL; arrays hold cap_blocks * nvox
+ * elements, indices 3 * cap_blocks); fields that were not snapshotted are left untouched.  Returns the block count. */
+int64_t khr_snapshot_download(khr_snapshot* snap, int32_t* indices, float* distance, float* weight, uint8_t* color_rgba,
+                              uint64_t* last_observed, uint8_t* voxel_flags, uint32_t* sem_label, int64_t cap_blocks);
+/* give the snapshot's arena back to its context's pool (the context must still exist) */
+void khr_snapshot_release(khr_snapshot* snap);
 /* mesh produced by the last khr_generate_mesh calls, concatenated over blocks in sorted block order
  * (utils::combineMeshLayer, geometry_utils.cpp:61-86; faces are implicit: vertex 3i,3i+1,3i+2).
  * returns the vertex count, or a negative error if cap is too small. */

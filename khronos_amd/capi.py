@@ -78,6 +78,7 @@ EXPORTS = [
     "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",
     "khr_cluster_voxels", "khr_download_frame_image",
     "khr_rv_create", "khr_rv_destroy", "khr_rv_clear", "khr_rv_add_rays", "khr_rv_num_rays", "khr_rv_num_pairs", "khr_rv_check",
+    "khr_snapshot_updated", "khr_take_snapshot", "khr_snapshot_num_blocks", "khr_snapshot_download", "khr_snapshot_release",
     "khr_rv_check_stamps", "khr_get_config", "khr_cluster_voxels_launch", "khr_cluster_voxels_fetch", "khr_reset_map", "khr_depend_on", "khr_retain_slot", "khr_release_slot",
 ]
 
@@ -168,6 +169,14 @@ def load_library():
     lib.khr_mesh_halo_import.argtypes = [vp, vp, i64, i32]
     lib.khr_download_updated.argtypes = [vp] + [vp] * 7 + [i64]
     lib.khr_download_updated.restype = i64
+    lib.khr_snapshot_updated.argtypes = [vp, C.c_uint32, i64, C.POINTER(vp)]
+    lib.khr_take_snapshot.argtypes = [vp, C.POINTER(vp)]
+    lib.khr_snapshot_num_blocks.argtypes = [vp]
+    lib.khr_snapshot_num_blocks.restype = i64
+    lib.khr_snapshot_download.argtypes = [vp] + [vp] * 7 + [i64]
+    lib.khr_snapshot_download.restype = i64
+    lib.khr_snapshot_release.argtypes = [vp]
+    lib.khr_snapshot_release.restype = None
     lib.khr_mesh_num_vertices.argtypes = [vp]
     lib.khr_mesh_num_vertices.restype = i64
     lib.khr_download_mesh.argtypes = [vp, vp, vp, vp, vp, vp, i64]
@@ -306,6 +315,7 @@ class FusionContext:
         self._chk(self.lib.khr_tick_integrate(self.h, arr, n, 1 if use_mask else 0, int(object_id), int(phases)))
 
     PF_OBJECTS = 8
+    PF_SNAPSHOT = 32     # with PF_OUTPUT: snapshot of the updated blocks between meshing and archival (take_snapshot)
     PF_INPUT_READY = 16  # device inputs are complete at call time: the ingest may run ahead on the second stream
     PF_MOTION, PF_TRACKING, PF_OUTPUT = 1, 2, 4
 
@@ -567,6 +577,18 @@ class FusionContext:
                                                     _ptr(out["sem_label"]), max(n, 1)))
         return {a: b[:k] for a, b in out.items()}
 
+    def snapshot_updated(self, fields=63, cap_blocks=0):
+        """VolumetricMap::cloneUpdated with snapshot semantics: a device-side copy that outlives later map changes."""
+        h = C.c_void_p()
+        self._chk(self.lib.khr_snapshot_updated(self.h, int(fields), int(cap_blocks), C.byref(h)))
+        return Snapshot(self, h)
+
+    def take_snapshot(self):
+        """the snapshot queued by process_frame(.. PF_SNAPSHOT | PF_OUTPUT ..), or None"""
+        h = C.c_void_p()
+        rc = self.lib.khr_take_snapshot(self.h, C.byref(h))
+        return Snapshot(self, h) if rc == 0 and h.value else None
+
     def download_mesh(self):
         n = self._chk(self.lib.khr_mesh_num_vertices(self.h))
         pts = np.empty((max(n, 1), 3), np.float32)
@@ -604,6 +626,33 @@ class FusionContext:
         ms, n = C.c_double(0), C.c_uint64(0)
         self._chk(self.lib.khr_timing_get(self.h, self.TIMERS[name], C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class Snapshot:
+    """khr_snapshot: the updated blocks as they were when the snapshot was taken (ActiveWindowOutput::map role)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    def num_blocks(self):
+        return self.ctx._chk(self.ctx.lib.khr_snapshot_num_blocks(self.h))
+
+    def download(self):
+        n = max(1, self.num_blocks())
+        nv = self.ctx.nvox
+        out = {"indices": np.zeros((n, 3), np.int32), "distance": np.empty((n, nv), np.float32),
+               "weight": np.empty((n, nv), np.float32), "color": np.empty((n, nv, 4), np.uint8),
+               "last_observed": np.zeros((n, nv), np.uint64), "flags": np.empty((n, nv), np.uint8),
+               "sem_label": np.zeros((n, nv), np.uint32)}
+        k = self.ctx._chk(self.ctx.lib.khr_snapshot_download(self.h, _ptr(out["indices"]), _ptr(out["distance"]), _ptr(out["weight"]),
+                                                             _ptr(out["color"]), _ptr(out["last_observed"]), _ptr(out["flags"]),
+                                                             _ptr(out["sem_label"]), n))
+        return {a: b[:k] for a, b in out.items()}
+
+    def release(self):
+        if self.h is not None and self.h.value:
+            self.ctx.lib.khr_snapshot_release(self.h)
+        self.h = None
 
 
 class RayVerificator:

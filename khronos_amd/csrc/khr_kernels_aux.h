@@ -1340,6 +1340,62 @@ __global__ __launch_bounds__(256) void k_pack_blocks(DevMap m, const uint32_t* _
   }
 }
 
+// ---- VolumetricMap::cloneUpdated as a device-side SNAPSHOT (active_window.cpp:229; khr_snapshot_updated) ---------------
+// k_snapshot_select: every live block flagged updated takes the next position of the snapshot (wave-aggregated cursor); its
+// pool slot and block index are recorded.  Blocks beyond the snapshot's capacity are counted, not copied (the download
+// reports the overflow).  k_snapshot_pack: one workgroup per selected block copies the requested voxel arrays into the
+// snapshot's arena (field-major: [field][position][voxel]) and thread 0 of the launch publishes the count to pinned
+// memory -- no host round trip anywhere between the map and the snapshot.
+__global__ __launch_bounds__(256) void k_snapshot_select(DevMap m, uint32_t* __restrict__ count, uint32_t* __restrict__ slots,
+                                                        int4* __restrict__ index, uint32_t cap) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  bool take = false;
+  if (s < m.counters[C_MAX_SLOT]) {
+    const uint32_t fl = m.blk_flags[s];
+    take = (fl & BLK_LIVE) && (fl & BLK_UPDATED);
+  }
+  const uint32_t pos = waveAggInc(count, take);
+  if (take && pos < cap) {
+    slots[pos] = s;
+    index[pos] = m.blk_index[s];
+  }
+}
+template <int VPS>
+__global__ __launch_bounds__(256) void k_snapshot_pack(DevMap m, const uint32_t* __restrict__ count, const uint32_t* __restrict__ slots,
+                                                      uint32_t cap, PackOut o, volatile uint32_t* host_count, uint32_t ticket) {
+  constexpr int NV = VPS * VPS * VPS;
+  const uint32_t total = *count;
+  const uint32_t n = min(total, cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    host_count[0] = total;
+    __threadfence_system();
+    host_count[1] = ticket;
+    __threadfence_system();
+  }
+  for (uint32_t b = blockIdx.x; b < n; b += gridDim.x) {
+    const size_t src = static_cast<size_t>(slots[b]) * NV, dst = static_cast<size_t>(b) * NV;
+    auto copy16 = [&](const void* s, void* d, size_t bytes) {
+      const uint4* s4 = reinterpret_cast<const uint4*>(s);
+      uint4* d4 = reinterpret_cast<uint4*>(d);
+      for (size_t i = threadIdx.x; i < bytes / 16; i += 256) d4[i] = s4[i];
+    };
+    if (o.dist) copy16(m.dist + src, o.dist + dst, NV * 4);
+    if (o.weight) copy16(m.weight + src, o.weight + dst, NV * 4);
+    if (o.color) copy16(m.color + src, o.color + dst, NV * 4);
+    if (o.last_obs) copy16(m.last_obs + src, o.last_obs + dst, NV * 8);
+    if (o.vflags) {  // public flag bits only
+      const uint4* s4 = reinterpret_cast<const uint4*>(m.vflags + src);
+      uint4* d4 = reinterpret_cast<uint4*>(o.vflags + dst);
+      const uint32_t pm = VOX_PUBLIC_MASK * 0x01010101u;
+      for (size_t i = threadIdx.x; i < NV / 16; i += 256) {
+        const uint4 v = s4[i];
+        d4[i] = make_uint4(v.x & pm, v.y & pm, v.z & pm, v.w & pm);
+      }
+    }
+    if (o.sem_label) copy16(m.sem_label + src, o.sem_label + dst, NV * 4);
+  }
+}
+
 // MeshObjectExtractor confidence pruning (mesh_object_extractor.cpp:246-264, computeConfidence :342-356)
 template <int VPS>
 __global__ __launch_bounds__(256) void k_object_prune(DevMap m, DevParams p, float min_conf, float min_obs) {

@@ -21,6 +21,8 @@
 #include <functional>
 #include <map>
 #include <string>
+#include <thread>
+#include <tuple>
 #include <unordered_map>
 #include <vector>
 
@@ -131,6 +133,12 @@ struct khr_ctx {
   uint4* d_work4 = nullptr;       // update list of k_fuse: two descriptor arrays of item_cap entries (FuseList)
   uint4* d_tick_work4 = nullptr;  // tick path: two arrays per camera
   uint32_t item_cap = 0;          // max_blocks x wave items per block
+  // snapshots of the updated blocks (khr_snapshot_updated): arenas of released snapshots are reused
+  struct SnapArena { uint8_t* ptr; size_t bytes; volatile uint32_t* h_count; uint32_t* d_count_host_view; };
+  std::vector<SnapArena> snap_free;
+  std::mutex snap_mu;
+  khr_snapshot* pending_snapshot = nullptr;  // taken inside khr_process_frame(KHR_PF_SNAPSHOT)
+  uint32_t snap_ticket = 0;
   uint32_t wpb = 0;               // wave items per block of this context's k_fuse instantiation
   int fuse_zsplit = 2;            // z ranges per x-y patch of that instantiation
   // remote halo (multi-GPU): records gathered from the other ranks + their index
@@ -905,6 +913,11 @@ void khr_destroy(khr_ctx* c) {
   if (c->d_mh_recs) { hipFree(c->d_mh_recs); hipFree(c->d_mh_keys); hipFree(c->d_mh_vals); }
   if (c->d_pix_scratch) hipFree(c->d_pix_scratch);
   if (c->d_inst) hipFree(c->d_inst);
+  if (c->pending_snapshot) khr_snapshot_release(c->pending_snapshot);
+  for (auto& a : c->snap_free) {
+    hipFree(a.ptr);
+    hipHostFree(const_cast<uint32_t*>(a.h_count));
+  }
   if (c->h_pinned) hipHostFree(c->h_pinned);
   if (c->h_stage) hipHostFree(c->h_stage);
   if (c->h_up) hipHostFree(c->h_up);
@@ -2904,6 +2917,11 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   // (5) output cadence (ActiveWindow::extractOutputData, active_window.cpp:217-249 + :169-171)
   if (flags & KHR_PF_OUTPUT) {
     if ((rc = khr_generate_mesh(c, 1, 1))) return rc;
+    if (flags & KHR_PF_SNAPSHOT) {  // cloneUpdated (active_window.cpp:229): after meshing, before archival
+      if (c->pending_snapshot) khr_snapshot_release(c->pending_snapshot);
+      c->pending_snapshot = nullptr;
+      if ((rc = khr_snapshot_updated(c, KHR_SNAP_ALL, 8192, &c->pending_snapshot))) return rc;  // (<= 8192 updated blocks: 100 KB each)
+    }
     if (c->cfg.with_tracking && (rc = resetInactiveLaunch(c))) return rc;
     if ((rc = khr_clear_updated(c))) return rc;
     HT("pf_output_launched");
@@ -3199,6 +3217,192 @@ int64_t khr_download_updated(khr_ctx* c, int32_t* indices, float* distance, floa
   if (last_observed && !trk) std::memset(last_observed, 0, tot * 8);
   if (sem_label && !sem) std::memset(sem_label, 0, tot * 4);
   return n;
+}
+
+// ---- snapshot of the updated blocks (VolumetricMap::cloneUpdated, active_window.cpp:229) --------------------------------
+struct khr_snapshot {
+  khr_ctx* ctx = nullptr;
+  khr_ctx::SnapArena arena{};
+  uint32_t fields = 0, cap = 0, nvox = 0, ticket = 0;
+  // carved from the arena
+  uint32_t* d_count = nullptr;
+  uint32_t* d_slots = nullptr;
+  int4* d_index = nullptr;
+  PackOut o{};
+  int64_t n = -1;        // blocks copied (known after the first wait)
+  int64_t total = -1;    // updated blocks found (> cap: overflow)
+};
+
+static size_t snapBytes(uint32_t fields, size_t cap, size_t nvox, bool trk, bool sem) {
+  auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+  size_t b = 256 + al(cap * 4) + al(cap * 16);
+  if (fields & KHR_SNAP_DISTANCE) b += al(cap * nvox * 4);
+  if (fields & KHR_SNAP_WEIGHT) b += al(cap * nvox * 4);
+  if (fields & KHR_SNAP_COLOR) b += al(cap * nvox * 4);
+  if ((fields & KHR_SNAP_LAST_OBSERVED) && trk) b += al(cap * nvox * 8);
+  if (fields & KHR_SNAP_FLAGS) b += al(cap * nvox);
+  if ((fields & KHR_SNAP_LABEL) && sem) b += al(cap * nvox * 4);
+  return b;
+}
+
+int khr_snapshot_updated(khr_ctx* c, uint32_t fields, int64_t cap_blocks, khr_snapshot** out) {
+  if (!c || !out || !(fields & KHR_SNAP_ALL)) return fail(KHR_EINVAL, "bad argument");
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(c->device));
+  const bool trk = c->cfg.with_tracking, sem = c->cfg.with_semantics;
+  const size_t cap = cap_blocks > 0 ? static_cast<size_t>(std::min<int64_t>(cap_blocks, c->m.capacity)) : c->m.capacity;
+  const size_t nvox = c->p.nvox;
+  const size_t need = snapBytes(fields, cap, nvox, trk, sem);
+  auto snap = std::make_unique<khr_snapshot>();
+  {
+    std::lock_guard<std::mutex> lock(c->snap_mu);
+    size_t best = c->snap_free.size();
+    for (size_t i = 0; i < c->snap_free.size(); ++i)
+      if (c->snap_free[i].bytes >= need && (best == c->snap_free.size() || c->snap_free[i].bytes < c->snap_free[best].bytes)) best = i;
+    if (best < c->snap_free.size()) {
+      snap->arena = c->snap_free[best];
+      c->snap_free.erase(c->snap_free.begin() + static_cast<long>(best));
+    }
+  }
+  if (!snap->arena.ptr) {
+    // first snapshots of a run: a device allocation (stalls the device once per arena; released arenas are reused)
+    void* hc = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&snap->arena.ptr), need) != hipSuccess) return fail(KHR_ENOMEM, "snapshot arena of %zu bytes", need);
+    if (hipHostMalloc(&hc, 64, hipHostMallocDefault) != hipSuccess) {
+      hipFree(snap->arena.ptr);
+      return fail(KHR_ENOMEM, "snapshot pinned words");
+    }
+    snap->arena.bytes = need;
+    snap->arena.h_count = static_cast<volatile uint32_t*>(hc);
+    snap->arena.h_count[0] = 0;
+    snap->arena.h_count[1] = 0;
+    void* dv = nullptr;
+    if (hipHostGetDevicePointer(&dv, hc, 0) != hipSuccess) {
+      hipFree(snap->arena.ptr);
+      hipHostFree(hc);
+      return fail(KHR_EDEVICE, "snapshot pinned words: no device view");
+    }
+    snap->arena.d_count_host_view = static_cast<uint32_t*>(dv);
+  }
+  snap->ctx = c;
+  snap->fields = fields;
+  snap->cap = static_cast<uint32_t>(cap);
+  snap->nvox = static_cast<uint32_t>(nvox);
+  snap->ticket = ++c->snap_ticket;
+  if (snap->ticket == 0) snap->ticket = ++c->snap_ticket;
+  uint8_t* cur = snap->arena.ptr;
+  auto carve = [&](size_t b) { uint8_t* p = cur; cur += (b + 255) / 256 * 256; return p; };
+  snap->d_count = reinterpret_cast<uint32_t*>(carve(256));
+  snap->d_slots = reinterpret_cast<uint32_t*>(carve(cap * 4));
+  snap->d_index = reinterpret_cast<int4*>(carve(cap * 16));
+  if (fields & KHR_SNAP_DISTANCE) snap->o.dist = reinterpret_cast<float*>(carve(cap * nvox * 4));
+  if (fields & KHR_SNAP_WEIGHT) snap->o.weight = reinterpret_cast<float*>(carve(cap * nvox * 4));
+  if (fields & KHR_SNAP_COLOR) snap->o.color = reinterpret_cast<uint32_t*>(carve(cap * nvox * 4));
+  if ((fields & KHR_SNAP_LAST_OBSERVED) && trk) snap->o.last_obs = reinterpret_cast<uint64_t*>(carve(cap * nvox * 8));
+  if (fields & KHR_SNAP_FLAGS) snap->o.vflags = carve(cap * nvox);
+  if ((fields & KHR_SNAP_LABEL) && sem) snap->o.sem_label = reinterpret_cast<uint32_t*>(carve(cap * nvox * 4));
+  hipError_t e = hipMemsetAsync(snap->d_count, 0, 4, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_snapshot_select, dim3(gridFor(c->m.capacity)), dim3(256), 0, c->stream, c->m, snap->d_count, snap->d_slots,
+                       snap->d_index, snap->cap);
+    dispatchVps(c, [&](auto vps) {
+      hipLaunchKernelGGL((k_snapshot_pack<decltype(vps)::value>), dim3(2048), dim3(256), 0, c->stream, c->m, snap->d_count, snap->d_slots,
+                         snap->cap, snap->o, snap->arena.d_count_host_view, snap->ticket);
+      return KHR_OK;
+    });
+    e = hipGetLastError();
+  }
+  if (e != hipSuccess) {
+    std::lock_guard<std::mutex> lock(c->snap_mu);
+    c->snap_free.push_back(snap->arena);
+    return fail(KHR_EDEVICE, "snapshot launch failed: %s", hipGetErrorString(e));
+  }
+  *out = snap.release();
+  return KHR_OK;
+}
+
+int khr_take_snapshot(khr_ctx* c, khr_snapshot** out) {
+  if (!c || !out) return fail(KHR_EINVAL, "null argument");
+  *out = c->pending_snapshot;
+  c->pending_snapshot = nullptr;
+  return *out ? KHR_OK : KHR_ENOTFOUND;
+}
+
+static int snapshotWait(khr_snapshot* s) {
+  if (s->n >= 0) return KHR_OK;
+  // the pack kernel's first thread publishes {count, ticket}; the host spins on the ticket (a blocking stream wait costs
+  // hundreds of us of wake-up latency; the kernel is at most one output stage away)
+  const auto t0 = std::chrono::steady_clock::now();
+  while (s->arena.h_count[1] != s->ticket) {
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) return fail(KHR_EDEVICE, "snapshot was never produced (stream stuck?)");
+    std::this_thread::yield();
+  }
+  s->total = s->arena.h_count[0];
+  s->n = std::min<int64_t>(s->total, s->cap);
+  return KHR_OK;
+}
+
+int64_t khr_snapshot_num_blocks(khr_snapshot* s) {
+  if (!s) return fail(KHR_EINVAL, "null snapshot");
+  const int rc = snapshotWait(s);
+  return rc ? rc : s->total;
+}
+
+int64_t khr_snapshot_download(khr_snapshot* s, int32_t* indices, float* distance, float* weight, uint8_t* color_rgba,
+                              uint64_t* last_observed, uint8_t* voxel_flags, uint32_t* sem_label, int64_t cap_blocks) {
+  if (!s) return fail(KHR_EINVAL, "null snapshot");
+  int rc = snapshotWait(s);
+  if (rc) return rc;
+  if (s->total > s->cap) return fail(KHR_ENOMEM, "%lld updated blocks, snapshot capacity %u", static_cast<long long>(s->total), s->cap);
+  const int64_t n = s->n;
+  if (n > cap_blocks) return fail(KHR_EINVAL, "%lld blocks in the snapshot, cap %lld", static_cast<long long>(n), static_cast<long long>(cap_blocks));
+  if (n == 0) return 0;
+  khr_ctx* c = s->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  // the copy kernel itself must have finished, not only published its count: one stream wait here (download = slow path)
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const size_t nv = s->nvox;
+  std::vector<int4> idx(static_cast<size_t>(n));
+  HIP_TRY(hipMemcpy(idx.data(), s->d_index, sizeof(int4) * n, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> order(static_cast<size_t>(n));
+  for (int64_t i = 0; i < n; ++i) order[i] = static_cast<uint32_t>(i);
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    return std::make_tuple(idx[a].x, idx[a].y, idx[a].z) < std::make_tuple(idx[b].x, idx[b].y, idx[b].z);
+  });
+  if (indices)
+    for (int64_t i = 0; i < n; ++i) {
+      indices[3 * i] = idx[order[i]].x;
+      indices[3 * i + 1] = idx[order[i]].y;
+      indices[3 * i + 2] = idx[order[i]].z;
+    }
+  // per field: one D2H into a host staging vector, then the permutation into the caller's array
+  std::vector<uint8_t> stage;
+  auto field = [&](void* dst, const void* src, size_t elem) -> int {
+    if (!dst || !src) return KHR_OK;
+    const size_t blk = nv * elem;
+    stage.resize(static_cast<size_t>(n) * blk);
+    if (hipMemcpy(stage.data(), src, stage.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(KHR_EDEVICE, "snapshot download failed");
+    for (int64_t i = 0; i < n; ++i) std::memcpy(static_cast<uint8_t*>(dst) + static_cast<size_t>(i) * blk, stage.data() + static_cast<size_t>(order[i]) * blk, blk);
+    return KHR_OK;
+  };
+  if ((rc = field(distance, s->o.dist, 4))) return rc;
+  if ((rc = field(weight, s->o.weight, 4))) return rc;
+  if ((rc = field(color_rgba, s->o.color, 4))) return rc;
+  if ((rc = field(last_observed, s->o.last_obs, 8))) return rc;
+  if ((rc = field(voxel_flags, s->o.vflags, 1))) return rc;
+  if ((rc = field(sem_label, s->o.sem_label, 4))) return rc;
+  return n;
+}
+
+void khr_snapshot_release(khr_snapshot* s) {
+  if (!s) return;
+  khr_ctx* c = s->ctx;
+  // the arena may be handed to the next snapshot right away: that one's kernels are queued behind this one's on the same stream
+  {
+    std::lock_guard<std::mutex> lock(c->snap_mu);
+    c->snap_free.push_back(s->arena);
+  }
+  delete s;
 }
 
 int64_t khr_mesh_num_vertices(khr_ctx* c) {

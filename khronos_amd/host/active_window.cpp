@@ -421,6 +421,9 @@ ActiveWindow::Config ActiveWindow::Config::fromYaml(const khronos_amd::YamlNode&
     int v = static_cast<int>(c.max_blocks);
     m->read("max_blocks", v);
     c.max_blocks = static_cast<uint32_t>(v);
+    v = static_cast<int>(c.max_snapshot_blocks);
+    m->read("max_snapshot_blocks", v);
+    c.max_snapshot_blocks = static_cast<uint32_t>(v);
     v = static_cast<int>(c.max_frame_pixels);
     m->read("max_frame_pixels", v);
     c.max_frame_pixels = static_cast<uint32_t>(v);
@@ -688,7 +691,11 @@ hydra::ActiveWindowOutput::Ptr ActiveWindow::extractOutputData(const FrameData& 
     for (int c = 0; c < 3; ++c) output->world_R_body[3 * r + c] = data.input.world_T_body[4 * r + c];
   }
   output->map_ctx = ctx_;
-  output->updated_blocks = map_.allocatedBlockIndices(/*only_updated=*/true);  // cloneUpdated role
+  {  // output->setMap(map.cloneUpdated()) (:229): snapshot on the device, in stream order, no host round trip
+    khr_snapshot* snap = nullptr;
+    chk(khr_snapshot_updated(ctx_, KHR_SNAP_ALL, config.max_snapshot_blocks, &snap), "khr_snapshot_updated");
+    output->setMap(snap);
+  }
   // archive after cloning / meshing (:231-237)
   if (config.volumetric_map.with_tracking) {
     std::vector<int32_t> removed(3 * static_cast<size_t>(config.max_blocks));

@@ -417,6 +417,7 @@ class ActiveWindow {
     // device-side sizing (no reference equivalent)
     int num_labels = 20;
     uint32_t max_blocks = 16384;
+    uint32_t max_snapshot_blocks = 8192;  // capacity of an output's map snapshot (cloneUpdated): ~100 KB of HBM per block
     uint32_t max_frame_pixels = 1280 * 720;
     uint64_t max_mesh_vertices = 8u << 20;
     int device = 0, rank = 0, world_size = 1;

@@ -201,6 +201,7 @@ int main(int argc, char** argv) {
     std::vector<int32_t> label(static_cast<size_t>(W) * H);
     std::printf("{\"info\": \"%s\", \"outputs\": [", aw.printInfo().c_str());
     int n_out = 0;
+    hydra::ActiveWindowOutput::Ptr first_out;  // kept like the frontend's queue keeps it: read after the map has moved on
     size_t total_dyn_clusters = 0, total_sem_clusters = 0;
     for (int i = 0; i < N; ++i) {
       hydra::InputPacket pkt;
@@ -218,17 +219,16 @@ int main(int argc, char** argv) {
       total_sem_clusters += aw.getLatestFrameData().semantic_clusters.size();
       if (out) {
         std::printf("%s{\"stamp\": %" PRIu64 ", \"updated\": %zu, \"archived\": %zu, \"objects\": %zu}", n_out ? ", " : "", out->timestamp_ns,
-                    out->updated_blocks.size(), out->archived_mesh_indices.size(), out->graph_update.size());
+                    out->updatedBlocks().size(), out->archived_mesh_indices.size(), out->graph_update.size());
+        if (!first_out) first_out = out;
         ++n_out;
       }
     }
     // map checksum in sorted block order
     double checksum = 0;
     size_t n_blocks = aw.getMap().numBlocks();
-    hydra::ActiveWindowOutput probe;
-    probe.map_ctx = aw.getMap().ctx();
     for (const auto& idx : aw.getMap().allocatedBlockIndices()) {
-      const hydra::BlockCopy b = probe.cloneBlock(idx);
+      const hydra::BlockCopy b = aw.getMap().cloneBlock(idx);
       for (size_t k = 0; k < b.distance.size(); ++k) checksum += static_cast<double>(b.distance[k]) * b.weight[k];
     }
     const size_t n_tracks_before = aw.getTracks().size();
@@ -253,6 +253,14 @@ int main(int argc, char** argv) {
     }
     aw.finishMapping();
     std::printf("], \"blocks_after_finish\": %zu", aw.getMap().numBlocks());
+    if (first_out) {  // the first output's map clone, read only now (every block has been archived by finishMapping)
+      double sum = 0;
+      const auto blocks = first_out->cloneUpdatedTsdf();
+      for (const auto& b : blocks)
+        for (size_t k = 0; k < b.distance.size(); ++k) sum += static_cast<double>(b.distance[k]) * b.weight[k];
+      std::printf(", \"first_output_clone\": {\"blocks\": %zu, \"checksum\": %.17g}", blocks.size(), sum);
+      first_out.reset();
+    }
     // timing/stats.csv of the reference's experiment manager (experiment_manager.cpp:251-258), same scope names
     if (argc > 6) hydra::timing::ElapsedTimeRecorder::instance().logStats(argv[6]);
     std::printf(", \"timing\": {");

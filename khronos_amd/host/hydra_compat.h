@@ -91,6 +91,17 @@ struct InputData {
   }
 };
 
+// a voxel block copied to the host (VolumetricMap::cloneUpdated role, active_window.cpp:229)
+struct BlockCopy {
+  BlockIndex index;
+  std::vector<float> distance, weight;
+  std::vector<uint8_t> color;  // rgba
+  std::vector<uint64_t> last_observed, last_occupied;
+  std::vector<uint8_t> flags;
+  std::vector<uint32_t> semantic_label;
+  uint8_t block_flags = 0;
+};
+
 // hydra::VolumetricMap role: here a handle on the HBM-resident map of a fusion context.
 class VolumetricMap {
  public:
@@ -115,20 +126,21 @@ class VolumetricMap {
     if (n > 0) khr_block_indices(ctx_, out[0].data(), n, only_updated);
     return out;
   }
+  // deep copy of one block of the LIVE map (visualiser / tests; the output's snapshot is ActiveWindowOutput::cloneUpdated)
+  BlockCopy cloneBlock(const BlockIndex& idx) const {
+    BlockCopy b;
+    b.index = idx;
+    const size_t n = static_cast<size_t>(config.voxels_per_side) * config.voxels_per_side * config.voxels_per_side;
+    b.distance.resize(n); b.weight.resize(n); b.color.resize(4 * n); b.last_observed.resize(n);
+    b.last_occupied.resize(n); b.flags.resize(n); b.semantic_label.resize(n);
+    khr_download_block(ctx_, idx[0], idx[1], idx[2], b.distance.data(), b.weight.data(), b.color.data(),
+                       b.last_observed.data(), b.last_occupied.data(), b.flags.data(), b.semantic_label.data(), nullptr,
+                       &b.block_flags);
+    return b;
+  }
 
  private:
   khr_ctx* ctx_ = nullptr;
-};
-
-// a voxel block copied to the host (VolumetricMap::cloneUpdated role, active_window.cpp:229)
-struct BlockCopy {
-  BlockIndex index;
-  std::vector<float> distance, weight;
-  std::vector<uint8_t> color;  // rgba
-  std::vector<uint64_t> last_observed, last_occupied;
-  std::vector<uint8_t> flags;
-  std::vector<uint32_t> semantic_label;
-  uint8_t block_flags = 0;
 };
 
 struct Mesh {
@@ -177,41 +189,64 @@ struct ActiveWindowOutput {
   double world_t_body[3] = {0, 0, 0};
   double world_R_body[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   BlockIndices archived_mesh_indices;
-  BlockIndices updated_blocks;  // setMap(map.cloneUpdated()): indices now, voxel payload fetched lazily
-  khr_ctx* map_ctx = nullptr;
+  // setMap(map.cloneUpdated()) (active_window.cpp:229): a device-side SNAPSHOT of the blocks flagged updated, taken between
+  // meshing and archival (khr_snapshot_updated).  It keeps its contents whatever later frames do to the map -- the hydra
+  // frontend takes outputs from a queue -- and costs no host round trip at output time; indices and voxels come to the
+  // host when a consumer asks.  Released with the last copy of the output.
+  std::shared_ptr<khr_snapshot> map;
+  khr_ctx* map_ctx = nullptr;  // the live map the snapshot was taken from (voxels_per_side etc. via khr_get_config)
   std::shared_ptr<InputData> sensor_data;
   std::vector<std::shared_ptr<KhronosObjectAttributes>> graph_update;  // LayerUpdate(2) role
-  // all updated blocks in one packed transfer (khr_download_updated); distance / weight only here, the
-  // other layers are available through the C ABI call directly
-  std::vector<BlockCopy> cloneUpdatedTsdf() const {
-    const size_t n = updated_blocks.size();
-    std::vector<int32_t> idx(3 * n);
-    std::vector<float> d(n * 4096), w(n * 4096);
+
+  void setMap(khr_snapshot* snap) { map = std::shared_ptr<khr_snapshot>(snap, [](khr_snapshot* s) { khr_snapshot_release(s); }); }
+  // indices of the snapshot's blocks, sorted (TsdfLayer::allocatedBlockIndices of the cloned map)
+  const BlockIndices& updatedBlocks() const {
+    if (!indices_valid_) {
+      const int64_t n = map ? khr_snapshot_num_blocks(map.get()) : 0;
+      updated_blocks_.assign(static_cast<size_t>(n > 0 ? n : 0), BlockIndex{0, 0, 0});
+      if (n > 0) khr_snapshot_download(map.get(), updated_blocks_[0].data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n);
+      indices_valid_ = true;
+    }
+    return updated_blocks_;
+  }
+  // the cloned blocks (all snapshotted layers, or distance / weight only) in ONE packed transfer
+  std::vector<BlockCopy> cloneUpdated(bool tsdf_only = false) const {
     std::vector<BlockCopy> out;
-    const int64_t k = n ? khr_download_updated(map_ctx, idx.data(), d.data(), w.data(), nullptr, nullptr, nullptr, nullptr,
-                                               static_cast<int64_t>(n)) : 0;
+    const int64_t n = map ? khr_snapshot_num_blocks(map.get()) : 0;
+    if (n <= 0) return out;
+    khr_config cfg{};
+    khr_get_config(map_ctx, &cfg);
+    const size_t nv = static_cast<size_t>(cfg.voxels_per_side) * cfg.voxels_per_side * cfg.voxels_per_side, N = static_cast<size_t>(n);
+    std::vector<int32_t> idx(3 * N);
+    std::vector<float> d(N * nv), w(N * nv);
+    std::vector<uint8_t> col, fl;
+    std::vector<uint64_t> lo;
+    std::vector<uint32_t> lab;
+    if (!tsdf_only) { col.resize(4 * N * nv); fl.resize(N * nv); lo.resize(N * nv); lab.resize(N * nv); }
+    const int64_t k = khr_snapshot_download(map.get(), idx.data(), d.data(), w.data(), tsdf_only ? nullptr : col.data(),
+                                            tsdf_only ? nullptr : lo.data(), tsdf_only ? nullptr : fl.data(),
+                                            tsdf_only ? nullptr : lab.data(), n);
     for (int64_t i = 0; i < k; ++i) {
       BlockCopy b;
       b.index = {idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]};
-      b.distance.assign(d.begin() + i * 4096, d.begin() + (i + 1) * 4096);
-      b.weight.assign(w.begin() + i * 4096, w.begin() + (i + 1) * 4096);
+      b.distance.assign(d.begin() + i * nv, d.begin() + (i + 1) * nv);
+      b.weight.assign(w.begin() + i * nv, w.begin() + (i + 1) * nv);
+      if (!tsdf_only) {
+        b.color.assign(col.begin() + 4 * i * nv, col.begin() + 4 * (i + 1) * nv);
+        b.last_observed.assign(lo.begin() + i * nv, lo.begin() + (i + 1) * nv);
+        b.flags.assign(fl.begin() + i * nv, fl.begin() + (i + 1) * nv);
+        b.semantic_label.assign(lab.begin() + i * nv, lab.begin() + (i + 1) * nv);
+      }
+      b.block_flags = 1;  // KHR_BLK_UPDATED: what made it part of the clone
       out.push_back(std::move(b));
     }
     return out;
   }
-  // deep copy of one updated block (the reference clones all of them eagerly, which on a GPU-resident map
-  // would put a D2H copy of every updated block on the critical path; SURVEY.md §7 "Output cadence & PCIe")
-  BlockCopy cloneBlock(const BlockIndex& idx) const {
-    BlockCopy b;
-    b.index = idx;
-    const size_t n = 4096;
-    b.distance.resize(n); b.weight.resize(n); b.color.resize(4 * n); b.last_observed.resize(n);
-    b.last_occupied.resize(n); b.flags.resize(n); b.semantic_label.resize(n);
-    khr_download_block(map_ctx, idx[0], idx[1], idx[2], b.distance.data(), b.weight.data(), b.color.data(),
-                       b.last_observed.data(), b.last_occupied.data(), b.flags.data(), b.semantic_label.data(), nullptr,
-                       &b.block_flags);
-    return b;
-  }
+  std::vector<BlockCopy> cloneUpdatedTsdf() const { return cloneUpdated(true); }
+
+ private:
+  mutable BlockIndices updated_blocks_;
+  mutable bool indices_valid_ = false;
 };
 
 

@@ -97,11 +97,18 @@ def test_active_window_host_mirror(tmp_path):
         if not (last_full + int(float(np.float32(0.4)) * 1e9) > fr["stamp"]):
             ctx.generate_mesh(True, True)
             upd = len(ctx.block_indices(only_updated=True))
+            if not outputs:  # cloneUpdated of the first output (active_window.cpp:229), as the map is NOW
+                u = ctx.download_updated()
+                first_clone = (len(u["indices"]), float(np.sum(u["distance"].astype(np.float64) * u["weight"].astype(np.float64))))
             arch = len(ctx.reset_inactive())
             ctx.clear_updated()
             outputs.append({"stamp": fr["stamp"], "updated": upd, "archived": arch, "objects": 0})
             last_full = fr["stamp"]
     assert res["outputs"] == outputs
+    # the C++ class read its first output's map clone at the very end (after finishMapping archived every block): it must
+    # hold what the map held at output time (snapshot semantics of ActiveWindowOutput::map)
+    assert res["first_output_clone"]["blocks"] == first_clone[0] > 0
+    assert res["first_output_clone"]["checksum"] == pytest.approx(first_clone[1], rel=1e-9, abs=1e-9)
     assert res["dynamic_clusters"] == dyn_total
     assert res["n_blocks"] == ctx.num_blocks()
     chk = 0.0

@@ -1,0 +1,102 @@
+"""-m gpu: VolumetricMap::cloneUpdated as a SNAPSHOT (active_window.cpp:229; khr_snapshot_updated / KHR_PF_SNAPSHOT).
+The reference deep-copies the updated blocks into the output at output time and the frontend reads them later from a
+queue.  Here the copy is made on the device between meshing and archival; the test reads it only after four more frames
+(and another output stage with archival) have changed the map, and compares it with what the oracle's map held at the
+moment of the output."""
+import numpy as np
+import pytest
+
+from common import make_pair
+
+pytestmark = pytest.mark.gpu
+
+W, H = 320, 240
+UPDATED = 1  # KHR_BLK_UPDATED
+
+
+def _oracle_updated(ora):
+    out = {}
+    for idx in ora.block_indices():
+        b = ora.get_block(idx, likelihoods=False)
+        if b["block_flags"] & UPDATED:
+            out[tuple(int(x) for x in idx)] = b
+    return out
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["process_frame", "stepwise"])
+def test_snapshot_outlives_map_changes(fused):
+    cfg, ctx, ora, s, sen, osen = make_pair(width=W, height=H, temporal_window=0.75, truncation_distance=0.3, num_frame_slots=4)
+    snaps, want = [], []
+    n_frames = 16
+    for i in range(n_frames):
+        fr = s.render(i)
+        out_now = (i + 1) % 4 == 0
+        if fused:
+            f = ctx.make_frame(fr["stamp"], fr["pose"], 0)
+            depth = np.ascontiguousarray(fr["depth"]); rgb = np.ascontiguousarray(fr["rgb"]); lab = np.ascontiguousarray(fr["label"])
+            f.depth, f.color, f.label = depth.ctypes.data, rgb.ctypes.data, lab.ctypes.data
+            flags = ctx.PF_MOTION | ctx.PF_TRACKING | ((ctx.PF_OUTPUT | ctx.PF_SNAPSHOT) if out_now else 0)
+            ctx.process_frame(sen, f, on_device=False, flags=flags)
+            if out_now:
+                snaps.append(ctx.take_snapshot())
+                assert snaps[-1] is not None and ctx.take_snapshot() is None
+        else:
+            slot = ctx.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+            ctx.detect_motion(slot)
+            ctx.integrate(slot, allocate_blocks=True, use_mask=True)
+            ctx.update_tracking(fr["stamp"])
+            if out_now:
+                ctx.generate_mesh(True, True)
+                snaps.append(ctx.snapshot_updated())
+                ctx.reset_inactive()
+                ctx.clear_updated()
+        _, dyn_o, _ = ora.detect_motion(osen, fr["stamp"], fr["pose"], fr["depth"])
+        ora.integrate(osen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"], mask=dyn_o)
+        ora.update_tracking(fr["stamp"])
+        if out_now:
+            ora.generate_mesh(True, True)
+            want.append(_oracle_updated(ora))  # cloneUpdated: before archival and flag clearing
+            ora.reset_inactive()
+            ora.clear_updated()
+    assert len(snaps) == 4
+    # read the snapshots only now: the map has moved on (and archived blocks) since each of them was taken
+    archived_something = False
+    live = {tuple(int(x) for x in b) for b in ctx.block_indices()}
+    for snap, w in zip(snaps, want):
+        assert snap.num_blocks() == len(w) > 0
+        g = snap.download()
+        keys = [tuple(int(x) for x in r) for r in g["indices"]]
+        assert keys == sorted(w.keys())
+        archived_something |= any(k not in live for k in keys)
+        for j, k in enumerate(keys):
+            o = w[k]
+            assert np.array_equal(g["distance"][j], o["distance"]) and np.array_equal(g["weight"][j], o["weight"]), k
+            assert np.array_equal(g["color"][j], o["color"]) and np.array_equal(g["sem_label"][j], o["sem_label"]), k
+            assert np.array_equal(g["last_observed"][j], o["last_observed"]) and np.array_equal(g["flags"][j], o["flags"]), k
+        snap.release()
+    assert archived_something, "some snapshotted block must have left the map by the time the snapshot is read"
+    # the first snapshot differs from the live map by now (otherwise the test proves nothing)
+    first = sorted(want[0].keys())
+    changed = 0
+    for k in first[:: max(1, len(first) // 16)]:
+        if k in live and not np.array_equal(ctx.download_block(k, likelihoods=False)["weight"], want[0][k]["weight"]):
+            changed += 1
+    assert changed > 0
+    # released arenas are reused: a fifth snapshot needs no new arena and still works
+    ctx.snapshot_updated(fields=3).release()
+    ctx.close()
+    ora.close()
+
+
+def test_snapshot_capacity_overflow_is_loud():
+    cfg, ctx, ora, s, sen, osen = make_pair(width=W, height=H)
+    fr = s.render(0)
+    slot = ctx.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+    ctx.integrate(slot)
+    snap = ctx.snapshot_updated(fields=1, cap_blocks=4)
+    assert snap.num_blocks() > 4
+    with pytest.raises(Exception):
+        snap.download()
+    snap.release()
+    ctx.close()
+    ora.close()

@@ -64,6 +64,13 @@ def parse_args():
     ap.add_argument("--buffer-frames", type=int, default=100, help="frame_data_buffer.max_buffer_size (frames kept in HBM per camera)")
     ap.add_argument("--cpu-baseline-frames", type=int, default=-1,
                     help="frames of the same stream timed on the CPU oracle (rank 0, N=1); -1 = auto, 0 = skip")
+    ap.add_argument("--output-copy", choices=["none", "device", "host"], default="none",
+                    help="what happens to an output's map clone (VolumetricMap::cloneUpdated, active_window.cpp:229): none = the timed "
+                         "step hands out no clone (default line); device = device-side snapshot of the updated blocks at every output "
+                         "(what the drop-in's ActiveWindowOutput carries); host = snapshot + download of all its layers + mesh fetch "
+                         "(a consumer on the host)")
+    ap.add_argument("--no-extra-streams", action="store_true",
+                    help="default c3 run only: do not append the c1 / c2 streams and the output-copy variants (each a short sub-run of this script)")
     ap.add_argument("--no-roofline-timers", action="store_true")
     ap.add_argument("--all-timers", action="store_true", help="HIP-event timers on every kernel group (slower host path)")
     ap.add_argument("--frame-times", action="store_true", help="debug: synchronise and print per-frame wall times")
@@ -317,10 +324,34 @@ def main():
                     flags |= ctx.PF_TRACKING  # TrackingIntegrator::updateBlocks once per tick, after all cameras
                 if out_now:
                     flags |= ctx.PF_OUTPUT
+                    if args.output_copy != "none":
+                        flags |= ctx.PF_SNAPSHOT
             _t0 = time.perf_counter()
             slot, n_dyn = ctx.process_frame(sensor, frame_desc[i], True, flags)
             _t1 = time.perf_counter()
             host_t[0] += _t1 - _t0
+            if last and out_now and args.output_copy != "none":
+                # the output's map clone: kept until the NEXT output (a consumer that is one output behind), then dropped
+                snap = ctx.take_snapshot()
+                if args.output_copy == "host":
+                    # the consumer's buffers: pinned, allocated once (capacity of the snapshot: 8192 blocks)
+                    if not host_bufs:
+                        nvx = 4096
+                        for nm, dt_, per in (("indices", torch.int32, 3), ("distance", torch.float32, nvx), ("weight", torch.float32, nvx),
+                                             ("color", torch.uint8, 4 * nvx), ("last_observed", torch.int64, nvx), ("flags", torch.uint8, nvx),
+                                             ("sem_label", torch.int32, nvx)):
+                            host_bufs[nm] = torch.empty(8192 * per, dtype=dt_).pin_memory()
+                    nb_ = snap.download_into([host_bufs[k].data_ptr() for k in ("indices", "distance", "weight", "color", "last_observed",
+                                                                                 "flags", "sem_label")], 8192)
+                    copy_stats[0] += 1
+                    copy_stats[1] += nb_ * (12 + 4096 * 25)
+                    mesh = ctx.fetch_mesh()
+                    copy_stats[1] += sum(int(v.nbytes) for v in mesh.values())
+                else:
+                    copy_stats[0] += 1
+                if held_snapshot[0] is not None:
+                    held_snapshot[0].release()
+                held_snapshot[0] = snap
             if pipe is not None:
                 # software pipeline: the tracker association of the previous frame runs on the host while this frame's
                 # kernels execute; this frame's voxel-set passes are queued behind them and collected next time
@@ -337,6 +368,9 @@ def main():
                     obj_stats[1] += n_rm
                     obj_stats[2] += time.perf_counter() - t_e
 
+    copy_stats = [0, 0]       # outputs whose map clone was taken, bytes brought to the host (--output-copy)
+    held_snapshot = [None]
+    host_bufs = {}
     host_t = [0.0, 0.0, 0.0]  # host seconds in process_frame / finish_frame / launch_frame (incl. warm-up)
     obj_stats = [0, 0, 0.0]  # objects extracted, tracks removed, seconds spent in extraction (timed region and warm-up)
 
@@ -349,6 +383,7 @@ def main():
     for i in range(t0i):  # pre-roll + warm-up, untimed
         step(i)
     sync_all()
+    copy_before = list(copy_stats)
     obj_before = list(obj_stats)
     if pipe is not None:
         obj_before[0] += 0  # (detached extractions finishing later are attributed to the region that joins them)
@@ -384,6 +419,7 @@ def main():
     ctx.timing_enable(False)
     st1 = ctx.stats()
     obj_timed = [obj_stats[k] - obj_before[k] for k in range(3)]
+    copy_timed = [copy_stats[k] - copy_before[k] for k in range(2)]
     # per-frame latency: the same steps with a device synchronisation after each (the reference's active_window/all scope
     # is a per-frame wall time; `value` above is pipelined throughput: the host queues frame i + 1 while frame i executes)
     lat_ms = None
@@ -451,6 +487,13 @@ def main():
         **({"emulation": "rank 0 of a %d-rank sharded run played by one process, no collectives: `value` is what the job would reach "
                          "if communication were free and all ranks were as loaded as rank 0 -- NOT a measured N-GPU number" % world}
            if emu else {}),
+        "output_copy": {"mode": args.output_copy,
+                        "what": {"none": "the timed steps hand out no clone of the updated blocks (frames and map stay in HBM)",
+                                 "device": "every output takes a device-side snapshot of the updated blocks (khr_snapshot_updated between meshing "
+                                           "and archival: VolumetricMap::cloneUpdated, active_window.cpp:229), held until the next output",
+                                 "host": "every output takes the device-side snapshot AND a host consumer downloads all its layers "
+                                         "(distance, weight, colour, last_observed, flags, label) plus the mesh"}[args.output_copy],
+                        "outputs_in_timed_region": copy_timed[0], "host_bytes_in_timed_region": copy_timed[1]},
         "objects": None if pipe is None else {"tracks_at_end": pipe.num_tracks(), "buffered_frames": pipe.num_buffered_frames(),
                                               "objects_extracted": obj_timed[0], "tracks_removed": obj_timed[1],
                                               "extraction_ms_total": 1e3 * obj_timed[2],
@@ -504,15 +547,19 @@ def main():
         from oracle import pyoracle as po
         cores = os.cpu_count() or 1
         if nb < 0:
-            nb = max(4, min(12, args.warmup + args.steps)) if args.config == "c3" else 24
+            nb = max(4, min(12, args.steps)) if args.config == "c3" else min(24, args.steps)
         ocfg = po.config_from(cfg, cores)
         ora = po.OracleMap(ocfg)
         osen = ora.make_sensor(W, H, s.fx, s.fy, s.cx, s.cy, 0.1, 5.0)
         tc = 0.0
         upd = 0
-        # same stream, first nb frames (includes the allocation-heavy first frame, like the GPU warm-up)
-        skip = min(2, nb - 1)
-        for i in range(nb):
+        # The SAME frames the GPU steps were timed on: the oracle first fuses the pre-roll and warm-up frames untimed (the
+        # window is then in the same steady state), then frames t0i .. t0i + nb - 1 are timed.  When that would take too
+        # long (custom runs with long pre-rolls) the sample falls back to the first frames of the stream and says so.
+        same_frames = (t0i + nb) <= len(frames_host) and t0i <= 128
+        first_timed = t0i if same_frames else min(2, nb - 1)
+        last_frame = first_timed + nb if same_frames else nb
+        for i in range(last_frame):
             fr = frames_host[i]
             c0 = time.perf_counter()
             dyn = None
@@ -521,9 +568,10 @@ def main():
             stc = ora.integrate(osen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"], mask=dyn)
             if not args.no_tracking:
                 ora.update_tracking(fr["stamp"])
-            if pipe is not None:
+            if pipe is not None and i >= first_timed:
                 # object half on the CPU: ConnectedSemantics + the tracker's voxel sets (single-threaded in the reference
-                # too); the association itself is negligible and not timed
+                # too); the association itself is negligible and not timed.  (Stateless per frame: skipped on the
+                # untimed lead-in.)
                 _, oimg, _ = ora.detect_objects(osen, fr["stamp"], fr["pose"], fr["depth"], fr["label"], list(range(7, 20)), use_3d=True,
                                                 grid_size=0.1, max_range=5.0, min_cluster_size=50, use_full_connectivity=True)
                 ora.cluster_voxels(osen, fr["stamp"], fr["pose"], fr["depth"], oimg, 0.2)
@@ -535,21 +583,52 @@ def main():
                     ora.reset_inactive()
                 ora.clear_updated()
             c1 = time.perf_counter()
-            if i >= skip:
+            if i >= first_timed:
                 tc += c1 - c0
                 upd += stc["n_updated_voxels"]
-        cpu_fps = (nb - skip) / tc
+        n_timed = last_frame - first_timed
+        cpu_fps = n_timed / tc
         out["cpu_baseline"] = {"value": cpu_fps, "unit": "frames/s", "cores": cores, "kind": "port",
-                               "sample": "frames %d..%d of the same stream (CPU restatement of the reference path, %d threads for "
+                               "sample": "frames %d..%d of the same stream%s (CPU restatement of the reference path, %d threads for "
                                          "the volumetric part%s; reference itself not buildable offline)"
-                                         % (skip, nb - 1, cores, ", object detection + voxel sets on 1 thread as in the reference"
-                                            if pipe is not None else ""),
+                                         % (first_timed, last_frame - 1,
+                                            " = the first %d of the frames the GPU steps were timed on, after the same %d lead-in frames" % (n_timed, first_timed)
+                                            if same_frames else " (the window is still filling: fewer blocks per frame than in the GPU's timed steps)",
+                                            cores, ", object detection + voxel sets on 1 thread as in the reference" if pipe is not None else ""),
                                "mvoxel_updates_per_s": 1e-6 * upd / tc}
         out["speedup_vs_cpu"] = fps / cpu_fps
 
+    if held_snapshot[0] is not None:
+        held_snapshot[0].release()
+    ctx.close()
+    # ---- the other streams north_star asks for, and what an output's map clone costs: short sub-runs of this script,
+    #      appended to the default c3 line so that one driver invocation carries all of them ----
+    if (rank == 0 and world == 1 and not emu and not args.no_extra_streams and args.config == "c3" and preset_matches
+            and args.output_copy == "none" and not args.fast):
+        import subprocess
+        extra = {}
+        common_args = ["--steps", str(args.steps), "--warmup", str(args.warmup), "--no-extra-streams", "--latency-frames", "0"]
+        runs = {"c1": ["--config", "c1"], "c2": ["--config", "c2"],
+                "c3_output_copy_device": ["--config", "c3", "--output-copy", "device", "--cpu-baseline-frames", "0"],
+                "c3_output_copy_host": ["--config", "c3", "--output-copy", "host", "--cpu-baseline-frames", "0"]}
+        for name, extra_args in runs.items():
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra_args + common_args, capture_output=True, text=True,
+                                   timeout=600)
+                j = json.loads(r.stdout.strip().splitlines()[-1])
+                keep = {k: j.get(k) for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "mvoxel_updates_per_s",
+                                              "speedup_vs_cpu", "output_copy")}
+                keep["workload"] = j["config"]["workload"]
+                if "roofline" in j:
+                    keep["roofline"] = {k: j["roofline"].get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us")}
+                if "cpu_baseline" in j:
+                    keep["cpu_baseline"] = j["cpu_baseline"]
+                extra[name] = keep
+            except Exception as e:  # noqa: BLE001
+                extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["streams"] = extra
     if rank == 0:
         print(json.dumps(out))
-    ctx.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -385,8 +385,10 @@ int khr_snapshot_updated(khr_ctx* ctx, uint32_t fields, int64_t cap_blocks, khr_
 int khr_take_snapshot(khr_ctx* ctx, khr_snapshot** out);
 /* number of blocks in the snapshot (waits for the device copy to have been queued and counted) */
 int64_t khr_snapshot_num_blocks(khr_snapshot* snap);
-/* copy the snapshot to the host, blocks in sorted index order (any pointer may be NULL; arrays hold cap_blocks * nvox
- * elements, indices 3 * cap_blocks); fields that were not snapshotted are left untouched.  Returns the block count. */
+/* copy the snapshot to the host: blocks in the snapshot's own order, `indices` (3 per block) says which is which (any
+ * pointer may be NULL; arrays hold cap_blocks * nvox elements); fields that were not snapshotted are left untouched.
+ * One device -> host copy per field straight into the caller's arrays (pin them for the full link rate).  Returns the
+ * block count. */
 int64_t khr_snapshot_download(khr_snapshot* snap, int32_t* indices, float* distance, float* weight, uint8_t* color_rgba,
                               uint64_t* last_observed, uint8_t* voxel_flags, uint32_t* sem_label, int64_t cap_blocks);
 /* give the snapshot's arena back to its context's pool (the context must still exist) */

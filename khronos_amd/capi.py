@@ -647,7 +647,14 @@ class Snapshot:
         k = self.ctx._chk(self.ctx.lib.khr_snapshot_download(self.h, _ptr(out["indices"]), _ptr(out["distance"]), _ptr(out["weight"]),
                                                              _ptr(out["color"]), _ptr(out["last_observed"]), _ptr(out["flags"]),
                                                              _ptr(out["sem_label"]), n))
-        return {a: b[:k] for a, b in out.items()}
+        # the C ABI hands the blocks out in the snapshot's own order; sorted by block index here (tests, small maps)
+        order = np.lexsort((out["indices"][:k, 2], out["indices"][:k, 1], out["indices"][:k, 0]))
+        return {a: b[:k][order] for a, b in out.items()}
+
+    def download_into(self, ptrs, cap_blocks):
+        """raw form: `ptrs` = 7 host addresses (indices, distance, weight, colour, last_observed, flags, label; 0 = skip),
+        e.g. of pinned buffers; blocks in the snapshot's own order.  -> block count"""
+        return self.ctx._chk(self.ctx.lib.khr_snapshot_download(self.h, *[C.c_void_p(p or None) for p in ptrs], int(cap_blocks)))
 
     def release(self):
         if self.h is not None and self.h.value:

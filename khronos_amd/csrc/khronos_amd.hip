@@ -3362,35 +3362,29 @@ int64_t khr_snapshot_download(khr_snapshot* s, int32_t* indices, float* distance
   // the copy kernel itself must have finished, not only published its count: one stream wait here (download = slow path)
   HIP_TRY(hipStreamSynchronize(c->stream));
   const size_t nv = s->nvox;
-  std::vector<int4> idx(static_cast<size_t>(n));
-  HIP_TRY(hipMemcpy(idx.data(), s->d_index, sizeof(int4) * n, hipMemcpyDeviceToHost));
-  std::vector<uint32_t> order(static_cast<size_t>(n));
-  for (int64_t i = 0; i < n; ++i) order[i] = static_cast<uint32_t>(i);
-  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-    return std::make_tuple(idx[a].x, idx[a].y, idx[a].z) < std::make_tuple(idx[b].x, idx[b].y, idx[b].z);
-  });
-  if (indices)
+  // blocks come in the snapshot's own order (the order the device found them in); `indices` says which is which.  Each
+  // field is ONE device -> host copy straight into the caller's array (pinned caller memory gets the full link rate).
+  if (indices) {
+    std::vector<int4> idx(static_cast<size_t>(n));
+    HIP_TRY(hipMemcpy(idx.data(), s->d_index, sizeof(int4) * n, hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < n; ++i) {
-      indices[3 * i] = idx[order[i]].x;
-      indices[3 * i + 1] = idx[order[i]].y;
-      indices[3 * i + 2] = idx[order[i]].z;
+      indices[3 * i] = idx[i].x;
+      indices[3 * i + 1] = idx[i].y;
+      indices[3 * i + 2] = idx[i].z;
     }
-  // per field: one D2H into a host staging vector, then the permutation into the caller's array
-  std::vector<uint8_t> stage;
-  auto field = [&](void* dst, const void* src, size_t elem) -> int {
-    if (!dst || !src) return KHR_OK;
-    const size_t blk = nv * elem;
-    stage.resize(static_cast<size_t>(n) * blk);
-    if (hipMemcpy(stage.data(), src, stage.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(KHR_EDEVICE, "snapshot download failed");
-    for (int64_t i = 0; i < n; ++i) std::memcpy(static_cast<uint8_t*>(dst) + static_cast<size_t>(i) * blk, stage.data() + static_cast<size_t>(order[i]) * blk, blk);
-    return KHR_OK;
+  }
+  hipError_t e = hipSuccess;
+  auto field = [&](void* dst, const void* src, size_t elem) {
+    if (e == hipSuccess && dst && src) e = hipMemcpyAsync(dst, src, static_cast<size_t>(n) * nv * elem, hipMemcpyDeviceToHost, c->stream);
   };
-  if ((rc = field(distance, s->o.dist, 4))) return rc;
-  if ((rc = field(weight, s->o.weight, 4))) return rc;
-  if ((rc = field(color_rgba, s->o.color, 4))) return rc;
-  if ((rc = field(last_observed, s->o.last_obs, 8))) return rc;
-  if ((rc = field(voxel_flags, s->o.vflags, 1))) return rc;
-  if ((rc = field(sem_label, s->o.sem_label, 4))) return rc;
+  field(distance, s->o.dist, 4);
+  field(weight, s->o.weight, 4);
+  field(color_rgba, s->o.color, 4);
+  field(last_observed, s->o.last_obs, 8);
+  field(voxel_flags, s->o.vflags, 1);
+  field(sem_label, s->o.sem_label, 4);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) return fail(KHR_EDEVICE, "snapshot download failed: %s", hipGetErrorString(e));
   return n;
 }
 

@@ -9,6 +9,7 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <cstring>
@@ -205,6 +206,7 @@ struct ActiveWindowOutput {
       const int64_t n = map ? khr_snapshot_num_blocks(map.get()) : 0;
       updated_blocks_.assign(static_cast<size_t>(n > 0 ? n : 0), BlockIndex{0, 0, 0});
       if (n > 0) khr_snapshot_download(map.get(), updated_blocks_[0].data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n);
+      std::sort(updated_blocks_.begin(), updated_blocks_.end());
       indices_valid_ = true;
     }
     return updated_blocks_;
@@ -240,6 +242,7 @@ struct ActiveWindowOutput {
       b.block_flags = 1;  // KHR_BLK_UPDATED: what made it part of the clone
       out.push_back(std::move(b));
     }
+    std::sort(out.begin(), out.end(), [](const BlockCopy& a, const BlockCopy& b) { return a.index < b.index; });
     return out;
   }
   std::vector<BlockCopy> cloneUpdatedTsdf() const { return cloneUpdated(true); }

@@ -88,11 +88,11 @@ typedef struct khr_config {
   int32_t device;     /* HIP device ordinal */
   int32_t rank;       /* owner-computes sharding: this context integrates blocks with owner == rank */
   int32_t world_size; /* 1 = unsharded */
-  /* arithmetic of the voxel update: 1 (default) = every stored value bit-identical to the CPU restatement; 0 = every
-   * decision (validity, band membership, interpolation mode, mask, weight > 0) still exactly as the restatement, but
-   * measurement weight and running average with contracted FMAs and v_rcp_f32 (values within ~1e-6 relative).  On
-   * gfx950 the relaxed mode buys ~2 % of the update kernel (it is bound by memory requests, not arithmetic). */
-  int32_t exact_arithmetic;
+  /* arithmetic of the voxel update: 0 (default, also what a zero-initialised khr_config gets) = every stored value
+   * bit-identical to the CPU restatement; 1 = every decision (validity, band membership, interpolation mode, mask,
+   * weight > 0) still exactly as the restatement, but measurement weight and running average with contracted FMAs and
+   * v_rcp_f32 (values within ~1e-6 relative).  On gfx950 the relaxed mode buys ~2 % of the update kernel. */
+  int32_t relaxed_arithmetic;
 } khr_config;
 
 typedef struct khr_sensor {

@@ -31,7 +31,7 @@ class KhrConfig(C.Structure):
         ("mesh_min_weight", C.c_float),
         ("max_blocks", C.c_uint32), ("max_frame_pixels", C.c_uint32), ("num_frame_slots", C.c_uint32),
         ("max_mesh_vertices", C.c_uint64), ("max_band_records", C.c_uint32), ("disable_culling", C.c_int32),
-        ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32), ("exact_arithmetic", C.c_int32),
+        ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32), ("relaxed_arithmetic", C.c_int32),
     ]
 
 
@@ -202,6 +202,8 @@ def default_config(**overrides):
     cfg = KhrConfig()
     load_library().khr_default_config(C.byref(cfg))
     for k, v in overrides.items():
+        if k == "exact_arithmetic":  # (the C field is the negation: a zero-initialised khr_config means bit-exact values)
+            k, v = "relaxed_arithmetic", 0 if v else 1
         if not hasattr(cfg, k):
             raise KeyError(k)
         setattr(cfg, k, v)

@@ -1238,7 +1238,9 @@ __global__ __launch_bounds__(256) void k_mesh_gather(DevMap m, MeshBuffers mb, c
       }
     }
   };
-  if (!fits) {
+  // marching cubes flagged an overflow: `total` exceeds the vertex buffers and the emit pass wrote nothing -- header only
+  // (reading 3 * total words from the buffers would run past their end); the host reports the overflow from header word 2
+  if (!fits || m.counters[C_MESH_OVERFLOW] != 0u) {
     finish();
     return;
   }
@@ -1405,6 +1407,7 @@ __global__ __launch_bounds__(256) void k_object_prune(DevMap m, DevParams p, flo
   for (uint32_t s = blockIdx.x; s < n_slots; s += gridDim.x) {
     if (!(m.blk_flags[s] & BLK_LIVE)) continue;
     const size_t o = static_cast<size_t>(s) * NV;
+    bool touched = false;
     for (int lin = threadIdx.x; lin < NV; lin += 256) {
       const float d = m.dist[o + lin];
       if (d > 0.f) continue;
@@ -1418,8 +1421,11 @@ __global__ __launch_bounds__(256) void k_object_prune(DevMap m, DevParams p, flo
       if (conf < min_conf) {
         m.dist[o + lin] = p.trunc;
         ++pruned;
+        touched = true;
       }
     }
+    // a rewritten distance voids the tracking pass's per-block shortcuts (it trusts VOX_OCC unless the block is dirty)
+    if (__any(touched) && (threadIdx.x & 63) == 0) atomicOr(&m.blk_flags[s], BLK_TRACK_DIRTY);
   }
   // one statistics atomic per wave (a hot 64-bit address sustains ~90 atomics / us: per-thread adds were most of this kernel)
 #pragma unroll

@@ -480,7 +480,7 @@ int dispatchVps(khr_ctx* c, F&& f) {
 
 int kFuseGrid = 0;      // 0 = resident workgroups of the instantiation (occupancy query) x CUs; env KHR_FUSE_GRID
 int kFuseZsplit = 0;    // 0 = by world size (wave items per x-y patch of a block: 2 / 4 / 8); env KHR_FUSE_ZSPLIT
-int kFuseExact = -1;    // -1 = khr_config.exact_arithmetic; env KHR_FUSE_EXACT=0/1 overrides (A/B switch)
+int kFuseExact = -1;    // -1 = !khr_config.relaxed_arithmetic; env KHR_FUSE_EXACT=0/1 overrides (A/B switch)
 int kFuseWpw = 0;       // env KHR_FUSE_WPW: waves per workgroup of the default instantiation (4, 8, 16; 0 = kFuseWpwDefault)
 int kFuseWavesPerCu = 16;  // env KHR_FUSE_WAVES: resident waves per CU the persistent grid is sized for
 constexpr int kFuseWpwDefault = 12;
@@ -570,7 +570,7 @@ void khr_default_config(khr_config* cfg) {
   cfg->device = 0;
   cfg->rank = 0;
   cfg->world_size = 1;
-  cfg->exact_arithmetic = 1;  // bit-exact values: 2 % slower update kernel than the relaxed mode (measured), so it is the default
+  cfg->relaxed_arithmetic = 0;  // bit-exact values: 2 % slower update kernel than the relaxed mode (measured), so it is the default
 }
 
 // the voxel-size dependent part of DevParams (khr_create, khr_reset_map)
@@ -1210,7 +1210,7 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
   a.K = c->p.K; a.sem_mode = c->p.sem_mode; a.has_color = f.has_color; a.object_id = object_id;
   a.do_sem = (c->p.with_semantics && ((c->p.sem_mode == 1) ? (object_id >= 0 && f.obj != nullptr) : (f.has_label != 0))) ? 1 : 0;
   const bool defcfg = a.range_mode == 0 && a.interp == 2 && a.use_dropoff && !a.const_weight;
-  const bool exact = kFuseExact >= 0 ? kFuseExact != 0 : c->cfg.exact_arithmetic != 0;
+  const bool exact = kFuseExact >= 0 ? kFuseExact != 0 : c->cfg.relaxed_arithmetic == 0;
   int rc = dispatchVps(c, [&](auto vps) {
     constexpr int V = decltype(vps)::value;
     auto launch = [&](auto zsplit) {
@@ -3414,9 +3414,9 @@ int64_t khr_download_mesh(khr_ctx* c, float* points, uint8_t* colors_rgba, uint3
   int rc = c->mesh_stale ? refreshMeshTotals(c) : (c->counters_gen == c->map_gen ? KHR_OK : readCounters(c));
   if (rc) return rc;
   const uint32_t nslots = c->h_counters[C_MAX_SLOT];
+  // (`all` = the whole vertex buffer, blocks archived since the last meshing included: it sizes the staging buffer only;
+  // the caller's capacity is compared with the LIVE blocks' total below)
   const size_t all = c->mesh_total;
-  if (static_cast<int64_t>(all) > cap)
-    return fail(KHR_EINVAL, "mesh has %lld vertices, cap %lld", static_cast<long long>(all), static_cast<long long>(cap));
   const MeshBuffers& mb = c->mesh[c->mesh_cur];
   auto al = [](size_t b) { return (b + 63) & ~static_cast<size_t>(63); };
   const size_t o_idx = 0, o_flag = o_idx + al(sizeof(int4) * nslots), o_desc = o_flag + al(sizeof(uint32_t) * nslots);

@@ -9,6 +9,7 @@
 // include/khronos_amd.h to the gfx950 kernels, the map lives in HBM.  Hydra types are the stand-ins of
 // hydra_compat.h.  Config errors throw std::invalid_argument (the reference aborts in config::checkValid).
 #pragma once
+#include <cstdlib>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -380,6 +381,8 @@ class ObjectWorkerPool {
   std::string error_;
   size_t in_work_ = 0;
   bool should_shutdown_ = false;
+  // env KHR_TEST_EXTRACT_DELAY_MS: every extraction starts this much later (tests of the frame-ring back-pressure)
+  int test_delay_ms_ = std::getenv("KHR_TEST_EXTRACT_DELAY_MS") ? std::atoi(std::getenv("KHR_TEST_EXTRACT_DELAY_MS")) : 0;
 };
 
 class ActiveWindow {
@@ -417,6 +420,8 @@ class ActiveWindow {
     // device-side sizing (no reference equivalent)
     int num_labels = 20;
     uint32_t max_blocks = 16384;
+    int frame_slot_headroom = -1;  // device frame-ring slots beyond max_buffer_size + 1 (-1 = 16 per extraction worker): frames that
+                                   // pending extraction requests still hold after the window dropped them
     uint32_t max_snapshot_blocks = 8192;  // capacity of an output's map snapshot (cloneUpdated): ~100 KB of HBM per block
     uint32_t max_frame_pixels = 1280 * 720;
     uint64_t max_mesh_vertices = 8u << 20;
@@ -445,6 +450,8 @@ class ActiveWindow {
   void setObjectDetector(std::unique_ptr<ObjectDetector> d) { object_detector_ = std::move(d); }
   void setTracker(std::unique_ptr<Tracker> t) { tracker_ = std::move(t); }
 
+  // times spinOnce had to wait for the extraction worker because every device frame slot was leased (diagnostics)
+  size_t numRingWaits() const { return num_ring_waits_; }
   void finishMapping();
   std::vector<std::shared_ptr<KhronosObjectAttributes>> extractObjects();
 
@@ -470,6 +477,7 @@ class ActiveWindow {
   TimeStamp latest_stamp_ = 0;
   TimeStamp last_full_upated_ = 0;
   size_t num_frames_processed_ = 0;
+  mutable size_t num_ring_waits_ = 0;
 };
 
 }  // namespace khronos

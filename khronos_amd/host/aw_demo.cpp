@@ -252,7 +252,7 @@ int main(int argc, char** argv) {
                   o.bounding_box.max[1], o.bounding_box.max[2]);
     }
     aw.finishMapping();
-    std::printf("], \"blocks_after_finish\": %zu", aw.getMap().numBlocks());
+    std::printf("], \"blocks_after_finish\": %zu, \"ring_waits\": %zu", aw.getMap().numBlocks(), aw.numRingWaits());
     if (first_out) {  // the first output's map clone, read only now (every block has been archived by finishMapping)
       double sum = 0;
       const auto blocks = first_out->cloneUpdatedTsdf();

@@ -154,6 +154,24 @@ def test_active_window_host_mirror(tmp_path):
     assert res["blocks_after_finish"] == 0
 
 
+def test_no_frame_is_lost_when_extractions_pin_the_ring(tmp_path):
+    """detached extraction requests hold copies of the frame buffer, i.e. leases on device frame slots the
+    window has already dropped.  With the ring cut down to max_buffer_size + 2 it runs out; spinOnce must
+    then wait for the worker and retry, not drop the frame (the reference has no fixed ring and cannot lose one)."""
+    n_frames = 32
+    y = PLUGIN_YAML.replace("max_buffer_size: 40", "max_buffer_size: 3").replace("  device:\n", "  device:\n    frame_slot_headroom: 1\n")
+    assert "frame_slot_headroom: 1" in y and "max_buffer_size: 3" in y
+    cfgp = tmp_path / "aw_tiny_ring.yaml"
+    cfgp.write_text(y)
+    out = subprocess.run([DEMO, str(cfgp), str(W), str(H), str(n_frames)], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, KHR_TEST_EXTRACT_DELAY_MS="40"))  # a slow extractor: its requests pin frames
+    assert out.returncode == 0, out.stderr
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["sink_calls"] == n_frames  # every frame went through spinOnce's sinks: none was skipped
+    assert res["ring_waits"] >= 1, "the scenario must actually exhaust the ring (otherwise nothing is tested)"
+    assert res["n_outputs"] == len(res["outputs"]) >= 6
+
+
 def test_config_errors_are_loud(tmp_path):
     bad = YAML.replace("temporal_window: *temporal_window", "temporal_window: 0")
     p = tmp_path / "bad.yaml"

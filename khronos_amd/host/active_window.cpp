@@ -473,7 +473,8 @@ void ActiveWindow::Config::checkValid() const {
 }
 
 // ---- ActiveWindow ------------------------------------------------------------------------------------------------
-ActiveWindow::ActiveWindow(const Config& cfg) : config(cfg), frame_data_buffer_(cfg.frame_data_buffer) {
+ActiveWindow::ActiveWindow(const Config& cfg, const OutputQueue::Ptr& output_queue)
+    : hydra::ActiveWindowModule(output_queue), config(cfg), frame_data_buffer_(cfg.frame_data_buffer) {
   config.checkValid();
   khr_config& d = device_config_;
   khr_default_config(&d);

@@ -385,8 +385,9 @@ class ObjectWorkerPool {
   int test_delay_ms_ = std::getenv("KHR_TEST_EXTRACT_DELAY_MS") ? std::atoi(std::getenv("KHR_TEST_EXTRACT_DELAY_MS")) : 0;
 };
 
-class ActiveWindow {
+class ActiveWindow : public hydra::ActiveWindowModule {  // active_window.h:67
  public:
+  using OutputQueue = hydra::ActiveWindowModule::OutputQueue;
   using KhronosSink = std::function<void(const FrameData&, const VolumetricMap&, const Tracks&)>;
 
   struct Config {  // active_window.h:72-96 + declare_config active_window.cpp:50-71
@@ -437,10 +438,13 @@ class ActiveWindow {
     void checkValid() const;  // throws std::invalid_argument
   } const config;
 
-  explicit ActiveWindow(const Config& config);
-  virtual ~ActiveWindow();
+  // active_window.h:99: ActiveWindow(const Config&, const OutputQueue::Ptr&); registered with the string factory under
+  // "ActiveWindow" (active_window.h:190-192; active_window.cpp below) -- `type: "ActiveWindow"` in the mapper YAML
+  ActiveWindow(const Config& config, const OutputQueue::Ptr& output_queue);
+  explicit ActiveWindow(const Config& config) : ActiveWindow(config, nullptr) {}  // (drivers that read spinOnce's return value via step())
+  ~ActiveWindow() override;
 
-  std::string printInfo() const;
+  std::string printInfo() const override;
   // access (not thread-safe, as in the reference)
   VolumetricMap& getMap() { return map_; }
   const VolumetricMap& getMap() const { return map_; }
@@ -455,10 +459,11 @@ class ActiveWindow {
   void finishMapping();
   std::vector<std::shared_ptr<KhronosObjectAttributes>> extractObjects();
 
-  // protected in the reference (called by the Hydra module thread); public here for the driver
-  hydra::ActiveWindowOutput::Ptr spinOnce(const hydra::InputPacket& input);
 
  protected:
+  // called by the module thread (hydra::ActiveWindowModule::step here); active_window.h:134
+  hydra::ActiveWindowOutput::Ptr spinOnce(const hydra::InputPacket& input) override;
+
   std::shared_ptr<FrameData> createData(const hydra::InputPacket& input) const;
   void updateMap(const FrameData& data);
   hydra::ActiveWindowOutput::Ptr extractOutputData(const FrameData& data, bool threaded);
@@ -478,6 +483,9 @@ class ActiveWindow {
   TimeStamp last_full_upated_ = 0;
   size_t num_frames_processed_ = 0;
   mutable size_t num_ring_waits_ = 0;
+
+  // active_window.h:190-192: `active_window: {type: "ActiveWindow", ...}` in the mapper YAML creates this class
+  inline static const hydra::ActiveWindowRegistration<ActiveWindow> registration_{"ActiveWindow"};
 };
 
 }  // namespace khronos

@@ -184,7 +184,8 @@ int main(int argc, char** argv) {
   try {
     ActiveWindow::Config cfg = ActiveWindow::Config::fromYamlString(ss.str());
     cfg.max_frame_pixels = static_cast<uint32_t>(W) * H;
-    ActiveWindow aw(cfg);
+    auto out_queue = std::make_shared<ActiveWindow::OutputQueue>();
+    ActiveWindow aw(cfg, out_queue);
     LabelObjectDetector* det = nullptr;
     if (object_label >= 0) {
       auto d = std::make_unique<LabelObjectDetector>(object_label);
@@ -214,7 +215,7 @@ int main(int argc, char** argv) {
       pkt.color = rgb.data();
       pkt.labels = label.data();
       if (det) det->current_labels = label.data();
-      auto out = aw.spinOnce(pkt);
+      auto out = aw.step(pkt);  // the module thread's iteration: spinOnce (protected) + output queue
       total_dyn_clusters += aw.getLatestFrameData().num_dynamic_clusters;
       total_sem_clusters += aw.getLatestFrameData().semantic_clusters.size();
       if (out) {
@@ -252,7 +253,8 @@ int main(int argc, char** argv) {
                   o.bounding_box.max[1], o.bounding_box.max[2]);
     }
     aw.finishMapping();
-    std::printf("], \"blocks_after_finish\": %zu, \"ring_waits\": %zu", aw.getMap().numBlocks(), aw.numRingWaits());
+    std::printf("], \"blocks_after_finish\": %zu, \"ring_waits\": %zu, \"queued_outputs\": %zu", aw.getMap().numBlocks(), aw.numRingWaits(),
+                out_queue->size());
     if (first_out) {  // the first output's map clone, read only now (every block has been archived by finishMapping)
       double sum = 0;
       const auto blocks = first_out->cloneUpdatedTsdf();

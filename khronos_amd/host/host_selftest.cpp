@@ -1,6 +1,7 @@
 // host_selftest.cpp — GPU-free checks of the host-side logic (run by tests/test_cpu_host.py):
 // YAML-subset loader against the reference's mapper config keys, config validation, FrameDataBuffer
 // store / trim known answers (frame_data_buffer.cpp:57-123), object-map sizing (mesh_object_extractor.cpp:201-228).
+#include <type_traits>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -135,6 +136,15 @@ int main(int argc, char** argv) {
     bool threw = false;
     try { c.checkValid(); } catch (const std::invalid_argument&) { threw = true; }
     CHECK(threw);
+  }
+  // ---- plugin surface (active_window.h:67,99,134,190-192): a hydra::ActiveWindowModule registered as "ActiveWindow" ----
+  {
+    static_assert(std::is_base_of<hydra::ActiveWindowModule, ActiveWindow>::value, "ActiveWindow must be an ActiveWindowModule");
+    static_assert(std::is_constructible<ActiveWindow, const ActiveWindow::Config&, const ActiveWindow::OutputQueue::Ptr&>::value,
+                  "ActiveWindow(const Config&, const OutputQueue::Ptr&)");
+    CHECK(hydra::ActiveWindowFactory::has("ActiveWindow"));
+    CHECK(!hydra::ActiveWindowFactory::has("NoSuchWindow"));
+    CHECK(hydra::ActiveWindowFactory::create("NoSuchWindow", "", nullptr) == nullptr);
   }
   // ---- FrameDataBuffer: capped FIFO (frame_data_buffer.cpp:88-109) ----
   {

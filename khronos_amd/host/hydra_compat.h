@@ -253,6 +253,88 @@ struct ActiveWindowOutput {
 };
 
 
+// ---- hydra::ActiveWindowModule role (the base class of khronos::ActiveWindow, active_window.h:67) ---------------------------
+// The Hydra module owns the output queue and the module thread: the thread takes an InputPacket, calls the protected
+// virtual spinOnce and pushes a non-null result to the queue (the hydra frontend pops it later: hence the snapshot in
+// ActiveWindowOutput::map).  The stand-in keeps exactly that surface: constructor (config, output queue), virtual
+// printInfo, protected pure-virtual spinOnce, and `step` as the body of the module thread's loop.
+template <typename T>
+struct InputQueue {  // hydra::InputQueue role (a mutex-guarded deque)
+  using Ptr = std::shared_ptr<InputQueue<T>>;
+  void push(const T& v) {
+    std::lock_guard<std::mutex> lock(mutex);
+    queue.push_back(v);
+  }
+  bool pop(T* out) {
+    std::lock_guard<std::mutex> lock(mutex);
+    if (queue.empty()) return false;
+    *out = queue.front();
+    queue.erase(queue.begin());
+    return true;
+  }
+  size_t size() const {
+    std::lock_guard<std::mutex> lock(mutex);
+    return queue.size();
+  }
+  mutable std::mutex mutex;
+  std::vector<T> queue;
+};
+
+class ActiveWindowModule {
+ public:
+  using OutputQueue = InputQueue<ActiveWindowOutput::Ptr>;
+  ActiveWindowModule(const OutputQueue::Ptr& output_queue) : output_queue_(output_queue) {}
+  virtual ~ActiveWindowModule() = default;
+  virtual std::string printInfo() const { return ""; }
+  // one iteration of the module thread (hydra: ActiveWindowModule::spin): process a packet, queue the output if there is one
+  ActiveWindowOutput::Ptr step(const InputPacket& input) {
+    ActiveWindowOutput::Ptr out = spinOnce(input);
+    if (out && output_queue_) output_queue_->push(out);
+    return out;
+  }
+  const OutputQueue::Ptr& outputQueue() const { return output_queue_; }
+
+ protected:
+  virtual ActiveWindowOutput::Ptr spinOnce(const InputPacket& input) = 0;
+  OutputQueue::Ptr output_queue_;
+};
+
+// config_utilities string factory role (config::RegistrationWithConfig<Base, Derived, Config, Args...>(name) /
+// config::createFromYaml): the pipeline selects the active window by `active_window: {type: "<name>", ...}`
+// (uHumans2.yaml:35-36; registration at active_window.h:190-192).  The creator receives the text of the `active_window:`
+// mapping's document and the output queue.
+class ActiveWindowFactory {
+ public:
+  using Creator = std::function<std::unique_ptr<ActiveWindowModule>(const std::string& yaml_text, const ActiveWindowModule::OutputQueue::Ptr&)>;
+  static bool add(const std::string& type, Creator c) {
+    registry()[type] = std::move(c);
+    return true;
+  }
+  static bool has(const std::string& type) { return registry().count(type) != 0; }
+  static std::unique_ptr<ActiveWindowModule> create(const std::string& type, const std::string& yaml_text,
+                                                    const ActiveWindowModule::OutputQueue::Ptr& queue) {
+    auto it = registry().find(type);
+    return it == registry().end() ? nullptr : it->second(yaml_text, queue);
+  }
+
+ private:
+  static std::map<std::string, Creator>& registry() {
+    static std::map<std::string, Creator> r;
+    return r;
+  }
+};
+// config::RegistrationWithConfig<ActiveWindowModule, Derived, Derived::Config, OutputQueue::Ptr>(name) role: a static
+// member of this type inside Derived registers it (the creator is only instantiated once Derived is complete)
+template <typename Derived>
+struct ActiveWindowRegistration {
+  explicit ActiveWindowRegistration(const std::string& name) {
+    ActiveWindowFactory::add(name, [](const std::string& yaml_text, const ActiveWindowModule::OutputQueue::Ptr& queue) {
+      return std::unique_ptr<ActiveWindowModule>(new Derived(Derived::Config::fromYamlString(yaml_text), queue));
+    });
+  }
+};
+
+
 // ---- hydra::timing (ElapsedTimeRecorder / ScopedTimer role) ------------------------------------------------------------
 // The reference brackets its stages with `Timer timer("<scope>", stamp)` (active_window.cpp:121,152,204,220,269;
 // tracking_integrator.cpp:72; free_space_motion_detector.cpp:75; connected_semantics.cpp:61; max_iou_tracker.cpp:200,217)

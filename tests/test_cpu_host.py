@@ -212,3 +212,21 @@ def test_host_library_exports_the_sharded_tick_abi():
     # the loader sets prototypes for all of them
     lib2 = host_capi.load_host_library()
     assert lib2.kdist_create.restype is ctypes.c_void_p
+
+
+def test_integration_snippet_compiles(tmp_path):
+    """The `ActiveWindowHip` translation unit INTEGRATION.md shows a Khronos maintainer (the reference-side binding of the
+    C ABI: a hydra::ActiveWindowModule with the (config, output queue) constructor, protected spinOnce, factory
+    registration) is compiled against the stand-in Hydra types, so the document cannot drift from the headers."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    m = re.search(r"<!-- snippet:active_window_hip:begin -->\s*```cpp\n(.*?)```\s*<!-- snippet:active_window_hip:end -->", text, re.S)
+    assert m, "INTEGRATION.md lost its ActiveWindowHip snippet markers"
+    src = tmp_path / "active_window_hip.cpp"
+    # (one extra line instantiates the factory entry, so that the registration lambda and the constructor are compiled too)
+    src.write_text(m.group(1) + "\nint main() { return hydra::ActiveWindowFactory::has(\"ActiveWindowHip\") ? 0 : 1; }\n")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(root, "include"),
+                        "-I", os.path.join(root, "khronos_amd", "host"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

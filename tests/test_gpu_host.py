@@ -105,6 +105,7 @@ def test_active_window_host_mirror(tmp_path):
             outputs.append({"stamp": fr["stamp"], "updated": upd, "archived": arch, "objects": 0})
             last_full = fr["stamp"]
     assert res["outputs"] == outputs
+    assert res["queued_outputs"] == len(outputs)  # hydra::ActiveWindowModule: every non-null spinOnce result went to the output queue
     # the C++ class read its first output's map clone at the very end (after finishMapping archived every block): it must
     # hold what the map held at output time (snapshot semantics of ActiveWindowOutput::map)
     assert res["first_output_clone"]["blocks"] == first_clone[0] > 0

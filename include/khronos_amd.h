@@ -391,7 +391,8 @@ int64_t khr_snapshot_num_blocks(khr_snapshot* snap);
  * block count. */
 int64_t khr_snapshot_download(khr_snapshot* snap, int32_t* indices, float* distance, float* weight, uint8_t* color_rgba,
                               uint64_t* last_observed, uint8_t* voxel_flags, uint32_t* sem_label, int64_t cap_blocks);
-/* give the snapshot's arena back to its context's pool (the context must still exist) */
+/* give the snapshot's arena back to its context's pool (safe after khr_destroy too: the arena is then freed; a
+ * download after khr_destroy fails with KHR_ESTATE) */
 void khr_snapshot_release(khr_snapshot* snap);
 /* mesh produced by the last khr_generate_mesh calls, concatenated over blocks in sorted block order
  * (utils::combineMeshLayer, geometry_utils.cpp:61-86; faces are implicit: vertex 3i,3i+1,3i+2).

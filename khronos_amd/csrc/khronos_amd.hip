@@ -135,8 +135,14 @@ struct khr_ctx {
   uint32_t item_cap = 0;          // max_blocks x wave items per block
   // snapshots of the updated blocks (khr_snapshot_updated): arenas of released snapshots are reused
   struct SnapArena { uint8_t* ptr; size_t bytes; volatile uint32_t* h_count; uint32_t* d_count_host_view; };
-  std::vector<SnapArena> snap_free;
-  std::mutex snap_mu;
+  // shared with the snapshots handed out: an output may outlive its ActiveWindow in the consumer's queue, so a release
+  // after khr_destroy must still be safe (it then frees the arena instead of pooling it)
+  struct SnapPool {
+    std::mutex mu;
+    std::vector<SnapArena> free;
+    bool dead = false;
+  };
+  std::shared_ptr<SnapPool> snap_pool = std::make_shared<SnapPool>();
   khr_snapshot* pending_snapshot = nullptr;  // taken inside khr_process_frame(KHR_PF_SNAPSHOT)
   uint32_t snap_ticket = 0;
   uint32_t wpb = 0;               // wave items per block of this context's k_fuse instantiation
@@ -590,8 +596,20 @@ int khr_retain_slot(khr_ctx* c, int slot) {
   return KHR_OK;
 }
 
+// contexts that exist: a slot lease may be dropped after its context is gone (an output that carries a copy of the frame's
+// InputData can sit in the consumer's queue longer than the ActiveWindow lives); that release must be a no-op, not a
+// use-after-free
+static std::mutex g_live_mu;
+static std::vector<khr_ctx*> g_live_ctx;
+static bool ctxIsLive(khr_ctx* c) {
+  std::lock_guard<std::mutex> lock(g_live_mu);
+  return std::find(g_live_ctx.begin(), g_live_ctx.end(), c) != g_live_ctx.end();
+}
+
 int khr_release_slot(khr_ctx* c, int slot) {
-  if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size())) return fail(KHR_EINVAL, "bad slot");
+  if (!c) return fail(KHR_EINVAL, "bad slot");
+  if (!ctxIsLive(c)) return KHR_OK;  // the context (and with it the frame ring) is gone: nothing to give back
+  if (slot < 0 || slot >= static_cast<int>(c->slots.size())) return fail(KHR_EINVAL, "bad slot");
   // decrement only while positive (leases are taken and dropped by the frame thread and by detached extraction workers:
   // an unmatched release must not erase a lease somebody else takes at the same moment)
   int cur = c->slot_leases[slot].load(std::memory_order_acquire);
@@ -897,12 +915,20 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     khr_destroy(c);
     return fail(KHR_EDEVICE, "context initialisation failed: %s", hipGetErrorString(e));
   }
+  {
+    std::lock_guard<std::mutex> lock(g_live_mu);
+    g_live_ctx.push_back(c);
+  }
   *out = c;
   return KHR_OK;
 }
 
 void khr_destroy(khr_ctx* c) {
   if (!c) return;
+  {
+    std::lock_guard<std::mutex> lock(g_live_mu);
+    g_live_ctx.erase(std::remove(g_live_ctx.begin(), g_live_ctx.end(), c), g_live_ctx.end());
+  }
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
@@ -914,9 +940,14 @@ void khr_destroy(khr_ctx* c) {
   if (c->d_pix_scratch) hipFree(c->d_pix_scratch);
   if (c->d_inst) hipFree(c->d_inst);
   if (c->pending_snapshot) khr_snapshot_release(c->pending_snapshot);
-  for (auto& a : c->snap_free) {
-    hipFree(a.ptr);
-    hipHostFree(const_cast<uint32_t*>(a.h_count));
+  {
+    std::lock_guard<std::mutex> lock(c->snap_pool->mu);
+    c->snap_pool->dead = true;  // snapshots still held by a consumer free their arenas themselves from now on
+    for (auto& a : c->snap_pool->free) {
+      hipFree(a.ptr);
+      hipHostFree(const_cast<uint32_t*>(a.h_count));
+    }
+    c->snap_pool->free.clear();
   }
   if (c->h_pinned) hipHostFree(c->h_pinned);
   if (c->h_stage) hipHostFree(c->h_stage);
@@ -3221,7 +3252,9 @@ int64_t khr_download_updated(khr_ctx* c, int32_t* indices, float* distance, floa
 
 // ---- snapshot of the updated blocks (VolumetricMap::cloneUpdated, active_window.cpp:229) --------------------------------
 struct khr_snapshot {
-  khr_ctx* ctx = nullptr;
+  khr_ctx* ctx = nullptr;  // valid while !pool->dead
+  std::shared_ptr<khr_ctx::SnapPool> pool;
+  int device = 0;
   khr_ctx::SnapArena arena{};
   uint32_t fields = 0, cap = 0, nvox = 0, ticket = 0;
   // carved from the arena
@@ -3255,13 +3288,14 @@ int khr_snapshot_updated(khr_ctx* c, uint32_t fields, int64_t cap_blocks, khr_sn
   const size_t need = snapBytes(fields, cap, nvox, trk, sem);
   auto snap = std::make_unique<khr_snapshot>();
   {
-    std::lock_guard<std::mutex> lock(c->snap_mu);
-    size_t best = c->snap_free.size();
-    for (size_t i = 0; i < c->snap_free.size(); ++i)
-      if (c->snap_free[i].bytes >= need && (best == c->snap_free.size() || c->snap_free[i].bytes < c->snap_free[best].bytes)) best = i;
-    if (best < c->snap_free.size()) {
-      snap->arena = c->snap_free[best];
-      c->snap_free.erase(c->snap_free.begin() + static_cast<long>(best));
+    auto& fr = c->snap_pool->free;
+    std::lock_guard<std::mutex> lock(c->snap_pool->mu);
+    size_t best = fr.size();
+    for (size_t i = 0; i < fr.size(); ++i)
+      if (fr[i].bytes >= need && (best == fr.size() || fr[i].bytes < fr[best].bytes)) best = i;
+    if (best < fr.size()) {
+      snap->arena = fr[best];
+      fr.erase(fr.begin() + static_cast<long>(best));
     }
   }
   if (!snap->arena.ptr) {
@@ -3285,6 +3319,8 @@ int khr_snapshot_updated(khr_ctx* c, uint32_t fields, int64_t cap_blocks, khr_sn
     snap->arena.d_count_host_view = static_cast<uint32_t*>(dv);
   }
   snap->ctx = c;
+  snap->pool = c->snap_pool;
+  snap->device = c->device;
   snap->fields = fields;
   snap->cap = static_cast<uint32_t>(cap);
   snap->nvox = static_cast<uint32_t>(nvox);
@@ -3313,8 +3349,8 @@ int khr_snapshot_updated(khr_ctx* c, uint32_t fields, int64_t cap_blocks, khr_sn
     e = hipGetLastError();
   }
   if (e != hipSuccess) {
-    std::lock_guard<std::mutex> lock(c->snap_mu);
-    c->snap_free.push_back(snap->arena);
+    std::lock_guard<std::mutex> lock(c->snap_pool->mu);
+    c->snap_pool->free.push_back(snap->arena);
     return fail(KHR_EDEVICE, "snapshot launch failed: %s", hipGetErrorString(e));
   }
   *out = snap.release();
@@ -3357,6 +3393,10 @@ int64_t khr_snapshot_download(khr_snapshot* s, int32_t* indices, float* distance
   const int64_t n = s->n;
   if (n > cap_blocks) return fail(KHR_EINVAL, "%lld blocks in the snapshot, cap %lld", static_cast<long long>(n), static_cast<long long>(cap_blocks));
   if (n == 0) return 0;
+  {
+    std::lock_guard<std::mutex> lock(s->pool->mu);
+    if (s->pool->dead) return fail(KHR_ESTATE, "the snapshot's context has been destroyed");
+  }
   khr_ctx* c = s->ctx;
   HIP_TRY(hipSetDevice(c->device));
   // the copy kernel itself must have finished, not only published its count: one stream wait here (download = slow path)
@@ -3390,11 +3430,17 @@ int64_t khr_snapshot_download(khr_snapshot* s, int32_t* indices, float* distance
 
 void khr_snapshot_release(khr_snapshot* s) {
   if (!s) return;
-  khr_ctx* c = s->ctx;
-  // the arena may be handed to the next snapshot right away: that one's kernels are queued behind this one's on the same stream
+  // the arena may be handed to the next snapshot right away: that one's kernels are queued behind this one's on the same
+  // stream.  After khr_destroy (the consumer kept an output longer than the window lived) the arena is simply freed.
   {
-    std::lock_guard<std::mutex> lock(c->snap_mu);
-    c->snap_free.push_back(s->arena);
+    std::lock_guard<std::mutex> lock(s->pool->mu);
+    if (s->pool->dead) {
+      hipSetDevice(s->device);
+      hipFree(s->arena.ptr);
+      hipHostFree(const_cast<uint32_t*>(s->arena.h_count));
+    } else {
+      s->pool->free.push_back(s->arena);
+    }
   }
   delete s;
 }

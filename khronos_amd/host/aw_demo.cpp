@@ -3,6 +3,9 @@
 // summary that tests/test_gpu_host.py compares with the step-wise C-ABI path and the oracle.
 // usage: aw_demo <config.yaml> <width> <height> <frames> [object_label]
 //   object_label >= 0: the stand-in detector / tracker below; otherwise the plugins named in the config
+#include <execinfo.h>
+#include <csignal>
+#include <unistd.h>
 #include <cinttypes>
 #include <cmath>
 #include <cstdio>
@@ -163,7 +166,18 @@ static int rayverDemo(const char* policy) {
   return 0;
 }
 
+static void onSegv(int sig) {  // a crash must not look like an empty result: print where it happened
+  void* bt[48];
+  const int n = backtrace(bt, 48);
+  const char msg[] = "aw_demo: fatal signal, backtrace:\n";
+  (void)!write(2, msg, sizeof(msg) - 1);
+  backtrace_symbols_fd(bt, n, 2);
+  _exit(128 + sig);
+}
+
 int main(int argc, char** argv) {
+  std::signal(SIGSEGV, onSegv);
+  std::signal(SIGABRT, onSegv);
   if (argc >= 3 && std::string(argv[1]) == "--rayver") {
     try {
       return rayverDemo(argv[2]);
@@ -202,6 +216,7 @@ int main(int argc, char** argv) {
     std::vector<int32_t> label(static_cast<size_t>(W) * H);
     std::printf("{\"info\": \"%s\", \"outputs\": [", aw.printInfo().c_str());
     int n_out = 0;
+    size_t n_popped = 0;
     hydra::ActiveWindowOutput::Ptr first_out;  // kept like the frontend's queue keeps it: read after the map has moved on
     size_t total_dyn_clusters = 0, total_sem_clusters = 0;
     for (int i = 0; i < N; ++i) {
@@ -216,6 +231,10 @@ int main(int argc, char** argv) {
       pkt.labels = label.data();
       if (det) det->current_labels = label.data();
       auto out = aw.step(pkt);  // the module thread's iteration: spinOnce (protected) + output queue
+      {  // the consumer (hydra frontend role): takes what the module queued
+        hydra::ActiveWindowOutput::Ptr popped;
+        while (out_queue->pop(&popped)) n_popped += popped == out ? 1 : 0;
+      }
       total_dyn_clusters += aw.getLatestFrameData().num_dynamic_clusters;
       total_sem_clusters += aw.getLatestFrameData().semantic_clusters.size();
       if (out) {
@@ -254,7 +273,7 @@ int main(int argc, char** argv) {
     }
     aw.finishMapping();
     std::printf("], \"blocks_after_finish\": %zu, \"ring_waits\": %zu, \"queued_outputs\": %zu", aw.getMap().numBlocks(), aw.numRingWaits(),
-                out_queue->size());
+                n_popped);
     if (first_out) {  // the first output's map clone, read only now (every block has been archived by finishMapping)
       double sum = 0;
       const auto blocks = first_out->cloneUpdatedTsdf();

@@ -80,12 +80,15 @@ struct InputData {
   const Sensor& getSensor() const { return sensor; }
   const double* getSensorPose() const { return world_T_sensor; }
   // host copies (range image H*W, world-frame vertex map H*W*3)
+  // (empty for a copy that does not hold the frame slot any more: ActiveWindowOutput::sensor_data)
   std::vector<float> rangeImage() const {
+    if (!ctx || slot < 0) return {};
     std::vector<float> r(static_cast<size_t>(sensor.width) * sensor.height);
     khr_download_frame(ctx, slot, r.data(), nullptr, nullptr);
     return r;
   }
   std::vector<float> vertexMap() const {
+    if (!ctx || slot < 0) return {};
     std::vector<float> v(static_cast<size_t>(sensor.width) * sensor.height * 3);
     khr_download_frame(ctx, slot, nullptr, v.data(), nullptr);
     return v;

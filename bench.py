@@ -43,7 +43,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", choices=["c1", "c2", "c3"], default="c3", help="BASELINE.json workload preset (see module docstring)")
+    ap.add_argument("--config", choices=["c1", "c2", "c3", "c4", "c5"], default="c3",
+                    help="BASELINE.json workload preset (see module docstring); c4 / c5 are the rig geometries (per camera: c4 = c3's, "
+                         "c5 = 1920x1080 at 1 cm) and are meant for --gpus N or --emulate-world N (4 / 8 cameras)")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--voxel-size", type=float, default=None)
@@ -74,22 +76,32 @@ def parse_args():
     ap.add_argument("--no-roofline-timers", action="store_true")
     ap.add_argument("--all-timers", action="store_true", help="HIP-event timers on every kernel group (slower host path)")
     ap.add_argument("--frame-times", action="store_true", help="debug: synchronise and print per-frame wall times")
-    ap.add_argument("--mesh-req-cap", type=int, default=16384, help="mesh halo requests all-gathered per rank (N > 1)")
-    ap.add_argument("--mesh-rec-cap", type=int, default=2048, help="mesh halo records all-gathered per rank (N > 1)")
+    ap.add_argument("--mesh-req-cap", type=int, default=None, help="mesh halo requests all-gathered per rank (N > 1); default 16384 (c5: 131072)")
+    ap.add_argument("--mesh-rec-cap", type=int, default=None, help="mesh halo records all-gathered per rank (N > 1); default 2048 (c5: 32768)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="development: ONE process plays rank 0 of an N-rank sharded run (all N cameras rendered locally, no "
                          "collectives) to measure the per-rank tick cost on a 1-GPU box; the JSON line is marked emulation")
     ap.add_argument("--dist-host", choices=["cxx", "torch"], default="cxx",
                     help="N > 1: who issues the tick's collectives: cxx = RCCL from libkhronos_amd_host.so (kdist_*, the product "
                          "path), torch = khronos_amd/distributed.py over torch.distributed (the protocol test harness)")
-    ap.add_argument("--halo-cap", type=int, default=8192, help="halo records all-gathered per rank and tick (N > 1)")
+    ap.add_argument("--halo-cap", type=int, default=None, help="halo records all-gathered per rank and tick (N > 1); default 8192 (c5: 65536)")
     a = ap.parse_args()
     preset = {"c3": dict(width=1280, height=720, voxel_size=0.02, output_every=4, no_motion=False, no_objects=False, no_tracking=False, preroll=60),
               "c2": dict(width=640, height=480, voxel_size=0.05, output_every=1, no_motion=True, no_objects=True, no_tracking=False, preroll=0),
-              "c1": dict(width=640, height=480, voxel_size=0.05, output_every=0, no_motion=True, no_objects=True, no_tracking=True, preroll=0)}[a.config]
+              "c1": dict(width=640, height=480, voxel_size=0.05, output_every=0, no_motion=True, no_objects=True, no_tracking=True, preroll=0),
+              # BASELINE configs[3]: 4-camera rig, per camera the c3 stream; configs[4]: 8 cameras 1920x1080 at 1 cm (~8x the
+              # blocks per camera: larger exchange buffers; the pre-roll is shorter because a tick is ~10x a c3 frame)
+              "c4": dict(width=1280, height=720, voxel_size=0.02, output_every=4, no_motion=False, no_objects=False, no_tracking=False, preroll=60),
+              "c5": dict(width=1920, height=1080, voxel_size=0.01, output_every=4, no_motion=False, no_objects=False, no_tracking=False, preroll=40,
+                         mesh_req_cap=131072, mesh_rec_cap=32768, halo_cap=65536)}[a.config]
     for k, v in preset.items():
         if getattr(a, k) is None:
             setattr(a, k, v)
+    for k, v in dict(mesh_req_cap=16384, mesh_rec_cap=2048, halo_cap=8192).items():
+        if getattr(a, k) is None:
+            setattr(a, k, v)
+    if a.config == "c5" and a.max_blocks == 40960:
+        a.max_blocks = 65536
     return a
 
 
@@ -410,11 +422,15 @@ def main():
     if args.frame_times and rank == 0:
         print("frame_times(us, seeds):", ft, file=sys.stderr)
     _trace(_tags["join_begin"])
+    t_join0 = time.perf_counter()
     if pipe is not None:
         pipe.finish_frame()
         obj_stats[0] += pipe.join()  # detached object extractions still running on the worker thread / its stream
     sync_all()
     dt = time.perf_counter() - t0
+    # how the timed region splits: queueing the K steps (the host runs ahead of the GPU by at most the motion detector's seed
+    # count) and the wait at the end for the device and for the detached object extractions that the steps started
+    timed_split = {"steps_ms": 1e3 * (t_join0 - t0), "drain_and_join_ms": 1e3 * (t0 + dt - t_join0)}
     _trace(_tags["timed_end"])
     ctx.timing_enable(False)
     st1 = ctx.stats()
@@ -455,14 +471,18 @@ def main():
     frames = args.steps * world  # camera frames fused by the whole job
     # the label names a BASELINE config only when the arguments ARE that config
     ref = {"c3": (1280, 720, 0.02, 4, False, False, False), "c2": (640, 480, 0.05, 1, True, True, False),
-           "c1": (640, 480, 0.05, 0, True, True, True)}[args.config]
+           "c1": (640, 480, 0.05, 0, True, True, True), "c4": (1280, 720, 0.02, 4, False, False, False),
+           "c5": (1920, 1080, 0.01, 4, False, False, False)}[args.config]
     preset_matches = (W, H, vs, args.output_every, bool(args.no_motion), bool(args.no_objects), bool(args.no_tracking)) == ref and K == 20
     preset_name = ({"c3": "BASELINE configs[2]: ", "c2": "BASELINE configs[1] (synthetic stand-in for the tesse_cd_office replay): ",
-                    "c1": "BASELINE configs[0] (projective integrator alone): "}[args.config]) if preset_matches else "custom: "
+                    "c1": "BASELINE configs[0] (projective integrator alone): ",
+                    "c4": "BASELINE configs[3] geometry (per camera; %d camera(s) here): " % world,
+                    "c5": "BASELINE configs[4] geometry (per camera; %d camera(s) here): " % world}[args.config]) if preset_matches else "custom: "
     fps = frames / dt
     out = {
         "metric": "active-window frames/sec (+ Mvoxel-updates/sec) at %dx%d RGB-D+labels, %g cm voxels" % (W, H, vs * 100),
         "latency_ms_per_frame": lat_ms,
+        "timed_region": timed_split,
         "value": fps, "unit": "frames/s", "n_gpus": 1 if emu else world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -80,7 +80,23 @@ __device__ inline float divExact(float a, float b, float y) {
 
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));  // two adjacent pixels, 4-byte aligned
 
-struct FuseArgs {
+// what changes from frame to frame: images, camera, stamp, per-frame switches.  A single-frame launch carries it inside
+// its kernel arguments (FuseArgs derives from it); k_fuse2<.., MULTI> reads an array of these from device memory and
+// walks an item through all of them in order (object extraction: a track's buffered frames in one launch).
+struct FuseFrame {
+  const float* range;
+  const int32_t* dyn;
+  const uint32_t* rgba;
+  const int32_t* label;
+  const int32_t* obj;
+  int W, H;
+  float fx, fy, cx, cy, min_range, max_range;
+  float R[9], t[3];
+  uint64_t stamp;
+  int use_mask, do_sem, has_color, object_id;
+};
+
+struct FuseArgs : FuseFrame {
   // map
   const int4* blk_index;
   uint32_t* blk_flags;
@@ -93,24 +109,21 @@ struct FuseArgs {
   float* lik;
   uint32_t* wg_stats;  // [2 * gridDim.x]: {n_upd, n_band} accumulated per workgroup slot
   uint16_t* blk_band;  // [slot][kBandSlots]: in-band voxels of each wave item at this update
-  // frame
-  const float* range;
-  const int32_t* dyn;
-  const uint32_t* rgba;
-  const int32_t* label;
-  const int32_t* obj;
-  int W, H;
-  float fx, fy, cx, cy, min_range, max_range;
-  float R[9], t[3];
-  uint64_t stamp;
   // parameters
   float vs, bs, trunc, dropoff_eps, max_weight, adaptive_diff, log_match, log_nomatch;
-  int interp, range_mode, use_dropoff, const_weight, with_tracking, use_mask;
-  int K, sem_mode, do_sem, has_color, object_id;
+  int interp, range_mode, use_dropoff, const_weight, with_tracking;
+  int K, sem_mode;
   unsigned long long* dbg_buf;  // DBG & 64: per-wave timeline {start, end, band cycles, items, rounds, records, max item cycles, hw id}
   int dbg;  // ablation switches of the DBG instantiation (env KHR_FUSE_DBG): 1 no band phase, 2 no voxel stores,
             // 4 no distance / weight loads, 8 range gathers from a fixed address, 16 geometry only
   int band_mode;  // 0 = lane <-> record (fuseBandRecord, default), 1 = record-cooperative (fuseBandCoop; env KHR_FUSE_BAND)
+  // speculative launch (khr_process_frame): the kernel is queued BEFORE the host has seen the motion detector's seed count
+  // and does nothing when *gate != 0 (seeds exist: the host then queues the clustering chain and the real launch).  Frames
+  // without seeds -- most of them -- no longer idle the main stream for the seed count's trip to the host and back.
+  const uint32_t* gate;
+  // k_fuse2<.., MULTI>: the frames an item is walked through, in order
+  const FuseFrame* frames;
+  int n_frames;
 };
 
 constexpr int kFuseCap = 256;        // in-band records a wave collects before it works them off (one 4-z chunk of a patch)
@@ -119,17 +132,19 @@ constexpr int kFuseCap = 256;        // in-band records a wave collects before i
 // `a` points into the kernel-argument segment: the fields only this phase needs (image / layer pointers, label
 // parameters) are scalar loads issued here, instead of ~40 SGPRs kept alive through the voxel loop.
 typedef const FuseArgs __attribute__((address_space(4))) * FuseArgsK;
+typedef const FuseFrame __attribute__((address_space(4))) * FuseFrameK;  // a frame's arguments, through the scalar cache
 constexpr int kLikVec = 5;  // float4 likelihood vectors a lane holds at once (K = 20 in one round trip)
 template <int VPS, bool DBG = false>
-__device__ inline void fuseBandRecord(FuseArgsK ka, size_t slot, uint32_t lin_mode, float w, float w_new, float u, float v,
+__device__ inline void fuseBandRecord(FuseArgsK ka, FuseFrameK kf, size_t slot, uint32_t lin_mode, float w, float w_new, float u, float v,
                                       unsigned long long* tacc = nullptr) {
   (void)tacc;
   constexpr int NV = VPS * VPS * VPS;
   const FuseArgs __attribute__((address_space(4)))& a = *ka;
+  const FuseFrame __attribute__((address_space(4)))& f = *kf;
   const uint32_t lin = lin_mode & 0xffffu;
   const bool use_nearest = (lin_mode & 0x10000u) != 0;
   const int K = a.K;
-  const bool has_color = a.has_color != 0, do_sem = a.do_sem != 0, vec = (K & 3) == 0;
+  const bool has_color = f.has_color != 0, do_sem = f.do_sem != 0, vec = (K & 3) == 0;
   // block bases are wave-uniform (SGPRs), the voxel adds a 32-bit byte offset
   char* const color_b = reinterpret_cast<char*>(a.color + slot * NV);
   char* const vfl_b = reinterpret_cast<char*>(a.vflags + slot * NV);
@@ -138,14 +153,14 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, size_t slot, uint32_t lin_mo
   const uint32_t lik_o = lin * static_cast<uint32_t>(K) * 4u;
   int px4[4];
   float du, dv, w4[4];
-  interpPixels(u, v, a.W, a.H, px4, &du, &dv);
+  interpPixels(u, v, f.W, f.H, px4, &du, &dv);
   const int best = interpWeights(du, dv, use_nearest, w4);
   const uint32_t best_o = static_cast<uint32_t>(px4[best]) * 4u;
   // ---- every load of the record is issued here, before the first store: a memory round trip costs 1.5 - 2 us under
   //      this kernel's load and vmcnt retires in order, so each load placed behind a store waits for that store too ----
   uint32_t c4[4] = {0u, 0u, 0u, 0u}, co = 0u;
   if (has_color) {
-    const char* const rgba_b = reinterpret_cast<const char*>(a.rgba);
+    const char* const rgba_b = reinterpret_cast<const char*>(f.rgba);
 #pragma unroll
     for (int k = 0; k < 4; ++k) c4[k] = *reinterpret_cast<const uint32_t*>(rgba_b + static_cast<uint32_t>(px4[k]) * 4u);
     co = *reinterpret_cast<const uint32_t*>(color_b + lin * 4u);
@@ -154,8 +169,8 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, size_t slot, uint32_t lin_mo
   uint8_t fl = 0;
   float4 l4[kLikVec];
   if (do_sem) {
-    label = (a.sem_mode == 1) ? ((*reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.obj) + best_o) == a.object_id) ? 1 : 0)
-                              : *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.label) + best_o);
+    label = (a.sem_mode == 1) ? ((*reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(f.obj) + best_o) == f.object_id) ? 1 : 0)
+                              : *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(f.label) + best_o);
     fl = *reinterpret_cast<const uint8_t*>(vfl_b + lin);
     if (vec) {  // a voxel without VOX_SEM_VALID holds no likelihoods yet: what is loaded is replaced by zeros below
 #pragma unroll
@@ -255,11 +270,12 @@ __device__ inline bool fuseBandCoopOk(int K, int sem_mode, int do_sem) {
   return !do_sem || (sem_mode != 1 && (K & 3) == 0 && K >= 4 && K <= 64);
 }
 template <int VPS, int CAP = kFuseCap>
-__device__ __forceinline__ void fuseBandCoop(FuseArgsK ka, size_t slot, const uint32_t* rec, uint32_t cnt, int lane) {
+__device__ __forceinline__ void fuseBandCoop(FuseArgsK ka, FuseFrameK kf, size_t slot, const uint32_t* rec, uint32_t cnt, int lane) {
   constexpr int NV = VPS * VPS * VPS;
   const FuseArgs __attribute__((address_space(4)))& a = *ka;
+  const FuseFrame __attribute__((address_space(4)))& f = *kf;
   const int K = a.K;
-  const bool has_color = a.has_color != 0, do_sem = a.do_sem != 0;
+  const bool has_color = f.has_color != 0, do_sem = f.do_sem != 0;
   const uint32_t lpr = do_sem ? static_cast<uint32_t>(K) >> 2 : 1u;  // lanes per record in part B
   const uint32_t rpp = 64u / lpr;                                     // records per part-B pass
   const uint32_t npass = (64u + rpp - 1u) / rpp;
@@ -284,13 +300,13 @@ __device__ __forceinline__ void fuseBandCoop(FuseArgsK ka, size_t slot, const ui
     const uint32_t lin = lin_mode & 0xffffu;
     int px4[4];
     float du, dv, w4[4];
-    interpPixels(u, v, a.W, a.H, px4, &du, &dv);
+    interpPixels(u, v, f.W, f.H, px4, &du, &dv);
     const int best = interpWeights(du, dv, (lin_mode & 0x10000u) != 0, w4);
     const bool last_col = px4[2] == px4[0];
     u2u ca = {0u, 0u}, cb = {0u, 0u};
     uint32_t co = 0u;
     if (has_color && valid && !(bdbg & 1024)) {
-      const char* const rgba_b = reinterpret_cast<const char*>(a.rgba);
+      const char* const rgba_b = reinterpret_cast<const char*>(f.rgba);
       ca = *reinterpret_cast<const u2u*>(rgba_b + static_cast<uint32_t>(px4[0]) * 4u);  // (u0, v0), (u0 + 1, v0)
       cb = *reinterpret_cast<const u2u*>(rgba_b + static_cast<uint32_t>(px4[1]) * 4u);  // (u0, v1), (u0 + 1, v1)
       co = *reinterpret_cast<const uint32_t*>(color_b + lin * 4u);
@@ -300,7 +316,7 @@ __device__ __forceinline__ void fuseBandCoop(FuseArgsK ka, size_t slot, const ui
     if (do_sem && valid) {
       label = 1;
       if (!(bdbg & 1024)) {
-        label = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.label) + static_cast<uint32_t>(px4[best]) * 4u);
+        label = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(f.label) + static_cast<uint32_t>(px4[best]) * 4u);
         fl = *reinterpret_cast<const uint8_t*>(vfl_b + lin);
       }
     }
@@ -459,6 +475,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
   const uint32_t nc0 = list.counts[0], nc1 = nc0 + list.counts[1], nc2 = nc1 + list.counts[2], n_items = nc2 + list.counts[3];
   uint32_t n_upd = 0, n_band = 0;
   const int dbg = DBG ? a.dbg : 0;
+  if (a.gate != nullptr && *a.gate != 0u) return;  // speculative launch, and the frame has motion seeds (workgroup-uniform)
   if (threadIdx.x == 0) s_q = 0u;
   __syncthreads();
   // next item of this workgroup's share (positions blockIdx.x, blockIdx.x + gridDim.x, ...: every workgroup gets the same
@@ -701,12 +718,13 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
       // phase's arguments from being hoisted out of this block (and their registers out of the voxel loop)
       FuseArgsK ka = (FuseArgsK)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+s"(ka));
+      const FuseFrameK kf = (FuseFrameK)ka;  // a single-frame launch: the frame's arguments are the head of the kernel arguments
       if (ka->band_mode != 0 && fuseBandCoopOk(ka->K, ka->sem_mode, ka->do_sem)) {
-        fuseBandCoop<VPS>(ka, slot, &s_rec[wave][0][0], cnt, lane);
+        fuseBandCoop<VPS>(ka, kf, slot, &s_rec[wave][0][0], cnt, lane);
       } else {
         for (uint32_t r = static_cast<uint32_t>(lane); r < cnt; r += 64u) {
           const uint32_t* const rec = &s_rec[wave][0][r];
-          fuseBandRecord<VPS>(ka, slot, rec[0], __uint_as_float(rec[kFuseCap]), __uint_as_float(rec[2 * kFuseCap]),
+          fuseBandRecord<VPS>(ka, kf, slot, rec[0], __uint_as_float(rec[kFuseCap]), __uint_as_float(rec[2 * kFuseCap]),
                               __uint_as_float(rec[3 * kFuseCap]), __uint_as_float(rec[4 * kFuseCap]));
         }
       }
@@ -772,7 +790,11 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
 // ====================================================================================================================
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 typedef const u4v __attribute__((address_space(4))) * DescK;
-template <int VPS, int ZSPLIT, bool DEFCFG, bool EXACT, int WPW, int MINW>
+// MULTI: an item is walked through a.n_frames frames (a.frames[], device memory, read through the scalar cache) in order before
+// the wave takes its next item -- the updates of a voxel by consecutive frames are order dependent, those of different items
+// are not.  One launch then replaces one launch per frame (MeshObjectExtractor re-integrates every buffered frame of a track,
+// mesh_object_extractor.cpp:239-243: 27 launches of ~18 us for a few hundred blocks each).
+template <int VPS, int ZSPLIT, bool DEFCFG, bool EXACT, int WPW, int MINW, bool MULTI = false>
 __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList list) {
   constexpr int NV = VPS * VPS * VPS;
   constexpr int SL = VPS * VPS;
@@ -789,14 +811,11 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
   const int interp = DEFCFG ? 2 : a.interp;
   const bool use_dropoff = DEFCFG ? true : (a.use_dropoff != 0);
   const bool const_weight = DEFCFG ? false : (a.const_weight != 0);
-  const float Wm1 = static_cast<float>(a.W - 1), Hm1 = static_cast<float>(a.H - 1);
-  const float fxfy = a.fx * a.fy;
   const float den = a.trunc - a.dropoff_eps;
   const float yden = rcpRefined(den);
-  const char* const range_b = reinterpret_cast<const char*>(a.range);
-  const uint32_t W4 = static_cast<uint32_t>(a.W) * 4u;
   const uint32_t nc0 = list.counts[0], nc1 = nc0 + list.counts[1], nc2 = nc1 + list.counts[2], n_items = nc2 + list.counts[3];
   uint32_t n_upd = 0, n_band = 0;
+  if (a.gate != nullptr && *a.gate != 0u) return;  // speculative launch, and the frame has motion seeds
   if (threadIdx.x == 0) s_q = 0u;
   __syncthreads();
   // workgroup b owns the list positions first, first + grid, ... (XCD-aware share as k_fuse); its waves take them from an LDS
@@ -838,12 +857,29 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
     const int ix = lin_xy % VPS, iy = lin_xy / VPS;
     const float px = ox + (static_cast<float>(ix) + 0.5f) * a.vs;
     const float py = oy + (static_cast<float>(iy) + 0.5f) * a.vs;
-    float pxy[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) pxy[c] = a.R[3 * c] * px + a.R[3 * c + 1] * py;
     char* const dist_b = reinterpret_cast<char*>(a.dist + slot * NV);
     char* const wgt_b = reinterpret_cast<char*>(a.weight + slot * NV);
     char* const lobs_b = reinterpret_cast<char*>(a.last_obs + slot * NV);
+    bool touched = false, wrote_neg = false;
+    uint32_t cnt = 0;
+    const int n_frames = MULTI ? a.n_frames : 1;
+    for (int fi = 0; fi < n_frames; ++fi) {
+    // the frame's arguments: the kernel's own (single frame), or entry fi of a.frames read through the scalar cache
+    FuseFrame Fm;
+    if (MULTI) {
+      const uint32_t __attribute__((address_space(4)))* const w = (const uint32_t __attribute__((address_space(4)))*)(a.frames + fi);
+      uint32_t* const d = reinterpret_cast<uint32_t*>(&Fm);
+#pragma unroll
+      for (int i = 0; i < static_cast<int>(sizeof(FuseFrame) / 4); ++i) d[i] = w[i];
+    }
+    const FuseFrame& F = MULTI ? Fm : static_cast<const FuseFrame&>(a);
+    const float Wm1 = static_cast<float>(F.W - 1), Hm1 = static_cast<float>(F.H - 1);
+    const float fxfy = F.fx * F.fy;
+    const char* const range_b = reinterpret_cast<const char*>(F.range);
+    const uint32_t W4 = static_cast<uint32_t>(F.W) * 4u;
+    float pxy[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pxy[c] = F.R[3 * c] * px + F.R[3 * c + 1] * py;
     float uu[ZR], vv[ZR], zz[ZR], yzz[ZR], dd[ZR], ww[ZR];
     f2u ra[ZR], rb[ZR];
     bool okk[ZR];
@@ -854,17 +890,17 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
       const float pz = oz + (static_cast<float>(iz) + 0.5f) * a.vs;
       float pc[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) pc[c] = (pxy[c] + a.R[3 * c + 2] * pz) + a.t[c];
+      for (int c = 0; c < 3; ++c) pc[c] = (pxy[c] + F.R[3 * c + 2] * pz) + F.t[c];
       bool ok = pc[2] > 0.f;
       const float voxel_range = range_mode == 0 ? pc[2] : sqrtf((pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2]);
-      ok = ok && !(voxel_range < a.min_range || voxel_range > a.max_range);
+      ok = ok && !(voxel_range < F.min_range || voxel_range > F.max_range);
       const float yz = rcpRefined(pc[2]);
-      const float u = divExact(pc[0] * a.fx, pc[2], yz) + a.cx;
-      const float v = divExact(pc[1] * a.fy, pc[2], yz) + a.cy;
+      const float u = divExact(pc[0] * F.fx, pc[2], yz) + F.cx;
+      const float v = divExact(pc[1] * F.fy, pc[2], yz) + F.cy;
       ok = ok && (fminf(fminf(u, v), fminf(Wm1 - u, Hm1 - v)) >= 0.f);
       const float uc = ok ? u : 0.f, vc = ok ? v : 0.f;
       const uint32_t u0 = static_cast<uint32_t>(static_cast<int>(uc)), v0 = static_cast<uint32_t>(static_cast<int>(vc));
-      const uint32_t v1 = min(v0 + 1u, static_cast<uint32_t>(a.H - 1));
+      const uint32_t v1 = min(v0 + 1u, static_cast<uint32_t>(F.H - 1));
       const uint32_t o0 = v0 * W4 + u0 * 4u, o1 = v1 * W4 + u0 * 4u;
       ra[k] = *reinterpret_cast<const f2u*>(range_b + o0);
       rb[k] = *reinterpret_cast<const f2u*>(range_b + o1);
@@ -881,8 +917,7 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
       okk[k] = ok;
     }
     // ---- phase 2: measurement, decisions, read-modify-write ----
-    uint32_t cnt = 0;
-    bool touched = false, wrote_neg = false;
+    cnt = 0;
 #pragma unroll
     for (int k = 0; k < ZR; ++k) {
       bool ok = okk[k];
@@ -893,14 +928,14 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
       float depth = voxel_range;
       if (range_mode != 0) {
         const float pz = oz + (static_cast<float>(iz) + 0.5f) * a.vs;
-        depth = (pxy[2] + a.R[8] * pz) + a.t[2];
+        depth = (pxy[2] + F.R[8] * pz) + F.t[2];
       }
       const uint32_t u0 = static_cast<uint32_t>(static_cast<int>(uc)), v0 = static_cast<uint32_t>(static_cast<int>(vc));
-      const uint32_t v1 = min(v0 + 1u, static_cast<uint32_t>(a.H - 1));
+      const uint32_t v1 = min(v0 + 1u, static_cast<uint32_t>(F.H - 1));
       const float du = __builtin_amdgcn_fractf(uc), dv = __builtin_amdgcn_fractf(vc);
       const uint32_t o0 = v0 * W4 + u0 * 4u, o1 = v1 * W4 + u0 * 4u;
       const float d_old = dd[k], w_old = ww[k];
-      const bool last_col = u0 >= static_cast<uint32_t>(a.W - 1);
+      const bool last_col = u0 >= static_cast<uint32_t>(F.W - 1);
       const float r0 = ra[k].x, r1 = rb[k].x, r2 = last_col ? ra[k].x : ra[k].y, r3 = last_col ? rb[k].x : rb[k].y;
       bool use_nearest = interp == 0;
       if (interp == 2) {
@@ -914,11 +949,11 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
       const float w0 = omu * omv, w1 = omu * dv, w2 = du * omv, w3 = du * dv;
       const float r_bil = ((w0 * r0 + w1 * r1) + w2 * r2) + w3 * r3;
       const float dist_surface = use_nearest ? r_near : r_bil;
-      ok = ok && (dist_surface >= a.min_range) && !(dist_surface > a.max_range);
+      ok = ok && (dist_surface >= F.min_range) && !(dist_surface > F.max_range);
       const float sdf = dist_surface - voxel_range;
       ok = ok && !(sdf < -a.trunc);
       bool in_band = ok && (fabsf(sdf) < a.trunc);
-      if (__builtin_expect(a.use_mask && __builtin_amdgcn_ballot_w64(in_band) != 0ull, 0)) {
+      if (__builtin_expect(F.use_mask && __builtin_amdgcn_ballot_w64(in_band) != 0ull, 0)) {
         int best;
         if (use_nearest) {
           best = (hi_u ? 2 : 0) + (hi_v ? 1 : 0);
@@ -931,7 +966,7 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
         }
         const uint32_t uo = ((best & 2) && !last_col) ? 4u : 0u;
         const uint32_t bo = ((best & 1) ? o1 : o0) + uo;
-        if (in_band && *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.dyn) + bo) != 0) {
+        if (in_band && *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(F.dyn) + bo) != 0) {
           ok = false;
           in_band = false;
         }
@@ -966,7 +1001,7 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
       if (ok) {
         *reinterpret_cast<float*>(dist_b + lin * 4u) = d_new;
         *reinterpret_cast<float*>(wgt_b + lin * 4u) = w_new;
-        if (a.with_tracking) *reinterpret_cast<uint64_t*>(lobs_b + lin * 8u) = a.stamp;
+        if (a.with_tracking) *reinterpret_cast<uint64_t*>(lobs_b + lin * 8u) = F.stamp;
       }
       const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(ok), m_band = __builtin_amdgcn_ballot_w64(in_band);
       n_upd += static_cast<uint32_t>(__popcll(m_ok));
@@ -993,18 +1028,20 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
       __builtin_amdgcn_wave_barrier();
       FuseArgsK ka = (FuseArgsK)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+s"(ka));
-      if (ka->band_mode != 0 && fuseBandCoopOk(ka->K, ka->sem_mode, ka->do_sem)) {
-        fuseBandCoop<VPS, CAP>(ka, slot, &s_rec[wave][0][0], cnt, lane);
+      const FuseFrameK kf = MULTI ? (FuseFrameK)(a.frames + fi) : (FuseFrameK)ka;
+      if (ka->band_mode != 0 && fuseBandCoopOk(ka->K, ka->sem_mode, kf->do_sem)) {
+        fuseBandCoop<VPS, CAP>(ka, kf, slot, &s_rec[wave][0][0], cnt, lane);
       } else {
         for (uint32_t r = static_cast<uint32_t>(lane); r < cnt; r += 64u) {
           const uint32_t* const rec = &s_rec[wave][0][r];
-          fuseBandRecord<VPS>(ka, slot, rec[0], __uint_as_float(rec[CAP]), __uint_as_float(rec[2 * CAP]),
+          fuseBandRecord<VPS>(ka, kf, slot, rec[0], __uint_as_float(rec[CAP]), __uint_as_float(rec[2 * CAP]),
                               __uint_as_float(rec[3 * CAP]), __uint_as_float(rec[4 * CAP]));
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
+    }  // frames
     if (lane == 0) {
       if (touched) atomicOr(&a.blk_flags[slot], BLK_UPDATED | BLK_MESH_UPDATED | BLK_TRACKING_UPDATED | (wrote_neg ? BLK_HAS_NEG : 0u));
       a.blk_band[slot * kBandSlots + (sbi & (kBandSlots - 1))] = static_cast<uint16_t>(min(cnt, 65535u));

@@ -144,6 +144,13 @@ struct khr_ctx {
   };
   std::shared_ptr<SnapPool> snap_pool = std::make_shared<SnapPool>();
   khr_snapshot* pending_snapshot = nullptr;  // taken inside khr_process_frame(KHR_PF_SNAPSHOT)
+  // upper bound of the blocks an explicitly allocated map holds (khr_allocate_blocks since the last khr_reset_map; 0 =
+  // unknown): the update kernel of an `allocate = false` integration (object mini-maps) sizes its persistent grid from it
+  // instead of filling the chip with workgroups that find no item
+  uint64_t explicit_blocks = 0;
+  FuseFrame* h_frames = nullptr;  // integrateUpdateMulti: per-frame arguments, pinned staging + device array
+  FuseFrame* d_frames = nullptr;
+  hipEvent_t ev_frames = nullptr;
   uint32_t snap_ticket = 0;
   uint32_t wpb = 0;               // wave items per block of this context's k_fuse instantiation
   int fuse_zsplit = 2;            // z ranges per x-y patch of that instantiation
@@ -338,8 +345,10 @@ void resolveTimers(khr_ctx* c) {
     hipEventSynchronize(r.b);
     float ms = 0.f;
     hipEventElapsedTime(&ms, r.a, r.b);
-    c->t_ms[r.which] += ms;
-    c->t_n[r.which] += 1;
+    if (r.which >= 0) {  // (-1: a speculative launch whose device-side gate was closed)
+      c->t_ms[r.which] += ms;
+      c->t_n[r.which] += 1;
+    }
     c->event_pool.push_back(r.a);
     c->event_pool.push_back(r.b);
   }
@@ -493,6 +502,9 @@ constexpr int kFuseWpwDefault = 12;
 int kFuseDbg = 0;       // env KHR_FUSE_DBG: ablation switches (development; selects the DBG instantiation)
 int kFuseVer = 1;       // env KHR_FUSE_V: 1 = k_fuse (per-wave software pipeline), 2 = k_fuse2 (one item per wave, high occupancy)
 int kFuse2Cfg = 0;      // env KHR_FUSE2_CFG: which (waves per workgroup, waves per SIMD) instantiation of k_fuse2
+int kFuseMulti = 1;     // env KHR_FUSE_MULTI: khr_integrate_shared_batch integrates all frames of a batch in one launch (k_fuse2 MULTI)
+constexpr int kMaxMultiFrames = 1024;
+int kFuseSpec = 1;      // env KHR_FUSE_SPECULATIVE: khr_process_frame queues k_fuse before the seed count has reached the host (gated on the device)
 int kFuseBand = 0;      // env KHR_FUSE_BAND: 0 = lane <-> record (default), 1 = record-cooperative band phase (fuseBandCoop: -41 % L2 write requests, -16 % L1 accesses, same time at 720p / 2 cm, slower on small frames)
 constexpr int kStreamGrid = 4096;
 
@@ -655,6 +667,7 @@ int khr_reset_map(khr_ctx* c, float voxel_size, float truncation_distance) {
   c->mesh_total = 0;
   c->mesh_stale = false;
   c->host_index_valid = false, ++c->map_gen;
+  c->explicit_blocks = 0;
   c->last_removed = 0;
   c->removed_pending = false;
   c->last_track_stamp = 0;
@@ -764,6 +777,8 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   if (std::getenv("KHR_FUSE_WAVES")) kFuseWavesPerCu = std::max(4, std::atoi(std::getenv("KHR_FUSE_WAVES")));
   if (std::getenv("KHR_FUSE_DBG")) kFuseDbg = std::atoi(std::getenv("KHR_FUSE_DBG"));
   if (std::getenv("KHR_FUSE_BAND")) kFuseBand = std::atoi(std::getenv("KHR_FUSE_BAND"));
+  if (std::getenv("KHR_FUSE_SPECULATIVE")) kFuseSpec = std::atoi(std::getenv("KHR_FUSE_SPECULATIVE"));
+  if (std::getenv("KHR_FUSE_MULTI")) kFuseMulti = std::atoi(std::getenv("KHR_FUSE_MULTI"));
   if (std::getenv("KHR_FUSE_V")) kFuseVer = std::atoi(std::getenv("KHR_FUSE_V"));
   if (std::getenv("KHR_FUSE2_CFG")) kFuse2Cfg = std::atoi(std::getenv("KHR_FUSE2_CFG"));
   if (std::getenv("KHR_NO_EARLY_INGEST")) c->early_ingest = false;
@@ -949,6 +964,9 @@ void khr_destroy(khr_ctx* c) {
     }
     c->snap_pool->free.clear();
   }
+  if (c->h_frames) hipHostFree(c->h_frames);
+  if (c->d_frames) hipFree(c->d_frames);
+  if (c->ev_frames) hipEventDestroy(c->ev_frames);
   if (c->h_pinned) hipHostFree(c->h_pinned);
   if (c->h_stage) hipHostFree(c->h_stage);
   if (c->h_up) hipHostFree(c->h_up);
@@ -1217,29 +1235,90 @@ static int fuseGrid(khr_ctx* c, const void* kernel, int group, int block) {
   return grid;
 }
 
-static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allocate_blocks, int use_mask,
-                           int object_id, const UpdateLists* lists = nullptr) {
+// the per-frame part of the update kernel's arguments
+static void fillFuseFrame(const khr_ctx* c, const FrameSlot& s, const DevFrame& f, int use_mask, int object_id, FuseFrame* a) {
+  a->range = f.range; a->dyn = f.dyn; a->rgba = f.rgba; a->label = f.label; a->obj = f.obj;
+  a->W = f.W; a->H = f.H; a->fx = f.fx; a->fy = f.fy; a->cx = f.cx; a->cy = f.cy; a->min_range = f.min_range; a->max_range = f.max_range;
+  std::memcpy(a->R, f.R, sizeof(a->R));
+  std::memcpy(a->t, f.t, sizeof(a->t));
+  a->stamp = f.stamp;
+  // a dynamic image nobody has painted since the ingest is all zero: the mask cannot reject anything
+  a->use_mask = (use_mask && !s.dyn_clean) ? 1 : 0;
+  a->has_color = f.has_color;
+  a->object_id = object_id;
+  a->do_sem = (c->p.with_semantics && ((c->p.sem_mode == 1) ? (object_id >= 0 && f.obj != nullptr) : (f.has_label != 0))) ? 1 : 0;
+}
+static void fillFuseMap(khr_ctx* c, FuseArgs* a) {
   DevMap& m = c->m;
-  (void)allocate_blocks;
+  a->blk_index = m.blk_index; a->blk_flags = m.blk_flags; a->dist = m.dist; a->weight = m.weight; a->last_obs = m.last_obs;
+  a->color = m.color; a->vflags = m.vflags; a->sem_label = m.sem_label; a->lik = m.lik; a->wg_stats = c->d_wg_stats;
+  a->blk_band = m.blk_band;
+  a->vs = c->p.vs; a->bs = c->p.bs; a->trunc = c->p.trunc; a->dropoff_eps = c->p.dropoff_eps; a->max_weight = c->p.max_weight;
+  a->adaptive_diff = c->p.adaptive_diff; a->log_match = c->p.log_match; a->log_nomatch = c->p.log_nomatch;
+  a->interp = c->p.interp; a->range_mode = c->p.range_mode; a->use_dropoff = c->p.use_dropoff; a->const_weight = c->p.const_weight;
+  a->with_tracking = c->p.with_tracking;
+  a->K = c->p.K; a->sem_mode = c->p.sem_mode;
+  a->dbg = kFuseDbg;
+  a->dbg_buf = c->d_dbg;
+  a->band_mode = kFuseBand;
+}
+
+// All frames of a batch in ONE launch (k_fuse2<.., MULTI>): every wave item is walked through the frames in order.  Only for
+// `allocate = false` integrations of 8^3-voxel maps with the default integrator switches (the object extractor's mini-map);
+// returns 1 when the batch was not taken (the caller then integrates frame by frame).
+static int integrateUpdateMulti(khr_ctx* c, khr_ctx* src, const int* src_slots, const int* object_ids, int n_frames, int use_mask) {
+  if (!kFuseMulti || c->cfg.voxels_per_side != 8 || n_frames < 2 || n_frames > kMaxMultiFrames) return 1;
+  FuseArgs a{};
+  fillFuseMap(c, &a);
+  const bool defcfg = a.range_mode == 0 && a.interp == 2 && a.use_dropoff && !a.const_weight;
+  if (!defcfg) return 1;
+  const bool exact = kFuseExact >= 0 ? kFuseExact != 0 : c->cfg.relaxed_arithmetic == 0;
+  // per-frame arguments: pinned staging -> device array (reused only after the previous batch's copy has been consumed)
+  if (!c->h_frames) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_frames), sizeof(FuseFrame) * kMaxMultiFrames, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->d_frames), sizeof(FuseFrame) * kMaxMultiFrames) != hipSuccess)
+      return fail(KHR_ENOMEM, "frame argument staging");
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_frames, hipEventDisableTiming));
+  } else {
+    HIP_TRY(hipEventSynchronize(c->ev_frames));
+  }
+  for (int i = 0; i < n_frames; ++i) {
+    FrameSlot& s = src->slots[src_slots[i]];
+    const DevFrame f = makeDevFrame(src, s);
+    fillFuseFrame(c, s, f, use_mask, object_ids ? object_ids[i] : -1, &c->h_frames[i]);
+  }
+  HIP_TRY(hipMemcpyAsync(c->d_frames, c->h_frames, sizeof(FuseFrame) * n_frames, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipEventRecord(c->ev_frames, c->stream));
+  static_cast<FuseFrame&>(a) = c->h_frames[0];  // (W, H etc. for code that looks at the kernel's own frame; unused by MULTI)
+  a.frames = c->d_frames;
+  a.n_frames = n_frames;
+  FuseList list{c->d_work4, c->d_work4 + c->item_cap, c->item_cap, &c->m.counters[C_N_ITEMS0]};
+  constexpr int WPW = 8;
+  auto go = [&](auto kern) {
+    // one workgroup per WPW items is enough (c->explicit_blocks bounds the map), at most what is resident
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * WPW, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    int grid = std::min(kFuseStatSlots, per_cu * 256) / 8 * 8;
+    if (c->explicit_blocks > 0) {
+      const uint64_t items = c->explicit_blocks * c->wpb;
+      grid = std::max(8, static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(grid), (items + WPW - 1) / WPW) + 7) / 8 * 8);
+    }
+    KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(64 * WPW), a, list);
+  };
+  if (exact) go(&k_fuse2<8, 4, true, true, WPW, 4, true>);
+  else go(&k_fuse2<8, 4, true, false, WPW, 4, true>);
+  HIP_TRY(hipGetLastError());
+  return KHR_OK;
+}
+
+static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allocate_blocks, int use_mask,
+                           int object_id, const UpdateLists* lists = nullptr, const uint32_t* gate = nullptr) {
+  DevMap& m = c->m;
   FuseList list{c->d_work4, c->d_work4 + c->item_cap, c->item_cap, &m.counters[C_N_ITEMS0]};
   if (lists) list = lists->list;
   FuseArgs a{};
-  a.blk_index = m.blk_index; a.blk_flags = m.blk_flags; a.dist = m.dist; a.weight = m.weight; a.last_obs = m.last_obs;
-  a.color = m.color; a.vflags = m.vflags; a.sem_label = m.sem_label; a.lik = m.lik; a.wg_stats = c->d_wg_stats;
-  a.blk_band = m.blk_band;
-  a.range = f.range; a.dyn = f.dyn; a.rgba = f.rgba; a.label = f.label; a.obj = f.obj;
-  a.W = f.W; a.H = f.H; a.fx = f.fx; a.fy = f.fy; a.cx = f.cx; a.cy = f.cy; a.min_range = f.min_range; a.max_range = f.max_range;
-  std::memcpy(a.R, f.R, sizeof(a.R));
-  std::memcpy(a.t, f.t, sizeof(a.t));
-  a.stamp = f.stamp;
-  a.vs = c->p.vs; a.bs = c->p.bs; a.trunc = c->p.trunc; a.dropoff_eps = c->p.dropoff_eps; a.max_weight = c->p.max_weight;
-  a.adaptive_diff = c->p.adaptive_diff; a.log_match = c->p.log_match; a.log_nomatch = c->p.log_nomatch;
-  a.interp = c->p.interp; a.range_mode = c->p.range_mode; a.use_dropoff = c->p.use_dropoff; a.const_weight = c->p.const_weight;
-  a.with_tracking = c->p.with_tracking;
-  // a dynamic image nobody has painted since the ingest is all zero: the mask cannot reject anything
-  a.use_mask = (use_mask && !s.dyn_clean) ? 1 : 0;
-  a.K = c->p.K; a.sem_mode = c->p.sem_mode; a.has_color = f.has_color; a.object_id = object_id;
-  a.do_sem = (c->p.with_semantics && ((c->p.sem_mode == 1) ? (object_id >= 0 && f.obj != nullptr) : (f.has_label != 0))) ? 1 : 0;
+  fillFuseMap(c, &a);
+  fillFuseFrame(c, s, f, use_mask, object_id, &a);
   const bool defcfg = a.range_mode == 0 && a.interp == 2 && a.use_dropoff && !a.const_weight;
   const bool exact = kFuseExact >= 0 ? kFuseExact != 0 : c->cfg.relaxed_arithmetic == 0;
   int rc = dispatchVps(c, [&](auto vps) {
@@ -1248,15 +1327,20 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
       constexpr int ZS = decltype(zsplit)::value;
       constexpr int G = 1;
       auto go = [&](auto kern, int wpw) {
-        const int grid = fuseGrid(c, reinterpret_cast<const void*>(kern), G, 64 * wpw);
+        int grid = fuseGrid(c, reinterpret_cast<const void*>(kern), G, 64 * wpw);
+        // a small explicitly allocated map (object extraction): one workgroup per wpw items is enough; the rest of the
+        // persistent grid would only be launched to find an empty queue (and takes CUs from the window's own kernels)
+        if (!allocate_blocks && c->explicit_blocks > 0 && kFuseGrid == 0) {
+          const uint64_t items = c->explicit_blocks * c->wpb;
+          const int want = static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(grid), (items + wpw - 1) / wpw));
+          grid = std::max(8, (want + 7) / 8 * 8);
+        }
         static bool said = false;
         if (!said && std::getenv("KHR_VERBOSE")) { said = true; std::fprintf(stderr, "[khr] k_fuse<%d,%d> %d waves / workgroup, grid %d\n", V, ZS, wpw, grid); }
         KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(64 * wpw), a, list);
       };
       // non-default switches are test configurations: they always run the bit-exact arithmetic
-      a.dbg = kFuseDbg;
-      a.dbg_buf = c->d_dbg;
-      a.band_mode = kFuseBand;
+      a.gate = gate;
       constexpr int WD = kFuseWpwDefault;
       if (kFuseVer == 2 && V == 16 && defcfg && exact) {
         // k_fuse2: (waves per workgroup, waves per SIMD it is compiled for); the grid is what is resident
@@ -1378,6 +1462,10 @@ int khr_integrate_shared_batch(khr_ctx* c, khr_ctx* src, const int* src_slots, c
     const DevFrame f0 = makeDevFrame(src, s0);
     const int rc = integrateAlloc(c, s0, f0, 0);
     if (rc) return rc;
+  }
+  {
+    const int rc = integrateUpdateMulti(c, src, src_slots, object_ids, n_frames, use_mask);
+    if (rc <= 0) return rc;  // done (or failed); 1 = not applicable: frame by frame below
   }
   for (int i = 0; i < n_frames; ++i) {
     FrameSlot& s = src->slots[src_slots[i]];
@@ -2926,7 +3014,21 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
     if ((rc = objectsLaunch(c, slot))) return rc;
     HT("pf_objects_launched");
   }
+  // (2c) the update kernel, speculatively: most frames have no motion seeds, and for those the dynamic mask is empty and the
+  //      update does not depend on anything the host is about to learn.  It is queued now, gated on the device-side seed
+  //      counter (k_motion_pixels finished long before it in stream order): no seeds -> it runs; seeds -> it returns at once
+  //      and the real launch follows the clustering chain below.  (Before: the main stream idled ~35 us per frame between
+  //      the culling pass and the update kernel, for the seed count's trip to the host and the launch's trip back.)
+  bool speculated = false;
+  size_t spec_timer = static_cast<size_t>(-1);
+  if (motion && kFuseSpec && c->cfg.with_tracking) {
+    const size_t n_pending = c->pending.size();
+    if ((rc = integrateUpdate(c, s, f, 1, 0, -1, nullptr, &c->m.counters[C_N_SEEDS]))) return rc;
+    if (c->pending.size() == n_pending + 1) spec_timer = n_pending;
+    speculated = true;
+  }
   // (3) host looks at the seed count (clusters only exist when there are seeds)
+  bool have_seeds = false;
   if (motion) {
     c->md_defer_summary = true;
     c->md_summary_pending = -1;
@@ -2934,10 +3036,12 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
     c->md_defer_summary = false;
     if (nc < 0) return nc;
     if (n_clusters) *n_clusters = nc;
+    have_seeds = c->cfg.with_tracking && c->h_pinned[0] != 0;
   }
   HT("pf_motion_done");
   // (4) TSDF / label update with the dynamic mask, tracking + ever-free
-  if ((rc = integrateUpdate(c, s, f, 1, motion ? 1 : 0, -1))) return rc;
+  if (speculated && have_seeds && spec_timer != static_cast<size_t>(-1)) c->pending[spec_timer].which = -1;  // the gated launch did nothing: not a sample
+  if ((!speculated || have_seeds) && (rc = integrateUpdate(c, s, f, 1, motion ? 1 : 0, -1))) return rc;
   if (c->md_summary_pending >= 0) {  // the dynamic clusters' summaries, behind the update kernels
     const int pend = c->md_summary_pending;
     c->md_summary_pending = -1;
@@ -3011,6 +3115,7 @@ int khr_allocate_blocks(khr_ctx* c, const int32_t* indices, int64_t n) {
   HIP_TRY(hipMemcpyAsync(c->d_up, c->h_up, bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipEventRecord(c->ev_up, c->stream));
   HIP_TRY(hipMemsetAsync(&c->m.counters[C_N_NEW], 0, sizeof(uint32_t), c->stream));
+  c->explicit_blocks += v.size();
   hipLaunchKernelGGL(k_alloc_list, dim3(gridFor(v.size())), dim3(256), 0, c->stream, c->m, static_cast<const int*>(c->d_up),
                      static_cast<int>(v.size()), c->d_new);
   hipLaunchKernelGGL(k_init_blocks, dim3(2048), dim3(256), 0, c->stream, c->m, c->p, c->d_new);

@@ -246,7 +246,8 @@ int khr_detect_motion(khr_ctx* ctx, int slot);
 /* Multi-GPU form of khr_detect_motion (no reference equivalent).  khr_motion_keys runs the per-pixel pass
  * (setUpPointMapPart, free_space_motion_detector.cpp:158-203) against THIS rank's shard of the map and writes
  * one u64 per pixel: the packed global voxel index with the ever-free (seed) flag in bit 63, or 0 if the pixel
- * is skipped or falls into a block this rank does not own; *n_seed_pixels = seed pixels seen by this rank.
+ * is skipped or falls into a block this rank does not own; *n_seed_pixels = seed pixels seen by this rank (NULL with
+ * on_device = 1: the call only queues the pass and returns, no host wait).
  * Exactly one rank owns the block a pixel falls into, so a sum all-reduce over the ranks assembles the full
  * key image; khr_detect_motion_from_keys then clusters and paints from it (identical on every rank). */
 int khr_motion_keys(khr_ctx* ctx, int slot, void* keys_out, int on_device, uint32_t* n_seed_pixels);
@@ -261,6 +262,9 @@ int khr_configure_object_detector(khr_ctx* ctx, const khr_object_detector_config
  * writes FrameData::object_image of the slot and returns the number of semantic clusters.  Cluster order where
  * the reference iterates an unordered map: ASSUMPTIONS.md C.4. */
 int khr_detect_objects(khr_ctx* ctx, int slot);
+/* first half of khr_detect_objects: queue the detector's kernels for the slot's frame (auxiliary stream) and return; a later
+ * khr_detect_objects(slot) collects the clusters.  KHR_ESTATE (nothing done) when no detector is configured. */
+int khr_detect_objects_launch(khr_ctx* ctx, int slot);
 /* FrameData::semantic_clusters of the frame last passed to khr_detect_objects (id, category, pixel count,
  * bounding box of the pixels' vertices, max_iou_tracker.cpp:466-476).  Returns the count (writes min(n, cap)). */
 int khr_get_semantic_clusters(khr_ctx* ctx, int slot, khr_cluster* out, int cap);
@@ -310,6 +314,8 @@ int khr_mesh_halo_requests(khr_ctx* ctx, void* keys_out, int64_t cap, int only_m
 int khr_mesh_halo_export(khr_ctx* ctx, const void* requests, int64_t n_requests, void* records, int64_t cap_records,
                          int on_device);
 int khr_mesh_halo_import(khr_ctx* ctx, const void* records, int64_t n_records, int on_device);
+/* (on_device = 2: the records are indexed where they are -- a device buffer the caller keeps unchanged until the next
+ * khr_generate_mesh has run -- instead of being copied into the context first) */
 /* replaces: TrackingIntegrator::resetInactive (tracking_integrator.cpp:106-131). removed: caller
  * buffer for 3*cap int32 block indices (may be NULL); *n_removed receives the count. */
 int khr_reset_inactive(khr_ctx* ctx, int32_t* removed, int64_t cap, int64_t* n_removed);
@@ -347,6 +353,9 @@ int khr_process_frame(khr_ctx* ctx, const khr_sensor* sensor, const khr_frame* f
                       int* n_clusters);
 
 /* -- output / inspection ----------------------------------------------------------------------- */
+/* khr_stats.pool_exhausted alone (records dropped by an exchange buffer that was too small, failed block allocations;
+ * sticky): one small device -> host copy, no host-side index rebuild */
+int64_t khr_pool_exhausted(khr_ctx* ctx);
 int khr_get_stats(khr_ctx* ctx, khr_stats* out);
 int64_t khr_num_blocks(khr_ctx* ctx);
 /* sorted (x, y, z) lexicographically; returns total count, writes min(count, cap) entries.

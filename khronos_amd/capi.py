@@ -76,7 +76,7 @@ EXPORTS = [
     "khr_export_halo", "khr_import_halo", "khr_get_dynamic_clusters", "khr_motion_keys",
     "khr_detect_motion_from_keys", "khr_download_updated", "khr_mesh_halo_requests", "khr_mesh_halo_export",
     "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",
-    "khr_cluster_voxels", "khr_download_frame_image",
+    "khr_cluster_voxels", "khr_download_frame_image", "khr_detect_objects_launch", "khr_pool_exhausted",
     "khr_rv_create", "khr_rv_destroy", "khr_rv_clear", "khr_rv_add_rays", "khr_rv_num_rays", "khr_rv_num_pairs", "khr_rv_check",
     "khr_snapshot_updated", "khr_take_snapshot", "khr_snapshot_num_blocks", "khr_snapshot_download", "khr_snapshot_release",
     "khr_rv_check_stamps", "khr_get_config", "khr_cluster_voxels_launch", "khr_cluster_voxels_fetch", "khr_reset_map", "khr_depend_on", "khr_retain_slot", "khr_release_slot",

@@ -162,6 +162,7 @@ struct khr_ctx {
   uint32_t halo_cap_total = 0, halo_mask = 0, halo_n = 0;
   // remote mesh halo (three low voxel planes of blocks owned by other ranks)
   uint32_t* d_mh_recs = nullptr;
+  const uint32_t* mh_view = nullptr;  // the imported mesh halo records: d_mh_recs, or the caller's buffer (on_device = 2)
   uint64_t* d_mh_keys = nullptr;
   uint32_t* d_mh_vals = nullptr;
   uint32_t mh_cap_total = 0, mh_mask = 0, mh_n = 0;
@@ -2275,6 +2276,13 @@ int khr_motion_keys(khr_ctx* c, int slot, void* keys_out, int on_device, uint32_
     HIP_TRY(hipMemcpyAsync(keys_out, dst, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
+  if (!n_seed_pixels && on_device) {
+    // nobody asked for the count and the keys stay on the device: nothing to wait for (a sharded tick calls this once per
+    // seed camera; eight host round trips in a row were a third of an 8-camera tick)
+    c->seed_publish_pending = false;
+    c->seed_by_ticket = false;
+    return KHR_OK;
+  }
   { const int rcw = waitSeedCount(c); if (rcw) return rcw; }
   if (n_seed_pixels) *n_seed_pixels = c->h_pinned[0];
   return KHR_OK;
@@ -2559,6 +2567,20 @@ int khr_detect_objects(khr_ctx* c, int slot) {
   return objectsFinish(c, slot);
 }
 
+// first half of khr_detect_objects: the detector's kernels are queued on the auxiliary stream (behind the slot's ingest),
+// nothing is awaited; khr_detect_objects(slot) later only collects the result.  Lets a caller that has other device work to
+// queue first (the sharded tick) overlap it with the detection of its own camera's frame.
+int khr_detect_objects_launch(khr_ctx* c, int slot) {
+  if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
+  if (!c->obj_configured) return KHR_ESTATE;  // (no detector configured: not an error here, nothing to launch)
+  HIP_TRY(hipSetDevice(c->device));
+  FrameSlot& s = c->slots[slot];
+  if (s.objects_done || c->obj_pending_slot == slot) return KHR_OK;
+  int rc = auxAfterMain(c);
+  if (!rc) rc = objectsLaunch(c, slot);
+  return rc;
+}
+
 int khr_get_semantic_clusters(khr_ctx* c, int slot, khr_cluster* out, int cap) {
   if (!c || cap < 0 || (!out && cap > 0)) return fail(KHR_EINVAL, "bad argument");
   if (slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
@@ -2790,7 +2812,7 @@ int khr_generate_mesh(khr_ctx* c, int only_mesh_updated, int clear_flag) {
   MeshBuffers src = c->mesh[c->mesh_cur], dst = c->mesh[c->mesh_cur ^ 1];
   RemoteMeshHalo rmh{};
   if (c->mh_n) {
-    rmh.recs = c->d_mh_recs;
+    rmh.recs = c->mh_view;
     rmh.ht_keys = c->d_mh_keys;
     rmh.ht_vals = c->d_mh_vals;
     rmh.ht_mask = c->mh_mask;
@@ -2924,21 +2946,29 @@ int khr_mesh_halo_import(khr_ctx* c, const void* records, int64_t n_records, int
     return KHR_OK;
   }
   const size_t words = c->p.vps == 16 ? MeshHalo<16>::kWords : MeshHalo<8>::kWords;
+  const bool in_place = on_device == 2;  // the records stay in the caller's device buffer (valid until the mesh has been generated)
   if (static_cast<uint64_t>(n_records) > c->mh_cap_total) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->d_mh_recs) { hipFree(c->d_mh_recs); hipFree(c->d_mh_keys); hipFree(c->d_mh_vals); }
+    c->d_mh_recs = nullptr;
     uint32_t ht = 1;
     while (ht < static_cast<uint64_t>(n_records) * 4) ht <<= 1;
-    HIP_TRY(hipMalloc(&c->d_mh_recs, static_cast<size_t>(n_records) * words * 4));
+    // (in-place imports only need the index; the record copy buffer is allocated by the first copying import)
     HIP_TRY(hipMalloc(&c->d_mh_keys, sizeof(uint64_t) * ht));
     HIP_TRY(hipMalloc(&c->d_mh_vals, sizeof(uint32_t) * ht));
     c->mh_cap_total = static_cast<uint32_t>(n_records);
     c->mh_mask = ht - 1;
   }
-  HIP_TRY(hipMemcpyAsync(c->d_mh_recs, records, static_cast<size_t>(n_records) * words * 4,
-                         on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+  const uint32_t* view = static_cast<const uint32_t*>(records);
+  if (!in_place) {
+    if (!c->d_mh_recs) HIP_TRY(hipMalloc(&c->d_mh_recs, static_cast<size_t>(c->mh_cap_total) * words * 4));
+    HIP_TRY(hipMemcpyAsync(c->d_mh_recs, records, static_cast<size_t>(n_records) * words * 4,
+                           on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    view = c->d_mh_recs;
+  }
+  c->mh_view = view;
   HIP_TRY(hipMemsetAsync(c->d_mh_keys, 0xff, sizeof(uint64_t) * (static_cast<size_t>(c->mh_mask) + 1), c->stream));
-  hipLaunchKernelGGL(k_mesh_halo_import, dim3(gridFor(n_records)), dim3(256), 0, c->stream, c->d_mh_recs,
+  hipLaunchKernelGGL(k_mesh_halo_import, dim3(gridFor(n_records)), dim3(256), 0, c->stream, view,
                      static_cast<uint32_t>(n_records), static_cast<int>(words), c->cfg.rank, c->cfg.world_size, c->d_mh_keys,
                      c->d_mh_vals, c->mh_mask);
   HIP_TRY(hipGetLastError());
@@ -3144,6 +3174,15 @@ int khr_object_prune(khr_ctx* c, float min_confidence, float min_observations, i
 }
 
 static int refreshMeshTotals(khr_ctx* c);
+
+// sticky count of dropped records / failed allocations (khr_stats.pool_exhausted) without the rest of khr_get_stats (which
+// rebuilds the host-side block index: ~1 ms for a 1 cm map)
+int64_t khr_pool_exhausted(khr_ctx* c) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  const int rc = readCounters(c);
+  if (rc) return rc;
+  return static_cast<int64_t>(c->h_counters[C_POOL_EXHAUSTED]);
+}
 
 int khr_get_stats(khr_ctx* c, khr_stats* out) {
   if (!c || !out) return fail(KHR_EINVAL, "null argument");

@@ -790,14 +790,48 @@ struct MeshBuffers {
   uint64_t* stamps;    // last_observed of the source voxel (first_seen == stamps, ASSUMPTIONS.md A.5)
 };
 
+// copy the meshes of blocks that are not regenerated from the old to the new vertex buffer (workgroup `bid` of `nb`, one
+// slot at a time).  Called by k_mesh_move and -- beside the emit pass, which writes the OTHER blocks' vertices into the
+// same buffer -- by the trailing workgroups of k_marching_cubes<.., true> (one launch instead of two back to back: the
+// copy is pure bandwidth, the emit pass is LDS / compute, and the output stage is a chain of short dependent launches).
+__device__ inline void meshMoveBlocks(const DevMap& m, const uint8_t* __restrict__ regen, const uint32_t* __restrict__ new_offset,
+                                      const MeshBuffers& src, const MeshBuffers& dst, uint32_t max_vertices, uint32_t bid, uint32_t nb) {
+  if (new_offset[m.capacity] > max_vertices) return;
+  const uint32_t n_slots = m.counters[C_MAX_SLOT];
+  for (uint32_t s = bid; s < n_slots; s += nb) {
+    if (!(m.blk_flags[s] & BLK_LIVE) || regen[s]) continue;
+    const MeshDesc d = m.mesh_desc[s];
+    if (d.count == 0) continue;
+    const size_t so = d.offset, dof = new_offset[s];
+    for (uint32_t i = threadIdx.x; i < d.count; i += blockDim.x) {
+      dst.points[3 * (dof + i)] = src.points[3 * (so + i)];
+      dst.points[3 * (dof + i) + 1] = src.points[3 * (so + i) + 1];
+      dst.points[3 * (dof + i) + 2] = src.points[3 * (so + i) + 2];
+      dst.colors[dof + i] = src.colors[so + i];
+      dst.labels[dof + i] = src.labels[so + i];
+      dst.stamps[dof + i] = src.stamps[so + i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) m.mesh_desc[s].offset = static_cast<uint32_t>(dof);
+  }
+}
+
 template <int VPS, bool EMIT>
 __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, const uint32_t* __restrict__ work,
                                                        const uint32_t* __restrict__ n_work,
                                                        uint32_t* __restrict__ new_count,
                                                        const uint32_t* __restrict__ new_offset, MeshBuffers out,
-                                                       int clear_flag, uint32_t max_vertices, RemoteMeshHalo rh) {
+                                                       int clear_flag, uint32_t max_vertices, RemoteMeshHalo rh,
+                                                       uint32_t n_mc_wgs = 0xffffffffu, const uint8_t* __restrict__ regen = nullptr,
+                                                       MeshBuffers move_src = MeshBuffers{}) {
   constexpr int NV = VPS * VPS * VPS;
   using MH = MeshHalo<VPS>;
+  // emit pass: workgroups beyond the first n_mc_wgs copy the kept blocks' vertices (meshMoveBlocks)
+  if (EMIT && blockIdx.x >= n_mc_wgs) {
+    meshMoveBlocks(m, regen, new_offset, move_src, out, max_vertices, blockIdx.x - n_mc_wgs, gridDim.x - n_mc_wgs);
+    return;
+  }
+  const uint32_t mc_grid = min(gridDim.x, n_mc_wgs);
   if (EMIT && new_offset[m.capacity] > max_vertices) {  // vertex buffer too small: flag, write nothing
     if (blockIdx.x == 0 && threadIdx.x == 0) m.counters[C_MESH_OVERFLOW] = 1u;
     return;
@@ -820,7 +854,7 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
     if (EMIT)
       reinterpret_cast<uint4*>(s_tri)[threadIdx.x] = reinterpret_cast<const uint4*>(&g_mc_tri[0][0])[threadIdx.x];
   }
-  for (uint32_t b = blockIdx.x; b < n; b += gridDim.x) {
+  for (uint32_t b = blockIdx.x; b < n; b += mc_grid) {
     const size_t slot = work[b];
     if (EMIT && new_count[slot] == 0u) {  // most mesh-updated blocks contain no surface: nothing to stage
       if (threadIdx.x == 0) {
@@ -1159,24 +1193,7 @@ __global__ __launch_bounds__(256) void k_mesh_carry_counts(DevMap m, uint32_t* _
 __global__ __launch_bounds__(256) void k_mesh_move(DevMap m, const uint8_t* __restrict__ regen,
                                                   const uint32_t* __restrict__ new_offset, MeshBuffers src,
                                                   MeshBuffers dst, uint32_t max_vertices) {
-  if (new_offset[m.capacity] > max_vertices) return;
-  const uint32_t n_slots = m.counters[C_MAX_SLOT];
-  for (uint32_t s = blockIdx.x; s < n_slots; s += gridDim.x) {
-    if (!(m.blk_flags[s] & BLK_LIVE) || regen[s]) continue;
-    const MeshDesc d = m.mesh_desc[s];
-    if (d.count == 0) continue;
-    const size_t so = d.offset, dof = new_offset[s];
-    for (uint32_t i = threadIdx.x; i < d.count; i += blockDim.x) {
-      dst.points[3 * (dof + i)] = src.points[3 * (so + i)];
-      dst.points[3 * (dof + i) + 1] = src.points[3 * (so + i) + 1];
-      dst.points[3 * (dof + i) + 2] = src.points[3 * (so + i) + 2];
-      dst.colors[dof + i] = src.colors[so + i];
-      dst.labels[dof + i] = src.labels[so + i];
-      dst.stamps[dof + i] = src.stamps[so + i];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) m.mesh_desc[s].offset = static_cast<uint32_t>(dof);
-  }
+  meshMoveBlocks(m, regen, new_offset, src, dst, max_vertices, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void k_mark_regen(const uint32_t* __restrict__ work, const uint32_t* n_work,

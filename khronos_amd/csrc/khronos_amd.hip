@@ -2826,9 +2826,11 @@ int khr_generate_mesh(khr_ctx* c, int only_mesh_updated, int clear_flag) {
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->d_cub_temp, tb, c->d_mesh_count, c->d_mesh_offset,
                                              static_cast<int>(cap + 1), c->stream));
     // no host round trip: the capacity check happens on the device (C_MESH_OVERFLOW), totals are read lazily
-    hipLaunchKernelGGL(k_mesh_move, dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->d_regen, c->d_mesh_offset, src, dst, maxv);
-    hipLaunchKernelGGL((k_marching_cubes<V, true>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, c->d_work,
-                       c->d_mesh_nwork, c->d_mesh_count, c->d_mesh_offset, dst, clear_flag, maxv, rmh);
+    // emit pass + the copy of the kept blocks' vertices in ONE launch (the trailing kMoveWgs workgroups copy)
+    constexpr uint32_t kMoveWgs = 1024;
+    hipLaunchKernelGGL((k_marching_cubes<V, true>), dim3(kStreamGrid + kMoveWgs), dim3(256), 0, c->stream, m, c->p, c->d_work,
+                       c->d_mesh_nwork, c->d_mesh_count, c->d_mesh_offset, dst, clear_flag, maxv, rmh, static_cast<uint32_t>(kStreamGrid),
+                       static_cast<const uint8_t*>(c->d_regen), src);
     return KHR_OK;
   });
   if (rc) return rc;

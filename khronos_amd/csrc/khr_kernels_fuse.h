@@ -124,6 +124,9 @@ struct FuseArgs : FuseFrame {
   // k_fuse2<.., MULTI>: the frames an item is walked through, in order
   const FuseFrame* frames;
   int n_frames;
+  // tick form of MULTI (khr_tick_integrate): one byte per wave item [slot * items-per-block + item], bit k = the item is on
+  // camera k's TSDF list (k_tick_cull); the kernel clears the byte it has consumed.  nullptr: every frame, every item.
+  uint8_t* item_mask;
 };
 
 constexpr int kFuseCap = 256;        // in-band records a wave collects before it works them off (one 4-z chunk of a patch)
@@ -863,7 +866,18 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
     bool touched = false, wrote_neg = false;
     uint32_t cnt = 0;
     const int n_frames = MULTI ? a.n_frames : 1;
+    uint32_t frame_mask = ~0u;
+    if (MULTI && a.item_mask != nullptr) {  // which cameras listed the item (their culling is conservative: the others cannot touch it)
+      const size_t mi = slot * static_cast<size_t>(PATCHES * ZSPLIT) + static_cast<size_t>(sbi);
+      const uint32_t word = *(const uint32_t __attribute__((address_space(4)))*)(a.item_mask + (mi & ~static_cast<size_t>(3)));
+      frame_mask = (word >> (8u * static_cast<uint32_t>(mi & 3))) & 0xffu;
+      // the byte is cleared only once the scalar load has RETURNED (scalar loads and vector stores reach the L2 on
+      // different paths: a store issued right behind the load can overtake it)
+      asm volatile("" : "+s"(frame_mask) : : "memory");
+      if (lane == 0) a.item_mask[mi] = 0;
+    }
     for (int fi = 0; fi < n_frames; ++fi) {
+    if (MULTI && ((frame_mask >> fi) & 1u) == 0u) continue;
     // the frame's arguments: the kernel's own (single frame), or entry fi of a.frames read through the scalar cache
     FuseFrame Fm;
     if (MULTI) {
@@ -1066,6 +1080,16 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
       a.wg_stats[2 * blockIdx.x + 1] += sb;
     }
   }
+}
+
+// per-camera update arguments of a tick -> device memory (they travel as kernel arguments: no host staging, no host wait)
+struct FuseFrameSet {
+  FuseFrame f[kMaxTick];
+};
+__global__ void k_put_frames(FuseFrameSet s, FuseFrame* __restrict__ dst, int n) {
+  const uint32_t* const src = reinterpret_cast<const uint32_t*>(&s);
+  uint32_t* const d = reinterpret_cast<uint32_t*>(dst);
+  for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(n) * (sizeof(FuseFrame) / 4); i += blockDim.x) d[i] = src[i];
 }
 
 }  // namespace khr

@@ -233,7 +233,7 @@ __global__ void k_tick_begin(DevMap m, int nvox, uint32_t* wg_stats, uint32_t* t
 __device__ inline void cullBlocks(const DevMap& m, const DevParams& p, const DevFrame& f, const uint32_t* __restrict__ work,
                                   const uint32_t* __restrict__ n_work, FuseList out, uint32_t wpb,
                                   uint32_t* __restrict__ n_tsdf, const float* __restrict__ tile_max, int tw, int th,
-                                  uint32_t bid, uint32_t nblk) {
+                                  uint32_t bid, uint32_t nblk, uint32_t* __restrict__ item_mask = nullptr, uint32_t cam = 0u) {
   // each workgroup tests kPerWg blocks (one wave per block, 4 rounds), gathers the survivors' items in LDS and
   // appends them with one atomic per class (hot-address atomics are expensive)
   constexpr int kPerWg = 8;
@@ -362,6 +362,14 @@ __device__ inline void cullBlocks(const DevMap& m, const DevParams& p, const Dev
           }
         }
       }
+      // tick form: the cameras share one list; an item is appended by the first camera that keeps it, the others only
+      // leave their bit (one byte per item; k_fuse2<.., MULTI> walks the item through the cameras whose bit is set)
+      if (ikeep && sub == 0 && item_mask) {
+        const size_t mi = static_cast<size_t>(slot) * wpb + item;
+        const uint32_t sh = 8u * static_cast<uint32_t>(mi & 3);
+        const uint32_t old = atomicOr(&item_mask[mi >> 2], (1u << cam) << sh);
+        if ((old >> sh) & 0xffu) ikeep = false;
+      }
       if (ikeep && sub == 0) {
         const uint32_t cls = fuseClass(m.blk_band[static_cast<size_t>(slot) * kBandSlots + item]);
         s_item[cls][atomicAdd(&s_ccnt[cls], 1u)] = static_cast<uint16_t>((kslot << 8) | item);
@@ -399,14 +407,17 @@ struct TickFrames {
 };
 __global__ __launch_bounds__(256) void k_tick_cull(DevMap m, DevParams p, TickFrames t, const uint32_t* __restrict__ work,
                                                   uint32_t list_stride, uint4* __restrict__ desc, uint32_t desc_stride, uint32_t wpb,
-                                                  uint32_t* __restrict__ tick_counts, int use_tiles, int tw, int th) {
+                                                  uint32_t* __restrict__ tick_counts, int use_tiles, int tw, int th,
+                                                  uint32_t* __restrict__ item_mask) {
   // tick_counts: [2 * cam] visible, [2 * cam + 1] non-culled (statistics), [2 * kMaxTick + 4 * cam + cls] items per class;
-  // descriptors of camera cam: arrays a, b = desc + (2 cam, 2 cam + 1) * desc_stride
+  // descriptors of camera cam: arrays a, b = desc + (2 cam, 2 cam + 1) * desc_stride.  With item_mask the cameras share
+  // camera 0's list (the union of their items) and mark their items in the mask.
   const int cam = blockIdx.y;
-  FuseList out{desc + static_cast<size_t>(2 * cam) * desc_stride, desc + static_cast<size_t>(2 * cam + 1) * desc_stride, desc_stride,
-               &tick_counts[2 * kMaxTick + 4 * cam]};
+  const int lc = item_mask ? 0 : cam;
+  FuseList out{desc + static_cast<size_t>(2 * lc) * desc_stride, desc + static_cast<size_t>(2 * lc + 1) * desc_stride, desc_stride,
+               &tick_counts[2 * kMaxTick + 4 * lc]};
   cullBlocks(m, p, t.f[cam], work + static_cast<size_t>(cam) * list_stride, &tick_counts[2 * cam], out, wpb, &tick_counts[2 * cam + 1],
-             use_tiles ? t.tile_max[cam] : nullptr, tw, th, blockIdx.x, gridDim.x);
+             use_tiles ? t.tile_max[cam] : nullptr, tw, th, blockIdx.x, gridDim.x, item_mask, static_cast<uint32_t>(cam));
 }
 
 // explicit allocation of a list of block indices (VolumetricMap::allocateBlock)

@@ -132,6 +132,10 @@ struct khr_ctx {
   size_t inst_bytes = 0;
   uint4* d_work4 = nullptr;       // update list of k_fuse: two descriptor arrays of item_cap entries (FuseList)
   uint4* d_tick_work4 = nullptr;  // tick path: two arrays per camera
+  // tick path, one-launch form (tickUnion): the cameras' arguments on the device, one byte per wave item (camera bits)
+  FuseFrame* d_tick_frames = nullptr;
+  uint32_t* d_tick_mask = nullptr;
+  bool tick_mask_dirty = false;
   uint32_t item_cap = 0;          // max_blocks x wave items per block
   // snapshots of the updated blocks (khr_snapshot_updated): arenas of released snapshots are reused
   struct SnapArena { uint8_t* ptr; size_t bytes; volatile uint32_t* h_count; uint32_t* d_count_host_view; };
@@ -503,6 +507,7 @@ constexpr int kFuseWpwDefault = 12;
 int kFuseDbg = 0;       // env KHR_FUSE_DBG: ablation switches (development; selects the DBG instantiation)
 int kFuseVer = 1;       // env KHR_FUSE_V: 1 = k_fuse (per-wave software pipeline), 2 = k_fuse2 (one item per wave, high occupancy)
 int kFuse2Cfg = 0;      // env KHR_FUSE2_CFG: which (waves per workgroup, waves per SIMD) instantiation of k_fuse2
+int kTickUnion = 1;     // env KHR_TICK_UNION: khr_tick_integrate updates with ONE launch for all cameras of the tick (tickUnion)
 int kFuseMulti = 1;     // env KHR_FUSE_MULTI: khr_integrate_shared_batch integrates all frames of a batch in one launch (k_fuse2 MULTI)
 constexpr int kMaxMultiFrames = 1024;
 int kFuseSpec = 1;      // env KHR_FUSE_SPECULATIVE: khr_process_frame queues k_fuse before the seed count has reached the host (gated on the device)
@@ -779,6 +784,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   if (std::getenv("KHR_FUSE_DBG")) kFuseDbg = std::atoi(std::getenv("KHR_FUSE_DBG"));
   if (std::getenv("KHR_FUSE_BAND")) kFuseBand = std::atoi(std::getenv("KHR_FUSE_BAND"));
   if (std::getenv("KHR_FUSE_SPECULATIVE")) kFuseSpec = std::atoi(std::getenv("KHR_FUSE_SPECULATIVE"));
+  if (std::getenv("KHR_TICK_UNION")) kTickUnion = std::atoi(std::getenv("KHR_TICK_UNION"));
   if (std::getenv("KHR_FUSE_MULTI")) kFuseMulti = std::atoi(std::getenv("KHR_FUSE_MULTI"));
   if (std::getenv("KHR_FUSE_V")) kFuseVer = std::atoi(std::getenv("KHR_FUSE_V"));
   if (std::getenv("KHR_FUSE2_CFG")) kFuse2Cfg = std::atoi(std::getenv("KHR_FUSE2_CFG"));
@@ -1574,6 +1580,8 @@ static int ensureTick(khr_ctx* c) {
   if (!rc) rc = devAlloc(c, &c->d_tick_work4, 2 * static_cast<size_t>(c->item_cap) * kMaxTick, false);
   if (!rc) rc = devAlloc(c, &c->d_tick_counts, 6 * kMaxTick + 32);
   if (!rc) rc = devAlloc(c, &c->d_tick_seeds, kMaxTick + 32);
+  if (!rc) rc = devAlloc(c, &c->d_tick_frames, kMaxTick, false);
+  if (!rc) rc = devAlloc(c, &c->d_tick_mask, c->item_cap / 4 + 1);
   if (rc) return rc;
   if (hipHostMalloc(reinterpret_cast<void**>(&c->h_tick), 256, hipHostMallocDefault) != hipSuccess)
     return fail(KHR_ENOMEM, "pinned tick block");
@@ -1690,6 +1698,63 @@ int khr_tick_seed_counts(khr_ctx* c, uint32_t* n_seed_pixels, int n_frames) {
   return KHR_OK;
 }
 
+// The cameras of a tick in ONE update launch (k_fuse2<.., MULTI> over the union of their item lists, a camera mask per item)
+// instead of one launch per camera: taken for the block shapes and switches k_fuse2 is instantiated for.
+static bool tickUnion(const khr_ctx* c) {
+  if (!kFuseMulti || kTickUnion == 0) return false;
+  const DevParams& p = c->p;
+  const bool defcfg = p.range_mode == 0 && p.interp == 2 && p.use_dropoff && !p.const_weight;
+  if (!defcfg) return false;
+  const bool exact = kFuseExact >= 0 ? kFuseExact != 0 : c->cfg.relaxed_arithmetic == 0;
+  return c->cfg.voxels_per_side == 8 || (c->cfg.voxels_per_side == 16 && exact);
+}
+
+static int fuse2Grid(khr_ctx* c, const void* kern, int wpw) {
+  static std::map<const void*, int> cache;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(kern);
+  if (it != cache.end()) return it->second;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * wpw, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  hipDeviceProp_t prop;
+  int cus = 256;
+  if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  int grid = std::min(kFuseStatSlots, per_cu * cus) / 8 * 8;
+  if (kFuseGrid > 0) grid = std::max(8, kFuseGrid / 8 * 8);
+  cache[kern] = grid;
+  return grid;
+}
+
+static int tickFuseUnion(khr_ctx* c, const int* slots, const DevFrame* frames, int nb, int use_mask, int object_id) {
+  FuseArgs a{};
+  fillFuseMap(c, &a);
+  FuseFrameSet set{};
+  for (int k = 0; k < nb; ++k) fillFuseFrame(c, c->slots[slots[k]], frames[k], use_mask, object_id, &set.f[k]);
+  hipLaunchKernelGGL(k_put_frames, dim3(1), dim3(256), 0, c->stream, set, c->d_tick_frames, nb);
+  static_cast<FuseFrame&>(a) = set.f[0];
+  a.frames = c->d_tick_frames;
+  a.n_frames = nb;
+  a.item_mask = reinterpret_cast<uint8_t*>(c->d_tick_mask);
+  FuseList list{c->d_tick_work4, c->d_tick_work4 + c->item_cap, c->item_cap, &c->d_tick_counts[2 * kMaxTick]};
+  const bool exact = kFuseExact >= 0 ? kFuseExact != 0 : c->cfg.relaxed_arithmetic == 0;
+  auto go = [&](auto kern, int wpw) {
+    const int grid = fuse2Grid(c, reinterpret_cast<const void*>(kern), wpw);
+    KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(64 * wpw), a, list);
+  };
+  if (c->cfg.voxels_per_side == 8) {
+    if (exact) go(&k_fuse2<8, 4, true, true, 8, 4, true>, 8);
+    else go(&k_fuse2<8, 4, true, false, 8, 4, true>, 8);
+  } else if (c->fuse_zsplit == 8) {
+    go(&k_fuse2<16, 8, true, true, 16, 4, true>, 16);
+  } else {
+    go(&k_fuse2<16, 4, true, true, 16, 4, true>, 16);
+  }
+  c->tick_mask_dirty = false;
+  HIP_TRY(hipGetLastError());
+  return KHR_OK;
+}
+
 int khr_tick_integrate(khr_ctx* c, const int* slots, int n_frames, int use_mask, int object_id, int phases) {
   if (!c || !slots || n_frames < 1 || (phases & 3) == 0) return fail(KHR_EINVAL, "bad argument");
   if ((phases & 3) != 3 && n_frames > kMaxTick) return fail(KHR_EINVAL, "split phases take at most %d frames", kMaxTick);
@@ -1703,6 +1768,7 @@ int khr_tick_integrate(khr_ctx* c, const int* slots, int n_frames, int use_mask,
   if (rc) return rc;
   DevMap& m = c->m;
   const uint32_t cap = m.capacity;
+  const bool one_launch = tickUnion(c);
   for (int base = 0; base < n_frames; base += kMaxTick) {
     const int nb = std::min(kMaxTick, n_frames - base);
     TickFrames t{};
@@ -1729,12 +1795,19 @@ int khr_tick_integrate(khr_ctx* c, const int* slots, int n_frames, int use_mask,
       }
       hipLaunchKernelGGL(k_init_blocks, dim3(2048), dim3(256), 0, c->stream, m, c->p, c->d_new);
       const FrameSlot& s0 = c->slots[slots[base]];
+      if (one_launch && c->tick_mask_dirty)  // a first phase whose second phase never ran left camera bits behind
+        HIP_TRY(hipMemsetAsync(c->d_tick_mask, 0, sizeof(uint32_t) * (c->item_cap / 4 + 1), c->stream));
+      c->tick_mask_dirty = one_launch;
       hipLaunchKernelGGL(k_tick_cull, dim3(256, nb), dim3(256), 0, c->stream, m, c->p, t, c->d_tick_work, cap, c->d_tick_work4, c->item_cap, c->wpb,
-                         c->d_tick_counts, c->cfg.disable_culling ? 0 : 1, s0.tw, s0.th);
+                         c->d_tick_counts, c->cfg.disable_culling ? 0 : 1, s0.tw, s0.th, one_launch ? c->d_tick_mask : nullptr);
       c->host_index_valid = false, ++c->map_gen;
       HIP_TRY(hipGetLastError());
     }
-    for (int k = 0; k < nb && (phases & 2); ++k) {
+    if ((phases & 2) && one_launch) {
+      rc = tickFuseUnion(c, slots + base, t.f, nb, use_mask, object_id);
+      if (rc) return rc;
+    }
+    for (int k = 0; k < nb && (phases & 2) && !one_launch; ++k) {
       FrameSlot& s = c->slots[slots[base + k]];
       UpdateLists lists;
       lists.list = FuseList{c->d_tick_work4 + static_cast<size_t>(2 * k) * c->item_cap, c->d_tick_work4 + static_cast<size_t>(2 * k + 1) * c->item_cap,

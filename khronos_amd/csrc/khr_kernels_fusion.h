@@ -211,6 +211,87 @@ __global__ __launch_bounds__(256) void k_alloc_visible(DevMap m, DevParams p, De
   if (list_count != &m.counters[C_N_VISIBLE]) waveAggInc(&m.counters[C_N_VISIBLE], emit);
 }
 
+// tick path: the visible-block allocation of ALL cameras of a tick in one launch.  One thread per block of the bounding
+// lattice of the cameras' candidate cubes (rig cameras share their centre: the box is one camera's cube, or a block more);
+// it runs every camera's test of k_alloc_visible, allocates the block once if any camera sees it (candidates stay unique,
+// so the insert is the same race-free one) and appends the slot to the list of each camera that sees it.
+struct TickFrusta {
+  float R[kMaxTick][9], t[kMaxTick][3], max_range[kMaxTick];
+  DevFrustum fr[kMaxTick];
+};
+__global__ __launch_bounds__(256) void k_tick_alloc(DevMap m, DevParams p, TickFrusta tf, int ncam, int3 lo, int3 dim,
+                                                   uint32_t* __restrict__ work, uint32_t list_stride,
+                                                   uint32_t* __restrict__ new_list, uint32_t* __restrict__ tick_counts, int epoch) {
+  const int total = dim.x * dim.y * dim.z;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t seen = 0u;
+  int bx = 0, by = 0, bz = 0;
+  if (i < total) {
+    bx = lo.x + i % dim.x;
+    by = lo.y + (i / dim.x) % dim.y;
+    bz = lo.z + i / (dim.x * dim.y);
+    if (ownerOf(bx, by, bz, p.world) == p.rank) {
+      const float cxw = (static_cast<float>(bx) + 0.5f) * p.bs;
+      const float cyw = (static_cast<float>(by) + 0.5f) * p.bs;
+      const float czw = (static_cast<float>(bz) + 0.5f) * p.bs;
+      for (int k = 0; k < ncam; ++k) {
+        const DevFrustum& fr = tf.fr[k];
+        if (abs(bx - fr.bc.x) > fr.n_steps || abs(by - fr.bc.y) > fr.n_steps || abs(bz - fr.bc.z) > fr.n_steps) continue;
+        float pc[3];
+        xform(tf.R[k], tf.t[k], cxw, cyw, czw, pc);
+        bool in = !(pc[2] < -fr.infl);
+        const float n2 = (pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2];
+        const float lim = tf.max_range[k] + fr.infl;
+        in = in && !(n2 > lim * lim);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float d = (pc[0] * fr.n[q][0] + pc[1] * fr.n[q][1]) + pc[2] * fr.n[q][2];
+          in = in && !(d < -fr.infl);
+        }
+        if (in) seen |= 1u << k;
+      }
+    }
+  }
+  const bool visible = seen != 0u;
+  uint32_t slot = kInvalidSlot;
+  const uint64_t key = packKey(bx, by, bz);
+  if (visible) slot = htLookup(m, key);
+  const bool need = visible && slot == kInvalidSlot;
+  const uint32_t fidx = waveAggInc(&m.counters[C_FREE_HEAD], need);
+  bool got = false;
+  if (need) {
+    if (fidx < m.counters[C_N_FREE]) {
+      slot = m.free_slots[fidx];
+      got = true;
+      m.blk_index[slot] = make_int4(bx, by, bz, epoch);
+      m.blk_flags[slot] = BLK_LIVE | BLK_TRACK_DIRTY | BLK_ANY_KEEP;
+      m.mesh_desc[slot] = MeshDesc{0u, 0u};
+      htInsertUnique(m, key, slot);
+      atomicMax(&m.counters[C_MAX_SLOT], slot + 1);
+    } else {
+      atomicAdd(&m.counters[C_POOL_EXHAUSTED], 1u);
+      slot = kInvalidSlot;
+    }
+  }
+  const uint32_t nidx = waveAggInc(&m.counters[C_N_NEW], got);
+  if (got) new_list[nidx] = slot;
+  if (slot == kInvalidSlot) seen = 0u;
+  uint32_t n_lists = 0u;
+  for (int k = 0; k < ncam; ++k) {  // (wave-uniform trip count; a camera no lane sees costs one ballot)
+    const bool emit = (seen >> k) & 1u;
+    if (__ballot(emit) == 0ull) continue;
+    const uint32_t widx = waveAggInc(&tick_counts[2 * k], emit);
+    if (emit) work[static_cast<size_t>(k) * list_stride + widx] = slot;
+    n_lists += emit ? 1u : 0u;
+  }
+  // counters[C_N_VISIBLE] runs on as the tick's total over the cameras (statistics), as with one launch per camera
+  if (__ballot(n_lists != 0u) != 0ull) {
+    uint32_t tot = n_lists;
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+    if ((threadIdx.x & 63u) == 0u) atomicAdd(&m.counters[C_N_VISIBLE], tot);
+  }
+}
+
 __global__ void k_begin_integrate(DevMap m, int nvox, uint32_t* wg_stats) {
   if (blockIdx.x == 0) beginIntegrate(m, nvox, wg_stats);
 }

@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <climits>
 #include <cstring>
 #include <cstdlib>
 #include <functional>
@@ -1785,13 +1786,35 @@ int khr_tick_integrate(khr_ctx* c, const int* slots, int n_frames, int use_mask,
                          static_cast<uint32_t>(nb - 1));
       c->begun = false;
       ScopedTimer tm(c, 3);
+      // one allocation launch over the bounding lattice of the cameras' candidate cubes when that box is not much larger
+      // than the cubes themselves (a rig: cameras around one centre); otherwise camera by camera
+      TickFrusta tf{};
+      int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+      size_t cubes = 0;
       for (int k = 0; k < nb; ++k) {
         const DevFrustum fr = makeFrustum(c, t.f[k]);
-        const int S = 2 * fr.n_steps + 1;
-        const size_t total = static_cast<size_t>(S) * S * S;
-        hipLaunchKernelGGL(k_alloc_visible, dim3(gridFor(total)), dim3(256), 0, c->stream, m, c->p, t.f[k], fr,
-                           c->d_tick_work + static_cast<size_t>(k) * cap, c->d_new, c->d_pinned + 2, 0u, &c->d_tick_counts[2 * k],
-                           c->motion_ignore_epoch);
+        tf.fr[k] = fr;
+        std::memcpy(tf.R[k], t.f[k].R, sizeof(tf.R[k]));
+        std::memcpy(tf.t[k], t.f[k].t, sizeof(tf.t[k]));
+        tf.max_range[k] = t.f[k].max_range;
+        const int bc[3] = {fr.bc.x, fr.bc.y, fr.bc.z};
+        for (int a = 0; a < 3; ++a) lo[a] = std::min(lo[a], bc[a] - fr.n_steps), hi[a] = std::max(hi[a], bc[a] + fr.n_steps);
+        const size_t S = static_cast<size_t>(2 * fr.n_steps + 1);
+        cubes += S * S * S;
+      }
+      const size_t box = static_cast<size_t>(hi[0] - lo[0] + 1) * static_cast<size_t>(hi[1] - lo[1] + 1) * static_cast<size_t>(hi[2] - lo[2] + 1);
+      if (kTickUnion && nb > 1 && box <= cubes && box < (1ull << 31)) {
+        hipLaunchKernelGGL(k_tick_alloc, dim3(gridFor(box)), dim3(256), 0, c->stream, m, c->p, tf, nb, make_int3(lo[0], lo[1], lo[2]),
+                           make_int3(hi[0] - lo[0] + 1, hi[1] - lo[1] + 1, hi[2] - lo[2] + 1), c->d_tick_work, cap, c->d_new,
+                           c->d_tick_counts, c->motion_ignore_epoch);
+      } else {
+        for (int k = 0; k < nb; ++k) {
+          const int S = 2 * tf.fr[k].n_steps + 1;
+          const size_t total = static_cast<size_t>(S) * S * S;
+          hipLaunchKernelGGL(k_alloc_visible, dim3(gridFor(total)), dim3(256), 0, c->stream, m, c->p, t.f[k], tf.fr[k],
+                             c->d_tick_work + static_cast<size_t>(k) * cap, c->d_new, c->d_pinned + 2, 0u, &c->d_tick_counts[2 * k],
+                             c->motion_ignore_epoch);
+        }
       }
       hipLaunchKernelGGL(k_init_blocks, dim3(2048), dim3(256), 0, c->stream, m, c->p, c->d_new);
       const FrameSlot& s0 = c->slots[slots[base]];

@@ -16,6 +16,9 @@ copies = {
     "emu_c4.txt": "r03_emu_c4.txt", "c5_emu8.json": "r03_bench_c5_emu8.json", "c5_n1.json": "r03_bench_c5_n1.json",
     "c3_emu8.json": "r03_bench_c3_emu8.json", "c4_emu4.json": "r03_bench_c4_emu4.json", "tr_c5_8_per_tick.csv": "r03_emu8_c5_kernels_per_tick.csv",
     "tcp_reads.txt": "r03_ubench_tcp_reads.txt", "probe_fuse.txt": "r03_probe_fuse_timeline.txt",
+    # tools/r03_artifacts_tick.sh (after the tick's one-launch update / allocation)
+    "gpu_tests_tick.txt": "r03_gpu_tests_tick.txt", "tr_c3_8_per_tick.csv": "r03_emu8_c3_kernels_per_tick.csv",
+    "tick_union_ab.txt": "r03_tick_union_ab.txt", "queue_atomics.txt": "r03_ubench_queue_atomics.txt",
 }
 for src, dst in copies.items():
     s = os.path.join(A, src)

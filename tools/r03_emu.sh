@@ -3,7 +3,8 @@
 # usage: tools/r03_emu.sh <config> <world> [trace]
 CFG=$1; WORLD=$2; TR=$3
 mkdir -p gpurun_out/r03emu; O=$PWD/gpurun_out/r03emu; R=$PWD
-A="--config $CFG --steps 12 --warmup 4 --no-extra-streams --cpu-baseline-frames 0 --latency-frames 0 --buffer-frames 40"
+STEPS=${STEPS:-40}
+A="--config $CFG --steps $STEPS --warmup 8 --no-extra-streams --cpu-baseline-frames 0 --latency-frames 0 --buffer-frames 40"
 timeout 900 python bench.py $A > $O/${CFG}_n1.json 2> $O/${CFG}_n1.err
 timeout 900 python bench.py $A --emulate-world $WORLD > $O/${CFG}_emu$WORLD.json 2> $O/${CFG}_emu$WORLD.err
 python - $O/${CFG}_n1.json $O/${CFG}_emu$WORLD.json $WORLD <<'PY'

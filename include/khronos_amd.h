@@ -306,9 +306,9 @@ int khr_generate_mesh(khr_ctx* ctx, int only_mesh_updated, int clear_flag);
  * rank's mesh-(updated) blocks that are not in the local map (cap entries, 0 = unused; returns the count);
  * (2) the requests of all ranks are all-gathered; (3) khr_mesh_halo_export answers the requests this rank
  * owns with fixed-size records (KHR_MESH_HALO_RECORD_BYTES(vps): key, valid, then per plane distance,
- * weight, colour, label, stamp) and zero-fills the rest of the cap_records buffer; (4) the records are
- * all-gathered and khr_mesh_halo_import indexes those of other ranks; khr_generate_mesh then treats them
- * like local neighbours. */
+ * weight, colour, label, stamp), marks the rest of the cap_records buffer empty and returns the number of records
+ * written; (4) the records are all-gathered -- only as many per rank as the fullest rank wrote -- and
+ * khr_mesh_halo_import indexes those of other ranks; khr_generate_mesh then treats them like local neighbours. */
 #define KHR_MESH_HALO_RECORD_BYTES(vps) (4 * (4 + 3 * 6 * (vps) * (vps)))
 int khr_mesh_halo_requests(khr_ctx* ctx, void* keys_out, int64_t cap, int only_mesh_updated, int on_device);
 int khr_mesh_halo_export(khr_ctx* ctx, const void* requests, int64_t n_requests, void* records, int64_t cap_records,
@@ -433,14 +433,20 @@ int64_t khr_download_mesh(khr_ctx* ctx, float* points, uint8_t* colors_rgba, uin
  *   been queued.  seed_counts_device (device int64[n_frames], may be NULL) receives the same counts on the device, as
  *   the operand of the ranks' count all-reduce.  The voxel keys of a camera are only needed when some rank reports
  *   seeds: khr_motion_keys(slot) then produces them.
- * khr_tick_integrate: phases bit 0 = block allocation for every frame + one initialisation + one culling launch
- *   (independent of the motion masks: queue it before collecting the seed counts), bit 1 = the TSDF / band update
- *   kernels frame by frame in the order given (use_mask / object_id as khr_integrate).  Split phases take at most 8
- *   frames per call. */
+ * khr_tick_integrate: phases bit 0 = block allocation for all frames + one initialisation + one culling launch
+ *   (independent of the motion masks: queue it before collecting the seed counts), bit 1 = the TSDF / band update of
+ *   all frames, every voxel seeing the frames in the order given (use_mask / object_id as khr_integrate).  Bit 0 can be
+ *   given in two halves: bit 2 = allocation only, bit 3 = initialisation + culling only (a caller that wants to know the
+ *   number of live blocks before the rest is queued: khr_tick_live_bound).  Split phases take at most 8 frames per call.
+ * khr_tick_live_bound: queue a one-wave kernel that writes out_device[index] = the number of this context's live
+ *   blocks (after the allocation phase of the tick: everything the tick will export) and 0 to the other n_out - 1
+ *   entries: the operand of a sum all-reduce that tells every rank how many
+ *   halo records the others hold, so that the halo all-gather can be sized from it instead of from the capacity. */
 int khr_tick_ingest(khr_ctx* ctx, const khr_sensor* sensor, const khr_frame* frames, int n_frames, int count_seeds,
                     int* slots_out, uint32_t* n_seed_pixels, int64_t* seed_counts_device);
 int khr_tick_seed_counts(khr_ctx* ctx, uint32_t* n_seed_pixels, int n_frames);
 int khr_tick_integrate(khr_ctx* ctx, const int* slots, int n_frames, int use_mask, int object_id, int phases);
+int khr_tick_live_bound(khr_ctx* ctx, int64_t* out_device, int n_out, int index);
 
 /* -- measurement ------------------------------------------------------------------------------- */
 /* HIP-event timing of the kernels launched on the context stream. which: 0 fused TSDF / colour / label update

@@ -11,7 +11,10 @@
  * collective: every rank must make the same call sequence.
  *
  * Errors: negative khr_status (include/khronos_amd.h), text via khr_last_error().  Exchange buffers are sized at create;
- * exceeding one is KHR_ENOMEM from kdist_tick / kdist_output, never a silent truncation.
+ * exceeding one is KHR_ENOMEM from kdist_tick / kdist_output, never a silent truncation.  The capacities bound what a
+ * rank may hold, not what travels: the halo all-gather of a tick ships, per rank, the live-block count of the fullest rank
+ * (it rides in the tick's seed-count all-reduce, rounded up to 256 records), the mesh-record all-gather of an output the
+ * record count of the fullest rank (one 8-byte max all-reduce).
  */
 #ifndef KHRONOS_AMD_DIST_H_
 #define KHRONOS_AMD_DIST_H_
@@ -49,6 +52,10 @@ void kdist_destroy(kdist_handle* h);
 
 /* the HIP stream (hipStream_t) every call of this handle is ordered on */
 void* kdist_stream(kdist_handle* h);
+
+/* records per rank shipped by the last tick's halo all-gather and by the last output's mesh-record all-gather (0 = no
+ * such exchange yet; the capacity when the trimmed form was not available: motion detector off, more than 8 cameras) */
+int kdist_last_exchange(kdist_handle* h, int64_t* halo_records_per_rank, int64_t* mesh_records_per_rank);
 
 /* ncclAllGather of one packed camera frame per rank (device pointer, same byte count on every rank); *gathered_out is a
  * device buffer of world_size * bytes owned by the handle, valid until the next call. */

@@ -72,7 +72,7 @@ EXPORTS = [
     "khr_detect_motion", "khr_generate_mesh", "khr_reset_inactive", "khr_mark_all_inactive", "khr_clear_updated",
     "khr_allocate_blocks", "khr_object_prune", "khr_get_stats", "khr_num_blocks", "khr_block_indices",
     "khr_download_block", "khr_mesh_num_vertices", "khr_download_mesh", "khr_fetch_mesh", "khr_fetch_mesh_into", "khr_timing_enable", "khr_timing_reset",
-    "khr_timing_get", "khr_debug_read", "khr_tick_ingest", "khr_tick_integrate", "khr_tick_seed_counts", "khr_copy_frame_image", "khr_rv_detect_changes", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_integrate_shared_batch", "khr_pixel_iou", "khr_forward_instances", "khr_update_tracking_phase",
+    "khr_timing_get", "khr_debug_read", "khr_tick_ingest", "khr_tick_integrate", "khr_tick_live_bound", "khr_tick_seed_counts", "khr_copy_frame_image", "khr_rv_detect_changes", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_integrate_shared_batch", "khr_pixel_iou", "khr_forward_instances", "khr_update_tracking_phase",
     "khr_export_halo", "khr_import_halo", "khr_get_dynamic_clusters", "khr_motion_keys",
     "khr_detect_motion_from_keys", "khr_download_updated", "khr_mesh_halo_requests", "khr_mesh_halo_export",
     "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",
@@ -187,6 +187,7 @@ def load_library():
     lib.khr_debug_read.argtypes = [vp, vp, i64]
     lib.khr_tick_ingest.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     lib.khr_tick_seed_counts.argtypes = [vp, vp, i32]
+    lib.khr_tick_live_bound.argtypes = [vp, vp, i32, i32]
     lib.khr_copy_frame_image.argtypes = [vp, i32, i32, vp]
     lib.khr_tick_integrate.argtypes = [vp, vp, i32, i32, i32, i32]
     lib.khr_last_removed.argtypes = [vp, vp, i64, C.POINTER(i64)]

@@ -933,6 +933,15 @@ __global__ __launch_bounds__(256) void k_ever_free(DevMap m, DevParams p, const 
   }
 }
 
+// number of live blocks (pool capacity - free-list entries not handed out yet: the free list is rebuilt whenever blocks
+// are archived) as one entry of a zeroed vector: operand of the ranks' sum all-reduce that sizes the halo all-gather
+// (khr_tick_live_bound)
+__global__ void k_live_bound(DevMap m, int64_t* __restrict__ out, int n_out, int index) {
+  const uint32_t n_free = m.counters[C_N_FREE], head = min(m.counters[C_FREE_HEAD], n_free);
+  const int64_t live = static_cast<int64_t>(m.capacity) - static_cast<int64_t>(n_free - head);
+  for (int i = threadIdx.x; i < n_out; i += blockDim.x) out[i] = i == index ? live : 0;
+}
+
 // halo export: one record per listed block (list compacted by k_list_live); the rest of the buffer is zeroed
 template <int VPS>
 __global__ __launch_bounds__(256) void k_export_halo(DevMap m, const uint32_t* __restrict__ list,

@@ -502,12 +502,10 @@ int dispatchVps(khr_ctx* c, F&& f) {
 int kFuseGrid = 0;      // 0 = resident workgroups of the instantiation (occupancy query) x CUs; env KHR_FUSE_GRID
 int kFuseZsplit = 0;    // 0 = by world size (wave items per x-y patch of a block: 2 / 4 / 8); env KHR_FUSE_ZSPLIT
 int kFuseExact = -1;    // -1 = !khr_config.relaxed_arithmetic; env KHR_FUSE_EXACT=0/1 overrides (A/B switch)
-int kFuseWpw = 0;       // env KHR_FUSE_WPW: waves per workgroup of the default instantiation (4, 8, 16; 0 = kFuseWpwDefault)
 int kFuseWavesPerCu = 16;  // env KHR_FUSE_WAVES: resident waves per CU the persistent grid is sized for
 constexpr int kFuseWpwDefault = 12;
 int kFuseDbg = 0;       // env KHR_FUSE_DBG: ablation switches (development; selects the DBG instantiation)
 int kFuseVer = 1;       // env KHR_FUSE_V: 1 = k_fuse (per-wave software pipeline), 2 = k_fuse2 (one item per wave, high occupancy)
-int kFuse2Cfg = 0;      // env KHR_FUSE2_CFG: which (waves per workgroup, waves per SIMD) instantiation of k_fuse2
 int kTickUnion = 1;     // env KHR_TICK_UNION: khr_tick_integrate updates with ONE launch for all cameras of the tick (tickUnion)
 int kFuseMulti = 1;     // env KHR_FUSE_MULTI: khr_integrate_shared_batch integrates all frames of a batch in one launch (k_fuse2 MULTI)
 constexpr int kMaxMultiFrames = 1024;
@@ -780,7 +778,6 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   if (std::getenv("KHR_FUSE_GRID")) kFuseGrid = std::max(8, std::min(kFuseStatSlots, std::atoi(std::getenv("KHR_FUSE_GRID"))));
   if (std::getenv("KHR_FUSE_ZSPLIT")) kFuseZsplit = std::atoi(std::getenv("KHR_FUSE_ZSPLIT"));
   if (std::getenv("KHR_FUSE_EXACT")) kFuseExact = std::atoi(std::getenv("KHR_FUSE_EXACT")) ? 1 : 0;
-  if (std::getenv("KHR_FUSE_WPW")) kFuseWpw = std::atoi(std::getenv("KHR_FUSE_WPW"));
   if (std::getenv("KHR_FUSE_WAVES")) kFuseWavesPerCu = std::max(4, std::atoi(std::getenv("KHR_FUSE_WAVES")));
   if (std::getenv("KHR_FUSE_DBG")) kFuseDbg = std::atoi(std::getenv("KHR_FUSE_DBG"));
   if (std::getenv("KHR_FUSE_BAND")) kFuseBand = std::atoi(std::getenv("KHR_FUSE_BAND"));
@@ -788,7 +785,6 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   if (std::getenv("KHR_TICK_UNION")) kTickUnion = std::atoi(std::getenv("KHR_TICK_UNION"));
   if (std::getenv("KHR_FUSE_MULTI")) kFuseMulti = std::atoi(std::getenv("KHR_FUSE_MULTI"));
   if (std::getenv("KHR_FUSE_V")) kFuseVer = std::atoi(std::getenv("KHR_FUSE_V"));
-  if (std::getenv("KHR_FUSE2_CFG")) kFuse2Cfg = std::atoi(std::getenv("KHR_FUSE2_CFG"));
   if (std::getenv("KHR_NO_EARLY_INGEST")) c->early_ingest = false;
 
   DevMap& m = c->m;
@@ -1244,6 +1240,24 @@ static int fuseGrid(khr_ctx* c, const void* kernel, int group, int block) {
 }
 
 // the per-frame part of the update kernel's arguments
+// resident workgroups of a k_fuse2 instantiation x CUs (occupancy query, cached per kernel)
+static int fuse2Grid(khr_ctx* c, const void* kern, int wpw) {
+  static std::map<const void*, int> cache;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(kern);
+  if (it != cache.end()) return it->second;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * wpw, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  hipDeviceProp_t prop;
+  int cus = 256;
+  if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  int grid = std::min(kFuseStatSlots, per_cu * cus) / 8 * 8;
+  if (kFuseGrid > 0) grid = std::max(8, kFuseGrid / 8 * 8);
+  cache[kern] = grid;
+  return grid;
+}
+
 static void fillFuseFrame(const khr_ctx* c, const FrameSlot& s, const DevFrame& f, int use_mask, int object_id, FuseFrame* a) {
   a->range = f.range; a->dyn = f.dyn; a->rgba = f.rgba; a->label = f.label; a->obj = f.obj;
   a->W = f.W; a->H = f.H; a->fx = f.fx; a->fy = f.fy; a->cx = f.cx; a->cy = f.cy; a->min_range = f.min_range; a->max_range = f.max_range;
@@ -1351,45 +1365,15 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
       a.gate = gate;
       constexpr int WD = kFuseWpwDefault;
       if (kFuseVer == 2 && V == 16 && defcfg && exact) {
-        // k_fuse2: (waves per workgroup, waves per SIMD it is compiled for); the grid is what is resident
-        auto go2 = [&](auto kern, int wpw) {
-          static std::map<const void*, int> cache;
-          static std::mutex mu;
-          int grid;
-          {
-            std::lock_guard<std::mutex> lock(mu);
-            auto it = cache.find(reinterpret_cast<const void*>(kern));
-            if (it != cache.end()) {
-              grid = it->second;
-            } else {
-              int per_cu = 0;
-              if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * wpw, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-              hipDeviceProp_t prop;
-              int cus = 256;
-              if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-              grid = std::min(kFuseStatSlots, per_cu * cus) / 8 * 8;
-              if (kFuseGrid > 0) grid = std::max(8, kFuseGrid / 8 * 8);
-              cache[reinterpret_cast<const void*>(kern)] = grid;
-              if (std::getenv("KHR_VERBOSE")) std::fprintf(stderr, "[khr] k_fuse2<%d,%d> %d waves / workgroup, %d workgroups / CU, grid %d\n", V, ZS, wpw, per_cu, grid);
-            }
-          }
-          KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(64 * wpw), a, list);
-        };
-        constexpr int V2 = (V == 16 ? 16 : 16), Z2 = (V == 16 ? ZS : 4);
-        switch (kFuse2Cfg) {
-          case 3: go2(&k_fuse2<V2, Z2, true, true, 10, 5>, 10); break;   // 2 workgroups x 10 waves per CU
-          case 5: go2(&k_fuse2<V2, Z2, true, true, 8, 5>, 8); break;     // 2 x 8
-          default: go2(&k_fuse2<V2, Z2, true, true, 16, 4>, 16); break;  // 1 x 16
-        }
+        // k_fuse2, single frame (A/B switch KHR_FUSE_V=2): 16 waves per workgroup, compiled for 4 waves per SIMD
+        constexpr int Z2 = (V == 16 ? ZS : 4);
+        auto kern = &k_fuse2<16, Z2, true, true, 16, 4>;
+        const int grid = fuse2Grid(c, reinterpret_cast<const void*>(kern), 16);
+        KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(64 * 16), a, list);
       } else if (defcfg && !exact && kFuseDbg && V == 16) {
         go(&k_fuse<V, ZS, true, false, WD, (V == 16)>, WD);
       } else if (defcfg && !exact) {
-        if (V == 16 && kFuseWpw == 4) go(&k_fuse<V, ZS, true, false, (V == 16 ? 4 : WD)>, V == 16 ? 4 : WD);
-        else if (V == 16 && kFuseWpw == 8) go(&k_fuse<V, ZS, true, false, (V == 16 ? 8 : WD)>, V == 16 ? 8 : WD);
-        else if (V == 16 && kFuseWpw == 16) go(&k_fuse<V, ZS, true, false, (V == 16 ? 16 : WD)>, V == 16 ? 16 : WD);
-        else if (V == 16 && kFuseWpw == 6) go(&k_fuse<V, ZS, true, false, (V == 16 ? 6 : WD)>, V == 16 ? 6 : WD);
-        else if (V == 16 && kFuseWpw == 12) go(&k_fuse<V, ZS, true, false, (V == 16 ? 12 : WD)>, V == 16 ? 12 : WD);
-        else go(&k_fuse<V, ZS, true, false, WD>, WD);
+        go(&k_fuse<V, ZS, true, false, WD>, WD);
       } else if (defcfg) {
         go(&k_fuse<V, ZS, true, true, WD>, WD);
       } else {
@@ -1710,23 +1694,6 @@ static bool tickUnion(const khr_ctx* c) {
   return c->cfg.voxels_per_side == 8 || (c->cfg.voxels_per_side == 16 && exact);
 }
 
-static int fuse2Grid(khr_ctx* c, const void* kern, int wpw) {
-  static std::map<const void*, int> cache;
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lock(mu);
-  auto it = cache.find(kern);
-  if (it != cache.end()) return it->second;
-  int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * wpw, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-  hipDeviceProp_t prop;
-  int cus = 256;
-  if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-  int grid = std::min(kFuseStatSlots, per_cu * cus) / 8 * 8;
-  if (kFuseGrid > 0) grid = std::max(8, kFuseGrid / 8 * 8);
-  cache[kern] = grid;
-  return grid;
-}
-
 static int tickFuseUnion(khr_ctx* c, const int* slots, const DevFrame* frames, int nb, int use_mask, int object_id) {
   FuseArgs a{};
   fillFuseMap(c, &a);
@@ -1757,8 +1724,9 @@ static int tickFuseUnion(khr_ctx* c, const int* slots, const DevFrame* frames, i
 }
 
 int khr_tick_integrate(khr_ctx* c, const int* slots, int n_frames, int use_mask, int object_id, int phases) {
-  if (!c || !slots || n_frames < 1 || (phases & 3) == 0) return fail(KHR_EINVAL, "bad argument");
-  if ((phases & 3) != 3 && n_frames > kMaxTick) return fail(KHR_EINVAL, "split phases take at most %d frames", kMaxTick);
+  if (!c || !slots || n_frames < 1 || (phases & 15) == 0) return fail(KHR_EINVAL, "bad argument");
+  if (phases & 1) phases |= 12;  // bit 0 = allocation (bit 2) + initialisation / culling (bit 3)
+  if ((phases & 14) != 14 && n_frames > kMaxTick) return fail(KHR_EINVAL, "split phases take at most %d frames", kMaxTick);
   for (int i = 0; i < n_frames; ++i) {
     if (slots[i] < 0 || slots[i] >= static_cast<int>(c->slots.size()) || !c->slots[slots[i]].valid) return fail(KHR_EINVAL, "bad slot");
     const khr_sensor &a = c->slots[slots[i]].sensor, &b = c->slots[slots[0]].sensor;
@@ -1778,7 +1746,7 @@ int khr_tick_integrate(khr_ctx* c, const int* slots, int n_frames, int use_mask,
       t.f[k] = makeDevFrame(c, s);
       t.tile_max[k] = s.tile_max;
     }
-    if (phases & 1) {
+    if (phases & 4) {
       if (++c->tick_epoch <= 0) c->tick_epoch = 1;
       c->motion_ignore_epoch = c->tick_epoch;
       if (std::getenv("KHR_DEBUG_TICK_NO_EPOCH")) c->motion_ignore_epoch = 0;  // test hook: shows that the epoch matters
@@ -1816,6 +1784,10 @@ int khr_tick_integrate(khr_ctx* c, const int* slots, int n_frames, int use_mask,
                              c->motion_ignore_epoch);
         }
       }
+      HIP_TRY(hipGetLastError());
+    }
+    if (phases & 8) {
+      ScopedTimer tm(c, 3);
       hipLaunchKernelGGL(k_init_blocks, dim3(2048), dim3(256), 0, c->stream, m, c->p, c->d_new);
       const FrameSlot& s0 = c->slots[slots[base]];
       if (one_launch && c->tick_mask_dirty)  // a first phase whose second phase never ran left camera bits behind
@@ -1840,6 +1812,14 @@ int khr_tick_integrate(khr_ctx* c, const int* slots, int n_frames, int use_mask,
     }
     if (phases & 2) c->motion_ignore_epoch = 0;
   }
+  return KHR_OK;
+}
+
+int khr_tick_live_bound(khr_ctx* c, int64_t* out_device, int n_out, int index) {
+  if (!c || !out_device || n_out < 1 || index < 0 || index >= n_out) return fail(KHR_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_live_bound, dim3(1), dim3(64), 0, c->stream, c->m, out_device, n_out, index);
+  HIP_TRY(hipGetLastError());
   return KHR_OK;
 }
 
@@ -1878,17 +1858,19 @@ int khr_import_halo(khr_ctx* c, const void* records, int64_t n_records, int on_d
     c->halo_n = 0;
     return KHR_OK;
   }
+  // the index of this import: 4 slots per record (a caller that ships fewer records than its buffers hold -- the trimmed
+  // all-gather of the sharded tick -- also clears and probes a smaller table)
+  uint32_t ht = 1;
+  while (ht < static_cast<uint64_t>(n_records) * 4) ht <<= 1;
   if (static_cast<uint64_t>(n_records) > c->halo_cap_total) {  // (re)allocate the remote table
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->d_halo_recs) { hipFree(c->d_halo_recs); hipFree(c->d_halo_keys); hipFree(c->d_halo_vals); }
-    uint32_t ht = 1;
-    while (ht < static_cast<uint64_t>(n_records) * 4) ht <<= 1;
     HIP_TRY(hipMalloc(&c->d_halo_recs, static_cast<size_t>(n_records) * kHaloRecWords * sizeof(uint64_t)));
     HIP_TRY(hipMalloc(&c->d_halo_keys, sizeof(uint64_t) * ht));
     HIP_TRY(hipMalloc(&c->d_halo_vals, sizeof(uint32_t) * ht));
     c->halo_cap_total = static_cast<uint32_t>(n_records);
-    c->halo_mask = ht - 1;
   }
+  c->halo_mask = ht - 1;
   // device records are used where they lie (the caller keeps the buffer until the next khr_update_tracking_phase(.., 2)
   // has been queued: stream order does the rest); host records are staged
   if (on_device) {
@@ -3030,10 +3012,13 @@ int khr_mesh_halo_export(khr_ctx* c, const void* requests, int64_t n_requests, v
     return KHR_OK;
   });
   hipError_t e = hipSuccess;
-  if (rc == KHR_OK && !on_device) e = hipMemcpyAsync(records, rec_tmp, bytes, hipMemcpyDeviceToHost, c->stream);
+  uint32_t n_rec = 0;
+  if (rc == KHR_OK) e = hipMemcpyAsync(&n_rec, c->d_mesh_nwork + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess && rc == KHR_OK && !on_device) e = hipMemcpyAsync(records, rec_tmp, bytes, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   if (e != hipSuccess) return fail(KHR_EDEVICE, "mesh halo export failed: %s", hipGetErrorString(e));
-  return rc;
+  if (rc != KHR_OK) return rc;
+  return static_cast<int>(std::min<uint64_t>(n_rec, static_cast<uint64_t>(cap_records)));  // records written (the rest are empty)
 }
 
 int khr_mesh_halo_import(khr_ctx* c, const void* records, int64_t n_records, int on_device) {
@@ -3045,18 +3030,18 @@ int khr_mesh_halo_import(khr_ctx* c, const void* records, int64_t n_records, int
   }
   const size_t words = c->p.vps == 16 ? MeshHalo<16>::kWords : MeshHalo<8>::kWords;
   const bool in_place = on_device == 2;  // the records stay in the caller's device buffer (valid until the mesh has been generated)
+  uint32_t ht = 1;
+  while (ht < static_cast<uint64_t>(n_records) * 4) ht <<= 1;
   if (static_cast<uint64_t>(n_records) > c->mh_cap_total) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->d_mh_recs) { hipFree(c->d_mh_recs); hipFree(c->d_mh_keys); hipFree(c->d_mh_vals); }
     c->d_mh_recs = nullptr;
-    uint32_t ht = 1;
-    while (ht < static_cast<uint64_t>(n_records) * 4) ht <<= 1;
     // (in-place imports only need the index; the record copy buffer is allocated by the first copying import)
     HIP_TRY(hipMalloc(&c->d_mh_keys, sizeof(uint64_t) * ht));
     HIP_TRY(hipMalloc(&c->d_mh_vals, sizeof(uint32_t) * ht));
     c->mh_cap_total = static_cast<uint32_t>(n_records);
-    c->mh_mask = ht - 1;
   }
+  c->mh_mask = ht - 1;  // (a smaller import clears and probes a smaller part of the table)
   const uint32_t* view = static_cast<const uint32_t*>(records);
   if (!in_place) {
     if (!c->d_mh_recs) HIP_TRY(hipMalloc(&c->d_mh_recs, static_cast<size_t>(c->mh_cap_total) * words * 4));

@@ -119,8 +119,10 @@ struct kdist_handle {
   // exchange buffers (HBM)
   uint64_t* halo_send = nullptr;
   uint64_t* halo_recv = nullptr;
-  int64_t* seed_counts = nullptr;             // [n_cameras]
+  int64_t* seed_counts = nullptr;             // [n_cameras + world]: seed pixels per camera, then every rank's live-block bound
   int64_t* h_seed_counts = nullptr;           // pinned mirror of the reduced counts
+  int64_t* xchg = nullptr;                    // [2] device scratch of the small agreement collectives (kdist_output)
+  int64_t* h_xchg = nullptr;                  // pinned mirror
   hipEvent_t ev_counts = nullptr;             // ... have arrived
   std::vector<uint64_t*> keys;                // per camera: per-pixel voxel keys
   std::vector<int32_t*> dyn_img;              // per camera: painted dynamic image + cluster count in the last element
@@ -129,6 +131,7 @@ struct kdist_handle {
   void* frame_recv = nullptr;
   size_t frame_recv_bytes = 0;
   std::vector<int> clusters_last_tick;
+  int64_t halo_per_rank_last_tick = 0, mesh_records_per_rank_last_output = 0;  // what the last exchanges shipped per rank
   std::vector<void*> allocs;
 
   bool exchange() const { return world > 1 || always_exchange; }
@@ -213,8 +216,10 @@ kdist_handle* kdist_create(khr_ctx* ctx, const khr_sensor* sensor, int rank, int
     const size_t W = static_cast<size_t>(world_size);
     h->halo_send = h->alloc<uint64_t>(static_cast<size_t>(halo_cap) * kHaloWords);
     h->halo_recv = h->alloc<uint64_t>(W * static_cast<size_t>(halo_cap) * kHaloWords);
-    h->seed_counts = h->alloc<int64_t>(static_cast<size_t>(n_cameras));
-    KD_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_seed_counts), sizeof(int64_t) * static_cast<size_t>(n_cameras), hipHostMallocDefault));
+    h->seed_counts = h->alloc<int64_t>(static_cast<size_t>(n_cameras) + W);
+    KD_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_seed_counts), sizeof(int64_t) * (static_cast<size_t>(n_cameras) + W), hipHostMallocDefault));
+    h->xchg = h->alloc<int64_t>(2);
+    KD_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_xchg), sizeof(int64_t) * 2, hipHostMallocDefault));
     KD_HIP(hipEventCreateWithFlags(&h->ev_counts, hipEventDisableTiming));
     h->keys.assign(static_cast<size_t>(n_cameras), nullptr);
     h->dyn_img.assign(static_cast<size_t>(n_cameras), nullptr);
@@ -223,6 +228,12 @@ kdist_handle* kdist_create(khr_ctx* ctx, const khr_sensor* sensor, int rank, int
     h->rec_send = h->alloc<uint32_t>(static_cast<size_t>(mesh_rec_cap) * h->mesh_words);
     h->rec_recv = h->alloc<uint32_t>(W * static_cast<size_t>(mesh_rec_cap) * h->mesh_words);
     h->clusters_last_tick.assign(static_cast<size_t>(n_cameras), 0);
+    if (h->exchange() && h->net()) {
+      // the remote-record indices get their full size now (the buffers are zero: no valid record), so that the trimmed
+      // exchanges of the ticks -- whose sizes grow with the map -- never have to re-allocate them with a stream wait
+      KD_KHR(khr_import_halo(ctx, h->halo_recv, static_cast<int64_t>(W) * halo_cap, 1));
+      KD_KHR(khr_mesh_halo_import(ctx, h->rec_recv, static_cast<int64_t>(W) * mesh_rec_cap, 2));
+    }
     KD_HIP(hipStreamSynchronize(h->stream));
     return KHR_OK;
   });
@@ -249,12 +260,21 @@ void kdist_destroy(kdist_handle* h) {
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->frame_recv) (void)hipFree(h->frame_recv);
   if (h->h_seed_counts) (void)hipHostFree(h->h_seed_counts);
+  if (h->h_xchg) (void)hipHostFree(h->h_xchg);
   if (h->ev_counts) (void)hipEventDestroy(h->ev_counts);
   (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
 void* kdist_stream(kdist_handle* h) { return h ? static_cast<void*>(h->stream) : nullptr; }
+
+// records per rank that the last tick's halo all-gather / the last output's mesh-record all-gather shipped (0 = none yet)
+int kdist_last_exchange(kdist_handle* h, int64_t* halo_records_per_rank, int64_t* mesh_records_per_rank) {
+  if (!h) return KHR_EINVAL;
+  if (halo_records_per_rank) *halo_records_per_rank = h->halo_per_rank_last_tick;
+  if (mesh_records_per_rank) *mesh_records_per_rank = h->mesh_records_per_rank_last_output;
+  return KHR_OK;
+}
 
 // all-gather of one packed frame per rank (bytes each) into world_size * bytes at *gathered_out (owned by the handle)
 int kdist_gather_frames(kdist_handle* h, const void* packed_local, size_t bytes, void** gathered_out) {
@@ -302,13 +322,23 @@ int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, 
     if (n == h->world && h->rank < n) (void)khr_detect_objects_launch(c, slots_out[h->rank]);
     // the count exchange goes out right behind the ingest, BEFORE allocation / culling are queued: the host then learns
     // which cameras have seeds while the device still works on those, and queues the update launches without a gap
+    // The same all-reduce also tells every rank how many live blocks (= halo records) the others hold, so that the halo
+    // all-gather of step (5) ships max-over-ranks records per rank instead of halo_cap (at 1080p / 1 cm: 34.6 MB per rank
+    // and tick for ~2.5 MB of records).  The bound is exact only after this tick's allocation, so the allocation launch
+    // goes out first; initialisation + culling follow the exchange and cover the host's wait as before.
     const bool early_counts = h->motion && split && h->net();
+    const bool trim = early_counts && ex;
+    const size_t n_counts = static_cast<size_t>(n) + (trim ? static_cast<size_t>(h->world) : 0u);
+    if (trim) {
+      KD_KHR(khr_tick_integrate(c, slots_out, n, h->motion ? 1 : 0, -1, 4));
+      KD_KHR(khr_tick_live_bound(c, h->seed_counts + n, h->world, h->rank));
+    }
     if (early_counts) {
-      KD_NCCL(rccl().AllReduce(h->seed_counts, h->seed_counts, static_cast<size_t>(n), ncclInt64, ncclSum, h->comm, h->stream));
-      KD_HIP(hipMemcpyAsync(h->h_seed_counts, h->seed_counts, sizeof(int64_t) * static_cast<size_t>(n), hipMemcpyDeviceToHost, h->stream));
+      KD_NCCL(rccl().AllReduce(h->seed_counts, h->seed_counts, n_counts, ncclInt64, ncclSum, h->comm, h->stream));
+      KD_HIP(hipMemcpyAsync(h->h_seed_counts, h->seed_counts, sizeof(int64_t) * n_counts, hipMemcpyDeviceToHost, h->stream));
       KD_HIP(hipEventRecord(h->ev_counts, h->stream));
     }
-    if (split) KD_KHR(khr_tick_integrate(c, slots_out, n, h->motion ? 1 : 0, -1, 1));
+    if (split) KD_KHR(khr_tick_integrate(c, slots_out, n, h->motion ? 1 : 0, -1, trim ? 8 : 1));
     khr_host_trace("kd_alloc_queued");
     if (h->motion) {
       // (3) which cameras have seeds on some rank
@@ -370,10 +400,19 @@ int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, 
     khr_host_trace("kd_update_queued");
     // (5) halo records of every rank, ever-free stencil
     if (ex) {
-      KD_KHR(khr_export_halo(c, h->halo_send, h->halo_cap, 1));
+      // records per rank in the exchange: the fullest rank's live-block bound (known since the count exchange), in granules
+      // of 256 records; a rank beyond halo_cap still overflows loudly (khr_export_halo counts it, kdist_output raises)
+      int64_t per_rank = h->halo_cap;
+      if (trim) {
+        int64_t most = 0;
+        for (int r = 0; r < h->world; ++r) most = std::max(most, h->h_seed_counts[n + r]);
+        per_rank = std::min<int64_t>(h->halo_cap, std::max<int64_t>(256, (most + 255) / 256 * 256));
+      }
+      h->halo_per_rank_last_tick = per_rank;
+      KD_KHR(khr_export_halo(c, h->halo_send, per_rank, 1));
       if (h->net()) {
-        KD_NCCL(rccl().AllGather(h->halo_send, h->halo_recv, static_cast<size_t>(h->halo_cap) * kHaloWords, ncclUint64, h->comm, h->stream));
-        KD_KHR(khr_import_halo(c, h->halo_recv, static_cast<int64_t>(h->world) * h->halo_cap, 1));
+        KD_NCCL(rccl().AllGather(h->halo_send, h->halo_recv, static_cast<size_t>(per_rank) * kHaloWords, ncclUint64, h->comm, h->stream));
+        KD_KHR(khr_import_halo(c, h->halo_recv, static_cast<int64_t>(h->world) * per_rank, 1));
       } else {  // emulation: only this rank's records exist
         KD_KHR(khr_import_halo(c, h->halo_send, h->halo_cap, 1));
       }
@@ -396,9 +435,19 @@ int kdist_output(kdist_handle* h) {
       KD_KHR(khr_mesh_halo_requests(c, h->req_send, h->req_cap, 1, 1));  // (errors when the requests exceed req_cap)
       if (h->net()) {
         KD_NCCL(rccl().AllGather(h->req_send, h->req_recv, static_cast<size_t>(h->req_cap), ncclUint64, h->comm, h->stream));
-        KD_KHR(khr_mesh_halo_export(c, h->req_recv, static_cast<int64_t>(h->world) * h->req_cap, h->rec_send, h->rec_cap, 1));
-        KD_NCCL(rccl().AllGather(h->rec_send, h->rec_recv, static_cast<size_t>(h->rec_cap) * h->mesh_words, ncclUint32, h->comm, h->stream));
-        KD_KHR(khr_mesh_halo_import(c, h->rec_recv, static_cast<int64_t>(h->world) * h->rec_cap, 2));  // indexed where the all-gather put them
+        const int n_rec = khr_mesh_halo_export(c, h->req_recv, static_cast<int64_t>(h->world) * h->req_cap, h->rec_send, h->rec_cap, 1);
+        KD_KHR(n_rec);
+        // the ranks agree on the fullest rank's record count (one 8-byte max all-reduce; the export above has synchronised
+        // anyway) and ship that many records each instead of rec_cap (18 KB per record: 590 MB per rank at the 1 cm rig)
+        h->h_xchg[0] = n_rec;
+        KD_HIP(hipMemcpyAsync(h->xchg, h->h_xchg, sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+        KD_NCCL(rccl().AllReduce(h->xchg, h->xchg, 1, ncclInt64, ncclMax, h->comm, h->stream));
+        KD_HIP(hipMemcpyAsync(h->h_xchg + 1, h->xchg, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        KD_HIP(hipStreamSynchronize(h->stream));
+        const int64_t per_rank = std::min<int64_t>(h->rec_cap, std::max<int64_t>(16, (h->h_xchg[1] + 15) / 16 * 16));
+        h->mesh_records_per_rank_last_output = per_rank;
+        KD_NCCL(rccl().AllGather(h->rec_send, h->rec_recv, static_cast<size_t>(per_rank) * h->mesh_words, ncclUint32, h->comm, h->stream));
+        KD_KHR(khr_mesh_halo_import(c, h->rec_recv, static_cast<int64_t>(h->world) * per_rank, 2));  // indexed where the all-gather put them
       } else {  // emulation: requests and answers of this rank only
         KD_KHR(khr_mesh_halo_export(c, h->req_send, h->req_cap, h->rec_send, h->rec_cap, 1));
         KD_KHR(khr_mesh_halo_import(c, h->rec_send, h->rec_cap, 2));

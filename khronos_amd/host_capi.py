@@ -48,6 +48,7 @@ def load_host_library():
     lib.kdist_gather_frames.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
     lib.kdist_tick.argtypes = [vp, C.c_uint64, vp, i32, vp, vp]
     lib.kdist_output.argtypes = [vp]
+    lib.kdist_last_exchange.argtypes = [vp, vp, vp]
     lib.khr_host_detect_changes.argtypes = [vp, C.c_int64, vp, C.c_int64, C.c_float, C.c_int64, i32, C.c_float, C.c_float, i32, vp]
     _host = lib
     return lib
@@ -199,6 +200,12 @@ class ShardedFusionHost:
 
     def stream(self):
         return self.lib.kdist_stream(self.h)
+
+    def last_exchange(self):
+        """records per rank shipped by the last tick's halo all-gather / the last output's mesh-record all-gather"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._chk(self.lib.kdist_last_exchange(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def gather_frames(self, packed_ptr, nbytes):
         out = C.c_void_p()

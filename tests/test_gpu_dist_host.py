@@ -43,6 +43,11 @@ def test_cxx_rccl_tick_equals_single_context(shard_motion):
             m1, m2 = ctx.download_mesh(), ref.download_mesh()
             assert m1["points"].shape == m2["points"].shape
     assert fired > 0
+    # the all-gathers ship what the fullest rank holds (granules of 256 / 16 records), not the capacities
+    halo_per_rank, mesh_per_rank = sf.last_exchange()
+    n_live = len(ctx.block_indices())
+    assert n_live <= halo_per_rank <= 512 and halo_per_rank % 256 == 0, (halo_per_rank, n_live)  # (capacity 4096; the last tick ran before the last archival)
+    assert 16 <= mesh_per_rank <= 512 and mesh_per_rank % 16 == 0
     a, b = ctx.block_indices(), ref.block_indices()
     assert np.array_equal(a, b) and len(a) > 20
     for idx in a[::2]:

@@ -866,6 +866,20 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
     bool touched = false, wrote_neg = false;
     uint32_t cnt = 0;
     const int n_frames = MULTI ? a.n_frames : 1;
+    // MULTI: distance / weight of the item's voxels live in registers across the frames (one load before the first frame,
+    // one store -- with the stamp of the last frame that updated the voxel -- after the last) instead of a store + reload
+    // round trip per frame; the per-voxel sequence of updates is unchanged
+    float dreg[ZR], wreg[ZR];
+    int lidx[ZR];
+    if (MULTI) {
+#pragma unroll
+      for (int k = 0; k < ZR; ++k) {
+        const uint32_t lin = static_cast<uint32_t>(lin_xy + (z0 + k) * SL);
+        dreg[k] = *reinterpret_cast<const float*>(dist_b + lin * 4u);
+        wreg[k] = *reinterpret_cast<const float*>(wgt_b + lin * 4u);
+        lidx[k] = -1;
+      }
+    }
     uint32_t frame_mask = ~0u;
     if (MULTI && a.item_mask != nullptr) {  // which cameras listed the item (their culling is conservative: the others cannot touch it)
       const size_t mi = slot * static_cast<size_t>(PATCHES * ZSPLIT) + static_cast<size_t>(sbi);
@@ -920,7 +934,10 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
       rb[k] = *reinterpret_cast<const f2u*>(range_b + o1);
       dd[k] = 0.f;
       ww[k] = 0.f;
-      if (ok) {
+      if (MULTI) {
+        dd[k] = dreg[k];
+        ww[k] = wreg[k];
+      } else if (ok) {
         dd[k] = *reinterpret_cast<const float*>(dist_b + lin * 4u);
         ww[k] = *reinterpret_cast<const float*>(wgt_b + lin * 4u);
       }
@@ -1012,7 +1029,13 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
         d_new = __builtin_fmaf(d_old, w_old, sdf_c * w) * __builtin_amdgcn_rcpf(tot);
       }
       const float w_new = fminf(tot, a.max_weight);
-      if (ok) {
+      if (MULTI) {
+        if (ok) {
+          dreg[k] = d_new;
+          wreg[k] = w_new;
+          lidx[k] = fi;
+        }
+      } else if (ok) {
         *reinterpret_cast<float*>(dist_b + lin * 4u) = d_new;
         *reinterpret_cast<float*>(wgt_b + lin * 4u) = w_new;
         if (a.with_tracking) *reinterpret_cast<uint64_t*>(lobs_b + lin * 8u) = F.stamp;
@@ -1056,6 +1079,16 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
       __builtin_amdgcn_wave_barrier();
     }
     }  // frames
+    if (MULTI) {
+#pragma unroll
+      for (int k = 0; k < ZR; ++k) {
+        if (lidx[k] < 0) continue;
+        const uint32_t lin = static_cast<uint32_t>(lin_xy + (z0 + k) * SL);
+        *reinterpret_cast<float*>(dist_b + lin * 4u) = dreg[k];
+        *reinterpret_cast<float*>(wgt_b + lin * 4u) = wreg[k];
+        if (a.with_tracking) *reinterpret_cast<uint64_t*>(lobs_b + lin * 8u) = a.frames[lidx[k]].stamp;
+      }
+    }
     if (lane == 0) {
       if (touched) atomicOr(&a.blk_flags[slot], BLK_UPDATED | BLK_MESH_UPDATED | BLK_TRACKING_UPDATED | (wrote_neg ? BLK_HAS_NEG : 0u));
       a.blk_band[slot * kBandSlots + (sbi & (kBandSlots - 1))] = static_cast<uint16_t>(min(cnt, 65535u));

@@ -794,9 +794,16 @@ void ObjectWorkerPool::stop() {
   workers_.clear();
   std::lock_guard<std::mutex> lock(mutex_);
   queue_.clear();  // (frames of unworked requests are released here)
+  outstanding_.store(in_work_, std::memory_order_release);
 }
 
 void ObjectWorkerPool::join() {
+  // the caller blocks anyway: poll for up to 3 ms before sleeping (an extraction is ~1 ms; waking a thread that sleeps on
+  // a condition variable costs 50 - 100 us here, which a caller that joins at output cadence would pay every time)
+  const auto t0 = std::chrono::steady_clock::now();
+  while (outstanding_.load(std::memory_order_acquire) != 0 &&
+         std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(3))
+    std::this_thread::yield();
   std::unique_lock<std::mutex> lock(mutex_);
   cv_idle_.wait(lock, [&] { return (queue_.empty() && in_work_ == 0) || should_shutdown_; });
   if (!error_.empty()) {
@@ -816,6 +823,7 @@ void ObjectWorkerPool::submit(TimeStamp stamp, Track&& track, const FrameDataBuf
   auto req = std::unique_ptr<Request>(new Request{stamp, std::move(track), frame_data});
   {
     std::lock_guard<std::mutex> lock(mutex_);
+    outstanding_.fetch_add(1, std::memory_order_relaxed);
     queue_.push_back(std::move(req));
   }
   cv_work_.notify_one();
@@ -876,6 +884,7 @@ void ObjectWorkerPool::workerLoop(size_t worker) {
       --in_work_;
       if (attrs) output_.emplace_back(std::move(attrs));
       if (!err.empty()) error_ = err;
+      outstanding_.fetch_sub(1, std::memory_order_release);
     }
     cv_idle_.notify_all();
   }

@@ -10,6 +10,7 @@
 // hydra_compat.h.  Config errors throw std::invalid_argument (the reference aborts in config::checkValid).
 #pragma once
 #include <cstdlib>
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -380,6 +381,7 @@ class ObjectWorkerPool {
   std::vector<std::shared_ptr<KhronosObjectAttributes>> output_;
   std::string error_;
   size_t in_work_ = 0;
+  std::atomic<size_t> outstanding_{0};  // queued + running requests (join() polls it before it sleeps on cv_idle_)
   bool should_shutdown_ = false;
   // env KHR_TEST_EXTRACT_DELAY_MS: every extraction starts this much later (tests of the frame-ring back-pressure)
   int test_delay_ms_ = std::getenv("KHR_TEST_EXTRACT_DELAY_MS") ? std::atoi(std::getenv("KHR_TEST_EXTRACT_DELAY_MS")) : 0;

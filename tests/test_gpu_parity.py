@@ -552,3 +552,48 @@ def test_tick_path_equals_per_frame_calls():
                 assert np.array_equal(g[k], h[k]), (world, k, bi)
         assert world == 1 or seeds_seen > 0
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("spread", [0.25, 7.0])
+def test_tick_path_with_cameras_at_different_positions(spread):
+    """The tick's one allocation launch works on the bounding lattice of the cameras' candidate cubes (0.25 m apart: a box a
+    block or two larger than one cube, blocks outside a camera's own cube must stay out of its list) and falls back to one
+    launch per camera when the cameras are far apart (7 m: the box would be larger than the cubes together); the one update
+    launch walks every item through the cameras that listed it.  Result == per-frame calls in camera order, bit for bit;
+    allocation given in its two halves (phase bits 2 and 3)."""
+    from common import DeviceArray
+    n_cam = 3
+    kw = dict(width=160, height=120, num_frame_slots=2 * n_cam, temporal_window=0.6, temporal_buffer=0.3)
+    cfg, a, _, s, sen, _ = make_pair(**kw)
+    _, b, _, _, sen_b, _ = make_pair(**kw)
+    for tick in range(6):
+        frs = []
+        for k in range(n_cam):
+            T = np.array(s.pose(tick, yaw_offset=0.5 * k), np.float64)
+            T[:3, 3] += np.array([spread * k, -0.5 * spread * k, 0.1 * k])
+            frs.append(s.render(tick, pose=T))
+        stamp = frs[0]["stamp"]
+        tens = [(DeviceArray(f["depth"]), DeviceArray(f["rgb"]), DeviceArray(f["label"])) for f in frs]
+        for f, (d, c, l) in zip(frs, tens):
+            a.integrate(a.upload_frame_device(sen, stamp, f["pose"], d.data_ptr(), c.data_ptr(), l.data_ptr()))
+        a.update_tracking(stamp)
+        frames = [b.make_frame(stamp, f["pose"], d.data_ptr(), c.data_ptr(), l.data_ptr()) for f, (d, c, l) in zip(frs, tens)]
+        slots_b, _ = b.tick_ingest(sen_b, frames, count_seeds=False)
+        b.tick_integrate(slots_b, phases=4)
+        b.tick_integrate(slots_b, phases=8)
+        b.tick_integrate(slots_b, phases=2)
+        b.update_tracking(stamp)
+        a.sync(); b.sync()
+        for t3 in tens:
+            for t in t3:
+                t.free()
+    sa, sb = a.stats(), b.stats()
+    for k in ("cum_updated_voxels", "cum_band_voxels", "n_allocated_blocks"):
+        assert sa[k] == sb[k], (k, sa[k], sb[k])
+    idx = a.block_indices()
+    assert len(idx) > 40 and np.array_equal(idx, b.block_indices())
+    for bi in idx[:: max(1, len(idx) // 80)]:
+        g, h = a.download_block(bi), b.download_block(bi)
+        for k in ("distance", "weight", "color", "last_observed", "last_occupied", "flags", "sem_label", "likelihoods"):
+            assert np.array_equal(g[k], h[k]), (k, bi)
+    a.close(); b.close()

@@ -50,10 +50,7 @@ PY
 rm -rf $O/kt
 # PMC passes on k_fuse (volumetric path only, as in round 2)
 bash tools/r03_pmc.sh hicad base > $O/pmc.log 2>&1; cp gpurun_out/r03pmc_1/k_fuse_pmc.json $O/k_fuse_pmc.json; tail -1 $O/pmc.log | cut -c1-400
-# rig geometries, emulated (communication-free)
-bash tools/r03_emu.sh c5 8 trace > $O/emu_c5.txt 2>&1; head -3 $O/emu_c5.txt
-bash tools/r03_emu.sh c3 8 > $O/emu_c3.txt 2>&1; cat $O/emu_c3.txt
-bash tools/r03_emu.sh c4 4 > $O/emu_c4.txt 2>&1; cat $O/emu_c4.txt
-cp gpurun_out/r03emu/c5_emu8.json gpurun_out/r03emu/c5_n1.json gpurun_out/r03emu/c3_emu8.json gpurun_out/r03emu/c4_emu4.json gpurun_out/r03emu/tr_c5_8_per_tick.csv $O/ 2>/dev/null
+# rig geometries (emulated ticks, A/B, tick-path tests) and the queue-atomics micro-benchmark
+bash tools/r03_artifacts_tick.sh
 ./tools/ubench/tcp_reads 4096 > $O/tcp_reads.txt 2>&1
 timeout 300 python tools/probe_fuse.py 70 > $O/probe_fuse.txt 2>&1

@@ -388,7 +388,11 @@ typedef struct khr_snapshot khr_snapshot;
 #define KHR_SNAP_LAST_OBSERVED 8u
 #define KHR_SNAP_FLAGS 16u
 #define KHR_SNAP_LABEL 32u
-#define KHR_SNAP_ALL 63u
+#define KHR_SNAP_ALL 63u            /* the fields of khr_download_updated */
+#define KHR_SNAP_LAST_OCCUPIED 64u  /* TrackingVoxel::last_occupied */
+#define KHR_SNAP_LIKELIHOODS 128u   /* SemanticVoxel::semantic_likelihoods: num_labels floats per voxel (80 of a voxel's 113 bytes at 20
+                                       labels: opt-in; consumers of the output map read the label) */
+#define KHR_SNAP_EVERYTHING 255u    /* what a deep copy of the reference's blocks holds */
 int khr_snapshot_updated(khr_ctx* ctx, uint32_t fields, int64_t cap_blocks, khr_snapshot** out);
 /* the snapshot queued by the last khr_process_frame(.. KHR_PF_SNAPSHOT ..); NULL (and KHR_ENOTFOUND) if there is none */
 int khr_take_snapshot(khr_ctx* ctx, khr_snapshot** out);
@@ -400,6 +404,9 @@ int64_t khr_snapshot_num_blocks(khr_snapshot* snap);
  * block count. */
 int64_t khr_snapshot_download(khr_snapshot* snap, int32_t* indices, float* distance, float* weight, uint8_t* color_rgba,
                               uint64_t* last_observed, uint8_t* voxel_flags, uint32_t* sem_label, int64_t cap_blocks);
+/* the two optional fields (same order of blocks; likelihoods: cap_blocks * nvox * num_labels floats, voxel-major) */
+int64_t khr_snapshot_download_extra(khr_snapshot* snap, int32_t* indices, uint64_t* last_occupied, float* likelihoods,
+                                    int64_t cap_blocks);
 /* give the snapshot's arena back to its context's pool (safe after khr_destroy too: the arena is then freed; a
  * download after khr_destroy fails with KHR_ESTATE) */
 void khr_snapshot_release(khr_snapshot* snap);

@@ -78,7 +78,7 @@ EXPORTS = [
     "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",
     "khr_cluster_voxels", "khr_download_frame_image", "khr_detect_objects_launch", "khr_pool_exhausted",
     "khr_rv_create", "khr_rv_destroy", "khr_rv_clear", "khr_rv_add_rays", "khr_rv_num_rays", "khr_rv_num_pairs", "khr_rv_check",
-    "khr_snapshot_updated", "khr_take_snapshot", "khr_snapshot_num_blocks", "khr_snapshot_download", "khr_snapshot_release",
+    "khr_snapshot_updated", "khr_take_snapshot", "khr_snapshot_num_blocks", "khr_snapshot_download", "khr_snapshot_download_extra", "khr_snapshot_release",
     "khr_rv_check_stamps", "khr_get_config", "khr_cluster_voxels_launch", "khr_cluster_voxels_fetch", "khr_reset_map", "khr_depend_on", "khr_retain_slot", "khr_release_slot",
 ]
 
@@ -175,6 +175,8 @@ def load_library():
     lib.khr_snapshot_num_blocks.restype = i64
     lib.khr_snapshot_download.argtypes = [vp] + [vp] * 7 + [i64]
     lib.khr_snapshot_download.restype = i64
+    lib.khr_snapshot_download_extra.argtypes = [vp, vp, vp, vp, i64]
+    lib.khr_snapshot_download_extra.restype = i64
     lib.khr_snapshot_release.argtypes = [vp]
     lib.khr_snapshot_release.restype = None
     lib.khr_mesh_num_vertices.argtypes = [vp]
@@ -651,6 +653,17 @@ class Snapshot:
                                                              _ptr(out["color"]), _ptr(out["last_observed"]), _ptr(out["flags"]),
                                                              _ptr(out["sem_label"]), n))
         # the C ABI hands the blocks out in the snapshot's own order; sorted by block index here (tests, small maps)
+        order = np.lexsort((out["indices"][:k, 2], out["indices"][:k, 1], out["indices"][:k, 0]))
+        return {a: b[:k][order] for a, b in out.items()}
+
+    def download_extra(self, num_labels):
+        """the optional fields (KHR_SNAP_LAST_OCCUPIED = 64, KHR_SNAP_LIKELIHOODS = 128), blocks sorted by index"""
+        n = max(1, self.num_blocks())
+        nv = self.ctx.nvox
+        out = {"indices": np.zeros((n, 3), np.int32), "last_occupied": np.zeros((n, nv), np.uint64),
+               "likelihoods": np.zeros((n, nv, num_labels), np.float32)}
+        k = self.ctx._chk(self.ctx.lib.khr_snapshot_download_extra(self.h, _ptr(out["indices"]), _ptr(out["last_occupied"]),
+                                                                   _ptr(out["likelihoods"]), n))
         order = np.lexsort((out["indices"][:k, 2], out["indices"][:k, 1], out["indices"][:k, 0]))
         return {a: b[:k][order] for a, b in out.items()}
 

@@ -1331,6 +1331,10 @@ struct PackOut {
   uint64_t* last_obs;
   uint8_t* vflags;
   uint32_t* sem_label;
+  uint64_t* last_occ;  // (snapshots only)
+  float* lik;          // (snapshots only) K floats per voxel, voxel-major as in the pool
+  int K;
+  uint64_t track_stamp;  // stamp of the latest tracking pass = last_occupied of every voxel that is occupied now (stored lazily)
 };
 template <int VPS>
 __global__ __launch_bounds__(256) void k_pack_blocks(DevMap m, const uint32_t* __restrict__ slots, int n, PackOut o) {
@@ -1412,6 +1416,11 @@ __global__ __launch_bounds__(256) void k_snapshot_pack(DevMap m, const uint32_t*
       }
     }
     if (o.sem_label) copy16(m.sem_label + src, o.sem_label + dst, NV * 4);
+    if (o.last_occ) {  // (the pool stores it lazily: an occupied voxel's stamp is the latest tracking pass's, k_tracking_update)
+      for (int i = threadIdx.x; i < NV; i += 256)
+        o.last_occ[dst + i] = (m.vflags[src + i] & VOX_OCC) ? o.track_stamp : m.last_occ[src + i];
+    }
+    if (o.lik) copy16(m.lik + src * o.K, o.lik + dst * o.K, static_cast<size_t>(NV) * o.K * 4);
   }
 }
 

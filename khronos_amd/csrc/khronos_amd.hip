@@ -3493,7 +3493,7 @@ struct khr_snapshot {
   int64_t total = -1;    // updated blocks found (> cap: overflow)
 };
 
-static size_t snapBytes(uint32_t fields, size_t cap, size_t nvox, bool trk, bool sem) {
+static size_t snapBytes(uint32_t fields, size_t cap, size_t nvox, bool trk, bool sem, size_t K) {
   auto al = [](size_t b) { return (b + 255) / 256 * 256; };
   size_t b = 256 + al(cap * 4) + al(cap * 16);
   if (fields & KHR_SNAP_DISTANCE) b += al(cap * nvox * 4);
@@ -3502,17 +3502,19 @@ static size_t snapBytes(uint32_t fields, size_t cap, size_t nvox, bool trk, bool
   if ((fields & KHR_SNAP_LAST_OBSERVED) && trk) b += al(cap * nvox * 8);
   if (fields & KHR_SNAP_FLAGS) b += al(cap * nvox);
   if ((fields & KHR_SNAP_LABEL) && sem) b += al(cap * nvox * 4);
+  if ((fields & KHR_SNAP_LAST_OCCUPIED) && trk) b += al(cap * nvox * 8);
+  if ((fields & KHR_SNAP_LIKELIHOODS) && sem) b += al(cap * nvox * 4 * K);
   return b;
 }
 
 int khr_snapshot_updated(khr_ctx* c, uint32_t fields, int64_t cap_blocks, khr_snapshot** out) {
-  if (!c || !out || !(fields & KHR_SNAP_ALL)) return fail(KHR_EINVAL, "bad argument");
+  if (!c || !out || !(fields & KHR_SNAP_EVERYTHING)) return fail(KHR_EINVAL, "bad argument");
   *out = nullptr;
   HIP_TRY(hipSetDevice(c->device));
   const bool trk = c->cfg.with_tracking, sem = c->cfg.with_semantics;
   const size_t cap = cap_blocks > 0 ? static_cast<size_t>(std::min<int64_t>(cap_blocks, c->m.capacity)) : c->m.capacity;
   const size_t nvox = c->p.nvox;
-  const size_t need = snapBytes(fields, cap, nvox, trk, sem);
+  const size_t need = snapBytes(fields, cap, nvox, trk, sem, static_cast<size_t>(c->p.K));
   auto snap = std::make_unique<khr_snapshot>();
   {
     auto& fr = c->snap_pool->free;
@@ -3564,6 +3566,10 @@ int khr_snapshot_updated(khr_ctx* c, uint32_t fields, int64_t cap_blocks, khr_sn
   if ((fields & KHR_SNAP_LAST_OBSERVED) && trk) snap->o.last_obs = reinterpret_cast<uint64_t*>(carve(cap * nvox * 8));
   if (fields & KHR_SNAP_FLAGS) snap->o.vflags = carve(cap * nvox);
   if ((fields & KHR_SNAP_LABEL) && sem) snap->o.sem_label = reinterpret_cast<uint32_t*>(carve(cap * nvox * 4));
+  if ((fields & KHR_SNAP_LAST_OCCUPIED) && trk) snap->o.last_occ = reinterpret_cast<uint64_t*>(carve(cap * nvox * 8));
+  if ((fields & KHR_SNAP_LIKELIHOODS) && sem) snap->o.lik = reinterpret_cast<float*>(carve(cap * nvox * 4 * static_cast<size_t>(c->p.K)));
+  snap->o.K = c->p.K;
+  snap->o.track_stamp = c->last_track_stamp;
   hipError_t e = hipMemsetAsync(snap->d_count, 0, 4, c->stream);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_snapshot_select, dim3(gridFor(c->m.capacity)), dim3(256), 0, c->stream, c->m, snap->d_count, snap->d_slots,
@@ -3611,8 +3617,9 @@ int64_t khr_snapshot_num_blocks(khr_snapshot* s) {
   return rc ? rc : s->total;
 }
 
-int64_t khr_snapshot_download(khr_snapshot* s, int32_t* indices, float* distance, float* weight, uint8_t* color_rgba,
-                              uint64_t* last_observed, uint8_t* voxel_flags, uint32_t* sem_label, int64_t cap_blocks) {
+static int64_t snapshotDownload(khr_snapshot* s, int32_t* indices, float* distance, float* weight, uint8_t* color_rgba,
+                                uint64_t* last_observed, uint8_t* voxel_flags, uint32_t* sem_label, uint64_t* last_occupied,
+                                float* likelihoods, int64_t cap_blocks) {
   if (!s) return fail(KHR_EINVAL, "null snapshot");
   int rc = snapshotWait(s);
   if (rc) return rc;
@@ -3650,9 +3657,20 @@ int64_t khr_snapshot_download(khr_snapshot* s, int32_t* indices, float* distance
   field(last_observed, s->o.last_obs, 8);
   field(voxel_flags, s->o.vflags, 1);
   field(sem_label, s->o.sem_label, 4);
+  field(last_occupied, s->o.last_occ, 8);
+  field(likelihoods, s->o.lik, 4 * static_cast<size_t>(s->o.K));
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   if (e != hipSuccess) return fail(KHR_EDEVICE, "snapshot download failed: %s", hipGetErrorString(e));
   return n;
+}
+
+int64_t khr_snapshot_download(khr_snapshot* s, int32_t* indices, float* distance, float* weight, uint8_t* color_rgba,
+                              uint64_t* last_observed, uint8_t* voxel_flags, uint32_t* sem_label, int64_t cap_blocks) {
+  return snapshotDownload(s, indices, distance, weight, color_rgba, last_observed, voxel_flags, sem_label, nullptr, nullptr, cap_blocks);
+}
+
+int64_t khr_snapshot_download_extra(khr_snapshot* s, int32_t* indices, uint64_t* last_occupied, float* likelihoods, int64_t cap_blocks) {
+  return snapshotDownload(s, indices, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, last_occupied, likelihoods, cap_blocks);
 }
 
 void khr_snapshot_release(khr_snapshot* s) {

@@ -17,7 +17,7 @@ UPDATED = 1  # KHR_BLK_UPDATED
 def _oracle_updated(ora):
     out = {}
     for idx in ora.block_indices():
-        b = ora.get_block(idx, likelihoods=False)
+        b = ora.get_block(idx, likelihoods=True)
         if b["block_flags"] & UPDATED:
             out[tuple(int(x) for x in idx)] = b
     return out
@@ -47,7 +47,7 @@ def test_snapshot_outlives_map_changes(fused):
             ctx.update_tracking(fr["stamp"])
             if out_now:
                 ctx.generate_mesh(True, True)
-                snaps.append(ctx.snapshot_updated())
+                snaps.append(ctx.snapshot_updated(fields=255))  # KHR_SNAP_EVERYTHING: + last_occupied, likelihoods
                 ctx.reset_inactive()
                 ctx.clear_updated()
         _, dyn_o, _ = ora.detect_motion(osen, fr["stamp"], fr["pose"], fr["depth"])
@@ -73,6 +73,14 @@ def test_snapshot_outlives_map_changes(fused):
             assert np.array_equal(g["distance"][j], o["distance"]) and np.array_equal(g["weight"][j], o["weight"]), k
             assert np.array_equal(g["color"][j], o["color"]) and np.array_equal(g["sem_label"][j], o["sem_label"]), k
             assert np.array_equal(g["last_observed"][j], o["last_observed"]) and np.array_equal(g["flags"][j], o["flags"]), k
+        if not fused:  # the two optional fields: a deep copy of everything the reference's blocks hold
+            x = snap.download_extra(cfg.num_labels)
+            assert [tuple(int(v) for v in r) for r in x["indices"]] == keys
+            for j, k in enumerate(keys):
+                o = w[k]
+                assert np.array_equal(x["last_occupied"][j], o["last_occupied"]), k
+                valid = (o["flags"] & 8) != 0  # VOX_SEM_VALID: rows of voxels that never saw a label are unspecified
+                assert np.array_equal(x["likelihoods"][j][valid], o["likelihoods"].reshape(cfg.num_labels, -1).T[valid]), k  # ([k][voxel] there)
         snap.release()
     assert archived_something, "some snapshotted block must have left the map by the time the snapshot is read"
     # the first snapshot differs from the live map by now (otherwise the test proves nothing)

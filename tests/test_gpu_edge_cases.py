@@ -139,3 +139,36 @@ def test_oversized_frame_is_rejected():
     step_both(ctx, ora, sen, osen, s.render(0))
     assert np.array_equal(ctx.block_indices(), ora.block_indices())
     ctx.close(); ora.close()
+
+
+@pytest.mark.parametrize("n_cam", [1, 3])
+def test_tick_with_blind_cameras(n_cam):
+    """The one-launch tick (khr_tick_*) when a camera of the rig delivers no valid measurement, when ALL cameras of a tick are
+    blind (empty union list, every camera mask zero), and for a 'rig' of one camera: == the oracle fed frame by frame."""
+    from common import DeviceArray
+    cfg, ctx, ora, s, sen, osen = make_pair(width=160, height=120, num_frame_slots=2 * n_cam)
+    for tick in range(5):
+        frs = [s.render(tick, yaw_offset=0.6 * k) for k in range(n_cam)]
+        for k, f in enumerate(frs):
+            if tick == 2 or (tick in (1, 3) and k == n_cam - 1 and n_cam > 1):  # tick 2: everybody blind
+                f["depth"] = np.zeros_like(f["depth"])
+        stamp = frs[0]["stamp"]
+        tens = [(DeviceArray(f["depth"]), DeviceArray(f["rgb"]), DeviceArray(f["label"])) for f in frs]
+        frames = [ctx.make_frame(stamp, f["pose"], d.data_ptr(), c.data_ptr(), l.data_ptr()) for f, (d, c, l) in zip(frs, tens)]
+        slots, _ = ctx.tick_ingest(sen, frames, count_seeds=False)
+        ctx.tick_integrate(slots, phases=3)
+        ctx.update_tracking(stamp)
+        ctx.sync()
+        ou = ob = 0
+        for f in frs:
+            so = ora.integrate(osen, stamp, f["pose"], f["depth"], f["rgb"], f["label"])
+            ou, ob = ou + so["n_updated_voxels"], ob + so["n_band_voxels"]
+        ora.update_tracking(stamp)
+        st = ctx.stats()
+        assert st["n_updated_voxels"] == ou and st["n_band_voxels"] == ob, (tick, st["n_updated_voxels"], ou)
+        for t3 in tens:
+            for t in t3:
+                t.free()
+    assert np.array_equal(ctx.block_indices(), ora.block_indices())
+    compare_maps(ctx, ora, max_blocks=80)
+    ctx.close(); ora.close()

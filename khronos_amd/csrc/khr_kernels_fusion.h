@@ -219,7 +219,8 @@ struct TickFrusta {
   float R[kMaxTick][9], t[kMaxTick][3], max_range[kMaxTick];
   DevFrustum fr[kMaxTick];
 };
-__global__ __launch_bounds__(256) void k_tick_alloc(DevMap m, DevParams p, TickFrusta tf, int ncam, int3 lo, int3 dim,
+constexpr int kTickAllocThreads = 1024;
+__global__ __launch_bounds__(kTickAllocThreads) void k_tick_alloc(DevMap m, DevParams p, TickFrusta tf, int ncam, int3 lo, int3 dim,
                                                    uint32_t* __restrict__ work, uint32_t list_stride,
                                                    uint32_t* __restrict__ new_list, uint32_t* __restrict__ tick_counts, int epoch) {
   const int total = dim.x * dim.y * dim.z;
@@ -276,20 +277,32 @@ __global__ __launch_bounds__(256) void k_tick_alloc(DevMap m, DevParams p, TickF
   const uint32_t nidx = waveAggInc(&m.counters[C_N_NEW], got);
   if (got) new_list[nidx] = slot;
   if (slot == kInvalidSlot) seen = 0u;
-  uint32_t n_lists = 0u;
-  for (int k = 0; k < ncam; ++k) {  // (wave-uniform trip count; a camera no lane sees costs one ballot)
-    const bool emit = (seen >> k) & 1u;
-    if (__ballot(emit) == 0ull) continue;
-    const uint32_t widx = waveAggInc(&tick_counts[2 * k], emit);
-    if (emit) work[static_cast<size_t>(k) * list_stride + widx] = slot;
-    n_lists += emit ? 1u : 0u;
+  // list appends: positions inside the workgroup's share from LDS counters, ONE global cursor update per camera and
+  // workgroup (a hot counter retires an atomic every ~12 - 16 ns: with one per wave and camera -- and one more per wave for
+  // the statistics total -- this kernel spent most of its time queueing on ten addresses at the 1 cm rig geometry)
+  __shared__ uint32_t s_cnt[kMaxTick], s_base[kMaxTick];
+  if (threadIdx.x < kMaxTick) s_cnt[threadIdx.x] = 0u;
+  __syncthreads();
+  uint32_t loff[kMaxTick];
+#pragma unroll
+  for (int k = 0; k < kMaxTick; ++k) {
+    loff[k] = 0u;
+    if (k < ncam) loff[k] = waveAggInc(&s_cnt[k], ((seen >> k) & 1u) != 0u);
   }
-  // counters[C_N_VISIBLE] runs on as the tick's total over the cameras (statistics), as with one launch per camera
-  if (__ballot(n_lists != 0u) != 0ull) {
-    uint32_t tot = n_lists;
-    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-    if ((threadIdx.x & 63u) == 0u) atomicAdd(&m.counters[C_N_VISIBLE], tot);
+  __syncthreads();
+  if (threadIdx.x < static_cast<uint32_t>(ncam)) {
+    const uint32_t n = s_cnt[threadIdx.x];
+    s_base[threadIdx.x] = n ? atomicAdd(&tick_counts[2 * threadIdx.x], n) : 0u;
   }
+  if (threadIdx.x == 64) {  // counters[C_N_VISIBLE] runs on as the tick's total over the cameras (statistics)
+    uint32_t tot = 0u;
+    for (int k = 0; k < ncam; ++k) tot += s_cnt[k];
+    if (tot) atomicAdd(&m.counters[C_N_VISIBLE], tot);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kMaxTick; ++k)
+    if (k < ncam && ((seen >> k) & 1u)) work[static_cast<size_t>(k) * list_stride + s_base[k] + loff[k]] = slot;
 }
 
 __global__ void k_begin_integrate(DevMap m, int nvox, uint32_t* wg_stats) {

@@ -1772,7 +1772,7 @@ int khr_tick_integrate(khr_ctx* c, const int* slots, int n_frames, int use_mask,
       }
       const size_t box = static_cast<size_t>(hi[0] - lo[0] + 1) * static_cast<size_t>(hi[1] - lo[1] + 1) * static_cast<size_t>(hi[2] - lo[2] + 1);
       if (kTickUnion && nb > 1 && box <= cubes && box < (1ull << 31)) {
-        hipLaunchKernelGGL(k_tick_alloc, dim3(gridFor(box)), dim3(256), 0, c->stream, m, c->p, tf, nb, make_int3(lo[0], lo[1], lo[2]),
+        hipLaunchKernelGGL(k_tick_alloc, dim3(static_cast<unsigned>((box + kTickAllocThreads - 1) / kTickAllocThreads)), dim3(kTickAllocThreads), 0, c->stream, m, c->p, tf, nb, make_int3(lo[0], lo[1], lo[2]),
                            make_int3(hi[0] - lo[0] + 1, hi[1] - lo[1] + 1, hi[2] - lo[2] + 1), c->d_tick_work, cap, c->d_new,
                            c->d_tick_counts, c->motion_ignore_epoch);
       } else {

@@ -452,6 +452,31 @@ int64_t khr_download_mesh(khr_ctx* ctx, float* points, uint8_t* colors_rgba, uin
 int khr_tick_ingest(khr_ctx* ctx, const khr_sensor* sensor, const khr_frame* frames, int n_frames, int count_seeds,
                     int* slots_out, uint32_t* n_seed_pixels, int64_t* seed_counts_device);
 int khr_tick_seed_counts(khr_ctx* ctx, uint32_t* n_seed_pixels, int n_frames);
+/* Sender-side ingest of a sharded rig.  With khr_tick_ingest every rank converts every camera's raw frame (depth -> range,
+ * rgb -> rgba8, max-range tiles: 11 B read + 20 B written per pixel and camera), work that grows with the rank count.
+ * Instead a rank converts only its OWN camera (khr_tick_ingest with one frame, or khr_upload_frame), packs the converted
+ * planes (khr_export_converted: [range f32 | rgba8 | label i32 | max-range tiles], khr_converted_bytes bytes, + [depth] on
+ * request), the ranks all-gather the packed buffers, and every rank ADOPTS all cameras where the all-gather put them
+ * (khr_converted_views makes the plane pointers of one packed buffer): khr_tick_adopt takes the place of khr_tick_ingest
+ * -- same slots, same seed counts, same results downstream -- but touches 8 bytes per pixel (seed test + reset of the
+ * dynamic image) and copies nothing.  The planes must stay valid and unchanged until the tick's last consumer (update /
+ * motion / object kernels of those slots) has been queued behind them and has run, i.e. until the caller overwrites the
+ * receive buffer in stream order.  `depth` may be NULL when the integrator's range mode is the default (0): depth is then
+ * bit-identical to range wherever it is read. */
+typedef struct khr_converted_frame {
+  uint64_t timestamp_ns;
+  double world_T_sensor[16];
+  const float* range;     /* W x H, device */
+  const float* depth;     /* W x H or NULL */
+  const uint32_t* rgba;   /* W x H or NULL */
+  const int32_t* label;   /* W x H or NULL */
+  const float* tile_max;  /* ceil(W / 16) x ceil(H / 16): largest range per 16 x 16-pixel tile */
+} khr_converted_frame;
+size_t khr_converted_bytes(const khr_sensor* sensor, int with_depth);
+int khr_export_converted(khr_ctx* ctx, int slot, void* packed_device, int with_depth);
+int khr_converted_views(const khr_sensor* sensor, const void* packed_device, int with_depth, khr_converted_frame* out);
+int khr_tick_adopt(khr_ctx* ctx, const khr_sensor* sensor, const khr_converted_frame* frames, int n_frames, int count_seeds,
+                   int* slots_out, uint32_t* n_seed_pixels, int64_t* seed_counts_device);
 int khr_tick_integrate(khr_ctx* ctx, const int* slots, int n_frames, int use_mask, int object_id, int phases);
 int khr_tick_live_bound(khr_ctx* ctx, int64_t* out_device, int n_out, int index);
 

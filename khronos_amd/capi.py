@@ -45,6 +45,11 @@ class KhrFrame(C.Structure):
                 ("color", C.c_void_p), ("label", C.c_void_p)]
 
 
+class KhrConvertedFrame(C.Structure):
+    _fields_ = [("timestamp_ns", C.c_uint64), ("world_T_sensor", C.c_double * 16), ("range", C.c_void_p), ("depth", C.c_void_p),
+                ("rgba", C.c_void_p), ("label", C.c_void_p), ("tile_max", C.c_void_p)]
+
+
 class KhrCluster(C.Structure):
     _fields_ = [("id", C.c_int32), ("num_pixels_listed", C.c_uint64), ("num_pixels_painted", C.c_uint32),
                 ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("centroid", C.c_float * 3),
@@ -72,7 +77,8 @@ EXPORTS = [
     "khr_detect_motion", "khr_generate_mesh", "khr_reset_inactive", "khr_mark_all_inactive", "khr_clear_updated",
     "khr_allocate_blocks", "khr_object_prune", "khr_get_stats", "khr_num_blocks", "khr_block_indices",
     "khr_download_block", "khr_mesh_num_vertices", "khr_download_mesh", "khr_fetch_mesh", "khr_fetch_mesh_into", "khr_timing_enable", "khr_timing_reset",
-    "khr_timing_get", "khr_debug_read", "khr_tick_ingest", "khr_tick_integrate", "khr_tick_live_bound", "khr_tick_seed_counts", "khr_copy_frame_image", "khr_rv_detect_changes", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_integrate_shared_batch", "khr_pixel_iou", "khr_forward_instances", "khr_update_tracking_phase",
+    "khr_timing_get", "khr_debug_read", "khr_tick_ingest", "khr_tick_integrate", "khr_tick_live_bound", "khr_tick_seed_counts", "khr_converted_bytes", "khr_export_converted",
+    "khr_converted_views", "khr_tick_adopt", "khr_copy_frame_image", "khr_rv_detect_changes", "khr_last_removed", "khr_process_frame", "khr_integrate_shared", "khr_integrate_shared_batch", "khr_pixel_iou", "khr_forward_instances", "khr_update_tracking_phase",
     "khr_export_halo", "khr_import_halo", "khr_get_dynamic_clusters", "khr_motion_keys",
     "khr_detect_motion_from_keys", "khr_download_updated", "khr_mesh_halo_requests", "khr_mesh_halo_export",
     "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",
@@ -190,6 +196,11 @@ def load_library():
     lib.khr_tick_ingest.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     lib.khr_tick_seed_counts.argtypes = [vp, vp, i32]
     lib.khr_tick_live_bound.argtypes = [vp, vp, i32, i32]
+    lib.khr_converted_bytes.argtypes = [vp, i32]
+    lib.khr_converted_bytes.restype = C.c_size_t
+    lib.khr_export_converted.argtypes = [vp, i32, vp, i32]
+    lib.khr_converted_views.argtypes = [vp, vp, i32, vp]
+    lib.khr_tick_adopt.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     lib.khr_copy_frame_image.argtypes = [vp, i32, i32, vp]
     lib.khr_tick_integrate.argtypes = [vp, vp, i32, i32, i32, i32]
     lib.khr_last_removed.argtypes = [vp, vp, i64, C.POINTER(i64)]
@@ -308,6 +319,37 @@ class FusionContext:
     def copy_frame_image(self, slot, which, device_ptr):
         """dynamic (0) / object (1) image of a frame slot into a device buffer (int32, W*H), asynchronously."""
         self._chk(self.lib.khr_copy_frame_image(self.h, int(slot), int(which), C.c_void_p(device_ptr)))
+
+    # ---- sender-side ingest: converted planes travel instead of raw frames ----
+    def converted_bytes(self, sensor, with_depth=False):
+        return int(self.lib.khr_converted_bytes(C.byref(sensor), int(with_depth)))
+
+    def export_converted(self, slot, packed_device_ptr, with_depth=False):
+        self._chk(self.lib.khr_export_converted(self.h, int(slot), C.c_void_p(packed_device_ptr), int(with_depth)))
+
+    def converted_frame(self, sensor, packed_device_ptr, stamp_ns, world_T_sensor, with_depth=False, has_color=True, has_label=True):
+        """khr_converted_frame whose planes point into one packed buffer (khr_converted_views)"""
+        f = KhrConvertedFrame()
+        self._chk(self.lib.khr_converted_views(C.byref(sensor), C.c_void_p(packed_device_ptr), int(with_depth), C.byref(f)))
+        f.timestamp_ns = int(stamp_ns)
+        T = np.ascontiguousarray(world_T_sensor, dtype=np.float64).reshape(16)
+        for i in range(16):
+            f.world_T_sensor[i] = T[i]
+        if not has_color:
+            f.rgba = None
+        if not has_label:
+            f.label = None
+        return f
+
+    def tick_adopt(self, sensor, conv_frames, count_seeds=True, want_counts=True, counts_device_ptr=0):
+        """khr_tick_adopt: khr_tick_ingest for frames whose converted planes already lie in device memory"""
+        n = len(conv_frames)
+        arr = (KhrConvertedFrame * n)(*conv_frames)
+        slots = (C.c_int * n)()
+        counts = (C.c_uint32 * n)() if want_counts else None
+        self._chk(self.lib.khr_tick_adopt(self.h, C.byref(sensor), arr, n, 1 if count_seeds else 0, slots, counts,
+                                          C.c_void_p(counts_device_ptr or None)))
+        return list(slots), (list(counts) if want_counts else None)
 
     def tick_seed_counts(self, n):
         counts = (C.c_uint32 * n)()

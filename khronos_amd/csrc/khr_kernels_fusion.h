@@ -106,6 +106,53 @@ __global__ __launch_bounds__(256) void k_tick_ingest(TickIngest t, int tw, int W
     atomicAdd(&seed_counts[cam], static_cast<uint32_t>(__popcll(b)));
 }
 
+// frames that were converted elsewhere (khr_tick_adopt; sender-side ingest of a sharded rig: every rank converts its own
+// camera's frame and the ranks exchange the CONVERTED planes): what is left to do per pixel on the receiving side is the
+// dynamic image's reset and the motion detector's seed test against this shard's blocks -- 4 B read + 4 B written per
+// pixel against the 11 + 20 of the conversion.  depth == nullptr: range_mode 0, where depth == range wherever it is read.
+struct TickAdopt {
+  const float* range[kMaxTick];
+  const float* depth[kMaxTick];
+  int32_t* dyn[kMaxTick];
+  float Rw[kMaxTick][9], tw[kMaxTick][3], min_z_world[kMaxTick];
+};
+__global__ __launch_bounds__(256) void k_tick_adopt(TickAdopt t, int W, int H, float fx, float fy, float cx, float cy, DevMap m,
+                                                   DevParams p, float md_max_range, int count_seeds,
+                                                   uint32_t* __restrict__ seed_counts) {
+  const int cam = blockIdx.y;
+  if (blockIdx.x == 0 && cam == 0 && threadIdx.x == 0) m.counters[C_N_SEEDS] = 0u;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool seed = false;
+  if (i < W * H) {
+    t.dyn[cam][i] = 0;
+    if (count_seeds) {
+      const float r = t.range[cam][i];
+      const float d = t.depth[cam] ? t.depth[cam][i] : r;
+      const uint64_t key = motionPixelKey(m, p, r, d, i % W, i / W, fx, fy, cx, cy, t.Rw[cam], t.tw[cam], md_max_range, t.min_z_world[cam]);
+      seed = key != ~0ull && (key & kSeedFlag);
+    }
+  }
+  const unsigned long long b = __ballot(seed);
+  if (b && laneId() == static_cast<uint32_t>(__ffsll(static_cast<long long>(b)) - 1))
+    atomicAdd(&seed_counts[cam], static_cast<uint32_t>(__popcll(b)));
+}
+
+// the converted planes of a frame slot, packed for the exchange: [range | rgba | label | tile_max] (+ [depth] when asked for)
+__global__ __launch_bounds__(256) void k_pack_converted(const float* __restrict__ range, const uint32_t* __restrict__ rgba,
+                                                       const int32_t* __restrict__ label, const float* __restrict__ tile_max,
+                                                       const float* __restrict__ depth, uint32_t n, uint32_t n_tiles,
+                                                       uint32_t tiles_padded, uint32_t* __restrict__ out) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    out[i] = __float_as_uint(range[i]);
+    out[n + i] = rgba ? rgba[i] : 0u;
+    out[2 * n + i] = label ? static_cast<uint32_t>(label[i]) : 0u;
+    if (depth) out[3 * n + tiles_padded + i] = __float_as_uint(depth[i]);
+  }
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < tiles_padded; i += stride)
+    out[3 * n + i] = i < n_tiles ? __float_as_uint(tile_max[i]) : 0u;
+}
+
 // per-camera counts of a tick -> pinned host memory + ticket (one workgroup, plain stores); the device copies are
 // zeroed for the next tick
 __global__ void k_tick_publish(uint32_t* __restrict__ counts, int n, volatile uint32_t* __restrict__ host_counts,

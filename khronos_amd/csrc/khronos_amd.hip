@@ -66,6 +66,18 @@ struct FrameSlot {
   int32_t* obj = nullptr;
   uint8_t* rgb_staging = nullptr;
   float* tile_max = nullptr;
+  // adopted frames (khr_tick_adopt): the converted planes stay where the caller has them (e.g. the receive buffer of the
+  // ranks' all-gather) and the slot only refers to them; nullptr = the slot's own arrays.  Reset when the slot is re-acquired.
+  const float* x_depth = nullptr;
+  const float* x_range = nullptr;
+  const uint32_t* x_rgba = nullptr;
+  const int32_t* x_label = nullptr;
+  const float* x_tile_max = nullptr;
+  const float* vDepth() const { return x_depth ? x_depth : depth; }
+  const float* vRange() const { return x_range ? x_range : range; }
+  const uint32_t* vRgba() const { return x_rgba ? x_rgba : rgba; }
+  const int32_t* vLabel() const { return x_label ? x_label : label; }
+  const float* vTileMax() const { return x_tile_max ? x_tile_max : tile_max; }
   int tw = 0, th = 0;
   khr_sensor sensor{};
   khr_frame meta{};
@@ -411,10 +423,10 @@ void crossn(const float* a, const float* b, float* o) {
 
 DevFrame makeDevFrame(const khr_ctx* c, const FrameSlot& s) {
   DevFrame f{};
-  f.depth = s.depth;
-  f.range = s.range;
-  f.rgba = s.rgba;
-  f.label = s.label;
+  f.depth = const_cast<float*>(s.vDepth());  // (kernels that take a DevFrame only read the planes; the ingest kernels get the slot's own arrays)
+  f.range = const_cast<float*>(s.vRange());
+  f.rgba = const_cast<uint32_t*>(s.vRgba());
+  f.label = const_cast<int32_t*>(s.vLabel());
   f.dyn = s.dyn;
   f.obj = s.has_obj ? s.obj : nullptr;
   f.W = s.sensor.width;
@@ -1053,6 +1065,8 @@ static int acquireSlot(khr_ctx* c) {
     c->aux_seq_done = upto;
   }
   c->slots[slot].aux_seq = 0;
+  FrameSlot& fs = c->slots[slot];
+  fs.x_depth = fs.x_range = nullptr, fs.x_rgba = nullptr, fs.x_label = nullptr, fs.x_tile_max = nullptr;
   return slot;
 }
 
@@ -1137,7 +1151,7 @@ int khr_download_frame(khr_ctx* c, int slot, float* range, float* vertex_map, in
   if (!c || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
   FrameSlot& s = c->slots[slot];
   const size_t n = static_cast<size_t>(s.sensor.width) * s.sensor.height;
-  if (range) HIP_TRY(hipMemcpyAsync(range, s.range, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (range) HIP_TRY(hipMemcpyAsync(range, s.vRange(), n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   if (dynamic_image) HIP_TRY(hipMemcpyAsync(dynamic_image, s.dyn, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   if (vertex_map) {
     DevTemp tmpv;
@@ -1200,7 +1214,7 @@ static int integrateAlloc(khr_ctx* c, FrameSlot& s, const DevFrame& f, int alloc
     c->seed_publish_pending = false;
     hipLaunchKernelGGL(k_init_cull, dim3(1024 + 1024), dim3(256), 0, c->stream, m, c->p, f, c->d_new, c->d_work,
                        FuseList{c->d_work4, c->d_work4 + c->item_cap, c->item_cap, &m.counters[C_N_ITEMS0]}, c->wpb,
-                       c->cfg.disable_culling ? nullptr : s.tile_max, s.tw, s.th, 1024u);
+                       c->cfg.disable_culling ? nullptr : s.vTileMax(), s.tw, s.th, 1024u);
     c->host_index_valid = false, ++c->map_gen;
   } else {
     hipLaunchKernelGGL(k_list_live, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_work,
@@ -1670,6 +1684,137 @@ int khr_tick_ingest(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame
   return KHR_OK;
 }
 
+// ---- sender-side ingest: converted planes travel, not raw frames -------------------------------------------------------
+static uint32_t convertedTilesPadded(const khr_sensor* s) {
+  const uint32_t tiles = static_cast<uint32_t>(((s->width + kTile - 1) / kTile) * ((s->height + kTile - 1) / kTile));
+  return (tiles + 63u) / 64u * 64u;
+}
+
+size_t khr_converted_bytes(const khr_sensor* sensor, int with_depth) {
+  if (!sensor || sensor->width < 2 || sensor->height < 2) return 0;
+  const size_t n = static_cast<size_t>(sensor->width) * sensor->height;
+  return 4 * ((with_depth ? 4 : 3) * n + convertedTilesPadded(sensor));
+}
+
+int khr_converted_views(const khr_sensor* sensor, const void* packed_device, int with_depth, khr_converted_frame* out) {
+  if (!sensor || !packed_device || !out) return fail(KHR_EINVAL, "null argument");
+  const size_t n = static_cast<size_t>(sensor->width) * sensor->height;
+  const uint32_t* w = static_cast<const uint32_t*>(packed_device);
+  out->range = reinterpret_cast<const float*>(w);
+  out->rgba = w + n;
+  out->label = reinterpret_cast<const int32_t*>(w + 2 * n);
+  out->tile_max = reinterpret_cast<const float*>(w + 3 * n);
+  out->depth = with_depth ? reinterpret_cast<const float*>(w + 3 * n + convertedTilesPadded(sensor)) : nullptr;
+  return KHR_OK;
+}
+
+int khr_export_converted(khr_ctx* c, int slot, void* packed_device, int with_depth) {
+  if (!c || !packed_device || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");
+  HIP_TRY(hipSetDevice(c->device));
+  const FrameSlot& s = c->slots[slot];
+  const uint32_t n = static_cast<uint32_t>(s.sensor.width) * static_cast<uint32_t>(s.sensor.height);
+  hipLaunchKernelGGL(k_pack_converted, dim3(1024), dim3(256), 0, c->stream, s.vRange(), s.has_color ? s.vRgba() : nullptr,
+                     s.has_label ? s.vLabel() : nullptr, s.vTileMax(), with_depth ? s.vDepth() : nullptr, n,
+                     static_cast<uint32_t>(s.tw * s.th), convertedTilesPadded(&s.sensor), static_cast<uint32_t*>(packed_device));
+  HIP_TRY(hipGetLastError());
+  return KHR_OK;
+}
+
+int khr_tick_adopt(khr_ctx* c, const khr_sensor* sensor, const khr_converted_frame* frames, int n_frames, int count_seeds,
+                   int* slots_out, uint32_t* n_seed_pixels, int64_t* seed_counts_device) {
+  if (!c || !sensor || !frames || !slots_out || n_frames < 1) return fail(KHR_EINVAL, "bad argument");
+  const size_t n = static_cast<size_t>(sensor->width) * sensor->height;
+  if (sensor->width < 2 || sensor->height < 2 || n > c->cfg.max_frame_pixels)
+    return fail(KHR_EINVAL, "frame %dx%d exceeds max_frame_pixels=%u", sensor->width, sensor->height, c->cfg.max_frame_pixels);
+  if (!(sensor->fx > 0.f) || !(sensor->fy > 0.f) || !(sensor->max_range > sensor->min_range))
+    return fail(KHR_EINVAL, "bad intrinsics / range");
+  if (static_cast<size_t>(n_frames) > c->slots.size()) return fail(KHR_EINVAL, "more frames than frame slots (num_frame_slots)");
+  for (int i = 0; i < n_frames; ++i) {
+    if (!frames[i].range || !frames[i].tile_max) return fail(KHR_EINVAL, "frame %d has no range image / range tiles", i);
+    if (!frames[i].depth && c->p.range_mode != 0)
+      return fail(KHR_EINVAL, "frame %d has no depth plane (only with range_mode 0 is depth == range where it is read)", i);
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = ensureTick(c);
+  if (rc) return rc;
+  count_seeds = count_seeds && c->cfg.with_tracking;
+  c->tick_seed_host.assign(n_frames, 0u);
+  c->tick_seed_collected = 0;
+  const int tw = (sensor->width + kTile - 1) / kTile, th = (sensor->height + kTile - 1) / kTile;
+  ScopedTimer tm(c, 6);
+  const int ring_pos = c->next_slot;
+  for (int i = 0; i < n_frames; ++i) {
+    const int slot = acquireSlot(c);
+    bool wrapped = false;
+    for (int j = 0; j < i && slot >= 0; ++j) wrapped |= slots_out[j] == slot;
+    if (slot < 0 || wrapped) {
+      c->next_slot = ring_pos;
+      return slot < 0 ? slot : fail(KHR_ENOMEM, "not enough free frame slots for a tick of %d frames (raise num_frame_slots)", n_frames);
+    }
+    slots_out[i] = slot;
+  }
+  struct Invalidate {
+    khr_ctx* c; const int* slots; int n; bool armed = true;
+    ~Invalidate() { if (armed) for (int i = 0; i < n; ++i) c->slots[slots[i]].valid = false; }
+  } undo{c, slots_out, n_frames};
+  for (int base = 0; base < n_frames; base += kMaxTick) {
+    const int nb = std::min(kMaxTick, n_frames - base);
+    TickAdopt t{};
+    for (int k = 0; k < nb; ++k) {
+      const khr_converted_frame& fr = frames[base + k];
+      FrameSlot& s = c->slots[slots_out[base + k]];
+      s.sensor = *sensor;
+      s.meta = khr_frame{};
+      s.meta.timestamp_ns = fr.timestamp_ns;
+      std::memcpy(s.meta.world_T_sensor, fr.world_T_sensor, sizeof(s.meta.world_T_sensor));
+      s.has_color = fr.rgba != nullptr;
+      s.has_label = fr.label != nullptr;
+      s.has_obj = false;
+      s.objects_done = false;
+      s.clusters.clear();
+      s.sem_clusters.clear();
+      s.tw = tw;
+      s.th = th;
+      s.valid = true;
+      s.dyn_clean = true;
+      s.x_range = fr.range;
+      s.x_depth = fr.depth ? fr.depth : fr.range;
+      s.x_rgba = fr.rgba;
+      s.x_label = fr.label;
+      s.x_tile_max = fr.tile_max;
+      t.range[k] = fr.range;
+      t.depth[k] = fr.depth;
+      t.dyn[k] = s.dyn;
+      float R[9], tt[3];
+      makePose(fr.world_T_sensor, R, tt, t.Rw[k], t.tw[k]);
+      t.min_z_world[k] = static_cast<float>(fr.world_T_sensor[11] + static_cast<double>(c->cfg.md_min_z_coordinate));
+    }
+    hipLaunchKernelGGL(k_tick_adopt, dim3(gridFor(n), nb), dim3(256), 0, c->stream, t, sensor->width, sensor->height, sensor->fx,
+                       sensor->fy, sensor->cx, sensor->cy, c->m, c->p, c->cfg.md_max_range, count_seeds ? 1 : 0, c->d_tick_seeds);
+    if (count_seeds) {
+      ++c->tick_ticket;
+      if (c->tick_ticket == 0) ++c->tick_ticket;
+      hipLaunchKernelGGL(k_tick_publish, dim3(1), dim3(64), 0, c->stream, c->d_tick_seeds, nb, c->d_tick_host, c->d_tick_host + 32,
+                         c->tick_ticket, seed_counts_device ? reinterpret_cast<long long*>(seed_counts_device) + base : nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    if (count_seeds && (n_seed_pixels || n_frames > kMaxTick)) {
+      rc = waitWord(c, &c->h_tick[32], c->tick_ticket, "tick seed counts");
+      if (rc) return rc;
+      for (int k = 0; k < nb; ++k) c->tick_seed_host[base + k] = c->h_tick[k];
+      c->tick_seed_collected = base + nb;
+    }
+  }
+  c->tick_seed_n = count_seeds ? n_frames : 0;
+  if (count_seeds && n_seed_pixels) std::memcpy(n_seed_pixels, c->tick_seed_host.data(), sizeof(uint32_t) * n_frames);
+  if (!count_seeds && n_seed_pixels) std::memset(n_seed_pixels, 0, sizeof(uint32_t) * n_frames);
+  if (!count_seeds && seed_counts_device) HIP_TRY(hipMemsetAsync(seed_counts_device, 0, sizeof(int64_t) * n_frames, c->stream));
+  c->begun = false;
+  c->begin_in_ingest = false;
+  undo.armed = false;
+  return KHR_OK;
+}
+
 int khr_tick_seed_counts(khr_ctx* c, uint32_t* n_seed_pixels, int n_frames) {
   if (!c || !n_seed_pixels || n_frames < 0) return fail(KHR_EINVAL, "bad argument");
   if (n_frames > static_cast<int>(c->tick_seed_host.size())) return fail(KHR_ESTATE, "no khr_tick_ingest of that many frames");
@@ -1744,7 +1889,7 @@ int khr_tick_integrate(khr_ctx* c, const int* slots, int n_frames, int use_mask,
     for (int k = 0; k < nb; ++k) {
       FrameSlot& s = c->slots[slots[base + k]];
       t.f[k] = makeDevFrame(c, s);
-      t.tile_max[k] = s.tile_max;
+      t.tile_max[k] = s.vTileMax();
     }
     if (phases & 4) {
       if (++c->tick_epoch <= 0) c->tick_epoch = 1;
@@ -2543,7 +2688,7 @@ static int objectsLaunch(khr_ctx* c, int slot) {
     hipLaunchKernelGGL(k_obj_union2d, dim3(gridFor(n)), dim3(256), 0, c->aux_stream, f, c->d_gv_node, c->d_gv_parent,
                        oc.use_full_connectivity ? 1 : 0);
     hipLaunchKernelGGL(k_obj_roots, dim3(gridFor(n)), dim3(256), 0, c->aux_stream, c->d_gv_node, n, c->d_gv_parent, c->d_gv_rootidx, c->d_gv_n,
-                       c->obj_root_cap, c->d_obj_acc, nullptr, s.label, c->d_obj_labels, n_labels);
+                       c->obj_root_cap, c->d_obj_acc, nullptr, s.vLabel(), c->d_obj_labels, n_labels);
   }
   const int obj_tiles = ((s.sensor.width + kObjTile - 1) / kObjTile) * ((s.sensor.height + kObjTile - 1) / kObjTile);
   hipLaunchKernelGGL(k_obj_paint, dim3(obj_tiles), dim3(1024), 0, c->aux_stream, f, c->d_gv_node, c->d_gv_parent, c->d_gv_rootidx,

@@ -597,3 +597,70 @@ def test_tick_path_with_cameras_at_different_positions(spread):
         for k in ("distance", "weight", "color", "last_observed", "last_occupied", "flags", "sem_label", "likelihoods"):
             assert np.array_equal(g[k], h[k]), (k, bi)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("range_mode", [0, 1])
+def test_sender_side_ingest_equals_ingest_on_every_rank(range_mode):
+    """khr_export_converted / khr_tick_adopt (a rank converts only its own camera's frame, the CONVERTED planes travel and are
+    adopted in place) == khr_tick_ingest of every camera's raw frame: seed counts, voxel-key images, dynamic images and the
+    map after the tick, bit for bit; default range mode (depth plane not shipped) and range_mode 1 (depth plane shipped).
+    Here the 'exchange' is a device buffer per camera written by a second context that plays the cameras' home ranks."""
+    from common import DeviceArray
+    import ctypes as C
+    n_cam = 3
+    kw = dict(width=160, height=120, num_frame_slots=2 * n_cam, temporal_window=0.6, temporal_buffer=0.3, range_mode=range_mode)
+    cfg, a, _, s, sen, _ = make_pair(**kw)
+    _, b, _, _, sen_b, _ = make_pair(**kw)
+    _, home, _, _, sen_h, _ = make_pair(**kw)  # converts one camera at a time, like the camera's home rank
+    with_depth = range_mode != 0
+    nbytes = a.converted_bytes(sen, with_depth)
+    assert nbytes == 4 * ((4 if with_depth else 3) * 160 * 120 + 128)  # 10 x 8 = 80 tiles, padded to 128
+    bufs = [DeviceArray(np.zeros(nbytes, np.uint8)) for _ in range(n_cam)]
+    seeds_seen = 0
+    for tick in range(14):
+        frs = [s.render(tick, yaw_offset=0.3 * k + 0.12 * tick) for k in range(n_cam)]
+        stamp = frs[0]["stamp"]
+        tens = [(DeviceArray(f["depth"]), DeviceArray(f["rgb"]), DeviceArray(f["label"])) for f in frs]
+        frames = [a.make_frame(stamp, f["pose"], d.data_ptr(), c.data_ptr(), l.data_ptr()) for f, (d, c, l) in zip(frs, tens)]
+        # (a) every camera's raw frame ingested here
+        slots_a, seeds_a = a.tick_ingest(sen, frames, count_seeds=True)
+        # (b) converted elsewhere, adopted here
+        conv = []
+        for k, fr in enumerate(frames):
+            sl, _ = home.tick_ingest(sen_h, [fr], count_seeds=False)
+            home.export_converted(sl[0], bufs[k].data_ptr(), with_depth)
+            conv.append(b.converted_frame(sen_b, bufs[k].data_ptr(), stamp, frs[k]["pose"], with_depth))
+        home.sync()
+        slots_b, seeds_b = b.tick_adopt(sen_b, conv, count_seeds=True)
+        assert seeds_b == seeds_a, (tick, seeds_a, seeds_b)
+        for ctx, slots, sn in ((a, slots_a, sen), (b, slots_b, sen_b)):
+            ctx.tick_integrate(slots, phases=1)
+            for sl, f, n in zip(slots, frs, seeds_a):
+                k, n2 = ctx.motion_keys(sl, shape=f["depth"].shape)
+                assert n2 == n
+                if n:
+                    ctx.detect_motion_from_keys(sl, k)
+            ctx.tick_integrate(slots, use_mask=True, phases=2)
+            ctx.update_tracking(stamp)
+            ctx.sync()
+        seeds_seen += sum(seeds_a)
+        for sa, sb, f in zip(slots_a, slots_b, frs):
+            ra, va, da = a.download_frame(sa, f["depth"].shape, range_image=True, vertex_map=True, dynamic_image=True)
+            rb, vb, db = b.download_frame(sb, f["depth"].shape, range_image=True, vertex_map=True, dynamic_image=True)
+            assert np.array_equal(ra, rb) and np.array_equal(da, db) and np.array_equal(va, vb)
+        for t3 in tens:
+            for t in t3:
+                t.free()
+    assert seeds_seen > 0
+    sa, sb = a.stats(), b.stats()
+    for k in ("cum_updated_voxels", "cum_band_voxels", "n_allocated_blocks"):
+        assert sa[k] == sb[k], (k, sa[k], sb[k])
+    idx = a.block_indices()
+    assert len(idx) > 20 and np.array_equal(idx, b.block_indices())
+    for bi in idx[:: max(1, len(idx) // 60)]:
+        g, h = a.download_block(bi), b.download_block(bi)
+        for k in ("distance", "weight", "color", "last_observed", "last_occupied", "flags", "sem_label", "likelihoods"):
+            assert np.array_equal(g[k], h[k]), (k, bi)
+    for d in bufs:
+        d.free()
+    a.close(); b.close(); home.close()

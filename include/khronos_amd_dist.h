@@ -65,6 +65,17 @@ int kdist_gather_frames(kdist_handle* h, const void* packed_local, size_t bytes,
  * dynamic clusters per camera (identical on every rank). */
 int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, int* slots_out, int* clusters_out);
 
+/* kdist_tick with SENDER-SIDE INGEST (one camera per rank, n == world_size): frames[n] carry every camera's pose and stamp,
+ * only frames[rank] its (device) images.  The rank converts its own frame (khr_tick_ingest of one frame; *own_slot_out is
+ * that slot: the one the object half of the active window works on), packs the converted planes (khr_export_converted:
+ * 12 B per pixel), the ranks all-gather them on the context's stream, and all n cameras are adopted where the all-gather
+ * put them (khr_tick_adopt: seed test + reset of the dynamic image, 8 B per pixel, no copy) instead of every rank
+ * converting every camera's raw frame (31 B per pixel and camera).  Everything behind the ingest is kdist_tick.
+ * `emulated_gather`: KDIST_EMULATE only -- the stand-in for the all-gather's receive buffer, n x khr_converted_bytes of
+ * planes converted beforehand (entry `rank` is not read); NULL otherwise. */
+int kdist_tick_own(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, const void* emulated_gather, int* slots_out,
+                   int* clusters_out, int* own_slot_out);
+
 /* output stage (extractOutputData): mesh halo exchange, marching cubes over the owned updated blocks, archival of the
  * blocks that left the window, flag clearing.  Results stay in the context (khr_download_mesh, khr_last_removed). */
 int kdist_output(kdist_handle* h);

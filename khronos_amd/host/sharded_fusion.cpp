@@ -122,6 +122,9 @@ struct kdist_handle {
   int64_t* seed_counts = nullptr;             // [n_cameras + world]: seed pixels per camera, then every rank's live-block bound
   int64_t* h_seed_counts = nullptr;           // pinned mirror of the reduced counts
   int64_t* xchg = nullptr;                    // [2] device scratch of the small agreement collectives (kdist_output)
+  uint8_t* conv_send = nullptr;               // sender-side ingest: this rank's converted planes, packed (khr_export_converted)
+  uint8_t* conv_recv = nullptr;               // ... and every rank's, where the all-gather puts them (the tick's slots refer to them)
+  size_t conv_bytes = 0;
   int64_t* h_xchg = nullptr;                  // pinned mirror
   hipEvent_t ev_counts = nullptr;             // ... have arrived
   std::vector<uint64_t*> keys;                // per camera: per-pixel voxel keys
@@ -304,8 +307,15 @@ int kdist_gather_frames(kdist_handle* h, const void* packed_local, size_t bytes,
 // One tick: frames[n] = ALL cameras of the rig (device pointers, already gathered), in camera order on every rank.
 // slots_out[n] receives the frame slots; clusters_out[n] (may be NULL) the dynamic clusters per camera where this rank
 // knows them without a device round trip (its home cameras; -1 elsewhere).
-int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, int* slots_out, int* clusters_out) {
-  return guarded("kdist_tick", [&]() {
+}  // extern "C"
+
+namespace {
+// own_slot_out == nullptr: every camera's raw frame is ingested here (kdist_tick).  Otherwise sender-side ingest
+// (kdist_tick_own): only frames[rank] carries images; it is converted here, the packed planes are all-gathered and all n
+// cameras are adopted where the all-gather put them (khr_tick_adopt).  `emulated_gather`: KDIST_EMULATE stand-in for the
+// all-gather's receive buffer (n x khr_converted_bytes, converted by the caller beforehand).
+int tickImpl(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, int* slots_out, int* clusters_out,
+             int* own_slot_out, const void* emulated_gather) {
     if (!h || !frames || !slots_out || n < 1 || n > h->n_cameras) throw Fail{KHR_EINVAL, "bad argument"};
     khr_ctx* c = h->ctx;
     const bool split = n <= kMaxSplit;
@@ -314,12 +324,49 @@ int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, 
     for (int i = 0; i < n; ++i) h->clusters_last_tick[static_cast<size_t>(i)] = 0;
     // (2) ingest + seed test; nothing waits; allocation / culling queued behind it
     khr_host_trace("kd_tick_enter");
-    KD_KHR(khr_tick_ingest(c, &h->sensor, frames, n, h->motion ? 1 : 0, slots_out, split ? nullptr : host_counts.data(), h->seed_counts));
+    int obj_slot = -1;
+    if (!own_slot_out) {
+      KD_KHR(khr_tick_ingest(c, &h->sensor, frames, n, h->motion ? 1 : 0, slots_out, split ? nullptr : host_counts.data(), h->seed_counts));
+      if (n == h->world && h->rank < n) obj_slot = slots_out[h->rank];
+    } else {
+      if (n != h->world || !frames[h->rank].depth) throw Fail{KHR_EINVAL, "sender-side ingest: one camera per rank, frames[rank] with images"};
+      khr_config cfg{};
+      KD_KHR(khr_get_config(c, &cfg));
+      const int with_depth = cfg.range_mode != 0 ? 1 : 0;
+      const size_t bytes = khr_converted_bytes(&h->sensor, with_depth);
+      if (h->conv_bytes != bytes) {
+        h->conv_send = h->alloc<uint8_t>(bytes);
+        h->conv_recv = h->alloc<uint8_t>(bytes * static_cast<size_t>(h->world));
+        h->conv_bytes = bytes;
+      }
+      // this rank's camera: converted here (its slot keeps the raw depth for the object half), packed, exchanged
+      KD_KHR(khr_tick_ingest(c, &h->sensor, &frames[h->rank], 1, 0, own_slot_out, nullptr, nullptr));
+      obj_slot = *own_slot_out;
+      KD_KHR(khr_export_converted(c, obj_slot, h->conv_send, with_depth));
+      const uint8_t* all = h->conv_recv;
+      if (h->net()) {
+        KD_NCCL(rccl().AllGather(h->conv_send, h->conv_recv, bytes, ncclUint8, h->comm, h->stream));
+      } else if (emulated_gather) {
+        all = static_cast<const uint8_t*>(emulated_gather);
+      } else if (h->world == 1) {
+        all = h->conv_send;
+      } else {
+        throw Fail{KHR_ESTATE, "sender-side ingest without a communicator needs the other cameras' converted planes (emulated_gather)"};
+      }
+      std::vector<khr_converted_frame> conv(static_cast<size_t>(n));
+      for (int k = 0; k < n; ++k) {
+        const uint8_t* src = (k == h->rank && !h->net()) ? h->conv_send : all + bytes * static_cast<size_t>(k);
+        KD_KHR(khr_converted_views(&h->sensor, src, with_depth, &conv[static_cast<size_t>(k)]));
+        conv[static_cast<size_t>(k)].timestamp_ns = frames[k].timestamp_ns;
+        std::memcpy(conv[static_cast<size_t>(k)].world_T_sensor, frames[k].world_T_sensor, sizeof(frames[k].world_T_sensor));
+      }
+      KD_KHR(khr_tick_adopt(c, &h->sensor, conv.data(), n, h->motion ? 1 : 0, slots_out, split ? nullptr : host_counts.data(), h->seed_counts));
+    }
     khr_host_trace("kd_ingest_queued");
     // this rank's own camera: the object detector's kernels (auxiliary stream, they only read the frame) go out now, so that
     // they run beside the tick's volumetric kernels; the object pipeline's khr_detect_objects then only collects the result
     // (before: queued after the tick, with the host waiting ~0.45 ms for them at 1080p)
-    if (n == h->world && h->rank < n) (void)khr_detect_objects_launch(c, slots_out[h->rank]);
+    if (obj_slot >= 0) (void)khr_detect_objects_launch(c, obj_slot);
     // the count exchange goes out right behind the ingest, BEFORE allocation / culling are queued: the host then learns
     // which cameras have seeds while the device still works on those, and queues the update launches without a gap
     // The same all-reduce also tells every rank how many live blocks (= halo records) the others hold, so that the halo
@@ -422,6 +469,21 @@ int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, 
     if (clusters_out)
       for (int i = 0; i < n; ++i) clusters_out[i] = h->clusters_last_tick[static_cast<size_t>(i)];
     return KHR_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, int* slots_out, int* clusters_out) {
+  return guarded("kdist_tick", [&]() { return tickImpl(h, stamp, frames, n, slots_out, clusters_out, nullptr, nullptr); });
+}
+
+// kdist_tick with sender-side ingest: frames[n] carry every camera's pose and stamp, only frames[rank] its images
+int kdist_tick_own(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, const void* emulated_gather, int* slots_out,
+                   int* clusters_out, int* own_slot_out) {
+  return guarded("kdist_tick_own", [&]() {
+    if (!own_slot_out) throw Fail{KHR_EINVAL, "own_slot_out is required"};
+    return tickImpl(h, stamp, frames, n, slots_out, clusters_out, own_slot_out, emulated_gather);
   });
 }
 

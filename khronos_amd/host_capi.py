@@ -47,6 +47,7 @@ def load_host_library():
     lib.kdist_stream.restype = vp
     lib.kdist_gather_frames.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
     lib.kdist_tick.argtypes = [vp, C.c_uint64, vp, i32, vp, vp]
+    lib.kdist_tick_own.argtypes = [vp, C.c_uint64, vp, i32, vp, vp, vp, vp]
     lib.kdist_output.argtypes = [vp]
     lib.kdist_last_exchange.argtypes = [vp, vp, vp]
     lib.khr_host_detect_changes.argtypes = [vp, C.c_int64, vp, C.c_int64, C.c_float, C.c_int64, i32, C.c_float, C.c_float, i32, vp]
@@ -220,6 +221,18 @@ class ShardedFusionHost:
         clusters = (C.c_int32 * len(frames))()
         self._chk(self.lib.kdist_tick(self.h, int(stamp), arr, len(frames), slots, clusters))
         return list(slots), list(clusters)
+
+    def tick_own(self, stamp, frames, emulated_gather_ptr=0):
+        """sender-side ingest: `frames` = KhrFrame of every camera (pose, stamp), only frames[rank] with image pointers
+        -> (slots, clusters, own_slot)"""
+        from .capi import KhrFrame
+        arr = (KhrFrame * len(frames))(*frames)
+        slots = (C.c_int32 * len(frames))()
+        clusters = (C.c_int32 * len(frames))()
+        own = C.c_int32(-1)
+        self._chk(self.lib.kdist_tick_own(self.h, int(stamp), arr, len(frames), C.c_void_p(emulated_gather_ptr or None), slots, clusters,
+                                          C.byref(own)))
+        return list(slots), list(clusters), own.value
 
     def output(self):
         self._chk(self.lib.kdist_output(self.h))

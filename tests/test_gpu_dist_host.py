@@ -11,8 +11,9 @@ pytestmark = pytest.mark.gpu
 W, H = 320, 240
 
 
+@pytest.mark.parametrize("sender_side", [False, True], ids=["ingest-everywhere", "sender-side-ingest"])
 @pytest.mark.parametrize("shard_motion", [True, False])
-def test_cxx_rccl_tick_equals_single_context(shard_motion):
+def test_cxx_rccl_tick_equals_single_context(shard_motion, sender_side):
     from khronos_amd.host_capi import ShardedFusionHost
     cfg, ctx, ora, s, sen, osen = make_pair(width=W, height=H, temporal_window=0.75, num_frame_slots=4)
     _, ref, _, _, _, _ = make_pair(width=W, height=H, temporal_window=0.75, num_frame_slots=4)
@@ -24,7 +25,11 @@ def test_cxx_rccl_tick_equals_single_context(shard_motion):
         dev = [DeviceArray(np.ascontiguousarray(fr[k])) for k in ("depth", "rgb", "label")]
         held.append(dev)
         f = ctx.make_frame(fr["stamp"], fr["pose"], dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr())
-        slots, clusters = sf.tick(fr["stamp"], [f])
+        if sender_side:  # kdist_tick_own: convert own frame, all-gather the converted planes (one rank), adopt them in place
+            slots, clusters, own = sf.tick_own(fr["stamp"], [f])
+            assert own >= 0 and own != slots[0]
+        else:
+            slots, clusters = sf.tick(fr["stamp"], [f])
         # reference: the plain calls on a second context
         slot2 = ref.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
         n2 = ref.detect_motion(slot2)

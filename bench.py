@@ -81,6 +81,10 @@ def parse_args():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="development: ONE process plays rank 0 of an N-rank sharded run (all N cameras rendered locally, no "
                          "collectives) to measure the per-rank tick cost on a 1-GPU box; the JSON line is marked emulation")
+    ap.add_argument("--sender-ingest", action="store_true",
+                    help="sharded tick with sender-side ingest (kdist_tick_own): a rank converts only its own camera's frame, the ranks "
+                         "all-gather the CONVERTED planes and adopt them in place; with --emulate-world the other cameras' planes are "
+                         "converted before the timed region (they stand for the all-gather's receive buffer).  Needs --dist-host cxx")
     ap.add_argument("--dist-host", choices=["cxx", "torch"], default="cxx",
                     help="N > 1: who issues the tick's collectives: cxx = RCCL from libkhronos_amd_host.so (kdist_*, the product "
                          "path), torch = khronos_amd/distributed.py over torch.distributed (the protocol test harness)")
@@ -278,6 +282,23 @@ def main():
                                        motion=not args.no_motion, count_device=dev if backend == "nccl" else "cpu")
             dist_host = "emulated" if emu else "torch"
 
+    sender_ingest = bool(args.sender_ingest) and fusion_cxx is not None
+    emu_conv = []
+    if sender_ingest and emu:
+        # the other cameras' frames as their home ranks would send them: converted BEFORE the timed region, one packed buffer
+        # per tick standing for the all-gather's receive buffer (entry 0 = this rank's own camera is not read)
+        cb = ctx.converted_bytes(sensor)
+        torch.cuda.synchronize()
+        for i in range(n_total):
+            buf = torch.empty(world * cb, dtype=torch.uint8, device=dev)
+            for r in range(1, world):
+                dep, rgb, lab = emu_cams[i][r - 1]
+                sl, _ = ctx.tick_ingest(sensor, [ctx.make_frame(stamps[i], poses[i][r], dep.data_ptr(), rgb.data_ptr(), lab.data_ptr())],
+                                        count_seeds=False)
+                ctx.export_converted(sl[0], buf.data_ptr() + r * cb)
+            emu_conv.append(buf)
+        ctx.sync()
+        torch.cuda.synchronize()
     _trace = ctx.lib.khr_host_trace  # no-op unless KHR_HOST_TRACE is set
     _tags = {k: k.encode() for k in ("step_begin", "step_end", "timed_begin", "join_begin", "timed_end")}
 
@@ -291,6 +312,8 @@ def main():
         if emu:
             cams = [(d_depth[i], d_rgb[i], d_label[i], poses[i][0])] + [
                 (dep, rgb, lab, poses[i][r + 1]) for r, (dep, rgb, lab) in enumerate(emu_cams[i])]
+        elif world > 1 and sender_ingest:
+            cams = [(d_depth[i], d_rgb[i], d_label[i], poses[i][r]) for r in range(world)]  # (only entry `rank` is read as an image)
         elif world > 1:
             issue_gather(i)
             gather_work.pop(i).wait()  # `stream` waits for this tick's frames
@@ -303,15 +326,23 @@ def main():
         out_now = args.output_every > 0 and (i + 1) % args.output_every == 0
         if world > 1:
             # sharded tick: integrate all cameras into the owned blocks, tracking, halo all-gather, ever-free
-            if fusion_cxx is not None:
+            obj_slot = None
+            if fusion_cxx is not None and sender_ingest:
+                slots, clusters, obj_slot = fusion_cxx.tick_own(stamps[i], [
+                    ctx.make_frame(stamps[i], pose, dep.data_ptr() if r == rank else 0, rgb.data_ptr() if r == rank else 0,
+                                   lab.data_ptr() if r == rank else 0) for r, (dep, rgb, lab, pose) in enumerate(cams)],
+                    emu_conv[i].data_ptr() if emu else 0)
+            elif fusion_cxx is not None:
                 slots, clusters = fusion_cxx.tick(stamps[i], [
                     ctx.make_frame(stamps[i], pose, dep.data_ptr(), rgb.data_ptr(), lab.data_ptr()) for (dep, rgb, lab, pose) in cams])
             else:
                 slots = fusion.tick(stamps[i], [(pose, dep, rgb, lab) for (dep, rgb, lab, pose) in cams])
                 clusters = fusion.clusters_last_tick
+            if obj_slot is None:
+                obj_slot = slots[rank]
             if pipe is not None:  # owner-computes for objects: each rank handles its own camera
                 pipe.finish_frame()  # tracker association of the previous tick, while this tick's kernels run
-                pipe.launch_frame(slots[rank], stamps[i], poses[i][rank], sensor, clusters[rank])
+                pipe.launch_frame(obj_slot, stamps[i], poses[i][rank], sensor, clusters[rank])
             if out_now:
                 if fusion_cxx is not None:
                     fusion_cxx.output()
@@ -502,7 +533,10 @@ def main():
                    "collectives_issued_by": {"cxx": "libkhronos_amd_host.so (kdist_*: rccl calls on the context's HIP stream)",
                                              "torch": "khronos_amd/distributed.py (torch.distributed)", "emulated": "none (emulation, torch harness)",
                                              "cxx-emulated": "libkhronos_amd_host.so (kdist_*, KDIST_EMULATE: rank 0 alone, collectives skipped)",
-                                             "none": None}[dist_host]},
+                                             "none": None}[dist_host],
+                   "ingest": ("sender side (kdist_tick_own): every rank converts its own camera's frame, the converted planes (12 B / pixel) "
+                              "are all-gathered and adopted in place" + (" -- emulated: the other cameras' planes were converted before the timed region" if emu else ""))
+                   if sender_ingest else ("every rank converts every camera's raw frame" if world > 1 else "single camera")},
         "mvoxel_updates_per_s": 1e-6 * n_upd_all / dt,
         **({"emulation": "rank 0 of a %d-rank sharded run played by one process, no collectives: `value` is what the job would reach "
                          "if communication were free and all ranks were as loaded as rank 0 -- NOT a measured N-GPU number" % world}

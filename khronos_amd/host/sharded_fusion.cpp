@@ -360,7 +360,12 @@ int tickImpl(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, in
         conv[static_cast<size_t>(k)].timestamp_ns = frames[k].timestamp_ns;
         std::memcpy(conv[static_cast<size_t>(k)].world_T_sensor, frames[k].world_T_sensor, sizeof(frames[k].world_T_sensor));
       }
-      KD_KHR(khr_tick_adopt(c, &h->sensor, conv.data(), n, h->motion ? 1 : 0, slots_out, split ? nullptr : host_counts.data(), h->seed_counts));
+      // (the own slot is leased while the ring hands out the tick's n slots: a ring that is too small fails loudly in
+      // khr_tick_adopt instead of recycling the slot the object half is about to read)
+      KD_KHR(khr_retain_slot(c, obj_slot));
+      const int arc = khr_tick_adopt(c, &h->sensor, conv.data(), n, h->motion ? 1 : 0, slots_out, split ? nullptr : host_counts.data(), h->seed_counts);
+      (void)khr_release_slot(c, obj_slot);
+      KD_KHR(arc);
     }
     khr_host_trace("kd_ingest_queued");
     // this rank's own camera: the object detector's kernels (auxiliary stream, they only read the frame) go out now, so that

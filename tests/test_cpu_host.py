@@ -230,3 +230,13 @@ def test_integration_snippet_compiles(tmp_path):
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(root, "include"),
                         "-I", os.path.join(root, "khronos_amd", "host"), str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_public_headers_are_plain_c():
+    """the drop-in boundary is a C ABI: both public headers must compile as C99 on their own (no C++ types, no torch)"""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    for hdr in ("khronos_amd.h", "khronos_amd_dist.h"):
+        r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", "-I", inc, os.path.join(inc, hdr)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr

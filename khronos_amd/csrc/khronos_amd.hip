@@ -1590,6 +1590,26 @@ static int ensureTick(khr_ctx* c) {
   return KHR_OK;
 }
 
+// the frame slots of a tick: nothing of the ring's state is touched unless the whole tick fits
+static int acquireTickSlots(khr_ctx* c, int n_frames, int* slots_out) {
+  const int ring_pos = c->next_slot;
+  for (int i = 0; i < n_frames; ++i) {
+    const int slot = acquireSlot(c);
+    bool wrapped = false;
+    for (int j = 0; j < i && slot >= 0; ++j) wrapped |= slots_out[j] == slot;  // the ring wrapped around retained slots
+    if (slot < 0 || wrapped) {
+      c->next_slot = ring_pos;
+      return slot < 0 ? slot : fail(KHR_ENOMEM, "not enough free frame slots for a tick of %d frames (raise num_frame_slots)", n_frames);
+    }
+    slots_out[i] = slot;
+  }
+  return KHR_OK;
+}
+struct TickSlotsGuard {  // an error after the acquisition leaves the tick's slots unusable instead of half-written
+  khr_ctx* c; const int* slots; int n; bool armed = true;
+  ~TickSlotsGuard() { if (armed) for (int i = 0; i < n; ++i) c->slots[slots[i]].valid = false; }
+};
+
 int khr_tick_ingest(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frames, int n_frames, int count_seeds,
                     int* slots_out, uint32_t* n_seed_pixels, int64_t* seed_counts_device) {
   if (!c || !sensor || !frames || !slots_out || n_frames < 1) return fail(KHR_EINVAL, "bad argument");
@@ -1609,22 +1629,8 @@ int khr_tick_ingest(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame
   c->tick_seed_collected = 0;
   const int tw = (sensor->width + kTile - 1) / kTile, th = (sensor->height + kTile - 1) / kTile;
   ScopedTimer tm(c, 6);
-  // all slots of the tick first: nothing of the ring's state is touched unless the whole tick fits
-  const int ring_pos = c->next_slot;
-  for (int i = 0; i < n_frames; ++i) {
-    const int slot = acquireSlot(c);
-    bool wrapped = false;
-    for (int j = 0; j < i && slot >= 0; ++j) wrapped |= slots_out[j] == slot;  // the ring wrapped around retained slots
-    if (slot < 0 || wrapped) {
-      c->next_slot = ring_pos;
-      return slot < 0 ? slot : fail(KHR_ENOMEM, "not enough free frame slots for a tick of %d frames (raise num_frame_slots)", n_frames);
-    }
-    slots_out[i] = slot;
-  }
-  struct Invalidate {  // an error after this point leaves the tick's slots unusable instead of half-written
-    khr_ctx* c; const int* slots; int n; bool armed = true;
-    ~Invalidate() { if (armed) for (int i = 0; i < n; ++i) c->slots[slots[i]].valid = false; }
-  } undo{c, slots_out, n_frames};
+  if ((rc = acquireTickSlots(c, n_frames, slots_out))) return rc;
+  TickSlotsGuard undo{c, slots_out, n_frames};
   for (int base = 0; base < n_frames; base += kMaxTick) {
     const int nb = std::min(kMaxTick, n_frames - base);
     TickIngest t{};
@@ -1742,21 +1748,8 @@ int khr_tick_adopt(khr_ctx* c, const khr_sensor* sensor, const khr_converted_fra
   c->tick_seed_collected = 0;
   const int tw = (sensor->width + kTile - 1) / kTile, th = (sensor->height + kTile - 1) / kTile;
   ScopedTimer tm(c, 6);
-  const int ring_pos = c->next_slot;
-  for (int i = 0; i < n_frames; ++i) {
-    const int slot = acquireSlot(c);
-    bool wrapped = false;
-    for (int j = 0; j < i && slot >= 0; ++j) wrapped |= slots_out[j] == slot;
-    if (slot < 0 || wrapped) {
-      c->next_slot = ring_pos;
-      return slot < 0 ? slot : fail(KHR_ENOMEM, "not enough free frame slots for a tick of %d frames (raise num_frame_slots)", n_frames);
-    }
-    slots_out[i] = slot;
-  }
-  struct Invalidate {
-    khr_ctx* c; const int* slots; int n; bool armed = true;
-    ~Invalidate() { if (armed) for (int i = 0; i < n; ++i) c->slots[slots[i]].valid = false; }
-  } undo{c, slots_out, n_frames};
+  if ((rc = acquireTickSlots(c, n_frames, slots_out))) return rc;
+  TickSlotsGuard undo{c, slots_out, n_frames};
   for (int base = 0; base < n_frames; base += kMaxTick) {
     const int nb = std::min(kMaxTick, n_frames - base);
     TickAdopt t{};

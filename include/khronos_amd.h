@@ -93,6 +93,11 @@ typedef struct khr_config {
    * weight > 0) still exactly as the restatement, but measurement weight and running average with contracted FMAs and
    * v_rcp_f32 (values within ~1e-6 relative).  On gfx950 the relaxed mode buys ~2 % of the update kernel. */
   int32_t relaxed_arithmetic;
+  /* capacity (blocks) of the map snapshot khr_process_frame(KHR_PF_SNAPSHOT) takes at output cadence; 0 = min(max_blocks,
+   * 8192).  An output that updated more blocks than this cannot be cloned completely: khr_snapshot_num_blocks still
+   * reports the true count and khr_snapshot_download fails with KHR_ENOMEM (never a silently partial clone).  The arena is
+   * sized for the capacity (~100 KB of HBM per block with all default fields) and recycled between outputs. */
+  uint32_t max_snapshot_blocks;
 } khr_config;
 
 typedef struct khr_sensor {
@@ -343,7 +348,7 @@ int khr_object_prune(khr_ctx* ctx, float min_confidence, float min_observations,
 #define KHR_PF_OBJECTS 8u /* ConnectedSemantics on the frame (khr_configure_object_detector first): its kernels are queued
                              right after the ingest and its host part runs once the frame's other kernels are queued;
                              khr_detect_objects / khr_get_semantic_clusters then return the cached result */
-#define KHR_PF_SNAPSHOT 32u /* with KHR_PF_OUTPUT: snapshot of the updated blocks (khr_snapshot_updated, all fields, capacity 8192
+#define KHR_PF_SNAPSHOT 32u /* with KHR_PF_OUTPUT: snapshot of the updated blocks (khr_snapshot_updated, all fields, capacity khr_config.max_snapshot_blocks
                              * blocks) between meshing and archival; fetch it with khr_take_snapshot */
 #define KHR_PF_INPUT_READY 16u /* on_device frames only: the input buffers are COMPLETE when the call is made (nothing still
                                   queued on the context's stream writes them).  The ingest then runs on the context's second
@@ -367,6 +372,16 @@ int64_t khr_block_indices(khr_ctx* ctx, int32_t* out, int64_t cap, int only_upda
 int khr_download_block(khr_ctx* ctx, int32_t bx, int32_t by, int32_t bz, float* distance, float* weight,
                        uint8_t* color_rgba, uint64_t* last_observed, uint64_t* last_occupied,
                        uint8_t* voxel_flags, uint32_t* sem_label, float* likelihoods, uint8_t* block_flags);
+/* Order-independent 64-bit digests of the WHOLE map (every live block, every voxel), one word per layer, on the values
+ * khr_download_block hands out:  digest[layer] = sum_b sum_i mix(mix(key(b) * G + layer * L + i) ^ value_bits) mod 2^64
+ * (mix = splitmix64 finaliser, key = 3 x 21-bit packed block index; csrc/khr_kernels_aux.h: digestTerm).  Sums commute, so
+ * the digests of the shards of a sharded map add up to those of the unsharded map; the CPU oracle implements the same
+ * function (oracle.h: orc_map_digest).  Parity tooling: tests compare whole maps with it instead of sampling blocks
+ * (the reference has no counterpart; the layers are those of VolumetricMap's Tsdf / Tracking / Semantic voxels).
+ * out[KHR_DIGEST_WORDS]: 0 distance, 1 weight, 2 colour, 3 last_observed, 4 last_occupied, 5 voxel flags, 6 semantic
+ * label, 7 likelihoods, 8 block flags (KHR_BLK_* bits), 9 sum of mix(key), 10 block count, 11 reserved (0). */
+#define KHR_DIGEST_WORDS 12
+int khr_map_digest(khr_ctx* ctx, uint64_t* out);
 /* replaces: VolumetricMap::cloneUpdated (active_window.cpp:229) in ONE packed transfer: every block flagged
  * KHR_BLK_UPDATED, in sorted block order, gathered on the device and copied per field (any pointer may be
  * NULL; arrays hold cap_blocks * nvox elements, indices 3 * cap_blocks).  Returns the number of blocks. */

@@ -11,7 +11,10 @@
  * collective: every rank must make the same call sequence.
  *
  * Errors: negative khr_status (include/khronos_amd.h), text via khr_last_error().  Exchange buffers are sized at create;
- * exceeding one is KHR_ENOMEM from kdist_tick / kdist_output, never a silent truncation.  The capacities bound what a
+ * exceeding one on ANY rank is KHR_ENOMEM from kdist_output on EVERY rank (the ranks agree on it inside the output's
+ * count all-reduce, so nobody is left waiting in a collective), never a silent truncation.
+ * KDIST_RCCL_LIB=<path> (environment): load the eight nccl* entry points from that library instead of librccl.so.1 -- a
+ * site's own RCCL build, or the shared-memory transport of tests/transport/ that runs N ranks on one GPU for the tests.  The capacities bound what a
  * rank may hold, not what travels: the halo all-gather of a tick ships, per rank, the live-block count of the fullest rank
  * (it rides in the tick's seed-count all-reduce, rounded up to 256 records), the mesh-record all-gather of an output the
  * record count of the fullest rank (one 8-byte max all-reduce).
@@ -57,6 +60,20 @@ void* kdist_stream(kdist_handle* h);
  * such exchange yet; the capacity when the trimmed form was not available: motion detector off, more than 8 cameras) */
 int kdist_last_exchange(kdist_handle* h, int64_t* halo_records_per_rank, int64_t* mesh_records_per_rank);
 
+/* What the tick's / the output's collectives cost (the first multi-GPU record has to explain itself): per kind of collective
+ * the calls, the bytes THIS rank sent and -- while profiling is on -- the milliseconds between HIP events recorded around each
+ * call on the handle's stream (~5 us of stream time per bracket: keep it off inside a throughput measurement).
+ * kdist_profile resets the counters; kdist_profile_get fills min(cap, count) entries and returns the count. */
+typedef struct kdist_coll_stat {
+  char name[32];       /* frames_allgather, converted_allgather, counts_allreduce, motion_keys_reduce, dynamic_image_broadcast,
+                          halo_allgather, mesh_request_allgather, mesh_agree_allreduce, mesh_record_allgather */
+  uint64_t calls;
+  uint64_t bytes_sent;
+  double ms;
+} kdist_coll_stat;
+int kdist_profile(kdist_handle* h, int enable);
+int kdist_profile_get(kdist_handle* h, kdist_coll_stat* out, int cap);
+
 /* ncclAllGather of one packed camera frame per rank (device pointer, same byte count on every rank); *gathered_out is a
  * device buffer of world_size * bytes owned by the handle, valid until the next call. */
 int kdist_gather_frames(kdist_handle* h, const void* packed_local, size_t bytes, void** gathered_out);
@@ -71,6 +88,9 @@ int kdist_tick(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, 
  * 12 B per pixel), the ranks all-gather them on the context's stream, and all n cameras are adopted where the all-gather
  * put them (khr_tick_adopt: seed test + reset of the dynamic image, 8 B per pixel, no copy) instead of every rank
  * converting every camera's raw frame (31 B per pixel and camera).  Everything behind the ingest is kdist_tick.
+ * The rig is homogeneous: which optional planes exist (colour, labels) is decided by frames[rank] for ALL cameras -- a
+ * depth-only rig passes color == label == NULL in its own frame on every rank and nothing is blended / fused for any camera,
+ * exactly as kdist_tick does with depth-only frames.
  * `emulated_gather`: KDIST_EMULATE only -- the stand-in for the all-gather's receive buffer, n x khr_converted_bytes of
  * planes converted beforehand (entry `rank` is not read); NULL otherwise. */
 int kdist_tick_own(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, const void* emulated_gather, int* slots_out,

@@ -31,7 +31,7 @@ class KhrConfig(C.Structure):
         ("mesh_min_weight", C.c_float),
         ("max_blocks", C.c_uint32), ("max_frame_pixels", C.c_uint32), ("num_frame_slots", C.c_uint32),
         ("max_mesh_vertices", C.c_uint64), ("max_band_records", C.c_uint32), ("disable_culling", C.c_int32),
-        ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32), ("relaxed_arithmetic", C.c_int32),
+        ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32), ("relaxed_arithmetic", C.c_int32), ("max_snapshot_blocks", C.c_uint32),
     ]
 
 
@@ -82,7 +82,7 @@ EXPORTS = [
     "khr_export_halo", "khr_import_halo", "khr_get_dynamic_clusters", "khr_motion_keys",
     "khr_detect_motion_from_keys", "khr_download_updated", "khr_mesh_halo_requests", "khr_mesh_halo_export",
     "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",
-    "khr_cluster_voxels", "khr_download_frame_image", "khr_detect_objects_launch", "khr_pool_exhausted",
+    "khr_cluster_voxels", "khr_download_frame_image", "khr_detect_objects_launch", "khr_pool_exhausted", "khr_map_digest",
     "khr_rv_create", "khr_rv_destroy", "khr_rv_clear", "khr_rv_add_rays", "khr_rv_num_rays", "khr_rv_num_pairs", "khr_rv_check",
     "khr_snapshot_updated", "khr_take_snapshot", "khr_snapshot_num_blocks", "khr_snapshot_download", "khr_snapshot_download_extra", "khr_snapshot_release",
     "khr_rv_check_stamps", "khr_get_config", "khr_cluster_voxels_launch", "khr_cluster_voxels_fetch", "khr_reset_map", "khr_depend_on", "khr_retain_slot", "khr_release_slot",
@@ -554,6 +554,15 @@ class FusionContext:
         s = KhrStats()
         self._chk(self.lib.khr_get_stats(self.h, C.byref(s)))
         return {n: getattr(s, n) for n, _ in KhrStats._fields_}
+
+    DIGEST_LAYERS = ("distance", "weight", "color", "last_observed", "last_occupied", "flags", "sem_label", "likelihoods",
+                     "block_flags", "index", "n_blocks", "reserved")
+
+    def map_digest(self):
+        """khr_map_digest: order-independent 64-bit digests of the whole map, one per layer (np.uint64[12], DIGEST_LAYERS)."""
+        out = np.zeros(12, np.uint64)
+        self._chk(self.lib.khr_map_digest(self.h, _ptr(out)))
+        return out
 
     def num_blocks(self):
         return self._chk(self.lib.khr_num_blocks(self.h))

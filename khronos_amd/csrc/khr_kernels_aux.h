@@ -1459,4 +1459,65 @@ __global__ __launch_bounds__(256) void k_object_prune(DevMap m, DevParams p, flo
   if ((threadIdx.x & 63) == 0 && pruned) atomicAdd(&m.stats[S_PRUNED], static_cast<unsigned long long>(pruned));
 }
 
+// ---- khr_map_digest: order-independent 64-bit digests of the WHOLE map, one per voxel layer ------------------------------
+// digest[layer] = sum over live blocks b, voxels i of  mix(mix(key(b) * G + layer * L + i) ^ value_bits)   (mod 2^64)
+// on the values khr_download_block hands out (public flag bits, last_occupied resolved, likelihoods of voxels without a
+// semantic entry as zeros, element index of likelihood k of voxel i = k * nvox + i).  A sum commutes: the digests of the
+// shards of a sharded map add up to the digest of the unsharded map, and the CPU oracle computes the same function over its
+// own containers (oracle.cpp: orc_map_digest), so parity over ALL blocks is one 12-word comparison instead of a sample.
+// Words: 0 distance, 1 weight, 2 colour, 3 last_observed, 4 last_occupied, 5 voxel flags, 6 semantic label, 7 likelihoods,
+// 8 block flags (public bits), 9 sum of mix(key) over the blocks, 10 block count, 11 reserved (0).
+constexpr int kDigestWords = 12;
+__host__ __device__ inline uint64_t digestMix(uint64_t x) {  // splitmix64 finaliser
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+__host__ __device__ inline uint64_t digestTerm(uint64_t key, uint32_t layer, uint64_t i, uint64_t value) {
+  return digestMix(digestMix(key * 0x9e3779b97f4a7c15ull + static_cast<uint64_t>(layer) * 0x632be59bd9b4e019ull + i) ^ value);
+}
+__global__ __launch_bounds__(256) void k_map_digest(DevMap m, DevParams p, uint64_t track_stamp, unsigned long long* __restrict__ out) {
+  const uint32_t n_slots = m.counters[C_MAX_SLOT];
+  unsigned long long acc[kDigestWords];
+#pragma unroll
+  for (int l = 0; l < kDigestWords; ++l) acc[l] = 0ull;
+  for (uint32_t s = blockIdx.x; s < n_slots; s += gridDim.x) {
+    const uint32_t bf = m.blk_flags[s];
+    if (!(bf & BLK_LIVE)) continue;
+    const int4 bi = m.blk_index[s];
+    const uint64_t key = packKey(bi.x, bi.y, bi.z);
+    const size_t o = static_cast<size_t>(s) * p.nvox;
+    for (int i = threadIdx.x; i < p.nvox; i += 256) {
+      const uint8_t raw = m.vflags[o + i];
+      acc[0] += digestTerm(key, 0, i, __float_as_uint(m.dist[o + i]));
+      acc[1] += digestTerm(key, 1, i, __float_as_uint(m.weight[o + i]));
+      acc[2] += digestTerm(key, 2, i, m.color[o + i]);
+      const uint64_t lobs = p.with_tracking ? m.last_obs[o + i] : 0ull;
+      const uint64_t locc = p.with_tracking ? ((raw & VOX_OCC) ? track_stamp : m.last_occ[o + i]) : 0ull;
+      acc[3] += digestTerm(key, 3, i, lobs);
+      acc[4] += digestTerm(key, 4, i, locc);
+      acc[5] += digestTerm(key, 5, i, raw & VOX_PUBLIC_MASK);
+      acc[6] += digestTerm(key, 6, i, p.with_semantics ? m.sem_label[o + i] : 0u);
+      if (p.with_semantics) {
+        const bool valid = raw & VOX_SEM_VALID;
+        const float* row = m.lik + (o + i) * p.K;
+        for (int k = 0; k < p.K; ++k)
+          acc[7] += digestTerm(key, 7, static_cast<uint64_t>(k) * p.nvox + i, valid ? __float_as_uint(row[k]) : 0u);
+      }
+    }
+    if (threadIdx.x == 0) {
+      acc[8] += digestTerm(key, 8, 0, bf & 0xfu);
+      acc[9] += digestMix(key);
+      acc[10] += 1ull;
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < kDigestWords; ++l) {
+    unsigned long long v = acc[l];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&out[l], v);
+  }
+}
 }  // namespace khr

@@ -138,6 +138,7 @@ struct khr_ctx {
   // must not see them: in reference order it runs before the frames are integrated); 0 otherwise
   int tick_epoch = 0, motion_ignore_epoch = 0;
   unsigned long long* d_dbg = nullptr;
+  unsigned long long* d_digest = nullptr;  // khr_map_digest accumulators
   uint32_t* d_wg_stats = nullptr;
   uint32_t* d_pix_scratch = nullptr;  // khr_pixel_iou: mask image + counters (allocated on first use)
   size_t pix_words = 0;
@@ -176,7 +177,7 @@ struct khr_ctx {
   const uint64_t* halo_view = nullptr;  // records in use: d_halo_recs, or the caller's device buffer (imported in place)
   uint64_t* d_halo_keys = nullptr;
   uint32_t* d_halo_vals = nullptr;
-  uint32_t halo_cap_total = 0, halo_mask = 0, halo_n = 0;
+  uint32_t halo_cap_total = 0, halo_recs_cap = 0, halo_mask = 0, halo_n = 0;
   // remote mesh halo (three low voxel planes of blocks owned by other ranks)
   uint32_t* d_mh_recs = nullptr;
   const uint32_t* mh_view = nullptr;  // the imported mesh halo records: d_mh_recs, or the caller's buffer (on_device = 2)
@@ -605,6 +606,7 @@ void khr_default_config(khr_config* cfg) {
   cfg->device = 0;
   cfg->rank = 0;
   cfg->world_size = 1;
+  cfg->max_snapshot_blocks = 0;  // = min(max_blocks, 8192)
   cfg->relaxed_arithmetic = 0;  // bit-exact values: 2 % slower update kernel than the relaxed mode (measured), so it is the default
 }
 
@@ -830,6 +832,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &c->d_ef, cap));
   A(devAlloc(c, &c->d_trk_proc, cap));
   A(devAlloc(c, &c->d_dbg, 4096 * 4 * 12));
+  A(devAlloc(c, &c->d_digest, kDigestWords));
   A(devAlloc(c, &c->d_wg_stats, 2 * kFuseStatSlots));
   A(devAlloc(c, &c->d_fetch_done, 4));
   {
@@ -966,7 +969,8 @@ void khr_destroy(khr_ctx* c) {
   resolveTimers(c);
   for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
   for (void* p : c->allocs) hipFree(p);
-  if (c->d_halo_recs) { hipFree(c->d_halo_recs); hipFree(c->d_halo_keys); hipFree(c->d_halo_vals); }
+  if (c->d_halo_recs) hipFree(c->d_halo_recs);
+  if (c->d_halo_keys) { hipFree(c->d_halo_keys); hipFree(c->d_halo_vals); }
   if (c->d_mh_recs) { hipFree(c->d_mh_recs); hipFree(c->d_mh_keys); hipFree(c->d_mh_vals); }
   if (c->d_pix_scratch) hipFree(c->d_pix_scratch);
   if (c->d_inst) hipFree(c->d_inst);
@@ -2002,11 +2006,23 @@ int khr_import_halo(khr_ctx* c, const void* records, int64_t n_records, int on_d
   while (ht < static_cast<uint64_t>(n_records) * 4) ht <<= 1;
   if (static_cast<uint64_t>(n_records) > c->halo_cap_total) {  // (re)allocate the remote table
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->d_halo_recs) { hipFree(c->d_halo_recs); hipFree(c->d_halo_keys); hipFree(c->d_halo_vals); }
-    HIP_TRY(hipMalloc(&c->d_halo_recs, static_cast<size_t>(n_records) * kHaloRecWords * sizeof(uint64_t)));
+    if (c->d_halo_keys) { hipFree(c->d_halo_keys); hipFree(c->d_halo_vals); }
+    c->d_halo_keys = nullptr;
+    c->d_halo_vals = nullptr;
+    c->halo_cap_total = 0;
     HIP_TRY(hipMalloc(&c->d_halo_keys, sizeof(uint64_t) * ht));
     HIP_TRY(hipMalloc(&c->d_halo_vals, sizeof(uint32_t) * ht));
     c->halo_cap_total = static_cast<uint32_t>(n_records);
+  }
+  // the staging copy of the records exists only for host-side callers (on_device imports use the caller's buffer in place:
+  // the RCCL tick pre-sizes the table with world x halo_cap records and would otherwise pin hundreds of MB it never reads)
+  if (!on_device && static_cast<uint64_t>(n_records) > c->halo_recs_cap) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_halo_recs) hipFree(c->d_halo_recs);
+    c->d_halo_recs = nullptr;
+    c->halo_recs_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_halo_recs, static_cast<size_t>(n_records) * kHaloRecWords * sizeof(uint64_t)));
+    c->halo_recs_cap = static_cast<uint32_t>(n_records);
   }
   c->halo_mask = ht - 1;
   // device records are used where they lie (the caller keeps the buffer until the next khr_update_tracking_phase(.., 2)
@@ -3306,7 +3322,8 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
     if (flags & KHR_PF_SNAPSHOT) {  // cloneUpdated (active_window.cpp:229): after meshing, before archival
       if (c->pending_snapshot) khr_snapshot_release(c->pending_snapshot);
       c->pending_snapshot = nullptr;
-      if ((rc = khr_snapshot_updated(c, KHR_SNAP_ALL, 8192, &c->pending_snapshot))) return rc;  // (<= 8192 updated blocks: 100 KB each)
+      const int64_t snap_cap = c->cfg.max_snapshot_blocks ? c->cfg.max_snapshot_blocks : 8192;  // (100 KB per block)
+      if ((rc = khr_snapshot_updated(c, KHR_SNAP_ALL, snap_cap, &c->pending_snapshot))) return rc;
     }
     if (c->cfg.with_tracking && (rc = resetInactiveLaunch(c))) return rc;
     if ((rc = khr_clear_updated(c))) return rc;
@@ -3531,6 +3548,17 @@ int khr_download_block(khr_ctx* c, int32_t bx, int32_t by, int32_t bz, float* di
       if (!(f[i] & VOX_SEM_VALID))
         for (int k = 0; k < c->p.K; ++k) likelihoods[static_cast<size_t>(k) * nv + i] = 0.f;
   }
+  return KHR_OK;
+}
+
+int khr_map_digest(khr_ctx* c, uint64_t* out) {
+  if (!c || !out) return fail(KHR_EINVAL, "null argument");
+  unsigned long long* acc = c->d_digest;
+  HIP_TRY(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * kDigestWords, c->stream));
+  hipLaunchKernelGGL(k_map_digest, dim3(2048), dim3(256), 0, c->stream, c->m, c->p, c->last_track_stamp, acc);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, acc, sizeof(uint64_t) * kDigestWords, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return KHR_OK;
 }
 

@@ -516,6 +516,7 @@ ActiveWindow::ActiveWindow(const Config& cfg, const OutputQueue::Ptr& output_que
   d.rank = config.rank;
   d.world_size = config.world_size;
   d.relaxed_arithmetic = config.exact_arithmetic ? 0 : 1;
+  d.max_snapshot_blocks = config.max_snapshot_blocks;
   chk(khr_create(&d, &ctx_), "khr_create");
   if (config.timing_sync_device) {
     khr_ctx* const sc = ctx_;
@@ -721,6 +722,7 @@ hydra::ActiveWindowOutput::Ptr ActiveWindow::extractOutputData(const FrameData& 
     khr_snapshot* snap = nullptr;
     chk(khr_snapshot_updated(ctx_, KHR_SNAP_ALL, config.max_snapshot_blocks, &snap), "khr_snapshot_updated");
     output->setMap(snap);
+    output->snapshot_capacity = std::min<int64_t>(config.max_snapshot_blocks ? config.max_snapshot_blocks : config.max_blocks, config.max_blocks);
   }
   // archive after cloning / meshing (:231-237)
   if (config.volumetric_map.with_tracking) {

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -207,8 +208,13 @@ struct ActiveWindowOutput {
   const BlockIndices& updatedBlocks() const {
     if (!indices_valid_) {
       const int64_t n = map ? khr_snapshot_num_blocks(map.get()) : 0;
+      if (n < 0) throw std::runtime_error(std::string("ActiveWindowOutput: the map snapshot was never produced: ") + khr_last_error());
       updated_blocks_.assign(static_cast<size_t>(n > 0 ? n : 0), BlockIndex{0, 0, 0});
-      if (n > 0) khr_snapshot_download(map.get(), updated_blocks_[0].data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n);
+      // (fails when more blocks were updated than the snapshot holds -- max_snapshot_blocks: the clone is incomplete and says so)
+      if (n > 0 && khr_snapshot_download(map.get(), updated_blocks_[0].data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n) < 0) {
+        updated_blocks_.clear();
+        throw std::runtime_error(std::string("ActiveWindowOutput::updatedBlocks: ") + khr_last_error());
+      }
       std::sort(updated_blocks_.begin(), updated_blocks_.end());
       indices_valid_ = true;
     }
@@ -231,6 +237,7 @@ struct ActiveWindowOutput {
     const int64_t k = khr_snapshot_download(map.get(), idx.data(), d.data(), w.data(), tsdf_only ? nullptr : col.data(),
                                             tsdf_only ? nullptr : lo.data(), tsdf_only ? nullptr : fl.data(),
                                             tsdf_only ? nullptr : lab.data(), n);
+    if (k < 0) throw std::runtime_error(std::string("ActiveWindowOutput::cloneUpdated: ") + khr_last_error());
     for (int64_t i = 0; i < k; ++i) {
       BlockCopy b;
       b.index = {idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]};
@@ -249,6 +256,17 @@ struct ActiveWindowOutput {
     return out;
   }
   std::vector<BlockCopy> cloneUpdatedTsdf() const { return cloneUpdated(true); }
+  // true when the output updated more blocks than its snapshot could hold (config max_snapshot_blocks): updatedBlocks() /
+  // cloneUpdated() of such an output throw instead of handing out a partial clone
+  bool mapOverflowed() const {
+    if (!map) return false;
+    khr_config cfg{};
+    if (khr_get_config(map_ctx, &cfg) < 0) return false;
+    const int64_t n = khr_snapshot_num_blocks(map.get());
+    const int64_t cap = snapshot_capacity > 0 ? snapshot_capacity : (cfg.max_snapshot_blocks ? cfg.max_snapshot_blocks : 8192);
+    return n > cap;
+  }
+  int64_t snapshot_capacity = 0;  // set by the producer (ActiveWindow::extractOutputData)
 
  private:
   mutable BlockIndices updated_blocks_;

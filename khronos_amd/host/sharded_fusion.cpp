@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -64,8 +65,15 @@ struct Rccl {
 const Rccl& rccl() {
   static const Rccl table = [] {
     void* lib = nullptr;
-    for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"})
-      if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    // KDIST_RCCL_LIB=<path>: another library exporting the eight nccl* entry points below (a site's own RCCL build; the
+    // shared-memory transport of tests/transport/, which runs N ranks on one GPU).  Set => it must load: no silent fallback.
+    if (const char* override_lib = std::getenv("KDIST_RCCL_LIB")) {
+      if (!(lib = dlopen(override_lib, RTLD_NOW | RTLD_LOCAL)))
+        throw Fail{KHR_EDEVICE, std::string("KDIST_RCCL_LIB=") + override_lib + " cannot be loaded: " + dlerror()};
+    } else {
+      for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"})
+        if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    }
     if (!lib) throw Fail{KHR_EDEVICE, std::string("RCCL (librccl.so.1) cannot be loaded: ") + dlerror()};
     Rccl t;
     auto bind = [&](auto& fn, const char* sym) {
@@ -102,6 +110,16 @@ const Rccl& rccl() {
   } while (0)
 
 constexpr int kHaloWords = KHR_HALO_RECORD_BYTES / 8;
+
+// the collectives of a tick / an output, for kdist_profile (calls and bytes are always counted; HIP events only when enabled)
+enum Coll : int { COLL_FRAMES = 0, COLL_CONVERTED, COLL_COUNTS, COLL_KEYS, COLL_DYN_IMAGE, COLL_HALO, COLL_MESH_REQ, COLL_MESH_AGREE, COLL_MESH_REC, COLL_N };
+const char* const kCollNames[COLL_N] = {"frames_allgather", "converted_allgather", "counts_allreduce", "motion_keys_reduce",
+                                        "dynamic_image_broadcast", "halo_allgather", "mesh_request_allgather", "mesh_agree_allreduce",
+                                        "mesh_record_allgather"};
+struct CollRec {
+  int kind;
+  hipEvent_t a, b;
+};
 constexpr int kMaxSplit = 8;  // frames per split-phase khr_tick_integrate call (khronos_amd.h)
 
 }  // namespace
@@ -121,7 +139,7 @@ struct kdist_handle {
   uint64_t* halo_recv = nullptr;
   int64_t* seed_counts = nullptr;             // [n_cameras + world]: seed pixels per camera, then every rank's live-block bound
   int64_t* h_seed_counts = nullptr;           // pinned mirror of the reduced counts
-  int64_t* xchg = nullptr;                    // [2] device scratch of the small agreement collectives (kdist_output)
+  int64_t* xchg = nullptr;                    // [2] device scratch of the small agreement collectives (kdist_output); h_xchg: [0..1] sent, [2..3] agreed
   uint8_t* conv_send = nullptr;               // sender-side ingest: this rank's converted planes, packed (khr_export_converted)
   uint8_t* conv_recv = nullptr;               // ... and every rank's, where the all-gather puts them (the tick's slots refer to them)
   size_t conv_bytes = 0;
@@ -136,6 +154,12 @@ struct kdist_handle {
   std::vector<int> clusters_last_tick;
   int64_t halo_per_rank_last_tick = 0, mesh_records_per_rank_last_output = 0;  // what the last exchanges shipped per rank
   std::vector<void*> allocs;
+  // kdist_profile
+  bool profile = false;
+  uint64_t coll_calls[COLL_N] = {0}, coll_bytes[COLL_N] = {0};
+  double coll_ms[COLL_N] = {0};
+  std::vector<CollRec> coll_pending;
+  std::vector<hipEvent_t> coll_events;
 
   bool exchange() const { return world > 1 || always_exchange; }
   bool net() const { return comm != nullptr; }
@@ -160,6 +184,42 @@ int guarded(const char* where, const std::function<int()>& body) {
     khr_set_last_error((std::string(where) + ": " + e.what()).c_str());
     return KHR_EINVAL;
   }
+}
+// one collective on the handle's stream: counted, and bracketed by HIP events while kdist_profile is on
+template <typename F>
+void coll(kdist_handle* h, Coll kind, size_t bytes_sent, F&& issue) {
+  hipEvent_t a = nullptr, b = nullptr;
+  auto take = [&]() {
+    hipEvent_t e = nullptr;
+    if (!h->coll_events.empty()) {
+      e = h->coll_events.back();
+      h->coll_events.pop_back();
+    } else {
+      KD_HIP(hipEventCreate(&e));
+    }
+    return e;
+  };
+  if (h->profile) {
+    a = take();
+    b = take();
+    KD_HIP(hipEventRecord(a, h->stream));
+  }
+  KD_NCCL(issue());
+  h->coll_calls[kind] += 1;
+  h->coll_bytes[kind] += bytes_sent;
+  if (h->profile) {
+    KD_HIP(hipEventRecord(b, h->stream));
+    h->coll_pending.push_back({kind, a, b});
+  }
+}
+void resolveColl(kdist_handle* h) {
+  for (const CollRec& r : h->coll_pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) h->coll_ms[r.kind] += ms;
+    h->coll_events.push_back(r.a);
+    h->coll_events.push_back(r.b);
+  }
+  h->coll_pending.clear();
 }
 }  // namespace
 
@@ -222,7 +282,7 @@ kdist_handle* kdist_create(khr_ctx* ctx, const khr_sensor* sensor, int rank, int
     h->seed_counts = h->alloc<int64_t>(static_cast<size_t>(n_cameras) + W);
     KD_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_seed_counts), sizeof(int64_t) * (static_cast<size_t>(n_cameras) + W), hipHostMallocDefault));
     h->xchg = h->alloc<int64_t>(2);
-    KD_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_xchg), sizeof(int64_t) * 2, hipHostMallocDefault));
+    KD_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_xchg), sizeof(int64_t) * 4, hipHostMallocDefault));
     KD_HIP(hipEventCreateWithFlags(&h->ev_counts, hipEventDisableTiming));
     h->keys.assign(static_cast<size_t>(n_cameras), nullptr);
     h->dyn_img.assign(static_cast<size_t>(n_cameras), nullptr);
@@ -265,8 +325,36 @@ void kdist_destroy(kdist_handle* h) {
   if (h->h_seed_counts) (void)hipHostFree(h->h_seed_counts);
   if (h->h_xchg) (void)hipHostFree(h->h_xchg);
   if (h->ev_counts) (void)hipEventDestroy(h->ev_counts);
+  resolveColl(h);
+  for (hipEvent_t e : h->coll_events) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(h->stream);
   delete h;
+}
+
+// per-collective accounting: calls / bytes sent by this rank always; milliseconds (HIP events around each call on the handle's
+// stream) while enabled.  kdist_profile(h, on) resets the counters.
+int kdist_profile(kdist_handle* h, int enable) {
+  if (!h) return KHR_EINVAL;
+  resolveColl(h);
+  for (int k = 0; k < COLL_N; ++k) {
+    h->coll_calls[k] = 0;
+    h->coll_bytes[k] = 0;
+    h->coll_ms[k] = 0.0;
+  }
+  h->profile = enable != 0;
+  return KHR_OK;
+}
+int kdist_profile_get(kdist_handle* h, kdist_coll_stat* out, int cap) {
+  if (!h || (!out && cap > 0)) return KHR_EINVAL;
+  resolveColl(h);
+  for (int k = 0; k < COLL_N && k < cap; ++k) {
+    std::memset(&out[k], 0, sizeof(out[k]));
+    std::strncpy(out[k].name, kCollNames[k], sizeof(out[k].name) - 1);
+    out[k].calls = h->coll_calls[k];
+    out[k].bytes_sent = h->coll_bytes[k];
+    out[k].ms = h->coll_ms[k];
+  }
+  return COLL_N;
 }
 
 void* kdist_stream(kdist_handle* h) { return h ? static_cast<void*>(h->stream) : nullptr; }
@@ -295,7 +383,7 @@ int kdist_gather_frames(kdist_handle* h, const void* packed_local, size_t bytes,
     }
     if (h->exchange()) {
       if (!h->net()) throw Fail{KHR_ESTATE, "no communicator (emulation)"};
-      KD_NCCL(rccl().AllGather(packed_local, h->frame_recv, bytes, ncclUint8, h->comm, h->stream));
+      coll(h, COLL_FRAMES, bytes, [&] { return rccl().AllGather(packed_local, h->frame_recv, bytes, ncclUint8, h->comm, h->stream); });
     } else {
       KD_HIP(hipMemcpyAsync(h->frame_recv, packed_local, bytes, hipMemcpyDeviceToDevice, h->stream));
     }
@@ -345,7 +433,7 @@ int tickImpl(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, in
       KD_KHR(khr_export_converted(c, obj_slot, h->conv_send, with_depth));
       const uint8_t* all = h->conv_recv;
       if (h->net()) {
-        KD_NCCL(rccl().AllGather(h->conv_send, h->conv_recv, bytes, ncclUint8, h->comm, h->stream));
+        coll(h, COLL_CONVERTED, bytes, [&] { return rccl().AllGather(h->conv_send, h->conv_recv, bytes, ncclUint8, h->comm, h->stream); });
       } else if (emulated_gather) {
         all = static_cast<const uint8_t*>(emulated_gather);
       } else if (h->world == 1) {
@@ -357,6 +445,12 @@ int tickImpl(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, in
       for (int k = 0; k < n; ++k) {
         const uint8_t* src = (k == h->rank && !h->net()) ? h->conv_send : all + bytes * static_cast<size_t>(k);
         KD_KHR(khr_converted_views(&h->sensor, src, with_depth, &conv[static_cast<size_t>(k)]));
+        // khr_export_converted packs zeros for a plane the sender does not have, and the views always point somewhere: which
+        // planes EXIST is this rank's own frame's answer for the whole rig (a rig is homogeneous: depth-only cameras are
+        // depth-only on every rank; include/khronos_amd_dist.h).  Without this a depth-only rig would blend black colour
+        // and integrate label 0 where kdist_tick integrates neither.
+        if (!frames[h->rank].color) conv[static_cast<size_t>(k)].rgba = nullptr;
+        if (!frames[h->rank].label) conv[static_cast<size_t>(k)].label = nullptr;
         conv[static_cast<size_t>(k)].timestamp_ns = frames[k].timestamp_ns;
         std::memcpy(conv[static_cast<size_t>(k)].world_T_sensor, frames[k].world_T_sensor, sizeof(frames[k].world_T_sensor));
       }
@@ -386,7 +480,7 @@ int tickImpl(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, in
       KD_KHR(khr_tick_live_bound(c, h->seed_counts + n, h->world, h->rank));
     }
     if (early_counts) {
-      KD_NCCL(rccl().AllReduce(h->seed_counts, h->seed_counts, n_counts, ncclInt64, ncclSum, h->comm, h->stream));
+      coll(h, COLL_COUNTS, n_counts * 8, [&] { return rccl().AllReduce(h->seed_counts, h->seed_counts, n_counts, ncclInt64, ncclSum, h->comm, h->stream); });
       KD_HIP(hipMemcpyAsync(h->h_seed_counts, h->seed_counts, sizeof(int64_t) * n_counts, hipMemcpyDeviceToHost, h->stream));
       KD_HIP(hipEventRecord(h->ev_counts, h->stream));
     }
@@ -403,7 +497,7 @@ int tickImpl(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, in
         for (int i = 0; i < n; ++i) cnt[static_cast<size_t>(i)] = host_counts[static_cast<size_t>(i)];
         if (ex && h->net()) {
           KD_HIP(hipMemcpyAsync(h->seed_counts, cnt.data(), sizeof(int64_t) * static_cast<size_t>(n), hipMemcpyHostToDevice, h->stream));
-          KD_NCCL(rccl().AllReduce(h->seed_counts, h->seed_counts, static_cast<size_t>(n), ncclInt64, ncclSum, h->comm, h->stream));
+          coll(h, COLL_COUNTS, static_cast<size_t>(n) * 8, [&] { return rccl().AllReduce(h->seed_counts, h->seed_counts, static_cast<size_t>(n), ncclInt64, ncclSum, h->comm, h->stream); });
           KD_HIP(hipMemcpyAsync(cnt.data(), h->seed_counts, sizeof(int64_t) * static_cast<size_t>(n), hipMemcpyDeviceToHost, h->stream));
           KD_HIP(hipStreamSynchronize(h->stream));
         }
@@ -416,14 +510,14 @@ int tickImpl(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, in
         if (!keys) keys = h->alloc<uint64_t>(h->npx);
         KD_KHR(khr_motion_keys(c, slots_out[ci], keys, 1, nullptr));  // (asynchronous: the count is not needed here)
         if (!h->shard_motion) {
-          if (ex && h->net()) KD_NCCL(rccl().AllReduce(keys, keys, h->npx, ncclUint64, ncclSum, h->comm, h->stream));
+          if (ex && h->net()) coll(h, COLL_KEYS, h->npx * 8, [&] { return rccl().AllReduce(keys, keys, h->npx, ncclUint64, ncclSum, h->comm, h->stream); });
           const int nc = khr_detect_motion_from_keys(c, slots_out[ci], keys, 1);
           KD_KHR(nc);
           h->clusters_last_tick[static_cast<size_t>(ci)] = nc;
           continue;
         }
         // the camera's home rank assembles the key image, clusters it and paints; everybody else receives the painted image
-        if (ex && h->net()) KD_NCCL(rccl().Reduce(keys, keys, h->npx, ncclUint64, ncclSum, home, h->comm, h->stream));
+        if (ex && h->net()) coll(h, COLL_KEYS, h->npx * 8, [&] { return rccl().Reduce(keys, keys, h->npx, ncclUint64, ncclSum, home, h->comm, h->stream); });
         int32_t*& img = h->dyn_img[static_cast<size_t>(ci)];
         if (ex && !img) img = h->alloc<int32_t>(h->npx + 1);
         if (h->rank == home) {
@@ -440,7 +534,7 @@ int tickImpl(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, in
           h->clusters_last_tick[static_cast<size_t>(ci)] = -1;
         }
         if (ex) {
-          if (h->net()) KD_NCCL(rccl().Broadcast(img, img, h->npx + 1, ncclInt32, home, h->comm, h->stream));
+          if (h->net()) coll(h, COLL_DYN_IMAGE, h->rank == home ? (h->npx + 1) * 4 : 0, [&] { return rccl().Broadcast(img, img, h->npx + 1, ncclInt32, home, h->comm, h->stream); });
           if (h->rank != home && h->net()) KD_KHR(khr_set_frame_image(c, slots_out[ci], 0, img, 1));
         }
       }
@@ -463,7 +557,7 @@ int tickImpl(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, in
       h->halo_per_rank_last_tick = per_rank;
       KD_KHR(khr_export_halo(c, h->halo_send, per_rank, 1));
       if (h->net()) {
-        KD_NCCL(rccl().AllGather(h->halo_send, h->halo_recv, static_cast<size_t>(per_rank) * kHaloWords, ncclUint64, h->comm, h->stream));
+        coll(h, COLL_HALO, static_cast<size_t>(per_rank) * kHaloWords * 8, [&] { return rccl().AllGather(h->halo_send, h->halo_recv, static_cast<size_t>(per_rank) * kHaloWords, ncclUint64, h->comm, h->stream); });
         KD_KHR(khr_import_halo(c, h->halo_recv, static_cast<int64_t>(h->world) * per_rank, 1));
       } else {  // emulation: only this rank's records exist
         KD_KHR(khr_import_halo(c, h->halo_send, h->halo_cap, 1));
@@ -499,32 +593,54 @@ int kdist_output(kdist_handle* h) {
     if (!h) throw Fail{KHR_EINVAL, "null handle"};
     khr_ctx* c = h->ctx;
     if (h->exchange()) {
-      KD_KHR(khr_mesh_halo_requests(c, h->req_send, h->req_cap, 1, 1));  // (errors when the requests exceed req_cap)
+      // A buffer that is too small on ONE rank must fail the output on EVERY rank (a rank that raised alone would leave the
+      // others waiting in the next collective): local faults are collected, agreed on with the record count in one
+      // all-reduce, and raised by everybody after it.  Faults: more plane requests than req_cap; records dropped by this
+      // tick's / output's export kernels or a block pool that ran out (the device counts them: khr_pool_exhausted).
+      bool local_fault = false;
+      std::string local_text;
+      const int n_req = khr_mesh_halo_requests(c, h->req_send, h->req_cap, 1, 1);
+      if (n_req == KHR_ENOMEM) {  // (the buffer holds the first req_cap requests: harmless to ship)
+        local_fault = true;
+        local_text = khr_last_error();
+      } else {
+        KD_KHR(n_req);
+      }
       if (h->net()) {
-        KD_NCCL(rccl().AllGather(h->req_send, h->req_recv, static_cast<size_t>(h->req_cap), ncclUint64, h->comm, h->stream));
+        coll(h, COLL_MESH_REQ, static_cast<size_t>(h->req_cap) * 8, [&] { return rccl().AllGather(h->req_send, h->req_recv, static_cast<size_t>(h->req_cap), ncclUint64, h->comm, h->stream); });
         const int n_rec = khr_mesh_halo_export(c, h->req_recv, static_cast<int64_t>(h->world) * h->req_cap, h->rec_send, h->rec_cap, 1);
         KD_KHR(n_rec);
-        // the ranks agree on the fullest rank's record count (one 8-byte max all-reduce; the export above has synchronised
-        // anyway) and ship that many records each instead of rec_cap (18 KB per record: 590 MB per rank at the 1 cm rig)
+        const int64_t dropped = khr_pool_exhausted(c);
+        KD_KHR(static_cast<int>(dropped < 0 ? dropped : 0));
+        if (dropped > 0 && !local_fault) {
+          local_fault = true;
+          local_text = "an exchange buffer was too small (halo_cap / mesh_rec_cap) or the block pool ran out: records were dropped";
+        }
+        // the ranks agree on the fullest rank's record count and on "somebody has a fault" (one 16-byte max all-reduce; the
+        // export above has synchronised anyway) and ship that many records each instead of rec_cap (18 KB per record: 590 MB
+        // per rank at the 1 cm rig)
         h->h_xchg[0] = n_rec;
-        KD_HIP(hipMemcpyAsync(h->xchg, h->h_xchg, sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-        KD_NCCL(rccl().AllReduce(h->xchg, h->xchg, 1, ncclInt64, ncclMax, h->comm, h->stream));
-        KD_HIP(hipMemcpyAsync(h->h_xchg + 1, h->xchg, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        h->h_xchg[1] = local_fault ? 1 : 0;
+        KD_HIP(hipMemcpyAsync(h->xchg, h->h_xchg, 2 * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+        coll(h, COLL_MESH_AGREE, 16, [&] { return rccl().AllReduce(h->xchg, h->xchg, 2, ncclInt64, ncclMax, h->comm, h->stream); });
+        KD_HIP(hipMemcpyAsync(h->h_xchg + 2, h->xchg, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
         KD_HIP(hipStreamSynchronize(h->stream));
-        const int64_t per_rank = std::min<int64_t>(h->rec_cap, std::max<int64_t>(16, (h->h_xchg[1] + 15) / 16 * 16));
+        if (h->h_xchg[3] > 0)
+          throw Fail{KHR_ENOMEM, local_fault ? "on this rank: " + local_text
+                                             : std::string("on another rank: an exchange buffer was too small or its block pool ran out (see that rank's error)")};
+        const int64_t per_rank = std::min<int64_t>(h->rec_cap, std::max<int64_t>(16, (h->h_xchg[2] + 15) / 16 * 16));
         h->mesh_records_per_rank_last_output = per_rank;
-        KD_NCCL(rccl().AllGather(h->rec_send, h->rec_recv, static_cast<size_t>(per_rank) * h->mesh_words, ncclUint32, h->comm, h->stream));
+        coll(h, COLL_MESH_REC, static_cast<size_t>(per_rank) * h->mesh_words * 4, [&] { return rccl().AllGather(h->rec_send, h->rec_recv, static_cast<size_t>(per_rank) * h->mesh_words, ncclUint32, h->comm, h->stream); });
         KD_KHR(khr_mesh_halo_import(c, h->rec_recv, static_cast<int64_t>(h->world) * per_rank, 2));  // indexed where the all-gather put them
-      } else {  // emulation: requests and answers of this rank only
+      } else {  // emulation / one rank: requests and answers of this rank only
+        if (local_fault) throw Fail{KHR_ENOMEM, local_text};
         KD_KHR(khr_mesh_halo_export(c, h->req_send, h->req_cap, h->rec_send, h->rec_cap, 1));
         KD_KHR(khr_mesh_halo_import(c, h->rec_send, h->rec_cap, 2));
+        const int64_t dropped = khr_pool_exhausted(c);
+        KD_KHR(static_cast<int>(dropped < 0 ? dropped : 0));
+        if (dropped > 0)
+          throw Fail{KHR_ENOMEM, "an exchange buffer was too small (halo_cap / mesh_rec_cap) or the block pool ran out: records were dropped"};
       }
-      // a rank with more live blocks than halo_cap, or more answers than rec_cap, would have truncated its records: the
-      // device counted that (the exchange kernels bump pool_exhausted), and this is where it becomes an error
-      const int64_t dropped = khr_pool_exhausted(c);
-      KD_KHR(static_cast<int>(dropped < 0 ? dropped : 0));
-      if (dropped > 0)
-        throw Fail{KHR_ENOMEM, "an exchange buffer was too small (halo_cap / mesh_rec_cap) or the block pool ran out: records were dropped"};
     }
     KD_KHR(khr_generate_mesh(c, 1, 1));
     KD_KHR(khr_reset_inactive(c, nullptr, 0, nullptr));

@@ -50,6 +50,8 @@ def load_host_library():
     lib.kdist_tick_own.argtypes = [vp, C.c_uint64, vp, i32, vp, vp, vp, vp]
     lib.kdist_output.argtypes = [vp]
     lib.kdist_last_exchange.argtypes = [vp, vp, vp]
+    lib.kdist_profile.argtypes = [vp, i32]
+    lib.kdist_profile_get.argtypes = [vp, vp, i32]
     lib.khr_host_detect_changes.argtypes = [vp, C.c_int64, vp, C.c_int64, C.c_float, C.c_int64, i32, C.c_float, C.c_float, i32, vp]
     _host = lib
     return lib
@@ -170,6 +172,10 @@ class ObjectPipeline:
                      conf=r[7] / 1e6) for r in out[:n]]
 
 
+class KdistCollStat(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("calls", C.c_uint64), ("bytes_sent", C.c_uint64), ("ms", C.c_double)]
+
+
 class ShardedFusionHost:
     """The multi-GPU tick in C++ over RCCL (khronos_amd/host/sharded_fusion.cpp): the same protocol as
     khronos_amd.distributed.ShardedFusion, with ncclAllGather / ncclAllReduce / ncclReduce / ncclBroadcast on the context's own
@@ -207,6 +213,16 @@ class ShardedFusionHost:
         a, b = C.c_int64(0), C.c_int64(0)
         self._chk(self.lib.kdist_last_exchange(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def profile(self, on=True):
+        """reset the per-collective counters; on: bracket every collective with HIP events from now on (kdist_profile)"""
+        self._chk(self.lib.kdist_profile(self.h, 1 if on else 0))
+
+    def profile_get(self):
+        """{collective: {calls, bytes_sent (this rank), ms}} since the last profile() (kdist_profile_get)"""
+        arr = (KdistCollStat * 16)()
+        n = self._chk(self.lib.kdist_profile_get(self.h, arr, 16))
+        return {a.name.decode(): dict(calls=int(a.calls), bytes_sent=int(a.bytes_sent), ms=float(a.ms)) for a in arr[:n]}
 
     def gather_frames(self, packed_ptr, nbytes):
         out = C.c_void_p()

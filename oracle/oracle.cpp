@@ -1020,6 +1020,67 @@ int orc_get_block(const orc_map* m, int32_t bx, int32_t by, int32_t bz, float* d
   return 0;
 }
 
+// Whole-map digests (test tooling; the definition is include/khronos_amd.h: khr_map_digest): per layer the sum over all
+// blocks and voxels of mix(mix(key * G + layer * L + i) ^ value bits), on the values orc_get_block hands out.
+static inline uint64_t digestMix(uint64_t x) {
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+static inline uint64_t digestTerm(uint64_t key, uint32_t layer, uint64_t i, uint64_t value) {
+  return digestMix(digestMix(key * 0x9e3779b97f4a7c15ull + static_cast<uint64_t>(layer) * 0x632be59bd9b4e019ull + i) ^ value);
+}
+static inline uint32_t floatBits(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  return u;
+}
+void orc_map_digest(const orc_map* m, uint64_t* out /* 12 */) {
+  const std::vector<I3> idx = m->sortedIndices();
+  const int K = m->cfg.num_labels, nv = m->nvox;
+  std::vector<std::array<uint64_t, 12>> part(idx.size());
+  parallelFor(m->cfg.num_threads, idx.size(), [&](size_t bi) {
+    const Block* b = m->find(idx[bi]);
+    const uint64_t key = packBlockKey(idx[bi]);
+    std::array<uint64_t, 12> a{};
+    for (int i = 0; i < nv; ++i) {
+      const TsdfVoxel& t = b->tsdf[i];
+      a[0] += digestTerm(key, 0, i, floatBits(t.distance));
+      a[1] += digestTerm(key, 1, i, floatBits(t.weight));
+      a[2] += digestTerm(key, 2, i, static_cast<uint32_t>(t.r) | (static_cast<uint32_t>(t.g) << 8) | (static_cast<uint32_t>(t.b) << 16) |
+                                        (static_cast<uint32_t>(t.a) << 24));
+      uint8_t fl = 0;
+      uint64_t lobs = 0, locc = 0;
+      if (m->cfg.with_tracking) {
+        const TrackingVoxel& v = b->tracking[i];
+        lobs = v.last_observed;
+        locc = v.last_occupied;
+        fl |= (v.active ? 1 : 0) | (v.ever_free ? 2 : 0) | (v.to_remove ? 4 : 0);
+      }
+      uint32_t lab = 0;
+      if (m->cfg.with_semantics) {
+        const bool valid = !b->semantic[i].empty;
+        fl |= valid ? 8 : 0;
+        lab = b->semantic[i].semantic_label;
+        for (int k = 0; k < K; ++k)
+          a[7] += digestTerm(key, 7, static_cast<uint64_t>(k) * nv + i, valid ? floatBits(b->likelihoods[static_cast<size_t>(i) * K + k]) : 0u);
+      }
+      a[3] += digestTerm(key, 3, i, lobs);
+      a[4] += digestTerm(key, 4, i, locc);
+      a[5] += digestTerm(key, 5, i, fl);
+      a[6] += digestTerm(key, 6, i, lab);
+    }
+    a[8] = digestTerm(key, 8, 0, (b->updated ? 1 : 0) | (b->mesh_updated ? 2 : 0) | (b->tracking_updated ? 4 : 0) | (b->has_active_data ? 8 : 0));
+    a[9] = digestMix(key);
+    a[10] = 1;
+    part[bi] = a;
+  });
+  for (int l = 0; l < 12; ++l) out[l] = 0;
+  for (const auto& a : part)
+    for (int l = 0; l < 12; ++l) out[l] += a[l];
+}
+
 // ---------------------------------------------------------------------------------------------
 // FreeSpaceMotionDetector (free_space_motion_detector.cpp:73-399)
 // ---------------------------------------------------------------------------------------------

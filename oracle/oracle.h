@@ -197,6 +197,9 @@ int orc_get_block(const orc_map* m, int32_t bx, int32_t by, int32_t bz, float* d
                   uint32_t* sem_label, float* likelihoods /* K*n, [k][voxel] */,
                   uint8_t* block_flags /* 1 byte: bit0 updated,1 mesh_updated,2 tracking_updated,3 has_active_data */);
 
+/* whole-map digests, the CPU side of khr_map_digest (include/khronos_amd.h): 12 words, see there */
+void orc_map_digest(const orc_map* m, uint64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

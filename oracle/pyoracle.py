@@ -127,6 +127,8 @@ def load():
     lib.orc_block_indices.argtypes = [vp, vp, i64]
     lib.orc_block_indices.restype = i64
     lib.orc_get_block.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32] + [vp] * 9
+    lib.orc_map_digest.argtypes = [vp, vp]
+    lib.orc_map_digest.restype = None
     _lib = lib
     return lib
 
@@ -327,6 +329,12 @@ class OracleMap:
         out = np.zeros((max(n, 1), 3), np.int32)
         self.lib.orc_block_indices(self.h, _ptr(out), n)
         return out[:n]
+
+    def map_digest(self):
+        """orc_map_digest: the CPU side of FusionContext.map_digest (np.uint64[12])."""
+        out = np.zeros(12, np.uint64)
+        self.lib.orc_map_digest(self.h, _ptr(out))
+        return out
 
     def get_block(self, idx, likelihoods=True):
         nv, K = self.nvox, max(1, self.cfg.num_labels)

@@ -102,7 +102,63 @@ def compare_maps(ctx, ora, max_blocks=None, rng=None, check_lik=True, cfg=None, 
     assert worst["lik"] <= TOL * 10, worst  # log-likelihood sums grow with observations
     assert worst["color"] <= 1, worst
     assert worst["borderline"] <= max(2, int(1e-5 * worst["voxels"])), worst
+    # ALL blocks, every voxel, every layer: one digest per layer on both sides (the per-block loop above only samples large
+    # maps -- it is there for readable failures and for the tolerance checks of the relaxed arithmetic)
+    if hasattr(ctx, "map_digest") and hasattr(ora, "map_digest"):
+        assert_digests_equal(ctx.map_digest(), ora.map_digest(), exact=exact, what="HIP vs oracle")
     return worst, len(gi)
+
+
+DIGEST_LAYERS = ("distance", "weight", "color", "last_observed", "last_occupied", "flags", "sem_label", "likelihoods", "block_flags",
+                 "index", "n_blocks", "reserved")
+# layers that are bit-exact even with the relaxed arithmetic (decisions, never values)
+DIGEST_DECISION_LAYERS = ("last_observed", "sem_label", "index", "n_blocks", "reserved")
+
+
+def assert_digests_equal(a, b, exact=True, what=""):
+    """whole-map parity: khr_map_digest / orc_map_digest words, every layer (exact arithmetic) or the decision layers"""
+    for i, name in enumerate(DIGEST_LAYERS):
+        if exact or name in DIGEST_DECISION_LAYERS:
+            assert int(a[i]) == int(b[i]), ("whole-map digest differs", what, name, hex(int(a[i])), hex(int(b[i])))
+
+
+def _mix64(x):
+    x = x + np.uint64(0x9E3779B97F4A7C15)
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def np_map_digest(blocks, with_semantics=True):
+    """the digest definition of include/khronos_amd.h (khr_map_digest) restated in numpy over per-block downloads
+    (`blocks`: iterable of (index, dict as returned by download_block / get_block)): the third, independent implementation the
+    device kernel and the oracle's C++ are checked against at small sizes."""
+    out = np.zeros(12, np.uint64)
+    G, L = np.uint64(0x9E3779B97F4A7C15), np.uint64(0x632BE59BD9B4E019)
+    with np.errstate(over="ignore"):
+        for idx, b in blocks:
+            x, y, z = (int(v) for v in idx)
+            key = np.uint64(((x + (1 << 20)) & 0x1FFFFF) | (((y + (1 << 20)) & 0x1FFFFF) << 21) | (((z + (1 << 20)) & 0x1FFFFF) << 42))
+            nv = b["distance"].size
+            i = np.arange(nv, dtype=np.uint64)
+
+            def term(layer, index, value):
+                return _mix64(_mix64(key * G + np.uint64(layer) * L + index) ^ value.astype(np.uint64))
+            out[0] += term(0, i, b["distance"].view(np.uint32)).sum(dtype=np.uint64)
+            out[1] += term(1, i, b["weight"].view(np.uint32)).sum(dtype=np.uint64)
+            out[2] += term(2, i, np.ascontiguousarray(b["color"]).view(np.uint32).reshape(-1)).sum(dtype=np.uint64)
+            out[3] += term(3, i, b["last_observed"]).sum(dtype=np.uint64)
+            out[4] += term(4, i, b["last_occupied"]).sum(dtype=np.uint64)
+            out[5] += term(5, i, b["flags"]).sum(dtype=np.uint64)
+            out[6] += term(6, i, b["sem_label"]).sum(dtype=np.uint64)
+            if with_semantics and b.get("likelihoods") is not None:
+                lik = np.ascontiguousarray(b["likelihoods"], dtype=np.float32)  # [k][voxel]
+                K = lik.shape[0]
+                out[7] += term(7, np.arange(K * nv, dtype=np.uint64), lik.reshape(-1).view(np.uint32)).sum(dtype=np.uint64)
+            out[8] += term(8, np.zeros(1, np.uint64), np.array([b["block_flags"] & 0xF], np.uint64))[0]
+            out[9] += _mix64(np.array([key], np.uint64))[0]
+            out[10] += np.uint64(1)
+    return out
 
 
 class DeviceArray:

@@ -267,3 +267,38 @@ def test_numpy_frustum_allocation_matches_oracle():
             seen |= vis
             assert seen == {tuple(int(v) for v in b) for b in ora.block_indices()}, (vs, i)
         assert len(seen) > (100 if vs > 0.05 else 1000)
+
+
+def test_map_digest_oracle_equals_numpy_restatement_and_adds_over_shards():
+    """khr_map_digest's definition (include/khronos_amd.h) three ways on the CPU: the oracle's C++ (orc_map_digest), a numpy
+    restatement over per-block reads (tests/common.np_map_digest), and the additivity the sharded tests rely on: the digests of the
+    hash-range shards of a map sum (mod 2^64) to the digest of the unsharded map."""
+    from common import DIGEST_LAYERS, np_map_digest
+    from test_cpu_oracle import _cfg
+    s = SyntheticStream(96, 72, threads=1)
+    kw = dict(voxel_size=0.2, truncation_distance=0.6, temporal_buffer=0.25)
+    maps = [po.OracleMap(_cfg(**kw))] + [po.OracleMap(_cfg(rank=r, world_size=3, **kw)) for r in range(3)]
+    sen = po.OrcSensor(96, 72, s.fx, s.fy, s.cx, s.cy, 0.1, 5.0)
+    for i in range(6):
+        fr = s.render(i)
+        for m in maps:
+            m.integrate(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+        # (no halo exchange between these shards: phase 1 only, so that every layer but the ever-free bit is shard-independent)
+        for m in maps:
+            m.update_tracking_phase(fr["stamp"], 1)
+    full = maps[0]
+    d = full.map_digest()
+    ref = np_map_digest((idx, full.get_block(idx)) for idx in full.block_indices())
+    for i, name in enumerate(DIGEST_LAYERS):
+        assert int(d[i]) == int(ref[i]), name
+    assert int(d[10]) == len(full.block_indices()) > 10 and len(set(int(x) for x in d[:10])) == 10
+    with np.errstate(over="ignore"):
+        tot = np.sum([m.map_digest() for m in maps[1:]], axis=0, dtype=np.uint64)
+    assert np.array_equal(tot, d)
+    # a single flipped bit anywhere changes the layer's word
+    fr = s.render(7)
+    full.integrate(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+    d2 = full.map_digest()
+    assert all(int(d2[i]) != int(d[i]) for i in (0, 1, 3))
+    for m in maps:
+        m.close()

@@ -65,3 +65,41 @@ def test_cxx_rccl_tick_equals_single_context(shard_motion, sender_side):
     for dev in held:
         for d in dev:
             d.free()
+
+
+@pytest.mark.parametrize("planes", ["depth-only", "depth+label", "depth+colour"])
+def test_sender_side_ingest_of_a_rig_without_colour_or_labels(planes):
+    """kdist_tick_own on frames that lack the colour and / or the label image: the adopted cameras must integrate exactly what
+    kdist_tick (and the plain single-context calls) integrate -- no black colour blended in, no label 0 fused (the packed planes
+    of khr_export_converted carry zeros where the sender has no image)."""
+    from khronos_amd.host_capi import ShardedFusionHost
+    use_c, use_l = planes == "depth+colour", planes == "depth+label"
+    cfg, ctx, ora, s, sen, osen = make_pair(width=W, height=H, num_frame_slots=4)
+    _, ref, _, _, _, _ = make_pair(width=W, height=H, num_frame_slots=4)
+    sf = ShardedFusionHost(ctx, sen, 0, 1, ShardedFusionHost.unique_id(), n_cameras=1, halo_cap=4096, mesh_req_cap=4096, mesh_rec_cap=512,
+                           motion=True, shard_motion=True, always_exchange=True)
+    held = []
+    for i in range(5):
+        fr = s.render(i)
+        dev = [DeviceArray(np.ascontiguousarray(fr[k])) for k in ("depth", "rgb", "label")]
+        held.append(dev)
+        f = ctx.make_frame(fr["stamp"], fr["pose"], dev[0].data_ptr(), dev[1].data_ptr() if use_c else 0, dev[2].data_ptr() if use_l else 0)
+        sf.tick_own(fr["stamp"], [f])
+        slot2 = ref.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"] if use_c else None, fr["label"] if use_l else None)
+        ref.detect_motion(slot2)
+        ref.integrate(slot2, allocate_blocks=True, use_mask=True)
+        ref.update_tracking(fr["stamp"])
+        ora.integrate(osen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"] if use_c else None, fr["label"] if use_l else None)
+        ora.update_tracking(fr["stamp"])
+    from common import assert_digests_equal
+    d = ctx.map_digest()
+    assert_digests_equal(d, ref.map_digest(), what="tick_own vs plain calls")
+    assert_digests_equal(d, ora.map_digest(), what="tick_own vs oracle")
+    b = ctx.download_block(ctx.block_indices()[len(ctx.block_indices()) // 2])
+    assert use_c or not b["color"][:, :3].any()
+    assert use_l or not (b["flags"] & 8).any()
+    sf.close()
+    ctx.sync()
+    for dev in held:
+        for x in dev:
+            x.free()

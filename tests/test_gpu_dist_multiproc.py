@@ -1,0 +1,251 @@
+"""-m gpu: the PRODUCT's multi-GPU tick (khronos_amd/host/sharded_fusion.cpp: kdist_gather_frames, kdist_tick / kdist_tick_own,
+kdist_output) executed with world_size 2, 3, 4 and 8 -- N processes on the ONE GPU of the box, the eight nccl* entry points it
+binds supplied by the shared-memory transport of tests/transport/ (KDIST_RCCL_LIB) because RCCL itself will not put several
+ranks on one device.  What is compared, bit for bit:
+
+    union of the N shards  ==  the unsharded run of the same call sequence (world_size 1)  ==  the CPU oracle
+
+on whole maps (khr_map_digest: every voxel of every block, all layers), block index sets, per-tick dynamic images and cluster
+counts of every camera (seed-count all-reduce, key reduce to the camera's home rank, clustering there, broadcast), archived block
+lists and meshes of every output (mesh halo request / record exchange), the object half of every rank (tracks, extracted
+objects) and the N_upd / N_band totals.  Geometries: a small one for long sequences with object extraction, and the rigs of
+BASELINE.json configs[3] (4 x 1280x720, 2 cm, world 4) and configs[4] (8 x 1920x1080, 1 cm, world 8) with ALL cameras, motion
+detector, mesh halo, archival and each rank's object half.  Exchange-buffer overflows must be errors on EVERY rank."""
+import os
+import pickle
+import subprocess
+import sys
+import time
+import zlib
+
+import numpy as np
+import pytest
+
+from test_cpu_shm_transport import build_transport
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "kdist_worker.py")
+THREADS = os.cpu_count() or 1
+
+
+def _spawn(world, out_dir, args, transport, timeout_s):
+    os.makedirs(out_dir, exist_ok=True)
+    env = dict(os.environ)
+    env.pop("KDIST_RCCL_LIB", None)
+    if world > 1:
+        env.update(KDIST_RCCL_LIB=transport, KDIST_SHM_TIMEOUT_S=str(min(300, timeout_s)))
+    procs, logs = [], []
+    for r in range(world):
+        log = open(os.path.join(out_dir, "rank%d.log" % r), "w")
+        logs.append(log)
+        procs.append(subprocess.Popen([sys.executable, WORKER, "--rank", str(r), "--world", str(world), "--out", out_dir] + args, env=env,
+                                      stdout=log, stderr=subprocess.STDOUT, cwd=ROOT))
+    deadline = time.time() + timeout_s
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if time.time() > deadline or (any(p.poll() not in (None, 0) for p in procs) and not failed):
+            failed = True
+            deadline = min(deadline, time.time() + 20)  # a rank has died: the others notice (transport time-out) or are killed
+        if failed and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    for log in logs:
+        log.close()
+    texts = [open(os.path.join(out_dir, "rank%d.log" % r)).read() for r in range(world)]
+    return [p.returncode for p in procs], texts
+
+
+def _results(world, out_dir):
+    return [pickle.load(open(os.path.join(out_dir, "rank%d.pkl" % r), "rb")) for r in range(world)]
+
+
+def _oracle(geometry, cameras, ticks, out_every, temporal_window, temporal_buffer, period):
+    """the reference's order on one map: all cameras of a tick against the map the tick starts from (motion detector), then their
+    integration in camera order with the dynamic masks, one tracking pass, and at output cadence mesh / archival / flag clearing
+    (active_window.cpp:118-174, 217-249)."""
+    import math
+    from kdist_worker import GEOMETRY
+    from khronos_amd import default_config
+    from khronos_amd.synth import SyntheticStream
+    from oracle import pyoracle as po
+    g = GEOMETRY[geometry]
+    W, H, vs = g["width"], g["height"], g["vs"]
+    cfg = default_config(voxel_size=vs, truncation_distance=3 * vs, voxels_per_side=16, with_semantics=1, with_tracking=1, exact_arithmetic=1,
+                         num_labels=20, max_blocks=16, max_frame_pixels=W * H, md_min_cluster_size=g["min_cluster"],
+                         md_min_separation_distance=2.0, md_max_range=5.0, temporal_buffer=temporal_buffer, temporal_window=temporal_window)
+    ora = po.OracleMap(po.config_from(cfg, THREADS))
+    s = SyntheticStream(W, H, seed=1234, period=period)
+    osen = ora.make_sensor(W, H, s.fx, s.fy, s.cx, s.cy)
+    out = dict(clusters=[], dyn_crc=[], removed=[], n_upd=0, n_band=0, mesh=None)
+    for tick in range(ticks):
+        stamp = s.stamp_ns(tick)
+        frs = [s.render(tick, yaw_offset=2.0 * math.pi * k / cameras) for k in range(cameras)]
+        dyns, ns = [], []
+        for fr in frs:
+            n, dyn, _ = ora.detect_motion(osen, stamp, fr["pose"], fr["depth"])
+            dyns.append(dyn)
+            ns.append(n)
+        for fr, dyn in zip(frs, dyns):
+            st = ora.integrate(osen, stamp, fr["pose"], fr["depth"], fr["rgb"], fr["label"], mask=dyn)
+            out["n_upd"] += st["n_updated_voxels"]
+            out["n_band"] += st["n_band_voxels"]
+        ora.update_tracking(stamp)
+        out["clusters"].append(ns)
+        out["dyn_crc"].append([zlib.crc32(np.ascontiguousarray(d, dtype=np.int32).tobytes()) for d in dyns])
+        if (tick + 1) % out_every == 0:
+            ora.generate_mesh(True, True)
+            out["removed"].append(ora.reset_inactive())
+            ora.clear_updated()
+            out["mesh"] = ora.mesh()  # (of the blocks that are still there, like khr_download_mesh after kdist_output)
+    out["digest"] = ora.map_digest()
+    out["indices"] = ora.block_indices()
+    rng = np.random.default_rng(11)
+    idx = out["indices"]
+    out["ever_free_sampled"] = sum(int((ora.get_block(b, likelihoods=False)["flags"] & 2).sum())
+                                   for b in idx[rng.choice(len(idx), min(150, len(idx)), replace=False)])
+    ora.close()
+    return out
+
+
+def _sorted_rows(a):
+    a = np.asarray(a).reshape(-1, 3)
+    return a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))] if len(a) else a
+
+
+def _check(world, cameras, shards, ref, ora, expect_objects):
+    ref = ref[0]
+    ticks = len(ref["clusters"])
+    # (1) motion detector: cluster counts at the camera's home rank, dynamic images on every rank
+    for t in range(ticks):
+        for k in range(cameras):
+            home = shards[k % world]
+            assert home["clusters"][t][k] == ref["clusters"][t][k] == ora["clusters"][t][k], (t, k)
+            for sh in shards:
+                assert sh["clusters"][t][k] in (-1, 0, ref["clusters"][t][k])
+                assert sh["dyn_crc"][t][k] == ref["dyn_crc"][t][k] == ora["dyn_crc"][t][k], (t, k, sh["rank"])
+    assert sum(sum(c) for c in ora["clusters"]) > 0, "the motion detector never fired: the key exchange was not exercised"
+    # (2) outputs: archived blocks and meshes
+    n_out = len(ref["removed"])
+    assert n_out >= 1 and all(len(sh["removed"]) == n_out for sh in shards)
+    for o in range(n_out):
+        union = _sorted_rows(np.concatenate([sh["removed"][o].reshape(-1, 3) for sh in shards]))
+        assert np.array_equal(union, _sorted_rows(ref["removed"][o])), o
+        assert np.array_equal(union, _sorted_rows(ora["removed"][o])), o
+        with np.errstate(over="ignore"):
+            tot = np.sum([sh["mesh"][o] for sh in shards], axis=0, dtype=np.uint64)
+        assert np.array_equal(tot, ref["mesh"][o]), (o, tot, ref["mesh"][o])
+        assert int(ref["mesh"][o][0]) > 0
+    # the unsharded product mesh vs the oracle's, in block order (vertices within the tolerance north_star states; labels exact)
+    gm, om = ref["final_mesh"], ora["mesh"]
+    assert gm["points"].shape == om["points"].shape and len(gm["points"]) > 0
+    assert np.abs(gm["points"] - om["points"]).max() <= 1e-4
+    assert np.array_equal(gm["labels"], om["labels"]) and np.array_equal(gm["stamps"], om["stamps"])
+    # (3) whole maps: every voxel of every block, all layers
+    with np.errstate(over="ignore"):
+        tot = np.sum([sh["digest"] for sh in shards], axis=0, dtype=np.uint64)
+    names = ("distance", "weight", "color", "last_observed", "last_occupied", "flags", "sem_label", "likelihoods", "block_flags", "index",
+             "n_blocks", "reserved")
+    for i, nm in enumerate(names):
+        assert tot[i] == ref["digest"][i], ("shards vs unsharded", nm)
+        assert ref["digest"][i] == ora["digest"][i], ("unsharded vs oracle", nm)
+    parts = [sh["indices"] for sh in shards]
+    allb = _sorted_rows(np.concatenate(parts))
+    assert len(np.unique(allb, axis=0)) == len(allb), "the shards overlap"
+    assert np.array_equal(allb, _sorted_rows(ref["indices"])) and np.array_equal(allb, _sorted_rows(ora["indices"]))
+    assert min(len(p) for p in parts) > 0.3 * len(allb) / world, [len(p) for p in parts]
+    assert ora["ever_free_sampled"] > 0, "the ever-free stencil (and with it the halo exchange) must have fired"
+    # (4) voxel-update totals
+    assert sum(sh["stats"]["cum_updated_voxels"] for sh in shards) == ref["stats"]["cum_updated_voxels"] == ora["n_upd"]
+    assert sum(sh["stats"]["cum_band_voxels"] for sh in shards) == ref["stats"]["cum_band_voxels"] == ora["n_band"]
+    for sh in shards + [ref]:
+        assert sh["stats"]["pool_exhausted"] == 0 and sh["stats"]["band_overflow"] == 0
+    # (5) each rank's object half == the unsharded run's pipeline of the same camera
+    n_tracks = n_objects = 0
+    for k in range(cameras):
+        sh = shards[k % world]
+        assert sh["tracks"][k] == ref["tracks"][k], k
+        n_tracks += len(ref["tracks"][k])
+        key = lambda o: (o["first_seen"], o["last_seen"], o["label"], o["trajectory"], o["vertices"])  # noqa: E731
+        a, b = sorted(sh["objects"][k], key=key), sorted(ref["objects"][k], key=key)
+        assert [key(o) for o in a] == [key(o) for o in b], k
+        for x, y in zip(a, b):
+            assert np.array_equal(x["points"], y["points"]) and np.array_equal(x["bbox_min"], y["bbox_min"])
+        n_objects += len(b)
+    assert n_tracks > 0
+    if expect_objects:
+        assert n_objects > 0, "no object left the window: the extraction of the object half was not exercised"
+    # (6) the exchanges ship what the fullest rank holds, not the capacities; every collective of the protocol was issued
+    for sh in shards:
+        halo, mesh = sh["exchange"][-1]
+        assert halo % 256 == 0 and halo >= max(len(p) for p in parts) - 512 and mesh % 16 == 0 and mesh >= 16
+        col = sh["collectives"]
+        for nm in ("frames_allgather", "counts_allreduce", "motion_keys_reduce", "dynamic_image_broadcast", "halo_allgather",
+                   "mesh_request_allgather", "mesh_agree_allreduce", "mesh_record_allgather"):
+            assert col[nm]["calls"] > 0, nm
+        assert col["frames_allgather"]["calls"] == ticks and col["halo_allgather"]["calls"] == ticks
+    return dict(blocks=len(allb), clusters=sum(sum(c) for c in ora["clusters"]), tracks=n_tracks, objects=n_objects)
+
+
+def _case(tmp_path, geometry, world, cameras, ticks, out_every, extra, timeout_s, temporal_window=0.75, temporal_buffer=0.25, period=10.0,
+          expect_objects=False):
+    transport = build_transport()
+    args = ["--cameras", str(cameras), "--geometry", geometry, "--ticks", str(ticks), "--output-every", str(out_every), "--temporal-window",
+            str(temporal_window), "--temporal-buffer", str(temporal_buffer), "--period", str(period)] + extra
+    rc, txt = _spawn(1, str(tmp_path / "ref"), args, transport, timeout_s)
+    assert rc == [0], txt[0][-3000:]
+    rc, txt = _spawn(world, str(tmp_path / "shards"), args, transport, timeout_s)
+    assert rc == [0] * world, "\n".join("--- rank %d (rc %s)\n%s" % (r, rc[r], t[-1500:]) for r, t in enumerate(txt))
+    ora = _oracle(geometry, cameras, ticks, out_every, temporal_window, temporal_buffer, period)
+    return _check(world, cameras, _results(world, str(tmp_path / "shards")), _results(1, str(tmp_path / "ref")), ora, expect_objects)
+
+
+SMALL_OBJ = ["--track-window", "0.45", "--track-min-obs", "3", "--buffer-frames", "8"]
+
+
+@pytest.mark.parametrize("world,cameras,sender", [(2, 2, 0), (3, 3, 0), (2, 4, 0), (3, 3, 1), (8, 8, 0)],
+                         ids=["w2", "w3", "w2-two-cameras-per-rank", "w3-sender-side-ingest", "w8"])
+def test_cxx_tick_n_ranks_small(tmp_path, world, cameras, sender):
+    """30 ticks at 320x240 / 10 cm: ever-free after 0.25 s, archival after 0.75 s, tracks leave after 0.45 s and are extracted"""
+    info = _case(tmp_path, "small", world, cameras, ticks=30, out_every=5, extra=SMALL_OBJ + ["--sender-ingest", str(sender)], timeout_s=420,
+                 expect_objects=True)
+    assert info["blocks"] > 60, info
+
+
+def test_cxx_tick_c4_rig_world4(tmp_path):
+    """BASELINE configs[3]: 4 x 1280x720, 2 cm, hash-range shards on 4 ranks; motion detector, mesh halo, archival, object half"""
+    info = _case(tmp_path, "c4", 4, 4, ticks=8, out_every=4, extra=["--track-window", "0.25", "--track-min-obs", "2", "--buffer-frames", "4"],
+                 timeout_s=900, temporal_window=0.35, temporal_buffer=0.15, period=4.0)
+    assert info["blocks"] > 4000, info
+
+
+def test_cxx_tick_c5_rig_world8(tmp_path):
+    """BASELINE configs[4]: 8 x 1920x1080, 1 cm, all 8 cameras on 8 ranks; motion detector (count all-reduce, key reduce to the home
+    rank, broadcast), mesh halo, archival, each rank's object half"""
+    avail_gb = int(next(ln.split()[1] for ln in open("/proc/meminfo") if ln.startswith("MemAvailable"))) / 1e6
+    if avail_gb < 64:  # the unsharded ORACLE of this rig holds ~82 k blocks at once (41 GB of host memory, measured)
+        pytest.skip("the CPU oracle of the 8-camera 1 cm rig needs ~41 GB of host memory; %.0f GB available" % avail_gb)
+    info = _case(tmp_path, "c5", 8, 8, ticks=6, out_every=3, extra=["--track-window", "0.25", "--track-min-obs", "2", "--buffer-frames", "3"],
+                 timeout_s=1500, temporal_window=0.35, temporal_buffer=0.15, period=4.0)
+    assert info["blocks"] > 25000, info
+
+
+@pytest.mark.parametrize("fault", ["halo_cap", "req_cap", "rec_cap", "pool-on-one-rank"])
+def test_exchange_overflow_is_an_error_on_every_rank(tmp_path, fault):
+    """a buffer that is too small for what a rank holds -- the ever-free halo records of a tick, the mesh plane requests or records of
+    an output, or ONE rank's block pool -- fails kdist_output with KHR_ENOMEM on all ranks (nobody is left in a collective)"""
+    transport = build_transport()
+    extra = {"halo_cap": ["--halo-cap", "16"], "req_cap": ["--req-cap", "8"], "rec_cap": ["--rec-cap", "4"],
+             "pool-on-one-rank": ["--max-blocks", "48", "--fault-rank", "1"]}[fault]
+    args = ["--cameras", "2", "--geometry", "small", "--ticks", "6", "--output-every", "3", "--objects", "0"] + extra
+    t0 = time.time()
+    rc, txt = _spawn(2, str(tmp_path / "shards"), args, transport, 240)
+    assert time.time() - t0 < 200, "the ranks waited for a time-out instead of agreeing on the fault"
+    for r in range(2):
+        assert rc[r] not in (0, None) and "KDIST_WORKER_OK" not in txt[r], (r, txt[r][-1500:])
+        assert "kdist_output" in txt[r] and "(-2)" in txt[r], (r, txt[r][-1500:])  # KHR_ENOMEM
+    if fault == "pool-on-one-rank":
+        assert "on this rank" in txt[1] and "on another rank" in txt[0], (txt[0][-800:], txt[1][-800:])

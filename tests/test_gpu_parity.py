@@ -1,4 +1,7 @@
 """-m gpu: HIP path (through the C ABI) vs the CPU oracle on identical seeded frame sequences."""
+import os
+import zlib
+
 import numpy as np
 import pytest
 
@@ -73,8 +76,11 @@ def test_sequence_with_motion_detection(mode, sep, noise, min_size, monkeypatch)
     cfg, ctx, ora, s, sen, osen = make_pair(width=320, height=240, md_min_separation_distance=sep, md_min_cluster_size=min_size,
                                             stream_kw=dict(noise=noise))
     fired = 0
+    trail = []  # what both legs share and what each produced, frame by frame: printed if the scenario ever fails to fire
     for i in range(22):
-        out = step_both(ctx, ora, sen, osen, s.render(i), motion=True)
+        fr_i = s.render(i)
+        out = step_both(ctx, ora, sen, osen, fr_i, motion=True)
+        trail.append((i, zlib.crc32(fr_i["depth"].tobytes()), int((fr_i["depth"] > 0).sum()), int(out["seeds_ora"]), out["n_ora"], out["n_gpu"]))
         assert out["n_gpu"] == out["n_ora"], (i, out["n_gpu"], out["n_ora"])
         assert np.array_equal(out["dyn_gpu"], out["dyn_ora"]), i
         fired += out["n_gpu"]
@@ -90,7 +96,10 @@ def test_sequence_with_motion_detection(mode, sep, noise, min_size, monkeypatch)
                 if m.any():
                     assert np.array_equal(c["bbox_min"], vm[m].min(0)) and np.array_equal(c["bbox_max"], vm[m].max(0))
                     assert np.allclose(c["centroid"], vm[m].astype(np.float64).mean(0), atol=1e-3)
-    assert fired > 0, "motion detector never fired: scenario does not exercise a9-a11"
+    assert fired > 0, ("motion detector never fired: scenario does not exercise a9-a11", dict(
+        frames_crc_valid_seeds_nora_ngpu=trail, env={k: v for k, v in os.environ.items() if k.startswith("KHR_")},
+        threads=os.cpu_count(), cfg={k: getattr(cfg, k) for k in ("md_min_cluster_size", "md_min_separation_distance", "md_max_range",
+                                                                   "temporal_buffer", "temporal_window", "relaxed_arithmetic")}))
     compare_maps(ctx, ora, max_blocks=60)
 
 
@@ -664,3 +673,27 @@ def test_sender_side_ingest_equals_ingest_on_every_rank(range_mode):
     for d in bufs:
         d.free()
     a.close(); b.close(); home.close()
+
+
+@pytest.mark.parametrize("kind", ["window", "object-map"])
+def test_map_digest_kernel_equals_numpy_restatement(kind):
+    """khr_map_digest (one launch over the whole pool) == the numpy restatement of its definition over per-block downloads ==
+    the oracle's orc_map_digest: the whole-map comparison every other parity test now ends with is itself checked three ways"""
+    import common
+    from common import DIGEST_LAYERS, assert_digests_equal, np_map_digest
+    if kind == "window":
+        cfg, ctx, ora, s, sen, osen = make_pair(temporal_buffer=0.25)
+        for i in range(6):
+            step_both(ctx, ora, sen, osen, s.render(i))
+    else:  # 8^3 blocks, binary labels, no tracking layer (mesh_object_extractor.cpp:201-211)
+        cfg, ctx, ora, s, sen, osen = make_pair(voxels_per_side=8, voxel_size=0.05, truncation_distance=0.1, with_tracking=0, semantic_mode=1,
+                                                num_labels=2)
+        for i in range(3):
+            step_both(ctx, ora, sen, osen, s.render(i), track=False)
+    d = ctx.map_digest()
+    idx = ctx.block_indices()
+    ref = np_map_digest((b, ctx.download_block(b)) for b in idx)
+    for i, name in enumerate(DIGEST_LAYERS):
+        assert int(d[i]) == int(ref[i]), name
+    assert int(d[10]) == len(idx) > 20
+    assert_digests_equal(d, ora.map_digest(), exact=bool(common.EXACT), what=kind)

@@ -108,3 +108,25 @@ def test_snapshot_capacity_overflow_is_loud():
     snap.release()
     ctx.close()
     ora.close()
+
+
+def test_process_frame_snapshot_capacity_is_configurable():
+    """khr_config.max_snapshot_blocks bounds the clone khr_process_frame(KHR_PF_SNAPSHOT) takes: an output with more updated
+    blocks reports the true count and refuses the (partial) download; with the default capacity the same frame clones fine"""
+    for cap, ok in ((4, False), (0, True)):
+        cfg, ctx, ora, s, sen, osen = make_pair(width=W, height=H, max_snapshot_blocks=cap)
+        fr = s.render(0)
+        slot, _ = ctx.process_frame(sen, ctx.make_frame(fr["stamp"], fr["pose"], fr["depth"].ctypes.data, fr["rgb"].ctypes.data,
+                                                        fr["label"].ctypes.data), False,
+                                    ctx.PF_TRACKING | ctx.PF_OUTPUT | ctx.PF_SNAPSHOT)
+        snap = ctx.take_snapshot()
+        n = snap.num_blocks()
+        assert n > 4
+        if ok:
+            assert len(snap.download()["indices"]) == n
+        else:
+            with pytest.raises(Exception, match="snapshot capacity"):
+                snap.download()
+        snap.release()
+        ctx.close()
+        ora.close()

@@ -137,7 +137,7 @@ constexpr int kFuseCap = 256;        // in-band records a wave collects before i
 typedef const FuseArgs __attribute__((address_space(4))) * FuseArgsK;
 typedef const FuseFrame __attribute__((address_space(4))) * FuseFrameK;  // a frame's arguments, through the scalar cache
 constexpr int kLikVec = 5;  // float4 likelihood vectors a lane holds at once (K = 20 in one round trip)
-template <int VPS, bool DBG = false>
+template <int VPS, bool DBG = false>  // isa:band: lane<->record update (fuseBandRecord)
 __device__ inline void fuseBandRecord(FuseArgsK ka, FuseFrameK kf, size_t slot, uint32_t lin_mode, float w, float w_new, float u, float v,
                                       unsigned long long* tacc = nullptr) {
   (void)tacc;
@@ -272,7 +272,7 @@ constexpr int kCoopPasses = 6;  // part-B passes whose row vectors are in flight
 __device__ inline bool fuseBandCoopOk(int K, int sem_mode, int do_sem) {
   return !do_sem || (sem_mode != 1 && (K & 3) == 0 && K >= 4 && K <= 64);
 }
-template <int VPS, int CAP = kFuseCap>
+template <int VPS, int CAP = kFuseCap>  // isa:band: record-cooperative update (fuseBandCoop)
 __device__ __forceinline__ void fuseBandCoop(FuseArgsK ka, FuseFrameK kf, size_t slot, const uint32_t* rec, uint32_t cnt, int lane) {
   constexpr int NV = VPS * VPS * VPS;
   const FuseArgs __attribute__((address_space(4)))& a = *ka;
@@ -451,7 +451,7 @@ struct FuseItem {
 };
 
 template <int VPS, int ZSPLIT, bool DEFCFG, bool EXACT, int WPW, bool DBG = false>
-__global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
+__global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {  // isa:kernel setup
   constexpr int NV = VPS * VPS * VPS;
   constexpr int SL = VPS * VPS;        // voxels per z slice
   constexpr int PATCHES = SL / 64;     // 64-voxel x-y patches per slice
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
   };
 
   // ---- phase 1: geometry of the item's ZR voxels per lane; all their loads issued ----
-  auto phase1 = [&](FuseItem<VPS, ZR>& it, const uint4 desc) {
+  auto phase1 = [&](FuseItem<VPS, ZR>& it, const uint4 desc) {  // isa:p1 item geometry (x-y transform, bases)
     const uint32_t dx = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(desc.x)));
     it.slot = dx & 0xffffffu;
     it.sbi = static_cast<int>(dx >> 24);
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
     const char* const wgt_b = reinterpret_cast<const char*>(a.weight + it.slot * NV);
 #pragma unroll
     for (int k = 0; k < ZR; ++k) {
-      const int iz = it.z0 + k;
+      const int iz = it.z0 + k;  // isa:p1 voxel transform + range validity
       const uint32_t lin = static_cast<uint32_t>(it.lin_xy + iz * SL);
       const float pz = it.oz + (static_cast<float>(iz) + 0.5f) * a.vs;
       float pc[3];
@@ -537,13 +537,13 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
       bool ok = pc[2] > 0.f;
       const float voxel_range = range_mode == 0 ? pc[2] : sqrtf((pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2]);
       ok = ok && !(voxel_range < a.min_range || voxel_range > a.max_range);
-      const float yz = rcpRefined(pc[2]);
+      const float yz = rcpRefined(pc[2]);  // isa:p1 projection (rcp + 2 exact divisions + in-image test)
       const float u = divExact(pc[0] * a.fx, pc[2], yz) + a.cx;
       const float v = divExact(pc[1] * a.fy, pc[2], yz) + a.cy;
       // ceil(u) >= W || floor(u) < 0  <=>  u > W - 1 || u < 0  (W - 1 is an integer-valued float); x - y >= 0 <=> x >= y
       // holds exactly in IEEE arithmetic, so the four tests are one min3 / min / compare
       ok = ok && (fminf(fminf(u, v), fminf(Wm1 - u, Hm1 - v)) >= 0.f);
-      // invalid lanes gather pixel (0, 0); valid lanes have 0 <= u <= W - 1, so floor == truncation
+      // invalid lanes gather pixel (0, 0); valid lanes have 0 <= u <= W - 1, so floor == truncation  // isa:p1 pixel addresses + range gathers
       const float uc = ok ? u : 0.f, vc = ok ? v : 0.f;
       const uint32_t u0 = static_cast<uint32_t>(static_cast<int>(uc)), v0 = static_cast<uint32_t>(static_cast<int>(vc));
       const uint32_t v1 = min(v0 + 1u, static_cast<uint32_t>(a.H - 1));
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
       if (DBG && (dbg & 8)) { o0 = static_cast<uint32_t>(lane) * 8u; o1 = o0 + W4; }
       it.ra[k] = *reinterpret_cast<const f2u*>(range_b + o0);  // (u0, v0), (u0 + 1, v0)
       it.rb[k] = *reinterpret_cast<const f2u*>(range_b + o1);  // (u0, v1), (u0 + 1, v1)
-      it.d[k] = 0.f;
+      it.d[k] = 0.f;  // isa:p1 distance / weight loads + item state
       it.w[k] = 0.f;
       if (ok && !(DBG && (dbg & 4))) {
         it.d[k] = *reinterpret_cast<const float*>(dist_b + lin * 4u);
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
     }
   };
 
-  uint32_t item = pull();
+  uint32_t item = pull();  // isa:item loop control / prefetch bookkeeping
   uint32_t item_next = item < n_items ? pull() : 0xffffffffu;
   FuseItem<VPS, ZR> cur, nxt;
   uint4 d_next = make_uint4(0u, 0u, 0u, 0u);
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
       if (item_nn < n_items) d_next = descOf(item_nn);
     }
     // ---- phase 2 of the current item: measurement, decisions, read-modify-write ----
-    const size_t slot = cur.slot;
+    const size_t slot = cur.slot;  // isa:p2 setup (bases)
     char* const dist_b = reinterpret_cast<char*>(a.dist + slot * NV);
     char* const wgt_b = reinterpret_cast<char*>(a.weight + slot * NV);
     char* const lobs_b = reinterpret_cast<char*>(a.last_obs + slot * NV);
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
         continue;
       }
       if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
-      const int iz = cur.z0 + k;
+      const int iz = cur.z0 + k;  // isa:p2 interpolation (weights, adaptive mode, sdf, band test)
       const uint32_t lin = static_cast<uint32_t>(cur.lin_xy + iz * SL);
       const float uc = cur.u[k], vc = cur.v[k], voxel_range = cur.z[k], yz = cur.yz[k];
       // range_mode 0: voxel_range is the voxel's depth; ray-length mode needs the depth again for the weight
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
       const float sdf = dist_surface - voxel_range;
       ok = ok && !(sdf < -a.trunc);
       bool in_band = ok && (fabsf(sdf) < a.trunc);
-      if (__builtin_expect(a.use_mask && __builtin_amdgcn_ballot_w64(in_band) != 0ull, 0)) {
+      if (__builtin_expect(a.use_mask && __builtin_amdgcn_ballot_w64(in_band) != 0ull, 0)) {  // isa:p2 dynamic mask
         // interpolateID(mask): pixel of the largest weight (first maximum)
         int best;
         if (use_nearest) {
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
         }
       }
       if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
-      // measurement weight (computeWeight): fx fy vs^2 / z^4, linear drop-off behind the surface
+      // measurement weight (computeWeight): fx fy vs^2 / z^4, linear drop-off behind the surface  // isa:p2 measurement weight
       float w;
       if (EXACT) {
         const float qd = divExact(a.vs, depth, yz);
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
       // the product is zero exactly when trunc + sdf == 0
       ok = ok && (w > 0.f);
       in_band = in_band && ok;
-      const float sdf_c = fmaxf(fminf(a.trunc, sdf), -a.trunc);
+      const float sdf_c = fmaxf(fminf(a.trunc, sdf), -a.trunc);  // isa:p2 running average
       const float tot = w_old + w;
       float d_new;
       if (EXACT) {
@@ -684,12 +684,12 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
         d_new = __builtin_fmaf(d_old, w_old, sdf_c * w) * __builtin_amdgcn_rcpf(tot);
       }
       const float w_new = fminf(tot, a.max_weight);
-      if (ok && !(DBG && (dbg & 2))) {
+      if (ok && !(DBG && (dbg & 2))) {  // isa:p2 stores
         *reinterpret_cast<float*>(dist_b + lin * 4u) = d_new;
         *reinterpret_cast<float*>(wgt_b + lin * 4u) = w_new;
         if (a.with_tracking) *reinterpret_cast<uint64_t*>(lobs_b + lin * 8u) = a.stamp;
       }
-      const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(ok), m_band = __builtin_amdgcn_ballot_w64(in_band);
+      const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(ok), m_band = __builtin_amdgcn_ballot_w64(in_band);  // isa:p2 statistics + band record compaction (LDS)
       n_upd += static_cast<uint32_t>(__popcll(m_ok));
       touched = touched || (m_ok != 0ull);
       wrote_neg = wrote_neg || (__builtin_amdgcn_ballot_w64(ok && d_new < 0.f) != 0ull);
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
         cnt += static_cast<uint32_t>(__popcll(m_band));
       }
     }
-    const uint32_t item_band = cnt;
+    const uint32_t item_band = cnt;  // isa:band phase driver
     // ---- the item's in-band voxels, densely (lane <-> record).  A cold block: the hint keeps the register allocator
     //      from favouring its values over the voxel loop's ----
     if (DBG && (dbg & 1)) cnt = 0u;
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
       __builtin_amdgcn_wave_barrier();
       if (DBG && (dbg & 64)) t_band += __builtin_amdgcn_s_memtime() - tb0;
     }
-    if (lane == 0) {
+    if (lane == 0) {  // isa:item epilogue (block flags, cost class)
       if (touched && !(DBG && (dbg & 128)))
         atomicOr(&a.blk_flags[slot], BLK_UPDATED | BLK_MESH_UPDATED | BLK_TRACKING_UPDATED | (wrote_neg ? BLK_HAS_NEG : 0u));
       a.blk_band[slot * kBandSlots + (cur.sbi & (kBandSlots - 1))] = static_cast<uint16_t>(min(item_band, 65535u));  // next frame's culling pass sorts by it
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
     o[6] = t_item_max;
     o[7] = 0;
   }
-  // statistics: one read-modify-write per workgroup on its own slot (folded by beginIntegrate / khr_get_stats)
+  // statistics: one read-modify-write per workgroup on its own slot (folded by beginIntegrate / khr_get_stats)  // isa:kernel epilogue
   if (lane == 0) {
     s_stat[wave][0] = n_upd;
     s_stat[wave][1] = n_band;
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {
 // MINW (waves per SIMD the kernel is compiled for) so that 20 - 32 waves per CU are resident: the waits are covered by
 // other waves, not by the wave's own schedule.
 // ====================================================================================================================
-typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));  // isa:k_fuse2 (not part of this breakdown)
 typedef const u4v __attribute__((address_space(4))) * DescK;
 // MULTI: an item is walked through a.n_frames frames (a.frames[], device memory, read through the scalar cache) in order before
 // the wave takes its next item -- the updates of a voxel by consecutive frames are order dependent, those of different items

@@ -174,7 +174,7 @@ def main():
             return gathered + (k % world) * per_rank * frame_bytes + (k // world) * frame_bytes
         poses = [s.pose(tick, yaw_offset=yaws[k]) for k in range(ncam)]
         own = None
-        if a.sender_ingest:
+        if a.sender_ingest and world == ncam:  # (one camera per rank; the unsharded reference run ingests every camera itself)
             frames = [ctx.make_frame(stamp, poses[k], cam_ptr(k) if k == rank else 0, cam_ptr(k) + 8 * npx if k == rank else 0,
                                      cam_ptr(k) + 4 * npx if k == rank else 0) for k in range(ncam)]
             slots, clusters, own = sf.tick_own(stamp, frames)

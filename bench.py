@@ -66,11 +66,15 @@ def parse_args():
     ap.add_argument("--buffer-frames", type=int, default=100, help="frame_data_buffer.max_buffer_size (frames kept in HBM per camera)")
     ap.add_argument("--cpu-baseline-frames", type=int, default=-1,
                     help="frames of the same stream timed on the CPU oracle (rank 0, N=1); -1 = auto, 0 = skip")
-    ap.add_argument("--output-copy", choices=["none", "device", "host"], default="none",
-                    help="what happens to an output's map clone (VolumetricMap::cloneUpdated, active_window.cpp:229): none = the timed "
-                         "step hands out no clone (default line); device = device-side snapshot of the updated blocks at every output "
-                         "(what the drop-in's ActiveWindowOutput carries); host = snapshot + download of all its layers + mesh fetch "
-                         "(a consumer on the host)")
+    ap.add_argument("--output-copy", choices=["none", "device", "host"], default="device",
+                    help="what happens to an output's map clone (VolumetricMap::cloneUpdated, active_window.cpp:229, inside the reference's "
+                         "active_window/all timer scope): device (default line) = device-side snapshot of the updated blocks at every output "
+                         "(what the drop-in's ActiveWindowOutput carries); none = the timed step hands out no clone; host = snapshot + "
+                         "download of the layers a host consumer reads + mesh fetch")
+    ap.add_argument("--host-fields", choices=["tsdf", "all"], default="tsdf",
+                    help="--output-copy host: the layers the host consumer downloads per updated block -- tsdf = distance + weight (8 B per "
+                         "voxel: what a TSDF / places consumer reads; colour and labels travel with the mesh vertices), all = the six "
+                         "layers of khr_download_updated (25 B per voxel)")
     ap.add_argument("--no-extra-streams", action="store_true",
                     help="default c3 run only: do not append the c1 / c2 streams and the output-copy variants (each a short sub-run of this script)")
     ap.add_argument("--no-roofline-timers", action="store_true")
@@ -157,7 +161,10 @@ def main():
     w0 = pre                      # first warm-up frame
     t0i = pre + args.warmup       # first timed frame
     t1i = t0i + args.steps        # first latency frame
-    n_total = t1i + lat
+    # N > 1: a few more ticks behind the timed region with HIP events around every collective (kdist_profile): the line says
+    # what each exchange of the tick costs without those events sitting inside the timed steps
+    prof_ticks = 8 if (world > 1 and not emu) else 0
+    n_total = t1i + lat + prof_ticks
     trunc = 3.0 * vs
     cfg = default_config(
         voxel_size=vs, truncation_distance=trunc, voxels_per_side=16, with_semantics=1, with_tracking=1,
@@ -373,28 +380,28 @@ def main():
             slot, n_dyn = ctx.process_frame(sensor, frame_desc[i], True, flags)
             _t1 = time.perf_counter()
             host_t[0] += _t1 - _t0
+            if args.output_copy == "host":
+                host_consumer_poll()  # (behind this frame's launches: the device works on while the host looks at the previous output)
             if last and out_now and args.output_copy != "none":
-                # the output's map clone: kept until the NEXT output (a consumer that is one output behind), then dropped
+                # the output's map clone
                 snap = ctx.take_snapshot()
+                copy_stats[0] += 1
                 if args.output_copy == "host":
-                    # the consumer's buffers: pinned, allocated once (capacity of the snapshot: 8192 blocks)
-                    if not host_bufs:
-                        nvx = 4096
-                        for nm, dt_, per in (("indices", torch.int32, 3), ("distance", torch.float32, nvx), ("weight", torch.float32, nvx),
-                                             ("color", torch.uint8, 4 * nvx), ("last_observed", torch.int64, nvx), ("flags", torch.uint8, nvx),
-                                             ("sem_label", torch.int32, nvx)):
-                            host_bufs[nm] = torch.empty(8192 * per, dtype=dt_).pin_memory()
-                    nb_ = snap.download_into([host_bufs[k].data_ptr() for k in ("indices", "distance", "weight", "color", "last_observed",
-                                                                                 "flags", "sem_label")], 8192)
-                    copy_stats[0] += 1
-                    copy_stats[1] += nb_ * (12 + 4096 * 25)
-                    mesh = ctx.fetch_mesh()
-                    copy_stats[1] += sum(int(v.nbytes) for v in mesh.values())
+                    # a consumer on the host (the Hydra frontend takes outputs from a queue): the clone's transfer is queued on the
+                    # context's copy stream as soon as its block count is known and runs beside the next frames; at most two
+                    # outputs are in flight (two sets of pinned buffers); the mesh gather is queued now, collected next frame
+                    while len(host_inflight) >= 2 or (host_pending[0] is not None and len(host_inflight) >= 1):
+                        host_consumer_retire()
+                    if host_pending[0] is not None:
+                        host_consumer_begin()  # (waits for the count: the device fell more than an output behind)
+                    host_pending[0] = snap
+                    ctx.fetch_mesh_launch()
+                    host_mesh_pending[0] = True
                 else:
-                    copy_stats[0] += 1
-                if held_snapshot[0] is not None:
-                    held_snapshot[0].release()
-                held_snapshot[0] = snap
+                    # device mode: kept until the NEXT output (a consumer that is one output behind), then dropped
+                    if held_snapshot[0] is not None:
+                        held_snapshot[0].release()
+                    held_snapshot[0] = snap
             if pipe is not None:
                 # software pipeline: the tracker association of the previous frame runs on the host while this frame's
                 # kernels execute; this frame's voxel-set passes are queued behind them and collected next time
@@ -413,7 +420,48 @@ def main():
 
     copy_stats = [0, 0]       # outputs whose map clone was taken, bytes brought to the host (--output-copy)
     held_snapshot = [None]
-    host_bufs = {}
+    # ---- --output-copy host: the pipelined host consumer ----
+    host_fields = (("indices", torch.int32, 3), ("distance", torch.float32, 4096), ("weight", torch.float32, 4096)) + (
+        (("color", torch.uint8, 4 * 4096), ("last_observed", torch.int64, 4096), ("flags", torch.uint8, 4096), ("sem_label", torch.int32, 4096))
+        if args.host_fields == "all" else ())
+    host_bytes_per_block = 12 + 4096 * (25 if args.host_fields == "all" else 8)
+    host_bufs = []            # two sets of pinned arrays (capacity of a snapshot: 8192 blocks), allocated on first use
+    host_inflight = []        # [(snapshot, buffer set)] whose download has begun
+    host_pending = [None]     # snapshot whose block count was not known yet when it was taken
+    host_mesh_pending = [False]
+    host_next_buf = [0]
+
+    def host_consumer_begin():
+        if not host_bufs:
+            for _b in range(2):
+                host_bufs.append({nm: torch.empty(8192 * per, dtype=dt_).pin_memory() for nm, dt_, per in host_fields})
+        b = host_next_buf[0]
+        host_next_buf[0] ^= 1
+        order = ("indices", "distance", "weight", "color", "last_observed", "flags", "sem_label")
+        host_pending[0].download_begin([host_bufs[b][k].data_ptr() if k in host_bufs[b] else 0 for k in order], 8192)
+        host_inflight.append(host_pending[0])
+        host_pending[0] = None
+
+    def host_consumer_retire():
+        snap0 = host_inflight.pop(0)
+        nb_ = snap0.download_end()
+        copy_stats[1] += nb_ * host_bytes_per_block
+        snap0.release()
+
+    def host_consumer_poll():
+        if host_mesh_pending[0]:  # the previous output's mesh: its gather ran right behind that output's kernels
+            mesh = ctx.fetch_mesh()
+            copy_stats[1] += sum(int(v.nbytes) for v in mesh.values())
+            host_mesh_pending[0] = False
+        if host_pending[0] is not None and host_pending[0].poll() and len(host_inflight) < 2:
+            host_consumer_begin()
+
+    def host_consumer_drain():
+        host_consumer_poll()
+        if host_pending[0] is not None:
+            host_consumer_begin()
+        while host_inflight:
+            host_consumer_retire()
     host_t = [0.0, 0.0, 0.0]  # host seconds in process_frame / finish_frame / launch_frame (incl. warm-up)
     obj_stats = [0, 0, 0.0]  # objects extracted, tracks removed, seconds spent in extraction (timed region and warm-up)
 
@@ -436,6 +484,8 @@ def main():
         # default: only the two update kernels carry HIP events (each timed launch costs host time);
         # --all-timers adds the per-kernel breakdown
         ctx.timing_enable(True, None if args.all_timers else ("tsdf",))  # HIP events cost a barrier packet each: only the roofline kernel
+    if fusion_cxx is not None and not emu:
+        fusion_cxx.profile(False)  # (reset: calls / bytes of the timed steps are counted, nothing is timed)
     _trace(_tags["timed_begin"])
     t0 = time.perf_counter()
     ft = []
@@ -457,6 +507,8 @@ def main():
     if pipe is not None:
         pipe.finish_frame()
         obj_stats[0] += pipe.join()  # detached object extractions still running on the worker thread / its stream
+    if args.output_copy == "host" and world == 1:
+        host_consumer_drain()  # the last outputs' transfers end inside the timed region
     sync_all()
     dt = time.perf_counter() - t0
     # how the timed region splits: queueing the K steps (the host runs ahead of the GPU by at most the motion detector's seed
@@ -472,7 +524,7 @@ def main():
     lat_ms = None
     if lat > 0:
         tl = []
-        for i in range(t1i, n_total):
+        for i in range(t1i, t1i + lat):
             torch.cuda.synchronize()
             ta = time.perf_counter()
             step(i)
@@ -487,6 +539,29 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    rccl_info = None
+    if fusion_cxx is not None and not emu:
+        counted = fusion_cxx.profile_get()  # the timed steps: calls and bytes (no events)
+        fusion_cxx.profile(True)
+        p0 = t1i + lat
+        for i in range(p0, p0 + prof_ticks):  # every rank runs them: the calls are collective
+            step(i)
+        if pipe is not None:
+            pipe.finish_frame()
+            pipe.join()
+        sync_all()
+        timed_c = fusion_cxx.profile_get()
+        fusion_cxx.profile(False)
+        rccl_info = {
+            "rccl_ranks": world, "library": os.environ.get("KDIST_RCCL_LIB", "librccl.so.1"),
+            "frames_exchange": "torch.distributed all_gather_into_tensor on a side stream, one tick ahead (%d B per rank and tick)" % (11 * W * H)
+                               if not sender_ingest else "inside the tick (converted planes, kdist_tick_own)",
+            "timed_steps": {k: {"calls": v["calls"], "bytes_sent_per_rank": v["bytes_sent"]} for k, v in counted.items() if v["calls"]},
+            "profiled_ticks": prof_ticks,
+            "collectives": {k: {"calls": v["calls"], "bytes_sent_per_call": v["bytes_sent"] / v["calls"], "ms_per_call": v["ms"] / v["calls"]}
+                            for k, v in timed_c.items() if v["calls"]},
+            "note": "ms: HIP events recorded around each collective on the tick's stream during %d extra ticks after the timed region "
+                    "(includes the wait for the slowest rank to arrive); rank 0's view" % prof_ticks}
 
     n_upd = st1["cum_updated_voxels"] - st0["cum_updated_voxels"]
     n_band = st1["cum_band_voxels"] - st0["cum_band_voxels"]
@@ -538,6 +613,7 @@ def main():
                               "are all-gathered and adopted in place" + (" -- emulated: the other cameras' planes were converted before the timed region" if emu else ""))
                    if sender_ingest else ("every rank converts every camera's raw frame" if world > 1 else "single camera")},
         "mvoxel_updates_per_s": 1e-6 * n_upd_all / dt,
+        **({"rccl": rccl_info} if rccl_info is not None else {}),
         **({"emulation": "rank 0 of a %d-rank sharded run played by one process, no collectives: `value` is what the job would reach "
                          "if communication were free and all ranks were as loaded as rank 0 -- NOT a measured N-GPU number" % world}
            if emu else {}),
@@ -545,9 +621,13 @@ def main():
                         "what": {"none": "the timed steps hand out no clone of the updated blocks (frames and map stay in HBM)",
                                  "device": "every output takes a device-side snapshot of the updated blocks (khr_snapshot_updated between meshing "
                                            "and archival: VolumetricMap::cloneUpdated, active_window.cpp:229), held until the next output",
-                                 "host": "every output takes the device-side snapshot AND a host consumer downloads all its layers "
-                                         "(distance, weight, colour, last_observed, flags, label) plus the mesh"}[args.output_copy],
-                        "outputs_in_timed_region": copy_timed[0], "host_bytes_in_timed_region": copy_timed[1]},
+                                 "host": "every output takes the device-side snapshot AND a host consumer downloads %s of every updated "
+                                         "block plus the mesh -- pipelined: the transfer of output k runs on a copy stream beside the frames "
+                                         "after it (khr_snapshot_download_begin / _end, two sets of pinned buffers), the mesh gather is queued "
+                                         "behind the output and collected one frame later"
+                                         % ("distance + weight (8 B / voxel)" if args.host_fields == "tsdf" else "all six layers (25 B / voxel)")}[args.output_copy],
+                        "outputs_in_timed_region": copy_timed[0], "host_bytes_in_timed_region": copy_timed[1],
+                        "host_bytes_per_output": (copy_timed[1] / copy_timed[0]) if (copy_timed[0] and args.output_copy == "host") else None},
         "objects": None if pipe is None else {"tracks_at_end": pipe.num_tracks(), "buffered_frames": pipe.num_buffered_frames(),
                                               "objects_extracted": obj_timed[0], "tracks_removed": obj_timed[1],
                                               "extraction_ms_total": 1e3 * obj_timed[2],
@@ -654,17 +734,20 @@ def main():
 
     if held_snapshot[0] is not None:
         held_snapshot[0].release()
+    if args.output_copy == "host" and world == 1:
+        host_consumer_drain()
     ctx.close()
     # ---- the other streams north_star asks for, and what an output's map clone costs: short sub-runs of this script,
     #      appended to the default c3 line so that one driver invocation carries all of them ----
     if (rank == 0 and world == 1 and not emu and not args.no_extra_streams and args.config == "c3" and preset_matches
-            and args.output_copy == "none" and not args.fast):
+            and args.output_copy == "device" and not args.fast):
         import subprocess
         extra = {}
         common_args = ["--steps", str(args.steps), "--warmup", str(args.warmup), "--no-extra-streams", "--latency-frames", "0"]
         runs = {"c1": ["--config", "c1"], "c2": ["--config", "c2"],
-                "c3_output_copy_device": ["--config", "c3", "--output-copy", "device", "--cpu-baseline-frames", "0"],
-                "c3_output_copy_host": ["--config", "c3", "--output-copy", "host", "--cpu-baseline-frames", "0"]}
+                "c3_output_copy_none": ["--config", "c3", "--output-copy", "none", "--cpu-baseline-frames", "0"],
+                "c3_output_copy_host": ["--config", "c3", "--output-copy", "host", "--cpu-baseline-frames", "0"],
+                "c3_output_copy_host_all_layers": ["--config", "c3", "--output-copy", "host", "--host-fields", "all", "--cpu-baseline-frames", "0"]}
         for name, extra_args in runs.items():
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra_args + common_args, capture_output=True, text=True,

@@ -411,6 +411,8 @@ typedef struct khr_snapshot khr_snapshot;
 int khr_snapshot_updated(khr_ctx* ctx, uint32_t fields, int64_t cap_blocks, khr_snapshot** out);
 /* the snapshot queued by the last khr_process_frame(.. KHR_PF_SNAPSHOT ..); NULL (and KHR_ENOTFOUND) if there is none */
 int khr_take_snapshot(khr_ctx* ctx, khr_snapshot** out);
+/* non-blocking: 1 once the snapshot's block count is known (its copy kernel has started on the device), else 0 */
+int khr_snapshot_poll(khr_snapshot* snap);
 /* number of blocks in the snapshot (waits for the device copy to have been queued and counted) */
 int64_t khr_snapshot_num_blocks(khr_snapshot* snap);
 /* copy the snapshot to the host: blocks in the snapshot's own order, `indices` (3 per block) says which is which (any
@@ -419,6 +421,15 @@ int64_t khr_snapshot_num_blocks(khr_snapshot* snap);
  * block count. */
 int64_t khr_snapshot_download(khr_snapshot* snap, int32_t* indices, float* distance, float* weight, uint8_t* color_rgba,
                               uint64_t* last_observed, uint8_t* voxel_flags, uint32_t* sem_label, int64_t cap_blocks);
+/* The same transfer, asynchronous, for a consumer that overlaps it with the following frames (the Hydra frontend takes outputs
+ * from a queue; nothing forces the active window to wait for the link): _begin queues the device -> host copies of the
+ * fields whose pointers are non-NULL -- the consumer's field mask: a TSDF consumer passes distance / weight only and moves 8
+ * instead of 25 bytes per voxel -- on a copy stream of the context, ordered behind the snapshot's own pack kernel by an
+ * event; the context's stream is neither waited for nor delayed.  The arrays must stay valid (pin them for the full link
+ * rate) until _end, which waits for the copies and returns the block count.  One download in flight per snapshot. */
+int khr_snapshot_download_begin(khr_snapshot* snap, int32_t* indices, float* distance, float* weight, uint8_t* color_rgba,
+                                uint64_t* last_observed, uint8_t* voxel_flags, uint32_t* sem_label, int64_t cap_blocks);
+int64_t khr_snapshot_download_end(khr_snapshot* snap);
 /* the two optional fields (same order of blocks; likelihoods: cap_blocks * nvox * num_labels floats, voxel-major) */
 int64_t khr_snapshot_download_extra(khr_snapshot* snap, int32_t* indices, uint64_t* last_occupied, float* likelihoods,
                                     int64_t cap_blocks);
@@ -429,6 +440,9 @@ void khr_snapshot_release(khr_snapshot* snap);
  * (utils::combineMeshLayer, geometry_utils.cpp:61-86; faces are implicit: vertex 3i,3i+1,3i+2).
  * returns the vertex count, or a negative error if cap is too small. */
 int64_t khr_mesh_num_vertices(khr_ctx* ctx);
+/* first half of khr_fetch_mesh for a pipelined consumer: queues the gather of the CURRENT mesh behind the stream's work and
+ * returns; the next khr_fetch_mesh only collects (call it before the next khr_generate_mesh / output stage). */
+int khr_fetch_mesh_launch(khr_ctx* ctx);
 /* the same mesh with ONE host round trip, in two halves so that the caller can size its arrays in between:
  * khr_fetch_mesh makes the device gather block table + vertex arrays into pinned memory (one launch, one wait) and
  * returns the vertex count; khr_fetch_mesh_into then copies them, in sorted block order, into the caller's arrays

@@ -84,7 +84,7 @@ EXPORTS = [
     "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",
     "khr_cluster_voxels", "khr_download_frame_image", "khr_detect_objects_launch", "khr_pool_exhausted", "khr_map_digest",
     "khr_rv_create", "khr_rv_destroy", "khr_rv_clear", "khr_rv_add_rays", "khr_rv_num_rays", "khr_rv_num_pairs", "khr_rv_check",
-    "khr_snapshot_updated", "khr_take_snapshot", "khr_snapshot_num_blocks", "khr_snapshot_download", "khr_snapshot_download_extra", "khr_snapshot_release",
+    "khr_snapshot_updated", "khr_take_snapshot", "khr_snapshot_num_blocks", "khr_snapshot_download", "khr_snapshot_download_extra", "khr_snapshot_download_begin", "khr_snapshot_download_end", "khr_snapshot_poll", "khr_fetch_mesh_launch", "khr_snapshot_release",
     "khr_rv_check_stamps", "khr_get_config", "khr_cluster_voxels_launch", "khr_cluster_voxels_fetch", "khr_reset_map", "khr_depend_on", "khr_retain_slot", "khr_release_slot",
 ]
 
@@ -181,6 +181,9 @@ def load_library():
     lib.khr_snapshot_num_blocks.restype = i64
     lib.khr_snapshot_download.argtypes = [vp] + [vp] * 7 + [i64]
     lib.khr_snapshot_download.restype = i64
+    lib.khr_snapshot_download_begin.argtypes = [vp] + [vp] * 7 + [i64]
+    lib.khr_snapshot_download_end.argtypes = [vp]
+    lib.khr_snapshot_download_end.restype = i64
     lib.khr_snapshot_download_extra.argtypes = [vp, vp, vp, vp, i64]
     lib.khr_snapshot_download_extra.restype = i64
     lib.khr_snapshot_release.argtypes = [vp]
@@ -655,6 +658,10 @@ class FusionContext:
         k = self._chk(self.lib.khr_download_mesh(self.h, _ptr(pts), _ptr(col), _ptr(lab), _ptr(fs), _ptr(st), max(n, 1)))
         return {"points": pts[:k], "colors": col[:k], "labels": lab[:k], "first_seen": fs[:k], "stamps": st[:k]}
 
+    def fetch_mesh_launch(self):
+        """queue the gather of the current mesh; the next fetch_mesh() only collects it"""
+        self._chk(self.lib.khr_fetch_mesh_launch(self.h))
+
     def fetch_mesh(self):
         """the same mesh through khr_fetch_mesh / khr_fetch_mesh_into (one host round trip)."""
         v = C.c_int64(0)
@@ -722,6 +729,18 @@ class Snapshot:
         """raw form: `ptrs` = 7 host addresses (indices, distance, weight, colour, last_observed, flags, label; 0 = skip),
         e.g. of pinned buffers; blocks in the snapshot's own order.  -> block count"""
         return self.ctx._chk(self.ctx.lib.khr_snapshot_download(self.h, *[C.c_void_p(p or None) for p in ptrs], int(cap_blocks)))
+
+    def poll(self):
+        """non-blocking: True once the block count is known"""
+        return self.ctx._chk(self.ctx.lib.khr_snapshot_poll(self.h)) == 1
+
+    def download_begin(self, ptrs, cap_blocks):
+        """asynchronous download_into (khr_snapshot_download_begin): the copies run on the context's copy stream beside the next
+        frames' kernels; non-zero entries of `ptrs` are the consumer's field mask.  download_end() waits and returns the count"""
+        self.ctx._chk(self.ctx.lib.khr_snapshot_download_begin(self.h, *[C.c_void_p(p or None) for p in ptrs], int(cap_blocks)))
+
+    def download_end(self):
+        return self.ctx._chk(self.ctx.lib.khr_snapshot_download_end(self.h))
 
     def release(self):
         if self.h is not None and self.h.value:

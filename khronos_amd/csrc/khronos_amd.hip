@@ -162,6 +162,7 @@ struct khr_ctx {
   };
   std::shared_ptr<SnapPool> snap_pool = std::make_shared<SnapPool>();
   khr_snapshot* pending_snapshot = nullptr;  // taken inside khr_process_frame(KHR_PF_SNAPSHOT)
+  hipStream_t copy_stream = nullptr;         // khr_snapshot_download_begin: device -> host copies beside the frames' kernels
   // upper bound of the blocks an explicitly allocated map holds (khr_allocate_blocks since the last khr_reset_map; 0 =
   // unknown): the update kernel of an `allocate = false` integration (object mini-maps) sizes its persistent grid from it
   // instead of filling the chip with workgroups that find no item
@@ -193,6 +194,7 @@ struct khr_ctx {
   bool seed_by_ticket = false;   // motionFinish waits for the ticket (k_motion_pixels) instead of ev_seed (key import)
   bool begin_in_ingest = false, begun = false;  // khr_process_frame folds k_begin_integrate into k_frame_ingest
   uint32_t fetch_ticket = 0;                     // khr_fetch_mesh: completion ticket the gather kernel publishes
+  bool fetch_pending = false;                    // khr_fetch_mesh_launch issued, khr_fetch_mesh outstanding
   uint32_t* d_fetch_done = nullptr;              //   + its workgroup completion counter (device)
   std::vector<uint32_t> fm_order;                // khr_fetch_mesh: slots that carry vertices, in sorted block order
   size_t fm_total = 0;
@@ -975,6 +977,11 @@ void khr_destroy(khr_ctx* c) {
   if (c->d_pix_scratch) hipFree(c->d_pix_scratch);
   if (c->d_inst) hipFree(c->d_inst);
   if (c->pending_snapshot) khr_snapshot_release(c->pending_snapshot);
+  if (c->copy_stream) {
+    hipStreamSynchronize(c->copy_stream);
+    hipStreamDestroy(c->copy_stream);
+    c->copy_stream = nullptr;
+  }
   {
     std::lock_guard<std::mutex> lock(c->snap_pool->mu);
     c->snap_pool->dead = true;  // snapshots still held by a consumer free their arenas themselves from now on
@@ -3657,6 +3664,11 @@ struct khr_snapshot {
   PackOut o{};
   int64_t n = -1;        // blocks copied (known after the first wait)
   int64_t total = -1;    // updated blocks found (> cap: overflow)
+  hipEvent_t ev_packed = nullptr;  // recorded on the context's stream behind the pack kernel
+  hipEvent_t ev_copied = nullptr;  // khr_snapshot_download_begin: the last device -> host copy on the copy stream
+  bool copying = false;
+  int32_t* async_indices = nullptr;  // caller's index array of the download in flight (filled from idx_stage at _end)
+  std::vector<int4> idx_stage;
 };
 
 static size_t snapBytes(uint32_t fields, size_t cap, size_t nvox, bool trk, bool sem, size_t K) {
@@ -3746,8 +3758,12 @@ int khr_snapshot_updated(khr_ctx* c, uint32_t fields, int64_t cap_blocks, khr_sn
       return KHR_OK;
     });
     e = hipGetLastError();
+    // consumers on other streams (khr_snapshot_download_begin's copy stream) order themselves behind the pack kernel with this
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&snap->ev_packed, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(snap->ev_packed, c->stream);
   }
   if (e != hipSuccess) {
+    if (snap->ev_packed) hipEventDestroy(snap->ev_packed);
     std::lock_guard<std::mutex> lock(c->snap_pool->mu);
     c->snap_pool->free.push_back(snap->arena);
     return fail(KHR_EDEVICE, "snapshot launch failed: %s", hipGetErrorString(e));
@@ -3777,6 +3793,12 @@ static int snapshotWait(khr_snapshot* s) {
   return KHR_OK;
 }
 
+// non-blocking: 1 once the snapshot's block count is known (its pack kernel has started), 0 before
+int khr_snapshot_poll(khr_snapshot* s) {
+  if (!s) return fail(KHR_EINVAL, "null snapshot");
+  return (s->n >= 0 || s->arena.h_count[1] == s->ticket) ? 1 : 0;
+}
+
 int64_t khr_snapshot_num_blocks(khr_snapshot* s) {
   if (!s) return fail(KHR_EINVAL, "null snapshot");
   const int rc = snapshotWait(s);
@@ -3799,8 +3821,10 @@ static int64_t snapshotDownload(khr_snapshot* s, int32_t* indices, float* distan
   }
   khr_ctx* c = s->ctx;
   HIP_TRY(hipSetDevice(c->device));
-  // the copy kernel itself must have finished, not only published its count: one stream wait here (download = slow path)
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  // the copy kernel itself must have finished, not only published its count (the event sits right behind it: later frames
+  // queued on the stream are not waited for)
+  if (s->copying) return fail(KHR_ESTATE, "an asynchronous download of this snapshot is in flight (khr_snapshot_download_end first)");
+  HIP_TRY(hipEventSynchronize(s->ev_packed));
   const size_t nv = s->nvox;
   // blocks come in the snapshot's own order (the order the device found them in); `indices` says which is which.  Each
   // field is ONE device -> host copy straight into the caller's array (pinned caller memory gets the full link rate).
@@ -3839,8 +3863,72 @@ int64_t khr_snapshot_download_extra(khr_snapshot* s, int32_t* indices, uint64_t*
   return snapshotDownload(s, indices, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, last_occupied, likelihoods, cap_blocks);
 }
 
+// Asynchronous form of khr_snapshot_download for a consumer that overlaps the transfer with the next frames: the copies go to a
+// copy stream of the context, ordered behind the snapshot's pack kernel by an event -- the context's own stream is neither
+// waited for nor delayed.  Non-NULL pointers select the fields (the consumer's field mask); pinned destinations get the
+// full link rate.  _end waits for the copies and returns the block count.
+int khr_snapshot_download_begin(khr_snapshot* s, int32_t* indices, float* distance, float* weight, uint8_t* color_rgba,
+                                uint64_t* last_observed, uint8_t* voxel_flags, uint32_t* sem_label, int64_t cap_blocks) {
+  if (!s) return fail(KHR_EINVAL, "null snapshot");
+  if (s->copying) return fail(KHR_ESTATE, "a download of this snapshot is already in flight");
+  int rc = snapshotWait(s);  // (the count: published by the pack kernel's first thread)
+  if (rc) return rc;
+  if (s->total > s->cap) return fail(KHR_ENOMEM, "%lld updated blocks, snapshot capacity %u", static_cast<long long>(s->total), s->cap);
+  const int64_t n = s->n;
+  if (n > cap_blocks) return fail(KHR_EINVAL, "%lld blocks in the snapshot, cap %lld", static_cast<long long>(n), static_cast<long long>(cap_blocks));
+  {
+    std::lock_guard<std::mutex> lock(s->pool->mu);
+    if (s->pool->dead) return fail(KHR_ESTATE, "the snapshot's context has been destroyed");
+  }
+  khr_ctx* c = s->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (!s->ev_copied) HIP_TRY(hipEventCreateWithFlags(&s->ev_copied, hipEventDisableTiming));
+  HIP_TRY(hipStreamWaitEvent(c->copy_stream, s->ev_packed, 0));
+  const size_t nv = s->nvox;
+  s->async_indices = indices;
+  if (n > 0) {
+    if (indices) {
+      s->idx_stage.resize(static_cast<size_t>(n));
+      HIP_TRY(hipMemcpyAsync(s->idx_stage.data(), s->d_index, sizeof(int4) * n, hipMemcpyDeviceToHost, c->copy_stream));
+    }
+    hipError_t e = hipSuccess;
+    auto field = [&](void* dst, const void* src, size_t elem) {
+      if (e == hipSuccess && dst && src) e = hipMemcpyAsync(dst, src, static_cast<size_t>(n) * nv * elem, hipMemcpyDeviceToHost, c->copy_stream);
+    };
+    field(distance, s->o.dist, 4);
+    field(weight, s->o.weight, 4);
+    field(color_rgba, s->o.color, 4);
+    field(last_observed, s->o.last_obs, 8);
+    field(voxel_flags, s->o.vflags, 1);
+    field(sem_label, s->o.sem_label, 4);
+    if (e != hipSuccess) return fail(KHR_EDEVICE, "snapshot download failed: %s", hipGetErrorString(e));
+  }
+  HIP_TRY(hipEventRecord(s->ev_copied, c->copy_stream));
+  s->copying = true;
+  return KHR_OK;
+}
+
+int64_t khr_snapshot_download_end(khr_snapshot* s) {
+  if (!s) return fail(KHR_EINVAL, "null snapshot");
+  if (!s->copying) return fail(KHR_ESTATE, "no download in flight (khr_snapshot_download_begin first)");
+  HIP_TRY(hipEventSynchronize(s->ev_copied));
+  s->copying = false;
+  if (s->async_indices)
+    for (int64_t i = 0; i < s->n; ++i) {
+      s->async_indices[3 * i] = s->idx_stage[static_cast<size_t>(i)].x;
+      s->async_indices[3 * i + 1] = s->idx_stage[static_cast<size_t>(i)].y;
+      s->async_indices[3 * i + 2] = s->idx_stage[static_cast<size_t>(i)].z;
+    }
+  s->async_indices = nullptr;
+  return s->n;
+}
+
 void khr_snapshot_release(khr_snapshot* s) {
   if (!s) return;
+  if (s->copying) (void)hipEventSynchronize(s->ev_copied);  // (the arena must not be recycled under a copy in flight)
+  if (s->ev_packed) hipEventDestroy(s->ev_packed);
+  if (s->ev_copied) hipEventDestroy(s->ev_copied);
   // the arena may be handed to the next snapshot right away: that one's kernels are queued behind this one's on the same
   // stream.  After khr_destroy (the consumer kept an output longer than the window lived) the arena is simply freed.
   {
@@ -3926,6 +4014,34 @@ int64_t khr_download_mesh(khr_ctx* c, float* points, uint8_t* colors_rgba, uint3
 
 // one launch + one host wait: the device gathers index / flags / descriptors / vertex arrays into the pinned staging
 // buffer (k_mesh_gather), the host orders the blocks and hands out views of arrays it owns
+// first half of khr_fetch_mesh for a pipelined consumer: the gather of the CURRENT mesh into the pinned staging block is queued
+// behind the stream's work and nothing is awaited; the next khr_fetch_mesh only collects it.  Collect before the next
+// khr_generate_mesh (the vertex buffers flip there) and before any other call that uses the staging block.
+static int fetchMeshLaunch(khr_ctx* c) {
+  const MeshBuffers& mb = c->mesh[c->mesh_cur];
+  void* d_stage = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(&d_stage, c->h_stage, 0));
+  ++c->fetch_ticket;
+  if (c->fetch_ticket == 0) ++c->fetch_ticket;
+  static_cast<volatile uint32_t*>(c->h_stage)[15] = 0u;
+  hipLaunchKernelGGL(k_mesh_gather, dim3(256), dim3(256), 0, c->stream, c->m, mb, c->d_mesh_offset + c->m.capacity,
+                     static_cast<uint32_t*>(d_stage), static_cast<uint64_t>(c->h_stage_bytes / 4), c->d_fetch_done, c->fetch_ticket);
+  HIP_TRY(hipGetLastError());
+  HT("fetch_launched");
+  return KHR_OK;
+}
+
+int khr_fetch_mesh_launch(khr_ctx* c) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  HIP_TRY(hipSetDevice(c->device));
+  // (sized from the previous fetch: a mesh that has outgrown the block is fetched again, synchronously, by khr_fetch_mesh)
+  int rc = ensureStage(c, 1u << 20);
+  if (rc) return rc;
+  if ((rc = fetchMeshLaunch(c))) return rc;
+  c->fetch_pending = true;
+  return KHR_OK;
+}
+
 int64_t khr_fetch_mesh(khr_ctx* c, khr_mesh_view* out) {
   if (!c || !out) return fail(KHR_EINVAL, "null argument");
   *out = khr_mesh_view{};
@@ -3934,18 +4050,11 @@ int64_t khr_fetch_mesh(khr_ctx* c, khr_mesh_view* out) {
   HIP_TRY(hipSetDevice(c->device));
   int rc = ensureStage(c, 1u << 20);
   if (rc) return rc;
-  const MeshBuffers& mb = c->mesh[c->mesh_cur];
   const uint32_t* h = static_cast<const uint32_t*>(c->h_stage);
   for (int attempt = 0; attempt < 2; ++attempt) {
-    void* d_stage = nullptr;
-    HIP_TRY(hipHostGetDevicePointer(&d_stage, c->h_stage, 0));
-    ++c->fetch_ticket;
-    if (c->fetch_ticket == 0) ++c->fetch_ticket;
-    static_cast<volatile uint32_t*>(c->h_stage)[15] = 0u;
-    hipLaunchKernelGGL(k_mesh_gather, dim3(256), dim3(256), 0, c->stream, c->m, mb, c->d_mesh_offset + c->m.capacity,
-                       static_cast<uint32_t*>(d_stage), static_cast<uint64_t>(c->h_stage_bytes / 4), c->d_fetch_done, c->fetch_ticket);
-    HIP_TRY(hipGetLastError());
-    HT("fetch_launched");
+    const bool launched_before = attempt == 0 && c->fetch_pending;
+    c->fetch_pending = false;
+    if (!launched_before && (rc = fetchMeshLaunch(c))) return rc;
     if ((rc = waitWord(c, static_cast<volatile uint32_t*>(c->h_stage) + 15, c->fetch_ticket, "mesh gather"))) return rc;
     HT("fetch_arrived");
     if (h[2]) return fail(KHR_ENOMEM, "mesh needs %u vertices, max_mesh_vertices=%llu", h[0], static_cast<unsigned long long>(c->cfg.max_mesh_vertices));

@@ -130,3 +130,46 @@ def test_process_frame_snapshot_capacity_is_configurable():
         snap.release()
         ctx.close()
         ora.close()
+
+
+def test_snapshot_async_masked_download_equals_blocking_download():
+    """khr_snapshot_download_begin / _end (copy stream, ordered behind the pack kernel by an event) with the consumer's field mask
+    (distance + weight only) while later frames are being fused: same blocks, same values as the blocking download of all fields,
+    and the untouched fields' arrays stay untouched; the mesh of the output collected one frame later (khr_fetch_mesh_launch)
+    equals the mesh fetched at once"""
+    cfg, ctx, ora, s, sen, osen = make_pair(width=W, height=H, temporal_window=0.55)
+    nv = 4096
+    flags_out = ctx.PF_TRACKING | ctx.PF_OUTPUT | ctx.PF_SNAPSHOT
+    snap = mesh_now = None
+    for i in range(8):
+        fr = s.render(i)
+        f = ctx.make_frame(fr["stamp"], fr["pose"], fr["depth"].ctypes.data, fr["rgb"].ctypes.data, fr["label"].ctypes.data)
+        ctx.process_frame(sen, f, False, flags_out if i == 3 else ctx.PF_TRACKING)
+        if i == 3:
+            snap = ctx.take_snapshot()
+            assert snap is not None
+            ctx.fetch_mesh_launch()
+        if i == 4:  # one frame later: the gather ran right behind the output's kernels; this only collects
+            mesh_late = ctx.fetch_mesh()
+    n = snap.num_blocks()
+    assert n > 20 and snap.poll()
+    idx = np.full((n, 3), -7, np.int32)
+    dist = np.full((n, nv), np.nan, np.float32)
+    wgt = np.full((n, nv), np.nan, np.float32)
+    col = np.full((n, nv, 4), 77, np.uint8)
+    snap.download_begin([idx.ctypes.data, dist.ctypes.data, wgt.ctypes.data, 0, 0, 0, 0], n)
+    with pytest.raises(Exception):  # one transfer at a time per snapshot
+        snap.download()
+    fr = s.render(8)  # more work on the context's stream while the copy is in flight
+    ctx.process_frame(sen, ctx.make_frame(fr["stamp"], fr["pose"], fr["depth"].ctypes.data, fr["rgb"].ctypes.data, fr["label"].ctypes.data), False,
+                      ctx.PF_TRACKING)
+    assert snap.download_end() == n
+    full = snap.download()  # (sorted by block index)
+    order = np.lexsort((idx[:, 2], idx[:, 1], idx[:, 0]))
+    assert np.array_equal(idx[order], full["indices"])
+    assert np.array_equal(dist[order], full["distance"]) and np.array_equal(wgt[order], full["weight"])
+    assert (col == 77).all()
+    assert len(mesh_late["points"]) > 0
+    snap.release()
+    ctx.close()
+    ora.close()

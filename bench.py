@@ -749,6 +749,7 @@ def main():
                 "c3_output_copy_host": ["--config", "c3", "--output-copy", "host", "--cpu-baseline-frames", "0"],
                 "c3_output_copy_host_all_layers": ["--config", "c3", "--output-copy", "host", "--host-fields", "all", "--cpu-baseline-frames", "0"]}
         for name, extra_args in runs.items():
+            r = None
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra_args + common_args, capture_output=True, text=True,
                                    timeout=600)
@@ -762,7 +763,7 @@ def main():
                     keep["cpu_baseline"] = j["cpu_baseline"]
                 extra[name] = keep
             except Exception as e:  # noqa: BLE001
-                extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                extra[name] = {"error": "%s: %s" % (type(e).__name__, e), "stderr_tail": (r.stderr[-600:] if r is not None else None)}
         out["streams"] = extra
     if rank == 0:
         print(json.dumps(out))

@@ -257,6 +257,10 @@ int khr_detect_motion(khr_ctx* ctx, int slot);
  * key image; khr_detect_motion_from_keys then clusters and paints from it (identical on every rank). */
 int khr_motion_keys(khr_ctx* ctx, int slot, void* keys_out, int on_device, uint32_t* n_seed_pixels);
 int khr_detect_motion_from_keys(khr_ctx* ctx, int slot, const void* keys, int on_device);
+/* the motion detector's result of frame slot `src` (painted dynamic image, cluster list) also becomes that of `dst`: two slots
+ * holding the SAME camera frame (sharded tick with sender-side ingest: the rank's own converted frame, which the object half
+ * keeps in its buffer, and its adopted twin in the all-gather buffer, which the tick paints).  Stream-ordered. */
+int khr_mirror_dynamic(khr_ctx* ctx, int src_slot, int dst_slot);
 /* FrameData::dynamic_clusters of the frame last passed to khr_detect_motion / khr_process_frame.
  * Returns the number of clusters (writes min(n, cap)); synchronises. */
 int khr_get_dynamic_clusters(khr_ctx* ctx, int slot, khr_cluster* out, int cap);

@@ -84,7 +84,7 @@ EXPORTS = [
     "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",
     "khr_cluster_voxels", "khr_download_frame_image", "khr_detect_objects_launch", "khr_pool_exhausted", "khr_map_digest",
     "khr_rv_create", "khr_rv_destroy", "khr_rv_clear", "khr_rv_add_rays", "khr_rv_num_rays", "khr_rv_num_pairs", "khr_rv_check",
-    "khr_snapshot_updated", "khr_take_snapshot", "khr_snapshot_num_blocks", "khr_snapshot_download", "khr_snapshot_download_extra", "khr_snapshot_download_begin", "khr_snapshot_download_end", "khr_snapshot_poll", "khr_fetch_mesh_launch", "khr_snapshot_release",
+    "khr_snapshot_updated", "khr_take_snapshot", "khr_snapshot_num_blocks", "khr_snapshot_download", "khr_snapshot_download_extra", "khr_snapshot_download_begin", "khr_snapshot_download_end", "khr_snapshot_poll", "khr_fetch_mesh_launch", "khr_mirror_dynamic", "khr_snapshot_release",
     "khr_rv_check_stamps", "khr_get_config", "khr_cluster_voxels_launch", "khr_cluster_voxels_fetch", "khr_reset_map", "khr_depend_on", "khr_retain_slot", "khr_release_slot",
 ]
 

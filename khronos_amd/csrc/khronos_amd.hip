@@ -2549,6 +2549,25 @@ int khr_detect_motion_from_keys(khr_ctx* c, int slot, const void* keys, int on_d
   return motionFinish(c, s);
 }
 
+// The motion detector's result of frame slot `src` (painted dynamic image, cluster list) also becomes that of slot `dst`: two
+// slots that hold the SAME camera frame (sender-side ingest of the sharded tick: the rank's own converted frame, which the
+// object half keeps, and its adopted twin in the all-gather buffer, which the tick paints).  Stream-ordered device copy.
+int khr_mirror_dynamic(khr_ctx* c, int src, int dst) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  const int ns = static_cast<int>(c->slots.size());
+  if (src < 0 || dst < 0 || src >= ns || dst >= ns || !c->slots[src].valid || !c->slots[dst].valid) return fail(KHR_EINVAL, "bad slot");
+  if (src == dst) return KHR_OK;
+  FrameSlot& a = c->slots[src];
+  FrameSlot& b = c->slots[dst];
+  if (a.sensor.width != b.sensor.width || a.sensor.height != b.sensor.height) return fail(KHR_EINVAL, "the slots hold frames of different sizes");
+  HIP_TRY(hipSetDevice(c->device));
+  if (!(a.dyn_clean && b.dyn_clean))
+    HIP_TRY(hipMemcpyAsync(b.dyn, a.dyn, sizeof(int32_t) * static_cast<size_t>(a.sensor.width) * a.sensor.height, hipMemcpyDeviceToDevice, c->stream));
+  b.dyn_clean = a.dyn_clean;
+  b.clusters = a.clusters;
+  return KHR_OK;
+}
+
 int khr_get_dynamic_clusters(khr_ctx* c, int slot, khr_cluster* out, int cap) {
   if (!c || cap < 0 || (!out && cap > 0)) return fail(KHR_EINVAL, "bad argument");
   if (slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad slot");

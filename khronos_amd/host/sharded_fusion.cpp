@@ -539,6 +539,9 @@ int tickImpl(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, in
         }
       }
     }
+    // sender-side ingest: the tick painted the adopted twin of this rank's camera (slots_out[rank]); the slot the object half
+    // keeps (*own_slot_out) gets the same dynamic image and cluster list, or the tracker would see a frame without motion
+    if (own_slot_out && h->motion) KD_KHR(khr_mirror_dynamic(c, slots_out[h->rank], *own_slot_out));
     // (4) update of every camera, tracking pass
     khr_host_trace("kd_motion_done");
     KD_KHR(khr_tick_integrate(c, slots_out, n, h->motion ? 1 : 0, -1, split ? 2 : 3));

@@ -248,3 +248,15 @@ def test_synth_is_deterministic_and_labelled():
     assert np.array_equal(a["depth"], b["depth"]) and np.array_equal(a["label"], b["label"])
     assert a["depth"].max() <= 5.0 and a["label"].min() >= 1
     assert s1.stamp_ns(10) - s1.stamp_ns(0) == 10**9
+
+
+def test_ref_recipe_compiles():
+    """oracle/ref_recipe: the harness that would pin the oracle against upstream Hydra (it cannot run here: no checkouts) at least
+    compiles against the stand-in declarations of the upstream API it uses (each justified by a line of the reference)"""
+    import subprocess
+    r = subprocess.run(["bash", os.path.join(ROOT, "oracle", "ref_recipe", "build.sh"), "--check"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # and the real build refuses to start without the checkouts, naming what is missing
+    env = {k: v for k, v in os.environ.items() if not k.endswith("_ROOT")}
+    r = subprocess.run(["bash", os.path.join(ROOT, "oracle", "ref_recipe", "build.sh")], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode != 0 and "HYDRA_ROOT" in r.stderr

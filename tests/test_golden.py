@@ -8,7 +8,28 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-G = np.load(os.path.join(ROOT, "tests", "golden", "aw_small.npz"))
+# vectors made by UPSTREAM code (oracle/ref_recipe/build.sh on a machine with Hydra / Spatial-Hash checkouts) take precedence
+# over the oracle-generated regression pin: with them the chain reads HIP == oracle == Hydra
+REF_PATH = os.path.join(ROOT, "oracle", "_ref", "ref_small.npz")
+UPSTREAM = os.path.exists(REF_PATH)
+G = np.load(REF_PATH if UPSTREAM else os.path.join(ROOT, "tests", "golden", "aw_small.npz"))
+# our own fixture is compared bit for bit; upstream floats within the tolerance BASELINE.json states (indices, labels, flags, stamps exact)
+FLOAT_KEYS = ("distance", "weight", "mesh_checksum")
+
+
+def _same(key, got, want):
+    if UPSTREAM and key in FLOAT_KEYS:
+        return np.allclose(np.asarray(got, np.float64), np.asarray(want, np.float64), rtol=1e-4 if key != "distance" else 0, atol=1e-4)
+    if UPSTREAM and key == "color":
+        return np.abs(np.asarray(got).astype(int) - np.asarray(want).astype(int)).max() <= 1
+    return np.array_equal(np.asarray(got), np.asarray(want))
+
+
+def test_upstream_vectors_present():
+    if not UPSTREAM:
+        pytest.skip("no upstream vectors: oracle/_ref/ref_small.npz is made by oracle/ref_recipe/build.sh from Hydra / Spatial-Hash "
+                    "checkouts, which are not on this machine -- parity stays 'HIP == our CPU restatement' (unpinned)")
+    assert "upstream" in str(G["provenance"])
 
 
 def _stream():
@@ -27,7 +48,7 @@ def test_oracle_reproduces_golden():
     out = make_golden.run()
     for k in ("block_indices", "distance", "weight", "flags", "sem_label", "last_observed", "color", "n_clusters",
               "dyn_pixels", "removed_counts", "mesh_vertices", "mesh_checksum"):
-        assert np.array_equal(np.asarray(out[k]), G[k]), k
+        assert _same(k, out[k], G[k]), k
 
 
 @pytest.mark.gpu
@@ -55,12 +76,12 @@ def test_hip_reproduces_golden():
     assert np.array_equal(idx, G["block_indices"])
     for j, b in enumerate(idx):
         blk = ctx.download_block(b, likelihoods=False)
-        assert np.array_equal(blk["distance"], G["distance"][j]), b
-        assert np.array_equal(blk["weight"], G["weight"][j]), b
+        assert _same("distance", blk["distance"], G["distance"][j]), b
+        assert _same("weight", blk["weight"], G["weight"][j]), b
         assert np.array_equal(blk["flags"], G["flags"][j]), b
         assert np.array_equal(blk["sem_label"].astype(np.uint8), G["sem_label"][j]), b
         assert np.array_equal(blk["last_observed"], G["last_observed"][j]), b
-        assert np.array_equal(blk["color"], G["color"][j]), b
+        assert _same("color", blk["color"], G["color"][j]), b
     mesh = ctx.download_mesh()
     assert len(mesh["points"]) == int(G["mesh_vertices"])
     assert float(mesh["points"].astype(np.float64).sum()) == pytest.approx(float(G["mesh_checksum"]), rel=1e-12)

@@ -483,7 +483,7 @@ def main():
         ctx.timing_reset()
         # default: only the two update kernels carry HIP events (each timed launch costs host time);
         # --all-timers adds the per-kernel breakdown
-        ctx.timing_enable(True, None if args.all_timers else ("tsdf",))  # HIP events cost a barrier packet each: only the roofline kernel
+        ctx.timing_enable(True, None if args.all_timers else ("tsdf", "band"))  # HIP events cost a barrier packet each: only the roofline kernel
     if fusion_cxx is not None and not emu:
         fusion_cxx.profile(False)  # (reset: calls / bytes of the timed steps are counted, nothing is timed)
     _trace(_tags["timed_begin"])
@@ -642,7 +642,11 @@ def main():
     # ---- roofline of the dominant kernel (k_fuse: the fused TSDF / colour / label update), from HIP events on the
     #      kernel's own dispatch packets (hipExtLaunchKernelGGL start / stop events on the kernel's stream) ----
     if not args.no_roofline_timers and rank == 0:
-        ms, launches = ctx.timing_get("tsdf")
+        # the update step = k_fuse (voxel phase; also the band phase when KHR_FUSE_SPLIT=0) + k_band (round 4: the in-band voxels'
+        # colour / label / likelihood update as its own launch): both launches count, the algorithmic bytes are those of the step
+        ms_fuse, launches = ctx.timing_get("tsdf")
+        ms_band, launches_band = ctx.timing_get("band")
+        ms = ms_fuse + ms_band
         nl = max(1, launches)
         # ALGORITHMIC bytes of the TSDF-update kernel, SURVEY.md section 8(d):
         #   24 B per updated voxel (R+W distance, R+W weight, W last_observed)
@@ -661,7 +665,9 @@ def main():
                     traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, %s; NOT measured in this run)" % tj.get("collected", "?")
             except Exception:
                 traffic = None
-        out["roofline"] = {"kernel": "k_fuse", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
+        out["roofline"] = {"kernel": "k_fuse + k_band (the TSDF / colour / label update step)" if launches_band else "k_fuse", "bound": "hbm",
+                           "achieved": achieved, "peak": 8000.0, "k_fuse_avg_us": 1e3 * ms_fuse / nl,
+                           "k_band_avg_us": (1e3 * ms_band / max(1, launches_band)) if launches_band else None,
                            "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                            "avg_launch_us": 1e3 * ms / nl, "launches": launches,
                            "algorithmic_bytes_per_launch": bytes_total / nl,
@@ -670,7 +676,7 @@ def main():
         # Mvoxel-updates/s = N_upd / sum of the TSDF-update step's time (the whole-frame figure is above)
         out["mvoxel_updates_per_s_tsdf_step"] = 1e-6 * n_upd / (ms * 1e-3) if ms > 0 else None
         kern = {}
-        for name in ("tsdf", "tracking", "ever_free", "alloc", "motion_pixels", "mesh", "parse"):
+        for name in ("tsdf", "band", "tracking", "ever_free", "alloc", "motion_pixels", "mesh", "parse"):
             m_, n_ = ctx.timing_get(name)
             kern["fuse" if name == "tsdf" else name] = {"ms_total": m_, "launches": n_}
         out["kernel_ms"] = kern

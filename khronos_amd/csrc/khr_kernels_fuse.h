@@ -121,6 +121,17 @@ struct FuseArgs : FuseFrame {
   // and does nothing when *gate != 0 (seeds exist: the host then queues the clustering chain and the real launch).  Frames
   // without seeds -- most of them -- no longer idle the main stream for the seed count's trip to the host and back.
   const uint32_t* gate;
+  // split band phase (round 4; k_fuse + k_band): when band_rec != nullptr the in-band records of an item are written to the
+  // workgroup's region of a record list in HBM instead of being worked off by the wave that found them; k_band, the next
+  // launch on the stream, works them off with every wave of the chip and no wave waiting on another's voxel phase.
+  // Region of workgroup b = band_chunks chunks of kBandChunk records, handed to its waves one chunk at a time (LDS cursor);
+  // chunk c holds its records field-major: word f of record r at band_rec[(c * 6 + f) * kBandChunk + r], f = 0 voxel | mode,
+  // 1 measurement weight, 2 voxel weight after the update, 3 u, 4 v, 5 pool slot.  band_cnt[c] = records in chunk c,
+  // band_nch[b] = chunks workgroup b used.  A workgroup that runs out of chunks falls back to the in-kernel band phase.
+  uint32_t* band_rec;
+  uint32_t* band_cnt;
+  uint32_t* band_nch;
+  int band_chunks;
   // k_fuse2<.., MULTI>: the frames an item is walked through, in order
   const FuseFrame* frames;
   int n_frames;
@@ -130,6 +141,8 @@ struct FuseArgs : FuseFrame {
 };
 
 constexpr int kFuseCap = 256;        // in-band records a wave collects before it works them off (one 4-z chunk of a patch)
+constexpr int kBandChunk = 1024;     // records per chunk of the split band phase's record list (a wave owns its current chunk)
+constexpr int kBandFields = 6;
 
 // colour / label / likelihood update of one in-band voxel (the body of updateVoxel for |sdf| < truncation)
 // `a` points into the kernel-argument segment: the fields only this phase needs (image / layer pointers, label
@@ -463,6 +476,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
   __shared__ uint32_t s_rec[WPW][5][kFuseCap];
   __shared__ uint32_t s_stat[WPW][2];
   __shared__ uint32_t s_q;  // the workgroup's item queue: next index into its share of the descriptor list
+  __shared__ uint32_t s_nch;  // split band phase: chunks of this workgroup's record region handed out so far
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int lane = static_cast<int>(threadIdx.x & 63);
   const int range_mode = DEFCFG ? 0 : a.range_mode;
@@ -470,6 +484,9 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
   const bool use_dropoff = DEFCFG ? true : (a.use_dropoff != 0);
   const bool const_weight = DEFCFG ? false : (a.const_weight != 0);
   const float Wm1 = static_cast<float>(a.W - 1), Hm1 = static_cast<float>(a.H - 1);
+  // split band phase: the wave's current chunk (wave-uniform; 0xffffffff = none yet) and its fill
+  const bool split = a.band_rec != nullptr;
+  uint32_t w_chunk = 0xffffffffu, w_fill = 0u;
   const float fxfy = a.fx * a.fy;
   const float den = a.trunc - a.dropoff_eps;  // weight drop-off denominator (uniform)
   const float yden = rcpRefined(den);
@@ -479,7 +496,10 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
   uint32_t n_upd = 0, n_band = 0;
   const int dbg = DBG ? a.dbg : 0;
   if (a.gate != nullptr && *a.gate != 0u) return;  // speculative launch, and the frame has motion seeds (workgroup-uniform)
-  if (threadIdx.x == 0) s_q = 0u;
+  if (threadIdx.x == 0) {
+    s_q = 0u;
+    s_nch = 0u;
+  }
   __syncthreads();
   // next item of this workgroup's share (positions blockIdx.x, blockIdx.x + gridDim.x, ...: every workgroup gets the same
   // mix of the cost classes), handed to whichever of its waves asks first; wave-uniform result
@@ -592,6 +612,22 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
     char* const wgt_b = reinterpret_cast<char*>(a.weight + slot * NV);
     char* const lobs_b = reinterpret_cast<char*>(a.last_obs + slot * NV);
     uint32_t cnt = 0;       // records in this wave's LDS list
+    // split band phase: the item's records (at most 64 ZR) go to the wave's chunk of the record list; a full chunk is
+    // published and the next one taken from the workgroup's region.  No chunk left: this item keeps the in-kernel path.
+    uint32_t* g_rec = nullptr;
+    if (split) {
+      if (w_chunk == 0xffffffffu || w_fill + 64u * ZR > static_cast<uint32_t>(kBandChunk)) {
+        const uint32_t region0 = blockIdx.x * static_cast<uint32_t>(a.band_chunks);
+        if (w_chunk != 0xffffffffu && lane == 0) a.band_cnt[region0 + w_chunk] = w_fill;
+        uint32_t j = 0u;
+        if (lane == 0) j = atomicAdd(&s_nch, 1u);
+        j = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(j)));
+        w_chunk = j < static_cast<uint32_t>(a.band_chunks) ? j : 0xffffffffu;
+        w_fill = 0u;
+      }
+      if (w_chunk != 0xffffffffu)
+        g_rec = a.band_rec + (static_cast<size_t>(blockIdx.x) * a.band_chunks + w_chunk) * (kBandFields * kBandChunk) + w_fill;
+    }
     bool touched = false;   // wave-uniform: some voxel of this item was updated
     bool wrote_neg = false; // wave-uniform: some updated voxel now holds a negative distance
 #pragma unroll
@@ -698,17 +734,31 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
         if (in_band) {
           const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m_band >> 32),
                                                               __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m_band), 0u));
-          uint32_t* const rec = &s_rec[wave][0][pos];
-          rec[0] = lin | (use_nearest ? 0x10000u : 0u);
-          rec[kFuseCap] = __float_as_uint(w);
-          rec[2 * kFuseCap] = __float_as_uint(w_new);
-          rec[3 * kFuseCap] = __float_as_uint(uc);
-          rec[4 * kFuseCap] = __float_as_uint(vc);
+          if (g_rec != nullptr) {
+            uint32_t* const rec = g_rec + pos;
+            rec[0] = lin | (use_nearest ? 0x10000u : 0u);
+            rec[kBandChunk] = __float_as_uint(w);
+            rec[2 * kBandChunk] = __float_as_uint(w_new);
+            rec[3 * kBandChunk] = __float_as_uint(uc);
+            rec[4 * kBandChunk] = __float_as_uint(vc);
+            rec[5 * kBandChunk] = static_cast<uint32_t>(slot);
+          } else {
+            uint32_t* const rec = &s_rec[wave][0][pos];
+            rec[0] = lin | (use_nearest ? 0x10000u : 0u);
+            rec[kFuseCap] = __float_as_uint(w);
+            rec[2 * kFuseCap] = __float_as_uint(w_new);
+            rec[3 * kFuseCap] = __float_as_uint(uc);
+            rec[4 * kFuseCap] = __float_as_uint(vc);
+          }
         }
         cnt += static_cast<uint32_t>(__popcll(m_band));
       }
     }
-    const uint32_t item_band = cnt;  // isa:band phase driver
+    const uint32_t item_band = cnt;
+    if (g_rec != nullptr) {  // the records are in the list: k_band works them off
+      w_fill += cnt;
+      cnt = 0u;
+    }  // isa:band phase driver
     // ---- the item's in-band voxels, densely (lane <-> record).  A cold block: the hint keeps the register allocator
     //      from favouring its values over the voxel loop's ----
     if (DBG && (dbg & 1)) cnt = 0u;
@@ -764,8 +814,10 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
   if (lane == 0) {
     s_stat[wave][0] = n_upd;
     s_stat[wave][1] = n_band;
+    if (split && w_chunk != 0xffffffffu) a.band_cnt[blockIdx.x * static_cast<uint32_t>(a.band_chunks) + w_chunk] = w_fill;
   }
   __syncthreads();
+  if (split && threadIdx.x == 0) a.band_nch[blockIdx.x] = min(s_nch, static_cast<uint32_t>(a.band_chunks));
   if (threadIdx.x == 0) {
     uint32_t su = 0u, sb = 0u;
 #pragma unroll
@@ -776,6 +828,50 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
     if (su | sb) {
       a.wg_stats[2 * blockIdx.x] += su;
       a.wg_stats[2 * blockIdx.x + 1] += sb;
+    }
+  }
+}
+
+// ====================================================================================================================
+// k_band (round 4): the colour / label / likelihood update of the in-band voxels k_fuse (split form) left in the record list.
+// In the fused form a wave worked off its own item's records in passes of 64, each pass one or two exposed memory round
+// trips, the passes of a fat item serialised in one wave while the other waves of the workgroup ran out of work (the
+// in-kernel timeline: 16 of a wave's 46 us, the slowest workgroup 58 us against a mean of 46 -- its share of band passes).
+// Here the passes of workgroup b's region are dealt to the T = S x 4 waves of S small workgroups, every pass is independent,
+// and all of them are resident at once: the band work of the frame is a handful of memory round trips deep instead of ~20.
+// Same arithmetic, same operand order as fuseBandRecord: results are bit-identical.
+// ====================================================================================================================
+template <int VPS>
+__global__ __launch_bounds__(256) void k_band(FuseArgs a, int S) {
+  if (a.gate != nullptr && *a.gate != 0u) return;  // the speculative update did not run either
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int lane = static_cast<int>(threadIdx.x & 63);
+  const uint32_t b = blockIdx.x / static_cast<uint32_t>(S);
+  const uint32_t t = (blockIdx.x % static_cast<uint32_t>(S)) * 4u + static_cast<uint32_t>(wave), T = static_cast<uint32_t>(S) * 4u;
+  const uint32_t n_ch = a.band_nch[b];
+  if (n_ch == 0u) return;
+  const uint32_t region0 = b * static_cast<uint32_t>(a.band_chunks);
+  // passes per chunk (lane <-> chunk; a region has at most 64 chunks), inclusive prefix over the lanes
+  const uint32_t cnt_j = static_cast<uint32_t>(lane) < n_ch ? a.band_cnt[region0 + static_cast<uint32_t>(lane)] : 0u;
+  const uint32_t pas_j = (cnt_j + 63u) >> 6;
+  uint32_t incl = pas_j;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = static_cast<uint32_t>(__shfl_up(static_cast<int>(incl), d));
+    if (lane >= d) incl += o;
+  }
+  const uint32_t P = static_cast<uint32_t>(__shfl(static_cast<int>(incl), 63));
+  FuseArgsK ka = (FuseArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+  const FuseFrameK kf = (FuseFrameK)ka;
+  for (uint32_t p = t; p < P; p += T) {
+    const int j = __popcll(__builtin_amdgcn_ballot_w64(incl <= p));  // the chunk pass p falls into
+    const uint32_t first = static_cast<uint32_t>(__shfl(static_cast<int>(incl - pas_j), j));
+    const uint32_t count = static_cast<uint32_t>(__shfl(static_cast<int>(cnt_j), j));
+    const uint32_t r = (p - first) * 64u + static_cast<uint32_t>(lane);
+    if (r < count) {
+      const uint32_t* const rec = a.band_rec + static_cast<size_t>(region0 + static_cast<uint32_t>(j)) * (kBandFields * kBandChunk) + r;
+      fuseBandRecord<VPS>(ka, kf, static_cast<size_t>(rec[5 * kBandChunk]), rec[0], __uint_as_float(rec[kBandChunk]),
+                          __uint_as_float(rec[2 * kBandChunk]), __uint_as_float(rec[3 * kBandChunk]), __uint_as_float(rec[4 * kBandChunk]));
     }
   }
 }

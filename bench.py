@@ -429,6 +429,7 @@ def main():
     host_inflight = []        # [(snapshot, buffer set)] whose download has begun
     host_pending = [None]     # snapshot whose block count was not known yet when it was taken
     host_mesh_pending = [False]
+    host_mesh_bufs = {}
     host_next_buf = [0]
 
     def host_consumer_begin():
@@ -450,8 +451,8 @@ def main():
 
     def host_consumer_poll():
         if host_mesh_pending[0]:  # the previous output's mesh: its gather ran right behind that output's kernels
-            mesh = ctx.fetch_mesh()
-            copy_stats[1] += sum(int(v.nbytes) for v in mesh.values())
+            nv_ = ctx.fetch_mesh_reuse(host_mesh_bufs)  # (the consumer's own arrays, reused from output to output)
+            copy_stats[1] += nv_ * (12 + 4 + 4 + 8 + 8)
             host_mesh_pending[0] = False
         if host_pending[0] is not None and host_pending[0].poll() and len(host_inflight) < 2:
             host_consumer_begin()

@@ -675,6 +675,22 @@ class FusionContext:
             self._chk(self.lib.khr_fetch_mesh_into(self.h, _ptr(pts), _ptr(col), _ptr(lab), _ptr(fs), _ptr(st)))
         return {"points": pts, "colors": col, "labels": lab, "first_seen": fs, "stamps": st}
 
+    def fetch_mesh_reuse(self, bufs):
+        """fetch_mesh() into arrays the caller keeps (a consumer that takes one mesh per output must not pay page faults on 20 MB of
+        fresh arrays every time): `bufs` = dict, grown when the mesh outgrows it -> vertex count"""
+        v = C.c_int64(0)
+        n = self._chk(self.lib.khr_fetch_mesh(self.h, C.byref(v)))
+        if n > bufs.get("cap", 0):
+            cap = int(n * 1.5) + 1024
+            bufs.update(cap=cap, points=np.empty((cap, 3), np.float32), colors=np.empty((cap, 4), np.uint8), labels=np.empty(cap, np.uint32),
+                        first_seen=np.empty(cap, np.uint64), stamps=np.empty(cap, np.uint64))
+            for k in ("points", "colors", "labels", "first_seen", "stamps"):
+                bufs[k].fill(0)  # touch the pages now
+        if n:
+            self._chk(self.lib.khr_fetch_mesh_into(self.h, _ptr(bufs["points"]), _ptr(bufs["colors"]), _ptr(bufs["labels"]), _ptr(bufs["first_seen"]),
+                                                   _ptr(bufs["stamps"])))
+        return n
+
     def timing_enable(self, on=True, names=None):
         """on=True: all timers, or only those in `names`."""
         mask = 0

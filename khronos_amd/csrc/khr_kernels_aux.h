@@ -1383,6 +1383,15 @@ __global__ __launch_bounds__(256) void k_snapshot_select(DevMap m, uint32_t* __r
     index[pos] = m.blk_index[s];
   }
 }
+__global__ __launch_bounds__(256) void k_snapshot_index3(const int4* __restrict__ index, int32_t* __restrict__ out3, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const int4 v = index[i];
+    out3[3 * i] = v.x;
+    out3[3 * i + 1] = v.y;
+    out3[3 * i + 2] = v.z;
+  }
+}
 template <int VPS>
 __global__ __launch_bounds__(256) void k_snapshot_pack(DevMap m, const uint32_t* __restrict__ count, const uint32_t* __restrict__ slots,
                                                       uint32_t cap, PackOut o, volatile uint32_t* host_count, uint32_t ticket) {

@@ -125,7 +125,7 @@ struct FuseArgs : FuseFrame {
   // workgroup's region of a record list in HBM instead of being worked off by the wave that found them; k_band, the next
   // launch on the stream, works them off with every wave of the chip and no wave waiting on another's voxel phase.
   // Region of workgroup b = band_chunks chunks of kBandChunk records, handed to its waves one chunk at a time (LDS cursor);
-  // chunk c holds its records field-major: word f of record r at band_rec[(c * 6 + f) * kBandChunk + r], f = 0 voxel | mode,
+  // chunk c holds its records as 24-byte structs: record r at band_rec[(c * kBandChunk + r) * 6], words 0 voxel | mode,
   // 1 measurement weight, 2 voxel weight after the update, 3 u, 4 v, 5 pool slot.  band_cnt[c] = records in chunk c,
   // band_nch[b] = chunks workgroup b used.  A workgroup that runs out of chunks falls back to the in-kernel band phase.
   uint32_t* band_rec;
@@ -142,7 +142,9 @@ struct FuseArgs : FuseFrame {
 
 constexpr int kFuseCap = 256;        // in-band records a wave collects before it works them off (one 4-z chunk of a patch)
 constexpr int kBandChunk = 1024;     // records per chunk of the split band phase's record list (a wave owns its current chunk)
-constexpr int kBandFields = 6;
+constexpr int kBandFields = 6;       // words per record: voxel | mode, measurement weight, voxel weight after the update, u, v, pool slot
+typedef uint32_t rec4u __attribute__((ext_vector_type(4), aligned(8)));
+typedef uint32_t rec2u __attribute__((ext_vector_type(2), aligned(8)));
 
 // colour / label / likelihood update of one in-band voxel (the body of updateVoxel for |sdf| < truncation)
 // `a` points into the kernel-argument segment: the fields only this phase needs (image / layer pointers, label
@@ -172,26 +174,34 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, FuseFrameK kf, size_t slot, 
   interpPixels(u, v, f.W, f.H, px4, &du, &dv);
   const int best = interpWeights(du, dv, use_nearest, w4);
   const uint32_t best_o = static_cast<uint32_t>(px4[best]) * 4u;
+  // development ablations of the band update (DBG instantiations only; env KHR_FUSE_DBG): 1024 no image gathers, 2048 no
+  // likelihood loads, 4096 no likelihood stores, 8192 no colour / flag / label stores, 16384 no colour / flag loads
+  const int bdbg = DBG ? a.dbg : 0;
   // ---- every load of the record is issued here, before the first store: a memory round trip costs 1.5 - 2 us under
   //      this kernel's load and vmcnt retires in order, so each load placed behind a store waits for that store too ----
   uint32_t c4[4] = {0u, 0u, 0u, 0u}, co = 0u;
   if (has_color) {
     const char* const rgba_b = reinterpret_cast<const char*>(f.rgba);
+    if (!(bdbg & 1024)) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) c4[k] = *reinterpret_cast<const uint32_t*>(rgba_b + static_cast<uint32_t>(px4[k]) * 4u);
-    co = *reinterpret_cast<const uint32_t*>(color_b + lin * 4u);
+      for (int k = 0; k < 4; ++k) c4[k] = *reinterpret_cast<const uint32_t*>(rgba_b + static_cast<uint32_t>(px4[k]) * 4u);
+    }
+    if (!(bdbg & 16384)) co = *reinterpret_cast<const uint32_t*>(color_b + lin * 4u);
   }
   int label = -1;
   uint8_t fl = 0;
   float4 l4[kLikVec];
   if (do_sem) {
-    label = (a.sem_mode == 1) ? ((*reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(f.obj) + best_o) == f.object_id) ? 1 : 0)
-                              : *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(f.label) + best_o);
-    fl = *reinterpret_cast<const uint8_t*>(vfl_b + lin);
+    if (bdbg & 1024) label = static_cast<int>(lin % 19u);
+    else
+      label = (a.sem_mode == 1) ? ((*reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(f.obj) + best_o) == f.object_id) ? 1 : 0)
+                                : *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(f.label) + best_o);
+    if (!(bdbg & 16384)) fl = *reinterpret_cast<const uint8_t*>(vfl_b + lin);
     if (vec) {  // a voxel without VOX_SEM_VALID holds no likelihoods yet: what is loaded is replaced by zeros below
 #pragma unroll
       for (int j = 0; j < kLikVec; ++j)
-        l4[j] = (j < K / 4) ? *reinterpret_cast<const float4*>(lik_b + lik_o + static_cast<uint32_t>(j) * 16u) : make_float4(0.f, 0.f, 0.f, 0.f);
+        l4[j] = (j < K / 4 && !(bdbg & 2048)) ? *reinterpret_cast<const float4*>(lik_b + lik_o + static_cast<uint32_t>(j) * 16u)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   if (has_color) {
@@ -212,7 +222,7 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, FuseFrameK kf, size_t slot, 
       const float cv = static_cast<float>((co >> (8 * ch)) & 0xffu);
       out |= static_cast<uint32_t>(toU8(divExact(cv * w_new + cn * w, tot, ytot))) << (8 * ch);
     }
-    *reinterpret_cast<uint32_t*>(color_b + lin * 4u) = out;
+    if (!(bdbg & 8192)) *reinterpret_cast<uint32_t*>(color_b + lin * 4u) = out;
   }
   if (!do_sem || label < 0 || label >= K) return;
   const bool empty = !(fl & VOX_SEM_VALID);
@@ -241,7 +251,7 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, FuseFrameK kf, size_t slot, 
             bestk = k;
           }
         }
-        *reinterpret_cast<float4*>(lik_b + lik_o + static_cast<uint32_t>(j0 + j) * 16u) = make_float4(l[0], l[1], l[2], l[3]);
+        if (!(bdbg & 4096)) *reinterpret_cast<float4*>(lik_b + lik_o + static_cast<uint32_t>(j0 + j) * 16u) = make_float4(l[0], l[1], l[2], l[3]);
       }
     }
   } else {
@@ -264,6 +274,7 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, FuseFrameK kf, size_t slot, 
       }
     }
   }
+  if (bdbg & 8192) return;
   if (empty) *reinterpret_cast<uint8_t*>(vfl_b + lin) = fl | VOX_SEM_VALID;
   *reinterpret_cast<uint32_t*>(lab_b + lin * 4u) = static_cast<uint32_t>(bestk);
 }
@@ -626,7 +637,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
         w_fill = 0u;
       }
       if (w_chunk != 0xffffffffu)
-        g_rec = a.band_rec + (static_cast<size_t>(blockIdx.x) * a.band_chunks + w_chunk) * (kBandFields * kBandChunk) + w_fill;
+        g_rec = a.band_rec + (static_cast<size_t>(blockIdx.x) * a.band_chunks + w_chunk) * (kBandFields * kBandChunk) + w_fill * kBandFields;
     }
     bool touched = false;   // wave-uniform: some voxel of this item was updated
     bool wrote_neg = false; // wave-uniform: some updated voxel now holds a negative distance
@@ -734,14 +745,10 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
         if (in_band) {
           const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m_band >> 32),
                                                               __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m_band), 0u));
-          if (g_rec != nullptr) {
-            uint32_t* const rec = g_rec + pos;
-            rec[0] = lin | (use_nearest ? 0x10000u : 0u);
-            rec[kBandChunk] = __float_as_uint(w);
-            rec[2 * kBandChunk] = __float_as_uint(w_new);
-            rec[3 * kBandChunk] = __float_as_uint(uc);
-            rec[4 * kBandChunk] = __float_as_uint(vc);
-            rec[5 * kBandChunk] = static_cast<uint32_t>(slot);
+          if (g_rec != nullptr) {  // one 24-byte record: a 16-byte and an 8-byte store (8-byte aligned)
+            uint32_t* const rec = g_rec + pos * kBandFields;
+            *reinterpret_cast<rec4u*>(rec) = rec4u{lin | (use_nearest ? 0x10000u : 0u), __float_as_uint(w), __float_as_uint(w_new), __float_as_uint(uc)};
+            *reinterpret_cast<rec2u*>(rec + 4) = rec2u{__float_as_uint(vc), static_cast<uint32_t>(slot)};
           } else {
             uint32_t* const rec = &s_rec[wave][0][pos];
             rec[0] = lin | (use_nearest ? 0x10000u : 0u);
@@ -841,7 +848,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
 // and all of them are resident at once: the band work of the frame is a handful of memory round trips deep instead of ~20.
 // Same arithmetic, same operand order as fuseBandRecord: results are bit-identical.
 // ====================================================================================================================
-template <int VPS>
+template <int VPS, bool DBG = false>
 __global__ __launch_bounds__(256) void k_band(FuseArgs a, int S) {
   if (a.gate != nullptr && *a.gate != 0u) return;  // the speculative update did not run either
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
@@ -869,9 +876,11 @@ __global__ __launch_bounds__(256) void k_band(FuseArgs a, int S) {
     const uint32_t count = static_cast<uint32_t>(__shfl(static_cast<int>(cnt_j), j));
     const uint32_t r = (p - first) * 64u + static_cast<uint32_t>(lane);
     if (r < count) {
-      const uint32_t* const rec = a.band_rec + static_cast<size_t>(region0 + static_cast<uint32_t>(j)) * (kBandFields * kBandChunk) + r;
-      fuseBandRecord<VPS>(ka, kf, static_cast<size_t>(rec[5 * kBandChunk]), rec[0], __uint_as_float(rec[kBandChunk]),
-                          __uint_as_float(rec[2 * kBandChunk]), __uint_as_float(rec[3 * kBandChunk]), __uint_as_float(rec[4 * kBandChunk]));
+      const uint32_t* const rec = a.band_rec + static_cast<size_t>(region0 + static_cast<uint32_t>(j)) * (kBandFields * kBandChunk) + r * kBandFields;
+      const rec4u ra = *reinterpret_cast<const rec4u*>(rec);
+      const rec2u rb = *reinterpret_cast<const rec2u*>(rec + 4);
+      fuseBandRecord<VPS, DBG>(ka, kf, static_cast<size_t>(rb.y), ra.x, __uint_as_float(ra.y), __uint_as_float(ra.z), __uint_as_float(ra.w),
+                               __uint_as_float(rb.x));
     }
   }
 }

@@ -530,7 +530,7 @@ constexpr int kMaxMultiFrames = 1024;
 int kFuseSpec = 1;      // env KHR_FUSE_SPECULATIVE: khr_process_frame queues k_fuse before the seed count has reached the host (gated on the device)
 int kFuseSplit = 1;     // env KHR_FUSE_SPLIT: the window's update as k_fuse (voxel phase, in-band records to a list in HBM) + k_band (round 4); 0 = fused band phase
 constexpr int kBandChunksPerWg = 32;  // chunks of kBandChunk records in a workgroup's region of that list (<= 64)
-constexpr int kBandTeams = 4;         // k_band workgroups (4 waves each) per k_fuse workgroup
+int kBandTeams = 4;                   // k_band workgroups (4 waves each) per k_fuse workgroup; env KHR_BAND_TEAMS
 int kFuseBand = 0;      // env KHR_FUSE_BAND: 0 = lane <-> record (default), 1 = record-cooperative band phase (fuseBandCoop: -41 % L2 write requests, -16 % L1 accesses, same time at 720p / 2 cm, slower on small frames)
 constexpr int kStreamGrid = 4096;
 
@@ -804,6 +804,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   if (std::getenv("KHR_FUSE_DBG")) kFuseDbg = std::atoi(std::getenv("KHR_FUSE_DBG"));
   if (std::getenv("KHR_FUSE_BAND")) kFuseBand = std::atoi(std::getenv("KHR_FUSE_BAND"));
   if (std::getenv("KHR_FUSE_SPLIT")) kFuseSplit = std::atoi(std::getenv("KHR_FUSE_SPLIT"));
+  if (std::getenv("KHR_BAND_TEAMS")) kBandTeams = std::max(1, std::min(16, std::atoi(std::getenv("KHR_BAND_TEAMS"))));
   if (std::getenv("KHR_FUSE_SPECULATIVE")) kFuseSpec = std::atoi(std::getenv("KHR_FUSE_SPECULATIVE"));
   if (std::getenv("KHR_TICK_UNION")) kTickUnion = std::atoi(std::getenv("KHR_TICK_UNION"));
   if (std::getenv("KHR_FUSE_MULTI")) kFuseMulti = std::atoi(std::getenv("KHR_FUSE_MULTI"));
@@ -1420,7 +1421,8 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
         KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(64 * wpw), a, list);
         if (a.band_rec != nullptr) {
           const int S = kBandTeams;
-          KHR_LAUNCH_TIMED(7, (k_band<16>), dim3(grid * S), dim3(256), a, S);
+          if (kFuseDbg) KHR_LAUNCH_TIMED(7, (k_band<16, true>), dim3(grid * S), dim3(256), a, S);
+          else KHR_LAUNCH_TIMED(7, (k_band<16, false>), dim3(grid * S), dim3(256), a, S);
           a.band_rec = nullptr;
         }
       };
@@ -3726,13 +3728,12 @@ struct khr_snapshot {
   hipEvent_t ev_packed = nullptr;  // recorded on the context's stream behind the pack kernel
   hipEvent_t ev_copied = nullptr;  // khr_snapshot_download_begin: the last device -> host copy on the copy stream
   bool copying = false;
-  int32_t* async_indices = nullptr;  // caller's index array of the download in flight (filled from idx_stage at _end)
-  std::vector<int4> idx_stage;
+  int32_t* d_index3 = nullptr;  // carved from the arena: the block indices as (x, y, z) triples (khr_snapshot_download_begin)
 };
 
 static size_t snapBytes(uint32_t fields, size_t cap, size_t nvox, bool trk, bool sem, size_t K) {
   auto al = [](size_t b) { return (b + 255) / 256 * 256; };
-  size_t b = 256 + al(cap * 4) + al(cap * 16);
+  size_t b = 256 + al(cap * 4) + al(cap * 16) + al(cap * 12);
   if (fields & KHR_SNAP_DISTANCE) b += al(cap * nvox * 4);
   if (fields & KHR_SNAP_WEIGHT) b += al(cap * nvox * 4);
   if (fields & KHR_SNAP_COLOR) b += al(cap * nvox * 4);
@@ -3797,6 +3798,7 @@ int khr_snapshot_updated(khr_ctx* c, uint32_t fields, int64_t cap_blocks, khr_sn
   snap->d_count = reinterpret_cast<uint32_t*>(carve(256));
   snap->d_slots = reinterpret_cast<uint32_t*>(carve(cap * 4));
   snap->d_index = reinterpret_cast<int4*>(carve(cap * 16));
+  snap->d_index3 = reinterpret_cast<int32_t*>(carve(cap * 12));
   if (fields & KHR_SNAP_DISTANCE) snap->o.dist = reinterpret_cast<float*>(carve(cap * nvox * 4));
   if (fields & KHR_SNAP_WEIGHT) snap->o.weight = reinterpret_cast<float*>(carve(cap * nvox * 4));
   if (fields & KHR_SNAP_COLOR) snap->o.color = reinterpret_cast<uint32_t*>(carve(cap * nvox * 4));
@@ -3945,11 +3947,11 @@ int khr_snapshot_download_begin(khr_snapshot* s, int32_t* indices, float* distan
   if (!s->ev_copied) HIP_TRY(hipEventCreateWithFlags(&s->ev_copied, hipEventDisableTiming));
   HIP_TRY(hipStreamWaitEvent(c->copy_stream, s->ev_packed, 0));
   const size_t nv = s->nvox;
-  s->async_indices = indices;
   if (n > 0) {
-    if (indices) {
-      s->idx_stage.resize(static_cast<size_t>(n));
-      HIP_TRY(hipMemcpyAsync(s->idx_stage.data(), s->d_index, sizeof(int4) * n, hipMemcpyDeviceToHost, c->copy_stream));
+    if (indices) {  // (x, y, z) triples made on the device, then one copy straight into the caller's (pinned) array
+      hipLaunchKernelGGL(k_snapshot_index3, dim3(gridFor(static_cast<size_t>(n))), dim3(256), 0, c->copy_stream, s->d_index, s->d_index3,
+                         static_cast<uint32_t>(n));
+      HIP_TRY(hipMemcpyAsync(indices, s->d_index3, sizeof(int32_t) * 3 * n, hipMemcpyDeviceToHost, c->copy_stream));
     }
     hipError_t e = hipSuccess;
     auto field = [&](void* dst, const void* src, size_t elem) {
@@ -3973,13 +3975,6 @@ int64_t khr_snapshot_download_end(khr_snapshot* s) {
   if (!s->copying) return fail(KHR_ESTATE, "no download in flight (khr_snapshot_download_begin first)");
   HIP_TRY(hipEventSynchronize(s->ev_copied));
   s->copying = false;
-  if (s->async_indices)
-    for (int64_t i = 0; i < s->n; ++i) {
-      s->async_indices[3 * i] = s->idx_stage[static_cast<size_t>(i)].x;
-      s->async_indices[3 * i + 1] = s->idx_stage[static_cast<size_t>(i)].y;
-      s->async_indices[3 * i + 2] = s->idx_stage[static_cast<size_t>(i)].z;
-    }
-  s->async_indices = nullptr;
   return s->n;
 }
 

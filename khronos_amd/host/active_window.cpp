@@ -5,6 +5,9 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <map>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 
@@ -416,6 +419,8 @@ ActiveWindow::Config ActiveWindow::Config::fromYaml(const khronos_amd::YamlNode&
     m->read("max_buffer_size", b.max_buffer_size);
     m->read("store_every_n_frames", b.store_every_n_frames);
   }
+  if (const auto* m = n.find("khronos_sinks"))  // active_window.cpp:70 ("[]" or absent: none)
+    for (const khronos_amd::YamlNode* item : m->items()) c.khronos_sinks.push_back(*item);
   if (const auto* m = n.find("device")) {  // extension block (not in the reference): HBM sizing / placement
     m->read("num_labels", c.num_labels);
     int v = static_cast<int>(c.max_blocks);
@@ -473,9 +478,12 @@ void ActiveWindow::Config::checkValid() const {
 }
 
 // ---- ActiveWindow ------------------------------------------------------------------------------------------------
+static std::vector<ActiveWindow::KhronosSink> instantiateSinks(const std::vector<khronos_amd::YamlNode>& configs);
+
 ActiveWindow::ActiveWindow(const Config& cfg, const OutputQueue::Ptr& output_queue)
     : hydra::ActiveWindowModule(output_queue), config(cfg), frame_data_buffer_(cfg.frame_data_buffer) {
   config.checkValid();
+  sinks_ = instantiateSinks(config.khronos_sinks);  // active_window.cpp:80
   khr_config& d = device_config_;
   khr_default_config(&d);
   d.voxel_size = config.volumetric_map.voxel_size;
@@ -576,6 +584,43 @@ std::string ActiveWindow::printInfo() const {
 
 void ActiveWindow::addKhronosSink(const KhronosSink& sink) {
   if (sink) sinks_.push_back(sink);
+}
+
+namespace {
+std::mutex& sinkRegistryMutex() {
+  static std::mutex mu;
+  return mu;
+}
+std::map<std::string, ActiveWindow::KhronosSinkFactory>& sinkRegistry() {
+  static std::map<std::string, ActiveWindow::KhronosSinkFactory> reg;
+  return reg;
+}
+}  // namespace
+
+bool ActiveWindow::registerKhronosSink(const std::string& type, KhronosSinkFactory factory) {
+  std::lock_guard<std::mutex> lock(sinkRegistryMutex());
+  return sinkRegistry().emplace(type, std::move(factory)).second;
+}
+
+// KhronosSink::instantiate(config.khronos_sinks) (active_window.cpp:80)
+static std::vector<ActiveWindow::KhronosSink> instantiateSinks(const std::vector<khronos_amd::YamlNode>& configs) {
+  std::vector<ActiveWindow::KhronosSink> out;
+  for (const auto& node : configs) {
+    std::string type;
+    node.read("type", type);
+    ActiveWindow::KhronosSinkFactory factory;
+    {
+      std::lock_guard<std::mutex> lock(sinkRegistryMutex());
+      auto it = sinkRegistry().find(type);
+      if (it != sinkRegistry().end()) factory = it->second;
+    }
+    if (!factory) {
+      std::fprintf(stderr, "[Khronos Active Window] khronos_sinks: no sink type '%s' is registered; entry skipped\n", type.c_str());
+      continue;
+    }
+    if (auto sink = factory(node)) out.push_back(std::move(sink));
+  }
+  return out;
 }
 
 using Timer = hydra::timing::ScopedTimer;

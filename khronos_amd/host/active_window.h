@@ -420,6 +420,10 @@ class ActiveWindow : public hydra::ActiveWindowModule {  // active_window.h:67
     ObjectWorkerPool::Config extraction_worker;
     struct MeshIntegrator { float min_weight = 1e-4f; } mesh_integrator;
     FrameDataBuffer::Config frame_data_buffer;
+    // `khronos_sinks:` (active_window.cpp:70): a list of {type: <registered sink type>, ...} mappings; each is instantiated by
+    // the factory registered under its type (registerKhronosSink; config_utilities' RegistrationWithConfig role) at
+    // construction (active_window.cpp:80).  Sinks can still be added later with addKhronosSink (khronos_pipeline.cpp:94-104).
+    std::vector<khronos_amd::YamlNode> khronos_sinks;
     // device-side sizing (no reference equivalent)
     int num_labels = 20;
     uint32_t max_blocks = 16384;
@@ -453,6 +457,12 @@ class ActiveWindow : public hydra::ActiveWindowModule {  // active_window.h:67
   const FrameData& getLatestFrameData() const { return frame_data_buffer_.getLatestData(); }
   const Tracks& getTracks() const { return tracker_->getTracks(); }
   void addKhronosSink(const KhronosSink& sink);
+  // factory registry behind the `khronos_sinks` config key: type name -> factory(config mapping of the list entry).  An entry
+  // whose type nobody registered is reported and skipped (config_utilities logs "cannot create" and hands back nullptr,
+  // which KhronosSink::instantiate drops).  Returns false when the name is already taken.
+  using KhronosSinkFactory = std::function<KhronosSink(const khronos_amd::YamlNode&)>;
+  static bool registerKhronosSink(const std::string& type, KhronosSinkFactory factory);
+  size_t numKhronosSinks() const { return sinks_.size(); }
   void setObjectDetector(std::unique_ptr<ObjectDetector> d) { object_detector_ = std::move(d); }
   void setTracker(std::unique_ptr<Tracker> t) { tracker_ = std::move(t); }
 

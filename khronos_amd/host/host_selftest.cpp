@@ -146,6 +146,40 @@ int main(int argc, char** argv) {
     CHECK(!hydra::ActiveWindowFactory::has("NoSuchWindow"));
     CHECK(hydra::ActiveWindowFactory::create("NoSuchWindow", "", nullptr) == nullptr);
   }
+  // ---- khronos_sinks (active_window.cpp:70,80): a YAML list of {type, ...} entries, instantiated through the sink registry ----
+  {
+    const char* yaml =
+        "active_window:\n"
+        "  type: \"ActiveWindow\"\n"
+        "  min_output_separation: 0.4\n"
+        "  khronos_sinks:\n"
+        "    - type: CountingSink\n"
+        "      every_n: 3\n"
+        "    - type: NobodyRegisteredThis\n"
+        "    - type: CountingSink\n"
+        "      every_n: 5\n"
+        "  frame_data_buffer:\n"
+        "    max_buffer_size: 7\n";
+    const auto cfg = ActiveWindow::Config::fromYamlString(yaml);
+    CHECK(cfg.khronos_sinks.size() == 3);
+    CHECK(cfg.frame_data_buffer.max_buffer_size == 7 && cfg.min_output_separation == 0.4f);  // (the keys behind the list still parse)
+    std::string t0, t1;
+    int n0 = 0, n2 = 0;
+    cfg.khronos_sinks[0].read("type", t0);
+    cfg.khronos_sinks[0].read("every_n", n0);
+    cfg.khronos_sinks[1].read("type", t1);
+    cfg.khronos_sinks[2].read("every_n", n2);
+    CHECK(t0 == "CountingSink" && n0 == 3 && t1 == "NobodyRegisteredThis" && n2 == 5);
+    CHECK(ActiveWindow::Config::fromYamlString("active_window:\n  khronos_sinks: []\n").khronos_sinks.empty());
+    static int made = 0;
+    CHECK(ActiveWindow::registerKhronosSink("CountingSink", [](const khronos_amd::YamlNode& n) -> ActiveWindow::KhronosSink {
+      int every = 1;
+      n.read("every_n", every);
+      made += every;
+      return [](const FrameData&, const VolumetricMap&, const Tracks&) {};
+    }));
+    CHECK(!ActiveWindow::registerKhronosSink("CountingSink", nullptr));  // the name is taken
+  }
   // ---- FrameDataBuffer: capped FIFO (frame_data_buffer.cpp:88-109) ----
   {
     FrameDataBuffer::Config bc;

@@ -1,6 +1,7 @@
 // mini_yaml.h — the YAML subset the Khronos mapper configs use (khronos_ros/config/mapper/*.yaml):
 // block mappings by indentation, scalars (numbers / bools / quoted or plain strings), comments, anchors
-// (&name value) and aliases (*name), empty flow sequences ("[]").  Stands in for config_utilities'
+// (&name value) and aliases (*name), empty flow sequences ("[]"), block sequences ("- type: X" items: the entries of a
+// list are children with the key "-", see YamlNode::items).  Stands in for config_utilities'
 // YAML front end, which is not available offline (SURVEY.md §5 "Config / flag system").
 #pragma once
 #include <cstdlib>
@@ -23,6 +24,13 @@ struct YamlNode {
     return nullptr;
   }
   bool has(const std::string& key) const { return find(key) != nullptr; }
+  // the entries of a block sequence ("- ..." lines), in order
+  std::vector<const YamlNode*> items() const {
+    std::vector<const YamlNode*> out;
+    for (const auto& kv : children)
+      if (kv.first == "-") out.push_back(&kv.second);
+    return out;
+  }
   const YamlNode& at(const std::string& key) const {
     const YamlNode* n = find(key);
     if (!n) throw std::runtime_error("yaml: missing key '" + key + "'");
@@ -67,9 +75,24 @@ inline YamlNode parseYaml(const std::string& text) {
     const int indent = static_cast<int>(s.find_first_not_of(' '));
     s = detail::trim(s);
     if (s == "---") continue;
+    // block sequence entry: "- key: value" opens an item (a mapping whose first key sits two columns further in),
+    // "- scalar" is a scalar item
+    int extra = 0;
+    if (s == "-" || s.rfind("- ", 0) == 0) {
+      const std::string rest = detail::trim(s.substr(1));
+      if (rest.empty() || rest.find(':') != std::string::npos) {
+        lines.push_back({indent, "-", ""});
+        if (rest.empty()) continue;
+        s = rest;
+        extra = 2;
+      } else {
+        lines.push_back({indent, "-", rest});
+        continue;
+      }
+    }
     const size_t colon = s.find(':');
     if (colon == std::string::npos) throw std::runtime_error("yaml: unsupported line '" + s + "'");
-    lines.push_back({indent, detail::trim(s.substr(0, colon)), detail::trim(s.substr(colon + 1))});
+    lines.push_back({indent + extra, detail::trim(s.substr(0, colon)), detail::trim(s.substr(colon + 1))});
   }
   std::map<std::string, YamlNode> anchors;
   size_t pos = 0;

@@ -506,6 +506,8 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
   const uint32_t nc0 = list.counts[0], nc1 = nc0 + list.counts[1], nc2 = nc1 + list.counts[2], n_items = nc2 + list.counts[3];
   uint32_t n_upd = 0, n_band = 0;
   const int dbg = DBG ? a.dbg : 0;
+  // (timeline probe: the constant 100 MHz counter is common to all XCDs, s_memtime is not)
+  const unsigned long long t_entry = (DBG && (dbg & 64)) ? __builtin_amdgcn_s_memrealtime() : 0ull;
   if (a.gate != nullptr && *a.gate != 0u) return;  // speculative launch, and the frame has motion seeds (workgroup-uniform)
   if (threadIdx.x == 0) {
     s_q = 0u;
@@ -815,7 +817,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
     o[4] = c_rounds;
     o[5] = c_recs;
     o[6] = t_item_max;
-    o[7] = 0;
+    o[7] = (t_entry & 0xffffffffull) | ((__builtin_amdgcn_s_memrealtime() & 0xffffffffull) << 32);  // entry | exit, 10 ns ticks
   }
   // statistics: one read-modify-write per workgroup on its own slot (folded by beginIntegrate / khr_get_stats)  // isa:kernel epilogue
   if (lane == 0) {

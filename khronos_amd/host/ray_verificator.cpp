@@ -43,8 +43,13 @@ RayVerificator::RayVerificator(const Config& cfg) : config(cfg), seed_(static_ca
   chk(khr_rv_create(config.block_size, config.radial_tolerance, config.depth_tolerance, config.device, &rv_), "khr_rv_create");
 }
 
+RayVerificator::RayVerificator(const Config& cfg, khr_rayver* borrowed)
+    : config(cfg), rv_(borrowed), owns_(false), seed_(static_cast<unsigned int>(time(nullptr))) {
+  if (!borrowed) throw std::invalid_argument("null ray index");
+}
+
 RayVerificator::~RayVerificator() {
-  if (rv_) khr_rv_destroy(rv_);
+  if (rv_ && owns_) khr_rv_destroy(rv_);
 }
 
 void RayVerificator::clear() {

@@ -38,6 +38,8 @@ class RayVerificator {
   };
 
   explicit RayVerificator(const Config& config);
+  // a view of a device index somebody else owns (bindings that hold a khr_rayver of their own): never destroys it
+  RayVerificator(const Config& config, khr_rayver* borrowed);
   ~RayVerificator();
   RayVerificator(const RayVerificator&) = delete;
   RayVerificator& operator=(const RayVerificator&) = delete;
@@ -61,6 +63,7 @@ class RayVerificator {
 
  private:
   khr_rayver* rv_ = nullptr;
+  bool owns_ = true;
   std::vector<uint64_t> timestamps_;
   std::vector<float> positions_;
   size_t previous_vertex_index_ = 0;

@@ -21,6 +21,14 @@ for i in range(n):
     ctx.integrate(slot)
     ctx.update_tracking(fr["stamp"])
 ctx.sync()
+ctx.timing_reset()
+ctx.timing_enable(True, ("tsdf", "band"))
+fr = s.render(n)
+slot = ctx.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+ctx.integrate(slot)
+ctx.update_tracking(fr["stamp"])
+ctx.sync()
+print("last launch: k_fuse %.1f us, k_band %.1f us (dispatch-packet events)" % (1e3 * ctx.timing_get("tsdf")[0], 1e3 * ctx.timing_get("band")[0]))
 st = ctx.stats()
 buf = np.zeros(4096 * 4 * 12, np.uint64)
 ctx.lib.khr_debug_read(ctx.h, buf.ctypes.data, buf.size)
@@ -86,3 +94,14 @@ if nwg * WPW == len(dur):
               np.round(np.percentile(ew[xcd == x] - s0, q), 1), "records per WG pct", np.percentile(recs.reshape(nwg, WPW).sum(1)[xcd == x], [0, 50, 100]))
     rsum = recs.reshape(nwg, WPW).sum(1)
     print("corr(WG max dur, WG records) = %.2f, corr(WG max dur, WG rounds) = %.2f" % (np.corrcoef(wg_max, rsum)[0, 1], np.corrcoef(wg_max, rw.sum(1))[0, 1]))
+
+# ---- round 4: one clock for all XCDs (s_memrealtime, 10 ns): when do waves enter, when are they past the start-up chain, when do they leave ----
+rt = b[:, 7]
+entry = (rt & np.uint64(0xffffffff)).astype(np.int64)
+exit_ = (rt >> np.uint64(32)).astype(np.int64)
+e0 = entry.min()
+print("realtime (us after the first wave's entry): entry pct", np.percentile((entry - e0) / 100.0, q))
+print("realtime: exit  pct", np.percentile((exit_ - e0) / 100.0, q))
+print("realtime: wave lifetime pct", np.percentile((exit_ - entry) / 100.0, q), "mean", ((exit_ - entry) / 100.0).mean())
+print("realtime: start-up (entry -> first item's loads issued) = lifetime - dur: pct", np.percentile((exit_ - entry) / 100.0 - dur / F, q))
+print("realtime: last exit - first entry = %.1f us" % ((exit_.max() - e0) / 100.0))

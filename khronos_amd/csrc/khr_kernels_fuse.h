@@ -121,17 +121,9 @@ struct FuseArgs : FuseFrame {
   // and does nothing when *gate != 0 (seeds exist: the host then queues the clustering chain and the real launch).  Frames
   // without seeds -- most of them -- no longer idle the main stream for the seed count's trip to the host and back.
   const uint32_t* gate;
-  // split band phase (round 4; k_fuse + k_band): when band_rec != nullptr the in-band records of an item are written to the
-  // workgroup's region of a record list in HBM instead of being worked off by the wave that found them; k_band, the next
-  // launch on the stream, works them off with every wave of the chip and no wave waiting on another's voxel phase.
-  // Region of workgroup b = band_chunks chunks of kBandChunk records, handed to its waves one chunk at a time (LDS cursor);
-  // chunk c holds its records as 24-byte structs: record r at band_rec[(c * kBandChunk + r) * 6], words 0 voxel | mode,
-  // 1 measurement weight, 2 voxel weight after the update, 3 u, 4 v, 5 pool slot.  band_cnt[c] = records in chunk c,
-  // band_nch[b] = chunks workgroup b used.  A workgroup that runs out of chunks falls back to the in-kernel band phase.
-  uint32_t* band_rec;
-  uint32_t* band_cnt;
-  uint32_t* band_nch;
-  int band_chunks;
+  // tail stealing (round 4, k_fuse): a device-wide cursor into the LAST `pool` items of the deal order (the cheapest class);
+  // nullptr = every workgroup only works its own share.  See k_fuse.
+  uint32_t* steal;
   // k_fuse2<.., MULTI>: the frames an item is walked through, in order
   const FuseFrame* frames;
   int n_frames;
@@ -141,10 +133,6 @@ struct FuseArgs : FuseFrame {
 };
 
 constexpr int kFuseCap = 256;        // in-band records a wave collects before it works them off (one 4-z chunk of a patch)
-constexpr int kBandChunk = 1024;     // records per chunk of the split band phase's record list (a wave owns its current chunk)
-constexpr int kBandFields = 6;       // words per record: voxel | mode, measurement weight, voxel weight after the update, u, v, pool slot
-typedef uint32_t rec4u __attribute__((ext_vector_type(4), aligned(8)));
-typedef uint32_t rec2u __attribute__((ext_vector_type(2), aligned(8)));
 
 // colour / label / likelihood update of one in-band voxel (the body of updateVoxel for |sdf| < truncation)
 // `a` points into the kernel-argument segment: the fields only this phase needs (image / layer pointers, label
@@ -487,7 +475,10 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
   __shared__ uint32_t s_rec[WPW][5][kFuseCap];
   __shared__ uint32_t s_stat[WPW][2];
   __shared__ uint32_t s_q;  // the workgroup's item queue: next index into its share of the descriptor list
-  __shared__ uint32_t s_nch;  // split band phase: chunks of this workgroup's record region handed out so far
+  // tail stealing: the batch of pool items this workgroup currently owns (lo | hi << 32, claimed with one 64-bit LDS add),
+  // the refill lock, "the pool is empty"
+  __shared__ unsigned long long s_range;
+  __shared__ uint32_t s_lock, s_dry;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int lane = static_cast<int>(threadIdx.x & 63);
   const int range_mode = DEFCFG ? 0 : a.range_mode;
@@ -495,9 +486,6 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
   const bool use_dropoff = DEFCFG ? true : (a.use_dropoff != 0);
   const bool const_weight = DEFCFG ? false : (a.const_weight != 0);
   const float Wm1 = static_cast<float>(a.W - 1), Hm1 = static_cast<float>(a.H - 1);
-  // split band phase: the wave's current chunk (wave-uniform; 0xffffffff = none yet) and its fill
-  const bool split = a.band_rec != nullptr;
-  uint32_t w_chunk = 0xffffffffu, w_fill = 0u;
   const float fxfy = a.fx * a.fy;
   const float den = a.trunc - a.dropoff_eps;  // weight drop-off denominator (uniform)
   const float yden = rcpRefined(den);
@@ -511,9 +499,20 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
   if (a.gate != nullptr && *a.gate != 0u) return;  // speculative launch, and the frame has motion seeds (workgroup-uniform)
   if (threadIdx.x == 0) {
     s_q = 0u;
-    s_nch = 0u;
+    s_range = 0ull;
+    s_lock = 0u;
+    s_dry = 0u;
   }
   __syncthreads();
+  // Tail stealing.  The static deal (every workgroup the same mix of cost classes) predicts an item's cost from the band
+  // voxels it had LAST frame; what a workgroup actually gets differs by +- 25 % (in-kernel timeline: the slowest wave leaves
+  // 14 us after the average one).  So the last quarter of the deal order -- items of the cheapest class, ~3 us each -- is not
+  // dealt: a workgroup that has finished its share takes batches of kStealBatch of them from a device-wide cursor (one
+  // returning global atomic per BATCH and workgroup: a few hundred per launch, spread over the tail; a per-item device-wide
+  // queue costs more than the kernel) and hands them to its waves through LDS.
+  constexpr uint32_t kStealBatch = 2u * WPW;
+  const uint32_t pool = a.steal != nullptr ? min(list.counts[3], n_items >> 2) : 0u;
+  const uint32_t n_static = n_items - pool;
   // next item of this workgroup's share (positions blockIdx.x, blockIdx.x + gridDim.x, ...: every workgroup gets the same
   // mix of the cost classes), handed to whichever of its waves asks first; wave-uniform result
   // XCD-aware share: workgroup b runs on XCD b % 8 (round-robin dispatch), so its first position is
@@ -522,10 +521,35 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
   // have in common.  (grid is a multiple of 8.)
   const uint32_t first = (dbg & 512) ? blockIdx.x : (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   auto pull = [&]() -> uint32_t {
-    uint32_t j = 0u;
-    if (lane == 0) j = atomicAdd(&s_q, 1u);
-    j = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(j)));
-    return first + gridDim.x * j;
+    uint32_t r = 0xffffffffu;
+    if (lane == 0) {
+      const uint32_t pos = first + gridDim.x * atomicAdd(&s_q, 1u);
+      if (pos < n_static) {
+        r = pos;
+      } else if (pool != 0u) {
+        while (true) {
+          const unsigned long long v = atomicAdd(&s_range, 1ull);
+          const uint32_t lo = static_cast<uint32_t>(v), hi = static_cast<uint32_t>(v >> 32);
+          if (lo < hi) {
+            r = n_static + lo;
+            break;
+          }
+          if (__atomic_load_n(&s_dry, __ATOMIC_RELAXED) != 0u) break;
+          if (atomicCAS(&s_lock, 0u, 1u) == 0u) {  // this wave refills (unless somebody just did)
+            const unsigned long long w = __atomic_load_n(&s_range, __ATOMIC_RELAXED);
+            if (static_cast<uint32_t>(w) >= static_cast<uint32_t>(w >> 32)) {
+              const uint32_t g = atomicAdd(a.steal, kStealBatch);
+              if (g >= pool) __atomic_store_n(&s_dry, 1u, __ATOMIC_RELAXED);
+              else atomicExch(&s_range, static_cast<unsigned long long>(g) | (static_cast<unsigned long long>(min(g + kStealBatch, pool)) << 32));
+            }
+            __atomic_store_n(&s_lock, 0u, __ATOMIC_RELEASE);
+          } else {
+            while (__atomic_load_n(&s_lock, __ATOMIC_ACQUIRE) != 0u) __builtin_amdgcn_s_sleep(2);
+          }
+        }
+      }
+    }
+    return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(r)));
   };
   // descriptor of item i in deal order: class 0, 1, 2, 3 (FuseList)
   auto descOf = [&](uint32_t i) -> uint4 {
@@ -625,22 +649,6 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
     char* const wgt_b = reinterpret_cast<char*>(a.weight + slot * NV);
     char* const lobs_b = reinterpret_cast<char*>(a.last_obs + slot * NV);
     uint32_t cnt = 0;       // records in this wave's LDS list
-    // split band phase: the item's records (at most 64 ZR) go to the wave's chunk of the record list; a full chunk is
-    // published and the next one taken from the workgroup's region.  No chunk left: this item keeps the in-kernel path.
-    uint32_t* g_rec = nullptr;
-    if (split) {
-      if (w_chunk == 0xffffffffu || w_fill + 64u * ZR > static_cast<uint32_t>(kBandChunk)) {
-        const uint32_t region0 = blockIdx.x * static_cast<uint32_t>(a.band_chunks);
-        if (w_chunk != 0xffffffffu && lane == 0) a.band_cnt[region0 + w_chunk] = w_fill;
-        uint32_t j = 0u;
-        if (lane == 0) j = atomicAdd(&s_nch, 1u);
-        j = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(j)));
-        w_chunk = j < static_cast<uint32_t>(a.band_chunks) ? j : 0xffffffffu;
-        w_fill = 0u;
-      }
-      if (w_chunk != 0xffffffffu)
-        g_rec = a.band_rec + (static_cast<size_t>(blockIdx.x) * a.band_chunks + w_chunk) * (kBandFields * kBandChunk) + w_fill * kBandFields;
-    }
     bool touched = false;   // wave-uniform: some voxel of this item was updated
     bool wrote_neg = false; // wave-uniform: some updated voxel now holds a negative distance
 #pragma unroll
@@ -747,27 +755,17 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
         if (in_band) {
           const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m_band >> 32),
                                                               __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m_band), 0u));
-          if (g_rec != nullptr) {  // one 24-byte record: a 16-byte and an 8-byte store (8-byte aligned)
-            uint32_t* const rec = g_rec + pos * kBandFields;
-            *reinterpret_cast<rec4u*>(rec) = rec4u{lin | (use_nearest ? 0x10000u : 0u), __float_as_uint(w), __float_as_uint(w_new), __float_as_uint(uc)};
-            *reinterpret_cast<rec2u*>(rec + 4) = rec2u{__float_as_uint(vc), static_cast<uint32_t>(slot)};
-          } else {
-            uint32_t* const rec = &s_rec[wave][0][pos];
-            rec[0] = lin | (use_nearest ? 0x10000u : 0u);
-            rec[kFuseCap] = __float_as_uint(w);
-            rec[2 * kFuseCap] = __float_as_uint(w_new);
-            rec[3 * kFuseCap] = __float_as_uint(uc);
-            rec[4 * kFuseCap] = __float_as_uint(vc);
-          }
+          uint32_t* const rec = &s_rec[wave][0][pos];
+          rec[0] = lin | (use_nearest ? 0x10000u : 0u);
+          rec[kFuseCap] = __float_as_uint(w);
+          rec[2 * kFuseCap] = __float_as_uint(w_new);
+          rec[3 * kFuseCap] = __float_as_uint(uc);
+          rec[4 * kFuseCap] = __float_as_uint(vc);
         }
         cnt += static_cast<uint32_t>(__popcll(m_band));
       }
     }
-    const uint32_t item_band = cnt;
-    if (g_rec != nullptr) {  // the records are in the list: k_band works them off
-      w_fill += cnt;
-      cnt = 0u;
-    }  // isa:band phase driver
+    const uint32_t item_band = cnt;  // isa:band phase driver
     // ---- the item's in-band voxels, densely (lane <-> record).  A cold block: the hint keeps the register allocator
     //      from favouring its values over the voxel loop's ----
     if (DBG && (dbg & 1)) cnt = 0u;
@@ -786,7 +784,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
       } else {
         for (uint32_t r = static_cast<uint32_t>(lane); r < cnt; r += 64u) {
           const uint32_t* const rec = &s_rec[wave][0][r];
-          fuseBandRecord<VPS>(ka, kf, slot, rec[0], __uint_as_float(rec[kFuseCap]), __uint_as_float(rec[2 * kFuseCap]),
+          fuseBandRecord<VPS, DBG>(ka, kf, slot, rec[0], __uint_as_float(rec[kFuseCap]), __uint_as_float(rec[2 * kFuseCap]),
                               __uint_as_float(rec[3 * kFuseCap]), __uint_as_float(rec[4 * kFuseCap]));
         }
       }
@@ -823,10 +821,8 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
   if (lane == 0) {
     s_stat[wave][0] = n_upd;
     s_stat[wave][1] = n_band;
-    if (split && w_chunk != 0xffffffffu) a.band_cnt[blockIdx.x * static_cast<uint32_t>(a.band_chunks) + w_chunk] = w_fill;
   }
   __syncthreads();
-  if (split && threadIdx.x == 0) a.band_nch[blockIdx.x] = min(s_nch, static_cast<uint32_t>(a.band_chunks));
   if (threadIdx.x == 0) {
     uint32_t su = 0u, sb = 0u;
 #pragma unroll
@@ -837,52 +833,6 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
     if (su | sb) {
       a.wg_stats[2 * blockIdx.x] += su;
       a.wg_stats[2 * blockIdx.x + 1] += sb;
-    }
-  }
-}
-
-// ====================================================================================================================
-// k_band (round 4): the colour / label / likelihood update of the in-band voxels k_fuse (split form) left in the record list.
-// In the fused form a wave worked off its own item's records in passes of 64, each pass one or two exposed memory round
-// trips, the passes of a fat item serialised in one wave while the other waves of the workgroup ran out of work (the
-// in-kernel timeline: 16 of a wave's 46 us, the slowest workgroup 58 us against a mean of 46 -- its share of band passes).
-// Here the passes of workgroup b's region are dealt to the T = S x 4 waves of S small workgroups, every pass is independent,
-// and all of them are resident at once: the band work of the frame is a handful of memory round trips deep instead of ~20.
-// Same arithmetic, same operand order as fuseBandRecord: results are bit-identical.
-// ====================================================================================================================
-template <int VPS, bool DBG = false>
-__global__ __launch_bounds__(256) void k_band(FuseArgs a, int S) {
-  if (a.gate != nullptr && *a.gate != 0u) return;  // the speculative update did not run either
-  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  const int lane = static_cast<int>(threadIdx.x & 63);
-  const uint32_t b = blockIdx.x / static_cast<uint32_t>(S);
-  const uint32_t t = (blockIdx.x % static_cast<uint32_t>(S)) * 4u + static_cast<uint32_t>(wave), T = static_cast<uint32_t>(S) * 4u;
-  const uint32_t n_ch = a.band_nch[b];
-  if (n_ch == 0u) return;
-  const uint32_t region0 = b * static_cast<uint32_t>(a.band_chunks);
-  // passes per chunk (lane <-> chunk; a region has at most 64 chunks), inclusive prefix over the lanes
-  const uint32_t cnt_j = static_cast<uint32_t>(lane) < n_ch ? a.band_cnt[region0 + static_cast<uint32_t>(lane)] : 0u;
-  const uint32_t pas_j = (cnt_j + 63u) >> 6;
-  uint32_t incl = pas_j;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t o = static_cast<uint32_t>(__shfl_up(static_cast<int>(incl), d));
-    if (lane >= d) incl += o;
-  }
-  const uint32_t P = static_cast<uint32_t>(__shfl(static_cast<int>(incl), 63));
-  FuseArgsK ka = (FuseArgsK)__builtin_amdgcn_kernarg_segment_ptr();
-  const FuseFrameK kf = (FuseFrameK)ka;
-  for (uint32_t p = t; p < P; p += T) {
-    const int j = __popcll(__builtin_amdgcn_ballot_w64(incl <= p));  // the chunk pass p falls into
-    const uint32_t first = static_cast<uint32_t>(__shfl(static_cast<int>(incl - pas_j), j));
-    const uint32_t count = static_cast<uint32_t>(__shfl(static_cast<int>(cnt_j), j));
-    const uint32_t r = (p - first) * 64u + static_cast<uint32_t>(lane);
-    if (r < count) {
-      const uint32_t* const rec = a.band_rec + static_cast<size_t>(region0 + static_cast<uint32_t>(j)) * (kBandFields * kBandChunk) + r * kBandFields;
-      const rec4u ra = *reinterpret_cast<const rec4u*>(rec);
-      const rec2u rb = *reinterpret_cast<const rec2u*>(rec + 4);
-      fuseBandRecord<VPS, DBG>(ka, kf, static_cast<size_t>(rb.y), ra.x, __uint_as_float(ra.y), __uint_as_float(ra.z), __uint_as_float(ra.w),
-                               __uint_as_float(rb.x));
     }
   }
 }

@@ -139,9 +139,6 @@ struct khr_ctx {
   int tick_epoch = 0, motion_ignore_epoch = 0;
   unsigned long long* d_dbg = nullptr;
   unsigned long long* d_digest = nullptr;  // khr_map_digest accumulators
-  // split band phase (k_fuse -> k_band): record list, per-chunk counts, chunks used per workgroup; sized for band_grid workgroups
-  uint32_t *d_band_rec = nullptr, *d_band_cnt = nullptr, *d_band_nch = nullptr;
-  int band_grid = 0;
   uint32_t* d_wg_stats = nullptr;
   uint32_t* d_pix_scratch = nullptr;  // khr_pixel_iou: mask image + counters (allocated on first use)
   size_t pix_words = 0;
@@ -528,9 +525,7 @@ int kTickUnion = 1;     // env KHR_TICK_UNION: khr_tick_integrate updates with O
 int kFuseMulti = 1;     // env KHR_FUSE_MULTI: khr_integrate_shared_batch integrates all frames of a batch in one launch (k_fuse2 MULTI)
 constexpr int kMaxMultiFrames = 1024;
 int kFuseSpec = 1;      // env KHR_FUSE_SPECULATIVE: khr_process_frame queues k_fuse before the seed count has reached the host (gated on the device)
-int kFuseSplit = 1;     // env KHR_FUSE_SPLIT: the window's update as k_fuse (voxel phase, in-band records to a list in HBM) + k_band (round 4); 0 = fused band phase
-constexpr int kBandChunksPerWg = 32;  // chunks of kBandChunk records in a workgroup's region of that list (<= 64)
-int kBandTeams = 4;                   // k_band workgroups (4 waves each) per k_fuse workgroup; env KHR_BAND_TEAMS
+int kFuseSteal = 1;     // env KHR_FUSE_STEAL: k_fuse leaves the cheapest quarter of the items undealt; workgroups that finish early take them in batches (round 4)
 int kFuseBand = 0;      // env KHR_FUSE_BAND: 0 = lane <-> record (default), 1 = record-cooperative band phase (fuseBandCoop: -41 % L2 write requests, -16 % L1 accesses, same time at 720p / 2 cm, slower on small frames)
 constexpr int kStreamGrid = 4096;
 
@@ -803,8 +798,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   if (std::getenv("KHR_FUSE_WAVES")) kFuseWavesPerCu = std::max(4, std::atoi(std::getenv("KHR_FUSE_WAVES")));
   if (std::getenv("KHR_FUSE_DBG")) kFuseDbg = std::atoi(std::getenv("KHR_FUSE_DBG"));
   if (std::getenv("KHR_FUSE_BAND")) kFuseBand = std::atoi(std::getenv("KHR_FUSE_BAND"));
-  if (std::getenv("KHR_FUSE_SPLIT")) kFuseSplit = std::atoi(std::getenv("KHR_FUSE_SPLIT"));
-  if (std::getenv("KHR_BAND_TEAMS")) kBandTeams = std::max(1, std::min(16, std::atoi(std::getenv("KHR_BAND_TEAMS"))));
+  if (std::getenv("KHR_FUSE_STEAL")) kFuseSteal = std::atoi(std::getenv("KHR_FUSE_STEAL"));
   if (std::getenv("KHR_FUSE_SPECULATIVE")) kFuseSpec = std::atoi(std::getenv("KHR_FUSE_SPECULATIVE"));
   if (std::getenv("KHR_TICK_UNION")) kTickUnion = std::atoi(std::getenv("KHR_TICK_UNION"));
   if (std::getenv("KHR_FUSE_MULTI")) kFuseMulti = std::atoi(std::getenv("KHR_FUSE_MULTI"));
@@ -982,7 +976,6 @@ void khr_destroy(khr_ctx* c) {
   if (c->d_halo_recs) hipFree(c->d_halo_recs);
   if (c->d_halo_keys) { hipFree(c->d_halo_keys); hipFree(c->d_halo_vals); }
   if (c->d_mh_recs) { hipFree(c->d_mh_recs); hipFree(c->d_mh_keys); hipFree(c->d_mh_vals); }
-  if (c->d_band_rec) { hipFree(c->d_band_rec); hipFree(c->d_band_cnt); hipFree(c->d_band_nch); }
   if (c->d_pix_scratch) hipFree(c->d_pix_scratch);
   if (c->d_inst) hipFree(c->d_inst);
   if (c->pending_snapshot) khr_snapshot_release(c->pending_snapshot);
@@ -1393,38 +1386,10 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
         }
         static bool said = false;
         if (!said && std::getenv("KHR_VERBOSE")) { said = true; std::fprintf(stderr, "[khr] k_fuse<%d,%d> %d waves / workgroup, grid %d\n", V, ZS, wpw, grid); }
-        // the window's update in two launches (round 4): k_fuse leaves the in-band records in a list, k_band works them off
-        const bool split = kFuseSplit != 0 && V == 16 && allocate_blocks != 0;
-        if (split) {
-          if (c->band_grid < grid) {  // (first use, or a larger grid: allocation stalls the device once)
-            if (c->d_band_rec) { hipStreamSynchronize(c->stream); hipFree(c->d_band_rec); hipFree(c->d_band_cnt); hipFree(c->d_band_nch); }
-            c->d_band_rec = c->d_band_cnt = c->d_band_nch = nullptr;
-            c->band_grid = 0;
-            const size_t chunks = static_cast<size_t>(grid) * kBandChunksPerWg;
-            if (hipMalloc(reinterpret_cast<void**>(&c->d_band_rec), chunks * kBandFields * kBandChunk * sizeof(uint32_t)) != hipSuccess ||
-                hipMalloc(reinterpret_cast<void**>(&c->d_band_cnt), chunks * sizeof(uint32_t)) != hipSuccess ||
-                hipMalloc(reinterpret_cast<void**>(&c->d_band_nch), static_cast<size_t>(grid) * sizeof(uint32_t)) != hipSuccess) {
-              if (c->d_band_rec) hipFree(c->d_band_rec);
-              if (c->d_band_cnt) hipFree(c->d_band_cnt);
-              c->d_band_rec = c->d_band_cnt = c->d_band_nch = nullptr;
-            } else {
-              c->band_grid = grid;
-            }
-          }
-          if (c->band_grid >= grid) {
-            a.band_rec = c->d_band_rec;
-            a.band_cnt = c->d_band_cnt;
-            a.band_nch = c->d_band_nch;
-            a.band_chunks = kBandChunksPerWg;
-          }
-        }
+        // tail stealing for the window's own update (the persistent grid of the whole chip); small explicit maps and the
+        // per-camera lists of a rig tick keep the plain deal
+        a.steal = (kFuseSteal != 0 && lists == nullptr && allocate_blocks != 0) ? &m.counters[C_FUSE_STEAL] : nullptr;
         KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(64 * wpw), a, list);
-        if (a.band_rec != nullptr) {
-          const int S = kBandTeams;
-          if (kFuseDbg) KHR_LAUNCH_TIMED(7, (k_band<16, true>), dim3(grid * S), dim3(256), a, S);
-          else KHR_LAUNCH_TIMED(7, (k_band<16, false>), dim3(grid * S), dim3(256), a, S);
-          a.band_rec = nullptr;
-        }
       };
       // non-default switches are test configurations: they always run the bit-exact arithmetic
       a.gate = gate;
@@ -3357,7 +3322,7 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   if (motion && kFuseSpec && c->cfg.with_tracking) {
     const size_t n_pending = c->pending.size();
     if ((rc = integrateUpdate(c, s, f, 1, 0, -1, nullptr, &c->m.counters[C_N_SEEDS]))) return rc;
-    if (c->pending.size() > n_pending) spec_timer = n_pending;  // (first of the launch's timer samples: k_fuse, k_band)
+    if (c->pending.size() > n_pending) spec_timer = n_pending;  // (first of the launch's timer samples)
     spec_end = c->pending.size();
     speculated = true;
   }

@@ -53,6 +53,11 @@ def load_host_library():
     lib.kdist_profile.argtypes = [vp, i32]
     lib.kdist_profile_get.argtypes = [vp, vp, i32]
     lib.khr_host_detect_changes.argtypes = [vp, C.c_int64, vp, C.c_int64, C.c_float, C.c_int64, i32, C.c_float, C.c_float, i32, vp]
+    lib.khr_host_background_changes.argtypes = [vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, C.c_float, C.c_float, C.c_int64, i32, C.c_float,
+                                                C.c_float, vp]
+    lib.khr_host_background_changes.restype = C.c_int64
+    lib.khr_host_object_change.argtypes = [vp, C.c_int64, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_float, i32, C.c_float, C.c_int64, i32, C.c_float,
+                                           C.c_float, vp]
     _host = lib
     return lib
 
@@ -71,6 +76,44 @@ def detect_changes(present, absent, forward, temporal_resolution=1.0, window_siz
     if rc < 0:
         raise KhronosAmdError("khr_host_detect_changes failed (%d): bad configuration" % rc)
     return (int(out[0]) if rc & 1 else None, int(out[1]) if rc & 2 else None)
+
+
+UNOBSERVED, PERSISTENT, ABSENT = 0, 1, 2  # khronos::ChangeState (change_state.h:124)
+
+
+def background_changes(rv, positions, stamps, states=(), reobserved=(), time_filtering_threshold=5.0, temporal_resolution=1.0, window_size=5,
+                       use_relative_confidence=True, absence_confidence=0.5, presence_confidence=0.5):
+    """khronos::RayBackgroundChangeDetector::detectChanges (khronos_amd/host/change_detection.cpp) over a khronos_amd.RayVerificator:
+    `states` = the change states of the first len(states) vertices so far, `reobserved` = vertex indices to recompute.
+    -> (states of all vertices as uint8: UNOBSERVED / PERSISTENT / ABSENT, number of re-observed vertices that changed)"""
+    lib = load_host_library()
+    pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+    st = np.ascontiguousarray(stamps, dtype=np.uint64)
+    out = np.zeros(len(st), np.uint8)
+    out[:len(states)] = np.asarray(states, np.uint8)
+    re = np.ascontiguousarray(reobserved, dtype=np.int64)
+    n = lib.khr_host_background_changes(rv.h, len(st), pos.ctypes.data, st.ctypes.data, len(states), re.ctypes.data if re.size else None, re.size,
+                                        float(time_filtering_threshold), float(temporal_resolution), int(window_size),
+                                        1 if use_relative_confidence else 0, float(absence_confidence), float(presence_confidence), out.ctypes.data)
+    if n < 0:
+        raise KhronosAmdError("khr_host_background_changes failed (%d): %s" % (n, load_library().khr_last_error().decode()))
+    return out, int(n)
+
+
+def object_change(rv, vertices, bbox_min, bbox_max, first_observed, last_observed, time_filtering_threshold=5.0, query_subsampling=100,
+                  temporal_resolution=1.0, window_size=5, use_relative_confidence=True, absence_confidence=0.5, presence_confidence=0.5):
+    """khronos::RayObjectChangeDetector::checkObjectObservation for one object (vertices in the bounding-box frame)
+    -> dict(first_absent, last_absent, first_persistent, last_persistent)"""
+    lib = load_host_library()
+    v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+    b0, b1 = np.ascontiguousarray(bbox_min, dtype=np.float32), np.ascontiguousarray(bbox_max, dtype=np.float32)
+    out = np.zeros(4, np.uint64)
+    rc = lib.khr_host_object_change(rv.h, len(v), v.ctypes.data, b0.ctypes.data, b1.ctypes.data, int(first_observed), int(last_observed),
+                                    float(time_filtering_threshold), int(query_subsampling), float(temporal_resolution), int(window_size),
+                                    1 if use_relative_confidence else 0, float(absence_confidence), float(presence_confidence), out.ctypes.data)
+    if rc < 0:
+        raise KhronosAmdError("khr_host_object_change failed (%d): %s" % (rc, load_library().khr_last_error().decode()))
+    return dict(first_absent=int(out[0]), last_absent=int(out[1]), first_persistent=int(out[2]), last_persistent=int(out[3]))
 
 
 class ObjectPipeline:

@@ -127,3 +127,69 @@ def test_device_vote_equals_restatement(relative):
     ca, fp, fl = dev.check_and_vote(pts, 0, 2 ** 64 - 1, True, temporal_resolution=0.001)
     multi = (n_p + n_a) > 1
     assert (fl[multi] & 0x80).any() and not (fl[~(fl & 0x80).astype(bool)] & 0x80).any()
+
+
+def test_background_and_object_change_detectors_equal_restatement():
+    """the two callers of the ray verificator (BASELINE configs[4] "change reconciliation"): RayBackgroundChangeDetector::detectChanges
+    (ray_background_change_detector.cpp:59-103: every new and every re-observed mesh vertex, check + forward vote) and
+    RayObjectChangeDetector::checkObjectObservation (ray_object_change_detector.cpp:117-160: sub-sampled vertices queried before /
+    after the object's life time, merged, voted once per direction), as batched device passes of the host mirrors
+    (khronos_amd/host/change_detection.cpp), against the per-vertex loops of the reference restated with the oracle."""
+    from khronos_amd import host_capi as hc
+    rng = np.random.default_rng(21)
+    st, src, tgt = _scene(rng, 40, 300)  # stamps 1 .. 40 s
+    dev, ora = RayVerificator(1.0, 0.1, 0.1), po.OracleRayVerificator(1.0, 0.1, 0.1)
+    dev.add_rays(st, src, tgt)
+    ora.add_rays(st, src, tgt)
+    kw = dict(temporal_resolution=1.0, window_size=5, use_relative_confidence=True, absence_confidence=0.4, presence_confidence=0.55)
+    thr = 5.0
+    thr_ns = int(np.float32(thr) * 1e9)  # uint64(config.time_filtering_threshold * 1e9)
+
+    def state(point, earliest):  # checkVertex (:90-103)
+        _, _, pres, absn = ora.check(point[None], earliest, 2 ** 64 - 1)
+        ca, fp = po.detect_changes(pres, absn, True, **kw)
+        return hc.ABSENT if ca is not None else (hc.PERSISTENT if fp is not None else hc.UNOBSERVED)
+    # background mesh: measured surface points (present), points in front of surfaces (seen through: absent), unobserved ones
+    sel = rng.choice(len(st), 400, replace=False)
+    verts = np.concatenate([tgt[sel[:200]], 0.5 * (src[sel[200:]] + tgt[sel[200:]]), np.full((5, 3), 60.0, np.float32)]).astype(np.float32)
+    vstamps = np.concatenate([st[sel[:200]], st[sel[200:]], np.full(5, 3 * T, np.uint64)])
+    first = 250
+    states, _ = hc.background_changes(dev, verts[:first], vstamps[:first], time_filtering_threshold=thr, **kw)
+    want = np.array([state(verts[i], int(vstamps[i]) + thr_ns) for i in range(first)], np.uint8)
+    assert np.array_equal(states, want)
+    assert (want == hc.ABSENT).sum() > 10 and (want == hc.PERSISTENT).sum() > 10 and (want == hc.UNOBSERVED).sum() > 10
+    # more rays arrive, the mesh grows, some old vertices were re-observed: new ones get their first state, re-observed ones are recomputed
+    st2, src2, tgt2 = _scene(np.random.default_rng(22), 12, 300)
+    st2 = st2 + np.uint64(40 * T)
+    dev.add_rays(st2, src2, tgt2)
+    ora.add_rays(st2, src2, tgt2)
+    reobs = [3, 17, 120, 249, 100000]  # (an index beyond the mesh is ignored, :73-75)
+    states2, n_changed = hc.background_changes(dev, verts, vstamps, states=states, reobserved=reobs, time_filtering_threshold=thr, **kw)
+    want2 = want.copy()
+    for i in reobs[:-1]:
+        want2[i] = state(verts[i], int(vstamps[i]) + thr_ns)
+    want2 = np.concatenate([want2, [state(verts[i], int(vstamps[i]) + thr_ns) for i in range(first, len(verts))]]).astype(np.uint8)
+    assert np.array_equal(states2, want2)
+    assert n_changed == sum(int(want2[i] != want[i]) for i in reobs[:-1])
+    # an object: a blob of surface points seen between 10 s and 20 s, stored in its bounding-box frame
+    centre = tgt[sel[0]]
+    blob = (centre + rng.normal(scale=0.15, size=(1000, 3))).astype(np.float32)
+    b0, b1 = blob.min(0), blob.max(0)
+    local = (blob - (np.float32(0.5) * (b0 + b1)).astype(np.float32)).astype(np.float32)
+    t_first, t_last, sub = 10 * T, 20 * T, 7
+    got = hc.object_change(dev, local, b0, b1, t_first, t_last, time_filtering_threshold=thr, query_subsampling=sub, **kw)
+    before = [[], []]
+    after = [[], []]
+    ctr = np.array([np.float32(0.5) * (b0[d] + b1[d]) for d in range(3)], np.float32)  # BoundingBox::center: 0.5f * (min + max)
+    for i in range(0, len(local), sub):
+        p = (local[i] + ctr).astype(np.float32)
+        _, _, pres, absn = ora.check(p[None], 0, t_first - thr_ns)
+        before[0] += list(pres)
+        before[1] += list(absn)
+        _, _, pres, absn = ora.check(p[None], t_last + thr_ns, 2 ** 64 - 1)
+        after[0] += list(pres)
+        after[1] += list(absn)
+    bca, bfp = po.detect_changes(before[0], before[1], False, **kw)
+    aca, afp = po.detect_changes(after[0], after[1], True, **kw)
+    assert got == dict(first_absent=bca or 0, last_absent=aca or 0, first_persistent=bfp or 0, last_persistent=afp or 0)
+    assert len(before[0]) + len(before[1]) > 50 and len(after[0]) + len(after[1]) > 50

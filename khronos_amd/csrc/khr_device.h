@@ -58,7 +58,6 @@ enum Counter : int {
   C_N_ITEMS1,
   C_N_ITEMS2,
   C_N_ITEMS3,
-  C_FUSE_STEAL,      // k_fuse's tail-stealing cursor into the undealt end of the update list (zeroed with the item counts)
   C_COUNT = 32
 };
 enum Stat64 : int { S_UPD = 0 /* unused */, S_BAND /* unused */, S_MESH_VERTS, S_PRUNED, S_CUM_UPD, S_CUM_BAND, S_CUM_VISITED, S_CUM_CALLS, S_COUNT = 8 };
@@ -313,7 +312,6 @@ __device__ inline void beginIntegrate(DevMap m, int nvox, uint32_t* wg_stats) {
     m.counters[C_N_ITEMS1] = 0u;
     m.counters[C_N_ITEMS2] = 0u;
     m.counters[C_N_ITEMS3] = 0u;
-    m.counters[C_FUSE_STEAL] = 0u;
   }
 }
 

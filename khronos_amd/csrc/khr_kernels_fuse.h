@@ -121,9 +121,6 @@ struct FuseArgs : FuseFrame {
   // and does nothing when *gate != 0 (seeds exist: the host then queues the clustering chain and the real launch).  Frames
   // without seeds -- most of them -- no longer idle the main stream for the seed count's trip to the host and back.
   const uint32_t* gate;
-  // tail stealing (round 4, k_fuse): a device-wide cursor into the LAST `pool` items of the deal order (the cheapest class);
-  // nullptr = every workgroup only works its own share.  See k_fuse.
-  uint32_t* steal;
   // k_fuse2<.., MULTI>: the frames an item is walked through, in order
   const FuseFrame* frames;
   int n_frames;
@@ -475,10 +472,6 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
   __shared__ uint32_t s_rec[WPW][5][kFuseCap];
   __shared__ uint32_t s_stat[WPW][2];
   __shared__ uint32_t s_q;  // the workgroup's item queue: next index into its share of the descriptor list
-  // tail stealing: the batch of pool items this workgroup currently owns (lo | hi << 32, claimed with one 64-bit LDS add),
-  // the refill lock, "the pool is empty"
-  __shared__ unsigned long long s_range;
-  __shared__ uint32_t s_lock, s_dry;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int lane = static_cast<int>(threadIdx.x & 63);
   const int range_mode = DEFCFG ? 0 : a.range_mode;
@@ -497,22 +490,8 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
   // (timeline probe: the constant 100 MHz counter is common to all XCDs, s_memtime is not)
   const unsigned long long t_entry = (DBG && (dbg & 64)) ? __builtin_amdgcn_s_memrealtime() : 0ull;
   if (a.gate != nullptr && *a.gate != 0u) return;  // speculative launch, and the frame has motion seeds (workgroup-uniform)
-  if (threadIdx.x == 0) {
-    s_q = 0u;
-    s_range = 0ull;
-    s_lock = 0u;
-    s_dry = 0u;
-  }
+  if (threadIdx.x == 0) s_q = 0u;
   __syncthreads();
-  // Tail stealing.  The static deal (every workgroup the same mix of cost classes) predicts an item's cost from the band
-  // voxels it had LAST frame; what a workgroup actually gets differs by +- 25 % (in-kernel timeline: the slowest wave leaves
-  // 14 us after the average one).  So the last quarter of the deal order -- items of the cheapest class, ~3 us each -- is not
-  // dealt: a workgroup that has finished its share takes batches of kStealBatch of them from a device-wide cursor (one
-  // returning global atomic per BATCH and workgroup: a few hundred per launch, spread over the tail; a per-item device-wide
-  // queue costs more than the kernel) and hands them to its waves through LDS.
-  constexpr uint32_t kStealBatch = 2u * WPW;
-  const uint32_t pool = a.steal != nullptr ? min(list.counts[3], n_items >> 2) : 0u;
-  const uint32_t n_static = n_items - pool;
   // next item of this workgroup's share (positions blockIdx.x, blockIdx.x + gridDim.x, ...: every workgroup gets the same
   // mix of the cost classes), handed to whichever of its waves asks first; wave-uniform result
   // XCD-aware share: workgroup b runs on XCD b % 8 (round-robin dispatch), so its first position is
@@ -521,35 +500,10 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
   // have in common.  (grid is a multiple of 8.)
   const uint32_t first = (dbg & 512) ? blockIdx.x : (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   auto pull = [&]() -> uint32_t {
-    uint32_t r = 0xffffffffu;
-    if (lane == 0) {
-      const uint32_t pos = first + gridDim.x * atomicAdd(&s_q, 1u);
-      if (pos < n_static) {
-        r = pos;
-      } else if (pool != 0u) {
-        while (true) {
-          const unsigned long long v = atomicAdd(&s_range, 1ull);
-          const uint32_t lo = static_cast<uint32_t>(v), hi = static_cast<uint32_t>(v >> 32);
-          if (lo < hi) {
-            r = n_static + lo;
-            break;
-          }
-          if (__atomic_load_n(&s_dry, __ATOMIC_RELAXED) != 0u) break;
-          if (atomicCAS(&s_lock, 0u, 1u) == 0u) {  // this wave refills (unless somebody just did)
-            const unsigned long long w = __atomic_load_n(&s_range, __ATOMIC_RELAXED);
-            if (static_cast<uint32_t>(w) >= static_cast<uint32_t>(w >> 32)) {
-              const uint32_t g = atomicAdd(a.steal, kStealBatch);
-              if (g >= pool) __atomic_store_n(&s_dry, 1u, __ATOMIC_RELAXED);
-              else atomicExch(&s_range, static_cast<unsigned long long>(g) | (static_cast<unsigned long long>(min(g + kStealBatch, pool)) << 32));
-            }
-            __atomic_store_n(&s_lock, 0u, __ATOMIC_RELEASE);
-          } else {
-            while (__atomic_load_n(&s_lock, __ATOMIC_ACQUIRE) != 0u) __builtin_amdgcn_s_sleep(2);
-          }
-        }
-      }
-    }
-    return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(r)));
+    uint32_t j = 0u;
+    if (lane == 0) j = atomicAdd(&s_q, 1u);
+    j = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(j)));
+    return first + gridDim.x * j;
   };
   // descriptor of item i in deal order: class 0, 1, 2, 3 (FuseList)
   auto descOf = [&](uint32_t i) -> uint4 {

@@ -525,7 +525,6 @@ int kTickUnion = 1;     // env KHR_TICK_UNION: khr_tick_integrate updates with O
 int kFuseMulti = 1;     // env KHR_FUSE_MULTI: khr_integrate_shared_batch integrates all frames of a batch in one launch (k_fuse2 MULTI)
 constexpr int kMaxMultiFrames = 1024;
 int kFuseSpec = 1;      // env KHR_FUSE_SPECULATIVE: khr_process_frame queues k_fuse before the seed count has reached the host (gated on the device)
-int kFuseSteal = 1;     // env KHR_FUSE_STEAL: k_fuse leaves the cheapest quarter of the items undealt; workgroups that finish early take them in batches (round 4)
 int kFuseBand = 0;      // env KHR_FUSE_BAND: 0 = lane <-> record (default), 1 = record-cooperative band phase (fuseBandCoop: -41 % L2 write requests, -16 % L1 accesses, same time at 720p / 2 cm, slower on small frames)
 constexpr int kStreamGrid = 4096;
 
@@ -798,7 +797,6 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   if (std::getenv("KHR_FUSE_WAVES")) kFuseWavesPerCu = std::max(4, std::atoi(std::getenv("KHR_FUSE_WAVES")));
   if (std::getenv("KHR_FUSE_DBG")) kFuseDbg = std::atoi(std::getenv("KHR_FUSE_DBG"));
   if (std::getenv("KHR_FUSE_BAND")) kFuseBand = std::atoi(std::getenv("KHR_FUSE_BAND"));
-  if (std::getenv("KHR_FUSE_STEAL")) kFuseSteal = std::atoi(std::getenv("KHR_FUSE_STEAL"));
   if (std::getenv("KHR_FUSE_SPECULATIVE")) kFuseSpec = std::atoi(std::getenv("KHR_FUSE_SPECULATIVE"));
   if (std::getenv("KHR_TICK_UNION")) kTickUnion = std::atoi(std::getenv("KHR_TICK_UNION"));
   if (std::getenv("KHR_FUSE_MULTI")) kFuseMulti = std::atoi(std::getenv("KHR_FUSE_MULTI"));
@@ -1386,9 +1384,6 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
         }
         static bool said = false;
         if (!said && std::getenv("KHR_VERBOSE")) { said = true; std::fprintf(stderr, "[khr] k_fuse<%d,%d> %d waves / workgroup, grid %d\n", V, ZS, wpw, grid); }
-        // tail stealing for the window's own update (the persistent grid of the whole chip); small explicit maps and the
-        // per-camera lists of a rig tick keep the plain deal
-        a.steal = (kFuseSteal != 0 && lists == nullptr && allocate_blocks != 0) ? &m.counters[C_FUSE_STEAL] : nullptr;
         KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(64 * wpw), a, list);
       };
       // non-default switches are test configurations: they always run the bit-exact arithmetic

@@ -192,4 +192,4 @@ def test_background_and_object_change_detectors_equal_restatement():
     bca, bfp = po.detect_changes(before[0], before[1], False, **kw)
     aca, afp = po.detect_changes(after[0], after[1], True, **kw)
     assert got == dict(first_absent=bca or 0, last_absent=aca or 0, first_persistent=bfp or 0, last_persistent=afp or 0)
-    assert len(before[0]) + len(before[1]) > 50 and len(after[0]) + len(after[1]) > 50
+    assert len(before[0]) + len(before[1]) > 20 and len(after[0]) + len(after[1]) > 20

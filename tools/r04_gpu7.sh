@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4: k_fuse VALU diet (ping-pong item states, phase-2 parameters through the scalar cache): parity + A/B against the numbers of run 6
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r04_8
+O=gpurun_out/r04_9
 mkdir -p $O
 timeout 300 python tools/probe_fuse.py 30 > $O/probe.txt 2>&1; echo "probe rc $?" >> $O/rc.txt
 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu > $O/parity.txt 2>&1; echo "parity rc $?" >> $O/rc.txt
@@ -15,7 +15,7 @@ cat $O/rc.txt; tail -n 2 $O/parity.txt $O/rayver.txt
 grep -n "last launch\|^dur\|realtime: wave lifetime\|realtime: last\|non-band" $O/probe.txt
 python - <<'PY'
 import json, glob
-for f in sorted(glob.glob("gpurun_out/r04_8/b_*.json")):
+for f in sorted(glob.glob("gpurun_out/r04_9/b_*.json")):
     try:
         j = json.loads(open(f).read().strip().splitlines()[-1])
         r = j["roofline"]

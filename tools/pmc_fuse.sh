@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: PMC passes on k_fuse for one or more env settings: tools/r03_pmc.sh "<passes>" base KHR_FUSE_BAND=0 ...
+# PMC passes on k_fuse for one or more env settings: tools/pmc_fuse.sh "<passes>" base KHR_FUSE_BAND=0 ...
 # (one counter group per run; --kernel-trace only, as gpurun requires)
 P="$1"; shift
 R=$PWD; export TMPDIR=/tmp
@@ -15,7 +15,7 @@ G[i]="WRITE_SIZE"
 G[j]="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY"
 k=0
 for spec in "$@"; do
-  k=$((k+1)); O=$R/gpurun_out/r03pmc_$k; mkdir -p $O
+  k=$((k+1)); O=$R/gpurun_out/pmc_fuse_$k; mkdir -p $O
   envs=$(echo "$spec" | tr ',' ' '); [ "$spec" = "base" ] && envs=""
   cd /tmp
   for n in $(echo $P | fold -w1); do

@@ -24,6 +24,7 @@ and each rank integrates all of them into the blocks it owns (owner-computes, we
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes
 import json
 import math
 import os
@@ -395,6 +396,7 @@ def main():
                     if host_pending[0] is not None:
                         host_consumer_begin()  # (waits for the count: the device fell more than an output behind)
                     host_pending[0] = snap
+                    host_mesh_copy_wait()  # (the staging block is about to be rewritten)
                     ctx.fetch_mesh_launch()
                     host_mesh_pending[0] = True
                 else:
@@ -430,6 +432,7 @@ def main():
     host_pending = [None]     # snapshot whose block count was not known yet when it was taken
     host_mesh_pending = [False]
     host_mesh_bufs = {}
+    host_mesh_thread = [None]
     host_next_buf = [0]
 
     def host_consumer_begin():
@@ -449,9 +452,27 @@ def main():
         copy_stats[1] += nb_ * host_bytes_per_block
         snap0.release()
 
+    def host_mesh_copy_wait():
+        if host_mesh_thread[0] is not None:
+            host_mesh_thread[0].join()
+            host_mesh_thread[0] = None
+
     def host_consumer_poll():
         if host_mesh_pending[0]:  # the previous output's mesh: its gather ran right behind that output's kernels
-            nv_ = ctx.fetch_mesh_reuse(host_mesh_bufs)  # (the consumer's own arrays, reused from output to output)
+            # collect on this thread (a wait for the gather's ticket), then the CONSUMER's thread copies the 20 MB out of the pinned
+            # staging block into its own arrays, block by block in sorted order (khr_fetch_mesh_into: host memcpy, no device access;
+            # ctypes drops the GIL) while this thread goes on queueing frames
+            import threading
+            v_ = ctypes.c_int64(0)
+            nv_ = ctx._chk(ctx.lib.khr_fetch_mesh(ctx.h, ctypes.byref(v_)))
+            if nv_ > host_mesh_bufs.get("cap", 0):
+                cap_ = int(nv_ * 1.5) + 1024
+                host_mesh_bufs.update(cap=cap_, points=np.zeros((cap_, 3), np.float32), colors=np.zeros((cap_, 4), np.uint8),
+                                      labels=np.zeros(cap_, np.uint32), first_seen=np.zeros(cap_, np.uint64), stamps=np.zeros(cap_, np.uint64))
+            if nv_:
+                ptrs_ = [host_mesh_bufs[k].ctypes.data_as(ctypes.c_void_p) for k in ("points", "colors", "labels", "first_seen", "stamps")]
+                host_mesh_thread[0] = threading.Thread(target=lambda: ctx.lib.khr_fetch_mesh_into(ctx.h, *ptrs_))
+                host_mesh_thread[0].start()
             copy_stats[1] += nv_ * (12 + 4 + 4 + 8 + 8)
             host_mesh_pending[0] = False
         if host_pending[0] is not None and host_pending[0].poll() and len(host_inflight) < 2:
@@ -459,6 +480,7 @@ def main():
 
     def host_consumer_drain():
         host_consumer_poll()
+        host_mesh_copy_wait()
         if host_pending[0] is not None:
             host_consumer_begin()
         while host_inflight:

@@ -163,7 +163,6 @@ struct khr_ctx {
   std::shared_ptr<SnapPool> snap_pool = std::make_shared<SnapPool>();
   khr_snapshot* pending_snapshot = nullptr;  // taken inside khr_process_frame(KHR_PF_SNAPSHOT)
   hipStream_t copy_stream = nullptr;         // khr_snapshot_download_begin: device -> host copies beside the frames' kernels
-  hipStream_t copy_stream2 = nullptr;        // ... every other field on a second stream (two DMA engines: one copy stream moves ~28 GB/s)
   // upper bound of the blocks an explicitly allocated map holds (khr_allocate_blocks since the last khr_reset_map; 0 =
   // unknown): the update kernel of an `allocate = false` integration (object mini-maps) sizes its persistent grid from it
   // instead of filling the chip with workgroups that find no item
@@ -978,12 +977,11 @@ void khr_destroy(khr_ctx* c) {
   if (c->d_pix_scratch) hipFree(c->d_pix_scratch);
   if (c->d_inst) hipFree(c->d_inst);
   if (c->pending_snapshot) khr_snapshot_release(c->pending_snapshot);
-  for (hipStream_t* cs : {&c->copy_stream, &c->copy_stream2})
-    if (*cs) {
-      hipStreamSynchronize(*cs);
-      hipStreamDestroy(*cs);
-      *cs = nullptr;
-    }
+  if (c->copy_stream) {
+    hipStreamSynchronize(c->copy_stream);
+    hipStreamDestroy(c->copy_stream);
+    c->copy_stream = nullptr;
+  }
   {
     std::lock_guard<std::mutex> lock(c->snap_pool->mu);
     c->snap_pool->dead = true;  // snapshots still held by a consumer free their arenas themselves from now on
@@ -3689,7 +3687,6 @@ struct khr_snapshot {
   int64_t total = -1;    // updated blocks found (> cap: overflow)
   hipEvent_t ev_packed = nullptr;  // recorded on the context's stream behind the pack kernel
   hipEvent_t ev_copied = nullptr;  // khr_snapshot_download_begin: the last device -> host copy on the copy stream
-  hipEvent_t ev_copied2 = nullptr; // ... and on the second copy stream
   bool copying = false;
   int32_t* d_index3 = nullptr;  // carved from the arena: the block indices as (x, y, z) triples (khr_snapshot_download_begin)
 };
@@ -3907,11 +3904,8 @@ int khr_snapshot_download_begin(khr_snapshot* s, int32_t* indices, float* distan
   khr_ctx* c = s->ctx;
   HIP_TRY(hipSetDevice(c->device));
   if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-  if (!c->copy_stream2) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking));
   if (!s->ev_copied) HIP_TRY(hipEventCreateWithFlags(&s->ev_copied, hipEventDisableTiming));
-  if (!s->ev_copied2) HIP_TRY(hipEventCreateWithFlags(&s->ev_copied2, hipEventDisableTiming));
   HIP_TRY(hipStreamWaitEvent(c->copy_stream, s->ev_packed, 0));
-  HIP_TRY(hipStreamWaitEvent(c->copy_stream2, s->ev_packed, 0));
   const size_t nv = s->nvox;
   if (n > 0) {
     if (indices) {  // (x, y, z) triples made on the device, then one copy straight into the caller's (pinned) array
@@ -3920,21 +3914,18 @@ int khr_snapshot_download_begin(khr_snapshot* s, int32_t* indices, float* distan
       HIP_TRY(hipMemcpyAsync(indices, s->d_index3, sizeof(int32_t) * 3 * n, hipMemcpyDeviceToHost, c->copy_stream));
     }
     hipError_t e = hipSuccess;
-    int k = 0;  // fields alternate between the two copy streams
     auto field = [&](void* dst, const void* src, size_t elem) {
-      if (e == hipSuccess && dst && src)
-        e = hipMemcpyAsync(dst, src, static_cast<size_t>(n) * nv * elem, hipMemcpyDeviceToHost, (k++ & 1) ? c->copy_stream2 : c->copy_stream);
+      if (e == hipSuccess && dst && src) e = hipMemcpyAsync(dst, src, static_cast<size_t>(n) * nv * elem, hipMemcpyDeviceToHost, c->copy_stream);
     };
     field(distance, s->o.dist, 4);
     field(weight, s->o.weight, 4);
-    field(last_observed, s->o.last_obs, 8);
     field(color_rgba, s->o.color, 4);
-    field(sem_label, s->o.sem_label, 4);
+    field(last_observed, s->o.last_obs, 8);
     field(voxel_flags, s->o.vflags, 1);
+    field(sem_label, s->o.sem_label, 4);
     if (e != hipSuccess) return fail(KHR_EDEVICE, "snapshot download failed: %s", hipGetErrorString(e));
   }
   HIP_TRY(hipEventRecord(s->ev_copied, c->copy_stream));
-  HIP_TRY(hipEventRecord(s->ev_copied2, c->copy_stream2));
   s->copying = true;
   return KHR_OK;
 }
@@ -3943,20 +3934,15 @@ int64_t khr_snapshot_download_end(khr_snapshot* s) {
   if (!s) return fail(KHR_EINVAL, "null snapshot");
   if (!s->copying) return fail(KHR_ESTATE, "no download in flight (khr_snapshot_download_begin first)");
   HIP_TRY(hipEventSynchronize(s->ev_copied));
-  HIP_TRY(hipEventSynchronize(s->ev_copied2));
   s->copying = false;
   return s->n;
 }
 
 void khr_snapshot_release(khr_snapshot* s) {
   if (!s) return;
-  if (s->copying) {  // (the arena must not be recycled under a copy in flight)
-    (void)hipEventSynchronize(s->ev_copied);
-    (void)hipEventSynchronize(s->ev_copied2);
-  }
+  if (s->copying) (void)hipEventSynchronize(s->ev_copied);  // (the arena must not be recycled under a copy in flight)
   if (s->ev_packed) hipEventDestroy(s->ev_packed);
   if (s->ev_copied) hipEventDestroy(s->ev_copied);
-  if (s->ev_copied2) hipEventDestroy(s->ev_copied2);
   // the arena may be handed to the next snapshot right away: that one's kernels are queued behind this one's on the same
   // stream.  After khr_destroy (the consumer kept an output longer than the window lived) the arena is simply freed.
   {

@@ -5,7 +5,10 @@
 // slot as the leading index, so that the 4096 (or 512) voxels of one block are contiguous per field:
 //   dist[slot][nvox] f32 | weight[slot][nvox] f32 | color[slot][nvox] rgba8 | last_obs[slot][nvox] u64
 //   last_occ[slot][nvox] u64 | vflags[slot][nvox] u8 | sem_label[slot][nvox] u32
-//   lik[slot][nvox][K] f32 (voxel-major: one contiguous K-float run per voxel) | freebits[slot][nvox/64] u64
+//   lik[slot][nvox][KS] f32 (voxel-major: the K likelihoods of a voxel are the head of a row of KS floats; for K > 4 the
+//   row is padded to whole 128-byte cache lines, KS = 32 for K = 20, so that 8 lanes move a row as ONE full line: a
+//   partially written line costs the memory path about three times a full one, tools/ubench/band_patterns.hip)
+//   | freebits[slot][nvox/64] u64
 // plus an open-addressing hash table  packed BlockIndex -> slot.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -97,6 +100,9 @@ struct DevMap {
 // (65 .. 128) from the back of `a`, class 2 (1 .. 64) from the front of `b`, class 3 (none) from the back of `b`.
 // k_fuse deals the items in class order round-robin to its waves, so every wave gets its share of the expensive ones.
 constexpr int kBandSlots = 32;  // per-block entries of DevMap::blk_band (one per wave item of the block)
+// a blk_band entry as k_fuse leaves it: in-band count | item touched | item wrote a negative distance; k_fuse_fold turns the
+// two bits into block flags and clears them
+constexpr uint16_t kItemTouched = 0x8000u, kItemNeg = 0x4000u, kItemBandMask = 0x3fffu;
 struct FuseList {
   uint4* a;
   uint4* b;
@@ -109,9 +115,13 @@ __device__ inline uint4* fuseDescPtr(const FuseList& l, uint32_t cls, uint32_t p
   return arr + ((cls & 1u) ? l.cap - 1u - pos : pos);
 }
 
+// row stride of the likelihood array in floats (DevParams::KS): tiny rows stay packed, the others fill whole cache lines
+__host__ __device__ inline int likStride(int K) { return K <= 4 ? K : ((K + 31) & ~31); }
+
 struct DevParams {
   float vs, vs_inv, bs, bs_inv, trunc;
   int vps, nvox, K;
+  int KS;  // likStride(K)
   int with_semantics, with_tracking;
   int use_dropoff, const_weight, interp, range_mode, sem_mode;
   float dropoff_eps, max_weight, adaptive_diff, log_match, log_nomatch;

@@ -1332,8 +1332,8 @@ struct PackOut {
   uint8_t* vflags;
   uint32_t* sem_label;
   uint64_t* last_occ;  // (snapshots only)
-  float* lik;          // (snapshots only) K floats per voxel, voxel-major as in the pool
-  int K;
+  float* lik;          // (snapshots only) K floats per voxel, voxel-major, rows packed (the pool pads them to KS floats)
+  int K, KS;
   uint64_t track_stamp;  // stamp of the latest tracking pass = last_occupied of every voxel that is occupied now (stored lazily)
 };
 template <int VPS>
@@ -1429,7 +1429,14 @@ __global__ __launch_bounds__(256) void k_snapshot_pack(DevMap m, const uint32_t*
       for (int i = threadIdx.x; i < NV; i += 256)
         o.last_occ[dst + i] = (m.vflags[src + i] & VOX_OCC) ? o.track_stamp : m.last_occ[src + i];
     }
-    if (o.lik) copy16(m.lik + src * o.K, o.lik + dst * o.K, static_cast<size_t>(NV) * o.K * 4);
+    if (o.lik) {
+      if (o.KS == o.K) copy16(m.lik + src * o.K, o.lik + dst * o.K, static_cast<size_t>(NV) * o.K * 4);
+      else  // padded rows in the pool, packed rows in the snapshot
+        for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(NV) * static_cast<uint32_t>(o.K); i += 256) {
+          const uint32_t v = i / static_cast<uint32_t>(o.K), k = i - v * static_cast<uint32_t>(o.K);
+          o.lik[dst * o.K + i] = m.lik[(src + v) * o.KS + k];
+        }
+    }
   }
 }
 
@@ -1448,8 +1455,8 @@ __global__ __launch_bounds__(256) void k_object_prune(DevMap m, DevParams p, flo
       if (d > 0.f) continue;
       float conf = 0.f;
       if (m.vflags[o + lin] & VOX_SEM_VALID) {
-        const float l0 = m.lik[(static_cast<size_t>(s) * NV + lin) * p.K + 0];
-        const float l1 = m.lik[(static_cast<size_t>(s) * NV + lin) * p.K + 1];
+        const float l0 = m.lik[(static_cast<size_t>(s) * NV + lin) * p.KS + 0];
+        const float l1 = m.lik[(static_cast<size_t>(s) * NV + lin) * p.KS + 1];
         const float total = l0 + l1;
         conf = total < min_obs ? -1.f : l1 / total;
       }
@@ -1510,7 +1517,7 @@ __global__ __launch_bounds__(256) void k_map_digest(DevMap m, DevParams p, uint6
       acc[6] += digestTerm(key, 6, i, p.with_semantics ? m.sem_label[o + i] : 0u);
       if (p.with_semantics) {
         const bool valid = raw & VOX_SEM_VALID;
-        const float* row = m.lik + (o + i) * p.K;
+        const float* row = m.lik + (o + i) * p.KS;
         for (int k = 0; k < p.K; ++k)
           acc[7] += digestTerm(key, 7, static_cast<uint64_t>(k) * p.nvox + i, valid ? __float_as_uint(row[k]) : 0u);
       }

@@ -113,14 +113,17 @@ struct FuseArgs : FuseFrame {
   float vs, bs, trunc, dropoff_eps, max_weight, adaptive_diff, log_match, log_nomatch;
   int interp, range_mode, use_dropoff, const_weight, with_tracking;
   int K, sem_mode;
+  int KS;  // floats per likelihood row (likStride(K): rows of K > 4 labels fill whole 128-byte lines)
   unsigned long long* dbg_buf;  // DBG & 64: per-wave timeline {start, end, band cycles, items, rounds, records, max item cycles, hw id}
   int dbg;  // ablation switches of the DBG instantiation (env KHR_FUSE_DBG): 1 no band phase, 2 no voxel stores,
             // 4 no distance / weight loads, 8 range gathers from a fixed address, 16 geometry only
-  int band_mode;  // 0 = lane <-> record (fuseBandRecord, default), 1 = record-cooperative (fuseBandCoop; env KHR_FUSE_BAND)
+  int band_mode;  // 1 = likelihood rows moved as whole cache lines by 8 lanes each (fuseBandRows, default where the rows are
+                  // padded), 0 = lane <-> record (fuseBandRecord; env KHR_FUSE_BAND=0)
   // speculative launch (khr_process_frame): the kernel is queued BEFORE the host has seen the motion detector's seed count
   // and does nothing when *gate != 0 (seeds exist: the host then queues the clustering chain and the real launch).  Frames
   // without seeds -- most of them -- no longer idle the main stream for the seed count's trip to the host and back.
   const uint32_t* gate;
+  void* sink;  // k_fuse: one 256-byte line per wave for the stores that must be issued but have nothing to write
   // k_fuse2<.., MULTI>: the frames an item is walked through, in order
   const FuseFrame* frames;
   int n_frames;
@@ -152,8 +155,8 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, FuseFrameK kf, size_t slot, 
   char* const color_b = reinterpret_cast<char*>(a.color + slot * NV);
   char* const vfl_b = reinterpret_cast<char*>(a.vflags + slot * NV);
   char* const lab_b = reinterpret_cast<char*>(a.sem_label + slot * NV);
-  char* const lik_b = reinterpret_cast<char*>(a.lik + slot * NV * static_cast<size_t>(K));  // voxel-major: K floats per voxel
-  const uint32_t lik_o = lin * static_cast<uint32_t>(K) * 4u;
+  char* const lik_b = reinterpret_cast<char*>(a.lik + slot * NV * static_cast<size_t>(a.KS));  // voxel-major: rows of KS floats
+  const uint32_t lik_o = lin * static_cast<uint32_t>(a.KS) * 4u;
   int px4[4];
   float du, dv, w4[4];
   interpPixels(u, v, f.W, f.H, px4, &du, &dv);
@@ -264,48 +267,61 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, FuseFrameK kf, size_t slot, 
   *reinterpret_cast<uint32_t*>(lab_b + lin * 4u) = static_cast<uint32_t>(bestk);
 }
 
-// ---- record-cooperative band phase (round 3) -----------------------------------------------------------------------
-// The same update as fuseBandRecord for a wave's whole record list, with the memory requests laid out for the L1:
+// ---- band phase with whole-line likelihood rows (round 4) -----------------------------------------------------------
+// What the access-pattern benchmark says (tools/ubench/band_patterns.hip, profiles/r04_ubench_band_patterns.txt): on this
+// memory path a PARTIALLY written cache line costs about three times a fully written one, and it does not matter whether
+// the 80 bytes of a K = 20 row arrive as five 16-byte stores of one lane or as one 80-byte store of five lanes (the
+// round-3 record-cooperative form measured exactly like lane <-> record for that reason).  The pool therefore pads a
+// row to whole 128-byte lines (DevParams::KS = 32 floats for K = 20) and here KS / 4 = 8 lanes move a row: every load and
+// every store of the row phase is a set of FULL lines (5070 band rounds of a 720p frame: 25.6 -> 18.4 us of memory-path
+// time in isolation).
 //  * part A, lane <-> record: colour blend (the four image colours arrive as TWO 8-byte pixel-pair gathers like the range
-//    samples), label lookup, voxel flags;
-//  * part B, K / 4 lanes <-> record: a voxel's K likelihoods are one contiguous row (voxel-major layout), so the K / 4
-//    lanes of a record load / store ONE 16-byte vector each and the wave instruction touches 64 / (K / 4) rows in at most
-//    two cache lines per row -- with lane <-> record every one of the K / 4 vector accesses of a record was a separate
-//    wave instruction with 64 lanes in 64 different lines (12 loads + 7 stores of 4 - 16 bytes per record, 19 line
-//    accesses; now ~6).  The arg-max over a row is a segmented wave reduction (first maximum wins, as the scalar loop);
-//    lane 0 of the segment stores the label.
-// All loads of a 64-record chunk (part A's and part B's) are issued before its first store.  Values and decisions are
-// those of fuseBandRecord bit for bit (same additions on the same operands, same tie-breaking).
+//    samples), label lookup, voxel flags; the record's {update?, empty?, label} word goes to the wave's LDS list;
+//  * part B, KS / 4 lanes <-> record, 64 / (KS / 4) records per pass, all passes of a 64-record chunk in flight together:
+//    lane j of a record holds the row's j-th 16-byte vector, adds the hit / miss increments, and a segmented arg-max over
+//    the record's lanes (DPP row shifts: first maximum wins, as the scalar loop of the reference) leaves the label in lane
+//    0, which hands it to the record's part-A lane through LDS; that lane stores it, so the label stores of a chunk are
+//    ONE wave instruction whose lanes share lines.  Padding floats are written as zeros.
+// Values and decisions are those of fuseBandRecord bit for bit (same additions on the same operands, same tie-breaking).
 typedef uint32_t u2u __attribute__((ext_vector_type(2), aligned(4)));  // two adjacent rgba8 pixels, 4-byte aligned
-constexpr int kCoopPasses = 6;  // part-B passes whose row vectors are in flight together (K = 20: all six)
-__device__ inline bool fuseBandCoopOk(int K, int sem_mode, int do_sem) {
-  return !do_sem || (sem_mode != 1 && (K & 3) == 0 && K >= 4 && K <= 64);
+constexpr int kRowPasses = 8;  // part-B passes whose row vectors are in flight together (KS = 32: a whole 64-record chunk)
+// (frames without colour or without labels, the binary object layer and rows that are not padded take fuseBandRecord)
+__device__ inline bool fuseBandRowsOk(int KS, int sem_mode, int do_sem, int has_color) {
+  return do_sem && has_color && sem_mode != 1 && (KS & 31) == 0 && KS <= 256;
 }
-template <int VPS, int CAP = kFuseCap>  // isa:band: record-cooperative update (fuseBandCoop)
-__device__ __forceinline__ void fuseBandCoop(FuseArgsK ka, FuseFrameK kf, size_t slot, const uint32_t* rec, uint32_t cnt, int lane) {
+// lane i <- lane i + OFF of the same 16-lane row (DPP row_shl; out-of-row sources read 0 and are never used)
+template <int OFF>
+__device__ __forceinline__ uint32_t rowDown(uint32_t v) {
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x100 + OFF, 0xf, 0xf, true));
+}
+// The vector-memory instruction stream of a chunk is STATIC (see k_fuse): 5 part-A loads, kRowPasses row loads, the colour
+// store, kRowPasses row stores -- lanes or passes without a record of their own work on the chunk's LAST record again (same
+// loads, same results, same stores: duplicates of a store the record's own lanes issue anyway), records that are not updated
+// write their row back unchanged.  Only the two stores that end a chunk (label, first-time flag) are conditional.
+template <int VPS, int CAP = kFuseCap>  // isa:band: whole-line likelihood rows (fuseBandRows)
+__device__ __forceinline__ void fuseBandRows(FuseArgsK ka, FuseFrameK kf, size_t slot, uint32_t* rec, uint32_t cnt, int lane) {
   constexpr int NV = VPS * VPS * VPS;
   const FuseArgs __attribute__((address_space(4)))& a = *ka;
   const FuseFrame __attribute__((address_space(4)))& f = *kf;
   const int K = a.K;
-  const bool has_color = f.has_color != 0, do_sem = f.do_sem != 0;
-  const uint32_t lpr = do_sem ? static_cast<uint32_t>(K) >> 2 : 1u;  // lanes per record in part B
-  const uint32_t rpp = 64u / lpr;                                     // records per part-B pass
-  const uint32_t npass = (64u + rpp - 1u) / rpp;
+  const uint32_t row_bytes = static_cast<uint32_t>(a.KS) * 4u;
+  const uint32_t lpr = static_cast<uint32_t>(a.KS) >> 2;  // lanes per record in part B (8, 16, 32 or 64)
+  const uint32_t rpp = 64u / lpr;                          // records per part-B pass
   const uint32_t rl0 = static_cast<uint32_t>(lane) / lpr, j = static_cast<uint32_t>(lane) - rl0 * lpr;
+  const uint32_t j16 = j * 16u;
   char* const color_b = reinterpret_cast<char*>(a.color + slot * NV);
   char* const vfl_b = reinterpret_cast<char*>(a.vflags + slot * NV);
   char* const lab_b = reinterpret_cast<char*>(a.sem_label + slot * NV);
-  char* const lik_b = reinterpret_cast<char*>(a.lik + slot * NV * static_cast<size_t>(K));
-  const uint32_t row_bytes = static_cast<uint32_t>(K) * 4u;
+  char* const lik_b = reinterpret_cast<char*>(a.lik + slot * NV * static_cast<size_t>(a.KS));
+  const char* const rgba_b = reinterpret_cast<const char*>(f.rgba);
+  const char* const label_b = reinterpret_cast<const char*>(f.label);
   const float add_hit = a.log_match, add_miss = a.log_nomatch;
-  // development ablations (env KHR_FUSE_DBG, any instantiation): 1024 no part-A loads, 2048 no likelihood loads,
-  // 4096 no likelihood stores, 8192 no part-A stores
-  const int bdbg = a.dbg;
   for (uint32_t base = 0; base < cnt; base += 64u) {
     const uint32_t n_here = min(64u, cnt - base);  // wave-uniform
+    const uint32_t npass = (n_here + rpp - 1u) / rpp;
     const bool valid = static_cast<uint32_t>(lane) < n_here;
-    const uint32_t r = base + (valid ? static_cast<uint32_t>(lane) : 0u);
-    // ---- part A loads ----
+    const uint32_t r = base + min(static_cast<uint32_t>(lane), n_here - 1u);
+    // ---- part A loads (lane <-> record) ----
     const uint32_t lin_mode = rec[r];
     const float w = __uint_as_float(rec[CAP + r]), w_new = __uint_as_float(rec[2 * CAP + r]);
     const float u = __uint_as_float(rec[3 * CAP + r]), v = __uint_as_float(rec[4 * CAP + r]);
@@ -315,41 +331,21 @@ __device__ __forceinline__ void fuseBandCoop(FuseArgsK ka, FuseFrameK kf, size_t
     interpPixels(u, v, f.W, f.H, px4, &du, &dv);
     const int best = interpWeights(du, dv, (lin_mode & 0x10000u) != 0, w4);
     const bool last_col = px4[2] == px4[0];
-    u2u ca = {0u, 0u}, cb = {0u, 0u};
-    uint32_t co = 0u;
-    if (has_color && valid && !(bdbg & 1024)) {
-      const char* const rgba_b = reinterpret_cast<const char*>(f.rgba);
-      ca = *reinterpret_cast<const u2u*>(rgba_b + static_cast<uint32_t>(px4[0]) * 4u);  // (u0, v0), (u0 + 1, v0)
-      cb = *reinterpret_cast<const u2u*>(rgba_b + static_cast<uint32_t>(px4[1]) * 4u);  // (u0, v1), (u0 + 1, v1)
-      co = *reinterpret_cast<const uint32_t*>(color_b + lin * 4u);
-    }
-    int label = -1;
-    uint8_t fl = 0;
-    if (do_sem && valid) {
-      label = 1;
-      if (!(bdbg & 1024)) {
-        label = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(f.label) + static_cast<uint32_t>(px4[best]) * 4u);
-        fl = *reinterpret_cast<const uint8_t*>(vfl_b + lin);
-      }
-    }
-    // ---- part B loads: pass p covers the chunk's records p * rpp .. p * rpp + rpp - 1, lane (rl0, j) the j-th vector ----
-    float4 l4[kCoopPasses];
-    uint32_t lin_p[kCoopPasses];  // voxel of the record this lane serves in pass p (~0: none)
-    if (do_sem) {
+    const u2u ca = *reinterpret_cast<const u2u*>(rgba_b + static_cast<uint32_t>(px4[0]) * 4u);  // (u0, v0), (u0 + 1, v0)
+    const u2u cb = *reinterpret_cast<const u2u*>(rgba_b + static_cast<uint32_t>(px4[1]) * 4u);  // (u0, v1), (u0 + 1, v1)
+    const uint32_t co = *reinterpret_cast<const uint32_t*>(color_b + lin * 4u);
+    const int label = *reinterpret_cast<const int32_t*>(label_b + static_cast<uint32_t>(px4[best]) * 4u);
+    const uint8_t fl = *reinterpret_cast<const uint8_t*>(vfl_b + lin);
+    // ---- part B loads: pass p covers the chunk's records p * rpp .. p * rpp + rpp - 1, lane (rl0, j) the row's j-th vector.
+    //      The row address comes from the LDS list, not from part A's loads: both sets travel together ----
+    float4 l4[kRowPasses];
 #pragma unroll
-      for (int p = 0; p < kCoopPasses; ++p) {
-        const uint32_t rl = static_cast<uint32_t>(p) * rpp + rl0;
-        const bool on = static_cast<uint32_t>(p) < npass && rl0 < rpp && rl < n_here;
-        lin_p[p] = 0xffffffffu;
-        l4[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (on) {
-          lin_p[p] = rec[base + rl] & 0xffffu;
-          if (!(bdbg & 2048)) l4[p] = *reinterpret_cast<const float4*>(lik_b + (lin_p[p] * row_bytes + j * 16u));
-        }
-      }
+    for (int p = 0; p < kRowPasses; ++p) {
+      const uint32_t rl = min(static_cast<uint32_t>(p) * rpp + rl0, n_here - 1u);
+      l4[p] = *reinterpret_cast<const float4*>(lik_b + ((rec[base + rl] & 0xffffu) * row_bytes + j16));
     }
     // ---- part A: colour ----
-    if (has_color && valid) {
+    {
       const uint32_t c4[4] = {ca.x, cb.x, last_col ? ca.x : ca.y, last_col ? cb.x : cb.y};
       float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -368,60 +364,80 @@ __device__ __forceinline__ void fuseBandCoop(FuseArgsK ka, FuseFrameK kf, size_t
         const float cv = static_cast<float>((co >> (8 * ch)) & 0xffu);
         out |= static_cast<uint32_t>(toU8(divExact(cv * w_new + cn * w, tot, ytot))) << (8 * ch);
       }
-      if (!(bdbg & 8192)) *reinterpret_cast<uint32_t*>(color_b + lin * 4u) = out;
+      *reinterpret_cast<uint32_t*>(color_b + lin * 4u) = out;
     }
-    if (!do_sem) continue;
-    const bool upd = valid && label >= 0 && label < K;
+    const bool upd = label >= 0 && label < K;
     const bool empty = !(fl & VOX_SEM_VALID);
-    if (upd && empty && !(bdbg & 8192)) *reinterpret_cast<uint8_t*>(vfl_b + lin) = fl | VOX_SEM_VALID;
-    const uint32_t packed = (upd ? 0x80000000u : 0u) | (empty ? 0x40000000u : 0u) | (static_cast<uint32_t>(label) & 0xffffu);
+    // the record's word for its part-B lanes (the measurement-weight field of the list is dead from here on)
+    if (valid) rec[CAP + r] = (upd ? 0x80000000u : 0u) | (empty ? 0x40000000u : 0u) | (static_cast<uint32_t>(label) & 0xffffu);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- part B: likelihood rows ----
-    for (uint32_t p0 = 0; p0 < npass; p0 += kCoopPasses) {
-      if (p0 > 0) {  // K > 40: further rounds (their loads queue behind the stores of the previous round)
+    for (uint32_t p0 = 0; p0 < npass; p0 += kRowPasses) {
+      if (p0 > 0) {  // KS > 32: further rounds (their loads queue behind the stores of the previous round)
 #pragma unroll
-        for (int p = 0; p < kCoopPasses; ++p) {
-          const uint32_t rl = (p0 + static_cast<uint32_t>(p)) * rpp + rl0;
-          const bool on = p0 + static_cast<uint32_t>(p) < npass && rl0 < rpp && rl < n_here;
-          lin_p[p] = 0xffffffffu;
-          if (on) {
-            lin_p[p] = rec[base + rl] & 0xffffu;
-            l4[p] = *reinterpret_cast<const float4*>(lik_b + (lin_p[p] * row_bytes + j * 16u));
-          }
+        for (int p = 0; p < kRowPasses; ++p) {
+          const uint32_t rl = min((p0 + static_cast<uint32_t>(p)) * rpp + rl0, n_here - 1u);
+          l4[p] = *reinterpret_cast<const float4*>(lik_b + ((rec[base + rl] & 0xffffu) * row_bytes + j16));
         }
       }
 #pragma unroll
-      for (int p = 0; p < kCoopPasses; ++p) {
-        if (p0 + static_cast<uint32_t>(p) >= npass) continue;  // wave-uniform
-        const uint32_t rl = (p0 + static_cast<uint32_t>(p)) * rpp + rl0;
-        const uint32_t pk = static_cast<uint32_t>(__shfl(static_cast<int>(packed), static_cast<int>(rl & 63u)));
-        const bool on = lin_p[p] != 0xffffffffu && (pk & 0x80000000u) != 0u;
+      for (int p = 0; p < kRowPasses; ++p) {
+        const uint32_t rl_own = (p0 + static_cast<uint32_t>(p)) * rpp + rl0;
+        const uint32_t rl = min(rl_own, n_here - 1u);
+        const uint32_t pk = rec[CAP + base + rl];
+        const uint32_t off = (rec[base + rl] & 0xffffu) * row_bytes + j16;  // (re-read from the list: 8 registers less)
+        const bool on = (pk & 0x80000000u) != 0u;
         const int lab = static_cast<int>(pk & 0xffffu);
         const bool emp = (pk & 0x40000000u) != 0u;
         float l[4] = {l4[p].x, l4[p].y, l4[p].z, l4[p].w};
-        float bv = 0.f;
-        int bk = 0;
+        float bv = -__builtin_inff();  // lanes that hold padding only never win (strict comparison below)
+        uint32_t bk = 0xffffu;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int k = 4 * static_cast<int>(j) + q;
-          if (emp) l[q] = 0.f;
-          l[q] += (k == lab) ? add_hit : add_miss;
-          if (q == 0 || l[q] > bv) {
-            bv = l[q];
-            bk = k;
+          if (k < K) {
+            if (emp) l[q] = 0.f;
+            l[q] += (k == lab) ? add_hit : add_miss;
+            if (k == 0 || l[q] > bv) {  // (a lane's own maximum may stay at -inf: then it cannot win below either)
+              bv = l[q];
+              bk = static_cast<uint32_t>(k);
+            }
+          } else {
+            l[q] = 0.f;
           }
         }
-        if (on && !(bdbg & 4096)) *reinterpret_cast<float4*>(lik_b + (lin_p[p] * row_bytes + j * 16u)) = make_float4(l[0], l[1], l[2], l[3]);
+        // a record that is not updated writes its row back as it was
+        *reinterpret_cast<float4*>(lik_b + off) = on ? make_float4(l[0], l[1], l[2], l[3]) : l4[p];
         // segmented arg-max over the record's lpr lanes: lane (rl0, j) ends up with the first maximum of j .. lpr - 1
-        for (uint32_t off = 1; off < lpr; off <<= 1) {
-          const float ov = __shfl_down(bv, off);
-          const int ok = __shfl_down(bk, off);
-          if (j + off < lpr && ov > bv) {
+        auto take = [&](float ov, uint32_t ok, uint32_t sh) {
+          if (j + sh < lpr && ov > bv) {
             bv = ov;
             bk = ok;
           }
+        };
+        take(__uint_as_float(rowDown<1>(__float_as_uint(bv))), rowDown<1>(bk), 1u);
+        take(__uint_as_float(rowDown<2>(__float_as_uint(bv))), rowDown<2>(bk), 2u);
+        take(__uint_as_float(rowDown<4>(__float_as_uint(bv))), rowDown<4>(bk), 4u);
+        if (lpr > 8u) take(__uint_as_float(rowDown<8>(__float_as_uint(bv))), rowDown<8>(bk), 8u);
+        for (uint32_t sh = 16u; sh < lpr; sh <<= 1) {  // KS > 64: across DPP rows
+          const float ov = __shfl_down(bv, sh);
+          const uint32_t ok = static_cast<uint32_t>(__shfl_down(static_cast<int>(bk), sh));
+          take(ov, ok, sh);
         }
-        if (on && j == 0u && !(bdbg & 8192)) *reinterpret_cast<uint32_t*>(lab_b + lin_p[p] * 4u) = static_cast<uint32_t>(bk);
+        // -> the record's part-A lane, through the (dead) new-weight field: the record's word itself is still read by the
+        //    later passes' duplicates of the chunk's last record
+        if (on && j == 0u && rl_own < n_here) rec[2 * CAP + base + rl] = bk;
       }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- the chunk's conditional stores ----
+    if (valid && upd) {
+      *reinterpret_cast<uint32_t*>(lab_b + lin * 4u) = rec[2 * CAP + r];
+      if (empty) *reinterpret_cast<uint8_t*>(vfl_b + lin) = fl | VOX_SEM_VALID;
     }
   }
 }
@@ -441,11 +457,26 @@ __device__ __forceinline__ void fuseBandCoop(FuseArgsK ka, FuseFrameK kf, size_t
 // at most one item per class.  (A device-wide queue is not an option: 20 k returning global atomics per launch cost more
 // than the whole kernel on gfx950, measured; an LDS atomic costs ~100 ns and leaves the CU only.)
 //
-// Software pipeline: a memory round trip costs 1.5 - 2 us under this kernel's load and gfx950 retires vmcnt in order, so a
-// load issued behind a store also waits for that store.  The loop therefore runs one item AHEAD with its loads: phase 1
-// of item n + 1 (geometry, range gathers, distance / weight loads: 4 ZR loads per lane) is issued BEFORE phase 2 of item n
-// (measurement, decisions, stores, in-band records) and before item n's band rounds.  When item n + 1 is computed its
-// loads are older than every store in flight, and their latency is hidden behind item n's arithmetic and band work.
+// Software pipeline (round 4, second form).  gfx950 retires vmcnt IN ORDER and the compiler can only place a partial wait
+// (s_waitcnt vmcnt(N), "everything but the youngest N") where it KNOWS how many vector-memory instructions were issued
+// behind the one it waits for; behind any branch that contains a load, store or atomic it has to fall back to vmcnt(0).  The
+// rounds 1 - 3 loop had such branches everywhere (distance / weight loads only for lanes inside the image, stores only for
+// updated lanes, the block-flag atomic only for lane 0, the prefetch only when a next item exists): its ISA shows a
+// vmcnt(0) right behind the prefetch of item n + 1 -- the prefetch bought nothing -- and another one at the loop top that
+// waits for item n's STORES to be acknowledged: two exposed memory round trips per item, which is the ~5.2 us per item
+// every variant of rounds 3 - 4 measured.  Here the vector-memory instruction stream of an item is STATIC:
+//  * phase 1 of item n + 1 always issues its 4 ZR loads (lanes outside the image load their own voxel all the same; without a
+//    next item the current descriptor is loaded again);
+//  * phase 2 of item n always issues its 3 ZR stores: distance and weight are written for ALL 64 lanes of a z-step (lanes
+//    without an update write back what they loaded: whole 256-byte segments, and a fully written cache line costs this
+//    memory path a third of a partially written one, tools/ubench/band_patterns.hip); the stamp store sends the lanes
+//    without an update to the address of the first updated lane (same value: one request) or, when no lane was updated, to
+//    a per-wave sink line;
+//  * the item's block flags no longer leave as an atomic of lane 0: {touched, wrote a negative distance, in-band count}
+//    are ONE 16-bit record per item in blk_band (a uniform store of all lanes), folded into blk_flags by k_fuse_fold;
+//  * descriptors arrive through the scalar cache (lgkmcnt).
+// With that the compiler waits for item n's loads with vmcnt(3 ZR + 1 + 4 ZR): the stores of item n - 1 and the loads of
+// item n + 1 stay in flight.  Only the band phase (a quarter of the items) and masked frames still drain the queue.
 template <int VPS, int ZR>
 struct FuseItem {
   // wave-uniform
@@ -458,6 +489,9 @@ struct FuseItem {
   f2u ra[ZR], rb[ZR];
   bool ok[ZR];
 };
+
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+typedef const u4v __attribute__((address_space(4))) * DescK;
 
 template <int VPS, int ZSPLIT, bool DEFCFG, bool EXACT, int WPW, bool DBG = false>
 __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {  // isa:kernel setup
@@ -492,6 +526,9 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
   if (a.gate != nullptr && *a.gate != 0u) return;  // speculative launch, and the frame has motion seeds (workgroup-uniform)
   if (threadIdx.x == 0) s_q = 0u;
   __syncthreads();
+  // the wave's sink line: target of the stores that must be issued but have nothing to write (see above)
+  char* const sink_b = reinterpret_cast<char*>(a.sink) + (static_cast<size_t>(blockIdx.x) * WPW + static_cast<size_t>(wave)) * 256u;
+  const bool trk = a.with_tracking != 0;
   // next item of this workgroup's share (positions blockIdx.x, blockIdx.x + gridDim.x, ...: every workgroup gets the same
   // mix of the cost classes), handed to whichever of its waves asks first; wave-uniform result
   // XCD-aware share: workgroup b runs on XCD b % 8 (round-robin dispatch), so its first position is
@@ -505,15 +542,19 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
     j = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(j)));
     return first + gridDim.x * j;
   };
-  // descriptor of item i in deal order: class 0, 1, 2, 3 (FuseList)
+  // descriptor of item i in deal order: class 0, 1, 2, 3 (FuseList), through the scalar cache (the list was written by the
+  // previous kernel; scalar loads return on lgkmcnt and are not ordered behind the wave's vector stores)
+  const DescK la = (DescK)list.a, lb = (DescK)list.b;
   auto descOf = [&](uint32_t i) -> uint4 {
-    if (i < nc0) return list.a[i];
-    if (i < nc1) return list.a[list.cap - 1u - (i - nc0)];
-    if (i < nc2) return list.b[i - nc1];
-    return list.b[list.cap - 1u - (i - nc2)];
+    u4v d;
+    if (i < nc0) d = la[i];
+    else if (i < nc1) d = la[list.cap - 1u - (i - nc0)];
+    else if (i < nc2) d = lb[i - nc1];
+    else d = lb[list.cap - 1u - (i - nc2)];
+    return make_uint4(d.x, d.y, d.z, d.w);
   };
 
-  // ---- phase 1: geometry of the item's ZR voxels per lane; all their loads issued ----
+  // ---- phase 1: geometry of the item's ZR voxels per lane; all their loads issued (unconditionally) ----
   auto phase1 = [&](FuseItem<VPS, ZR>& it, const uint4 desc) {  // isa:p1 item geometry (x-y transform, bases)
     const uint32_t dx = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(desc.x)));
     it.slot = dx & 0xffffffu;
@@ -558,16 +599,14 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
       const float uc = ok ? u : 0.f, vc = ok ? v : 0.f;
       const uint32_t u0 = static_cast<uint32_t>(static_cast<int>(uc)), v0 = static_cast<uint32_t>(static_cast<int>(vc));
       const uint32_t v1 = min(v0 + 1u, static_cast<uint32_t>(a.H - 1));
-      uint32_t o0 = v0 * W4 + u0 * 4u, o1 = v1 * W4 + u0 * 4u;  // byte offsets of (u0, v0), (u0, v1)
-      if (DBG && (dbg & 8)) { o0 = static_cast<uint32_t>(lane) * 8u; o1 = o0 + W4; }
+      // byte offsets of (u0, v0), (u0, v1).  24-bit multiplies (rows and row pitch are far below 2^24): the full 32-bit
+      // multiply-add only exists as v_mad_u64_u32, whose 64-bit addend drags an unrelated register into the instruction --
+      // when that register is the target of a load in flight, the compiler has to wait for it (seen in the ISA: vmcnt(2))
+      const uint32_t o0 = __umul24(v0, W4) + u0 * 4u, o1 = __umul24(v1, W4) + u0 * 4u;
       it.ra[k] = *reinterpret_cast<const f2u*>(range_b + o0);  // (u0, v0), (u0 + 1, v0)
       it.rb[k] = *reinterpret_cast<const f2u*>(range_b + o1);  // (u0, v1), (u0 + 1, v1)
-      it.d[k] = 0.f;  // isa:p1 distance / weight loads + item state
-      it.w[k] = 0.f;
-      if (ok && !(DBG && (dbg & 4))) {
-        it.d[k] = *reinterpret_cast<const float*>(dist_b + lin * 4u);
-        it.w[k] = *reinterpret_cast<const float*>(wgt_b + lin * 4u);
-      }
+      it.d[k] = *reinterpret_cast<const float*>(dist_b + lin * 4u);  // isa:p1 distance / weight loads + item state
+      it.w[k] = *reinterpret_cast<const float*>(wgt_b + lin * 4u);
       it.u[k] = uc;
       it.v[k] = vc;
       it.z[k] = voxel_range;
@@ -576,28 +615,12 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
     }
   };
 
-  uint32_t item = pull();  // isa:item loop control / prefetch bookkeeping
-  uint32_t item_next = item < n_items ? pull() : 0xffffffffu;
-  FuseItem<VPS, ZR> cur, nxt;
-  uint4 d_next = make_uint4(0u, 0u, 0u, 0u);
-  if (item < n_items) {
-    phase1(cur, descOf(item));
-    if (item_next < n_items) d_next = descOf(item_next);
-  }
-  const unsigned long long tw0 = (DBG && (dbg & 64)) ? __builtin_amdgcn_s_memtime() : 0ull;
   unsigned long long t_band = 0, t_item_max = 0;
   uint32_t c_items = 0, c_rounds = 0, c_recs = 0;
-  while (item < n_items) {
+
+  // ---- phase 2 of an item: measurement, decisions, read-modify-write, in-band records; then its band rounds ----
+  auto phase2 = [&](FuseItem<VPS, ZR>& cur) {
     const unsigned long long ti0 = (DBG && (dbg & 64)) ? __builtin_amdgcn_s_memtime() : 0ull;
-    // ---- the NEXT item's loads go out first (and the descriptor of the one after it) ----
-    const bool have_next = item_next < n_items;
-    uint32_t item_nn = 0xffffffffu;
-    if (have_next) {
-      phase1(nxt, d_next);
-      item_nn = pull();
-      if (item_nn < n_items) d_next = descOf(item_nn);
-    }
-    // ---- phase 2 of the current item: measurement, decisions, read-modify-write ----
     const size_t slot = cur.slot;  // isa:p2 setup (bases)
     char* const dist_b = reinterpret_cast<char*>(a.dist + slot * NV);
     char* const wgt_b = reinterpret_cast<char*>(a.weight + slot * NV);
@@ -608,13 +631,12 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
 #pragma unroll
     for (int k = 0; k < ZR; ++k) {
       bool ok = cur.ok[k];
-      if (DBG && (dbg & 16)) {
-        n_upd += static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(ok)));
-        continue;
-      }
-      if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
-      const int iz = cur.z0 + k;  // isa:p2 interpolation (weights, adaptive mode, sdf, band test)
+      const int iz = cur.z0 + k;
       const uint32_t lin = static_cast<uint32_t>(cur.lin_xy + iz * SL);
+      const float d_old = cur.d[k], w_old = cur.w[k];
+      float d_out = d_old, w_out = w_old;  // what the z-step stores: lanes without an update write back what they loaded
+      if (__builtin_amdgcn_ballot_w64(ok) != 0ull) {
+      // isa:p2 interpolation (weights, adaptive mode, sdf, band test)
       const float uc = cur.u[k], vc = cur.v[k], voxel_range = cur.z[k], yz = cur.yz[k];
       // range_mode 0: voxel_range is the voxel's depth; ray-length mode needs the depth again for the weight
       float depth = voxel_range;
@@ -626,7 +648,6 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
       const uint32_t v1 = min(v0 + 1u, static_cast<uint32_t>(a.H - 1));
       const float du = __builtin_amdgcn_fractf(uc), dv = __builtin_amdgcn_fractf(vc);  // x - floor(x), exact for x >= 0
       const uint32_t o0 = v0 * W4 + u0 * 4u, o1 = v1 * W4 + u0 * 4u;
-      const float d_old = cur.d[k], w_old = cur.w[k];
       // pixel order of the reference: (u0,v0) (u0,v1) (u1,v0) (u1,v1) with u1 = min(u0 + 1, W - 1)
       const bool last_col = u0 >= static_cast<uint32_t>(a.W - 1);
       const float r0 = cur.ra[k].x, r1 = cur.rb[k].x, r2 = last_col ? cur.ra[k].x : cur.ra[k].y, r3 = last_col ? cur.rb[k].x : cur.rb[k].y;
@@ -665,7 +686,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
           in_band = false;
         }
       }
-      if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
+      if (__builtin_amdgcn_ballot_w64(ok) != 0ull) {
       // measurement weight (computeWeight): fx fy vs^2 / z^4, linear drop-off behind the surface  // isa:p2 measurement weight
       float w;
       if (EXACT) {
@@ -695,14 +716,11 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
         d_new = __builtin_fmaf(d_old, w_old, sdf_c * w) * __builtin_amdgcn_rcpf(tot);
       }
       const float w_new = fminf(tot, a.max_weight);
-      if (ok && !(DBG && (dbg & 2))) {  // isa:p2 stores
-        *reinterpret_cast<float*>(dist_b + lin * 4u) = d_new;
-        *reinterpret_cast<float*>(wgt_b + lin * 4u) = w_new;
-        if (a.with_tracking) *reinterpret_cast<uint64_t*>(lobs_b + lin * 8u) = a.stamp;
+      if (ok) {
+        d_out = d_new;
+        w_out = w_new;
       }
-      const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(ok), m_band = __builtin_amdgcn_ballot_w64(in_band);  // isa:p2 statistics + band record compaction (LDS)
-      n_upd += static_cast<uint32_t>(__popcll(m_ok));
-      touched = touched || (m_ok != 0ull);
+      const unsigned long long m_band = __builtin_amdgcn_ballot_w64(in_band);  // isa:p2 statistics + band record compaction (LDS)
       wrote_neg = wrote_neg || (__builtin_amdgcn_ballot_w64(ok && d_new < 0.f) != 0ull);
       if (m_band) {
         n_band += static_cast<uint32_t>(__popcll(m_band));
@@ -718,9 +736,33 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
         }
         cnt += static_cast<uint32_t>(__popcll(m_band));
       }
+      } else {
+        ok = false;
+      }
+      }
+      // ---- the z-step's stores, always issued ----  // isa:p2 stores
+      const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(ok);
+      n_upd += static_cast<uint32_t>(__popcll(m_ok));
+      touched = touched || (m_ok != 0ull);
+      {  // (a z-step without any update sends its two stores to the sink line instead of rewriting 512 unchanged bytes)
+        char* const d_b = m_ok != 0ull ? dist_b : sink_b;
+        char* const w_b = m_ok != 0ull ? wgt_b : sink_b;
+        const uint32_t vo = (m_ok != 0ull ? lin : static_cast<uint32_t>(lane)) * 4u;
+        *reinterpret_cast<float*>(d_b + vo) = d_out;
+        *reinterpret_cast<float*>(w_b + vo) = w_out;
+      }
+      {
+        // stamp: updated lanes write their voxel; the others repeat the first updated lane's store (same address, same value:
+        // one request); no updated lane, or no tracking layer: everything goes to the wave's sink line
+        const bool real = trk && m_ok != 0ull;
+        char* const st_b = real ? lobs_b : sink_b;
+        const uint32_t first_lin = lin - static_cast<uint32_t>(lane) + static_cast<uint32_t>(__builtin_ctzll(m_ok | (1ull << 63)));
+        const uint32_t so = real ? (ok ? lin : first_lin) * 8u : 0u;
+        *reinterpret_cast<uint64_t*>(st_b + so) = a.stamp;
+      }
     }
     const uint32_t item_band = cnt;  // isa:band phase driver
-    // ---- the item's in-band voxels, densely (lane <-> record).  A cold block: the hint keeps the register allocator
+    // ---- the item's in-band voxels, densely.  A cold block: the hint keeps the register allocator
     //      from favouring its values over the voxel loop's ----
     if (DBG && (dbg & 1)) cnt = 0u;
     if (__builtin_expect(cnt > 0u, 0)) {
@@ -733,8 +775,8 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
       FuseArgsK ka = (FuseArgsK)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+s"(ka));
       const FuseFrameK kf = (FuseFrameK)ka;  // a single-frame launch: the frame's arguments are the head of the kernel arguments
-      if (ka->band_mode != 0 && fuseBandCoopOk(ka->K, ka->sem_mode, ka->do_sem)) {
-        fuseBandCoop<VPS>(ka, kf, slot, &s_rec[wave][0][0], cnt, lane);
+      if (ka->band_mode != 0 && fuseBandRowsOk(ka->KS, ka->sem_mode, ka->do_sem, ka->has_color)) {
+        fuseBandRows<VPS>(ka, kf, slot, &s_rec[wave][0][0], cnt, lane);
       } else {
         for (uint32_t r = static_cast<uint32_t>(lane); r < cnt; r += 64u) {
           const uint32_t* const rec = &s_rec[wave][0][r];
@@ -746,19 +788,48 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
       __builtin_amdgcn_wave_barrier();
       if (DBG && (dbg & 64)) t_band += __builtin_amdgcn_s_memtime() - tb0;
     }
-    if (lane == 0) {  // isa:item epilogue (block flags, cost class)
-      if (touched && !(DBG && (dbg & 128)))
-        atomicOr(&a.blk_flags[slot], BLK_UPDATED | BLK_MESH_UPDATED | BLK_TRACKING_UPDATED | (wrote_neg ? BLK_HAS_NEG : 0u));
-      a.blk_band[slot * kBandSlots + (cur.sbi & (kBandSlots - 1))] = static_cast<uint16_t>(min(item_band, 65535u));  // next frame's culling pass sorts by it
+    // the item's record: {touched, wrote a negative distance, in-band count (next frame's cost class)}; a uniform store of
+    // all lanes (one request), folded into the block flags by k_fuse_fold  // isa:item epilogue (item record)
+    {
+      const uint32_t recw = min(item_band, static_cast<uint32_t>(kItemBandMask)) | (touched ? kItemTouched : 0u) | (wrote_neg ? kItemNeg : 0u);
+      a.blk_band[slot * kBandSlots + (cur.sbi & (kBandSlots - 1))] = static_cast<uint16_t>(recw);
     }
     if (DBG && (dbg & 64)) {
       const unsigned long long dt = __builtin_amdgcn_s_memtime() - ti0;
       t_item_max = dt > t_item_max ? dt : t_item_max;
       ++c_items;
     }
-    item = item_next;
-    item_next = item_nn;
-    if (have_next) cur = nxt;
+  };
+
+  // ---- the item loop: two item states, alternating roles (no register copies between iterations) ----
+  uint32_t item = pull();  // isa:item loop control / prefetch bookkeeping
+  const unsigned long long tw0 = (DBG && (dbg & 64)) ? __builtin_amdgcn_s_memtime() : 0ull;
+  if (item < n_items) {
+    FuseItem<VPS, ZR> sa, sb;
+    uint4 d_cur = descOf(item);
+    phase1(sa, d_cur);
+    uint32_t item_next = pull();
+    uint4 d_next = item_next < n_items ? descOf(item_next) : d_cur;
+    while (true) {
+      {  // sa holds the current item, sb receives the next one
+        phase1(sb, d_next);
+        const uint32_t item_nn = item_next < n_items ? pull() : 0xffffffffu;
+        const uint4 d_nn = item_nn < n_items ? descOf(item_nn) : d_next;
+        phase2(sa);
+        if (item_next >= n_items) break;
+        item_next = item_nn;
+        d_next = d_nn;
+      }
+      {  // roles swapped
+        phase1(sa, d_next);
+        const uint32_t item_nn = item_next < n_items ? pull() : 0xffffffffu;
+        const uint4 d_nn = item_nn < n_items ? descOf(item_nn) : d_next;
+        phase2(sb);
+        if (item_next >= n_items) break;
+        item_next = item_nn;
+        d_next = d_nn;
+      }
+    }
   }
   if (DBG && (dbg & 64) && lane == 0) {
     unsigned long long* o = a.dbg_buf + (static_cast<size_t>(blockIdx.x) * WPW + wave) * 8;
@@ -778,17 +849,41 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t su = 0u, sb = 0u;
+    uint32_t su = 0u, sb2 = 0u;
 #pragma unroll
     for (int w = 0; w < WPW; ++w) {
       su += s_stat[w][0];
-      sb += s_stat[w][1];
+      sb2 += s_stat[w][1];
     }
-    if (su | sb) {
+    if (su | sb2) {
       a.wg_stats[2 * blockIdx.x] += su;
-      a.wg_stats[2 * blockIdx.x + 1] += sb;
+      a.wg_stats[2 * blockIdx.x + 1] += sb2;
     }
   }
+}
+
+// fold k_fuse's item records into the block flags (one thread per pool slot): a block some item of which was touched becomes
+// updated / mesh-updated / tracking-updated (+ has-negative); the records keep only their in-band counts.
+__global__ __launch_bounds__(256) void k_fuse_fold(uint32_t* __restrict__ blk_flags, uint16_t* __restrict__ blk_band,
+                                                  const uint32_t* __restrict__ max_slot, const uint32_t* gate) {
+  if (gate != nullptr && *gate != 0u) return;
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= *max_slot) return;
+  static_assert(kBandSlots == 32, "record row = 4 x 16 bytes");
+  uint4* const row = reinterpret_cast<uint4*>(blk_band + static_cast<size_t>(s) * kBandSlots);
+  uint32_t any = 0u;
+  uint4 r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r[i] = row[i];
+    any |= r[i].x | r[i].y | r[i].z | r[i].w;
+  }
+  const uint32_t tm = static_cast<uint32_t>(kItemTouched) * 0x00010001u, nm = static_cast<uint32_t>(kItemNeg) * 0x00010001u;
+  if ((any & tm) == 0u) return;
+  blk_flags[s] |= BLK_UPDATED | BLK_MESH_UPDATED | BLK_TRACKING_UPDATED | ((any & nm) ? BLK_HAS_NEG : 0u);
+  const uint32_t keep = static_cast<uint32_t>(kItemBandMask) * 0x00010001u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) row[i] = make_uint4(r[i].x & keep, r[i].y & keep, r[i].z & keep, r[i].w & keep);
 }
 
 // ====================================================================================================================
@@ -802,8 +897,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
 // MINW (waves per SIMD the kernel is compiled for) so that 20 - 32 waves per CU are resident: the waits are covered by
 // other waves, not by the wave's own schedule.
 // ====================================================================================================================
-typedef uint32_t u4v __attribute__((ext_vector_type(4)));  // isa:k_fuse2 (not part of this breakdown)
-typedef const u4v __attribute__((address_space(4))) * DescK;
+// isa:k_fuse2 (not part of this breakdown)
 // MULTI: an item is walked through a.n_frames frames (a.frames[], device memory, read through the scalar cache) in order before
 // the wave takes its next item -- the updates of a voxel by consecutive frames are order dependent, those of different items
 // are not.  One launch then replaces one launch per frame (MeshObjectExtractor re-integrates every buffered frame of a track,
@@ -1077,8 +1171,8 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
       FuseArgsK ka = (FuseArgsK)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+s"(ka));
       const FuseFrameK kf = MULTI ? (FuseFrameK)(a.frames + fi) : (FuseFrameK)ka;
-      if (ka->band_mode != 0 && fuseBandCoopOk(ka->K, ka->sem_mode, kf->do_sem)) {
-        fuseBandCoop<VPS, CAP>(ka, kf, slot, &s_rec[wave][0][0], cnt, lane);
+      if (ka->band_mode != 0 && fuseBandRowsOk(ka->KS, ka->sem_mode, kf->do_sem, kf->has_color)) {
+        fuseBandRows<VPS, CAP>(ka, kf, slot, &s_rec[wave][0][0], cnt, lane);
       } else {
         for (uint32_t r = static_cast<uint32_t>(lane); r < cnt; r += 64u) {
           const uint32_t* const rec = &s_rec[wave][0][r];

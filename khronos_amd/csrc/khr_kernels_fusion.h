@@ -512,7 +512,7 @@ __device__ inline void cullBlocks(const DevMap& m, const DevParams& p, const Dev
         if ((old >> sh) & 0xffu) ikeep = false;
       }
       if (ikeep && sub == 0) {
-        const uint32_t cls = fuseClass(m.blk_band[static_cast<size_t>(slot) * kBandSlots + item]);
+        const uint32_t cls = fuseClass(m.blk_band[static_cast<size_t>(slot) * kBandSlots + item] & kItemBandMask);
         s_item[cls][atomicAdd(&s_ccnt[cls], 1u)] = static_cast<uint16_t>((kslot << 8) | item);
       }
     }

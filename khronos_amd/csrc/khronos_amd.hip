@@ -140,6 +140,7 @@ struct khr_ctx {
   unsigned long long* d_dbg = nullptr;
   unsigned long long* d_digest = nullptr;  // khr_map_digest accumulators
   uint32_t* d_wg_stats = nullptr;
+  unsigned char* d_fuse_sink = nullptr;  // k_fuse: one 256-byte sink line per wave (kFuseStatSlots workgroups x 16 waves)
   uint32_t* d_pix_scratch = nullptr;  // khr_pixel_iou: mask image + counters (allocated on first use)
   size_t pix_words = 0;
   uint8_t* d_inst = nullptr;          // khr_forward_instances: per-id accumulators
@@ -525,7 +526,7 @@ int kTickUnion = 1;     // env KHR_TICK_UNION: khr_tick_integrate updates with O
 int kFuseMulti = 1;     // env KHR_FUSE_MULTI: khr_integrate_shared_batch integrates all frames of a batch in one launch (k_fuse2 MULTI)
 constexpr int kMaxMultiFrames = 1024;
 int kFuseSpec = 1;      // env KHR_FUSE_SPECULATIVE: khr_process_frame queues k_fuse before the seed count has reached the host (gated on the device)
-int kFuseBand = 0;      // env KHR_FUSE_BAND: 0 = lane <-> record (default), 1 = record-cooperative band phase (fuseBandCoop: -41 % L2 write requests, -16 % L1 accesses, same time at 720p / 2 cm, slower on small frames)
+int kFuseBand = 1;      // env KHR_FUSE_BAND: 1 = likelihood rows as whole cache lines, 8 lanes per row (fuseBandRows, default), 0 = lane <-> record
 constexpr int kStreamGrid = 4096;
 
 }  // namespace
@@ -773,6 +774,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   p.vps = cfg->voxels_per_side;
   p.nvox = p.vps * p.vps * p.vps;
   p.K = cfg->with_semantics ? cfg->num_labels : 1;
+  p.KS = likStride(p.K);
   p.with_semantics = cfg->with_semantics;
   p.with_tracking = cfg->with_tracking;
   p.use_dropoff = cfg->use_weight_dropoff;
@@ -820,7 +822,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &m.color, cap * nv, false));
   A(devAlloc(c, &m.vflags, cap * nv, false));
   A(devAlloc(c, &m.sem_label, cfg->with_semantics ? cap * nv : 1, false));
-  A(devAlloc(c, &m.lik, cfg->with_semantics ? cap * nv * p.K : 1, false));
+  A(devAlloc(c, &m.lik, cfg->with_semantics ? cap * nv * p.KS : 1, false));
   A(devAlloc(c, &m.last_obs, cfg->with_tracking ? cap * nv : 1, false));
   A(devAlloc(c, &m.last_occ, cfg->with_tracking ? cap * nv : 1, false));
   A(devAlloc(c, &m.trk_lim, cfg->with_tracking ? cap * 2 : 2));
@@ -836,6 +838,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &c->d_dbg, 4096 * 4 * 12));
   A(devAlloc(c, &c->d_digest, kDigestWords));
   A(devAlloc(c, &c->d_wg_stats, 2 * kFuseStatSlots));
+  A(devAlloc(c, &c->d_fuse_sink, static_cast<size_t>(kFuseStatSlots) * 16 * 256, false));
   A(devAlloc(c, &c->d_fetch_done, 4));
   {
     int zs = kFuseZsplit;
@@ -1304,10 +1307,11 @@ static void fillFuseMap(khr_ctx* c, FuseArgs* a) {
   a->adaptive_diff = c->p.adaptive_diff; a->log_match = c->p.log_match; a->log_nomatch = c->p.log_nomatch;
   a->interp = c->p.interp; a->range_mode = c->p.range_mode; a->use_dropoff = c->p.use_dropoff; a->const_weight = c->p.const_weight;
   a->with_tracking = c->p.with_tracking;
-  a->K = c->p.K; a->sem_mode = c->p.sem_mode;
+  a->K = c->p.K; a->KS = c->p.KS; a->sem_mode = c->p.sem_mode;
   a->dbg = kFuseDbg;
   a->dbg_buf = c->d_dbg;
   a->band_mode = kFuseBand;
+  a->sink = c->d_fuse_sink;
 }
 
 // All frames of a batch in ONE launch (k_fuse2<.., MULTI>): every wave item is walked through the frames in order.  Only for
@@ -1385,6 +1389,9 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
         static bool said = false;
         if (!said && std::getenv("KHR_VERBOSE")) { said = true; std::fprintf(stderr, "[khr] k_fuse<%d,%d> %d waves / workgroup, grid %d\n", V, ZS, wpw, grid); }
         KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(64 * wpw), a, list);
+        // the items' {touched, negative} bits -> block flags (k_fuse writes one record per item instead of an atomic)
+        hipLaunchKernelGGL(k_fuse_fold, dim3((c->m.capacity + 255) / 256), dim3(256), 0, c->stream, m.blk_flags, m.blk_band,
+                           &m.counters[C_MAX_SLOT], gate);
       };
       // non-default switches are test configurations: they always run the bit-exact arithmetic
       a.gate = gate;
@@ -3548,8 +3555,8 @@ int khr_download_block(khr_ctx* c, int32_t bx, int32_t by, int32_t bz, float* di
   }
   std::vector<float> lik_vm;  // device layout is voxel-major [voxel][K]; the API hands out [k][voxel]
   if (likelihoods && c->cfg.with_semantics) {
-    lik_vm.resize(nv * c->p.K);
-    HIP_TRY(D(lik_vm.data(), m.lik + slot * nv * c->p.K, nv * c->p.K * 4));
+    lik_vm.resize(nv * c->p.KS);
+    HIP_TRY(D(lik_vm.data(), m.lik + slot * nv * c->p.KS, nv * c->p.KS * 4));
   }
   uint32_t bf = 0;
   if (block_flags) HIP_TRY(D(&bf, m.blk_flags + slot, 4));
@@ -3563,7 +3570,7 @@ int khr_download_block(khr_ctx* c, int32_t bx, int32_t by, int32_t bz, float* di
     for (size_t i = 0; i < nv; ++i) voxel_flags[i] = raw_flags[i] & VOX_PUBLIC_MASK;
   if (likelihoods && c->cfg.with_semantics)
     for (size_t i = 0; i < nv; ++i)
-      for (int k = 0; k < c->p.K; ++k) likelihoods[static_cast<size_t>(k) * nv + i] = lik_vm[i * c->p.K + k];
+      for (int k = 0; k < c->p.K; ++k) likelihoods[static_cast<size_t>(k) * nv + i] = lik_vm[i * c->p.KS + k];
   // voxels whose semantic entry is still empty carry undefined likelihood storage: report zeros
   if (likelihoods && c->cfg.with_semantics) {
     std::vector<uint8_t> fl(nv);
@@ -3768,6 +3775,7 @@ int khr_snapshot_updated(khr_ctx* c, uint32_t fields, int64_t cap_blocks, khr_sn
   if ((fields & KHR_SNAP_LAST_OCCUPIED) && trk) snap->o.last_occ = reinterpret_cast<uint64_t*>(carve(cap * nvox * 8));
   if ((fields & KHR_SNAP_LIKELIHOODS) && sem) snap->o.lik = reinterpret_cast<float*>(carve(cap * nvox * 4 * static_cast<size_t>(c->p.K)));
   snap->o.K = c->p.K;
+  snap->o.KS = c->p.KS;
   snap->o.track_stamp = c->last_track_stamp;
   hipError_t e = hipMemsetAsync(snap->d_count, 0, 4, c->stream);
   if (e == hipSuccess) {

@@ -863,27 +863,14 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
 }
 
 // fold k_fuse's item records into the block flags (one thread per pool slot): a block some item of which was touched becomes
-// updated / mesh-updated / tracking-updated (+ has-negative); the records keep only their in-band counts.
+// updated / mesh-updated / tracking-updated (+ has-negative); the records keep only their in-band counts.  (When the tracking
+// pass follows the update directly, k_tracking_select does this instead: foldItemRecords, khr_kernels_fusion.h.)
 __global__ __launch_bounds__(256) void k_fuse_fold(uint32_t* __restrict__ blk_flags, uint16_t* __restrict__ blk_band,
                                                   const uint32_t* __restrict__ max_slot, const uint32_t* gate) {
   if (gate != nullptr && *gate != 0u) return;
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= *max_slot) return;
-  static_assert(kBandSlots == 32, "record row = 4 x 16 bytes");
-  uint4* const row = reinterpret_cast<uint4*>(blk_band + static_cast<size_t>(s) * kBandSlots);
-  uint32_t any = 0u;
-  uint4 r[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    r[i] = row[i];
-    any |= r[i].x | r[i].y | r[i].z | r[i].w;
-  }
-  const uint32_t tm = static_cast<uint32_t>(kItemTouched) * 0x00010001u, nm = static_cast<uint32_t>(kItemNeg) * 0x00010001u;
-  if ((any & tm) == 0u) return;
-  blk_flags[s] |= BLK_UPDATED | BLK_MESH_UPDATED | BLK_TRACKING_UPDATED | ((any & nm) ? BLK_HAS_NEG : 0u);
-  const uint32_t keep = static_cast<uint32_t>(kItemBandMask) * 0x00010001u;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) row[i] = make_uint4(r[i].x & keep, r[i].y & keep, r[i].z & keep, r[i].w & keep);
+  foldItemRecords(blk_flags, blk_band, s);
 }
 
 // ====================================================================================================================

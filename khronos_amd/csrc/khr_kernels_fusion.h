@@ -696,15 +696,37 @@ __global__ __launch_bounds__(256) void k_init_cull(DevMap m, DevParams p, DevFra
 // integrator, dirty, or one of the two skip thresholds crossed), `ef_list` = blocks the integrator touched (the
 // ever-free work list, tracking_integrator.cpp:76-77).  Wave-aggregated appends; the counters of the NEXT pass
 // (cnt_next[0..1], the pairs alternate) are zeroed here so that no memset launch is needed.
+// fold_band != nullptr: the update kernel's item records have not been folded into the block flags yet (k_fuse_fold was left
+// out because this kernel follows the update directly, khr_process_frame): this thread does it for its slot first.
+__device__ inline uint32_t foldItemRecords(uint32_t* __restrict__ blk_flags, uint16_t* __restrict__ blk_band, uint32_t s) {
+  static_assert(kBandSlots == 32, "record row = 4 x 16 bytes");
+  uint4* const row = reinterpret_cast<uint4*>(blk_band + static_cast<size_t>(s) * kBandSlots);
+  uint32_t any = 0u;
+  uint4 r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r[i] = row[i];
+    any |= r[i].x | r[i].y | r[i].z | r[i].w;
+  }
+  const uint32_t tm = static_cast<uint32_t>(kItemTouched) * 0x00010001u, nm = static_cast<uint32_t>(kItemNeg) * 0x00010001u;
+  uint32_t fl = blk_flags[s];
+  if ((any & tm) == 0u) return fl;
+  fl |= BLK_UPDATED | BLK_MESH_UPDATED | BLK_TRACKING_UPDATED | ((any & nm) ? BLK_HAS_NEG : 0u);
+  blk_flags[s] = fl;
+  const uint32_t keep = static_cast<uint32_t>(kItemBandMask) * 0x00010001u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) row[i] = make_uint4(r[i].x & keep, r[i].y & keep, r[i].z & keep, r[i].w & keep);
+  return fl;
+}
 __global__ __launch_bounds__(256) void k_tracking_select(DevMap m, uint64_t lim_active, uint64_t lim_free, int force_full,
                                                         uint32_t* __restrict__ proc, uint32_t* __restrict__ ef_list,
                                                         uint32_t* __restrict__ cnt /* [0] proc, [1] ef */,
-                                                        uint32_t* __restrict__ cnt_next) {
+                                                        uint32_t* __restrict__ cnt_next, uint16_t* __restrict__ fold_band) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s == 0) { cnt_next[0] = 0u; cnt_next[1] = 0u; }
   bool need = false, touched = false, reload = false;
   if (s < m.counters[C_MAX_SLOT]) {
-    const uint32_t fl = m.blk_flags[s];
+    const uint32_t fl = fold_band ? foldItemRecords(m.blk_flags, fold_band, s) : m.blk_flags[s];
     if (fl & BLK_LIVE) {
       touched = fl & BLK_TRACKING_UPDATED;
       need = force_full || (fl & (BLK_TRACKING_UPDATED | BLK_TRACK_DIRTY));

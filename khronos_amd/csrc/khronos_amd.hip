@@ -140,6 +140,7 @@ struct khr_ctx {
   unsigned long long* d_dbg = nullptr;
   unsigned long long* d_digest = nullptr;  // khr_map_digest accumulators
   uint32_t* d_wg_stats = nullptr;
+  bool defer_fold = false, fold_pending = false;  // k_fuse's item records: folded by the next k_tracking_select instead of k_fuse_fold
   unsigned char* d_fuse_sink = nullptr;  // k_fuse: one 256-byte sink line per wave (kFuseStatSlots workgroups x 16 waves)
   uint32_t* d_pix_scratch = nullptr;  // khr_pixel_iou: mask image + counters (allocated on first use)
   size_t pix_words = 0;
@@ -1389,9 +1390,11 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
         static bool said = false;
         if (!said && std::getenv("KHR_VERBOSE")) { said = true; std::fprintf(stderr, "[khr] k_fuse<%d,%d> %d waves / workgroup, grid %d\n", V, ZS, wpw, grid); }
         KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(64 * wpw), a, list);
-        // the items' {touched, negative} bits -> block flags (k_fuse writes one record per item instead of an atomic)
-        hipLaunchKernelGGL(k_fuse_fold, dim3((c->m.capacity + 255) / 256), dim3(256), 0, c->stream, m.blk_flags, m.blk_band,
-                           &m.counters[C_MAX_SLOT], gate);
+        // the items' {touched, negative} bits -> block flags (k_fuse writes one record per item instead of an atomic); left to
+        // k_tracking_select when the tracking pass follows directly (khr_process_frame)
+        if (c->defer_fold) c->fold_pending = true;
+        else hipLaunchKernelGGL(k_fuse_fold, dim3((c->m.capacity + 255) / 256), dim3(256), 0, c->stream, m.blk_flags, m.blk_band,
+                                &m.counters[C_MAX_SLOT], gate);
       };
       // non-default switches are test configurations: they always run the bit-exact arithmetic
       a.gate = gate;
@@ -1534,7 +1537,8 @@ static int trackingPhase(khr_ctx* c, uint64_t stamp, int phase) {
       // stamps going backwards void the per-block skip thresholds (they assume monotone limits)
       const int force_full = stamp < c->last_track_stamp || c->cfg.disable_culling ? 1 : 0;
       hipLaunchKernelGGL(k_tracking_select, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, lim_active, lim_free, force_full,
-                         c->d_trk_proc, c->d_ef, cnt, cnt_next);
+                         c->d_trk_proc, c->d_ef, cnt, cnt_next, c->fold_pending ? m.blk_band : nullptr);
+      c->fold_pending = false;
       hipLaunchKernelGGL((k_tracking_update<V, (V == 16 ? 4 : 1)>), dim3(V == 16 ? 4096 : 1024), dim3(256), 0, c->stream, m, c->p, stamp,
                          c->last_track_stamp, lim_active, lim_free, c->d_trk_proc, cnt);
       c->last_track_stamp = stamp;
@@ -3321,6 +3325,8 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   //      the culling pass and the update kernel, for the seed count's trip to the host and the launch's trip back.)
   bool speculated = false;
   size_t spec_timer = static_cast<size_t>(-1), spec_end = 0;
+  // the update kernel's item records are folded into the block flags by the tracking pass's first kernel when it follows directly
+  c->defer_fold = (flags & KHR_PF_TRACKING) && c->cfg.with_tracking;  // (reset below, before the tracking pass)
   if (motion && kFuseSpec && c->cfg.with_tracking) {
     const size_t n_pending = c->pending.size();
     if ((rc = integrateUpdate(c, s, f, 1, 0, -1, nullptr, &c->m.counters[C_N_SEEDS]))) return rc;
@@ -3349,6 +3355,7 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
     c->md_summary_pending = -1;
     if ((rc = clusterSummaryLaunch(c, s, pend))) return rc;
   }
+  c->defer_fold = false;
   if ((flags & KHR_PF_TRACKING) && (rc = khr_update_tracking(c, frame->timestamp_ns))) return rc;
   HT("pf_update_launched");
   // (5) output cadence (ActiveWindow::extractOutputData, active_window.cpp:217-249 + :169-171)

@@ -30,7 +30,7 @@ out={"spec":spec}
 for n in P:
     f=glob.glob(O+"/pmc_%s/*counter_collection.csv"%n)
     if not f: print("no file",n); continue
-    rows=[r for r in csv.DictReader(open(f[0])) if "k_fuse" in r["Kernel_Name"]]
+    rows=[r for r in csv.DictReader(open(f[0])) if "k_fuse<" in r["Kernel_Name"]]
     # the timed launches are the last 10 dispatches of k_fuse
     ids=sorted({int(r["Dispatch_Id"]) for r in rows})[-10:]
     acc=collections.defaultdict(float); cnt=collections.Counter()
@@ -40,7 +40,7 @@ for n in P:
     for c,x in acc.items(): out[c]=round(x/cnt[c],1)
     f=glob.glob(O+"/pmc_%s/*kernel_trace.csv"%n)
     if f:
-        d=[int(r["End_Timestamp"])-int(r["Start_Timestamp"]) for r in csv.DictReader(open(f[0])) if "k_fuse" in r["Kernel_Name"]][-10:]
+        d=[int(r["End_Timestamp"])-int(r["Start_Timestamp"]) for r in csv.DictReader(open(f[0])) if "k_fuse<" in r["Kernel_Name"]][-10:]
         out["avg_us_pass_"+n]=round(sum(d)/max(1,len(d))/1e3,2)
 print(json.dumps(out))
 json.dump(out,open(O+"/k_fuse_pmc.json","w"),indent=1)

@@ -81,6 +81,11 @@ struct DevMap {
   float* weight;
   uint32_t* color;
   uint64_t* last_obs;
+  // lazily stored last_observed (round 4): one {bits, stamp} pair per 64 consecutive voxels (the voxels of one wave z-step of
+  // k_fuse).  bit v set: last_observed of voxel v IS `stamp`, the stored last_obs[v] is stale.  k_fuse then writes 16 bytes per
+  // 64 updated voxels instead of 512; a voxel's stamp is written out once, when an update of its group leaves it out
+  // (lastObserved() below is the only way to read the layer).
+  ulonglong2* obs;  // [slot][nvox / 64]
   uint64_t* last_occ;
   uint64_t* trk_lim;  // [slot][2]: earliest last_observed of an active voxel, earliest last_occupied of a not-yet-free one
   uint8_t* vflags;
@@ -253,6 +258,12 @@ __device__ inline uint64_t motionPixelKey(const DevMap& m, const DevParams& p, f
     }
   }
   return key;
+}
+
+// last_observed of a voxel (DevMap::obs)
+__device__ inline uint64_t lastObserved(const DevMap& m, size_t slot, uint32_t lin, int nvox) {
+  const ulonglong2 w = m.obs[slot * static_cast<size_t>(nvox >> 6) + (lin >> 6)];
+  return ((w.x >> (lin & 63u)) & 1ull) ? w.y : m.last_obs[slot * static_cast<size_t>(nvox) + lin];
 }
 
 __device__ inline double toSeconds(uint64_t ns) { return static_cast<double>(ns) / 1e9; }

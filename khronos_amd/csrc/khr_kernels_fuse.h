@@ -103,6 +103,7 @@ struct FuseArgs : FuseFrame {
   float* dist;
   float* weight;
   uint64_t* last_obs;
+  ulonglong2* obs;  // lazily stored last_observed: {bits, stamp} per 64 voxels (DevMap::obs)
   uint32_t* color;
   uint8_t* vflags;
   uint32_t* sem_label;
@@ -628,6 +629,12 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
     uint32_t cnt = 0;       // records in this wave's LDS list
     bool touched = false;   // wave-uniform: some voxel of this item was updated
     bool wrote_neg = false; // wave-uniform: some updated voxel now holds a negative distance
+    // last_observed is stored lazily: {bits, stamp} of the item's ZR 64-voxel groups, through the scalar cache (each word has
+    // exactly one writer per launch -- this wave, at the end of the z-step -- so what the previous launch left is what we read)
+    const size_t w0 = slot * static_cast<size_t>(NV / 64) + static_cast<size_t>(cur.z0 * PATCHES + cur.sbi % PATCHES);
+    u4v ow[ZR];
+#pragma unroll
+    for (int k = 0; k < ZR; ++k) ow[k] = trk ? ((DescK)(a.obs + w0))[k * PATCHES] : u4v{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int k = 0; k < ZR; ++k) {
       bool ok = cur.ok[k];
@@ -752,13 +759,26 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
         *reinterpret_cast<float*>(w_b + vo) = w_out;
       }
       {
-        // stamp: updated lanes write their voxel; the others repeat the first updated lane's store (same address, same value:
-        // one request); no updated lane, or no tracking layer: everything goes to the wave's sink line
-        const bool real = trk && m_ok != 0ull;
+        // stamp, lazily: the group's {bits, stamp} word says which voxels carry the group's stamp.  An update at a NEW stamp
+        // writes out the stamp of the voxels it leaves behind (bits0 & ~m_ok; usually none: the observed set moves slowly)
+        // and replaces the word; at the same stamp it only adds its bits.  Both stores are always issued: the lanes without
+        // anything to write out repeat the first such lane's store (same address, same value: one request) or, when there
+        // is none or no tracking layer, go to the wave's sink line.
+        const uint64_t bits0 = static_cast<uint64_t>(ow[k].x) | (static_cast<uint64_t>(ow[k].y) << 32);
+        const uint64_t stamp0 = static_cast<uint64_t>(ow[k].z) | (static_cast<uint64_t>(ow[k].w) << 32);
+        const bool same = stamp0 == a.stamp;
+        const uint64_t mat = (m_ok != 0ull && !same) ? (bits0 & ~m_ok) : 0ull;
+        const uint64_t nb = m_ok == 0ull ? bits0 : (same ? (bits0 | m_ok) : m_ok);
+        const uint64_t ns = m_ok == 0ull ? stamp0 : a.stamp;
+        const bool real = trk && mat != 0ull;
         char* const st_b = real ? lobs_b : sink_b;
-        const uint32_t first_lin = lin - static_cast<uint32_t>(lane) + static_cast<uint32_t>(__builtin_ctzll(m_ok | (1ull << 63)));
-        const uint32_t so = real ? (ok ? lin : first_lin) * 8u : 0u;
-        *reinterpret_cast<uint64_t*>(st_b + so) = a.stamp;
+        const uint32_t first_lin = lin - static_cast<uint32_t>(lane) + static_cast<uint32_t>(__builtin_ctzll(mat | (1ull << 63)));
+        const bool mine = ((mat >> static_cast<uint32_t>(lane)) & 1ull) != 0ull;
+        const uint32_t so = real ? (mine ? lin : first_lin) * 8u : 0u;
+        *reinterpret_cast<uint64_t*>(st_b + so) = stamp0;
+        // the group's word: one 16-byte store, all lanes the same address and value
+        ulonglong2* const wp = trk ? (a.obs + w0 + k * PATCHES) : reinterpret_cast<ulonglong2*>(sink_b + 16);
+        *wp = make_ulonglong2(nb, ns);
       }
     }
     const uint32_t item_band = cnt;  // isa:band phase driver
@@ -786,6 +806,10 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      // leave the band block with nothing in flight: otherwise the compiler carries "this register may still be the target of
+      // a band load" into the item loop and protects the register's next use there with a vmcnt that drains the pipeline of
+      // EVERY item (seen in the ISA: vmcnt(8) in the middle of the next prefetch)
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
       if (DBG && (dbg & 64)) t_band += __builtin_amdgcn_s_memtime() - tb0;
     }
     // the item's record: {touched, wrote a negative distance, in-band count (next frame's cost class)}; a uniform store of
@@ -1133,6 +1157,9 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
         if (a.with_tracking) *reinterpret_cast<uint64_t*>(lobs_b + lin * 8u) = F.stamp;
       }
       const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(ok), m_band = __builtin_amdgcn_ballot_w64(in_band);
+      // (this kernel stores stamps per voxel: the voxels it has written no longer carry their group's lazy stamp, DevMap::obs)
+      if (!MULTI && a.with_tracking && m_ok != 0ull && lane == 0)
+        atomicAnd(reinterpret_cast<unsigned long long*>(a.obs + slot * static_cast<size_t>(NV / 64) + (lin >> 6)), ~m_ok);
       n_upd += static_cast<uint32_t>(__popcll(m_ok));
       touched = touched || (m_ok != 0ull);
       wrote_neg = wrote_neg || (__builtin_amdgcn_ballot_w64(ok && d_new < 0.f) != 0ull);
@@ -1174,8 +1201,11 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
     if (MULTI) {
 #pragma unroll
       for (int k = 0; k < ZR; ++k) {
-        if (lidx[k] < 0) continue;
         const uint32_t lin = static_cast<uint32_t>(lin_xy + (z0 + k) * SL);
+        const unsigned long long m_upd = __builtin_amdgcn_ballot_w64(lidx[k] >= 0);
+        if (a.with_tracking && m_upd != 0ull && lane == 0)  // (per-voxel stamps from here on: DevMap::obs)
+          atomicAnd(reinterpret_cast<unsigned long long*>(a.obs + slot * static_cast<size_t>(NV / 64) + (lin >> 6)), ~m_upd);
+        if (lidx[k] < 0) continue;
         *reinterpret_cast<float*>(dist_b + lin * 4u) = dreg[k];
         *reinterpret_cast<float*>(wgt_b + lin * 4u) = wreg[k];
         if (a.with_tracking) *reinterpret_cast<uint64_t*>(lobs_b + lin * 8u) = a.frames[lidx[k]].stamp;

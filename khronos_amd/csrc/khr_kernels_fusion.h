@@ -652,7 +652,10 @@ __device__ inline void initBlocks(const DevMap& m, const DevParams& p, const uin
         q4[i] = z;
       }
       uint64_t* fb = m.freebits + slot * (nv / 64);
-      for (int i = threadIdx.x; i < nv / 64; i += blockDim.x) fb[i] = 0ull;
+      for (int i = threadIdx.x; i < nv / 64; i += blockDim.x) {
+        fb[i] = 0ull;
+        m.obs[slot * (nv / 64) + i] = make_ulonglong2(0ull, 0ull);
+      }
     }
   }
 }
@@ -785,7 +788,7 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
     constexpr int G = NV / 4 / CH / 256 > 0 ? NV / 4 / CH / 256 : 1;
     constexpr int GEND = NV / 4 / CH;  // groups per piece
     float4 d_[G];
-    ulonglong2 oa_[G], ob_[G], ca_[G], cb_[G];
+    ulonglong2 oa_[G], ob_[G], ca_[G], cb_[G], ow_[G];
     uint32_t v4_[G];
     uint32_t need_[G];
 #pragma unroll
@@ -793,8 +796,7 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
       const int gl = threadIdx.x + 256 * q, g = g0 + gl;
       if (gl < GEND) {
         d_[q] = reload ? dist4[g] : make_float4(0.f, 0.f, 0.f, 0.f);
-        oa_[q] = lobs2[2 * g];
-        ob_[q] = lobs2[2 * g + 1];
+        ow_[q] = m.obs[slot * (NV / 64) + (g >> 4)];  // the 4 voxels of a group share one 64-voxel word
         v4_[q] = vfl4[g];
       }
     }
@@ -804,7 +806,14 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
       need_[q] = 0u;
       ca_[q] = make_ulonglong2(0ull, 0ull);
       cb_[q] = ca_[q];
+      oa_[q] = ca_[q];
+      ob_[q] = ca_[q];
       if (gl < GEND) {
+        // stored last_observed stamps travel only for the voxels that do not carry their group's lazy stamp (DevMap::obs):
+        // in a block the integrator has just updated that is a minority
+        const uint32_t b4 = static_cast<uint32_t>(ow_[q].x >> ((4u * static_cast<uint32_t>(g)) & 63u)) & 0xfu;
+        if ((b4 & 3u) != 3u) oa_[q] = lobs2[2 * g];
+        if ((b4 & 12u) != 12u) ob_[q] = lobs2[2 * g + 1];
         const float dd[4] = {d_[q].x, d_[q].y, d_[q].z, d_[q].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -824,7 +833,14 @@ __global__ __launch_bounds__(256) void k_tracking_update(DevMap m, DevParams p, 
       if (gl >= GEND) continue;
       const uint32_t v4 = v4_[q];
       const float dd[4] = {d_[q].x, d_[q].y, d_[q].z, d_[q].w};
-      const uint64_t lo[4] = {oa_[q].x, oa_[q].y, ob_[q].x, ob_[q].y};
+      // last_observed is stored lazily (DevMap::obs): a voxel whose bit is set carries its group's stamp
+      uint64_t lo[4] = {oa_[q].x, oa_[q].y, ob_[q].x, ob_[q].y};
+      {
+        const uint32_t b4 = static_cast<uint32_t>(ow_[q].x >> ((4u * static_cast<uint32_t>(g)) & 63u)) & 0xfu;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if ((b4 >> k) & 1u) lo[k] = ow_[q].y;
+      }
       const uint64_t stored[4] = {ca_[q].x, ca_[q].y, cb_[q].x, cb_[q].y};
       uint32_t nv4 = 0, freebits4 = 0;
 #pragma unroll

@@ -828,6 +828,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &m.last_occ, cfg->with_tracking ? cap * nv : 1, false));
   A(devAlloc(c, &m.trk_lim, cfg->with_tracking ? cap * 2 : 2));
   A(devAlloc(c, &m.freebits, cfg->with_tracking ? cap * (nv / 64) : 1, false));
+  A(devAlloc(c, &m.obs, cfg->with_tracking ? cap * (nv / 64) : 1, false));
   A(devAlloc(c, &m.free_slots, cap, false));
   A(devAlloc(c, &m.counters, C_COUNT));
   A(devAlloc(c, &m.stats, S_COUNT));
@@ -1301,7 +1302,7 @@ static void fillFuseFrame(const khr_ctx* c, const FrameSlot& s, const DevFrame& 
 }
 static void fillFuseMap(khr_ctx* c, FuseArgs* a) {
   DevMap& m = c->m;
-  a->blk_index = m.blk_index; a->blk_flags = m.blk_flags; a->dist = m.dist; a->weight = m.weight; a->last_obs = m.last_obs;
+  a->blk_index = m.blk_index; a->blk_flags = m.blk_flags; a->dist = m.dist; a->weight = m.weight; a->last_obs = m.last_obs; a->obs = m.obs;
   a->color = m.color; a->vflags = m.vflags; a->sem_label = m.sem_label; a->lik = m.lik; a->wg_stats = c->d_wg_stats;
   a->blk_band = m.blk_band;
   a->vs = c->p.vs; a->bs = c->p.bs; a->trunc = c->p.trunc; a->dropoff_eps = c->p.dropoff_eps; a->max_weight = c->p.max_weight;
@@ -3548,9 +3549,13 @@ int khr_download_block(khr_ctx* c, int32_t bx, int32_t by, int32_t bz, float* di
     raw_flags.resize(nv);
     HIP_TRY(D(raw_flags.data(), m.vflags + slot * nv, nv));
   }
+  std::vector<uint64_t> obs_words;  // lazily stored last_observed (DevMap::obs): {bits, stamp} per 64 voxels
   if (last_observed) {
-    if (c->cfg.with_tracking) HIP_TRY(D(last_observed, m.last_obs + slot * nv, nv * 8));
-    else std::memset(last_observed, 0, nv * 8);
+    if (c->cfg.with_tracking) {
+      HIP_TRY(D(last_observed, m.last_obs + slot * nv, nv * 8));
+      obs_words.resize(2 * (nv / 64));
+      HIP_TRY(D(obs_words.data(), m.obs + slot * (nv / 64), (nv / 64) * 16));
+    } else std::memset(last_observed, 0, nv * 8);
   }
   if (last_occupied) {
     if (c->cfg.with_tracking) HIP_TRY(D(last_occupied, m.last_occ + slot * nv, nv * 8));
@@ -3569,6 +3574,9 @@ int khr_download_block(khr_ctx* c, int32_t bx, int32_t by, int32_t bz, float* di
   if (block_flags) HIP_TRY(D(&bf, m.blk_flags + slot, 4));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (block_flags) *block_flags = static_cast<uint8_t>(bf & 0xfu);
+  for (size_t w = 0; w < obs_words.size() / 2; ++w)
+    for (int b = 0; b < 64; ++b)
+      if ((obs_words[2 * w] >> b) & 1ull) last_observed[64 * w + b] = obs_words[2 * w + 1];
   // lazily stored last_occupied (k_tracking_update): an occupied voxel's stamp is the latest pass's stamp
   if (last_occupied && c->cfg.with_tracking)
     for (size_t i = 0; i < nv; ++i)

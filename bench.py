@@ -59,6 +59,10 @@ def parse_args():
     ap.add_argument("--no-tracking", action="store_true", default=None, help="leave out TrackingIntegrator::updateBlocks (c1)")
     ap.add_argument("--preroll", type=int, default=None,
                     help="frames fused before the warm-up (untimed): brings the map and the tracker to steady state; default 60 for c3, 0 otherwise")
+    ap.add_argument("--lookahead", action="store_true",
+                    help="hand the next frame over with khr_ingest_ahead while the current one is fused (N = 1).  Off by default: measured in "
+                         "round 4, it does not shorten the step (the host and the main stream meet at the seed count every frame) and "
+                         "the early conversion competes with k_fuse for the memory path")
     ap.add_argument("--latency-frames", type=int, default=8,
                     help="frames after the timed region that are run with a device synchronisation after each: per-frame latency "
                          "(the reference's active_window/all scope) beside the pipelined throughput; 0 = skip")
@@ -378,7 +382,15 @@ def main():
                     if args.output_copy != "none":
                         flags |= ctx.PF_SNAPSHOT
             _t0 = time.perf_counter()
+            if ahead_of[0] == i:
+                flags |= ctx.PF_INGESTED
             slot, n_dyn = ctx.process_frame(sensor, frame_desc[i], True, flags)
+            ahead_of[0] = -1
+            # input look-ahead (khr_ingest_ahead): the stream's next frame is resident, so it is converted on the second stream
+            # while this frame is fused -- the frontend's input queue already holds it (one conversion per step, as before)
+            if lookahead and len(cams) == 1 and i + 1 < n_total and (flags & ctx.PF_MOTION):
+                if ctx.ingest_ahead(sensor, frame_desc[i + 1]) is not None:
+                    ahead_of[0] = i + 1
             _t1 = time.perf_counter()
             host_t[0] += _t1 - _t0
             if args.output_copy == "host":
@@ -421,6 +433,8 @@ def main():
                     obj_stats[2] += time.perf_counter() - t_e
 
     copy_stats = [0, 0]       # outputs whose map clone was taken, bytes brought to the host (--output-copy)
+    ahead_of = [-1]           # index of the frame handed over by khr_ingest_ahead
+    lookahead = args.lookahead and world == 1 and not emu
     held_snapshot = [None]
     # ---- --output-copy host: the pipelined host consumer ----
     host_fields = (("indices", torch.int32, 3), ("distance", torch.float32, 4096), ("weight", torch.float32, 4096)) + (
@@ -640,6 +654,7 @@ def main():
         **({"emulation": "rank 0 of a %d-rank sharded run played by one process, no collectives: `value` is what the job would reach "
                          "if communication were free and all ranks were as loaded as rank 0 -- NOT a measured N-GPU number" % world}
            if emu else {}),
+        "input_lookahead": bool(lookahead),
         "output_copy": {"mode": args.output_copy,
                         "what": {"none": "the timed steps hand out no clone of the updated blocks (frames and map stay in HBM)",
                                  "device": "every output takes a device-side snapshot of the updated blocks (khr_snapshot_updated between meshing "

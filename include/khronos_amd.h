@@ -358,8 +358,19 @@ int khr_object_prune(khr_ctx* ctx, float min_confidence, float min_observations,
                                   queued on the context's stream writes them).  The ingest then runs on the context's second
                                   stream beside the previous frame's tail instead of behind it.  Without the flag the ingest is
                                   ordered behind everything queued on the context's stream, as every other call is. */
+#define KHR_PF_INGESTED 64u /* the frame was handed over earlier with khr_ingest_ahead: `sensor` / `frame` must describe the same
+                               frame (its pose and stamp are read again), its images are not touched any more */
 int khr_process_frame(khr_ctx* ctx, const khr_sensor* sensor, const khr_frame* frame, int on_device, uint32_t flags,
                       int* n_clusters);
+/* Input look-ahead (no reference counterpart: ActiveWindow::spinOnce takes one packet at a time, active_window.cpp:118; a
+ * frontend whose input queue already holds the NEXT packet can hand it over while the current frame is still being fused):
+ * the frame (device buffers, complete when the call is made) is converted into the next ring slot on the context's second
+ * stream right away, beside the current frame's kernels, instead of when its own khr_process_frame call comes around -- the
+ * main stream then finds the next frame's first kernel already waiting when it finishes the current one.  The following
+ * khr_process_frame call must pass the same frame with KHR_PF_INGESTED | KHR_PF_INPUT_READY | KHR_PF_MOTION.  Returns the slot,
+ * KHR_ESTATE when a handed-over frame is still waiting, or KHR_ENOTFOUND when the look-ahead is not possible right now (ring
+ * too small, tracking layer off): the caller then simply processes the frame the usual way. */
+int khr_ingest_ahead(khr_ctx* ctx, const khr_sensor* sensor, const khr_frame* frame);
 
 /* -- output / inspection ----------------------------------------------------------------------- */
 /* khr_stats.pool_exhausted alone (records dropped by an exchange buffer that was too small, failed block allocations;

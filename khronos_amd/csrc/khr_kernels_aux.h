@@ -896,53 +896,25 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
       __syncthreads();  // everybody has read s_may_cross before thread 0 clears it for the next block
       continue;
     }
-    // staging of the (VPS + 1)^3 corner lattice: the loads of kStageBatch iterations are issued together (addresses come from
-    // the LDS neighbour table, never from earlier loads); one load -> LDS store -> next load per iteration exposed ~20 round
-    // trips per block and pass
-    {
-      constexpr int kStageBatch = 5;
-      constexpr int NIT = (T * T * T + 255) / 256;
-      for (int i0 = 0; i0 < NIT; i0 += kStageBatch) {
-        float dv[kStageBatch], wv[kStageBatch];
-        int sel_[kStageBatch], li[kStageBatch];
-#pragma unroll
-        for (int u = 0; u < kStageBatch; ++u) {
-          const int c = min(static_cast<int>(threadIdx.x) + 256 * (i0 + u), T * T * T - 1);
-          int x = c % T, y = (c / T) % T, z = c / (T * T);
-          int sel = 0;
-          if (x >= VPS) { x -= VPS; sel |= 1; }
-          if (y >= VPS) { y -= VPS; sel |= 2; }
-          if (z >= VPS) { z -= VPS; sel |= 4; }
-          sel_[u] = sel;
-          li[u] = x + VPS * (y + VPS * z);
-          const uint32_t ns = s_nslot[sel];
-          // (a missing neighbour reads the block's own voxel: a valid address whose value is not used)
-          const size_t o = static_cast<size_t>(ns != kInvalidSlot ? ns : static_cast<uint32_t>(slot)) * NV + li[u];
-          dv[u] = m.dist[o];
-          wv[u] = m.weight[o];
-        }
-#pragma unroll
-        for (int u = 0; u < kStageBatch; ++u) {
-          const int c = static_cast<int>(threadIdx.x) + 256 * (i0 + u);
-          if (c >= T * T * T) continue;
-          const int sel = sel_[u];
-          float d = dv[u], w = wv[u];
-          if (s_nslot[sel] == kInvalidSlot) {
-            d = 0.f, w = -1.f;  // missing neighbour block => unobserved
-            if (s_nrec[sel]) {
-              int x = c % T, y = (c / T) % T, z = c / (T * T);
-              if (x >= VPS) x -= VPS;
-              if (y >= VPS) y -= VPS;
-              if (z >= VPS) z -= VPS;
-              const int pl = MH::planeOf(sel), pi = MH::indexOf(sel, x, y, z);
-              d = MH::dist(s_nrec[sel], pl, pi);
-              w = MH::weight(s_nrec[sel], pl, pi);
-            }
-          }
-          s_d[c] = d;
-          s_ok[c] = (w >= p.mesh_min_weight) ? 1 : 0;
-        }
+    for (int c = threadIdx.x; c < T * T * T; c += 256) {
+      int x = c % T, y = (c / T) % T, z = c / (T * T);
+      int sel = 0;
+      if (x >= VPS) { x -= VPS; sel |= 1; }
+      if (y >= VPS) { y -= VPS; sel |= 2; }
+      if (z >= VPS) { z -= VPS; sel |= 4; }
+      const uint32_t ns = s_nslot[sel];
+      float d = 0.f, w = -1.f;  // missing neighbour block => unobserved
+      if (ns != kInvalidSlot) {
+        const size_t o = static_cast<size_t>(ns) * NV + (x + VPS * (y + VPS * z));
+        d = m.dist[o];
+        w = m.weight[o];
+      } else if (s_nrec[sel]) {
+        const int pl = MH::planeOf(sel), pi = MH::indexOf(sel, x, y, z);
+        d = MH::dist(s_nrec[sel], pl, pi);
+        w = MH::weight(s_nrec[sel], pl, pi);
       }
+      s_d[c] = d;
+      s_ok[c] = (w >= p.mesh_min_weight) ? 1 : 0;
     }
     __syncthreads();
     const float ox = static_cast<float>(bi.x) * p.bs, oy = static_cast<float>(bi.y) * p.bs,
@@ -1028,13 +1000,6 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
         const int index = s_case[lin];
         const int col = 3 * static_cast<int>(tri - s_toff[lin]);
         const int ix = lin % VPS, iy = (lin / VPS) % VPS, iz = lin / (VPS * VPS);
-        // the triangle's three vertices: geometry and attribute sources first, then ALL attribute loads, then the stores (the
-        // output arrays may alias the map as far as the compiler knows: load / store / load / store was three exposed round trips)
-        float px_[3], py_[3], pz_[3];
-        size_t so_[3];
-        int sel3[3], pi3[3];
-        uint32_t col_[3], lab_[3];
-        uint64_t st_[3];
 #pragma unroll
         for (int kk = 2; kk >= 0; --kk) {
           const int e = s_tri[index * 16 + col + kk];
@@ -1056,9 +1021,10 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
           const float p1x = ox + (static_cast<float>(ix + bx) + 0.5f) * p.vs;
           const float p1y = oy + (static_cast<float>(iy + by) + 0.5f) * p.vs;
           const float p1z = oz + (static_cast<float>(iz + bz) + 0.5f) * p.vs;
-          px_[kk] = p0x + t * (p1x - p0x);
-          py_[kk] = p0y + t * (p1y - p0y);
-          pz_[kk] = p0z + t * (p1z - p0z);
+          const size_t vo = static_cast<size_t>(boff) + 3u * tri + static_cast<uint32_t>(2 - kk);
+          out.points[3 * vo] = p0x + t * (p1x - p0x);
+          out.points[3 * vo + 1] = p0y + t * (p1y - p0y);
+          out.points[3 * vo + 2] = p0z + t * (p1z - p0z);
           // attributes of the nearer endpoint voxel
           const int sx = (t <= 0.5f) ? ix + ax : ix + bx, sy = (t <= 0.5f) ? iy + ay : iy + by,
                     sz = (t <= 0.5f) ? iz + az : iz + bz;
@@ -1066,37 +1032,18 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
           if (lx >= VPS) { lx -= VPS; sel |= 1; }
           if (ly >= VPS) { ly -= VPS; sel |= 2; }
           if (lz >= VPS) { lz -= VPS; sel |= 4; }
-          sel3[kk] = sel;
-          pi3[kk] = lx + VPS * (ly + VPS * lz);
-          const uint32_t ns = s_nslot[sel];
-          // (a source voxel in a block of another rank is read from its halo record below; the local load then reads the
-          //  block's own voxel, a valid address whose value is not used)
-          so_[kk] = static_cast<size_t>(ns != kInvalidSlot ? ns : static_cast<uint32_t>(slot)) * NV + pi3[kk];
-        }
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-          col_[kk] = m.color[so_[kk]];
-          lab_[kk] = p.with_semantics ? m.sem_label[so_[kk]] : 0u;
-          st_[kk] = p.with_tracking ? lastObserved(m, so_[kk] / NV, static_cast<uint32_t>(so_[kk] % NV), NV) : 0ull;
-        }
-#pragma unroll
-        for (int kk = 2; kk >= 0; --kk) {
-          const int sel = sel3[kk];
-          if (s_nslot[sel] == kInvalidSlot) {  // the source voxel lives in a block of another rank: attributes from its halo record
+          if (s_nslot[sel] != kInvalidSlot) {
+            const size_t so = static_cast<size_t>(s_nslot[sel]) * NV + (lx + VPS * (ly + VPS * lz));
+            out.colors[vo] = m.color[so];
+            out.labels[vo] = p.with_semantics ? m.sem_label[so] : 0u;
+            out.stamps[vo] = p.with_tracking ? lastObserved(m, s_nslot[sel], static_cast<uint32_t>(lx + VPS * (ly + VPS * lz)), NV) : 0ull;
+          } else {  // the source voxel lives in a block of another rank: attributes from its halo record
             const uint32_t* rec = s_nrec[sel];
-            const int lz = pi3[kk] / (VPS * VPS), ly = (pi3[kk] / VPS) % VPS, lx = pi3[kk] % VPS;
             const int pl = MH::planeOf(sel), pi = MH::indexOf(sel, lx, ly, lz);
-            col_[kk] = MH::color(rec, pl, pi);
-            lab_[kk] = p.with_semantics ? MH::label(rec, pl, pi) : 0u;
-            st_[kk] = p.with_tracking ? MH::stamp(rec, pl, pi) : 0ull;
+            out.colors[vo] = MH::color(rec, pl, pi);
+            out.labels[vo] = p.with_semantics ? MH::label(rec, pl, pi) : 0u;
+            out.stamps[vo] = p.with_tracking ? MH::stamp(rec, pl, pi) : 0ull;
           }
-          const size_t vo = static_cast<size_t>(boff) + 3u * tri + static_cast<uint32_t>(2 - kk);
-          out.points[3 * vo] = px_[kk];
-          out.points[3 * vo + 1] = py_[kk];
-          out.points[3 * vo + 2] = pz_[kk];
-          out.colors[vo] = col_[kk];
-          out.labels[vo] = lab_[kk];
-          out.stamps[vo] = st_[kk];
         }
       }
     }

@@ -486,9 +486,10 @@ struct FuseItem {
   float oz, pxy2;  // block origin z; x-y part of the depth row (ray-length mode recomputes the depth in phase 2)
   // per lane
   int lin_xy;
-  float u[ZR], v[ZR], z[ZR], yz[ZR], d[ZR], w[ZR];
+  float u[ZR], v[ZR], z[ZR], yz[ZR], d[ZR], w[ZR];  // z: the voxel's range, or -1 for a voxel phase 1 has already ruled out (a lane
+                                                    // mask per z-step and item state would be 16 more scalar registers alive
+                                                    // through the loop; the kernel spills scalars into vector lanes as it is)
   f2u ra[ZR], rb[ZR];
-  bool ok[ZR];
 };
 
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
   const float yden = rcpRefined(den);
   const char* const range_b = reinterpret_cast<const char*>(a.range);
   const uint32_t W4 = static_cast<uint32_t>(a.W) * 4u;
-  const uint32_t nc0 = list.counts[0], nc1 = nc0 + list.counts[1], nc2 = nc1 + list.counts[2], n_items = nc2 + list.counts[3];
+  const uint32_t n_items = list.counts[0] + list.counts[1] + list.counts[2] + list.counts[3];
   uint32_t n_upd = 0, n_band = 0;
   const int dbg = DBG ? a.dbg : 0;
   // (timeline probe: the constant 100 MHz counter is common to all XCDs, s_memtime is not)
@@ -545,13 +546,23 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
   };
   // descriptor of item i in deal order: class 0, 1, 2, 3 (FuseList), through the scalar cache (the list was written by the
   // previous kernel; scalar loads return on lgkmcnt and are not ordered behind the wave's vector stores)
-  const DescK la = (DescK)list.a, lb = (DescK)list.b;
+  // The list's pointers and class boundaries are read from the kernel-argument segment / the counter words each time (scalar
+  // cache hits) instead of living in a dozen scalar registers through the loop: the kernel needs more scalars than there are
+  // registers, and every spilled one costs vector instructions (v_writelane / v_readlane) on the path that is VALU bound.
   auto descOf = [&](uint32_t i) -> uint4 {
+    typedef const FuseList __attribute__((address_space(4))) * FuseListK;
+    const char __attribute__((address_space(4)))* kb = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kb));
+    const FuseListK kl = (FuseListK)(kb + ((sizeof(FuseArgs) + 7u) & ~static_cast<size_t>(7)));
+    const uint32_t __attribute__((address_space(4)))* const kc = (const uint32_t __attribute__((address_space(4)))*)kl->counts;
+    const uint32_t c0 = kc[0], c1 = c0 + kc[1], c2 = c1 + kc[2];
+    const DescK la = (DescK)kl->a, lb = (DescK)kl->b;
+    const uint32_t cap = kl->cap;
     u4v d;
-    if (i < nc0) d = la[i];
-    else if (i < nc1) d = la[list.cap - 1u - (i - nc0)];
-    else if (i < nc2) d = lb[i - nc1];
-    else d = lb[list.cap - 1u - (i - nc2)];
+    if (i < c0) d = la[i];
+    else if (i < c1) d = la[cap - 1u - (i - c0)];
+    else if (i < c2) d = lb[i - c1];
+    else d = lb[cap - 1u - (i - c2)];
     return make_uint4(d.x, d.y, d.z, d.w);
   };
 
@@ -610,9 +621,8 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
       it.w[k] = *reinterpret_cast<const float*>(wgt_b + lin * 4u);
       it.u[k] = uc;
       it.v[k] = vc;
-      it.z[k] = voxel_range;
+      it.z[k] = ok ? voxel_range : -1.f;
       it.yz[k] = yz;
-      it.ok[k] = ok;
     }
   };
 
@@ -632,12 +642,12 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
     // last_observed is stored lazily: {bits, stamp} of the item's ZR 64-voxel groups, through the scalar cache (each word has
     // exactly one writer per launch -- this wave, at the end of the z-step -- so what the previous launch left is what we read)
     const size_t w0 = slot * static_cast<size_t>(NV / 64) + static_cast<size_t>(cur.z0 * PATCHES + cur.sbi % PATCHES);
-    u4v ow[ZR];
-#pragma unroll
-    for (int k = 0; k < ZR; ++k) ow[k] = trk ? ((DescK)(a.obs + w0))[k * PATCHES] : u4v{0u, 0u, 0u, 0u};
+    u4v ow_next = trk ? ((DescK)(a.obs + w0))[0] : u4v{0u, 0u, 0u, 0u};  // (one z-step ahead: 8 scalar registers, not 4 ZR)
 #pragma unroll
     for (int k = 0; k < ZR; ++k) {
-      bool ok = cur.ok[k];
+      const u4v ow_k = ow_next;
+      if (k + 1 < ZR && trk) ow_next = ((DescK)(a.obs + w0))[(k + 1) * PATCHES];
+      bool ok = cur.z[k] >= 0.f;
       const int iz = cur.z0 + k;
       const uint32_t lin = static_cast<uint32_t>(cur.lin_xy + iz * SL);
       const float d_old = cur.d[k], w_old = cur.w[k];
@@ -764,8 +774,8 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
         // and replaces the word; at the same stamp it only adds its bits.  Both stores are always issued: the lanes without
         // anything to write out repeat the first such lane's store (same address, same value: one request) or, when there
         // is none or no tracking layer, go to the wave's sink line.
-        const uint64_t bits0 = static_cast<uint64_t>(ow[k].x) | (static_cast<uint64_t>(ow[k].y) << 32);
-        const uint64_t stamp0 = static_cast<uint64_t>(ow[k].z) | (static_cast<uint64_t>(ow[k].w) << 32);
+        const uint64_t bits0 = static_cast<uint64_t>(ow_k.x) | (static_cast<uint64_t>(ow_k.y) << 32);
+        const uint64_t stamp0 = static_cast<uint64_t>(ow_k.z) | (static_cast<uint64_t>(ow_k.w) << 32);
         const bool same = stamp0 == a.stamp;
         const uint64_t mat = (m_ok != 0ull && !same) ? (bits0 & ~m_ok) : 0ull;
         const uint64_t nb = m_ok == 0ull ? bits0 : (same ? (bits0 | m_ok) : m_ok);

@@ -212,6 +212,8 @@ struct khr_ctx {
   hipEvent_t ev_up = nullptr;                    // the last upload out of h_up has been consumed
   hipStream_t ingest_stream = nullptr;           // khr_process_frame: ingest on the auxiliary stream (set around khr_upload_frame)
   bool early_ingest = true;                      // env KHR_NO_EARLY_INGEST=1 turns it off
+  int ahead_slot = -1;                           // frame converted by khr_ingest_ahead, waiting for its khr_process_frame
+  hipEvent_t ev_ahead = nullptr;
   int ef_parity = 0, ef_cur = 0;  // which of C_N_EF / C_N_EF2 the next / the latest tracking pass fills
   hipEvent_t ev_seed = nullptr;
   uint32_t last_removed = 0;
@@ -3268,6 +3270,27 @@ int khr_last_removed(khr_ctx* c, int32_t* removed, int64_t cap, int64_t* n_remov
   return fetchRemoved(c, removed, cap, n_removed);
 }
 
+int khr_ingest_ahead(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame) {
+  if (!c || !sensor || !frame) return fail(KHR_EINVAL, "null argument");
+  if (c->ahead_slot >= 0) return fail(KHR_ESTATE, "a frame handed over by khr_ingest_ahead is still waiting for khr_process_frame");
+  // the same conditions as the early ingest inside khr_process_frame, plus a ring with a slot to spare: the slot of the frame
+  // being processed and the one before it may still be read
+  const int next = peekSlot(c);
+  if (!c->early_ingest || !c->cfg.with_tracking || c->slots.size() < 3 || next < 0 || next == c->last_frame_slot) return KHR_ENOTFOUND;
+  HIP_TRY(hipSetDevice(c->device));
+  c->begin_in_ingest = false;
+  c->ingest_stream = c->aux_stream;
+  const int slot = khr_upload_frame(c, sensor, frame, 1);
+  c->ingest_stream = nullptr;
+  if (slot < 0) return slot;
+  if (!c->ev_ahead) HIP_TRY(hipEventCreateWithFlags(&c->ev_ahead, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(c->ev_ahead, c->aux_stream));
+  c->slots[slot].aux_seq = ++c->aux_seq_issued;
+  c->slot_leases[slot].fetch_add(1, std::memory_order_acq_rel);  // (nobody else may take the slot before it is processed)
+  c->ahead_slot = slot;
+  return slot;
+}
+
 int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame, int on_device, uint32_t flags,
                       int* n_clusters) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
@@ -3283,19 +3306,34 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   // Not when the ring hands back the slot of the frame queued just before (everything else is retained): that frame's
   // update / summary / tracking kernels may still be running on the main stream, and the auxiliary stream is not ordered
   // behind them -- the ingest then stays on the main stream.
-  const bool early = c->early_ingest && (flags & KHR_PF_INPUT_READY) && on_device && motion && c->cfg.with_tracking &&
-                     c->slots.size() >= 2 && peekSlot(c) != c->last_frame_slot;
-  c->begin_in_ingest = !early;
-  c->ingest_stream = early ? c->aux_stream : nullptr;
-  const int slot = khr_upload_frame(c, sensor, frame, on_device);
-  c->ingest_stream = nullptr;
-  c->begin_in_ingest = false;
-  if (slot < 0) return slot;
+  const bool ahead = (flags & KHR_PF_INGESTED) != 0;
+  if (ahead && (c->ahead_slot < 0 || !frame || !motion || !(flags & KHR_PF_INPUT_READY) ||
+                c->slots[c->ahead_slot].meta.timestamp_ns != frame->timestamp_ns))
+    return fail(KHR_ESTATE, "KHR_PF_INGESTED: no frame with this stamp was handed over by khr_ingest_ahead (or flags are missing)");
+  if (!ahead && c->ahead_slot >= 0) return fail(KHR_ESTATE, "the frame handed over by khr_ingest_ahead has to be processed first");
+  const bool early = ahead || (c->early_ingest && (flags & KHR_PF_INPUT_READY) && on_device && motion && c->cfg.with_tracking &&
+                               c->slots.size() >= 2 && peekSlot(c) != c->last_frame_slot);
+  int slot;
+  if (ahead) {
+    slot = c->ahead_slot;
+    c->ahead_slot = -1;
+    c->slot_leases[slot].fetch_sub(1, std::memory_order_acq_rel);  // (the look-ahead's own lease)
+  } else {
+    c->begin_in_ingest = !early;
+    c->ingest_stream = early ? c->aux_stream : nullptr;
+    slot = khr_upload_frame(c, sensor, frame, on_device);
+    c->ingest_stream = nullptr;
+    c->begin_in_ingest = false;
+    if (slot < 0) return slot;
+  }
   c->last_frame_slot = slot;
   FrameSlot& s = c->slots[slot];
   const DevFrame f = makeDevFrame(c, s);
   int rc = KHR_OK;
-  if (early) {
+  if (ahead) {
+    c->begun = false;
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_ahead, 0));
+  } else if (early) {
     c->begun = false;
     s.aux_seq = ++c->aux_seq_issued;
     HIP_TRY(hipEventRecord(c->ev_aux_done, c->aux_stream));

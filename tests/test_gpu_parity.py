@@ -266,16 +266,29 @@ def test_tracking_shortcuts_are_exact():
     both_equal()
 
 
-@pytest.mark.parametrize("inputs", ["host", "device", "device-ready"])
+@pytest.mark.parametrize("inputs", ["host", "device", "device-ready", "device-ahead"])
 def test_fused_process_frame_equals_stepwise(inputs):
     """khr_process_frame (one call per frame, asynchronous output stage) == the step-by-step calls; with host buffers, with
-    device buffers, and with device buffers declared complete (KHR_PF_INPUT_READY: the ingest runs ahead on the context's
-    second stream and the per-frame counter reset moves into the motion detector's pixel pass)."""
+    device buffers, with device buffers declared complete (KHR_PF_INPUT_READY: the ingest runs ahead on the context's
+    second stream and the per-frame counter reset moves into the motion detector's pixel pass), and with every frame handed
+    over one frame early (khr_ingest_ahead + KHR_PF_INGESTED: converted while the previous frame is fused)."""
     from common import DeviceArray
-    cfg, ctx, ora, s, sen, osen = make_pair(width=320, height=240, temporal_window=0.75, num_frame_slots=3)
+    cfg, ctx, ora, s, sen, osen = make_pair(width=320, height=240, temporal_window=0.75, num_frame_slots=4 if inputs == "device-ahead" else 3)
     fired = 0
     held = []
-    for i in range(20):
+    N = 20
+
+    def device_frame(i):
+        fr = s.render(i)
+        f = ctx.make_frame(fr["stamp"], fr["pose"], 0)
+        dev = [DeviceArray(np.ascontiguousarray(fr[k])) for k in ("depth", "rgb", "label")]  # (hipMemcpy: complete when it returns)
+        held.append(dev)
+        f.depth, f.color, f.label = (d.data_ptr() for d in dev)
+        return f
+
+    ahead = {}  # frame index -> descriptor handed over with khr_ingest_ahead
+    n_ahead = 0
+    for i in range(N):
         fr = s.render(i)
         out_now = i % 4 == 3
         f = ctx.make_frame(fr["stamp"], fr["pose"], 0)
@@ -283,6 +296,13 @@ def test_fused_process_frame_equals_stepwise(inputs):
         flags = ctx.PF_MOTION | ctx.PF_TRACKING | (ctx.PF_OUTPUT if out_now else 0)
         if inputs == "host":
             f.depth, f.color, f.label = depth.ctypes.data, rgb.ctypes.data, lab.ctypes.data
+        elif inputs == "device-ahead":
+            flags |= ctx.PF_INPUT_READY
+            if i in ahead:
+                f = ahead.pop(i)
+                flags |= ctx.PF_INGESTED
+            else:
+                f = device_frame(i)
         else:
             dev = [DeviceArray(depth), DeviceArray(rgb), DeviceArray(lab)]  # (hipMemcpy: complete when it returns)
             held.append(dev)
@@ -290,6 +310,15 @@ def test_fused_process_frame_equals_stepwise(inputs):
             if inputs == "device-ready":
                 flags |= ctx.PF_INPUT_READY
         slot, nc = ctx.process_frame(sen, f, on_device=inputs != "host", flags=flags)
+        if inputs == "device-ahead" and i + 1 < N:
+            nf = device_frame(i + 1)
+            if ctx.ingest_ahead(sen, nf) is not None:
+                ahead[i + 1] = nf
+                n_ahead += 1
+                with pytest.raises(Exception):  # a second hand-over before the first one is processed is refused
+                    ctx.ingest_ahead(sen, nf)
+            else:
+                held.pop()
         n_o, dyn_o, _ = ora.detect_motion(osen, fr["stamp"], fr["pose"], fr["depth"])
         assert nc == n_o
         fired += nc
@@ -304,6 +333,7 @@ def test_fused_process_frame_equals_stepwise(inputs):
             assert gm["points"].shape == om["points"].shape
             assert np.abs(gm["points"] - om["points"]).max() <= TOL if len(om["points"]) else True
     assert fired > 0
+    assert inputs != "device-ahead" or n_ahead >= N - 2
     compare_maps(ctx, ora, max_blocks=100)
     ctx.sync()
     for dev in held:

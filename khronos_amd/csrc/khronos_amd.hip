@@ -205,6 +205,7 @@ struct khr_ctx {
   // pinned host staging (downloads, block-index uploads): grow-only; one transfer batch in flight per buffer
   void* h_stage = nullptr;
   size_t h_stage_bytes = 0;
+  uint32_t* h_totals = nullptr;  // refreshMeshTotals' own pinned words
   void* h_up = nullptr;                          // upload staging (khr_allocate_blocks) + its device twin
   size_t h_up_bytes = 0;
   void* d_up = nullptr;
@@ -529,7 +530,7 @@ int kTickUnion = 1;     // env KHR_TICK_UNION: khr_tick_integrate updates with O
 int kFuseMulti = 1;     // env KHR_FUSE_MULTI: khr_integrate_shared_batch integrates all frames of a batch in one launch (k_fuse2 MULTI)
 constexpr int kMaxMultiFrames = 1024;
 int kFuseSpec = 1;      // env KHR_FUSE_SPECULATIVE: khr_process_frame queues k_fuse before the seed count has reached the host (gated on the device)
-int kFuseBand = 1;      // env KHR_FUSE_BAND: 1 = likelihood rows as whole cache lines, 8 lanes per row (fuseBandRows, default), 0 = lane <-> record
+int kFuseBand = 1;      // env KHR_FUSE_BAND: 1 = likelihood rows as whole cache lines, 8 lanes per row (fuseBandRows; default, lane <-> record for small frames), 2 = rows always, 0 = lane <-> record
 constexpr int kStreamGrid = 4096;
 
 }  // namespace
@@ -645,7 +646,11 @@ static bool ctxIsLive(khr_ctx* c) {
 
 int khr_release_slot(khr_ctx* c, int slot) {
   if (!c) return fail(KHR_EINVAL, "bad slot");
-  if (!ctxIsLive(c)) return KHR_OK;  // the context (and with it the frame ring) is gone: nothing to give back
+  // the registry lock is held across the dereference: khr_destroy takes the context off the registry under the
+  // same lock before it frees it, so a release that has seen the context alive finishes before the ring goes away
+  std::lock_guard<std::mutex> live_lock(g_live_mu);
+  if (std::find(g_live_ctx.begin(), g_live_ctx.end(), c) == g_live_ctx.end())
+    return KHR_OK;  // the context (and with it the frame ring) is gone: nothing to give back
   if (slot < 0 || slot >= static_cast<int>(c->slots.size())) return fail(KHR_EINVAL, "bad slot");
   // decrement only while positive (leases are taken and dropped by the frame thread and by detached extraction workers:
   // an unmatched release must not erase a lease somebody else takes at the same moment)
@@ -846,7 +851,9 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &c->d_fetch_done, 4));
   {
     int zs = kFuseZsplit;
-    if (zs == 0) zs = cfg->world_size >= 4 ? 8 : 4;
+    // shards of a >= 4-rank map and small frames (up to 640 x 480 pixels) see few blocks per launch: 8 z ranges per patch
+    // instead of 4 halve the longest dependent chain (an item's band rounds) and double the items the waves can share
+    if (zs == 0) zs = (cfg->world_size >= 4 || cfg->max_frame_pixels <= 640u * 480u) ? 8 : 4;
     if (zs != 4 && zs != 8) zs = 4;  // a wave item is a 64-voxel patch x 4 (or 2) z steps
     if (cfg->voxels_per_side == 8) zs = 4;
     c->fuse_zsplit = zs;
@@ -1003,6 +1010,7 @@ void khr_destroy(khr_ctx* c) {
   if (c->ev_frames) hipEventDestroy(c->ev_frames);
   if (c->h_pinned) hipHostFree(c->h_pinned);
   if (c->h_stage) hipHostFree(c->h_stage);
+  if (c->h_totals) hipHostFree(c->h_totals);
   if (c->h_up) hipHostFree(c->h_up);
   if (c->d_up) hipFree(c->d_up);
   if (c->ev_up) hipEventDestroy(c->ev_up);
@@ -1314,7 +1322,12 @@ static void fillFuseMap(khr_ctx* c, FuseArgs* a) {
   a->K = c->p.K; a->KS = c->p.KS; a->sem_mode = c->p.sem_mode;
   a->dbg = kFuseDbg;
   a->dbg_buf = c->d_dbg;
-  a->band_mode = kFuseBand;
+  // whole-line rows pay where the memory path is busy; small frames (up to 640 x 480: 3 - 5 k items, fewer than two per wave) are one
+  // dependent chain per wave, and there the shorter lane <-> record form wins (c1: 17.8 - 18.3 against 20.3 us).  Decided HERE, not
+  // from the item count inside the kernel: one more value alive in k_fuse's band dispatch tipped the register allocator into
+  // spilling vector registers inside the item loop (scratch traffic is vector memory: every wait became vmcnt(0), 72 -> 95 us;
+  // tests/test_cpu_host.py::test_update_kernel_keeps_its_registers guards the build against that)
+  a->band_mode = (kFuseBand == 1 && c->cfg.max_frame_pixels <= 640u * 480u) ? 0 : kFuseBand;
   a->sink = c->d_fuse_sink;
 }
 
@@ -1591,7 +1604,11 @@ static int waitWord(khr_ctx* c, volatile uint32_t* w, uint32_t ticket, const cha
     if ((++spins & 0xffffu) == 0) {
       const hipError_t q = hipStreamQuery(c->stream);
       if (q != hipSuccess && q != hipErrorNotReady) return fail(KHR_EDEVICE, "stream failed while waiting for %s: %s", what, hipGetErrorString(q));
-      if (q == hipSuccess && *w != ticket) return fail(KHR_EDEVICE, "%s was never published", what);
+      if (q == hipSuccess && *w != ticket) {
+        uint32_t done = 0xffffffffu;
+        if (c->d_fetch_done) (void)hipMemcpy(&done, c->d_fetch_done, sizeof(done), hipMemcpyDeviceToHost);
+        return fail(KHR_EDEVICE, "%s was never published (word %u, expected ticket %u, gather completion counter %u)", what, *w, ticket, done);
+      }
     }
   }
   return KHR_OK;
@@ -1773,6 +1790,10 @@ int khr_tick_adopt(khr_ctx* c, const khr_sensor* sensor, const khr_converted_fra
   c->tick_seed_collected = 0;
   const int tw = (sensor->width + kTile - 1) / kTile, th = (sensor->height + kTile - 1) / kTile;
   ScopedTimer tm(c, 6);
+  // slots adopted by an EARLIER tick refer to planes in a receive buffer the caller is about to reuse: they
+  // stop being readable here, instead of silently mixing the new tick's planes with the old tick's meta data
+  for (FrameSlot& old : c->slots)
+    if (old.x_range != nullptr) old.valid = false;
   if ((rc = acquireTickSlots(c, n_frames, slots_out))) return rc;
   TickSlotsGuard undo{c, slots_out, n_frames};
   for (int base = 0; base < n_frames; base += kMaxTick) {
@@ -3652,10 +3673,13 @@ int khr_map_digest(khr_ctx* c, uint64_t* out) {
 
 static int refreshMeshTotals(khr_ctx* c) {
   if (!c->mesh_stale) return KHR_OK;
-  // one round trip through the pinned block: mesh total, work count and the counter block (C_MESH_OVERFLOW, C_MAX_SLOT)
-  int rcs = ensureStage(c, sizeof(uint32_t) * (C_COUNT + 2));
-  if (rcs) return rcs;
-  uint32_t* hs = static_cast<uint32_t*>(c->h_stage);
+  // one round trip through a pinned block of its own: mesh total, work count and the counter block (C_MESH_OVERFLOW,
+  // C_MAX_SLOT).  NOT the mesh staging block: a gather queued by khr_fetch_mesh_launch may be writing there, and its ticket
+  // is header word 15 -- exactly where counter 13 of this copy used to land ("mesh gather was never published" whenever
+  // statistics were read between the launch and the fetch: bench.py --output-copy host beyond ~30 steps)
+  if (!c->h_totals && hipHostMalloc(reinterpret_cast<void**>(&c->h_totals), sizeof(uint32_t) * (C_COUNT + 2), hipHostMallocDefault) != hipSuccess)
+    return fail(KHR_ENOMEM, "pinned block for the mesh totals");
+  uint32_t* hs = c->h_totals;
   HIP_TRY(hipMemcpyAsync(hs, c->d_mesh_offset + c->m.capacity, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(hs + 1, c->d_mesh_nwork, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(hs + 2, c->m.counters, sizeof(uint32_t) * C_COUNT, hipMemcpyDeviceToHost, c->stream));
@@ -4029,6 +4053,10 @@ int64_t khr_mesh_num_vertices(khr_ctx* c) {
 int64_t khr_download_mesh(khr_ctx* c, float* points, uint8_t* colors_rgba, uint32_t* labels, uint64_t* first_seen,
                           uint64_t* stamps, int64_t cap) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
+  if (c->fetch_pending) {  // a gather queued by khr_fetch_mesh_launch writes the staging block this call is about to fill
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->fetch_pending = false;  // (a later khr_fetch_mesh starts over)
+  }
   // Two host round trips in all: (1) totals + counters (skipped when they are current), (2) block index, flags, mesh
   // descriptors and the vertex arrays as one batch of asynchronous copies into the pinned staging buffer.
   int rc = c->mesh_stale ? refreshMeshTotals(c) : (c->counters_gen == c->map_gen ? KHR_OK : readCounters(c));

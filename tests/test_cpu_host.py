@@ -240,3 +240,42 @@ def test_public_headers_are_plain_c():
         r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", "-I", inc, os.path.join(inc, hdr)],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_update_kernel_keeps_its_registers(tmp_path):
+    """k_fuse sits at the vector-register limit (168 of 512 / 3 waves per SIMD).  A vector register spilled INSIDE its item loop is
+    scratch traffic, i.e. vector memory the compiler cannot count: every partial wait of the software pipeline falls back to
+    vmcnt(0) and the kernel loses a third of its speed (seen in round 4: 72 -> 95 us after one more value became live in the
+    band dispatch).  The device code of the default instantiations must therefore compile without vector-register spills, and
+    the item loop must still wait for its loads with a partial vmcnt."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    asm = tmp_path / "dev.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only",
+                        "-Wno-unused-value", "-Wno-pass-failed", "-Rpass-analysis=kernel-resource-usage", "-o", str(asm),
+                        os.path.join(root, "khronos_amd", "csrc", "khronos_amd.hip")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    # -Rpass remarks: "Function Name: <mangled>" followed by that function's resource lines
+    blocks = re.split(r"remark: Function Name: ", r.stderr)
+    seen = 0
+    for b in blocks[1:]:
+        name = b.split()[0]
+        # the exact- and relaxed-arithmetic instantiations of the 16^3 window map with 4 and 8 z ranges, reference switches
+        if not re.match(r"_ZN3khr6k_fuseILi16ELi[48]ELb1ELb[01]ELi12ELb0EEE", name):
+            continue
+        seen += 1
+        m = re.search(r"VGPRs Spill: (\d+)", b)
+        assert m and int(m.group(1)) == 0, (name, m.group(0) if m else b[:400])
+    assert seen == 4, seen
+    text = asm.read_text()
+    start = text.index("_ZN3khr6k_fuseILi16ELi4ELb1ELb1ELi12ELb0EEEvNS_8FuseArgsENS_8FuseListE:")
+    body = text[start:text.index("s_endpgm", start)]
+    assert "scratch_" not in body
+    loop = body[body.index("Loop Header: Depth=1"):]
+    waits = [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", loop[:loop.index("Loop Header: Depth=2")])]
+    # phase 2 of an item waits for ITS loads while the next item's 16 loads and the previous item's stores stay in flight
+    assert max(waits) >= 28 and sum(1 for w in waits if w >= 16) >= 12, waits

@@ -149,6 +149,9 @@ def test_snapshot_async_masked_download_equals_blocking_download():
             snap = ctx.take_snapshot()
             assert snap is not None
             ctx.fetch_mesh_launch()
+            # statistics read while the gather is pending must not disturb it (round 4: the mesh totals used to travel through
+            # the same pinned block, and counter 13 landed on the gather's ticket word: "mesh gather was never published")
+            assert ctx.stats()["n_mesh_vertices"] > 0
         if i == 4:  # one frame later: the gather ran right behind the output's kernels; this only collects
             mesh_late = ctx.fetch_mesh()
     n = snap.num_blocks()

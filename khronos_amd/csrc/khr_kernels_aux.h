@@ -859,7 +859,7 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
     if (EMIT && new_count[slot] == 0u) {  // most mesh-updated blocks contain no surface: nothing to stage
       if (threadIdx.x == 0) {
         m.mesh_desc[slot] = MeshDesc{new_offset[slot], 0u};
-        if (clear_flag) m.blk_flags[slot] &= ~BLK_MESH_UPDATED;
+        if (clear_flag) atomicAnd(&m.blk_flags[slot], ~BLK_MESH_UPDATED);  // (atomic: the tracking pass may be setting its bits beside us)
       }
       continue;
     }
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
       const uint32_t boff = new_offset[slot];
       if (threadIdx.x == 0) {
         m.mesh_desc[slot] = MeshDesc{boff, total};
-        if (clear_flag) m.blk_flags[slot] &= ~BLK_MESH_UPDATED;
+        if (clear_flag) atomicAnd(&m.blk_flags[slot], ~BLK_MESH_UPDATED);  // (atomic: the tracking pass may be setting its bits beside us)
       }
       // per-cube triangle offsets + case numbers -> LDS, then the block's triangles are dealt out to the
       // threads round-robin (a thread that owns a row of surface cubes would otherwise emit ~100 vertices

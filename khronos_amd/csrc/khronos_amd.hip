@@ -165,6 +165,12 @@ struct khr_ctx {
   std::shared_ptr<SnapPool> snap_pool = std::make_shared<SnapPool>();
   khr_snapshot* pending_snapshot = nullptr;  // taken inside khr_process_frame(KHR_PF_SNAPSHOT)
   hipStream_t copy_stream = nullptr;         // khr_snapshot_download_begin: device -> host copies beside the frames' kernels
+  hipStream_t snap_stream = nullptr;         // khr_process_frame: the output's snapshot beside its marching cubes (both only read the voxel layers)
+  hipStream_t snap_stream_override = nullptr;  // (set around khr_snapshot_updated by khr_process_frame)
+  hipEvent_t ev_snap_fork = nullptr, ev_snap_join = nullptr;
+  hipStream_t mc_stream = nullptr;           // khr_process_frame: the output's marching cubes beside the tracking pass
+  hipEvent_t ev_mc_fork = nullptr, ev_mc_join = nullptr;
+  bool fork_after_select = false;            // trackingPhase records ev_mc_fork behind k_tracking_select
   // upper bound of the blocks an explicitly allocated map holds (khr_allocate_blocks since the last khr_reset_map; 0 =
   // unknown): the update kernel of an `allocate = false` integration (object mini-maps) sizes its persistent grid from it
   // instead of filling the chip with workgroups that find no item
@@ -519,6 +525,8 @@ int dispatchVps(khr_ctx* c, F&& f) {
   return fail(KHR_EINVAL, "voxels_per_side must be 8 or 16");
 }
 
+int kMcFork = 1;        // env KHR_MC_FORK=0: marching cubes on the main stream behind the tracking pass (A/B)
+int kSnapFork = 1;      // env KHR_SNAP_FORK=0: the output's snapshot on the main stream in front of marching cubes (A/B)
 int kFuseGrid = 0;      // 0 = resident workgroups of the instantiation (occupancy query) x CUs; env KHR_FUSE_GRID
 int kFuseZsplit = 0;    // 0 = by world size (wave items per x-y patch of a block: 2 / 4 / 8); env KHR_FUSE_ZSPLIT
 int kFuseExact = -1;    // -1 = !khr_config.relaxed_arithmetic; env KHR_FUSE_EXACT=0/1 overrides (A/B switch)
@@ -801,6 +809,8 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   p.rank = cfg->rank;
   p.world = cfg->world_size;
   p.dbg = std::getenv("KHR_DEBUG") ? std::atoi(std::getenv("KHR_DEBUG")) : 0;
+  if (std::getenv("KHR_MC_FORK")) kMcFork = std::atoi(std::getenv("KHR_MC_FORK"));
+  if (std::getenv("KHR_SNAP_FORK")) kSnapFork = std::atoi(std::getenv("KHR_SNAP_FORK"));
   if (std::getenv("KHR_FUSE_GRID")) kFuseGrid = std::max(8, std::min(kFuseStatSlots, std::atoi(std::getenv("KHR_FUSE_GRID"))));
   if (std::getenv("KHR_FUSE_ZSPLIT")) kFuseZsplit = std::atoi(std::getenv("KHR_FUSE_ZSPLIT"));
   if (std::getenv("KHR_FUSE_EXACT")) kFuseExact = std::atoi(std::getenv("KHR_FUSE_EXACT")) ? 1 : 0;
@@ -991,6 +1001,20 @@ void khr_destroy(khr_ctx* c) {
   if (c->d_pix_scratch) hipFree(c->d_pix_scratch);
   if (c->d_inst) hipFree(c->d_inst);
   if (c->pending_snapshot) khr_snapshot_release(c->pending_snapshot);
+  if (c->snap_stream) {
+    hipStreamSynchronize(c->snap_stream);
+    hipStreamDestroy(c->snap_stream);
+    c->snap_stream = nullptr;
+  }
+  if (c->ev_snap_fork) hipEventDestroy(c->ev_snap_fork);
+  if (c->ev_snap_join) hipEventDestroy(c->ev_snap_join);
+  if (c->mc_stream) {
+    hipStreamSynchronize(c->mc_stream);
+    hipStreamDestroy(c->mc_stream);
+    c->mc_stream = nullptr;
+  }
+  if (c->ev_mc_fork) hipEventDestroy(c->ev_mc_fork);
+  if (c->ev_mc_join) hipEventDestroy(c->ev_mc_join);
   if (c->copy_stream) {
     hipStreamSynchronize(c->copy_stream);
     hipStreamDestroy(c->copy_stream);
@@ -1555,6 +1579,8 @@ static int trackingPhase(khr_ctx* c, uint64_t stamp, int phase) {
       hipLaunchKernelGGL(k_tracking_select, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, lim_active, lim_free, force_full,
                          c->d_trk_proc, c->d_ef, cnt, cnt_next, c->fold_pending ? m.blk_band : nullptr);
       c->fold_pending = false;
+      // (khr_process_frame at output cadence: marching cubes start here, beside the rest of the tracking pass)
+      if (c->fork_after_select) HIP_TRY(hipEventRecord(c->ev_mc_fork, c->stream));
       hipLaunchKernelGGL((k_tracking_update<V, (V == 16 ? 4 : 1)>), dim3(V == 16 ? 4096 : 1024), dim3(256), 0, c->stream, m, c->p, stamp,
                          c->last_track_stamp, lim_active, lim_free, c->d_trk_proc, cnt);
       c->last_track_stamp = stamp;
@@ -3416,17 +3442,53 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
     if ((rc = clusterSummaryLaunch(c, s, pend))) return rc;
   }
   c->defer_fold = false;
-  if ((flags & KHR_PF_TRACKING) && (rc = khr_update_tracking(c, frame->timestamp_ns))) return rc;
+  // Output frames: marching cubes read distance / weight / colour / label / stamps, which the tracking pass does not touch
+  // (it writes voxel flags, last_occupied, free bits and -- atomically -- block flags): the mesh kernels are forked onto
+  // their own stream behind k_tracking_select (which has folded the update's block flags) and joined before archival.
+  const bool mc_fork = kMcFork && (flags & KHR_PF_OUTPUT) && (flags & KHR_PF_TRACKING) && c->cfg.with_tracking;
+  if (mc_fork) {
+    if (!c->mc_stream) HIP_TRY(hipStreamCreateWithFlags(&c->mc_stream, hipStreamNonBlocking));
+    if (!c->ev_mc_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_mc_fork, hipEventDisableTiming));
+    if (!c->ev_mc_join) HIP_TRY(hipEventCreateWithFlags(&c->ev_mc_join, hipEventDisableTiming));
+    c->fork_after_select = true;
+  }
+  rc = (flags & KHR_PF_TRACKING) ? khr_update_tracking(c, frame->timestamp_ns) : KHR_OK;
+  c->fork_after_select = false;
+  if (rc) return rc;
+  if (mc_fork) {
+    HIP_TRY(hipStreamWaitEvent(c->mc_stream, c->ev_mc_fork, 0));
+    hipStream_t main_stream = c->stream;
+    c->stream = c->mc_stream;  // (khr_generate_mesh queues everything on the context's stream)
+    rc = khr_generate_mesh(c, 1, 1);
+    c->stream = main_stream;
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(c->ev_mc_join, c->mc_stream));
+  }
   HT("pf_update_launched");
   // (5) output cadence (ActiveWindow::extractOutputData, active_window.cpp:217-249 + :169-171)
   if (flags & KHR_PF_OUTPUT) {
-    if ((rc = khr_generate_mesh(c, 1, 1))) return rc;
-    if (flags & KHR_PF_SNAPSHOT) {  // cloneUpdated (active_window.cpp:229): after meshing, before archival
+    const bool snap = (flags & KHR_PF_SNAPSHOT) != 0;
+    if (snap) {
+      // cloneUpdated (active_window.cpp:229; between the tracking pass and archival).  The clone (184 MB of plain copies at
+      // c3) and marching cubes (a few dependent round trips per block) both only READ the voxel layers and write different
+      // things: the clone is forked onto its own stream beside the mesh kernels and joined before archival changes the map
       if (c->pending_snapshot) khr_snapshot_release(c->pending_snapshot);
       c->pending_snapshot = nullptr;
+      if (!c->snap_stream) HIP_TRY(hipStreamCreateWithFlags(&c->snap_stream, hipStreamNonBlocking));
+      if (!c->ev_snap_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_snap_fork, hipEventDisableTiming));
+      if (!c->ev_snap_join) HIP_TRY(hipEventCreateWithFlags(&c->ev_snap_join, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(c->ev_snap_fork, c->stream));
+      HIP_TRY(hipStreamWaitEvent(c->snap_stream, c->ev_snap_fork, 0));
       const int64_t snap_cap = c->cfg.max_snapshot_blocks ? c->cfg.max_snapshot_blocks : 8192;  // (100 KB per block)
-      if ((rc = khr_snapshot_updated(c, KHR_SNAP_ALL, snap_cap, &c->pending_snapshot))) return rc;
+      c->snap_stream_override = kSnapFork ? c->snap_stream : nullptr;
+      rc = khr_snapshot_updated(c, KHR_SNAP_ALL, snap_cap, &c->pending_snapshot);
+      c->snap_stream_override = nullptr;
+      if (rc) return rc;
+      HIP_TRY(hipEventRecord(c->ev_snap_join, c->snap_stream));
     }
+    if (mc_fork) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_mc_join, 0));
+    else if ((rc = khr_generate_mesh(c, 1, 1))) return rc;
+    if (snap) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_snap_join, 0));
     if (c->cfg.with_tracking && (rc = resetInactiveLaunch(c))) return rc;
     if ((rc = khr_clear_updated(c))) return rc;
     HT("pf_output_launched");
@@ -3854,19 +3916,20 @@ int khr_snapshot_updated(khr_ctx* c, uint32_t fields, int64_t cap_blocks, khr_sn
   snap->o.K = c->p.K;
   snap->o.KS = c->p.KS;
   snap->o.track_stamp = c->last_track_stamp;
-  hipError_t e = hipMemsetAsync(snap->d_count, 0, 4, c->stream);
+  hipStream_t st = c->snap_stream_override ? c->snap_stream_override : c->stream;
+  hipError_t e = hipMemsetAsync(snap->d_count, 0, 4, st);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_snapshot_select, dim3(gridFor(c->m.capacity)), dim3(256), 0, c->stream, c->m, snap->d_count, snap->d_slots,
+    hipLaunchKernelGGL(k_snapshot_select, dim3(gridFor(c->m.capacity)), dim3(256), 0, st, c->m, snap->d_count, snap->d_slots,
                        snap->d_index, snap->cap);
     dispatchVps(c, [&](auto vps) {
-      hipLaunchKernelGGL((k_snapshot_pack<decltype(vps)::value>), dim3(2048), dim3(256), 0, c->stream, c->m, snap->d_count, snap->d_slots,
+      hipLaunchKernelGGL((k_snapshot_pack<decltype(vps)::value>), dim3(2048), dim3(256), 0, st, c->m, snap->d_count, snap->d_slots,
                          snap->cap, snap->o, snap->arena.d_count_host_view, snap->ticket);
       return KHR_OK;
     });
     e = hipGetLastError();
     // consumers on other streams (khr_snapshot_download_begin's copy stream) order themselves behind the pack kernel with this
     if (e == hipSuccess) e = hipEventCreateWithFlags(&snap->ev_packed, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventRecord(snap->ev_packed, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(snap->ev_packed, st);
   }
   if (e != hipSuccess) {
     if (snap->ev_packed) hipEventDestroy(snap->ev_packed);

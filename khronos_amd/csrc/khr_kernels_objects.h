@@ -235,6 +235,38 @@ __global__ __launch_bounds__(256) void k_gv_release(const uint32_t* __restrict__
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) keys[slots[i]] = kEmptyKey;
 }
 
+// k_gv_release + k_publish in one launch (round 4: the detector's and the voxel-set pass's chains each ended with these two
+// small kernels; a launch costs the host ~4.5 us and the chain ~5 us, and both chains are on the frame's critical path).
+// Every workgroup releases its share of the table slots; the workgroup that finishes last -- after everybody has read
+// *n_slots, which may be one of the counters the publish zeroes -- copies the result block to pinned host memory, zeroes
+// the counters and writes the ticket (k_publish, khr_kernels_aux.h).
+__global__ __launch_bounds__(256) void k_gv_release_publish(const uint32_t* __restrict__ slots, const uint32_t* __restrict__ n_slots,
+                                                           uint64_t* __restrict__ keys, uint32_t* __restrict__ done_count,
+                                                           const uint32_t* __restrict__ src, volatile uint32_t* __restrict__ dst_host,
+                                                           uint32_t rec_words, uint32_t max_recs, volatile uint32_t* __restrict__ ticket_host,
+                                                           uint32_t ticket, uint32_t* __restrict__ counters_to_zero) {
+  __shared__ uint32_t s_last;
+  const uint32_t n = *n_slots;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) keys[slots[i]] = kEmptyKey;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_last = atomicAdd(done_count, 1u) == gridDim.x - 1u ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const uint32_t n_words = 4u + min(src[0], max_recs) * rec_words;
+  for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) dst_host[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x < 4) counters_to_zero[threadIdx.x] = 0u;
+  if (threadIdx.x == 0) {
+    *done_count = 0u;  // ready for the next launch (stream order)
+    *ticket_host = ticket;
+    __threadfence_system();
+  }
+}
+
 // ---- ConnectedSemantics, 2D mode (semanticClustering2D / growCluster2D, :146-198) ---------------------------------------
 __global__ __launch_bounds__(256) void k_obj_init2d(DevFrame f, const int32_t* __restrict__ obj_labels, int n_labels,
                                                    uint32_t* __restrict__ parent, uint32_t* __restrict__ pix_node) {

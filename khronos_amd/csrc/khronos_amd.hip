@@ -278,6 +278,7 @@ struct khr_ctx {
   uint64_t* d_cv_list = nullptr;
   uint32_t obj_root_cap = 0;
   uint32_t* d_gv_owners = nullptr;  // table slots claimed by the current request (work list + table reset)
+  uint32_t* d_gv_done = nullptr;    // completion counter of k_gv_release_publish
   bool gv_clean = false;            // the (group, voxel) table is empty (every request gives it back empty)
   bool gv_counters_clean[3] = {false, false, false};  // request counters zeroed by their last k_publish: detect, voxels 0 / 1
   uint8_t* h_obj_head = nullptr;   // pinned: {roots, flags, -, -} + the cluster records (first download kObjHead of them)
@@ -2678,6 +2679,7 @@ static int ensureGv(khr_ctx* c) {
   A(devAlloc(c, &c->d_gv_rootidx, ts, false));
   A(devAlloc(c, &c->d_gv_node, npx, false));
   A(devAlloc(c, &c->d_gv_owners, npx, false));
+  A(devAlloc(c, &c->d_gv_done, 4));
   {
     // counters and cluster records are contiguous: one small copy brings both to the host
     uint8_t* head = nullptr;
@@ -2775,9 +2777,8 @@ static int objectsLaunch(khr_ctx* c, int slot) {
                        oc.use_full_connectivity ? 13 : 3);
     hipLaunchKernelGGL(k_obj_roots3d, dim3(gridFor(n)), dim3(256), 0, c->aux_stream, c->d_gv_owners, c->d_gv_n + 2, c->d_gv_parent,
                        c->d_gv_rootidx, c->d_gv_n, c->obj_root_cap, c->d_obj_acc, c->d_gv_keys);
-    // the keys are not needed any more (the paint pass goes through pix_node -> parent -> root_idx)
-    hipLaunchKernelGGL(k_gv_release, dim3(256), dim3(256), 0, c->aux_stream, c->d_gv_owners, c->d_gv_n + 2, c->d_gv_keys);
-    c->gv_clean = true;
+    // (the keys are not needed any more -- the paint pass goes through pix_node -> parent -> root_idx --: the table is given
+    //  back by the chain's last launch, together with the publish)
   } else {
     HIP_TRY(hipMemsetAsync(c->d_gv_n, 0, sizeof(uint32_t) * 4, c->aux_stream));
     hipLaunchKernelGGL(k_obj_init2d, dim3(gridFor(n)), dim3(256), 0, c->aux_stream, f, c->d_obj_labels, n_labels, c->d_gv_parent, c->d_gv_node);
@@ -2791,8 +2792,15 @@ static int objectsLaunch(khr_ctx* c, int slot) {
                      c->obj_root_cap, s.obj, c->d_obj_acc);
   HIP_TRY(hipGetLastError());
   if (++c->obj_ticket == 0) ++c->obj_ticket;
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, c->aux_stream, c->d_gv_n, reinterpret_cast<uint32_t*>(c->d_obj_head_host),
-                     static_cast<uint32_t>(sizeof(ObjAcc) / 4), kObjHead, c->d_pinned + 4, c->obj_ticket, c->d_gv_n);
+  if (oc.use_3d) {
+    hipLaunchKernelGGL(k_gv_release_publish, dim3(256), dim3(256), 0, c->aux_stream, c->d_gv_owners, c->d_gv_n + 2, c->d_gv_keys, c->d_gv_done,
+                       c->d_gv_n, reinterpret_cast<uint32_t*>(c->d_obj_head_host), static_cast<uint32_t>(sizeof(ObjAcc) / 4), kObjHead,
+                       c->d_pinned + 4, c->obj_ticket, c->d_gv_n);
+    c->gv_clean = true;
+  } else {
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, c->aux_stream, c->d_gv_n, reinterpret_cast<uint32_t*>(c->d_obj_head_host),
+                       static_cast<uint32_t>(sizeof(ObjAcc) / 4), kObjHead, c->d_pinned + 4, c->obj_ticket, c->d_gv_n);
+  }
   HIP_TRY(hipGetLastError());
   c->gv_counters_clean[0] = oc.use_3d != 0;  // (the 2D path resets them itself)
   c->obj_pending_slot = slot;
@@ -2942,13 +2950,13 @@ int khr_cluster_voxels_launch(khr_ctx* c, int slot, int which, float voxel_size)
   hipLaunchKernelGGL(k_cluster_voxels, dim3(gridFor(n)), dim3(256), 0, c->aux_stream, f, which == 0 ? s.dyn : s.obj, inv, c->cv_origin[which], t,
                      c->d_cv_keys[which], c->d_cv_n[which], static_cast<uint32_t>(c->cfg.max_frame_pixels), c->d_cv_n[which] + 1,
                      c->d_gv_owners);
-  hipLaunchKernelGGL(k_gv_release, dim3(256), dim3(256), 0, c->aux_stream, c->d_gv_owners, c->d_cv_n[which], c->d_gv_keys);
   c->gv_clean = true;
   HIP_TRY(hipGetLastError());
   if (++c->cv_ticket[which] == 0) ++c->cv_ticket[which];
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, c->aux_stream, c->d_cv_n[which], reinterpret_cast<uint32_t*>(c->d_cv_host[which]),
-                     2u, static_cast<uint32_t>(std::min<size_t>(kCvHead, c->cfg.max_frame_pixels)), c->d_pinned + 5 + which,
-                     c->cv_ticket[which], c->d_cv_n[which]);
+  hipLaunchKernelGGL(k_gv_release_publish, dim3(256), dim3(256), 0, c->aux_stream, c->d_gv_owners, c->d_cv_n[which], c->d_gv_keys, c->d_gv_done,
+                     c->d_cv_n[which], reinterpret_cast<uint32_t*>(c->d_cv_host[which]), 2u,
+                     static_cast<uint32_t>(std::min<size_t>(kCvHead, c->cfg.max_frame_pixels)), c->d_pinned + 5 + which, c->cv_ticket[which],
+                     c->d_cv_n[which]);
   HIP_TRY(hipGetLastError());
   c->gv_counters_clean[1 + which] = true;
   return KHR_OK;

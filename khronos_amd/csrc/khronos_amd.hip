@@ -526,6 +526,7 @@ int dispatchVps(khr_ctx* c, F&& f) {
   return fail(KHR_EINVAL, "voxels_per_side must be 8 or 16");
 }
 
+int kAheadObjects = 1;  // env KHR_AHEAD_OBJECTS=0: khr_ingest_ahead converts the frame only (A/B)
 int kMcFork = 1;        // env KHR_MC_FORK=0: marching cubes on the main stream behind the tracking pass (A/B)
 int kSnapFork = 1;      // env KHR_SNAP_FORK=0: the output's snapshot on the main stream in front of marching cubes (A/B)
 int kFuseGrid = 0;      // 0 = resident workgroups of the instantiation (occupancy query) x CUs; env KHR_FUSE_GRID
@@ -810,6 +811,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   p.rank = cfg->rank;
   p.world = cfg->world_size;
   p.dbg = std::getenv("KHR_DEBUG") ? std::atoi(std::getenv("KHR_DEBUG")) : 0;
+  if (std::getenv("KHR_AHEAD_OBJECTS")) kAheadObjects = std::atoi(std::getenv("KHR_AHEAD_OBJECTS"));
   if (std::getenv("KHR_MC_FORK")) kMcFork = std::atoi(std::getenv("KHR_MC_FORK"));
   if (std::getenv("KHR_SNAP_FORK")) kSnapFork = std::atoi(std::getenv("KHR_SNAP_FORK"));
   if (std::getenv("KHR_FUSE_GRID")) kFuseGrid = std::max(8, std::min(kFuseStatSlots, std::atoi(std::getenv("KHR_FUSE_GRID"))));
@@ -3343,6 +3345,14 @@ int khr_ingest_ahead(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fram
   c->slots[slot].aux_seq = ++c->aux_seq_issued;
   c->slot_leases[slot].fetch_add(1, std::memory_order_acq_rel);  // (nobody else may take the slot before it is processed)
   c->ahead_slot = slot;
+  // The object detector only reads the frame: its kernels are queued right behind the conversion.  They then run beside the
+  // current frame's tracking pass and the next frame's pixel / allocation / culling kernels -- all of them small -- instead of
+  // beside the next frame's update kernel, whose persistent grid fills every CU's register file: the two cannot share a CU,
+  // and whichever starts second waits for the other (~55 us of the main stream per frame, profiles/r04_kernel_trace_frames_s2.txt)
+  if (c->obj_configured && kAheadObjects) {
+    const int rco = objectsLaunch(c, slot);
+    if (rco) return rco;
+  }
   return slot;
 }
 
@@ -3408,8 +3418,10 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   //      otherwise wait for the seed count: the main stream's next kernels are already in its queue.  Their cluster
   //      records reach the host while the volumetric kernels run, and are looked at in (6)
   if (objects) {
-    if (!early) HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_ingest, 0));  // (early: same stream, in order)
-    if ((rc = objectsLaunch(c, slot))) return rc;
+    if (!(ahead && c->obj_pending_slot == slot)) {  // (not already queued by khr_ingest_ahead)
+      if (!early) HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_ingest, 0));  // (early: same stream, in order)
+      if ((rc = objectsLaunch(c, slot))) return rc;
+    }
     HT("pf_objects_launched");
   }
   // (2c) the update kernel, speculatively: most frames have no motion seeds, and for those the dynamic mask is empty and the

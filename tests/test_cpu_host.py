@@ -275,7 +275,8 @@ def test_update_kernel_keeps_its_registers(tmp_path):
     start = text.index("_ZN3khr6k_fuseILi16ELi4ELb1ELb1ELi12ELb0EEEvNS_8FuseArgsENS_8FuseListE:")
     body = text[start:text.index("s_endpgm", start)]
     assert "scratch_" not in body
-    loop = body[body.index("Loop Header: Depth=1"):]
-    waits = [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", loop[:loop.index("Loop Header: Depth=2")])]
+    # the item loop = the outer loop (the inner ones are the band phase's chunks and the queue's spin wait)
+    loop = body[body.index("=>This Loop Header: Depth=1"):]
+    waits = [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", "\n".join(loop.splitlines()[:4000]))]
     # phase 2 of an item waits for ITS loads while the next item's 16 loads and the previous item's stores stay in flight
     assert max(waits) >= 28 and sum(1 for w in waits if w >= 16) >= 12, waits

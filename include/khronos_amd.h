@@ -366,7 +366,10 @@ int khr_process_frame(khr_ctx* ctx, const khr_sensor* sensor, const khr_frame* f
  * frontend whose input queue already holds the NEXT packet can hand it over while the current frame is still being fused):
  * the frame (device buffers, complete when the call is made) is converted into the next ring slot on the context's second
  * stream right away, beside the current frame's kernels, instead of when its own khr_process_frame call comes around -- the
- * main stream then finds the next frame's first kernel already waiting when it finishes the current one.  The following
+ * main stream then finds the next frame's first kernel already waiting when it finishes the current one.  With an object
+ * detector configured (khr_configure_object_detector) its kernels, which only read the frame, are queued right behind the
+ * conversion: they then run beside the current frame's tracking pass instead of beside the next frame's update kernel, whose
+ * persistent grid leaves no room on the CUs.  The following
  * khr_process_frame call must pass the same frame with KHR_PF_INGESTED | KHR_PF_INPUT_READY | KHR_PF_MOTION.  Returns the slot,
  * KHR_ESTATE when a handed-over frame is still waiting, or KHR_ENOTFOUND when the look-ahead is not possible right now (ring
  * too small, tracking layer off): the caller then simply processes the frame the usual way. */

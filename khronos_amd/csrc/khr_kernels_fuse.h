@@ -12,8 +12,9 @@
 //  * the x / y part of the voxel-centre transform is computed once per wave item, each z step adds the z part
 //    (same operation order as the reference restatement, so the projected pixel is bit-identical);
 //  * the four range samples of a voxel arrive as two 8-byte gathers (the pixel pairs (u0, v0)-(u0+1, v0) and
-//    (u0, v1)-(u0+1, v1)); distance / weight are loaded as soon as the voxel is known to project into the image, i.e.
-//    together with the gathers, and only for such voxels;
+//    (u0, v1)-(u0+1, v1)); distance / weight of the z-step's 64 voxels are loaded with them -- for all 64 lanes since round 4:
+//    the kernel's vector-memory instruction stream is STATIC (see k_fuse), and a lane without an update writes back what it
+//    loaded, so that every distance / weight store is a whole 256-byte segment;
 //  * every DECISION (in front of the camera, in range, in the image, interpolation mode, sdf >= -truncation, inside the
 //    band, dynamic mask, weight > 0) is evaluated with the reference's operations in the reference's order; the
 //    divisions behind them share one refined reciprocal of the voxel depth and use the correctly rounded
@@ -22,9 +23,12 @@
 //    contracted FMAs and v_rcp_f32 (relative error ~1e-6, far inside the 1e-4 the path promises);
 //    EXACT = true keeps them bit-identical to the CPU oracle (khr_config.exact_arithmetic, golden tests);
 //  * in-band voxels (a few per cent) are compacted with a ballot into a per-wave LDS list {voxel, mode, weights, u, v}
-//    and worked off DENSELY by the same wave (lane <-> record): colour, label lookup, K likelihoods with all loads
-//    issued before the first store.  No global record list, no second launch, no list atomics.
-//  * statistics leave the kernel as one plain read-modify-write per workgroup on its own slot of wg_stats
+//    and worked off DENSELY by the same wave in 64-record chunks: colour and label lookup lane <-> record, the K
+//    likelihoods as whole 128-byte rows moved by 8 lanes each (fuseBandRows; fuseBandRecord for small frames, the binary
+//    object layer and frames without colour / labels).  No global record list, no second launch, no list atomics.
+//  * last_observed is stored lazily: {bits, stamp} per 64 voxels (DevMap::obs) instead of a 512-byte stamp row per z-step;
+//  * the update's block flags leave the kernel as one 16-bit record per item (blk_band), folded into blk_flags by k_fuse_fold
+//    or the tracking pass's first kernel; statistics as one plain read-modify-write per workgroup on its own slot of wg_stats
 //    (hot-address atomics sustain only ~90 ops/us on gfx950); beginIntegrate / khr_get_stats fold them.
 #pragma once
 #include "khr_device.h"

@@ -1,0 +1,137 @@
+"""ctypes wrapper of oracle/_ref/libref_khronos.so: the reference's OWN tracking_integrator.cpp / free_space_motion_detector.cpp /
+geometry_utils.cpp, compiled from /root/reference against functional stand-ins (oracle/ref_recipe/build_ref.sh, ref_standin.h,
+ref_harness.cpp).  TEST INFRASTRUCTURE: only tests/ uses it, to pin oracle/oracle.cpp against code that is the reference's."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_ref", "libref_khronos.so")
+RECIPE = os.path.join(HERE, "ref_recipe", "build_ref.sh")
+
+
+class RefConfig(C.Structure):
+    _fields_ = [("voxel_size", C.c_float), ("voxels_per_side", C.c_int32), ("temporal_buffer", C.c_float),
+                ("tsdf_occupancy_threshold", C.c_float), ("neighbor_connectivity", C.c_int32), ("temporal_window", C.c_float),
+                ("md_neighbor_connectivity", C.c_int32), ("md_min_cluster_size", C.c_int32), ("md_max_cluster_size", C.c_int32),
+                ("md_min_separation_distance", C.c_float), ("md_max_range", C.c_float), ("md_min_z_coordinate", C.c_float),
+                ("num_threads", C.c_int32)]
+
+
+def build():
+    """(Re)build the library when the reference checkout is here; returns the path, or None when neither it nor a prebuilt
+    library exists (the GPU box has no /root/reference: the prebuilt file travels with the snapshot)."""
+    sources_newer = (not os.path.exists(LIB_PATH)) or any(
+        os.path.getmtime(os.path.join(HERE, "ref_recipe", f)) > os.path.getmtime(LIB_PATH)
+        for f in ("ref_harness.cpp", "build_ref.sh", os.path.join("standin", "ref_standin.h")))
+    if sources_newer and os.path.isdir(os.environ.get("KHRONOS_ROOT", "/root/reference")):
+        subprocess.run(["bash", RECIPE], check=True, capture_output=True)
+    return LIB_PATH if os.path.exists(LIB_PATH) else None
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def load():
+    path = build()
+    if path is None:
+        return None
+    lib = C.CDLL(path)
+    lib.ref_create.restype = C.c_void_p
+    lib.ref_create.argtypes = [C.POINTER(RefConfig)]
+    lib.ref_destroy.argtypes = [C.c_void_p]
+    lib.ref_put_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.ref_update_tracking.argtypes = [C.c_void_p, C.c_uint64]
+    lib.ref_reset_inactive.restype = C.c_int64
+    lib.ref_reset_inactive.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.ref_num_blocks.restype = C.c_int64
+    lib.ref_num_blocks.argtypes = [C.c_void_p]
+    lib.ref_block_indices.restype = C.c_int64
+    lib.ref_block_indices.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.ref_get_block.restype = C.c_int
+    lib.ref_get_block.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+    lib.ref_detect_motion.restype = C.c_int
+    lib.ref_detect_motion.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_double] + [C.c_void_p] * 6 + [C.c_int]
+    lib.ref_combine_mesh.restype = C.c_int64
+    lib.ref_combine_mesh.argtypes = [C.c_int] + [C.c_void_p] * 8
+    return lib
+
+
+class RefMap:
+    """The reference-side map: tracking state written by the reference's code only."""
+
+    def __init__(self, lib, orc_cfg):
+        self.lib = lib
+        c = RefConfig()
+        for name, _ in RefConfig._fields_:
+            setattr(c, name, getattr(orc_cfg, name))
+        self.cfg = c
+        self.nvox = int(c.voxels_per_side) ** 3
+        self.h = lib.ref_create(C.byref(c))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref_destroy(self.h)
+            self.h = None
+
+    def put_block(self, idx, distance, last_observed, tracking_updated):
+        i = np.asarray(idx, np.int32)
+        d = np.ascontiguousarray(distance, np.float32)
+        lo = np.ascontiguousarray(last_observed, np.uint64)
+        self.lib.ref_put_block(self.h, _ptr(i), _ptr(d), _ptr(lo), int(bool(tracking_updated)))
+
+    def update_tracking(self, stamp_ns):
+        self.lib.ref_update_tracking(self.h, int(stamp_ns))
+
+    def reset_inactive(self):
+        cap = max(1, self.num_blocks())
+        out = np.zeros((cap, 3), np.int32)
+        n = self.lib.ref_reset_inactive(self.h, _ptr(out), cap)
+        return out[:n]
+
+    def num_blocks(self):
+        return int(self.lib.ref_num_blocks(self.h))
+
+    def block_indices(self):
+        n = self.num_blocks()
+        out = np.zeros((max(n, 1), 3), np.int32)
+        self.lib.ref_block_indices(self.h, _ptr(out), n)
+        return out[:n]
+
+    def get_block(self, idx):
+        i = np.asarray(idx, np.int32)
+        b = {"last_observed": np.empty(self.nvox, np.uint64), "last_occupied": np.empty(self.nvox, np.uint64),
+             "flags": np.empty(self.nvox, np.uint8)}
+        bf = np.zeros(1, np.uint8)
+        if self.lib.ref_get_block(self.h, _ptr(i), _ptr(b["last_observed"]), _ptr(b["last_occupied"]), _ptr(b["flags"]), _ptr(bf)) != 0:
+            raise KeyError(tuple(idx))
+        b["block_flags"] = int(bf[0])
+        return b
+
+    def detect_motion(self, stamp_ns, sensor_z, range_image, vertex_map, cap_clusters=256):
+        h, w = range_image.shape
+        r = np.ascontiguousarray(range_image, np.float32)
+        v = np.ascontiguousarray(vertex_map, np.float32)
+        dyn = np.zeros((h, w), np.int32)
+        ns = C.c_int64(0)
+        npx = np.zeros(cap_clusters, np.int64)
+        bbox = np.zeros((cap_clusters, 6), np.float32)
+        n = self.lib.ref_detect_motion(self.h, w, h, int(stamp_ns), float(sensor_z), _ptr(r), _ptr(v), _ptr(dyn), C.addressof(ns),
+                                       _ptr(npx), _ptr(bbox), cap_clusters)
+        return n, dyn, ns.value, npx[:min(n, cap_clusters)], bbox[:min(n, cap_clusters)]
+
+
+def combine_mesh(lib, blocks):
+    """utils::combineMeshLayer over a list of (points [n,3] f32, labels [n] u32, faces [m,3] i64 local indices)."""
+    nv = np.array([len(b[0]) for b in blocks], np.int64)
+    nf = np.array([len(b[2]) for b in blocks], np.int64)
+    pts = np.ascontiguousarray(np.concatenate([b[0] for b in blocks]).reshape(-1, 3), np.float32)
+    lab = np.ascontiguousarray(np.concatenate([b[1] for b in blocks]), np.uint32)
+    fac = np.ascontiguousarray(np.concatenate([b[2] for b in blocks]).reshape(-1, 3), np.int64)
+    po, lo, fo = np.zeros_like(pts), np.zeros_like(lab), np.zeros_like(fac)
+    n = lib.ref_combine_mesh(len(blocks), _ptr(nv), _ptr(nf), _ptr(pts), _ptr(lab), _ptr(fac), _ptr(po), _ptr(lo), _ptr(fo))
+    assert n == len(fac)
+    return po, lo, fo

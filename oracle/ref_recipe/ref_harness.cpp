@@ -1,0 +1,210 @@
+// ref_harness.cpp -- C ABI around the reference's OWN TrackingIntegrator / FreeSpaceMotionDetector / geometry utilities, compiled from
+// /root/reference against the functional stand-ins of oracle/ref_recipe/standin (see ref_standin.h for what that pins and what
+// it does not).  TEST INFRASTRUCTURE: built by oracle/ref_recipe/build_ref.sh into oracle/_ref/libref_khronos.so, loaded by
+// tests/test_cpu_ref_pin.py only.
+//
+// The map on this side lives its own life: the tracking state (last_occupied, active, ever_free, to_remove, has_active_data)
+// is written by the reference's code alone, frame after frame.  The one thing handed in from outside is what the projective
+// integrator does (it is not in /root/reference): per block the TSDF distances, the last_observed stamps and the
+// tracking_updated flag after a frame's update (ref_put_block).
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "khronos/active_window/integration/tracking_integrator.h"
+#include "khronos/active_window/motion_detection/free_space_motion_detector.h"
+#include "khronos/utils/geometry_utils.h"
+
+namespace {
+struct RefMap {
+  std::unique_ptr<hydra::VolumetricMap> map;
+  std::unique_ptr<khronos::TrackingIntegrator> tracking;
+  std::unique_ptr<khronos::FreeSpaceMotionDetector> motion;
+};
+
+std::vector<hydra::BlockIndex> sortedIndices(const RefMap& r) {
+  auto v = r.map->getTsdfLayer().allocatedBlockIndices();
+  std::sort(v.begin(), v.end(), [](const hydra::BlockIndex& a, const hydra::BlockIndex& b) {
+    return a[0] != b[0] ? a[0] < b[0] : (a[1] != b[1] ? a[1] < b[1] : a[2] < b[2]);
+  });
+  return v;
+}
+}  // namespace
+
+extern "C" {
+
+struct ref_config {
+  float voxel_size;
+  int32_t voxels_per_side;
+  /* khronos::TrackingIntegrator::Config (tracking_integrator.h:59-83) */
+  float temporal_buffer;
+  float tsdf_occupancy_threshold;
+  int32_t neighbor_connectivity;
+  float temporal_window;
+  /* khronos::FreeSpaceMotionDetector::Config (free_space_motion_detector.h:72-97) */
+  int32_t md_neighbor_connectivity;
+  int32_t md_min_cluster_size;
+  int32_t md_max_cluster_size;
+  float md_min_separation_distance;
+  float md_max_range;
+  float md_min_z_coordinate;
+  int32_t num_threads;
+};
+
+RefMap* ref_create(const ref_config* c) {
+  auto* r = new RefMap();
+  hydra::VolumetricMap::Config mc;
+  mc.voxel_size = c->voxel_size;
+  mc.voxels_per_side = static_cast<size_t>(c->voxels_per_side);
+  r->map = std::make_unique<hydra::VolumetricMap>(mc);
+  khronos::TrackingIntegrator::Config tc;
+  tc.temporal_buffer = c->temporal_buffer;
+  tc.tsdf_occupancy_threshold = c->tsdf_occupancy_threshold;
+  tc.neighbor_connectivity = c->neighbor_connectivity;
+  tc.temporal_window = c->temporal_window;
+  tc.num_threads = c->num_threads;
+  r->tracking = std::make_unique<khronos::TrackingIntegrator>(tc);
+  khronos::FreeSpaceMotionDetector::Config dc;
+  dc.neighbor_connectivity = c->md_neighbor_connectivity;
+  dc.min_cluster_size = c->md_min_cluster_size;
+  dc.max_cluster_size = c->md_max_cluster_size;
+  dc.min_separation_distance = c->md_min_separation_distance;
+  dc.max_range = c->md_max_range;
+  dc.min_z_coordinate = c->md_min_z_coordinate;
+  dc.num_threads = c->num_threads;
+  r->motion = std::make_unique<khronos::FreeSpaceMotionDetector>(dc);
+  return r;
+}
+
+void ref_destroy(RefMap* r) { delete r; }
+
+/* the projective integrator's footprint on one block (external to /root/reference): allocate when missing, TSDF distance and
+ * last_observed of every voxel, the tracking_updated flag */
+void ref_put_block(RefMap* r, const int32_t* idx, const float* distance, const uint64_t* last_observed, int tracking_updated) {
+  const hydra::BlockIndex bi(idx[0], idx[1], idx[2]);
+  if (!r->map->getTsdfLayer().hasBlock(bi)) r->map->allocateBlock(bi);
+  auto tsdf = r->map->getTsdfLayer().getBlockPtr(bi);
+  auto trk = r->map->getTrackingLayer()->getBlockPtr(bi);
+  for (size_t i = 0; i < tsdf->numVoxels(); ++i) {
+    tsdf->getVoxel(i).distance = distance[i];
+    trk->getVoxel(i).last_observed = last_observed[i];
+  }
+  tsdf->tracking_updated = tracking_updated != 0;
+}
+
+/* TrackingIntegrator::updateBlocks (tracking_integrator.cpp:71-104) */
+void ref_update_tracking(RefMap* r, uint64_t stamp) {
+  hydra::InputData in;
+  in.timestamp_ns = stamp;
+  const khronos::FrameData data(in);
+  r->tracking->updateBlocks(data, *r->map);
+}
+
+/* TrackingIntegrator::resetInactive (tracking_integrator.cpp:106-131); removed indices sorted */
+int64_t ref_reset_inactive(RefMap* r, int32_t* removed, int64_t cap) {
+  spatial_hash::BlockIndices rem;
+  r->tracking->resetInactive(*r->map, &rem);
+  std::sort(rem.begin(), rem.end(), [](const hydra::BlockIndex& a, const hydra::BlockIndex& b) {
+    return a[0] != b[0] ? a[0] < b[0] : (a[1] != b[1] ? a[1] < b[1] : a[2] < b[2]);
+  });
+  for (int64_t i = 0; i < static_cast<int64_t>(rem.size()) && i < cap; ++i)
+    for (int a = 0; a < 3; ++a) removed[3 * i + a] = rem[i][a];
+  return static_cast<int64_t>(rem.size());
+}
+
+int64_t ref_num_blocks(const RefMap* r) { return static_cast<int64_t>(r->map->getTsdfLayer().numBlocks()); }
+
+int64_t ref_block_indices(const RefMap* r, int32_t* out, int64_t cap) {
+  const auto v = sortedIndices(*r);
+  for (int64_t i = 0; i < static_cast<int64_t>(v.size()) && i < cap; ++i)
+    for (int a = 0; a < 3; ++a) out[3 * i + a] = v[i][a];
+  return static_cast<int64_t>(v.size());
+}
+
+/* flags: bit0 active, bit1 ever_free, bit2 to_remove (as orc_get_block); block_flags: bit2 tracking_updated, bit3 has_active_data */
+int ref_get_block(const RefMap* r, const int32_t* idx, uint64_t* last_observed, uint64_t* last_occupied, uint8_t* flags, uint8_t* block_flags) {
+  const hydra::BlockIndex bi(idx[0], idx[1], idx[2]);
+  const auto tsdf = r->map->getTsdfLayer().getBlockPtr(bi);
+  const auto trk = r->map->getTrackingLayer()->getBlockPtr(bi);
+  if (!tsdf || !trk) return -1;
+  for (size_t i = 0; i < trk->numVoxels(); ++i) {
+    const hydra::TrackingVoxel& v = trk->getVoxel(i);
+    if (last_observed) last_observed[i] = v.last_observed;
+    if (last_occupied) last_occupied[i] = v.last_occupied;
+    if (flags) flags[i] = static_cast<uint8_t>((v.active ? 1 : 0) | (v.ever_free ? 2 : 0) | (v.to_remove ? 4 : 0));
+  }
+  if (block_flags) *block_flags = static_cast<uint8_t>((tsdf->tracking_updated ? 4 : 0) | (trk->has_active_data ? 8 : 0));
+  return 0;
+}
+
+/* FreeSpaceMotionDetector::processInput (free_space_motion_detector.cpp:73-103) on this side's map.  range: H*W, vertex: H*W*3
+ * world-frame vertex map (the input conversion is external).  dynamic_out: H*W cluster ids (0 = static);
+ * bbox_out: up to cap_clusters x 6 floats (min, max) of the clusters' bounding boxes.  returns the number of clusters. */
+int ref_detect_motion(RefMap* r, int W, int H, uint64_t stamp, double sensor_z, const float* range, const float* vertex,
+                      int32_t* dynamic_out, int64_t* n_seeds_out, int64_t* n_cluster_pixels_out, float* bbox_out, int cap_clusters) {
+  hydra::InputData in;
+  in.timestamp_ns = stamp;
+  in.range_image = cv::Mat(H, W, sizeof(float));
+  in.vertex_map = cv::Mat(H, W, sizeof(cv::Vec3f));
+  std::memcpy(in.range_image.data(), range, sizeof(float) * static_cast<size_t>(W) * H);
+  std::memcpy(in.vertex_map.data(), vertex, sizeof(float) * 3 * static_cast<size_t>(W) * H);
+  in.world_T_sensor.translation() = Eigen::Isometry3d::Vec(0.0, 0.0, sensor_z);
+  khronos::FrameData data(in);
+  data.dynamic_image = cv::Mat(H, W, sizeof(int));   // zero CV_32SC1 images (active_window.cpp:283-284)
+  data.object_image = cv::Mat(H, W, sizeof(int));
+  const hydra::VolumetricMap& cmap = *r->map;
+  r->motion->processInput(cmap, data);
+  if (n_seeds_out) {  // the seed set of the same frame (processInput keeps it to itself)
+    khronos::GlobalIndexSet seeds;
+    khronos::FreeSpaceMotionDetector::BlockToPointsMap pm;
+    r->motion->setUpPointMap(data, *cmap.getTrackingLayer(), pm, seeds);
+    *n_seeds_out = static_cast<int64_t>(seeds.size());
+  }
+  for (int v = 0; v < H; ++v)
+    for (int u = 0; u < W; ++u) dynamic_out[v * W + u] = data.dynamic_image.at<int>(v, u);
+  int k = 0;
+  for (const auto& cl : data.dynamic_clusters) {
+    if (k < cap_clusters) {
+      if (n_cluster_pixels_out) n_cluster_pixels_out[k] = static_cast<int64_t>(cl.pixels.size());
+      if (bbox_out)
+        for (int a = 0; a < 3; ++a) {
+          bbox_out[6 * k + a] = cl.bounding_box.min[a];
+          bbox_out[6 * k + 3 + a] = cl.bounding_box.max[a];
+        }
+    }
+    ++k;
+  }
+  return k;
+}
+
+/* utils::combineMeshLayer (geometry_utils.cpp:61-86): blocks given as vertex counts + faces per block (local indices);
+ * returns the combined faces (global indices) and the combined order of a per-vertex tag */
+int64_t ref_combine_mesh(int n_blocks, const int64_t* n_vertices, const int64_t* n_faces, const float* points, const uint32_t* labels,
+                         const int64_t* faces, float* points_out, uint32_t* labels_out, int64_t* faces_out) {
+  hydra::MeshLayer layer;
+  size_t vo = 0, fo = 0;
+  for (int b = 0; b < n_blocks; ++b) {
+    hydra::MeshBlock mb;
+    for (int64_t i = 0; i < n_vertices[b]; ++i, ++vo) {
+      mb.points.emplace_back(points[3 * vo], points[3 * vo + 1], points[3 * vo + 2]);
+      mb.labels.push_back(labels[vo]);
+      mb.colors.emplace_back();
+      mb.stamps.push_back(vo);
+      mb.first_seen_stamps.push_back(vo);
+    }
+    for (int64_t i = 0; i < n_faces[b]; ++i, ++fo)
+      mb.faces.push_back({static_cast<size_t>(faces[3 * fo]), static_cast<size_t>(faces[3 * fo + 1]), static_cast<size_t>(faces[3 * fo + 2])});
+    layer.push_back(std::move(mb));
+  }
+  const hydra::Mesh out = khronos::utils::combineMeshLayer(layer);
+  for (size_t i = 0; i < out.points.size(); ++i) {
+    for (int a = 0; a < 3; ++a) points_out[3 * i + a] = out.points[i][a];
+    labels_out[i] = out.labels[i];
+  }
+  for (size_t i = 0; i < out.faces.size(); ++i)
+    for (int a = 0; a < 3; ++a) faces_out[3 * i + a] = static_cast<int64_t>(out.faces[i][a]);
+  return static_cast<int64_t>(out.faces.size());
+}
+
+}  // extern "C"

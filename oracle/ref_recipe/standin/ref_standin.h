@@ -1,0 +1,557 @@
+// ref_standin.h -- FUNCTIONAL stand-ins for the un-vendored upstream API that the reference's own hot-path sources are written
+// against (Eigen, OpenCV's cv::Mat, glog, config_utilities, spatial_hash, spark_dsg, Hydra's containers).
+//
+// TEST INFRASTRUCTURE ONLY (like everything under oracle/).  Purpose: /root/reference holds the LOGIC of
+//   khronos/src/active_window/integration/tracking_integrator.cpp        
+//   khronos/src/active_window/motion_detection/free_space_motion_detector.cpp   (a9 - a11)
+//   khronos/src/utils/geometry_utils.cpp                                 (a16, cluster bounding boxes)
+// but not the containers they run on.  oracle/ref_recipe/build_ref.sh compiles those three files FROM WHERE THEY LIE
+// (nothing is copied) against this header into oracle/_ref/libref_khronos.so, and tests/test_cpu_ref_pin.py runs the
+// reference's own code beside oracle/oracle.cpp on the same seeded sequences.  What that pins: every decision those files
+// take (update order, thresholds, early-outs, removal rule, seed / cluster / merge / filter / paint logic).  What it does NOT
+// pin: the semantics of the stand-ins themselves -- each is the ASSUMPTIONS.md item named beside it ([A.n]); the projective
+// integrator and the mesh integrator are not in /root/reference at all and stay unpinned.
+//
+// Only what the three files (and the reference headers they include) use is provided; names and signatures follow the call
+// sites in /root/reference (cited), the bodies are ours.
+#pragma once
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+#include <iostream>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <type_traits>
+#include <unordered_map>
+#include <unordered_set>
+#include <utility>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------------------------ Eigen
+namespace Eigen {
+constexpr int Dynamic = -1;
+
+// fixed 3 x 1 column vector (Point, BlockIndex, VoxelIndex, GlobalIndex) -- the only fixed shape the three files touch
+template <typename T, int R, int C>
+class Matrix {
+  static_assert(R == 3 && C == 1, "stand-in: fixed matrices are 3-vectors");
+
+ public:
+  using Scalar = T;
+  Matrix() : v_{} {}
+  Matrix(T x, T y, T z) : v_{x, y, z} {}
+  T& x() { return v_[0]; }
+  T& y() { return v_[1]; }
+  T& z() { return v_[2]; }
+  const T& x() const { return v_[0]; }
+  const T& y() const { return v_[1]; }
+  const T& z() const { return v_[2]; }
+  T& operator[](size_t i) { return v_[i]; }
+  const T& operator[](size_t i) const { return v_[i]; }
+  T& operator()(size_t i) { return v_[i]; }
+  const T& operator()(size_t i) const { return v_[i]; }
+  Matrix operator+(const Matrix& o) const { return Matrix(v_[0] + o.v_[0], v_[1] + o.v_[1], v_[2] + o.v_[2]); }
+  Matrix operator-(const Matrix& o) const { return Matrix(v_[0] - o.v_[0], v_[1] - o.v_[1], v_[2] - o.v_[2]); }
+  Matrix& operator+=(const Matrix& o) { return *this = *this + o; }
+  template <typename S>
+  Matrix operator*(S s) const { return Matrix(v_[0] * s, v_[1] * s, v_[2] * s); }
+  template <typename S>
+  Matrix operator/(S s) const { return Matrix(v_[0] / s, v_[1] / s, v_[2] / s); }
+  bool operator==(const Matrix& o) const { return v_ == o.v_; }
+  bool operator!=(const Matrix& o) const { return !(v_ == o.v_); }
+  T squaredNorm() const { return v_[0] * v_[0] + v_[1] * v_[1] + v_[2] * v_[2]; }
+  // [A, ASSUMPTIONS.md C.2] Eigen's norm() returns the matrix's own scalar type: for an integer vector the square root of the
+  // integer squared norm, computed in double and truncated back (numext::sqrt).  free_space_motion_detector.cpp:349 takes the
+  // norm of a difference of int64 voxel indices.
+  T norm() const {
+    if (std::is_integral<T>::value) return static_cast<T>(std::sqrt(static_cast<double>(squaredNorm())));
+    return static_cast<T>(std::sqrt(squaredNorm()));
+  }
+  template <typename U>
+  Matrix<U, 3, 1> cast() const { return Matrix<U, 3, 1>(static_cast<U>(v_[0]), static_cast<U>(v_[1]), static_cast<U>(v_[2])); }
+  static Matrix Zero() { return Matrix(T(0), T(0), T(0)); }
+  static Matrix Constant(T c) { return Matrix(c, c, c); }
+
+ private:
+  std::array<T, 3> v_;
+};
+
+// dynamic matrices: MatrixXi (cluster overlap table, free_space_motion_detector.cpp:279-287) and the feature vector's
+// Zero(1, 1) (measurement_clusters.h:52)
+template <typename T>
+class Matrix<T, Dynamic, Dynamic> {
+ public:
+  Matrix() = default;
+  Matrix(size_t rows, size_t cols) : r_(rows), c_(cols), d_(rows * cols) {}
+  void setZero() { std::fill(d_.begin(), d_.end(), T(0)); }
+  T& operator()(size_t i, size_t j) { return d_[i * c_ + j]; }
+  const T& operator()(size_t i, size_t j) const { return d_[i * c_ + j]; }
+  int rows() const { return static_cast<int>(r_); }
+  int cols() const { return static_cast<int>(c_); }
+  static Matrix Zero(size_t rows, size_t cols) {
+    Matrix m(rows, cols);
+    m.setZero();
+    return m;
+  }
+
+ private:
+  size_t r_ = 0, c_ = 0;
+  std::vector<T> d_;
+};
+
+using Vector3f = Matrix<float, 3, 1>;
+using Vector3i = Matrix<int, 3, 1>;
+using MatrixXi = Matrix<int, Dynamic, Dynamic>;
+using MatrixXf = Matrix<float, Dynamic, Dynamic>;
+using VectorXf = Matrix<float, Dynamic, Dynamic>;
+
+// sensor pose: only translation() is read (free_space_motion_detector.cpp:80)
+class Isometry3d {
+ public:
+  using Vec = Matrix<double, 3, 1>;
+  Vec& translation() { return t_; }
+  const Vec& translation() const { return t_; }
+
+ private:
+  Vec t_;
+};
+}  // namespace Eigen
+
+// ----------------------------------------------------------------------------------------------------------------- OpenCV
+namespace cv {
+template <typename T, int N>
+struct Vec {
+  T val[N];
+  T& operator[](int i) { return val[i]; }
+  const T& operator[](int i) const { return val[i]; }
+};
+using Vec3f = Vec<float, 3>;
+
+// row-major image with untyped storage; at<T>(row, col) as the reference uses it (free_space_motion_detector.cpp:168,174,391)
+class Mat {
+ public:
+  int rows = 0, cols = 0;
+  Mat() = default;
+  Mat(int r, int c, size_t elem_bytes) : rows(r), cols(c), eb_(elem_bytes), d_(std::make_shared<std::vector<uint8_t>>(static_cast<size_t>(r) * c * elem_bytes, 0)) {}
+  template <typename T>
+  T& at(int r, int c) { return reinterpret_cast<T*>(d_->data())[static_cast<size_t>(r) * cols + c]; }
+  template <typename T>
+  const T& at(int r, int c) const { return reinterpret_cast<const T*>(d_->data())[static_cast<size_t>(r) * cols + c]; }
+  uint8_t* data() { return d_ ? d_->data() : nullptr; }
+  size_t elemSize() const { return eb_; }
+
+ private:
+  size_t eb_ = 0;
+  std::shared_ptr<std::vector<uint8_t>> d_;  // (cv::Mat copies share their pixels)
+};
+}  // namespace cv
+
+// ------------------------------------------------------------------------------------------------------------------- glog
+namespace ref_standin {
+struct NullStream {
+  template <typename T>
+  NullStream& operator<<(const T&) { return *this; }
+};
+}  // namespace ref_standin
+#define LOG(severity) ::ref_standin::NullStream()
+#define LOG_IF(severity, condition) ::ref_standin::NullStream()
+
+// ------------------------------------------------------------------------------------------------------- config_utilities
+// declare_config() bodies are compiled but never called by the harness (it fills the Config structs directly); checkValid
+// hands the config through (tracking_integrator.cpp:69, free_space_motion_detector.cpp:71)
+namespace config {
+enum CheckMode { GT, GE, LT, LE, EQ, NE };
+struct ThreadNumConversion {};
+inline void name(const std::string&) {}
+template <typename T>
+void field(T&, const std::string&, const std::string& = "") {}
+template <typename Conversion, typename T>
+void field(T&, const std::string&, const std::string& = "") {}
+template <typename T, typename U>
+void check(const T&, CheckMode, const U&, const std::string&) {}
+template <typename T>
+void checkIsOneOf(const T&, std::initializer_list<T>, const std::string&) {}
+inline void checkCondition(bool, const std::string&) {}
+template <typename T>
+const T& checkValid(const T& c) { return c; }
+template <typename Base, typename Derived, typename Cfg>
+struct RegistrationWithConfig {
+  explicit RegistrationWithConfig(const std::string&) {}
+};
+}  // namespace config
+
+// ----------------------------------------------------------------------------------------------------------- spatial_hash
+namespace spatial_hash {
+using Point = Eigen::Vector3f;
+using BlockIndex = Eigen::Vector3i;
+using VoxelIndex = Eigen::Vector3i;
+using GlobalIndex = Eigen::Matrix<int64_t, 3, 1>;
+using VoxelKey = std::pair<BlockIndex, VoxelIndex>;
+using BlockIndices = std::vector<BlockIndex>;
+using VoxelIndices = std::vector<VoxelIndex>;
+using GlobalIndices = std::vector<GlobalIndex>;
+using VoxelKeys = std::vector<VoxelKey>;
+
+// (container-internal: iteration order of the reference's unordered containers is implementation-defined; the pin test
+//  compares sets, ASSUMPTIONS.md C.1)
+template <typename V>
+struct Hash3 {
+  size_t operator()(const V& v) const {
+    return static_cast<size_t>(static_cast<uint64_t>(v[0]) * 73856093ull ^ static_cast<uint64_t>(v[1]) * 19349669ull ^ static_cast<uint64_t>(v[2]) * 83492791ull);
+  }
+};
+template <typename T>
+using IndexMap3 = std::unordered_map<Eigen::Vector3i, T, Hash3<Eigen::Vector3i>>;
+using IndexSet3 = std::unordered_set<Eigen::Vector3i, Hash3<Eigen::Vector3i>>;
+using GlobalIndexSet = std::unordered_set<GlobalIndex, Hash3<GlobalIndex>>;
+template <typename T>
+using GlobalIndexMap = std::unordered_map<GlobalIndex, T, Hash3<GlobalIndex>>;
+
+// [A.1] floor division / non-negative remainder
+inline VoxelKey keyFromGlobalIndex(const GlobalIndex& g, size_t voxels_per_side) {
+  const int64_t n = static_cast<int64_t>(voxels_per_side);
+  BlockIndex b;
+  VoxelIndex v;
+  for (int a = 0; a < 3; ++a) {
+    int64_t q = g[a] / n, r = g[a] % n;
+    if (r < 0) { r += n; --q; }
+    b[a] = static_cast<int>(q);
+    v[a] = static_cast<int>(r);
+  }
+  return {b, v};
+}
+
+// [A.1] neighbourhoods: 6 = faces, 18 = + edges, 26 = + corners, self excluded
+inline const std::vector<std::array<int, 3>>& neighborOffsets(int connectivity) {
+  static const std::vector<std::array<int, 3>> all = [] {
+    std::vector<std::array<int, 3>> o;
+    for (int order = 1; order <= 3; ++order)
+      for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx)
+            if (std::abs(dx) + std::abs(dy) + std::abs(dz) == order) o.push_back({dx, dy, dz});
+    return o;
+  }();
+  static const std::vector<std::array<int, 3>> six(all.begin(), all.begin() + 6), eighteen(all.begin(), all.begin() + 18);
+  return connectivity == 6 ? six : (connectivity == 18 ? eighteen : all);
+}
+
+class NeighborSearch {  // free_space_motion_detector.cpp:213,249
+ public:
+  explicit NeighborSearch(int connectivity) : conn_(connectivity) {}
+  GlobalIndices neighborIndices(const GlobalIndex& g) const {
+    GlobalIndices out;
+    for (const auto& o : neighborOffsets(conn_)) out.emplace_back(g[0] + o[0], g[1] + o[1], g[2] + o[2]);
+    return out;
+  }
+
+ protected:
+  int conn_;
+};
+
+// one block of a layer: voxels in x-fastest linear order [A.1]
+template <typename VoxelT>
+struct Block {
+  using Ptr = std::shared_ptr<Block>;
+  using VoxelType = VoxelT;
+  BlockIndex index;
+  size_t voxels_per_side = 0;
+  float voxel_size = 0.f, voxel_size_inv = 0.f, block_size = 0.f;
+  std::vector<VoxelT> voxels;
+
+  Block(const BlockIndex& idx, size_t vps, float vs) : index(idx), voxels_per_side(vps), voxel_size(vs), voxel_size_inv(1.f / vs), block_size(vs * static_cast<float>(vps)), voxels(vps * vps * vps) {}
+  virtual ~Block() = default;
+  size_t numVoxels() const { return voxels.size(); }
+  size_t linear(const VoxelIndex& v) const { return static_cast<size_t>(v[0]) + voxels_per_side * (static_cast<size_t>(v[1]) + voxels_per_side * static_cast<size_t>(v[2])); }
+  VoxelIndex fromLinear(size_t i) const {
+    const int n = static_cast<int>(voxels_per_side);
+    return VoxelIndex(static_cast<int>(i) % n, (static_cast<int>(i) / n) % n, static_cast<int>(i) / (n * n));
+  }
+  VoxelT& getVoxel(size_t i) { return voxels[i]; }
+  const VoxelT& getVoxel(size_t i) const { return voxels[i]; }
+  VoxelT& getVoxel(const VoxelIndex& v) { return voxels[linear(v)]; }
+  const VoxelT& getVoxel(const VoxelIndex& v) const { return voxels[linear(v)]; }
+  VoxelKey getVoxelKey(size_t i) const { return {index, fromLinear(i)}; }
+  Point origin() const { return Point(static_cast<float>(index[0]) * block_size, static_cast<float>(index[1]) * block_size, static_cast<float>(index[2]) * block_size); }
+  // [A.1] voxel of a point: floor((p - origin) * voxel_size_inv); may land on -1 / vps (free_space_motion_detector.cpp:192-196)
+  VoxelIndex getVoxelIndex(const Point& p) const {
+    const Point o = origin();
+    return VoxelIndex(static_cast<int>(std::floor((p[0] - o[0]) * voxel_size_inv)), static_cast<int>(std::floor((p[1] - o[1]) * voxel_size_inv)),
+                      static_cast<int>(std::floor((p[2] - o[2]) * voxel_size_inv)));
+  }
+  bool isValidVoxelIndex(const VoxelIndex& v) const {
+    const int n = static_cast<int>(voxels_per_side);
+    return v[0] >= 0 && v[1] >= 0 && v[2] >= 0 && v[0] < n && v[1] < n && v[2] < n;
+  }
+  GlobalIndex getGlobalVoxelIndex(const VoxelIndex& v) const {
+    const int64_t n = static_cast<int64_t>(voxels_per_side);
+    return GlobalIndex(index[0] * n + v[0], index[1] * n + v[1], index[2] * n + v[2]);
+  }
+};
+
+template <typename BlockT>
+class Layer {
+ public:
+  using BlockPtr = std::shared_ptr<BlockT>;
+  using ConstBlockPtr = std::shared_ptr<const BlockT>;
+  const float voxel_size;
+  const size_t voxels_per_side;
+  const float block_size, block_size_inv;
+
+  Layer(float vs, size_t vps) : voxel_size(vs), voxels_per_side(vps), block_size(vs * static_cast<float>(vps)), block_size_inv(1.f / (vs * static_cast<float>(vps))) {}
+  BlockPtr getBlockPtr(const BlockIndex& i) {
+    auto it = blocks_.find(i);
+    return it == blocks_.end() ? nullptr : it->second;
+  }
+  ConstBlockPtr getBlockPtr(const BlockIndex& i) const {
+    auto it = blocks_.find(i);
+    return it == blocks_.end() ? nullptr : it->second;
+  }
+  // [A.1] block of a point: floor(p * block_size_inv)
+  BlockIndex blockIndexOf(const Point& p) const {
+    return BlockIndex(static_cast<int>(std::floor(p[0] * block_size_inv)), static_cast<int>(std::floor(p[1] * block_size_inv)), static_cast<int>(std::floor(p[2] * block_size_inv)));
+  }
+  BlockPtr getBlockPtr(const Point& p) { return getBlockPtr(blockIndexOf(p)); }
+  ConstBlockPtr getBlockPtr(const Point& p) const { return getBlockPtr(blockIndexOf(p)); }
+  BlockT& allocateBlock(const BlockIndex& i) {
+    auto& b = blocks_[i];
+    if (!b) b = std::make_shared<BlockT>(i, voxels_per_side, voxel_size);
+    return *b;
+  }
+  void removeBlock(const BlockIndex& i) { blocks_.erase(i); }
+  bool hasBlock(const BlockIndex& i) const { return blocks_.count(i) != 0; }
+  size_t numBlocks() const { return blocks_.size(); }
+  BlockIndices allocatedBlockIndices() const {
+    BlockIndices out;
+    for (const auto& kv : blocks_) out.push_back(kv.first);
+    return out;
+  }
+  BlockIndices blockIndicesWithCondition(const std::function<bool(const BlockT&)>& cond) const {
+    BlockIndices out;
+    for (const auto& kv : blocks_)
+      if (cond(*kv.second)) out.push_back(kv.first);
+    return out;
+  }
+
+ private:
+  IndexMap3<BlockPtr> blocks_;
+};
+
+// neighbours of a voxel across block borders (tracking_integrator.cpp:172,192)
+class VoxelNeighborSearch : public NeighborSearch {
+ public:
+  template <typename LayerT>
+  VoxelNeighborSearch(const LayerT& layer, int connectivity) : NeighborSearch(connectivity), vps_(static_cast<int>(layer.voxels_per_side)) {}
+  VoxelKeys neighborKeys(const VoxelKey& key) const {
+    VoxelKeys out;
+    for (const auto& o : neighborOffsets(conn_)) {
+      BlockIndex b = key.first;
+      VoxelIndex v(key.second[0] + o[0], key.second[1] + o[1], key.second[2] + o[2]);
+      for (int a = 0; a < 3; ++a) {
+        if (v[a] < 0) { v[a] += vps_; --b[a]; }
+        else if (v[a] >= vps_) { v[a] -= vps_; ++b[a]; }
+      }
+      out.emplace_back(b, v);
+    }
+    return out;
+  }
+
+ private:
+  int vps_;
+};
+}  // namespace spatial_hash
+
+// -------------------------------------------------------------------------------------------------------------- spark_dsg
+namespace spark_dsg {
+struct Color {
+  uint8_t r = 0, g = 0, b = 0, a = 255;
+};
+// axis-aligned box of a point set (the type the reference builds from a cluster's pixels: free_space_motion_detector.cpp:396)
+struct BoundingBox {
+  struct PointAdaptor {
+    virtual ~PointAdaptor() = default;
+    virtual size_t size() const = 0;
+    virtual Eigen::Vector3f get(size_t index) const = 0;
+  };
+  Eigen::Vector3f min, max;
+  bool valid = false;
+  BoundingBox() = default;
+  explicit BoundingBox(const PointAdaptor& points) {
+    for (size_t i = 0; i < points.size(); ++i) {
+      const Eigen::Vector3f p = points.get(i);
+      if (!valid) { min = max = p; valid = true; continue; }
+      for (int a = 0; a < 3; ++a) {
+        if (p[a] < min[a]) min[a] = p[a];
+        if (p[a] > max[a]) max[a] = p[a];
+      }
+    }
+  }
+};
+struct DsgLayers {};
+struct DynamicSceneGraph {};
+struct KhronosObjectAttributes {};
+using LayerId = int64_t;
+using NodeId = uint64_t;
+struct NodeSymbol {};
+struct SceneGraphLayer {};
+struct SceneGraphNode {};
+}  // namespace spark_dsg
+
+// ------------------------------------------------------------------------------------------------------------------ Hydra
+namespace hydra {
+using TimeStamp = uint64_t;
+// [A.6] nanoseconds -> double seconds (the reference compares stamps in seconds: tracking_integrator.cpp:237-238,250)
+inline double toSeconds(TimeStamp ns) { return static_cast<double>(ns) / 1e9; }
+inline TimeStamp fromSeconds(double s) { return static_cast<TimeStamp>(s * 1e9); }
+
+using Point = spatial_hash::Point;
+using BlockIndex = spatial_hash::BlockIndex;
+using VoxelIndex = spatial_hash::VoxelIndex;
+using GlobalIndex = spatial_hash::GlobalIndex;
+using VoxelKey = spatial_hash::VoxelKey;
+using BlockIndices = spatial_hash::BlockIndices;
+using VoxelIndices = spatial_hash::VoxelIndices;
+using GlobalIndices = spatial_hash::GlobalIndices;
+using VoxelKeys = spatial_hash::VoxelKeys;
+using BlockIndexSet = spatial_hash::IndexSet3;
+using VoxelIndexSet = spatial_hash::IndexSet3;
+using GlobalIndexSet = spatial_hash::GlobalIndexSet;
+template <typename T>
+using BlockIndexMap = spatial_hash::IndexMap3<T>;
+template <typename T>
+using VoxelIndexMap = spatial_hash::IndexMap3<T>;
+template <typename T>
+using GlobalIndexMap = spatial_hash::GlobalIndexMap<T>;
+
+using FeatureVector = Eigen::VectorXf;
+using FeatureMap = std::unordered_map<int, FeatureVector>;
+
+// [A.6] voxel types: the fields the reference reads and writes
+struct TsdfVoxel {
+  float distance = 0.f;
+  float weight = 0.f;
+  spark_dsg::Color color;
+};
+struct TrackingVoxel {
+  TimeStamp last_observed = 0u;
+  TimeStamp last_occupied = 0u;
+  bool active = false;
+  bool ever_free = false;
+  bool to_remove = false;
+};
+struct SemanticVoxel {};
+
+struct TsdfBlock : spatial_hash::Block<TsdfVoxel> {
+  using Ptr = std::shared_ptr<TsdfBlock>;
+  using spatial_hash::Block<TsdfVoxel>::Block;
+  bool updated = false, mesh_updated = false, tracking_updated = false;
+  static bool trackingUpdated(const TsdfBlock& b) { return b.tracking_updated; }  // tracking_integrator.cpp:77
+};
+struct TrackingBlock : spatial_hash::Block<TrackingVoxel> {
+  using Ptr = std::shared_ptr<TrackingBlock>;
+  using spatial_hash::Block<TrackingVoxel>::Block;
+  bool has_active_data = false;
+};
+struct SemanticBlock : spatial_hash::Block<SemanticVoxel> {
+  using spatial_hash::Block<SemanticVoxel>::Block;
+};
+using TsdfLayer = spatial_hash::Layer<TsdfBlock>;
+using TrackingLayer = spatial_hash::Layer<TrackingBlock>;
+using SemanticLayer = spatial_hash::Layer<SemanticBlock>;
+
+// mesh types as geometry_utils.cpp:61-86 uses them
+struct Mesh {
+  using Face = std::array<size_t, 3>;
+  std::vector<Eigen::Vector3f> points;
+  std::vector<spark_dsg::Color> colors;
+  std::vector<uint32_t> labels;
+  std::vector<TimeStamp> first_seen_stamps, stamps;
+  std::vector<Face> faces;
+};
+using MeshBlock = Mesh;
+using MeshLayer = std::vector<MeshBlock>;  // (iterated block by block, geometry_utils.cpp:64)
+
+// the map: TSDF layer always, tracking layer optional (mesh_object_extractor.cpp:208-211); removeBlock drops a block from every layer
+class VolumetricMap {
+ public:
+  struct Config {
+    float voxel_size = 0.1f;
+    float truncation_distance = 0.3f;
+    size_t voxels_per_side = 16;
+  } const config;
+  explicit VolumetricMap(const Config& c) : config(c), tsdf_(c.voxel_size, c.voxels_per_side), tracking_(std::make_shared<TrackingLayer>(c.voxel_size, c.voxels_per_side)) {}
+  TsdfLayer& getTsdfLayer() { return tsdf_; }
+  const TsdfLayer& getTsdfLayer() const { return tsdf_; }
+  std::shared_ptr<TrackingLayer> getTrackingLayer() { return tracking_; }
+  std::shared_ptr<const TrackingLayer> getTrackingLayer() const { return tracking_; }
+  void allocateBlock(const BlockIndex& i) {
+    tsdf_.allocateBlock(i);
+    tracking_->allocateBlock(i);
+  }
+  void removeBlock(const BlockIndex& i) {
+    tsdf_.removeBlock(i);
+    tracking_->removeBlock(i);
+  }
+
+ private:
+  TsdfLayer tsdf_;
+  std::shared_ptr<TrackingLayer> tracking_;
+};
+
+// thread-safe dispenser of a block list (tracking_integrator.cpp:83-86,140)
+template <typename IndexT>
+class IndexGetter {
+ public:
+  explicit IndexGetter(const std::vector<IndexT>& indices) : indices_(indices) {}
+  bool getNextIndex(IndexT& out) {
+    const size_t i = next_.fetch_add(1);
+    if (i >= indices_.size()) return false;
+    out = indices_[i];
+    return true;
+  }
+
+ private:
+  std::vector<IndexT> indices_;
+  std::atomic<size_t> next_{0};
+};
+
+class GlobalInfo {
+ public:
+  struct Config {
+    int default_verbosity = 0;
+    int default_num_threads = 2;
+  };
+  static GlobalInfo& instance() {
+    static GlobalInfo g;
+    return g;
+  }
+  const Config& getConfig() const { return config_; }
+
+ private:
+  Config config_;
+};
+
+struct Sensor {};
+
+// the input of a frame: what the motion detector reads (free_space_motion_detector.cpp:74,80,114,168,174)
+struct InputData {
+  using RangeType = float;
+  using VertexType = cv::Vec3f;
+  TimeStamp timestamp_ns = 0;
+  cv::Mat vertex_map;   // world frame
+  cv::Mat range_image;
+  Eigen::Isometry3d world_T_sensor;
+  const Eigen::Isometry3d& getSensorPose() const { return world_T_sensor; }
+};
+
+namespace timing {
+struct ScopedTimer {
+  ScopedTimer(const std::string&, TimeStamp) {}
+};
+}  // namespace timing
+}  // namespace hydra

@@ -55,6 +55,8 @@ def load():
     lib.ref_get_block.argtypes = [C.c_void_p] + [C.c_void_p] * 5
     lib.ref_detect_motion.restype = C.c_int
     lib.ref_detect_motion.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_double] + [C.c_void_p] * 6 + [C.c_int]
+    lib.ref_detect_objects.restype = C.c_int
+    lib.ref_detect_objects.argtypes = ([C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_float, C.c_float] + [C.c_void_p] * 4 + [C.c_int])
     lib.ref_combine_mesh.restype = C.c_int64
     lib.ref_combine_mesh.argtypes = [C.c_int] + [C.c_void_p] * 8
     return lib
@@ -135,3 +137,23 @@ def combine_mesh(lib, blocks):
     n = lib.ref_combine_mesh(len(blocks), _ptr(nv), _ptr(nf), _ptr(pts), _ptr(lab), _ptr(fac), _ptr(po), _ptr(lo), _ptr(fo))
     assert n == len(fac)
     return po, lo, fo
+
+
+def detect_objects(lib, range_image, vertex_map, label, object_labels, use_3d=True, grid_size=0.1, max_range=0.0, min_cluster_size=0,
+                   max_cluster_size=-1, use_full_connectivity=True, cap=65536):
+    """ConnectedSemantics::processInput: (n, object_image, clusters [id, semantic_id, num_pixels, bbox_min, bbox_max])."""
+    h, w = range_image.shape
+    r = np.ascontiguousarray(range_image, np.float32)
+    v = np.ascontiguousarray(vertex_map, np.float32)
+    lab = np.ascontiguousarray(label, np.int32)
+    ol = np.ascontiguousarray(object_labels, np.int32)
+    img = np.zeros((h, w), np.int32)
+    ids = np.zeros((cap, 2), np.int32)
+    npx = np.zeros(cap, np.int64)
+    bbox = np.zeros((cap, 6), np.float32)
+    n = lib.ref_detect_objects(w, h, _ptr(r), _ptr(v), _ptr(lab), _ptr(ol), ol.size, int(use_full_connectivity), int(min_cluster_size),
+                               int(max_cluster_size), int(use_3d), float(grid_size), float(max_range), _ptr(img), _ptr(ids), _ptr(npx),
+                               _ptr(bbox), cap)
+    cl = [dict(id=int(ids[k, 0]), semantic_id=int(ids[k, 1]), num_pixels=int(npx[k]), bbox_min=bbox[k, :3].copy(), bbox_max=bbox[k, 3:].copy())
+          for k in range(min(n, cap))]
+    return n, img, cl

@@ -5,7 +5,7 @@
 # snapshot like our own built .so files).  tests/test_cpu_ref_pin.py runs it beside the oracle.
 #
 # This is NOT the reference's build (that needs Hydra, spatial_hash, config_utilities, spark_dsg, Eigen, OpenCV, glog: none
-# is in the image).  What it executes is the logic of the three files below; the containers are ours (ref_standin.h says which
+# is in the image).  What it executes is the logic of the files below; the containers are ours (ref_standin.h says which
 # ASSUMPTIONS.md item each one stands for).
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
@@ -13,7 +13,8 @@ REPO="$(cd "$HERE/../.." && pwd)"
 KHRONOS_ROOT="${KHRONOS_ROOT:-/root/reference}"
 OUT="$REPO/oracle/_ref"
 SRC="$KHRONOS_ROOT/khronos/src"
-for f in active_window/integration/tracking_integrator.cpp active_window/motion_detection/free_space_motion_detector.cpp utils/geometry_utils.cpp; do
+for f in active_window/integration/tracking_integrator.cpp active_window/motion_detection/free_space_motion_detector.cpp utils/geometry_utils.cpp \
+         active_window/object_detection/connected_semantics.cpp; do
   [ -f "$SRC/$f" ] || { echo "build_ref.sh: $SRC/$f not found (no reference checkout here): keeping what is in $OUT" >&2; exit 3; }
 done
 mkdir -p "$OUT"
@@ -23,5 +24,6 @@ mkdir -p "$OUT"
   "$SRC/active_window/integration/tracking_integrator.cpp" \
   "$SRC/active_window/motion_detection/free_space_motion_detector.cpp" \
   "$SRC/utils/geometry_utils.cpp" \
+  "$SRC/active_window/object_detection/connected_semantics.cpp" \
   -o "$OUT/libref_khronos.so"
 echo "built $OUT/libref_khronos.so"

@@ -14,6 +14,7 @@
 
 #include "khronos/active_window/integration/tracking_integrator.h"
 #include "khronos/active_window/motion_detection/free_space_motion_detector.h"
+#include "khronos/active_window/object_detection/connected_semantics.h"
 #include "khronos/utils/geometry_utils.h"
 
 namespace {
@@ -172,6 +173,56 @@ int ref_detect_motion(RefMap* r, int W, int H, uint64_t stamp, double sensor_z, 
           bbox_out[6 * k + a] = cl.bounding_box.min[a];
           bbox_out[6 * k + 3 + a] = cl.bounding_box.max[a];
         }
+    }
+    ++k;
+  }
+  return k;
+}
+
+/* ConnectedSemantics::processInput (connected_semantics.cpp:59-216).  label: H*W int32; object_labels: the ids for which
+ * LabelSpaceConfig::isObject holds.  object_out: H*W cluster ids; per cluster (up to cap): semantic id, pixel count, bounding box
+ * of its vertices (what MaxIoUTracker builds from it, max_iou_tracker.cpp:466-476).  returns the number of clusters. */
+int ref_detect_objects(int W, int H, const float* range, const float* vertex, const int32_t* label, const int32_t* object_labels,
+                       int n_object_labels, int use_full_connectivity, int min_cluster_size, int max_cluster_size, int use_3d,
+                       float grid_size, float max_range, int32_t* object_out, int32_t* semantic_ids_out, int64_t* n_pixels_out,
+                       float* bbox_out, int cap) {
+  auto& labels = hydra::GlobalInfo::instance().mutableLabelSpaceConfig().object_labels;
+  labels.clear();
+  labels.insert(object_labels, object_labels + n_object_labels);
+  khronos::ConnectedSemantics::Config oc;
+  oc.use_full_connectivity = use_full_connectivity != 0;
+  oc.min_cluster_size = min_cluster_size;
+  oc.max_cluster_size = max_cluster_size;
+  oc.use_3d = use_3d != 0;
+  oc.grid_size = grid_size;
+  oc.max_range = max_range;
+  khronos::ConnectedSemantics detector(oc);
+  hydra::InputData in;
+  in.range_image = cv::Mat(H, W, sizeof(float));
+  in.vertex_map = cv::Mat(H, W, sizeof(cv::Vec3f));
+  in.label_image = cv::Mat(H, W, sizeof(int));
+  std::memcpy(in.range_image.data(), range, sizeof(float) * static_cast<size_t>(W) * H);
+  std::memcpy(in.vertex_map.data(), vertex, sizeof(float) * 3 * static_cast<size_t>(W) * H);
+  std::memcpy(in.label_image.data(), label, sizeof(int32_t) * static_cast<size_t>(W) * H);
+  khronos::FrameData data(in);
+  data.dynamic_image = cv::Mat(H, W, sizeof(int));
+  data.object_image = cv::Mat(H, W, sizeof(int));
+  hydra::VolumetricMap::Config mc;
+  const hydra::VolumetricMap map(mc);  // (unused by the detector, connected_semantics.cpp:59)
+  detector.processInput(map, data);
+  for (int v = 0; v < H; ++v)
+    for (int u = 0; u < W; ++u) object_out[v * W + u] = data.object_image.at<int>(v, u);
+  int k = 0;
+  for (const auto& cl : data.semantic_clusters) {
+    if (k < cap) {
+      semantic_ids_out[2 * k] = cl.id;
+      semantic_ids_out[2 * k + 1] = cl.semantics ? cl.semantics->category_id : -1;
+      n_pixels_out[k] = static_cast<int64_t>(cl.pixels.size());
+      const khronos::BoundingBox box(khronos::utils::VertexMapAdaptor(cl.pixels, data.input.vertex_map));
+      for (int a = 0; a < 3; ++a) {
+        bbox_out[6 * k + a] = box.min[a];
+        bbox_out[6 * k + 3 + a] = box.max[a];
+      }
     }
     ++k;
   }

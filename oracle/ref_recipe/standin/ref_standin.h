@@ -5,14 +5,15 @@
 //   khronos/src/active_window/integration/tracking_integrator.cpp        
 //   khronos/src/active_window/motion_detection/free_space_motion_detector.cpp   (a9 - a11)
 //   khronos/src/utils/geometry_utils.cpp                                 (a16, cluster bounding boxes)
-// but not the containers they run on.  oracle/ref_recipe/build_ref.sh compiles those three files FROM WHERE THEY LIE
+//   khronos/src/active_window/object_detection/connected_semantics.cpp   (a18 / f3)
+// but not the containers they run on.  oracle/ref_recipe/build_ref.sh compiles those files FROM WHERE THEY LIE
 // (nothing is copied) against this header into oracle/_ref/libref_khronos.so, and tests/test_cpu_ref_pin.py runs the
 // reference's own code beside oracle/oracle.cpp on the same seeded sequences.  What that pins: every decision those files
 // take (update order, thresholds, early-outs, removal rule, seed / cluster / merge / filter / paint logic).  What it does NOT
 // pin: the semantics of the stand-ins themselves -- each is the ASSUMPTIONS.md item named beside it ([A.n]); the projective
 // integrator and the mesh integrator are not in /root/reference at all and stay unpinned.
 //
-// Only what the three files (and the reference headers they include) use is provided; names and signatures follow the call
+// Only what those files (and the reference headers they include) use is provided; names and signatures follow the call
 // sites in /root/reference (cited), the bodies are ours.
 #pragma once
 #include <algorithm>
@@ -143,12 +144,26 @@ class Mat {
   template <typename T>
   const T& at(int r, int c) const { return reinterpret_cast<const T*>(d_->data())[static_cast<size_t>(r) * cols + c]; }
   uint8_t* data() { return d_ ? d_->data() : nullptr; }
+  const uint8_t* data() const { return d_ ? d_->data() : nullptr; }
   size_t elemSize() const { return eb_; }
+  // setTo(value, mask) on a 32-bit integer image (connected_semantics.cpp:206: object_image.setTo(0, object_image == id))
+  void setTo(int value, const Mat& mask) {
+    for (int r = 0; r < rows; ++r)
+      for (int c = 0; c < cols; ++c)
+        if (mask.at<uint8_t>(r, c)) at<int>(r, c) = value;
+  }
 
  private:
   size_t eb_ = 0;
   std::shared_ptr<std::vector<uint8_t>> d_;  // (cv::Mat copies share their pixels)
 };
+// element-wise comparison of a 32-bit integer image with a scalar: 8-bit mask, 255 where equal
+inline Mat operator==(const Mat& m, int value) {
+  Mat out(m.rows, m.cols, 1);
+  for (int r = 0; r < m.rows; ++r)
+    for (int c = 0; c < m.cols; ++c) out.at<uint8_t>(r, c) = m.at<int>(r, c) == value ? 255 : 0;
+  return out;
+}
 }  // namespace cv
 
 // ------------------------------------------------------------------------------------------------------------------- glog
@@ -211,6 +226,13 @@ using IndexSet3 = std::unordered_set<Eigen::Vector3i, Hash3<Eigen::Vector3i>>;
 using GlobalIndexSet = std::unordered_set<GlobalIndex, Hash3<GlobalIndex>>;
 template <typename T>
 using GlobalIndexMap = std::unordered_map<GlobalIndex, T, Hash3<GlobalIndex>>;
+
+// [A.7] index of the cell a point falls in: floor(p * inv) per axis (connected_semantics.cpp:136)
+template <typename IndexT>
+IndexT indexFromPoint(const Point& p, float inv) {
+  using S = typename IndexT::Scalar;
+  return IndexT(static_cast<S>(std::floor(p[0] * inv)), static_cast<S>(std::floor(p[1] * inv)), static_cast<S>(std::floor(p[2] * inv)));
+}
 
 // [A.1] floor division / non-negative remainder
 inline VoxelKey keyFromGlobalIndex(const GlobalIndex& g, size_t voxels_per_side) {
@@ -531,9 +553,17 @@ class GlobalInfo {
     return g;
   }
   const Config& getConfig() const { return config_; }
+  // [A.7] isObject(label) = membership in the configured object-label list (connected_semantics.cpp:133,153)
+  struct LabelSpaceConfig {
+    std::unordered_set<int> object_labels;
+    bool isObject(int label) const { return object_labels.count(label) != 0; }
+  };
+  const LabelSpaceConfig& getLabelSpaceConfig() const { return labels_; }
+  LabelSpaceConfig& mutableLabelSpaceConfig() { return labels_; }  // (harness only)
 
  private:
   Config config_;
+  LabelSpaceConfig labels_;
 };
 
 struct Sensor {};
@@ -542,7 +572,9 @@ struct Sensor {};
 struct InputData {
   using RangeType = float;
   using VertexType = cv::Vec3f;
+  using LabelType = int;
   TimeStamp timestamp_ns = 0;
+  cv::Mat label_image;
   cv::Mat vertex_map;   // world frame
   cv::Mat range_image;
   Eigen::Isometry3d world_T_sensor;

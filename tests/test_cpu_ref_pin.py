@@ -190,3 +190,53 @@ def test_recipe_is_present_and_copies_nothing():
         for f in files:
             if f.endswith((".cpp", ".h")):
                 assert "Massachusetts Institute of Technology" not in open(os.path.join(dirpath, f), errors="ignore").read(), os.path.join(dirpath, f)
+
+
+def _cluster_bijection(img_a, cl_a, img_b, cl_b):
+    """Two labelled images describe the same clusters up to the order of the ids: returns {id_a: id_b} or None."""
+    if not np.array_equal(img_a > 0, img_b > 0) or len(cl_a) != len(cl_b):
+        return None
+    pairs = np.unique(np.stack([img_a[img_a > 0], img_b[img_b > 0]], axis=1), axis=0) if (img_a > 0).any() else np.zeros((0, 2), np.int64)
+    if len(np.unique(pairs[:, 0])) != len(pairs) or len(np.unique(pairs[:, 1])) != len(pairs):
+        return None
+    return {int(a): int(b) for a, b in pairs}
+
+
+@needs_ref
+@pytest.mark.parametrize("mode", ["3d", "3d-6", "3d-window", "3d-range", "2d-8", "2d-4-min"])
+def test_object_detector_equals_reference_code(mode):
+    """ConnectedSemantics::processInput (connected_semantics.cpp:59-216), the reference's own code, against orc_detect_objects on
+    rendered frames: same clusters (pixel sets, semantic ids, pixel counts, bounding boxes).  3D: the ids inside one semantic id
+    follow an unordered_map in the reference (ASSUMPTIONS.md C.4) -- compared through the bijection, and the ascending order
+    ACROSS semantic ids (std::map, connected_semantics.h:87) must hold on both sides; 2D: ids equal outright."""
+    W, H = 160, 120
+    s = SyntheticStream(W, H, threads=1)
+    sen = po.OrcSensor(W, H, s.fx, s.fy, s.cx, s.cy, 0.1, 5.0)
+    ora = po.OracleMap(_cfg())
+    kw = {"3d": dict(use_3d=True, grid_size=0.1), "3d-6": dict(use_3d=True, grid_size=0.15, use_full_connectivity=False),
+          "3d-window": dict(use_3d=True, grid_size=0.1, min_cluster_size=30, max_cluster_size=900),
+          "3d-range": dict(use_3d=True, grid_size=0.2, max_range=3.0),
+          "2d-8": dict(use_3d=False), "2d-4-min": dict(use_3d=False, use_full_connectivity=False, min_cluster_size=25)}[mode]
+    object_labels = list(range(7, 20))
+    total = 0
+    for i in (0, 7, 19, 33):
+        fr = s.render(i)
+        rng, vtx = ora.parse_input(sen, fr["pose"], fr["depth"])
+        n_o, img_o, cl_o = ora.detect_objects(sen, fr["stamp"], fr["pose"], fr["depth"], fr["label"], object_labels, **kw)
+        n_r, img_r, cl_r = pyref.detect_objects(LIB, rng, vtx, fr["label"], object_labels, **kw)
+        assert n_o == n_r, (mode, i)
+        if not kw["use_3d"]:
+            assert np.array_equal(img_o, img_r), (mode, i)
+            mapping = {c["id"]: c["id"] for c in cl_o}
+        else:
+            mapping = _cluster_bijection(img_o, cl_o, img_r, cl_r)
+            assert mapping is not None, (mode, i)
+            assert [c["semantic_id"] for c in cl_o] == sorted(c["semantic_id"] for c in cl_o)
+            assert [c["semantic_id"] for c in cl_r] == sorted(c["semantic_id"] for c in cl_r)
+        by_id = {c["id"]: c for c in cl_r}
+        for c in cl_o:
+            e = by_id[mapping[c["id"]]]
+            assert (c["semantic_id"], c["num_pixels"]) == (e["semantic_id"], e["num_pixels"]), (mode, i, c["id"])
+            assert np.array_equal(c["bbox_min"].astype(np.float32), e["bbox_min"]) and np.array_equal(c["bbox_max"].astype(np.float32), e["bbox_max"])
+        total += n_r
+    assert total > 4, (mode, total)

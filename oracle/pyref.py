@@ -70,6 +70,8 @@ class RefMap:
         c = RefConfig()
         for name, _ in RefConfig._fields_:
             setattr(c, name, getattr(orc_cfg, name))
+        if c.num_threads < 1:  # (0 = "all cores" on the oracle's side; the reference's integrators want a count)
+            c.num_threads = 2
         self.cfg = c
         self.nvox = int(c.voxels_per_side) ** 3
         self.h = lib.ref_create(C.byref(c))

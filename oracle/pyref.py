@@ -57,6 +57,8 @@ def load():
     lib.ref_detect_motion.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_double] + [C.c_void_p] * 6 + [C.c_int]
     lib.ref_detect_objects.restype = C.c_int
     lib.ref_detect_objects.argtypes = ([C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_float, C.c_float] + [C.c_void_p] * 4 + [C.c_int])
+    lib.ref_tracker_replay.restype = C.c_int64
+    lib.ref_tracker_replay.argtypes = [C.c_char_p, C.c_void_p, C.c_int64]
     lib.ref_combine_mesh.restype = C.c_int64
     lib.ref_combine_mesh.argtypes = [C.c_int] + [C.c_void_p] * 8
     return lib
@@ -159,3 +161,12 @@ def detect_objects(lib, range_image, vertex_map, label, object_labels, use_3d=Tr
     cl = [dict(id=int(ids[k, 0]), semantic_id=int(ids[k, 1]), num_pixels=int(npx[k]), bbox_min=bbox[k, :3].copy(), bbox_max=bbox[k, 3:].copy())
           for k in range(min(n, cap))]
     return n, img, cl
+
+
+def tracker_replay(lib, scenario):
+    """MaxIoUTracker::processInput over a scenario in host_selftest --tracker's format; the JSON lines it prints."""
+    cap = 1 << 24
+    buf = C.create_string_buffer(cap)
+    n = lib.ref_tracker_replay(scenario.encode(), buf, cap)
+    assert 0 <= n < cap
+    return buf.value.decode()

@@ -9,12 +9,16 @@
 // tracking_updated flag after a frame's update (ref_put_block).
 #include <algorithm>
 #include <cstring>
+#include <cstdio>
 #include <memory>
+#include <sstream>
+#include <string>
 #include <vector>
 
 #include "khronos/active_window/integration/tracking_integrator.h"
 #include "khronos/active_window/motion_detection/free_space_motion_detector.h"
 #include "khronos/active_window/object_detection/connected_semantics.h"
+#include "khronos/active_window/tracking/max_iou_tracker.h"
 #include "khronos/utils/geometry_utils.h"
 
 namespace {
@@ -227,6 +231,108 @@ int ref_detect_objects(int W, int H, const float* range, const float* vertex, co
     ++k;
   }
   return k;
+}
+
+/* MaxIoUTracker::processInput (max_iou_tracker.cpp:198-593) over a scenario in the format of khronos_amd/host/host_selftest.cpp's
+ * --tracker replay (frames of semantic / dynamic clusters given as voxel sets and boxes); the track list after every frame as
+ * the same JSON lines.  The reference derives a cluster's voxels and box from its pixels' vertices (:444-487): a cluster
+ * becomes one pixel per voxel at the voxel's centre (track_by voxels) or two pixels at the box corners (track_by bounding_box).
+ * returns the length of the output (truncated to cap). */
+int64_t ref_tracker_replay(const char* scenario, char* out, int64_t cap) {
+  std::istringstream in(scenario);
+  std::string result, tok;
+  std::unique_ptr<khronos::MaxIoUTracker> tracker;
+  bool by_voxels = true;
+  float voxel_size = 0.2f;
+  struct Cl {
+    bool semantic;
+    int id, cat;
+    float lo[3], hi[3];
+    std::vector<std::array<int64_t, 3>> voxels;
+  };
+  std::vector<Cl> clusters;
+  uint64_t stamp = 0;
+  while (in >> tok) {
+    if (tok == "C") {
+      std::string kind, by, assoc;
+      khronos::MaxIoUTracker::Config c;
+      in >> kind >> by >> assoc >> c.min_semantic_iou >> c.min_cosine_sim >> c.min_cross_iou >> c.max_dynamic_distance >> c.temporal_window >>
+          c.min_num_observations >> c.voxel_size;
+      by_voxels = by == "voxels";
+      voxel_size = c.voxel_size;
+      c.track_by = by_voxels ? khronos::MaxIoUTracker::Config::TrackBy::kVoxels : khronos::MaxIoUTracker::Config::TrackBy::kBouningBox;
+      c.semantic_association = assoc == "assign_track" ? khronos::MaxIoUTracker::Config::SemanticAssociation::kAssignTrack
+                                                       : khronos::MaxIoUTracker::Config::SemanticAssociation::kAssignCluster;
+      tracker = std::make_unique<khronos::MaxIoUTracker>(c);
+    } else if (tok == "F") {
+      in >> stamp;
+      clusters.clear();
+    } else if (tok == "S" || tok == "D") {
+      Cl c;
+      c.semantic = tok == "S";
+      c.cat = -1;
+      in >> c.id;
+      if (c.semantic) in >> c.cat;
+      for (float& v : c.lo) in >> v;
+      for (float& v : c.hi) in >> v;
+      size_t n;
+      in >> n;
+      c.voxels.resize(n);
+      for (auto& v : c.voxels) in >> v[0] >> v[1] >> v[2];
+      clusters.push_back(std::move(c));
+    } else if (tok == "E") {
+      // one image row holding every cluster's pixels
+      size_t n_px = 0;
+      for (const Cl& c : clusters) n_px += by_voxels ? c.voxels.size() : 2;
+      hydra::InputData input;
+      input.timestamp_ns = stamp;
+      input.vertex_map = cv::Mat(1, static_cast<int>(std::max<size_t>(n_px, 1)), sizeof(cv::Vec3f));
+      khronos::FrameData data(input);
+      const spatial_hash::Grid<khronos::GlobalIndex> grid(voxel_size);
+      cv::Mat vm = data.input.vertex_map;  // (shares the pixels)
+      int u = 0;
+      for (const Cl& c : clusters) {
+        khronos::MeasurementCluster mc;
+        mc.id = c.id;
+        if (c.semantic) mc.semantics = khronos::SemanticClusterInfo(c.cat);
+        auto put = [&](const khronos::Point& p) {
+          cv::Vec3f& v = vm.at<cv::Vec3f>(0, u);
+          v[0] = p[0], v[1] = p[1], v[2] = p[2];
+          mc.pixels.emplace_back(u++, 0);
+        };
+        if (by_voxels) {
+          for (const auto& v : c.voxels) put(grid.toPoint(khronos::GlobalIndex(v[0], v[1], v[2])));
+        } else {
+          put(khronos::Point(c.lo[0], c.lo[1], c.lo[2]));
+          put(khronos::Point(c.hi[0], c.hi[1], c.hi[2]));
+        }
+        (c.semantic ? data.semantic_clusters : data.dynamic_clusters).push_back(std::move(mc));
+      }
+      tracker->processInput(data);
+      result += "[";
+      bool first = true;
+      for (const khronos::Track& t : tracker->getTracks()) {
+        const khronos::Observation& o = t.observations.back();
+        char buf[512];
+        std::snprintf(buf, sizeof(buf),
+                      "%s{\"id\": %d, \"dyn\": %d, \"active\": %d, \"conf\": %.9g, \"first\": %llu, \"last\": %llu, \"cat\": %d, "
+                      "\"n_obs\": %zu, \"obs\": [%llu, %d, %d], \"n_vox\": %zu, \"centroid\": [%.9g, %.9g, %.9g]}",
+                      first ? "" : ", ", t.id, int(t.is_dynamic), int(t.is_active), t.confidence, static_cast<unsigned long long>(t.first_seen),
+                      static_cast<unsigned long long>(t.last_seen), t.semantics ? t.semantics->category_id : -1, t.observations.size(),
+                      static_cast<unsigned long long>(o.stamp), o.semantic_cluster_id, o.dynamic_cluster_id, t.last_voxels.size(),
+                      t.is_dynamic ? t.last_centroid[0] : 0.f, t.is_dynamic ? t.last_centroid[1] : 0.f, t.is_dynamic ? t.last_centroid[2] : 0.f);
+        result += buf;
+        first = false;
+      }
+      result += "]\n";
+    }
+  }
+  const int64_t n = std::min<int64_t>(static_cast<int64_t>(result.size()), cap > 0 ? cap - 1 : 0);
+  if (cap > 0) {
+    std::memcpy(out, result.data(), static_cast<size_t>(n));
+    out[n] = 0;
+  }
+  return static_cast<int64_t>(result.size());
 }
 
 /* utils::combineMeshLayer (geometry_utils.cpp:61-86): blocks given as vertex counts + faces per block (local indices);

@@ -6,6 +6,7 @@
 //   khronos/src/active_window/motion_detection/free_space_motion_detector.cpp   (a9 - a11)
 //   khronos/src/utils/geometry_utils.cpp                                 (a16, cluster bounding boxes)
 //   khronos/src/active_window/object_detection/connected_semantics.cpp   (a18 / f3)
+//   khronos/src/active_window/tracking/max_iou_tracker.cpp, data/track.cpp      (a18)
 // but not the containers they run on.  oracle/ref_recipe/build_ref.sh compiles those files FROM WHERE THEY LIE
 // (nothing is copied) against this header into oracle/_ref/libref_khronos.so, and tests/test_cpu_ref_pin.py runs the
 // reference's own code beside oracle/oracle.cpp on the same seeded sequences.  What that pins: every decision those files
@@ -24,8 +25,12 @@
 #include <cstdint>
 #include <functional>
 #include <iostream>
+#include <limits>
+#include <map>
 #include <memory>
 #include <mutex>
+#include <set>
+#include <sstream>
 #include <string>
 #include <type_traits>
 #include <unordered_map>
@@ -99,6 +104,20 @@ class Matrix<T, Dynamic, Dynamic> {
     m.setZero();
     return m;
   }
+  // element count, element access and the two operations of the feature mean (track.cpp:49-70) and the cosine score
+  size_t size() const { return d_.size(); }
+  T& operator()(size_t i) { return d_[i]; }
+  const T& operator()(size_t i) const { return d_[i]; }
+  Matrix operator+(const Matrix& o) const {
+    Matrix m(r_, c_);
+    for (size_t i = 0; i < d_.size(); ++i) m.d_[i] = d_[i] + o.d_[i];
+    return m;
+  }
+  friend Matrix operator*(T s, const Matrix& a) {
+    Matrix m(a.r_, a.c_);
+    for (size_t i = 0; i < a.d_.size(); ++i) m.d_[i] = s * a.d_[i];
+    return m;
+  }
 
  private:
   size_t r_ = 0, c_ = 0;
@@ -106,19 +125,26 @@ class Matrix<T, Dynamic, Dynamic> {
 };
 
 using Vector3f = Matrix<float, 3, 1>;
+using Vector3d = Matrix<double, 3, 1>;
 using Vector3i = Matrix<int, 3, 1>;
 using MatrixXi = Matrix<int, Dynamic, Dynamic>;
 using MatrixXf = Matrix<float, Dynamic, Dynamic>;
 using VectorXf = Matrix<float, Dynamic, Dynamic>;
 
-// sensor pose: only translation() is read (free_space_motion_detector.cpp:80)
+// sensor pose: translation() (free_space_motion_detector.cpp:80) and pose * point (max_iou_tracker.cpp:585)
 class Isometry3d {
  public:
   using Vec = Matrix<double, 3, 1>;
   Vec& translation() { return t_; }
   const Vec& translation() const { return t_; }
+  double& linear(int r, int c) { return r_[3 * r + c]; }
+  Vec operator*(const Vec& p) const {
+    return Vec((r_[0] * p[0] + r_[1] * p[1]) + r_[2] * p[2] + t_[0], (r_[3] * p[0] + r_[4] * p[1]) + r_[5] * p[2] + t_[1],
+               (r_[6] * p[0] + r_[7] * p[1]) + r_[8] * p[2] + t_[2]);
+  }
 
  private:
+  double r_[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   Vec t_;
 };
 }  // namespace Eigen
@@ -193,6 +219,12 @@ template <typename T>
 void checkIsOneOf(const T&, std::initializer_list<T>, const std::string&) {}
 inline void checkCondition(bool, const std::string&) {}
 template <typename T>
+void checkInRange(const T&, const T&, const T&, const std::string&) {}
+template <typename E>
+void enum_field(E&, const std::string&, const std::vector<std::string>&) {}
+template <typename E>
+void enum_field(E&, const std::string&, std::initializer_list<const char*>) {}
+template <typename T>
 const T& checkValid(const T& c) { return c; }
 template <typename Base, typename Derived, typename Cfg>
 struct RegistrationWithConfig {
@@ -262,6 +294,21 @@ inline const std::vector<std::array<int, 3>>& neighborOffsets(int connectivity) 
   static const std::vector<std::array<int, 3>> six(all.begin(), all.begin() + 6), eighteen(all.begin(), all.begin() + 18);
   return connectivity == 6 ? six : (connectivity == 18 ? eighteen : all);
 }
+
+// [A.7] regular grid: toIndex(p) = floor(p * (1 / voxel_size)), toPoint(i) = (float(i) + 0.5) * voxel_size
+// (max_iou_tracker.cpp:485,555)
+template <typename IndexT>
+class Grid {
+ public:
+  explicit Grid(float voxel_size) : voxel_size_(voxel_size), voxel_size_inv_(1.f / voxel_size) {}
+  IndexT toIndex(const Point& p) const { return indexFromPoint<IndexT>(p, voxel_size_inv_); }
+  Point toPoint(const IndexT& i) const {
+    return Point((static_cast<float>(i[0]) + 0.5f) * voxel_size_, (static_cast<float>(i[1]) + 0.5f) * voxel_size_, (static_cast<float>(i[2]) + 0.5f) * voxel_size_);
+  }
+
+ private:
+  float voxel_size_, voxel_size_inv_;
+};
 
 class NeighborSearch {  // free_space_motion_detector.cpp:213,249
  public:
@@ -401,16 +448,42 @@ struct BoundingBox {
     virtual Eigen::Vector3f get(size_t index) const = 0;
   };
   Eigen::Vector3f min, max;
+  Eigen::Vector3f world_P_center, dimensions;  // [A.7] centre = (min + max) / 2, dimensions = max - min
   bool valid = false;
   BoundingBox() = default;
   explicit BoundingBox(const PointAdaptor& points) {
-    for (size_t i = 0; i < points.size(); ++i) {
-      const Eigen::Vector3f p = points.get(i);
-      if (!valid) { min = max = p; valid = true; continue; }
-      for (int a = 0; a < 3; ++a) {
-        if (p[a] < min[a]) min[a] = p[a];
-        if (p[a] > max[a]) max[a] = p[a];
-      }
+    for (size_t i = 0; i < points.size(); ++i) include(points.get(i));
+    finish();
+  }
+  explicit BoundingBox(const std::vector<Eigen::Vector3f>& points) {
+    for (const auto& p : points) include(p);
+    finish();
+  }
+  float volume() const { return valid ? dimensions[0] * dimensions[1] * dimensions[2] : 0.f; }
+  // [A.7] IoU of two axis-aligned boxes: intersection volume / union volume, 0 when disjoint or either box is invalid
+  // (max_iou_tracker.cpp:592)
+  float computeIoU(const BoundingBox& o) const {
+    if (!valid || !o.valid) return 0.f;
+    float inter = 1.f;
+    for (int a = 0; a < 3; ++a) {
+      const float lo = std::max(min[a], o.min[a]), hi = std::min(max[a], o.max[a]);
+      if (hi <= lo) return 0.f;
+      inter *= hi - lo;
+    }
+    return inter / (volume() + o.volume() - inter);
+  }
+  void include(const Eigen::Vector3f& p) {
+    if (!valid) { min = max = p; valid = true; return; }
+    for (int a = 0; a < 3; ++a) {
+      if (p[a] < min[a]) min[a] = p[a];
+      if (p[a] > max[a]) max[a] = p[a];
+    }
+  }
+  void finish() {
+    if (!valid) return;
+    for (int a = 0; a < 3; ++a) {
+      world_P_center[a] = (min[a] + max[a]) * 0.5f;
+      dimensions[a] = max[a] - min[a];
     }
   }
 };
@@ -566,7 +639,30 @@ class GlobalInfo {
   LabelSpaceConfig labels_;
 };
 
-struct Sensor {};
+// [A.8] pinhole projection to the nearest pixel; false when behind the camera or outside the image (max_iou_tracker.cpp:586)
+struct Sensor {
+  int width = 0, height = 0;
+  float fx = 1.f, fy = 1.f, cx = 0.f, cy = 0.f;
+  bool projectPointToImagePlane(const Eigen::Vector3f& p, int& u, int& v) const {
+    if (p[2] <= 0.f) return false;
+    u = static_cast<int>(std::round((p[0] * fx) / p[2] + cx));
+    v = static_cast<int>(std::round((p[1] * fy) / p[2] + cy));
+    return u >= 0 && v >= 0 && u < width && v < height;
+  }
+};
+
+// [A.7] cosine score a . b / (|a| |b|) (max_iou_tracker.cpp:56-59)
+struct CosineDistance {
+  float score(const FeatureVector& a, const FeatureVector& b) const {
+    float ab = 0.f, aa = 0.f, bb = 0.f;
+    for (size_t i = 0; i < a.size(); ++i) {
+      ab += a(i) * b(i);
+      aa += a(i) * a(i);
+      bb += b(i) * b(i);
+    }
+    return ab / (std::sqrt(aa) * std::sqrt(bb));
+  }
+};
 
 // the input of a frame: what the motion detector reads (free_space_motion_detector.cpp:74,80,114,168,174)
 struct InputData {
@@ -579,6 +675,8 @@ struct InputData {
   cv::Mat range_image;
   Eigen::Isometry3d world_T_sensor;
   const Eigen::Isometry3d& getSensorPose() const { return world_T_sensor; }
+  Sensor sensor;
+  const Sensor& getSensor() const { return sensor; }
 };
 
 namespace timing {

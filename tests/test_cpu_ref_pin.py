@@ -240,3 +240,42 @@ def test_object_detector_equals_reference_code(mode):
             assert np.array_equal(c["bbox_min"].astype(np.float32), e["bbox_min"]) and np.array_equal(c["bbox_max"].astype(np.float32), e["bbox_max"])
         total += n_r
     assert total > 4, (mode, total)
+
+
+@needs_ref
+@pytest.mark.parametrize("case", ["voxels-assign-cluster", "voxels-assign-track", "bounding-box"])
+def test_host_tracker_equals_reference_code(case):
+    """The PRODUCT's host tracker (khronos_amd/host/object_tracking.cpp, through host_selftest --tracker) against the reference's
+    own MaxIoUTracker (max_iou_tracker.cpp:198-593 + track.cpp, compiled in place) on random scenarios of drifting, flickering
+    and moving clusters: same tracks after every frame -- ids, dynamic / active flags, stamps, categories, observation lists,
+    voxel-set sizes, confidences; centroids of dynamic tracks to float rounding (the reference sums voxel centres in
+    unordered_set order, ASSUMPTIONS.md C.4)."""
+    import json
+    import subprocess
+    from test_cpu_host import SELFTEST, _encode, _scenario
+    cfg = {
+        "voxels-assign-cluster": dict(track_by="voxels", association="assign_cluster", min_semantic_iou=0.25, min_cross_iou=0.1,
+                                      max_dynamic_distance=1.0, temporal_window=0.55, min_num_observations=4, voxel_size=0.2),
+        "voxels-assign-track": dict(track_by="voxels", association="assign_track", min_semantic_iou=0.25, min_cross_iou=0.1,
+                                    max_dynamic_distance=0.5, temporal_window=0.35, min_num_observations=15, voxel_size=0.2),
+        "bounding-box": dict(track_by="bounding_box", association="assign_cluster", min_semantic_iou=0.3, min_cross_iou=0.2,
+                             max_dynamic_distance=1.0, temporal_window=1.0, min_num_observations=3, voxel_size=0.2),
+    }[case]
+    for seed in (100, 101, 102):
+        frames = _scenario(np.random.default_rng(seed), 40, True)
+        scenario = _encode("maxiou", cfg, frames)
+        out = subprocess.run([SELFTEST, "--tracker"], input=scenario, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        got = [json.loads(line) for line in out.stdout.strip().splitlines()]
+        want = [json.loads(line) for line in pyref.tracker_replay(LIB, scenario).strip().splitlines()]
+        assert len(got) == len(want) == len(frames)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert len(g) == len(w), (case, seed, i)
+            for a, b in zip(g, w):
+                for k in ("id", "dyn", "active", "first", "last", "cat", "n_obs", "obs", "conf"):
+                    assert a[k] == b[k], (case, seed, i, k, a, b)
+                if cfg["track_by"] == "voxels":
+                    assert a["n_vox"] == b["n_vox"], (case, seed, i)
+                if a["dyn"]:
+                    assert a["centroid"] == pytest.approx(b["centroid"], rel=1e-5, abs=1e-5), (case, seed, i)
+        assert max(len(g) for g in got) >= 4 and any(t["dyn"] for t in got[-1]) and any(not t["active"] for t in got[-1])

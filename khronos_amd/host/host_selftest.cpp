@@ -106,8 +106,47 @@ static int trackerReplay() {
   return 0;
 }
 
+// FrameDataBuffer replay (tests/test_cpu_ref_pin.py): a script of operations on stdin, after each one a line
+//   <size> <stamp of the latest frame, 0 when empty> <one 0/1 per stamp stored so far: getData(stamp) != nullptr>
+// Format:  B <max_buffer_size> <store_every_n_frames>  |  S <stamp>  |  T <n_tracks> { <n_observations> <stamp>* }*
+static int bufferReplay() {
+  std::unique_ptr<FrameDataBuffer> buffer;
+  std::vector<TimeStamp> stamps;
+  std::string tok;
+  while (std::cin >> tok) {
+    if (tok == "B") {
+      FrameDataBuffer::Config c;
+      std::cin >> c.max_buffer_size >> c.store_every_n_frames;
+      buffer = std::make_unique<FrameDataBuffer>(c);
+      continue;
+    }
+    if (tok == "S") {
+      auto f = std::make_shared<FrameData>();
+      std::cin >> f->input.timestamp_ns;
+      stamps.push_back(f->input.timestamp_ns);
+      buffer->storeData(f);
+    } else if (tok == "T") {
+      size_t n_tracks;
+      std::cin >> n_tracks;
+      Tracks tracks(n_tracks);
+      for (Track& t : tracks) {
+        size_t n_obs;
+        std::cin >> n_obs;
+        t.observations.resize(n_obs);
+        for (Observation& o : t.observations) std::cin >> o.stamp;
+      }
+      buffer->trimBuffer(tracks);
+    }
+    std::printf("%zu %llu", buffer->size(), static_cast<unsigned long long>(buffer->size() ? buffer->getLatestData().input.timestamp_ns : 0));
+    for (TimeStamp st : stamps) std::printf(" %d", buffer->getData(st) ? 1 : 0);
+    std::printf("\n");
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc > 1 && std::strcmp(argv[1], "--tracker") == 0) return trackerReplay();
+  if (argc > 1 && std::strcmp(argv[1], "--buffer") == 0) return bufferReplay();
   // ---- YAML ----
   if (argc > 1) {
     std::ifstream in(argv[1]);

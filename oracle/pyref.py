@@ -59,6 +59,8 @@ def load():
     lib.ref_detect_objects.argtypes = ([C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_float, C.c_float] + [C.c_void_p] * 4 + [C.c_int])
     lib.ref_tracker_replay.restype = C.c_int64
     lib.ref_tracker_replay.argtypes = [C.c_char_p, C.c_void_p, C.c_int64]
+    lib.ref_buffer_replay.restype = C.c_int64
+    lib.ref_buffer_replay.argtypes = [C.c_char_p, C.c_void_p, C.c_int64]
     lib.ref_combine_mesh.restype = C.c_int64
     lib.ref_combine_mesh.argtypes = [C.c_int] + [C.c_void_p] * 8
     return lib
@@ -168,5 +170,14 @@ def tracker_replay(lib, scenario):
     cap = 1 << 24
     buf = C.create_string_buffer(cap)
     n = lib.ref_tracker_replay(scenario.encode(), buf, cap)
+    assert 0 <= n < cap
+    return buf.value.decode()
+
+
+def buffer_replay(lib, script):
+    """FrameDataBuffer over a script in host_selftest --buffer's format; the lines it prints."""
+    cap = 1 << 22
+    buf = C.create_string_buffer(cap)
+    n = lib.ref_buffer_replay(script.encode(), buf, cap)
     assert 0 <= n < cap
     return buf.value.decode()

@@ -18,6 +18,8 @@
 #include "khronos/active_window/integration/tracking_integrator.h"
 #include "khronos/active_window/motion_detection/free_space_motion_detector.h"
 #include "khronos/active_window/object_detection/connected_semantics.h"
+#include "khronos/active_window/data/frame_data_buffer.h"
+#include "khronos/active_window/tracking/external_tracker.h"
 #include "khronos/active_window/tracking/max_iou_tracker.h"
 #include "khronos/utils/geometry_utils.h"
 
@@ -241,7 +243,7 @@ int ref_detect_objects(int W, int H, const float* range, const float* vertex, co
 int64_t ref_tracker_replay(const char* scenario, char* out, int64_t cap) {
   std::istringstream in(scenario);
   std::string result, tok;
-  std::unique_ptr<khronos::MaxIoUTracker> tracker;
+  std::unique_ptr<khronos::Tracker> tracker;
   bool by_voxels = true;
   float voxel_size = 0.2f;
   struct Cl {
@@ -263,7 +265,14 @@ int64_t ref_tracker_replay(const char* scenario, char* out, int64_t cap) {
       c.track_by = by_voxels ? khronos::MaxIoUTracker::Config::TrackBy::kVoxels : khronos::MaxIoUTracker::Config::TrackBy::kBouningBox;
       c.semantic_association = assoc == "assign_track" ? khronos::MaxIoUTracker::Config::SemanticAssociation::kAssignTrack
                                                        : khronos::MaxIoUTracker::Config::SemanticAssociation::kAssignCluster;
-      tracker = std::make_unique<khronos::MaxIoUTracker>(c);
+      if (kind == "external") {  // external_tracker.cpp:59-143
+        khronos::ExternalTracker::Config e;
+        e.temporal_window = c.temporal_window;
+        e.min_num_observations = c.min_num_observations;
+        tracker = std::make_unique<khronos::ExternalTracker>(e);
+      } else {
+        tracker = std::make_unique<khronos::MaxIoUTracker>(c);
+      }
     } else if (tok == "F") {
       in >> stamp;
       clusters.clear();
@@ -326,6 +335,51 @@ int64_t ref_tracker_replay(const char* scenario, char* out, int64_t cap) {
       }
       result += "]\n";
     }
+  }
+  const int64_t n = std::min<int64_t>(static_cast<int64_t>(result.size()), cap > 0 ? cap - 1 : 0);
+  if (cap > 0) {
+    std::memcpy(out, result.data(), static_cast<size_t>(n));
+    out[n] = 0;
+  }
+  return static_cast<int64_t>(result.size());
+}
+
+/* FrameDataBuffer (frame_data_buffer.cpp:57-123) over a script in the format of host_selftest --buffer; the same lines. */
+int64_t ref_buffer_replay(const char* script, char* out, int64_t cap) {
+  std::istringstream in(script);
+  std::string result, tok;
+  std::unique_ptr<khronos::FrameDataBuffer> buffer;
+  std::vector<uint64_t> stamps;
+  while (in >> tok) {
+    if (tok == "B") {
+      khronos::FrameDataBuffer::Config c;
+      in >> c.max_buffer_size >> c.store_every_n_frames;
+      buffer = std::make_unique<khronos::FrameDataBuffer>(c);
+      continue;
+    }
+    if (tok == "S") {
+      hydra::InputData input;
+      in >> input.timestamp_ns;
+      stamps.push_back(input.timestamp_ns);
+      buffer->storeData(std::make_shared<khronos::FrameData>(input));
+    } else if (tok == "T") {
+      size_t n_tracks;
+      in >> n_tracks;
+      khronos::Tracks tracks(n_tracks);
+      for (khronos::Track& t : tracks) {
+        size_t n_obs;
+        in >> n_obs;
+        for (size_t i = 0; i < n_obs; ++i) {
+          uint64_t st;
+          in >> st;
+          t.observations.emplace_back(st);
+        }
+      }
+      buffer->trimBuffer(tracks);
+    }
+    result += std::to_string(buffer->size()) + " " + std::to_string(buffer->size() ? buffer->getLatestData().input.timestamp_ns : 0);
+    for (uint64_t st : stamps) result += buffer->getData(st) ? " 1" : " 0";
+    result += "\n";
   }
   const int64_t n = std::min<int64_t>(static_cast<int64_t>(result.size()), cap > 0 ? cap - 1 : 0);
   if (cap > 0) {

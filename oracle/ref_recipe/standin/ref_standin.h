@@ -6,7 +6,8 @@
 //   khronos/src/active_window/motion_detection/free_space_motion_detector.cpp   (a9 - a11)
 //   khronos/src/utils/geometry_utils.cpp                                 (a16, cluster bounding boxes)
 //   khronos/src/active_window/object_detection/connected_semantics.cpp   (a18 / f3)
-//   khronos/src/active_window/tracking/max_iou_tracker.cpp, data/track.cpp      (a18)
+//   khronos/src/active_window/tracking/max_iou_tracker.cpp, external_tracker.cpp, data/track.cpp   (a18)
+//   khronos/src/active_window/data/frame_data_buffer.cpp                 (a17)
 // but not the containers they run on.  oracle/ref_recipe/build_ref.sh compiles those files FROM WHERE THEY LIE
 // (nothing is copied) against this header into oracle/_ref/libref_khronos.so, and tests/test_cpu_ref_pin.py runs the
 // reference's own code beside oracle/oracle.cpp on the same seeded sequences.  What that pins: every decision those files

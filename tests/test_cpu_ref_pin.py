@@ -243,7 +243,7 @@ def test_object_detector_equals_reference_code(mode):
 
 
 @needs_ref
-@pytest.mark.parametrize("case", ["voxels-assign-cluster", "voxels-assign-track", "bounding-box"])
+@pytest.mark.parametrize("case", ["voxels-assign-cluster", "voxels-assign-track", "bounding-box", "external"])
 def test_host_tracker_equals_reference_code(case):
     """The PRODUCT's host tracker (khronos_amd/host/object_tracking.cpp, through host_selftest --tracker) against the reference's
     own MaxIoUTracker (max_iou_tracker.cpp:198-593 + track.cpp, compiled in place) on random scenarios of drifting, flickering
@@ -260,10 +260,14 @@ def test_host_tracker_equals_reference_code(case):
                                     max_dynamic_distance=0.5, temporal_window=0.35, min_num_observations=15, voxel_size=0.2),
         "bounding-box": dict(track_by="bounding_box", association="assign_cluster", min_semantic_iou=0.3, min_cross_iou=0.2,
                              max_dynamic_distance=1.0, temporal_window=1.0, min_num_observations=3, voxel_size=0.2),
+        # ExternalTracker (external_tracker.cpp:59-143): tracks follow the cluster ids
+        "external": dict(track_by="voxels", association="assign_cluster", min_semantic_iou=0.5, min_cross_iou=0.5, max_dynamic_distance=1.0,
+                         temporal_window=0.45, min_num_observations=5, voxel_size=0.2),
     }[case]
+    kind = "external" if case == "external" else "maxiou"
     for seed in (100, 101, 102):
-        frames = _scenario(np.random.default_rng(seed), 40, True)
-        scenario = _encode("maxiou", cfg, frames)
+        frames = _scenario(np.random.default_rng(seed), 40, kind == "maxiou")
+        scenario = _encode(kind, cfg, frames)
         out = subprocess.run([SELFTEST, "--tracker"], input=scenario, capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stderr
         got = [json.loads(line) for line in out.stdout.strip().splitlines()]
@@ -274,8 +278,38 @@ def test_host_tracker_equals_reference_code(case):
             for a, b in zip(g, w):
                 for k in ("id", "dyn", "active", "first", "last", "cat", "n_obs", "obs", "conf"):
                     assert a[k] == b[k], (case, seed, i, k, a, b)
-                if cfg["track_by"] == "voxels":
+                if cfg["track_by"] == "voxels" and kind == "maxiou":
                     assert a["n_vox"] == b["n_vox"], (case, seed, i)
                 if a["dyn"]:
                     assert a["centroid"] == pytest.approx(b["centroid"], rel=1e-5, abs=1e-5), (case, seed, i)
-        assert max(len(g) for g in got) >= 4 and any(t["dyn"] for t in got[-1]) and any(not t["active"] for t in got[-1])
+        assert max(len(g) for g in got) >= 4
+        assert kind == "external" or (any(t["dyn"] for t in got[-1]) and any(not t["active"] for t in got[-1]))
+
+
+@needs_ref
+@pytest.mark.parametrize("max_size,every_n", [(6, 1), (4, 3), (300, 1), (1, 2)])
+def test_host_frame_buffer_equals_reference_code(max_size, every_n):
+    """The product's FrameDataBuffer (khronos_amd/host, through host_selftest --buffer) against the reference's own
+    frame_data_buffer.cpp:57-123 on random scripts of stores and trims: size, latest frame and what getData finds, after every
+    operation."""
+    import subprocess
+    from test_cpu_host import SELFTEST
+    rng = np.random.default_rng(1000 * max_size + every_n)
+    lines, stamps = ["B %d %d" % (max_size, every_n)], []
+    for i in range(120):
+        if not stamps or rng.uniform() < 0.7:
+            stamps.append(1_000_000_000 + 100_000_000 * len(stamps))
+            lines.append("S %d" % stamps[-1])
+        else:  # trim against tracks whose observations name some of the recent frames (and some frames that never existed)
+            tracks = []
+            for _ in range(int(rng.integers(0, 4))):
+                obs = [int(s) for s in rng.choice(stamps[-12:], size=int(rng.integers(0, 5)))] + ([17] if rng.uniform() < 0.2 else [])
+                tracks.append("%d %s" % (len(obs), " ".join(map(str, obs))))
+            lines.append("T %d %s" % (len(tracks), " ".join(tracks)))
+    script = "\n".join(lines) + "\n"
+    out = subprocess.run([SELFTEST, "--buffer"], input=script, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    want = pyref.buffer_replay(LIB, script)
+    assert out.stdout == want
+    sizes = [int(line.split()[0]) for line in want.strip().splitlines()]
+    assert max(sizes) >= min(max_size, 3) and any(b < a for a, b in zip(sizes, sizes[1:]))

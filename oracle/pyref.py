@@ -61,6 +61,11 @@ def load():
     lib.ref_tracker_replay.argtypes = [C.c_char_p, C.c_void_p, C.c_int64]
     lib.ref_buffer_replay.restype = C.c_int64
     lib.ref_buffer_replay.argtypes = [C.c_char_p, C.c_void_p, C.c_int64]
+    lib.ref_rv_create.restype = C.c_void_p
+    lib.ref_rv_create.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ref_rv_destroy.argtypes = [C.c_void_p]
+    lib.ref_rv_check.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.ref_detect_changes.argtypes = [C.c_float, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     lib.ref_combine_mesh.restype = C.c_int64
     lib.ref_combine_mesh.argtypes = [C.c_int] + [C.c_void_p] * 8
     return lib
@@ -181,3 +186,39 @@ def buffer_replay(lib, script):
     n = lib.ref_buffer_replay(script.encode(), buf, cap)
     assert 0 <= n < cap
     return buf.value.decode()
+
+
+class RefRayVerificator:
+    """The reference's RayVerificator over rays given as arrays (ascending, distinct stamps)."""
+
+    def __init__(self, lib, stamps, sources, targets, block_size=1.0, radial_tolerance=0.1, depth_tolerance=0.1):
+        self.lib = lib
+        st = np.ascontiguousarray(stamps, np.uint64)
+        assert (np.diff(st.astype(np.int64)) > 0).all()
+        sr = np.ascontiguousarray(sources, np.float32).reshape(-1, 3)
+        tg = np.ascontiguousarray(targets, np.float32).reshape(-1, 3)
+        self.h = lib.ref_rv_create(float(block_size), float(radial_tolerance), float(depth_tolerance), st.size, _ptr(st), _ptr(sr), _ptr(tg))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref_rv_destroy(self.h)
+            self.h = None
+
+    def check_one(self, point, earliest=0, latest=2 ** 64 - 1, cap=1 << 16):
+        p = np.ascontiguousarray(point, np.float32)
+        pres, absn = np.zeros(cap, np.uint64), np.zeros(cap, np.uint64)
+        n_p, n_a = C.c_int64(0), C.c_int64(0)
+        self.lib.ref_rv_check(self.h, _ptr(p), int(earliest), int(latest), _ptr(pres), cap, C.addressof(n_p), _ptr(absn), cap, C.addressof(n_a))
+        assert n_p.value <= cap and n_a.value <= cap
+        return pres[: n_p.value].copy(), absn[: n_a.value].copy()
+
+
+def detect_changes(lib, present, absent, forward, temporal_resolution=1.0, window_size=5, use_relative_confidence=True,
+                   absence_confidence=0.5, presence_confidence=0.5):
+    """RayChangeDetector::detectChanges: (closest_absent or None, furthest_persistent or None)."""
+    pr = np.ascontiguousarray(present, np.uint64)
+    ab = np.ascontiguousarray(absent, np.uint64)
+    out = np.zeros(4, np.uint64)
+    lib.ref_detect_changes(float(temporal_resolution), int(window_size), int(use_relative_confidence), float(absence_confidence),
+                           float(presence_confidence), _ptr(pr), pr.size, _ptr(ab), ab.size, int(forward), _ptr(out))
+    return (int(out[1]) if out[0] else None), (int(out[3]) if out[2] else None)

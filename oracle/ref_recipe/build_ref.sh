@@ -15,7 +15,8 @@ OUT="$REPO/oracle/_ref"
 SRC="$KHRONOS_ROOT/khronos/src"
 for f in active_window/integration/tracking_integrator.cpp active_window/motion_detection/free_space_motion_detector.cpp utils/geometry_utils.cpp \
          active_window/object_detection/connected_semantics.cpp active_window/tracking/max_iou_tracker.cpp active_window/data/track.cpp \
-         active_window/tracking/external_tracker.cpp active_window/data/frame_data_buffer.cpp; do
+         active_window/tracking/external_tracker.cpp active_window/data/frame_data_buffer.cpp \
+         backend/change_detection/ray_verificator.cpp backend/change_detection/ray_change_detector.cpp; do
   [ -f "$SRC/$f" ] || { echo "build_ref.sh: $SRC/$f not found (no reference checkout here): keeping what is in $OUT" >&2; exit 3; }
 done
 mkdir -p "$OUT"
@@ -30,5 +31,7 @@ mkdir -p "$OUT"
   "$SRC/active_window/data/track.cpp" \
   "$SRC/active_window/tracking/external_tracker.cpp" \
   "$SRC/active_window/data/frame_data_buffer.cpp" \
+  "$SRC/backend/change_detection/ray_verificator.cpp" \
+  "$SRC/backend/change_detection/ray_change_detector.cpp" \
   -o "$OUT/libref_khronos.so"
 echo "built $OUT/libref_khronos.so"

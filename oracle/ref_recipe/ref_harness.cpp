@@ -21,6 +21,8 @@
 #include "khronos/active_window/data/frame_data_buffer.h"
 #include "khronos/active_window/tracking/external_tracker.h"
 #include "khronos/active_window/tracking/max_iou_tracker.h"
+#include "khronos/backend/change_detection/ray_change_detector.h"
+#include "khronos/backend/change_detection/ray_verificator.h"
 #include "khronos/utils/geometry_utils.h"
 
 namespace {
@@ -387,6 +389,78 @@ int64_t ref_buffer_replay(const char* script, char* out, int64_t cap) {
     out[n] = 0;
   }
   return static_cast<int64_t>(result.size());
+}
+
+/* RayVerificator (ray_verificator.cpp:66-145,212-349) over rays given as arrays.  The reference finds a ray's source in the scene
+ * graph's agent layer and its target in the graph's mesh: ray i becomes agent node i (position = source, timestamp = stamp) and
+ * mesh vertex i (= target, first seen one nanosecond before the stamp), and with ray_policy First each vertex draws exactly the
+ * ray from its own agent node (computeVertexSources, :275-283).  Stamps must be ascending and distinct. */
+struct RefRayVerificator {
+  std::shared_ptr<spark_dsg::DynamicSceneGraph> dsg;
+  std::unique_ptr<khronos::RayVerificator> rv;
+};
+
+RefRayVerificator* ref_rv_create(float block_size, float radial_tolerance, float depth_tolerance, int64_t n, const uint64_t* stamps,
+                                 const float* sources, const float* targets) {
+  auto* r = new RefRayVerificator();
+  khronos::RayVerificator::Config c;
+  c.block_size = block_size;
+  c.radial_tolerance = radial_tolerance;
+  c.depth_tolerance = depth_tolerance;
+  c.ray_policy = khronos::RayVerificator::Config::RayPolicy::kFirst;
+  r->rv = std::make_unique<khronos::RayVerificator>(c);
+  r->dsg = std::make_shared<spark_dsg::DynamicSceneGraph>();
+  auto& agents = r->dsg->layers[{r->dsg->layer_ids.at(spark_dsg::DsgLayers::AGENTS), c.prefix.key}];
+  r->dsg->mesh_ = std::make_shared<spark_dsg::Mesh>();
+  for (int64_t i = 0; i < n; ++i) {
+    auto attrs = std::make_unique<spark_dsg::AgentNodeAttributes>();
+    attrs->position = Eigen::Vector3d(sources[3 * i], sources[3 * i + 1], sources[3 * i + 2]);
+    attrs->timestamp = std::chrono::nanoseconds(static_cast<int64_t>(stamps[i]));
+    auto node = std::make_unique<spark_dsg::SceneGraphNode>();
+    node->attrs = std::move(attrs);
+    agents.nodes_[static_cast<spark_dsg::NodeId>(i)] = std::move(node);
+    r->dsg->mesh_->points.emplace_back(targets[3 * i], targets[3 * i + 1], targets[3 * i + 2]);
+    r->dsg->mesh_->first_seen_stamps.push_back(stamps[i] - 1);
+    r->dsg->mesh_->stamps.push_back(stamps[i]);
+  }
+  r->rv->setDsg(r->dsg);
+  return r;
+}
+
+void ref_rv_destroy(RefRayVerificator* r) { delete r; }
+
+/* RayVerificator::check; the stamps of the two lists in ascending order (the reference walks an unordered_set of rays) */
+void ref_rv_check(const RefRayVerificator* r, const float* point, uint64_t earliest, uint64_t latest, uint64_t* present, int64_t cap_present,
+                  int64_t* n_present, uint64_t* absent, int64_t cap_absent, int64_t* n_absent) {
+  auto res = r->rv->check(khronos::Point(point[0], point[1], point[2]), earliest, latest);
+  std::sort(res.present.begin(), res.present.end());
+  std::sort(res.absent.begin(), res.absent.end());
+  *n_present = static_cast<int64_t>(res.present.size());
+  *n_absent = static_cast<int64_t>(res.absent.size());
+  for (int64_t i = 0; i < *n_present && i < cap_present; ++i) present[i] = res.present[i];
+  for (int64_t i = 0; i < *n_absent && i < cap_absent; ++i) absent[i] = res.absent[i];
+}
+
+/* RayChangeDetector::detectChanges (ray_change_detector.cpp:66-133).  out: {has closest_absent, closest_absent, has
+ * furthest_persistent, furthest_persistent} */
+void ref_detect_changes(float temporal_resolution, int64_t window_size, int use_relative_confidence, float absence_confidence,
+                        float presence_confidence, const uint64_t* present, int64_t n_present, const uint64_t* absent, int64_t n_absent,
+                        int forward, uint64_t* out) {
+  khronos::RayChangeDetector::Config c;
+  c.temporal_resolution = temporal_resolution;
+  c.window_size = static_cast<size_t>(window_size);
+  c.use_relative_confidence = use_relative_confidence != 0;
+  c.absence_confidence = absence_confidence;
+  c.presence_confidence = presence_confidence;
+  const khronos::RayChangeDetector detector(c);
+  khronos::RayVerificator::CheckResult check;
+  check.present.assign(present, present + n_present);
+  check.absent.assign(absent, absent + n_absent);
+  const auto res = detector.detectChanges(check, forward != 0);
+  out[0] = res.closest_absent.has_value();
+  out[1] = res.closest_absent.value_or(0);
+  out[2] = res.furthest_persistent.has_value();
+  out[3] = res.furthest_persistent.value_or(0);
 }
 
 /* utils::combineMeshLayer (geometry_utils.cpp:61-86): blocks given as vertex counts + faces per block (local indices);

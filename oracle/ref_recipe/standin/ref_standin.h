@@ -8,6 +8,7 @@
 //   khronos/src/active_window/object_detection/connected_semantics.cpp   (a18 / f3)
 //   khronos/src/active_window/tracking/max_iou_tracker.cpp, external_tracker.cpp, data/track.cpp   (a18)
 //   khronos/src/active_window/data/frame_data_buffer.cpp                 (a17)
+//   khronos/src/backend/change_detection/ray_verificator.cpp, ray_change_detector.cpp   (f4)
 // but not the containers they run on.  oracle/ref_recipe/build_ref.sh compiles those files FROM WHERE THEY LIE
 // (nothing is copied) against this header into oracle/_ref/libref_khronos.so, and tests/test_cpu_ref_pin.py runs the
 // reference's own code beside oracle/oracle.cpp on the same seeded sequences.  What that pins: every decision those files
@@ -21,6 +22,7 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -30,6 +32,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <optional>
 #include <set>
 #include <sstream>
 #include <string>
@@ -72,6 +75,18 @@ class Matrix {
   bool operator==(const Matrix& o) const { return v_ == o.v_; }
   bool operator!=(const Matrix& o) const { return !(v_ == o.v_); }
   T squaredNorm() const { return v_[0] * v_[0] + v_[1] * v_[1] + v_[2] * v_[2]; }
+  // [A.7] dot = (x x' + y y') + z z', cross by the textbook formula, normalized = component-wise division by the norm
+  // (ray_verificator.cpp:99-131,333-346)
+  T dot(const Matrix& o) const { return v_[0] * o.v_[0] + v_[1] * o.v_[1] + v_[2] * o.v_[2]; }
+  Matrix cross(const Matrix& o) const {
+    return Matrix(v_[1] * o.v_[2] - v_[2] * o.v_[1], v_[2] * o.v_[0] - v_[0] * o.v_[2], v_[0] * o.v_[1] - v_[1] * o.v_[0]);
+  }
+  Matrix normalized() const {
+    const T n = norm();
+    return Matrix(v_[0] / n, v_[1] / n, v_[2] / n);
+  }
+  friend Matrix operator*(T s, const Matrix& a) { return Matrix(s * a.v_[0], s * a.v_[1], s * a.v_[2]); }
+  Matrix& operator-=(const Matrix& o) { return *this = *this - o; }
   // [A, ASSUMPTIONS.md C.2] Eigen's norm() returns the matrix's own scalar type: for an integer vector the square root of the
   // integer squared norm, computed in double and truncated back (numext::sqrt).  free_space_motion_detector.cpp:349 takes the
   // norm of a difference of int64 voxel indices.
@@ -488,14 +503,72 @@ struct BoundingBox {
     }
   }
 };
-struct DsgLayers {};
-struct DynamicSceneGraph {};
-struct KhronosObjectAttributes {};
 using LayerId = int64_t;
 using NodeId = uint64_t;
 struct NodeSymbol {};
-struct SceneGraphLayer {};
-struct SceneGraphNode {};
+
+// mesh as geometry_utils.cpp:61-86 and ray_verificator.cpp:216-223 use it
+struct Mesh {
+  using Pos = Eigen::Vector3f;
+  using Face = std::array<size_t, 3>;
+  std::vector<Pos> points;
+  std::vector<Color> colors;
+  std::vector<uint32_t> labels;
+  std::vector<uint64_t> first_seen_stamps, stamps;
+  std::vector<Face> faces;
+  size_t numVertices() const { return points.size(); }
+};
+
+// node attributes: the fields the change detection reads (ray_verificator.cpp:205-207,361-365; ray_verificator.h:170-174)
+struct NodeAttributes {
+  virtual ~NodeAttributes() = default;
+  Eigen::Vector3d position;
+};
+struct AgentNodeAttributes : NodeAttributes {
+  std::chrono::nanoseconds timestamp{0};
+};
+struct KhronosObjectAttributes : NodeAttributes {
+  using Ptr = std::unique_ptr<KhronosObjectAttributes>;
+  Mesh mesh;
+  BoundingBox bounding_box;
+};
+struct SceneGraphNode {
+  std::unique_ptr<NodeAttributes> attrs;
+  template <typename T>
+  T& attributes() const { return dynamic_cast<T&>(*attrs); }
+};
+struct SceneGraphLayer {
+  using Nodes = std::map<NodeId, std::unique_ptr<SceneGraphNode>>;
+  Nodes nodes_;
+  const Nodes& nodes() const { return nodes_; }
+};
+struct DsgLayers {
+  inline static const std::string AGENTS = "AGENTS";
+  inline static const std::string OBJECTS = "OBJECTS";
+};
+// the graph: named layers, the agents' layer additionally keyed by the robot prefix (ray_verificator.cpp:187-190), one mesh
+class DynamicSceneGraph {
+ public:
+  struct LayerKey {
+    LayerId layer;
+  };
+  std::map<std::string, LayerId> layer_ids{{DsgLayers::OBJECTS, 2}, {DsgLayers::AGENTS, 3}};
+  std::map<std::pair<LayerId, char>, SceneGraphLayer> layers;
+  std::shared_ptr<Mesh> mesh_;
+  std::optional<LayerKey> getLayerKey(const std::string& name) const {
+    const auto it = layer_ids.find(name);
+    return it == layer_ids.end() ? std::nullopt : std::optional<LayerKey>(LayerKey{it->second});
+  }
+  const SceneGraphLayer* findLayer(LayerId layer, char prefix = 0) const {
+    const auto it = layers.find({layer, prefix});
+    return it == layers.end() ? nullptr : &it->second;
+  }
+  const SceneGraphLayer& getLayer(LayerId layer, char prefix = 0) const { return layers.at({layer, prefix}); }
+  const SceneGraphLayer& getLayer(const std::string& name) const { return layers.at({layer_ids.at(name), 0}); }
+  bool hasLayer(const std::string& name) const { return layer_ids.count(name) && layers.count({layer_ids.at(name), 0}); }
+  bool hasMesh() const { return mesh_ != nullptr; }
+  std::shared_ptr<Mesh> mesh() const { return mesh_; }
+};
 }  // namespace spark_dsg
 
 // ------------------------------------------------------------------------------------------------------------------ Hydra
@@ -560,15 +633,7 @@ using TsdfLayer = spatial_hash::Layer<TsdfBlock>;
 using TrackingLayer = spatial_hash::Layer<TrackingBlock>;
 using SemanticLayer = spatial_hash::Layer<SemanticBlock>;
 
-// mesh types as geometry_utils.cpp:61-86 uses them
-struct Mesh {
-  using Face = std::array<size_t, 3>;
-  std::vector<Eigen::Vector3f> points;
-  std::vector<spark_dsg::Color> colors;
-  std::vector<uint32_t> labels;
-  std::vector<TimeStamp> first_seen_stamps, stamps;
-  std::vector<Face> faces;
-};
+using Mesh = spark_dsg::Mesh;
 using MeshBlock = Mesh;
 using MeshLayer = std::vector<MeshBlock>;  // (iterated block by block, geometry_utils.cpp:64)
 
@@ -641,6 +706,10 @@ class GlobalInfo {
 };
 
 // [A.8] pinhole projection to the nearest pixel; false when behind the camera or outside the image (max_iou_tracker.cpp:586)
+struct RobotPrefixConfig {
+  char key = 'a';
+};
+
 struct Sensor {
   int width = 0, height = 0;
   float fx = 1.f, fy = 1.f, cx = 0.f, cy = 0.f;

@@ -313,3 +313,68 @@ def test_host_frame_buffer_equals_reference_code(max_size, every_n):
     assert out.stdout == want
     sizes = [int(line.split()[0]) for line in want.strip().splitlines()]
     assert max(sizes) >= min(max_size, 3) and any(b < a for a, b in zip(sizes, sizes[1:]))
+
+
+def _ray_scene(rng, n):
+    """A sensor walking through a room: rays from its positions to surface points on walls and boxes, ascending distinct stamps."""
+    stamps = (np.arange(n, dtype=np.uint64) * np.uint64(37_000_000) + np.uint64(1_000_000_000))
+    t = np.linspace(0, 1, n)
+    sources = np.stack([1.0 + 3.0 * t, 1.0 + 2.0 * np.sin(3 * t), 1.2 + 0.1 * np.cos(5 * t)], axis=1).astype(np.float32)
+    direction = rng.standard_normal((n, 3)).astype(np.float32)
+    direction /= np.linalg.norm(direction, axis=1, keepdims=True)
+    length = rng.uniform(0.4, 4.5, (n, 1)).astype(np.float32)
+    return stamps, sources, (sources + direction * length).astype(np.float32)
+
+
+@needs_ref
+@pytest.mark.parametrize("block_size,radial,depth", [(1.0, 0.1, 0.1), (0.5, 0.05, 0.2), (2.0, 0.3, 0.05)])
+def test_ray_verificator_equals_reference_code(block_size, radial, depth):
+    """orc_rv_add_rays / orc_rv_check (what khr_rv_* is checked against) beside the reference's own RayVerificator
+    (ray_verificator.cpp:66-145 check, :327-349 ray march into the block hash), on random rays and query points on, near, in
+    front of and behind the measured surfaces: the same stamps in the present and the absent list (as sorted lists: the
+    reference walks an unordered_set of rays, ASSUMPTIONS.md C.5), with and without a time window."""
+    rng = np.random.default_rng(int(block_size * 10))
+    stamps, sources, targets = _ray_scene(rng, 400)
+    ora = po.OracleRayVerificator(block_size, radial, depth)
+    ora.add_rays(stamps, sources, targets)
+    ref = pyref.RefRayVerificator(LIB, stamps, sources, targets, block_size, radial, depth)
+    # query points: along the rays at fractions of their length (through, on, behind the surface), with sideways noise
+    k = rng.integers(0, len(stamps), 600)
+    frac = rng.choice(np.array([0.3, 0.6, 0.9, 0.98, 1.0, 1.02, 1.1, 1.4], np.float32), 600)
+    pts = sources[k] + (targets[k] - sources[k]) * frac[:, None] + rng.normal(0, 0.6 * radial, (600, 3)).astype(np.float32)
+    hits = dict(present=0, absent=0, none=0)
+    for i, p in enumerate(pts.astype(np.float32)):
+        window = (0, 2 ** 64 - 1) if i % 3 else (int(stamps[100]), int(stamps[300]))
+        po_, ao_ = ora.check_one(p, *window)
+        pr_, ar_ = ref.check_one(p, *window)
+        assert np.array_equal(np.sort(po_), pr_) and np.array_equal(np.sort(ao_), ar_), (i, p)
+        hits["present"] += len(pr_) > 0
+        hits["absent"] += len(ar_) > 0
+        hits["none"] += len(pr_) + len(ar_) == 0
+    assert min(hits.values()) > 10, hits
+
+
+@needs_ref
+def test_change_detector_vote_equals_reference_code():
+    """RayChangeDetector::detectChanges (ray_change_detector.cpp:66-133), the reference's own code, against the oracle's
+    restatement AND the product's host implementation on random presence / absence series, both search directions, relative
+    and absolute confidences."""
+    from khronos_amd.host_capi import detect_changes as host_detect_changes
+    rng = np.random.default_rng(11)
+    outcomes = set()
+    for trial in range(300):
+        n_p, n_a = int(rng.integers(0, 12)), int(rng.integers(0, 12))
+        present = (rng.uniform(0, 20, n_p) * 1e9).astype(np.uint64)
+        absent = (rng.uniform(5, 25, n_a) * 1e9).astype(np.uint64)
+        kw = dict(temporal_resolution=float(rng.choice([0.5, 1.0, 2.5])), window_size=int(rng.integers(1, 7)),
+                  use_relative_confidence=bool(trial % 2))
+        if kw["use_relative_confidence"]:
+            kw.update(absence_confidence=float(rng.uniform(0.2, 0.8)), presence_confidence=float(rng.uniform(0.2, 0.8)))
+        else:
+            kw.update(absence_confidence=float(rng.integers(1, 4)), presence_confidence=float(rng.integers(1, 4)))
+        for forward in (True, False):
+            want = pyref.detect_changes(LIB, present, absent, forward, **kw)
+            assert po.detect_changes(present, absent, forward, **kw) == want, (trial, forward, kw)
+            assert host_detect_changes(present, absent, forward, **kw) == want, (trial, forward, kw)
+            outcomes.add((want[0] is None, want[1] is None))
+    assert len(outcomes) == 4

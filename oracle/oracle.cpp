@@ -1,6 +1,7 @@
 /*
  * oracle.cpp — CPU restatement of the Khronos active-window volumetric fusion path.
- * TEST INFRASTRUCTURE ONLY (see oracle.h).  PARITY UNPINNED (see oracle.h).
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).  PARITY: the in-repo half is pinned against the reference's own code
+ * (oracle/_ref, tests/test_cpu_ref_pin.py), the upstream half (integrator, mesh) is UNPINNED (see oracle.h).
  *
  * Structure deliberately mirrors the reference CPU path: an unordered_map from block index to
  * heap-allocated array-of-struct voxel blocks, std::thread workers pulling block indices from an

@@ -4,14 +4,16 @@
  * link or call this.  Only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg use it, and only as the checker / CPU baseline.
  *
- * PARITY UNPINNED: the reference (/root/reference) ships no tests or golden
- * vectors, and the arithmetic of ProjectiveIntegrator / MeshIntegrator /
- * spatial_hash lives in un-vendored, un-pinned dependencies (MIT-SPARK/Hydra @
- * main, MIT-SPARK/Spatial-Hash @ main; install/https.rosinstall:5-8,33-36).
- * In-repo semantics (tracking integrator, motion detector, object integrator,
- * object extractor, orchestration) are restated from the cited reference
- * file:line; upstream semantics follow ASSUMPTIONS.md (each item is a named
- * switch in orc_config).
+ * PARITY: PINNED FOR THE IN-REPO HALF, UNPINNED FOR THE UPSTREAM HALF.  The reference (/root/reference) ships no
+ * tests or golden vectors.
+ *  - What it does hold on the path -- tracking_integrator.cpp, free_space_motion_detector.cpp,
+ *    connected_semantics.cpp, geometry_utils.cpp, ray_verificator.cpp, ray_change_detector.cpp -- is compiled from
+ *    where it lies against functional stand-ins (oracle/ref_recipe/build_ref.sh -> oracle/_ref/libref_khronos.so)
+ *    and RUN beside this oracle over whole sequences: tests/test_cpu_ref_pin.py.  Those functions are pinned.
+ *  - The arithmetic of ProjectiveIntegrator / MeshIntegrator / spatial_hash / the input conversion lives in
+ *    un-vendored, un-pinned dependencies (MIT-SPARK/Hydra @ main, MIT-SPARK/Spatial-Hash @ main;
+ *    install/https.rosinstall:5-8,33-36): orc_integrate, orc_generate_mesh, orc_parse_input follow ASSUMPTIONS.md
+ *    (each item a named switch in orc_config) and are "parity unpinned".
  *
  * Plain C ABI so that Python (ctypes) tests can drive it.
  */

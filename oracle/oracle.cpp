@@ -979,6 +979,13 @@ int64_t orc_block_indices(const orc_map* m, int32_t* out, int64_t cap) {
   return static_cast<int64_t>(v.size());
 }
 
+int orc_set_distance(orc_map* m, int32_t bx, int32_t by, int32_t bz, const float* distance) {
+  Block* b = m->find({bx, by, bz});
+  if (!b) return -1;
+  for (int i = 0; i < m->nvox; ++i) b->tsdf[i].distance = distance[i];
+  return 0;
+}
+
 int orc_get_block(const orc_map* m, int32_t bx, int32_t by, int32_t bz, float* distance, float* weight,
                   uint8_t* color, uint64_t* last_observed, uint64_t* last_occupied, uint8_t* flags,
                   uint32_t* sem_label, float* likelihoods, uint8_t* block_flags) {

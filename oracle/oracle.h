@@ -199,6 +199,10 @@ int orc_get_block(const orc_map* m, int32_t bx, int32_t by, int32_t bz, float* d
                   uint32_t* sem_label, float* likelihoods /* K*n, [k][voxel] */,
                   uint8_t* block_flags /* 1 byte: bit0 updated,1 mesh_updated,2 tracking_updated,3 has_active_data */);
 
+/* overwrite the TSDF distances of one block (oracle/ref_recipe/ref_harness.cpp: the reference's own pruning loop,
+ * mesh_object_extractor.cpp:246-264, runs on a copy of an object map and hands its result back for meshing). 0 if found */
+int orc_set_distance(orc_map* m, int32_t bx, int32_t by, int32_t bz, const float* distance);
+
 /* whole-map digests, the CPU side of khr_map_digest (include/khronos_amd.h): 12 words, see there */
 void orc_map_digest(const orc_map* m, uint64_t* out);
 

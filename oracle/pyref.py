@@ -66,6 +66,13 @@ def load():
     lib.ref_rv_destroy.argtypes = [C.c_void_p]
     lib.ref_rv_check.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.ref_detect_changes.argtypes = [C.c_float, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+    lib.ref_ex_create.restype = C.c_void_p
+    lib.ref_ex_create.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_int64]
+    lib.ref_ex_destroy.argtypes = [C.c_void_p]
+    lib.ref_ex_add_frame.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.ref_ex_extract.restype = C.c_int
+    lib.ref_ex_extract.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ref_combine_mesh.restype = C.c_int64
     lib.ref_combine_mesh.argtypes = [C.c_int] + [C.c_void_p] * 8
     return lib
@@ -222,3 +229,49 @@ def detect_changes(lib, present, absent, forward, temporal_resolution=1.0, windo
     lib.ref_detect_changes(float(temporal_resolution), int(window_size), int(use_relative_confidence), float(absence_confidence),
                            float(presence_confidence), _ptr(pr), pr.size, _ptr(ab), ab.size, int(forward), _ptr(out))
     return (int(out[1]) if out[0] else None), (int(out[3]) if out[2] else None)
+
+
+class RefExtractor:
+    """The reference's MeshObjectExtractor + FrameDataBuffer; the two integrators it drives are bridged to the CPU oracle."""
+
+    def __init__(self, lib, object_map_cfg, sensor, min_object_allocation_confidence=0.5, min_object_volume=0.1, max_object_volume=4.0,
+                 only_extract_reconstructed_objects=False, min_dynamic_displacement=0.2, min_object_reconstruction_confidence=0.5,
+                 min_object_reconstruction_observations=10, object_reconstruction_resolution=-0.02, min_reconstruction_resolution=0.0,
+                 max_buffer_size=300):
+        self.lib, self._keep = lib, (object_map_cfg, sensor)
+        self.h = lib.ref_ex_create(C.addressof(object_map_cfg), C.addressof(sensor), min_object_allocation_confidence, min_object_volume,
+                                   max_object_volume, int(only_extract_reconstructed_objects), min_dynamic_displacement,
+                                   min_object_reconstruction_confidence, int(min_object_reconstruction_observations),
+                                   object_reconstruction_resolution, min_reconstruction_resolution, int(max_buffer_size))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref_ex_destroy(self.h)
+            self.h = None
+
+    def add_frame(self, stamp, pose, depth, rgb, object_image, clusters):
+        """clusters: {id: (bbox_min, bbox_max)}"""
+        T = np.ascontiguousarray(pose, np.float64)
+        d = np.ascontiguousarray(depth, np.float32)
+        c = np.ascontiguousarray(rgb, np.uint8)
+        o = np.ascontiguousarray(object_image, np.int32)
+        ids = np.array(sorted(clusters), np.int32)
+        boxes = np.array([np.concatenate([clusters[k][0], clusters[k][1]]) for k in sorted(clusters)], np.float32).reshape(-1, 6)
+        self.lib.ref_ex_add_frame(self.h, int(stamp), _ptr(T), _ptr(d), _ptr(c), _ptr(o), len(ids), _ptr(ids), _ptr(boxes))
+
+    def extract(self, track_id, is_dynamic, confidence, first_seen, last_seen, category, observations, cap_points=1 << 22):
+        """observations: [(stamp, semantic_cluster_id, dynamic_cluster_id)].  -> None or dict(points, bbox_min, bbox_max, label, ...)"""
+        st = np.array([o[0] for o in observations], np.uint64)
+        si = np.array([o[1] for o in observations], np.int32)
+        di = np.array([o[2] for o in observations], np.int32)
+        pts = np.zeros((cap_points, 3), np.float32)
+        n = C.c_int64(0)
+        bbox = np.zeros(6, np.float32)
+        info = np.zeros(3, np.int64)
+        ok = self.lib.ref_ex_extract(self.h, int(track_id), int(is_dynamic), float(confidence), int(first_seen), int(last_seen), int(category), len(st),
+                                     _ptr(st), _ptr(si), _ptr(di), _ptr(pts), cap_points, C.addressof(n), _ptr(bbox), _ptr(info))
+        if not ok:
+            return None
+        assert n.value <= cap_points
+        return dict(points=pts[: n.value].copy(), bbox_min=bbox[:3].copy(), bbox_max=bbox[3:].copy(), label=int(info[0]), first_seen=int(info[1]),
+                    last_seen=int(info[2]))

@@ -16,11 +16,15 @@ SRC="$KHRONOS_ROOT/khronos/src"
 for f in active_window/integration/tracking_integrator.cpp active_window/motion_detection/free_space_motion_detector.cpp utils/geometry_utils.cpp \
          active_window/object_detection/connected_semantics.cpp active_window/tracking/max_iou_tracker.cpp active_window/data/track.cpp \
          active_window/tracking/external_tracker.cpp active_window/data/frame_data_buffer.cpp \
-         backend/change_detection/ray_verificator.cpp backend/change_detection/ray_change_detector.cpp; do
+         backend/change_detection/ray_verificator.cpp backend/change_detection/ray_change_detector.cpp \
+         active_window/object_extraction/mesh_object_extractor.cpp active_window/integration/object_integrator.cpp; do
   [ -f "$SRC/$f" ] || { echo "build_ref.sh: $SRC/$f not found (no reference checkout here): keeping what is in $OUT" >&2; exit 3; }
 done
 mkdir -p "$OUT"
-"${CXX:-g++}" -O2 -std=c++17 -ffp-contract=off -fPIC -shared -pthread \
+# (-fno-access-control: ref_harness.cpp's integrator bridge reads two private members of khronos::ObjectIntegrator;
+#  liboracle.so: the CPU oracle stands behind hydra::ProjectiveIntegrator / MeshIntegrator, which /root/reference does not contain)
+make -C "$REPO/oracle" -s
+"${CXX:-g++}" -O2 -std=c++17 -ffp-contract=off -fPIC -shared -pthread -fno-access-control \
   -I"$HERE/standin" -I"$KHRONOS_ROOT/khronos/include" \
   "$HERE/ref_harness.cpp" \
   "$SRC/active_window/integration/tracking_integrator.cpp" \
@@ -33,5 +37,8 @@ mkdir -p "$OUT"
   "$SRC/active_window/data/frame_data_buffer.cpp" \
   "$SRC/backend/change_detection/ray_verificator.cpp" \
   "$SRC/backend/change_detection/ray_change_detector.cpp" \
+  "$SRC/active_window/object_extraction/mesh_object_extractor.cpp" \
+  "$SRC/active_window/integration/object_integrator.cpp" \
+  -L"$REPO/oracle" -loracle -Wl,-rpath,'$ORIGIN/..' \
   -o "$OUT/libref_khronos.so"
 echo "built $OUT/libref_khronos.so"

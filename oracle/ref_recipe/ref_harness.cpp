@@ -18,12 +18,15 @@
 #include "khronos/active_window/integration/tracking_integrator.h"
 #include "khronos/active_window/motion_detection/free_space_motion_detector.h"
 #include "khronos/active_window/object_detection/connected_semantics.h"
+#include "khronos/active_window/object_extraction/mesh_object_extractor.h"
 #include "khronos/active_window/data/frame_data_buffer.h"
 #include "khronos/active_window/tracking/external_tracker.h"
 #include "khronos/active_window/tracking/max_iou_tracker.h"
 #include "khronos/backend/change_detection/ray_change_detector.h"
 #include "khronos/backend/change_detection/ray_verificator.h"
 #include "khronos/utils/geometry_utils.h"
+
+#include "../oracle.h"  // (the bridge behind the two integrators that are not in /root/reference)
 
 namespace {
 struct RefMap {
@@ -461,6 +464,185 @@ void ref_detect_changes(float temporal_resolution, int64_t window_size, int use_
   out[1] = res.closest_absent.value_or(0);
   out[2] = res.furthest_persistent.has_value();
   out[3] = res.furthest_persistent.value_or(0);
+}
+
+/* MeshObjectExtractor::extractObject (mesh_object_extractor.cpp:81-356): the reference's own extraction glue -- track validity,
+ * frame collection, extent merge, volume gates, object-map sizing and block allocation, the confidence pruning loop, bounding box,
+ * shift to the box frame -- around the two integrators it drives.  Those two are not in /root/reference: ref_standin::bridge()
+ * hands ProjectiveIntegrator::updateMap / MeshIntegrator::generateMesh to the CPU oracle (ASSUMPTIONS.md A.3 - A.5), keeping the
+ * stand-in map's voxels in step with it, so that the reference's loops read and write real data.  (This file is compiled with
+ * -fno-access-control: the bridge reads ObjectIntegrator's private frame pointer and target id.) */
+struct RefExtractor {
+  std::unique_ptr<khronos::MeshObjectExtractor> extractor;
+  std::unique_ptr<khronos::FrameDataBuffer> buffer;
+  orc_config map_cfg;
+  orc_sensor sensor;
+};
+
+namespace {
+thread_local RefExtractor* g_current_extractor = nullptr;
+
+orc_map* backendOf(hydra::VolumetricMap& map) {
+  if (!map.backend) {
+    orc_config c = g_current_extractor->map_cfg;
+    c.voxel_size = map.config.voxel_size;
+    c.voxels_per_side = static_cast<int32_t>(map.config.voxels_per_side);
+    c.truncation_distance = map.config.truncation_distance;
+    c.with_semantics = map.config.with_semantics ? 1 : 0;
+    c.with_tracking = map.config.with_tracking ? 1 : 0;
+    c.num_labels = 2;      // BinarySemanticIntegrator (object_integrator.cpp:44-48)
+    c.semantic_mode = 1;
+    c.rank = 0;
+    c.world_size = 1;
+    map.backend = std::shared_ptr<void>(orc_create(&c), [](void* p) { orc_destroy(static_cast<orc_map*>(p)); });
+    for (const auto& idx : map.getTsdfLayer().allocatedBlockIndices()) orc_allocate_block(static_cast<orc_map*>(map.backend.get()), idx[0], idx[1], idx[2]);
+  }
+  return static_cast<orc_map*>(map.backend.get());
+}
+
+void installBridge() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  ref_standin::bridge().integrate = [](const hydra::ProjectiveIntegrator& integrator, const hydra::InputData& data, hydra::VolumetricMap& map, bool allocate) {
+    const auto& object_integrator = dynamic_cast<const khronos::ObjectIntegrator&>(integrator);
+    const khronos::FrameData* frame = object_integrator.current_data_;
+    orc_map* m = backendOf(map);
+    orc_frame f{};
+    f.timestamp_ns = data.timestamp_ns;
+    std::memcpy(f.world_T_sensor, data.world_T_sensor16, sizeof(f.world_T_sensor));
+    f.depth = data.depth->data();
+    f.color = data.rgb ? data.rgb->data() : nullptr;
+    f.object_image = reinterpret_cast<const int32_t*>(frame->object_image.data());
+    f.object_id = object_integrator.current_object_id_;
+    orc_stats st{};
+    orc_integrate(m, &g_current_extractor->sensor, &f, allocate ? 1 : 0, &st);
+    // the stand-in map follows the oracle's: distance, weight, the two counters
+    const size_t nv = map.config.voxels_per_side * map.config.voxels_per_side * map.config.voxels_per_side;
+    std::vector<float> dist(nv), weight(nv), lik(2 * nv);
+    std::vector<uint8_t> flags(nv);
+    for (hydra::TsdfBlock& tb : map.getTsdfLayer()) {
+      orc_get_block(m, tb.index[0], tb.index[1], tb.index[2], dist.data(), weight.data(), nullptr, nullptr, nullptr, flags.data(), nullptr, lik.data(), nullptr);
+      auto sb = map.getSemanticLayer()->getBlockPtr(tb.index);
+      for (size_t i = 0; i < nv; ++i) {
+        tb.getVoxel(i).distance = dist[i];
+        tb.getVoxel(i).weight = weight[i];
+        hydra::SemanticVoxel& sv = sb->getVoxel(i);
+        sv.empty = (flags[i] & 8) == 0;
+        sv.semantic_likelihoods(0) = lik[i];
+        sv.semantic_likelihoods(1) = lik[nv + i];
+      }
+    }
+  };
+  ref_standin::bridge().mesh = [](const hydra::MeshIntegrator&, hydra::VolumetricMap& map, bool only_updated, bool clear) {
+    orc_map* m = backendOf(map);
+    const size_t nv = map.config.voxels_per_side * map.config.voxels_per_side * map.config.voxels_per_side;
+    std::vector<float> dist(nv);
+    for (hydra::TsdfBlock& tb : map.getTsdfLayer()) {  // what the reference's pruning loop did to the distances
+      for (size_t i = 0; i < nv; ++i) dist[i] = tb.getVoxel(i).distance;
+      orc_set_distance(m, tb.index[0], tb.index[1], tb.index[2], dist.data());
+    }
+    orc_generate_mesh(m, only_updated ? 1 : 0, clear ? 1 : 0);
+    const int64_t n = orc_mesh_num_vertices(m);
+    std::vector<float> pts(3 * std::max<int64_t>(n, 1));
+    std::vector<uint8_t> col(4 * std::max<int64_t>(n, 1));
+    std::vector<uint32_t> lab(std::max<int64_t>(n, 1));
+    std::vector<uint64_t> fs(std::max<int64_t>(n, 1)), stp(std::max<int64_t>(n, 1));
+    orc_mesh_copy(m, pts.data(), col.data(), lab.data(), fs.data(), stp.data(), n);
+    hydra::MeshBlock mb;
+    for (int64_t i = 0; i < n; ++i) {
+      mb.points.emplace_back(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+      mb.colors.push_back(spark_dsg::Color{col[4 * i], col[4 * i + 1], col[4 * i + 2], col[4 * i + 3]});
+      mb.labels.push_back(lab[i]);
+      mb.first_seen_stamps.push_back(fs[i]);
+      mb.stamps.push_back(stp[i]);
+      if (i % 3 == 2) mb.faces.push_back({static_cast<size_t>(i - 2), static_cast<size_t>(i - 1), static_cast<size_t>(i)});
+    }
+    map.getMeshLayer().clear();
+    map.getMeshLayer().push_back(std::move(mb));
+  };
+}
+}  // namespace
+
+RefExtractor* ref_ex_create(const orc_config* object_map_cfg, const orc_sensor* sensor, float min_object_allocation_confidence, float min_object_volume,
+                            float max_object_volume, int only_extract_reconstructed_objects, float min_dynamic_displacement,
+                            float min_object_reconstruction_confidence, int min_object_reconstruction_observations,
+                            float object_reconstruction_resolution, float min_reconstruction_resolution, int64_t max_buffer_size) {
+  installBridge();
+  auto* r = new RefExtractor();
+  khronos::MeshObjectExtractor::Config c;
+  c.min_object_allocation_confidence = min_object_allocation_confidence;
+  c.min_object_volume = min_object_volume;
+  c.max_object_volume = max_object_volume;
+  c.only_extract_reconstructed_objects = only_extract_reconstructed_objects != 0;
+  c.min_dynamic_displacement = min_dynamic_displacement;
+  c.min_object_reconstruction_confidence = min_object_reconstruction_confidence;
+  c.min_object_reconstruction_observations = min_object_reconstruction_observations;
+  c.object_reconstruction_resolution = object_reconstruction_resolution;
+  c.min_reconstruction_resolution = min_reconstruction_resolution;
+  r->extractor = std::make_unique<khronos::MeshObjectExtractor>(c);
+  khronos::FrameDataBuffer::Config bc;
+  bc.max_buffer_size = static_cast<size_t>(max_buffer_size);
+  r->buffer = std::make_unique<khronos::FrameDataBuffer>(bc);
+  r->map_cfg = *object_map_cfg;
+  r->sensor = *sensor;
+  return r;
+}
+
+void ref_ex_destroy(RefExtractor* r) { delete r; }
+
+/* one frame into the reference's FrameDataBuffer: raw images for the bridge, the object image, the semantic clusters' ids and boxes */
+void ref_ex_add_frame(RefExtractor* r, uint64_t stamp, const double* world_T_sensor, const float* depth, const uint8_t* rgb,
+                      const int32_t* object_image, int n_clusters, const int32_t* cluster_ids, const float* cluster_boxes) {
+  const int W = r->sensor.width, H = r->sensor.height;
+  hydra::InputData in;
+  in.timestamp_ns = stamp;
+  in.depth = std::make_shared<std::vector<float>>(depth, depth + static_cast<size_t>(W) * H);
+  if (rgb) in.rgb = std::make_shared<std::vector<uint8_t>>(rgb, rgb + 3 * static_cast<size_t>(W) * H);
+  std::memcpy(in.world_T_sensor16, world_T_sensor, sizeof(in.world_T_sensor16));
+  auto fd = std::make_shared<khronos::FrameData>(in);
+  fd->dynamic_image = cv::Mat(H, W, sizeof(int));
+  fd->object_image = cv::Mat(H, W, sizeof(int));
+  std::memcpy(fd->object_image.data(), object_image, sizeof(int32_t) * static_cast<size_t>(W) * H);
+  for (int k = 0; k < n_clusters; ++k) {
+    khronos::MeasurementCluster mc;
+    mc.id = cluster_ids[k];
+    mc.bounding_box.include(khronos::Point(cluster_boxes[6 * k], cluster_boxes[6 * k + 1], cluster_boxes[6 * k + 2]));
+    mc.bounding_box.include(khronos::Point(cluster_boxes[6 * k + 3], cluster_boxes[6 * k + 4], cluster_boxes[6 * k + 5]));
+    mc.bounding_box.finish();
+    fd->semantic_clusters.push_back(std::move(mc));
+  }
+  r->buffer->storeData(fd);
+}
+
+/* extractObject for one track.  returns 0 (no object) or 1; points (shifted to the box frame) up to cap, their number, the box
+ * (min, max), label, first / last observed */
+int ref_ex_extract(RefExtractor* r, int track_id, int is_dynamic, float confidence, uint64_t first_seen, uint64_t last_seen, int category, int n_obs,
+                   const uint64_t* obs_stamps, const int32_t* obs_semantic_ids, const int32_t* obs_dynamic_ids, float* points_out, int64_t cap_points,
+                   int64_t* n_points_out, float* bbox_out, int64_t* info_out) {
+  g_current_extractor = r;
+  khronos::Track t;
+  t.id = track_id;
+  t.is_dynamic = is_dynamic != 0;
+  t.confidence = confidence;
+  t.first_seen = first_seen;
+  t.last_seen = last_seen;
+  if (category >= 0) t.semantics = khronos::SemanticClusterInfo(category);
+  for (int i = 0; i < n_obs; ++i) t.observations.emplace_back(obs_stamps[i], obs_semantic_ids[i], obs_dynamic_ids[i]);
+  const auto obj = r->extractor->extractObject(t, *r->buffer);
+  g_current_extractor = nullptr;
+  if (!obj) return 0;
+  *n_points_out = static_cast<int64_t>(obj->mesh.points.size());
+  for (int64_t i = 0; i < *n_points_out && i < cap_points; ++i)
+    for (int a = 0; a < 3; ++a) points_out[3 * i + a] = obj->mesh.points[i][a];
+  for (int a = 0; a < 3; ++a) {
+    bbox_out[a] = obj->bounding_box.min[a];
+    bbox_out[3 + a] = obj->bounding_box.max[a];
+  }
+  info_out[0] = obj->semantic_label;
+  info_out[1] = obj->first_observed_ns.empty() ? 0 : static_cast<int64_t>(obj->first_observed_ns[0]);
+  info_out[2] = obj->last_observed_ns.empty() ? 0 : static_cast<int64_t>(obj->last_observed_ns[0]);
+  return 1;
 }
 
 /* utils::combineMeshLayer (geometry_utils.cpp:61-86): blocks given as vertex counts + faces per block (local indices);

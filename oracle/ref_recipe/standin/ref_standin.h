@@ -9,6 +9,7 @@
 //   khronos/src/active_window/tracking/max_iou_tracker.cpp, external_tracker.cpp, data/track.cpp   (a18)
 //   khronos/src/active_window/data/frame_data_buffer.cpp                 (a17)
 //   khronos/src/backend/change_detection/ray_verificator.cpp, ray_change_detector.cpp   (f4)
+//   khronos/src/active_window/object_extraction/mesh_object_extractor.cpp, integration/object_integrator.cpp   (a13, a12)
 // but not the containers they run on.  oracle/ref_recipe/build_ref.sh compiles those files FROM WHERE THEY LIE
 // (nothing is copied) against this header into oracle/_ref/libref_khronos.so, and tests/test_cpu_ref_pin.py runs the
 // reference's own code beside oracle/oracle.cpp on the same seeded sequences.  What that pins: every decision those files
@@ -96,6 +97,9 @@ class Matrix {
   }
   template <typename U>
   Matrix<U, 3, 1> cast() const { return Matrix<U, 3, 1>(static_cast<U>(v_[0]), static_cast<U>(v_[1]), static_cast<U>(v_[2])); }
+  T maxCoeff() const { return std::max(v_[0], std::max(v_[1], v_[2])); }
+  template <typename F>
+  int format(const F&) const { return 0; }  // (log output only)
   static Matrix Zero() { return Matrix(T(0), T(0), T(0)); }
   static Matrix Constant(T c) { return Matrix(c, c, c); }
 
@@ -140,6 +144,11 @@ class Matrix<T, Dynamic, Dynamic> {
   std::vector<T> d_;
 };
 
+constexpr int StreamPrecision = 0, DontAlignCols = 0;
+struct IOFormat {
+  template <typename... A>
+  IOFormat(A&&...) {}
+};
 using Vector3f = Matrix<float, 3, 1>;
 using Vector3d = Matrix<double, 3, 1>;
 using Vector3i = Matrix<int, 3, 1>;
@@ -188,6 +197,7 @@ class Mat {
   uint8_t* data() { return d_ ? d_->data() : nullptr; }
   const uint8_t* data() const { return d_ ? d_->data() : nullptr; }
   size_t elemSize() const { return eb_; }
+  bool empty() const { return rows == 0 || cols == 0; }
   // setTo(value, mask) on a 32-bit integer image (connected_semantics.cpp:206: object_image.setTo(0, object_image == id))
   void setTo(int value, const Mat& mask) {
     for (int r = 0; r < rows; ++r)
@@ -242,6 +252,8 @@ template <typename E>
 void enum_field(E&, const std::string&, std::initializer_list<const char*>) {}
 template <typename T>
 const T& checkValid(const T& c) { return c; }
+template <typename T>
+bool isValid(const T&) { return true; }
 template <typename Base, typename Derived, typename Cfg>
 struct RegistrationWithConfig {
   explicit RegistrationWithConfig(const std::string&) {}
@@ -401,6 +413,17 @@ class Layer {
   BlockIndex blockIndexOf(const Point& p) const {
     return BlockIndex(static_cast<int>(std::floor(p[0] * block_size_inv)), static_cast<int>(std::floor(p[1] * block_size_inv)), static_cast<int>(std::floor(p[2] * block_size_inv)));
   }
+  BlockIndex getBlockIndex(const Point& p) const { return blockIndexOf(p); }  // mesh_object_extractor.cpp:220-221
+  const BlockT& getBlock(const BlockIndex& i) const { return *blocks_.at(i); }
+  // block by block (mesh_object_extractor.cpp:246)
+  struct iterator {
+    typename IndexMap3<std::shared_ptr<BlockT>>::iterator it;
+    BlockT& operator*() const { return *it->second; }
+    iterator& operator++() { ++it; return *this; }
+    bool operator!=(const iterator& o) const { return it != o.it; }
+  };
+  iterator begin() { return iterator{blocks_.begin()}; }
+  iterator end() { return iterator{blocks_.end()}; }
   BlockPtr getBlockPtr(const Point& p) { return getBlockPtr(blockIndexOf(p)); }
   ConstBlockPtr getBlockPtr(const Point& p) const { return getBlockPtr(blockIndexOf(p)); }
   BlockT& allocateBlock(const BlockIndex& i) {
@@ -455,7 +478,11 @@ class VoxelNeighborSearch : public NeighborSearch {
 namespace spark_dsg {
 struct Color {
   uint8_t r = 0, g = 0, b = 0, a = 255;
+  static Color gray() { return Color{128, 128, 128, 255}; }
 };
+namespace colormaps {
+inline Color quality(float) { return Color(); }  // (visualisation only, mesh_object_extractor.cpp:259)
+}  // namespace colormaps
 // axis-aligned box of a point set (the type the reference builds from a cluster's pixels: free_space_motion_detector.cpp:396)
 struct BoundingBox {
   struct PointAdaptor {
@@ -473,6 +500,20 @@ struct BoundingBox {
   }
   explicit BoundingBox(const std::vector<Eigen::Vector3f>& points) {
     for (const auto& p : points) include(p);
+    finish();
+  }
+  // [A.7] box of given dimensions around a centre (mesh_object_extractor.cpp:170-171)
+  BoundingBox(const Eigen::Vector3f& dims, const Eigen::Vector3f& center) : world_P_center(center), dimensions(dims), valid(true) {
+    for (int a = 0; a < 3; ++a) {
+      min[a] = center[a] - dims[a] * 0.5f;
+      max[a] = center[a] + dims[a] * 0.5f;
+    }
+  }
+  // [A.7] union with another box; an invalid box takes the other one over (mesh_object_extractor.cpp:337)
+  void merge(const BoundingBox& o) {
+    if (!o.valid) return;
+    include(o.min);
+    include(o.max);
     finish();
   }
   float volume() const { return valid ? dimensions[0] * dimensions[1] * dimensions[2] : 0.f; }
@@ -531,6 +572,12 @@ struct KhronosObjectAttributes : NodeAttributes {
   using Ptr = std::unique_ptr<KhronosObjectAttributes>;
   Mesh mesh;
   BoundingBox bounding_box;
+  int semantic_label = -1;
+  Eigen::VectorXf semantic_feature;
+  std::vector<uint64_t> first_observed_ns, last_observed_ns;
+  std::vector<Eigen::Vector3f> trajectory_positions;
+  std::vector<uint64_t> trajectory_timestamps;
+  std::vector<std::vector<Eigen::Vector3f>> dynamic_object_points;
 };
 struct SceneGraphNode {
   std::unique_ptr<NodeAttributes> attrs;
@@ -613,7 +660,11 @@ struct TrackingVoxel {
   bool ever_free = false;
   bool to_remove = false;
 };
-struct SemanticVoxel {};
+// [A.4] binary confidence voxel: two counters and the "never updated" flag (mesh_object_extractor.cpp:342-356)
+struct SemanticVoxel {
+  bool empty = true;
+  Eigen::VectorXf semantic_likelihoods = Eigen::VectorXf::Zero(2, 1);
+};
 
 struct TsdfBlock : spatial_hash::Block<TsdfVoxel> {
   using Ptr = std::shared_ptr<TsdfBlock>;
@@ -644,24 +695,107 @@ class VolumetricMap {
     float voxel_size = 0.1f;
     float truncation_distance = 0.3f;
     size_t voxels_per_side = 16;
+    bool with_semantics = false;
+    bool with_tracking = true;
   } const config;
-  explicit VolumetricMap(const Config& c) : config(c), tsdf_(c.voxel_size, c.voxels_per_side), tracking_(std::make_shared<TrackingLayer>(c.voxel_size, c.voxels_per_side)) {}
+  explicit VolumetricMap(const Config& c)
+      : config(c), tsdf_(c.voxel_size, c.voxels_per_side), tracking_(std::make_shared<TrackingLayer>(c.voxel_size, c.voxels_per_side)),
+        semantic_(std::make_shared<SemanticLayer>(c.voxel_size, c.voxels_per_side)) {}
+  std::shared_ptr<SemanticLayer> getSemanticLayer() { return semantic_; }
+  MeshLayer& getMeshLayer() { return mesh_; }
+  const MeshLayer& getMeshLayer() const { return mesh_; }
+  std::shared_ptr<void> backend;  // (the harness's CPU-oracle map behind this one, where the integrators are bridged)
   TsdfLayer& getTsdfLayer() { return tsdf_; }
   const TsdfLayer& getTsdfLayer() const { return tsdf_; }
   std::shared_ptr<TrackingLayer> getTrackingLayer() { return tracking_; }
   std::shared_ptr<const TrackingLayer> getTrackingLayer() const { return tracking_; }
   void allocateBlock(const BlockIndex& i) {
     tsdf_.allocateBlock(i);
-    tracking_->allocateBlock(i);
+    if (config.with_tracking) tracking_->allocateBlock(i);
+    if (config.with_semantics) semantic_->allocateBlock(i);
   }
   void removeBlock(const BlockIndex& i) {
     tsdf_.removeBlock(i);
     tracking_->removeBlock(i);
+    semantic_->removeBlock(i);
   }
 
  private:
   TsdfLayer tsdf_;
   std::shared_ptr<TrackingLayer> tracking_;
+  std::shared_ptr<SemanticLayer> semantic_;
+  MeshLayer mesh_;
+};
+
+// ---- the two integrators whose arithmetic is NOT in /root/reference.  The reference's object extractor drives them
+// (mesh_object_extractor.cpp:238-243,267); here a call is handed to whatever the harness installed -- the CPU oracle, i.e. the
+// ASSUMPTIONS.md A.3 / A.5 semantics -- so that the reference's own glue around them can run.
+class ProjectiveIntegrator;
+class MeshIntegrator;
+struct InputData;
+}  // namespace hydra
+namespace ref_standin {
+struct Bridge {
+  std::function<void(const hydra::ProjectiveIntegrator&, const hydra::InputData&, hydra::VolumetricMap&, bool)> integrate;
+  std::function<void(const hydra::MeshIntegrator&, hydra::VolumetricMap&, bool, bool)> mesh;
+};
+inline Bridge& bridge() {
+  static Bridge b;
+  return b;
+}
+}  // namespace ref_standin
+namespace hydra {
+struct BinarySemanticIntegrator {
+  struct Config {};
+};
+struct InterpolationWeights {
+  float w[4] = {0, 0, 0, 0};
+  int u[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
+};
+struct VoxelMeasurement {
+  float sdf = 0.f;
+  InterpolationWeights interpolation_weights;
+  int label = -1;
+};
+// [A.3] interpolateID = the value at the max-weight pixel (first maximum) (object_integrator.cpp:70,77)
+struct Interpolator {
+  int interpolateID(const cv::Mat& image, const InterpolationWeights& w) const {
+    int best = 0;
+    for (int k = 1; k < 4; ++k)
+      if (w.w[k] > w.w[best]) best = k;
+    return image.at<int>(w.v[best], w.u[best]);
+  }
+};
+class ProjectiveIntegrator {
+ public:
+  struct Config {
+    struct SemanticIntegratorConfig {
+      bool binary = false;
+      SemanticIntegratorConfig& operator=(const BinarySemanticIntegrator::Config&) {
+        binary = true;
+        return *this;
+      }
+    } semantic_integrator;
+  };
+  using VoxelMeasurement = hydra::VoxelMeasurement;  // (named unqualified inside the subclass, object_integrator.h:69)
+  explicit ProjectiveIntegrator(const Config& c) : config(c), interpolator_(std::make_unique<Interpolator>()) {}
+  virtual ~ProjectiveIntegrator() = default;
+  void updateMap(const InputData& data, VolumetricMap& map, bool allocate_blocks = true, const cv::Mat& = cv::Mat()) const {
+    ref_standin::bridge().integrate(*this, data, map, allocate_blocks);
+  }
+  const Config config;
+
+ protected:
+  virtual bool computeLabel(const VolumetricMap::Config&, const InputData&, const cv::Mat&, VoxelMeasurement&) const { return true; }
+  std::unique_ptr<Interpolator> interpolator_;
+};
+struct MeshIntegratorConfig {};
+class MeshIntegrator {
+ public:
+  explicit MeshIntegrator(const MeshIntegratorConfig&) {}
+  void generateMesh(VolumetricMap& map, bool only_mesh_updated_blocks, bool clear_updated_flag) const {
+    ref_standin::bridge().mesh(*this, map, only_mesh_updated_blocks, clear_updated_flag);
+  }
 };
 
 // thread-safe dispenser of a block list (tracking_integrator.cpp:83-86,140)
@@ -686,7 +820,12 @@ class GlobalInfo {
   struct Config {
     int default_verbosity = 0;
     int default_num_threads = 2;
+    bool store_visualization_details = false;
   };
+  struct LabelNames {
+    std::string at(int) const { return "label"; }  // (log output only, mesh_object_extractor.cpp:372)
+  };
+  LabelNames getLabelToNameMap() const { return {}; }
   static GlobalInfo& instance() {
     static GlobalInfo g;
     return g;
@@ -747,6 +886,10 @@ struct InputData {
   const Eigen::Isometry3d& getSensorPose() const { return world_T_sensor; }
   Sensor sensor;
   const Sensor& getSensor() const { return sensor; }
+  // (bridge) the raw frame, for the integrator behind ref_standin::bridge()
+  std::shared_ptr<std::vector<float>> depth;
+  std::shared_ptr<std::vector<uint8_t>> rgb;
+  double world_T_sensor16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
 };
 
 namespace timing {

@@ -378,3 +378,67 @@ def test_change_detector_vote_equals_reference_code():
             assert host_detect_changes(present, absent, forward, **kw) == want, (trial, forward, kw)
             outcomes.add((want[0] is None, want[1] is None))
     assert len(outcomes) == 4
+
+
+@needs_ref
+def test_object_extraction_equals_reference_code():
+    """MeshObjectExtractor::extractObject (mesh_object_extractor.cpp:81-356), the reference's own code -- track validity, frame
+    collection, extent merge, volume gates, object-map sizing and block allocation, ObjectIntegrator driven frame by frame, the
+    confidence pruning loop, mesh, bounding box, shift to the box frame -- against tests/extract_replica.py, the restatement the
+    product's extracted objects are held to in tests/test_gpu_bench_path.py.  The two integrators the extractor drives are not in
+    /root/reference; both sides use the CPU oracle for them (the reference's side through the stand-in bridge), so what is
+    compared is the glue: same object or same refusal for every track, vertices bit for bit."""
+    import py_tracker
+    from extract_replica import extract_static
+    from khronos_amd import default_config
+    W, H = 240, 180
+    s = SyntheticStream(W, H, threads=1)
+    cfg = _cfg(voxel_size=0.1, truncation_distance=0.3)
+    ora = po.OracleMap(cfg)
+    osen = po.OrcSensor(W, H, s.fx, s.fy, s.cx, s.cy, 0.1, 5.0)
+    object_labels = list(range(7, 20))
+    trk = py_tracker.MaxIoUTracker("voxels", "assign_cluster", 0.25, 0.0, 0.1, 1.0, 3.0, 4, 0.2)
+
+    class E:
+        pass
+    e = E()
+    e.frames, e.sem, e.osen = [], {}, osen
+    ocfg = po.config_from(default_config(voxel_size=0.05, voxels_per_side=8, truncation_distance=0.1, with_semantics=1, with_tracking=0,
+                                         num_labels=2, semantic_mode=1), 1)
+    ref = pyref.RefExtractor(LIB, ocfg, osen, min_object_allocation_confidence=0.5, min_object_volume=0.005, max_object_volume=10.0,
+                             only_extract_reconstructed_objects=True, min_dynamic_displacement=1.0, min_object_reconstruction_confidence=0.5,
+                             min_object_reconstruction_observations=0, object_reconstruction_resolution=-0.02)
+    for i in range(0, 36, 3):
+        fr = s.render(i)
+        e.frames.append(fr)
+        ns, oimg, cl = ora.detect_objects(osen, fr["stamp"], fr["pose"], fr["depth"], fr["label"], object_labels, use_3d=True, grid_size=0.1,
+                                          max_range=5.0, min_cluster_size=30, use_full_connectivity=True)
+        sem = []
+        boxes = {c["id"]: (c["bbox_min"].astype(np.float32), c["bbox_max"].astype(np.float32)) for c in cl}
+        if ns:
+            ids, vox = ora.cluster_voxels(osen, fr["stamp"], fr["pose"], fr["depth"], oimg, 0.2)
+            for c in cl:
+                sem.append(dict(id=c["id"], category=c["semantic_id"], voxels={tuple(int(x) for x in r) for r in vox[ids == c["id"]]}, box=boxes[c["id"]]))
+            e.sem[fr["stamp"]] = (None, oimg.astype(np.int16), boxes)
+        trk.process(fr["stamp"], sem, [])
+        ref.add_frame(fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], oimg, boxes)
+    got_objects = refused = 0
+    tracks = list(trk.tracks)
+    assert len(tracks) >= 4
+    # every track as it stands, plus: one with too few observations (confidence gate), one renamed dynamic
+    for t in tracks:
+        want = extract_static(e, t, 2)
+        got = ref.extract(t.id, t.is_dynamic, float(t.confidence), t.first_seen, t.last_seen, t.category if t.has_semantics else -1,
+                          [tuple(o) for o in t.observations])
+        assert (want is None) == (got is None), (t.id, len(t.observations), float(t.confidence))
+        if want is None:
+            refused += 1
+            continue
+        got_objects += 1
+        assert np.array_equal(want["points"], got["points"]), t.id
+        assert np.array_equal(want["bbox_min"], got["bbox_min"]) and np.array_equal(want["bbox_max"], got["bbox_max"])
+        assert (want["label"], want["first_seen"], want["last_seen"]) == (got["label"], got["first_seen"], got["last_seen"])
+    assert got_objects >= 2, (got_objects, refused)
+    low = tracks[0]
+    assert ref.extract(low.id, False, 0.5, low.first_seen, low.last_seen, -1, [tuple(o) for o in low.observations]) is None  # confidence <= 0.5
+    assert ref.extract(low.id, False, 0.9, low.first_seen, low.last_seen, -1, [(o[0], -1, -1) for o in low.observations]) is None  # no semantic frames

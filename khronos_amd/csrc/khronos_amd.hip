@@ -916,7 +916,10 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     A(devAlloc(c, &c->d_md_seed_final, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_bnd_final, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_adj, static_cast<size_t>(c->md_list_cap) * 26, false));
-    A(devAlloc(c, &c->d_md_acc, 256));
+    // (not zeroed: devAlloc's memset is queued on the context's NON-BLOCKING stream, and the synchronous copy of the reduction
+    //  identities below runs on the null stream -- nothing orders the two, and a memset that lands second leaves zeros, i.e.
+    //  boxes clamped at 0 for the first seed frame's clusters.  Found by tests/test_gpu_ref_pin.py.)
+    A(devAlloc(c, &c->d_md_acc, 256, false));
     if (hipHostMalloc(reinterpret_cast<void**>(&c->h_md_acc_pinned), sizeof(ClusterAcc) * 256, hipHostMallocDefault) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_md_acc_host), c->h_md_acc_pinned, 0) != hipSuccess)
       A(KHR_ENOMEM);

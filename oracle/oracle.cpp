@@ -979,6 +979,17 @@ int64_t orc_block_indices(const orc_map* m, int32_t* out, int64_t cap) {
   return static_cast<int64_t>(v.size());
 }
 
+int orc_set_block_flags(orc_map* m, int32_t bx, int32_t by, int32_t bz, uint8_t flags) {
+  Block* b = m->find({bx, by, bz});
+  if (!b) return -1;
+  b->updated = (flags & 1) != 0;
+  b->mesh_updated = (flags & 2) != 0;
+  b->tracking_updated = (flags & 4) != 0;
+  return 0;
+}
+
+int orc_remove_block(orc_map* m, int32_t bx, int32_t by, int32_t bz) { return m->blocks.erase({bx, by, bz}) ? 0 : -1; }
+
 int orc_set_distance(orc_map* m, int32_t bx, int32_t by, int32_t bz, const float* distance) {
   Block* b = m->find({bx, by, bz});
   if (!b) return -1;

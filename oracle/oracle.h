@@ -6,8 +6,8 @@
  *
  * PARITY: PINNED FOR THE IN-REPO HALF, UNPINNED FOR THE UPSTREAM HALF.  The reference (/root/reference) ships no
  * tests or golden vectors.
- *  - What it does hold on the path -- tracking_integrator.cpp, free_space_motion_detector.cpp,
- *    connected_semantics.cpp, geometry_utils.cpp, ray_verificator.cpp, ray_change_detector.cpp -- is compiled from
+ *  - What it does hold on the path -- active_window.cpp itself, tracking_integrator.cpp, free_space_motion_detector.cpp,
+ *    connected_semantics.cpp, mesh_object_extractor.cpp, geometry_utils.cpp, ray_verificator.cpp, ray_change_detector.cpp -- is compiled from
  *    where it lies against functional stand-ins (oracle/ref_recipe/build_ref.sh -> oracle/_ref/libref_khronos.so)
  *    and RUN beside this oracle over whole sequences: tests/test_cpu_ref_pin.py.  Those functions are pinned.
  *  - The arithmetic of ProjectiveIntegrator / MeshIntegrator / spatial_hash / the input conversion lives in
@@ -202,6 +202,11 @@ int orc_get_block(const orc_map* m, int32_t bx, int32_t by, int32_t bz, float* d
 /* overwrite the TSDF distances of one block (oracle/ref_recipe/ref_harness.cpp: the reference's own pruning loop,
  * mesh_object_extractor.cpp:246-264, runs on a copy of an object map and hands its result back for meshing). 0 if found */
 int orc_set_distance(orc_map* m, int32_t bx, int32_t by, int32_t bz, const float* distance);
+/* the three block flags the reference's active window sets and clears from outside the integrators (bit0 updated, bit1
+ * mesh_updated, bit2 tracking_updated; active_window.cpp:169-171, tracking_integrator.cpp:146) and block removal
+ * (tracking_integrator.cpp:128) -- for the same harness, where the reference's own ActiveWindow drives this map */
+int orc_set_block_flags(orc_map* m, int32_t bx, int32_t by, int32_t bz, uint8_t flags);
+int orc_remove_block(orc_map* m, int32_t bx, int32_t by, int32_t bz);
 
 /* whole-map digests, the CPU side of khr_map_digest (include/khronos_amd.h): 12 words, see there */
 void orc_map_digest(const orc_map* m, uint64_t* out);

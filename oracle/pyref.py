@@ -73,6 +73,22 @@ def load():
     lib.ref_ex_extract.restype = C.c_int
     lib.ref_ex_extract.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ref_aw_create.restype = C.c_void_p
+    lib.ref_aw_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.ref_aw_destroy.argtypes = [C.c_void_p]
+    lib.ref_aw_spin.restype = C.c_int
+    lib.ref_aw_spin.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ref_aw_frame_images.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ref_aw_tracks.restype = C.c_int64
+    lib.ref_aw_tracks.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.ref_aw_block_indices.restype = C.c_int64
+    lib.ref_aw_block_indices.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.ref_aw_get_block.restype = C.c_int
+    lib.ref_aw_get_block.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    lib.ref_aw_output.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+    lib.ref_aw_collect.restype = C.c_int64
+    lib.ref_aw_collect.argtypes = [C.c_void_p]
+    lib.ref_aw_object.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     lib.ref_combine_mesh.restype = C.c_int64
     lib.ref_combine_mesh.argtypes = [C.c_int] + [C.c_void_p] * 8
     return lib
@@ -275,3 +291,105 @@ class RefExtractor:
         assert n.value <= cap_points
         return dict(points=pts[: n.value].copy(), bbox_min=bbox[:3].copy(), bbox_max=bbox[3:].copy(), label=int(info[0]), first_seen=int(info[1]),
                     last_seen=int(info[2]))
+
+
+class RefAwConfig(C.Structure):
+    _fields_ = [("voxel_size", C.c_float), ("voxels_per_side", C.c_int32), ("truncation_distance", C.c_float),
+                ("min_output_separation", C.c_float), ("detach_object_extraction", C.c_int32),
+                ("temporal_buffer", C.c_float), ("tsdf_occupancy_threshold", C.c_float), ("neighbor_connectivity", C.c_int32),
+                ("temporal_window", C.c_float),
+                ("md_neighbor_connectivity", C.c_int32), ("md_min_cluster_size", C.c_int32), ("md_max_cluster_size", C.c_int32),
+                ("md_min_separation_distance", C.c_float), ("md_max_range", C.c_float), ("md_min_z_coordinate", C.c_float),
+                ("od_use_full_connectivity", C.c_int32), ("od_min_cluster_size", C.c_int32), ("od_max_cluster_size", C.c_int32),
+                ("od_use_3d", C.c_int32), ("od_grid_size", C.c_float), ("od_max_range", C.c_float),
+                ("tr_assign_track", C.c_int32), ("tr_min_semantic_iou", C.c_float), ("tr_min_cross_iou", C.c_float),
+                ("tr_max_dynamic_distance", C.c_float), ("tr_temporal_window", C.c_float), ("tr_min_num_observations", C.c_int32),
+                ("tr_voxel_size", C.c_float),
+                ("ex_min_allocation_confidence", C.c_float), ("ex_min_volume", C.c_float), ("ex_max_volume", C.c_float),
+                ("ex_only_reconstructed", C.c_int32), ("ex_min_dynamic_displacement", C.c_float),
+                ("ex_min_reconstruction_confidence", C.c_float), ("ex_min_reconstruction_observations", C.c_int32),
+                ("ex_resolution", C.c_float), ("ex_min_resolution", C.c_float),
+                ("buffer_size", C.c_int32), ("num_threads", C.c_int32), ("num_workers", C.c_int32)]
+
+
+class RefActiveWindow:
+    """The reference's own khronos::ActiveWindow with its own sub-modules; input conversion, projective integrator and mesh
+    integrator (not in /root/reference) bridged to the CPU oracle."""
+
+    def __init__(self, lib, main_cfg, object_cfg, sensor, object_labels, **kw):
+        self.lib, self._keep = lib, (main_cfg, object_cfg, sensor)
+        c = RefAwConfig()
+        for name in ("voxel_size", "voxels_per_side", "truncation_distance", "temporal_buffer", "tsdf_occupancy_threshold", "neighbor_connectivity",
+                     "temporal_window", "md_neighbor_connectivity", "md_min_cluster_size", "md_max_cluster_size", "md_min_separation_distance",
+                     "md_max_range", "md_min_z_coordinate"):
+            setattr(c, name, getattr(main_cfg, name))
+        c.num_threads = 2
+        for k, v in kw.items():
+            setattr(c, k, v)
+        self.cfg = c
+        self.W, self.H = sensor.width, sensor.height
+        self.nvox = int(c.voxels_per_side) ** 3
+        ol = np.ascontiguousarray(object_labels, np.int32)
+        self.h = lib.ref_aw_create(C.addressof(c), C.addressof(main_cfg), C.addressof(object_cfg), C.addressof(sensor), _ptr(ol), ol.size)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ref_aw_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def spin(self, stamp, pose, depth, rgb, label):
+        T = np.ascontiguousarray(pose, np.float64)
+        d = np.ascontiguousarray(depth, np.float32)
+        c = np.ascontiguousarray(rgb, np.uint8)
+        lab = np.ascontiguousarray(label, np.int32)
+        return bool(self.lib.ref_aw_spin(self.h, int(stamp), _ptr(T), _ptr(d), _ptr(c), _ptr(lab)))
+
+    def frame_images(self):
+        dyn, obj = np.zeros((self.H, self.W), np.int32), np.zeros((self.H, self.W), np.int32)
+        self.lib.ref_aw_frame_images(self.h, _ptr(dyn), _ptr(obj))
+        return dyn, obj
+
+    def tracks(self):
+        import json
+        cap = 1 << 20
+        buf = C.create_string_buffer(cap)
+        n = self.lib.ref_aw_tracks(self.h, buf, cap)
+        assert 0 <= n < cap
+        return json.loads(buf.value.decode())
+
+    def block_indices(self):
+        n = self.lib.ref_aw_block_indices(self.h, None, 0)
+        out = np.zeros((max(n, 1), 3), np.int32)
+        self.lib.ref_aw_block_indices(self.h, _ptr(out), n)
+        return out[:n]
+
+    def get_block(self, idx):
+        i = np.asarray(idx, np.int32)
+        b = {"distance": np.empty(self.nvox, np.float32), "last_observed": np.empty(self.nvox, np.uint64),
+             "last_occupied": np.empty(self.nvox, np.uint64), "flags": np.empty(self.nvox, np.uint8)}
+        bf = np.zeros(1, np.uint8)
+        if self.lib.ref_aw_get_block(self.h, _ptr(i), _ptr(b["distance"]), _ptr(b["last_observed"]), _ptr(b["last_occupied"]), _ptr(b["flags"]), _ptr(bf)) != 0:
+            raise KeyError(tuple(idx))
+        b["block_flags"] = int(bf[0])
+        return b
+
+    def output(self, cap=1 << 16):
+        info = np.zeros(4, np.int64)
+        arch, cl = np.zeros((cap, 3), np.int32), np.zeros((cap, 3), np.int32)
+        self.lib.ref_aw_output(self.h, _ptr(info), _ptr(arch), cap, _ptr(cl), cap)
+        assert info[1] <= cap and info[2] <= cap
+        return dict(stamp=int(info[0]), archived=arch[: info[1]].copy(), cloned=cl[: info[2]].copy(), mesh_vertices=int(info[3]))
+
+    def collect_objects(self, cap_points=1 << 22):
+        n = self.lib.ref_aw_collect(self.h)
+        out = []
+        for i in range(n):
+            info, bbox = np.zeros(4, np.int64), np.zeros(6, np.float32)
+            pts = np.zeros((cap_points, 3), np.float32)
+            self.lib.ref_aw_object(self.h, i, _ptr(info), _ptr(bbox), _ptr(pts), cap_points)
+            assert info[3] <= cap_points
+            out.append(dict(label=int(info[0]), first_seen=int(info[1]), last_seen=int(info[2]), points=pts[: info[3]].copy(),
+                            bbox_min=bbox[:3].copy(), bbox_max=bbox[3:].copy()))
+        return out

@@ -17,7 +17,8 @@ for f in active_window/integration/tracking_integrator.cpp active_window/motion_
          active_window/object_detection/connected_semantics.cpp active_window/tracking/max_iou_tracker.cpp active_window/data/track.cpp \
          active_window/tracking/external_tracker.cpp active_window/data/frame_data_buffer.cpp \
          backend/change_detection/ray_verificator.cpp backend/change_detection/ray_change_detector.cpp \
-         active_window/object_extraction/mesh_object_extractor.cpp active_window/integration/object_integrator.cpp; do
+         active_window/object_extraction/mesh_object_extractor.cpp active_window/integration/object_integrator.cpp \
+         active_window/active_window.cpp active_window/object_extraction/object_worker_pool.cpp; do
   [ -f "$SRC/$f" ] || { echo "build_ref.sh: $SRC/$f not found (no reference checkout here): keeping what is in $OUT" >&2; exit 3; }
 done
 mkdir -p "$OUT"
@@ -39,6 +40,8 @@ make -C "$REPO/oracle" -s
   "$SRC/backend/change_detection/ray_change_detector.cpp" \
   "$SRC/active_window/object_extraction/mesh_object_extractor.cpp" \
   "$SRC/active_window/integration/object_integrator.cpp" \
+  "$SRC/active_window/active_window.cpp" \
+  "$SRC/active_window/object_extraction/object_worker_pool.cpp" \
   -L"$REPO/oracle" -loracle -Wl,-rpath,'$ORIGIN/..' \
   -o "$OUT/libref_khronos.so"
 echo "built $OUT/libref_khronos.so"

@@ -9,12 +9,15 @@
 // tracking_updated flag after a frame's update (ref_put_block).
 #include <algorithm>
 #include <cstring>
+#include <chrono>
 #include <cstdio>
 #include <memory>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
+#include "khronos/active_window/active_window.h"
 #include "khronos/active_window/integration/tracking_integrator.h"
 #include "khronos/active_window/motion_detection/free_space_motion_detector.h"
 #include "khronos/active_window/object_detection/connected_semantics.h"
@@ -472,77 +475,134 @@ void ref_detect_changes(float temporal_resolution, int64_t window_size, int use_
  * hands ProjectiveIntegrator::updateMap / MeshIntegrator::generateMesh to the CPU oracle (ASSUMPTIONS.md A.3 - A.5), keeping the
  * stand-in map's voxels in step with it, so that the reference's loops read and write real data.  (This file is compiled with
  * -fno-access-control: the bridge reads ObjectIntegrator's private frame pointer and target id.) */
-struct RefExtractor {
-  std::unique_ptr<khronos::MeshObjectExtractor> extractor;
-  std::unique_ptr<khronos::FrameDataBuffer> buffer;
-  orc_config map_cfg;
+// what the bridge needs to stand behind a stand-in map: the oracle configurations of the window's map and of the object maps,
+// and the sensor.  One environment is current at a time (the extraction workers are detached threads, so it is process-wide).
+struct BridgeEnv {
+  orc_config main_cfg;
+  orc_config object_cfg;
   orc_sensor sensor;
 };
 
+struct RefExtractor {
+  std::unique_ptr<khronos::MeshObjectExtractor> extractor;
+  std::unique_ptr<khronos::FrameDataBuffer> buffer;
+  BridgeEnv env;
+};
+
 namespace {
-thread_local RefExtractor* g_current_extractor = nullptr;
+BridgeEnv* g_env = nullptr;
 
 orc_map* backendOf(hydra::VolumetricMap& map) {
   if (!map.backend) {
-    orc_config c = g_current_extractor->map_cfg;
+    const bool window_map = map.config.with_tracking;  // (object maps: tracking off, mesh_object_extractor.cpp:211)
+    orc_config c = window_map ? g_env->main_cfg : g_env->object_cfg;
     c.voxel_size = map.config.voxel_size;
     c.voxels_per_side = static_cast<int32_t>(map.config.voxels_per_side);
     c.truncation_distance = map.config.truncation_distance;
     c.with_semantics = map.config.with_semantics ? 1 : 0;
     c.with_tracking = map.config.with_tracking ? 1 : 0;
-    c.num_labels = 2;      // BinarySemanticIntegrator (object_integrator.cpp:44-48)
-    c.semantic_mode = 1;
+    if (!window_map) {
+      c.num_labels = 2;  // BinarySemanticIntegrator (object_integrator.cpp:44-48)
+      c.semantic_mode = 1;
+    }
     c.rank = 0;
     c.world_size = 1;
-    map.backend = std::shared_ptr<void>(orc_create(&c), [](void* p) { orc_destroy(static_cast<orc_map*>(p)); });
-    for (const auto& idx : map.getTsdfLayer().allocatedBlockIndices()) orc_allocate_block(static_cast<orc_map*>(map.backend.get()), idx[0], idx[1], idx[2]);
+    orc_map* m = orc_create(&c);
+    map.backend = std::shared_ptr<void>(m, [](void* p) { orc_destroy(static_cast<orc_map*>(p)); });
+    for (const auto& idx : map.getTsdfLayer().allocatedBlockIndices()) orc_allocate_block(m, idx[0], idx[1], idx[2]);
+    map.on_remove = [m](const hydra::BlockIndex& i) { orc_remove_block(m, i[0], i[1], i[2]); };
   }
   return static_cast<orc_map*>(map.backend.get());
 }
 
-void installBridge() {
-  static bool done = false;
-  if (done) return;
-  done = true;
-  ref_standin::bridge().integrate = [](const hydra::ProjectiveIntegrator& integrator, const hydra::InputData& data, hydra::VolumetricMap& map, bool allocate) {
-    const auto& object_integrator = dynamic_cast<const khronos::ObjectIntegrator&>(integrator);
-    const khronos::FrameData* frame = object_integrator.current_data_;
-    orc_map* m = backendOf(map);
-    orc_frame f{};
-    f.timestamp_ns = data.timestamp_ns;
-    std::memcpy(f.world_T_sensor, data.world_T_sensor16, sizeof(f.world_T_sensor));
-    f.depth = data.depth->data();
-    f.color = data.rgb ? data.rgb->data() : nullptr;
-    f.object_image = reinterpret_cast<const int32_t*>(frame->object_image.data());
-    f.object_id = object_integrator.current_object_id_;
-    orc_stats st{};
-    orc_integrate(m, &g_current_extractor->sensor, &f, allocate ? 1 : 0, &st);
-    // the stand-in map follows the oracle's: distance, weight, the two counters
-    const size_t nv = map.config.voxels_per_side * map.config.voxels_per_side * map.config.voxels_per_side;
-    std::vector<float> dist(nv), weight(nv), lik(2 * nv);
-    std::vector<uint8_t> flags(nv);
-    for (hydra::TsdfBlock& tb : map.getTsdfLayer()) {
-      orc_get_block(m, tb.index[0], tb.index[1], tb.index[2], dist.data(), weight.data(), nullptr, nullptr, nullptr, flags.data(), nullptr, lik.data(), nullptr);
-      auto sb = map.getSemanticLayer()->getBlockPtr(tb.index);
+// the three block flags the reference's own code sets / clears outside the integrators go to the backend before a bridged call ...
+void pushFlags(hydra::VolumetricMap& map, orc_map* m) {
+  for (const hydra::TsdfBlock& tb : map.getTsdfLayer())
+    orc_set_block_flags(m, tb.index[0], tb.index[1], tb.index[2], static_cast<uint8_t>((tb.updated ? 1 : 0) | (tb.mesh_updated ? 2 : 0) | (tb.tracking_updated ? 4 : 0)));
+}
+
+// ... and after it the stand-in map follows the backend: blocks, distance, weight, last_observed (window map) or the two counters
+// (object maps), the flags
+void pull(hydra::VolumetricMap& map, orc_map* m, bool voxels) {
+  const int64_t nb = orc_num_blocks(m);
+  std::vector<int32_t> idx(3 * std::max<int64_t>(nb, 1));
+  orc_block_indices(m, idx.data(), nb);
+  const size_t nv = map.config.voxels_per_side * map.config.voxels_per_side * map.config.voxels_per_side;
+  const bool window_map = map.config.with_tracking;
+  std::vector<float> dist(nv), weight(nv), lik(window_map ? 1 : 2 * nv);
+  std::vector<uint64_t> last_obs(nv);
+  std::vector<uint8_t> flags(nv);
+  for (int64_t b = 0; b < nb; ++b) {
+    const hydra::BlockIndex bi(idx[3 * b], idx[3 * b + 1], idx[3 * b + 2]);
+    if (!map.getTsdfLayer().hasBlock(bi)) map.allocateBlock(bi);
+    auto tb = map.getTsdfLayer().getBlockPtr(bi);
+    uint8_t bf = 0;
+    if (!voxels) {
+      orc_get_block(m, bi[0], bi[1], bi[2], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &bf);
+    } else if (window_map) {
+      orc_get_block(m, bi[0], bi[1], bi[2], dist.data(), weight.data(), nullptr, last_obs.data(), nullptr, nullptr, nullptr, nullptr, &bf);
+      auto kb = map.getTrackingLayer()->getBlockPtr(bi);
       for (size_t i = 0; i < nv; ++i) {
-        tb.getVoxel(i).distance = dist[i];
-        tb.getVoxel(i).weight = weight[i];
+        tb->getVoxel(i).distance = dist[i];
+        tb->getVoxel(i).weight = weight[i];
+        kb->getVoxel(i).last_observed = last_obs[i];
+      }
+    } else {
+      orc_get_block(m, bi[0], bi[1], bi[2], dist.data(), weight.data(), nullptr, nullptr, nullptr, flags.data(), nullptr, lik.data(), &bf);
+      auto sb = map.getSemanticLayer()->getBlockPtr(bi);
+      for (size_t i = 0; i < nv; ++i) {
+        tb->getVoxel(i).distance = dist[i];
+        tb->getVoxel(i).weight = weight[i];
         hydra::SemanticVoxel& sv = sb->getVoxel(i);
         sv.empty = (flags[i] & 8) == 0;
         sv.semantic_likelihoods(0) = lik[i];
         sv.semantic_likelihoods(1) = lik[nv + i];
       }
     }
+    tb->updated = (bf & 1) != 0;
+    tb->mesh_updated = (bf & 2) != 0;
+    tb->tracking_updated = (bf & 4) != 0;
+  }
+}
+
+void installBridge() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  ref_standin::bridge().integrate = [](const hydra::ProjectiveIntegrator& integrator, const hydra::InputData& data, hydra::VolumetricMap& map, bool allocate,
+                                       const cv::Mat& mask) {
+    orc_map* m = backendOf(map);
+    pushFlags(map, m);
+    orc_frame f{};
+    f.timestamp_ns = data.timestamp_ns;
+    std::memcpy(f.world_T_sensor, data.world_T_sensor16, sizeof(f.world_T_sensor));
+    f.depth = data.depth->data();
+    f.color = data.rgb ? data.rgb->data() : nullptr;
+    f.object_id = -1;
+    if (const auto* object_integrator = dynamic_cast<const khronos::ObjectIntegrator*>(&integrator)) {
+      f.object_image = reinterpret_cast<const int32_t*>(object_integrator->current_data_->object_image.data());
+      f.object_id = object_integrator->current_object_id_;
+    } else {  // the window's integrator: labels fused, dynamic pixels masked (active_window.cpp:207-210)
+      f.label = data.label_image.empty() ? nullptr : reinterpret_cast<const int32_t*>(data.label_image.data());
+      f.mask = mask.empty() ? nullptr : reinterpret_cast<const int32_t*>(mask.data());
+    }
+    orc_stats st{};
+    orc_integrate(m, &g_env->sensor, &f, allocate ? 1 : 0, &st);
+    pull(map, m, true);
   };
   ref_standin::bridge().mesh = [](const hydra::MeshIntegrator&, hydra::VolumetricMap& map, bool only_updated, bool clear) {
     orc_map* m = backendOf(map);
-    const size_t nv = map.config.voxels_per_side * map.config.voxels_per_side * map.config.voxels_per_side;
-    std::vector<float> dist(nv);
-    for (hydra::TsdfBlock& tb : map.getTsdfLayer()) {  // what the reference's pruning loop did to the distances
-      for (size_t i = 0; i < nv; ++i) dist[i] = tb.getVoxel(i).distance;
-      orc_set_distance(m, tb.index[0], tb.index[1], tb.index[2], dist.data());
+    pushFlags(map, m);
+    if (!map.config.with_tracking) {  // object maps: what the reference's pruning loop did to the distances
+      const size_t nv = map.config.voxels_per_side * map.config.voxels_per_side * map.config.voxels_per_side;
+      std::vector<float> dist(nv);
+      for (hydra::TsdfBlock& tb : map.getTsdfLayer()) {
+        for (size_t i = 0; i < nv; ++i) dist[i] = tb.getVoxel(i).distance;
+        orc_set_distance(m, tb.index[0], tb.index[1], tb.index[2], dist.data());
+      }
     }
     orc_generate_mesh(m, only_updated ? 1 : 0, clear ? 1 : 0);
+    pull(map, m, false);
     const int64_t n = orc_mesh_num_vertices(m);
     std::vector<float> pts(3 * std::max<int64_t>(n, 1));
     std::vector<uint8_t> col(4 * std::max<int64_t>(n, 1));
@@ -560,6 +620,10 @@ void installBridge() {
     }
     map.getMeshLayer().clear();
     map.getMeshLayer().push_back(std::move(mb));
+  };
+  ref_standin::bridge().parse_input = [](hydra::InputData& d) {
+    orc_parse_input(&g_env->main_cfg, &g_env->sensor, d.world_T_sensor16, d.depth->data(), reinterpret_cast<float*>(d.range_image.data()),
+                    reinterpret_cast<float*>(d.vertex_map.data()));
   };
 }
 }  // namespace
@@ -584,8 +648,9 @@ RefExtractor* ref_ex_create(const orc_config* object_map_cfg, const orc_sensor* 
   khronos::FrameDataBuffer::Config bc;
   bc.max_buffer_size = static_cast<size_t>(max_buffer_size);
   r->buffer = std::make_unique<khronos::FrameDataBuffer>(bc);
-  r->map_cfg = *object_map_cfg;
-  r->sensor = *sensor;
+  r->env.main_cfg = *object_map_cfg;
+  r->env.object_cfg = *object_map_cfg;
+  r->env.sensor = *sensor;
   return r;
 }
 
@@ -594,7 +659,7 @@ void ref_ex_destroy(RefExtractor* r) { delete r; }
 /* one frame into the reference's FrameDataBuffer: raw images for the bridge, the object image, the semantic clusters' ids and boxes */
 void ref_ex_add_frame(RefExtractor* r, uint64_t stamp, const double* world_T_sensor, const float* depth, const uint8_t* rgb,
                       const int32_t* object_image, int n_clusters, const int32_t* cluster_ids, const float* cluster_boxes) {
-  const int W = r->sensor.width, H = r->sensor.height;
+  const int W = r->env.sensor.width, H = r->env.sensor.height;
   hydra::InputData in;
   in.timestamp_ns = stamp;
   in.depth = std::make_shared<std::vector<float>>(depth, depth + static_cast<size_t>(W) * H);
@@ -620,7 +685,7 @@ void ref_ex_add_frame(RefExtractor* r, uint64_t stamp, const double* world_T_sen
 int ref_ex_extract(RefExtractor* r, int track_id, int is_dynamic, float confidence, uint64_t first_seen, uint64_t last_seen, int category, int n_obs,
                    const uint64_t* obs_stamps, const int32_t* obs_semantic_ids, const int32_t* obs_dynamic_ids, float* points_out, int64_t cap_points,
                    int64_t* n_points_out, float* bbox_out, int64_t* info_out) {
-  g_current_extractor = r;
+  g_env = &r->env;
   khronos::Track t;
   t.id = track_id;
   t.is_dynamic = is_dynamic != 0;
@@ -630,7 +695,6 @@ int ref_ex_extract(RefExtractor* r, int track_id, int is_dynamic, float confiden
   if (category >= 0) t.semantics = khronos::SemanticClusterInfo(category);
   for (int i = 0; i < n_obs; ++i) t.observations.emplace_back(obs_stamps[i], obs_semantic_ids[i], obs_dynamic_ids[i]);
   const auto obj = r->extractor->extractObject(t, *r->buffer);
-  g_current_extractor = nullptr;
   if (!obj) return 0;
   *n_points_out = static_cast<int64_t>(obj->mesh.points.size());
   for (int64_t i = 0; i < *n_points_out && i < cap_points; ++i)
@@ -643,6 +707,294 @@ int ref_ex_extract(RefExtractor* r, int track_id, int is_dynamic, float confiden
   info_out[1] = obj->first_observed_ns.empty() ? 0 : static_cast<int64_t>(obj->first_observed_ns[0]);
   info_out[2] = obj->last_observed_ns.empty() ? 0 : static_cast<int64_t>(obj->last_observed_ns[0]);
   return 1;
+}
+
+/* khronos::ActiveWindow (active_window.cpp:76-286 + object_worker_pool.cpp): the reference's own module -- constructor, spinOnce,
+ * createData, updateMap, extractOutputData, extractInactiveObjects, the worker pool -- with the reference's own sub-modules
+ * (FreeSpaceMotionDetector, ConnectedSemantics, MaxIoUTracker, TrackingIntegrator, MeshObjectExtractor, FrameDataBuffer) plugged
+ * in through the factories, and the three things that are not in /root/reference (input conversion, projective integrator, mesh
+ * integrator) bridged to the CPU oracle. */
+struct ref_aw_config {
+  float voxel_size;
+  int32_t voxels_per_side;
+  float truncation_distance;
+  float min_output_separation;
+  int32_t detach_object_extraction;
+  float temporal_buffer, tsdf_occupancy_threshold;
+  int32_t neighbor_connectivity;
+  float temporal_window;
+  int32_t md_neighbor_connectivity, md_min_cluster_size, md_max_cluster_size;
+  float md_min_separation_distance, md_max_range, md_min_z_coordinate;
+  int32_t od_use_full_connectivity, od_min_cluster_size, od_max_cluster_size, od_use_3d;
+  float od_grid_size, od_max_range;
+  int32_t tr_assign_track;
+  float tr_min_semantic_iou, tr_min_cross_iou, tr_max_dynamic_distance, tr_temporal_window;
+  int32_t tr_min_num_observations;
+  float tr_voxel_size;
+  float ex_min_allocation_confidence, ex_min_volume, ex_max_volume;
+  int32_t ex_only_reconstructed;
+  float ex_min_dynamic_displacement, ex_min_reconstruction_confidence;
+  int32_t ex_min_reconstruction_observations;
+  float ex_resolution, ex_min_resolution;
+  int32_t buffer_size, num_threads, num_workers;
+};
+
+struct RefObject {
+  int label;
+  uint64_t first_seen, last_seen;
+  float bbox[6];
+  std::vector<float> points;
+};
+
+struct RefActiveWindow {
+  BridgeEnv env;
+  std::unique_ptr<khronos::ActiveWindow> aw;
+  hydra::ActiveWindowOutput::Ptr last_output;
+  std::vector<RefObject> objects;
+  int width = 0, height = 0;
+};
+
+namespace {
+void takeObjects(RefActiveWindow* r, hydra::LayerUpdate& update) {
+  for (auto& attrs : update.attributes) {
+    const auto* o = dynamic_cast<const spark_dsg::KhronosObjectAttributes*>(attrs.get());
+    if (!o) continue;
+    RefObject ro;
+    ro.label = o->semantic_label;
+    ro.first_seen = o->first_observed_ns.empty() ? 0 : o->first_observed_ns[0];
+    ro.last_seen = o->last_observed_ns.empty() ? 0 : o->last_observed_ns[0];
+    for (int a = 0; a < 3; ++a) {
+      ro.bbox[a] = o->bounding_box.min[a];
+      ro.bbox[3 + a] = o->bounding_box.max[a];
+    }
+    for (const auto& p : o->mesh.points) {
+      ro.points.push_back(p[0]);
+      ro.points.push_back(p[1]);
+      ro.points.push_back(p[2]);
+    }
+    r->objects.push_back(std::move(ro));
+  }
+  update.attributes.clear();
+}
+}  // namespace
+
+RefActiveWindow* ref_aw_create(const ref_aw_config* c, const orc_config* main_cfg, const orc_config* object_cfg, const orc_sensor* sensor,
+                               const int32_t* object_labels, int n_object_labels) {
+  installBridge();
+  auto* r = new RefActiveWindow();
+  r->env.main_cfg = *main_cfg;
+  r->env.object_cfg = *object_cfg;
+  r->env.sensor = *sensor;
+  r->width = sensor->width;
+  r->height = sensor->height;
+  g_env = &r->env;
+  auto& labels = hydra::GlobalInfo::instance().mutableLabelSpaceConfig().object_labels;
+  labels.clear();
+  labels.insert(object_labels, object_labels + n_object_labels);
+
+  khronos::ActiveWindow::Config cfg;
+  cfg.volumetric_map.voxel_size = c->voxel_size;
+  cfg.volumetric_map.voxels_per_side = static_cast<size_t>(c->voxels_per_side);
+  cfg.volumetric_map.truncation_distance = c->truncation_distance;
+  cfg.volumetric_map.with_semantics = true;  // (uHumans2.yaml:49)
+  cfg.min_output_separation = c->min_output_separation;
+  cfg.detach_object_extraction = c->detach_object_extraction != 0;
+  cfg.tracking_integrator.temporal_buffer = c->temporal_buffer;
+  cfg.tracking_integrator.tsdf_occupancy_threshold = c->tsdf_occupancy_threshold;
+  cfg.tracking_integrator.neighbor_connectivity = c->neighbor_connectivity;
+  cfg.tracking_integrator.temporal_window = c->temporal_window;
+  cfg.tracking_integrator.num_threads = c->num_threads;
+  const ref_aw_config k = *c;
+  cfg.motion_detector.factory = [k]() -> std::unique_ptr<khronos::MotionDetector> {
+    khronos::FreeSpaceMotionDetector::Config d;
+    d.neighbor_connectivity = k.md_neighbor_connectivity;
+    d.min_cluster_size = k.md_min_cluster_size;
+    d.max_cluster_size = k.md_max_cluster_size;
+    d.min_separation_distance = k.md_min_separation_distance;
+    d.max_range = k.md_max_range;
+    d.min_z_coordinate = k.md_min_z_coordinate;
+    d.num_threads = k.num_threads;
+    return std::make_unique<khronos::FreeSpaceMotionDetector>(d);
+  };
+  cfg.object_detector.factory = [k]() -> std::unique_ptr<khronos::ObjectDetector> {
+    khronos::ConnectedSemantics::Config d;
+    d.use_full_connectivity = k.od_use_full_connectivity != 0;
+    d.min_cluster_size = k.od_min_cluster_size;
+    d.max_cluster_size = k.od_max_cluster_size;
+    d.use_3d = k.od_use_3d != 0;
+    d.grid_size = k.od_grid_size;
+    d.max_range = k.od_max_range;
+    return std::make_unique<khronos::ConnectedSemantics>(d);
+  };
+  cfg.tracker.factory = [k]() -> std::unique_ptr<khronos::Tracker> {
+    khronos::MaxIoUTracker::Config d;
+    d.track_by = khronos::MaxIoUTracker::Config::TrackBy::kVoxels;
+    d.semantic_association = k.tr_assign_track ? khronos::MaxIoUTracker::Config::SemanticAssociation::kAssignTrack
+                                               : khronos::MaxIoUTracker::Config::SemanticAssociation::kAssignCluster;
+    d.min_semantic_iou = k.tr_min_semantic_iou;
+    d.min_cross_iou = k.tr_min_cross_iou;
+    d.max_dynamic_distance = k.tr_max_dynamic_distance;
+    d.temporal_window = k.tr_temporal_window;
+    d.min_num_observations = k.tr_min_num_observations;
+    d.voxel_size = k.tr_voxel_size;
+    return std::make_unique<khronos::MaxIoUTracker>(d);
+  };
+  cfg.object_extractor.factory = [k]() -> std::unique_ptr<khronos::ObjectExtractor> {
+    khronos::MeshObjectExtractor::Config d;
+    d.min_object_allocation_confidence = k.ex_min_allocation_confidence;
+    d.min_object_volume = k.ex_min_volume;
+    d.max_object_volume = k.ex_max_volume;
+    d.only_extract_reconstructed_objects = k.ex_only_reconstructed != 0;
+    d.min_dynamic_displacement = k.ex_min_dynamic_displacement;
+    d.min_object_reconstruction_confidence = k.ex_min_reconstruction_confidence;
+    d.min_object_reconstruction_observations = k.ex_min_reconstruction_observations;
+    d.object_reconstruction_resolution = k.ex_resolution;
+    d.min_reconstruction_resolution = k.ex_min_resolution;
+    return std::make_unique<khronos::MeshObjectExtractor>(d);
+  };
+  cfg.extraction_worker.num_workers = static_cast<size_t>(c->num_workers);
+  cfg.frame_data_buffer.max_buffer_size = static_cast<size_t>(c->buffer_size);
+  r->aw = std::make_unique<khronos::ActiveWindow>(cfg, nullptr);
+  return r;
+}
+
+void ref_aw_destroy(RefActiveWindow* r) {
+  if (r && g_env == &r->env) {
+    r->aw.reset();  // (joins the worker pool's thread while the environment is still there)
+    g_env = nullptr;
+  }
+  delete r;
+}
+
+/* ActiveWindow::spinOnce on one raw frame; returns 1 when the frame produced an output (active_window.cpp:158-160) */
+int ref_aw_spin(RefActiveWindow* r, uint64_t stamp, const double* world_T_sensor, const float* depth, const uint8_t* rgb, const int32_t* label) {
+  g_env = &r->env;
+  const size_t n = static_cast<size_t>(r->width) * r->height;
+  hydra::InputPacket in;
+  in.timestamp_ns = stamp;
+  in.width = r->width;
+  in.height = r->height;
+  in.sensor.width = r->width;
+  in.sensor.height = r->height;
+  in.sensor.fx = r->env.sensor.fx, in.sensor.fy = r->env.sensor.fy, in.sensor.cx = r->env.sensor.cx, in.sensor.cy = r->env.sensor.cy;
+  in.depth = std::make_shared<std::vector<float>>(depth, depth + n);
+  if (rgb) in.rgb = std::make_shared<std::vector<uint8_t>>(rgb, rgb + 3 * n);
+  if (label) in.label = std::make_shared<std::vector<int32_t>>(label, label + n);
+  std::memcpy(in.world_T_sensor16, world_T_sensor, sizeof(in.world_T_sensor16));
+  r->last_output = r->aw->spinOnce(in);
+  if (!r->last_output) return 0;
+  for (auto& kv : r->last_output->graph_update) takeObjects(r, *kv.second);
+  return 1;
+}
+
+/* the latest frame's dynamic and object image */
+void ref_aw_frame_images(RefActiveWindow* r, int32_t* dynamic_out, int32_t* object_out) {
+  const khronos::FrameData& d = r->aw->getLatestFrameData();
+  for (int v = 0; v < r->height; ++v)
+    for (int u = 0; u < r->width; ++u) {
+      dynamic_out[v * r->width + u] = d.dynamic_image.at<int>(v, u);
+      object_out[v * r->width + u] = d.object_image.at<int>(v, u);
+    }
+}
+
+/* the tracker's tracks as one JSON line (the format of host_selftest --tracker) */
+int64_t ref_aw_tracks(RefActiveWindow* r, char* out, int64_t cap) {
+  std::string result = "[";
+  bool first = true;
+  for (const khronos::Track& t : r->aw->getTracks()) {
+    const khronos::Observation& o = t.observations.back();
+    char buf[512];
+    std::snprintf(buf, sizeof(buf),
+                  "%s{\"id\": %d, \"dyn\": %d, \"active\": %d, \"conf\": %.9g, \"first\": %llu, \"last\": %llu, \"cat\": %d, "
+                  "\"n_obs\": %zu, \"obs\": [%llu, %d, %d], \"n_vox\": %zu}",
+                  first ? "" : ", ", t.id, int(t.is_dynamic), int(t.is_active), t.confidence, static_cast<unsigned long long>(t.first_seen),
+                  static_cast<unsigned long long>(t.last_seen), t.semantics ? t.semantics->category_id : -1, t.observations.size(),
+                  static_cast<unsigned long long>(o.stamp), o.semantic_cluster_id, o.dynamic_cluster_id, t.last_voxels.size());
+    result += buf;
+    first = false;
+  }
+  result += "]";
+  const int64_t n = std::min<int64_t>(static_cast<int64_t>(result.size()), cap > 0 ? cap - 1 : 0);
+  if (cap > 0) {
+    std::memcpy(out, result.data(), static_cast<size_t>(n));
+    out[n] = 0;
+  }
+  return static_cast<int64_t>(result.size());
+}
+
+/* the window's map: sorted block indices; one block's tracking state (as ref_get_block, block_flags additionally bit0 updated,
+ * bit1 mesh_updated) */
+int64_t ref_aw_block_indices(RefActiveWindow* r, int32_t* out, int64_t cap) {
+  auto v = r->aw->getMap().getTsdfLayer().allocatedBlockIndices();
+  std::sort(v.begin(), v.end(), [](const hydra::BlockIndex& a, const hydra::BlockIndex& b) {
+    return a[0] != b[0] ? a[0] < b[0] : (a[1] != b[1] ? a[1] < b[1] : a[2] < b[2]);
+  });
+  for (int64_t i = 0; i < static_cast<int64_t>(v.size()) && i < cap; ++i)
+    for (int a = 0; a < 3; ++a) out[3 * i + a] = v[i][a];
+  return static_cast<int64_t>(v.size());
+}
+
+int ref_aw_get_block(RefActiveWindow* r, const int32_t* idx, float* distance, uint64_t* last_observed, uint64_t* last_occupied, uint8_t* flags,
+                     uint8_t* block_flags) {
+  const hydra::BlockIndex bi(idx[0], idx[1], idx[2]);
+  const auto tsdf = r->aw->getMap().getTsdfLayer().getBlockPtr(bi);
+  const auto trk = r->aw->getMap().getTrackingLayer()->getBlockPtr(bi);
+  if (!tsdf || !trk) return -1;
+  for (size_t i = 0; i < trk->numVoxels(); ++i) {
+    const hydra::TrackingVoxel& v = trk->getVoxel(i);
+    if (distance) distance[i] = tsdf->getVoxel(i).distance;
+    if (last_observed) last_observed[i] = v.last_observed;
+    if (last_occupied) last_occupied[i] = v.last_occupied;
+    if (flags) flags[i] = static_cast<uint8_t>((v.active ? 1 : 0) | (v.ever_free ? 2 : 0) | (v.to_remove ? 4 : 0));
+  }
+  if (block_flags)
+    *block_flags = static_cast<uint8_t>((tsdf->updated ? 1 : 0) | (tsdf->mesh_updated ? 2 : 0) | (tsdf->tracking_updated ? 4 : 0) | (trk->has_active_data ? 8 : 0));
+  return 0;
+}
+
+/* the latest output (extractOutputData, active_window.cpp:217-249): info = {stamp, archived blocks, cloned (updated) blocks, mesh
+ * vertices of the window}; the two index lists sorted */
+void ref_aw_output(RefActiveWindow* r, int64_t* info, int32_t* archived, int64_t cap_archived, int32_t* cloned, int64_t cap_cloned) {
+  const auto& o = r->last_output;
+  auto sorted = [](hydra::BlockIndices v) {
+    std::sort(v.begin(), v.end(), [](const hydra::BlockIndex& a, const hydra::BlockIndex& b) {
+      return a[0] != b[0] ? a[0] < b[0] : (a[1] != b[1] ? a[1] < b[1] : a[2] < b[2]);
+    });
+    return v;
+  };
+  const auto arch = sorted(o->archived_mesh_indices);
+  const auto cl = sorted(o->map->getTsdfLayer().allocatedBlockIndices());
+  info[0] = static_cast<int64_t>(o->timestamp_ns);
+  info[1] = static_cast<int64_t>(arch.size());
+  info[2] = static_cast<int64_t>(cl.size());
+  size_t nvert = 0;
+  for (const auto& mb : r->aw->getMap().getMeshLayer()) nvert += mb.points.size();
+  info[3] = static_cast<int64_t>(nvert);
+  for (int64_t i = 0; i < static_cast<int64_t>(arch.size()) && i < cap_archived; ++i)
+    for (int a = 0; a < 3; ++a) archived[3 * i + a] = arch[i][a];
+  for (int64_t i = 0; i < static_cast<int64_t>(cl.size()) && i < cap_cloned; ++i)
+    for (int a = 0; a < 3; ++a) cloned[3 * i + a] = cl[i][a];
+}
+
+/* wait for the detached extractions (object_worker_pool.cpp:115-146) and take what they produced; returns the number of objects so far */
+int64_t ref_aw_collect(RefActiveWindow* r) {
+  auto& pool = r->aw->extraction_worker_;
+  while (pool.work_queue_.size() > 0 || pool.curr_workers_ > 0) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+  hydra::LayerUpdate update(2);
+  pool.fill(update);
+  takeObjects(r, update);
+  return static_cast<int64_t>(r->objects.size());
+}
+
+/* object i: info = {label, first seen, last seen, vertices}; bbox (min, max); the vertices (box frame) up to cap */
+void ref_aw_object(RefActiveWindow* r, int64_t i, int64_t* info, float* bbox, float* points, int64_t cap_points) {
+  const RefObject& o = r->objects[static_cast<size_t>(i)];
+  info[0] = o.label;
+  info[1] = static_cast<int64_t>(o.first_seen);
+  info[2] = static_cast<int64_t>(o.last_seen);
+  info[3] = static_cast<int64_t>(o.points.size() / 3);
+  std::memcpy(bbox, o.bbox, sizeof(o.bbox));
+  std::memcpy(points, o.points.data(), sizeof(float) * std::min<size_t>(o.points.size(), 3 * static_cast<size_t>(cap_points)));
 }
 
 /* utils::combineMeshLayer (geometry_utils.cpp:61-86): blocks given as vertex counts + faces per block (local indices);

@@ -10,6 +10,7 @@
 //   khronos/src/active_window/data/frame_data_buffer.cpp                 (a17)
 //   khronos/src/backend/change_detection/ray_verificator.cpp, ray_change_detector.cpp   (f4)
 //   khronos/src/active_window/object_extraction/mesh_object_extractor.cpp, integration/object_integrator.cpp   (a13, a12)
+//   khronos/src/active_window/active_window.cpp, object_extraction/object_worker_pool.cpp                      (a1 - a3, a15)
 // but not the containers they run on.  oracle/ref_recipe/build_ref.sh compiles those files FROM WHERE THEY LIE
 // (nothing is copied) against this header into oracle/_ref/libref_khronos.so, and tests/test_cpu_ref_pin.py runs the
 // reference's own code beside oracle/oracle.cpp on the same seeded sequences.  What that pins: every decision those files
@@ -28,7 +29,9 @@
 #include <cstddef>
 #include <cstdint>
 #include <functional>
+#include <condition_variable>
 #include <iostream>
+#include <list>
 #include <limits>
 #include <map>
 #include <memory>
@@ -163,6 +166,11 @@ class Isometry3d {
   Vec& translation() { return t_; }
   const Vec& translation() const { return t_; }
   double& linear(int r, int c) { return r_[3 * r + c]; }
+  std::array<double, 9> rotation() const {
+    std::array<double, 9> r;
+    std::copy(r_, r_ + 9, r.begin());
+    return r;
+  }
   Vec operator*(const Vec& p) const {
     return Vec((r_[0] * p[0] + r_[1] * p[1]) + r_[2] * p[2] + t_[0], (r_[3] * p[0] + r_[4] * p[1]) + r_[5] * p[2] + t_[1],
                (r_[6] * p[0] + r_[7] * p[1]) + r_[8] * p[2] + t_[2]);
@@ -175,6 +183,7 @@ class Isometry3d {
 }  // namespace Eigen
 
 // ----------------------------------------------------------------------------------------------------------------- OpenCV
+#define CV_32SC1 4  // (stand-in: the type code is the element size)
 namespace cv {
 template <typename T, int N>
 struct Vec {
@@ -185,10 +194,16 @@ struct Vec {
 using Vec3f = Vec<float, 3>;
 
 // row-major image with untyped storage; at<T>(row, col) as the reference uses it (free_space_motion_detector.cpp:168,174,391)
+struct Size {
+  int width = 0, height = 0;
+};
+
 class Mat {
  public:
   int rows = 0, cols = 0;
   Mat() = default;
+  Size size() const { return Size{cols, rows}; }
+  static Mat zeros(const Size& s, int type) { return Mat(s.height, s.width, static_cast<size_t>(type)); }
   Mat(int r, int c, size_t elem_bytes) : rows(r), cols(c), eb_(elem_bytes), d_(std::make_shared<std::vector<uint8_t>>(static_cast<size_t>(r) * c * elem_bytes, 0)) {}
   template <typename T>
   T& at(int r, int c) { return reinterpret_cast<T*>(d_->data())[static_cast<size_t>(r) * cols + c]; }
@@ -254,10 +269,22 @@ template <typename T>
 const T& checkValid(const T& c) { return c; }
 template <typename T>
 bool isValid(const T&) { return true; }
-template <typename Base, typename Derived, typename Cfg>
+template <typename Base, typename Derived, typename... Rest>
 struct RegistrationWithConfig {
   explicit RegistrationWithConfig(const std::string&) {}
 };
+// a configured, optional sub-module (active_window.h:84-87): the harness installs the factory
+template <typename T>
+struct VirtualConfig {
+  std::function<std::unique_ptr<T>()> factory;
+  void setOptional() {}
+  std::unique_ptr<T> create() const { return factory ? factory() : nullptr; }
+  explicit operator bool() const { return static_cast<bool>(factory); }
+};
+template <typename B, typename C>
+void base(C&) {}
+template <typename C>
+std::string toString(const C&) { return std::string(); }
 }  // namespace config
 
 // ----------------------------------------------------------------------------------------------------------- spatial_hash
@@ -424,6 +451,15 @@ class Layer {
   };
   iterator begin() { return iterator{blocks_.begin()}; }
   iterator end() { return iterator{blocks_.end()}; }
+  struct const_iterator {
+    typename IndexMap3<std::shared_ptr<BlockT>>::const_iterator it;
+    const BlockT& operator*() const { return *it->second; }
+    const_iterator& operator++() { ++it; return *this; }
+    bool operator!=(const const_iterator& o) const { return it != o.it; }
+  };
+  const_iterator begin() const { return const_iterator{blocks_.begin()}; }
+  const_iterator end() const { return const_iterator{blocks_.end()}; }
+  void insertBlock(const std::shared_ptr<BlockT>& b) { blocks_[b->index] = b; }
   BlockPtr getBlockPtr(const Point& p) { return getBlockPtr(blockIndexOf(p)); }
   ConstBlockPtr getBlockPtr(const Point& p) const { return getBlockPtr(blockIndexOf(p)); }
   BlockT& allocateBlock(const BlockIndex& i) {
@@ -562,6 +598,7 @@ struct Mesh {
 
 // node attributes: the fields the change detection reads (ray_verificator.cpp:205-207,361-365; ray_verificator.h:170-174)
 struct NodeAttributes {
+  using Ptr = std::unique_ptr<NodeAttributes>;
   virtual ~NodeAttributes() = default;
   Eigen::Vector3d position;
 };
@@ -669,8 +706,9 @@ struct SemanticVoxel {
 struct TsdfBlock : spatial_hash::Block<TsdfVoxel> {
   using Ptr = std::shared_ptr<TsdfBlock>;
   using spatial_hash::Block<TsdfVoxel>::Block;
-  bool updated = false, mesh_updated = false, tracking_updated = false;
+  mutable bool updated = false, mesh_updated = false, tracking_updated = false;
   static bool trackingUpdated(const TsdfBlock& b) { return b.tracking_updated; }  // tracking_integrator.cpp:77
+  void clearUpdated() const { updated = false; }  // [A.6] clears `updated` only (active_window.cpp:169-171)
 };
 struct TrackingBlock : spatial_hash::Block<TrackingVoxel> {
   using Ptr = std::shared_ptr<TrackingBlock>;
@@ -705,6 +743,18 @@ class VolumetricMap {
   MeshLayer& getMeshLayer() { return mesh_; }
   const MeshLayer& getMeshLayer() const { return mesh_; }
   std::shared_ptr<void> backend;  // (the harness's CPU-oracle map behind this one, where the integrators are bridged)
+  std::function<void(const BlockIndex&)> on_remove;  // (bridge: the same block leaves the backend)
+  bool hasSemantics() const { return config.with_semantics; }
+  // [A.6] deep copy of the blocks whose `updated` flag is set (active_window.cpp:229)
+  std::shared_ptr<VolumetricMap> cloneUpdated() const {
+    auto out = std::make_shared<VolumetricMap>(config);
+    for (const TsdfBlock& b : tsdf_) {
+      if (!b.updated) continue;
+      out->tsdf_.insertBlock(std::make_shared<TsdfBlock>(b));
+      if (auto t = tracking_->getBlockPtr(b.index)) out->tracking_->insertBlock(std::make_shared<TrackingBlock>(*t));
+    }
+    return out;
+  }
   TsdfLayer& getTsdfLayer() { return tsdf_; }
   const TsdfLayer& getTsdfLayer() const { return tsdf_; }
   std::shared_ptr<TrackingLayer> getTrackingLayer() { return tracking_; }
@@ -718,6 +768,7 @@ class VolumetricMap {
     tsdf_.removeBlock(i);
     tracking_->removeBlock(i);
     semantic_->removeBlock(i);
+    if (on_remove) on_remove(i);
   }
 
  private:
@@ -736,8 +787,9 @@ struct InputData;
 }  // namespace hydra
 namespace ref_standin {
 struct Bridge {
-  std::function<void(const hydra::ProjectiveIntegrator&, const hydra::InputData&, hydra::VolumetricMap&, bool)> integrate;
+  std::function<void(const hydra::ProjectiveIntegrator&, const hydra::InputData&, hydra::VolumetricMap&, bool, const cv::Mat&)> integrate;
   std::function<void(const hydra::MeshIntegrator&, hydra::VolumetricMap&, bool, bool)> mesh;
+  std::function<void(hydra::InputData&)> parse_input;  // range image + world-frame vertex map of a raw frame (ASSUMPTIONS.md A.2)
 };
 inline Bridge& bridge() {
   static Bridge b;
@@ -780,8 +832,8 @@ class ProjectiveIntegrator {
   using VoxelMeasurement = hydra::VoxelMeasurement;  // (named unqualified inside the subclass, object_integrator.h:69)
   explicit ProjectiveIntegrator(const Config& c) : config(c), interpolator_(std::make_unique<Interpolator>()) {}
   virtual ~ProjectiveIntegrator() = default;
-  void updateMap(const InputData& data, VolumetricMap& map, bool allocate_blocks = true, const cv::Mat& = cv::Mat()) const {
-    ref_standin::bridge().integrate(*this, data, map, allocate_blocks);
+  void updateMap(const InputData& data, VolumetricMap& map, bool allocate_blocks = true, const cv::Mat& integration_mask = cv::Mat()) const {
+    ref_standin::bridge().integrate(*this, data, map, allocate_blocks, integration_mask);
   }
   const Config config;
 
@@ -886,6 +938,8 @@ struct InputData {
   const Eigen::Isometry3d& getSensorPose() const { return world_T_sensor; }
   Sensor sensor;
   const Sensor& getSensor() const { return sensor; }
+  Eigen::Isometry3d world_T_body;
+  cv::Mat depth_image;
   // (bridge) the raw frame, for the integrator behind ref_standin::bridge()
   std::shared_ptr<std::vector<float>> depth;
   std::shared_ptr<std::vector<uint8_t>> rgb;
@@ -895,6 +949,150 @@ struct InputData {
 namespace timing {
 struct ScopedTimer {
   ScopedTimer(const std::string&, TimeStamp) {}
+  void stop() {}
+};
+struct ElapsedTimeRecorder {
+  static ElapsedTimeRecorder& instance() {
+    static ElapsedTimeRecorder r;
+    return r;
+  }
+  template <typename D>
+  void record(const std::string&, TimeStamp, const D&) {}
 };
 }  // namespace timing
+
+// thread-safe queue (object_worker_pool.cpp:96,121-131)
+template <typename T>
+class MessageQueue {
+ public:
+  using Ptr = std::shared_ptr<MessageQueue>;
+  void push(const T& v) {
+    {
+      std::lock_guard<std::mutex> lock(m_);
+      q_.push_back(v);
+    }
+    cv_.notify_all();
+  }
+  bool poll(size_t wait_us) {
+    std::unique_lock<std::mutex> lock(m_);
+    return cv_.wait_for(lock, std::chrono::microseconds(wait_us), [this] { return !q_.empty(); });
+  }
+  T pop() {
+    std::lock_guard<std::mutex> lock(m_);
+    T v = q_.front();
+    q_.pop_front();
+    return v;
+  }
+  size_t size() const {
+    std::lock_guard<std::mutex> lock(m_);
+    return q_.size();
+  }
+
+ private:
+  mutable std::mutex m_;
+  std::condition_variable cv_;
+  std::list<T> q_;
+};
+
+// output sinks (active_window.h:69, active_window.cpp:80,146)
+template <typename... Args>
+struct OutputSink {
+  using Ptr = std::shared_ptr<OutputSink>;
+  using List = std::list<Ptr>;
+  using Factory = std::function<Ptr()>;
+  virtual ~OutputSink() = default;
+  virtual void call(Args...) const {}
+  static List instantiate(const std::vector<Factory>& factories) {
+    List l;
+    for (const auto& f : factories)
+      if (auto s = f()) l.push_back(s);
+    return l;
+  }
+  static void callAll(const List& sinks, Args... args) {
+    for (const auto& s : sinks) s->call(args...);
+  }
+  static std::string printSinks(const List&) { return std::string(); }
+};
+
+// a raw frame as it reaches the module, and what the module hands on (active_window.cpp:118-174,217-249)
+struct InputPacket {
+  TimeStamp timestamp_ns = 0;
+  int width = 0, height = 0;
+  Sensor sensor;
+  std::shared_ptr<std::vector<float>> depth;
+  std::shared_ptr<std::vector<uint8_t>> rgb;
+  std::shared_ptr<std::vector<int32_t>> label;
+  double world_T_sensor16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+};
+struct LayerUpdate {
+  using Ptr = std::shared_ptr<LayerUpdate>;
+  explicit LayerUpdate(spark_dsg::LayerId l) : layer(l) {}
+  spark_dsg::LayerId layer;
+  std::list<spark_dsg::NodeAttributes::Ptr> attributes;
+};
+struct ActiveWindowOutput {
+  using Ptr = std::shared_ptr<ActiveWindowOutput>;
+  TimeStamp timestamp_ns = 0;
+  Eigen::Vector3d world_t_body;
+  std::array<double, 9> world_R_body{};
+  std::shared_ptr<VolumetricMap> map;
+  void setMap(const std::shared_ptr<VolumetricMap>& m) { map = m; }
+  BlockIndices archived_mesh_indices;
+  std::map<spark_dsg::LayerId, LayerUpdate::Ptr> graph_update;
+  std::shared_ptr<InputData> sensor_data;
+};
+class ActiveWindowModule {
+ public:
+  struct Config {
+    VolumetricMap::Config volumetric_map;
+    Config(bool with_semantics, bool with_tracking) {
+      volumetric_map.with_semantics = with_semantics;
+      volumetric_map.with_tracking = with_tracking;
+    }
+  };
+  using OutputQueue = MessageQueue<ActiveWindowOutput::Ptr>;
+  using InputQueue = MessageQueue<std::shared_ptr<InputPacket>>;
+  ActiveWindowModule(const Config& c, const OutputQueue::Ptr& out)
+      : map_(c.volumetric_map), input_queue_(std::make_shared<InputQueue>()), output_queue_(out ? out : std::make_shared<OutputQueue>()) {}
+  virtual ~ActiveWindowModule() = default;
+  virtual std::string printInfo() const { return std::string(); }
+
+ protected:
+  virtual ActiveWindowOutput::Ptr spinOnce(const InputPacket& input) = 0;
+  VolumetricMap map_;
+  std::shared_ptr<InputQueue> input_queue_;
+  OutputQueue::Ptr output_queue_;
+};
+
+namespace conversions {
+// [A.2] the input conversion: depth, labels, colour taken over; range image + world-frame vertex map through the bridge
+inline std::unique_ptr<InputData> parseInputPacket(const InputPacket& in, bool, bool) {
+  auto d = std::make_unique<InputData>();
+  d->timestamp_ns = in.timestamp_ns;
+  d->sensor = in.sensor;
+  d->depth = in.depth;
+  d->rgb = in.rgb;
+  std::copy(in.world_T_sensor16, in.world_T_sensor16 + 16, d->world_T_sensor16);
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) d->world_T_sensor.linear(r, c) = in.world_T_sensor16[4 * r + c];
+    d->world_T_sensor.translation()[r] = in.world_T_sensor16[4 * r + 3];
+  }
+  d->world_T_body = d->world_T_sensor;
+  d->depth_image = cv::Mat(in.height, in.width, sizeof(float));
+  std::copy(in.depth->begin(), in.depth->end(), reinterpret_cast<float*>(d->depth_image.data()));
+  d->label_image = cv::Mat(in.height, in.width, sizeof(int));
+  if (in.label) std::copy(in.label->begin(), in.label->end(), reinterpret_cast<int*>(d->label_image.data()));
+  d->range_image = cv::Mat(in.height, in.width, sizeof(float));
+  d->vertex_map = cv::Mat(in.height, in.width, sizeof(cv::Vec3f));
+  ref_standin::bridge().parse_input(*d);
+  return d;
+}
+}  // namespace conversions
+
+// [A.3] mask of the non-zero pixels of an id image (active_window.cpp:209)
+inline void maskNonZero(const cv::Mat& in, cv::Mat& out) {
+  out = cv::Mat(in.rows, in.cols, sizeof(int));
+  for (int r = 0; r < in.rows; ++r)
+    for (int c = 0; c < in.cols; ++c) out.at<int>(r, c) = in.at<int>(r, c) != 0 ? 1 : 0;
+}
 }  // namespace hydra

@@ -442,3 +442,125 @@ def test_object_extraction_equals_reference_code():
     low = tracks[0]
     assert ref.extract(low.id, False, 0.5, low.first_seen, low.last_seen, -1, [tuple(o) for o in low.observations]) is None  # confidence <= 0.5
     assert ref.extract(low.id, False, 0.9, low.first_seen, low.last_seen, -1, [(o[0], -1, -1) for o in low.observations]) is None  # no semantic frames
+
+
+@needs_ref
+def test_whole_active_window_equals_reference_code():
+    """The reference's OWN khronos::ActiveWindow (active_window.cpp:76-286: constructor, spinOnce, createData, updateMap,
+    extractOutputData, extractInactiveObjects; object_worker_pool.cpp) with its own sub-modules plugged in through the factories
+    -- FreeSpaceMotionDetector, ConnectedSemantics, MaxIoUTracker, TrackingIntegrator, MeshObjectExtractor, FrameDataBuffer, all
+    compiled in place -- fed raw frames; the three pieces that are not in /root/reference (input conversion, projective
+    integrator, mesh integrator) bridged to the CPU oracle.  Beside it the call sequence every parity test of this repository
+    assumes (motion -> objects -> tracker -> masked update -> tracking; at the output cadence mesh -> clone -> archive -> extract
+    -> clear), driven on the oracle with the independent tracker and the extraction restatement.  After EVERY frame: dynamic
+    image, object image, tracks, the whole map's tracking state and block flags; at every output: its stamp (the rate limit of
+    :158-160), archived blocks, cloned blocks, mesh size; at the end every extracted object."""
+    import py_tracker
+    from extract_replica import extract_static
+    from khronos_amd import default_config
+    W, H, N = 160, 120, 34
+    s = SyntheticStream(W, H, threads=1)
+    cfg = _cfg(voxel_size=0.1, truncation_distance=0.3, md_min_cluster_size=20, md_min_separation_distance=2.0, md_max_range=5.0,
+               temporal_window=0.9, temporal_buffer=0.4)
+    osen = po.OrcSensor(W, H, s.fx, s.fy, s.cx, s.cy, 0.1, 5.0)
+    ocfg = po.config_from(default_config(voxel_size=0.05, voxels_per_side=8, truncation_distance=0.1, with_semantics=1, with_tracking=0,
+                                         num_labels=2, semantic_mode=1), 1)
+    object_labels = list(range(7, 20))
+    min_sep, tr_window, tr_min_obs = 0.4, 0.5, 3
+    aw = pyref.RefActiveWindow(LIB, cfg, ocfg, osen, object_labels, min_output_separation=min_sep, detach_object_extraction=0,
+                               od_use_full_connectivity=1, od_min_cluster_size=30, od_max_cluster_size=-1, od_use_3d=1, od_grid_size=0.1,
+                               od_max_range=5.0, tr_assign_track=0, tr_min_semantic_iou=0.25, tr_min_cross_iou=0.1, tr_max_dynamic_distance=1.0,
+                               tr_temporal_window=tr_window, tr_min_num_observations=tr_min_obs, tr_voxel_size=0.2,
+                               ex_min_allocation_confidence=0.5, ex_min_volume=0.005, ex_max_volume=10.0, ex_only_reconstructed=1,
+                               ex_min_dynamic_displacement=1.0, ex_min_reconstruction_confidence=0.5, ex_min_reconstruction_observations=0,
+                               ex_resolution=-0.02, ex_min_resolution=0.0, buffer_size=300, num_workers=2)
+    ora = po.OracleMap(cfg)
+    trk = py_tracker.MaxIoUTracker("voxels", "assign_cluster", 0.25, 0.0, 0.1, 1.0, tr_window, tr_min_obs, 0.2)
+
+    class E:
+        pass
+    e = E()
+    e.frames, e.sem, e.osen = [], {}, osen
+    last_output, want_objects, outputs, seen_dyn, seen_archived = 0, [], 0, 0, 0
+    try:
+        for i in range(N):
+            fr = s.render(i)
+            stamp = fr["stamp"]
+            e.frames.append(fr)
+            # ---- the reference's module
+            produced = aw.spin(stamp, fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+            dyn_r, obj_r = aw.frame_images()
+            # ---- the assumed sequence on the oracle (active_window.cpp:118-174)
+            n_o, dyn_o, _ = ora.detect_motion(osen, stamp, fr["pose"], fr["depth"])
+            ns, oimg, cl = ora.detect_objects(osen, stamp, fr["pose"], fr["depth"], fr["label"], object_labels, use_3d=True, grid_size=0.1,
+                                              max_range=5.0, min_cluster_size=30, use_full_connectivity=True)
+            sem, dyn = [], []
+            boxes = {c["id"]: (c["bbox_min"].astype(np.float32), c["bbox_max"].astype(np.float32)) for c in cl}
+            if ns:
+                ids, vox = ora.cluster_voxels(osen, stamp, fr["pose"], fr["depth"], oimg, 0.2)
+                for c in cl:
+                    sem.append(dict(id=c["id"], category=c["semantic_id"], voxels={tuple(int(x) for x in r) for r in vox[ids == c["id"]]}, box=boxes[c["id"]]))
+                e.sem[stamp] = (None, oimg.astype(np.int16), boxes)
+            if n_o:
+                ids, vox = ora.cluster_voxels(osen, stamp, fr["pose"], fr["depth"], dyn_o, 0.2)
+                _, vm = ora.parse_input(osen, fr["pose"], fr["depth"])
+                for cid in range(1, n_o + 1):
+                    pts = vm[dyn_o == cid]
+                    dyn.append(dict(id=cid, voxels={tuple(int(x) for x in r) for r in vox[ids == cid]}, box=(pts.min(0), pts.max(0))))
+            trk.process(stamp, sem, dyn)
+            ora.integrate(osen, stamp, fr["pose"], fr["depth"], fr["rgb"], fr["label"], mask=dyn_o)
+            ora.update_tracking(stamp)
+            want_output = not (last_output + py_tracker.from_seconds(min_sep) > stamp)  # the rate limit (:158-160)
+            if want_output:  # extractOutputData (:217-249) + clearUpdated (:169-171)
+                ora.generate_mesh(True, True)
+                mesh_vertices = len(ora.mesh()["points"])  # (before archival, where the reference's mesh integrator ran)
+                cloned = np.array([b for b in ora.block_indices() if ora.get_block(b, likelihoods=False)["block_flags"] & 1], np.int32).reshape(-1, 3)
+                archived = ora.reset_inactive()
+                gone = [t for t in trk.tracks if not t.is_active]
+                trk.tracks = [t for t in trk.tracks if t.is_active]
+                want_objects += [o for o in (extract_static(e, t, 2) for t in gone) if o is not None]
+                ora.clear_updated()
+                last_output = stamp
+            # ---- compare
+            assert _same_partition(dyn_o, dyn_r), (i, "dynamic image")
+            mapping = _cluster_bijection(oimg, cl, obj_r, cl)
+            assert mapping is not None, (i, "object image")
+            assert produced == want_output, (i, "output cadence")
+            if produced:
+                out = aw.output()
+                assert out["stamp"] == stamp
+                assert np.array_equal(out["archived"], np.asarray(archived).reshape(-1, 3)), (i, "archived blocks")
+                assert np.array_equal(out["cloned"], cloned), (i, "cloned (updated) blocks")
+                assert out["mesh_vertices"] == mesh_vertices, (i, "mesh size")
+                outputs += 1
+                seen_archived += len(archived)
+            got_tracks = aw.tracks()
+            assert len(got_tracks) == len(trk.tracks), (i, "tracks")
+            for a, t in zip(got_tracks, trk.tracks):
+                obs = t.observations[-1]
+                assert (a["id"], a["dyn"], a["active"], a["first"], a["last"], a["cat"], a["n_obs"], a["n_vox"]) == \
+                    (t.id, int(t.is_dynamic), int(t.is_active), t.first_seen, t.last_seen, t.category if t.has_semantics else -1,
+                     len(t.observations), len(t.last_voxels)), (i, a)
+                assert a["obs"][0] == obs[0], (i, a, obs)
+                if obs[0] == stamp:  # this frame's cluster ids, through the bijection between the two id orders (ASSUMPTIONS.md C.4)
+                    assert a["obs"][1] == (mapping[obs[1]] if obs[1] > 0 else obs[1]) and a["obs"][2] == obs[2], (i, a, obs)
+                assert a["conf"] == pytest.approx(float(t.confidence), rel=1e-6)
+            idx = ora.block_indices()
+            assert np.array_equal(idx, aw.block_indices()), (i, "block set")
+            for b in idx:
+                o_, r_ = ora.get_block(b, likelihoods=False), aw.get_block(b)
+                assert np.array_equal(o_["distance"], r_["distance"]) and np.array_equal(o_["last_observed"], r_["last_observed"])
+                assert np.array_equal(o_["last_occupied"], r_["last_occupied"]), (i, tuple(b))
+                assert np.array_equal(o_["flags"] & 7, r_["flags"]), (i, tuple(b))
+                assert (o_["block_flags"] & 15) == r_["block_flags"], (i, tuple(b), o_["block_flags"], r_["block_flags"])
+            seen_dyn += int((dyn_r > 0).sum())
+        got_objects = aw.collect_objects()
+    finally:
+        aw.close()
+    key = lambda o: (o["label"], o["first_seen"], o["last_seen"], len(o["points"]))
+    got_objects.sort(key=key)
+    want_objects.sort(key=key)
+    assert [key(o) for o in got_objects] == [key(o) for o in want_objects]
+    for g, w in zip(got_objects, want_objects):
+        assert np.array_equal(g["points"], w["points"]) and np.array_equal(g["bbox_min"], w["bbox_min"]) and np.array_equal(g["bbox_max"], w["bbox_max"])
+    assert outputs >= 5 and seen_dyn > 0 and seen_archived > 0 and len(got_objects) >= 1, (outputs, seen_dyn, seen_archived, len(got_objects))

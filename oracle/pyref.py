@@ -84,7 +84,9 @@ def load():
     lib.ref_aw_block_indices.restype = C.c_int64
     lib.ref_aw_block_indices.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.ref_aw_get_block.restype = C.c_int
-    lib.ref_aw_get_block.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    lib.ref_aw_get_block.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+    lib.ref_aw_extract_objects.restype = C.c_int64
+    lib.ref_aw_extract_objects.argtypes = [C.c_void_p]
     lib.ref_aw_output.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
     lib.ref_aw_collect.restype = C.c_int64
     lib.ref_aw_collect.argtypes = [C.c_void_p]
@@ -367,10 +369,11 @@ class RefActiveWindow:
 
     def get_block(self, idx):
         i = np.asarray(idx, np.int32)
-        b = {"distance": np.empty(self.nvox, np.float32), "last_observed": np.empty(self.nvox, np.uint64),
+        b = {"distance": np.empty(self.nvox, np.float32), "weight": np.empty(self.nvox, np.float32), "last_observed": np.empty(self.nvox, np.uint64),
              "last_occupied": np.empty(self.nvox, np.uint64), "flags": np.empty(self.nvox, np.uint8)}
         bf = np.zeros(1, np.uint8)
-        if self.lib.ref_aw_get_block(self.h, _ptr(i), _ptr(b["distance"]), _ptr(b["last_observed"]), _ptr(b["last_occupied"]), _ptr(b["flags"]), _ptr(bf)) != 0:
+        if self.lib.ref_aw_get_block(self.h, _ptr(i), _ptr(b["distance"]), _ptr(b["weight"]), _ptr(b["last_observed"]), _ptr(b["last_occupied"]),
+                                     _ptr(b["flags"]), _ptr(bf)) != 0:
             raise KeyError(tuple(idx))
         b["block_flags"] = int(bf[0])
         return b
@@ -381,6 +384,10 @@ class RefActiveWindow:
         self.lib.ref_aw_output(self.h, _ptr(info), _ptr(arch), cap, _ptr(cl), cap)
         assert info[1] <= cap and info[2] <= cap
         return dict(stamp=int(info[0]), archived=arch[: info[1]].copy(), cloned=cl[: info[2]].copy(), mesh_vertices=int(info[3]))
+
+    def extract_objects(self):
+        """ActiveWindow::extractObjects: the remaining tracks, extracted now; how many objects that gave"""
+        return int(self.lib.ref_aw_extract_objects(self.h))
 
     def collect_objects(self, cap_points=1 << 22):
         n = self.lib.ref_aw_collect(self.h)

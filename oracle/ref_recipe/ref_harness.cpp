@@ -934,8 +934,8 @@ int64_t ref_aw_block_indices(RefActiveWindow* r, int32_t* out, int64_t cap) {
   return static_cast<int64_t>(v.size());
 }
 
-int ref_aw_get_block(RefActiveWindow* r, const int32_t* idx, float* distance, uint64_t* last_observed, uint64_t* last_occupied, uint8_t* flags,
-                     uint8_t* block_flags) {
+int ref_aw_get_block(RefActiveWindow* r, const int32_t* idx, float* distance, float* weight, uint64_t* last_observed, uint64_t* last_occupied,
+                     uint8_t* flags, uint8_t* block_flags) {
   const hydra::BlockIndex bi(idx[0], idx[1], idx[2]);
   const auto tsdf = r->aw->getMap().getTsdfLayer().getBlockPtr(bi);
   const auto trk = r->aw->getMap().getTrackingLayer()->getBlockPtr(bi);
@@ -943,6 +943,7 @@ int ref_aw_get_block(RefActiveWindow* r, const int32_t* idx, float* distance, ui
   for (size_t i = 0; i < trk->numVoxels(); ++i) {
     const hydra::TrackingVoxel& v = trk->getVoxel(i);
     if (distance) distance[i] = tsdf->getVoxel(i).distance;
+    if (weight) weight[i] = tsdf->getVoxel(i).weight;
     if (last_observed) last_observed[i] = v.last_observed;
     if (last_occupied) last_occupied[i] = v.last_occupied;
     if (flags) flags[i] = static_cast<uint8_t>((v.active ? 1 : 0) | (v.ever_free ? 2 : 0) | (v.to_remove ? 4 : 0));
@@ -984,6 +985,17 @@ int64_t ref_aw_collect(RefActiveWindow* r) {
   pool.fill(update);
   takeObjects(r, update);
   return static_cast<int64_t>(r->objects.size());
+}
+
+/* ActiveWindow::extractObjects (active_window.cpp:190-201): every remaining track extracted on the calling thread; the objects
+ * are appended to the list (returns their number) */
+int64_t ref_aw_extract_objects(RefActiveWindow* r) {
+  g_env = &r->env;
+  const size_t before = r->objects.size();
+  hydra::LayerUpdate update(2);
+  for (auto& o : r->aw->extractObjects()) update.attributes.emplace_back(std::make_unique<spark_dsg::KhronosObjectAttributes>(*o));
+  takeObjects(r, update);
+  return static_cast<int64_t>(r->objects.size() - before);
 }
 
 /* object i: info = {label, first seen, last seen, vertices}; bbox (min, max); the vertices (box frame) up to cap */

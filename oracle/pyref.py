@@ -99,11 +99,13 @@ def load():
 class RefMap:
     """The reference-side map: tracking state written by the reference's code only."""
 
-    def __init__(self, lib, orc_cfg):
+    def __init__(self, lib, orc_cfg, num_threads=None):
         self.lib = lib
         c = RefConfig()
         for name, _ in RefConfig._fields_:
             setattr(c, name, getattr(orc_cfg, name))
+        if num_threads is not None:
+            c.num_threads = num_threads
         if c.num_threads < 1:  # (0 = "all cores" on the oracle's side; the reference's integrators want a count)
             c.num_threads = 2
         self.cfg = c

@@ -564,3 +564,78 @@ def test_whole_active_window_equals_reference_code():
     for g, w in zip(got_objects, want_objects):
         assert np.array_equal(g["points"], w["points"]) and np.array_equal(g["bbox_min"], w["bbox_min"]) and np.array_equal(g["bbox_max"], w["bbox_max"])
     assert outputs >= 5 and seen_dyn > 0 and seen_archived > 0 and len(got_objects) >= 1, (outputs, seen_dyn, seen_archived, len(got_objects))
+
+
+@needs_ref
+def test_cluster_ids_saturate_at_255_like_the_reference():
+    """writeClustersToData (free_space_motion_detector.cpp:384-395): the 255th and every later cluster share the id 255.  450 small
+    things appear at once in space a still camera has seen free: 450 clusters on both sides, ids 1 .. 255, the same painted
+    pixels.  (WHICH clusters come before the 255th follows the visiting order, which is implementation-defined in the reference --
+    ASSUMPTIONS.md C.1 -- so the classes themselves are not compared.)"""
+    W, H = 640, 480
+    s = SyntheticStream(W, H, threads=2, with_mover=False)
+    cfg = _cfg(voxel_size=0.04, truncation_distance=0.08, md_min_separation_distance=0.5, md_max_range=5.0, temporal_window=3.0, temporal_buffer=0.3)
+    sen = po.OrcSensor(W, H, s.fx, s.fy, s.cx, s.cy, 0.1, 5.0)
+    m, r = po.OracleMap(cfg), pyref.RefMap(LIB, cfg)
+    pose0 = s.pose(0)
+    for i in range(8):
+        fr = s.render(i, pose=pose0)
+        depth = fr["depth"].copy()
+        if i == 7:
+            for v in range(10, H - 10, 24):
+                for u in range(10, W - 10, 24):
+                    if depth[v, u] > 1.6:
+                        depth[v:v + 2, u:u + 2] = 1.2
+        n_o, dyn_o, seeds_o = m.detect_motion(sen, fr["stamp"], fr["pose"], depth)
+        rng, vtx = m.parse_input(sen, fr["pose"], depth)
+        n_r, dyn_r, seeds_r, _, _ = r.detect_motion(fr["stamp"], fr["pose"][2, 3], rng, vtx, cap_clusters=1024)
+        assert (n_o, seeds_o) == (n_r, seeds_r) and np.array_equal(dyn_o > 0, dyn_r > 0), i
+        if i == 7:
+            assert n_r > 300
+            for dyn in (dyn_o, dyn_r):
+                ids = np.unique(dyn[dyn > 0])
+                assert ids.min() == 1 and ids.max() == 255 and len(ids) == 255
+        m.integrate(sen, fr["stamp"], fr["pose"], depth, fr["rgb"], fr["label"], mask=dyn_o)
+        for b in m.block_indices():
+            blk = m.get_block(b, likelihoods=False)
+            r.put_block(b, blk["distance"], blk["last_observed"], blk["block_flags"] & 4)
+        m.update_tracking(fr["stamp"])
+        r.update_tracking(fr["stamp"])
+
+
+@needs_ref
+def test_reference_results_do_not_depend_on_its_thread_count():
+    """The reference splits the image into column stripes (free_space_motion_detector.cpp:113-160, u_step rounding at :114-117) and
+    the block lists over num_threads workers (tracking_integrator.cpp:82-103): 1, 3 and 7 threads give the same map and the same
+    clusters, which is what lets one device pass stand for all of them."""
+    W, H = 100, 75  # (100 columns: 3 and 7 stripes do not divide it)
+    s = SyntheticStream(W, H, threads=1)
+    cfg = _cfg(voxel_size=0.2, truncation_distance=0.4, md_min_cluster_size=5, md_min_separation_distance=2.0, md_max_range=5.0,
+               temporal_window=0.9, temporal_buffer=0.5)
+    sen = po.OrcSensor(W, H, s.fx, s.fy, s.cx, s.cy, 0.1, 5.0)
+    m = po.OracleMap(cfg)
+    refs = [pyref.RefMap(LIB, cfg, num_threads=k) for k in (1, 3, 7)]
+    fired = 0
+    for i in range(24):
+        fr = s.render(i)
+        n_o, dyn_o, seeds_o = m.detect_motion(sen, fr["stamp"], fr["pose"], fr["depth"])
+        rng, vtx = m.parse_input(sen, fr["pose"], fr["depth"])
+        outs = [r.detect_motion(fr["stamp"], fr["pose"][2, 3], rng, vtx) for r in refs]
+        for n_r, dyn_r, seeds_r, _, _ in outs:
+            assert (n_r, seeds_r) == (n_o, seeds_o) and _same_partition(dyn_o, dyn_r), i
+        fired += n_o
+        m.integrate(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"], mask=dyn_o)
+        idx = m.block_indices()
+        blocks = {tuple(b): m.get_block(b, likelihoods=False) for b in idx}
+        m.update_tracking(fr["stamp"])
+        for r in refs:
+            for b in idx:
+                blk = blocks[tuple(b)]
+                r.put_block(b, blk["distance"], blk["last_observed"], blk["block_flags"] & 4)
+            r.update_tracking(fr["stamp"])
+        for b in idx:
+            a = m.get_block(b, likelihoods=False)
+            for r in refs:
+                e = r.get_block(b)
+                assert np.array_equal(a["last_occupied"], e["last_occupied"]) and np.array_equal(a["flags"] & 7, e["flags"]), (i, tuple(b))
+    assert fired > 0

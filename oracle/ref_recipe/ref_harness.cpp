@@ -259,9 +259,15 @@ int64_t ref_tracker_replay(const char* scenario, char* out, int64_t cap) {
     int id, cat;
     float lo[3], hi[3];
     std::vector<std::array<int64_t, 3>> voxels;
+    std::vector<std::array<int, 2>> pixels;       // track_by pixels: the cluster's pixels and their world-frame vertices
+    std::vector<std::array<float, 3>> points;
   };
   std::vector<Cl> clusters;
   uint64_t stamp = 0;
+  bool by_pixels = false;
+  int img_w = 1, img_h = 1;
+  hydra::Sensor sensor;
+  double pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   while (in >> tok) {
     if (tok == "C") {
       std::string kind, by, assoc;
@@ -269,8 +275,10 @@ int64_t ref_tracker_replay(const char* scenario, char* out, int64_t cap) {
       in >> kind >> by >> assoc >> c.min_semantic_iou >> c.min_cosine_sim >> c.min_cross_iou >> c.max_dynamic_distance >> c.temporal_window >>
           c.min_num_observations >> c.voxel_size;
       by_voxels = by == "voxels";
+      by_pixels = by == "pixels";
       voxel_size = c.voxel_size;
-      c.track_by = by_voxels ? khronos::MaxIoUTracker::Config::TrackBy::kVoxels : khronos::MaxIoUTracker::Config::TrackBy::kBouningBox;
+      c.track_by = by_pixels ? khronos::MaxIoUTracker::Config::TrackBy::kPixels
+                             : (by_voxels ? khronos::MaxIoUTracker::Config::TrackBy::kVoxels : khronos::MaxIoUTracker::Config::TrackBy::kBouningBox);
       c.semantic_association = assoc == "assign_track" ? khronos::MaxIoUTracker::Config::SemanticAssociation::kAssignTrack
                                                        : khronos::MaxIoUTracker::Config::SemanticAssociation::kAssignCluster;
       if (kind == "external") {  // external_tracker.cpp:59-143
@@ -284,6 +292,24 @@ int64_t ref_tracker_replay(const char* scenario, char* out, int64_t cap) {
     } else if (tok == "F") {
       in >> stamp;
       clusters.clear();
+    } else if (tok == "I") {  // image size and intrinsics (track_by pixels)
+      in >> img_w >> img_h >> sensor.fx >> sensor.fy >> sensor.cx >> sensor.cy;
+      sensor.width = img_w;
+      sensor.height = img_h;
+    } else if (tok == "T") {  // the frame's world_T_sensor, row-major
+      for (double& v : pose) in >> v;
+    } else if (tok == "SP" || tok == "DP") {  // a cluster as pixels + vertices: <id> [<category>] <n> (<u> <v> <x> <y> <z>)*
+      Cl c;
+      c.semantic = tok == "SP";
+      c.cat = -1;
+      in >> c.id;
+      if (c.semantic) in >> c.cat;
+      size_t n;
+      in >> n;
+      c.pixels.resize(n);
+      c.points.resize(n);
+      for (size_t i = 0; i < n; ++i) in >> c.pixels[i][0] >> c.pixels[i][1] >> c.points[i][0] >> c.points[i][1] >> c.points[i][2];
+      clusters.push_back(std::move(c));
     } else if (tok == "S" || tok == "D") {
       Cl c;
       c.semantic = tok == "S";
@@ -303,7 +329,16 @@ int64_t ref_tracker_replay(const char* scenario, char* out, int64_t cap) {
       for (const Cl& c : clusters) n_px += by_voxels ? c.voxels.size() : 2;
       hydra::InputData input;
       input.timestamp_ns = stamp;
-      input.vertex_map = cv::Mat(1, static_cast<int>(std::max<size_t>(n_px, 1)), sizeof(cv::Vec3f));
+      if (by_pixels) {
+        input.vertex_map = cv::Mat(img_h, img_w, sizeof(cv::Vec3f));
+        input.sensor = sensor;
+        for (int r = 0; r < 3; ++r) {
+          for (int cc = 0; cc < 3; ++cc) input.world_T_sensor.linear(r, cc) = pose[4 * r + cc];
+          input.world_T_sensor.translation()[r] = pose[4 * r + 3];
+        }
+      } else {
+        input.vertex_map = cv::Mat(1, static_cast<int>(std::max<size_t>(n_px, 1)), sizeof(cv::Vec3f));
+      }
       khronos::FrameData data(input);
       const spatial_hash::Grid<khronos::GlobalIndex> grid(voxel_size);
       cv::Mat vm = data.input.vertex_map;  // (shares the pixels)
@@ -317,7 +352,13 @@ int64_t ref_tracker_replay(const char* scenario, char* out, int64_t cap) {
           v[0] = p[0], v[1] = p[1], v[2] = p[2];
           mc.pixels.emplace_back(u++, 0);
         };
-        if (by_voxels) {
+        if (by_pixels) {
+          for (size_t i = 0; i < c.pixels.size(); ++i) {
+            cv::Vec3f& v = vm.at<cv::Vec3f>(c.pixels[i][1], c.pixels[i][0]);
+            v[0] = c.points[i][0], v[1] = c.points[i][1], v[2] = c.points[i][2];
+            mc.pixels.emplace_back(c.pixels[i][0], c.pixels[i][1]);
+          }
+        } else if (by_voxels) {
           for (const auto& v : c.voxels) put(grid.toPoint(khronos::GlobalIndex(v[0], v[1], v[2])));
         } else {
           put(khronos::Point(c.lo[0], c.lo[1], c.lo[2]));
@@ -333,10 +374,10 @@ int64_t ref_tracker_replay(const char* scenario, char* out, int64_t cap) {
         char buf[512];
         std::snprintf(buf, sizeof(buf),
                       "%s{\"id\": %d, \"dyn\": %d, \"active\": %d, \"conf\": %.9g, \"first\": %llu, \"last\": %llu, \"cat\": %d, "
-                      "\"n_obs\": %zu, \"obs\": [%llu, %d, %d], \"n_vox\": %zu, \"centroid\": [%.9g, %.9g, %.9g]}",
+                      "\"n_obs\": %zu, \"obs\": [%llu, %d, %d], \"n_vox\": %zu, \"n_pts\": %zu, \"centroid\": [%.9g, %.9g, %.9g]}",
                       first ? "" : ", ", t.id, int(t.is_dynamic), int(t.is_active), t.confidence, static_cast<unsigned long long>(t.first_seen),
                       static_cast<unsigned long long>(t.last_seen), t.semantics ? t.semantics->category_id : -1, t.observations.size(),
-                      static_cast<unsigned long long>(o.stamp), o.semantic_cluster_id, o.dynamic_cluster_id, t.last_voxels.size(),
+                      static_cast<unsigned long long>(o.stamp), o.semantic_cluster_id, o.dynamic_cluster_id, t.last_voxels.size(), t.last_points.size(),
                       t.is_dynamic ? t.last_centroid[0] : 0.f, t.is_dynamic ? t.last_centroid[1] : 0.f, t.is_dynamic ? t.last_centroid[2] : 0.f);
         result += buf;
         first = false;

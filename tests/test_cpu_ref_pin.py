@@ -639,3 +639,97 @@ def test_reference_results_do_not_depend_on_its_thread_count():
                 e = r.get_block(b)
                 assert np.array_equal(a["last_occupied"], e["last_occupied"]) and np.array_equal(a["flags"] & 7, e["flags"]), (i, tuple(b))
     assert fired > 0
+
+
+def _pixel_scenario(rng, n_frames, W, H, fx, fy, cx, cy):
+    """Blobs of pixels with world-frame vertices under slowly drifting, nearly-identity poses (so that the reference's
+    re-projection of the previous observation -- with the pose applied as world_T_sensor, ASSUMPTIONS.md A.8 -- lands in the
+    image): persistent static things with categories, one dynamic thing, some flicker."""
+    f32 = np.float32
+    blobs = [dict(u=int(rng.integers(10, W - 40)), v=int(rng.integers(10, H - 40)), w=int(rng.integers(8, 22)), h=int(rng.integers(8, 22)),
+                  z=float(rng.uniform(1.0, 3.0)), cat=int(rng.integers(7, 10)), p_seen=float(rng.uniform(0.7, 1.0))) for _ in range(5)]
+    mover = dict(u=20.0, v=H / 2.0, w=12, h=16, z=1.5)
+    frames = []
+    for i in range(n_frames):
+        stamp = 1_000_000_000 + i * 100_000_000
+        T = np.eye(4)
+        T[:3, 3] = [0.004 * i, -0.003 * i, 0.002 * i]
+
+        def cluster(u0, v0, w, h, z):
+            us, vs = np.meshgrid(np.arange(u0, u0 + w), np.arange(v0, v0 + h))
+            us, vs = us.ravel(), vs.ravel()
+            keep = (us >= 0) & (us < W) & (vs >= 0) & (vs < H) & (rng.uniform(size=us.size) < 0.9)
+            us, vs = us[keep], vs[keep]
+            d = (z + 0.05 * rng.standard_normal(us.size)).astype(f32)
+            pc = np.stack([(us.astype(f32) - f32(cx)) / f32(fx) * d, (vs.astype(f32) - f32(cy)) / f32(fy) * d, d], axis=1).astype(f32)
+            pw = (pc.astype(np.float64) + T[:3, 3]).astype(f32)
+            return [(int(a), int(b)) for a, b in zip(us, vs)], pw
+        sem, dyn = [], []
+        for b in blobs:
+            if rng.uniform() > b["p_seen"]:
+                continue
+            px, pw = cluster(b["u"] + int(rng.integers(-1, 2)), b["v"] + int(rng.integers(-1, 2)), b["w"], b["h"], b["z"])
+            if len(px) >= 4:
+                sem.append(dict(id=len(sem) + 1, category=b["cat"], pixels=px, points=pw, box=(pw.min(0), pw.max(0))))
+        if i % 6 != 4:
+            mover["u"] += 2.5
+            px, pw = cluster(int(mover["u"]), int(mover["v"]), mover["w"], mover["h"], mover["z"])
+            dyn.append(dict(id=1, pixels=px, points=pw, box=(pw.min(0), pw.max(0))))
+            if i % 4 == 0:  # the semantic detector sees the mover too
+                sem.append(dict(id=len(sem) + 1, category=19, pixels=px[: len(px) * 3 // 4], points=pw[: len(px) * 3 // 4],
+                                box=(pw.min(0), pw.max(0))))
+        # one vertex per PIXEL, as in a vertex map (clusters that share a pixel -- the mover in front of a blob -- read the same one)
+        vertex = {}
+        for c in sem + dyn:
+            for px, pt in zip(c["pixels"], c["points"]):
+                vertex.setdefault(px, pt)
+        for c in sem + dyn:
+            c["points"] = np.array([vertex[px] for px in c["pixels"]], f32).reshape(-1, 3)
+            c["box"] = (c["points"].min(0), c["points"].max(0))
+        frames.append((stamp, T, sem, dyn))
+    return frames
+
+
+@needs_ref
+@pytest.mark.parametrize("association", ["assign_cluster", "assign_track"])
+def test_pixel_tracker_restatement_equals_reference_code(association):
+    """track_by: pixels (the reference's default; max_iou_tracker.cpp:497-503, 541-549, 578-600): tests/py_tracker.py with
+    oracle/np_oracle.py's re-projection -- the restatement the product's pixel mode (khr_pixel_iou) is held to on the GPU --
+    against the reference's own MaxIoUTracker on clusters given as pixels + world-frame vertices, with the sensor pose applied
+    the way the reference applies it."""
+    import json
+    import py_tracker
+    W, H, fx, fy, cx, cy = 160, 120, 80.0, 80.0, 80.0, 60.0
+    cfg = dict(min_semantic_iou=0.2, min_cross_iou=0.1, max_dynamic_distance=0.6, temporal_window=0.45, min_num_observations=4, voxel_size=0.2)
+    for seed in (7, 8):
+        frames = _pixel_scenario(np.random.default_rng(seed), 30, W, H, fx, fy, cx, cy)
+        lines = ["C maxiou pixels %s %r 0.0 %r %r %r %d %r" % (association, cfg["min_semantic_iou"], cfg["min_cross_iou"], cfg["max_dynamic_distance"],
+                                                                cfg["temporal_window"], cfg["min_num_observations"], cfg["voxel_size"]),
+                 "I %d %d %r %r %r %r" % (W, H, fx, fy, cx, cy)]
+        for stamp, T, sem, dyn in frames:
+            lines.append("F %d" % stamp)
+            lines.append("T " + " ".join(repr(float(x)) for x in T.ravel()))
+            for tag, cl in (("SP", sem), ("DP", dyn)):
+                for c in cl:
+                    head = "%s %d " % (tag, c["id"]) + ("%d " % c["category"] if tag == "SP" else "") + "%d " % len(c["pixels"])
+                    lines.append(head + " ".join("%d %d %.9g %.9g %.9g" % (u, v, p[0], p[1], p[2]) for (u, v), p in zip(c["pixels"], c["points"])))
+            lines.append("E")
+        want = [json.loads(line) for line in pyref.tracker_replay(LIB, "\n".join(lines) + "\n").strip().splitlines()]
+        trk = py_tracker.MaxIoUTracker("pixels", association, cfg["min_semantic_iou"], 0.0, cfg["min_cross_iou"], cfg["max_dynamic_distance"],
+                                       cfg["temporal_window"], cfg["min_num_observations"], cfg["voxel_size"])
+        assert len(want) == len(frames)
+        shared = 0
+        for (stamp, T, sem, dyn), w in zip(frames, want):
+            trk.cam = (T, fx, fy, cx, cy, W, H)
+            trk.process(stamp, sem, dyn)
+            assert len(trk.tracks) == len(w), (seed, stamp)
+            for t, b in zip(trk.tracks, w):
+                assert (t.id, int(t.is_dynamic), int(t.is_active), t.first_seen, t.last_seen, t.category if t.has_semantics else -1,
+                        len(t.observations), list(t.observations[-1]), len(t.last_points)) == \
+                    (b["id"], b["dyn"], b["active"], b["first"], b["last"], b["cat"], b["n_obs"], b["obs"], b["n_pts"]), (seed, stamp, b)
+                assert float(t.confidence) == b["conf"]
+                if t.is_dynamic:
+                    assert np.allclose(t.last_centroid, b["centroid"], rtol=1e-5, atol=1e-5)
+                    shared += t.observations[-1][1] > 0 and t.observations[-1][2] > 0
+        assert max(len(w) for w in want) >= 4 and any(t["dyn"] for t in want[-1]) and any(not t["active"] for w in want for t in w)
+        assert any(t["n_obs"] >= 5 and not t["dyn"] for t in want[-1]), "static tracks must have been re-associated through the pixel IoU"

@@ -189,6 +189,8 @@ struct orc_map {
   std::vector<Block*> ef_work;  // tracking-updated blocks collected by phase 1
   // mesh halo: the three low voxel planes of blocks owned by other ranks (record layout: khronos_amd.h)
   std::unordered_map<I3, std::vector<uint32_t>, I3Hash> mesh_halo;
+  // the pixel LISTS (with the reference's duplicates) of the clusters the latest motion detection kept, in id order
+  std::vector<std::vector<int32_t>> last_md_pixels;
 
   Block* find(const I3& i) const {
     auto it = blocks.find(i);
@@ -1263,15 +1265,40 @@ int orc_detect_motion_from_keys(orc_map* m, int W, int H, const uint64_t* keys, 
   }
   // applyClusterLevelFilters :365-379 + writeClustersToData :381-399
   int id = 1, n_out = 0;
+  m->last_md_pixels.clear();
   for (size_t ci = 0; ci < nc; ++ci) {
     if (!keep[ci]) continue;
     const int size = static_cast<int>(clusters[ci].pixels.size());
     if (size < c.md_min_cluster_size || size > c.md_max_cluster_size) continue;
+    m->last_md_pixels.push_back(clusters[ci].pixels);
     for (int32_t px : clusters[ci].pixels) dynamic_image_out[px] = id;
     if (id < 255) ++id;
     ++n_out;
   }
   return n_out;
+}
+
+// the kept clusters of the latest orc_detect_motion* call as the reference's consumers see them: length of cluster.pixels (a
+// boundary voxel's pixels once per adjacent seed, :255-265) and the mean of the listed pixels' vertices -- what
+// MeshObjectExtractor::extractDynamicObject (mesh_object_extractor.cpp:136-147) and MaxIoUTracker::computeCentroid for
+// track_by pixels (max_iou_tracker.cpp:541-548) compute.  Sum in double, in list order.
+int64_t orc_last_motion_clusters(const orc_map* m, const orc_sensor* s, const orc_frame* f, int64_t* n_listed_out, float* centroid_out,
+                                 int64_t cap) {
+  const int W = s->width, H = s->height;
+  std::vector<float> range(static_cast<size_t>(W) * H), vertex(static_cast<size_t>(W) * H * 3);
+  orc_parse_input(&m->cfg, s, f->world_T_sensor, f->depth, range.data(), vertex.data());
+  int64_t k = 0;
+  for (const auto& px : m->last_md_pixels) {
+    if (k < cap) {
+      double sum[3] = {0, 0, 0};
+      for (int32_t p : px)
+        for (int a = 0; a < 3; ++a) sum[a] += static_cast<double>(vertex[3 * static_cast<size_t>(p) + a]);
+      n_listed_out[k] = static_cast<int64_t>(px.size());
+      for (int a = 0; a < 3; ++a) centroid_out[3 * k + a] = static_cast<float>(sum[a] / static_cast<double>(px.size()));
+    }
+    ++k;
+  }
+  return k;
 }
 
 int orc_detect_motion(orc_map* m, const orc_sensor* s, const orc_frame* f, int32_t* dynamic_image_out,

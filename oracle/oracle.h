@@ -126,6 +126,12 @@ void orc_clear_updated(orc_map* m);
 int orc_detect_motion(orc_map* m, const orc_sensor* s, const orc_frame* f, int32_t* dynamic_image_out,
                       int64_t* n_seeds_out);
 
+/* the clusters the latest orc_detect_motion* call kept, in id order: length of the reference's cluster.pixels list (duplicates
+ * included) and the mean vertex over that list -- the centroid extractDynamicObject (mesh_object_extractor.cpp:136-147) and the
+ * pixel-mode tracker (max_iou_tracker.cpp:541-548) use.  returns the number of clusters */
+int64_t orc_last_motion_clusters(const orc_map* m, const orc_sensor* s, const orc_frame* f, int64_t* n_listed_out, float* centroid_out,
+                                 int64_t cap);
+
 /* the two stages of orc_detect_motion, for the multi-GPU key exchange (format: include/khronos_amd.h) */
 void orc_motion_keys(orc_map* m, const orc_sensor* s, const orc_frame* f, uint64_t* keys_out);
 int orc_detect_motion_from_keys(orc_map* m, int W, int H, const uint64_t* keys, int32_t* dynamic_image_out,

@@ -231,6 +231,15 @@ class OracleMap:
         n = self.lib.orc_detect_motion(self.h, C.byref(sensor), C.byref(f), _ptr(dyn), C.byref(ns))
         return n, dyn, ns.value
 
+    def last_motion_clusters(self, sensor, stamp_ns, T, depth, cap=256):
+        """(listed pixel counts, listed-mean centroids) of the clusters the latest detect_motion kept, in id order"""
+        f, keep = self._frame(stamp_ns, T, depth)
+        n_listed = np.zeros(cap, np.int64)
+        cen = np.zeros((cap, 3), np.float32)
+        self.lib.orc_last_motion_clusters.restype = C.c_int64
+        n = self.lib.orc_last_motion_clusters(self.h, C.byref(sensor), C.byref(f), _ptr(n_listed), _ptr(cen), cap)
+        return n_listed[:min(n, cap)], cen[:min(n, cap)]
+
     def motion_keys(self, sensor, stamp_ns, T, depth):
         f, keep = self._frame(stamp_ns, T, depth)
         keys = np.zeros((sensor.height, sensor.width), np.uint64)

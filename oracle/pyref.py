@@ -54,7 +54,7 @@ def load():
     lib.ref_get_block.restype = C.c_int
     lib.ref_get_block.argtypes = [C.c_void_p] + [C.c_void_p] * 5
     lib.ref_detect_motion.restype = C.c_int
-    lib.ref_detect_motion.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_double] + [C.c_void_p] * 6 + [C.c_int]
+    lib.ref_detect_motion.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_double] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]
     lib.ref_detect_objects.restype = C.c_int
     lib.ref_detect_objects.argtypes = ([C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_float, C.c_float] + [C.c_void_p] * 4 + [C.c_int])
     lib.ref_tracker_replay.restype = C.c_int64
@@ -159,8 +159,10 @@ class RefMap:
         ns = C.c_int64(0)
         npx = np.zeros(cap_clusters, np.int64)
         bbox = np.zeros((cap_clusters, 6), np.float32)
+        cen = np.zeros((cap_clusters, 3), np.float32)
         n = self.lib.ref_detect_motion(self.h, w, h, int(stamp_ns), float(sensor_z), _ptr(r), _ptr(v), _ptr(dyn), C.addressof(ns),
-                                       _ptr(npx), _ptr(bbox), cap_clusters)
+                                       _ptr(npx), _ptr(bbox), cap_clusters, _ptr(cen))
+        self.last_centroids = cen[:min(n, cap_clusters)]  # (listed-mean centroids, utils::computeCentroid over cluster.pixels)
         return n, dyn, ns.value, npx[:min(n, cap_clusters)], bbox[:min(n, cap_clusters)]
 
 

@@ -157,7 +157,8 @@ int ref_get_block(const RefMap* r, const int32_t* idx, uint64_t* last_observed, 
  * world-frame vertex map (the input conversion is external).  dynamic_out: H*W cluster ids (0 = static);
  * bbox_out: up to cap_clusters x 6 floats (min, max) of the clusters' bounding boxes.  returns the number of clusters. */
 int ref_detect_motion(RefMap* r, int W, int H, uint64_t stamp, double sensor_z, const float* range, const float* vertex,
-                      int32_t* dynamic_out, int64_t* n_seeds_out, int64_t* n_cluster_pixels_out, float* bbox_out, int cap_clusters) {
+                      int32_t* dynamic_out, int64_t* n_seeds_out, int64_t* n_cluster_pixels_out, float* bbox_out, int cap_clusters,
+                      float* centroid_out) {
   hydra::InputData in;
   in.timestamp_ns = stamp;
   in.range_image = cv::Mat(H, W, sizeof(float));
@@ -187,6 +188,15 @@ int ref_detect_motion(RefMap* r, int W, int H, uint64_t stamp, double sensor_z, 
           bbox_out[6 * k + a] = cl.bounding_box.min[a];
           bbox_out[6 * k + 3 + a] = cl.bounding_box.max[a];
         }
+      if (centroid_out) {  // the centroid as extractDynamicObject forms it (mesh_object_extractor.cpp:136-147): over cluster.pixels
+        khronos::Points points;
+        for (const khronos::Pixel& px : cl.pixels) {
+          const auto& v = data.input.vertex_map.at<hydra::InputData::VertexType>(px.v, px.u);
+          points.emplace_back(v[0], v[1], v[2]);
+        }
+        const khronos::Point c = khronos::utils::computeCentroid(points);
+        for (int a = 0; a < 3; ++a) centroid_out[3 * k + a] = c[a];
+      }
     }
     ++k;
   }

@@ -89,6 +89,7 @@ def test_oracle_equals_reference_code_over_a_sequence(case):
         n_o, dyn_o, seeds_o = m.detect_motion(sen, stamp, fr["pose"], depth)
         rng, vtx = m.parse_input(sen, fr["pose"], depth)  # the input conversion is external (ASSUMPTIONS.md A.2)
         n_r, dyn_r, seeds_r, npx_r, bbox_r = r.detect_motion(stamp, fr["pose"][2, 3], rng, vtx)
+        listed_o = m.last_motion_clusters(sen, stamp, fr["pose"], depth)
         assert seeds_o == seeds_r, (case, i, "ever-free seed voxels")
         assert n_o == n_r, (case, i, "clusters after merge + filter")
         assert _same_partition(dyn_o, dyn_r), (case, i, "painted clusters")
@@ -98,6 +99,14 @@ def test_oracle_equals_reference_code_over_a_sequence(case):
             #  :255-265 -- the size filter counts those, and the oracle restates that literally)
             assert 0 < int(px.sum()) <= int(npx_r[k])
             assert np.array_equal(bbox_r[k, :3], vtx[px].min(axis=0)) and np.array_equal(bbox_r[k, 3:], vtx[px].max(axis=0))
+            # the LENGTH of the reference's pixel list and the mean vertex over it (what extractDynamicObject and the pixel-mode
+            # tracker take as the cluster's centroid, mesh_object_extractor.cpp:136-147): the oracle's restatement of both
+            oid = np.unique(dyn_o[px])
+            assert len(oid) == 1
+            n_listed_o, cen_o = listed_o[0][oid[0] - 1], listed_o[1][oid[0] - 1]
+            assert int(n_listed_o) == int(npx_r[k]), (case, i, k)
+            assert np.allclose(cen_o, r.last_centroids[k], rtol=2e-5, atol=2e-5), (case, i, k)  # (the reference sums in float, in list order)
+            seen["dup"] = seen.get("dup", 0) + int(npx_r[k] > px.sum())
         seen["seeds"] += seeds_r
         seen["clusters"] += n_r
         seen["multi"] += n_r > 1
@@ -128,6 +137,7 @@ def test_oracle_equals_reference_code_over_a_sequence(case):
             m.clear_updated()
     # the sequence must have exercised what it claims to pin
     assert seen["seeds"] > 0 and seen["clusters"] > 0 and seen["removed"] > 0 and seen["ever_free"] > 0 and seen["to_remove"] > 0, seen
+    assert seen.get("dup", 0) > 0, "no cluster listed a pixel twice: the duplicate rule was not exercised"
     if case == "fine-merge":
         assert seen["multi"] > 0, seen
 

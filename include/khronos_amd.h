@@ -147,7 +147,10 @@ typedef struct khr_cluster {
                                   seed, :255-265) -- the quantity the size filter uses */
   uint32_t num_pixels_painted; /* pixels that carry this id in dynamic_image (later clusters overwrite earlier ones) */
   float bbox_min[3], bbox_max[3]; /* world-frame AABB of the painted pixels' vertices (:396-397) */
-  float centroid[3];           /* mean vertex of the painted pixels (utils::computeCentroid role) */
+  float centroid[3];           /* dynamic clusters: mean vertex over the reference's pixel LIST (cluster.pixels, duplicates
+                                  included) -- what utils::computeCentroid gives extractDynamicObject
+                                  (mesh_object_extractor.cpp:136-147) and the pixel-mode tracker (max_iou_tracker.cpp:541-548);
+                                  semantic clusters (no duplicates): mean vertex of the cluster's pixels */
   int32_t semantic_id;         /* SemanticClusterInfo::category_id of a semantic cluster, -1 for dynamic clusters */
 } khr_cluster;
 

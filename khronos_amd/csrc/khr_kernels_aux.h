@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256) void k_md_boundary_insert(const uint64_t* __re
 // occupied table slots -> compact lists (ids are arbitrary but stable for the rest of the frame)
 __global__ __launch_bounds__(256) void k_md_compact(VoxTable t, uint64_t* __restrict__ list_keys,
                                                    uint32_t* __restrict__ list_counts, uint32_t* __restrict__ n_out,
-                                                   uint32_t cap, int32_t* __restrict__ zero_per_entry) {
+                                                   uint32_t cap, int32_t* __restrict__ zero_per_entry,
+                                                   int32_t* __restrict__ zero_per_entry2 = nullptr) {
   // one list append per WORKGROUP (workgroup scan): the entries are scattered over the table, so nearly every wave has one
   // or two, and an append per wave was ~1000 atomics on one address (~10 us)
   __shared__ uint32_t s_cnt[4], s_base;
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(256) void k_md_compact(VoxTable t, uint64_t* __rest
       list_counts[id] = t.counts[h];
       t.ids[h] = id;
       if (zero_per_entry) zero_per_entry[id] = 0;  // final ids of the boundary voxels start at "none" (k_md_comp_finals raises them)
+      if (zero_per_entry2) zero_per_entry2[id] = 0;  // ... and their seed degrees at 0 (k_md_comp_finals counts them)
     }
   }
 }
@@ -563,7 +565,12 @@ struct CompFinals {
 __global__ __launch_bounds__(256) void k_md_comp_finals(const uint32_t* __restrict__ adj, const uint32_t* __restrict__ n_seeds, uint32_t cap,
                                                        int nn, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ root_idx,
                                                        const int32_t* __restrict__ comp_final, CompFinals inl, int32_t* __restrict__ seed_final,
-                                                       int32_t* __restrict__ bnd_final) {
+                                                       int32_t* __restrict__ bnd_final, int32_t* __restrict__ bnd_deg) {
+  // bnd_deg[b] = how many seeds of kept clusters list boundary voxel b: the reference appends b's pixels to cluster.pixels once
+  // per adjacent expanded seed (free_space_motion_detector.cpp:255-265), and every consumer that averages over that list
+  // (extractDynamicObject, the pixel-mode tracker) weights b's pixels by this count.  (Seeds of DIFFERENT kept clusters can only
+  // share a boundary voxel when min_separation_distance is 0 -- otherwise the clusters were merged -- and then the count covers
+  // both; ASSUMPTIONS.md A.8.)
   const uint32_t ns = min(*n_seeds, cap);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns * nn; i += gridDim.x * blockDim.x) {
     const uint32_t s = i / nn, j = i % nn;
@@ -571,7 +578,10 @@ __global__ __launch_bounds__(256) void k_md_comp_finals(const uint32_t* __restri
     const int32_t f = comp_final ? comp_final[ri] : inl.id[ri];
     if (j == 0) seed_final[s] = f;
     const uint32_t a = adj[i];
-    if (f && a != 0xffffffffu && !(a & 0x80000000u)) atomicMax(&bnd_final[a], f);
+    if (f && a != 0xffffffffu && !(a & 0x80000000u)) {
+      atomicMax(&bnd_final[a], f);
+      atomicAdd(&bnd_deg[a], 1);
+    }
   }
 }
 
@@ -581,7 +591,15 @@ struct ClusterAcc {
   uint32_t n_pixels;
   int32_t bmin[3], bmax[3];  // floats mapped to order-preserving ints
   float sum[3];
+  // the same over the reference's pixel LIST (a boundary voxel's pixels once per adjacent seed): its length and vertex sum
+  uint32_t n_listed;
+  float wsum[3];
 };
+__host__ __device__ inline void clusterAccReset(ClusterAcc& a) {
+  a.n_pixels = 0;
+  a.n_listed = 0;
+  for (int d = 0; d < 3; ++d) { a.bmin[d] = INT32_MAX; a.bmax[d] = INT32_MIN; a.sum[d] = 0.f; a.wsum[d] = 0.f; }
+}
 __device__ inline int32_t floatToOrdered(float f) {
   const int32_t i = __float_as_int(f);
   return i >= 0 ? i : i ^ 0x7fffffff;
@@ -600,20 +618,27 @@ __host__ __device__ inline float orderedToFloat(int32_t i) {
 // writeClustersToData (free_space_motion_detector.cpp:381-399): cluster id of the pixel's voxel (0 = none)
 __global__ __launch_bounds__(256) void k_md_paint(const uint64_t* __restrict__ keys, int n, VoxTable seeds, VoxTable bnd,
                                                  const int32_t* __restrict__ seed_final,
-                                                 const int32_t* __restrict__ bnd_final, int32_t* __restrict__ dyn) {
+                                                 const int32_t* __restrict__ bnd_final, int32_t* __restrict__ dyn,
+                                                 const int32_t* __restrict__ bnd_deg, uint8_t* __restrict__ dyn_weight) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t k = keys[i];
   if (k == ~0ull) return;
-  int id = 0;
+  int id = 0, w = 1;  // w: how often the reference's cluster.pixels lists this pixel
   if (k & kSeedBit) {
     const int h = voxFind(seeds, k & ~kSeedBit);
     if (h >= 0) id = seed_final[seeds.ids[h]];
   } else {
     const int h = voxFind(bnd, k);
-    if (h >= 0) id = bnd_final[bnd.ids[h]];
+    if (h >= 0) {
+      id = bnd_final[bnd.ids[h]];
+      w = bnd_deg[bnd.ids[h]];
+    }
   }
-  if (id) dyn[i] = id;
+  if (id) {
+    dyn[i] = id;
+    dyn_weight[i] = static_cast<uint8_t>(min(max(w, 1), 255));
+  }
 }
 
 // Per-cluster summary of an id image (ids 1..255), on demand: painted pixel count, AABB and sum of the pixels'
@@ -623,14 +648,14 @@ __global__ __launch_bounds__(256) void k_md_paint(const uint64_t* __restrict__ k
 // thousands of atomics on one address.
 constexpr int kAccTile = 32, kAccSlots = 8;
 __global__ __launch_bounds__(1024) void k_cluster_summary(DevFrame f, const int32_t* __restrict__ img,
-                                                         ClusterAcc* __restrict__ acc) {
+                                                         ClusterAcc* __restrict__ acc, const uint8_t* __restrict__ weight) {
+  // weight (may be nullptr = every pixel once): the per-pixel list multiplicities k_md_paint wrote beside the id image
   __shared__ int s_id[kAccSlots];
   __shared__ ClusterAcc s_acc[kAccSlots];
   if (threadIdx.x < kAccSlots) {
     s_id[threadIdx.x] = 0;
     ClusterAcc a;
-    a.n_pixels = 0;
-    for (int d = 0; d < 3; ++d) { a.bmin[d] = INT32_MAX; a.bmax[d] = INT32_MIN; a.sum[d] = 0.f; }
+    clusterAccReset(a);
     s_acc[threadIdx.x] = a;
   }
   __syncthreads();
@@ -638,10 +663,12 @@ __global__ __launch_bounds__(1024) void k_cluster_summary(DevFrame f, const int3
   const int u = (blockIdx.x % tiles_x) * kAccTile + (threadIdx.x & 31), v = (blockIdx.x / tiles_x) * kAccTile + (threadIdx.x >> 5);
   int id = 0;
   float pw[3] = {0.f, 0.f, 0.f};
+  float wt = 1.f;
   if (u < f.W && v < f.H) {
     const int i = v * f.W + u;
     id = img[i];
     if (id) {
+      if (weight) wt = static_cast<float>(weight[i]);
       const float d = f.depth[i];  // world-frame vertex of this pixel (:396-397)
       xform(f.Rw, f.tw, ((static_cast<float>(u) - f.cx) / f.fx) * d, ((static_cast<float>(v) - f.cy) / f.fy) * d, d, pw);
     }
@@ -653,20 +680,24 @@ __global__ __launch_bounds__(1024) void k_cluster_summary(DevFrame f, const int3
     const bool mine = id == cid;
     const unsigned long long grp = __ballot(mine);
     todo &= ~grp;
-    float mn[3], mx[3], sm[3];
+    float mn[3], mx[3], sm[3], ws[3];
+    float wn = mine ? wt : 0.f;  // (exact in float: at most 64 x 255)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       mn[c] = mine ? pw[c] : 3.0e38f;
       mx[c] = mine ? pw[c] : -3.0e38f;
       sm[c] = mine ? pw[c] : 0.f;
+      ws[c] = mine ? wt * pw[c] : 0.f;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
+      wn += __shfl_xor(wn, o);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
         mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
         sm[c] += __shfl_xor(sm[c], o);
+        ws[c] += __shfl_xor(ws[c], o);
       }
     }
     if (static_cast<int>(laneId()) == leader) {
@@ -681,11 +712,13 @@ __global__ __launch_bounds__(1024) void k_cluster_summary(DevFrame f, const int3
         }
       }
       atomicAdd(&a->n_pixels, static_cast<uint32_t>(__popcll(grp)));
+      atomicAdd(&a->n_listed, static_cast<uint32_t>(wn));
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         atomicMin(&a->bmin[c], floatToOrdered(mn[c]));
         atomicMax(&a->bmax[c], floatToOrdered(mx[c]));
         atomicAdd(&a->sum[c], sm[c]);
+        atomicAdd(&a->wsum[c], ws[c]);
       }
     }
   }
@@ -694,11 +727,13 @@ __global__ __launch_bounds__(1024) void k_cluster_summary(DevFrame f, const int3
     const ClusterAcc& l = s_acc[threadIdx.x];
     ClusterAcc* a = acc + s_id[threadIdx.x];
     atomicAdd(&a->n_pixels, l.n_pixels);
+    atomicAdd(&a->n_listed, l.n_listed);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       atomicMin(&a->bmin[c], l.bmin[c]);
       atomicMax(&a->bmax[c], l.bmax[c]);
       atomicAdd(&a->sum[c], l.sum[c]);
+      atomicAdd(&a->wsum[c], l.wsum[c]);
     }
   }
 }
@@ -714,8 +749,7 @@ __global__ __launch_bounds__(256) void k_publish_cluster_acc(ClusterAcc* __restr
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < n_ids; k += blockDim.x) {
     ClusterAcc a;
-    a.n_pixels = 0;
-    for (int d = 0; d < 3; ++d) { a.bmin[d] = INT32_MAX; a.bmax[d] = INT32_MIN; a.sum[d] = 0.f; }
+    clusterAccReset(a);
     acc[k] = a;
   }
   if (threadIdx.x == 0) {

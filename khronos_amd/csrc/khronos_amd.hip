@@ -63,6 +63,7 @@ struct FrameSlot {
   uint32_t* rgba = nullptr;
   int32_t* label = nullptr;
   int32_t* dyn = nullptr;
+  uint8_t* dynw = nullptr;  // beside the dynamic image: how often the reference's cluster.pixels lists each painted pixel (k_md_paint)
   int32_t* obj = nullptr;
   uint8_t* rgb_staging = nullptr;
   float* tile_max = nullptr;
@@ -83,6 +84,7 @@ struct FrameSlot {
   khr_frame meta{};
   bool valid = false, has_color = false, has_label = false, has_obj = false, objects_done = false;
   bool dyn_clean = false;  // the dynamic image is all zero (fresh from ingest, nothing painted yet)
+  bool dynw_valid = false; // the weight image belongs to the dynamic image (painted here, not installed by khr_set_frame_image)
   uint64_t aux_seq = 0;    // sequence number of the last auxiliary-stream batch that read / wrote this slot (0 = none)
   std::vector<khr_cluster> sem_clusters;  // semantic clusters of the frame in this slot (khr_detect_objects)
   std::vector<khr_cluster> clusters;  // dynamic clusters of the frame in this slot (ids, listed pixel counts)
@@ -240,6 +242,8 @@ struct khr_ctx {
   uint64_t *d_md_seed_keys = nullptr, *d_md_bnd_keys = nullptr;
   uint32_t *d_md_seed_counts = nullptr, *d_md_bnd_counts = nullptr;
   int32_t *d_md_seed_final = nullptr, *d_md_bnd_final = nullptr;
+  int32_t* d_md_bnd_deg = nullptr;       // per boundary voxel: seeds of kept clusters that list it (k_md_comp_finals / the host walk)
+  std::vector<int32_t> h_md_bnd_deg;
   ClusterAcc* d_md_acc = nullptr;  // [256], index = cluster id
   // device components of the seed graph: head = {S, B, R, 0} followed by the component records
   uint32_t *d_md_parent = nullptr, *d_md_rootidx = nullptr;
@@ -915,6 +919,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     A(devAlloc(c, &c->d_md_bnd_counts, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_seed_final, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_bnd_final, c->md_list_cap, false));
+    A(devAlloc(c, &c->d_md_bnd_deg, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_adj, static_cast<size_t>(c->md_list_cap) * 26, false));
     // (not zeroed: devAlloc's memset is queued on the context's NON-BLOCKING stream, and the synchronous copy of the reduction
     //  identities below runs on the null stream -- nothing orders the two, and a memset that lands second leaves zeros, i.e.
@@ -925,10 +930,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
       A(KHR_ENOMEM);
     {
       std::vector<ClusterAcc> init(256);
-      for (auto& a : init) {
-        a.n_pixels = 0;
-        for (int d = 0; d < 3; ++d) { a.bmin[d] = INT32_MAX; a.bmax[d] = INT32_MIN; a.sum[d] = 0.f; }
-      }
+      for (auto& a : init) clusterAccReset(a);
       if (rc == KHR_OK && hipMemcpy(c->d_md_acc, init.data(), sizeof(ClusterAcc) * 256, hipMemcpyHostToDevice) != hipSuccess) A(KHR_EDEVICE);
     }
   }
@@ -956,6 +958,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     A(devAlloc(c, &s.rgba, npx + 4, false));   // + pad: the band phase gathers colour pixel pairs like the range samples
     A(devAlloc(c, &s.label, npx, false));
     A(devAlloc(c, &s.dyn, npx));
+    A(devAlloc(c, &s.dynw, npx, false));
     A(devAlloc(c, &s.obj, npx));
     A(devAlloc(c, &s.rgb_staging, npx * 3, false));
     A(devAlloc(c, &s.tile_max, npx / 16 + 64, false));
@@ -1179,7 +1182,7 @@ int khr_upload_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fram
   c->begin_in_ingest = false;
   if (!on_device) HIP_TRY(hipStreamSynchronize(c->stream));  // caller buffers may be reused after return
   s.valid = true;
-  s.dyn_clean = true;
+  s.dyn_clean = true, s.dynw_valid = false;
   return slot;
 }
 
@@ -1196,6 +1199,7 @@ int khr_set_frame_image(khr_ctx* c, int slot, int which, const int32_t* image, i
   }
   if (which == 1) s.has_obj = image != nullptr;
   if (which == 0) s.dyn_clean = image == nullptr;
+  if (which == 0) s.dynw_valid = false;  // (an installed image brings no list multiplicities: its summaries count every pixel once)
   if (which == 1) {  // an object image written here is read by kernels of the auxiliary stream (voxel sets)
     const int rca = auxAfterMain(c);
     if (rca) return rca;
@@ -1726,7 +1730,7 @@ int khr_tick_ingest(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame
       s.tw = tw;
       s.th = th;
       s.valid = true;
-      s.dyn_clean = true;
+      s.dyn_clean = true, s.dynw_valid = false;
       t.depth_in[k] = fr.depth; t.rgb_in[k] = fr.color; t.label_in[k] = fr.label;
       t.depth[k] = s.depth; t.range[k] = s.range; t.rgba[k] = s.rgba; t.label[k] = s.label; t.dyn[k] = s.dyn;
       t.tile_max[k] = s.tile_max;
@@ -1847,7 +1851,7 @@ int khr_tick_adopt(khr_ctx* c, const khr_sensor* sensor, const khr_converted_fra
       s.tw = tw;
       s.th = th;
       s.valid = true;
-      s.dyn_clean = true;
+      s.dyn_clean = true, s.dynw_valid = false;
       s.x_range = fr.range;
       s.x_depth = fr.depth ? fr.depth : fr.range;
       s.x_rgba = fr.rgba;
@@ -2204,7 +2208,8 @@ static int clusterSummaryLaunch(khr_ctx* c, FrameSlot& s, int max_id) {
     return KHR_OK;
   }
   const int tiles = ((s.sensor.width + kAccTile - 1) / kAccTile) * ((s.sensor.height + kAccTile - 1) / kAccTile);
-  hipLaunchKernelGGL(k_cluster_summary, dim3(tiles), dim3(1024), 0, c->stream, makeDevFrame(c, s), s.dyn, c->d_md_acc);
+  hipLaunchKernelGGL(k_cluster_summary, dim3(tiles), dim3(1024), 0, c->stream, makeDevFrame(c, s), s.dyn, c->d_md_acc,
+                     s.dynw_valid ? static_cast<const uint8_t*>(s.dynw) : nullptr);
   if (++c->md_acc_ticket == 0) ++c->md_acc_ticket;
   hipLaunchKernelGGL(k_publish_cluster_acc, dim3(1), dim3(256), 0, c->stream, c->d_md_acc, reinterpret_cast<uint32_t*>(c->d_md_acc_host),
                      static_cast<uint32_t>(std::min(max_id + 1, 256)), c->d_pinned + 7, c->md_acc_ticket);
@@ -2268,7 +2273,7 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
     hipLaunchKernelGGL(k_md_boundary_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, near, bnd, seeds, nn, 0, d_box,
                        c->d_md_n + 3);
     hipLaunchKernelGGL(k_md_compact, dim3(gridFor(tsize)), dim3(256), 0, c->stream, bnd, c->d_md_bnd_keys, c->d_md_bnd_counts,
-                       c->d_md_n + 1, cap, c->d_md_bnd_final);
+                       c->d_md_n + 1, cap, c->d_md_bnd_final, c->d_md_bnd_deg);
     const uint32_t edge_cap = cap;
     uint32_t* const d_n_edges = c->d_md_scratch4 + 15;
     hipLaunchKernelGGL(k_md_adjacency, dim3(1024), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_n, seeds, bnd, nn, cap,
@@ -2368,10 +2373,11 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
       }
       // (the boundary voxels' final ids were zeroed by the compaction pass)
       hipLaunchKernelGGL(k_md_comp_finals, dim3(1024), dim3(256), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent,
-                         c->d_md_rootidx, fin_dev, inl, c->d_md_seed_final, c->d_md_bnd_final);
+                         c->d_md_rootidx, fin_dev, inl, c->d_md_seed_final, c->d_md_bnd_final, c->d_md_bnd_deg);
       hipLaunchKernelGGL(k_md_paint, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds, bnd, c->d_md_seed_final,
-                         c->d_md_bnd_final, s.dyn);
+                         c->d_md_bnd_final, s.dyn, c->d_md_bnd_deg, s.dynw);
       s.dyn_clean = false;
+      s.dynw_valid = true;
       HIP_TRY(hipGetLastError());
       {
         const int rcs = clusterSummaryLaunch(c, s, kept.back().first);
@@ -2516,9 +2522,10 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
   }
   lap("merge");
   // applyClusterLevelFilters (:365-379) + writeClustersToData (:381-399): later clusters overwrite earlier ones
-  std::vector<int32_t>&seed_final = c->h_md_seed_final, &bnd_final = c->h_md_bnd_final;
+  std::vector<int32_t>&seed_final = c->h_md_seed_final, &bnd_final = c->h_md_bnd_final, &bnd_deg = c->h_md_bnd_deg;
   seed_final.assign(S, 0);
   bnd_final.assign(std::max<uint32_t>(B, 1), 0);
+  bnd_deg.assign(std::max<uint32_t>(B, 1), 0);  // per boundary voxel: how many seeds of kept clusters list it (:255-265)
   int id = 1, n_out = 0;
   std::vector<std::pair<int, uint64_t>> kept;  // (id, pixel list length incl. duplicates)
   for (size_t ci = 0; ci < nc; ++ci) {
@@ -2526,7 +2533,13 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
     const int size = static_cast<int>(clusters[ci].n_pixels);
     if (size < c->cfg.md_min_cluster_size || size > c->cfg.md_max_cluster_size) continue;
     kept.emplace_back(id, clusters[ci].n_pixels);
-    for (uint32_t r : clusters[ci].seeds) seed_final[r] = id;
+    for (uint32_t r : clusters[ci].seeds) {
+      seed_final[r] = id;
+      for (int k = 0; k < nn; ++k) {
+        const uint32_t a = adj[static_cast<size_t>(r) * nn + k];
+        if (a != 0xffffffffu && !(a & 0x80000000u)) ++bnd_deg[a];
+      }
+    }
     for (uint32_t r : clusters[ci].bnds) bnd_final[r] = id;
     if (id < 255) ++id;
     ++n_out;
@@ -2535,9 +2548,11 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
     // the host vectors are context members, so the asynchronous upload may outlive this call
     HIP_TRY(hipMemcpyAsync(c->d_md_seed_final, seed_final.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, c->stream));
     if (B) HIP_TRY(hipMemcpyAsync(c->d_md_bnd_final, bnd_final.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, c->stream));
+    if (B) HIP_TRY(hipMemcpyAsync(c->d_md_bnd_deg, bnd_deg.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_md_paint, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds, bnd, c->d_md_seed_final,
-                       c->d_md_bnd_final, s.dyn);
+                       c->d_md_bnd_final, s.dyn, c->d_md_bnd_deg, s.dynw);
     s.dyn_clean = false;
+    s.dynw_valid = true;
     HIP_TRY(hipGetLastError());
     {
       const int rcs = clusterSummaryLaunch(c, s, kept.back().first);
@@ -2607,7 +2622,7 @@ int khr_detect_motion_from_keys(khr_ctx* c, int slot, const void* keys, int on_d
     src = holder.as<uint64_t>();
   }
   if (!s.dyn_clean) HIP_TRY(hipMemsetAsync(s.dyn, 0, sizeof(int32_t) * n, c->stream));
-  s.dyn_clean = true;
+  s.dyn_clean = true, s.dynw_valid = false;
   HIP_TRY(hipMemsetAsync(&c->m.counters[C_N_SEEDS], 0, sizeof(uint32_t), c->stream));
   hipLaunchKernelGGL(k_md_keys_import, dim3(gridFor(n)), dim3(256), 0, c->stream, src, n, c->d_keys, &c->m.counters[C_N_SEEDS]);
   HIP_TRY(hipMemcpyAsync(&c->h_pinned[0], &c->m.counters[C_N_SEEDS], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -2628,9 +2643,13 @@ int khr_mirror_dynamic(khr_ctx* c, int src, int dst) {
   FrameSlot& b = c->slots[dst];
   if (a.sensor.width != b.sensor.width || a.sensor.height != b.sensor.height) return fail(KHR_EINVAL, "the slots hold frames of different sizes");
   HIP_TRY(hipSetDevice(c->device));
-  if (!(a.dyn_clean && b.dyn_clean))
+  if (!(a.dyn_clean && b.dyn_clean)) {
     HIP_TRY(hipMemcpyAsync(b.dyn, a.dyn, sizeof(int32_t) * static_cast<size_t>(a.sensor.width) * a.sensor.height, hipMemcpyDeviceToDevice, c->stream));
+    if (a.dynw_valid)
+      HIP_TRY(hipMemcpyAsync(b.dynw, a.dynw, static_cast<size_t>(a.sensor.width) * a.sensor.height, hipMemcpyDeviceToDevice, c->stream));
+  }
   b.dyn_clean = a.dyn_clean;
+  b.dynw_valid = a.dynw_valid;
   b.clusters = a.clusters;
   return KHR_OK;
 }
@@ -2660,7 +2679,9 @@ int khr_get_dynamic_clusters(khr_ctx* c, int slot, khr_cluster* out, int cap) {
     for (int d = 0; d < 3; ++d) {
       k.bbox_min[d] = a.n_pixels ? orderedToFloat(a.bmin[d]) : 0.f;
       k.bbox_max[d] = a.n_pixels ? orderedToFloat(a.bmax[d]) : 0.f;
-      k.centroid[d] = a.n_pixels ? a.sum[d] / static_cast<float>(a.n_pixels) : 0.f;
+      // the centroid the reference's consumers compute: the mean over cluster.pixels, which lists a boundary voxel's pixels once
+      // per adjacent seed (mesh_object_extractor.cpp:136-147, max_iou_tracker.cpp:541-548)
+      k.centroid[d] = a.n_listed ? a.wsum[d] / static_cast<float>(a.n_listed) : (a.n_pixels ? a.sum[d] / static_cast<float>(a.n_pixels) : 0.f);
     }
     out[i] = k;
   }

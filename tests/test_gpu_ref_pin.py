@@ -42,19 +42,25 @@ def test_hip_path_equals_reference_code(case):
     cfg, ctx, ora, s, sen, osen = make_pair(width=W, height=H, **kw)
     r = pyref.RefMap(LIB, po.config_from(cfg, 0))
     seen = dict(seeds=0, clusters=0, removed=0, ever_free=0, to_remove=0)
+    dup = 0  # clusters whose pixel list is longer than their painted area
     for i in range(26):
         fr = s.render(i)
         slot = ctx.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
         # FreeSpaceMotionDetector::processInput, each side on its own map
         n_gpu = ctx.detect_motion(slot)
         rng, vtx, dyn_gpu = ctx.download_frame(slot, (H, W), range_image=True, vertex_map=True, dynamic_image=True)
-        n_ref, dyn_ref, seeds_ref, _, bbox_ref = r.detect_motion(fr["stamp"], fr["pose"][2, 3], rng, vtx)
+        n_ref, dyn_ref, seeds_ref, npx_ref, bbox_ref = r.detect_motion(fr["stamp"], fr["pose"][2, 3], rng, vtx)
         assert n_gpu == n_ref, (case, i)
         assert _same_partition(dyn_gpu, dyn_ref), (case, i)
         cl = {c["id"]: c for c in ctx.dynamic_clusters(slot)}
-        for k in range(n_ref):  # the cluster records: bounding boxes as the reference builds them (free_space_motion_detector.cpp:396)
+        for k in range(n_ref):  # the cluster records: bounding boxes as the reference builds them (free_space_motion_detector.cpp:396),
+            # the length of its pixel list (a boundary voxel's pixels once per adjacent seed, :255-265) and the mean vertex over that
+            # list -- the centroid of extractDynamicObject (mesh_object_extractor.cpp:136-147), by utils::computeCentroid itself
             ids = np.unique(dyn_gpu[dyn_ref == k + 1])
             assert len(ids) == 1 and np.array_equal(cl[int(ids[0])]["bbox_min"], bbox_ref[k, :3]) and np.array_equal(cl[int(ids[0])]["bbox_max"], bbox_ref[k, 3:])
+            assert cl[int(ids[0])]["num_pixels_listed"] == int(npx_ref[k]), (case, i, k)
+            assert np.allclose(cl[int(ids[0])]["centroid"], r.last_centroids[k], rtol=3e-5, atol=3e-5), (case, i, k)
+            dup += int(npx_ref[k] > (dyn_ref == k + 1).sum())
         seen["seeds"] += seeds_ref
         seen["clusters"] += n_ref
         # masked update on the device; its footprint goes to the reference side
@@ -196,10 +202,7 @@ def test_product_active_window_equals_reference_active_window(tmp_path):
         assert np.allclose(a["bbox_min"], b["bbox_min"], atol=2e-6) and np.allclose(a["bbox_max"], b["bbox_max"], atol=2e-6)
     g_dyn = np.array(sorted(tuple(o["bbox_min"]) + tuple(o["bbox_max"]) for o in got["objects"] if not o["vertices"])).reshape(-1, 6)
     w_dyn = np.array(sorted(tuple(o["bbox_min"]) + tuple(o["bbox_max"]) for o in want["objects"] if not len(o["points"]))).reshape(-1, 6)
-    assert len(g_dyn) == len(w_dyn)
-    # the box's DIMENSIONS (mean extent of the observations' boxes, mesh_object_extractor.cpp:148,170) agree; its CENTRE -- the
-    # centroid of the first observation (:146-147,171) -- is a KNOWN OPEN DEVIATION of the product (ASSUMPTIONS.md A.8, found by
-    # this test): the reference averages cluster.pixels, which lists a boundary voxel's pixels once per adjacent seed
-    # (free_space_motion_detector.cpp:255-265), the product averages every painted pixel once.  Bounded here, not hidden.
-    assert np.allclose(g_dyn[:, 3:] - g_dyn[:, :3], w_dyn[:, 3:] - w_dyn[:, :3], atol=4e-6)
-    assert np.abs(0.5 * (g_dyn[:, 3:] + g_dyn[:, :3]) - 0.5 * (w_dyn[:, 3:] + w_dyn[:, :3])).max(initial=0.0) < 0.05
+    # dimensions = mean extent of the observations' boxes, centre = centroid of the first observation over the reference's pixel
+    # LIST (mesh_object_extractor.cpp:136-148,170-171).  (This test found the product averaging every painted pixel once instead:
+    # 2.6 cm off here; ASSUMPTIONS.md A.8.)
+    assert len(g_dyn) == len(w_dyn) and np.allclose(g_dyn, w_dyn, atol=5e-5)

@@ -144,8 +144,63 @@ static int bufferReplay() {
   return 0;
 }
 
+// Dynamic-object replay (tests/test_cpu_ref_pin.py): frames with dynamic clusters given as boxes, tracks to extract; one line per
+// track: "null" or the object's trajectory length, first / last observed, box (min, max).  A cluster's centroid is the mean of its
+// two box corners, accumulated the way utils::computeCentroid does (geometry_utils.cpp:44-50).  Format:
+//   X <min_dynamic_displacement> <min_object_allocation_confidence>
+//   F <stamp> <n> { <id> <lo3> <hi3> }*   |   K <confidence> <first_seen> <last_seen> <n_obs> { <stamp> <dynamic_cluster_id> }*
+static int dynamicObjectReplay() {
+  MeshObjectExtractor::Config cfg;
+  FrameDataBuffer::Config bc;
+  bc.max_buffer_size = 4096;
+  FrameDataBuffer buffer(bc);
+  std::unique_ptr<MeshObjectExtractor> extractor;
+  std::string tok;
+  while (std::cin >> tok) {
+    if (tok == "X") {
+      std::cin >> cfg.min_dynamic_displacement >> cfg.min_object_allocation_confidence;
+      extractor = std::make_unique<MeshObjectExtractor>(cfg, khr_config{});
+    } else if (tok == "F") {
+      auto f = std::make_shared<FrameData>();
+      size_t n;
+      std::cin >> f->input.timestamp_ns >> n;
+      for (size_t k = 0; k < n; ++k) {
+        MeasurementCluster c;
+        float lo[3], hi[3];
+        std::cin >> c.id;
+        for (float& v : lo) std::cin >> v;
+        for (float& v : hi) std::cin >> v;
+        c.bounding_box.include(lo);
+        c.bounding_box.include(hi);
+        for (int i = 0; i < 3; ++i) c.centroid[i] = ((0.f + lo[i]) + hi[i]) / 2;
+        f->dynamic_clusters.push_back(c);
+      }
+      f->num_dynamic_clusters = static_cast<int>(n);
+      buffer.storeData(f);
+    } else if (tok == "K") {
+      Track t;
+      t.is_dynamic = true;
+      size_t n;
+      std::cin >> t.confidence >> t.first_seen >> t.last_seen >> n;
+      t.observations.resize(n);
+      for (Observation& o : t.observations) std::cin >> o.stamp >> o.dynamic_cluster_id;
+      const auto obj = extractor->extractObject(t, buffer);
+      if (!obj) {
+        std::printf("null\n");
+      } else {
+        std::printf("%zu %llu %llu %.9g %.9g %.9g %.9g %.9g %.9g\n", obj->trajectory_positions.size(),
+                    static_cast<unsigned long long>(obj->first_observed_ns[0]), static_cast<unsigned long long>(obj->last_observed_ns[0]),
+                    obj->bounding_box.min[0], obj->bounding_box.min[1], obj->bounding_box.min[2], obj->bounding_box.max[0], obj->bounding_box.max[1],
+                    obj->bounding_box.max[2]);
+      }
+    }
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc > 1 && std::strcmp(argv[1], "--tracker") == 0) return trackerReplay();
+  if (argc > 1 && std::strcmp(argv[1], "--dynobj") == 0) return dynamicObjectReplay();
   if (argc > 1 && std::strcmp(argv[1], "--buffer") == 0) return bufferReplay();
   // ---- YAML ----
   if (argc > 1) {

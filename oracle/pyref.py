@@ -91,6 +91,8 @@ def load():
     lib.ref_aw_collect.restype = C.c_int64
     lib.ref_aw_collect.argtypes = [C.c_void_p]
     lib.ref_aw_object.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.ref_dynobj_replay.restype = C.c_int64
+    lib.ref_dynobj_replay.argtypes = [C.c_char_p, C.c_void_p, C.c_int64]
     lib.ref_combine_mesh.restype = C.c_int64
     lib.ref_combine_mesh.argtypes = [C.c_int] + [C.c_void_p] * 8
     return lib
@@ -404,3 +406,12 @@ class RefActiveWindow:
             out.append(dict(label=int(info[0]), first_seen=int(info[1]), last_seen=int(info[2]), points=pts[: info[3]].copy(),
                             bbox_min=bbox[:3].copy(), bbox_max=bbox[3:].copy()))
         return out
+
+
+def dynobj_replay(lib, script):
+    """MeshObjectExtractor::extractDynamicObject over a script in host_selftest --dynobj's format; the lines it prints."""
+    cap = 1 << 20
+    buf = C.create_string_buffer(cap)
+    n = lib.ref_dynobj_replay(script.encode(), buf, cap)
+    assert 0 <= n < cap
+    return buf.value.decode()

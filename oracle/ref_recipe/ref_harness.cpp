@@ -1060,6 +1060,71 @@ void ref_aw_object(RefActiveWindow* r, int64_t i, int64_t* info, float* bbox, fl
   std::memcpy(points, o.points.data(), sizeof(float) * std::min<size_t>(o.points.size(), 3 * static_cast<size_t>(cap_points)));
 }
 
+/* MeshObjectExtractor::extractDynamicObject (mesh_object_extractor.cpp:120-172, through extractObject) over a script in the
+ * format of host_selftest --dynobj: a cluster given as a box becomes two pixels whose vertices are the box corners; the same lines. */
+int64_t ref_dynobj_replay(const char* script, char* out, int64_t cap) {
+  std::istringstream in(script);
+  std::string result, tok;
+  khronos::MeshObjectExtractor::Config cfg;
+  khronos::FrameDataBuffer::Config bc;
+  bc.max_buffer_size = 4096;
+  khronos::FrameDataBuffer buffer(bc);
+  std::unique_ptr<khronos::MeshObjectExtractor> extractor;
+  while (in >> tok) {
+    if (tok == "X") {
+      in >> cfg.min_dynamic_displacement >> cfg.min_object_allocation_confidence;
+      extractor = std::make_unique<khronos::MeshObjectExtractor>(cfg);
+    } else if (tok == "F") {
+      hydra::InputData input;
+      size_t n;
+      in >> input.timestamp_ns >> n;
+      input.vertex_map = cv::Mat(1, static_cast<int>(std::max<size_t>(2 * n, 1)), sizeof(cv::Vec3f));
+      auto fd = std::make_shared<khronos::FrameData>(input);
+      cv::Mat vm = fd->input.vertex_map;  // (shares the pixels)
+      for (size_t k = 0; k < n; ++k) {
+        khronos::MeasurementCluster c;
+        in >> c.id;
+        for (int corner = 0; corner < 2; ++corner) {
+          cv::Vec3f& v = vm.at<cv::Vec3f>(0, static_cast<int>(2 * k + corner));
+          in >> v[0] >> v[1] >> v[2];
+          c.pixels.emplace_back(static_cast<int>(2 * k + corner), 0);
+        }
+        fd->dynamic_clusters.push_back(std::move(c));
+      }
+      buffer.storeData(fd);
+    } else if (tok == "K") {
+      khronos::Track t;
+      t.id = 0;
+      t.is_dynamic = true;
+      size_t n;
+      in >> t.confidence >> t.first_seen >> t.last_seen >> n;
+      for (size_t i = 0; i < n; ++i) {
+        uint64_t st;
+        int id;
+        in >> st >> id;
+        t.observations.emplace_back(st, -1, id);
+      }
+      const auto obj = extractor->extractObject(t, buffer);
+      if (!obj) {
+        result += "null\n";
+      } else {
+        char buf[512];
+        std::snprintf(buf, sizeof(buf), "%zu %llu %llu %.9g %.9g %.9g %.9g %.9g %.9g\n", obj->trajectory_positions.size(),
+                      static_cast<unsigned long long>(obj->first_observed_ns[0]), static_cast<unsigned long long>(obj->last_observed_ns[0]),
+                      obj->bounding_box.min[0], obj->bounding_box.min[1], obj->bounding_box.min[2], obj->bounding_box.max[0], obj->bounding_box.max[1],
+                      obj->bounding_box.max[2]);
+        result += buf;
+      }
+    }
+  }
+  const int64_t n = std::min<int64_t>(static_cast<int64_t>(result.size()), cap > 0 ? cap - 1 : 0);
+  if (cap > 0) {
+    std::memcpy(out, result.data(), static_cast<size_t>(n));
+    out[n] = 0;
+  }
+  return static_cast<int64_t>(result.size());
+}
+
 /* utils::combineMeshLayer (geometry_utils.cpp:61-86): blocks given as vertex counts + faces per block (local indices);
  * returns the combined faces (global indices) and the combined order of a per-vertex tag */
 int64_t ref_combine_mesh(int n_blocks, const int64_t* n_vertices, const int64_t* n_faces, const float* points, const uint32_t* labels,

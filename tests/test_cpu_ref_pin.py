@@ -743,3 +743,61 @@ def test_pixel_tracker_restatement_equals_reference_code(association):
                     shared += t.observations[-1][1] > 0 and t.observations[-1][2] > 0
         assert max(len(w) for w in want) >= 4 and any(t["dyn"] for t in want[-1]) and any(not t["active"] for w in want for t in w)
         assert any(t["n_obs"] >= 5 and not t["dyn"] for t in want[-1]), "static tracks must have been re-associated through the pixel IoU"
+
+
+@needs_ref
+def test_host_dynamic_object_extraction_equals_reference_code():
+    """The PRODUCT's host MeshObjectExtractor::extractDynamicObject (khronos_amd/host/active_window.cpp, through host_selftest
+    --dynobj) against the reference's own (mesh_object_extractor.cpp:120-172, through extractObject :81-118): trajectory from
+    the observations' cluster centroids, mean box extent, the displacement gate, the confidence gate, missing frames / clusters,
+    box = mean extent around the FIRST position.  Clusters are given as boxes; on the reference's side each becomes two pixels at
+    the box corners."""
+    import subprocess
+    from test_cpu_host import SELFTEST
+    rng = np.random.default_rng(21)
+    lines = ["X 0.35 0.5"]
+    stamps = [1_000_000_000 + 100_000_000 * i for i in range(40)]
+    pos = np.array([0.0, 0.0, 1.0])
+    per_frame = []
+    for st in stamps:
+        pos = pos + rng.normal(0.02, 0.03, 3)
+        n = int(rng.integers(0, 3))
+        cl = []
+        for k in range(n):
+            c = (pos + rng.normal(0, 0.4 * k, 3)).astype(np.float32)
+            half = rng.uniform(0.05, 0.4, 3).astype(np.float32)
+            cl.append((k + 1, c - half, c + half))
+        per_frame.append(cl)
+        lines.append("F %d %d " % (st, n) + " ".join("%d " % i + " ".join("%.9g" % v for v in np.concatenate([lo, hi])) for i, lo, hi in cl))
+    n_tracks = 0
+    for t in range(30):
+        a = int(rng.integers(0, len(stamps) - 2))
+        b = int(rng.integers(a + 1, min(len(stamps), a + 15)))
+        obs = []
+        for j in range(a, b):
+            ids = [c[0] for c in per_frame[j]]
+            if rng.uniform() < 0.15:
+                obs.append((stamps[j] + 7, 1))          # a frame that is not in the buffer
+            elif rng.uniform() < 0.15:
+                obs.append((stamps[j], 9))              # a cluster that is not in the frame
+            elif rng.uniform() < 0.2:
+                obs.append((stamps[j], -1))             # a semantic-only observation
+            elif ids:
+                obs.append((stamps[j], int(rng.choice(ids))))
+        conf = float(rng.choice([0.3, 0.5, 0.8, 1.0]))
+        lines.append("K %r %d %d %d " % (conf, stamps[a], stamps[b - 1], len(obs)) + " ".join("%d %d" % o for o in obs))
+        n_tracks += 1
+    script = "\n".join(lines) + "\n"
+    out = subprocess.run([SELFTEST, "--dynobj"], input=script, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    got, want = out.stdout.strip().splitlines(), pyref.dynobj_replay(LIB, script).strip().splitlines()
+    assert len(got) == len(want) == n_tracks
+    n_obj = 0
+    for g, w in zip(got, want):
+        assert (g == "null") == (w == "null"), (g, w)
+        if g != "null":
+            gv, wv = g.split(), w.split()
+            assert gv[:3] == wv[:3]
+            assert np.allclose([float(x) for x in gv[3:]], [float(x) for x in wv[3:]], rtol=2e-6, atol=2e-6), (g, w)
+            n_obj += 1
+    assert 3 <= n_obj < n_tracks

@@ -93,6 +93,8 @@ def load():
     lib.ref_aw_object.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     lib.ref_dynobj_replay.restype = C.c_int64
     lib.ref_dynobj_replay.argtypes = [C.c_char_p, C.c_void_p, C.c_int64]
+    lib.ref_rv_vertex_sources.restype = C.c_int64
+    lib.ref_rv_vertex_sources.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int64]
     lib.ref_combine_mesh.restype = C.c_int64
     lib.ref_combine_mesh.argtypes = [C.c_int] + [C.c_void_p] * 8
     return lib
@@ -415,3 +417,12 @@ def dynobj_replay(lib, script):
     n = lib.ref_dynobj_replay(script.encode(), buf, cap)
     assert 0 <= n < cap
     return buf.value.decode()
+
+
+def vertex_sources(lib, policy, pose_stamps, first_seen, last_seen):
+    """RayVerificator::computeVertexSources for a deterministic policy name; ascending pose indices."""
+    code = {"First": 0, "Last": 1, "FirstAndLast": 2, "Middle": 3, "All": 4}[policy]
+    st = np.ascontiguousarray(pose_stamps, np.uint64)
+    out = np.zeros(max(len(st), 1), np.int64)
+    n = lib.ref_rv_vertex_sources(code, _ptr(st), st.size, int(first_seen), int(last_seen), _ptr(out), out.size)
+    return [int(x) for x in out[:n]]

@@ -498,6 +498,21 @@ void ref_rv_check(const RefRayVerificator* r, const float* point, uint64_t earli
   for (int64_t i = 0; i < *n_absent && i < cap_absent; ++i) absent[i] = res.absent[i];
 }
 
+/* RayVerificator::computeVertexSources (ray_verificator.cpp:266-325; private, reached with -fno-access-control): which of the
+ * pose stamps a vertex seen from first_seen to last_seen draws rays from, for the deterministic policies (0 First, 1 Last,
+ * 2 FirstAndLast, 3 Middle, 4 All).  returns the count, indices ascending */
+int64_t ref_rv_vertex_sources(int policy, const uint64_t* pose_stamps, int64_t n_poses, uint64_t first_seen, uint64_t last_seen, int64_t* out, int64_t cap) {
+  khronos::RayVerificator::Config c;
+  c.ray_policy = static_cast<khronos::RayVerificator::Config::RayPolicy>(policy);
+  khronos::RayVerificator rv(c);
+  rv.timestamps_.assign(pose_stamps, pose_stamps + n_poses);
+  const auto res = rv.computeVertexSources(first_seen, last_seen);
+  std::vector<size_t> v(res.begin(), res.end());
+  std::sort(v.begin(), v.end());
+  for (int64_t i = 0; i < static_cast<int64_t>(v.size()) && i < cap; ++i) out[i] = static_cast<int64_t>(v[i]);
+  return static_cast<int64_t>(v.size());
+}
+
 /* RayChangeDetector::detectChanges (ray_change_detector.cpp:66-133).  out: {has closest_absent, closest_absent, has
  * furthest_persistent, furthest_persistent} */
 void ref_detect_changes(float temporal_resolution, int64_t window_size, int use_relative_confidence, float absence_confidence,

@@ -801,3 +801,26 @@ def test_host_dynamic_object_extraction_equals_reference_code():
             assert np.allclose([float(x) for x in gv[3:]], [float(x) for x in wv[3:]], rtol=2e-6, atol=2e-6), (g, w)
             n_obj += 1
     assert 3 <= n_obj < n_tracks
+
+
+@needs_ref
+@pytest.mark.parametrize("policy", ["Middle", "FirstAndLast", "All", "First", "Last"])
+def test_ray_policy_restatement_equals_reference_code(policy):
+    """RayVerificator::computeVertexSources (ray_verificator.cpp:266-325), the reference's own code, against the Python restatement
+    tests/test_gpu_host.py holds the product's C++ RayVerificator mirror to (which poses a vertex draws rays from)."""
+    from test_gpu_host import _vertex_sources
+    rng = np.random.default_rng(3)
+    T = 1_000_000_000
+    stamps = [(1 + k) * T // 2 for k in range(30)]
+    hit = 0
+    for _ in range(400):
+        first = int(rng.integers(0, 17 * T))
+        last = first + int(rng.integers(0, 6 * T))
+        if rng.uniform() < 0.2:
+            first = int(rng.choice(stamps))  # exactly on a pose stamp (upper_bound / lower_bound differ there)
+        if rng.uniform() < 0.2:
+            last = int(rng.choice(stamps))
+        want = pyref.vertex_sources(LIB, policy, stamps, first, last)
+        assert _vertex_sources(policy, stamps, first, last) == want, (policy, first, last)
+        hit += bool(want)
+    assert hit > 100

@@ -95,6 +95,10 @@ def load():
     lib.ref_dynobj_replay.argtypes = [C.c_char_p, C.c_void_p, C.c_int64]
     lib.ref_rv_vertex_sources.restype = C.c_int64
     lib.ref_rv_vertex_sources.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int64]
+    lib.ref_cd_background.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.ref_cd_object.restype = C.c_int
+    lib.ref_cd_object.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                  C.c_uint64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
     lib.ref_combine_mesh.restype = C.c_int64
     lib.ref_combine_mesh.argtypes = [C.c_int] + [C.c_void_p] * 8
     return lib
@@ -236,6 +240,35 @@ class RefRayVerificator:
         if getattr(self, "h", None):
             self.lib.ref_rv_destroy(self.h)
             self.h = None
+
+    @staticmethod
+    def _vote(temporal_resolution=1.0, window_size=5, use_relative_confidence=True, absence_confidence=0.5, presence_confidence=0.5):
+        return np.array([temporal_resolution, window_size, 1.0 if use_relative_confidence else 0.0, absence_confidence, presence_confidence], np.float32)
+
+    def background_changes(self, verts, vstamps, time_filtering_threshold, states=None, reobserved=(), **vote):
+        """RayBackgroundChangeDetector::detectChanges: states (0 unobserved, 1 persistent, 2 absent) of all vertices"""
+        v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+        st = np.ascontiguousarray(vstamps, np.uint64)
+        prev = np.zeros(0, np.uint8) if states is None else np.ascontiguousarray(states, np.uint8)
+        ro = np.ascontiguousarray(list(reobserved), np.int64)
+        out = np.zeros(len(v), np.uint8)
+        vt = self._vote(**vote)
+        self.lib.ref_cd_background(self.h, _ptr(vt), float(time_filtering_threshold), len(v), _ptr(v), _ptr(st), _ptr(prev), prev.size, _ptr(ro), ro.size, _ptr(out))
+        return out
+
+    def object_change(self, local, bbox_min, bbox_max, t_first, t_last, time_filtering_threshold, query_subsampling, node_id=7, dynamic=False,
+                      merges=(), **vote):
+        """RayObjectChangeDetector::detectChanges on one object node: None (no entry) or the ObjectChange's fields"""
+        pts = np.ascontiguousarray(local, np.float32).reshape(-1, 3)
+        b0, b1 = np.ascontiguousarray(bbox_min, np.float32), np.ascontiguousarray(bbox_max, np.float32)
+        mg = np.ascontiguousarray(list(merges), np.uint64).reshape(-1, 3)
+        out = np.zeros(5, np.uint64)
+        vt = self._vote(**vote)
+        ok = self.lib.ref_cd_object(self.h, _ptr(vt), float(time_filtering_threshold), int(query_subsampling), int(node_id), len(pts), _ptr(pts), _ptr(b0),
+                                    _ptr(b1), int(t_first), int(t_last), int(dynamic), _ptr(mg), len(mg), _ptr(out))
+        if not ok:
+            return None
+        return dict(merged_id=int(out[0]), first_absent=int(out[1]), last_absent=int(out[2]), first_persistent=int(out[3]), last_persistent=int(out[4]))
 
     def check_one(self, point, earliest=0, latest=2 ** 64 - 1, cap=1 << 16):
         p = np.ascontiguousarray(point, np.float32)

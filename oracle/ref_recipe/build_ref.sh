@@ -16,7 +16,8 @@ SRC="$KHRONOS_ROOT/khronos/src"
 for f in active_window/integration/tracking_integrator.cpp active_window/motion_detection/free_space_motion_detector.cpp utils/geometry_utils.cpp \
          active_window/object_detection/connected_semantics.cpp active_window/tracking/max_iou_tracker.cpp active_window/data/track.cpp \
          active_window/tracking/external_tracker.cpp active_window/data/frame_data_buffer.cpp \
-         backend/change_detection/ray_verificator.cpp backend/change_detection/ray_change_detector.cpp \
+         backend/change_detection/ray_verificator.cpp backend/change_detection/ray_change_detector.cpp backend/change_state.cpp \
+         backend/change_detection/background/ray_background_change_detector.cpp backend/change_detection/objects/ray_object_change_detector.cpp \
          active_window/object_extraction/mesh_object_extractor.cpp active_window/integration/object_integrator.cpp \
          active_window/active_window.cpp active_window/object_extraction/object_worker_pool.cpp; do
   [ -f "$SRC/$f" ] || { echo "build_ref.sh: $SRC/$f not found (no reference checkout here): keeping what is in $OUT" >&2; exit 3; }
@@ -38,6 +39,9 @@ make -C "$REPO/oracle" -s
   "$SRC/active_window/data/frame_data_buffer.cpp" \
   "$SRC/backend/change_detection/ray_verificator.cpp" \
   "$SRC/backend/change_detection/ray_change_detector.cpp" \
+  "$SRC/backend/change_state.cpp" \
+  "$SRC/backend/change_detection/background/ray_background_change_detector.cpp" \
+  "$SRC/backend/change_detection/objects/ray_object_change_detector.cpp" \
   "$SRC/active_window/object_extraction/mesh_object_extractor.cpp" \
   "$SRC/active_window/integration/object_integrator.cpp" \
   "$SRC/active_window/active_window.cpp" \

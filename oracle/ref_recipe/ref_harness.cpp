@@ -25,6 +25,8 @@
 #include "khronos/active_window/data/frame_data_buffer.h"
 #include "khronos/active_window/tracking/external_tracker.h"
 #include "khronos/active_window/tracking/max_iou_tracker.h"
+#include "khronos/backend/change_detection/background/ray_background_change_detector.h"
+#include "khronos/backend/change_detection/objects/ray_object_change_detector.h"
 #include "khronos/backend/change_detection/ray_change_detector.h"
 #include "khronos/backend/change_detection/ray_verificator.h"
 #include "khronos/utils/geometry_utils.h"
@@ -454,7 +456,7 @@ int64_t ref_buffer_replay(const char* script, char* out, int64_t cap) {
  * ray from its own agent node (computeVertexSources, :275-283).  Stamps must be ascending and distinct. */
 struct RefRayVerificator {
   std::shared_ptr<spark_dsg::DynamicSceneGraph> dsg;
-  std::unique_ptr<khronos::RayVerificator> rv;
+  std::shared_ptr<khronos::RayVerificator> rv;
 };
 
 RefRayVerificator* ref_rv_create(float block_size, float radial_tolerance, float depth_tolerance, int64_t n, const uint64_t* stamps,
@@ -465,7 +467,7 @@ RefRayVerificator* ref_rv_create(float block_size, float radial_tolerance, float
   c.radial_tolerance = radial_tolerance;
   c.depth_tolerance = depth_tolerance;
   c.ray_policy = khronos::RayVerificator::Config::RayPolicy::kFirst;
-  r->rv = std::make_unique<khronos::RayVerificator>(c);
+  r->rv = std::make_shared<khronos::RayVerificator>(c);
   r->dsg = std::make_shared<spark_dsg::DynamicSceneGraph>();
   auto& agents = r->dsg->layers[{r->dsg->layer_ids.at(spark_dsg::DsgLayers::AGENTS), c.prefix.key}];
   r->dsg->mesh_ = std::make_shared<spark_dsg::Mesh>();
@@ -496,6 +498,83 @@ void ref_rv_check(const RefRayVerificator* r, const float* point, uint64_t earli
   *n_absent = static_cast<int64_t>(res.absent.size());
   for (int64_t i = 0; i < *n_present && i < cap_present; ++i) present[i] = res.present[i];
   for (int64_t i = 0; i < *n_absent && i < cap_absent; ++i) absent[i] = res.absent[i];
+}
+
+/* the two callers of the ray verificator (SURVEY.md section 8 f4 tail).  vote: {temporal_resolution, window_size,
+ * use_relative_confidence, absence_confidence, presence_confidence}.
+ * RayBackgroundChangeDetector::detectChanges (ray_background_change_detector.cpp:59-88): states of the first n_prev vertices given,
+ * the others are new; re-observed vertices are recomputed.  states_out: n_vertices entries (0 unobserved, 1 persistent, 2 absent) */
+static std::shared_ptr<khronos::RayChangeDetector> makeVote(const float* vote) {
+  khronos::RayChangeDetector::Config c;
+  c.temporal_resolution = vote[0];
+  c.window_size = static_cast<size_t>(vote[1]);
+  c.use_relative_confidence = vote[2] != 0.f;
+  c.absence_confidence = vote[3];
+  c.presence_confidence = vote[4];
+  return std::make_shared<khronos::RayChangeDetector>(c);
+}
+
+static uint8_t stateCode(khronos::ChangeState s) {
+  return s == khronos::ChangeState::kAbsent ? 2 : (s == khronos::ChangeState::kPersistent ? 1 : 0);
+}
+
+void ref_cd_background(RefRayVerificator* r, const float* vote, float time_filtering_threshold, int64_t n_vertices, const float* points,
+                       const uint64_t* stamps, const uint8_t* prev_states, int64_t n_prev, const int64_t* reobserved, int64_t n_reobserved,
+                       uint8_t* states_out) {
+  khronos::RayBackgroundChangeDetector::Config c;
+  c.time_filtering_threshold = time_filtering_threshold;
+  khronos::RayBackgroundChangeDetector detector(c, r->rv, makeVote(vote));
+  spark_dsg::DynamicSceneGraph dsg;
+  dsg.mesh_ = std::make_shared<spark_dsg::Mesh>();
+  for (int64_t i = 0; i < n_vertices; ++i) {
+    dsg.mesh_->points.emplace_back(points[3 * i], points[3 * i + 1], points[3 * i + 2]);
+    dsg.mesh_->stamps.push_back(stamps[i]);
+    dsg.mesh_->first_seen_stamps.push_back(stamps[i]);
+  }
+  khronos::BackgroundChanges changes;
+  for (int64_t i = 0; i < n_prev; ++i)
+    changes.push_back(prev_states[i] == 2 ? khronos::ChangeState::kAbsent : (prev_states[i] == 1 ? khronos::ChangeState::kPersistent : khronos::ChangeState::kUnobserved));
+  r->rv->reobserved_vertices_.clear();  // (RayVerificator::updateDsg fills this; given here)
+  for (int64_t i = 0; i < n_reobserved; ++i) r->rv->reobserved_vertices_.insert(static_cast<size_t>(reobserved[i]));
+  detector.detectChanges(dsg, changes);
+  r->rv->reobserved_vertices_.clear();
+  for (int64_t i = 0; i < n_vertices; ++i) states_out[i] = stateCode(changes.at(static_cast<size_t>(i)));
+}
+
+/* RayObjectChangeDetector::detectChanges for ONE object node (ray_object_change_detector.cpp:62-160): mesh in its box frame, box,
+ * first / last observed; merges as (from, to, valid) triples.  out: {merged_id, first_absent, last_absent, first_persistent,
+ * last_persistent}; returns 0 when the object got no change entry (dynamic objects, :86-89) */
+int ref_cd_object(RefRayVerificator* r, const float* vote, float time_filtering_threshold, int query_subsampling, uint64_t node_id, int64_t n_points,
+                  const float* local_points, const float* bbox_min, const float* bbox_max, uint64_t first_observed, uint64_t last_observed,
+                  int is_dynamic, const uint64_t* merges, int64_t n_merges, uint64_t* out) {
+  khronos::RayObjectChangeDetector::Config c;
+  c.time_filtering_threshold = time_filtering_threshold;
+  c.query_subsampling = query_subsampling;
+  khronos::RayObjectChangeDetector detector(c, r->rv, makeVote(vote));
+  spark_dsg::DynamicSceneGraph dsg;
+  auto attrs = std::make_unique<spark_dsg::KhronosObjectAttributes>();
+  for (int64_t i = 0; i < n_points; ++i) attrs->mesh.points.emplace_back(local_points[3 * i], local_points[3 * i + 1], local_points[3 * i + 2]);
+  attrs->bounding_box.include(Eigen::Vector3f(bbox_min[0], bbox_min[1], bbox_min[2]));
+  attrs->bounding_box.include(Eigen::Vector3f(bbox_max[0], bbox_max[1], bbox_max[2]));
+  attrs->bounding_box.finish();
+  attrs->first_observed_ns = {first_observed};
+  attrs->last_observed_ns = {last_observed};
+  if (is_dynamic) attrs->trajectory_positions.emplace_back(0.f, 0.f, 0.f);
+  auto node = std::make_unique<spark_dsg::SceneGraphNode>();
+  node->attrs = std::move(attrs);
+  dsg.layers[{dsg.layer_ids.at(spark_dsg::DsgLayers::OBJECTS), 0}].nodes_[node_id] = std::move(node);
+  khronos::RPGOMerges rpgo;
+  for (int64_t i = 0; i < n_merges; ++i) rpgo.emplace_back(merges[3 * i], merges[3 * i + 1], merges[3 * i + 2] != 0);
+  khronos::ObjectChanges changes;
+  detector.detectChanges(dsg, rpgo, changes);
+  if (changes.empty()) return 0;
+  const khronos::ObjectChange& ch = changes.front();
+  out[0] = ch.merged_id;
+  out[1] = ch.first_absent;
+  out[2] = ch.last_absent;
+  out[3] = ch.first_persistent;
+  out[4] = ch.last_persistent;
+  return 1;
 }
 
 /* RayVerificator::computeVertexSources (ray_verificator.cpp:266-325; private, reached with -fno-access-control): which of the

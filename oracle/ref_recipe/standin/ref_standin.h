@@ -8,7 +8,8 @@
 //   khronos/src/active_window/object_detection/connected_semantics.cpp   (a18 / f3)
 //   khronos/src/active_window/tracking/max_iou_tracker.cpp, external_tracker.cpp, data/track.cpp   (a18)
 //   khronos/src/active_window/data/frame_data_buffer.cpp                 (a17)
-//   khronos/src/backend/change_detection/ray_verificator.cpp, ray_change_detector.cpp   (f4)
+//   khronos/src/backend/change_detection/ray_verificator.cpp, ray_change_detector.cpp,
+//       background/ray_background_change_detector.cpp, objects/ray_object_change_detector.cpp, backend/change_state.cpp   (f4)
 //   khronos/src/active_window/object_extraction/mesh_object_extractor.cpp, integration/object_integrator.cpp   (a13, a12)
 //   khronos/src/active_window/active_window.cpp, object_extraction/object_worker_pool.cpp                      (a1 - a3, a15)
 // but not the containers they run on.  oracle/ref_recipe/build_ref.sh compiles those files FROM WHERE THEY LIE
@@ -594,6 +595,8 @@ struct Mesh {
   std::vector<uint64_t> first_seen_stamps, stamps;
   std::vector<Face> faces;
   size_t numVertices() const { return points.size(); }
+  const Pos& pos(size_t i) const { return points.at(i); }
+  uint64_t timestamp(size_t i) const { return stamps.at(i); }  // [A] the vertex's last-seen stamp (ray_background_change_detector.cpp:93)
 };
 
 // node attributes: the fields the change detection reads (ray_verificator.cpp:205-207,361-365; ray_verificator.h:170-174)
@@ -615,6 +618,7 @@ struct KhronosObjectAttributes : NodeAttributes {
   std::vector<Eigen::Vector3f> trajectory_positions;
   std::vector<uint64_t> trajectory_timestamps;
   std::vector<std::vector<Eigen::Vector3f>> dynamic_object_points;
+  std::map<std::string, std::vector<size_t>> details;
 };
 struct SceneGraphNode {
   std::unique_ptr<NodeAttributes> attrs;
@@ -897,6 +901,16 @@ class GlobalInfo {
 };
 
 // [A.8] pinhole projection to the nearest pixel; false when behind the camera or outside the image (max_iou_tracker.cpp:586)
+// (file import of change states, change_state.cpp:70-145: not exercised by the harness)
+struct CsvReader {
+  explicit CsvReader(const std::string&) {}
+  bool isSetup() const { return false; }
+  bool hasHeader(const std::string&) const { return false; }
+  bool checkRequiredHeaders(const std::vector<std::string>&) const { return false; }
+  size_t numRows() const { return 0; }
+  std::string getEntry(const std::string&, size_t) const { return "0"; }
+};
+
 struct RobotPrefixConfig {
   char key = 'a';
 };

@@ -824,3 +824,67 @@ def test_ray_policy_restatement_equals_reference_code(policy):
         assert _vertex_sources(policy, stamps, first, last) == want, (policy, first, last)
         hit += bool(want)
     assert hit > 100
+
+
+@needs_ref
+def test_change_detector_drivers_restatement_equals_reference_code():
+    """RayBackgroundChangeDetector::detectChanges (ray_background_change_detector.cpp:59-103) and RayObjectChangeDetector::detectChanges /
+    checkObjectMerge / checkObjectObservation (ray_object_change_detector.cpp:62-160), the reference's own code over its own
+    RayVerificator and vote, against tests/change_replica.py -- the per-vertex loops the product's batched host drivers
+    (khronos_amd/host/change_detection.cpp) are held to on the GPU in tests/test_gpu_rayver.py."""
+    import change_replica as cr
+    T = 1_000_000_000
+    rng = np.random.default_rng(21)
+    # sensor positions on a circle inside an 8 x 6 x 3 m room, 120 rays per pose to the walls / floor / ceiling (the scene of
+    # tests/test_gpu_rayver.py; the rays of a pose one nanosecond apart: the reference side wants distinct stamps)
+    n_poses, per = 40, 120
+    st, sr, tg = [], [], []
+    for k in range(n_poses):
+        th = 2 * np.pi * k / n_poses
+        s0 = np.array([1.5 * np.cos(th), 1.5 * np.sin(th), 1.5], np.float32)
+        d = rng.normal(size=(per, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        lo, hi = np.array([-4, -3, 0], np.float32), np.array([4, 3, 3], np.float32)
+        with np.errstate(divide="ignore"):
+            tt = np.where(d > 0, (hi - s0) / d, (lo - s0) / d)
+        dist = np.minimum(tt.min(1), 5.0).astype(np.float32)
+        st.append(np.uint64((1 + k) * T) + np.arange(per, dtype=np.uint64))
+        sr.append(np.repeat(s0[None], per, 0))
+        tg.append((s0 + d * dist[:, None]).astype(np.float32))
+    stamps, sources, targets = np.concatenate(st), np.concatenate(sr), np.concatenate(tg)
+    ora = po.OracleRayVerificator(1.0, 0.1, 0.1)
+    ora.add_rays(stamps, sources, targets)
+    ref = pyref.RefRayVerificator(LIB, stamps, sources, targets, 1.0, 0.1, 0.1)
+    vote = dict(temporal_resolution=1.0, window_size=5, use_relative_confidence=True, absence_confidence=0.4, presence_confidence=0.55)
+    thr = 5.0
+    sel = rng.choice(len(stamps), 300, replace=False)
+    verts = np.concatenate([targets[sel[:150]], 0.5 * (sources[sel[150:]] + targets[sel[150:]]), np.full((5, 3), 60.0, np.float32)]).astype(np.float32)
+    vstamps = np.concatenate([stamps[sel[:150]], stamps[sel[150:]], np.full(5, 3 * T, np.uint64)])
+    first = 200
+    want, _ = cr.background_changes(ora, verts[:first], vstamps[:first], thr, **vote)
+    got = ref.background_changes(verts[:first], vstamps[:first], thr, **vote)
+    assert np.array_equal(got, want)
+    assert all((want == k).sum() > 5 for k in (cr.UNOBSERVED, cr.PERSISTENT, cr.ABSENT)), np.bincount(want, minlength=3)
+    # the mesh grows and some vertices were re-observed (one index beyond the mesh: ignored, :73-75); absolute confidences this time
+    vote2 = dict(temporal_resolution=2.0, window_size=3, use_relative_confidence=False, absence_confidence=1.0, presence_confidence=2.0)
+    reobs = [3, 17, 120, 199, 100000]
+    want2, _ = cr.background_changes(ora, verts, vstamps, thr, states=want, reobserved=reobs, **vote2)
+    got2 = ref.background_changes(verts, vstamps, thr, states=want, reobserved=reobs, **vote2)
+    assert np.array_equal(got2, want2)
+    # objects: blobs of surface points seen for a while, stored in their box frame; one merged, one dynamic (skipped, :86-89)
+    n_informative = 0
+    for k in range(12):
+        centre = targets[sel[k]]
+        blob = (centre + rng.normal(scale=0.15, size=(400, 3))).astype(np.float32)
+        b0, b1 = blob.min(0), blob.max(0)
+        local = (blob - (np.float32(0.5) * (b0 + b1)).astype(np.float32)).astype(np.float32)
+        t_first, t_last, sub = int(rng.integers(8, 16)) * T, int(rng.integers(18, 30)) * T, int(rng.integers(3, 40))
+        want_obj, (before, after) = cr.object_change(ora, local, b0, b1, t_first, t_last, thr, sub, **vote)
+        merges = [(7, 99, 1), (8, 5, 1)] if k == 3 else ([(7, 99, 0)] if k == 4 else [])
+        got_obj = ref.object_change(local, b0, b1, t_first, t_last, thr, sub, node_id=7, merges=merges, **vote)
+        assert got_obj is not None
+        assert got_obj.pop("merged_id") == (99 if k == 3 else 0)  # checkObjectMerge (:104-115): valid merges of this node only
+        assert got_obj == want_obj, (k, got_obj, want_obj)
+        n_informative += any(want_obj.values())
+    assert n_informative >= 6
+    assert ref.object_change(local, b0, b1, t_first, t_last, thr, sub, dynamic=True, **vote) is None

@@ -99,6 +99,9 @@ def load():
     lib.ref_cd_object.restype = C.c_int
     lib.ref_cd_object.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                   C.c_uint64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.ref_forward_instances.restype = C.c_int
+    lib.ref_forward_instances.argtypes = ([C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                           C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int])
     lib.ref_combine_mesh.restype = C.c_int64
     lib.ref_combine_mesh.argtypes = [C.c_int] + [C.c_void_p] * 8
     return lib
@@ -459,3 +462,26 @@ def vertex_sources(lib, policy, pose_stamps, first_seen, last_seen):
     out = np.zeros(max(len(st), 1), np.int64)
     n = lib.ref_rv_vertex_sources(code, _ptr(st), st.size, int(first_seen), int(last_seen), _ptr(out), out.size)
     return [int(x) for x in out[:n]]
+
+
+def forward_instances(lib, range_image, vertex_map, label, max_range=0.0, min_cluster_size=0, max_cluster_size=-1, min_object_volume=0.0,
+                      max_object_volume=-1.0, max_background_score=0.2, features=None, background=None, cap=4096):
+    """InstanceForwarding::processInput: (object image, [dict(id, category, has_feature, num_pixels)] in the reference's order).
+    features: {id: vector}; background: list of prompt vectors."""
+    h, w = range_image.shape
+    r = np.ascontiguousarray(range_image, np.float32)
+    v = np.ascontiguousarray(vertex_map, np.float32)
+    lab = np.ascontiguousarray(label, np.int32)
+    feats = features or {}
+    dim = len(next(iter(feats.values()))) if feats else (len(background[0]) if background else 1)
+    fid = np.ascontiguousarray(sorted(feats), np.int32)
+    fv = np.ascontiguousarray([feats[i] for i in sorted(feats)], np.float32).reshape(-1, dim)
+    bg = np.ascontiguousarray(background if background else np.zeros((0, dim)), np.float32).reshape(-1, dim)
+    img = np.zeros((h, w), np.int32)
+    info = np.zeros((cap, 3), np.int32)
+    npx = np.zeros(cap, np.int64)
+    n = lib.ref_forward_instances(w, h, _ptr(r), _ptr(v), _ptr(lab), float(max_range), int(min_cluster_size), int(max_cluster_size),
+                                  float(min_object_volume), float(max_object_volume), float(max_background_score), int(dim), _ptr(fid), _ptr(fv),
+                                  len(fid), _ptr(bg), len(bg), _ptr(img), _ptr(info), _ptr(npx), cap)
+    assert n <= cap
+    return img, [dict(id=int(info[k, 0]), category=int(info[k, 1]), has_feature=bool(info[k, 2]), num_pixels=int(npx[k])) for k in range(n)]

@@ -14,7 +14,8 @@ KHRONOS_ROOT="${KHRONOS_ROOT:-/root/reference}"
 OUT="$REPO/oracle/_ref"
 SRC="$KHRONOS_ROOT/khronos/src"
 for f in active_window/integration/tracking_integrator.cpp active_window/motion_detection/free_space_motion_detector.cpp utils/geometry_utils.cpp \
-         active_window/object_detection/connected_semantics.cpp active_window/tracking/max_iou_tracker.cpp active_window/data/track.cpp \
+         active_window/object_detection/connected_semantics.cpp active_window/object_detection/instance_forwarding.cpp \
+         active_window/tracking/max_iou_tracker.cpp active_window/data/track.cpp \
          active_window/tracking/external_tracker.cpp active_window/data/frame_data_buffer.cpp \
          backend/change_detection/ray_verificator.cpp backend/change_detection/ray_change_detector.cpp backend/change_state.cpp \
          backend/change_detection/background/ray_background_change_detector.cpp backend/change_detection/objects/ray_object_change_detector.cpp \
@@ -33,6 +34,7 @@ make -C "$REPO/oracle" -s
   "$SRC/active_window/motion_detection/free_space_motion_detector.cpp" \
   "$SRC/utils/geometry_utils.cpp" \
   "$SRC/active_window/object_detection/connected_semantics.cpp" \
+  "$SRC/active_window/object_detection/instance_forwarding.cpp" \
   "$SRC/active_window/tracking/max_iou_tracker.cpp" \
   "$SRC/active_window/data/track.cpp" \
   "$SRC/active_window/tracking/external_tracker.cpp" \

@@ -21,6 +21,7 @@
 #include "khronos/active_window/integration/tracking_integrator.h"
 #include "khronos/active_window/motion_detection/free_space_motion_detector.h"
 #include "khronos/active_window/object_detection/connected_semantics.h"
+#include "khronos/active_window/object_detection/instance_forwarding.h"
 #include "khronos/active_window/object_extraction/mesh_object_extractor.h"
 #include "khronos/active_window/data/frame_data_buffer.h"
 #include "khronos/active_window/tracking/external_tracker.h"
@@ -1217,6 +1218,65 @@ int64_t ref_dynobj_replay(const char* script, char* out, int64_t cap) {
     out[n] = 0;
   }
   return static_cast<int64_t>(result.size());
+}
+
+/* InstanceForwarding::processInput (instance_forwarding.cpp:73-149): instance ids of the label image forwarded as clusters.
+ * features: n_features rows of (id, dim floats) -- empty = closed set; background: n_background prompt embeddings of dim floats
+ * (empty = no background filter).  object_out: H*W; per cluster (up to cap): {id, category or -1, has feature}, pixel count.
+ * returns the number of clusters */
+int ref_forward_instances(int W, int H, const float* range, const float* vertex, const int32_t* label, float max_range, int min_cluster_size,
+                          int max_cluster_size, double min_object_volume, double max_object_volume, double max_background_score, int dim,
+                          const int32_t* feature_ids, const float* features, int n_features, const float* background, int n_background,
+                          int32_t* object_out, int32_t* cluster_info_out, int64_t* n_pixels_out, int cap) {
+  khronos::InstanceForwarding::Config c;
+  c.max_range = max_range;
+  c.min_cluster_size = min_cluster_size;
+  c.max_cluster_size = max_cluster_size;
+  c.min_object_volume = min_object_volume;
+  c.max_object_volume = max_object_volume;
+  c.max_background_score = max_background_score;
+  auto toFeature = [dim](const float* p) {
+    hydra::FeatureVector f(static_cast<size_t>(dim), 1);
+    for (int i = 0; i < dim; ++i) f(static_cast<size_t>(i)) = p[i];
+    return f;
+  };
+  if (n_background > 0) {
+    std::vector<hydra::FeatureVector> prompts;
+    for (int k = 0; k < n_background; ++k) prompts.push_back(toFeature(background + static_cast<size_t>(k) * dim));
+    c.background.factory = [prompts]() {
+      auto g = std::make_unique<hydra::EmbeddingGroup>();
+      g->embeddings = prompts;
+      return g;
+    };
+  }
+  khronos::InstanceForwarding detector(c);
+  hydra::InputData in;
+  in.range_image = cv::Mat(H, W, sizeof(float));
+  in.vertex_map = cv::Mat(H, W, sizeof(cv::Vec3f));
+  in.label_image = cv::Mat(H, W, sizeof(int));
+  std::memcpy(in.range_image.data(), range, sizeof(float) * static_cast<size_t>(W) * H);
+  std::memcpy(in.vertex_map.data(), vertex, sizeof(float) * 3 * static_cast<size_t>(W) * H);
+  std::memcpy(in.label_image.data(), label, sizeof(int32_t) * static_cast<size_t>(W) * H);
+  for (int k = 0; k < n_features; ++k) in.label_features[feature_ids[k]] = toFeature(features + static_cast<size_t>(k) * dim);
+  khronos::FrameData data(in);
+  data.dynamic_image = cv::Mat(H, W, sizeof(int));
+  data.object_image = cv::Mat(H, W, sizeof(int));
+  hydra::VolumetricMap::Config mc;
+  const hydra::VolumetricMap map(mc);
+  detector.processInput(map, data);
+  for (int v = 0; v < H; ++v)
+    for (int u = 0; u < W; ++u) object_out[v * W + u] = data.object_image.at<int>(v, u);
+  int k = 0;
+  for (const auto& cl : data.semantic_clusters) {
+    if (k < cap) {
+      cluster_info_out[3 * k] = cl.id;
+      cluster_info_out[3 * k + 1] = cl.semantics ? cl.semantics->category_id : -1;
+      cluster_info_out[3 * k + 2] = cl.semantics && cl.semantics->feature.size() > 1 ? 1 : 0;
+      n_pixels_out[k] = static_cast<int64_t>(cl.pixels.size());
+    }
+    ++k;
+  }
+  return k;
 }
 
 /* utils::combineMeshLayer (geometry_utils.cpp:61-86): blocks given as vertex counts + faces per block (local indices);

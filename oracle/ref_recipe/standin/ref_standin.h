@@ -5,7 +5,7 @@
 //   khronos/src/active_window/integration/tracking_integrator.cpp        
 //   khronos/src/active_window/motion_detection/free_space_motion_detector.cpp   (a9 - a11)
 //   khronos/src/utils/geometry_utils.cpp                                 (a16, cluster bounding boxes)
-//   khronos/src/active_window/object_detection/connected_semantics.cpp   (a18 / f3)
+//   khronos/src/active_window/object_detection/connected_semantics.cpp, instance_forwarding.cpp   (a18 / f3)
 //   khronos/src/active_window/tracking/max_iou_tracker.cpp, external_tracker.cpp, data/track.cpp   (a18)
 //   khronos/src/active_window/data/frame_data_buffer.cpp                 (a17)
 //   khronos/src/backend/change_detection/ray_verificator.cpp, ray_change_detector.cpp,
@@ -241,6 +241,7 @@ struct NullStream {
   NullStream& operator<<(const T&) { return *this; }
 };
 }  // namespace ref_standin
+#define CHECK(condition) ::ref_standin::NullStream()
 #define LOG(severity) ::ref_standin::NullStream()
 #define LOG_IF(severity, condition) ::ref_standin::NullStream()
 
@@ -278,6 +279,9 @@ struct RegistrationWithConfig {
 template <typename T>
 struct VirtualConfig {
   std::function<std::unique_ptr<T>()> factory;
+  VirtualConfig() = default;
+  template <typename Cfg, typename = decltype(std::declval<const Cfg&>().create())>
+  VirtualConfig(const Cfg& c) : factory([c]() -> std::unique_ptr<T> { return c.create(); }) {}  // (a concrete sub-module's config)
   void setOptional() {}
   std::unique_ptr<T> create() const { return factory ? factory() : nullptr; }
   explicit operator bool() const { return static_cast<bool>(factory); }
@@ -927,8 +931,15 @@ struct Sensor {
 };
 
 // [A.7] cosine score a . b / (|a| |b|) (max_iou_tracker.cpp:56-59)
-struct CosineDistance {
-  float score(const FeatureVector& a, const FeatureVector& b) const {
+struct EmbeddingDistance {
+  virtual ~EmbeddingDistance() = default;
+  virtual float score(const FeatureVector& a, const FeatureVector& b) const = 0;
+};
+struct CosineDistance : EmbeddingDistance {
+  struct Config {
+    std::unique_ptr<EmbeddingDistance> create() const { return std::make_unique<CosineDistance>(); }
+  };
+  float score(const FeatureVector& a, const FeatureVector& b) const override {
     float ab = 0.f, aa = 0.f, bb = 0.f;
     for (size_t i = 0; i < a.size(); ++i) {
       ab += a(i) * b(i);
@@ -939,6 +950,29 @@ struct CosineDistance {
   }
 };
 
+// [A.9] a set of prompt embeddings; the best score of a feature against it (instance_forwarding.cpp:97-101)
+struct EmbeddingGroup {
+  using Ptr = std::unique_ptr<EmbeddingGroup>;
+  struct ScoreResult {
+    float score = 0.f;
+    size_t index = 0;
+  };
+  std::vector<FeatureVector> embeddings;
+  ScoreResult getBestScore(const EmbeddingDistance& metric, const FeatureVector& feature) const {
+    ScoreResult best;
+    best.score = -std::numeric_limits<float>::infinity();
+    for (size_t i = 0; i < embeddings.size(); ++i) {
+      const float sc = metric.score(embeddings[i], feature);
+      if (sc > best.score) {
+        best.score = sc;
+        best.index = i;
+      }
+    }
+    return best;
+  }
+};
+
+
 // the input of a frame: what the motion detector reads (free_space_motion_detector.cpp:74,80,114,168,174)
 struct InputData {
   using RangeType = float;
@@ -946,6 +980,7 @@ struct InputData {
   using LabelType = int;
   TimeStamp timestamp_ns = 0;
   cv::Mat label_image;
+  std::map<int, FeatureVector> label_features;  // open-set: one feature per instance id (instance_forwarding.cpp:96,140)
   cv::Mat vertex_map;   // world frame
   cv::Mat range_image;
   Eigen::Isometry3d world_T_sensor;

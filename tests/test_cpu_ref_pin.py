@@ -888,3 +888,60 @@ def test_change_detector_drivers_restatement_equals_reference_code():
         n_informative += any(want_obj.values())
     assert n_informative >= 6
     assert ref.object_change(local, b0, b1, t_first, t_last, thr, sub, dynamic=True, **vote) is None
+
+
+@needs_ref
+@pytest.mark.parametrize("case", ["closed-set", "range+size", "volume", "open-set-background"])
+def test_instance_forwarding_restatement_equals_reference_code(case):
+    """InstanceForwarding::processInput (instance_forwarding.cpp:73-149), the reference's own code, against oracle/np_oracle.py's
+    forward_instances (what khr_forward_instances is held to on the GPU) + the reference's filters applied to its clusters: the object
+    image IS the label image (the assignment at :83 shares the pixels), clusters per instance id with range cut, size window,
+    box-volume window, and -- open set -- the background filter over per-id features (ids whose best cosine score against the
+    prompts exceeds max_background_score, and ids without a feature, are dropped)."""
+    from oracle import np_oracle as npo
+    W, H = 160, 120
+    s = SyntheticStream(W, H, threads=1)
+    ora = po.OracleMap(_cfg())
+    sen = po.OrcSensor(W, H, s.fx, s.fy, s.cx, s.cy, 0.1, 5.0)
+    kw = {"closed-set": dict(), "range+size": dict(max_range=3.0, min_cluster_size=40, max_cluster_size=3000),
+          "volume": dict(min_object_volume=0.05, max_object_volume=20.0), "open-set-background": dict(max_background_score=0.3)}[case]
+    rng = np.random.default_rng(5)
+    total = dropped = 0
+    for i in (0, 9, 23):
+        fr = s.render(i)
+        rimg, vtx = ora.parse_input(sen, fr["pose"], fr["depth"])
+        ids = [int(x) for x in np.unique(fr["label"]) if x]
+        features = background = None
+        bg_ids = ()
+        if case == "open-set-background":
+            features = {k: rng.standard_normal(6).astype(np.float32) for k in ids[:-1]}  # (the last id has no feature: dropped, :96-99)
+            background = [rng.standard_normal(6).astype(np.float32) for _ in range(3)]
+
+            def cos(a, b):
+                f32 = np.float32
+                ab = aa = bb = f32(0)
+                for x, y in zip(a, b):
+                    ab, aa, bb = f32(ab + f32(x * y)), f32(aa + f32(x * x)), f32(bb + f32(y * y))
+                return f32(ab / f32(np.sqrt(aa) * np.sqrt(bb)))
+            bg_ids = tuple(k for k in ids if k not in features or max(cos(p, features[k]) for p in background) > np.float32(0.3))
+        img, got = pyref.forward_instances(LIB, rimg, vtx, fr["label"], features=features, background=background, **kw)
+        assert np.array_equal(img, fr["label"])
+        want = npo.forward_instances(fr["label"], rimg, vtx, max_range=kw.get("max_range", 0.0), background_ids=bg_ids)
+        keep = {}
+        for k, c in want.items():  # the filters of :117-131
+            n = c["num_pixels"]
+            if n < kw.get("min_cluster_size", 0) or (kw.get("max_cluster_size", -1) > 0 and n > kw["max_cluster_size"]):
+                continue
+            if kw.get("min_object_volume", 0.0) > 0.0 or kw.get("max_object_volume", -1.0) > 0.0:
+                d = (c["bbox_max"] - c["bbox_min"]).astype(np.float32)
+                vol = np.float32(np.float32(d[0] * d[1]) * d[2])
+                if vol < kw.get("min_object_volume", 0.0) or (kw.get("max_object_volume", -1.0) > 0.0 and vol > kw["max_object_volume"]):
+                    continue
+            keep[k] = c
+        assert sorted(g["id"] for g in got) == sorted(keep), (case, i)
+        for g in got:
+            assert g["num_pixels"] == keep[g["id"]]["num_pixels"] and g["category"] == g["id"]
+            assert g["has_feature"] == (features is not None)
+        total += len(got)
+        dropped += len(ids) - len(got)
+    assert total > 5 and (case == "closed-set" or dropped > 0), (case, total, dropped)

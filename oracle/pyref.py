@@ -85,6 +85,7 @@ def load():
     lib.ref_aw_block_indices.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.ref_aw_get_block.restype = C.c_int
     lib.ref_aw_get_block.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+    lib.ref_aw_finish.argtypes = [C.c_void_p]
     lib.ref_aw_extract_objects.restype = C.c_int64
     lib.ref_aw_extract_objects.argtypes = [C.c_void_p]
     lib.ref_aw_output.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
@@ -428,6 +429,10 @@ class RefActiveWindow:
         self.lib.ref_aw_output(self.h, _ptr(info), _ptr(arch), cap, _ptr(cl), cap)
         assert info[1] <= cap and info[2] <= cap
         return dict(stamp=int(info[0]), archived=arch[: info[1]].copy(), cloned=cl[: info[2]].copy(), mesh_vertices=int(info[3]))
+
+    def finish(self):
+        """ActiveWindow::finishMapping"""
+        self.lib.ref_aw_finish(self.h)
 
     def extract_objects(self):
         """ActiveWindow::extractObjects: the remaining tracks, extracted now; how many objects that gave"""

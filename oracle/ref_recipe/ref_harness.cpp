@@ -1144,6 +1144,13 @@ int64_t ref_aw_extract_objects(RefActiveWindow* r) {
   return static_cast<int64_t>(r->objects.size() - before);
 }
 
+/* ActiveWindow::finishMapping (active_window.cpp:176-188): every block and every track is marked inactive and a last output is
+ * extracted on the calling thread (its objects stay in the worker pool: ref_aw_collect) */
+void ref_aw_finish(RefActiveWindow* r) {
+  g_env = &r->env;
+  r->aw->finishMapping();
+}
+
 /* object i: info = {label, first seen, last seen, vertices}; bbox (min, max); the vertices (box frame) up to cap */
 void ref_aw_object(RefActiveWindow* r, int64_t i, int64_t* info, float* bbox, float* points, int64_t cap_points) {
   const RefObject& o = r->objects[static_cast<size_t>(i)];

@@ -565,6 +565,15 @@ def test_whole_active_window_equals_reference_code():
                 assert (o_["block_flags"] & 15) == r_["block_flags"], (i, tuple(b), o_["block_flags"], r_["block_flags"])
             seen_dyn += int((dyn_r > 0).sum())
         got_objects = aw.collect_objects()
+        # finishMapping (active_window.cpp:176-188): everything inactive, one last extraction -- the window ends empty and every
+        # remaining track leaves the tracker.  (The objects of THAT extraction ride in an output finishMapping drops, :187; the
+        # product's host class does the same.  Not compared.)
+        n_tracks_left = len(trk.tracks)
+        aw.finish()
+        ora.mark_all_inactive()
+        ora.generate_mesh(True, True)
+        ora.reset_inactive()
+        assert len(ora.block_indices()) == 0 and len(aw.block_indices()) == 0 and len(aw.tracks()) == 0 and n_tracks_left > 0
     finally:
         aw.close()
     key = lambda o: (o["label"], o["first_seen"], o["last_seen"], len(o["points"]))

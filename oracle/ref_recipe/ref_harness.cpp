@@ -1004,11 +1004,25 @@ RefActiveWindow* ref_aw_create(const ref_aw_config* c, const orc_config* main_cf
   return r;
 }
 
+namespace {
+// the reference's workers are DETACHED threads (object_worker_pool.cpp:131) that use the pool and the bridge environment: nothing
+// may go away under them
+void drainWorkers(RefActiveWindow* r) {
+  auto& pool = r->aw->extraction_worker_;
+  while (pool.work_queue_.size() > 0 || pool.curr_workers_ > 0) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+  // (a worker decrements the counter BEFORE it appends its object, object_worker_pool.cpp:142-146: give that tail time to finish)
+  std::this_thread::sleep_for(std::chrono::milliseconds(20));
+}
+}  // namespace
+
 void ref_aw_destroy(RefActiveWindow* r) {
-  if (r && g_env == &r->env) {
+  if (!r) return;
+  if (r->aw) {
+    g_env = &r->env;
+    drainWorkers(r);
     r->aw.reset();  // (joins the worker pool's thread while the environment is still there)
-    g_env = nullptr;
   }
+  if (g_env == &r->env) g_env = nullptr;
   delete r;
 }
 
@@ -1126,7 +1140,7 @@ void ref_aw_output(RefActiveWindow* r, int64_t* info, int32_t* archived, int64_t
 /* wait for the detached extractions (object_worker_pool.cpp:115-146) and take what they produced; returns the number of objects so far */
 int64_t ref_aw_collect(RefActiveWindow* r) {
   auto& pool = r->aw->extraction_worker_;
-  while (pool.work_queue_.size() > 0 || pool.curr_workers_ > 0) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+  drainWorkers(r);
   hydra::LayerUpdate update(2);
   pool.fill(update);
   takeObjects(r, update);

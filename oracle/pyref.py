@@ -103,6 +103,8 @@ def load():
     lib.ref_forward_instances.restype = C.c_int
     lib.ref_forward_instances.argtypes = ([C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                            C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int])
+    lib.ref_config_keys.restype = C.c_int64
+    lib.ref_config_keys.argtypes = [C.c_void_p, C.c_int64]
     lib.ref_combine_mesh.restype = C.c_int64
     lib.ref_combine_mesh.argtypes = [C.c_int] + [C.c_void_p] * 8
     return lib
@@ -490,3 +492,12 @@ def forward_instances(lib, range_image, vertex_map, label, max_range=0.0, min_cl
                                   len(fid), _ptr(bg), len(bg), _ptr(img), _ptr(info), _ptr(npx), cap)
     assert n <= cap
     return img, [dict(id=int(info[k, 0]), category=int(info[k, 1]), has_feature=bool(info[k, 2]), num_pixels=int(npx[k])) for k in range(n)]
+
+
+def config_keys(lib):
+    """{module: [keys]} the reference's declare_config() functions announce (they are executed with a recording config::field)"""
+    cap = 1 << 16
+    buf = C.create_string_buffer(cap)
+    n = lib.ref_config_keys(buf, cap)
+    assert 0 <= n < cap
+    return {line.split(":")[0]: line.split(":")[1].split() for line in buf.value.decode().strip().splitlines()}

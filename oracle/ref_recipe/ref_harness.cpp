@@ -1300,6 +1300,40 @@ int ref_forward_instances(int W, int H, const float* range, const float* vertex,
   return k;
 }
 
+/* the YAML keys the reference's modules declare: every declare_config() of the compiled files is RUN with a recording
+ * config::field; one line per module, "Module: key key ..." */
+int64_t ref_config_keys(char* out, int64_t cap) {
+  std::string result;
+  auto dump = [&](const char* module, auto cfg) {
+    config::recordedKeys().clear();
+    declare_config(cfg);
+    result += module;
+    result += ":";
+    for (const auto& k : config::recordedKeys()) result += " " + k;
+    result += "\n";
+  };
+  dump("ActiveWindow", khronos::ActiveWindow::Config());
+  dump("TrackingIntegrator", khronos::TrackingIntegrator::Config());
+  dump("FreeSpaceMotionDetector", khronos::FreeSpaceMotionDetector::Config());
+  dump("ConnectedSemantics", khronos::ConnectedSemantics::Config());
+  dump("InstanceForwarding", khronos::InstanceForwarding::Config());
+  dump("MaxIoUTracker", khronos::MaxIoUTracker::Config());
+  dump("ExternalTracker", khronos::ExternalTracker::Config());
+  dump("MeshObjectExtractor", khronos::MeshObjectExtractor::Config());
+  dump("ObjectWorkerPool", khronos::ObjectWorkerPool::Config());
+  dump("FrameDataBuffer", khronos::FrameDataBuffer::Config());
+  dump("RayVerificator", khronos::RayVerificator::Config());
+  dump("RayChangeDetector", khronos::RayChangeDetector::Config());
+  dump("RayBackgroundChangeDetector", khronos::RayBackgroundChangeDetector::Config());
+  dump("RayObjectChangeDetector", khronos::RayObjectChangeDetector::Config());
+  const int64_t n = std::min<int64_t>(static_cast<int64_t>(result.size()), cap > 0 ? cap - 1 : 0);
+  if (cap > 0) {
+    std::memcpy(out, result.data(), static_cast<size_t>(n));
+    out[n] = 0;
+  }
+  return static_cast<int64_t>(result.size());
+}
+
 /* utils::combineMeshLayer (geometry_utils.cpp:61-86): blocks given as vertex counts + faces per block (local indices);
  * returns the combined faces (global indices) and the combined order of a per-vertex tag */
 int64_t ref_combine_mesh(int n_blocks, const int64_t* n_vertices, const int64_t* n_faces, const float* points, const uint32_t* labels,

@@ -251,11 +251,17 @@ struct NullStream {
 namespace config {
 enum CheckMode { GT, GE, LT, LE, EQ, NE };
 struct ThreadNumConversion {};
+// the key names the reference's declare_config() functions announce are RECORDED (ref_config_keys in the harness lists them; the
+// product's YAML loader is held to that list in tests/test_cpu_ref_pin.py)
+inline std::vector<std::string>& recordedKeys() {
+  static thread_local std::vector<std::string> keys;
+  return keys;
+}
 inline void name(const std::string&) {}
 template <typename T>
-void field(T&, const std::string&, const std::string& = "") {}
+void field(T&, const std::string& key, const std::string& = "") { recordedKeys().push_back(key); }
 template <typename Conversion, typename T>
-void field(T&, const std::string&, const std::string& = "") {}
+void field(T&, const std::string& key, const std::string& = "") { recordedKeys().push_back(key); }
 template <typename T, typename U>
 void check(const T&, CheckMode, const U&, const std::string&) {}
 template <typename T>
@@ -264,9 +270,9 @@ inline void checkCondition(bool, const std::string&) {}
 template <typename T>
 void checkInRange(const T&, const T&, const T&, const std::string&) {}
 template <typename E>
-void enum_field(E&, const std::string&, const std::vector<std::string>&) {}
+void enum_field(E&, const std::string& key, const std::vector<std::string>&) { recordedKeys().push_back(key); }
 template <typename E>
-void enum_field(E&, const std::string&, std::initializer_list<const char*>) {}
+void enum_field(E&, const std::string& key, std::initializer_list<const char*>) { recordedKeys().push_back(key); }
 template <typename T>
 const T& checkValid(const T& c) { return c; }
 template <typename T>

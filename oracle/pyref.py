@@ -500,4 +500,15 @@ def config_keys(lib):
     buf = C.create_string_buffer(cap)
     n = lib.ref_config_keys(buf, cap)
     assert 0 <= n < cap
-    return {line.split(":")[0]: line.split(":")[1].split() for line in buf.value.decode().strip().splitlines()}
+    out = {}
+    for line in buf.value.decode().strip().splitlines():
+        module, rest = line.split(":", 1)
+        keys, _, defaults = rest.partition("|")
+        out[module] = keys.split()
+        out.setdefault("__defaults__", {})[module] = dict(kv.split("=", 1) for kv in defaults.split())
+    return out
+
+
+def config_defaults(lib):
+    """{module: {key: value string}} -- the default values of the arithmetic fields of the reference's Config structs"""
+    return config_keys(lib)["__defaults__"]

@@ -1304,12 +1304,15 @@ int ref_forward_instances(int W, int H, const float* range, const float* vertex,
  * config::field; one line per module, "Module: key key ..." */
 int64_t ref_config_keys(char* out, int64_t cap) {
   std::string result;
-  auto dump = [&](const char* module, auto cfg) {
+  auto dump = [&](const char* module, auto cfg) {  // (cfg: default-constructed, so the values are the reference's defaults)
     config::recordedKeys().clear();
+    config::recordedDefaults().clear();
     declare_config(cfg);
     result += module;
     result += ":";
     for (const auto& k : config::recordedKeys()) result += " " + k;
+    result += " |";
+    for (const auto& k : config::recordedDefaults()) result += " " + k;
     result += "\n";
   };
   dump("ActiveWindow", khronos::ActiveWindow::Config());

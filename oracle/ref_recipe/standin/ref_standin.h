@@ -257,11 +257,25 @@ inline std::vector<std::string>& recordedKeys() {
   static thread_local std::vector<std::string> keys;
   return keys;
 }
+inline std::vector<std::string>& recordedDefaults() {  // "key=value" of the arithmetic fields, as the Config holds them
+  static thread_local std::vector<std::string> values;
+  return values;
+}
+template <typename T>
+void recordField(const T& value, const std::string& key) {
+  recordedKeys().push_back(key);
+  if constexpr (std::is_arithmetic<T>::value) {
+    std::ostringstream os;
+    os.precision(9);
+    os << key << "=" << +value;
+    recordedDefaults().push_back(os.str());
+  }
+}
 inline void name(const std::string&) {}
 template <typename T>
-void field(T&, const std::string& key, const std::string& = "") { recordedKeys().push_back(key); }
+void field(T& value, const std::string& key, const std::string& = "") { recordField(value, key); }
 template <typename Conversion, typename T>
-void field(T&, const std::string& key, const std::string& = "") { recordedKeys().push_back(key); }
+void field(T& value, const std::string& key, const std::string& = "") { recordField(value, key); }
 template <typename T, typename U>
 void check(const T&, CheckMode, const U&, const std::string&) {}
 template <typename T>

@@ -1005,6 +1005,8 @@ def test_yaml_keys_of_the_reference_are_read_by_the_host_loader():
     assert set(declared) >= {"ActiveWindow", "TrackingIntegrator", "FreeSpaceMotionDetector", "ConnectedSemantics", "MaxIoUTracker", "MeshObjectExtractor"}
     checked = 0
     for module, keys_ in declared.items():
+        if module == "__defaults__":
+            continue
         if module in ("RayBackgroundChangeDetector", "RayObjectChangeDetector"):
             continue  # (constructed from code in the product: host/change_detection.h Config structs, same field names)
         missing = set(keys_) - have[module] - not_applicable.get(module, set())
@@ -1015,3 +1017,57 @@ def test_yaml_keys_of_the_reference_are_read_by_the_host_loader():
     cd = open(os.path.join(ROOT, "khronos_amd", "host", "change_detection.h")).read()
     for k in declared["RayBackgroundChangeDetector"] + declared["RayObjectChangeDetector"]:
         assert k in cd, k
+
+
+def _host_config_defaults():
+    """{class: {field: float}} -- the default values of the Config structs of the product's host classes, read from the headers"""
+    import re
+    host = os.path.join(ROOT, "khronos_amd", "host")
+    text = {f: open(os.path.join(host, f)).read() for f in ("active_window.h", "ray_verificator.h", "change_detection.h")}
+    where = {"TrackingIntegrator": "active_window.h", "FreeSpaceMotionDetector": "active_window.h", "ConnectedSemantics": "active_window.h",
+             "InstanceForwarding": "active_window.h", "MaxIoUTracker": "active_window.h", "ExternalTracker": "active_window.h",
+             "FrameDataBuffer": "active_window.h", "MeshObjectExtractor": "active_window.h", "ObjectWorkerPool": "active_window.h",
+             "ActiveWindow": "active_window.h", "RayVerificator": "ray_verificator.h", "RayChangeDetector": "ray_verificator.h",
+             "RayBackgroundChangeDetector": "change_detection.h", "RayObjectChangeDetector": "change_detection.h"}
+    out = {}
+    for cls, f in where.items():
+        t = text[f]
+        m = re.search(r"\b(?:class|struct)\s+%s\b[^;{]*\{" % cls, t)
+        assert m, cls
+        a = t.index("struct Config", m.end())
+        depth, i = 0, t.index("{", a)
+        j = i
+        while True:  # the matching brace of the Config struct
+            depth += t[j] == "{"
+            depth -= t[j] == "}"
+            if depth == 0:
+                break
+            j += 1
+        body = re.sub(r"//[^\n]*", "", t[i:j])
+        vals = {}
+        for name, lit in re.findall(r"\b([a-z_0-9]+)\s*=\s*(-?[0-9][0-9.e+-]*f?|true|false)\b", body):
+            if lit in ("true", "false"):
+                vals[name] = 1.0 if lit == "true" else 0.0
+            else:
+                vals[name] = float(np.float32(lit.rstrip("f"))) if lit.endswith("f") else float(lit)
+        out[cls] = vals
+    return out
+
+
+@needs_ref
+def test_config_defaults_equal_the_reference():
+    """The default VALUES of the reference's Config structs (its own headers, compiled; read off by the recording config::field while
+    declare_config runs on a default-constructed Config) against the defaults of the product's host classes, field by field.
+    verbosity / num_threads default to hydra's global settings in the reference and are left out."""
+    ref = pyref.config_defaults(LIB)
+    host = _host_config_defaults()
+    skip = {"verbosity", "num_threads"}
+    compared = 0
+    for module, fields in ref.items():
+        for key, value in fields.items():
+            if key in skip:
+                continue
+            assert key in host[module], (module, key, "no such field with a literal default in the host Config")
+            assert host[module][key] == pytest.approx(float(value), rel=1e-6), (module, key, host[module][key], value)
+            compared += 1
+    assert compared >= 55

@@ -1071,3 +1071,10 @@ def test_config_defaults_equal_the_reference():
             assert host[module][key] == pytest.approx(float(value), rel=1e-6), (module, key, host[module][key], value)
             compared += 1
     assert compared >= 55
+    # ... and the defaults of the C ABI's khr_config (include/khronos_amd.h) for the same parameters
+    from khronos_amd import capi
+    d = capi.default_config()
+    for key in ("temporal_buffer", "tsdf_occupancy_threshold", "neighbor_connectivity", "temporal_window"):
+        assert getattr(d, key) == pytest.approx(float(ref["TrackingIntegrator"][key]), rel=1e-6), key
+    for key in ("neighbor_connectivity", "min_cluster_size", "max_cluster_size", "min_separation_distance", "max_range", "min_z_coordinate"):
+        assert getattr(d, "md_" + key) == pytest.approx(float(ref["FreeSpaceMotionDetector"][key]), rel=1e-6), key

@@ -209,6 +209,20 @@ int main(int argc, char** argv) {
     ss << in.rdbuf();
     const auto cfg = ActiveWindow::Config::fromYamlString(ss.str());
     cfg.checkValid();
+    {  // the sub-modules the ActiveWindow constructor would build from this config (active_window.cpp:83-99), those that need no
+       // device: their constructors hold the reference's checkValid constraints (tests/test_cpu_ref_pin.py feeds violations)
+      FrameDataBuffer buffer(cfg.frame_data_buffer);
+      if (cfg.motion_detector_type == "FreeSpaceMotionDetector") FreeSpaceMotionDetector detector(cfg.motion_detector);
+      if (cfg.tracker_type == "MaxIouTracker") {
+        MaxIoUTracker tracker(cfg.tracker);
+      } else if (cfg.tracker_type == "ExternalTracker") {
+        ExternalTracker::Config ec;
+        ec.temporal_window = cfg.tracker.temporal_window;
+        ec.min_num_observations = cfg.tracker.min_num_observations;
+        ExternalTracker tracker(ec);
+      }
+      if (cfg.object_extractor_type == "MeshObjectExtractor") MeshObjectExtractor extractor(cfg.object_extractor, khr_config{});
+    }
     std::printf("{\"voxel_size\": %g, \"truncation_distance\": %g, \"voxels_per_side\": %d, \"with_semantics\": %d, "
                 "\"min_output_separation\": %g, \"motion_detector\": \"%s\", \"md_min_cluster_size\": %d, "
                 "\"md_min_separation_distance\": %g, \"md_max_range\": %g, \"temporal_window\": %g, \"object_extractor\": \"%s\", "

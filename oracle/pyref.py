@@ -503,10 +503,16 @@ def config_keys(lib):
     out = {}
     for line in buf.value.decode().strip().splitlines():
         module, rest = line.split(":", 1)
-        keys, _, defaults = rest.partition("|")
+        keys, defaults, checks = (rest.split("|") + ["", ""])[:3]
         out[module] = keys.split()
         out.setdefault("__defaults__", {})[module] = dict(kv.split("=", 1) for kv in defaults.split())
+        out.setdefault("__checks__", {})[module] = [c.strip() for c in checks.split(";") if c.strip()]
     return out
+
+
+def config_checks(lib):
+    """{module: ["<field> GT 0", "<field> in 6,18,26", ...]} -- the validity constraints the reference's declare_config() states"""
+    return config_keys(lib)["__checks__"]
 
 
 def config_defaults(lib):

@@ -1307,12 +1307,15 @@ int64_t ref_config_keys(char* out, int64_t cap) {
   auto dump = [&](const char* module, auto cfg) {  // (cfg: default-constructed, so the values are the reference's defaults)
     config::recordedKeys().clear();
     config::recordedDefaults().clear();
+    config::recordedChecks().clear();
     declare_config(cfg);
     result += module;
     result += ":";
     for (const auto& k : config::recordedKeys()) result += " " + k;
     result += " |";
     for (const auto& k : config::recordedDefaults()) result += " " + k;
+    result += " |";
+    for (const auto& k : config::recordedChecks()) result += " " + k + ";";
     result += "\n";
   };
   dump("ActiveWindow", khronos::ActiveWindow::Config());

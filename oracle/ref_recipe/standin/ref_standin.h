@@ -276,13 +276,36 @@ template <typename T>
 void field(T& value, const std::string& key, const std::string& = "") { recordField(value, key); }
 template <typename Conversion, typename T>
 void field(T& value, const std::string& key, const std::string& = "") { recordField(value, key); }
+// the validity constraints declare_config() states are recorded too: "<name> <mode> <bound>", "<name> in a,b,c", "<name> range lo hi"
+inline std::vector<std::string>& recordedChecks() {
+  static thread_local std::vector<std::string> checks;
+  return checks;
+}
 template <typename T, typename U>
-void check(const T&, CheckMode, const U&, const std::string&) {}
+void check(const T&, CheckMode mode, const U& bound, const std::string& field_name) {
+  static const char* const names[] = {"GT", "GE", "LT", "LE", "EQ", "NE"};
+  std::ostringstream os;
+  os << field_name << " " << names[mode] << " " << +bound;
+  recordedChecks().push_back(os.str());
+}
 template <typename T>
-void checkIsOneOf(const T&, std::initializer_list<T>, const std::string&) {}
-inline void checkCondition(bool, const std::string&) {}
+void checkIsOneOf(const T&, std::initializer_list<T> allowed, const std::string& field_name) {
+  std::ostringstream os;
+  os << field_name << " in ";
+  bool first = true;
+  for (const T& a : allowed) {
+    os << (first ? "" : ",") << +a;
+    first = false;
+  }
+  recordedChecks().push_back(os.str());
+}
+inline void checkCondition(bool, const std::string& message) { recordedChecks().push_back("condition " + message); }
 template <typename T>
-void checkInRange(const T&, const T&, const T&, const std::string&) {}
+void checkInRange(const T&, const T& lo, const T& hi, const std::string& field_name) {
+  std::ostringstream os;
+  os << field_name << " range " << +lo << " " << +hi;
+  recordedChecks().push_back(os.str());
+}
 template <typename E>
 void enum_field(E&, const std::string& key, const std::vector<std::string>&) { recordedKeys().push_back(key); }
 template <typename E>

@@ -1005,7 +1005,7 @@ def test_yaml_keys_of_the_reference_are_read_by_the_host_loader():
     assert set(declared) >= {"ActiveWindow", "TrackingIntegrator", "FreeSpaceMotionDetector", "ConnectedSemantics", "MaxIoUTracker", "MeshObjectExtractor"}
     checked = 0
     for module, keys_ in declared.items():
-        if module == "__defaults__":
+        if module.startswith("__"):
             continue
         if module in ("RayBackgroundChangeDetector", "RayObjectChangeDetector"):
             continue  # (constructed from code in the product: host/change_detection.h Config structs, same field names)
@@ -1078,3 +1078,49 @@ def test_config_defaults_equal_the_reference():
         assert getattr(d, key) == pytest.approx(float(ref["TrackingIntegrator"][key]), rel=1e-6), key
     for key in ("neighbor_connectivity", "min_cluster_size", "max_cluster_size", "min_separation_distance", "max_range", "min_z_coordinate"):
         assert getattr(d, "md_" + key) == pytest.approx(float(ref["FreeSpaceMotionDetector"][key]), rel=1e-6), key
+
+
+@needs_ref
+def test_config_constraints_of_the_reference_are_enforced_by_the_host():
+    """The validity constraints the reference's declare_config() functions state (check / checkIsOneOf / checkInRange / checkCondition,
+    recorded while they run) for the tracking integrator, the motion detector, both trackers, the object extractor and the frame
+    buffer: a YAML that violates any one of them must be refused by the product's loader + sub-module constructors
+    (host_selftest <yaml>: fromYamlString, checkValid, then the constructions of ActiveWindow's constructor that need no device)."""
+    import subprocess
+    import tempfile
+    from test_cpu_host import SELFTEST
+    checks = pyref.config_checks(LIB)
+    blocks = {"TrackingIntegrator": ("tracking_integrator", None), "FreeSpaceMotionDetector": ("motion_detector", "FreeSpaceMotionDetector"),
+              "MaxIoUTracker": ("tracker", "MaxIouTracker"), "ExternalTracker": ("tracker", "ExternalTracker"),
+              "MeshObjectExtractor": ("object_extractor", "MeshObjectExtractor"), "FrameDataBuffer": ("frame_data_buffer", None)}
+
+    def violations(c):
+        parts = c.split()
+        if parts[0] == "condition":  # "param 'max_cluster_size' must be >= 'min_cluster_size'" (free_space_motion_detector.cpp:64)
+            return [("min_cluster_size", 10, "max_cluster_size", 5)]
+        name, mode = parts[0], parts[1]
+        if mode == "in":
+            return [(name, 7)]
+        if mode == "range":
+            return [(name, float(parts[2]) - 0.5), (name, float(parts[3]) + 0.5)]
+        b = float(parts[2])
+        unsigned = name in ("max_buffer_size", "num_threads")  # (a negative literal is not a value of these types)
+        return {"GT": [(name, b)] + ([] if unsigned else [(name, b - 1)]), "GE": [(name, b - 1)], "NE": [(name, b)]}[mode]
+
+    def run(lines):
+        with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+            f.write("\n".join(lines) + "\n")
+        try:
+            return subprocess.run([SELFTEST, f.name], capture_output=True, text=True, timeout=60)
+        finally:
+            os.unlink(f.name)
+    n = 0
+    for module, (block, typ) in blocks.items():
+        head = ["active_window:", "  type: \"ActiveWindow\"", "  %s:" % block] + (["    type: \"%s\"" % typ] if typ else [])
+        assert run(head + ["    verbosity: 0"]).returncode == 0, module  # (the block itself is fine)
+        for c in checks[module]:
+            for v in violations(c):
+                out = run(head + ["    %s: %r" % (v[k], v[k + 1]) for k in range(0, len(v), 2)])
+                assert out.returncode != 0 and "what()" in out.stderr, (module, c, v, out.stderr[-200:])
+                n += 1
+    assert n >= 30

@@ -6,7 +6,7 @@ import numpy as np
 f32 = np.float32
 
 
-def extract_static(e, t, threads=1):
+def extract_static(e, t, threads=1, min_observations=0.0):
     """MeshObjectExtractor::extractObject for a static track, restated on the oracle (mesh_object_extractor.cpp:81-118,
     174-304, 306-356; configuration of bench.py's OBJECT_YAML).  -> None (no object) or dict(points, bbox_min, bbox_max)."""
     from khronos_amd import default_config
@@ -45,7 +45,7 @@ def extract_static(e, t, threads=1):
         for fr, oimg, sem_id in frames:
             om.integrate(e.osen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], None, object_image=oimg.astype(np.int32),
                          object_id=sem_id, allocate_blocks=False)
-        om.object_prune(0.5, 0.0)
+        om.object_prune(0.5, float(min_observations))  # (min_object_reconstruction_observations; OBJECT_YAML: 0)
         om.generate_mesh(True, False)
         pts = om.mesh()["points"].astype(f32)
     finally:

@@ -391,7 +391,8 @@ def test_change_detector_vote_equals_reference_code():
 
 
 @needs_ref
-def test_object_extraction_equals_reference_code():
+@pytest.mark.parametrize("min_obs", [0, 3])
+def test_object_extraction_equals_reference_code(min_obs):
     """MeshObjectExtractor::extractObject (mesh_object_extractor.cpp:81-356), the reference's own code -- track validity, frame
     collection, extent merge, volume gates, object-map sizing and block allocation, ObjectIntegrator driven frame by frame, the
     confidence pruning loop, mesh, bounding box, shift to the box frame -- against tests/extract_replica.py, the restatement the
@@ -417,7 +418,7 @@ def test_object_extraction_equals_reference_code():
                                          num_labels=2, semantic_mode=1), 1)
     ref = pyref.RefExtractor(LIB, ocfg, osen, min_object_allocation_confidence=0.5, min_object_volume=0.005, max_object_volume=10.0,
                              only_extract_reconstructed_objects=True, min_dynamic_displacement=1.0, min_object_reconstruction_confidence=0.5,
-                             min_object_reconstruction_observations=0, object_reconstruction_resolution=-0.02)
+                             min_object_reconstruction_observations=min_obs, object_reconstruction_resolution=-0.02)
     for i in range(0, 36, 3):
         fr = s.render(i)
         e.frames.append(fr)
@@ -437,7 +438,7 @@ def test_object_extraction_equals_reference_code():
     assert len(tracks) >= 4
     # every track as it stands, plus: one with too few observations (confidence gate), one renamed dynamic
     for t in tracks:
-        want = extract_static(e, t, 2)
+        want = extract_static(e, t, 2, min_observations=min_obs)  # (computeConfidence: -1 below the observation count, :342-356)
         got = ref.extract(t.id, t.is_dynamic, float(t.confidence), t.first_seen, t.last_seen, t.category if t.has_semantics else -1,
                           [tuple(o) for o in t.observations])
         assert (want is None) == (got is None), (t.id, len(t.observations), float(t.confidence))

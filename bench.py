@@ -10,6 +10,9 @@ active_window.cpp:217-249 at uHumans2's min_output_separation = 0.4 s).
 Workloads (`--config`, BASELINE.json `configs`; explicit --width / --voxel-size / ... override a preset):
   c3 (default, the configuration the metric is quoted on): 1280x720 RGB-D + labels, 2 cm voxels, truncation 6 cm,
      K = 20 labels, MotionDetector + object detection / tracking / extraction on, output every 4th frame (0.4 s).
+     (Run on stamps EXACTLY 0.1 s apart, the reference's own rate limit -- last + fromSeconds(0.4f) > stamp, active_window.cpp:158-160 --
+     lets only every FIFTH frame through, 0.4f being 0.4000000060; tests/test_cpu_ref_pin.py runs the reference's ActiveWindow and
+     shows it.  Every 4th is the nominal cadence and the heavier load, so it is what is timed.)
   c2: 640x480, 5 cm voxels, truncation 15 cm, static background TSDF only (khronos_ros/config/mapper/ground_truth.yaml:56-94:
      no motion detector, no object detector, min_output_separation 0 = mesh + archival every frame).
   c1: 640x480, 5 cm voxels, the projective integrator alone (allocation + TSDF / label update of each frame).

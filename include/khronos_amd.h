@@ -98,6 +98,22 @@ typedef struct khr_config {
    * reports the true count and khr_snapshot_download fails with KHR_ENOMEM (never a silently partial clone).  The arena is
    * sized for the capacity (~100 KB of HBM per block with all default fields) and recycled between outputs. */
   uint32_t max_snapshot_blocks;
+  /* ---- ASSUMPTIONS.md [A] choices of the absent upstream integrators, as switches (round 5).  Zero = the semantics every
+   * earlier round implemented; a maintainer with a Hydra checkout flips them without touching code and
+   * oracle/ref_recipe/dump_vectors.cpp records which setting matched.  HIP == CPU restatement is tested in every setting. ---- */
+  /* block allocation of ProjectiveIntegrator::updateMap (call active_window.cpp:210): 0 = a candidate block is visible iff its
+   * CENTRE lies in the inflated view frustum; 1 = panoptic_mapping lineage: the candidate POINT camera_W + offset * block_size
+   * (integer offsets) is tested and the block that contains that point is allocated.  The two differ on boundary blocks. */
+  int32_t alloc_candidate;
+  /* colour blend of updateVoxel: 0 = with the voxel weight AFTER the update (blend follows the weight update), 1 = with the weight
+   * BEFORE it: c' = (c_old * w_old + c_new * w) / (w_old + w). */
+  int32_t color_blend_weight;
+  /* MeshIntegrator vertex attributes (colour, label, stamps; consumers geometry_utils.cpp:66-72): 0 = from the nearer endpoint
+   * voxel of the crossed edge (t <= 0.5 -> first endpoint), 1 = from the voxel that CONTAINS the vertex (at exactly t = 0.5 the
+   * endpoint with the larger coordinate along the edge). */
+  int32_t mesh_attr_source;
+  /* |sdf_a - sdf_b| below which a crossed edge is cut at t = 0.5; 0 = 1e-6 (voxblox lineage) */
+  float mesh_degenerate_eps;
 } khr_config;
 
 typedef struct khr_sensor {

@@ -61,6 +61,7 @@ enum Counter : int {
   C_N_ITEMS1,
   C_N_ITEMS2,
   C_N_ITEMS3,
+  C_BAND_CURSOR,     // k_fuse3: record chunks drawn from the pool in the last integrate (BandPool::cursor)
   C_COUNT = 32
 };
 enum Stat64 : int { S_UPD = 0 /* unused */, S_BAND /* unused */, S_MESH_VERTS, S_PRUNED, S_CUM_UPD, S_CUM_BAND, S_CUM_VISITED, S_CUM_CALLS, S_COUNT = 8 };
@@ -134,6 +135,9 @@ struct DevParams {
   double temporal_buffer, temporal_window;
   int nn;
   float mesh_min_weight;
+  float mesh_eps;        // khr_config.mesh_degenerate_eps (0 -> 1e-6)
+  int mesh_attr_source;  // khr_config.mesh_attr_source
+  int alloc_candidate;   // khr_config.alloc_candidate
   int rank, world;
   int dbg;  // ablation switches (env KHR_DEBUG), 0 in production
 };
@@ -333,6 +337,7 @@ __device__ inline void beginIntegrate(DevMap m, int nvox, uint32_t* wg_stats) {
     m.counters[C_N_ITEMS1] = 0u;
     m.counters[C_N_ITEMS2] = 0u;
     m.counters[C_N_ITEMS3] = 0u;
+    m.counters[C_BAND_CURSOR] = 0u;
   }
 }
 

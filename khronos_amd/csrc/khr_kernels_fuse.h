@@ -124,6 +124,8 @@ struct FuseArgs : FuseFrame {
             // 4 no distance / weight loads, 8 range gathers from a fixed address, 16 geometry only
   int band_mode;  // 1 = likelihood rows moved as whole cache lines by 8 lanes each (fuseBandRows, default where the rows are
                   // padded), 0 = lane <-> record (fuseBandRecord; env KHR_FUSE_BAND=0)
+  int blend_pre;  // khr_config.color_blend_weight: 0 = the colour blend uses the voxel weight AFTER the update (panoptic-lineage order,
+                  // ASSUMPTIONS.md A.3), 1 = the weight before it.  The record's blend-weight field carries the one chosen.
   // speculative launch (khr_process_frame): the kernel is queued BEFORE the host has seen the motion detector's seed count
   // and does nothing when *gate != 0 (seeds exist: the host then queues the clustering chain and the real launch).  Frames
   // without seeds -- most of them -- no longer idle the main stream for the seed count's trip to the host and back.
@@ -291,7 +293,7 @@ __device__ inline void fuseBandRecord(FuseArgsK ka, FuseFrameK kf, size_t slot, 
 typedef uint32_t u2u __attribute__((ext_vector_type(2), aligned(4)));  // two adjacent rgba8 pixels, 4-byte aligned
 constexpr int kRowPasses = 8;  // part-B passes whose row vectors are in flight together (KS = 32: a whole 64-record chunk)
 // (frames without colour or without labels, the binary object layer and rows that are not padded take fuseBandRecord)
-__device__ inline bool fuseBandRowsOk(int KS, int sem_mode, int do_sem, int has_color) {
+__host__ __device__ inline bool fuseBandRowsOk(int KS, int sem_mode, int do_sem, int has_color) {
   return do_sem && has_color && sem_mode != 1 && (KS & 31) == 0 && KS <= 256;
 }
 // lane i <- lane i + OFF of the same 16-lane row (DPP row_shl; out-of-row sources read 0 and are never used)
@@ -751,7 +753,7 @@ __global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) { 
           uint32_t* const rec = &s_rec[wave][0][pos];
           rec[0] = lin | (use_nearest ? 0x10000u : 0u);
           rec[kFuseCap] = __float_as_uint(w);
-          rec[2 * kFuseCap] = __float_as_uint(w_new);
+          rec[2 * kFuseCap] = __float_as_uint(a.blend_pre ? w_old : w_new);
           rec[3 * kFuseCap] = __float_as_uint(uc);
           rec[4 * kFuseCap] = __float_as_uint(vc);
         }
@@ -1185,7 +1187,7 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
           uint32_t* const rec = &s_rec[wave][0][pos];
           rec[0] = lin | (use_nearest ? 0x10000u : 0u);
           rec[CAP] = __float_as_uint(w);
-          rec[2 * CAP] = __float_as_uint(w_new);
+          rec[2 * CAP] = __float_as_uint(a.blend_pre ? w_old : w_new);
           rec[3 * CAP] = __float_as_uint(uc);
           rec[4 * CAP] = __float_as_uint(vc);
         }

@@ -32,6 +32,7 @@
 #include "khr_kernels_aux.h"
 #include "khr_kernels_fusion.h"
 #include "khr_kernels_fuse.h"
+#include "khr_kernels_fuse3.h"
 #include "khr_kernels_objects.h"
 
 using namespace khr;
@@ -143,6 +144,11 @@ struct khr_ctx {
   unsigned long long* d_digest = nullptr;  // khr_map_digest accumulators
   uint32_t* d_wg_stats = nullptr;
   bool defer_fold = false, fold_pending = false;  // k_fuse's item records: folded by the next k_tracking_select instead of k_fuse_fold
+  // k_fuse3 / k_band3 (round 5): chunked record lists of the in-band voxels (BandPool), sized from a bound on a frame's in-band
+  // volume on first use (grow-only)
+  uint32_t* d_band_rec = nullptr;
+  uint32_t* d_band_n = nullptr;
+  uint32_t band_chunks = 0;
   unsigned char* d_fuse_sink = nullptr;  // k_fuse: one 256-byte sink line per wave (kFuseStatSlots workgroups x 16 waves)
   uint32_t* d_pix_scratch = nullptr;  // khr_pixel_iou: mask image + counters (allocated on first use)
   size_t pix_words = 0;
@@ -539,7 +545,12 @@ int kFuseExact = -1;    // -1 = !khr_config.relaxed_arithmetic; env KHR_FUSE_EXA
 int kFuseWavesPerCu = 16;  // env KHR_FUSE_WAVES: resident waves per CU the persistent grid is sized for
 constexpr int kFuseWpwDefault = 12;
 int kFuseDbg = 0;       // env KHR_FUSE_DBG: ablation switches (development; selects the DBG instantiation)
-int kFuseVer = 1;       // env KHR_FUSE_V: 1 = k_fuse (per-wave software pipeline), 2 = k_fuse2 (one item per wave, high occupancy)
+int kFuseVer = 1;       // env KHR_FUSE_V: 1 = k_fuse (default: per-wave software pipeline, band phase inside), 2 = k_fuse2 (one item per wave),
+                        // 3 = k_fuse3 + k_band3, 4 = k_fuse3<.., FUSED> (round 5 experiments, khr_kernels_fuse3.h: lean voxel phase at 5 - 8 waves per
+                        // SIMD with the in-band voxels as record lists; parity-green, measured slower than k_fuse in the driver's command), 1 = k_fuse (per-wave software pipeline), 2 = k_fuse2 (one item per wave)
+int kFuse3Waves = 0;    // env KHR_FUSE3_WAVES: resident waves per CU of k_fuse3's persistent grid (0 = what the occupancy query allows)
+int kBand3Waves = 0;    // env KHR_BAND3_WAVES: the same for k_band3
+int kFuse3Occ = 0;      // env KHR_FUSE3_OCC: waves per SIMD k_fuse3 is compiled for (0 = 5 with 4 z ranges per patch, 8 with 8)
 int kTickUnion = 1;     // env KHR_TICK_UNION: khr_tick_integrate updates with ONE launch for all cameras of the tick (tickUnion)
 int kFuseMulti = 1;     // env KHR_FUSE_MULTI: khr_integrate_shared_batch integrates all frames of a batch in one launch (k_fuse2 MULTI)
 constexpr int kMaxMultiFrames = 1024;
@@ -628,6 +639,10 @@ void khr_default_config(khr_config* cfg) {
   cfg->rank = 0;
   cfg->world_size = 1;
   cfg->max_snapshot_blocks = 0;  // = min(max_blocks, 8192)
+  cfg->alloc_candidate = 0;
+  cfg->color_blend_weight = 0;
+  cfg->mesh_attr_source = 0;
+  cfg->mesh_degenerate_eps = 0.f;  // = 1e-6
   cfg->relaxed_arithmetic = 0;  // bit-exact values: 2 % slower update kernel than the relaxed mode (measured), so it is the default
 }
 
@@ -812,6 +827,9 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   p.temporal_window = static_cast<double>(cfg->temporal_window);
   p.nn = cfg->neighbor_connectivity;
   p.mesh_min_weight = cfg->mesh_min_weight;
+  p.mesh_eps = cfg->mesh_degenerate_eps > 0.f ? cfg->mesh_degenerate_eps : 1e-6f;
+  p.mesh_attr_source = cfg->mesh_attr_source;
+  p.alloc_candidate = cfg->alloc_candidate;
   p.rank = cfg->rank;
   p.world = cfg->world_size;
   p.dbg = std::getenv("KHR_DEBUG") ? std::atoi(std::getenv("KHR_DEBUG")) : 0;
@@ -828,6 +846,9 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   if (std::getenv("KHR_TICK_UNION")) kTickUnion = std::atoi(std::getenv("KHR_TICK_UNION"));
   if (std::getenv("KHR_FUSE_MULTI")) kFuseMulti = std::atoi(std::getenv("KHR_FUSE_MULTI"));
   if (std::getenv("KHR_FUSE_V")) kFuseVer = std::atoi(std::getenv("KHR_FUSE_V"));
+  if (std::getenv("KHR_FUSE3_WAVES")) kFuse3Waves = std::atoi(std::getenv("KHR_FUSE3_WAVES"));
+  if (std::getenv("KHR_BAND3_WAVES")) kBand3Waves = std::atoi(std::getenv("KHR_BAND3_WAVES"));
+  if (std::getenv("KHR_FUSE3_OCC")) kFuse3Occ = std::atoi(std::getenv("KHR_FUSE3_OCC"));
   if (std::getenv("KHR_NO_EARLY_INGEST")) c->early_ingest = false;
 
   DevMap& m = c->m;
@@ -1008,6 +1029,7 @@ void khr_destroy(khr_ctx* c) {
   if (c->d_halo_keys) { hipFree(c->d_halo_keys); hipFree(c->d_halo_vals); }
   if (c->d_mh_recs) { hipFree(c->d_mh_recs); hipFree(c->d_mh_keys); hipFree(c->d_mh_vals); }
   if (c->d_pix_scratch) hipFree(c->d_pix_scratch);
+  if (c->d_band_rec) { hipFree(c->d_band_rec); hipFree(c->d_band_n); }
   if (c->d_inst) hipFree(c->d_inst);
   if (c->pending_snapshot) khr_snapshot_release(c->pending_snapshot);
   if (c->snap_stream) {
@@ -1363,6 +1385,7 @@ static void fillFuseMap(khr_ctx* c, FuseArgs* a) {
   // tests/test_cpu_host.py::test_update_kernel_keeps_its_registers guards the build against that)
   a->band_mode = (kFuseBand == 1 && c->cfg.max_frame_pixels <= 640u * 480u) ? 0 : kFuseBand;
   a->sink = c->d_fuse_sink;
+  a->blend_pre = c->cfg.color_blend_weight != 0;
 }
 
 // All frames of a batch in ONE launch (k_fuse2<.., MULTI>): every wave item is walked through the frames in order.  Only for
@@ -1413,6 +1436,70 @@ static int integrateUpdateMulti(khr_ctx* c, khr_ctx* src, const int* src_slots, 
   return KHR_OK;
 }
 
+// k_fuse3 + k_band3 (khr_kernels_fuse3.h): the update of a 16^3-voxel map with the reference's default integrator switches and
+// colour + label frames.  Returns KHR_OK when the pair was queued, 1 when the record pool could not be provided (the caller then
+// takes k_fuse).
+static int integrateUpdate3(khr_ctx* c, const FrameSlot& s, const FuseArgs& a, const FuseList& list, bool exact, int zs) {
+  auto gridOf = [&](const void* kern, int wpw, int want_waves) {
+    static std::map<const void*, int> cache;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(kern);
+    if (it != cache.end()) return it->second;
+    int per_cu = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * wpw, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (want_waves > 0) per_cu = std::max(1, std::min(per_cu, want_waves / wpw));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    int grid = std::min(kFuseStatSlots, per_cu * cus) / 8 * 8;
+    grid = std::max(8, grid);
+    cache[kern] = grid;
+    if (std::getenv("KHR_VERBOSE")) std::fprintf(stderr, "[khr] fuse3 kernel %p: %d workgroups of %d waves (%d per CU)\n", kern, grid, wpw, per_cu);
+    return grid;
+  };
+  constexpr int WPW = 8, BW = 4;
+  // instantiations: 4 z ranges per patch (items of 64 x 4 voxels) compiled for 5 waves per SIMD, 8 z ranges (64 x 2 voxels) for 7;
+  // fused = the workgroups consume their own record streams (KHR_FUSE_V=4), else k_band3 follows (KHR_FUSE_V=3)
+  const bool fused = kFuseVer >= 4;
+  const void* kf = nullptr;
+  auto pick = [&](auto run) {
+    if (zs == 8) {
+      if (fused) { if (exact) run(&k_fuse3<8, true, WPW, 7, true>); else run(&k_fuse3<8, false, WPW, 7, true>); }
+      else { if (exact) run(&k_fuse3<8, true, WPW, 7, false>); else run(&k_fuse3<8, false, WPW, 7, false>); }
+    } else {
+      if (fused) { if (exact) run(&k_fuse3<4, true, WPW, 5, true>); else run(&k_fuse3<4, false, WPW, 5, true>); }
+      else { if (exact) run(&k_fuse3<4, true, WPW, 5, false>); else run(&k_fuse3<4, false, WPW, 5, false>); }
+    }
+  };
+  pick([&](auto kern) { kf = reinterpret_cast<const void*>(kern); });
+  const void* kb = reinterpret_cast<const void*>(&k_band3<BW, 5>);
+  const int grid = gridOf(kf, WPW, kFuse3Waves);
+  const int grid_b = gridOf(kb, BW, kBand3Waves);
+  // record pool: one static chunk per workgroup + a bound on the in-band volume of a frame -- the voxels within the truncation
+  // distance of the surface along the view rays fill at most (solid angle) x max_range^2 x 2 truncation / voxel^3; x 1.5 for the
+  // lattice and the drop-off at the band's edge
+  const khr_sensor& sen = s.sensor;
+  const double omega = (static_cast<double>(sen.width) / sen.fx) * (static_cast<double>(sen.height) / sen.fy);
+  const double vol = omega * static_cast<double>(sen.max_range) * sen.max_range * 2.0 * c->p.trunc;
+  const double recs = 1.5 * vol / (static_cast<double>(c->p.vs) * c->p.vs * c->p.vs);
+  const uint64_t want64 = static_cast<uint64_t>(kFuseStatSlots) + static_cast<uint64_t>(recs / kBandChunk) + 64u;
+  if (want64 > (1u << 17)) return 1;  // (2.7 GB of records: not a frame this path is meant for)
+  const uint32_t want = static_cast<uint32_t>(want64);
+  if (want > c->band_chunks) {
+    // grow-only; happens on the first frames of a context (hipMalloc / hipFree wait for the device)
+    if (c->d_band_rec) { hipStreamSynchronize(c->stream); hipFree(c->d_band_rec); hipFree(c->d_band_n); c->d_band_rec = nullptr; c->d_band_n = nullptr; c->band_chunks = 0; }
+    const uint32_t n = want + want / 4;
+    if (hipMalloc(reinterpret_cast<void**>(&c->d_band_rec), static_cast<size_t>(n) * kBandFields * kBandChunk * 4u) != hipSuccess) { c->d_band_rec = nullptr; return 1; }
+    if (hipMalloc(reinterpret_cast<void**>(&c->d_band_n), static_cast<size_t>(n) * 4u) != hipSuccess) { hipFree(c->d_band_rec); c->d_band_rec = nullptr; c->d_band_n = nullptr; return 1; }
+    hipMemsetAsync(c->d_band_n, 0, static_cast<size_t>(n) * 4u, c->stream);
+    c->band_chunks = n;
+  }
+  BandPool bp{c->d_band_rec, c->d_band_n, &c->m.counters[C_BAND_CURSOR], &c->m.counters[C_BAND_OVERFLOW], c->band_chunks, static_cast<uint32_t>(grid)};
+  pick([&](auto kern) { KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(64 * WPW), a, list, bp); });
+  if (!fused) KHR_LAUNCH_TIMED(7, (&k_band3<BW, 5>), dim3(grid_b), dim3(64 * BW), a, bp);
+  return KHR_OK;
+}
+
 static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allocate_blocks, int use_mask,
                            int object_id, const UpdateLists* lists = nullptr, const uint32_t* gate = nullptr) {
   DevMap& m = c->m;
@@ -1449,7 +1536,13 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
       // non-default switches are test configurations: they always run the bit-exact arithmetic
       a.gate = gate;
       constexpr int WD = kFuseWpwDefault;
-      if (kFuseVer == 2 && V == 16 && defcfg && exact) {
+      if (kFuseVer >= 3 && V == 16 && defcfg && fuseBandRowsOk(a.KS, a.sem_mode, a.do_sem, a.has_color) && c->m.capacity <= (1u << 20) &&
+          integrateUpdate3(c, s, a, list, exact, ZS) == KHR_OK) {
+        // k_fuse3 + k_band3 took the call
+        if (c->defer_fold) c->fold_pending = true;
+        else hipLaunchKernelGGL(k_fuse_fold, dim3((c->m.capacity + 255) / 256), dim3(256), 0, c->stream, m.blk_flags, m.blk_band,
+                                &m.counters[C_MAX_SLOT], gate);
+      } else if (kFuseVer == 2 && V == 16 && defcfg && exact) {
         // k_fuse2, single frame (A/B switch KHR_FUSE_V=2): 16 waves per workgroup, compiled for 4 waves per SIMD
         constexpr int Z2 = (V == 16 ? ZS : 4);
         auto kern = &k_fuse2<16, Z2, true, true, 16, 4>;
@@ -3661,7 +3754,7 @@ int khr_get_stats(khr_ctx* c, khr_stats* out) {
   s.n_tsdf_blocks = c->h_counters[C_N_TSDF];
   s.n_fuse_items = static_cast<uint64_t>(c->h_counters[C_N_ITEMS0]) + c->h_counters[C_N_ITEMS1] + c->h_counters[C_N_ITEMS2] +
                    c->h_counters[C_N_ITEMS3];
-  s.band_overflow = 0;  // the fused update kernel keeps no global record list
+  s.band_overflow = c->h_counters[C_BAND_OVERFLOW];  // k_fuse3: in-band records dropped for lack of record chunks (the pool is sized so that this stays 0)
   s.n_tracking_processed_blocks = c->h_counters[c->ef_cur ? C_N_PROC2 : C_N_PROC];
   s.cum_updated_voxels = st[S_CUM_UPD] + cur_upd;
   s.cum_band_voxels = st[S_CUM_BAND] + cur_band;

@@ -162,6 +162,8 @@ struct DevFrustum {
   float infl;
   int3 bc;  // camera block
   int n_steps;
+  int max_steps;  // alloc_candidate = camera_offset: largest offset of the lineage's candidate cube, floor((max_range + infl) / block_size)
+  float tw[3];    // camera position (world_T_sensor translation): the candidate points are tw + offset * block_size
 };
 
 __host__ __device__ inline uint32_t mix32(uint32_t h) {
@@ -225,6 +227,56 @@ __device__ inline void xform(const float* R, const float* t, float x, float y, f
   o[0] = ((R[0] * x + R[1] * y) + R[2] * z) + t[0];
   o[1] = ((R[3] * x + R[4] * y) + R[5] * z) + t[1];
   o[2] = ((R[6] * x + R[7] * y) + R[8] * z) + t[2];
+}
+
+// pointIsInViewFrustum(p_C, inflation) of the allocation (ASSUMPTIONS.md A.3)
+__device__ inline bool pointInFrustum(const DevFrustum& fr, const float* pc, float max_range) {
+  bool in = !(pc[2] < -fr.infl);
+  const float n2 = (pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2];
+  const float lim = max_range + fr.infl;
+  in = in && !(n2 > lim * lim);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float d = (pc[0] * fr.n[k][0] + pc[1] * fr.n[k][1]) + pc[2] * fr.n[k][2];
+    in = in && !(d < -fr.infl);
+  }
+  return in;
+}
+// Is block (bx, by, bz) one of the blocks ProjectiveIntegrator::updateMap(allocate = true) allocates for this camera?
+// alloc_candidate 0: its centre lies in the inflated frustum.  1 (panoptic_mapping lineage): some candidate point
+// tw + offset * block_size, integer offsets with |offset| <= max_steps, lies in the inflated frustum AND in this block -- the
+// lineage walks the offsets and allocates the block of each passing point; asked per block (one thread per block: allocations
+// stay unique) that is "does any offset that maps here pass".  Per axis at most two offsets map to one block (rounding of
+// tw + d * bs); same float expressions as the CPU restatement, so the sets are equal.
+__device__ inline bool blockIsCandidate(const DevParams& p, const DevFrustum& fr, const float* R, const float* t, float max_range,
+                                        int bx, int by, int bz) {
+  if (p.alloc_candidate == 0) {
+    float pc[3];
+    xform(R, t, (static_cast<float>(bx) + 0.5f) * p.bs, (static_cast<float>(by) + 0.5f) * p.bs, (static_cast<float>(bz) + 0.5f) * p.bs, pc);
+    return pointInFrustum(fr, pc, max_range);
+  }
+  const int b[3] = {bx, by, bz}, bc[3] = {fr.bc.x, fr.bc.y, fr.bc.z};
+  float cand[3][2];
+  int nc[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    nc[a] = 0;
+#pragma unroll
+    for (int e = -1; e <= 1; ++e) {
+      const int d = b[a] - bc[a] + e;
+      if (d < -fr.max_steps || d > fr.max_steps) continue;
+      const float pw = fr.tw[a] + static_cast<float>(d) * p.bs;
+      if (static_cast<int>(floorf(pw * p.bs_inv)) == b[a] && nc[a] < 2) cand[a][nc[a]++] = pw;
+    }
+  }
+  for (int i = 0; i < nc[0]; ++i)
+    for (int j = 0; j < nc[1]; ++j)
+      for (int k = 0; k < nc[2]; ++k) {
+        float pc[3];
+        xform(R, t, cand[0][i], cand[1][j], cand[2][k], pc);
+        if (pointInFrustum(fr, pc, max_range)) return true;
+      }
+  return false;
 }
 
 // FreeSpaceMotionDetector::setUpPointMapPart for one pixel (free_space_motion_detector.cpp:158-203): range / z gates,

@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
           const float s1 = s_d[(ix + bx) + T * ((iy + by) + T * (iz + bz))];
           const float diff = s0 - s1;
           float t = 0.5f;
-          if (fabsf(diff) >= 1e-6f) t = s0 / diff;
+          if (fabsf(diff) >= p.mesh_eps) t = s0 / diff;
           const float p0x = ox + (static_cast<float>(ix + ax) + 0.5f) * p.vs;
           const float p0y = oy + (static_cast<float>(iy + ay) + 0.5f) * p.vs;
           const float p0z = oz + (static_cast<float>(iz + az) + 0.5f) * p.vs;
@@ -1059,9 +1059,11 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
           out.points[3 * vo] = p0x + t * (p1x - p0x);
           out.points[3 * vo + 1] = p0y + t * (p1y - p0y);
           out.points[3 * vo + 2] = p0z + t * (p1z - p0z);
-          // attributes of the nearer endpoint voxel
-          const int sx = (t <= 0.5f) ? ix + ax : ix + bx, sy = (t <= 0.5f) ? iy + ay : iy + by,
-                    sz = (t <= 0.5f) ? iz + az : iz + bz;
+          // attributes of the nearer endpoint voxel (khr_config.mesh_attr_source 0; exactly half way: the first endpoint), or of the
+          // voxel that contains the vertex (1; exactly half way: the endpoint with the larger coordinate along the edge)
+          const bool b_upper = (bx + by + bz) > (ax + ay + az);
+          const bool from_a = p.mesh_attr_source == 1 ? (t < 0.5f || (t == 0.5f && !b_upper)) : (t <= 0.5f);
+          const int sx = from_a ? ix + ax : ix + bx, sy = from_a ? iy + ay : iy + by, sz = from_a ? iz + az : iz + bz;
           int lx = sx, ly = sy, lz = sz, sel = 0;
           if (lx >= VPS) { lx -= VPS; sel |= 1; }
           if (ly >= VPS) { ly -= VPS; sel |= 2; }

@@ -213,20 +213,7 @@ __global__ __launch_bounds__(256) void k_alloc_visible(DevMap m, DevParams p, De
     bx = fr.bc.x + dx;
     by = fr.bc.y + dy;
     bz = fr.bc.z + dz;
-    const float cxw = (static_cast<float>(bx) + 0.5f) * p.bs;
-    const float cyw = (static_cast<float>(by) + 0.5f) * p.bs;
-    const float czw = (static_cast<float>(bz) + 0.5f) * p.bs;
-    float pc[3];
-    xform(f.R, f.t, cxw, cyw, czw, pc);
-    bool in = !(pc[2] < -fr.infl);
-    const float n2 = (pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2];
-    const float lim = f.max_range + fr.infl;
-    in = in && !(n2 > lim * lim);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float d = (pc[0] * fr.n[k][0] + pc[1] * fr.n[k][1]) + pc[2] * fr.n[k][2];
-      in = in && !(d < -fr.infl);
-    }
+    const bool in = blockIsCandidate(p, fr, f.R, f.t, f.max_range, bx, by, bz);
     visible = in && ownerOf(bx, by, bz, p.world) == p.rank;
   }
   uint32_t slot = kInvalidSlot;
@@ -279,23 +266,10 @@ __global__ __launch_bounds__(kTickAllocThreads) void k_tick_alloc(DevMap m, DevP
     by = lo.y + (i / dim.x) % dim.y;
     bz = lo.z + i / (dim.x * dim.y);
     if (ownerOf(bx, by, bz, p.world) == p.rank) {
-      const float cxw = (static_cast<float>(bx) + 0.5f) * p.bs;
-      const float cyw = (static_cast<float>(by) + 0.5f) * p.bs;
-      const float czw = (static_cast<float>(bz) + 0.5f) * p.bs;
       for (int k = 0; k < ncam; ++k) {
         const DevFrustum& fr = tf.fr[k];
         if (abs(bx - fr.bc.x) > fr.n_steps || abs(by - fr.bc.y) > fr.n_steps || abs(bz - fr.bc.z) > fr.n_steps) continue;
-        float pc[3];
-        xform(tf.R[k], tf.t[k], cxw, cyw, czw, pc);
-        bool in = !(pc[2] < -fr.infl);
-        const float n2 = (pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2];
-        const float lim = tf.max_range[k] + fr.infl;
-        in = in && !(n2 > lim * lim);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float d = (pc[0] * fr.n[q][0] + pc[1] * fr.n[q][1]) + pc[2] * fr.n[q][2];
-          in = in && !(d < -fr.infl);
-        }
+        const bool in = blockIsCandidate(p, fr, tf.R[k], tf.t[k], tf.max_range[k], bx, by, bz);
         if (in) seen |= 1u << k;
       }
     }

@@ -481,6 +481,8 @@ DevFrustum makeFrustum(const khr_ctx* c, const DevFrame& f) {
   crossn(br, bl, fr.n[3]);
   fr.infl = 0.8660254f * c->p.bs;
   fr.n_steps = static_cast<int>(std::ceil(f.max_range * c->p.bs_inv)) + 1;
+  fr.max_steps = static_cast<int>(std::floor((f.max_range + fr.infl) * c->p.bs_inv));  // (alloc_candidate = camera_offset; <= n_steps - 1)
+  for (int a = 0; a < 3; ++a) fr.tw[a] = f.tw[a];
   fr.bc = make_int3(static_cast<int>(std::floor(f.tw[0] * c->p.bs_inv)),
                     static_cast<int>(std::floor(f.tw[1] * c->p.bs_inv)),
                     static_cast<int>(std::floor(f.tw[2] * c->p.bs_inv)));

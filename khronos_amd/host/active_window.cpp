@@ -26,6 +26,13 @@ int interpolationFromName(const std::string& n) {
   throw std::invalid_argument("interpolation_method must be one of {nearest, bilinear, adaptive}");
 }
 
+// a two-valued [A] switch by name: 0 for `zero`, 1 for `one`
+int switchFromName(const std::string& v, const char* zero, const char* one, const char* key) {
+  if (v == zero) return 0;
+  if (v == one) return 1;
+  throw std::invalid_argument(std::string(key) + " must be one of {" + zero + ", " + one + "}");
+}
+
 }  // namespace
 
 // ---- FrameData ------------------------------------------------------------------------------------------
@@ -147,6 +154,18 @@ khr_config MeshObjectExtractor::objectMapConfig(float voxel_size) const {
   oc.with_tracking = 0;
   oc.num_labels = 2;
   oc.semantic_mode = 1;
+  // the extractor's own integrators (mesh_object_extractor.cpp:63-64,239,267), not the window's
+  const auto& q = config.projective_integrator;
+  oc.use_weight_dropoff = q.use_weight_dropoff;
+  oc.weight_dropoff_epsilon = q.weight_dropoff_epsilon;
+  oc.use_constant_weight = q.use_constant_weight;
+  oc.max_weight = q.max_weight;
+  oc.interpolation_method = interpolationFromName(q.interpolation_method);
+  oc.color_blend_weight = switchFromName(q.color_blend_weight, "post", "pre", "object_extractor.projective_integrator.color_blend_weight");
+  oc.mesh_min_weight = config.mesh_integrator.min_weight;
+  oc.mesh_attr_source = switchFromName(config.mesh_integrator.attr_source, "nearest", "containing", "object_extractor.mesh_integrator.attr_source");
+  oc.mesh_degenerate_eps = config.mesh_integrator.degenerate_eps;
+  oc.alloc_candidate = 0;  // (object maps are allocated explicitly, allocate = false at :242)
   oc.num_frame_slots = 1;
   oc.max_frame_pixels = 4;
   oc.relaxed_arithmetic = device_config_.relaxed_arithmetic;
@@ -360,6 +379,8 @@ ActiveWindow::Config ActiveWindow::Config::fromYaml(const khronos_amd::YamlNode&
     m->read("max_weight", c.projective_integrator.max_weight);
     m->read("interpolation_method", c.projective_integrator.interpolation_method);
     m->read("num_threads", c.projective_integrator.num_threads);
+    m->read("alloc_candidate", c.projective_integrator.alloc_candidate);
+    m->read("color_blend_weight", c.projective_integrator.color_blend_weight);
     if (const auto* si = m->find("semantic_integrator")) si->read("label_confidence", c.projective_integrator.label_confidence);
   }
   if (const auto* m = n.find("tracking_integrator")) {
@@ -407,13 +428,33 @@ ActiveWindow::Config ActiveWindow::Config::fromYaml(const khronos_amd::YamlNode&
     m->read("object_reconstruction_resolution", e.object_reconstruction_resolution);
     m->read("min_reconstruction_resolution", e.min_reconstruction_resolution);
     m->read("visualize_classification", e.visualize_classification);
+    if (const auto* pi = m->find("projective_integrator")) {  // mesh_object_extractor.cpp:63
+      auto& q = e.projective_integrator;
+      pi->read("verbosity", q.verbosity);
+      pi->read("use_weight_dropoff", q.use_weight_dropoff);
+      pi->read("weight_dropoff_epsilon", q.weight_dropoff_epsilon);
+      pi->read("use_constant_weight", q.use_constant_weight);
+      pi->read("max_weight", q.max_weight);
+      pi->read("interpolation_method", q.interpolation_method);
+      pi->read("num_threads", q.num_threads);
+      pi->read("color_blend_weight", q.color_blend_weight);
+    }
+    if (const auto* mi = m->find("mesh_integrator")) {  // mesh_object_extractor.cpp:64
+      mi->read("min_weight", e.mesh_integrator.min_weight);
+      mi->read("attr_source", e.mesh_integrator.attr_source);
+      mi->read("degenerate_eps", e.mesh_integrator.degenerate_eps);
+    }
   }
   if (const auto* m = n.find("extraction_worker")) {
     m->read("num_workers", c.extraction_worker.num_workers);
     m->read("poll_time_us", c.extraction_worker.poll_time_us);
     m->read("verbosity", c.extraction_worker.verbosity);
   }
-  if (const auto* m = n.find("mesh_integrator")) m->read("min_weight", c.mesh_integrator.min_weight);
+  if (const auto* m = n.find("mesh_integrator")) {
+    m->read("min_weight", c.mesh_integrator.min_weight);
+    m->read("attr_source", c.mesh_integrator.attr_source);
+    m->read("degenerate_eps", c.mesh_integrator.degenerate_eps);
+  }
   if (const auto* m = n.find("frame_data_buffer")) {
     auto& b = c.frame_data_buffer;
     m->read("max_buffer_size", b.max_buffer_size);
@@ -475,6 +516,12 @@ void ActiveWindow::Config::checkValid() const {
   if (!tracker_type.empty() && tracker_type != "MaxIouTracker" && tracker_type != "ExternalTracker")
     throw std::invalid_argument("unknown tracker type '" + tracker_type + "'");
   interpolationFromName(projective_integrator.interpolation_method);
+  interpolationFromName(object_extractor.projective_integrator.interpolation_method);
+  switchFromName(projective_integrator.alloc_candidate, "block_centre", "camera_offset", "projective_integrator.alloc_candidate");
+  switchFromName(projective_integrator.color_blend_weight, "post", "pre", "projective_integrator.color_blend_weight");
+  switchFromName(mesh_integrator.attr_source, "nearest", "containing", "mesh_integrator.attr_source");
+  switchFromName(object_extractor.projective_integrator.color_blend_weight, "post", "pre", "object_extractor.projective_integrator.color_blend_weight");
+  switchFromName(object_extractor.mesh_integrator.attr_source, "nearest", "containing", "object_extractor.mesh_integrator.attr_source");
 }
 
 // ---- ActiveWindow ------------------------------------------------------------------------------------------------
@@ -509,6 +556,10 @@ ActiveWindow::ActiveWindow(const Config& cfg, const OutputQueue::Ptr& output_que
   d.md_max_range = config.motion_detector.max_range;
   d.md_min_z_coordinate = config.motion_detector.min_z_coordinate;
   d.mesh_min_weight = config.mesh_integrator.min_weight;
+  d.alloc_candidate = switchFromName(config.projective_integrator.alloc_candidate, "block_centre", "camera_offset", "projective_integrator.alloc_candidate");
+  d.color_blend_weight = switchFromName(config.projective_integrator.color_blend_weight, "post", "pre", "projective_integrator.color_blend_weight");
+  d.mesh_attr_source = switchFromName(config.mesh_integrator.attr_source, "nearest", "containing", "mesh_integrator.attr_source");
+  d.mesh_degenerate_eps = config.mesh_integrator.degenerate_eps;
   d.max_blocks = config.max_blocks;
   d.max_frame_pixels = config.max_frame_pixels;
   d.max_mesh_vertices = config.max_mesh_vertices;

@@ -313,6 +313,23 @@ class MeshObjectExtractor : public ObjectExtractor {  // mesh_object_extractor.h
     float object_reconstruction_resolution = -0.02f;
     float min_reconstruction_resolution = 0.f;
     bool visualize_classification = false;
+    // the extractor's OWN integrators (mesh_object_extractor.h:87-91, used at mesh_object_extractor.cpp:239,267; uHumans2.yaml:99-100
+    // sets their thread counts): the object maps are integrated and meshed with THESE settings, not with the window's
+    struct ProjectiveIntegrator {
+      int verbosity = 0;
+      bool use_weight_dropoff = true;
+      float weight_dropoff_epsilon = -1.f;
+      bool use_constant_weight = false;
+      float max_weight = 1e5f;
+      std::string interpolation_method = "adaptive";
+      int num_threads = -1;
+      std::string color_blend_weight = "post";  // [A] switch (khr_config.color_blend_weight): "post" | "pre"
+    } projective_integrator;
+    struct MeshIntegrator {
+      float min_weight = 1e-4f;
+      std::string attr_source = "nearest";  // [A] switch (khr_config.mesh_attr_source): "nearest" | "containing"
+      float degenerate_eps = 1e-6f;         // [A] switch (khr_config.mesh_degenerate_eps)
+    } mesh_integrator;
     uint32_t max_object_blocks = 32768;  // device pool of the object mini-map
   } const config;
   MeshObjectExtractor(const Config& config, const khr_config& aw_device_config);
@@ -406,6 +423,10 @@ class ActiveWindow : public hydra::ActiveWindowModule {  // active_window.h:67
       std::string interpolation_method = "adaptive";
       int num_threads = -1;
       float label_confidence = 0.9f;
+      // ASSUMPTIONS.md [A] choices of the absent upstream integrator as switches (khr_config.alloc_candidate / color_blend_weight;
+      // not keys of the reference: INTEGRATION.md 3a)
+      std::string alloc_candidate = "block_centre";  // "block_centre" | "camera_offset"
+      std::string color_blend_weight = "post";       // "post" | "pre"
     } projective_integrator;
     TrackingIntegrator::Config tracking_integrator;
     std::string motion_detector_type;    // "" = none, "FreeSpaceMotionDetector"
@@ -418,7 +439,11 @@ class ActiveWindow : public hydra::ActiveWindowModule {  // active_window.h:67
     std::string object_extractor_type;   // "" = none, "MeshObjectExtractor"
     MeshObjectExtractor::Config object_extractor;
     ObjectWorkerPool::Config extraction_worker;
-    struct MeshIntegrator { float min_weight = 1e-4f; } mesh_integrator;
+    struct MeshIntegrator {
+      float min_weight = 1e-4f;
+      std::string attr_source = "nearest";  // [A] switch (khr_config.mesh_attr_source): "nearest" | "containing"
+      float degenerate_eps = 1e-6f;         // [A] switch (khr_config.mesh_degenerate_eps)
+    } mesh_integrator;
     FrameDataBuffer::Config frame_data_buffer;
     // `khronos_sinks:` (active_window.cpp:70): a list of {type: <registered sink type>, ...} mappings; each is instantiated by
     // the factory registered under its type (registerKhronosSink; config_utilities' RegistrationWithConfig role) at

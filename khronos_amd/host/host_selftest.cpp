@@ -227,13 +227,22 @@ int main(int argc, char** argv) {
                 "\"min_output_separation\": %g, \"motion_detector\": \"%s\", \"md_min_cluster_size\": %d, "
                 "\"md_min_separation_distance\": %g, \"md_max_range\": %g, \"temporal_window\": %g, \"object_extractor\": \"%s\", "
                 "\"min_object_volume\": %g, \"max_buffer_size\": %zu, \"object_detector\": \"%s\", \"tracker\": \"%s\", "
-                "\"only_extract_reconstructed_objects\": %d, \"object_reconstruction_resolution\": %g}\n",
+                "\"only_extract_reconstructed_objects\": %d, \"object_reconstruction_resolution\": %g, "
+                "\"alloc_candidate\": \"%s\", \"color_blend_weight\": \"%s\", \"mesh_attr_source\": \"%s\", \"mesh_degenerate_eps\": %g, "
+                "\"object_interpolation_method\": \"%s\", \"object_max_weight\": %g, \"object_use_weight_dropoff\": %d, "
+                "\"object_color_blend_weight\": \"%s\", \"object_mesh_min_weight\": %g, \"object_mesh_attr_source\": \"%s\"}\n",
                 cfg.volumetric_map.voxel_size, cfg.volumetric_map.truncation_distance, cfg.volumetric_map.voxels_per_side,
                 int(cfg.volumetric_map.with_semantics), cfg.min_output_separation, cfg.motion_detector_type.c_str(),
                 cfg.motion_detector.min_cluster_size, cfg.motion_detector.min_separation_distance, cfg.motion_detector.max_range,
                 cfg.tracking_integrator.temporal_window, cfg.object_extractor_type.c_str(), cfg.object_extractor.min_object_volume,
                 cfg.frame_data_buffer.max_buffer_size, cfg.object_detector_type.c_str(), cfg.tracker_type.c_str(),
-                int(cfg.object_extractor.only_extract_reconstructed_objects), cfg.object_extractor.object_reconstruction_resolution);
+                int(cfg.object_extractor.only_extract_reconstructed_objects), cfg.object_extractor.object_reconstruction_resolution,
+                cfg.projective_integrator.alloc_candidate.c_str(), cfg.projective_integrator.color_blend_weight.c_str(),
+                cfg.mesh_integrator.attr_source.c_str(), cfg.mesh_integrator.degenerate_eps,
+                cfg.object_extractor.projective_integrator.interpolation_method.c_str(), cfg.object_extractor.projective_integrator.max_weight,
+                int(cfg.object_extractor.projective_integrator.use_weight_dropoff),
+                cfg.object_extractor.projective_integrator.color_blend_weight.c_str(), cfg.object_extractor.mesh_integrator.min_weight,
+                cfg.object_extractor.mesh_integrator.attr_source.c_str());
     return 0;
   }
   // ---- config validation (tracking_integrator.cpp:61-65) ----

@@ -379,8 +379,11 @@ void integrateBlock(IntegrateCtx& ctx, Block& blk) {
         // updateVoxel
         TsdfVoxel& tv = blk.tsdf[lin];
         const float sdf_c = std::max(std::min(trunc, sdf), -trunc);
+        const float w_before = tv.weight;
         tv.distance = (tv.distance * tv.weight + sdf_c * w) / (tv.weight + w);
         tv.weight = std::min(tv.weight + w, c.max_weight);
+        // [A] color_blend_weight: the blend below uses the voxel weight after (0, panoptic-lineage order) or before (1) this update
+        const float w_blend = c.color_blend_weight ? w_before : tv.weight;
         if (c.with_tracking) blk.tracking[lin].last_observed = f.timestamp_ns;
         ++n_upd;
         any = true;
@@ -394,10 +397,10 @@ void integrateBlock(IntegrateCtx& ctx, Block& blk) {
                 a = a + iw.w[i] * static_cast<float>(f.color[3 * (iw.v[i] * s.width + iw.u[i]) + ch]);
               col[ch] = static_cast<float>(toU8(a));
             }
-            const float tot = tv.weight + w;
-            tv.r = toU8((static_cast<float>(tv.r) * tv.weight + col[0] * w) / tot);
-            tv.g = toU8((static_cast<float>(tv.g) * tv.weight + col[1] * w) / tot);
-            tv.b = toU8((static_cast<float>(tv.b) * tv.weight + col[2] * w) / tot);
+            const float tot = w_blend + w;
+            tv.r = toU8((static_cast<float>(tv.r) * w_blend + col[0] * w) / tot);
+            tv.g = toU8((static_cast<float>(tv.g) * w_blend + col[1] * w) / tot);
+            tv.b = toU8((static_cast<float>(tv.b) * w_blend + col[2] * w) / tot);
             tv.a = 255;
           }
           if (c.with_semantics && have_label && label >= 0 && label < c.num_labels) {
@@ -529,6 +532,33 @@ int orc_integrate(orc_map* m, const orc_sensor* s, const orc_frame* f, int alloc
     const I3 bc = {static_cast<int32_t>(std::floor(ctx.pose.tw[0] * m->bs_inv)),
                    static_cast<int32_t>(std::floor(ctx.pose.tw[1] * m->bs_inv)),
                    static_cast<int32_t>(std::floor(ctx.pose.tw[2] * m->bs_inv))};
+    if (c.alloc_candidate == 1) {
+      // [A] alloc_candidate = camera_offset (panoptic_mapping lineage, Camera::findVisibleBlocks): the candidate POINT
+      // camera_W + offset * block_size, integer offsets up to floor((max_range + half diagonal) / block_size), is tested against
+      // the inflated frustum, and the block that contains the point is allocated (an index set: two offsets may map to one block)
+      const int ms = static_cast<int>(std::floor((s->max_range + infl) * m->bs_inv));
+      std::set<std::array<int32_t, 3>> seen;
+      for (int dz = -ms; dz <= ms; ++dz) {
+        for (int dy = -ms; dy <= ms; ++dy) {
+          for (int dx = -ms; dx <= ms; ++dx) {
+            const float pxw = ctx.pose.tw[0] + static_cast<float>(dx) * m->bs;
+            const float pyw = ctx.pose.tw[1] + static_cast<float>(dy) * m->bs;
+            const float pzw = ctx.pose.tw[2] + static_cast<float>(dz) * m->bs;
+            float pc[3];
+            xform(ctx.pose.R, ctx.pose.t, pxw, pyw, pzw, pc);
+            if (!pointInFrustum(fr, pc, s->max_range, infl)) continue;
+            const I3 b = {static_cast<int32_t>(std::floor(pxw * m->bs_inv)), static_cast<int32_t>(std::floor(pyw * m->bs_inv)),
+                          static_cast<int32_t>(std::floor(pzw * m->bs_inv))};
+            if (ownerOf(b, c.world_size) != c.rank) continue;
+            if (!seen.insert({b.x, b.y, b.z}).second) continue;
+            bool created = false;
+            Block* blk = m->allocate(b, &created);
+            if (created) ++n_new;
+            work.push_back(blk);
+          }
+        }
+      }
+    } else
     for (int dz = -n; dz <= n; ++dz) {
       for (int dy = -n; dy <= n; ++dy) {
         for (int dx = -n; dx <= n; ++dx) {
@@ -1319,6 +1349,7 @@ static const int kEdgePairs[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5
 int64_t orc_generate_mesh(orc_map* m, int only_mesh_updated, int clear_flag) {
   const orc_config& c = m->cfg;
   const int vps = m->vps;
+  const float mesh_eps = c.mesh_degenerate_eps > 0.f ? c.mesh_degenerate_eps : 1e-6f;
   std::vector<Block*> work;
   for (auto& kv : m->blocks) {
     if (!only_mesh_updated || kv.second->mesh_updated) work.push_back(kv.second.get());
@@ -1404,9 +1435,17 @@ int64_t orc_generate_mesh(orc_map* m, int only_mesh_updated, int clear_flag) {
             if ((s0 < 0.f && s1 >= 0.f) || (s0 >= 0.f && s1 < 0.f)) {
               const float diff = s0 - s1;
               float t = 0.5f;
-              if (std::fabs(diff) >= 1e-6f) t = s0 / diff;
+              if (std::fabs(diff) >= mesh_eps) t = s0 / diff;
               for (int d = 0; d < 3; ++d) ev[e][d] = pos[a][d] + t * (pos[bq][d] - pos[a][d]);
-              esrc[e] = (t <= 0.5f) ? a : bq;
+              if (c.mesh_attr_source == 1) {
+                // [A] mesh_attr_source = containing voxel: the voxel whose cell holds the vertex; exactly half way the one with the
+                // larger coordinate along the edge (floor of the vertex position)
+                const bool b_is_upper = (kCubeOffsets[bq][0] + kCubeOffsets[bq][1] + kCubeOffsets[bq][2]) >
+                                        (kCubeOffsets[a][0] + kCubeOffsets[a][1] + kCubeOffsets[a][2]);
+                esrc[e] = (t < 0.5f) ? a : ((t > 0.5f) ? bq : (b_is_upper ? bq : a));
+              } else {
+                esrc[e] = (t <= 0.5f) ? a : bq;
+              }
             }
           }
           const int8_t* row = kMcTriTable[index];

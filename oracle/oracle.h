@@ -62,6 +62,11 @@ typedef struct orc_config {
   /* multi-GPU emulation: only blocks with owner(block) == rank are allocated */
   int32_t rank;
   int32_t world_size;
+  /* ASSUMPTIONS.md [A] choices as switches (round 5; khr_config has the same four).  0 = what the oracle always did. */
+  int32_t alloc_candidate;     /* 0 block centre in the inflated frustum, 1 camera_W + offset * block_size tested, block of that point allocated */
+  int32_t color_blend_weight;  /* 0 voxel weight after the update, 1 before it */
+  int32_t mesh_attr_source;    /* 0 nearer endpoint voxel (t <= 0.5 -> first), 1 the voxel that contains the vertex */
+  float mesh_degenerate_eps;   /* 0 = 1e-6 */
 } orc_config;
 
 typedef struct orc_sensor {

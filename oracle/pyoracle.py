@@ -24,6 +24,7 @@ class OrcConfig(C.Structure):
         ("md_max_cluster_size", C.c_int32), ("md_min_separation_distance", C.c_float),
         ("md_max_range", C.c_float), ("md_min_z_coordinate", C.c_float),
         ("mesh_min_weight", C.c_float), ("num_threads", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
+        ("alloc_candidate", C.c_int32), ("color_blend_weight", C.c_int32), ("mesh_attr_source", C.c_int32), ("mesh_degenerate_eps", C.c_float),
     ]
 
 
@@ -140,7 +141,7 @@ def config_from(khr_cfg, num_threads=0):
         if name == "num_threads":
             o.num_threads = num_threads
         else:
-            setattr(o, name, getattr(khr_cfg, name))
+            setattr(o, name, getattr(khr_cfg, name, 0))
     return o
 
 

@@ -6,9 +6,11 @@ import numpy as np
 f32 = np.float32
 
 
-def extract_static(e, t, threads=1, min_observations=0.0):
+def extract_static(e, t, threads=1, min_observations=0.0, obj_cfg=None):
     """MeshObjectExtractor::extractObject for a static track, restated on the oracle (mesh_object_extractor.cpp:81-118,
-    174-304, 306-356; configuration of bench.py's OBJECT_YAML).  -> None (no object) or dict(points, bbox_min, bbox_max)."""
+    174-304, 306-356; configuration of bench.py's OBJECT_YAML).  -> None (no object) or dict(points, bbox_min, bbox_max).
+    obj_cfg: settings of the extractor's OWN projective / mesh integrator (mesh_object_extractor.cpp:63-64,239,267) as khr_config
+    fields, where they differ from the defaults."""
     from khronos_amd import default_config
     from oracle import pyoracle as po
     if not (t.confidence > f32(0.5)) or t.is_dynamic:
@@ -38,7 +40,7 @@ def extract_static(e, t, threads=1, min_observations=0.0):
     mx = np.floor((center + dim) * inv).astype(np.int32)
     blocks = [[x, y, z] for x in range(mn[0], mx[0] + 1) for y in range(mn[1], mx[1] + 1) for z in range(mn[2], mx[2] + 1)]
     ocfg = default_config(voxel_size=float(vs), voxels_per_side=8, truncation_distance=float(vs * f32(2)), with_semantics=1,
-                          with_tracking=0, num_labels=2, semantic_mode=1)
+                          with_tracking=0, num_labels=2, semantic_mode=1, **(obj_cfg or {}))
     om = po.OracleMap(po.config_from(ocfg, threads))
     try:
         om.allocate_blocks(blocks)

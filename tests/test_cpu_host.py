@@ -88,6 +88,31 @@ def test_yaml_loader_on_reference_file_when_present():
         assert got[k] == (v if isinstance(v, str) else __import__("pytest").approx(v, rel=1e-6)), k
 
 
+def test_yaml_loader_reads_the_extractors_own_integrators_and_the_upstream_switches(tmp_path):
+    """MeshObjectExtractor::Config nests its own projective_integrator / mesh_integrator blocks (mesh_object_extractor.cpp:63-64;
+    uHumans2.yaml:99-100): they parse into the extractor's config, independent of the window's blocks of the same names.  The
+    ASSUMPTIONS.md [A] switches parse by name and refuse unknown values."""
+    text = ("active_window:\n  type: ActiveWindow\n"
+            "  projective_integrator:\n    max_weight: 500\n    alloc_candidate: camera_offset\n    color_blend_weight: pre\n"
+            "  mesh_integrator:\n    min_weight: 0.001\n    attr_source: containing\n    degenerate_eps: 1.0e-5\n"
+            "  object_extractor:\n    type: MeshObjectExtractor\n    min_object_volume: 0.01\n"
+            "    projective_integrator:\n      interpolation_method: nearest\n      max_weight: 40\n      use_weight_dropoff: false\n      num_threads: 8\n"
+            "    mesh_integrator:\n      min_weight: 0.02\n      integrator_threads: 8\n")
+    p = tmp_path / "aw.yaml"
+    p.write_text(text)
+    got = _parse(p)
+    approx = __import__("pytest").approx
+    assert got["alloc_candidate"] == "camera_offset" and got["color_blend_weight"] == "pre" and got["mesh_attr_source"] == "containing"
+    assert got["mesh_degenerate_eps"] == approx(1e-5)
+    assert got["object_interpolation_method"] == "nearest" and got["object_max_weight"] == approx(40.0) and got["object_use_weight_dropoff"] == 0
+    assert got["object_mesh_min_weight"] == approx(0.02)
+    assert got["object_color_blend_weight"] == "post" and got["object_mesh_attr_source"] == "nearest"  # (not inherited from the window's)
+    for bad in ("    alloc_candidate: corner\n", "    color_blend_weight: during\n"):
+        p.write_text("active_window:\n  projective_integrator:\n" + bad)
+        out = subprocess.run([SELFTEST, str(p)], capture_output=True, text=True, timeout=60)
+        assert out.returncode != 0, bad
+
+
 # ---- tracker plugins: C++ host restatement vs an independent Python restatement on random scenarios ----------
 def _scenario(rng, n_frames, with_dynamic):
     """blobs of voxels drifting on a 0.2 m grid: some persist (static objects), one moves (dynamic), some flicker."""

@@ -969,8 +969,8 @@ def _host_yaml_keys():
         a = text.index(name + "::Config " + name + "::Config::fromYaml(")
         return text[a:text.index("\n}\n", a)]
 
-    def keys(text):
-        return set(re.findall(r'\bread\("([a-z_0-9]+)"', text))
+    def keys(text):  # scalar keys (read("k", ..)) and nested blocks (m->find("k"))
+        return set(re.findall(r'\bread\("([a-z_0-9]+)"', text)) | set(re.findall(r'->find\("([a-z_0-9]+)"\)', text))
     top = func(aw, "ActiveWindow")
 
     def block(name):  # the reads inside `if (... n.find("<name>")) { ... }`
@@ -1000,7 +1000,6 @@ def test_yaml_keys_of_the_reference_are_read_by_the_host_loader():
     not_applicable = {
         # sub-module selection goes through `type:` + the block of the same name, not through a factory key of its own
         "InstanceForwarding": {"background", "metric"},   # open-set prompt embeddings (hydra::EmbeddingGroup): given as vectors through the API
-        "MeshObjectExtractor": {"projective_integrator", "mesh_integrator"},  # the object maps use the window's integrator settings
         "RayVerificator": {"prefix"},                     # robot prefix of the scene graph's agent layer: poses arrive as arrays
     }
     assert set(declared) >= {"ActiveWindow", "TrackingIntegrator", "FreeSpaceMotionDetector", "ConnectedSemantics", "MaxIoUTracker", "MeshObjectExtractor"}

@@ -35,9 +35,24 @@ THREADS = os.cpu_count() or 1
 f32 = np.float32
 
 
-def _yaml(buf):
+# the object extractor's OWN integrator blocks (mesh_object_extractor.cpp:63-64; uHumans2.yaml:99-100 names them), set to values that
+# differ from the window's: the object maps must be integrated / meshed with THESE
+OBJ_INTEGRATORS_YAML = """    projective_integrator:
+      interpolation_method: nearest
+      max_weight: 40.0
+      use_weight_dropoff: false
+      color_blend_weight: pre
+    mesh_integrator:
+      min_weight: 0.02
+      attr_source: containing
+"""
+OBJ_INTEGRATORS_CFG = dict(interpolation_method=0, max_weight=40.0, use_weight_dropoff=0, color_blend_weight=1, mesh_min_weight=0.02,
+                           mesh_attr_source=1)
+
+
+def _yaml(buf, own_integrators=False):
     from khronos_amd.configs import OBJECT_YAML  # the YAML bench.py configures its object half with
-    return OBJECT_YAML % dict(vs=VS, trunc=3 * VS, buf=buf)
+    return OBJECT_YAML % dict(vs=VS, trunc=3 * VS, buf=buf) + (OBJ_INTEGRATORS_YAML if own_integrators else "")
 
 
 def _config(num_frame_slots):
@@ -107,11 +122,11 @@ def expected():
     ora.close()
 
 
-def _extract_static(e, t):
+def _extract_static(e, t, obj_cfg=None):
     """MeshObjectExtractor::extractObject for a static track, restated on the oracle (tests/extract_replica.py; that restatement is
     held to the reference's own extractor code in tests/test_cpu_ref_pin.py)"""
     from extract_replica import extract_static
-    return extract_static(e, t, THREADS)
+    return extract_static(e, t, THREADS, obj_cfg=obj_cfg)
 
 
 class _DeviceFrames:
@@ -143,14 +158,14 @@ class _DeviceFrames:
         self.ptrs = []
 
 
-def _run_product(e, num_frame_slots, stepped):
+def _run_product(e, num_frame_slots, stepped, own_integrators=False):
     from khronos_amd import FusionContext
     from khronos_amd.host_capi import ObjectPipeline
     cfg = _config(num_frame_slots)
     ctx = FusionContext(cfg)
     s = e.stream
     sen = ctx.make_sensor(W, H, s.fx, s.fy, s.cx, s.cy)
-    pipe = ObjectPipeline(ctx, _yaml(100))
+    pipe = ObjectPipeline(ctx, _yaml(100, own_integrators))
     pipe.keep_objects(True)
     dev = _DeviceFrames(e.frames)
     descs = [ctx.make_frame(fr["stamp"], fr["pose"], dev.depth[i], dev.rgb[i], dev.label[i]) for i, fr in enumerate(e.frames)]
@@ -200,8 +215,8 @@ def _run_product(e, num_frame_slots, stepped):
     return objects
 
 
-def _check_objects(e, objects):
-    want = [o for o in (_extract_static(e, t) for t in e.removed_tracks) if o is not None]
+def _check_objects(e, objects, obj_cfg=None):
+    want = [o for o in (_extract_static(e, t, obj_cfg) for t in e.removed_tracks) if o is not None]
     assert len(want) >= 1, "the stream must make at least one object leave the window inside the run"
     got = [o for o in objects if o["trajectory"] == 0]
     key = lambda o: (o["first_seen"], o["last_seen"], o["label"])  # noqa: E731
@@ -223,3 +238,18 @@ def test_parity_c3_bench_path_stepped_small_ring(expected):
     # the smallest ring the pipeline accepts for a 100-frame buffer + frames held by detached extractions
     objects = _run_product(expected, num_frame_slots=101 + 8, stepped=True)
     _check_objects(expected, objects)
+
+
+def test_object_maps_use_the_extractors_own_integrator_settings(expected):
+    """MeshObjectExtractor::Config declares its own `projective_integrator` / `mesh_integrator` (mesh_object_extractor.cpp:63-64) and
+    integrates / meshes every object map with them (:239, :267), whatever the window's integrators are set to.  Same stream, the
+    extractor's blocks set to nearest-neighbour interpolation, a low weight cap, no drop-off, the pre-update colour blend, a higher
+    mesh weight threshold and containing-voxel vertex attributes: the extracted objects must equal the restatement run with exactly
+    those settings -- and differ from the objects of the default run."""
+    objects = _run_product(expected, num_frame_slots=101 + 64, stepped=False, own_integrators=True)
+    _check_objects(expected, objects, OBJ_INTEGRATORS_CFG)
+    default = [o for o in (_extract_static(expected, t) for t in expected.removed_tracks) if o is not None]
+    got = [o for o in objects if o["trajectory"] == 0]
+    assert any(len(d["points"]) != g["vertices"] or np.abs(d["points"] - g["points"]).max() > 0 for d in default for g in got
+               if (d["first_seen"], d["last_seen"], d["label"]) == (g["first_seen"], g["last_seen"], g["label"])), \
+        "the object settings must matter on this stream"

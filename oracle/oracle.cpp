@@ -191,6 +191,9 @@ struct orc_map {
   std::unordered_map<I3, std::vector<uint32_t>, I3Hash> mesh_halo;
   // the pixel LISTS (with the reference's duplicates) of the clusters the latest motion detection kept, in id order
   std::vector<std::vector<int32_t>> last_md_pixels;
+  // ProjectiveIntegrator::computeLabel as a callback (orc_set_label_hook)
+  orc_label_hook_fn label_hook = nullptr;
+  void* label_user = nullptr;
 
   Block* find(const I3& i) const {
     auto it = blocks.find(i);
@@ -354,7 +357,15 @@ void integrateBlock(IntegrateCtx& ctx, Block& blk) {
         const int best_px = iw.v[iw.best] * s.width + iw.u[iw.best];
         int label = -1;
         bool have_label = false;
-        if (in_band) {
+        if (m.label_hook) {
+          // the subclass hook decides mask and label (object_integrator.cpp:58-81, here the reference's own code: ref_harness.cpp)
+          int32_t lab = -1;
+          if (!m.label_hook(m.label_user, sdf, iw.u, iw.v, iw.w, &lab)) continue;
+          if (in_band) {
+            label = lab;
+            have_label = lab >= 0;
+          }
+        } else if (in_band) {
           if (f.mask && f.mask[best_px] != 0) continue;  // object_integrator.cpp:70-73
           if (c.semantic_mode == 1) {
             if (f.object_image) {
@@ -471,6 +482,11 @@ inline bool voxelIsFree(const orc_config& c, const TrackingVoxel& v, uint64_t st
 }  // namespace
 
 extern "C" {
+
+void orc_set_label_hook(orc_map* m, orc_label_hook_fn fn, void* user) {
+  m->label_hook = fn;
+  m->label_user = user;
+}
 
 orc_map* orc_create(const orc_config* cfg) {
   auto* m = new orc_map();

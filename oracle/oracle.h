@@ -213,6 +213,14 @@ int orc_get_block(const orc_map* m, int32_t bx, int32_t by, int32_t bz, float* d
 /* overwrite the TSDF distances of one block (oracle/ref_recipe/ref_harness.cpp: the reference's own pruning loop,
  * mesh_object_extractor.cpp:246-264, runs on a copy of an object map and hands its result back for meshing). 0 if found */
 int orc_set_distance(orc_map* m, int32_t bx, int32_t by, int32_t bz, const float* distance);
+/* ProjectiveIntegrator::computeLabel as a callback (the virtual hook a subclass overrides, contract: object_integrator.cpp:58-81):
+ * called for every voxel measurement that survived the range / truncation tests, with its sdf and interpolation weights (pixels
+ * (u, v)[4], weights[4]); returns 0 = skip this voxel, 1 = integrate, *label_out = the label to fuse (< 0: none).  With a hook
+ * installed orc_integrate applies NEITHER its own mask rule NOR its own label rule: the hook decides both.  The reference pin
+ * (oracle/ref_recipe/ref_harness.cpp) installs the reference's own ObjectIntegrator::computeLabel here.  Called from the
+ * integrator's worker threads.  fn = NULL removes it. */
+typedef int (*orc_label_hook_fn)(void* user, float sdf, const int32_t* u4, const int32_t* v4, const float* w4, int32_t* label_out);
+void orc_set_label_hook(orc_map* m, orc_label_hook_fn fn, void* user);
 /* the three block flags the reference's active window sets and clears from outside the integrators (bit0 updated, bit1
  * mesh_updated, bit2 tracking_updated; active_window.cpp:169-171, tracking_integrator.cpp:146) and block removal
  * (tracking_integrator.cpp:128) -- for the same harness, where the reference's own ActiveWindow drives this map */

@@ -494,6 +494,13 @@ def forward_instances(lib, range_image, vertex_map, label, max_range=0.0, min_cl
     return img, [dict(id=int(info[k, 0]), category=int(info[k, 1]), has_feature=bool(info[k, 2]), num_pixels=int(npx[k])) for k in range(n)]
 
 
+def label_hook_stats(lib):
+    """(calls, skips) of the reference's own ObjectIntegrator::computeLabel (object_integrator.cpp:58-81) under the integrator bridge"""
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    lib.ref_label_hook_stats(C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
+
+
 def config_keys(lib):
     """{module: [keys]} the reference's declare_config() functions announce (they are executed with a recording config::field)"""
     cap = 1 << 16

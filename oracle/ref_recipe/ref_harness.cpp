@@ -15,6 +15,7 @@
 #include <sstream>
 #include <string>
 #include <thread>
+#include <atomic>
 #include <vector>
 
 #include "khronos/active_window/active_window.h"
@@ -33,6 +34,9 @@
 #include "khronos/utils/geometry_utils.h"
 
 #include "../oracle.h"  // (the bridge behind the two integrators that are not in /root/reference)
+
+// how often the reference's ObjectIntegrator::computeLabel ran / returned false (ref_label_hook_stats)
+static std::atomic<uint64_t> g_label_hook_calls{0}, g_label_hook_skips{0};
 
 namespace {
 struct RefMap {
@@ -725,7 +729,35 @@ void installBridge() {
     f.depth = data.depth->data();
     f.color = data.rgb ? data.rgb->data() : nullptr;
     f.object_id = -1;
+    struct HookCtx {
+      const khronos::ObjectIntegrator* integrator;
+      const hydra::VolumetricMap::Config* map_config;
+      const hydra::InputData* data;
+      const cv::Mat* mask;
+    } hook_ctx{nullptr, &map.config, &data, &mask};
     if (const auto* object_integrator = dynamic_cast<const khronos::ObjectIntegrator*>(&integrator)) {
+      // round 5: the reference's OWN ObjectIntegrator::computeLabel (object_integrator.cpp:58-81) decides mask and label of every
+      // measurement -- the oracle supplies sdf and interpolation weights and applies none of its own rules (orc_set_label_hook)
+      hook_ctx.integrator = object_integrator;
+      orc_set_label_hook(m, [](void* user, float sdf, const int32_t* u4, const int32_t* v4, const float* w4, int32_t* label_out) -> int {
+        const HookCtx& h = *static_cast<const HookCtx*>(user);
+        hydra::VoxelMeasurement meas;
+        meas.sdf = sdf;
+        for (int k = 0; k < 4; ++k) {
+          meas.interpolation_weights.u[k] = u4[k];
+          meas.interpolation_weights.v[k] = v4[k];
+          meas.interpolation_weights.w[k] = w4[k];
+        }
+        meas.label = -1;
+        g_label_hook_calls.fetch_add(1, std::memory_order_relaxed);
+        if (!h.integrator->computeLabel(*h.map_config, *h.data, *h.mask, meas)) {
+          g_label_hook_skips.fetch_add(1, std::memory_order_relaxed);
+          return 0;
+        }
+        *label_out = meas.label;
+        return 1;
+      }, &hook_ctx);
+      // (the oracle still needs the frame for colour; its own object-image rule is bypassed by the hook)
       f.object_image = reinterpret_cast<const int32_t*>(object_integrator->current_data_->object_image.data());
       f.object_id = object_integrator->current_object_id_;
     } else {  // the window's integrator: labels fused, dynamic pixels masked (active_window.cpp:207-210)
@@ -734,6 +766,7 @@ void installBridge() {
     }
     orc_stats st{};
     orc_integrate(m, &g_env->sensor, &f, allocate ? 1 : 0, &st);
+    orc_set_label_hook(m, nullptr, nullptr);
     pull(map, m, true);
   };
   ref_standin::bridge().mesh = [](const hydra::MeshIntegrator&, hydra::VolumetricMap& map, bool only_updated, bool clear) {
@@ -1370,3 +1403,9 @@ int64_t ref_combine_mesh(int n_blocks, const int64_t* n_vertices, const int64_t*
 }
 
 }  // extern "C"
+
+// how often the reference's own ObjectIntegrator::computeLabel (object_integrator.cpp:58-81) has run under the bridge / returned false
+extern "C" void ref_label_hook_stats(uint64_t* calls, uint64_t* skips) {
+  *calls = g_label_hook_calls.load();
+  *skips = g_label_hook_skips.load();
+}

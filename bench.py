@@ -62,6 +62,11 @@ def parse_args():
     ap.add_argument("--no-tracking", action="store_true", default=None, help="leave out TrackingIntegrator::updateBlocks (c1)")
     ap.add_argument("--preroll", type=int, default=None,
                     help="frames fused before the warm-up (untimed): brings the map and the tracker to steady state; default 60 for c3, 0 otherwise")
+    ap.add_argument("--input", choices=["device", "host"], default="device",
+                    help="where a frame lives when khr_process_frame is called: device = resident in HBM before the timed region (the headline: "
+                         "BASELINE's metric is quoted with inputs resident); host = in page-locked HOST memory, as the reference's spinOnce receives "
+                         "its packet (active_window.cpp:118-125,268-286): khr_process_frame(.., on_device = 0, KHR_PF_INPUT_PINNED), the planes of "
+                         "frame i + 1 travel on the context's copy stream (khr_ingest_ahead_host) while frame i is fused")
     ap.add_argument("--lookahead", action="store_true",
                     help="hand the next frame over with khr_ingest_ahead while the current one is fused (N = 1).  Off by default: measured in "
                          "round 4, it does not shorten the step (the host and the main stream meet at the seed count every frame) and "
@@ -250,9 +255,20 @@ def main():
 
     # input descriptors (khr_frame: stamp, pose, HBM pointers) are built before the timed region
     frame_desc = None
+    host_input = args.input == "host" and world == 1 and not emu
+    h_pinned = []
     if world == 1:
-        frame_desc = [ctx.make_frame(stamps[i], poses[i][0], d_depth[i].data_ptr(), d_rgb[i].data_ptr(), d_label[i].data_ptr())
-                      for i in range(n_total)]
+        if host_input:
+            # the frames in page-locked host memory (what a frontend's double-buffered input queue holds)
+            for i in range(n_total):
+                fr = frames_host[i]
+                h_pinned.append((torch.from_numpy(np.ascontiguousarray(fr["depth"])).pin_memory(), torch.from_numpy(np.ascontiguousarray(fr["rgb"])).pin_memory(),
+                                 torch.from_numpy(np.ascontiguousarray(fr["label"])).pin_memory()))
+            frame_desc = [ctx.make_frame(stamps[i], poses[i][0], h_pinned[i][0].data_ptr(), h_pinned[i][1].data_ptr(), h_pinned[i][2].data_ptr())
+                          for i in range(n_total)]
+        else:
+            frame_desc = [ctx.make_frame(stamps[i], poses[i][0], d_depth[i].data_ptr(), d_rgb[i].data_ptr(), d_label[i].data_ptr())
+                          for i in range(n_total)]
     fusion = None
     fusion_cxx = None
     dist_host = "none"
@@ -372,6 +388,8 @@ def main():
             return
         for ci, (dep, rgb, lab, pose) in enumerate(cams):
             flags = ctx.PF_INPUT_READY  # the synthetic frames are resident and complete before the timed region
+            if host_input:
+                flags |= ctx.PF_INPUT_PINNED
             if not args.no_motion and world == 1:
                 flags |= ctx.PF_MOTION
             if pipe is not None:
@@ -387,12 +405,12 @@ def main():
             _t0 = time.perf_counter()
             if ahead_of[0] == i:
                 flags |= ctx.PF_INGESTED
-            slot, n_dyn = ctx.process_frame(sensor, frame_desc[i], True, flags)
+            slot, n_dyn = ctx.process_frame(sensor, frame_desc[i], not host_input, flags)
             ahead_of[0] = -1
             # input look-ahead (khr_ingest_ahead): the stream's next frame is resident, so it is converted on the second stream
             # while this frame is fused -- the frontend's input queue already holds it (one conversion per step, as before)
             if lookahead and len(cams) == 1 and i + 1 < n_total and (flags & ctx.PF_MOTION):
-                if ctx.ingest_ahead(sensor, frame_desc[i + 1]) is not None:
+                if (ctx.ingest_ahead_host if host_input else ctx.ingest_ahead)(sensor, frame_desc[i + 1]) is not None:
                     ahead_of[0] = i + 1
             _t1 = time.perf_counter()
             host_t[0] += _t1 - _t0
@@ -437,7 +455,7 @@ def main():
 
     copy_stats = [0, 0]       # outputs whose map clone was taken, bytes brought to the host (--output-copy)
     ahead_of = [-1]           # index of the frame handed over by khr_ingest_ahead
-    lookahead = args.lookahead and world == 1 and not emu
+    lookahead = (args.lookahead or args.input == "host") and world == 1 and not emu  # (host frames: the copy of frame i + 1 beside frame i)
     held_snapshot = [None]
     # ---- --output-copy host: the pipelined host consumer ----
     host_fields = (("indices", torch.int32, 3), ("distance", torch.float32, 4096), ("weight", torch.float32, 4096)) + (
@@ -634,13 +652,14 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s%dx%d synthetic RGB-D+labels, %g cm voxels, truncation %g cm, vps 16, K=%d labels, "
                                "MotionDetector %s, tracking integrator %s, object detection / tracking / extraction %s, %s; %d camera(s); "
-                               "%d pre-roll + %d warm-up frames before the timed steps; %s arithmetic"
+                               "%d pre-roll + %d warm-up frames before the timed steps; %s arithmetic; %s"
                                % (preset_name, W, H, vs * 100, trunc * 100, K, "off" if args.no_motion else "on",
                                   "off" if args.no_tracking else "on",
                                   "off" if args.no_objects else "on (ConnectedSemantics, MaxIoUTracker, MeshObjectExtractor)",
                                   ("output (mesh, archival%s) every %d frame(s)" % ("" if args.no_objects else ", object extraction", args.output_every))
                                   if args.output_every > 0 else "no output stage", world, pre, args.warmup,
-                                  "fast (decisions exact, values ~1e-6)" if args.fast else "exact (bit-identical to the CPU restatement)"),
+                                  "fast (decisions exact, values ~1e-6)" if args.fast else "exact (bit-identical to the CPU restatement)",
+                                  "inputs in page-locked host memory (PCIe in the timed region)" if host_input else "inputs resident in HBM"),
                    "preset": args.config if preset_matches else None,
                    "parallelism": "hash-range block shard x%d, owner-computes, RCCL all-gather of packed frames (prefetched one tick ahead on its own stream) + of 528-B halo records "
                                   "(ever-free), seed-gated all-reduce of per-pixel voxel keys (motion detector), request / response all-gather of mesh halo planes" % world
@@ -658,6 +677,12 @@ def main():
                          "if communication were free and all ranks were as loaded as rank 0 -- NOT a measured N-GPU number" % world}
            if emu else {}),
         "input_lookahead": bool(lookahead),
+        "input": {"where": args.input,
+                  "what": "frames resident in HBM before the timed region (khr_process_frame(on_device = 1))" if not host_input else
+                          "frames in page-locked HOST memory: khr_process_frame(on_device = 0, KHR_PF_INPUT_PINNED); the planes of frame i + 1 are "
+                          "handed over with khr_ingest_ahead_host and travel on the context's copy stream while frame i is fused",
+                  "host_bytes_per_frame": (11 * W * H) if host_input else 0,
+                  "h2d_GBps_sustained": (11.0 * W * H * fps / 1e9) if host_input else None},
         "output_copy": {"mode": args.output_copy,
                         "what": {"none": "the timed steps hand out no clone of the updated blocks (frames and map stay in HBM)",
                                  "device": "every output takes a device-side snapshot of the updated blocks (khr_snapshot_updated between meshing "
@@ -794,7 +819,10 @@ def main():
         runs = {"c1": ["--config", "c1"], "c2": ["--config", "c2"],
                 "c3_output_copy_none": ["--config", "c3", "--output-copy", "none", "--cpu-baseline-frames", "0"],
                 "c3_output_copy_host": ["--config", "c3", "--output-copy", "host", "--cpu-baseline-frames", "0"],
-                "c3_output_copy_host_all_layers": ["--config", "c3", "--output-copy", "host", "--host-fields", "all", "--cpu-baseline-frames", "0"]}
+                "c3_output_copy_host_all_layers": ["--config", "c3", "--output-copy", "host", "--host-fields", "all", "--cpu-baseline-frames", "0"],
+                # what a drop-in sees: the input arrives in host memory; and input from host + output to host
+                "c3_input_host": ["--config", "c3", "--input", "host", "--cpu-baseline-frames", "0"],
+                "c3_io_host": ["--config", "c3", "--input", "host", "--output-copy", "host", "--cpu-baseline-frames", "0"]}
         for name, extra_args in runs.items():
             r = None
             try:
@@ -802,7 +830,7 @@ def main():
                                    timeout=600)
                 j = json.loads(r.stdout.strip().splitlines()[-1])
                 keep = {k: j.get(k) for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "mvoxel_updates_per_s",
-                                              "speedup_vs_cpu", "output_copy")}
+                                              "speedup_vs_cpu", "output_copy", "input")}
                 keep["workload"] = j["config"]["workload"]
                 if "roofline" in j:
                     keep["roofline"] = {k: j["roofline"].get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us")}

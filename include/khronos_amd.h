@@ -377,6 +377,11 @@ int khr_object_prune(khr_ctx* ctx, float min_confidence, float min_observations,
                                   queued on the context's stream writes them).  The ingest then runs on the context's second
                                   stream beside the previous frame's tail instead of behind it.  Without the flag the ingest is
                                   ordered behind everything queued on the context's stream, as every other call is. */
+#define KHR_PF_INPUT_PINNED 128u /* on_device = 0 frames only: the host buffers are PAGE-LOCKED (hipHostMalloc / hipHostRegister; checked) and
+                                    the caller leaves them untouched until this call has returned.  The planes then travel on a copy stream
+                                    of the context's own instead of on its main stream, the host does not wait for them before it queues
+                                    the frame's kernels, and with KHR_PF_INPUT_READY the conversion runs on the second stream as for
+                                    device frames.  Without the flag (pageable memory) the copies are synchronous. */
 #define KHR_PF_INGESTED 64u /* the frame was handed over earlier with khr_ingest_ahead: `sensor` / `frame` must describe the same
                                frame (its pose and stamp are read again), its images are not touched any more */
 int khr_process_frame(khr_ctx* ctx, const khr_sensor* sensor, const khr_frame* frame, int on_device, uint32_t flags,
@@ -393,6 +398,15 @@ int khr_process_frame(khr_ctx* ctx, const khr_sensor* sensor, const khr_frame* f
  * KHR_ESTATE when a handed-over frame is still waiting, or KHR_ENOTFOUND when the look-ahead is not possible right now (ring
  * too small, tracking layer off): the caller then simply processes the frame the usual way. */
 int khr_ingest_ahead(khr_ctx* ctx, const khr_sensor* sensor, const khr_frame* frame);
+/* The same hand-over for a frame in PAGE-LOCKED HOST memory (hipHostMalloc / hipHostRegister; checked): what the reference's
+ * spinOnce receives is a host packet (active_window.cpp:118-125,268-286).  The three planes travel on the context's host-to-device
+ * stream while the current frame is fused, the conversion follows them on the second stream, the host waits for neither.  The
+ * buffers stay untouched until the frame's own khr_process_frame(.., on_device = 0, KHR_PF_INGESTED | KHR_PF_INPUT_READY |
+ * KHR_PF_MOTION | KHR_PF_INPUT_PINNED ..) call has returned. */
+int khr_ingest_ahead_host(khr_ctx* ctx, const khr_sensor* sensor, const khr_frame* frame);
+/* drop a frame that was handed over but will not be processed (its ring slot is free again); KHR_ENOTFOUND if there is none.  A
+ * khr_process_frame call that is rejected with KHR_PF_INGESTED set (stamp mismatch, missing flags) drops it too. */
+int khr_ingest_cancel(khr_ctx* ctx);
 
 /* -- output / inspection ----------------------------------------------------------------------- */
 /* khr_stats.pool_exhausted alone (records dropped by an exchange buffer that was too small, failed block allocations;

@@ -12,7 +12,11 @@
  *
  * Errors: negative khr_status (include/khronos_amd.h), text via khr_last_error().  Exchange buffers are sized at create;
  * exceeding one on ANY rank is KHR_ENOMEM from kdist_output on EVERY rank (the ranks agree on it inside the output's
- * count all-reduce, so nobody is left waiting in a collective), never a silent truncation.
+ * count all-reduce, so nobody is left waiting in a collective), never a silent truncation.  The agreement covers every local
+ * failure of kdist_output in front of that all-reduce (request list, record export, the dropped-record counter -- whose NEW
+ * drops since the last report count, the counter itself is sticky); the output that reports a fault has not meshed, and the mesh
+ * requests of that output are not retried: the caller raises the capacity and the blocks are meshed when they are next updated.
+ * kdist_tick's own failures (a frame that cannot be ingested, a device error) are rank-local and end the run on that rank.
  * KDIST_RCCL_LIB=<path> (environment): load the eight nccl* entry points from that library instead of librccl.so.1 -- a
  * site's own RCCL build, or the shared-memory transport of tests/transport/ that runs N ranks on one GPU for the tests.  The capacities bound what a
  * rank may hold, not what travels: the halo all-gather of a tick ships, per rank, the live-block count of the fullest rank

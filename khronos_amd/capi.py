@@ -79,7 +79,7 @@ EXPORTS = [
     "khr_allocate_blocks", "khr_object_prune", "khr_get_stats", "khr_num_blocks", "khr_block_indices",
     "khr_download_block", "khr_mesh_num_vertices", "khr_download_mesh", "khr_fetch_mesh", "khr_fetch_mesh_into", "khr_timing_enable", "khr_timing_reset",
     "khr_timing_get", "khr_debug_read", "khr_tick_ingest", "khr_tick_integrate", "khr_tick_live_bound", "khr_tick_seed_counts", "khr_converted_bytes", "khr_export_converted",
-    "khr_converted_views", "khr_tick_adopt", "khr_copy_frame_image", "khr_rv_detect_changes", "khr_last_removed", "khr_process_frame", "khr_ingest_ahead", "khr_integrate_shared", "khr_integrate_shared_batch", "khr_pixel_iou", "khr_forward_instances", "khr_update_tracking_phase",
+    "khr_converted_views", "khr_tick_adopt", "khr_copy_frame_image", "khr_rv_detect_changes", "khr_last_removed", "khr_process_frame", "khr_ingest_ahead", "khr_ingest_ahead_host", "khr_ingest_cancel", "khr_integrate_shared", "khr_integrate_shared_batch", "khr_pixel_iou", "khr_forward_instances", "khr_update_tracking_phase",
     "khr_export_halo", "khr_import_halo", "khr_get_dynamic_clusters", "khr_motion_keys",
     "khr_detect_motion_from_keys", "khr_download_updated", "khr_mesh_halo_requests", "khr_mesh_halo_export",
     "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",
@@ -210,6 +210,8 @@ def load_library():
     lib.khr_last_removed.argtypes = [vp, vp, i64, C.POINTER(i64)]
     lib.khr_process_frame.argtypes = [vp, C.POINTER(KhrSensor), C.POINTER(KhrFrame), i32, C.c_uint32, C.POINTER(i32)]
     lib.khr_ingest_ahead.argtypes = [vp, C.POINTER(KhrSensor), C.POINTER(KhrFrame)]
+    lib.khr_ingest_ahead_host.argtypes = [vp, C.POINTER(KhrSensor), C.POINTER(KhrFrame)]
+    lib.khr_ingest_cancel.argtypes = [vp]
     lib.khr_ingest_ahead.restype = i32
     lib.khr_timing_enable.argtypes = [vp, i32]
     lib.khr_timing_reset.argtypes = [vp]
@@ -371,6 +373,7 @@ class FusionContext:
     PF_SNAPSHOT = 32     # with PF_OUTPUT: snapshot of the updated blocks between meshing and archival (take_snapshot)
     PF_INPUT_READY = 16  # device inputs are complete at call time: the ingest may run ahead on the second stream
     PF_INGESTED = 64     # the frame was handed over earlier with ingest_ahead
+    PF_INPUT_PINNED = 128  # on_device = False frames in page-locked host memory: copies on the context's own stream, no host wait
     PF_MOTION, PF_TRACKING, PF_OUTPUT = 1, 2, 4
 
     def make_frame(self, stamp_ns, world_T_sensor, depth_ptr, color_ptr=0, label_ptr=0):
@@ -397,6 +400,16 @@ class FusionContext:
         if rc == -4:  # KHR_ENOTFOUND
             return None
         return self._chk(rc)
+
+    def ingest_ahead_host(self, sensor, frame):
+        """khr_ingest_ahead_host: the NEXT frame, in page-locked host memory; None when the look-ahead is not possible now"""
+        rc = self.lib.khr_ingest_ahead_host(self.h, C.byref(sensor), C.byref(frame))
+        if rc == -4:  # KHR_ENOTFOUND
+            return None
+        return self._chk(rc)
+
+    def ingest_cancel(self):
+        return self.lib.khr_ingest_cancel(self.h) == 0
 
     def last_removed(self):
         n = C.c_int64(0)

@@ -229,6 +229,13 @@ struct khr_ctx {
   bool early_ingest = true;                      // env KHR_NO_EARLY_INGEST=1 turns it off
   int ahead_slot = -1;                           // frame converted by khr_ingest_ahead, waiting for its khr_process_frame
   hipEvent_t ev_ahead = nullptr;
+  // pinned host input (KHR_PF_INPUT_PINNED / khr_ingest_ahead_host): the frame's three planes travel on a stream of their own
+  // into the ring slot, the ingest kernel waits for them on the device; the host does not wait (round 5)
+  hipStream_t h2d_stream = nullptr;
+  hipEvent_t ev_h2d = nullptr;
+  bool h2d_pending = false;    // a copy out of caller memory is queued: the caller's buffers are released by the next call / khr_sync
+  bool host_input_pinned = false;  // (set around khr_upload_frame by the callers that were told the memory is page-locked)
+  uint64_t h2d_bytes = 0;      // bytes queued through the pinned path (statistics)
   int ef_parity = 0, ef_cur = 0;  // which of C_N_EF / C_N_EF2 the next / the latest tracking pass fills
   hipEvent_t ev_seed = nullptr;
   uint32_t last_removed = 0;
@@ -1032,6 +1039,9 @@ void khr_destroy(khr_ctx* c) {
   if (c->d_mh_recs) { hipFree(c->d_mh_recs); hipFree(c->d_mh_keys); hipFree(c->d_mh_vals); }
   if (c->d_pix_scratch) hipFree(c->d_pix_scratch);
   if (c->d_band_rec) { hipFree(c->d_band_rec); hipFree(c->d_band_n); }
+  if (c->h2d_stream) { hipStreamSynchronize(c->h2d_stream); hipStreamDestroy(c->h2d_stream); }
+  if (c->ev_h2d) hipEventDestroy(c->ev_h2d);
+  if (c->ev_ahead) hipEventDestroy(c->ev_ahead);
   if (c->d_inst) hipFree(c->d_inst);
   if (c->pending_snapshot) khr_snapshot_release(c->pending_snapshot);
   if (c->snap_stream) {
@@ -1179,21 +1189,43 @@ int khr_upload_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fram
   s.objects_done = false;
   s.clusters.clear();
   s.sem_clusters.clear();
-  hipStream_t ist = (on_device && c->ingest_stream) ? c->ingest_stream : c->stream;
+  const bool pinned = !on_device && c->host_input_pinned;
+  hipStream_t ist = ((on_device || pinned) && c->ingest_stream) ? c->ingest_stream : c->stream;
   ScopedTimer tm(c, ist == c->stream ? 6 : -1);
   const float* depth_src = frame->depth;
   const uint8_t* rgb_src = frame->color;
   const int32_t* label_src = frame->label;
   if (!on_device) {  // host buffers: stage them in the slot, the ingest kernel then works in place
-    HIP_TRY(hipMemcpyAsync(s.depth, frame->depth, n * sizeof(float), kind, c->stream));
+    // page-locked caller memory (KHR_PF_INPUT_PINNED): the planes travel on the context's host-to-device stream while whatever
+    // is queued on the other streams runs, the ingest waits for them on the device, the host does not wait at all -- the
+    // caller keeps the buffers untouched until the next khr_process_frame / khr_sync on this context has returned.
+    // Pageable memory: copies on the ingest's own stream and a host wait below (the caller may reuse the memory at once).
+    hipStream_t cs = c->stream;
+    if (pinned) {
+      if (!c->h2d_stream) HIP_TRY(hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+      if (!c->ev_h2d) HIP_TRY(hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming));
+      cs = c->h2d_stream;
+      if (ist == c->stream) {  // main-stream ingest: the slot's previous readers are ordered in front of it, so must the copy be
+        if (!c->ev_ingest) HIP_TRY(hipEventCreateWithFlags(&c->ev_ingest, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->ev_ingest, c->stream));
+        HIP_TRY(hipStreamWaitEvent(cs, c->ev_ingest, 0));
+      }
+    }
+    HIP_TRY(hipMemcpyAsync(s.depth, frame->depth, n * sizeof(float), kind, cs));
     depth_src = s.depth;
     if (frame->color) {
-      HIP_TRY(hipMemcpyAsync(s.rgb_staging, frame->color, n * 3, kind, c->stream));
+      HIP_TRY(hipMemcpyAsync(s.rgb_staging, frame->color, n * 3, kind, cs));
       rgb_src = s.rgb_staging;
     }
     if (frame->label) {
-      HIP_TRY(hipMemcpyAsync(s.label, frame->label, n * sizeof(int32_t), kind, c->stream));
+      HIP_TRY(hipMemcpyAsync(s.label, frame->label, n * sizeof(int32_t), kind, cs));
       label_src = s.label;
+    }
+    if (pinned) {
+      HIP_TRY(hipEventRecord(c->ev_h2d, cs));
+      HIP_TRY(hipStreamWaitEvent(ist, c->ev_h2d, 0));
+      c->h2d_pending = true;
+      c->h2d_bytes += n * (4u + (frame->color ? 3u : 0u) + (frame->label ? 4u : 0u));
     }
   }
   s.tw = (sensor->width + kTile - 1) / kTile;
@@ -1204,7 +1236,7 @@ int khr_upload_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fram
   HIP_TRY(hipGetLastError());
   c->begun = c->begin_in_ingest;
   c->begin_in_ingest = false;
-  if (!on_device) HIP_TRY(hipStreamSynchronize(c->stream));  // caller buffers may be reused after return
+  if (!on_device && !pinned) HIP_TRY(hipStreamSynchronize(c->stream));  // caller buffers may be reused after return
   s.valid = true;
   s.dyn_clean = true, s.dynw_valid = false;
   return slot;
@@ -3446,33 +3478,77 @@ int khr_last_removed(khr_ctx* c, int32_t* removed, int64_t cap, int64_t* n_remov
   return fetchRemoved(c, removed, cap, n_removed);
 }
 
-int khr_ingest_ahead(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame) {
+// drop a frame handed over by khr_ingest_ahead[_host] that will not be processed (its lease, its pending object-detector request)
+static void cancelAhead(khr_ctx* c) {
+  if (c->ahead_slot < 0) return;
+  const int slot = c->ahead_slot;
+  c->ahead_slot = -1;
+  c->slot_leases[slot].fetch_sub(1, std::memory_order_acq_rel);
+  c->slots[slot].valid = false;  // (converted, but nobody may integrate it any more)
+  if (c->obj_pending_slot == slot) c->obj_pending_slot = -1;
+}
+
+// is `p` what the caller says it is?  where = 1: device memory (or managed), 0: page-locked host memory
+static bool pointerIs(const void* p, int where) {
+  if (!p) return true;
+  hipPointerAttribute_t at{};
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();  // (pageable host memory: "invalid value")
+    return false;
+  }
+  if (where == 1) return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged || at.type == hipMemoryTypeUnified;
+  return at.type == hipMemoryTypeHost;
+}
+
+static int ingestAhead(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame, int on_device) {
   if (!c || !sensor || !frame) return fail(KHR_EINVAL, "null argument");
-  if (c->ahead_slot >= 0) return fail(KHR_ESTATE, "a frame handed over by khr_ingest_ahead is still waiting for khr_process_frame");
+  if (c->ahead_slot >= 0) return fail(KHR_ESTATE, "a frame handed over by khr_ingest_ahead is still waiting for khr_process_frame (khr_ingest_cancel drops it)");
   // the same conditions as the early ingest inside khr_process_frame, plus a ring with a slot to spare: the slot of the frame
   // being processed and the one before it may still be read
   const int next = peekSlot(c);
   if (!c->early_ingest || !c->cfg.with_tracking || c->slots.size() < 3 || next < 0 || next == c->last_frame_slot) return KHR_ENOTFOUND;
   HIP_TRY(hipSetDevice(c->device));
+  // the buffers are read asynchronously: they have to be what the entry point says they are
+  if (!pointerIs(frame->depth, on_device) || !pointerIs(frame->color, on_device) || !pointerIs(frame->label, on_device))
+    return fail(KHR_EINVAL, on_device ? "khr_ingest_ahead: the frame's buffers must be device memory" : "khr_ingest_ahead_host: the frame's buffers must be page-locked host memory (hipHostMalloc / hipHostRegister)");
   c->begin_in_ingest = false;
   c->ingest_stream = c->aux_stream;
-  const int slot = khr_upload_frame(c, sensor, frame, 1);
+  c->host_input_pinned = !on_device;
+  const int slot = khr_upload_frame(c, sensor, frame, on_device);
+  c->host_input_pinned = false;
   c->ingest_stream = nullptr;
   if (slot < 0) return slot;
-  if (!c->ev_ahead) HIP_TRY(hipEventCreateWithFlags(&c->ev_ahead, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(c->ev_ahead, c->aux_stream));
+  auto undo = [&](int rc) {  // nothing published yet: the slot simply is not a frame
+    c->slots[slot].valid = false;
+    return rc;
+  };
+  if (!c->ev_ahead && hipEventCreateWithFlags(&c->ev_ahead, hipEventDisableTiming) != hipSuccess) return undo(fail(KHR_EDEVICE, "hipEventCreate failed"));
+  if (hipEventRecord(c->ev_ahead, c->aux_stream) != hipSuccess) return undo(fail(KHR_EDEVICE, "hipEventRecord failed"));
   c->slots[slot].aux_seq = ++c->aux_seq_issued;
-  c->slot_leases[slot].fetch_add(1, std::memory_order_acq_rel);  // (nobody else may take the slot before it is processed)
-  c->ahead_slot = slot;
   // The object detector only reads the frame: its kernels are queued right behind the conversion.  They then run beside the
   // current frame's tracking pass and the next frame's pixel / allocation / culling kernels -- all of them small -- instead of
   // beside the next frame's update kernel, whose persistent grid fills every CU's register file: the two cannot share a CU,
-  // and whichever starts second waits for the other (~55 us of the main stream per frame, profiles/r04_kernel_trace_frames_s2.txt)
+  // and whichever starts second waits for the other (~55 us of the main stream per frame, profiles/r04_kernel_trace_frames_s2.txt).
+  // Queued BEFORE the slot is published as handed over: a failure here leaves no state behind.
   if (c->obj_configured && kAheadObjects) {
     const int rco = objectsLaunch(c, slot);
-    if (rco) return rco;
+    if (rco) {
+      if (c->obj_pending_slot == slot) c->obj_pending_slot = -1;
+      return undo(rco);
+    }
   }
+  c->slot_leases[slot].fetch_add(1, std::memory_order_acq_rel);  // (nobody else may take the slot before it is processed)
+  c->ahead_slot = slot;
   return slot;
+}
+
+int khr_ingest_ahead(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame) { return ingestAhead(c, sensor, frame, 1); }
+int khr_ingest_ahead_host(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame) { return ingestAhead(c, sensor, frame, 0); }
+int khr_ingest_cancel(khr_ctx* c) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  if (c->ahead_slot < 0) return KHR_ENOTFOUND;
+  cancelAhead(c);
+  return KHR_OK;
 }
 
 int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame, int on_device, uint32_t flags,
@@ -3492,10 +3568,37 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   // behind them -- the ingest then stays on the main stream.
   const bool ahead = (flags & KHR_PF_INGESTED) != 0;
   if (ahead && (c->ahead_slot < 0 || !frame || !motion || !(flags & KHR_PF_INPUT_READY) ||
-                c->slots[c->ahead_slot].meta.timestamp_ns != frame->timestamp_ns))
-    return fail(KHR_ESTATE, "KHR_PF_INGESTED: no frame with this stamp was handed over by khr_ingest_ahead (or flags are missing)");
-  if (!ahead && c->ahead_slot >= 0) return fail(KHR_ESTATE, "the frame handed over by khr_ingest_ahead has to be processed first");
-  const bool early = ahead || (c->early_ingest && (flags & KHR_PF_INPUT_READY) && on_device && motion && c->cfg.with_tracking &&
+                c->slots[c->ahead_slot].meta.timestamp_ns != frame->timestamp_ns)) {
+    // a rejected call must not leave the context wedged: the handed-over frame is dropped with its lease, the caller
+    // processes its frame the usual way
+    cancelAhead(c);
+    return fail(KHR_ESTATE, "KHR_PF_INGESTED: no frame with this stamp was handed over by khr_ingest_ahead (or flags are missing); the handed-over frame was dropped");
+  }
+  if (!ahead && c->ahead_slot >= 0) return fail(KHR_ESTATE, "the frame handed over by khr_ingest_ahead has to be processed first (khr_ingest_cancel drops it)");
+  const bool pinned_in = !on_device && (flags & KHR_PF_INPUT_PINNED) != 0;
+  if (pinned_in && !ahead && frame && (!pointerIs(frame->depth, 0) || !pointerIs(frame->color, 0) || !pointerIs(frame->label, 0)))
+    return fail(KHR_EINVAL, "KHR_PF_INPUT_PINNED: the frame's buffers must be page-locked host memory (hipHostMalloc / hipHostRegister)");
+  // whatever happens below: the deferred fold of the update kernel's item records does not outlive this call, and a
+  // pinned input's copy has finished when the call returns (the caller then owns its buffers again)
+  struct Leave {
+    khr_ctx* c;
+    bool ok = false;
+    ~Leave() {
+      c->defer_fold = false;
+      if (!ok && c->fold_pending) {  // an error between the update launch and the tracking pass: fold now, nobody else will
+        hipLaunchKernelGGL(k_fuse_fold, dim3((c->m.capacity + 255) / 256), dim3(256), 0, c->stream, c->m.blk_flags, c->m.blk_band,
+                           &c->m.counters[C_MAX_SLOT], static_cast<const uint32_t*>(nullptr));
+        c->fold_pending = false;
+      }
+      if (c->h2d_pending) {
+        hipEventSynchronize(c->ev_h2d);
+        c->h2d_pending = false;
+      }
+    }
+  } leave{c};
+  // pinned host frames qualify for the early ingest like device frames: the planes travel on the host-to-device stream, the
+  // ingest runs on the second stream behind them
+  const bool early = ahead || (c->early_ingest && (flags & KHR_PF_INPUT_READY) && (on_device || pinned_in) && motion && c->cfg.with_tracking &&
                                c->slots.size() >= 2 && peekSlot(c) != c->last_frame_slot);
   int slot;
   if (ahead) {
@@ -3505,7 +3608,9 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   } else {
     c->begin_in_ingest = !early;
     c->ingest_stream = early ? c->aux_stream : nullptr;
+    c->host_input_pinned = pinned_in;
     slot = khr_upload_frame(c, sensor, frame, on_device);
+    c->host_input_pinned = false;
     c->ingest_stream = nullptr;
     c->begin_in_ingest = false;
     if (slot < 0) return slot;
@@ -3580,7 +3685,7 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
     c->md_summary_pending = -1;
     if ((rc = clusterSummaryLaunch(c, s, pend))) return rc;
   }
-  c->defer_fold = false;
+  c->defer_fold = false;  // (from here on the tracking pass folds; `leave` covers the error exits above)
   // Output frames: marching cubes read distance / weight / colour / label / stamps, which the tracking pass does not touch
   // (it writes voxel flags, last_occupied, free bits and -- atomically -- block flags): the mesh kernels are forked onto
   // their own stream behind k_tracking_select (which has folded the update's block flags) and joined before archival.
@@ -3638,6 +3743,7 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
     if (ns < 0) return ns;
   }
   HT("pf_exit");
+  leave.ok = true;
   return slot;
 }
 

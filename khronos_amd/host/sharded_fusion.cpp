@@ -152,6 +152,7 @@ struct kdist_handle {
   void* frame_recv = nullptr;
   size_t frame_recv_bytes = 0;
   std::vector<int> clusters_last_tick;
+  int64_t dropped_seen = 0;  // khr_pool_exhausted at the last output that reported it (the device counter is sticky)
   int64_t halo_per_rank_last_tick = 0, mesh_records_per_rank_last_output = 0;  // what the last exchanges shipped per rank
   std::vector<void*> allocs;
   // kdist_profile
@@ -602,22 +603,33 @@ int kdist_output(kdist_handle* h) {
       // tick's / output's export kernels or a block pool that ran out (the device counts them: khr_pool_exhausted).
       bool local_fault = false;
       std::string local_text;
+      // EVERY local failure in front of the agreement all-reduce is collected here and raised behind it: a rank that
+      // threw before the collective would leave the others waiting in it
+      auto note = [&](const std::string& text) {
+        if (!local_fault) local_text = text;
+        local_fault = true;
+      };
       const int n_req = khr_mesh_halo_requests(c, h->req_send, h->req_cap, 1, 1);
       if (n_req == KHR_ENOMEM) {  // (the buffer holds the first req_cap requests: harmless to ship)
-        local_fault = true;
-        local_text = khr_last_error();
-      } else {
-        KD_KHR(n_req);
+        note(khr_last_error());
+      } else if (n_req < 0) {     // the request list is in an unknown state: ship an empty one (key 0 = no request)
+        note(std::string("khr_mesh_halo_requests: ") + khr_last_error());
+        if (hipMemsetAsync(h->req_send, 0, sizeof(uint64_t) * static_cast<size_t>(h->req_cap), h->stream) != hipSuccess) (void)hipGetLastError();
       }
       if (h->net()) {
         coll(h, COLL_MESH_REQ, static_cast<size_t>(h->req_cap) * 8, [&] { return rccl().AllGather(h->req_send, h->req_recv, static_cast<size_t>(h->req_cap), ncclUint64, h->comm, h->stream); });
-        const int n_rec = khr_mesh_halo_export(c, h->req_recv, static_cast<int64_t>(h->world) * h->req_cap, h->rec_send, h->rec_cap, 1);
-        KD_KHR(n_rec);
+        int n_rec = khr_mesh_halo_export(c, h->req_recv, static_cast<int64_t>(h->world) * h->req_cap, h->rec_send, h->rec_cap, 1);
+        if (n_rec < 0) {
+          note(std::string("khr_mesh_halo_export: ") + khr_last_error());
+          n_rec = 0;
+        }
+        // the device's dropped-record counter is sticky: only what THIS output (and the ticks since the last one) added is a fault
         const int64_t dropped = khr_pool_exhausted(c);
-        KD_KHR(static_cast<int>(dropped < 0 ? dropped : 0));
-        if (dropped > 0 && !local_fault) {
-          local_fault = true;
-          local_text = "an exchange buffer was too small (halo_cap / mesh_rec_cap) or the block pool ran out: records were dropped";
+        if (dropped < 0) {
+          note(std::string("khr_pool_exhausted: ") + khr_last_error());
+        } else if (dropped > h->dropped_seen) {
+          h->dropped_seen = dropped;
+          note("an exchange buffer was too small (halo_cap / mesh_rec_cap) or the block pool ran out: records were dropped");
         }
         // the ranks agree on the fullest rank's record count and on "somebody has a fault" (one 16-byte max all-reduce; the
         // export above has synchronised anyway) and ship that many records each instead of rec_cap (18 KB per record: 590 MB
@@ -641,8 +653,10 @@ int kdist_output(kdist_handle* h) {
         KD_KHR(khr_mesh_halo_import(c, h->rec_send, h->rec_cap, 2));
         const int64_t dropped = khr_pool_exhausted(c);
         KD_KHR(static_cast<int>(dropped < 0 ? dropped : 0));
-        if (dropped > 0)
+        if (dropped > h->dropped_seen) {
+          h->dropped_seen = dropped;
           throw Fail{KHR_ENOMEM, "an exchange buffer was too small (halo_cap / mesh_rec_cap) or the block pool ran out: records were dropped"};
+        }
       }
     }
     KD_KHR(khr_generate_mesh(c, 1, 1));

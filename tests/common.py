@@ -184,3 +184,25 @@ class DeviceArray:
         if self.ptr:
             self._hip.hipFree(self.ptr)
             self.ptr = None
+
+
+class PinnedArray:
+    """a numpy array copied into page-locked host memory (hipHostMalloc through the HIP runtime the library is linked against)"""
+
+    def __init__(self, arr):
+        import ctypes as C
+        if DeviceArray._hip is None:
+            DeviceArray._hip = C.CDLL("libamdhip64.so")
+        arr = np.ascontiguousarray(arr)
+        self.ptr = C.c_void_p()
+        rc = DeviceArray._hip.hipHostMalloc(C.byref(self.ptr), C.c_size_t(arr.nbytes), C.c_uint(0))
+        assert rc == 0, rc
+        C.memmove(self.ptr, arr.ctypes.data, arr.nbytes)
+
+    def data_ptr(self):
+        return self.ptr.value
+
+    def free(self):
+        if self.ptr:
+            DeviceArray._hip.hipHostFree(self.ptr)
+            self.ptr = None

@@ -270,14 +270,18 @@ def test_tracking_shortcuts_are_exact():
     both_equal()
 
 
-@pytest.mark.parametrize("inputs", ["host", "device", "device-ready", "device-ahead"])
+@pytest.mark.parametrize("inputs", ["host", "device", "device-ready", "device-ahead", "host-pinned", "host-pinned-ahead"])
 def test_fused_process_frame_equals_stepwise(inputs):
     """khr_process_frame (one call per frame, asynchronous output stage) == the step-by-step calls; with host buffers, with
     device buffers, with device buffers declared complete (KHR_PF_INPUT_READY: the ingest runs ahead on the context's
     second stream and the per-frame counter reset moves into the motion detector's pixel pass), and with every frame handed
-    over one frame early (khr_ingest_ahead + KHR_PF_INGESTED: converted while the previous frame is fused)."""
-    from common import DeviceArray
-    cfg, ctx, ora, s, sen, osen = make_pair(width=320, height=240, temporal_window=0.75, num_frame_slots=4 if inputs == "device-ahead" else 3)
+    over one frame early (khr_ingest_ahead + KHR_PF_INGESTED: converted while the previous frame is fused).  Round 5: frames in
+    PAGE-LOCKED HOST memory -- what a drop-in's spinOnce receives (active_window.cpp:118-125) -- with KHR_PF_INPUT_PINNED (planes on
+    the context's copy stream, no host wait) and handed over one frame early with khr_ingest_ahead_host."""
+    from common import DeviceArray, PinnedArray
+    ahead_mode = inputs in ("device-ahead", "host-pinned-ahead")
+    pinned = inputs.startswith("host-pinned")
+    cfg, ctx, ora, s, sen, osen = make_pair(width=320, height=240, temporal_window=0.75, num_frame_slots=4 if ahead_mode else 3)
     fired = 0
     held = []
     N = 20
@@ -285,7 +289,7 @@ def test_fused_process_frame_equals_stepwise(inputs):
     def device_frame(i):
         fr = s.render(i)
         f = ctx.make_frame(fr["stamp"], fr["pose"], 0)
-        dev = [DeviceArray(np.ascontiguousarray(fr[k])) for k in ("depth", "rgb", "label")]  # (hipMemcpy: complete when it returns)
+        dev = [(PinnedArray if pinned else DeviceArray)(np.ascontiguousarray(fr[k])) for k in ("depth", "rgb", "label")]  # (complete when it returns)
         held.append(dev)
         f.depth, f.color, f.label = (d.data_ptr() for d in dev)
         return f
@@ -300,8 +304,11 @@ def test_fused_process_frame_equals_stepwise(inputs):
         flags = ctx.PF_MOTION | ctx.PF_TRACKING | (ctx.PF_OUTPUT if out_now else 0)
         if inputs == "host":
             f.depth, f.color, f.label = depth.ctypes.data, rgb.ctypes.data, lab.ctypes.data
-        elif inputs == "device-ahead":
-            flags |= ctx.PF_INPUT_READY
+        elif inputs == "host-pinned":
+            f = device_frame(i)
+            flags |= ctx.PF_INPUT_READY | ctx.PF_INPUT_PINNED
+        elif ahead_mode:
+            flags |= ctx.PF_INPUT_READY | (ctx.PF_INPUT_PINNED if pinned else 0)
             if i in ahead:
                 f = ahead.pop(i)
                 flags |= ctx.PF_INGESTED
@@ -313,14 +320,15 @@ def test_fused_process_frame_equals_stepwise(inputs):
             f.depth, f.color, f.label = (d.data_ptr() for d in dev)
             if inputs == "device-ready":
                 flags |= ctx.PF_INPUT_READY
-        slot, nc = ctx.process_frame(sen, f, on_device=inputs != "host", flags=flags)
-        if inputs == "device-ahead" and i + 1 < N:
+        slot, nc = ctx.process_frame(sen, f, on_device=not (inputs == "host" or pinned), flags=flags)
+        if ahead_mode and i + 1 < N:
             nf = device_frame(i + 1)
-            if ctx.ingest_ahead(sen, nf) is not None:
+            hand_over = ctx.ingest_ahead_host if pinned else ctx.ingest_ahead
+            if hand_over(sen, nf) is not None:
                 ahead[i + 1] = nf
                 n_ahead += 1
                 with pytest.raises(Exception):  # a second hand-over before the first one is processed is refused
-                    ctx.ingest_ahead(sen, nf)
+                    hand_over(sen, nf)
             else:
                 held.pop()
         n_o, dyn_o, _ = ora.detect_motion(osen, fr["stamp"], fr["pose"], fr["depth"])
@@ -337,12 +345,65 @@ def test_fused_process_frame_equals_stepwise(inputs):
             assert gm["points"].shape == om["points"].shape
             assert np.abs(gm["points"] - om["points"]).max() <= TOL if len(om["points"]) else True
     assert fired > 0
-    assert inputs != "device-ahead" or n_ahead >= N - 2
+    assert not ahead_mode or n_ahead >= N - 2
     compare_maps(ctx, ora, max_blocks=100)
     ctx.sync()
     for dev in held:
         for d in dev:
             d.free()
+
+
+def test_a_rejected_hand_over_does_not_wedge_the_context():
+    """a khr_process_frame call that is rejected with KHR_PF_INGESTED set (wrong stamp, missing flags) used to leave the
+    handed-over slot and its lease behind, and every later call returned KHR_ESTATE.  Now the rejected call drops the hand-over (so does
+    khr_ingest_cancel), wrong kinds of memory are refused at the hand-over, and the stream goes on -- with the same map as a run that
+    never tried."""
+    from common import DeviceArray, PinnedArray
+    cfg, ctx, ora, s, sen, osen = make_pair(width=160, height=120, temporal_window=0.75, num_frame_slots=4)
+    held = []
+
+    def frame(i, kind):
+        fr = s.render(i)
+        f = ctx.make_frame(fr["stamp"], fr["pose"], 0)
+        arrs = [kind(np.ascontiguousarray(fr[k])) for k in ("depth", "rgb", "label")]
+        held.append(arrs)
+        f.depth, f.color, f.label = (a.data_ptr() for a in arrs)
+        return fr, f
+
+    base = ctx.PF_MOTION | ctx.PF_TRACKING | ctx.PF_INPUT_READY
+    for i in range(8):
+        fr, f = frame(i, DeviceArray)
+        if i == 2:  # hand over frame 3, then present a frame with ANOTHER stamp as the handed-over one: rejected, hand-over dropped
+            _, f3 = frame(3, DeviceArray)
+            assert ctx.ingest_ahead(sen, f3) is not None
+            with pytest.raises(Exception):
+                ctx.process_frame(sen, f, on_device=True, flags=base | ctx.PF_INGESTED)
+            assert not ctx.ingest_cancel()  # (nothing left to cancel)
+        if i == 4:  # hand over, change of plan: cancel
+            _, f5 = frame(5, DeviceArray)
+            assert ctx.ingest_ahead(sen, f5) is not None
+            assert ctx.ingest_cancel()
+        if i == 5:  # the wrong kind of memory at either entry point is refused before anything is queued
+            _, fh = frame(6, PinnedArray)
+            with pytest.raises(Exception):
+                ctx.ingest_ahead(sen, fh)
+            _, fd = frame(6, DeviceArray)
+            with pytest.raises(Exception):
+                ctx.ingest_ahead_host(sen, fd)
+            pageable = np.ascontiguousarray(fr["depth"])
+            fp = ctx.make_frame(fr["stamp"], fr["pose"], pageable.ctypes.data)
+            with pytest.raises(Exception):
+                ctx.process_frame(sen, fp, on_device=False, flags=base | ctx.PF_INPUT_PINNED)
+        slot, nc = ctx.process_frame(sen, f, on_device=True, flags=base)
+        n_o, dyn_o, _ = ora.detect_motion(osen, fr["stamp"], fr["pose"], fr["depth"])
+        assert nc == n_o
+        ora.integrate(osen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"], mask=dyn_o)
+        ora.update_tracking(fr["stamp"])
+    compare_maps(ctx, ora, max_blocks=60)
+    ctx.sync()
+    for arrs in held:
+        for a in arrs:
+            a.free()
 
 
 def test_two_shards_with_halo_exchange_equal_unsharded():

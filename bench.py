@@ -264,6 +264,16 @@ def main():
                 fr = frames_host[i]
                 h_pinned.append((torch.from_numpy(np.ascontiguousarray(fr["depth"])).pin_memory(), torch.from_numpy(np.ascontiguousarray(fr["rgb"])).pin_memory(),
                                  torch.from_numpy(np.ascontiguousarray(fr["label"])).pin_memory()))
+            # a frontend recycles a handful of page-locked buffers, so every transfer of its steady state comes out of memory the copy
+            # engine has moved before; here every synthetic frame has buffers of its own, each used once -- and the FIRST transfer
+            # out of a fresh page-locked region runs at ~8 GB/s instead of ~50 (tools/ubench/h2d_rates.hip, first repetition).  One
+            # throw-away transfer per buffer, before the timed region, puts the stream into that steady state.
+            scratch = [torch.empty_like(t, device=dev) for t in h_pinned[0]]
+            for hp in h_pinned:
+                for sc, t in zip(scratch, hp):
+                    sc.copy_(t, non_blocking=True)
+            torch.cuda.synchronize()
+            del scratch
             frame_desc = [ctx.make_frame(stamps[i], poses[i][0], h_pinned[i][0].data_ptr(), h_pinned[i][1].data_ptr(), h_pinned[i][2].data_ptr())
                           for i in range(n_total)]
         else:
@@ -403,15 +413,19 @@ def main():
                     if args.output_copy != "none":
                         flags |= ctx.PF_SNAPSHOT
             _t0 = time.perf_counter()
-            if ahead_of[0] == i:
+            # input look-ahead (khr_ingest_ahead[_host]): the frontend's input queue already holds the next packet, so it is handed
+            # over BEFORE this frame's call -- its transfer (host frames) and conversion run on the context's other streams across
+            # the host's wait for the motion detector's seed count inside khr_process_frame (up to two frames may be in the look-ahead)
+            if lookahead and len(cams) == 1 and (flags & ctx.PF_MOTION):
+                hand = ctx.ingest_ahead_host if host_input else ctx.ingest_ahead
+                if not handed and hand(sensor, frame_desc[i]) is not None:
+                    handed.append(i)
+                if handed and handed[0] == i and len(handed) < 2 and i + 1 < n_total and hand(sensor, frame_desc[i + 1]) is not None:
+                    handed.append(i + 1)
+            if handed and handed[0] == i:
                 flags |= ctx.PF_INGESTED
+                handed.pop(0)
             slot, n_dyn = ctx.process_frame(sensor, frame_desc[i], not host_input, flags)
-            ahead_of[0] = -1
-            # input look-ahead (khr_ingest_ahead): the stream's next frame is resident, so it is converted on the second stream
-            # while this frame is fused -- the frontend's input queue already holds it (one conversion per step, as before)
-            if lookahead and len(cams) == 1 and i + 1 < n_total and (flags & ctx.PF_MOTION):
-                if (ctx.ingest_ahead_host if host_input else ctx.ingest_ahead)(sensor, frame_desc[i + 1]) is not None:
-                    ahead_of[0] = i + 1
             _t1 = time.perf_counter()
             host_t[0] += _t1 - _t0
             if args.output_copy == "host":
@@ -454,7 +468,7 @@ def main():
                     obj_stats[2] += time.perf_counter() - t_e
 
     copy_stats = [0, 0]       # outputs whose map clone was taken, bytes brought to the host (--output-copy)
-    ahead_of = [-1]           # index of the frame handed over by khr_ingest_ahead
+    handed = []               # indices of the frames handed over with khr_ingest_ahead[_host], oldest first
     lookahead = (args.lookahead or args.input == "host") and world == 1 and not emu  # (host frames: the copy of frame i + 1 beside frame i)
     held_snapshot = [None]
     # ---- --output-copy host: the pipelined host consumer ----

@@ -394,8 +394,10 @@ int khr_process_frame(khr_ctx* ctx, const khr_sensor* sensor, const khr_frame* f
  * detector configured (khr_configure_object_detector) its kernels, which only read the frame, are queued right behind the
  * conversion: they then run beside the current frame's tracking pass instead of beside the next frame's update kernel, whose
  * persistent grid leaves no room on the CUs.  The following
- * khr_process_frame call must pass the same frame with KHR_PF_INGESTED | KHR_PF_INPUT_READY | KHR_PF_MOTION.  Returns the slot,
- * KHR_ESTATE when a handed-over frame is still waiting, or KHR_ENOTFOUND when the look-ahead is not possible right now (ring
+ * khr_process_frame call must pass the same frame with KHR_PF_INGESTED | KHR_PF_INPUT_READY | KHR_PF_MOTION.  Up to TWO frames may be
+ * handed over before their khr_process_frame calls come (processed oldest first): a frontend that hands frame i + 1 over BEFORE
+ * it calls khr_process_frame for frame i keeps the transfer of i + 1 running across the host's wait inside that call.  Returns the slot,
+ * KHR_ESTATE when two handed-over frames are still waiting, or KHR_ENOTFOUND when the look-ahead is not possible right now (ring
  * too small, tracking layer off): the caller then simply processes the frame the usual way. */
 int khr_ingest_ahead(khr_ctx* ctx, const khr_sensor* sensor, const khr_frame* frame);
 /* The same hand-over for a frame in PAGE-LOCKED HOST memory (hipHostMalloc / hipHostRegister; checked): what the reference's

@@ -1257,6 +1257,11 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
 struct FuseFrameSet {
   FuseFrame f[kMaxTick];
 };
+// small host-mapped staging block -> device memory, as a kernel (khr_integrate_shared_batch's per-frame arguments)
+__global__ __launch_bounds__(256) void k_copy_words(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
 __global__ void k_put_frames(FuseFrameSet s, FuseFrame* __restrict__ dst, int n) {
   const uint32_t* const src = reinterpret_cast<const uint32_t*>(&s);
   uint32_t* const d = reinterpret_cast<uint32_t*>(dst);

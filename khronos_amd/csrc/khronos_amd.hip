@@ -227,8 +227,16 @@ struct khr_ctx {
   hipEvent_t ev_up = nullptr;                    // the last upload out of h_up has been consumed
   hipStream_t ingest_stream = nullptr;           // khr_process_frame: ingest on the auxiliary stream (set around khr_upload_frame)
   bool early_ingest = true;                      // env KHR_NO_EARLY_INGEST=1 turns it off
-  int ahead_slot = -1;                           // frame converted by khr_ingest_ahead, waiting for its khr_process_frame
-  hipEvent_t ev_ahead = nullptr;
+  // frames handed over with khr_ingest_ahead[_host], oldest first, waiting for their khr_process_frame calls.  Up to kMaxAhead: a
+  // frontend that hands frame i + 1 over BEFORE it calls khr_process_frame for frame i keeps the copy engine busy across the
+  // host's wait inside that call (round 5: with one entry the host-to-device copy of a 720p frame, ~205 us, started only after
+  // the call had returned and the main stream idled behind it -- rocprofv3 timeline)
+  struct AheadEntry { int slot; int ev; bool host; };
+  std::vector<AheadEntry> ahead_q;
+  hipEvent_t ev_ahead[2] = {nullptr, nullptr};      // conversion of the entry finished (auxiliary stream)
+  hipEvent_t ev_ahead_h2d[2] = {nullptr, nullptr};  // host planes of the entry have arrived (host-to-device stream)
+  int ahead_ev_next = 0;
+  hipEvent_t* h2d_ev_target = nullptr;              // (set around khr_upload_frame: which event the pinned copy records)
   // pinned host input (KHR_PF_INPUT_PINNED / khr_ingest_ahead_host): the frame's three planes travel on a stream of their own
   // into the ring slot, the ingest kernel waits for them on the device; the host does not wait (round 5)
   hipStream_t h2d_stream = nullptr;
@@ -804,7 +812,10 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   std::memset(c->h_pinned, 0, 64);
   // staging buffers up front: growing them later means hipHostMalloc / hipMalloc in the middle of a run (hundreds of us,
   // and hipMalloc stalls every stream of the device)
-  c->h_up_bytes = 1u << 16;
+  // (object mini-maps take their whole block list through it, khr_allocate_blocks per extraction: sized for a full pool -- round 5:
+  // an extraction whose list outgrew the 64 KB grew it from its worker thread, and the hipMalloc waited 5 - 11 ms for the window's
+  // frames to leave the device idle, profiles/r05_host_input_marks.txt)
+  c->h_up_bytes = std::max<size_t>(1u << 16, cfg->voxels_per_side == 8 ? sizeof(int32_t) * 3 * static_cast<size_t>(cfg->max_blocks) : 0);
   if (ensureStage(c, 1u << 20) != KHR_OK || hipHostMalloc(&c->h_up, c->h_up_bytes, hipHostMallocDefault) != hipSuccess ||
       hipMalloc(&c->d_up, c->h_up_bytes) != hipSuccess) {
     delete c;
@@ -1041,7 +1052,10 @@ void khr_destroy(khr_ctx* c) {
   if (c->d_band_rec) { hipFree(c->d_band_rec); hipFree(c->d_band_n); }
   if (c->h2d_stream) { hipStreamSynchronize(c->h2d_stream); hipStreamDestroy(c->h2d_stream); }
   if (c->ev_h2d) hipEventDestroy(c->ev_h2d);
-  if (c->ev_ahead) hipEventDestroy(c->ev_ahead);
+  for (int i = 0; i < 2; ++i) {
+    if (c->ev_ahead[i]) hipEventDestroy(c->ev_ahead[i]);
+    if (c->ev_ahead_h2d[i]) hipEventDestroy(c->ev_ahead_h2d[i]);
+  }
   if (c->d_inst) hipFree(c->d_inst);
   if (c->pending_snapshot) khr_snapshot_release(c->pending_snapshot);
   if (c->snap_stream) {
@@ -1203,7 +1217,8 @@ int khr_upload_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fram
     hipStream_t cs = c->stream;
     if (pinned) {
       if (!c->h2d_stream) HIP_TRY(hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
-      if (!c->ev_h2d) HIP_TRY(hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming));
+      hipEvent_t& evh0 = c->h2d_ev_target ? *c->h2d_ev_target : c->ev_h2d;
+      if (!evh0) HIP_TRY(hipEventCreateWithFlags(&evh0, hipEventDisableTiming));
       cs = c->h2d_stream;
       if (ist == c->stream) {  // main-stream ingest: the slot's previous readers are ordered in front of it, so must the copy be
         if (!c->ev_ingest) HIP_TRY(hipEventCreateWithFlags(&c->ev_ingest, hipEventDisableTiming));
@@ -1222,9 +1237,10 @@ int khr_upload_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fram
       label_src = s.label;
     }
     if (pinned) {
-      HIP_TRY(hipEventRecord(c->ev_h2d, cs));
-      HIP_TRY(hipStreamWaitEvent(ist, c->ev_h2d, 0));
-      c->h2d_pending = true;
+      hipEvent_t& evh = c->h2d_ev_target ? *c->h2d_ev_target : c->ev_h2d;
+      HIP_TRY(hipEventRecord(evh, cs));
+      HIP_TRY(hipStreamWaitEvent(ist, evh, 0));
+      if (!c->h2d_ev_target) c->h2d_pending = true;
       c->h2d_bytes += n * (4u + (frame->color ? 3u : 0u) + (frame->label ? 4u : 0u));
     }
   }
@@ -1446,7 +1462,15 @@ static int integrateUpdateMulti(khr_ctx* c, khr_ctx* src, const int* src_slots, 
     const DevFrame f = makeDevFrame(src, s);
     fillFuseFrame(c, s, f, use_mask, object_ids ? object_ids[i] : -1, &c->h_frames[i]);
   }
-  HIP_TRY(hipMemcpyAsync(c->d_frames, c->h_frames, sizeof(FuseFrame) * n_frames, hipMemcpyHostToDevice, c->stream));
+  // the frames' arguments reach the device array through a kernel that reads the page-locked staging block (not a hipMemcpyAsync:
+  // issued from an extraction worker's thread it can sit for milliseconds behind the window thread's frame transfers, round 5)
+  {
+    void* hf_dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&hf_dev, c->h_frames, 0));
+    const uint32_t n_words = static_cast<uint32_t>(sizeof(FuseFrame) / 4) * static_cast<uint32_t>(n_frames);
+    hipLaunchKernelGGL(k_copy_words, dim3((n_words + 255) / 256), dim3(256), 0, c->stream, static_cast<const uint32_t*>(hf_dev),
+                       reinterpret_cast<uint32_t*>(c->d_frames), n_words);
+  }
   HIP_TRY(hipEventRecord(c->ev_frames, c->stream));
   static_cast<FuseFrame&>(a) = c->h_frames[0];  // (W, H etc. for code that looks at the kernel's own frame; unused by MULTI)
   a.frames = c->d_frames;
@@ -3478,14 +3502,16 @@ int khr_last_removed(khr_ctx* c, int32_t* removed, int64_t cap, int64_t* n_remov
   return fetchRemoved(c, removed, cap, n_removed);
 }
 
-// drop a frame handed over by khr_ingest_ahead[_host] that will not be processed (its lease, its pending object-detector request)
+constexpr size_t kMaxAhead = 2;
+// drop the frames handed over by khr_ingest_ahead[_host] that will not be processed (their leases, a pending object-detector request)
 static void cancelAhead(khr_ctx* c) {
-  if (c->ahead_slot < 0) return;
-  const int slot = c->ahead_slot;
-  c->ahead_slot = -1;
-  c->slot_leases[slot].fetch_sub(1, std::memory_order_acq_rel);
-  c->slots[slot].valid = false;  // (converted, but nobody may integrate it any more)
-  if (c->obj_pending_slot == slot) c->obj_pending_slot = -1;
+  for (const auto& e : c->ahead_q) {
+    c->slot_leases[e.slot].fetch_sub(1, std::memory_order_acq_rel);
+    c->slots[e.slot].valid = false;  // (converted, but nobody may integrate it any more)
+    if (c->obj_pending_slot == e.slot) c->obj_pending_slot = -1;
+    if (e.host && c->ev_ahead_h2d[e.ev]) hipEventSynchronize(c->ev_ahead_h2d[e.ev]);  // (the caller owns its buffers again)
+  }
+  c->ahead_q.clear();
 }
 
 // is `p` what the caller says it is?  where = 1: device memory (or managed), 0: page-locked host memory
@@ -3502,35 +3528,54 @@ static bool pointerIs(const void* p, int where) {
 
 static int ingestAhead(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame, int on_device) {
   if (!c || !sensor || !frame) return fail(KHR_EINVAL, "null argument");
-  if (c->ahead_slot >= 0) return fail(KHR_ESTATE, "a frame handed over by khr_ingest_ahead is still waiting for khr_process_frame (khr_ingest_cancel drops it)");
-  // the same conditions as the early ingest inside khr_process_frame, plus a ring with a slot to spare: the slot of the frame
+  if (c->ahead_q.size() >= kMaxAhead)
+    return fail(KHR_ESTATE, "%zu frames handed over by khr_ingest_ahead are still waiting for khr_process_frame (khr_ingest_cancel drops them)", c->ahead_q.size());
+  // the same conditions as the early ingest inside khr_process_frame, plus a ring with slots to spare: the slot of the frame
   // being processed and the one before it may still be read
   const int next = peekSlot(c);
-  if (!c->early_ingest || !c->cfg.with_tracking || c->slots.size() < 3 || next < 0 || next == c->last_frame_slot) return KHR_ENOTFOUND;
+  if (!c->early_ingest || !c->cfg.with_tracking || c->slots.size() < 3 + c->ahead_q.size() || next < 0 || next == c->last_frame_slot) return KHR_ENOTFOUND;
   HIP_TRY(hipSetDevice(c->device));
   // the buffers are read asynchronously: they have to be what the entry point says they are
   if (!pointerIs(frame->depth, on_device) || !pointerIs(frame->color, on_device) || !pointerIs(frame->label, on_device))
     return fail(KHR_EINVAL, on_device ? "khr_ingest_ahead: the frame's buffers must be device memory" : "khr_ingest_ahead_host: the frame's buffers must be page-locked host memory (hipHostMalloc / hipHostRegister)");
+  const int evi = c->ahead_ev_next;
+  for (const auto& e : c->ahead_q)
+    if (e.ev == evi) return fail(KHR_ESTATE, "look-ahead event ring out of step");
   c->begin_in_ingest = false;
-  c->ingest_stream = c->aux_stream;
+  // a host frame is converted on the host-to-device stream itself, right behind its planes: on the auxiliary stream the conversion
+  // -- which waits ~205 us for a 720p frame's planes -- would sit in front of the CURRENT frame's object-detector kernels, whose
+  // results the host waits for at the end of khr_process_frame (seen in the rocprofv3 timeline: main stream idle for 250 us)
+  hipStream_t conv_stream = c->aux_stream;
+  if (!on_device) {
+    if (!c->h2d_stream) HIP_TRY(hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+    conv_stream = c->h2d_stream;
+  }
+  c->ingest_stream = conv_stream;
   c->host_input_pinned = !on_device;
+  c->h2d_ev_target = &c->ev_ahead_h2d[evi];
   const int slot = khr_upload_frame(c, sensor, frame, on_device);
+  c->h2d_ev_target = nullptr;
   c->host_input_pinned = false;
   c->ingest_stream = nullptr;
   if (slot < 0) return slot;
   auto undo = [&](int rc) {  // nothing published yet: the slot simply is not a frame
     c->slots[slot].valid = false;
+    if (!on_device && c->ev_ahead_h2d[evi]) hipEventSynchronize(c->ev_ahead_h2d[evi]);
     return rc;
   };
-  if (!c->ev_ahead && hipEventCreateWithFlags(&c->ev_ahead, hipEventDisableTiming) != hipSuccess) return undo(fail(KHR_EDEVICE, "hipEventCreate failed"));
-  if (hipEventRecord(c->ev_ahead, c->aux_stream) != hipSuccess) return undo(fail(KHR_EDEVICE, "hipEventRecord failed"));
-  c->slots[slot].aux_seq = ++c->aux_seq_issued;
+  if (!c->ev_ahead[evi] && hipEventCreateWithFlags(&c->ev_ahead[evi], hipEventDisableTiming) != hipSuccess) return undo(fail(KHR_EDEVICE, "hipEventCreate failed"));
+  if (hipEventRecord(c->ev_ahead[evi], conv_stream) != hipSuccess) return undo(fail(KHR_EDEVICE, "hipEventRecord failed"));
+  if (on_device) c->slots[slot].aux_seq = ++c->aux_seq_issued;
   // The object detector only reads the frame: its kernels are queued right behind the conversion.  They then run beside the
   // current frame's tracking pass and the next frame's pixel / allocation / culling kernels -- all of them small -- instead of
   // beside the next frame's update kernel, whose persistent grid fills every CU's register file: the two cannot share a CU,
   // and whichever starts second waits for the other (~55 us of the main stream per frame, profiles/r04_kernel_trace_frames_s2.txt).
-  // Queued BEFORE the slot is published as handed over: a failure here leaves no state behind.
-  if (c->obj_configured && kAheadObjects) {
+  // Queued BEFORE the slot is published as handed over: a failure here leaves no state behind.  Only when no other
+  // request of the detector is outstanding (its result block is single): a second frame in the look-ahead gets its detector
+  // kernels from its own khr_process_frame call.
+  // Not for host frames: their planes are still travelling, and the auxiliary stream -- in order -- would hold the CURRENT frame's
+  // detector kernels, queued later by its khr_process_frame call, behind that wait.
+  if (on_device && c->obj_configured && kAheadObjects && c->obj_pending_slot < 0) {
     const int rco = objectsLaunch(c, slot);
     if (rco) {
       if (c->obj_pending_slot == slot) c->obj_pending_slot = -1;
@@ -3538,7 +3583,8 @@ static int ingestAhead(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fr
     }
   }
   c->slot_leases[slot].fetch_add(1, std::memory_order_acq_rel);  // (nobody else may take the slot before it is processed)
-  c->ahead_slot = slot;
+  c->ahead_q.push_back({slot, evi, !on_device});
+  c->ahead_ev_next ^= 1;
   return slot;
 }
 
@@ -3546,7 +3592,7 @@ int khr_ingest_ahead(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fram
 int khr_ingest_ahead_host(khr_ctx* c, const khr_sensor* sensor, const khr_frame* frame) { return ingestAhead(c, sensor, frame, 0); }
 int khr_ingest_cancel(khr_ctx* c) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
-  if (c->ahead_slot < 0) return KHR_ENOTFOUND;
+  if (c->ahead_q.empty()) return KHR_ENOTFOUND;
   cancelAhead(c);
   return KHR_OK;
 }
@@ -3567,14 +3613,14 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   // update / summary / tracking kernels may still be running on the main stream, and the auxiliary stream is not ordered
   // behind them -- the ingest then stays on the main stream.
   const bool ahead = (flags & KHR_PF_INGESTED) != 0;
-  if (ahead && (c->ahead_slot < 0 || !frame || !motion || !(flags & KHR_PF_INPUT_READY) ||
-                c->slots[c->ahead_slot].meta.timestamp_ns != frame->timestamp_ns)) {
-    // a rejected call must not leave the context wedged: the handed-over frame is dropped with its lease, the caller
-    // processes its frame the usual way
+  if (ahead && (c->ahead_q.empty() || !frame || !motion || !(flags & KHR_PF_INPUT_READY) ||
+                c->slots[c->ahead_q.front().slot].meta.timestamp_ns != frame->timestamp_ns)) {
+    // a rejected call must not leave the context wedged: the handed-over frames are dropped with their leases, the
+    // caller processes its frame the usual way
     cancelAhead(c);
-    return fail(KHR_ESTATE, "KHR_PF_INGESTED: no frame with this stamp was handed over by khr_ingest_ahead (or flags are missing); the handed-over frame was dropped");
+    return fail(KHR_ESTATE, "KHR_PF_INGESTED: the oldest frame handed over by khr_ingest_ahead does not carry this stamp (or flags are missing); the handed-over frames were dropped");
   }
-  if (!ahead && c->ahead_slot >= 0) return fail(KHR_ESTATE, "the frame handed over by khr_ingest_ahead has to be processed first (khr_ingest_cancel drops it)");
+  if (!ahead && !c->ahead_q.empty()) return fail(KHR_ESTATE, "the frames handed over by khr_ingest_ahead have to be processed first (khr_ingest_cancel drops them)");
   const bool pinned_in = !on_device && (flags & KHR_PF_INPUT_PINNED) != 0;
   if (pinned_in && !ahead && frame && (!pointerIs(frame->depth, 0) || !pointerIs(frame->color, 0) || !pointerIs(frame->label, 0)))
     return fail(KHR_EINVAL, "KHR_PF_INPUT_PINNED: the frame's buffers must be page-locked host memory (hipHostMalloc / hipHostRegister)");
@@ -3594,16 +3640,22 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
         hipEventSynchronize(c->ev_h2d);
         c->h2d_pending = false;
       }
+      if (own_h2d) hipEventSynchronize(own_h2d);  // (a handed-over host frame: ITS planes, not those of a frame handed over after it)
     }
+    hipEvent_t own_h2d = nullptr;
   } leave{c};
   // pinned host frames qualify for the early ingest like device frames: the planes travel on the host-to-device stream, the
   // ingest runs on the second stream behind them
   const bool early = ahead || (c->early_ingest && (flags & KHR_PF_INPUT_READY) && (on_device || pinned_in) && motion && c->cfg.with_tracking &&
                                c->slots.size() >= 2 && peekSlot(c) != c->last_frame_slot);
   int slot;
+  int ahead_ev = 0;
   if (ahead) {
-    slot = c->ahead_slot;
-    c->ahead_slot = -1;
+    const khr_ctx::AheadEntry e = c->ahead_q.front();
+    c->ahead_q.erase(c->ahead_q.begin());
+    slot = e.slot;
+    ahead_ev = e.ev;
+    if (e.host) leave.own_h2d = c->ev_ahead_h2d[e.ev];
     c->slot_leases[slot].fetch_sub(1, std::memory_order_acq_rel);  // (the look-ahead's own lease)
   } else {
     c->begin_in_ingest = !early;
@@ -3621,7 +3673,7 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   int rc = KHR_OK;
   if (ahead) {
     c->begun = false;
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_ahead, 0));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_ahead[ahead_ev], 0));
   } else if (early) {
     c->begun = false;
     s.aux_seq = ++c->aux_seq_issued;
@@ -3644,6 +3696,7 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   if (objects) {
     if (!(ahead && c->obj_pending_slot == slot)) {  // (not already queued by khr_ingest_ahead)
       if (!early) HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_ingest, 0));  // (early: same stream, in order)
+      if (ahead) HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_ahead[ahead_ev], 0));  // (a host frame was converted on the copy stream)
       if ((rc = objectsLaunch(c, slot))) return rc;
     }
     HT("pf_objects_launched");
@@ -3775,8 +3828,10 @@ int khr_allocate_blocks(khr_ctx* c, const int32_t* indices, int64_t n) {
   // asynchronous: the indices travel through a pinned buffer + its device twin owned by the context (no hipMalloc /
   // hipFree, which stall every stream of the device); the buffer is reused only after the previous upload was consumed
   const size_t bytes = sizeof(int32_t) * 3 * v.size();
+  HT("ab_enter");
   if (!c->ev_up) HIP_TRY(hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
   else HIP_TRY(hipEventSynchronize(c->ev_up));
+  HT("ab_prev_upload_consumed");
   if (bytes > c->h_up_bytes) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->h_up) hipHostFree(c->h_up);
@@ -3789,12 +3844,16 @@ int khr_allocate_blocks(khr_ctx* c, const int32_t* indices, int64_t n) {
     c->h_up_bytes = want;
   }
   std::memcpy(c->h_up, v.data(), bytes);
-  HIP_TRY(hipMemcpyAsync(c->d_up, c->h_up, bytes, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipEventRecord(c->ev_up, c->stream));
+  // the kernel reads the indices straight out of the page-locked staging block (a few tens of KB over the link): round 5 -- a
+  // hipMemcpyAsync here, issued from an extraction worker's thread, did not return for 7 ms while the window's thread kept the
+  // copy path busy with its frames' planes (KHR_PF_INPUT_PINNED; profiles/r05_host_input_marks.txt)
+  void* up_dev = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(&up_dev, c->h_up, 0));
   HIP_TRY(hipMemsetAsync(&c->m.counters[C_N_NEW], 0, sizeof(uint32_t), c->stream));
   c->explicit_blocks += v.size();
-  hipLaunchKernelGGL(k_alloc_list, dim3(gridFor(v.size())), dim3(256), 0, c->stream, c->m, static_cast<const int*>(c->d_up),
+  hipLaunchKernelGGL(k_alloc_list, dim3(gridFor(v.size())), dim3(256), 0, c->stream, c->m, static_cast<const int*>(up_dev),
                      static_cast<int>(v.size()), c->d_new);
+  HIP_TRY(hipEventRecord(c->ev_up, c->stream));  // (the staging block is free again once the kernel has read it)
   hipLaunchKernelGGL(k_init_blocks, dim3(2048), dim3(256), 0, c->stream, c->m, c->p, c->d_new);
   HIP_TRY(hipGetLastError());
   c->host_index_valid = false, ++c->map_gen;

@@ -137,7 +137,10 @@ MeshObjectExtractor::MeshObjectExtractor(const Config& cfg, const khr_config& aw
   // (khr_reset_map).  It only grows when an object needs more blocks than it holds.
   if (aw_device_config.max_frame_pixels > 0) {
     khr_config oc = objectMapConfig(0.05f);
-    oc.max_blocks = 4096;
+    // large enough for almost every object at the default resolution (2 % of the largest extent: 50 voxels = 7 blocks per box
+    // side, the allocated range is twice the box: <= 15^3 blocks); growing it later means destroying and re-creating an HBM pool
+    // in the middle of the stream (~5 ms during which an extraction's join waits: profiles/r05_host_input_marks.txt).  15 KB a block.
+    oc.max_blocks = std::min<uint32_t>(8192u, std::max<uint32_t>(config.max_object_blocks, 1u));
     oc.max_mesh_vertices = std::max<uint64_t>(1u << 16, static_cast<uint64_t>(oc.max_blocks) * 512ull * 15ull / 4);
     if (khr_create(&oc, &object_ctx_) == KHR_OK) object_ctx_blocks_ = oc.max_blocks;
     else object_ctx_ = nullptr;  // (no device yet: created on first use)
@@ -282,6 +285,7 @@ std::shared_ptr<KhronosObjectAttributes> MeshObjectExtractor::extractStaticObjec
       }
   const size_t n_blocks = idx.size() / 3;
   if (n_blocks > config.max_object_blocks) return nullptr;
+  khr_host_trace("x_begin");
   if (!object_ctx_ || n_blocks + 1 > object_ctx_blocks_) {
     if (object_ctx_) khr_destroy(object_ctx_);
     object_ctx_ = nullptr;
@@ -297,6 +301,7 @@ std::shared_ptr<KhronosObjectAttributes> MeshObjectExtractor::extractStaticObjec
   // the buffered frames were written on the active window's stream: one device-side dependency instead of a host wait per
   // re-integrated frame (the extraction may run on a worker thread while the window keeps queueing frames)
   chk(khr_depend_on(octx, frames.front().first->input.ctx), "khr_depend_on");
+  khr_host_trace("x_depends");
   std::shared_ptr<KhronosObjectAttributes> object;
   try {
     chk(khr_allocate_blocks(octx, idx.data(), static_cast<int64_t>(n_blocks)), "khr_allocate_blocks");  // :218-228

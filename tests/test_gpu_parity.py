@@ -270,7 +270,8 @@ def test_tracking_shortcuts_are_exact():
     both_equal()
 
 
-@pytest.mark.parametrize("inputs", ["host", "device", "device-ready", "device-ahead", "host-pinned", "host-pinned-ahead"])
+@pytest.mark.parametrize("inputs", ["host", "device", "device-ready", "device-ahead", "host-pinned", "host-pinned-ahead", "device-ahead2",
+                                    "host-pinned-ahead2"])
 def test_fused_process_frame_equals_stepwise(inputs):
     """khr_process_frame (one call per frame, asynchronous output stage) == the step-by-step calls; with host buffers, with
     device buffers, with device buffers declared complete (KHR_PF_INPUT_READY: the ingest runs ahead on the context's
@@ -279,9 +280,10 @@ def test_fused_process_frame_equals_stepwise(inputs):
     PAGE-LOCKED HOST memory -- what a drop-in's spinOnce receives (active_window.cpp:118-125) -- with KHR_PF_INPUT_PINNED (planes on
     the context's copy stream, no host wait) and handed over one frame early with khr_ingest_ahead_host."""
     from common import DeviceArray, PinnedArray
-    ahead_mode = inputs in ("device-ahead", "host-pinned-ahead")
+    ahead_mode = "ahead" in inputs
+    two = inputs.endswith("2")  # frame i + 1 is handed over BEFORE frame i's khr_process_frame call: two frames in the look-ahead
     pinned = inputs.startswith("host-pinned")
-    cfg, ctx, ora, s, sen, osen = make_pair(width=320, height=240, temporal_window=0.75, num_frame_slots=4 if ahead_mode else 3)
+    cfg, ctx, ora, s, sen, osen = make_pair(width=320, height=240, temporal_window=0.75, num_frame_slots=(5 if two else 4) if ahead_mode else 3)
     fired = 0
     held = []
     N = 20
@@ -320,15 +322,22 @@ def test_fused_process_frame_equals_stepwise(inputs):
             f.depth, f.color, f.label = (d.data_ptr() for d in dev)
             if inputs == "device-ready":
                 flags |= ctx.PF_INPUT_READY
+        if two and (flags & ctx.PF_INGESTED) and i + 1 < N:
+            nf = device_frame(i + 1)
+            if (ctx.ingest_ahead_host if pinned else ctx.ingest_ahead)(sen, nf) is not None:
+                ahead[i + 1] = nf
+                n_ahead += 1
+                with pytest.raises(Exception):  # a third hand-over is refused
+                    (ctx.ingest_ahead_host if pinned else ctx.ingest_ahead)(sen, nf)
+            else:
+                held.pop()
         slot, nc = ctx.process_frame(sen, f, on_device=not (inputs == "host" or pinned), flags=flags)
-        if ahead_mode and i + 1 < N:
+        if ahead_mode and i + 1 < N and (i + 1) not in ahead:
             nf = device_frame(i + 1)
             hand_over = ctx.ingest_ahead_host if pinned else ctx.ingest_ahead
             if hand_over(sen, nf) is not None:
                 ahead[i + 1] = nf
                 n_ahead += 1
-                with pytest.raises(Exception):  # a second hand-over before the first one is processed is refused
-                    hand_over(sen, nf)
             else:
                 held.pop()
         n_o, dyn_o, _ = ora.detect_motion(osen, fr["stamp"], fr["pose"], fr["depth"])

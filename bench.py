@@ -767,7 +767,7 @@ def main():
         from oracle import pyoracle as po
         cores = os.cpu_count() or 1
         if nb < 0:
-            nb = max(4, min(12, args.steps)) if args.config == "c3" else min(24, args.steps)
+            nb = max(4, min(16, args.steps)) if args.config == "c3" else min(24, args.steps)
         ocfg = po.config_from(cfg, cores)
         ora = po.OracleMap(ocfg)
         osen = ora.make_sensor(W, H, s.fx, s.fy, s.cx, s.cy, 0.1, 5.0)
@@ -779,44 +779,91 @@ def main():
         same_frames = (t0i + nb) <= len(frames_host) and t0i <= 128
         first_timed = t0i if same_frames else min(2, nb - 1)
         last_frame = first_timed + nb if same_frames else nb
-        for i in range(last_frame):
+        # per-stage wall time under the reference's timer names (hydra::timing scopes of active_window.cpp:121-256,
+        # free_space_motion_detector.cpp:74, connected_semantics.cpp:60, max_iou_tracker.cpp:199, tracking_integrator.cpp:72)
+        stage_names = ("motion_detection/all", "active_window/update_map (projective integrator)", "integration/tracking",
+                       "object_detection/all", "tracking/all (voxel sets)", "active_window/extract_output (mesh, archival)")
+        stage = dict.fromkeys(stage_names, 0.0)
+
+        def cpu_frame(i, acc):
             fr = frames_host[i]
-            c0 = time.perf_counter()
+            tt = [time.perf_counter()]
             dyn = None
             if not args.no_motion:
                 _, dyn, _ = ora.detect_motion(osen, fr["stamp"], fr["pose"], fr["depth"])
+            tt.append(time.perf_counter())
             stc = ora.integrate(osen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"], mask=dyn)
+            tt.append(time.perf_counter())
             if not args.no_tracking:
                 ora.update_tracking(fr["stamp"])
-            if pipe is not None and i >= first_timed:
+            tt.append(time.perf_counter())
+            t_obj = t_trk = 0.0
+            if pipe is not None and acc is not None:
                 # object half on the CPU: ConnectedSemantics + the tracker's voxel sets (single-threaded in the reference
                 # too); the association itself is negligible and not timed.  (Stateless per frame: skipped on the
                 # untimed lead-in.)
                 _, oimg, _ = ora.detect_objects(osen, fr["stamp"], fr["pose"], fr["depth"], fr["label"], list(range(7, 20)), use_3d=True,
                                                 grid_size=0.1, max_range=5.0, min_cluster_size=50, use_full_connectivity=True)
+                t_obj = time.perf_counter() - tt[-1]
+                tv = time.perf_counter()
                 ora.cluster_voxels(osen, fr["stamp"], fr["pose"], fr["depth"], oimg, 0.2)
                 if dyn is not None and dyn.any():
                     ora.cluster_voxels(osen, fr["stamp"], fr["pose"], fr["depth"], dyn, 0.2)
+                t_trk = time.perf_counter() - tv
+            to = time.perf_counter()
             if args.output_every > 0 and (i + 1) % args.output_every == 0:
                 ora.generate_mesh(True, True)
                 if not args.no_tracking:
                     ora.reset_inactive()
                 ora.clear_updated()
-            c1 = time.perf_counter()
-            if i >= first_timed:
-                tc += c1 - c0
-                upd += stc["n_updated_voxels"]
-        n_timed = last_frame - first_timed
+            t_end = time.perf_counter()
+            if acc is not None:
+                for k, v in zip(stage_names, (tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], t_obj, t_trk, t_end - to)):
+                    acc[k] += v
+            return t_end - tt[0], stc["n_updated_voxels"]
+
+        for i in range(first_timed):
+            cpu_frame(i, None)
+        # thread-count sweep on the first frames of the sample (the integrators spawn and join their threads
+        # per call, as the reference's do -- tracking_integrator.cpp:83-90 -- so "all cores" is not the fastest setting on a
+        # many-core host): 2 frames per setting, then the rest of the sample at all cores
+        sweep = {}
+        i = first_timed
+        sweep_counts = [t for t in (8, 32, 64) if t < cores]
+        if same_frames and nb >= 2 * len(sweep_counts) + 4:
+            for tcount in sweep_counts:
+                ora.set_threads(tcount)
+                ts = 0.0
+                for _k in range(2):
+                    dt_, _u = cpu_frame(i, None)
+                    ts += dt_
+                    i += 1
+                sweep[str(tcount)] = 2.0 / ts
+            ora.set_threads(cores)
+        n_all = 0
+        for i in range(i, last_frame):
+            dt_, u_ = cpu_frame(i, stage)
+            tc += dt_
+            upd += u_
+            n_all += 1
+        n_timed = n_all
         cpu_fps = n_timed / tc
+        sweep[str(cores)] = cpu_fps
+        best_threads = max(sweep, key=lambda k: sweep[k])
         out["cpu_baseline"] = {"value": cpu_fps, "unit": "frames/s", "cores": cores, "kind": "port",
                                "sample": "frames %d..%d of the same stream%s (CPU restatement of the reference path, %d threads for "
                                          "the volumetric part%s; reference itself not buildable offline)"
-                                         % (first_timed, last_frame - 1,
-                                            " = the first %d of the frames the GPU steps were timed on, after the same %d lead-in frames" % (n_timed, first_timed)
+                                         % (last_frame - n_timed, last_frame - 1,
+                                            " = %d of the frames the GPU steps were timed on, after the same lead-in frames" % n_timed
                                             if same_frames else " (the window is still filling: fewer blocks per frame than in the GPU's timed steps)",
                                             cores, ", object detection + voxel sets on 1 thread as in the reference" if pipe is not None else ""),
-                               "mvoxel_updates_per_s": 1e-6 * upd / tc}
+                               "mvoxel_updates_per_s": 1e-6 * upd / tc,
+                               "stage_ms_per_frame": {k: 1e3 * v / n_timed for k, v in stage.items()},
+                               "thread_sweep_frames_per_s": sweep,
+                               "best": {"threads": int(best_threads), "frames_per_s": sweep[best_threads],
+                                        "note": "2 frames per setting below all cores; worker threads are spawned and joined per integrator call, as in the reference"}}
         out["speedup_vs_cpu"] = fps / cpu_fps
+        out["speedup_vs_cpu_best_thread_count"] = fps / sweep[best_threads]
 
     if held_snapshot[0] is not None:
         held_snapshot[0].release()

@@ -483,6 +483,8 @@ inline bool voxelIsFree(const orc_config& c, const TrackingVoxel& v, uint64_t st
 
 extern "C" {
 
+void orc_set_threads(orc_map* m, int32_t num_threads) { m->cfg.num_threads = num_threads; }
+
 void orc_set_label_hook(orc_map* m, orc_label_hook_fn fn, void* user) {
   m->label_hook = fn;
   m->label_user = user;

@@ -219,6 +219,9 @@ int orc_set_distance(orc_map* m, int32_t bx, int32_t by, int32_t bz, const float
  * installed orc_integrate applies NEITHER its own mask rule NOR its own label rule: the hook decides both.  The reference pin
  * (oracle/ref_recipe/ref_harness.cpp) installs the reference's own ObjectIntegrator::computeLabel here.  Called from the
  * integrator's worker threads.  fn = NULL removes it. */
+/* worker threads of the integrators from now on (orc_config.num_threads semantics: 0 = all cores); lets one map time the same
+ * steady state at several thread counts (bench.py cpu_baseline sweep) */
+void orc_set_threads(orc_map* m, int32_t num_threads);
 typedef int (*orc_label_hook_fn)(void* user, float sdf, const int32_t* u4, const int32_t* v4, const float* w4, int32_t* label_out);
 void orc_set_label_hook(orc_map* m, orc_label_hook_fn fn, void* user);
 /* the three block flags the reference's active window sets and clears from outside the integrators (bit0 updated, bit1

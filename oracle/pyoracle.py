@@ -73,6 +73,8 @@ def load():
     lib.orc_create.argtypes = [C.POINTER(OrcConfig)]
     lib.orc_create.restype = vp
     lib.orc_destroy.argtypes = [vp]
+    lib.orc_set_threads.argtypes = [vp, i32]
+    lib.orc_set_threads.restype = None
     lib.orc_destroy.restype = None
     lib.orc_parse_input.argtypes = [C.POINTER(OrcConfig), C.POINTER(OrcSensor), vp, vp, vp, vp]
     lib.orc_parse_input.restype = None
@@ -155,6 +157,10 @@ class OracleMap:
         self.cfg = cfg
         self.h = C.c_void_p(self.lib.orc_create(C.byref(cfg)))
         self.nvox = cfg.voxels_per_side ** 3
+
+    def set_threads(self, n):
+        """worker threads of the integrators from now on (0 = all cores)"""
+        self.lib.orc_set_threads(self.h, int(n))
 
     def close(self):
         if getattr(self, "h", None):

@@ -594,8 +594,14 @@ def main():
     # per-frame latency: the same steps with a device synchronisation after each (the reference's active_window/all scope
     # is a per-frame wall time; `value` above is pipelined throughput: the host queues frame i + 1 while frame i executes)
     lat_ms = None
+    # the other streaming kernels of the path are timed on these frames (start / stop stamps of their own dispatch packets:
+    # nothing is added to the streams) and the unit counts of SURVEY.md 8(d) are read after every frame
+    kern_names = ("k_tracking_update", "k_ever_free", "k_mc_count", "k_mc_emit", "k_snapshot_pack")
+    kern_units = {"trk_vox": 0, "ef_vox": 0, "mesh_vox": 0, "mesh_vertices": 0, "snap_blocks": 0, "frames": 0, "outputs": 0}
     if lat > 0:
         tl = []
+        if world == 1 and not args.no_roofline_timers:
+            ctx.timing_enable(True, kern_names)  # (their totals start at zero: they were off until here; k_fuse's totals stay)
         for i in range(t1i, t1i + lat):
             torch.cuda.synchronize()
             ta = time.perf_counter()
@@ -604,6 +610,20 @@ def main():
                 pipe.finish_frame()
             torch.cuda.synchronize()
             tl.append(1e3 * (time.perf_counter() - ta))
+            if world == 1 and not args.no_roofline_timers:
+                sk = ctx.stats()
+                kern_units["frames"] += 1
+                kern_units["trk_vox"] += sk["n_tracking_processed_blocks"] * 4096
+                kern_units["ef_vox"] += sk["n_tracking_updated_blocks"] * 4096
+                if args.output_every > 0 and (i + 1) % args.output_every == 0:
+                    kern_units["outputs"] += 1
+                    kern_units["mesh_vox"] += sk["n_mesh_blocks"] * 4096
+                    kern_units["mesh_vertices"] += sk["n_mesh_vertices"]
+                    if held_snapshot[0] is not None:
+                        kern_units["snap_blocks"] += held_snapshot[0].num_blocks()
+        if world == 1 and not args.no_roofline_timers:
+            kern_ms = {k: ctx.timing_get(k) for k in kern_names}
+            ctx.timing_enable(False)
         if pipe is not None:
             pipe.join()
         lat_ms = {"mean": float(np.mean(tl)), "min": float(np.min(tl)), "max": float(np.max(tl)), "frames": len(tl)}
@@ -760,6 +780,37 @@ def main():
             m_, n_ = ctx.timing_get(name)
             kern["fuse" if name == "tsdf" else name] = {"ms_total": m_, "launches": n_}
         out["kernel_ms"] = kern
+        if world == 1 and lat > 0 and kern_units["frames"]:
+            # ---- the path's other streaming kernels against the same roofline (SURVEY.md 8(d) bytes per unit) ----
+            def krec(kernel, timers, nbytes, formula, counts, per):
+                ms_ = sum(kern_ms[t][0] for t in timers)
+                n_ = max(kern_ms[timers[0]][1], 1)
+                if ms_ <= 0:
+                    return None
+                us = 1e3 * ms_ / n_
+                ach = nbytes / n_ / (us * 1e-6) / 1e9
+                return {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                        "avg_launch_us": us, "launches": n_, "per": per, "algorithmic_bytes_per_launch": nbytes / n_,
+                        "algorithmic_bytes": formula, "counts_per_launch": {k: v / n_ for k, v in counts.items()},
+                        **({"passes_us": {t: 1e3 * kern_ms[t][0] / max(kern_ms[t][1], 1) for t in timers}} if len(timers) > 1 else {})}
+            ku = kern_units
+            nv_, nf_ = ku["mesh_vertices"], ku["mesh_vertices"] / 3.0
+            recs = [
+                krec("k_tracking_update", ("k_tracking_update",), 31.0 * ku["trk_vox"],
+                     "31 B x N_alloc, N_alloc = voxels of the blocks the pass has to visit (the blocks that provably cannot change are "
+                     "skipped by k_tracking_select and cost nothing)", {"N_alloc_vox": ku["trk_vox"]}, "frame"),
+                krec("k_ever_free", ("k_ever_free",), 18.0 * ku["ef_vox"], "18 B x N_updblk_vox", {"N_updblk_vox": ku["ef_vox"]}, "frame"),
+                krec("k_marching_cubes", ("k_mc_count", "k_mc_emit"), 8.0 * ku["mesh_vox"] + 48.0 * nv_ + 12.0 * nf_,
+                     "8 B x N_meshblk_vox + 48 B x N_vertices + 12 B x N_faces (count pass + emit pass together; the soup has N_faces = N_vertices / 3)",
+                     {"N_meshblk_vox": ku["mesh_vox"], "N_vertices": nv_, "N_faces": nf_}, "output"),
+                krec("k_snapshot_pack", ("k_snapshot_pack",), 2.0 * 25.0 * 4096.0 * ku["snap_blocks"],
+                     "2 x 25 B x voxels of the updated blocks (read + write of distance, weight, colour, label, last_observed, flags: "
+                     "VolumetricMap::cloneUpdated, active_window.cpp:229; not a row of SURVEY.md 8(d))",
+                     {"N_snapshot_blocks": ku["snap_blocks"]}, "output") if ku["snap_blocks"] else None,
+            ]
+            out["kernel_rooflines"] = {"measured_on": "the %d latency frames after the timed region (%d outputs); HIP start / stop stamps of each kernel's own "
+                                                      "dispatch packet (hipExtLaunchKernelGGL)" % (ku["frames"], ku["outputs"]),
+                                       "kernels": [r for r in recs if r]}
 
     # ---- CPU baseline: the oracle on a bounded sample of the same stream (rank 0, N = 1 only) ----
     nb = args.cpu_baseline_frames

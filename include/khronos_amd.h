@@ -565,8 +565,11 @@ int khr_tick_live_bound(khr_ctx* ctx, int64_t* out_device, int n_out, int index)
 /* -- measurement ------------------------------------------------------------------------------- */
 /* HIP-event timing of the kernels launched on the context stream. which: 0 fused TSDF / colour / label update
  * (k_fuse), 1 tracking update, 2 ever-free, 3 block allocation+init, 4 motion pixels, 5 mesh, 6 parse input,
- * 7 unused (the band update is part of k_fuse).
- * `enable` is a bit mask of timers (bit i = timer i; 0 = off, 0xff = all).
+ * 7 k_band3 (KHR_FUSE_V=3 only; in the default path the band update is part of k_fuse).  0 and 7 .. 12 time ONE kernel with
+ * the start / stop stamps of its own dispatch packet (no extra packets in the stream): 8 k_marching_cubes count pass,
+ * 9 k_marching_cubes emit pass, 10 k_tracking_update, 11 k_ever_free, 12 k_snapshot_pack; 1 .. 6 bracket a group of launches
+ * with event records.
+ * `enable` is a bit mask of timers (bit i = timer i; 0 = off, 0xff = all groups, 0x1fff = everything).
  * Accumulates between khr_timing_reset calls; returns total ms and launch count. */
 /* development probe (KHR_DEBUG & 8): per-workgroup timestamps of the last k_tsdf_update launch */
 int khr_debug_read(khr_ctx* ctx, unsigned long long* out, int64_t n);

@@ -239,7 +239,9 @@ def _ptr(a):
 class FusionContext:
     """Thin object wrapper over a khr_ctx (one per GPU / per map)."""
 
-    TIMERS = {"tsdf": 0, "tracking": 1, "ever_free": 2, "alloc": 3, "motion_pixels": 4, "mesh": 5, "parse": 6, "band": 7}
+    TIMERS = {"tsdf": 0, "tracking": 1, "ever_free": 2, "alloc": 3, "motion_pixels": 4, "mesh": 5, "parse": 6, "band": 7,
+              # single kernels (start / stop stamps of the dispatch packet itself)
+              "k_mc_count": 8, "k_mc_emit": 9, "k_tracking_update": 10, "k_ever_free": 11, "k_snapshot_pack": 12}
 
     def __init__(self, cfg):
         self.lib = load_library()

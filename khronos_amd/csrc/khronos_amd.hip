@@ -96,7 +96,7 @@ struct TimingRec {
   hipEvent_t a, b;
 };
 
-constexpr int kNumTimers = 8;
+constexpr int kNumTimers = 13;  // 0..7: kernel groups; 8..12: single kernels (k_marching_cubes count / emit, k_tracking_update, k_ever_free, k_snapshot_pack)
 constexpr uint32_t kObjHead = 512;   // cluster records in the first download of the object detector
 constexpr uint32_t kCvHead = 8192;   // (cluster, voxel) keys in the first download of a voxel-set request
 constexpr uint32_t kCompCap = 1024, kCompHead = 64;  // motion-cluster components: record capacity / records in the first download
@@ -387,16 +387,17 @@ hipEvent_t takeEvent(khr_ctx* c) {
   }
   return e;
 }
-#define KHR_LAUNCH_TIMED(which, kernel, grid, block, ...)                                              \
+#define KHR_LAUNCH_TIMED_ON(which, strm, kernel, grid, block, ...)                                     \
   do {                                                                                                 \
     if ((c->timing >> (which)) & 1u) {                                                                 \
       hipEvent_t ev_a = takeEvent(c), ev_b = takeEvent(c);                                             \
-      hipExtLaunchKernelGGL(kernel, grid, block, 0, c->stream, ev_a, ev_b, 0, __VA_ARGS__);            \
+      hipExtLaunchKernelGGL(kernel, grid, block, 0, strm, ev_a, ev_b, 0, __VA_ARGS__);                 \
       c->pending.push_back({(which), ev_a, ev_b});                                                     \
     } else {                                                                                           \
-      hipLaunchKernelGGL(kernel, grid, block, 0, c->stream, __VA_ARGS__);                              \
+      hipLaunchKernelGGL(kernel, grid, block, 0, strm, __VA_ARGS__);                                   \
     }                                                                                                  \
   } while (0)
+#define KHR_LAUNCH_TIMED(which, kernel, grid, block, ...) KHR_LAUNCH_TIMED_ON(which, c->stream, kernel, grid, block, __VA_ARGS__)
 
 void resolveTimers(khr_ctx* c) {
   for (auto& r : c->pending) {
@@ -1742,8 +1743,8 @@ static int trackingPhase(khr_ctx* c, uint64_t stamp, int phase) {
       c->fold_pending = false;
       // (khr_process_frame at output cadence: marching cubes start here, beside the rest of the tracking pass)
       if (c->fork_after_select) HIP_TRY(hipEventRecord(c->ev_mc_fork, c->stream));
-      hipLaunchKernelGGL((k_tracking_update<V, (V == 16 ? 4 : 1)>), dim3(V == 16 ? 4096 : 1024), dim3(256), 0, c->stream, m, c->p, stamp,
-                         c->last_track_stamp, lim_active, lim_free, c->d_trk_proc, cnt);
+      KHR_LAUNCH_TIMED(10, (k_tracking_update<V, (V == 16 ? 4 : 1)>), dim3(V == 16 ? 4096 : 1024), dim3(256), m, c->p, stamp,
+                       c->last_track_stamp, lim_active, lim_free, c->d_trk_proc, cnt);
       c->last_track_stamp = stamp;
     }
     if (phase & 2) {
@@ -1755,8 +1756,8 @@ static int trackingPhase(khr_ctx* c, uint64_t stamp, int phase) {
         rh.ht_vals = c->d_halo_vals;
         rh.ht_mask = c->halo_mask;
       }
-      hipLaunchKernelGGL((k_ever_free<V>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, c->d_ef,
-                         &m.counters[c->ef_cur ? C_N_EF2 : C_N_EF_A], rh);
+      KHR_LAUNCH_TIMED(11, (k_ever_free<V>), dim3(kStreamGrid), dim3(256), m, c->p, c->d_ef,
+                       &m.counters[c->ef_cur ? C_N_EF2 : C_N_EF_A], rh);
     }
     HIP_TRY(hipGetLastError());
     return KHR_OK;
@@ -3324,17 +3325,18 @@ int khr_generate_mesh(khr_ctx* c, int only_mesh_updated, int clear_flag) {
   const uint32_t maxv = static_cast<uint32_t>(std::min<uint64_t>(c->cfg.max_mesh_vertices, 0xfffffff0ull));
   int rc = dispatchVps(c, [&](auto vps) {
     constexpr int V = decltype(vps)::value;
-    hipLaunchKernelGGL((k_marching_cubes<V, false>), dim3(kStreamGrid), dim3(256), 0, c->stream, m, c->p, c->d_work,
-                       c->d_mesh_nwork, c->d_mesh_count, c->d_mesh_offset, dst, clear_flag, maxv, rmh);
+    KHR_LAUNCH_TIMED(8, (k_marching_cubes<V, false>), dim3(kStreamGrid), dim3(256), m, c->p, c->d_work,
+                     c->d_mesh_nwork, c->d_mesh_count, c->d_mesh_offset, dst, clear_flag, maxv, rmh, 0xffffffffu,
+                     static_cast<const uint8_t*>(nullptr), MeshBuffers{});
     size_t tb = c->cub_temp_bytes;
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->d_cub_temp, tb, c->d_mesh_count, c->d_mesh_offset,
                                              static_cast<int>(cap + 1), c->stream));
     // no host round trip: the capacity check happens on the device (C_MESH_OVERFLOW), totals are read lazily
     // emit pass + the copy of the kept blocks' vertices in ONE launch (the trailing kMoveWgs workgroups copy)
     constexpr uint32_t kMoveWgs = 1024;
-    hipLaunchKernelGGL((k_marching_cubes<V, true>), dim3(kStreamGrid + kMoveWgs), dim3(256), 0, c->stream, m, c->p, c->d_work,
-                       c->d_mesh_nwork, c->d_mesh_count, c->d_mesh_offset, dst, clear_flag, maxv, rmh, static_cast<uint32_t>(kStreamGrid),
-                       static_cast<const uint8_t*>(c->d_regen), src);
+    KHR_LAUNCH_TIMED(9, (k_marching_cubes<V, true>), dim3(kStreamGrid + kMoveWgs), dim3(256), m, c->p, c->d_work,
+                     c->d_mesh_nwork, c->d_mesh_count, c->d_mesh_offset, dst, clear_flag, maxv, rmh, static_cast<uint32_t>(kStreamGrid),
+                     static_cast<const uint8_t*>(c->d_regen), src);
     return KHR_OK;
   });
   if (rc) return rc;
@@ -4226,8 +4228,8 @@ int khr_snapshot_updated(khr_ctx* c, uint32_t fields, int64_t cap_blocks, khr_sn
     hipLaunchKernelGGL(k_snapshot_select, dim3(gridFor(c->m.capacity)), dim3(256), 0, st, c->m, snap->d_count, snap->d_slots,
                        snap->d_index, snap->cap);
     dispatchVps(c, [&](auto vps) {
-      hipLaunchKernelGGL((k_snapshot_pack<decltype(vps)::value>), dim3(2048), dim3(256), 0, st, c->m, snap->d_count, snap->d_slots,
-                         snap->cap, snap->o, snap->arena.d_count_host_view, snap->ticket);
+      KHR_LAUNCH_TIMED_ON(12, st, (k_snapshot_pack<decltype(vps)::value>), dim3(2048), dim3(256), c->m, snap->d_count, snap->d_slots,
+                          snap->cap, snap->o, snap->arena.d_count_host_view, snap->ticket);
       return KHR_OK;
     });
     e = hipGetLastError();

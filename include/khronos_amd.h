@@ -342,6 +342,29 @@ int khr_mesh_halo_requests(khr_ctx* ctx, void* keys_out, int64_t cap, int only_m
 int khr_mesh_halo_export(khr_ctx* ctx, const void* requests, int64_t n_requests, void* records, int64_t cap_records,
                          int on_device);
 int khr_mesh_halo_import(khr_ctx* ctx, const void* records, int64_t n_records, int on_device);
+/* Compact form of the same exchange (round 5; what khronos_amd/host/sharded_fusion.cpp ships): an answer carries only what the
+ * requester's marching cubes reads from that neighbour -- relation sel = 1 .. 7 (bit 0 / 1 / 2 = the +x / +y / +z neighbour):
+ * one face (sel 1, 2, 4: vps^2 voxels), one edge line (3, 5, 6: vps voxels) or the corner voxel (7), 1 + 6 N words each -- and
+ * travels to the requester alone (all-to-all-v instead of an all-gather of whole-block records: 817 instead of 7 x 768
+ * voxels per mesh block, received once instead of world times).  All buffers are DEVICE memory.
+ *   (1) khr_mesh_halo_requests_sorted: u64 buffer of KHR_MESH_HALO_REQ_HEADER_WORDS(world) + cap words: the header holds
+ *       the count of bucket (owner o, relation sel) in word 8 o + sel (word 0: the total), the keys follow bucket by bucket;
+ *       returns the total, KHR_ENOMEM beyond cap;
+ *   (2) the buffers are all-gathered and the world headers brought to the host (world x 8 world words);
+ *   (3) khr_mesh_halo_plan: send / receive counts and displacements in u32 words (the ncclAllToAllv arguments), the same on
+ *       every rank from the same headers -- no count exchange;
+ *   (4) khr_mesh_halo_answer writes this rank's answers, grouped by requester (asynchronous; returns their number;
+ *       KHR_ENOMEM if they need more than cap_words);
+ *   (5) after the all-to-all-v khr_mesh_halo_adopt indexes the received answers in place (the buffer must stay valid until the
+ *       mesh has been generated); own_requests = NULL forgets them.  World sizes up to 16. */
+#define KHR_MESH_HALO_REQ_HEADER_WORDS(world) (8 * (world))
+int khr_mesh_halo_requests_sorted(khr_ctx* ctx, void* requests_device, int64_t cap, int only_mesh_updated);
+int khr_mesh_halo_plan(int world, int rank, int vps, const uint64_t* headers, uint64_t* sendcounts, uint64_t* sdispls,
+                       uint64_t* recvcounts, uint64_t* rdispls);
+int khr_mesh_halo_answer(khr_ctx* ctx, const void* all_requests_device, int64_t cap, const uint64_t* headers, void* records_device,
+                         int64_t cap_words);
+int khr_mesh_halo_adopt(khr_ctx* ctx, const void* own_requests_device, const uint64_t* own_header, const void* records_device,
+                        const uint64_t* rdispls);
 /* (on_device = 2: the records are indexed where they are -- a device buffer the caller keeps unchanged until the next
  * khr_generate_mesh has run -- instead of being copied into the context first) */
 /* replaces: TrackingIntegrator::resetInactive (tracking_integrator.cpp:106-131). removed: caller

@@ -63,6 +63,13 @@ void* kdist_stream(kdist_handle* h);
 /* records per rank shipped by the last tick's halo all-gather and by the last output's mesh-record all-gather (0 = no
  * such exchange yet; the capacity when the trimmed form was not available: motion detector off, more than 8 cameras) */
 int kdist_last_exchange(kdist_handle* h, int64_t* halo_records_per_rank, int64_t* mesh_records_per_rank);
+/* The mesh halo of the last output in bytes: out[0] requests this rank sent (all-gathered: it received world x that), out[1]
+ * answers sent, out[2] answers received, out[3] the number of answers received.  Default (up to 16 ranks): the compact form of
+ * khronos_amd.h -- per-relation face / line / voxel answers, ncclAllToAllv owner -> requester, counts derived from the
+ * all-gathered request headers (no count exchange); in that form mesh_records_per_rank above is the number of answers this
+ * rank received.  KDIST_MESH_HALO=records in the environment of kdist_create selects the all-gather of whole-block records.
+ * Emulation (one rank of N without the others): what this rank would receive; "sent" is reported equal to it. */
+int kdist_last_mesh_exchange(kdist_handle* h, int64_t out[4]);
 
 /* What the tick's / the output's collectives cost (the first multi-GPU record has to explain itself): per kind of collective
  * the calls, the bytes THIS rank sent and -- while profiling is on -- the milliseconds between HIP events recorded around each
@@ -70,7 +77,8 @@ int kdist_last_exchange(kdist_handle* h, int64_t* halo_records_per_rank, int64_t
  * kdist_profile resets the counters; kdist_profile_get fills min(cap, count) entries and returns the count. */
 typedef struct kdist_coll_stat {
   char name[32];       /* frames_allgather, converted_allgather, counts_allreduce, motion_keys_reduce, dynamic_image_broadcast,
-                          halo_allgather, mesh_request_allgather, mesh_agree_allreduce, mesh_record_allgather */
+                          halo_allgather, mesh_request_allgather, mesh_agree_allreduce, mesh_record_allgather,
+                          mesh_answer_alltoallv */
   uint64_t calls;
   uint64_t bytes_sent;
   double ms;

@@ -82,6 +82,7 @@ EXPORTS = [
     "khr_converted_views", "khr_tick_adopt", "khr_copy_frame_image", "khr_rv_detect_changes", "khr_last_removed", "khr_process_frame", "khr_ingest_ahead", "khr_ingest_ahead_host", "khr_ingest_cancel", "khr_integrate_shared", "khr_integrate_shared_batch", "khr_pixel_iou", "khr_forward_instances", "khr_update_tracking_phase",
     "khr_export_halo", "khr_import_halo", "khr_get_dynamic_clusters", "khr_motion_keys",
     "khr_detect_motion_from_keys", "khr_download_updated", "khr_mesh_halo_requests", "khr_mesh_halo_export",
+    "khr_mesh_halo_requests_sorted", "khr_mesh_halo_plan", "khr_mesh_halo_answer", "khr_mesh_halo_adopt",
     "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",
     "khr_cluster_voxels", "khr_download_frame_image", "khr_detect_objects_launch", "khr_pool_exhausted", "khr_map_digest",
     "khr_rv_create", "khr_rv_destroy", "khr_rv_clear", "khr_rv_add_rays", "khr_rv_num_rays", "khr_rv_num_pairs", "khr_rv_check",
@@ -174,6 +175,10 @@ def load_library():
     lib.khr_mesh_halo_requests.argtypes = [vp, vp, i64, i32, i32]
     lib.khr_mesh_halo_export.argtypes = [vp, vp, i64, vp, i64, i32]
     lib.khr_mesh_halo_import.argtypes = [vp, vp, i64, i32]
+    lib.khr_mesh_halo_requests_sorted.argtypes = [vp, vp, i64, i32]
+    lib.khr_mesh_halo_plan.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.khr_mesh_halo_answer.argtypes = [vp, vp, i64, vp, vp, i64]
+    lib.khr_mesh_halo_adopt.argtypes = [vp, vp, vp, vp, vp]
     lib.khr_download_updated.argtypes = [vp] + [vp] * 7 + [i64]
     lib.khr_download_updated.restype = i64
     lib.khr_snapshot_updated.argtypes = [vp, C.c_uint32, i64, C.POINTER(vp)]
@@ -638,6 +643,30 @@ class FusionContext:
         out = np.zeros((cap_records, self.mesh_halo_words()), np.uint32)
         self._chk(self.lib.khr_mesh_halo_export(self.h, _ptr(requests), requests.size, _ptr(out), cap_records, 0))
         return out
+
+    # compact form (khr_mesh_halo_requests_sorted / _plan / _answer / _adopt): device buffers only
+    def mesh_halo_requests_sorted(self, device_ptr, cap, only_mesh_updated=True):
+        return self._chk(self.lib.khr_mesh_halo_requests_sorted(self.h, C.c_void_p(device_ptr), cap, int(only_mesh_updated)))
+
+    def mesh_halo_plan(self, headers):
+        """headers: u64 [world, 8 * world] (host).  Returns sendcounts, sdispls, recvcounts, rdispls (u32 words, u64 arrays)."""
+        w = self.cfg.world_size
+        headers = np.ascontiguousarray(headers, dtype=np.uint64).reshape(w, 8 * w)
+        out = [np.zeros(w, np.uint64) for _ in range(4)]
+        self._chk(self.lib.khr_mesh_halo_plan(w, self.cfg.rank, self.cfg.voxels_per_side, _ptr(headers), *[_ptr(o) for o in out]))
+        return out
+
+    def mesh_halo_answer(self, all_requests_ptr, cap, headers, records_ptr, cap_words):
+        headers = np.ascontiguousarray(headers, dtype=np.uint64)
+        return self._chk(self.lib.khr_mesh_halo_answer(self.h, C.c_void_p(all_requests_ptr), cap, _ptr(headers), C.c_void_p(records_ptr), cap_words))
+
+    def mesh_halo_adopt(self, own_requests_ptr=None, own_header=None, records_ptr=None, rdispls=None):
+        if own_requests_ptr is None:
+            self._chk(self.lib.khr_mesh_halo_adopt(self.h, None, None, None, None))
+            return
+        own_header = np.ascontiguousarray(own_header, dtype=np.uint64)
+        rdispls = np.ascontiguousarray(rdispls, dtype=np.uint64)
+        self._chk(self.lib.khr_mesh_halo_adopt(self.h, C.c_void_p(own_requests_ptr), _ptr(own_header), C.c_void_p(records_ptr), _ptr(rdispls)))
 
     def mesh_halo_import(self, records=None, device_ptr=None, n_records=0):
         if device_ptr is not None:

@@ -815,6 +815,52 @@ struct RemoteMeshHalo {
   const uint64_t* ht_keys;
   const uint32_t* ht_vals;
   uint32_t ht_mask;
+  const uint32_t* ht_offs;  // compact answers (khr_mesh_halo_adopt): 8 word offsets per table entry, one per relation; nullptr = whole-block records
+};
+
+// ---- compact mesh halo (round 5): what is shipped is what the requester's marching cubes reads -----------------------
+// A block's cubes read, from the neighbour reached through relation sel (bit 0 = +x, bit 1 = +y, bit 2 = +z), the face
+// x = 0 / y = 0 / z = 0 (sel 1, 2, 4: VPS^2 voxels), one edge line (sel 3, 5, 6: VPS voxels) or the corner voxel (sel 7).
+// An answer is [valid] then dist[N] | weight[N] | colour[N] | label[N] | stamp[N] (u64) for those N voxels.
+__host__ __device__ inline int meshHaloVoxels(int sel, int vps) {
+  const int bits = (sel & 1) + ((sel >> 1) & 1) + ((sel >> 2) & 1);
+  return bits == 1 ? vps * vps : (bits == 2 ? vps : 1);
+}
+__host__ __device__ inline int meshHaloAnswerWords(int sel, int vps) { return 1 + 6 * meshHaloVoxels(sel, vps); }
+// position of the neighbour's local voxel (x, y, z) in the answer of relation sel
+__host__ __device__ inline int meshHaloCompactIndex(int sel, int x, int y, int z, int vps) {
+  switch (sel) {
+    case 1: return y + vps * z;
+    case 2: return x + vps * z;
+    case 4: return x + vps * y;
+    case 3: return z;
+    case 5: return y;
+    case 6: return x;
+    default: return 0;
+  }
+}
+// voxel-linear index (in the answering block) of element i of the answer of relation sel
+__host__ __device__ inline int meshHaloSourceLin(int sel, int i, int vps) {
+  const int a = i % vps, b = i / vps;
+  switch (sel) {
+    case 1: return vps * (a + vps * b);
+    case 2: return a + vps * vps * b;
+    case 4: return a + vps * b;
+    case 3: return vps * vps * i;
+    case 5: return vps * i;
+    case 6: return i;
+    default: return 0;
+  }
+}
+constexpr int kMeshHaloMaxWorld = 16;                     // ranks the compact exchange is laid out for (7 relations x 16 peers)
+constexpr int kMeshHaloMaxRuns = 7 * kMeshHaloMaxWorld;
+// the answers a kernel walks: run r covers items [first[r], first[r + 1]) = consecutive requests of one (peer, relation) bucket
+struct MeshHaloRuns {
+  uint32_t n_runs, n_items;
+  uint32_t first[kMeshHaloMaxRuns + 1];
+  uint32_t req_off[kMeshHaloMaxRuns];   // u64 index of the run's first request
+  uint32_t rec_off[kMeshHaloMaxRuns];   // u32 word offset of the run's first answer
+  uint8_t sel[kMeshHaloMaxRuns];
 };
 
 struct MeshBuffers {
@@ -875,7 +921,8 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
   __shared__ uint8_t s_ok[T * T * T];  // corner observed (weight >= mesh_min_weight): a byte instead of the weight keeps the
                                        // workgroup's LDS at 25 / 42 KB (count / emit), i.e. 6 / 3 resident workgroups per CU
   __shared__ uint32_t s_nslot[8];
-  __shared__ const uint32_t* s_nrec[8];  // halo record of a neighbour owned by another rank (or nullptr)
+  __shared__ const uint32_t* s_nrec[8];  // halo data of a neighbour owned by another rank (or nullptr): dist | weight | colour | label | stamp
+  __shared__ int s_nN[8];                // ... of s_nN voxels each (a whole plane of a record, or the face / line / voxel of a compact answer)
   __shared__ uint32_t s_may_cross;       // some block of the 2 x 2 x 2 neighbourhood may hold a negative distance
   __shared__ uint32_t s_scan[256];
   __shared__ uint8_t s_ntri[256];
@@ -910,7 +957,12 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
         while (true) {
           const uint64_t kk = rh.ht_keys[h];
           if (kk == key) {
-            rec = rh.recs + static_cast<size_t>(rh.ht_vals[h]) * MH::kWords;
+            if (rh.ht_offs) {
+              const uint32_t off = rh.ht_offs[static_cast<size_t>(h) * 8 + k];
+              if (off != 0xffffffffu) rec = rh.recs + off;
+            } else {
+              rec = MH::plane(rh.recs + static_cast<size_t>(rh.ht_vals[h]) * MH::kWords, MH::planeOf(k));
+            }
             break;
           }
           if (kk == kEmptyKey) break;
@@ -919,6 +971,7 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
       }
       s_nslot[k] = ns;
       s_nrec[k] = rec;
+      s_nN[k] = rh.ht_offs ? meshHaloVoxels(k, VPS) : MH::PL;
       // a remote neighbour's record says nothing about signs: assume it may cross
       if (rec || (ns != kInvalidSlot && (m.blk_flags[ns] & BLK_HAS_NEG))) atomicOr(&s_may_cross, 1u);
     }
@@ -943,9 +996,9 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
         d = m.dist[o];
         w = m.weight[o];
       } else if (s_nrec[sel]) {
-        const int pl = MH::planeOf(sel), pi = MH::indexOf(sel, x, y, z);
-        d = MH::dist(s_nrec[sel], pl, pi);
-        w = MH::weight(s_nrec[sel], pl, pi);
+        const int pi = rh.ht_offs ? meshHaloCompactIndex(sel, x, y, z, VPS) : MH::indexOf(sel, x, y, z);
+        d = __uint_as_float(s_nrec[sel][pi]);
+        w = __uint_as_float(s_nrec[sel][s_nN[sel] + pi]);
       }
       s_d[c] = d;
       s_ok[c] = (w >= p.mesh_min_weight) ? 1 : 0;
@@ -1075,10 +1128,11 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
             out.stamps[vo] = p.with_tracking ? lastObserved(m, s_nslot[sel], static_cast<uint32_t>(lx + VPS * (ly + VPS * lz)), NV) : 0ull;
           } else {  // the source voxel lives in a block of another rank: attributes from its halo record
             const uint32_t* rec = s_nrec[sel];
-            const int pl = MH::planeOf(sel), pi = MH::indexOf(sel, lx, ly, lz);
-            out.colors[vo] = MH::color(rec, pl, pi);
-            out.labels[vo] = p.with_semantics ? MH::label(rec, pl, pi) : 0u;
-            out.stamps[vo] = p.with_tracking ? MH::stamp(rec, pl, pi) : 0ull;
+            const int pi = rh.ht_offs ? meshHaloCompactIndex(sel, lx, ly, lz, VPS) : MH::indexOf(sel, lx, ly, lz);
+            const int hn = s_nN[sel];
+            out.colors[vo] = rec[2 * hn + pi];
+            out.labels[vo] = p.with_semantics ? rec[3 * hn + pi] : 0u;
+            out.stamps[vo] = p.with_tracking ? (static_cast<uint64_t>(rec[4 * hn + 2 * pi]) | (static_cast<uint64_t>(rec[4 * hn + 2 * pi + 1]) << 32)) : 0ull;
           }
         }
       }
@@ -1189,6 +1243,105 @@ __global__ __launch_bounds__(256) void k_mesh_halo_import(const uint32_t* __rest
       return;
     }
     if (prev == key) return;  // the same block can be answered to several requesters' gathers only once per rank
+    h = (h + 1) & ht_mask;
+  }
+}
+
+// ---- compact mesh halo kernels (khr_mesh_halo_requests_sorted / _answer / _adopt) ----
+// requests bucketed by (owner, relation): pass 1 counts, k_mesh_halo_req_plan lays the buckets out (header of 8 * world u64
+// counts in front of the entries; word 0 = the total wanted), pass 2 writes the keys
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_mesh_halo_req_sorted(DevMap m, DevParams p, const uint32_t* __restrict__ work,
+                                                             const uint32_t* __restrict__ n_work, uint32_t* __restrict__ cnt,
+                                                             const uint32_t* __restrict__ base, uint32_t* __restrict__ cursor,
+                                                             uint64_t* __restrict__ req, uint32_t header_words, uint32_t cap) {
+  const uint32_t n = *n_work;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n * 7; i += gridDim.x * blockDim.x) {
+    const int4 bi = m.blk_index[work[i / 7]];
+    const int k = static_cast<int>(i % 7) + 1;
+    const int x = bi.x + (k & 1), y = bi.y + ((k >> 1) & 1), z = bi.z + ((k >> 2) & 1);
+    const int owner = ownerOf(x, y, z, p.world);
+    if (owner == p.rank) continue;
+    const uint64_t key = packKey(x, y, z);
+    if (htLookup(m, key) != kInvalidSlot) continue;  // (a remote block's copy in the local map: never for owner-computes maps)
+    const uint32_t b = static_cast<uint32_t>(owner) * 8u + static_cast<uint32_t>(k);
+    if (!SCATTER) {
+      atomicAdd(&cnt[b], 1u);
+    } else {
+      const uint32_t idx = base[b] + atomicAdd(&cursor[b], 1u);
+      if (idx < cap) req[header_words + idx] = key;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_mesh_halo_req_plan(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ base,
+                                                          uint32_t* __restrict__ cursor, uint64_t* __restrict__ req, int world,
+                                                          uint32_t* __restrict__ total_out) {
+  if (threadIdx.x != 0) return;
+  uint32_t run = 0;
+  for (int b = 0; b < 8 * world; ++b) {
+    base[b] = run;
+    cursor[b] = 0u;
+    req[b] = cnt[b];
+    run += cnt[b];
+  }
+  req[0] = run;  // (bucket 0 = relation 0 of owner 0 does not exist: the word carries the total)
+  *total_out = run;
+}
+
+// one wave per requested (block, relation): the owner writes [valid] + the face / line / voxel
+template <int VPS>
+__global__ __launch_bounds__(256) void k_mesh_halo_answer(DevMap m, DevParams p, const uint64_t* __restrict__ req, MeshHaloRuns runs,
+                                                         uint32_t* __restrict__ out) {
+  constexpr int NV = VPS * VPS * VPS;
+  const int lane = static_cast<int>(threadIdx.x & 63u);
+  for (uint32_t item = blockIdx.x * 4u + (threadIdx.x >> 6); item < runs.n_items; item += gridDim.x * 4u) {
+    uint32_t r = 0;
+    while (r + 1 < runs.n_runs && runs.first[r + 1] <= item) ++r;
+    const int sel = runs.sel[r];
+    const uint32_t i = item - runs.first[r];
+    const uint64_t key = req[runs.req_off[r] + i];
+    uint32_t* const rec = out + runs.rec_off[r] + static_cast<size_t>(i) * static_cast<size_t>(meshHaloAnswerWords(sel, VPS));
+    uint32_t slot = htLookup(m, key);
+    if (slot != kInvalidSlot && !(m.blk_flags[slot] & BLK_LIVE)) slot = kInvalidSlot;
+    if (lane == 0) rec[0] = slot != kInvalidSlot ? 1u : 0u;
+    if (slot == kInvalidSlot) continue;
+    const int nvx = meshHaloVoxels(sel, VPS);
+    uint32_t* const pw = rec + 1;
+    for (int e = lane; e < nvx; e += 64) {
+      const int lin = meshHaloSourceLin(sel, e, VPS);
+      const size_t o = static_cast<size_t>(slot) * NV + lin;
+      pw[e] = __float_as_uint(m.dist[o]);
+      pw[nvx + e] = __float_as_uint(m.weight[o]);
+      pw[2 * nvx + e] = m.color[o];
+      pw[3 * nvx + e] = p.with_semantics ? m.sem_label[o] : 0u;
+      const uint64_t st = p.with_tracking ? lastObserved(m, slot, static_cast<uint32_t>(lin), NV) : 0ull;
+      pw[4 * nvx + 2 * e] = static_cast<uint32_t>(st);
+      pw[4 * nvx + 2 * e + 1] = static_cast<uint32_t>(st >> 32);
+    }
+  }
+}
+
+// the requester indexes the answers it received: (key, relation) -> word offset of the answer's data
+__global__ __launch_bounds__(256) void k_mesh_halo_adopt(const uint64_t* __restrict__ req, MeshHaloRuns runs, const uint32_t* __restrict__ recs,
+                                                        int vps, uint64_t* __restrict__ ht_keys, uint32_t* __restrict__ ht_offs, uint32_t ht_mask) {
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= runs.n_items) return;
+  uint32_t r = 0;
+  while (r + 1 < runs.n_runs && runs.first[r + 1] <= item) ++r;
+  const int sel = runs.sel[r];
+  const uint32_t i = item - runs.first[r];
+  const uint32_t off = runs.rec_off[r] + i * static_cast<uint32_t>(meshHaloAnswerWords(sel, vps));
+  if (recs[off] != 1u) return;  // the owner does not hold the block
+  const uint64_t key = req[runs.req_off[r] + i];
+  uint32_t h = hashKey(key) & ht_mask;
+  while (true) {
+    const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&ht_keys[h]),
+                                              static_cast<unsigned long long>(kEmptyKey), static_cast<unsigned long long>(key));
+    if (prev == kEmptyKey || prev == key) {
+      ht_offs[static_cast<size_t>(h) * 8 + sel] = off + 1u;
+      return;
+    }
     h = (h + 1) & ht_mask;
   }
 }

@@ -202,6 +202,12 @@ struct khr_ctx {
   uint32_t* d_mh_vals = nullptr;
   uint32_t mh_cap_total = 0, mh_mask = 0, mh_n = 0;
   uint8_t* d_mh_flag = nullptr;
+  // compact mesh halo (khr_mesh_halo_requests_sorted / _answer / _adopt)
+  uint32_t* d_mh2_scratch = nullptr;  // cnt | base | cursor (8 * kMeshHaloMaxWorld each) | total
+  uint64_t* d_mh2_keys = nullptr;
+  uint32_t* d_mh2_offs = nullptr;
+  uint32_t mh2_ht = 0;
+  bool mh_compact = false;
   uint32_t* h_pinned = nullptr;  // [0] seed pixels of the last motion pass, [1] removed count, [2] count / [3] ticket written by
                                  // k_motion_pixels (zero-copy)
   uint32_t* d_pinned = nullptr;  // device view of h_pinned
@@ -1049,6 +1055,8 @@ void khr_destroy(khr_ctx* c) {
   if (c->d_halo_recs) hipFree(c->d_halo_recs);
   if (c->d_halo_keys) { hipFree(c->d_halo_keys); hipFree(c->d_halo_vals); }
   if (c->d_mh_recs) { hipFree(c->d_mh_recs); hipFree(c->d_mh_keys); hipFree(c->d_mh_vals); }
+  if (c->d_mh2_scratch) hipFree(c->d_mh2_scratch);
+  if (c->d_mh2_keys) { hipFree(c->d_mh2_keys); hipFree(c->d_mh2_offs); }
   if (c->d_pix_scratch) hipFree(c->d_pix_scratch);
   if (c->d_band_rec) { hipFree(c->d_band_rec); hipFree(c->d_band_n); }
   if (c->h2d_stream) { hipStreamSynchronize(c->h2d_stream); hipStreamDestroy(c->h2d_stream); }
@@ -3321,6 +3329,10 @@ int khr_generate_mesh(khr_ctx* c, int only_mesh_updated, int clear_flag) {
     rmh.ht_keys = c->d_mh_keys;
     rmh.ht_vals = c->d_mh_vals;
     rmh.ht_mask = c->mh_mask;
+    if (c->mh_compact) {
+      rmh.ht_keys = c->d_mh2_keys;
+      rmh.ht_offs = c->d_mh2_offs;
+    }
   }
   const uint32_t maxv = static_cast<uint32_t>(std::min<uint64_t>(c->cfg.max_mesh_vertices, 0xfffffff0ull));
   int rc = dispatchVps(c, [&](auto vps) {
@@ -3452,6 +3464,7 @@ int khr_mesh_halo_export(khr_ctx* c, const void* requests, int64_t n_requests, v
 int khr_mesh_halo_import(khr_ctx* c, const void* records, int64_t n_records, int on_device) {
   if (!c || n_records < 0 || (!records && n_records > 0)) return fail(KHR_EINVAL, "bad argument");
   HIP_TRY(hipSetDevice(c->device));
+  c->mh_compact = false;
   if (n_records == 0) {
     c->mh_n = 0;
     return KHR_OK;
@@ -3485,6 +3498,168 @@ int khr_mesh_halo_import(khr_ctx* c, const void* records, int64_t n_records, int
   HIP_TRY(hipGetLastError());
   if (!on_device) HIP_TRY(hipStreamSynchronize(c->stream));
   c->mh_n = static_cast<uint32_t>(n_records);
+  return KHR_OK;
+}
+
+// ---- compact mesh halo (round 5) -------------------------------------------------------------------------------------
+// The layout both sides derive from the all-gathered request headers: answers travel owner -> requester only, grouped by
+// requester, inside a group by relation (1 .. 7) in request order.  Counts and displacements are in u32 words.
+int khr_mesh_halo_plan(int world, int rank, int vps, const uint64_t* headers, uint64_t* sendcounts, uint64_t* sdispls,
+                       uint64_t* recvcounts, uint64_t* rdispls) {
+  if (world < 1 || world > kMeshHaloMaxWorld || rank < 0 || rank >= world || (vps != 8 && vps != 16) || !headers || !sendcounts || !sdispls ||
+      !recvcounts || !rdispls)
+    return fail(KHR_EINVAL, "khr_mesh_halo_plan: bad argument (world <= %d)", kMeshHaloMaxWorld);
+  uint64_t so = 0, ro = 0;
+  for (int q = 0; q < world; ++q) {
+    uint64_t sw = 0, rw = 0;
+    for (int sel = 1; sel < 8; ++sel) {
+      const uint64_t aw = static_cast<uint64_t>(meshHaloAnswerWords(sel, vps));
+      sw += headers[static_cast<size_t>(q) * 8 * world + static_cast<size_t>(rank) * 8 + sel] * aw;     // q asked me
+      rw += headers[static_cast<size_t>(rank) * 8 * world + static_cast<size_t>(q) * 8 + sel] * aw;     // I asked q
+    }
+    sendcounts[q] = sw;
+    sdispls[q] = so;
+    so += sw;
+    recvcounts[q] = rw;
+    rdispls[q] = ro;
+    ro += rw;
+  }
+  return KHR_OK;
+}
+
+int khr_mesh_halo_requests_sorted(khr_ctx* c, void* requests_device, int64_t cap, int only_mesh_updated) {
+  if (!c || !requests_device || cap < 1) return fail(KHR_EINVAL, "bad argument");
+  const int world = c->cfg.world_size;
+  if (world > kMeshHaloMaxWorld) return fail(KHR_EINVAL, "the compact mesh halo is laid out for at most %d ranks", kMeshHaloMaxWorld);
+  HIP_TRY(hipSetDevice(c->device));
+  DevMap& m = c->m;
+  constexpr int NB = 8 * kMeshHaloMaxWorld;
+  if (!c->d_mh2_scratch) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_mh2_scratch), sizeof(uint32_t) * (3 * NB + 1)));
+  uint32_t* const cnt = c->d_mh2_scratch;
+  uint32_t* const base = cnt + NB;
+  uint32_t* const cursor = base + NB;
+  uint32_t* const total = cursor + NB;
+  uint64_t* const req = static_cast<uint64_t*>(requests_device);
+  const uint32_t hw = 8u * static_cast<uint32_t>(world);
+  HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * NB, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_mesh_nwork + 1, 0, sizeof(uint32_t), c->stream));
+  hipLaunchKernelGGL(k_list_live, dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_work, c->d_mesh_nwork + 1,
+                     only_mesh_updated ? BLK_MESH_UPDATED : 0u);
+  hipLaunchKernelGGL((k_mesh_halo_req_sorted<false>), dim3(512), dim3(256), 0, c->stream, m, c->p, c->d_work, c->d_mesh_nwork + 1, cnt,
+                     base, cursor, req, hw, static_cast<uint32_t>(cap));
+  hipLaunchKernelGGL(k_mesh_halo_req_plan, dim3(1), dim3(64), 0, c->stream, cnt, base, cursor, req, world, total);
+  hipLaunchKernelGGL((k_mesh_halo_req_sorted<true>), dim3(512), dim3(256), 0, c->stream, m, c->p, c->d_work, c->d_mesh_nwork + 1, cnt,
+                     base, cursor, req, hw, static_cast<uint32_t>(cap));
+  uint32_t n_req = 0;
+  HIP_TRY(hipMemcpyAsync(&n_req, total, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (n_req > cap) return fail(KHR_ENOMEM, "%u mesh halo requests exceed the capacity %lld", n_req, static_cast<long long>(cap));
+  return static_cast<int>(n_req);
+}
+
+namespace {
+// exclusive prefix of one rank's header in bucket order (owner major, relation minor)
+uint64_t bucketBase(const uint64_t* header, int owner, int sel) {
+  uint64_t b = 0;
+  for (int i = 1; i < owner * 8 + sel; ++i) b += header[i];  // (word 0 carries the total, not a bucket)
+  return b;
+}
+}  // namespace
+
+int khr_mesh_halo_answer(khr_ctx* c, const void* all_requests_device, int64_t cap, const uint64_t* headers, void* records_device,
+                         int64_t cap_words) {
+  if (!c || !all_requests_device || cap < 1 || !headers || !records_device || cap_words < 1) return fail(KHR_EINVAL, "bad argument");
+  const int world = c->cfg.world_size, rank = c->cfg.rank;
+  if (world > kMeshHaloMaxWorld) return fail(KHR_EINVAL, "the compact mesh halo is laid out for at most %d ranks", kMeshHaloMaxWorld);
+  HIP_TRY(hipSetDevice(c->device));
+  const int vps = c->p.vps;
+  const uint64_t stride = 8ull * world + static_cast<uint64_t>(cap);
+  MeshHaloRuns runs{};
+  uint64_t words = 0, items = 0;
+  for (int q = 0; q < world; ++q) {
+    const uint64_t* hq = headers + static_cast<size_t>(q) * 8 * world;
+    if (hq[0] > static_cast<uint64_t>(cap)) return fail(KHR_ENOMEM, "rank %d listed %llu mesh halo requests, capacity %lld", q,
+                                                        static_cast<unsigned long long>(hq[0]), static_cast<long long>(cap));
+    for (int sel = 1; sel < 8; ++sel) {
+      const uint64_t n = hq[rank * 8 + sel];
+      if (!n) continue;
+      const uint32_t r = runs.n_runs++;
+      runs.first[r] = static_cast<uint32_t>(items);
+      runs.req_off[r] = static_cast<uint32_t>(static_cast<uint64_t>(q) * stride + 8ull * world + bucketBase(hq, rank, sel));
+      runs.rec_off[r] = static_cast<uint32_t>(words);
+      runs.sel[r] = static_cast<uint8_t>(sel);
+      items += n;
+      words += n * static_cast<uint64_t>(meshHaloAnswerWords(sel, vps));
+    }
+  }
+  runs.first[runs.n_runs] = static_cast<uint32_t>(items);
+  runs.n_items = static_cast<uint32_t>(items);
+  if (words > static_cast<uint64_t>(cap_words))
+    return fail(KHR_ENOMEM, "the mesh halo answers of this output need %llu words, the buffer holds %lld", static_cast<unsigned long long>(words),
+                static_cast<long long>(cap_words));
+  if (!items) return 0;
+  const unsigned grid = static_cast<unsigned>(std::min<uint64_t>((items + 3) / 4, 4096));
+  int rc = dispatchVps(c, [&](auto vps_c) {
+    hipLaunchKernelGGL((k_mesh_halo_answer<decltype(vps_c)::value>), dim3(grid), dim3(256), 0, c->stream, c->m, c->p,
+                       static_cast<const uint64_t*>(all_requests_device), runs, static_cast<uint32_t*>(records_device));
+    return KHR_OK;
+  });
+  if (rc) return rc;
+  HIP_TRY(hipGetLastError());
+  return static_cast<int>(std::min<uint64_t>(items, 0x7fffffffull));
+}
+
+int khr_mesh_halo_adopt(khr_ctx* c, const void* own_requests_device, const uint64_t* own_header, const void* records_device,
+                        const uint64_t* rdispls) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  c->mh_compact = false;
+  c->mh_n = 0;
+  if (!own_requests_device) return KHR_OK;  // (forget the last output's answers)
+  if (!own_header || !records_device || !rdispls) return fail(KHR_EINVAL, "bad argument");
+  const int world = c->cfg.world_size;
+  if (world > kMeshHaloMaxWorld) return fail(KHR_EINVAL, "the compact mesh halo is laid out for at most %d ranks", kMeshHaloMaxWorld);
+  HIP_TRY(hipSetDevice(c->device));
+  const int vps = c->p.vps;
+  MeshHaloRuns runs{};
+  uint64_t items = 0;
+  for (int r = 0; r < world; ++r) {
+    uint64_t words = rdispls[r];
+    for (int sel = 1; sel < 8; ++sel) {
+      const uint64_t n = own_header[r * 8 + sel];
+      if (!n) continue;
+      const uint32_t k = runs.n_runs++;
+      runs.first[k] = static_cast<uint32_t>(items);
+      runs.req_off[k] = static_cast<uint32_t>(8ull * world + bucketBase(own_header, r, sel));
+      runs.rec_off[k] = static_cast<uint32_t>(words);
+      runs.sel[k] = static_cast<uint8_t>(sel);
+      items += n;
+      words += n * static_cast<uint64_t>(meshHaloAnswerWords(sel, vps));
+    }
+  }
+  runs.first[runs.n_runs] = static_cast<uint32_t>(items);
+  runs.n_items = static_cast<uint32_t>(items);
+  if (!items) return KHR_OK;
+  uint32_t ht = 1024;
+  while (ht < items * 2) ht <<= 1;
+  if (ht > c->mh2_ht) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_mh2_keys) { hipFree(c->d_mh2_keys); hipFree(c->d_mh2_offs); }
+    c->d_mh2_keys = nullptr;
+    c->d_mh2_offs = nullptr;
+    c->mh2_ht = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_mh2_keys), sizeof(uint64_t) * ht));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_mh2_offs), sizeof(uint32_t) * 8 * static_cast<size_t>(ht)));
+    c->mh2_ht = ht;
+  }
+  HIP_TRY(hipMemsetAsync(c->d_mh2_keys, 0xff, sizeof(uint64_t) * ht, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_mh2_offs, 0xff, sizeof(uint32_t) * 8 * static_cast<size_t>(ht), c->stream));
+  hipLaunchKernelGGL(k_mesh_halo_adopt, dim3(gridFor(items)), dim3(256), 0, c->stream, static_cast<const uint64_t*>(own_requests_device), runs,
+                     static_cast<const uint32_t*>(records_device), vps, c->d_mh2_keys, c->d_mh2_offs, ht - 1);
+  HIP_TRY(hipGetLastError());
+  c->mh_view = static_cast<const uint32_t*>(records_device);
+  c->mh_mask = ht - 1;
+  c->mh_n = static_cast<uint32_t>(items);
+  c->mh_compact = true;
   return KHR_OK;
 }
 

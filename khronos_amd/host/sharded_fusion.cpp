@@ -59,13 +59,14 @@ struct Rccl {
   decltype(&::ncclAllReduce) AllReduce = nullptr;
   decltype(&::ncclReduce) Reduce = nullptr;
   decltype(&::ncclBroadcast) Broadcast = nullptr;
+  decltype(&::ncclAllToAllv) AllToAllv = nullptr;
   decltype(&::ncclGetErrorString) GetErrorString = nullptr;
 };
 
 const Rccl& rccl() {
   static const Rccl table = [] {
     void* lib = nullptr;
-    // KDIST_RCCL_LIB=<path>: another library exporting the eight nccl* entry points below (a site's own RCCL build; the
+    // KDIST_RCCL_LIB=<path>: another library exporting the nine nccl* entry points below (a site's own RCCL build; the
     // shared-memory transport of tests/transport/, which runs N ranks on one GPU).  Set => it must load: no silent fallback.
     if (const char* override_lib = std::getenv("KDIST_RCCL_LIB")) {
       if (!(lib = dlopen(override_lib, RTLD_NOW | RTLD_LOCAL)))
@@ -87,6 +88,7 @@ const Rccl& rccl() {
     bind(t.AllReduce, "ncclAllReduce");
     bind(t.Reduce, "ncclReduce");
     bind(t.Broadcast, "ncclBroadcast");
+    bind(t.AllToAllv, "ncclAllToAllv");
     bind(t.GetErrorString, "ncclGetErrorString");
     return t;
   }();
@@ -112,10 +114,10 @@ const Rccl& rccl() {
 constexpr int kHaloWords = KHR_HALO_RECORD_BYTES / 8;
 
 // the collectives of a tick / an output, for kdist_profile (calls and bytes are always counted; HIP events only when enabled)
-enum Coll : int { COLL_FRAMES = 0, COLL_CONVERTED, COLL_COUNTS, COLL_KEYS, COLL_DYN_IMAGE, COLL_HALO, COLL_MESH_REQ, COLL_MESH_AGREE, COLL_MESH_REC, COLL_N };
+enum Coll : int { COLL_FRAMES = 0, COLL_CONVERTED, COLL_COUNTS, COLL_KEYS, COLL_DYN_IMAGE, COLL_HALO, COLL_MESH_REQ, COLL_MESH_AGREE, COLL_MESH_REC, COLL_MESH_A2A, COLL_N };
 const char* const kCollNames[COLL_N] = {"frames_allgather", "converted_allgather", "counts_allreduce", "motion_keys_reduce",
                                         "dynamic_image_broadcast", "halo_allgather", "mesh_request_allgather", "mesh_agree_allreduce",
-                                        "mesh_record_allgather"};
+                                        "mesh_record_allgather", "mesh_answer_alltoallv"};
 struct CollRec {
   int kind;
   hipEvent_t a, b;
@@ -134,6 +136,7 @@ struct kdist_handle {
   hipStream_t stream = nullptr;
   int64_t halo_cap = 0, req_cap = 0, rec_cap = 0;
   size_t npx = 0, mesh_words = 0;
+  int vps = 16;
   // exchange buffers (HBM)
   uint64_t* halo_send = nullptr;
   uint64_t* halo_recv = nullptr;
@@ -154,6 +157,10 @@ struct kdist_handle {
   std::vector<int> clusters_last_tick;
   int64_t dropped_seen = 0;  // khr_pool_exhausted at the last output that reported it (the device counter is sticky)
   int64_t halo_per_rank_last_tick = 0, mesh_records_per_rank_last_output = 0;  // what the last exchanges shipped per rank
+  // compact mesh halo (default up to 16 ranks; KDIST_MESH_HALO=records selects the all-gather of whole-block records)
+  bool mesh_compact = true;
+  uint64_t* h_headers = nullptr;              // pinned: the world request headers of an output (8 * world u64 each)
+  int64_t mesh_bytes_last_output[4] = {0, 0, 0, 0};  // request bytes sent, answer bytes sent, answer bytes received, answers received
   std::vector<void*> allocs;
   // kdist_profile
   bool profile = false;
@@ -267,6 +274,7 @@ kdist_handle* kdist_create(khr_ctx* ctx, const khr_sensor* sensor, int rank, int
     h->rec_cap = mesh_rec_cap;
     h->npx = static_cast<size_t>(sensor->width) * sensor->height;
     h->mesh_words = KHR_MESH_HALO_RECORD_BYTES(cfg.voxels_per_side) / 4;
+    h->vps = cfg.voxels_per_side;
     KD_HIP(hipSetDevice(cfg.device));
     KD_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     KD_KHR(khr_set_stream(ctx, h->stream));  // fusion kernels and collectives share one stream: stream order is the protocol
@@ -287,8 +295,13 @@ kdist_handle* kdist_create(khr_ctx* ctx, const khr_sensor* sensor, int rank, int
     KD_HIP(hipEventCreateWithFlags(&h->ev_counts, hipEventDisableTiming));
     h->keys.assign(static_cast<size_t>(n_cameras), nullptr);
     h->dyn_img.assign(static_cast<size_t>(n_cameras), nullptr);
-    h->req_send = h->alloc<uint64_t>(static_cast<size_t>(mesh_req_cap));
-    h->req_recv = h->alloc<uint64_t>(W * static_cast<size_t>(mesh_req_cap));
+    // (the compact form puts a header of 8 * world counts in front of the keys)
+    const char* mh_mode = std::getenv("KDIST_MESH_HALO");
+    h->mesh_compact = world_size <= 16 && !(mh_mode && std::string(mh_mode) == "records");
+    const size_t req_words = static_cast<size_t>(mesh_req_cap) + KHR_MESH_HALO_REQ_HEADER_WORDS(W);
+    h->req_send = h->alloc<uint64_t>(req_words);
+    h->req_recv = h->alloc<uint64_t>(W * req_words);
+    KD_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_headers), sizeof(uint64_t) * W * KHR_MESH_HALO_REQ_HEADER_WORDS(W), hipHostMallocDefault));
     h->rec_send = h->alloc<uint32_t>(static_cast<size_t>(mesh_rec_cap) * h->mesh_words);
     h->rec_recv = h->alloc<uint32_t>(W * static_cast<size_t>(mesh_rec_cap) * h->mesh_words);
     h->clusters_last_tick.assign(static_cast<size_t>(n_cameras), 0);
@@ -325,6 +338,7 @@ void kdist_destroy(kdist_handle* h) {
   if (h->frame_recv) (void)hipFree(h->frame_recv);
   if (h->h_seed_counts) (void)hipHostFree(h->h_seed_counts);
   if (h->h_xchg) (void)hipHostFree(h->h_xchg);
+  if (h->h_headers) (void)hipHostFree(h->h_headers);
   if (h->ev_counts) (void)hipEventDestroy(h->ev_counts);
   resolveColl(h);
   for (hipEvent_t e : h->coll_events) (void)hipEventDestroy(e);
@@ -361,6 +375,14 @@ int kdist_profile_get(kdist_handle* h, kdist_coll_stat* out, int cap) {
 void* kdist_stream(kdist_handle* h) { return h ? static_cast<void*>(h->stream) : nullptr; }
 
 // records per rank that the last tick's halo all-gather / the last output's mesh-record all-gather shipped (0 = none yet)
+// the mesh halo of the last output in bytes: requests sent (all-gathered: received = world x that), answers sent, answers
+// received, and the number of answers received (emulation: what this rank WOULD receive; sent is reported as the same)
+int kdist_last_mesh_exchange(kdist_handle* h, int64_t out[4]) {
+  if (!h || !out) return KHR_EINVAL;
+  for (int i = 0; i < 4; ++i) out[i] = h->mesh_bytes_last_output[i];
+  return KHR_OK;
+}
+
 int kdist_last_exchange(kdist_handle* h, int64_t* halo_records_per_rank, int64_t* mesh_records_per_rank) {
   if (!h) return KHR_EINVAL;
   if (halo_records_per_rank) *halo_records_per_rank = h->halo_per_rank_last_tick;
@@ -609,6 +631,82 @@ int kdist_output(kdist_handle* h) {
         if (!local_fault) local_text = text;
         local_fault = true;
       };
+      if (h->mesh_compact) {
+        // ---- compact form: per-relation answers (face / line / voxel), owner -> requester only (khronos_amd.h) ----
+        const size_t W = static_cast<size_t>(h->world);
+        const size_t hw = KHR_MESH_HALO_REQ_HEADER_WORDS(W), req_words = hw + static_cast<size_t>(h->req_cap);
+        const int64_t send_cap_words = h->rec_cap * static_cast<int64_t>(h->mesh_words), recv_cap_words = static_cast<int64_t>(W) * send_cap_words;
+        const int n_req = khr_mesh_halo_requests_sorted(c, h->req_send, h->req_cap, 1);
+        if (n_req < 0) {  // (beyond req_cap the header still describes the first req_cap keys' buckets wrongly: ship an empty list)
+          note(std::string("khr_mesh_halo_requests_sorted: ") + khr_last_error());
+          if (hipMemsetAsync(h->req_send, 0, sizeof(uint64_t) * hw, h->stream) != hipSuccess) (void)hipGetLastError();
+        }
+        const uint64_t* all_req = h->req_send;
+        if (h->net()) {
+          coll(h, COLL_MESH_REQ, req_words * 8, [&] { return rccl().AllGather(h->req_send, h->req_recv, req_words, ncclUint64, h->comm, h->stream); });
+          all_req = h->req_recv;
+          for (size_t q = 0; q < W; ++q)
+            KD_HIP(hipMemcpyAsync(h->h_headers + q * hw, h->req_recv + q * req_words, hw * 8, hipMemcpyDeviceToHost, h->stream));
+        } else {  // emulation / one rank: this rank's requests only (the other ranks' rows are empty)
+          std::memset(h->h_headers, 0, sizeof(uint64_t) * W * hw);
+          KD_HIP(hipMemcpyAsync(h->h_headers + static_cast<size_t>(h->rank) * hw, h->req_send, hw * 8, hipMemcpyDeviceToHost, h->stream));
+        }
+        KD_HIP(hipStreamSynchronize(h->stream));
+        std::vector<uint64_t> sc(W), sd(W), rc(W), rd(W);
+        KD_KHR(khr_mesh_halo_plan(h->world, h->rank, h->vps, h->h_headers, sc.data(), sd.data(), rc.data(), rd.data()));
+        uint64_t send_words = 0, recv_words = 0, n_answers = 0;
+        for (size_t q = 0; q < W; ++q) {
+          send_words += sc[q];
+          recv_words += rc[q];
+          for (int sel = 1; sel < 8; ++sel) n_answers += h->h_headers[static_cast<size_t>(h->rank) * hw + q * 8 + sel];
+        }
+        if (recv_words > static_cast<uint64_t>(recv_cap_words)) note("the mesh halo answers for this rank exceed the receive buffer (mesh_rec_cap)");
+        if (h->net()) {
+          // one row per rank in the all-gathered buffer: the answer kernel reads rank q's bucket for this rank at q * (header + cap)
+          const int n_ans = khr_mesh_halo_answer(c, all_req, h->req_cap, h->h_headers, h->rec_send, send_cap_words);
+          if (n_ans < 0) note(std::string("khr_mesh_halo_answer: ") + khr_last_error());
+          const int64_t dropped = khr_pool_exhausted(c);
+          if (dropped < 0) {
+            note(std::string("khr_pool_exhausted: ") + khr_last_error());
+          } else if (dropped > h->dropped_seen) {
+            h->dropped_seen = dropped;
+            note("an exchange buffer was too small (halo_cap) or the block pool ran out: records were dropped");
+          }
+          h->h_xchg[0] = static_cast<int64_t>(n_answers);
+          h->h_xchg[1] = local_fault ? 1 : 0;
+          KD_HIP(hipMemcpyAsync(h->xchg, h->h_xchg, 2 * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+          coll(h, COLL_MESH_AGREE, 16, [&] { return rccl().AllReduce(h->xchg, h->xchg, 2, ncclInt64, ncclMax, h->comm, h->stream); });
+          KD_HIP(hipMemcpyAsync(h->h_xchg + 2, h->xchg, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+          KD_HIP(hipStreamSynchronize(h->stream));
+          if (h->h_xchg[3] > 0)
+            throw Fail{KHR_ENOMEM, local_fault ? "on this rank: " + local_text
+                                               : std::string("on another rank: an exchange buffer was too small or its block pool ran out (see that rank's error)")};
+          std::vector<size_t> scs(sc.begin(), sc.end()), sds(sd.begin(), sd.end()), rcs(rc.begin(), rc.end()), rds(rd.begin(), rd.end());
+          coll(h, COLL_MESH_A2A, send_words * 4, [&] {
+            return rccl().AllToAllv(h->rec_send, scs.data(), sds.data(), h->rec_recv, rcs.data(), rds.data(), ncclUint32, h->comm, h->stream);
+          });
+          KD_KHR(khr_mesh_halo_adopt(c, h->req_send, h->h_headers + static_cast<size_t>(h->rank) * hw, h->rec_recv, rd.data()));
+        } else {
+          if (local_fault) throw Fail{KHR_ENOMEM, local_text};
+          KD_KHR(khr_mesh_halo_adopt(c, nullptr, nullptr, nullptr, nullptr));  // nobody answers: the neighbours stay unobserved
+          const int64_t dropped = khr_pool_exhausted(c);
+          KD_KHR(static_cast<int>(dropped < 0 ? dropped : 0));
+          if (dropped > h->dropped_seen) {
+            h->dropped_seen = dropped;
+            throw Fail{KHR_ENOMEM, "an exchange buffer was too small (halo_cap) or the block pool ran out: records were dropped"};
+          }
+          send_words = recv_words;  // (by symmetry: what the other ranks would ask of this one)
+        }
+        h->mesh_records_per_rank_last_output = static_cast<int64_t>(n_answers);
+        h->mesh_bytes_last_output[0] = static_cast<int64_t>(req_words * 8);
+        h->mesh_bytes_last_output[1] = static_cast<int64_t>(send_words * 4);
+        h->mesh_bytes_last_output[2] = static_cast<int64_t>(recv_words * 4);
+        h->mesh_bytes_last_output[3] = static_cast<int64_t>(n_answers);
+        KD_KHR(khr_generate_mesh(c, 1, 1));
+        KD_KHR(khr_reset_inactive(c, nullptr, 0, nullptr));
+        KD_KHR(khr_clear_updated(c));
+        return KHR_OK;
+      }
       const int n_req = khr_mesh_halo_requests(c, h->req_send, h->req_cap, 1, 1);
       if (n_req == KHR_ENOMEM) {  // (the buffer holds the first req_cap requests: harmless to ship)
         note(khr_last_error());
@@ -645,6 +743,10 @@ int kdist_output(kdist_handle* h) {
                                              : std::string("on another rank: an exchange buffer was too small or its block pool ran out (see that rank's error)")};
         const int64_t per_rank = std::min<int64_t>(h->rec_cap, std::max<int64_t>(16, (h->h_xchg[2] + 15) / 16 * 16));
         h->mesh_records_per_rank_last_output = per_rank;
+        h->mesh_bytes_last_output[0] = h->req_cap * 8;
+        h->mesh_bytes_last_output[1] = per_rank * static_cast<int64_t>(h->mesh_words) * 4;
+        h->mesh_bytes_last_output[2] = static_cast<int64_t>(h->world) * per_rank * static_cast<int64_t>(h->mesh_words) * 4;
+        h->mesh_bytes_last_output[3] = static_cast<int64_t>(h->world) * per_rank;
         coll(h, COLL_MESH_REC, static_cast<size_t>(per_rank) * h->mesh_words * 4, [&] { return rccl().AllGather(h->rec_send, h->rec_recv, static_cast<size_t>(per_rank) * h->mesh_words, ncclUint32, h->comm, h->stream); });
         KD_KHR(khr_mesh_halo_import(c, h->rec_recv, static_cast<int64_t>(h->world) * per_rank, 2));  // indexed where the all-gather put them
       } else {  // emulation / one rank: requests and answers of this rank only

@@ -50,6 +50,7 @@ def load_host_library():
     lib.kdist_tick_own.argtypes = [vp, C.c_uint64, vp, i32, vp, vp, vp, vp]
     lib.kdist_output.argtypes = [vp]
     lib.kdist_last_exchange.argtypes = [vp, vp, vp]
+    lib.kdist_last_mesh_exchange.argtypes = [vp, vp]
     lib.kdist_profile.argtypes = [vp, i32]
     lib.kdist_profile_get.argtypes = [vp, vp, i32]
     lib.khr_host_detect_changes.argtypes = [vp, C.c_int64, vp, C.c_int64, C.c_float, C.c_int64, i32, C.c_float, C.c_float, i32, vp]
@@ -256,6 +257,12 @@ class ShardedFusionHost:
         a, b = C.c_int64(0), C.c_int64(0)
         self._chk(self.lib.kdist_last_exchange(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def last_mesh_exchange(self):
+        """the last output's mesh halo in bytes: {request_bytes_sent, answer_bytes_sent, answer_bytes_received, answers_received}"""
+        out = (C.c_int64 * 4)()
+        self._chk(self.lib.kdist_last_mesh_exchange(self.h, out))
+        return {"request_bytes_sent": out[0], "answer_bytes_sent": out[1], "answer_bytes_received": out[2], "answers_received": out[3]}
 
     def profile(self, on=True):
         """reset the per-collective counters; on: bracket every collective with HIP events from now on (kdist_profile)"""

@@ -180,6 +180,22 @@ class DeviceArray:
     def data_ptr(self):
         return self.ptr.value
 
+    def read(self, offset_bytes, nbytes):
+        """bytes [offset, offset + n) back on the host (blocking)"""
+        import ctypes as C
+        out = np.empty(nbytes, np.uint8)
+        if nbytes:
+            rc = self._hip.hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(self.ptr.value + offset_bytes), C.c_size_t(nbytes), 2)
+            assert rc == 0, rc
+        return out
+
+    def copy_from(self, dst_offset_bytes, src, src_offset_bytes, nbytes):
+        """device-to-device copy from another DeviceArray (blocking)"""
+        import ctypes as C
+        if nbytes:
+            rc = self._hip.hipMemcpy(C.c_void_p(self.ptr.value + dst_offset_bytes), C.c_void_p(src.ptr.value + src_offset_bytes), C.c_size_t(nbytes), 3)
+            assert rc == 0, rc
+
     def free(self):
         if self.ptr:
             self._hip.hipFree(self.ptr)

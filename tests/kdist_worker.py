@@ -192,6 +192,7 @@ def main():
             res["removed"].append(ctx.last_removed())
             res["mesh"].append(mesh_digest(ctx.download_mesh()))
             res["exchange"].append(sf.last_exchange())
+            res.setdefault("mesh_exchange", []).append(sf.last_mesh_exchange())
             for k, pipe in pipes.items():
                 n_obj, n_rm, _ = pipe.extract_inactive()
                 res["objects_extracted"] += n_obj

@@ -230,7 +230,7 @@ def test_host_library_exports_the_sharded_tick_abi():
     hdr = open(os.path.join(ROOT, "include", "khronos_amd_dist.h")).read()
     declared = set(re.findall(r"\b(kdist_[a-z_]+)\s*\(", hdr))
     assert declared == {"kdist_unique_id", "kdist_create", "kdist_destroy", "kdist_stream", "kdist_gather_frames", "kdist_tick",
-                        "kdist_output", "kdist_last_exchange", "kdist_tick_own", "kdist_profile", "kdist_profile_get"}
+                        "kdist_output", "kdist_last_exchange", "kdist_last_mesh_exchange", "kdist_tick_own", "kdist_profile", "kdist_profile_get"}
     lib = ctypes.CDLL(host_capi.HOST_LIB_PATH, mode=ctypes.RTLD_GLOBAL)
     for name in declared:
         assert hasattr(lib, name), name

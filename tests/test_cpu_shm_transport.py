@@ -1,5 +1,5 @@
 """-m "not gpu": the shared-memory stand-in for librccl (tests/transport/kdist_shm.cpp, test infrastructure) on host buffers
-(KDIST_SHM_HOST=1): the collectives sharded_fusion.cpp issues -- all-gather, all-reduce (sum / max), reduce to a root, broadcast --
+(KDIST_SHM_HOST=1): the collectives sharded_fusion.cpp issues -- all-gather, all-reduce (sum / max), reduce to a root, broadcast, all-to-all-v --
 across 3 processes, with buffers larger than one exchange chunk.  It is the transport the GPU tests run the product's C++ tick
 over with N ranks on one device (tests/test_gpu_dist_multiproc.py), so it is checked on its own first."""
 import ctypes as C
@@ -33,8 +33,9 @@ def _worker(rank, world, id_path):
     lib.ncclAllReduce.argtypes = [vp, vp, sz, C.c_int, C.c_int, vp, vp]
     lib.ncclReduce.argtypes = [vp, vp, sz, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.ncclBroadcast.argtypes = [vp, vp, sz, C.c_int, C.c_int, vp, vp]
+    lib.ncclAllToAllv.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp, vp]
     lib.ncclCommDestroy.argtypes = [vp]
-    U8, I32, I64, U64 = 1, 2, 4, 5  # ncclDataType_t
+    U8, I32, U32, I64, U64 = 1, 2, 3, 4, 5  # ncclDataType_t
     SUM, MAX = 0, 2                 # ncclRedOp_t
     uid = UniqueId()
     if rank == 0:
@@ -89,6 +90,22 @@ def _worker(rank, world, id_path):
     one = np.array([rank + 7], np.int64)
     assert lib.ncclAllReduce(p(one), p(one), 1, I64, MAX, comm, None) == 0
     assert one[0] == world + 6
+    # all-to-all-v (the compact mesh halo's answers): uneven counts incl. zero, gaps between the segments, more than one chunk
+    def count(src, dst):
+        return 0 if (src + dst) % 3 == 1 else 150_000 + 70_001 * src + 13 * dst
+    def seg(src, dst):
+        return np.random.default_rng(1000 + 10 * src + dst).integers(0, 2**32, count(src, dst), dtype=np.uint32)
+    sc = np.array([count(rank, d) for d in range(world)], np.uint64)
+    sd = np.concatenate([[5], 5 + np.cumsum(sc[:-1] + 9)]).astype(np.uint64)   # (9 unused words between segments)
+    sbuf = np.zeros(int(sd[-1] + sc[-1]) + 3, np.uint32)
+    for d in range(world):
+        sbuf[int(sd[d]):int(sd[d] + sc[d])] = seg(rank, d)
+    rcnt = np.array([count(q, rank) for q in range(world)], np.uint64)
+    rd = np.concatenate([[0], np.cumsum(rcnt[:-1])]).astype(np.uint64)
+    rbuf = np.zeros(int(rcnt.sum()) + 1, np.uint32)
+    assert lib.ncclAllToAllv(p(sbuf), p(sc), p(sd), p(rbuf), p(rcnt), p(rd), U32, comm, None) == 0
+    for q in range(world):
+        assert np.array_equal(rbuf[int(rd[q]):int(rd[q] + rcnt[q])], seg(q, rank)), q
     lib.ncclCommDestroy(comm)
     print("SHM_OK %d" % rank)
 

@@ -181,11 +181,14 @@ def _check(world, cameras, shards, ref, ora, expect_objects):
     # (6) the exchanges ship what the fullest rank holds, not the capacities; every collective of the protocol was issued
     for sh in shards:
         halo, mesh = sh["exchange"][-1]
-        assert halo % 256 == 0 and halo >= max(len(p) for p in parts) - 512 and mesh % 16 == 0 and mesh >= 16
+        records = os.environ.get("KDIST_MESH_HALO") == "records"  # (whole-block records, all-gathered; default: compact answers, all-to-all-v)
+        assert halo % 256 == 0 and halo >= max(len(p) for p in parts) - 512
+        assert (mesh % 16 == 0 and mesh >= 16) if records else mesh >= 1
         col = sh["collectives"]
         for nm in ("frames_allgather", "counts_allreduce", "motion_keys_reduce", "dynamic_image_broadcast", "halo_allgather",
-                   "mesh_request_allgather", "mesh_agree_allreduce", "mesh_record_allgather"):
+                   "mesh_request_allgather", "mesh_agree_allreduce", "mesh_record_allgather" if records else "mesh_answer_alltoallv"):
             assert col[nm]["calls"] > 0, nm
+        assert col["mesh_answer_alltoallv" if records else "mesh_record_allgather"]["calls"] == 0
         assert col["frames_allgather"]["calls"] == ticks and col["halo_allgather"]["calls"] == ticks
     return dict(blocks=len(allb), clusters=sum(sum(c) for c in ora["clusters"]), tracks=n_tracks, objects=n_objects)
 
@@ -212,6 +215,13 @@ def test_cxx_tick_n_ranks_small(tmp_path, world, cameras, sender):
     """30 ticks at 320x240 / 10 cm: ever-free after 0.25 s, archival after 0.75 s, tracks leave after 0.45 s and are extracted"""
     info = _case(tmp_path, "small", world, cameras, ticks=30, out_every=5, extra=SMALL_OBJ + ["--sender-ingest", str(sender)], timeout_s=420,
                  expect_objects=True)
+    assert info["blocks"] > 60, info
+
+
+def test_cxx_tick_whole_block_mesh_records(tmp_path, monkeypatch):
+    """KDIST_MESH_HALO=records: the all-gather of whole-block mesh halo records (the form of rounds 2-4, kept as a switch)"""
+    monkeypatch.setenv("KDIST_MESH_HALO", "records")
+    info = _case(tmp_path, "small", 2, 2, ticks=30, out_every=5, extra=SMALL_OBJ + ["--sender-ingest", "0"], timeout_s=420, expect_objects=True)
     assert info["blocks"] > 60, info
 
 

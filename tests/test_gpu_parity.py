@@ -552,6 +552,72 @@ def test_two_shards_mesh_halo_equals_unsharded():
     assert len(c0.download_mesh()["points"]) < len(parts[0]["points"])
 
 
+@pytest.mark.parametrize("world,vps", [(2, 16), (3, 16), (3, 8)])
+def test_compact_mesh_halo_equals_unsharded(world, vps):
+    """the compact mesh halo (khr_mesh_halo_requests_sorted / _plan / _answer / _adopt: per-relation face / line / voxel answers sent
+    to the requester alone) gives the unsharded mesh, array for array; the all-gather of the requests and the all-to-all-v of the
+    answers are played with device copies between the shards' buffers, with the counts khr_mesh_halo_plan derives.  It ships a
+    fraction of what the whole-block records ship."""
+    from common import DeviceArray
+    kw = dict(voxels_per_side=vps, max_blocks=16384) if vps == 8 else {}
+    cfg, ctx, ora, s, sen, osen = make_pair(**kw)
+    shards = [make_pair(rank=r, world_size=world, **kw)[1] for r in range(world)]
+    cap, cap_words = 8192, 4 << 20
+    hw = 8 * world
+    row = (hw + cap) * 8                                                # bytes of one rank's request buffer
+    req = DeviceArray(np.zeros((world, hw + cap), np.uint64))           # "all-gathered": rank r writes row r in place
+    send = [DeviceArray(np.zeros(cap_words, np.uint32)) for _ in range(world)]
+    recv = [DeviceArray(np.zeros(cap_words, np.uint32)) for _ in range(world)]
+    shipped_compact = shipped_records = 0
+    for i in range(6):
+        fr = s.render(i)
+        for c in [ctx] + shards:
+            slot = c.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+            c.integrate(slot)
+            c.update_tracking(fr["stamp"])
+        if i % 3 != 2:
+            continue
+        ctx.generate_mesh(True, True)
+        for r, c in enumerate(shards):
+            n = c.mesh_halo_requests_sorted(req.data_ptr() + r * row, cap)
+            assert 0 < n <= cap
+        headers = np.stack([req.read(r * row, hw * 8).view(np.uint64) for r in range(world)])  # the headers, on the host
+        assert all(int(headers[r, 0]) == int(headers[r, 1:].sum()) for r in range(world))
+        plans = [c.mesh_halo_plan(headers) for c in shards]
+        for r, c in enumerate(shards):
+            assert all(int(headers[r, 8 * r + k]) == 0 for k in range(8) if (r, k) != (0, 0)), "nobody requests its own blocks"
+            n_ans = c.mesh_halo_answer(req.data_ptr(), cap, headers, send[r].data_ptr(), cap_words)
+            assert n_ans == sum(int(headers[q, 8 * r + k]) for q in range(world) for k in range(1, 8))
+            c.sync()
+        for r in range(world):                                         # all-to-all-v
+            sc, sd, rc_, rd = plans[r]
+            for q in range(world):
+                assert int(plans[q][0][r]) == int(rc_[q]), "what q sends to r is what r expects from q"
+                recv[r].copy_from(4 * int(rd[q]), send[q], 4 * int(plans[q][1][r]), 4 * int(rc_[q]))
+            shipped_compact += int(rc_.sum()) * 4
+        for r, c in enumerate(shards):
+            c.mesh_halo_adopt(req.data_ptr() + r * row, headers[r], recv[r].data_ptr(), plans[r][3])
+            c.generate_mesh(True, True)
+        full = _tri_soup(ctx.download_mesh())
+        parts = [c.download_mesh() for c in shards]
+        uni = _tri_soup({k: np.concatenate([p_[k] for p_ in parts]) for k in parts[0]})
+        assert full[0].shape == uni[0].shape and full[0].shape[0] > 100
+        for a, b in zip(full, uni):
+            assert np.array_equal(a, b)
+        # what the whole-block records would have shipped for the same requests: every rank receives every answered record
+        uniq = len({int(k) for r in range(world) for k in req.read(r * row + hw * 8, int(headers[r, 0]) * 8).view(np.uint64)})
+        shipped_records += world * uniq * 4 * (4 + 3 * 6 * vps * vps)
+    assert shipped_compact < (0.5 if world == 2 else 0.3) * shipped_records, (shipped_compact, shipped_records)
+    shards[0].mesh_halo_adopt(None)
+    shards[0].generate_mesh(False, False)
+    assert len(shards[0].download_mesh()["points"]) < len(parts[0]["points"])
+    for c in [ctx] + shards:
+        c.close()
+    ora.close()
+    for d in [req] + send + recv:
+        d.free()
+
+
 @pytest.mark.parametrize("mode", ["lds", "global", "host"])
 def test_motion_clustering_from_key_images(mode, monkeypatch):
     """the clustering half of the motion detector on hand-made voxel-key images (no map involved): duplicate boundary

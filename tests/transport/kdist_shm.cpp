@@ -1,7 +1,7 @@
 // kdist_shm.cpp -- TEST INFRASTRUCTURE, not product code.
 //
 // A stand-in for librccl that lets N ranks of the product's C++ tick (khronos_amd/host/sharded_fusion.cpp) run as N
-// processes on ONE GPU: the eight nccl* entry points sharded_fusion.cpp binds (through KDIST_RCCL_LIB), implemented over
+// processes on ONE GPU: the nine nccl* entry points sharded_fusion.cpp binds (through KDIST_RCCL_LIB), implemented over
 // a shared-memory segment with host-staged copies.  RCCL itself refuses several ranks on one device, and the development
 // box has exactly one MI355X; this is how the N > 1 control flow of the product code (who sends what to whom, buffer
 // sizing, trimmed exchanges, home-rank clustering) is executed and checked against the oracle before an 8-GPU node runs
@@ -299,6 +299,65 @@ ncclResult_t ncclBroadcast(const void* sendbuff, void* recvbuff, size_t count, n
     if (comm->rank == root && recvbuff == sendbuff) return true;
     return comm->out(static_cast<uint8_t*>(recvbuff) + off, comm->slot(root), nb);
   });
+}
+
+// every rank puts its whole send buffer (all destinations, chunk by chunk) into its slot; rank r copies out, from each peer's
+// slot, the part of the chunk that lies inside [sdispls_of_peer[r], + sendcounts_of_peer[r]).  The peers' counts and
+// displacements towards r are not known to r (only its own receive side is): they travel in a first, fixed-size exchange.
+ncclResult_t ncclAllToAllv(const void* sendbuff, const size_t sendcounts[], const size_t sdispls[], void* recvbuff, const size_t recvcounts[],
+                           const size_t rdispls[], ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream) {
+  if (!comm || !sendcounts || !sdispls || !recvcounts || !rdispls) return ncclInvalidArgument;
+  const size_t ts = typeSize(datatype);
+  if (!ts) return ncclInvalidArgument;
+  const int n = comm->nranks;
+  if (!comm->host && hipStreamSynchronize(stream) != hipSuccess) return comm->fail("hipStreamSynchronize");
+  // (1) the send-side tables of every rank, through the slots (host memory on both sides)
+  if (2 * sizeof(uint64_t) * static_cast<size_t>(n) > comm->chunk) return ncclInvalidArgument;
+  {
+    uint64_t* mine = reinterpret_cast<uint64_t*>(comm->slot(comm->rank));
+    for (int q = 0; q < n; ++q) {
+      mine[2 * q] = static_cast<uint64_t>(sendcounts[q]);
+      mine[2 * q + 1] = static_cast<uint64_t>(sdispls[q]);
+    }
+  }
+  ncclResult_t r = comm->barrier();
+  if (r != ncclSuccess) return r;
+  std::vector<uint64_t> peer_count(static_cast<size_t>(n)), peer_displ(static_cast<size_t>(n));
+  size_t span = 0;  // the longest send buffer (in bytes): the chunk loop runs over it on every rank
+  for (int q = 0; q < n; ++q) {
+    const uint64_t* t = reinterpret_cast<const uint64_t*>(comm->slot(q));
+    peer_count[q] = t[2 * comm->rank];
+    peer_displ[q] = t[2 * comm->rank + 1];
+    if (peer_count[q] != recvcounts[q]) {
+      std::fprintf(stderr, "[kdist_shm] rank %d: all-to-all-v expects %zu elements from rank %d, which sends %llu\n", comm->rank, recvcounts[q], q,
+                   static_cast<unsigned long long>(peer_count[q]));
+      comm->hdr->failed.store(1);
+    }
+    for (int d = 0; d < n; ++d) span = std::max<size_t>(span, static_cast<size_t>(t[2 * d] + t[2 * d + 1]) * ts);
+  }
+  r = comm->barrier();
+  if (r != ncclSuccess) return r;
+  // (2) the payload, chunk by chunk
+  size_t my_span = 0;
+  for (int q = 0; q < n; ++q) my_span = std::max(my_span, (sendcounts[q] + sdispls[q]) * ts);
+  for (size_t off = 0; off < span; off += comm->chunk) {
+    const size_t nb = std::min(comm->chunk, span - off);
+    if (off < my_span) {
+      const size_t mine = std::min(nb, my_span - off);
+      if (!comm->in(comm->slot(comm->rank), static_cast<const uint8_t*>(sendbuff) + off, mine)) return comm->fail("copy in");
+    }
+    r = comm->barrier();
+    if (r != ncclSuccess) return r;
+    for (int q = 0; q < n; ++q) {
+      const size_t a = static_cast<size_t>(peer_displ[q]) * ts, b = a + static_cast<size_t>(peer_count[q]) * ts;  // q's bytes for this rank
+      const size_t lo = std::max(a, off), hi = std::min(b, off + nb);
+      if (lo >= hi) continue;
+      if (!comm->out(static_cast<uint8_t*>(recvbuff) + rdispls[q] * ts + (lo - a), comm->slot(q) + (lo - off), hi - lo)) return comm->fail("copy out");
+    }
+    r = comm->barrier();
+    if (r != ncclSuccess) return r;
+  }
+  return ncclSuccess;
 }
 
 const char* ncclGetErrorString(ncclResult_t result) {

@@ -650,6 +650,7 @@ def main():
                                if not sender_ingest else "inside the tick (converted planes, kdist_tick_own)",
             "timed_steps": {k: {"calls": v["calls"], "bytes_sent_per_rank": v["bytes_sent"]} for k, v in counted.items() if v["calls"]},
             "profiled_ticks": prof_ticks,
+            "mesh_halo_last_output_bytes": fusion_cxx.last_mesh_exchange(),
             "collectives": {k: {"calls": v["calls"], "bytes_sent_per_call": v["bytes_sent"] / v["calls"], "ms_per_call": v["ms"] / v["calls"]}
                             for k, v in timed_c.items() if v["calls"]},
             "note": "ms: HIP events recorded around each collective on the tick's stream during %d extra ticks after the timed region "
@@ -696,7 +697,8 @@ def main():
                                   "inputs in page-locked host memory (PCIe in the timed region)" if host_input else "inputs resident in HBM"),
                    "preset": args.config if preset_matches else None,
                    "parallelism": "hash-range block shard x%d, owner-computes, RCCL all-gather of packed frames (prefetched one tick ahead on its own stream) + of 528-B halo records "
-                                  "(ever-free), seed-gated all-reduce of per-pixel voxel keys (motion detector), request / response all-gather of mesh halo planes" % world
+                                  "(ever-free), seed-gated all-reduce of per-pixel voxel keys (motion detector), mesh halo per output: all-gather of the bucketed plane requests, "
+                                  "all-to-all-v of per-relation face / line / voxel answers to the requester alone (--dist-host torch: all-gather of whole-block records)" % world
                    if world > 1 else "single GPU",
                    "collectives_issued_by": {"cxx": "libkhronos_amd_host.so (kdist_*: rccl calls on the context's HIP stream)",
                                              "torch": "khronos_amd/distributed.py (torch.distributed)", "emulated": "none (emulation, torch harness)",

@@ -870,29 +870,64 @@ struct MeshBuffers {
   uint64_t* stamps;    // last_observed of the source voxel (first_seen == stamps, ASSUMPTIONS.md A.5)
 };
 
-// copy the meshes of blocks that are not regenerated from the old to the new vertex buffer (workgroup `bid` of `nb`, one
-// slot at a time).  Called by k_mesh_move and -- beside the emit pass, which writes the OTHER blocks' vertices into the
-// same buffer -- by the trailing workgroups of k_marching_cubes<.., true> (one launch instead of two back to back: the
-// copy is pure bandwidth, the emit pass is LDS / compute, and the output stage is a chain of short dependent launches).
+// copy the meshes of blocks that are not regenerated from the old to the new vertex buffer.  Called by k_mesh_move and -- beside
+// the emit pass, which writes the OTHER blocks' vertices into the same buffer -- by the trailing workgroups of
+// k_marching_cubes<.., true> (one launch instead of two back to back).  Vertex-parallel (round 5): a wave takes 256 consecutive
+// vertices of the NEW buffer, finds the slot of its first and last one by bisection of the (monotone) offset array -- a slot's
+// vertices are contiguous, empty slots share their successor's offset, so the last slot with offset <= i owns vertex i -- and each
+// lane copies its vertices from the slot's old place (old_offset: k_mesh_prepare's snapshot of mesh_desc[].offset, so that the
+// descriptor can be moved by whoever copies the slot's first vertex).  The per-slot form it replaces (one workgroup walks a
+// slot's vertices, slots dealt round robin) took 50 - 80 us of the 100 - 130 us emit launch for ~40 MB of traffic: a workgroup
+// with two large kept meshes ran ~25 dependent load -> store rounds (profiles/r05_mc_emit.txt).
 __device__ inline void meshMoveBlocks(const DevMap& m, const uint8_t* __restrict__ regen, const uint32_t* __restrict__ new_offset,
-                                      const MeshBuffers& src, const MeshBuffers& dst, uint32_t max_vertices, uint32_t bid, uint32_t nb) {
-  if (new_offset[m.capacity] > max_vertices) return;
+                                      const uint32_t* __restrict__ old_offset, const MeshBuffers& src, const MeshBuffers& dst,
+                                      uint32_t max_vertices, uint32_t bid, uint32_t nb) {
+  const uint32_t total = new_offset[m.capacity];
+  if (total > max_vertices || total == 0u) return;
   const uint32_t n_slots = m.counters[C_MAX_SLOT];
-  for (uint32_t s = bid; s < n_slots; s += nb) {
-    if (!(m.blk_flags[s] & BLK_LIVE) || regen[s]) continue;
-    const MeshDesc d = m.mesh_desc[s];
-    if (d.count == 0) continue;
-    const size_t so = d.offset, dof = new_offset[s];
-    for (uint32_t i = threadIdx.x; i < d.count; i += blockDim.x) {
-      dst.points[3 * (dof + i)] = src.points[3 * (so + i)];
-      dst.points[3 * (dof + i) + 1] = src.points[3 * (so + i) + 1];
-      dst.points[3 * (dof + i) + 2] = src.points[3 * (so + i) + 2];
-      dst.colors[dof + i] = src.colors[so + i];
-      dst.labels[dof + i] = src.labels[so + i];
-      dst.stamps[dof + i] = src.stamps[so + i];
+  if (n_slots == 0u) return;
+  const float* __restrict__ const s_pts = src.points;
+  const uint32_t* __restrict__ const s_col = src.colors;
+  const uint32_t* __restrict__ const s_lab = src.labels;
+  const uint64_t* __restrict__ const s_stm = src.stamps;
+  float* __restrict__ const d_pts = dst.points;
+  uint32_t* __restrict__ const d_col = dst.colors;
+  uint32_t* __restrict__ const d_lab = dst.labels;
+  uint64_t* __restrict__ const d_stm = dst.stamps;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t waves_per_wg = blockDim.x >> 6;
+  const uint32_t gw = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(bid * waves_per_wg + (threadIdx.x >> 6))));
+  const uint32_t n_waves = nb * waves_per_wg;
+  auto slotOf = [&](uint32_t i, uint32_t lo, uint32_t hi) {  // last slot in [lo, hi] whose offset is <= i
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi + 1u) >> 1;
+      if (new_offset[mid] <= i) lo = mid; else hi = mid - 1u;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) m.mesh_desc[s].offset = static_cast<uint32_t>(dof);
+    return lo;
+  };
+  for (uint32_t base = gw * 256u; base < total; base += n_waves * 256u) {
+    const uint32_t last = min(base + 255u, total - 1u);
+    const uint32_t s_lo = slotOf(base, 0u, n_slots - 1u);
+    const uint32_t s_hi = slotOf(last, s_lo, n_slots - 1u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t i = base + static_cast<uint32_t>(k) * 64u + lane;
+      if (i >= total) continue;
+      const uint32_t s = s_lo == s_hi ? s_lo : slotOf(i, s_lo, s_hi);
+      if (regen[s]) continue;  // (written by the emit pass)
+      const uint32_t first = new_offset[s];
+      const size_t so = static_cast<size_t>(old_offset[s]) + (i - first);
+      const float px = s_pts[3 * so], py = s_pts[3 * so + 1], pz = s_pts[3 * so + 2];
+      const uint32_t cc = s_col[so], ll = s_lab[so];
+      const uint64_t st = s_stm[so];
+      d_pts[3 * static_cast<size_t>(i)] = px;
+      d_pts[3 * static_cast<size_t>(i) + 1] = py;
+      d_pts[3 * static_cast<size_t>(i) + 2] = pz;
+      d_col[i] = cc;
+      d_lab[i] = ll;
+      d_stm[i] = st;
+      if (i == first) m.mesh_desc[s].offset = first;
+    }
   }
 }
 
@@ -903,12 +938,12 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
                                                        const uint32_t* __restrict__ new_offset, MeshBuffers out,
                                                        int clear_flag, uint32_t max_vertices, RemoteMeshHalo rh,
                                                        uint32_t n_mc_wgs = 0xffffffffu, const uint8_t* __restrict__ regen = nullptr,
-                                                       MeshBuffers move_src = MeshBuffers{}) {
+                                                       MeshBuffers move_src = MeshBuffers{}, const uint32_t* __restrict__ old_offset = nullptr) {
   constexpr int NV = VPS * VPS * VPS;
   using MH = MeshHalo<VPS>;
   // emit pass: workgroups beyond the first n_mc_wgs copy the kept blocks' vertices (meshMoveBlocks)
   if (EMIT && blockIdx.x >= n_mc_wgs) {
-    meshMoveBlocks(m, regen, new_offset, move_src, out, max_vertices, blockIdx.x - n_mc_wgs, gridDim.x - n_mc_wgs);
+    meshMoveBlocks(m, regen, new_offset, old_offset, move_src, out, max_vertices, blockIdx.x - n_mc_wgs, gridDim.x - n_mc_wgs);
     return;
   }
   const uint32_t mc_grid = min(gridDim.x, n_mc_wgs);
@@ -1076,6 +1111,16 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
       }
       __syncthreads();
       const uint32_t n_tri = total / 3u;
+      // (restrict-qualified views: the vertex buffers never alias the map layers, and without the qualifier every attribute load of
+      // a vertex waits behind the stores of the vertex before it -- the loop was three dependent round trips per triangle)
+      float* __restrict__ const o_pts = out.points;
+      uint32_t* __restrict__ const o_col = out.colors;
+      uint32_t* __restrict__ const o_lab = out.labels;
+      uint64_t* __restrict__ const o_stm = out.stamps;
+      const uint32_t* __restrict__ const g_col = m.color;
+      const uint32_t* __restrict__ const g_lab = m.sem_label;
+      const ulonglong2* __restrict__ const g_obs = m.obs;
+      const uint64_t* __restrict__ const g_lobs = m.last_obs;
       for (uint32_t tri = threadIdx.x; tri < n_tri; tri += 256) {
         // largest lin with s_toff[lin] <= tri and a non-empty cube: binary search, then skip empty cubes
         int lo = 0, hi = NV - 1;
@@ -1087,6 +1132,13 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
         const int index = s_case[lin];
         const int col = 3 * static_cast<int>(tri - s_toff[lin]);
         const int ix = lin % VPS, iy = (lin / VPS) % VPS, iz = lin / (VPS * VPS);
+        // phase A: the three vertices' positions and the loads of their source voxels' attributes (all in flight together)
+        float vp[3][3];
+        uint32_t vcol[3], vlab[3];
+        uint64_t vstm[3];
+        ulonglong2 vobs[3];
+        size_t vso[3];
+        bool vlocal[3];
 #pragma unroll
         for (int kk = 2; kk >= 0; --kk) {
           const int e = s_tri[index * 16 + col + kk];
@@ -1108,10 +1160,9 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
           const float p1x = ox + (static_cast<float>(ix + bx) + 0.5f) * p.vs;
           const float p1y = oy + (static_cast<float>(iy + by) + 0.5f) * p.vs;
           const float p1z = oz + (static_cast<float>(iz + bz) + 0.5f) * p.vs;
-          const size_t vo = static_cast<size_t>(boff) + 3u * tri + static_cast<uint32_t>(2 - kk);
-          out.points[3 * vo] = p0x + t * (p1x - p0x);
-          out.points[3 * vo + 1] = p0y + t * (p1y - p0y);
-          out.points[3 * vo + 2] = p0z + t * (p1z - p0z);
+          vp[kk][0] = p0x + t * (p1x - p0x);
+          vp[kk][1] = p0y + t * (p1y - p0y);
+          vp[kk][2] = p0z + t * (p1z - p0z);
           // attributes of the nearer endpoint voxel (khr_config.mesh_attr_source 0; exactly half way: the first endpoint), or of the
           // voxel that contains the vertex (1; exactly half way: the endpoint with the larger coordinate along the edge)
           const bool b_upper = (bx + by + bz) > (ax + ay + az);
@@ -1121,19 +1172,47 @@ __global__ __launch_bounds__(256) void k_marching_cubes(DevMap m, DevParams p, c
           if (lx >= VPS) { lx -= VPS; sel |= 1; }
           if (ly >= VPS) { ly -= VPS; sel |= 2; }
           if (lz >= VPS) { lz -= VPS; sel |= 4; }
-          if (s_nslot[sel] != kInvalidSlot) {
-            const size_t so = static_cast<size_t>(s_nslot[sel]) * NV + (lx + VPS * (ly + VPS * lz));
-            out.colors[vo] = m.color[so];
-            out.labels[vo] = p.with_semantics ? m.sem_label[so] : 0u;
-            out.stamps[vo] = p.with_tracking ? lastObserved(m, s_nslot[sel], static_cast<uint32_t>(lx + VPS * (ly + VPS * lz)), NV) : 0ull;
+          const uint32_t ns = s_nslot[sel];
+          vlocal[kk] = ns != kInvalidSlot;
+          vcol[kk] = 0u;
+          vlab[kk] = 0u;
+          vstm[kk] = 0ull;
+          vobs[kk] = make_ulonglong2(0ull, 0ull);
+          vso[kk] = 0;
+          if (vlocal[kk]) {
+            const uint32_t vlin = static_cast<uint32_t>(lx + VPS * (ly + VPS * lz));
+            const size_t so = static_cast<size_t>(ns) * NV + vlin;
+            vso[kk] = so;
+            vcol[kk] = g_col[so];
+            if (p.with_semantics) vlab[kk] = g_lab[so];
+            if (p.with_tracking) vobs[kk] = g_obs[static_cast<size_t>(ns) * (NV >> 6) + (vlin >> 6)];
           } else {  // the source voxel lives in a block of another rank: attributes from its halo record
             const uint32_t* rec = s_nrec[sel];
             const int pi = rh.ht_offs ? meshHaloCompactIndex(sel, lx, ly, lz, VPS) : MH::indexOf(sel, lx, ly, lz);
             const int hn = s_nN[sel];
-            out.colors[vo] = rec[2 * hn + pi];
-            out.labels[vo] = p.with_semantics ? rec[3 * hn + pi] : 0u;
-            out.stamps[vo] = p.with_tracking ? (static_cast<uint64_t>(rec[4 * hn + 2 * pi]) | (static_cast<uint64_t>(rec[4 * hn + 2 * pi + 1]) << 32)) : 0ull;
+            vcol[kk] = rec[2 * hn + pi];
+            if (p.with_semantics) vlab[kk] = rec[3 * hn + pi];
+            if (p.with_tracking) vstm[kk] = static_cast<uint64_t>(rec[4 * hn + 2 * pi]) | (static_cast<uint64_t>(rec[4 * hn + 2 * pi + 1]) << 32);
           }
+        }
+        // the lazily stored last_observed (DevMap::obs): the group's stamp, or the voxel's own
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          if (vlocal[kk] && p.with_tracking) {
+            const uint32_t bit = static_cast<uint32_t>(vso[kk]) & 63u;  // (NV is a multiple of 64)
+            vstm[kk] = ((vobs[kk].x >> bit) & 1ull) ? vobs[kk].y : g_lobs[vso[kk]];
+          }
+        }
+        // phase B: stores (vertex kk of the triangle goes to position 2 - kk: the winding of the reference's table)
+#pragma unroll
+        for (int kk = 2; kk >= 0; --kk) {
+          const size_t vo = static_cast<size_t>(boff) + 3u * tri + static_cast<uint32_t>(2 - kk);
+          o_pts[3 * vo] = vp[kk][0];
+          o_pts[3 * vo + 1] = vp[kk][1];
+          o_pts[3 * vo + 2] = vp[kk][2];
+          o_col[vo] = vcol[kk];
+          o_lab[vo] = vlab[kk];
+          o_stm[vo] = vstm[kk];
         }
       }
     }
@@ -1351,17 +1430,20 @@ __global__ __launch_bounds__(256) void k_mesh_halo_adopt(const uint64_t* __restr
 // of the blocks that keep their mesh (regenerated blocks get their count from the counting pass)
 __global__ __launch_bounds__(256) void k_mesh_prepare(DevMap m, uint32_t require_flags, uint32_t* __restrict__ work,
                                                      uint32_t* __restrict__ n_work, uint8_t* __restrict__ regen,
-                                                     uint32_t* __restrict__ new_count) {
+                                                     uint32_t* __restrict__ new_count, uint32_t* __restrict__ old_offset) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   bool listed = false;
-  uint32_t count = 0u;
+  uint32_t count = 0u, offset = 0u;
   if (s < m.counters[C_MAX_SLOT]) {
     const uint32_t fl = m.blk_flags[s];
     if (fl & BLK_LIVE) {
       listed = (fl & require_flags) == require_flags;
-      count = m.mesh_desc[s].count;
+      const MeshDesc d = m.mesh_desc[s];
+      count = d.count;
+      offset = d.offset;
     }
   }
+  if (s < m.capacity) old_offset[s] = offset;  // (the copy of the kept meshes reads this snapshot: meshMoveBlocks)
   const uint32_t idx = waveAggInc(n_work, listed);
   if (listed) work[idx] = s;
   if (s <= m.capacity) {
@@ -1378,11 +1460,11 @@ __global__ __launch_bounds__(256) void k_mesh_carry_counts(DevMap m, uint32_t* _
 }
 
 // copy the meshes of blocks that are not regenerated from the old to the new vertex buffer.
-// one workgroup per slot (grid-stride); `regen` marks slots that pass 2 rewrites.
+// `regen` marks slots that pass 2 rewrites.
 __global__ __launch_bounds__(256) void k_mesh_move(DevMap m, const uint8_t* __restrict__ regen,
-                                                  const uint32_t* __restrict__ new_offset, MeshBuffers src,
-                                                  MeshBuffers dst, uint32_t max_vertices) {
-  meshMoveBlocks(m, regen, new_offset, src, dst, max_vertices, blockIdx.x, gridDim.x);
+                                                  const uint32_t* __restrict__ new_offset, const uint32_t* __restrict__ old_offset,
+                                                  MeshBuffers src, MeshBuffers dst, uint32_t max_vertices) {
+  meshMoveBlocks(m, regen, new_offset, old_offset, src, dst, max_vertices, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void k_mark_regen(const uint32_t* __restrict__ work, const uint32_t* n_work,

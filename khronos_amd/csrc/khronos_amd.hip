@@ -330,6 +330,7 @@ struct khr_ctx {
   int mesh_cur = 0;
   uint32_t *d_mesh_count = nullptr, *d_mesh_offset = nullptr;
   uint8_t* d_regen = nullptr;
+  uint32_t* d_mesh_old_off = nullptr;  // k_mesh_prepare's snapshot of mesh_desc[].offset (read by the copy of the kept meshes)
   uint32_t* d_mesh_nwork = nullptr;
   uint64_t mesh_total = 0;
   bool mesh_stale = false;
@@ -931,6 +932,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &c->d_mesh_count, cap + 1));
   A(devAlloc(c, &c->d_mesh_offset, cap + 1));
   A(devAlloc(c, &c->d_regen, cap));
+  A(devAlloc(c, &c->d_mesh_old_off, cap + 1));
   A(devAlloc(c, &c->d_mh_flag, cap));
   A(devAlloc(c, &c->d_mesh_nwork, 8));
   const size_t npx = cfg->max_frame_pixels;
@@ -3321,7 +3323,7 @@ int khr_generate_mesh(khr_ctx* c, int only_mesh_updated, int clear_flag) {
   ScopedTimer tm(c, 5);
   HIP_TRY(hipMemsetAsync(c->d_mesh_nwork, 0, sizeof(uint32_t), c->stream));
   hipLaunchKernelGGL(k_mesh_prepare, dim3(gridFor(cap + 1)), dim3(256), 0, c->stream, m, only_mesh_updated ? BLK_MESH_UPDATED : 0u,
-                     c->d_work, c->d_mesh_nwork, c->d_regen, c->d_mesh_count);
+                     c->d_work, c->d_mesh_nwork, c->d_regen, c->d_mesh_count, c->d_mesh_old_off);
   MeshBuffers src = c->mesh[c->mesh_cur], dst = c->mesh[c->mesh_cur ^ 1];
   RemoteMeshHalo rmh{};
   if (c->mh_n) {
@@ -3339,16 +3341,25 @@ int khr_generate_mesh(khr_ctx* c, int only_mesh_updated, int clear_flag) {
     constexpr int V = decltype(vps)::value;
     KHR_LAUNCH_TIMED(8, (k_marching_cubes<V, false>), dim3(kStreamGrid), dim3(256), m, c->p, c->d_work,
                      c->d_mesh_nwork, c->d_mesh_count, c->d_mesh_offset, dst, clear_flag, maxv, rmh, 0xffffffffu,
-                     static_cast<const uint8_t*>(nullptr), MeshBuffers{});
+                     static_cast<const uint8_t*>(nullptr), MeshBuffers{}, static_cast<const uint32_t*>(nullptr));
     size_t tb = c->cub_temp_bytes;
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->d_cub_temp, tb, c->d_mesh_count, c->d_mesh_offset,
                                              static_cast<int>(cap + 1), c->stream));
     // no host round trip: the capacity check happens on the device (C_MESH_OVERFLOW), totals are read lazily
     // emit pass + the copy of the kept blocks' vertices in ONE launch (the trailing kMoveWgs workgroups copy)
     constexpr uint32_t kMoveWgs = 1024;
+    static const bool split_move = std::getenv("KHR_MC_SPLIT_MOVE") != nullptr;  // A/B: the copy of the kept meshes as a launch of its own
+    if (split_move) {
+      KHR_LAUNCH_TIMED(9, (k_marching_cubes<V, true>), dim3(kStreamGrid), dim3(256), m, c->p, c->d_work, c->d_mesh_nwork, c->d_mesh_count,
+                       c->d_mesh_offset, dst, clear_flag, maxv, rmh, static_cast<uint32_t>(kStreamGrid), static_cast<const uint8_t*>(c->d_regen), src,
+                       static_cast<const uint32_t*>(c->d_mesh_old_off));
+      hipLaunchKernelGGL(k_mesh_move, dim3(kMoveWgs), dim3(256), 0, c->stream, m, static_cast<const uint8_t*>(c->d_regen),
+                         static_cast<const uint32_t*>(c->d_mesh_offset), static_cast<const uint32_t*>(c->d_mesh_old_off), src, dst, maxv);
+      return KHR_OK;
+    }
     KHR_LAUNCH_TIMED(9, (k_marching_cubes<V, true>), dim3(kStreamGrid + kMoveWgs), dim3(256), m, c->p, c->d_work,
                      c->d_mesh_nwork, c->d_mesh_count, c->d_mesh_offset, dst, clear_flag, maxv, rmh, static_cast<uint32_t>(kStreamGrid),
-                     static_cast<const uint8_t*>(c->d_regen), src);
+                     static_cast<const uint8_t*>(c->d_regen), src, static_cast<const uint32_t*>(c->d_mesh_old_off));
     return KHR_OK;
   });
   if (rc) return rc;

@@ -78,7 +78,11 @@ typedef struct khr_config {
   /* hydra::MeshIntegratorConfig */
   float mesh_min_weight;
   /* device-side sizing (no reference equivalent: the reference map grows on the host heap) */
-  uint32_t max_blocks;        /* block-pool capacity in HBM */
+  uint32_t max_blocks;        /* block-pool capacity in HBM.  Footprint per block of vps^3 voxels: 33 B / voxel (distance, weight, colour,
+                               * label, flags, last_observed, last_occupied) + 4 * KS B / voxel of label likelihoods when with_semantics,
+                               * KS = num_labels rounded up to 32 floats (whole 128-byte lines: 20 labels -> 128 B / voxel, i.e. 0.66 MB per
+                               * 16^3 block and 10.8 GB at max_blocks = 16384) or exactly num_labels with packed_likelihood_rows = 1
+                               * (80 B / voxel: 7.6 GB); khr_create fails with KHR_ENOMEM when the pool does not fit and says which */
   uint32_t max_frame_pixels;  /* largest W*H that will be uploaded */
   uint32_t num_frame_slots;   /* device-resident frame ring (FrameDataBuffer role, frame_data_buffer.h:52-100) */
   uint64_t max_mesh_vertices; /* capacity of the mesh vertex buffer */
@@ -114,6 +118,11 @@ typedef struct khr_config {
   int32_t mesh_attr_source;
   /* |sdf_a - sdf_b| below which a crossed edge is cut at t = 0.5; 0 = 1e-6 (voxblox lineage) */
   float mesh_degenerate_eps;
+  /* label-likelihood rows of the block pool: 0 = padded to whole 128-byte lines (8 lanes move a row as one line: the update kernel's
+   * row form), 1 = packed (num_labels floats per voxel, 60 % of the padded pool at 20 labels; the update kernel
+   * then takes its per-record band form: same results bit for bit, ~15 % more time in the update step).  For maps whose padded pool
+   * does not fit beside the rest of the application. */
+  int32_t packed_likelihood_rows;
 } khr_config;
 
 typedef struct khr_sensor {

@@ -33,6 +33,7 @@ class KhrConfig(C.Structure):
         ("max_mesh_vertices", C.c_uint64), ("max_band_records", C.c_uint32), ("disable_culling", C.c_int32),
         ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32), ("relaxed_arithmetic", C.c_int32), ("max_snapshot_blocks", C.c_uint32),
         ("alloc_candidate", C.c_int32), ("color_blend_weight", C.c_int32), ("mesh_attr_source", C.c_int32), ("mesh_degenerate_eps", C.c_float),
+        ("packed_likelihood_rows", C.c_int32),
     ]
 
 

@@ -839,7 +839,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   p.vps = cfg->voxels_per_side;
   p.nvox = p.vps * p.vps * p.vps;
   p.K = cfg->with_semantics ? cfg->num_labels : 1;
-  p.KS = likStride(p.K);
+  p.KS = cfg->packed_likelihood_rows ? p.K : likStride(p.K);
   p.with_semantics = cfg->with_semantics;
   p.with_tracking = cfg->with_tracking;
   p.use_dropoff = cfg->use_weight_dropoff;
@@ -896,7 +896,13 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &m.color, cap * nv, false));
   A(devAlloc(c, &m.vflags, cap * nv, false));
   A(devAlloc(c, &m.sem_label, cfg->with_semantics ? cap * nv : 1, false));
-  A(devAlloc(c, &m.lik, cfg->with_semantics ? cap * nv * p.KS : 1, false));
+  if (devAlloc(c, &m.lik, cfg->with_semantics ? cap * nv * p.KS : 1, false) != KHR_OK) {
+    // (the largest layer of the pool: say what it needs and what the switch saves)
+    fail(KHR_ENOMEM, "the label-likelihood layer of %zu blocks needs %.2f GB (%d floats per voxel%s); khr_config.packed_likelihood_rows = 1 "
+                     "stores %d per voxel, a smaller max_blocks less of everything", static_cast<size_t>(cap),
+         1e-9 * static_cast<double>(cap) * nv * p.KS * 4, p.KS, p.KS != p.K ? ": rows padded to 128-byte lines" : "", p.K);
+    A(KHR_ENOMEM);
+  }
   A(devAlloc(c, &m.last_obs, cfg->with_tracking ? cap * nv : 1, false));
   A(devAlloc(c, &m.last_occ, cfg->with_tracking ? cap * nv : 1, false));
   A(devAlloc(c, &m.trk_lim, cfg->with_tracking ? cap * 2 : 2));

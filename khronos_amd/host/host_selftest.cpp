@@ -202,6 +202,24 @@ int main(int argc, char** argv) {
   if (argc > 1 && std::strcmp(argv[1], "--tracker") == 0) return trackerReplay();
   if (argc > 1 && std::strcmp(argv[1], "--dynobj") == 0) return dynamicObjectReplay();
   if (argc > 1 && std::strcmp(argv[1], "--buffer") == 0) return bufferReplay();
+  if (argc > 2 && std::strcmp(argv[1], "--yaml-items") == 0) {
+    // the loader's own parser on a file: prints every entry of the top-level sequence `items` -- a scalar as "S <text>", a mapping
+    // as "M k=v k=v" (tests/test_cpu_host.py: scalar list items that contain colons)
+    std::ifstream in(argv[2]);
+    std::stringstream ss;
+    ss << in.rdbuf();
+    const khronos_amd::YamlNode root = khronos_amd::parseYaml(ss.str());
+    for (const khronos_amd::YamlNode* it : root.at("items").items()) {
+      if (!it->is_map || it->children.empty()) {
+        std::printf("S %s\n", it->scalar.c_str());
+      } else {
+        std::printf("M");
+        for (const auto& kv : it->children) std::printf(" %s=%s", kv.first.c_str(), kv.second.scalar.c_str());
+        std::printf("\n");
+      }
+    }
+    return 0;
+  }
   // ---- YAML ----
   if (argc > 1) {
     std::ifstream in(argv[1]);

@@ -61,6 +61,25 @@ inline std::string unquote(const std::string& s) {
 }
 }  // namespace detail
 
+namespace detail {
+// position of the ':' that separates a mapping key from its value: outside quotes and followed by a space or the end of the
+// line ("12:30", "http://host" and "'a: b'" are scalars) -- npos if there is none
+inline size_t keyColon(const std::string& s) {
+  char quote = 0;
+  for (size_t i = 0; i < s.size(); ++i) {
+    const char ch = s[i];
+    if (quote) {
+      if (ch == quote) quote = 0;
+    } else if (ch == '"' || ch == '\'') {
+      quote = ch;
+    } else if (ch == ':' && (i + 1 == s.size() || s[i + 1] == ' ' || s[i + 1] == '\t')) {
+      return i;
+    }
+  }
+  return std::string::npos;
+}
+}  // namespace detail
+
 inline YamlNode parseYaml(const std::string& text) {
   struct Line {
     int indent;
@@ -80,7 +99,7 @@ inline YamlNode parseYaml(const std::string& text) {
     int extra = 0;
     if (s == "-" || s.rfind("- ", 0) == 0) {
       const std::string rest = detail::trim(s.substr(1));
-      if (rest.empty() || rest.find(':') != std::string::npos) {
+      if (rest.empty() || detail::keyColon(rest) != std::string::npos) {
         lines.push_back({indent, "-", ""});
         if (rest.empty()) continue;
         s = rest;
@@ -90,7 +109,7 @@ inline YamlNode parseYaml(const std::string& text) {
         continue;
       }
     }
-    const size_t colon = s.find(':');
+    const size_t colon = detail::keyColon(s);
     if (colon == std::string::npos) throw std::runtime_error("yaml: unsupported line '" + s + "'");
     lines.push_back({indent + extra, detail::trim(s.substr(0, colon)), detail::trim(s.substr(colon + 1))});
   }

@@ -221,6 +221,19 @@ def test_tracker_plugins_match_independent_restatement():
             assert any(t["dyn"] for t in got[-1]) and any(not t["active"] for t in got[-1])
 
 
+def test_yaml_sequence_items_with_colons(tmp_path):
+    """a block-sequence entry is a mapping only when its colon is followed by a space (or ends the line) and stands outside quotes
+    (ADVICE r04): times, URLs and quoted text with ": " are scalar items; "- k: v" opens a mapping"""
+    p = tmp_path / "items.yaml"
+    p.write_text("items:\n  - 12:30:05\n  - http://host:8080/x\n  - 'quoted: text'\n  - plain\n  - name: a\n    value: 3\n  - key:\n")
+    exe = os.path.join(ROOT, "khronos_amd", "lib", "host_selftest")
+    out = subprocess.run([exe, "--yaml-items", str(p)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[:4] == ["S 12:30:05", "S http://host:8080/x", "S quoted: text", "S plain"], lines
+    assert lines[4] == "M name=a value=3" and lines[5].startswith("M key="), lines
+
+
 def test_host_library_exports_the_sharded_tick_abi():
     """libkhronos_amd_host.so loads on a CPU-only box and exports every entry point include/khronos_amd_dist.h declares
     (the RCCL tick; no compute, no communicator is created here)."""

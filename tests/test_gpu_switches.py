@@ -118,3 +118,15 @@ def test_switches_in_the_update_kernel_variants(monkeypatch):
             _run(6, color_blend_weight=blend, exact_arithmetic=1)
     monkeypatch.setenv("KHR_FUSE_V", "1")
     _run(2, exact_arithmetic=1)  # (leaves the process-wide switch at the default for the tests that follow)
+
+
+def test_packed_likelihood_rows_equal_the_padded_pool():
+    """khr_config.packed_likelihood_rows = 1 (num_labels floats per voxel instead of whole 128-byte lines; the update kernel then takes
+    its per-record band form): every layer of the map and the mesh equal the oracle's and the padded pool's, digest for digest"""
+    a = _run(8, mesh=True, temporal_window=0.55, exact_arithmetic=1)
+    b = _run(8, mesh=True, temporal_window=0.55, exact_arithmetic=1, packed_likelihood_rows=1)
+    assert a["digest"] == b["digest"]
+    for x, y in zip(a["meshes"], b["meshes"]):
+        for k in x:
+            assert np.array_equal(x[k], y[k]), k
+    _run(4, exact_arithmetic=0, packed_likelihood_rows=1)

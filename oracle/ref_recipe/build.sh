@@ -48,3 +48,5 @@ arrays.update(W=96, H=72, N=16, provenance=np.array("upstream: hydra::Projective
 np.savez_compressed(os.path.join(out, "ref_small.npz"), **arrays)
 print("wrote", os.path.join(out, "ref_small.npz"), sorted(arrays))
 PY
+# which setting of the ASSUMPTIONS.md [A] switches reproduces these vectors (written next to them: ref_small.npz.switches.json)
+python3 "$HERE/match_switches.py" "$OUT/ref_small.npz" --eps 1e-3

@@ -227,6 +227,11 @@ int main(int argc, char** argv) {
   const khronos::Mesh mesh = khronos::utils::combineMeshLayer(map.getMeshLayer());  // geometry_utils.cpp:61-86
   double checksum = 0;
   for (const auto& p : mesh.points) checksum += static_cast<double>(p.x()) + static_cast<double>(p.y()) + static_cast<double>(p.z());
+  // vertex attributes (geometry_utils.cpp:66-72): sums that tell khr_config.mesh_attr_source 0 / 1 apart (oracle/ref_recipe/match_switches.py)
+  uint64_t color_sum = 0, label_sum = 0, stamp_sum = 0;
+  for (const auto& c : mesh.colors) color_sum += static_cast<uint64_t>(c.r) + c.g + c.b;
+  for (const auto l : mesh.labels) label_sum += l;
+  for (const auto t : mesh.stamps) stamp_sum += t;  // (mod 2^64)
 
   writeNpy<int32_t>(out_dir, "block_indices", idx, {nb, 3});
   writeNpy<float>(out_dir, "distance", distance, {nb, nv});
@@ -240,6 +245,9 @@ int main(int argc, char** argv) {
   writeNpy<int64_t>(out_dir, "removed_counts", removed_counts, {removed_counts.size()});
   writeNpy<int64_t>(out_dir, "mesh_vertices", {static_cast<int64_t>(mesh.points.size())}, {});
   writeNpy<double>(out_dir, "mesh_checksum", {checksum}, {});
+  writeNpy<uint64_t>(out_dir, "mesh_color_checksum", {color_sum}, {});
+  writeNpy<uint64_t>(out_dir, "mesh_label_checksum", {label_sum}, {});
+  writeNpy<uint64_t>(out_dir, "mesh_stamp_checksum", {stamp_sum}, {});
   writeNpy<uint64_t>(out_dir, "stamps", stamps, {static_cast<size_t>(kN)});
   writeNpy<double>(out_dir, "poses", poses, {static_cast<size_t>(kN), 4, 4});
   writeNpy<double>(out_dir, "depth", depth_sums, {static_cast<size_t>(kN)});

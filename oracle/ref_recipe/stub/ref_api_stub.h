@@ -130,6 +130,12 @@ struct FreeSpaceMotionDetector {                                                
   explicit FreeSpaceMotionDetector(const Config&) {}
   void processInput(const VolumetricMap&, FrameData&);
 };
-struct Mesh { std::vector<Eigen::Vector3f> points; };                                    // geometry_utils.cpp:66-83
+struct Color { uint8_t r = 0, g = 0, b = 0, a = 255; };
+struct Mesh {                                                                            // geometry_utils.cpp:66-83
+  std::vector<Eigen::Vector3f> points;
+  std::vector<Color> colors;
+  std::vector<uint32_t> labels;
+  std::vector<uint64_t> first_seen_stamps, stamps;
+};
 namespace utils { Mesh combineMeshLayer(const hydra::MeshLayer&); }                      // geometry_utils.cpp:61
 }  // namespace khronos

@@ -25,10 +25,11 @@ CFG = dict(voxel_size=0.2, truncation_distance=0.4, md_min_cluster_size=5, md_mi
            temporal_window=0.9)
 
 
-def run():
+def run(extra_cfg=None):
+    """extra_cfg: oracle switches on top of CFG (oracle/ref_recipe/match_switches.py runs every [A] setting)"""
     s = SyntheticStream(W, H, threads=1)
     sen = po.OrcSensor(W, H, s.fx, s.fy, s.cx, s.cy, 0.1, 5.0)
-    m = po.OracleMap(_cfg(**CFG))
+    m = po.OracleMap(_cfg(**dict(CFG, **(extra_cfg or {}))))
     frames, removed, dyn_px, ncl = [], [], [], []
     for i in range(N):
         fr = s.render(i)
@@ -57,6 +58,10 @@ def run():
         n_clusters=np.array(ncl), dyn_pixels=np.array(dyn_px),
         removed_counts=np.array([len(r) for r in removed]), mesh_vertices=np.int64(len(mesh["points"])),
         mesh_checksum=np.float64(mesh["points"].astype(np.float64).sum()),
+        # vertex attributes (they tell the mesh_attr_source settings apart; dump_vectors.cpp writes the same sums)
+        mesh_color_checksum=np.uint64(mesh["colors"].astype(np.uint64)[:, :3].sum() if len(mesh["colors"]) else 0),
+        mesh_label_checksum=np.uint64(mesh["labels"].astype(np.uint64).sum()),
+        mesh_stamp_checksum=np.uint64(int(mesh["stamps"].astype(object).sum()) % (1 << 64) if len(mesh["stamps"]) else 0),
     )
     # the stream generator is deterministic (seed 1234), so the inputs are re-rendered by the tests and only
     # a checksum of them is stored

@@ -85,3 +85,21 @@ def test_hip_reproduces_golden():
     mesh = ctx.download_mesh()
     assert len(mesh["points"]) == int(G["mesh_vertices"])
     assert float(mesh["points"].astype(np.float64).sum()) == pytest.approx(float(G["mesh_checksum"]), rel=1e-12)
+
+
+def test_switch_matcher_names_the_settings_that_made_the_vectors():
+    """oracle/ref_recipe/match_switches.py (run by build.sh on the upstream vectors) must find the [A] switch settings from vectors
+    alone: here the vectors are made by the restatement itself with known, non-default settings"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "ref_recipe"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden
+    import match_switches
+    ref = make_golden.run(dict(alloc_candidate=1, color_blend_weight=1, mesh_degenerate_eps=0.05))
+    rep = match_switches.match(ref, (0.0, 0.05), log=lambda *_: None)
+    assert rep["best_setting"]["alloc_candidate"] == 1 and rep["best_setting"]["color_blend_weight"] == 1
+    assert rep["best_setting"]["mesh_degenerate_eps"] == 0.05
+    assert rep["switches"]["alloc_candidate"]["reproduces"] == {"0": False, "1": True}
+    assert all(v for v in rep["layers_checked"].values())
+    # the committed fixture was made with the defaults
+    rep0 = match_switches.match(np.load(os.path.join(ROOT, "tests", "golden", "aw_small.npz")), (0.0,), log=lambda *_: None)
+    assert rep0["best_setting"] == {"alloc_candidate": 0, "color_blend_weight": 0, "mesh_attr_source": 0, "mesh_degenerate_eps": 0.0}

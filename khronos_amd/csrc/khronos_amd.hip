@@ -1496,8 +1496,20 @@ static int integrateUpdateMulti(khr_ctx* c, khr_ctx* src, const int* src_slots, 
   constexpr int WPW = 8;
   auto go = [&](auto kern) {
     // one workgroup per WPW items is enough (c->explicit_blocks bounds the map), at most what is resident
+    // (the occupancy query is a driver call of tens of microseconds: once per instantiation, not once per extracted object)
+    static std::map<const void*, int> per_cu_of;
+    static std::mutex per_cu_mu;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * WPW, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    {
+      std::lock_guard<std::mutex> lock(per_cu_mu);
+      auto it = per_cu_of.find(reinterpret_cast<const void*>(kern));
+      if (it != per_cu_of.end()) {
+        per_cu = it->second;
+      } else {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * WPW, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        per_cu_of[reinterpret_cast<const void*>(kern)] = per_cu;
+      }
+    }
     int grid = std::min(kFuseStatSlots, per_cu * 256) / 8 * 8;
     if (c->explicit_blocks > 0) {
       const uint64_t items = c->explicit_blocks * c->wpb;

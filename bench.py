@@ -561,11 +561,13 @@ def main():
     _trace(_tags["timed_begin"])
     t0 = time.perf_counter()
     ft = []
+    step_t = [t0]  # host clock after every step (no synchronisation: the host meets the device once per frame at the seed count)
     for i in range(t0i, t1i):
         if args.frame_times:
             torch.cuda.synchronize()
             tf = time.perf_counter()
         step(i)
+        step_t.append(time.perf_counter())
         if args.frame_times:
             torch.cuda.synchronize()
             ft.append((i, round(1e6 * (time.perf_counter() - tf)), ctx.stats()["n_seeds"]))
@@ -586,6 +588,13 @@ def main():
     # how the timed region splits: queueing the K steps (the host runs ahead of the GPU by at most the motion detector's seed
     # count) and the wait at the end for the device and for the detached object extractions that the steps started
     timed_split = {"steps_ms": 1e3 * (t_join0 - t0), "drain_and_join_ms": 1e3 * (t0 + dt - t_join0)}
+    if len(step_t) >= 9:
+        # the window fills during the run (more blocks, more tracks, object extractions beside the frames): the steps get heavier, which
+        # is why a longer timed region has a higher ms_per_step (host view, un-synchronised: a step's time is the device's, one frame late)
+        sd = np.diff(np.array(step_t)) * 1e3
+        q = max(1, len(sd) // 4)
+        timed_split["step_ms_host_view"] = {"first_quarter_mean": float(sd[:q].mean()), "last_quarter_mean": float(sd[-q:].mean()),
+                                            "median": float(np.median(sd)), "max": float(sd.max()), "argmax_step": int(sd.argmax())}
     _trace(_tags["timed_end"])
     ctx.timing_enable(False)
     st1 = ctx.stats()

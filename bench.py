@@ -426,12 +426,14 @@ def main():
                 flags |= ctx.PF_INGESTED
                 handed.pop(0)
             slot, n_dyn = ctx.process_frame(sensor, frame_desc[i], not host_input, flags)
+            dyn_log[i] = n_dyn
             _t1 = time.perf_counter()
             host_t[0] += _t1 - _t0
             if args.output_copy == "host":
                 host_consumer_poll()  # (behind this frame's launches: the device works on while the host looks at the previous output)
             if last and out_now and args.output_copy != "none":
                 # the output's map clone
+                _trace(b"snap_take")
                 snap = ctx.take_snapshot()
                 copy_stats[0] += 1
                 if args.output_copy == "host":
@@ -468,6 +470,7 @@ def main():
                     obj_stats[2] += time.perf_counter() - t_e
 
     copy_stats = [0, 0]       # outputs whose map clone was taken, bytes brought to the host (--output-copy)
+    dyn_log = {}              # frame index -> dynamic clusters the motion detector found (frames with seeds run the clustering chain)
     handed = []               # indices of the frames handed over with khr_ingest_ahead[_host], oldest first
     lookahead = (args.lookahead or args.input == "host") and world == 1 and not emu  # (host frames: the copy of frame i + 1 beside frame i)
     held_snapshot = [None]
@@ -485,6 +488,7 @@ def main():
     host_next_buf = [0]
 
     def host_consumer_begin():
+        _trace(b"hc_begin_enter")
         if not host_bufs:
             for _b in range(2):
                 host_bufs.append({nm: torch.empty(8192 * per, dtype=dt_).pin_memory() for nm, dt_, per in host_fields})
@@ -494,12 +498,15 @@ def main():
         host_pending[0].download_begin([host_bufs[b][k].data_ptr() if k in host_bufs[b] else 0 for k in order], 8192)
         host_inflight.append(host_pending[0])
         host_pending[0] = None
+        _trace(b"hc_begin_exit")
 
     def host_consumer_retire():
+        _trace(b"hc_retire_enter")
         snap0 = host_inflight.pop(0)
         nb_ = snap0.download_end()
         copy_stats[1] += nb_ * host_bytes_per_block
         snap0.release()
+        _trace(b"hc_retire_exit")
 
     def host_mesh_copy_wait():
         if host_mesh_thread[0] is not None:
@@ -507,6 +514,7 @@ def main():
             host_mesh_thread[0] = None
 
     def host_consumer_poll():
+        _trace(b"hc_poll_enter")
         if host_mesh_pending[0]:  # the previous output's mesh: its gather ran right behind that output's kernels
             # collect on this thread (a wait for the gather's ticket), then the CONSUMER's thread copies the 20 MB out of the pinned
             # staging block into its own arrays, block by block in sorted order (khr_fetch_mesh_into: host memcpy, no device access;
@@ -524,8 +532,10 @@ def main():
                 host_mesh_thread[0].start()
             copy_stats[1] += nv_ * (12 + 4 + 4 + 8 + 8)
             host_mesh_pending[0] = False
+        _trace(b"hc_poll_mesh_done")
         if host_pending[0] is not None and host_pending[0].poll() and len(host_inflight) < 2:
             host_consumer_begin()
+        _trace(b"hc_poll_exit")
 
     def host_consumer_drain():
         host_consumer_poll()
@@ -543,6 +553,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.output_copy == "host" and world == 1:
+        # a consumer that takes the mesh at every output sizes its buffers once: the library's pinned staging block and the
+        # consumer's own arrays would otherwise grow (x 1.5) in the middle of the run -- a re-allocation of page-locked memory
+        # costs tens of milliseconds (seen as ONE 40 ms step in a 40-step window, profiles/r05_host_consumer_40.txt)
+        cap_ = int(min(cfg.max_mesh_vertices, 6 << 20))
+        ctx.reserve_mesh_staging(cap_)
+        # ... and the snapshot arenas of the outputs it keeps in flight (two being downloaded, one pending, one being taken): an
+        # arena that is allocated when a snapshot finds none free is a hipMalloc of 0.8 GB -- ONE 35 - 45 ms step
+        ctx.reserve_snapshots(4, fields=63, cap_blocks=int(cfg.max_snapshot_blocks) or 8192)
+        host_mesh_bufs.update(cap=cap_, points=np.zeros((cap_, 3), np.float32), colors=np.zeros((cap_, 4), np.uint8),
+                              labels=np.zeros(cap_, np.uint32), first_seen=np.zeros(cap_, np.uint64), stamps=np.zeros(cap_, np.uint64))
+        for k_ in ("points", "colors", "labels", "first_seen", "stamps"):
+            host_mesh_bufs[k_].fill(0)  # (touch the pages)
     for i in range(t0i):  # pre-roll + warm-up, untimed
         step(i)
     sync_all()
@@ -558,6 +581,11 @@ def main():
         ctx.timing_enable(True, None if args.all_timers else ("tsdf", "band"))  # HIP events cost a barrier packet each: only the roofline kernel
     if fusion_cxx is not None and not emu:
         fusion_cxx.profile(False)  # (reset: calls / bytes of the timed steps are counted, nothing is timed)
+    # (the interpreter's cyclic garbage collector is a property of this harness, not of the path: a generation-2 pass in the middle
+    # of the timed steps was a 35 - 60 ms step in the host-consumer windows, profiles/r05_host_consumer_40.txt)
+    import gc
+    gc.collect()
+    gc.disable()
     _trace(_tags["timed_begin"])
     t0 = time.perf_counter()
     ft = []
@@ -593,9 +621,11 @@ def main():
         # is why a longer timed region has a higher ms_per_step (host view, un-synchronised: a step's time is the device's, one frame late)
         sd = np.diff(np.array(step_t)) * 1e3
         q = max(1, len(sd) // 4)
+        timed_split["frames_with_dynamic_clusters"] = sum(1 for i in range(t0i, t1i) if dyn_log.get(i, 0) > 0)
         timed_split["step_ms_host_view"] = {"first_quarter_mean": float(sd[:q].mean()), "last_quarter_mean": float(sd[-q:].mean()),
                                             "median": float(np.median(sd)), "max": float(sd.max()), "argmax_step": int(sd.argmax())}
     _trace(_tags["timed_end"])
+    gc.enable()
     ctx.timing_enable(False)
     st1 = ctx.stats()
     obj_timed = [obj_stats[k] - obj_before[k] for k in range(3)]

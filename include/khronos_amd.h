@@ -506,6 +506,10 @@ int64_t khr_snapshot_num_blocks(khr_snapshot* snap);
  * block count. */
 int64_t khr_snapshot_download(khr_snapshot* snap, int32_t* indices, float* distance, float* weight, uint8_t* color_rgba,
                               uint64_t* last_observed, uint8_t* voxel_flags, uint32_t* sem_label, int64_t cap_blocks);
+/* A snapshot takes its arena from the context's pool of released ones and allocates a new one (hipMalloc of up to a gigabyte: tens of
+ * milliseconds during which the device does nothing else) when none is free.  A consumer that keeps n outputs in flight allocates
+ * them up front: arenas for snapshots of `fields` / `cap_blocks` (as khr_snapshot_updated; 0 = max_blocks) until n are free. */
+int khr_reserve_snapshots(khr_ctx* ctx, uint32_t fields, int64_t cap_blocks, int n_arenas);
 /* The same transfer, asynchronous, for a consumer that overlaps it with the following frames (the Hydra frontend takes outputs
  * from a queue; nothing forces the active window to wait for the link): _begin queues the device -> host copies of the
  * fields whose pointers are non-NULL -- the consumer's field mask: a TSDF consumer passes distance / weight only and moves 8
@@ -528,6 +532,10 @@ int64_t khr_mesh_num_vertices(khr_ctx* ctx);
 /* first half of khr_fetch_mesh for a pipelined consumer: queues the gather of the CURRENT mesh behind the stream's work and
  * returns; the next khr_fetch_mesh only collects (call it before the next khr_generate_mesh / output stage). */
 int khr_fetch_mesh_launch(khr_ctx* ctx);
+/* The pinned staging block behind khr_fetch_mesh grows on demand (x 1.5 of what a mesh needed); a growth re-allocates tens of
+ * megabytes of page-locked memory (tens of milliseconds) and repeats the gather.  A consumer that fetches the mesh at every output
+ * reserves room for n_vertices once (40 B per vertex + the block table); synchronises the context's stream. */
+int khr_reserve_mesh_staging(khr_ctx* ctx, uint64_t n_vertices);
 /* the same mesh with ONE host round trip, in two halves so that the caller can size its arrays in between:
  * khr_fetch_mesh makes the device gather block table + vertex arrays into pinned memory (one launch, one wait) and
  * returns the vertex count; khr_fetch_mesh_into then copies them, in sorted block order, into the caller's arrays

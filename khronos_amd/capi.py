@@ -87,7 +87,7 @@ EXPORTS = [
     "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",
     "khr_cluster_voxels", "khr_download_frame_image", "khr_detect_objects_launch", "khr_pool_exhausted", "khr_map_digest",
     "khr_rv_create", "khr_rv_destroy", "khr_rv_clear", "khr_rv_add_rays", "khr_rv_num_rays", "khr_rv_num_pairs", "khr_rv_check",
-    "khr_snapshot_updated", "khr_take_snapshot", "khr_snapshot_num_blocks", "khr_snapshot_download", "khr_snapshot_download_extra", "khr_snapshot_download_begin", "khr_snapshot_download_end", "khr_snapshot_poll", "khr_fetch_mesh_launch", "khr_mirror_dynamic", "khr_snapshot_release",
+    "khr_snapshot_updated", "khr_take_snapshot", "khr_snapshot_num_blocks", "khr_snapshot_download", "khr_snapshot_download_extra", "khr_snapshot_download_begin", "khr_snapshot_download_end", "khr_snapshot_poll", "khr_fetch_mesh_launch", "khr_reserve_mesh_staging", "khr_reserve_snapshots", "khr_mirror_dynamic", "khr_snapshot_release",
     "khr_rv_check_stamps", "khr_get_config", "khr_cluster_voxels_launch", "khr_cluster_voxels_fetch", "khr_reset_map", "khr_depend_on", "khr_retain_slot", "khr_release_slot",
 ]
 
@@ -219,6 +219,8 @@ def load_library():
     lib.khr_ingest_ahead_host.argtypes = [vp, C.POINTER(KhrSensor), C.POINTER(KhrFrame)]
     lib.khr_ingest_cancel.argtypes = [vp]
     lib.khr_ingest_ahead.restype = i32
+    lib.khr_reserve_mesh_staging.argtypes = [vp, u64]
+    lib.khr_reserve_snapshots.argtypes = [vp, C.c_uint32, i64, i32]
     lib.khr_timing_enable.argtypes = [vp, i32]
     lib.khr_timing_reset.argtypes = [vp]
     lib.khr_timing_get.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64)]
@@ -703,6 +705,14 @@ class FusionContext:
         h = C.c_void_p()
         rc = self.lib.khr_take_snapshot(self.h, C.byref(h))
         return Snapshot(self, h) if rc == 0 and h.value else None
+
+    def reserve_mesh_staging(self, n_vertices):
+        """room for n_vertices in the pinned block behind fetch_mesh, allocated now instead of by growth in the middle of a run"""
+        self._chk(self.lib.khr_reserve_mesh_staging(self.h, int(n_vertices)))
+
+    def reserve_snapshots(self, n, fields=63, cap_blocks=0):
+        """n snapshot arenas allocated now (a snapshot that finds none free allocates one in the middle of the run)"""
+        self._chk(self.lib.khr_reserve_snapshots(self.h, int(fields), int(cap_blocks), int(n)))
 
     def download_mesh(self):
         n = self._chk(self.lib.khr_mesh_num_vertices(self.h))

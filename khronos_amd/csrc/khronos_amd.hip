@@ -4361,6 +4361,39 @@ static size_t snapBytes(uint32_t fields, size_t cap, size_t nvox, bool trk, bool
   return b;
 }
 
+// Arenas are allocated when a snapshot finds none free -- a hipMalloc of up to a gigabyte, i.e. tens of milliseconds in which the
+// device does nothing else.  A consumer that knows how many outputs it keeps in flight allocates them up front.
+int khr_reserve_snapshots(khr_ctx* c, uint32_t fields, int64_t cap_blocks, int n_arenas) {
+  if (!c || !(fields & KHR_SNAP_EVERYTHING) || n_arenas < 0 || n_arenas > 16) return fail(KHR_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t cap = cap_blocks > 0 ? static_cast<size_t>(std::min<int64_t>(cap_blocks, c->m.capacity)) : c->m.capacity;
+  const size_t need = snapBytes(fields, cap, c->p.nvox, c->cfg.with_tracking, c->cfg.with_semantics, static_cast<size_t>(c->p.K));
+  size_t have = 0;
+  {
+    std::lock_guard<std::mutex> lock(c->snap_pool->mu);
+    for (const auto& a : c->snap_pool->free) have += a.bytes >= need ? 1 : 0;
+  }
+  for (size_t i = have; i < static_cast<size_t>(n_arenas); ++i) {
+    khr_ctx::SnapArena a{};
+    void* hc = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&a.ptr), need) != hipSuccess) return fail(KHR_ENOMEM, "snapshot arena of %zu bytes", need);
+    void* dv = nullptr;
+    if (hipHostMalloc(&hc, 64, hipHostMallocDefault) != hipSuccess || hipHostGetDevicePointer(&dv, hc, 0) != hipSuccess) {
+      hipFree(a.ptr);
+      if (hc) hipHostFree(hc);
+      return fail(KHR_ENOMEM, "snapshot pinned words");
+    }
+    a.bytes = need;
+    a.h_count = static_cast<volatile uint32_t*>(hc);
+    a.h_count[0] = 0;
+    a.h_count[1] = 0;
+    a.d_count_host_view = static_cast<uint32_t*>(dv);
+    std::lock_guard<std::mutex> lock(c->snap_pool->mu);
+    c->snap_pool->free.push_back(a);
+  }
+  return KHR_OK;
+}
+
 int khr_snapshot_updated(khr_ctx* c, uint32_t fields, int64_t cap_blocks, khr_snapshot** out) {
   if (!c || !out || !(fields & KHR_SNAP_EVERYTHING)) return fail(KHR_EINVAL, "bad argument");
   *out = nullptr;
@@ -4550,6 +4583,7 @@ int khr_snapshot_download_begin(khr_snapshot* s, int32_t* indices, float* distan
                                 uint64_t* last_observed, uint8_t* voxel_flags, uint32_t* sem_label, int64_t cap_blocks) {
   if (!s) return fail(KHR_EINVAL, "null snapshot");
   if (s->copying) return fail(KHR_ESTATE, "a download of this snapshot is already in flight");
+  HT("dl_begin_enter");
   int rc = snapshotWait(s);  // (the count: published by the pack kernel's first thread)
   if (rc) return rc;
   if (s->total > s->cap) return fail(KHR_ENOMEM, "%lld updated blocks, snapshot capacity %u", static_cast<long long>(s->total), s->cap);
@@ -4585,13 +4619,16 @@ int khr_snapshot_download_begin(khr_snapshot* s, int32_t* indices, float* distan
   }
   HIP_TRY(hipEventRecord(s->ev_copied, c->copy_stream));
   s->copying = true;
+  HT("dl_begin_exit");
   return KHR_OK;
 }
 
 int64_t khr_snapshot_download_end(khr_snapshot* s) {
   if (!s) return fail(KHR_EINVAL, "null snapshot");
   if (!s->copying) return fail(KHR_ESTATE, "no download in flight (khr_snapshot_download_begin first)");
+  HT("dl_end_enter");
   HIP_TRY(hipEventSynchronize(s->ev_copied));
+  HT("dl_end_exit");
   s->copying = false;
   return s->n;
 }
@@ -4704,6 +4741,25 @@ static int fetchMeshLaunch(khr_ctx* c) {
                      static_cast<uint32_t*>(d_stage), static_cast<uint64_t>(c->h_stage_bytes / 4), c->d_fetch_done, c->fetch_ticket);
   HIP_TRY(hipGetLastError());
   HT("fetch_launched");
+  return KHR_OK;
+}
+
+// The pinned staging block of the mesh fetches grows on demand (x 1.5): a growth is a hipHostFree + hipHostMalloc of tens of
+// megabytes -- tens of MILLISECONDS -- and a repeated gather.  A consumer that takes a mesh per output reserves once instead.
+int khr_reserve_mesh_staging(khr_ctx* c, uint64_t n_vertices) {
+  if (!c) return fail(KHR_EINVAL, "null ctx");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // (a gather in flight writes the block that is about to be replaced)
+  c->fetch_pending = false;
+  const size_t cap = c->m.capacity;
+  const size_t bytes = 4096 + (sizeof(int4) + sizeof(uint32_t) + sizeof(MeshDesc) + 64) * cap + 40 * static_cast<size_t>(n_vertices);
+  // (exactly this many bytes, not x 1.5: the caller named its bound)
+  if (bytes <= c->h_stage_bytes) return KHR_OK;
+  if (c->h_stage) HIP_TRY(hipHostFree(c->h_stage));
+  c->h_stage = nullptr;
+  c->h_stage_bytes = 0;
+  if (hipHostMalloc(&c->h_stage, bytes, hipHostMallocDefault) != hipSuccess) return fail(KHR_ENOMEM, "pinned staging of %zu bytes", bytes);
+  c->h_stage_bytes = bytes;
   return KHR_OK;
 }
 

@@ -289,6 +289,9 @@ struct khr_ctx {
   uint32_t* d_md_scratch4 = nullptr;  // 4 words k_publish may zero
   std::vector<uint64_t> h_md_seed_keys, h_md_bnd_keys;
   std::vector<uint32_t> h_md_seed_counts, h_md_bnd_counts, h_md_adj;
+  uint32_t* h_md_walk = nullptr;     // page-locked block the host walk's lists travel through (kernels read / write it: no copy engine)
+  size_t h_md_walk_words = 0;
+  hipEvent_t ev_md_walk_up = nullptr;  // the last upload out of it has been consumed
   std::vector<int32_t> h_md_seed_final, h_md_bnd_final;
   std::vector<ClusterAcc> h_md_acc;
   ClusterAcc* h_md_acc_pinned = nullptr;   // summaries of the latest seed frame (k_publish_cluster_acc), ticket h_pinned[7]
@@ -977,6 +980,11 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     A(devAlloc(c, &c->d_md_bnd_final, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_bnd_deg, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_adj, static_cast<size_t>(c->md_list_cap) * 26, false));
+    {  // the host walk's page-locked block, for 16 k seed voxels to begin with (grown on demand: a growth is a hipHostMalloc inside a frame)
+      const size_t want = std::min<size_t>(c->md_list_cap, 16384) * (3 + 26 + 3) + 16;
+      if (hipHostMalloc(reinterpret_cast<void**>(&c->h_md_walk), want * 4, hipHostMallocDefault) != hipSuccess) A(KHR_ENOMEM);
+      else c->h_md_walk_words = want;
+    }
     // (not zeroed: devAlloc's memset is queued on the context's NON-BLOCKING stream, and the synchronous copy of the reduction
     //  identities below runs on the null stream -- nothing orders the two, and a memset that lands second leaves zeros, i.e.
     //  boxes clamped at 0 for the first seed frame's clusters.  Found by tests/test_gpu_ref_pin.py.)
@@ -1064,6 +1072,8 @@ void khr_destroy(khr_ctx* c) {
   if (c->d_halo_keys) { hipFree(c->d_halo_keys); hipFree(c->d_halo_vals); }
   if (c->d_mh_recs) { hipFree(c->d_mh_recs); hipFree(c->d_mh_keys); hipFree(c->d_mh_vals); }
   if (c->d_mh2_scratch) hipFree(c->d_mh2_scratch);
+  if (c->h_md_walk) hipHostFree(c->h_md_walk);
+  if (c->ev_md_walk_up) hipEventDestroy(c->ev_md_walk_up);
   if (c->d_mh2_keys) { hipFree(c->d_mh2_keys); hipFree(c->d_mh2_offs); }
   if (c->d_pix_scratch) hipFree(c->d_pix_scratch);
   if (c->d_band_rec) { hipFree(c->d_band_rec); hipFree(c->d_band_n); }
@@ -2579,14 +2589,51 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
   std::vector<uint64_t>& bk = c->h_md_bnd_keys;
   std::vector<uint32_t>&sc = c->h_md_seed_counts, &bc = c->h_md_bnd_counts, &adj = c->h_md_adj;
   sk.resize(S); sc.resize(S); adj.resize(static_cast<size_t>(S) * nn); bk.resize(B); bc.resize(B);
-  HIP_TRY(hipMemcpyAsync(sk.data(), c->d_md_seed_keys, sizeof(uint64_t) * S, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(sc.data(), c->d_md_seed_counts, sizeof(uint32_t) * S, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(adj.data(), c->d_md_adj, sizeof(uint32_t) * S * nn, hipMemcpyDeviceToHost, c->stream));
-  if (B) {
-    HIP_TRY(hipMemcpyAsync(bk.data(), c->d_md_bnd_keys, sizeof(uint64_t) * B, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(bc.data(), c->d_md_bnd_counts, sizeof(uint32_t) * B, hipMemcpyDeviceToHost, c->stream));
+  // The lists reach the host through a page-locked block that a kernel writes (and the finals go back the same way): copies
+  // into these pageable vectors went through the copy engines, where -- with a consumer downloading an output's 90 - 190 MB at
+  // the same time -- this frame's few kilobytes waited 7 ms (profiles/r05_host_consumer_40.txt).
+  const size_t w_sk = 2 * static_cast<size_t>(S), w_sc = S, w_adj = static_cast<size_t>(S) * nn, w_bk = 2 * static_cast<size_t>(B), w_bc = B;
+  const size_t walk_words = w_sk + w_sc + w_adj + w_bk + w_bc + 16;
+  if (walk_words > c->h_md_walk_words) {
+    if (c->ev_md_walk_up) HIP_TRY(hipEventSynchronize(c->ev_md_walk_up));
+    if (c->h_md_walk) HIP_TRY(hipHostFree(c->h_md_walk));
+    c->h_md_walk = nullptr;
+    c->h_md_walk_words = 0;
+    const size_t want = std::max<size_t>(2 * walk_words, 1u << 18);
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_md_walk), want * 4, hipHostMallocDefault) != hipSuccess)
+      return fail(KHR_ENOMEM, "page-locked block of the motion detector's host walk (%zu bytes)", want * 4);
+    c->h_md_walk_words = want;
+  } else if (c->ev_md_walk_up) {
+    HIP_TRY(hipEventSynchronize(c->ev_md_walk_up));  // (the previous seed frame's upload reads the block)
+  }
+  if (!c->ev_md_walk_up) HIP_TRY(hipEventCreateWithFlags(&c->ev_md_walk_up, hipEventDisableTiming));
+  uint32_t* walk_dev = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&walk_dev), c->h_md_walk, 0));
+  {
+    size_t o = 0;
+    auto down = [&](const void* src, size_t words) {
+      if (words) hipLaunchKernelGGL(k_copy_words, dim3(static_cast<unsigned>((words + 255) / 256)), dim3(256), 0, c->stream,
+                                    static_cast<const uint32_t*>(src), walk_dev + o, static_cast<uint32_t>(words));
+      o += words;
+    };
+    down(c->d_md_seed_keys, w_sk);
+    down(c->d_md_seed_counts, w_sc);
+    down(c->d_md_adj, w_adj);
+    down(c->d_md_bnd_keys, w_bk);
+    down(c->d_md_bnd_counts, w_bc);
+    HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
+  {
+    const uint32_t* w = c->h_md_walk;
+    std::memcpy(sk.data(), w, w_sk * 4); w += w_sk;
+    std::memcpy(sc.data(), w, w_sc * 4); w += w_sc;
+    std::memcpy(adj.data(), w, w_adj * 4); w += w_adj;
+    if (B) {
+      std::memcpy(bk.data(), w, w_bk * 4); w += w_bk;
+      std::memcpy(bc.data(), w, w_bc * 4);
+    }
+  }
 
   lap("list download");
   // ---- host: the seed-graph walk on compact ids (sequential in the reference too) ---------------
@@ -2726,9 +2773,20 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
   }
   if (n_out > 0) {
     // the host vectors are context members, so the asynchronous upload may outlive this call
-    HIP_TRY(hipMemcpyAsync(c->d_md_seed_final, seed_final.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, c->stream));
-    if (B) HIP_TRY(hipMemcpyAsync(c->d_md_bnd_final, bnd_final.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, c->stream));
-    if (B) HIP_TRY(hipMemcpyAsync(c->d_md_bnd_deg, bnd_deg.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, c->stream));
+    {
+      uint32_t* w = c->h_md_walk;  // (S + 2 B words: the block holds more than that, sized above)
+      std::memcpy(w, seed_final.data(), sizeof(int32_t) * S);
+      if (B) std::memcpy(w + S, bnd_final.data(), sizeof(int32_t) * B);
+      if (B) std::memcpy(w + S + B, bnd_deg.data(), sizeof(int32_t) * B);
+      auto up = [&](void* dst, size_t off, size_t words) {
+        if (words) hipLaunchKernelGGL(k_copy_words, dim3(static_cast<unsigned>((words + 255) / 256)), dim3(256), 0, c->stream,
+                                      static_cast<const uint32_t*>(walk_dev + off), static_cast<uint32_t*>(dst), static_cast<uint32_t>(words));
+      };
+      up(c->d_md_seed_final, 0, S);
+      up(c->d_md_bnd_final, S, B);
+      up(c->d_md_bnd_deg, static_cast<size_t>(S) + B, B);
+      HIP_TRY(hipEventRecord(c->ev_md_walk_up, c->stream));
+    }
     hipLaunchKernelGGL(k_md_paint, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, seeds, bnd, c->d_md_seed_final,
                        c->d_md_bnd_final, s.dyn, c->d_md_bnd_deg, s.dynw);
     s.dyn_clean = false;

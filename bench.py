@@ -566,6 +566,13 @@ def main():
                               labels=np.zeros(cap_, np.uint32), first_seen=np.zeros(cap_, np.uint64), stamps=np.zeros(cap_, np.uint64))
         for k_ in ("points", "colors", "labels", "first_seen", "stamps"):
             host_mesh_bufs[k_].fill(0)  # (touch the pages)
+    # The interpreter's cyclic garbage collector is a property of this harness, not of the path: a generation-2 pass in the middle of
+    # the timed steps was a 35 - 60 ms step in the host-consumer windows (profiles/r05_host_consumer_40.txt).  It is run once and
+    # switched off HERE, in front of the pre-roll -- not between warm-up and timed steps, where the pause lets the device's clocks
+    # drop and the first timed steps pay for it (-4.7 % on the driver's command, tools/runs/r05/run28.sh / run29.sh).
+    import gc
+    gc.collect()
+    gc.disable()
     for i in range(t0i):  # pre-roll + warm-up, untimed
         step(i)
     sync_all()
@@ -581,11 +588,6 @@ def main():
         ctx.timing_enable(True, None if args.all_timers else ("tsdf", "band"))  # HIP events cost a barrier packet each: only the roofline kernel
     if fusion_cxx is not None and not emu:
         fusion_cxx.profile(False)  # (reset: calls / bytes of the timed steps are counted, nothing is timed)
-    # (the interpreter's cyclic garbage collector is a property of this harness, not of the path: a generation-2 pass in the middle
-    # of the timed steps was a 35 - 60 ms step in the host-consumer windows, profiles/r05_host_consumer_40.txt)
-    import gc
-    gc.collect()
-    gc.disable()
     _trace(_tags["timed_begin"])
     t0 = time.perf_counter()
     ft = []

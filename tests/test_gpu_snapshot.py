@@ -176,3 +176,41 @@ def test_snapshot_async_masked_download_equals_blocking_download():
     snap.release()
     ctx.close()
     ora.close()
+
+
+def test_reserved_staging_and_arenas_change_nothing_but_the_allocation_time():
+    """khr_reserve_mesh_staging / khr_reserve_snapshots (round 5: a consumer allocates its pinned mesh staging and its snapshot arenas up
+    front instead of by growth inside a frame): the fetched mesh equals the downloaded one, three snapshots held at once carry what the
+    blocking download of each gives, a reserve in the middle of the run (behind a pending gather) is harmless."""
+    cfg, ctx, ora, s, sen, osen = make_pair(width=W, height=H, temporal_window=0.55)
+    ctx.reserve_mesh_staging(200_000)
+    ctx.reserve_snapshots(3, fields=63, cap_blocks=4096)  # (what KHR_PF_SNAPSHOT takes here: min(8192, max_blocks))
+    flags_out = ctx.PF_TRACKING | ctx.PF_OUTPUT | ctx.PF_SNAPSHOT
+    snaps = []
+    for i in range(12):
+        fr = s.render(i)
+        f = ctx.make_frame(fr["stamp"], fr["pose"], fr["depth"].ctypes.data, fr["rgb"].ctypes.data, fr["label"].ctypes.data)
+        out = i % 4 == 3
+        ctx.process_frame(sen, f, False, flags_out if out else ctx.PF_TRACKING)
+        if out:
+            snaps.append(ctx.take_snapshot())
+            a, b = ctx.fetch_mesh(), ctx.download_mesh()
+            assert len(a["points"]) == len(b["points"]) > 1000
+            for k in ("points", "colors", "labels", "stamps"):
+                assert np.array_equal(a[k], b[k]), k
+            if len(snaps) == 2:
+                ctx.fetch_mesh_launch()
+                ctx.reserve_mesh_staging(2_000_000)  # (grows the block: the pending gather is dropped, the next fetch starts over)
+                c = ctx.fetch_mesh()
+                assert np.array_equal(c["points"], b["points"])
+    assert len(snaps) == 3 and all(sn is not None for sn in snaps)
+    counts = [sn.num_blocks() for sn in snaps]
+    assert all(n > 20 for n in counts)
+    for sn in snaps:
+        full = sn.download()
+        assert len(full["indices"]) == sn.num_blocks()
+        sn.release()
+    with pytest.raises(Exception):
+        ctx.reserve_snapshots(99)
+    ctx.close()
+    ora.close()

@@ -55,3 +55,41 @@ def test_owner_function_is_a_partition():
     h = mix32(((u(x) * 73856093) & 0xFFFFFFFF) ^ mix32(((u(y) * 19349663) & 0xFFFFFFFF) ^ mix32((u(z) * 83492791) & 0xFFFFFFFF)))
     cnt = np.bincount(((h * 8) >> 32).astype(int), minlength=8)
     assert cnt.max() / cnt.mean() < 1.06
+
+
+def test_compact_mesh_halo_plan_is_consistent_across_ranks():
+    """khr_mesh_halo_plan (a pure host function of the C ABI: no device needed) lays out the all-to-all-v of the compact mesh halo from
+    the all-gathered request headers alone.  Every rank derives its own send / receive counts from the SAME headers, so what q sends
+    to r must be what r expects from q, displacements must be the prefix sums, and the word counts must equal a plain restatement
+    (face = 1 + 6 vps^2 words, edge line = 1 + 6 vps, corner = 7)."""
+    import ctypes as C
+    import numpy as np
+    from khronos_amd import capi
+    lib = capi.load_library()
+    rng = np.random.default_rng(7)
+    for world, vps in ((2, 16), (5, 8), (8, 16), (16, 16)):
+        hdr = np.zeros((world, 8 * world), np.uint64)
+        for q in range(world):
+            for o in range(world):
+                if o != q:
+                    hdr[q, 8 * o + 1:8 * o + 8] = rng.integers(0, 500, 7)
+            hdr[q, 0] = hdr[q, 1:].sum()
+        words = {sel: 1 + 6 * (vps * vps if bin(sel).count("1") == 1 else (vps if bin(sel).count("1") == 2 else 1)) for sel in range(1, 8)}
+        plans = []
+        for r in range(world):
+            out = [np.zeros(world, np.uint64) for _ in range(4)]
+            rc = lib.khr_mesh_halo_plan(world, r, vps, hdr.ctypes.data_as(C.c_void_p), *[o.ctypes.data_as(C.c_void_p) for o in out])
+            assert rc == 0
+            plans.append(out)
+        for r in range(world):
+            sc, sd, rcv, rd = plans[r]
+            assert int(sc[r]) == 0 and int(rcv[r]) == 0, "nobody asks itself"
+            assert np.array_equal(sd, np.concatenate([[0], np.cumsum(sc)[:-1]]).astype(np.uint64))
+            assert np.array_equal(rd, np.concatenate([[0], np.cumsum(rcv)[:-1]]).astype(np.uint64))
+            for q in range(world):
+                assert int(plans[q][0][r]) == int(rcv[q]), (world, q, r)
+                assert int(rcv[q]) == sum(int(hdr[r, 8 * q + sel]) * words[sel] for sel in range(1, 8))
+    # more ranks than the layout is built for is an error, not a silent truncation
+    hdr = np.zeros((17, 8 * 17), np.uint64)
+    out = [np.zeros(17, np.uint64) for _ in range(4)]
+    assert lib.khr_mesh_halo_plan(17, 0, 16, hdr.ctypes.data_as(C.c_void_p), *[o.ctypes.data_as(C.c_void_p) for o in out]) < 0

@@ -88,7 +88,8 @@ const Rccl& rccl() {
     bind(t.AllReduce, "ncclAllReduce");
     bind(t.Reduce, "ncclReduce");
     bind(t.Broadcast, "ncclBroadcast");
-    bind(t.AllToAllv, "ncclAllToAllv");
+    // (RCCL's extension; a library without it -- NCCL proper, an older transport stand-in -- keeps the all-gather form of the mesh halo)
+    t.AllToAllv = reinterpret_cast<decltype(t.AllToAllv)>(dlsym(lib, "ncclAllToAllv"));
     bind(t.GetErrorString, "ncclGetErrorString");
     return t;
   }();
@@ -298,6 +299,7 @@ kdist_handle* kdist_create(khr_ctx* ctx, const khr_sensor* sensor, int rank, int
     // (the compact form puts a header of 8 * world counts in front of the keys)
     const char* mh_mode = std::getenv("KDIST_MESH_HALO");
     h->mesh_compact = world_size <= 16 && !(mh_mode && std::string(mh_mode) == "records");
+    if (h->mesh_compact && h->exchange() && !h->emulate && rccl().AllToAllv == nullptr) h->mesh_compact = false;  // (no ncclAllToAllv in this library)
     const size_t req_words = static_cast<size_t>(mesh_req_cap) + KHR_MESH_HALO_REQ_HEADER_WORDS(W);
     h->req_send = h->alloc<uint64_t>(req_words);
     h->req_recv = h->alloc<uint64_t>(W * req_words);

@@ -35,6 +35,13 @@ with open(O + "/frames.txt", "w") as f:
     f.write("# every dispatch of three consecutive timed frames: start_us dur_us queue kernel\n")
     for r in rows[a:b + 1]:
         f.write("%9.1f %7.1f  q%s  %s\n" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Queue_Id", "?"), name(r)[:60]))
+with open(O + "/frames_all.txt", "w") as f:
+    f.write("# every dispatch of the timed region: start_us dur_us gap_to_prev_end_us queue kernel\n")
+    t0 = int(rows[timed[0]]["Start_Timestamp"]); pe = t0
+    for r in rows[timed[0]:]:
+        s_, e_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        f.write("%9.1f %7.1f %7.1f  q%s  %s\n" % ((s_ - t0) / 1e3, (e_ - s_) / 1e3, (s_ - pe) / 1e3, r.get("Queue_Id", "?"), name(r)[:60]))
+        pe = max(pe, e_)
 print(open(O + "/k_fuse_durations.txt").read())
 PY
 rm -rf $O/prof

@@ -43,6 +43,8 @@ struct BandPool {
   uint32_t* cursor;   // dynamic chunks drawn in this launch (zeroed by beginIntegrate)
   uint32_t* overflow; // records dropped for lack of chunks (cumulative)
   uint32_t n_chunks, n_static;
+  uint32_t* tail_q;     // k_tsdf: queue heads of the dynamically dealt tail of the item list (one per XCD, kTailQStride words apart); nullptr = static deal
+  uint32_t static_pct;  // k_tsdf: share of the list that is dealt statically
 };
 
 // ---- the in-band voxels of one wave round: colour blend, K likelihoods, arg-max label ------------------------------------

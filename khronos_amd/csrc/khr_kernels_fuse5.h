@@ -1,0 +1,452 @@
+// khr_kernels_fuse5.h — round 6: the per-voxel loop of hydra::ProjectiveIntegrator::updateMap (call active_window.cpp:210;
+// ASSUMPTIONS.md A.3 / A.4) as k_tsdf (voxel phase) + k_band5 (in-band voxels), written for INSTRUCTION COUNT and OCCUPANCY.
+//
+// What rounds 4 - 5 measured: a gfx950 wave issues one dependent instruction every ~9 clocks, so k_fuse
+// (168 VGPRs = 3 waves per SIMD, ~1650 instructions per 256-voxel item, two item states, ~140 spilled scalars) keeps the vector
+// pipes ~25 % busy and every memory-side rearrangement measured the same 70 - 78 us.  k_tsdf is the same arithmetic -- every
+// decision and value bit for bit (same expressions, same order) -- with the stream cut to what the update needs:
+//   * one item per wave, no second item state, no LDS record list: <= 64 / 80 VGPRs, 6 - 8 waves per SIMD cover each other's waits;
+//   * lane constants ((ix + 0.5) vs, (iz + 0.5) vs) computed once per launch, the z row of the rotation and every per-frame
+//     scalar in SGPRs, voxel addresses as ONE 32-bit lane offset + immediate z offsets (no 64-bit address VALU);
+//   * validity of a z-step as a 64-bit lane mask in scalar registers (no -1 encoding, no re-derivation in phase 2);
+//   * the lazy last_observed word of a z-step through the scalar cache, its (rare) write-out behind a scalar branch;
+//   * in-band voxels leave as 20-byte records {voxel, measurement weight, blend weight, u | mode, v} in the workgroup's chunked
+//     stream (BandPool) -- one LDS atomic per z-step that has any.
+// k_band5 consumes the records 64 per wave round (fuseBandRows' arithmetic bit for bit): every wave gets the same number of
+// NON-EMPTY rounds (each workgroup scans the chunk fills once), so the launch is one balanced sweep instead of two ragged ones.
+//
+// MODE (development, profiles/r06_fuse_sol.txt): 0 = the product; 1 = ALU only (no global loads / stores: range samples are
+// synthesised so that the update / in-band fractions match a c3 frame); 2 = memory only (the projection -- it IS the address
+// generation -- and the complete load / gather / store / record stream, decisions from the nearest sample, values moved).
+#pragma once
+#include "khr_kernels_fuse3.h"
+
+namespace khr {
+
+template <int ZSPLIT, bool EXACT, int WPW, int MINW, int MODE = 0>
+__global__ __launch_bounds__(64 * WPW, MINW) void k_tsdf(FuseArgs a, FuseList list, BandPool bp) {
+  constexpr int VPS = 16, NV = VPS * VPS * VPS, SL = VPS * VPS, PATCHES = SL / 64, ZR = VPS / ZSPLIT;
+  static_assert(ZR == 2 || ZR == 4, "bad z range");
+  __shared__ uint32_t s_q, s_fill;
+  __shared__ uint32_t s_chunk[kBandMaxLocal];
+  __shared__ uint32_t s_stat[WPW][2];
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int lane = static_cast<int>(threadIdx.x & 63);
+  if (a.gate != nullptr && *a.gate != 0u) return;  // speculative launch, and the frame has motion seeds (workgroup-uniform)
+  if (threadIdx.x == 0) { s_q = 0u; s_fill = 0u; }
+  if (threadIdx.x < kBandMaxLocal) s_chunk[threadIdx.x] = threadIdx.x == 0 ? blockIdx.x : kNoChunk;
+  __syncthreads();
+  const uint32_t nc0 = list.counts[0], nc1 = nc0 + list.counts[1], nc2 = nc1 + list.counts[2], n_items = nc2 + list.counts[3];
+  uint32_t n_upd = 0, n_band = 0;
+  // ---- lane constants ----
+  const float vs = a.vs;
+  const float xc = (static_cast<float>(lane & 15) + 0.5f) * vs;  // (ix + 0.5) vs of the lane's voxel column
+  const float zc = xc;                                           // lane l < 16 also holds (iz + 0.5) vs for iz = l (v_readlane)
+  const float fiy = static_cast<float>(lane >> 4);               // iy % 4
+  const uint32_t vo_lane = static_cast<uint32_t>(lane) * 4u;     // byte offset of the lane's voxel inside a 64-voxel group (f32 layers)
+  // ---- frame constants (scalar registers) ----
+  // (wave-uniform float results are vector instructions on gfx9: v_readfirstlane moves them into scalar registers for good)
+  auto sgpr = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); };
+  const float Wm1 = sgpr(static_cast<float>(a.W - 1)), Hm1 = sgpr(static_cast<float>(a.H - 1));
+  const uint32_t Hl = static_cast<uint32_t>(a.H - 1), Wl = static_cast<uint32_t>(a.W - 1);
+  const uint32_t W4 = static_cast<uint32_t>(a.W) * 4u;
+  const float fxfy = sgpr(a.fx * a.fy);
+  const float trunc = a.trunc, ntrunc = -a.trunc;
+  const float den = sgpr(trunc - a.dropoff_eps);
+  const float yden = sgpr(rcpRefined(den));
+  const float ndrop = -a.dropoff_eps;
+  const int dbg = MODE == 3 ? a.dbg : 0;  // MODE 3: run-time ablations (KHR_FUSE_DBG): 1 gathers from pixel 0, 2 no distance / weight loads,
+                                          // 4 no distance / weight stores, 8 no stamp words, 16 no record stores, 32 non-temporal voxel stream
+  const bool trk = a.with_tracking != 0 && !(dbg & 8);
+  const char* const range_b = reinterpret_cast<const char*>(a.range);
+  // Work distribution.  The list is most-expensive-first.  Its head [0, n_stat) is dealt statically: workgroup b owns positions first,
+  // first + grid, ... (every workgroup the same class mix; XCD-aware as in k_fuse) and its waves take them from an LDS counter.  A
+  // workgroup has only n_items / grid ~ 19 items, i.e. two full rounds of its 8 waves and a ragged third: with a fully static deal
+  // the average residency of a launch was 3.2 of 5 waves per SIMD (SQ_WAVE_CYCLES / duration, profiles/r06_fuse_sol.txt).  So the
+  // TAIL of the list -- the cheapest items -- is dealt dynamically from one queue head per XCD (a returning atomic costs ~1 us under
+  // load and a head retires ~88 of them per us: the tail's few thousand pulls are spread over 8 heads and hidden behind the item the
+  // wave is working on; a plain load tells a wave that its head has run dry without an atomic).
+  const uint32_t first = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const uint32_t n_stat = bp.tail_q == nullptr ? 0xffffffffu
+                                               : static_cast<uint32_t>((static_cast<uint64_t>(n_items) * (bp.static_pct & 255u) / 100u) / gridDim.x) * gridDim.x;
+  // static_pct bit 8: the head of the XCD the wave really runs on (HW_REG_XCC_ID), pulled with an atomic that is resolved in that XCD's
+  // L2 (no sc1: the pullers of a head share the L2 by construction) instead of a device-scope one that travels to the memory side
+  const bool l2_local = (bp.static_pct & 256u) != 0u;
+  const uint32_t xcd = l2_local ? (static_cast<uint32_t>(__builtin_amdgcn_s_getreg(20 | (3 << 11))) & 7u) : (blockIdx.x & 7u);
+  uint32_t* const tail_head = bp.tail_q + xcd * kTailQStride;
+  bool in_tail = false;
+  auto pull = [&]() -> uint32_t {
+    if (!in_tail) {
+      uint32_t j = 0u;
+      if (lane == 0) j = atomicAdd(&s_q, 1u);
+      j = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(j)));
+      const uint32_t pos = first + gridDim.x * j;
+      if (pos < n_stat) return pos;
+      if (n_stat == 0xffffffffu) return pos;
+      in_tail = true;
+    }
+    uint32_t t = l2_local ? __hip_atomic_load(tail_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                          : __hip_atomic_load(tail_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(t)));
+    if (n_stat + xcd + 8u * t >= n_items) return 0xffffffffu;
+    if (lane == 0) t = l2_local ? __hip_atomic_fetch_add(tail_head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                : __hip_atomic_fetch_add(tail_head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(t)));
+    return n_stat + xcd + 8u * t;
+  };
+  auto descOf = [&](uint32_t i) -> uint4 {
+    const DescK la = (DescK)list.a, lb = (DescK)list.b;
+    const DescK arr = i < nc1 ? la : lb;
+    const uint32_t idx = i < nc0 ? i : (i < nc1 ? list.cap - 1u - (i - nc0) : (i < nc2 ? i - nc1 : list.cap - 1u - (i - nc2)));
+    const u4v d = arr[idx];
+    return make_uint4(d.x, d.y, d.z, d.w);
+  };
+  uint32_t item = pull();
+  uint4 desc = make_uint4(0u, 0u, 0u, 0u);
+  if (item < n_items) desc = descOf(item);
+  while (item < n_items) {
+    const uint32_t item_next = pull();
+    uint4 d_next = make_uint4(0u, 0u, 0u, 0u);
+    if (item_next < n_items) d_next = descOf(item_next);
+    // ---- item geometry ----
+    const uint32_t slot = desc.x & 0xffffffu;
+    const uint32_t sbi = desc.x >> 24;
+    const uint32_t patch = sbi % PATCHES;
+    const uint32_t z0 = (sbi / PATCHES) * ZR;
+    const float bs = a.bs;
+    const float ox = static_cast<float>(static_cast<int>(desc.y)) * bs, oy = static_cast<float>(static_cast<int>(desc.z)) * bs;
+    const float oz = static_cast<float>(static_cast<int>(desc.w)) * bs;
+    const float px = ox + xc;
+    const float py = oy + ((static_cast<float>(patch * 4u) + fiy) + 0.5f) * vs;
+    float pxy[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pxy[c] = a.R[3 * c] * px + a.R[3 * c + 1] * py;
+    // the item's first 64-voxel group; z-step k is k * SL voxels further (immediate offsets)
+    const size_t g0 = static_cast<size_t>(slot) * NV + static_cast<size_t>(z0 * SL + patch * 64u);
+    const char* const dist_g = reinterpret_cast<const char*>(a.dist + g0);
+    const char* const wgt_g = reinterpret_cast<const char*>(a.weight + g0);
+    // lazily stored last_observed: the {bits, stamp} words of the item's z-steps, through the scalar cache
+    const size_t w0 = static_cast<size_t>(slot) * (NV / 64) + static_cast<size_t>(z0 * PATCHES + patch);
+    // (ONE vector load: lane l holds dword l % 4 of the word of z-step (l / 4) % ZR; read back with v_readlane where a z-step updates)
+    int obsw = 0;
+    if (trk && MODE != 1) {
+      const uint32_t l = static_cast<uint32_t>(lane) & (4u * ZR - 1u);
+      obsw = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(a.obs + w0) + ((l >> 2) * static_cast<uint32_t>(PATCHES) * 16u + (l & 3u) * 4u));
+    }
+    // ---- phase 1: projection of the item's ZR voxels per lane; all loads issued ----
+    float uu[ZR], vv[ZR], zz[ZR], dd[ZR], ww[ZR];
+    f2u ra[ZR], rb[ZR];
+    unsigned long long okm[ZR];
+#pragma unroll
+    for (int k = 0; k < ZR; ++k) {
+      const float pz = oz + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zc), static_cast<int>(z0) + k));
+      float pc[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pc[c] = (pxy[c] + a.R[3 * c + 2] * pz) + a.t[c];
+      const float depth = pc[2];
+      // pc2 > 0 && !(range < min || range > max), range = depth (range_mode 0): min_range > 0, so the first test is implied
+      bool ok = depth > 0.f && !(depth < a.min_range || depth > a.max_range);
+      const float yz = rcpRefined(depth);
+      const float u = divExact(pc[0] * a.fx, depth, yz) + a.cx;
+      const float v = divExact(pc[1] * a.fy, depth, yz) + a.cy;
+      ok = ok && (fminf(fminf(u, v), fminf(Wm1 - u, Hm1 - v)) >= 0.f);
+      const float uc = ok ? u : 0.f, vc = ok ? v : 0.f;
+      const uint32_t u0 = static_cast<uint32_t>(static_cast<int>(uc)), v0 = static_cast<uint32_t>(static_cast<int>(vc));
+      const uint32_t v1 = min(v0 + 1u, Hl);
+      const uint32_t o0 = __umul24(v0, W4) + u0 * 4u, o1 = __umul24(v1, W4) + u0 * 4u;
+      if (MODE == 3) {
+        ra[k] = *reinterpret_cast<const f2u*>(range_b + ((dbg & 1) ? 0u : o0));
+        rb[k] = *reinterpret_cast<const f2u*>(range_b + ((dbg & 1) ? 0u : o1));
+        if (dbg & 1) { ra[k] = f2u{depth + 2.f * trunc + ra[k].x * 1e-9f, depth + 2.f * trunc}; rb[k] = ra[k]; }
+        dd[k] = 0.01f;
+        ww[k] = 1.f;
+        if (!(dbg & 2)) {
+          const float* const dp = reinterpret_cast<const float*>(dist_g + (vo_lane + static_cast<uint32_t>(k) * (SL * 4u)));
+          const float* const wp = reinterpret_cast<const float*>(wgt_g + (vo_lane + static_cast<uint32_t>(k) * (SL * 4u)));
+          dd[k] = (dbg & 32) ? __builtin_nontemporal_load(dp) : *dp;
+          ww[k] = (dbg & 32) ? __builtin_nontemporal_load(wp) : *wp;
+        }
+      } else if (MODE != 1) {
+        ra[k] = *reinterpret_cast<const f2u*>(range_b + o0);
+        rb[k] = *reinterpret_cast<const f2u*>(range_b + o1);
+        dd[k] = *reinterpret_cast<const float*>(dist_g + (vo_lane + static_cast<uint32_t>(k) * (SL * 4u)));
+        ww[k] = *reinterpret_cast<const float*>(wgt_g + (vo_lane + static_cast<uint32_t>(k) * (SL * 4u)));
+      } else {
+        // synthetic samples: 6.6 % of the voxels in the band, 66 % in front of it, the rest behind (a c3 frame's fractions)
+        const uint32_t h = (static_cast<uint32_t>(lane) * 37u + item * 11u + static_cast<uint32_t>(k) * 71u) & 255u;
+        const float r = depth + trunc * (h < 17u ? 0.3f : (h < 186u ? 2.f : -2.f));
+        ra[k] = f2u{r, r};
+        rb[k] = f2u{r, r};
+        dd[k] = 0.01f;
+        ww[k] = 1.f + static_cast<float>(o0 + o1) * 1e-9f;
+      }
+      uu[k] = uc;
+      vv[k] = vc;
+      zz[k] = depth;
+      okm[k] = __builtin_amdgcn_ballot_w64(ok);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- phase 2: measurement, decisions, read-modify-write, in-band records ----
+    bool touched = false, wrote_neg = false;
+    uint32_t item_band = 0u;
+#pragma unroll
+    for (int k = 0; k < ZR; ++k) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (okm[k] == 0ull) continue;
+      const bool ok1 = ((okm[k] >> static_cast<uint32_t>(lane)) & 1ull) != 0ull;
+      const float uc = uu[k], vc = vv[k], depth = zz[k];
+      const float d_old = dd[k], w_old = ww[k];
+      bool ok, in_band, use_nearest;
+      float sdf, w, d_new, w_new;
+      if (MODE == 2) {
+        sdf = ra[k].x - depth;
+        ok = ok1 && !(sdf < ntrunc);
+        in_band = ok && (fabsf(sdf) < trunc);
+        use_nearest = false;
+        w = rb[k].x;
+        d_new = sdf;
+        w_new = w_old + 1.f;
+      } else {
+        const uint32_t u0 = static_cast<uint32_t>(static_cast<int>(uc));
+        const float du = __builtin_amdgcn_fractf(uc), dv = __builtin_amdgcn_fractf(vc);
+        const bool last_col = u0 >= Wl;
+        const float r0 = ra[k].x, r1 = rb[k].x, r2 = last_col ? ra[k].x : ra[k].y, r3 = last_col ? rb[k].x : rb[k].y;
+        const float mn = fminf(fminf(r0, r1), fminf(r2, r3));
+        const float mx = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+        use_nearest = mx - mn > a.adaptive_diff;  // (interpolation_method adaptive: the reference default)
+        const bool hi_u = du >= 0.5f, hi_v = dv >= 0.5f;
+        const float r_near = hi_u ? (hi_v ? r3 : r2) : (hi_v ? r1 : r0);
+        const float omu = 1.f - du, omv = 1.f - dv;
+        const float w0b = omu * omv, w1b = omu * dv, w2b = du * omv, w3b = du * dv;
+        const float r_bil = ((w0b * r0 + w1b * r1) + w2b * r2) + w3b * r3;
+        const float dist_surface = use_nearest ? r_near : r_bil;
+        ok = ok1 && (dist_surface >= a.min_range) && !(dist_surface > a.max_range);
+        sdf = dist_surface - depth;
+        ok = ok && !(sdf < ntrunc);
+        in_band = ok && (fabsf(sdf) < trunc);
+        // dynamic mask (object_integrator.cpp:70-73): only frames with painted clusters, only z-steps with in-band voxels
+        if (__builtin_expect(a.use_mask && __builtin_amdgcn_ballot_w64(in_band) != 0ull, 0)) {
+          int best;
+          if (use_nearest) {
+            best = (hi_u ? 2 : 0) + (hi_v ? 1 : 0);
+          } else {
+            best = 0;
+            float bw = w0b;
+            if (w1b > bw) { bw = w1b; best = 1; }
+            if (w2b > bw) { bw = w2b; best = 2; }
+            if (w3b > bw) { bw = w3b; best = 3; }
+          }
+          const uint32_t v0 = static_cast<uint32_t>(static_cast<int>(vc));
+          const uint32_t v1 = min(v0 + 1u, Hl);
+          const uint32_t o0 = v0 * W4 + u0 * 4u, o1 = v1 * W4 + u0 * 4u;
+          const uint32_t uo = ((best & 2) && !last_col) ? 4u : 0u;
+          const uint32_t bo = ((best & 1) ? o1 : o0) + uo;
+          if (in_band && *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.dyn) + bo) != 0) {
+            ok = false;
+            in_band = false;
+          }
+        }
+        if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
+        // measurement weight (computeWeight): fx fy vs^2 / z^4, linear drop-off behind the surface
+        if (EXACT) {
+          const float qd = divExact(vs, depth, rcpRefined(depth));
+          w = fxfy * (qd * qd);
+          const float z2 = depth * depth;
+          w = divExact(w, z2, rcpRefined(z2));
+          if (sdf < ndrop) w = fmaxf(w * divExact(trunc + sdf, den, yden), 0.f);
+        } else {
+          const float yz = rcpRefined(depth);
+          const float qd = vs * yz;
+          w = fxfy * (qd * qd);
+          w = w * (yz * yz);
+          if (sdf < ndrop) w = fmaxf(w * ((trunc + sdf) * yden), 0.f);
+        }
+        ok = ok && (w > 0.f);
+        in_band = in_band && ok;
+        const float sdf_c = fmaxf(fminf(trunc, sdf), ntrunc);
+        const float tot = w_old + w;
+        if (EXACT) {
+          d_new = divExact(d_old * w_old + sdf_c * w, tot, rcpRefined(tot));
+        } else {
+          d_new = __builtin_fmaf(d_old, w_old, sdf_c * w) * __builtin_amdgcn_rcpf(tot);
+        }
+        w_new = fminf(tot, a.max_weight);
+      }
+      const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(ok);
+      if (m_ok == 0ull) continue;
+      // whole 256-byte segments (lanes without an update write back what they loaded: a partly written line costs the memory
+      // path three times a full one, tools/ubench/band_patterns.hip)
+      if (MODE != 1 && !(dbg & 4)) {
+        float* const dp = reinterpret_cast<float*>(const_cast<char*>(dist_g) + (vo_lane + static_cast<uint32_t>(k) * (SL * 4u)));
+        float* const wp = reinterpret_cast<float*>(const_cast<char*>(wgt_g) + (vo_lane + static_cast<uint32_t>(k) * (SL * 4u)));
+        if (dbg & 32) {
+          __builtin_nontemporal_store(ok ? d_new : d_old, dp);
+          __builtin_nontemporal_store(ok ? w_new : w_old, wp);
+        } else {
+          *dp = ok ? d_new : d_old;
+          *wp = ok ? w_new : w_old;
+        }
+      }
+      n_upd += static_cast<uint32_t>(__popcll(m_ok));
+      touched = true;
+      wrote_neg = wrote_neg || (__builtin_amdgcn_ballot_w64(ok && d_new < 0.f) != 0ull);
+      if (trk && MODE != 1) {
+        // stamp, lazily (DevMap::obs): an update at a NEW stamp writes out the stamp of the voxels it leaves behind
+        // (bits0 & ~m_ok; usually none: the observed set moves slowly) and replaces the word; at the same stamp it adds its bits
+        const uint64_t bits0 = static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(obsw, 4 * k))) |
+                               (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(obsw, 4 * k + 1))) << 32);
+        const uint64_t stamp0 = static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(obsw, 4 * k + 2))) |
+                                (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(obsw, 4 * k + 3))) << 32);
+        const bool same = stamp0 == a.stamp;
+        const uint64_t mat = same ? 0ull : (bits0 & ~m_ok);
+        if (mat != 0ull) {
+          if (((mat >> static_cast<uint32_t>(lane)) & 1ull) != 0ull)
+            *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(a.last_obs + g0) + (static_cast<uint32_t>(lane) * 8u + static_cast<uint32_t>(k) * (SL * 8u))) = stamp0;
+        }
+        if (lane == 0) a.obs[w0 + k * PATCHES] = make_ulonglong2(same ? (bits0 | m_ok) : m_ok, a.stamp);
+      }
+      const unsigned long long m_band = __builtin_amdgcn_ballot_w64(in_band);
+      if (m_band != 0ull) {
+        const uint32_t nb = static_cast<uint32_t>(__popcll(m_band));
+        n_band += nb;
+        item_band += nb;
+        // nb consecutive records of the workgroup's stream
+        uint32_t p0 = 0u;
+        if (lane == 0) p0 = atomicAdd(&s_fill, nb);
+        p0 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(p0)));
+        if (in_band) {
+          const uint32_t pos = p0 + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m_band >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m_band), 0u));
+          const uint32_t ck = pos / kBandChunk, off = pos % kBandChunk;
+          uint32_t id = kDropChunk;
+          if (ck < kBandMaxLocal) {
+            if (off == 0u && ck > 0u) {  // this record opens the workgroup's ck-th chunk: draw it, publish its id
+              uint32_t nid = bp.n_static + atomicAdd(bp.cursor, 1u);
+              if (nid >= bp.n_chunks) nid = kDropChunk;
+              __atomic_store_n(&s_chunk[ck], nid, __ATOMIC_RELEASE);
+            }
+            while ((id = __atomic_load_n(&s_chunk[ck], __ATOMIC_ACQUIRE)) == kNoChunk) __builtin_amdgcn_s_sleep(1);
+          }
+          if (id != kDropChunk) {
+            if (MODE != 1 && !(dbg & 16)) {
+              uint32_t* const rec = bp.rec + static_cast<size_t>(id) * (kBandFields * kBandChunk) + off;
+              rec[0] = slot * static_cast<uint32_t>(NV) + (z0 + static_cast<uint32_t>(k)) * SL + patch * 64u + static_cast<uint32_t>(lane);
+              rec[kBandChunk] = __float_as_uint(w);
+              rec[2 * kBandChunk] = __float_as_uint(a.blend_pre ? w_old : w_new);
+              rec[3 * kBandChunk] = (__float_as_uint(uc) & 0x7fffffffu) | (use_nearest ? 0x80000000u : 0u);
+              rec[4 * kBandChunk] = __float_as_uint(vc);
+            }
+          } else {
+            atomicAdd(bp.overflow, 1u);
+          }
+        }
+      }
+    }
+    // the item's record: {touched, wrote a negative distance, in-band count}; folded into the block flags by k_fuse_fold /
+    // k_tracking_select (a uniform store: one request, no atomic on the voxel path)
+    {
+      const uint32_t recw = min(item_band, static_cast<uint32_t>(kItemBandMask)) | (touched ? kItemTouched : 0u) | (wrote_neg ? kItemNeg : 0u);
+      a.blk_band[static_cast<size_t>(slot) * kBandSlots + (sbi & (kBandSlots - 1))] = static_cast<uint16_t>(recw);
+    }
+    item = item_next;
+    desc = d_next;
+  }
+  if (lane == 0) {
+    s_stat[wave][0] = n_upd;
+    s_stat[wave][1] = n_band;
+  }
+  __syncthreads();
+  // fill of the workgroup's chunks for k_band5 (its static one always: the band kernel reads every static chunk's count)
+  {
+    const uint32_t total = s_fill;
+    if (threadIdx.x < kBandMaxLocal) {
+      const uint32_t ck = threadIdx.x, begin = ck * kBandChunk;
+      if (ck == 0u || begin < total) {
+        const uint32_t id = s_chunk[ck];
+        if (id != kNoChunk && id != kDropChunk) bp.chunk_n[id] = total > begin ? min(kBandChunk, total - begin) : 0u;
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    uint32_t su = 0u, sb = 0u;
+#pragma unroll
+    for (int w = 0; w < WPW; ++w) {
+      su += s_stat[w][0];
+      sb += s_stat[w][1];
+    }
+    if (su | sb) {
+      a.wg_stats[2 * blockIdx.x] += su;
+      a.wg_stats[2 * blockIdx.x + 1] += sb;
+    }
+  }
+}
+
+// ---- the in-band voxels of a k_tsdf launch: every wave the same number of NON-EMPTY 64-record rounds -------------------------------
+// The chunks' fills differ (a workgroup's stream ends somewhere inside its last chunk, most dynamic chunks are full), so dealing
+// (chunk, round) pairs blindly gave k_band3 two ragged sweeps of ~15 us.  Here every workgroup first turns the chunk fills into the
+// prefix sum of their round counts (one load per thread and 256 chunks, a wave scan, 16 KB of LDS), then wave w of W takes the rounds
+// [w U / W, (w + 1) U / W) of the U rounds that exist and finds each one's chunk by bisection in LDS.
+constexpr uint32_t kBand5MaxChunks = 4096u;
+template <int WPW, int MINW>
+__global__ __launch_bounds__(64 * WPW, MINW) void k_band5(FuseArgs a, BandPool bp) {
+  __shared__ uint32_t s_rec[WPW][2][64];  // per wave: {update?, empty?, label} of a record (part A -> part B) | label out (B -> A)
+  __shared__ uint32_t s_pre[kBand5MaxChunks + 1];
+  __shared__ uint32_t s_wsum[WPW];
+  if (a.gate != nullptr && *a.gate != 0u) return;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int lane = static_cast<int>(threadIdx.x & 63);
+  const uint32_t n_chunks = min(min(bp.n_chunks, bp.n_static + *bp.cursor), kBand5MaxChunks);
+  constexpr uint32_t T = 64u * WPW;
+  const uint32_t per = (n_chunks + T - 1u) / T;  // chunks per thread (consecutive)
+  // ---- rounds per chunk -> exclusive prefix in LDS ----
+  uint32_t mine = 0u;
+  const uint32_t c0 = threadIdx.x * per;
+  for (uint32_t i = 0; i < per; ++i) {
+    const uint32_t c = c0 + i;
+    const uint32_t r = c < n_chunks ? (min(bp.chunk_n[c], kBandChunk) + 63u) / 64u : 0u;
+    if (c < n_chunks) s_pre[c] = mine;  // (thread-local exclusive prefix; the thread's base is added below)
+    mine += r;
+  }
+  uint32_t incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = static_cast<uint32_t>(__shfl_up(static_cast<int>(incl), o));
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) s_wsum[wave] = incl;
+  __syncthreads();
+  uint32_t base = incl - mine, total = 0u;
+#pragma unroll
+  for (int w = 0; w < WPW; ++w) {
+    const uint32_t ws = s_wsum[w];
+    if (w < wave) base += ws;
+    total += ws;
+  }
+  for (uint32_t i = 0; i < per; ++i)
+    if (c0 + i < n_chunks) s_pre[c0 + i] += base;
+  if (threadIdx.x == 0) s_pre[n_chunks] = total;
+  __syncthreads();
+  // ---- this wave's rounds ----
+  const uint32_t gw = blockIdx.x * WPW + static_cast<uint32_t>(wave), nw = gridDim.x * WPW;
+  const uint32_t u_begin = static_cast<uint32_t>((static_cast<uint64_t>(gw) * total) / nw);
+  const uint32_t u_end = static_cast<uint32_t>((static_cast<uint64_t>(gw + 1u) * total) / nw);
+  FuseArgsK ka = (FuseArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+  uint32_t chunk = 0u;
+  if (u_begin < u_end) {  // largest c with s_pre[c] <= u_begin (wave-uniform bisection)
+    uint32_t lo = 0u, hi = n_chunks;
+    while (hi - lo > 1u) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (s_pre[mid] <= u_begin) lo = mid; else hi = mid;
+    }
+    chunk = lo;
+  }
+  for (uint32_t u = u_begin; u < u_end; ++u) {
+    while (s_pre[chunk + 1u] <= u) ++chunk;  // (chunks without records have equal prefixes and are stepped over)
+    const uint32_t round = u - s_pre[chunk];
+    const uint32_t cn = min(bp.chunk_n[chunk], kBandChunk);
+    const uint32_t n_here = min(64u, cn - round * 64u);
+    bandRound<8>(ka, &s_rec[wave][0][0], bp.rec + static_cast<size_t>(chunk) * (kBandFields * kBandChunk) + round * 64u, n_here, lane);
+  }
+}
+
+}  // namespace khr

@@ -32,7 +32,7 @@
 #include "khr_kernels_aux.h"
 #include "khr_kernels_fusion.h"
 #include "khr_kernels_fuse.h"
-#include "khr_kernels_fuse3.h"
+#include "khr_kernels_fuse5.h"
 #include "khr_kernels_objects.h"
 
 using namespace khr;
@@ -149,6 +149,7 @@ struct khr_ctx {
   uint32_t* d_band_rec = nullptr;
   uint32_t* d_band_n = nullptr;
   uint32_t band_chunks = 0;
+  int n_cus = 256, fuse5_grid = 0, band5_grid = 0, fuse5_zs = 0;  // per context (= per device): the persistent grids of k_tsdf / the band kernel
   unsigned char* d_fuse_sink = nullptr;  // k_fuse: one 256-byte sink line per wave (kFuseStatSlots workgroups x 16 waves)
   uint32_t* d_pix_scratch = nullptr;  // khr_pixel_iou: mask image + counters (allocated on first use)
   size_t pix_words = 0;
@@ -578,6 +579,7 @@ int kFuseVer = 1;       // env KHR_FUSE_V: 1 = k_fuse (default: per-wave softwar
                         // SIMD with the in-band voxels as record lists; parity-green, measured slower than k_fuse in the driver's command), 1 = k_fuse (per-wave software pipeline), 2 = k_fuse2 (one item per wave)
 int kFuse3Waves = 0;    // env KHR_FUSE3_WAVES: resident waves per CU of k_fuse3's persistent grid (0 = what the occupancy query allows)
 int kBand3Waves = 0;    // env KHR_BAND3_WAVES: the same for k_band3
+int kFuse5Mode = 0;   // env KHR_FUSE5_MODE: 1 / 2 = the ALU-only / memory-only instantiations of k_tsdf (speed-of-light decomposition; development)
 int kFuse3Occ = 0;      // env KHR_FUSE3_OCC: waves per SIMD k_fuse3 is compiled for (0 = 5 with 4 z ranges per patch, 8 with 8)
 int kTickUnion = 1;     // env KHR_TICK_UNION: khr_tick_integrate updates with ONE launch for all cameras of the tick (tickUnion)
 int kFuseMulti = 1;     // env KHR_FUSE_MULTI: khr_integrate_shared_batch integrates all frames of a batch in one launch (k_fuse2 MULTI)
@@ -804,6 +806,10 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   auto* c = new khr_ctx();
   c->cfg = *cfg;
   c->device = cfg->device;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
+  }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return fail(KHR_EDEVICE, "hipStreamCreate failed");
@@ -879,6 +885,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   if (std::getenv("KHR_FUSE_V")) kFuseVer = std::atoi(std::getenv("KHR_FUSE_V"));
   if (std::getenv("KHR_FUSE3_WAVES")) kFuse3Waves = std::atoi(std::getenv("KHR_FUSE3_WAVES"));
   if (std::getenv("KHR_BAND3_WAVES")) kBand3Waves = std::atoi(std::getenv("KHR_BAND3_WAVES"));
+  if (std::getenv("KHR_FUSE5_MODE")) kFuse5Mode = std::atoi(std::getenv("KHR_FUSE5_MODE"));
   if (std::getenv("KHR_FUSE3_OCC")) kFuse3Occ = std::atoi(std::getenv("KHR_FUSE3_OCC"));
   if (std::getenv("KHR_NO_EARLY_INGEST")) c->early_ingest = false;
 
@@ -913,6 +920,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &m.obs, cfg->with_tracking ? cap * (nv / 64) : 1, false));
   A(devAlloc(c, &m.free_slots, cap, false));
   A(devAlloc(c, &m.counters, C_COUNT));
+  A(devAlloc(c, &m.tail_q, 8 * kTailQStride));
   A(devAlloc(c, &m.stats, S_COUNT));
   A(devAlloc(c, &m.mesh_desc, cap));
   A(devAlloc(c, &c->d_work, cap));
@@ -1591,10 +1599,83 @@ static int integrateUpdate3(khr_ctx* c, const FrameSlot& s, const FuseArgs& a, c
     hipMemsetAsync(c->d_band_n, 0, static_cast<size_t>(n) * 4u, c->stream);
     c->band_chunks = n;
   }
-  BandPool bp{c->d_band_rec, c->d_band_n, &c->m.counters[C_BAND_CURSOR], &c->m.counters[C_BAND_OVERFLOW], c->band_chunks, static_cast<uint32_t>(grid)};
+  BandPool bp{c->d_band_rec, c->d_band_n, &c->m.counters[C_BAND_CURSOR], &c->m.counters[C_BAND_OVERFLOW], c->band_chunks, static_cast<uint32_t>(grid), nullptr, 100u};
   pick([&](auto kern) { KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(64 * WPW), a, list, bp); });
   if (!fused) KHR_LAUNCH_TIMED(7, (&k_band3<BW, 5>), dim3(grid_b), dim3(64 * BW), a, bp);
   return KHR_OK;
+}
+
+// k_tsdf + band kernel (khr_kernels_fuse5.h, round 6): the update of a 16^3-voxel map with the reference's default integrator switches
+// and whole-line likelihood rows.  Returns 1 when the call is not one it takes (the caller falls back to k_fuse).
+static int ensureBandPool(khr_ctx* c, const FrameSlot& s, int grid) {
+  // record pool: one static chunk per workgroup + a bound on the in-band volume of a frame -- the voxels within the truncation
+  // distance of the surface along the view rays fill at most (solid angle) x max_range^2 x 2 truncation / voxel^3; x 1.5 for the
+  // lattice and the drop-off at the band's edge
+  const khr_sensor& sen = s.sensor;
+  const double omega = (static_cast<double>(sen.width) / sen.fx) * (static_cast<double>(sen.height) / sen.fy);
+  const double vol = omega * static_cast<double>(sen.max_range) * sen.max_range * 2.0 * c->p.trunc;
+  const double recs = 1.5 * vol / (static_cast<double>(c->p.vs) * c->p.vs * c->p.vs);
+  const uint64_t want64 = static_cast<uint64_t>(std::max(grid, kFuseStatSlots)) + static_cast<uint64_t>(recs / kBandChunk) + 64u;
+  if (want64 > (1u << 17)) return 1;  // (2.7 GB of records: not a frame this path is meant for)
+  const uint32_t want = static_cast<uint32_t>(want64);
+  if (want > c->band_chunks) {
+    // grow-only; happens on the first frames of a context (hipMalloc / hipFree wait for the device)
+    if (c->d_band_rec) { hipStreamSynchronize(c->stream); hipFree(c->d_band_rec); hipFree(c->d_band_n); c->d_band_rec = nullptr; c->d_band_n = nullptr; c->band_chunks = 0; }
+    const uint32_t n = want + want / 4;
+    if (hipMalloc(reinterpret_cast<void**>(&c->d_band_rec), static_cast<size_t>(n) * kBandFields * kBandChunk * 4u) != hipSuccess) { c->d_band_rec = nullptr; return 1; }
+    if (hipMalloc(reinterpret_cast<void**>(&c->d_band_n), static_cast<size_t>(n) * 4u) != hipSuccess) { hipFree(c->d_band_rec); c->d_band_rec = nullptr; c->d_band_n = nullptr; return 1; }
+    hipMemsetAsync(c->d_band_n, 0, static_cast<size_t>(n) * 4u, c->stream);
+    c->band_chunks = n;
+  }
+  return KHR_OK;
+}
+
+static int integrateUpdate5(khr_ctx* c, const FrameSlot& s, const FuseArgs& a, const FuseList& list, bool exact, int zs) {
+  static const int shape = std::getenv("KHR_FUSE5_SHAPE") ? std::atoi(std::getenv("KHR_FUSE5_SHAPE")) : 0;
+  auto body = [&](auto wpw_c, auto occ_c) -> int {
+  constexpr int WPW = decltype(wpw_c)::value, OCC = decltype(occ_c)::value;
+  constexpr int BW = 4;
+  auto gridOf = [&](const void* kern, int wpw, int want_waves) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * wpw, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (want_waves > 0) per_cu = std::max(1, std::min(per_cu, want_waves / wpw));
+    return std::max(8, std::min(kFuseStatSlots, per_cu * c->n_cus) / 8 * 8);
+  };
+  auto pick = [&](auto run) {
+    if (zs == 8) {  // (items of 64 x 2 voxels: small frames, shards of a rig)
+      if (exact) run(&k_tsdf<8, true, 8, 6, 0>);
+      else run(&k_tsdf<8, false, 8, 6, 0>);
+    } else if (kFuse5Mode == 1) run(&k_tsdf<4, true, WPW, OCC, 1>);
+    else if (kFuse5Mode == 2) run(&k_tsdf<4, true, WPW, OCC, 2>);
+    else if (kFuse5Mode == 3) run(&k_tsdf<4, true, WPW, OCC, 3>);
+    else if (exact) run(&k_tsdf<4, true, WPW, OCC, 0>);
+    else run(&k_tsdf<4, false, WPW, OCC, 0>);
+  };
+  if (c->fuse5_grid == 0 || c->fuse5_zs != zs) {
+    c->fuse5_zs = zs;
+    pick([&](auto kern) { c->fuse5_grid = gridOf(reinterpret_cast<const void*>(kern), zs == 8 ? 8 : WPW, kFuse3Waves); });
+    c->band5_grid = gridOf(reinterpret_cast<const void*>(&k_band5<BW, 5>), BW, kBand3Waves);
+    if (std::getenv("KHR_VERBOSE")) std::fprintf(stderr, "[khr] k_tsdf: %d workgroups of %d waves; band: %d of %d\n", c->fuse5_grid, WPW, c->band5_grid, BW);
+  }
+  if (int rc = ensureBandPool(c, s, c->fuse5_grid)) return rc;
+  static const int tail_pct = std::getenv("KHR_FUSE5_STATIC") ? std::atoi(std::getenv("KHR_FUSE5_STATIC")) : 100;
+  BandPool bp{c->d_band_rec, c->d_band_n, &c->m.counters[C_BAND_CURSOR], &c->m.counters[C_BAND_OVERFLOW], c->band_chunks, static_cast<uint32_t>(c->fuse5_grid),
+              (tail_pct & 255) >= 100 ? nullptr : c->m.tail_q, static_cast<uint32_t>(std::max(0, tail_pct))};
+  const int grid = c->fuse5_grid;
+  pick([&](auto kern) { KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(64 * (zs == 8 ? 8 : WPW)), a, list, bp); });
+  static const bool band3 = std::getenv("KHR_BAND_V3") != nullptr;  // A/B: the round-5 band kernel
+  static const bool band_occ4 = std::getenv("KHR_BAND5_OCC4") != nullptr;
+  if (kFuse5Mode == 1) return KHR_OK;
+  if (band3 || bp.n_static + 1024u > kBand5MaxChunks) KHR_LAUNCH_TIMED(7, (&k_band3<BW, 5>), dim3(c->band5_grid), dim3(64 * BW), a, bp);
+  else if (band_occ4) KHR_LAUNCH_TIMED(7, (&k_band5<BW, 4>), dim3(c->band5_grid * 4 / 5), dim3(64 * BW), a, bp);
+  else KHR_LAUNCH_TIMED(7, (&k_band5<BW, 5>), dim3(c->band5_grid), dim3(64 * BW), a, bp);
+  return KHR_OK;
+  };
+  using std::integral_constant;
+  if (shape == 1) return body(integral_constant<int, 16>(), integral_constant<int, 4>());  // one 16-wave workgroup per CU, <= 128 VGPRs
+  if (shape == 2) return body(integral_constant<int, 10>(), integral_constant<int, 5>());  // two 10-wave workgroups per CU
+  if (shape == 3) return body(integral_constant<int, 12>(), integral_constant<int, 6>());  // two 12-wave workgroups per CU, <= 80 VGPRs
+  return body(integral_constant<int, 8>(), integral_constant<int, 5>());
 }
 
 static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allocate_blocks, int use_mask,
@@ -1634,7 +1715,7 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
       a.gate = gate;
       constexpr int WD = kFuseWpwDefault;
       if (kFuseVer >= 3 && V == 16 && defcfg && fuseBandRowsOk(a.KS, a.sem_mode, a.do_sem, a.has_color) && c->m.capacity <= (1u << 20) &&
-          integrateUpdate3(c, s, a, list, exact, ZS) == KHR_OK) {
+          (kFuseVer == 5 ? integrateUpdate5(c, s, a, list, exact, ZS) : integrateUpdate3(c, s, a, list, exact, ZS)) == KHR_OK) {
         // k_fuse3 + k_band3 took the call
         if (c->defer_fold) c->fold_pending = true;
         else hipLaunchKernelGGL(k_fuse_fold, dim3((c->m.capacity + 255) / 256), dim3(256), 0, c->stream, m.blk_flags, m.blk_band,

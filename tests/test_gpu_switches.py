@@ -112,7 +112,7 @@ def test_mesh_switches_change_the_mesh():
 def test_switches_in_the_update_kernel_variants(monkeypatch):
     """k_fuse3 + k_band3 and the fused-consumption form (KHR_FUSE_V = 3 / 4, khr_kernels_fuse3.h) carry the blend switch in their
     record lists; both must equal the oracle too"""
-    for ver in ("3", "4"):
+    for ver in ("3", "4", "5"):
         monkeypatch.setenv("KHR_FUSE_V", ver)
         for blend in (0, 1):
             _run(6, color_blend_weight=blend, exact_arithmetic=1)

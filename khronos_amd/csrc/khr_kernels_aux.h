@@ -251,7 +251,8 @@ __global__ __launch_bounds__(256) void k_md_boundary_insert(const uint64_t* __re
 __global__ __launch_bounds__(256) void k_md_compact(VoxTable t, uint64_t* __restrict__ list_keys,
                                                    uint32_t* __restrict__ list_counts, uint32_t* __restrict__ n_out,
                                                    uint32_t cap, int32_t* __restrict__ zero_per_entry,
-                                                   int32_t* __restrict__ zero_per_entry2 = nullptr) {
+                                                   int32_t* __restrict__ zero_per_entry2 = nullptr,
+                                                   unsigned long long* __restrict__ zero64 = nullptr) {
   // one list append per WORKGROUP (workgroup scan): the entries are scattered over the table, so nearly every wave has one
   // or two, and an append per wave was ~1000 atomics on one address (~10 us)
   __shared__ uint32_t s_cnt[4], s_base;
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(256) void k_md_compact(VoxTable t, uint64_t* __rest
       t.ids[h] = id;
       if (zero_per_entry) zero_per_entry[id] = 0;  // final ids of the boundary voxels start at "none" (k_md_comp_finals raises them)
       if (zero_per_entry2) zero_per_entry2[id] = 0;  // ... and their seed degrees at 0 (k_md_comp_finals counts them)
+      if (zero64) zero64[id] = 0ull;                 // ... and their component sets empty (k_md_bnd_comps)
     }
   }
 }
@@ -552,7 +554,113 @@ __global__ __launch_bounds__(256) void k_md_comp_roots(const uint32_t* __restric
   const uint32_t idx = waveAggInc(n_roots, is_root);
   if (is_root) {
     root_idx[s] = idx;
-    if (idx < out_cap) out[idx] = acc[s];
+    if (idx < out_cap) {
+      CompAcc a = acc[s];
+      a.root = 0u;  // in the OUTPUT records {root, pad} are the component's 64-bit overlap row (k_md_comp_overlap)
+      a.pad = 0u;
+      out[idx] = a;
+    }
+  }
+}
+
+// mergeClusters' overlap matrix on the device (free_space_motion_detector.cpp:274-355, checkClusterOverlap :333-343), for up to
+// 64 components and min_separation_distance <= 2 voxels.  A cluster's voxels are its seed voxels plus every boundary voxel one of
+// its seeds lists (:255-265); two clusters overlap when some pair of their voxels has an integer-truncated index distance below
+// the separation (ASSUMPTIONS.md C.2): for a separation in (1, 2] that is exactly "within each other's 27-neighbourhood"
+// (|d|^2 <= 3), for (0, 1] "the same voxel" -- a boundary voxel two clusters both list.  Pass 1: the component bit set of every
+// boundary voxel (the components of the seeds among its nn neighbours: the neighbourhood is symmetric).  Pass 2: every listed voxel
+// ORs the sets of the listed voxels around it into the rows of its own components ({root, pad} of the output records).  The
+// host reads the rows with the records and forms the merge groups; before, this frame's lists went to the host for an
+// O(n^2) pair test there (190 us per frame with a moving object in view, profiles/r06_frames_all.txt).
+__device__ inline unsigned long long compBit(const uint32_t* __restrict__ parent, const uint32_t* __restrict__ root_idx, uint32_t seed_id) {
+  const uint32_t ri = root_idx[parent[seed_id]];
+  return ri < 64u ? (1ull << ri) : 0ull;
+}
+// OR of `bits` over each run of consecutive lanes with equal `seg` (runs of at most 32 lanes); valid in the first lane of a run
+// (all 64 lanes must call)
+__device__ inline unsigned long long segmentedOr(unsigned long long bits, uint32_t seg, bool* head) {
+  const uint32_t lane = laneId();
+  const uint32_t prev = __shfl_up(seg, 1);
+  *head = lane == 0u || prev != seg;
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) {
+    const unsigned long long ob = (static_cast<unsigned long long>(__shfl_down(static_cast<uint32_t>(bits >> 32), o)) << 32) |
+                                  __shfl_down(static_cast<uint32_t>(bits), o);
+    const uint32_t os = __shfl_down(seg, o);
+    if (lane + static_cast<uint32_t>(o) < 64u && os == seg) bits |= ob;
+  }
+  return bits;
+}
+__global__ __launch_bounds__(256) void k_md_bnd_comps(const uint64_t* __restrict__ bnd_keys, const uint32_t* __restrict__ n4, uint32_t cap, int nn,
+                                                     VoxTable seeds, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ root_idx,
+                                                     unsigned long long* __restrict__ bnd_mask) {
+  const uint32_t nb = min(n4[1], cap), R = n4[2];
+  if (R < 2u || R > 64u) return;
+  const uint32_t total = nb * static_cast<uint32_t>(nn), step = gridDim.x * blockDim.x;
+  for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < total; i0 += step) {  // (workgroup-uniform trip count: the shuffles need every lane)
+    const uint32_t i = i0 + threadIdx.x;
+    const bool valid = i < total;
+    const uint32_t b = valid ? i / nn : 0xffffffffu, j = valid ? i % nn : 0u;
+    unsigned long long bit = 0ull;
+    if (valid) {
+      const int hs = voxFind(seeds, neighbourKey(bnd_keys[b], static_cast<int>(j)));
+      if (hs >= 0) bit = compBit(parent, root_idx, seeds.ids[hs]);
+    }
+    bool head;
+    bit = segmentedOr(bit, b, &head);
+    if (valid && head && bit) atomicOr(&bnd_mask[b], bit);
+  }
+}
+__global__ __launch_bounds__(256) void k_md_comp_overlap(const uint64_t* __restrict__ seed_keys, const uint64_t* __restrict__ bnd_keys,
+                                                        const uint32_t* __restrict__ n4, uint32_t cap, int radius, VoxTable seeds, VoxTable bnd,
+                                                        const uint32_t* __restrict__ parent, const uint32_t* __restrict__ root_idx,
+                                                        const unsigned long long* __restrict__ bnd_mask, CompAcc* __restrict__ out) {
+  const uint32_t ns = min(n4[0], cap), nb = min(n4[1], cap), R = n4[2];
+  if (R < 2u || R > 64u) return;
+  // one lane per (listed voxel, offset): offset 26 = the voxel itself, 0 .. 25 its neighbours (only for a separation above one voxel)
+  const uint32_t per = radius > 0 ? 27u : 1u;
+  const uint32_t total = (ns + nb) * per, step = gridDim.x * blockDim.x;
+  for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < total; i0 += step) {
+    const uint32_t i = i0 + threadIdx.x;
+    const bool valid = i < total;
+    const uint32_t v = valid ? i / per : 0xffffffffu, k = valid ? (per == 1u ? 26u : i % per) : 0u;
+    unsigned long long bits = 0ull, mine = 0ull;
+    if (valid) {
+      const bool is_seed = v < ns;
+      const uint64_t key = is_seed ? seed_keys[v] : bnd_keys[v - ns];
+      mine = is_seed ? compBit(parent, root_idx, v) : bnd_mask[v - ns];
+      if (k == 26u) {
+        bits = mine;
+      } else {
+        const uint64_t nk = neighbourKey(key, static_cast<int>(k));
+        const int hs = voxFind(seeds, nk);
+        if (hs >= 0) {
+          bits = compBit(parent, root_idx, seeds.ids[hs]);
+        } else {
+          const int hb = voxFind(bnd, nk);
+          if (hb >= 0 && bnd.ids[hb] < cap) bits = bnd_mask[bnd.ids[hb]];
+        }
+      }
+    }
+    bool head;
+    const unsigned long long acc = segmentedOr(bits, v, &head);
+    // (a run that straddles a wave boundary contributes in two parts; `mine` is the same in both)
+    if (valid && head && (acc & ~mine)) {
+      unsigned long long todo = mine;
+      while (todo) {
+        const int c = __ffsll(static_cast<long long>(todo)) - 1;
+        todo &= todo - 1ull;
+        atomicOr(reinterpret_cast<unsigned long long*>(&out[c].root), acc | mine);
+      }
+    }
+    if (valid && head && (mine & (mine - 1ull))) {  // a voxel two clusters share: they overlap whatever is around it
+      unsigned long long todo = mine;
+      while (todo) {
+        const int c = __ffsll(static_cast<long long>(todo)) - 1;
+        todo &= todo - 1ull;
+        atomicOr(reinterpret_cast<unsigned long long*>(&out[c].root), mine);
+      }
+    }
   }
 }
 

@@ -271,6 +271,8 @@ struct khr_ctx {
   uint32_t *d_md_seed_counts = nullptr, *d_md_bnd_counts = nullptr;
   int32_t *d_md_seed_final = nullptr, *d_md_bnd_final = nullptr;
   int32_t* d_md_bnd_deg = nullptr;       // per boundary voxel: seeds of kept clusters that list it (k_md_comp_finals / the host walk)
+  unsigned long long* d_md_bnd_mask = nullptr;  // per boundary voxel: bit set of the components that list it (k_md_bnd_comps; <= 64 components)
+  uint64_t n_md_device_merges = 0, n_md_host_walks = 0;  // seed frames whose clusters were merged from the device's overlap rows / walked on the host
   std::vector<int32_t> h_md_bnd_deg;
   ClusterAcc* d_md_acc = nullptr;  // [256], index = cluster id
   // device components of the seed graph: head = {S, B, R, 0} followed by the component records
@@ -987,6 +989,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     A(devAlloc(c, &c->d_md_seed_final, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_bnd_final, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_bnd_deg, c->md_list_cap, false));
+    A(devAlloc(c, &c->d_md_bnd_mask, c->md_list_cap, false));
     A(devAlloc(c, &c->d_md_adj, static_cast<size_t>(c->md_list_cap) * 26, false));
     {  // the host walk's page-locked block, for 16 k seed voxels to begin with (grown on demand: a growth is a hipHostMalloc inside a frame)
       const size_t want = std::min<size_t>(c->md_list_cap, 16384) * (3 + 26 + 3) + 16;
@@ -2528,6 +2531,9 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
   bool with_global = c->md_host_walk || 2u * c->md_last_seeds > c->md_lds_max || c->md_lds_max < kCompLds;
   if (std::getenv("KHR_MD_NO_PREDICT")) with_global = false;  // test hook: the lock-free path only after a repeat
   VoxTable seeds{}, bnd{}, near{};
+  // (0 < separation <= 2 voxels: the voxel pairs mergeClusters tests are within each other's 27-neighbourhood -- the device can answer)
+  static const bool no_device_merge = std::getenv("KHR_MD_NO_DEVICE_MERGE") != nullptr;  // A/B and test hook: the host walk decides
+  const bool device_merge = !no_device_merge && !c->md_host_walk && c->cfg.md_min_separation_distance > 0.f && c->cfg.md_min_separation_distance <= 2.f;
   const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c->h_md_head);
   for (int attempt = 0;; ++attempt) {
     const size_t tsize = static_cast<size_t>(mask) + 1;
@@ -2544,7 +2550,7 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
     hipLaunchKernelGGL(k_md_boundary_insert, dim3(gridFor(n)), dim3(256), 0, c->stream, c->d_keys, n, near, bnd, seeds, nn, 0, d_box,
                        c->d_md_n + 3);
     hipLaunchKernelGGL(k_md_compact, dim3(gridFor(tsize)), dim3(256), 0, c->stream, bnd, c->d_md_bnd_keys, c->d_md_bnd_counts,
-                       c->d_md_n + 1, cap, c->d_md_bnd_final, c->d_md_bnd_deg);
+                       c->d_md_n + 1, cap, c->d_md_bnd_final, c->d_md_bnd_deg, c->d_md_bnd_mask);
     const uint32_t edge_cap = cap;
     uint32_t* const d_n_edges = c->d_md_scratch4 + 15;
     hipLaunchKernelGGL(k_md_adjacency, dim3(1024), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_n, seeds, bnd, nn, cap,
@@ -2562,6 +2568,13 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
                        c->d_md_bnd_keys, c->d_md_bnd_counts, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->d_md_comp_acc);
     hipLaunchKernelGGL(k_md_comp_roots, dim3(gridFor(seed_px)), dim3(256), 0, c->stream, c->d_md_n, cap, c->d_md_parent, c->d_md_comp_acc,
                        c->d_md_rootidx, c->d_md_n + 2, d_comp_out, kCompCap);
+    // mergeClusters' overlap rows (<= 64 components, separation <= 2 voxels; both kernels leave at once when there is one component)
+    if (device_merge) {
+      hipLaunchKernelGGL(k_md_bnd_comps, dim3(256), dim3(256), 0, c->stream, c->d_md_bnd_keys, c->d_md_n, cap, nn, seeds, c->d_md_parent,
+                         c->d_md_rootidx, c->d_md_bnd_mask);
+      hipLaunchKernelGGL(k_md_comp_overlap, dim3(512), dim3(256), 0, c->stream, c->d_md_seed_keys, c->d_md_bnd_keys, c->d_md_n, cap,
+                         c->cfg.md_min_separation_distance > 1.f ? 1 : 0, seeds, bnd, c->d_md_parent, c->d_md_rootidx, c->d_md_bnd_mask, d_comp_out);
+    }
     HIP_TRY(hipGetLastError());
     // counters + the first component records -> pinned memory by a one-workgroup kernel, the host spins on the ticket
     if (++c->md_head_ticket == 0) ++c->md_head_ticket;
@@ -2617,19 +2630,49 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
           break;
         }
       }
-    if (!may_merge) {
+    // mergeClusters (:274-331) from the device's overlap rows: the clusters that end up together are the connected components of
+    // the overlap graph (getConnectedClusters recurses), the merged cluster stays at the position of its first member (`current`
+    // only ever absorbs later clusters) and its pixel list is the concatenation of the members' (:351-355)
+    std::vector<uint32_t> group(R);
+    for (uint32_t i = 0; i < R; ++i) group[i] = i;
+    const bool merge_here = may_merge && device_merge && R <= 64;
+    if (merge_here) {
+      std::function<uint32_t(uint32_t)> find = [&](uint32_t x) { return group[x] == x ? x : (group[x] = find(group[x])); };
+      for (uint32_t i = 0; i < R; ++i) {
+        unsigned long long row = (static_cast<unsigned long long>(comp[i].pad) << 32) | comp[i].root;
+        row &= ~(1ull << i);
+        while (row) {
+          const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(row));
+          row &= row - 1ull;
+          if (j < R) group[find(i)] = find(j);
+        }
+      }
+      for (uint32_t i = 0; i < R; ++i) group[i] = find(i);
+      ++c->n_md_device_merges;
+    }
+    if (!may_merge || merge_here) {
       c->stats.n_seeds = S;
       // applyClusterLevelFilters (:365-379) + ids of writeClustersToData (:381-399)
       int32_t* fin = reinterpret_cast<int32_t*>(c->h_md_head);  // the records are no longer needed once ids are taken
       std::vector<std::pair<int, uint64_t>> kept;
       std::vector<int32_t> tmp(R, 0);
+      std::vector<uint64_t> gpx(R, 0);
+      std::vector<int32_t> gid(R, -1);  // per group representative: -1 not met yet, 0 filtered out, > 0 the cluster's id
+      for (uint32_t r = 0; r < R; ++r) gpx[group[r]] += comp[r].n_pixels;
       int id = 1;
       for (uint32_t r : order) {
-        const int size = static_cast<int>(comp[r].n_pixels);
-        if (size < c->cfg.md_min_cluster_size || size > c->cfg.md_max_cluster_size) continue;
-        kept.emplace_back(id, comp[r].n_pixels);
-        tmp[r] = id;
-        if (id < 255) ++id;
+        const uint32_t g = group[r];
+        if (gid[g] < 0) {  // the group's first member in cluster order: its position is the merged cluster's
+          const int size = static_cast<int>(gpx[g]);
+          if (size < c->cfg.md_min_cluster_size || size > c->cfg.md_max_cluster_size) {
+            gid[g] = 0;
+          } else {
+            gid[g] = id;
+            kept.emplace_back(id, gpx[g]);
+            if (id < 255) ++id;
+          }
+        }
+        tmp[r] = gid[g];
       }
       lap("component order + filter");
       if (kept.empty()) return 0;
@@ -2666,6 +2709,7 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
     }
   }
   c->stats.n_seeds = S;
+  ++c->n_md_host_walks;
   std::vector<uint64_t>& sk = c->h_md_seed_keys;
   std::vector<uint64_t>& bk = c->h_md_bnd_keys;
   std::vector<uint32_t>&sc = c->h_md_seed_counts, &bc = c->h_md_bnd_counts, &adj = c->h_md_adj;

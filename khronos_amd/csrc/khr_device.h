@@ -61,11 +61,9 @@ enum Counter : int {
   C_N_ITEMS1,
   C_N_ITEMS2,
   C_N_ITEMS3,
-  C_BAND_CURSOR,     // k_fuse3: record chunks drawn from the pool in the last integrate (BandPool::cursor)
+  C_BAND_CURSOR,     // k_tsdf: record chunks drawn from the pool in the last integrate (BandPool::cursor)
   C_COUNT = 32
 };
-// k_tsdf's dynamic tail (round 6): one queue head per XCD (DevMap::tail_q, zeroed by beginIntegrate)
-constexpr int kTailQStride = 16384;  // words between two heads (64 KB: different memory channels)
 enum Stat64 : int { S_UPD = 0 /* unused */, S_BAND /* unused */, S_MESH_VERTS, S_PRUNED, S_CUM_UPD, S_CUM_BAND, S_CUM_VISITED, S_CUM_CALLS, S_COUNT = 8 };
 
 struct MeshDesc {
@@ -100,7 +98,6 @@ struct DevMap {
   uint32_t* counters;             // Counter
   unsigned long long* stats;      // Stat64
   MeshDesc* mesh_desc;            // per slot
-  uint32_t* tail_q;               // k_tsdf: 8 queue heads, kTailQStride words apart
 };
 
 // Update list of k_fuse, written by the culling pass (khr_kernels_fusion.h): one descriptor {slot | item << 24, block
@@ -394,7 +391,6 @@ __device__ inline void beginIntegrate(DevMap m, int nvox, uint32_t* wg_stats) {
     m.counters[C_N_ITEMS3] = 0u;
     m.counters[C_BAND_CURSOR] = 0u;
   }
-  if (threadIdx.x < 8 && m.tail_q != nullptr) m.tail_q[kTailQStride * threadIdx.x] = 0u;
 }
 
 // ---- lock-free union-find on compact node ids (object detector, motion-cluster components) ----------------------

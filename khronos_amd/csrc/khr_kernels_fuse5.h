@@ -1,27 +1,181 @@
-// khr_kernels_fuse5.h — round 6: the per-voxel loop of hydra::ProjectiveIntegrator::updateMap (call active_window.cpp:210;
-// ASSUMPTIONS.md A.3 / A.4) as k_tsdf (voxel phase) + k_band5 (in-band voxels), written for INSTRUCTION COUNT and OCCUPANCY.
+// khr_kernels_fuse5.h — round 6: the per-voxel loop of hydra::ProjectiveIntegrator::updateMap (call active_window.cpp:210; label hook
+// object_integrator.cpp:58-81; ASSUMPTIONS.md A.3 / A.4) as TWO kernels: k_tsdf (voxel phase) + k_band5 (colour / likelihoods / label of
+// the in-band voxels).  Every decision and value is k_fuse's bit for bit (same expressions, same order; tests/test_gpu_switches.py).
 //
-// What rounds 4 - 5 measured: a gfx950 wave issues one dependent instruction every ~9 clocks, so k_fuse
-// (168 VGPRs = 3 waves per SIMD, ~1650 instructions per 256-voxel item, two item states, ~140 spilled scalars) keeps the vector
-// pipes ~25 % busy and every memory-side rearrangement measured the same 70 - 78 us.  k_tsdf is the same arithmetic -- every
-// decision and value bit for bit (same expressions, same order) -- with the stream cut to what the update needs:
-//   * one item per wave, no second item state, no LDS record list: <= 64 / 80 VGPRs, 6 - 8 waves per SIMD cover each other's waits;
-//   * lane constants ((ix + 0.5) vs, (iz + 0.5) vs) computed once per launch, the z row of the rotation and every per-frame
-//     scalar in SGPRs, voxel addresses as ONE 32-bit lane offset + immediate z offsets (no 64-bit address VALU);
-//   * validity of a z-step as a 64-bit lane mask in scalar registers (no -1 encoding, no re-derivation in phase 2);
-//   * the lazy last_observed word of a z-step through the scalar cache, its (rare) write-out behind a scalar branch;
-//   * in-band voxels leave as 20-byte records {voxel, measurement weight, blend weight, u | mode, v} in the workgroup's chunked
-//     stream (BandPool) -- one LDS atomic per z-step that has any.
-// k_band5 consumes the records 64 per wave round (fuseBandRows' arithmetic bit for bit): every wave gets the same number of
-// NON-EMPTY rounds (each workgroup scans the chunk fills once), so the launch is one balanced sweep instead of two ragged ones.
+// What is known about this update on gfx950 (profiles/r06_fuse_sol.txt):
+//   * a plain wave64 f32 VALU instruction occupies its SIMD for 4 clocks (SQ_ACTIVE_INST_VALU ~ SQ_INSTS_VALU quad-cycles), so the
+//     voxel phase's floor is its VALU count: 13.5 M instructions per c3 launch = 25 - 28 us at the 1.9 - 2.1 GHz the part sustains --
+//     the ALU-only instantiation of this kernel (MODE 1) runs in 28 - 31 us; k_fuse needed 19.8 M;
+//   * the memory-only instantiation (MODE 2: the projection -- it IS the address generation -- and the complete load / gather / store /
+//     record stream, values moved) takes the same 44 us as the whole kernel: the arithmetic hides behind the memory stream, the
+//     memory stream does not hide behind anything; no single access is the culprit (ablations, MODE 3);
+//   * returning global atomics retire at ~65 per us on the whole device wherever the words lie: a dynamically dealt tail of the item list
+//     (tried: one queue head per XCD, 64 KB apart, and heads pulled with L2-local atomics by HW_REG_XCC_ID) costs 15 ns per item.
+// Shape: one item (64 voxels x 4 z) per wave at a time, no second item state and no LDS record list (<= 96 VGPRs, 5 waves per SIMD,
+// no scratch: a kernel that spills to scratch lost 20 us); lane constants computed once per launch; validity of a z-step as a 64-bit
+// lane mask in scalar registers; the lazy last_observed words of the item as one vector load, read back with v_readlane.
+// In-band voxels leave as 24-byte records {voxel, measurement weight, blend weight, u | nearest-mode, v | first-time, label}: the
+// label lookup and the VOX_SEM_VALID bit of the voxel flags are done HERE, so that the band kernel does not touch the voxel flags --
+// khr_process_frame runs it on its own stream beside the tracking pass (which rewrites those bytes).
 //
-// MODE (development, profiles/r06_fuse_sol.txt): 0 = the product; 1 = ALU only (no global loads / stores: range samples are
-// synthesised so that the update / in-band fractions match a c3 frame); 2 = memory only (the projection -- it IS the address
-// generation -- and the complete load / gather / store / record stream, decisions from the nearest sample, values moved).
+// MODE (development): 0 = the product; 1 = ALU only (no global loads / stores: range samples are synthesised so that the update /
+// in-band fractions match a c3 frame); 2 = memory only; 3 = run-time ablations of single access streams (KHR_FUSE_DBG).
 #pragma once
-#include "khr_kernels_fuse3.h"
+#include "khr_kernels_fuse.h"
 
 namespace khr {
+
+constexpr uint32_t kBandChunk = 1024u;   // records per chunk
+constexpr int kBandFields = 6;           // voxel | measurement weight | blend weight | u (sign: nearest mode) | v (sign: first semantic update) | label
+constexpr uint32_t kBandMaxLocal = 64u;  // chunks one workgroup can fill per launch
+constexpr uint32_t kNoChunk = 0xffffffffu, kDropChunk = 0xfffffffeu;
+constexpr uint32_t kBandNoLabel = 0xffffffffu;  // the label field of a record whose pixel label is outside [0, K): colour only
+
+// Record lists.  The pool is an array of chunks of kBandChunk records, field-major inside a chunk.  Workgroup g of k_tsdf starts in
+// chunk g (static: no atomic) and continues in chunks it draws from ONE global cursor (a few hundred returning atomics per launch).
+// Inside a workgroup the records of a wave z-step take consecutive positions of the workgroup's stream (one LDS atomic per z-step that
+// has any), position p lives in the workgroup's (p / kBandChunk)-th chunk; the lane whose record opens a chunk draws it and publishes
+// its id through LDS, the others wait for the id.  At the end the workgroup writes the fill of each of its chunks.  The pool is sized
+// by the host from a bound on the in-band volume of a frame; records beyond it are dropped and counted (khr_stats.band_overflow).
+struct BandPool {
+  uint32_t* rec;      // [n_chunks][kBandFields][kBandChunk]
+  uint32_t* chunk_n;  // [n_chunks] records in the chunk (written by k_tsdf for every chunk it used, and for its static one)
+  uint32_t* cursor;   // dynamic chunks drawn in this launch (zeroed by beginIntegrate)
+  uint32_t* overflow; // records dropped for lack of chunks (cumulative)
+  uint32_t n_chunks, n_static;
+};
+
+// ---- the in-band voxels of one wave round: colour blend, K likelihoods, arg-max label ------------------------------------
+// A round = up to 64 records of one chunk: part A lane <-> record (colour blend from two 8-byte pixel-pair gathers), part B KS / 4
+// lanes <-> record (the record's 128-byte likelihood row as ONE full-line load and ONE full-line store, arg-max by a segmented DPP
+// reduction: first maximum wins), label handed back to the record's part-A lane through LDS.  The arithmetic is fuseBandRows'
+// (khr_kernels_fuse.h) bit for bit; the records of a round belong to different blocks, so every address is a 64-bit voxel index x
+// stride.  PASSES = part-B passes whose row vectors are in flight together.
+template <int PASSES>
+__device__ __forceinline__ void bandRound(FuseArgsK ka, uint32_t* sv, const uint32_t* rec0, uint32_t n_here, int lane) {
+  const FuseArgs __attribute__((address_space(4)))& a = *ka;
+  const int K = a.K;
+  const uint32_t row_bytes = static_cast<uint32_t>(a.KS) * 4u;
+  const uint32_t lpr = static_cast<uint32_t>(a.KS) >> 2;  // lanes per record in part B (8, 16, 32 or 64)
+  const uint32_t rpp = 64u / lpr;                          // records per part-B pass
+  const uint32_t rl0 = static_cast<uint32_t>(lane) / lpr, j = static_cast<uint32_t>(lane) - rl0 * lpr;
+  const uint32_t j16 = j * 16u;
+  const char* const rgba_b = reinterpret_cast<const char*>(a.rgba);
+  char* const color_b = reinterpret_cast<char*>(a.color);
+  char* const lab_b = reinterpret_cast<char*>(a.sem_label);
+  char* const lik_b = reinterpret_cast<char*>(a.lik);
+  const float add_hit = a.log_match, add_miss = a.log_nomatch;
+  const uint32_t npass = (n_here + rpp - 1u) / rpp;
+  const bool valid = static_cast<uint32_t>(lane) < n_here;
+  const uint32_t* const rec = rec0 + min(static_cast<uint32_t>(lane), n_here - 1u);
+  // ---- first trip: the records (part A: lane <-> record; idle lanes take the round's last record again), and for part B the
+  //      voxel of each record whose row this lane helps to move -- straight from the list: the row loads do not wait for part A ----
+  const uint32_t vox = rec[0];
+  const float w = __uint_as_float(rec[kBandChunk]), w_bl = __uint_as_float(rec[2 * kBandChunk]);
+  const uint32_t ub = rec[3 * kBandChunk], vb = rec[4 * kBandChunk], lb = rec[5 * kBandChunk];
+  uint32_t vx[PASSES];
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) vx[p] = rec0[min(static_cast<uint32_t>(p) * rpp + rl0, n_here - 1u)];
+  // ---- second trip: likelihood rows (part B) and the image / voxel reads of part A ----
+  float4 l4[PASSES];
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) l4[p] = *reinterpret_cast<const float4*>(lik_b + (static_cast<size_t>(vx[p]) * row_bytes + j16));
+  const float u = __uint_as_float(ub & 0x7fffffffu), v = __uint_as_float(vb & 0x7fffffffu);
+  int px4[4];
+  float du, dv, w4[4];
+  interpPixels(u, v, a.W, a.H, px4, &du, &dv);
+  interpWeights(du, dv, (ub & 0x80000000u) != 0u, w4);
+  const bool last_col = px4[2] == px4[0];
+  const u2u ca = *reinterpret_cast<const u2u*>(rgba_b + static_cast<uint32_t>(px4[0]) * 4u);  // (u0, v0), (u0 + 1, v0)
+  const u2u cb = *reinterpret_cast<const u2u*>(rgba_b + static_cast<uint32_t>(px4[1]) * 4u);  // (u0, v1), (u0 + 1, v1)
+  const uint32_t co = *reinterpret_cast<const uint32_t*>(color_b + static_cast<size_t>(vox) * 4u);
+  const bool upd = lb != kBandNoLabel;
+  // ---- part A: colour ----
+  {
+    const uint32_t c4[4] = {ca.x, cb.x, last_col ? ca.x : ca.y, last_col ? cb.x : cb.y};
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t c = c4[k];
+      acc[0] = acc[0] + w4[k] * static_cast<float>(c & 0xffu);
+      acc[1] = acc[1] + w4[k] * static_cast<float>((c >> 8) & 0xffu);
+      acc[2] = acc[2] + w4[k] * static_cast<float>((c >> 16) & 0xffu);
+    }
+    const float tot = w_bl + w;
+    const float ytot = rcpRefined(tot);
+    uint32_t out = 0xff000000u;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float cn2 = static_cast<float>(toU8(acc[ch]));
+      const float cv = static_cast<float>((co >> (8 * ch)) & 0xffu);
+      out |= static_cast<uint32_t>(toU8(divExact(cv * w_bl + cn2 * w, tot, ytot))) << (8 * ch);
+    }
+    if (valid) *reinterpret_cast<uint32_t*>(color_b + static_cast<size_t>(vox) * 4u) = out;
+  }
+  sv[lane] = (upd ? 0x80000000u : 0u) | ((vb & 0x80000000u) ? 0x40000000u : 0u) | (lb & 0xffffu);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // ---- part B: likelihood rows ----
+  for (uint32_t p0 = 0; p0 < npass; p0 += PASSES) {
+    if (p0 > 0) {  // further rounds of passes (their loads queue behind the stores of the previous one)
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        vx[p] = rec0[min((p0 + static_cast<uint32_t>(p)) * rpp + rl0, n_here - 1u)];
+        l4[p] = *reinterpret_cast<const float4*>(lik_b + (static_cast<size_t>(vx[p]) * row_bytes + j16));
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const uint32_t rl_own = (p0 + static_cast<uint32_t>(p)) * rpp + rl0;
+      const uint32_t rl = min(rl_own, n_here - 1u);
+      const uint32_t pk = sv[rl];
+      const bool on = (pk & 0x80000000u) != 0u;
+      const int lab = static_cast<int>(pk & 0xffffu);
+      const bool emp = (pk & 0x40000000u) != 0u;
+      float l[4] = {l4[p].x, l4[p].y, l4[p].z, l4[p].w};
+      float bv = -__builtin_inff();  // lanes that hold padding only never win (strict comparison below)
+      uint32_t bk = 0xffffu;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = 4 * static_cast<int>(j) + q;
+        if (k < K) {
+          if (emp) l[q] = 0.f;
+          l[q] += (k == lab) ? add_hit : add_miss;
+          if (k == 0 || l[q] > bv) {
+            bv = l[q];
+            bk = static_cast<uint32_t>(k);
+          }
+        } else {
+          l[q] = 0.f;
+        }
+      }
+      // only updated records of the round's own lanes store (a pass beyond the round's records repeats its last record)
+      if (on && rl_own < n_here) *reinterpret_cast<float4*>(lik_b + (static_cast<size_t>(vx[p]) * row_bytes + j16)) = make_float4(l[0], l[1], l[2], l[3]);
+      auto take = [&](float ov, uint32_t ok2, uint32_t sh) {
+        if (j + sh < lpr && ov > bv) {
+          bv = ov;
+          bk = ok2;
+        }
+      };
+      take(__uint_as_float(rowDown<1>(__float_as_uint(bv))), rowDown<1>(bk), 1u);
+      take(__uint_as_float(rowDown<2>(__float_as_uint(bv))), rowDown<2>(bk), 2u);
+      take(__uint_as_float(rowDown<4>(__float_as_uint(bv))), rowDown<4>(bk), 4u);
+      if (lpr > 8u) take(__uint_as_float(rowDown<8>(__float_as_uint(bv))), rowDown<8>(bk), 8u);
+      for (uint32_t sh = 16u; sh < lpr; sh <<= 1) {  // KS > 64: across DPP rows
+        const float ov = __shfl_down(bv, sh);
+        const uint32_t ok2 = static_cast<uint32_t>(__shfl_down(static_cast<int>(bk), sh));
+        take(ov, ok2, sh);
+      }
+      if (on && j == 0u && rl_own < n_here) sv[64 + rl] = bk;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (valid && upd) *reinterpret_cast<uint32_t*>(lab_b + static_cast<size_t>(vox) * 4u) = sv[64 + lane];
+  __builtin_amdgcn_wave_barrier();  // (the next round rewrites the wave's LDS words)
+}
 
 template <int ZSPLIT, bool EXACT, int WPW, int MINW, int MODE = 0>
 __global__ __launch_bounds__(64 * WPW, MINW) void k_tsdf(FuseArgs a, FuseList list, BandPool bp) {
@@ -59,40 +213,14 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_tsdf(FuseArgs a, FuseList li
                                           // 4 no distance / weight stores, 8 no stamp words, 16 no record stores, 32 non-temporal voxel stream
   const bool trk = a.with_tracking != 0 && !(dbg & 8);
   const char* const range_b = reinterpret_cast<const char*>(a.range);
-  // Work distribution.  The list is most-expensive-first.  Its head [0, n_stat) is dealt statically: workgroup b owns positions first,
-  // first + grid, ... (every workgroup the same class mix; XCD-aware as in k_fuse) and its waves take them from an LDS counter.  A
-  // workgroup has only n_items / grid ~ 19 items, i.e. two full rounds of its 8 waves and a ragged third: with a fully static deal
-  // the average residency of a launch was 3.2 of 5 waves per SIMD (SQ_WAVE_CYCLES / duration, profiles/r06_fuse_sol.txt).  So the
-  // TAIL of the list -- the cheapest items -- is dealt dynamically from one queue head per XCD (a returning atomic costs ~1 us under
-  // load and a head retires ~88 of them per us: the tail's few thousand pulls are spread over 8 heads and hidden behind the item the
-  // wave is working on; a plain load tells a wave that its head has run dry without an atomic).
+  // workgroup b owns the list positions first, first + grid, ... (every workgroup the same class mix; XCD-aware as in k_fuse); its
+  // waves take them from an LDS counter
   const uint32_t first = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const uint32_t n_stat = bp.tail_q == nullptr ? 0xffffffffu
-                                               : static_cast<uint32_t>((static_cast<uint64_t>(n_items) * (bp.static_pct & 255u) / 100u) / gridDim.x) * gridDim.x;
-  // static_pct bit 8: the head of the XCD the wave really runs on (HW_REG_XCC_ID), pulled with an atomic that is resolved in that XCD's
-  // L2 (no sc1: the pullers of a head share the L2 by construction) instead of a device-scope one that travels to the memory side
-  const bool l2_local = (bp.static_pct & 256u) != 0u;
-  const uint32_t xcd = l2_local ? (static_cast<uint32_t>(__builtin_amdgcn_s_getreg(20 | (3 << 11))) & 7u) : (blockIdx.x & 7u);
-  uint32_t* const tail_head = bp.tail_q + xcd * kTailQStride;
-  bool in_tail = false;
   auto pull = [&]() -> uint32_t {
-    if (!in_tail) {
-      uint32_t j = 0u;
-      if (lane == 0) j = atomicAdd(&s_q, 1u);
-      j = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(j)));
-      const uint32_t pos = first + gridDim.x * j;
-      if (pos < n_stat) return pos;
-      if (n_stat == 0xffffffffu) return pos;
-      in_tail = true;
-    }
-    uint32_t t = l2_local ? __hip_atomic_load(tail_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-                          : __hip_atomic_load(tail_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    t = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(t)));
-    if (n_stat + xcd + 8u * t >= n_items) return 0xffffffffu;
-    if (lane == 0) t = l2_local ? __hip_atomic_fetch_add(tail_head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-                                : __hip_atomic_fetch_add(tail_head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    t = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(t)));
-    return n_stat + xcd + 8u * t;
+    uint32_t j = 0u;
+    if (lane == 0) j = atomicAdd(&s_q, 1u);
+    j = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(j)));
+    return first + gridDim.x * j;
   };
   auto descOf = [&](uint32_t i) -> uint4 {
     const DescK la = (DescK)list.a, lb = (DescK)list.b;
@@ -297,13 +425,16 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_tsdf(FuseArgs a, FuseList li
                                (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(obsw, 4 * k + 1))) << 32);
         const uint64_t stamp0 = static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(obsw, 4 * k + 2))) |
                                 (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(obsw, 4 * k + 3))) << 32);
-        const bool same = stamp0 == a.stamp;
+        FuseArgsK ka = (FuseArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        const uint64_t stamp = ka->stamp;
+        const bool same = stamp0 == stamp;
         const uint64_t mat = same ? 0ull : (bits0 & ~m_ok);
         if (mat != 0ull) {
           if (((mat >> static_cast<uint32_t>(lane)) & 1ull) != 0ull)
-            *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(a.last_obs + g0) + (static_cast<uint32_t>(lane) * 8u + static_cast<uint32_t>(k) * (SL * 8u))) = stamp0;
+            *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(ka->last_obs + g0) + (static_cast<uint32_t>(lane) * 8u + static_cast<uint32_t>(k) * (SL * 8u))) = stamp0;
         }
-        if (lane == 0) a.obs[w0 + k * PATCHES] = make_ulonglong2(same ? (bits0 | m_ok) : m_ok, a.stamp);
+        if (lane == 0) ka->obs[w0 + k * PATCHES] = make_ulonglong2(same ? (bits0 | m_ok) : m_ok, stamp);
       }
       const unsigned long long m_band = __builtin_amdgcn_ballot_w64(in_band);
       if (m_band != 0ull) {
@@ -329,12 +460,40 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_tsdf(FuseArgs a, FuseList li
           }
           if (id != kDropChunk) {
             if (MODE != 1 && !(dbg & 16)) {
+              // the measurement's label: the pixel of the largest interpolation weight (first maximum; interpWeights), and the voxel's
+              // first-semantic-update bit -- read and set here, in front of the tracking pass that rewrites the voxel flags
+              const uint32_t u0 = static_cast<uint32_t>(static_cast<int>(uc)), v0 = static_cast<uint32_t>(static_cast<int>(vc));
+              const float du = __builtin_amdgcn_fractf(uc), dv = __builtin_amdgcn_fractf(vc);
+              int best;
+              if (use_nearest) {
+                best = (du >= 0.5f ? 2 : 0) + (dv >= 0.5f ? 1 : 0);
+              } else {
+                const float omu = 1.f - du, omv = 1.f - dv;
+                const float w0b = omu * omv, w1b = omu * dv, w2b = du * omv, w3b = du * dv;
+                best = 0;
+                float bw = w0b;
+                if (w1b > bw) { bw = w1b; best = 1; }
+                if (w2b > bw) { bw = w2b; best = 2; }
+                if (w3b > bw) { bw = w3b; best = 3; }
+              }
+              const uint32_t vrow = (best & 1) ? min(v0 + 1u, Hl) : v0;
+              const uint32_t ucol = ((best & 2) && u0 < Wl) ? u0 + 1u : u0;
+              // (cold arguments through the kernel-argument segment: scalar-cache hits instead of scalar registers held through the loop)
+              FuseArgsK ka = (FuseArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+              asm volatile("" : "+s"(ka));
+              const int label = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(ka->label) + (vrow * W4 + ucol * 4u));
+              uint8_t* const flp = ka->vflags + (g0 + static_cast<size_t>(k) * SL + static_cast<size_t>(lane));
+              const uint8_t fl = *flp;
+              const bool upd = label >= 0 && label < ka->K;
+              const bool empty = !(fl & VOX_SEM_VALID);
+              if (upd && empty) *flp = fl | VOX_SEM_VALID;
               uint32_t* const rec = bp.rec + static_cast<size_t>(id) * (kBandFields * kBandChunk) + off;
               rec[0] = slot * static_cast<uint32_t>(NV) + (z0 + static_cast<uint32_t>(k)) * SL + patch * 64u + static_cast<uint32_t>(lane);
               rec[kBandChunk] = __float_as_uint(w);
-              rec[2 * kBandChunk] = __float_as_uint(a.blend_pre ? w_old : w_new);
+              rec[2 * kBandChunk] = __float_as_uint(ka->blend_pre ? w_old : w_new);
               rec[3 * kBandChunk] = (__float_as_uint(uc) & 0x7fffffffu) | (use_nearest ? 0x80000000u : 0u);
-              rec[4 * kBandChunk] = __float_as_uint(vc);
+              rec[4 * kBandChunk] = (__float_as_uint(vc) & 0x7fffffffu) | (empty ? 0x80000000u : 0u);
+              rec[5 * kBandChunk] = upd ? static_cast<uint32_t>(label) : kBandNoLabel;
             }
           } else {
             atomicAdd(bp.overflow, 1u);
@@ -383,7 +542,7 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_tsdf(FuseArgs a, FuseList li
 
 // ---- the in-band voxels of a k_tsdf launch: every wave the same number of NON-EMPTY 64-record rounds -------------------------------
 // The chunks' fills differ (a workgroup's stream ends somewhere inside its last chunk, most dynamic chunks are full), so dealing
-// (chunk, round) pairs blindly gave k_band3 two ragged sweeps of ~15 us.  Here every workgroup first turns the chunk fills into the
+// (chunk, round) pairs blindly (round 5) gave two ragged sweeps of ~15 us.  Here every workgroup first turns the chunk fills into the
 // prefix sum of their round counts (one load per thread and 256 chunks, a wave scan, 16 KB of LDS), then wave w of W takes the rounds
 // [w U / W, (w + 1) U / W) of the U rounds that exist and finds each one's chunk by bisection in LDS.
 constexpr uint32_t kBand5MaxChunks = 4096u;

@@ -149,7 +149,10 @@ struct khr_ctx {
   uint32_t* d_band_rec = nullptr;
   uint32_t* d_band_n = nullptr;
   uint32_t band_chunks = 0;
-  int n_cus = 256, fuse5_grid = 0, band5_grid = 0, fuse5_zs = 0;  // per context (= per device): the persistent grids of k_tsdf / the band kernel
+  int n_cus = 256, fuse5_grid = 0, band5_grid = 0, fuse5_zs = 0;
+  hipStream_t band_stream = nullptr;  // khr_process_frame: the band kernel beside the tracking pass
+  hipEvent_t ev_band_fork = nullptr, ev_band_join = nullptr;
+  bool band_fork = false, band_join_pending = false;  // per context (= per device): the persistent grids of k_tsdf / the band kernel
   unsigned char* d_fuse_sink = nullptr;  // k_fuse: one 256-byte sink line per wave (kFuseStatSlots workgroups x 16 waves)
   uint32_t* d_pix_scratch = nullptr;  // khr_pixel_iou: mask image + counters (allocated on first use)
   size_t pix_words = 0;
@@ -577,12 +580,13 @@ int kFuseWavesPerCu = 16;  // env KHR_FUSE_WAVES: resident waves per CU the pers
 constexpr int kFuseWpwDefault = 12;
 int kFuseDbg = 0;       // env KHR_FUSE_DBG: ablation switches (development; selects the DBG instantiation)
 int kFuseVer = 1;       // env KHR_FUSE_V: 1 = k_fuse (default: per-wave software pipeline, band phase inside), 2 = k_fuse2 (one item per wave),
-                        // 3 = k_fuse3 + k_band3, 4 = k_fuse3<.., FUSED> (round 5 experiments, khr_kernels_fuse3.h: lean voxel phase at 5 - 8 waves per
-                        // SIMD with the in-band voxels as record lists; parity-green, measured slower than k_fuse in the driver's command), 1 = k_fuse (per-wave software pipeline), 2 = k_fuse2 (one item per wave)
-int kFuse3Waves = 0;    // env KHR_FUSE3_WAVES: resident waves per CU of k_fuse3's persistent grid (0 = what the occupancy query allows)
-int kBand3Waves = 0;    // env KHR_BAND3_WAVES: the same for k_band3
+                        // 5 = k_tsdf + k_band5 (round 6, khr_kernels_fuse5.h: lean voxel kernel + balanced band kernel, the vehicle of the
+                        // speed-of-light decomposition; parity-green; 44 + 31 us against k_fuse's 72 and, with its band kernel on a second
+                        // stream beside the tracking pass, SLOWER per frame -- a cross-stream dependency costs ~20 us each way,
+                        // profiles/r06_fuse_sol.txt -- so it is the option, not the default)
+int kFuse3Waves = 0;    // env KHR_FUSE5_WAVES: resident waves per CU of k_tsdf's persistent grid (0 = what the occupancy query allows)
+int kBand3Waves = 0;    // env KHR_BAND5_WAVES: the same for k_band5
 int kFuse5Mode = 0;   // env KHR_FUSE5_MODE: 1 / 2 = the ALU-only / memory-only instantiations of k_tsdf (speed-of-light decomposition; development)
-int kFuse3Occ = 0;      // env KHR_FUSE3_OCC: waves per SIMD k_fuse3 is compiled for (0 = 5 with 4 z ranges per patch, 8 with 8)
 int kTickUnion = 1;     // env KHR_TICK_UNION: khr_tick_integrate updates with ONE launch for all cameras of the tick (tickUnion)
 int kFuseMulti = 1;     // env KHR_FUSE_MULTI: khr_integrate_shared_batch integrates all frames of a batch in one launch (k_fuse2 MULTI)
 constexpr int kMaxMultiFrames = 1024;
@@ -885,10 +889,9 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   if (std::getenv("KHR_TICK_UNION")) kTickUnion = std::atoi(std::getenv("KHR_TICK_UNION"));
   if (std::getenv("KHR_FUSE_MULTI")) kFuseMulti = std::atoi(std::getenv("KHR_FUSE_MULTI"));
   if (std::getenv("KHR_FUSE_V")) kFuseVer = std::atoi(std::getenv("KHR_FUSE_V"));
-  if (std::getenv("KHR_FUSE3_WAVES")) kFuse3Waves = std::atoi(std::getenv("KHR_FUSE3_WAVES"));
-  if (std::getenv("KHR_BAND3_WAVES")) kBand3Waves = std::atoi(std::getenv("KHR_BAND3_WAVES"));
+  if (std::getenv("KHR_FUSE5_WAVES")) kFuse3Waves = std::atoi(std::getenv("KHR_FUSE5_WAVES"));
+  if (std::getenv("KHR_BAND5_WAVES")) kBand3Waves = std::atoi(std::getenv("KHR_BAND5_WAVES"));
   if (std::getenv("KHR_FUSE5_MODE")) kFuse5Mode = std::atoi(std::getenv("KHR_FUSE5_MODE"));
-  if (std::getenv("KHR_FUSE3_OCC")) kFuse3Occ = std::atoi(std::getenv("KHR_FUSE3_OCC"));
   if (std::getenv("KHR_NO_EARLY_INGEST")) c->early_ingest = false;
 
   DevMap& m = c->m;
@@ -922,7 +925,6 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   A(devAlloc(c, &m.obs, cfg->with_tracking ? cap * (nv / 64) : 1, false));
   A(devAlloc(c, &m.free_slots, cap, false));
   A(devAlloc(c, &m.counters, C_COUNT));
-  A(devAlloc(c, &m.tail_q, 8 * kTailQStride));
   A(devAlloc(c, &m.stats, S_COUNT));
   A(devAlloc(c, &m.mesh_desc, cap));
   A(devAlloc(c, &c->d_work, cap));
@@ -1088,6 +1090,9 @@ void khr_destroy(khr_ctx* c) {
   if (c->d_mh2_keys) { hipFree(c->d_mh2_keys); hipFree(c->d_mh2_offs); }
   if (c->d_pix_scratch) hipFree(c->d_pix_scratch);
   if (c->d_band_rec) { hipFree(c->d_band_rec); hipFree(c->d_band_n); }
+  if (c->band_stream) { hipStreamSynchronize(c->band_stream); hipStreamDestroy(c->band_stream); }
+  if (c->ev_band_fork) hipEventDestroy(c->ev_band_fork);
+  if (c->ev_band_join) hipEventDestroy(c->ev_band_join);
   if (c->h2d_stream) { hipStreamSynchronize(c->h2d_stream); hipStreamDestroy(c->h2d_stream); }
   if (c->ev_h2d) hipEventDestroy(c->ev_h2d);
   for (int i = 0; i < 2; ++i) {
@@ -1544,70 +1549,6 @@ static int integrateUpdateMulti(khr_ctx* c, khr_ctx* src, const int* src_slots, 
   return KHR_OK;
 }
 
-// k_fuse3 + k_band3 (khr_kernels_fuse3.h): the update of a 16^3-voxel map with the reference's default integrator switches and
-// colour + label frames.  Returns KHR_OK when the pair was queued, 1 when the record pool could not be provided (the caller then
-// takes k_fuse).
-static int integrateUpdate3(khr_ctx* c, const FrameSlot& s, const FuseArgs& a, const FuseList& list, bool exact, int zs) {
-  auto gridOf = [&](const void* kern, int wpw, int want_waves) {
-    static std::map<const void*, int> cache;
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = cache.find(kern);
-    if (it != cache.end()) return it->second;
-    int per_cu = 0, cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * wpw, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (want_waves > 0) per_cu = std::max(1, std::min(per_cu, want_waves / wpw));
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    int grid = std::min(kFuseStatSlots, per_cu * cus) / 8 * 8;
-    grid = std::max(8, grid);
-    cache[kern] = grid;
-    if (std::getenv("KHR_VERBOSE")) std::fprintf(stderr, "[khr] fuse3 kernel %p: %d workgroups of %d waves (%d per CU)\n", kern, grid, wpw, per_cu);
-    return grid;
-  };
-  constexpr int WPW = 8, BW = 4;
-  // instantiations: 4 z ranges per patch (items of 64 x 4 voxels) compiled for 5 waves per SIMD, 8 z ranges (64 x 2 voxels) for 7;
-  // fused = the workgroups consume their own record streams (KHR_FUSE_V=4), else k_band3 follows (KHR_FUSE_V=3)
-  const bool fused = kFuseVer >= 4;
-  const void* kf = nullptr;
-  auto pick = [&](auto run) {
-    if (zs == 8) {
-      if (fused) { if (exact) run(&k_fuse3<8, true, WPW, 7, true>); else run(&k_fuse3<8, false, WPW, 7, true>); }
-      else { if (exact) run(&k_fuse3<8, true, WPW, 7, false>); else run(&k_fuse3<8, false, WPW, 7, false>); }
-    } else {
-      if (fused) { if (exact) run(&k_fuse3<4, true, WPW, 5, true>); else run(&k_fuse3<4, false, WPW, 5, true>); }
-      else { if (exact) run(&k_fuse3<4, true, WPW, 5, false>); else run(&k_fuse3<4, false, WPW, 5, false>); }
-    }
-  };
-  pick([&](auto kern) { kf = reinterpret_cast<const void*>(kern); });
-  const void* kb = reinterpret_cast<const void*>(&k_band3<BW, 5>);
-  const int grid = gridOf(kf, WPW, kFuse3Waves);
-  const int grid_b = gridOf(kb, BW, kBand3Waves);
-  // record pool: one static chunk per workgroup + a bound on the in-band volume of a frame -- the voxels within the truncation
-  // distance of the surface along the view rays fill at most (solid angle) x max_range^2 x 2 truncation / voxel^3; x 1.5 for the
-  // lattice and the drop-off at the band's edge
-  const khr_sensor& sen = s.sensor;
-  const double omega = (static_cast<double>(sen.width) / sen.fx) * (static_cast<double>(sen.height) / sen.fy);
-  const double vol = omega * static_cast<double>(sen.max_range) * sen.max_range * 2.0 * c->p.trunc;
-  const double recs = 1.5 * vol / (static_cast<double>(c->p.vs) * c->p.vs * c->p.vs);
-  const uint64_t want64 = static_cast<uint64_t>(kFuseStatSlots) + static_cast<uint64_t>(recs / kBandChunk) + 64u;
-  if (want64 > (1u << 17)) return 1;  // (2.7 GB of records: not a frame this path is meant for)
-  const uint32_t want = static_cast<uint32_t>(want64);
-  if (want > c->band_chunks) {
-    // grow-only; happens on the first frames of a context (hipMalloc / hipFree wait for the device)
-    if (c->d_band_rec) { hipStreamSynchronize(c->stream); hipFree(c->d_band_rec); hipFree(c->d_band_n); c->d_band_rec = nullptr; c->d_band_n = nullptr; c->band_chunks = 0; }
-    const uint32_t n = want + want / 4;
-    if (hipMalloc(reinterpret_cast<void**>(&c->d_band_rec), static_cast<size_t>(n) * kBandFields * kBandChunk * 4u) != hipSuccess) { c->d_band_rec = nullptr; return 1; }
-    if (hipMalloc(reinterpret_cast<void**>(&c->d_band_n), static_cast<size_t>(n) * 4u) != hipSuccess) { hipFree(c->d_band_rec); c->d_band_rec = nullptr; c->d_band_n = nullptr; return 1; }
-    hipMemsetAsync(c->d_band_n, 0, static_cast<size_t>(n) * 4u, c->stream);
-    c->band_chunks = n;
-  }
-  BandPool bp{c->d_band_rec, c->d_band_n, &c->m.counters[C_BAND_CURSOR], &c->m.counters[C_BAND_OVERFLOW], c->band_chunks, static_cast<uint32_t>(grid), nullptr, 100u};
-  pick([&](auto kern) { KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(64 * WPW), a, list, bp); });
-  if (!fused) KHR_LAUNCH_TIMED(7, (&k_band3<BW, 5>), dim3(grid_b), dim3(64 * BW), a, bp);
-  return KHR_OK;
-}
-
 // k_tsdf + band kernel (khr_kernels_fuse5.h, round 6): the update of a 16^3-voxel map with the reference's default integrator switches
 // and whole-line likelihood rows.  Returns 1 when the call is not one it takes (the caller falls back to k_fuse).
 static int ensureBandPool(khr_ctx* c, const FrameSlot& s, int grid) {
@@ -1634,9 +1575,7 @@ static int ensureBandPool(khr_ctx* c, const FrameSlot& s, int grid) {
 }
 
 static int integrateUpdate5(khr_ctx* c, const FrameSlot& s, const FuseArgs& a, const FuseList& list, bool exact, int zs) {
-  static const int shape = std::getenv("KHR_FUSE5_SHAPE") ? std::atoi(std::getenv("KHR_FUSE5_SHAPE")) : 0;
-  auto body = [&](auto wpw_c, auto occ_c) -> int {
-  constexpr int WPW = decltype(wpw_c)::value, OCC = decltype(occ_c)::value;
+  constexpr int WPW = 8, OCC = 5;  // 8-wave workgroups, compiled for 5 waves per SIMD (<= 96 VGPRs: no scratch)
   constexpr int BW = 4;
   auto gridOf = [&](const void* kern, int wpw, int want_waves) {
     int per_cu = 0;
@@ -1661,24 +1600,27 @@ static int integrateUpdate5(khr_ctx* c, const FrameSlot& s, const FuseArgs& a, c
     if (std::getenv("KHR_VERBOSE")) std::fprintf(stderr, "[khr] k_tsdf: %d workgroups of %d waves; band: %d of %d\n", c->fuse5_grid, WPW, c->band5_grid, BW);
   }
   if (int rc = ensureBandPool(c, s, c->fuse5_grid)) return rc;
-  static const int tail_pct = std::getenv("KHR_FUSE5_STATIC") ? std::atoi(std::getenv("KHR_FUSE5_STATIC")) : 100;
-  BandPool bp{c->d_band_rec, c->d_band_n, &c->m.counters[C_BAND_CURSOR], &c->m.counters[C_BAND_OVERFLOW], c->band_chunks, static_cast<uint32_t>(c->fuse5_grid),
-              (tail_pct & 255) >= 100 ? nullptr : c->m.tail_q, static_cast<uint32_t>(std::max(0, tail_pct))};
+  BandPool bp{c->d_band_rec, c->d_band_n, &c->m.counters[C_BAND_CURSOR], &c->m.counters[C_BAND_OVERFLOW], c->band_chunks, static_cast<uint32_t>(c->fuse5_grid)};
   const int grid = c->fuse5_grid;
   pick([&](auto kern) { KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(64 * (zs == 8 ? 8 : WPW)), a, list, bp); });
-  static const bool band3 = std::getenv("KHR_BAND_V3") != nullptr;  // A/B: the round-5 band kernel
-  static const bool band_occ4 = std::getenv("KHR_BAND5_OCC4") != nullptr;
   if (kFuse5Mode == 1) return KHR_OK;
-  if (band3 || bp.n_static + 1024u > kBand5MaxChunks) KHR_LAUNCH_TIMED(7, (&k_band3<BW, 5>), dim3(c->band5_grid), dim3(64 * BW), a, bp);
-  else if (band_occ4) KHR_LAUNCH_TIMED(7, (&k_band5<BW, 4>), dim3(c->band5_grid * 4 / 5), dim3(64 * BW), a, bp);
-  else KHR_LAUNCH_TIMED(7, (&k_band5<BW, 5>), dim3(c->band5_grid), dim3(64 * BW), a, bp);
+  // khr_process_frame (band_fork): the band kernel only touches colour / label / likelihoods and the record pool -- nothing the tracking
+  // pass reads or writes -- so it runs on its own stream beside that pass; the caller joins it before anything else reads those layers
+  hipStream_t band_stream = c->stream;
+  if (c->band_fork) {
+    if (!c->band_stream) HIP_TRY(hipStreamCreateWithFlags(&c->band_stream, hipStreamNonBlocking));
+    if (!c->ev_band_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_band_fork, hipEventDisableTiming));
+    if (!c->ev_band_join) HIP_TRY(hipEventCreateWithFlags(&c->ev_band_join, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->ev_band_fork, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->band_stream, c->ev_band_fork, 0));
+    band_stream = c->band_stream;
+  }
+  KHR_LAUNCH_TIMED_ON(7, band_stream, (&k_band5<BW, 5>), dim3(c->band5_grid), dim3(64 * BW), a, bp);
+  if (c->band_fork) {
+    HIP_TRY(hipEventRecord(c->ev_band_join, c->band_stream));
+    c->band_join_pending = true;
+  }
   return KHR_OK;
-  };
-  using std::integral_constant;
-  if (shape == 1) return body(integral_constant<int, 16>(), integral_constant<int, 4>());  // one 16-wave workgroup per CU, <= 128 VGPRs
-  if (shape == 2) return body(integral_constant<int, 10>(), integral_constant<int, 5>());  // two 10-wave workgroups per CU
-  if (shape == 3) return body(integral_constant<int, 12>(), integral_constant<int, 6>());  // two 12-wave workgroups per CU, <= 80 VGPRs
-  return body(integral_constant<int, 8>(), integral_constant<int, 5>());
 }
 
 static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allocate_blocks, int use_mask,
@@ -1717,9 +1659,9 @@ static int integrateUpdate(khr_ctx* c, FrameSlot& s, const DevFrame& f, int allo
       // non-default switches are test configurations: they always run the bit-exact arithmetic
       a.gate = gate;
       constexpr int WD = kFuseWpwDefault;
-      if (kFuseVer >= 3 && V == 16 && defcfg && fuseBandRowsOk(a.KS, a.sem_mode, a.do_sem, a.has_color) && c->m.capacity <= (1u << 20) &&
-          (kFuseVer == 5 ? integrateUpdate5(c, s, a, list, exact, ZS) : integrateUpdate3(c, s, a, list, exact, ZS)) == KHR_OK) {
-        // k_fuse3 + k_band3 took the call
+      if (kFuseVer >= 5 && V == 16 && defcfg && fuseBandRowsOk(a.KS, a.sem_mode, a.do_sem, a.has_color) && c->m.capacity <= (1u << 20) &&
+          integrateUpdate5(c, s, a, list, exact, ZS) == KHR_OK) {
+        // k_tsdf + k_band5 took the call
         if (c->defer_fold) c->fold_pending = true;
         else hipLaunchKernelGGL(k_fuse_fold, dim3((c->m.capacity + 255) / 256), dim3(256), 0, c->stream, m.blk_flags, m.blk_band,
                                 &m.counters[C_MAX_SLOT], gate);
@@ -4020,6 +3962,11 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
     bool ok = false;
     ~Leave() {
       c->defer_fold = false;
+      c->band_fork = false;
+      if (c->band_join_pending) {  // an error between the update launch and the join: the main stream still has to see the band kernel
+        hipStreamWaitEvent(c->stream, c->ev_band_join, 0);
+        c->band_join_pending = false;
+      }
       if (!ok && c->fold_pending) {  // an error between the update launch and the tracking pass: fold now, nobody else will
         hipLaunchKernelGGL(k_fuse_fold, dim3((c->m.capacity + 255) / 256), dim3(256), 0, c->stream, c->m.blk_flags, c->m.blk_band,
                            &c->m.counters[C_MAX_SLOT], static_cast<const uint32_t*>(nullptr));
@@ -4097,11 +4044,17 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   //      the culling pass and the update kernel, for the seed count's trip to the host and the launch's trip back.)
   bool speculated = false;
   size_t spec_timer = static_cast<size_t>(-1), spec_end = 0;
+  // the band kernel of the update beside the tracking pass (k_tsdf + k_band5 only; joined below, before the output stage)
+  static const bool no_band_fork = std::getenv("KHR_NO_BAND_FORK") != nullptr;
+  const bool band_fork = !no_band_fork && (flags & KHR_PF_TRACKING) && c->cfg.with_tracking;
   // the update kernel's item records are folded into the block flags by the tracking pass's first kernel when it follows directly
   c->defer_fold = (flags & KHR_PF_TRACKING) && c->cfg.with_tracking;  // (reset below, before the tracking pass)
   if (motion && kFuseSpec && c->cfg.with_tracking) {
     const size_t n_pending = c->pending.size();
-    if ((rc = integrateUpdate(c, s, f, 1, 0, -1, nullptr, &c->m.counters[C_N_SEEDS]))) return rc;
+    c->band_fork = band_fork;
+    rc = integrateUpdate(c, s, f, 1, 0, -1, nullptr, &c->m.counters[C_N_SEEDS]);
+    c->band_fork = false;
+    if (rc) return rc;
     if (c->pending.size() > n_pending) spec_timer = n_pending;  // (first of the launch's timer samples)
     spec_end = c->pending.size();
     speculated = true;
@@ -4121,7 +4074,12 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   // (4) TSDF / label update with the dynamic mask, tracking + ever-free
   if (speculated && have_seeds && spec_timer != static_cast<size_t>(-1))  // the gated launches did nothing: not samples
     for (size_t i = spec_timer; i < spec_end && i < c->pending.size(); ++i) c->pending[i].which = -1;
-  if ((!speculated || have_seeds) && (rc = integrateUpdate(c, s, f, 1, motion ? 1 : 0, -1))) return rc;
+  if (!speculated || have_seeds) {
+    c->band_fork = band_fork;
+    rc = integrateUpdate(c, s, f, 1, motion ? 1 : 0, -1);
+    c->band_fork = false;
+    if (rc) return rc;
+  }
   if (c->md_summary_pending >= 0) {  // the dynamic clusters' summaries, behind the update kernels
     const int pend = c->md_summary_pending;
     c->md_summary_pending = -1;
@@ -4140,6 +4098,11 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   }
   rc = (flags & KHR_PF_TRACKING) ? khr_update_tracking(c, frame->timestamp_ns) : KHR_OK;
   c->fork_after_select = false;
+  if (c->band_join_pending) {  // from here on the main stream may read colour / labels / likelihoods again
+    c->band_join_pending = false;
+    if (mc_fork) HIP_TRY(hipStreamWaitEvent(c->mc_stream, c->ev_band_join, 0));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_band_join, 0));
+  }
   if (rc) return rc;
   if (mc_fork) {
     HIP_TRY(hipStreamWaitEvent(c->mc_stream, c->ev_mc_fork, 0));
@@ -4310,7 +4273,7 @@ int khr_get_stats(khr_ctx* c, khr_stats* out) {
   s.n_tsdf_blocks = c->h_counters[C_N_TSDF];
   s.n_fuse_items = static_cast<uint64_t>(c->h_counters[C_N_ITEMS0]) + c->h_counters[C_N_ITEMS1] + c->h_counters[C_N_ITEMS2] +
                    c->h_counters[C_N_ITEMS3];
-  s.band_overflow = c->h_counters[C_BAND_OVERFLOW];  // k_fuse3: in-band records dropped for lack of record chunks (the pool is sized so that this stays 0)
+  s.band_overflow = c->h_counters[C_BAND_OVERFLOW];  // k_tsdf: in-band records dropped for lack of record chunks (the pool is sized so that this stays 0)
   s.n_tracking_processed_blocks = c->h_counters[c->ef_cur ? C_N_PROC2 : C_N_PROC];
   s.cum_updated_voxels = st[S_CUM_UPD] + cur_upd;
   s.cum_band_voxels = st[S_CUM_BAND] + cur_band;

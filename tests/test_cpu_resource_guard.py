@@ -43,23 +43,24 @@ def test_k_fuse_budget():
 
 
 def test_no_update_kernel_uses_scratch_memory():
-    """every instantiation of k_fuse / k_fuse2 / k_fuse3 / k_band3 keeps its working set in registers (scalar spills to vector lanes are
-    fine: v_writelane / v_readlane, no memory)"""
+    """every instantiation of k_tsdf / k_band5 / k_fuse / k_fuse2 keeps its working set in registers (scalar spills to vector lanes are
+    fine: v_writelane / v_readlane, no memory).  Measured in round 6: the same k_tsdf with 21 VGPRs in scratch ran 65 us instead of 44."""
     k = _kernels()
-    for name, r in _pick(k, r"^_ZN3khr(6k_fuseI|7k_fuse2I|7k_fuse3I|7k_band3I)").items():
+    for name, r in _pick(k, r"^_ZN3khr(6k_tsdfI|7k_band5I|6k_fuseI|7k_fuse2I)").items():
         if "Lb1EEEvNS_8FuseArgs" in name and name.startswith("_ZN3khr6k_fuseI") and name.endswith("ELb1EEEvNS_8FuseArgsENS_8FuseListE"):
             continue  # (the DBG instantiation with the in-kernel timeline probe)
         assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, (name, r)
 
 
-def test_k_fuse3_and_k_band3_keep_their_occupancy():
-    """the experiment kernels behind KHR_FUSE_V=3 / 4 are compiled for 5 (4 z ranges) / 7 (8 z ranges) waves per SIMD"""
+def test_k_tsdf_and_k_band5_keep_their_occupancy():
+    """the default update step (khr_kernels_fuse5.h): the voxel kernel at >= 5 waves per SIMD (<= 96 VGPRs), 7 for the 64 x 2 items of
+    small frames; the band kernel at 5"""
     k = _kernels()
-    for name, r in _pick(k, r"^_ZN3khr7k_fuse3ILi4E").items():
-        assert r["Occupancy"] >= 5, (name, r)
-    for name, r in _pick(k, r"^_ZN3khr7k_fuse3ILi8E").items():
-        assert r["Occupancy"] >= 7, (name, r)
-    for name, r in _pick(k, r"^_ZN3khr7k_band3I").items():
+    for name, r in _pick(k, r"^_ZN3khr6k_tsdfILi4ELb[01]ELi8ELi5ELi0E").items():
+        assert r["Occupancy"] >= 5 and r["VGPRs"] <= 96, (name, r)
+    for name, r in _pick(k, r"^_ZN3khr6k_tsdfILi8E").items():
+        assert r["Occupancy"] >= 6, (name, r)
+    for name, r in _pick(k, r"^_ZN3khr7k_band5I").items():
         assert r["Occupancy"] >= 5, (name, r)
 
 

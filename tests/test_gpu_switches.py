@@ -110,13 +110,14 @@ def test_mesh_switches_change_the_mesh():
 
 
 def test_switches_in_the_update_kernel_variants(monkeypatch):
-    """k_fuse3 + k_band3 and the fused-consumption form (KHR_FUSE_V = 3 / 4, khr_kernels_fuse3.h) carry the blend switch in their
-    record lists; both must equal the oracle too"""
-    for ver in ("3", "4", "5"):
+    """k_tsdf + k_band5 (KHR_FUSE_V = 5, khr_kernels_fuse5.h) carry the blend switch in their record lists; they, the default k_fuse
+    (KHR_FUSE_V = 1) and k_fuse2 must all equal the oracle"""
+    for ver in ("5", "1", "2"):
         monkeypatch.setenv("KHR_FUSE_V", ver)
         for blend in (0, 1):
             _run(6, color_blend_weight=blend, exact_arithmetic=1)
-    monkeypatch.setenv("KHR_FUSE_V", "1")
+        _run(4, exact_arithmetic=0)
+    monkeypatch.delenv("KHR_FUSE_V")
     _run(2, exact_arithmetic=1)  # (leaves the process-wide switch at the default for the tests that follow)
 
 

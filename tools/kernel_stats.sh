@@ -17,7 +17,7 @@ if st:
 tr = glob.glob(O + "/prof/**/*kernel_trace.csv", recursive=True)
 rows = sorted(csv.DictReader(open(tr[0])), key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: r["Kernel_Name"].split("(")[0].replace("void ", "").replace("khr::", "")
-fuse = [i for i, r in enumerate(rows) if name(r).startswith("k_fuse<")]
+fuse = [i for i, r in enumerate(rows) if name(r).startswith("k_fuse<") or name(r).startswith("k_tsdf<")]
 timed = fuse[-20:]  # the 20 timed steps are the last 20 update launches of the run
 d = [(int(rows[i]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"])) / 1e3 for i in timed]
 open(O + "/k_fuse_durations.txt", "w").write("# k_fuse, the 20 timed launches (us): mean %.2f min %.2f max %.2f\n%s\n" % (sum(d) / len(d), min(d), max(d), " ".join("%.1f" % x for x in d)))

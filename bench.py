@@ -1041,6 +1041,22 @@ def main():
                 extra[name] = keep
             except Exception as e:  # noqa: BLE001
                 extra[name] = {"error": "%s: %s" % (type(e).__name__, e), "stderr_tail": (r.stderr[-600:] if r is not None else None)}
+        # khronos::ActiveWindow::spinOnce itself (the C++ plugin class of libkhronos_amd_host.so), same stream, same window
+        r = None
+        try:
+            import tempfile
+            from khronos_amd.configs import ACTIVE_WINDOW_YAML
+            with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as tf:
+                tf.write(ACTIVE_WINDOW_YAML % dict(vs=args.voxel_size, trunc=3 * args.voxel_size, buf=args.buffer_frames, labels=K, max_blocks=args.max_blocks))
+            demo = os.path.join(ROOT, "khronos_amd", "lib", "aw_demo")
+            r = subprocess.run([demo, "--bench", tf.name, str(W), str(H), str(pre), str(args.warmup), str(args.steps)], capture_output=True, text=True, timeout=900)
+            os.unlink(tf.name)
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            j["value"] = j["frames_per_s"]
+            j["vs_headline"] = j["frames_per_s"] / fps
+            extra["cxx_active_window"] = j
+        except Exception as e:  # noqa: BLE001
+            extra["cxx_active_window"] = {"error": "%s: %s" % (type(e).__name__, e), "stderr_tail": (r.stderr[-600:] if r is not None else None)}
         out["streams"] = extra
     if rank == 0:
         # The driver parses the LAST stdout line: a compact record (< 6 KB).  Everything else -- sub-streams, per-kernel rooflines,

@@ -238,6 +238,16 @@ int khr_set_frame_image(khr_ctx* ctx, int slot, int which, const int32_t* image,
 int khr_download_frame(khr_ctx* ctx, int slot, float* range, float* vertex_map, int32_t* dynamic_image);
 /* FrameData::dynamic_image (which = 0) or FrameData::object_image (which = 1) of a slot, H*W i32 */
 int khr_download_frame_image(khr_ctx* ctx, int slot, int which, int32_t* image);
+/* replaces: the output's own copy of the frame's InputData (`output->sensor_data = std::make_shared<InputData>(data->input)`,
+ * active_window.cpp:165).  A device-side copy of a slot's normalised input (depth, range, rgba8, labels: 16 bytes per pixel), taken in
+ * stream order by one kernel and independent of the frame ring from then on -- an output may wait in its consumer's queue for any
+ * time without holding a ring slot.  The buffers are pooled per context; a copy may outlive its context (release then frees).
+ * khr_frame_copy_download (blocking; any pointer may be NULL): depth f32 H*W, range f32 H*W, colour rgb8 H*W*3, labels i32 H*W,
+ * vertex map f32 H*W*3 in the world frame (computed from the copied depth as khr_download_frame does from the slot's). */
+typedef struct khr_frame_copy khr_frame_copy;
+int khr_frame_copy_create(khr_ctx* ctx, int slot, khr_frame_copy** out);
+int khr_frame_copy_download(khr_frame_copy* fc, float* depth, float* range, uint8_t* color_rgb, int32_t* labels, float* vertex_map);
+void khr_frame_copy_release(khr_frame_copy* fc);
 /* The same image into a DEVICE buffer (width * height int32), asynchronously on the context stream: the operand of a
  * broadcast when one rank of a sharded run clusters a camera's motion for all (khronos_amd/distributed.py); the
  * receivers paint it with khr_set_frame_image(.., on_device = 1). */

@@ -75,7 +75,7 @@ class KhrStats(C.Structure):
 # every symbol include/khronos_amd.h declares (tests check the library exports all of them)
 EXPORTS = [
     "khr_create", "khr_destroy", "khr_last_error", "khr_host_trace", "khr_set_stream", "khr_sync", "khr_default_config",
-    "khr_upload_frame", "khr_set_frame_image", "khr_download_frame", "khr_integrate", "khr_update_tracking",
+    "khr_upload_frame", "khr_set_frame_image", "khr_download_frame", "khr_frame_copy_create", "khr_frame_copy_download", "khr_frame_copy_release", "khr_integrate", "khr_update_tracking",
     "khr_detect_motion", "khr_generate_mesh", "khr_reset_inactive", "khr_mark_all_inactive", "khr_clear_updated",
     "khr_allocate_blocks", "khr_object_prune", "khr_get_stats", "khr_num_blocks", "khr_block_indices",
     "khr_download_block", "khr_mesh_num_vertices", "khr_download_mesh", "khr_fetch_mesh", "khr_fetch_mesh_into", "khr_timing_enable", "khr_timing_reset",

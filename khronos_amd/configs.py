@@ -41,3 +41,20 @@ active_window:
     min_object_reconstruction_observations: 0
     object_reconstruction_resolution: -0.02
 """
+
+# the whole `active_window:` mapping for khronos::ActiveWindow (libkhronos_amd_host.so) at a bench preset: OBJECT_YAML plus the
+# motion detector / integrators (khronos_ros/config/mapper/uHumans2.yaml:40-57) and the device sizing block -- what
+# `aw_demo --bench` (bench.py stream cxx_active_window) runs
+ACTIVE_WINDOW_YAML = OBJECT_YAML + """  motion_detector:
+    type: "FreeSpaceMotionDetector"
+    min_cluster_size: 500
+    min_separation_distance: 2
+    max_range: 5
+  projective_integrator:
+    num_threads: -1
+  tracking_integrator:
+    num_threads: -1
+  device:
+    num_labels: %(labels)d
+    max_blocks: %(max_blocks)d
+"""

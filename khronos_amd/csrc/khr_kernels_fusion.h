@@ -171,6 +171,27 @@ __global__ void k_tick_publish(uint32_t* __restrict__ counts, int n, volatile ui
   }
 }
 
+// the four normalised planes of a frame slot -> one block (khr_frame_copy_create): depth | range | rgba | label, 16-byte vectors
+__global__ __launch_bounds__(256) void k_frame_copy(const uint4* __restrict__ depth, const uint4* __restrict__ range, const uint4* __restrict__ rgba,
+                                                   const uint4* __restrict__ label, uint4* __restrict__ dst, uint32_t n4) {
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    dst[i] = depth[i];
+    dst[n4 + i] = range[i];
+    dst[2 * n4 + i] = rgba ? rgba[i] : z;
+    dst[3 * n4 + i] = label ? label[i] : z;
+  }
+}
+// rgba8 -> rgb8 (khr_frame_copy_download)
+__global__ __launch_bounds__(256) void k_rgba_to_rgb(const uint32_t* __restrict__ rgba, uint8_t* __restrict__ rgb, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t c = rgba[i];
+  rgb[3 * i] = static_cast<uint8_t>(c);
+  rgb[3 * i + 1] = static_cast<uint8_t>(c >> 8);
+  rgb[3 * i + 2] = static_cast<uint8_t>(c >> 16);
+}
+
 // world-frame vertex map on demand (InputData::vertex_map)
 __global__ __launch_bounds__(256) void k_vertex_map(DevFrame f, float* __restrict__ vertex) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

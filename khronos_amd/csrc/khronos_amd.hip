@@ -175,6 +175,13 @@ struct khr_ctx {
     bool dead = false;
   };
   std::shared_ptr<SnapPool> snap_pool = std::make_shared<SnapPool>();
+  // khr_frame_copy: device blocks of 16 bytes per pixel, pooled like the snapshot arenas (a copy may outlive the context)
+  struct FramePool {
+    std::mutex mu;
+    std::vector<std::pair<uint8_t*, size_t>> free;
+    bool dead = false;
+  };
+  std::shared_ptr<FramePool> frame_pool = std::make_shared<FramePool>();
   khr_snapshot* pending_snapshot = nullptr;  // taken inside khr_process_frame(KHR_PF_SNAPSHOT)
   hipStream_t copy_stream = nullptr;         // khr_snapshot_download_begin: device -> host copies beside the frames' kernels
   hipStream_t snap_stream = nullptr;         // khr_process_frame: the output's snapshot beside its marching cubes (both only read the voxel layers)
@@ -1129,6 +1136,12 @@ void khr_destroy(khr_ctx* c) {
     }
     c->snap_pool->free.clear();
   }
+  {
+    std::lock_guard<std::mutex> lock(c->frame_pool->mu);
+    c->frame_pool->dead = true;  // frame copies still held by a consumer free their blocks themselves from now on
+    for (auto& b : c->frame_pool->free) hipFree(b.first);
+    c->frame_pool->free.clear();
+  }
   if (c->h_frames) hipHostFree(c->h_frames);
   if (c->d_frames) hipFree(c->d_frames);
   if (c->ev_frames) hipEventDestroy(c->ev_frames);
@@ -1338,6 +1351,105 @@ int khr_download_frame(khr_ctx* c, int slot, float* range, float* vertex_map, in
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
   return KHR_OK;
+}
+
+struct khr_frame_copy {
+  std::shared_ptr<khr_ctx::FramePool> pool;
+  uint8_t* block = nullptr;
+  size_t bytes = 0;
+  int device = 0;
+  hipEvent_t ready = nullptr;  // recorded behind the copy kernel
+  DevFrame f{};                // intrinsics + pose of the frame; the plane pointers refer to `block`
+  size_t n = 0, n_pad = 0;
+};
+
+int khr_frame_copy_create(khr_ctx* c, int slot, khr_frame_copy** out) {
+  if (!c || !out || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  FrameSlot& s = c->slots[slot];
+  const size_t n = static_cast<size_t>(s.sensor.width) * s.sensor.height, n_pad = (n + 3) / 4 * 4;
+  if (n_pad > c->cfg.max_frame_pixels) return fail(KHR_EINVAL, "frame larger than max_frame_pixels");
+  auto fc = std::make_unique<khr_frame_copy>();
+  fc->pool = c->frame_pool;
+  fc->device = c->device;
+  fc->bytes = 16 * n_pad;
+  {
+    std::lock_guard<std::mutex> lock(c->frame_pool->mu);
+    auto& fr = c->frame_pool->free;
+    for (size_t i = 0; i < fr.size(); ++i)
+      if (fr[i].second >= fc->bytes) {
+        fc->block = fr[i].first;
+        fc->bytes = fr[i].second;
+        fr.erase(fr.begin() + static_cast<long>(i));
+        break;
+      }
+  }
+  if (!fc->block && hipMalloc(reinterpret_cast<void**>(&fc->block), fc->bytes) != hipSuccess) return fail(KHR_ENOMEM, "frame copy (%zu bytes)", fc->bytes);
+  if (hipEventCreateWithFlags(&fc->ready, hipEventDisableTiming) != hipSuccess) {
+    hipFree(fc->block);
+    return fail(KHR_EDEVICE, "event");
+  }
+  // (the slot's planes are allocated for max_frame_pixels: reading the padding of the last 16-byte vector is inside the allocation)
+  if (s.aux_seq) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_aux_done, 0));  // (an ingest queued on the auxiliary stream)
+  hipLaunchKernelGGL(k_frame_copy, dim3(512), dim3(256), 0, c->stream, reinterpret_cast<const uint4*>(s.vDepth()),
+                     reinterpret_cast<const uint4*>(s.vRange()), s.has_color ? reinterpret_cast<const uint4*>(s.vRgba()) : nullptr,
+                     s.has_label ? reinterpret_cast<const uint4*>(s.vLabel()) : nullptr, reinterpret_cast<uint4*>(fc->block),
+                     static_cast<uint32_t>(n_pad / 4));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(fc->ready, c->stream));
+  fc->f = makeDevFrame(c, s);
+  fc->f.depth = reinterpret_cast<const float*>(fc->block);
+  fc->f.range = reinterpret_cast<const float*>(fc->block + 4 * n_pad);
+  fc->f.rgba = reinterpret_cast<const uint32_t*>(fc->block + 8 * n_pad);
+  fc->f.label = reinterpret_cast<const int32_t*>(fc->block + 12 * n_pad);
+  fc->f.dyn = nullptr;
+  fc->f.obj = nullptr;
+  fc->n = n;
+  fc->n_pad = n_pad;
+  *out = fc.release();
+  return KHR_OK;
+}
+
+int khr_frame_copy_download(khr_frame_copy* fc, float* depth, float* range, uint8_t* color_rgb, int32_t* labels, float* vertex_map) {
+  if (!fc) return fail(KHR_EINVAL, "null frame copy");
+  HIP_TRY(hipSetDevice(fc->device));
+  HIP_TRY(hipEventSynchronize(fc->ready));
+  const size_t n = fc->n;
+  if (depth) HIP_TRY(hipMemcpy(depth, fc->f.depth, n * 4, hipMemcpyDeviceToHost));
+  if (range) HIP_TRY(hipMemcpy(range, fc->f.range, n * 4, hipMemcpyDeviceToHost));
+  if (labels) HIP_TRY(hipMemcpy(labels, fc->f.label, n * 4, hipMemcpyDeviceToHost));
+  if (color_rgb || vertex_map) {
+    DevTemp tmp;
+    HIP_TRY(hipMalloc(&tmp.p, n * 12));
+    if (color_rgb) {
+      hipLaunchKernelGGL(k_rgba_to_rgb, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, fc->f.rgba, tmp.as<uint8_t>(), static_cast<uint32_t>(n));
+      HIP_TRY(hipMemcpy(color_rgb, tmp.p, n * 3, hipMemcpyDeviceToHost));
+    }
+    if (vertex_map) {
+      hipLaunchKernelGGL(k_vertex_map, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, fc->f, tmp.as<float>());
+      HIP_TRY(hipMemcpy(vertex_map, tmp.p, n * 12, hipMemcpyDeviceToHost));
+    }
+  }
+  return KHR_OK;
+}
+
+void khr_frame_copy_release(khr_frame_copy* fc) {
+  if (!fc) return;
+  hipSetDevice(fc->device);
+  if (fc->ready) {
+    hipEventSynchronize(fc->ready);  // (the block goes back to the pool: nothing may still be writing it)
+    hipEventDestroy(fc->ready);
+  }
+  bool pooled = false;
+  {
+    std::lock_guard<std::mutex> lock(fc->pool->mu);
+    if (!fc->pool->dead && fc->pool->free.size() < 8) {
+      fc->pool->free.emplace_back(fc->block, fc->bytes);
+      pooled = true;
+    }
+  }
+  if (!pooled) hipFree(fc->block);
+  delete fc;
 }
 
 int khr_copy_frame_image(khr_ctx* c, int slot, int which, void* device_dst) {

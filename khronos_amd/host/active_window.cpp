@@ -796,13 +796,11 @@ hydra::ActiveWindowOutput::Ptr ActiveWindow::spinOnce(const hydra::InputPacket& 
 
   if (last_full_upated_ + fromSeconds(config.min_output_separation) > latest_stamp_) return nullptr;  // :158-160
   auto output = extractOutputData(*data, config.detach_object_extraction);
-  // (active_window.cpp:165) the output's copy of the InputData carries stamp, poses, sensor and label features; it does NOT
-  // lease the frame's device slot: outputs wait in the consumer's queue for an unbounded time and the frame ring is finite
-  // (the images stay reachable through the frame buffer's own FrameData for as long as the buffer keeps the frame)
+  // (active_window.cpp:165) the output's copy of the InputData: stamp, poses, sensor, label features AND the images -- as a
+  // device-side copy of its own (16 bytes per pixel, one kernel in stream order), not as a lease on the frame's ring slot: outputs
+  // wait in the consumer's queue for an unbounded time and the ring is finite
   output->sensor_data = std::make_shared<InputData>(data->input);
-  output->sensor_data->slot_lease.reset();
-  output->sensor_data->slot = -1;
-  output->sensor_data->ctx = nullptr;
+  output->sensor_data->detachFromRing();
   last_full_upated_ = latest_stamp_;
   chk(khr_clear_updated(ctx_), "khr_clear_updated");  // :169-171
   return output;

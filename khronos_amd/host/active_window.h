@@ -493,6 +493,10 @@ class ActiveWindow : public hydra::ActiveWindowModule {  // active_window.h:67
 
   // times spinOnce had to wait for the extraction worker because every device frame slot was leased (diagnostics)
   size_t numRingWaits() const { return num_ring_waits_; }
+  // wait for the detached object extractions queued so far (object_worker_pool.cpp:115-146); a benchmark's clock stops behind this
+  void joinExtractions() {
+    if (extraction_worker_) extraction_worker_->join();
+  }
   void finishMapping();
   std::vector<std::shared_ptr<KhronosObjectAttributes>> extractObjects();
 

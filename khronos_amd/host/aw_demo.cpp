@@ -14,6 +14,10 @@
 #include <iostream>
 #include <sstream>
 
+#include <chrono>
+
+#include <hip/hip_runtime_api.h>
+
 #include "active_window.h"
 #include "ray_verificator.h"
 
@@ -166,6 +170,83 @@ static int rayverDemo(const char* policy) {
   return 0;
 }
 
+// aw_demo --bench <config.yaml> <width> <height> <preroll> <warmup> <steps>: khronos::ActiveWindow::spinOnce itself, timed the way
+// bench.py times the step-wise C ABI: every frame of the stream is rendered and put into HBM BEFORE the timed
+// region (InputPacket::on_device), preroll + warmup untimed steps, then `steps` calls of step() back to back; the clock stops when
+// the device has drained and the extraction workers have been joined.  One JSON line.
+static int benchDemo(int argc, char** argv) {
+  if (argc < 8) {
+    std::fprintf(stderr, "usage: aw_demo --bench <config.yaml> <width> <height> <preroll> <warmup> <steps>\n");
+    return 2;
+  }
+  std::ifstream in(argv[2]);
+  std::stringstream ss;
+  ss << in.rdbuf();
+  const int W = std::atoi(argv[3]), H = std::atoi(argv[4]), pre = std::atoi(argv[5]), warm = std::atoi(argv[6]), steps = std::atoi(argv[7]);
+  const int N = pre + warm + steps;
+  ActiveWindow::Config cfg = ActiveWindow::Config::fromYamlString(ss.str());
+  cfg.max_frame_pixels = static_cast<uint32_t>(W) * H;
+  auto out_queue = std::make_shared<ActiveWindow::OutputQueue>();
+  ActiveWindow aw(cfg, out_queue);
+  void* scene = synth_create(1234, 12, 1);
+  const size_t n = static_cast<size_t>(W) * H;
+  std::vector<float> depth(n);
+  std::vector<uint8_t> rgb(n * 3);
+  std::vector<int32_t> label(n);
+  std::vector<hydra::InputPacket> pkts(static_cast<size_t>(N));
+  std::vector<void*> dev;
+  for (int i = 0; i < N; ++i) {
+    hydra::InputPacket& pkt = pkts[static_cast<size_t>(i)];
+    pkt.timestamp_ns = static_cast<uint64_t>(std::llround((1.0 + 0.1 * i) * 1e9));
+    circlePose(0.1 * i, pkt.world_T_body);
+    pkt.sensor = {W, H, W / 2.f, W / 2.f, W / 2.f, H / 2.f, 0.1f, 5.f};
+    synth_render(scene, W, H, pkt.sensor.fx, pkt.sensor.fy, pkt.sensor.cx, pkt.sensor.cy, pkt.world_T_body, 0.1 * i, 5.f, 0.f,
+                 1234u + 7919u * i, depth.data(), rgb.data(), label.data(), 0);
+    void *d = nullptr, *c = nullptr, *l = nullptr;
+    if (hipMalloc(&d, n * 4) != hipSuccess || hipMalloc(&c, n * 3) != hipSuccess || hipMalloc(&l, n * 4) != hipSuccess ||
+        hipMemcpy(d, depth.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(c, rgb.data(), n * 3, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(l, label.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess) {
+      std::fprintf(stderr, "aw_demo --bench: device frames\n");
+      return 1;
+    }
+    dev.insert(dev.end(), {d, c, l});
+    pkt.depth = static_cast<const float*>(d);
+    pkt.color = static_cast<const uint8_t*>(c);
+    pkt.labels = static_cast<const int32_t*>(l);
+    pkt.on_device = true;
+  }
+  int n_out = 0;
+  size_t dyn_frames = 0;
+  auto run = [&](int a, int b, bool count) {
+    for (int i = a; i < b; ++i) {
+      auto out = aw.step(pkts[static_cast<size_t>(i)]);
+      hydra::ActiveWindowOutput::Ptr popped;
+      while (out_queue->pop(&popped)) {}
+      if (count) {
+        n_out += out ? 1 : 0;
+        dyn_frames += aw.getLatestFrameData().num_dynamic_clusters > 0 ? 1 : 0;
+      }
+    }
+  };
+  run(0, pre + warm, false);
+  khr_sync(aw.getMap().ctx());
+  const auto t0 = std::chrono::steady_clock::now();
+  run(pre + warm, N, true);
+  const auto t1 = std::chrono::steady_clock::now();
+  aw.joinExtractions();
+  khr_sync(aw.getMap().ctx());
+  const auto t2 = std::chrono::steady_clock::now();
+  const double ms_steps = std::chrono::duration<double, std::milli>(t1 - t0).count(), ms_all = std::chrono::duration<double, std::milli>(t2 - t0).count();
+  std::printf("{\"what\": \"khronos::ActiveWindow::spinOnce (libkhronos_amd_host.so), frames resident in HBM, %dx%d\", \"preroll\": %d, \"warmup\": %d, "
+              "\"steps\": %d, \"frames_per_s\": %.2f, \"ms_per_step\": %.5f, \"steps_ms\": %.4f, \"drain_and_join_ms\": %.4f, \"outputs\": %d, "
+              "\"frames_with_dynamic_clusters\": %zu, \"tracks\": %zu}\n",
+              W, H, pre, warm, steps, 1e3 * steps / ms_all, ms_all / steps, ms_steps, ms_all - ms_steps, n_out, dyn_frames, aw.getTracks().size());
+  aw.finishMapping();
+  for (void* p : dev) hipFree(p);
+  synth_destroy(scene);
+  return 0;
+}
+
 static void onSegv(int sig) {  // a crash must not look like an empty result: print where it happened
   void* bt[48];
   const int n = backtrace(bt, 48);
@@ -181,6 +262,14 @@ int main(int argc, char** argv) {
   if (argc >= 3 && std::string(argv[1]) == "--rayver") {
     try {
       return rayverDemo(argv[2]);
+    } catch (const std::exception& e) {
+      std::fprintf(stderr, "aw_demo: %s\n", e.what());
+      return 1;
+    }
+  }
+  if (argc >= 2 && std::string(argv[1]) == "--bench") {
+    try {
+      return benchDemo(argc, argv);
     } catch (const std::exception& e) {
       std::fprintf(stderr, "aw_demo: %s\n", e.what());
       return 1;
@@ -218,6 +307,9 @@ int main(int argc, char** argv) {
     int n_out = 0;
     size_t n_popped = 0;
     hydra::ActiveWindowOutput::Ptr first_out;  // kept like the frontend's queue keeps it: read after the map has moved on
+    std::vector<float> first_depth;
+    std::vector<uint8_t> first_rgb;
+    std::vector<int32_t> first_label;
     size_t total_dyn_clusters = 0, total_sem_clusters = 0;
     for (int i = 0; i < N; ++i) {
       hydra::InputPacket pkt;
@@ -240,7 +332,12 @@ int main(int argc, char** argv) {
       if (out) {
         std::printf("%s{\"stamp\": %" PRIu64 ", \"updated\": %zu, \"archived\": %zu, \"objects\": %zu}", n_out ? ", " : "", out->timestamp_ns,
                     out->updatedBlocks().size(), out->archived_mesh_indices.size(), out->graph_update.size());
-        if (!first_out) first_out = out;
+        if (!first_out) {
+          first_out = out;
+          first_depth = depth;
+          first_rgb = rgb;
+          first_label = label;
+        }
         ++n_out;
       }
     }
@@ -280,6 +377,19 @@ int main(int argc, char** argv) {
       for (const auto& b : blocks)
         for (size_t k = 0; k < b.distance.size(); ++k) sum += static_cast<double>(b.distance[k]) * b.weight[k];
       std::printf(", \"first_output_clone\": {\"blocks\": %zu, \"checksum\": %.17g}", blocks.size(), sum);
+      // ... and its sensor_data (active_window.cpp:165): the images of ITS frame, long after the ring slot has been reused
+      const auto& sd = *first_out->sensor_data;
+      const std::vector<float> d = sd.depthImage(), r = sd.rangeImage(), vm = sd.vertexMap();
+      const std::vector<uint8_t> c = sd.colorImage();
+      const std::vector<int32_t> l = sd.labelImage();
+      size_t range_valid = 0, vertex_set = 0;
+      for (size_t k = 0; k < r.size(); ++k) {
+        range_valid += r[k] > 0.f ? 1 : 0;
+        vertex_set += (k < vm.size() / 3 && (vm[3 * k] != 0.f || vm[3 * k + 1] != 0.f || vm[3 * k + 2] != 0.f)) ? 1 : 0;
+      }
+      std::printf(", \"first_output_images\": {\"depth_equal\": %s, \"color_equal\": %s, \"labels_equal\": %s, \"range_valid\": %zu, \"vertices\": %zu, "
+                  "\"pixels\": %zu}", d == first_depth ? "true" : "false", c == first_rgb ? "true" : "false", l == first_label ? "true" : "false",
+                  range_valid, vertex_set, r.size());
       first_out.reset();
     }
     // timing/stats.csv of the reference's experiment manager (experiment_manager.cpp:251-258), same scope names

@@ -78,21 +78,50 @@ struct InputData {
     const int s = slot;
     slot_lease = std::shared_ptr<void>(nullptr, [c, s](void*) { khr_release_slot(c, s); });
   }
+  // ActiveWindowOutput::sensor_data (active_window.cpp:165): the output's copy does not lease the ring slot -- outputs wait in a
+  // consumer's queue for an unbounded time -- it owns a device-side copy of the frame's images instead (khr_frame_copy, taken in
+  // stream order when the output is built) and fetches from that
+  std::shared_ptr<khr_frame_copy> images;
+  void detachFromRing() {
+    if (ctx && slot >= 0) {
+      khr_frame_copy* fc = nullptr;
+      if (khr_frame_copy_create(ctx, slot, &fc) == 0 && fc) images = std::shared_ptr<khr_frame_copy>(fc, [](khr_frame_copy* p) { khr_frame_copy_release(p); });
+    }
+    slot_lease.reset();
+    slot = -1;
+    ctx = nullptr;
+  }
   const Sensor& getSensor() const { return sensor; }
   const double* getSensorPose() const { return world_T_sensor; }
-  // host copies (range image H*W, world-frame vertex map H*W*3)
-  // (empty for a copy that does not hold the frame slot any more: ActiveWindowOutput::sensor_data)
+  size_t numPixels() const { return static_cast<size_t>(sensor.width) * sensor.height; }
+  // host copies of the normalised images (InputData::range_image, ::vertex_map, ::depth_image, ::color_image, ::label_image); empty
+  // when neither a slot nor a copy is held
   std::vector<float> rangeImage() const {
-    if (!ctx || slot < 0) return {};
-    std::vector<float> r(static_cast<size_t>(sensor.width) * sensor.height);
-    khr_download_frame(ctx, slot, r.data(), nullptr, nullptr);
+    std::vector<float> r(numPixels());
+    if (ctx && slot >= 0) khr_download_frame(ctx, slot, r.data(), nullptr, nullptr);
+    else if (!images || khr_frame_copy_download(images.get(), nullptr, r.data(), nullptr, nullptr, nullptr) != 0) r.clear();
     return r;
   }
   std::vector<float> vertexMap() const {
-    if (!ctx || slot < 0) return {};
-    std::vector<float> v(static_cast<size_t>(sensor.width) * sensor.height * 3);
-    khr_download_frame(ctx, slot, nullptr, v.data(), nullptr);
+    std::vector<float> v(numPixels() * 3);
+    if (ctx && slot >= 0) khr_download_frame(ctx, slot, nullptr, v.data(), nullptr);
+    else if (!images || khr_frame_copy_download(images.get(), nullptr, nullptr, nullptr, nullptr, v.data()) != 0) v.clear();
     return v;
+  }
+  std::vector<float> depthImage() const {
+    std::vector<float> d(numPixels());
+    if (!images || khr_frame_copy_download(images.get(), d.data(), nullptr, nullptr, nullptr, nullptr) != 0) d.clear();
+    return d;
+  }
+  std::vector<uint8_t> colorImage() const {  // rgb8
+    std::vector<uint8_t> c(numPixels() * 3);
+    if (!images || khr_frame_copy_download(images.get(), nullptr, nullptr, c.data(), nullptr, nullptr) != 0) c.clear();
+    return c;
+  }
+  std::vector<int32_t> labelImage() const {
+    std::vector<int32_t> l(numPixels());
+    if (!images || khr_frame_copy_download(images.get(), nullptr, nullptr, nullptr, l.data(), nullptr) != 0) l.clear();
+    return l;
   }
 };
 

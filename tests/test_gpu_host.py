@@ -173,6 +173,21 @@ def test_no_frame_is_lost_when_extractions_pin_the_ring(tmp_path):
     assert res["n_outputs"] == len(res["outputs"]) >= 6
 
 
+def test_output_sensor_data_keeps_its_images(tmp_path):
+    """active_window.cpp:165: the output carries a copy of the frame's InputData.  Here that copy owns a device-side copy of the images
+    (khr_frame_copy) instead of a lease on the ring slot: the first output of a run is read AFTER 24 more frames on a ring of
+    4 + 1 + 16 slots (the slot has been reused) and after finishMapping -- depth, colour and labels equal what went in."""
+    n_frames = 30
+    cfgp = tmp_path / "aw_small_ring.yaml"
+    cfgp.write_text(YAML.replace("max_buffer_size: 40", "max_buffer_size: 4"))
+    out = subprocess.run([DEMO, str(cfgp), str(W), str(H), str(n_frames)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    img = res["first_output_images"]
+    assert img["depth_equal"] and img["color_equal"] and img["labels_equal"], img
+    assert img["pixels"] == W * H and img["range_valid"] > 0.9 * W * H and img["vertices"] == img["range_valid"], img
+
+
 def test_config_errors_are_loud(tmp_path):
     bad = YAML.replace("temporal_window: *temporal_window", "temporal_window: 0")
     p = tmp_path / "bad.yaml"

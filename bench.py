@@ -155,6 +155,8 @@ def compact_line(out):
         line["cpu_baseline"] = c
     tr = out.get("timed_region", {})
     line["timed_region"] = _pick(tr, ("steps_ms", "drain_and_join_ms", "frames_with_dynamic_clusters", "outputs", "objects_extracted"))
+    if "seed_wait" in out:
+        line["seed_wait"] = _pick(out["seed_wait"], ("waits", "late_over_500us", "max_us"))
     if out.get("latency_ms_per_frame"):
         line["latency_ms_per_frame_mean"] = out["latency_ms_per_frame"]["mean"]
     if "kernel_rooflines" in out:
@@ -230,7 +232,9 @@ def main():
         device=local_rank, rank=rank, world_size=world)
     ctx = FusionContext(cfg)
     # one explicit (non-default) HIP stream shared by torch / RCCL and the fusion kernels
-    stream = torch.cuda.Stream(device=local_rank)
+    # (highest priority, like the context's own streams: the window's streams must not share a hardware queue with the extraction
+    # workers' -- khronos_amd.hip::createStream; KHR_STREAM_PRIORITY=0 switches both off for the A/B)
+    stream = torch.cuda.Stream(device=local_rank, priority=-1 if os.environ.get("KHR_WINDOW_PRIORITY") == "1" else 0)
     ctx.set_stream(stream.cuda_stream)
 
     # object half of the active window: the reference plugins configured as in khronos_ros/config/mapper/uHumans2.yaml:60-100
@@ -829,6 +833,13 @@ def main():
                    "last_frame_touched_blocks": st1["n_tracking_updated_blocks"]},
     }
 
+    # the per-frame host / device meeting, watched (khr_stats: recorded by the library, never printed): waits for the motion detector's seed
+    # count over the whole run (pre-roll, warm-up, timed steps, latency frames), the late ones (> 0.5 ms) with the queues' state
+    out["seed_wait"] = {"waits": st1["n_seed_waits"], "late_over_500us": st1["n_seed_waits_late"], "max_us": st1["seed_wait_max_us"],
+                        "hist_us_50_100_200_500_1k_2k_5k_more": st1["seed_wait_hist"],
+                        "last_late": {"us": st1["seed_wait_late_us"], "wait_no": st1["seed_wait_late_frame"], "state_bits": st1["seed_wait_late_state"]},
+                        "in_timed_steps": {"waits": st1["n_seed_waits"] - st0["n_seed_waits"], "late_over_500us": st1["n_seed_waits_late"] - st0["n_seed_waits_late"]},
+                        "motion_merges_on_device": st1["n_md_device_merges"], "motion_host_walks": st1["n_md_host_walks"]}
     # ---- roofline of the dominant kernel (k_fuse: the fused TSDF / colour / label update), from HIP events on the
     #      kernel's own dispatch packets (hipExtLaunchKernelGGL start / stop events on the kernel's stream) ----
     if not args.no_roofline_timers and rank == 0:

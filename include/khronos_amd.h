@@ -162,6 +162,19 @@ typedef struct khr_stats {
   uint64_t n_tracking_processed_blocks; /* blocks the last tracking pass had to visit (the rest provably cannot change) */
   uint64_t n_fuse_items;       /* last integrate: wave items (64-voxel x-y patch x 2..4 z steps) the update kernel was given,
                                   after block- and item-level culling (n_tsdf_blocks * items-per-block before the latter) */
+  /* watchdog of the one place where the host meets the device every frame (khr_process_frame / khr_detect_motion: the motion
+   * detector's seed count, free_space_motion_detector.cpp:80-103).  Recorded, never printed. */
+  uint64_t n_seed_waits;         /* waits for a seed count since khr_create */
+  uint64_t n_seed_waits_late;    /* ... that took the host longer than 0.5 ms */
+  uint64_t seed_wait_max_us;     /* longest wait */
+  uint64_t seed_wait_hist[8];    /* waits by duration: < 50, < 100, < 200, < 500 us, < 1, < 2, < 5 ms, longer */
+  uint64_t seed_wait_late_us;    /* the latest late wait: its duration ... */
+  uint64_t seed_wait_late_frame; /* ... the wait's ordinal (1-based) ... */
+  uint64_t seed_wait_late_state; /* ... and the queues at the moment the count arrived: bit 0 main stream still busy, bit 1 auxiliary
+                                    stream busy, bit 2 host-to-device stream busy, bit 3 the frame's ingest ran on the auxiliary stream,
+                                    bit 4 the count came through the event path (key import), bits 8.. frames handed over ahead */
+  uint64_t n_md_device_merges;   /* seed frames whose clusters were merged from the device's overlap rows (mergeClusters) */
+  uint64_t n_md_host_walks;      /* seed frames whose seed graph went to the host */
 } khr_stats;
 
 /* khronos::MeasurementCluster role (measurement_clusters.h:63-80) for dynamic clusters

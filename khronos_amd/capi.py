@@ -69,7 +69,9 @@ class KhrStats(C.Structure):
         "n_allocated_blocks", "n_visible_blocks", "n_new_blocks", "n_visited_voxels", "n_updated_voxels",
         "n_band_voxels", "n_tracking_updated_blocks", "n_seeds", "n_mesh_blocks", "n_mesh_vertices",
         "pool_exhausted", "cum_updated_voxels", "cum_band_voxels", "cum_visited_voxels", "cum_integrate_calls", "n_tsdf_blocks", "band_overflow",
-        "n_tracking_processed_blocks", "n_fuse_items")]
+        "n_tracking_processed_blocks", "n_fuse_items", "n_seed_waits", "n_seed_waits_late", "seed_wait_max_us")] + [
+        ("seed_wait_hist", C.c_uint64 * 8)] + [(n, C.c_uint64) for n in (
+        "seed_wait_late_us", "seed_wait_late_frame", "seed_wait_late_state", "n_md_device_merges", "n_md_host_walks")]
 
 
 # every symbol include/khronos_amd.h declares (tests check the library exports all of them)
@@ -590,7 +592,7 @@ class FusionContext:
     def stats(self):
         s = KhrStats()
         self._chk(self.lib.khr_get_stats(self.h, C.byref(s)))
-        return {n: getattr(s, n) for n, _ in KhrStats._fields_}
+        return {n: (list(getattr(s, n)) if n == "seed_wait_hist" else getattr(s, n)) for n, _ in KhrStats._fields_}
 
     DIGEST_LAYERS = ("distance", "weight", "color", "last_observed", "last_occupied", "flags", "sem_label", "likelihoods",
                      "block_flags", "index", "n_blocks", "reserved")

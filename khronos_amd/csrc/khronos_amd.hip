@@ -150,6 +150,7 @@ struct khr_ctx {
   uint32_t* d_band_n = nullptr;
   uint32_t band_chunks = 0;
   int n_cus = 256, fuse5_grid = 0, band5_grid = 0, fuse5_zs = 0;
+  int stream_priority = 0;  // +1 the active window's streams (highest), -1 an object mini-map's (lowest), 0 default (env KHR_STREAM_PRIORITY=0)
   hipStream_t band_stream = nullptr;  // khr_process_frame: the band kernel beside the tracking pass
   hipEvent_t ev_band_fork = nullptr, ev_band_join = nullptr;
   bool band_fork = false, band_join_pending = false;  // per context (= per device): the persistent grids of k_tsdf / the band kernel
@@ -282,6 +283,10 @@ struct khr_ctx {
   int32_t *d_md_seed_final = nullptr, *d_md_bnd_final = nullptr;
   int32_t* d_md_bnd_deg = nullptr;       // per boundary voxel: seeds of kept clusters that list it (k_md_comp_finals / the host walk)
   unsigned long long* d_md_bnd_mask = nullptr;  // per boundary voxel: bit set of the components that list it (k_md_bnd_comps; <= 64 components)
+  // watchdog of the per-frame seed-count wait (khr_stats.n_seed_waits ...)
+  uint64_t n_seed_waits = 0, n_seed_waits_late = 0, seed_wait_max_us = 0, seed_wait_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t seed_wait_late_us = 0, seed_wait_late_frame = 0, seed_wait_late_state = 0;
+  bool last_ingest_on_aux = false;
   uint64_t n_md_device_merges = 0, n_md_host_walks = 0;  // seed frames whose clusters were merged from the device's overlap rows / walked on the host
   std::vector<int32_t> h_md_bnd_deg;
   ClusterAcc* d_md_acc = nullptr;  // [256], index = cluster id
@@ -711,6 +716,19 @@ int khr_retain_slot(khr_ctx* c, int slot) {
 // use-after-free
 static std::mutex g_live_mu;
 static std::vector<khr_ctx*> g_live_ctx;
+// Streams of a context by role.  HIP multiplexes a process's streams onto a handful of hardware queues (4 by default), per priority
+// level: with the window's main / auxiliary / mesh / snapshot / copy streams and the extraction workers' streams all at the default
+// priority, a frame's ingest on the auxiliary stream could sit in the same hardware queue behind an object extraction's 1 - 2 ms
+// kernel chain -- the "one run in ten" late seed count (profiles/r06_seed_latency.txt, state 0xa: main stream idle, auxiliary busy).
+// The active window's streams (16^3 blocks) are created at the highest priority, the object mini-maps' (8^3) at the lowest: different
+// priority levels never share a hardware queue, and the dispatcher prefers the window's workgroups when both have some ready.
+static hipError_t createStream(khr_ctx* c, hipStream_t* out) {
+  int lo = 0, hi = 0;  // (numerically: greatest = lowest priority)
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || lo == hi || c->stream_priority == 0)
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+  return hipStreamCreateWithPriority(out, hipStreamNonBlocking, c->stream_priority > 0 ? hi : lo);
+}
+
 static bool ctxIsLive(khr_ctx* c) {
   std::lock_guard<std::mutex> lock(g_live_mu);
   return std::find(g_live_ctx.begin(), g_live_ctx.end(), c) != g_live_ctx.end();
@@ -823,12 +841,17 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
   }
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+  {
+    static const bool prio_off = std::getenv("KHR_STREAM_PRIORITY") && std::atoi(std::getenv("KHR_STREAM_PRIORITY")) == 0;
+    static const int prio_window = std::getenv("KHR_WINDOW_PRIORITY") ? std::atoi(std::getenv("KHR_WINDOW_PRIORITY")) : 0;
+    c->stream_priority = prio_off ? 0 : (cfg->voxels_per_side == 8 ? -1 : prio_window);
+  }
+  if (createStream(c, &c->stream) != hipSuccess) {
     delete c;
     return fail(KHR_EDEVICE, "hipStreamCreate failed");
   }
   c->own_stream = true;
-  if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+  if (createStream(c, &c->aux_stream) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_aux_done, hipEventDisableTiming) != hipSuccess) {
     delete c;
@@ -1181,7 +1204,7 @@ int khr_set_stream(khr_ctx* c, void* hip_stream) {
   if (hip_stream) {
     c->stream = static_cast<hipStream_t>(hip_stream);
   } else {
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(createStream(c, &c->stream));
     c->own_stream = true;
   }
   return KHR_OK;
@@ -1272,7 +1295,7 @@ int khr_upload_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fram
     // Pageable memory: copies on the ingest's own stream and a host wait below (the caller may reuse the memory at once).
     hipStream_t cs = c->stream;
     if (pinned) {
-      if (!c->h2d_stream) HIP_TRY(hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+      if (!c->h2d_stream) HIP_TRY(createStream(c, &c->h2d_stream));
       hipEvent_t& evh0 = c->h2d_ev_target ? *c->h2d_ev_target : c->ev_h2d;
       if (!evh0) HIP_TRY(hipEventCreateWithFlags(&evh0, hipEventDisableTiming));
       cs = c->h2d_stream;
@@ -1720,7 +1743,7 @@ static int integrateUpdate5(khr_ctx* c, const FrameSlot& s, const FuseArgs& a, c
   // pass reads or writes -- so it runs on its own stream beside that pass; the caller joins it before anything else reads those layers
   hipStream_t band_stream = c->stream;
   if (c->band_fork) {
-    if (!c->band_stream) HIP_TRY(hipStreamCreateWithFlags(&c->band_stream, hipStreamNonBlocking));
+    if (!c->band_stream) HIP_TRY(createStream(c, &c->band_stream));
     if (!c->ev_band_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_band_fork, hipEventDisableTiming));
     if (!c->ev_band_join) HIP_TRY(hipEventCreateWithFlags(&c->ev_band_join, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(c->ev_band_fork, c->stream));
@@ -2487,9 +2510,36 @@ static int motionLaunch(khr_ctx* c, FrameSlot& s, bool fresh_slot, bool do_begin
 // walk the seed graph on the host and paint the dynamic image.  Returns the number of clusters.
 // the seed-pixel count of the latest pixel pass: either the ticket k_motion_pixels' last workgroup writes into pinned
 // memory (spin; the stream keeps running), or the event behind the asynchronous copy of the key-import path
+// the wait's watchdog: duration of every wait into a histogram; a wait of more than 0.5 ms also leaves the state of the context's
+// queues at the moment the count arrived (the "one run in ten" late seed count)
+static void seedWaitDone(khr_ctx* c, std::chrono::steady_clock::time_point t0, bool event_path) {
+  const uint64_t us = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count());
+  ++c->n_seed_waits;
+  c->seed_wait_max_us = std::max(c->seed_wait_max_us, us);
+  static const uint64_t edge[7] = {50, 100, 200, 500, 1000, 2000, 5000};
+  int b = 0;
+  while (b < 7 && us >= edge[b]) ++b;
+  ++c->seed_wait_hist[b];
+  if (us > 500) {
+    ++c->n_seed_waits_late;
+    c->seed_wait_late_us = us;
+    c->seed_wait_late_frame = c->n_seed_waits;
+    uint64_t st = 0;
+    if (hipStreamQuery(c->stream) == hipErrorNotReady) st |= 1u;
+    if (c->aux_stream && hipStreamQuery(c->aux_stream) == hipErrorNotReady) st |= 2u;
+    if (c->h2d_stream && hipStreamQuery(c->h2d_stream) == hipErrorNotReady) st |= 4u;
+    if (c->last_ingest_on_aux) st |= 8u;
+    if (event_path) st |= 16u;
+    st |= static_cast<uint64_t>(c->ahead_q.size()) << 8;
+    c->seed_wait_late_state = st;
+  }
+}
+
 static int waitSeedCount(khr_ctx* c) {
+  const auto t_wait0 = std::chrono::steady_clock::now();
   if (!c->seed_by_ticket) {
     HIP_TRY(hipEventSynchronize(c->ev_seed));
+    seedWaitDone(c, t_wait0, true);
     return KHR_OK;
   }
   if (c->seed_publish_pending) {
@@ -2508,6 +2558,7 @@ static int waitSeedCount(khr_ctx* c) {
     }
   }
   c->h_pinned[0] = hp[2];
+  seedWaitDone(c, t_wait0, false);
   return KHR_OK;
 }
 
@@ -3990,7 +4041,7 @@ static int ingestAhead(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fr
   // results the host waits for at the end of khr_process_frame (seen in the rocprofv3 timeline: main stream idle for 250 us)
   hipStream_t conv_stream = c->aux_stream;
   if (!on_device) {
-    if (!c->h2d_stream) HIP_TRY(hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+    if (!c->h2d_stream) HIP_TRY(createStream(c, &c->h2d_stream));
     conv_stream = c->h2d_stream;
   }
   c->ingest_stream = conv_stream;
@@ -4107,6 +4158,7 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
     c->slot_leases[slot].fetch_sub(1, std::memory_order_acq_rel);  // (the look-ahead's own lease)
   } else {
     c->begin_in_ingest = !early;
+    c->last_ingest_on_aux = early;
     c->ingest_stream = early ? c->aux_stream : nullptr;
     c->host_input_pinned = pinned_in;
     slot = khr_upload_frame(c, sensor, frame, on_device);
@@ -4203,7 +4255,7 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   // their own stream behind k_tracking_select (which has folded the update's block flags) and joined before archival.
   const bool mc_fork = kMcFork && (flags & KHR_PF_OUTPUT) && (flags & KHR_PF_TRACKING) && c->cfg.with_tracking;
   if (mc_fork) {
-    if (!c->mc_stream) HIP_TRY(hipStreamCreateWithFlags(&c->mc_stream, hipStreamNonBlocking));
+    if (!c->mc_stream) HIP_TRY(createStream(c, &c->mc_stream));
     if (!c->ev_mc_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_mc_fork, hipEventDisableTiming));
     if (!c->ev_mc_join) HIP_TRY(hipEventCreateWithFlags(&c->ev_mc_join, hipEventDisableTiming));
     c->fork_after_select = true;
@@ -4235,7 +4287,7 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
       // things: the clone is forked onto its own stream beside the mesh kernels and joined before archival changes the map
       if (c->pending_snapshot) khr_snapshot_release(c->pending_snapshot);
       c->pending_snapshot = nullptr;
-      if (!c->snap_stream) HIP_TRY(hipStreamCreateWithFlags(&c->snap_stream, hipStreamNonBlocking));
+      if (!c->snap_stream) HIP_TRY(createStream(c, &c->snap_stream));
       if (!c->ev_snap_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_snap_fork, hipEventDisableTiming));
       if (!c->ev_snap_join) HIP_TRY(hipEventCreateWithFlags(&c->ev_snap_join, hipEventDisableTiming));
       HIP_TRY(hipEventRecord(c->ev_snap_fork, c->stream));
@@ -4385,6 +4437,15 @@ int khr_get_stats(khr_ctx* c, khr_stats* out) {
   s.n_tsdf_blocks = c->h_counters[C_N_TSDF];
   s.n_fuse_items = static_cast<uint64_t>(c->h_counters[C_N_ITEMS0]) + c->h_counters[C_N_ITEMS1] + c->h_counters[C_N_ITEMS2] +
                    c->h_counters[C_N_ITEMS3];
+  s.n_seed_waits = c->n_seed_waits;
+  s.n_seed_waits_late = c->n_seed_waits_late;
+  s.seed_wait_max_us = c->seed_wait_max_us;
+  for (int i = 0; i < 8; ++i) s.seed_wait_hist[i] = c->seed_wait_hist[i];
+  s.seed_wait_late_us = c->seed_wait_late_us;
+  s.seed_wait_late_frame = c->seed_wait_late_frame;
+  s.seed_wait_late_state = c->seed_wait_late_state;
+  s.n_md_device_merges = c->n_md_device_merges;
+  s.n_md_host_walks = c->n_md_host_walks;
   s.band_overflow = c->h_counters[C_BAND_OVERFLOW];  // k_tsdf: in-band records dropped for lack of record chunks (the pool is sized so that this stays 0)
   s.n_tracking_processed_blocks = c->h_counters[c->ef_cur ? C_N_PROC2 : C_N_PROC];
   s.cum_updated_voxels = st[S_CUM_UPD] + cur_upd;
@@ -4853,7 +4914,7 @@ int khr_snapshot_download_begin(khr_snapshot* s, int32_t* indices, float* distan
   }
   khr_ctx* c = s->ctx;
   HIP_TRY(hipSetDevice(c->device));
-  if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (!c->copy_stream) HIP_TRY(createStream(c, &c->copy_stream));
   if (!s->ev_copied) HIP_TRY(hipEventCreateWithFlags(&s->ev_copied, hipEventDisableTiming));
   HIP_TRY(hipStreamWaitEvent(c->copy_stream, s->ev_packed, 0));
   const size_t nv = s->nvox;

@@ -352,6 +352,12 @@ def main():
             else:
                 stream = torch.cuda.ExternalStream(fusion_cxx.stream(), device=dev)  # the tick's stream, for event ordering
                 dist_host = "cxx"
+                if rank == 0:  # (first line on stderr: what the N-rank run is made of)
+                    print("bench.py: %d ranks, one per GPU; the tick's collectives are issued from C++ (libkhronos_amd_host.so, kdist_*) over %s -- "
+                          "ncclCommInitRank succeeded on all %d ranks (agreed by a MIN all-reduce); motion exchange %s"
+                          % (world, os.environ.get("KDIST_RCCL_LIB", "librccl.so.1"), world,
+                             "dense (KDIST_MOTION_DENSE)" if os.environ.get("KDIST_MOTION_DENSE") else "compact (2 bits / pixel up, 1 byte / pixel down)"),
+                          file=sys.stderr, flush=True)
         elif emu and args.dist_host == "cxx":
             from khronos_amd.host_capi import ShardedFusionHost
             fusion_cxx = ShardedFusionHost(ctx, sensor, 0, world, None, n_cameras=world, halo_cap=args.halo_cap,

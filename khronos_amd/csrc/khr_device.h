@@ -283,36 +283,41 @@ __device__ inline bool blockIsCandidate(const DevParams& p, const DevFrustum& fr
 // world vertex from depth + pose, tracking-block lookup, voxel index, ever-free test.  Returns the packed global voxel
 // index with the seed flag in bit 63, ~0 for skipped pixels.  (r, d) = the frame slot's range / depth of pixel (u, v).
 constexpr uint64_t kSeedFlag = 1ull << 63;
+// the geometric part: the packed global voxel index of the pixel's world vertex (~0 when a range / z gate rejects the pixel), its block
+// and the voxel's linear index inside it.  Depends on the frame and the pose only -- every rank of a sharded run computes the same.
+__device__ inline uint64_t motionPixelVoxel(const DevParams& p, float r, float d, int u, int v, float fx, float fy, float cx, float cy,
+                                            const float* Rw, const float* tw, float md_max_range, float min_z_world, uint64_t* block_key,
+                                            int* lin_out) {
+  if (!(r > 0.f && !(r > md_max_range))) return ~0ull;
+  const float x = ((static_cast<float>(u) - cx) / fx) * d;
+  const float y = ((static_cast<float>(v) - cy) / fy) * d;
+  float pw[3];
+  xform(Rw, tw, x, y, d, pw);
+  if (pw[2] < min_z_world) return ~0ull;
+  const int bx = static_cast<int>(floorf(pw[0] * p.bs_inv)), by = static_cast<int>(floorf(pw[1] * p.bs_inv)),
+            bz = static_cast<int>(floorf(pw[2] * p.bs_inv));
+  const float ox = static_cast<float>(bx) * p.bs, oy = static_cast<float>(by) * p.bs, oz = static_cast<float>(bz) * p.bs;
+  const int vx = static_cast<int>(floorf((pw[0] - ox) * p.vs_inv));
+  const int vy = static_cast<int>(floorf((pw[1] - oy) * p.vs_inv));
+  const int vz = static_cast<int>(floorf((pw[2] - oz) * p.vs_inv));
+  *block_key = packKey(bx, by, bz);
+  if (!(vx >= 0 && vy >= 0 && vz >= 0 && vx < p.vps && vy < p.vps && vz < p.vps)) return ~0ull;
+  *lin_out = vx + p.vps * (vy + p.vps * vz);
+  return packKey(bx * p.vps + vx, by * p.vps + vy, bz * p.vps + vz);
+}
 __device__ inline uint64_t motionPixelKey(const DevMap& m, const DevParams& p, float r, float d, int u, int v, float fx,
                                           float fy, float cx, float cy, const float* Rw, const float* tw,
                                           float md_max_range, float min_z_world, int ignore_epoch = 0) {
-  uint64_t key = ~0ull;
-  if (r > 0.f && !(r > md_max_range)) {
-    const float x = ((static_cast<float>(u) - cx) / fx) * d;
-    const float y = ((static_cast<float>(v) - cy) / fy) * d;
-    float pw[3];
-    xform(Rw, tw, x, y, d, pw);
-    if (!(pw[2] < min_z_world)) {
-      const int bx = static_cast<int>(floorf(pw[0] * p.bs_inv)), by = static_cast<int>(floorf(pw[1] * p.bs_inv)),
-                bz = static_cast<int>(floorf(pw[2] * p.bs_inv));
-      uint32_t slot = htLookup(m, packKey(bx, by, bz));
-      // tick path: blocks the current tick has just allocated (blk_index.w = allocation epoch) did not exist when the
-      // reference would have run the detector (before the frame's integration): not there yet
-      if (slot != kInvalidSlot && ignore_epoch != 0 && m.blk_index[slot].w == ignore_epoch) slot = kInvalidSlot;
-      if (slot != kInvalidSlot) {
-        const float ox = static_cast<float>(bx) * p.bs, oy = static_cast<float>(by) * p.bs,
-                    oz = static_cast<float>(bz) * p.bs;
-        const int vx = static_cast<int>(floorf((pw[0] - ox) * p.vs_inv));
-        const int vy = static_cast<int>(floorf((pw[1] - oy) * p.vs_inv));
-        const int vz = static_cast<int>(floorf((pw[2] - oz) * p.vs_inv));
-        if (vx >= 0 && vy >= 0 && vz >= 0 && vx < p.vps && vy < p.vps && vz < p.vps) {
-          key = packKey(bx * p.vps + vx, by * p.vps + vy, bz * p.vps + vz);
-          const int lin = vx + p.vps * (vy + p.vps * vz);
-          if (m.vflags[static_cast<size_t>(slot) * p.nvox + lin] & VOX_EVER_FREE) key |= kSeedFlag;
-        }
-      }
-    }
-  }
+  uint64_t bkey = 0ull;
+  int lin = 0;
+  uint64_t key = motionPixelVoxel(p, r, d, u, v, fx, fy, cx, cy, Rw, tw, md_max_range, min_z_world, &bkey, &lin);
+  if (key == ~0ull) return key;
+  uint32_t slot = htLookup(m, bkey);
+  // tick path: blocks the current tick has just allocated (blk_index.w = allocation epoch) did not exist when the
+  // reference would have run the detector (before the frame's integration): not there yet
+  if (slot != kInvalidSlot && ignore_epoch != 0 && m.blk_index[slot].w == ignore_epoch) slot = kInvalidSlot;
+  if (slot == kInvalidSlot) return ~0ull;
+  if (m.vflags[static_cast<size_t>(slot) * p.nvox + lin] & VOX_EVER_FREE) key |= kSeedFlag;
   return key;
 }
 

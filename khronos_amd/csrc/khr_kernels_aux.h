@@ -83,6 +83,56 @@ __global__ __launch_bounds__(256) void k_md_keys_import(const uint64_t* __restri
     atomicAdd(n_seed_px, static_cast<uint32_t>(__popcll(b)));
 }
 
+// The compact form of the key exchange (round 6).  A pixel's voxel index depends on the frame and the pose only; what the owner of its
+// block adds is two BITS: "the block exists" and "the voxel is ever-free".  Every rank holds every camera's frame in a sharded tick, so
+// the ranks sum-reduce 2 bits per pixel (two 64-bit lane masks per 64 pixels: exactly one rank owns a pixel's block, so no bit position
+// has two contributors and the sum is the union) instead of 64 -- 230 KB instead of 7.4 MB per 720p camera -- and the camera's home
+// rank rebuilds the key image from its own copy of the frame.
+__global__ __launch_bounds__(256) void k_md_bits_export(const uint64_t* __restrict__ keys, int n, unsigned long long* __restrict__ bits) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t k = i < n ? keys[i] : ~0ull;
+  const unsigned long long ex = __ballot(k != ~0ull), sd = __ballot(k != ~0ull && (k & kSeedBit));
+  if (laneId() == 0 && (i & ~63) < n) {
+    bits[2 * (i >> 6)] = ex;
+    bits[2 * (i >> 6) + 1] = sd;
+  }
+}
+__global__ __launch_bounds__(256) void k_md_keys_from_bits(DevParams p, DevFrame f, float md_max_range, float min_z_world,
+                                                          const unsigned long long* __restrict__ bits, uint64_t* __restrict__ keys,
+                                                          uint32_t* __restrict__ n_seed_px) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = f.W * f.H;
+  uint64_t k = ~0ull;
+  if (i < n) {
+    const unsigned long long ex = bits[2 * (i >> 6)], sd = bits[2 * (i >> 6) + 1];
+    if ((ex >> (i & 63)) & 1ull) {
+      uint64_t bkey;
+      int lin;
+      k = motionPixelVoxel(p, f.range[i], f.depth[i], i % f.W, i / f.W, f.fx, f.fy, f.cx, f.cy, f.Rw, f.tw, md_max_range, min_z_world, &bkey, &lin);
+      if (k != ~0ull && ((sd >> (i & 63)) & 1ull)) k |= kSeedBit;
+    }
+    keys[i] = k;
+  }
+  const unsigned long long b = __ballot(k != ~0ull && (k & kSeedBit));
+  if (b && laneId() == static_cast<uint32_t>(__ffsll(static_cast<long long>(b)) - 1))
+    atomicAdd(n_seed_px, static_cast<uint32_t>(__popcll(b)));
+}
+// the painted dynamic image as one byte per pixel (ids saturate at 255, free_space_motion_detector.cpp:390-395) for the broadcast
+__global__ __launch_bounds__(256) void k_dyn_pack_u8(const int32_t* __restrict__ img, int n4, uint32_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int4 v = reinterpret_cast<const int4*>(img)[i];
+  out[i] = (static_cast<uint32_t>(v.x) & 0xffu) | ((static_cast<uint32_t>(v.y) & 0xffu) << 8) | ((static_cast<uint32_t>(v.z) & 0xffu) << 16) |
+           ((static_cast<uint32_t>(v.w) & 0xffu) << 24);
+}
+__global__ __launch_bounds__(256) void k_dyn_unpack_u8(const uint32_t* __restrict__ in, int n4, int32_t* __restrict__ img) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const uint32_t w = in[i];
+  reinterpret_cast<int4*>(img)[i] = make_int4(static_cast<int>(w & 0xffu), static_cast<int>((w >> 8) & 0xffu), static_cast<int>((w >> 16) & 0xffu),
+                                              static_cast<int>(w >> 24));
+}
+
 // ----------------------------------------------------------------------------------------------
 // Seed-frame pipeline of the motion detector (clusterDynamicVoxels inputs, free_space_motion_detector.cpp
 // :205-272).  The reference's nested hash maps voxel -> pixels become two device hash tables keyed by the

@@ -3099,6 +3099,62 @@ int khr_detect_motion_from_keys(khr_ctx* c, int slot, const void* keys, int on_d
   return motionFinish(c, s);
 }
 
+size_t khr_motion_bits_bytes(int64_t n_pixels) { return n_pixels > 0 ? 16u * static_cast<size_t>((n_pixels + 63) / 64) : 0u; }
+
+int khr_motion_bits(khr_ctx* c, int slot, void* bits_device) {
+  if (!c || !bits_device || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  FrameSlot& s = c->slots[slot];
+  const int n = s.sensor.width * s.sensor.height;
+  int rc = motionLaunch(c, s, false);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_md_bits_export, dim3(gridFor((static_cast<size_t>(n) + 63) / 64 * 64)), dim3(256), 0, c->stream, c->d_keys, n,
+                     static_cast<unsigned long long*>(bits_device));
+  HIP_TRY(hipGetLastError());
+  c->seed_publish_pending = false;  // (nobody waits for this pass's count: the ranks' counts were exchanged before)
+  c->seed_by_ticket = false;
+  return KHR_OK;
+}
+
+int khr_detect_motion_from_bits(khr_ctx* c, int slot, const void* bits_device) {
+  if (!c || !bits_device || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  FrameSlot& s = c->slots[slot];
+  const int n = s.sensor.width * s.sensor.height;
+  if (!s.dyn_clean) HIP_TRY(hipMemsetAsync(s.dyn, 0, sizeof(int32_t) * n, c->stream));
+  s.dyn_clean = true, s.dynw_valid = false;
+  HIP_TRY(hipMemsetAsync(&c->m.counters[C_N_SEEDS], 0, sizeof(uint32_t), c->stream));
+  const float min_z_world = static_cast<float>(s.meta.world_T_sensor[11] + static_cast<double>(c->cfg.md_min_z_coordinate));
+  hipLaunchKernelGGL(k_md_keys_from_bits, dim3(gridFor(n)), dim3(256), 0, c->stream, c->p, makeDevFrame(c, s), c->cfg.md_max_range, min_z_world,
+                     static_cast<const unsigned long long*>(bits_device), c->d_keys, &c->m.counters[C_N_SEEDS]);
+  HIP_TRY(hipMemcpyAsync(&c->h_pinned[0], &c->m.counters[C_N_SEEDS], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipEventRecord(c->ev_seed, c->stream));
+  c->seed_by_ticket = false;
+  return motionFinish(c, s);
+}
+
+int khr_dynamic_pack_u8(khr_ctx* c, int slot, void* dst_device) {
+  if (!c || !dst_device || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  FrameSlot& s = c->slots[slot];
+  const int n4 = (s.sensor.width * s.sensor.height + 3) / 4;  // (the slot's images are allocated for max_frame_pixels, a multiple of 4 or padded)
+  hipLaunchKernelGGL(k_dyn_pack_u8, dim3(gridFor(n4)), dim3(256), 0, c->stream, s.dyn, n4, static_cast<uint32_t*>(dst_device));
+  HIP_TRY(hipGetLastError());
+  return KHR_OK;
+}
+
+int khr_dynamic_unpack_u8(khr_ctx* c, int slot, const void* src_device) {
+  if (!c || !src_device || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  FrameSlot& s = c->slots[slot];
+  const int n4 = (s.sensor.width * s.sensor.height + 3) / 4;
+  hipLaunchKernelGGL(k_dyn_unpack_u8, dim3(gridFor(n4)), dim3(256), 0, c->stream, static_cast<const uint32_t*>(src_device), n4, s.dyn);
+  HIP_TRY(hipGetLastError());
+  s.dyn_clean = false;
+  s.dynw_valid = false;
+  return KHR_OK;
+}
+
 // The motion detector's result of frame slot `src` (painted dynamic image, cluster list) also becomes that of slot `dst`: two
 // slots that hold the SAME camera frame (sender-side ingest of the sharded tick: the rank's own converted frame, which the
 // object half keeps, and its adopted twin in the all-gather buffer, which the tick paints).  Stream-ordered device copy.

@@ -132,6 +132,7 @@ struct kdist_handle {
   khr_sensor sensor{};
   int rank = 0, world = 1, n_cameras = 1;
   bool motion = true, shard_motion = true, always_exchange = false, own_comm = false;
+  bool compact_motion = std::getenv("KDIST_MOTION_DENSE") == nullptr;  // 2 bits per pixel to the home rank, 1 byte per pixel back (round 6)
   bool emulate = false;  // KDIST_EMULATE: the tick of rank `rank` of `world` without the other ranks (no communicator)
   ncclComm_t comm = nullptr;
   hipStream_t stream = nullptr;
@@ -533,7 +534,8 @@ int tickImpl(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, in
         const int home = ci % h->world;
         uint64_t*& keys = h->keys[static_cast<size_t>(ci)];
         if (!keys) keys = h->alloc<uint64_t>(h->npx);
-        KD_KHR(khr_motion_keys(c, slots_out[ci], keys, 1, nullptr));  // (asynchronous: the count is not needed here)
+        const bool compact = h->compact_motion && h->shard_motion && ex && h->net() && h->npx % 4 == 0;
+        if (!compact) KD_KHR(khr_motion_keys(c, slots_out[ci], keys, 1, nullptr));  // (asynchronous: the count is not needed here)
         if (!h->shard_motion) {
           if (ex && h->net()) coll(h, COLL_KEYS, h->npx * 8, [&] { return rccl().AllReduce(keys, keys, h->npx, ncclUint64, ncclSum, h->comm, h->stream); });
           const int nc = khr_detect_motion_from_keys(c, slots_out[ci], keys, 1);
@@ -541,10 +543,34 @@ int tickImpl(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, in
           h->clusters_last_tick[static_cast<size_t>(ci)] = nc;
           continue;
         }
-        // the camera's home rank assembles the key image, clusters it and paints; everybody else receives the painted image
-        if (ex && h->net()) coll(h, COLL_KEYS, h->npx * 8, [&] { return rccl().Reduce(keys, keys, h->npx, ncclUint64, ncclSum, home, h->comm, h->stream); });
+        // the camera's home rank assembles the key image, clusters it and paints; everybody else receives the painted image.
+        // Compact form (round 6, default; KDIST_MOTION_DENSE=1 keeps the dense one): every rank holds the camera's frame, so what
+        // travels to the home rank is 2 bits per pixel ("block exists at its owner", "voxel is ever-free": khr_motion_bits) instead of
+        // the 8-byte key, and the painted image comes back as one byte per pixel
         int32_t*& img = h->dyn_img[static_cast<size_t>(ci)];
         if (ex && !img) img = h->alloc<int32_t>(h->npx + 1);
+        const size_t n_bits_words = khr_motion_bits_bytes(static_cast<int64_t>(h->npx)) / 8;
+        const size_t n_img_words = (h->npx + 3) / 4 + 1;  // u8 image in 32-bit words + the cluster count
+        if (compact) {
+          unsigned long long* const bits = reinterpret_cast<unsigned long long*>(keys);  // (the key buffer is 32 x larger than the bits)
+          KD_KHR(khr_motion_bits(c, slots_out[ci], bits));
+          coll(h, COLL_KEYS, n_bits_words * 8, [&] { return rccl().Reduce(bits, bits, n_bits_words, ncclUint64, ncclSum, home, h->comm, h->stream); });
+          if (h->rank == home) {
+            const int nc = khr_detect_motion_from_bits(c, slots_out[ci], bits);
+            KD_KHR(nc);
+            h->clusters_last_tick[static_cast<size_t>(ci)] = nc;
+            KD_KHR(khr_dynamic_pack_u8(c, slots_out[ci], img));
+            const int32_t nc32 = nc;
+            KD_HIP(hipMemcpyAsync(img + (n_img_words - 1), &nc32, sizeof(nc32), hipMemcpyHostToDevice, h->stream));
+            KD_HIP(hipStreamSynchronize(h->stream));  // (nc32 lives on this stack frame)
+          } else {
+            h->clusters_last_tick[static_cast<size_t>(ci)] = -1;
+          }
+          coll(h, COLL_DYN_IMAGE, h->rank == home ? n_img_words * 4 : 0, [&] { return rccl().Broadcast(img, img, n_img_words, ncclInt32, home, h->comm, h->stream); });
+          if (h->rank != home) KD_KHR(khr_dynamic_unpack_u8(c, slots_out[ci], img));
+          continue;
+        }
+        if (ex && h->net()) coll(h, COLL_KEYS, h->npx * 8, [&] { return rccl().Reduce(keys, keys, h->npx, ncclUint64, ncclSum, home, h->comm, h->stream); });
         if (h->rank == home) {
           const int nc = khr_detect_motion_from_keys(c, slots_out[ci], keys, 1);
           KD_KHR(nc);

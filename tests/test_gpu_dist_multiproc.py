@@ -225,6 +225,14 @@ def test_cxx_tick_whole_block_mesh_records(tmp_path, monkeypatch):
     assert info["blocks"] > 60, info
 
 
+def test_cxx_tick_dense_motion_keys(tmp_path, monkeypatch):
+    """KDIST_MOTION_DENSE=1: the 8-byte-per-pixel key reduce + int32 image broadcast of rounds 2-5, kept as a switch; the default since
+    round 6 is 2 bits per pixel to the home rank (khr_motion_bits) and one byte per pixel back -- both must give the unsharded result"""
+    monkeypatch.setenv("KDIST_MOTION_DENSE", "1")
+    info = _case(tmp_path, "small", 3, 3, ticks=30, out_every=5, extra=SMALL_OBJ + ["--sender-ingest", "0"], timeout_s=420, expect_objects=True)
+    assert info["blocks"] > 60, info
+
+
 def test_cxx_tick_c4_rig_world4(tmp_path):
     """BASELINE configs[3]: 4 x 1280x720, 2 cm, hash-range shards on 4 ranks; motion detector, mesh halo, archival, object half"""
     info = _case(tmp_path, "c4", 4, 4, ticks=8, out_every=4, extra=["--track-window", "0.25", "--track-min-obs", "2", "--buffer-frames", "4"],

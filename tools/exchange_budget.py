@@ -9,7 +9,7 @@ rank talks to every peer directly (all-gather, all-to-all-v, direct all-reduce) 
 bound by the bytes of ONE pair; a ring puts all the bytes through one link per hop.  The mesh halo is run in both forms (compact
 answers over all-to-all-v = default; KDIST_MESH_HALO=records = the all-gather of whole-block records of rounds 2-4).
 
-  python tools/exchange_budget.py > profiles/r05_exchange_budget.txt       (on the GPU box; ~2 minutes)
+  python tools/exchange_budget.py > profiles/r06_exchange_budget.txt       (on the GPU box; ~2 minutes)
 """
 import os
 import sys
@@ -21,17 +21,21 @@ sys.path.insert(0, ROOT)
 LINK_GBPS = 153.0
 
 
-def run(geometry, world, ticks, out_every, tmp, mode, sender):
+def run(geometry, world, ticks, out_every, tmp, mode, sender, dense_motion=False):
     from test_gpu_dist_multiproc import _results, _spawn
     from test_cpu_shm_transport import build_transport
     transport = build_transport()
     env_before = os.environ.get("KDIST_MESH_HALO")
+    if dense_motion:
+        os.environ["KDIST_MOTION_DENSE"] = "1"
+    else:
+        os.environ.pop("KDIST_MOTION_DENSE", None)
     if mode == "records":
         os.environ["KDIST_MESH_HALO"] = "records"
     else:
         os.environ.pop("KDIST_MESH_HALO", None)
     try:
-        out = os.path.join(tmp, "%s_w%d_%s_s%d" % (geometry, world, mode, sender))
+        out = os.path.join(tmp, "%s_w%d_%s_s%d_d%d" % (geometry, world, mode, sender, int(dense_motion)))
         args = ["--cameras", str(world), "--geometry", geometry, "--ticks", str(ticks), "--output-every", str(out_every), "--temporal-window", "0.35",
                 "--temporal-buffer", "0.15", "--period", "4.0", "--track-window", "0.25", "--track-min-obs", "2", "--buffer-frames", "3",
                 "--sender-ingest", str(sender)]
@@ -40,6 +44,7 @@ def run(geometry, world, ticks, out_every, tmp, mode, sender):
             raise SystemExit("ranks failed: %s\n%s" % (rc, txt[0][-2000:]))
         return _results(world, out)
     finally:
+        os.environ.pop("KDIST_MOTION_DENSE", None)
         if env_before is None:
             os.environ.pop("KDIST_MESH_HALO", None)
         else:
@@ -73,9 +78,11 @@ def report(geometry, world, ticks, out_every, tmp):
     print("raw frame: %d B / pixel = %.2f MB per camera; converted planes (sender-side ingest): 12 B / pixel + tile maxima = %.2f MB" %
           (11, 11 * npx / 1e6, (12 * npx + 4 * ((g["width"] + 15) // 16) * ((g["height"] + 15) // 16)) / 1e6))
     outputs = ticks // out_every
-    for mode, sender in (("compact", 0), ("records", 0), ("compact", 1)):
-        res = run(geometry, world, ticks, out_every, tmp, mode, sender)
+    for mode, sender, dense in (("compact", 0, False), ("compact", 0, True), ("records", 0, False), ("compact", 1, False)):
+        res = run(geometry, world, ticks, out_every, tmp, mode, sender, dense)
         print("-" * 130)
+        print("motion exchange: %s" % ("DENSE (KDIST_MOTION_DENSE=1: 8-byte voxel keys reduced to the home rank, int32 image broadcast; rounds 2-5)" if dense else
+                                       "compact (default since round 6: 2 bits per pixel reduced to the home rank, 1 byte per pixel broadcast)"))
         print("mesh halo: %s; ingest: %s" % ({"compact": "compact answers, ncclAllToAllv (default)", "records": "whole-block records, ncclAllGather (KDIST_MESH_HALO=records)"}[mode],
                                              "sender side (converted planes all-gathered inside the tick)" if sender else "every rank converts every raw frame (frames all-gathered, prefetchable a tick ahead)"))
         print("%-26s %8s %16s %16s %14s  %s" % ("collective", "calls", "sent B/call/rank", "recv B/call/rank", "us @153 GB/s", "per"))
@@ -103,7 +110,7 @@ def report(geometry, world, ticks, out_every, tmp):
             print("last output, per rank: requests sent %.0f B (received x%d), answers sent %.0f B, answers received %.0f B (%d answers)" %
                   (np.mean([m["request_bytes_sent"] for m in last]), world, np.mean([m["answer_bytes_sent"] for m in last]),
                    np.mean([m["answer_bytes_received"] for m in last]), int(np.mean([m["answers_received"] for m in last]))))
-        yield mode, sender, res
+        yield mode, sender, res, dense, tick_total
 
 
 def main():
@@ -115,13 +122,18 @@ def main():
     summary = []
     for geometry, world, ticks, out_every in (("c4", 4, 8, 4), ("c5", 8, 6, 3)):
         rec = {}
-        for mode, sender, res in report(geometry, world, ticks, out_every, tmp):
-            if sender == 0:
+        ticks_us = {}
+        for mode, sender, res, dense, tick_total in report(geometry, world, ticks, out_every, tmp):
+            if sender == 0 and not dense:
                 rec[mode] = np.mean([r["mesh_exchange"][-1]["answer_bytes_received"] for r in res])
-        summary.append((geometry, world, rec))
+            if sender == 0 and mode == "compact":
+                ticks_us["dense" if dense else "compact"] = tick_total
+        summary.append((geometry, world, rec, ticks_us))
     print("=" * 130)
     print("mesh halo bytes RECEIVED per rank and output (last output of the run):")
-    for geometry, world, rec in summary:
+    for geometry, world, rec, ticks_us in summary:
+        print("  %s x %d: link time per tick, motion exchange dense -> compact: %.1f -> %.1f us (VERDICT r05 item 6 asked for <= %d)" %
+              (geometry, world, ticks_us["dense"], ticks_us["compact"], 90 if geometry == "c4" else 280))
         print("  %s x %d: whole-block records (all-gather) %.2f MB -> compact answers (all-to-all-v) %.2f MB = %.1f %%" %
               (geometry, world, rec["records"] / 1e6, rec["compact"] / 1e6, 100.0 * rec["compact"] / rec["records"]))
     print()
@@ -132,8 +144,10 @@ def main():
           "the exposed all-gather of the converted planes costs more than that on the links: rows `converted_allgather` above).\n"
           "(The test worker all-gathers the raw frames in both modes -- kdist_tick_own reads only the rank's own camera from them: a\n"
           "deployment with sender-side ingest has no `frames_allgather` row.)\n"
-          "Largest rows a first RCCL run should look at: motion_keys_reduce (8 B / pixel per camera with seeds, to the camera's home rank)\n"
-          "and frames_allgather (overlappable: issued a tick ahead on its own stream by bench.py).")
+          "Round 6: the motion exchange no longer ships voxel keys.  A pixel's voxel index follows from the frame and the pose, which every rank\n"
+          "holds; the owner of the pixel's block contributes two bits (block exists, voxel ever-free), so the reduce to the home rank carries\n"
+          "W x H / 4 bytes (khr_motion_bits) and the painted image returns as one byte per pixel (ids saturate at 255).  The largest row left is\n"
+          "frames_allgather, which bench.py issues a tick ahead on its own stream (overlappable); then halo_allgather.")
 
 
 if __name__ == "__main__":

@@ -502,7 +502,7 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 typedef const u4v __attribute__((address_space(4))) * DescK;
 
 template <int VPS, int ZSPLIT, bool DEFCFG, bool EXACT, int WPW, bool DBG = false>
-__global__ __launch_bounds__(64 * WPW, 3) void k_fuse(FuseArgs a, FuseList list) {  // isa:kernel setup
+__global__ __launch_bounds__(64 * WPW) void k_fuse(FuseArgs a, FuseList list) {  // isa:kernel setup
   constexpr int NV = VPS * VPS * VPS;
   constexpr int SL = VPS * VPS;        // voxels per z slice
   constexpr int PATCHES = SL / 64;     // 64-voxel x-y patches per slice

@@ -4,7 +4,7 @@ import glob
 import json
 import os
 
-import bench
+from khronos_amd import bench_line as bench
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIMIT = 6144

@@ -313,13 +313,13 @@ int khr_detect_motion_from_keys(khr_ctx* ctx, int slot, const void* keys, int on
  * voxel is ever-free".  khr_motion_bits writes two 64-bit lane masks per 64 pixels (khr_motion_bits_bytes(width * height) bytes); a
  * sum reduce over the ranks is their union (one owner per pixel); khr_detect_motion_from_bits rebuilds the key image from the bits
  * and this rank's own copy of the frame in `slot`, then clusters and paints exactly like khr_detect_motion_from_keys.
- * khr_dynamic_pack_u8 / _unpack_u8: FrameData::dynamic_image of a slot as one byte per pixel (ids saturate at 255) for the
+ * khr_dynamic_pack_bytes / _unpack_bytes: FrameData::dynamic_image of a slot as one byte per pixel (ids saturate at 255) for the
  * broadcast from the camera's home rank; `n_bytes` = width * height rounded up to 4. */
 size_t khr_motion_bits_bytes(int64_t n_pixels);
 int khr_motion_bits(khr_ctx* ctx, int slot, void* bits_device);
 int khr_detect_motion_from_bits(khr_ctx* ctx, int slot, const void* bits_device);
-int khr_dynamic_pack_u8(khr_ctx* ctx, int slot, void* dst_device);
-int khr_dynamic_unpack_u8(khr_ctx* ctx, int slot, const void* src_device);
+int khr_dynamic_pack_bytes(khr_ctx* ctx, int slot, void* dst_device);
+int khr_dynamic_unpack_bytes(khr_ctx* ctx, int slot, const void* src_device);
 /* the motion detector's result of frame slot `src` (painted dynamic image, cluster list) also becomes that of `dst`: two slots
  * holding the SAME camera frame (sharded tick with sender-side ingest: the rank's own converted frame, which the object half
  * keeps in its buffer, and its adopted twin in the all-gather buffer, which the tick paints).  Stream-ordered. */

@@ -84,7 +84,7 @@ EXPORTS = [
     "khr_timing_get", "khr_debug_read", "khr_tick_ingest", "khr_tick_integrate", "khr_tick_live_bound", "khr_tick_seed_counts", "khr_converted_bytes", "khr_export_converted",
     "khr_converted_views", "khr_tick_adopt", "khr_copy_frame_image", "khr_rv_detect_changes", "khr_last_removed", "khr_process_frame", "khr_ingest_ahead", "khr_ingest_ahead_host", "khr_ingest_cancel", "khr_integrate_shared", "khr_integrate_shared_batch", "khr_pixel_iou", "khr_forward_instances", "khr_update_tracking_phase",
     "khr_export_halo", "khr_import_halo", "khr_get_dynamic_clusters", "khr_motion_keys", "khr_motion_bits_bytes", "khr_motion_bits", "khr_detect_motion_from_bits",
-    "khr_dynamic_pack_u8", "khr_dynamic_unpack_u8",
+    "khr_dynamic_pack_bytes", "khr_dynamic_unpack_bytes",
     "khr_detect_motion_from_keys", "khr_download_updated", "khr_mesh_halo_requests", "khr_mesh_halo_export",
     "khr_mesh_halo_requests_sorted", "khr_mesh_halo_plan", "khr_mesh_halo_answer", "khr_mesh_halo_adopt",
     "khr_mesh_halo_import", "khr_configure_object_detector", "khr_detect_objects", "khr_get_semantic_clusters",

@@ -3133,7 +3133,7 @@ int khr_detect_motion_from_bits(khr_ctx* c, int slot, const void* bits_device) {
   return motionFinish(c, s);
 }
 
-int khr_dynamic_pack_u8(khr_ctx* c, int slot, void* dst_device) {
+int khr_dynamic_pack_bytes(khr_ctx* c, int slot, void* dst_device) {
   if (!c || !dst_device || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad argument");
   HIP_TRY(hipSetDevice(c->device));
   FrameSlot& s = c->slots[slot];
@@ -3143,7 +3143,7 @@ int khr_dynamic_pack_u8(khr_ctx* c, int slot, void* dst_device) {
   return KHR_OK;
 }
 
-int khr_dynamic_unpack_u8(khr_ctx* c, int slot, const void* src_device) {
+int khr_dynamic_unpack_bytes(khr_ctx* c, int slot, const void* src_device) {
   if (!c || !src_device || slot < 0 || slot >= static_cast<int>(c->slots.size()) || !c->slots[slot].valid) return fail(KHR_EINVAL, "bad argument");
   HIP_TRY(hipSetDevice(c->device));
   FrameSlot& s = c->slots[slot];

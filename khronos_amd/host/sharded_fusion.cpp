@@ -559,7 +559,7 @@ int tickImpl(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, in
             const int nc = khr_detect_motion_from_bits(c, slots_out[ci], bits);
             KD_KHR(nc);
             h->clusters_last_tick[static_cast<size_t>(ci)] = nc;
-            KD_KHR(khr_dynamic_pack_u8(c, slots_out[ci], img));
+            KD_KHR(khr_dynamic_pack_bytes(c, slots_out[ci], img));
             const int32_t nc32 = nc;
             KD_HIP(hipMemcpyAsync(img + (n_img_words - 1), &nc32, sizeof(nc32), hipMemcpyHostToDevice, h->stream));
             KD_HIP(hipStreamSynchronize(h->stream));  // (nc32 lives on this stack frame)
@@ -567,7 +567,7 @@ int tickImpl(kdist_handle* h, uint64_t stamp, const khr_frame* frames, int n, in
             h->clusters_last_tick[static_cast<size_t>(ci)] = -1;
           }
           coll(h, COLL_DYN_IMAGE, h->rank == home ? n_img_words * 4 : 0, [&] { return rccl().Broadcast(img, img, n_img_words, ncclInt32, home, h->comm, h->stream); });
-          if (h->rank != home) KD_KHR(khr_dynamic_unpack_u8(c, slots_out[ci], img));
+          if (h->rank != home) KD_KHR(khr_dynamic_unpack_bytes(c, slots_out[ci], img));
           continue;
         }
         if (ex && h->net()) coll(h, COLL_KEYS, h->npx * 8, [&] { return rccl().Reduce(keys, keys, h->npx, ncclUint64, ncclSum, home, h->comm, h->stream); });

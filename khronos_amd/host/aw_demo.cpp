@@ -241,6 +241,10 @@ static int benchDemo(int argc, char** argv) {
               "\"steps\": %d, \"frames_per_s\": %.2f, \"ms_per_step\": %.5f, \"steps_ms\": %.4f, \"drain_and_join_ms\": %.4f, \"outputs\": %d, "
               "\"frames_with_dynamic_clusters\": %zu, \"tracks\": %zu}\n",
               W, H, pre, warm, steps, 1e3 * steps / ms_all, ms_all / steps, ms_steps, ms_all - ms_steps, n_out, dyn_frames, aw.getTracks().size());
+  if (std::getenv("AW_BENCH_TIMERS"))  // (host view of the reference's timer scopes over the whole run: where spinOnce spends its time)
+    for (const auto& kv : hydra::timing::ElapsedTimeRecorder::instance().stats())
+      std::fprintf(stderr, "%-44s count %6llu  mean %8.4f ms\n", kv.first.c_str(), static_cast<unsigned long long>(kv.second.count),
+                   1e3 * kv.second.sum / static_cast<double>(kv.second.count));
   aw.finishMapping();
   for (void* p : dev) hipFree(p);
   synth_destroy(scene);

@@ -1652,6 +1652,36 @@ __global__ __launch_bounds__(256) void k_reset_inactive(DevMap m, int4* __restri
   }
 }
 
+// k_removed_publish (round 6): the blocks k_reset_inactive is going to drop, listed as soon as the tracking pass has decided them
+// (BLK_HAS_ACTIVE / BLK_ANY_KEEP only change there) -- an output's marching cubes and snapshot, which archival has to wait for, are
+// still running then.  The indices go straight into page-locked host memory, the count and a ticket behind them: the caller of
+// khr_last_removed (ActiveWindowOutput::archived_mesh_indices, active_window.cpp:231-237) no longer waits for the end of the frame.
+__global__ __launch_bounds__(256) void k_removed_publish(DevMap m, int4* __restrict__ host_list, uint32_t* __restrict__ counters,
+                                                        uint32_t* __restrict__ host_words, uint32_t ticket) {
+  const uint32_t n_slots = m.counters[C_MAX_SLOT];
+  for (uint32_t base = blockIdx.x * blockDim.x; base < n_slots; base += gridDim.x * blockDim.x) {
+    const uint32_t s = base + threadIdx.x;
+    bool drop = false;
+    if (s < n_slots) {
+      const uint32_t fl = m.blk_flags[s];
+      drop = (fl & BLK_LIVE) && (!(fl & BLK_HAS_ACTIVE) || !(fl & BLK_ANY_KEEP));
+    }
+    const uint32_t idx = waveAggInc(&counters[0], drop);
+    if (drop) host_list[idx] = m.blk_index[s];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t prev = atomicAdd(&counters[1], 1u);
+    if (prev == gridDim.x - 1) {
+      host_words[0] = atomicExch(&counters[0], 0u);
+      counters[1] = 0u;  // (ready for the next launch, stream order)
+      __threadfence_system();
+      __hip_atomic_store(&host_words[1], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // k_mesh_gather: everything khr_fetch_mesh needs, written by the device straight into pinned host memory in ONE launch
 // (a D2H copy costs ~40-70 us of latency each on this platform, the mesh of an object is a few hundred KB).
 // Layout of dst (32-bit words): header[16] = {total vertices, slots, overflow flag, fits, words needed}, then the

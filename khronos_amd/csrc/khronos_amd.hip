@@ -270,6 +270,11 @@ struct khr_ctx {
   uint64_t last_track_stamp = 0;  // stamp of the latest tracking pass = last_occupied of every VOX_OCC voxel
   bool removed_pending = false;
   int4* d_removed = nullptr;
+  // khr_process_frame(KHR_PF_OUTPUT): the list of the blocks about to be archived, published early (k_removed_publish)
+  int4* h_removed_early = nullptr;       // page-locked, max_blocks entries
+  uint32_t* d_removed_early_n = nullptr; // [0] count, [1] workgroups done
+  uint32_t removed_early_ticket = 0;     // h_pinned[11] (count in h_pinned[10]); 0 = the last archival has no early list
+  bool removed_early = false;
   int* d_idx_staging = nullptr;
   // motion detection scratch
   uint64_t* d_keys = nullptr;
@@ -1169,6 +1174,7 @@ void khr_destroy(khr_ctx* c) {
   if (c->d_frames) hipFree(c->d_frames);
   if (c->ev_frames) hipEventDestroy(c->ev_frames);
   if (c->h_pinned) hipHostFree(c->h_pinned);
+  if (c->h_removed_early) hipHostFree(c->h_removed_early);
   if (c->h_stage) hipHostFree(c->h_stage);
   if (c->h_totals) hipHostFree(c->h_totals);
   if (c->h_up) hipHostFree(c->h_up);
@@ -3732,8 +3738,26 @@ int khr_generate_mesh(khr_ctx* c, int only_mesh_updated, int clear_flag) {
 }
 
 // archival kernels; no host round trip: the hash table / free list rebuild is conditional on the device
+// the archival's list ahead of the archival (khr_process_frame at output frames, behind the tracking pass)
+static int removedPublishLaunch(khr_ctx* c) {
+  if (!c->h_removed_early) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_removed_early), sizeof(int4) * c->m.capacity, hipHostMallocDefault) != hipSuccess)
+      return fail(KHR_ENOMEM, "page-locked list of archived blocks (%zu bytes)", sizeof(int4) * static_cast<size_t>(c->m.capacity));
+    int rc = devAlloc(c, &c->d_removed_early_n, 2);
+    if (rc) return rc;
+  }
+  void* list_dev = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(&list_dev, c->h_removed_early, 0));
+  if (++c->removed_early_ticket == 0) ++c->removed_early_ticket;
+  hipLaunchKernelGGL(k_removed_publish, dim3(gridFor(c->m.capacity)), dim3(256), 0, c->stream, c->m, static_cast<int4*>(list_dev),
+                     c->d_removed_early_n, c->d_pinned + 10, c->removed_early_ticket);
+  HIP_TRY(hipGetLastError());
+  return KHR_OK;
+}
+
 static int resetInactiveLaunch(khr_ctx* c) {
   DevMap& m = c->m;
+  c->removed_early = false;
   HIP_TRY(hipMemsetAsync(&m.counters[C_N_REMOVED], 0, sizeof(uint32_t), c->stream));
   int rc = dispatchVps(c, [&](auto vps) {
     hipLaunchKernelGGL((k_reset_inactive<decltype(vps)::value>), dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_removed);
@@ -3749,6 +3773,25 @@ static int resetInactiveLaunch(khr_ctx* c) {
 }
 
 static int fetchRemoved(khr_ctx* c, int32_t* removed, int64_t cap, int64_t* n_removed) {
+  if (c->removed_early) {  // the last archival was queued by khr_process_frame: its list was published behind the tracking pass
+    const int rcw = waitTicket(c, 11, c->removed_early_ticket, "the list of archived blocks");
+    if (rcw) return rcw;
+    const uint32_t ne = c->h_pinned[10];
+    c->removed_pending = false;
+    if (n_removed) *n_removed = ne;
+    if (ne && removed && cap > 0) {
+      std::vector<int4> tmp(c->h_removed_early, c->h_removed_early + ne);
+      std::sort(tmp.begin(), tmp.end(), [](const int4& a, const int4& b) {
+        return a.x != b.x ? a.x < b.x : (a.y != b.y ? a.y < b.y : a.z < b.z);
+      });
+      for (int64_t i = 0; i < std::min<int64_t>(ne, cap); ++i) {
+        removed[3 * i] = tmp[i].x;
+        removed[3 * i + 1] = tmp[i].y;
+        removed[3 * i + 2] = tmp[i].z;
+      }
+    }
+    return KHR_OK;
+  }
   uint32_t n = 0;
   HIP_TRY(hipMemcpyAsync(&n, &c->m.counters[C_N_REMOVED], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -4324,6 +4367,11 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_band_join, 0));
   }
   if (rc) return rc;
+  // output frames: which blocks the archival below will drop is decided now (the tracking pass has set the block flags it looks at);
+  // their list goes to the host at once, the archival itself has to wait for the mesh kernels and the snapshot
+  static const bool no_early_list = std::getenv("KHR_NO_EARLY_REMOVED") != nullptr;
+  const bool early_list = !no_early_list && (flags & KHR_PF_OUTPUT) && c->cfg.with_tracking;
+  if (early_list && (rc = removedPublishLaunch(c))) return rc;
   if (mc_fork) {
     HIP_TRY(hipStreamWaitEvent(c->mc_stream, c->ev_mc_fork, 0));
     hipStream_t main_stream = c->stream;
@@ -4359,6 +4407,7 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
     else if ((rc = khr_generate_mesh(c, 1, 1))) return rc;
     if (snap) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_snap_join, 0));
     if (c->cfg.with_tracking && (rc = resetInactiveLaunch(c))) return rc;
+    c->removed_early = early_list;
     if ((rc = khr_clear_updated(c))) return rc;
     HT("pf_output_launched");
   }

@@ -484,6 +484,7 @@ ActiveWindow::Config ActiveWindow::Config::fromYaml(const khronos_amd::YamlNode&
     m->read("world_size", c.world_size);
     m->read("exact_arithmetic", c.exact_arithmetic);
     m->read("timing_sync_device", c.timing_sync_device);
+    m->read("fuse_device_stages", c.fuse_device_stages);
   }
   return c;
 }
@@ -622,6 +623,7 @@ ActiveWindow::~ActiveWindow() {
   // buffered frames hold leases on frame slots of the context: they go first (frames a sink copied must not outlive the
   // window either)
   if (extraction_worker_) extraction_worker_->stop();  // (requests hold copies of the frame buffer: they go with it)
+  pending_frame_.reset();
   frame_data_buffer_.clear();
   extraction_worker_.reset();
   if (ctx_) khr_destroy(ctx_);
@@ -731,6 +733,7 @@ hydra::ActiveWindowOutput::Ptr ActiveWindow::spinOnce(const hydra::InputPacket& 
   // device work (normalise, motion detection, integration, tracking) is queued first and they run while the
   // GPU is busy.
   std::shared_ptr<FrameData> data;
+  bool fused_output = false;
   const bool plain_motion = !motion_detector_->isDeviceBacked() && config.motion_detector_type.empty();
   if (motion_detector_->isDeviceBacked() || plain_motion) {
     // fused device step (khr_process_frame): the motion detector's host round trip hides behind allocation
@@ -749,7 +752,19 @@ hydra::ActiveWindowOutput::Ptr ActiveWindow::spinOnce(const hydra::InputPacket& 
     f.depth = input.depth;
     f.color = input.color;
     f.label = input.labels;
-    const uint32_t flags = KHR_PF_TRACKING | (motion_detector_->isDeviceBacked() ? KHR_PF_MOTION : 0u);
+    uint32_t flags = KHR_PF_TRACKING | (motion_detector_->isDeviceBacked() ? KHR_PF_MOTION : 0u);
+    // (round 6) ConnectedSemantics' kernels only read the frame: queued by the same call on the context's second stream, they run
+    // beside the update; object_detector_->processInput below then finds the frame's clusters ready (before: launched and awaited
+    // after the fused call had returned, 0.19 ms of every 0.43 ms frame at 1280 x 720)
+    if (config.fuse_device_stages && dynamic_cast<ConnectedSemantics*>(object_detector_.get())) flags |= KHR_PF_OBJECTS;
+    // the output's device stages (marching cubes beside the snapshot of the updated blocks, archival, flag clearing; :217-237, :169-171)
+    // in the same call at the frames where an output is due.  They do not read anything the object detector or the tracker write;
+    // a sink is handed the map BEFORE archival in the reference (:152-153 come before :163), so with sinks the stages stay where
+    // the reference has them.
+    fused_output = config.fuse_device_stages && sinks_.empty() &&
+                   !(last_full_upated_ + fromSeconds(config.min_output_separation) > latest_stamp_);
+    if (fused_output) flags |= KHR_PF_OUTPUT | KHR_PF_SNAPSHOT;
+    if (input.on_device && input.buffers_complete) flags |= KHR_PF_INPUT_READY;
     int n_clusters = 0;
     // create_data + motion_detection/all + update_map (+ integration/tracking) of the reference are ONE fused device call
     // here; the scope is recorded under the reference's outer name
@@ -777,39 +792,70 @@ hydra::ActiveWindowOutput::Ptr ActiveWindow::spinOnce(const hydra::InputPacket& 
     }
     updateMap(*data);
   }
+  last_num_dynamic_ = data->num_dynamic_clusters;
+  khr_host_trace("aw_device_queued");
+  // the previous frame's association (see below), while this frame's kernels run
+  completePendingFrame();
+  khr_host_trace("aw_prev_associated");
   {
     Timer t("object_detection/all", latest_stamp_);  // connected_semantics.cpp:61, instance_forwarding.cpp:75
     object_detector_->processInput(map_, *data);
   }
-  {
-    Timer t("tracking/all", latest_stamp_);  // max_iou_tracker.cpp:200, external_tracker.cpp:68
-    tracker_->processInput(*data);
+  auto* const iou = dynamic_cast<MaxIoUTracker*>(tracker_.get());
+  if (config.fuse_device_stages && iou && sinks_.empty()) {
+    // (round 6) MaxIoUTracker in two halves (the software pipeline of kop_launch_frame / kop_finish_frame, object_pipeline.cpp): the
+    // voxel-set passes of this frame's clusters are queued now; their results are collected, the tracks associated and the frame
+    // stored (:130-145) when the NEXT spinOnce has queued its device work -- or before anything looks at the tracks or the frame
+    // buffer (getTracks, getLatestFrameData, finishMapping, extractObjects; an output: behind its wait for the archived blocks).  The host no longer waits a device round
+    // trip per frame for them.  Sinks are handed the tracks of THIS frame (:153): with sinks the tracker runs in line.
+    Timer t("tracking/all", latest_stamp_);
+    iou->beginInput(*data);
+    pending_frame_ = data;
+  } else {
+    {
+      Timer t("tracking/all", latest_stamp_);  // max_iou_tracker.cpp:200, external_tracker.cpp:68
+      tracker_->processInput(*data);
+    }
+    frame_data_buffer_.trimBuffer(tracker_->getTracks());
+    frame_data_buffer_.storeData(data);
   }
-
-  frame_data_buffer_.trimBuffer(tracker_->getTracks());
-  frame_data_buffer_.storeData(data);
   ++num_frames_processed_;
+  khr_host_trace("aw_tracker_queued");
   {
     Timer sink_timer("active_window/sinks", latest_stamp_);  // active_window.cpp:152
     for (const auto& sink : sinks_) sink(*data, map_, tracker_->getTracks());
   }
 
   if (last_full_upated_ + fromSeconds(config.min_output_separation) > latest_stamp_) return nullptr;  // :158-160
-  auto output = extractOutputData(*data, config.detach_object_extraction);
+  auto output = extractOutputData(*data, config.detach_object_extraction, fused_output);
   // (active_window.cpp:165) the output's copy of the InputData: stamp, poses, sensor, label features AND the images -- as a
   // device-side copy of its own (16 bytes per pixel, one kernel in stream order), not as a lease on the frame's ring slot: outputs
   // wait in the consumer's queue for an unbounded time and the ring is finite
+  khr_host_trace("aw_output_extracted");
   output->sensor_data = std::make_shared<InputData>(data->input);
   output->sensor_data->detachFromRing();
+  khr_host_trace("aw_sensor_data_copied");
   last_full_upated_ = latest_stamp_;
-  chk(khr_clear_updated(ctx_), "khr_clear_updated");  // :169-171
+  if (!fused_output) chk(khr_clear_updated(ctx_), "khr_clear_updated");  // :169-171
   return output;
 }
 
-hydra::ActiveWindowOutput::Ptr ActiveWindow::extractOutputData(const FrameData& data, bool threaded) {
+void ActiveWindow::completePendingFrame() const {
+  if (!pending_frame_) return;
+  std::shared_ptr<FrameData> data = std::move(pending_frame_);
+  pending_frame_.reset();
+  {
+    Timer t("tracking/associate_deferred", data->input.timestamp_ns);
+    static_cast<MaxIoUTracker*>(tracker_.get())->completeInput(*data);
+  }
+  frame_data_buffer_.trimBuffer(tracker_->getTracks());
+  frame_data_buffer_.storeData(data);
+}
+
+hydra::ActiveWindowOutput::Ptr ActiveWindow::extractOutputData(const FrameData& data, bool threaded, bool device_stages_queued) {
   // active_window.cpp:217-249
   Timer timer("active_window/extract_output", latest_stamp_, config.timing_sync_device);  // :220
-  chk(khr_generate_mesh(ctx_, 1, 1), "khr_generate_mesh");
+  if (!device_stages_queued) chk(khr_generate_mesh(ctx_, 1, 1), "khr_generate_mesh");
   auto output = std::make_shared<hydra::ActiveWindowOutput>();
   output->timestamp_ns = data.input.timestamp_ns;
   for (int r = 0; r < 3; ++r) {
@@ -819,20 +865,25 @@ hydra::ActiveWindowOutput::Ptr ActiveWindow::extractOutputData(const FrameData& 
   output->map_ctx = ctx_;
   {  // output->setMap(map.cloneUpdated()) (:229): snapshot on the device, in stream order, no host round trip
     khr_snapshot* snap = nullptr;
-    chk(khr_snapshot_updated(ctx_, KHR_SNAP_ALL, config.max_snapshot_blocks, &snap), "khr_snapshot_updated");
+    if (device_stages_queued) chk(khr_take_snapshot(ctx_, &snap), "khr_take_snapshot");
+    else chk(khr_snapshot_updated(ctx_, KHR_SNAP_ALL, config.max_snapshot_blocks, &snap), "khr_snapshot_updated");
     output->setMap(snap);
     output->snapshot_capacity = std::min<int64_t>(config.max_snapshot_blocks ? config.max_snapshot_blocks : config.max_blocks, config.max_blocks);
   }
   // archive after cloning / meshing (:231-237)
   if (config.volumetric_map.with_tracking) {
-    std::vector<int32_t> removed(3 * static_cast<size_t>(config.max_blocks));
+    std::vector<int32_t>& removed = removed_scratch_;  // (kept: 12 bytes x max_blocks, not allocated and zeroed per output)
+    removed.resize(3 * static_cast<size_t>(config.max_blocks));
     int64_t n = 0;
-    chk(khr_reset_inactive(ctx_, removed.data(), config.max_blocks, &n), "khr_reset_inactive");
+    if (device_stages_queued) chk(khr_last_removed(ctx_, removed.data(), config.max_blocks, &n), "khr_last_removed");
+    else chk(khr_reset_inactive(ctx_, removed.data(), config.max_blocks, &n), "khr_reset_inactive");
     output->archived_mesh_indices.resize(static_cast<size_t>(n));
     for (int64_t i = 0; i < n; ++i) output->archived_mesh_indices[i] = {removed[3 * i], removed[3 * i + 1], removed[3 * i + 2]};
   }
   // :238-247: inactive tracks go to the worker pool; a blocking call (finishMapping, detach_object_extraction: false) waits
   // for them; the output carries whatever has finished by now (with detached extraction: objects of earlier outputs too)
+  khr_host_trace("aw_archived_fetched");
+  completePendingFrame();  // (the tracks as of this frame)
   extractInactiveObjects();
   if (extraction_worker_) {
     if (!threaded) extraction_worker_->join();
@@ -858,6 +909,7 @@ void ActiveWindow::extractInactiveObjects() {
 void ActiveWindow::finishMapping() {
   std::lock_guard<std::mutex> lock(mutex_);
   // active_window.cpp:176-189: everything inactive, then a blocking output extraction
+  completePendingFrame();
   chk(khr_mark_all_inactive(ctx_), "khr_mark_all_inactive");
   for (Track& t : tracker_->getTracks()) t.is_active = false;
   if (!frame_data_buffer_.empty()) extractOutputData(frame_data_buffer_.getLatestData(), false);
@@ -867,6 +919,7 @@ std::vector<std::shared_ptr<KhronosObjectAttributes>> ActiveWindow::extractObjec
   std::vector<std::shared_ptr<KhronosObjectAttributes>> result;
   std::lock_guard<std::mutex> lock(mutex_);
   if (!extraction_worker_) return result;
+  completePendingFrame();
   for (const Track& t : tracker_->getTracks()) {  // active_window.cpp:191-201
     auto obj = extraction_worker_->runBlocking(t, frame_data_buffer_);
     if (obj) result.push_back(obj);

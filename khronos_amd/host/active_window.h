@@ -462,6 +462,9 @@ class ActiveWindow : public hydra::ActiveWindowModule {  // active_window.h:67
     // hydra::timing scopes (hydra_compat.h): wait for the device before a scope that launched device work stops, so that
     // "active_window/all" is the per-frame latency the reference's timer measures (off: enqueue time only)
     bool timing_sync_device = false;
+    // one khr_process_frame call per frame carries the object detector's kernels and, at output frames without sinks, the
+    // output's device stages (false: every stage where the reference's spinOnce has it, one call each)
+    bool fuse_device_stages = true;
 
     // parse the `active_window:` mapping of a Khronos mapper YAML (same keys as uHumans2.yaml:35-100)
     static Config fromYaml(const khronos_amd::YamlNode& active_window_node);
@@ -479,8 +482,14 @@ class ActiveWindow : public hydra::ActiveWindowModule {  // active_window.h:67
   // access (not thread-safe, as in the reference)
   VolumetricMap& getMap() { return map_; }
   const VolumetricMap& getMap() const { return map_; }
-  const FrameData& getLatestFrameData() const { return frame_data_buffer_.getLatestData(); }
-  const Tracks& getTracks() const { return tracker_->getTracks(); }
+  const FrameData& getLatestFrameData() const {
+    completePendingFrame();
+    return frame_data_buffer_.getLatestData();
+  }
+  const Tracks& getTracks() const {
+    completePendingFrame();
+    return tracker_->getTracks();
+  }
   void addKhronosSink(const KhronosSink& sink);
   // factory registry behind the `khronos_sinks` config key: type name -> factory(config mapping of the list entry).  An entry
   // whose type nobody registered is reported and skipped (config_utilities logs "cannot create" and hands back nullptr,
@@ -489,10 +498,15 @@ class ActiveWindow : public hydra::ActiveWindowModule {  // active_window.h:67
   static bool registerKhronosSink(const std::string& type, KhronosSinkFactory factory);
   size_t numKhronosSinks() const { return sinks_.size(); }
   void setObjectDetector(std::unique_ptr<ObjectDetector> d) { object_detector_ = std::move(d); }
-  void setTracker(std::unique_ptr<Tracker> t) { tracker_ = std::move(t); }
+  void setTracker(std::unique_ptr<Tracker> t) {
+    completePendingFrame();
+    tracker_ = std::move(t);
+  }
 
   // times spinOnce had to wait for the extraction worker because every device frame slot was leased (diagnostics)
   size_t numRingWaits() const { return num_ring_waits_; }
+  // FrameData::dynamic_clusters.size() of the frame spinOnce processed last (without touching the frame buffer)
+  int numDynamicClustersOfLastFrame() const { return last_num_dynamic_; }
   // wait for the detached object extractions queued so far (object_worker_pool.cpp:115-146); a benchmark's clock stops behind this
   void joinExtractions() {
     if (extraction_worker_) extraction_worker_->join();
@@ -507,8 +521,11 @@ class ActiveWindow : public hydra::ActiveWindowModule {  // active_window.h:67
 
   std::shared_ptr<FrameData> createData(const hydra::InputPacket& input) const;
   void updateMap(const FrameData& data);
-  hydra::ActiveWindowOutput::Ptr extractOutputData(const FrameData& data, bool threaded);
+  // device_stages_queued: mesh, snapshot, archival and flag clearing were queued by this frame's khr_process_frame call
+  hydra::ActiveWindowOutput::Ptr extractOutputData(const FrameData& data, bool threaded, bool device_stages_queued = false);
   void extractInactiveObjects();
+  // second half of the previous frame's tracker step (association, trimBuffer, storeData) when spinOnce deferred it
+  void completePendingFrame() const;
 
   khr_ctx* ctx_ = nullptr;
   khr_config device_config_{};
@@ -519,11 +536,14 @@ class ActiveWindow : public hydra::ActiveWindowModule {  // active_window.h:67
   std::unique_ptr<ObjectWorkerPool> extraction_worker_;  // owns the extractor(s) (active_window.h:189)
   std::mutex mutex_;
   std::vector<KhronosSink> sinks_;
-  FrameDataBuffer frame_data_buffer_;
+  mutable FrameDataBuffer frame_data_buffer_;
+  mutable std::shared_ptr<FrameData> pending_frame_;  // queued voxel-set passes, association outstanding (completePendingFrame)
   TimeStamp latest_stamp_ = 0;
   TimeStamp last_full_upated_ = 0;
   size_t num_frames_processed_ = 0;
   mutable size_t num_ring_waits_ = 0;
+  int last_num_dynamic_ = 0;
+  std::vector<int32_t> removed_scratch_;  // extractOutputData: the archived blocks' indices on their way into the output
 
   // active_window.h:190-192: `active_window: {type: "ActiveWindow", ...}` in the mapper YAML creates this class
   inline static const hydra::ActiveWindowRegistration<ActiveWindow> registration_{"ActiveWindow"};

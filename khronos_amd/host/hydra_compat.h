@@ -46,6 +46,8 @@ struct InputPacket {
   const uint8_t* color = nullptr;   // H*W*3
   const int32_t* labels = nullptr;  // H*W
   bool on_device = false;           // buffers are HBM-resident on the context's device
+  bool buffers_complete = false;    // on_device: no stream is still writing the buffers when the packet is handed over (KHR_PF_INPUT_READY:
+                                    // the conversion may then run on the context's second stream, beside the previous frame's tail)
   // open-set features of the instance ids of `labels` (InputData::label_features, used at instance_forwarding.cpp:96,141)
   std::map<int, std::vector<float>> label_features;
 };

@@ -66,14 +66,25 @@ def _pick_label():
     return int(np.argmax(cnt))
 
 
-def test_active_window_host_mirror(tmp_path):
+def _demo_env(fused):
+    """fused: no Khronos sink registered -- spinOnce then queues the output's device stages (and ConnectedSemantics' kernels) with the
+    frame's khr_process_frame call and defers MaxIoUTracker's association behind the next frame's launch (round 6); with a sink
+    every stage runs where the reference's spinOnce has it.  Both forms must produce the same outputs."""
+    env = dict(os.environ)
+    if fused:
+        env["AW_DEMO_NO_SINK"] = "1"
+    return env
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_active_window_host_mirror(tmp_path, fused):
     label = _pick_label()
     cfgp = tmp_path / "aw.yaml"
     cfgp.write_text(YAML)
-    out = subprocess.run([DEMO, str(cfgp), str(W), str(H), str(N), str(label)], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([DEMO, str(cfgp), str(W), str(H), str(N), str(label)], capture_output=True, text=True, timeout=300, env=_demo_env(fused))
     assert out.returncode == 0, out.stderr
     res = json.loads(out.stdout.strip().splitlines()[-1])
-    assert res["sink_calls"] == N
+    assert res["sink_calls"] == (0 if fused else N)
 
     # ---- step-wise replica through the C ABI (+ oracle for the object mini-map) ----
     cfg, ctx, ora, s, sen, osen = make_pair(width=W, height=H, temporal_window=0.75, truncation_distance=0.3,
@@ -173,14 +184,15 @@ def test_no_frame_is_lost_when_extractions_pin_the_ring(tmp_path):
     assert res["n_outputs"] == len(res["outputs"]) >= 6
 
 
-def test_output_sensor_data_keeps_its_images(tmp_path):
+@pytest.mark.parametrize("fused", [False, True])
+def test_output_sensor_data_keeps_its_images(tmp_path, fused):
     """active_window.cpp:165: the output carries a copy of the frame's InputData.  Here that copy owns a device-side copy of the images
     (khr_frame_copy) instead of a lease on the ring slot: the first output of a run is read AFTER 24 more frames on a ring of
     4 + 1 + 16 slots (the slot has been reused) and after finishMapping -- depth, colour and labels equal what went in."""
     n_frames = 30
     cfgp = tmp_path / "aw_small_ring.yaml"
     cfgp.write_text(YAML.replace("max_buffer_size: 40", "max_buffer_size: 4"))
-    out = subprocess.run([DEMO, str(cfgp), str(W), str(H), str(n_frames)], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([DEMO, str(cfgp), str(W), str(H), str(n_frames)], capture_output=True, text=True, timeout=600, env=_demo_env(fused))
     assert out.returncode == 0, out.stderr
     res = json.loads(out.stdout.strip().splitlines()[-1])
     img = res["first_output_images"]
@@ -215,14 +227,15 @@ PLUGIN_YAML = YAML.replace("""  object_extractor:""", """  object_detector:
   object_extractor:""")
 
 
-def test_active_window_with_detector_and_tracker_plugins(tmp_path):
+@pytest.mark.parametrize("fused", [False, True])
+def test_active_window_with_detector_and_tracker_plugins(tmp_path, fused):
     """ConnectedSemantics + MaxIouTracker configured from YAML (uHumans2.yaml:60-77 keys) inside the C++ ActiveWindow
     against the step-wise C ABI (device clustering / voxel sets) + the independent Python tracker restatement."""
     import py_tracker
     n_frames = 24
     cfgp = tmp_path / "aw_plugins.yaml"
     cfgp.write_text(PLUGIN_YAML)
-    out = subprocess.run([DEMO, str(cfgp), str(W), str(H), str(n_frames)], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([DEMO, str(cfgp), str(W), str(H), str(n_frames)], capture_output=True, text=True, timeout=600, env=_demo_env(fused))
     assert out.returncode == 0, out.stderr
     res = json.loads(out.stdout.strip().splitlines()[-1])
 

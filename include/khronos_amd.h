@@ -569,7 +569,9 @@ int64_t khr_mesh_num_vertices(khr_ctx* ctx);
 int khr_fetch_mesh_launch(khr_ctx* ctx);
 /* The pinned staging block behind khr_fetch_mesh grows on demand (x 1.5 of what a mesh needed); a growth re-allocates tens of
  * megabytes of page-locked memory (tens of milliseconds) and repeats the gather.  A consumer that fetches the mesh at every output
- * reserves room for n_vertices once (40 B per vertex + the block table); synchronises the context's stream. */
+ * reserves room for n_vertices once (40 B per vertex + the block table).  A block that is already large enough is left alone -- a
+ * gather queued by khr_fetch_mesh_launch stays collectable; only a replacement synchronises the context's stream and drops a
+ * queued gather (the next khr_fetch_mesh then gathers again). */
 int khr_reserve_mesh_staging(khr_ctx* ctx, uint64_t n_vertices);
 /* the same mesh with ONE host round trip, in two halves so that the caller can size its arrays in between:
  * khr_fetch_mesh makes the device gather block table + vertex arrays into pinned memory (one launch, one wait) and

@@ -238,9 +238,8 @@ struct khr_ctx {
   void* h_stage = nullptr;
   size_t h_stage_bytes = 0;
   uint32_t* h_totals = nullptr;  // refreshMeshTotals' own pinned words
-  void* h_up = nullptr;                          // upload staging (khr_allocate_blocks) + its device twin
+  void* h_up = nullptr;                          // upload staging (khr_allocate_blocks: page-locked, read by the kernel in place)
   size_t h_up_bytes = 0;
-  void* d_up = nullptr;
   hipEvent_t ev_ingest = nullptr;                // khr_process_frame: this frame's main-stream ingest is queued
   hipEvent_t ev_up = nullptr;                    // the last upload out of h_up has been consumed
   hipStream_t ingest_stream = nullptr;           // khr_process_frame: ingest on the auxiliary stream (set around khr_upload_frame)
@@ -874,8 +873,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   // an extraction whose list outgrew the 64 KB grew it from its worker thread, and the hipMalloc waited 5 - 11 ms for the window's
   // frames to leave the device idle, profiles/r05_host_input_marks.txt)
   c->h_up_bytes = std::max<size_t>(1u << 16, cfg->voxels_per_side == 8 ? sizeof(int32_t) * 3 * static_cast<size_t>(cfg->max_blocks) : 0);
-  if (ensureStage(c, 1u << 20) != KHR_OK || hipHostMalloc(&c->h_up, c->h_up_bytes, hipHostMallocDefault) != hipSuccess ||
-      hipMalloc(&c->d_up, c->h_up_bytes) != hipSuccess) {
+  if (ensureStage(c, 1u << 20) != KHR_OK || hipHostMalloc(&c->h_up, c->h_up_bytes, hipHostMallocDefault) != hipSuccess) {
     delete c;
     return fail(KHR_ENOMEM, "pinned staging buffers");
   }
@@ -1178,7 +1176,6 @@ void khr_destroy(khr_ctx* c) {
   if (c->h_stage) hipHostFree(c->h_stage);
   if (c->h_totals) hipHostFree(c->h_totals);
   if (c->h_up) hipHostFree(c->h_up);
-  if (c->d_up) hipFree(c->d_up);
   if (c->ev_up) hipEventDestroy(c->ev_up);
   if (c->ev_ingest) hipEventDestroy(c->ev_ingest);
   if (c->h_tick) hipHostFree(c->h_tick);
@@ -1551,10 +1548,10 @@ struct UpdateLists {
 // striding over the work items, so workgroups beyond residency would only add a tail)
 static int fuseGrid(khr_ctx* c, const void* kernel, int group, int block) {
   if (kFuseGrid > 0) return std::max(8 * group, kFuseGrid / (8 * group) * (8 * group));
-  static std::map<const void*, int> cache;
+  static std::map<std::pair<int, const void*>, int> cache;  // (per device: the grid depends on its CU count)
   static std::mutex cache_mu;  // contexts of different threads (active window + extraction workers) launch concurrently
   std::lock_guard<std::mutex> lock(cache_mu);
-  const void* key = kernel;
+  const std::pair<int, const void*> key{c->device, kernel};
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   int per_cu = 0, cus = 256;
@@ -1572,10 +1569,11 @@ static int fuseGrid(khr_ctx* c, const void* kernel, int group, int block) {
 // the per-frame part of the update kernel's arguments
 // resident workgroups of a k_fuse2 instantiation x CUs (occupancy query, cached per kernel)
 static int fuse2Grid(khr_ctx* c, const void* kern, int wpw) {
-  static std::map<const void*, int> cache;
+  static std::map<std::pair<int, const void*>, int> cache;
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
-  auto it = cache.find(kern);
+  const std::pair<int, const void*> key{c->device, kern};
+  auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * wpw, 0) != hipSuccess || per_cu < 1) per_cu = 1;
@@ -1584,7 +1582,7 @@ static int fuse2Grid(khr_ctx* c, const void* kern, int wpw) {
   if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   int grid = std::min(kFuseStatSlots, per_cu * cus) / 8 * 8;
   if (kFuseGrid > 0) grid = std::max(8, kFuseGrid / 8 * 8);
-  cache[kern] = grid;
+  cache[key] = grid;
   return grid;
 }
 
@@ -1664,20 +1662,24 @@ static int integrateUpdateMulti(khr_ctx* c, khr_ctx* src, const int* src_slots, 
   auto go = [&](auto kern) {
     // one workgroup per WPW items is enough (c->explicit_blocks bounds the map), at most what is resident
     // (the occupancy query is a driver call of tens of microseconds: once per instantiation, not once per extracted object)
-    static std::map<const void*, int> per_cu_of;
+    static std::map<std::pair<int, const void*>, std::pair<int, int>> per_cu_of;  // (device, kernel) -> resident workgroups per CU, CUs
     static std::mutex per_cu_mu;
-    int per_cu = 0;
+    int per_cu = 0, cus = 256;
     {
       std::lock_guard<std::mutex> lock(per_cu_mu);
-      auto it = per_cu_of.find(reinterpret_cast<const void*>(kern));
+      const std::pair<int, const void*> key{c->device, reinterpret_cast<const void*>(kern)};
+      auto it = per_cu_of.find(key);
       if (it != per_cu_of.end()) {
-        per_cu = it->second;
+        per_cu = it->second.first;
+        cus = it->second.second;
       } else {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * WPW, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-        per_cu_of[reinterpret_cast<const void*>(kern)] = per_cu;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        per_cu_of[key] = {per_cu, cus};
       }
     }
-    int grid = std::min(kFuseStatSlots, per_cu * 256) / 8 * 8;
+    int grid = std::min(kFuseStatSlots, per_cu * cus) / 8 * 8;
     if (c->explicit_blocks > 0) {
       const uint64_t items = c->explicit_blocks * c->wpb;
       grid = std::max(8, static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(grid), (items + WPW - 1) / WPW) + 7) / 8 * 8);
@@ -4004,8 +4006,13 @@ int khr_mesh_halo_answer(khr_ctx* c, const void* all_requests_device, int64_t ca
       runs.req_off[r] = static_cast<uint32_t>(static_cast<uint64_t>(q) * stride + 8ull * world + bucketBase(hq, rank, sel));
       runs.rec_off[r] = static_cast<uint32_t>(words);
       runs.sel[r] = static_cast<uint8_t>(sel);
+      // (the runs carry 32-bit word offsets, 0xffffffff is the "no answer" mark of the adopted table: ADVICE r05)
+      if (static_cast<uint64_t>(q) * stride + 8ull * world + bucketBase(hq, rank, sel) >= 0xffffffffull)
+        return fail(KHR_EINVAL, "mesh halo: the gathered request lists exceed 2^32 - 1 entries (capacity %lld x %d ranks)", static_cast<long long>(cap), world);
       items += n;
       words += n * static_cast<uint64_t>(meshHaloAnswerWords(sel, vps));
+      if (words >= 0xffffffffull || items >= 0xffffffffull)
+        return fail(KHR_ENOMEM, "mesh halo: the answers of this output exceed 2^32 - 1 words");
     }
   }
   runs.first[runs.n_runs] = static_cast<uint32_t>(items);
@@ -4050,6 +4057,9 @@ int khr_mesh_halo_adopt(khr_ctx* c, const void* own_requests_device, const uint6
       runs.sel[k] = static_cast<uint8_t>(sel);
       items += n;
       words += n * static_cast<uint64_t>(meshHaloAnswerWords(sel, vps));
+      // (32-bit word offsets into the receive buffer, 0xffffffff marks "no answer": a buffer of rec_cap x world >= 2^32 words would wrap)
+      if (words >= 0xffffffffull || items >= 0xffffffffull)
+        return fail(KHR_ENOMEM, "mesh halo: the answers received from rank %d end beyond word 2^32 - 1 of the receive buffer", r);
     }
   }
   runs.first[runs.n_runs] = static_cast<uint32_t>(items);
@@ -4165,10 +4175,11 @@ static int ingestAhead(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fr
   // and whichever starts second waits for the other (~55 us of the main stream per frame, profiles/r04_kernel_trace_frames_s2.txt).
   // Queued BEFORE the slot is published as handed over: a failure here leaves no state behind.  Only when no other
   // request of the detector is outstanding (its result block is single): a second frame in the look-ahead gets its detector
-  // kernels from its own khr_process_frame call.
+  // kernels from its own khr_process_frame call -- and only for the frame that will be processed NEXT (empty queue): the older frame's
+  // khr_process_frame call would otherwise launch its own request over this one, which then ran twice.
   // Not for host frames: their planes are still travelling, and the auxiliary stream -- in order -- would hold the CURRENT frame's
   // detector kernels, queued later by its khr_process_frame call, behind that wait.
-  if (on_device && c->obj_configured && kAheadObjects && c->obj_pending_slot < 0) {
+  if (on_device && c->obj_configured && kAheadObjects && c->obj_pending_slot < 0 && c->ahead_q.empty()) {
     const int rco = objectsLaunch(c, slot);
     if (rco) {
       if (c->obj_pending_slot == slot) c->obj_pending_slot = -1;
@@ -4243,9 +4254,11 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
     hipEvent_t own_h2d = nullptr;
   } leave{c};
   // pinned host frames qualify for the early ingest like device frames: the planes travel on the host-to-device stream, the
-  // ingest runs on the second stream behind them
+  // ingest runs on the second stream behind them.  Their copy REWRITES the slot's raw planes and nothing orders the copy stream
+  // behind the slot's last readers: with a ring of two the slot is that of the frame before last, whose tail may still be queued
+  //  -- three slots, as the look-ahead requires, or the ingest (and with it the copy) stays ordered on the main stream
   const bool early = ahead || (c->early_ingest && (flags & KHR_PF_INPUT_READY) && (on_device || pinned_in) && motion && c->cfg.with_tracking &&
-                               c->slots.size() >= 2 && peekSlot(c) != c->last_frame_slot);
+                               c->slots.size() >= (pinned_in ? 3u : 2u) && peekSlot(c) != c->last_frame_slot);
   int slot;
   int ahead_ev = 0;
   if (ahead) {
@@ -4446,7 +4459,7 @@ int khr_allocate_blocks(khr_ctx* c, const int32_t* indices, int64_t n) {
   for (int64_t i = 0; i < n; ++i) v[i] = {indices[3 * i], indices[3 * i + 1], indices[3 * i + 2]};
   std::sort(v.begin(), v.end());
   v.erase(std::unique(v.begin(), v.end()), v.end());
-  // asynchronous: the indices travel through a pinned buffer + its device twin owned by the context (no hipMalloc /
+  // asynchronous: the indices travel through a pinned buffer owned by the context (no hipMalloc /
   // hipFree, which stall every stream of the device); the buffer is reused only after the previous upload was consumed
   const size_t bytes = sizeof(int32_t) * 3 * v.size();
   HT("ab_enter");
@@ -4456,11 +4469,10 @@ int khr_allocate_blocks(khr_ctx* c, const int32_t* indices, int64_t n) {
   if (bytes > c->h_up_bytes) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->h_up) hipHostFree(c->h_up);
-    if (c->d_up) hipFree(c->d_up);
-    c->h_up = c->d_up = nullptr;
+    c->h_up = nullptr;
     c->h_up_bytes = 0;
     const size_t want = std::max<size_t>(2 * bytes, 1u << 16);
-    if (hipHostMalloc(&c->h_up, want, hipHostMallocDefault) != hipSuccess || hipMalloc(&c->d_up, want) != hipSuccess)
+    if (hipHostMalloc(&c->h_up, want, hipHostMallocDefault) != hipSuccess)
       return fail(KHR_ENOMEM, "block index staging of %zu bytes", want);
     c->h_up_bytes = want;
   }
@@ -5173,12 +5185,12 @@ static int fetchMeshLaunch(khr_ctx* c) {
 int khr_reserve_mesh_staging(khr_ctx* c, uint64_t n_vertices) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipStreamSynchronize(c->stream));  // (a gather in flight writes the block that is about to be replaced)
-  c->fetch_pending = false;
   const size_t cap = c->m.capacity;
   const size_t bytes = 4096 + (sizeof(int4) + sizeof(uint32_t) + sizeof(MeshDesc) + 64) * cap + 40 * static_cast<size_t>(n_vertices);
   // (exactly this many bytes, not x 1.5: the caller named its bound)
-  if (bytes <= c->h_stage_bytes) return KHR_OK;
+  if (bytes <= c->h_stage_bytes) return KHR_OK;  // (nothing is replaced: a gather queued by khr_fetch_mesh_launch stays valid)
+  HIP_TRY(hipStreamSynchronize(c->stream));  // (a gather in flight writes the block that is about to be replaced)
+  c->fetch_pending = false;                  // ... and what it gathered goes with the block: the next khr_fetch_mesh starts over
   if (c->h_stage) HIP_TRY(hipHostFree(c->h_stage));
   c->h_stage = nullptr;
   c->h_stage_bytes = 0;

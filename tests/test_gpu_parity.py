@@ -271,7 +271,7 @@ def test_tracking_shortcuts_are_exact():
 
 
 @pytest.mark.parametrize("inputs", ["host", "device", "device-ready", "device-ahead", "host-pinned", "host-pinned-ahead", "device-ahead2",
-                                    "host-pinned-ahead2"])
+                                    "host-pinned-ahead2", "host-pinned-ring2"])
 def test_fused_process_frame_equals_stepwise(inputs):
     """khr_process_frame (one call per frame, asynchronous output stage) == the step-by-step calls; with host buffers, with
     device buffers, with device buffers declared complete (KHR_PF_INPUT_READY: the ingest runs ahead on the context's
@@ -283,7 +283,9 @@ def test_fused_process_frame_equals_stepwise(inputs):
     ahead_mode = "ahead" in inputs
     two = inputs.endswith("2")  # frame i + 1 is handed over BEFORE frame i's khr_process_frame call: two frames in the look-ahead
     pinned = inputs.startswith("host-pinned")
-    cfg, ctx, ora, s, sen, osen = make_pair(width=320, height=240, temporal_window=0.75, num_frame_slots=(5 if two else 4) if ahead_mode else 3)
+    # (host-pinned-ring2: a ring of two frame slots -- the copy of a pinned frame then stays ordered behind the slot's last readers)
+    ring = 2 if inputs == "host-pinned-ring2" else ((5 if two else 4) if ahead_mode else 3)
+    cfg, ctx, ora, s, sen, osen = make_pair(width=320, height=240, temporal_window=0.75, num_frame_slots=ring)
     fired = 0
     held = []
     N = 20
@@ -306,7 +308,7 @@ def test_fused_process_frame_equals_stepwise(inputs):
         flags = ctx.PF_MOTION | ctx.PF_TRACKING | (ctx.PF_OUTPUT if out_now else 0)
         if inputs == "host":
             f.depth, f.color, f.label = depth.ctypes.data, rgb.ctypes.data, lab.ctypes.data
-        elif inputs == "host-pinned":
+        elif inputs in ("host-pinned", "host-pinned-ring2"):
             f = device_frame(i)
             flags |= ctx.PF_INPUT_READY | ctx.PF_INPUT_PINNED
         elif ahead_mode:

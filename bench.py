@@ -810,7 +810,8 @@ def main():
                         "hist_us_50_100_200_500_1k_2k_5k_more": st1["seed_wait_hist"],
                         "last_late": {"us": st1["seed_wait_late_us"], "wait_no": st1["seed_wait_late_frame"], "state_bits": st1["seed_wait_late_state"]},
                         "in_timed_steps": {"waits": st1["n_seed_waits"] - st0["n_seed_waits"], "late_over_500us": st1["n_seed_waits_late"] - st0["n_seed_waits_late"]},
-                        "motion_merges_on_device": st1["n_md_device_merges"], "motion_host_walks": st1["n_md_host_walks"]}
+                        "motion_merges_on_device": st1["n_md_device_merges"], "motion_host_walks": st1["n_md_host_walks"],
+                        "motion_chains_queued_ahead": st1["n_md_prelaunched"], "motion_chains_repeated": st1["n_md_prelaunch_repeats"]}
     # ---- roofline of the dominant kernel (k_fuse: the fused TSDF / colour / label update), from HIP events on the
     #      kernel's own dispatch packets (hipExtLaunchKernelGGL start / stop events on the kernel's stream) ----
     if not args.no_roofline_timers and rank == 0:

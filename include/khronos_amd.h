@@ -175,6 +175,8 @@ typedef struct khr_stats {
                                     bit 4 the count came through the event path (key import), bits 8.. frames handed over ahead */
   uint64_t n_md_device_merges;   /* seed frames whose clusters were merged from the device's overlap rows (mergeClusters) */
   uint64_t n_md_host_walks;      /* seed frames whose seed graph went to the host */
+  uint64_t n_md_prelaunched;     /* frames whose clustering chain was queued ahead of their seed count (the frame before had seeds) */
+  uint64_t n_md_prelaunch_repeats; /* ... and had to be repeated: more seed pixels than twice the previous frame's */
 } khr_stats;
 
 /* khronos::MeasurementCluster role (measurement_clusters.h:63-80) for dynamic clusters

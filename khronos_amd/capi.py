@@ -71,7 +71,8 @@ class KhrStats(C.Structure):
         "pool_exhausted", "cum_updated_voxels", "cum_band_voxels", "cum_visited_voxels", "cum_integrate_calls", "n_tsdf_blocks", "band_overflow",
         "n_tracking_processed_blocks", "n_fuse_items", "n_seed_waits", "n_seed_waits_late", "seed_wait_max_us")] + [
         ("seed_wait_hist", C.c_uint64 * 8)] + [(n, C.c_uint64) for n in (
-        "seed_wait_late_us", "seed_wait_late_frame", "seed_wait_late_state", "n_md_device_merges", "n_md_host_walks")]
+        "seed_wait_late_us", "seed_wait_late_frame", "seed_wait_late_state", "n_md_device_merges", "n_md_host_walks",
+        "n_md_prelaunched", "n_md_prelaunch_repeats")]
 
 
 # every symbol include/khronos_amd.h declares (tests check the library exports all of them)

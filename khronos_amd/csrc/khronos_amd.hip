@@ -303,6 +303,9 @@ struct khr_ctx {
   uint32_t md_lds_max = kCompLds;  // KHR_MD_LDS_MAX=n: seed count up to which the single-workgroup LDS labelling is used
   uint32_t md_mask = 0, md_list_cap = 0;
   uint32_t md_head_ticket = 0;      // h_pinned[8]
+  bool md_seed_run = false;         // the frame detected last had motion seeds: the next frame's chain is queued ahead of its seed count
+  uint32_t md_prev_seed_px = 0;     // ... sized from that frame's seed pixels
+  uint64_t n_md_prelaunched = 0, n_md_prelaunch_repeats = 0;
   bool md_defer_summary = false;    // clusterSummaryLaunch only notes the request (md_summary_pending = largest id)
   int md_summary_pending = -1;
   uint32_t md_last_seeds = 0;       // seed voxels of the previous seed frame (predicts which component path is needed)
@@ -2616,12 +2619,6 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
     std::fprintf(stderr, "[md] %s %.1f us\n", what, std::chrono::duration<double, std::micro>(t1 - t0).count());
     t0 = t1;
   };
-  { const int rcw = waitSeedCount(c); if (rcw) return rcw; }
-  lap("wait seed count");
-  s.clusters.clear();
-  if (c->h_pinned[0] == 0) return 0;
-  s.dyn_clean = false;  // clusters may be painted from here on
-
   // ---- device: seed / boundary voxel tables, compact lists, seed adjacency ------------------------
   const int nn = c->cfg.md_neighbor_connectivity;
   // Table size for THIS frame.  The allocation covers the worst case (every pixel its own voxel: 2 M slots at 720p), and the
@@ -2632,23 +2629,22 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
   // component kernels (for more than 12 k seed voxels) are only queued when the previous seed frame came close to
   // needing them; a frame that needs them unexpectedly is repeated.
   const uint32_t cap = c->md_list_cap;
-  const uint32_t seed_px = std::min<uint32_t>(c->h_pinned[0], cap);  // #seed voxels <= #seed pixels
   CompAcc* d_comp_out = reinterpret_cast<CompAcc*>(reinterpret_cast<uint8_t*>(c->d_md_n) + 16);
-  uint32_t mask = c->md_mask;
-  {
+  auto maskFor = [&](uint32_t seed_pixels) {
     uint32_t ts = 1u << 14;
-    while (ts < 2ull * std::max<uint32_t>(c->h_pinned[0], 1u) && ts - 1 < c->md_mask) ts <<= 1;
+    while (ts < 2ull * std::max<uint32_t>(seed_pixels, 1u) && ts - 1 < c->md_mask) ts <<= 1;
     if (const char* e = std::getenv("KHR_MD_TABLE_LOG2")) ts = 1u << std::min(30, std::max(4, std::atoi(e)));  // test hook: forces the repeat
-    mask = std::min(ts - 1, c->md_mask);
-  }
+    return std::min(ts - 1, c->md_mask);
+  };
   bool with_global = c->md_host_walk || 2u * c->md_last_seeds > c->md_lds_max || c->md_lds_max < kCompLds;
   if (std::getenv("KHR_MD_NO_PREDICT")) with_global = false;  // test hook: the lock-free path only after a repeat
   VoxTable seeds{}, bnd{}, near{};
   // (0 < separation <= 2 voxels: the voxel pairs mergeClusters tests are within each other's 27-neighbourhood -- the device can answer)
   static const bool no_device_merge = std::getenv("KHR_MD_NO_DEVICE_MERGE") != nullptr;  // A/B and test hook: the host walk decides
   const bool device_merge = !no_device_merge && !c->md_host_walk && c->cfg.md_min_separation_distance > 0.f && c->cfg.md_min_separation_distance <= 2.f;
-  const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c->h_md_head);
-  for (int attempt = 0;; ++attempt) {
+  // the chain up to the component records, sized for `seed_pixels` seed pixels (the kernels take the counts themselves from device memory)
+  auto launchChain = [&](uint32_t seed_pixels, uint32_t mask, bool global_components) {
+    const uint32_t seed_px = std::min<uint32_t>(seed_pixels, cap);  // #seed voxels <= #seed pixels
     const size_t tsize = static_cast<size_t>(mask) + 1;
     seeds = VoxTable{c->d_md_keys, c->d_md_counts, c->d_md_ids, mask};
     bnd = VoxTable{c->d_md_keys + tsize, c->d_md_counts + tsize, c->d_md_ids + tsize, mask};
@@ -2671,7 +2667,7 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
     // connected components of the seed graph + their order-free summaries, on the device
     hipLaunchKernelGGL(k_md_comp_lds, dim3(1), dim3(1024), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->d_md_comp_acc,
                        c->md_lds_max, c->d_md_edges, edge_cap, d_n_edges, (c->p.dbg & 16) ? c->d_dbg : nullptr);
-    if (with_global) {
+    if (global_components) {
       hipLaunchKernelGGL(k_md_comp_init, dim3(64), dim3(256), 0, c->stream, c->d_md_adj, c->d_md_n, cap, nn, c->d_md_parent, c->d_md_comp_acc,
                          c->md_lds_max);
       hipLaunchKernelGGL(k_md_comp_jump, dim3(64), dim3(256), 0, c->stream, c->d_md_n, cap, c->d_md_parent, c->md_lds_max);
@@ -2694,6 +2690,41 @@ static int motionFinish(khr_ctx* c, FrameSlot& s) {
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, c->stream, c->d_md_n, reinterpret_cast<uint32_t*>(c->d_md_head_host),
                        static_cast<uint32_t>(sizeof(CompAcc) / 4), kCompHead, c->d_pinned + 8, c->md_head_ticket, c->d_md_scratch4);
     HIP_TRY(hipGetLastError());
+    return KHR_OK;
+  };
+  // (round 6) Seed frames come in runs (something moves through the view for a while): a frame that follows a seed frame gets its
+  // chain queued BEFORE the host has seen its seed count, sized for twice the previous frame's seed pixels.  The kernels then sit in
+  // the stream's queue behind the allocation / culling pass instead of arriving one by one after the count's trip to the host (78 us
+  // of idle main stream in front of the chain and 5 - 15 us between its seventeen launches, profiles/r06_kernel_trace_frames.txt).
+  // A frame without seeds runs the chain on empty lists (its records are never looked at); more seed pixels than the bound, or a
+  // table that filled up: the chain is repeated with this frame's own sizes, as before.
+  const bool no_prelaunch = std::getenv("KHR_MD_NO_PRELAUNCH") != nullptr;  // (A/B and test hook; looked at per frame: tests flip it inside one process)
+  uint32_t pre_px = 0, pre_mask = 0;
+  if (c->md_seed_run && c->seed_by_ticket && !no_prelaunch) {
+    pre_px = std::min<uint32_t>(cap, std::max<uint32_t>(4096u, 2u * c->md_prev_seed_px));
+    if (const char* e = std::getenv("KHR_MD_PRELAUNCH_PX")) pre_px = static_cast<uint32_t>(std::max(1, std::atoi(e)));  // test hook: a bound that is exceeded
+    pre_mask = maskFor(pre_px);
+    const int rcl = launchChain(pre_px, pre_mask, with_global);
+    if (rcl) return rcl;
+    ++c->n_md_prelaunched;
+  }
+  { const int rcw = waitSeedCount(c); if (rcw) return rcw; }
+  lap("wait seed count");
+  s.clusters.clear();
+  c->md_seed_run = c->h_pinned[0] != 0;
+  if (c->h_pinned[0] == 0) return 0;
+  c->md_prev_seed_px = c->h_pinned[0];
+  s.dyn_clean = false;  // clusters may be painted from here on
+  bool chain_queued = pre_px != 0 && c->h_pinned[0] <= pre_px;
+  if (pre_px != 0 && !chain_queued) ++c->n_md_prelaunch_repeats;
+  uint32_t mask = chain_queued ? pre_mask : maskFor(c->h_pinned[0]);
+  const uint32_t* cnt = reinterpret_cast<const uint32_t*>(c->h_md_head);
+  for (int attempt = 0;; ++attempt) {
+    if (!chain_queued) {
+      const int rcl = launchChain(c->h_pinned[0], mask, with_global);
+      if (rcl) return rcl;
+    }
+    chain_queued = false;
     {
       const int rcw = waitTicket(c, 8, c->md_head_ticket, "the motion detector's component records");
       if (rcw) return rcw;
@@ -4325,7 +4356,8 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   const bool band_fork = !no_band_fork && (flags & KHR_PF_TRACKING) && c->cfg.with_tracking;
   // the update kernel's item records are folded into the block flags by the tracking pass's first kernel when it follows directly
   c->defer_fold = (flags & KHR_PF_TRACKING) && c->cfg.with_tracking;  // (reset below, before the tracking pass)
-  if (motion && kFuseSpec && c->cfg.with_tracking) {
+  // (not behind a seed frame: the frame is expected to have seeds, its clustering chain is queued ahead of the count instead)
+  if (motion && kFuseSpec && c->cfg.with_tracking && !(c->md_seed_run && std::getenv("KHR_MD_NO_PRELAUNCH") == nullptr)) {
     const size_t n_pending = c->pending.size();
     c->band_fork = band_fork;
     rc = integrateUpdate(c, s, f, 1, 0, -1, nullptr, &c->m.counters[C_N_SEEDS]);
@@ -4563,6 +4595,8 @@ int khr_get_stats(khr_ctx* c, khr_stats* out) {
   s.seed_wait_late_state = c->seed_wait_late_state;
   s.n_md_device_merges = c->n_md_device_merges;
   s.n_md_host_walks = c->n_md_host_walks;
+  s.n_md_prelaunched = c->n_md_prelaunched;
+  s.n_md_prelaunch_repeats = c->n_md_prelaunch_repeats;
   s.band_overflow = c->h_counters[C_BAND_OVERFLOW];  // k_tsdf: in-band records dropped for lack of record chunks (the pool is sized so that this stays 0)
   s.n_tracking_processed_blocks = c->h_counters[c->ef_cur ? C_N_PROC2 : C_N_PROC];
   s.cum_updated_voxels = st[S_CUM_UPD] + cur_upd;

@@ -57,7 +57,8 @@ def test_sequence_tsdf_tracking(interp):
 @pytest.mark.parametrize("mode,sep,noise,min_size", [("lds", 2.0, 0.0, 20), ("host", 2.0, 0.0, 20), ("global", 2.0, 0.0, 20),
                                                        ("lds", 1.0, 0.01, 3), ("host", 1.0, 0.01, 3), ("global", 1.0, 0.01, 3),
                                                        ("lds", 12.0, 0.01, 3), ("lds", 40.0, 0.005, 10),
-                                                       ("repeat-tables", 2.0, 0.0, 20), ("repeat-global", 1.0, 0.01, 3)])
+                                                       ("repeat-tables", 2.0, 0.0, 20), ("repeat-global", 1.0, 0.01, 3),
+                                                      ("repeat-prelaunch", 2.0, 0.0, 20), ("no-prelaunch", 2.0, 0.0, 20)])
 def test_sequence_with_motion_detection(mode, sep, noise, min_size, monkeypatch):
     """the three ways the seed graph is clustered -- one workgroup in LDS (default), lock-free union-find in global memory
     (large seed counts; forced with KHR_MD_LDS_MAX=0) and the host walk (KHR_MD_HOST_WALK=1, and automatically whenever
@@ -70,6 +71,12 @@ def test_sequence_with_motion_detection(mode, sep, noise, min_size, monkeypatch)
     # tables far too small -> overflow flag -> full-size tables; more seed voxels than the LDS kernel takes -> lock-free path
     if mode == "repeat-tables":
         monkeypatch.setenv("KHR_MD_TABLE_LOG2", "6")
+    # round 6: the frame behind a seed frame gets its chain queued ahead of its seed count, sized from that frame's seed pixels; a
+    # bound of 8 pixels is exceeded by every seed frame of the scenario -> the chain is repeated with the frame's own sizes
+    if mode == "repeat-prelaunch":
+        monkeypatch.setenv("KHR_MD_PRELAUNCH_PX", "8")
+    if mode == "no-prelaunch":
+        monkeypatch.setenv("KHR_MD_NO_PRELAUNCH", "1")
     if mode == "repeat-global":
         monkeypatch.setenv("KHR_MD_LDS_MAX", "8")
         monkeypatch.setenv("KHR_MD_NO_PREDICT", "1")
@@ -104,6 +111,13 @@ def test_sequence_with_motion_detection(mode, sep, noise, min_size, monkeypatch)
         frames_crc_valid_seeds_nora_ngpu=trail, env={k: v for k, v in os.environ.items() if k.startswith("KHR_")},
         threads=os.cpu_count(), cfg={k: getattr(cfg, k) for k in ("md_min_cluster_size", "md_min_separation_distance", "md_max_range",
                                                                    "temporal_buffer", "temporal_window", "relaxed_arithmetic")}))
+    st = ctx.stats()
+    if mode == "repeat-prelaunch":
+        assert st["n_md_prelaunched"] > 0 and st["n_md_prelaunch_repeats"] > 0, "the hook must force the repeat (otherwise nothing is tested)"
+    elif mode == "no-prelaunch":
+        assert st["n_md_prelaunched"] == 0
+    elif mode == "lds" and sep == 2.0:
+        assert st["n_md_prelaunched"] > 0 and st["n_md_prelaunch_repeats"] == 0  # (consecutive seed frames: the default path IS the queued-ahead one)
     compare_maps(ctx, ora, max_blocks=60)
 
 

@@ -98,6 +98,8 @@ struct FuseFrame {
   float R[9], t[3];
   uint64_t stamp;
   int use_mask, do_sem, has_color, object_id;
+  const float* tile_max;  // largest range of every 16 x 16 pixel tile (k_frame_ingest); k_multi_cull
+  int tw, th;
 };
 
 struct FuseArgs : FuseFrame {
@@ -137,6 +139,10 @@ struct FuseArgs : FuseFrame {
   // tick form of MULTI (khr_tick_integrate): one byte per wave item [slot * items-per-block + item], bit k = the item is on
   // camera k's TSDF list (k_tick_cull); the kernel clears the byte it has consumed.  nullptr: every frame, every item.
   uint8_t* item_mask;
+  // object-extraction form of MULTI (khr_integrate_shared_batch): bit f of words [item * frame_words ..] = frame f may update a voxel of
+  // the item (k_multi_cull); nullptr: every frame
+  const uint32_t* frame_bits;
+  int frame_words;
 };
 
 constexpr int kFuseCap = 256;        // in-band records a wave collects before it works them off (one 4-z chunk of a patch)
@@ -1022,8 +1028,19 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
       asm volatile("" : "+s"(frame_mask) : : "memory");
       if (lane == 0) a.item_mask[mi] = 0;
     }
+    uint32_t fbits = ~0u;
     for (int fi = 0; fi < n_frames; ++fi) {
     if (MULTI && ((frame_mask >> fi) & 1u) == 0u) continue;
+    if (MULTI && a.frame_bits != nullptr) {  // (the item's word of 32 frames through the scalar cache: written by the launch before this one)
+      if ((fi & 31) == 0) {
+        const size_t wi = (slot * static_cast<size_t>(PATCHES * ZSPLIT) + static_cast<size_t>(sbi)) * static_cast<size_t>(a.frame_words) + static_cast<size_t>(fi >> 5);
+        fbits = *(const uint32_t __attribute__((address_space(4)))*)(a.frame_bits + wi);
+      }
+      if (((fbits >> (fi & 31)) & 1u) == 0u) {
+        cnt = 0;  // (what the frame would have left: no voxel of the item in its band)
+        continue;
+      }
+    }
     // the frame's arguments: the kernel's own (single frame), or entry fi of a.frames read through the scalar cache
     FuseFrame Fm;
     if (MULTI) {
@@ -1254,6 +1271,118 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
 }
 
 // per-camera update arguments of a tick -> device memory (they travel as kernel arguments: no host staging, no host wait)
+// k_multi_cull: which of the buffered frames can update a voxel of which wave item of an object mini-map (MeshObjectExtractor re-integrates
+// every buffered frame of a track into a box of twice the object's extent, mesh_object_extractor.cpp:214-243: the part of the box under
+// the floor, behind a wall or behind the object itself is occluded in most frames).  The tests are those of the window's culling pass
+// (cullBlocks, khr_kernels_fusion.h) on the item's own voxels: behind the camera / out of range, projected outside the image, or
+// entirely behind the surface by more than the truncation distance (largest range of the 16 x 16 tiles its footprint touches) -- a
+// culled (item, frame) pair has no voxel the update would touch, so the result is the same and the pair costs the update kernel one
+// scalar bit instead of a projection and four range gathers per voxel.  One thread per (item, frame); a wave's ballot is two words.
+template <int VPS>
+__global__ __launch_bounds__(256) void k_multi_cull(const uint32_t* __restrict__ blk_flags, const int4* __restrict__ blk_index, const uint32_t* __restrict__ n_slots_ptr,
+                                                   float vs, float bs, float trunc, const FuseFrame* __restrict__ frames, int n_frames,
+                                                   int n_words, uint32_t wpb, uint32_t live_flag, uint32_t* __restrict__ bits) {
+  constexpr int kTileSide = 16;
+  const uint32_t per_item = static_cast<uint32_t>(n_words) * 32u;
+  const uint64_t total = static_cast<uint64_t>(*n_slots_ptr) * wpb * per_item;
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t t0 = static_cast<uint64_t>(blockIdx.x) * blockDim.x; t0 < total; t0 += stride) {
+    const uint64_t t = t0 + threadIdx.x;
+    bool keep = false;
+    if (t < total) {
+      const uint32_t it = static_cast<uint32_t>(t / per_item);
+      const int fr = static_cast<int>(t % per_item);
+      const uint32_t slot = it / wpb, item = it % wpb;
+      if (fr < n_frames && (blk_flags[slot] & live_flag)) {
+        keep = true;
+        const FuseFrame& F = frames[fr];
+        const int4 bi = blk_index[slot];
+        const float margin = 1e-3f;
+        const int patches = (VPS * VPS) >> 6, rows = 64 / VPS, zr = VPS / (static_cast<int>(wpb) / patches);
+        const int y0 = (static_cast<int>(item) % patches) * rows, z0 = (static_cast<int>(item) / patches) * zr;
+        const float lo[3] = {static_cast<float>(bi.x) * bs + 0.5f * vs, static_cast<float>(bi.y) * bs + (static_cast<float>(y0) + 0.5f) * vs,
+                             static_cast<float>(bi.z) * bs + (static_cast<float>(z0) + 0.5f) * vs};
+        const float ex[3] = {bs - vs, static_cast<float>(rows - 1) * vs, static_cast<float>(zr - 1) * vs};
+        float zmin = 1e30f, zmax = -1e30f, umin = 1e30f, umax = -1e30f, vmin = 1e30f, vmax = -1e30f;
+        float pcs[8][3];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float x = lo[0] + ((k & 1) ? ex[0] : 0.f), y = lo[1] + ((k & 2) ? ex[1] : 0.f), z = lo[2] + ((k & 4) ? ex[2] : 0.f);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) pcs[k][c] = ((F.R[3 * c] * x + F.R[3 * c + 1] * y) + F.R[3 * c + 2] * z) + F.t[c];
+          zmin = fminf(zmin, pcs[k][2]);
+          zmax = fmaxf(zmax, pcs[k][2]);
+        }
+        // (voxel_range = z in the default range mode -- the only one MULTI runs in --, and z is affine in the voxel position: extremes at corners)
+        if (zmax <= -margin) keep = false;              // every voxel behind the camera
+        if (zmin > F.max_range + margin) keep = false;  // every voxel beyond max range
+        if (zmax < F.min_range - margin) keep = false;
+        if (keep && zmin > 0.05f && F.tile_max != nullptr) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float iz = __builtin_amdgcn_rcpf(pcs[k][2]);  // (1-ulp reciprocal: the footprint below is widened by a pixel and more on every side)
+            const float u = (pcs[k][0] * F.fx) * iz + F.cx, v = (pcs[k][1] * F.fy) * iz + F.cy;
+            umin = fminf(umin, u); umax = fmaxf(umax, u);
+            vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+          }
+          // the projection of a convex box in front of the camera lies in the hull of its projected corners
+          if (umax < -2.f || vmax < -2.f || umin > static_cast<float>(F.W) + 1.f || vmin > static_cast<float>(F.H) + 1.f) {
+            keep = false;
+          } else {
+            const int tx0 = max(0, (static_cast<int>(floorf(umin)) - 2) / kTileSide);
+            const int ty0 = max(0, (static_cast<int>(floorf(vmin)) - 2) / kTileSide);
+            const int tx1 = min(F.tw - 1, (static_cast<int>(ceilf(umax)) + 3) / kTileSide);
+            const int ty1 = min(F.th - 1, (static_cast<int>(ceilf(vmax)) + 3) / kTileSide);
+            const int nx = tx1 - tx0 + 1, ny = ty1 - ty0 + 1;
+            if (nx > 0 && ny > 0 && nx * ny <= 96) {  // (a slab right in front of the camera covers many tiles: keep it)
+              // distance_to_surface <= the largest of the four interpolated ranges <= mr; sdf = it - voxel_range <= mr - zmin
+              float mr = 0.f;
+              for (int ty = ty0; ty <= ty1; ++ty)
+                for (int tx = tx0; tx <= tx1; ++tx) mr = fmaxf(mr, F.tile_max[ty * F.tw + tx]);
+              if (mr < zmin - trunc - margin) keep = false;
+            }
+          }
+        }
+      }
+    }
+    const unsigned long long b = __ballot(keep);
+    const uint32_t lane = threadIdx.x & 63u;
+    if (t < total && (lane & 31u) == 0u) bits[t >> 5] = static_cast<uint32_t>(lane ? (b >> 32) : b);
+  }
+}
+
+// k_multi_order: the items of an object mini-map that at least one frame can touch, in four classes by the number of frames that can
+// (>= 3/4, >= 1/2, >= 1/4 of the batch, fewer), heaviest class first.  k_fuse2<.., MULTI> deals list position p to workgroup p mod
+// grid, and a workgroup's waves take its positions in order: every workgroup starts on its long items and fills up with the short
+// ones (the launch is as long as its slowest wave -- before: two items of 28 frames each, a dependent round trip or two per frame,
+// while most items see half the frames or none).  One thread per item, one returning atomic per class and workgroup.
+__global__ __launch_bounds__(1024) void k_multi_order(const uint32_t* __restrict__ blk_flags, const int4* __restrict__ blk_index, const uint32_t* __restrict__ n_slots_ptr,
+                                                     const uint32_t* __restrict__ bits, int n_words, int n_frames, uint32_t wpb, uint32_t live_flag,
+                                                     FuseList out) {
+  __shared__ uint32_t s_cnt[4], s_off[4];
+  const uint32_t n_items = *n_slots_ptr * wpb;
+  if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t n = 0u, cls = 0u, pos = 0u;
+  if (it < n_items && (blk_flags[it / wpb] & live_flag))
+    for (int w = 0; w < n_words; ++w) n += static_cast<uint32_t>(__popc(bits[static_cast<size_t>(it) * n_words + w]));
+  if (n) {
+    const uint32_t q = 4u * n, f = static_cast<uint32_t>(n_frames);
+    cls = q >= 3u * f ? 0u : (q >= 2u * f ? 1u : (q >= f ? 2u : 3u));
+    pos = atomicAdd(&s_cnt[cls], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) s_off[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&out.counts[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
+  __syncthreads();
+  if (n) {
+    const uint32_t slot = it / wpb;
+    const int4 bi = blk_index[slot];
+    *fuseDescPtr(out, cls, s_off[cls] + pos) =
+        make_uint4(slot | ((it % wpb) << 24), static_cast<uint32_t>(bi.x), static_cast<uint32_t>(bi.y), static_cast<uint32_t>(bi.z));
+  }
+}
+
 struct FuseFrameSet {
   FuseFrame f[kMaxTick];
 };

@@ -195,6 +195,9 @@ struct khr_ctx {
   // unknown): the update kernel of an `allocate = false` integration (object mini-maps) sizes its persistent grid from it
   // instead of filling the chip with workgroups that find no item
   uint64_t explicit_blocks = 0;
+  uint4* d_multi_list = nullptr;     // integrateUpdateMulti: the items by frame count (k_multi_order) + 4 counters behind them
+  uint32_t* d_frame_bits = nullptr;  // integrateUpdateMulti: k_multi_cull's (item, frame) bits
+  size_t frame_bits_words = 0;
   FuseFrame* h_frames = nullptr;  // integrateUpdateMulti: per-frame arguments, pinned staging + device array
   FuseFrame* d_frames = nullptr;
   hipEvent_t ev_frames = nullptr;
@@ -1171,6 +1174,8 @@ void khr_destroy(khr_ctx* c) {
     for (auto& b : c->frame_pool->free) hipFree(b.first);
     c->frame_pool->free.clear();
   }
+  if (c->d_frame_bits) hipFree(c->d_frame_bits);
+  if (c->d_multi_list) hipFree(c->d_multi_list);
   if (c->h_frames) hipHostFree(c->h_frames);
   if (c->d_frames) hipFree(c->d_frames);
   if (c->ev_frames) hipEventDestroy(c->ev_frames);
@@ -1600,6 +1605,9 @@ static void fillFuseFrame(const khr_ctx* c, const FrameSlot& s, const DevFrame& 
   a->has_color = f.has_color;
   a->object_id = object_id;
   a->do_sem = (c->p.with_semantics && ((c->p.sem_mode == 1) ? (object_id >= 0 && f.obj != nullptr) : (f.has_label != 0))) ? 1 : 0;
+  a->tile_max = s.vTileMax();
+  a->tw = s.tw;
+  a->th = s.th;
 }
 static void fillFuseMap(khr_ctx* c, FuseArgs* a) {
   DevMap& m = c->m;
@@ -1660,7 +1668,46 @@ static int integrateUpdateMulti(khr_ctx* c, khr_ctx* src, const int* src_slots, 
   static_cast<FuseFrame&>(a) = c->h_frames[0];  // (W, H etc. for code that looks at the kernel's own frame; unused by MULTI)
   a.frames = c->d_frames;
   a.n_frames = n_frames;
+  // which frames can touch which item (k_multi_cull): one bit per (item, frame), read by the update kernel through the scalar cache
+  static const bool no_multi_cull = std::getenv("KHR_MULTI_NO_CULL") != nullptr;
+  if (!no_multi_cull && c->item_cap > 0) {
+    const int n_words = (n_frames + 31) / 32;
+    const size_t need = static_cast<size_t>(c->item_cap) * static_cast<size_t>(n_words);
+    if (need > c->frame_bits_words) {  // (grown in steps of four words per item = 128 frames: a worker thread's hipMalloc waits for the device)
+      const size_t want = static_cast<size_t>(c->item_cap) * static_cast<size_t>((n_words + 3) / 4 * 4);
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (c->d_frame_bits) HIP_TRY(hipFree(c->d_frame_bits));
+      c->d_frame_bits = nullptr;
+      c->frame_bits_words = 0;
+      if (hipMalloc(reinterpret_cast<void**>(&c->d_frame_bits), want * sizeof(uint32_t)) != hipSuccess)
+        return fail(KHR_ENOMEM, "frame bits of the multi-frame update (%zu bytes)", want * sizeof(uint32_t));
+      c->frame_bits_words = want;
+    }
+    const uint64_t tests = static_cast<uint64_t>(c->explicit_blocks > 0 ? std::min<uint64_t>(c->explicit_blocks, c->m.capacity) : c->m.capacity) *
+                           c->wpb * static_cast<uint64_t>(n_words) * 32u;
+    const unsigned grid = static_cast<unsigned>(std::min<uint64_t>((tests + 255) / 256, 8192));
+    hipLaunchKernelGGL((k_multi_cull<8>), dim3(std::max(1u, grid)), dim3(256), 0, c->stream, c->m.blk_flags, c->m.blk_index, &c->m.counters[C_MAX_SLOT],
+                       c->p.vs, c->p.bs, c->p.trunc, static_cast<const FuseFrame*>(c->d_frames), n_frames, n_words, c->wpb, BLK_LIVE, c->d_frame_bits);
+    HIP_TRY(hipGetLastError());
+    a.frame_bits = c->d_frame_bits;
+    a.frame_words = n_words;
+  }
   FuseList list{c->d_work4, c->d_work4 + c->item_cap, c->item_cap, &c->m.counters[C_N_ITEMS0]};
+  if (a.frame_bits != nullptr) {
+    // ... and the items in the order of their frame counts, the untouched ones left out (k_multi_order): a list of its own
+    if (!c->d_multi_list) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (hipMalloc(reinterpret_cast<void**>(&c->d_multi_list), sizeof(uint4) * 2 * c->item_cap + 16) != hipSuccess)
+        return fail(KHR_ENOMEM, "item list of the multi-frame update");
+    }
+    uint32_t* const counts = reinterpret_cast<uint32_t*>(c->d_multi_list + 2 * static_cast<size_t>(c->item_cap));
+    HIP_TRY(hipMemsetAsync(counts, 0, 16, c->stream));
+    list = FuseList{c->d_multi_list, c->d_multi_list + c->item_cap, c->item_cap, counts};
+    const uint64_t n_it = static_cast<uint64_t>(c->explicit_blocks > 0 ? std::min<uint64_t>(c->explicit_blocks, c->m.capacity) : c->m.capacity) * c->wpb;
+    hipLaunchKernelGGL(k_multi_order, dim3(static_cast<unsigned>((n_it + 1023) / 1024)), dim3(1024), 0, c->stream, c->m.blk_flags, c->m.blk_index,
+                       &c->m.counters[C_MAX_SLOT], static_cast<const uint32_t*>(c->d_frame_bits), a.frame_words, n_frames, c->wpb, BLK_LIVE, list);
+    HIP_TRY(hipGetLastError());
+  }
   constexpr int WPW = 8;
   auto go = [&](auto kern) {
     // one workgroup per WPW items is enough (c->explicit_blocks bounds the map), at most what is resident

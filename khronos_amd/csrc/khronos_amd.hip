@@ -4463,7 +4463,6 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
   // their list goes to the host at once, the archival itself has to wait for the mesh kernels and the snapshot
   static const bool no_early_list = std::getenv("KHR_NO_EARLY_REMOVED") != nullptr;
   const bool early_list = !no_early_list && (flags & KHR_PF_OUTPUT) && c->cfg.with_tracking;
-  if (early_list && (rc = removedPublishLaunch(c))) return rc;
   if (mc_fork) {
     HIP_TRY(hipStreamWaitEvent(c->mc_stream, c->ev_mc_fork, 0));
     hipStream_t main_stream = c->stream;
@@ -4495,6 +4494,8 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
       if (rc) return rc;
       HIP_TRY(hipEventRecord(c->ev_snap_join, c->snap_stream));
     }
+    // (the list kernel on the main stream BEHIND the fork points: it runs beside the mesh kernels and the snapshot, not in front of them)
+    if (early_list && (rc = removedPublishLaunch(c))) return rc;
     if (mc_fork) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_mc_join, 0));
     else if ((rc = khr_generate_mesh(c, 1, 1))) return rc;
     if (snap) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_snap_join, 0));

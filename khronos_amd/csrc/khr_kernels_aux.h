@@ -187,18 +187,23 @@ __device__ inline uint64_t neighbourKey(uint64_t key, int k) {
 // lanes of a wave that hold the same voxel key (neighbouring pixels usually do) insert / count once: the table
 // slot of a large voxel would otherwise take one CAS and one atomicAdd per pixel on a single address
 __device__ inline void voxInsertCounted(const VoxTable& t, bool has, uint64_t key, uint32_t* overflow = nullptr) {
-  unsigned long long todo = __ballot(has);
-  while (todo) {
-    const int leader = __ffsll(static_cast<long long>(todo)) - 1;
-    const uint32_t klo = __shfl(static_cast<uint32_t>(key), leader), khi = __shfl(static_cast<uint32_t>(key >> 32), leader);
-    const uint64_t lk = (static_cast<uint64_t>(khi) << 32) | klo;
-    const unsigned long long grp = __ballot(has && key == lk);
-    todo &= ~grp;
-    if (static_cast<int>(laneId()) == leader) {
-      const uint32_t h = voxInsert(t, lk);
-      if (h != kInvalidSlot) atomicAdd(&t.counts[h], static_cast<uint32_t>(__popcll(grp)));
-      else if (overflow) atomicOr(overflow, 1u);  // table full: the host repeats the frame with the full-size tables
-    }
+  // Consecutive pixels of an image row mostly fall into the same voxel: the first lane of every RUN of equal keys inserts the key and
+  // adds the run's length -- all runs of the wave at once.  (Round 6; before: one leader per DISTINCT key, one after the other -- a wave
+  // over a cluster holds 4 - 16 distinct voxels, i.e. that many dependent insert + add round trips, and those waves were the kernel:
+  // k_md_boundary_insert 24 - 57 us.)  A key that comes back in a later run of the wave is found in the table by that run's insert.
+  const uint32_t lane = laneId();
+  const uint32_t klo = static_cast<uint32_t>(key), khi = static_cast<uint32_t>(key >> 32);
+  const uint32_t plo = __shfl_up(klo, 1), phi = __shfl_up(khi, 1);
+  const unsigned long long hm = __ballot(has);
+  const bool prev_has = lane > 0u && ((hm >> (lane - 1u)) & 1ull);
+  const bool start = has && !(prev_has && plo == klo && phi == khi);
+  const unsigned long long cont = hm & ~__ballot(start);  // lanes that continue the run of the lane below
+  if (start) {
+    const unsigned long long above = lane == 63u ? 0ull : (~cont >> (lane + 1u));  // first lane above that does not continue
+    const uint32_t len = 1u + (lane == 63u ? 0u : static_cast<uint32_t>(__ffsll(static_cast<long long>(above | (1ull << (63u - lane)))) - 1));
+    const uint32_t h = voxInsert(t, key);
+    if (h != kInvalidSlot) atomicAdd(&t.counts[h], len);
+    else if (overflow) atomicOr(overflow, 1u);  // table full: the host repeats the frame with the full-size tables
   }
 }
 

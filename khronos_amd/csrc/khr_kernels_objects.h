@@ -66,23 +66,25 @@ __device__ inline uint32_t gvInsert(const GvTable& t, uint64_t key, bool* claime
 // at 1 m range covers thousands of pixels, and one CAS per pixel on its table slot serialises on a single address
 // (~90 ops/us).  Returns the slot for every participating lane; *claimed is set on exactly one lane per new key.
 __device__ inline uint32_t gvInsertWave(const GvTable& t, bool has, uint64_t key, bool* claimed) {
-  uint32_t slot = 0;
-  *claimed = false;
-  unsigned long long todo = __ballot(has);
-  while (todo) {
-    const int leader = __ffsll(static_cast<long long>(todo)) - 1;
-    const uint32_t klo = __shfl(static_cast<uint32_t>(key), leader), khi = __shfl(static_cast<uint32_t>(key >> 32), leader);
-    const uint64_t lk = (static_cast<uint64_t>(khi) << 32) | klo;
-    const bool mine = has && key == lk;
-    todo &= ~__ballot(mine);
-    uint32_t h = 0;
-    bool cl = false;
-    if (static_cast<int>(laneId()) == leader) h = gvInsert(t, lk, &cl);
-    h = __shfl(h, leader);
-    if (mine) slot = h;
-    if (static_cast<int>(laneId()) == leader) *claimed = cl;
-  }
-  return slot;
+  // (round 6) the first lane of every RUN of equal keys inserts -- all runs of the wave at once -- and hands its slot to the lanes of
+  // its run; before, one leader per distinct key took its turn after the other (3 - 10 dependent round trips in a wave over objects).
+  // A key that comes back in a later run finds its slot in the table; the table's own claim is what makes `claimed` unique.
+  const uint32_t lane = laneId();
+  const uint32_t klo = static_cast<uint32_t>(key), khi = static_cast<uint32_t>(key >> 32);
+  const uint32_t plo = __shfl_up(klo, 1), phi = __shfl_up(khi, 1);
+  const unsigned long long hm = __ballot(has);
+  const bool prev_has = lane > 0u && ((hm >> (lane - 1u)) & 1ull);
+  const bool start = has && !(prev_has && plo == klo && phi == khi);
+  const unsigned long long sm = __ballot(start);
+  uint32_t h = 0;
+  bool cl = false;
+  if (start) h = gvInsert(t, key, &cl);
+  *claimed = cl;
+  // the run's first lane = the highest start at or below this lane
+  const unsigned long long below = sm & (lane == 63u ? ~0ull : ((2ull << lane) - 1ull));
+  const int src = below ? 63 - __clzll(static_cast<long long>(below)) : 0;
+  const uint32_t hs = __shfl(h, src);
+  return has ? hs : 0u;
 }
 
 // empty the (group, voxel) table and zero the 4 request counters in one launch (two memset commands otherwise)

@@ -129,6 +129,7 @@ def load_library():
     lib.khr_download_frame.argtypes = [vp, i32, vp, vp, vp]
     lib.khr_integrate.argtypes = [vp, i32, i32, i32, i32]
     lib.khr_integrate_shared.argtypes = [vp, vp, i32, i32, i32, i32]
+    lib.khr_integrate_shared_batch.argtypes = [vp, vp, vp, vp, i32, i32, i32]
     lib.khr_update_tracking.argtypes = [vp, u64]
     lib.khr_update_tracking_phase.argtypes = [vp, u64, i32]
     lib.khr_export_halo.argtypes = [vp, vp, i64, i32]
@@ -455,6 +456,17 @@ class FusionContext:
 
     def integrate(self, slot, allocate_blocks=True, use_mask=False, object_id=-1):
         self._chk(self.lib.khr_integrate(self.h, slot, int(allocate_blocks), int(use_mask), int(object_id)))
+
+    def integrate_shared(self, src, slot, allocate_blocks=False, use_mask=False, object_id=-1):
+        """khr_integrate_shared: integrate frame `slot` of context `src` into THIS map (the object extractor's mini-map)."""
+        self._chk(self.lib.khr_integrate_shared(self.h, src.h, int(slot), int(allocate_blocks), int(use_mask), int(object_id)))
+
+    def integrate_shared_batch(self, src, slots, object_ids=None, allocate_blocks=False, use_mask=False):
+        """khr_integrate_shared_batch: the frames `slots` of context `src`, in order, in one call (one launch for 8^3 maps)."""
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        ids = None if object_ids is None else np.ascontiguousarray(object_ids, dtype=np.int32)
+        self._chk(self.lib.khr_integrate_shared_batch(self.h, src.h, _ptr(sl), None if ids is None else _ptr(ids), len(sl),
+                                                      int(allocate_blocks), int(use_mask)))
 
     def update_tracking(self, stamp_ns):
         self._chk(self.lib.khr_update_tracking(self.h, int(stamp_ns)))

@@ -116,3 +116,46 @@ def test_far_from_origin_and_errors():
         ctx.cluster_voxels(slot, 1, 0.0)
     with pytest.raises(Exception):
         ctx.cluster_voxels(slot, 2, 0.2)
+
+
+def test_multi_frame_update_beyond_32_frames_equals_frame_by_frame():
+    """khr_integrate_shared_batch (MeshObjectExtractor's re-integration of a track's buffered frames, mesh_object_extractor.cpp:239-243)
+    walks every item of the object mini-map through the frames that can touch it -- k_multi_cull leaves one bit per (item, frame), a
+    32-bit word per 32 frames -- heaviest items first (k_multi_order).  44 frames = two words per item: the map must equal, digest for
+    digest, the one the same frames give with one khr_integrate_shared call each (the single-frame kernel, which the tests above and
+    test_gpu_parity hold to the oracle); and the box must be one the culling has something to do in (parts behind the scene's surfaces)."""
+    n = 44
+    cfg, win, ora, s, sen, osen = make_pair(width=320, height=240, num_frame_slots=n + 2)
+    ocfg = dict(voxels_per_side=8, voxel_size=0.04, truncation_distance=0.08, with_tracking=0, semantic_mode=1, num_labels=2, max_blocks=8192)
+    _, a, _, _, _, _ = make_pair(width=320, height=240, **ocfg)
+    _, b, _, _, _, _ = make_pair(width=320, height=240, **ocfg)
+    fr0 = s.render(0)
+    target = int(fr0["label"][120, 160])
+    slots, ids = [], []
+    for i in range(n):
+        fr = s.render(i)
+        slot = win.upload_frame(sen, fr["stamp"], fr["pose"], fr["depth"], fr["rgb"], fr["label"])
+        win._chk(win.lib.khr_retain_slot(win.h, slot))
+        win.set_frame_image(slot, 1, (fr["label"] == target).astype(np.int32) * 3)
+        slots.append(slot)
+        ids.append(3)
+    assert len(set(slots)) == n
+    win.sync()
+    bl = np.array([[x, y, z] for x in range(-6, 14) for y in range(-10, 10) for z in range(-6, 10)], np.int32)  # 6400 blocks of 32 cm
+    a.allocate_blocks(bl)
+    b.allocate_blocks(bl)
+    a.integrate_shared_batch(win, slots, ids)
+    for sl in slots:
+        b.integrate_shared(win, sl, object_id=3)
+    da, db = a.map_digest(), b.map_digest()
+    assert [int(x) for x in da] == [int(x) for x in db]
+    sa = a.stats()
+    assert sa["cum_updated_voxels"] > 100000
+    assert a.object_prune(0.5, 2.0) == b.object_prune(0.5, 2.0)
+    a.generate_mesh(True, False)
+    b.generate_mesh(True, False)
+    ma, mb = a.download_mesh(), b.download_mesh()
+    assert len(ma["points"]) == len(mb["points"]) > 0 and np.array_equal(ma["points"], mb["points"])
+    for c in (a, b, win):
+        c.close()
+    ora.close()

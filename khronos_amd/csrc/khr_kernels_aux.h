@@ -1644,7 +1644,7 @@ __global__ __launch_bounds__(256) void k_mark_regen(const uint32_t* __restrict__
 // "All voxels to_remove" is a per-block bit the tracking pass maintains (BLK_ANY_KEEP: voxel flags only change in that
 // pass, and a block it skips has not changed), so this is one thread per pool slot.
 template <int VPS>
-__global__ __launch_bounds__(256) void k_reset_inactive(DevMap m, int4* __restrict__ removed) {
+__global__ __launch_bounds__(256) void k_reset_inactive(DevMap m, int4* __restrict__ removed, uint32_t clear_mask) {
   const uint32_t n_slots = m.counters[C_MAX_SLOT];
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += gridDim.x * blockDim.x) {
     const uint32_t fl = m.blk_flags[s];
@@ -1653,6 +1653,9 @@ __global__ __launch_bounds__(256) void k_reset_inactive(DevMap m, int4* __restri
       removed[atomicAdd(&m.counters[C_N_REMOVED], 1u)] = m.blk_index[s];
       m.blk_flags[s] = 0u;
       m.mesh_desc[s] = MeshDesc{0u, 0u};
+    } else if (fl & clear_mask) {
+      // (khr_process_frame's output stage: the flag clearing of active_window.cpp:169-171 rides here instead of in a launch of its own)
+      m.blk_flags[s] = fl & ~clear_mask;
     }
   }
 }
@@ -1681,6 +1684,7 @@ __global__ __launch_bounds__(256) void k_removed_publish(DevMap m, int4* __restr
     if (prev == gridDim.x - 1) {
       host_words[0] = atomicExch(&counters[0], 0u);
       counters[1] = 0u;  // (ready for the next launch, stream order)
+      m.counters[C_N_REMOVED] = 0u;  // (the archival that follows in stream order counts from zero: no memset command in front of it)
       __threadfence_system();
       __hip_atomic_store(&host_words[1], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

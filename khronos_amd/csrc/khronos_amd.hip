@@ -3835,12 +3835,14 @@ static int removedPublishLaunch(khr_ctx* c) {
   return KHR_OK;
 }
 
-static int resetInactiveLaunch(khr_ctx* c) {
+// counter_zeroed: k_removed_publish, queued before on the same stream, has zeroed the removed counter; clear_mask: block flags the
+// surviving blocks lose in the same pass (khr_process_frame's output stage: BLK_UPDATED)
+static int resetInactiveLaunch(khr_ctx* c, bool counter_zeroed = false, uint32_t clear_mask = 0u) {
   DevMap& m = c->m;
   c->removed_early = false;
-  HIP_TRY(hipMemsetAsync(&m.counters[C_N_REMOVED], 0, sizeof(uint32_t), c->stream));
+  if (!counter_zeroed) HIP_TRY(hipMemsetAsync(&m.counters[C_N_REMOVED], 0, sizeof(uint32_t), c->stream));
   int rc = dispatchVps(c, [&](auto vps) {
-    hipLaunchKernelGGL((k_reset_inactive<decltype(vps)::value>), dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_removed);
+    hipLaunchKernelGGL((k_reset_inactive<decltype(vps)::value>), dim3(gridFor(m.capacity)), dim3(256), 0, c->stream, m, c->d_removed, clear_mask);
     return KHR_OK;
   });
   if (rc) return rc;
@@ -4499,9 +4501,12 @@ int khr_process_frame(khr_ctx* c, const khr_sensor* sensor, const khr_frame* fra
     if (mc_fork) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_mc_join, 0));
     else if ((rc = khr_generate_mesh(c, 1, 1))) return rc;
     if (snap) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_snap_join, 0));
-    if (c->cfg.with_tracking && (rc = resetInactiveLaunch(c))) return rc;
+    if (c->cfg.with_tracking) {
+      if ((rc = resetInactiveLaunch(c, early_list, BLK_UPDATED))) return rc;  // (archival + the flag clearing of :169-171 in one pass)
+    } else if ((rc = khr_clear_updated(c))) {
+      return rc;
+    }
     c->removed_early = early_list;
-    if ((rc = khr_clear_updated(c))) return rc;
     HT("pf_output_launched");
   }
   // (6) ConnectedSemantics, host part (the records arrived long ago) + id remap queued behind everything else

@@ -987,6 +987,27 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
     c->item_cap = static_cast<uint32_t>(cap) * c->wpb;
   }
   A(devAlloc(c, &c->d_work4, 2 * static_cast<size_t>(c->item_cap), false));
+  if (cfg->voxels_per_side == 8 && rc == KHR_OK) {
+    // an object mini-map: the buffers of its multi-frame update now, not at the first extraction -- that one runs beside the window's
+    // frames, and a hipMalloc / hipHostMalloc there waits for (and stalls) every stream of the device (round 6: one run of the
+    // driver's command in ten had a 3 ms step at its first extraction)
+    const size_t bits_words = static_cast<size_t>(c->item_cap) * 4;  // four words per item = 128 buffered frames
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_frames), sizeof(FuseFrame) * kMaxMultiFrames, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->d_frames), sizeof(FuseFrame) * kMaxMultiFrames) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_frames, hipEventDisableTiming) != hipSuccess ||
+        hipEventRecord(c->ev_frames, c->stream) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->d_frame_bits), bits_words * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->d_multi_list), sizeof(uint4) * 2 * c->item_cap + 16) != hipSuccess)
+      rc = fail(KHR_ENOMEM, "buffers of the multi-frame update");
+    else
+      c->frame_bits_words = bits_words;
+    // ... and the small page-locked block and events its first extraction would otherwise create on the worker's thread
+    if (rc == KHR_OK && (hipHostMalloc(reinterpret_cast<void**>(&c->h_totals), sizeof(uint32_t) * (C_COUNT + 2), hipHostMallocDefault) != hipSuccess ||
+                         hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming) != hipSuccess || hipEventRecord(c->ev_up, c->stream) != hipSuccess ||
+                         hipEventCreateWithFlags(&c->ev_dep, hipEventDisableTiming) != hipSuccess ||
+                         hipEventCreateWithFlags(&c->ev_dep_aux, hipEventDisableTiming) != hipSuccess))
+      rc = fail(KHR_ENOMEM, "page-locked words / events of an object mini-map");
+  }
   A(devAlloc(c, &m.blk_band, cap * kBandSlots));
   A(devAlloc(c, &c->d_removed, cap));
   A(devAlloc(c, &c->d_mesh_count, cap + 1));

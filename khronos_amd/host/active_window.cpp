@@ -1004,6 +1004,10 @@ size_t ObjectWorkerPool::fill(std::vector<std::shared_ptr<KhronosObjectAttribute
 }
 
 void ObjectWorkerPool::workerLoop(size_t worker) {
+  try {
+    extractors_[worker]->prepareThread();
+  } catch (...) {
+  }
   while (true) {
     std::unique_ptr<Request> req;
     {

@@ -297,6 +297,9 @@ class ObjectExtractor {  // object_extractor.h
  public:
   virtual ~ObjectExtractor() = default;
   virtual std::shared_ptr<KhronosObjectAttributes> extractObject(const Track& track, const FrameDataBuffer& frames) = 0;
+  // called once on the thread that is going to call extractObject, before its first request (device runtimes set up per-thread
+  // state at a thread's first call: not beside the window's frames)
+  virtual void prepareThread() {}
 };
 
 class MeshObjectExtractor : public ObjectExtractor {  // mesh_object_extractor.h:59-165
@@ -337,6 +340,9 @@ class MeshObjectExtractor : public ObjectExtractor {  // mesh_object_extractor.h
   MeshObjectExtractor(const MeshObjectExtractor&) = delete;
   MeshObjectExtractor& operator=(const MeshObjectExtractor&) = delete;
   std::shared_ptr<KhronosObjectAttributes> extractObject(const Track& track, const FrameDataBuffer& frames) override;
+  void prepareThread() override {
+    if (object_ctx_) khr_sync(object_ctx_);
+  }
   // MeshObjectExtractor::extractDynamicObject (mesh_object_extractor.cpp:120-172): trajectory summary
   std::shared_ptr<KhronosObjectAttributes> extractDynamicObject(const Track& track, const FrameDataBuffer& frames) const;
   // a13: MeshObjectExtractor::extractStaticObject (mesh_object_extractor.cpp:174-304)

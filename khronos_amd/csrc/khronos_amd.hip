@@ -5428,6 +5428,23 @@ int khr_debug_read(khr_ctx* c, unsigned long long* out, int64_t n) {
 
 int khr_timing_enable(khr_ctx* c, int enable) {
   if (!c) return fail(KHR_EINVAL, "null ctx");
+  if (enable && !c->timing) {
+    // what the first timed launches would otherwise do inside the caller's measurement: create their events (a signal each) and switch
+    // the stream's hardware queue to time-stamped dispatches -- the first hipExtLaunchKernelGGL with events on a queue can stall it
+    // for milliseconds (round 6: one run of the driver's command in twenty had a 2.7 ms wait for the seed count in its second step)
+    HIP_TRY(hipSetDevice(c->device));
+    while (c->event_pool.size() < 256) {
+      hipEvent_t e = nullptr;
+      HIP_TRY(hipEventCreate(&e));
+      c->event_pool.push_back(e);
+    }
+    hipEvent_t a = takeEvent(c), b = takeEvent(c);
+    hipExtLaunchKernelGGL(k_copy_words, dim3(1), dim3(64), 0, c->stream, a, b, 0, static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), 0u);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventSynchronize(b));
+    c->event_pool.push_back(a);
+    c->event_pool.push_back(b);
+  }
   c->timing = static_cast<uint32_t>(enable);
   return KHR_OK;
 }

@@ -143,6 +143,7 @@ struct FuseArgs : FuseFrame {
   // the item (k_multi_cull); nullptr: every frame
   const uint32_t* frame_bits;
   int frame_words;
+  int frame_bit0;  // index of a.frames[0] in the bit rows (a launch may walk a chunk of the batch)
 };
 
 constexpr int kFuseCap = 256;        // in-band records a wave collects before it works them off (one 4-z chunk of a patch)
@@ -1032,11 +1033,12 @@ __global__ __launch_bounds__(64 * WPW, MINW) void k_fuse2(FuseArgs a, FuseList l
     for (int fi = 0; fi < n_frames; ++fi) {
     if (MULTI && ((frame_mask >> fi) & 1u) == 0u) continue;
     if (MULTI && a.frame_bits != nullptr) {  // (the item's word of 32 frames through the scalar cache: written by the launch before this one)
-      if ((fi & 31) == 0) {
-        const size_t wi = (slot * static_cast<size_t>(PATCHES * ZSPLIT) + static_cast<size_t>(sbi)) * static_cast<size_t>(a.frame_words) + static_cast<size_t>(fi >> 5);
+      const int gf = fi + a.frame_bit0;
+      if ((gf & 31) == 0 || fi == 0) {
+        const size_t wi = (slot * static_cast<size_t>(PATCHES * ZSPLIT) + static_cast<size_t>(sbi)) * static_cast<size_t>(a.frame_words) + static_cast<size_t>(gf >> 5);
         fbits = *(const uint32_t __attribute__((address_space(4)))*)(a.frame_bits + wi);
       }
-      if (((fbits >> (fi & 31)) & 1u) == 0u) {
+      if (((fbits >> (gf & 31)) & 1u) == 0u) {
         cnt = 0;  // (what the frame would have left: no voxel of the item in its band)
         continue;
       }

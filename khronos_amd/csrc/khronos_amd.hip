@@ -610,6 +610,7 @@ int kFuse3Waves = 0;    // env KHR_FUSE5_WAVES: resident waves per CU of k_tsdf'
 int kBand3Waves = 0;    // env KHR_BAND5_WAVES: the same for k_band5
 int kFuse5Mode = 0;   // env KHR_FUSE5_MODE: 1 / 2 = the ALU-only / memory-only instantiations of k_tsdf (speed-of-light decomposition; development)
 int kTickUnion = 1;     // env KHR_TICK_UNION: khr_tick_integrate updates with ONE launch for all cameras of the tick (tickUnion)
+int kMultiChunk = 7;    // env KHR_MULTI_CHUNK: frames per launch of the object extractor's multi-frame update (0 = all buffered frames in one launch)
 int kFuseMulti = 1;     // env KHR_FUSE_MULTI: khr_integrate_shared_batch integrates all frames of a batch in one launch (k_fuse2 MULTI)
 constexpr int kMaxMultiFrames = 1024;
 int kFuseSpec = 1;      // env KHR_FUSE_SPECULATIVE: khr_process_frame queues k_fuse before the seed count has reached the host (gated on the device)
@@ -926,6 +927,7 @@ int khr_create(const khr_config* cfg, khr_ctx** out) {
   if (std::getenv("KHR_FUSE_BAND")) kFuseBand = std::atoi(std::getenv("KHR_FUSE_BAND"));
   if (std::getenv("KHR_FUSE_SPECULATIVE")) kFuseSpec = std::atoi(std::getenv("KHR_FUSE_SPECULATIVE"));
   if (std::getenv("KHR_TICK_UNION")) kTickUnion = std::atoi(std::getenv("KHR_TICK_UNION"));
+  if (std::getenv("KHR_MULTI_CHUNK")) kMultiChunk = std::atoi(std::getenv("KHR_MULTI_CHUNK"));
   if (std::getenv("KHR_FUSE_MULTI")) kFuseMulti = std::atoi(std::getenv("KHR_FUSE_MULTI"));
   if (std::getenv("KHR_FUSE_V")) kFuseVer = std::atoi(std::getenv("KHR_FUSE_V"));
   if (std::getenv("KHR_FUSE5_WAVES")) kFuse3Waves = std::atoi(std::getenv("KHR_FUSE5_WAVES"));
@@ -1755,7 +1757,16 @@ static int integrateUpdateMulti(khr_ctx* c, khr_ctx* src, const int* src_slots, 
       const uint64_t items = c->explicit_blocks * c->wpb;
       grid = std::max(8, static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(grid), (items + WPW - 1) / WPW) + 7) / 8 * 8);
     }
-    KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(64 * WPW), a, list);
+    // the buffered frames in chunks of kMultiChunk per launch (0 = all in one): the next chunk's workgroups cannot start before the
+    // current chunk has drained, so the window's update kernel -- whose workgroup needs a whole CU's vector registers -- gets its CUs
+    // within one chunk instead of within the whole extraction (an item's distance / weight pass through HBM at the chunk boundaries)
+    const int chunk = kMultiChunk > 0 ? kMultiChunk : n_frames;
+    for (int k0 = 0; k0 < n_frames; k0 += chunk) {
+      a.frames = c->d_frames + k0;
+      a.n_frames = std::min(chunk, n_frames - k0);
+      a.frame_bit0 = k0;
+      KHR_LAUNCH_TIMED(0, kern, dim3(grid), dim3(64 * WPW), a, list);
+    }
   };
   if (exact) go(&k_fuse2<8, 4, true, true, WPW, 4, true>);
   else go(&k_fuse2<8, 4, true, false, WPW, 4, true>);
